@@ -1,0 +1,285 @@
+"""Test-side helpers: ctypes binding of the CPU oracle (oracle/ldoracle.c), genotype packing,
+PLINK file writers and a runner for the reference binary (oracle/_ref/plink2, when present).
+
+TEST INFRASTRUCTURE ONLY -- the product (plink-ng_amd/) never imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(REPO, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "libldoracle.so")
+REF_BIN = os.path.join(ORACLE_DIR, "_ref", "plink2")
+
+K_SMALL_EPSILON = 2.0 ** -44
+
+
+class LdoVaggs(ctypes.Structure):
+    _fields_ = [("nm_ct", ctypes.c_uint32), ("sum", ctypes.c_int32), ("ssq", ctypes.c_uint32),
+                ("plusone_ct", ctypes.c_uint32), ("minusone_ct", ctypes.c_uint32)]
+
+
+class LdoPairStats(ctypes.Structure):
+    _fields_ = [("nm", ctypes.c_uint32), ("sum1", ctypes.c_int32), ("ssq1", ctypes.c_uint32),
+                ("sum2", ctypes.c_int32), ("ssq2", ctypes.c_uint32), ("dot", ctypes.c_int32)]
+
+    def astuple(self):
+        return (self.nm, self.sum1, self.ssq1, self.sum2, self.ssq2, self.dot)
+
+
+def build_oracle():
+    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < max(
+            os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("ldoracle.c", "ldoracle.h")):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        lib = ctypes.CDLL(build_oracle())
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        f64p = ctypes.POINTER(ctypes.c_double)
+        lib.ldo_split_hom_ref2het.argtypes = [u64p, ctypes.c_uint32, u64p, u64p]
+        lib.ldo_fill_vaggs.argtypes = [u64p, u64p, ctypes.c_uint32, ctypes.POINTER(LdoVaggs)]
+        lib.ldo_is_monomorphic.argtypes = [ctypes.POINTER(LdoVaggs)]
+        lib.ldo_pair_stats.argtypes = [u64p, u64p, ctypes.POINTER(LdoVaggs), u64p, u64p, ctypes.POINTER(LdoVaggs),
+                                       ctypes.c_uint32, ctypes.POINTER(LdoPairStats)]
+        lib.ldo_exceeds.argtypes = [ctypes.POINTER(LdoPairStats), ctypes.c_double]
+        lib.ldo_cov_vars.argtypes = [ctypes.POINTER(LdoPairStats), f64p, f64p, f64p]
+        lib.ldo_prune_thresh.argtypes = [ctypes.c_double]
+        lib.ldo_prune_thresh.restype = ctypes.c_double
+        lib.ldo_major_allele.argtypes = [u64p, ctypes.c_uint32, u32p, f64p]
+        lib.ldo_invert_geno.argtypes = [u64p, ctypes.c_uint32, u64p]
+        lib.ldo_subcontig_split.argtypes = [u32p, u32p, ctypes.c_uint32, ctypes.c_uint32, u32p, u32p]
+        lib.ldo_subcontig_split.restype = ctypes.c_uint32
+        lib.ldo_indep_pairwise.argtypes = [u64p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, u32p, u32p, f64p,
+                                           ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_double,
+                                           ctypes.c_int, u64p, u64p]
+        lib.ldo_indep_pairwise.restype = ctypes.c_int
+        _oracle = lib
+    return _oracle
+
+
+def _p(arr, ctype):
+    return arr.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+# ---------------------------------------------------------------- genotype packing
+def pack_2bit(codes):
+    """codes: (M, N) uint8 array of 2-bit codes -> (M, stride_words) uint64, 32 genotypes per word,
+    little-endian bit order (sample s -> bits 2*(s%32) of word s//32).  Trailing bits are zero."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    m, n = codes.shape
+    stride_words = (n + 31) // 32
+    padded = np.zeros((m, stride_words * 32), dtype=np.uint8)
+    padded[:, :n] = codes & 3
+    quads = padded.reshape(m, stride_words * 8, 4)
+    bytes_ = (quads[:, :, 0] | (quads[:, :, 1] << 2) | (quads[:, :, 2] << 4) | (quads[:, :, 3] << 6)).astype(np.uint8)
+    return np.ascontiguousarray(bytes_).view(np.uint64).reshape(m, stride_words)
+
+
+def unpack_2bit(words, n):
+    m = words.shape[0]
+    b = np.ascontiguousarray(words).view(np.uint8).reshape(m, -1)
+    out = np.empty((m, b.shape[1] * 4), dtype=np.uint8)
+    for k in range(4):
+        out[:, k::4] = (b >> (2 * k)) & 3
+    return out[:, :n]
+
+
+def bitmap_to_bool(bm, n):
+    return np.unpackbits(np.ascontiguousarray(bm).view(np.uint8), bitorder="little")[:n].astype(bool)
+
+
+# ---------------------------------------------------------------- oracle wrappers
+def oracle_prepare(raw_codes):
+    """raw REF-based codes (0 hom-REF,1 het,2 hom-ALT,3 missing), (M,N) -> (inv packed words, maj_freq, alt_major)"""
+    lib = oracle()
+    raw = pack_2bit(raw_codes)
+    m, n = raw_codes.shape
+    inv = np.empty_like(raw)
+    mf = np.empty(m, dtype=np.float64)
+    altmaj = np.empty(m, dtype=np.uint32)
+    for v in range(m):
+        am = ctypes.c_uint32()
+        f = ctypes.c_double()
+        lib.ldo_major_allele(_p(raw[v], ctypes.c_uint64), n, ctypes.byref(am), ctypes.byref(f))
+        mf[v] = f.value
+        altmaj[v] = am.value
+        if am.value:
+            lib.ldo_invert_geno(_p(raw[v], ctypes.c_uint64), n, _p(inv[v], ctypes.c_uint64))
+        else:
+            inv[v] = raw[v]
+    return inv, mf, altmaj
+
+
+def oracle_split(inv_words, n):
+    """(M, stride) packed inverse codes -> hom, r2h planes (M, ceil(n/64)) uint64 + list of vaggs"""
+    lib = oracle()
+    m = inv_words.shape[0]
+    wc = (n + 63) // 64
+    gw = (n + 31) // 32
+    hom = np.zeros((m, wc), dtype=np.uint64)
+    r2h = np.zeros((m, wc), dtype=np.uint64)
+    vaggs = (LdoVaggs * m)()
+    for v in range(m):
+        row = np.zeros(gw + 1, dtype=np.uint64)
+        row[:gw] = inv_words[v, :gw]
+        lib.ldo_split_hom_ref2het(_p(row, ctypes.c_uint64), n, _p(hom[v], ctypes.c_uint64), _p(r2h[v], ctypes.c_uint64))
+        lib.ldo_fill_vaggs(_p(hom[v], ctypes.c_uint64), _p(r2h[v], ctypes.c_uint64), wc, ctypes.byref(vaggs[v]))
+    return hom, r2h, vaggs
+
+
+def oracle_pair_stats(hom, r2h, vaggs, n, first, second):
+    lib = oracle()
+    st = LdoPairStats()
+    lib.ldo_pair_stats(_p(hom[first], ctypes.c_uint64), _p(r2h[first], ctypes.c_uint64), ctypes.byref(vaggs[first]),
+                       _p(hom[second], ctypes.c_uint64), _p(r2h[second], ctypes.c_uint64), ctypes.byref(vaggs[second]),
+                       n, ctypes.byref(st))
+    return st
+
+
+def oracle_r2(st):
+    lib = oracle()
+    c, v1, v2 = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    lib.ldo_cov_vars(ctypes.byref(st), ctypes.byref(c), ctypes.byref(v1), ctypes.byref(v2))
+    return c.value, v1.value, v2.value
+
+
+def oracle_indep_pairwise(inv_words, n, chr_idx, bps, maj_freqs, window, step, is_bp, r2, order=2):
+    """Returns (removed bool array, pair evaluation count)."""
+    lib = oracle()
+    m = inv_words.shape[0]
+    inv_words = np.ascontiguousarray(inv_words, dtype=np.uint64)
+    chr_idx = np.ascontiguousarray(chr_idx, dtype=np.uint32)
+    bps = np.ascontiguousarray(bps, dtype=np.uint32)
+    maj_freqs = np.ascontiguousarray(maj_freqs, dtype=np.float64)
+    removed = np.zeros((m + 63) // 64 + 1, dtype=np.uint64)
+    evals = ctypes.c_uint64()
+    rc = lib.ldo_indep_pairwise(_p(inv_words, ctypes.c_uint64), inv_words.shape[1], m, n, _p(chr_idx, ctypes.c_uint32),
+                                _p(bps, ctypes.c_uint32), _p(maj_freqs, ctypes.c_double), window, step, int(is_bp),
+                                r2, int(order == 1), _p(removed, ctypes.c_uint64), ctypes.byref(evals))
+    assert rc == 0
+    return bitmap_to_bool(removed, m), evals.value
+
+
+def oracle_subcontig_split(chr_idx, bps, window):
+    lib = oracle()
+    chr_idx = np.ascontiguousarray(chr_idx, dtype=np.uint32)
+    m = len(chr_idx)
+    info = np.zeros(2 * max(m, 1), dtype=np.uint32)
+    wmax = ctypes.c_uint32()
+    bp_ptr = None
+    if bps is not None:
+        bps = np.ascontiguousarray(bps, dtype=np.uint32)
+        bp_ptr = _p(bps, ctypes.c_uint32)
+    ct = lib.ldo_subcontig_split(_p(chr_idx, ctypes.c_uint32), bp_ptr, m, window, _p(info, ctypes.c_uint32), ctypes.byref(wmax))
+    return [(int(info[2 * k]), int(info[2 * k + 1])) for k in range(ct)], wmax.value
+
+
+# ---------------------------------------------------------------- synthetic data (numpy; small sizes)
+def synth_raw_codes(m, n, seed, missing_rate=0.0, ld_copy_prob=0.5, redraw=0.05, maf_lo=0.01):
+    """REF-based codes with planted LD between consecutive variants (same spirit as the reference's
+    --dummy generator, plink2_import.cc:16387-16432)."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((m, n), dtype=np.uint8)
+    prev = None
+    for v in range(m):
+        maf = rng.uniform(maf_lo, 0.5)
+        if rng.random() < 0.5:
+            maf = 1.0 - maf  # ALT may be the major allele
+        fresh = (rng.random(n) < maf).astype(np.uint8) + (rng.random(n) < maf).astype(np.uint8)
+        if prev is not None and rng.random() < ld_copy_prob:
+            keep = rng.random(n) >= redraw
+            cur = np.where(keep, prev, fresh)
+        else:
+            cur = fresh
+        prev = cur.copy()
+        if missing_rate > 0:
+            cur = np.where(rng.random(n) < missing_rate, 3, cur).astype(np.uint8)
+        out[v] = cur
+    return out
+
+
+# ---------------------------------------------------------------- PLINK file writers / reference runner
+def write_pgen_fixed(prefix, raw_codes, chroms, bps, ids=None, sexes=None):
+    """Fixed-width .pgen (storage mode 0x02: pgenlib_read.cc:881-911) + .pvar + .psam."""
+    m, n = raw_codes.shape
+    rec = (n + 3) // 4
+    packed = pack_2bit(raw_codes).view(np.uint8).reshape(m, -1)[:, :rec]
+    with open(prefix + ".pgen", "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x02]))
+        f.write(np.uint32(m).tobytes())
+        f.write(np.uint32(n).tobytes())
+        f.write(bytes([0x40]))
+        f.write(np.ascontiguousarray(packed).tobytes())
+    if ids is None:
+        ids = ["snp%d" % i for i in range(m)]
+    with open(prefix + ".pvar", "w") as f:
+        f.write("#CHROM\tPOS\tID\tREF\tALT\n")
+        for i in range(m):
+            f.write("%s\t%d\t%s\tA\tC\n" % (chroms[i], bps[i], ids[i]))
+    with open(prefix + ".psam", "w") as f:
+        f.write("#IID\tSEX\n")
+        for s in range(n):
+            f.write("s%d\t%s\n" % (s, "2" if sexes is None else str(sexes[s])))
+    return ids
+
+
+def write_bed(prefix, raw_codes, chroms, bps, ids=None):
+    """PLINK 1 .bed/.bim/.fam (pgen_spec.tex:425-428: 00 hom-A1(ALT) 01 missing 10 het 11 hom-A2(REF))."""
+    m, n = raw_codes.shape
+    lut = np.array([3, 2, 0, 1], dtype=np.uint8)  # pgen code -> bed code
+    rec = (n + 3) // 4
+    packed = pack_2bit(lut[raw_codes]).view(np.uint8).reshape(m, -1)[:, :rec]
+    with open(prefix + ".bed", "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x01]))
+        f.write(np.ascontiguousarray(packed).tobytes())
+    if ids is None:
+        ids = ["snp%d" % i for i in range(m)]
+    with open(prefix + ".bim", "w") as f:
+        for i in range(m):
+            f.write("%s\t%s\t0\t%d\tC\tA\n" % (chroms[i], ids[i], bps[i]))
+    with open(prefix + ".fam", "w") as f:
+        for s in range(n):
+            f.write("s%d s%d 0 0 2 -9\n" % (s, s))
+    return ids
+
+
+def have_ref():
+    return os.path.exists(REF_BIN) and os.access(REF_BIN, os.X_OK)
+
+
+def run_ref(args, cwd, timeout=600):
+    """Run the reference binary; returns CompletedProcess (stdout+stderr captured as text)."""
+    return subprocess.run([REF_BIN] + list(args), cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                          text=True, timeout=timeout)
+
+
+def read_id_list(path):
+    with open(path) as f:
+        return [ln.rstrip("\n") for ln in f if ln.strip()]
+
+
+def ref_indep_pairwise(prefix, window_args, r2, order=2, threads=2, bad_ld=True, fmt="pfile", extra=()):
+    """Run reference --indep-pairwise on <prefix>; returns (kept ids, removed ids, log text)."""
+    cwd = os.path.dirname(prefix)
+    out = prefix + ".ref"
+    args = ["--" + fmt, os.path.basename(prefix), "--indep-pairwise"] + [str(a) for a in window_args] + [repr(float(r2))]
+    if order == 1:
+        args += ["--indep-order", "1"]
+    if bad_ld:
+        args += ["--bad-ld"]
+    args += ["--threads", str(threads), "--out", os.path.basename(out)] + list(extra)
+    cp = run_ref(args, cwd)
+    if cp.returncode != 0:
+        raise RuntimeError("reference plink2 failed:\n" + cp.stdout)
+    return read_id_list(out + ".prune.in"), read_id_list(out + ".prune.out"), cp.stdout
