@@ -1,0 +1,169 @@
+/* ldprune_hip.h -- C-ABI of the MI355X-native pairwise-LD pruning engine.
+ *
+ * Drop-in boundary for PLINK 2.0's --indep-pairwise hot path.  The reference has no FFI for this
+ * path; the seam replaced here is the hand-off inside LdPrune() (2.0/plink2_ld.cc:2530) between
+ * "everything upstream is file decoding" and the worker pool:
+ *
+ *     LdPruneSubcontigSplitAll()  2.0/plink2_ld.cc:2165   -> ldp_set_variants()
+ *     LoadBalance()               2.0/plink2_ld.cc:2341   -> ldp_set_shard()        (subcontig -> GPU)
+ *     IndepPairwise() decode loop 2.0/plink2_ld.cc:1345   -> ldp_load_genotypes()   (PgrGetInv1 output,
+ *                                                            or raw .pgen/.bed codes + device-side
+ *                                                            allele counts: plink2_data.cc:2304,
+ *                                                            plink2_filter.cc:2113,3311)
+ *     IndepPairwiseThread()       2.0/plink2_ld.cc:801    -> ldp_run()              (HIP kernels + replay)
+ *     removed_variants_collapsed  2.0/plink2_ld.cc:2555   <- ldp_run() output bitmap
+ *
+ * Conventions follow the reference's own GPU seam (2.0/cuda/plink2_matrix_cuda.h:24-104): plain C
+ * types, int return codes (0 = success), caller owns every buffer it passes in, the engine owns its
+ * device memory, no exceptions cross the boundary.  A nonzero code maps to kPglRetGpuFail /
+ * kPglRetNomem (2.0/include/plink2_base.h:351-395) on the reference side; see INTEGRATION.md.
+ *
+ * There is NO CPU fallback behind this API: without a usable HIP device every compute entry point
+ * returns LDP_ERR_GPU.
+ */
+#ifndef LDPRUNE_HIP_H
+#define LDPRUNE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ldp_engine ldp_engine;
+
+enum {
+  LDP_OK = 0,
+  LDP_ERR_INVALID = 1,     /* bad argument / inconsistent input  (kPglRetInconsistentInput) */
+  LDP_ERR_NOMEM = 2,       /* host or device allocation failed   (kPglRetNomem)             */
+  LDP_ERR_GPU = 3,         /* HIP runtime / kernel failure       (kPglRetGpuFail)           */
+  LDP_ERR_STATE = 4,       /* call sequence error                (kPglRetImproperFunctionCall) */
+  LDP_ERR_UNSUPPORTED = 5  /* e.g. >= 2^30 founders              (kPglRetNotYetSupported)   */
+};
+
+/* Genotype encodings accepted by ldp_load_genotypes(); all are 2 bits per sample, sample-minor,
+ * little-endian within bytes, ceil(founder_ct/4) meaningful bytes per variant row. */
+enum {
+  LDP_GENO_INVERSE = 0, /* PgrGetInv1 output (pgenlib_read.cc:5544): 0 hom-major, 1 het, 2 hom-nonmajor,
+                           3 missing.  Caller supplies maj_freqs via ldp_set_maj_freqs(). */
+  LDP_GENO_REF = 1,     /* .pgen main-track coding: 0 hom-REF, 1 het, 2 hom-ALT, 3 missing.  The engine
+                           counts alleles, picks the major allele and inverts on the device. */
+  LDP_GENO_BED = 2      /* PLINK 1 .bed coding: 0 hom-A1(ALT), 1 missing, 2 het, 3 hom-A2(REF)
+                           (pgenlib_read.cc:2157 PgrPlink1ToPlink2InplaceUnsafe), then as LDP_GENO_REF. */
+};
+
+enum { LDP_MEM_HOST = 0, LDP_MEM_DEVICE = 1 };
+
+/* Mirrors the fields of LdInfo (2.0/plink2_ld.h:113-120) that --indep-pairwise consumes. */
+typedef struct {
+  uint32_t founder_ct;         /* samples per variant row; 2 <= founder_ct < 2^30 (plink2_ld.cc:1122,2537) */
+  uint32_t prune_window_size;  /* bp when window_is_bp (already kb*1000*(1+2^-44), plink2.cc:7266), else variants */
+  uint32_t prune_window_incr;  /* step; must be 1 when window_is_bp (plink2.cc:7290) */
+  uint32_t window_is_bp;       /* kfLdPruneWindowBp */
+  uint32_t plink1_order;       /* kfLdPrunePlink1Order (--indep-order 1) */
+  double prune_last_param;     /* raw r^2 in [0,1); the engine applies *(1+2^-44) as plink2_ld.cc:1255 does */
+  int32_t device;              /* HIP device ordinal; -1 = current device */
+  void* stream;                /* hipStream_t to run on; NULL = engine creates its own */
+} ldp_params;
+
+/* Integer 6-tuple of ComputeIndepPairwiseR2Components (plink2_ld.cc:699-723); 1 = first (lower
+ * index), 2 = second.  cov12 = dot*nm - sum1*sum2, var_k = ssq_k*nm - sum_k^2 (:1085-1087). */
+typedef struct {
+  uint32_t nm;
+  int32_t sum1;
+  uint32_t ssq1;
+  int32_t sum2;
+  uint32_t ssq2;
+  int32_t dot;
+} ldp_pair_stats_t;
+
+/* Per-variant aggregates (VariantAggs, plink2_ld.cc:691-695) + what the allele-count pass produced. */
+typedef struct {
+  uint32_t nm_ct;
+  int32_t sum;
+  uint32_t ssq;
+  uint32_t flags;        /* bit0: ALT was major (row inverted), bit1: monomorphic (:902), bit2: has missing calls */
+  uint32_t n_homref;     /* raw counts before inversion (all zero for LDP_GENO_INVERSE input) */
+  uint32_t n_het;
+  uint32_t n_homalt;
+  uint32_t reserved;
+} ldp_variant_rec;
+
+typedef struct {
+  uint64_t candidate_pairs;  /* in-window pairs the pair kernel was asked to decide */
+  uint64_t computed_pairs;   /* pair slots the kernel actually evaluated (tile padding included) */
+  uint64_t replay_pairs;     /* predicate bits the greedy replay consumed */
+  uint64_t pred_true;        /* candidate pairs above threshold */
+  double ms_prepare;         /* device time of the split/count kernels in the last ldp_load_genotypes() (HIP events) */
+  double ms_pair_kernel;     /* device time of the pair kernel launches in the last ldp_run() (HIP events) */
+  double ms_replay;          /* host wall time of the replay in the last ldp_run() */
+  double ms_run_total;       /* host wall time of the last ldp_run() */
+  uint32_t pair_kernel_launches;
+  uint32_t subcontig_ct;
+  uint32_t owned_subcontig_ct;
+  uint32_t window_max;       /* as LdPruneSubcontigSplitAll reports it */
+} ldp_counters;
+
+/* ---- lifecycle ---- */
+int ldp_create(const ldp_params* params, ldp_engine** out);
+void ldp_destroy(ldp_engine* e);
+const char* ldp_last_error(const ldp_engine* e);
+/* number of usable HIP devices (0 when there is none); never fails */
+int ldp_device_count(void);
+
+/* ---- planning (host only; usable without a GPU) ---- */
+/* variant_ct included variants in file order with chr0/unplaced already stripped (StripUnplacedK,
+ * plink2_ld.cc:2542); chr_idx[v] = chromosome order index (nondecreasing); bps[v] = position (may be
+ * NULL for count-based windows).  Runs the subcontig split and the window iterator
+ * (LdPruneNextSubcontig/LdPruneNextWindow, plink2_ld.cc:605-689) to fix the candidate-pair band. */
+int ldp_set_variants(ldp_engine* e, uint32_t variant_ct, const uint32_t* chr_idx, const uint32_t* bps);
+/* subcontig table: info[2*k] = length, info[2*k+1] = first variant index; returns count via *ct */
+int ldp_get_subcontigs(const ldp_engine* e, uint32_t* ct, uint32_t* info, uint32_t info_capacity_pairs);
+/* Restrict this engine to the subcontigs LPT assigns to `rank` of `world` (weights = lengths,
+ * cf. plink2_ld.cc:2686-2694).  Only owned variants need genotype rows; ldp_run() reports bits for
+ * owned variants only.  owner[k] (optional, subcontig_ct entries) receives the rank of subcontig k. */
+int ldp_set_shard(ldp_engine* e, uint32_t rank, uint32_t world, uint32_t* owner);
+/* per-variant window start lo[v] (first candidate partner index) and candidate pair total */
+int ldp_get_band(const ldp_engine* e, uint32_t* lo, uint64_t* candidate_pairs);
+
+/* ---- data ---- */
+/* Rows [first_variant, first_variant+n) of the variant table.  `geno` points at row first_variant;
+ * rows are stride_bytes apart.  location: LDP_MEM_HOST or LDP_MEM_DEVICE.  Rows outside this
+ * engine's shard are ignored.  The engine converts to bit-planes resident in HBM, computes the
+ * per-variant aggregates (FillVaggs, plink2_ld.cc:725) and, for REF/BED encodings, the allele counts,
+ * major allele and inversion. */
+int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* geno, uint64_t stride_bytes,
+                       int location, int encoding);
+/* major-allele frequencies (GetAlleleFreq(..., maj_alleles[v]), plink2_ld.cc:915) for LDP_GENO_INVERSE
+ * input; for REF/BED input the engine derives them itself and this call overrides them. */
+int ldp_set_maj_freqs(ldp_engine* e, uint32_t first_variant, uint32_t n, const double* maj_freqs);
+/* --indep-preferred (plink2_ld.cc:916-918): bitmap over variants, bit set = preferred */
+int ldp_set_preferred(ldp_engine* e, const uint64_t* preferred_bitmap);
+
+/* ---- compute ---- */
+/* removed: bitmap of variant_ct bits (caller-allocated, (variant_ct+63)/64 words), bit v set <=> variant v
+ * pruned == removed_variants_collapsed (plink2_ld.cc:2555,1424).  Non-owned variants' bits are 0. */
+int ldp_run(ldp_engine* e, uint64_t* removed);
+/* Same, additionally returning the integer 6-tuple of every candidate pair: stats[pair_off[j] + (i - lo[j])]
+ * for lo[j] <= i < j, pair_off = exclusive prefix sum of (j - lo[j]).  Intended for parity tests. */
+int ldp_run_with_stats(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t stats_capacity);
+/* Arbitrary pairs (first[k] < second[k] not required) through the reference kernel (one wave per pair). */
+int ldp_pair_stats(ldp_engine* e, uint32_t n_pairs, const uint32_t* first, const uint32_t* second, ldp_pair_stats_t* out);
+/* Host-only replay of the greedy scan (plink2_ld.cc:931-1100) from a caller-supplied list of the candidate
+ * pairs whose predicate is TRUE (global variant indices, first < second, each inside the band).  Needs
+ * variant records (ldp_debug_set_variant_recs, for the monomorphic flags) and maj_freqs.  No GPU is
+ * touched: this is how the host logic is tested on a CPU-only machine. */
+int ldp_debug_set_variant_recs(ldp_engine* e, const ldp_variant_rec* recs);
+int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first, const uint32_t* second, uint64_t* removed);
+
+/* ---- inspection ---- */
+int ldp_get_variant_recs(ldp_engine* e, uint32_t first_variant, uint32_t n, ldp_variant_rec* out);
+int ldp_get_maj_freqs(ldp_engine* e, uint32_t first_variant, uint32_t n, double* out);
+/* bit-planes of one variant as the kernels see them: hom and ref2het, ceil(founder_ct/32) dwords each */
+int ldp_get_planes(ldp_engine* e, uint32_t variant, uint32_t* hom, uint32_t* ref2het);
+int ldp_get_counters(const ldp_engine* e, ldp_counters* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDPRUNE_HIP_H */

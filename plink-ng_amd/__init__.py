@@ -1,0 +1,340 @@
+"""plink-ng_amd: MI355X-native --indep-pairwise (pairwise-LD pruning) engine.
+
+The product is the C-ABI shared library built from csrc/ (include/ldprune_hip.h) plus the C++
+`plink2-hip` front-end.  This module is only the thin ctypes plumbing that tests/ and bench.py use to
+drive the C ABI from Python; it holds no algorithmic code and has NO CPU fallback: if the HIP library
+is missing or no GPU is usable, compute calls raise.
+
+The directory name contains a hyphen, so import it through `load_package()` in __graft_entry__.py
+(registered as module `plink_ng_amd`).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+BIN_DIR = os.path.join(_HERE, "bin")
+LIB_PATH = os.path.join(LIB_DIR, "libldprune_hip.so")
+CLI_PATH = os.path.join(BIN_DIR, "plink2-hip")
+
+LDP_OK, LDP_ERR_INVALID, LDP_ERR_NOMEM, LDP_ERR_GPU, LDP_ERR_STATE, LDP_ERR_UNSUPPORTED = range(6)
+LDP_GENO_INVERSE, LDP_GENO_REF, LDP_GENO_BED = 0, 1, 2
+LDP_MEM_HOST, LDP_MEM_DEVICE = 0, 1
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+
+
+class LdpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ldp error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ldp_params(ctypes.Structure):
+    _fields_ = [("founder_ct", ctypes.c_uint32), ("prune_window_size", ctypes.c_uint32),
+                ("prune_window_incr", ctypes.c_uint32), ("window_is_bp", ctypes.c_uint32),
+                ("plink1_order", ctypes.c_uint32), ("prune_last_param", ctypes.c_double),
+                ("device", ctypes.c_int32), ("stream", ctypes.c_void_p)]
+
+
+class ldp_pair_stats_t(ctypes.Structure):
+    _fields_ = [("nm", ctypes.c_uint32), ("sum1", ctypes.c_int32), ("ssq1", ctypes.c_uint32),
+                ("sum2", ctypes.c_int32), ("ssq2", ctypes.c_uint32), ("dot", ctypes.c_int32)]
+
+
+class ldp_variant_rec(ctypes.Structure):
+    _fields_ = [("nm_ct", ctypes.c_uint32), ("sum", ctypes.c_int32), ("ssq", ctypes.c_uint32),
+                ("flags", ctypes.c_uint32), ("n_homref", ctypes.c_uint32), ("n_het", ctypes.c_uint32),
+                ("n_homalt", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+class ldp_counters(ctypes.Structure):
+    _fields_ = [("candidate_pairs", ctypes.c_uint64), ("computed_pairs", ctypes.c_uint64),
+                ("replay_pairs", ctypes.c_uint64), ("pred_true", ctypes.c_uint64),
+                ("ms_prepare", ctypes.c_double), ("ms_pair_kernel", ctypes.c_double),
+                ("ms_replay", ctypes.c_double), ("ms_run_total", ctypes.c_double),
+                ("pair_kernel_launches", ctypes.c_uint32), ("subcontig_ct", ctypes.c_uint32),
+                ("owned_subcontig_ct", ctypes.c_uint32), ("window_max", ctypes.c_uint32)]
+
+    def asdict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+PAIR_STATS_DTYPE = np.dtype([("nm", "<u4"), ("sum1", "<i4"), ("ssq1", "<u4"), ("sum2", "<i4"), ("ssq2", "<u4"), ("dot", "<i4")])
+VARIANT_REC_DTYPE = np.dtype([("nm_ct", "<u4"), ("sum", "<i4"), ("ssq", "<u4"), ("flags", "<u4"), ("n_homref", "<u4"),
+                              ("n_het", "<u4"), ("n_homalt", "<u4"), ("reserved", "<u4")])
+
+# Every symbol include/ldprune_hip.h declares (checked by tests/test_cabi_symbols.py).
+CABI_SYMBOLS = [
+    "ldp_create", "ldp_destroy", "ldp_last_error", "ldp_device_count", "ldp_set_variants", "ldp_get_subcontigs",
+    "ldp_set_shard", "ldp_get_band", "ldp_load_genotypes", "ldp_set_maj_freqs", "ldp_set_preferred", "ldp_run",
+    "ldp_run_with_stats", "ldp_pair_stats", "ldp_debug_set_variant_recs", "ldp_debug_replay_pairs",
+    "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters",
+]
+
+
+def _sources():
+    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_engine.cpp")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    """Compile the HIP kernels + host runtime into lib/libldprune_hip.so for gfx950 (hipcc cross-compiles
+    without a GPU).  In-tree so the .so travels with the repo snapshot."""
+    deps = _sources() + [os.path.join(CSRC, "ldp_device.h"), os.path.join(REPO, "include", "ldprune_hip.h")]
+    if force or _stale(LIB_PATH, deps):
+        os.makedirs(LIB_DIR, exist_ok=True)
+        cmd = ["hipcc"] + HIPCC_FLAGS + ["-shared", "-o", LIB_PATH] + _sources()
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def build_cli(force=False, verbose=False):
+    src = os.path.join(CSRC, "plink2_hip_cli.cpp")
+    if not os.path.exists(src):
+        return None
+    deps = [src, LIB_PATH, os.path.join(REPO, "include", "ldprune_hip.h")]
+    if force or _stale(CLI_PATH, deps):
+        os.makedirs(BIN_DIR, exist_ok=True)
+        cmd = ["hipcc", "-O2", "-std=c++17", "-ffp-contract=off", "-o", CLI_PATH, src, "-L" + LIB_DIR, "-lldprune_hip",
+               "-Wl,-rpath,$ORIGIN/../lib", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return CLI_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the C-ABI library.  torch (when importable) is imported first so that the process ends up
+    with ONE libamdhip64 (torch bundles its own copy under the same soname)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LdpError(LDP_ERR_GPU, "HIP extension %s is missing; run __graft_entry__.build()" % LIB_PATH)
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional plumbing
+        pass
+    L = ctypes.CDLL(LIB_PATH)
+    vp = ctypes.c_void_p
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    f64p = ctypes.POINTER(ctypes.c_double)
+    L.ldp_create.argtypes = [ctypes.POINTER(ldp_params), ctypes.POINTER(vp)]
+    L.ldp_destroy.argtypes = [vp]
+    L.ldp_destroy.restype = None
+    L.ldp_last_error.argtypes = [vp]
+    L.ldp_last_error.restype = ctypes.c_char_p
+    L.ldp_device_count.argtypes = []
+    L.ldp_set_variants.argtypes = [vp, ctypes.c_uint32, u32p, u32p]
+    L.ldp_get_subcontigs.argtypes = [vp, u32p, u32p, ctypes.c_uint32]
+    L.ldp_set_shard.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, u32p]
+    L.ldp_get_band.argtypes = [vp, u32p, u64p]
+    L.ldp_load_genotypes.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]
+    L.ldp_set_maj_freqs.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, f64p]
+    L.ldp_set_preferred.argtypes = [vp, u64p]
+    L.ldp_run.argtypes = [vp, u64p]
+    L.ldp_run_with_stats.argtypes = [vp, u64p, vp, ctypes.c_uint64]
+    L.ldp_pair_stats.argtypes = [vp, ctypes.c_uint32, u32p, u32p, vp]
+    L.ldp_debug_set_variant_recs.argtypes = [vp, vp]
+    L.ldp_debug_replay_pairs.argtypes = [vp, ctypes.c_uint64, u32p, u32p, u64p]
+    L.ldp_get_variant_recs.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp]
+    L.ldp_get_maj_freqs.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, f64p]
+    L.ldp_get_planes.argtypes = [vp, ctypes.c_uint32, u32p, u32p]
+    L.ldp_get_counters.argtypes = [vp, ctypes.POINTER(ldp_counters)]
+    _lib = L
+    return L
+
+
+def device_count():
+    return int(lib().ldp_device_count())
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def kb_window(kb):
+    """plink2.cc:7266: window in bp = int32(kb * 1000 * (1 + 2^-44))."""
+    return int(float(kb) * 1000 * (1 + 2.0 ** -44))
+
+
+class LdPruneEngine:
+    """Mirror of the C ABI, one engine per GPU (one per process under torch.distributed)."""
+
+    def __init__(self, founder_ct, window, step=1, window_is_bp=False, r2=0.2, order=2, device=-1, stream=None):
+        self._L = lib()
+        p = ldp_params()
+        p.founder_ct = int(founder_ct)
+        p.prune_window_size = int(window)
+        p.prune_window_incr = int(step)
+        p.window_is_bp = 1 if window_is_bp else 0
+        p.plink1_order = 1 if order == 1 else 0
+        p.prune_last_param = float(r2)
+        p.device = int(device)
+        p.stream = ctypes.c_void_p(stream) if stream else None
+        self._h = ctypes.c_void_p()
+        rc = self._L.ldp_create(ctypes.byref(p), ctypes.byref(self._h))
+        if rc != LDP_OK:
+            raise LdpError(rc, "ldp_create failed")
+        self.founder_ct = int(founder_ct)
+        self.variant_ct = 0
+
+    def close(self):
+        if self._h:
+            self._L.ldp_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != LDP_OK:
+            raise LdpError(rc, self._L.ldp_last_error(self._h).decode())
+
+    # ---- planning
+    def set_variants(self, chr_idx, bps=None):
+        chr_idx = _u32(chr_idx)
+        self.variant_ct = len(chr_idx)
+        bp_ptr = None
+        if bps is not None:
+            bps = _u32(bps)
+            assert len(bps) == len(chr_idx)
+            bp_ptr = _ptr(bps, ctypes.c_uint32)
+        self._ck(self._L.ldp_set_variants(self._h, self.variant_ct, _ptr(chr_idx, ctypes.c_uint32), bp_ptr))
+
+    def subcontigs(self):
+        ct = ctypes.c_uint32()
+        self._ck(self._L.ldp_get_subcontigs(self._h, ctypes.byref(ct), None, 0))
+        info = np.zeros(2 * max(ct.value, 1), dtype=np.uint32)
+        self._ck(self._L.ldp_get_subcontigs(self._h, ctypes.byref(ct), _ptr(info, ctypes.c_uint32), ct.value))
+        return [(int(info[2 * k]), int(info[2 * k + 1])) for k in range(ct.value)]
+
+    def set_shard(self, rank, world):
+        n = len(self.subcontigs())
+        owner = np.zeros(max(n, 1), dtype=np.uint32)
+        self._ck(self._L.ldp_set_shard(self._h, rank, world, _ptr(owner, ctypes.c_uint32)))
+        return owner[:n].copy()
+
+    def band(self):
+        lo = np.zeros(max(self.variant_ct, 1), dtype=np.uint32)
+        tot = ctypes.c_uint64()
+        self._ck(self._L.ldp_get_band(self._h, _ptr(lo, ctypes.c_uint32), ctypes.byref(tot)))
+        return lo[:self.variant_ct], tot.value
+
+    # ---- data
+    def load_genotypes_host(self, first_variant, rows, encoding=LDP_GENO_INVERSE):
+        """rows: C-contiguous 2-D uint8/uint64 array, one packed 2-bit row per variant."""
+        rows = np.ascontiguousarray(rows)
+        stride = rows.strides[0]
+        self._ck(self._L.ldp_load_genotypes(self._h, first_variant, rows.shape[0], rows.ctypes.data_as(ctypes.c_void_p),
+                                            stride, LDP_MEM_HOST, encoding))
+
+    def load_genotypes_device(self, first_variant, n, device_ptr, stride_bytes, encoding=LDP_GENO_INVERSE):
+        self._ck(self._L.ldp_load_genotypes(self._h, first_variant, n, ctypes.c_void_p(device_ptr), stride_bytes,
+                                            LDP_MEM_DEVICE, encoding))
+
+    def set_maj_freqs(self, first_variant, freqs):
+        freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+        self._ck(self._L.ldp_set_maj_freqs(self._h, first_variant, len(freqs), _ptr(freqs, ctypes.c_double)))
+
+    def set_preferred(self, mask_bool):
+        if mask_bool is None:
+            self._ck(self._L.ldp_set_preferred(self._h, None))
+            return
+        bits = np.packbits(np.asarray(mask_bool, dtype=bool), bitorder="little")
+        buf = np.zeros(((self.variant_ct + 63) // 64) * 8, dtype=np.uint8)
+        buf[:len(bits)] = bits
+        self._ck(self._L.ldp_set_preferred(self._h, _ptr(buf.view(np.uint64), ctypes.c_uint64)))
+
+    # ---- compute
+    def _removed_buf(self):
+        return np.zeros((self.variant_ct + 63) // 64 + 1, dtype=np.uint64)
+
+    def _to_bool(self, bm):
+        return np.unpackbits(bm.view(np.uint8), bitorder="little")[:self.variant_ct].astype(bool)
+
+    def run(self):
+        bm = self._removed_buf()
+        self._ck(self._L.ldp_run(self._h, _ptr(bm, ctypes.c_uint64)))
+        return self._to_bool(bm)
+
+    def run_bitmap(self):
+        bm = self._removed_buf()
+        self._ck(self._L.ldp_run(self._h, _ptr(bm, ctypes.c_uint64)))
+        return bm
+
+    def run_with_stats(self):
+        _, cand = self.band()
+        stats = np.zeros(max(cand, 1), dtype=PAIR_STATS_DTYPE)
+        bm = self._removed_buf()
+        self._ck(self._L.ldp_run_with_stats(self._h, _ptr(bm, ctypes.c_uint64), stats.ctypes.data_as(ctypes.c_void_p), len(stats)))
+        return self._to_bool(bm), stats[:cand]
+
+    def pair_stats(self, first, second):
+        first, second = _u32(first), _u32(second)
+        out = np.zeros(max(len(first), 1), dtype=PAIR_STATS_DTYPE)
+        self._ck(self._L.ldp_pair_stats(self._h, len(first), _ptr(first, ctypes.c_uint32), _ptr(second, ctypes.c_uint32),
+                                        out.ctypes.data_as(ctypes.c_void_p)))
+        return out[:len(first)]
+
+    def debug_set_variant_recs(self, recs):
+        recs = np.ascontiguousarray(recs, dtype=VARIANT_REC_DTYPE)
+        assert len(recs) == self.variant_ct
+        self._ck(self._L.ldp_debug_set_variant_recs(self._h, recs.ctypes.data_as(ctypes.c_void_p)))
+
+    def debug_replay_pairs(self, first, second):
+        first, second = _u32(first), _u32(second)
+        bm = self._removed_buf()
+        self._ck(self._L.ldp_debug_replay_pairs(self._h, len(first), _ptr(first, ctypes.c_uint32), _ptr(second, ctypes.c_uint32),
+                                                _ptr(bm, ctypes.c_uint64)))
+        return self._to_bool(bm)
+
+    # ---- inspection
+    def variant_recs(self, first=0, n=None):
+        n = self.variant_ct - first if n is None else n
+        out = np.zeros(max(n, 1), dtype=VARIANT_REC_DTYPE)
+        self._ck(self._L.ldp_get_variant_recs(self._h, first, n, out.ctypes.data_as(ctypes.c_void_p)))
+        return out[:n]
+
+    def maj_freqs(self, first=0, n=None):
+        n = self.variant_ct - first if n is None else n
+        out = np.zeros(max(n, 1), dtype=np.float64)
+        self._ck(self._L.ldp_get_maj_freqs(self._h, first, n, _ptr(out, ctypes.c_double)))
+        return out[:n]
+
+    def planes(self, variant):
+        w = (self.founder_ct + 31) // 32
+        hom = np.zeros(w, dtype=np.uint32)
+        r2h = np.zeros(w, dtype=np.uint32)
+        self._ck(self._L.ldp_get_planes(self._h, variant, _ptr(hom, ctypes.c_uint32), _ptr(r2h, ctypes.c_uint32)))
+        return hom, r2h
+
+    def counters(self):
+        c = ldp_counters()
+        self._ck(self._L.ldp_get_counters(self._h, ctypes.byref(c)))
+        return c.asdict()

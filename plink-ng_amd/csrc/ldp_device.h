@@ -1,0 +1,80 @@
+// ldp_device.h -- layout constants and launch-side declarations shared by the HIP kernels
+// (ldp_kernels.hip) and the host runtime (ldp_engine.cpp).
+#ifndef LDP_DEVICE_H
+#define LDP_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ldprune_hip.h"
+
+namespace ldp {
+
+// ---- HBM layout of the bit-planes -------------------------------------------------------------
+// One variant = row of `chunks` k-chunks; a k-chunk = kChunkDwords dwords of the `hom` plane followed
+// by kChunkDwords dwords of the `ref2het` plane (256 contiguous bytes), so one k-chunk of one variant
+// is exactly what 16 lanes x 16 B stage into one LDS row.  Bit s%32 of plane dword s/32 = sample s.
+// Pad dwords (samples >= founder_ct) are zero in both planes == "missing", which contributes to no count.
+constexpr int kChunkDwords = 32;                 // plane dwords per k-chunk (1024 samples)
+constexpr int kRowChunkDwords = 2 * kChunkDwords; // hom + ref2het
+constexpr int kLdsRowDwords = kRowChunkDwords + 4; // 68: odd number of 16-B slots -> conflict-free b128 reads
+
+// ---- pair-tile geometry -------------------------------------------------------------------------
+// A block owns kTileJ consecutive "second" variants j and a run of distances d = j - i, split in
+// units of 8 among its 4 waves.  Lane (tx = lane&7, ty = lane>>3) of a wave owns j = j0 + tx + 8b
+// (b < 4) and d = dw0 + ty + 8a (a < NA <= 4).
+constexpr int kTileJ = 32;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlockThreads = 64 * kWavesPerBlock;
+constexpr int kMaxUnitsPerWave = 4;              // NA
+constexpr int kMaxUnitsPerBlock = kWavesPerBlock * kMaxUnitsPerWave;  // 16 -> 128 distances
+
+struct WorkItem {
+  uint32_t j0;        // first second-variant index
+  uint32_t jend;      // exclusive end (<= j0 + kTileJ)
+  uint32_t d0;        // first distance handled by the block (>= 1)
+  uint32_t units;     // units[w] in byte w: number of 8-distance units wave w handles
+  uint32_t sfirst;    // subcontig bounds (row clamp)
+  uint32_t send;
+};
+
+struct PairKernelArgs {
+  const uint32_t* planes;        // [variant][chunk][2][kChunkDwords]
+  uint64_t row_dwords;           // dwords per variant row = chunks * kRowChunkDwords
+  uint32_t chunks;
+  uint32_t founder_ct;
+  const ldp_variant_rec* recs;
+  const uint32_t* lo;            // window start per variant
+  const uint64_t* row_off;       // predicate row offset (u32 words) per variant
+  uint32_t* pred;                // predicate bit rows
+  const WorkItem* items;
+  uint32_t n_items;
+  uint32_t plane_base_variant;   // variant index of planes row 0
+  double thresh;                 // r2 * (1 + 2^-44)
+  ldp_pair_stats_t* stats;       // optional (parity tests)
+  const uint64_t* pair_off;      // optional, with stats
+  unsigned long long* counters;  // [0] = predicates true
+  uint8_t* item_general;         // per work item: 1 = some row has missing calls -> general kernel
+};
+
+struct PrepareArgs {
+  const uint8_t* geno;           // row 0 = variant `first`
+  uint64_t stride_bytes;
+  uint32_t n_variants;
+  uint32_t founder_ct;
+  int encoding;
+  uint32_t* planes;              // row 0 = variant `first`
+  uint64_t row_dwords;
+  uint32_t chunks;
+  ldp_variant_rec* recs;         // entry 0 = variant `first`
+};
+
+hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream);
+hipError_t launch_pair_tiles(const PairKernelArgs& a, uint32_t max_units, hipStream_t stream);
+hipError_t launch_pair_stats_ref(const uint32_t* planes, uint64_t row_dwords, uint32_t chunks, uint32_t plane_base_variant,
+                                 const uint32_t* first, const uint32_t* second, uint32_t n_pairs,
+                                 ldp_pair_stats_t* out, hipStream_t stream);
+size_t pair_tiles_lds_bytes(uint32_t max_units);
+
+}  // namespace ldp
+#endif

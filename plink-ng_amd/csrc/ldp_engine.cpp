@@ -1,0 +1,1215 @@
+// ldp_engine.cpp -- host runtime behind include/ldprune_hip.h.
+//
+// Host side of the MI355X-native --indep-pairwise path:
+//   * planning: subcontig split (LdPruneSubcontigSplitAll, plink2_ld.cc:2165-2268) and the window
+//     iterator (LdPruneNextSubcontig / LdPruneNextWindow, :605-689) are run ONCE up front -- they depend
+//     only on positions -- to fix, for every variant j, the first partner index lo[j] it is ever
+//     compared with.  The candidate pairs form a band {lo[j] <= i < j}.
+//   * tile scheduling: the band is cut into (32 seconds) x (<=128 distances) parallelogram work items
+//     for pair_tiles_kernel.
+//   * replay: the order-dependent greedy scan (:931-1100) consumes only predicate bits and major-allele
+//     frequencies, so it is replayed sequentially on the host from the kernel's bit rows.
+// There is deliberately no CPU implementation of the pair statistics here: without a HIP device
+// ldp_load_genotypes()/ldp_run() fail with LDP_ERR_GPU.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ldp_device.h"
+
+using namespace ldp;
+
+namespace {
+
+constexpr double kSmallEpsilon = 0.00000000000005684341886080801486968994140625;  // 2^-44 (plink2_float.h:119)
+
+struct Subcontig {
+  uint32_t len;
+  uint32_t first;        // global variant index
+  uint32_t owner;        // rank
+  uint32_t local_first;  // valid when owned
+};
+
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct ldp_engine {
+  ldp_params P;
+  int device = -1;
+  bool gpu_ok = false;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // ---- plan (global indices) ----
+  bool planned = false;
+  uint32_t variant_ct = 0;
+  std::vector<uint32_t> bps;
+  std::vector<Subcontig> subs;
+  uint32_t window_max = 0;
+  std::vector<uint32_t> lo_global;   // window start per variant (== v for variants outside every subcontig)
+  std::vector<uint8_t> batch_end;    // 1 = a window batch ends with this variant
+
+  // ---- shard (local indices = owned subcontigs concatenated) ----
+  uint32_t rank = 0, world = 1;
+  uint32_t local_ct = 0;
+  std::vector<uint32_t> owned;            // subcontig ids
+  std::vector<uint32_t> local_to_global;
+  std::vector<int64_t> global_to_local;   // -1 = not owned
+  std::vector<uint32_t> lo_local;
+  std::vector<uint64_t> row_off;          // local_ct + 1
+  std::vector<uint64_t> pair_off;         // local_ct + 1
+  uint64_t pred_words = 0;
+  uint64_t cand_pairs = 0;
+  uint64_t computed_pairs = 0;
+  std::vector<WorkItem> items;
+  uint32_t max_units = 0;
+
+  // ---- data ----
+  uint32_t chunks = 0;
+  uint64_t row_dwords = 0;
+  std::vector<uint8_t> loaded;            // local
+  std::vector<ldp_variant_rec> recs;      // local (host mirror)
+  bool recs_host_valid = false;
+  std::vector<double> maj_freq;           // local
+  std::vector<uint8_t> mf_set;            // local
+  std::vector<uint64_t> preferred;        // global bitmap (may be empty)
+
+  // ---- device ----
+  uint32_t* d_planes = nullptr;
+  ldp_variant_rec* d_recs = nullptr;
+  uint32_t* d_lo = nullptr;
+  uint64_t* d_row_off = nullptr;
+  uint64_t* d_pair_off = nullptr;
+  uint32_t* d_pred = nullptr;
+  WorkItem* d_items = nullptr;
+  uint8_t* d_item_general = nullptr;
+  unsigned long long* d_counters = nullptr;
+  uint32_t* h_pred = nullptr;  // pinned
+  bool plan_uploaded = false;
+
+  ldp_counters ctr;
+
+  ldp_engine() { memset(&ctr, 0, sizeof(ctr)); }
+};
+
+namespace {
+
+int fail(ldp_engine* e, int code, const std::string& msg) {
+  if (e) {
+    e->err = msg;
+  }
+  return code;
+}
+
+int hipfail(ldp_engine* e, hipError_t rc, const char* what) {
+  if (rc == hipErrorOutOfMemory) {
+    return fail(e, LDP_ERR_NOMEM, std::string(what) + ": " + hipGetErrorString(rc));
+  }
+  return fail(e, LDP_ERR_GPU, std::string(what) + ": " + hipGetErrorString(rc));
+}
+
+#define HIP_TRY(e, call)                              \
+  do {                                                \
+    hipError_t rc__ = (call);                         \
+    if (rc__ != hipSuccess) {                         \
+      return hipfail((e), rc__, #call);               \
+    }                                                 \
+  } while (0)
+
+void free_device(ldp_engine* e) {
+  if (!e->gpu_ok) {
+    return;
+  }
+  (void)hipFree(e->d_planes);
+  (void)hipFree(e->d_recs);
+  (void)hipFree(e->d_lo);
+  (void)hipFree(e->d_row_off);
+  (void)hipFree(e->d_pair_off);
+  (void)hipFree(e->d_pred);
+  (void)hipFree(e->d_items);
+  (void)hipFree(e->d_item_general);
+  (void)hipFree(e->d_counters);
+  if (e->h_pred) {
+    (void)hipHostFree(e->h_pred);
+  }
+  e->d_planes = nullptr;
+  e->d_recs = nullptr;
+  e->d_lo = nullptr;
+  e->d_row_off = nullptr;
+  e->d_pair_off = nullptr;
+  e->d_pred = nullptr;
+  e->d_items = nullptr;
+  e->d_item_general = nullptr;
+  e->d_counters = nullptr;
+  e->h_pred = nullptr;
+  e->plan_uploaded = false;
+}
+
+// LdPruneSubcontigSplitAll, plink2_ld.cc:2165-2268 (every variant included).
+void subcontig_split(const uint32_t* chr_idx, const uint32_t* bps, uint32_t variant_ct, uint32_t window, std::vector<Subcontig>* subs, uint32_t* window_max_out) {
+  subs->clear();
+  uint32_t window_max = bps ? 1 : 0;
+  uint32_t vidx0 = 0;
+  auto push = [&](uint32_t first, uint32_t len) {
+    Subcontig s;
+    s.len = len;
+    s.first = first;
+    s.owner = 0;
+    s.local_first = 0;
+    subs->push_back(s);
+  };
+  while (vidx0 < variant_ct) {
+    uint32_t chr_end = vidx0 + 1;
+    while ((chr_end < variant_ct) && (chr_idx[chr_end] == chr_idx[vidx0])) {
+      ++chr_end;
+    }
+    const uint32_t chr_variant_ct = chr_end - vidx0;
+    if (chr_variant_ct > 1) {
+      if (bps) {
+        uint32_t sub_first = vidx0;
+        uint32_t win_first = vidx0;
+        uint32_t win_pos_first = bps[vidx0];
+        uint32_t prev_pos = win_pos_first;
+        uint32_t v = vidx0 + 1;
+        do {
+          uint32_t bp_thresh = bps[v];
+          if (bp_thresh < window) {
+            prev_pos = bp_thresh;
+            bp_thresh = 0;
+          } else {
+            if (bp_thresh - window > prev_pos) {  // gap wider than the window: new subcontig (:2200)
+              if (v > sub_first + 1) {
+                push(sub_first, v - sub_first);
+              }
+              sub_first = v;
+            }
+            prev_pos = bp_thresh;
+            bp_thresh -= window;
+          }
+          if (bp_thresh > win_pos_first) {
+            do {
+              ++win_first;
+              win_pos_first = bps[win_first];
+            } while (bp_thresh > win_pos_first);
+          } else if (v - win_first == window_max) {
+            ++window_max;
+          }
+        } while (++v < chr_end);
+        if (v > sub_first + 1) {
+          push(sub_first, v - sub_first);
+        }
+      } else {
+        push(vidx0, chr_variant_ct);
+        if ((window_max < window) && (chr_variant_ct > window_max)) {
+          window_max = chr_variant_ct;
+        }
+      }
+    }
+    vidx0 = chr_end;
+  }
+  if ((!bps) && (window_max > window)) {
+    window_max = window;
+  }
+  *window_max_out = window_max;
+}
+
+// LdPruneNextSubcontig + LdPruneNextWindow (plink2_ld.cc:605-689) reduced to what they decide:
+// the sequence of batches [cur, next_end) and the window start each batch is scanned against.
+void plan_subcontig(const ldp_engine* e, const Subcontig& s, std::vector<uint32_t>* lo, std::vector<uint8_t>* batch_end) {
+  const uint32_t* bps = e->P.window_is_bp ? e->bps.data() : nullptr;
+  const uint32_t W = e->P.prune_window_size;
+  const uint32_t incr = e->P.prune_window_incr;
+  const uint32_t first = s.first;
+  const uint32_t end = s.first + s.len;
+  uint32_t window_start = first;
+  uint32_t winstart_v = first;
+  uint32_t winend_v = first;
+  uint32_t next_end;
+  if (bps) {
+    const uint32_t bp_thresh = bps[first] + W;
+    uint32_t first_window_len = 1;
+    do {
+      ++winend_v;
+    } while ((bps[winend_v] <= bp_thresh) && (++first_window_len < s.len));
+    next_end = first + first_window_len;
+  } else {
+    next_end = first + std::min(s.len, W);
+  }
+  uint32_t cur = first;
+  while (true) {
+    for (uint32_t j = cur; j < next_end; ++j) {
+      (*lo)[j] = window_start;
+    }
+    (*batch_end)[next_end - 1] = 1;
+    cur = next_end;
+    if (next_end == end) {
+      break;
+    }
+    if (bps) {
+      const uint32_t start_min_bp = bps[winend_v] - W;
+      uint32_t start_bp;
+      do {
+        ++window_start;
+        ++winstart_v;
+        start_bp = bps[winstart_v];
+      } while (start_bp < start_min_bp);
+      const uint32_t end_thresh = start_bp + W;
+      do {
+        if (++next_end == end) {
+          break;
+        }
+        ++winend_v;
+      } while (bps[winend_v] <= end_thresh);
+    } else {
+      window_start += incr;
+      next_end = std::min(window_start + W, end);
+    }
+  }
+}
+
+void build_shard(ldp_engine* e) {
+  // local index space
+  e->owned.clear();
+  e->local_to_global.clear();
+  e->global_to_local.assign(e->variant_ct, -1);
+  uint32_t local = 0;
+  for (uint32_t k = 0; k < e->subs.size(); ++k) {
+    Subcontig& s = e->subs[k];
+    if (s.owner != e->rank) {
+      continue;
+    }
+    s.local_first = local;
+    e->owned.push_back(k);
+    for (uint32_t v = 0; v < s.len; ++v) {
+      e->global_to_local[s.first + v] = local + v;
+      e->local_to_global.push_back(s.first + v);
+    }
+    local += s.len;
+  }
+  e->local_ct = local;
+  e->lo_local.assign(local, 0);
+  e->row_off.assign(static_cast<size_t>(local) + 1, 0);
+  e->pair_off.assign(static_cast<size_t>(local) + 1, 0);
+  uint64_t words = 0, pairs = 0;
+  for (uint32_t k : e->owned) {
+    const Subcontig& s = e->subs[k];
+    for (uint32_t v = 0; v < s.len; ++v) {
+      const uint32_t j = s.local_first + v;
+      const uint32_t lo = e->lo_global[s.first + v] - s.first + s.local_first;
+      e->lo_local[j] = lo;
+      e->row_off[j] = words;
+      e->pair_off[j] = pairs;
+      if (j > lo) {
+        words += ((j - 1) >> 5) - (lo >> 5) + 1;
+        pairs += j - lo;
+      }
+    }
+  }
+  e->row_off[local] = words;
+  e->pair_off[local] = pairs;
+  e->pred_words = words;
+  e->cand_pairs = pairs;
+
+  // work items: 32 seconds x runs of 8-distance units, <= 16 units per block, spread over waves
+  e->items.clear();
+  e->max_units = 0;
+  e->computed_pairs = 0;
+  for (uint32_t k : e->owned) {
+    const Subcontig& s = e->subs[k];
+    const uint32_t sfirst = s.local_first;
+    const uint32_t send = s.local_first + s.len;
+    for (uint32_t j0 = sfirst; j0 < send; j0 += kTileJ) {
+      const uint32_t jend = std::min(j0 + kTileJ, send);
+      uint32_t dmax = 0;
+      for (uint32_t j = j0; j < jend; ++j) {
+        dmax = std::max(dmax, j - e->lo_local[j]);
+      }
+      if (!dmax) {
+        continue;
+      }
+      const uint32_t units = (dmax + 7) / 8;
+      const uint32_t blocks = (units + kMaxUnitsPerBlock - 1) / kMaxUnitsPerBlock;
+      const uint32_t base = units / blocks;
+      const uint32_t extra = units % blocks;
+      uint32_t d0 = 1;
+      for (uint32_t blk = 0; blk < blocks; ++blk) {
+        const uint32_t u = base + ((blk < extra) ? 1 : 0);
+        const uint32_t waves_used = (u + kMaxUnitsPerWave - 1) / kMaxUnitsPerWave;
+        const uint32_t wb = u / waves_used;
+        const uint32_t we = u % waves_used;
+        WorkItem it;
+        it.j0 = j0;
+        it.jend = jend;
+        it.d0 = d0;
+        it.units = 0;
+        for (uint32_t w = 0; w < waves_used; ++w) {
+          it.units |= (wb + ((w < we) ? 1 : 0)) << (8 * w);
+        }
+        it.sfirst = sfirst;
+        it.send = send;
+        e->items.push_back(it);
+        e->max_units = std::max(e->max_units, u);
+        e->computed_pairs += static_cast<uint64_t>(u) * 8 * kTileJ;
+        d0 += 8 * u;
+      }
+    }
+  }
+  e->loaded.assign(local, 0);
+  e->recs.assign(local, ldp_variant_rec());
+  e->recs_host_valid = false;
+  e->maj_freq.assign(local, 0.0);
+  e->mf_set.assign(local, 0);
+  free_device(e);
+}
+
+int ensure_device_plan(ldp_engine* e) {
+  if (!e->gpu_ok) {
+    return fail(e, LDP_ERR_GPU, "no usable HIP device");
+  }
+  if (e->plan_uploaded) {
+    return LDP_OK;
+  }
+  HIP_TRY(e, hipSetDevice(e->device));
+  const uint32_t plane_dwords = (e->P.founder_ct + 31) / 32;
+  e->chunks = (plane_dwords + kChunkDwords - 1) / kChunkDwords;
+  e->row_dwords = static_cast<uint64_t>(e->chunks) * kRowChunkDwords;
+  const size_t n = std::max<size_t>(e->local_ct, 1);
+  HIP_TRY(e, hipMalloc(&e->d_planes, n * e->row_dwords * sizeof(uint32_t)));
+  HIP_TRY(e, hipMalloc(&e->d_recs, n * sizeof(ldp_variant_rec)));
+  HIP_TRY(e, hipMalloc(&e->d_lo, n * sizeof(uint32_t)));
+  HIP_TRY(e, hipMalloc(&e->d_row_off, (n + 1) * sizeof(uint64_t)));
+  HIP_TRY(e, hipMalloc(&e->d_pair_off, (n + 1) * sizeof(uint64_t)));
+  HIP_TRY(e, hipMalloc(&e->d_pred, std::max<size_t>(e->pred_words, 1) * sizeof(uint32_t)));
+  HIP_TRY(e, hipMalloc(&e->d_items, std::max<size_t>(e->items.size(), 1) * sizeof(WorkItem)));
+  HIP_TRY(e, hipMalloc(&e->d_item_general, std::max<size_t>(e->items.size(), 1)));
+  HIP_TRY(e, hipMalloc(&e->d_counters, 4 * sizeof(unsigned long long)));
+  HIP_TRY(e, hipHostMalloc(&e->h_pred, std::max<size_t>(e->pred_words, 1) * sizeof(uint32_t), hipHostMallocDefault));
+  if (e->local_ct) {
+    HIP_TRY(e, hipMemcpyAsync(e->d_lo, e->lo_local.data(), e->local_ct * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->d_row_off, e->row_off.data(), (e->local_ct + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->d_pair_off, e->pair_off.data(), (e->local_ct + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+  }
+  if (!e->items.empty()) {
+    HIP_TRY(e, hipMemcpyAsync(e->d_items, e->items.data(), e->items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, e->stream));
+  }
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  e->plan_uploaded = true;
+  return LDP_OK;
+}
+
+int fetch_recs(ldp_engine* e) {
+  if (e->recs_host_valid) {
+    return LDP_OK;
+  }
+  if (e->local_ct) {
+    HIP_TRY(e, hipMemcpyAsync(e->recs.data(), e->d_recs, e->local_ct * sizeof(ldp_variant_rec), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+  }
+  e->recs_host_valid = true;
+  return LDP_OK;
+}
+
+// Major-allele frequency from the device's allele counts, in the reference's arithmetic:
+// freq_ref = ref * (1/tot) (plink2_filter.cc:2144-2147), major = REF iff >= 0.5 (plink2_common.h:559-567),
+// GetAlleleFreq for the last allele = max(1 - freq_ref, 0) (plink2_common.h:584-593).
+int derive_maj_freq(ldp_engine* e, uint32_t l) {
+  const ldp_variant_rec& r = e->recs[l];
+  const uint64_t ref_ct = 2ull * r.n_homref + r.n_het;
+  const uint64_t alt_ct = 2ull * r.n_homalt + r.n_het;
+  const uint64_t tot = ref_ct + alt_ct;
+  double ref_freq = 0.5;
+  if (tot) {
+    const double tot_recip = 1.0 / static_cast<double>(tot);
+    ref_freq = static_cast<double>(ref_ct) * tot_recip;
+  }
+  const bool alt_major = !(ref_freq >= 0.5);
+  if (alt_major != static_cast<bool>(r.flags & 1)) {
+    return fail(e, LDP_ERR_GPU, "device and host disagree on the major allele");
+  }
+  double mf = ref_freq;
+  if (alt_major) {
+    mf = 1.0 - ref_freq;
+    if (mf < 0.0) {
+      mf = 0.0;
+    }
+  }
+  e->maj_freq[l] = mf;
+  return LDP_OK;
+}
+
+inline bool bit32(const std::vector<uint32_t>& bm, uint32_t i) { return (bm[i >> 5] >> (i & 31)) & 1; }
+inline void set32(std::vector<uint32_t>& bm, uint32_t i) { bm[i >> 5] |= 1u << (i & 31); }
+
+// next index >= from with a clear bit, or `limit` if none below it
+inline uint32_t next_clear(const std::vector<uint32_t>& bm, uint32_t from, uint32_t limit) {
+  while (from < limit) {
+    const uint32_t w = ~bm[from >> 5] >> (from & 31);
+    if (w) {
+      const uint32_t r = from + __builtin_ctz(w);
+      return (r < limit) ? r : limit;
+    }
+    from = (from | 31) + 1;
+  }
+  return limit;
+}
+
+// The greedy scan of IndepPairwiseThread (plink2_ld.cc:931-1100) replayed from predicate bits.
+// R = removed bitmap over local indices (u32 words).  pred row j: bit i of word (i>>5)-(lo[j]>>5).
+void replay(ldp_engine* e, const uint32_t* pred, const std::vector<double>& mf, std::vector<uint32_t>& R, uint64_t* replay_pairs_out) {
+  uint64_t replay_pairs = 0;
+  const bool plink1 = e->P.plink1_order != 0;
+  std::vector<uint32_t> first_unchecked;
+  if (plink1) {
+    first_unchecked.assign(e->local_ct, 0);
+  }
+  for (uint32_t k : e->owned) {
+    const Subcontig& s = e->subs[k];
+    const uint32_t sfirst = s.local_first;
+    const uint32_t send = s.local_first + s.len;
+    uint32_t ns = sfirst;
+    while (ns < send) {
+      uint32_t ne = ns;
+      while (!e->batch_end[e->local_to_global[ne]]) {
+        ++ne;
+      }
+      ++ne;
+      const uint32_t lo = e->lo_local[ns];
+      // load-time removal of monomorphic variants (:902-904)
+      for (uint32_t j = ns; j < ne; ++j) {
+        if (e->recs[j].flags & 2u) {
+          set32(R, j);
+        } else if (plink1) {
+          first_unchecked[j] = j + 1;
+        }
+      }
+      if (!plink1) {
+        // :1042-1100 -- seconds newest first, firsts descending over live window members.  The second is
+        // NOT re-checked for having been removed earlier in this batch (quirk kept on purpose).
+        for (uint32_t j = ne; j-- > ns;) {
+          if (j <= lo) {
+            continue;
+          }
+          const uint32_t* row = pred + e->row_off[j];
+          const uint32_t wbase = lo >> 5;
+          const uint32_t nw = ((j - 1) >> 5) - wbase + 1;
+          const double mf_j_eps = mf[j] * (1 + kSmallEpsilon);
+          bool second_removed = false;
+          for (uint32_t w = nw; (w-- > 0) && !second_removed;) {
+            uint32_t bits = row[w] & ~R[wbase + w];
+            while (bits) {
+              const uint32_t t = 31 - __builtin_clz(bits);
+              bits &= ~(1u << t);
+              const uint32_t i = ((wbase + w) << 5) + t;
+              ++replay_pairs;
+              if (mf[i] <= mf_j_eps) {
+                set32(R, j);
+                second_removed = true;
+                break;
+              }
+              set32(R, i);
+            }
+          }
+        }
+      } else {
+        // :931-1037 PLINK 1 order
+        bool changed;
+        do {
+          changed = false;
+          for (uint32_t first = next_clear(R, lo, ne); first < ne; first = next_clear(R, first + 1, ne)) {
+            const uint32_t fu = first_unchecked[first];
+            if (fu == ne) {
+              continue;
+            }
+            uint32_t second = next_clear(R, first + 1, ne);
+            while ((second < ne) && (second < fu)) {
+              second = next_clear(R, second + 1, ne);
+            }
+            if (second >= ne) {
+              first_unchecked[first] = ne;
+              continue;
+            }
+            while (true) {
+              const uint32_t lo2 = e->lo_local[second];
+              const uint32_t word = pred[e->row_off[second] + ((first >> 5) - (lo2 >> 5))];
+              ++replay_pairs;
+              if ((word >> (first & 31)) & 1) {
+                if (mf[first] > mf[second] * (1 + kSmallEpsilon)) {
+                  set32(R, first);
+                } else {
+                  set32(R, second);
+                  const uint32_t nxt = next_clear(R, second + 1, ne);
+                  first_unchecked[first] = (nxt < ne) ? nxt : ne;
+                }
+                changed = true;
+                break;
+              }
+              second = next_clear(R, second + 1, ne);
+              if (second >= ne) {
+                first_unchecked[first] = ne;
+                break;
+              }
+            }
+          }
+        } while (changed);
+      }
+      ns = ne;
+    }
+  }
+  *replay_pairs_out = replay_pairs;
+}
+
+int finish_removed(ldp_engine* e, const std::vector<uint32_t>& R, uint64_t* removed) {
+  memset(removed, 0, ((static_cast<size_t>(e->variant_ct) + 63) / 64) * sizeof(uint64_t));
+  for (uint32_t l = 0; l < e->local_ct; ++l) {
+    if (bit32(R, l)) {
+      const uint32_t g = e->local_to_global[l];
+      removed[g >> 6] |= 1ull << (g & 63);
+    }
+  }
+  return LDP_OK;
+}
+
+int prepare_mf(ldp_engine* e, std::vector<double>* mf) {
+  *mf = e->maj_freq;
+  for (uint32_t l = 0; l < e->local_ct; ++l) {
+    if (!e->mf_set[l]) {
+      return fail(e, LDP_ERR_STATE, "major-allele frequency missing for an owned variant (ldp_set_maj_freqs)");
+    }
+    if (!e->preferred.empty()) {
+      const uint32_t g = e->local_to_global[l];
+      if ((e->preferred[g >> 6] >> (g & 63)) & 1) {
+        (*mf)[l] -= 1.0;  // plink2_ld.cc:916-918
+      }
+    }
+  }
+  return LDP_OK;
+}
+
+int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t stats_capacity) {
+  if (!e->planned) {
+    return fail(e, LDP_ERR_STATE, "ldp_set_variants() has not been called");
+  }
+  if (!removed) {
+    return fail(e, LDP_ERR_INVALID, "removed bitmap is NULL");
+  }
+  const double t_start = now_ms();
+  int rc = ensure_device_plan(e);
+  if (rc) {
+    return rc;
+  }
+  for (uint32_t l = 0; l < e->local_ct; ++l) {
+    if (!e->loaded[l]) {
+      return fail(e, LDP_ERR_STATE, "genotypes missing for an owned variant (ldp_load_genotypes)");
+    }
+  }
+  rc = fetch_recs(e);
+  if (rc) {
+    return rc;
+  }
+  std::vector<double> mf;
+  rc = prepare_mf(e, &mf);
+  if (rc) {
+    return rc;
+  }
+  if (stats && (stats_capacity < e->cand_pairs)) {
+    return fail(e, LDP_ERR_INVALID, "stats buffer smaller than the candidate pair count");
+  }
+  HIP_TRY(e, hipSetDevice(e->device));
+  ldp_pair_stats_t* d_stats = nullptr;
+  if (stats && e->cand_pairs) {
+    HIP_TRY(e, hipMalloc(&d_stats, e->cand_pairs * sizeof(ldp_pair_stats_t)));
+    HIP_TRY(e, hipMemsetAsync(d_stats, 0, e->cand_pairs * sizeof(ldp_pair_stats_t), e->stream));
+  }
+  HIP_TRY(e, hipMemsetAsync(e->d_pred, 0, std::max<size_t>(e->pred_words, 1) * sizeof(uint32_t), e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
+
+  PairKernelArgs A;
+  A.planes = e->d_planes;
+  A.row_dwords = e->row_dwords;
+  A.chunks = e->chunks;
+  A.founder_ct = e->P.founder_ct;
+  A.recs = e->d_recs;
+  A.lo = e->d_lo;
+  A.row_off = e->d_row_off;
+  A.pred = e->d_pred;
+  A.items = e->d_items;
+  A.n_items = static_cast<uint32_t>(e->items.size());
+  A.plane_base_variant = 0;
+  A.thresh = e->P.prune_last_param * (1 + kSmallEpsilon);  // plink2_ld.cc:1255
+  A.stats = d_stats;
+  A.pair_off = e->d_pair_off;
+  A.counters = e->d_counters;
+  A.item_general = e->d_item_general;
+
+  hipEvent_t ev0, ev1;
+  HIP_TRY(e, hipEventCreate(&ev0));
+  HIP_TRY(e, hipEventCreate(&ev1));
+  HIP_TRY(e, hipEventRecord(ev0, e->stream));
+  hipError_t krc = launch_pair_tiles(A, e->max_units, e->stream);
+  if (krc != hipSuccess) {
+    return hipfail(e, krc, "pair_tiles_kernel launch");
+  }
+  HIP_TRY(e, hipEventRecord(ev1, e->stream));
+  if (e->pred_words) {
+    HIP_TRY(e, hipMemcpyAsync(e->h_pred, e->d_pred, e->pred_words * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  }
+  unsigned long long h_counters[4] = {0, 0, 0, 0};
+  HIP_TRY(e, hipMemcpyAsync(h_counters, e->d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, e->stream));
+  if (d_stats) {
+    HIP_TRY(e, hipMemcpyAsync(stats, d_stats, e->cand_pairs * sizeof(ldp_pair_stats_t), hipMemcpyDeviceToHost, e->stream));
+  }
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  float kms = 0.f;
+  HIP_TRY(e, hipEventElapsedTime(&kms, ev0, ev1));
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  if (d_stats) {
+    (void)hipFree(d_stats);
+  }
+
+  const double t_replay = now_ms();
+  std::vector<uint32_t> R((static_cast<size_t>(e->local_ct) + 31) / 32 + 1, 0);
+  uint64_t replay_pairs = 0;
+  replay(e, e->h_pred, mf, R, &replay_pairs);
+  finish_removed(e, R, removed);
+  const double t_end = now_ms();
+
+  e->ctr.candidate_pairs = e->cand_pairs;
+  e->ctr.computed_pairs = e->computed_pairs;
+  e->ctr.replay_pairs = replay_pairs;
+  e->ctr.pred_true = h_counters[0];
+  e->ctr.ms_pair_kernel = kms;
+  e->ctr.ms_replay = t_end - t_replay;
+  e->ctr.ms_run_total = t_end - t_start;
+  e->ctr.pair_kernel_launches = e->items.empty() ? 0 : 1;
+  return LDP_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int ldp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int ldp_create(const ldp_params* params, ldp_engine** out) {
+  if (!params || !out) {
+    return LDP_ERR_INVALID;
+  }
+  *out = nullptr;
+  if (params->founder_ct < 2) {  // plink2_ld.cc:2537
+    return LDP_ERR_INVALID;
+  }
+  if (params->founder_ct >= (1u << 30)) {  // plink2_ld.cc:1122
+    return LDP_ERR_UNSUPPORTED;
+  }
+  if (!(params->prune_last_param >= 0.0) || !(params->prune_last_param < 1.0)) {  // plink2.cc:7303
+    return LDP_ERR_INVALID;
+  }
+  if (params->window_is_bp) {
+    if ((params->prune_window_incr != 1) || (params->prune_window_size < 2)) {  // plink2.cc:7268,7290
+      return LDP_ERR_INVALID;
+    }
+  } else if ((params->prune_window_size < 1) || (params->prune_window_incr < 1) || (params->prune_window_incr > params->prune_window_size)) {
+    return LDP_ERR_INVALID;
+  }
+  ldp_engine* e = new (std::nothrow) ldp_engine();
+  if (!e) {
+    return LDP_ERR_NOMEM;
+  }
+  e->P = *params;
+  e->ctr = ldp_counters();
+  const int ndev = ldp_device_count();
+  if (ndev > 0) {
+    int dev = params->device;
+    if (dev < 0) {
+      if (hipGetDevice(&dev) != hipSuccess) {
+        dev = 0;
+      }
+    }
+    if ((dev < ndev) && (hipSetDevice(dev) == hipSuccess)) {
+      e->device = dev;
+      e->gpu_ok = true;
+      if (params->stream) {
+        e->stream = static_cast<hipStream_t>(params->stream);
+      } else if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess) {
+        e->own_stream = true;
+      } else {
+        e->gpu_ok = false;
+      }
+    }
+  }
+  *out = e;
+  return LDP_OK;
+}
+
+void ldp_destroy(ldp_engine* e) {
+  if (!e) {
+    return;
+  }
+  if (e->gpu_ok) {
+    (void)hipSetDevice(e->device);
+    free_device(e);
+    if (e->own_stream) {
+      (void)hipStreamDestroy(e->stream);
+    }
+  }
+  delete e;
+}
+
+const char* ldp_last_error(const ldp_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int ldp_set_variants(ldp_engine* e, uint32_t variant_ct, const uint32_t* chr_idx, const uint32_t* bps) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  if (variant_ct && !chr_idx) {
+    return fail(e, LDP_ERR_INVALID, "chr_idx is NULL");
+  }
+  if (e->P.window_is_bp && variant_ct && !bps) {
+    return fail(e, LDP_ERR_INVALID, "bp-based window needs variant positions");
+  }
+  for (uint32_t v = 1; v < variant_ct; ++v) {
+    if (chr_idx[v] < chr_idx[v - 1]) {
+      return fail(e, LDP_ERR_INVALID, "chr_idx must be nondecreasing");
+    }
+    if (e->P.window_is_bp && (chr_idx[v] == chr_idx[v - 1]) && (bps[v] < bps[v - 1])) {
+      return fail(e, LDP_ERR_INVALID, "positions must be sorted within a chromosome (plink2.cc:2926)");
+    }
+  }
+  e->variant_ct = variant_ct;
+  e->bps.clear();
+  if (bps) {
+    e->bps.assign(bps, bps + variant_ct);
+  }
+  subcontig_split(chr_idx, e->P.window_is_bp ? e->bps.data() : nullptr, variant_ct, e->P.prune_window_size, &e->subs, &e->window_max);
+  e->lo_global.resize(variant_ct);
+  for (uint32_t v = 0; v < variant_ct; ++v) {
+    e->lo_global[v] = v;
+  }
+  e->batch_end.assign(variant_ct, 0);
+  for (const Subcontig& s : e->subs) {
+    plan_subcontig(e, s, &e->lo_global, &e->batch_end);
+  }
+  e->rank = 0;
+  e->world = 1;
+  for (Subcontig& s : e->subs) {
+    s.owner = 0;
+  }
+  e->planned = true;
+  build_shard(e);
+  e->ctr.subcontig_ct = static_cast<uint32_t>(e->subs.size());
+  e->ctr.owned_subcontig_ct = static_cast<uint32_t>(e->owned.size());
+  e->ctr.window_max = e->window_max;
+  return LDP_OK;
+}
+
+int ldp_get_subcontigs(const ldp_engine* e, uint32_t* ct, uint32_t* info, uint32_t info_capacity_pairs) {
+  if (!e || !e->planned || !ct) {
+    return LDP_ERR_STATE;
+  }
+  *ct = static_cast<uint32_t>(e->subs.size());
+  if (info) {
+    const uint32_t n = std::min<uint32_t>(*ct, info_capacity_pairs);
+    for (uint32_t k = 0; k < n; ++k) {
+      info[2 * k] = e->subs[k].len;
+      info[2 * k + 1] = e->subs[k].first;
+    }
+  }
+  return LDP_OK;
+}
+
+int ldp_set_shard(ldp_engine* e, uint32_t rank, uint32_t world, uint32_t* owner) {
+  if (!e || !e->planned) {
+    return e ? fail(e, LDP_ERR_STATE, "ldp_set_variants() first") : LDP_ERR_INVALID;
+  }
+  if (!world || (rank >= world)) {
+    return fail(e, LDP_ERR_INVALID, "rank/world out of range");
+  }
+  // LPT: longest subcontig first onto the least-loaded rank (ties: lower rank; equal lengths: file order)
+  std::vector<uint32_t> order(e->subs.size());
+  for (uint32_t k = 0; k < order.size(); ++k) {
+    order[k] = k;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return e->subs[a].len > e->subs[b].len; });
+  std::vector<uint64_t> load(world, 0);
+  for (uint32_t k : order) {
+    uint32_t best = 0;
+    for (uint32_t r = 1; r < world; ++r) {
+      if (load[r] < load[best]) {
+        best = r;
+      }
+    }
+    e->subs[k].owner = best;
+    load[best] += e->subs[k].len;
+  }
+  if (owner) {
+    for (uint32_t k = 0; k < e->subs.size(); ++k) {
+      owner[k] = e->subs[k].owner;
+    }
+  }
+  e->rank = rank;
+  e->world = world;
+  build_shard(e);
+  e->ctr.owned_subcontig_ct = static_cast<uint32_t>(e->owned.size());
+  return LDP_OK;
+}
+
+int ldp_get_band(const ldp_engine* e, uint32_t* lo, uint64_t* candidate_pairs) {
+  if (!e || !e->planned) {
+    return LDP_ERR_STATE;
+  }
+  if (lo) {
+    memcpy(lo, e->lo_global.data(), e->variant_ct * sizeof(uint32_t));
+  }
+  if (candidate_pairs) {
+    uint64_t tot = 0;
+    for (uint32_t v = 0; v < e->variant_ct; ++v) {
+      tot += v - e->lo_global[v];
+    }
+    *candidate_pairs = tot;
+  }
+  return LDP_OK;
+}
+
+int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* geno, uint64_t stride_bytes, int location, int encoding) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  if (!e->planned) {
+    return fail(e, LDP_ERR_STATE, "ldp_set_variants() first");
+  }
+  if ((encoding < LDP_GENO_INVERSE) || (encoding > LDP_GENO_BED) || ((location != LDP_MEM_HOST) && (location != LDP_MEM_DEVICE))) {
+    return fail(e, LDP_ERR_INVALID, "bad encoding/location");
+  }
+  if ((static_cast<uint64_t>(first_variant) + n > e->variant_ct) || (n && !geno)) {
+    return fail(e, LDP_ERR_INVALID, "variant range out of bounds");
+  }
+  const uint64_t row_bytes = (static_cast<uint64_t>(e->P.founder_ct) + 3) / 4;
+  if (stride_bytes < row_bytes) {
+    return fail(e, LDP_ERR_INVALID, "stride smaller than a genotype row");
+  }
+  int rc = ensure_device_plan(e);
+  if (rc) {
+    return rc;
+  }
+  HIP_TRY(e, hipSetDevice(e->device));
+  hipEvent_t ev0, ev1;
+  HIP_TRY(e, hipEventCreate(&ev0));
+  HIP_TRY(e, hipEventCreate(&ev1));
+  float total_ms = 0.f;
+  const uint8_t* src = static_cast<const uint8_t*>(geno);
+  uint8_t* d_stage = nullptr;
+  size_t stage_rows = 0;
+  if (location == LDP_MEM_HOST) {
+    stage_rows = std::max<size_t>(1, std::min<size_t>(n, (256ull << 20) / stride_bytes));
+    HIP_TRY(e, hipMalloc(&d_stage, stage_rows * stride_bytes));
+  }
+  uint32_t g = first_variant;
+  const uint32_t gend = first_variant + n;
+  while (g < gend) {
+    if (e->global_to_local[g] < 0) {
+      ++g;
+      continue;
+    }
+    // maximal run of owned variants consecutive both globally and locally
+    uint32_t run = 1;
+    while ((g + run < gend) && (e->global_to_local[g + run] == e->global_to_local[g] + run)) {
+      ++run;
+    }
+    uint32_t done = 0;
+    while (done < run) {
+      uint32_t cnt = run - done;
+      const uint8_t* d_src;
+      if (location == LDP_MEM_HOST) {
+        cnt = static_cast<uint32_t>(std::min<size_t>(cnt, stage_rows));
+        HIP_TRY(e, hipMemcpyAsync(d_stage, src + static_cast<uint64_t>(g + done - first_variant) * stride_bytes,
+                                  static_cast<size_t>(cnt) * stride_bytes, hipMemcpyHostToDevice, e->stream));
+        d_src = d_stage;
+      } else {
+        d_src = src + static_cast<uint64_t>(g + done - first_variant) * stride_bytes;
+      }
+      const uint32_t l0 = static_cast<uint32_t>(e->global_to_local[g + done]);
+      PrepareArgs PA;
+      PA.geno = d_src;
+      PA.stride_bytes = stride_bytes;
+      PA.n_variants = cnt;
+      PA.founder_ct = e->P.founder_ct;
+      PA.encoding = encoding;
+      PA.planes = e->d_planes + static_cast<uint64_t>(l0) * e->row_dwords;
+      PA.row_dwords = e->row_dwords;
+      PA.chunks = e->chunks;
+      PA.recs = e->d_recs + l0;
+      HIP_TRY(e, hipEventRecord(ev0, e->stream));
+      hipError_t krc = launch_prepare(PA, e->stream);
+      if (krc != hipSuccess) {
+        return hipfail(e, krc, "prepare_kernel launch");
+      }
+      HIP_TRY(e, hipEventRecord(ev1, e->stream));
+      HIP_TRY(e, hipStreamSynchronize(e->stream));  // staging buffer reuse + timing
+      float ms = 0.f;
+      HIP_TRY(e, hipEventElapsedTime(&ms, ev0, ev1));
+      total_ms += ms;
+      for (uint32_t q = 0; q < cnt; ++q) {
+        e->loaded[l0 + q] = 1;
+      }
+      done += cnt;
+    }
+    // frequencies: derived for REF/BED input, caller-supplied for INVERSE input
+    e->recs_host_valid = false;
+    if (encoding != LDP_GENO_INVERSE) {
+      const uint32_t l0 = static_cast<uint32_t>(e->global_to_local[g]);
+      HIP_TRY(e, hipMemcpy(e->recs.data() + l0, e->d_recs + l0, run * sizeof(ldp_variant_rec), hipMemcpyDeviceToHost));
+      for (uint32_t q = 0; q < run; ++q) {
+        rc = derive_maj_freq(e, l0 + q);
+        if (rc) {
+          return rc;
+        }
+        e->mf_set[l0 + q] = 1;
+      }
+    }
+    g += run;
+  }
+  if (d_stage) {
+    (void)hipFree(d_stage);
+  }
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  e->ctr.ms_prepare = total_ms;
+  return LDP_OK;
+}
+
+int ldp_set_maj_freqs(ldp_engine* e, uint32_t first_variant, uint32_t n, const double* maj_freqs) {
+  if (!e || !e->planned) {
+    return e ? fail(e, LDP_ERR_STATE, "ldp_set_variants() first") : LDP_ERR_INVALID;
+  }
+  if ((static_cast<uint64_t>(first_variant) + n > e->variant_ct) || (n && !maj_freqs)) {
+    return fail(e, LDP_ERR_INVALID, "variant range out of bounds");
+  }
+  for (uint32_t q = 0; q < n; ++q) {
+    const int64_t l = e->global_to_local[first_variant + q];
+    if (l >= 0) {
+      e->maj_freq[l] = maj_freqs[q];
+      e->mf_set[l] = 1;
+    }
+  }
+  return LDP_OK;
+}
+
+int ldp_set_preferred(ldp_engine* e, const uint64_t* preferred_bitmap) {
+  if (!e || !e->planned) {
+    return e ? fail(e, LDP_ERR_STATE, "ldp_set_variants() first") : LDP_ERR_INVALID;
+  }
+  if (!preferred_bitmap) {
+    e->preferred.clear();
+    return LDP_OK;
+  }
+  e->preferred.assign(preferred_bitmap, preferred_bitmap + (static_cast<size_t>(e->variant_ct) + 63) / 64);
+  return LDP_OK;
+}
+
+int ldp_run(ldp_engine* e, uint64_t* removed) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  return run_impl(e, removed, nullptr, 0);
+}
+
+int ldp_run_with_stats(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t stats_capacity) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  if (!stats) {
+    return fail(e, LDP_ERR_INVALID, "stats is NULL");
+  }
+  return run_impl(e, removed, stats, stats_capacity);
+}
+
+int ldp_pair_stats(ldp_engine* e, uint32_t n_pairs, const uint32_t* first, const uint32_t* second, ldp_pair_stats_t* out) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  if (!e->planned) {
+    return fail(e, LDP_ERR_STATE, "ldp_set_variants() first");
+  }
+  if (n_pairs && (!first || !second || !out)) {
+    return fail(e, LDP_ERR_INVALID, "NULL argument");
+  }
+  int rc = ensure_device_plan(e);
+  if (rc) {
+    return rc;
+  }
+  std::vector<uint32_t> lf(n_pairs), ls(n_pairs);
+  for (uint32_t k = 0; k < n_pairs; ++k) {
+    if ((first[k] >= e->variant_ct) || (second[k] >= e->variant_ct)) {
+      return fail(e, LDP_ERR_INVALID, "variant index out of range");
+    }
+    const int64_t a = e->global_to_local[first[k]];
+    const int64_t b = e->global_to_local[second[k]];
+    if ((a < 0) || (b < 0) || !e->loaded[a] || !e->loaded[b]) {
+      return fail(e, LDP_ERR_STATE, "pair refers to a variant that is not owned/loaded");
+    }
+    lf[k] = static_cast<uint32_t>(a);
+    ls[k] = static_cast<uint32_t>(b);
+  }
+  if (!n_pairs) {
+    return LDP_OK;
+  }
+  HIP_TRY(e, hipSetDevice(e->device));
+  uint32_t* d_idx = nullptr;
+  ldp_pair_stats_t* d_out = nullptr;
+  HIP_TRY(e, hipMalloc(&d_idx, 2ull * n_pairs * sizeof(uint32_t)));
+  HIP_TRY(e, hipMalloc(&d_out, static_cast<size_t>(n_pairs) * sizeof(ldp_pair_stats_t)));
+  HIP_TRY(e, hipMemcpyAsync(d_idx, lf.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(d_idx + n_pairs, ls.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+  hipError_t krc = launch_pair_stats_ref(e->d_planes, e->row_dwords, e->chunks, 0, d_idx, d_idx + n_pairs, n_pairs, d_out, e->stream);
+  if (krc != hipSuccess) {
+    return hipfail(e, krc, "pair_stats_ref launch");
+  }
+  HIP_TRY(e, hipMemcpyAsync(out, d_out, static_cast<size_t>(n_pairs) * sizeof(ldp_pair_stats_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  (void)hipFree(d_idx);
+  (void)hipFree(d_out);
+  return LDP_OK;
+}
+
+int ldp_debug_set_variant_recs(ldp_engine* e, const ldp_variant_rec* recs) {
+  if (!e || !e->planned || !recs) {
+    return LDP_ERR_STATE;
+  }
+  for (uint32_t l = 0; l < e->local_ct; ++l) {
+    e->recs[l] = recs[e->local_to_global[l]];
+  }
+  e->recs_host_valid = true;
+  return LDP_OK;
+}
+
+int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first, const uint32_t* second, uint64_t* removed) {
+  if (!e || !e->planned || !removed || (n_true && (!first || !second))) {
+    return LDP_ERR_STATE;
+  }
+  if (!e->recs_host_valid) {
+    return fail(e, LDP_ERR_STATE, "variant records not set");
+  }
+  std::vector<double> mf;
+  int rc = prepare_mf(e, &mf);
+  if (rc) {
+    return rc;
+  }
+  std::vector<uint32_t> pred(std::max<size_t>(e->pred_words, 1), 0);
+  for (uint64_t k = 0; k < n_true; ++k) {
+    if ((first[k] >= e->variant_ct) || (second[k] >= e->variant_ct)) {
+      return fail(e, LDP_ERR_INVALID, "variant index out of range");
+    }
+    const int64_t i = e->global_to_local[first[k]];
+    const int64_t j = e->global_to_local[second[k]];
+    if ((i < 0) || (j < 0)) {
+      continue;  // not this shard's pair
+    }
+    const uint32_t lo = e->lo_local[j];
+    if ((i >= j) || (i < lo)) {
+      return fail(e, LDP_ERR_INVALID, "pair outside the candidate band");
+    }
+    pred[e->row_off[j] + ((static_cast<uint32_t>(i) >> 5) - (lo >> 5))] |= 1u << (i & 31);
+  }
+  std::vector<uint32_t> R((static_cast<size_t>(e->local_ct) + 31) / 32 + 1, 0);
+  uint64_t replay_pairs = 0;
+  replay(e, pred.data(), mf, R, &replay_pairs);
+  e->ctr.replay_pairs = replay_pairs;
+  return finish_removed(e, R, removed);
+}
+
+int ldp_get_variant_recs(ldp_engine* e, uint32_t first_variant, uint32_t n, ldp_variant_rec* out) {
+  if (!e || !e->planned || !out) {
+    return LDP_ERR_STATE;
+  }
+  if (static_cast<uint64_t>(first_variant) + n > e->variant_ct) {
+    return fail(e, LDP_ERR_INVALID, "variant range out of bounds");
+  }
+  if (!e->recs_host_valid) {
+    int rc = ensure_device_plan(e);
+    if (rc) {
+      return rc;
+    }
+    rc = fetch_recs(e);
+    if (rc) {
+      return rc;
+    }
+  }
+  for (uint32_t q = 0; q < n; ++q) {
+    const int64_t l = e->global_to_local[first_variant + q];
+    if (l >= 0) {
+      out[q] = e->recs[l];
+    } else {
+      memset(&out[q], 0, sizeof(ldp_variant_rec));
+    }
+  }
+  return LDP_OK;
+}
+
+int ldp_get_maj_freqs(ldp_engine* e, uint32_t first_variant, uint32_t n, double* out) {
+  if (!e || !e->planned || !out) {
+    return LDP_ERR_STATE;
+  }
+  if (static_cast<uint64_t>(first_variant) + n > e->variant_ct) {
+    return fail(e, LDP_ERR_INVALID, "variant range out of bounds");
+  }
+  for (uint32_t q = 0; q < n; ++q) {
+    const int64_t l = e->global_to_local[first_variant + q];
+    out[q] = ((l >= 0) && e->mf_set[l]) ? e->maj_freq[l] : 0.0;
+  }
+  return LDP_OK;
+}
+
+int ldp_get_planes(ldp_engine* e, uint32_t variant, uint32_t* hom, uint32_t* ref2het) {
+  if (!e || !e->planned || !hom || !ref2het) {
+    return LDP_ERR_STATE;
+  }
+  if (variant >= e->variant_ct) {
+    return fail(e, LDP_ERR_INVALID, "variant out of range");
+  }
+  const int64_t l = e->global_to_local[variant];
+  if ((l < 0) || !e->loaded[l]) {
+    return fail(e, LDP_ERR_STATE, "variant not owned/loaded");
+  }
+  int rc = ensure_device_plan(e);
+  if (rc) {
+    return rc;
+  }
+  std::vector<uint32_t> row(e->row_dwords);
+  HIP_TRY(e, hipMemcpy(row.data(), e->d_planes + static_cast<uint64_t>(l) * e->row_dwords, e->row_dwords * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  const uint32_t plane_dwords = (e->P.founder_ct + 31) / 32;
+  for (uint32_t p = 0; p < plane_dwords; ++p) {
+    const uint32_t off = (p / kChunkDwords) * kRowChunkDwords + (p % kChunkDwords);
+    hom[p] = row[off];
+    ref2het[p] = row[off + kChunkDwords];
+  }
+  return LDP_OK;
+}
+
+int ldp_get_counters(const ldp_engine* e, ldp_counters* out) {
+  if (!e || !out) {
+    return LDP_ERR_INVALID;
+  }
+  *out = e->ctr;
+  return LDP_OK;
+}
+
+}  // extern "C"

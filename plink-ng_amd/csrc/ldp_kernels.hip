@@ -1,0 +1,607 @@
+// ldp_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the --indep-pairwise hot path.
+//
+//   prepare_kernel      2-bit genotype rows -> hom / ref2het bit-planes in HBM + per-variant aggregates
+//                       (SplitHomRef2het pgenlib_misc.cc:1797-1885, FillVaggs plink2_ld.cc:725-738,
+//                        allele counts / major allele plink2_data.cc:2421-2443, plink2_filter.cc:2113-2153,
+//                        plink2_common.h:559-567, GenovecInvertUnsafe pgenlib_misc.cc:1090,
+//                        PgrPlink1ToPlink2InplaceUnsafe pgenlib_read.cc:2157)
+//   pair_tiles_kernel   banded all-pairs statistics + FP64 prune predicate
+//                       (DotprodWords/SumSsqWords/SumSsqNmWords plink2_ld.cc:189-602,
+//                        ComputeIndepPairwiseR2Components :699-723, decision :1085-1090)
+//   pair_stats_ref      one wave per arbitrary pair, same integer statistics (parity/inspection)
+//
+// No MFMA: this is AND/XOR/popcount work.  v_bcnt_u32_b32 (popcount with accumulate) is the inner op;
+// tiles are staged through LDS as 16-byte words and reused from registers 4 x NA times per thread.
+#include "ldp_device.h"
+
+namespace ldp {
+
+// ================================================================================================
+// prepare
+// ================================================================================================
+__device__ __forceinline__ uint32_t pack_even_bits(uint32_t x) {
+  x &= 0x55555555u;
+  x = (x | (x >> 1)) & 0x33333333u;
+  x = (x | (x >> 2)) & 0x0f0f0f0fu;
+  x = (x | (x >> 4)) & 0x00ff00ffu;
+  x = (x | (x >> 8)) & 0x0000ffffu;
+  return x;
+}
+
+__device__ __forceinline__ uint32_t load_geno_dword(const uint8_t* row, uint32_t nbytes, uint32_t didx, bool aligned4) {
+  const uint32_t off = didx * 4;
+  if (aligned4 && (off + 4 <= nbytes)) {
+    return *reinterpret_cast<const uint32_t*>(row + off);
+  }
+  uint32_t w = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (off + k < nbytes) {
+      w |= static_cast<uint32_t>(row[off + k]) << (8 * k);
+    }
+  }
+  return w;
+}
+
+// One plane dword (32 samples) from two input dwords (16 samples each).
+__device__ __forceinline__ void convert_plane_dword(const uint8_t* row, uint32_t nbytes, bool aligned4, int encoding,
+                                                    uint32_t founder_ct, uint32_t p, uint32_t* hom_out, uint32_t* r2h_out) {
+  const uint32_t first_sample = p * 32;
+  if (first_sample >= founder_ct) {
+    *hom_out = 0;
+    *r2h_out = 0;
+    return;
+  }
+  const uint32_t w0 = load_geno_dword(row, nbytes, 2 * p, aligned4);
+  const uint32_t w1 = load_geno_dword(row, nbytes, 2 * p + 1, aligned4);
+  uint32_t hom, r2h;
+  if (encoding == LDP_GENO_BED) {
+    // bed code b1b0 -> pgen: lo = b0^b1, hi = ~b1; hom = ~lo, ref2het = ~hi = b1
+    hom = pack_even_bits(~(w0 ^ (w0 >> 1))) | (pack_even_bits(~(w1 ^ (w1 >> 1))) << 16);
+    r2h = pack_even_bits(w0 >> 1) | (pack_even_bits(w1 >> 1) << 16);
+  } else {
+    hom = pack_even_bits(~w0) | (pack_even_bits(~w1) << 16);
+    r2h = pack_even_bits((~w0) >> 1) | (pack_even_bits((~w1) >> 1) << 16);
+  }
+  const uint32_t remaining = founder_ct - first_sample;
+  if (remaining < 32) {
+    const uint32_t mask = (1u << remaining) - 1;
+    hom &= mask;
+    r2h &= mask;
+  }
+  *hom_out = hom;
+  *r2h_out = r2h;
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    v += __shfl_down(v, off, 64);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void prepare_kernel(PrepareArgs A) {
+  __shared__ uint32_t red[4][3];
+  __shared__ uint32_t s_alt_major;
+  const uint32_t v = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const uint8_t* row = A.geno + static_cast<uint64_t>(v) * A.stride_bytes;
+  const uint32_t nbytes = (A.founder_ct + 3) / 4;
+  const bool aligned4 = ((reinterpret_cast<uintptr_t>(row) & 3) == 0);
+  const uint32_t plane_dwords = A.chunks * kChunkDwords;
+
+  uint32_t hom_ct = 0, r2h_ct = 0, both_ct = 0;
+  for (uint32_t p = tid; p < plane_dwords; p += 256) {
+    uint32_t hom, r2h;
+    convert_plane_dword(row, nbytes, aligned4, A.encoding, A.founder_ct, p, &hom, &r2h);
+    hom_ct += __popc(hom);
+    r2h_ct += __popc(r2h);
+    both_ct += __popc(hom & r2h);
+  }
+  hom_ct = wave_reduce_add(hom_ct);
+  r2h_ct = wave_reduce_add(r2h_ct);
+  both_ct = wave_reduce_add(both_ct);
+  if ((tid & 63) == 0) {
+    red[tid >> 6][0] = hom_ct;
+    red[tid >> 6][1] = r2h_ct;
+    red[tid >> 6][2] = both_ct;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    hom_ct = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    r2h_ct = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    both_ct = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+    // raw genotype counts: code 0 = hom&r2h, code 1 = r2h only, code 2 = hom only
+    const uint32_t n0 = both_ct;
+    const uint32_t n1 = r2h_ct - both_ct;
+    const uint32_t n2 = hom_ct - both_ct;
+    uint32_t alt_major = 0;
+    ldp_variant_rec rec;
+    rec.n_homref = 0;
+    rec.n_het = 0;
+    rec.n_homalt = 0;
+    rec.reserved = 0;
+    if (A.encoding != LDP_GENO_INVERSE) {
+      // plink2_filter.cc:2137-2147: freq = ref * (1 / tot), 1/2 when nothing is observed;
+      // major = REF iff freq >= 0.5 (plink2_common.h:559-567)
+      const uint64_t ref_ct = 2ull * n0 + n1;
+      const uint64_t alt_ct = 2ull * n2 + n1;
+      const uint64_t tot = ref_ct + alt_ct;
+      double ref_freq = 0.5;
+      if (tot) {
+        const double tot_recip = __ddiv_rn(1.0, static_cast<double>(tot));
+        ref_freq = __dmul_rn(static_cast<double>(ref_ct), tot_recip);
+      }
+      alt_major = !(ref_freq >= 0.5);
+      rec.n_homref = n0;
+      rec.n_het = n1;
+      rec.n_homalt = n2;
+    }
+    // after the (optional) 0<->2 inversion
+    const uint32_t plus_ct = alt_major ? n2 : n0;
+    const uint32_t minus_ct = alt_major ? n0 : n2;
+    const uint32_t nm_ct = plus_ct + minus_ct + n1;
+    rec.nm_ct = nm_ct;
+    rec.sum = static_cast<int32_t>(plus_ct - minus_ct);
+    rec.ssq = hom_ct;
+    const uint32_t mono = ((!plus_ct) && (!minus_ct)) || (plus_ct == nm_ct) || (minus_ct == nm_ct);  // plink2_ld.cc:902
+    rec.flags = alt_major | (mono << 1) | ((nm_ct != A.founder_ct) ? 4u : 0u);
+    A.recs[v] = rec;
+    s_alt_major = alt_major;
+  }
+  __syncthreads();
+  const uint32_t alt_major = s_alt_major;
+  uint32_t* out_row = A.planes + static_cast<uint64_t>(v) * A.row_dwords;
+  for (uint32_t p = tid; p < plane_dwords; p += 256) {
+    uint32_t hom, r2h;
+    convert_plane_dword(row, nbytes, aligned4, A.encoding, A.founder_ct, p, &hom, &r2h);
+    if (alt_major) {
+      r2h ^= hom;  // 0 <-> 2 swaps ref2het on the homozygous calls only
+    }
+    const uint32_t off = (p / kChunkDwords) * kRowChunkDwords + (p % kChunkDwords);
+    out_row[off] = hom;
+    out_row[off + kChunkDwords] = r2h;
+  }
+}
+
+hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream) {
+  if (!a.n_variants) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(prepare_kernel, dim3(a.n_variants), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+// ================================================================================================
+// pair tiles
+// ================================================================================================
+constexpr int kLdsRowSlots = kLdsRowDwords / 4;  // 17 16-byte slots per LDS row
+
+__device__ __forceinline__ uint32_t popc4(const uint4& v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+__device__ __forceinline__ uint4 and4(const uint4& a, const uint4& b) { return make_uint4(a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w); }
+__device__ __forceinline__ uint4 or4(const uint4& a, const uint4& b) { return make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w); }
+__device__ __forceinline__ uint4 xor4(const uint4& a, const uint4& b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
+
+// acc += popcount(x) as ONE v_bcnt_u32_b32 (popcount with accumulate).  Written as inline asm because the
+// optimizer otherwise reassociates chains of ctpop+add into ctpop(.,0) trees plus v_add3.
+__device__ __forceinline__ void bcnt_acc(uint32_t& acc, uint32_t x) {
+  asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(x));
+}
+__device__ __forceinline__ void bcnt_acc4(uint32_t& acc, const uint4& v) {
+  bcnt_acc(acc, v.x);
+  bcnt_acc(acc, v.y);
+  bcnt_acc(acc, v.z);
+  bcnt_acc(acc, v.w);
+}
+
+__device__ __forceinline__ uint4 lds_row_slot(const uint4* __restrict__ l4, int row, int slot) { return l4[row * kLdsRowSlots + slot]; }
+
+// Complete-data path: dot = popcnt(hom1&hom2) - 2*popcnt(hom1&hom2&(r2h1^r2h2))  (plink2_ld.cc:244-250)
+// Per 16-byte k-group a thread holds its 4 second-variants (jH/jR) and streams the NA+3 first-variants
+// it needs (one LDS row per value of c = b - a), software-pipelined one row ahead.
+template <int NA>
+__device__ __forceinline__ void tile_chunk_fast(const uint4* __restrict__ l4, int jrow, int irow, uint32_t (&hh)[4][4], uint32_t (&xx)[4][4]) {
+#pragma unroll 1
+  for (int g = 0; g < kChunkDwords / 4; ++g) {
+    uint4 jH[4], jR[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      jH[b] = lds_row_slot(l4, jrow + 8 * b, g);
+      jR[b] = lds_row_slot(l4, jrow + 8 * b, (kChunkDwords / 4) + g);
+    }
+    uint4 iH = lds_row_slot(l4, irow - 8 * (NA - 1), g);
+    uint4 iR = lds_row_slot(l4, irow - 8 * (NA - 1), (kChunkDwords / 4) + g);
+#pragma unroll
+    for (int c = -(NA - 1); c <= 3; ++c) {
+      uint4 nH = iH, nR = iR;
+      if (c < 3) {
+        nH = lds_row_slot(l4, irow + 8 * (c + 1), g);
+        nR = lds_row_slot(l4, irow + 8 * (c + 1), (kChunkDwords / 4) + g);
+      }
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        const int b = c + a;
+        if (b >= 0 && b < 4) {
+          const uint4 h = and4(jH[b], iH);
+          const uint4 x = and4(h, xor4(jR[b], iR));
+          bcnt_acc4(hh[a][b], h);
+          bcnt_acc4(xx[a][b], x);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      iH = nH;
+      iR = nR;
+    }
+  }
+}
+
+// General path (missing calls present), all seven counts of plink2_ld.cc:244-250, :329-334, :590-601:
+//   [0] popcnt(hom_i & hom_j)              [1] popcnt(hom_i & hom_j & (r2h_i ^ r2h_j))
+//   [2] popcnt(nm_i & nm_j)                [3] popcnt(nm_i & hom_j)   [4] popcnt(nm_i & hom_j & r2h_j)
+//   [5] popcnt(nm_j & hom_i)               [6] popcnt(nm_j & hom_i & r2h_i)          nm = hom | r2h
+template <int NA>
+__device__ __forceinline__ void tile_chunk_general(const uint4* __restrict__ l4, int jrow, int irow, uint32_t (&acc)[2][4][7]) {
+#pragma unroll 1
+  for (int g = 0; g < kChunkDwords / 4; ++g) {
+    uint4 jH[4], jR[4], jN[4], jP[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      jH[b] = lds_row_slot(l4, jrow + 8 * b, g);
+      jR[b] = lds_row_slot(l4, jrow + 8 * b, (kChunkDwords / 4) + g);
+      jN[b] = or4(jH[b], jR[b]);
+      jP[b] = and4(jH[b], jR[b]);
+    }
+    uint4 iH = lds_row_slot(l4, irow - 8 * (NA - 1), g);
+    uint4 iR = lds_row_slot(l4, irow - 8 * (NA - 1), (kChunkDwords / 4) + g);
+#pragma unroll
+    for (int c = -(NA - 1); c <= 3; ++c) {
+      uint4 nH = iH, nR = iR;
+      if (c < 3) {
+        nH = lds_row_slot(l4, irow + 8 * (c + 1), g);
+        nR = lds_row_slot(l4, irow + 8 * (c + 1), (kChunkDwords / 4) + g);
+      }
+      const uint4 iN = or4(iH, iR);
+      const uint4 iP = and4(iH, iR);
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        const int b = c + a;
+        if (b >= 0 && b < 4) {
+          const uint4 h = and4(jH[b], iH);
+          bcnt_acc4(acc[a][b][0], h);
+          bcnt_acc4(acc[a][b][1], and4(h, xor4(jR[b], iR)));
+          bcnt_acc4(acc[a][b][2], and4(iN, jN[b]));
+          bcnt_acc4(acc[a][b][3], and4(iN, jH[b]));
+          bcnt_acc4(acc[a][b][4], and4(iN, jP[b]));
+          bcnt_acc4(acc[a][b][5], and4(jN[b], iH));
+          bcnt_acc4(acc[a][b][6], and4(jN[b], iP));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      iH = nH;
+      iR = nR;
+    }
+  }
+}
+
+struct TileGeom {
+  uint32_t j0, jend, sfirst, send;
+  int64_t ilo;  // variant index of I-row 0
+  int rtot;     // LDS rows in use
+};
+
+__device__ __forceinline__ int64_t row_variant(const TileGeom& G, int r) {
+  int64_t v = (r < kTileJ) ? (static_cast<int64_t>(G.j0) + r) : (G.ilo + (r - kTileJ));
+  if (v < static_cast<int64_t>(G.sfirst)) {
+    v = G.sfirst;
+  }
+  if (v >= static_cast<int64_t>(G.send)) {
+    v = static_cast<int64_t>(G.send) - 1;
+  }
+  return v;
+}
+
+__device__ __forceinline__ TileGeom make_geom(const WorkItem& it, uint32_t units_total) {
+  TileGeom G;
+  G.j0 = it.j0;
+  G.jend = it.jend;
+  G.sfirst = it.sfirst;
+  G.send = it.send;
+  G.ilo = static_cast<int64_t>(it.j0) - (it.d0 + 8 * units_total - 1);
+  G.rtot = kTileJ + 8 * units_total + 31;
+  return G;
+}
+
+// 16 lanes x 16 B move one k-chunk (hom+ref2het, 256 B) of one variant into one LDS row.
+__device__ __forceinline__ void stage_chunk(const uint32_t* __restrict__ planes, uint64_t row_dwords, const TileGeom& G, uint32_t* lds, uint32_t kc, uint32_t tid) {
+  const uint32_t sub = tid & 15;
+#pragma unroll 4
+  for (int r = tid >> 4; r < G.rtot; r += kBlockThreads / 16) {
+    const int64_t v = row_variant(G, r);
+    const uint4* src = reinterpret_cast<const uint4*>(planes + static_cast<uint64_t>(v) * row_dwords + static_cast<uint64_t>(kc) * kRowChunkDwords) + sub;
+    reinterpret_cast<uint4*>(lds + r * kLdsRowDwords)[sub] = *src;
+  }
+}
+
+// plink2_ld.cc:1085-1090, no FMA contraction possible (multiplies only); var1 belongs to the FIRST variant.
+__device__ __forceinline__ bool exceeds(const ldp_pair_stats_t& s, double thresh) {
+  const double cov12 = static_cast<double>(static_cast<int64_t>(s.dot) * static_cast<int64_t>(s.nm) - static_cast<int64_t>(s.sum1) * static_cast<int64_t>(s.sum2));
+  const double var1 = static_cast<double>(static_cast<int64_t>(s.ssq1) * static_cast<int64_t>(s.nm) - static_cast<int64_t>(s.sum1) * static_cast<int64_t>(s.sum1));
+  const double var2 = static_cast<double>(static_cast<int64_t>(s.ssq2) * static_cast<int64_t>(s.nm) - static_cast<int64_t>(s.sum2) * static_cast<int64_t>(s.sum2));
+  return __dmul_rn(cov12, cov12) > __dmul_rn(__dmul_rn(thresh, var1), var2);
+}
+
+__device__ __forceinline__ void emit_pair(const PairKernelArgs& A, uint32_t i, uint32_t j, uint32_t lo_j, const ldp_pair_stats_t& st) {
+  if (A.stats) {
+    A.stats[A.pair_off[j] + (i - lo_j)] = st;
+  }
+  if (exceeds(st, A.thresh)) {
+    atomicOr(&A.pred[A.row_off[j] + ((i >> 5) - (lo_j >> 5))], 1u << (i & 31));
+    atomicAdd(A.counters, 1ull);
+  }
+}
+
+// One wave per work item: does any LDS row of the tile carry missing calls?  Decides which of the two
+// pair_tiles_kernel instantiations owns the item (the other one exits at once).
+__global__ __launch_bounds__(256) void classify_items_kernel(PairKernelArgs A) {
+  const uint32_t item_idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  if (item_idx >= A.n_items) {
+    return;
+  }
+  const WorkItem it = A.items[item_idx];
+  uint32_t units_total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < kWavesPerBlock; ++w) {
+    units_total += (it.units >> (8 * w)) & 0xff;
+  }
+  const TileGeom G = make_geom(it, units_total);
+  int miss = 0;
+  for (int r = lane; r < G.rtot; r += 64) {
+    miss |= (A.recs[row_variant(G, r)].flags & 4u) ? 1 : 0;
+  }
+  const unsigned long long any = __ballot(miss);
+  if (lane == 0) {
+    A.item_general[item_idx] = any ? 1 : 0;
+  }
+}
+
+// Epilogue staging: accumulators go through LDS ([counter][thread]) so the per-pair decision code runs
+// as a rolled loop with a handful of live registers instead of 16 unrolled copies.
+constexpr int kEpilogueLdsDwords = 32 * kBlockThreads;  // 32 KiB
+
+template <bool GENERAL>
+__global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_kernel(PairKernelArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  // XCD-aware order: hardware places block b on XCD b % 8; give each XCD a contiguous run of work
+  // items so neighbouring J-blocks (which share most of their window rows) hit the same L2.
+  const uint32_t per_xcd = (A.n_items + 7) / 8;
+  const uint32_t item_idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (item_idx >= A.n_items) {
+    return;
+  }
+  if ((A.item_general[item_idx] != 0) != GENERAL) {
+    return;
+  }
+  const WorkItem it = A.items[item_idx];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t wave = tid >> 6;
+  const uint32_t lane = tid & 63;
+  const int tx = lane & 7;
+  const int ty = lane >> 3;
+
+  uint32_t units_total = 0, units_before = 0, units_max = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < kWavesPerBlock; ++w) {
+    const uint32_t u = (it.units >> (8 * w)) & 0xff;
+    if (w < wave) {
+      units_before += u;
+    }
+    units_total += u;
+    units_max = (u > units_max) ? u : units_max;
+  }
+  const TileGeom G = make_geom(it, units_total);
+  const uint32_t units_w = (it.units >> (8 * wave)) & 0xff;
+  const uint32_t dw0 = it.d0 + 8 * units_before;  // first distance of this wave
+
+  const uint4* l4 = reinterpret_cast<const uint4*>(lds);
+  const int jrow = tx;
+  // I-row of (b = 0, a = 0): i = j0 + tx - (dw0 + ty)
+  const int irow0 = kTileJ + static_cast<int>(static_cast<int64_t>(it.j0) - dw0 - G.ilo) + tx - ty;
+  const uint32_t* planes = A.planes;
+  const uint64_t row_dwords = A.row_dwords;
+
+  if constexpr (!GENERAL) {
+    uint32_t hh[4][4], xx[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        hh[a][b] = 0;
+        xx[a][b] = 0;
+      }
+    }
+    for (uint32_t kc = 0; kc < A.chunks; ++kc) {
+      stage_chunk(planes, row_dwords, G, lds, kc, tid);
+      __syncthreads();
+      switch (units_w) {
+        case 1: tile_chunk_fast<1>(l4, jrow, irow0, hh, xx); break;
+        case 2: tile_chunk_fast<2>(l4, jrow, irow0, hh, xx); break;
+        case 3: tile_chunk_fast<3>(l4, jrow, irow0, hh, xx); break;
+        case 4: tile_chunk_fast<4>(l4, jrow, irow0, hh, xx); break;
+        default: break;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        lds[(2 * (a * 4 + b)) * kBlockThreads + tid] = hh[a][b];
+        lds[(2 * (a * 4 + b) + 1) * kBlockThreads + tid] = xx[a][b];
+      }
+    }
+#pragma unroll 1
+    for (uint32_t p = 0; p < 4 * units_w; ++p) {
+      const uint32_t a = p >> 2, b = p & 3;
+      const uint32_t j = it.j0 + tx + 8 * b;
+      const uint32_t d = dw0 + ty + 8 * a;
+      if (j >= it.jend) {
+        continue;
+      }
+      const uint32_t lo_j = A.lo[j];
+      if (d > j - lo_j) {
+        continue;
+      }
+      const uint32_t i = j - d;
+      ldp_pair_stats_t st;
+      st.nm = A.founder_ct;
+      st.sum1 = A.recs[i].sum;
+      st.ssq1 = A.recs[i].ssq;
+      st.sum2 = A.recs[j].sum;
+      st.ssq2 = A.recs[j].ssq;
+      st.dot = static_cast<int32_t>(lds[(2 * p) * kBlockThreads + tid]) - 2 * static_cast<int32_t>(lds[(2 * p + 1) * kBlockThreads + tid]);
+      emit_pair(A, i, j, lo_j, st);
+    }
+  } else {
+    // general path: two distance-units per pass to bound register use (7 counters per pair)
+    for (uint32_t a0 = 0; a0 < units_max; a0 += 2) {
+      uint32_t acc[2][4][7];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+          for (int q = 0; q < 7; ++q) {
+            acc[a][b][q] = 0;
+          }
+        }
+      }
+      const uint32_t na = (units_w > a0) ? ((units_w - a0 >= 2) ? 2 : 1) : 0;
+      const int irow = irow0 - 8 * static_cast<int>(a0);
+      for (uint32_t kc = 0; kc < A.chunks; ++kc) {
+        stage_chunk(planes, row_dwords, G, lds, kc, tid);
+        __syncthreads();
+        if (na == 2) {
+          tile_chunk_general<2>(l4, jrow, irow, acc);
+        } else if (na == 1) {
+          tile_chunk_general<1>(l4, jrow, irow, acc);
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        // one distance-unit at a time through LDS: 4 pairs x 7 counters = 28 dwords per thread
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+          for (int q = 0; q < 7; ++q) {
+            lds[(b * 7 + q) * kBlockThreads + tid] = acc[a][b][q];
+          }
+        }
+        if (a < static_cast<int>(na)) {
+#pragma unroll 1
+          for (uint32_t b = 0; b < 4; ++b) {
+            const uint32_t j = it.j0 + tx + 8 * b;
+            const uint32_t d = dw0 + ty + 8 * (a0 + a);
+            if (j >= it.jend) {
+              continue;
+            }
+            const uint32_t lo_j = A.lo[j];
+            if (d > j - lo_j) {
+              continue;
+            }
+            const uint32_t i = j - d;
+            const uint32_t* c = lds + (b * 7) * kBlockThreads + tid;
+            const uint32_t c0 = c[0], c1 = c[kBlockThreads], c2 = c[2 * kBlockThreads], c3 = c[3 * kBlockThreads];
+            const uint32_t c4 = c[4 * kBlockThreads], c5 = c[5 * kBlockThreads], c6 = c[6 * kBlockThreads];
+            ldp_pair_stats_t st;
+            st.nm = c2;
+            st.ssq2 = c3;
+            st.sum2 = static_cast<int32_t>(2 * c4 - c3);
+            st.ssq1 = c5;
+            st.sum1 = static_cast<int32_t>(2 * c6 - c5);
+            st.dot = static_cast<int32_t>(c0) - 2 * static_cast<int32_t>(c1);
+            emit_pair(A, i, j, lo_j, st);
+          }
+        }
+      }
+      __syncthreads();  // LDS is restaged by the next pass
+    }
+  }
+}
+
+size_t pair_tiles_lds_bytes(uint32_t max_units) {
+  const size_t rows = kTileJ + 8 * static_cast<size_t>(max_units) + 31;
+  const size_t tile = rows * kLdsRowDwords * sizeof(uint32_t);
+  const size_t epi = static_cast<size_t>(kEpilogueLdsDwords) * sizeof(uint32_t);
+  return (tile > epi) ? tile : epi;
+}
+
+hipError_t launch_pair_tiles(const PairKernelArgs& a, uint32_t max_units, hipStream_t stream) {
+  if (!a.n_items) {
+    return hipSuccess;
+  }
+  const uint32_t per_xcd = (a.n_items + 7) / 8;
+  const size_t lds = pair_tiles_lds_bytes(max_units);
+  hipLaunchKernelGGL(classify_items_kernel, dim3((a.n_items + 3) / 4), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(pair_tiles_kernel<false>, dim3(per_xcd * 8), dim3(kBlockThreads), lds, stream, a);
+  hipLaunchKernelGGL(pair_tiles_kernel<true>, dim3(per_xcd * 8), dim3(kBlockThreads), lds, stream, a);
+  return hipGetLastError();
+}
+
+// ================================================================================================
+// reference pair kernel: one wave per pair, lanes across plane dwords
+// ================================================================================================
+__global__ __launch_bounds__(256) void pair_stats_ref_kernel(const uint32_t* planes, uint64_t row_dwords, uint32_t chunks, uint32_t base_variant,
+                                                            const uint32_t* first, const uint32_t* second, uint32_t n_pairs, ldp_pair_stats_t* out) {
+  const uint32_t pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  if (pair >= n_pairs) {
+    return;
+  }
+  const uint32_t* r1 = planes + static_cast<uint64_t>(first[pair] - base_variant) * row_dwords;
+  const uint32_t* r2 = planes + static_cast<uint64_t>(second[pair] - base_variant) * row_dwords;
+  uint32_t c[7] = {0, 0, 0, 0, 0, 0, 0};
+  const uint32_t plane_dwords = chunks * kChunkDwords;
+  for (uint32_t p = lane; p < plane_dwords; p += 64) {
+    const uint32_t off = (p / kChunkDwords) * kRowChunkDwords + (p % kChunkDwords);
+    const uint32_t h1 = r1[off], q1 = r1[off + kChunkDwords];
+    const uint32_t h2 = r2[off], q2 = r2[off + kChunkDwords];
+    const uint32_t n1 = h1 | q1, n2 = h2 | q2;
+    const uint32_t h = h1 & h2;
+    c[0] += __popc(h);
+    c[1] += __popc(h & (q1 ^ q2));
+    c[2] += __popc(n1 & n2);
+    c[3] += __popc(n1 & h2);
+    c[4] += __popc(n1 & h2 & q2);
+    c[5] += __popc(n2 & h1);
+    c[6] += __popc(n2 & h1 & q1);
+  }
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    c[q] = wave_reduce_add(c[q]);
+  }
+  if (lane == 0) {
+    ldp_pair_stats_t st;
+    st.nm = c[2];
+    st.ssq2 = c[3];
+    st.sum2 = static_cast<int32_t>(2 * c[4] - c[3]);
+    st.ssq1 = c[5];
+    st.sum1 = static_cast<int32_t>(2 * c[6] - c[5]);
+    st.dot = static_cast<int32_t>(c[0]) - 2 * static_cast<int32_t>(c[1]);
+    out[pair] = st;
+  }
+}
+
+hipError_t launch_pair_stats_ref(const uint32_t* planes, uint64_t row_dwords, uint32_t chunks, uint32_t plane_base_variant,
+                                 const uint32_t* first, const uint32_t* second, uint32_t n_pairs,
+                                 ldp_pair_stats_t* out, hipStream_t stream) {
+  if (!n_pairs) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(pair_stats_ref_kernel, dim3((n_pairs + 3) / 4), dim3(256), 0, stream, planes, row_dwords, chunks, plane_base_variant, first, second, n_pairs, out);
+  return hipGetLastError();
+}
+
+}  // namespace ldp

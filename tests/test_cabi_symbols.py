@@ -1,0 +1,45 @@
+"""The C-ABI shared library must load (no GPU needed) and export every entry point that
+include/ldprune_hip.h declares -- no compute calls here."""
+import ctypes
+import os
+import re
+
+
+def declared_symbols():
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(repo, "include", "ldprune_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ldp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(pkg):
+    assert declared_symbols() == sorted(pkg.CABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = ctypes.CDLL(pkg.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(L, name), "missing export: " + name
+
+
+def test_struct_layouts_match_the_header(pkg):
+    # sizes the C side was compiled with (plain C structs, natural alignment)
+    assert ctypes.sizeof(pkg.ldp_pair_stats_t) == 24 == pkg.PAIR_STATS_DTYPE.itemsize
+    assert ctypes.sizeof(pkg.ldp_variant_rec) == 32 == pkg.VARIANT_REC_DTYPE.itemsize
+    assert ctypes.sizeof(pkg.ldp_params) == 48
+    assert ctypes.sizeof(pkg.ldp_counters) == 80
+
+
+def test_device_count_never_fails(pkg):
+    assert pkg.device_count() >= 0
+
+
+def test_product_does_not_reference_the_oracle():
+    """oracle/ is test infrastructure: nothing under plink-ng_amd/ or include/ may mention it."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for root in (os.path.join(repo, "plink-ng_amd"), os.path.join(repo, "include")):
+        for dirpath, _, files in os.walk(root):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".h")):
+                    src = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert "ldoracle" not in src and "oracle/" not in src and "ldtools" not in src, os.path.join(dirpath, f)

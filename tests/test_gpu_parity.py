@@ -1,0 +1,226 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Integer work is compared bit-exactly: bit-planes, per-variant aggregates, the 6-tuple of every
+candidate pair out of the tile kernel, and the final prune set."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import ldtools as T
+from test_host_logic import make_positions
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_recs(raw, n):
+    inv, mf, altmaj = T.oracle_prepare(raw)
+    hom, r2h, vaggs = T.oracle_split(inv, n)
+    return inv, mf, altmaj, hom, r2h, vaggs
+
+
+@pytest.mark.parametrize("n", [2, 31, 32, 33, 63, 64, 65, 100, 1023, 1024, 1025, 2049, 5000])
+@pytest.mark.parametrize("encoding", ["ref", "bed", "inverse"])
+def test_prepare_planes_and_aggregates(gpu_pkg, n, encoding):
+    pkg = gpu_pkg
+    m = 40
+    raw = T.synth_raw_codes(m, n, seed=n, missing_rate=0.07)
+    raw[3] = 0          # monomorphic hom-REF
+    raw[4] = 2          # monomorphic hom-ALT
+    raw[5] = 3          # all missing
+    raw[6] = 1          # all het
+    if n >= 4:
+        raw[7] = 0
+        raw[7, : n // 2] = 2  # ref_ct == alt_ct: tie goes to REF (plink2_common.h:559-567)
+    inv, mf, altmaj, hom, r2h, vaggs = oracle_recs(raw, n)
+    eng = pkg.LdPruneEngine(n, 10, 1, False, 0.2, device=0)
+    eng.set_variants(np.zeros(m, dtype=np.uint32), None)
+    if encoding == "ref":
+        eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+    elif encoding == "bed":
+        lut = np.array([3, 2, 0, 1], dtype=np.uint8)
+        rec = (n + 3) // 4
+        eng.load_genotypes_host(0, np.ascontiguousarray(T.pack_2bit(lut[raw]).view(np.uint8).reshape(m, -1)[:, :rec]), pkg.LDP_GENO_BED)
+    else:
+        eng.load_genotypes_host(0, inv, pkg.LDP_GENO_INVERSE)
+        eng.set_maj_freqs(0, mf)
+    recs = eng.variant_recs()
+    lib = T.oracle()
+    for v in range(m):
+        gh, gr = eng.planes(v)
+        w32 = (n + 31) // 32
+        assert np.array_equal(gh, hom[v].view(np.uint32)[:w32]), (v, "hom plane")
+        assert np.array_equal(gr, r2h[v].view(np.uint32)[:w32]), (v, "ref2het plane")
+        assert (recs[v]["nm_ct"], recs[v]["sum"], recs[v]["ssq"]) == (vaggs[v].nm_ct, vaggs[v].sum, vaggs[v].ssq)
+        assert bool(recs[v]["flags"] & 2) == bool(lib.ldo_is_monomorphic(ctypes.byref(vaggs[v])))
+        assert bool(recs[v]["flags"] & 4) == (vaggs[v].nm_ct != n)
+        if encoding != "inverse":
+            assert bool(recs[v]["flags"] & 1) == bool(altmaj[v])
+    assert np.array_equal(eng.maj_freqs(), mf)  # exact doubles
+    eng.close()
+
+
+@pytest.mark.parametrize("n,miss", [(65, 0.0), (100, 0.1), (1025, 0.02), (4097, 0.3), (50000, 0.05)])
+def test_pair_stats_reference_kernel(gpu_pkg, n, miss):
+    pkg = gpu_pkg
+    m = 24
+    raw = T.synth_raw_codes(m, n, seed=7 * n + 1, missing_rate=miss)
+    raw[0] = np.where(raw[0] == 3, 0, raw[0])  # one complete variant among incomplete ones
+    inv, mf, altmaj, hom, r2h, vaggs = oracle_recs(raw, n)
+    eng = pkg.LdPruneEngine(n, 10, 1, False, 0.2, device=0)
+    eng.set_variants(np.zeros(m, dtype=np.uint32), None)
+    eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+    first, second = np.triu_indices(m, 1)
+    got = eng.pair_stats(first, second)
+    for k in range(len(first)):
+        st = T.oracle_pair_stats(hom, r2h, vaggs, n, int(first[k]), int(second[k]))
+        assert tuple(int(x) for x in got[k]) == st.astuple(), (first[k], second[k])
+    eng.close()
+
+
+def check_run(pkg, raw, chr_idx, bps, window, step, is_bp, r2, order, shard_world=1, device_input=False):
+    m, n = raw.shape
+    inv, mf, altmaj, hom, r2h, vaggs = oracle_recs(raw, n)
+    want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, window, step, is_bp, r2, order)
+    union = np.zeros(m, dtype=bool)
+    for rank in range(shard_world):
+        eng = pkg.LdPruneEngine(n, window, step, is_bp, r2, order=order, device=0)
+        eng.set_variants(chr_idx, bps)
+        if shard_world > 1:
+            eng.set_shard(rank, shard_world)
+        packed = T.pack_2bit(raw)
+        if device_input:
+            import torch
+            t = torch.from_numpy(packed.view(np.int64)).to("cuda:0")
+            torch.cuda.synchronize()
+            eng.load_genotypes_device(0, m, t.data_ptr(), packed.strides[0], pkg.LDP_GENO_REF)
+        else:
+            eng.load_genotypes_host(0, packed, pkg.LDP_GENO_REF)
+        if shard_world == 1:
+            removed, stats = eng.run_with_stats()
+            lo, cand = eng.band()
+            assert len(stats) == cand
+            k = 0
+            for j in range(m):
+                for i in range(int(lo[j]), j):
+                    st = T.oracle_pair_stats(hom, r2h, vaggs, n, i, j)
+                    assert tuple(int(x) for x in stats[k]) == st.astuple(), ("pair", i, j)
+                    k += 1
+            ctr = eng.counters()
+            assert ctr["candidate_pairs"] == cand
+            assert ctr["computed_pairs"] >= cand
+        else:
+            removed = eng.run()
+        union |= removed
+        eng.close()
+    assert np.array_equal(union, want), "removed sets differ: %d vs %d" % (union.sum(), want.sum())
+
+
+RUN_CASES = [
+    # m, n, seed, window, step, is_bp, r2, order, missing
+    (300, 70, 1, 50, 5, False, 0.2, 2, 0.0),       # fast path only, one block per J-tile
+    (300, 70, 2, 50, 5, False, 0.2, 1, 0.0),
+    (300, 65, 3, 30, 1, False, 0.5, 2, 0.05),      # general path
+    (300, 1100, 4, 15000, 1, True, 0.2, 2, 0.0),   # two k-chunks
+    (300, 1100, 5, 15000, 1, True, 0.5, 1, 0.03),
+    (420, 33, 6, 200, 40, False, 0.1, 2, 0.0),     # window > 128 distances: several blocks per J-tile
+    (420, 33, 7, 300, 1, False, 0.3, 2, 0.1),
+    (200, 40, 8, 2, 1, False, 0.3, 2, 0.0),        # minimal window
+    (333, 2100, 9, 60, 60, False, 0.2, 2, 0.0),    # step == window, 3 k-chunks
+]
+
+
+@pytest.mark.parametrize("case", RUN_CASES)
+def test_tile_kernel_and_prune_set(gpu_pkg, case):
+    m, n, seed, window, step, is_bp, r2, order, miss = case
+    raw = T.synth_raw_codes(m, n, seed, missing_rate=miss)
+    chr_idx, bps = make_positions(m, 3, seed + 100)
+    check_run(gpu_pkg, raw, chr_idx, bps, window, step, is_bp, r2, order)
+
+
+def test_mixed_missingness_tiles(gpu_pkg):
+    """Only a stretch of variants has missing calls: neighbouring tiles take different kernels."""
+    m, n = 400, 130
+    raw = T.synth_raw_codes(m, n, seed=21, missing_rate=0.0)
+    rng = np.random.default_rng(5)
+    raw[150:190] = np.where(rng.random((40, n)) < 0.1, 3, raw[150:190])
+    chr_idx, bps = make_positions(m, 2, 77)
+    check_run(gpu_pkg, raw, chr_idx, bps, 40, 3, False, 0.2, 2)
+
+
+def test_device_pointer_input(gpu_pkg):
+    m, n = 300, 257
+    raw = T.synth_raw_codes(m, n, seed=31, missing_rate=0.02)
+    chr_idx, bps = make_positions(m, 2, 78)
+    check_run(gpu_pkg, raw, chr_idx, bps, 20000, 1, True, 0.2, 2, device_input=True)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_union_equals_unsharded(gpu_pkg, world):
+    m, n = 900, 96
+    raw = T.synth_raw_codes(m, n, seed=41, missing_rate=0.01)
+    chr_idx, bps = make_positions(m, 7, 79)
+    check_run(gpu_pkg, raw, chr_idx, bps, 10000, 1, True, 0.2, 2, shard_world=world)
+
+
+def test_degenerate_inputs(gpu_pkg):
+    pkg = gpu_pkg
+    # every chromosome has one variant: no subcontigs, nothing loaded, nothing removed (plink2_ld.cc:2182)
+    eng = pkg.LdPruneEngine(50, 1000, 1, True, 0.2, device=0)
+    eng.set_variants(np.arange(5, dtype=np.uint32), np.full(5, 100, dtype=np.uint32))
+    assert eng.subcontigs() == []
+    assert not eng.run().any()
+    eng.close()
+    # empty variant table
+    eng = pkg.LdPruneEngine(50, 1000, 1, True, 0.2, device=0)
+    eng.set_variants(np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint32))
+    assert len(eng.run()) == 0
+    eng.close()
+    # a monomorphic variant alone in a length-1 subcontig is never loaded and stays in (SURVEY 8(c) edge (i))
+    raw = np.zeros((3, 60), dtype=np.uint8)
+    raw[1, :10] = 1
+    raw[2, :10] = 2
+    eng = pkg.LdPruneEngine(60, 1000, 1, True, 0.2, device=0)
+    eng.set_variants(np.zeros(3, dtype=np.uint32), np.array([1000, 5000000, 5000100], dtype=np.uint32))
+    assert eng.subcontigs() == [(2, 1)]
+    eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+    removed = eng.run()
+    assert not removed[0]
+    eng.close()
+
+
+def test_preferred_variants(gpu_pkg):
+    """--indep-preferred subtracts 1.0 from the major frequency (plink2_ld.cc:916-918): with every pair in
+    LD, a preferred variant always wins its tie-breaks."""
+    pkg = gpu_pkg
+    m, n = 12, 200
+    base = T.synth_raw_codes(1, n, seed=3)[0]
+    raw = np.tile(base, (m, 1))
+    eng = pkg.LdPruneEngine(n, 50, 1, False, 0.5, device=0)
+    eng.set_variants(np.zeros(m, dtype=np.uint32), None)
+    eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+    pref = np.zeros(m, dtype=bool)
+    pref[4] = True
+    eng.set_preferred(pref)
+    removed = eng.run()
+    assert not removed[4] and removed.sum() == m - 1
+    eng.close()
+
+
+def test_config2_sample_count(gpu_pkg):
+    """BASELINE config 2's sample count (N = 50,000, 200 kb window at ~2.9 kb spacing), a few thousand
+    variants: prune set against the oracle."""
+    pkg = gpu_pkg
+    m, n = 1500, 50000
+    raw = T.synth_raw_codes(m, n, seed=2, missing_rate=0.0)
+    chr_idx = (np.arange(m) // 750).astype(np.uint32)
+    bps = (10000 + 2875 * (np.arange(m) % 750)).astype(np.uint32)
+    inv, mf, _ = T.oracle_prepare(raw)
+    want, evals = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 200000, 1, True, 0.5, 2)
+    eng = pkg.LdPruneEngine(n, 200000, 1, True, 0.5, device=0)
+    eng.set_variants(chr_idx, bps)
+    eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+    got = eng.run()
+    ctr = eng.counters()
+    eng.close()
+    assert np.array_equal(got, want)
+    assert ctr["candidate_pairs"] >= evals

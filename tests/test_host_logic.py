@@ -1,0 +1,190 @@
+"""CPU-only tests of the host logic behind the C ABI: subcontig split, window/band planning, LPT
+sharding and the greedy replay.  The pair predicate bits are produced here by the ORACLE and pushed
+through ldp_debug_replay_pairs(), so no GPU is needed; the result must equal the oracle's own
+end-to-end --indep-pairwise."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import ldtools as T
+
+
+def make_positions(m, nchr, seed, spacing=300, big_gap_prob=0.01, big_gap=400000):
+    rng = np.random.default_rng(seed)
+    per = (m + nchr - 1) // nchr
+    chr_idx = (np.arange(m) // per).astype(np.uint32)
+    bps = np.zeros(m, dtype=np.uint32)
+    for c in range(nchr):
+        idx = np.where(chr_idx == c)[0]
+        gaps = rng.integers(0, 2 * spacing, size=len(idx))  # 0 allowed: duplicate positions
+        gaps = np.where(rng.random(len(idx)) < big_gap_prob, gaps + big_gap, gaps)
+        bps[idx] = 1000 + np.cumsum(gaps)
+    return chr_idx, bps
+
+
+def oracle_band_predicates(inv, n, lo, thresh_r2):
+    """All candidate pairs (lo[j] <= i < j) whose oracle predicate is true."""
+    lib = T.oracle()
+    hom, r2h, vaggs = T.oracle_split(inv, n)
+    thr = lib.ldo_prune_thresh(thresh_r2)
+    first, second = [], []
+    for j in range(len(lo)):
+        for i in range(int(lo[j]), j):
+            st = T.oracle_pair_stats(hom, r2h, vaggs, n, i, j)
+            if lib.ldo_exceeds(ctypes.byref(st), thr):
+                first.append(i)
+                second.append(j)
+    return np.array(first, dtype=np.uint32), np.array(second, dtype=np.uint32), vaggs
+
+
+def recs_from_vaggs(pkg, vaggs, n, m):
+    lib = T.oracle()
+    recs = np.zeros(m, dtype=pkg.VARIANT_REC_DTYPE)
+    for v in range(m):
+        recs[v]["nm_ct"] = vaggs[v].nm_ct
+        recs[v]["sum"] = vaggs[v].sum
+        recs[v]["ssq"] = vaggs[v].ssq
+        mono = lib.ldo_is_monomorphic(ctypes.byref(vaggs[v]))
+        recs[v]["flags"] = (2 if mono else 0) | (4 if vaggs[v].nm_ct != n else 0)
+    return recs
+
+
+CASES = [
+    # m, n, seed, window, step, is_bp, r2, order, missing
+    (400, 70, 1, 50, 5, False, 0.2, 2, 0.0),
+    (400, 70, 2, 50, 5, False, 0.2, 1, 0.0),
+    (400, 65, 3, 30, 1, False, 0.5, 2, 0.05),
+    (400, 65, 4, 15000, 1, True, 0.2, 2, 0.05),
+    (400, 65, 5, 15000, 1, True, 0.5, 1, 0.03),
+    (500, 33, 6, 40, 40, False, 0.1, 2, 0.1),
+    (500, 33, 7, 2, 1, False, 0.3, 2, 0.0),
+    (500, 40, 8, 25, 7, False, 0.3, 1, 0.1),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_replay_matches_oracle(pkg, case):
+    m, n, seed, window, step, is_bp, r2, order, miss = case
+    raw = T.synth_raw_codes(m, n, seed, missing_rate=miss)
+    chr_idx, bps = make_positions(m, 3, seed + 100)
+    inv, mf, _ = T.oracle_prepare(raw)
+    want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, window, step, is_bp, r2, order)
+
+    eng = pkg.LdPruneEngine(n, window, step, is_bp, r2, order=order)
+    eng.set_variants(chr_idx, bps)
+    lo, cand = eng.band()
+    assert cand == int(np.sum(np.arange(m) - lo))
+    first, second, vaggs = oracle_band_predicates(inv, n, lo, r2)
+    eng.debug_set_variant_recs(recs_from_vaggs(pkg, vaggs, n, m))
+    eng.set_maj_freqs(0, mf)
+    got = eng.debug_replay_pairs(first, second)
+    eng.close()
+    assert np.array_equal(got, want), "removed sets differ: %d vs %d" % (got.sum(), want.sum())
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+@pytest.mark.parametrize("is_bp,window", [(True, 5000), (True, 100000), (False, 7), (False, 1000)])
+def test_subcontig_split_matches_oracle(pkg, seed, is_bp, window):
+    m = 3000
+    chr_idx, bps = make_positions(m, 5, seed, spacing=200, big_gap_prob=0.02, big_gap=20000)
+    # a chromosome with a single variant, and one of length 2
+    chr_idx = np.concatenate([chr_idx, [5, 6, 6]]).astype(np.uint32)
+    bps = np.concatenate([bps, [10, 10, 2000000]]).astype(np.uint32)
+    want, wmax = T.oracle_subcontig_split(chr_idx, bps if is_bp else None, window)
+    eng = pkg.LdPruneEngine(100, window, 1, is_bp, 0.2)
+    eng.set_variants(chr_idx, bps)
+    got = eng.subcontigs()
+    assert got == want
+    assert eng.counters()["window_max"] == wmax
+    eng.close()
+
+
+def test_band_is_the_window_rule_in_kb_mode(pkg):
+    """kb mode: candidates are exactly the in-subcontig pairs with bp[j]-bp[i] <= W."""
+    m, W = 2000, 7000
+    chr_idx, bps = make_positions(m, 2, 9, spacing=150, big_gap_prob=0.01, big_gap=30000)
+    eng = pkg.LdPruneEngine(100, W, 1, True, 0.2)
+    eng.set_variants(chr_idx, bps)
+    lo, _ = eng.band()
+    subs = eng.subcontigs()
+    eng.close()
+    in_sub = np.full(m, -1)
+    for k, (ln, first) in enumerate(subs):
+        in_sub[first:first + ln] = k
+    for j in range(m):
+        if in_sub[j] < 0:
+            assert lo[j] == j
+            continue
+        first = subs[in_sub[j]][1]
+        cand = [i for i in range(first, j) if int(bps[j]) - int(bps[i]) <= W]
+        want_lo = cand[0] if cand else j
+        # the reference's window iterator never reaches back further than the rule, and never less
+        assert lo[j] == want_lo, (j, lo[j], want_lo)
+
+
+def test_count_mode_band_follows_window_iterator(pkg):
+    """`50 5`: variant 50 is compared with 5..49 but never with 4."""
+    m = 200
+    eng = pkg.LdPruneEngine(100, 50, 5, False, 0.2)
+    eng.set_variants(np.zeros(m, dtype=np.uint32), None)
+    lo, _ = eng.band()
+    eng.close()
+    assert list(lo[:50]) == [0] * 50
+    assert lo[50] == 5 and lo[54] == 5 and lo[55] == 10
+
+
+def test_lpt_shard_partition(pkg):
+    m = 5000
+    chr_idx, bps = make_positions(m, 11, 5, spacing=100, big_gap_prob=0.005, big_gap=50000)
+    engs = []
+    owners = None
+    for r in range(4):
+        e = pkg.LdPruneEngine(64, 3000, 1, True, 0.2)
+        e.set_variants(chr_idx, bps)
+        o = e.set_shard(r, 4)
+        if owners is None:
+            owners = o
+        assert np.array_equal(o, owners)  # every rank computes the same assignment
+        engs.append(e)
+    subs = engs[0].subcontigs()
+    loads = np.zeros(4, dtype=np.int64)
+    for (ln, _), o in zip(subs, owners):
+        loads[o] += ln
+    assert loads.max() - loads.min() <= max(ln for ln, _ in subs)
+    assert sum(e.counters()["owned_subcontig_ct"] for e in engs) == len(subs)
+    for e in engs:
+        e.close()
+
+
+def test_parameter_validation(pkg):
+    with pytest.raises(pkg.LdpError):
+        pkg.LdPruneEngine(1, 50, 5, False, 0.2)          # < 2 founders (plink2_ld.cc:2537)
+    with pytest.raises(pkg.LdpError):
+        pkg.LdPruneEngine(100, 50, 51, False, 0.2)       # step > window (plink2.cc:7285)
+    with pytest.raises(pkg.LdpError):
+        pkg.LdPruneEngine(100, 50000, 2, True, 0.2)      # kb window needs step 1 (plink2.cc:7290)
+    with pytest.raises(pkg.LdpError):
+        pkg.LdPruneEngine(100, 50, 5, False, 1.0)        # r2 must be < 1 (plink2.cc:7303)
+    with pytest.raises(pkg.LdpError) as ei:
+        pkg.LdPruneEngine(1 << 30, 50, 5, False, 0.2)    # plink2_ld.cc:1122
+    assert ei.value.code == pkg.LDP_ERR_UNSUPPORTED
+    e = pkg.LdPruneEngine(100, 5000, 1, True, 0.2)
+    with pytest.raises(pkg.LdpError):
+        e.set_variants(np.array([0, 0, 0]), np.array([5, 3, 9]))  # unsorted positions
+    e.close()
+
+
+def test_no_cpu_fallback_without_gpu(pkg):
+    """The product path must fail loudly when no HIP device is usable."""
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is present; the no-device path cannot be exercised here")
+    e = pkg.LdPruneEngine(64, 50, 5, False, 0.2)
+    e.set_variants(np.zeros(10, dtype=np.uint32), None)
+    with pytest.raises(pkg.LdpError) as ei:
+        e.load_genotypes_host(0, np.zeros((10, 16), dtype=np.uint8))
+    assert ei.value.code == pkg.LDP_ERR_GPU
+    with pytest.raises(pkg.LdpError) as ei:
+        e.run()
+    assert ei.value.code == pkg.LDP_ERR_GPU
+    e.close()
