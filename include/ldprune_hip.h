@@ -95,7 +95,9 @@ typedef struct {
   uint64_t replay_pairs;     /* predicate bits the greedy replay consumed */
   uint64_t pred_true;        /* candidate pairs above threshold */
   double ms_prepare;         /* device time of the split/count kernels in the last ldp_load_genotypes() (HIP events) */
-  double ms_pair_kernel;     /* device time of the pair kernel launches in the last ldp_run() (HIP events) */
+  double ms_pair_kernel;     /* device time of all pair-kernel launches in the last ldp_run() (HIP events on the engine stream) */
+  double ms_pair_fast;       /* ... of pair_tiles_kernel<false> (complete-data tiles) alone */
+  double ms_pair_general;    /* ... of pair_tiles_kernel<true> (tiles with missing calls) alone */
   double ms_replay;          /* host wall time of the replay in the last ldp_run() */
   double ms_run_total;       /* host wall time of the last ldp_run() */
   uint32_t pair_kernel_launches;
@@ -162,6 +164,14 @@ int ldp_get_maj_freqs(ldp_engine* e, uint32_t first_variant, uint32_t n, double*
 /* bit-planes of one variant as the kernels see them: hom and ref2het, ceil(founder_ct/32) dwords each */
 int ldp_get_planes(ldp_engine* e, uint32_t variant, uint32_t* hom, uint32_t* ref2het);
 int ldp_get_counters(const ldp_engine* e, ldp_counters* out);
+
+/* ---- synthetic workload (benchmark / test support, not part of the reference seam) ---- */
+/* Deterministic genotype generator for the SURVEY.md 8(d) workload: rows [first_variant, +n_variants) of
+ * REF-based codes (LDP_GENO_REF) written to `out` (host or device memory), each genotype a pure function of
+ * (seed, variant index, sample index).  LD is planted like the reference's --dummy
+ * (plink2_import.cc:16387-16432).  `stream` is a hipStream_t (device output only; may be NULL). */
+int ldp_synth_genotypes(uint64_t seed, uint64_t first_variant, uint32_t n_variants, uint32_t founder_ct, double missing_rate,
+                        void* out, uint64_t stride_bytes, int location, void* stream);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,7 @@ class ldp_counters(ctypes.Structure):
     _fields_ = [("candidate_pairs", ctypes.c_uint64), ("computed_pairs", ctypes.c_uint64),
                 ("replay_pairs", ctypes.c_uint64), ("pred_true", ctypes.c_uint64),
                 ("ms_prepare", ctypes.c_double), ("ms_pair_kernel", ctypes.c_double),
+                ("ms_pair_fast", ctypes.c_double), ("ms_pair_general", ctypes.c_double),
                 ("ms_replay", ctypes.c_double), ("ms_run_total", ctypes.c_double),
                 ("pair_kernel_launches", ctypes.c_uint32), ("subcontig_ct", ctypes.c_uint32),
                 ("owned_subcontig_ct", ctypes.c_uint32), ("window_max", ctypes.c_uint32)]
@@ -74,12 +75,12 @@ CABI_SYMBOLS = [
     "ldp_create", "ldp_destroy", "ldp_last_error", "ldp_device_count", "ldp_set_variants", "ldp_get_subcontigs",
     "ldp_set_shard", "ldp_get_band", "ldp_load_genotypes", "ldp_set_maj_freqs", "ldp_set_preferred", "ldp_run",
     "ldp_run_with_stats", "ldp_pair_stats", "ldp_debug_set_variant_recs", "ldp_debug_replay_pairs",
-    "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters",
+    "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
 ]
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_engine.cpp")]
+    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_synth.hip", "ldp_engine.cpp")]
 
 
 def _stale(target, deps):
@@ -159,12 +160,31 @@ def lib():
     L.ldp_get_maj_freqs.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, f64p]
     L.ldp_get_planes.argtypes = [vp, ctypes.c_uint32, u32p, u32p]
     L.ldp_get_counters.argtypes = [vp, ctypes.POINTER(ldp_counters)]
+    L.ldp_synth_genotypes.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, vp,
+                                      ctypes.c_uint64, ctypes.c_int, vp]
     _lib = L
     return L
 
 
 def device_count():
     return int(lib().ldp_device_count())
+
+
+def synth_genotypes_host(seed, first_variant, n_variants, founder_ct, missing_rate=0.0):
+    """Host-side run of the synthetic generator (small sizes): (n_variants, ceil(founder_ct/4)) uint8 REF codes."""
+    out = np.zeros((n_variants, (founder_ct + 3) // 4), dtype=np.uint8)
+    rc = lib().ldp_synth_genotypes(seed, first_variant, n_variants, founder_ct, missing_rate, out.ctypes.data_as(ctypes.c_void_p),
+                                   out.strides[0] if n_variants else (founder_ct + 3) // 4, LDP_MEM_HOST, None)
+    if rc != LDP_OK:
+        raise LdpError(rc, "ldp_synth_genotypes failed")
+    return out
+
+
+def synth_genotypes_device(seed, first_variant, n_variants, founder_ct, missing_rate, device_ptr, stride_bytes, stream=None):
+    rc = lib().ldp_synth_genotypes(seed, first_variant, n_variants, founder_ct, missing_rate, ctypes.c_void_p(device_ptr), stride_bytes,
+                                   LDP_MEM_DEVICE, ctypes.c_void_p(stream) if stream else None)
+    if rc != LDP_OK:
+        raise LdpError(rc, "ldp_synth_genotypes failed")
 
 
 def _u32(a):

@@ -70,7 +70,8 @@ struct PrepareArgs {
 };
 
 hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream);
-hipError_t launch_pair_tiles(const PairKernelArgs& a, uint32_t max_units, hipStream_t stream);
+// ev[0..3] (optional): recorded before/after the complete-data kernel and before/after the general kernel
+hipError_t launch_pair_tiles(const PairKernelArgs& a, uint32_t max_units, hipStream_t stream, hipEvent_t* ev);
 hipError_t launch_pair_stats_ref(const uint32_t* planes, uint64_t row_dwords, uint32_t chunks, uint32_t plane_base_variant,
                                  const uint32_t* first, const uint32_t* second, uint32_t n_pairs,
                                  ldp_pair_stats_t* out, hipStream_t stream);

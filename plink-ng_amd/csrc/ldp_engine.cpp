@@ -650,10 +650,14 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   A.item_general = e->d_item_general;
 
   hipEvent_t ev0, ev1;
+  hipEvent_t evk[4];
   HIP_TRY(e, hipEventCreate(&ev0));
   HIP_TRY(e, hipEventCreate(&ev1));
+  for (int q = 0; q < 4; ++q) {
+    HIP_TRY(e, hipEventCreate(&evk[q]));
+  }
   HIP_TRY(e, hipEventRecord(ev0, e->stream));
-  hipError_t krc = launch_pair_tiles(A, e->max_units, e->stream);
+  hipError_t krc = launch_pair_tiles(A, e->max_units, e->stream, evk);
   if (krc != hipSuccess) {
     return hipfail(e, krc, "pair_tiles_kernel launch");
   }
@@ -667,8 +671,15 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     HIP_TRY(e, hipMemcpyAsync(stats, d_stats, e->cand_pairs * sizeof(ldp_pair_stats_t), hipMemcpyDeviceToHost, e->stream));
   }
   HIP_TRY(e, hipStreamSynchronize(e->stream));
-  float kms = 0.f;
+  float kms = 0.f, kms_fast = 0.f, kms_general = 0.f;
   HIP_TRY(e, hipEventElapsedTime(&kms, ev0, ev1));
+  if (!e->items.empty()) {
+    HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
+    HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[2], evk[3]));
+  }
+  for (int q = 0; q < 4; ++q) {
+    (void)hipEventDestroy(evk[q]);
+  }
   (void)hipEventDestroy(ev0);
   (void)hipEventDestroy(ev1);
   if (d_stats) {
@@ -687,6 +698,8 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   e->ctr.replay_pairs = replay_pairs;
   e->ctr.pred_true = h_counters[0];
   e->ctr.ms_pair_kernel = kms;
+  e->ctr.ms_pair_fast = kms_fast;
+  e->ctr.ms_pair_general = kms_general;
   e->ctr.ms_replay = t_end - t_replay;
   e->ctr.ms_run_total = t_end - t_start;
   e->ctr.pair_kernel_launches = e->items.empty() ? 0 : 1;

@@ -538,15 +538,25 @@ size_t pair_tiles_lds_bytes(uint32_t max_units) {
   return (tile > epi) ? tile : epi;
 }
 
-hipError_t launch_pair_tiles(const PairKernelArgs& a, uint32_t max_units, hipStream_t stream) {
+hipError_t launch_pair_tiles(const PairKernelArgs& a, uint32_t max_units, hipStream_t stream, hipEvent_t* ev) {
   if (!a.n_items) {
     return hipSuccess;
   }
   const uint32_t per_xcd = (a.n_items + 7) / 8;
   const size_t lds = pair_tiles_lds_bytes(max_units);
   hipLaunchKernelGGL(classify_items_kernel, dim3((a.n_items + 3) / 4), dim3(256), 0, stream, a);
+  if (ev) {
+    (void)hipEventRecord(ev[0], stream);
+  }
   hipLaunchKernelGGL(pair_tiles_kernel<false>, dim3(per_xcd * 8), dim3(kBlockThreads), lds, stream, a);
+  if (ev) {
+    (void)hipEventRecord(ev[1], stream);
+    (void)hipEventRecord(ev[2], stream);
+  }
   hipLaunchKernelGGL(pair_tiles_kernel<true>, dim3(per_xcd * 8), dim3(kBlockThreads), lds, stream, a);
+  if (ev) {
+    (void)hipEventRecord(ev[3], stream);
+  }
   return hipGetLastError();
 }
 
