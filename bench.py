@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--window-kb", type=float, default=200.0)
     ap.add_argument("--r2", type=float, default=0.5)
     ap.add_argument("--missing-rate", type=float, default=0.0)
-    ap.add_argument("--cpu-sample-variants", type=int, default=176000)
+    ap.add_argument("--cpu-sample-variants", type=int, default=440000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -12,10 +12,12 @@
 // There is deliberately no CPU implementation of the pair statistics here: without a HIP device
 // ldp_load_genotypes()/ldp_run() fail with LDP_ERR_GPU.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ldp_device.h"
@@ -36,6 +38,33 @@ struct Subcontig {
 double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// Dynamic work queue over [0, n): fn(task) on up to max_threads host threads (the reference spreads
+// subcontigs over a ThreadGroup the same way, plink2_ld.cc:2686-2700).
+template <class F>
+void parallel_for(uint32_t n, uint32_t max_threads, F fn) {
+  uint32_t nt = std::thread::hardware_concurrency();
+  nt = std::max(1u, std::min(std::min(nt, max_threads), n));
+  if (nt <= 1) {
+    for (uint32_t t = 0; t < n; ++t) {
+      fn(t);
+    }
+    return;
+  }
+  std::atomic<uint32_t> next(0);
+  std::vector<std::thread> pool;
+  pool.reserve(nt);
+  for (uint32_t w = 0; w < nt; ++w) {
+    pool.emplace_back([&]() {
+      for (uint32_t t = next.fetch_add(1); t < n; t = next.fetch_add(1)) {
+        fn(t);
+      }
+    });
+  }
+  for (std::thread& th : pool) {
+    th.join();
+  }
 }
 
 }  // namespace
@@ -79,7 +108,7 @@ struct ldp_engine {
   std::vector<ldp_variant_rec> recs;      // local (host mirror)
   bool recs_host_valid = false;
   std::vector<double> maj_freq;           // local
-  std::vector<uint8_t> mf_set;            // local
+  std::vector<uint8_t> mf_set;            // local: 0 unset, 1 caller-supplied, 2 to be derived from device counts, 3 derived
   std::vector<uint64_t> preferred;        // global bitmap (may be empty)
 
   // ---- device ----
@@ -94,6 +123,9 @@ struct ldp_engine {
   unsigned long long* d_counters = nullptr;
   uint32_t* h_pred = nullptr;  // pinned
   bool plan_uploaded = false;
+  bool recs_registered = false;
+  hipEvent_t prep_ev0 = nullptr, prep_ev1 = nullptr;
+  bool prep_pending = false;
 
   ldp_counters ctr;
 
@@ -140,6 +172,17 @@ void free_device(ldp_engine* e) {
   if (e->h_pred) {
     (void)hipHostFree(e->h_pred);
   }
+  if (e->recs_registered) {
+    (void)hipHostUnregister(e->recs.data());
+    e->recs_registered = false;
+  }
+  if (e->prep_ev0) {
+    (void)hipEventDestroy(e->prep_ev0);
+    (void)hipEventDestroy(e->prep_ev1);
+    e->prep_ev0 = nullptr;
+    e->prep_ev1 = nullptr;
+  }
+  e->prep_pending = false;
   e->d_planes = nullptr;
   e->d_recs = nullptr;
   e->d_lo = nullptr;
@@ -362,12 +405,12 @@ void build_shard(ldp_engine* e) {
       }
     }
   }
+  free_device(e);
   e->loaded.assign(local, 0);
   e->recs.assign(local, ldp_variant_rec());
   e->recs_host_valid = false;
   e->maj_freq.assign(local, 0.0);
   e->mf_set.assign(local, 0);
-  free_device(e);
 }
 
 int ensure_device_plan(ldp_engine* e) {
@@ -400,27 +443,21 @@ int ensure_device_plan(ldp_engine* e) {
   if (!e->items.empty()) {
     HIP_TRY(e, hipMemcpyAsync(e->d_items, e->items.data(), e->items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, e->stream));
   }
+  if (e->local_ct) {
+    HIP_TRY(e, hipHostRegister(e->recs.data(), e->recs.size() * sizeof(ldp_variant_rec), hipHostRegisterDefault));
+    e->recs_registered = true;
+  }
+  HIP_TRY(e, hipEventCreate(&e->prep_ev0));
+  HIP_TRY(e, hipEventCreate(&e->prep_ev1));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   e->plan_uploaded = true;
-  return LDP_OK;
-}
-
-int fetch_recs(ldp_engine* e) {
-  if (e->recs_host_valid) {
-    return LDP_OK;
-  }
-  if (e->local_ct) {
-    HIP_TRY(e, hipMemcpyAsync(e->recs.data(), e->d_recs, e->local_ct * sizeof(ldp_variant_rec), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-  }
-  e->recs_host_valid = true;
   return LDP_OK;
 }
 
 // Major-allele frequency from the device's allele counts, in the reference's arithmetic:
 // freq_ref = ref * (1/tot) (plink2_filter.cc:2144-2147), major = REF iff >= 0.5 (plink2_common.h:559-567),
 // GetAlleleFreq for the last allele = max(1 - freq_ref, 0) (plink2_common.h:584-593).
-int derive_maj_freq(ldp_engine* e, uint32_t l) {
+bool derive_maj_freq(ldp_engine* e, uint32_t l) {
   const ldp_variant_rec& r = e->recs[l];
   const uint64_t ref_ct = 2ull * r.n_homref + r.n_het;
   const uint64_t alt_ct = 2ull * r.n_homalt + r.n_het;
@@ -432,7 +469,7 @@ int derive_maj_freq(ldp_engine* e, uint32_t l) {
   }
   const bool alt_major = !(ref_freq >= 0.5);
   if (alt_major != static_cast<bool>(r.flags & 1)) {
-    return fail(e, LDP_ERR_GPU, "device and host disagree on the major allele");
+    return false;
   }
   double mf = ref_freq;
   if (alt_major) {
@@ -442,16 +479,57 @@ int derive_maj_freq(ldp_engine* e, uint32_t l) {
     }
   }
   e->maj_freq[l] = mf;
+  return true;
+}
+
+// Bring the per-variant records to the host (one D2H per ldp_run, not per load call) and derive the
+// major-allele frequencies that are still pending.
+int fetch_recs(ldp_engine* e) {
+  if (e->recs_host_valid) {
+    return LDP_OK;
+  }
+  if (e->local_ct) {
+    HIP_TRY(e, hipMemcpyAsync(e->recs.data(), e->d_recs, e->local_ct * sizeof(ldp_variant_rec), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+  }
+  if (e->prep_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->prep_ev0, e->prep_ev1) == hipSuccess) {
+      e->ctr.ms_prepare = ms;
+    }
+    e->prep_pending = false;
+  }
+  std::atomic<int> bad(0);
+  const uint32_t kBlock = 65536;
+  const uint32_t nblk = (e->local_ct + kBlock - 1) / kBlock;
+  parallel_for(nblk, 32, [&](uint32_t blk) {
+    const uint32_t lend = std::min(e->local_ct, (blk + 1) * kBlock);
+    for (uint32_t l = blk * kBlock; l < lend; ++l) {
+      if (e->mf_set[l] == 2) {
+        if (!derive_maj_freq(e, l)) {
+          bad.store(1);
+        }
+        e->mf_set[l] = 3;
+      }
+    }
+  });
+  if (bad.load()) {
+    return fail(e, LDP_ERR_GPU, "device and host disagree on the major allele");
+  }
+  e->recs_host_valid = true;
   return LDP_OK;
 }
 
 inline bool bit32(const std::vector<uint32_t>& bm, uint32_t i) { return (bm[i >> 5] >> (i & 31)) & 1; }
-inline void set32(std::vector<uint32_t>& bm, uint32_t i) { bm[i >> 5] |= 1u << (i & 31); }
+// Subcontigs are replayed concurrently and neighbouring ones can share a bitmap word, so bits are set
+// atomically; reads only ever look at bits of the reader's own subcontig.
+inline void set32(std::vector<uint32_t>& bm, uint32_t i) { __atomic_fetch_or(&bm[i >> 5], 1u << (i & 31), __ATOMIC_RELAXED); }
+inline uint32_t load32(const std::vector<uint32_t>& bm, uint32_t w) { return __atomic_load_n(&bm[w], __ATOMIC_RELAXED); }
 
 // next index >= from with a clear bit, or `limit` if none below it
 inline uint32_t next_clear(const std::vector<uint32_t>& bm, uint32_t from, uint32_t limit) {
   while (from < limit) {
-    const uint32_t w = ~bm[from >> 5] >> (from & 31);
+    const uint32_t w = ~load32(bm, from >> 5) >> (from & 31);
     if (w) {
       const uint32_t r = from + __builtin_ctz(w);
       return (r < limit) ? r : limit;
@@ -461,135 +539,168 @@ inline uint32_t next_clear(const std::vector<uint32_t>& bm, uint32_t from, uint3
   return limit;
 }
 
-// The greedy scan of IndepPairwiseThread (plink2_ld.cc:931-1100) replayed from predicate bits.
-// R = removed bitmap over local indices (u32 words).  pred row j: bit i of word (i>>5)-(lo[j]>>5).
-void replay(ldp_engine* e, const uint32_t* pred, const std::vector<double>& mf, std::vector<uint32_t>& R, uint64_t* replay_pairs_out) {
+// The greedy scan of IndepPairwiseThread (plink2_ld.cc:931-1100) for one subcontig, replayed from
+// predicate bits.  R = removed bitmap over local indices (u32 words).  pred row j: bit i of word
+// (i>>5)-(lo[j]>>5).
+uint64_t replay_subcontig(const ldp_engine* e, uint32_t k, const uint32_t* pred, const double* mf, std::vector<uint32_t>& R,
+                          std::vector<uint32_t>& first_unchecked) {
   uint64_t replay_pairs = 0;
   const bool plink1 = e->P.plink1_order != 0;
-  std::vector<uint32_t> first_unchecked;
-  if (plink1) {
-    first_unchecked.assign(e->local_ct, 0);
-  }
-  for (uint32_t k : e->owned) {
-    const Subcontig& s = e->subs[k];
-    const uint32_t sfirst = s.local_first;
-    const uint32_t send = s.local_first + s.len;
-    uint32_t ns = sfirst;
-    while (ns < send) {
-      uint32_t ne = ns;
-      while (!e->batch_end[e->local_to_global[ne]]) {
-        ++ne;
-      }
+  const Subcontig& s = e->subs[k];
+  const uint32_t sfirst = s.local_first;
+  const uint32_t send = s.local_first + s.len;
+  uint32_t ns = sfirst;
+  while (ns < send) {
+    uint32_t ne = ns;
+    while (!e->batch_end[s.first + (ne - sfirst)]) {
       ++ne;
-      const uint32_t lo = e->lo_local[ns];
-      // load-time removal of monomorphic variants (:902-904)
-      for (uint32_t j = ns; j < ne; ++j) {
-        if (e->recs[j].flags & 2u) {
-          set32(R, j);
-        } else if (plink1) {
-          first_unchecked[j] = j + 1;
-        }
+    }
+    ++ne;
+    const uint32_t lo = e->lo_local[ns];
+    // load-time removal of monomorphic variants (:902-904)
+    for (uint32_t j = ns; j < ne; ++j) {
+      if (e->recs[j].flags & 2u) {
+        set32(R, j);
+      } else if (plink1) {
+        first_unchecked[j] = j + 1;
       }
-      if (!plink1) {
-        // :1042-1100 -- seconds newest first, firsts descending over live window members.  The second is
-        // NOT re-checked for having been removed earlier in this batch (quirk kept on purpose).
-        for (uint32_t j = ne; j-- > ns;) {
-          if (j <= lo) {
+    }
+    if (!plink1) {
+      // :1042-1100 -- seconds newest first, firsts descending over live window members.  The second is
+      // NOT re-checked for having been removed earlier in this batch (quirk kept on purpose).
+      for (uint32_t j = ne; j-- > ns;) {
+        if (j <= lo) {
+          continue;
+        }
+        const uint32_t* row = pred + e->row_off[j];
+        const uint32_t wbase = lo >> 5;
+        const uint32_t nw = ((j - 1) >> 5) - wbase + 1;
+        const double mf_j_eps = mf[j] * (1 + kSmallEpsilon);
+        bool second_removed = false;
+        for (uint32_t w = nw; (w-- > 0) && !second_removed;) {
+          uint32_t bits = row[w];
+          if (!bits) {
             continue;
           }
-          const uint32_t* row = pred + e->row_off[j];
-          const uint32_t wbase = lo >> 5;
-          const uint32_t nw = ((j - 1) >> 5) - wbase + 1;
-          const double mf_j_eps = mf[j] * (1 + kSmallEpsilon);
-          bool second_removed = false;
-          for (uint32_t w = nw; (w-- > 0) && !second_removed;) {
-            uint32_t bits = row[w] & ~R[wbase + w];
-            while (bits) {
-              const uint32_t t = 31 - __builtin_clz(bits);
-              bits &= ~(1u << t);
-              const uint32_t i = ((wbase + w) << 5) + t;
-              ++replay_pairs;
-              if (mf[i] <= mf_j_eps) {
-                set32(R, j);
-                second_removed = true;
-                break;
+          bits &= ~load32(R, wbase + w);
+          while (bits) {
+            const uint32_t t = 31 - __builtin_clz(bits);
+            bits &= ~(1u << t);
+            const uint32_t i = ((wbase + w) << 5) + t;
+            ++replay_pairs;
+            if (mf[i] <= mf_j_eps) {
+              set32(R, j);
+              second_removed = true;
+              break;
+            }
+            set32(R, i);
+          }
+        }
+      }
+    } else {
+      // :931-1037 PLINK 1 order
+      bool changed;
+      do {
+        changed = false;
+        for (uint32_t first = next_clear(R, lo, ne); first < ne; first = next_clear(R, first + 1, ne)) {
+          const uint32_t fu = first_unchecked[first];
+          if (fu == ne) {
+            continue;
+          }
+          uint32_t second = next_clear(R, first + 1, ne);
+          while ((second < ne) && (second < fu)) {
+            second = next_clear(R, second + 1, ne);
+          }
+          if (second >= ne) {
+            first_unchecked[first] = ne;
+            continue;
+          }
+          while (true) {
+            const uint32_t lo2 = e->lo_local[second];
+            const uint32_t word = pred[e->row_off[second] + ((first >> 5) - (lo2 >> 5))];
+            ++replay_pairs;
+            if ((word >> (first & 31)) & 1) {
+              if (mf[first] > mf[second] * (1 + kSmallEpsilon)) {
+                set32(R, first);
+              } else {
+                set32(R, second);
+                const uint32_t nxt = next_clear(R, second + 1, ne);
+                first_unchecked[first] = (nxt < ne) ? nxt : ne;
               }
-              set32(R, i);
+              changed = true;
+              break;
+            }
+            second = next_clear(R, second + 1, ne);
+            if (second >= ne) {
+              first_unchecked[first] = ne;
+              break;
             }
           }
         }
-      } else {
-        // :931-1037 PLINK 1 order
-        bool changed;
-        do {
-          changed = false;
-          for (uint32_t first = next_clear(R, lo, ne); first < ne; first = next_clear(R, first + 1, ne)) {
-            const uint32_t fu = first_unchecked[first];
-            if (fu == ne) {
-              continue;
-            }
-            uint32_t second = next_clear(R, first + 1, ne);
-            while ((second < ne) && (second < fu)) {
-              second = next_clear(R, second + 1, ne);
-            }
-            if (second >= ne) {
-              first_unchecked[first] = ne;
-              continue;
-            }
-            while (true) {
-              const uint32_t lo2 = e->lo_local[second];
-              const uint32_t word = pred[e->row_off[second] + ((first >> 5) - (lo2 >> 5))];
-              ++replay_pairs;
-              if ((word >> (first & 31)) & 1) {
-                if (mf[first] > mf[second] * (1 + kSmallEpsilon)) {
-                  set32(R, first);
-                } else {
-                  set32(R, second);
-                  const uint32_t nxt = next_clear(R, second + 1, ne);
-                  first_unchecked[first] = (nxt < ne) ? nxt : ne;
-                }
-                changed = true;
-                break;
-              }
-              second = next_clear(R, second + 1, ne);
-              if (second >= ne) {
-                first_unchecked[first] = ne;
-                break;
-              }
-            }
-          }
-        } while (changed);
-      }
-      ns = ne;
+      } while (changed);
     }
+    ns = ne;
   }
-  *replay_pairs_out = replay_pairs;
+  return replay_pairs;
+}
+
+void replay(ldp_engine* e, const uint32_t* pred, const double* mf, std::vector<uint32_t>& R, uint64_t* replay_pairs_out) {
+  std::vector<uint32_t> first_unchecked;
+  if (e->P.plink1_order) {
+    first_unchecked.assign(e->local_ct, 0);
+  }
+  // longest subcontig first
+  std::vector<uint32_t> order(e->owned);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return e->subs[a].len > e->subs[b].len; });
+  std::atomic<uint64_t> total(0);
+  parallel_for(static_cast<uint32_t>(order.size()), 64, [&](uint32_t t) {
+    total.fetch_add(replay_subcontig(e, order[t], pred, mf, R, first_unchecked));
+  });
+  *replay_pairs_out = total.load();
 }
 
 int finish_removed(ldp_engine* e, const std::vector<uint32_t>& R, uint64_t* removed) {
   memset(removed, 0, ((static_cast<size_t>(e->variant_ct) + 63) / 64) * sizeof(uint64_t));
-  for (uint32_t l = 0; l < e->local_ct; ++l) {
-    if (bit32(R, l)) {
-      const uint32_t g = e->local_to_global[l];
-      removed[g >> 6] |= 1ull << (g & 63);
+  for (uint32_t k : e->owned) {
+    const Subcontig& s = e->subs[k];
+    uint32_t v = 0;
+    while (v < s.len) {
+      // up to 32 bits at a time: local bits [l, l+n) -> global bits [g, g+n)
+      const uint32_t l = s.local_first + v;
+      const uint32_t g = s.first + v;
+      const uint32_t n = std::min<uint32_t>(std::min<uint32_t>(32 - (l & 31), 64 - (g & 63)), s.len - v);
+      uint64_t bits = (R[l >> 5] >> (l & 31));
+      if (n < 32) {
+        bits &= (1ull << n) - 1;
+      }
+      if (bits) {
+        removed[g >> 6] |= bits << (g & 63);
+      }
+      v += n;
     }
   }
   return LDP_OK;
 }
 
-int prepare_mf(ldp_engine* e, std::vector<double>* mf) {
-  *mf = e->maj_freq;
+// frequencies the replay compares: GetAlleleFreq(maj allele), minus 1.0 for --indep-preferred variants
+int prepare_mf(ldp_engine* e, std::vector<double>* scratch, const double** mf_out) {
   for (uint32_t l = 0; l < e->local_ct; ++l) {
     if (!e->mf_set[l]) {
       return fail(e, LDP_ERR_STATE, "major-allele frequency missing for an owned variant (ldp_set_maj_freqs)");
     }
-    if (!e->preferred.empty()) {
-      const uint32_t g = e->local_to_global[l];
-      if ((e->preferred[g >> 6] >> (g & 63)) & 1) {
-        (*mf)[l] -= 1.0;  // plink2_ld.cc:916-918
-      }
+  }
+  if (e->preferred.empty()) {
+    *mf_out = e->maj_freq.data();
+    return LDP_OK;
+  }
+  *scratch = e->maj_freq;
+  for (uint32_t l = 0; l < e->local_ct; ++l) {
+    const uint32_t g = e->local_to_global[l];
+    if ((e->preferred[g >> 6] >> (g & 63)) & 1) {
+      (*scratch)[l] -= 1.0;  // plink2_ld.cc:916-918
     }
   }
+  *mf_out = scratch->data();
   return LDP_OK;
 }
 
@@ -614,8 +725,9 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   if (rc) {
     return rc;
   }
-  std::vector<double> mf;
-  rc = prepare_mf(e, &mf);
+  std::vector<double> mf_scratch;
+  const double* mf = nullptr;
+  rc = prepare_mf(e, &mf_scratch, &mf);
   if (rc) {
     return rc;
   }
@@ -924,10 +1036,6 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
     return rc;
   }
   HIP_TRY(e, hipSetDevice(e->device));
-  hipEvent_t ev0, ev1;
-  HIP_TRY(e, hipEventCreate(&ev0));
-  HIP_TRY(e, hipEventCreate(&ev1));
-  float total_ms = 0.f;
   const uint8_t* src = static_cast<const uint8_t*>(geno);
   uint8_t* d_stage = nullptr;
   size_t stage_rows = 0;
@@ -970,42 +1078,33 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
       PA.row_dwords = e->row_dwords;
       PA.chunks = e->chunks;
       PA.recs = e->d_recs + l0;
-      HIP_TRY(e, hipEventRecord(ev0, e->stream));
+      if (!e->prep_pending) {
+        HIP_TRY(e, hipEventRecord(e->prep_ev0, e->stream));
+        e->prep_pending = true;
+      }
       hipError_t krc = launch_prepare(PA, e->stream);
       if (krc != hipSuccess) {
         return hipfail(e, krc, "prepare_kernel launch");
       }
-      HIP_TRY(e, hipEventRecord(ev1, e->stream));
-      HIP_TRY(e, hipStreamSynchronize(e->stream));  // staging buffer reuse + timing
-      float ms = 0.f;
-      HIP_TRY(e, hipEventElapsedTime(&ms, ev0, ev1));
-      total_ms += ms;
+      HIP_TRY(e, hipEventRecord(e->prep_ev1, e->stream));
+      if (location == LDP_MEM_HOST) {
+        HIP_TRY(e, hipStreamSynchronize(e->stream));  // the staging buffer is reused
+      }
       for (uint32_t q = 0; q < cnt; ++q) {
         e->loaded[l0 + q] = 1;
+        if (encoding != LDP_GENO_INVERSE) {
+          e->mf_set[l0 + q] = 2;  // derived from the device's allele counts at the next ldp_run()
+        }
       }
       done += cnt;
     }
-    // frequencies: derived for REF/BED input, caller-supplied for INVERSE input
-    e->recs_host_valid = false;
-    if (encoding != LDP_GENO_INVERSE) {
-      const uint32_t l0 = static_cast<uint32_t>(e->global_to_local[g]);
-      HIP_TRY(e, hipMemcpy(e->recs.data() + l0, e->d_recs + l0, run * sizeof(ldp_variant_rec), hipMemcpyDeviceToHost));
-      for (uint32_t q = 0; q < run; ++q) {
-        rc = derive_maj_freq(e, l0 + q);
-        if (rc) {
-          return rc;
-        }
-        e->mf_set[l0 + q] = 1;
-      }
-    }
     g += run;
   }
+  e->recs_host_valid = false;
   if (d_stage) {
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
     (void)hipFree(d_stage);
   }
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
-  e->ctr.ms_prepare = total_ms;
   return LDP_OK;
 }
 
@@ -1121,8 +1220,9 @@ int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first
   if (!e->recs_host_valid) {
     return fail(e, LDP_ERR_STATE, "variant records not set");
   }
-  std::vector<double> mf;
-  int rc = prepare_mf(e, &mf);
+  std::vector<double> mf_scratch;
+  const double* mf = nullptr;
+  int rc = prepare_mf(e, &mf_scratch, &mf);
   if (rc) {
     return rc;
   }
@@ -1183,6 +1283,12 @@ int ldp_get_maj_freqs(ldp_engine* e, uint32_t first_variant, uint32_t n, double*
   }
   if (static_cast<uint64_t>(first_variant) + n > e->variant_ct) {
     return fail(e, LDP_ERR_INVALID, "variant range out of bounds");
+  }
+  if (!e->recs_host_valid && e->plan_uploaded) {
+    const int rc = fetch_recs(e);  // derives the frequencies still pending from the device's allele counts
+    if (rc) {
+      return rc;
+    }
   }
   for (uint32_t q = 0; q < n; ++q) {
     const int64_t l = e->global_to_local[first_variant + q];
