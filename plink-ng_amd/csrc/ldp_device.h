@@ -12,12 +12,12 @@ namespace ldp {
 
 // ---- HBM layout of the bit-planes -------------------------------------------------------------
 // One variant = row of `chunks` k-chunks; a k-chunk = kChunkDwords dwords of the `hom` plane followed
-// by kChunkDwords dwords of the `ref2het` plane (256 contiguous bytes), so one k-chunk of one variant
-// is exactly what 16 lanes x 16 B stage into one LDS row.  Bit s%32 of plane dword s/32 = sample s.
+// by kChunkDwords dwords of the `ref2het` plane, so one k-chunk of one variant
+// (128 contiguous bytes) is exactly what 8 lanes x 16 B DMA into one LDS row.  Bit s%32 of plane dword s/32 = sample s.
 // Pad dwords (samples >= founder_ct) are zero in both planes == "missing", which contributes to no count.
-constexpr int kChunkDwords = 32;                 // plane dwords per k-chunk (1024 samples)
-constexpr int kRowChunkDwords = 2 * kChunkDwords; // hom + ref2het
-constexpr int kLdsRowDwords = kRowChunkDwords + 4; // 68: odd number of 16-B slots -> conflict-free b128 reads
+constexpr int kChunkDwords = 16;                 // plane dwords per k-chunk (512 samples)
+constexpr int kRowChunkDwords = 2 * kChunkDwords; // hom + ref2het = 128 B
+constexpr int kLdsRowDwords = kRowChunkDwords + 4; // 36: odd number (9) of 16-B slots -> conflict-free b128 reads
 
 // ---- pair-tile geometry -------------------------------------------------------------------------
 // A block owns kTileJ consecutive "second" variants j and a run of distances d = j - i, split in

@@ -81,8 +81,14 @@ __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void prepare_kernel(PrepareArgs A) {
-  __shared__ uint32_t red[4][3];
+// One block per variant.  Pass 1 converts the row to bit-planes held in registers (MAXIT plane dwords per
+// thread) while counting; after the block-wide reduction decides the major allele, pass 2 writes the planes
+// (with ref2het ^= hom when ALT is major) without touching the input again.  MAXIT == 0: rows too long
+// for the register budget are simply converted twice (second read comes from L2).
+template <int THREADS, int MAXIT>
+__global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
+  constexpr int kWaves = THREADS / 64;
+  __shared__ uint32_t red[kWaves][3];
   __shared__ uint32_t s_alt_major;
   const uint32_t v = blockIdx.x;
   const uint32_t tid = threadIdx.x;
@@ -91,13 +97,30 @@ __global__ __launch_bounds__(256) void prepare_kernel(PrepareArgs A) {
   const bool aligned4 = ((reinterpret_cast<uintptr_t>(row) & 3) == 0);
   const uint32_t plane_dwords = A.chunks * kChunkDwords;
 
+  uint32_t keep_hom[MAXIT ? MAXIT : 1], keep_r2h[MAXIT ? MAXIT : 1];
   uint32_t hom_ct = 0, r2h_ct = 0, both_ct = 0;
-  for (uint32_t p = tid; p < plane_dwords; p += 256) {
-    uint32_t hom, r2h;
-    convert_plane_dword(row, nbytes, aligned4, A.encoding, A.founder_ct, p, &hom, &r2h);
-    hom_ct += __popc(hom);
-    r2h_ct += __popc(r2h);
-    both_ct += __popc(hom & r2h);
+  if constexpr (MAXIT > 0) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const uint32_t p = tid + it * THREADS;
+      uint32_t hom = 0, r2h = 0;
+      if (p < plane_dwords) {
+        convert_plane_dword(row, nbytes, aligned4, A.encoding, A.founder_ct, p, &hom, &r2h);
+      }
+      keep_hom[it] = hom;
+      keep_r2h[it] = r2h;
+      hom_ct += __popc(hom);
+      r2h_ct += __popc(r2h);
+      both_ct += __popc(hom & r2h);
+    }
+  } else {
+    for (uint32_t p = tid; p < plane_dwords; p += THREADS) {
+      uint32_t hom, r2h;
+      convert_plane_dword(row, nbytes, aligned4, A.encoding, A.founder_ct, p, &hom, &r2h);
+      hom_ct += __popc(hom);
+      r2h_ct += __popc(r2h);
+      both_ct += __popc(hom & r2h);
+    }
   }
   hom_ct = wave_reduce_add(hom_ct);
   r2h_ct = wave_reduce_add(r2h_ct);
@@ -109,9 +132,15 @@ __global__ __launch_bounds__(256) void prepare_kernel(PrepareArgs A) {
   }
   __syncthreads();
   if (tid == 0) {
-    hom_ct = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-    r2h_ct = red[0][1] + red[1][1] + red[2][1] + red[3][1];
-    both_ct = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+    hom_ct = 0;
+    r2h_ct = 0;
+    both_ct = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      hom_ct += red[w][0];
+      r2h_ct += red[w][1];
+      both_ct += red[w][2];
+    }
     // raw genotype counts: code 0 = hom&r2h, code 1 = r2h only, code 2 = hom only
     const uint32_t n0 = both_ct;
     const uint32_t n1 = r2h_ct - both_ct;
@@ -153,15 +182,29 @@ __global__ __launch_bounds__(256) void prepare_kernel(PrepareArgs A) {
   __syncthreads();
   const uint32_t alt_major = s_alt_major;
   uint32_t* out_row = A.planes + static_cast<uint64_t>(v) * A.row_dwords;
-  for (uint32_t p = tid; p < plane_dwords; p += 256) {
-    uint32_t hom, r2h;
-    convert_plane_dword(row, nbytes, aligned4, A.encoding, A.founder_ct, p, &hom, &r2h);
-    if (alt_major) {
-      r2h ^= hom;  // 0 <-> 2 swaps ref2het on the homozygous calls only
+  if constexpr (MAXIT > 0) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const uint32_t p = tid + it * THREADS;
+      if (p < plane_dwords) {
+        const uint32_t hom = keep_hom[it];
+        const uint32_t r2h = alt_major ? (keep_r2h[it] ^ hom) : keep_r2h[it];  // 0 <-> 2 flips ref2het on homozygous calls
+        const uint32_t off = (p / kChunkDwords) * kRowChunkDwords + (p % kChunkDwords);
+        out_row[off] = hom;
+        out_row[off + kChunkDwords] = r2h;
+      }
     }
-    const uint32_t off = (p / kChunkDwords) * kRowChunkDwords + (p % kChunkDwords);
-    out_row[off] = hom;
-    out_row[off + kChunkDwords] = r2h;
+  } else {
+    for (uint32_t p = tid; p < plane_dwords; p += THREADS) {
+      uint32_t hom, r2h;
+      convert_plane_dword(row, nbytes, aligned4, A.encoding, A.founder_ct, p, &hom, &r2h);
+      if (alt_major) {
+        r2h ^= hom;
+      }
+      const uint32_t off = (p / kChunkDwords) * kRowChunkDwords + (p % kChunkDwords);
+      out_row[off] = hom;
+      out_row[off + kChunkDwords] = r2h;
+    }
   }
 }
 
@@ -169,14 +212,27 @@ hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream) {
   if (!a.n_variants) {
     return hipSuccess;
   }
-  hipLaunchKernelGGL(prepare_kernel, dim3(a.n_variants), dim3(256), 0, stream, a);
+  const uint32_t plane_dwords = a.chunks * kChunkDwords;
+  if (plane_dwords <= 256 * 4) {
+    hipLaunchKernelGGL((prepare_kernel<256, 4>), dim3(a.n_variants), dim3(256), 0, stream, a);
+  } else if (plane_dwords <= 256 * 8) {
+    hipLaunchKernelGGL((prepare_kernel<256, 8>), dim3(a.n_variants), dim3(256), 0, stream, a);
+  } else if (plane_dwords <= 1024 * 8) {
+    hipLaunchKernelGGL((prepare_kernel<1024, 8>), dim3(a.n_variants), dim3(1024), 0, stream, a);
+  } else if (plane_dwords <= 1024 * 16) {
+    hipLaunchKernelGGL((prepare_kernel<1024, 16>), dim3(a.n_variants), dim3(1024), 0, stream, a);
+  } else if (plane_dwords <= 1024 * 32) {
+    hipLaunchKernelGGL((prepare_kernel<1024, 32>), dim3(a.n_variants), dim3(1024), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((prepare_kernel<1024, 0>), dim3(a.n_variants), dim3(1024), 0, stream, a);
+  }
   return hipGetLastError();
 }
 
 // ================================================================================================
 // pair tiles
 // ================================================================================================
-constexpr int kLdsRowSlots = kLdsRowDwords / 4;  // 17 16-byte slots per LDS row
+constexpr int kLdsRowSlots = kLdsRowDwords / 4;  // 9 16-byte slots per LDS row (8 data + 1 pad)
 
 __device__ __forceinline__ uint32_t popc4(const uint4& v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
 __device__ __forceinline__ uint4 and4(const uint4& a, const uint4& b) { return make_uint4(a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w); }
@@ -312,15 +368,52 @@ __device__ __forceinline__ TileGeom make_geom(const WorkItem& it, uint32_t units
   return G;
 }
 
-// 16 lanes x 16 B move one k-chunk (hom+ref2het, 256 B) of one variant into one LDS row.
-__device__ __forceinline__ void stage_chunk(const uint32_t* __restrict__ planes, uint64_t row_dwords, const TileGeom& G, uint32_t* lds, uint32_t kc, uint32_t tid) {
-  const uint32_t sub = tid & 15;
-#pragma unroll 4
-  for (int r = tid >> 4; r < G.rtot; r += kBlockThreads / 16) {
-    const int64_t v = row_variant(G, r);
-    const uint4* src = reinterpret_cast<const uint4*>(planes + static_cast<uint64_t>(v) * row_dwords + static_cast<uint64_t>(kc) * kRowChunkDwords) + sub;
-    reinterpret_cast<uint4*>(lds + r * kLdsRowDwords)[sub] = *src;
+// ---- global -> LDS staging by LDS-DMA (global_load_lds_dwordx4), double-buffered -----------------------
+// An LDS buffer is a linear array of 16-byte slots, kLdsRowSlots (9) per row: 8 data slots (4 hom + 4
+// ref2het) + 1 pad slot that keeps the row stride odd.  One DMA wave-instruction fills 64 consecutive
+// slots (1 KiB, lane l -> slot 64*T + l); the per-lane GLOBAL address is free, so each lane simply fetches
+// the 16 bytes that belong in its slot (pad slots re-fetch slot 0 of their row and are never read).
+// The lane->source mapping does not depend on the k-chunk, so it is computed once per block.
+constexpr int kMaxDmaPerWave = 7;  // ceil(ceil(191 rows * 9 slots / 64) / 4 waves)
+
+struct DmaPlan {
+  uint32_t src_off[kMaxDmaPerWave];  // byte offset of this lane's 16 B relative to the block's first variant row
+  uint32_t n_instr;                  // DMA wave-instructions per k-chunk for the whole block
+};
+
+__device__ __forceinline__ DmaPlan make_dma_plan(const TileGeom& G, uint64_t row_bytes, uint32_t wave, uint32_t lane, int64_t vmin) {
+  DmaPlan P;
+  const uint32_t total_slots = static_cast<uint32_t>(G.rtot) * kLdsRowSlots;
+  P.n_instr = (total_slots + 63) / 64;
+#pragma unroll
+  for (int t = 0; t < kMaxDmaPerWave; ++t) {
+    const uint32_t L = (wave + kWavesPerBlock * t) * 64 + lane;
+    int row = static_cast<int>(L / kLdsRowSlots);
+    uint32_t sl = L % kLdsRowSlots;
+    if (row >= G.rtot) {
+      row = G.rtot - 1;
+    }
+    if (sl == kLdsRowSlots - 1) {
+      sl = 0;
+    }
+    P.src_off[t] = static_cast<uint32_t>((row_variant(G, row) - vmin) * static_cast<int64_t>(row_bytes)) + sl * 16;
   }
+  return P;
+}
+
+__device__ __forceinline__ void dma_chunk(const DmaPlan& P, const uint8_t* chunk_base, uint32_t* lds_buf, uint32_t wave) {
+#pragma unroll
+  for (int t = 0; t < kMaxDmaPerWave; ++t) {
+    const uint32_t T = wave + kWavesPerBlock * t;
+    if (T < P.n_instr) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(chunk_base + P.src_off[t]),
+                                       (__attribute__((address_space(3))) void*)(lds_buf + T * 256), 16, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t lds_buffer_dwords(int rtot) {
+  return ((static_cast<uint32_t>(rtot) * kLdsRowSlots + 63) / 64) * 256;
 }
 
 // plink2_ld.cc:1085-1090, no FMA contraction possible (multiplies only); var1 belongs to the FIRST variant.
@@ -404,12 +497,16 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_ker
   const uint32_t units_w = (it.units >> (8 * wave)) & 0xff;
   const uint32_t dw0 = it.d0 + 8 * units_before;  // first distance of this wave
 
-  const uint4* l4 = reinterpret_cast<const uint4*>(lds);
   const int jrow = tx;
   // I-row of (b = 0, a = 0): i = j0 + tx - (dw0 + ty)
   const int irow0 = kTileJ + static_cast<int>(static_cast<int64_t>(it.j0) - dw0 - G.ilo) + tx - ty;
-  const uint32_t* planes = A.planes;
-  const uint64_t row_dwords = A.row_dwords;
+  // double-buffered LDS-DMA staging: chunk kc+1 streams in while chunk kc is being consumed
+  const uint64_t row_bytes = A.row_dwords * sizeof(uint32_t);
+  const int64_t vmin = row_variant(G, kTileJ);  // first I-row: the lowest variant the tile touches
+  const DmaPlan plan = make_dma_plan(G, row_bytes, wave, lane, vmin);
+  const uint8_t* tile_base = reinterpret_cast<const uint8_t*>(A.planes) + static_cast<uint64_t>(vmin) * row_bytes;
+  const uint32_t buf_dwords = lds_buffer_dwords(G.rtot);
+  constexpr uint32_t kChunkBytes = kRowChunkDwords * sizeof(uint32_t);
 
   if constexpr (!GENERAL) {
     uint32_t hh[4][4], xx[4][4];
@@ -421,9 +518,13 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_ker
         xx[a][b] = 0;
       }
     }
+    dma_chunk(plan, tile_base, lds, wave);
+    __syncthreads();  // (drains this wave's DMA, then barrier)
     for (uint32_t kc = 0; kc < A.chunks; ++kc) {
-      stage_chunk(planes, row_dwords, G, lds, kc, tid);
-      __syncthreads();
+      if (kc + 1 < A.chunks) {
+        dma_chunk(plan, tile_base + static_cast<uint64_t>(kc + 1) * kChunkBytes, lds + ((kc + 1) & 1) * buf_dwords, wave);
+      }
+      const uint4* l4 = reinterpret_cast<const uint4*>(lds + (kc & 1) * buf_dwords);
       switch (units_w) {
         case 1: tile_chunk_fast<1>(l4, jrow, irow0, hh, xx); break;
         case 2: tile_chunk_fast<2>(l4, jrow, irow0, hh, xx); break;
@@ -431,7 +532,7 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_ker
         case 4: tile_chunk_fast<4>(l4, jrow, irow0, hh, xx); break;
         default: break;
       }
-      __syncthreads();
+      __syncthreads();  // next chunk landed (vmcnt drained) and every wave is done reading this one
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -479,9 +580,13 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_ker
       }
       const uint32_t na = (units_w > a0) ? ((units_w - a0 >= 2) ? 2 : 1) : 0;
       const int irow = irow0 - 8 * static_cast<int>(a0);
+      dma_chunk(plan, tile_base, lds, wave);
+      __syncthreads();
       for (uint32_t kc = 0; kc < A.chunks; ++kc) {
-        stage_chunk(planes, row_dwords, G, lds, kc, tid);
-        __syncthreads();
+        if (kc + 1 < A.chunks) {
+          dma_chunk(plan, tile_base + static_cast<uint64_t>(kc + 1) * kChunkBytes, lds + ((kc + 1) & 1) * buf_dwords, wave);
+        }
+        const uint4* l4 = reinterpret_cast<const uint4*>(lds + (kc & 1) * buf_dwords);
         if (na == 2) {
           tile_chunk_general<2>(l4, jrow, irow, acc);
         } else if (na == 1) {
@@ -533,9 +638,9 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_ker
 
 size_t pair_tiles_lds_bytes(uint32_t max_units) {
   const size_t rows = kTileJ + 8 * static_cast<size_t>(max_units) + 31;
-  const size_t tile = rows * kLdsRowDwords * sizeof(uint32_t);
+  const size_t buf = ((rows * kLdsRowSlots + 63) / 64) * 1024;  // one staging buffer, whole DMA instructions
   const size_t epi = static_cast<size_t>(kEpilogueLdsDwords) * sizeof(uint32_t);
-  return (tile > epi) ? tile : epi;
+  return (2 * buf > epi) ? 2 * buf : epi;
 }
 
 hipError_t launch_pair_tiles(const PairKernelArgs& a, uint32_t max_units, hipStream_t stream, hipEvent_t* ev) {

@@ -59,6 +59,37 @@ def test_prepare_planes_and_aggregates(gpu_pkg, n, encoding):
     eng.close()
 
 
+@pytest.mark.parametrize("n", [40000, 200001, 500000, 1100003])
+def test_prepare_large_sample_counts(gpu_pkg, n):
+    """Every register-budget variant of prepare_kernel (rows of 1k .. 34k plane dwords), incl. 500k samples
+    (BASELINE configs 3-5) and the two-pass fallback above 1M samples."""
+    pkg = gpu_pkg
+    m = 6
+    raw = T.synth_raw_codes(m, n, seed=n % 1000, missing_rate=0.03)
+    inv, mf, altmaj, hom, r2h, vaggs = oracle_recs(raw, n)
+    eng = pkg.LdPruneEngine(n, 10, 1, False, 0.2, device=0)
+    eng.set_variants(np.zeros(m, dtype=np.uint32), None)
+    eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+    recs = eng.variant_recs()
+    w32 = (n + 31) // 32
+    for v in range(m):
+        gh, gr = eng.planes(v)
+        assert np.array_equal(gh, hom[v].view(np.uint32)[:w32])
+        assert np.array_equal(gr, r2h[v].view(np.uint32)[:w32])
+        assert (recs[v]["nm_ct"], recs[v]["sum"], recs[v]["ssq"]) == (vaggs[v].nm_ct, vaggs[v].sum, vaggs[v].ssq)
+    assert np.array_equal(eng.maj_freqs(), mf)
+    st = eng.pair_stats([0, 1, 2], [3, 4, 5])
+    for k, (i, j) in enumerate([(0, 3), (1, 4), (2, 5)]):
+        assert tuple(int(x) for x in st[k]) == T.oracle_pair_stats(hom, r2h, vaggs, n, i, j).astuple()
+    removed, stats = eng.run_with_stats()  # 15 candidate pairs through the tile kernel at this row length
+    k = 0
+    for j in range(m):
+        for i in range(j):
+            assert tuple(int(x) for x in stats[k]) == T.oracle_pair_stats(hom, r2h, vaggs, n, i, j).astuple()
+            k += 1
+    eng.close()
+
+
 @pytest.mark.parametrize("n,miss", [(65, 0.0), (100, 0.1), (1025, 0.02), (4097, 0.3), (50000, 0.05)])
 def test_pair_stats_reference_kernel(gpu_pkg, n, miss):
     pkg = gpu_pkg
