@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--window-kb", type=float, default=200.0)
     ap.add_argument("--r2", type=float, default=0.5)
     ap.add_argument("--missing-rate", type=float, default=0.0)
+    ap.add_argument("--spacing", type=int, default=2875, help="bp between consecutive variants")
     ap.add_argument("--cpu-sample-variants", type=int, default=440000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -150,7 +151,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     founder_ct = args.samples
-    spacing = 2875
+    spacing = args.spacing
     window_bp = pkg.kb_window(args.window_kb)
     chr_idx, bps = genome_layout(args.variants, world, spacing)
     m_total = len(chr_idx)
@@ -173,31 +174,16 @@ def main():
         off += ln
     torch.cuda.synchronize()
 
-    # per-rank removed-bit segments (local order) for the all_gather
-    seg_words = (max(sum(ln for (ln, _), o in zip(subs, owner) if o == r) for r in range(world)) + 63) // 64
-    gather_in = torch.zeros(seg_words, dtype=torch.int64, device="cuda")
-    gather_out = [torch.zeros(seg_words, dtype=torch.int64, device="cuda") for _ in range(world)] if world > 1 else None
+    import importlib
+    distmod = importlib.import_module("plink_ng_amd.dist")
 
     def step():
         for first, ln, o in seg:
             eng.load_genotypes_device(first, ln, geno.data_ptr() + o * stride, stride, pkg.LDP_GENO_REF)
         removed = eng.run()
         if world > 1:
-            local_bits = np.concatenate([removed[first:first + ln] for first, ln, _ in seg]) if seg else np.zeros(0, dtype=bool)
-            packed = np.zeros(seg_words * 8, dtype=np.uint8)
-            pb = np.packbits(local_bits, bitorder="little")
-            packed[:len(pb)] = pb
-            gather_in.copy_(torch.from_numpy(packed.view(np.int64)))
-            dist.all_gather(gather_out, gather_in)
-            full = np.zeros(m_total, dtype=bool)
-            for r in range(world):
-                bits = np.unpackbits(gather_out[r].cpu().numpy().view(np.uint8), bitorder="little")
-                pos = 0
-                for (ln, first), o in zip(subs, owner):
-                    if o == r:
-                        full[first:first + ln] = bits[pos:pos + ln]
-                        pos += ln
-            return full
+            # the one exchange step: all_gather of the per-rank removed-bit segments (RCCL over xGMI)
+            return distmod.allgather_removed(removed, subs, owner, rank, world, m_total, device="cuda")
         return removed
 
     def sync():

@@ -126,6 +126,7 @@ struct ldp_engine {
   bool plan_uploaded = false;
   bool recs_registered = false;
   hipEvent_t prep_ev0 = nullptr, prep_ev1 = nullptr;
+  hipStream_t copy_stream = nullptr;
   bool prep_pending = false;
 
   ldp_counters ctr;
@@ -493,8 +494,12 @@ int fetch_recs(ldp_engine* e) {
     return LDP_OK;
   }
   if (e->local_ct) {
-    HIP_TRY(e, hipMemcpyAsync(e->recs.data(), e->d_recs, e->local_ct * sizeof(ldp_variant_rec), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    // copy stream: ordered after the last prepare kernel only, so it overlaps whatever else is queued
+    if (e->prep_pending) {
+      HIP_TRY(e, hipStreamWaitEvent(e->copy_stream, e->prep_ev1, 0));
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->recs.data(), e->d_recs, e->local_ct * sizeof(ldp_variant_rec), hipMemcpyDeviceToHost, e->copy_stream));
+    HIP_TRY(e, hipStreamSynchronize(e->copy_stream));
   }
   if (e->prep_pending) {
     float ms = 0.f;
@@ -724,16 +729,9 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     if (!e->loaded[l]) {
       return fail(e, LDP_ERR_STATE, "genotypes missing for an owned variant (ldp_load_genotypes)");
     }
-  }
-  rc = fetch_recs(e);
-  if (rc) {
-    return rc;
-  }
-  std::vector<double> mf_scratch;
-  const double* mf = nullptr;
-  rc = prepare_mf(e, &mf_scratch, &mf);
-  if (rc) {
-    return rc;
+    if (!e->mf_set[l]) {
+      return fail(e, LDP_ERR_STATE, "major-allele frequency missing for an owned variant (ldp_set_maj_freqs)");
+    }
   }
   if (stats && (stats_capacity < e->cand_pairs)) {
     return fail(e, LDP_ERR_INVALID, "stats buffer smaller than the candidate pair count");
@@ -765,6 +763,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   A.counters = e->d_counters;
   A.item_general = e->d_item_general;
 
+  // 1. everything the device has to do is queued first ...
   hipEvent_t ev0, ev1;
   hipEvent_t evk[4];
   HIP_TRY(e, hipEventCreate(&ev0));
@@ -786,6 +785,18 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   if (d_stats) {
     HIP_TRY(e, hipMemcpyAsync(stats, d_stats, e->cand_pairs * sizeof(ldp_pair_stats_t), hipMemcpyDeviceToHost, e->stream));
   }
+  // 2. ... then, while the pair kernel runs, the per-variant records come back on the copy stream and the
+  //    host derives the major-allele frequencies the replay needs.
+  rc = fetch_recs(e);
+  if (rc) {
+    return rc;
+  }
+  std::vector<double> mf_scratch;
+  const double* mf = nullptr;
+  rc = prepare_mf(e, &mf_scratch, &mf);
+  if (rc) {
+    return rc;
+  }
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   float kms = 0.f, kms_fast = 0.f, kms_general = 0.f;
   HIP_TRY(e, hipEventElapsedTime(&kms, ev0, ev1));
@@ -802,6 +813,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     (void)hipFree(d_stats);
   }
 
+  // 3. greedy replay on the host
   const double t_replay = now_ms();
   std::vector<uint32_t> R((static_cast<size_t>(e->local_ct) + 31) / 32 + 1, 0);
   uint64_t replay_pairs = 0;
@@ -883,6 +895,9 @@ int ldp_create(const ldp_params* params, ldp_engine** out) {
       } else {
         e->gpu_ok = false;
       }
+      if (e->gpu_ok && (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess)) {
+        e->gpu_ok = false;
+      }
     }
   }
   *out = e;
@@ -898,6 +913,9 @@ void ldp_destroy(ldp_engine* e) {
     free_device(e);
     if (e->own_stream) {
       (void)hipStreamDestroy(e->stream);
+    }
+    if (e->copy_stream) {
+      (void)hipStreamDestroy(e->copy_stream);
     }
   }
   delete e;

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 CSVs tools/profile.sh collected into the small files kept under profiles/:
+  <tag>_kernel_stats.csv   per-kernel calls / total / average / min / max duration (from kernel_trace)
+  <tag>_pmc.json           per-kernel mean counter values (one dispatch = one launch)
+  pmc_traffic.json         HBM bytes per pair_tiles_kernel launch, read by bench.py as roofline.traffic
+HBM bytes follow MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+reports half of the bytes of a wide coalesced streaming read, so the read side is doubled."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    os.makedirs(dst, exist_ok=True)
+    # ---- kernel trace
+    rows = []
+    for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        rows += list(csv.DictReader(open(f)))
+    dur = collections.defaultdict(list)
+    for r in rows:
+        dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    total = sum(sum(v) for v in dur.values()) or 1
+    with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as f:
+        f.write("kernel,calls,total_ms,avg_ms,min_ms,max_ms,percent\n")
+        for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+            f.write('"%s",%d,%.4f,%.4f,%.4f,%.4f,%.2f\n' % (k, len(v), sum(v) / 1e6, sum(v) / len(v) / 1e6, min(v) / 1e6, max(v) / 1e6,
+                                                       100.0 * sum(v) / total))
+    # ---- counters
+    pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            pmc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in pmc.items() if "ldp::" in k}
+    json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
+    for k, cs in out.items():
+        if "pair_tiles_kernel<false>" in k and "FETCH_SIZE" in cs:
+            read_b = cs["FETCH_SIZE"] * 1024 * 2
+            write_b = cs.get("WRITE_SIZE", 0.0) * 1024
+            json.dump({"kernel": k, "samples": 50000, "variants": 1000000, "window_kb": 200.0,
+                       "hbm_bytes_per_launch": read_b + write_b, "fetch_size_kib": cs["FETCH_SIZE"], "write_size_kib": cs.get("WRITE_SIZE"),
+                       "note": "FETCH_SIZE x 1024 x 2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE x 1024",
+                       "tag": tag}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    print(open(os.path.join(dst, tag + "_kernel_stats.csv")).read())
+
+
+if __name__ == "__main__":
+    main()
