@@ -1,0 +1,785 @@
+// plink2_hip_cli.cpp -- `plink2-hip`: process-level drop-in for the --indep-pairwise path of plink2.
+//
+// Same flag spellings (2.0/plink2.cc:7238-7337, 2.0/plink2_help.cc:948-969), same inputs
+// (.bed/.bim/.fam, fixed-width .pgen/.pvar/.psam) and byte-identical <out>.prune.in / <out>.prune.out
+// (LdPruneWrite, 2.0/plink2_ld.cc:2464-2528).  Everything between "files are open" and "bitmap of removed
+// variants" goes through the C ABI in include/ldprune_hip.h, i.e. through the HIP kernels; there is no CPU
+// compute path here, so without a usable GPU the program exits with an error.
+//
+// What this front-end does itself (host C++): argument parsing incl. the reference's decimal scanner
+// (ScanadvDouble, 2.0/include/plink2_string.cc:1264-1528), .fam/.psam founder detection
+// (2.0/plink2_psam.cc:804-813), .bim/.pvar parsing, chromosome-0 stripping (StripUnplacedK,
+// plink2_ld.cc:113-164), the sorted-positions and unique-ID checks (plink2.cc:2926, plink2_ld.cc:2573-2592),
+// the <50-founders guard (plink2.cc:2063-2071) and the output writer.
+// Not yet supported (reported as such, never silently mis-handled): variable-width .pgen (mode 0x10),
+// chrX/chrY/MT/haploid contigs, .pvar.zst, multiallelic variants.
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/ldprune_hip.h"
+
+namespace {
+
+constexpr double kSmallEpsilon = 0.00000000000005684341886080801486968994140625;  // 2^-44
+FILE* g_log = nullptr;
+
+void logprintf(const char* fmt, ...) {
+  char buf[4096];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  fputs(buf, stdout);
+  if (g_log) {
+    fputs(buf, g_log);
+  }
+}
+
+[[noreturn]] void die(int code, const char* fmt, ...) {
+  char buf[4096];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  fflush(stdout);
+  fputs(buf, stderr);
+  if (g_log) {
+    fputs(buf, g_log);
+    fclose(g_log);
+  }
+  exit(code);
+}
+
+// The reference's decimal scanner: up to 16-17 significant digits accumulated in an int64, then ONE
+// multiplication by a table power of ten -- so "0.3" parses as 3 * 0.1 = 0.30000000000000004, not as strtod
+// would.  Returns false on malformed input.  (plink2_string.cc:1264-1528; exponents beyond the tables unsupported)
+bool scan_double_plink(const char* s, double* out, const char** endp) {
+  static const double kNegPow10[16] = {1.0, 1.0e-1, 1.0e-2, 1.0e-3, 1.0e-4, 1.0e-5, 1.0e-6, 1.0e-7, 1.0e-8, 1.0e-9, 1.0e-10, 1.0e-11, 1.0e-12, 1.0e-13, 1.0e-14, 1.0e-15};
+  static const double kPosPow10[16] = {1.0, 1.0e1, 1.0e2, 1.0e3, 1.0e4, 1.0e5, 1.0e6, 1.0e7, 1.0e8, 1.0e9, 1.0e10, 1.0e11, 1.0e12, 1.0e13, 1.0e14, 1.0e15};
+  const char* p = s;
+  bool neg = false;
+  if (*p == '-' || *p == '+') {
+    neg = (*p == '-');
+    ++p;
+  }
+  int64_t digits = 0;
+  long e10 = 0;
+  bool any = false;
+  bool seen_dot = false;
+  for (;; ++p) {
+    if (*p >= '0' && *p <= '9') {
+      any = true;
+      if (digits < 10000000000000000LL) {
+        digits = digits * 10 + (*p - '0');
+        if (seen_dot) {
+          --e10;
+        }
+      } else if (!seen_dot) {
+        ++e10;
+      }
+    } else if (*p == '.' && !seen_dot) {
+      seen_dot = true;
+    } else {
+      break;
+    }
+  }
+  if (!any) {
+    return false;
+  }
+  if (*p == 'e' || *p == 'E') {
+    const char* q = p + 1;
+    bool eneg = false;
+    if (*q == '-' || *q == '+') {
+      eneg = (*q == '-');
+      ++q;
+    }
+    if (*q >= '0' && *q <= '9') {
+      long ev = 0;
+      while (*q >= '0' && *q <= '9' && ev < 100000) {
+        ev = ev * 10 + (*q - '0');
+        ++q;
+      }
+      e10 += eneg ? -ev : ev;
+      p = q;
+    }
+  }
+  double d = static_cast<double>(neg ? -digits : digits);
+  if (digits && e10) {
+    if (e10 < 0) {
+      if (-e10 > 15) {
+        long pe = -e10;
+        d *= kNegPow10[pe & 15];
+        for (pe /= 16; pe > 0; --pe) {
+          d *= 1.0e-16;
+        }
+      } else {
+        d *= kNegPow10[-e10];
+      }
+    } else {
+      if (e10 > 15) {
+        long pe = e10;
+        d *= kPosPow10[pe & 15];
+        for (pe /= 16; pe > 0; --pe) {
+          d *= 1.0e16;
+        }
+      } else {
+        d *= kPosPow10[e10];
+      }
+    }
+  }
+  *out = d;
+  if (endp) {
+    *endp = p;
+  }
+  return true;
+}
+
+struct Args {
+  std::string bed, bim, fam, pgen, pvar, psam, out = "plink2";
+  bool have_prune = false;
+  uint32_t window = 0, step = 1;
+  bool window_is_bp = false;
+  double r2 = 0.0;
+  int order = 2;
+  bool bad_ld = false;
+  bool allow_extra_chr = false;
+  std::string preferred;
+  int gpus = 1;
+  bool dry_run = false;  // parse + plan only, print the parameters exactly (%a) and exit: used by the CPU tests
+};
+
+std::vector<std::string> split_ws(const std::string& line) {
+  std::vector<std::string> out;
+  size_t i = 0;
+  while (i < line.size()) {
+    while (i < line.size() && (line[i] == ' ' || line[i] == '\t' || line[i] == '\r')) {
+      ++i;
+    }
+    size_t j = i;
+    while (j < line.size() && line[j] != ' ' && line[j] != '\t' && line[j] != '\r') {
+      ++j;
+    }
+    if (j > i) {
+      out.emplace_back(line.substr(i, j - i));
+    }
+    i = j;
+  }
+  return out;
+}
+
+bool ieq(const char* a, const char* b) {
+  for (; *a && *b; ++a, ++b) {
+    if ((*a | 32) != (*b | 32)) {
+      return false;
+    }
+  }
+  return !*a && !*b;
+}
+
+Args parse_args(int argc, char** argv) {
+  Args A;
+  auto need = [&](int i, int n, const char* flag) {
+    if (i + n >= argc) {
+      die(5, "Error: Missing argument for %s.\n", flag);
+    }
+  };
+  for (int i = 1; i < argc; ++i) {
+    std::string f = argv[i];
+    if (f == "--bfile" || f == "--pfile" || f == "--bpfile") {
+      need(i, 1, f.c_str());
+      std::string pre = argv[++i];
+      if (f == "--bfile") {
+        A.bed = pre + ".bed";
+        A.bim = pre + ".bim";
+        A.fam = pre + ".fam";
+      } else if (f == "--pfile") {
+        A.pgen = pre + ".pgen";
+        A.pvar = pre + ".pvar";
+        A.psam = pre + ".psam";
+      } else {
+        A.pgen = pre + ".pgen";
+        A.bim = pre + ".bim";
+        A.fam = pre + ".fam";
+      }
+    } else if (f == "--bed" || f == "--bim" || f == "--fam" || f == "--pgen" || f == "--pvar" || f == "--psam" || f == "--out" || f == "--indep-preferred") {
+      need(i, 1, f.c_str());
+      std::string v = argv[++i];
+      if (f == "--bed") A.bed = v;
+      else if (f == "--bim") A.bim = v;
+      else if (f == "--fam") A.fam = v;
+      else if (f == "--pgen") A.pgen = v;
+      else if (f == "--pvar") A.pvar = v;
+      else if (f == "--psam") A.psam = v;
+      else if (f == "--out") A.out = v;
+      else A.preferred = v;
+    } else if (f == "--indep-pairwise") {
+      // <window size>['kb'] [step size (variant ct)] <unphased-hardcall-r^2 threshold>   (plink2.cc:7238-7313)
+      std::vector<std::string> par;
+      while (i + 1 < argc && !(argv[i + 1][0] == '-' && argv[i + 1][1] == '-')) {
+        par.emplace_back(argv[++i]);
+      }
+      if (par.size() < 2 || par.size() > 4) {
+        die(5, "Error: --indep-pairwise accepts 2-4 arguments.\n");
+      }
+      double first;
+      const char* endp;
+      if (!scan_double_plink(par[0].c_str(), &first, &endp) || first < 0.0) {
+        die(5, "Error: Invalid --indep-pairwise window size '%s'.\n", par[0].c_str());
+      }
+      size_t next = 1;
+      bool is_kb = false;
+      if (ieq(endp, "kb")) {
+        is_kb = true;
+      } else if (*endp) {
+        die(5, "Error: Invalid --indep-pairwise window size '%s'.\n", par[0].c_str());
+      } else if (ieq(par[1].c_str(), "kb")) {
+        is_kb = true;
+        next = 2;
+      }
+      if (is_kb) {
+        A.window_is_bp = true;
+        if (first > 2147483.646) {
+          A.window = 2147483646;
+        } else {
+          const int32_t w = static_cast<int32_t>(first * 1000 * (1 + kSmallEpsilon));
+          if (w < 2) {
+            die(5, "Error: --indep-pairwise window size cannot be smaller than 2.\n");
+          }
+          A.window = w;
+        }
+      } else {
+        A.window = (first > 2147483647) ? 2147483647u : static_cast<uint32_t>(static_cast<int32_t>(first));
+      }
+      if (next + 2 == par.size()) {
+        // explicit step size
+        char* e2;
+        const long st = strtol(par[next].c_str(), &e2, 10);
+        if (*e2 || st < 1 || st > 2147483646) {
+          die(5, "Error: Invalid --indep-pairwise window-increment '%s'.\n", par[next].c_str());
+        }
+        A.step = static_cast<uint32_t>(st);
+        if (!is_kb) {
+          if (A.step > A.window) {
+            die(5, "Error: --indep-pairwise window-increment cannot be larger than window size.\n");
+          }
+        } else if (A.step != 1) {
+          die(5, "Error: --indep-pairwise window-increment must be 1 when window size is in\nkilobase units.\n");
+        }
+        ++next;
+      } else if (next + 1 != par.size()) {
+        die(5, "Error: Invalid --indep-pairwise argument sequence.\n");
+      }
+      const char* e3;
+      if (!scan_double_plink(par[next].c_str(), &A.r2, &e3) || *e3 || A.r2 < 0.0 || A.r2 >= 1.0) {
+        die(5, "Error: Invalid --indep-pairwise r^2 threshold '%s'.\n", par[next].c_str());
+      }
+      A.have_prune = true;
+    } else if (f == "--indep-order") {
+      need(i, 1, "--indep-order");
+      std::string v = argv[++i];
+      if (v == "1") A.order = 1;
+      else if (v == "2") A.order = 2;
+      else die(5, "Error: Invalid --indep-order mode '%s' ('1' or '2' expected).\n", v.c_str());
+    } else if (f == "--bad-ld") {
+      A.bad_ld = true;
+    } else if (f == "--allow-extra-chr") {
+      A.allow_extra_chr = true;
+    } else if (f == "--dry-run") {
+      A.dry_run = true;
+    } else if (f == "--gpus") {
+      need(i, 1, "--gpus");
+      A.gpus = atoi(argv[++i]);
+    } else if (f == "--threads" || f == "--memory" || f == "--seed") {
+      need(i, 1, f.c_str());
+      ++i;  // accepted for command-line compatibility; the work runs on the GPU(s)
+    } else {
+      die(5, "Error: Unrecognized flag ('%s').  plink2-hip implements the --indep-pairwise path only.\n", f.c_str());
+    }
+  }
+  if (!A.have_prune) {
+    die(5, "Error: no command given (plink2-hip implements --indep-pairwise).\n");
+  }
+  if (A.gpus < 1) {
+    die(5, "Error: --gpus must be positive.\n");
+  }
+  return A;
+}
+
+// founder <=> PAT and MAT are both exactly "0" (plink2_psam.cc:804-806); absent columns => founder
+void load_samples(const Args& A, std::vector<uint8_t>* is_founder) {
+  const bool psam = !A.psam.empty();
+  const std::string& path = psam ? A.psam : A.fam;
+  std::ifstream in(path);
+  if (!in) {
+    die(2, "Error: Failed to open %s.\n", path.c_str());
+  }
+  std::string line;
+  int pat_col = -1, mat_col = -1;
+  bool header_seen = false;
+  while (std::getline(in, line)) {
+    if (line.empty()) {
+      continue;
+    }
+    if (psam && line[0] == '#') {
+      if (line.rfind("#FID", 0) == 0 || line.rfind("#IID", 0) == 0) {
+        std::vector<std::string> cols = split_ws(line);
+        for (size_t c = 0; c < cols.size(); ++c) {
+          if (cols[c] == "PAT") pat_col = static_cast<int>(c);
+          if (cols[c] == "MAT") mat_col = static_cast<int>(c);
+        }
+        header_seen = true;
+      }
+      continue;
+    }
+    std::vector<std::string> t = split_ws(line);
+    if (t.empty()) {
+      continue;
+    }
+    if (!psam || !header_seen) {
+      // .fam layout: FID IID PAT MAT SEX PHENO
+      if (t.size() < 5) {
+        die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
+      }
+      is_founder->push_back((t[2] == "0") && (t[3] == "0"));
+    } else {
+      bool founder = true;
+      if (pat_col >= 0 && mat_col >= 0) {
+        if (static_cast<size_t>(std::max(pat_col, mat_col)) >= t.size()) {
+          die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
+        }
+        founder = (t[pat_col] == "0") && (t[mat_col] == "0");
+      }
+      is_founder->push_back(founder);
+    }
+  }
+}
+
+struct Variants {
+  std::vector<std::string> chrom, id;
+  std::vector<uint32_t> bp;
+};
+
+void load_variants(const Args& A, Variants* V) {
+  const bool pvar = !A.pvar.empty();
+  const std::string& path = pvar ? A.pvar : A.bim;
+  if (path.size() > 4 && path.compare(path.size() - 4, 4, ".zst") == 0) {
+    die(9, "Error: zstd-compressed .pvar is not supported yet by plink2-hip.\n");
+  }
+  std::ifstream in(path);
+  if (!in) {
+    die(2, "Error: Failed to open %s.\n", path.c_str());
+  }
+  std::string line;
+  bool header = false;
+  int c_chrom = 0, c_pos = 3, c_id = 1, c_alt = -1;
+  while (std::getline(in, line)) {
+    if (line.empty()) {
+      continue;
+    }
+    if (line[0] == '#') {
+      if (line.rfind("#CHROM", 0) == 0) {
+        std::vector<std::string> cols = split_ws(line);
+        c_chrom = 0;
+        c_pos = c_id = -1;
+        for (size_t c = 0; c < cols.size(); ++c) {
+          if (cols[c] == "POS") c_pos = static_cast<int>(c);
+          if (cols[c] == "ID") c_id = static_cast<int>(c);
+          if (cols[c] == "ALT") c_alt = static_cast<int>(c);
+        }
+        if (c_pos < 0 || c_id < 0) {
+          die(3, "Error: %s header lacks POS/ID.\n", path.c_str());
+        }
+        header = true;
+      }
+      continue;
+    }
+    std::vector<std::string> t = split_ws(line);
+    if (!header) {
+      // .bim layout: chrom id cM bp A1 A2 (5-column variant without cM also accepted by plink2)
+      if (t.size() == 5) {
+        c_pos = 2;
+      } else if (t.size() < 6) {
+        die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
+      }
+    }
+    if (static_cast<size_t>(std::max(std::max(c_chrom, c_pos), c_id)) >= t.size()) {
+      die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
+    }
+    if (c_alt >= 0 && static_cast<size_t>(c_alt) < t.size() && t[c_alt].find(',') != std::string::npos) {
+      die(9, "Error: multiallelic variants are not supported yet by plink2-hip ('%s').\n", t[c_id].c_str());
+    }
+    V->chrom.push_back(t[c_chrom]);
+    V->id.push_back(t[c_id]);
+    char* e;
+    const long long pos = strtoll(t[c_pos].c_str(), &e, 10);
+    if (*e || pos < 0 || pos > 0x7ffffffe) {
+      die(3, "Error: Invalid bp coordinate in %s.\n", path.c_str());
+    }
+    V->bp.push_back(static_cast<uint32_t>(pos));
+  }
+}
+
+// chromosome code: 1..22 autosomes (optional "chr" prefix), 0 = unplaced; anything haploid/sex is refused
+int chrom_class(const std::string& name_in, bool allow_extra, bool* is_zero) {
+  std::string name = name_in;
+  if (name.size() > 3 && (name[0] | 32) == 'c' && (name[1] | 32) == 'h' && (name[2] | 32) == 'r') {
+    name = name.substr(3);
+  }
+  *is_zero = false;
+  bool numeric = !name.empty();
+  for (char c : name) {
+    numeric = numeric && (c >= '0' && c <= '9');
+  }
+  if (numeric) {
+    const long v = strtol(name.c_str(), nullptr, 10);
+    if (v == 0) {
+      *is_zero = true;
+      return 0;
+    }
+    if (v <= 22) {
+      return 0;
+    }
+    if (v == 25) {
+      return 0;  // XY (pseudo-autosomal) is diploid
+    }
+    return 1;  // 23 X, 24 Y, 26 MT
+  }
+  if (ieq(name.c_str(), "X") || ieq(name.c_str(), "Y") || ieq(name.c_str(), "MT") || ieq(name.c_str(), "M")) {
+    return 1;
+  }
+  if (ieq(name.c_str(), "XY") || ieq(name.c_str(), "PAR1") || ieq(name.c_str(), "PAR2")) {
+    return 0;
+  }
+  return allow_extra ? 0 : 2;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  Args A = parse_args(argc, argv);
+  g_log = fopen((A.out + ".log").c_str(), "w");
+  logprintf("plink2-hip: MI355X-native --indep-pairwise (drop-in for that path of PLINK v2.0)\n");
+  logprintf("Options in effect:\n ");
+  for (int i = 1; i < argc; ++i) {
+    logprintf(" %s", argv[i]);
+  }
+  logprintf("\n\n");
+
+  std::vector<uint8_t> is_founder;
+  load_samples(A, &is_founder);
+  const uint32_t raw_sample_ct = static_cast<uint32_t>(is_founder.size());
+  uint32_t founder_ct = 0;
+  for (uint8_t f : is_founder) {
+    founder_ct += f;
+  }
+  logprintf("%u sample%s loaded from %s (%u founder%s).\n", raw_sample_ct, raw_sample_ct == 1 ? "" : "s",
+            (A.psam.empty() ? A.fam : A.psam).c_str(), founder_ct, founder_ct == 1 ? "" : "s");
+  Variants V;
+  load_variants(A, &V);
+  const uint32_t raw_variant_ct = static_cast<uint32_t>(V.id.size());
+  logprintf("%u variant%s loaded from %s.\n", raw_variant_ct, raw_variant_ct == 1 ? "" : "s", (A.pvar.empty() ? A.bim : A.pvar).c_str());
+
+  if (founder_ct < 50 && !A.bad_ld) {  // plink2.cc:2063-2071
+    if (raw_sample_ct < 50) {
+      die(7, "Error: This run estimates linkage disequilibrium between variants, but there\nare less than 50 samples to estimate from.  You should perform this operation\non a larger dataset.\n(Strictly speaking, you can also override this error with --bad-ld, but this is\nalmost always a bad idea.)\n");
+    }
+    die(7, "Error: This run estimates linkage disequilibrium between variants, but there\nare less than 50 founders to estimate from.  --make-founders may help.\n(Strictly speaking, you can also override this error with --bad-ld, but this is\nalmost always a bad idea.)\n");
+  }
+  if (founder_ct < 2) {
+    die(7, "Error: --indep-pairwise requires at least two founders. (--make-founders may come in handy here.)\n");
+  }
+
+  // ---- genotype file
+  const bool is_bed = !A.bed.empty();
+  const std::string& gpath = is_bed ? A.bed : A.pgen;
+  const int fd = open(gpath.c_str(), O_RDONLY);
+  if (fd < 0) {
+    die(2, "Error: Failed to open %s.\n", gpath.c_str());
+  }
+  struct stat st;
+  fstat(fd, &st);
+  const uint64_t rec_bytes = (static_cast<uint64_t>(raw_sample_ct) + 3) / 4;
+  const uint8_t* fmap = static_cast<const uint8_t*>(mmap(nullptr, st.st_size, PROT_READ, MAP_PRIVATE, fd, 0));
+  if (fmap == MAP_FAILED || st.st_size < 12) {
+    die(2, "Error: Failed to map %s.\n", gpath.c_str());
+  }
+  uint64_t data_off;
+  int encoding;
+  if (fmap[0] != 0x6c || fmap[1] != 0x1b) {
+    die(3, "Error: %s is not a PLINK binary genotype file.\n", gpath.c_str());
+  }
+  if (fmap[2] == 0x01) {
+    data_off = 3;
+    encoding = LDP_GENO_BED;  // pgenlib_read.cc:767-789
+  } else if (fmap[2] == 0x02) {
+    uint32_t m, n;
+    memcpy(&m, fmap + 3, 4);
+    memcpy(&n, fmap + 7, 4);
+    if (m != raw_variant_ct || n != raw_sample_ct) {
+      die(3, "Error: %s header (%u variants, %u samples) does not match the variant/sample files.\n", gpath.c_str(), m, n);
+    }
+    data_off = 12;
+    if ((fmap[11] >> 6) == 3) {
+      data_off += (static_cast<uint64_t>(raw_variant_ct) + 7) / 8;  // nonref flags (pgenlib_read.cc:881-884)
+    }
+    encoding = LDP_GENO_REF;
+  } else {
+    die(9, "Error: %s uses .pgen storage mode 0x%02x; plink2-hip currently reads .bed (0x01) and fixed-width .pgen (0x02) only.\nConvert with `plink2 --make-pgen format=2` or `--make-bed`.\n", gpath.c_str(), fmap[2]);
+  }
+  if (static_cast<uint64_t>(st.st_size) != data_off + rec_bytes * raw_variant_ct) {
+    die(3, "Error: Unexpected %s file size (expected %llu bytes).\n", gpath.c_str(), static_cast<unsigned long long>(data_off + rec_bytes * raw_variant_ct));
+  }
+
+  // ---- variant table: strip chromosome 0, chromosome order index, sortedness, unique IDs
+  std::vector<uint32_t> inc;  // raw index of every included variant
+  std::vector<uint32_t> chr_idx, bps;
+  uint32_t skipped = 0;
+  {
+    std::unordered_set<std::string> seen_chr;
+    std::string cur;
+    uint32_t fo = 0;
+    bool first = true;
+    for (uint32_t v = 0; v < raw_variant_ct; ++v) {
+      if (first || V.chrom[v] != cur) {
+        if (!seen_chr.insert(V.chrom[v]).second) {
+          die(3, "Error: %s has a split chromosome. Use --make-pgen + --sort-vars to remedy this.\n", (A.pvar.empty() ? A.bim : A.pvar).c_str());
+        }
+        cur = V.chrom[v];
+        if (!first) {
+          ++fo;
+        }
+        first = false;
+      }
+      bool zero;
+      const int cls = chrom_class(cur, A.allow_extra_chr, &zero);
+      if (zero) {
+        ++skipped;
+        continue;
+      }
+      if (cls == 1) {
+        die(9, "Error: chromosome '%s': chrX/chrY/MT handling is not supported yet by plink2-hip.\n", cur.c_str());
+      }
+      if (cls == 2) {
+        die(3, "Error: Invalid chromosome code '%s'. (Use --allow-extra-chr to force it to be accepted.)\n", cur.c_str());
+      }
+      inc.push_back(v);
+      chr_idx.push_back(fo);
+      bps.push_back(V.bp[v]);
+    }
+  }
+  if (skipped) {
+    logprintf("--indep-pairwise: Ignoring %u chromosome 0 variant%s.\n", skipped, skipped == 1 ? "" : "s");
+  }
+  const uint32_t variant_ct = static_cast<uint32_t>(inc.size());
+  if (A.window_is_bp) {
+    for (uint32_t k = 1; k < variant_ct; ++k) {
+      if (chr_idx[k] == chr_idx[k - 1] && bps[k] < bps[k - 1]) {
+        die(3, "Error: --indep-pairwise with a kb window requires a sorted .pvar/.bim.  Retry this command after using\n--make-pgen/--make-bed + --sort-vars to sort your data.\n");
+      }
+    }
+  }
+
+  ldp_params P;
+  memset(&P, 0, sizeof(P));
+  P.founder_ct = founder_ct;
+  P.prune_window_size = A.window;
+  P.prune_window_incr = A.step;
+  P.window_is_bp = A.window_is_bp;
+  P.plink1_order = (A.order == 1);
+  P.prune_last_param = A.r2;
+  if (A.dry_run) {
+    ldp_engine* e = nullptr;
+    P.device = -1;
+    if (ldp_create(&P, &e) || ldp_set_variants(e, variant_ct, chr_idx.data(), A.window_is_bp ? bps.data() : nullptr)) {
+      die(12, "Error: planning failed.\n");
+    }
+    uint32_t sct = 0;
+    uint64_t cand = 0;
+    ldp_get_subcontigs(e, &sct, nullptr, 0);
+    ldp_get_band(e, nullptr, &cand);
+    logprintf("dry-run: founders=%u variants=%u window=%u step=%u window_is_bp=%d r2=%a order=%d subcontigs=%u candidate_pairs=%llu\n",
+              founder_ct, variant_ct, A.window, A.step, A.window_is_bp ? 1 : 0, A.r2, A.order, sct, static_cast<unsigned long long>(cand));
+    ldp_destroy(e);
+    return 0;
+  }
+  const int ndev = ldp_device_count();
+  if (ndev < 1) {
+    die(12, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
+  }
+  const int world = std::min(A.gpus, ndev);
+  std::vector<ldp_engine*> eng(world, nullptr);
+  uint32_t subcontig_ct = 0;
+  for (int r = 0; r < world; ++r) {
+    P.device = r;
+    int rc = ldp_create(&P, &eng[r]);
+    if (rc) {
+      die(12, "Error: ldp_create failed (%d).\n", rc);
+    }
+    rc = ldp_set_variants(eng[r], variant_ct, chr_idx.data(), A.window_is_bp ? bps.data() : nullptr);
+    if (rc) {
+      die(12, "Error: %s\n", ldp_last_error(eng[r]));
+    }
+    ldp_get_subcontigs(eng[r], &subcontig_ct, nullptr, 0);
+    if (world > 1) {
+      rc = ldp_set_shard(eng[r], r, world, nullptr);
+      if (rc) {
+        die(12, "Error: %s\n", ldp_last_error(eng[r]));
+      }
+    }
+  }
+  std::vector<uint64_t> removed((static_cast<size_t>(variant_ct) + 63) / 64 + 1, 0);
+  if (subcontig_ct) {
+    // unique IDs (plink2_ld.cc:2573-2592)
+    {
+      std::unordered_set<std::string> ids;
+      ids.reserve(variant_ct * 2);
+      for (uint32_t k = 0; k < variant_ct; ++k) {
+        if (!ids.insert(V.id[inc[k]]).second) {
+          die(7, "Error: --indep-pairwise requires unique variant IDs. (--set-all-var-ids and/or --rm-dup may help.)\n");
+        }
+      }
+    }
+    std::vector<uint64_t> preferred;
+    if (!A.preferred.empty()) {
+      std::unordered_set<std::string> want;
+      std::ifstream pin(A.preferred);
+      if (!pin) {
+        die(2, "Error: Failed to open %s.\n", A.preferred.c_str());
+      }
+      std::string tok;
+      while (pin >> tok) {
+        want.insert(tok);
+      }
+      preferred.assign((static_cast<size_t>(variant_ct) + 63) / 64, 0);
+      uint32_t ct = 0;
+      for (uint32_t k = 0; k < variant_ct; ++k) {
+        if (want.count(V.id[inc[k]])) {
+          preferred[k >> 6] |= 1ull << (k & 63);
+          ++ct;
+        }
+      }
+      logprintf("--indep-preferred: %u variant%s loaded.\n", ct, ct == 1 ? "" : "s");
+    }
+    logprintf("--indep-pairwise (%d GPU%s): ", world, world == 1 ? "" : "s");
+    fflush(stdout);
+
+    // ---- genotype rows of the included variants -> engines.  All-founder files go straight from the
+    // mapping; otherwise the founder columns are gathered on the host first (CopyNyparrNonemptySubset,
+    // pgenlib_misc.cc:32,185).
+    const uint8_t* rows = fmap + data_off;
+    const bool all_founders = (founder_ct == raw_sample_ct);
+    const uint64_t out_rec = (static_cast<uint64_t>(founder_ct) + 3) / 4;
+    std::vector<uint32_t> founder_idx;
+    if (!all_founders) {
+      for (uint32_t s = 0; s < raw_sample_ct; ++s) {
+        if (is_founder[s]) {
+          founder_idx.push_back(s);
+        }
+      }
+    }
+    const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((512ull << 20) / std::max<uint64_t>(out_rec, 1)));
+    std::vector<uint8_t> gather;
+    uint32_t k = 0;
+    while (k < variant_ct) {
+      // maximal run of included variants that is contiguous in the file
+      uint32_t run = 1;
+      while (k + run < variant_ct && inc[k + run] == inc[k] + run && run < kChunk) {
+        ++run;
+      }
+      const uint8_t* src = rows + static_cast<uint64_t>(inc[k]) * rec_bytes;
+      uint64_t stride = rec_bytes;
+      if (!all_founders) {
+        gather.assign(static_cast<size_t>(run) * out_rec, 0);
+        for (uint32_t q = 0; q < run; ++q) {
+          const uint8_t* in_row = src + static_cast<uint64_t>(q) * rec_bytes;
+          uint8_t* out_row = gather.data() + static_cast<uint64_t>(q) * out_rec;
+          for (uint32_t f = 0; f < founder_ct; ++f) {
+            const uint32_t s = founder_idx[f];
+            const uint32_t code = (in_row[s >> 2] >> (2 * (s & 3))) & 3;
+            out_row[f >> 2] |= code << (2 * (f & 3));
+          }
+          if (encoding == LDP_GENO_BED) {
+            // trailing pad samples would read as code 0 = hom-ALT; the kernel masks by founder_ct, nothing to do
+          }
+        }
+        src = gather.data();
+        stride = out_rec;
+      }
+      for (int r = 0; r < world; ++r) {
+        const int rc = ldp_load_genotypes(eng[r], k, run, src, stride, LDP_MEM_HOST, encoding);
+        if (rc) {
+          die(12, "Error: %s\n", ldp_last_error(eng[r]));
+        }
+      }
+      k += run;
+    }
+    std::vector<std::vector<uint64_t>> part(world, std::vector<uint64_t>(removed.size(), 0));
+    std::vector<int> rcs(world, 0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; ++r) {
+      th.emplace_back([&, r]() {
+        if (!preferred.empty()) {
+          ldp_set_preferred(eng[r], preferred.data());
+        }
+        rcs[r] = ldp_run(eng[r], part[r].data());
+      });
+    }
+    for (std::thread& t : th) {
+      t.join();
+    }
+    for (int r = 0; r < world; ++r) {
+      if (rcs[r]) {
+        die(12, "\nError: %s\n", ldp_last_error(eng[r]));
+      }
+      for (size_t w = 0; w < removed.size(); ++w) {
+        removed[w] |= part[r][w];
+      }
+    }
+  }
+  uint32_t removed_ct = 0;
+  for (uint64_t w : removed) {
+    removed_ct += static_cast<uint32_t>(__builtin_popcountll(w));
+  }
+  logprintf("%u/%u variants removed.\n", removed_ct, variant_ct);  // plink2_ld.cc:2707
+  // LdPruneWrite, plink2_ld.cc:2464-2528
+  for (int pass = 0; pass < 2; ++pass) {
+    const std::string path = A.out + (pass ? ".prune.out" : ".prune.in");
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) {
+      die(2, "Error: Failed to open %s for writing.\n", path.c_str());
+    }
+    for (uint32_t k = 0; k < variant_ct; ++k) {
+      const bool rem = (removed[k >> 6] >> (k & 63)) & 1;
+      if (rem == static_cast<bool>(pass)) {
+        fputs(V.id[inc[k]].c_str(), f);
+        fputc('\n', f);
+      }
+    }
+    if (fclose(f)) {
+      die(2, "Error: File write failure: %s.\n", path.c_str());
+    }
+  }
+  logprintf("Variant lists written to %s.prune.in and %s.prune.out .\n", A.out.c_str(), A.out.c_str());
+  for (ldp_engine* e : eng) {
+    ldp_destroy(e);
+  }
+  if (g_log) {
+    fclose(g_log);
+  }
+  return 0;
+}

@@ -1,0 +1,153 @@
+"""plink2-hip, the process-level drop-in: flag parsing and guards on CPU (no GPU needed: --dry-run stops
+after planning), byte-identical .prune.in/.prune.out against the reference binary on the GPU box."""
+import filecmp
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ldtools as T
+from test_host_logic import make_positions
+
+
+@pytest.fixture(scope="module")
+def cli(pkg):
+    path = pkg.build_cli()
+    assert path and os.path.exists(path)
+    return path
+
+
+def run_cli(cli, args, cwd):
+    return subprocess.run([cli] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+
+
+def small_fileset(tmp_path, m=120, n=60, seed=1, nonfounders=0, chr0=0):
+    raw = T.synth_raw_codes(m, n, seed, missing_rate=0.03)
+    chr_idx, bps = make_positions(m, 3, seed + 5)
+    chroms = [str(c + 1) for c in chr_idx]
+    for k in range(chr0):
+        chroms[k] = "0"
+    prefix = str(tmp_path / "d")
+    T.write_bed(prefix, raw, chroms, bps)
+    T.write_pgen_fixed(prefix, raw, chroms, bps)
+    if nonfounders:
+        lines = open(prefix + ".fam").read().splitlines()
+        for s in range(nonfounders):
+            t = lines[3 * s + 1].split()
+            t[2], t[3] = "s0", "s2"
+            lines[3 * s + 1] = " ".join(t)
+        open(prefix + ".fam", "w").write("\n".join(lines) + "\n")
+        with open(prefix + ".psam", "w") as f:
+            f.write("#IID\tPAT\tMAT\tSEX\n")
+            for s in range(n):
+                nf = (s % 3 == 1) and (s // 3 < nonfounders)
+                f.write("s%d\t%s\t%s\t2\n" % (s, "s0" if nf else "0", "s2" if nf else "0"))
+    return prefix, raw, chr_idx, bps
+
+
+def test_dry_run_parses_like_plink(cli, tmp_path):
+    prefix, raw, chr_idx, bps = small_fileset(tmp_path)
+    cp = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "200kb", "0.3", "--dry-run", "--out", "o"], str(tmp_path))
+    assert cp.returncode == 0, cp.stdout
+    line = [ln for ln in cp.stdout.splitlines() if ln.startswith("dry-run:")][0]
+    # 200kb -> 200000 bp (plink2.cc:7266); "0.3" -> 3 * 0.1 = 0.30000000000000004 (ScanadvDouble), one ulp above strtod
+    assert "window=200000 step=1 window_is_bp=1" in line
+    assert ("r2=%s" % float.hex(3 * 0.1)) in line and float.hex(3 * 0.1) != float.hex(0.3)
+    cp = run_cli(cli, ["--pfile", "d", "--indep-pairwise", "50", "5", "0.2", "--indep-order", "1", "--dry-run", "--out", "o"], str(tmp_path))
+    line = [ln for ln in cp.stdout.splitlines() if ln.startswith("dry-run:")][0]
+    assert "window=50 step=5 window_is_bp=0" in line and "order=1" in line and ("r2=%s" % float.hex(0.2)) in line
+    cp = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "0.5", "kb", "0.2", "--dry-run", "--out", "o"], str(tmp_path))
+    assert "window=500 step=1 window_is_bp=1" in cp.stdout
+
+
+@pytest.mark.parametrize("args,needle", [
+    (["--indep-pairwise", "50", "60", "0.2"], "window-increment cannot be larger than window size"),
+    (["--indep-pairwise", "50kb", "2", "0.2"], "window-increment must be 1"),
+    (["--indep-pairwise", "50", "5", "1.0"], "Invalid --indep-pairwise r^2 threshold"),
+    (["--indep-pairwise", "50"], "accepts 2-4 arguments"),
+    (["--indep-pairwise", "50", "5", "0.2", "--indep-order", "3"], "Invalid --indep-order mode"),
+    (["--glm"], "Unrecognized flag"),
+])
+def test_argument_errors(cli, tmp_path, args, needle):
+    small_fileset(tmp_path)
+    cp = run_cli(cli, ["--bfile", "d"] + args + ["--dry-run", "--out", "o"], str(tmp_path))
+    assert cp.returncode != 0 and needle in cp.stdout, cp.stdout
+
+
+def test_founder_guard_and_format_errors(cli, tmp_path):
+    small_fileset(tmp_path, n=30)
+    cp = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "50", "5", "0.2", "--dry-run", "--out", "o"], str(tmp_path))
+    assert cp.returncode != 0 and "less than 50 samples" in cp.stdout
+    cp = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "50", "5", "0.2", "--bad-ld", "--dry-run", "--out", "o"], str(tmp_path))
+    assert cp.returncode == 0
+    # wrong .bed size
+    with open(str(tmp_path / "d.bed"), "ab") as f:
+        f.write(b"\0")
+    cp = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "50", "5", "0.2", "--bad-ld", "--dry-run", "--out", "o"], str(tmp_path))
+    assert cp.returncode != 0 and "Unexpected" in cp.stdout
+    # variable-width .pgen is refused, not mis-read
+    with open(str(tmp_path / "d.pgen"), "r+b") as f:
+        f.seek(2)
+        f.write(bytes([0x10]))
+    cp = run_cli(cli, ["--pfile", "d", "--indep-pairwise", "50", "5", "0.2", "--bad-ld", "--dry-run", "--out", "o"], str(tmp_path))
+    assert cp.returncode != 0 and "storage mode 0x10" in cp.stdout
+
+
+def test_cli_refuses_to_compute_without_gpu(cli, pkg, tmp_path):
+    if pkg.device_count() > 0:
+        pytest.skip("GPU present")
+    small_fileset(tmp_path)
+    cp = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "50", "5", "0.2", "--out", "o"], str(tmp_path))
+    assert cp.returncode == 12 and "no usable HIP device" in cp.stdout
+    assert not os.path.exists(str(tmp_path / "o.prune.in"))
+
+
+CLI_CASES = [
+    # fmt, window args, r2, order, nonfounders, chr0, preferred
+    ("bfile", ["50", "5"], "0.2", 2, 0, 0, False),
+    ("pfile", ["50", "5"], "0.2", 1, 0, 0, False),
+    ("bfile", ["20kb"], "0.5", 2, 0, 3, False),
+    ("pfile", ["20kb"], "0.3", 2, 7, 0, False),
+    ("bfile", ["30", "kb"], "0.1", 1, 5, 2, False),
+    ("pfile", ["100", "10"], "0.4", 2, 0, 0, True),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CLI_CASES)
+def test_cli_byte_identical_to_reference(gpu_pkg, cli, tmp_path, case):
+    fmt, wargs, r2, order, nonfounders, chr0, preferred = case
+    assert T.have_ref(), "reference binary oracle/_ref/plink2 must travel with the repo snapshot"
+    prefix, raw, chr_idx, bps = small_fileset(tmp_path, m=900, n=120, seed=len(wargs) + order + nonfounders, nonfounders=nonfounders, chr0=chr0)
+    common = ["--" + fmt, "d", "--indep-pairwise"] + wargs + [r2]
+    if order == 1:
+        common += ["--indep-order", "1"]
+    if preferred:
+        with open(str(tmp_path / "pref.txt"), "w") as f:
+            f.write("\n".join("snp%d" % i for i in range(0, 900, 7)) + "\n")
+        common += ["--indep-preferred", "pref.txt"]
+    ref = T.run_ref(common + ["--threads", "4", "--out", "ref"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    got = run_cli(cli, common + ["--out", "hip"], str(tmp_path))
+    assert got.returncode == 0, got.stdout
+    assert filecmp.cmp(str(tmp_path / "ref.prune.in"), str(tmp_path / "hip.prune.in"), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "ref.prune.out"), str(tmp_path / "hip.prune.out"), shallow=False)
+    want = [ln for ln in ref.stdout.splitlines() if "variants removed." in ln][-1].split(":")[-1].split("%")[-1].strip()
+    assert want in got.stdout  # "<k>/<n> variants removed."
+
+
+@pytest.mark.gpu
+def test_cli_config1_toy(gpu_pkg, cli, tmp_path):
+    """BASELINE config 1 (1.9/toy.ped -> .bed; 2 samples x 2 variants): rs0 is monomorphic and goes to .prune.out."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "toy_50_5_0.2.npz"))
+    m, n = int(z["m"]), int(z["n"])
+    raw = T.unpack_2bit(z["raw_packed"].reshape(m, -1).view(np.uint64), n)
+    T.write_bed(str(tmp_path / "toy"), raw, [str(c) for c in z["chroms"]], z["bps"], ids=["rs0", "rs10"])
+    cp = run_cli(cli, ["--bfile", "toy", "--indep-pairwise", "50", "5", "0.2", "--out", "o"], str(tmp_path))
+    assert cp.returncode != 0 and "less than 50 samples" in cp.stdout
+    cp = run_cli(cli, ["--bfile", "toy", "--indep-pairwise", "50", "5", "0.2", "--bad-ld", "--out", "o"], str(tmp_path))
+    assert cp.returncode == 0, cp.stdout
+    assert "1/2 variants removed." in cp.stdout
+    assert open(str(tmp_path / "o.prune.in")).read() == "rs10\n"
+    assert open(str(tmp_path / "o.prune.out")).read() == "rs0\n"
