@@ -108,7 +108,18 @@ def cpu_baseline(pkg, torch, args, founder_ct, spacing, window_bp, r2):
         removed_ids = set(ln.strip() for ln in open(os.path.join(tmp, "ref.prune.out")) if ln.strip())
         removed_ref = np.array([("snp%d" % i) in removed_ids for i in range(m)])
         threads_line = [ln for ln in cp.stdout.splitlines() if "compute thread" in ln]
-        return {"value": cand / wall, "unit": "variant-pairs/s", "cores": cores, "kind": "reference",
+        cli = {}
+        cli_bin = os.path.join(REPO, "plink-ng_amd", "bin", "plink2-hip")
+        if args.cli_compare and os.path.exists(cli_bin):
+            # the process-level drop-in on the same files (file mapping + H2D + kernels + replay + writer)
+            t1 = time.perf_counter()
+            cc = subprocess.run([cli_bin, "--bfile", "sample", "--indep-pairwise", "%gkb" % (window_bp / 1000.0), repr(r2), "--out", "hip"],
+                                cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+            cli_wall = time.perf_counter() - t1
+            same = (cc.returncode == 0 and open(os.path.join(tmp, "hip.prune.out")).read() == open(os.path.join(tmp, "ref.prune.out")).read()
+                    and open(os.path.join(tmp, "hip.prune.in")).read() == open(os.path.join(tmp, "ref.prune.in")).read())
+            cli = {"plink2_hip_wall_s": cli_wall, "plink2_hip_files_identical": bool(same), "plink2_hip_rc": cc.returncode}
+        return {**cli, "value": cand / wall, "unit": "variant-pairs/s", "cores": cores, "kind": "reference",
                 "sample": "%d variants x %d samples of the same generator (22 chromosomes, %d bp spacing, %d candidate pairs), "
                           "reference plink2 AVX2 end-to-end wall %.2f s incl. file load + freq pass; %s" %
                           (m, founder_ct, spacing, cand, wall, (threads_line[-1].split(":")[0].strip() if threads_line else "")),
@@ -131,6 +142,7 @@ def main():
     ap.add_argument("--spacing", type=int, default=2875, help="bp between consecutive variants")
     ap.add_argument("--cpu-sample-variants", type=int, default=440000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cli-compare", action="store_true", help="also time plink2-hip end-to-end on the CPU-baseline sample files")
     args = ap.parse_args()
 
     import torch

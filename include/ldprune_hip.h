@@ -165,6 +165,23 @@ int ldp_get_maj_freqs(ldp_engine* e, uint32_t first_variant, uint32_t n, double*
 int ldp_get_planes(ldp_engine* e, uint32_t variant, uint32_t* hom, uint32_t* ref2het);
 int ldp_get_counters(const ldp_engine* e, ldp_counters* out);
 
+/* ---- genotype file reader (host-side I/O edge; no GPU involved) ---- */
+/* Main-track reader for PLINK binary genotype files: .bed (storage mode 0x01), fixed-width .pgen (0x02) and
+ * standard variable-width .pgen (0x10: raw / one-bit / LD-compressed / difflist records).  Replaces, for this
+ * path, PgfiInitPhase1/2 + PgrInit + ReadGenovecSubsetUnsafe (pgenlib_read.cc:691,1101,2044,2849).  Rows come
+ * out as 2-bit codes, ceil(sample_ct/4) bytes each, in the encoding ldp_pgen_info reports (LDP_GENO_BED for
+ * .bed, LDP_GENO_REF otherwise), ready for ldp_load_genotypes().  sample_ct_hint/variant_ct_hint: required
+ * for .bed (dimensions live in .fam/.bim), cross-checked against the header otherwise (0 = no check). */
+typedef struct ldp_pgen ldp_pgen;
+int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct_hint, ldp_pgen** out);
+int ldp_pgen_info(const ldp_pgen* p, uint32_t* variant_ct, uint32_t* sample_ct, int* storage_mode, int* row_encoding, int* has_multiallelic);
+/* fixed-width modes only: pointer to row 0 inside the file mapping (zero-copy), NULL for variable-width files */
+const void* ldp_pgen_direct_rows(const ldp_pgen* p, uint64_t* stride_bytes);
+/* decode rows [first_variant, first_variant+n) into out_rows; 64k-variant blocks decode on up to `threads` host threads (0 = all) */
+int ldp_pgen_read(ldp_pgen* p, uint32_t first_variant, uint32_t n, void* out_rows, uint64_t stride_bytes, uint32_t threads);
+const char* ldp_pgen_last_error(const ldp_pgen* p);
+void ldp_pgen_close(ldp_pgen* p);
+
 /* ---- synthetic workload (benchmark / test support, not part of the reference seam) ---- */
 /* Deterministic genotype generator for the SURVEY.md 8(d) workload: rows [first_variant, +n_variants) of
  * REF-based codes (LDP_GENO_REF) written to `out` (host or device memory), each genotype a pure function of

@@ -76,11 +76,12 @@ CABI_SYMBOLS = [
     "ldp_set_shard", "ldp_get_band", "ldp_load_genotypes", "ldp_set_maj_freqs", "ldp_set_preferred", "ldp_run",
     "ldp_run_with_stats", "ldp_pair_stats", "ldp_debug_set_variant_recs", "ldp_debug_replay_pairs",
     "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
+    "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
 ]
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_synth.hip", "ldp_engine.cpp")]
+    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_synth.hip", "ldp_engine.cpp", "ldp_pgen.cpp")]
 
 
 def _stale(target, deps):
@@ -162,6 +163,15 @@ def lib():
     L.ldp_get_counters.argtypes = [vp, ctypes.POINTER(ldp_counters)]
     L.ldp_synth_genotypes.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, vp,
                                       ctypes.c_uint64, ctypes.c_int, vp]
+    L.ldp_pgen_open.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp)]
+    L.ldp_pgen_info.argtypes = [vp, u32p, u32p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    L.ldp_pgen_direct_rows.argtypes = [vp, u64p]
+    L.ldp_pgen_direct_rows.restype = ctypes.c_void_p
+    L.ldp_pgen_read.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.c_uint32]
+    L.ldp_pgen_last_error.argtypes = [vp]
+    L.ldp_pgen_last_error.restype = ctypes.c_char_p
+    L.ldp_pgen_close.argtypes = [vp]
+    L.ldp_pgen_close.restype = None
     _lib = L
     return L
 
@@ -185,6 +195,42 @@ def synth_genotypes_device(seed, first_variant, n_variants, founder_ct, missing_
                                    LDP_MEM_DEVICE, ctypes.c_void_p(stream) if stream else None)
     if rc != LDP_OK:
         raise LdpError(rc, "ldp_synth_genotypes failed")
+
+
+class PgenFile:
+    """ctypes mirror of the ldp_pgen_* reader (main track of .bed / .pgen files)."""
+
+    def __init__(self, path, sample_ct_hint=0, variant_ct_hint=0):
+        self._L = lib()
+        self._h = ctypes.c_void_p()
+        rc = self._L.ldp_pgen_open(path.encode(), sample_ct_hint, variant_ct_hint, ctypes.byref(self._h))
+        if rc != LDP_OK:
+            msg = self._L.ldp_pgen_last_error(self._h).decode() if self._h else "open failed"
+            self.close()
+            raise LdpError(rc, msg)
+        m, n = ctypes.c_uint32(), ctypes.c_uint32()
+        mode, enc, multi = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self._L.ldp_pgen_info(self._h, ctypes.byref(m), ctypes.byref(n), ctypes.byref(mode), ctypes.byref(enc), ctypes.byref(multi))
+        self.variant_ct, self.sample_ct, self.mode, self.encoding, self.has_multiallelic = m.value, n.value, mode.value, enc.value, bool(multi.value)
+
+    def read(self, first=0, n=None, threads=0):
+        n = self.variant_ct - first if n is None else n
+        out = np.zeros((n, (self.sample_ct + 3) // 4), dtype=np.uint8)
+        rc = self._L.ldp_pgen_read(self._h, first, n, out.ctypes.data_as(ctypes.c_void_p), out.strides[0] if n else 1, threads)
+        if rc != LDP_OK:
+            raise LdpError(rc, self._L.ldp_pgen_last_error(self._h).decode())
+        return out
+
+    def close(self):
+        if self._h:
+            self._L.ldp_pgen_close(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _u32(a):

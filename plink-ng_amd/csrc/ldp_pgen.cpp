@@ -1,0 +1,453 @@
+// ldp_pgen.cpp -- from-scratch reader for the genotype main track of PLINK binary files: .bed (storage
+// mode 0x01), fixed-width .pgen (0x02) and standard variable-width .pgen (0x10).  Host-side I/O edge of the
+// --indep-pairwise path: it produces the 2-bit rows ldp_load_genotypes() consumes (what
+// ReadGenovecSubsetUnsafe, 2.0/include/pgenlib_read.cc:2849-2912, produces before sample subsetting).
+//
+// Written from the format specification (pgen_spec/pgen_spec.tex:87-235 header, :321-467 difflists and main
+// track record types) and checked against files the reference binary writes.  Only the main track is decoded;
+// phase/dosage/multiallelic auxiliary tracks that may follow it inside a record are skipped.  Variable-width
+// records inside one 65,536-variant block are decoded in order (LD-compressed records patch the most recent
+// non-LD record of the same block, pgenlib_read.cc:1848 GetLdbaseVidx); blocks decode concurrently.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/ldprune_hip.h"
+
+struct ldp_pgen {
+  std::string err;
+  int fd = -1;
+  const uint8_t* map = nullptr;
+  uint64_t size = 0;
+  int mode = 0;
+  uint32_t variant_ct = 0;
+  uint32_t sample_ct = 0;
+  uint64_t rec_bytes = 0;       // ceil(sample_ct / 4)
+  uint64_t data_off = 0;        // fixed-width modes
+  // variable-width index
+  std::vector<uint8_t> vrtype;  // per variant
+  std::vector<uint64_t> fpos;   // variant_ct + 1 record offsets
+  bool any_multiallelic = false;
+};
+
+namespace {
+
+constexpr uint32_t kBlockVariants = 65536;
+
+int pfail(ldp_pgen* p, int code, const std::string& msg) {
+  p->err = msg;
+  return code;
+}
+
+struct Cursor {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool ok = true;
+  uint32_t varint() {
+    uint32_t v = 0;
+    for (int shift = 0; shift < 35; shift += 7) {
+      if (p >= end) {
+        ok = false;
+        return 0;
+      }
+      const uint8_t b = *p++;
+      v |= static_cast<uint32_t>(b & 0x7f) << shift;
+      if (!(b & 0x80)) {
+        return v;
+      }
+    }
+    ok = false;
+    return 0;
+  }
+  bool skip(uint64_t n) {
+    if (static_cast<uint64_t>(end - p) < n) {
+      ok = false;
+      return false;
+    }
+    p += n;
+    return true;
+  }
+};
+
+inline void set_code(uint8_t* row, uint32_t s, uint32_t code) {
+  uint8_t& b = row[s >> 2];
+  const uint32_t sh = 2 * (s & 3);
+  b = static_cast<uint8_t>((b & ~(3u << sh)) | (code << sh));
+}
+
+// Difflist (pgen_spec.tex:367-430) of (sample id, 2-bit value) pairs applied onto `row`.
+bool apply_difflist(Cursor& c, uint32_t sample_ct, uint8_t* row) {
+  const uint32_t L = c.varint();
+  if (!c.ok) {
+    return false;
+  }
+  if (!L) {
+    return true;
+  }
+  if (L > sample_ct) {
+    return false;
+  }
+  const uint32_t G = (L + 63) / 64;
+  const uint32_t idw = (sample_ct <= 256) ? 1 : ((sample_ct <= 65536) ? 2 : ((sample_ct <= 16777216) ? 3 : 4));
+  const uint8_t* first_ids = c.p;
+  if (!c.skip(static_cast<uint64_t>(G) * idw)) {
+    return false;
+  }
+  if (!c.skip(G - 1)) {  // group byte sizes: only needed for random access
+    return false;
+  }
+  const uint8_t* vals = c.p;
+  if (!c.skip((L + 3) / 4)) {
+    return false;
+  }
+  for (uint32_t g = 0; g < G; ++g) {
+    uint32_t id = 0;
+    memcpy(&id, first_ids + static_cast<uint64_t>(g) * idw, idw);
+    const uint32_t kend = std::min(L, (g + 1) * 64);
+    for (uint32_t k = g * 64; k < kend; ++k) {
+      if (k != g * 64) {
+        id += c.varint();
+        if (!c.ok) {
+          return false;
+        }
+      }
+      if (id >= sample_ct) {
+        return false;
+      }
+      set_code(row, id, (vals[k >> 2] >> (2 * (k & 3))) & 3);
+    }
+  }
+  return true;
+}
+
+// 0 <-> 2 (GenovecInvertUnsafe semantics) over a whole row
+inline void invert_row(uint8_t* row, uint64_t nbytes) {
+  for (uint64_t b = 0; b < nbytes; ++b) {
+    const uint8_t g = row[b];
+    row[b] = static_cast<uint8_t>(g ^ ((~g << 1) & 0xaa));
+  }
+}
+
+// Decode one main-track record into `row` (rec_bytes, trailing bits zero).  ldbase = most recent non-LD row.
+bool decode_record(const ldp_pgen* P, uint32_t v, const uint8_t* ldbase, uint8_t* row) {
+  const uint32_t type = P->vrtype[v] & 7;
+  Cursor c{P->map + P->fpos[v], P->map + P->fpos[v + 1]};
+  const uint64_t nb = P->rec_bytes;
+  const uint32_t n = P->sample_ct;
+  switch (type) {
+    case 0:
+      if (static_cast<uint64_t>(c.end - c.p) < nb) {
+        return false;
+      }
+      memcpy(row, c.p, nb);
+      break;
+    case 1: {
+      // one-bit representation: byte = low*4 + (high-low); bit set -> high category; then exceptions
+      if (c.p >= c.end) {
+        return false;
+      }
+      const uint32_t code = *c.p++;
+      const uint32_t low = code >> 2;
+      const uint32_t high = low + (code & 3);
+      if (high > 3 || high == low) {
+        return false;
+      }
+      const uint64_t bit_bytes = (static_cast<uint64_t>(n) + 7) / 8;
+      if (static_cast<uint64_t>(c.end - c.p) < bit_bytes) {
+        return false;
+      }
+      const uint8_t* bits = c.p;
+      c.p += bit_bytes;
+      // expand 4 samples (4 bits) -> one output byte
+      uint8_t lut[16];
+      for (uint32_t q = 0; q < 16; ++q) {
+        uint32_t o = 0;
+        for (uint32_t k = 0; k < 4; ++k) {
+          o |= (((q >> k) & 1) ? high : low) << (2 * k);
+        }
+        lut[q] = static_cast<uint8_t>(o);
+      }
+      for (uint64_t b = 0; b < nb; ++b) {
+        const uint8_t src = bits[b >> 1];
+        row[b] = lut[(b & 1) ? (src >> 4) : (src & 15)];
+      }
+      if (!apply_difflist(c, n, row)) {
+        return false;
+      }
+      break;
+    }
+    case 2:
+    case 3:
+      if (!ldbase) {
+        return false;
+      }
+      memcpy(row, ldbase, nb);
+      if (!apply_difflist(c, n, row)) {
+        return false;
+      }
+      if (type == 3) {
+        invert_row(row, nb);
+      }
+      break;
+    case 4:
+    case 6:
+    case 7: {
+      const uint32_t fill = (type == 4) ? 0 : ((type == 6) ? 2 : 3);
+      memset(row, static_cast<int>(fill * 0x55), nb);
+      if (!apply_difflist(c, n, row)) {
+        return false;
+      }
+      break;
+    }
+    default:  // 5: reserved; the reference decodes it as all hom-REF (pgenlib_read.cc:2740-2742)
+      memset(row, 0, nb);
+      break;
+  }
+  const uint32_t rem = n & 3;
+  if (rem) {
+    row[nb - 1] &= static_cast<uint8_t>((1u << (2 * rem)) - 1);
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct_hint, ldp_pgen** out) {
+  if (!path || !out) {
+    return LDP_ERR_INVALID;
+  }
+  ldp_pgen* P = new (std::nothrow) ldp_pgen();
+  if (!P) {
+    return LDP_ERR_NOMEM;
+  }
+  *out = P;
+  P->fd = open(path, O_RDONLY);
+  if (P->fd < 0) {
+    return pfail(P, LDP_ERR_INVALID, std::string("Failed to open ") + path + ".");
+  }
+  struct stat st;
+  if (fstat(P->fd, &st) || st.st_size < 3) {
+    return pfail(P, LDP_ERR_INVALID, std::string(path) + " is too small to be a PLINK genotype file.");
+  }
+  P->size = static_cast<uint64_t>(st.st_size);
+  void* m = mmap(nullptr, P->size, PROT_READ, MAP_PRIVATE, P->fd, 0);
+  if (m == MAP_FAILED) {
+    return pfail(P, LDP_ERR_NOMEM, std::string("Failed to map ") + path + ".");
+  }
+  P->map = static_cast<const uint8_t*>(m);
+  if (P->map[0] != 0x6c || P->map[1] != 0x1b) {
+    return pfail(P, LDP_ERR_INVALID, std::string(path) + " is not a PLINK binary genotype file.");
+  }
+  P->mode = P->map[2];
+  if (P->mode == 0x01) {
+    // PLINK 1 variant-major .bed: dimensions come from .fam/.bim (pgenlib_read.cc:767-789)
+    P->sample_ct = sample_ct_hint;
+    P->variant_ct = variant_ct_hint;
+    P->rec_bytes = (static_cast<uint64_t>(P->sample_ct) + 3) / 4;
+    P->data_off = 3;
+    if (P->size != 3 + P->rec_bytes * P->variant_ct) {
+      return pfail(P, LDP_ERR_INVALID, "Unexpected .bed file size (expected " + std::to_string(3 + P->rec_bytes * P->variant_ct) + " bytes).");
+    }
+    return LDP_OK;
+  }
+  if (P->size < 12) {
+    return pfail(P, LDP_ERR_INVALID, std::string(path) + " is too small to be a .pgen file.");
+  }
+  memcpy(&P->variant_ct, P->map + 3, 4);
+  memcpy(&P->sample_ct, P->map + 7, 4);
+  if ((sample_ct_hint && sample_ct_hint != P->sample_ct) || (variant_ct_hint && variant_ct_hint != P->variant_ct)) {
+    return pfail(P, LDP_ERR_INVALID, ".pgen header (" + std::to_string(P->variant_ct) + " variants, " + std::to_string(P->sample_ct) +
+                                         " samples) does not match the variant/sample files.");
+  }
+  P->rec_bytes = (static_cast<uint64_t>(P->sample_ct) + 3) / 4;
+  const uint8_t ctrl = P->map[11];
+  const uint32_t nonref_storage = ctrl >> 6;
+  if (P->mode == 0x02) {
+    if (ctrl & 63) {
+      return pfail(P, LDP_ERR_INVALID, "fixed-width .pgen with a variable-width control byte.");
+    }
+    P->data_off = 12 + ((nonref_storage == 3) ? (static_cast<uint64_t>(P->variant_ct) + 7) / 8 : 0);
+    if (P->size != P->data_off + P->rec_bytes * P->variant_ct) {
+      return pfail(P, LDP_ERR_INVALID, "Unexpected .pgen file size (expected " + std::to_string(P->data_off + P->rec_bytes * P->variant_ct) + " bytes).");
+    }
+    return LDP_OK;
+  }
+  if (P->mode != 0x10) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), ".pgen storage mode 0x%02x is not supported (supported: 0x01 .bed, 0x02 fixed-width, 0x10 standard).", P->mode);
+    return pfail(P, LDP_ERR_UNSUPPORTED, buf);
+  }
+  // ---- standard variable-width header (pgen_spec.tex:160-235)
+  const uint32_t tl = ctrl & 15;
+  if (tl > 7) {
+    return pfail(P, LDP_ERR_UNSUPPORTED, "reserved record-type/length storage (control bits 0-3 > 7).");
+  }
+  const uint32_t type_bits = (tl < 4) ? 4 : 8;
+  const uint32_t len_bytes = (tl & 3) + 1;
+  const uint32_t ac_bytes = (ctrl >> 4) & 3;
+  const uint32_t M = P->variant_ct;
+  const uint32_t B = (M + kBlockVariants - 1) / kBlockVariants;
+  uint64_t pos = 12 + 8ull * B;
+  if (pos > P->size) {
+    return pfail(P, LDP_ERR_INVALID, "truncated .pgen header.");
+  }
+  P->vrtype.resize(M);
+  P->fpos.resize(static_cast<size_t>(M) + 1);
+  for (uint32_t b = 0; b < B; ++b) {
+    const uint32_t cnt = std::min(kBlockVariants, M - b * kBlockVariants);
+    uint64_t block_off;
+    memcpy(&block_off, P->map + 12 + 8ull * b, 8);
+    const uint64_t types_bytes = (type_bits == 4) ? (cnt + 1) / 2 : cnt;
+    const uint64_t need = types_bytes + static_cast<uint64_t>(cnt) * len_bytes + static_cast<uint64_t>(cnt) * ac_bytes +
+                          ((nonref_storage == 3) ? (cnt + 7) / 8 : 0);
+    if (pos + need > P->size) {
+      return pfail(P, LDP_ERR_INVALID, "truncated .pgen header.");
+    }
+    const uint8_t* types = P->map + pos;
+    const uint8_t* lens = types + types_bytes;
+    uint64_t rec = block_off;
+    for (uint32_t k = 0; k < cnt; ++k) {
+      const uint32_t v = b * kBlockVariants + k;
+      const uint8_t t = (type_bits == 4) ? ((types[k >> 1] >> (4 * (k & 1))) & 15) : types[k];
+      P->vrtype[v] = t;
+      if (t & 8) {
+        P->any_multiallelic = true;
+      }
+      uint32_t len = 0;
+      memcpy(&len, lens + static_cast<uint64_t>(k) * len_bytes, len_bytes);
+      P->fpos[v] = rec;
+      rec += len;
+    }
+    if (rec > P->size) {
+      return pfail(P, LDP_ERR_INVALID, "variant records run past the end of the .pgen file.");
+    }
+    if (b + 1 == B) {
+      P->fpos[M] = rec;
+    }
+    pos += need;
+  }
+  if (!M) {
+    P->fpos[0] = pos;
+  }
+  return LDP_OK;
+}
+
+int ldp_pgen_info(const ldp_pgen* P, uint32_t* variant_ct, uint32_t* sample_ct, int* storage_mode, int* row_encoding, int* has_multiallelic) {
+  if (!P) {
+    return LDP_ERR_INVALID;
+  }
+  if (variant_ct) *variant_ct = P->variant_ct;
+  if (sample_ct) *sample_ct = P->sample_ct;
+  if (storage_mode) *storage_mode = P->mode;
+  if (row_encoding) *row_encoding = (P->mode == 0x01) ? LDP_GENO_BED : LDP_GENO_REF;
+  if (has_multiallelic) *has_multiallelic = P->any_multiallelic ? 1 : 0;
+  return LDP_OK;
+}
+
+const void* ldp_pgen_direct_rows(const ldp_pgen* P, uint64_t* stride_bytes) {
+  if (!P || (P->mode != 0x01 && P->mode != 0x02)) {
+    return nullptr;
+  }
+  if (stride_bytes) {
+    *stride_bytes = P->rec_bytes;
+  }
+  return P->map + P->data_off;
+}
+
+int ldp_pgen_read(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_rows, uint64_t stride_bytes, uint32_t threads) {
+  if (!P || (n && !out_rows)) {
+    return LDP_ERR_INVALID;
+  }
+  if ((static_cast<uint64_t>(first_variant) + n > P->variant_ct) || (stride_bytes < P->rec_bytes)) {
+    return pfail(P, LDP_ERR_INVALID, "variant range / stride out of bounds");
+  }
+  uint8_t* out = static_cast<uint8_t*>(out_rows);
+  if (P->mode == 0x01 || P->mode == 0x02) {
+    for (uint32_t k = 0; k < n; ++k) {
+      memcpy(out + k * stride_bytes, P->map + P->data_off + (static_cast<uint64_t>(first_variant) + k) * P->rec_bytes, P->rec_bytes);
+    }
+    return LDP_OK;
+  }
+  if (!n) {
+    return LDP_OK;
+  }
+  // one task per 65,536-variant block touched; inside a block walk forward from the block start or the
+  // nearest non-LD record at or before first_variant
+  const uint32_t b0 = first_variant / kBlockVariants;
+  const uint32_t b1 = (first_variant + n - 1) / kBlockVariants;
+  std::atomic<uint32_t> next(b0);
+  std::atomic<int> bad(0);
+  auto worker = [&]() {
+    std::vector<uint8_t> ldbase(P->rec_bytes), scratch(P->rec_bytes);
+    for (uint32_t b = next.fetch_add(1); b <= b1; b = next.fetch_add(1)) {
+      const uint32_t blk_first = b * kBlockVariants;
+      const uint32_t want_first = std::max(first_variant, blk_first);
+      const uint32_t want_end = std::min(first_variant + n, std::min(P->variant_ct, blk_first + kBlockVariants));
+      // the LD base of the first wanted record: latest non-LD record at or before it
+      uint32_t start = want_first;
+      while (start > blk_first && ((P->vrtype[start] & 6) == 2)) {
+        --start;
+      }
+      bool have_base = false;
+      for (uint32_t v = start; v < want_end; ++v) {
+        const bool is_ld = ((P->vrtype[v] & 6) == 2);
+        if (v < want_first && is_ld) {
+          continue;  // only the base row matters before the wanted range
+        }
+        uint8_t* dst = (v >= want_first) ? (out + static_cast<uint64_t>(v - first_variant) * stride_bytes) : scratch.data();
+        if (!decode_record(P, v, have_base ? ldbase.data() : nullptr, dst)) {
+          bad.store(1);
+          return;
+        }
+        if (!is_ld) {
+          memcpy(ldbase.data(), dst, P->rec_bytes);
+          have_base = true;
+        }
+      }
+    }
+  };
+  uint32_t nt = std::max(1u, std::min({threads ? threads : std::thread::hardware_concurrency(), b1 - b0 + 1, 64u}));
+  if (nt == 1) {
+    worker();
+  } else {
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < nt; ++t) {
+      pool.emplace_back(worker);
+    }
+    for (std::thread& t : pool) {
+      t.join();
+    }
+  }
+  if (bad.load()) {
+    return pfail(P, LDP_ERR_INVALID, "malformed variant record in .pgen file");
+  }
+  return LDP_OK;
+}
+
+const char* ldp_pgen_last_error(const ldp_pgen* P) { return P ? P->err.c_str() : "null reader"; }
+
+void ldp_pgen_close(ldp_pgen* P) {
+  if (!P) {
+    return;
+  }
+  if (P->map) {
+    munmap(const_cast<uint8_t*>(P->map), P->size);
+  }
+  if (P->fd >= 0) {
+    close(P->fd);
+  }
+  delete P;
+}
+
+}  // extern "C"

@@ -1,7 +1,7 @@
 // plink2_hip_cli.cpp -- `plink2-hip`: process-level drop-in for the --indep-pairwise path of plink2.
 //
 // Same flag spellings (2.0/plink2.cc:7238-7337, 2.0/plink2_help.cc:948-969), same inputs
-// (.bed/.bim/.fam, fixed-width .pgen/.pvar/.psam) and byte-identical <out>.prune.in / <out>.prune.out
+// (.bed/.bim/.fam, fixed- and variable-width .pgen/.pvar/.psam) and byte-identical <out>.prune.in / <out>.prune.out
 // (LdPruneWrite, 2.0/plink2_ld.cc:2464-2528).  Everything between "files are open" and "bitmap of removed
 // variants" goes through the C ABI in include/ldprune_hip.h, i.e. through the HIP kernels; there is no CPU
 // compute path here, so without a usable GPU the program exits with an error.
@@ -11,8 +11,8 @@
 // (2.0/plink2_psam.cc:804-813), .bim/.pvar parsing, chromosome-0 stripping (StripUnplacedK,
 // plink2_ld.cc:113-164), the sorted-positions and unique-ID checks (plink2.cc:2926, plink2_ld.cc:2573-2592),
 // the <50-founders guard (plink2.cc:2063-2071) and the output writer.
-// Not yet supported (reported as such, never silently mis-handled): variable-width .pgen (mode 0x10),
-// chrX/chrY/MT/haploid contigs, .pvar.zst, multiallelic variants.
+// Not yet supported (reported as such, never silently mis-handled): chrX/chrY/MT/haploid contigs, .pvar.zst,
+// multiallelic variants, external-index .pgen (modes 0x20/0x21).
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <fcntl.h>
@@ -504,46 +504,20 @@ int main(int argc, char** argv) {
     die(7, "Error: --indep-pairwise requires at least two founders. (--make-founders may come in handy here.)\n");
   }
 
-  // ---- genotype file
+  // ---- genotype file (.bed / fixed-width .pgen / standard variable-width .pgen)
   const bool is_bed = !A.bed.empty();
   const std::string& gpath = is_bed ? A.bed : A.pgen;
-  const int fd = open(gpath.c_str(), O_RDONLY);
-  if (fd < 0) {
-    die(2, "Error: Failed to open %s.\n", gpath.c_str());
+  ldp_pgen* pg = nullptr;
+  if (ldp_pgen_open(gpath.c_str(), raw_sample_ct, raw_variant_ct, &pg)) {
+    die(3, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
   }
-  struct stat st;
-  fstat(fd, &st);
-  const uint64_t rec_bytes = (static_cast<uint64_t>(raw_sample_ct) + 3) / 4;
-  const uint8_t* fmap = static_cast<const uint8_t*>(mmap(nullptr, st.st_size, PROT_READ, MAP_PRIVATE, fd, 0));
-  if (fmap == MAP_FAILED || st.st_size < 12) {
-    die(2, "Error: Failed to map %s.\n", gpath.c_str());
+  int storage_mode = 0, encoding = LDP_GENO_REF, has_multiallelic = 0;
+  ldp_pgen_info(pg, nullptr, nullptr, &storage_mode, &encoding, &has_multiallelic);
+  if (has_multiallelic) {
+    die(9, "Error: %s contains multiallelic records, which plink2-hip does not support yet.\n", gpath.c_str());
   }
-  uint64_t data_off;
-  int encoding;
-  if (fmap[0] != 0x6c || fmap[1] != 0x1b) {
-    die(3, "Error: %s is not a PLINK binary genotype file.\n", gpath.c_str());
-  }
-  if (fmap[2] == 0x01) {
-    data_off = 3;
-    encoding = LDP_GENO_BED;  // pgenlib_read.cc:767-789
-  } else if (fmap[2] == 0x02) {
-    uint32_t m, n;
-    memcpy(&m, fmap + 3, 4);
-    memcpy(&n, fmap + 7, 4);
-    if (m != raw_variant_ct || n != raw_sample_ct) {
-      die(3, "Error: %s header (%u variants, %u samples) does not match the variant/sample files.\n", gpath.c_str(), m, n);
-    }
-    data_off = 12;
-    if ((fmap[11] >> 6) == 3) {
-      data_off += (static_cast<uint64_t>(raw_variant_ct) + 7) / 8;  // nonref flags (pgenlib_read.cc:881-884)
-    }
-    encoding = LDP_GENO_REF;
-  } else {
-    die(9, "Error: %s uses .pgen storage mode 0x%02x; plink2-hip currently reads .bed (0x01) and fixed-width .pgen (0x02) only.\nConvert with `plink2 --make-pgen format=2` or `--make-bed`.\n", gpath.c_str(), fmap[2]);
-  }
-  if (static_cast<uint64_t>(st.st_size) != data_off + rec_bytes * raw_variant_ct) {
-    die(3, "Error: Unexpected %s file size (expected %llu bytes).\n", gpath.c_str(), static_cast<unsigned long long>(data_off + rec_bytes * raw_variant_ct));
-  }
+  uint64_t rec_bytes = (static_cast<uint64_t>(raw_sample_ct) + 3) / 4;
+  const uint8_t* direct_rows = static_cast<const uint8_t*>(ldp_pgen_direct_rows(pg, &rec_bytes));  // NULL for variable-width
 
   // ---- variant table: strip chromosome 0, chromosome order index, sortedness, unique IDs
   std::vector<uint32_t> inc;  // raw index of every included variant
@@ -681,7 +655,6 @@ int main(int argc, char** argv) {
     // ---- genotype rows of the included variants -> engines.  All-founder files go straight from the
     // mapping; otherwise the founder columns are gathered on the host first (CopyNyparrNonemptySubset,
     // pgenlib_misc.cc:32,185).
-    const uint8_t* rows = fmap + data_off;
     const bool all_founders = (founder_ct == raw_sample_ct);
     const uint64_t out_rec = (static_cast<uint64_t>(founder_ct) + 3) / 4;
     std::vector<uint32_t> founder_idx;
@@ -692,8 +665,8 @@ int main(int argc, char** argv) {
         }
       }
     }
-    const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((512ull << 20) / std::max<uint64_t>(out_rec, 1)));
-    std::vector<uint8_t> gather;
+    const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((1024ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
+    std::vector<uint8_t> decoded, gather;
     uint32_t k = 0;
     while (k < variant_ct) {
       // maximal run of included variants that is contiguous in the file
@@ -701,20 +674,27 @@ int main(int argc, char** argv) {
       while (k + run < variant_ct && inc[k + run] == inc[k] + run && run < kChunk) {
         ++run;
       }
-      const uint8_t* src = rows + static_cast<uint64_t>(inc[k]) * rec_bytes;
+      const uint8_t* src;
       uint64_t stride = rec_bytes;
+      if (direct_rows) {
+        src = direct_rows + static_cast<uint64_t>(inc[k]) * rec_bytes;
+      } else {
+        decoded.resize(static_cast<size_t>(run) * rec_bytes);
+        if (ldp_pgen_read(pg, inc[k], run, decoded.data(), rec_bytes, 0)) {
+          die(3, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+        }
+        src = decoded.data();
+      }
       if (!all_founders) {
+        // gather the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185)
         gather.assign(static_cast<size_t>(run) * out_rec, 0);
         for (uint32_t q = 0; q < run; ++q) {
           const uint8_t* in_row = src + static_cast<uint64_t>(q) * rec_bytes;
           uint8_t* out_row = gather.data() + static_cast<uint64_t>(q) * out_rec;
           for (uint32_t f = 0; f < founder_ct; ++f) {
-            const uint32_t s = founder_idx[f];
-            const uint32_t code = (in_row[s >> 2] >> (2 * (s & 3))) & 3;
+            const uint32_t sidx = founder_idx[f];
+            const uint32_t code = (in_row[sidx >> 2] >> (2 * (sidx & 3))) & 3;
             out_row[f >> 2] |= code << (2 * (f & 3));
-          }
-          if (encoding == LDP_GENO_BED) {
-            // trailing pad samples would read as code 0 = hom-ALT; the kernel masks by founder_ct, nothing to do
           }
         }
         src = gather.data();
@@ -778,6 +758,7 @@ int main(int argc, char** argv) {
   for (ldp_engine* e : eng) {
     ldp_destroy(e);
   }
+  ldp_pgen_close(pg);
   if (g_log) {
     fclose(g_log);
   }

@@ -87,12 +87,12 @@ def test_founder_guard_and_format_errors(cli, tmp_path):
         f.write(b"\0")
     cp = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "50", "5", "0.2", "--bad-ld", "--dry-run", "--out", "o"], str(tmp_path))
     assert cp.returncode != 0 and "Unexpected" in cp.stdout
-    # variable-width .pgen is refused, not mis-read
+    # external-index .pgen is refused, not mis-read
     with open(str(tmp_path / "d.pgen"), "r+b") as f:
         f.seek(2)
-        f.write(bytes([0x10]))
+        f.write(bytes([0x20]))
     cp = run_cli(cli, ["--pfile", "d", "--indep-pairwise", "50", "5", "0.2", "--bad-ld", "--dry-run", "--out", "o"], str(tmp_path))
-    assert cp.returncode != 0 and "storage mode 0x10" in cp.stdout
+    assert cp.returncode != 0 and "storage mode 0x20 is not supported" in cp.stdout
 
 
 def test_cli_refuses_to_compute_without_gpu(cli, pkg, tmp_path):
@@ -112,6 +112,8 @@ CLI_CASES = [
     ("pfile", ["20kb"], "0.3", 2, 7, 0, False),
     ("bfile", ["30", "kb"], "0.1", 1, 5, 2, False),
     ("pfile", ["100", "10"], "0.4", 2, 0, 0, True),
+    ("vpfile", ["20kb"], "0.2", 2, 0, 0, False),     # standard variable-width .pgen written by the reference
+    ("vpfile", ["60", "3"], "0.5", 1, 9, 4, False),
 ]
 
 
@@ -121,7 +123,14 @@ def test_cli_byte_identical_to_reference(gpu_pkg, cli, tmp_path, case):
     fmt, wargs, r2, order, nonfounders, chr0, preferred = case
     assert T.have_ref(), "reference binary oracle/_ref/plink2 must travel with the repo snapshot"
     prefix, raw, chr_idx, bps = small_fileset(tmp_path, m=900, n=120, seed=len(wargs) + order + nonfounders, nonfounders=nonfounders, chr0=chr0)
-    common = ["--" + fmt, "d", "--indep-pairwise"] + wargs + [r2]
+    if fmt == "vpfile":
+        # let the reference re-encode the fileset into its default variable-width .pgen (mode 0x10)
+        mk = T.run_ref(["--pfile", "d", "--make-pgen", "--out", "v"], str(tmp_path))
+        assert mk.returncode == 0, mk.stdout
+        assert open(str(tmp_path / "v.pgen"), "rb").read(3)[2] == 0x10
+        common = ["--pfile", "v", "--indep-pairwise"] + wargs + [r2]
+    else:
+        common = ["--" + fmt, "d", "--indep-pairwise"] + wargs + [r2]
     if order == 1:
         common += ["--indep-order", "1"]
     if preferred:
