@@ -11,7 +11,7 @@ import pytest
 
 import ldtools as T
 
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pgen")
 
 
 def codes(rows, n):
