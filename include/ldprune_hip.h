@@ -158,6 +158,16 @@ int ldp_pair_stats(ldp_engine* e, uint32_t n_pairs, const uint32_t* first, const
 int ldp_debug_set_variant_recs(ldp_engine* e, const ldp_variant_rec* recs);
 int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first, const uint32_t* second, uint64_t* removed);
 
+/* ---- --r2-unphased matrices (Vcor / VcorMatrix, plink2_ld.cc:12050,9766; ComputeR2 :6654-6682) ---- */
+/* All-pairs plan over variant_ct variants (inter-chromosomal pairs included, as the matrix shapes of
+ * --r2-unphased do): use instead of ldp_set_variants(), then ldp_load_genotypes() as usual. */
+int ldp_set_variants_matrix(ldp_engine* e, uint32_t variant_ct);
+/* r^2 for rows [row_first, row_first+row_ct) of the lower triangle incl. the diagonal: out[(j-row_first)*ld_elems
+ * + i] for i <= j, as float (bin4) or double (bin); elements with i > j are set to 0.  Undefined pairs are NaN with
+ * the reference's bit pattern.  `out` is host memory; ld_elems >= row_first+row_ct.  The caller assembles
+ * square / square0 / triangle files from row chunks (VcorMatrixThread :9518-9652 computes the same rows). */
+int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t ld_elems);
+
 /* ---- inspection ---- */
 int ldp_get_variant_recs(ldp_engine* e, uint32_t first_variant, uint32_t n, ldp_variant_rec* out);
 int ldp_get_maj_freqs(ldp_engine* e, uint32_t first_variant, uint32_t n, double* out);

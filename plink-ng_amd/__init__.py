@@ -76,6 +76,7 @@ CABI_SYMBOLS = [
     "ldp_set_shard", "ldp_get_band", "ldp_load_genotypes", "ldp_set_maj_freqs", "ldp_set_preferred", "ldp_run",
     "ldp_run_with_stats", "ldp_pair_stats", "ldp_debug_set_variant_recs", "ldp_debug_replay_pairs",
     "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
+    "ldp_set_variants_matrix", "ldp_r2_unphased_rows",
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
 ]
 
@@ -163,6 +164,8 @@ def lib():
     L.ldp_get_counters.argtypes = [vp, ctypes.POINTER(ldp_counters)]
     L.ldp_synth_genotypes.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, vp,
                                       ctypes.c_uint64, ctypes.c_int, vp]
+    L.ldp_set_variants_matrix.argtypes = [vp, ctypes.c_uint32]
+    L.ldp_r2_unphased_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, vp, ctypes.c_uint64]
     L.ldp_pgen_open.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp)]
     L.ldp_pgen_info.argtypes = [vp, u32p, u32p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.ldp_pgen_direct_rows.argtypes = [vp, u64p]
@@ -292,6 +295,18 @@ class LdPruneEngine:
             assert len(bps) == len(chr_idx)
             bp_ptr = _ptr(bps, ctypes.c_uint32)
         self._ck(self._L.ldp_set_variants(self._h, self.variant_ct, _ptr(chr_idx, ctypes.c_uint32), bp_ptr))
+
+    def set_variants_matrix(self, variant_ct):
+        self.variant_ct = int(variant_ct)
+        self._ck(self._L.ldp_set_variants_matrix(self._h, self.variant_ct))
+
+    def r2_unphased_rows(self, row_first=0, row_ct=None, as_float=False):
+        """Lower-triangle rows (incl. diagonal) of the --r2-unphased matrix: (row_ct, row_first+row_ct) array."""
+        row_ct = self.variant_ct - row_first if row_ct is None else row_ct
+        ld = row_first + row_ct
+        out = np.zeros((row_ct, ld), dtype=np.float32 if as_float else np.float64)
+        self._ck(self._L.ldp_r2_unphased_rows(self._h, row_first, row_ct, 1 if as_float else 0, out.ctypes.data_as(ctypes.c_void_p), ld))
+        return out
 
     def subcontigs(self):
         ct = ctypes.c_uint32()

@@ -55,6 +55,12 @@ struct PairKernelArgs {
   const uint64_t* pair_off;      // optional, with stats
   unsigned long long* counters;  // [0] = predicates true
   uint8_t* item_general;         // per work item: 1 = some row has missing calls -> general kernel
+  // --r2-unphased matrix mode: when r2_out != nullptr the epilogue stores r^2 of pair (i<j) at
+  // r2_out[(j - r2_row_first) * r2_ld + i] (float or double) instead of predicate bits
+  void* r2_out;
+  uint64_t r2_ld;
+  uint32_t r2_row_first;
+  uint32_t r2_float;
 };
 
 struct PrepareArgs {

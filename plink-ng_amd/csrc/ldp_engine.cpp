@@ -80,6 +80,7 @@ struct ldp_engine {
 
   // ---- plan (global indices) ----
   bool planned = false;
+  bool matrix_mode = false;  // all-pairs plan for --r2-unphased matrices (no band, no predicate rows)
   uint32_t variant_ct = 0;
   std::vector<uint32_t> bps;
   std::vector<Subcontig> subs;
@@ -345,6 +346,9 @@ void build_shard(ldp_engine* e) {
   e->pair_off.assign(static_cast<size_t>(local) + 1, 0);
   uint64_t words = 0, pairs = 0;
   for (uint32_t k : e->owned) {
+    if (e->matrix_mode) {
+      break;  // lo = 0 everywhere; tiles are generated per row chunk by ldp_r2_unphased_rows()
+    }
     const Subcontig& s = e->subs[k];
     for (uint32_t v = 0; v < s.len; ++v) {
       const uint32_t j = s.local_first + v;
@@ -368,6 +372,9 @@ void build_shard(ldp_engine* e) {
   e->max_units = 0;
   e->computed_pairs = 0;
   for (uint32_t k : e->owned) {
+    if (e->matrix_mode) {
+      break;
+    }
     const Subcontig& s = e->subs[k];
     const uint32_t sfirst = s.local_first;
     const uint32_t send = s.local_first + s.len;
@@ -720,6 +727,9 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   if (!removed) {
     return fail(e, LDP_ERR_INVALID, "removed bitmap is NULL");
   }
+  if (e->matrix_mode) {
+    return fail(e, LDP_ERR_STATE, "engine is planned for --r2-unphased matrices (ldp_set_variants_matrix)");
+  }
   const double t_start = now_ms();
   int rc = ensure_device_plan(e);
   if (rc) {
@@ -762,6 +772,10 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   A.pair_off = e->d_pair_off;
   A.counters = e->d_counters;
   A.item_general = e->d_item_general;
+  A.r2_out = nullptr;
+  A.r2_ld = 0;
+  A.r2_row_first = 0;
+  A.r2_float = 0;
 
   // 1. everything the device has to do is queued first ...
   hipEvent_t ev0, ev1;
@@ -941,6 +955,7 @@ int ldp_set_variants(ldp_engine* e, uint32_t variant_ct, const uint32_t* chr_idx
       return fail(e, LDP_ERR_INVALID, "positions must be sorted within a chromosome (plink2.cc:2926)");
     }
   }
+  e->matrix_mode = false;
   e->variant_ct = variant_ct;
   e->bps.clear();
   if (bps) {
@@ -965,6 +980,180 @@ int ldp_set_variants(ldp_engine* e, uint32_t variant_ct, const uint32_t* chr_idx
   e->ctr.subcontig_ct = static_cast<uint32_t>(e->subs.size());
   e->ctr.owned_subcontig_ct = static_cast<uint32_t>(e->owned.size());
   e->ctr.window_max = e->window_max;
+  return LDP_OK;
+}
+
+int ldp_set_variants_matrix(ldp_engine* e, uint32_t variant_ct) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  e->matrix_mode = true;
+  e->variant_ct = variant_ct;
+  e->bps.clear();
+  e->subs.clear();
+  if (variant_ct) {
+    Subcontig s;
+    s.len = variant_ct;
+    s.first = 0;
+    s.owner = 0;
+    s.local_first = 0;
+    e->subs.push_back(s);
+  }
+  e->window_max = variant_ct;
+  e->lo_global.assign(variant_ct, 0);
+  e->batch_end.assign(variant_ct, 0);
+  e->rank = 0;
+  e->world = 1;
+  e->planned = true;
+  build_shard(e);
+  e->ctr.subcontig_ct = static_cast<uint32_t>(e->subs.size());
+  e->ctr.owned_subcontig_ct = e->ctr.subcontig_ct;
+  e->ctr.window_max = variant_ct;
+  return LDP_OK;
+}
+
+int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t ld_elems) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  if (!e->planned || !e->matrix_mode) {
+    return fail(e, LDP_ERR_STATE, "ldp_set_variants_matrix() first");
+  }
+  if ((static_cast<uint64_t>(row_first) + row_ct > e->variant_ct) || (row_ct && !out) || (ld_elems < static_cast<uint64_t>(row_first) + row_ct)) {
+    return fail(e, LDP_ERR_INVALID, "row range / leading dimension out of bounds");
+  }
+  int rc = ensure_device_plan(e);
+  if (rc) {
+    return rc;
+  }
+  for (uint32_t l = 0; l < e->local_ct; ++l) {
+    if (!e->loaded[l]) {
+      return fail(e, LDP_ERR_STATE, "genotypes missing for a variant (ldp_load_genotypes)");
+    }
+  }
+  if (!row_ct) {
+    return LDP_OK;
+  }
+  const double t_start = now_ms();
+  HIP_TRY(e, hipSetDevice(e->device));
+  // tiles of the rows' lower triangle: (32 seconds) x (all distances 1..j), <= 128 distances per block
+  std::vector<WorkItem> items;
+  uint32_t max_units = 0;
+  uint64_t computed = 0, cand = 0;
+  const uint32_t row_end = row_first + row_ct;
+  for (uint32_t j0 = row_first; j0 < row_end; j0 += kTileJ) {
+    const uint32_t jend = std::min(j0 + kTileJ, row_end);
+    const uint32_t dmax = jend - 1;
+    for (uint32_t j = j0; j < jend; ++j) {
+      cand += j;
+    }
+    if (!dmax) {
+      continue;
+    }
+    const uint32_t units = (dmax + 7) / 8;
+    const uint32_t blocks = (units + kMaxUnitsPerBlock - 1) / kMaxUnitsPerBlock;
+    const uint32_t base = units / blocks;
+    const uint32_t extra = units % blocks;
+    uint32_t d0 = 1;
+    for (uint32_t blk = 0; blk < blocks; ++blk) {
+      const uint32_t u = base + ((blk < extra) ? 1 : 0);
+      const uint32_t waves_used = std::min<uint32_t>(u, kWavesPerBlock);
+      const uint32_t wb = u / waves_used;
+      const uint32_t we = u % waves_used;
+      WorkItem it;
+      it.j0 = j0;
+      it.jend = jend;
+      it.d0 = d0;
+      it.units = 0;
+      for (uint32_t w = 0; w < waves_used; ++w) {
+        it.units |= (wb + ((w < we) ? 1 : 0)) << (8 * w);
+      }
+      it.sfirst = 0;
+      it.send = e->local_ct;
+      items.push_back(it);
+      max_units = std::max(max_units, u);
+      computed += static_cast<uint64_t>(u) * 8 * kTileJ;
+      d0 += 8 * u;
+    }
+  }
+  const size_t esz = as_float ? sizeof(float) : sizeof(double);
+  const uint64_t out_elems = static_cast<uint64_t>(row_ct) * ld_elems;
+  void* d_out = nullptr;
+  WorkItem* d_items = nullptr;
+  uint8_t* d_general = nullptr;
+  HIP_TRY(e, hipMalloc(&d_out, out_elems * esz));
+  HIP_TRY(e, hipMemsetAsync(d_out, 0, out_elems * esz, e->stream));
+  if (!items.empty()) {
+    HIP_TRY(e, hipMalloc(&d_items, items.size() * sizeof(WorkItem)));
+    HIP_TRY(e, hipMalloc(&d_general, items.size()));
+    HIP_TRY(e, hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, e->stream));
+  }
+  PairKernelArgs A;
+  A.planes = e->d_planes;
+  A.row_dwords = e->row_dwords;
+  A.chunks = e->chunks;
+  A.founder_ct = e->P.founder_ct;
+  A.recs = e->d_recs;
+  A.lo = e->d_lo;  // all zero in matrix mode
+  A.row_off = e->d_row_off;
+  A.pred = e->d_pred;
+  A.items = d_items;
+  A.n_items = static_cast<uint32_t>(items.size());
+  A.plane_base_variant = 0;
+  A.thresh = 0.0;
+  A.stats = nullptr;
+  A.pair_off = nullptr;
+  A.counters = e->d_counters;
+  A.item_general = d_general;
+  A.r2_out = d_out;
+  A.r2_ld = ld_elems;
+  A.r2_row_first = row_first;
+  A.r2_float = as_float ? 1 : 0;
+  hipEvent_t evk[4];
+  for (int q = 0; q < 4; ++q) {
+    HIP_TRY(e, hipEventCreate(&evk[q]));
+  }
+  hipError_t krc = launch_pair_tiles(A, std::max<uint32_t>(max_units, 1), e->stream, evk);
+  if (krc != hipSuccess) {
+    return hipfail(e, krc, "pair_tiles_kernel launch");
+  }
+  HIP_TRY(e, hipMemcpyAsync(out, d_out, out_elems * esz, hipMemcpyDeviceToHost, e->stream));
+  rc = fetch_recs(e);  // diagonal needs each variant's own variance
+  if (rc) {
+    return rc;
+  }
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  float kms_fast = 0.f, kms_general = 0.f;
+  if (!items.empty()) {
+    HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
+    HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[2], evk[3]));
+  }
+  for (int q = 0; q < 4; ++q) {
+    (void)hipEventDestroy(evk[q]);
+  }
+  (void)hipFree(d_out);
+  (void)hipFree(d_items);
+  (void)hipFree(d_general);
+  // diagonal: r^2(v, v) through the same formula = 1.0, or NaN when the variant has no variance
+  for (uint32_t j = row_first; j < row_end; ++j) {
+    const ldp_variant_rec& r = e->recs[j];
+    const int64_t var = static_cast<int64_t>(r.ssq) * static_cast<int64_t>(r.nm_ct) - static_cast<int64_t>(r.sum) * static_cast<int64_t>(r.sum);
+    const bool defined = r.nm_ct && (static_cast<double>(var) * static_cast<double>(var) != 0.0);
+    const uint64_t idx = static_cast<uint64_t>(j - row_first) * ld_elems + j;
+    if (as_float) {
+      const uint32_t bits = defined ? 0x3f800000u : 0xffc00000u;
+      memcpy(static_cast<float*>(out) + idx, &bits, 4);
+    } else {
+      const uint64_t bits = defined ? 0x3ff0000000000000ull : 0xfff8000000000000ull;
+      memcpy(static_cast<double*>(out) + idx, &bits, 8);
+    }
+  }
+  e->ctr.candidate_pairs = cand;
+  e->ctr.computed_pairs = computed;
+  e->ctr.ms_pair_fast = kms_fast;
+  e->ctr.ms_pair_general = kms_general;
+  e->ctr.ms_pair_kernel = kms_fast + kms_general;
+  e->ctr.ms_run_total = now_ms() - t_start;
   return LDP_OK;
 }
 

@@ -424,9 +424,38 @@ __device__ __forceinline__ bool exceeds(const ldp_pair_stats_t& s, double thresh
   return __dmul_rn(cov12, cov12) > __dmul_rn(__dmul_rn(thresh, var1), var2);
 }
 
+// r^2 of --r2-unphased exactly as ComputeR2 writes it (plink2_ld.cc:6654-6682): NaN when there is no joint
+// observation or a zero variance product, else cov01*cov01 / (double(var0)*double(var1)).  The NaN bit
+// patterns are the ones the reference's `0.0 / 0.0` produces on x86 (sign bit set).
+__device__ __forceinline__ double r2_unphased(const ldp_pair_stats_t& s) {
+  const double nan_ref = __longlong_as_double(static_cast<long long>(0xfff8000000000000ull));
+  if (!s.nm) {
+    return nan_ref;
+  }
+  const int64_t var0 = static_cast<int64_t>(s.ssq1) * static_cast<int64_t>(s.nm) - static_cast<int64_t>(s.sum1) * static_cast<int64_t>(s.sum1);
+  const int64_t var1 = static_cast<int64_t>(s.ssq2) * static_cast<int64_t>(s.nm) - static_cast<int64_t>(s.sum2) * static_cast<int64_t>(s.sum2);
+  const double variance_prod = __dmul_rn(static_cast<double>(var0), static_cast<double>(var1));
+  if (variance_prod == 0.0) {
+    return nan_ref;
+  }
+  const double cov01 = static_cast<double>(static_cast<int64_t>(s.dot) * static_cast<int64_t>(s.nm) - static_cast<int64_t>(s.sum1) * static_cast<int64_t>(s.sum2));
+  return __ddiv_rn(__dmul_rn(cov01, cov01), variance_prod);
+}
+
 __device__ __forceinline__ void emit_pair(const PairKernelArgs& A, uint32_t i, uint32_t j, uint32_t lo_j, const ldp_pair_stats_t& st) {
   if (A.stats) {
     A.stats[A.pair_off[j] + (i - lo_j)] = st;
+  }
+  if (A.r2_out) {
+    const double r2 = r2_unphased(st);
+    const uint64_t idx = static_cast<uint64_t>(j - A.r2_row_first) * A.r2_ld + i;
+    if (A.r2_float) {
+      const float f = (r2 != r2) ? __uint_as_float(0xffc00000u) : static_cast<float>(r2);
+      static_cast<float*>(A.r2_out)[idx] = f;
+    } else {
+      static_cast<double*>(A.r2_out)[idx] = r2;
+    }
+    return;
   }
   if (exceeds(st, A.thresh)) {
     atomicOr(&A.pred[A.row_off[j] + ((i >> 5) - (lo_j >> 5))], 1u << (i & 31));
@@ -464,7 +493,7 @@ __global__ __launch_bounds__(256) void classify_items_kernel(PairKernelArgs A) {
 constexpr int kEpilogueLdsDwords = 32 * kBlockThreads;  // 32 KiB
 
 template <bool GENERAL>
-__global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_kernel(PairKernelArgs A) {
+__global__ __launch_bounds__(kBlockThreads, GENERAL ? 3 : 4) void pair_tiles_kernel(PairKernelArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   // XCD-aware order: hardware places block b on XCD b % 8; give each XCD a contiguous run of work
   // items so neighbouring J-blocks (which share most of their window rows) hit the same L2.

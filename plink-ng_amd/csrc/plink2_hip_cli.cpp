@@ -160,6 +160,10 @@ struct Args {
   bool allow_extra_chr = false;
   std::string preferred;
   int gpus = 1;
+  bool have_r2 = false;
+  int r2_shape = -1;      // 0 square, 1 square0, 2 triangle
+  int r2_float = -1;      // 1 bin4, 0 bin
+  bool yes_really = false;
   bool dry_run = false;  // parse + plan only, print the parameters exactly (%a) and exit: used by the CPU tests
 };
 
@@ -289,6 +293,23 @@ Args parse_args(int argc, char** argv) {
         die(5, "Error: Invalid --indep-pairwise r^2 threshold '%s'.\n", par[next].c_str());
       }
       A.have_prune = true;
+    } else if (f == "--r2-unphased") {
+      // [{square | square0 | triangle | inter-chr}] ['yes-really'] [{zs | bin | bin4}] ... (plink2.cc:11090-11210)
+      while (i + 1 < argc && !(argv[i + 1][0] == '-' && argv[i + 1][1] == '-')) {
+        std::string m = argv[++i];
+        if (m == "square") A.r2_shape = 0;
+        else if (m == "square0") A.r2_shape = 1;
+        else if (m == "triangle") A.r2_shape = 2;
+        else if (m == "bin") A.r2_float = 0;
+        else if (m == "bin4") A.r2_float = 1;
+        else if (m == "yes-really") A.yes_really = true;
+        else if (m == "ref-based" || m == "allow-ambiguous-allele") { /* no effect on r^2 */ }
+        else die(9, "Error: --r2-unphased modifier '%s' is not supported by plink2-hip (matrix shapes with bin/bin4 only).\n", m.c_str());
+      }
+      if (A.r2_shape < 0 || A.r2_float < 0) {
+        die(9, "Error: plink2-hip supports --r2-unphased {square | square0 | triangle} {bin | bin4}; tabular (.vcor) and text matrices are not implemented yet.\n");
+      }
+      A.have_r2 = true;
     } else if (f == "--indep-order") {
       need(i, 1, "--indep-order");
       std::string v = argv[++i];
@@ -311,8 +332,11 @@ Args parse_args(int argc, char** argv) {
       die(5, "Error: Unrecognized flag ('%s').  plink2-hip implements the --indep-pairwise path only.\n", f.c_str());
     }
   }
-  if (!A.have_prune) {
-    die(5, "Error: no command given (plink2-hip implements --indep-pairwise).\n");
+  if (!A.have_prune && !A.have_r2) {
+    die(5, "Error: no command given (plink2-hip implements --indep-pairwise and --r2-unphased matrices).\n");
+  }
+  if (A.have_prune && A.have_r2) {
+    die(5, "Error: run --indep-pairwise and --r2-unphased separately.\n");
   }
   if (A.gpus < 1) {
     die(5, "Error: --gpus must be positive.\n");
@@ -494,14 +518,14 @@ int main(int argc, char** argv) {
   const uint32_t raw_variant_ct = static_cast<uint32_t>(V.id.size());
   logprintf("%u variant%s loaded from %s.\n", raw_variant_ct, raw_variant_ct == 1 ? "" : "s", (A.pvar.empty() ? A.bim : A.pvar).c_str());
 
-  if (founder_ct < 50 && !A.bad_ld) {  // plink2.cc:2063-2071
+  if (A.have_prune && founder_ct < 50 && !A.bad_ld) {  // plink2.cc:2063-2071
     if (raw_sample_ct < 50) {
       die(7, "Error: This run estimates linkage disequilibrium between variants, but there\nare less than 50 samples to estimate from.  You should perform this operation\non a larger dataset.\n(Strictly speaking, you can also override this error with --bad-ld, but this is\nalmost always a bad idea.)\n");
     }
     die(7, "Error: This run estimates linkage disequilibrium between variants, but there\nare less than 50 founders to estimate from.  --make-founders may help.\n(Strictly speaking, you can also override this error with --bad-ld, but this is\nalmost always a bad idea.)\n");
   }
   if (founder_ct < 2) {
-    die(7, "Error: --indep-pairwise requires at least two founders. (--make-founders may come in handy here.)\n");
+    die(7, "Error: %s requires at least two founders. (--make-founders may come in handy here.)\n", A.have_prune ? "--indep-pairwise" : "--r2-unphased");
   }
 
   // ---- genotype file (.bed / fixed-width .pgen / standard variable-width .pgen)
@@ -541,7 +565,7 @@ int main(int argc, char** argv) {
       }
       bool zero;
       const int cls = chrom_class(cur, A.allow_extra_chr, &zero);
-      if (zero) {
+      if (zero && A.have_prune) {
         ++skipped;
         continue;
       }
@@ -566,6 +590,138 @@ int main(int argc, char** argv) {
         die(3, "Error: --indep-pairwise with a kb window requires a sorted .pvar/.bim.  Retry this command after using\n--make-pgen/--make-bed + --sort-vars to sort your data.\n");
       }
     }
+  }
+
+  if (A.have_r2) {
+    // ---- --r2-unphased {square|square0|triangle} {bin|bin4}: every variant, every pair (Vcor, plink2_ld.cc:12050)
+    if (variant_ct > 400000 && !A.yes_really) {  // plink2_ld.cc:9788
+      die(7, "Error: Gigantic (over 400k variants) --r2-unphased unfiltered, non-distributed\ncomputation.  Rerun with the 'yes-really' modifier if you are SURE you have enough\nhard drive space and want to do this.\n");
+    }
+    ldp_params RP;
+    memset(&RP, 0, sizeof(RP));
+    RP.founder_ct = founder_ct;
+    RP.prune_window_size = 2;
+    RP.prune_window_incr = 1;
+    RP.prune_last_param = 0.5;
+    RP.device = 0;
+    if (ldp_device_count() < 1) {
+      die(12, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
+    }
+    ldp_engine* e = nullptr;
+    if (ldp_create(&RP, &e) || ldp_set_variants_matrix(e, variant_ct)) {
+      die(12, "Error: engine setup failed.\n");
+    }
+    const std::string base = A.out + ".unphased.vcor2.bin";
+    {
+      FILE* vf = fopen((base + ".vars").c_str(), "wb");
+      if (!vf) {
+        die(2, "Error: Failed to open %s.vars for writing.\n", base.c_str());
+      }
+      for (uint32_t k = 0; k < variant_ct; ++k) {
+        fputs(V.id[inc[k]].c_str(), vf);
+        fputc('\n', vf);
+      }
+      fclose(vf);
+    }
+    logprintf("--r2-unphased: Variant IDs written to %s.vars .\n", base.c_str());
+    // genotype rows -> engine (same feeder as the prune path)
+    {
+      const bool all_founders = (founder_ct == raw_sample_ct);
+      const uint64_t out_rec = (static_cast<uint64_t>(founder_ct) + 3) / 4;
+      std::vector<uint32_t> founder_idx;
+      for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+        if (is_founder[sx]) {
+          founder_idx.push_back(sx);
+        }
+      }
+      const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((1024ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
+      std::vector<uint8_t> decoded, gather;
+      for (uint32_t k = 0; k < variant_ct;) {
+        const uint32_t run = std::min(kChunk, variant_ct - k);
+        const uint8_t* src;
+        uint64_t stride = rec_bytes;
+        if (direct_rows) {
+          src = direct_rows + static_cast<uint64_t>(k) * rec_bytes;
+        } else {
+          decoded.resize(static_cast<size_t>(run) * rec_bytes);
+          if (ldp_pgen_read(pg, k, run, decoded.data(), rec_bytes, 0)) {
+            die(3, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+          }
+          src = decoded.data();
+        }
+        if (!all_founders) {
+          gather.assign(static_cast<size_t>(run) * out_rec, 0);
+          for (uint32_t q = 0; q < run; ++q) {
+            const uint8_t* in_row = src + static_cast<uint64_t>(q) * rec_bytes;
+            uint8_t* out_row = gather.data() + static_cast<uint64_t>(q) * out_rec;
+            for (uint32_t f = 0; f < founder_ct; ++f) {
+              const uint32_t sidx = founder_idx[f];
+              out_row[f >> 2] |= ((in_row[sidx >> 2] >> (2 * (sidx & 3))) & 3) << (2 * (f & 3));
+            }
+          }
+          src = gather.data();
+          stride = out_rec;
+        }
+        if (ldp_load_genotypes(e, k, run, src, stride, LDP_MEM_HOST, encoding)) {
+          die(12, "Error: %s\n", ldp_last_error(e));
+        }
+        k += run;
+      }
+    }
+    const size_t esz = A.r2_float ? 4 : 8;
+    FILE* mf = fopen(base.c_str(), "wb");
+    if (!mf) {
+      die(2, "Error: Failed to open %s for writing.\n", base.c_str());
+    }
+    std::vector<uint8_t> full;  // square needs the mirrored upper triangle: whole matrix in host memory
+    if (A.r2_shape == 0) {
+      full.assign(static_cast<size_t>(variant_ct) * variant_ct * esz, 0);
+    }
+    std::vector<uint8_t> chunk;
+    for (uint32_t r0 = 0; r0 < variant_ct;) {
+      // rows per chunk: about 1 GiB of output
+      uint32_t rows = static_cast<uint32_t>(std::max<uint64_t>(32, (1ull << 30) / (static_cast<uint64_t>(r0 + 4096) * esz)));
+      rows = std::min(std::min(rows, variant_ct - r0), 65536u);
+      const uint64_t ld = static_cast<uint64_t>(r0) + rows;
+      chunk.assign(static_cast<size_t>(rows) * ld * esz, 0);
+      if (ldp_r2_unphased_rows(e, r0, rows, A.r2_float, chunk.data(), ld)) {
+        die(12, "Error: %s\n", ldp_last_error(e));
+      }
+      for (uint32_t q = 0; q < rows; ++q) {
+        const uint32_t j = r0 + q;
+        const uint8_t* row = chunk.data() + static_cast<uint64_t>(q) * ld * esz;
+        if (A.r2_shape == 2) {
+          fwrite(row, esz, static_cast<size_t>(j) + 1, mf);
+        } else if (A.r2_shape == 1) {
+          fwrite(row, esz, static_cast<size_t>(j) + 1, mf);
+          static const std::vector<uint8_t> zeros(1 << 20, 0);
+          for (uint64_t left = (static_cast<uint64_t>(variant_ct) - j - 1) * esz; left;) {
+            const size_t w = static_cast<size_t>(std::min<uint64_t>(left, zeros.size()));
+            fwrite(zeros.data(), 1, w, mf);
+            left -= w;
+          }
+        } else {
+          memcpy(full.data() + static_cast<uint64_t>(j) * variant_ct * esz, row, (static_cast<size_t>(j) + 1) * esz);
+          for (uint32_t i = 0; i < j; ++i) {
+            memcpy(full.data() + (static_cast<uint64_t>(i) * variant_ct + j) * esz, row + static_cast<uint64_t>(i) * esz, esz);
+          }
+        }
+      }
+      r0 += rows;
+    }
+    if (A.r2_shape == 0 && !full.empty()) {
+      fwrite(full.data(), 1, full.size(), mf);
+    }
+    if (fclose(mf)) {
+      die(2, "Error: File write failure: %s.\n", base.c_str());
+    }
+    logprintf("--r2-unphased: Matrix written to %s .\n", base.c_str());
+    ldp_destroy(e);
+    ldp_pgen_close(pg);
+    if (g_log) {
+      fclose(g_log);
+    }
+    return 0;
   }
 
   ldp_params P;

@@ -1,0 +1,93 @@
+"""--r2-unphased matrices (BASELINE config 4 path): the tile kernel's matrix mode against the oracle's
+integer statistics (r^2 doubles must be bit-identical: same integers, same IEEE operations as ComputeR2,
+plink2_ld.cc:6654-6682), against the golden doubles recorded from the reference, and -- through plink2-hip --
+byte-for-byte against the files the reference binary writes."""
+import filecmp
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ldtools as T
+from test_golden import GOLDEN, load
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_r2_lower(raw):
+    m, n = raw.shape
+    inv, mf, _ = T.oracle_prepare(raw)
+    hom, r2h, vaggs = T.oracle_split(inv, n)
+    out = np.zeros((m, m), dtype=np.float64)
+    for j in range(m):
+        for i in range(j + 1):
+            st = T.oracle_pair_stats(hom, r2h, vaggs, n, i, j)
+            cov, v1, v2 = T.oracle_r2(st)
+            prod = v1 * v2
+            out[j, i] = np.nan if (st.nm == 0 or prod == 0.0) else cov * cov / prod
+    return out
+
+
+def same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint64 if a.dtype == np.float64 else np.uint32),
+                          np.ascontiguousarray(b).view(np.uint64 if b.dtype == np.float64 else np.uint32))
+
+
+@pytest.mark.parametrize("m,n,miss", [(70, 90, 0.0), (150, 130, 0.05), (300, 40, 0.2), (45, 1100, 0.01)])
+def test_matrix_rows_match_oracle(gpu_pkg, m, n, miss):
+    pkg = gpu_pkg
+    raw = T.synth_raw_codes(m, n, seed=m + n, missing_rate=miss)
+    raw[3] = 0   # monomorphic: undefined r^2 (NaN) against everything, incl. itself
+    raw[5] = 3   # all missing
+    want = oracle_r2_lower(raw)
+    eng = pkg.LdPruneEngine(n, 2, 1, False, 0.5, device=0)
+    eng.set_variants_matrix(m)
+    eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+    got = eng.r2_unphased_rows()
+    il = np.tril_indices(m)
+    nan_w, nan_g = np.isnan(want[il]), np.isnan(got[il])
+    assert np.array_equal(nan_w, nan_g)
+    assert np.array_equal(want[il][~nan_w], got[il][~nan_g])            # exact doubles
+    assert (got[np.triu_indices(m, 1)] == 0).all()
+    # NaN carries the reference's bit pattern
+    assert set(got[il][nan_g].view(np.uint64)) <= {0xfff8000000000000}
+    # row chunks + float output
+    part = eng.r2_unphased_rows(33, 20, as_float=True)
+    ref32 = want[33:53, :53].astype(np.float32)
+    for q in range(20):
+        a, b = part[q, :33 + q + 1], ref32[q, :33 + q + 1]
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+    eng.close()
+
+
+def test_matrix_matches_golden_reference_doubles(gpu_pkg):
+    pkg = gpu_pkg
+    for name in ("kat_missing.npz", "kat_quirk_o2.npz"):
+        g = load([p for p in GOLDEN if p.endswith(name)][0])
+        eng = pkg.LdPruneEngine(g["n"], 2, 1, False, 0.5, device=0)
+        eng.set_variants_matrix(g["m"])
+        eng.load_genotypes_host(0, T.pack_2bit(g["raw"]), pkg.LDP_GENO_REF)
+        got = eng.r2_unphased_rows()
+        il = np.tril_indices(g["m"])
+        assert same_bits(got[il], g["r2_square"][il])
+        eng.close()
+
+
+@pytest.mark.parametrize("shape,enc", [("square", "bin"), ("square0", "bin4"), ("triangle", "bin"), ("triangle", "bin4")])
+def test_cli_matrix_files_byte_identical(gpu_pkg, tmp_path, shape, enc):
+    assert T.have_ref()
+    cli = gpu_pkg.build_cli()
+    m, n = 700, 150
+    raw = T.synth_raw_codes(m, n, seed=9, missing_rate=0.03)
+    raw[10] = 2
+    raw[11] = 3
+    chroms = ["0"] * 5 + ["1"] * 400 + ["7"] * 295
+    T.write_pgen_fixed(str(tmp_path / "d"), raw, chroms, np.arange(m) + 1)
+    ref = T.run_ref(["--pfile", "d", "--r2-unphased", shape, enc, "--out", "ref"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    got = subprocess.run([cli, "--pfile", "d", "--r2-unphased", shape, enc, "--out", "hip"], cwd=str(tmp_path), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert got.returncode == 0, got.stdout
+    assert filecmp.cmp(str(tmp_path / "ref.unphased.vcor2.bin.vars"), str(tmp_path / "hip.unphased.vcor2.bin.vars"), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "ref.unphased.vcor2.bin"), str(tmp_path / "hip.unphased.vcor2.bin"), shallow=False)
