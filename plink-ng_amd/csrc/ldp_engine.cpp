@@ -128,6 +128,9 @@ struct ldp_engine {
   bool recs_registered = false;
   hipEvent_t prep_ev0 = nullptr, prep_ev1 = nullptr;
   hipStream_t copy_stream = nullptr;
+  uint8_t* h_stage[3] = {nullptr, nullptr, nullptr};  // pinned staging ring for host-memory genotype input
+  uint8_t* d_stage[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t stage_done[3] = {nullptr, nullptr, nullptr};
   bool prep_pending = false;
 
   ldp_counters ctr;
@@ -159,6 +162,9 @@ int hipfail(ldp_engine* e, hipError_t rc, const char* what) {
     }                                                 \
   } while (0)
 
+constexpr uint32_t kStageSlots = 3;
+constexpr size_t kStageBytes = 64ull << 20;
+
 void free_device(ldp_engine* e) {
   if (!e->gpu_ok) {
     return;
@@ -178,6 +184,16 @@ void free_device(ldp_engine* e) {
   if (e->recs_registered) {
     (void)hipHostUnregister(e->recs.data());
     e->recs_registered = false;
+  }
+  for (uint32_t k = 0; k < kStageSlots; ++k) {
+    if (e->h_stage[k]) {
+      (void)hipHostFree(e->h_stage[k]);
+      (void)hipFree(e->d_stage[k]);
+      (void)hipEventDestroy(e->stage_done[k]);
+      e->h_stage[k] = nullptr;
+      e->d_stage[k] = nullptr;
+      e->stage_done[k] = nullptr;
+    }
   }
   if (e->prep_ev0) {
     (void)hipEventDestroy(e->prep_ev0);
@@ -496,6 +512,21 @@ bool derive_maj_freq(ldp_engine* e, uint32_t l) {
 
 // Bring the per-variant records to the host (one D2H per ldp_run, not per load call) and derive the
 // major-allele frequencies that are still pending.
+int ensure_staging(ldp_engine* e) {
+  if (e->h_stage[0]) {
+    return LDP_OK;
+  }
+  const size_t row_bytes = (static_cast<size_t>(e->P.founder_ct) + 3) / 4;
+  const size_t bytes = std::max(kStageBytes, row_bytes);
+  for (uint32_t k = 0; k < kStageSlots; ++k) {
+    HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_stage[k]), bytes, hipHostMallocDefault));
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_stage[k]), bytes));
+    HIP_TRY(e, hipEventCreate(&e->stage_done[k]));
+    HIP_TRY(e, hipEventRecord(e->stage_done[k], e->stream));
+  }
+  return LDP_OK;
+}
+
 int fetch_recs(ldp_engine* e) {
   if (e->recs_host_valid) {
     return LDP_OK;
@@ -1248,12 +1279,17 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
   }
   HIP_TRY(e, hipSetDevice(e->device));
   const uint8_t* src = static_cast<const uint8_t*>(geno);
-  uint8_t* d_stage = nullptr;
+  // Host input goes through a 3-deep ring of pinned staging buffers: host threads gather rows into
+  // pinned memory (packed to row_bytes) while the previous slot's H2D copy and prepare kernel are in flight.
   size_t stage_rows = 0;
   if (location == LDP_MEM_HOST) {
-    stage_rows = std::max<size_t>(1, std::min<size_t>(n, (256ull << 20) / stride_bytes));
-    HIP_TRY(e, hipMalloc(&d_stage, stage_rows * stride_bytes));
+    rc = ensure_staging(e);
+    if (rc) {
+      return rc;
+    }
+    stage_rows = std::max<size_t>(1, kStageBytes / row_bytes);
   }
+  uint32_t slot = 0;
   uint32_t g = first_variant;
   const uint32_t gend = first_variant + n;
   while (g < gend) {
@@ -1270,18 +1306,35 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
     while (done < run) {
       uint32_t cnt = run - done;
       const uint8_t* d_src;
+      uint64_t d_stride = stride_bytes;
       if (location == LDP_MEM_HOST) {
         cnt = static_cast<uint32_t>(std::min<size_t>(cnt, stage_rows));
-        HIP_TRY(e, hipMemcpyAsync(d_stage, src + static_cast<uint64_t>(g + done - first_variant) * stride_bytes,
-                                  static_cast<size_t>(cnt) * stride_bytes, hipMemcpyHostToDevice, e->stream));
-        d_src = d_stage;
+        HIP_TRY(e, hipEventSynchronize(e->stage_done[slot]));  // slot free again?
+        uint8_t* pin = e->h_stage[slot];
+        const uint8_t* from = src + static_cast<uint64_t>(g + done - first_variant) * stride_bytes;
+        const uint32_t kRowsPerTask = std::max<uint32_t>(1, static_cast<uint32_t>((4ull << 20) / row_bytes));
+        const uint32_t tasks = (cnt + kRowsPerTask - 1) / kRowsPerTask;
+        parallel_for(tasks, 16, [&](uint32_t t) {
+          const uint32_t r0 = t * kRowsPerTask;
+          const uint32_t r1 = std::min(cnt, r0 + kRowsPerTask);
+          if (stride_bytes == row_bytes) {
+            memcpy(pin + static_cast<uint64_t>(r0) * row_bytes, from + static_cast<uint64_t>(r0) * row_bytes, static_cast<uint64_t>(r1 - r0) * row_bytes);
+          } else {
+            for (uint32_t r = r0; r < r1; ++r) {
+              memcpy(pin + static_cast<uint64_t>(r) * row_bytes, from + static_cast<uint64_t>(r) * stride_bytes, row_bytes);
+            }
+          }
+        });
+        HIP_TRY(e, hipMemcpyAsync(e->d_stage[slot], pin, static_cast<size_t>(cnt) * row_bytes, hipMemcpyHostToDevice, e->stream));
+        d_src = e->d_stage[slot];
+        d_stride = row_bytes;
       } else {
         d_src = src + static_cast<uint64_t>(g + done - first_variant) * stride_bytes;
       }
       const uint32_t l0 = static_cast<uint32_t>(e->global_to_local[g + done]);
       PrepareArgs PA;
       PA.geno = d_src;
-      PA.stride_bytes = stride_bytes;
+      PA.stride_bytes = d_stride;
       PA.n_variants = cnt;
       PA.founder_ct = e->P.founder_ct;
       PA.encoding = encoding;
@@ -1299,7 +1352,8 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
       }
       HIP_TRY(e, hipEventRecord(e->prep_ev1, e->stream));
       if (location == LDP_MEM_HOST) {
-        HIP_TRY(e, hipStreamSynchronize(e->stream));  // the staging buffer is reused
+        HIP_TRY(e, hipEventRecord(e->stage_done[slot], e->stream));
+        slot = (slot + 1) % kStageSlots;
       }
       for (uint32_t q = 0; q < cnt; ++q) {
         e->loaded[l0 + q] = 1;
@@ -1312,9 +1366,8 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
     g += run;
   }
   e->recs_host_valid = false;
-  if (d_stage) {
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    (void)hipFree(d_stage);
+  if (location == LDP_MEM_HOST) {
+    HIP_TRY(e, hipStreamSynchronize(e->stream));  // the caller may reuse its buffer once we return
   }
   return LDP_OK;
 }

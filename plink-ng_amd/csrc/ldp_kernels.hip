@@ -374,7 +374,7 @@ __device__ __forceinline__ TileGeom make_geom(const WorkItem& it, uint32_t units
 // slots (1 KiB, lane l -> slot 64*T + l); the per-lane GLOBAL address is free, so each lane simply fetches
 // the 16 bytes that belong in its slot (pad slots re-fetch slot 0 of their row and are never read).
 // The lane->source mapping does not depend on the k-chunk, so it is computed once per block.
-constexpr int kMaxDmaPerWave = 7;  // ceil(ceil(191 rows * 9 slots / 64) / 4 waves)
+constexpr int kMaxDmaPerWave = ((191 * kLdsRowSlots + 63) / 64 + kWavesPerBlock - 1) / kWavesPerBlock;  // 7 at 9 slots/row
 
 struct DmaPlan {
   uint32_t src_off[kMaxDmaPerWave];  // byte offset of this lane's 16 B relative to the block's first variant row
