@@ -19,6 +19,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -37,6 +38,11 @@ namespace {
 
 constexpr double kSmallEpsilon = 0.00000000000005684341886080801486968994140625;  // 2^-44
 FILE* g_log = nullptr;
+
+double now_s() {
+  using namespace std::chrono;
+  return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
 
 void logprintf(const char* fmt, ...) {
   char buf[4096];
@@ -164,6 +170,7 @@ struct Args {
   int r2_shape = -1;      // 0 square, 1 square0, 2 triangle
   int r2_float = -1;      // 1 bin4, 0 bin
   bool yes_really = false;
+  bool timing = false;    // --timing: print per-phase wall times
   bool dry_run = false;  // parse + plan only, print the parameters exactly (%a) and exit: used by the CPU tests
 };
 
@@ -320,6 +327,8 @@ Args parse_args(int argc, char** argv) {
       A.bad_ld = true;
     } else if (f == "--allow-extra-chr") {
       A.allow_extra_chr = true;
+    } else if (f == "--timing") {
+      A.timing = true;
     } else if (f == "--dry-run") {
       A.dry_run = true;
     } else if (f == "--gpus") {
@@ -495,6 +504,7 @@ int chrom_class(const std::string& name_in, bool allow_extra, bool* is_zero) {
 }  // namespace
 
 int main(int argc, char** argv) {
+  const double t_begin = now_s();
   Args A = parse_args(argc, argv);
   g_log = fopen((A.out + ".log").c_str(), "w");
   logprintf("plink2-hip: MI355X-native --indep-pairwise (drop-in for that path of PLINK v2.0)\n");
@@ -807,6 +817,7 @@ int main(int argc, char** argv) {
     }
     logprintf("--indep-pairwise (%d GPU%s): ", world, world == 1 ? "" : "s");
     fflush(stdout);
+    const double t_load0 = now_s();
 
     // ---- genotype rows of the included variants -> engines.  All-founder files go straight from the
     // mapping; otherwise the founder columns are gathered on the host first (CopyNyparrNonemptySubset,
@@ -864,6 +875,7 @@ int main(int argc, char** argv) {
       }
       k += run;
     }
+    const double t_load1 = now_s();
     std::vector<std::vector<uint64_t>> part(world, std::vector<uint64_t>(removed.size(), 0));
     std::vector<int> rcs(world, 0);
     std::vector<std::thread> th;
@@ -885,6 +897,12 @@ int main(int argc, char** argv) {
       for (size_t w = 0; w < removed.size(); ++w) {
         removed[w] |= part[r][w];
       }
+    }
+    if (A.timing) {
+      ldp_counters c;
+      ldp_get_counters(eng[0], &c);
+      logprintf("\n[timing] setup+parse %.3f s | genotype load (file -> HBM bit-planes) %.3f s | run %.3f s (pair kernel %.1f ms, replay %.1f ms; %llu candidate pairs)\n",
+                t_load0 - t_begin, t_load1 - t_load0, now_s() - t_load1, c.ms_pair_kernel, c.ms_replay, static_cast<unsigned long long>(c.candidate_pairs));
     }
   }
   uint32_t removed_ct = 0;
