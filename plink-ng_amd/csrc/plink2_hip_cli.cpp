@@ -407,32 +407,90 @@ struct Variants {
   std::vector<uint32_t> bp;
 };
 
+// whole file -> memory; the variant/sample tables are a few tens of MB even at 10M variants
+std::string slurp(const std::string& path) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) {
+    die(2, "Error: Failed to open %s.\n", path.c_str());
+  }
+  std::string buf;
+  fseek(f, 0, SEEK_END);
+  const long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  buf.resize(sz > 0 ? static_cast<size_t>(sz) : 0);
+  if (sz > 0 && fread(&buf[0], 1, buf.size(), f) != buf.size()) {
+    die(2, "Error: Failed to read %s.\n", path.c_str());
+  }
+  fclose(f);
+  return buf;
+}
+
+struct Tok {
+  const char* p;
+  size_t n;
+  bool eq(const char* s) const { return strlen(s) == n && !memcmp(p, s, n); }
+};
+
+// split [p, e) on spaces/tabs into at most `cap` tokens; returns the token count (capped)
+inline int tokenize(const char* p, const char* e, Tok* out, int cap) {
+  int n = 0;
+  while (p < e) {
+    while (p < e && (*p == ' ' || *p == '\t' || *p == '\r')) {
+      ++p;
+    }
+    if (p >= e) {
+      break;
+    }
+    const char* q = p;
+    while (q < e && *q != ' ' && *q != '\t' && *q != '\r') {
+      ++q;
+    }
+    if (n < cap) {
+      out[n].p = p;
+      out[n].n = static_cast<size_t>(q - p);
+    }
+    ++n;
+    p = q;
+  }
+  return n;
+}
+
 void load_variants(const Args& A, Variants* V) {
   const bool pvar = !A.pvar.empty();
   const std::string& path = pvar ? A.pvar : A.bim;
   if (path.size() > 4 && path.compare(path.size() - 4, 4, ".zst") == 0) {
     die(9, "Error: zstd-compressed .pvar is not supported yet by plink2-hip.\n");
   }
-  std::ifstream in(path);
-  if (!in) {
-    die(2, "Error: Failed to open %s.\n", path.c_str());
-  }
-  std::string line;
+  const std::string buf = slurp(path);
   bool header = false;
   int c_chrom = 0, c_pos = 3, c_id = 1, c_alt = -1;
-  while (std::getline(in, line)) {
-    if (line.empty()) {
+  constexpr int kCap = 64;
+  Tok t[kCap];
+  const char* p = buf.data();
+  const char* end = p + buf.size();
+  size_t guess = std::count(buf.begin(), buf.end(), '\n') + 1;
+  V->chrom.reserve(guess);
+  V->id.reserve(guess);
+  V->bp.reserve(guess);
+  while (p < end) {
+    const char* eol = static_cast<const char*>(memchr(p, '\n', static_cast<size_t>(end - p)));
+    if (!eol) {
+      eol = end;
+    }
+    const char* line = p;
+    p = (eol < end) ? eol + 1 : end;
+    if (line == eol) {
       continue;
     }
-    if (line[0] == '#') {
-      if (line.rfind("#CHROM", 0) == 0) {
-        std::vector<std::string> cols = split_ws(line);
+    if (*line == '#') {
+      if ((eol - line) >= 6 && !memcmp(line, "#CHROM", 6)) {
+        const int nc = std::min(tokenize(line, eol, t, kCap), kCap);
         c_chrom = 0;
         c_pos = c_id = -1;
-        for (size_t c = 0; c < cols.size(); ++c) {
-          if (cols[c] == "POS") c_pos = static_cast<int>(c);
-          if (cols[c] == "ID") c_id = static_cast<int>(c);
-          if (cols[c] == "ALT") c_alt = static_cast<int>(c);
+        for (int c = 0; c < nc; ++c) {
+          if (t[c].eq("POS")) c_pos = c;
+          if (t[c].eq("ID")) c_id = c;
+          if (t[c].eq("ALT")) c_alt = c;
         }
         if (c_pos < 0 || c_id < 0) {
           die(3, "Error: %s header lacks POS/ID.\n", path.c_str());
@@ -441,26 +499,38 @@ void load_variants(const Args& A, Variants* V) {
       }
       continue;
     }
-    std::vector<std::string> t = split_ws(line);
+    const int nt = tokenize(line, eol, t, kCap);
+    if (!nt) {
+      continue;
+    }
     if (!header) {
       // .bim layout: chrom id cM bp A1 A2 (5-column variant without cM also accepted by plink2)
-      if (t.size() == 5) {
+      if (nt == 5) {
         c_pos = 2;
-      } else if (t.size() < 6) {
+      } else if (nt < 6) {
         die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
       }
     }
-    if (static_cast<size_t>(std::max(std::max(c_chrom, c_pos), c_id)) >= t.size()) {
+    if (std::max(std::max(c_chrom, c_pos), c_id) >= std::min(nt, kCap)) {
       die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
     }
-    if (c_alt >= 0 && static_cast<size_t>(c_alt) < t.size() && t[c_alt].find(',') != std::string::npos) {
-      die(9, "Error: multiallelic variants are not supported yet by plink2-hip ('%s').\n", t[c_id].c_str());
+    if (c_alt >= 0 && c_alt < std::min(nt, kCap) && memchr(t[c_alt].p, ',', t[c_alt].n)) {
+      die(9, "Error: multiallelic variants are not supported yet by plink2-hip ('%.*s').\n", static_cast<int>(t[c_id].n), t[c_id].p);
     }
-    V->chrom.push_back(t[c_chrom]);
-    V->id.push_back(t[c_id]);
-    char* e;
-    const long long pos = strtoll(t[c_pos].c_str(), &e, 10);
-    if (*e || pos < 0 || pos > 0x7ffffffe) {
+    V->chrom.emplace_back(t[c_chrom].p, t[c_chrom].n);
+    V->id.emplace_back(t[c_id].p, t[c_id].n);
+    uint64_t pos = 0;
+    const Tok& tp = t[c_pos];
+    if (!tp.n || tp.n > 10) {
+      die(3, "Error: Invalid bp coordinate in %s.\n", path.c_str());
+    }
+    for (size_t k = 0; k < tp.n; ++k) {
+      if (tp.p[k] < '0' || tp.p[k] > '9') {
+        die(3, "Error: Invalid bp coordinate in %s.\n", path.c_str());
+      }
+      pos = pos * 10 + static_cast<uint64_t>(tp.p[k] - '0');
+    }
+    if (pos > 0x7ffffffe) {
       die(3, "Error: Invalid bp coordinate in %s.\n", path.c_str());
     }
     V->bp.push_back(static_cast<uint32_t>(pos));
@@ -514,8 +584,15 @@ int main(int argc, char** argv) {
   }
   logprintf("\n\n");
 
+  // the variant table parses on its own thread and the HIP runtime initialises on another while the
+  // sample file is read
+  Variants V;
+  std::thread t_variants([&]() { load_variants(A, &V); });
+  std::thread t_hip([]() { (void)ldp_device_count(); });
   std::vector<uint8_t> is_founder;
   load_samples(A, &is_founder);
+  t_variants.join();
+  t_hip.join();
   const uint32_t raw_sample_ct = static_cast<uint32_t>(is_founder.size());
   uint32_t founder_ct = 0;
   for (uint8_t f : is_founder) {
@@ -523,8 +600,6 @@ int main(int argc, char** argv) {
   }
   logprintf("%u sample%s loaded from %s (%u founder%s).\n", raw_sample_ct, raw_sample_ct == 1 ? "" : "s",
             (A.psam.empty() ? A.fam : A.psam).c_str(), founder_ct, founder_ct == 1 ? "" : "s");
-  Variants V;
-  load_variants(A, &V);
   const uint32_t raw_variant_ct = static_cast<uint32_t>(V.id.size());
   logprintf("%u variant%s loaded from %s.\n", raw_variant_ct, raw_variant_ct == 1 ? "" : "s", (A.pvar.empty() ? A.bim : A.pvar).c_str());
 
@@ -929,12 +1004,13 @@ int main(int argc, char** argv) {
     }
   }
   logprintf("Variant lists written to %s.prune.in and %s.prune.out .\n", A.out.c_str(), A.out.c_str());
-  for (ldp_engine* e : eng) {
-    ldp_destroy(e);
+  if (A.timing) {
+    logprintf("[timing] total %.3f s\n", now_s() - t_begin);
   }
-  ldp_pgen_close(pg);
   if (g_log) {
     fclose(g_log);
   }
-  return 0;
+  fflush(nullptr);
+  // everything is on disk; releasing tens of GB of device memory and unmapping the input only costs time
+  _exit(0);
 }
