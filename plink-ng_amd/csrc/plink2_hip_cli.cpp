@@ -588,11 +588,14 @@ int main(int argc, char** argv) {
   // sample file is read
   Variants V;
   std::thread t_variants([&]() { load_variants(A, &V); });
-  std::thread t_hip([]() { (void)ldp_device_count(); });
+  double t_hip_init = 0.0, t_parse = 0.0;
+  std::thread t_hip([&]() { const double t0 = now_s(); (void)ldp_device_count(); t_hip_init = now_s() - t0; });
   std::vector<uint8_t> is_founder;
   load_samples(A, &is_founder);
   t_variants.join();
+  t_parse = now_s() - t_begin;
   t_hip.join();
+  const double t_joined = now_s();
   const uint32_t raw_sample_ct = static_cast<uint32_t>(is_founder.size());
   uint32_t founder_ct = 0;
   for (uint8_t f : is_founder) {
@@ -637,6 +640,11 @@ int main(int argc, char** argv) {
     std::string cur;
     uint32_t fo = 0;
     bool first = true;
+    bool zero = false;
+    int cls = 0;
+    inc.reserve(raw_variant_ct);
+    chr_idx.reserve(raw_variant_ct);
+    bps.reserve(raw_variant_ct);
     for (uint32_t v = 0; v < raw_variant_ct; ++v) {
       if (first || V.chrom[v] != cur) {
         if (!seen_chr.insert(V.chrom[v]).second) {
@@ -647,9 +655,8 @@ int main(int argc, char** argv) {
           ++fo;
         }
         first = false;
+        cls = chrom_class(cur, A.allow_extra_chr, &zero);
       }
-      bool zero;
-      const int cls = chrom_class(cur, A.allow_extra_chr, &zero);
       if (zero && A.have_prune) {
         ++skipped;
         continue;
@@ -861,12 +868,27 @@ int main(int argc, char** argv) {
   if (subcontig_ct) {
     // unique IDs (plink2_ld.cc:2573-2592)
     {
-      std::unordered_set<std::string> ids;
-      ids.reserve(variant_ct * 2);
+      // open-addressing table of variant indices keyed by a 64-bit FNV-1a hash of the ID
+      uint32_t bits = 4;
+      while ((1ull << bits) < 2ull * variant_ct) {
+        ++bits;
+      }
+      const uint64_t mask = (1ull << bits) - 1;
+      std::vector<uint32_t> table(static_cast<size_t>(1) << bits, 0xffffffffu);
       for (uint32_t k = 0; k < variant_ct; ++k) {
-        if (!ids.insert(V.id[inc[k]]).second) {
-          die(7, "Error: --indep-pairwise requires unique variant IDs. (--set-all-var-ids and/or --rm-dup may help.)\n");
+        const std::string& id = V.id[inc[k]];
+        uint64_t h = 0xcbf29ce484222325ull;
+        for (unsigned char ch : id) {
+          h = (h ^ ch) * 0x100000001b3ull;
         }
+        uint64_t slot = (h ^ (h >> 29)) & mask;
+        while (table[slot] != 0xffffffffu) {
+          if (V.id[inc[table[slot]]] == id) {
+            die(7, "Error: --indep-pairwise requires unique variant IDs. (--set-all-var-ids and/or --rm-dup may help.)\n");
+          }
+          slot = (slot + 1) & mask;
+        }
+        table[slot] = k;
       }
     }
     std::vector<uint64_t> preferred;
@@ -893,6 +915,10 @@ int main(int argc, char** argv) {
     logprintf("--indep-pairwise (%d GPU%s): ", world, world == 1 ? "" : "s");
     fflush(stdout);
     const double t_load0 = now_s();
+    if (A.timing) {
+      logprintf("\n[timing] table parse %.3f s, HIP init %.3f s (concurrent; joined at %.3f s), tables+engine plan+ID check %.3f s\n", t_parse, t_hip_init,
+                t_joined - t_begin, t_load0 - t_joined);
+    }
 
     // ---- genotype rows of the included variants -> engines.  All-founder files go straight from the
     // mapping; otherwise the founder columns are gathered on the host first (CopyNyparrNonemptySubset,
