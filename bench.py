@@ -24,6 +24,7 @@ identical to the HIP path's on that sample.
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import tempfile
@@ -119,7 +120,9 @@ def cpu_baseline(pkg, torch, args, founder_ct, spacing, window_bp, r2):
             same = (cc.returncode == 0 and open(os.path.join(tmp, "hip.prune.out")).read() == open(os.path.join(tmp, "ref.prune.out")).read()
                     and open(os.path.join(tmp, "hip.prune.in")).read() == open(os.path.join(tmp, "ref.prune.in")).read())
             cli = {"plink2_hip_wall_s": cli_wall, "plink2_hip_files_identical": bool(same), "plink2_hip_rc": cc.returncode}
-        return {**cli, "value": cand / wall, "unit": "variant-pairs/s", "cores": cores, "kind": "reference",
+        mt = re.search(r"\((\d+) compute thread", cp.stdout)
+        used = (int(mt.group(1)) + 1) if mt else cores  # LD compute threads + the decode/main thread (plink2_ld.cc:2599-2604)
+        return {**cli, "value": cand / wall, "unit": "variant-pairs/s", "cores": used, "threads_requested": cores, "kind": "reference",
                 "sample": "%d variants x %d samples of the same generator (22 chromosomes, %d bp spacing, %d candidate pairs), "
                           "reference plink2 AVX2 end-to-end wall %.2f s incl. file load + freq pass; %s" %
                           (m, founder_ct, spacing, cand, wall, (threads_line[-1].split(":")[0].strip() if threads_line else "")),
