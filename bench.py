@@ -162,7 +162,10 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback exists for the hot path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run the RCCL path is used even for a single rank, so the exchange code is
+    # exercised on a 1-GPU box as well
+    use_dist = (world > 1) or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     founder_ct = args.samples
@@ -195,15 +198,15 @@ def main():
     def step():
         for first, ln, o in seg:
             eng.load_genotypes_device(first, ln, geno.data_ptr() + o * stride, stride, pkg.LDP_GENO_REF)
-        removed = eng.run()
-        if world > 1:
-            # the one exchange step: all_gather of the per-rank removed-bit segments (RCCL over xGMI)
-            return distmod.allgather_removed(removed, subs, owner, rank, world, m_total, device="cuda")
-        return removed
+        bm = eng.run_bitmap()  # uint64 words over all variants; only this rank's bits are set
+        if use_dist:
+            # the one exchange step: all_gather of the per-rank removed bitmaps (RCCL over xGMI), OR-ed on the device
+            return distmod.allgather_bitmaps(bm, world, device="cuda")
+        return bm
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -222,7 +225,8 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     ctr = eng.counters()
-    if world > 1:
+    removed = distmod.bitmap_to_mask(removed.cpu().numpy() if use_dist else removed, m_total)
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -276,7 +280,7 @@ def main():
                                    "sample": "measured at N=1 only"}
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -54,3 +54,22 @@ def allgather_removed(removed, subcontigs, owner, rank, world, variant_ct, devic
     out = [torch.zeros(words, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(out, mine)
     return unpack_all([t.cpu().numpy() for t in out], subcontigs, owner, variant_ct)
+
+
+def allgather_bitmaps(bitmap_u64, world, device="cpu"):
+    """The exchange bench.py times: every rank contributes its global-index removed bitmap (uint64 words, only the
+    bits of its own subcontigs set); one all_gather, then an OR over the `world` disjoint pieces on the device.
+    Returns the combined bitmap as a torch int64 tensor on `device` (no host round trip)."""
+    import torch
+    import torch.distributed as dist
+    mine = torch.from_numpy(bitmap_u64.view(np.int64)).to(device)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    acc = out[0]
+    for t in out[1:]:
+        acc = torch.bitwise_or(acc, t)
+    return acc
+
+
+def bitmap_to_mask(words, variant_ct):
+    return np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little")[:variant_ct].astype(bool)

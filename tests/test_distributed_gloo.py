@@ -55,7 +55,12 @@ def _worker(rank, world, port, case, ret):
                 owned[f0:f0 + ln] = True
         assert not (mine & ~owned).any()
         full = distmod.allgather_removed(mine, subs, owner, rank, world, m, device="cpu")
-        ret[rank] = bool(np.array_equal(full, want)) and (int(owned.sum()) > 0)
+        # the bitmap form bench.py uses
+        bm = np.zeros((m + 63) // 64 + 1, dtype=np.uint64)
+        pb = np.packbits(mine, bitorder="little")
+        bm.view(np.uint8)[:len(pb)] = pb
+        full2 = distmod.bitmap_to_mask(distmod.allgather_bitmaps(bm, world, device="cpu").numpy(), m)
+        ret[rank] = bool(np.array_equal(full, want)) and bool(np.array_equal(full2, want)) and (int(owned.sum()) > 0)
         eng.close()
     finally:
         dist.destroy_process_group()
