@@ -1,0 +1,138 @@
+"""BASELINE.json's full single-GPU size (config 2: 50,000 samples x 1,000,000 variants, --indep-pairwise 200kb 0.5)
+is far beyond what the CPU oracle finishes in seconds, so parity at that size goes through size-independent
+properties of the algorithm:
+  * idempotence -- after a kb-window prune no candidate pair of kept variants exceeds the threshold, so pruning the
+    kept set again removes nothing;
+  * shard invariance -- the union of the per-shard prune sets (LPT over subcontigs) equals the unsharded set;
+  * input-form invariance -- raw REF-coded input and .bed-coded input of the same data give the same set;
+  * pair symmetry -- swapping the roles of the two variants swaps (sum1,ssq1)<->(sum2,ssq2) and keeps nm and dot;
+and a sample of the 6.9e7 candidate pairs is checked against the oracle's integers directly.
+Config-3's sample count (500,000) is covered on a short table against the oracle."""
+import numpy as np
+import pytest
+
+import ldtools as T
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20260925 + 2
+
+
+def layout(m):
+    import bench
+    return bench.genome_layout(m, 1, 2875)
+
+
+@pytest.fixture(scope="module")
+def full(gpu_pkg):
+    import torch
+    pkg = gpu_pkg
+    n, m = 50000, 1000000
+    stride = (n + 3) // 4
+    geno = torch.empty((m, stride), dtype=torch.uint8, device="cuda:0")
+    pkg.synth_genotypes_device(SEED, 0, m, n, 0.0, geno.data_ptr(), stride)
+    torch.cuda.synchronize()
+    chr_idx, bps = layout(m)
+    eng = pkg.LdPruneEngine(n, pkg.kb_window(200), 1, True, 0.5, device=0)
+    eng.set_variants(chr_idx, bps)
+    eng.load_genotypes_device(0, m, geno.data_ptr(), stride, pkg.LDP_GENO_REF)
+    removed = eng.run()
+    yield dict(pkg=pkg, n=n, m=m, stride=stride, geno=geno, chr_idx=chr_idx, bps=bps, eng=eng, removed=removed)
+    eng.close()
+
+
+def test_full_size_run_is_sane(full):
+    c = full["eng"].counters()
+    assert c["candidate_pairs"] == 68946870
+    assert 0.3 * full["m"] < full["removed"].sum() < 0.6 * full["m"]
+    assert c["pred_true"] >= full["removed"].sum() - np.count_nonzero(full["eng"].variant_recs()["flags"] & 2)
+
+
+def test_idempotent_on_kept_set(full):
+    import torch
+    pkg, n, stride = full["pkg"], full["n"], full["stride"]
+    keep = np.flatnonzero(~full["removed"])
+    sub = full["geno"].index_select(0, torch.from_numpy(keep).to("cuda:0"))
+    torch.cuda.synchronize()
+    eng = pkg.LdPruneEngine(n, pkg.kb_window(200), 1, True, 0.5, device=0)
+    eng.set_variants(full["chr_idx"][keep], full["bps"][keep])
+    eng.load_genotypes_device(0, len(keep), sub.data_ptr(), stride, pkg.LDP_GENO_REF)
+    again = eng.run()
+    eng.close()
+    assert not again.any(), "%d variants removed on the second pass" % again.sum()
+
+
+def test_shard_union_equals_unsharded(full):
+    pkg, n, m, stride = full["pkg"], full["n"], full["m"], full["stride"]
+    union = np.zeros(m, dtype=bool)
+    for rank in range(3):
+        eng = pkg.LdPruneEngine(n, pkg.kb_window(200), 1, True, 0.5, device=0)
+        eng.set_variants(full["chr_idx"], full["bps"])
+        owner = eng.set_shard(rank, 3)
+        for (ln, first), o in zip(eng.subcontigs(), owner):
+            if o == rank:
+                eng.load_genotypes_device(first, ln, full["geno"].data_ptr() + first * stride, stride, pkg.LDP_GENO_REF)
+        part = eng.run()
+        assert not (part & union).any()
+        union |= part
+        eng.close()
+    assert np.array_equal(union, full["removed"])
+
+
+def test_bed_coded_input_gives_the_same_set(full):
+    import torch
+    pkg, n, stride = full["pkg"], full["n"], full["stride"]
+    m = 200000  # first chromosomes only: keeps the recoded copy small
+    lut = torch.tensor([sum([3, 2, 0, 1][(b >> (2 * k)) & 3] << (2 * k) for k in range(4)) for b in range(256)], dtype=torch.uint8, device="cuda:0")
+    bed = lut[full["geno"][:m].long()]
+    torch.cuda.synchronize()
+    out = []
+    for rows, enc in ((full["geno"][:m], pkg.LDP_GENO_REF), (bed, pkg.LDP_GENO_BED)):
+        eng = pkg.LdPruneEngine(n, pkg.kb_window(200), 1, True, 0.5, device=0)
+        eng.set_variants(full["chr_idx"][:m], full["bps"][:m])
+        eng.load_genotypes_device(0, m, rows.data_ptr(), stride, enc)
+        out.append(eng.run())
+        eng.close()
+    assert np.array_equal(out[0], out[1])
+
+
+def test_pair_symmetry_and_oracle_sample(full):
+    eng, n = full["eng"], full["n"]
+    rng = np.random.default_rng(3)
+    j = rng.integers(100, full["m"], size=40)
+    i = j - rng.integers(1, 60, size=40)
+    ab = eng.pair_stats(i, j)
+    ba = eng.pair_stats(j, i)
+    assert np.array_equal(ab["nm"], ba["nm"]) and np.array_equal(ab["dot"], ba["dot"])
+    assert np.array_equal(ab["sum1"], ba["sum2"]) and np.array_equal(ab["ssq1"], ba["ssq2"])
+    # oracle on the same rows (fetched back from the device)
+    rows = np.unique(np.concatenate([i, j]))
+    host = full["geno"][rows].cpu().numpy()
+    raw = T.unpack_2bit(np.ascontiguousarray(np.pad(host, ((0, 0), (0, (-host.shape[1]) % 8)))).view(np.uint64), n)
+    inv, mf, _ = T.oracle_prepare(raw)
+    hom, r2h, vaggs = T.oracle_split(inv, n)
+    pos = {int(v): k for k, v in enumerate(rows)}
+    for k in range(len(i)):
+        st = T.oracle_pair_stats(hom, r2h, vaggs, n, pos[int(i[k])], pos[int(j[k])])
+        assert tuple(int(x) for x in ab[k]) == st.astuple()
+    assert np.array_equal(eng.maj_freqs()[rows], mf)
+
+
+def test_config3_sample_count_against_oracle(gpu_pkg):
+    """N = 500,000 (configs 3-5), windows wider than one block's 128 distances, complete and incomplete data."""
+    pkg = gpu_pkg
+    n, m = 500000, 260
+    for miss, order in ((0.0, 2), (0.02, 1)):
+        rows = pkg.synth_genotypes_host(7, 0, m, n, miss)
+        raw = T.unpack_2bit(np.ascontiguousarray(np.pad(rows, ((0, 0), (0, (-rows.shape[1]) % 8)))).view(np.uint64), n)
+        chr_idx = np.zeros(m, dtype=np.uint32)
+        bps = (1000 + 290 * np.arange(m)).astype(np.uint32)
+        inv, mf, _ = T.oracle_prepare(raw)
+        want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 50000, 1, True, 0.2, order)
+        eng = pkg.LdPruneEngine(n, 50000, 1, True, 0.2, order=order, device=0)
+        eng.set_variants(chr_idx, bps)
+        eng.load_genotypes_host(0, rows, pkg.LDP_GENO_REF)
+        got = eng.run()
+        assert eng.counters()["window_max"] > 128
+        eng.close()
+        assert np.array_equal(got, want)
