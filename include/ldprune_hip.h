@@ -189,6 +189,11 @@ int ldp_pgen_info(const ldp_pgen* p, uint32_t* variant_ct, uint32_t* sample_ct, 
 const void* ldp_pgen_direct_rows(const ldp_pgen* p, uint64_t* stride_bytes);
 /* decode rows [first_variant, first_variant+n) into out_rows; 64k-variant blocks decode on up to `threads` host threads (0 = all) */
 int ldp_pgen_read(ldp_pgen* p, uint32_t first_variant, uint32_t n, void* out_rows, uint64_t stride_bytes, uint32_t threads);
+/* Multiallelic hard-call track (pgen_spec.tex:469-540; what Get1Multiallelic, pgenlib_read.cc:5417, consumes):
+ * per-sample allele index pairs of one variant, allele_lo <= allele_hi, 0 = REF, k = ALTk, 255 = missing.
+ * alt_ct = number of ALT alleles in the .pvar (<= 254).  Works for biallelic records too. */
+int ldp_pgen_variant_is_multiallelic(const ldp_pgen* p, uint32_t variant);
+int ldp_pgen_read_alleles(ldp_pgen* p, uint32_t variant, uint32_t alt_ct, uint8_t* allele_lo, uint8_t* allele_hi);
 const char* ldp_pgen_last_error(const ldp_pgen* p);
 void ldp_pgen_close(ldp_pgen* p);
 

@@ -78,6 +78,7 @@ CABI_SYMBOLS = [
     "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
     "ldp_set_variants_matrix", "ldp_r2_unphased_rows",
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
+    "ldp_pgen_variant_is_multiallelic", "ldp_pgen_read_alleles",
 ]
 
 
@@ -171,6 +172,8 @@ def lib():
     L.ldp_pgen_direct_rows.argtypes = [vp, u64p]
     L.ldp_pgen_direct_rows.restype = ctypes.c_void_p
     L.ldp_pgen_read.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.c_uint32]
+    L.ldp_pgen_variant_is_multiallelic.argtypes = [vp, ctypes.c_uint32]
+    L.ldp_pgen_read_alleles.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8)]
     L.ldp_pgen_last_error.argtypes = [vp]
     L.ldp_pgen_last_error.restype = ctypes.c_char_p
     L.ldp_pgen_close.argtypes = [vp]
@@ -223,6 +226,19 @@ class PgenFile:
         if rc != LDP_OK:
             raise LdpError(rc, self._L.ldp_pgen_last_error(self._h).decode())
         return out
+
+    def read_alleles(self, variant, alt_ct):
+        """(allele_lo, allele_hi) uint8 arrays over samples: 0 REF, k ALTk, 255 missing."""
+        lo = np.zeros(self.sample_ct, dtype=np.uint8)
+        hi = np.zeros(self.sample_ct, dtype=np.uint8)
+        rc = self._L.ldp_pgen_read_alleles(self._h, variant, alt_ct, lo.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                           hi.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+        if rc != LDP_OK:
+            raise LdpError(rc, self._L.ldp_pgen_last_error(self._h).decode())
+        return lo, hi
+
+    def is_multiallelic(self, variant):
+        return bool(self._L.ldp_pgen_variant_is_multiallelic(self._h, variant))
 
     def close(self):
         if self._h:

@@ -138,7 +138,7 @@ inline void invert_row(uint8_t* row, uint64_t nbytes) {
 }
 
 // Decode one main-track record into `row` (rec_bytes, trailing bits zero).  ldbase = most recent non-LD row.
-bool decode_record(const ldp_pgen* P, uint32_t v, const uint8_t* ldbase, uint8_t* row) {
+bool decode_record(const ldp_pgen* P, uint32_t v, const uint8_t* ldbase, uint8_t* row, const uint8_t** main_track_end = nullptr) {
   const uint32_t type = P->vrtype[v] & 7;
   Cursor c{P->map + P->fpos[v], P->map + P->fpos[v + 1]};
   const uint64_t nb = P->rec_bytes;
@@ -216,7 +216,63 @@ bool decode_record(const ldp_pgen* P, uint32_t v, const uint8_t* ldbase, uint8_t
   if (rem) {
     row[nb - 1] &= static_cast<uint8_t>((1u << (2 * rem)) - 1);
   }
+  if (main_track_end) {
+    if (type == 0) {
+      c.p += nb;
+    }
+    *main_track_end = c.p;
+  }
   return true;
+}
+
+// Difflist that carries sample IDs only (no 2-bit values component), pgen_spec.tex:367-398.
+bool read_id_difflist(Cursor& c, uint32_t sample_ct, std::vector<uint32_t>* ids) {
+  ids->clear();
+  const uint32_t L = c.varint();
+  if (!c.ok || L > sample_ct) {
+    return false;
+  }
+  if (!L) {
+    return true;
+  }
+  const uint32_t G = (L + 63) / 64;
+  const uint32_t idw = (sample_ct <= 256) ? 1 : ((sample_ct <= 65536) ? 2 : ((sample_ct <= 16777216) ? 3 : 4));
+  const uint8_t* first_ids = c.p;
+  if (!c.skip(static_cast<uint64_t>(G) * idw) || !c.skip(G - 1)) {
+    return false;
+  }
+  ids->reserve(L);
+  for (uint32_t g = 0; g < G; ++g) {
+    uint32_t id = 0;
+    memcpy(&id, first_ids + static_cast<uint64_t>(g) * idw, idw);
+    const uint32_t kend = std::min(L, (g + 1) * 64);
+    for (uint32_t k = g * 64; k < kend; ++k) {
+      if (k != g * 64) {
+        id += c.varint();
+        if (!c.ok) {
+          return false;
+        }
+      }
+      if (id >= sample_ct) {
+        return false;
+      }
+      ids->push_back(id);
+    }
+  }
+  return true;
+}
+
+inline uint32_t packed_get(const uint8_t* base, uint64_t idx, uint32_t width_bits) {
+  if (!width_bits) {
+    return 0;
+  }
+  if (width_bits >= 8) {
+    uint32_t v = 0;
+    memcpy(&v, base + idx * (width_bits / 8), width_bits / 8);
+    return v;
+  }
+  const uint64_t bit = idx * width_bits;
+  return (base[bit >> 3] >> (bit & 7)) & ((1u << width_bits) - 1);
 }
 
 }  // namespace
@@ -431,6 +487,178 @@ int ldp_pgen_read(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_row
   }
   if (bad.load()) {
     return pfail(P, LDP_ERR_INVALID, "malformed variant record in .pgen file");
+  }
+  return LDP_OK;
+}
+
+int ldp_pgen_variant_is_multiallelic(const ldp_pgen* P, uint32_t variant) {
+  if (!P || variant >= P->variant_ct || P->mode != 0x10) {
+    return 0;
+  }
+  return (P->vrtype[variant] & 8) ? 1 : 0;
+}
+
+// Per-sample allele pairs of one variant (multiallelic hard-call track, pgen_spec.tex:469-540): allele_lo[s] <=
+// allele_hi[s] are allele indices (0 = REF, k = ALTk), 255/255 = missing.  alt_ct = number of ALT alleles the
+// variant has in the .pvar (<= 254 supported).
+int ldp_pgen_read_alleles(ldp_pgen* P, uint32_t variant, uint32_t alt_ct, uint8_t* allele_lo, uint8_t* allele_hi) {
+  if (!P || !allele_lo || !allele_hi) {
+    return LDP_ERR_INVALID;
+  }
+  if (variant >= P->variant_ct || alt_ct < 1 || alt_ct > 254) {
+    return pfail(P, LDP_ERR_INVALID, "variant index / ALT allele count out of range");
+  }
+  const uint32_t n = P->sample_ct;
+  std::vector<uint8_t> row(P->rec_bytes + 8, 0);
+  const uint8_t* aux = nullptr;
+  bool multi = false;
+  if (P->mode == 0x01 || P->mode == 0x02) {
+    int rc = ldp_pgen_read(P, variant, 1, row.data(), P->rec_bytes, 1);
+    if (rc) {
+      return rc;
+    }
+    if (P->mode == 0x01) {  // .bed -> pgen codes
+      static const uint8_t conv[4] = {2, 3, 1, 0};
+      for (uint32_t s = 0; s < n; ++s) {
+        const uint32_t code = (row[s >> 2] >> (2 * (s & 3))) & 3;
+        set_code(row.data(), s, conv[code]);
+      }
+    }
+  } else {
+    // walk from the LD base like ldp_pgen_read does, keeping the end of the main track of `variant`
+    const uint32_t blk_first = (variant / kBlockVariants) * kBlockVariants;
+    uint32_t start = variant;
+    while (start > blk_first && ((P->vrtype[start] & 6) == 2)) {
+      --start;
+    }
+    std::vector<uint8_t> base(P->rec_bytes + 8, 0);
+    bool have_base = false;
+    for (uint32_t v = start; v <= variant; ++v) {
+      const bool is_ld = ((P->vrtype[v] & 6) == 2);
+      if (v < variant && is_ld) {
+        continue;
+      }
+      if (!decode_record(P, v, have_base ? base.data() : nullptr, row.data(), (v == variant) ? &aux : nullptr)) {
+        return pfail(P, LDP_ERR_INVALID, "malformed variant record in .pgen file");
+      }
+      if (!is_ld) {
+        memcpy(base.data(), row.data(), P->rec_bytes);
+        have_base = true;
+      }
+    }
+    multi = (P->vrtype[variant] & 8) != 0;
+  }
+  // main track: 0 = REF/REF, 1 = REF/ALT1, 2 = ALT1/ALT1, 3 = missing
+  std::vector<uint32_t> cat1, cat2;
+  for (uint32_t s = 0; s < n; ++s) {
+    const uint32_t code = (row[s >> 2] >> (2 * (s & 3))) & 3;
+    switch (code) {
+      case 0: allele_lo[s] = 0; allele_hi[s] = 0; break;
+      case 1: allele_lo[s] = 0; allele_hi[s] = 1; cat1.push_back(s); break;
+      case 2: allele_lo[s] = 1; allele_hi[s] = 1; cat2.push_back(s); break;
+      default: allele_lo[s] = 255; allele_hi[s] = 255; break;
+    }
+  }
+  if (!multi) {
+    return LDP_OK;
+  }
+  if (alt_ct < 2) {
+    return pfail(P, LDP_ERR_INVALID, "record carries multiallelic hard-calls but the variant has one ALT allele");
+  }
+  Cursor c{aux, P->map + P->fpos[variant + 1]};
+  if (c.p >= c.end) {
+    return pfail(P, LDP_ERR_INVALID, "truncated multiallelic track");
+  }
+  const uint32_t fmt = *c.p++;
+  const uint32_t fmt1 = fmt & 15, fmt2 = fmt >> 4;
+  std::vector<uint32_t> ids;
+  // ---- category 1 patch set: REF/ALTx with x >= 2
+  if (fmt1 != 15) {
+    std::vector<uint32_t> patched;  // sample ids
+    if (fmt1 == 0) {
+      const uint64_t nbytes = (cat1.size() + 7) / 8;
+      const uint8_t* bits = c.p;
+      if (!c.skip(nbytes)) {
+        return pfail(P, LDP_ERR_INVALID, "truncated multiallelic track");
+      }
+      for (size_t k = 0; k < cat1.size(); ++k) {
+        if ((bits[k >> 3] >> (k & 7)) & 1) {
+          patched.push_back(cat1[k]);
+        }
+      }
+    } else if (fmt1 == 1) {
+      if (!read_id_difflist(c, n, &patched)) {
+        return pfail(P, LDP_ERR_INVALID, "malformed multiallelic difflist");
+      }
+    } else {
+      return pfail(P, LDP_ERR_UNSUPPORTED, "reserved multiallelic patch format");
+    }
+    const uint32_t w = (alt_ct == 2) ? 0 : ((alt_ct == 3) ? 1 : ((alt_ct <= 5) ? 2 : ((alt_ct <= 17) ? 4 : 8)));
+    const uint8_t* vals = c.p;
+    if (!c.skip((patched.size() * w + 7) / 8)) {
+      return pfail(P, LDP_ERR_INVALID, "truncated multiallelic track");
+    }
+    for (size_t k = 0; k < patched.size(); ++k) {
+      const uint32_t s = patched[k];
+      if (s >= n || allele_hi[s] != 1 || allele_lo[s] != 0) {
+        return pfail(P, LDP_ERR_INVALID, "multiallelic patch does not match the main track");
+      }
+      allele_hi[s] = static_cast<uint8_t>(2 + packed_get(vals, k, w));
+    }
+  }
+  // ---- category 2 patch set: ALTx/ALTy other than ALT1/ALT1
+  if (fmt2 != 15) {
+    std::vector<uint32_t> patched;
+    if (fmt2 == 0) {
+      const uint64_t nbytes = (cat2.size() + 7) / 8;
+      const uint8_t* bits = c.p;
+      if (!c.skip(nbytes)) {
+        return pfail(P, LDP_ERR_INVALID, "truncated multiallelic track");
+      }
+      for (size_t k = 0; k < cat2.size(); ++k) {
+        if ((bits[k >> 3] >> (k & 7)) & 1) {
+          patched.push_back(cat2[k]);
+        }
+      }
+    } else if (fmt2 == 1) {
+      if (!read_id_difflist(c, n, &patched)) {
+        return pfail(P, LDP_ERR_INVALID, "malformed multiallelic difflist");
+      }
+    } else {
+      return pfail(P, LDP_ERR_UNSUPPORTED, "reserved multiallelic patch format");
+    }
+    if (alt_ct == 2) {
+      const uint8_t* bits = c.p;
+      if (!c.skip((patched.size() + 7) / 8)) {
+        return pfail(P, LDP_ERR_INVALID, "truncated multiallelic track");
+      }
+      for (size_t k = 0; k < patched.size(); ++k) {
+        const uint32_t s = patched[k];
+        if (s >= n || allele_lo[s] != 1 || allele_hi[s] != 1) {
+          return pfail(P, LDP_ERR_INVALID, "multiallelic patch does not match the main track");
+        }
+        if ((bits[k >> 3] >> (k & 7)) & 1) {
+          allele_lo[s] = 2;
+          allele_hi[s] = 2;
+        } else {
+          allele_hi[s] = 2;
+        }
+      }
+    } else {
+      const uint32_t w = (alt_ct <= 4) ? 2 : ((alt_ct <= 16) ? 4 : 8);
+      const uint8_t* vals = c.p;
+      if (!c.skip((patched.size() * 2 * w + 7) / 8)) {
+        return pfail(P, LDP_ERR_INVALID, "truncated multiallelic track");
+      }
+      for (size_t k = 0; k < patched.size(); ++k) {
+        const uint32_t s = patched[k];
+        if (s >= n || allele_lo[s] != 1 || allele_hi[s] != 1) {
+          return pfail(P, LDP_ERR_INVALID, "multiallelic patch does not match the main track");
+        }
+        allele_lo[s] = static_cast<uint8_t>(1 + packed_get(vals, 2 * k, w));
+        allele_hi[s] = static_cast<uint8_t>(1 + packed_get(vals, 2 * k + 1, w));
+      }
+    }
   }
   return LDP_OK;
 }

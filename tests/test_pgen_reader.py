@@ -109,3 +109,48 @@ def test_malformed_files_are_rejected(pkg, tmp_path):
     open(bad, "wb").write(b"\x00\x01\x02")
     with pytest.raises(pkg.LdpError):
         pkg.PgenFile(bad)
+
+
+# ---------------------------------------------------------------- multiallelic hard-call track
+def make_multiallelic_vcf(path, m, n, seed, max_alt=5, missing=0.03):
+    """VCF with 1..max_alt ALT alleles per site; returns (alt_ct[m], lo[m,n], hi[m,n]) with 255 = missing."""
+    rng = np.random.default_rng(seed)
+    alt_ct = rng.integers(1, max_alt + 1, size=m)
+    alt_ct[:4] = [1, 2, 3, min(max_alt, 5)]
+    lo = np.zeros((m, n), dtype=np.uint8)
+    hi = np.zeros((m, n), dtype=np.uint8)
+    bases = ["C", "G", "T", "AC", "AG", "AT", "ACC", "AGG", "ATT", "ACCC", "AGGG", "ATTT", "ACCCC", "AGGGG", "ATTTT", "ACCCCC", "AGGGGG", "ATTTTT"]
+    with open(path, "w") as f:
+        f.write("##fileformat=VCFv4.2\n##contig=<ID=1>\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"GT\">\n")
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join("s%d" % s for s in range(n)) + "\n")
+        for v in range(m):
+            k = int(alt_ct[v])
+            # allele frequencies: sometimes an ALT allele is the most common one
+            w = rng.dirichlet(np.ones(k + 1) * (0.6 if v % 3 else 2.0))
+            a = rng.choice(k + 1, size=n, p=w)
+            b = rng.choice(k + 1, size=n, p=w)
+            l, h = np.minimum(a, b), np.maximum(a, b)
+            miss = rng.random(n) < missing
+            l = np.where(miss, 255, l).astype(np.uint8)
+            h = np.where(miss, 255, h).astype(np.uint8)
+            if v == 5 and k >= 2:      # a declared-multiallelic site where only REF and ALT1 occur
+                l = np.where(l == 255, 255, np.minimum(l, 1)).astype(np.uint8)
+                h = np.where(h == 255, 255, np.minimum(h, 1)).astype(np.uint8)
+            lo[v], hi[v] = l, h
+            gts = ["./." if l[s] == 255 else "%d/%d" % (l[s], h[s]) for s in range(n)]
+            f.write("1\t%d\tsnp%d\tA\t%s\t.\t.\t.\tGT\t%s\n" % (1000 + 37 * v, v, ",".join(bases[:k]), "\t".join(gts)))
+    return alt_ct, lo, hi
+
+
+@pytest.mark.skipif(not T.have_ref(), reason="reference binary not built")
+@pytest.mark.parametrize("m,n,seed,max_alt", [(120, 90, 1, 2), (150, 300, 2, 5), (80, 70, 3, 17), (60, 40, 4, 18)])
+def test_multiallelic_track_against_vcf(pkg, tmp_path, m, n, seed, max_alt):
+    alt_ct, lo, hi = make_multiallelic_vcf(str(tmp_path / "m.vcf"), m, n, seed, max_alt=max_alt)
+    cp = T.run_ref(["--vcf", "m.vcf", "--make-pgen", "--out", "mv"], str(tmp_path))
+    assert cp.returncode == 0, cp.stdout
+    f = pkg.PgenFile(str(tmp_path / "mv.pgen"))
+    assert f.mode == 0x10 and f.has_multiallelic
+    for v in range(m):
+        glo, ghi = f.read_alleles(v, int(alt_ct[v]))
+        assert np.array_equal(glo, lo[v]) and np.array_equal(ghi, hi[v]), v
+    f.close()
