@@ -11,8 +11,9 @@
 // (2.0/plink2_psam.cc:804-813), .bim/.pvar parsing, chromosome-0 stripping (StripUnplacedK,
 // plink2_ld.cc:113-164), the sorted-positions and unique-ID checks (plink2.cc:2926, plink2_ld.cc:2573-2592),
 // the <50-founders guard (plink2.cc:2063-2071) and the output writer.
+// Multiallelic variants are collapsed major-vs-rest on the host (Get1Multiallelic semantics).
 // Not yet supported (reported as such, never silently mis-handled): chrX/chrY/MT/haploid contigs, .pvar.zst,
-// multiallelic variants, external-index .pgen (modes 0x20/0x21).
+// external-index .pgen (modes 0x20/0x21), more than 254 ALT alleles.
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <fcntl.h>
@@ -405,6 +406,7 @@ void load_samples(const Args& A, std::vector<uint8_t>* is_founder) {
 struct Variants {
   std::vector<std::string> chrom, id;
   std::vector<uint32_t> bp;
+  std::vector<uint8_t> alt_ct;  // number of ALT alleles (1 for biallelic / .bim), capped at 255
 };
 
 // whole file -> memory; the variant/sample tables are a few tens of MB even at 10M variants
@@ -514,9 +516,14 @@ void load_variants(const Args& A, Variants* V) {
     if (std::max(std::max(c_chrom, c_pos), c_id) >= std::min(nt, kCap)) {
       die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
     }
-    if (c_alt >= 0 && c_alt < std::min(nt, kCap) && memchr(t[c_alt].p, ',', t[c_alt].n)) {
-      die(9, "Error: multiallelic variants are not supported yet by plink2-hip ('%.*s').\n", static_cast<int>(t[c_id].n), t[c_id].p);
+    uint32_t alts = 1;
+    if (c_alt >= 0 && c_alt < std::min(nt, kCap)) {
+      alts += static_cast<uint32_t>(std::count(t[c_alt].p, t[c_alt].p + t[c_alt].n, ','));
     }
+    if (alts > 254) {
+      die(9, "Error: variant '%.*s' has more than 254 ALT alleles, which plink2-hip does not support.\n", static_cast<int>(t[c_id].n), t[c_id].p);
+    }
+    V->alt_ct.push_back(static_cast<uint8_t>(alts));
     V->chrom.emplace_back(t[c_chrom].p, t[c_chrom].n);
     V->id.emplace_back(t[c_id].p, t[c_id].n);
     uint64_t pos = 0;
@@ -569,6 +576,91 @@ int chrom_class(const std::string& name_in, bool allow_extra, bool* is_zero) {
     return 0;
   }
   return allow_extra ? 0 : 2;
+}
+
+// Multiallelic variant on the host (rare: a few percent of sites): founder allele counts -> allele frequencies in
+// the reference's arithmetic (ComputeAlleleFreqs, plink2_filter.cc:2113-2153: freq[a] = count[a] * (1/total), 1/k
+// when nothing is observed) -> major allele (GetMajIdx / GetMajIdxMulti, plink2_common.h:559-567,
+// plink2_common.cc:1042-1070) -> its frequency (GetAlleleFreq, plink2_common.h:584-593) -> the 2-bit row
+// PgrGetInv1 would return for that allele (pgenlib_read.cc:5544-5563): copies of non-major alleles, 3 = missing.
+void multiallelic_inverse_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_ct, const std::vector<uint32_t>& founder_idx,
+                              std::vector<uint8_t>* lo, std::vector<uint8_t>* hi, uint8_t* out_row, uint64_t out_rec, double* maj_freq) {
+  if (ldp_pgen_read_alleles(pg, raw_variant, alt_ct, lo->data(), hi->data())) {
+    die(3, "\nError: %s\n", ldp_pgen_last_error(pg));
+  }
+  const uint32_t allele_ct = alt_ct + 1;
+  std::vector<uint64_t> cnt(allele_ct, 0);
+  for (uint32_t s : founder_idx) {
+    if ((*lo)[s] != 255) {
+      if ((*lo)[s] >= allele_ct || (*hi)[s] >= allele_ct) {
+        die(3, "\nError: allele index out of range in multiallelic record.\n");
+      }
+      ++cnt[(*lo)[s]];
+      ++cnt[(*hi)[s]];
+    }
+  }
+  uint64_t tot = 0;
+  for (uint64_t c : cnt) {
+    tot += c;
+  }
+  std::vector<double> freq(allele_ct - 1);
+  if (!tot) {
+    const double recip = 1.0 / static_cast<double>(allele_ct);
+    for (double& f : freq) {
+      f = recip;
+    }
+  } else {
+    const double tot_recip = 1.0 / static_cast<double>(tot);
+    for (uint32_t a = 0; a + 1 < allele_ct; ++a) {
+      freq[a] = static_cast<double>(cnt[a]) * tot_recip;
+    }
+  }
+  uint32_t maj;
+  if (freq[0] >= 0.5) {
+    maj = 0;
+  } else if (allele_ct == 2) {
+    maj = 1;
+  } else {
+    const double alt1_freq = freq[1];
+    if (alt1_freq >= 0.5) {
+      maj = 1;
+    } else {
+      const double ref_freq = freq[0];
+      maj = 1;
+      double max_freq = alt1_freq;
+      if (ref_freq >= alt1_freq) {
+        maj = 0;
+        max_freq = ref_freq;
+      }
+      double tot_nonlast = ref_freq + alt1_freq;
+      for (uint32_t a = 2; a + 1 < allele_ct; ++a) {
+        if (freq[a] > max_freq) {
+          maj = a;
+          max_freq = freq[a];
+        }
+        tot_nonlast += freq[a];
+      }
+      if (max_freq + tot_nonlast < 1.0 - kSmallEpsilon) {
+        maj = allele_ct - 1;
+      }
+    }
+  }
+  if (maj + 1 < allele_ct) {
+    *maj_freq = freq[maj];
+  } else {
+    double last = 1.0 - freq[0];
+    for (uint32_t a = 1; a + 1 < allele_ct; ++a) {
+      last -= freq[a];
+    }
+    *maj_freq = (last > 0.0) ? last : 0.0;
+  }
+  memset(out_row, 0, out_rec);
+  uint32_t f = 0;
+  for (uint32_t s : founder_idx) {
+    const uint32_t code = ((*lo)[s] == 255) ? 3u : (static_cast<uint32_t>((*lo)[s] != maj) + static_cast<uint32_t>((*hi)[s] != maj));
+    out_row[f >> 2] |= static_cast<uint8_t>(code << (2 * (f & 3)));
+    ++f;
+  }
 }
 
 }  // namespace
@@ -625,8 +717,8 @@ int main(int argc, char** argv) {
   }
   int storage_mode = 0, encoding = LDP_GENO_REF, has_multiallelic = 0;
   ldp_pgen_info(pg, nullptr, nullptr, &storage_mode, &encoding, &has_multiallelic);
-  if (has_multiallelic) {
-    die(9, "Error: %s contains multiallelic records, which plink2-hip does not support yet.\n", gpath.c_str());
+  if (has_multiallelic && A.have_r2) {
+    die(9, "Error: %s contains multiallelic records, which --r2-unphased in plink2-hip does not support yet.\n", gpath.c_str());
   }
   uint64_t rec_bytes = (static_cast<uint64_t>(raw_sample_ct) + 3) / 4;
   const uint8_t* direct_rows = static_cast<const uint8_t*>(ldp_pgen_direct_rows(pg, &rec_bytes));  // NULL for variable-width
@@ -926,11 +1018,9 @@ int main(int argc, char** argv) {
     const bool all_founders = (founder_ct == raw_sample_ct);
     const uint64_t out_rec = (static_cast<uint64_t>(founder_ct) + 3) / 4;
     std::vector<uint32_t> founder_idx;
-    if (!all_founders) {
-      for (uint32_t s = 0; s < raw_sample_ct; ++s) {
-        if (is_founder[s]) {
-          founder_idx.push_back(s);
-        }
+    for (uint32_t s = 0; s < raw_sample_ct; ++s) {
+      if (is_founder[s]) {
+        founder_idx.push_back(s);
       }
     }
     const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((1024ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
@@ -975,6 +1065,32 @@ int main(int argc, char** argv) {
         }
       }
       k += run;
+    }
+    // variants with more than one ALT allele are collapsed major-vs-rest on the host and overwrite their rows
+    {
+      uint32_t multi_ct = 0;
+      std::vector<uint8_t> lo(raw_sample_ct), hi(raw_sample_ct), inv_row(out_rec);
+      for (uint32_t kk = 0; kk < variant_ct; ++kk) {
+        const uint32_t alts = V.alt_ct[inc[kk]];
+        if (alts < 2) {
+          continue;
+        }
+        if (storage_mode == 0x01) {
+          die(3, "\nError: multiallelic variant in a .bim/.bed fileset.\n");
+        }
+        double mf = 0.0;
+        multiallelic_inverse_row(pg, inc[kk], alts, founder_idx, &lo, &hi, inv_row.data(), out_rec, &mf);
+        for (int r = 0; r < world; ++r) {
+          if (ldp_load_genotypes(eng[r], kk, 1, inv_row.data(), out_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) ||
+              ldp_set_maj_freqs(eng[r], kk, 1, &mf)) {
+            die(12, "\nError: %s\n", ldp_last_error(eng[r]));
+          }
+        }
+        ++multi_ct;
+      }
+      if (multi_ct && A.timing) {
+        logprintf("\n[timing] %u multiallelic variants collapsed on the host\n", multi_ct);
+      }
     }
     const double t_load1 = now_s();
     std::vector<std::vector<uint64_t>> part(world, std::vector<uint64_t>(removed.size(), 0));

@@ -161,3 +161,26 @@ def test_cli_config1_toy(gpu_pkg, cli, tmp_path):
     assert "1/2 variants removed." in cp.stdout
     assert open(str(tmp_path / "o.prune.in")).read() == "rs10\n"
     assert open(str(tmp_path / "o.prune.out")).read() == "rs0\n"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_alt,order,wargs", [(2, 2, ["30kb"]), (5, 2, ["80", "7"]), (18, 1, ["30kb"])])
+def test_cli_multiallelic_collapse_matches_reference(gpu_pkg, cli, tmp_path, max_alt, order, wargs):
+    """BASELINE config 5's mask path: missing calls + multiallelic sites (collapsed major-vs-rest like
+    PgrGetInv1 / Get1Multiallelic), imported by the reference from a VCF into a variable-width .pgen."""
+    from test_pgen_reader import make_multiallelic_vcf
+    assert T.have_ref()
+    m, n = 700, 160
+    make_multiallelic_vcf(str(tmp_path / "m.vcf"), m, n, seed=max_alt, max_alt=max_alt, missing=0.05)
+    mk = T.run_ref(["--vcf", "m.vcf", "--make-pgen", "--out", "mv"], str(tmp_path))
+    assert mk.returncode == 0, mk.stdout
+    common = ["--pfile", "mv", "--indep-pairwise"] + wargs + ["0.1"]
+    if order == 1:
+        common += ["--indep-order", "1"]
+    ref = T.run_ref(common + ["--threads", "2", "--out", "ref"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    got = run_cli(cli, common + ["--out", "hip"], str(tmp_path))
+    assert got.returncode == 0, got.stdout
+    assert filecmp.cmp(str(tmp_path / "ref.prune.in"), str(tmp_path / "hip.prune.in"), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "ref.prune.out"), str(tmp_path / "hip.prune.out"), shallow=False)
+    assert 0 < len(open(str(tmp_path / "hip.prune.out")).read().split()) < m
