@@ -81,10 +81,49 @@ __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
   return v;
 }
 
-// One block per variant.  Pass 1 converts the row to bit-planes held in registers (MAXIT plane dwords per
-// thread) while counting; after the block-wide reduction decides the major allele, pass 2 writes the planes
-// (with ref2het ^= hom when ALT is major) without touching the input again.  MAXIT == 0: rows too long
-// for the register budget are simply converted twice (second read comes from L2).
+// Two adjacent plane dwords (64 samples) from four input dwords; one 16-byte load when the row allows it.
+__device__ __forceinline__ void planes_from_words(uint32_t w0, uint32_t w1, int encoding, uint32_t founder_ct, uint32_t p, uint32_t* hom_out, uint32_t* r2h_out) {
+  uint32_t hom, r2h;
+  if (encoding == LDP_GENO_BED) {
+    hom = pack_even_bits(~(w0 ^ (w0 >> 1))) | (pack_even_bits(~(w1 ^ (w1 >> 1))) << 16);
+    r2h = pack_even_bits(w0 >> 1) | (pack_even_bits(w1 >> 1) << 16);
+  } else {
+    hom = pack_even_bits(~w0) | (pack_even_bits(~w1) << 16);
+    r2h = pack_even_bits((~w0) >> 1) | (pack_even_bits((~w1) >> 1) << 16);
+  }
+  const uint32_t first_sample = p * 32;
+  if (first_sample >= founder_ct) {
+    hom = 0;
+    r2h = 0;
+  } else if (founder_ct - first_sample < 32) {
+    const uint32_t mask = (1u << (founder_ct - first_sample)) - 1;
+    hom &= mask;
+    r2h &= mask;
+  }
+  *hom_out = hom;
+  *r2h_out = r2h;
+}
+
+__device__ __forceinline__ void convert_plane_pair(const uint8_t* row, uint32_t nbytes, bool aligned4, bool aligned16, int encoding,
+                                                   uint32_t founder_ct, uint32_t p, uint32_t (&hom)[2], uint32_t (&r2h)[2]) {
+  // p is even; input bytes [8p, 8p+16)
+  // global_load_dwordx4 only needs dword alignment on gfx950, which is all a packed row guarantees
+  typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+  (void)aligned16;
+  if (aligned4 && (8u * p + 16u <= nbytes)) {
+    const u32x4_a4 w = *reinterpret_cast<const u32x4_a4*>(row + 8u * p);
+    planes_from_words(w.x, w.y, encoding, founder_ct, p, &hom[0], &r2h[0]);
+    planes_from_words(w.z, w.w, encoding, founder_ct, p + 1, &hom[1], &r2h[1]);
+  } else {
+    convert_plane_dword(row, nbytes, aligned4, encoding, founder_ct, p, &hom[0], &r2h[0]);
+    convert_plane_dword(row, nbytes, aligned4, encoding, founder_ct, p + 1, &hom[1], &r2h[1]);
+  }
+}
+
+// One block per variant.  Pass 1 converts the row to bit-planes held in registers (MAXIT pairs of plane dwords
+// per thread, 16-byte loads) while counting; after the block-wide reduction decides the major allele, pass 2
+// writes the planes (with ref2het ^= hom when ALT is major, 8-byte stores) without touching the input again.
+// MAXIT == 0: rows too long for the register budget are simply converted twice (second read comes from L2).
 template <int THREADS, int MAXIT>
 __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
   constexpr int kWaves = THREADS / 64;
@@ -95,31 +134,31 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
   const uint8_t* row = A.geno + static_cast<uint64_t>(v) * A.stride_bytes;
   const uint32_t nbytes = (A.founder_ct + 3) / 4;
   const bool aligned4 = ((reinterpret_cast<uintptr_t>(row) & 3) == 0);
-  const uint32_t plane_dwords = A.chunks * kChunkDwords;
+  const bool aligned16 = ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
+  const uint32_t plane_dwords = A.chunks * kChunkDwords;  // even
 
-  uint32_t keep_hom[MAXIT ? MAXIT : 1], keep_r2h[MAXIT ? MAXIT : 1];
+  uint32_t keep_hom[MAXIT ? MAXIT : 1][2], keep_r2h[MAXIT ? MAXIT : 1][2];
   uint32_t hom_ct = 0, r2h_ct = 0, both_ct = 0;
   if constexpr (MAXIT > 0) {
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-      const uint32_t p = tid + it * THREADS;
-      uint32_t hom = 0, r2h = 0;
+      const uint32_t p = 2 * (tid + it * THREADS);
+      keep_hom[it][0] = keep_hom[it][1] = 0;
+      keep_r2h[it][0] = keep_r2h[it][1] = 0;
       if (p < plane_dwords) {
-        convert_plane_dword(row, nbytes, aligned4, A.encoding, A.founder_ct, p, &hom, &r2h);
+        convert_plane_pair(row, nbytes, aligned4, aligned16, A.encoding, A.founder_ct, p, keep_hom[it], keep_r2h[it]);
       }
-      keep_hom[it] = hom;
-      keep_r2h[it] = r2h;
-      hom_ct += __popc(hom);
-      r2h_ct += __popc(r2h);
-      both_ct += __popc(hom & r2h);
+      hom_ct += __popc(keep_hom[it][0]) + __popc(keep_hom[it][1]);
+      r2h_ct += __popc(keep_r2h[it][0]) + __popc(keep_r2h[it][1]);
+      both_ct += __popc(keep_hom[it][0] & keep_r2h[it][0]) + __popc(keep_hom[it][1] & keep_r2h[it][1]);
     }
   } else {
-    for (uint32_t p = tid; p < plane_dwords; p += THREADS) {
-      uint32_t hom, r2h;
-      convert_plane_dword(row, nbytes, aligned4, A.encoding, A.founder_ct, p, &hom, &r2h);
-      hom_ct += __popc(hom);
-      r2h_ct += __popc(r2h);
-      both_ct += __popc(hom & r2h);
+    for (uint32_t p = 2 * tid; p < plane_dwords; p += 2 * THREADS) {
+      uint32_t hom[2], r2h[2];
+      convert_plane_pair(row, nbytes, aligned4, aligned16, A.encoding, A.founder_ct, p, hom, r2h);
+      hom_ct += __popc(hom[0]) + __popc(hom[1]);
+      r2h_ct += __popc(r2h[0]) + __popc(r2h[1]);
+      both_ct += __popc(hom[0] & r2h[0]) + __popc(hom[1] & r2h[1]);
     }
   }
   hom_ct = wave_reduce_add(hom_ct);
@@ -185,25 +224,27 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
   if constexpr (MAXIT > 0) {
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-      const uint32_t p = tid + it * THREADS;
+      const uint32_t p = 2 * (tid + it * THREADS);
       if (p < plane_dwords) {
-        const uint32_t hom = keep_hom[it];
-        const uint32_t r2h = alt_major ? (keep_r2h[it] ^ hom) : keep_r2h[it];  // 0 <-> 2 flips ref2het on homozygous calls
         const uint32_t off = (p / kChunkDwords) * kRowChunkDwords + (p % kChunkDwords);
-        out_row[off] = hom;
-        out_row[off + kChunkDwords] = r2h;
+        const uint2 hv = make_uint2(keep_hom[it][0], keep_hom[it][1]);
+        // 0 <-> 2 flips ref2het on homozygous calls
+        const uint2 rv = alt_major ? make_uint2(keep_r2h[it][0] ^ hv.x, keep_r2h[it][1] ^ hv.y) : make_uint2(keep_r2h[it][0], keep_r2h[it][1]);
+        *reinterpret_cast<uint2*>(out_row + off) = hv;
+        *reinterpret_cast<uint2*>(out_row + off + kChunkDwords) = rv;
       }
     }
   } else {
-    for (uint32_t p = tid; p < plane_dwords; p += THREADS) {
-      uint32_t hom, r2h;
-      convert_plane_dword(row, nbytes, aligned4, A.encoding, A.founder_ct, p, &hom, &r2h);
+    for (uint32_t p = 2 * tid; p < plane_dwords; p += 2 * THREADS) {
+      uint32_t hom[2], r2h[2];
+      convert_plane_pair(row, nbytes, aligned4, aligned16, A.encoding, A.founder_ct, p, hom, r2h);
       if (alt_major) {
-        r2h ^= hom;
+        r2h[0] ^= hom[0];
+        r2h[1] ^= hom[1];
       }
       const uint32_t off = (p / kChunkDwords) * kRowChunkDwords + (p % kChunkDwords);
-      out_row[off] = hom;
-      out_row[off + kChunkDwords] = r2h;
+      *reinterpret_cast<uint2*>(out_row + off) = make_uint2(hom[0], hom[1]);
+      *reinterpret_cast<uint2*>(out_row + off + kChunkDwords) = make_uint2(r2h[0], r2h[1]);
     }
   }
 }
@@ -212,17 +253,17 @@ hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream) {
   if (!a.n_variants) {
     return hipSuccess;
   }
-  const uint32_t plane_dwords = a.chunks * kChunkDwords;
-  if (plane_dwords <= 256 * 4) {
+  const uint32_t pairs = (a.chunks * kChunkDwords + 1) / 2;  // pairs of plane dwords per row
+  if (pairs <= 256 * 2) {
+    hipLaunchKernelGGL((prepare_kernel<256, 2>), dim3(a.n_variants), dim3(256), 0, stream, a);
+  } else if (pairs <= 256 * 4) {
     hipLaunchKernelGGL((prepare_kernel<256, 4>), dim3(a.n_variants), dim3(256), 0, stream, a);
-  } else if (plane_dwords <= 256 * 8) {
-    hipLaunchKernelGGL((prepare_kernel<256, 8>), dim3(a.n_variants), dim3(256), 0, stream, a);
-  } else if (plane_dwords <= 1024 * 8) {
+  } else if (pairs <= 1024 * 4) {
+    hipLaunchKernelGGL((prepare_kernel<1024, 4>), dim3(a.n_variants), dim3(1024), 0, stream, a);
+  } else if (pairs <= 1024 * 8) {
     hipLaunchKernelGGL((prepare_kernel<1024, 8>), dim3(a.n_variants), dim3(1024), 0, stream, a);
-  } else if (plane_dwords <= 1024 * 16) {
+  } else if (pairs <= 1024 * 16) {
     hipLaunchKernelGGL((prepare_kernel<1024, 16>), dim3(a.n_variants), dim3(1024), 0, stream, a);
-  } else if (plane_dwords <= 1024 * 32) {
-    hipLaunchKernelGGL((prepare_kernel<1024, 32>), dim3(a.n_variants), dim3(1024), 0, stream, a);
   } else {
     hipLaunchKernelGGL((prepare_kernel<1024, 0>), dim3(a.n_variants), dim3(1024), 0, stream, a);
   }
