@@ -133,7 +133,10 @@ int ldp_get_band(const ldp_engine* e, uint32_t* lo, uint64_t* candidate_pairs);
  * rows are stride_bytes apart.  location: LDP_MEM_HOST or LDP_MEM_DEVICE.  Rows outside this
  * engine's shard are ignored.  The engine converts to bit-planes resident in HBM, computes the
  * per-variant aggregates (FillVaggs, plink2_ld.cc:725) and, for REF/BED encodings, the allele counts,
- * major allele and inversion. */
+ * major allele and inversion.  Host buffers may be reused as soon as the call returns (rows travel through a
+ * pinned staging ring).  Device buffers are read asynchronously on the engine's stream: the data must be
+ * complete before the call (synchronise the producing stream) and must stay valid until the next ldp_run() /
+ * ldp_get_* call returns. */
 int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* geno, uint64_t stride_bytes,
                        int location, int encoding);
 /* major-allele frequencies (GetAlleleFreq(..., maj_alleles[v]), plink2_ld.cc:915) for LDP_GENO_INVERSE

@@ -165,6 +165,20 @@ int hipfail(ldp_engine* e, hipError_t rc, const char* what) {
 constexpr uint32_t kStageSlots = 3;
 constexpr size_t kStageBytes = 64ull << 20;
 
+// temporary device allocation released on every exit path
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) {
+      (void)hipFree(p);
+    }
+  }
+  template <class T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
 void free_device(ldp_engine* e) {
   if (!e->gpu_ok) {
     return;
@@ -567,7 +581,6 @@ int fetch_recs(ldp_engine* e) {
   return LDP_OK;
 }
 
-inline bool bit32(const std::vector<uint32_t>& bm, uint32_t i) { return (bm[i >> 5] >> (i & 31)) & 1; }
 // Subcontigs are replayed concurrently and neighbouring ones can share a bitmap word, so bits are set
 // atomically; reads only ever look at bits of the reader's own subcontig.
 inline void set32(std::vector<uint32_t>& bm, uint32_t i) { __atomic_fetch_or(&bm[i >> 5], 1u << (i & 31), __ATOMIC_RELAXED); }
@@ -778,9 +791,11 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     return fail(e, LDP_ERR_INVALID, "stats buffer smaller than the candidate pair count");
   }
   HIP_TRY(e, hipSetDevice(e->device));
+  DevBuf stats_buf;
   ldp_pair_stats_t* d_stats = nullptr;
   if (stats && e->cand_pairs) {
-    HIP_TRY(e, hipMalloc(&d_stats, e->cand_pairs * sizeof(ldp_pair_stats_t)));
+    HIP_TRY(e, hipMalloc(&stats_buf.p, e->cand_pairs * sizeof(ldp_pair_stats_t)));
+    d_stats = stats_buf.as<ldp_pair_stats_t>();
     HIP_TRY(e, hipMemsetAsync(d_stats, 0, e->cand_pairs * sizeof(ldp_pair_stats_t), e->stream));
   }
   HIP_TRY(e, hipMemsetAsync(e->d_pred, 0, std::max<size_t>(e->pred_words, 1) * sizeof(uint32_t), e->stream));
@@ -854,9 +869,6 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   }
   (void)hipEventDestroy(ev0);
   (void)hipEventDestroy(ev1);
-  if (d_stats) {
-    (void)hipFree(d_stats);
-  }
 
   // 3. greedy replay on the host
   const double t_replay = now_ms();
@@ -1109,14 +1121,17 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
   }
   const size_t esz = as_float ? sizeof(float) : sizeof(double);
   const uint64_t out_elems = static_cast<uint64_t>(row_ct) * ld_elems;
-  void* d_out = nullptr;
+  DevBuf out_buf, items_buf, general_buf;
+  HIP_TRY(e, hipMalloc(&out_buf.p, out_elems * esz));
+  void* d_out = out_buf.p;
   WorkItem* d_items = nullptr;
   uint8_t* d_general = nullptr;
-  HIP_TRY(e, hipMalloc(&d_out, out_elems * esz));
   HIP_TRY(e, hipMemsetAsync(d_out, 0, out_elems * esz, e->stream));
   if (!items.empty()) {
-    HIP_TRY(e, hipMalloc(&d_items, items.size() * sizeof(WorkItem)));
-    HIP_TRY(e, hipMalloc(&d_general, items.size()));
+    HIP_TRY(e, hipMalloc(&items_buf.p, items.size() * sizeof(WorkItem)));
+    HIP_TRY(e, hipMalloc(&general_buf.p, items.size()));
+    d_items = items_buf.as<WorkItem>();
+    d_general = general_buf.as<uint8_t>();
     HIP_TRY(e, hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, e->stream));
   }
   PairKernelArgs A;
@@ -1162,9 +1177,6 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
   for (int q = 0; q < 4; ++q) {
     (void)hipEventDestroy(evk[q]);
   }
-  (void)hipFree(d_out);
-  (void)hipFree(d_items);
-  (void)hipFree(d_general);
   // diagonal: r^2(v, v) through the same formula = 1.0, or NaN when the variant has no variance
   for (uint32_t j = row_first; j < row_end; ++j) {
     const ldp_variant_rec& r = e->recs[j];
@@ -1449,10 +1461,11 @@ int ldp_pair_stats(ldp_engine* e, uint32_t n_pairs, const uint32_t* first, const
     return LDP_OK;
   }
   HIP_TRY(e, hipSetDevice(e->device));
-  uint32_t* d_idx = nullptr;
-  ldp_pair_stats_t* d_out = nullptr;
-  HIP_TRY(e, hipMalloc(&d_idx, 2ull * n_pairs * sizeof(uint32_t)));
-  HIP_TRY(e, hipMalloc(&d_out, static_cast<size_t>(n_pairs) * sizeof(ldp_pair_stats_t)));
+  DevBuf idx_buf, out_buf;
+  HIP_TRY(e, hipMalloc(&idx_buf.p, 2ull * n_pairs * sizeof(uint32_t)));
+  HIP_TRY(e, hipMalloc(&out_buf.p, static_cast<size_t>(n_pairs) * sizeof(ldp_pair_stats_t)));
+  uint32_t* d_idx = idx_buf.as<uint32_t>();
+  ldp_pair_stats_t* d_out = out_buf.as<ldp_pair_stats_t>();
   HIP_TRY(e, hipMemcpyAsync(d_idx, lf.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(d_idx + n_pairs, ls.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
   hipError_t krc = launch_pair_stats_ref(e->d_planes, e->row_dwords, e->chunks, 0, d_idx, d_idx + n_pairs, n_pairs, d_out, e->stream);
@@ -1461,8 +1474,6 @@ int ldp_pair_stats(ldp_engine* e, uint32_t n_pairs, const uint32_t* first, const
   }
   HIP_TRY(e, hipMemcpyAsync(out, d_out, static_cast<size_t>(n_pairs) * sizeof(ldp_pair_stats_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
-  (void)hipFree(d_idx);
-  (void)hipFree(d_out);
   return LDP_OK;
 }
 
