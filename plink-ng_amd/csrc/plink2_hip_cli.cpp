@@ -355,7 +355,8 @@ Args parse_args(int argc, char** argv) {
 }
 
 // founder <=> PAT and MAT are both exactly "0" (plink2_psam.cc:804-806); absent columns => founder
-void load_samples(const Args& A, std::vector<uint8_t>* is_founder) {
+// sex: 1 = male, 2 = female, anything else = unknown (plink2_psam.cc:808-813)
+void load_samples(const Args& A, std::vector<uint8_t>* is_founder, std::vector<uint8_t>* sex) {
   const bool psam = !A.psam.empty();
   const std::string& path = psam ? A.psam : A.fam;
   std::ifstream in(path);
@@ -363,7 +364,7 @@ void load_samples(const Args& A, std::vector<uint8_t>* is_founder) {
     die(2, "Error: Failed to open %s.\n", path.c_str());
   }
   std::string line;
-  int pat_col = -1, mat_col = -1;
+  int pat_col = -1, mat_col = -1, sex_col = -1;
   bool header_seen = false;
   while (std::getline(in, line)) {
     if (line.empty()) {
@@ -375,6 +376,7 @@ void load_samples(const Args& A, std::vector<uint8_t>* is_founder) {
         for (size_t c = 0; c < cols.size(); ++c) {
           if (cols[c] == "PAT") pat_col = static_cast<int>(c);
           if (cols[c] == "MAT") mat_col = static_cast<int>(c);
+          if (cols[c] == "SEX") sex_col = static_cast<int>(c);
         }
         header_seen = true;
       }
@@ -390,6 +392,7 @@ void load_samples(const Args& A, std::vector<uint8_t>* is_founder) {
         die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
       }
       is_founder->push_back((t[2] == "0") && (t[3] == "0"));
+      sex->push_back((t[4] == "1") ? 1 : ((t[4] == "2") ? 2 : 0));
     } else {
       bool founder = true;
       if (pat_col >= 0 && mat_col >= 0) {
@@ -399,6 +402,12 @@ void load_samples(const Args& A, std::vector<uint8_t>* is_founder) {
         founder = (t[pat_col] == "0") && (t[mat_col] == "0");
       }
       is_founder->push_back(founder);
+      uint8_t sx = 0;
+      if (sex_col >= 0 && static_cast<size_t>(sex_col) < t.size()) {
+        const std::string& v = t[sex_col];
+        sx = (v == "1" || v == "M" || v == "m") ? 1 : ((v == "2" || v == "F" || v == "f") ? 2 : 0);
+      }
+      sex->push_back(sx);
     }
   }
 }
@@ -544,7 +553,8 @@ void load_variants(const Args& A, Variants* V) {
   }
 }
 
-// chromosome code: 1..22 autosomes (optional "chr" prefix), 0 = unplaced; anything haploid/sex is refused
+// chromosome class: 0 = diploid autosome / PAR (1..22, XY, extra contigs with --allow-extra-chr; *is_zero for
+// chromosome 0), 2 = invalid code, 3 = chrX, 4 = chrY, 5 = MT (haploid)
 int chrom_class(const std::string& name_in, bool allow_extra, bool* is_zero) {
   std::string name = name_in;
   if (name.size() > 3 && (name[0] | 32) == 'c' && (name[1] | 32) == 'h' && (name[2] | 32) == 'r') {
@@ -567,11 +577,14 @@ int chrom_class(const std::string& name_in, bool allow_extra, bool* is_zero) {
     if (v == 25) {
       return 0;  // XY (pseudo-autosomal) is diploid
     }
-    return 1;  // 23 X, 24 Y, 26 MT
+    if (v == 23) return 3;
+    if (v == 24) return 4;
+    if (v == 26) return 5;
+    return 2;
   }
-  if (ieq(name.c_str(), "X") || ieq(name.c_str(), "Y") || ieq(name.c_str(), "MT") || ieq(name.c_str(), "M")) {
-    return 1;
-  }
+  if (ieq(name.c_str(), "X")) return 3;
+  if (ieq(name.c_str(), "Y")) return 4;
+  if (ieq(name.c_str(), "MT") || ieq(name.c_str(), "M")) return 5;
   if (ieq(name.c_str(), "XY") || ieq(name.c_str(), "PAR1") || ieq(name.c_str(), "PAR2")) {
     return 0;
   }
@@ -663,6 +676,97 @@ void multiallelic_inverse_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_c
   }
 }
 
+// ---- chrX / chrY / MT ---------------------------------------------------------------------------------------
+// The reference feeds IndepPairwiseThread differently shaped genotype vectors on these chromosomes
+// (plink2_ld.cc:1356-1388): MT/haploid = founders with hets set to missing; chrY = non-female founders, hets to
+// missing; chrX = male founders (hets to missing) followed by non-male founders, whose statistics count twice
+// (:890-901, :1066-1082).  All of the prune's statistics are sums over samples, so "count twice" is reproduced
+// exactly by emitting the non-male block twice; the engine then runs unchanged on founder_ct' samples.
+// Allele frequencies follow LoadAlleleAndGenoCountsThread (plink2_data.cc:2421-2700): diploid-style counts over the
+// relevant founders (hets count half/half) for MT and chrY, and for chrX non-males weigh twice as much as males
+// with a male het counting half (alt = 4*G2 + 2*G1 - 2*M2 - M1 over all / male founders, :2641).
+struct SexPlan {
+  std::vector<uint32_t> part1;  // samples whose hets become missing
+  std::vector<uint32_t> part2;  // chrX non-males (emitted twice); empty otherwise
+  bool x_freq = false;
+  uint32_t out_ct() const { return static_cast<uint32_t>(part1.size() + 2 * part2.size()); }
+};
+
+inline uint32_t code_at(const uint8_t* row, uint32_t s) { return (row[s >> 2] >> (2 * (s & 3))) & 3; }
+
+// raw_row: REF-based pgen codes of all samples.  Writes the PgrGetInv1-style row (+ het->missing) and maj_freq.
+void build_sex_row(const SexPlan& sp, const uint8_t* raw_row, uint8_t* out_row, uint64_t out_rec, double* maj_freq) {
+  uint64_t g[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0};
+  for (uint32_t s : sp.part1) {
+    ++m[code_at(raw_row, s)];
+  }
+  for (uint32_t s : sp.part2) {
+    ++g[code_at(raw_row, s)];
+  }
+  uint64_t ref_ct, alt_ct;
+  if (sp.x_freq) {
+    for (int q = 0; q < 4; ++q) {
+      g[q] += m[q];  // all founders
+    }
+    const uint64_t n_all = g[0] + g[1] + g[2];
+    const uint64_t n_male = m[0] + m[1] + m[2];
+    alt_ct = 4 * g[2] + 2 * g[1] - 2 * m[2] - m[1];
+    const uint64_t tot = 2 * (2 * n_all - n_male);
+    ref_ct = tot - alt_ct;
+  } else {
+    ref_ct = 2 * m[0] + m[1];
+    alt_ct = 2 * m[2] + m[1];
+  }
+  const uint64_t tot = ref_ct + alt_ct;
+  double ref_freq = 0.5;
+  if (tot) {
+    const double tot_recip = 1.0 / static_cast<double>(tot);
+    ref_freq = static_cast<double>(ref_ct) * tot_recip;
+  }
+  const bool alt_major = !(ref_freq >= 0.5);
+  double mf = ref_freq;
+  if (alt_major) {
+    mf = 1.0 - ref_freq;
+    if (mf < 0.0) {
+      mf = 0.0;
+    }
+  }
+  *maj_freq = mf;
+  memset(out_row, 0, out_rec);
+  static const uint8_t inv[4] = {2, 1, 0, 3};
+  uint32_t f = 0;
+  for (uint32_t s : sp.part1) {
+    uint32_t c = code_at(raw_row, s);
+    c = (c == 1) ? 3u : (alt_major ? inv[c] : c);  // SetHetMissing
+    out_row[f >> 2] |= static_cast<uint8_t>(c << (2 * (f & 3)));
+    ++f;
+  }
+  for (int rep = 0; rep < 2; ++rep) {
+    for (uint32_t s : sp.part2) {
+      uint32_t c = code_at(raw_row, s);
+      c = alt_major ? inv[c] : c;
+      out_row[f >> 2] |= static_cast<uint8_t>(c << (2 * (f & 3)));
+      ++f;
+    }
+  }
+}
+
+// raw REF-coded row of one variant (decoding / .bed recoding as needed) into `buf`
+void fetch_raw_row(ldp_pgen* pg, int storage_mode, uint32_t raw_variant, uint32_t raw_sample_ct, uint64_t rec_bytes, uint8_t* buf) {
+  if (ldp_pgen_read(pg, raw_variant, 1, buf, rec_bytes, 1)) {
+    die(3, "\nError: %s\n", ldp_pgen_last_error(pg));
+  }
+  if (storage_mode == 0x01) {
+    static const uint8_t conv[4] = {2, 3, 1, 0};  // .bed -> pgen codes (pgenlib_read.cc:2157)
+    for (uint32_t sidx = 0; sidx < raw_sample_ct; ++sidx) {
+      const uint32_t c = conv[code_at(buf, sidx)];
+      uint8_t& b = buf[sidx >> 2];
+      const uint32_t sh = 2 * (sidx & 3);
+      b = static_cast<uint8_t>((b & ~(3u << sh)) | (c << sh));
+    }
+  }
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -683,7 +787,8 @@ int main(int argc, char** argv) {
   double t_hip_init = 0.0, t_parse = 0.0;
   std::thread t_hip([&]() { const double t0 = now_s(); (void)ldp_device_count(); t_hip_init = now_s() - t0; });
   std::vector<uint8_t> is_founder;
-  load_samples(A, &is_founder);
+  std::vector<uint8_t> sex;
+  load_samples(A, &is_founder, &sex);
   t_variants.join();
   t_parse = now_s() - t_begin;
   t_hip.join();
@@ -726,6 +831,7 @@ int main(int argc, char** argv) {
   // ---- variant table: strip chromosome 0, chromosome order index, sortedness, unique IDs
   std::vector<uint32_t> inc;  // raw index of every included variant
   std::vector<uint32_t> chr_idx, bps;
+  std::vector<uint8_t> vcls;  // per included variant: 0 diploid, 3 chrX, 4 chrY, 5 MT
   uint32_t skipped = 0;
   {
     std::unordered_set<std::string> seen_chr;
@@ -753,12 +859,16 @@ int main(int argc, char** argv) {
         ++skipped;
         continue;
       }
-      if (cls == 1) {
-        die(9, "Error: chromosome '%s': chrX/chrY/MT handling is not supported yet by plink2-hip.\n", cur.c_str());
+      if (cls >= 3 && A.have_r2) {
+        die(9, "Error: chromosome '%s': chrX/chrY/MT are not supported yet by --r2-unphased in plink2-hip.\n", cur.c_str());
       }
       if (cls == 2) {
         die(3, "Error: Invalid chromosome code '%s'. (Use --allow-extra-chr to force it to be accepted.)\n", cur.c_str());
       }
+      if (cls >= 3 && V.alt_ct[v] > 1) {
+        die(9, "Error: multiallelic variant '%s' on chrX/chrY/MT is not supported yet by plink2-hip.\n", V.id[v].c_str());
+      }
+      vcls.push_back(static_cast<uint8_t>(cls));
       inc.push_back(v);
       chr_idx.push_back(fo);
       bps.push_back(V.bp[v]);
@@ -774,6 +884,18 @@ int main(int argc, char** argv) {
         die(3, "Error: --indep-pairwise with a kb window requires a sorted .pvar/.bim.  Retry this command after using\n--make-pgen/--make-bed + --sort-vars to sort your data.\n");
       }
     }
+  }
+
+  // chrX and chrY variants run on engines of their own (different sample sets); MT stays with the autosomes
+  std::vector<uint32_t> mk, xk, yk;  // indices into inc[]
+  for (uint32_t k = 0; k < variant_ct; ++k) {
+    (vcls[k] == 3 ? xk : (vcls[k] == 4 ? yk : mk)).push_back(k);
+  }
+  const uint32_t m_ct = static_cast<uint32_t>(mk.size());
+  std::vector<uint32_t> m_chr(m_ct), m_bps(m_ct);
+  for (uint32_t q = 0; q < m_ct; ++q) {
+    m_chr[q] = chr_idx[mk[q]];
+    m_bps[q] = bps[mk[q]];
   }
 
   if (A.have_r2) {
@@ -919,7 +1041,7 @@ int main(int argc, char** argv) {
   if (A.dry_run) {
     ldp_engine* e = nullptr;
     P.device = -1;
-    if (ldp_create(&P, &e) || ldp_set_variants(e, variant_ct, chr_idx.data(), A.window_is_bp ? bps.data() : nullptr)) {
+    if (ldp_create(&P, &e) || ldp_set_variants(e, m_ct, m_chr.data(), A.window_is_bp ? m_bps.data() : nullptr)) {
       die(12, "Error: planning failed.\n");
     }
     uint32_t sct = 0;
@@ -927,7 +1049,10 @@ int main(int argc, char** argv) {
     ldp_get_subcontigs(e, &sct, nullptr, 0);
     ldp_get_band(e, nullptr, &cand);
     logprintf("dry-run: founders=%u variants=%u window=%u step=%u window_is_bp=%d r2=%a order=%d subcontigs=%u candidate_pairs=%llu\n",
-              founder_ct, variant_ct, A.window, A.step, A.window_is_bp ? 1 : 0, A.r2, A.order, sct, static_cast<unsigned long long>(cand));
+              founder_ct, m_ct, A.window, A.step, A.window_is_bp ? 1 : 0, A.r2, A.order, sct, static_cast<unsigned long long>(cand));
+    if (!xk.empty() || !yk.empty()) {
+      logprintf("dry-run: chrX variants=%zu chrY variants=%zu (separate engines)\n", xk.size(), yk.size());
+    }
     ldp_destroy(e);
     return 0;
   }
@@ -944,7 +1069,7 @@ int main(int argc, char** argv) {
     if (rc) {
       die(12, "Error: ldp_create failed (%d).\n", rc);
     }
-    rc = ldp_set_variants(eng[r], variant_ct, chr_idx.data(), A.window_is_bp ? bps.data() : nullptr);
+    rc = ldp_set_variants(eng[r], m_ct, m_chr.data(), A.window_is_bp ? m_bps.data() : nullptr);
     if (rc) {
       die(12, "Error: %s\n", ldp_last_error(eng[r]));
     }
@@ -957,7 +1082,7 @@ int main(int argc, char** argv) {
     }
   }
   std::vector<uint64_t> removed((static_cast<size_t>(variant_ct) + 63) / 64 + 1, 0);
-  if (subcontig_ct) {
+  if (subcontig_ct || !xk.empty() || !yk.empty()) {
     // unique IDs (plink2_ld.cc:2573-2592)
     {
       // open-addressing table of variant indices keyed by a 64-bit FNV-1a hash of the ID
@@ -1012,7 +1137,7 @@ int main(int argc, char** argv) {
                 t_joined - t_begin, t_load0 - t_joined);
     }
 
-    // ---- genotype rows of the included variants -> engines.  All-founder files go straight from the
+    // ---- genotype rows of the diploid (+MT) variants -> engines.  All-founder files go straight from the
     // mapping; otherwise the founder columns are gathered on the host first (CopyNyparrNonemptySubset,
     // pgenlib_misc.cc:32,185).
     const bool all_founders = (founder_ct == raw_sample_ct);
@@ -1023,96 +1148,128 @@ int main(int argc, char** argv) {
         founder_idx.push_back(s);
       }
     }
-    const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((1024ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
-    std::vector<uint8_t> decoded, gather;
-    uint32_t k = 0;
-    while (k < variant_ct) {
-      // maximal run of included variants that is contiguous in the file
-      uint32_t run = 1;
-      while (k + run < variant_ct && inc[k + run] == inc[k] + run && run < kChunk) {
-        ++run;
-      }
-      const uint8_t* src;
-      uint64_t stride = rec_bytes;
-      if (direct_rows) {
-        src = direct_rows + static_cast<uint64_t>(inc[k]) * rec_bytes;
-      } else {
-        decoded.resize(static_cast<size_t>(run) * rec_bytes);
-        if (ldp_pgen_read(pg, inc[k], run, decoded.data(), rec_bytes, 0)) {
-          die(3, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
-        }
-        src = decoded.data();
-      }
-      if (!all_founders) {
-        // gather the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185)
-        gather.assign(static_cast<size_t>(run) * out_rec, 0);
-        for (uint32_t q = 0; q < run; ++q) {
-          const uint8_t* in_row = src + static_cast<uint64_t>(q) * rec_bytes;
-          uint8_t* out_row = gather.data() + static_cast<uint64_t>(q) * out_rec;
-          for (uint32_t f = 0; f < founder_ct; ++f) {
-            const uint32_t sidx = founder_idx[f];
-            const uint32_t code = (in_row[sidx >> 2] >> (2 * (sidx & 3))) & 3;
-            out_row[f >> 2] |= code << (2 * (f & 3));
+    auto sub_preferred = [&](const std::vector<uint32_t>& ks) {
+      std::vector<uint64_t> out;
+      if (!preferred.empty()) {
+        out.assign((ks.size() + 63) / 64 + 1, 0);
+        for (size_t q = 0; q < ks.size(); ++q) {
+          if ((preferred[ks[q] >> 6] >> (ks[q] & 63)) & 1) {
+            out[q >> 6] |= 1ull << (q & 63);
           }
         }
-        src = gather.data();
-        stride = out_rec;
+      }
+      return out;
+    };
+    auto scatter = [&](const std::vector<uint64_t>& bm, const std::vector<uint32_t>& ks) {
+      for (size_t q = 0; q < ks.size(); ++q) {
+        if ((bm[q >> 6] >> (q & 63)) & 1) {
+          removed[ks[q] >> 6] |= 1ull << (ks[q] & 63);
+        }
+      }
+    };
+    double t_load1 = now_s();
+    if (subcontig_ct) {
+      const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((1024ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
+      std::vector<uint8_t> decoded, gather;
+      uint32_t q = 0;
+      while (q < m_ct) {
+        // maximal run of variants that is contiguous in the file
+        const uint32_t raw0 = inc[mk[q]];
+        uint32_t run = 1;
+        while (q + run < m_ct && inc[mk[q + run]] == raw0 + run && run < kChunk) {
+          ++run;
+        }
+        const uint8_t* src;
+        uint64_t stride = rec_bytes;
+        if (direct_rows) {
+          src = direct_rows + static_cast<uint64_t>(raw0) * rec_bytes;
+        } else {
+          decoded.resize(static_cast<size_t>(run) * rec_bytes);
+          if (ldp_pgen_read(pg, raw0, run, decoded.data(), rec_bytes, 0)) {
+            die(3, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+          }
+          src = decoded.data();
+        }
+        if (!all_founders) {
+          // gather the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185)
+          gather.assign(static_cast<size_t>(run) * out_rec, 0);
+          for (uint32_t w = 0; w < run; ++w) {
+            const uint8_t* in_row = src + static_cast<uint64_t>(w) * rec_bytes;
+            uint8_t* out_row = gather.data() + static_cast<uint64_t>(w) * out_rec;
+            for (uint32_t f = 0; f < founder_ct; ++f) {
+              out_row[f >> 2] |= static_cast<uint8_t>(code_at(in_row, founder_idx[f]) << (2 * (f & 3)));
+            }
+          }
+          src = gather.data();
+          stride = out_rec;
+        }
+        for (int r = 0; r < world; ++r) {
+          const int rc = ldp_load_genotypes(eng[r], q, run, src, stride, LDP_MEM_HOST, encoding);
+          if (rc) {
+            die(12, "Error: %s\n", ldp_last_error(eng[r]));
+          }
+        }
+        q += run;
+      }
+      // rows that need host treatment overwrite their bulk-loaded versions: variants with more than one ALT
+      // allele (collapsed major-vs-rest) and MT variants (hets -> missing, plink2_ld.cc:1362-1364)
+      {
+        uint32_t multi_ct = 0, mt_ct = 0;
+        std::vector<uint8_t> lo(raw_sample_ct), hi(raw_sample_ct), inv_row(out_rec), raw_row(rec_bytes + 8);
+        SexPlan mt_plan;
+        mt_plan.part1 = founder_idx;
+        for (uint32_t qq = 0; qq < m_ct; ++qq) {
+          const uint32_t raw_v = inc[mk[qq]];
+          const uint32_t alts = V.alt_ct[raw_v];
+          const bool is_mt = (vcls[mk[qq]] == 5);
+          if (alts < 2 && !is_mt) {
+            continue;
+          }
+          double mf = 0.0;
+          if (is_mt) {
+            fetch_raw_row(pg, storage_mode, raw_v, raw_sample_ct, rec_bytes, raw_row.data());
+            build_sex_row(mt_plan, raw_row.data(), inv_row.data(), out_rec, &mf);
+            ++mt_ct;
+          } else {
+            if (storage_mode == 0x01) {
+              die(3, "\nError: multiallelic variant in a .bim/.bed fileset.\n");
+            }
+            multiallelic_inverse_row(pg, raw_v, alts, founder_idx, &lo, &hi, inv_row.data(), out_rec, &mf);
+            ++multi_ct;
+          }
+          for (int r = 0; r < world; ++r) {
+            if (ldp_load_genotypes(eng[r], qq, 1, inv_row.data(), out_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) ||
+                ldp_set_maj_freqs(eng[r], qq, 1, &mf)) {
+              die(12, "\nError: %s\n", ldp_last_error(eng[r]));
+            }
+          }
+        }
+        if ((multi_ct || mt_ct) && A.timing) {
+          logprintf("\n[timing] host-built rows: %u multiallelic, %u MT\n", multi_ct, mt_ct);
+        }
+      }
+      t_load1 = now_s();
+      const std::vector<uint64_t> pref_m = sub_preferred(mk);
+      const size_t m_words = (static_cast<size_t>(m_ct) + 63) / 64 + 1;
+      std::vector<std::vector<uint64_t>> part(world, std::vector<uint64_t>(m_words, 0));
+      std::vector<int> rcs(world, 0);
+      std::vector<std::thread> th;
+      for (int r = 0; r < world; ++r) {
+        th.emplace_back([&, r]() {
+          if (!pref_m.empty()) {
+            ldp_set_preferred(eng[r], pref_m.data());
+          }
+          rcs[r] = ldp_run(eng[r], part[r].data());
+        });
+      }
+      for (std::thread& t : th) {
+        t.join();
       }
       for (int r = 0; r < world; ++r) {
-        const int rc = ldp_load_genotypes(eng[r], k, run, src, stride, LDP_MEM_HOST, encoding);
-        if (rc) {
-          die(12, "Error: %s\n", ldp_last_error(eng[r]));
+        if (rcs[r]) {
+          die(12, "\nError: %s\n", ldp_last_error(eng[r]));
         }
-      }
-      k += run;
-    }
-    // variants with more than one ALT allele are collapsed major-vs-rest on the host and overwrite their rows
-    {
-      uint32_t multi_ct = 0;
-      std::vector<uint8_t> lo(raw_sample_ct), hi(raw_sample_ct), inv_row(out_rec);
-      for (uint32_t kk = 0; kk < variant_ct; ++kk) {
-        const uint32_t alts = V.alt_ct[inc[kk]];
-        if (alts < 2) {
-          continue;
-        }
-        if (storage_mode == 0x01) {
-          die(3, "\nError: multiallelic variant in a .bim/.bed fileset.\n");
-        }
-        double mf = 0.0;
-        multiallelic_inverse_row(pg, inc[kk], alts, founder_idx, &lo, &hi, inv_row.data(), out_rec, &mf);
-        for (int r = 0; r < world; ++r) {
-          if (ldp_load_genotypes(eng[r], kk, 1, inv_row.data(), out_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) ||
-              ldp_set_maj_freqs(eng[r], kk, 1, &mf)) {
-            die(12, "\nError: %s\n", ldp_last_error(eng[r]));
-          }
-        }
-        ++multi_ct;
-      }
-      if (multi_ct && A.timing) {
-        logprintf("\n[timing] %u multiallelic variants collapsed on the host\n", multi_ct);
-      }
-    }
-    const double t_load1 = now_s();
-    std::vector<std::vector<uint64_t>> part(world, std::vector<uint64_t>(removed.size(), 0));
-    std::vector<int> rcs(world, 0);
-    std::vector<std::thread> th;
-    for (int r = 0; r < world; ++r) {
-      th.emplace_back([&, r]() {
-        if (!preferred.empty()) {
-          ldp_set_preferred(eng[r], preferred.data());
-        }
-        rcs[r] = ldp_run(eng[r], part[r].data());
-      });
-    }
-    for (std::thread& t : th) {
-      t.join();
-    }
-    for (int r = 0; r < world; ++r) {
-      if (rcs[r]) {
-        die(12, "\nError: %s\n", ldp_last_error(eng[r]));
-      }
-      for (size_t w = 0; w < removed.size(); ++w) {
-        removed[w] |= part[r][w];
+        scatter(part[r], mk);
       }
     }
     if (A.timing) {
@@ -1120,6 +1277,74 @@ int main(int argc, char** argv) {
       ldp_get_counters(eng[0], &c);
       logprintf("\n[timing] setup+parse %.3f s | genotype load (file -> HBM bit-planes) %.3f s | run %.3f s (pair kernel %.1f ms, replay %.1f ms; %llu candidate pairs)\n",
                 t_load0 - t_begin, t_load1 - t_load0, now_s() - t_load1, c.ms_pair_kernel, c.ms_replay, static_cast<unsigned long long>(c.candidate_pairs));
+    }
+    // ---- chrX, chrY: their own sample sets, rows built on the host, one engine each on device 0
+    for (int which = 0; which < 2; ++which) {
+      const std::vector<uint32_t>& ks = which ? yk : xk;
+      if (ks.empty()) {
+        continue;
+      }
+      SexPlan sp;
+      for (uint32_t sidx : founder_idx) {
+        if (!which) {
+          (sex[sidx] == 1 ? sp.part1 : sp.part2).push_back(sidx);  // males | non-males (female + unknown)
+        } else if (sex[sidx] != 2) {
+          sp.part1.push_back(sidx);                                  // non-females
+        }
+      }
+      sp.x_freq = !which;
+      const uint32_t fct = sp.out_ct();
+      if (fct < 2) {
+        die(9, "\nError: fewer than two usable founders on chr%s; not supported by plink2-hip.\n", which ? "Y" : "X");
+      }
+      ldp_params SP = P;
+      SP.founder_ct = fct;
+      SP.device = 0;
+      ldp_engine* se = nullptr;
+      std::vector<uint32_t> s_chr(ks.size()), s_bps(ks.size());
+      for (size_t w = 0; w < ks.size(); ++w) {
+        s_chr[w] = chr_idx[ks[w]];
+        s_bps[w] = bps[ks[w]];
+      }
+      if (ldp_create(&SP, &se) || ldp_set_variants(se, static_cast<uint32_t>(ks.size()), s_chr.data(), A.window_is_bp ? s_bps.data() : nullptr)) {
+        die(12, "\nError: chr%s engine setup failed.\n", which ? "Y" : "X");
+      }
+      const uint64_t s_rec = (static_cast<uint64_t>(fct) + 3) / 4;
+      const uint32_t chunk = std::max<uint32_t>(1, static_cast<uint32_t>((256ull << 20) / std::max<uint64_t>(s_rec, 1)));
+      std::vector<uint8_t> rows;
+      std::vector<double> mfs;
+      for (uint32_t w0 = 0; w0 < ks.size(); w0 += chunk) {
+        const uint32_t cnt = std::min<uint32_t>(chunk, static_cast<uint32_t>(ks.size()) - w0);
+        rows.assign(static_cast<size_t>(cnt) * s_rec, 0);
+        mfs.assign(cnt, 0.0);
+        const uint32_t nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < nthreads; ++t) {
+          pool.emplace_back([&, t]() {
+            std::vector<uint8_t> raw_row(rec_bytes + 8);
+            for (uint32_t w = t; w < cnt; w += nthreads) {
+              fetch_raw_row(pg, storage_mode, inc[ks[w0 + w]], raw_sample_ct, rec_bytes, raw_row.data());
+              build_sex_row(sp, raw_row.data(), rows.data() + static_cast<uint64_t>(w) * s_rec, s_rec, &mfs[w]);
+            }
+          });
+        }
+        for (std::thread& t : pool) {
+          t.join();
+        }
+        if (ldp_load_genotypes(se, w0, cnt, rows.data(), s_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) || ldp_set_maj_freqs(se, w0, cnt, mfs.data())) {
+          die(12, "\nError: %s\n", ldp_last_error(se));
+        }
+      }
+      const std::vector<uint64_t> pref_s = sub_preferred(ks);
+      if (!pref_s.empty()) {
+        ldp_set_preferred(se, pref_s.data());
+      }
+      std::vector<uint64_t> bm((ks.size() + 63) / 64 + 1, 0);
+      if (ldp_run(se, bm.data())) {
+        die(12, "\nError: %s\n", ldp_last_error(se));
+      }
+      scatter(bm, ks);
+      ldp_destroy(se);
     }
   }
   uint32_t removed_ct = 0;

@@ -184,3 +184,47 @@ def test_cli_multiallelic_collapse_matches_reference(gpu_pkg, cli, tmp_path, max
     assert filecmp.cmp(str(tmp_path / "ref.prune.in"), str(tmp_path / "hip.prune.in"), shallow=False)
     assert filecmp.cmp(str(tmp_path / "ref.prune.out"), str(tmp_path / "hip.prune.out"), shallow=False)
     assert 0 < len(open(str(tmp_path / "hip.prune.out")).read().split()) < m
+
+
+def sexed_fileset(tmp_path, m=900, n=140, seed=5, nonfounders=6, unknown_sex=True):
+    """Autosomes + chrX + chrY + MT, males/females/unknown sex, a few non-founders."""
+    raw = T.synth_raw_codes(m, n, seed, missing_rate=0.04)
+    per = m // 5
+    chroms = (["1"] * per + ["2"] * per + ["X"] * per + ["Y"] * per + ["MT"] * (m - 4 * per))
+    bps = np.concatenate([1000 + 211 * np.arange(per)] * 4 + [1000 + 211 * np.arange(m - 4 * per)]).astype(np.uint32)
+    rng = np.random.default_rng(seed)
+    sexes = rng.choice([1, 2, 0] if unknown_sex else [1, 2], size=n, p=[0.45, 0.45, 0.1] if unknown_sex else [0.5, 0.5])
+    prefix = str(tmp_path / "sx")
+    T.write_pgen_fixed(prefix, raw, chroms, bps, sexes=sexes)
+    T.write_bed(prefix, raw, chroms, bps)
+    fam = []
+    psam = ["#IID\tPAT\tMAT\tSEX"]
+    for s in range(n):
+        nf = (s % 11 == 3) and (s // 11 < nonfounders)
+        fam.append("s%d s%d %s %s %d -9" % (s, s, "s0" if nf else "0", "s1" if nf else "0", sexes[s]))
+        psam.append("s%d\t%s\t%s\t%s" % (s, "s0" if nf else "0", "s1" if nf else "0", "NA" if sexes[s] == 0 else str(sexes[s])))
+    open(prefix + ".fam", "w").write("\n".join(fam) + "\n")
+    open(prefix + ".psam", "w").write("\n".join(psam) + "\n")
+    return prefix
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,wargs,order,unknown", [("pfile", ["40kb"], 2, True), ("bfile", ["70", "9"], 1, True), ("pfile", ["100", "1"], 2, False)])
+def test_cli_sex_chromosomes_match_reference(gpu_pkg, cli, tmp_path, fmt, wargs, order, unknown):
+    """chrX (males het->missing, non-males weighted 2x), chrY (non-females, haploid) and MT (haploid):
+    plink2_ld.cc:890-901,1066-1082,1356-1388 and the reference's haploid allele-frequency rules."""
+    assert T.have_ref()
+    sexed_fileset(tmp_path, unknown_sex=unknown)
+    common = ["--" + fmt, "sx", "--indep-pairwise"] + wargs + ["0.2"]
+    if order == 1:
+        common += ["--indep-order", "1"]
+    ref = T.run_ref(common + ["--threads", "3", "--out", "ref"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    got = run_cli(cli, common + ["--out", "hip"], str(tmp_path))
+    assert got.returncode == 0, got.stdout
+    ref_out = open(str(tmp_path / "ref.prune.out")).read().split()
+    hip_out = open(str(tmp_path / "hip.prune.out")).read().split()
+    diff = sorted(set(ref_out) ^ set(hip_out), key=lambda x: int(x[3:]))
+    assert not diff, "differs on %d variants, e.g. %s" % (len(diff), diff[:10])
+    assert filecmp.cmp(str(tmp_path / "ref.prune.in"), str(tmp_path / "hip.prune.in"), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "ref.prune.out"), str(tmp_path / "hip.prune.out"), shallow=False)
