@@ -11,9 +11,10 @@
 // (2.0/plink2_psam.cc:804-813), .bim/.pvar parsing, chromosome-0 stripping (StripUnplacedK,
 // plink2_ld.cc:113-164), the sorted-positions and unique-ID checks (plink2.cc:2926, plink2_ld.cc:2573-2592),
 // the <50-founders guard (plink2.cc:2063-2071) and the output writer.
-// Multiallelic variants are collapsed major-vs-rest on the host (Get1Multiallelic semantics).
-// Not yet supported (reported as such, never silently mis-handled): chrX/chrY/MT/haploid contigs, .pvar.zst,
-// external-index .pgen (modes 0x20/0x21), more than 254 ALT alleles.
+// Multiallelic variants are collapsed major-vs-rest on the host (Get1Multiallelic semantics); chrX / chrY / MT get
+// their sample-mapped rows (males het->missing, non-males x2, ...) built on the host as well.
+// Not yet supported (reported as such, never silently mis-handled): .pvar.zst, external-index .pgen (modes
+// 0x20/0x21), more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, chrX/Y/MT in --r2-unphased.
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <fcntl.h>
