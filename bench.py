@@ -272,6 +272,8 @@ def main():
                                  "physical HBM traffic, the kernel is integer-VALU bound",
                          "valu_frac": (ctr["candidate_pairs"] / (kms * 1e-3)) / valu_peak_pairs if kms > 0 else 0.0},
             "stage_ms": {"prepare_kernel": float(np.mean(prep_ms)), "pair_kernel": kms, "host_replay": float(np.mean(replay_ms))},
+            "early_termination": {"tile_unit_chunks": ctr["tile_unit_chunks"], "skipped_unit_chunks": ctr["early_exit_unit_chunks"],
+                                  "skipped_frac": (ctr["early_exit_unit_chunks"] / ctr["tile_unit_chunks"]) if ctr["tile_unit_chunks"] else 0.0},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, torch, args, founder_ct, spacing, window_bp, args.r2)

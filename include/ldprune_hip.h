@@ -104,6 +104,8 @@ typedef struct {
   uint32_t subcontig_ct;
   uint32_t owned_subcontig_ct;
   uint32_t window_max;       /* as LdPruneSubcontigSplitAll reports it */
+  uint64_t tile_unit_chunks;       /* pair-kernel work of the last run in (8-distance unit x k-chunk) steps ... */
+  uint64_t early_exit_unit_chunks; /* ... and how many of them early termination skipped (provably sub-threshold tiles) */
 } ldp_counters;
 
 /* ---- lifecycle ---- */

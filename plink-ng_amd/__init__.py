@@ -60,7 +60,8 @@ class ldp_counters(ctypes.Structure):
                 ("ms_pair_fast", ctypes.c_double), ("ms_pair_general", ctypes.c_double),
                 ("ms_replay", ctypes.c_double), ("ms_run_total", ctypes.c_double),
                 ("pair_kernel_launches", ctypes.c_uint32), ("subcontig_ct", ctypes.c_uint32),
-                ("owned_subcontig_ct", ctypes.c_uint32), ("window_max", ctypes.c_uint32)]
+                ("owned_subcontig_ct", ctypes.c_uint32), ("window_max", ctypes.c_uint32),
+                ("tile_unit_chunks", ctypes.c_uint64), ("early_exit_unit_chunks", ctypes.c_uint64)]
 
     def asdict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -38,6 +38,24 @@ struct WorkItem {
   uint32_t send;
 };
 
+// ---- early termination of hopeless tiles (complete-data path) --------------------------------------------
+// Early termination of hopeless tiles (complete-data kernel).  At up to kCheckpoints k-chunk boundaries a wave
+// bounds, for each of its pairs, how large |N*dot - S_i*S_j| can still become.  With R = the samples not yet
+// visited, s = sum over R, q = sum of squares over R, n = |R|:
+//     dot_R = sum_R (x-s_i/n)(y-s_j/n) + s_i*s_j/n,   |first term| <= sqrt(q_i - s_i^2/n) * sqrt(q_j - s_j^2/n)
+// (Cauchy-Schwarz on the centred remainders).  prepare_kernel stores per variant, per checkpoint, the two numbers
+// this needs, pre-scaled so the pair test is a handful of FP64 ops (cp_stats, kCpSlots x 16 bytes per variant):
+//     slot k < kCheckpoints: { s_R * sqrt(N / n_R),  sqrt(N * (q_R - s_R^2 / n_R)) }
+//     slot kCheckpoints    : { S (whole-row sum),    sqrt(N*Q - S^2) * sqrt(sqrt(thresh) * (1 - 1e-6)) }
+// When every pair of the wave provably stays below the r^2 threshold the wave stops accumulating and emits
+// nothing; a block whose four waves have all stopped leaves the k-loop.  Results are unchanged: only pairs whose
+// predicate is provably false are skipped.
+constexpr int kCheckpoints = 5;
+constexpr int kCpSlots = kCheckpoints + 1;
+struct cp_slot {
+  double a, b;
+};
+
 struct PairKernelArgs {
   const uint32_t* planes;        // [variant][chunk][2][kChunkDwords]
   uint64_t row_dwords;           // dwords per variant row = chunks * kRowChunkDwords
@@ -57,6 +75,9 @@ struct PairKernelArgs {
   uint8_t* item_general;         // per work item: 1 = some row has missing calls -> general kernel
   // --r2-unphased matrix mode: when r2_out != nullptr the epilogue stores r^2 of pair (i<j) at
   // r2_out[(j - r2_row_first) * r2_ld + i] (float or double) instead of predicate bits
+  const cp_slot* cp_stats;       // [variant][kCpSlots]; nullptr disables early termination
+  uint32_t checkpoint_chunk[kCheckpoints];  // ascending; a checkpoint fires after chunk (value - 1) is consumed
+  uint32_t n_checkpoints;
   void* r2_out;
   uint64_t r2_ld;
   uint32_t r2_row_first;
@@ -73,6 +94,10 @@ struct PrepareArgs {
   uint64_t row_dwords;
   uint32_t chunks;
   ldp_variant_rec* recs;         // entry 0 = variant `first`
+  cp_slot* cp_stats;             // entry 0 = variant `first`, kCpSlots each; may be nullptr
+  double cp_tv_scale;            // sqrt(sqrt(thresh) * (1 - 1e-6))
+  uint32_t checkpoint_chunk[kCheckpoints];
+  uint32_t n_checkpoints;
 };
 
 hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream);

@@ -123,6 +123,9 @@ struct ldp_engine {
   WorkItem* d_items = nullptr;
   uint8_t* d_item_general = nullptr;
   unsigned long long* d_counters = nullptr;
+  cp_slot* d_cp_stats = nullptr;           // per-variant checkpoint statistics (early termination)
+  uint32_t checkpoint_chunk[kCheckpoints];
+  uint32_t n_checkpoints = 0;
   uint32_t* h_pred = nullptr;  // pinned
   bool plan_uploaded = false;
   bool recs_registered = false;
@@ -192,6 +195,7 @@ void free_device(ldp_engine* e) {
   (void)hipFree(e->d_items);
   (void)hipFree(e->d_item_general);
   (void)hipFree(e->d_counters);
+  (void)hipFree(e->d_cp_stats);
   if (e->h_pred) {
     (void)hipHostFree(e->h_pred);
   }
@@ -225,6 +229,7 @@ void free_device(ldp_engine* e) {
   e->d_items = nullptr;
   e->d_item_general = nullptr;
   e->d_counters = nullptr;
+  e->d_cp_stats = nullptr;
   e->h_pred = nullptr;
   e->plan_uploaded = false;
 }
@@ -351,6 +356,81 @@ void plan_subcontig(const ldp_engine* e, const Subcontig& s, std::vector<uint32_
   }
 }
 
+// ---- early termination planning (ldp_device.h) -----------------------------------------------------------
+// A pair of unrelated variants becomes provably hopeless once the unvisited share of the samples drops below
+// ~sqrt(thresh): checkpoint fractions start just past 1 - sqrt(thresh) and spread out from there.
+bool early_exit_requested() {
+  const char* ee = getenv("LDP_EARLY_EXIT");
+  return !(ee && (strcmp(ee, "0") == 0));
+}
+
+int checkpoint_fractions(double r2_param, double* frac) {
+  static const double kStep[kCheckpoints] = {0.05, 0.10, 0.17, 0.30, 0.50};
+  const double f0 = 1.0 - sqrt(r2_param);
+  int n = 0;
+  if (const char* dbg = getenv("LDP_DEBUG_CP_FRACS")) {  // tuning aid: comma-separated absolute fractions
+    while (*dbg && (n < kCheckpoints)) {
+      char* end;
+      const double f = strtod(dbg, &end);
+      if (end == dbg) {
+        break;
+      }
+      frac[n++] = f;
+      dbg = (*end == ',') ? end + 1 : end;
+    }
+    return n;
+  }
+  for (int k = 0; k < kCheckpoints; ++k) {
+    const double f = f0 + kStep[k];
+    if (f < 0.93) {
+      frac[n++] = f;
+    }
+  }
+  return n;
+}
+
+// Split u distance units of one block over the four waves (contiguous runs, <= kMaxUnitsPerWave each) so that the
+// slowest wave is as fast as possible under a simple cost model: the unit holding the nearest distances runs to
+// the end (neighbouring variants are the ones in LD), every other unit stops after a fraction f of the k-chunks.
+// f = 1 (no early termination expected) gives the even split.
+uint32_t split_units(uint32_t u, bool nearest_block, double f) {
+  uint32_t best = 0;
+  double best_cost = 1e30;
+  uint32_t best_sq = 0xffffffffu;
+  uint32_t c[kWavesPerBlock];
+  for (c[0] = 0; c[0] <= kMaxUnitsPerWave; ++c[0]) {
+    for (c[1] = 0; c[1] <= kMaxUnitsPerWave; ++c[1]) {
+      for (c[2] = 0; c[2] <= kMaxUnitsPerWave; ++c[2]) {
+        if (c[0] + c[1] + c[2] > u || u - (c[0] + c[1] + c[2]) > kMaxUnitsPerWave) {
+          continue;
+        }
+        c[3] = u - (c[0] + c[1] + c[2]);
+        double cost = 0.0;
+        uint32_t sq = 0, first = 0;
+        for (uint32_t w = 0; w < kWavesPerBlock; ++w) {
+          double cw = f * c[w];
+          if (nearest_block && (first == 0) && c[w]) {
+            cw += 1.0 - f;
+          }
+          // a lone unit reads two LDS rows per pair tile instead of ~one: count it as slightly dearer
+          if (c[w] == 1) {
+            cw *= 1.1;
+          }
+          first += c[w];
+          cost = std::max(cost, cw);
+          sq += c[w] * c[w];
+        }
+        if ((cost < best_cost - 1e-9) || ((cost < best_cost + 1e-9) && (sq < best_sq))) {
+          best_cost = cost;
+          best_sq = sq;
+          best = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+        }
+      }
+    }
+  }
+  return best;
+}
+
 void build_shard(ldp_engine* e) {
   // local index space
   e->owned.clear();
@@ -401,6 +481,15 @@ void build_shard(ldp_engine* e) {
   e->items.clear();
   e->max_units = 0;
   e->computed_pairs = 0;
+  // expected share of the k-chunks a far unit runs before early termination stops it (1 = never)
+  double stop_frac = 1.0;
+  {
+    double frac[kCheckpoints];
+    const uint32_t plane_chunks = ((e->P.founder_ct + 31) / 32 + kChunkDwords - 1) / kChunkDwords;
+    if (early_exit_requested() && (plane_chunks >= 4) && checkpoint_fractions(e->P.prune_last_param, frac)) {
+      stop_frac = std::min(1.0, frac[0] + 1.0 / plane_chunks);
+    }
+  }
   for (uint32_t k : e->owned) {
     if (e->matrix_mode) {
       break;
@@ -424,19 +513,24 @@ void build_shard(ldp_engine* e) {
       uint32_t d0 = 1;
       for (uint32_t blk = 0; blk < blocks; ++blk) {
         const uint32_t u = base + ((blk < extra) ? 1 : 0);
-        // default: spread the units over all four waves (even SIMD load; measured 7 % faster on config 2);
-        // LDP_UNIT_SPLIT=packed uses as few waves as possible (fewer second-variant operand loads per pair).
+        // default: cost-model split (even when no early termination is expected: measured 7 % faster on config 2
+        // than packing); LDP_UNIT_SPLIT=packed uses as few waves as possible (fewer second-variant loads per pair).
         static const bool spread = !((getenv("LDP_UNIT_SPLIT") != nullptr) && (strcmp(getenv("LDP_UNIT_SPLIT"), "packed") == 0));
-        const uint32_t waves_used = spread ? std::min<uint32_t>(u, kWavesPerBlock) : (u + kMaxUnitsPerWave - 1) / kMaxUnitsPerWave;
-        const uint32_t wb = u / waves_used;
-        const uint32_t we = u % waves_used;
         WorkItem it;
         it.j0 = j0;
         it.jend = jend;
         it.d0 = d0;
         it.units = 0;
-        for (uint32_t w = 0; w < waves_used; ++w) {
-          it.units |= (wb + ((w < we) ? 1 : 0)) << (8 * w);
+        static const bool even = (getenv("LDP_UNIT_SPLIT") != nullptr) && (strcmp(getenv("LDP_UNIT_SPLIT"), "even") == 0);
+        if (spread) {
+          it.units = split_units(u, d0 == 1, even ? 1.0 : stop_frac);
+        } else {
+          const uint32_t waves_used = (u + kMaxUnitsPerWave - 1) / kMaxUnitsPerWave;
+          const uint32_t wb = u / waves_used;
+          const uint32_t we = u % waves_used;
+          for (uint32_t w = 0; w < waves_used; ++w) {
+            it.units |= (wb + ((w < we) ? 1 : 0)) << (8 * w);
+          }
         }
         it.sfirst = sfirst;
         it.send = send;
@@ -476,6 +570,22 @@ int ensure_device_plan(ldp_engine* e) {
   HIP_TRY(e, hipMalloc(&e->d_items, std::max<size_t>(e->items.size(), 1) * sizeof(WorkItem)));
   HIP_TRY(e, hipMalloc(&e->d_item_general, std::max<size_t>(e->items.size(), 1)));
   HIP_TRY(e, hipMalloc(&e->d_counters, 4 * sizeof(unsigned long long)));
+  HIP_TRY(e, hipMalloc(&e->d_cp_stats, n * kCpSlots * sizeof(cp_slot)));
+  // checkpoints for early termination
+  e->n_checkpoints = 0;
+  for (int k = 0; k < kCheckpoints; ++k) {
+    e->checkpoint_chunk[k] = 0xffffffffu;
+  }
+  if ((e->chunks >= 4) && !e->matrix_mode) {
+    double frac[kCheckpoints];
+    const int nf = checkpoint_fractions(e->P.prune_last_param, frac);
+    for (int k = 0; k < nf; ++k) {
+      const uint32_t c = static_cast<uint32_t>(ceil(e->chunks * frac[k]));
+      if (c && (c < e->chunks) && (!e->n_checkpoints || c > e->checkpoint_chunk[e->n_checkpoints - 1])) {
+        e->checkpoint_chunk[e->n_checkpoints++] = c;
+      }
+    }
+  }
   HIP_TRY(e, hipHostMalloc(&e->h_pred, std::max<size_t>(e->pred_words, 1) * sizeof(uint32_t), hipHostMallocDefault));
   if (e->local_ct) {
     HIP_TRY(e, hipMemcpyAsync(e->d_lo, e->lo_local.data(), e->local_ct * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
@@ -818,6 +928,12 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   A.pair_off = e->d_pair_off;
   A.counters = e->d_counters;
   A.item_general = e->d_item_general;
+  // early termination is off when the caller wants every pair's integers (parity runs) or LDP_EARLY_EXIT=0
+  A.cp_stats = (early_exit_requested() && !stats && e->n_checkpoints) ? e->d_cp_stats : nullptr;
+  for (int k = 0; k < kCheckpoints; ++k) {
+    A.checkpoint_chunk[k] = e->checkpoint_chunk[k];
+  }
+  A.n_checkpoints = A.cp_stats ? e->n_checkpoints : 0;
   A.r2_out = nullptr;
   A.r2_ld = 0;
   A.r2_row_first = 0;
@@ -882,6 +998,8 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   e->ctr.computed_pairs = e->computed_pairs;
   e->ctr.replay_pairs = replay_pairs;
   e->ctr.pred_true = h_counters[0];
+  e->ctr.early_exit_unit_chunks = h_counters[1];
+  e->ctr.tile_unit_chunks = (e->computed_pairs / (8 * kTileJ)) * e->chunks;
   e->ctr.ms_pair_kernel = kms;
   e->ctr.ms_pair_fast = kms_fast;
   e->ctr.ms_pair_general = kms_general;
@@ -1151,6 +1269,11 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
   A.pair_off = nullptr;
   A.counters = e->d_counters;
   A.item_general = d_general;
+  A.cp_stats = nullptr;  // every r^2 is wanted: no early termination
+  for (int k = 0; k < kCheckpoints; ++k) {
+    A.checkpoint_chunk[k] = 0xffffffffu;
+  }
+  A.n_checkpoints = 0;
   A.r2_out = d_out;
   A.r2_ld = ld_elems;
   A.r2_row_first = row_first;
@@ -1354,6 +1477,12 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
       PA.row_dwords = e->row_dwords;
       PA.chunks = e->chunks;
       PA.recs = e->d_recs + l0;
+      PA.cp_stats = e->d_cp_stats + static_cast<uint64_t>(l0) * kCpSlots;
+      PA.cp_tv_scale = sqrt(sqrt(e->P.prune_last_param * (1 + kSmallEpsilon)) * (1.0 - 1e-6));
+      for (int k = 0; k < kCheckpoints; ++k) {
+        PA.checkpoint_chunk[k] = e->checkpoint_chunk[k];
+      }
+      PA.n_checkpoints = e->n_checkpoints;
       if (!e->prep_pending) {
         HIP_TRY(e, hipEventRecord(e->prep_ev0, e->stream));
         e->prep_pending = true;

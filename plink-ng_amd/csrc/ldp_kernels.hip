@@ -127,8 +127,9 @@ __device__ __forceinline__ void convert_plane_pair(const uint8_t* row, uint32_t 
 template <int THREADS, int MAXIT>
 __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
   constexpr int kWaves = THREADS / 64;
-  __shared__ uint32_t red[kWaves][3];
+  __shared__ uint32_t red[kWaves][3 + 2 * kCheckpoints];
   __shared__ uint32_t s_alt_major;
+  __shared__ int32_t s_sum;
   const uint32_t v = blockIdx.x;
   const uint32_t tid = threadIdx.x;
   const uint8_t* row = A.geno + static_cast<uint64_t>(v) * A.stride_bytes;
@@ -139,6 +140,13 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
 
   uint32_t keep_hom[MAXIT ? MAXIT : 1][2], keep_r2h[MAXIT ? MAXIT : 1][2];
   uint32_t hom_ct = 0, r2h_ct = 0, both_ct = 0;
+  // hom calls / code-0 calls in k-chunks >= checkpoint k (suffix counts for early termination)
+  uint32_t rest[kCheckpoints], rest_both[kCheckpoints];
+#pragma unroll
+  for (int k = 0; k < kCheckpoints; ++k) {
+    rest[k] = 0;
+    rest_both[k] = 0;
+  }
   if constexpr (MAXIT > 0) {
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
@@ -148,26 +156,52 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
       if (p < plane_dwords) {
         convert_plane_pair(row, nbytes, aligned4, aligned16, A.encoding, A.founder_ct, p, keep_hom[it], keep_r2h[it]);
       }
-      hom_ct += __popc(keep_hom[it][0]) + __popc(keep_hom[it][1]);
+      const uint32_t hc = __popc(keep_hom[it][0]) + __popc(keep_hom[it][1]);
+      hom_ct += hc;
       r2h_ct += __popc(keep_r2h[it][0]) + __popc(keep_r2h[it][1]);
-      both_ct += __popc(keep_hom[it][0] & keep_r2h[it][0]) + __popc(keep_hom[it][1] & keep_r2h[it][1]);
+      const uint32_t bc = __popc(keep_hom[it][0] & keep_r2h[it][0]) + __popc(keep_hom[it][1] & keep_r2h[it][1]);
+      both_ct += bc;
+      const uint32_t chunk = p / kChunkDwords;
+#pragma unroll
+      for (int k = 0; k < kCheckpoints; ++k) {
+        rest[k] += (chunk >= A.checkpoint_chunk[k]) ? hc : 0;
+        rest_both[k] += (chunk >= A.checkpoint_chunk[k]) ? bc : 0;
+      }
     }
   } else {
     for (uint32_t p = 2 * tid; p < plane_dwords; p += 2 * THREADS) {
       uint32_t hom[2], r2h[2];
       convert_plane_pair(row, nbytes, aligned4, aligned16, A.encoding, A.founder_ct, p, hom, r2h);
-      hom_ct += __popc(hom[0]) + __popc(hom[1]);
+      const uint32_t hc = __popc(hom[0]) + __popc(hom[1]);
+      hom_ct += hc;
       r2h_ct += __popc(r2h[0]) + __popc(r2h[1]);
-      both_ct += __popc(hom[0] & r2h[0]) + __popc(hom[1] & r2h[1]);
+      const uint32_t bc = __popc(hom[0] & r2h[0]) + __popc(hom[1] & r2h[1]);
+      both_ct += bc;
+      const uint32_t chunk = p / kChunkDwords;
+#pragma unroll
+      for (int k = 0; k < kCheckpoints; ++k) {
+        rest[k] += (chunk >= A.checkpoint_chunk[k]) ? hc : 0;
+        rest_both[k] += (chunk >= A.checkpoint_chunk[k]) ? bc : 0;
+      }
     }
   }
   hom_ct = wave_reduce_add(hom_ct);
   r2h_ct = wave_reduce_add(r2h_ct);
   both_ct = wave_reduce_add(both_ct);
+#pragma unroll
+  for (int k = 0; k < kCheckpoints; ++k) {
+    rest[k] = wave_reduce_add(rest[k]);
+    rest_both[k] = wave_reduce_add(rest_both[k]);
+  }
   if ((tid & 63) == 0) {
     red[tid >> 6][0] = hom_ct;
     red[tid >> 6][1] = r2h_ct;
     red[tid >> 6][2] = both_ct;
+#pragma unroll
+    for (int k = 0; k < kCheckpoints; ++k) {
+      red[tid >> 6][3 + k] = rest[k];
+      red[tid >> 6][3 + kCheckpoints + k] = rest_both[k];
+    }
   }
   __syncthreads();
   if (tid == 0) {
@@ -217,9 +251,38 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
     rec.flags = alt_major | (mono << 1) | ((nm_ct != A.founder_ct) ? 4u : 0u);
     A.recs[v] = rec;
     s_alt_major = alt_major;
+    s_sum = rec.sum;
   }
   __syncthreads();
   const uint32_t alt_major = s_alt_major;
+  if (A.cp_stats && (tid < kCpSlots)) {
+    // early-termination statistics (layout: ldp_device.h); only ever read for complete-data rows
+    const double N = static_cast<double>(A.founder_ct);
+    cp_slot slot;
+    if (tid < kCheckpoints) {
+      uint32_t hom_r = 0, both_r = 0;
+      for (int w = 0; w < kWaves; ++w) {
+        hom_r += red[w][3 + tid];
+        both_r += red[w][3 + kCheckpoints + tid];
+      }
+      const uint32_t plus_r = alt_major ? (hom_r - both_r) : both_r;
+      const double s_r = static_cast<double>(static_cast<int32_t>(2 * plus_r - hom_r));
+      const uint64_t seen = static_cast<uint64_t>(A.checkpoint_chunk[tid]) * (kChunkDwords * 32);
+      const double n_r = (seen < A.founder_ct) ? static_cast<double>(A.founder_ct - seen) : 1.0;
+      const double v_r = fmax(static_cast<double>(hom_r) - s_r * s_r / n_r, 0.0);
+      slot.a = s_r * sqrt(N / n_r);
+      slot.b = sqrt(N * v_r);
+    } else {
+      uint32_t hom_all = 0;
+      for (int w = 0; w < kWaves; ++w) {
+        hom_all += red[w][0];
+      }
+      const double S = static_cast<double>(s_sum);
+      slot.a = S;
+      slot.b = sqrt(fmax(N * static_cast<double>(hom_all) - S * S, 0.0)) * A.cp_tv_scale;
+    }
+    A.cp_stats[static_cast<uint64_t>(v) * kCpSlots + tid] = slot;
+  }
   uint32_t* out_row = A.planes + static_cast<uint64_t>(v) * A.row_dwords;
   if constexpr (MAXIT > 0) {
 #pragma unroll
@@ -504,6 +567,60 @@ __device__ __forceinline__ void emit_pair(const PairKernelArgs& A, uint32_t i, u
   }
 }
 
+// Early termination test (complete data), see ldp_device.h.  After the chunks before checkpoint `cp` the partial
+// dot product of pair (i,j) is dot_p = hh - 2*xx.  |N*dot - S_i*S_j| <= |c0| + B with
+//   c0 = N*dot_p + a_i*a_j - S_i*S_j,  B = b_i*b_j   (a, b = the checkpoint slot of each variant)
+// and the pair cannot reach the threshold when |c0| + B + 1 < t_i*t_j (t = the scaled sqrt(variance numerator);
+// the +1 and the 1e-6 folded into t dwarf every FP64 rounding error here).  Returns how many of the wave's NA
+// distance units (nearest first) must stay live.
+template <int NA>
+__device__ __forceinline__ uint32_t wave_live_units(const PairKernelArgs& A, uint32_t j0, uint32_t jend, uint32_t dw0, int tx, int ty,
+                                                    const uint32_t (&hh)[4][4], const uint32_t (&xx)[4][4], uint32_t cp) {
+  bool hopeless[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    hopeless[a] = true;
+  }
+  uint32_t founder_ct = A.founder_ct;
+  asm volatile("" : "+s"(founder_ct));  // (same reason as for j below)
+  const double N = static_cast<double>(founder_ct);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    uint32_t j = j0 + tx + 8 * b;
+    // (keeps the 16 pairs' address arithmetic inside the checkpoint instead of hoisted into long-lived registers)
+    asm volatile("" : "+v"(j));
+    if (j < jend) {
+      const uint32_t span_j = j - A.lo[j];
+      const cp_slot cj = A.cp_stats[static_cast<uint64_t>(j) * kCpSlots + cp];
+      const cp_slot gj = A.cp_stats[static_cast<uint64_t>(j) * kCpSlots + kCheckpoints];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        const uint32_t d = dw0 + ty + 8 * a;
+        if (d <= span_j) {
+          const uint32_t i = j - d;
+          const cp_slot ci = A.cp_stats[static_cast<uint64_t>(i) * kCpSlots + cp];
+          const cp_slot gi = A.cp_stats[static_cast<uint64_t>(i) * kCpSlots + kCheckpoints];
+          const double dot_p = static_cast<double>(static_cast<int32_t>(hh[a][b] - 2 * xx[a][b]));
+          const double c0 = fma(N, dot_p, fma(ci.a, cj.a, -(gi.a * gj.a)));
+          const double bound = fabs(c0) + fma(ci.b, cj.b, 1.0);
+          hopeless[a] = hopeless[a] && (bound < gi.b * gj.b);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // units are ordered by distance and LD decays with it: drop the hopeless far end, keep everything nearer than
+  // the farthest unit that still has a live pair
+  uint32_t live = 0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    if (!__all(hopeless[a])) {
+      live = a + 1;
+    }
+  }
+  return live;
+}
+
 // One wave per work item: does any LDS row of the tile carry missing calls?  Decides which of the two
 // pair_tiles_kernel instantiations owns the item (the other one exits at once).
 __global__ __launch_bounds__(256) void classify_items_kernel(PairKernelArgs A) {
@@ -536,6 +653,7 @@ constexpr int kEpilogueLdsDwords = 32 * kBlockThreads;  // 32 KiB
 template <bool GENERAL>
 __global__ __launch_bounds__(kBlockThreads, GENERAL ? 3 : 4) void pair_tiles_kernel(PairKernelArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ uint32_t s_waves_done;
   // XCD-aware order: hardware places block b on XCD b % 8; give each XCD a contiguous run of work
   // items so neighbouring J-blocks (which share most of their window rows) hit the same L2.
   const uint32_t per_xcd = (A.n_items + 7) / 8;
@@ -588,21 +706,58 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 3 : 4) void pair_tiles_ker
         xx[a][b] = 0;
       }
     }
+    if (tid == 0) {
+      s_waves_done = 0;
+    }
     dma_chunk(plan, tile_base, lds, wave);
     __syncthreads();  // (drains this wave's DMA, then barrier)
+    uint32_t live = units_w;  // distance units this wave still accumulates (wave-uniform)
+    if ((!live) && (lane == 0)) {
+      atomicOr(&s_waves_done, 1u << wave);
+    }
+    uint32_t next_cp = 0;
+    const uint32_t n_cp = A.cp_stats ? A.n_checkpoints : 0;
     for (uint32_t kc = 0; kc < A.chunks; ++kc) {
       if (kc + 1 < A.chunks) {
         dma_chunk(plan, tile_base + static_cast<uint64_t>(kc + 1) * kChunkBytes, lds + ((kc + 1) & 1) * buf_dwords, wave);
       }
       const uint4* l4 = reinterpret_cast<const uint4*>(lds + (kc & 1) * buf_dwords);
-      switch (units_w) {
+      const bool at_cp = (next_cp < n_cp) && (kc + 1 == A.checkpoint_chunk[next_cp]);  // block-uniform
+      switch (live) {
         case 1: tile_chunk_fast<1>(l4, jrow, irow0, hh, xx); break;
         case 2: tile_chunk_fast<2>(l4, jrow, irow0, hh, xx); break;
         case 3: tile_chunk_fast<3>(l4, jrow, irow0, hh, xx); break;
         case 4: tile_chunk_fast<4>(l4, jrow, irow0, hh, xx); break;
         default: break;
       }
+      if (at_cp && live) {
+        uint32_t keep = live;
+        switch (live) {
+          case 1: keep = wave_live_units<1>(A, it.j0, it.jend, dw0, tx, ty, hh, xx, next_cp); break;
+          case 2: keep = wave_live_units<2>(A, it.j0, it.jend, dw0, tx, ty, hh, xx, next_cp); break;
+          case 3: keep = wave_live_units<3>(A, it.j0, it.jend, dw0, tx, ty, hh, xx, next_cp); break;
+          case 4: keep = wave_live_units<4>(A, it.j0, it.jend, dw0, tx, ty, hh, xx, next_cp); break;
+          default: break;
+        }
+        if (keep != live) {
+          // every pair of the dropped units is provably below the threshold
+          if (lane == 0) {
+            atomicAdd(A.counters + 1, static_cast<unsigned long long>(A.chunks - kc - 1) * (live - keep));
+            if (!keep) {
+              atomicOr(&s_waves_done, 1u << wave);
+            }
+          }
+          live = __builtin_amdgcn_readfirstlane(keep);
+        }
+      }
       __syncthreads();  // next chunk landed (vmcnt drained) and every wave is done reading this one
+      if (at_cp) {
+        ++next_cp;
+        // s_waves_done only changes at checkpoints, before a barrier every wave must pass: this read is block-uniform
+        if (s_waves_done == (1u << kWavesPerBlock) - 1) {
+          break;
+        }
+      }
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -612,8 +767,9 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 3 : 4) void pair_tiles_ker
         lds[(2 * (a * 4 + b) + 1) * kBlockThreads + tid] = xx[a][b];
       }
     }
+    const uint32_t emit_units = live;  // pairs of dropped units are all below the threshold
 #pragma unroll 1
-    for (uint32_t p = 0; p < 4 * units_w; ++p) {
+    for (uint32_t p = 0; p < 4 * emit_units; ++p) {
       const uint32_t a = p >> 2, b = p & 3;
       const uint32_t j = it.j0 + tx + 8 * b;
       const uint32_t d = dw0 + ty + 8 * a;

@@ -2,6 +2,7 @@
 inputs.  Integer work is compared bit-exactly: bit-planes, per-variant aggregates, the 6-tuple of every
 candidate pair out of the tile kernel, and the final prune set."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -139,6 +140,9 @@ def check_run(pkg, raw, chr_idx, bps, window, step, is_bp, r2, order, shard_worl
             ctr = eng.counters()
             assert ctr["candidate_pairs"] == cand
             assert ctr["computed_pairs"] >= cand
+            # the production path (early termination of hopeless tiles enabled) must agree
+            assert np.array_equal(eng.run(), removed)
+            assert eng.counters()["pred_true"] == ctr["pred_true"]
         else:
             removed = eng.run()
         union |= removed
@@ -255,3 +259,65 @@ def test_config2_sample_count(gpu_pkg):
     eng.close()
     assert np.array_equal(got, want)
     assert ctr["candidate_pairs"] >= evals
+
+
+def _run_early_exit(pkg, packed, n, chr_idx, bps, window, step, is_bp, r2, order, enabled):
+    old = os.environ.get("LDP_EARLY_EXIT")
+    os.environ["LDP_EARLY_EXIT"] = "1" if enabled else "0"
+    try:
+        eng = pkg.LdPruneEngine(n, window, step, is_bp, r2, order=order, device=0)
+        eng.set_variants(chr_idx, bps)
+        eng.load_genotypes_host(0, packed, pkg.LDP_GENO_REF)
+        removed = eng.run()
+        ctr = eng.counters()
+        eng.close()
+    finally:
+        if old is None:
+            del os.environ["LDP_EARLY_EXIT"]
+        else:
+            os.environ["LDP_EARLY_EXIT"] = old
+    return removed, ctr
+
+
+@pytest.mark.parametrize("n,r2,order", [(2100, 0.5, 2), (5000, 0.2, 2), (5000, 0.9, 1), (20000, 0.5, 2), (20000, 0.05, 2)])
+def test_early_termination_is_invisible(gpu_pkg, n, r2, order):
+    """Waves that stop at a checkpoint (ldp_device.h) may only ever skip pairs whose predicate is false: the
+    prune set and the number of true predicates are those of the exhaustive run and of the oracle."""
+    m = 700
+    raw = T.synth_raw_codes(m, n, seed=n % 97, missing_rate=0.0)
+    chr_idx, bps = make_positions(m, 2, 5)
+    packed = T.pack_2bit(raw)
+    off, c0 = _run_early_exit(gpu_pkg, packed, n, chr_idx, bps, 150, 1, False, r2, order, False)
+    on, c1 = _run_early_exit(gpu_pkg, packed, n, chr_idx, bps, 150, 1, False, r2, order, True)
+    assert c0["early_exit_unit_chunks"] == 0
+    assert np.array_equal(on, off)
+    assert c1["pred_true"] == c0["pred_true"]
+    assert c1["tile_unit_chunks"] == c0["tile_unit_chunks"] > 0
+    if r2 >= 0.5:
+        assert c1["early_exit_unit_chunks"] > 0  # unrelated pairs are provably hopeless early on
+    inv, mf, _ = T.oracle_prepare(raw)
+    want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 150, 1, False, r2, order)
+    assert np.array_equal(on, want)
+
+
+def test_early_termination_late_correlation(gpu_pkg):
+    """Adversarial layout: pairs that look unrelated over the first 45 % of the samples and are identical over
+    the rest.  A bound that extrapolated from the visited samples would drop them; the remainder bound keeps them."""
+    n, m = 6000, 260
+    rng = np.random.default_rng(11)
+    raw = T.synth_raw_codes(m, n, seed=12, missing_rate=0.0)
+    cut = int(0.45 * n)
+    for v in range(1, m, 2):
+        raw[v, cut:] = raw[v - 1, cut:]
+        raw[v, :cut] = rng.permutation(raw[v, :cut])
+    chr_idx = np.zeros(m, dtype=np.uint32)
+    packed = T.pack_2bit(raw)
+    inv, mf, _ = T.oracle_prepare(raw)
+    for r2 in (0.2, 0.3):
+        want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, np.arange(m, dtype=np.uint32), mf, 100, 1, False, r2, 2)
+        on, c1 = _run_early_exit(gpu_pkg, packed, n, chr_idx, None, 100, 1, False, r2, 2, True)
+        off, c0 = _run_early_exit(gpu_pkg, packed, n, chr_idx, None, 100, 1, False, r2, 2, False)
+        assert want.sum() >= m // 4
+        assert np.array_equal(off, want)
+        assert np.array_equal(on, want)
+        assert c1["pred_true"] == c0["pred_true"]
