@@ -26,7 +26,10 @@ constexpr int kLdsRowDwords = kRowChunkDwords + 4; // 36: odd number (9) of 16-B
 constexpr int kTileJ = 32;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlockThreads = 64 * kWavesPerBlock;
-constexpr int kMaxUnitsPerWave = 4;              // NA
+#ifndef LDP_MAX_UNITS_PER_WAVE
+#define LDP_MAX_UNITS_PER_WAVE 3
+#endif
+constexpr int kMaxUnitsPerWave = LDP_MAX_UNITS_PER_WAVE;  // NA: 8-distance units a wave accumulates at once
 constexpr int kMaxUnitsPerBlock = kWavesPerBlock * kMaxUnitsPerWave;  // 16 -> 128 distances
 
 struct WorkItem {
@@ -78,6 +81,7 @@ struct PairKernelArgs {
   const cp_slot* cp_stats;       // [variant][kCpSlots]; nullptr disables early termination
   uint32_t checkpoint_chunk[kCheckpoints];  // ascending; a checkpoint fires after chunk (value - 1) is consumed
   uint32_t n_checkpoints;
+  uint32_t lds_dwords;           // dynamic LDS of the launch (set by launch_pair_tiles)
   void* r2_out;
   uint64_t r2_ld;
   uint32_t r2_row_first;
@@ -102,11 +106,18 @@ struct PrepareArgs {
 
 hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream);
 // ev[0..3] (optional): recorded before/after the complete-data kernel and before/after the general kernel
-hipError_t launch_pair_tiles(const PairKernelArgs& a, uint32_t max_units, hipStream_t stream, hipEvent_t* ev);
+hipError_t launch_pair_tiles(const PairKernelArgs& a, uint32_t max_rows, hipStream_t stream, hipEvent_t* ev);
 hipError_t launch_pair_stats_ref(const uint32_t* planes, uint64_t row_dwords, uint32_t chunks, uint32_t plane_base_variant,
                                  const uint32_t* first, const uint32_t* second, uint32_t n_pairs,
                                  ldp_pair_stats_t* out, hipStream_t stream);
-size_t pair_tiles_lds_bytes(uint32_t max_units);
+size_t pair_tiles_lds_bytes(uint32_t max_rows);
+
+// LDS rows of a work item that stages `units` 8-distance units starting at distance d0 (make_geom in the kernel)
+inline uint32_t tile_rows(uint32_t d0, uint32_t units) {
+  const uint32_t dmax = d0 + 8 * units - 1;
+  const uint32_t n_irows = 8 * units + 31;
+  return ((dmax < n_irows) ? dmax : n_irows) + kTileJ;
+}
 
 }  // namespace ldp
 #endif

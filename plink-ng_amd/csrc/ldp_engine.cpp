@@ -101,7 +101,7 @@ struct ldp_engine {
   uint64_t cand_pairs = 0;
   uint64_t computed_pairs = 0;
   std::vector<WorkItem> items;
-  uint32_t max_units = 0;
+  uint32_t max_rows = 0;                   // largest LDS row count over the work items
 
   // ---- data ----
   uint32_t chunks = 0;
@@ -479,7 +479,7 @@ void build_shard(ldp_engine* e) {
 
   // work items: 32 seconds x runs of 8-distance units, <= 16 units per block, spread over waves
   e->items.clear();
-  e->max_units = 0;
+  e->max_rows = 0;
   e->computed_pairs = 0;
   // expected share of the k-chunks a far unit runs before early termination stops it (1 = never)
   double stop_frac = 1.0;
@@ -535,7 +535,7 @@ void build_shard(ldp_engine* e) {
         it.sfirst = sfirst;
         it.send = send;
         e->items.push_back(it);
-        e->max_units = std::max(e->max_units, u);
+        e->max_rows = std::max(e->max_rows, tile_rows(d0, u));
         e->computed_pairs += static_cast<uint64_t>(u) * 8 * kTileJ;
         d0 += 8 * u;
       }
@@ -948,7 +948,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     HIP_TRY(e, hipEventCreate(&evk[q]));
   }
   HIP_TRY(e, hipEventRecord(ev0, e->stream));
-  hipError_t krc = launch_pair_tiles(A, e->max_units, e->stream, evk);
+  hipError_t krc = launch_pair_tiles(A, e->max_rows, e->stream, evk);
   if (krc != hipSuccess) {
     return hipfail(e, krc, "pair_tiles_kernel launch");
   }
@@ -998,7 +998,10 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   e->ctr.computed_pairs = e->computed_pairs;
   e->ctr.replay_pairs = replay_pairs;
   e->ctr.pred_true = h_counters[0];
-  e->ctr.early_exit_unit_chunks = h_counters[1];
+  if (getenv("LDP_DEBUG_PHASE_CLOCKS")) {
+    fprintf(stderr, "phase clocks: before switch %llu, after switch %llu (sum over blocks, cycles)\n", h_counters[2], h_counters[3]);
+  }
+  e->ctr.early_exit_unit_chunks = h_counters[1] / 4;  // the kernel counts quarter units (one second-variant group)
   e->ctr.tile_unit_chunks = (e->computed_pairs / (8 * kTileJ)) * e->chunks;
   e->ctr.ms_pair_kernel = kms;
   e->ctr.ms_pair_fast = kms_fast;
@@ -1199,7 +1202,7 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
   HIP_TRY(e, hipSetDevice(e->device));
   // tiles of the rows' lower triangle: (32 seconds) x (all distances 1..j), <= 128 distances per block
   std::vector<WorkItem> items;
-  uint32_t max_units = 0;
+  uint32_t max_rows = 0;
   uint64_t computed = 0, cand = 0;
   const uint32_t row_end = row_first + row_ct;
   for (uint32_t j0 = row_first; j0 < row_end; j0 += kTileJ) {
@@ -1232,7 +1235,7 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
       it.sfirst = 0;
       it.send = e->local_ct;
       items.push_back(it);
-      max_units = std::max(max_units, u);
+      max_rows = std::max(max_rows, tile_rows(d0, u));
       computed += static_cast<uint64_t>(u) * 8 * kTileJ;
       d0 += 8 * u;
     }
@@ -1282,7 +1285,7 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
   for (int q = 0; q < 4; ++q) {
     HIP_TRY(e, hipEventCreate(&evk[q]));
   }
-  hipError_t krc = launch_pair_tiles(A, std::max<uint32_t>(max_units, 1), e->stream, evk);
+  hipError_t krc = launch_pair_tiles(A, std::max<uint32_t>(max_rows, kTileJ + 8), e->stream, evk);
   if (krc != hipSuccess) {
     return hipfail(e, krc, "pair_tiles_kernel launch");
   }

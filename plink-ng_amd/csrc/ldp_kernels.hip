@@ -361,7 +361,7 @@ __device__ __forceinline__ uint4 lds_row_slot(const uint4* __restrict__ l4, int 
 // Per 16-byte k-group a thread holds its 4 second-variants (jH/jR) and streams the NA+3 first-variants
 // it needs (one LDS row per value of c = b - a), software-pipelined one row ahead.
 template <int NA>
-__device__ __forceinline__ void tile_chunk_fast(const uint4* __restrict__ l4, int jrow, int irow, uint32_t (&hh)[4][4], uint32_t (&xx)[4][4]) {
+__device__ __forceinline__ void tile_chunk_fast(const uint4* __restrict__ l4, int jrow, int irow, uint32_t (&hh)[kMaxUnitsPerWave][4], uint32_t (&xx)[kMaxUnitsPerWave][4]) {
 #pragma unroll 1
   for (int g = 0; g < kChunkDwords / 4; ++g) {
     uint4 jH[4], jR[4];
@@ -392,6 +392,56 @@ __device__ __forceinline__ void tile_chunk_fast(const uint4* __restrict__ l4, in
       __builtin_amdgcn_sched_barrier(0);
       iH = nH;
       iR = nR;
+    }
+  }
+}
+
+// Column mode (after early termination has left only a block's nearest <= 4 units live, see pair_tiles_kernel): a
+// wave owns ONE of the four second-variant groups (b) across all NA live units, so the four waves share what is
+// left evenly.  One J row and NA I rows per 16-byte k-group; the next group's rows are fetched while the current
+// one is consumed.  Accumulators live in hh[a][0] / xx[a][0].
+template <int NA>
+__device__ __forceinline__ void tile_chunk_column(const uint4* __restrict__ l4, int jrow, int irow, uint32_t (&hh)[kMaxUnitsPerWave][4], uint32_t (&xx)[kMaxUnitsPerWave][4]) {
+  uint4 jH = lds_row_slot(l4, jrow, 0);
+  uint4 jR = lds_row_slot(l4, jrow, kChunkDwords / 4);
+  uint4 iH[NA], iR[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    iH[a] = lds_row_slot(l4, irow - 8 * a, 0);
+    iR[a] = lds_row_slot(l4, irow - 8 * a, kChunkDwords / 4);
+  }
+#pragma unroll
+  for (int g = 0; g < kChunkDwords / 4; ++g) {
+    uint4 njH = jH, njR = jR;
+    uint4 niH[NA], niR[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      niH[a] = iH[a];
+      niR[a] = iR[a];
+    }
+    if (g + 1 < kChunkDwords / 4) {
+      njH = lds_row_slot(l4, jrow, g + 1);
+      njR = lds_row_slot(l4, jrow, (kChunkDwords / 4) + g + 1);
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        niH[a] = lds_row_slot(l4, irow - 8 * a, g + 1);
+        niR[a] = lds_row_slot(l4, irow - 8 * a, (kChunkDwords / 4) + g + 1);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      const uint4 h = and4(jH, iH[a]);
+      const uint4 x = and4(h, xor4(jR, iR[a]));
+      bcnt_acc4(hh[a][0], h);
+      bcnt_acc4(xx[a][0], x);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    jH = njH;
+    jR = njR;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      iH[a] = niH[a];
+      iR[a] = niR[a];
     }
   }
 }
@@ -444,14 +494,20 @@ __device__ __forceinline__ void tile_chunk_general(const uint4* __restrict__ l4,
   }
 }
 
+// LDS rows of a tile.  Row r holds variant vlo + r for the first-variant (I) rows r < jrow_base; the 32
+// second-variant (J) rows follow at jrow_base.  When the block's distance range starts within 32 variants of the
+// diagonal the two ranges touch or overlap and the J rows simply ARE the upper I rows (one copy, one DMA):
+// a tile over distances 1..8U stages 8U+32 rows instead of 8U+63.
 struct TileGeom {
-  uint32_t j0, jend, sfirst, send;
-  int64_t ilo;  // variant index of I-row 0
-  int rtot;     // LDS rows in use
+  uint32_t j0, sfirst, send;
+  int64_t vlo;    // variant of LDS row 0, before clamping to the subcontig
+  int dmax;       // farthest distance staged
+  int jrow_base;  // LDS row of variant j0
+  int rtot;       // LDS rows in use
 };
 
 __device__ __forceinline__ int64_t row_variant(const TileGeom& G, int r) {
-  int64_t v = (r < kTileJ) ? (static_cast<int64_t>(G.j0) + r) : (G.ilo + (r - kTileJ));
+  int64_t v = (r < G.jrow_base) ? (G.vlo + r) : (static_cast<int64_t>(G.j0) + (r - G.jrow_base));
   if (v < static_cast<int64_t>(G.sfirst)) {
     v = G.sfirst;
   }
@@ -461,34 +517,57 @@ __device__ __forceinline__ int64_t row_variant(const TileGeom& G, int r) {
   return v;
 }
 
+// units_total = how many of the item's 8-distance units (nearest first) are staged
 __device__ __forceinline__ TileGeom make_geom(const WorkItem& it, uint32_t units_total) {
   TileGeom G;
   G.j0 = it.j0;
-  G.jend = it.jend;
   G.sfirst = it.sfirst;
   G.send = it.send;
-  G.ilo = static_cast<int64_t>(it.j0) - (it.d0 + 8 * units_total - 1);
-  G.rtot = kTileJ + 8 * units_total + 31;
+  G.dmax = static_cast<int>(it.d0 + 8 * units_total - 1);
+  const int n_irows = static_cast<int>(8 * units_total) + 31;
+  G.jrow_base = (G.dmax < n_irows) ? G.dmax : n_irows;
+  G.rtot = G.jrow_base + kTileJ;
+  G.vlo = static_cast<int64_t>(it.j0) - G.dmax;
   return G;
 }
 
-// ---- global -> LDS staging by LDS-DMA (global_load_lds_dwordx4), double-buffered -----------------------
-// An LDS buffer is a linear array of 16-byte slots, kLdsRowSlots (9) per row: 8 data slots (4 hom + 4
-// ref2het) + 1 pad slot that keeps the row stride odd.  One DMA wave-instruction fills 64 consecutive
-// slots (1 KiB, lane l -> slot 64*T + l); the per-lane GLOBAL address is free, so each lane simply fetches
-// the 16 bytes that belong in its slot (pad slots re-fetch slot 0 of their row and are never read).
-// The lane->source mapping does not depend on the k-chunk, so it is computed once per block.
-constexpr int kMaxDmaPerWave = ((191 * kLdsRowSlots + 63) / 64 + kWavesPerBlock - 1) / kWavesPerBlock;  // 7 at 9 slots/row
+// ---- global -> LDS staging by LDS-DMA (global_load_lds_dwordx4), a ring of 2..4 stages ------------------
+// A stage is a linear array of 16-byte slots, kLdsRowSlots (9) per row: 8 data slots (4 hom + 4 ref2het) + 1 pad
+// slot that keeps the row stride odd.  One DMA wave-instruction fills 64 consecutive slots (1 KiB, lane l ->
+// slot 64*T + l); the per-lane GLOBAL address is free, so each lane simply fetches the 16 bytes that belong in its
+// slot (pad slots re-fetch slot 0 of their row and are never read).  The lane->source mapping does not depend on
+// the k-chunk: it is computed when the tile is planned and again whenever early termination shrinks the tile.
+// Stage count S = how many stages of the current tile fit the block's LDS (>= 2): chunk kc lives in stage kc % S
+// and up to S-1 chunks are in flight, so a tile that has shrunk to its near units hides the DMA latency that a
+// double buffer cannot.
+constexpr int kMaxTileRows = kTileJ + 8 * kMaxUnitsPerBlock + 31;
+constexpr int kMaxDmaPerWave = ((kMaxTileRows * kLdsRowSlots + 63) / 64 + kWavesPerBlock - 1) / kWavesPerBlock;  // 6 at 12 units
+constexpr uint32_t kMaxStages = 4;
+constexpr uint32_t kChunkBytes = kRowChunkDwords * sizeof(uint32_t);
 
-struct DmaPlan {
-  uint32_t src_off[kMaxDmaPerWave];  // byte offset of this lane's 16 B relative to the block's first variant row
+struct Stager {
+  uint32_t* src_off;                 // [kMaxDmaPerWave][kBlockThreads] in LDS: byte offset of a lane's 16 B relative to tile_base
+  const uint8_t* tile_base;          // chunk 0 of the lowest variant the tile touches
   uint32_t n_instr;                  // DMA wave-instructions per k-chunk for the whole block
+  uint32_t mine;                     // ... of which this wave issues
+  uint32_t stage_dwords;
+  uint32_t stages;
 };
 
-__device__ __forceinline__ DmaPlan make_dma_plan(const TileGeom& G, uint64_t row_bytes, uint32_t wave, uint32_t lane, int64_t vmin) {
-  DmaPlan P;
+// NOTE on registers: nothing that lives across the k-loop may be spilled.  A spill comes back through a scratch
+// load, and the vmcnt wait in front of its first use drains the very DMA queue the ring keeps full (measured:
+// 2x on the latency-bound tail of a tile).  Hence kMaxUnitsPerWave = 3, and hence the per-lane source offsets
+// live in LDS (6 KiB, read back with one ds_read per DMA instruction) instead of six registers.
+__device__ __forceinline__ void plan_stager(Stager& st, const TileGeom& G, const PairKernelArgs& A, uint32_t wave, uint32_t lane) {
+  const uint32_t row_bytes = static_cast<uint32_t>(A.row_dwords * sizeof(uint32_t));
+  const int64_t vmin = row_variant(G, 0);
   const uint32_t total_slots = static_cast<uint32_t>(G.rtot) * kLdsRowSlots;
-  P.n_instr = (total_slots + 63) / 64;
+  st.n_instr = (total_slots + 63) / 64;
+  st.mine = (st.n_instr > wave) ? (st.n_instr - wave + kWavesPerBlock - 1) / kWavesPerBlock : 0;
+  st.stage_dwords = st.n_instr * 256;
+  const uint32_t fit = A.lds_dwords / st.stage_dwords;
+  st.stages = (fit < kMaxStages) ? fit : kMaxStages;
+  st.tile_base = reinterpret_cast<const uint8_t*>(A.planes) + static_cast<uint64_t>(vmin) * row_bytes;
 #pragma unroll
   for (int t = 0; t < kMaxDmaPerWave; ++t) {
     const uint32_t L = (wave + kWavesPerBlock * t) * 64 + lane;
@@ -500,24 +579,70 @@ __device__ __forceinline__ DmaPlan make_dma_plan(const TileGeom& G, uint64_t row
     if (sl == kLdsRowSlots - 1) {
       sl = 0;
     }
-    P.src_off[t] = static_cast<uint32_t>((row_variant(G, row) - vmin) * static_cast<int64_t>(row_bytes)) + sl * 16;
+    st.src_off[t * kBlockThreads + wave * 64 + lane] = static_cast<uint32_t>(row_variant(G, row) - vmin) * row_bytes + sl * 16;
   }
-  return P;
 }
 
-__device__ __forceinline__ void dma_chunk(const DmaPlan& P, const uint8_t* chunk_base, uint32_t* lds_buf, uint32_t wave) {
+// queue k-chunk kc into ring stage `stage`
+__device__ __forceinline__ void dma_chunk(const Stager& st, uint32_t* lds, uint32_t kc, uint32_t stage, uint32_t wave, uint32_t lane) {
+  const uint8_t* chunk_base = st.tile_base + static_cast<uint64_t>(kc) * kChunkBytes;
+  uint32_t* dst = lds + stage * st.stage_dwords;
 #pragma unroll
   for (int t = 0; t < kMaxDmaPerWave; ++t) {
     const uint32_t T = wave + kWavesPerBlock * t;
-    if (T < P.n_instr) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(chunk_base + P.src_off[t]),
-                                       (__attribute__((address_space(3))) void*)(lds_buf + T * 256), 16, 0, 0);
+    if (T < st.n_instr) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(chunk_base + st.src_off[t * kBlockThreads + wave * 64 + lane]),
+                                       (__attribute__((address_space(3))) void*)(dst + T * 256), 16, 0, 0);
     }
   }
 }
 
-__device__ __forceinline__ uint32_t lds_buffer_dwords(int rtot) {
-  return ((static_cast<uint32_t>(rtot) * kLdsRowSlots + 63) / 64) * 256;
+// Wait until at most `allowed` of this wave's memory operations are still in flight (they complete in order, so
+// everything older has landed), then the workgroup barrier.  Hand-written because __syncthreads() always drains
+// to zero, which would serialise the ring.  The "memory" clobber keeps LDS reads and DMA issues on their side.
+__device__ __forceinline__ void wait_dma_then_barrier(uint32_t allowed) {
+#define LDP_WAIT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory"); break;
+  switch (allowed) {
+    LDP_WAIT_CASE(1) LDP_WAIT_CASE(2) LDP_WAIT_CASE(3) LDP_WAIT_CASE(4) LDP_WAIT_CASE(5) LDP_WAIT_CASE(6) LDP_WAIT_CASE(7)
+    LDP_WAIT_CASE(8) LDP_WAIT_CASE(9) LDP_WAIT_CASE(10) LDP_WAIT_CASE(11) LDP_WAIT_CASE(12) LDP_WAIT_CASE(13) LDP_WAIT_CASE(14)
+    default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+  }
+#undef LDP_WAIT_CASE
+}
+
+// Position in the ring: next chunk to consume / to queue and the stages they map to.
+struct Ring {
+  uint32_t kc, read_stage;
+  uint32_t issued, issue_stage;
+};
+
+__device__ __forceinline__ void ring_start(Ring& R, const Stager& st, uint32_t* lds, uint32_t kc, uint32_t chunks, uint32_t wave, uint32_t lane) {
+  R.kc = kc;
+  R.read_stage = 0;
+  R.issued = kc;
+  R.issue_stage = 0;
+  while ((R.issued < chunks) && (R.issued + 1 < kc + st.stages)) {
+    dma_chunk(st, lds, R.issued, R.issue_stage, wave, lane);
+    ++R.issued;
+    R.issue_stage = (R.issue_stage + 1 == st.stages) ? 0 : R.issue_stage + 1;
+  }
+}
+
+// chunk R.kc is ready in stage R.read_stage for every wave on return; the chunk that reuses the stage consumed in
+// the previous iteration is queued (every wave is past the barrier, so nobody still reads it)
+__device__ __forceinline__ const uint4* ring_acquire(Ring& R, const Stager& st, uint32_t* lds, uint32_t chunks, uint32_t wave, uint32_t lane) {
+  wait_dma_then_barrier(st.mine * (R.issued - R.kc - 1));
+  if (R.issued < chunks) {
+    dma_chunk(st, lds, R.issued, R.issue_stage, wave, lane);
+    ++R.issued;
+    R.issue_stage = (R.issue_stage + 1 == st.stages) ? 0 : R.issue_stage + 1;
+  }
+  return reinterpret_cast<const uint4*>(lds + R.read_stage * st.stage_dwords);
+}
+
+__device__ __forceinline__ void ring_release(Ring& R, const Stager& st) {
+  ++R.kc;
+  R.read_stage = (R.read_stage + 1 == st.stages) ? 0 : R.read_stage + 1;
 }
 
 // plink2_ld.cc:1085-1090, no FMA contraction possible (multiplies only); var1 belongs to the FIRST variant.
@@ -546,7 +671,8 @@ __device__ __forceinline__ double r2_unphased(const ldp_pair_stats_t& s) {
   return __ddiv_rn(__dmul_rn(cov01, cov01), variance_prod);
 }
 
-__device__ __forceinline__ void emit_pair(const PairKernelArgs& A, uint32_t i, uint32_t j, uint32_t lo_j, const ldp_pair_stats_t& st) {
+// returns true when the prune predicate holds (the caller counts)
+__device__ __forceinline__ bool emit_pair(const PairKernelArgs& A, uint32_t i, uint32_t j, uint32_t lo_j, const ldp_pair_stats_t& st) {
   if (A.stats) {
     A.stats[A.pair_off[j] + (i - lo_j)] = st;
   }
@@ -559,12 +685,13 @@ __device__ __forceinline__ void emit_pair(const PairKernelArgs& A, uint32_t i, u
     } else {
       static_cast<double*>(A.r2_out)[idx] = r2;
     }
-    return;
+    return false;
   }
   if (exceeds(st, A.thresh)) {
     atomicOr(&A.pred[A.row_off[j] + ((i >> 5) - (lo_j >> 5))], 1u << (i & 31));
-    atomicAdd(A.counters, 1ull);
+    return true;
   }
+  return false;
 }
 
 // Early termination test (complete data), see ldp_device.h.  After the chunks before checkpoint `cp` the partial
@@ -573,9 +700,11 @@ __device__ __forceinline__ void emit_pair(const PairKernelArgs& A, uint32_t i, u
 // and the pair cannot reach the threshold when |c0| + B + 1 < t_i*t_j (t = the scaled sqrt(variance numerator);
 // the +1 and the 1e-6 folded into t dwarf every FP64 rounding error here).  Returns how many of the wave's NA
 // distance units (nearest first) must stay live.
-template <int NA>
-__device__ __forceinline__ uint32_t wave_live_units(const PairKernelArgs& A, uint32_t j0, uint32_t jend, uint32_t dw0, int tx, int ty,
-                                                    const uint32_t (&hh)[4][4], const uint32_t (&xx)[4][4], uint32_t cp) {
+// NB = 4: the wave owns all four second-variant groups b (accumulators hh[a][b]); NB = 1: column mode, the wave
+// owns group b0 only (accumulators hh[a][0]).
+template <int NA, int NB>
+__device__ __forceinline__ uint32_t wave_live_units(const PairKernelArgs& A, uint32_t j0, uint32_t jend, uint32_t dw0, int tx, int ty, uint32_t b0,
+                                                    const uint32_t (&hh)[kMaxUnitsPerWave][4], const uint32_t (&xx)[kMaxUnitsPerWave][4], uint32_t cp) {
   bool hopeless[NA];
 #pragma unroll
   for (int a = 0; a < NA; ++a) {
@@ -585,29 +714,35 @@ __device__ __forceinline__ uint32_t wave_live_units(const PairKernelArgs& A, uin
   asm volatile("" : "+s"(founder_ct));  // (same reason as for j below)
   const double N = static_cast<double>(founder_ct);
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    uint32_t j = j0 + tx + 8 * b;
+  for (int b = 0; b < NB; ++b) {
+    uint32_t j = j0 + tx + 8 * (b + b0);
     // (keeps the 16 pairs' address arithmetic inside the checkpoint instead of hoisted into long-lived registers)
     asm volatile("" : "+v"(j));
     if (j < jend) {
       const uint32_t span_j = j - A.lo[j];
       const cp_slot cj = A.cp_stats[static_cast<uint64_t>(j) * kCpSlots + cp];
       const cp_slot gj = A.cp_stats[static_cast<uint64_t>(j) * kCpSlots + kCheckpoints];
+      // all loads of this j first (one memory latency per b instead of one per pair), then the arithmetic
+      cp_slot ci[NA], gi[NA];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        const uint32_t d = dw0 + ty + 8 * a;
+        const uint32_t i = (d <= j) ? (j - d) : 0;  // (in range whatever lo[j] turns out to be: no dependent load)
+        ci[a] = A.cp_stats[static_cast<uint64_t>(i) * kCpSlots + cp];
+        gi[a] = A.cp_stats[static_cast<uint64_t>(i) * kCpSlots + kCheckpoints];
+      }
 #pragma unroll
       for (int a = 0; a < NA; ++a) {
         const uint32_t d = dw0 + ty + 8 * a;
         if (d <= span_j) {
-          const uint32_t i = j - d;
-          const cp_slot ci = A.cp_stats[static_cast<uint64_t>(i) * kCpSlots + cp];
-          const cp_slot gi = A.cp_stats[static_cast<uint64_t>(i) * kCpSlots + kCheckpoints];
           const double dot_p = static_cast<double>(static_cast<int32_t>(hh[a][b] - 2 * xx[a][b]));
-          const double c0 = fma(N, dot_p, fma(ci.a, cj.a, -(gi.a * gj.a)));
-          const double bound = fabs(c0) + fma(ci.b, cj.b, 1.0);
-          hopeless[a] = hopeless[a] && (bound < gi.b * gj.b);
+          const double c0 = fma(N, dot_p, fma(ci[a].a, cj.a, -(gi[a].a * gj.a)));
+          const double bound = fabs(c0) + fma(ci[a].b, cj.b, 1.0);
+          hopeless[a] = hopeless[a] && (bound < gi[a].b * gj.b);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
   // units are ordered by distance and LD decays with it: drop the hopeless far end, keep everything nearer than
   // the farthest unit that still has a live pair
@@ -648,12 +783,13 @@ __global__ __launch_bounds__(256) void classify_items_kernel(PairKernelArgs A) {
 
 // Epilogue staging: accumulators go through LDS ([counter][thread]) so the per-pair decision code runs
 // as a rolled loop with a handful of live registers instead of 16 unrolled copies.
-constexpr int kEpilogueLdsDwords = 32 * kBlockThreads;  // 32 KiB
+constexpr int kEpilogueLdsDwords = ((8 * kMaxUnitsPerWave > 28) ? 8 * kMaxUnitsPerWave : 28) * kBlockThreads;  // 28 = the general path
 
 template <bool GENERAL>
-__global__ __launch_bounds__(kBlockThreads, GENERAL ? 3 : 4) void pair_tiles_kernel(PairKernelArgs A) {
+__global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_kernel(PairKernelArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  __shared__ uint32_t s_waves_done;
+  __shared__ uint32_t s_live[kWavesPerBlock];
+  __shared__ uint32_t s_src_off[kMaxDmaPerWave * kBlockThreads];
   // XCD-aware order: hardware places block b on XCD b % 8; give each XCD a contiguous run of work
   // items so neighbouring J-blocks (which share most of their window rows) hit the same L2.
   const uint32_t per_xcd = (A.n_items + 7) / 8;
@@ -666,7 +802,8 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 3 : 4) void pair_tiles_ker
   }
   const WorkItem it = A.items[item_idx];
   const uint32_t tid = threadIdx.x;
-  const uint32_t wave = tid >> 6;
+  // (readfirstlane: tells the compiler the wave index, and everything derived from it, is wave-uniform -> SGPRs)
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t lane = tid & 63;
   const int tx = lane & 7;
   const int ty = lane >> 3;
@@ -681,98 +818,198 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 3 : 4) void pair_tiles_ker
     units_total += u;
     units_max = (u > units_max) ? u : units_max;
   }
-  const TileGeom G = make_geom(it, units_total);
   const uint32_t units_w = (it.units >> (8 * wave)) & 0xff;
   const uint32_t dw0 = it.d0 + 8 * units_before;  // first distance of this wave
 
-  const int jrow = tx;
-  // I-row of (b = 0, a = 0): i = j0 + tx - (dw0 + ty)
-  const int irow0 = kTileJ + static_cast<int>(static_cast<int64_t>(it.j0) - dw0 - G.ilo) + tx - ty;
-  // double-buffered LDS-DMA staging: chunk kc+1 streams in while chunk kc is being consumed
-  const uint64_t row_bytes = A.row_dwords * sizeof(uint32_t);
-  const int64_t vmin = row_variant(G, kTileJ);  // first I-row: the lowest variant the tile touches
-  const DmaPlan plan = make_dma_plan(G, row_bytes, wave, lane, vmin);
-  const uint8_t* tile_base = reinterpret_cast<const uint8_t*>(A.planes) + static_cast<uint64_t>(vmin) * row_bytes;
-  const uint32_t buf_dwords = lds_buffer_dwords(G.rtot);
-  constexpr uint32_t kChunkBytes = kRowChunkDwords * sizeof(uint32_t);
+  TileGeom G = make_geom(it, units_total);
+  Stager st;
+  st.src_off = s_src_off;
+  plan_stager(st, G, A, wave, lane);
+  int jrow = G.jrow_base + tx;
+  // I-row of (b = 0, a = 0): variant j0 + tx - (dw0 + ty)
+  int irow0 = G.dmax + tx - static_cast<int>(dw0) - ty;
+  Ring R;
+  uint32_t n_true = 0;  // predicates this thread found true
 
   if constexpr (!GENERAL) {
-    uint32_t hh[4][4], xx[4][4];
+    uint32_t hh[kMaxUnitsPerWave][4], xx[kMaxUnitsPerWave][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < kMaxUnitsPerWave; ++a) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         hh[a][b] = 0;
         xx[a][b] = 0;
       }
     }
-    if (tid == 0) {
-      s_waves_done = 0;
-    }
-    dma_chunk(plan, tile_base, lds, wave);
-    __syncthreads();  // (drains this wave's DMA, then barrier)
-    uint32_t live = units_w;  // distance units this wave still accumulates (wave-uniform)
-    if ((!live) && (lane == 0)) {
-      atomicOr(&s_waves_done, 1u << wave);
-    }
+    // Row mode (start): the wave owns `live` contiguous units from distance dw0, all four second-variant groups.
+    // Column mode (see below): the wave owns group b = wave of the block's first `live` units (from distance d0).
+    uint32_t live = units_w;          // distance units this wave still accumulates (wave-uniform)
+    uint32_t staged = units_total;    // distance units of the block still staged (block-uniform)
+    bool column = false;              // block-uniform
+    uint32_t dist0 = dw0;             // first distance this wave owns
     uint32_t next_cp = 0;
     const uint32_t n_cp = A.cp_stats ? A.n_checkpoints : 0;
-    for (uint32_t kc = 0; kc < A.chunks; ++kc) {
-      if (kc + 1 < A.chunks) {
-        dma_chunk(plan, tile_base + static_cast<uint64_t>(kc + 1) * kChunkBytes, lds + ((kc + 1) & 1) * buf_dwords, wave);
-      }
-      const uint4* l4 = reinterpret_cast<const uint4*>(lds + (kc & 1) * buf_dwords);
-      const bool at_cp = (next_cp < n_cp) && (kc + 1 == A.checkpoint_chunk[next_cp]);  // block-uniform
-      switch (live) {
-        case 1: tile_chunk_fast<1>(l4, jrow, irow0, hh, xx); break;
-        case 2: tile_chunk_fast<2>(l4, jrow, irow0, hh, xx); break;
-        case 3: tile_chunk_fast<3>(l4, jrow, irow0, hh, xx); break;
-        case 4: tile_chunk_fast<4>(l4, jrow, irow0, hh, xx); break;
-        default: break;
-      }
-      if (at_cp && live) {
-        uint32_t keep = live;
+#ifdef LDP_DEBUG_PHASE_CLOCKS
+    const uint64_t t_begin = __builtin_readcyclecounter();
+    uint64_t t_switch = 0;
+    uint32_t kc_switch = 0;
+#endif
+    ring_start(R, st, lds, 0, A.chunks, wave, lane);
+    while (R.kc < A.chunks) {
+      const uint4* l4 = ring_acquire(R, st, lds, A.chunks, wave, lane);
+      if (!column) {
         switch (live) {
-          case 1: keep = wave_live_units<1>(A, it.j0, it.jend, dw0, tx, ty, hh, xx, next_cp); break;
-          case 2: keep = wave_live_units<2>(A, it.j0, it.jend, dw0, tx, ty, hh, xx, next_cp); break;
-          case 3: keep = wave_live_units<3>(A, it.j0, it.jend, dw0, tx, ty, hh, xx, next_cp); break;
-          case 4: keep = wave_live_units<4>(A, it.j0, it.jend, dw0, tx, ty, hh, xx, next_cp); break;
+          case 1: tile_chunk_fast<1>(l4, jrow, irow0, hh, xx); break;
+          case 2: tile_chunk_fast<2>(l4, jrow, irow0, hh, xx); break;
+          case 3: tile_chunk_fast<3>(l4, jrow, irow0, hh, xx); break;
+#if LDP_MAX_UNITS_PER_WAVE >= 4
+          case 4: tile_chunk_fast<4>(l4, jrow, irow0, hh, xx); break;
+#endif
           default: break;
         }
-        if (keep != live) {
-          // every pair of the dropped units is provably below the threshold
-          if (lane == 0) {
-            atomicAdd(A.counters + 1, static_cast<unsigned long long>(A.chunks - kc - 1) * (live - keep));
-            if (!keep) {
-              atomicOr(&s_waves_done, 1u << wave);
-            }
-          }
-          live = __builtin_amdgcn_readfirstlane(keep);
+      } else {
+        switch (live) {
+          case 1: tile_chunk_column<1>(l4, jrow, irow0, hh, xx); break;
+          case 2: tile_chunk_column<2>(l4, jrow, irow0, hh, xx); break;
+          case 3: tile_chunk_column<3>(l4, jrow, irow0, hh, xx); break;
+#if LDP_MAX_UNITS_PER_WAVE >= 4
+          case 4: tile_chunk_column<4>(l4, jrow, irow0, hh, xx); break;
+#endif
+          default: break;
         }
       }
-      __syncthreads();  // next chunk landed (vmcnt drained) and every wave is done reading this one
+      const bool at_cp = (next_cp < n_cp) && (R.kc + 1 == A.checkpoint_chunk[next_cp]);  // block-uniform
+      ring_release(R, st);
       if (at_cp) {
+        if (live) {
+          uint32_t keep = live;
+          if (!column) {
+            switch (live) {
+              case 1: keep = wave_live_units<1, 4>(A, it.j0, it.jend, dist0, tx, ty, 0, hh, xx, next_cp); break;
+              case 2: keep = wave_live_units<2, 4>(A, it.j0, it.jend, dist0, tx, ty, 0, hh, xx, next_cp); break;
+              case 3: keep = wave_live_units<3, 4>(A, it.j0, it.jend, dist0, tx, ty, 0, hh, xx, next_cp); break;
+#if LDP_MAX_UNITS_PER_WAVE >= 4
+              case 4: keep = wave_live_units<4, 4>(A, it.j0, it.jend, dist0, tx, ty, 0, hh, xx, next_cp); break;
+#endif
+              default: break;
+            }
+          } else {
+            switch (live) {
+              case 1: keep = wave_live_units<1, 1>(A, it.j0, it.jend, dist0, tx, ty, wave, hh, xx, next_cp); break;
+              case 2: keep = wave_live_units<2, 1>(A, it.j0, it.jend, dist0, tx, ty, wave, hh, xx, next_cp); break;
+              case 3: keep = wave_live_units<3, 1>(A, it.j0, it.jend, dist0, tx, ty, wave, hh, xx, next_cp); break;
+#if LDP_MAX_UNITS_PER_WAVE >= 4
+              case 4: keep = wave_live_units<4, 1>(A, it.j0, it.jend, dist0, tx, ty, wave, hh, xx, next_cp); break;
+#endif
+              default: break;
+            }
+          }
+          if (keep != live) {
+            // every pair of the dropped units is provably below the threshold (counter in quarter units x chunks)
+            if (lane == 0) {
+              atomicAdd(A.counters + 1, static_cast<unsigned long long>(A.chunks - R.kc) * (live - keep) * (column ? 1 : 4));
+            }
+            live = __builtin_amdgcn_readfirstlane(keep);
+          }
+        }
         ++next_cp;
-        // s_waves_done only changes at checkpoints, before a barrier every wave must pass: this read is block-uniform
-        if (s_waves_done == (1u << kWavesPerBlock) - 1) {
-          break;
+        // how much of the distance range does the block still need?
+        if (lane == 0) {
+          s_live[wave] = live;
+        }
+        __syncthreads();  // (a full fence: this wave's queued chunks have landed, too)
+        uint32_t need = 0;
+        bool prefix = true;  // do the live units form the block's first `need` units exactly?
+        {
+          uint32_t before = 0;
+#pragma unroll
+          for (uint32_t w = 0; w < kWavesPerBlock; ++w) {
+            const uint32_t lw = s_live[w];
+            const uint32_t uw = column ? lw : ((it.units >> (8 * w)) & 0xff);
+            const uint32_t first = column ? 0 : before;
+            if (lw) {
+              prefix = prefix && (first <= need);  // no dropped unit between the previous waves' and this one's
+              need = (first + lw > need) ? first + lw : need;
+            }
+            before += uw;
+          }
+        }
+        if (!need) {
+          break;  // nothing left that could reach the threshold
+        }
+        bool replan = (need < staged);
+        if ((!column) && (need <= static_cast<uint32_t>(kMaxUnitsPerWave)) && (need < units_total) && prefix) {
+          // Re-deal: what is left is the block's first `need` units.  Hand every wave one second-variant group of
+          // all of them (column mode), partial sums travelling through the (idle) staging area: the four waves,
+          // hence the four SIMDs, then share the remaining work evenly, whichever wave owned the near units.
+#pragma unroll
+          for (int a = 0; a < kMaxUnitsPerWave; ++a) {
+            if (static_cast<uint32_t>(a) < live) {
+              const uint32_t u = units_before + a;
+#pragma unroll
+              for (int bb = 0; bb < 4; ++bb) {
+                const uint32_t base = ((u * 4 + bb) * 2) * 64 + lane;
+                lds[base] = hh[a][bb];
+                lds[base + 64] = xx[a][bb];
+              }
+            }
+          }
+          __syncthreads();
+#pragma unroll
+          for (int a = 0; a < kMaxUnitsPerWave; ++a) {
+            const uint32_t base = ((a * 4 + wave) * 2) * 64 + lane;
+            hh[a][0] = (static_cast<uint32_t>(a) < need) ? lds[base] : 0;
+            xx[a][0] = (static_cast<uint32_t>(a) < need) ? lds[base + 64] : 0;
+          }
+          __syncthreads();  // the scratch is staging area again from here
+          column = true;
+          live = need;
+          dist0 = it.d0;
+          replan = true;
+#ifdef LDP_DEBUG_PHASE_CLOCKS
+          t_switch = __builtin_readcyclecounter();
+          kc_switch = R.kc;
+#endif
+        }
+        if (replan) {
+          // shrink the tile to the units still live: fewer rows per chunk, more chunks in flight.  Every wave is
+          // past the barrier and none has outstanding DMA, so the ring can simply be restarted at the next chunk.
+          staged = need;
+          G = make_geom(it, staged);
+          plan_stager(st, G, A, wave, lane);
+          const int col = column ? 8 * static_cast<int>(wave) : 0;
+          jrow = G.jrow_base + tx + col;
+          irow0 = G.dmax + tx + col - static_cast<int>(dist0) - ty;
+          ring_start(R, st, lds, R.kc, A.chunks, wave, lane);
         }
       }
     }
+#ifdef LDP_DEBUG_PHASE_CLOCKS
+    {
+      const uint64_t t_loop_end = __builtin_readcyclecounter();
+      if ((tid == 0) && t_switch) {
+        atomicAdd(A.counters + 2, static_cast<unsigned long long>(t_switch - t_begin));
+        atomicAdd(A.counters + 3, static_cast<unsigned long long>(t_loop_end - t_switch));
+      }
+    }
+#endif
+    __syncthreads();  // staging is over: LDS becomes the epilogue's scratch
+    // accumulators of the tiles this wave owns, p-th tile = (unit a, group b)
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < kMaxUnitsPerWave; ++a) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         lds[(2 * (a * 4 + b)) * kBlockThreads + tid] = hh[a][b];
         lds[(2 * (a * 4 + b) + 1) * kBlockThreads + tid] = xx[a][b];
       }
     }
-    const uint32_t emit_units = live;  // pairs of dropped units are all below the threshold
+    const uint32_t n_tiles = column ? live : 4 * live;  // pairs of dropped units are all below the threshold
 #pragma unroll 1
-    for (uint32_t p = 0; p < 4 * emit_units; ++p) {
-      const uint32_t a = p >> 2, b = p & 3;
+    for (uint32_t p = 0; p < n_tiles; ++p) {
+      const uint32_t a = column ? p : (p >> 2), b = column ? wave : (p & 3);
+      const uint32_t slot = column ? (4 * p) : p;  // (a, 0) in column mode
       const uint32_t j = it.j0 + tx + 8 * b;
-      const uint32_t d = dw0 + ty + 8 * a;
+      const uint32_t d = dist0 + ty + 8 * a;
       if (j >= it.jend) {
         continue;
       }
@@ -781,14 +1018,14 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 3 : 4) void pair_tiles_ker
         continue;
       }
       const uint32_t i = j - d;
-      ldp_pair_stats_t st;
-      st.nm = A.founder_ct;
-      st.sum1 = A.recs[i].sum;
-      st.ssq1 = A.recs[i].ssq;
-      st.sum2 = A.recs[j].sum;
-      st.ssq2 = A.recs[j].ssq;
-      st.dot = static_cast<int32_t>(lds[(2 * p) * kBlockThreads + tid]) - 2 * static_cast<int32_t>(lds[(2 * p + 1) * kBlockThreads + tid]);
-      emit_pair(A, i, j, lo_j, st);
+      ldp_pair_stats_t ps;
+      ps.nm = A.founder_ct;
+      ps.sum1 = A.recs[i].sum;
+      ps.ssq1 = A.recs[i].ssq;
+      ps.sum2 = A.recs[j].sum;
+      ps.ssq2 = A.recs[j].ssq;
+      ps.dot = static_cast<int32_t>(lds[(2 * slot) * kBlockThreads + tid]) - 2 * static_cast<int32_t>(lds[(2 * slot + 1) * kBlockThreads + tid]);
+      n_true += emit_pair(A, i, j, lo_j, ps) ? 1 : 0;
     }
   } else {
     // general path: two distance-units per pass to bound register use (7 counters per pair)
@@ -806,20 +1043,17 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 3 : 4) void pair_tiles_ker
       }
       const uint32_t na = (units_w > a0) ? ((units_w - a0 >= 2) ? 2 : 1) : 0;
       const int irow = irow0 - 8 * static_cast<int>(a0);
-      dma_chunk(plan, tile_base, lds, wave);
-      __syncthreads();
-      for (uint32_t kc = 0; kc < A.chunks; ++kc) {
-        if (kc + 1 < A.chunks) {
-          dma_chunk(plan, tile_base + static_cast<uint64_t>(kc + 1) * kChunkBytes, lds + ((kc + 1) & 1) * buf_dwords, wave);
-        }
-        const uint4* l4 = reinterpret_cast<const uint4*>(lds + (kc & 1) * buf_dwords);
+      ring_start(R, st, lds, 0, A.chunks, wave, lane);
+      while (R.kc < A.chunks) {
+        const uint4* l4 = ring_acquire(R, st, lds, A.chunks, wave, lane);
         if (na == 2) {
           tile_chunk_general<2>(l4, jrow, irow, acc);
         } else if (na == 1) {
           tile_chunk_general<1>(l4, jrow, irow, acc);
         }
-        __syncthreads();
+        ring_release(R, st);
       }
+      __syncthreads();  // staging of this pass is over: LDS becomes the epilogue's scratch
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         // one distance-unit at a time through LDS: 4 pairs x 7 counters = 28 dwords per thread
@@ -846,35 +1080,41 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 3 : 4) void pair_tiles_ker
             const uint32_t* c = lds + (b * 7) * kBlockThreads + tid;
             const uint32_t c0 = c[0], c1 = c[kBlockThreads], c2 = c[2 * kBlockThreads], c3 = c[3 * kBlockThreads];
             const uint32_t c4 = c[4 * kBlockThreads], c5 = c[5 * kBlockThreads], c6 = c[6 * kBlockThreads];
-            ldp_pair_stats_t st;
-            st.nm = c2;
-            st.ssq2 = c3;
-            st.sum2 = static_cast<int32_t>(2 * c4 - c3);
-            st.ssq1 = c5;
-            st.sum1 = static_cast<int32_t>(2 * c6 - c5);
-            st.dot = static_cast<int32_t>(c0) - 2 * static_cast<int32_t>(c1);
-            emit_pair(A, i, j, lo_j, st);
+            ldp_pair_stats_t ps;
+            ps.nm = c2;
+            ps.ssq2 = c3;
+            ps.sum2 = static_cast<int32_t>(2 * c4 - c3);
+            ps.ssq1 = c5;
+            ps.sum1 = static_cast<int32_t>(2 * c6 - c5);
+            ps.dot = static_cast<int32_t>(c0) - 2 * static_cast<int32_t>(c1);
+            n_true += emit_pair(A, i, j, lo_j, ps) ? 1 : 0;
           }
         }
       }
       __syncthreads();  // LDS is restaged by the next pass
     }
   }
+  n_true = wave_reduce_add(n_true);
+  if ((lane == 0) && n_true) {
+    atomicAdd(A.counters, static_cast<unsigned long long>(n_true));
+  }
 }
 
-size_t pair_tiles_lds_bytes(uint32_t max_units) {
-  const size_t rows = kTileJ + 8 * static_cast<size_t>(max_units) + 31;
-  const size_t buf = ((rows * kLdsRowSlots + 63) / 64) * 1024;  // one staging buffer, whole DMA instructions
+// max_rows = the largest TileGeom::rtot over the work items (ldp_tile_rows() in the engine mirrors make_geom)
+size_t pair_tiles_lds_bytes(uint32_t max_rows) {
+  const size_t stage = ((static_cast<size_t>(max_rows) * kLdsRowSlots + 63) / 64) * 1024;  // whole DMA instructions
   const size_t epi = static_cast<size_t>(kEpilogueLdsDwords) * sizeof(uint32_t);
-  return (2 * buf > epi) ? 2 * buf : epi;
+  return (2 * stage > epi) ? 2 * stage : epi;
 }
 
-hipError_t launch_pair_tiles(const PairKernelArgs& a, uint32_t max_units, hipStream_t stream, hipEvent_t* ev) {
-  if (!a.n_items) {
+hipError_t launch_pair_tiles(const PairKernelArgs& a_in, uint32_t max_rows, hipStream_t stream, hipEvent_t* ev) {
+  if (!a_in.n_items) {
     return hipSuccess;
   }
+  PairKernelArgs a = a_in;
   const uint32_t per_xcd = (a.n_items + 7) / 8;
-  const size_t lds = pair_tiles_lds_bytes(max_units);
+  const size_t lds = pair_tiles_lds_bytes(max_rows);
+  a.lds_dwords = static_cast<uint32_t>(lds / sizeof(uint32_t));
   hipLaunchKernelGGL(classify_items_kernel, dim3((a.n_items + 3) / 4), dim3(256), 0, stream, a);
   if (ev) {
     (void)hipEventRecord(ev[0], stream);
