@@ -239,12 +239,19 @@ def main():
     if rank == 0:
         ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
         value = total_pairs * args.steps / elapsed
+        # the pair kernel runs as a few launches per step (groups of J-tiles, back to back on one stream):
+        # kms = their summed duration per step, HIP events around every launch on the stream it is launched on
         kms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
+        launches = max(int(ctr["pair_kernel_launches"]), 1)
         alg_bytes_per_pair = founder_ct / 2.0
         achieved = (ctr["candidate_pairs"] * alg_bytes_per_pair / (kms * 1e-3)) / 1e9 if kms > 0 else 0.0
-        # integer-VALU ceiling of the same kernel: 4 lane-ops per pair per 32 samples (and, bitop3, 2 x bcnt)
+        # integer-VALU side of the same kernel: 4 lane-ops per pair per 32 samples (and, bitop3, 2 x bcnt) on the pair
+        # slots it really walks (early termination skips the rest), against the measured issue ceiling of exactly
+        # this op mix (tools/ubench_valu.hip, profiles/r01_ubench_valu.txt: 4.118e13 lane-ops/s)
         plane_dwords = (founder_ct + 31) // 32
-        valu_peak_pairs = 256 * 4 * 32 * 2.4e9 / (4.0 * plane_dwords)
+        skipped = (ctr["early_exit_unit_chunks"] / ctr["tile_unit_chunks"]) if ctr["tile_unit_chunks"] else 0.0
+        executed_lane_ops = ctr["computed_pairs"] * plane_dwords * 4.0 * (1.0 - skipped)
+        valu_mix_peak = 4.118e13
         traffic = None
         tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
@@ -267,10 +274,14 @@ def main():
                        "variants_removed": int(removed.sum()), "variants_total": m_total},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "pair_tiles_kernel<%s>" % ("true" if args.missing_rate > 0 else "false"),
-                         "kernel_ms_per_launch": kms, "algorithmic_bytes_per_pair": alg_bytes_per_pair,
-                         "note": "achieved = algorithmic stream rate (pairs x N/2 B / kernel time); LDS/register tiling makes it exceed "
-                                 "physical HBM traffic, the kernel is integer-VALU bound",
-                         "valu_frac": (ctr["candidate_pairs"] / (kms * 1e-3)) / valu_peak_pairs if kms > 0 else 0.0},
+                         "kernel_ms_per_launch": kms / launches, "launches_per_step": launches, "kernel_ms_per_step": kms,
+                         "algorithmic_bytes_per_pair": alg_bytes_per_pair,
+                         "note": "achieved = algorithmic stream rate (candidate pairs x N/2 B / summed kernel time; traffic is per step, "
+                                 "too); LDS/register tiling and early termination make it exceed physical HBM traffic, the kernel is "
+                                 "integer-VALU bound: valu_frac = executed and/bitop3/bcnt lane-ops per second over the measured "
+                                 "ceiling of that op mix",
+                         "valu_lane_ops_per_s": (executed_lane_ops / (kms * 1e-3)) if kms > 0 else 0.0, "valu_mix_peak": valu_mix_peak,
+                         "valu_frac": (executed_lane_ops / (kms * 1e-3)) / valu_mix_peak if kms > 0 else 0.0},
             "stage_ms": {"prepare_kernel": float(np.mean(prep_ms)), "pair_kernel": kms, "host_replay": float(np.mean(replay_ms))},
             "early_termination": {"tile_unit_chunks": ctr["tile_unit_chunks"], "skipped_unit_chunks": ctr["early_exit_unit_chunks"],
                                   "skipped_frac": (ctr["early_exit_unit_chunks"] / ctr["tile_unit_chunks"]) if ctr["tile_unit_chunks"] else 0.0},

@@ -70,6 +70,8 @@ void parallel_for(uint32_t n, uint32_t max_threads, F fn) {
 
 }  // namespace
 
+constexpr int kPairStreams = 1;
+
 struct ldp_engine {
   ldp_params P;
   int device = -1;
@@ -102,6 +104,23 @@ struct ldp_engine {
   uint64_t computed_pairs = 0;
   std::vector<WorkItem> items;
   uint32_t max_rows = 0;                   // largest LDS row count over the work items
+  // Pair-kernel launch groups: runs of J-tiles in item order.  A group is launched (on a side stream) as
+  // soon as every variant below need_end has been converted, i.e. while prepare_kernel is still working on the
+  // variants behind it: the HBM-bound conversion and the VALU-bound pair kernel overlap.
+  struct PairGroup {
+    uint32_t item_first = 0, item_ct = 0;
+    uint32_t need_end = 0;               // local variants [0, need_end) must be loaded
+    uint64_t word_first = 0, word_end = 0;  // predicate words the group's J-tiles own
+    bool launched = false;
+    hipEvent_t ev_ready = nullptr;
+    hipEvent_t ev_done = nullptr;         // kernels finished and the group's predicate words are back on the host
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  };
+  std::vector<PairGroup> groups;
+  uint32_t next_group = 0;                 // groups before this one are launched for the current load epoch
+  uint32_t loaded_prefix = 0;              // local variants [0, loaded_prefix) were loaded in the current epoch
+  uint32_t load_epoch = 1;
+  std::vector<uint32_t> load_tag;          // local: epoch of the last load
 
   // ---- data ----
   uint32_t chunks = 0;
@@ -109,6 +128,7 @@ struct ldp_engine {
   std::vector<uint8_t> loaded;            // local
   std::vector<ldp_variant_rec> recs;      // local (host mirror)
   bool recs_host_valid = false;
+  bool recs_copy_queued = false;
   std::vector<double> maj_freq;           // local
   std::vector<uint8_t> mf_set;            // local: 0 unset, 1 caller-supplied, 2 to be derived from device counts, 3 derived
   std::vector<uint64_t> preferred;        // global bitmap (may be empty)
@@ -127,10 +147,16 @@ struct ldp_engine {
   uint32_t checkpoint_chunk[kCheckpoints];
   uint32_t n_checkpoints = 0;
   uint32_t* h_pred = nullptr;  // pinned
+  unsigned long long* h_counters_pin = nullptr;  // pinned: a pageable destination would make the 'async' copy block the host
   bool plan_uploaded = false;
   bool recs_registered = false;
   hipEvent_t prep_ev0 = nullptr, prep_ev1 = nullptr;
   hipStream_t copy_stream = nullptr;
+  // One side stream: groups run back to back (two streams gave the same step time and made every launch's
+  // duration overlap its neighbour's, i.e. unreadable in a profile).
+  hipStream_t pair_stream[kPairStreams] = {nullptr};
+  hipEvent_t pair_tail[kPairStreams] = {nullptr};  // last thing queued on each pair stream
+  bool pair_tail_set[kPairStreams] = {false};
   uint8_t* h_stage[3] = {nullptr, nullptr, nullptr};  // pinned staging ring for host-memory genotype input
   uint8_t* d_stage[3] = {nullptr, nullptr, nullptr};
   hipEvent_t stage_done[3] = {nullptr, nullptr, nullptr};
@@ -142,6 +168,18 @@ struct ldp_engine {
 };
 
 namespace {
+
+// The main stream (conversion) outranks the pair streams: conversion blocks are short and HBM-bound, and the sooner
+// they are through the sooner the host has the per-variant records it needs to start replaying finished groups.
+hipError_t create_stream(hipStream_t* out, bool high_priority) {
+  int lo = 0, hi = 0;
+  static const bool flat = (getenv("LDP_STREAM_PRIORITY") != nullptr) && (strcmp(getenv("LDP_STREAM_PRIORITY"), "0") == 0);
+  if (flat || (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) || (lo == hi)) {
+    (void)hipGetLastError();
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+  }
+  return hipStreamCreateWithPriority(out, hipStreamNonBlocking, high_priority ? hi : lo);
+}
 
 int fail(ldp_engine* e, int code, const std::string& msg) {
   if (e) {
@@ -199,6 +237,10 @@ void free_device(ldp_engine* e) {
   if (e->h_pred) {
     (void)hipHostFree(e->h_pred);
   }
+  if (e->h_counters_pin) {
+    (void)hipHostFree(e->h_counters_pin);
+    e->h_counters_pin = nullptr;
+  }
   if (e->recs_registered) {
     (void)hipHostUnregister(e->recs.data());
     e->recs_registered = false;
@@ -219,6 +261,30 @@ void free_device(ldp_engine* e) {
     e->prep_ev0 = nullptr;
     e->prep_ev1 = nullptr;
   }
+  for (ldp_engine::PairGroup& g : e->groups) {
+    if (g.ev_ready) {
+      (void)hipEventDestroy(g.ev_ready);
+      (void)hipEventDestroy(g.ev_done);
+      g.ev_ready = nullptr;
+      g.ev_done = nullptr;
+    }
+    for (int q = 0; q < 4; ++q) {
+      if (g.ev[q]) {
+        (void)hipEventDestroy(g.ev[q]);
+        g.ev[q] = nullptr;
+      }
+    }
+    g.launched = false;
+  }
+  for (int k = 0; k < kPairStreams; ++k) {
+    if (e->pair_tail[k]) {
+      (void)hipEventDestroy(e->pair_tail[k]);
+      e->pair_tail[k] = nullptr;
+    }
+    e->pair_tail_set[k] = false;
+  }
+  e->next_group = 0;
+  e->loaded_prefix = 0;
   e->prep_pending = false;
   e->d_planes = nullptr;
   e->d_recs = nullptr;
@@ -542,6 +608,33 @@ void build_shard(ldp_engine* e) {
     }
   }
   free_device(e);
+  // launch groups: ~kTargetGroups runs of whole J-tiles (a J-tile's blocks share predicate rows)
+  e->groups.clear();
+  {
+    uint32_t kTargetGroups = 4;
+    if (const char* tg = getenv("LDP_DEBUG_GROUPS")) {
+      kTargetGroups = std::max(1, atoi(tg));
+    }
+    const uint32_t n_items = static_cast<uint32_t>(e->items.size());
+    const uint32_t per_group = std::max<uint32_t>(512, (n_items + kTargetGroups - 1) / kTargetGroups);
+    uint32_t i0 = 0;
+    while (i0 < n_items) {
+      uint32_t i1 = std::min(n_items, i0 + per_group);
+      while ((i1 < n_items) && (e->items[i1].j0 == e->items[i1 - 1].j0)) {
+        ++i1;
+      }
+      ldp_engine::PairGroup g;
+      g.item_first = i0;
+      g.item_ct = i1 - i0;
+      g.need_end = e->items[i1 - 1].jend;
+      g.word_first = e->row_off[e->items[i0].j0];
+      g.word_end = e->row_off[e->items[i1 - 1].jend];
+      e->groups.push_back(g);
+      i0 = i1;
+    }
+  }
+  e->load_tag.assign(local, 0);
+  e->load_epoch = 1;
   e->loaded.assign(local, 0);
   e->recs.assign(local, ldp_variant_rec());
   e->recs_host_valid = false;
@@ -570,6 +663,7 @@ int ensure_device_plan(ldp_engine* e) {
   HIP_TRY(e, hipMalloc(&e->d_items, std::max<size_t>(e->items.size(), 1) * sizeof(WorkItem)));
   HIP_TRY(e, hipMalloc(&e->d_item_general, std::max<size_t>(e->items.size(), 1)));
   HIP_TRY(e, hipMalloc(&e->d_counters, 4 * sizeof(unsigned long long)));
+  HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
   HIP_TRY(e, hipMalloc(&e->d_cp_stats, n * kCpSlots * sizeof(cp_slot)));
   // checkpoints for early termination
   e->n_checkpoints = 0;
@@ -587,6 +681,7 @@ int ensure_device_plan(ldp_engine* e) {
     }
   }
   HIP_TRY(e, hipHostMalloc(&e->h_pred, std::max<size_t>(e->pred_words, 1) * sizeof(uint32_t), hipHostMallocDefault));
+  HIP_TRY(e, hipHostMalloc(&e->h_counters_pin, 4 * sizeof(unsigned long long), hipHostMallocDefault));
   if (e->local_ct) {
     HIP_TRY(e, hipMemcpyAsync(e->d_lo, e->lo_local.data(), e->local_ct * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->d_row_off, e->row_off.data(), (e->local_ct + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
@@ -601,6 +696,16 @@ int ensure_device_plan(ldp_engine* e) {
   }
   HIP_TRY(e, hipEventCreate(&e->prep_ev0));
   HIP_TRY(e, hipEventCreate(&e->prep_ev1));
+  for (ldp_engine::PairGroup& g : e->groups) {
+    HIP_TRY(e, hipEventCreateWithFlags(&g.ev_ready, hipEventDisableTiming));
+    HIP_TRY(e, hipEventCreateWithFlags(&g.ev_done, hipEventDisableTiming));
+    for (int q = 0; q < 4; ++q) {
+      HIP_TRY(e, hipEventCreate(&g.ev[q]));
+    }
+  }
+  for (int k = 0; k < kPairStreams; ++k) {
+    HIP_TRY(e, hipEventCreateWithFlags(&e->pair_tail[k], hipEventDisableTiming));
+  }
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   e->plan_uploaded = true;
   return LDP_OK;
@@ -651,17 +756,36 @@ int ensure_staging(ldp_engine* e) {
   return LDP_OK;
 }
 
+// Queue the copy of the per-variant records (copy stream, ordered after the last prepare kernel only).  Call this
+// BEFORE queueing anything else that ends in a device-to-host copy: the copy engine serves its queue in order, so a
+// copy that waits for a kernel holds up every copy submitted after it.
+int start_fetch_recs(ldp_engine* e) {
+  if (e->recs_host_valid || e->recs_copy_queued || (!e->local_ct)) {
+    return LDP_OK;
+  }
+  if (e->prep_pending) {
+    HIP_TRY(e, hipStreamWaitEvent(e->copy_stream, e->prep_ev1, 0));
+  }
+  HIP_TRY(e, hipMemcpyAsync(e->recs.data(), e->d_recs, e->local_ct * sizeof(ldp_variant_rec), hipMemcpyDeviceToHost, e->copy_stream));
+  e->recs_copy_queued = true;
+  return LDP_OK;
+}
+
 int fetch_recs(ldp_engine* e) {
   if (e->recs_host_valid) {
     return LDP_OK;
   }
   if (e->local_ct) {
-    // copy stream: ordered after the last prepare kernel only, so it overlaps whatever else is queued
-    if (e->prep_pending) {
-      HIP_TRY(e, hipStreamWaitEvent(e->copy_stream, e->prep_ev1, 0));
+    const int rc = start_fetch_recs(e);
+    if (rc) {
+      return rc;
     }
-    HIP_TRY(e, hipMemcpyAsync(e->recs.data(), e->d_recs, e->local_ct * sizeof(ldp_variant_rec), hipMemcpyDeviceToHost, e->copy_stream));
+    const double t0 = now_ms();
     HIP_TRY(e, hipStreamSynchronize(e->copy_stream));
+    if (getenv("LDP_DEBUG_TIMELINE")) {
+      fprintf(stderr, "recs copy: waited %.2f ms\n", now_ms() - t0);
+    }
+    e->recs_copy_queued = false;
   }
   if (e->prep_pending) {
     float ms = 0.f;
@@ -814,6 +938,45 @@ uint64_t replay_subcontig(const ldp_engine* e, uint32_t k, const uint32_t* pred,
   return replay_pairs;
 }
 
+// Replay as the launch groups come back: group g is waited for, then every subcontig whose variants all lie below
+// its need_end is replayed (concurrently) while the GPU works on the later groups.
+int replay_progressive(ldp_engine* e, const uint32_t* pred, const double* mf, std::vector<uint32_t>& R, uint64_t* replay_pairs_out, double* busy_ms_out) {
+  double busy_ms = 0.0;
+  std::vector<uint32_t> first_unchecked;
+  if (e->P.plink1_order) {
+    first_unchecked.assign(e->local_ct, 0);
+  }
+  std::atomic<uint64_t> total(0);
+  size_t si = 0;  // e->owned is in local order
+  std::vector<uint32_t> batch;
+  const size_t n_groups = e->groups.size();
+  for (size_t gi = 0; gi <= n_groups; ++gi) {
+    uint32_t covered = e->local_ct;
+    if (gi < n_groups) {
+      HIP_TRY(e, hipEventSynchronize(e->groups[gi].ev_done));
+      // take along every later group that has finished in the meantime: one wide batch instead of several narrow ones
+      while ((gi + 1 < n_groups) && (hipEventQuery(e->groups[gi + 1].ev_done) == hipSuccess)) {
+        ++gi;
+      }
+      (void)hipGetLastError();  // (hipErrorNotReady from the query is not an error)
+      covered = (gi + 1 < n_groups) ? e->groups[gi].need_end : e->local_ct;
+    }
+    batch.clear();
+    while ((si < e->owned.size()) && (e->subs[e->owned[si]].local_first + e->subs[e->owned[si]].len <= covered)) {
+      batch.push_back(e->owned[si++]);
+    }
+    std::stable_sort(batch.begin(), batch.end(), [&](uint32_t a, uint32_t b) { return e->subs[a].len > e->subs[b].len; });
+    const double t0 = now_ms();
+    parallel_for(static_cast<uint32_t>(batch.size()), 64, [&](uint32_t t) {
+      total.fetch_add(replay_subcontig(e, batch[t], pred, mf, R, first_unchecked));
+    });
+    busy_ms += now_ms() - t0;
+  }
+  *replay_pairs_out = total.load();
+  *busy_ms_out = busy_ms;
+  return LDP_OK;
+}
+
 void replay(ldp_engine* e, const uint32_t* pred, const double* mf, std::vector<uint32_t>& R, uint64_t* replay_pairs_out) {
   std::vector<uint32_t> first_unchecked;
   if (e->P.plink1_order) {
@@ -874,6 +1037,100 @@ int prepare_mf(ldp_engine* e, std::vector<double>* scratch, const double** mf_ou
   return LDP_OK;
 }
 
+void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_exit) {
+  PairKernelArgs& A = *out;
+  A.planes = e->d_planes;
+  A.row_dwords = e->row_dwords;
+  A.chunks = e->chunks;
+  A.founder_ct = e->P.founder_ct;
+  A.recs = e->d_recs;
+  A.lo = e->d_lo;
+  A.row_off = e->d_row_off;
+  A.pred = e->d_pred;
+  A.items = e->d_items;
+  A.n_items = static_cast<uint32_t>(e->items.size());
+  A.plane_base_variant = 0;
+  A.thresh = e->P.prune_last_param * (1 + kSmallEpsilon);  // plink2_ld.cc:1255
+  A.stats = nullptr;
+  A.pair_off = e->d_pair_off;
+  A.counters = e->d_counters;
+  A.item_general = e->d_item_general;
+  // early termination is off when the caller wants every pair's integers (parity runs) or LDP_EARLY_EXIT=0
+  A.cp_stats = (with_early_exit && early_exit_requested() && e->n_checkpoints) ? e->d_cp_stats : nullptr;
+  for (int k = 0; k < kCheckpoints; ++k) {
+    A.checkpoint_chunk[k] = e->checkpoint_chunk[k];
+  }
+  A.n_checkpoints = A.cp_stats ? e->n_checkpoints : 0;
+  A.lds_dwords = 0;
+  A.r2_out = nullptr;
+  A.r2_ld = 0;
+  A.r2_row_first = 0;
+  A.r2_float = 0;
+}
+
+// A new load epoch begins (variants are being loaded again): whatever the pair streams still run belongs to the
+// old data.  Order the main stream behind it, forget the launches and clear the counters.
+int begin_load_epoch(ldp_engine* e) {
+  for (int k = 0; k < kPairStreams; ++k) {
+    if (e->pair_tail_set[k]) {
+      HIP_TRY(e, hipStreamWaitEvent(e->stream, e->pair_tail[k], 0));
+      e->pair_tail_set[k] = false;
+    }
+  }
+  HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
+  ++e->load_epoch;
+  e->loaded_prefix = 0;
+  e->next_group = 0;
+  for (ldp_engine::PairGroup& g : e->groups) {
+    g.launched = false;
+  }
+  return LDP_OK;
+}
+
+// Queue group gi behind everything the main stream holds right now (the prepare kernels it depends on).
+int launch_group(ldp_engine* e, uint32_t gi) {
+  ldp_engine::PairGroup& g = e->groups[gi];
+  const int k = static_cast<int>(gi % kPairStreams);
+  hipStream_t ps = e->pair_stream[k];
+  HIP_TRY(e, hipEventRecord(g.ev_ready, e->stream));
+  HIP_TRY(e, hipStreamWaitEvent(ps, g.ev_ready, 0));
+  if (g.word_end > g.word_first) {
+    HIP_TRY(e, hipMemsetAsync(e->d_pred + g.word_first, 0, (g.word_end - g.word_first) * sizeof(uint32_t), ps));
+  }
+  PairKernelArgs A;
+  fill_pair_args(e, &A, true);
+  A.items = e->d_items + g.item_first;
+  A.item_general = e->d_item_general + g.item_first;
+  A.n_items = g.item_ct;
+  const hipError_t krc = launch_pair_tiles(A, e->max_rows, ps, g.ev);
+  if (krc != hipSuccess) {
+    return hipfail(e, krc, "pair_tiles_kernel launch");
+  }
+  if (g.word_end > g.word_first) {
+    HIP_TRY(e, hipMemcpyAsync(e->h_pred + g.word_first, e->d_pred + g.word_first, (g.word_end - g.word_first) * sizeof(uint32_t), hipMemcpyDeviceToHost, ps));
+  }
+  HIP_TRY(e, hipEventRecord(g.ev_done, ps));
+  HIP_TRY(e, hipEventRecord(e->pair_tail[k], ps));
+  e->pair_tail_set[k] = true;
+  g.launched = true;
+  return LDP_OK;
+}
+
+// launch every group whose variants are all converted (in order)
+int launch_ready_groups(ldp_engine* e) {
+  while ((e->loaded_prefix < e->local_ct) && (e->load_tag[e->loaded_prefix] == e->load_epoch)) {
+    ++e->loaded_prefix;
+  }
+  while ((e->next_group < e->groups.size()) && (e->groups[e->next_group].need_end <= e->loaded_prefix)) {
+    const int rc = launch_group(e, e->next_group);
+    if (rc) {
+      return rc;
+    }
+    ++e->next_group;
+  }
+  return LDP_OK;
+}
+
 int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t stats_capacity) {
   if (!e->planned) {
     return fail(e, LDP_ERR_STATE, "ldp_set_variants() has not been called");
@@ -885,6 +1142,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     return fail(e, LDP_ERR_STATE, "engine is planned for --r2-unphased matrices (ldp_set_variants_matrix)");
   }
   const double t_start = now_ms();
+  double tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int rc = ensure_device_plan(e);
   if (rc) {
     return rc;
@@ -903,96 +1161,152 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   HIP_TRY(e, hipSetDevice(e->device));
   DevBuf stats_buf;
   ldp_pair_stats_t* d_stats = nullptr;
-  if (stats && e->cand_pairs) {
-    HIP_TRY(e, hipMalloc(&stats_buf.p, e->cand_pairs * sizeof(ldp_pair_stats_t)));
-    d_stats = stats_buf.as<ldp_pair_stats_t>();
-    HIP_TRY(e, hipMemsetAsync(d_stats, 0, e->cand_pairs * sizeof(ldp_pair_stats_t), e->stream));
-  }
-  HIP_TRY(e, hipMemsetAsync(e->d_pred, 0, std::max<size_t>(e->pred_words, 1) * sizeof(uint32_t), e->stream));
-  HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
-
-  PairKernelArgs A;
-  A.planes = e->d_planes;
-  A.row_dwords = e->row_dwords;
-  A.chunks = e->chunks;
-  A.founder_ct = e->P.founder_ct;
-  A.recs = e->d_recs;
-  A.lo = e->d_lo;
-  A.row_off = e->d_row_off;
-  A.pred = e->d_pred;
-  A.items = e->d_items;
-  A.n_items = static_cast<uint32_t>(e->items.size());
-  A.plane_base_variant = 0;
-  A.thresh = e->P.prune_last_param * (1 + kSmallEpsilon);  // plink2_ld.cc:1255
-  A.stats = d_stats;
-  A.pair_off = e->d_pair_off;
-  A.counters = e->d_counters;
-  A.item_general = e->d_item_general;
-  // early termination is off when the caller wants every pair's integers (parity runs) or LDP_EARLY_EXIT=0
-  A.cp_stats = (early_exit_requested() && !stats && e->n_checkpoints) ? e->d_cp_stats : nullptr;
-  for (int k = 0; k < kCheckpoints; ++k) {
-    A.checkpoint_chunk[k] = e->checkpoint_chunk[k];
-  }
-  A.n_checkpoints = A.cp_stats ? e->n_checkpoints : 0;
-  A.r2_out = nullptr;
-  A.r2_ld = 0;
-  A.r2_row_first = 0;
-  A.r2_float = 0;
-
-  // 1. everything the device has to do is queued first ...
-  hipEvent_t ev0, ev1;
-  hipEvent_t evk[4];
-  HIP_TRY(e, hipEventCreate(&ev0));
-  HIP_TRY(e, hipEventCreate(&ev1));
-  for (int q = 0; q < 4; ++q) {
-    HIP_TRY(e, hipEventCreate(&evk[q]));
-  }
-  HIP_TRY(e, hipEventRecord(ev0, e->stream));
-  hipError_t krc = launch_pair_tiles(A, e->max_rows, e->stream, evk);
-  if (krc != hipSuccess) {
-    return hipfail(e, krc, "pair_tiles_kernel launch");
-  }
-  HIP_TRY(e, hipEventRecord(ev1, e->stream));
-  if (e->pred_words) {
-    HIP_TRY(e, hipMemcpyAsync(e->h_pred, e->d_pred, e->pred_words * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-  }
-  unsigned long long h_counters[4] = {0, 0, 0, 0};
-  HIP_TRY(e, hipMemcpyAsync(h_counters, e->d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, e->stream));
-  if (d_stats) {
-    HIP_TRY(e, hipMemcpyAsync(stats, d_stats, e->cand_pairs * sizeof(ldp_pair_stats_t), hipMemcpyDeviceToHost, e->stream));
-  }
-  // 2. ... then, while the pair kernel runs, the per-variant records come back on the copy stream and the
-  //    host derives the major-allele frequencies the replay needs.
-  rc = fetch_recs(e);
-  if (rc) {
-    return rc;
-  }
+  float kms = 0.f, kms_fast = 0.f, kms_general = 0.f;
+  uint32_t launches = 0;
   std::vector<double> mf_scratch;
   const double* mf = nullptr;
-  rc = prepare_mf(e, &mf_scratch, &mf);
-  if (rc) {
-    return rc;
-  }
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  float kms = 0.f, kms_fast = 0.f, kms_general = 0.f;
-  HIP_TRY(e, hipEventElapsedTime(&kms, ev0, ev1));
-  if (!e->items.empty()) {
-    HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
-    HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[2], evk[3]));
-  }
-  for (int q = 0; q < 4; ++q) {
-    (void)hipEventDestroy(evk[q]);
-  }
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
-
-  // 3. greedy replay on the host
-  const double t_replay = now_ms();
   std::vector<uint32_t> R((static_cast<size_t>(e->local_ct) + 31) / 32 + 1, 0);
   uint64_t replay_pairs = 0;
-  replay(e, e->h_pred, mf, R, &replay_pairs);
+  double t_replay = now_ms();
+  bool replayed = false;
+  double replay_busy_ms = 0.0;
+  unsigned long long h_counters[4] = {0, 0, 0, 0};
+  if (stats) {
+    // Inspection run: one launch over every item, every pair's integers stored, no early termination.
+    // Whatever the side streams hold is waited for and superseded.
+    for (int k = 0; k < kPairStreams; ++k) {
+      if (e->pair_tail_set[k]) {
+        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->pair_tail[k], 0));
+        e->pair_tail_set[k] = false;
+      }
+    }
+    if (e->cand_pairs) {
+      HIP_TRY(e, hipMalloc(&stats_buf.p, e->cand_pairs * sizeof(ldp_pair_stats_t)));
+      d_stats = stats_buf.as<ldp_pair_stats_t>();
+      HIP_TRY(e, hipMemsetAsync(d_stats, 0, e->cand_pairs * sizeof(ldp_pair_stats_t), e->stream));
+    }
+    HIP_TRY(e, hipMemsetAsync(e->d_pred, 0, std::max<size_t>(e->pred_words, 1) * sizeof(uint32_t), e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
+    PairKernelArgs A;
+    fill_pair_args(e, &A, false);
+    A.stats = d_stats;
+    hipEvent_t evk[4];
+    for (int q = 0; q < 4; ++q) {
+      HIP_TRY(e, hipEventCreate(&evk[q]));
+    }
+    const hipError_t krc = launch_pair_tiles(A, e->max_rows, e->stream, evk);
+    if (krc != hipSuccess) {
+      return hipfail(e, krc, "pair_tiles_kernel launch");
+    }
+    if (e->pred_words) {
+      HIP_TRY(e, hipMemcpyAsync(e->h_pred, e->d_pred, e->pred_words * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters_pin, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    if (d_stats) {
+      HIP_TRY(e, hipMemcpyAsync(stats, d_stats, e->cand_pairs * sizeof(ldp_pair_stats_t), hipMemcpyDeviceToHost, e->stream));
+    }
+    rc = fetch_recs(e);
+    if (rc) {
+      return rc;
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (!e->items.empty()) {
+      HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
+      HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[2], evk[3]));
+      launches = 1;
+    }
+    for (int q = 0; q < 4; ++q) {
+      (void)hipEventDestroy(evk[q]);
+    }
+    // the next plain run recomputes with the production settings
+    for (ldp_engine::PairGroup& g : e->groups) {
+      g.launched = false;
+    }
+    e->next_group = 0;
+  } else {
+    // 1. Most groups were queued while the genotypes were still being converted (ldp_load_genotypes); queue the
+    //    rest, then the copies back, behind the two pair streams.
+    rc = start_fetch_recs(e);  // (first in the copy engine's queue, see there)
+    if (rc) {
+      return rc;
+    }
+    bool any_launched = false;
+    for (const ldp_engine::PairGroup& g : e->groups) {
+      any_launched = any_launched || g.launched;
+    }
+    if (!any_launched) {
+      HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));  // (ahead of every ev_ready)
+    }
+    rc = launch_ready_groups(e);
+    if (rc) {
+      return rc;
+    }
+    for (uint32_t gi = 0; gi < e->groups.size(); ++gi) {
+      if (!e->groups[gi].launched) {
+        rc = launch_group(e, gi);
+        if (rc) {
+          return rc;
+        }
+      }
+    }
+    e->next_group = static_cast<uint32_t>(e->groups.size());
+    for (int k = 0; k < kPairStreams; ++k) {
+      if (e->pair_tail_set[k]) {
+        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->pair_tail[k], 0));
+      }
+    }
+    tl[0] = now_ms();
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters_pin, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    // 2. ... meanwhile the per-variant records come back on the copy stream and the host derives the
+    //    major-allele frequencies the replay needs ...
+    rc = fetch_recs(e);
+    if (rc) {
+      return rc;
+    }
+    tl[1] = now_ms();
+    rc = prepare_mf(e, &mf_scratch, &mf);
+    if (rc) {
+      return rc;
+    }
+    tl[2] = now_ms();
+    // 3. ... and replays each group's subcontigs as soon as its predicate words are back.
+    t_replay = now_ms();
+    rc = replay_progressive(e, e->h_pred, mf, R, &replay_pairs, &replay_busy_ms);
+    if (rc) {
+      return rc;
+    }
+    replayed = true;
+    tl[3] = now_ms();
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    tl[4] = now_ms();
+    for (const ldp_engine::PairGroup& g : e->groups) {
+      float f = 0.f, gen = 0.f;
+      HIP_TRY(e, hipEventElapsedTime(&f, g.ev[0], g.ev[1]));
+      HIP_TRY(e, hipEventElapsedTime(&gen, g.ev[2], g.ev[3]));
+      kms_fast += f;
+      kms_general += gen;
+      ++launches;
+    }
+  }
+  for (int q = 0; q < 4; ++q) {
+    h_counters[q] = e->h_counters_pin[q];  // (the stream that carried the copy has been synchronised in both branches)
+  }
+  kms = kms_fast + kms_general;
+  if (!replayed) {
+    rc = prepare_mf(e, &mf_scratch, &mf);
+    if (rc) {
+      return rc;
+    }
+    // greedy replay on the host
+    t_replay = now_ms();
+    replay(e, e->h_pred, mf, R, &replay_pairs);
+  }
   finish_removed(e, R, removed);
   const double t_end = now_ms();
+  if (getenv("LDP_DEBUG_TIMELINE")) {
+    fprintf(stderr, "run timeline (ms since entry): queued %.2f recs %.2f mf %.2f replayed %.2f synced %.2f end %.2f\n", tl[0] - t_start, tl[1] - t_start,
+            tl[2] - t_start, tl[3] - t_start, tl[4] - t_start, t_end - t_start);
+  }
 
   e->ctr.candidate_pairs = e->cand_pairs;
   e->ctr.computed_pairs = e->computed_pairs;
@@ -1006,9 +1320,9 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   e->ctr.ms_pair_kernel = kms;
   e->ctr.ms_pair_fast = kms_fast;
   e->ctr.ms_pair_general = kms_general;
-  e->ctr.ms_replay = t_end - t_replay;
+  e->ctr.ms_replay = replayed ? replay_busy_ms : (t_end - t_replay);  // (time spent replaying, not waiting for groups)
   e->ctr.ms_run_total = t_end - t_start;
-  e->ctr.pair_kernel_launches = e->items.empty() ? 0 : 1;
+  e->ctr.pair_kernel_launches = launches;
   return LDP_OK;
 }
 
@@ -1068,13 +1382,18 @@ int ldp_create(const ldp_params* params, ldp_engine** out) {
       e->gpu_ok = true;
       if (params->stream) {
         e->stream = static_cast<hipStream_t>(params->stream);
-      } else if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess) {
+      } else if (create_stream(&e->stream, true) == hipSuccess) {
         e->own_stream = true;
       } else {
         e->gpu_ok = false;
       }
-      if (e->gpu_ok && (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess)) {
+      if (e->gpu_ok && (create_stream(&e->copy_stream, true) != hipSuccess)) {
         e->gpu_ok = false;
+      }
+      for (int k = 0; (k < kPairStreams) && e->gpu_ok; ++k) {
+        if (create_stream(&e->pair_stream[k], false) != hipSuccess) {
+          e->gpu_ok = false;
+        }
       }
     }
   }
@@ -1094,6 +1413,11 @@ void ldp_destroy(ldp_engine* e) {
     }
     if (e->copy_stream) {
       (void)hipStreamDestroy(e->copy_stream);
+    }
+    for (int k = 0; k < kPairStreams; ++k) {
+      if (e->pair_stream[k]) {
+        (void)hipStreamDestroy(e->pair_stream[k]);
+      }
     }
   }
   delete e;
@@ -1427,6 +1751,19 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
     }
     stage_rows = std::max<size_t>(1, kStageBytes / row_bytes);
   }
+  // loading a variant a second time since the last epoch began starts a new epoch (see begin_load_epoch)
+  for (uint32_t q = first_variant; q < first_variant + n; ++q) {
+    const int64_t l = e->global_to_local[q];
+    if ((l >= 0) && (e->load_tag[l] == e->load_epoch)) {
+      rc = begin_load_epoch(e);
+      if (rc) {
+        return rc;
+      }
+      break;
+    }
+  }
+  static const bool eager_always = (getenv("LDP_EAGER_PAIRS") != nullptr) && (strcmp(getenv("LDP_EAGER_PAIRS"), "1") == 0);
+  const bool eager = (!e->matrix_mode) && ((location == LDP_MEM_HOST) || eager_always);
   uint32_t slot = 0;
   uint32_t g = first_variant;
   const uint32_t gend = first_variant + n;
@@ -1443,6 +1780,14 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
     uint32_t done = 0;
     while (done < run) {
       uint32_t cnt = run - done;
+      const uint32_t l0 = static_cast<uint32_t>(e->global_to_local[g + done]);
+      // end the conversion launch where the next pair group becomes ready, so that group starts behind it
+      if (eager && (e->next_group < e->groups.size())) {
+        const uint32_t need = e->groups[e->next_group].need_end;
+        if ((l0 < need) && (l0 + cnt > need)) {
+          cnt = need - l0;
+        }
+      }
       const uint8_t* d_src;
       uint64_t d_stride = stride_bytes;
       if (location == LDP_MEM_HOST) {
@@ -1469,7 +1814,6 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
       } else {
         d_src = src + static_cast<uint64_t>(g + done - first_variant) * stride_bytes;
       }
-      const uint32_t l0 = static_cast<uint32_t>(e->global_to_local[g + done]);
       PrepareArgs PA;
       PA.geno = d_src;
       PA.stride_bytes = d_stride;
@@ -1501,8 +1845,18 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
       }
       for (uint32_t q = 0; q < cnt; ++q) {
         e->loaded[l0 + q] = 1;
+        e->load_tag[l0 + q] = e->load_epoch;
         if (encoding != LDP_GENO_INVERSE) {
           e->mf_set[l0 + q] = 2;  // derived from the device's allele counts at the next ldp_run()
+        }
+      }
+      // Pair tiles whose variants are all converted start right away when the input comes over PCIe (the GPU is
+      // mostly idle then).  With device-resident input the conversion is HBM-bound and gains nothing from sharing
+      // the CUs (measured), it only finishes later -- and with it the records the host replay is waiting for.
+      if (eager) {
+        rc = launch_ready_groups(e);
+        if (rc) {
+          return rc;
         }
       }
       done += cnt;
@@ -1510,6 +1864,7 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
     g += run;
   }
   e->recs_host_valid = false;
+  e->recs_copy_queued = false;
   if (location == LDP_MEM_HOST) {
     HIP_TRY(e, hipStreamSynchronize(e->stream));  // the caller may reuse its buffer once we return
   }

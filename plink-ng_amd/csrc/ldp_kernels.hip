@@ -14,18 +14,44 @@
 // tiles are staged through LDS as 16-byte words and reused from registers 4 x NA times per thread.
 #include "ldp_device.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace ldp {
 
 // ================================================================================================
 // prepare
 // ================================================================================================
-__device__ __forceinline__ uint32_t pack_even_bits(uint32_t x) {
-  x &= 0x55555555u;
-  x = (x | (x >> 1)) & 0x33333333u;
-  x = (x | (x >> 2)) & 0x0f0f0f0fu;
-  x = (x | (x >> 4)) & 0x00ff00ffu;
-  x = (x | (x >> 8)) & 0x0000ffffu;
+// Three of the four stages of the 32-bit perfect unshuffle (Hacker's Delight 7-2).  Afterwards each byte of x holds
+// [even bits of the low half, odd bits of the low half, even bits of the high half, odd bits of the high half];
+// the last stage (a byte swap) is folded into the v_perm_b32 that merges two input words into one plane dword.
+__device__ __forceinline__ uint32_t unshuffle_to_bytes(uint32_t x) {
+  uint32_t t;
+  t = (x ^ (x >> 1)) & 0x22222222u;
+  x = x ^ t ^ (t << 1);
+  t = (x ^ (x >> 2)) & 0x0c0c0c0cu;
+  x = x ^ t ^ (t << 2);
+  t = (x ^ (x >> 4)) & 0x00f000f0u;
+  x = x ^ t ^ (t << 4);
   return x;
+}
+
+// 32 samples (two input dwords, 2 bits per sample) -> one dword of each plane: ~30 VALU ops instead of the ~60 of
+// four separate even-bit gathers (matters once the conversion shares the CUs with the pair kernel).
+// .pgen codes: hom = !lo, ref2het = !hi.  .bed code b1b0 -> pgen lo = b0^b1, hi = !b1: hom = !(b0^b1), ref2het = b1.
+__device__ __forceinline__ void planes_of_32(uint32_t w0, uint32_t w1, int encoding, uint32_t* hom, uint32_t* r2h) {
+  uint32_t x0, x1;
+  if (encoding == LDP_GENO_BED) {
+    x0 = ((~(w0 ^ (w0 >> 1))) & 0x55555555u) | (w0 & 0xaaaaaaaau);
+    x1 = ((~(w1 ^ (w1 >> 1))) & 0x55555555u) | (w1 & 0xaaaaaaaau);
+  } else {
+    x0 = ~w0;
+    x1 = ~w1;
+  }
+  x0 = unshuffle_to_bytes(x0);
+  x1 = unshuffle_to_bytes(x1);
+  *hom = __builtin_amdgcn_perm(x1, x0, 0x06040200u);
+  *r2h = __builtin_amdgcn_perm(x1, x0, 0x07050301u);
 }
 
 __device__ __forceinline__ uint32_t load_geno_dword(const uint8_t* row, uint32_t nbytes, uint32_t didx, bool aligned4) {
@@ -55,14 +81,7 @@ __device__ __forceinline__ void convert_plane_dword(const uint8_t* row, uint32_t
   const uint32_t w0 = load_geno_dword(row, nbytes, 2 * p, aligned4);
   const uint32_t w1 = load_geno_dword(row, nbytes, 2 * p + 1, aligned4);
   uint32_t hom, r2h;
-  if (encoding == LDP_GENO_BED) {
-    // bed code b1b0 -> pgen: lo = b0^b1, hi = ~b1; hom = ~lo, ref2het = ~hi = b1
-    hom = pack_even_bits(~(w0 ^ (w0 >> 1))) | (pack_even_bits(~(w1 ^ (w1 >> 1))) << 16);
-    r2h = pack_even_bits(w0 >> 1) | (pack_even_bits(w1 >> 1) << 16);
-  } else {
-    hom = pack_even_bits(~w0) | (pack_even_bits(~w1) << 16);
-    r2h = pack_even_bits((~w0) >> 1) | (pack_even_bits((~w1) >> 1) << 16);
-  }
+  planes_of_32(w0, w1, encoding, &hom, &r2h);
   const uint32_t remaining = founder_ct - first_sample;
   if (remaining < 32) {
     const uint32_t mask = (1u << remaining) - 1;
@@ -84,13 +103,7 @@ __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
 // Two adjacent plane dwords (64 samples) from four input dwords; one 16-byte load when the row allows it.
 __device__ __forceinline__ void planes_from_words(uint32_t w0, uint32_t w1, int encoding, uint32_t founder_ct, uint32_t p, uint32_t* hom_out, uint32_t* r2h_out) {
   uint32_t hom, r2h;
-  if (encoding == LDP_GENO_BED) {
-    hom = pack_even_bits(~(w0 ^ (w0 >> 1))) | (pack_even_bits(~(w1 ^ (w1 >> 1))) << 16);
-    r2h = pack_even_bits(w0 >> 1) | (pack_even_bits(w1 >> 1) << 16);
-  } else {
-    hom = pack_even_bits(~w0) | (pack_even_bits(~w1) << 16);
-    r2h = pack_even_bits((~w0) >> 1) | (pack_even_bits((~w1) >> 1) << 16);
-  }
+  planes_of_32(w0, w1, encoding, &hom, &r2h);
   const uint32_t first_sample = p * 32;
   if (first_sample >= founder_ct) {
     hom = 0;
@@ -162,10 +175,10 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
       const uint32_t bc = __popc(keep_hom[it][0] & keep_r2h[it][0]) + __popc(keep_hom[it][1] & keep_r2h[it][1]);
       both_ct += bc;
       const uint32_t chunk = p / kChunkDwords;
+      const uint32_t packed = hc | (bc << 16);  // per-thread totals stay below 2^16 here (<= 16 x 64 samples)
 #pragma unroll
       for (int k = 0; k < kCheckpoints; ++k) {
-        rest[k] += (chunk >= A.checkpoint_chunk[k]) ? hc : 0;
-        rest_both[k] += (chunk >= A.checkpoint_chunk[k]) ? bc : 0;
+        rest[k] += (chunk >= A.checkpoint_chunk[k]) ? packed : 0;
       }
     }
   } else {
@@ -190,6 +203,10 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
   both_ct = wave_reduce_add(both_ct);
 #pragma unroll
   for (int k = 0; k < kCheckpoints; ++k) {
+    if constexpr (MAXIT > 0) {
+      rest_both[k] = rest[k] >> 16;  // (accumulated packed in the register-resident pass)
+      rest[k] &= 0xffff;
+    }
     rest[k] = wave_reduce_add(rest[k]);
     rest_both[k] = wave_reduce_add(rest_both[k]);
   }
@@ -1145,7 +1162,10 @@ hipError_t launch_pair_tiles(const PairKernelArgs& a_in, uint32_t max_rows, hipS
   }
   PairKernelArgs a = a_in;
   const uint32_t per_xcd = (a.n_items + 7) / 8;
-  const size_t lds = pair_tiles_lds_bytes(max_rows);
+  size_t lds = pair_tiles_lds_bytes(max_rows);
+  if (const char* pad = getenv("LDP_DEBUG_LDS_KB")) {  // tuning aid: force fewer resident blocks per CU
+    lds = std::max<size_t>(lds, static_cast<size_t>(atoi(pad)) * 1024);
+  }
   a.lds_dwords = static_cast<uint32_t>(lds / sizeof(uint32_t));
   hipLaunchKernelGGL(classify_items_kernel, dim3((a.n_items + 3) / 4), dim3(256), 0, stream, a);
   if (ev) {
