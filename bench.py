@@ -258,7 +258,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 if tj.get("samples") == founder_ct and tj.get("variants") == args.variants and tj.get("window_kb") == args.window_kb:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic = tj.get("hbm_bytes_per_step", tj.get("hbm_bytes_per_launch"))
             except Exception:
                 traffic = None
         out = {
