@@ -431,7 +431,7 @@ bool early_exit_requested() {
 }
 
 int checkpoint_fractions(double r2_param, double* frac) {
-  static const double kStep[kCheckpoints] = {0.05, 0.10, 0.17, 0.30, 0.50};
+  static const double kStep[kCheckpoints] = {0.012, 0.04, 0.08, 0.16, 0.36};  // (tuned on config 2: an earlier first checkpoint pays, a failed one costs little)
   const double f0 = 1.0 - sqrt(r2_param);
   int n = 0;
   if (const char* dbg = getenv("LDP_DEBUG_CP_FRACS")) {  // tuning aid: comma-separated absolute fractions
@@ -611,15 +611,19 @@ void build_shard(ldp_engine* e) {
   // launch groups: ~kTargetGroups runs of whole J-tiles (a J-tile's blocks share predicate rows)
   e->groups.clear();
   {
+    // ~4 groups of decreasing size (40/30/20/10 %): what is exposed after the last kernel is that group's copy back
+    // and replay, so it should be the small one
     uint32_t kTargetGroups = 4;
     if (const char* tg = getenv("LDP_DEBUG_GROUPS")) {
       kTargetGroups = std::max(1, atoi(tg));
     }
     const uint32_t n_items = static_cast<uint32_t>(e->items.size());
-    const uint32_t per_group = std::max<uint32_t>(512, (n_items + kTargetGroups - 1) / kTargetGroups);
+    const double weight_sum = kTargetGroups * (kTargetGroups + 1) / 2.0;
     uint32_t i0 = 0;
-    while (i0 < n_items) {
-      uint32_t i1 = std::min(n_items, i0 + per_group);
+    for (uint32_t k = 0; i0 < n_items; ++k) {
+      const double share = (k < kTargetGroups) ? (kTargetGroups - k) / weight_sum : 1.0;
+      const uint32_t want = std::max<uint32_t>(512, static_cast<uint32_t>(n_items * share));
+      uint32_t i1 = ((k + 1 >= kTargetGroups) || (n_items - i0 <= want)) ? n_items : i0 + want;
       while ((i1 < n_items) && (e->items[i1].j0 == e->items[i1 - 1].j0)) {
         ++i1;
       }
