@@ -173,6 +173,19 @@ int ldp_set_variants_matrix(ldp_engine* e, uint32_t variant_ct);
  * square / square0 / triangle files from row chunks (VcorMatrixThread :9518-9652 computes the same rows). */
 int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t ld_elems);
 
+/* ---- --r2-unphased table (VcorTable, plink2_ld.cc:11025; window: UpdateVcorWindow :10984-11023) ---- */
+/* Windowed plan: variant B is paired with the earlier variants A of its chromosome with bp[B] - bp[A] <= bp_radius
+ * and at most var_ct_radius variants between... i.e. B - A <= var_ct_radius in include-order (the reference's
+ * --ld-window-kb / --ld-window).  Use instead of ldp_set_variants(), then ldp_load_genotypes();
+ * ldp_get_band() returns lo[] (first partner of each second variant). */
+int ldp_set_variants_vcor(ldp_engine* e, uint32_t variant_ct, const uint32_t* chr_idx, const uint32_t* bps, uint32_t bp_radius,
+                          uint32_t var_ct_radius);
+/* r^2 of every candidate pair whose SECOND variant j lies in [row_first, row_first+row_ct), band order: the pairs of j
+ * start at element sum_{row_first <= j' < j} (j' - lo[j']) and run over first variants i = lo[j] .. j-1.  Same doubles
+ * (bin) / floats (bin4) as ldp_r2_unphased_rows, NaN included; filtering (--ld-window-r2) and the A-major order of the
+ * .vcor file are the caller's (VcorTableWriteThread :10680-10950).  `out` is host memory of capacity_elems elements. */
+int ldp_r2_unphased_band_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t capacity_elems);
+
 /* ---- inspection ---- */
 int ldp_get_variant_recs(ldp_engine* e, uint32_t first_variant, uint32_t n, ldp_variant_rec* out);
 int ldp_get_maj_freqs(ldp_engine* e, uint32_t first_variant, uint32_t n, double* out);

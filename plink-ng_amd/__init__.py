@@ -77,7 +77,7 @@ CABI_SYMBOLS = [
     "ldp_set_shard", "ldp_get_band", "ldp_load_genotypes", "ldp_set_maj_freqs", "ldp_set_preferred", "ldp_run",
     "ldp_run_with_stats", "ldp_pair_stats", "ldp_debug_set_variant_recs", "ldp_debug_replay_pairs",
     "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
-    "ldp_set_variants_matrix", "ldp_r2_unphased_rows",
+    "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
     "ldp_pgen_variant_is_multiallelic", "ldp_pgen_read_alleles",
 ]
@@ -168,6 +168,9 @@ def lib():
                                       ctypes.c_uint64, ctypes.c_int, vp]
     L.ldp_set_variants_matrix.argtypes = [vp, ctypes.c_uint32]
     L.ldp_r2_unphased_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, vp, ctypes.c_uint64]
+    L.ldp_set_variants_vcor.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
+                                        ctypes.c_uint32, ctypes.c_uint32]
+    L.ldp_r2_unphased_band_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, vp, ctypes.c_uint64]
     L.ldp_pgen_open.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp)]
     L.ldp_pgen_info.argtypes = [vp, u32p, u32p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.ldp_pgen_direct_rows.argtypes = [vp, u64p]
@@ -324,6 +327,24 @@ class LdPruneEngine:
         out = np.zeros((row_ct, ld), dtype=np.float32 if as_float else np.float64)
         self._ck(self._L.ldp_r2_unphased_rows(self._h, row_first, row_ct, 1 if as_float else 0, out.ctypes.data_as(ctypes.c_void_p), ld))
         return out
+
+    def set_variants_vcor(self, chr_idx, bps, bp_radius, var_ct_radius=0x7fffffff):
+        """Windowed plan of the --r2-unphased table (--ld-window-kb / --ld-window)."""
+        chr_idx = _u32(chr_idx)
+        bps = _u32(bps)
+        self.variant_ct = len(chr_idx)
+        self._ck(self._L.ldp_set_variants_vcor(self._h, self.variant_ct, _ptr(chr_idx, ctypes.c_uint32), _ptr(bps, ctypes.c_uint32),
+                                               int(bp_radius), int(var_ct_radius)))
+
+    def r2_unphased_band_rows(self, row_first=0, row_ct=None, as_float=False):
+        """r^2 of the candidate pairs of second variants [row_first, row_first+row_ct), band order (see band())."""
+        row_ct = self.variant_ct - row_first if row_ct is None else row_ct
+        lo, _ = self.band()
+        j = np.arange(row_first, row_first + row_ct, dtype=np.int64)
+        n = int((j - lo[row_first:row_first + row_ct]).sum())
+        out = np.zeros(max(n, 1), dtype=np.float32 if as_float else np.float64)
+        self._ck(self._L.ldp_r2_unphased_band_rows(self._h, row_first, row_ct, 1 if as_float else 0, out.ctypes.data_as(ctypes.c_void_p), n))
+        return out[:n]
 
     def subcontigs(self):
         ct = ctypes.c_uint32()

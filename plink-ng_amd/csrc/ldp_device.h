@@ -84,7 +84,9 @@ struct PairKernelArgs {
   uint32_t lds_dwords;           // dynamic LDS of the launch (set by launch_pair_tiles)
   void* r2_out;
   uint64_t r2_ld;
-  uint32_t r2_row_first;
+  uint32_t r2_row_first;         // only second variants j in [r2_row_first, r2_row_end) are stored
+  uint32_t r2_row_end;
+  uint64_t r2_band_base;         // r2_ld == 0: band layout, element pair_off[j] - r2_band_base + (i - lo[j])
   uint32_t r2_float;
 };
 

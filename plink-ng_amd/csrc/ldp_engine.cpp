@@ -83,6 +83,7 @@ struct ldp_engine {
   // ---- plan (global indices) ----
   bool planned = false;
   bool matrix_mode = false;  // all-pairs plan for --r2-unphased matrices (no band, no predicate rows)
+  bool band_r2_mode = false; // windowed plan for the --r2-unphased table (band of r^2 values, no prune run)
   uint32_t variant_ct = 0;
   std::vector<uint32_t> bps;
   std::vector<Subcontig> subs;
@@ -1069,6 +1070,8 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.r2_out = nullptr;
   A.r2_ld = 0;
   A.r2_row_first = 0;
+  A.r2_row_end = 0;
+  A.r2_band_base = 0;
   A.r2_float = 0;
 }
 
@@ -1142,8 +1145,8 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   if (!removed) {
     return fail(e, LDP_ERR_INVALID, "removed bitmap is NULL");
   }
-  if (e->matrix_mode) {
-    return fail(e, LDP_ERR_STATE, "engine is planned for --r2-unphased matrices (ldp_set_variants_matrix)");
+  if (e->matrix_mode || e->band_r2_mode) {
+    return fail(e, LDP_ERR_STATE, "engine is planned for --r2-unphased output (ldp_set_variants_matrix / ldp_set_variants_vcor)");
   }
   const double t_start = now_ms();
   double tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1448,6 +1451,7 @@ int ldp_set_variants(ldp_engine* e, uint32_t variant_ct, const uint32_t* chr_idx
     }
   }
   e->matrix_mode = false;
+  e->band_r2_mode = false;
   e->variant_ct = variant_ct;
   e->bps.clear();
   if (bps) {
@@ -1480,6 +1484,7 @@ int ldp_set_variants_matrix(ldp_engine* e, uint32_t variant_ct) {
     return LDP_ERR_INVALID;
   }
   e->matrix_mode = true;
+  e->band_r2_mode = false;
   e->variant_ct = variant_ct;
   e->bps.clear();
   e->subs.clear();
@@ -1501,6 +1506,166 @@ int ldp_set_variants_matrix(ldp_engine* e, uint32_t variant_ct) {
   e->ctr.subcontig_ct = static_cast<uint32_t>(e->subs.size());
   e->ctr.owned_subcontig_ct = e->ctr.subcontig_ct;
   e->ctr.window_max = variant_ct;
+  return LDP_OK;
+}
+
+// Window of the --r2-unphased table (UpdateVcorWindow, plink2_ld.cc:10984-11023): second variant B is paired with
+// the earlier variants A of its chromosome that are at most var_ct_radius variants and bp_radius base pairs away.
+int ldp_set_variants_vcor(ldp_engine* e, uint32_t variant_ct, const uint32_t* chr_idx, const uint32_t* bps, uint32_t bp_radius, uint32_t var_ct_radius) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  if (variant_ct && (!chr_idx || !bps)) {
+    return fail(e, LDP_ERR_INVALID, "chr_idx / bps is NULL");
+  }
+  for (uint32_t v = 1; v < variant_ct; ++v) {
+    if (chr_idx[v] < chr_idx[v - 1]) {
+      return fail(e, LDP_ERR_INVALID, "chr_idx must be nondecreasing");
+    }
+    if ((chr_idx[v] == chr_idx[v - 1]) && (bps[v] < bps[v - 1])) {
+      return fail(e, LDP_ERR_INVALID, "positions must be sorted within a chromosome (plink2.cc:2926)");
+    }
+  }
+  e->matrix_mode = false;
+  e->band_r2_mode = true;
+  e->variant_ct = variant_ct;
+  e->bps.assign(bps, bps + variant_ct);
+  e->subs.clear();
+  e->lo_global.resize(variant_ct);
+  e->batch_end.assign(variant_ct, 0);
+  uint32_t window_max = 0;
+  uint32_t c0 = 0;
+  while (c0 < variant_ct) {
+    uint32_t c1 = c0 + 1;
+    while ((c1 < variant_ct) && (chr_idx[c1] == chr_idx[c0])) {
+      ++c1;
+    }
+    uint32_t lo = c0;
+    for (uint32_t j = c0; j < c1; ++j) {
+      while ((bps[j] - bps[lo] > bp_radius) || (j - lo > var_ct_radius)) {
+        ++lo;
+      }
+      e->lo_global[j] = lo;
+      window_max = std::max(window_max, j - lo + 1);
+    }
+    if (c1 - c0 >= 2) {
+      Subcontig s;
+      s.len = c1 - c0;
+      s.first = c0;
+      s.owner = 0;
+      s.local_first = 0;
+      e->subs.push_back(s);
+    } else {
+      e->lo_global[c0] = c0;
+    }
+    c0 = c1;
+  }
+  e->window_max = window_max;
+  e->rank = 0;
+  e->world = 1;
+  e->planned = true;
+  build_shard(e);
+  e->ctr.subcontig_ct = static_cast<uint32_t>(e->subs.size());
+  e->ctr.owned_subcontig_ct = e->ctr.subcontig_ct;
+  e->ctr.window_max = window_max;
+  return LDP_OK;
+}
+
+// r^2 of every candidate pair whose SECOND variant lies in [row_first, row_first + row_ct), in band order: the
+// pairs of second variant j start at sum_{row_first <= j' < j} (j' - lo[j']) and run over i = lo[j] .. j-1
+// (lo from ldp_get_band).  Same doubles as ldp_r2_unphased_rows.
+int ldp_r2_unphased_band_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t capacity_elems) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  if (!e->planned || !e->band_r2_mode) {
+    return fail(e, LDP_ERR_STATE, "ldp_set_variants_vcor() first");
+  }
+  if (static_cast<uint64_t>(row_first) + row_ct > e->variant_ct) {
+    return fail(e, LDP_ERR_INVALID, "row range out of bounds");
+  }
+  int rc = ensure_device_plan(e);
+  if (rc) {
+    return rc;
+  }
+  for (uint32_t l = 0; l < e->local_ct; ++l) {
+    if (!e->loaded[l]) {
+      return fail(e, LDP_ERR_STATE, "genotypes missing for a variant (ldp_load_genotypes)");
+    }
+  }
+  // owned (= paired) variants of the global row range are contiguous in local order
+  const uint32_t row_end = row_first + row_ct;
+  uint32_t l_first = e->local_ct, l_end = 0;
+  for (uint32_t g = row_first; g < row_end; ++g) {
+    const int64_t l = e->global_to_local[g];
+    if (l >= 0) {
+      l_first = std::min<uint32_t>(l_first, static_cast<uint32_t>(l));
+      l_end = std::max<uint32_t>(l_end, static_cast<uint32_t>(l) + 1);
+    }
+  }
+  if (l_first >= l_end) {
+    return LDP_OK;
+  }
+  const uint64_t n_elems = e->pair_off[l_end] - e->pair_off[l_first];
+  if (n_elems > capacity_elems) {
+    return fail(e, LDP_ERR_INVALID, "output buffer smaller than the rows' candidate pair count");
+  }
+  if (!n_elems) {
+    return LDP_OK;
+  }
+  if (!out) {
+    return fail(e, LDP_ERR_INVALID, "output buffer is NULL");
+  }
+  const double t_start = now_ms();
+  HIP_TRY(e, hipSetDevice(e->device));
+  // items are sorted by J-tile: the ones that touch [l_first, l_end)
+  size_t i0 = 0, i1 = e->items.size();
+  while ((i0 < i1) && (e->items[i0].jend <= l_first)) {
+    ++i0;
+  }
+  while ((i1 > i0) && (e->items[i1 - 1].j0 >= l_end)) {
+    --i1;
+  }
+  const size_t esz = as_float ? sizeof(float) : sizeof(double);
+  DevBuf out_buf;
+  HIP_TRY(e, hipMalloc(&out_buf.p, n_elems * esz));
+  HIP_TRY(e, hipMemsetAsync(out_buf.p, 0, n_elems * esz, e->stream));
+  PairKernelArgs A;
+  fill_pair_args(e, &A, false);  // every r^2 is wanted: no early termination
+  A.items = e->d_items + i0;
+  A.item_general = e->d_item_general + i0;
+  A.n_items = static_cast<uint32_t>(i1 - i0);
+  A.thresh = 0.0;
+  A.r2_out = out_buf.p;
+  A.r2_ld = 0;
+  A.r2_row_first = l_first;
+  A.r2_row_end = l_end;
+  A.r2_band_base = e->pair_off[l_first];
+  A.r2_float = as_float ? 1 : 0;
+  hipEvent_t evk[4];
+  for (int q = 0; q < 4; ++q) {
+    HIP_TRY(e, hipEventCreate(&evk[q]));
+  }
+  const hipError_t krc = launch_pair_tiles(A, e->max_rows, e->stream, evk);
+  if (krc != hipSuccess) {
+    return hipfail(e, krc, "pair_tiles_kernel launch");
+  }
+  HIP_TRY(e, hipMemcpyAsync(out, out_buf.p, n_elems * esz, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  float kms_fast = 0.f, kms_general = 0.f;
+  if (A.n_items) {
+    HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
+    HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[2], evk[3]));
+  }
+  for (int q = 0; q < 4; ++q) {
+    (void)hipEventDestroy(evk[q]);
+  }
+  e->ctr.candidate_pairs = n_elems;
+  e->ctr.ms_pair_fast = kms_fast;
+  e->ctr.ms_pair_general = kms_general;
+  e->ctr.ms_pair_kernel = kms_fast + kms_general;
+  e->ctr.ms_run_total = now_ms() - t_start;
+  e->ctr.pair_kernel_launches = A.n_items ? 1 : 0;
   return LDP_OK;
 }
 
@@ -1608,6 +1773,8 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
   A.r2_out = d_out;
   A.r2_ld = ld_elems;
   A.r2_row_first = row_first;
+  A.r2_row_end = row_end;
+  A.r2_band_base = 0;
   A.r2_float = as_float ? 1 : 0;
   hipEvent_t evk[4];
   for (int q = 0; q < 4; ++q) {
@@ -1767,7 +1934,7 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
     }
   }
   static const bool eager_always = (getenv("LDP_EAGER_PAIRS") != nullptr) && (strcmp(getenv("LDP_EAGER_PAIRS"), "1") == 0);
-  const bool eager = (!e->matrix_mode) && ((location == LDP_MEM_HOST) || eager_always);
+  const bool eager = (!e->matrix_mode) && (!e->band_r2_mode) && ((location == LDP_MEM_HOST) || eager_always);
   uint32_t slot = 0;
   uint32_t g = first_variant;
   const uint32_t gend = first_variant + n;

@@ -694,8 +694,12 @@ __device__ __forceinline__ bool emit_pair(const PairKernelArgs& A, uint32_t i, u
     A.stats[A.pair_off[j] + (i - lo_j)] = st;
   }
   if (A.r2_out) {
+    if ((j < A.r2_row_first) || (j >= A.r2_row_end)) {
+      return false;  // a J-tile can straddle the edge of the requested rows
+    }
     const double r2 = r2_unphased(st);
-    const uint64_t idx = static_cast<uint64_t>(j - A.r2_row_first) * A.r2_ld + i;
+    // dense rows of the lower triangle (matrix shapes), or the band itself (windowed table)
+    const uint64_t idx = A.r2_ld ? (static_cast<uint64_t>(j - A.r2_row_first) * A.r2_ld + i) : (A.pair_off[j] - A.r2_band_base + (i - lo_j));
     if (A.r2_float) {
       const float f = (r2 != r2) ? __uint_as_float(0xffc00000u) : static_cast<float>(r2);
       static_cast<float*>(A.r2_out)[idx] = f;

@@ -13,8 +13,11 @@
 // the <50-founders guard (plink2.cc:2063-2071) and the output writer.
 // Multiallelic variants are collapsed major-vs-rest on the host (Get1Multiallelic semantics); chrX / chrY / MT get
 // their sample-mapped rows (males het->missing, non-males x2, ...) built on the host as well.
+// --r2-unphased: the binary matrix shapes (square/square0/triangle x bin/bin4) and the windowed .vcor table with the
+// default columns (--ld-window, --ld-window-kb, --ld-window-r2), number formatting restated from dtoa_g.
 // Not yet supported (reported as such, never silently mis-handled): .pvar.zst, external-index .pgen (modes
-// 0x20/0x21), more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, chrX/Y/MT in --r2-unphased.
+// 0x20/0x21), more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, chrX/Y/MT and multiallelic sites in
+// --r2-unphased, its cols=/zs/inter-chr modifiers, --ld-snp*, --ld-window-cm.
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <fcntl.h>
@@ -157,6 +160,120 @@ bool scan_double_plink(const char* s, double* out, const char** endp) {
   return true;
 }
 
+// The reference's 6-significant-digit double formatter (dtoa_g, include/plink2_string.cc:2507-2639, with its
+// BankerRoundD* helpers :2231-2295), restated: the value is scaled by the same sequence of powers of ten (each
+// product rounds, so the sequence matters), rounded to six digits with ties-to-even inside a 5e-9 tolerance band,
+// and printed without trailing zeros; exponent form below 1e-4 and from 1e6.
+uint32_t banker_round(double v) {  // v >= 0, < 2^31
+  static const double kTie[2] = {0.499999995, 0.500000005};
+  const uint32_t t = static_cast<uint32_t>(static_cast<int32_t>(v));
+  return t + static_cast<uint32_t>(static_cast<int32_t>((v - static_cast<double>(t)) + kTie[t & 1]));
+}
+
+// `digits` decimal digits of u, zero-padded, trailing zeros dropped (at least `keep` stay)
+char* put_digits_trimmed(uint32_t u, int digits, int keep, char* out) {
+  char buf[16];
+  for (int k = digits - 1; k >= 0; --k) {
+    buf[k] = static_cast<char>('0' + u % 10);
+    u /= 10;
+  }
+  int n = digits;
+  while (n > keep && buf[n - 1] == '0') {
+    --n;
+  }
+  memcpy(out, buf, n);
+  return out + n;
+}
+
+char* format_g6(double x, char* out) {
+  if (x != x) {
+    memcpy(out, "nan", 3);
+    return out + 3;
+  }
+  if (x < 0) {
+    *out++ = '-';
+    x = -x;
+  }
+  if (x == 0.0) {
+    *out++ = '0';
+    return out;
+  }
+  static const int kExp[9] = {256, 128, 64, 32, 16, 8, 4, 2, 1};
+  static const double kUp[9] = {1.0e256, 1.0e128, 1.0e64, 1.0e32, 1.0e16, 100000000, 10000, 100, 10};
+  static const double kDown[9] = {1.0e-256, 1.0e-128, 1.0e-64, 1.0e-32, 1.0e-16, 1.0e-8, 1.0e-4, 1.0e-2, 1.0e-1};
+  static const double kSmallBound[9] = {9.9999949999999e-256, 9.9999949999999e-128, 9.9999949999999e-64, 9.9999949999999e-32, 9.9999949999999e-16,
+                                        9.9999949999999e-8,   9.9999949999999e-4,   9.9999949999999e-2,  9.9999949999999e-1};
+  static const double kLargeBound[9] = {9.9999949999999e255, 9.9999949999999e127, 9.9999949999999e63, 9.9999949999999e31, 9.9999949999999e15,
+                                        9.9999949999999e7,   9.9999949999999e3,   9.9999949999999e1,  9.9999949999999e0};
+  const bool small = (x < 9.9999949999999e-5);
+  if (small || (x >= 999999.49999999)) {
+    if ((!small) && (x > 1.7976931348623157e308)) {
+      memcpy(out, "inf", 3);
+      return out + 3;
+    }
+    int xp10 = 0;
+    for (int k = 0; k < 9; ++k) {
+      if (small ? (x < kSmallBound[k]) : (x >= kLargeBound[k])) {
+        x *= small ? kUp[k] : kDown[k];
+        xp10 += kExp[k];
+        if (k == 0) {
+          ++k;  // (the reference takes either the 256 or the 128 step, never both)
+        }
+      }
+    }
+    const uint32_t t = banker_round(x * 100000);
+    *out++ = static_cast<char>('0' + t / 100000);
+    if (t % 100000) {
+      *out++ = '.';
+      out = put_digits_trimmed(t % 100000, 5, 1, out);
+    }
+    *out++ = 'e';
+    *out++ = small ? '-' : '+';
+    if (xp10 >= 100) {
+      *out++ = static_cast<char>('0' + xp10 / 100);
+      xp10 %= 100;
+    }
+    *out++ = static_cast<char>('0' + xp10 / 10);
+    *out++ = static_cast<char>('0' + xp10 % 10);
+    return out;
+  }
+  if (x >= 0.99999949999999) {
+    // six significant digits of a number in [1, 1e6): the digits before the point, then what is left of the six
+    int int_digits = 1;
+    double bound = 9.9999949999999;
+    while ((int_digits < 6) && (x >= bound)) {
+      ++int_digits;
+      bound = (int_digits == 2) ? 99.999949999999 : ((int_digits == 3) ? 999.99949999999 : ((int_digits == 4) ? 9999.9949999999 : 99999.949999999));
+    }
+    static const double kScale[7] = {0, 100000, 10000, 1000, 100, 10, 1};
+    static const uint32_t kDiv[7] = {0, 100000, 10000, 1000, 100, 10, 1};
+    const uint32_t t = banker_round(x * kScale[int_digits]);
+    const uint32_t q = t / kDiv[int_digits], r = t % kDiv[int_digits];
+    char tmp[16];
+    const int n = snprintf(tmp, sizeof(tmp), "%u", q);
+    memcpy(out, tmp, n);
+    out += n;
+    if (r) {
+      *out++ = '.';
+      out = put_digits_trimmed(r, 6 - int_digits, 1, out);
+    }
+    return out;
+  }
+  // [~1e-4, 1): "0." + leading zeros + six significant digits
+  *out++ = '0';
+  *out++ = '.';
+  if (x < 9.9999949999999e-3) {
+    x *= 100;
+    *out++ = '0';
+    *out++ = '0';
+  }
+  if (x < 9.9999949999999e-2) {
+    x *= 10;
+    *out++ = '0';
+  }
+  return put_digits_trimmed(banker_round(x * 1000000), 6, 1, out);
+}
+
 struct Args {
   std::string bed, bim, fam, pgen, pvar, psam, out = "plink2";
   bool have_prune = false;
@@ -172,6 +289,10 @@ struct Args {
   int r2_shape = -1;      // 0 square, 1 square0, 2 triangle
   int r2_float = -1;      // 1 bin4, 0 bin
   bool yes_really = false;
+  bool r2_table = false;   // --r2-unphased without a matrix shape: windowed .vcor table
+  uint32_t ld_var_ct_radius = 0x7fffffff;  // --ld-window N: N - 1
+  uint32_t ld_bp_radius = 0xffffffffu;     // --ld-window-kb; UINT32_MAX = not given (table default 1000 kb)
+  double ld_min_r2 = 2.0;                  // --ld-window-r2 (after the reference's epsilon); 2.0 = not given
   bool timing = false;    // --timing: print per-phase wall times
   bool dry_run = false;  // parse + plan only, print the parameters exactly (%a) and exit: used by the CPU tests
 };
@@ -313,12 +434,46 @@ Args parse_args(int argc, char** argv) {
         else if (m == "bin4") A.r2_float = 1;
         else if (m == "yes-really") A.yes_really = true;
         else if (m == "ref-based" || m == "allow-ambiguous-allele") { /* no effect on r^2 */ }
-        else die(9, "Error: --r2-unphased modifier '%s' is not supported by plink2-hip (matrix shapes with bin/bin4 only).\n", m.c_str());
+        else die(9, "Error: --r2-unphased modifier '%s' is not supported by plink2-hip (matrix shapes with bin/bin4, or the default-column table).\n", m.c_str());
       }
-      if (A.r2_shape < 0 || A.r2_float < 0) {
-        die(9, "Error: plink2-hip supports --r2-unphased {square | square0 | triangle} {bin | bin4}; tabular (.vcor) and text matrices are not implemented yet.\n");
+      if ((A.r2_shape < 0) != (A.r2_float < 0)) {
+        die(9, "Error: plink2-hip supports --r2-unphased {square | square0 | triangle} {bin | bin4} (binary matrices) or --r2-unphased without a shape (windowed .vcor table); text matrices are not implemented.\n");
       }
+      A.r2_table = (A.r2_shape < 0);
       A.have_r2 = true;
+    } else if (f == "--ld-window") {  // plink2.cc:7908-7920
+      need(i, 1, "--ld-window");
+      const std::string v = argv[++i];
+      char* endp;
+      const unsigned long n = strtoul(v.c_str(), &endp, 10);
+      if (v.empty() || *endp || n < 2 || n > 0x7ffffffeul) {
+        die(5, "Error: Invalid --ld-window argument '%s'.\n", v.c_str());
+      }
+      A.ld_var_ct_radius = static_cast<uint32_t>(n) - 1;
+    } else if (f == "--ld-window-kb") {  // plink2.cc:7921-7937
+      need(i, 1, "--ld-window-kb");
+      const std::string v = argv[++i];
+      double d;
+      const char* endp;
+      if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || d < 0) {
+        die(5, "Error: Invalid --ld-window-kb argument '%s'.\n", v.c_str());
+      }
+      d *= 1000 * (1 + kSmallEpsilon);
+      A.ld_bp_radius = (d > 2147483646) ? 2147483646u : static_cast<uint32_t>(static_cast<int32_t>(d));
+    } else if (f == "--ld-window-r2") {  // plink2.cc:7950-7964
+      need(i, 1, "--ld-window-r2");
+      const std::string v = argv[++i];
+      double d;
+      const char* endp;
+      if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || d > 1.0) {
+        die(5, "Error: Invalid --ld-window-r2 argument '%s'.\n", v.c_str());
+      }
+      if (d > 0.0) {
+        d *= 1 - kSmallEpsilon;
+      }
+      A.ld_min_r2 = d;
+    } else if (f == "--ld-window-cm" || f == "--ld-snp" || f == "--ld-snps" || f == "--ld-snp-list") {
+      die(9, "Error: %s is not supported by plink2-hip.\n", f.c_str());
     } else if (f == "--indep-order") {
       need(i, 1, "--indep-order");
       std::string v = argv[++i];
@@ -333,6 +488,23 @@ Args parse_args(int argc, char** argv) {
       A.timing = true;
     } else if (f == "--dry-run") {
       A.dry_run = true;
+    } else if (f == "--debug-format-g6") {
+      // test hook (no GPU needed): one hex bit pattern of a double per line in, the .vcor number formatting out
+      need(i, 1, "--debug-format-g6");
+      FILE* df = fopen(argv[++i], "r");
+      if (!df) {
+        die(2, "Error: Failed to open %s.\n", argv[i]);
+      }
+      char line[64], num[40];
+      while (fgets(line, sizeof(line), df)) {
+        const unsigned long long bits = strtoull(line, nullptr, 16);
+        double d;
+        memcpy(&d, &bits, sizeof(d));
+        *format_g6(d, num) = '\0';
+        puts(num);
+      }
+      fclose(df);
+      exit(0);
     } else if (f == "--gpus") {
       need(i, 1, "--gpus");
       A.gpus = atoi(argv[++i]);
@@ -348,6 +520,26 @@ Args parse_args(int argc, char** argv) {
   }
   if (A.have_prune && A.have_r2) {
     die(5, "Error: run --indep-pairwise and --r2-unphased separately.\n");
+  }
+  const bool ld_window_given = (A.ld_var_ct_radius != 0x7fffffff) || (A.ld_bp_radius != 0xffffffffu);
+  if ((ld_window_given || A.ld_min_r2 != 2.0) && !A.have_r2) {
+    die(5, "Error: --ld-window.../--ld-snp... must be used with --r[2]-[un]phased.\n");  // plink2.cc:12960
+  }
+  if (A.have_r2 && !A.r2_table) {
+    if (ld_window_given) {  // plink2.cc:11175-11179
+      die(5, "Error: All-pairs --r2-unphased settings cannot be used with --ld-window/--ld-window-kb/--ld-window-cm.\n");
+    }
+    if (A.ld_min_r2 != 2.0) {  // plink2.cc:11186-11191
+      die(5, "Error: Matrix-only and table-only --r2-unphased settings cannot be used together.\n");
+    }
+  }
+  if (A.r2_table) {  // table defaults, plink2.cc:11181-11205
+    if (A.ld_bp_radius == 0xffffffffu) {
+      A.ld_bp_radius = 1000000;
+    }
+    if (A.ld_min_r2 == 2.0) {
+      A.ld_min_r2 = 0.2 * (1 - kSmallEpsilon);
+    }
   }
   if (A.gpus < 1) {
     die(5, "Error: --gpus must be positive.\n");
@@ -856,7 +1048,7 @@ int main(int argc, char** argv) {
         first = false;
         cls = chrom_class(cur, A.allow_extra_chr, &zero);
       }
-      if (zero && A.have_prune) {
+      if (zero && (A.have_prune || A.r2_table)) {  // (the matrix shapes keep chromosome 0: they are all-pairs)
         ++skipped;
         continue;
       }
@@ -876,13 +1068,16 @@ int main(int argc, char** argv) {
     }
   }
   if (skipped) {
-    logprintf("--indep-pairwise: Ignoring %u chromosome 0 variant%s.\n", skipped, skipped == 1 ? "" : "s");
+    logprintf("--%s: Ignoring %u chromosome 0 variant%s.\n", A.have_prune ? "indep-pairwise" : "r2-unphased", skipped, skipped == 1 ? "" : "s");
   }
   const uint32_t variant_ct = static_cast<uint32_t>(inc.size());
-  if (A.window_is_bp) {
+  if (A.window_is_bp || A.r2_table) {
     for (uint32_t k = 1; k < variant_ct; ++k) {
       if (chr_idx[k] == chr_idx[k - 1] && bps[k] < bps[k - 1]) {
-        die(3, "Error: --indep-pairwise with a kb window requires a sorted .pvar/.bim.  Retry this command after using\n--make-pgen/--make-bed + --sort-vars to sort your data.\n");
+        if (A.have_prune) {  // plink2.cc:2926-2929
+          die(3, "Error: When the window size is in kb units, LD-based pruning requires a sorted\n.pvar/.bim.  Retry this command after using --make-pgen/--make-bed +\n--sort-vars to sort your data.\n");
+        }
+        die(3, "Error: --r[2]-[un]phased runs require a sorted .pvar/.bim.  Retry this command\nafter using --make-pgen/--make-bed + --sort-vars to sort your data.\n");  // plink2.cc:2944-2947
       }
     }
   }
@@ -901,7 +1096,7 @@ int main(int argc, char** argv) {
 
   if (A.have_r2) {
     // ---- --r2-unphased {square|square0|triangle} {bin|bin4}: every variant, every pair (Vcor, plink2_ld.cc:12050)
-    if (variant_ct > 400000 && !A.yes_really) {  // plink2_ld.cc:9788
+    if ((!A.r2_table) && variant_ct > 400000 && !A.yes_really) {  // plink2_ld.cc:9788
       die(7, "Error: Gigantic (over 400k variants) --r2-unphased unfiltered, non-distributed\ncomputation.  Rerun with the 'yes-really' modifier if you are SURE you have enough\nhard drive space and want to do this.\n");
     }
     ldp_params RP;
@@ -915,11 +1110,15 @@ int main(int argc, char** argv) {
       die(12, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
     }
     ldp_engine* e = nullptr;
-    if (ldp_create(&RP, &e) || ldp_set_variants_matrix(e, variant_ct)) {
+    if (ldp_create(&RP, &e)) {
       die(12, "Error: engine setup failed.\n");
     }
+    if (A.r2_table ? ldp_set_variants_vcor(e, variant_ct, chr_idx.data(), bps.data(), A.ld_bp_radius, A.ld_var_ct_radius)
+                   : ldp_set_variants_matrix(e, variant_ct)) {
+      die(12, "Error: engine setup failed: %s\n", ldp_last_error(e));
+    }
     const std::string base = A.out + ".unphased.vcor2.bin";
-    {
+    if (!A.r2_table) {
       FILE* vf = fopen((base + ".vars").c_str(), "wb");
       if (!vf) {
         die(2, "Error: Failed to open %s.vars for writing.\n", base.c_str());
@@ -929,8 +1128,8 @@ int main(int argc, char** argv) {
         fputc('\n', vf);
       }
       fclose(vf);
+      logprintf("--r2-unphased: Variant IDs written to %s.vars .\n", base.c_str());
     }
-    logprintf("--r2-unphased: Variant IDs written to %s.vars .\n", base.c_str());
     // genotype rows -> engine (same feeder as the prune path)
     {
       const bool all_founders = (founder_ct == raw_sample_ct);
@@ -944,14 +1143,19 @@ int main(int argc, char** argv) {
       const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((1024ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
       std::vector<uint8_t> decoded, gather;
       for (uint32_t k = 0; k < variant_ct;) {
-        const uint32_t run = std::min(kChunk, variant_ct - k);
+        // a run of included variants that are consecutive in the file (chromosome 0 is stripped in table mode)
+        const uint32_t raw_first = inc[k];
+        uint32_t run = 1;
+        while ((run < kChunk) && (k + run < variant_ct) && (inc[k + run] == raw_first + run)) {
+          ++run;
+        }
         const uint8_t* src;
         uint64_t stride = rec_bytes;
         if (direct_rows) {
-          src = direct_rows + static_cast<uint64_t>(k) * rec_bytes;
+          src = direct_rows + static_cast<uint64_t>(raw_first) * rec_bytes;
         } else {
           decoded.resize(static_cast<size_t>(run) * rec_bytes);
-          if (ldp_pgen_read(pg, k, run, decoded.data(), rec_bytes, 0)) {
+          if (ldp_pgen_read(pg, raw_first, run, decoded.data(), rec_bytes, 0)) {
             die(3, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
           }
           src = decoded.data();
@@ -974,6 +1178,141 @@ int main(int argc, char** argv) {
         }
         k += run;
       }
+    }
+    if (A.r2_table) {
+      // ---- windowed table (VcorTable, plink2_ld.cc:11025): one line per pair A < B inside the window whose r^2 passes
+      //      --ld-window-r2, A-major; default column set (plink2_ld.h:101)
+      std::vector<uint32_t> lo(std::max<uint32_t>(variant_ct, 1));
+      uint64_t cand = 0;
+      ldp_get_band(e, lo.data(), &cand);
+      // hi[i] = last second variant paired with i (lo is nondecreasing inside a chromosome and == j outside windows)
+      std::vector<uint32_t> hi(variant_ct);
+      {
+        uint32_t j = 0;
+        for (uint32_t i = 0; i < variant_ct; ++i) {
+          j = std::max(j, i);
+          while ((j + 1 < variant_ct) && (lo[j + 1] <= i) && (chr_idx[j + 1] == chr_idx[i])) {
+            ++j;
+          }
+          hi[i] = j;
+        }
+      }
+      // names as the reference prints them (chrtoa with the default --output-chr: bare numbers, XY/PAR1/PAR2, contig names)
+      auto chrom_out = [&](const std::string& raw) {
+        std::string name = raw;
+        if (name.size() > 3 && (name[0] | 32) == 'c' && (name[1] | 32) == 'h' && (name[2] | 32) == 'r') {
+          bool zero = false;
+          const std::string rest = name.substr(3);
+          bool numeric = !rest.empty();
+          for (char c : rest) {
+            numeric = numeric && (c >= '0' && c <= '9');
+          }
+          if (numeric || ieq(rest.c_str(), "XY") || ieq(rest.c_str(), "PAR1") || ieq(rest.c_str(), "PAR2")) {
+            name = rest;
+          }
+          (void)zero;
+        }
+        bool numeric = !name.empty();
+        for (char c : name) {
+          numeric = numeric && (c >= '0' && c <= '9');
+        }
+        if (numeric) {
+          const long v = strtol(name.c_str(), nullptr, 10);
+          return (v == 25) ? std::string("XY") : std::to_string(v);
+        }
+        if (ieq(name.c_str(), "XY")) return std::string("XY");
+        if (ieq(name.c_str(), "PAR1")) return std::string("PAR1");
+        if (ieq(name.c_str(), "PAR2")) return std::string("PAR2");
+        return name;
+      };
+      const std::string tpath = A.out + ".vcor";
+      FILE* tf = fopen(tpath.c_str(), "wb");
+      if (!tf) {
+        die(2, "Error: Failed to open %s for writing.\n", tpath.c_str());
+      }
+      fputs("#CHROM_A\tPOS_A\tID_A\tCHROM_B\tPOS_B\tID_B\tUNPHASED_R2\n", tf);
+      const double thresh = A.ld_min_r2;
+      std::vector<double> band;
+      std::vector<uint64_t> off;
+      std::string linebuf;
+      linebuf.reserve(1 << 22);
+      std::string chr_a_name;
+      uint32_t chr_a_idx = 0xffffffffu;
+      uint64_t written = 0;
+      const uint64_t kMaxPairs = 1ull << 25;  // 256 MiB of doubles per chunk
+      for (uint32_t a0 = 0; a0 < variant_ct;) {
+        // first variants [a0, a1): their partners are the second variants (a0, hi[a1-1]]
+        uint32_t a1 = a0;
+        uint64_t pairs = 0;
+        uint32_t row_end = a0 + 1;
+        while (a1 < variant_ct) {
+          const uint32_t new_end = std::max(row_end, hi[a1] + 1);
+          uint64_t add = 0;
+          for (uint32_t j = row_end; j < new_end; ++j) {
+            add += j - lo[j];
+          }
+          if ((a1 > a0) && (pairs + add > kMaxPairs)) {
+            break;
+          }
+          pairs += add;
+          row_end = new_end;
+          ++a1;
+        }
+        const uint32_t row_first = a0;
+        const uint32_t row_ct = row_end - row_first;
+        off.assign(static_cast<size_t>(row_ct) + 1, 0);
+        for (uint32_t q = 0; q < row_ct; ++q) {
+          off[q + 1] = off[q] + ((row_first + q) - lo[row_first + q]);
+        }
+        band.resize(std::max<uint64_t>(off[row_ct], 1));
+        if (off[row_ct] && ldp_r2_unphased_band_rows(e, row_first, row_ct, 0, band.data(), off[row_ct])) {
+          die(12, "Error: %s\n", ldp_last_error(e));
+        }
+        char num[40];
+        for (uint32_t i = a0; i < a1; ++i) {
+          if (chr_idx[i] != chr_a_idx) {
+            chr_a_idx = chr_idx[i];
+            chr_a_name = chrom_out(V.chrom[inc[i]]);
+          }
+          for (uint32_t j = i + 1; j <= hi[i]; ++j) {
+            const double r2 = band[off[j - row_first] + (i - lo[j])];
+            if ((thresh >= 0.0) && (!(fabs(r2) >= thresh))) {  // VcorTableWriteThread :10816-10821 (NaN never passes)
+              continue;
+            }
+            linebuf += chr_a_name;
+            linebuf += '\t';
+            linebuf += std::to_string(bps[i]);
+            linebuf += '\t';
+            linebuf += V.id[inc[i]];
+            linebuf += '\t';
+            linebuf += chr_a_name;  // same chromosome: the table never pairs across chromosomes without inter-chr
+            linebuf += '\t';
+            linebuf += std::to_string(bps[j]);
+            linebuf += '\t';
+            linebuf += V.id[inc[j]];
+            linebuf += '\t';
+            linebuf.append(num, format_g6(r2, num) - num);
+            linebuf += '\n';
+            ++written;
+          }
+          if (linebuf.size() > (1u << 21)) {
+            fwrite(linebuf.data(), 1, linebuf.size(), tf);
+            linebuf.clear();
+          }
+        }
+        a0 = a1;
+      }
+      fwrite(linebuf.data(), 1, linebuf.size(), tf);
+      if (fclose(tf)) {
+        die(2, "Error: File write failure: %s.\n", tpath.c_str());
+      }
+      logprintf("--r2-unphased: %llu variant pair%s written to %s .\n", static_cast<unsigned long long>(written), written == 1 ? "" : "s", tpath.c_str());
+      ldp_destroy(e);
+      ldp_pgen_close(pg);
+      if (g_log) {
+        fclose(g_log);
+      }
+      return 0;
     }
     const size_t esz = A.r2_float ? 4 : 8;
     FILE* mf = fopen(base.c_str(), "wb");

@@ -228,3 +228,33 @@ def test_cli_sex_chromosomes_match_reference(gpu_pkg, cli, tmp_path, fmt, wargs,
     assert not diff, "differs on %d variants, e.g. %s" % (len(diff), diff[:10])
     assert filecmp.cmp(str(tmp_path / "ref.prune.in"), str(tmp_path / "hip.prune.in"), shallow=False)
     assert filecmp.cmp(str(tmp_path / "ref.prune.out"), str(tmp_path / "hip.prune.out"), shallow=False)
+
+
+def test_vcor_number_formatting_matches_reference(cli, tmp_path):
+    """The .vcor writer's 6-significant-digit formatter against 26k (double, text) pairs recorded from the
+    reference's own table output (tests/golden/make_golden_vcor.py).  No GPU involved."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pgen", "vcor_format_g6.npz"))
+    path = tmp_path / "bits.txt"
+    with open(path, "w") as f:
+        for b in g["bits"]:
+            f.write("%016x\n" % int(b))
+    out = subprocess.run([cli, "--debug-format-g6", str(path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout
+    got = out.stdout.split("\n")[:-1]
+    want = [str(t) for t in g["texts"]]
+    assert len(got) == len(want)
+    bad = [(w, x) for w, x in zip(want, got) if w != x]
+    assert not bad, bad[:5]
+
+
+def test_vcor_flag_rules(cli, tmp_path):
+    """--ld-window* belong to --r2-unphased tables only (plink2.cc:11175-11191, :12960)."""
+    small_fileset(tmp_path)
+    r = run_cli(cli, ["--pfile", "d", "--indep-pairwise", "50", "5", "0.2", "--ld-window-kb", "10", "--dry-run"], str(tmp_path))
+    assert r.returncode != 0 and "--ld-window" in r.stdout
+    r = run_cli(cli, ["--pfile", "d", "--r2-unphased", "square", "bin", "--ld-window", "5", "--dry-run"], str(tmp_path))
+    assert r.returncode != 0 and "All-pairs" in r.stdout
+    r = run_cli(cli, ["--pfile", "d", "--r2-unphased", "triangle", "bin4", "--ld-window-r2", "0.1", "--dry-run"], str(tmp_path))
+    assert r.returncode != 0 and "Matrix-only" in r.stdout
+    r = run_cli(cli, ["--pfile", "d", "--r2-unphased", "--ld-window", "1", "--dry-run"], str(tmp_path))
+    assert r.returncode != 0 and "Invalid --ld-window argument" in r.stdout

@@ -92,3 +92,69 @@ def test_cli_matrix_files_byte_identical(gpu_pkg, tmp_path, shape, enc):
     assert got.returncode == 0, got.stdout
     assert filecmp.cmp(str(tmp_path / "ref.unphased.vcor2.bin.vars"), str(tmp_path / "hip.unphased.vcor2.bin.vars"), shallow=False)
     assert filecmp.cmp(str(tmp_path / "ref.unphased.vcor2.bin"), str(tmp_path / "hip.unphased.vcor2.bin"), shallow=False)
+
+
+@pytest.mark.parametrize("bp_radius,var_radius", [(3000, 0x7fffffff), (100000, 6), (900, 3), (0, 0x7fffffff)])
+def test_band_rows_match_oracle(gpu_pkg, bp_radius, var_radius):
+    """Windowed plan of the --r2-unphased table: the band of r^2 doubles against the oracle, window membership
+    against UpdateVcorWindow's rule (bp[B] - bp[A] <= bp_radius, B - A <= var_ct_radius, same chromosome)."""
+    pkg = gpu_pkg
+    m, n = 260, 150
+    raw = T.synth_raw_codes(m, n, seed=77, missing_rate=0.04)
+    raw[7] = 0
+    rng = np.random.default_rng(3)
+    chr_idx = np.repeat(np.arange(4), [100, 1, 80, 79]).astype(np.uint32)
+    bps = np.zeros(m, dtype=np.uint32)
+    for c in range(4):
+        sel = np.where(chr_idx == c)[0]
+        bps[sel] = np.sort(rng.integers(1, 40000, size=len(sel)))
+    want = oracle_r2_lower(raw)
+    eng = pkg.LdPruneEngine(n, 2, 1, False, 0.5, device=0)
+    eng.set_variants_vcor(chr_idx, bps, bp_radius, var_radius)
+    eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+    lo, cand = eng.band()
+    for j in range(m):
+        i = j
+        while i > 0 and chr_idx[i - 1] == chr_idx[j] and int(bps[j]) - int(bps[i - 1]) <= bp_radius and j - (i - 1) <= var_radius:
+            i -= 1
+        assert lo[j] == i, (j, lo[j], i)
+    for r0, cnt in ((0, m), (37, 101), (m - 5, 5)):
+        got = eng.r2_unphased_band_rows(r0, cnt)
+        k = 0
+        for j in range(r0, r0 + cnt):
+            for i in range(int(lo[j]), j):
+                w, g = want[j, i], got[k]
+                assert (np.isnan(w) and np.isnan(g)) or w == g, (i, j, w, g)
+                k += 1
+        assert k == len(got)
+    eng.close()
+
+
+VCOR_CASES = [
+    [],
+    ["--ld-window-kb", "5", "--ld-window-r2", "0.05"],
+    ["--ld-window", "7", "--ld-window-r2", "0"],
+    ["--ld-window-kb", "0.4", "--ld-window", "3", "--ld-window-r2", "0.5"],
+]
+
+
+@pytest.mark.parametrize("extra", VCOR_CASES)
+def test_cli_vcor_table_byte_identical(gpu_pkg, tmp_path, extra):
+    """--r2-unphased without a matrix shape: the .vcor table (default columns) against the reference's file."""
+    assert T.have_ref()
+    cli = gpu_pkg.build_cli()
+    m, n = 900, 160
+    raw = T.synth_raw_codes(m, n, seed=19, missing_rate=0.02)
+    raw[10] = 2
+    raw[11] = 3
+    chroms = ["0"] * 4 + ["1"] * 500 + ["3"] * 1 + ["7"] * 395
+    rng = np.random.default_rng(8)
+    pos = np.concatenate([np.arange(4) + 1, np.sort(rng.integers(1, 60000, 500)), [5], np.sort(rng.integers(1, 2000000, 395))])
+    T.write_pgen_fixed(str(tmp_path / "d"), raw, chroms, pos)
+    ref = T.run_ref(["--pfile", "d", "--r2-unphased"] + extra + ["--out", "ref"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    got = subprocess.run([cli, "--pfile", "d", "--r2-unphased"] + extra + ["--out", "hip"], cwd=str(tmp_path), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert got.returncode == 0, got.stdout
+    assert os.path.getsize(str(tmp_path / "ref.vcor")) > 100
+    assert filecmp.cmp(str(tmp_path / "ref.vcor"), str(tmp_path / "hip.vcor"), shallow=False)
