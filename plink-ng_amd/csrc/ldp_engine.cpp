@@ -1286,14 +1286,16 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     tl[3] = now_ms();
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     tl[4] = now_ms();
-    for (const ldp_engine::PairGroup& g : e->groups) {
+    for (ldp_engine::PairGroup& g : e->groups) {
       float f = 0.f, gen = 0.f;
       HIP_TRY(e, hipEventElapsedTime(&f, g.ev[0], g.ev[1]));
       HIP_TRY(e, hipEventElapsedTime(&gen, g.ev[2], g.ev[3]));
       kms_fast += f;
       kms_general += gen;
       ++launches;
+      g.launched = false;  // a run consumes its launches: the next one recomputes (or picks up eager launches of new loads)
     }
+    e->next_group = 0;
   }
   for (int q = 0; q < 4; ++q) {
     h_counters[q] = e->h_counters_pin[q];  // (the stream that carried the copy has been synchronised in both branches)

@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--window-kb", type=float, default=200.0)
     ap.add_argument("--r2", type=float, default=0.5)
     ap.add_argument("--no-ref", action="store_true")
+    ap.add_argument("--vcor", action="store_true", help="time the --r2-unphased table (--ld-window-kb = --window-kb, --ld-window-r2 = --r2) instead")
     args = ap.parse_args()
     import torch
     import __graft_entry__ as ge
@@ -43,20 +44,24 @@ def main():
     del buf
     torch.cuda.empty_cache()
     common = ["--bfile", "s", "--indep-pairwise", "%gkb" % args.window_kb, repr(args.r2)]
+    outs = (".prune.in", ".prune.out")
+    if args.vcor:
+        common = ["--bfile", "s", "--r2-unphased", "--ld-window-kb", "%g" % args.window_kb, "--ld-window-r2", repr(args.r2)]
+        outs = (".vcor",)
     for rep in range(2):
         t0 = time.perf_counter()
         cp = subprocess.run([os.path.join(REPO, "plink-ng_amd", "bin", "plink2-hip")] + common + ["--timing", "--out", "hip"], cwd=tmp,
                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         t_hip = time.perf_counter() - t0
         print("plink2-hip rc", cp.returncode, "wall %.3f s" % t_hip)
-        print("\n".join(ln for ln in cp.stdout.splitlines() if "timing" in ln or "removed" in ln))
+        print("\n".join(ln for ln in cp.stdout.splitlines() if "timing" in ln or "removed" in ln or "written" in ln or "Error" in ln))
     if not args.no_ref:
         t0 = time.perf_counter()
         cp = subprocess.run([os.path.join(REPO, "oracle", "_ref", "plink2")] + common + ["--threads", str(os.cpu_count()), "--out", "ref"], cwd=tmp,
                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         t_ref = time.perf_counter() - t0
         print("reference rc", cp.returncode, "wall %.3f s" % t_ref, "speedup %.1fx" % (t_ref / t_hip))
-        same = all(open(os.path.join(tmp, "hip" + e)).read() == open(os.path.join(tmp, "ref" + e)).read() for e in (".prune.in", ".prune.out"))
+        same = all(open(os.path.join(tmp, "hip" + e)).read() == open(os.path.join(tmp, "ref" + e)).read() for e in outs)
         print("files identical:", same)
     subprocess.call(["rm", "-rf", tmp])
 
