@@ -194,8 +194,9 @@ def main():
             for c0 in range(0, ln, chunk_rows):
                 cnt = min(chunk_rows, ln - c0)
                 pkg.synth_genotypes_device(SEED, first + c0, cnt, founder_ct, args.missing_rate, geno.data_ptr(), stride)
+                torch.cuda.synchronize()  # the generator runs on the null stream, the engine on its own: order them
                 eng.load_genotypes_device(first + c0, cnt, geno.data_ptr(), stride, pkg.LDP_GENO_REF)
-                torch.cuda.synchronize()
+                torch.cuda.synchronize()  # ... and the chunk buffer is reused
         del geno
         torch.cuda.empty_cache()
     else:
