@@ -22,7 +22,8 @@ constexpr int kLdsRowDwords = kRowChunkDwords + 4; // 36: odd number (9) of 16-B
 // ---- pair-tile geometry -------------------------------------------------------------------------
 // A block owns kTileJ consecutive "second" variants j and a run of distances d = j - i, split in
 // units of 8 among its 4 waves.  Lane (tx = lane&7, ty = lane>>3) of a wave owns j = j0 + tx + 8b
-// (b < 4) and d = dw0 + ty + 8a (a < NA <= 4).
+// (b < 4) and d = dw0 + ty + 8a (a < NA <= kMaxUnitsPerWave).  Three units per wave is what keeps the complete-data
+// kernel at 128 VGPRs (4 waves/SIMD) with nothing spilled inside the k-loop, see plan_stager in ldp_kernels.hip.
 constexpr int kTileJ = 32;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlockThreads = 64 * kWavesPerBlock;
@@ -30,7 +31,7 @@ constexpr int kBlockThreads = 64 * kWavesPerBlock;
 #define LDP_MAX_UNITS_PER_WAVE 3
 #endif
 constexpr int kMaxUnitsPerWave = LDP_MAX_UNITS_PER_WAVE;  // NA: 8-distance units a wave accumulates at once
-constexpr int kMaxUnitsPerBlock = kWavesPerBlock * kMaxUnitsPerWave;  // 16 -> 128 distances
+constexpr int kMaxUnitsPerBlock = kWavesPerBlock * kMaxUnitsPerWave;  // 12 -> 96 distances; wider windows take several blocks per J-tile
 
 struct WorkItem {
   uint32_t j0;        // first second-variant index
@@ -41,8 +42,8 @@ struct WorkItem {
   uint32_t send;
 };
 
-// ---- early termination of hopeless tiles (complete-data path) --------------------------------------------
-// Early termination of hopeless tiles (complete-data kernel).  At up to kCheckpoints k-chunk boundaries a wave
+// ---- early termination of hopeless tiles (complete-data kernel) ----------------------------------------------
+// At up to kCheckpoints k-chunk boundaries a wave
 // bounds, for each of its pairs, how large |N*dot - S_i*S_j| can still become.  With R = the samples not yet
 // visited, s = sum over R, q = sum of squares over R, n = |R|:
 //     dot_R = sum_R (x-s_i/n)(y-s_j/n) + s_i*s_j/n,   |first term| <= sqrt(q_i - s_i^2/n) * sqrt(q_j - s_j^2/n)
@@ -50,9 +51,10 @@ struct WorkItem {
 // this needs, pre-scaled so the pair test is a handful of FP64 ops (cp_stats, kCpSlots x 16 bytes per variant):
 //     slot k < kCheckpoints: { s_R * sqrt(N / n_R),  sqrt(N * (q_R - s_R^2 / n_R)) }
 //     slot kCheckpoints    : { S (whole-row sum),    sqrt(N*Q - S^2) * sqrt(sqrt(thresh) * (1 - 1e-6)) }
-// When every pair of the wave provably stays below the r^2 threshold the wave stops accumulating and emits
-// nothing; a block whose four waves have all stopped leaves the k-loop.  Results are unchanged: only pairs whose
-// predicate is provably false are skipped.
+// A distance unit whose pairs all provably stay below the r^2 threshold is dropped (far end of a wave's range
+// first); when only a block's nearest units are left they are re-dealt over the four waves (column mode) and the
+// tile is re-planned to the rows still needed; a block with nothing left leaves the k-loop.  Results are unchanged:
+// only pairs whose predicate is provably false are skipped.
 constexpr int kCheckpoints = 5;
 constexpr int kCpSlots = kCheckpoints + 1;
 struct cp_slot {
