@@ -124,13 +124,22 @@ __device__ __forceinline__ void convert_plane_pair(const uint8_t* row, uint32_t 
   typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
   (void)aligned16;
   if (aligned4 && (8u * p + 16u <= nbytes)) {
-    const u32x4_a4 w = *reinterpret_cast<const u32x4_a4*>(row + 8u * p);
+    // streamed once: non-temporal, so the rows do not displace what the pair kernel keeps in L2
+    const u32x4_a4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4*>(row + 8u * p));
     planes_from_words(w.x, w.y, encoding, founder_ct, p, &hom[0], &r2h[0]);
     planes_from_words(w.z, w.w, encoding, founder_ct, p + 1, &hom[1], &r2h[1]);
   } else {
     convert_plane_dword(row, nbytes, aligned4, encoding, founder_ct, p, &hom[0], &r2h[0]);
     convert_plane_dword(row, nbytes, aligned4, encoding, founder_ct, p + 1, &hom[1], &r2h[1]);
   }
+}
+
+__device__ __forceinline__ void store_plane_pair(uint32_t* dst, uint2 v) {
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 t;
+  t.x = v.x;
+  t.y = v.y;
+  __builtin_nontemporal_store(t, reinterpret_cast<u32x2*>(dst));
 }
 
 // One block per variant.  Pass 1 converts the row to bit-planes held in registers (MAXIT pairs of plane dwords
@@ -310,8 +319,8 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
         const uint2 hv = make_uint2(keep_hom[it][0], keep_hom[it][1]);
         // 0 <-> 2 flips ref2het on homozygous calls
         const uint2 rv = alt_major ? make_uint2(keep_r2h[it][0] ^ hv.x, keep_r2h[it][1] ^ hv.y) : make_uint2(keep_r2h[it][0], keep_r2h[it][1]);
-        *reinterpret_cast<uint2*>(out_row + off) = hv;
-        *reinterpret_cast<uint2*>(out_row + off + kChunkDwords) = rv;
+        store_plane_pair(out_row + off, hv);
+        store_plane_pair(out_row + off + kChunkDwords, rv);
       }
     }
   } else {
@@ -323,8 +332,8 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
         r2h[1] ^= hom[1];
       }
       const uint32_t off = (p / kChunkDwords) * kRowChunkDwords + (p % kChunkDwords);
-      *reinterpret_cast<uint2*>(out_row + off) = make_uint2(hom[0], hom[1]);
-      *reinterpret_cast<uint2*>(out_row + off + kChunkDwords) = make_uint2(r2h[0], r2h[1]);
+      store_plane_pair(out_row + off, make_uint2(hom[0], hom[1]));
+      store_plane_pair(out_row + off + kChunkDwords, make_uint2(r2h[0], r2h[1]));
     }
   }
 }

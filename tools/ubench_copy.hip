@@ -41,6 +41,66 @@ __global__ __launch_bounds__(256) void copy_kernel(const uint4* __restrict__ in,
   }
 }
 
+// mode 5: four 16-B loads in flight per thread, then four 16-B stores;  mode 6: same with non-temporal stores;
+// mode 7: non-temporal loads and stores
+template <int MODE>
+__global__ __launch_bounds__(256) void copy4_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n16, uint32_t* sink) {
+  (void)sink;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (MODE == 7) {
+        v[k].x = __builtin_nontemporal_load(&in[i + k * stride].x);
+        v[k].y = __builtin_nontemporal_load(&in[i + k * stride].y);
+        v[k].z = __builtin_nontemporal_load(&in[i + k * stride].z);
+        v[k].w = __builtin_nontemporal_load(&in[i + k * stride].w);
+      } else {
+        v[k] = in[i + k * stride];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (MODE == 5) {
+        out[i + k * stride] = v[k];
+      } else {
+        __builtin_nontemporal_store(v[k].x, &out[i + k * stride].x);
+        __builtin_nontemporal_store(v[k].y, &out[i + k * stride].y);
+        __builtin_nontemporal_store(v[k].z, &out[i + k * stride].z);
+        __builtin_nontemporal_store(v[k].w, &out[i + k * stride].w);
+      }
+    }
+  }
+  for (; i < n16; i += stride) {
+    out[i] = in[i];
+  }
+}
+
+template <int MODE>
+int run4(const char* name, const uint4* in, uint4* out, size_t n16, uint32_t* sink, double bytes_moved) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int blocks_per_cu : {2, 4, 8, 16, 64}) {
+    const int grid = 256 * blocks_per_cu;
+    hipLaunchKernelGGL(copy4_kernel<MODE>, dim3(grid), dim3(256), 0, 0, in, out, n16, sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    const int reps = 5;
+    for (int r = 0; r < reps; ++r) {
+      hipLaunchKernelGGL(copy4_kernel<MODE>, dim3(grid), dim3(256), 0, 0, in, out, n16, sink);
+    }
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-44s grid %5d: %7.3f ms/launch  %6.2f TB/s\n", name, grid, ms / reps, bytes_moved / (ms / reps * 1e-3) / 1e12);
+  }
+  return 0;
+}
+
 template <int MODE>
 int run(const char* name, const uint4* in, uint4* out, size_t n16, uint32_t* sink, double bytes_moved) {
   hipEvent_t e0, e1;
@@ -77,6 +137,9 @@ int main() {
   run<0>("copy 16B/16B contiguous", in, out, n16, sink, 2.0 * bytes);
   run<1>("copy 16B loads, 8B stores to line halves", in, out, n16, sink, 2.0 * bytes);
   run<4>("copy 16B loads, 16B stores permuted in line", in, out, n16, sink, 2.0 * bytes);
+  run4<5>("copy 4x16B in flight per thread", in, out, n16, sink, 2.0 * bytes);
+  run4<6>("copy 4x16B in flight, nontemporal stores", in, out, n16, sink, 2.0 * bytes);
+  run4<7>("copy 4x16B in flight, nontemporal ld+st", in, out, n16, sink, 2.0 * bytes);
   run<2>("read only", in, out, n16, sink, 1.0 * bytes);
   run<3>("write only", in, out, n16, sink, 1.0 * bytes);
   return 0;
