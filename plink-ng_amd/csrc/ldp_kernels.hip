@@ -354,12 +354,12 @@ hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream) {
     LDP_PREP(128, 6);
   } else if (pairs <= 128 * 8) {
     LDP_PREP(128, 8);
-  } else if (pairs <= 256 * 8) {
-    LDP_PREP(256, 8);
-  } else if (pairs <= 512 * 8) {
-    LDP_PREP(512, 8);
-  } else if (pairs <= 1024 * 8) {
-    LDP_PREP(1024, 8);
+  } else if (pairs <= 128 * 16) {  // longer rows: 16 iterations (N = 500,000: 512 x 16 runs at 5.75 ms, 1024 x 8 at 6.6)
+    LDP_PREP(128, 16);
+  } else if (pairs <= 256 * 16) {
+    LDP_PREP(256, 16);
+  } else if (pairs <= 512 * 16) {
+    LDP_PREP(512, 16);
   } else if (pairs <= 1024 * 16) {
     LDP_PREP(1024, 16);
   } else {
