@@ -60,6 +60,15 @@ constexpr int kCpSlots = kCheckpoints + 1;
 struct cp_slot {
   double a, b;
 };
+// Tiles with missing calls: the pair statistics run over the pairwise-complete samples, which no per-variant number
+// pins down, so the bound works on intervals.  Per variant and checkpoint, over the not-yet-visited samples R where
+// the variant itself is called, in z = 1 - x (0 = homozygous major, 1 = het, 2 = homozygous minor):
+struct cp_gen_slot {
+  uint32_t nm_r;  // calls
+  uint32_t zs_r;  // sum z
+  uint32_t zq_r;  // sum z^2
+  uint32_t pad;
+};
 
 struct PairKernelArgs {
   const uint32_t* planes;        // [variant][chunk][2][kChunkDwords]
@@ -81,6 +90,7 @@ struct PairKernelArgs {
   // --r2-unphased matrix mode: when r2_out != nullptr the epilogue stores r^2 of pair (i<j) at
   // r2_out[(j - r2_row_first) * r2_ld + i] (float or double) instead of predicate bits
   const cp_slot* cp_stats;       // [variant][kCpSlots]; nullptr disables early termination
+  const cp_gen_slot* cp_gen;     // [variant][kCheckpoints]: the same for tiles with missing calls
   uint32_t checkpoint_chunk[kCheckpoints];  // ascending; a checkpoint fires after chunk (value - 1) is consumed
   uint32_t n_checkpoints;
   uint32_t lds_dwords;           // dynamic LDS of the launch (set by launch_pair_tiles)
@@ -103,6 +113,7 @@ struct PrepareArgs {
   uint32_t chunks;
   ldp_variant_rec* recs;         // entry 0 = variant `first`
   cp_slot* cp_stats;             // entry 0 = variant `first`, kCpSlots each; may be nullptr
+  cp_gen_slot* cp_gen;           // entry 0 = variant `first`, kCheckpoints each (written iff cp_stats is)
   double cp_tv_scale;            // sqrt(sqrt(thresh) * (1 - 1e-6))
   uint32_t checkpoint_chunk[kCheckpoints];
   uint32_t n_checkpoints;

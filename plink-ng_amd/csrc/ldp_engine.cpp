@@ -145,6 +145,7 @@ struct ldp_engine {
   uint8_t* d_item_general = nullptr;
   unsigned long long* d_counters = nullptr;
   cp_slot* d_cp_stats = nullptr;           // per-variant checkpoint statistics (early termination)
+  cp_gen_slot* d_cp_gen = nullptr;         // ... for tiles with missing calls
   uint32_t checkpoint_chunk[kCheckpoints];
   uint32_t n_checkpoints = 0;
   uint32_t* h_pred = nullptr;  // pinned
@@ -235,6 +236,7 @@ void free_device(ldp_engine* e) {
   (void)hipFree(e->d_item_general);
   (void)hipFree(e->d_counters);
   (void)hipFree(e->d_cp_stats);
+  (void)hipFree(e->d_cp_gen);
   if (e->h_pred) {
     (void)hipHostFree(e->h_pred);
   }
@@ -297,6 +299,7 @@ void free_device(ldp_engine* e) {
   e->d_item_general = nullptr;
   e->d_counters = nullptr;
   e->d_cp_stats = nullptr;
+  e->d_cp_gen = nullptr;
   e->h_pred = nullptr;
   e->plan_uploaded = false;
 }
@@ -670,6 +673,7 @@ int ensure_device_plan(ldp_engine* e) {
   HIP_TRY(e, hipMalloc(&e->d_counters, 4 * sizeof(unsigned long long)));
   HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
   HIP_TRY(e, hipMalloc(&e->d_cp_stats, n * kCpSlots * sizeof(cp_slot)));
+  HIP_TRY(e, hipMalloc(&e->d_cp_gen, n * kCheckpoints * sizeof(cp_gen_slot)));
   // checkpoints for early termination
   e->n_checkpoints = 0;
   for (int k = 0; k < kCheckpoints; ++k) {
@@ -1062,6 +1066,7 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.item_general = e->d_item_general;
   // early termination is off when the caller wants every pair's integers (parity runs) or LDP_EARLY_EXIT=0
   A.cp_stats = (with_early_exit && early_exit_requested() && e->n_checkpoints) ? e->d_cp_stats : nullptr;
+  A.cp_gen = A.cp_stats ? e->d_cp_gen : nullptr;
   for (int k = 0; k < kCheckpoints; ++k) {
     A.checkpoint_chunk[k] = e->checkpoint_chunk[k];
   }
@@ -1768,6 +1773,7 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
   A.counters = e->d_counters;
   A.item_general = d_general;
   A.cp_stats = nullptr;  // every r^2 is wanted: no early termination
+  A.cp_gen = nullptr;
   for (int k = 0; k < kCheckpoints; ++k) {
     A.checkpoint_chunk[k] = 0xffffffffu;
   }
@@ -1998,6 +2004,7 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
       PA.chunks = e->chunks;
       PA.recs = e->d_recs + l0;
       PA.cp_stats = e->d_cp_stats + static_cast<uint64_t>(l0) * kCpSlots;
+      PA.cp_gen = e->d_cp_gen + static_cast<uint64_t>(l0) * kCheckpoints;
       PA.cp_tv_scale = sqrt(sqrt(e->P.prune_last_param * (1 + kSmallEpsilon)) * (1.0 - 1e-6));
       for (int k = 0; k < kCheckpoints; ++k) {
         PA.checkpoint_chunk[k] = e->checkpoint_chunk[k];

@@ -292,6 +292,21 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
         both_r += red[w][3 + kCheckpoints + tid];
       }
       const uint32_t plus_r = alt_major ? (hom_r - both_r) : both_r;
+      {
+        // the interval bound's numbers (ldp_device.h): calls, sum z, sum z^2 over the remainder, z = 1 - x.
+        // Het calls = remainder size - hom calls: right for a complete row; cp_gen_fix_kernel redoes the rows
+        // with missing calls (keeping their het suffix counts here costs registers, hence occupancy, for every row).
+        const uint64_t seen_k = static_cast<uint64_t>(A.checkpoint_chunk[tid]) * (kChunkDwords * 32);
+        const uint32_t rs_k = (seen_k < A.founder_ct) ? static_cast<uint32_t>(A.founder_ct - seen_k) : 0;
+        const uint32_t het_r = (rs_k >= hom_r) ? (rs_k - hom_r) : 0;
+        const uint32_t minus_r = hom_r - plus_r;
+        cp_gen_slot gs;
+        gs.nm_r = hom_r + het_r;
+        gs.zs_r = het_r + 2 * minus_r;
+        gs.zq_r = het_r + 4 * minus_r;
+        gs.pad = 0;
+        A.cp_gen[static_cast<uint64_t>(v) * kCheckpoints + tid] = gs;
+      }
       const double s_r = static_cast<double>(static_cast<int32_t>(2 * plus_r - hom_r));
       const uint64_t seen = static_cast<uint64_t>(A.checkpoint_chunk[tid]) * (kChunkDwords * 32);
       const double n_r = (seen < A.founder_ct) ? static_cast<double>(A.founder_ct - seen) : 1.0;
@@ -338,6 +353,64 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
   }
 }
 
+// One wave per variant with missing calls: het calls of the remainders from the written planes (het = ref2het and
+// not hom, which the 0 <-> 2 inversion leaves alone), then the row's cp_gen slots again.  Complete rows leave at once.
+__global__ __launch_bounds__(256) void cp_gen_fix_kernel(PrepareArgs A) {
+  const uint32_t v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  if (v >= A.n_variants) {
+    return;
+  }
+  const ldp_variant_rec rec = A.recs[v];
+  if (!(rec.flags & 4u)) {
+    return;
+  }
+  const uint32_t* row = A.planes + static_cast<uint64_t>(v) * A.row_dwords;
+  uint32_t het[kCheckpoints], hom[kCheckpoints], minus[kCheckpoints];
+#pragma unroll
+  for (int k = 0; k < kCheckpoints; ++k) {
+    het[k] = 0;
+    hom[k] = 0;
+    minus[k] = 0;
+  }
+  // four k-chunks per step: lane -> (chunk step + lane / 16, plane dword lane % 16)
+  for (uint32_t c0 = 0; c0 < A.chunks; c0 += 64 / kChunkDwords) {
+    const uint32_t chunk = c0 + lane / kChunkDwords;
+    uint32_t h = 0, r = 0;
+    if (chunk < A.chunks) {
+      h = row[static_cast<uint64_t>(chunk) * kRowChunkDwords + (lane % kChunkDwords)];
+      r = row[static_cast<uint64_t>(chunk) * kRowChunkDwords + kChunkDwords + (lane % kChunkDwords)];
+    }
+    const uint32_t hc = __popc(h), tc = __popc(r & ~h), mc = __popc(h & ~r);  // hom, het, homozygous minor (x = -1)
+#pragma unroll
+    for (int k = 0; k < kCheckpoints; ++k) {
+      const bool in = (chunk >= A.checkpoint_chunk[k]);
+      hom[k] += in ? hc : 0;
+      het[k] += in ? tc : 0;
+      minus[k] += in ? mc : 0;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kCheckpoints; ++k) {
+    hom[k] = wave_reduce_add(hom[k]);
+    het[k] = wave_reduce_add(het[k]);
+    minus[k] = wave_reduce_add(minus[k]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < kCheckpoints; ++k) {
+      if (static_cast<uint32_t>(k) < A.n_checkpoints) {
+        cp_gen_slot gs;
+        gs.nm_r = hom[k] + het[k];
+        gs.zs_r = het[k] + 2 * minus[k];
+        gs.zq_r = het[k] + 4 * minus[k];
+        gs.pad = 0;
+        A.cp_gen[static_cast<uint64_t>(v) * kCheckpoints + k] = gs;
+      }
+    }
+  }
+}
+
 hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream) {
   if (!a.n_variants) {
     return hipSuccess;
@@ -366,6 +439,9 @@ hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream) {
     LDP_PREP(1024, 0);
   }
 #undef LDP_PREP
+  if (a.cp_stats && a.n_checkpoints) {
+    hipLaunchKernelGGL(cp_gen_fix_kernel, dim3((a.n_variants + 3) / 4), dim3(256), 0, stream, a);
+  }
   return hipGetLastError();
 }
 
@@ -796,6 +872,93 @@ __device__ __forceinline__ uint32_t wave_live_units(const PairKernelArgs& A, uin
   return live;
 }
 
+// The same question for tiles with missing calls (general path, 7 partial counts per pair).  The final statistics
+// run over the pairwise-complete samples C = C_P + C_R; everything over the visited part C_P is known exactly, and
+// C_R is what is left of each variant's own called samples in the remainder R after dropping the (unknown) ones
+// where the partner is missing -- at most min(partner's missing calls in R, own calls in R) of them.  In z = 1 - x
+// (all quantities >= 0; r^2 is invariant under the recoding):
+//   n   in [n_P + max(nR_i - dmax_i, nR_j - dmax_j), n_P + min(nR_i, nR_j)]
+//   Zs  in [Zs_P + a_i - min(2 dmax_i, a_i), Zs_P + a_i]       Zq >= Zq_P + b_i - min(4 dmax_i, b_i)     (same for w)
+//   ZW  in ZW_P + a_i a_j / |R| +- sqrt((b_i - a_i^2/|R|)(b_j - a_j^2/|R|))   (Cauchy-Schwarz on R, missing = 0), ZW >= ZW_P
+// and interval arithmetic gives |n ZW - Zs Ws| <= cmax, n Zq - Zs^2 >= var_lo.  The pair is hopeless when
+// (cmax + 1)^2 (1 + 1e-6) < thresh var1_lo var2_lo (1 - 1e-6).  Worst case (a rare variant whose remaining carriers
+// could all coincide with the partner's missing calls) the variance bound falls back to what the visited samples
+// alone guarantee, so such pairs terminate later, never wrongly.
+template <int NA>
+__device__ __forceinline__ uint32_t general_live_units(const PairKernelArgs& A, uint32_t j0, uint32_t jend, uint32_t d_first, int tx, int ty,
+                                                       const uint32_t (&acc)[2][4][7], uint32_t cp) {
+  bool hopeless[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    hopeless[a] = true;
+  }
+  const uint64_t seen = static_cast<uint64_t>(A.checkpoint_chunk[cp]) * (kChunkDwords * 32);
+  const double rs = static_cast<double>(A.founder_ct - static_cast<uint32_t>(seen));  // |R| (checkpoints lie inside the row)
+  const double thr = A.thresh * (1.0 - 1e-6);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    uint32_t j = j0 + tx + 8 * b;
+    asm volatile("" : "+v"(j));  // (keeps the address arithmetic inside the checkpoint)
+    if (j < jend) {
+      const uint32_t span_j = j - A.lo[j];
+      const cp_gen_slot gj = A.cp_gen[static_cast<uint64_t>(j) * kCheckpoints + cp];
+      cp_gen_slot gi[NA];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        const uint32_t d = d_first + ty + 8 * a;
+        const uint32_t i = (d <= j) ? (j - d) : 0;
+        gi[a] = A.cp_gen[static_cast<uint64_t>(i) * kCheckpoints + cp];
+      }
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        const uint32_t d = d_first + ty + 8 * a;
+        if (d <= span_j) {
+          const uint32_t* c = acc[a][b];
+          // visited part, exact
+          const double n_p = c[2];
+          const double s1 = 2.0 * c[6] - static_cast<double>(c[5]), q1 = c[5];
+          const double s2 = 2.0 * c[4] - static_cast<double>(c[3]), q2 = c[3];
+          const double dot = static_cast<double>(c[0]) - 2.0 * c[1];
+          const double zs_p = n_p - s1, zq_p = n_p - 2.0 * s1 + q1;
+          const double ws_p = n_p - s2, wq_p = n_p - 2.0 * s2 + q2;
+          const double zw_p = n_p - s1 - s2 + dot;
+          // remainder
+          const double nr_i = gi[a].nm_r, a_i = gi[a].zs_r, b_i = gi[a].zq_r;
+          const double nr_j = gj.nm_r, a_j = gj.zs_r, b_j = gj.zq_r;
+          const double dmax_i = fmin(rs - nr_j, nr_i);
+          const double dmax_j = fmin(rs - nr_i, nr_j);
+          const double n_lo = n_p + fmax(nr_i - dmax_i, nr_j - dmax_j);
+          const double n_hi = n_p + fmin(nr_i, nr_j);
+          const double zs_hi = zs_p + a_i, zs_lo = zs_hi - fmin(2.0 * dmax_i, a_i);
+          const double ws_hi = ws_p + a_j, ws_lo = ws_hi - fmin(2.0 * dmax_j, a_j);
+          const double zq_lo = zq_p + b_i - fmin(4.0 * dmax_i, b_i);
+          const double wq_lo = wq_p + b_j - fmin(4.0 * dmax_j, b_j);
+          const double centre = a_i * a_j / rs;
+          const double spread = sqrt(fmax(b_i - a_i * a_i / rs, 0.0) * fmax(b_j - a_j * a_j / rs, 0.0)) * (1.0 + 1e-9);
+          const double zw_hi = zw_p + centre + spread;
+          const double zw_lo = fmax(zw_p, zw_p + centre - spread);
+          const double cov_hi = n_hi * zw_hi - zs_lo * ws_lo;
+          const double cov_lo = n_lo * zw_lo - zs_hi * ws_hi;
+          const double cmax = fmax(fabs(cov_hi), fabs(cov_lo)) + 1.0;
+          const double var1_lo = n_lo * zq_lo - zs_hi * zs_hi;
+          const double var2_lo = n_lo * wq_lo - ws_hi * ws_hi;
+          const bool h = (var1_lo > 0.0) && (var2_lo > 0.0) && (cmax * cmax * (1.0 + 1e-6) < thr * var1_lo * var2_lo);
+          hopeless[a] = hopeless[a] && h;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  uint32_t live = 0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    if (!__all(hopeless[a])) {
+      live = a + 1;
+    }
+  }
+  return live;
+}
+
 // One wave per work item: does any LDS row of the tile carry missing calls?  Decides which of the two
 // pair_tiles_kernel instantiations owns the item (the other one exits at once).
 __global__ __launch_bounds__(256) void classify_items_kernel(PairKernelArgs A) {
@@ -812,12 +975,19 @@ __global__ __launch_bounds__(256) void classify_items_kernel(PairKernelArgs A) {
   }
   const TileGeom G = make_geom(it, units_total);
   int miss = 0;
+  uint32_t missing_calls = 0;
   for (int r = lane; r < G.rtot; r += 64) {
-    miss |= (A.recs[row_variant(G, r)].flags & 4u) ? 1 : 0;
+    const ldp_variant_rec rec = A.recs[row_variant(G, r)];
+    miss |= (rec.flags & 4u) ? 1 : 0;
+    missing_calls += A.founder_ct - rec.nm_ct;
   }
   const unsigned long long any = __ballot(miss);
+  missing_calls = wave_reduce_add(missing_calls);
   if (lane == 0) {
-    A.item_general[item_idx] = any ? 1 : 0;
+    // 0: complete data.  1: missing calls, sparse enough (< 1 % of the tile's genotypes) for the interval bound of
+    // general_live_units to pay; 2: missing calls, checkpoints off (measured: no tile terminates at 5 %).
+    const bool sparse = (static_cast<uint64_t>(missing_calls) * 100 < static_cast<uint64_t>(G.rtot) * A.founder_ct);
+    A.item_general[item_idx] = any ? (sparse ? 1 : 2) : 0;
   }
 }
 
@@ -845,9 +1015,9 @@ __device__ __forceinline__ void run_chunks(Ring& R, const Stager& st, uint32_t* 
 }
 
 template <int NA>
-__device__ __forceinline__ void run_chunks_general(Ring& R, const Stager& st, uint32_t* lds, uint32_t chunks, uint32_t wave, uint32_t lane,
+__device__ __forceinline__ void run_chunks_general(Ring& R, const Stager& st, uint32_t* lds, uint32_t kc_end, uint32_t chunks, uint32_t wave, uint32_t lane,
                                                    int jrow, int irow, uint32_t (&acc)[2][4][7]) {
-  while (R.kc < chunks) {
+  while (R.kc < kc_end) {
     const uint4* l4 = ring_acquire(R, st, lds, chunks, wave, lane);
     if constexpr (NA > 0) {
       tile_chunk_general<NA>(l4, jrow, irow, acc);
@@ -1117,13 +1287,45 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_ker
       }
       const uint32_t na = (units_w > a0) ? ((units_w - a0 >= 2) ? 2 : 1) : 0;
       const int irow = irow0 - 8 * static_cast<int>(a0);
+      // early termination as in the complete-data path, without the re-dealing: a wave drops the far unit of the
+      // pass, or both, and the pass ends when no wave has anything left
+      uint32_t live_g = na;
+      uint32_t next_cp = 0;
+      const uint32_t n_cp = (A.cp_gen && (A.item_general[item_idx] == 1)) ? A.n_checkpoints : 0;
       ring_start(R, st, lds, 0, A.chunks, wave, lane);
-      if (na == 2) {
-        run_chunks_general<2>(R, st, lds, A.chunks, wave, lane, jrow, irow, acc);
-      } else if (na == 1) {
-        run_chunks_general<1>(R, st, lds, A.chunks, wave, lane, jrow, irow, acc);
-      } else {
-        run_chunks_general<0>(R, st, lds, A.chunks, wave, lane, jrow, irow, acc);
+      while (R.kc < A.chunks) {
+        const bool cp_ahead = (next_cp < n_cp);  // block-uniform
+        const uint32_t kc_end = cp_ahead ? A.checkpoint_chunk[next_cp] : A.chunks;
+        if (live_g == 2) {
+          run_chunks_general<2>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow, acc);
+        } else if (live_g == 1) {
+          run_chunks_general<1>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow, acc);
+        } else {
+          run_chunks_general<0>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow, acc);
+        }
+        if (cp_ahead) {
+          if (live_g) {
+            const uint32_t d_first = dw0 + 8 * a0;
+            uint32_t keep = (live_g == 2) ? general_live_units<2>(A, it.j0, it.jend, d_first, tx, ty, acc, next_cp)
+                                          : general_live_units<1>(A, it.j0, it.jend, d_first, tx, ty, acc, next_cp);
+            if (keep != live_g) {
+              if (lane == 0) {
+                atomicAdd(A.counters + 1, static_cast<unsigned long long>(A.chunks - R.kc) * (live_g - keep) * 4);
+              }
+              live_g = __builtin_amdgcn_readfirstlane(keep);
+            }
+          }
+          ++next_cp;
+          if (lane == 0) {
+            s_live[wave] = live_g;
+          }
+          __syncthreads();
+          const uint32_t any_live = s_live[0] | s_live[1] | s_live[2] | s_live[3];
+          __syncthreads();  // (s_live is rewritten at the next checkpoint or pass)
+          if (!any_live) {
+            break;
+          }
+        }
       }
       __syncthreads();  // staging of this pass is over: LDS becomes the epilogue's scratch
 #pragma unroll
@@ -1136,7 +1338,7 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_ker
             lds[(b * 7 + q) * kBlockThreads + tid] = acc[a][b][q];
           }
         }
-        if (a < static_cast<int>(na)) {
+        if (a < static_cast<int>(live_g)) {  // (pairs of dropped units are all below the threshold)
 #pragma unroll 1
           for (uint32_t b = 0; b < 4; ++b) {
             const uint32_t j = it.j0 + tx + 8 * b;

@@ -279,12 +279,15 @@ def _run_early_exit(pkg, packed, n, chr_idx, bps, window, step, is_bp, r2, order
     return removed, ctr
 
 
-@pytest.mark.parametrize("n,r2,order", [(2100, 0.5, 2), (5000, 0.2, 2), (5000, 0.9, 1), (20000, 0.5, 2), (20000, 0.05, 2)])
-def test_early_termination_is_invisible(gpu_pkg, n, r2, order):
+@pytest.mark.parametrize("n,r2,order,miss", [(2100, 0.5, 2, 0.0), (5000, 0.2, 2, 0.0), (5000, 0.9, 1, 0.0), (20000, 0.5, 2, 0.0), (20000, 0.05, 2, 0.0),
+                                             (2100, 0.5, 2, 0.002), (5000, 0.5, 1, 0.05), (20000, 0.5, 2, 0.001), (20000, 0.2, 2, 0.01),
+                                             (20000, 0.7, 2, 0.2)])
+def test_early_termination_is_invisible(gpu_pkg, n, r2, order, miss):
     """Waves that stop at a checkpoint (ldp_device.h) may only ever skip pairs whose predicate is false: the
-    prune set and the number of true predicates are those of the exhaustive run and of the oracle."""
+    prune set and the number of true predicates are those of the exhaustive run and of the oracle.  With missing
+    calls the tiles take the general kernel and its interval bound."""
     m = 700
-    raw = T.synth_raw_codes(m, n, seed=n % 97, missing_rate=0.0)
+    raw = T.synth_raw_codes(m, n, seed=n % 97, missing_rate=miss)
     chr_idx, bps = make_positions(m, 2, 5)
     packed = T.pack_2bit(raw)
     off, c0 = _run_early_exit(gpu_pkg, packed, n, chr_idx, bps, 150, 1, False, r2, order, False)
@@ -293,7 +296,7 @@ def test_early_termination_is_invisible(gpu_pkg, n, r2, order):
     assert np.array_equal(on, off)
     assert c1["pred_true"] == c0["pred_true"]
     assert c1["tile_unit_chunks"] == c0["tile_unit_chunks"] > 0
-    if r2 >= 0.5:
+    if r2 >= 0.5 and miss <= 0.01:
         assert c1["early_exit_unit_chunks"] > 0  # unrelated pairs are provably hopeless early on
     inv, mf, _ = T.oracle_prepare(raw)
     want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 150, 1, False, r2, order)
@@ -318,6 +321,36 @@ def test_early_termination_late_correlation(gpu_pkg):
         on, c1 = _run_early_exit(gpu_pkg, packed, n, chr_idx, None, 100, 1, False, r2, 2, True)
         off, c0 = _run_early_exit(gpu_pkg, packed, n, chr_idx, None, 100, 1, False, r2, 2, False)
         assert want.sum() >= m // 4
+        assert np.array_equal(off, want)
+        assert np.array_equal(on, want)
+        assert c1["pred_true"] == c0["pred_true"]
+
+
+def test_early_termination_missing_calls_adversarial(gpu_pkg):
+    """Missing calls placed where they hurt an interval bound most: rare variants whose carriers sit in the last
+    third of the samples, partners whose missing calls cover exactly those carriers (so the pairwise-complete
+    variance collapses), plus pairs that only become correlated late."""
+    n, m = 6000, 240
+    rng = np.random.default_rng(5)
+    raw = T.synth_raw_codes(m, n, seed=33, missing_rate=0.0)
+    tail = np.arange(int(0.7 * n), n)
+    for v in range(0, m, 6):
+        raw[v] = 0
+        carriers = rng.choice(tail, size=25, replace=False)
+        raw[v, carriers] = 1                         # rare variant, carriers late
+        raw[v + 1, carriers[:20]] = 3                # partner missing on most of them
+        raw[v + 2] = raw[v]                          # perfect copy of the rare variant ...
+        raw[v + 2, carriers[:5]] = 3                 # ... with a few of the carriers missing
+        raw[v + 3, :int(0.5 * n)] = rng.permutation(raw[v + 3, :int(0.5 * n)])
+        raw[v + 3, int(0.5 * n):] = raw[v + 4, int(0.5 * n):]
+        raw[v + 3, rng.choice(n, size=60, replace=False)] = 3
+    chr_idx = np.zeros(m, dtype=np.uint32)
+    packed = T.pack_2bit(raw)
+    inv, mf, _ = T.oracle_prepare(raw)
+    for r2 in (0.2, 0.5):
+        want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, np.arange(m, dtype=np.uint32), mf, 60, 1, False, r2, 2)
+        on, c1 = _run_early_exit(gpu_pkg, packed, n, chr_idx, None, 60, 1, False, r2, 2, True)
+        off, c0 = _run_early_exit(gpu_pkg, packed, n, chr_idx, None, 60, 1, False, r2, 2, False)
         assert np.array_equal(off, want)
         assert np.array_equal(on, want)
         assert c1["pred_true"] == c0["pred_true"]
