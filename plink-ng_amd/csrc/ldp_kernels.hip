@@ -562,43 +562,37 @@ __device__ __forceinline__ void tile_chunk_column(const uint4* __restrict__ l4, 
 //   [0] popcnt(hom_i & hom_j)              [1] popcnt(hom_i & hom_j & (r2h_i ^ r2h_j))
 //   [2] popcnt(nm_i & nm_j)                [3] popcnt(nm_i & hom_j)   [4] popcnt(nm_i & hom_j & r2h_j)
 //   [5] popcnt(nm_j & hom_i)               [6] popcnt(nm_j & hom_i & r2h_i)          nm = hom | r2h
+// Column layout from the start: wave w owns second-variant group b = w of ALL the block's distance units (up to 12),
+// one pair per lane and unit.  Whatever the unit count, the four waves carry the same load (with 7 half-rate
+// popcounts per pair-dword nothing else matters), everything is accumulated in one pass over the samples, and
+// early termination only ever shortens the unit list.  One J row and NA I rows per 16-byte k-group.
 template <int NA>
-__device__ __forceinline__ void tile_chunk_general(const uint4* __restrict__ l4, int jrow, int irow, uint32_t (&acc)[2][4][7]) {
+__device__ __forceinline__ void tile_chunk_general(const uint4* __restrict__ l4, int jrow, int irow, uint32_t (&acc)[kMaxUnitsPerBlock][7]) {
 #pragma unroll 1
   for (int g = 0; g < kChunkDwords / 4; ++g) {
-    uint4 jH[4], jR[4], jN[4], jP[4];
+    const uint4 jH = lds_row_slot(l4, jrow, g);
+    const uint4 jR = lds_row_slot(l4, jrow, (kChunkDwords / 4) + g);
+    const uint4 jN = or4(jH, jR);
+    const uint4 jP = and4(jH, jR);
+    uint4 iH = lds_row_slot(l4, irow, g);
+    uint4 iR = lds_row_slot(l4, irow, (kChunkDwords / 4) + g);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      jH[b] = lds_row_slot(l4, jrow + 8 * b, g);
-      jR[b] = lds_row_slot(l4, jrow + 8 * b, (kChunkDwords / 4) + g);
-      jN[b] = or4(jH[b], jR[b]);
-      jP[b] = and4(jH[b], jR[b]);
-    }
-    uint4 iH = lds_row_slot(l4, irow - 8 * (NA - 1), g);
-    uint4 iR = lds_row_slot(l4, irow - 8 * (NA - 1), (kChunkDwords / 4) + g);
-#pragma unroll
-    for (int c = -(NA - 1); c <= 3; ++c) {
+    for (int a = 0; a < NA; ++a) {
       uint4 nH = iH, nR = iR;
-      if (c < 3) {
-        nH = lds_row_slot(l4, irow + 8 * (c + 1), g);
-        nR = lds_row_slot(l4, irow + 8 * (c + 1), (kChunkDwords / 4) + g);
+      if (a + 1 < NA) {
+        nH = lds_row_slot(l4, irow - 8 * (a + 1), g);
+        nR = lds_row_slot(l4, irow - 8 * (a + 1), (kChunkDwords / 4) + g);
       }
       const uint4 iN = or4(iH, iR);
       const uint4 iP = and4(iH, iR);
-#pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        const int b = c + a;
-        if (b >= 0 && b < 4) {
-          const uint4 h = and4(jH[b], iH);
-          bcnt_acc4(acc[a][b][0], h);
-          bcnt_acc4(acc[a][b][1], and4(h, xor4(jR[b], iR)));
-          bcnt_acc4(acc[a][b][2], and4(iN, jN[b]));
-          bcnt_acc4(acc[a][b][3], and4(iN, jH[b]));
-          bcnt_acc4(acc[a][b][4], and4(iN, jP[b]));
-          bcnt_acc4(acc[a][b][5], and4(jN[b], iH));
-          bcnt_acc4(acc[a][b][6], and4(jN[b], iP));
-        }
-      }
+      const uint4 h = and4(jH, iH);
+      bcnt_acc4(acc[a][0], h);
+      bcnt_acc4(acc[a][1], and4(h, xor4(jR, iR)));
+      bcnt_acc4(acc[a][2], and4(iN, jN));
+      bcnt_acc4(acc[a][3], and4(iN, jH));
+      bcnt_acc4(acc[a][4], and4(iN, jP));
+      bcnt_acc4(acc[a][5], and4(jN, iH));
+      bcnt_acc4(acc[a][6], and4(jN, iP));
       __builtin_amdgcn_sched_barrier(0);
       iH = nH;
       iR = nR;
@@ -885,8 +879,8 @@ __device__ __forceinline__ uint32_t wave_live_units(const PairKernelArgs& A, uin
 // could all coincide with the partner's missing calls) the variance bound falls back to what the visited samples
 // alone guarantee, so such pairs terminate later, never wrongly.
 template <int NA>
-__device__ __forceinline__ uint32_t general_live_units(const PairKernelArgs& A, uint32_t j0, uint32_t jend, uint32_t d_first, int tx, int ty,
-                                                       const uint32_t (&acc)[2][4][7], uint32_t cp) {
+__device__ __forceinline__ uint32_t general_live_units(const PairKernelArgs& A, uint32_t j0, uint32_t jend, uint32_t d_first, int tx, int ty, uint32_t b,
+                                                       const uint32_t (&acc)[kMaxUnitsPerBlock][7], uint32_t cp) {
   bool hopeless[NA];
 #pragma unroll
   for (int a = 0; a < NA; ++a) {
@@ -895,59 +889,50 @@ __device__ __forceinline__ uint32_t general_live_units(const PairKernelArgs& A, 
   const uint64_t seen = static_cast<uint64_t>(A.checkpoint_chunk[cp]) * (kChunkDwords * 32);
   const double rs = static_cast<double>(A.founder_ct - static_cast<uint32_t>(seen));  // |R| (checkpoints lie inside the row)
   const double thr = A.thresh * (1.0 - 1e-6);
+  const uint32_t j = j0 + tx + 8 * b;
+  if (j < jend) {
+    const uint32_t span_j = j - A.lo[j];
+    const cp_gen_slot gj = A.cp_gen[static_cast<uint64_t>(j) * kCheckpoints + cp];
+    const double nr_j = gj.nm_r, a_j = gj.zs_r, b_j = gj.zq_r;
+    const double var_r_j = fmax(b_j - a_j * a_j / rs, 0.0);
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    uint32_t j = j0 + tx + 8 * b;
-    asm volatile("" : "+v"(j));  // (keeps the address arithmetic inside the checkpoint)
-    if (j < jend) {
-      const uint32_t span_j = j - A.lo[j];
-      const cp_gen_slot gj = A.cp_gen[static_cast<uint64_t>(j) * kCheckpoints + cp];
-      cp_gen_slot gi[NA];
-#pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        const uint32_t d = d_first + ty + 8 * a;
-        const uint32_t i = (d <= j) ? (j - d) : 0;
-        gi[a] = A.cp_gen[static_cast<uint64_t>(i) * kCheckpoints + cp];
+    for (int a = 0; a < NA; ++a) {
+      const uint32_t d = d_first + ty + 8 * a;
+      if (d <= span_j) {
+        const cp_gen_slot gi = A.cp_gen[static_cast<uint64_t>(j - d) * kCheckpoints + cp];
+        const uint32_t* c = acc[a];
+        // visited part, exact
+        const double n_p = c[2];
+        const double s1 = 2.0 * c[6] - static_cast<double>(c[5]), q1 = c[5];
+        const double s2 = 2.0 * c[4] - static_cast<double>(c[3]), q2 = c[3];
+        const double dot = static_cast<double>(c[0]) - 2.0 * c[1];
+        const double zs_p = n_p - s1, zq_p = n_p - 2.0 * s1 + q1;
+        const double ws_p = n_p - s2, wq_p = n_p - 2.0 * s2 + q2;
+        const double zw_p = n_p - s1 - s2 + dot;
+        // remainder
+        const double nr_i = gi.nm_r, a_i = gi.zs_r, b_i = gi.zq_r;
+        const double dmax_i = fmin(rs - nr_j, nr_i);
+        const double dmax_j = fmin(rs - nr_i, nr_j);
+        const double n_lo = n_p + fmax(nr_i - dmax_i, nr_j - dmax_j);
+        const double n_hi = n_p + fmin(nr_i, nr_j);
+        const double zs_hi = zs_p + a_i, zs_lo = zs_hi - fmin(2.0 * dmax_i, a_i);
+        const double ws_hi = ws_p + a_j, ws_lo = ws_hi - fmin(2.0 * dmax_j, a_j);
+        const double zq_lo = zq_p + b_i - fmin(4.0 * dmax_i, b_i);
+        const double wq_lo = wq_p + b_j - fmin(4.0 * dmax_j, b_j);
+        const double centre = a_i * a_j / rs;
+        const double spread = sqrt(fmax(b_i - a_i * a_i / rs, 0.0) * var_r_j) * (1.0 + 1e-9);
+        const double zw_hi = zw_p + centre + spread;
+        const double zw_lo = fmax(zw_p, zw_p + centre - spread);
+        const double cov_hi = n_hi * zw_hi - zs_lo * ws_lo;
+        const double cov_lo = n_lo * zw_lo - zs_hi * ws_hi;
+        const double cmax = fmax(fabs(cov_hi), fabs(cov_lo)) + 1.0;
+        const double var1_lo = n_lo * zq_lo - zs_hi * zs_hi;
+        const double var2_lo = n_lo * wq_lo - ws_hi * ws_hi;
+        const bool h = (var1_lo > 0.0) && (var2_lo > 0.0) && (cmax * cmax * (1.0 + 1e-6) < thr * var1_lo * var2_lo);
+        hopeless[a] = hopeless[a] && h;
       }
-#pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        const uint32_t d = d_first + ty + 8 * a;
-        if (d <= span_j) {
-          const uint32_t* c = acc[a][b];
-          // visited part, exact
-          const double n_p = c[2];
-          const double s1 = 2.0 * c[6] - static_cast<double>(c[5]), q1 = c[5];
-          const double s2 = 2.0 * c[4] - static_cast<double>(c[3]), q2 = c[3];
-          const double dot = static_cast<double>(c[0]) - 2.0 * c[1];
-          const double zs_p = n_p - s1, zq_p = n_p - 2.0 * s1 + q1;
-          const double ws_p = n_p - s2, wq_p = n_p - 2.0 * s2 + q2;
-          const double zw_p = n_p - s1 - s2 + dot;
-          // remainder
-          const double nr_i = gi[a].nm_r, a_i = gi[a].zs_r, b_i = gi[a].zq_r;
-          const double nr_j = gj.nm_r, a_j = gj.zs_r, b_j = gj.zq_r;
-          const double dmax_i = fmin(rs - nr_j, nr_i);
-          const double dmax_j = fmin(rs - nr_i, nr_j);
-          const double n_lo = n_p + fmax(nr_i - dmax_i, nr_j - dmax_j);
-          const double n_hi = n_p + fmin(nr_i, nr_j);
-          const double zs_hi = zs_p + a_i, zs_lo = zs_hi - fmin(2.0 * dmax_i, a_i);
-          const double ws_hi = ws_p + a_j, ws_lo = ws_hi - fmin(2.0 * dmax_j, a_j);
-          const double zq_lo = zq_p + b_i - fmin(4.0 * dmax_i, b_i);
-          const double wq_lo = wq_p + b_j - fmin(4.0 * dmax_j, b_j);
-          const double centre = a_i * a_j / rs;
-          const double spread = sqrt(fmax(b_i - a_i * a_i / rs, 0.0) * fmax(b_j - a_j * a_j / rs, 0.0)) * (1.0 + 1e-9);
-          const double zw_hi = zw_p + centre + spread;
-          const double zw_lo = fmax(zw_p, zw_p + centre - spread);
-          const double cov_hi = n_hi * zw_hi - zs_lo * ws_lo;
-          const double cov_lo = n_lo * zw_lo - zs_hi * ws_hi;
-          const double cmax = fmax(fabs(cov_hi), fabs(cov_lo)) + 1.0;
-          const double var1_lo = n_lo * zq_lo - zs_hi * zs_hi;
-          const double var2_lo = n_lo * wq_lo - ws_hi * ws_hi;
-          const bool h = (var1_lo > 0.0) && (var2_lo > 0.0) && (cmax * cmax * (1.0 + 1e-6) < thr * var1_lo * var2_lo);
-          hopeless[a] = hopeless[a] && h;
-        }
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
   uint32_t live = 0;
 #pragma unroll
@@ -1016,13 +1001,39 @@ __device__ __forceinline__ void run_chunks(Ring& R, const Stager& st, uint32_t* 
 
 template <int NA>
 __device__ __forceinline__ void run_chunks_general(Ring& R, const Stager& st, uint32_t* lds, uint32_t kc_end, uint32_t chunks, uint32_t wave, uint32_t lane,
-                                                   int jrow, int irow, uint32_t (&acc)[2][4][7]) {
+                                                   int jrow, int irow, uint32_t (&acc)[kMaxUnitsPerBlock][7]) {
   while (R.kc < kc_end) {
     const uint4* l4 = ring_acquire(R, st, lds, chunks, wave, lane);
     if constexpr (NA > 0) {
       tile_chunk_general<NA>(l4, jrow, irow, acc);
     }
     ring_release(R, st);
+  }
+}
+
+// (a switch over NA = 1 .. kMaxUnitsPerBlock with one k-loop instantiation per case, cf. run_chunks)
+template <int NA>
+__device__ __forceinline__ void dispatch_general_run(uint32_t live, Ring& R, const Stager& st, uint32_t* lds, uint32_t kc_end, uint32_t chunks, uint32_t wave,
+                                                     uint32_t lane, int jrow, int irow, uint32_t (&acc)[kMaxUnitsPerBlock][7]) {
+  if constexpr (NA <= kMaxUnitsPerBlock) {
+    if (live == static_cast<uint32_t>(NA)) {
+      run_chunks_general<NA>(R, st, lds, kc_end, chunks, wave, lane, jrow, irow, acc);
+    } else {
+      dispatch_general_run<NA + 1>(live, R, st, lds, kc_end, chunks, wave, lane, jrow, irow, acc);
+    }
+  }
+}
+
+template <int NA>
+__device__ __forceinline__ uint32_t dispatch_general_live(uint32_t live, const PairKernelArgs& A, uint32_t j0, uint32_t jend, uint32_t d_first, int tx, int ty,
+                                                          uint32_t b, const uint32_t (&acc)[kMaxUnitsPerBlock][7], uint32_t cp) {
+  if constexpr (NA <= kMaxUnitsPerBlock) {
+    if (live == static_cast<uint32_t>(NA)) {
+      return general_live_units<NA>(A, j0, jend, d_first, tx, ty, b, acc, cp);
+    }
+    return dispatch_general_live<NA + 1>(live, A, j0, jend, d_first, tx, ty, b, acc, cp);
+  } else {
+    return live;
   }
 }
 
@@ -1272,86 +1283,91 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_ker
       n_true += emit_pair(A, i, j, lo_j, ps) ? 1 : 0;
     }
   } else {
-    // general path: two distance-units per pass to bound register use (7 counters per pair)
-    for (uint32_t a0 = 0; a0 < units_max; a0 += 2) {
-      uint32_t acc[2][4][7];
+    // general path, column layout (see tile_chunk_general): wave w = second-variant group b = w of every unit
+    uint32_t acc[kMaxUnitsPerBlock][7];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < kMaxUnitsPerBlock; ++a) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-#pragma unroll
-          for (int q = 0; q < 7; ++q) {
-            acc[a][b][q] = 0;
-          }
-        }
+      for (int q = 0; q < 7; ++q) {
+        acc[a][q] = 0;
       }
-      const uint32_t na = (units_w > a0) ? ((units_w - a0 >= 2) ? 2 : 1) : 0;
-      const int irow = irow0 - 8 * static_cast<int>(a0);
-      // early termination as in the complete-data path, without the re-dealing: a wave drops the far unit of the
-      // pass, or both, and the pass ends when no wave has anything left
-      uint32_t live_g = na;
-      uint32_t next_cp = 0;
-      const uint32_t n_cp = (A.cp_gen && (A.item_general[item_idx] == 1)) ? A.n_checkpoints : 0;
-      ring_start(R, st, lds, 0, A.chunks, wave, lane);
-      while (R.kc < A.chunks) {
-        const bool cp_ahead = (next_cp < n_cp);  // block-uniform
-        const uint32_t kc_end = cp_ahead ? A.checkpoint_chunk[next_cp] : A.chunks;
-        if (live_g == 2) {
-          run_chunks_general<2>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow, acc);
-        } else if (live_g == 1) {
-          run_chunks_general<1>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow, acc);
-        } else {
-          run_chunks_general<0>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow, acc);
-        }
-        if (cp_ahead) {
-          if (live_g) {
-            const uint32_t d_first = dw0 + 8 * a0;
-            uint32_t keep = (live_g == 2) ? general_live_units<2>(A, it.j0, it.jend, d_first, tx, ty, acc, next_cp)
-                                          : general_live_units<1>(A, it.j0, it.jend, d_first, tx, ty, acc, next_cp);
-            if (keep != live_g) {
-              if (lane == 0) {
-                atomicAdd(A.counters + 1, static_cast<unsigned long long>(A.chunks - R.kc) * (live_g - keep) * 4);
-              }
-              live_g = __builtin_amdgcn_readfirstlane(keep);
+    }
+    (void)units_w;
+    (void)units_max;
+    (void)dw0;
+    (void)irow0;
+    uint32_t live = units_total;    // units this wave still accumulates (nearest first; wave-uniform)
+    uint32_t staged = units_total;  // block-uniform
+    jrow = G.jrow_base + tx + 8 * static_cast<int>(wave);
+    int irow = G.dmax + tx + 8 * static_cast<int>(wave) - static_cast<int>(it.d0) - ty;  // I-row of unit 0
+    uint32_t next_cp = 0;
+    const uint32_t n_cp = (A.cp_gen && (A.item_general[item_idx] == 1)) ? A.n_checkpoints : 0;
+    ring_start(R, st, lds, 0, A.chunks, wave, lane);
+    while (R.kc < A.chunks) {
+      const bool cp_ahead = (next_cp < n_cp);  // block-uniform
+      const uint32_t kc_end = cp_ahead ? A.checkpoint_chunk[next_cp] : A.chunks;
+      if (live) {
+        dispatch_general_run<1>(live, R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow, acc);
+      } else {
+        run_chunks_general<0>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow, acc);
+      }
+      if (cp_ahead) {
+        if (live) {
+          const uint32_t keep = dispatch_general_live<1>(live, A, it.j0, it.jend, it.d0, tx, ty, wave, acc, next_cp);
+          if (keep != live) {
+            if (lane == 0) {
+              atomicAdd(A.counters + 1, static_cast<unsigned long long>(A.chunks - R.kc) * (live - keep));
             }
+            live = __builtin_amdgcn_readfirstlane(keep);
           }
-          ++next_cp;
-          if (lane == 0) {
-            s_live[wave] = live_g;
-          }
-          __syncthreads();
-          const uint32_t any_live = s_live[0] | s_live[1] | s_live[2] | s_live[3];
-          __syncthreads();  // (s_live is rewritten at the next checkpoint or pass)
-          if (!any_live) {
-            break;
-          }
+        }
+        ++next_cp;
+        if (lane == 0) {
+          s_live[wave] = live;
+        }
+        __syncthreads();  // (a full fence: this wave's queued chunks have landed, too)
+        uint32_t need = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kWavesPerBlock; ++w) {
+          need = (s_live[w] > need) ? s_live[w] : need;
+        }
+        __syncthreads();  // (s_live is rewritten at the next checkpoint)
+        if (!need) {
+          break;
+        }
+        if (need < staged) {
+          staged = need;
+          G = make_geom(it, staged);
+          plan_stager(st, G, A, wave, lane);
+          jrow = G.jrow_base + tx + 8 * static_cast<int>(wave);
+          irow = G.dmax + tx + 8 * static_cast<int>(wave) - static_cast<int>(it.d0) - ty;
+          ring_start(R, st, lds, R.kc, A.chunks, wave, lane);
         }
       }
-      __syncthreads();  // staging of this pass is over: LDS becomes the epilogue's scratch
+    }
+    __syncthreads();  // staging is over: LDS becomes the epilogue's scratch
+    // four units at a time through LDS (28 dwords per thread), so the decision code stays a rolled loop
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        // one distance-unit at a time through LDS: 4 pairs x 7 counters = 28 dwords per thread
+    for (int a0 = 0; a0 < kMaxUnitsPerBlock; a0 += 4) {
+      if (static_cast<uint32_t>(a0) < live) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int a = 0; a < 4; ++a) {
 #pragma unroll
           for (int q = 0; q < 7; ++q) {
-            lds[(b * 7 + q) * kBlockThreads + tid] = acc[a][b][q];
+            lds[(a * 7 + q) * kBlockThreads + tid] = acc[(a0 + a < kMaxUnitsPerBlock) ? a0 + a : 0][q];
           }
         }
-        if (a < static_cast<int>(live_g)) {  // (pairs of dropped units are all below the threshold)
+        const uint32_t j = it.j0 + tx + 8 * wave;
+        if (j < it.jend) {
+          const uint32_t lo_j = A.lo[j];
 #pragma unroll 1
-          for (uint32_t b = 0; b < 4; ++b) {
-            const uint32_t j = it.j0 + tx + 8 * b;
-            const uint32_t d = dw0 + ty + 8 * (a0 + a);
-            if (j >= it.jend) {
-              continue;
-            }
-            const uint32_t lo_j = A.lo[j];
+          for (uint32_t a = 0; (a < 4) && (a0 + a < live); ++a) {
+            const uint32_t d = it.d0 + ty + 8 * (a0 + a);
             if (d > j - lo_j) {
               continue;
             }
             const uint32_t i = j - d;
-            const uint32_t* c = lds + (b * 7) * kBlockThreads + tid;
+            const uint32_t* c = lds + (a * 7) * kBlockThreads + tid;
             const uint32_t c0 = c[0], c1 = c[kBlockThreads], c2 = c[2 * kBlockThreads], c3 = c[3 * kBlockThreads];
             const uint32_t c4 = c[4 * kBlockThreads], c5 = c[5 * kBlockThreads], c6 = c[6 * kBlockThreads];
             ldp_pair_stats_t ps;
@@ -1365,7 +1381,6 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_ker
           }
         }
       }
-      __syncthreads();  // LDS is restaged by the next pass
     }
   }
   n_true = wave_reduce_add(n_true);
