@@ -20,24 +20,19 @@ constexpr int kRowChunkDwords = 2 * kChunkDwords; // hom + ref2het = 128 B
 constexpr int kLdsRowDwords = kRowChunkDwords + 4; // 36: odd number (9) of 16-B slots -> conflict-free b128 reads
 
 // ---- pair-tile geometry -------------------------------------------------------------------------
-// A block owns kTileJ consecutive "second" variants j and a run of distances d = j - i, split in
-// units of 8 among its 4 waves.  Lane (tx = lane&7, ty = lane>>3) of a wave owns j = j0 + tx + 8b
-// (b < 4) and d = dw0 + ty + 8a (a < NA <= kMaxUnitsPerWave).  Three units per wave is what keeps the complete-data
-// kernel at 128 VGPRs (4 waves/SIMD) with nothing spilled inside the k-loop, see plan_stager in ldp_kernels.hip.
+// A block owns kTileJ consecutive "second" variants j and a run of distances d = j - i in units of 8.  Wave w owns
+// second-variant group w (lane (tx = lane&7, ty = lane>>3): j = j0 + tx + 8w) of ALL the block's units
+// (d = d0 + ty + 8a, a < units <= kMaxUnitsPerBlock): one pair per lane and unit ("column layout").
 constexpr int kTileJ = 32;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlockThreads = 64 * kWavesPerBlock;
-#ifndef LDP_MAX_UNITS_PER_WAVE
-#define LDP_MAX_UNITS_PER_WAVE 3
-#endif
-constexpr int kMaxUnitsPerWave = LDP_MAX_UNITS_PER_WAVE;  // NA: 8-distance units a wave accumulates at once
-constexpr int kMaxUnitsPerBlock = kWavesPerBlock * kMaxUnitsPerWave;  // 12 -> 96 distances; wider windows take several blocks per J-tile
+constexpr int kMaxUnitsPerBlock = 12;  // 96 distances; wider windows take several blocks per J-tile
 
 struct WorkItem {
   uint32_t j0;        // first second-variant index
   uint32_t jend;      // exclusive end (<= j0 + kTileJ)
   uint32_t d0;        // first distance handled by the block (>= 1)
-  uint32_t units;     // units[w] in byte w: number of 8-distance units wave w handles
+  uint32_t units;     // number of 8-distance units (<= kMaxUnitsPerBlock)
   uint32_t sfirst;    // subcontig bounds (row clamp)
   uint32_t send;
 };
@@ -51,10 +46,9 @@ struct WorkItem {
 // this needs, pre-scaled so the pair test is a handful of FP64 ops (cp_stats, kCpSlots x 16 bytes per variant):
 //     slot k < kCheckpoints: { s_R * sqrt(N / n_R),  sqrt(N * (q_R - s_R^2 / n_R)) }
 //     slot kCheckpoints    : { S (whole-row sum),    sqrt(N*Q - S^2) * sqrt(sqrt(thresh) * (1 - 1e-6)) }
-// A distance unit whose pairs all provably stay below the r^2 threshold is dropped (far end of a wave's range
-// first); when only a block's nearest units are left they are re-dealt over the four waves (column mode) and the
-// tile is re-planned to the rows still needed; a block with nothing left leaves the k-loop.  Results are unchanged:
-// only pairs whose predicate is provably false are skipped.
+// A distance unit whose pairs all provably stay below the r^2 threshold is dropped (far end of a wave's unit list
+// first); the tile is re-planned to the rows the block still needs; a block with nothing left leaves the k-loop.
+// Results are unchanged: only pairs whose predicate is provably false are skipped.
 constexpr int kCheckpoints = 5;
 constexpr int kCpSlots = kCheckpoints + 1;
 struct cp_slot {

@@ -459,48 +459,6 @@ int checkpoint_fractions(double r2_param, double* frac) {
   return n;
 }
 
-// Split u distance units of one block over the four waves (contiguous runs, <= kMaxUnitsPerWave each) so that the
-// slowest wave is as fast as possible under a simple cost model: the unit holding the nearest distances runs to
-// the end (neighbouring variants are the ones in LD), every other unit stops after a fraction f of the k-chunks.
-// f = 1 (no early termination expected) gives the even split.
-uint32_t split_units(uint32_t u, bool nearest_block, double f) {
-  uint32_t best = 0;
-  double best_cost = 1e30;
-  uint32_t best_sq = 0xffffffffu;
-  uint32_t c[kWavesPerBlock];
-  for (c[0] = 0; c[0] <= kMaxUnitsPerWave; ++c[0]) {
-    for (c[1] = 0; c[1] <= kMaxUnitsPerWave; ++c[1]) {
-      for (c[2] = 0; c[2] <= kMaxUnitsPerWave; ++c[2]) {
-        if (c[0] + c[1] + c[2] > u || u - (c[0] + c[1] + c[2]) > kMaxUnitsPerWave) {
-          continue;
-        }
-        c[3] = u - (c[0] + c[1] + c[2]);
-        double cost = 0.0;
-        uint32_t sq = 0, first = 0;
-        for (uint32_t w = 0; w < kWavesPerBlock; ++w) {
-          double cw = f * c[w];
-          if (nearest_block && (first == 0) && c[w]) {
-            cw += 1.0 - f;
-          }
-          // a lone unit reads two LDS rows per pair tile instead of ~one: count it as slightly dearer
-          if (c[w] == 1) {
-            cw *= 1.1;
-          }
-          first += c[w];
-          cost = std::max(cost, cw);
-          sq += c[w] * c[w];
-        }
-        if ((cost < best_cost - 1e-9) || ((cost < best_cost + 1e-9) && (sq < best_sq))) {
-          best_cost = cost;
-          best_sq = sq;
-          best = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
-        }
-      }
-    }
-  }
-  return best;
-}
-
 void build_shard(ldp_engine* e) {
   // local index space
   e->owned.clear();
@@ -547,19 +505,10 @@ void build_shard(ldp_engine* e) {
   e->pred_words = words;
   e->cand_pairs = pairs;
 
-  // work items: 32 seconds x runs of 8-distance units, <= 16 units per block, spread over waves
+  // work items: 32 seconds x runs of 8-distance units, <= kMaxUnitsPerBlock units per block
   e->items.clear();
   e->max_rows = 0;
   e->computed_pairs = 0;
-  // expected share of the k-chunks a far unit runs before early termination stops it (1 = never)
-  double stop_frac = 1.0;
-  {
-    double frac[kCheckpoints];
-    const uint32_t plane_chunks = ((e->P.founder_ct + 31) / 32 + kChunkDwords - 1) / kChunkDwords;
-    if (early_exit_requested() && (plane_chunks >= 4) && checkpoint_fractions(e->P.prune_last_param, frac)) {
-      stop_frac = std::min(1.0, frac[0] + 1.0 / plane_chunks);
-    }
-  }
   for (uint32_t k : e->owned) {
     if (e->matrix_mode) {
       break;
@@ -583,25 +532,11 @@ void build_shard(ldp_engine* e) {
       uint32_t d0 = 1;
       for (uint32_t blk = 0; blk < blocks; ++blk) {
         const uint32_t u = base + ((blk < extra) ? 1 : 0);
-        // default: cost-model split (even when no early termination is expected: measured 7 % faster on config 2
-        // than packing); LDP_UNIT_SPLIT=packed uses as few waves as possible (fewer second-variant loads per pair).
-        static const bool spread = !((getenv("LDP_UNIT_SPLIT") != nullptr) && (strcmp(getenv("LDP_UNIT_SPLIT"), "packed") == 0));
         WorkItem it;
         it.j0 = j0;
         it.jend = jend;
         it.d0 = d0;
-        it.units = 0;
-        static const bool even = (getenv("LDP_UNIT_SPLIT") != nullptr) && (strcmp(getenv("LDP_UNIT_SPLIT"), "even") == 0);
-        if (spread) {
-          it.units = split_units(u, d0 == 1, even ? 1.0 : stop_frac);
-        } else {
-          const uint32_t waves_used = (u + kMaxUnitsPerWave - 1) / kMaxUnitsPerWave;
-          const uint32_t wb = u / waves_used;
-          const uint32_t we = u % waves_used;
-          for (uint32_t w = 0; w < waves_used; ++w) {
-            it.units |= (wb + ((w < we) ? 1 : 0)) << (8 * w);
-          }
-        }
+        it.units = u;
         it.sfirst = sfirst;
         it.send = send;
         e->items.push_back(it);
@@ -1721,17 +1656,11 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
     uint32_t d0 = 1;
     for (uint32_t blk = 0; blk < blocks; ++blk) {
       const uint32_t u = base + ((blk < extra) ? 1 : 0);
-      const uint32_t waves_used = std::min<uint32_t>(u, kWavesPerBlock);
-      const uint32_t wb = u / waves_used;
-      const uint32_t we = u % waves_used;
       WorkItem it;
       it.j0 = j0;
       it.jend = jend;
       it.d0 = d0;
-      it.units = 0;
-      for (uint32_t w = 0; w < waves_used; ++w) {
-        it.units |= (wb + ((w < we) ? 1 : 0)) << (8 * w);
-      }
+      it.units = u;
       it.sfirst = 0;
       it.send = e->local_ct;
       items.push_back(it);

@@ -469,111 +469,29 @@ __device__ __forceinline__ void bcnt_acc4(uint32_t& acc, const uint4& v) {
 
 __device__ __forceinline__ uint4 lds_row_slot(const uint4* __restrict__ l4, int row, int slot) { return l4[row * kLdsRowSlots + slot]; }
 
-// Complete-data path: dot = popcnt(hom1&hom2) - 2*popcnt(hom1&hom2&(r2h1^r2h2))  (plink2_ld.cc:244-250)
-// Per 16-byte k-group a thread holds its 4 second-variants (jH/jR) and streams the NA+3 first-variants
-// it needs (one LDS row per value of c = b - a), software-pipelined one row ahead.
-template <int NA>
-__device__ __forceinline__ void tile_chunk_fast(const uint4* __restrict__ l4, int jrow, int irow, uint32_t (&hh)[kMaxUnitsPerWave][4], uint32_t (&xx)[kMaxUnitsPerWave][4]) {
-#pragma unroll 1
-  for (int g = 0; g < kChunkDwords / 4; ++g) {
-    uint4 jH[4], jR[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      jH[b] = lds_row_slot(l4, jrow + 8 * b, g);
-      jR[b] = lds_row_slot(l4, jrow + 8 * b, (kChunkDwords / 4) + g);
-    }
-    uint4 iH = lds_row_slot(l4, irow - 8 * (NA - 1), g);
-    uint4 iR = lds_row_slot(l4, irow - 8 * (NA - 1), (kChunkDwords / 4) + g);
-#pragma unroll
-    for (int c = -(NA - 1); c <= 3; ++c) {
-      uint4 nH = iH, nR = iR;
-      if (c < 3) {
-        nH = lds_row_slot(l4, irow + 8 * (c + 1), g);
-        nR = lds_row_slot(l4, irow + 8 * (c + 1), (kChunkDwords / 4) + g);
-      }
-#pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        const int b = c + a;
-        if (b >= 0 && b < 4) {
-          const uint4 h = and4(jH[b], iH);
-          const uint4 x = and4(h, xor4(jR[b], iR));
-          bcnt_acc4(hh[a][b], h);
-          bcnt_acc4(xx[a][b], x);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      iH = nH;
-      iR = nR;
-    }
-  }
-}
-
-// Column mode (after early termination has left only a block's nearest <= 4 units live, see pair_tiles_kernel): a
-// wave owns ONE of the four second-variant groups (b) across all NA live units, so the four waves share what is
-// left evenly.  One J row and NA I rows per 16-byte k-group; the next group's rows are fetched while the current
-// one is consumed.  Accumulators live in hh[a][0] / xx[a][0].
-template <int NA>
-__device__ __forceinline__ void tile_chunk_column(const uint4* __restrict__ l4, int jrow, int irow, uint32_t (&hh)[kMaxUnitsPerWave][4], uint32_t (&xx)[kMaxUnitsPerWave][4]) {
-  uint4 jH = lds_row_slot(l4, jrow, 0);
-  uint4 jR = lds_row_slot(l4, jrow, kChunkDwords / 4);
-  uint4 iH[NA], iR[NA];
-#pragma unroll
-  for (int a = 0; a < NA; ++a) {
-    iH[a] = lds_row_slot(l4, irow - 8 * a, 0);
-    iR[a] = lds_row_slot(l4, irow - 8 * a, kChunkDwords / 4);
-  }
-#pragma unroll
-  for (int g = 0; g < kChunkDwords / 4; ++g) {
-    uint4 njH = jH, njR = jR;
-    uint4 niH[NA], niR[NA];
-#pragma unroll
-    for (int a = 0; a < NA; ++a) {
-      niH[a] = iH[a];
-      niR[a] = iR[a];
-    }
-    if (g + 1 < kChunkDwords / 4) {
-      njH = lds_row_slot(l4, jrow, g + 1);
-      njR = lds_row_slot(l4, jrow, (kChunkDwords / 4) + g + 1);
-#pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        niH[a] = lds_row_slot(l4, irow - 8 * a, g + 1);
-        niR[a] = lds_row_slot(l4, irow - 8 * a, (kChunkDwords / 4) + g + 1);
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < NA; ++a) {
-      const uint4 h = and4(jH, iH[a]);
-      const uint4 x = and4(h, xor4(jR, iR[a]));
-      bcnt_acc4(hh[a][0], h);
-      bcnt_acc4(xx[a][0], x);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    jH = njH;
-    jR = njR;
-#pragma unroll
-    for (int a = 0; a < NA; ++a) {
-      iH[a] = niH[a];
-      iR[a] = niR[a];
-    }
-  }
-}
-
-// General path (missing calls present), all seven counts of plink2_ld.cc:244-250, :329-334, :590-601:
+// ---- the inner loop ---------------------------------------------------------------------------------------
+// Column layout: wave w of a block owns second-variant group b = w (j = j0 + tx + 8w) of ALL the block's distance
+// units a (d = d0 + ty + 8a), one pair per lane and unit, NA <= kMaxUnitsPerBlock units.  Whatever the unit count
+// the four waves carry the same load, a wave's accumulators are few (2 or 7 per unit), and early termination only
+// ever shortens the unit list from the far end.  Per 16-byte k-group a lane reads its J row once and streams the NA
+// I rows (row of unit a = irow - 8a), the next one in flight while the current one is consumed.
+//
+// Complete data (2 counts): dot = popcnt(hom1&hom2) - 2*popcnt(hom1&hom2&(r2h1^r2h2))          (plink2_ld.cc:244-250)
+// Missing calls (7 counts, plink2_ld.cc:244-250, :329-334, :590-601), nm = hom | r2h:
 //   [0] popcnt(hom_i & hom_j)              [1] popcnt(hom_i & hom_j & (r2h_i ^ r2h_j))
 //   [2] popcnt(nm_i & nm_j)                [3] popcnt(nm_i & hom_j)   [4] popcnt(nm_i & hom_j & r2h_j)
-//   [5] popcnt(nm_j & hom_i)               [6] popcnt(nm_j & hom_i & r2h_i)          nm = hom | r2h
-// Column layout from the start: wave w owns second-variant group b = w of ALL the block's distance units (up to 12),
-// one pair per lane and unit.  Whatever the unit count, the four waves carry the same load (with 7 half-rate
-// popcounts per pair-dword nothing else matters), everything is accumulated in one pass over the samples, and
-// early termination only ever shortens the unit list.  One J row and NA I rows per 16-byte k-group.
-template <int NA>
-__device__ __forceinline__ void tile_chunk_general(const uint4* __restrict__ l4, int jrow, int irow, uint32_t (&acc)[kMaxUnitsPerBlock][7]) {
+//   [5] popcnt(nm_j & hom_i)               [6] popcnt(nm_j & hom_i & r2h_i)
+template <bool GENERAL>
+struct Counts {
+  static constexpr int n = GENERAL ? 7 : 2;
+};
+
+template <bool GENERAL, int NA>
+__device__ __forceinline__ void tile_chunk(const uint4* __restrict__ l4, int jrow, int irow, uint32_t (&acc)[kMaxUnitsPerBlock][Counts<GENERAL>::n]) {
 #pragma unroll 1
   for (int g = 0; g < kChunkDwords / 4; ++g) {
     const uint4 jH = lds_row_slot(l4, jrow, g);
     const uint4 jR = lds_row_slot(l4, jrow, (kChunkDwords / 4) + g);
-    const uint4 jN = or4(jH, jR);
-    const uint4 jP = and4(jH, jR);
     uint4 iH = lds_row_slot(l4, irow, g);
     uint4 iR = lds_row_slot(l4, irow, (kChunkDwords / 4) + g);
 #pragma unroll
@@ -583,16 +501,20 @@ __device__ __forceinline__ void tile_chunk_general(const uint4* __restrict__ l4,
         nH = lds_row_slot(l4, irow - 8 * (a + 1), g);
         nR = lds_row_slot(l4, irow - 8 * (a + 1), (kChunkDwords / 4) + g);
       }
-      const uint4 iN = or4(iH, iR);
-      const uint4 iP = and4(iH, iR);
       const uint4 h = and4(jH, iH);
       bcnt_acc4(acc[a][0], h);
       bcnt_acc4(acc[a][1], and4(h, xor4(jR, iR)));
-      bcnt_acc4(acc[a][2], and4(iN, jN));
-      bcnt_acc4(acc[a][3], and4(iN, jH));
-      bcnt_acc4(acc[a][4], and4(iN, jP));
-      bcnt_acc4(acc[a][5], and4(jN, iH));
-      bcnt_acc4(acc[a][6], and4(jN, iP));
+      if constexpr (GENERAL) {
+        const uint4 jN = or4(jH, jR);
+        const uint4 jP = and4(jH, jR);
+        const uint4 iN = or4(iH, iR);
+        const uint4 iP = and4(iH, iR);
+        bcnt_acc4(acc[a][2], and4(iN, jN));
+        bcnt_acc4(acc[a][3], and4(iN, jH));
+        bcnt_acc4(acc[a][4], and4(iN, jP));
+        bcnt_acc4(acc[a][5], and4(jN, iH));
+        bcnt_acc4(acc[a][6], and4(jN, iP));
+      }
       __builtin_amdgcn_sched_barrier(0);
       iH = nH;
       iR = nR;
@@ -662,8 +584,8 @@ struct Stager {
 
 // NOTE on registers: nothing that lives across the k-loop may be spilled.  A spill comes back through a scratch
 // load, and the vmcnt wait in front of its first use drains the very DMA queue the ring keeps full (measured:
-// 2x on the latency-bound tail of a tile).  Hence kMaxUnitsPerWave = 3, and hence the per-lane source offsets
-// live in LDS (6 KiB, read back with one ds_read per DMA instruction) instead of six registers.
+// 2x on the latency-bound tail of a tile).  Hence the per-lane source offsets live in LDS (6 KiB, read back with
+// one ds_read per DMA instruction) instead of six registers.
 __device__ __forceinline__ void plan_stager(Stager& st, const TileGeom& G, const PairKernelArgs& A, uint32_t wave, uint32_t lane) {
   const uint32_t row_bytes = static_cast<uint32_t>(A.row_dwords * sizeof(uint32_t));
   const int64_t vmin = row_variant(G, 0);
@@ -804,73 +726,24 @@ __device__ __forceinline__ bool emit_pair(const PairKernelArgs& A, uint32_t i, u
   return false;
 }
 
-// Early termination test (complete data), see ldp_device.h.  After the chunks before checkpoint `cp` the partial
-// dot product of pair (i,j) is dot_p = hh - 2*xx.  |N*dot - S_i*S_j| <= |c0| + B with
+// Early termination test, complete data (see ldp_device.h).  After the chunks before checkpoint `cp` the partial dot
+// product of pair (i,j) is dot_p = acc[0] - 2*acc[1].  |N*dot - S_i*S_j| <= |c0| + B with
 //   c0 = N*dot_p + a_i*a_j - S_i*S_j,  B = b_i*b_j   (a, b = the checkpoint slot of each variant)
 // and the pair cannot reach the threshold when |c0| + B + 1 < t_i*t_j (t = the scaled sqrt(variance numerator);
-// the +1 and the 1e-6 folded into t dwarf every FP64 rounding error here).  Returns how many of the wave's NA
-// distance units (nearest first) must stay live.
-// NB = 4: the wave owns all four second-variant groups b (accumulators hh[a][b]); NB = 1: column mode, the wave
-// owns group b0 only (accumulators hh[a][0]).
-template <int NA, int NB>
-__device__ __forceinline__ uint32_t wave_live_units(const PairKernelArgs& A, uint32_t j0, uint32_t jend, uint32_t dw0, int tx, int ty, uint32_t b0,
-                                                    const uint32_t (&hh)[kMaxUnitsPerWave][4], const uint32_t (&xx)[kMaxUnitsPerWave][4], uint32_t cp) {
-  bool hopeless[NA];
-#pragma unroll
-  for (int a = 0; a < NA; ++a) {
-    hopeless[a] = true;
-  }
-  uint32_t founder_ct = A.founder_ct;
-  asm volatile("" : "+s"(founder_ct));  // (same reason as for j below)
-  const double N = static_cast<double>(founder_ct);
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    uint32_t j = j0 + tx + 8 * (b + b0);
-    // (keeps the 16 pairs' address arithmetic inside the checkpoint instead of hoisted into long-lived registers)
-    asm volatile("" : "+v"(j));
-    if (j < jend) {
-      const uint32_t span_j = j - A.lo[j];
-      const cp_slot cj = A.cp_stats[static_cast<uint64_t>(j) * kCpSlots + cp];
-      const cp_slot gj = A.cp_stats[static_cast<uint64_t>(j) * kCpSlots + kCheckpoints];
-      // all loads of this j first (one memory latency per b instead of one per pair), then the arithmetic
-      cp_slot ci[NA], gi[NA];
-#pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        const uint32_t d = dw0 + ty + 8 * a;
-        const uint32_t i = (d <= j) ? (j - d) : 0;  // (in range whatever lo[j] turns out to be: no dependent load)
-        ci[a] = A.cp_stats[static_cast<uint64_t>(i) * kCpSlots + cp];
-        gi[a] = A.cp_stats[static_cast<uint64_t>(i) * kCpSlots + kCheckpoints];
-      }
-#pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        const uint32_t d = dw0 + ty + 8 * a;
-        if (d <= span_j) {
-          const double dot_p = static_cast<double>(static_cast<int32_t>(hh[a][b] - 2 * xx[a][b]));
-          const double c0 = fma(N, dot_p, fma(ci[a].a, cj.a, -(gi[a].a * gj.a)));
-          const double bound = fabs(c0) + fma(ci[a].b, cj.b, 1.0);
-          hopeless[a] = hopeless[a] && (bound < gi[a].b * gj.b);
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // units are ordered by distance and LD decays with it: drop the hopeless far end, keep everything nearer than
-  // the farthest unit that still has a live pair
-  uint32_t live = 0;
-#pragma unroll
-  for (int a = 0; a < NA; ++a) {
-    if (!__all(hopeless[a])) {
-      live = a + 1;
-    }
-  }
-  return live;
+// the +1 and the 1e-6 folded into t dwarf every FP64 rounding error here).
+__device__ __forceinline__ bool pair_hopeless(const PairKernelArgs& A, const uint32_t (&c)[2], const cp_slot& ci, const cp_slot& gi, const cp_slot& cj,
+                                              const cp_slot& gj) {
+  const double dot_p = static_cast<double>(static_cast<int32_t>(c[0] - 2 * c[1]));
+  const double c0 = fma(static_cast<double>(A.founder_ct), dot_p, fma(ci.a, cj.a, -(gi.a * gj.a)));
+  const double bound = fabs(c0) + fma(ci.b, cj.b, 1.0);
+  return bound < gi.b * gj.b;
 }
 
-// The same question for tiles with missing calls (general path, 7 partial counts per pair).  The final statistics
-// run over the pairwise-complete samples C = C_P + C_R; everything over the visited part C_P is known exactly, and
-// C_R is what is left of each variant's own called samples in the remainder R after dropping the (unknown) ones
-// where the partner is missing -- at most min(partner's missing calls in R, own calls in R) of them.  In z = 1 - x
-// (all quantities >= 0; r^2 is invariant under the recoding):
+// The same question for tiles with missing calls (7 partial counts per pair).  The final statistics run over the
+// pairwise-complete samples C = C_P + C_R; everything over the visited part C_P is known exactly, and C_R is what is
+// left of each variant's own called samples in the remainder R after dropping the (unknown) ones where the partner
+// is missing -- at most min(partner's missing calls in R, own calls in R) of them.  In z = 1 - x (all quantities
+// >= 0; r^2 is invariant under the recoding):
 //   n   in [n_P + max(nR_i - dmax_i, nR_j - dmax_j), n_P + min(nR_i, nR_j)]
 //   Zs  in [Zs_P + a_i - min(2 dmax_i, a_i), Zs_P + a_i]       Zq >= Zq_P + b_i - min(4 dmax_i, b_i)     (same for w)
 //   ZW  in ZW_P + a_i a_j / |R| +- sqrt((b_i - a_i^2/|R|)(b_j - a_j^2/|R|))   (Cauchy-Schwarz on R, missing = 0), ZW >= ZW_P
@@ -878,60 +751,94 @@ __device__ __forceinline__ uint32_t wave_live_units(const PairKernelArgs& A, uin
 // (cmax + 1)^2 (1 + 1e-6) < thresh var1_lo var2_lo (1 - 1e-6).  Worst case (a rare variant whose remaining carriers
 // could all coincide with the partner's missing calls) the variance bound falls back to what the visited samples
 // alone guarantee, so such pairs terminate later, never wrongly.
-template <int NA>
-__device__ __forceinline__ uint32_t general_live_units(const PairKernelArgs& A, uint32_t j0, uint32_t jend, uint32_t d_first, int tx, int ty, uint32_t b,
-                                                       const uint32_t (&acc)[kMaxUnitsPerBlock][7], uint32_t cp) {
+__device__ __forceinline__ bool pair_hopeless(const PairKernelArgs& A, const uint32_t (&c)[7], const cp_gen_slot& gi, const cp_gen_slot& gj, double rs) {
+  // visited part, exact
+  const double n_p = c[2];
+  const double s1 = 2.0 * c[6] - static_cast<double>(c[5]), q1 = c[5];
+  const double s2 = 2.0 * c[4] - static_cast<double>(c[3]), q2 = c[3];
+  const double dot = static_cast<double>(c[0]) - 2.0 * c[1];
+  const double zs_p = n_p - s1, zq_p = n_p - 2.0 * s1 + q1;
+  const double ws_p = n_p - s2, wq_p = n_p - 2.0 * s2 + q2;
+  const double zw_p = n_p - s1 - s2 + dot;
+  // remainder
+  const double nr_i = gi.nm_r, a_i = gi.zs_r, b_i = gi.zq_r;
+  const double nr_j = gj.nm_r, a_j = gj.zs_r, b_j = gj.zq_r;
+  const double dmax_i = fmin(rs - nr_j, nr_i);
+  const double dmax_j = fmin(rs - nr_i, nr_j);
+  const double n_lo = n_p + fmax(nr_i - dmax_i, nr_j - dmax_j);
+  const double n_hi = n_p + fmin(nr_i, nr_j);
+  const double zs_hi = zs_p + a_i, zs_lo = zs_hi - fmin(2.0 * dmax_i, a_i);
+  const double ws_hi = ws_p + a_j, ws_lo = ws_hi - fmin(2.0 * dmax_j, a_j);
+  const double zq_lo = zq_p + b_i - fmin(4.0 * dmax_i, b_i);
+  const double wq_lo = wq_p + b_j - fmin(4.0 * dmax_j, b_j);
+  const double centre = a_i * a_j / rs;
+  const double spread = sqrt(fmax(b_i - a_i * a_i / rs, 0.0) * fmax(b_j - a_j * a_j / rs, 0.0)) * (1.0 + 1e-9);
+  const double zw_hi = zw_p + centre + spread;
+  const double zw_lo = fmax(zw_p, zw_p + centre - spread);
+  const double cov_hi = n_hi * zw_hi - zs_lo * ws_lo;
+  const double cov_lo = n_lo * zw_lo - zs_hi * ws_hi;
+  const double cmax = fmax(fabs(cov_hi), fabs(cov_lo)) + 1.0;
+  const double var1_lo = n_lo * zq_lo - zs_hi * zs_hi;
+  const double var2_lo = n_lo * wq_lo - ws_hi * ws_hi;
+  return (var1_lo > 0.0) && (var2_lo > 0.0) && (cmax * cmax * (1.0 + 1e-6) < A.thresh * (1.0 - 1e-6) * var1_lo * var2_lo);
+}
+
+// How many of the wave's NA units (nearest first) must stay live after checkpoint cp: everything up to the farthest
+// unit that still has a pair that could reach the threshold (LD decays with distance: the far end goes first).
+template <bool GENERAL, int NA>
+__device__ __forceinline__ uint32_t live_units(const PairKernelArgs& A, uint32_t j0, uint32_t jend, uint32_t d_first, int tx, int ty, uint32_t b,
+                                               const uint32_t (&acc)[kMaxUnitsPerBlock][Counts<GENERAL>::n], uint32_t cp) {
   bool hopeless[NA];
 #pragma unroll
   for (int a = 0; a < NA; ++a) {
     hopeless[a] = true;
   }
-  const uint64_t seen = static_cast<uint64_t>(A.checkpoint_chunk[cp]) * (kChunkDwords * 32);
-  const double rs = static_cast<double>(A.founder_ct - static_cast<uint32_t>(seen));  // |R| (checkpoints lie inside the row)
-  const double thr = A.thresh * (1.0 - 1e-6);
-  const uint32_t j = j0 + tx + 8 * b;
+  uint32_t j = j0 + tx + 8 * b;
+  asm volatile("" : "+v"(j));  // (keeps the units' address arithmetic inside the checkpoint instead of hoisted into long-lived registers)
   if (j < jend) {
     const uint32_t span_j = j - A.lo[j];
-    const cp_gen_slot gj = A.cp_gen[static_cast<uint64_t>(j) * kCheckpoints + cp];
-    const double nr_j = gj.nm_r, a_j = gj.zs_r, b_j = gj.zq_r;
-    const double var_r_j = fmax(b_j - a_j * a_j / rs, 0.0);
+    // four units' records per round trip to memory (one latency per group, few registers)
+    if constexpr (GENERAL) {
+      const uint64_t seen = static_cast<uint64_t>(A.checkpoint_chunk[cp]) * (kChunkDwords * 32);
+      const double rs = static_cast<double>(A.founder_ct - static_cast<uint32_t>(seen));  // |R| (checkpoints lie inside the row)
+      const cp_gen_slot gj = A.cp_gen[static_cast<uint64_t>(j) * kCheckpoints + cp];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {
-      const uint32_t d = d_first + ty + 8 * a;
-      if (d <= span_j) {
-        const cp_gen_slot gi = A.cp_gen[static_cast<uint64_t>(j - d) * kCheckpoints + cp];
-        const uint32_t* c = acc[a];
-        // visited part, exact
-        const double n_p = c[2];
-        const double s1 = 2.0 * c[6] - static_cast<double>(c[5]), q1 = c[5];
-        const double s2 = 2.0 * c[4] - static_cast<double>(c[3]), q2 = c[3];
-        const double dot = static_cast<double>(c[0]) - 2.0 * c[1];
-        const double zs_p = n_p - s1, zq_p = n_p - 2.0 * s1 + q1;
-        const double ws_p = n_p - s2, wq_p = n_p - 2.0 * s2 + q2;
-        const double zw_p = n_p - s1 - s2 + dot;
-        // remainder
-        const double nr_i = gi.nm_r, a_i = gi.zs_r, b_i = gi.zq_r;
-        const double dmax_i = fmin(rs - nr_j, nr_i);
-        const double dmax_j = fmin(rs - nr_i, nr_j);
-        const double n_lo = n_p + fmax(nr_i - dmax_i, nr_j - dmax_j);
-        const double n_hi = n_p + fmin(nr_i, nr_j);
-        const double zs_hi = zs_p + a_i, zs_lo = zs_hi - fmin(2.0 * dmax_i, a_i);
-        const double ws_hi = ws_p + a_j, ws_lo = ws_hi - fmin(2.0 * dmax_j, a_j);
-        const double zq_lo = zq_p + b_i - fmin(4.0 * dmax_i, b_i);
-        const double wq_lo = wq_p + b_j - fmin(4.0 * dmax_j, b_j);
-        const double centre = a_i * a_j / rs;
-        const double spread = sqrt(fmax(b_i - a_i * a_i / rs, 0.0) * var_r_j) * (1.0 + 1e-9);
-        const double zw_hi = zw_p + centre + spread;
-        const double zw_lo = fmax(zw_p, zw_p + centre - spread);
-        const double cov_hi = n_hi * zw_hi - zs_lo * ws_lo;
-        const double cov_lo = n_lo * zw_lo - zs_hi * ws_hi;
-        const double cmax = fmax(fabs(cov_hi), fabs(cov_lo)) + 1.0;
-        const double var1_lo = n_lo * zq_lo - zs_hi * zs_hi;
-        const double var2_lo = n_lo * wq_lo - ws_hi * ws_hi;
-        const bool h = (var1_lo > 0.0) && (var2_lo > 0.0) && (cmax * cmax * (1.0 + 1e-6) < thr * var1_lo * var2_lo);
-        hopeless[a] = hopeless[a] && h;
+      for (int a0 = 0; a0 < NA; a0 += 4) {
+        cp_gen_slot gi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t d = d_first + ty + 8 * (a0 + q);
+          gi[q] = A.cp_gen[static_cast<uint64_t>((d <= j) ? (j - d) : 0) * kCheckpoints + cp];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if ((a0 + q < NA) && (d_first + ty + 8 * (a0 + q) <= span_j)) {
+            hopeless[(a0 + q < NA) ? a0 + q : 0] = hopeless[(a0 + q < NA) ? a0 + q : 0] && pair_hopeless(A, acc[(a0 + q < NA) ? a0 + q : 0], gi[q], gj, rs);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      const cp_slot cj = A.cp_stats[static_cast<uint64_t>(j) * kCpSlots + cp];
+      const cp_slot gj = A.cp_stats[static_cast<uint64_t>(j) * kCpSlots + kCheckpoints];
+#pragma unroll
+      for (int a0 = 0; a0 < NA; a0 += 4) {
+        cp_slot ci[4], gi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t d = d_first + ty + 8 * (a0 + q);
+          const uint64_t i = (d <= j) ? (j - d) : 0;
+          ci[q] = A.cp_stats[i * kCpSlots + cp];
+          gi[q] = A.cp_stats[i * kCpSlots + kCheckpoints];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if ((a0 + q < NA) && (d_first + ty + 8 * (a0 + q) <= span_j)) {
+            hopeless[(a0 + q < NA) ? a0 + q : 0] = hopeless[(a0 + q < NA) ? a0 + q : 0] && pair_hopeless(A, acc[(a0 + q < NA) ? a0 + q : 0], ci[q], gi[q], cj, gj);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
   uint32_t live = 0;
@@ -953,12 +860,7 @@ __global__ __launch_bounds__(256) void classify_items_kernel(PairKernelArgs A) {
     return;
   }
   const WorkItem it = A.items[item_idx];
-  uint32_t units_total = 0;
-#pragma unroll
-  for (uint32_t w = 0; w < kWavesPerBlock; ++w) {
-    units_total += (it.units >> (8 * w)) & 0xff;
-  }
-  const TileGeom G = make_geom(it, units_total);
+  const TileGeom G = make_geom(it, it.units);
   int miss = 0;
   uint32_t missing_calls = 0;
   for (int r = lane; r < G.rtot; r += 64) {
@@ -976,62 +878,46 @@ __global__ __launch_bounds__(256) void classify_items_kernel(PairKernelArgs A) {
   }
 }
 
-// Epilogue staging: accumulators go through LDS ([counter][thread]) so the per-pair decision code runs
-// as a rolled loop with a handful of live registers instead of 16 unrolled copies.
-constexpr int kEpilogueLdsDwords = ((8 * kMaxUnitsPerWave > 28) ? 8 * kMaxUnitsPerWave : 28) * kBlockThreads;  // 28 = the general path
+// Epilogue staging: accumulators go through LDS ([counter][thread]) so the per-pair decision code runs as a rolled
+// loop with a handful of live registers instead of one unrolled copy per unit; four units at a time.
+constexpr int kEpilogueLdsDwords = 4 * 7 * kBlockThreads;
 
-// The k-loop between two checkpoints, one instantiation per (mode, live units).  The dispatch sits OUTSIDE the
-// chunk loop on purpose: with it inside, the register allocator gives every case its own homes for the
-// accumulators and pays for that with ~100 v_mov per chunk (measured: 19 % of all VALU instructions).
-template <bool COLUMN, int NA>
+// The k-loop between two checkpoints, one instantiation per unit count.  The dispatch sits OUTSIDE the chunk loop on
+// purpose: with it inside, the register allocator gives every case its own homes for the accumulators and pays for
+// that with ~100 v_mov per chunk (measured: 19 % of all VALU instructions).
+template <bool GENERAL, int NA>
 __device__ __forceinline__ void run_chunks(Ring& R, const Stager& st, uint32_t* lds, uint32_t kc_end, uint32_t chunks, uint32_t wave, uint32_t lane,
-                                           int jrow, int irow0, uint32_t (&hh)[kMaxUnitsPerWave][4], uint32_t (&xx)[kMaxUnitsPerWave][4]) {
+                                           int jrow, int irow, uint32_t (&acc)[kMaxUnitsPerBlock][Counts<GENERAL>::n]) {
   while (R.kc < kc_end) {
     const uint4* l4 = ring_acquire(R, st, lds, chunks, wave, lane);
     if constexpr (NA > 0) {
-      if constexpr (COLUMN) {
-        tile_chunk_column<NA>(l4, jrow, irow0, hh, xx);
-      } else {
-        tile_chunk_fast<NA>(l4, jrow, irow0, hh, xx);
-      }
+      tile_chunk<GENERAL, NA>(l4, jrow, irow, acc);
     }
     ring_release(R, st);
   }
 }
 
-template <int NA>
-__device__ __forceinline__ void run_chunks_general(Ring& R, const Stager& st, uint32_t* lds, uint32_t kc_end, uint32_t chunks, uint32_t wave, uint32_t lane,
-                                                   int jrow, int irow, uint32_t (&acc)[kMaxUnitsPerBlock][7]) {
-  while (R.kc < kc_end) {
-    const uint4* l4 = ring_acquire(R, st, lds, chunks, wave, lane);
-    if constexpr (NA > 0) {
-      tile_chunk_general<NA>(l4, jrow, irow, acc);
-    }
-    ring_release(R, st);
-  }
-}
-
-// (a switch over NA = 1 .. kMaxUnitsPerBlock with one k-loop instantiation per case, cf. run_chunks)
-template <int NA>
-__device__ __forceinline__ void dispatch_general_run(uint32_t live, Ring& R, const Stager& st, uint32_t* lds, uint32_t kc_end, uint32_t chunks, uint32_t wave,
-                                                     uint32_t lane, int jrow, int irow, uint32_t (&acc)[kMaxUnitsPerBlock][7]) {
+// (a switch over NA = 1 .. kMaxUnitsPerBlock)
+template <bool GENERAL, int NA>
+__device__ __forceinline__ void dispatch_run(uint32_t live, Ring& R, const Stager& st, uint32_t* lds, uint32_t kc_end, uint32_t chunks, uint32_t wave,
+                                             uint32_t lane, int jrow, int irow, uint32_t (&acc)[kMaxUnitsPerBlock][Counts<GENERAL>::n]) {
   if constexpr (NA <= kMaxUnitsPerBlock) {
     if (live == static_cast<uint32_t>(NA)) {
-      run_chunks_general<NA>(R, st, lds, kc_end, chunks, wave, lane, jrow, irow, acc);
+      run_chunks<GENERAL, NA>(R, st, lds, kc_end, chunks, wave, lane, jrow, irow, acc);
     } else {
-      dispatch_general_run<NA + 1>(live, R, st, lds, kc_end, chunks, wave, lane, jrow, irow, acc);
+      dispatch_run<GENERAL, NA + 1>(live, R, st, lds, kc_end, chunks, wave, lane, jrow, irow, acc);
     }
   }
 }
 
-template <int NA>
-__device__ __forceinline__ uint32_t dispatch_general_live(uint32_t live, const PairKernelArgs& A, uint32_t j0, uint32_t jend, uint32_t d_first, int tx, int ty,
-                                                          uint32_t b, const uint32_t (&acc)[kMaxUnitsPerBlock][7], uint32_t cp) {
+template <bool GENERAL, int NA>
+__device__ __forceinline__ uint32_t dispatch_live(uint32_t live, const PairKernelArgs& A, uint32_t j0, uint32_t jend, uint32_t d_first, int tx, int ty,
+                                                  uint32_t b, const uint32_t (&acc)[kMaxUnitsPerBlock][Counts<GENERAL>::n], uint32_t cp) {
   if constexpr (NA <= kMaxUnitsPerBlock) {
     if (live == static_cast<uint32_t>(NA)) {
-      return general_live_units<NA>(A, j0, jend, d_first, tx, ty, b, acc, cp);
+      return live_units<GENERAL, NA>(A, j0, jend, d_first, tx, ty, b, acc, cp);
     }
-    return dispatch_general_live<NA + 1>(live, A, j0, jend, d_first, tx, ty, b, acc, cp);
+    return dispatch_live<GENERAL, NA + 1>(live, A, j0, jend, d_first, tx, ty, b, acc, cp);
   } else {
     return live;
   }
@@ -1039,6 +925,7 @@ __device__ __forceinline__ uint32_t dispatch_general_live(uint32_t live, const P
 
 template <bool GENERAL>
 __global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_kernel(PairKernelArgs A) {
+  constexpr int kCounts = Counts<GENERAL>::n;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_live[kWavesPerBlock];
   __shared__ uint32_t s_src_off[kMaxDmaPerWave * kBlockThreads];
@@ -1049,7 +936,8 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_ker
   if (item_idx >= A.n_items) {
     return;
   }
-  if ((A.item_general[item_idx] != 0) != GENERAL) {
+  const uint32_t item_class = A.item_general[item_idx];  // classify_items_kernel: 0 complete, 1 / 2 missing calls
+  if ((item_class != 0) != GENERAL) {
     return;
   }
   const WorkItem it = A.items[item_idx];
@@ -1059,326 +947,118 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_ker
   const uint32_t lane = tid & 63;
   const int tx = lane & 7;
   const int ty = lane >> 3;
+  const int col = tx + 8 * static_cast<int>(wave);  // this lane's second variant within the J-tile
 
-  uint32_t units_total = 0, units_before = 0, units_max = 0;
+  uint32_t acc[kMaxUnitsPerBlock][kCounts];
 #pragma unroll
-  for (uint32_t w = 0; w < kWavesPerBlock; ++w) {
-    const uint32_t u = (it.units >> (8 * w)) & 0xff;
-    if (w < wave) {
-      units_before += u;
+  for (int a = 0; a < kMaxUnitsPerBlock; ++a) {
+#pragma unroll
+    for (int q = 0; q < kCounts; ++q) {
+      acc[a][q] = 0;
     }
-    units_total += u;
-    units_max = (u > units_max) ? u : units_max;
   }
-  const uint32_t units_w = (it.units >> (8 * wave)) & 0xff;
-  const uint32_t dw0 = it.d0 + 8 * units_before;  // first distance of this wave
-
-  TileGeom G = make_geom(it, units_total);
+  uint32_t live = it.units;    // units this wave still accumulates (nearest first; wave-uniform)
+  uint32_t staged = it.units;  // units the block still stages (block-uniform)
+  TileGeom G = make_geom(it, staged);
   Stager st;
   st.src_off = s_src_off;
   plan_stager(st, G, A, wave, lane);
-  int jrow = G.jrow_base + tx;
-  // I-row of (b = 0, a = 0): variant j0 + tx - (dw0 + ty)
-  int irow0 = G.dmax + tx - static_cast<int>(dw0) - ty;
+  int jrow = G.jrow_base + col;
+  int irow = G.dmax + col - static_cast<int>(it.d0) - ty;  // I-row of unit 0: variant j - (d0 + ty)
   Ring R;
-  uint32_t n_true = 0;  // predicates this thread found true
-
-  if constexpr (!GENERAL) {
-    uint32_t hh[kMaxUnitsPerWave][4], xx[kMaxUnitsPerWave][4];
-#pragma unroll
-    for (int a = 0; a < kMaxUnitsPerWave; ++a) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        hh[a][b] = 0;
-        xx[a][b] = 0;
-      }
+  uint32_t next_cp = 0;
+  // checkpoints: off for inspection / r^2 runs (cp_stats null) and for tiles where missing calls are too dense for
+  // the interval bound to ever fire (class 2)
+  const uint32_t n_cp = (A.cp_stats && (item_class != 2)) ? A.n_checkpoints : 0;
+  ring_start(R, st, lds, 0, A.chunks, wave, lane);
+  while (R.kc < A.chunks) {
+    // run to the next checkpoint (or to the end of the rows)
+    const bool cp_ahead = (next_cp < n_cp);  // block-uniform
+    const uint32_t kc_end = cp_ahead ? A.checkpoint_chunk[next_cp] : A.chunks;  // checkpoints are < chunks
+    if (live) {
+      dispatch_run<GENERAL, 1>(live, R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow, acc);
+    } else {
+      run_chunks<GENERAL, 0>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow, acc);  // (still stages its share)
     }
-    // Row mode (start): the wave owns `live` contiguous units from distance dw0, all four second-variant groups.
-    // Column mode (see below): the wave owns group b = wave of the block's first `live` units (from distance d0).
-    uint32_t live = units_w;          // distance units this wave still accumulates (wave-uniform)
-    uint32_t staged = units_total;    // distance units of the block still staged (block-uniform)
-    bool column = false;              // block-uniform
-    uint32_t dist0 = dw0;             // first distance this wave owns
-    uint32_t next_cp = 0;
-    const uint32_t n_cp = A.cp_stats ? A.n_checkpoints : 0;
-#ifdef LDP_DEBUG_PHASE_CLOCKS
-    const uint64_t t_begin = __builtin_readcyclecounter();
-    uint64_t t_switch = 0;
-    uint32_t kc_switch = 0;
-#endif
-    ring_start(R, st, lds, 0, A.chunks, wave, lane);
-    while (R.kc < A.chunks) {
-      // run to the next checkpoint (or to the end of the rows)
-      const bool cp_ahead = (next_cp < n_cp);  // block-uniform
-      const uint32_t kc_end = cp_ahead ? A.checkpoint_chunk[next_cp] : A.chunks;  // checkpoints are < chunks
-      if (!column) {
-        switch (live) {
-          case 0: run_chunks<false, 0>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow0, hh, xx); break;
-          case 1: run_chunks<false, 1>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow0, hh, xx); break;
-          case 2: run_chunks<false, 2>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow0, hh, xx); break;
-          case 3: run_chunks<false, 3>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow0, hh, xx); break;
-#if LDP_MAX_UNITS_PER_WAVE >= 4
-          case 4: run_chunks<false, 4>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow0, hh, xx); break;
-#endif
-          default: break;
-        }
-      } else {
-        switch (live) {
-          case 0: run_chunks<true, 0>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow0, hh, xx); break;
-          case 1: run_chunks<true, 1>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow0, hh, xx); break;
-          case 2: run_chunks<true, 2>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow0, hh, xx); break;
-          case 3: run_chunks<true, 3>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow0, hh, xx); break;
-#if LDP_MAX_UNITS_PER_WAVE >= 4
-          case 4: run_chunks<true, 4>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow0, hh, xx); break;
-#endif
-          default: break;
-        }
-      }
-      const bool at_cp = cp_ahead;
-      if (at_cp) {
-        if (live) {
-          uint32_t keep = live;
-          if (!column) {
-            switch (live) {
-              case 1: keep = wave_live_units<1, 4>(A, it.j0, it.jend, dist0, tx, ty, 0, hh, xx, next_cp); break;
-              case 2: keep = wave_live_units<2, 4>(A, it.j0, it.jend, dist0, tx, ty, 0, hh, xx, next_cp); break;
-              case 3: keep = wave_live_units<3, 4>(A, it.j0, it.jend, dist0, tx, ty, 0, hh, xx, next_cp); break;
-#if LDP_MAX_UNITS_PER_WAVE >= 4
-              case 4: keep = wave_live_units<4, 4>(A, it.j0, it.jend, dist0, tx, ty, 0, hh, xx, next_cp); break;
-#endif
-              default: break;
-            }
-          } else {
-            switch (live) {
-              case 1: keep = wave_live_units<1, 1>(A, it.j0, it.jend, dist0, tx, ty, wave, hh, xx, next_cp); break;
-              case 2: keep = wave_live_units<2, 1>(A, it.j0, it.jend, dist0, tx, ty, wave, hh, xx, next_cp); break;
-              case 3: keep = wave_live_units<3, 1>(A, it.j0, it.jend, dist0, tx, ty, wave, hh, xx, next_cp); break;
-#if LDP_MAX_UNITS_PER_WAVE >= 4
-              case 4: keep = wave_live_units<4, 1>(A, it.j0, it.jend, dist0, tx, ty, wave, hh, xx, next_cp); break;
-#endif
-              default: break;
-            }
-          }
-          if (keep != live) {
-            // every pair of the dropped units is provably below the threshold (counter in quarter units x chunks)
-            if (lane == 0) {
-              atomicAdd(A.counters + 1, static_cast<unsigned long long>(A.chunks - R.kc) * (live - keep) * (column ? 1 : 4));
-            }
-            live = __builtin_amdgcn_readfirstlane(keep);
-          }
-        }
-        ++next_cp;
-        // how much of the distance range does the block still need?
-        if (lane == 0) {
-          s_live[wave] = live;
-        }
-        __syncthreads();  // (a full fence: this wave's queued chunks have landed, too)
-        uint32_t need = 0;
-        bool prefix = true;  // do the live units form the block's first `need` units exactly?
-        {
-          uint32_t before = 0;
-#pragma unroll
-          for (uint32_t w = 0; w < kWavesPerBlock; ++w) {
-            const uint32_t lw = s_live[w];
-            const uint32_t uw = column ? lw : ((it.units >> (8 * w)) & 0xff);
-            const uint32_t first = column ? 0 : before;
-            if (lw) {
-              prefix = prefix && (first <= need);  // no dropped unit between the previous waves' and this one's
-              need = (first + lw > need) ? first + lw : need;
-            }
-            before += uw;
-          }
-        }
-        if (!need) {
-          break;  // nothing left that could reach the threshold
-        }
-        bool replan = (need < staged);
-        if ((!column) && (need <= static_cast<uint32_t>(kMaxUnitsPerWave)) && (need < units_total) && prefix) {
-          // Re-deal: what is left is the block's first `need` units.  Hand every wave one second-variant group of
-          // all of them (column mode), partial sums travelling through the (idle) staging area: the four waves,
-          // hence the four SIMDs, then share the remaining work evenly, whichever wave owned the near units.
-#pragma unroll
-          for (int a = 0; a < kMaxUnitsPerWave; ++a) {
-            if (static_cast<uint32_t>(a) < live) {
-              const uint32_t u = units_before + a;
-#pragma unroll
-              for (int bb = 0; bb < 4; ++bb) {
-                const uint32_t base = ((u * 4 + bb) * 2) * 64 + lane;
-                lds[base] = hh[a][bb];
-                lds[base + 64] = xx[a][bb];
-              }
-            }
-          }
-          __syncthreads();
-#pragma unroll
-          for (int a = 0; a < kMaxUnitsPerWave; ++a) {
-            const uint32_t base = ((a * 4 + wave) * 2) * 64 + lane;
-            hh[a][0] = (static_cast<uint32_t>(a) < need) ? lds[base] : 0;
-            xx[a][0] = (static_cast<uint32_t>(a) < need) ? lds[base + 64] : 0;
-          }
-          __syncthreads();  // the scratch is staging area again from here
-          column = true;
-          live = need;
-          dist0 = it.d0;
-          replan = true;
-#ifdef LDP_DEBUG_PHASE_CLOCKS
-          t_switch = __builtin_readcyclecounter();
-          kc_switch = R.kc;
-#endif
-        }
-        if (replan) {
-          // shrink the tile to the units still live: fewer rows per chunk, more chunks in flight.  Every wave is
-          // past the barrier and none has outstanding DMA, so the ring can simply be restarted at the next chunk.
-          staged = need;
-          G = make_geom(it, staged);
-          plan_stager(st, G, A, wave, lane);
-          const int col = column ? 8 * static_cast<int>(wave) : 0;
-          jrow = G.jrow_base + tx + col;
-          irow0 = G.dmax + tx + col - static_cast<int>(dist0) - ty;
-          ring_start(R, st, lds, R.kc, A.chunks, wave, lane);
-        }
-      }
-    }
-#ifdef LDP_DEBUG_PHASE_CLOCKS
-    {
-      const uint64_t t_loop_end = __builtin_readcyclecounter();
-      if ((tid == 0) && t_switch) {
-        atomicAdd(A.counters + 2, static_cast<unsigned long long>(t_switch - t_begin));
-        atomicAdd(A.counters + 3, static_cast<unsigned long long>(t_loop_end - t_switch));
-      }
-    }
-#endif
-    __syncthreads();  // staging is over: LDS becomes the epilogue's scratch
-    // accumulators of the tiles this wave owns, p-th tile = (unit a, group b)
-#pragma unroll
-    for (int a = 0; a < kMaxUnitsPerWave; ++a) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        lds[(2 * (a * 4 + b)) * kBlockThreads + tid] = hh[a][b];
-        lds[(2 * (a * 4 + b) + 1) * kBlockThreads + tid] = xx[a][b];
-      }
-    }
-    const uint32_t n_tiles = column ? live : 4 * live;  // pairs of dropped units are all below the threshold
-#pragma unroll 1
-    for (uint32_t p = 0; p < n_tiles; ++p) {
-      const uint32_t a = column ? p : (p >> 2), b = column ? wave : (p & 3);
-      const uint32_t slot = column ? (4 * p) : p;  // (a, 0) in column mode
-      const uint32_t j = it.j0 + tx + 8 * b;
-      const uint32_t d = dist0 + ty + 8 * a;
-      if (j >= it.jend) {
-        continue;
-      }
-      const uint32_t lo_j = A.lo[j];
-      if (d > j - lo_j) {
-        continue;
-      }
-      const uint32_t i = j - d;
-      ldp_pair_stats_t ps;
-      ps.nm = A.founder_ct;
-      ps.sum1 = A.recs[i].sum;
-      ps.ssq1 = A.recs[i].ssq;
-      ps.sum2 = A.recs[j].sum;
-      ps.ssq2 = A.recs[j].ssq;
-      ps.dot = static_cast<int32_t>(lds[(2 * slot) * kBlockThreads + tid]) - 2 * static_cast<int32_t>(lds[(2 * slot + 1) * kBlockThreads + tid]);
-      n_true += emit_pair(A, i, j, lo_j, ps) ? 1 : 0;
-    }
-  } else {
-    // general path, column layout (see tile_chunk_general): wave w = second-variant group b = w of every unit
-    uint32_t acc[kMaxUnitsPerBlock][7];
-#pragma unroll
-    for (int a = 0; a < kMaxUnitsPerBlock; ++a) {
-#pragma unroll
-      for (int q = 0; q < 7; ++q) {
-        acc[a][q] = 0;
-      }
-    }
-    (void)units_w;
-    (void)units_max;
-    (void)dw0;
-    (void)irow0;
-    uint32_t live = units_total;    // units this wave still accumulates (nearest first; wave-uniform)
-    uint32_t staged = units_total;  // block-uniform
-    jrow = G.jrow_base + tx + 8 * static_cast<int>(wave);
-    int irow = G.dmax + tx + 8 * static_cast<int>(wave) - static_cast<int>(it.d0) - ty;  // I-row of unit 0
-    uint32_t next_cp = 0;
-    const uint32_t n_cp = (A.cp_gen && (A.item_general[item_idx] == 1)) ? A.n_checkpoints : 0;
-    ring_start(R, st, lds, 0, A.chunks, wave, lane);
-    while (R.kc < A.chunks) {
-      const bool cp_ahead = (next_cp < n_cp);  // block-uniform
-      const uint32_t kc_end = cp_ahead ? A.checkpoint_chunk[next_cp] : A.chunks;
+    if (cp_ahead) {
       if (live) {
-        dispatch_general_run<1>(live, R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow, acc);
-      } else {
-        run_chunks_general<0>(R, st, lds, kc_end, A.chunks, wave, lane, jrow, irow, acc);
-      }
-      if (cp_ahead) {
-        if (live) {
-          const uint32_t keep = dispatch_general_live<1>(live, A, it.j0, it.jend, it.d0, tx, ty, wave, acc, next_cp);
-          if (keep != live) {
-            if (lane == 0) {
-              atomicAdd(A.counters + 1, static_cast<unsigned long long>(A.chunks - R.kc) * (live - keep));
-            }
-            live = __builtin_amdgcn_readfirstlane(keep);
+        const uint32_t keep = dispatch_live<GENERAL, 1>(live, A, it.j0, it.jend, it.d0, tx, ty, wave, acc, next_cp);
+        if (keep != live) {
+          // every pair of the dropped units is provably below the threshold
+          if (lane == 0) {
+            atomicAdd(A.counters + 1, static_cast<unsigned long long>(A.chunks - R.kc) * (live - keep));
           }
+          live = __builtin_amdgcn_readfirstlane(keep);
         }
-        ++next_cp;
-        if (lane == 0) {
-          s_live[wave] = live;
-        }
-        __syncthreads();  // (a full fence: this wave's queued chunks have landed, too)
-        uint32_t need = 0;
+      }
+      ++next_cp;
+      // how much of the distance range does the block still need?
+      if (lane == 0) {
+        s_live[wave] = live;
+      }
+      __syncthreads();  // (a full fence: this wave's queued chunks have landed, too)
+      uint32_t need = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < kWavesPerBlock; ++w) {
-          need = (s_live[w] > need) ? s_live[w] : need;
-        }
-        __syncthreads();  // (s_live is rewritten at the next checkpoint)
-        if (!need) {
-          break;
-        }
-        if (need < staged) {
-          staged = need;
-          G = make_geom(it, staged);
-          plan_stager(st, G, A, wave, lane);
-          jrow = G.jrow_base + tx + 8 * static_cast<int>(wave);
-          irow = G.dmax + tx + 8 * static_cast<int>(wave) - static_cast<int>(it.d0) - ty;
-          ring_start(R, st, lds, R.kc, A.chunks, wave, lane);
-        }
+      for (uint32_t w = 0; w < kWavesPerBlock; ++w) {
+        need = (s_live[w] > need) ? s_live[w] : need;
+      }
+      __syncthreads();  // (s_live is rewritten at the next checkpoint)
+      if (!need) {
+        break;  // nothing left that could reach the threshold
+      }
+      if (need < staged) {
+        // shrink the tile to the units still live: fewer rows per chunk, more chunks in flight.  Every wave is past
+        // the barrier and none has outstanding DMA, so the ring can simply be restarted at the next chunk.
+        staged = need;
+        G = make_geom(it, staged);
+        plan_stager(st, G, A, wave, lane);
+        jrow = G.jrow_base + col;
+        irow = G.dmax + col - static_cast<int>(it.d0) - ty;
+        ring_start(R, st, lds, R.kc, A.chunks, wave, lane);
       }
     }
-    __syncthreads();  // staging is over: LDS becomes the epilogue's scratch
-    // four units at a time through LDS (28 dwords per thread), so the decision code stays a rolled loop
+  }
+  __syncthreads();  // staging is over: LDS becomes the epilogue's scratch
+  uint32_t n_true = 0;  // predicates this thread found true
+  const uint32_t j = it.j0 + col;
+  const uint32_t lo_j = (j < it.jend) ? A.lo[j] : 0;
 #pragma unroll
-    for (int a0 = 0; a0 < kMaxUnitsPerBlock; a0 += 4) {
-      if (static_cast<uint32_t>(a0) < live) {
+  for (int a0 = 0; a0 < kMaxUnitsPerBlock; a0 += 4) {
+    if (static_cast<uint32_t>(a0) < live) {  // (pairs of dropped units are all below the threshold)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
+      for (int a = 0; a < 4; ++a) {
 #pragma unroll
-          for (int q = 0; q < 7; ++q) {
-            lds[(a * 7 + q) * kBlockThreads + tid] = acc[(a0 + a < kMaxUnitsPerBlock) ? a0 + a : 0][q];
-          }
+        for (int q = 0; q < kCounts; ++q) {
+          lds[(a * kCounts + q) * kBlockThreads + tid] = acc[(a0 + a < kMaxUnitsPerBlock) ? a0 + a : 0][q];
         }
-        const uint32_t j = it.j0 + tx + 8 * wave;
-        if (j < it.jend) {
-          const uint32_t lo_j = A.lo[j];
+      }
+      if (j < it.jend) {
 #pragma unroll 1
-          for (uint32_t a = 0; (a < 4) && (a0 + a < live); ++a) {
-            const uint32_t d = it.d0 + ty + 8 * (a0 + a);
-            if (d > j - lo_j) {
-              continue;
-            }
-            const uint32_t i = j - d;
-            const uint32_t* c = lds + (a * 7) * kBlockThreads + tid;
-            const uint32_t c0 = c[0], c1 = c[kBlockThreads], c2 = c[2 * kBlockThreads], c3 = c[3 * kBlockThreads];
-            const uint32_t c4 = c[4 * kBlockThreads], c5 = c[5 * kBlockThreads], c6 = c[6 * kBlockThreads];
-            ldp_pair_stats_t ps;
+        for (uint32_t a = 0; (a < 4) && (a0 + a < live); ++a) {
+          const uint32_t d = it.d0 + ty + 8 * (a0 + a);
+          if (d > j - lo_j) {
+            continue;
+          }
+          const uint32_t i = j - d;
+          const uint32_t* c = lds + (a * kCounts) * kBlockThreads + tid;
+          ldp_pair_stats_t ps;
+          ps.dot = static_cast<int32_t>(c[0]) - 2 * static_cast<int32_t>(c[kBlockThreads]);
+          if constexpr (GENERAL) {
+            const uint32_t c2 = c[2 * kBlockThreads], c3 = c[3 * kBlockThreads], c4 = c[4 * kBlockThreads];
+            const uint32_t c5 = c[5 * kBlockThreads], c6 = c[6 * kBlockThreads];
             ps.nm = c2;
             ps.ssq2 = c3;
             ps.sum2 = static_cast<int32_t>(2 * c4 - c3);
             ps.ssq1 = c5;
             ps.sum1 = static_cast<int32_t>(2 * c6 - c5);
-            ps.dot = static_cast<int32_t>(c0) - 2 * static_cast<int32_t>(c1);
-            n_true += emit_pair(A, i, j, lo_j, ps) ? 1 : 0;
+          } else {
+            ps.nm = A.founder_ct;
+            ps.sum1 = A.recs[i].sum;
+            ps.ssq1 = A.recs[i].ssq;
+            ps.sum2 = A.recs[j].sum;
+            ps.ssq2 = A.recs[j].ssq;
           }
+          n_true += emit_pair(A, i, j, lo_j, ps) ? 1 : 0;
         }
       }
     }
