@@ -354,3 +354,23 @@ def test_early_termination_missing_calls_adversarial(gpu_pkg):
         assert np.array_equal(off, want)
         assert np.array_equal(on, want)
         assert c1["pred_true"] == c0["pred_true"]
+
+
+@pytest.mark.parametrize("miss", [0.0, 0.003])
+def test_early_termination_wide_window(gpu_pkg, miss):
+    """A 400-variant window: five blocks per J-tile, the far ones (their own second-variant rows, d0 >= 32) stop at the
+    first checkpoint and leave the k-loop as a whole; near ones shrink their tile."""
+    n, m = 3000, 1300
+    raw = T.synth_raw_codes(m, n, seed=71, missing_rate=miss)
+    chr_idx = np.zeros(m, dtype=np.uint32)
+    chr_idx[900:] = 1
+    bps = np.arange(m, dtype=np.uint32)
+    packed = T.pack_2bit(raw)
+    inv, mf, _ = T.oracle_prepare(raw)
+    want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 400, 7, False, 0.5, 2)
+    on, c1 = _run_early_exit(gpu_pkg, packed, n, chr_idx, bps, 400, 7, False, 0.5, 2, True)
+    off, c0 = _run_early_exit(gpu_pkg, packed, n, chr_idx, bps, 400, 7, False, 0.5, 2, False)
+    assert np.array_equal(off, want)
+    assert np.array_equal(on, want)
+    assert c1["pred_true"] == c0["pred_true"]
+    assert c1["early_exit_unit_chunks"] > 0.3 * c1["tile_unit_chunks"]
