@@ -374,3 +374,16 @@ def test_early_termination_wide_window(gpu_pkg, miss):
     assert np.array_equal(on, want)
     assert c1["pred_true"] == c0["pred_true"]
     assert c1["early_exit_unit_chunks"] > 0.3 * c1["tile_unit_chunks"]
+
+
+def test_randomised_differential(gpu_pkg):
+    """tools/fuzz_parity.py: 80 random shapes (chunk-boundary sample counts, count/kb windows, steps, both orders,
+    thresholds 0.02-0.95, 0-20 % missing, LD blocks, degenerate rows) against the oracle, early termination on."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(20260925)
+    for k in range(80):
+        ok, desc = fz.one_case(gpu_pkg, rng, k)
+        assert ok, desc
