@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Randomised end-to-end comparison on the GPU box: plink2-hip against the reference binary (oracle/_ref/plink2) on
+random small filesets -- .bed or fixed-width .pgen, chromosome 0 rows, non-founders, missing calls, kb / count windows,
+both scan orders -- for --indep-pairwise (.prune.in/.prune.out) and the --r2-unphased table (.vcor).  Files must be
+byte-identical.
+    python tools/fuzz_cli.py [--cases 40] [--seed 1]"""
+import argparse
+import filecmp
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import ldtools as T  # noqa: E402
+import __graft_entry__ as ge  # noqa: E402
+
+
+def run(cmd, cwd):
+    return subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+
+
+def one_case(cli, ref, rng, idx, tmp):
+    n = int(rng.choice([60, 97, 130, 513, 700]))
+    m = int(rng.integers(60, 500))
+    miss = float(rng.choice([0.0, 0.0, 0.01, 0.08]))
+    raw = T.synth_raw_codes(m, n, seed=int(rng.integers(1, 1 << 30)), missing_rate=miss)
+    for _ in range(m // 5):
+        a = int(rng.integers(1, m))
+        keep = rng.random(n) < 0.9
+        raw[a] = np.where(keep, raw[max(0, a - int(rng.integers(1, 6)))], raw[a])
+    n_zero = int(rng.integers(0, 4))
+    names = ["0"] * n_zero
+    chr_ct = int(rng.integers(1, 4))
+    per = np.sort(rng.integers(0, chr_ct, size=m - n_zero))
+    labels = [str(c) for c in rng.choice(np.arange(1, 23), size=chr_ct, replace=False)]
+    labels.sort(key=int)
+    names += [labels[c] for c in per]
+    pos = np.zeros(m, dtype=np.int64)
+    pos[:n_zero] = np.arange(n_zero) + 1
+    for c in range(chr_ct):
+        sel = np.where(per == c)[0] + n_zero
+        pos[sel] = np.sort(rng.integers(1, 80000, size=len(sel)))
+    d = os.path.join(tmp, "c%d" % idx)
+    os.makedirs(d)
+    use_bed = bool(rng.random() < 0.5)
+    if use_bed:
+        T.write_bed(os.path.join(d, "d"), raw, names, pos)
+        inp = ["--bfile", "d"]
+    else:
+        T.write_pgen_fixed(os.path.join(d, "d"), raw, names, pos)
+        inp = ["--pfile", "d"]
+    if rng.random() < 0.6:
+        if rng.random() < 0.5:
+            win = ["%gkb" % float(rng.choice([0.5, 2, 7.5, 20]))]
+        else:
+            w = int(rng.integers(2, 120))
+            win = [str(w), str(int(rng.integers(1, max(2, w))))]
+        args = inp + ["--indep-pairwise"] + win + [str(rng.choice([0.1, 0.2, 0.3, 0.5, 0.8])), "--indep-order", str(int(rng.integers(1, 3)))]
+        if n < 50:
+            args.append("--bad-ld")
+        outs = [".prune.in", ".prune.out"]
+    else:
+        args = inp + ["--r2-unphased", "--ld-window-kb", str(rng.choice([1, 5, 30])), "--ld-window-r2", str(rng.choice([0, 0.05, 0.2, 0.6]))]
+        if rng.random() < 0.5:
+            args += ["--ld-window", str(int(rng.integers(2, 40)))]
+        outs = [".vcor"]
+    r = run([ref] + args + ["--out", "ref"], d)
+    g = run([cli] + args + ["--out", "hip"], d)
+    if r.returncode != g.returncode and not (r.returncode != 0 and g.returncode != 0):
+        return False, "case %d: exit codes differ (ref %d, hip %d): %s\n%s" % (idx, r.returncode, g.returncode, " ".join(args), g.stdout[-400:])
+    if r.returncode != 0:
+        return True, "case %d: both refuse (%s)" % (idx, " ".join(args))
+    for e in outs:
+        if not filecmp.cmp(os.path.join(d, "ref" + e), os.path.join(d, "hip" + e), shallow=False):
+            return False, "case %d: %s differs: %s (n=%d m=%d miss=%g %s)" % (idx, e, " ".join(args), n, m, miss, "bed" if use_bed else "pgen")
+    return True, "case %d ok: %s" % (idx, " ".join(args))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    pkg = ge.load_package()
+    cli = pkg.build_cli()
+    ref = os.path.join(REPO, "oracle", "_ref", "plink2")
+    if not os.path.exists(ref):
+        sys.exit("oracle/_ref/plink2 is missing")
+    rng = np.random.default_rng(args.seed)
+    with tempfile.TemporaryDirectory() as tmp:
+        for k in range(args.cases):
+            ok, desc = one_case(cli, ref, rng, k, tmp)
+            if not ok:
+                print("MISMATCH", desc, "(--seed %d)" % args.seed)
+                sys.exit(1)
+            if k % 10 == 0:
+                print(desc, flush=True)
+    print("%d cases byte-identical to the reference" % args.cases)
+
+
+if __name__ == "__main__":
+    main()
