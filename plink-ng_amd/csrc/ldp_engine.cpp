@@ -1261,9 +1261,6 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   e->ctr.computed_pairs = e->computed_pairs;
   e->ctr.replay_pairs = replay_pairs;
   e->ctr.pred_true = h_counters[0];
-  if (getenv("LDP_DEBUG_PHASE_CLOCKS")) {
-    fprintf(stderr, "phase clocks: before switch %llu, after switch %llu (sum over blocks, cycles)\n", h_counters[2], h_counters[3]);
-  }
   e->ctr.early_exit_unit_chunks = h_counters[1] / 4;  // the kernel counts quarter units (one second-variant group)
   e->ctr.tile_unit_chunks = (e->computed_pairs / (8 * kTileJ)) * e->chunks;
   e->ctr.ms_pair_kernel = kms;
