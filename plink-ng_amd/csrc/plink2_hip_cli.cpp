@@ -13,7 +13,7 @@
 // the <50-founders guard (plink2.cc:2063-2071) and the output writer.
 // Multiallelic variants are collapsed major-vs-rest on the host (Get1Multiallelic semantics); chrX / chrY / MT get
 // their sample-mapped rows (males het->missing, non-males x2, ...) built on the host as well.
-// --r2-unphased: the binary matrix shapes (square/square0/triangle x bin/bin4) and the windowed .vcor table with the
+// --r2-unphased: the matrix shapes (square/square0/triangle as bin, bin4 or text) and the windowed .vcor table with the
 // default columns (--ld-window, --ld-window-kb, --ld-window-r2), number formatting restated from dtoa_g.
 // Not yet supported (reported as such, never silently mis-handled): .pvar.zst, external-index .pgen (modes
 // 0x20/0x21), more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, chrX/Y/MT and multiallelic sites in
@@ -290,6 +290,7 @@ struct Args {
   int r2_float = -1;      // 1 bin4, 0 bin
   bool yes_really = false;
   bool r2_table = false;   // --r2-unphased without a matrix shape: windowed .vcor table
+  bool r2_text = false;    // matrix shape without bin/bin4: text matrix
   uint32_t ld_var_ct_radius = 0x7fffffff;  // --ld-window N: N - 1
   uint32_t ld_bp_radius = 0xffffffffu;     // --ld-window-kb; UINT32_MAX = not given (table default 1000 kb)
   double ld_min_r2 = 2.0;                  // --ld-window-r2 (after the reference's epsilon); 2.0 = not given
@@ -436,10 +437,14 @@ Args parse_args(int argc, char** argv) {
         else if (m == "ref-based" || m == "allow-ambiguous-allele") { /* no effect on r^2 */ }
         else die(9, "Error: --r2-unphased modifier '%s' is not supported by plink2-hip (matrix shapes with bin/bin4, or the default-column table).\n", m.c_str());
       }
-      if ((A.r2_shape < 0) != (A.r2_float < 0)) {
-        die(9, "Error: plink2-hip supports --r2-unphased {square | square0 | triangle} {bin | bin4} (binary matrices) or --r2-unphased without a shape (windowed .vcor table); text matrices are not implemented.\n");
+      if ((A.r2_shape < 0) && (A.r2_float >= 0)) {
+        die(5, "Error: --r2-unphased 'bin' and 'bin4' require a matrix shape (square, square0 or triangle).\n");
       }
       A.r2_table = (A.r2_shape < 0);
+      A.r2_text = (A.r2_shape >= 0) && (A.r2_float < 0);  // shape without bin/bin4: tab-delimited text matrix
+      if (A.r2_text) {
+        A.r2_float = 0;  // computed as doubles, printed with 6 significant digits
+      }
       A.have_r2 = true;
     } else if (f == "--ld-window") {  // plink2.cc:7908-7920
       need(i, 1, "--ld-window");
@@ -1117,7 +1122,7 @@ int main(int argc, char** argv) {
                    : ldp_set_variants_matrix(e, variant_ct)) {
       die(12, "Error: engine setup failed: %s\n", ldp_last_error(e));
     }
-    const std::string base = A.out + ".unphased.vcor2.bin";
+    const std::string base = A.out + (A.r2_text ? ".unphased.vcor2" : ".unphased.vcor2.bin");
     if (!A.r2_table) {
       FILE* vf = fopen((base + ".vars").c_str(), "wb");
       if (!vf) {
@@ -1324,6 +1329,7 @@ int main(int argc, char** argv) {
       full.assign(static_cast<size_t>(variant_ct) * variant_ct * esz, 0);
     }
     std::vector<uint8_t> chunk;
+    std::string textbuf;
     for (uint32_t r0 = 0; r0 < variant_ct;) {
       // rows per chunk: about 1 GiB of output
       uint32_t rows = static_cast<uint32_t>(std::max<uint64_t>(32, (1ull << 30) / (static_cast<uint64_t>(r0 + 4096) * esz)));
@@ -1336,7 +1342,23 @@ int main(int argc, char** argv) {
       for (uint32_t q = 0; q < rows; ++q) {
         const uint32_t j = r0 + q;
         const uint8_t* row = chunk.data() + static_cast<uint64_t>(q) * ld * esz;
-        if (A.r2_shape == 2) {
+        if (A.r2_text && (A.r2_shape != 0)) {
+          // VcorMatrixWriteThread :9733-9752: dtoa_g values, tab-separated, square0 padded with "0" entries
+          const double* drow = reinterpret_cast<const double*>(row);
+          textbuf.clear();
+          char num[40];
+          for (uint32_t i = 0; i <= j; ++i) {
+            textbuf.append(num, format_g6(drow[i], num) - num);
+            textbuf += '\t';
+          }
+          if (A.r2_shape == 1) {
+            for (uint32_t i = j + 1; i < variant_ct; ++i) {
+              textbuf += "0\t";
+            }
+          }
+          textbuf.back() = '\n';
+          fwrite(textbuf.data(), 1, textbuf.size(), mf);
+        } else if (A.r2_shape == 2) {
           fwrite(row, esz, static_cast<size_t>(j) + 1, mf);
         } else if (A.r2_shape == 1) {
           fwrite(row, esz, static_cast<size_t>(j) + 1, mf);
@@ -1356,7 +1378,21 @@ int main(int argc, char** argv) {
       r0 += rows;
     }
     if (A.r2_shape == 0 && !full.empty()) {
-      fwrite(full.data(), 1, full.size(), mf);
+      if (A.r2_text) {
+        const double* dm = reinterpret_cast<const double*>(full.data());
+        char num[40];
+        for (uint32_t j = 0; j < variant_ct; ++j) {
+          textbuf.clear();
+          for (uint32_t i = 0; i < variant_ct; ++i) {
+            textbuf.append(num, format_g6(dm[static_cast<uint64_t>(j) * variant_ct + i], num) - num);
+            textbuf += '\t';
+          }
+          textbuf.back() = '\n';
+          fwrite(textbuf.data(), 1, textbuf.size(), mf);
+        }
+      } else {
+        fwrite(full.data(), 1, full.size(), mf);
+      }
     }
     if (fclose(mf)) {
       die(2, "Error: File write failure: %s.\n", base.c_str());

@@ -158,3 +158,23 @@ def test_cli_vcor_table_byte_identical(gpu_pkg, tmp_path, extra):
     assert got.returncode == 0, got.stdout
     assert os.path.getsize(str(tmp_path / "ref.vcor")) > 100
     assert filecmp.cmp(str(tmp_path / "ref.vcor"), str(tmp_path / "hip.vcor"), shallow=False)
+
+
+@pytest.mark.parametrize("shape", ["square", "square0", "triangle"])
+def test_cli_text_matrix_byte_identical(gpu_pkg, tmp_path, shape):
+    """--r2-unphased <shape> without bin/bin4: the tab-delimited text matrix (dtoa_g formatting)."""
+    assert T.have_ref()
+    cli = gpu_pkg.build_cli()
+    m, n = 230, 140
+    raw = T.synth_raw_codes(m, n, seed=29, missing_rate=0.03)
+    raw[10] = 2
+    raw[11] = 3
+    chroms = ["0"] * 3 + ["1"] * 127 + ["9"] * 100
+    T.write_pgen_fixed(str(tmp_path / "d"), raw, chroms, np.arange(m) + 1)
+    ref = T.run_ref(["--pfile", "d", "--r2-unphased", shape, "--out", "ref"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    got = subprocess.run([cli, "--pfile", "d", "--r2-unphased", shape, "--out", "hip"], cwd=str(tmp_path), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert got.returncode == 0, got.stdout
+    assert filecmp.cmp(str(tmp_path / "ref.unphased.vcor2.vars"), str(tmp_path / "hip.unphased.vcor2.vars"), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "ref.unphased.vcor2"), str(tmp_path / "hip.unphased.vcor2"), shallow=False)
