@@ -138,7 +138,10 @@ int ldp_get_band(const ldp_engine* e, uint32_t* lo, uint64_t* candidate_pairs);
  * major allele and inversion.  Host buffers may be reused as soon as the call returns (rows travel through a
  * pinned staging ring).  Device buffers are read asynchronously on the engine's stream: the data must be
  * complete before the call (synchronise the producing stream) and must stay valid until the next ldp_run() /
- * ldp_get_* call returns. */
+ * ldp_get_* call returns.
+ * Load in variant order when you can: with host buffers the engine starts the pair kernel for a group of variants
+ * as soon as everything the group needs has been converted, so the pair work overlaps the remaining transfers.
+ * Loading a variant again (a new pass over the data) simply starts over. */
 int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* geno, uint64_t stride_bytes,
                        int location, int encoding);
 /* major-allele frequencies (GetAlleleFreq(..., maj_alleles[v]), plink2_ld.cc:915) for LDP_GENO_INVERSE
@@ -149,7 +152,11 @@ int ldp_set_preferred(ldp_engine* e, const uint64_t* preferred_bitmap);
 
 /* ---- compute ---- */
 /* removed: bitmap of variant_ct bits (caller-allocated, (variant_ct+63)/64 words), bit v set <=> variant v
- * pruned == removed_variants_collapsed (plink2_ld.cc:2555,1424).  Non-owned variants' bits are 0. */
+ * pruned == removed_variants_collapsed (plink2_ld.cc:2555,1424).  Non-owned variants' bits are 0.
+ * Queues whatever pair work ldp_load_genotypes() has not started yet, replays each group of variants on host
+ * threads as its predicate rows come back (overlapping the GPU), and returns when the bitmap is complete.
+ * Pairs whose predicate is provably false are dropped early inside the kernel; the bitmap is
+ * exactly the reference's.  Calling it again recomputes from the resident bit-planes. */
 int ldp_run(ldp_engine* e, uint64_t* removed);
 /* Same, additionally returning the integer 6-tuple of every candidate pair: stats[pair_off[j] + (i - lo[j])]
  * for lo[j] <= i < j, pair_off = exclusive prefix sum of (j - lo[j]).  Intended for parity tests. */
