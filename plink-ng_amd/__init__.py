@@ -115,7 +115,7 @@ def build_cli(force=False, verbose=False):
     if force or _stale(CLI_PATH, deps):
         os.makedirs(BIN_DIR, exist_ok=True)
         cmd = ["hipcc", "-O2", "-std=c++17", "-ffp-contract=off", "-o", CLI_PATH, src, "-L" + LIB_DIR, "-lldprune_hip",
-               "-Wl,-rpath,$ORIGIN/../lib", "-lpthread"]
+               "-Wl,-rpath,$ORIGIN/../lib", "-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -15,9 +15,10 @@
 // their sample-mapped rows (males het->missing, non-males x2, ...) built on the host as well.
 // --r2-unphased: the matrix shapes (square/square0/triangle as bin, bin4 or text) and the windowed .vcor table with the
 // default columns (--ld-window, --ld-window-kb, --ld-window-r2), number formatting restated from dtoa_g.
-// Not yet supported (reported as such, never silently mis-handled): .pvar.zst, external-index .pgen (modes
+// Not yet supported (reported as such, never silently mis-handled): external-index .pgen (modes
 // 0x20/0x21), more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, chrX/Y/MT and multiallelic sites in
 // --r2-unphased, its cols=/zs/inter-chr modifiers, --ld-snp*, --ld-window-cm.
+#include <dlfcn.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <fcntl.h>
@@ -338,17 +339,23 @@ Args parse_args(int argc, char** argv) {
     if (f == "--bfile" || f == "--pfile" || f == "--bpfile") {
       need(i, 1, f.c_str());
       std::string pre = argv[++i];
+      // optional 'vzs' modifier: the variant table is zstd-compressed (<prefix>.pvar.zst / .bim.zst)
+      std::string vz;
+      if (i + 1 < argc && std::string(argv[i + 1]) == "vzs") {
+        vz = ".zst";
+        ++i;
+      }
       if (f == "--bfile") {
         A.bed = pre + ".bed";
-        A.bim = pre + ".bim";
+        A.bim = pre + ".bim" + vz;
         A.fam = pre + ".fam";
       } else if (f == "--pfile") {
         A.pgen = pre + ".pgen";
-        A.pvar = pre + ".pvar";
+        A.pvar = pre + ".pvar" + vz;
         A.psam = pre + ".psam";
       } else {
         A.pgen = pre + ".pgen";
-        A.bim = pre + ".bim";
+        A.bim = pre + ".bim" + vz;
         A.fam = pre + ".fam";
       }
     } else if (f == "--bed" || f == "--bim" || f == "--fam" || f == "--pgen" || f == "--pvar" || f == "--psam" || f == "--out" || f == "--indep-preferred") {
@@ -634,6 +641,62 @@ std::string slurp(const std::string& path) {
   return buf;
 }
 
+// zstd-compressed text (.pvar.zst / .bim.zst): the image ships libzstd.so.1 without headers, so the few streaming
+// entry points are bound by hand (stable C ABI since zstd 1.0: zstd.h "Streaming decompression").
+std::string slurp_zst(const std::string& path) {
+  struct InBuf {
+    const void* src;
+    size_t size, pos;
+  };
+  struct OutBuf {
+    void* dst;
+    size_t size, pos;
+  };
+  void* lib = dlopen("libzstd.so.1", RTLD_NOW);
+  if (!lib) {
+    die(9, "Error: %s is zstd-compressed and libzstd.so.1 could not be loaded (%s).\n", path.c_str(), dlerror());
+  }
+  auto create = reinterpret_cast<void* (*)()>(dlsym(lib, "ZSTD_createDStream"));
+  auto destroy = reinterpret_cast<size_t (*)(void*)>(dlsym(lib, "ZSTD_freeDStream"));
+  auto init = reinterpret_cast<size_t (*)(void*)>(dlsym(lib, "ZSTD_initDStream"));
+  auto step = reinterpret_cast<size_t (*)(void*, OutBuf*, InBuf*)>(dlsym(lib, "ZSTD_decompressStream"));
+  auto is_error = reinterpret_cast<unsigned (*)(size_t)>(dlsym(lib, "ZSTD_isError"));
+  if (!create || !destroy || !init || !step || !is_error) {
+    die(9, "Error: libzstd.so.1 lacks the streaming decompression API.\n");
+  }
+  const std::string in = slurp(path);
+  void* ds = create();
+  if (!ds || is_error(init(ds))) {
+    die(9, "Error: zstd decompressor setup failed.\n");
+  }
+  std::string out;
+  std::vector<char> chunk(4u << 20);
+  InBuf ib = {in.data(), in.size(), 0};
+  size_t last = 0;  // 0 = at a frame boundary with everything flushed
+  while (ib.pos < ib.size) {
+    OutBuf ob = {chunk.data(), chunk.size(), 0};
+    last = step(ds, &ob, &ib);
+    if (is_error(last)) {
+      die(3, "Error: %s is not a valid zstd stream.\n", path.c_str());
+    }
+    out.append(chunk.data(), ob.pos);
+  }
+  while (last != 0) {  // input exhausted inside a frame: the decoder may still hold output
+    OutBuf ob = {chunk.data(), chunk.size(), 0};
+    InBuf none = {in.data(), ib.size, ib.size};
+    last = step(ds, &ob, &none);
+    if (is_error(last)) {
+      die(3, "Error: %s is not a valid zstd stream.\n", path.c_str());
+    }
+    out.append(chunk.data(), ob.pos);
+    if (!ob.pos && last) {
+      die(3, "Error: %s ends inside a zstd frame.\n", path.c_str());
+    }
+  }
+  destroy(ds);
+  return out;
+}
+
 struct Tok {
   const char* p;
   size_t n;
@@ -667,10 +730,8 @@ inline int tokenize(const char* p, const char* e, Tok* out, int cap) {
 void load_variants(const Args& A, Variants* V) {
   const bool pvar = !A.pvar.empty();
   const std::string& path = pvar ? A.pvar : A.bim;
-  if (path.size() > 4 && path.compare(path.size() - 4, 4, ".zst") == 0) {
-    die(9, "Error: zstd-compressed .pvar is not supported yet by plink2-hip.\n");
-  }
-  const std::string buf = slurp(path);
+  const bool zst = (path.size() > 4) && (path.compare(path.size() - 4, 4, ".zst") == 0);
+  const std::string buf = zst ? slurp_zst(path) : slurp(path);
   bool header = false;
   int c_chrom = 0, c_pos = 3, c_id = 1, c_alt = -1;
   constexpr int kCap = 64;

@@ -258,3 +258,26 @@ def test_vcor_flag_rules(cli, tmp_path):
     assert r.returncode != 0 and "Matrix-only" in r.stdout
     r = run_cli(cli, ["--pfile", "d", "--r2-unphased", "--ld-window", "1", "--dry-run"], str(tmp_path))
     assert r.returncode != 0 and "Invalid --ld-window argument" in r.stdout
+
+
+def test_zstd_variant_table(cli, tmp_path):
+    """<prefix>.pvar.zst / 'vzs' (written by the reference's --make-pgen vzs) parses to the same plan as the plain
+    .pvar (libzstd.so.1 is bound by hand: the image has no zstd headers)."""
+    if not T.have_ref():
+        pytest.skip("reference binary not built")
+    small_fileset(tmp_path, m=150, n=60, seed=3)
+    r = T.run_ref(["--pfile", "d", "--make-pgen", "vzs", "--out", "z"], str(tmp_path))
+    assert r.returncode == 0 and os.path.exists(str(tmp_path / "z.pvar.zst")), r.stdout
+    a = run_cli(cli, ["--pfile", "d", "--indep-pairwise", "50", "5", "0.2", "--dry-run"], str(tmp_path))
+    b = run_cli(cli, ["--pfile", "z", "vzs", "--indep-pairwise", "50", "5", "0.2", "--dry-run"], str(tmp_path))
+    assert a.returncode == 0 and b.returncode == 0, a.stdout + b.stdout
+    la = [ln for ln in a.stdout.splitlines() if ln.startswith("dry-run:")]
+    lb = [ln for ln in b.stdout.splitlines() if ln.startswith("dry-run:")]
+    assert la and la == lb
+    # truncated stream is an error, not a short table
+    data = open(str(tmp_path / "z.pvar.zst"), "rb").read()
+    open(str(tmp_path / "t.pvar.zst"), "wb").write(data[:len(data) // 2])
+    for ext in (".pgen", ".psam"):
+        os.link(str(tmp_path / ("z" + ext)), str(tmp_path / ("t" + ext)))
+    c = run_cli(cli, ["--pfile", "t", "vzs", "--indep-pairwise", "50", "5", "0.2", "--dry-run"], str(tmp_path))
+    assert c.returncode != 0 and "zstd" in c.stdout
