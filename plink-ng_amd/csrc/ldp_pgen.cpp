@@ -438,18 +438,28 @@ int ldp_pgen_read(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_row
   if (!n) {
     return LDP_OK;
   }
-  // one task per 65,536-variant block touched; inside a block walk forward from the block start or the
-  // nearest non-LD record at or before first_variant
-  const uint32_t b0 = first_variant / kBlockVariants;
-  const uint32_t b1 = (first_variant + n - 1) / kBlockVariants;
-  std::atomic<uint32_t> next(b0);
+  // Tasks of kTaskVariants consecutive variants (never across a 65,536-variant block: LD-compressed records patch the
+  // latest non-LD record of their own block).  A task walks back to that base record first, so tasks are independent
+  // and a call that spans only one or two blocks still keeps every host thread busy.
+  constexpr uint32_t kTaskVariants = 256;
+  struct Task {
+    uint32_t first, end;
+  };
+  std::vector<Task> tasks;
+  for (uint32_t v = first_variant; v < first_variant + n;) {
+    const uint32_t blk_end = std::min(P->variant_ct, (v / kBlockVariants + 1) * kBlockVariants);
+    const uint32_t e = std::min({first_variant + n, blk_end, v + kTaskVariants});
+    tasks.push_back({v, e});
+    v = e;
+  }
+  std::atomic<uint32_t> next(0);
   std::atomic<int> bad(0);
   auto worker = [&]() {
     std::vector<uint8_t> ldbase(P->rec_bytes), scratch(P->rec_bytes);
-    for (uint32_t b = next.fetch_add(1); b <= b1; b = next.fetch_add(1)) {
-      const uint32_t blk_first = b * kBlockVariants;
-      const uint32_t want_first = std::max(first_variant, blk_first);
-      const uint32_t want_end = std::min(first_variant + n, std::min(P->variant_ct, blk_first + kBlockVariants));
+    for (uint32_t t = next.fetch_add(1); t < tasks.size(); t = next.fetch_add(1)) {
+      const uint32_t want_first = tasks[t].first;
+      const uint32_t want_end = tasks[t].end;
+      const uint32_t blk_first = (want_first / kBlockVariants) * kBlockVariants;
       // the LD base of the first wanted record: latest non-LD record at or before it
       uint32_t start = want_first;
       while (start > blk_first && ((P->vrtype[start] & 6) == 2)) {
@@ -473,7 +483,7 @@ int ldp_pgen_read(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_row
       }
     }
   };
-  uint32_t nt = std::max(1u, std::min({threads ? threads : std::thread::hardware_concurrency(), b1 - b0 + 1, 64u}));
+  uint32_t nt = std::max(1u, std::min({threads ? threads : std::thread::hardware_concurrency(), static_cast<uint32_t>(tasks.size()), 64u}));
   if (nt == 1) {
     worker();
   } else {

@@ -1605,27 +1605,55 @@ int main(int argc, char** argv) {
       }
     };
     double t_load1 = now_s();
+    double t_run1 = 0;
     if (subcontig_ct) {
-      const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((1024ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
-      std::vector<uint8_t> decoded, gather;
-      uint32_t q = 0;
-      while (q < m_ct) {
-        // maximal run of variants that is contiguous in the file
+      // Chunks of ~256 MiB of decoded rows.  Variable-width .pgen: the next chunk is decoded (all host threads, see
+      // ldp_pgen_read) while the engine takes the current one, two buffers alternating; small enough that the
+      // buffers' first-touch page faults are paid once, large enough for ~60 decode tasks per chunk.
+      const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((direct_rows ? (1024ull << 20) : (256ull << 20)) / std::max<uint64_t>(rec_bytes, 1)));
+      // never freed: returning ~0.5 GiB of touched pages to the kernel costs tens of ms and the process exits soon
+      std::vector<uint8_t>* decoded = new std::vector<uint8_t>[2];
+      std::vector<uint8_t> gather;
+      // the runs (maximal stretches of included variants that are contiguous in the file, capped at kChunk)
+      struct Run {
+        uint32_t q, raw0, n;
+      };
+      std::vector<Run> runs;
+      for (uint32_t q = 0; q < m_ct;) {
         const uint32_t raw0 = inc[mk[q]];
         uint32_t run = 1;
         while (q + run < m_ct && inc[mk[q + run]] == raw0 + run && run < kChunk) {
           ++run;
         }
+        runs.push_back({q, raw0, run});
+        q += run;
+      }
+      std::thread decoder;
+      int decode_rc = 0;
+      auto start_decode = [&](size_t k) {
+        if (direct_rows || k >= runs.size()) {
+          return;
+        }
+        std::vector<uint8_t>& buf = decoded[k & 1];
+        buf.resize(static_cast<size_t>(runs[k].n) * rec_bytes);
+        decoder = std::thread([&, k]() { decode_rc = ldp_pgen_read(pg, runs[k].raw0, runs[k].n, decoded[k & 1].data(), rec_bytes, 0); });
+      };
+      start_decode(0);
+      for (size_t k = 0; k < runs.size(); ++k) {
+        const uint32_t q = runs[k].q;
+        const uint32_t raw0 = runs[k].raw0;
+        const uint32_t run = runs[k].n;
         const uint8_t* src;
         uint64_t stride = rec_bytes;
         if (direct_rows) {
           src = direct_rows + static_cast<uint64_t>(raw0) * rec_bytes;
         } else {
-          decoded.resize(static_cast<size_t>(run) * rec_bytes);
-          if (ldp_pgen_read(pg, raw0, run, decoded.data(), rec_bytes, 0)) {
+          decoder.join();
+          if (decode_rc) {
             die(3, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
           }
-          src = decoded.data();
+          src = decoded[k & 1].data();
+          start_decode(k + 1);
         }
         if (!all_founders) {
           // gather the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185)
@@ -1646,7 +1674,6 @@ int main(int argc, char** argv) {
             die(12, "Error: %s\n", ldp_last_error(eng[r]));
           }
         }
-        q += run;
       }
       // rows that need host treatment overwrite their bulk-loaded versions: variants with more than one ALT
       // allele (collapsed major-vs-rest) and MT variants (hets -> missing, plink2_ld.cc:1362-1364)
@@ -1708,12 +1735,13 @@ int main(int argc, char** argv) {
         }
         scatter(part[r], mk);
       }
+      t_run1 = now_s();
     }
     if (A.timing) {
       ldp_counters c;
       ldp_get_counters(eng[0], &c);
-      logprintf("\n[timing] setup+parse %.3f s | genotype load (file -> HBM bit-planes) %.3f s | run %.3f s (pair kernel %.1f ms, replay %.1f ms; %llu candidate pairs)\n",
-                t_load0 - t_begin, t_load1 - t_load0, now_s() - t_load1, c.ms_pair_kernel, c.ms_replay, static_cast<unsigned long long>(c.candidate_pairs));
+      logprintf("\n[timing] setup+parse %.3f s | genotype load (file -> HBM bit-planes) %.3f s | run %.3f s (pair kernel %.1f ms, replay %.1f ms; %llu candidate pairs) | buffer release %.3f s\n",
+                t_load0 - t_begin, t_load1 - t_load0, (t_run1 ? t_run1 : now_s()) - t_load1, c.ms_pair_kernel, c.ms_replay, static_cast<unsigned long long>(c.candidate_pairs), t_run1 ? now_s() - t_run1 : 0.0);
     }
     // ---- chrX, chrY: their own sample sets, rows built on the host, one engine each on device 0
     for (int which = 0; which < 2; ++which) {

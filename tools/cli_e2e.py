@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--window-kb", type=float, default=200.0)
     ap.add_argument("--r2", type=float, default=0.5)
     ap.add_argument("--no-ref", action="store_true")
+    ap.add_argument("--pgen", action="store_true", help="convert the .bed with the reference's --make-pgen first (variable-width .pgen) and time both tools on that")
     ap.add_argument("--vcor", action="store_true", help="time the --r2-unphased table (--ld-window-kb = --window-kb, --ld-window-r2 = --r2) instead")
     args = ap.parse_args()
     import torch
@@ -48,13 +49,19 @@ def main():
     if args.vcor:
         common = ["--bfile", "s", "--r2-unphased", "--ld-window-kb", "%g" % args.window_kb, "--ld-window-r2", repr(args.r2)]
         outs = (".vcor",)
+    if args.pgen:
+        t0 = time.perf_counter()
+        cp = subprocess.run([os.path.join(REPO, "oracle", "_ref", "plink2"), "--bfile", "s", "--make-pgen", "--out", "s", "--threads", str(os.cpu_count())], cwd=tmp,
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        print("reference --make-pgen rc", cp.returncode, "wall %.1f s, .pgen %.2f GB" % (time.perf_counter() - t0, os.path.getsize(os.path.join(tmp, "s.pgen")) / 1e9))
+        common = ["--pfile", "s"] + common[2:]
     for rep in range(2):
         t0 = time.perf_counter()
         cp = subprocess.run([os.path.join(REPO, "plink-ng_amd", "bin", "plink2-hip")] + common + ["--timing", "--out", "hip"], cwd=tmp,
                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         t_hip = time.perf_counter() - t0
         print("plink2-hip rc", cp.returncode, "wall %.3f s" % t_hip)
-        print("\n".join(ln for ln in cp.stdout.splitlines() if "timing" in ln or "removed" in ln or "written" in ln or "Error" in ln))
+        print("\n".join(ln for ln in cp.stdout.splitlines() if "timing" in ln or "removed" in ln or "written" in ln or "Error" in ln or "timeline" in ln or "recs copy" in ln))
     if not args.no_ref:
         t0 = time.perf_counter()
         cp = subprocess.run([os.path.join(REPO, "oracle", "_ref", "plink2")] + common + ["--threads", str(os.cpu_count()), "--out", "ref"], cwd=tmp,
