@@ -38,7 +38,8 @@ enum {
   LDP_ERR_NOMEM = 2,       /* host or device allocation failed   (kPglRetNomem)             */
   LDP_ERR_GPU = 3,         /* HIP runtime / kernel failure       (kPglRetGpuFail)           */
   LDP_ERR_STATE = 4,       /* call sequence error                (kPglRetImproperFunctionCall) */
-  LDP_ERR_UNSUPPORTED = 5  /* e.g. >= 2^30 founders              (kPglRetNotYetSupported)   */
+  LDP_ERR_UNSUPPORTED = 5, /* e.g. >= 2^30 founders              (kPglRetNotYetSupported)   */
+  LDP_ERR_UNPHASED = 6     /* --indep-pairphase: a het call without phase (kPglRetInconsistentInput, plink2_ld.cc:2045-2049) */
 };
 
 /* Genotype encodings accepted by ldp_load_genotypes(); all are 2 bits per sample, sample-minor,
@@ -48,9 +49,25 @@ enum {
                            3 missing.  Caller supplies maj_freqs via ldp_set_maj_freqs(). */
   LDP_GENO_REF = 1,     /* .pgen main-track coding: 0 hom-REF, 1 het, 2 hom-ALT, 3 missing.  The engine
                            counts alleles, picks the major allele and inverts on the device. */
-  LDP_GENO_BED = 2      /* PLINK 1 .bed coding: 0 hom-A1(ALT), 1 missing, 2 het, 3 hom-A2(REF)
+  LDP_GENO_BED = 2,     /* PLINK 1 .bed coding: 0 hom-A1(ALT), 1 missing, 2 het, 3 hom-A2(REF)
                            (pgenlib_read.cc:2157 PgrPlink1ToPlink2InplaceUnsafe), then as LDP_GENO_REF. */
+  /* --indep-pairphase (plink2_ld.cc:1449-2163): OR this into LDP_GENO_INVERSE or LDP_GENO_REF.  The engine's
+   * founder_ct is then the HAPLOTYPE count (2 x samples); a row holds, for S = founder_ct/2 samples, ceil(S/4)
+   * bytes of 2-bit codes, zero padding to a multiple of 4 bytes, then ceil(S/8) bytes of phaseinfo bits (sample s =
+   * bit s%8 of byte s/8; set = the counted allele of a het call sits on the first haplotype, as PgrGetInv1P /
+   * HapsplitMustPhased define it, pgenlib_read.cc:7016, pgenlib_misc.cc:1887; ignored for non-het calls) --
+   * ldp_phased_row_bytes() bytes in all.  Every het call must be phased (the caller checks, as the reference does at
+   * plink2_ld.cc:2045).  The conversion kernel splits each sample into its two haplotypes (hom -> both, het -> the
+   * phased one, missing -> both missing); haplotype h in {0,1} is carried as the genotype code 2h, whose
+   * pair statistics are exactly 4 x the reference's cov12 / variance1 / variance2 (ldp_kernels.hip), so the prune
+   * decision is the same bit. */
+  LDP_GENO_PHASED = 4
 };
+static inline uint64_t ldp_phased_row_bytes(uint32_t hap_ct) {
+  const uint64_t s = hap_ct / 2;
+  return (((s + 3) / 4 + 3) & ~(uint64_t)3) + (s + 7) / 8;
+}
+static inline uint64_t ldp_phased_phase_offset(uint32_t hap_ct) { return (((uint64_t)(hap_ct / 2) + 3) / 4 + 3) & ~(uint64_t)3; }
 
 enum { LDP_MEM_HOST = 0, LDP_MEM_DEVICE = 1 };
 
@@ -217,6 +234,14 @@ int ldp_pgen_read(ldp_pgen* p, uint32_t first_variant, uint32_t n, void* out_row
 /* Multiallelic hard-call track (pgen_spec.tex:469-540; what Get1Multiallelic, pgenlib_read.cc:5417, consumes):
  * per-sample allele index pairs of one variant, allele_lo <= allele_hi, 0 = REF, k = ALTk, 255 = missing.
  * alt_ct = number of ALT alleles in the .pvar (<= 254).  Works for biallelic records too. */
+/* --indep-pairphase input (what PgrGetInv1P delivers, minus the major-allele inversion): rows in the
+ * LDP_GENO_REF | LDP_GENO_PHASED layout for hap_ct = 2 * sample_ct (2-bit codes, padding, phaseinfo bits from the
+ * hardcall-phase track, pgen_spec.tex:541-562; phaseinfo set = ALT on the first haplotype, "1|0").
+ * sample_mask (optional, ceil(sample_ct/8) bytes): only these samples' het calls must be phased (the reference
+ * checks after founder subsetting).  Returns LDP_ERR_UNPHASED and the lowest offending variant index in
+ * *unphased_variant when a het call of a masked sample has no phase.  Multiallelic records are refused. */
+int ldp_pgen_read_phased(ldp_pgen* p, uint32_t first_variant, uint32_t n, void* out_rows, uint64_t stride_bytes,
+                         const uint8_t* sample_mask, uint32_t threads, uint32_t* unphased_variant);
 int ldp_pgen_variant_is_multiallelic(const ldp_pgen* p, uint32_t variant);
 int ldp_pgen_read_alleles(ldp_pgen* p, uint32_t variant, uint32_t alt_ct, uint8_t* allele_lo, uint8_t* allele_hi);
 const char* ldp_pgen_last_error(const ldp_pgen* p);

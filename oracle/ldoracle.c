@@ -288,11 +288,13 @@ static inline void bit_set(uint64_t* bm, uint32_t i) { bm[i / 64] |= 1ULL << (i 
 
 typedef struct {
   /* per-variant state for the subcontig being processed (index = variant idx - subcontig first) */
-  uint64_t* planes; /* 2*word_ct per variant: hom then ref2het */
+  uint64_t* planes; /* 2*word_ct per variant: hom then ref2het (pairwise) / hap then nm (pairphase) */
   LdoVaggs* vaggs;
+  LdoVhaggs* vhaggs;
+  int pairphase;
   uint32_t word_ct;
   uint32_t first;
-  uint32_t founder_ct;
+  uint32_t founder_ct; /* pairphase: haplotype count */
   double thresh;
   uint64_t eval_ct;
 } SubcontigCtx;
@@ -300,16 +302,167 @@ typedef struct {
 static int pair_exceeds(SubcontigCtx* c, uint32_t first_v, uint32_t second_v) {
   const uint64_t* fp = &c->planes[(uint64_t)(first_v - c->first) * 2 * c->word_ct];
   const uint64_t* sp = &c->planes[(uint64_t)(second_v - c->first) * 2 * c->word_ct];
+  ++c->eval_ct;
+  if (c->pairphase) {
+    LdoHapPairStats hs;
+    ldo_hap_pair_stats(fp, fp + c->word_ct, &c->vhaggs[first_v - c->first], sp, sp + c->word_ct, &c->vhaggs[second_v - c->first], c->founder_ct, &hs);
+    return ldo_hap_exceeds(&hs, c->thresh);
+  }
   LdoPairStats st;
   ldo_pair_stats(fp, fp + c->word_ct, &c->vaggs[first_v - c->first], sp, sp + c->word_ct, &c->vaggs[second_v - c->first], c->founder_ct, &st);
-  ++c->eval_ct;
   return ldo_exceeds(&st, c->thresh);
 }
+
+/* ---- --indep-pairphase: the same scan over haplotype bit-vectors -------------------------------------------- */
+
+/* include/pgenlib_misc.cc:1887-1931 HapsplitMustPhased.  geno: 2-bit codes (0/1/2 = copies of the counted allele,
+ * 3 missing; trailing bits zero); phasepresent/phaseinfo: one bit per sample (phaseinfo only meaningful where
+ * phasepresent is set; phasepresent may be NULL = no phase information at all).  hap/nm get 2 bits per sample
+ * (hap_ct = 2*sample_ct): hom -> 00 / 11, het -> 01 (unswapped) or 10 (phaseinfo set), missing -> hap 00, nm 00.
+ * Returns nonzero when a het call is not covered by phasepresent ("is not fully phased", plink2_ld.cc:2045-2049). */
+int ldo_hapsplit_must_phased(const uint64_t* geno, const uint64_t* phasepresent, const uint64_t* phaseinfo, uint32_t sample_ct, uint64_t* hap, uint64_t* nm) {
+  const uint32_t word_ct = ldo_geno_word_ct(sample_ct);
+  const uint64_t m5 = 0x5555555555555555ULL;
+  uint64_t detect_unphased = 0;
+  for (uint32_t w = 0; w != word_ct; ++w) {
+    uint64_t g = geno[w];
+    if ((w == word_ct - 1) && (sample_ct % 32)) {
+      g &= (1ULL << (2 * (sample_ct % 32))) - 1;
+    }
+    const uint64_t nm_word = 3 * (m5 & (~(g & (g >> 1))));
+    const uint64_t g_nm = g & nm_word; /* {00, 01, 10, 00} */
+    const uint64_t g_nm_hi = (g_nm >> 1) & m5;
+    const uint64_t het = g_nm & m5;
+    /* this word covers samples [32w, 32w+32): spread their phase bits to the even positions
+     * (UnpackHalfwordToWord, :1913-1914) */
+    uint64_t pp = 0, pi = 0;
+    if (phasepresent) {
+      const uint32_t half = (uint32_t)((phasepresent[w / 2] >> (32 * (w & 1))) & 0xffffffffULL);
+      const uint32_t halfi = (uint32_t)((phaseinfo[w / 2] >> (32 * (w & 1))) & 0xffffffffULL);
+      for (uint32_t b = 0; b != 32; ++b) {
+        pp |= (uint64_t)((half >> b) & 1) << (2 * b);
+        pi |= (uint64_t)((halfi >> b) & 1) << (2 * b);
+      }
+      pi &= pp;
+    }
+    nm[w] = nm_word;
+    /* geno_nm + geno_nm_hi + phaseinfo_word (:1917); without phase information geno_nm | geno_nm_hi (:1899) */
+    hap[w] = g_nm + g_nm_hi + pi;
+    detect_unphased |= het & ~pp;
+  }
+  const uint32_t trailing = sample_ct % 32;
+  if (trailing) {
+    const uint64_t mask = (1ULL << (2 * trailing)) - 1;
+    nm[word_ct - 1] &= mask;
+    hap[word_ct - 1] &= mask;
+  }
+  return detect_unphased != 0;
+}
+
+/* include/pgenlib_misc.cc:2010-2041 HapsplitHaploid: one haplotype per sample, a het call counts as missing.
+ * hap/nm get one bit per sample (hap_ct = sample_ct). */
+void ldo_hapsplit_haploid(const uint64_t* geno, uint32_t sample_ct, uint64_t* hap, uint64_t* nm) {
+  const uint32_t out_word_ct = ldo_word_ct(sample_ct);
+  const uint32_t in_word_ct = ldo_geno_word_ct(sample_ct);
+  for (uint32_t w = 0; w != out_word_ct; ++w) {
+    const uint64_t g0 = geno[2 * w];
+    const uint64_t g1 = (2 * w + 1 < in_word_ct) ? geno[2 * w + 1] : 0;
+    /* nm = low bit clear (codes 0, 2); hap = nm and high bit set (code 2) */
+    const uint64_t nm0 = ~g0, nm1 = ~g1;
+    const uint64_t h0 = nm0 & (g0 >> 1), h1 = nm1 & (g1 >> 1);
+    uint64_t nm_word = (uint64_t)pack_even_bits(nm0) | ((uint64_t)pack_even_bits(nm1) << 32);
+    uint64_t hap_word = (uint64_t)pack_even_bits(h0) | ((uint64_t)pack_even_bits(h1) << 32);
+    if ((w == out_word_ct - 1) && (sample_ct % 64)) {
+      const uint64_t mask = (1ULL << (sample_ct % 64)) - 1;
+      nm_word &= mask;
+      hap_word &= mask;
+    }
+    nm[w] = nm_word;
+    hap[w] = hap_word;
+  }
+}
+
+/* plink2_ld.cc:1484-1490 FillVhaggs; returns 1 if monomorphic */
+int ldo_fill_vhaggs(const uint64_t* hap, const uint64_t* nm, uint32_t word_ct, LdoVhaggs* out) {
+  uint32_t nm_ct = 0, sum = 0;
+  for (uint32_t w = 0; w != word_ct; ++w) {
+    nm_ct += popcount64(nm[w]);
+    sum += popcount64(hap[w]);
+  }
+  out->nm_ct = nm_ct;
+  out->sum = sum;
+  return (!sum) || (sum == nm_ct);
+}
+
+static uint32_t popcount_intersect(const uint64_t* a, const uint64_t* b, uint32_t word_ct) {
+  uint32_t ct = 0;
+  for (uint32_t w = 0; w != word_ct; ++w) {
+    ct += popcount64(a[w] & b[w]);
+  }
+  return ct;
+}
+
+/* plink2_ld.cc:1456-1481 ComputeIndepPairphaseR2Components, reported as first/second */
+void ldo_hap_pair_stats(const uint64_t* first_hap, const uint64_t* first_nm, const LdoVhaggs* first_vh,
+                        const uint64_t* second_hap, const uint64_t* second_nm, const LdoVhaggs* second_vh,
+                        uint32_t hap_ct, LdoHapPairStats* out) {
+  const uint32_t word_ct = ldo_word_ct(hap_ct);
+  uint32_t cur_nm_ct = first_vh->nm_ct;
+  uint32_t cur_first_sum = first_vh->sum;
+  uint32_t second_sum;
+  out->dot = popcount_intersect(first_hap, second_hap, word_ct);
+  if (cur_nm_ct != hap_ct) {
+    second_sum = popcount_intersect(first_nm, second_hap, word_ct);
+  } else {
+    second_sum = second_vh->sum;
+  }
+  if (second_vh->nm_ct != hap_ct) {
+    cur_first_sum = popcount_intersect(first_hap, second_nm, word_ct);
+    if (cur_nm_ct != hap_ct) {
+      cur_nm_ct = popcount_intersect(first_nm, second_nm, word_ct);
+    } else {
+      cur_nm_ct = second_vh->nm_ct;
+    }
+  }
+  out->nm = cur_nm_ct;
+  out->sum1 = cur_first_sum;
+  out->sum2 = second_sum;
+}
+
+/* plink2_ld.cc:1708-1713 (order 1) / :1769-1776 (order 2): the three doubles and the comparison */
+int ldo_hap_exceeds(const LdoHapPairStats* s, double prune_ld_thresh) {
+  const double cov12 = (double)((int64_t)(s->dot * (uint64_t)s->nm - (uint64_t)s->sum1 * s->sum2));
+  const double variance1 = (double)(s->sum1 * (int64_t)(s->nm - s->sum1));
+  const double variance2 = (double)(s->sum2 * (int64_t)(s->nm - s->sum2));
+  return cov12 * cov12 > prune_ld_thresh * variance1 * variance2;
+}
+
+static int prune_scan(int pairphase, const uint64_t* geno, uint64_t stride_words, uint32_t variant_ct, uint32_t founder_ct,
+                      const uint32_t* chr_idx, const uint32_t* bps_in, const double* maj_freqs,
+                      uint32_t prune_window_size, uint32_t window_incr, int window_is_bp,
+                      double r2, int plink1_order, uint64_t* removed, uint64_t* pair_eval_ct);
 
 int ldo_indep_pairwise(const uint64_t* geno, uint64_t stride_words, uint32_t variant_ct, uint32_t founder_ct,
                        const uint32_t* chr_idx, const uint32_t* bps_in, const double* maj_freqs,
                        uint32_t prune_window_size, uint32_t window_incr, int window_is_bp,
                        double r2, int plink1_order, uint64_t* removed, uint64_t* pair_eval_ct) {
+  return prune_scan(0, geno, stride_words, variant_ct, founder_ct, chr_idx, bps_in, maj_freqs, prune_window_size, window_incr, window_is_bp, r2, plink1_order, removed, pair_eval_ct);
+}
+
+/* plink2_ld.cc:1549-1800 IndepPairphaseThread: the scan of IndepPairwiseThread over haplotype vectors.
+ * hap_nm: per variant hap bits then nm bits, ldo_word_ct(hap_ct) words each (the loader_hap_then_nm_vecs rows of
+ * :2018-2019), hap bit = haplotype carries the NON-major allele. */
+int ldo_indep_pairphase(const uint64_t* hap_nm, uint64_t stride_words, uint32_t variant_ct, uint32_t hap_ct,
+                        const uint32_t* chr_idx, const uint32_t* bps_in, const double* maj_freqs,
+                        uint32_t prune_window_size, uint32_t window_incr, int window_is_bp,
+                        double r2, int plink1_order, uint64_t* removed, uint64_t* pair_eval_ct) {
+  return prune_scan(1, hap_nm, stride_words, variant_ct, hap_ct, chr_idx, bps_in, maj_freqs, prune_window_size, window_incr, window_is_bp, r2, plink1_order, removed, pair_eval_ct);
+}
+
+static int prune_scan(int pairphase, const uint64_t* geno, uint64_t stride_words, uint32_t variant_ct, uint32_t founder_ct,
+                      const uint32_t* chr_idx, const uint32_t* bps_in, const double* maj_freqs,
+                      uint32_t prune_window_size, uint32_t window_incr, int window_is_bp,
+                      double r2, int plink1_order, uint64_t* removed, uint64_t* pair_eval_ct) {
   const uint32_t* bps = window_is_bp ? bps_in : NULL; /* plink2_ld.cc:2551-2553 */
   memset(removed, 0, ((variant_ct + 63) / 64) * sizeof(uint64_t));
   if (pair_eval_ct) {
@@ -330,6 +483,7 @@ int ldo_indep_pairwise(const uint64_t* geno, uint64_t stride_words, uint32_t var
   SubcontigCtx ctx;
   ctx.word_ct = ldo_word_ct(founder_ct);
   ctx.founder_ct = founder_ct;
+  ctx.pairphase = pairphase;
   ctx.thresh = ldo_prune_thresh(r2);
   ctx.eval_ct = 0;
   for (uint32_t sidx = 0; sidx != subcontig_ct; ++sidx) {
@@ -339,7 +493,8 @@ int ldo_indep_pairwise(const uint64_t* geno, uint64_t stride_words, uint32_t var
     ctx.first = subcontig_first;
     ctx.planes = (uint64_t*)malloc(sizeof(uint64_t) * 2 * ctx.word_ct * (size_t)subcontig_len);
     ctx.vaggs = (LdoVaggs*)malloc(sizeof(LdoVaggs) * (size_t)subcontig_len);
-    if (!ctx.planes || !ctx.vaggs) {
+    ctx.vhaggs = (LdoVhaggs*)malloc(sizeof(LdoVhaggs) * (size_t)subcontig_len);
+    if (!ctx.planes || !ctx.vaggs || !ctx.vhaggs) {
       return 1;
     }
     /* LdPruneNextSubcontig, plink2_ld.cc:605-633 */
@@ -362,10 +517,18 @@ int ldo_indep_pairwise(const uint64_t* geno, uint64_t stride_words, uint32_t var
     for (uint32_t cur = subcontig_first; cur < subcontig_end;) {
       /* load one variant, :877-925 */
       uint64_t* hom = &ctx.planes[(uint64_t)(cur - subcontig_first) * 2 * ctx.word_ct];
-      ldo_split_hom_ref2het(&geno[(uint64_t)cur * stride_words], founder_ct, hom, hom + ctx.word_ct);
-      LdoVaggs* va = &ctx.vaggs[cur - subcontig_first];
-      ldo_fill_vaggs(hom, hom + ctx.word_ct, ctx.word_ct, va);
-      if (ldo_is_monomorphic(va)) {
+      int monomorphic;
+      if (pairphase) {
+        /* :1620-1624 */
+        memcpy(hom, &geno[(uint64_t)cur * stride_words], sizeof(uint64_t) * 2 * ctx.word_ct);
+        monomorphic = ldo_fill_vhaggs(hom, hom + ctx.word_ct, ctx.word_ct, &ctx.vhaggs[cur - subcontig_first]);
+      } else {
+        ldo_split_hom_ref2het(&geno[(uint64_t)cur * stride_words], founder_ct, hom, hom + ctx.word_ct);
+        LdoVaggs* va = &ctx.vaggs[cur - subcontig_first];
+        ldo_fill_vaggs(hom, hom + ctx.word_ct, ctx.word_ct, va);
+        monomorphic = ldo_is_monomorphic(va);
+      }
+      if (monomorphic) {
         win_removed[cur_window_size] = 1;
         bit_set(removed, cur);
       } else {
@@ -522,6 +685,7 @@ int ldo_indep_pairwise(const uint64_t* geno, uint64_t stride_words, uint32_t var
     }
     free(ctx.planes);
     free(ctx.vaggs);
+    free(ctx.vhaggs);
   }
   if (pair_eval_ct) {
     *pair_eval_ct = ctx.eval_ct;

@@ -24,6 +24,8 @@ CLI_PATH = os.path.join(BIN_DIR, "plink2-hip")
 
 LDP_OK, LDP_ERR_INVALID, LDP_ERR_NOMEM, LDP_ERR_GPU, LDP_ERR_STATE, LDP_ERR_UNSUPPORTED = range(6)
 LDP_GENO_INVERSE, LDP_GENO_REF, LDP_GENO_BED = 0, 1, 2
+LDP_GENO_PHASED = 4  # OR into INVERSE / REF: --indep-pairphase rows (include/ldprune_hip.h)
+LDP_ERR_UNPHASED = 6
 LDP_MEM_HOST, LDP_MEM_DEVICE = 0, 1
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
@@ -79,7 +81,7 @@ CABI_SYMBOLS = [
     "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
     "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
-    "ldp_pgen_variant_is_multiallelic", "ldp_pgen_read_alleles",
+    "ldp_pgen_variant_is_multiallelic", "ldp_pgen_read_alleles", "ldp_pgen_read_phased",
 ]
 
 
@@ -177,6 +179,8 @@ def lib():
     L.ldp_pgen_direct_rows.restype = ctypes.c_void_p
     L.ldp_pgen_read.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.c_uint32]
     L.ldp_pgen_variant_is_multiallelic.argtypes = [vp, ctypes.c_uint32]
+    L.ldp_pgen_read_phased.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint8), ctypes.c_uint32,
+                                       ctypes.POINTER(ctypes.c_uint32)]
     L.ldp_pgen_read_alleles.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8)]
     L.ldp_pgen_last_error.argtypes = [vp]
     L.ldp_pgen_last_error.restype = ctypes.c_char_p
@@ -207,6 +211,24 @@ def synth_genotypes_device(seed, first_variant, n_variants, founder_ct, missing_
         raise LdpError(rc, "ldp_synth_genotypes failed")
 
 
+def phased_row_bytes(hap_ct):
+    """ldp_phased_row_bytes (include/ldprune_hip.h)"""
+    s = hap_ct // 2
+    return (((s + 3) // 4 + 3) & ~3) + (s + 7) // 8
+
+
+def pack_phased_rows(codes_packed, phaseinfo_bits, sample_ct):
+    """(M, >= ceil(S/4)) uint8 packed 2-bit codes + (M, S) 0/1 phaseinfo -> rows in the LDP_GENO_PHASED layout"""
+    m = codes_packed.shape[0]
+    cb = (sample_ct + 3) // 4
+    off = (cb + 3) & ~3
+    out = np.zeros((m, phased_row_bytes(2 * sample_ct)), dtype=np.uint8)
+    out[:, :cb] = np.ascontiguousarray(codes_packed).view(np.uint8).reshape(m, -1)[:, :cb]
+    bits = np.packbits(np.asarray(phaseinfo_bits, dtype=np.uint8) & 1, axis=1, bitorder="little")
+    out[:, off:off + bits.shape[1]] = bits
+    return out
+
+
 class PgenFile:
     """ctypes mirror of the ldp_pgen_* reader (main track of .bed / .pgen files)."""
 
@@ -229,6 +251,23 @@ class PgenFile:
         rc = self._L.ldp_pgen_read(self._h, first, n, out.ctypes.data_as(ctypes.c_void_p), out.strides[0] if n else 1, threads)
         if rc != LDP_OK:
             raise LdpError(rc, self._L.ldp_pgen_last_error(self._h).decode())
+        return out
+
+    def read_phased(self, first=0, n=None, sample_mask=None, threads=0):
+        """Rows in the LDP_GENO_REF | LDP_GENO_PHASED layout (2-bit codes, padding to a dword, phaseinfo bits).
+        Raises LdpError(LDP_ERR_UNPHASED) -- .unphased_variant set -- when a het call of a masked sample has no phase."""
+        n = self.variant_ct - first if n is None else n
+        out = np.zeros((n, phased_row_bytes(2 * self.sample_ct)), dtype=np.uint8)
+        mask = None
+        if sample_mask is not None:
+            mask = np.packbits(np.asarray(sample_mask, dtype=bool), bitorder="little")
+        bad = ctypes.c_uint32(0xffffffff)
+        rc = self._L.ldp_pgen_read_phased(self._h, first, n, out.ctypes.data_as(ctypes.c_void_p), out.strides[0] if n else 1,
+                                          mask.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)) if mask is not None else None, threads, ctypes.byref(bad))
+        if rc != LDP_OK:
+            err = LdpError(rc, self._L.ldp_pgen_last_error(self._h).decode())
+            err.unphased_variant = bad.value
+            raise err
         return out
 
     def read_alleles(self, variant, alt_ct):

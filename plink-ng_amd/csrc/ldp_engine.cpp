@@ -689,7 +689,7 @@ int ensure_staging(ldp_engine* e) {
   if (e->h_stage[0]) {
     return LDP_OK;
   }
-  const size_t row_bytes = (static_cast<size_t>(e->P.founder_ct) + 3) / 4;
+  const size_t row_bytes = std::max<size_t>((static_cast<size_t>(e->P.founder_ct) + 3) / 4, ldp_phased_row_bytes(e->P.founder_ct)) + 4;
   const size_t bytes = std::max(kStageBytes, row_bytes);
   for (uint32_t k = 0; k < kStageSlots; ++k) {
     HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_stage[k]), bytes, hipHostMallocDefault));
@@ -1830,13 +1830,19 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
   if (!e->planned) {
     return fail(e, LDP_ERR_STATE, "ldp_set_variants() first");
   }
-  if ((encoding < LDP_GENO_INVERSE) || (encoding > LDP_GENO_BED) || ((location != LDP_MEM_HOST) && (location != LDP_MEM_DEVICE))) {
+  const bool phased = (encoding & LDP_GENO_PHASED) != 0;
+  const int base_encoding = encoding & ~LDP_GENO_PHASED;
+  if ((base_encoding < LDP_GENO_INVERSE) || (base_encoding > LDP_GENO_BED) || (phased && (base_encoding == LDP_GENO_BED)) ||
+      ((location != LDP_MEM_HOST) && (location != LDP_MEM_DEVICE))) {
     return fail(e, LDP_ERR_INVALID, "bad encoding/location");
+  }
+  if (phased && (e->P.founder_ct & 1)) {
+    return fail(e, LDP_ERR_INVALID, "LDP_GENO_PHASED rows need an even founder_ct (haplotype count = 2 x samples)");
   }
   if ((static_cast<uint64_t>(first_variant) + n > e->variant_ct) || (n && !geno)) {
     return fail(e, LDP_ERR_INVALID, "variant range out of bounds");
   }
-  const uint64_t row_bytes = (static_cast<uint64_t>(e->P.founder_ct) + 3) / 4;
+  const uint64_t row_bytes = phased ? ldp_phased_row_bytes(e->P.founder_ct) : ((static_cast<uint64_t>(e->P.founder_ct) + 3) / 4);
   if (stride_bytes < row_bytes) {
     return fail(e, LDP_ERR_INVALID, "stride smaller than a genotype row");
   }
@@ -1847,14 +1853,16 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
   HIP_TRY(e, hipSetDevice(e->device));
   const uint8_t* src = static_cast<const uint8_t*>(geno);
   // Host input goes through a 3-deep ring of pinned staging buffers: host threads gather rows into
-  // pinned memory (packed to row_bytes) while the previous slot's H2D copy and prepare kernel are in flight.
+  // pinned memory (packed to row_bytes rounded up to a dword, so the conversion kernel's wide loads stay aligned)
+  // while the previous slot's H2D copy and prepare kernel are in flight.
+  const uint64_t pack_stride = (row_bytes + 3) & ~static_cast<uint64_t>(3);
   size_t stage_rows = 0;
   if (location == LDP_MEM_HOST) {
     rc = ensure_staging(e);
     if (rc) {
       return rc;
     }
-    stage_rows = std::max<size_t>(1, kStageBytes / row_bytes);
+    stage_rows = std::max<size_t>(1, kStageBytes / pack_stride);
   }
   // loading a variant a second time since the last epoch began starts a new epoch (see begin_load_epoch)
   for (uint32_t q = first_variant; q < first_variant + n; ++q) {
@@ -1900,22 +1908,23 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
         HIP_TRY(e, hipEventSynchronize(e->stage_done[slot]));  // slot free again?
         uint8_t* pin = e->h_stage[slot];
         const uint8_t* from = src + static_cast<uint64_t>(g + done - first_variant) * stride_bytes;
-        const uint32_t kRowsPerTask = std::max<uint32_t>(1, static_cast<uint32_t>((4ull << 20) / row_bytes));
+        const uint32_t kRowsPerTask = std::max<uint32_t>(1, static_cast<uint32_t>((4ull << 20) / pack_stride));
         const uint32_t tasks = (cnt + kRowsPerTask - 1) / kRowsPerTask;
         parallel_for(tasks, 16, [&](uint32_t t) {
           const uint32_t r0 = t * kRowsPerTask;
           const uint32_t r1 = std::min(cnt, r0 + kRowsPerTask);
-          if (stride_bytes == row_bytes) {
-            memcpy(pin + static_cast<uint64_t>(r0) * row_bytes, from + static_cast<uint64_t>(r0) * row_bytes, static_cast<uint64_t>(r1 - r0) * row_bytes);
+          if (stride_bytes == pack_stride) {
+            const uint64_t len = static_cast<uint64_t>(r1 - r0 - 1) * pack_stride + row_bytes;  // the last row may end at the caller's buffer end
+            memcpy(pin + static_cast<uint64_t>(r0) * pack_stride, from + static_cast<uint64_t>(r0) * pack_stride, len);
           } else {
             for (uint32_t r = r0; r < r1; ++r) {
-              memcpy(pin + static_cast<uint64_t>(r) * row_bytes, from + static_cast<uint64_t>(r) * stride_bytes, row_bytes);
+              memcpy(pin + static_cast<uint64_t>(r) * pack_stride, from + static_cast<uint64_t>(r) * stride_bytes, row_bytes);
             }
           }
         });
-        HIP_TRY(e, hipMemcpyAsync(e->d_stage[slot], pin, static_cast<size_t>(cnt) * row_bytes, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(e, hipMemcpyAsync(e->d_stage[slot], pin, static_cast<size_t>(cnt) * pack_stride, hipMemcpyHostToDevice, e->stream));
         d_src = e->d_stage[slot];
-        d_stride = row_bytes;
+        d_stride = pack_stride;
       } else {
         d_src = src + static_cast<uint64_t>(g + done - first_variant) * stride_bytes;
       }
@@ -1952,7 +1961,7 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
       for (uint32_t q = 0; q < cnt; ++q) {
         e->loaded[l0 + q] = 1;
         e->load_tag[l0 + q] = e->load_epoch;
-        if (encoding != LDP_GENO_INVERSE) {
+        if (base_encoding != LDP_GENO_INVERSE) {
           e->mf_set[l0 + q] = 2;  // derived from the device's allele counts at the next ldp_run()
         }
       }

@@ -117,8 +117,60 @@ __device__ __forceinline__ void planes_from_words(uint32_t w0, uint32_t w1, int 
   *r2h_out = r2h;
 }
 
+// --indep-pairphase input (LDP_GENO_PHASED, include/ldprune_hip.h): 16 samples (one dword of 2-bit codes + 16 phaseinfo
+// bits) -> 32 haplotypes = one dword of each plane.  Haplotype h (1 = carries the counted allele) is stored as the
+// genotype code 2h: hom plane = non-missing, ref2het plane = non-missing and h == 0, x = 1 - 2h.  Then, against the
+// reference's nm / sum / dot of plink2_ld.cc:1456-1481:  N*dot_x - S1*S2 = 4*(nm*dot - sum1*sum2),
+// N*ssq - S^2 = 4*sum*(nm - sum), so cov12^2 > thr*var1*var2 compares 16x both sides of :1713 -- the same decision,
+// power-of-two scalings being exact.  Which of a sample's two haplotypes gets the het's counted allele follows
+// HapsplitMustPhased (pgenlib_misc.cc:1917: het + phaseinfo -> the second one).
+__device__ __forceinline__ void hap_planes_of_16(uint32_t w, uint32_t phase16, uint32_t* hom, uint32_t* r2h) {
+  const uint32_t lo = w & 0x55555555u;
+  const uint32_t hi = (w >> 1) & 0x55555555u;
+  const uint32_t miss = lo & hi;
+  const uint32_t het = lo & ~hi;
+  const uint32_t two = hi & ~lo;
+  uint32_t ph = phase16 & 0xffffu;  // bit s -> bit 2s
+  ph = (ph | (ph << 8)) & 0x00ff00ffu;
+  ph = (ph | (ph << 4)) & 0x0f0f0f0fu;
+  ph = (ph | (ph << 2)) & 0x33333333u;
+  ph = (ph | (ph << 1)) & 0x55555555u;
+  const uint32_t first = two | (het & ~ph);
+  const uint32_t second = two | (het & ph);
+  const uint32_t carries = first | (second << 1);
+  const uint32_t nm = ~(miss | (miss << 1));
+  *hom = nm;
+  *r2h = nm & ~carries;
+}
+
 __device__ __forceinline__ void convert_plane_pair(const uint8_t* row, uint32_t nbytes, bool aligned4, bool aligned16, int encoding,
                                                    uint32_t founder_ct, uint32_t p, uint32_t (&hom)[2], uint32_t (&r2h)[2]) {
+  if (encoding & LDP_GENO_PHASED) {
+    // plane dwords p, p+1 = haplotypes [32p, 32p+64) = samples [16p, 16p+32): code bytes [4p, 4p+8), phase bytes [2p, 2p+4)
+    const uint32_t samples = founder_ct >> 1;
+    const uint32_t code_bytes = (samples + 3) >> 2;
+    const uint32_t phase_off = (code_bytes + 3) & ~3u;
+    const uint32_t phase_bytes = (samples + 7) >> 3;
+    const uint32_t ph = load_geno_dword(row + phase_off, phase_bytes, p >> 1, aligned4);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t w = load_geno_dword(row, code_bytes, p + k, aligned4);
+      uint32_t h, r;
+      hap_planes_of_16(w, ph >> (16 * k), &h, &r);
+      const uint32_t first_hap = (p + k) * 32;
+      if (first_hap >= founder_ct) {
+        h = 0;
+        r = 0;
+      } else if (founder_ct - first_hap < 32) {
+        const uint32_t mask = (1u << (founder_ct - first_hap)) - 1;
+        h &= mask;
+        r &= mask;
+      }
+      hom[k] = h;
+      r2h[k] = r;
+    }
+    return;
+  }
   // p is even; input bytes [8p, 8p+16)
   // global_load_dwordx4 only needs dword alignment on gfx950, which is all a packed row guarantees
   typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -250,7 +302,7 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
     rec.n_het = 0;
     rec.n_homalt = 0;
     rec.reserved = 0;
-    if (A.encoding != LDP_GENO_INVERSE) {
+    if ((A.encoding & 3) != LDP_GENO_INVERSE) {
       // plink2_filter.cc:2137-2147: freq = ref * (1 / tot), 1/2 when nothing is observed;
       // major = REF iff freq >= 0.5 (plink2_common.h:559-567)
       const uint64_t ref_ct = 2ull * n0 + n1;

@@ -421,14 +421,116 @@ const void* ldp_pgen_direct_rows(const ldp_pgen* P, uint64_t* stride_bytes) {
   return P->map + P->data_off;
 }
 
-int ldp_pgen_read(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_rows, uint64_t stride_bytes, uint32_t threads) {
+}  // extern "C"
+
+namespace {
+
+// Hardcall-phase track (pgen_spec.tex:541-562; parsed as ParseAux2Subset does, pgenlib_read.cc:6774-6836) of a record
+// whose main track has just been decoded into `row`: writes the phaseinfo bit of every phased het call to `phase`
+// (ceil(sample_ct/8) bytes, zeroed here).  Returns false on a malformed track; *unphased = some het call of a
+// masked sample carries no phase.
+bool decode_phase(const ldp_pgen* P, uint32_t v, const uint8_t* row, const uint8_t* aux2, const uint8_t* sample_mask, uint8_t* phase, bool* unphased) {
+  const uint32_t n = P->sample_ct;
+  const uint64_t phase_bytes = (static_cast<uint64_t>(n) + 7) / 8;
+  memset(phase, 0, phase_bytes);
+  *unphased = false;
+  const bool has_track = (P->vrtype[v] & 0x10) != 0;
+  const uint8_t* end = P->map + P->fpos[v + 1];
+  uint32_t het_ct = 0;
+  if (has_track) {
+    for (uint64_t b = 0; b < P->rec_bytes; ++b) {
+      const uint32_t x = row[b];
+      het_ct += __builtin_popcount(x & ~(x >> 1) & 0x55u);
+    }
+    if (static_cast<uint64_t>(end - aux2) < 1 + het_ct / 8) {
+      return false;
+    }
+  }
+  const bool explicit_present = has_track && (aux2[0] & 1);
+  const uint8_t* info = aux2;  // implicit: phaseinfo bits 1..het_ct of the first part
+  uint64_t info_bit = 1;
+  if (explicit_present) {
+    uint32_t present_ct = 0;
+    for (uint32_t b = 0; b < 1 + het_ct / 8; ++b) {
+      present_ct += __builtin_popcount(aux2[b]);
+    }
+    present_ct -= 1;
+    info = aux2 + 1 + het_ct / 8;
+    info_bit = 0;
+    if ((!present_ct) || (static_cast<uint64_t>(end - info) < (present_ct + 7) / 8)) {
+      return false;
+    }
+  }
+  uint64_t het_idx = 0;
+  for (uint32_t s = 0; s < n; ++s) {
+    if (((row[s >> 2] >> (2 * (s & 3))) & 3) != 1) {
+      continue;
+    }
+    bool present = has_track;
+    if (explicit_present) {
+      const uint64_t pb = 1 + het_idx;
+      present = (aux2[pb >> 3] >> (pb & 7)) & 1;
+    }
+    ++het_idx;
+    if (!present) {
+      if ((!sample_mask) || ((sample_mask[s >> 3] >> (s & 7)) & 1)) {
+        *unphased = true;
+      }
+      continue;
+    }
+    if ((info[info_bit >> 3] >> (info_bit & 7)) & 1) {
+      phase[s >> 3] |= static_cast<uint8_t>(1u << (s & 7));
+    }
+    ++info_bit;
+  }
+  return true;
+}
+
+int read_impl(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_rows, uint64_t stride_bytes, uint32_t threads,
+              bool phased, const uint8_t* sample_mask, uint32_t* unphased_variant) {
   if (!P || (n && !out_rows)) {
     return LDP_ERR_INVALID;
   }
-  if ((static_cast<uint64_t>(first_variant) + n > P->variant_ct) || (stride_bytes < P->rec_bytes)) {
+  const uint64_t phase_off = (P->rec_bytes + 3) & ~static_cast<uint64_t>(3);
+  const uint64_t need_bytes = phased ? (phase_off + (static_cast<uint64_t>(P->sample_ct) + 7) / 8) : P->rec_bytes;
+  if ((static_cast<uint64_t>(first_variant) + n > P->variant_ct) || (stride_bytes < need_bytes)) {
     return pfail(P, LDP_ERR_INVALID, "variant range / stride out of bounds");
   }
   uint8_t* out = static_cast<uint8_t*>(out_rows);
+  if (phased && (P->mode == 0x01 || P->mode == 0x02)) {
+    // no phase track in the fixed-width modes: any het call is unphased
+    std::atomic<uint32_t> lowest(UINT32_MAX);
+    for (uint32_t k = 0; k < n; ++k) {
+      uint8_t* row = out + k * stride_bytes;
+      memcpy(row, P->map + P->data_off + (static_cast<uint64_t>(first_variant) + k) * P->rec_bytes, P->rec_bytes);
+      memset(row + P->rec_bytes, 0, need_bytes - P->rec_bytes);
+      if (P->mode == 0x01) {
+        // .bed -> .pgen codes (PgrPlink1ToPlink2InplaceUnsafe, pgenlib_read.cc:2157): phased rows are always REF-coded
+        static const uint8_t conv[4] = {2, 3, 1, 0};
+        for (uint64_t b = 0; b < P->rec_bytes; ++b) {
+          const uint32_t x = row[b];
+          row[b] = static_cast<uint8_t>(conv[x & 3] | (conv[(x >> 2) & 3] << 2) | (conv[(x >> 4) & 3] << 4) | (conv[x >> 6] << 6));
+        }
+        const uint32_t rem = P->sample_ct & 3;
+        if (rem) {
+          row[P->rec_bytes - 1] &= static_cast<uint8_t>((1u << (2 * rem)) - 1);
+        }
+      }
+      for (uint32_t s = 0; s < P->sample_ct; ++s) {
+        if ((((row[s >> 2] >> (2 * (s & 3))) & 3) == 1) && ((!sample_mask) || ((sample_mask[s >> 3] >> (s & 7)) & 1))) {
+          lowest.store(std::min(lowest.load(), first_variant + k));
+          break;
+        }
+      }
+    }
+    if (lowest.load() != UINT32_MAX) {
+      if (unphased_variant) {
+        *unphased_variant = lowest.load();
+      }
+      return pfail(P, LDP_ERR_UNPHASED, "a heterozygous call has no phase");
+    }
+    return LDP_OK;
+  }
   if (P->mode == 0x01 || P->mode == 0x02) {
     for (uint32_t k = 0; k < n; ++k) {
       memcpy(out + k * stride_bytes, P->map + P->data_off + (static_cast<uint64_t>(first_variant) + k) * P->rec_bytes, P->rec_bytes);
@@ -454,6 +556,7 @@ int ldp_pgen_read(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_row
   }
   std::atomic<uint32_t> next(0);
   std::atomic<int> bad(0);
+  std::atomic<uint32_t> lowest_unphased(UINT32_MAX);
   auto worker = [&]() {
     std::vector<uint8_t> ldbase(P->rec_bytes), scratch(P->rec_bytes);
     for (uint32_t t = next.fetch_add(1); t < tasks.size(); t = next.fetch_add(1)) {
@@ -472,9 +575,27 @@ int ldp_pgen_read(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_row
           continue;  // only the base row matters before the wanted range
         }
         uint8_t* dst = (v >= want_first) ? (out + static_cast<uint64_t>(v - first_variant) * stride_bytes) : scratch.data();
-        if (!decode_record(P, v, have_base ? ldbase.data() : nullptr, dst)) {
+        const uint8_t* track_end = nullptr;
+        if (!decode_record(P, v, have_base ? ldbase.data() : nullptr, dst, &track_end)) {
           bad.store(1);
           return;
+        }
+        if (phased && (v >= want_first)) {
+          if (P->vrtype[v] & 8) {
+            bad.store(2);  // multiallelic record: the phase track sits behind aux track 1
+            return;
+          }
+          memset(dst + P->rec_bytes, 0, phase_off - P->rec_bytes);
+          bool unphased = false;
+          if (!decode_phase(P, v, dst, track_end, sample_mask, dst + phase_off, &unphased)) {
+            bad.store(1);
+            return;
+          }
+          if (unphased) {
+            uint32_t cur = lowest_unphased.load();
+            while ((v < cur) && !lowest_unphased.compare_exchange_weak(cur, v)) {
+            }
+          }
         }
         if (!is_ld) {
           memcpy(ldbase.data(), dst, P->rec_bytes);
@@ -495,10 +616,32 @@ int ldp_pgen_read(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_row
       t.join();
     }
   }
+  if (bad.load() == 2) {
+    return pfail(P, LDP_ERR_UNSUPPORTED, "phased read of a multiallelic record is not supported yet");
+  }
   if (bad.load()) {
     return pfail(P, LDP_ERR_INVALID, "malformed variant record in .pgen file");
   }
+  if (lowest_unphased.load() != UINT32_MAX) {
+    if (unphased_variant) {
+      *unphased_variant = lowest_unphased.load();
+    }
+    return pfail(P, LDP_ERR_UNPHASED, "a heterozygous call has no phase");
+  }
   return LDP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ldp_pgen_read(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_rows, uint64_t stride_bytes, uint32_t threads) {
+  return read_impl(P, first_variant, n, out_rows, stride_bytes, threads, false, nullptr, nullptr);
+}
+
+int ldp_pgen_read_phased(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_rows, uint64_t stride_bytes,
+                         const uint8_t* sample_mask, uint32_t threads, uint32_t* unphased_variant) {
+  return read_impl(P, first_variant, n, out_rows, stride_bytes, threads, true, sample_mask, unphased_variant);
 }
 
 int ldp_pgen_variant_is_multiallelic(const ldp_pgen* P, uint32_t variant) {

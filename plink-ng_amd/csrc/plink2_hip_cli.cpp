@@ -25,6 +25,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdint>
@@ -278,6 +279,7 @@ char* format_g6(double x, char* out) {
 struct Args {
   std::string bed, bim, fam, pgen, pvar, psam, out = "plink2";
   bool have_prune = false;
+  bool pairphase = false;  // --indep-pairphase instead of --indep-pairwise
   uint32_t window = 0, step = 1;
   bool window_is_bp = false;
   double r2 = 0.0;
@@ -369,26 +371,31 @@ Args parse_args(int argc, char** argv) {
       else if (f == "--psam") A.psam = v;
       else if (f == "--out") A.out = v;
       else A.preferred = v;
-    } else if (f == "--indep-pairwise") {
+    } else if (f == "--indep-pairwise" || f == "--indep-pairphase") {
+      if (A.have_prune) {
+        die(5, "Error: --indep-pairwise and --indep-pairphase cannot be used together.\n");
+      }
+      A.pairphase = (f == "--indep-pairphase");
+      const char* fl = f.c_str();
       // <window size>['kb'] [step size (variant ct)] <unphased-hardcall-r^2 threshold>   (plink2.cc:7238-7313)
       std::vector<std::string> par;
       while (i + 1 < argc && !(argv[i + 1][0] == '-' && argv[i + 1][1] == '-')) {
         par.emplace_back(argv[++i]);
       }
       if (par.size() < 2 || par.size() > 4) {
-        die(5, "Error: --indep-pairwise accepts 2-4 arguments.\n");
+        die(5, "Error: %s accepts 2-4 arguments.\n", fl);
       }
       double first;
       const char* endp;
       if (!scan_double_plink(par[0].c_str(), &first, &endp) || first < 0.0) {
-        die(5, "Error: Invalid --indep-pairwise window size '%s'.\n", par[0].c_str());
+        die(5, "Error: Invalid %s window size '%s'.\n", fl, par[0].c_str());
       }
       size_t next = 1;
       bool is_kb = false;
       if (ieq(endp, "kb")) {
         is_kb = true;
       } else if (*endp) {
-        die(5, "Error: Invalid --indep-pairwise window size '%s'.\n", par[0].c_str());
+        die(5, "Error: Invalid %s window size '%s'.\n", fl, par[0].c_str());
       } else if (ieq(par[1].c_str(), "kb")) {
         is_kb = true;
         next = 2;
@@ -400,7 +407,7 @@ Args parse_args(int argc, char** argv) {
         } else {
           const int32_t w = static_cast<int32_t>(first * 1000 * (1 + kSmallEpsilon));
           if (w < 2) {
-            die(5, "Error: --indep-pairwise window size cannot be smaller than 2.\n");
+            die(5, "Error: %s window size cannot be smaller than 2.\n", fl);
           }
           A.window = w;
         }
@@ -412,23 +419,23 @@ Args parse_args(int argc, char** argv) {
         char* e2;
         const long st = strtol(par[next].c_str(), &e2, 10);
         if (*e2 || st < 1 || st > 2147483646) {
-          die(5, "Error: Invalid --indep-pairwise window-increment '%s'.\n", par[next].c_str());
+          die(5, "Error: Invalid %s window-increment '%s'.\n", fl, par[next].c_str());
         }
         A.step = static_cast<uint32_t>(st);
         if (!is_kb) {
           if (A.step > A.window) {
-            die(5, "Error: --indep-pairwise window-increment cannot be larger than window size.\n");
+            die(5, "Error: %s window-increment cannot be larger than window size.\n", fl);
           }
         } else if (A.step != 1) {
-          die(5, "Error: --indep-pairwise window-increment must be 1 when window size is in\nkilobase units.\n");
+          die(5, "Error: %s window-increment must be 1 when window size is in\nkilobase units.\n", fl);
         }
         ++next;
       } else if (next + 1 != par.size()) {
-        die(5, "Error: Invalid --indep-pairwise argument sequence.\n");
+        die(5, "Error: Invalid %s argument sequence.\n", fl);
       }
       const char* e3;
       if (!scan_double_plink(par[next].c_str(), &A.r2, &e3) || *e3 || A.r2 < 0.0 || A.r2 >= 1.0) {
-        die(5, "Error: Invalid --indep-pairwise r^2 threshold '%s'.\n", par[next].c_str());
+        die(5, "Error: Invalid %s r^2 threshold '%s'.\n", fl, par[next].c_str());
       }
       A.have_prune = true;
     } else if (f == "--r2-unphased") {
@@ -954,7 +961,10 @@ struct SexPlan {
 inline uint32_t code_at(const uint8_t* row, uint32_t s) { return (row[s >> 2] >> (2 * (s & 3))) & 3; }
 
 // raw_row: REF-based pgen codes of all samples.  Writes the PgrGetInv1-style row (+ het->missing) and maj_freq.
-void build_sex_row(const SexPlan& sp, const uint8_t* raw_row, uint8_t* out_row, uint64_t out_rec, double* maj_freq) {
+// phase != nullptr (--indep-pairphase on chrX, plink2_ld.cc:2060-2097): the non-male founders contribute their two
+// haplotypes, split by the phaseinfo bits of all samples (HapsplitMustPhased), instead of their genotype twice; a
+// haplotype h is carried as the genotype code 2h (include/ldprune_hip.h, LDP_GENO_PHASED).
+void build_sex_row(const SexPlan& sp, const uint8_t* raw_row, uint8_t* out_row, uint64_t out_rec, double* maj_freq, const uint8_t* phase = nullptr) {
   uint64_t g[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0};
   for (uint32_t s : sp.part1) {
     ++m[code_at(raw_row, s)];
@@ -999,6 +1009,24 @@ void build_sex_row(const SexPlan& sp, const uint8_t* raw_row, uint8_t* out_row, 
     c = (c == 1) ? 3u : (alt_major ? inv[c] : c);  // SetHetMissing
     out_row[f >> 2] |= static_cast<uint8_t>(c << (2 * (f & 3)));
     ++f;
+  }
+  if (phase) {
+    for (uint32_t s : sp.part2) {
+      const uint32_t c = code_at(raw_row, s);
+      const bool ph = (phase[s >> 3] >> (s & 7)) & 1;
+      uint32_t hap[2] = {3, 3};
+      if (c != 3) {
+        const bool alt_first = (c == 2) || ((c == 1) && ph);
+        const bool alt_second = (c == 2) || ((c == 1) && !ph);
+        hap[0] = (alt_first != alt_major) ? 2 : 0;
+        hap[1] = (alt_second != alt_major) ? 2 : 0;
+      }
+      for (int k = 0; k < 2; ++k) {
+        out_row[f >> 2] |= static_cast<uint8_t>(hap[k] << (2 * (f & 3)));
+        ++f;
+      }
+    }
+    return;
   }
   for (int rep = 0; rep < 2; ++rep) {
     for (uint32_t s : sp.part2) {
@@ -1069,7 +1097,7 @@ int main(int argc, char** argv) {
     die(7, "Error: This run estimates linkage disequilibrium between variants, but there\nare less than 50 founders to estimate from.  --make-founders may help.\n(Strictly speaking, you can also override this error with --bad-ld, but this is\nalmost always a bad idea.)\n");
   }
   if (founder_ct < 2) {
-    die(7, "Error: %s requires at least two founders. (--make-founders may come in handy here.)\n", A.have_prune ? "--indep-pairwise" : "--r2-unphased");
+    die(7, "Error: %s requires at least two founders. (--make-founders may come in handy here.)\n", A.have_prune ? (A.pairphase ? "--indep-pairphase" : "--indep-pairwise") : "--r2-unphased");
   }
 
   // ---- genotype file (.bed / fixed-width .pgen / standard variable-width .pgen)
@@ -1124,6 +1152,9 @@ int main(int argc, char** argv) {
       if (cls == 2) {
         die(3, "Error: Invalid chromosome code '%s'. (Use --allow-extra-chr to force it to be accepted.)\n", cur.c_str());
       }
+      if (A.pairphase && V.alt_ct[v] > 1) {
+        die(9, "Error: multiallelic variant '%s': --indep-pairphase on multiallelic variants is not supported yet by plink2-hip.\n", V.id[v].c_str());
+      }
       if (cls >= 3 && V.alt_ct[v] > 1) {
         die(9, "Error: multiallelic variant '%s' on chrX/chrY/MT is not supported yet by plink2-hip.\n", V.id[v].c_str());
       }
@@ -1134,7 +1165,7 @@ int main(int argc, char** argv) {
     }
   }
   if (skipped) {
-    logprintf("--%s: Ignoring %u chromosome 0 variant%s.\n", A.have_prune ? "indep-pairwise" : "r2-unphased", skipped, skipped == 1 ? "" : "s");
+    logprintf("--%s: Ignoring %u chromosome 0 variant%s.\n", A.have_prune ? (A.pairphase ? "indep-pairphase" : "indep-pairwise") : "r2-unphased", skipped, skipped == 1 ? "" : "s");
   }
   const uint32_t variant_ct = static_cast<uint32_t>(inc.size());
   if (A.window_is_bp || A.r2_table) {
@@ -1148,10 +1179,12 @@ int main(int argc, char** argv) {
     }
   }
 
-  // chrX and chrY variants run on engines of their own (different sample sets); MT stays with the autosomes
-  std::vector<uint32_t> mk, xk, yk;  // indices into inc[]
+  // chrX and chrY variants run on engines of their own (different sample sets); MT stays with the autosomes --
+  // except under --indep-pairphase, where the autosomes carry two haplotypes per founder and MT one
+  // (IndepPairphaseUpdateSubcontig, plink2_ld.cc:1491-1511)
+  std::vector<uint32_t> mk, xk, yk, tk;  // indices into inc[]
   for (uint32_t k = 0; k < variant_ct; ++k) {
-    (vcls[k] == 3 ? xk : (vcls[k] == 4 ? yk : mk)).push_back(k);
+    (vcls[k] == 3 ? xk : (vcls[k] == 4 ? yk : ((vcls[k] == 5 && A.pairphase) ? tk : mk))).push_back(k);
   }
   const uint32_t m_ct = static_cast<uint32_t>(mk.size());
   std::vector<uint32_t> m_chr(m_ct), m_bps(m_ct);
@@ -1469,7 +1502,7 @@ int main(int argc, char** argv) {
 
   ldp_params P;
   memset(&P, 0, sizeof(P));
-  P.founder_ct = founder_ct;
+  P.founder_ct = A.pairphase ? 2 * founder_ct : founder_ct;  // --indep-pairphase: haplotypes (plink2_ld.cc:1506)
   P.prune_window_size = A.window;
   P.prune_window_incr = A.step;
   P.window_is_bp = A.window_is_bp;
@@ -1487,8 +1520,8 @@ int main(int argc, char** argv) {
     ldp_get_band(e, nullptr, &cand);
     logprintf("dry-run: founders=%u variants=%u window=%u step=%u window_is_bp=%d r2=%a order=%d subcontigs=%u candidate_pairs=%llu\n",
               founder_ct, m_ct, A.window, A.step, A.window_is_bp ? 1 : 0, A.r2, A.order, sct, static_cast<unsigned long long>(cand));
-    if (!xk.empty() || !yk.empty()) {
-      logprintf("dry-run: chrX variants=%zu chrY variants=%zu (separate engines)\n", xk.size(), yk.size());
+    if (!xk.empty() || !yk.empty() || !tk.empty()) {
+      logprintf("dry-run: chrX variants=%zu chrY variants=%zu%s (separate engines)\n", xk.size(), yk.size(), tk.empty() ? "" : " + MT");
     }
     ldp_destroy(e);
     return 0;
@@ -1519,7 +1552,7 @@ int main(int argc, char** argv) {
     }
   }
   std::vector<uint64_t> removed((static_cast<size_t>(variant_ct) + 63) / 64 + 1, 0);
-  if (subcontig_ct || !xk.empty() || !yk.empty()) {
+  if (subcontig_ct || !xk.empty() || !yk.empty() || !tk.empty()) {
     // unique IDs (plink2_ld.cc:2573-2592)
     {
       // open-addressing table of variant indices keyed by a 64-bit FNV-1a hash of the ID
@@ -1538,7 +1571,7 @@ int main(int argc, char** argv) {
         uint64_t slot = (h ^ (h >> 29)) & mask;
         while (table[slot] != 0xffffffffu) {
           if (V.id[inc[table[slot]]] == id) {
-            die(7, "Error: --indep-pairwise requires unique variant IDs. (--set-all-var-ids and/or --rm-dup may help.)\n");
+            die(7, "Error: --indep-pair%s requires unique variant IDs. (--set-all-var-ids and/or --rm-dup may help.)\n", A.pairphase ? "phase" : "wise");
           }
           slot = (slot + 1) & mask;
         }
@@ -1566,7 +1599,7 @@ int main(int argc, char** argv) {
       }
       logprintf("--indep-preferred: %u variant%s loaded.\n", ct, ct == 1 ? "" : "s");
     }
-    logprintf("--indep-pairwise (%d GPU%s): ", world, world == 1 ? "" : "s");
+    logprintf("--indep-pair%s (%d GPU%s): ", A.pairphase ? "phase" : "wise", world, world == 1 ? "" : "s");
     fflush(stdout);
     const double t_load0 = now_s();
     if (A.timing) {
@@ -1578,7 +1611,22 @@ int main(int argc, char** argv) {
     // mapping; otherwise the founder columns are gathered on the host first (CopyNyparrNonemptySubset,
     // pgenlib_misc.cc:32,185).
     const bool all_founders = (founder_ct == raw_sample_ct);
-    const uint64_t out_rec = (static_cast<uint64_t>(founder_ct) + 3) / 4;
+    // --indep-pairphase rows: 2-bit codes, padding to a dword, phaseinfo bits (LDP_GENO_PHASED, ldprune_hip.h)
+    const uint64_t in_rec = A.pairphase ? ldp_phased_row_bytes(2 * raw_sample_ct) : rec_bytes;
+    const uint64_t in_phase_off = ldp_phased_phase_offset(2 * raw_sample_ct);
+    const uint64_t out_rec = A.pairphase ? ldp_phased_row_bytes(2 * founder_ct) : ((static_cast<uint64_t>(founder_ct) + 3) / 4);
+    const uint64_t out_phase_off = ldp_phased_phase_offset(2 * founder_ct);
+    const int load_encoding = A.pairphase ? (LDP_GENO_REF | LDP_GENO_PHASED) : encoding;
+    const uint8_t* direct = A.pairphase ? nullptr : direct_rows;  // phased rows always come through the decoder
+    std::vector<uint8_t> founder_mask((static_cast<size_t>(raw_sample_ct) + 7) / 8, 0);
+    for (uint32_t sidx = 0; sidx < raw_sample_ct; ++sidx) {
+      if (is_founder[sidx]) {
+        founder_mask[sidx >> 3] |= static_cast<uint8_t>(1u << (sidx & 7));
+      }
+    }
+    auto die_unphased = [&](uint32_t raw_v) {
+      die(7, "\nError: --indep-pairphase: 0-based variant #%u is not fully phased.\n", raw_v);  // plink2_ld.cc:2047
+    };
     std::vector<uint32_t> founder_idx;
     for (uint32_t s = 0; s < raw_sample_ct; ++s) {
       if (is_founder[s]) {
@@ -1610,7 +1658,7 @@ int main(int argc, char** argv) {
       // Chunks of ~256 MiB of decoded rows.  Variable-width .pgen: the next chunk is decoded (all host threads, see
       // ldp_pgen_read) while the engine takes the current one, two buffers alternating; small enough that the
       // buffers' first-touch page faults are paid once, large enough for ~60 decode tasks per chunk.
-      const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((direct_rows ? (1024ull << 20) : (256ull << 20)) / std::max<uint64_t>(rec_bytes, 1)));
+      const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((direct ? (1024ull << 20) : (256ull << 20)) / std::max<uint64_t>(in_rec, 1)));
       // never freed: returning ~0.5 GiB of touched pages to the kernel costs tens of ms and the process exits soon
       std::vector<uint8_t>* decoded = new std::vector<uint8_t>[2];
       std::vector<uint8_t> gather;
@@ -1630,13 +1678,17 @@ int main(int argc, char** argv) {
       }
       std::thread decoder;
       int decode_rc = 0;
+      uint32_t unphased_at = 0;
       auto start_decode = [&](size_t k) {
-        if (direct_rows || k >= runs.size()) {
+        if (direct || k >= runs.size()) {
           return;
         }
         std::vector<uint8_t>& buf = decoded[k & 1];
-        buf.resize(static_cast<size_t>(runs[k].n) * rec_bytes);
-        decoder = std::thread([&, k]() { decode_rc = ldp_pgen_read(pg, runs[k].raw0, runs[k].n, decoded[k & 1].data(), rec_bytes, 0); });
+        buf.resize(static_cast<size_t>(runs[k].n) * in_rec);
+        decoder = std::thread([&, k]() {
+          decode_rc = A.pairphase ? ldp_pgen_read_phased(pg, runs[k].raw0, runs[k].n, decoded[k & 1].data(), in_rec, founder_mask.data(), 0, &unphased_at)
+                                  : ldp_pgen_read(pg, runs[k].raw0, runs[k].n, decoded[k & 1].data(), rec_bytes, 0);
+        });
       };
       start_decode(0);
       for (size_t k = 0; k < runs.size(); ++k) {
@@ -1644,11 +1696,14 @@ int main(int argc, char** argv) {
         const uint32_t raw0 = runs[k].raw0;
         const uint32_t run = runs[k].n;
         const uint8_t* src;
-        uint64_t stride = rec_bytes;
-        if (direct_rows) {
-          src = direct_rows + static_cast<uint64_t>(raw0) * rec_bytes;
+        uint64_t stride = in_rec;
+        if (direct) {
+          src = direct + static_cast<uint64_t>(raw0) * rec_bytes;
         } else {
           decoder.join();
+          if (decode_rc == LDP_ERR_UNPHASED) {
+            die_unphased(unphased_at);
+          }
           if (decode_rc) {
             die(3, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
           }
@@ -1659,17 +1714,23 @@ int main(int argc, char** argv) {
           // gather the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185)
           gather.assign(static_cast<size_t>(run) * out_rec, 0);
           for (uint32_t w = 0; w < run; ++w) {
-            const uint8_t* in_row = src + static_cast<uint64_t>(w) * rec_bytes;
+            const uint8_t* in_row = src + static_cast<uint64_t>(w) * in_rec;
             uint8_t* out_row = gather.data() + static_cast<uint64_t>(w) * out_rec;
             for (uint32_t f = 0; f < founder_ct; ++f) {
               out_row[f >> 2] |= static_cast<uint8_t>(code_at(in_row, founder_idx[f]) << (2 * (f & 3)));
+            }
+            if (A.pairphase) {  // CopyBitarrSubset of phaseinfo (plink2_ld.cc:2075)
+              for (uint32_t f = 0; f < founder_ct; ++f) {
+                const uint32_t sidx = founder_idx[f];
+                out_row[out_phase_off + (f >> 3)] |= static_cast<uint8_t>(((in_row[in_phase_off + (sidx >> 3)] >> (sidx & 7)) & 1) << (f & 7));
+              }
             }
           }
           src = gather.data();
           stride = out_rec;
         }
         for (int r = 0; r < world; ++r) {
-          const int rc = ldp_load_genotypes(eng[r], q, run, src, stride, LDP_MEM_HOST, encoding);
+          const int rc = ldp_load_genotypes(eng[r], q, run, src, stride, LDP_MEM_HOST, load_encoding);
           if (rc) {
             die(12, "Error: %s\n", ldp_last_error(eng[r]));
           }
@@ -1744,23 +1805,33 @@ int main(int argc, char** argv) {
                 t_load0 - t_begin, t_load1 - t_load0, (t_run1 ? t_run1 : now_s()) - t_load1, c.ms_pair_kernel, c.ms_replay, static_cast<unsigned long long>(c.candidate_pairs), t_run1 ? now_s() - t_run1 : 0.0);
     }
     // ---- chrX, chrY: their own sample sets, rows built on the host, one engine each on device 0
-    for (int which = 0; which < 2; ++which) {
-      const std::vector<uint32_t>& ks = which ? yk : xk;
+    // (--indep-pairphase: MT too, one haplotype per founder with hets missing -- HapsplitHaploid, plink2_ld.cc:2051)
+    for (int which = 0; which < 3; ++which) {
+      const std::vector<uint32_t>& ks = (which == 0) ? xk : ((which == 1) ? yk : tk);
       if (ks.empty()) {
         continue;
       }
+      static const char* const kSexName[3] = {"X", "Y", "MT"};
       SexPlan sp;
       for (uint32_t sidx : founder_idx) {
-        if (!which) {
+        if (which == 0) {
           (sex[sidx] == 1 ? sp.part1 : sp.part2).push_back(sidx);  // males | non-males (female + unknown)
-        } else if (sex[sidx] != 2) {
-          sp.part1.push_back(sidx);                                  // non-females
+        } else if ((which == 2) || (sex[sidx] != 2)) {
+          sp.part1.push_back(sidx);                                  // non-females (chrY) / every founder (MT)
         }
       }
-      sp.x_freq = !which;
+      sp.x_freq = (which == 0);
+      const bool x_phased = A.pairphase && (which == 0) && !sp.part2.empty();
+      std::vector<uint8_t> nonmale_mask;
+      if (x_phased) {
+        nonmale_mask.assign((static_cast<size_t>(raw_sample_ct) + 7) / 8, 0);
+        for (uint32_t sidx : sp.part2) {
+          nonmale_mask[sidx >> 3] |= static_cast<uint8_t>(1u << (sidx & 7));
+        }
+      }
       const uint32_t fct = sp.out_ct();
       if (fct < 2) {
-        die(9, "\nError: fewer than two usable founders on chr%s; not supported by plink2-hip.\n", which ? "Y" : "X");
+        die(9, "\nError: fewer than two usable founders on chr%s; not supported by plink2-hip.\n", kSexName[which]);
       }
       ldp_params SP = P;
       SP.founder_ct = fct;
@@ -1772,12 +1843,13 @@ int main(int argc, char** argv) {
         s_bps[w] = bps[ks[w]];
       }
       if (ldp_create(&SP, &se) || ldp_set_variants(se, static_cast<uint32_t>(ks.size()), s_chr.data(), A.window_is_bp ? s_bps.data() : nullptr)) {
-        die(12, "\nError: chr%s engine setup failed.\n", which ? "Y" : "X");
+        die(12, "\nError: chr%s engine setup failed.\n", kSexName[which]);
       }
       const uint64_t s_rec = (static_cast<uint64_t>(fct) + 3) / 4;
       const uint32_t chunk = std::max<uint32_t>(1, static_cast<uint32_t>((256ull << 20) / std::max<uint64_t>(s_rec, 1)));
       std::vector<uint8_t> rows;
       std::vector<double> mfs;
+      std::atomic<uint32_t> x_unphased(UINT32_MAX);
       for (uint32_t w0 = 0; w0 < ks.size(); w0 += chunk) {
         const uint32_t cnt = std::min<uint32_t>(chunk, static_cast<uint32_t>(ks.size()) - w0);
         rows.assign(static_cast<size_t>(cnt) * s_rec, 0);
@@ -1786,15 +1858,34 @@ int main(int argc, char** argv) {
         std::vector<std::thread> pool;
         for (uint32_t t = 0; t < nthreads; ++t) {
           pool.emplace_back([&, t]() {
-            std::vector<uint8_t> raw_row(rec_bytes + 8);
+            std::vector<uint8_t> raw_row(in_rec + 8);
             for (uint32_t w = t; w < cnt; w += nthreads) {
-              fetch_raw_row(pg, storage_mode, inc[ks[w0 + w]], raw_sample_ct, rec_bytes, raw_row.data());
+              const uint32_t raw_v = inc[ks[w0 + w]];
+              if (x_phased) {
+                uint32_t at = 0;
+                const int prc = ldp_pgen_read_phased(pg, raw_v, 1, raw_row.data(), in_rec, nonmale_mask.data(), 1, &at);
+                if (prc == LDP_ERR_UNPHASED) {
+                  uint32_t cur = x_unphased.load();
+                  while ((raw_v < cur) && !x_unphased.compare_exchange_weak(cur, raw_v)) {
+                  }
+                  continue;
+                }
+                if (prc) {
+                  die(3, "\nError: %s\n", ldp_pgen_last_error(pg));
+                }
+                build_sex_row(sp, raw_row.data(), rows.data() + static_cast<uint64_t>(w) * s_rec, s_rec, &mfs[w], raw_row.data() + in_phase_off);
+                continue;
+              }
+              fetch_raw_row(pg, storage_mode, raw_v, raw_sample_ct, rec_bytes, raw_row.data());
               build_sex_row(sp, raw_row.data(), rows.data() + static_cast<uint64_t>(w) * s_rec, s_rec, &mfs[w]);
             }
           });
         }
         for (std::thread& t : pool) {
           t.join();
+        }
+        if (x_unphased.load() != UINT32_MAX) {
+          die_unphased(x_unphased.load());
         }
         if (ldp_load_genotypes(se, w0, cnt, rows.data(), s_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) || ldp_set_maj_freqs(se, w0, cnt, mfs.data())) {
           die(12, "\nError: %s\n", ldp_last_error(se));

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Golden vectors for --indep-pairphase, produced by the REFERENCE binary (oracle/_ref/plink2) in this container:
+phased VCFs written from seeded numpy haplotypes -> the reference's --vcf import (variable-width .pgen with the
+hardcall-phase track) -> its --indep-pairphase prune lists for a grid of windows / thresholds / scan orders.
+Kept: the small .pgen files the reference wrote (reader tests), the generating arrays, and the removed sets.
+Re-run:  python tests/golden/make_golden_pairphase.py"""
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import ldtools as T  # noqa: E402
+
+GRID = [(["50", "5"], 0.2, 2), (["50", "5"], 0.2, 1), (["50", "5"], 0.5, 2), (["30"], 0.5, 1),
+        (["20kb"], 0.2, 2), (["20kb"], 0.5, 1), (["8kb"], 0.8, 2)]
+
+
+def positions(m, nchr, seed):
+    rng = np.random.default_rng(seed)
+    per = (m + nchr - 1) // nchr
+    chr_idx = np.arange(m) // per
+    bps = np.zeros(m, dtype=np.uint32)
+    for c in range(nchr):
+        idx = np.where(chr_idx == c)[0]
+        gaps = rng.integers(1, 600, size=len(idx))
+        gaps = np.where(rng.random(len(idx)) < 0.01, gaps + 300000, gaps)
+        bps[idx] = 1000 + np.cumsum(gaps)
+    return [str(c + 1) for c in chr_idx], bps
+
+
+def main():
+    if not T.have_ref():
+        sys.exit("reference binary missing: make -C oracle ref")
+    os.makedirs(os.path.join(HERE, "pgen"), exist_ok=True)
+    tmp = tempfile.mkdtemp(prefix="golden_pp_")
+    try:
+        # ---- fully phased, some missing calls
+        m, n = 500, 150
+        raw, pp, pi = T.synth_phased(m, n, seed=20260925, missing_rate=0.02)
+        raw[17] = 0  # monomorphic
+        pp[17] = 0
+        pi[17] = 0
+        chroms, bps = positions(m, 3, 11)
+        ids = T.write_vcf(os.path.join(tmp, "a.vcf"), raw, chroms, bps, pp, pi)
+        T.ref_import_vcf(os.path.join(tmp, "a.vcf"), os.path.join(tmp, "a"))
+        out = dict(raw=raw, phasepresent=pp, phaseinfo=pi, chroms=np.array([int(c) for c in chroms], dtype=np.uint32), bps=bps)
+        for k, (win, r2, order) in enumerate(GRID):
+            kept, removed, log = T.ref_indep_pairwise(os.path.join(tmp, "a"), win, r2, order=order, mode="phase")
+            out["removed_%d" % k] = np.isin(np.array(ids), np.array(removed))
+            print("phased_small", win, r2, order, [ln for ln in log.splitlines() if "variants removed" in ln][-1])
+        out["grid"] = np.array(["%s|%r|%d" % (" ".join(w), r, o) for w, r, o in GRID])
+        shutil.copy(os.path.join(tmp, "a.pgen"), os.path.join(HERE, "pgen", "phased_small.pgen"))
+        np.savez_compressed(os.path.join(HERE, "pgen", "phased_small.npz"), **out)
+        # ---- partially phased (the reader must report phasepresent exactly; the command must refuse)
+        m2, n2 = 120, 67
+        raw2, pp2, pi2 = T.synth_phased(m2, n2, seed=7, missing_rate=0.05)
+        rng = np.random.default_rng(3)
+        drop = rng.random(raw2.shape) < 0.3
+        drop[:40] = False     # first 40 variants stay fully phased
+        drop[60:70] = True    # ten variants without any phase -> no phase track at all
+        pp2 = (pp2.astype(bool) & ~drop).astype(np.uint8)
+        pi2 = pi2 & pp2
+        chroms2, bps2 = positions(m2, 1, 5)
+        T.write_vcf(os.path.join(tmp, "b.vcf"), raw2, chroms2, bps2, pp2, pi2)
+        T.ref_import_vcf(os.path.join(tmp, "b.vcf"), os.path.join(tmp, "b"))
+        cp = T.run_ref(["--pfile", "b", "--indep-pairphase", "50", "5", "0.5", "--out", "b"], tmp)
+        msg = [ln for ln in cp.stdout.splitlines() if ln.startswith("Error")]
+        print("partial:", cp.returncode, msg)
+        shutil.copy(os.path.join(tmp, "b.pgen"), os.path.join(HERE, "pgen", "phased_partial.pgen"))
+        np.savez_compressed(os.path.join(HERE, "pgen", "phased_partial.npz"), raw=raw2, phasepresent=pp2, phaseinfo=pi2,
+                            ref_returncode=np.int32(cp.returncode), ref_error=np.array(msg[0] if msg else ""))
+    finally:
+        shutil.rmtree(tmp)
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,17 @@ class LdoPairStats(ctypes.Structure):
         return (self.nm, self.sum1, self.ssq1, self.sum2, self.ssq2, self.dot)
 
 
+class LdoVhaggs(ctypes.Structure):
+    _fields_ = [("nm_ct", ctypes.c_uint32), ("sum", ctypes.c_uint32)]
+
+
+class LdoHapPairStats(ctypes.Structure):
+    _fields_ = [("nm", ctypes.c_uint32), ("sum1", ctypes.c_uint32), ("sum2", ctypes.c_uint32), ("dot", ctypes.c_uint32)]
+
+    def astuple(self):
+        return (self.nm, self.sum1, self.sum2, self.dot)
+
+
 def build_oracle():
     if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < max(
             os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("ldoracle.c", "ldoracle.h")):
@@ -64,6 +75,16 @@ def oracle():
                                            ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_double,
                                            ctypes.c_int, u64p, u64p]
         lib.ldo_indep_pairwise.restype = ctypes.c_int
+        lib.ldo_hapsplit_must_phased.argtypes = [u64p, u64p, u64p, ctypes.c_uint32, u64p, u64p]
+        lib.ldo_hapsplit_must_phased.restype = ctypes.c_int
+        lib.ldo_hapsplit_haploid.argtypes = [u64p, ctypes.c_uint32, u64p, u64p]
+        lib.ldo_fill_vhaggs.argtypes = [u64p, u64p, ctypes.c_uint32, ctypes.POINTER(LdoVhaggs)]
+        lib.ldo_fill_vhaggs.restype = ctypes.c_int
+        lib.ldo_hap_pair_stats.argtypes = [u64p, u64p, ctypes.POINTER(LdoVhaggs), u64p, u64p, ctypes.POINTER(LdoVhaggs),
+                                           ctypes.c_uint32, ctypes.POINTER(LdoHapPairStats)]
+        lib.ldo_hap_exceeds.argtypes = [ctypes.POINTER(LdoHapPairStats), ctypes.c_double]
+        lib.ldo_indep_pairphase.argtypes = lib.ldo_indep_pairwise.argtypes
+        lib.ldo_indep_pairphase.restype = ctypes.c_int
         _oracle = lib
     return _oracle
 
@@ -171,6 +192,82 @@ def oracle_indep_pairwise(inv_words, n, chr_idx, bps, maj_freqs, window, step, i
     return bitmap_to_bool(removed, m), evals.value
 
 
+def pack_bits(bits):
+    """(M, N) 0/1 array -> (M, ceil(N/64)) uint64, sample s -> bit s%64 of word s//64"""
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    m, n = bits.shape
+    wc = (n + 63) // 64
+    padded = np.zeros((m, wc * 64), dtype=np.uint8)
+    padded[:, :n] = bits & 1
+    return np.ascontiguousarray(np.packbits(padded, axis=1, bitorder="little")).view(np.uint64).reshape(m, wc)
+
+
+def oracle_hapsplit(raw_codes, phasepresent, phaseinfo, haploid=False):
+    """REF-based codes (M, N) + per-sample phase bits (0/1 arrays, phaseinfo 1 = ALT on the first haplotype) ->
+    (hap_nm rows (M, 2*wc) uint64 in the major-allele-inverse coding the pruner sees, maj_freq, unphased flags, hap_ct).
+    Mirrors what the reference's loader hands to IndepPairphaseThread (plink2_ld.cc:2040-2052): PgrGetInv1P
+    output through HapsplitMustPhased / HapsplitHaploid."""
+    lib = oracle()
+    m, n = raw_codes.shape
+    inv, mf, altmaj = oracle_prepare(raw_codes)
+    hap_ct = n if haploid else 2 * n
+    wc = (hap_ct + 63) // 64
+    rows = np.zeros((m, 2 * wc), dtype=np.uint64)
+    unphased = np.zeros(m, dtype=bool)
+    pp = pack_bits(phasepresent)
+    gw = (n + 31) // 32
+    for v in range(m):
+        g = np.zeros(gw + 2, dtype=np.uint64)
+        g[:gw] = inv[v, :gw]
+        if haploid:
+            lib.ldo_hapsplit_haploid(_p(g, ctypes.c_uint64), n, _p(rows[v, :wc], ctypes.c_uint64), _p(rows[v, wc:], ctypes.c_uint64))
+            continue
+        # inverting the counted allele swaps which haplotype carries it (IMPLPgrGetInv1P, pgenlib_read.cc:7016)
+        info = phaseinfo[v:v + 1] ^ 1 if altmaj[v] else phaseinfo[v:v + 1]
+        pi = pack_bits(info & phasepresent[v:v + 1])
+        hap = np.zeros(gw + 1, dtype=np.uint64)
+        nm = np.zeros(gw + 1, dtype=np.uint64)
+        ppv = np.zeros(pp.shape[1] + 1, dtype=np.uint64)
+        ppv[:pp.shape[1]] = pp[v]
+        piv = np.zeros(pp.shape[1] + 1, dtype=np.uint64)
+        piv[:pp.shape[1]] = pi[0]
+        unphased[v] = bool(lib.ldo_hapsplit_must_phased(_p(g, ctypes.c_uint64), _p(ppv, ctypes.c_uint64), _p(piv, ctypes.c_uint64), n,
+                                                        _p(hap, ctypes.c_uint64), _p(nm, ctypes.c_uint64)))
+        rows[v, :wc] = hap[:wc]
+        rows[v, wc:] = nm[:wc]
+    return rows, mf, unphased, hap_ct
+
+
+def oracle_hap_pair_stats(rows, hap_ct, first, second):
+    lib = oracle()
+    wc = (hap_ct + 63) // 64
+    vh = [LdoVhaggs(), LdoVhaggs()]
+    for k, v in enumerate((first, second)):
+        lib.ldo_fill_vhaggs(_p(rows[v, :wc], ctypes.c_uint64), _p(rows[v, wc:], ctypes.c_uint64), wc, ctypes.byref(vh[k]))
+    st = LdoHapPairStats()
+    lib.ldo_hap_pair_stats(_p(rows[first, :wc], ctypes.c_uint64), _p(rows[first, wc:], ctypes.c_uint64), ctypes.byref(vh[0]),
+                           _p(rows[second, :wc], ctypes.c_uint64), _p(rows[second, wc:], ctypes.c_uint64), ctypes.byref(vh[1]),
+                           hap_ct, ctypes.byref(st))
+    return st
+
+
+def oracle_indep_pairphase(hap_nm_rows, hap_ct, chr_idx, bps, maj_freqs, window, step, is_bp, r2, order=2):
+    """Returns (removed bool array, pair evaluation count)."""
+    lib = oracle()
+    m = hap_nm_rows.shape[0]
+    rows = np.ascontiguousarray(hap_nm_rows, dtype=np.uint64)
+    chr_idx = np.ascontiguousarray(chr_idx, dtype=np.uint32)
+    bps = np.ascontiguousarray(bps, dtype=np.uint32)
+    maj_freqs = np.ascontiguousarray(maj_freqs, dtype=np.float64)
+    removed = np.zeros((m + 63) // 64 + 1, dtype=np.uint64)
+    evals = ctypes.c_uint64()
+    rc = lib.ldo_indep_pairphase(_p(rows, ctypes.c_uint64), rows.shape[1], m, hap_ct, _p(chr_idx, ctypes.c_uint32),
+                                 _p(bps, ctypes.c_uint32), _p(maj_freqs, ctypes.c_double), window, step, int(is_bp),
+                                 r2, int(order == 1), _p(removed, ctypes.c_uint64), ctypes.byref(evals))
+    assert rc == 0
+    return bitmap_to_bool(removed, m), evals.value
+
+
 def oracle_subcontig_split(chr_idx, bps, window):
     lib = oracle()
     chr_idx = np.ascontiguousarray(chr_idx, dtype=np.uint32)
@@ -254,6 +351,73 @@ def write_bed(prefix, raw_codes, chroms, bps, ids=None):
     return ids
 
 
+def synth_phase(raw_codes, seed, unphased_rate=0.0):
+    """Random phase for every het call: (phasepresent, phaseinfo) 0/1 arrays; phaseinfo 1 = "1|0"."""
+    rng = np.random.default_rng(seed)
+    het = (raw_codes == 1)
+    present = het & (rng.random(raw_codes.shape) >= unphased_rate)
+    info = present & (rng.random(raw_codes.shape) < 0.5)
+    return present.astype(np.uint8), info.astype(np.uint8)
+
+
+def synth_phased(m, n, seed, missing_rate=0.0, ld_copy_prob=0.5, redraw=0.05, maf_lo=0.01):
+    """Phased data with LD planted between consecutive variants on the haplotype level: returns (raw REF-based codes
+    (M, N), phasepresent, phaseinfo); every het is phased, phaseinfo 1 = ALT on the first haplotype ("1|0")."""
+    rng = np.random.default_rng(seed)
+    raw = np.empty((m, n), dtype=np.uint8)
+    info = np.zeros((m, n), dtype=np.uint8)
+    prev = None
+    for v in range(m):
+        maf = rng.uniform(maf_lo, 0.5)
+        if rng.random() < 0.5:
+            maf = 1.0 - maf
+        fresh = (rng.random((2, n)) < maf).astype(np.uint8)
+        if prev is not None and rng.random() < ld_copy_prob:
+            cur = np.where(rng.random((2, n)) >= redraw, prev, fresh)
+        else:
+            cur = fresh
+        prev = cur.copy()
+        code = (cur[0] + cur[1]).astype(np.uint8)
+        info[v] = ((code == 1) & (cur[0] == 1)).astype(np.uint8)
+        if missing_rate > 0:
+            code = np.where(rng.random(n) < missing_rate, 3, code).astype(np.uint8)
+        raw[v] = code
+    present = (raw == 1).astype(np.uint8)
+    return raw, present, info & present
+
+
+def write_vcf(path, raw_codes, chroms, bps, phasepresent=None, phaseinfo=None, ids=None):
+    """VCF 4.2 with GT only; phased hets written 0|1 / 1|0, everything else with '/'."""
+    m, n = raw_codes.shape
+    if ids is None:
+        ids = ["snp%d" % i for i in range(m)]
+    table = {0: "0/0", 1: "0/1", 2: "1/1", 3: "./."}
+    with open(path, "w") as f:
+        f.write("##fileformat=VCFv4.2\n")
+        for c in sorted(set(chroms), key=lambda x: (len(x), x)):
+            f.write("##contig=<ID=%s>\n" % c)
+        f.write('##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n')
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join("s%d" % s for s in range(n)) + "\n")
+        for v in range(m):
+            gts = []
+            for s in range(n):
+                c = int(raw_codes[v, s])
+                if c == 1 and phasepresent is not None and phasepresent[v, s]:
+                    gts.append("1|0" if phaseinfo[v, s] else "0|1")
+                else:
+                    gts.append(table[c])
+            f.write("%s\t%d\t%s\tA\tC\t.\t.\t.\tGT\t%s\n" % (chroms[v], bps[v], ids[v], "\t".join(gts)))
+    return ids
+
+
+def ref_import_vcf(vcf_path, prefix, extra=()):
+    """reference: --vcf -> variable-width .pgen (with the hardcall-phase track when the VCF has phased hets)"""
+    cp = run_ref(["--vcf", os.path.basename(vcf_path), "--make-pgen", "--out", os.path.basename(prefix)] + list(extra), os.path.dirname(prefix))
+    if cp.returncode != 0:
+        raise RuntimeError("reference plink2 --vcf failed:\n" + cp.stdout)
+    return cp.stdout
+
+
 def have_ref():
     return os.path.exists(REF_BIN) and os.access(REF_BIN, os.X_OK)
 
@@ -269,11 +433,11 @@ def read_id_list(path):
         return [ln.rstrip("\n") for ln in f if ln.strip()]
 
 
-def ref_indep_pairwise(prefix, window_args, r2, order=2, threads=2, bad_ld=True, fmt="pfile", extra=()):
-    """Run reference --indep-pairwise on <prefix>; returns (kept ids, removed ids, log text)."""
+def ref_indep_pairwise(prefix, window_args, r2, order=2, threads=2, bad_ld=True, fmt="pfile", extra=(), mode="wise"):
+    """Run reference --indep-pairwise (mode="phase": --indep-pairphase) on <prefix>; returns (kept ids, removed ids, log text)."""
     cwd = os.path.dirname(prefix)
     out = prefix + ".ref"
-    args = ["--" + fmt, os.path.basename(prefix), "--indep-pairwise"] + [str(a) for a in window_args] + [repr(float(r2))]
+    args = ["--" + fmt, os.path.basename(prefix), "--indep-pair" + mode] + [str(a) for a in window_args] + [repr(float(r2))]
     if order == 1:
         args += ["--indep-order", "1"]
     if bad_ld:

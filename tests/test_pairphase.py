@@ -1,0 +1,297 @@
+"""--indep-pairphase (plink2_ld.cc:1449-2163): the oracle restatement against the reference's recorded prune sets,
+the hardcall-phase reader against reference-written .pgen files, and (GPU) the HIP path against the oracle.
+Golden files: tests/golden/make_golden_pairphase.py."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import ldtools as T
+import __graft_entry__ as ge
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "pgen")
+
+
+def _grid(z):
+    for k, g in enumerate(z["grid"]):
+        win, r2, order = str(g).split("|")
+        win = win.split()
+        is_bp = win[0].endswith("kb")
+        window = int(float(win[0][:-2]) * 1000 * (1 + T.K_SMALL_EPSILON)) if is_bp else int(win[0])
+        step = 1 if (is_bp or len(win) < 2) else int(win[1])
+        yield k, window, step, is_bp, float(r2), int(order)
+
+
+def _chr_idx(z):
+    return (z["chroms"] - 1).astype(np.uint32)
+
+
+def test_oracle_pairphase_matches_reference_golden():
+    z = np.load(os.path.join(GOLD, "phased_small.npz"))
+    rows, mf, unphased, hap_ct = T.oracle_hapsplit(z["raw"], z["phasepresent"], z["phaseinfo"])
+    assert not unphased.any()
+    for k, window, step, is_bp, r2, order in _grid(z):
+        got, _ = T.oracle_indep_pairphase(rows, hap_ct, _chr_idx(z), z["bps"], mf, window, step, is_bp, r2, order)
+        assert np.array_equal(got, z["removed_%d" % k]), (k, window, r2, order)
+
+
+def test_oracle_detects_unphased_hets():
+    z = np.load(os.path.join(GOLD, "phased_partial.npz"))
+    _, _, unphased, _ = T.oracle_hapsplit(z["raw"], z["phasepresent"], z["phaseinfo"])
+    want = ((z["raw"] == 1) & (z["phasepresent"] == 0)).any(axis=1)
+    assert np.array_equal(unphased, want)
+    assert int(np.argmax(unphased)) == 40 and "variant #40 is not fully phased" in str(z["ref_error"])
+
+
+def test_haplotype_statistics_are_a_quarter_of_the_genotype_coded_ones():
+    """The device carries haplotype h as genotype code 2h (x = 1 - 2h); the reference's nm / sum / dot
+    (plink2_ld.cc:1456-1481) then satisfy N*dot_x - S1*S2 = 4*(nm*dot - sum1*sum2), N*ssq - S^2 = 4*sum*(nm-sum)."""
+    raw, pp, pi = T.synth_phased(40, 77, seed=3, missing_rate=0.1)
+    rows, _, _, hap_ct = T.oracle_hapsplit(raw, pp, pi)
+    wc = (hap_ct + 63) // 64
+    hap = T.bitmap_to_bool(rows[:, :wc].copy().reshape(-1), wc * 64 * 40).reshape(40, -1)[:, :hap_ct]
+    nm = T.bitmap_to_bool(rows[:, wc:].copy().reshape(-1), wc * 64 * 40).reshape(40, -1)[:, :hap_ct]
+    codes = np.where(nm, np.where(hap, 2, 0), 3).astype(np.uint8)
+    hom, r2h, vaggs = T.oracle_split(T.pack_2bit(codes), hap_ct)
+    for a, b in [(0, 1), (3, 9), (10, 39), (20, 21)]:
+        g = T.oracle_pair_stats(hom, r2h, vaggs, hap_ct, a, b)
+        h = T.oracle_hap_pair_stats(rows, hap_ct, a, b)
+        assert g.nm == h.nm
+        assert g.nm * g.dot - g.sum1 * g.sum2 == 4 * (h.nm * h.dot - h.sum1 * h.sum2)
+        assert g.nm * g.ssq1 - g.sum1 ** 2 == 4 * h.sum1 * (h.nm - h.sum1)
+        assert g.nm * g.ssq2 - g.sum2 ** 2 == 4 * h.sum2 * (h.nm - h.sum2)
+
+
+def _unpack_phased(rows, n):
+    cb = (n + 3) // 4
+    off = (cb + 3) & ~3
+    b = rows[:, :cb]
+    out = np.empty((rows.shape[0], cb * 4), dtype=np.uint8)
+    for k in range(4):
+        out[:, k::4] = (b >> (2 * k)) & 3
+    codes = out[:, :n]
+    phase = np.unpackbits(rows[:, off:], axis=1, bitorder="little")[:, :n]
+    return codes, phase
+
+
+def test_phase_track_reader_against_reference_written_file():
+    pkg = ge.load_package()
+    z = np.load(os.path.join(GOLD, "phased_small.npz"))
+    m, n = z["raw"].shape
+    pg = pkg.PgenFile(os.path.join(GOLD, "phased_small.pgen"))
+    assert (pg.variant_ct, pg.sample_ct) == (m, n)
+    rows = pg.read_phased()
+    codes, phase = _unpack_phased(rows, n)
+    assert np.array_equal(codes, z["raw"])
+    assert np.array_equal(phase, z["phaseinfo"] & (z["raw"] == 1))
+    # ragged ranges, one thread and many
+    for first, cnt, threads in [(0, 1, 1), (7, 300, 3), (499, 1, 0), (250, 250, 0)]:
+        part = pg.read_phased(first, cnt, threads=threads)
+        assert np.array_equal(part, rows[first:first + cnt])
+    pg.close()
+
+
+def test_phase_track_reader_reports_unphased_hets():
+    pkg = ge.load_package()
+    z = np.load(os.path.join(GOLD, "phased_partial.npz"))
+    m, n = z["raw"].shape
+    pg = pkg.PgenFile(os.path.join(GOLD, "phased_partial.pgen"))
+    rows = pg.read_phased(0, 40)  # the fully phased head
+    codes, phase = _unpack_phased(rows, n)
+    assert np.array_equal(codes, z["raw"][:40])
+    assert np.array_equal(phase, (z["phaseinfo"] & z["phasepresent"])[:40])
+    with pytest.raises(pkg.LdpError) as ei:
+        pg.read_phased()
+    assert ei.value.code == pkg.LDP_ERR_UNPHASED and ei.value.unphased_variant == 40
+    # only the samples in the mask matter (the reference checks after founder subsetting)
+    unphased = (z["raw"] == 1) & (z["phasepresent"] == 0)
+    mask = ~unphased[40:60].any(axis=0)
+    if mask.any():
+        pg.read_phased(0, 60, sample_mask=mask)
+        first_bad = int(np.argmax((unphased & mask[None, :]).any(axis=1))) if (unphased & mask[None, :]).any() else None
+        if first_bad is not None:
+            with pytest.raises(pkg.LdpError) as ei:
+                pg.read_phased(sample_mask=mask)
+            assert ei.value.unphased_variant == first_bad
+    pg.close()
+
+
+# ---------------------------------------------------------------------------------------------------------- GPU
+def _engine_rows(pkg, raw, pi):
+    return pkg.pack_phased_rows(T.pack_2bit(raw).view(np.uint8).reshape(raw.shape[0], -1), pi & (raw == 1), raw.shape[1])
+
+
+@pytest.mark.gpu
+def test_hip_pairphase_matches_reference_golden():
+    pkg = ge.load_package()
+    z = np.load(os.path.join(GOLD, "phased_small.npz"))
+    m, n = z["raw"].shape
+    rows = _engine_rows(pkg, z["raw"], z["phaseinfo"])
+    for k, window, step, is_bp, r2, order in _grid(z):
+        eng = pkg.LdPruneEngine(2 * n, window, step, is_bp, r2, order=order, device=0)
+        eng.set_variants(_chr_idx(z), z["bps"])
+        eng.load_genotypes_host(0, rows, pkg.LDP_GENO_REF | pkg.LDP_GENO_PHASED)
+        got = eng.run()
+        eng.close()
+        assert np.array_equal(got, z["removed_%d" % k]), (k, window, r2, order)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,miss", [(33, 0.0), (100, 0.03), (257, 0.0), (1000, 0.01), (2049, 0.0)])
+def test_hip_pairphase_matches_oracle(n, miss):
+    pkg = ge.load_package()
+    m = 400
+    raw, pp, pi = T.synth_phased(m, n, seed=1000 + n, missing_rate=miss)
+    raw[5] = 2
+    rng = np.random.default_rng(n)
+    chr_idx = np.sort(rng.integers(0, 2, size=m)).astype(np.uint32)
+    bps = np.zeros(m, dtype=np.uint32)
+    for c in range(2):
+        sel = np.where(chr_idx == c)[0]
+        bps[sel] = np.sort(rng.integers(1, 50000, size=len(sel)))
+    hrows, mf, unphased, hap_ct = T.oracle_hapsplit(raw, (raw == 1).astype(np.uint8), pi)
+    assert not unphased.any()
+    rows = _engine_rows(pkg, raw, pi)
+    for window, step, is_bp, r2, order in [(60, 7, False, 0.3, 2), (60, 7, False, 0.3, 1), (8000, 1, True, 0.5, 2), (8000, 1, True, 0.1, 1)]:
+        want, _ = T.oracle_indep_pairphase(hrows, hap_ct, chr_idx, bps, mf, window, step, is_bp, r2, order)
+        eng = pkg.LdPruneEngine(hap_ct, window, step, is_bp, r2, order=order, device=0)
+        eng.set_variants(chr_idx, bps)
+        # several uneven pieces
+        for a, b in [(0, 123), (123, 124), (124, m)]:
+            eng.load_genotypes_host(a, rows[a:b], pkg.LDP_GENO_REF | pkg.LDP_GENO_PHASED)
+        got = eng.run()
+        assert np.array_equal(eng.maj_freqs(), mf)
+        eng.close()
+        assert np.array_equal(got, want), (n, miss, window, r2, order)
+
+
+# ---------------------------------------------------------------------------------------------------------- CLI
+import filecmp  # noqa: E402
+import subprocess  # noqa: E402
+
+
+def _cli(pkg):
+    path = pkg.build_cli()
+    assert path and os.path.exists(path)
+    return path
+
+
+def _run(cli, args, cwd):
+    return subprocess.run([cli] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+
+
+def _phased_fileset(tmp, m, n, seed, chrom_plan, sexes=None, nonfounders=0, unphased_rate=0.0, missing=0.03):
+    """phased VCF -> the reference's import -> <tmp>/p.{pgen,pvar,psam}; .psam rewritten with parents / sex"""
+    raw, pp, pi = T.synth_phased(m, n, seed, missing_rate=missing)
+    if unphased_rate:
+        drop = np.random.default_rng(seed + 1).random(raw.shape) < unphased_rate
+        drop[:m // 3] = False
+        pp = (pp.astype(bool) & ~drop).astype(np.uint8)
+        pi = pi & pp
+    chroms, bps = [], []
+    for name, cnt in chrom_plan:
+        chroms += [name] * cnt
+        bps += list((3000000 if name == "X" else 1000) + 173 * np.arange(cnt))  # chrX: clear of PAR1
+    assert len(chroms) == m
+    T.write_vcf(os.path.join(tmp, "p.vcf"), raw, chroms, np.array(bps), pp, pi)
+    lines = ["#IID\tPAT\tMAT\tSEX"]
+    for s in range(n):
+        nf = (s % 11 == 3) and (s // 11 < nonfounders)
+        sx = "NA" if (sexes is None or sexes[s] == 0) else str(sexes[s])
+        lines.append("s%d\t%s\t%s\t%s" % (s, "s0" if nf else "0", "s1" if nf else "0", sx))
+    open(os.path.join(tmp, "in.psam"), "w").write("\n".join(lines) + "\n")
+    T.ref_import_vcf(os.path.join(tmp, "p.vcf"), os.path.join(tmp, "p"), extra=["--allow-extra-chr", "--psam", "in.psam"])
+    return raw, pp, pi
+
+
+def test_cli_pairphase_flag_parses(tmp_path):
+    pkg = ge.load_package()
+    cli = _cli(pkg)
+    z = np.load(os.path.join(GOLD, "phased_small.npz"))
+    m, n = z["raw"].shape
+    # a fileset around the reference-written phased .pgen
+    import shutil
+    shutil.copy(os.path.join(GOLD, "phased_small.pgen"), str(tmp_path / "g.pgen"))
+    with open(str(tmp_path / "g.pvar"), "w") as f:
+        f.write("#CHROM\tPOS\tID\tREF\tALT\n")
+        for v in range(m):
+            f.write("%d\t%d\tsnp%d\tA\tC\n" % (z["chroms"][v], z["bps"][v], v))
+    with open(str(tmp_path / "g.psam"), "w") as f:
+        f.write("#IID\tSEX\n" + "".join("s%d\tNA\n" % s for s in range(n)))
+    r = _run(cli, ["--pfile", "g", "--indep-pairphase", "20kb", "0.5", "--dry-run"], str(tmp_path))
+    assert r.returncode == 0, r.stdout
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("dry-run:")][0]
+    assert "founders=%d " % n in line and "window=20000 " in line and "window_is_bp=1" in line
+    r = _run(cli, ["--pfile", "g", "--indep-pairphase", "50", "60", "0.5", "--dry-run"], str(tmp_path))
+    assert r.returncode != 0 and "--indep-pairphase window-increment" in r.stdout
+    r = _run(cli, ["--pfile", "g", "--indep-pairphase", "50", "5", "0.5", "--indep-pairwise", "50", "5", "0.5", "--dry-run"], str(tmp_path))
+    assert r.returncode != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wargs,r2,order,nonfounders", [(["30kb"], "0.5", 2, 0), (["60", "7"], "0.2", 1, 5), (["100", "1"], "0.8", 2, 5)])
+def test_cli_pairphase_autosomes_match_reference(tmp_path, wargs, r2, order, nonfounders):
+    assert T.have_ref()
+    pkg = ge.load_package()
+    cli = _cli(pkg)
+    tmp = str(tmp_path)
+    _phased_fileset(tmp, 700, 131, seed=11 + order, chrom_plan=[("0", 3), ("1", 300), ("2", 250), ("7", 147)], nonfounders=nonfounders)
+    common = ["--pfile", "p", "--indep-pairphase"] + wargs + [r2] + (["--indep-order", "1"] if order == 1 else [])
+    ref = T.run_ref(common + ["--threads", "3", "--out", "ref"], tmp)
+    assert ref.returncode == 0, ref.stdout
+    got = _run(cli, common + ["--out", "hip"], tmp)
+    assert got.returncode == 0, got.stdout
+    for ext in (".prune.in", ".prune.out"):
+        assert filecmp.cmp(os.path.join(tmp, "ref" + ext), os.path.join(tmp, "hip" + ext), shallow=False), ext
+    assert 0 < len(open(os.path.join(tmp, "hip.prune.out")).read().split()) < 697
+    assert "Ignoring 3 chromosome 0 variants" in got.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wargs,order,unknown", [(["40kb"], 2, True), (["70", "9"], 1, False)])
+def test_cli_pairphase_sex_chromosomes_match_reference(tmp_path, wargs, order, unknown):
+    """chrX: male founders one haplotype each (hets missing), non-males two, split by phase; chrY / MT haploid
+    (plink2_ld.cc:2040-2110)."""
+    assert T.have_ref()
+    pkg = ge.load_package()
+    cli = _cli(pkg)
+    tmp = str(tmp_path)
+    n = 140
+    rng = np.random.default_rng(5)
+    sexes = rng.choice([1, 2, 0] if unknown else [1, 2], size=n, p=[0.45, 0.45, 0.1] if unknown else [0.5, 0.5])
+    _phased_fileset(tmp, 900, n, seed=21, chrom_plan=[("1", 180), ("2", 180), ("X", 180), ("Y", 180), ("MT", 180)], sexes=sexes, nonfounders=6)
+    common = ["--pfile", "p", "--indep-pairphase"] + wargs + ["0.3"] + (["--indep-order", "1"] if order == 1 else [])
+    ref = T.run_ref(common + ["--threads", "3", "--out", "ref"], tmp)
+    assert ref.returncode == 0, ref.stdout
+    got = _run(cli, common + ["--out", "hip"], tmp)
+    assert got.returncode == 0, got.stdout
+    ref_out = open(os.path.join(tmp, "ref.prune.out")).read().split()
+    hip_out = open(os.path.join(tmp, "hip.prune.out")).read().split()
+    diff = sorted(set(ref_out) ^ set(hip_out), key=lambda x: int(x[3:]))
+    assert not diff, "differs on %d variants, e.g. %s" % (len(diff), diff[:10])
+    for ext in (".prune.in", ".prune.out"):
+        assert filecmp.cmp(os.path.join(tmp, "ref" + ext), os.path.join(tmp, "hip" + ext), shallow=False), ext
+
+
+@pytest.mark.gpu
+def test_cli_pairphase_refuses_partially_phased_like_reference(tmp_path):
+    assert T.have_ref()
+    pkg = ge.load_package()
+    cli = _cli(pkg)
+    tmp = str(tmp_path)
+    _phased_fileset(tmp, 300, 90, seed=31, chrom_plan=[("1", 300)], unphased_rate=0.2)
+    common = ["--pfile", "p", "--indep-pairphase", "50", "5", "0.5"]
+    ref = T.run_ref(common + ["--out", "ref"], tmp)
+    got = _run(cli, common + ["--out", "hip"], tmp)
+    ref_err = [ln for ln in ref.stdout.splitlines() if ln.startswith("Error")]
+    hip_err = [ln for ln in got.stdout.splitlines() if ln.startswith("Error")]
+    assert ref.returncode == got.returncode == 7, (ref.returncode, got.returncode, got.stdout)
+    assert ref_err == hip_err and "is not fully phased" in hip_err[0]
+    # .bed input: every het is unphased
+    T.run_ref(["--pfile", "p", "--make-bed", "--out", "b"], tmp)
+    refb = T.run_ref(["--bfile", "b", "--indep-pairphase", "50", "5", "0.5", "--out", "refb"], tmp)
+    gotb = _run(cli, ["--bfile", "b", "--indep-pairphase", "50", "5", "0.5", "--out", "hipb"], tmp)
+    assert refb.returncode == gotb.returncode == 7
+    assert [ln for ln in refb.stdout.splitlines() if ln.startswith("Error")] == [ln for ln in gotb.stdout.splitlines() if ln.startswith("Error")]
