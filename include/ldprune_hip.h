@@ -63,11 +63,9 @@ enum {
    * decision is the same bit. */
   LDP_GENO_PHASED = 4
 };
-static inline uint64_t ldp_phased_row_bytes(uint32_t hap_ct) {
-  const uint64_t s = hap_ct / 2;
-  return (((s + 3) / 4 + 3) & ~(uint64_t)3) + (s + 7) / 8;
-}
-static inline uint64_t ldp_phased_phase_offset(uint32_t hap_ct) { return (((uint64_t)(hap_ct / 2) + 3) / 4 + 3) & ~(uint64_t)3; }
+/* bytes of one LDP_GENO_PHASED row / offset of its phaseinfo bits, for hap_ct haplotypes (= the engine's founder_ct) */
+uint64_t ldp_phased_row_bytes(uint32_t hap_ct);
+uint64_t ldp_phased_phase_offset(uint32_t hap_ct);
 
 enum { LDP_MEM_HOST = 0, LDP_MEM_DEVICE = 1 };
 

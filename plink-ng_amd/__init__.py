@@ -81,7 +81,7 @@ CABI_SYMBOLS = [
     "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
     "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
-    "ldp_pgen_variant_is_multiallelic", "ldp_pgen_read_alleles", "ldp_pgen_read_phased",
+    "ldp_pgen_variant_is_multiallelic", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
 ]
 
 
@@ -179,6 +179,10 @@ def lib():
     L.ldp_pgen_direct_rows.restype = ctypes.c_void_p
     L.ldp_pgen_read.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.c_uint32]
     L.ldp_pgen_variant_is_multiallelic.argtypes = [vp, ctypes.c_uint32]
+    L.ldp_phased_row_bytes.argtypes = [ctypes.c_uint32]
+    L.ldp_phased_row_bytes.restype = ctypes.c_uint64
+    L.ldp_phased_phase_offset.argtypes = [ctypes.c_uint32]
+    L.ldp_phased_phase_offset.restype = ctypes.c_uint64
     L.ldp_pgen_read_phased.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint8), ctypes.c_uint32,
                                        ctypes.POINTER(ctypes.c_uint32)]
     L.ldp_pgen_read_alleles.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8)]

@@ -1823,6 +1823,9 @@ int ldp_get_band(const ldp_engine* e, uint32_t* lo, uint64_t* candidate_pairs) {
   return LDP_OK;
 }
 
+uint64_t ldp_phased_phase_offset(uint32_t hap_ct) { return ((static_cast<uint64_t>(hap_ct / 2) + 3) / 4 + 3) & ~static_cast<uint64_t>(3); }
+uint64_t ldp_phased_row_bytes(uint32_t hap_ct) { return ldp_phased_phase_offset(hap_ct) + (static_cast<uint64_t>(hap_ct / 2) + 7) / 8; }
+
 int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* geno, uint64_t stride_bytes, int location, int encoding) {
   if (!e) {
     return LDP_ERR_INVALID;
