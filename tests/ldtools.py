@@ -331,6 +331,64 @@ def write_pgen_fixed(prefix, raw_codes, chroms, bps, ids=None, sexes=None):
     return ids
 
 
+def phased_pgen_records(raw_codes, phaseinfo):
+    """Variable-width .pgen records with the hardcall-phase track (pgen_spec.tex:541-562), every het phased: record =
+    raw 2-bit main track (type 0) + aux track 2 = 1 + H bits (bit 0 clear: no explicit phasepresent; then the H
+    phaseinfo bits of the het calls in sample order).  Returns (list of record bytes, vrtype array)."""
+    m, n = raw_codes.shape
+    rec = (n + 3) // 4
+    packed = pack_2bit(raw_codes).view(np.uint8).reshape(m, -1)[:, :rec]
+    records = []
+    vrtypes = np.zeros(m, dtype=np.uint8)
+    for v in range(m):
+        het = np.flatnonzero(raw_codes[v] == 1)
+        body = packed[v].tobytes()
+        if len(het):
+            bits = np.zeros(1 + len(het), dtype=np.uint8)
+            bits[1:] = phaseinfo[v, het] & 1
+            body += np.packbits(bits, bitorder="little").tobytes()
+            vrtypes[v] = 0x10
+        records.append(body)
+    return records, vrtypes
+
+
+def write_pgen_phased(prefix, raw_codes, phaseinfo, chroms, bps, ids=None, sexes=None, parents=None):
+    """Standard variable-width .pgen (storage mode 0x10, 8-bit record types, 3-byte record lengths;
+    pgen_spec.tex:160-235) whose records carry the hardcall-phase track, + .pvar + .psam."""
+    m, n = raw_codes.shape
+    records, vrtypes = phased_pgen_records(raw_codes, phaseinfo)
+    blocks = (m + 65535) // 65536
+    header_len = 12 + 8 * blocks + sum(min(65536, m - b * 65536) * 4 for b in range(blocks))
+    with open(prefix + ".pgen", "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x10]))
+        f.write(np.uint32(m).tobytes())
+        f.write(np.uint32(n).tobytes())
+        f.write(bytes([0x40 | 6]))
+        off = header_len
+        for b in range(blocks):
+            f.write(np.uint64(off).tobytes())
+            off += sum(len(r) for r in records[b * 65536:(b + 1) * 65536])
+        for b in range(blocks):
+            lo, hi = b * 65536, min(m, (b + 1) * 65536)
+            f.write(vrtypes[lo:hi].tobytes())
+            for r in records[lo:hi]:
+                f.write(len(r).to_bytes(3, "little"))
+        for r in records:
+            f.write(r)
+    if ids is None:
+        ids = ["snp%d" % i for i in range(m)]
+    with open(prefix + ".pvar", "w") as f:
+        f.write("#CHROM\tPOS\tID\tREF\tALT\n")
+        for i in range(m):
+            f.write("%s\t%d\t%s\tA\tC\n" % (chroms[i], bps[i], ids[i]))
+    with open(prefix + ".psam", "w") as f:
+        f.write("#IID\tPAT\tMAT\tSEX\n")
+        for s in range(n):
+            pat, mat = parents[s] if parents is not None else ("0", "0")
+            f.write("s%d\t%s\t%s\t%s\n" % (s, pat, mat, "NA" if (sexes is None or sexes[s] == 0) else str(sexes[s])))
+    return ids
+
+
 def write_bed(prefix, raw_codes, chroms, bps, ids=None):
     """PLINK 1 .bed/.bim/.fam (pgen_spec.tex:425-428: 00 hom-A1(ALT) 01 missing 10 het 11 hom-A2(REF))."""
     m, n = raw_codes.shape

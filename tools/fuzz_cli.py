@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised end-to-end comparison on the GPU box: plink2-hip against the reference binary (oracle/_ref/plink2) on
 random small filesets -- .bed or fixed-width .pgen, chromosome 0 rows, non-founders, missing calls, kb / count windows,
-both scan orders -- for --indep-pairwise (.prune.in/.prune.out) and the --r2-unphased table (.vcor).  Files must be
+both scan orders -- for --indep-pairwise (.prune.in/.prune.out), --indep-pairphase on phased variable-width .pgen
+(autosomes, chrX/chrY/MT with random sexes, non-founders) and the --r2-unphased table (.vcor).  Files must be
 byte-identical.
     python tools/fuzz_cli.py [--cases 40] [--seed 1]"""
 import argparse
@@ -24,7 +25,48 @@ def run(cmd, cwd):
     return subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
 
 
+def pairphase_case(cli, ref, rng, idx, tmp):
+    n = int(rng.choice([60, 97, 130, 513]))
+    m = int(rng.integers(80, 500))
+    raw, pp, pi = T.synth_phased(m, n, int(rng.integers(1, 1 << 30)), missing_rate=float(rng.choice([0.0, 0.02, 0.1])),
+                                 redraw=float(rng.choice([0.02, 0.1, 0.3])))
+    names = ["1", "2", "5"]
+    if rng.random() < 0.5:
+        names += ["X", "Y", "MT"]
+    cuts = np.sort(rng.integers(0, m, size=len(names) - 1))
+    sizes = np.diff(np.concatenate([[0], cuts, [m]]))
+    chroms, pos = [], []
+    for name, cnt in zip(names, sizes):
+        chroms += [name] * int(cnt)
+        pos += list((3000000 if name == "X" else 1) + np.sort(rng.integers(1, 60000, size=int(cnt))))
+    if rng.random() < 0.3 and sizes[0] > 3:
+        chroms[0] = chroms[1] = "0"
+    sexes = rng.choice([0, 1, 2], size=n, p=[0.1, 0.45, 0.45])
+    parents = [("s0", "s1") if (s > 1 and rng.random() < 0.05) else ("0", "0") for s in range(n)]
+    d = os.path.join(tmp, "c%d" % idx)
+    os.makedirs(d)
+    T.write_pgen_phased(os.path.join(d, "d"), raw, pi, chroms, np.array(pos), sexes=sexes, parents=parents)
+    if rng.random() < 0.5:
+        win = ["%gkb" % float(rng.choice([0.5, 2, 7.5, 20]))]
+    else:
+        w = int(rng.integers(2, 120))
+        win = [str(w), str(int(rng.integers(1, max(2, w))))]
+    args = ["--pfile", "d", "--indep-pairphase"] + win + [str(rng.choice([0.1, 0.2, 0.3, 0.5, 0.8])), "--indep-order", str(int(rng.integers(1, 3)))]
+    r = run([ref] + args + ["--out", "ref"], d)
+    g = run([cli] + args + ["--out", "hip"], d)
+    if r.returncode != g.returncode:
+        return False, "case %d: exit codes differ (ref %d, hip %d): %s\n%s\n%s" % (idx, r.returncode, g.returncode, " ".join(args), r.stdout[-300:], g.stdout[-400:])
+    if r.returncode != 0:
+        return True, "case %d: both refuse (%s)" % (idx, " ".join(args))
+    for e in (".prune.in", ".prune.out"):
+        if not filecmp.cmp(os.path.join(d, "ref" + e), os.path.join(d, "hip" + e), shallow=False):
+            return False, "case %d: %s differs: %s (n=%d m=%d chroms=%s)" % (idx, e, " ".join(args), n, m, ",".join(names))
+    return True, "case %d ok: %s (%s)" % (idx, " ".join(args), ",".join(names))
+
+
 def one_case(cli, ref, rng, idx, tmp):
+    if rng.random() < 0.3:
+        return pairphase_case(cli, ref, rng, idx, tmp)
     n = int(rng.choice([60, 97, 130, 513, 700]))
     m = int(rng.integers(60, 500))
     miss = float(rng.choice([0.0, 0.0, 0.01, 0.08]))
