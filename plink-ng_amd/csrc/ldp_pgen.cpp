@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -425,20 +426,61 @@ const void* ldp_pgen_direct_rows(const ldp_pgen* P, uint64_t* stride_bytes) {
 
 namespace {
 
-// Hardcall-phase track (pgen_spec.tex:541-562; parsed as ParseAux2Subset does, pgenlib_read.cc:6774-6836) of a record
-// whose main track has just been decoded into `row`: writes the phaseinfo bit of every phased het call to `phase`
-// (ceil(sample_ct/8) bytes, zeroed here).  Returns false on a malformed track; *unphased = some het call of a
-// masked sample carries no phase.
-bool decode_phase(const ldp_pgen* P, uint32_t v, const uint8_t* row, const uint8_t* aux2, const uint8_t* sample_mask, uint8_t* phase, bool* unphased) {
+// gather the bits of x selected by mask / scatter the low bits of x to the positions set in mask (pext / pdep);
+// the BMI2 instructions when the host has them (decided once), a loop over the set bits otherwise
+inline uint64_t pext64_loop(uint64_t x, uint64_t mask) {
+  uint64_t out = 0;
+  for (uint32_t k = 0; mask; mask &= mask - 1, ++k) {
+    out |= ((x >> __builtin_ctzll(mask)) & 1) << k;
+  }
+  return out;
+}
+inline uint64_t pdep64_loop(uint64_t x, uint64_t mask) {
+  uint64_t out = 0;
+  for (uint32_t k = 0; mask; mask &= mask - 1, ++k) {
+    out |= ((x >> k) & 1) << __builtin_ctzll(mask);
+  }
+  return out;
+}
+#if defined(__x86_64__)
+// (out of line on purpose: only these two functions may contain BMI2 instructions)
+__attribute__((target("bmi2"), noinline)) uint64_t pext64_hw(uint64_t x, uint64_t mask) { return __builtin_ia32_pext_di(x, mask); }
+__attribute__((target("bmi2"), noinline)) uint64_t pdep64_hw(uint64_t x, uint64_t mask) { return __builtin_ia32_pdep_di(x, mask); }
+#else
+inline uint64_t pext64_hw(uint64_t x, uint64_t mask) { return pext64_loop(x, mask); }
+inline uint64_t pdep64_hw(uint64_t x, uint64_t mask) { return pdep64_loop(x, mask); }
+#endif
+
+// up to 57 bits starting at bit `bit` of a byte stream that ends at `end` (bits past the end read as zero)
+inline uint64_t read_bits(const uint8_t* base, const uint8_t* end, uint64_t bit, uint32_t count) {
+  const uint8_t* p = base + (bit >> 3);
+  uint64_t w = 0;
+  if (p + 8 <= end) {
+    memcpy(&w, p, 8);
+  } else if (p < end) {
+    memcpy(&w, p, static_cast<size_t>(end - p));
+  }
+  w >>= (bit & 7);
+  return (count >= 64) ? w : (w & ((1ull << count) - 1));
+}
+
+template <bool HW>
+bool decode_phase_impl(const ldp_pgen* P, uint32_t v, const uint8_t* row, const uint8_t* aux2, const uint8_t* sample_mask, uint8_t* phase, bool* unphased) {
   const uint32_t n = P->sample_ct;
   const uint64_t phase_bytes = (static_cast<uint64_t>(n) + 7) / 8;
-  memset(phase, 0, phase_bytes);
   *unphased = false;
   const bool has_track = (P->vrtype[v] & 0x10) != 0;
   const uint8_t* end = P->map + P->fpos[v + 1];
+  const uint64_t m5 = 0x5555555555555555ull;
   uint32_t het_ct = 0;
   if (has_track) {
-    for (uint64_t b = 0; b < P->rec_bytes; ++b) {
+    uint64_t b = 0;
+    for (; b + 8 <= P->rec_bytes; b += 8) {
+      uint64_t g;
+      memcpy(&g, row + b, 8);
+      het_ct += static_cast<uint32_t>(__builtin_popcountll(g & ~(g >> 1) & m5));
+    }
+    for (; b < P->rec_bytes; ++b) {
       const uint32_t x = row[b];
       het_ct += __builtin_popcount(x & ~(x >> 1) & 0x55u);
     }
@@ -447,8 +489,9 @@ bool decode_phase(const ldp_pgen* P, uint32_t v, const uint8_t* row, const uint8
     }
   }
   const bool explicit_present = has_track && (aux2[0] & 1);
-  const uint8_t* info = aux2;  // implicit: phaseinfo bits 1..het_ct of the first part
+  const uint8_t* info = aux2;  // implicit: phaseinfo = bits 1..het_ct of the first part
   uint64_t info_bit = 1;
+  uint64_t present_bit = 1;    // explicit: phasepresent = bits 1..het_ct of the first part
   if (explicit_present) {
     uint32_t present_ct = 0;
     for (uint32_t b = 0; b < 1 + het_ct / 8; ++b) {
@@ -461,29 +504,57 @@ bool decode_phase(const ldp_pgen* P, uint32_t v, const uint8_t* row, const uint8
       return false;
     }
   }
-  uint64_t het_idx = 0;
-  for (uint32_t s = 0; s < n; ++s) {
-    if (((row[s >> 2] >> (2 * (s & 3))) & 3) != 1) {
-      continue;
-    }
-    bool present = has_track;
-    if (explicit_present) {
-      const uint64_t pb = 1 + het_idx;
-      present = (aux2[pb >> 3] >> (pb & 7)) & 1;
-    }
-    ++het_idx;
-    if (!present) {
-      if ((!sample_mask) || ((sample_mask[s >> 3] >> (s & 7)) & 1)) {
-        *unphased = true;
+  // 32 samples (one 64-bit word of codes) at a time
+  bool any_unphased = false;
+  for (uint32_t s0 = 0; s0 < n; s0 += 32) {
+    const uint64_t byte0 = s0 >> 2;
+    uint64_t g = 0;
+    const uint64_t avail = P->rec_bytes - byte0;
+    memcpy(&g, row + byte0, avail < 8 ? avail : 8);
+    const uint64_t het64 = g & ~(g >> 1) & m5;
+    const uint32_t out_bytes = static_cast<uint32_t>(std::min<uint64_t>(4, phase_bytes - (s0 >> 3)));
+    uint32_t ph32 = 0;
+    if (het64) {
+      const uint32_t het32 = static_cast<uint32_t>(HW ? pext64_hw(het64, m5) : pext64_loop(het64, m5));
+      const uint32_t k = static_cast<uint32_t>(__builtin_popcount(het32));
+      uint32_t present32 = has_track ? het32 : 0;
+      if (explicit_present) {
+        const uint64_t pres = read_bits(aux2, end, present_bit, k);
+        present_bit += k;
+        present32 = static_cast<uint32_t>(HW ? pdep64_hw(pres, het32) : pdep64_loop(pres, het32));
       }
-      continue;
+      const uint32_t kk = static_cast<uint32_t>(__builtin_popcount(present32));
+      if (kk) {
+        const uint64_t bits = read_bits(info, end, info_bit, kk);
+        info_bit += kk;
+        ph32 = static_cast<uint32_t>(HW ? pdep64_hw(bits, present32) : pdep64_loop(bits, present32));
+      }
+      uint32_t missing_phase = het32 & ~present32;
+      if (missing_phase && sample_mask) {
+        uint32_t mk = 0;
+        memcpy(&mk, sample_mask + (s0 >> 3), out_bytes);
+        missing_phase &= mk;
+      }
+      any_unphased |= (missing_phase != 0);
     }
-    if ((info[info_bit >> 3] >> (info_bit & 7)) & 1) {
-      phase[s >> 3] |= static_cast<uint8_t>(1u << (s & 7));
-    }
-    ++info_bit;
+    memcpy(phase + (s0 >> 3), &ph32, out_bytes);
   }
+  *unphased = any_unphased;
   return true;
+}
+
+// Hardcall-phase track (pgen_spec.tex:541-562; parsed as ParseAux2Subset does, pgenlib_read.cc:6774-6836) of a record
+// whose main track has just been decoded into `row`: writes the phaseinfo bit of every phased het call to `phase`
+// (ceil(sample_ct/8) bytes).  Returns false on a malformed track; *unphased = some het call of a masked sample
+// carries no phase.
+bool decode_phase(const ldp_pgen* P, uint32_t v, const uint8_t* row, const uint8_t* aux2, const uint8_t* sample_mask, uint8_t* phase, bool* unphased) {
+#if defined(__x86_64__)
+  static const bool have_bmi2 = __builtin_cpu_supports("bmi2") && !getenv("LDP_PGEN_NO_BMI2");  // (the variable: tests of the portable path)
+  if (have_bmi2) {
+    return decode_phase_impl<true>(P, v, row, aux2, sample_mask, phase, unphased);
+  }
+#endif
+  return decode_phase_impl<false>(P, v, row, aux2, sample_mask, phase, unphased);
 }
 
 int read_impl(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_rows, uint64_t stride_bytes, uint32_t threads,
