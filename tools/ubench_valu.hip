@@ -9,7 +9,8 @@
 
 constexpr int kIters = 4096;
 
-// MODE 0: 8 independent v_bcnt chains; 1: v_and; 2: v_bitop3 (xor-and); 3: the kernel's mix per pair-dword
+// MODE 0: 8 independent v_bcnt chains; 1: v_and; 2: v_bitop3 (xor-and); 3: the kernel's mix per pair-dword;
+// 4: the missing-call (general) kernel's mix per pair-dword: 9 logic ops + 7 v_bcnt
 template <int MODE>
 __global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, uint32_t seed) {
   uint32_t a[8], x = seed + threadIdx.x, y = seed * 3 + threadIdx.x, z = seed * 7;
@@ -24,6 +25,25 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, uint32_t seed)
         asm volatile("v_and_b32 %0, %1, %0" : "+v"(a[k]) : "v"(x));
       } else if (MODE == 2) {
         asm volatile("v_bitop3_b32 %0, %1, %0, %2 bitop3:0x48" : "+v"(a[k]) : "v"(x), "v"(y));
+      } else if (MODE == 4) {
+        uint32_t h, t, iN, iP, n2, n3, n4, n5, n6;
+        const uint32_t iH = a[(k + 1) & 7], iR = a[(k + 2) & 7];
+        asm volatile("v_and_b32 %0, %1, %2" : "=v"(h) : "v"(x), "v"(iH));
+        asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x48" : "=v"(t) : "v"(y), "v"(h), "v"(iR));
+        asm volatile("v_or_b32 %0, %1, %2" : "=v"(iN) : "v"(iH), "v"(iR));
+        asm volatile("v_and_b32 %0, %1, %2" : "=v"(iP) : "v"(iH), "v"(iR));
+        asm volatile("v_and_b32 %0, %1, %2" : "=v"(n2) : "v"(iN), "v"(z));
+        asm volatile("v_and_b32 %0, %1, %2" : "=v"(n3) : "v"(iN), "v"(x));
+        asm volatile("v_and_b32 %0, %1, %2" : "=v"(n4) : "v"(iN), "v"(y));
+        asm volatile("v_and_b32 %0, %1, %2" : "=v"(n5) : "v"(z), "v"(iH));
+        asm volatile("v_and_b32 %0, %1, %2" : "=v"(n6) : "v"(z), "v"(iP));
+        asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[k]) : "v"(h));
+        asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[(k + 3) & 7]) : "v"(t));
+        asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[(k + 4) & 7]) : "v"(n2));
+        asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[(k + 5) & 7]) : "v"(n3));
+        asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[(k + 6) & 7]) : "v"(n4));
+        asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[(k + 7) & 7]) : "v"(n5));
+        asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[k]) : "v"(n6));
       } else {
         uint32_t h, t;
         asm volatile("v_and_b32 %0, %1, %2" : "=v"(h) : "v"(x), "v"(a[(k + 1) & 7]));
@@ -69,6 +89,7 @@ int main() {
     run<1>("v_and_b32", bpc, 1);
     run<2>("v_bitop3_b32", bpc, 1);
     run<3>("and+bitop3+2bcnt mix", bpc, 4);
+    run<4>("general mix (9 logic+7 bcnt)", bpc, 16);
   }
   return 0;
 }
