@@ -293,6 +293,7 @@ struct Args {
   int r2_float = -1;      // 1 bin4, 0 bin
   bool yes_really = false;
   bool r2_table = false;   // --r2-unphased without a matrix shape: windowed .vcor table
+  bool r2_inter = false;   // 'inter-chr': the table over ALL pairs, chromosome 0 included (plink2_ld.cc:11082-11116)
   bool r2_text = false;    // matrix shape without bin/bin4: text matrix
   uint32_t ld_var_ct_radius = 0x7fffffff;  // --ld-window N: N - 1
   uint32_t ld_bp_radius = 0xffffffffu;     // --ld-window-kb; UINT32_MAX = not given (table default 1000 kb)
@@ -445,6 +446,7 @@ Args parse_args(int argc, char** argv) {
         if (m == "square") A.r2_shape = 0;
         else if (m == "square0") A.r2_shape = 1;
         else if (m == "triangle") A.r2_shape = 2;
+        else if (m == "inter-chr") A.r2_inter = true;
         else if (m == "bin") A.r2_float = 0;
         else if (m == "bin4") A.r2_float = 1;
         else if (m == "yes-really") A.yes_really = true;
@@ -453,6 +455,9 @@ Args parse_args(int argc, char** argv) {
       }
       if ((A.r2_shape < 0) && (A.r2_float >= 0)) {
         die(5, "Error: --r2-unphased 'bin' and 'bin4' require a matrix shape (square, square0 or triangle).\n");
+      }
+      if (A.r2_inter && (A.r2_shape >= 0)) {
+        die(5, "Error: Multiple --r2-unphased shape modifiers.\n");
       }
       A.r2_table = (A.r2_shape < 0);
       A.r2_text = (A.r2_shape >= 0) && (A.r2_float < 0);  // shape without bin/bin4: tab-delimited text matrix
@@ -544,10 +549,12 @@ Args parse_args(int argc, char** argv) {
   if ((ld_window_given || A.ld_min_r2 != 2.0) && !A.have_r2) {
     die(5, "Error: --ld-window.../--ld-snp... must be used with --r[2]-[un]phased.\n");  // plink2.cc:12960
   }
-  if (A.have_r2 && !A.r2_table) {
+  if (A.have_r2 && ((!A.r2_table) || A.r2_inter)) {
     if (ld_window_given) {  // plink2.cc:11175-11179
       die(5, "Error: All-pairs --r2-unphased settings cannot be used with --ld-window/--ld-window-kb/--ld-window-cm.\n");
     }
+  }
+  if (A.have_r2 && !A.r2_table) {
     if (A.ld_min_r2 != 2.0) {  // plink2.cc:11186-11191
       die(5, "Error: Matrix-only and table-only --r2-unphased settings cannot be used together.\n");
     }
@@ -1142,7 +1149,7 @@ int main(int argc, char** argv) {
         first = false;
         cls = chrom_class(cur, A.allow_extra_chr, &zero);
       }
-      if (zero && (A.have_prune || A.r2_table)) {  // (the matrix shapes keep chromosome 0: they are all-pairs)
+      if (zero && (A.have_prune || (A.r2_table && !A.r2_inter))) {  // (the all-pairs modes keep chromosome 0)
         ++skipped;
         continue;
       }
@@ -1212,8 +1219,11 @@ int main(int argc, char** argv) {
     if (ldp_create(&RP, &e)) {
       die(12, "Error: engine setup failed.\n");
     }
-    if (A.r2_table ? ldp_set_variants_vcor(e, variant_ct, chr_idx.data(), bps.data(), A.ld_bp_radius, A.ld_var_ct_radius)
-                   : ldp_set_variants_matrix(e, variant_ct)) {
+    if (A.r2_inter && (A.ld_min_r2 <= 0.0) && (variant_ct > 400000) && !A.yes_really) {  // plink2_ld.cc:11087
+      die(7, "Error: Gigantic (over 400k variants) --r2-unphased unfiltered, non-distributed\ncomputation.  Rerun with the 'yes-really' modifier if you are SURE you have enough\nhard drive space and want to do this.\n");
+    }
+    if ((A.r2_table && !A.r2_inter) ? ldp_set_variants_vcor(e, variant_ct, chr_idx.data(), bps.data(), A.ld_bp_radius, A.ld_var_ct_radius)
+                                    : ldp_set_variants_matrix(e, variant_ct)) {
       die(12, "Error: engine setup failed: %s\n", ldp_last_error(e));
     }
     const std::string base = A.out + (A.r2_text ? ".unphased.vcor2" : ".unphased.vcor2.bin");
@@ -1283,10 +1293,12 @@ int main(int argc, char** argv) {
       //      --ld-window-r2, A-major; default column set (plink2_ld.h:101)
       std::vector<uint32_t> lo(std::max<uint32_t>(variant_ct, 1));
       uint64_t cand = 0;
-      ldp_get_band(e, lo.data(), &cand);
+      if (!A.r2_inter) {
+        ldp_get_band(e, lo.data(), &cand);
+      }
       // hi[i] = last second variant paired with i (lo is nondecreasing inside a chromosome and == j outside windows)
       std::vector<uint32_t> hi(variant_ct);
-      {
+      if (!A.r2_inter) {
         uint32_t j = 0;
         for (uint32_t i = 0; i < variant_ct; ++i) {
           j = std::max(j, i);
@@ -1331,6 +1343,110 @@ int main(int argc, char** argv) {
       }
       fputs("#CHROM_A\tPOS_A\tID_A\tCHROM_B\tPOS_B\tID_B\tUNPHASED_R2\n", tf);
       const double thresh = A.ld_min_r2;
+      if (A.r2_inter) {
+        // ---- inter-chr: every pair A < B of the whole variant set, chromosome 0 included (plink2_ld.cc:11082-11116).
+        // The r^2 values come row chunk by row chunk (second variant B) from the all-pairs plan; pairs that pass
+        // --ld-window-r2 are kept as (A, B, r^2) and bucketed by A afterwards, which gives the file's A-major order.
+        struct Hit {
+          uint32_t i, j;
+          double r2;
+        };
+        std::vector<Hit> hits;
+        std::vector<double> chunk;
+        const uint32_t nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        for (uint32_t r0 = 0; r0 < variant_ct;) {
+          uint32_t rows = static_cast<uint32_t>(std::max<uint64_t>(32, (1ull << 28) / (static_cast<uint64_t>(r0 + 4096) * 8)));
+          rows = std::min(std::min(rows, variant_ct - r0), 65536u);
+          const uint64_t ld = static_cast<uint64_t>(r0) + rows;
+          chunk.assign(static_cast<size_t>(rows) * ld, 0.0);
+          if (ldp_r2_unphased_rows(e, r0, rows, 0, chunk.data(), ld)) {
+            die(12, "Error: %s\n", ldp_last_error(e));
+          }
+          std::vector<std::vector<Hit>> part(nthreads);
+          std::vector<std::thread> pool;
+          for (uint32_t t = 0; t < nthreads; ++t) {
+            pool.emplace_back([&, t]() {
+              const uint32_t q0 = static_cast<uint32_t>(static_cast<uint64_t>(rows) * t / nthreads);
+              const uint32_t q1 = static_cast<uint32_t>(static_cast<uint64_t>(rows) * (t + 1) / nthreads);
+              for (uint32_t q = q0; q < q1; ++q) {
+                const uint32_t j = r0 + q;
+                const double* row = chunk.data() + static_cast<uint64_t>(q) * ld;
+                for (uint32_t i = 0; i < j; ++i) {
+                  const double r2 = row[i];
+                  if ((thresh >= 0.0) && (!(fabs(r2) >= thresh))) {  // VcorTableWriteThread :10816-10821
+                    continue;
+                  }
+                  part[t].push_back({i, j, r2});
+                }
+              }
+            });
+          }
+          for (std::thread& th : pool) {
+            th.join();
+          }
+          for (const std::vector<Hit>& v : part) {
+            hits.insert(hits.end(), v.begin(), v.end());
+          }
+          r0 += rows;
+        }
+        // stable bucket by first variant (second variants arrive in increasing order)
+        std::vector<uint64_t> start(static_cast<size_t>(variant_ct) + 1, 0);
+        for (const Hit& h : hits) {
+          ++start[h.i + 1];
+        }
+        for (uint32_t i = 0; i < variant_ct; ++i) {
+          start[i + 1] += start[i];
+        }
+        std::vector<Hit> sorted(hits.size());
+        {
+          std::vector<uint64_t> cursor(start.begin(), start.end() - 1);
+          for (const Hit& h : hits) {
+            sorted[cursor[h.i]++] = h;
+          }
+        }
+        std::vector<Hit>().swap(hits);
+        std::vector<std::string> chr_name;  // by chromosome order index
+        for (uint32_t k = 0; k < variant_ct; ++k) {
+          if (chr_idx[k] >= chr_name.size()) {
+            chr_name.resize(chr_idx[k] + 1);
+            chr_name[chr_idx[k]] = chrom_out(V.chrom[inc[k]]);
+          }
+        }
+        std::string out;
+        out.reserve(1 << 22);
+        char num[40];
+        for (const Hit& h : sorted) {
+          out += chr_name[chr_idx[h.i]];
+          out += '\t';
+          out += std::to_string(bps[h.i]);
+          out += '\t';
+          out += V.id[inc[h.i]];
+          out += '\t';
+          out += chr_name[chr_idx[h.j]];
+          out += '\t';
+          out += std::to_string(bps[h.j]);
+          out += '\t';
+          out += V.id[inc[h.j]];
+          out += '\t';
+          out.append(num, format_g6(h.r2, num) - num);
+          out += '\n';
+          if (out.size() > (1u << 21)) {
+            fwrite(out.data(), 1, out.size(), tf);
+            out.clear();
+          }
+        }
+        fwrite(out.data(), 1, out.size(), tf);
+        if (fclose(tf)) {
+          die(2, "Error: File write failure: %s.\n", tpath.c_str());
+        }
+        logprintf("--r2-unphased: %llu variant pair%s written to %s .\n", static_cast<unsigned long long>(sorted.size()), sorted.size() == 1 ? "" : "s", tpath.c_str());
+        ldp_destroy(e);
+        ldp_pgen_close(pg);
+        if (g_log) {
+          fclose(g_log);
+        }
+        return 0;
+      }
       std::vector<double> band;
       std::vector<uint64_t> off;
       std::string linebuf;

@@ -476,6 +476,19 @@ def ref_import_vcf(vcf_path, prefix, extra=()):
     return cp.stdout
 
 
+def ref_pairphase_chrx_is_unreliable(sexes, founder_mask):
+    """The reference's --indep-pairphase chrX loader ORs the male remainder word into a word it never initialised
+    when 2 x (non-male founders) is a multiple of 64 and the male founder count is not (plink2_ld.cc:2087-2091:
+    word_idx is then one past what HapsplitMustPhased wrote) -- its output then depends on stale memory (observed:
+    --threads 1..8 vs 64 vs the default give three different prune lists on the same input).  Comparisons against the
+    reference have to stay clear of that sample layout."""
+    sexes = np.asarray(sexes)
+    founder_mask = np.asarray(founder_mask, dtype=bool)
+    males = int(((sexes == 1) & founder_mask).sum())
+    nonmales = int(founder_mask.sum()) - males
+    return (males % 64 != 0) and ((2 * nonmales) % 64 == 0)
+
+
 def have_ref():
     return os.path.exists(REF_BIN) and os.access(REF_BIN, os.X_OK)
 

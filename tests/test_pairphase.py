@@ -261,6 +261,9 @@ def test_cli_pairphase_sex_chromosomes_match_reference(tmp_path, wargs, order, u
     n = 140
     rng = np.random.default_rng(5)
     sexes = rng.choice([1, 2, 0] if unknown else [1, 2], size=n, p=[0.45, 0.45, 0.1] if unknown else [0.5, 0.5])
+    founders = np.array([not ((s % 11 == 3) and (s // 11 < 6)) for s in range(n)])
+    while T.ref_pairphase_chrx_is_unreliable(sexes, founders):  # a layout where the reference itself is not reproducible
+        sexes[np.flatnonzero(founders & (sexes != 1))[0]] = 1
     _phased_fileset(tmp, 900, n, seed=21, chrom_plan=[("1", 180), ("2", 180), ("X", 180), ("Y", 180), ("MT", 180)], sexes=sexes, nonfounders=6)
     common = ["--pfile", "p", "--indep-pairphase"] + wargs + ["0.3"] + (["--indep-order", "1"] if order == 1 else [])
     ref = T.run_ref(common + ["--threads", "3", "--out", "ref"], tmp)

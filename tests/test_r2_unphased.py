@@ -178,3 +178,30 @@ def test_cli_text_matrix_byte_identical(gpu_pkg, tmp_path, shape):
     assert got.returncode == 0, got.stdout
     assert filecmp.cmp(str(tmp_path / "ref.unphased.vcor2.vars"), str(tmp_path / "hip.unphased.vcor2.vars"), shallow=False)
     assert filecmp.cmp(str(tmp_path / "ref.unphased.vcor2"), str(tmp_path / "hip.unphased.vcor2"), shallow=False)
+
+
+@pytest.mark.parametrize("extra", [[], ["--ld-window-r2", "0.02"], ["--ld-window-r2", "0"], ["--ld-window-r2", "0.7"]])
+def test_cli_inter_chr_table_byte_identical(gpu_pkg, tmp_path, extra):
+    """--r2-unphased inter-chr (the command BASELINE config 4 names): every pair A < B across and within chromosomes,
+    chromosome 0 included, filtered by --ld-window-r2 only (plink2_ld.cc:11082-11116)."""
+    assert T.have_ref()
+    cli = gpu_pkg.build_cli()
+    m, n = 700, 150
+    raw = T.synth_raw_codes(m, n, seed=23, missing_rate=0.02)
+    raw[10] = 2
+    raw[11] = 3
+    chroms = ["0"] * 4 + ["1"] * 300 + ["3"] * 1 + ["7"] * 395
+    rng = np.random.default_rng(9)
+    pos = np.concatenate([np.arange(4) + 1, np.sort(rng.integers(1, 60000, 300)), [5], np.sort(rng.integers(1, 2000000, 395))])
+    T.write_pgen_fixed(str(tmp_path / "d"), raw, chroms, pos)
+    ref = T.run_ref(["--pfile", "d", "--r2-unphased", "inter-chr"] + extra + ["--out", "ref"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    got = subprocess.run([cli, "--pfile", "d", "--r2-unphased", "inter-chr"] + extra + ["--out", "hip"], cwd=str(tmp_path), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert got.returncode == 0, got.stdout
+    assert os.path.getsize(str(tmp_path / "ref.vcor")) > 100
+    assert filecmp.cmp(str(tmp_path / "ref.vcor"), str(tmp_path / "hip.vcor"), shallow=False)
+    # the window flags do not combine with an all-pairs mode
+    bad = subprocess.run([cli, "--pfile", "d", "--r2-unphased", "inter-chr", "--ld-window-kb", "5", "--out", "x", "--dry-run"], cwd=str(tmp_path),
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
+    assert bad.returncode != 0 and "All-pairs" in bad.stdout
