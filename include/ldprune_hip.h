@@ -195,6 +195,18 @@ int ldp_set_variants_matrix(ldp_engine* e, uint32_t variant_ct);
  * square / square0 / triangle files from row chunks (VcorMatrixThread :9518-9652 computes the same rows). */
 int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t ld_elems);
 
+/* The same rows filtered on the device (what the table writers keep, VcorTableWriteThread :10816-10821): every pair
+ * first < second with second in [row_first, row_first+row_ct) whose |r^2| >= min_r2 (NaN never passes), in NO
+ * particular order -- sort by (first, second) for the .vcor file's order.  *count receives the number found; when it
+ * exceeds `capacity` only the first `capacity` stored are valid: call again with a smaller row range or a larger
+ * buffer.  All-pairs plan (ldp_set_variants_matrix): this is --r2-unphased inter-chr (plink2_ld.cc:11082-11116). */
+typedef struct {
+  uint32_t first;
+  uint32_t second;
+  double r2;
+} ldp_r2_hit;
+int ldp_r2_unphased_hits(ldp_engine* e, uint32_t row_first, uint32_t row_ct, double min_r2, ldp_r2_hit* out, uint64_t capacity, uint64_t* count);
+
 /* ---- --r2-unphased table (VcorTable, plink2_ld.cc:11025; window: UpdateVcorWindow :10984-11023) ---- */
 /* Windowed plan: variant B is paired with the earlier variants A of its chromosome with bp[B] - bp[A] <= bp_radius
  * and at most var_ct_radius variants between... i.e. B - A <= var_ct_radius in include-order (the reference's

@@ -70,6 +70,7 @@ class ldp_counters(ctypes.Structure):
 
 
 PAIR_STATS_DTYPE = np.dtype([("nm", "<u4"), ("sum1", "<i4"), ("ssq1", "<u4"), ("sum2", "<i4"), ("ssq2", "<u4"), ("dot", "<i4")])
+R2_HIT_DTYPE = np.dtype([("first", "<u4"), ("second", "<u4"), ("r2", "<f8")])
 VARIANT_REC_DTYPE = np.dtype([("nm_ct", "<u4"), ("sum", "<i4"), ("ssq", "<u4"), ("flags", "<u4"), ("n_homref", "<u4"),
                               ("n_het", "<u4"), ("n_homalt", "<u4"), ("reserved", "<u4")])
 
@@ -79,7 +80,7 @@ CABI_SYMBOLS = [
     "ldp_set_shard", "ldp_get_band", "ldp_load_genotypes", "ldp_set_maj_freqs", "ldp_set_preferred", "ldp_run",
     "ldp_run_with_stats", "ldp_pair_stats", "ldp_debug_set_variant_recs", "ldp_debug_replay_pairs",
     "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
-    "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
+    "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_r2_unphased_hits", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
     "ldp_pgen_variant_is_multiallelic", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
 ]
@@ -170,6 +171,7 @@ def lib():
                                       ctypes.c_uint64, ctypes.c_int, vp]
     L.ldp_set_variants_matrix.argtypes = [vp, ctypes.c_uint32]
     L.ldp_r2_unphased_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, vp, ctypes.c_uint64]
+    L.ldp_r2_unphased_hits.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
     L.ldp_set_variants_vcor.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
                                         ctypes.c_uint32, ctypes.c_uint32]
     L.ldp_r2_unphased_band_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, vp, ctypes.c_uint64]
@@ -370,6 +372,16 @@ class LdPruneEngine:
         out = np.zeros((row_ct, ld), dtype=np.float32 if as_float else np.float64)
         self._ck(self._L.ldp_r2_unphased_rows(self._h, row_first, row_ct, 1 if as_float else 0, out.ctypes.data_as(ctypes.c_void_p), ld))
         return out
+
+    def r2_unphased_hits(self, min_r2, row_first=0, row_ct=None, capacity=1 << 20):
+        """Pairs first < second (second among the rows) with |r^2| >= min_r2, filtered on the device; sorted here by
+        (first, second).  Returns (structured array, total found) -- found > len(array) means the buffer was too small."""
+        row_ct = self.variant_ct - row_first if row_ct is None else row_ct
+        out = np.zeros(max(capacity, 1), dtype=R2_HIT_DTYPE)
+        found = ctypes.c_uint64()
+        self._ck(self._L.ldp_r2_unphased_hits(self._h, row_first, row_ct, float(min_r2), out.ctypes.data_as(ctypes.c_void_p), capacity, ctypes.byref(found)))
+        out = out[:min(found.value, capacity)]
+        return out[np.lexsort((out["second"], out["first"]))], found.value
 
     def set_variants_vcor(self, chr_idx, bps, bp_radius, var_ct_radius=0x7fffffff):
         """Windowed plan of the --r2-unphased table (--ld-window-kb / --ld-window)."""

@@ -94,6 +94,11 @@ struct PairKernelArgs {
   uint32_t r2_row_end;
   uint64_t r2_band_base;         // r2_ld == 0: band layout, element pair_off[j] - r2_band_base + (i - lo[j])
   uint32_t r2_float;
+  // device-side filter (ldp_r2_unphased_hits): with r2_hits != nullptr a pair with |r^2| >= r2_min is appended at
+  // slot atomicAdd(counters[3]) when that is below r2_hit_capacity, and nothing is stored to r2_out
+  ldp_r2_hit* r2_hits;
+  uint64_t r2_hit_capacity;
+  double r2_min;
 };
 
 struct PrepareArgs {

@@ -1008,6 +1008,9 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.n_checkpoints = A.cp_stats ? e->n_checkpoints : 0;
   A.lds_dwords = 0;
   A.r2_out = nullptr;
+  A.r2_hits = nullptr;
+  A.r2_hit_capacity = 0;
+  A.r2_min = 0.0;
   A.r2_ld = 0;
   A.r2_row_first = 0;
   A.r2_row_end = 0;
@@ -1576,6 +1579,9 @@ int ldp_r2_unphased_band_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct
   A.n_items = static_cast<uint32_t>(i1 - i0);
   A.thresh = 0.0;
   A.r2_out = out_buf.p;
+  A.r2_hits = nullptr;
+  A.r2_hit_capacity = 0;
+  A.r2_min = 0.0;
   A.r2_ld = 0;
   A.r2_row_first = l_first;
   A.r2_row_end = l_end;
@@ -1608,14 +1614,30 @@ int ldp_r2_unphased_band_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct
   return LDP_OK;
 }
 
-int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t ld_elems) {
+}  // extern "C"
+
+namespace {
+struct HitRequest {
+  double min_r2;
+  ldp_r2_hit* out;
+  uint64_t capacity;
+  uint64_t* count;
+};
+
+// rows [row_first, row_first+row_ct) of the all-pairs plan: dense into `out` (hits == nullptr) or filtered into hits->out
+int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t ld_elems, const HitRequest* hits) {
   if (!e) {
     return LDP_ERR_INVALID;
   }
   if (!e->planned || !e->matrix_mode) {
     return fail(e, LDP_ERR_STATE, "ldp_set_variants_matrix() first");
   }
-  if ((static_cast<uint64_t>(row_first) + row_ct > e->variant_ct) || (row_ct && !out) || (ld_elems < static_cast<uint64_t>(row_first) + row_ct)) {
+  if (hits) {
+    if ((static_cast<uint64_t>(row_first) + row_ct > e->variant_ct) || (hits->capacity && !hits->out) || !hits->count) {
+      return fail(e, LDP_ERR_INVALID, "row range / hit buffer out of bounds");
+    }
+    *hits->count = 0;
+  } else if ((static_cast<uint64_t>(row_first) + row_ct > e->variant_ct) || (row_ct && !out) || (ld_elems < static_cast<uint64_t>(row_first) + row_ct)) {
     return fail(e, LDP_ERR_INVALID, "row range / leading dimension out of bounds");
   }
   int rc = ensure_device_plan(e);
@@ -1667,13 +1689,19 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
     }
   }
   const size_t esz = as_float ? sizeof(float) : sizeof(double);
-  const uint64_t out_elems = static_cast<uint64_t>(row_ct) * ld_elems;
+  const uint64_t out_elems = hits ? 0 : (static_cast<uint64_t>(row_ct) * ld_elems);
   DevBuf out_buf, items_buf, general_buf;
-  HIP_TRY(e, hipMalloc(&out_buf.p, out_elems * esz));
-  void* d_out = out_buf.p;
+  void* d_out = nullptr;
+  if (hits) {
+    HIP_TRY(e, hipMalloc(&out_buf.p, std::max<uint64_t>(hits->capacity, 1) * sizeof(ldp_r2_hit)));
+    HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
+  } else {
+    HIP_TRY(e, hipMalloc(&out_buf.p, out_elems * esz));
+    d_out = out_buf.p;
+    HIP_TRY(e, hipMemsetAsync(d_out, 0, out_elems * esz, e->stream));
+  }
   WorkItem* d_items = nullptr;
   uint8_t* d_general = nullptr;
-  HIP_TRY(e, hipMemsetAsync(d_out, 0, out_elems * esz, e->stream));
   if (!items.empty()) {
     HIP_TRY(e, hipMalloc(&items_buf.p, items.size() * sizeof(WorkItem)));
     HIP_TRY(e, hipMalloc(&general_buf.p, items.size()));
@@ -1705,6 +1733,9 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
   }
   A.n_checkpoints = 0;
   A.r2_out = d_out;
+  A.r2_hits = hits ? out_buf.as<ldp_r2_hit>() : nullptr;
+  A.r2_hit_capacity = hits ? hits->capacity : 0;
+  A.r2_min = hits ? hits->min_r2 : 0.0;
   A.r2_ld = ld_elems;
   A.r2_row_first = row_first;
   A.r2_row_end = row_end;
@@ -1718,12 +1749,23 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
   if (krc != hipSuccess) {
     return hipfail(e, krc, "pair_tiles_kernel launch");
   }
-  HIP_TRY(e, hipMemcpyAsync(out, d_out, out_elems * esz, hipMemcpyDeviceToHost, e->stream));
-  rc = fetch_recs(e);  // diagonal needs each variant's own variance
-  if (rc) {
-    return rc;
+  if (hits) {
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters_pin, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const uint64_t found = e->h_counters_pin[3];
+    *hits->count = found;
+    const uint64_t stored = std::min<uint64_t>(found, hits->capacity);
+    if (stored) {
+      HIP_TRY(e, hipMemcpy(hits->out, out_buf.p, stored * sizeof(ldp_r2_hit), hipMemcpyDeviceToHost));
+    }
+  } else {
+    HIP_TRY(e, hipMemcpyAsync(out, d_out, out_elems * esz, hipMemcpyDeviceToHost, e->stream));
+    rc = fetch_recs(e);  // diagonal needs each variant's own variance
+    if (rc) {
+      return rc;
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
   }
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
   float kms_fast = 0.f, kms_general = 0.f;
   if (!items.empty()) {
     HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
@@ -1733,7 +1775,7 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
     (void)hipEventDestroy(evk[q]);
   }
   // diagonal: r^2(v, v) through the same formula = 1.0, or NaN when the variant has no variance
-  for (uint32_t j = row_first; j < row_end; ++j) {
+  for (uint32_t j = row_first; (!hits) && (j < row_end); ++j) {
     const ldp_variant_rec& r = e->recs[j];
     const int64_t var = static_cast<int64_t>(r.ssq) * static_cast<int64_t>(r.nm_ct) - static_cast<int64_t>(r.sum) * static_cast<int64_t>(r.sum);
     const bool defined = r.nm_ct && (static_cast<double>(var) * static_cast<double>(var) != 0.0);
@@ -1753,6 +1795,18 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
   e->ctr.ms_pair_kernel = kms_fast + kms_general;
   e->ctr.ms_run_total = now_ms() - t_start;
   return LDP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t ld_elems) {
+  return r2_rows_impl(e, row_first, row_ct, as_float, out, ld_elems, nullptr);
+}
+
+int ldp_r2_unphased_hits(ldp_engine* e, uint32_t row_first, uint32_t row_ct, double min_r2, ldp_r2_hit* out, uint64_t capacity, uint64_t* count) {
+  HitRequest hr{min_r2, out, capacity, count};
+  return r2_rows_impl(e, row_first, row_ct, 0, nullptr, static_cast<uint64_t>(row_first) + row_ct, &hr);
 }
 
 int ldp_get_subcontigs(const ldp_engine* e, uint32_t* ct, uint32_t* info, uint32_t info_capacity_pairs) {

@@ -756,11 +756,24 @@ __device__ __forceinline__ bool emit_pair(const PairKernelArgs& A, uint32_t i, u
   if (A.stats) {
     A.stats[A.pair_off[j] + (i - lo_j)] = st;
   }
-  if (A.r2_out) {
+  if (A.r2_out || A.r2_hits) {
     if ((j < A.r2_row_first) || (j >= A.r2_row_end)) {
       return false;  // a J-tile can straddle the edge of the requested rows
     }
     const double r2 = r2_unphased(st);
+    if (A.r2_hits) {
+      if (fabs(r2) >= A.r2_min) {  // (false for NaN)
+        const unsigned long long slot = atomicAdd(&A.counters[3], 1ull);
+        if (slot < A.r2_hit_capacity) {
+          ldp_r2_hit h;
+          h.first = i;
+          h.second = j;
+          h.r2 = r2;
+          A.r2_hits[slot] = h;
+        }
+      }
+      return false;
+    }
     // dense rows of the lower triangle (matrix shapes), or the band itself (windowed table)
     const uint64_t idx = A.r2_ld ? (static_cast<uint64_t>(j - A.r2_row_first) * A.r2_ld + i) : (A.pair_off[j] - A.r2_band_base + (i - lo_j));
     if (A.r2_float) {

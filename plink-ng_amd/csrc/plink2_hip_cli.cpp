@@ -1354,9 +1354,30 @@ int main(int argc, char** argv) {
         std::vector<Hit> hits;
         std::vector<double> chunk;
         const uint32_t nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        // With a positive threshold the filter runs in the kernel's epilogue (ldp_r2_unphased_hits) and only the
+        // passing pairs cross PCIe; a row chunk whose hits overflow the buffer is redone through the dense path below.
+        const bool device_filter = (thresh > 0.0);
+        std::vector<ldp_r2_hit> dev_hits(device_filter ? (1u << 24) : 0);
         for (uint32_t r0 = 0; r0 < variant_ct;) {
           uint32_t rows = static_cast<uint32_t>(std::max<uint64_t>(32, (1ull << 28) / (static_cast<uint64_t>(r0 + 4096) * 8)));
           rows = std::min(std::min(rows, variant_ct - r0), 65536u);
+          if (device_filter) {
+            const uint32_t big = std::min(std::min<uint32_t>(rows * 16, variant_ct - r0), 65536u);  // (no dense buffer to size)
+            uint64_t found = 0;
+            if (ldp_r2_unphased_hits(e, r0, big, thresh, dev_hits.data(), dev_hits.size(), &found)) {
+              die(12, "Error: %s\n", ldp_last_error(e));
+            }
+            if (found <= dev_hits.size()) {
+              std::sort(dev_hits.begin(), dev_hits.begin() + found, [](const ldp_r2_hit& a, const ldp_r2_hit& b) {
+                return (a.second != b.second) ? (a.second < b.second) : (a.first < b.first);
+              });
+              for (uint64_t q = 0; q < found; ++q) {
+                hits.push_back({dev_hits[q].first, dev_hits[q].second, dev_hits[q].r2});
+              }
+              r0 += big;
+              continue;
+            }
+          }
           const uint64_t ld = static_cast<uint64_t>(r0) + rows;
           chunk.assign(static_cast<size_t>(rows) * ld, 0.0);
           if (ldp_r2_unphased_rows(e, r0, rows, 0, chunk.data(), ld)) {

@@ -205,3 +205,25 @@ def test_cli_inter_chr_table_byte_identical(gpu_pkg, tmp_path, extra):
     bad = subprocess.run([cli, "--pfile", "d", "--r2-unphased", "inter-chr", "--ld-window-kb", "5", "--out", "x", "--dry-run"], cwd=str(tmp_path),
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
     assert bad.returncode != 0 and "All-pairs" in bad.stdout
+
+
+def test_device_side_hit_filter_matches_dense_rows(gpu_pkg):
+    """ldp_r2_unphased_hits = the dense rows filtered by |r^2| >= min (NaN never passes), incl. buffer overflow reporting."""
+    m, n = 500, 333
+    raw = T.synth_raw_codes(m, n, seed=77, missing_rate=0.02)
+    raw[7] = 0
+    raw[8] = 3
+    eng = gpu_pkg.LdPruneEngine(n, 2, 1, False, 0.5, device=0)
+    eng.set_variants_matrix(m)
+    eng.load_genotypes_host(0, T.pack_2bit(raw), gpu_pkg.LDP_GENO_REF)
+    dense = eng.r2_unphased_rows()
+    for thr, first, cnt in [(0.3, 0, m), (0.05, 100, 217), (1e-9, 0, 64)]:
+        hits, found = eng.r2_unphased_hits(thr, first, cnt, capacity=1 << 18)
+        want = [(i, j, dense[j, i]) for j in range(first, first + cnt) for i in range(j) if abs(dense[j, i]) >= thr]
+        want.sort()
+        assert found == len(want) == len(hits)
+        assert [(int(h["first"]), int(h["second"])) for h in hits] == [(a, b) for a, b, _ in want]
+        assert np.array_equal(hits["r2"], np.array([w[2] for w in want]))
+    hits, found = eng.r2_unphased_hits(0.05, 0, m, capacity=10)
+    assert found > 10 and len(hits) == 10
+    eng.close()

@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--no-ref", action="store_true")
     ap.add_argument("--pgen", action="store_true", help="convert the .bed with the reference's --make-pgen first (variable-width .pgen) and time both tools on that")
     ap.add_argument("--phased", action="store_true", help="--indep-pairphase on a phased variable-width .pgen (haplotypes = the synthetic generator's pseudo-samples, paired up)")
+    ap.add_argument("--inter-chr", action="store_true", help="time --r2-unphased inter-chr --ld-window-r2 <--r2> (all pairs; keep --variants small)")
     ap.add_argument("--vcor", action="store_true", help="time the --r2-unphased table (--ld-window-kb = --window-kb, --ld-window-r2 = --r2) instead")
     args = ap.parse_args()
     import torch
@@ -143,6 +144,9 @@ def main():
     outs = (".prune.in", ".prune.out")
     if args.vcor:
         common = ["--bfile", "s", "--r2-unphased", "--ld-window-kb", "%g" % args.window_kb, "--ld-window-r2", repr(args.r2)]
+        outs = (".vcor",)
+    if args.inter_chr:
+        common = ["--bfile", "s", "--r2-unphased", "inter-chr", "--ld-window-r2", repr(args.r2)]
         outs = (".vcor",)
     if args.pgen:
         t0 = time.perf_counter()
