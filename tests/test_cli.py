@@ -258,6 +258,11 @@ def test_vcor_flag_rules(cli, tmp_path):
     assert r.returncode != 0 and "Matrix-only" in r.stdout
     r = run_cli(cli, ["--pfile", "d", "--r2-unphased", "--ld-window", "1", "--dry-run"], str(tmp_path))
     assert r.returncode != 0 and "Invalid --ld-window argument" in r.stdout
+    # inter-chr is an all-pairs mode: the r^2 filter applies, the window flags do not (plink2.cc:11175-11179)
+    r = run_cli(cli, ["--pfile", "d", "--r2-unphased", "inter-chr", "--ld-window-kb", "10", "--dry-run"], str(tmp_path))
+    assert r.returncode != 0 and "All-pairs" in r.stdout
+    r = run_cli(cli, ["--pfile", "d", "--r2-unphased", "inter-chr", "square", "--dry-run"], str(tmp_path))
+    assert r.returncode != 0
 
 
 def test_zstd_variant_table(cli, tmp_path):
