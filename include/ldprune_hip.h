@@ -249,11 +249,18 @@ int ldp_pgen_read(ldp_pgen* p, uint32_t first_variant, uint32_t n, void* out_row
  * hardcall-phase track, pgen_spec.tex:541-562; phaseinfo set = ALT on the first haplotype, "1|0").
  * sample_mask (optional, ceil(sample_ct/8) bytes): only these samples' het calls must be phased (the reference
  * checks after founder subsetting).  Returns LDP_ERR_UNPHASED and the lowest offending variant index in
- * *unphased_variant when a het call of a masked sample has no phase.  Multiallelic records are refused. */
+ * *unphased_variant when a het call of a masked sample has no phase.  Records with multiallelic hard-calls get
+ * their main-track codes and all-zero phase bits, unchecked (see ldp_pgen_read_alleles_phased). */
 int ldp_pgen_read_phased(ldp_pgen* p, uint32_t first_variant, uint32_t n, void* out_rows, uint64_t stride_bytes,
                          const uint8_t* sample_mask, uint32_t threads, uint32_t* unphased_variant);
 int ldp_pgen_variant_is_multiallelic(const ldp_pgen* p, uint32_t variant);
 int ldp_pgen_read_alleles(ldp_pgen* p, uint32_t variant, uint32_t alt_ct, uint8_t* allele_lo, uint8_t* allele_hi);
+/* ... plus the hardcall phase of every heterozygous call (allele_lo != allele_hi), multiallelic ones included, as the
+ * file stores it (what ReadGenovecHphaseSubsetUnsafe / Get1MP parse, pgenlib_read.cc:6704,6962): one bit per sample,
+ * ceil(sample_ct/8) bytes each; phaseinfo set = the HIGHER-indexed allele sits on the first haplotype ("1|0", "2|1").
+ * ldp_pgen_read_phased() leaves the phase bits of multiallelic records zero: this is the reader for them. */
+int ldp_pgen_read_alleles_phased(ldp_pgen* p, uint32_t variant, uint32_t alt_ct, uint8_t* allele_lo, uint8_t* allele_hi,
+                                 uint8_t* phasepresent, uint8_t* phaseinfo);
 const char* ldp_pgen_last_error(const ldp_pgen* p);
 void ldp_pgen_close(ldp_pgen* p);
 

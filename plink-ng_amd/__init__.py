@@ -82,7 +82,7 @@ CABI_SYMBOLS = [
     "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
     "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_r2_unphased_hits", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
-    "ldp_pgen_variant_is_multiallelic", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
+    "ldp_pgen_variant_is_multiallelic", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
 ]
 
 
@@ -187,6 +187,7 @@ def lib():
     L.ldp_phased_phase_offset.restype = ctypes.c_uint64
     L.ldp_pgen_read_phased.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint8), ctypes.c_uint32,
                                        ctypes.POINTER(ctypes.c_uint32)]
+    L.ldp_pgen_read_alleles_phased.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32] + [ctypes.POINTER(ctypes.c_uint8)] * 4
     L.ldp_pgen_read_alleles.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8)]
     L.ldp_pgen_last_error.argtypes = [vp]
     L.ldp_pgen_last_error.restype = ctypes.c_char_p
@@ -285,6 +286,20 @@ class PgenFile:
         if rc != LDP_OK:
             raise LdpError(rc, self._L.ldp_pgen_last_error(self._h).decode())
         return lo, hi
+
+    def read_alleles_phased(self, variant, alt_ct):
+        """(allele_lo, allele_hi, phasepresent, phaseinfo) over samples; phaseinfo 1 = the higher allele on the first haplotype"""
+        lo = np.zeros(self.sample_ct, dtype=np.uint8)
+        hi = np.zeros(self.sample_ct, dtype=np.uint8)
+        nb = (self.sample_ct + 7) // 8
+        pp = np.zeros(nb, dtype=np.uint8)
+        pi = np.zeros(nb, dtype=np.uint8)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        rc = self._L.ldp_pgen_read_alleles_phased(self._h, variant, alt_ct, lo.ctypes.data_as(u8p), hi.ctypes.data_as(u8p),
+                                                  pp.ctypes.data_as(u8p), pi.ctypes.data_as(u8p))
+        if rc != LDP_OK:
+            raise LdpError(rc, self._L.ldp_pgen_last_error(self._h).decode())
+        return (lo, hi, np.unpackbits(pp, bitorder="little")[:self.sample_ct], np.unpackbits(pi, bitorder="little")[:self.sample_ct])
 
     def is_multiallelic(self, variant):
         return bool(self._L.ldp_pgen_variant_is_multiallelic(self._h, variant))

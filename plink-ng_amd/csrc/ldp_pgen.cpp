@@ -652,13 +652,14 @@ int read_impl(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_rows, u
           return;
         }
         if (phased && (v >= want_first)) {
-          if (P->vrtype[v] & 8) {
-            bad.store(2);  // multiallelic record: the phase track sits behind aux track 1
-            return;
-          }
           memset(dst + P->rec_bytes, 0, phase_off - P->rec_bytes);
+          if (P->vrtype[v] & 8) {
+            // multiallelic record: the phase track sits behind aux track 1 and refers to allele pairs, not to the
+            // main track's codes -- ldp_pgen_read_alleles_phased() is the reader for these; here: codes only
+            memset(dst + phase_off, 0, need_bytes - phase_off);
+          }
           bool unphased = false;
-          if (!decode_phase(P, v, dst, track_end, sample_mask, dst + phase_off, &unphased)) {
+          if ((!(P->vrtype[v] & 8)) && !decode_phase(P, v, dst, track_end, sample_mask, dst + phase_off, &unphased)) {
             bad.store(1);
             return;
           }
@@ -686,9 +687,6 @@ int read_impl(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_rows, u
     for (std::thread& t : pool) {
       t.join();
     }
-  }
-  if (bad.load() == 2) {
-    return pfail(P, LDP_ERR_UNSUPPORTED, "phased read of a multiallelic record is not supported yet");
   }
   if (bad.load()) {
     return pfail(P, LDP_ERR_INVALID, "malformed variant record in .pgen file");
@@ -725,9 +723,16 @@ int ldp_pgen_variant_is_multiallelic(const ldp_pgen* P, uint32_t variant) {
 // Per-sample allele pairs of one variant (multiallelic hard-call track, pgen_spec.tex:469-540): allele_lo[s] <=
 // allele_hi[s] are allele indices (0 = REF, k = ALTk), 255/255 = missing.  alt_ct = number of ALT alleles the
 // variant has in the .pvar (<= 254 supported).
-int ldp_pgen_read_alleles(ldp_pgen* P, uint32_t variant, uint32_t alt_ct, uint8_t* allele_lo, uint8_t* allele_hi) {
+}  // extern "C"
+
+namespace {
+// *track_end (optional): first byte behind the main track and, if present, aux track 1 of the record
+int read_alleles_impl(ldp_pgen* P, uint32_t variant, uint32_t alt_ct, uint8_t* allele_lo, uint8_t* allele_hi, const uint8_t** track_end) {
   if (!P || !allele_lo || !allele_hi) {
     return LDP_ERR_INVALID;
+  }
+  if (track_end) {
+    *track_end = nullptr;
   }
   if (variant >= P->variant_ct || alt_ct < 1 || alt_ct > 254) {
     return pfail(P, LDP_ERR_INVALID, "variant index / ALT allele count out of range");
@@ -784,6 +789,9 @@ int ldp_pgen_read_alleles(ldp_pgen* P, uint32_t variant, uint32_t alt_ct, uint8_
     }
   }
   if (!multi) {
+    if (track_end) {
+      *track_end = aux;
+    }
     return LDP_OK;
   }
   if (alt_ct < 2) {
@@ -883,6 +891,81 @@ int ldp_pgen_read_alleles(ldp_pgen* P, uint32_t variant, uint32_t alt_ct, uint8_
         allele_hi[s] = static_cast<uint8_t>(1 + packed_get(vals, 2 * k + 1, w));
       }
     }
+  }
+  if (track_end) {
+    *track_end = c.p;
+  }
+  return LDP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ldp_pgen_read_alleles(ldp_pgen* P, uint32_t variant, uint32_t alt_ct, uint8_t* allele_lo, uint8_t* allele_hi) {
+  return read_alleles_impl(P, variant, alt_ct, allele_lo, allele_hi, nullptr);
+}
+
+int ldp_pgen_read_alleles_phased(ldp_pgen* P, uint32_t variant, uint32_t alt_ct, uint8_t* allele_lo, uint8_t* allele_hi, uint8_t* phasepresent,
+                                 uint8_t* phaseinfo) {
+  if (!phasepresent || !phaseinfo) {
+    return LDP_ERR_INVALID;
+  }
+  const uint8_t* aux2 = nullptr;
+  const int rc = read_alleles_impl(P, variant, alt_ct, allele_lo, allele_hi, &aux2);
+  if (rc) {
+    return rc;
+  }
+  const uint32_t n = P->sample_ct;
+  const uint64_t nbytes = (static_cast<uint64_t>(n) + 7) / 8;
+  memset(phasepresent, 0, nbytes);
+  memset(phaseinfo, 0, nbytes);
+  if ((P->mode != 0x10) || !(P->vrtype[variant] & 0x10)) {
+    return LDP_OK;  // no hardcall-phase track: nothing is phased
+  }
+  // pgen_spec.tex:541-562 over ALL heterozygous calls, multiallelic ones included (ReadGenovecHphaseSubsetUnsafe /
+  // Get1Multiallelic: all_hets |= aux1b hets, pgenlib_read.cc:5497-5510)
+  const uint8_t* end = P->map + P->fpos[variant + 1];
+  uint32_t het_ct = 0;
+  for (uint32_t s = 0; s < n; ++s) {
+    het_ct += (allele_lo[s] != allele_hi[s]) ? 1 : 0;
+  }
+  if ((!aux2) || (static_cast<uint64_t>(end - aux2) < 1 + het_ct / 8)) {
+    return pfail(P, LDP_ERR_INVALID, "truncated hardcall-phase track");
+  }
+  const bool explicit_present = aux2[0] & 1;
+  const uint8_t* info = aux2;
+  uint64_t info_bit = 1;
+  if (explicit_present) {
+    uint32_t present_ct = 0;
+    for (uint32_t b = 0; b < 1 + het_ct / 8; ++b) {
+      present_ct += __builtin_popcount(aux2[b]);
+    }
+    present_ct -= 1;
+    info = aux2 + 1 + het_ct / 8;
+    info_bit = 0;
+    if ((!present_ct) || (static_cast<uint64_t>(end - info) < (present_ct + 7) / 8)) {
+      return pfail(P, LDP_ERR_INVALID, "truncated hardcall-phase track");
+    }
+  }
+  uint64_t het_idx = 0;
+  for (uint32_t s = 0; s < n; ++s) {
+    if (allele_lo[s] == allele_hi[s]) {
+      continue;
+    }
+    bool present = true;
+    if (explicit_present) {
+      const uint64_t pb = 1 + het_idx;
+      present = (aux2[pb >> 3] >> (pb & 7)) & 1;
+    }
+    ++het_idx;
+    if (!present) {
+      continue;
+    }
+    phasepresent[s >> 3] |= static_cast<uint8_t>(1u << (s & 7));
+    if ((info[info_bit >> 3] >> (info_bit & 7)) & 1) {
+      phaseinfo[s >> 3] |= static_cast<uint8_t>(1u << (s & 7));
+    }
+    ++info_bit;
   }
   return LDP_OK;
 }

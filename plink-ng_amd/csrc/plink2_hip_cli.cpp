@@ -869,9 +869,20 @@ int chrom_class(const std::string& name_in, bool allow_extra, bool* is_zero) {
 // when nothing is observed) -> major allele (GetMajIdx / GetMajIdxMulti, plink2_common.h:559-567,
 // plink2_common.cc:1042-1070) -> its frequency (GetAlleleFreq, plink2_common.h:584-593) -> the 2-bit row
 // PgrGetInv1 would return for that allele (pgenlib_read.cc:5544-5563): copies of non-major alleles, 3 = missing.
+//
+// phase != nullptr (--indep-pairphase; two byte buffers of ceil(raw samples / 8), phasepresent then phaseinfo): the row
+// holds two haplotypes per founder instead (haplotype = genotype code 2h, h = carries a non-major allele; index 2f =
+// the second haplotype of the file, 2f+1 the first, as the conversion kernel lays out LDP_GENO_PHASED rows), following
+// PgrGetInv1P -> Get1MP (pgenlib_read.cc:7016,6962) -> HapsplitMustPhased.  Get1MP hands the file's phaseinfo through
+// unchanged, which means "the HIGHER allele of the het is on the first haplotype"; read as "the counted allele is"
+// it is off by a swap whenever the major allele is the LOWER allele of a multiallelic het (1|2 with major = 1).  The
+// reference prunes with that assignment (reproduced here; the physically right one gives different lists on
+// VCF-imported data, tests/test_pairphase.py).  *unphased: a collapsed het (one major allele) without phase.
 void multiallelic_inverse_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_ct, const std::vector<uint32_t>& founder_idx,
-                              std::vector<uint8_t>* lo, std::vector<uint8_t>* hi, uint8_t* out_row, uint64_t out_rec, double* maj_freq) {
-  if (ldp_pgen_read_alleles(pg, raw_variant, alt_ct, lo->data(), hi->data())) {
+                              std::vector<uint8_t>* lo, std::vector<uint8_t>* hi, uint8_t* out_row, uint64_t out_rec, double* maj_freq,
+                              uint8_t* phase = nullptr, uint64_t phase_bytes = 0, bool* unphased = nullptr) {
+  if (phase ? ldp_pgen_read_alleles_phased(pg, raw_variant, alt_ct, lo->data(), hi->data(), phase, phase + phase_bytes)
+            : ldp_pgen_read_alleles(pg, raw_variant, alt_ct, lo->data(), hi->data())) {
     die(3, "\nError: %s\n", ldp_pgen_last_error(pg));
   }
   const uint32_t allele_ct = alt_ct + 1;
@@ -942,6 +953,32 @@ void multiallelic_inverse_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_c
   }
   memset(out_row, 0, out_rec);
   uint32_t f = 0;
+  if (phase) {
+    const uint8_t* present = phase;
+    const uint8_t* info = phase + phase_bytes;
+    for (uint32_t s : founder_idx) {
+      uint32_t hap_second = 3, hap_first = 3;
+      const uint32_t a = (*lo)[s], b = (*hi)[s];
+      if (a != 255) {
+        const bool swapped = (info[s >> 3] >> (s & 7)) & 1;
+        uint32_t first_allele = swapped ? b : a;
+        uint32_t second_allele = swapped ? a : b;
+        if ((maj >= 1) && (a == maj) && (b != maj)) {
+          std::swap(first_allele, second_allele);  // (the reference's reading of phaseinfo, see above)
+        }
+        hap_first = (first_allele != maj) ? 2 : 0;
+        hap_second = (second_allele != maj) ? 2 : 0;
+        if (((a == maj) != (b == maj)) && !((present[s >> 3] >> (s & 7)) & 1)) {
+          *unphased = true;
+        }
+      }
+      out_row[f >> 2] |= static_cast<uint8_t>(hap_second << (2 * (f & 3)));
+      ++f;
+      out_row[f >> 2] |= static_cast<uint8_t>(hap_first << (2 * (f & 3)));
+      ++f;
+    }
+    return;
+  }
   for (uint32_t s : founder_idx) {
     const uint32_t code = ((*lo)[s] == 255) ? 3u : (static_cast<uint32_t>((*lo)[s] != maj) + static_cast<uint32_t>((*hi)[s] != maj));
     out_row[f >> 2] |= static_cast<uint8_t>(code << (2 * (f & 3)));
@@ -1158,9 +1195,6 @@ int main(int argc, char** argv) {
       }
       if (cls == 2) {
         die(3, "Error: Invalid chromosome code '%s'. (Use --allow-extra-chr to force it to be accepted.)\n", cur.c_str());
-      }
-      if (A.pairphase && V.alt_ct[v] > 1) {
-        die(9, "Error: multiallelic variant '%s': --indep-pairphase on multiallelic variants is not supported yet by plink2-hip.\n", V.id[v].c_str());
       }
       if (cls >= 3 && V.alt_ct[v] > 1) {
         die(9, "Error: multiallelic variant '%s' on chrX/chrY/MT is not supported yet by plink2-hip.\n", V.id[v].c_str());
@@ -1816,6 +1850,7 @@ int main(int argc, char** argv) {
       std::thread decoder;
       int decode_rc = 0;
       uint32_t unphased_at = 0;
+      uint32_t pending_unphased = UINT32_MAX;
       auto start_decode = [&](size_t k) {
         if (direct || k >= runs.size()) {
           return;
@@ -1839,7 +1874,8 @@ int main(int argc, char** argv) {
         } else {
           decoder.join();
           if (decode_rc == LDP_ERR_UNPHASED) {
-            die_unphased(unphased_at);
+            pending_unphased = unphased_at;  // reported below, unless a multiallelic variant before it is unphased too
+            break;
           }
           if (decode_rc) {
             die(3, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
@@ -1877,7 +1913,11 @@ int main(int argc, char** argv) {
       // allele (collapsed major-vs-rest) and MT variants (hets -> missing, plink2_ld.cc:1362-1364)
       {
         uint32_t multi_ct = 0, mt_ct = 0;
-        std::vector<uint8_t> lo(raw_sample_ct), hi(raw_sample_ct), inv_row(out_rec), raw_row(rec_bytes + 8);
+        // (--indep-pairphase: a multiallelic row is 2 haplotypes per founder as plain 2-bit codes on the 2N-haplotype engine)
+        const uint64_t host_rec = A.pairphase ? ((2ull * founder_ct + 3) / 4) : out_rec;
+        const uint64_t raw_phase_bytes = (static_cast<uint64_t>(raw_sample_ct) + 7) / 8;
+        std::vector<uint8_t> lo(raw_sample_ct), hi(raw_sample_ct), inv_row(host_rec), raw_row(rec_bytes + 8), phase_buf(2 * raw_phase_bytes);
+        uint32_t multi_unphased = UINT32_MAX;
         SexPlan mt_plan;
         mt_plan.part1 = founder_idx;
         for (uint32_t qq = 0; qq < m_ct; ++qq) {
@@ -1896,15 +1936,26 @@ int main(int argc, char** argv) {
             if (storage_mode == 0x01) {
               die(3, "\nError: multiallelic variant in a .bim/.bed fileset.\n");
             }
-            multiallelic_inverse_row(pg, raw_v, alts, founder_idx, &lo, &hi, inv_row.data(), out_rec, &mf);
+            if (A.pairphase) {
+              bool unphased = false;
+              multiallelic_inverse_row(pg, raw_v, alts, founder_idx, &lo, &hi, inv_row.data(), host_rec, &mf, phase_buf.data(), raw_phase_bytes, &unphased);
+              if (unphased) {
+                multi_unphased = std::min(multi_unphased, raw_v);
+              }
+            } else {
+              multiallelic_inverse_row(pg, raw_v, alts, founder_idx, &lo, &hi, inv_row.data(), out_rec, &mf);
+            }
             ++multi_ct;
           }
           for (int r = 0; r < world; ++r) {
-            if (ldp_load_genotypes(eng[r], qq, 1, inv_row.data(), out_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) ||
+            if (ldp_load_genotypes(eng[r], qq, 1, inv_row.data(), host_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) ||
                 ldp_set_maj_freqs(eng[r], qq, 1, &mf)) {
               die(12, "\nError: %s\n", ldp_last_error(eng[r]));
             }
           }
+        }
+        if (std::min(multi_unphased, pending_unphased) != UINT32_MAX) {
+          die_unphased(std::min(multi_unphased, pending_unphased));
         }
         if ((multi_ct || mt_ct) && A.timing) {
           logprintf("\n[timing] host-built rows: %u multiallelic, %u MT\n", multi_ct, mt_ct);

@@ -73,6 +73,21 @@ def main():
         shutil.copy(os.path.join(tmp, "b.pgen"), os.path.join(HERE, "pgen", "phased_partial.pgen"))
         np.savez_compressed(os.path.join(HERE, "pgen", "phased_partial.npz"), raw=raw2, phasepresent=pp2, phaseinfo=pi2,
                             ref_returncode=np.int32(cp.returncode), ref_error=np.array(msg[0] if msg else ""))
+        # ---- multiallelic + phased: the collapse with phase (Get1MP, pgenlib_read.cc:6962) incl. its reading of phaseinfo
+        m3, n3 = 400, 120
+        first, second, alt_ct = T.synth_multiallelic_haps(m3, n3, seed=5)
+        chroms3 = ["1"] * 200 + ["2"] * 200
+        bps3 = np.concatenate([1000 + 97 * np.arange(200)] * 2).astype(np.uint32)
+        ids3 = T.write_vcf_haps(os.path.join(tmp, "c.vcf"), first, second, alt_ct, chroms3, bps3)
+        T.ref_import_vcf(os.path.join(tmp, "c.vcf"), os.path.join(tmp, "c"))
+        out3 = dict(first=first, second=second, alt_ct=alt_ct.astype(np.uint32), chroms=np.array([int(c) for c in chroms3], dtype=np.uint32), bps=bps3)
+        for k, (win, r2, order) in enumerate(GRID):
+            kept, removed, log = T.ref_indep_pairwise(os.path.join(tmp, "c"), win, r2, order=order, mode="phase")
+            out3["removed_%d" % k] = np.isin(np.array(ids3), np.array(removed))
+            print("phased_multi", win, r2, order, [ln for ln in log.splitlines() if "variants removed" in ln][-1])
+        out3["grid"] = np.array(["%s|%r|%d" % (" ".join(w), r, o) for w, r, o in GRID])
+        shutil.copy(os.path.join(tmp, "c.pgen"), os.path.join(HERE, "pgen", "phased_multi.pgen"))
+        np.savez_compressed(os.path.join(HERE, "pgen", "phased_multi.npz"), **out3)
     finally:
         shutil.rmtree(tmp)
 

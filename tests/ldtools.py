@@ -468,6 +468,120 @@ def write_vcf(path, raw_codes, chroms, bps, phasepresent=None, phaseinfo=None, i
     return ids
 
 
+def synth_multiallelic_haps(m, n, seed, max_alt=3, multi_rate=0.3, missing_rate=0.02, ld_copy_prob=0.5, redraw=0.08):
+    """Phased multiallelic data: (first, second) haplotype allele indices (M, N) int arrays (-1 = missing call),
+    alt_ct per variant.  LD planted by copying the previous variant's haplotypes (allele indices clipped)."""
+    rng = np.random.default_rng(seed)
+    first = np.zeros((m, n), dtype=np.int16)
+    second = np.zeros((m, n), dtype=np.int16)
+    alt_ct = np.where(rng.random(m) < multi_rate, rng.integers(2, max_alt + 1, size=m), 1)
+    prev = None
+    for v in range(m):
+        k = int(alt_ct[v]) + 1
+        w = rng.dirichlet(np.ones(k) * rng.uniform(0.3, 2.0))
+        fresh = rng.choice(k, size=(2, n), p=w)
+        if prev is not None and rng.random() < ld_copy_prob:
+            cur = np.where(rng.random((2, n)) >= redraw, np.minimum(prev, k - 1), fresh)
+        else:
+            cur = fresh
+        prev = cur.copy()
+        miss = rng.random(n) < missing_rate
+        first[v] = np.where(miss, -1, cur[0])
+        second[v] = np.where(miss, -1, cur[1])
+    return first, second, alt_ct
+
+
+def write_vcf_haps(path, first, second, alt_ct, chroms, bps, ids=None, unphased=None):
+    """VCF with phased GTs a|b from haplotype allele indices (-1 = ./.); unphased (optional bool (M, N)): write a/b"""
+    m, n = first.shape
+    if ids is None:
+        ids = ["snp%d" % i for i in range(m)]
+    alts = "CGTN"
+    with open(path, "w") as f:
+        f.write("##fileformat=VCFv4.2\n")
+        for c in sorted(set(chroms), key=lambda x: (len(x), x)):
+            f.write("##contig=<ID=%s>\n" % c)
+        f.write('##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n')
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join("s%d" % s for s in range(n)) + "\n")
+        for v in range(m):
+            gts = []
+            for s in range(n):
+                a, b = int(first[v, s]), int(second[v, s])
+                if a < 0:
+                    gts.append("./.")
+                elif unphased is not None and unphased[v, s]:
+                    gts.append("%d/%d" % (min(a, b), max(a, b)))
+                else:
+                    gts.append("%d|%d" % (a, b))
+            f.write("%s\t%d\t%s\tA\t%s\t.\t.\t.\tGT\t%s\n" % (chroms[v], bps[v], ids[v], ",".join(alts[:int(alt_ct[v])]), "\t".join(gts)))
+    return ids
+
+
+def major_allele_multi(cnt):
+    """Allele counts of one variant -> (major allele index, its frequency) the way the reference picks them
+    (ComputeAlleleFreqs plink2_filter.cc:2113-2153, GetMajIdxMulti plink2_common.cc:1042-1070, GetAlleleFreq
+    plink2_common.h:584-593): frequencies of all alleles but the last are count * (1/total)."""
+    k = len(cnt)
+    tot = int(np.sum(cnt))
+    if tot == 0:
+        freq = [1.0 / k] * (k - 1)
+    else:
+        recip = 1.0 / tot
+        freq = [float(cnt[a]) * recip for a in range(k - 1)]
+    if freq[0] >= 0.5:
+        maj = 0
+    elif k == 2:
+        maj = 1
+    elif freq[1] >= 0.5:
+        maj = 1
+    else:
+        maj, mx = 1, freq[1]
+        if freq[0] >= freq[1]:
+            maj, mx = 0, freq[0]
+        tot_nonlast = freq[0] + freq[1]
+        for a in range(2, k - 1):
+            if freq[a] > mx:
+                maj, mx = a, freq[a]
+            tot_nonlast += freq[a]
+        if mx + tot_nonlast < 1.0 - K_SMALL_EPSILON:
+            maj = k - 1
+    if maj + 1 < k:
+        return maj, freq[maj]
+    last = 1.0 - freq[0]
+    for a in range(1, k - 1):
+        last -= freq[a]
+    return maj, max(last, 0.0)
+
+
+def pairphase_hap_rows_multiallelic(lo, hi, phasepresent, phaseinfo, alt_ct, quirk=True):
+    """What PgrGetInv1P -> HapsplitMustPhased hand to the pairphase scan for possibly multiallelic variants, from allele
+    pairs (lo <= hi, 255 missing) and the file's phase bits (phaseinfo 1 = the higher allele on the first haplotype):
+    (hap_nm rows for oracle_indep_pairphase, maj_freq, unphased flags).  quirk=True reproduces the reference, whose
+    Get1MP (pgenlib_read.cc:6962) passes phaseinfo through unchanged, i.e. reads it as "the counted allele is on the
+    first haplotype" even when the major allele is the LOWER allele of a multiallelic het."""
+    m, n = lo.shape
+    codes = np.full((m, 2 * n), 3, dtype=np.uint8)
+    mf = np.zeros(m)
+    unphased = np.zeros(m, dtype=bool)
+    for v in range(m):
+        k = int(alt_ct[v]) + 1
+        nm = lo[v] != 255
+        cnt = [int((lo[v][nm] == a).sum() + (hi[v][nm] == a).sum()) for a in range(k)]
+        maj, mf[v] = major_allele_multi(cnt)
+        a, b = lo[v].astype(int), hi[v].astype(int)
+        sw = phaseinfo[v].astype(bool)
+        first = np.where(sw, b, a)
+        second = np.where(sw, a, b)
+        if quirk and maj >= 1:
+            flip = (a == maj) & (b != maj)
+            first, second = np.where(flip, second, first), np.where(flip, first, second)
+        codes[v, 1::2] = np.where(nm, np.where(first != maj, 2, 0), 3)
+        codes[v, 0::2] = np.where(nm, np.where(second != maj, 2, 0), 3)
+        unphased[v] = bool((nm & ((a == maj) != (b == maj)) & ~phasepresent[v].astype(bool)).any())
+    rows = np.concatenate([pack_bits((codes == 2).astype(np.uint8)), pack_bits((codes != 3).astype(np.uint8))], axis=1)
+    return rows, mf, unphased
+
+
 def ref_import_vcf(vcf_path, prefix, extra=()):
     """reference: --vcf -> variable-width .pgen (with the hardcall-phase track when the VCF has phased hets)"""
     cp = run_ref(["--vcf", os.path.basename(vcf_path), "--make-pgen", "--out", os.path.basename(prefix)] + list(extra), os.path.dirname(prefix))

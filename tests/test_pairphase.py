@@ -118,6 +118,63 @@ def test_phase_track_reader_reports_unphased_hets():
     pg.close()
 
 
+def _multi_arrays(pkg):
+    z = np.load(os.path.join(GOLD, "phased_multi.npz"))
+    m, n = z["first"].shape
+    pg = pkg.PgenFile(os.path.join(GOLD, "phased_multi.pgen"))
+    lo = np.zeros((m, n), dtype=np.uint8)
+    hi = np.zeros((m, n), dtype=np.uint8)
+    pp = np.zeros((m, n), dtype=np.uint8)
+    pi = np.zeros((m, n), dtype=np.uint8)
+    for v in range(m):
+        lo[v], hi[v], pp[v], pi[v] = pg.read_alleles_phased(v, int(z["alt_ct"][v]))
+    return z, pg, lo, hi, pp, pi
+
+
+def test_multiallelic_phase_reader_against_reference_written_file():
+    """allele pairs + phase of every het, multiallelic ones included, from a file the reference imported from a VCF"""
+    pkg = ge.load_package()
+    z, pg, lo, hi, pp, pi = _multi_arrays(pkg)
+    a, b = z["first"].astype(int), z["second"].astype(int)
+    assert sum(pg.is_multiallelic(v) for v in range(pg.variant_ct)) > 50
+    assert np.array_equal(lo, np.where(a < 0, 255, np.minimum(a, b)))
+    assert np.array_equal(hi, np.where(a < 0, 255, np.maximum(a, b)))
+    het = (a != b) & (a >= 0)
+    assert np.array_equal(pp.astype(bool), het)
+    assert np.array_equal(pi.astype(bool), het & (a > b))  # set = the higher allele on the first haplotype
+    # the bulk reader hands multiallelic records through with their main-track codes and no phase
+    rows = pg.read_phased()
+    codes, phase = _unpack_phased(rows, pg.sample_ct)
+    for v in range(pg.variant_ct):
+        want = np.where(lo[v] == 255, 3, np.minimum(lo[v], 1) + np.minimum(hi[v], 1))
+        assert np.array_equal(codes[v], want)
+        if pg.is_multiallelic(v):
+            assert not phase[v].any()
+        else:
+            assert np.array_equal(phase[v].astype(bool), het[v] & (a[v] > b[v]))
+    pg.close()
+
+
+def test_oracle_pairphase_multiallelic_collapse_matches_reference_golden():
+    """PgrGetInv1P -> Get1MP on multiallelic variants: the collapse on the major allele and the reference's reading of
+    phaseinfo (ldtools.pairphase_hap_rows_multiallelic).  The physically right haplotype assignment does NOT give the
+    reference's lists -- recorded here so that nobody 'fixes' it."""
+    pkg = ge.load_package()
+    z, pg, lo, hi, pp, pi = _multi_arrays(pkg)
+    pg.close()
+    n = lo.shape[1]
+    rows, mf, unphased = T.pairphase_hap_rows_multiallelic(lo, hi, pp, pi, z["alt_ct"])
+    rows_phys, _, _ = T.pairphase_hap_rows_multiallelic(lo, hi, pp, pi, z["alt_ct"], quirk=False)
+    assert not unphased.any()
+    physical_differs = False
+    for k, window, step, is_bp, r2, order in _grid(z):
+        got, _ = T.oracle_indep_pairphase(rows, 2 * n, _chr_idx(z), z["bps"], mf, window, step, is_bp, r2, order)
+        assert np.array_equal(got, z["removed_%d" % k]), (k, window, r2, order)
+        phys, _ = T.oracle_indep_pairphase(rows_phys, 2 * n, _chr_idx(z), z["bps"], mf, window, step, is_bp, r2, order)
+        physical_differs |= not np.array_equal(phys, z["removed_%d" % k])
+    assert physical_differs
+
+
 # ---------------------------------------------------------------------------------------------------------- GPU
 def _engine_rows(pkg, raw, pi):
     return pkg.pack_phased_rows(T.pack_2bit(raw).view(np.uint8).reshape(raw.shape[0], -1), pi & (raw == 1), raw.shape[1])
@@ -165,6 +222,25 @@ def test_hip_pairphase_matches_oracle(n, miss):
         assert np.array_equal(eng.maj_freqs(), mf)
         eng.close()
         assert np.array_equal(got, want), (n, miss, window, r2, order)
+    # the seam's own form: major-allele-inverse codes + phaseinfo re-oriented with them (PgrGetInv1P), caller-supplied
+    # frequencies, rows resident in device memory at an odd stride
+    import torch
+    inv, mf2, altmaj = T.oracle_prepare(raw)
+    pi_inv = np.where(altmaj[:, None].astype(bool), pi ^ 1, pi) & (raw == 1)
+    rows_inv = pkg.pack_phased_rows(inv.view(np.uint8).reshape(m, -1), pi_inv, n)
+    stride = rows_inv.shape[1] + 3
+    padded = np.zeros((m, stride), dtype=np.uint8)
+    padded[:, :rows_inv.shape[1]] = rows_inv
+    dev = torch.from_numpy(padded).cuda()
+    torch.cuda.synchronize()
+    eng = pkg.LdPruneEngine(hap_ct, 60, 7, False, 0.3, order=2, device=0)
+    eng.set_variants(chr_idx, bps)
+    eng.load_genotypes_device(0, m, dev.data_ptr(), stride, pkg.LDP_GENO_INVERSE | pkg.LDP_GENO_PHASED)
+    eng.set_maj_freqs(0, mf2)
+    got = eng.run()
+    eng.close()
+    want, _ = T.oracle_indep_pairphase(hrows, hap_ct, chr_idx, bps, mf, 60, 7, False, 0.3, 2)
+    assert np.array_equal(got, want)
 
 
 # ---------------------------------------------------------------------------------------------------------- CLI
@@ -276,6 +352,42 @@ def test_cli_pairphase_sex_chromosomes_match_reference(tmp_path, wargs, order, u
     assert not diff, "differs on %d variants, e.g. %s" % (len(diff), diff[:10])
     for ext in (".prune.in", ".prune.out"):
         assert filecmp.cmp(os.path.join(tmp, "ref" + ext), os.path.join(tmp, "hip" + ext), shallow=False), ext
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wargs,r2,order", [(["30kb"], "0.5", 2), (["60", "7"], "0.2", 1)])
+def test_cli_pairphase_multiallelic_matches_reference(tmp_path, wargs, r2, order):
+    """multiallelic + phased input (collapse on the major allele with phase, Get1MP) next to biallelic variants"""
+    assert T.have_ref()
+    pkg = ge.load_package()
+    cli = _cli(pkg)
+    tmp = str(tmp_path)
+    m, n = 600, 131
+    first, second, alt_ct = T.synth_multiallelic_haps(m, n, seed=40 + order, max_alt=4)
+    chroms = ["1"] * 250 + ["2"] * 200 + ["9"] * 150
+    bps = np.concatenate([1000 + 151 * np.arange(250), 1000 + 151 * np.arange(200), 1000 + 151 * np.arange(150)])
+    T.write_vcf_haps(os.path.join(tmp, "p.vcf"), first, second, alt_ct, chroms, bps)
+    lines = ["#IID\tPAT\tMAT\tSEX"] + ["s%d\t%s\t%s\tNA" % (s, "s0" if s in (14, 47) else "0", "s1" if s in (14, 47) else "0") for s in range(n)]
+    open(os.path.join(tmp, "in.psam"), "w").write("\n".join(lines) + "\n")
+    T.ref_import_vcf(os.path.join(tmp, "p.vcf"), os.path.join(tmp, "p"), extra=["--psam", "in.psam"])
+    common = ["--pfile", "p", "--indep-pairphase"] + wargs + [r2] + (["--indep-order", "1"] if order == 1 else [])
+    ref = T.run_ref(common + ["--threads", "3", "--out", "ref"], tmp)
+    assert ref.returncode == 0, ref.stdout
+    got = _run(cli, common + ["--out", "hip"], tmp)
+    assert got.returncode == 0, got.stdout
+    for ext in (".prune.in", ".prune.out"):
+        assert filecmp.cmp(os.path.join(tmp, "ref" + ext), os.path.join(tmp, "hip" + ext), shallow=False), ext
+    # an unphased het at a multiallelic site is refused like the reference does
+    unph = np.zeros(first.shape, dtype=bool)
+    v_bad = int(np.flatnonzero(alt_ct > 1)[5])
+    s_bad = int(np.flatnonzero((first[v_bad] != second[v_bad]) & (first[v_bad] >= 0))[0])
+    unph[v_bad, s_bad] = True
+    T.write_vcf_haps(os.path.join(tmp, "u.vcf"), first, second, alt_ct, chroms, bps, unphased=unph)
+    T.ref_import_vcf(os.path.join(tmp, "u.vcf"), os.path.join(tmp, "u"))
+    refu = T.run_ref(["--pfile", "u", "--indep-pairphase", "50", "5", "0.5", "--out", "refu"], tmp)
+    gotu = _run(cli, ["--pfile", "u", "--indep-pairphase", "50", "5", "0.5", "--out", "hipu"], tmp)
+    assert refu.returncode == gotu.returncode, (refu.stdout[-300:], gotu.stdout[-300:])
+    assert [ln for ln in refu.stdout.splitlines() if ln.startswith("Error")] == [ln for ln in gotu.stdout.splitlines() if ln.startswith("Error")]
 
 
 @pytest.mark.gpu
