@@ -292,7 +292,7 @@ def main():
                                     "; bit-planes resident, conversion outside the timed step" if args.resident_planes else ""),
                        "samples": founder_ct, "variants_per_gpu": args.variants, "window_kb": args.window_kb, "r2": args.r2,
                        "candidate_pairs_per_gpu": ctr["candidate_pairs"], "computed_pair_slots_per_gpu": ctr["computed_pairs"],
-                       "evaluated_pairs_per_gpu": ctr["replay_pairs"], "pairs_above_threshold_per_gpu": ctr["pred_true"],
+                       "pairs_above_threshold_per_gpu": ctr["pred_true"], "above_threshold_pairs_consumed_by_replay_per_gpu": ctr["replay_pairs"],
                        "variants_removed": int(removed.sum()), "variants_total": m_total},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "pair_tiles_kernel<%s>" % ("true" if args.missing_rate > 0 else "false"),

@@ -496,7 +496,7 @@ def write_vcf_haps(path, first, second, alt_ct, chroms, bps, ids=None, unphased=
     m, n = first.shape
     if ids is None:
         ids = ["snp%d" % i for i in range(m)]
-    alts = "CGTN"
+    alts = ["C", "G", "T", "AC", "AG", "AT", "CA", "CC", "CG", "CT"]
     with open(path, "w") as f:
         f.write("##fileformat=VCFv4.2\n")
         for c in sorted(set(chroms), key=lambda x: (len(x), x)):

@@ -25,7 +25,42 @@ def run(cmd, cwd):
     return subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
 
 
+def pairphase_multiallelic_case(cli, ref, rng, idx, tmp, execute=True):
+    """autosomes with multiallelic sites: phased VCF -> the reference's import -> both tools"""
+    n = int(rng.choice([60, 97, 130]))
+    m = int(rng.integers(80, 300))
+    first, second, alt_ct = T.synth_multiallelic_haps(m, n, int(rng.integers(1, 1 << 30)), max_alt=int(rng.integers(2, 6)),
+                                                      multi_rate=float(rng.choice([0.1, 0.4])), missing_rate=float(rng.choice([0.0, 0.03])))
+    cut = int(rng.integers(1, m))
+    chroms = ["1"] * cut + ["4"] * (m - cut)
+    pos = list(np.sort(rng.integers(1, 60000, size=cut))) + list(np.sort(rng.integers(1, 60000, size=m - cut)))
+    d = os.path.join(tmp, "c%d" % idx)
+    os.makedirs(d)
+    T.write_vcf_haps(os.path.join(d, "d.vcf"), first, second, alt_ct, chroms, pos)
+    if rng.random() < 0.5:
+        win = ["%gkb" % float(rng.choice([2, 7.5, 20]))]
+    else:
+        w = int(rng.integers(2, 120))
+        win = [str(w), str(int(rng.integers(1, max(2, w))))]
+    args = ["--pfile", "d", "--indep-pairphase"] + win + [str(rng.choice([0.1, 0.2, 0.5, 0.8])), "--indep-order", str(int(rng.integers(1, 3)))]
+    if not execute:
+        return True, "case %d skipped" % idx
+    T.ref_import_vcf(os.path.join(d, "d.vcf"), os.path.join(d, "d"))
+    r = run([ref] + args + ["--threads", "2", "--out", "ref"], d)
+    g = run([cli] + args + ["--out", "hip"], d)
+    if r.returncode != g.returncode:
+        return False, "case %d: exit codes differ (ref %d, hip %d): %s\n%s\n%s" % (idx, r.returncode, g.returncode, " ".join(args), r.stdout[-300:], g.stdout[-400:])
+    if r.returncode != 0:
+        return True, "case %d: both refuse (%s)" % (idx, " ".join(args))
+    for e in (".prune.in", ".prune.out"):
+        if not filecmp.cmp(os.path.join(d, "ref" + e), os.path.join(d, "hip" + e), shallow=False):
+            return False, "case %d: %s differs: %s (multiallelic, n=%d m=%d)" % (idx, e, " ".join(args), n, m)
+    return True, "case %d ok: %s (multiallelic VCF import)" % (idx, " ".join(args))
+
+
 def pairphase_case(cli, ref, rng, idx, tmp, execute=True):
+    if rng.random() < 0.25:
+        return pairphase_multiallelic_case(cli, ref, rng, idx, tmp, execute)
     n = int(rng.choice([60, 97, 130, 513]))
     m = int(rng.integers(80, 500))
     raw, pp, pi = T.synth_phased(m, n, int(rng.integers(1, 1 << 30)), missing_rate=float(rng.choice([0.0, 0.02, 0.1])),
