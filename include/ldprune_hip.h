@@ -199,7 +199,8 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
  * first < second with second in [row_first, row_first+row_ct) whose |r^2| >= min_r2 (NaN never passes), in NO
  * particular order -- sort by (first, second) for the .vcor file's order.  *count receives the number found; when it
  * exceeds `capacity` only the first `capacity` stored are valid: call again with a smaller row range or a larger
- * buffer.  All-pairs plan (ldp_set_variants_matrix): this is --r2-unphased inter-chr (plink2_ld.cc:11082-11116). */
+ * buffer.  On the all-pairs plan (ldp_set_variants_matrix) this is --r2-unphased inter-chr (plink2_ld.cc:11082-11116);
+ * on the windowed plan (ldp_set_variants_vcor) the band's pairs, i.e. the default .vcor table. */
 typedef struct {
   uint32_t first;
   uint32_t second;

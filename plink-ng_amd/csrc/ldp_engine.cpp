@@ -1516,12 +1516,29 @@ int ldp_set_variants_vcor(ldp_engine* e, uint32_t variant_ct, const uint32_t* ch
 // r^2 of every candidate pair whose SECOND variant lies in [row_first, row_first + row_ct), in band order: the
 // pairs of second variant j start at sum_{row_first <= j' < j} (j' - lo[j']) and run over i = lo[j] .. j-1
 // (lo from ldp_get_band).  Same doubles as ldp_r2_unphased_rows.
-int ldp_r2_unphased_band_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t capacity_elems) {
+}  // extern "C"
+
+namespace {
+struct HitRequest {
+  double min_r2;
+  ldp_r2_hit* out;
+  uint64_t capacity;
+  uint64_t* count;
+};
+
+// band rows: dense into `out` (hits == nullptr) or filtered on the device into hits->out (global variant indices)
+int r2_band_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t capacity_elems, const HitRequest* hits) {
   if (!e) {
     return LDP_ERR_INVALID;
   }
   if (!e->planned || !e->band_r2_mode) {
     return fail(e, LDP_ERR_STATE, "ldp_set_variants_vcor() first");
+  }
+  if (hits) {
+    if ((hits->capacity && !hits->out) || !hits->count) {
+      return fail(e, LDP_ERR_INVALID, "hit buffer missing");
+    }
+    *hits->count = 0;
   }
   if (static_cast<uint64_t>(row_first) + row_ct > e->variant_ct) {
     return fail(e, LDP_ERR_INVALID, "row range out of bounds");
@@ -1549,13 +1566,13 @@ int ldp_r2_unphased_band_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct
     return LDP_OK;
   }
   const uint64_t n_elems = e->pair_off[l_end] - e->pair_off[l_first];
-  if (n_elems > capacity_elems) {
+  if ((!hits) && (n_elems > capacity_elems)) {
     return fail(e, LDP_ERR_INVALID, "output buffer smaller than the rows' candidate pair count");
   }
   if (!n_elems) {
     return LDP_OK;
   }
-  if (!out) {
+  if ((!hits) && !out) {
     return fail(e, LDP_ERR_INVALID, "output buffer is NULL");
   }
   const double t_start = now_ms();
@@ -1570,18 +1587,23 @@ int ldp_r2_unphased_band_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct
   }
   const size_t esz = as_float ? sizeof(float) : sizeof(double);
   DevBuf out_buf;
-  HIP_TRY(e, hipMalloc(&out_buf.p, n_elems * esz));
-  HIP_TRY(e, hipMemsetAsync(out_buf.p, 0, n_elems * esz, e->stream));
+  if (hits) {
+    HIP_TRY(e, hipMalloc(&out_buf.p, std::max<uint64_t>(hits->capacity, 1) * sizeof(ldp_r2_hit)));
+    HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
+  } else {
+    HIP_TRY(e, hipMalloc(&out_buf.p, n_elems * esz));
+    HIP_TRY(e, hipMemsetAsync(out_buf.p, 0, n_elems * esz, e->stream));
+  }
   PairKernelArgs A;
   fill_pair_args(e, &A, false);  // every r^2 is wanted: no early termination
   A.items = e->d_items + i0;
   A.item_general = e->d_item_general + i0;
   A.n_items = static_cast<uint32_t>(i1 - i0);
   A.thresh = 0.0;
-  A.r2_out = out_buf.p;
-  A.r2_hits = nullptr;
-  A.r2_hit_capacity = 0;
-  A.r2_min = 0.0;
+  A.r2_out = hits ? nullptr : out_buf.p;
+  A.r2_hits = hits ? out_buf.as<ldp_r2_hit>() : nullptr;
+  A.r2_hit_capacity = hits ? hits->capacity : 0;
+  A.r2_min = hits ? hits->min_r2 : 0.0;
   A.r2_ld = 0;
   A.r2_row_first = l_first;
   A.r2_row_end = l_end;
@@ -1595,8 +1617,23 @@ int ldp_r2_unphased_band_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct
   if (krc != hipSuccess) {
     return hipfail(e, krc, "pair_tiles_kernel launch");
   }
-  HIP_TRY(e, hipMemcpyAsync(out, out_buf.p, n_elems * esz, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (hits) {
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters_pin, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const uint64_t found = e->h_counters_pin[3];
+    *hits->count = found;
+    const uint64_t stored = std::min<uint64_t>(found, hits->capacity);
+    if (stored) {
+      HIP_TRY(e, hipMemcpy(hits->out, out_buf.p, stored * sizeof(ldp_r2_hit), hipMemcpyDeviceToHost));
+      for (uint64_t q = 0; q < stored; ++q) {  // the kernel works in local (paired-variant) order
+        hits->out[q].first = e->local_to_global[hits->out[q].first];
+        hits->out[q].second = e->local_to_global[hits->out[q].second];
+      }
+    }
+  } else {
+    HIP_TRY(e, hipMemcpyAsync(out, out_buf.p, n_elems * esz, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+  }
   float kms_fast = 0.f, kms_general = 0.f;
   if (A.n_items) {
     HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
@@ -1613,16 +1650,6 @@ int ldp_r2_unphased_band_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct
   e->ctr.pair_kernel_launches = A.n_items ? 1 : 0;
   return LDP_OK;
 }
-
-}  // extern "C"
-
-namespace {
-struct HitRequest {
-  double min_r2;
-  ldp_r2_hit* out;
-  uint64_t capacity;
-  uint64_t* count;
-};
 
 // rows [row_first, row_first+row_ct) of the all-pairs plan: dense into `out` (hits == nullptr) or filtered into hits->out
 int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t ld_elems, const HitRequest* hits) {
@@ -1806,7 +1833,14 @@ int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int
 
 int ldp_r2_unphased_hits(ldp_engine* e, uint32_t row_first, uint32_t row_ct, double min_r2, ldp_r2_hit* out, uint64_t capacity, uint64_t* count) {
   HitRequest hr{min_r2, out, capacity, count};
+  if (e && e->planned && e->band_r2_mode) {  // windowed plan (ldp_set_variants_vcor): the band's pairs
+    return r2_band_impl(e, row_first, row_ct, 0, nullptr, 0, &hr);
+  }
   return r2_rows_impl(e, row_first, row_ct, 0, nullptr, static_cast<uint64_t>(row_first) + row_ct, &hr);
+}
+
+int ldp_r2_unphased_band_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t capacity_elems) {
+  return r2_band_impl(e, row_first, row_ct, as_float, out, capacity_elems, nullptr);
 }
 
 int ldp_get_subcontigs(const ldp_engine* e, uint32_t* ct, uint32_t* info, uint32_t info_capacity_pairs) {

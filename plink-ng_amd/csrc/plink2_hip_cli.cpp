@@ -1377,10 +1377,11 @@ int main(int argc, char** argv) {
       }
       fputs("#CHROM_A\tPOS_A\tID_A\tCHROM_B\tPOS_B\tID_B\tUNPHASED_R2\n", tf);
       const double thresh = A.ld_min_r2;
-      if (A.r2_inter) {
+      if (A.r2_inter || (thresh > 0.0)) {
         // ---- inter-chr: every pair A < B of the whole variant set, chromosome 0 included (plink2_ld.cc:11082-11116).
         // The r^2 values come row chunk by row chunk (second variant B) from the all-pairs plan; pairs that pass
         // --ld-window-r2 are kept as (A, B, r^2) and bucketed by A afterwards, which gives the file's A-major order.
+        // ---- windowed table with a positive threshold (the default): the same, over the band's pairs.
         struct Hit {
           uint32_t i, j;
           double r2;
@@ -1392,11 +1393,13 @@ int main(int argc, char** argv) {
         // passing pairs cross PCIe; a row chunk whose hits overflow the buffer is redone through the dense path below.
         const bool device_filter = (thresh > 0.0);
         std::vector<ldp_r2_hit> dev_hits(device_filter ? (1u << 24) : 0);
+        uint32_t big_rows = 65536;
         for (uint32_t r0 = 0; r0 < variant_ct;) {
           uint32_t rows = static_cast<uint32_t>(std::max<uint64_t>(32, (1ull << 28) / (static_cast<uint64_t>(r0 + 4096) * 8)));
           rows = std::min(std::min(rows, variant_ct - r0), 65536u);
           if (device_filter) {
-            const uint32_t big = std::min(std::min<uint32_t>(rows * 16, variant_ct - r0), 65536u);  // (no dense buffer to size)
+            const uint32_t big = A.r2_inter ? std::min(std::min<uint32_t>(rows * 16, variant_ct - r0), 65536u)  // (no dense buffer to size)
+                                            : std::min(big_rows, variant_ct - r0);
             uint64_t found = 0;
             if (ldp_r2_unphased_hits(e, r0, big, thresh, dev_hits.data(), dev_hits.size(), &found)) {
               die(12, "Error: %s\n", ldp_last_error(e));
@@ -1409,6 +1412,10 @@ int main(int argc, char** argv) {
                 hits.push_back({dev_hits[q].first, dev_hits[q].second, dev_hits[q].r2});
               }
               r0 += big;
+              continue;
+            }
+            if (!A.r2_inter) {
+              big_rows = std::max(1u, big / 2);  // more hits than the buffer holds: fewer second variants per call
               continue;
             }
           }

@@ -227,3 +227,39 @@ def test_device_side_hit_filter_matches_dense_rows(gpu_pkg):
     hits, found = eng.r2_unphased_hits(0.05, 0, m, capacity=10)
     assert found > 10 and len(hits) == 10
     eng.close()
+
+
+def test_device_side_hit_filter_on_the_windowed_plan(gpu_pkg):
+    """ldp_r2_unphased_hits on a ldp_set_variants_vcor plan = the band's pairs filtered, global variant indices
+    (the plan leaves out variants without partners, so local and global indices differ)."""
+    m, n = 420, 200
+    raw = T.synth_raw_codes(m, n, seed=31, missing_rate=0.01)
+    rng = np.random.default_rng(4)
+    chr_idx = np.sort(rng.integers(0, 3, size=m)).astype(np.uint32)
+    bps = np.zeros(m, dtype=np.uint32)
+    for c in range(3):
+        sel = np.where(chr_idx == c)[0]
+        gaps = rng.integers(1, 400, size=len(sel))
+        gaps[rng.random(len(sel)) < 0.05] += 50000  # isolated variants: no partner inside the window
+        bps[sel] = np.cumsum(gaps)
+    eng = gpu_pkg.LdPruneEngine(n, 2, 1, False, 0.5, device=0)
+    eng.set_variants_vcor(chr_idx, bps, 3000, 25)
+    eng.load_genotypes_host(0, T.pack_2bit(raw), gpu_pkg.LDP_GENO_REF)
+    lo, cand = eng.band()
+    dense = eng.r2_unphased_band_rows()
+    want = []
+    off = 0
+    for j in range(m):
+        for i in range(int(lo[j]), j):
+            r2 = dense[off + (i - int(lo[j]))]
+            if abs(r2) >= 0.1:
+                want.append((i, j, r2))
+        off += j - int(lo[j])
+    want.sort()
+    hits, found = eng.r2_unphased_hits(0.1, 0, m, capacity=1 << 18)
+    assert found == len(want) == len(hits) and found > 50
+    assert [(int(h["first"]), int(h["second"])) for h in hits] == [(a, b) for a, b, _ in want]
+    assert np.array_equal(hits["r2"], np.array([w[2] for w in want]))
+    part, found2 = eng.r2_unphased_hits(0.1, 100, 150, capacity=1 << 18)
+    assert [(int(h["first"]), int(h["second"])) for h in part] == [(a, b) for a, b, _ in want if 100 <= b < 250]
+    eng.close()
