@@ -443,6 +443,14 @@ Args parse_args(int argc, char** argv) {
       // [{square | square0 | triangle | inter-chr}] ['yes-really'] [{zs | bin | bin4}] ... (plink2.cc:11090-11210)
       while (i + 1 < argc && !(argv[i + 1][0] == '-' && argv[i + 1][1] == '-')) {
         std::string m = argv[++i];
+        const bool is_shape = (m == "square") || (m == "square0") || (m == "triangle");
+        const bool is_encoding = (m == "bin") || (m == "bin4");
+        if (is_shape && (A.r2_shape >= 0)) {
+          die(5, "Error: Multiple --r2-unphased shape modifiers.\n");  // plink2.cc:11068-11090
+        }
+        if (is_encoding && (A.r2_float >= 0)) {
+          die(5, "Error: Multiple --r2-unphased encoding modifiers.\n");  // plink2.cc:11106-11118
+        }
         if (m == "square") A.r2_shape = 0;
         else if (m == "square0") A.r2_shape = 1;
         else if (m == "triangle") A.r2_shape = 2;
@@ -454,10 +462,10 @@ Args parse_args(int argc, char** argv) {
         else die(9, "Error: --r2-unphased modifier '%s' is not supported by plink2-hip (matrix shapes with bin/bin4, or the default-column table).\n", m.c_str());
       }
       if ((A.r2_shape < 0) && (A.r2_float >= 0)) {
-        die(5, "Error: --r2-unphased 'bin' and 'bin4' require a matrix shape (square, square0 or triangle).\n");
+        A.r2_shape = 0;  // an encoding without a shape: square (plink2_help.cc:1015-1017)
       }
       if (A.r2_inter && (A.r2_shape >= 0)) {
-        die(5, "Error: Multiple --r2-unphased shape modifiers.\n");
+        die(5, "Error: Matrix-only and table-only --r2-unphased settings cannot be used together.\n");  // plink2.cc:11187-11191
       }
       A.r2_table = (A.r2_shape < 0);
       A.r2_text = (A.r2_shape >= 0) && (A.r2_float < 0);  // shape without bin/bin4: tab-delimited text matrix

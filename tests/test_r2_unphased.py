@@ -75,7 +75,8 @@ def test_matrix_matches_golden_reference_doubles(gpu_pkg):
         eng.close()
 
 
-@pytest.mark.parametrize("shape,enc", [("square", "bin"), ("square0", "bin4"), ("triangle", "bin"), ("triangle", "bin4")])
+@pytest.mark.parametrize("shape,enc", [("square", "bin"), ("square0", "bin4"), ("triangle", "bin"), ("triangle", "bin4"),
+                                       ("yes-really", "bin4")])  # (an encoding without a shape: square, plink2_help.cc:1015)
 def test_cli_matrix_files_byte_identical(gpu_pkg, tmp_path, shape, enc):
     assert T.have_ref()
     cli = gpu_pkg.build_cli()
