@@ -276,6 +276,93 @@ char* format_g6(double x, char* out) {
   return put_digits_trimmed(banker_round(x * 1000000), 6, 1, out);
 }
 
+// Output file, optionally Zstandard-compressed ('zs': <name>.zst, as the reference's compress stream writes it;
+// plink2_compress_stream.cc).  libzstd.so.1 is bound by hand (no zstd headers in the image); the default compression
+// level (3) is used, so the bytes may differ from the reference's file while the decompressed text is identical.
+class OutFile {
+ public:
+  void open(const std::string& path, bool zs) {
+    path_ = path;
+    f_ = fopen(path.c_str(), "wb");
+    if (!f_) {
+      die(2, "Error: Failed to open %s for writing.\n", path.c_str());
+    }
+    if (!zs) {
+      return;
+    }
+    void* lib = dlopen("libzstd.so.1", RTLD_NOW);
+    if (!lib) {
+      die(9, "Error: 'zs' output needs libzstd.so.1, which could not be loaded.\n");
+    }
+    create_ = reinterpret_cast<void* (*)()>(dlsym(lib, "ZSTD_createCCtx"));
+    destroy_ = reinterpret_cast<size_t (*)(void*)>(dlsym(lib, "ZSTD_freeCCtx"));
+    step_ = reinterpret_cast<size_t (*)(void*, Buf*, CBuf*, int)>(dlsym(lib, "ZSTD_compressStream2"));
+    is_error_ = reinterpret_cast<unsigned (*)(size_t)>(dlsym(lib, "ZSTD_isError"));
+    if (!create_ || !destroy_ || !step_ || !is_error_) {
+      die(9, "Error: libzstd.so.1 lacks the streaming compression API.\n");
+    }
+    ctx_ = create_();
+    if (!ctx_) {
+      die(8, "Error: Out of memory.\n");
+    }
+    obuf_.resize(1 << 20);
+  }
+  void write(const void* p, size_t n) {
+    if (!ctx_) {
+      if (n && (fwrite(p, 1, n, f_) != n)) {
+        die(2, "Error: File write failure: %s.\n", path_.c_str());
+      }
+      return;
+    }
+    pump(p, n, 0);
+  }
+  void close() {
+    if (ctx_) {
+      pump(nullptr, 0, 2);  // ZSTD_e_end
+      destroy_(ctx_);
+      ctx_ = nullptr;
+    }
+    if (fclose(f_)) {
+      die(2, "Error: File write failure: %s.\n", path_.c_str());
+    }
+    f_ = nullptr;
+  }
+
+ private:
+  struct Buf {
+    void* dst;
+    size_t size, pos;
+  };
+  struct CBuf {
+    const void* src;
+    size_t size, pos;
+  };
+  void pump(const void* p, size_t n, int end_op) {
+    CBuf in{p, n, 0};
+    while (true) {
+      Buf out{obuf_.data(), obuf_.size(), 0};
+      const size_t left = step_(ctx_, &out, &in, end_op);
+      if (is_error_(left)) {
+        die(2, "Error: zstd compression failure: %s.\n", path_.c_str());
+      }
+      if (out.pos && (fwrite(obuf_.data(), 1, out.pos, f_) != out.pos)) {
+        die(2, "Error: File write failure: %s.\n", path_.c_str());
+      }
+      if (end_op ? (left == 0) : (in.pos == in.size)) {
+        break;
+      }
+    }
+  }
+  std::string path_;
+  FILE* f_ = nullptr;
+  void* ctx_ = nullptr;
+  void* (*create_)() = nullptr;
+  size_t (*destroy_)(void*) = nullptr;
+  size_t (*step_)(void*, Buf*, CBuf*, int) = nullptr;
+  unsigned (*is_error_)(size_t) = nullptr;
+  std::vector<uint8_t> obuf_;
+};
+
 struct Args {
   std::string bed, bim, fam, pgen, pvar, psam, out = "plink2";
   bool have_prune = false;
@@ -293,6 +380,7 @@ struct Args {
   int r2_float = -1;      // 1 bin4, 0 bin
   bool yes_really = false;
   bool r2_table = false;   // --r2-unphased without a matrix shape: windowed .vcor table
+  bool r2_zs = false;      // 'zs': Zstandard-compressed table / text matrix
   bool r2_inter = false;   // 'inter-chr': the table over ALL pairs, chromosome 0 included (plink2_ld.cc:11082-11116)
   bool r2_text = false;    // matrix shape without bin/bin4: text matrix
   uint32_t ld_var_ct_radius = 0x7fffffff;  // --ld-window N: N - 1
@@ -444,11 +532,11 @@ Args parse_args(int argc, char** argv) {
       while (i + 1 < argc && !(argv[i + 1][0] == '-' && argv[i + 1][1] == '-')) {
         std::string m = argv[++i];
         const bool is_shape = (m == "square") || (m == "square0") || (m == "triangle");
-        const bool is_encoding = (m == "bin") || (m == "bin4");
+        const bool is_encoding = (m == "bin") || (m == "bin4") || (m == "zs");
         if (is_shape && (A.r2_shape >= 0)) {
           die(5, "Error: Multiple --r2-unphased shape modifiers.\n");  // plink2.cc:11068-11090
         }
-        if (is_encoding && (A.r2_float >= 0)) {
+        if (is_encoding && ((A.r2_float >= 0) || A.r2_zs)) {
           die(5, "Error: Multiple --r2-unphased encoding modifiers.\n");  // plink2.cc:11106-11118
         }
         if (m == "square") A.r2_shape = 0;
@@ -457,6 +545,7 @@ Args parse_args(int argc, char** argv) {
         else if (m == "inter-chr") A.r2_inter = true;
         else if (m == "bin") A.r2_float = 0;
         else if (m == "bin4") A.r2_float = 1;
+        else if (m == "zs") A.r2_zs = true;
         else if (m == "yes-really") A.yes_really = true;
         else if (m == "ref-based" || m == "allow-ambiguous-allele") { /* no effect on r^2 */ }
         else die(9, "Error: --r2-unphased modifier '%s' is not supported by plink2-hip (matrix shapes with bin/bin4, or the default-column table).\n", m.c_str());
@@ -536,6 +625,24 @@ Args parse_args(int argc, char** argv) {
         puts(num);
       }
       fclose(df);
+      exit(0);
+    } else if (f == "--debug-zstd") {
+      // test hook (no GPU needed): <in> <out.zst> through the 'zs' output writer, in odd-sized pieces
+      need(i, 2, "--debug-zstd");
+      std::ifstream in(argv[i + 1], std::ios::binary);
+      if (!in) {
+        die(2, "Error: Failed to open %s.\n", argv[i + 1]);
+      }
+      std::stringstream ss;
+      ss << in.rdbuf();
+      const std::string data = ss.str();
+      OutFile of;
+      of.open(argv[i + 2], true);
+      for (size_t pos = 0, piece = 1; pos < data.size(); pos += piece, piece = piece * 3 + 1) {
+        piece = std::min(piece, data.size() - pos);
+        of.write(data.data() + pos, piece);
+      }
+      of.close();
       exit(0);
     } else if (f == "--gpus") {
       need(i, 1, "--gpus");
@@ -1378,12 +1485,11 @@ int main(int argc, char** argv) {
         if (ieq(name.c_str(), "PAR2")) return std::string("PAR2");
         return name;
       };
-      const std::string tpath = A.out + ".vcor";
-      FILE* tf = fopen(tpath.c_str(), "wb");
-      if (!tf) {
-        die(2, "Error: Failed to open %s for writing.\n", tpath.c_str());
-      }
-      fputs("#CHROM_A\tPOS_A\tID_A\tCHROM_B\tPOS_B\tID_B\tUNPHASED_R2\n", tf);
+      const std::string tpath = A.out + (A.r2_zs ? ".vcor.zst" : ".vcor");
+      OutFile tf;
+      tf.open(tpath, A.r2_zs);
+      static const char kVcorHeader[] = "#CHROM_A\tPOS_A\tID_A\tCHROM_B\tPOS_B\tID_B\tUNPHASED_R2\n";
+      tf.write(kVcorHeader, sizeof(kVcorHeader) - 1);
       const double thresh = A.ld_min_r2;
       if (A.r2_inter || (thresh > 0.0)) {
         // ---- inter-chr: every pair A < B of the whole variant set, chromosome 0 included (plink2_ld.cc:11082-11116).
@@ -1501,14 +1607,12 @@ int main(int argc, char** argv) {
           out.append(num, format_g6(h.r2, num) - num);
           out += '\n';
           if (out.size() > (1u << 21)) {
-            fwrite(out.data(), 1, out.size(), tf);
+            tf.write(out.data(), out.size());
             out.clear();
           }
         }
-        fwrite(out.data(), 1, out.size(), tf);
-        if (fclose(tf)) {
-          die(2, "Error: File write failure: %s.\n", tpath.c_str());
-        }
+        tf.write(out.data(), out.size());
+        tf.close();
         logprintf("--r2-unphased: %llu variant pair%s written to %s .\n", static_cast<unsigned long long>(sorted.size()), sorted.size() == 1 ? "" : "s", tpath.c_str());
         ldp_destroy(e);
         ldp_pgen_close(pg);
@@ -1581,16 +1685,14 @@ int main(int argc, char** argv) {
             ++written;
           }
           if (linebuf.size() > (1u << 21)) {
-            fwrite(linebuf.data(), 1, linebuf.size(), tf);
+            tf.write(linebuf.data(), linebuf.size());
             linebuf.clear();
           }
         }
         a0 = a1;
       }
-      fwrite(linebuf.data(), 1, linebuf.size(), tf);
-      if (fclose(tf)) {
-        die(2, "Error: File write failure: %s.\n", tpath.c_str());
-      }
+      tf.write(linebuf.data(), linebuf.size());
+      tf.close();
       logprintf("--r2-unphased: %llu variant pair%s written to %s .\n", static_cast<unsigned long long>(written), written == 1 ? "" : "s", tpath.c_str());
       ldp_destroy(e);
       ldp_pgen_close(pg);
@@ -1600,10 +1702,9 @@ int main(int argc, char** argv) {
       return 0;
     }
     const size_t esz = A.r2_float ? 4 : 8;
-    FILE* mf = fopen(base.c_str(), "wb");
-    if (!mf) {
-      die(2, "Error: Failed to open %s for writing.\n", base.c_str());
-    }
+    const std::string mpath = base + ((A.r2_text && A.r2_zs) ? ".zst" : "");
+    OutFile mf;
+    mf.open(mpath, A.r2_text && A.r2_zs);
     std::vector<uint8_t> full;  // square needs the mirrored upper triangle: whole matrix in host memory
     if (A.r2_shape == 0) {
       full.assign(static_cast<size_t>(variant_ct) * variant_ct * esz, 0);
@@ -1637,15 +1738,15 @@ int main(int argc, char** argv) {
             }
           }
           textbuf.back() = '\n';
-          fwrite(textbuf.data(), 1, textbuf.size(), mf);
+          mf.write(textbuf.data(), textbuf.size());
         } else if (A.r2_shape == 2) {
-          fwrite(row, esz, static_cast<size_t>(j) + 1, mf);
+          mf.write(row, esz * (static_cast<size_t>(j) + 1));
         } else if (A.r2_shape == 1) {
-          fwrite(row, esz, static_cast<size_t>(j) + 1, mf);
+          mf.write(row, esz * (static_cast<size_t>(j) + 1));
           static const std::vector<uint8_t> zeros(1 << 20, 0);
           for (uint64_t left = (static_cast<uint64_t>(variant_ct) - j - 1) * esz; left;) {
             const size_t w = static_cast<size_t>(std::min<uint64_t>(left, zeros.size()));
-            fwrite(zeros.data(), 1, w, mf);
+            mf.write(zeros.data(), w);
             left -= w;
           }
         } else {
@@ -1668,16 +1769,14 @@ int main(int argc, char** argv) {
             textbuf += '\t';
           }
           textbuf.back() = '\n';
-          fwrite(textbuf.data(), 1, textbuf.size(), mf);
+          mf.write(textbuf.data(), textbuf.size());
         }
       } else {
-        fwrite(full.data(), 1, full.size(), mf);
+        mf.write(full.data(), full.size());
       }
     }
-    if (fclose(mf)) {
-      die(2, "Error: File write failure: %s.\n", base.c_str());
-    }
-    logprintf("--r2-unphased: Matrix written to %s .\n", base.c_str());
+    mf.close();
+    logprintf("--r2-unphased: Matrix written to %s .\n", mpath.c_str());
     ldp_destroy(e);
     ldp_pgen_close(pg);
     if (g_log) {

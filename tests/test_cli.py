@@ -286,3 +286,17 @@ def test_zstd_variant_table(cli, tmp_path):
         os.link(str(tmp_path / ("z" + ext)), str(tmp_path / ("t" + ext)))
     c = run_cli(cli, ["--pfile", "t", "vzs", "--indep-pairwise", "50", "5", "0.2", "--dry-run"], str(tmp_path))
     assert c.returncode != 0 and "zstd" in c.stdout
+
+
+def test_zstd_output_writer_roundtrip(cli, tmp_path):
+    """'zs' outputs go through a hand-bound libzstd stream; the reference's own --zst-decompress must give the text back."""
+    if not T.have_ref():
+        pytest.skip("reference binary not built")
+    rng = np.random.default_rng(1)
+    text = "\n".join("%d\t%s" % (k, "ACGT"[k % 4] * int(rng.integers(1, 40))) for k in range(60000)) + "\n"
+    open(str(tmp_path / "in.txt"), "w").write(text)
+    r = run_cli(cli, ["--debug-zstd", "in.txt", "out.zst"], str(tmp_path))
+    assert r.returncode == 0, r.stdout
+    assert os.path.getsize(str(tmp_path / "out.zst")) < len(text) // 2
+    back = subprocess.run([T.REF_BIN, "--zst-decompress", "out.zst"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
+    assert back.returncode == 0 and back.stdout.decode() == text

@@ -264,3 +264,22 @@ def test_device_side_hit_filter_on_the_windowed_plan(gpu_pkg):
     part, found2 = eng.r2_unphased_hits(0.1, 100, 150, capacity=1 << 18)
     assert [(int(h["first"]), int(h["second"])) for h in part] == [(a, b) for a, b, _ in want if 100 <= b < 250]
     eng.close()
+
+
+@pytest.mark.parametrize("mods,ext", [([], ".vcor"), (["inter-chr"], ".vcor"), (["square"], ".unphased.vcor2"), (["triangle"], ".unphased.vcor2")])
+def test_cli_zs_outputs_decompress_to_the_reference_text(gpu_pkg, tmp_path, mods, ext):
+    """'zs': <out><ext>.zst whose decompressed text equals the reference's uncompressed file"""
+    assert T.have_ref()
+    cli = gpu_pkg.build_cli()
+    m, n = 260, 120
+    raw = T.synth_raw_codes(m, n, seed=41, missing_rate=0.02)
+    chroms = ["1"] * 150 + ["4"] * 110
+    T.write_pgen_fixed(str(tmp_path / "d"), raw, chroms, np.concatenate([np.arange(150), np.arange(110)]) * 300 + 1)
+    ref = T.run_ref(["--pfile", "d", "--r2-unphased"] + mods + ["--out", "ref"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    got = subprocess.run([cli, "--pfile", "d", "--r2-unphased"] + mods + ["zs", "--out", "hip"], cwd=str(tmp_path), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert got.returncode == 0, got.stdout
+    back = subprocess.run([T.REF_BIN, "--zst-decompress", "hip" + ext + ".zst"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
+    assert back.returncode == 0
+    assert back.stdout == open(str(tmp_path / ("ref" + ext)), "rb").read()
