@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end wall-clock of plink2-hip vs reference plink2 on the same .bed fileset (GPU box).
-    python tools/cli_e2e.py --variants 1000000 --samples 50000"""
+    python tests/cli_e2e.py --variants 1000000 --samples 50000"""
 import argparse, os, subprocess, sys, tempfile, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

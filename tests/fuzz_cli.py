@@ -4,7 +4,7 @@ random small filesets -- .bed or fixed-width .pgen, chromosome 0 rows, non-found
 both scan orders -- for --indep-pairwise (.prune.in/.prune.out), --indep-pairphase on phased variable-width .pgen
 (autosomes, chrX/chrY/MT with random sexes, non-founders) and the --r2-unphased table (.vcor).  Files must be
 byte-identical.
-    python tools/fuzz_cli.py [--cases 40] [--seed 1]"""
+    python tests/fuzz_cli.py [--cases 40] [--seed 1]"""
 import argparse
 import filecmp
 import os

@@ -2,7 +2,7 @@
 """CPU-only randomised check of the test ORACLE (oracle/ldoracle.c) against the reference binary (oracle/_ref/plink2):
 --indep-pairwise on .bed / fixed-width .pgen and --indep-pairphase on phased variable-width .pgen, random shapes,
 windows, thresholds, scan orders, missing rates.  No GPU involved: this pins the checker the GPU parity tests use.
-    python tools/fuzz_oracle.py [--cases 100] [--seed 1]"""
+    python tests/fuzz_oracle.py [--cases 100] [--seed 1]"""
 import argparse
 import os
 import sys

@@ -3,7 +3,7 @@
 CPU oracle over random shapes -- sample counts around the 512-sample chunk boundaries, count/kb windows with steps,
 both scan orders, thresholds from 0.02 to 0.95, missing rates from 0 to 20 %, LD blocks, monomorphic and all-missing
 rows, several chromosomes.  Prints the first mismatching case (seed) and exits non-zero.
-    python tools/fuzz_parity.py [--cases 150] [--seed 1]"""
+    python tests/fuzz_parity.py [--cases 150] [--seed 1]"""
 import argparse
 import os
 import sys

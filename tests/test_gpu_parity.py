@@ -377,10 +377,10 @@ def test_early_termination_wide_window(gpu_pkg, miss):
 
 
 def test_randomised_differential(gpu_pkg):
-    """tools/fuzz_parity.py: 80 random shapes (chunk-boundary sample counts, count/kb windows, steps, both orders,
+    """tests/fuzz_parity.py: 80 random shapes (chunk-boundary sample counts, count/kb windows, steps, both orders,
     thresholds 0.02-0.95, 0-20 % missing, LD blocks, degenerate rows) against the oracle, early termination on."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     rng = np.random.default_rng(20260925)
