@@ -526,7 +526,12 @@ void build_shard(ldp_engine* e) {
         continue;
       }
       const uint32_t units = (dmax + 7) / 8;
-      const uint32_t blocks = (units + kMaxUnitsPerBlock - 1) / kMaxUnitsPerBlock;
+      static const uint32_t max_units = []() {  // tuning aid: blocks of fewer units than the kernel's limit
+        const char* mu = getenv("LDP_DEBUG_MAX_UNITS");
+        const int v = mu ? atoi(mu) : kMaxUnitsPerBlock;
+        return static_cast<uint32_t>(std::min(std::max(v, 1), kMaxUnitsPerBlock));
+      }();
+      const uint32_t blocks = (units + max_units - 1) / max_units;
       const uint32_t base = units / blocks;
       const uint32_t extra = units % blocks;
       uint32_t d0 = 1;
