@@ -88,6 +88,15 @@ def main():
         out3["grid"] = np.array(["%s|%r|%d" % (" ".join(w), r, o) for w, r, o in GRID])
         shutil.copy(os.path.join(tmp, "c.pgen"), os.path.join(HERE, "pgen", "phased_multi.pgen"))
         np.savez_compressed(os.path.join(HERE, "pgen", "phased_multi.npz"), **out3)
+        # ---- multiallelic, partially phased: the explicit-phasepresent form of the phase track over multiallelic hets
+        m4, n4 = 150, 83
+        first4, second4, alt_ct4 = T.synth_multiallelic_haps(m4, n4, seed=9, max_alt=4, multi_rate=0.5)
+        unph = (np.random.default_rng(10).random(first4.shape) < 0.35) & (first4 != second4) & (first4 >= 0)
+        unph[:20] = False
+        T.write_vcf_haps(os.path.join(tmp, "e.vcf"), first4, second4, alt_ct4, ["1"] * m4, 1 + 50 * np.arange(m4), unphased=unph)
+        T.ref_import_vcf(os.path.join(tmp, "e.vcf"), os.path.join(tmp, "e"))
+        shutil.copy(os.path.join(tmp, "e.pgen"), os.path.join(HERE, "pgen", "phased_multi_partial.pgen"))
+        np.savez_compressed(os.path.join(HERE, "pgen", "phased_multi_partial.npz"), first=first4, second=second4, alt_ct=alt_ct4.astype(np.uint32), unphased=unph)
     finally:
         shutil.rmtree(tmp)
 

@@ -155,6 +155,26 @@ def test_multiallelic_phase_reader_against_reference_written_file():
     pg.close()
 
 
+def test_multiallelic_phase_reader_partially_phased_file():
+    """explicit phasepresent bits over all hets, multiallelic ones included (pgen_spec.tex:541-562)"""
+    pkg = ge.load_package()
+    z = np.load(os.path.join(GOLD, "phased_multi_partial.npz"))
+    pg = pkg.PgenFile(os.path.join(GOLD, "phased_multi_partial.pgen"))
+    a, b = z["first"].astype(int), z["second"].astype(int)
+    het = (a != b) & (a >= 0)
+    seen_explicit = 0
+    for v in range(pg.variant_ct):
+        lo, hi, pp, pi = pg.read_alleles_phased(v, int(z["alt_ct"][v]))
+        assert np.array_equal(lo, np.where(a[v] < 0, 255, np.minimum(a[v], b[v])))
+        assert np.array_equal(hi, np.where(a[v] < 0, 255, np.maximum(a[v], b[v])))
+        want_pp = het[v] & ~z["unphased"][v]
+        assert np.array_equal(pp.astype(bool), want_pp), v
+        assert np.array_equal(pi.astype(bool), want_pp & (a[v] > b[v])), v
+        seen_explicit += int(z["unphased"][v].any() and want_pp.any())
+    assert seen_explicit > 30
+    pg.close()
+
+
 def test_oracle_pairphase_multiallelic_collapse_matches_reference_golden():
     """PgrGetInv1P -> Get1MP on multiallelic variants: the collapse on the major allele and the reference's reading of
     phaseinfo (ldtools.pairphase_hap_rows_multiallelic).  The physically right haplotype assignment does NOT give the
