@@ -3,6 +3,7 @@ the hardcall-phase reader against reference-written .pgen files, and (GPU) the H
 Golden files: tests/golden/make_golden_pairphase.py."""
 import ctypes
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -173,6 +174,15 @@ def test_multiallelic_phase_reader_partially_phased_file():
         seen_explicit += int(z["unphased"][v].any() and want_pp.any())
     assert seen_explicit > 30
     pg.close()
+
+
+def test_portable_bit_deposit_path():
+    """the phase decoder uses pext/pdep when the host has BMI2; LDP_PGEN_NO_BMI2 forces the portable loops"""
+    import sys
+    env = dict(os.environ, LDP_PGEN_NO_BMI2="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "not gpu", "-k", "reader", "-p", "no:cacheprovider"],
+                       env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-800:]
 
 
 def test_oracle_pairphase_multiallelic_collapse_matches_reference_golden():
