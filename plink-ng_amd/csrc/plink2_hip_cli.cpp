@@ -381,6 +381,8 @@ struct Args {
   int r2_float = -1;      // 1 bin4, 0 bin
   bool yes_really = false;
   bool r2_table = false;   // --r2-unphased without a matrix shape: windowed .vcor table
+  bool r2_ref_based = false;
+  bool r2_allow_ambiguous = false;
   bool r2_zs = false;      // 'zs': Zstandard-compressed table / text matrix
   bool r2_inter = false;   // 'inter-chr': the table over ALL pairs, chromosome 0 included (plink2_ld.cc:11082-11116)
   bool r2_text = false;    // matrix shape without bin/bin4: text matrix
@@ -548,7 +550,8 @@ Args parse_args(int argc, char** argv) {
         else if (m == "bin4") A.r2_float = 1;
         else if (m == "zs") A.r2_zs = true;
         else if (m == "yes-really") A.yes_really = true;
-        else if (m == "ref-based" || m == "allow-ambiguous-allele") { /* no effect on r^2 */ }
+        else if (m == "ref-based") A.r2_ref_based = true;          // multiallelic variants: REF vs the rest instead of major vs the rest
+        else if (m == "allow-ambiguous-allele") A.r2_allow_ambiguous = true;
         else die(9, "Error: --r2-unphased modifier '%s' is not supported by plink2-hip (matrix shapes with bin/bin4, or the default-column table).\n", m.c_str());
       }
       if ((A.r2_shape < 0) && (A.r2_float >= 0)) {
@@ -1269,9 +1272,6 @@ int main(int argc, char** argv) {
   }
   int storage_mode = 0, encoding = LDP_GENO_REF, has_multiallelic = 0;
   ldp_pgen_info(pg, nullptr, nullptr, &storage_mode, &encoding, &has_multiallelic);
-  if (has_multiallelic && A.have_r2) {
-    die(9, "Error: %s contains multiallelic records, which --r2-unphased in plink2-hip does not support yet.\n", gpath.c_str());
-  }
   uint64_t rec_bytes = (static_cast<uint64_t>(raw_sample_ct) + 3) / 4;
   const uint8_t* direct_rows = static_cast<const uint8_t*>(ldp_pgen_direct_rows(pg, &rec_bytes));  // NULL for variable-width
 
@@ -1369,6 +1369,13 @@ int main(int argc, char** argv) {
     if (ldp_create(&RP, &e)) {
       die(12, "Error: engine setup failed.\n");
     }
+    if (A.r2_table && !A.r2_allow_ambiguous) {  // plink2_ld.cc:11063-11072 (the default column set has no allele columns)
+      for (uint32_t k = 0; k < variant_ct; ++k) {
+        if (V.alt_ct[inc[k]] > 1) {
+          die(7, "Error: --r2-unphased column-set doesn't include allele columns which clarify\nwhich calculation is being performed at multiallelic variants. Either filter\nout multiallelic variants, revise the column-set (with e.g. \"cols=+%s\"), or\nuse the 'allow-ambiguous-allele' modifier to override this error.\n", A.r2_ref_based ? "ref" : "maj");
+        }
+      }
+    }
     if (A.r2_inter && (A.ld_min_r2 <= 0.0) && (variant_ct > 400000) && !A.yes_really) {  // plink2_ld.cc:11087
       die(7, "Error: Gigantic (over 400k variants) --r2-unphased unfiltered, non-distributed\ncomputation.  Rerun with the 'yes-really' modifier if you are SURE you have enough\nhard drive space and want to do this.\n");
     }
@@ -1436,6 +1443,26 @@ int main(int argc, char** argv) {
           die(12, "Error: %s\n", ldp_last_error(e));
         }
         k += run;
+      }
+      // Multiallelic variants (R2NondosageVariant works on PgrGetInv1(major allele) rows, plink2_ld.cc:6039-6048):
+      // collapsed major-vs-rest on the host, as for the prune.  With 'ref-based' the collapse is REF-vs-rest, which
+      // is what the main track's codes already are.
+      if (!A.r2_ref_based) {
+        std::vector<uint8_t> lo(raw_sample_ct), hi(raw_sample_ct), inv_row(out_rec);
+        for (uint32_t k = 0; k < variant_ct; ++k) {
+          const uint32_t alts = V.alt_ct[inc[k]];
+          if (alts < 2) {
+            continue;
+          }
+          if (storage_mode == 0x01) {
+            die(3, "Error: multiallelic variant in a .bim/.bed fileset.\n");
+          }
+          double mf = 0.0;
+          multiallelic_inverse_row(pg, inc[k], alts, founder_idx, &lo, &hi, inv_row.data(), out_rec, &mf);
+          if (ldp_load_genotypes(e, k, 1, inv_row.data(), out_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) || ldp_set_maj_freqs(e, k, 1, &mf)) {
+            die(12, "Error: %s\n", ldp_last_error(e));
+          }
+        }
       }
     }
     if (A.r2_table) {

@@ -283,3 +283,31 @@ def test_cli_zs_outputs_decompress_to_the_reference_text(gpu_pkg, tmp_path, mods
     back = subprocess.run([T.REF_BIN, "--zst-decompress", "hip" + ext + ".zst"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
     assert back.returncode == 0
     assert back.stdout == open(str(tmp_path / ("ref" + ext)), "rb").read()
+
+
+def test_cli_r2_multiallelic_variants_match_reference(gpu_pkg, tmp_path):
+    """multiallelic variants in --r2-unphased: major-vs-rest collapse (or REF-vs-rest with 'ref-based'), the table's
+    ambiguity guard (plink2_ld.cc:11063-11072) and its 'allow-ambiguous-allele' override"""
+    assert T.have_ref()
+    cli = gpu_pkg.build_cli()
+    tmp = str(tmp_path)
+    m, n = 260, 110
+    first, second, alt_ct = T.synth_multiallelic_haps(m, n, seed=3, max_alt=4, multi_rate=0.4)
+    T.write_vcf_haps(os.path.join(tmp, "d.vcf"), first, second, alt_ct, ["1"] * 150 + ["6"] * 110, np.concatenate([np.arange(150), np.arange(110)]) * 211 + 1,
+                     unphased=np.ones(first.shape, dtype=bool))
+    T.ref_import_vcf(os.path.join(tmp, "d.vcf"), os.path.join(tmp, "d"))
+
+    def both(args):
+        ref = T.run_ref(["--pfile", "d", "--r2-unphased"] + args + ["--out", "ref"], tmp)
+        got = subprocess.run([cli, "--pfile", "d", "--r2-unphased"] + args + ["--out", "hip"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        return ref, got
+
+    ref, got = both([])
+    assert ref.returncode == got.returncode == 7
+    assert [ln for ln in ref.stdout.splitlines() if ln.startswith("Error")] == [ln for ln in got.stdout.splitlines() if ln.startswith("Error")]
+    for args, ext in [(["allow-ambiguous-allele", "--ld-window-r2", "0.05"], ".vcor"), (["allow-ambiguous-allele", "ref-based", "--ld-window-r2", "0.05"], ".vcor"),
+                      (["square", "bin"], ".unphased.vcor2.bin"), (["triangle", "bin4", "ref-based"], ".unphased.vcor2.bin"),
+                      (["inter-chr", "allow-ambiguous-allele"], ".vcor")]:
+        ref, got = both(args)
+        assert ref.returncode == 0 and got.returncode == 0, (args, ref.stdout[-300:], got.stdout[-300:])
+        assert filecmp.cmp(os.path.join(tmp, "ref" + ext), os.path.join(tmp, "hip" + ext), shallow=False), args
