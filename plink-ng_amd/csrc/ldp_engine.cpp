@@ -76,6 +76,7 @@ struct ldp_engine {
   ldp_params P;
   int device = -1;
   bool gpu_ok = false;
+  bool gpu_probed = false;  // bind_gpu() ran (it runs at the first device use, not in ldp_create)
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
@@ -590,7 +591,45 @@ void build_shard(ldp_engine* e) {
   e->mf_set.assign(local, 0);
 }
 
+// Device selection and stream creation, at the first use of the device: ldp_create() and ldp_set_variants() are host
+// work, so a caller can plan while the HIP runtime is still starting up on another thread (plink2-hip does).
+void bind_gpu(ldp_engine* e) {
+  if (e->gpu_probed) {
+    return;
+  }
+  e->gpu_probed = true;
+  const int ndev = ldp_device_count();
+  if (ndev > 0) {
+    int dev = e->P.device;
+    if (dev < 0) {
+      if (hipGetDevice(&dev) != hipSuccess) {
+        dev = 0;
+      }
+    }
+    if ((dev < ndev) && (hipSetDevice(dev) == hipSuccess)) {
+      e->device = dev;
+      e->gpu_ok = true;
+      if (e->P.stream) {
+        e->stream = static_cast<hipStream_t>(e->P.stream);
+      } else if (create_stream(&e->stream, true) == hipSuccess) {
+        e->own_stream = true;
+      } else {
+        e->gpu_ok = false;
+      }
+      if (e->gpu_ok && (create_stream(&e->copy_stream, true) != hipSuccess)) {
+        e->gpu_ok = false;
+      }
+      for (int k = 0; (k < kPairStreams) && e->gpu_ok; ++k) {
+        if (create_stream(&e->pair_stream[k], false) != hipSuccess) {
+          e->gpu_ok = false;
+        }
+      }
+    }
+  }
+}
+
 int ensure_device_plan(ldp_engine* e) {
+  bind_gpu(e);
   if (!e->gpu_ok) {
     return fail(e, LDP_ERR_GPU, "no usable HIP device");
   }
@@ -1323,34 +1362,6 @@ int ldp_create(const ldp_params* params, ldp_engine** out) {
   }
   e->P = *params;
   e->ctr = ldp_counters();
-  const int ndev = ldp_device_count();
-  if (ndev > 0) {
-    int dev = params->device;
-    if (dev < 0) {
-      if (hipGetDevice(&dev) != hipSuccess) {
-        dev = 0;
-      }
-    }
-    if ((dev < ndev) && (hipSetDevice(dev) == hipSuccess)) {
-      e->device = dev;
-      e->gpu_ok = true;
-      if (params->stream) {
-        e->stream = static_cast<hipStream_t>(params->stream);
-      } else if (create_stream(&e->stream, true) == hipSuccess) {
-        e->own_stream = true;
-      } else {
-        e->gpu_ok = false;
-      }
-      if (e->gpu_ok && (create_stream(&e->copy_stream, true) != hipSuccess)) {
-        e->gpu_ok = false;
-      }
-      for (int k = 0; (k < kPairStreams) && e->gpu_ok; ++k) {
-        if (create_stream(&e->pair_stream[k], false) != hipSuccess) {
-          e->gpu_ok = false;
-        }
-      }
-    }
-  }
   *out = e;
   return LDP_OK;
 }

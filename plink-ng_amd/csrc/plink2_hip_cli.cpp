@@ -1236,13 +1236,28 @@ int main(int argc, char** argv) {
   std::thread t_variants([&]() { load_variants(A, &V); });
   double t_hip_init = 0.0, t_parse = 0.0;
   std::thread t_hip([&]() { const double t0 = now_s(); (void)ldp_device_count(); t_hip_init = now_s() - t0; });
+  // joined where the first engine is created (HIP context creation is the longest setup item; the variant-table
+  // passes and the ID check below run beside it), or on the way out
+  struct Joiner {
+    std::thread& t;
+    ~Joiner() {
+      if (t.joinable()) {
+        t.join();
+      }
+    }
+  } hip_guard{t_hip};
+  double t_joined = 0.0;
+  auto join_hip = [&]() {
+    if (t_hip.joinable()) {
+      t_hip.join();
+      t_joined = now_s();
+    }
+  };
   std::vector<uint8_t> is_founder;
   std::vector<uint8_t> sex;
   load_samples(A, &is_founder, &sex);
   t_variants.join();
   t_parse = now_s() - t_begin;
-  t_hip.join();
-  const double t_joined = now_s();
   const uint32_t raw_sample_ct = static_cast<uint32_t>(is_founder.size());
   uint32_t founder_ct = 0;
   for (uint8_t f : is_founder) {
@@ -1362,6 +1377,7 @@ int main(int argc, char** argv) {
     RP.prune_window_incr = 1;
     RP.prune_last_param = 0.5;
     RP.device = 0;
+    join_hip();
     if (ldp_device_count() < 1) {
       die(12, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
     }
@@ -1824,8 +1840,14 @@ int main(int argc, char** argv) {
   if (A.dry_run) {
     ldp_engine* e = nullptr;
     P.device = -1;
+    join_hip();
+    const double t_plan0 = now_s();
     if (ldp_create(&P, &e) || ldp_set_variants(e, m_ct, m_chr.data(), A.window_is_bp ? m_bps.data() : nullptr)) {
       die(12, "Error: planning failed.\n");
+    }
+    if (A.timing) {
+      logprintf("[timing] table parse %.3f s, joined at %.3f s, variant table passes %.3f s, engine plan %.3f s\n", t_parse, t_joined - t_begin,
+                t_plan0 - t_joined, now_s() - t_plan0);
     }
     uint32_t sct = 0;
     uint64_t cand = 0;
@@ -1839,11 +1861,45 @@ int main(int argc, char** argv) {
     ldp_destroy(e);
     return 0;
   }
-  const int ndev = ldp_device_count();
-  if (ndev < 1) {
-    die(12, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
+  // unique IDs (plink2_ld.cc:2573-2592): checked here, beside the HIP start-up, reported where the reference does
+  bool duplicate_ids = false;
+  {
+    // open-addressing table of variant indices keyed by a 64-bit FNV-1a hash of the ID
+    uint32_t bits = 4;
+    while ((1ull << bits) < 2ull * variant_ct) {
+      ++bits;
+    }
+    const uint64_t mask = (1ull << bits) - 1;
+    std::vector<uint32_t> table(static_cast<size_t>(1) << bits, 0xffffffffu);
+    for (uint32_t k = 0; (k < variant_ct) && !duplicate_ids; ++k) {
+      const std::string& id = V.id[inc[k]];
+      uint64_t h = 0xcbf29ce484222325ull;
+      for (unsigned char ch : id) {
+        h = (h ^ ch) * 0x100000001b3ull;
+      }
+      uint64_t slot = (h ^ (h >> 29)) & mask;
+      while (table[slot] != 0xffffffffu) {
+        if (V.id[inc[table[slot]]] == id) {
+          duplicate_ids = true;
+          break;
+        }
+        slot = (slot + 1) & mask;
+      }
+      table[slot] = k;
+    }
   }
-  const int world = std::min(A.gpus, ndev);
+  const double t_tables_done = now_s();
+  // One GPU: the engine is created and planned (host work: ldp_create binds the device lazily) while the HIP runtime
+  // is still starting; several GPUs: the device count decides how many engines there are, so wait for it first.
+  int world = 1;
+  if (A.gpus > 1) {
+    join_hip();
+    const int ndev = ldp_device_count();
+    if (ndev < 1) {
+      die(12, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
+    }
+    world = std::min(A.gpus, ndev);
+  }
   std::vector<ldp_engine*> eng(world, nullptr);
   uint32_t subcontig_ct = 0;
   for (int r = 0; r < world; ++r) {
@@ -1864,32 +1920,15 @@ int main(int argc, char** argv) {
       }
     }
   }
+  const double t_planned = now_s();
+  join_hip();
+  if (ldp_device_count() < 1) {
+    die(12, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
+  }
   std::vector<uint64_t> removed((static_cast<size_t>(variant_ct) + 63) / 64 + 1, 0);
   if (subcontig_ct || !xk.empty() || !yk.empty() || !tk.empty()) {
-    // unique IDs (plink2_ld.cc:2573-2592)
-    {
-      // open-addressing table of variant indices keyed by a 64-bit FNV-1a hash of the ID
-      uint32_t bits = 4;
-      while ((1ull << bits) < 2ull * variant_ct) {
-        ++bits;
-      }
-      const uint64_t mask = (1ull << bits) - 1;
-      std::vector<uint32_t> table(static_cast<size_t>(1) << bits, 0xffffffffu);
-      for (uint32_t k = 0; k < variant_ct; ++k) {
-        const std::string& id = V.id[inc[k]];
-        uint64_t h = 0xcbf29ce484222325ull;
-        for (unsigned char ch : id) {
-          h = (h ^ ch) * 0x100000001b3ull;
-        }
-        uint64_t slot = (h ^ (h >> 29)) & mask;
-        while (table[slot] != 0xffffffffu) {
-          if (V.id[inc[table[slot]]] == id) {
-            die(7, "Error: --indep-pair%s requires unique variant IDs. (--set-all-var-ids and/or --rm-dup may help.)\n", A.pairphase ? "phase" : "wise");
-          }
-          slot = (slot + 1) & mask;
-        }
-        table[slot] = k;
-      }
+    if (duplicate_ids) {  // plink2_ld.cc:2590-2592
+      die(7, "Error: --indep-pair%s requires unique variant IDs. (--set-all-var-ids and/or --rm-dup may help.)\n", A.pairphase ? "phase" : "wise");
     }
     std::vector<uint64_t> preferred;
     if (!A.preferred.empty()) {
@@ -1916,8 +1955,8 @@ int main(int argc, char** argv) {
     fflush(stdout);
     const double t_load0 = now_s();
     if (A.timing) {
-      logprintf("\n[timing] table parse %.3f s, HIP init %.3f s (concurrent; joined at %.3f s), tables+engine plan+ID check %.3f s\n", t_parse, t_hip_init,
-                t_joined - t_begin, t_load0 - t_joined);
+      logprintf("\n[timing] table parse %.3f s, variant-table passes + ID check done at %.3f s, engine planned at %.3f s, HIP init %.3f s (concurrent; joined at %.3f s)\n",
+                t_parse, t_tables_done - t_begin, t_planned - t_begin, t_hip_init, t_joined - t_begin);
     }
 
     // ---- genotype rows of the diploid (+MT) variants -> engines.  All-founder files go straight from the
