@@ -262,6 +262,13 @@ int ldp_pgen_read_alleles(ldp_pgen* p, uint32_t variant, uint32_t alt_ct, uint8_
  * ldp_pgen_read_phased() leaves the phase bits of multiallelic records zero: this is the reader for them. */
 int ldp_pgen_read_alleles_phased(ldp_pgen* p, uint32_t variant, uint32_t alt_ct, uint8_t* allele_lo, uint8_t* allele_hi,
                                  uint8_t* phasepresent, uint8_t* phaseinfo);
+/* Keep the samples whose bit is set in sample_mask (ceil(raw_sample_ct/8) bytes), for n_rows rows at once: the 2-bit
+ * codes (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185) and, with phased != 0, the phaseinfo bits of
+ * LDP_GENO_PHASED rows (CopyBitarrSubset; input rows laid out for 2*raw_sample_ct haplotypes, output rows for
+ * 2*kept).  The founder subsetting PgrGetInv1 does while decoding (plink2_ld.cc:1357).  Host memory, host threads
+ * (0 = all). */
+int ldp_subset_samples(const void* in_rows, uint64_t in_stride, uint32_t n_rows, uint32_t raw_sample_ct, const uint8_t* sample_mask,
+                       void* out_rows, uint64_t out_stride, int phased, uint32_t threads);
 const char* ldp_pgen_last_error(const ldp_pgen* p);
 void ldp_pgen_close(ldp_pgen* p);
 

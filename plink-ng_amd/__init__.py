@@ -82,7 +82,7 @@ CABI_SYMBOLS = [
     "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
     "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_r2_unphased_hits", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
-    "ldp_pgen_variant_is_multiallelic", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
+    "ldp_pgen_variant_is_multiallelic", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_subset_samples", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
 ]
 
 
@@ -187,6 +187,8 @@ def lib():
     L.ldp_phased_phase_offset.restype = ctypes.c_uint64
     L.ldp_pgen_read_phased.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint8), ctypes.c_uint32,
                                        ctypes.POINTER(ctypes.c_uint32)]
+    L.ldp_subset_samples.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint8), vp, ctypes.c_uint64,
+                                     ctypes.c_int, ctypes.c_uint32]
     L.ldp_pgen_read_alleles_phased.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32] + [ctypes.POINTER(ctypes.c_uint8)] * 4
     L.ldp_pgen_read_alleles.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8)]
     L.ldp_pgen_last_error.argtypes = [vp]
@@ -233,6 +235,21 @@ def pack_phased_rows(codes_packed, phaseinfo_bits, sample_ct):
     out[:, :cb] = np.ascontiguousarray(codes_packed).view(np.uint8).reshape(m, -1)[:, :cb]
     bits = np.packbits(np.asarray(phaseinfo_bits, dtype=np.uint8) & 1, axis=1, bitorder="little")
     out[:, off:off + bits.shape[1]] = bits
+    return out
+
+
+def subset_samples(rows, raw_sample_ct, keep_mask, phased=False, threads=0):
+    """ldp_subset_samples: rows (M, stride) uint8 -> rows of the kept samples (packed 2-bit codes [+ phase bits])"""
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    keep = np.asarray(keep_mask, dtype=bool)
+    kept = int(keep.sum())
+    out_stride = phased_row_bytes(2 * kept) if phased else (kept + 3) // 4
+    out = np.zeros((rows.shape[0], max(out_stride, 1)), dtype=np.uint8)
+    mask = np.packbits(keep, bitorder="little")
+    rc = lib().ldp_subset_samples(rows.ctypes.data_as(ctypes.c_void_p), rows.strides[0] if rows.shape[0] else 1, rows.shape[0], raw_sample_ct,
+                                  mask.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), out.ctypes.data_as(ctypes.c_void_p), out.strides[0], 1 if phased else 0, threads)
+    if rc != LDP_OK:
+        raise LdpError(rc, "ldp_subset_samples failed")
     return out
 
 

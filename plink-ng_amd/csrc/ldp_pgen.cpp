@@ -970,6 +970,108 @@ int ldp_pgen_read_alleles_phased(ldp_pgen* P, uint32_t variant, uint32_t alt_ct,
   return LDP_OK;
 }
 
+// CopyNyparrNonemptySubset (include/pgenlib_misc.cc:32,185) -- and CopyBitarrSubset for the phase bits of
+// LDP_GENO_PHASED rows -- over a block of rows: per 64-bit input word one pext (bit-gather) with a mask prepared once,
+// appended to the output bit stream; rows in parallel on host threads.
+int ldp_subset_samples(const void* in_rows, uint64_t in_stride, uint32_t n_rows, uint32_t raw_sample_ct, const uint8_t* sample_mask,
+                       void* out_rows, uint64_t out_stride, int phased, uint32_t threads) {
+  if ((n_rows && (!in_rows || !out_rows)) || !sample_mask || !raw_sample_ct) {
+    return LDP_ERR_INVALID;
+  }
+  const uint64_t m5 = 0x5555555555555555ull;
+  uint32_t kept = 0;
+  for (uint32_t s0 = 0; s0 < raw_sample_ct; ++s0) {
+    kept += (sample_mask[s0 >> 3] >> (s0 & 7)) & 1;
+  }
+  const uint64_t in_code_bytes = (static_cast<uint64_t>(raw_sample_ct) + 3) / 4;
+  const uint64_t out_code_bytes = (static_cast<uint64_t>(kept) + 3) / 4;
+  const uint64_t in_phase_off = (in_code_bytes + 3) & ~static_cast<uint64_t>(3);
+  const uint64_t out_phase_off = (out_code_bytes + 3) & ~static_cast<uint64_t>(3);
+  const uint64_t in_phase_bytes = (static_cast<uint64_t>(raw_sample_ct) + 7) / 8;
+  const uint64_t out_phase_bytes = (static_cast<uint64_t>(kept) + 7) / 8;
+  const uint64_t in_need = phased ? (in_phase_off + in_phase_bytes) : in_code_bytes;
+  const uint64_t out_need = phased ? (out_phase_off + out_phase_bytes) : out_code_bytes;
+  if ((in_stride < in_need) || (out_stride < out_need)) {
+    return LDP_ERR_INVALID;
+  }
+  // per input word of 32 codes: the 2-bit-expanded mask and the output bit offset; per word of 64 phase bits likewise
+  const uint32_t code_words = static_cast<uint32_t>((in_code_bytes + 7) / 8);
+  const uint32_t bit_words = static_cast<uint32_t>((in_phase_bytes + 7) / 8);
+  std::vector<uint64_t> mask2(code_words, 0), mask1(bit_words, 0);
+  std::vector<uint64_t> off2(code_words + 1, 0), off1(bit_words + 1, 0);
+  for (uint32_t s0 = 0; s0 < raw_sample_ct; ++s0) {
+    if ((sample_mask[s0 >> 3] >> (s0 & 7)) & 1) {
+      mask2[s0 >> 5] |= 3ull << (2 * (s0 & 31));
+      mask1[s0 >> 6] |= 1ull << (s0 & 63);
+    }
+  }
+  for (uint32_t w = 0; w < code_words; ++w) {
+    off2[w + 1] = off2[w] + static_cast<uint64_t>(__builtin_popcountll(mask2[w]));
+  }
+  for (uint32_t w = 0; w < bit_words; ++w) {
+    off1[w + 1] = off1[w] + static_cast<uint64_t>(__builtin_popcountll(mask1[w]));
+  }
+  (void)m5;
+#if defined(__x86_64__)
+  static const bool have_bmi2 = __builtin_cpu_supports("bmi2") && !getenv("LDP_PGEN_NO_BMI2");
+#else
+  static const bool have_bmi2 = false;
+#endif
+  const uint8_t* in = static_cast<const uint8_t*>(in_rows);
+  uint8_t* out = static_cast<uint8_t*>(out_rows);
+  auto gather_bits = [&](const uint8_t* src, uint64_t src_bytes, const std::vector<uint64_t>& mask, const std::vector<uint64_t>& off, std::vector<uint64_t>& acc,
+                         uint8_t* dst, uint64_t dst_bytes) {
+    std::fill(acc.begin(), acc.end(), 0);
+    const uint32_t words = static_cast<uint32_t>(mask.size());
+    for (uint32_t w = 0; w < words; ++w) {
+      if (!mask[w]) {
+        continue;
+      }
+      uint64_t v = 0;
+      const uint64_t byte0 = 8ull * w;
+      memcpy(&v, src + byte0, std::min<uint64_t>(8, src_bytes - byte0));
+      v = have_bmi2 ? pext64_hw(v, mask[w]) : pext64_loop(v, mask[w]);
+      const uint64_t o = off[w];
+      acc[o >> 6] |= v << (o & 63);
+      if ((o & 63) && ((o & 63) + (off[w + 1] - o) > 64)) {
+        acc[(o >> 6) + 1] |= v >> (64 - (o & 63));
+      }
+    }
+    memcpy(dst, acc.data(), dst_bytes);
+  };
+  constexpr uint32_t kRowsPerTask = 64;
+  const uint32_t tasks = (n_rows + kRowsPerTask - 1) / kRowsPerTask;
+  std::atomic<uint32_t> next(0);
+  auto worker = [&]() {
+    std::vector<uint64_t> acc2((out_code_bytes + 7) / 8 + 2, 0), acc1((out_phase_bytes + 7) / 8 + 2, 0);
+    for (uint32_t t = next.fetch_add(1); t < tasks; t = next.fetch_add(1)) {
+      const uint32_t r1 = std::min(n_rows, (t + 1) * kRowsPerTask);
+      for (uint32_t r = t * kRowsPerTask; r < r1; ++r) {
+        const uint8_t* src = in + static_cast<uint64_t>(r) * in_stride;
+        uint8_t* dst = out + static_cast<uint64_t>(r) * out_stride;
+        gather_bits(src, in_code_bytes, mask2, off2, acc2, dst, out_code_bytes);
+        if (phased) {
+          memset(dst + out_code_bytes, 0, out_phase_off - out_code_bytes);
+          gather_bits(src + in_phase_off, in_phase_bytes, mask1, off1, acc1, dst + out_phase_off, out_phase_bytes);
+        }
+      }
+    }
+  };
+  const uint32_t nt = std::max(1u, std::min({threads ? threads : std::thread::hardware_concurrency(), tasks, 64u}));
+  if (nt == 1) {
+    worker();
+  } else {
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < nt; ++t) {
+      pool.emplace_back(worker);
+    }
+    for (std::thread& th : pool) {
+      th.join();
+    }
+  }
+  return LDP_OK;
+}
+
 const char* ldp_pgen_last_error(const ldp_pgen* P) { return P ? P->err.c_str() : "null reader"; }
 
 void ldp_pgen_close(ldp_pgen* P) {

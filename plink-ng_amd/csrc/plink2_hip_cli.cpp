@@ -1424,6 +1424,10 @@ int main(int argc, char** argv) {
       }
       const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((1024ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
       std::vector<uint8_t> decoded, gather;
+      std::vector<uint8_t> founder_mask((static_cast<size_t>(raw_sample_ct) + 7) / 8, 0);
+      for (uint32_t sidx : founder_idx) {
+        founder_mask[sidx >> 3] |= static_cast<uint8_t>(1u << (sidx & 7));
+      }
       for (uint32_t k = 0; k < variant_ct;) {
         // a run of included variants that are consecutive in the file (chromosome 0 is stripped in table mode)
         const uint32_t raw_first = inc[k];
@@ -1443,14 +1447,10 @@ int main(int argc, char** argv) {
           src = decoded.data();
         }
         if (!all_founders) {
-          gather.assign(static_cast<size_t>(run) * out_rec, 0);
-          for (uint32_t q = 0; q < run; ++q) {
-            const uint8_t* in_row = src + static_cast<uint64_t>(q) * rec_bytes;
-            uint8_t* out_row = gather.data() + static_cast<uint64_t>(q) * out_rec;
-            for (uint32_t f = 0; f < founder_ct; ++f) {
-              const uint32_t sidx = founder_idx[f];
-              out_row[f >> 2] |= ((in_row[sidx >> 2] >> (2 * (sidx & 3))) & 3) << (2 * (f & 3));
-            }
+          // the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185)
+          gather.resize(static_cast<size_t>(run) * out_rec);
+          if (ldp_subset_samples(src, rec_bytes, run, raw_sample_ct, founder_mask.data(), gather.data(), out_rec, 0, 0)) {
+            die(12, "Error: founder subsetting failed.\n");
           }
           src = gather.data();
           stride = out_rec;
@@ -1967,7 +1967,6 @@ int main(int argc, char** argv) {
     const uint64_t in_rec = A.pairphase ? ldp_phased_row_bytes(2 * raw_sample_ct) : rec_bytes;
     const uint64_t in_phase_off = ldp_phased_phase_offset(2 * raw_sample_ct);
     const uint64_t out_rec = A.pairphase ? ldp_phased_row_bytes(2 * founder_ct) : ((static_cast<uint64_t>(founder_ct) + 3) / 4);
-    const uint64_t out_phase_off = ldp_phased_phase_offset(2 * founder_ct);
     const int load_encoding = A.pairphase ? (LDP_GENO_REF | LDP_GENO_PHASED) : encoding;
     const uint8_t* direct = A.pairphase ? nullptr : direct_rows;  // phased rows always come through the decoder
     std::vector<uint8_t> founder_mask((static_cast<size_t>(raw_sample_ct) + 7) / 8, 0);
@@ -2066,19 +2065,10 @@ int main(int argc, char** argv) {
         }
         if (!all_founders) {
           // gather the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185)
-          gather.assign(static_cast<size_t>(run) * out_rec, 0);
-          for (uint32_t w = 0; w < run; ++w) {
-            const uint8_t* in_row = src + static_cast<uint64_t>(w) * in_rec;
-            uint8_t* out_row = gather.data() + static_cast<uint64_t>(w) * out_rec;
-            for (uint32_t f = 0; f < founder_ct; ++f) {
-              out_row[f >> 2] |= static_cast<uint8_t>(code_at(in_row, founder_idx[f]) << (2 * (f & 3)));
-            }
-            if (A.pairphase) {  // CopyBitarrSubset of phaseinfo (plink2_ld.cc:2075)
-              for (uint32_t f = 0; f < founder_ct; ++f) {
-                const uint32_t sidx = founder_idx[f];
-                out_row[out_phase_off + (f >> 3)] |= static_cast<uint8_t>(((in_row[in_phase_off + (sidx >> 3)] >> (sidx & 7)) & 1) << (f & 7));
-              }
-            }
+          // (+ CopyBitarrSubset of phaseinfo under --indep-pairphase, plink2_ld.cc:2075), all host threads
+          gather.resize(static_cast<size_t>(run) * out_rec);
+          if (ldp_subset_samples(src, direct ? rec_bytes : in_rec, run, raw_sample_ct, founder_mask.data(), gather.data(), out_rec, A.pairphase ? 1 : 0, 0)) {
+            die(12, "\nError: founder subsetting failed.\n");
           }
           src = gather.data();
           stride = out_rec;

@@ -154,3 +154,28 @@ def test_multiallelic_track_against_vcf(pkg, tmp_path, m, n, seed, max_alt):
         glo, ghi = f.read_alleles(v, int(alt_ct[v]))
         assert np.array_equal(glo, lo[v]) and np.array_equal(ghi, hi[v]), v
     f.close()
+
+
+@pytest.mark.parametrize("raw_n,keep_rate,phased", [(1, 1.0, False), (5, 0.5, True), (63, 0.9, False), (64, 0.3, True), (129, 0.97, True),
+                                                     (1000, 0.99, False), (4097, 0.6, True), (257, 0.0, False)])
+def test_subset_samples_matches_numpy(pkg, raw_n, keep_rate, phased):
+    """ldp_subset_samples = CopyNyparrNonemptySubset (+ CopyBitarrSubset for phase bits) on row blocks"""
+    import ldtools as T
+    rng = np.random.default_rng(raw_n)
+    m = 37
+    codes = rng.integers(0, 4, size=(m, raw_n)).astype(np.uint8)
+    phase = rng.integers(0, 2, size=(m, raw_n)).astype(np.uint8)
+    keep = rng.random(raw_n) < keep_rate
+    if not keep.any():
+        keep[raw_n // 2] = True
+    packed = T.pack_2bit(codes).view(np.uint8).reshape(m, -1)
+    rows = pkg.pack_phased_rows(packed, phase, raw_n) if phased else np.ascontiguousarray(packed[:, :(raw_n + 3) // 4])
+    # an input stride with slack, like a caller's buffer
+    wide = np.full((m, rows.shape[1] + 5), 0xAB, dtype=np.uint8)
+    wide[:, :rows.shape[1]] = rows
+    for threads in (1, 0):
+        got = pkg.subset_samples(wide, raw_n, keep, phased=phased, threads=threads)
+        kept = int(keep.sum())
+        want_codes = T.pack_2bit(codes[:, keep]).view(np.uint8).reshape(m, -1)
+        want = pkg.pack_phased_rows(want_codes, phase[:, keep], kept) if phased else want_codes[:, :(kept + 3) // 4]
+        assert np.array_equal(got, want), (raw_n, phased, threads)
