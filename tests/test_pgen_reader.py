@@ -179,3 +179,31 @@ def test_subset_samples_matches_numpy(pkg, raw_n, keep_rate, phased):
         want_codes = T.pack_2bit(codes[:, keep]).view(np.uint8).reshape(m, -1)
         want = pkg.pack_phased_rows(want_codes, phase[:, keep], kept) if phased else want_codes[:, :(kept + 3) // 4]
         assert np.array_equal(got, want), (raw_n, phased, threads)
+
+
+def test_subset_samples_property(pkg):
+    """hypothesis: arbitrary sample counts / masks / strides against the numpy definition"""
+    from hypothesis import given, settings, strategies as st
+    import ldtools as T
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 300), st.integers(0, 2 ** 32 - 1), st.booleans(), st.integers(0, 9))
+    def check(raw_n, seed, phased, slack):
+        rng = np.random.default_rng(seed)
+        m = int(rng.integers(1, 6))
+        codes = rng.integers(0, 4, size=(m, raw_n)).astype(np.uint8)
+        phase = rng.integers(0, 2, size=(m, raw_n)).astype(np.uint8)
+        keep = rng.random(raw_n) < rng.random()
+        if not keep.any():
+            keep[int(rng.integers(0, raw_n))] = True
+        packed = T.pack_2bit(codes).view(np.uint8).reshape(m, -1)
+        rows = pkg.pack_phased_rows(packed, phase, raw_n) if phased else np.ascontiguousarray(packed[:, :(raw_n + 3) // 4])
+        wide = np.full((m, rows.shape[1] + slack), 0x5A, dtype=np.uint8)
+        wide[:, :rows.shape[1]] = rows
+        got = pkg.subset_samples(wide, raw_n, keep, phased=phased, threads=1)
+        kept = int(keep.sum())
+        want_codes = T.pack_2bit(codes[:, keep]).view(np.uint8).reshape(m, -1)
+        want = pkg.pack_phased_rows(want_codes, phase[:, keep], kept) if phased else want_codes[:, :(kept + 3) // 4]
+        assert np.array_equal(got, want)
+
+    check()
