@@ -1573,6 +1573,9 @@ int main(int argc, char** argv) {
               continue;
             }
             if (!A.r2_inter) {
+              if (big == 1) {
+                die(8, "Error: one variant has more passing partners than the filter buffer holds.\n");
+              }
               big_rows = std::max(1u, big / 2);  // more hits than the buffer holds: fewer second variants per call
               continue;
             }
