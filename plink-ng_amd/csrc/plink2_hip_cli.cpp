@@ -730,7 +730,8 @@ void load_samples(const Args& A, std::vector<uint8_t>* is_founder, std::vector<u
         die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
       }
       is_founder->push_back((t[2] == "0") && (t[3] == "0"));
-      sex->push_back((t[4] == "1") ? 1 : ((t[4] == "2") ? 2 : 0));
+      const std::string& v = t[4];  // CharToSex on a one-character token (plink2_psam.cc:505-509), for .fam as for .psam
+      sex->push_back((v == "1" || v == "M" || v == "m") ? 1 : ((v == "2" || v == "F" || v == "f") ? 2 : 0));
     } else {
       bool founder = true;
       if (pat_col >= 0 && mat_col >= 0) {
