@@ -614,7 +614,9 @@ int read_impl(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_rows, u
   // Tasks of kTaskVariants consecutive variants (never across a 65,536-variant block: LD-compressed records patch the
   // latest non-LD record of their own block).  A task walks back to that base record first, so tasks are independent
   // and a call that spans only one or two blocks still keeps every host thread busy.
-  constexpr uint32_t kTaskVariants = 256;
+  // ~2 MiB of decoded rows per task: 256 variants at 50,000 samples, 16 at 500,000 (a 256 MiB chunk of the caller is
+  // then still >100 tasks)
+  const uint32_t kTaskVariants = static_cast<uint32_t>(std::min<uint64_t>(256, std::max<uint64_t>(16, (2ull << 20) / std::max<uint64_t>(P->rec_bytes, 1))));
   struct Task {
     uint32_t first, end;
   };
