@@ -134,7 +134,7 @@ bool apply_difflist(Cursor& c, uint32_t sample_ct, uint8_t* row) {
 inline void invert_row(uint8_t* row, uint64_t nbytes) {
   for (uint64_t b = 0; b < nbytes; ++b) {
     const uint8_t g = row[b];
-    row[b] = static_cast<uint8_t>(g ^ ((~g << 1) & 0xaa));
+    row[b] = static_cast<uint8_t>(g ^ (((~static_cast<uint32_t>(g)) << 1) & 0xaau));
   }
 }
 
