@@ -1,0 +1,48 @@
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "ldprune_hip.h"
+int main(int argc, char** argv) {
+  for (int a = 1; a + 1 < argc; a += 2) {
+    ldp_pgen* pg = nullptr;
+    if (ldp_pgen_open(argv[a], 0, 0, &pg)) { printf("open failed %s\n", argv[a]); return 1; }
+    const uint32_t alt_max = atoi(argv[a + 1]);
+    uint32_t m, n; int mode, enc, multi;
+    ldp_pgen_info(pg, &m, &n, &mode, &enc, &multi);
+    const uint64_t rec = (n + 3) / 4;
+    std::vector<uint8_t> rows((size_t)m * rec);
+    for (uint32_t th : {1u, 0u}) {
+      int rc = ldp_pgen_read(pg, 0, m, rows.data(), rec, th);
+      if (rc) { printf("read rc %d\n", rc); }
+    }
+    // ragged single reads
+    std::vector<uint8_t> one(rec);
+    for (uint32_t v = 0; v < m; v += 7) ldp_pgen_read(pg, v, 1, one.data(), rec, 1);
+    const uint64_t prow = ldp_phased_row_bytes(2 * n);
+    std::vector<uint8_t> prows((size_t)m * prow);
+    std::vector<uint8_t> mask((n + 7) / 8, 0xff);
+    uint32_t bad = 0;
+    int rc = ldp_pgen_read_phased(pg, 0, m, prows.data(), prow, mask.data(), 0, &bad);
+    printf("%s: m=%u n=%u mode=%d multi=%d read_phased rc=%d bad=%u\n", argv[a], m, n, mode, multi, rc, bad);
+    for (uint32_t v = 0; v < m; v += 3) ldp_pgen_read_phased(pg, v, 1, prows.data(), prow, nullptr, 1, &bad);
+    std::vector<uint8_t> lo(n), hi(n), pp((n + 7) / 8), pi((n + 7) / 8);
+    for (uint32_t v = 0; v < m; ++v) {
+      for (uint32_t alts = 1; alts <= alt_max; ++alts) {
+        ldp_pgen_read_alleles_phased(pg, v, alts, lo.data(), hi.data(), pp.data(), pi.data());
+      }
+    }
+    // subset
+    std::vector<uint8_t> keep((n + 7) / 8, 0);
+    uint32_t kept = 0;
+    for (uint32_t s = 0; s < n; ++s) if (s % 3) { keep[s >> 3] |= 1u << (s & 7); ++kept; }
+    const uint64_t orow = ldp_phased_row_bytes(2 * kept);
+    std::vector<uint8_t> out((size_t)m * orow);
+    rc = ldp_subset_samples(prows.data(), prow, m, n, keep.data(), out.data(), orow, 1, 0);
+    std::vector<uint8_t> out2((size_t)m * ((kept + 3) / 4));
+    rc |= ldp_subset_samples(rows.data(), rec, m, n, keep.data(), out2.data(), (kept + 3) / 4, 0, 1);
+    printf("subset rc %d\n", rc);
+    ldp_pgen_close(pg);
+  }
+  return 0;
+}

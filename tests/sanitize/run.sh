@@ -1,0 +1,32 @@
+#!/bin/bash
+# AddressSanitizer + UndefinedBehaviorSanitizer over the host-side file reader (ldp_pgen.cpp: main track, phase track,
+# multiallelic + phase, sample subsetting) on every committed golden .pgen, and over plink2-hip's host-only paths
+# (argument parsing + planning with --dry-run, the .vcor number formatter, the zstd output stream).  No GPU involved.
+#   bash tests/sanitize/run.sh
+set -eu
+R=$(cd "$(dirname "$0")/../.." && pwd)
+T=$(mktemp -d)
+trap 'rm -rf "$T"' EXIT
+SAN="-std=c++17 -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined"
+g++ $SAN -I"$R/include" -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ "$R/tests/sanitize/reader_harness.cpp" "$R/tests/sanitize/geometry_stub.cpp" \
+    "$R/plink-ng_amd/csrc/ldp_pgen.cpp" -o "$T/reader" -lpthread
+G="$R/tests/golden/pgen"
+"$T/reader" "$G/varwidth_small.pgen" 1 "$G/phased_small.pgen" 1 "$G/phased_partial.pgen" 1 "$G/phased_multi.pgen" 4 "$G/phased_multi_partial.pgen" 4
+LDP_PGEN_NO_BMI2=1 "$T/reader" "$G/phased_partial.pgen" 1 "$G/phased_multi.pgen" 4 > /dev/null
+if [ -f "$R/plink-ng_amd/lib/libldprune_hip.so" ]; then
+  g++ $SAN -I/opt/rocm/include "$R/plink-ng_amd/csrc/plink2_hip_cli.cpp" -o "$T/cli" -L"$R/plink-ng_amd/lib" -lldprune_hip -Wl,-rpath,"$R/plink-ng_amd/lib" -lpthread -ldl
+  export ASAN_OPTIONS=detect_leaks=0
+  python3 - "$T" "$R" <<'PY'
+import sys, subprocess, numpy as np
+T, R = sys.argv[1], sys.argv[2]
+g = np.load(R + "/tests/golden/pgen/vcor_format_g6.npz")
+open(T + "/bits.txt", "w").write("".join("%016x\n" % int(b) for b in g["bits"]))
+out = subprocess.run([T + "/cli", "--debug-format-g6", T + "/bits.txt"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+assert out.returncode == 0 and out.stdout.split("\n")[:-1] == [str(t) for t in g["texts"]], out.stderr[-400:]
+open(T + "/in.txt", "w").write("line\n" * 200000)
+z = subprocess.run([T + "/cli", "--debug-zstd", T + "/in.txt", T + "/out.zst"], stderr=subprocess.PIPE, text=True)
+assert z.returncode == 0, z.stderr[-400:]
+print("plink2-hip host paths: clean")
+PY
+fi
+echo "sanitizers: clean"
