@@ -1,7 +1,7 @@
 #!/bin/bash
 # AddressSanitizer + UndefinedBehaviorSanitizer over the host-side file reader (ldp_pgen.cpp: main track, phase track,
 # multiallelic + phase, sample subsetting) on every committed golden .pgen, and over plink2-hip's host-only paths
-# (argument parsing + planning with --dry-run, the .vcor number formatter, the zstd output stream).  No GPU involved.
+# (the .vcor number formatter, the zstd output stream), and over the engine's host logic.  No GPU involved.
 #   bash tests/sanitize/run.sh
 set -eu
 R=$(cd "$(dirname "$0")/../.." && pwd)
@@ -28,5 +28,13 @@ z = subprocess.run([T + "/cli", "--debug-zstd", T + "/in.txt", T + "/out.zst"], 
 assert z.returncode == 0, z.stderr[-400:]
 print("plink2-hip host paths: clean")
 PY
+fi
+if command -v hipcc > /dev/null; then
+  # the engine's host logic (window planning in all three modes, sharding, greedy replay in both orders) on random
+  # variant tables; the HIP runtime is linked but never finds a device here
+  hipcc -std=c++17 -g -O1 --offload-arch=gfx950 -fsanitize=address,undefined -fno-omit-frame-pointer -fno-gpu-sanitize -I"$R/include" \
+      "$R/tests/sanitize/engine_host_harness.cpp" "$R/plink-ng_amd/csrc/ldp_engine.cpp" "$R/plink-ng_amd/csrc/ldp_kernels.hip" \
+      "$R/plink-ng_amd/csrc/ldp_synth.hip" "$R/plink-ng_amd/csrc/ldp_pgen.cpp" -o "$T/engine" -lpthread 2> "$T/engine_build.log" || { tail -5 "$T/engine_build.log"; exit 1; }
+  ASAN_OPTIONS=detect_leaks=0 "$T/engine"
 fi
 echo "sanitizers: clean"
