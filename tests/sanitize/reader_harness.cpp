@@ -6,7 +6,11 @@
 int main(int argc, char** argv) {
   for (int a = 1; a + 1 < argc; a += 2) {
     ldp_pgen* pg = nullptr;
-    if (ldp_pgen_open(argv[a], 0, 0, &pg)) { printf("open failed %s\n", argv[a]); return 1; }
+    if (ldp_pgen_open(argv[a], 0, 0, &pg)) {
+      printf("open failed %s: %s\n", argv[a], ldp_pgen_last_error(pg));
+      ldp_pgen_close(pg);  // (a failed open keeps the handle alive for the message)
+      return 1;
+    }
     const uint32_t alt_max = atoi(argv[a + 1]);
     uint32_t m, n; int mode, enc, multi;
     ldp_pgen_info(pg, &m, &n, &mode, &enc, &multi);
