@@ -97,6 +97,30 @@ def main():
         T.ref_import_vcf(os.path.join(tmp, "e.vcf"), os.path.join(tmp, "e"))
         shutil.copy(os.path.join(tmp, "e.pgen"), os.path.join(HERE, "pgen", "phased_multi_partial.pgen"))
         np.savez_compressed(os.path.join(HERE, "pgen", "phased_multi_partial.npz"), first=first4, second=second4, alt_ct=alt_ct4.astype(np.uint32), unphased=unph)
+        # ---- chrX / chrY / MT next to autosomes, males / females / unknown sex, a few non-founders: both prune commands
+        m5, n5 = 600, 110
+        raw5, pp5, pi5 = T.synth_phased(m5, n5, seed=77, missing_rate=0.03)
+        plan = [("1", 150), ("2", 100), ("X", 150), ("Y", 80), ("MT", 120)]
+        chroms5, bps5 = [], []
+        for name, cnt in plan:
+            chroms5 += [name] * cnt
+            bps5 += list((3000000 if name == "X" else 1000) + 173 * np.arange(cnt))
+        rng5 = np.random.default_rng(5)
+        sexes5 = rng5.choice([1, 2, 0], size=n5, p=[0.45, 0.45, 0.1])
+        parents5 = [("s0", "s1") if (s % 13 == 5) else ("0", "0") for s in range(n5)]
+        founders5 = np.array([p == ("0", "0") for p in parents5])
+        while T.ref_pairphase_chrx_is_unreliable(sexes5, founders5):
+            sexes5[np.flatnonzero(founders5 & (sexes5 != 1))[0]] = 1
+        ids5 = T.write_pgen_phased(os.path.join(tmp, "s"), raw5, pi5, chroms5, np.array(bps5), sexes=sexes5, parents=parents5)
+        out5 = dict(raw=raw5, phaseinfo=pi5, chroms=np.array(chroms5), bps=np.array(bps5, dtype=np.uint32), sexes=sexes5.astype(np.int8), founders=founders5)
+        grid5 = [(["40kb"], 0.3, 2), (["70", "9"], 0.3, 1), (["60", "1"], 0.6, 2)]
+        for mode in ("wise", "phase"):
+            for k, (win, r2, order) in enumerate(grid5):
+                kept, removed, log = T.ref_indep_pairwise(os.path.join(tmp, "s"), win, r2, order=order, mode=mode, threads=2)
+                out5["removed_%s_%d" % (mode, k)] = np.isin(np.array(ids5), np.array(removed))
+                print("sexed", mode, win, r2, order, [ln for ln in log.splitlines() if "variants removed" in ln][-1])
+        out5["grid"] = np.array(["%s|%r|%d" % (" ".join(w), r, o) for w, r, o in grid5])
+        np.savez_compressed(os.path.join(HERE, "pgen", "sexed_phased.npz"), **out5)
     finally:
         shutil.rmtree(tmp)
 

@@ -582,6 +582,56 @@ def pairphase_hap_rows_multiallelic(lo, hi, phasepresent, phaseinfo, alt_ct, qui
     return rows, mf, unphased
 
 
+def _haploid_style_freqs(codes_subset):
+    """diploid-style counts over the given samples: (ALT-is-major flags, major allele frequencies), a*(1/t) arithmetic"""
+    cnt = np.stack([(codes_subset == k).sum(1) for k in range(3)], 1).astype(np.int64)
+    refc = 2 * cnt[:, 0] + cnt[:, 1]
+    tot = refc + 2 * cnt[:, 2] + cnt[:, 1]
+    ref_freq = np.where(tot > 0, refc * (1.0 / np.maximum(tot, 1)), 0.5)
+    altmaj = ~(ref_freq >= 0.5)
+    return altmaj, np.where(altmaj, np.maximum(1.0 - ref_freq, 0.0), ref_freq)
+
+
+def sex_chromosome_rows(raw, founder, sex, kind, phaseinfo=None):
+    """What the reference's loaders hand to the scan on chrX / chrY / MT, as 2-bit codes of 'virtual samples' + the major
+    allele frequencies (LoadAlleleAndGenoCountsThread, plink2_data.cc:2421-2700):
+      kind "Y": non-female founders, hets -> missing;  "MT": every founder, hets -> missing  (haploid);
+      kind "X", --indep-pairwise (phaseinfo None): male founders (hets -> missing) followed by the non-male founders
+        TWICE (their statistics count double, plink2_ld.cc:890-901,1066-1082);
+      kind "X", --indep-pairphase (phaseinfo given): male founders one haplotype each (hets missing), non-male founders
+        two haplotypes split by phase (plink2_ld.cc:2060-2097); a haplotype h is the code 2h.
+    raw: REF-based codes (M, N); founder: bool (N,); sex: 1 male / 2 female / 0 unknown."""
+    founder = np.asarray(founder, dtype=bool)
+    sex = np.asarray(sex)
+    if kind in ("Y", "MT"):
+        smp = np.where(founder & ((sex != 2) if kind == "Y" else True))[0]
+        rs = raw[:, smp]
+        _, mf = _haploid_style_freqs(rs)
+        return np.where(rs == 1, 3, rs).astype(np.uint8), mf
+    males = np.where(founder & (sex == 1))[0]
+    non = np.where(founder & (sex != 1))[0]
+    rm, rn = raw[:, males], raw[:, non]
+    g = np.stack([(raw[:, founder] == k).sum(1) for k in range(3)], 1).astype(np.int64)
+    mm = np.stack([(rm == k).sum(1) for k in range(3)], 1).astype(np.int64)
+    alt = 4 * g[:, 2] + 2 * g[:, 1] - 2 * mm[:, 2] - mm[:, 1]  # plink2_data.cc:2641
+    tot = 2 * (2 * g.sum(1) - mm.sum(1))
+    ref_freq = np.where(tot > 0, (tot - alt) * (1.0 / np.maximum(tot, 1)), 0.5)
+    altmaj = ~(ref_freq >= 0.5)
+    mf = np.where(altmaj, np.maximum(1.0 - ref_freq, 0.0), ref_freq)
+    hm = np.where(rm == 1, 3, rm)
+    if phaseinfo is None:
+        return np.concatenate([hm, rn, rn], axis=1).astype(np.uint8), mf
+    pin = phaseinfo[:, non]
+    ha = np.where(rn == 3, 3, np.where((rn == 2) | ((rn == 1) & (pin == 1)), 2, 0))
+    hb = np.where(rn == 3, 3, np.where((rn == 2) | ((rn == 1) & (pin == 0)), 2, 0))
+    return np.concatenate([hm, np.stack([ha, hb], 2).reshape(raw.shape[0], -1)], axis=1).astype(np.uint8), mf
+
+
+def haploid_codes_to_hap_rows(codes):
+    """codes in {0, 2, 3} (haplotype h as 2h, 3 missing) -> hap_nm rows for oracle_indep_pairphase"""
+    return np.concatenate([pack_bits((codes == 2).astype(np.uint8)), pack_bits((codes != 3).astype(np.uint8))], axis=1)
+
+
 def ref_import_vcf(vcf_path, prefix, extra=()):
     """reference: --vcf -> variable-width .pgen (with the hardcall-phase track when the VCF has phased hets)"""
     cp = run_ref(["--vcf", os.path.basename(vcf_path), "--make-pgen", "--out", os.path.basename(prefix)] + list(extra), os.path.dirname(prefix))

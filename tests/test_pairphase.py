@@ -176,6 +176,39 @@ def test_multiallelic_phase_reader_partially_phased_file():
     pg.close()
 
 
+def test_oracle_sex_chromosome_layouts_match_reference_golden():
+    """chrX / chrY / MT as the reference's loaders shape them (ldtools.sex_chromosome_rows), through the oracle scan,
+    against prune lists recorded from the reference for BOTH --indep-pairwise and --indep-pairphase (CPU-only pin of
+    what the GPU tests check end to end)."""
+    z = np.load(os.path.join(GOLD, "sexed_phased.npz"))
+    raw, pi, chroms, bps = z["raw"], z["phaseinfo"], [str(c) for c in z["chroms"]], z["bps"]
+    founders, sexes = z["founders"], z["sexes"]
+    n_f = int(founders.sum())
+    for k, window, step, is_bp, r2, order in _grid(z):
+        for mode in ("wise", "phase"):
+            want = z["removed_%s_%d" % (mode, k)]
+            got = np.zeros(len(chroms), dtype=bool)
+            for name in dict.fromkeys(chroms):
+                vs = np.array([i for i, c in enumerate(chroms) if c == name])
+                zeros = np.zeros(len(vs), dtype=np.uint32)
+                if name in ("X", "Y", "MT"):
+                    codes, mf = T.sex_chromosome_rows(raw[vs], founders, sexes, name, phaseinfo=pi[vs] if (mode == "phase" and name == "X") else None)
+                    if mode == "phase":
+                        res, _ = T.oracle_indep_pairphase(T.haploid_codes_to_hap_rows(codes), codes.shape[1], zeros, bps[vs], mf, window, step, is_bp, r2, order)
+                    else:
+                        # the virtual-sample row is already major-allele-inverse up to orientation: r^2 does not care
+                        res, _ = T.oracle_indep_pairwise(T.pack_2bit(codes), codes.shape[1], zeros, bps[vs], mf, window, step, is_bp, r2, order)
+                elif mode == "phase":
+                    rows, mf, unphased, hap_ct = T.oracle_hapsplit(raw[vs][:, founders], (raw[vs][:, founders] == 1).astype(np.uint8), pi[vs][:, founders])
+                    assert not unphased.any()
+                    res, _ = T.oracle_indep_pairphase(rows, hap_ct, zeros, bps[vs], mf, window, step, is_bp, r2, order)
+                else:
+                    inv, mf, _ = T.oracle_prepare(raw[vs][:, founders])
+                    res, _ = T.oracle_indep_pairwise(inv, n_f, zeros, bps[vs], mf, window, step, is_bp, r2, order)
+                got[vs] = res
+            assert np.array_equal(got, want), (mode, k, np.flatnonzero(got != want)[:10])
+
+
 def test_portable_bit_deposit_path():
     """the phase decoder uses pext/pdep when the host has BMI2; LDP_PGEN_NO_BMI2 forces the portable loops"""
     import sys
