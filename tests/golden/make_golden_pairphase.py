@@ -85,6 +85,9 @@ def main():
             kept, removed, log = T.ref_indep_pairwise(os.path.join(tmp, "c"), win, r2, order=order, mode="phase")
             out3["removed_%d" % k] = np.isin(np.array(ids3), np.array(removed))
             print("phased_multi", win, r2, order, [ln for ln in log.splitlines() if "variants removed" in ln][-1])
+            # the unphased command on the same file: major-vs-rest collapse of multiallelic sites (Get1Multiallelic)
+            kept, removed, log = T.ref_indep_pairwise(os.path.join(tmp, "c"), win, r2, order=order)
+            out3["removed_wise_%d" % k] = np.isin(np.array(ids3), np.array(removed))
         out3["grid"] = np.array(["%s|%r|%d" % (" ".join(w), r, o) for w, r, o in GRID])
         shutil.copy(os.path.join(tmp, "c.pgen"), os.path.join(HERE, "pgen", "phased_multi.pgen"))
         np.savez_compressed(os.path.join(HERE, "pgen", "phased_multi.npz"), **out3)

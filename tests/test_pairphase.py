@@ -176,6 +176,26 @@ def test_multiallelic_phase_reader_partially_phased_file():
     pg.close()
 
 
+def test_oracle_multiallelic_collapse_pairwise_matches_reference_golden():
+    """--indep-pairwise on multiallelic sites: major allele by GetMajIdxMulti, genotype = copies of non-major alleles
+    (PgrGetInv1 -> Get1Multiallelic), CPU-only against lists recorded from the reference"""
+    pkg = ge.load_package()
+    z, pg, lo, hi, pp, pi = _multi_arrays(pkg)
+    pg.close()
+    m, n = lo.shape
+    codes = np.zeros((m, n), dtype=np.uint8)
+    mf = np.zeros(m)
+    for v in range(m):
+        k = int(z["alt_ct"][v]) + 1
+        nm = lo[v] != 255
+        cnt = [int((lo[v][nm] == a).sum() + (hi[v][nm] == a).sum()) for a in range(k)]
+        maj, mf[v] = T.major_allele_multi(cnt)
+        codes[v] = np.where(nm, (lo[v] != maj).astype(np.uint8) + (hi[v] != maj).astype(np.uint8), 3)
+    for k, window, step, is_bp, r2, order in _grid(z):
+        got, _ = T.oracle_indep_pairwise(T.pack_2bit(codes), n, _chr_idx(z), z["bps"], mf, window, step, is_bp, r2, order)
+        assert np.array_equal(got, z["removed_wise_%d" % k]), (k, window, r2, order)
+
+
 def test_oracle_sex_chromosome_layouts_match_reference_golden():
     """chrX / chrY / MT as the reference's loaders shape them (ldtools.sex_chromosome_rows), through the oracle scan,
     against prune lists recorded from the reference for BOTH --indep-pairwise and --indep-pairphase (CPU-only pin of
