@@ -124,6 +124,24 @@ def main():
                 print("sexed", mode, win, r2, order, [ln for ln in log.splitlines() if "variants removed" in ln][-1])
         out5["grid"] = np.array(["%s|%r|%d" % (" ".join(w), r, o) for w, r, o in grid5])
         np.savez_compressed(os.path.join(HERE, "pgen", "sexed_phased.npz"), **out5)
+        # ---- --indep-preferred (plink2_ld.cc:916-918: listed variants get major frequency - 1, so they win tie-breaks)
+        m6, n6 = 500, 140
+        raw6 = T.synth_raw_codes(m6, n6, seed=66, missing_rate=0.02)
+        chroms6 = ["1"] * 300 + ["2"] * 200
+        bps6 = np.concatenate([1000 + 120 * np.arange(300), 1000 + 120 * np.arange(200)]).astype(np.uint32)
+        ids6 = T.write_pgen_fixed(os.path.join(tmp, "f"), raw6, chroms6, bps6)
+        pref6 = np.random.default_rng(6).random(m6) < 0.3
+        open(os.path.join(tmp, "pref.txt"), "w").write("\n".join(i for i, p in zip(ids6, pref6) if p) + "\n")
+        out6 = dict(raw=raw6, chroms=np.array([int(c) for c in chroms6], dtype=np.uint32), bps=bps6, preferred=pref6)
+        grid6 = [(["50", "5"], 0.2, 2), (["50", "5"], 0.2, 1), (["20kb"], 0.5, 2)]
+        for k, (win, r2, order) in enumerate(grid6):
+            kept, removed, log = T.ref_indep_pairwise(os.path.join(tmp, "f"), win, r2, order=order, extra=["--indep-preferred", "pref.txt"])
+            out6["removed_%d" % k] = np.isin(np.array(ids6), np.array(removed))
+            kept0, removed0, _ = T.ref_indep_pairwise(os.path.join(tmp, "f"), win, r2, order=order)
+            out6["removed_plain_%d" % k] = np.isin(np.array(ids6), np.array(removed0))
+            print("preferred", win, r2, order, int(out6["removed_%d" % k].sum()), "vs plain", int(out6["removed_plain_%d" % k].sum()))
+        out6["grid"] = np.array(["%s|%r|%d" % (" ".join(w), r, o) for w, r, o in grid6])
+        np.savez_compressed(os.path.join(HERE, "pgen", "preferred.npz"), **out6)
     finally:
         shutil.rmtree(tmp)
 

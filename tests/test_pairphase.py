@@ -196,6 +196,20 @@ def test_oracle_multiallelic_collapse_pairwise_matches_reference_golden():
         assert np.array_equal(got, z["removed_wise_%d" % k]), (k, window, r2, order)
 
 
+def test_oracle_indep_preferred_matches_reference_golden():
+    """--indep-preferred: listed variants enter the scan with (major frequency - 1) (plink2_ld.cc:916-918)"""
+    z = np.load(os.path.join(GOLD, "preferred.npz"))
+    raw = z["raw"]
+    inv, mf, _ = T.oracle_prepare(raw)
+    differs = False
+    for k, window, step, is_bp, r2, order in _grid(z):
+        got, _ = T.oracle_indep_pairwise(inv, raw.shape[1], _chr_idx(z), z["bps"], mf - z["preferred"].astype(np.float64), window, step, is_bp, r2, order)
+        assert np.array_equal(got, z["removed_%d" % k]), (k, window, r2, order)
+        assert not (got & z["preferred"] & ~z["removed_plain_%d" % k]).all()
+        differs |= not np.array_equal(z["removed_%d" % k], z["removed_plain_%d" % k])
+    assert differs  # (the list changed the outcome, so the test exercises something)
+
+
 def test_oracle_sex_chromosome_layouts_match_reference_golden():
     """chrX / chrY / MT as the reference's loaders shape them (ldtools.sex_chromosome_rows), through the oracle scan,
     against prune lists recorded from the reference for BOTH --indep-pairwise and --indep-pairphase (CPU-only pin of
