@@ -142,6 +142,26 @@ def main():
             print("preferred", win, r2, order, int(out6["removed_%d" % k].sum()), "vs plain", int(out6["removed_plain_%d" % k].sum()))
         out6["grid"] = np.array(["%s|%r|%d" % (" ".join(w), r, o) for w, r, o in grid6])
         np.savez_compressed(os.path.join(HERE, "pgen", "preferred.npz"), **out6)
+        # ---- the windowed --r2-unphased table's pair set (UpdateVcorWindow, plink2_ld.cc:10984-11023) with no r^2 filter
+        m7, n7 = 400, 90
+        raw7 = T.synth_raw_codes(m7, n7, seed=88, missing_rate=0.02)
+        raw7[17] = 0   # monomorphic: its pairs are NaN and never written
+        rng7 = np.random.default_rng(8)
+        chroms7 = ["1"] * 220 + ["5"] * 1 + ["9"] * 179
+        bps7 = np.concatenate([np.sort(rng7.integers(1, 40000, 220)), [7], np.sort(rng7.integers(1, 3000000, 179))]).astype(np.uint32)
+        ids7 = T.write_pgen_fixed(os.path.join(tmp, "w"), raw7, chroms7, bps7)
+        out7 = dict(raw=raw7, chroms=np.array([int(c) for c in chroms7], dtype=np.uint32), bps=bps7)
+        settings = [("5", None), ("0.4", "3"), ("1000", "12"), ("30", None)]
+        for k, (kb, cnt) in enumerate(settings):
+            args = ["--pfile", "w", "--r2-unphased", "--ld-window-kb", kb, "--ld-window-r2", "0", "--out", "w%d" % k] + (["--ld-window", cnt] if cnt else [])
+            cp = T.run_ref(args, tmp)
+            assert cp.returncode == 0, cp.stdout
+            idx = {v: i for i, v in enumerate(ids7)}
+            pairs = [(idx[t[2]], idx[t[5]]) for t in (ln.split("\t") for ln in open(os.path.join(tmp, "w%d.vcor" % k)).read().splitlines()[1:])]
+            out7["pairs_%d" % k] = np.array(pairs, dtype=np.uint32).reshape(-1, 2)
+            print("vcor window", kb, cnt, len(pairs), "pairs")
+        out7["settings"] = np.array(["%s|%s" % (kb, cnt or "") for kb, cnt in settings])
+        np.savez_compressed(os.path.join(HERE, "pgen", "vcor_windows.npz"), **out7)
     finally:
         shutil.rmtree(tmp)
 

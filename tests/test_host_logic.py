@@ -3,6 +3,7 @@ sharding and the greedy replay.  The pair predicate bits are produced here by th
 through ldp_debug_replay_pairs(), so no GPU is needed; the result must equal the oracle's own
 end-to-end --indep-pairwise."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -188,3 +189,32 @@ def test_no_cpu_fallback_without_gpu(pkg):
         e.run()
     assert ei.value.code == pkg.LDP_ERR_GPU
     e.close()
+
+
+def test_vcor_window_plan_matches_reference_pair_set(pkg):
+    """The windowed --r2-unphased plan (ldp_set_variants_vcor; UpdateVcorWindow, plink2_ld.cc:10984-11023) against the
+    pair sets of .vcor tables the reference wrote with --ld-window-r2 0: planned band = written pairs + the pairs whose
+    r^2 is undefined (NaN never passes the filter).  Host logic only: no GPU."""
+    import ldtools as T
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pgen", "vcor_windows.npz"))
+    raw = z["raw"]
+    m, n = raw.shape
+    chr_idx = np.unique(z["chroms"], return_inverse=True)[1].astype(np.uint32)
+    inv, mf, _ = T.oracle_prepare(raw)
+    hom, r2h, vaggs = T.oracle_split(inv, n)
+    for k, s in enumerate(z["settings"]):
+        kb, cnt = str(s).split("|")
+        bp_radius = int(float(kb) * 1000 * (1 + T.K_SMALL_EPSILON))
+        var_radius = (int(cnt) - 1) if cnt else 0x7fffffff
+        eng = pkg.LdPruneEngine(n, 2, 1, False, 0.5, device=-1)
+        eng.set_variants_vcor(chr_idx, z["bps"], bp_radius, var_radius)
+        lo, cand = eng.band()
+        eng.close()
+        planned = {(i, j) for j in range(m) for i in range(int(lo[j]), j)}
+        assert len(planned) == cand
+        written = {(int(a), int(b)) for a, b in z["pairs_%d" % k]}
+        assert written <= planned, (k, sorted(written - planned)[:5])
+        for i, j in planned - written:
+            st = T.oracle_pair_stats(hom, r2h, vaggs, n, i, j)
+            cov, v1, v2 = T.oracle_r2(st)
+            assert (st.nm == 0) or (v1 * v2 == 0.0), (k, i, j)  # ComputeR2: undefined -> NaN -> not written
