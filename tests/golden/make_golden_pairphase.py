@@ -159,6 +159,7 @@ def main():
             idx = {v: i for i, v in enumerate(ids7)}
             pairs = [(idx[t[2]], idx[t[5]]) for t in (ln.split("\t") for ln in open(os.path.join(tmp, "w%d.vcor" % k)).read().splitlines()[1:])]
             out7["pairs_%d" % k] = np.array(pairs, dtype=np.uint32).reshape(-1, 2)
+            out7["r2_text_%d" % k] = np.array([ln.split("\t")[6] for ln in open(os.path.join(tmp, "w%d.vcor" % k)).read().splitlines()[1:]])
             print("vcor window", kb, cnt, len(pairs), "pairs")
         out7["settings"] = np.array(["%s|%s" % (kb, cnt or "") for kb, cnt in settings])
         np.savez_compressed(os.path.join(HERE, "pgen", "vcor_windows.npz"), **out7)

@@ -300,3 +300,27 @@ def test_zstd_output_writer_roundtrip(cli, tmp_path):
     assert os.path.getsize(str(tmp_path / "out.zst")) < len(text) // 2
     back = subprocess.run([T.REF_BIN, "--zst-decompress", "out.zst"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
     assert back.returncode == 0 and back.stdout.decode() == text
+
+
+def test_vcor_values_oracle_plus_formatter_reproduce_reference_text(cli, tmp_path):
+    """Every r^2 the reference printed in a windowed .vcor table = the oracle's exact double (ComputeR2 arithmetic)
+    through plink2-hip's number formatter.  CPU only: pins value + text without the GPU in the loop."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "pgen", "vcor_windows.npz"))
+    raw = z["raw"]
+    n = raw.shape[1]
+    inv, mf, _ = T.oracle_prepare(raw)
+    hom, r2h, vaggs = T.oracle_split(inv, n)
+    bits, want = [], []
+    for k in range(len(z["settings"])):
+        for (i, j), text in zip(z["pairs_%d" % k], z["r2_text_%d" % k]):
+            cov, v1, v2 = T.oracle_r2(T.oracle_pair_stats(hom, r2h, vaggs, n, int(i), int(j)))
+            bits.append(np.float64(cov * cov / (v1 * v2)).view(np.uint64))
+            want.append(str(text))
+    path = tmp_path / "bits.txt"
+    open(path, "w").write("".join("%016x\n" % int(b) for b in bits))
+    out = subprocess.run([cli, "--debug-format-g6", str(path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout
+    got = out.stdout.split("\n")[:-1]
+    assert len(got) == len(want) > 30000
+    bad = [(w, g) for w, g in zip(want, got) if w != g]
+    assert not bad, bad[:5]
