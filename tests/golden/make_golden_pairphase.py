@@ -161,6 +161,14 @@ def main():
             out7["pairs_%d" % k] = np.array(pairs, dtype=np.uint32).reshape(-1, 2)
             out7["r2_text_%d" % k] = np.array([ln.split("\t")[6] for ln in open(os.path.join(tmp, "w%d.vcor" % k)).read().splitlines()[1:]])
             print("vcor window", kb, cnt, len(pairs), "pairs")
+        # inter-chr with the default --ld-window-r2 (0.2 * (1 - 2^-44)): all pairs, A-major, chromosome 0 would be kept
+        cp = T.run_ref(["--pfile", "w", "--r2-unphased", "inter-chr", "--out", "wi"], tmp)
+        assert cp.returncode == 0, cp.stdout
+        lines = [ln.split("\t") for ln in open(os.path.join(tmp, "wi.vcor")).read().splitlines()[1:]]
+        idx = {v: i for i, v in enumerate(ids7)}
+        out7["inter_pairs"] = np.array([(idx[t[2]], idx[t[5]]) for t in lines], dtype=np.uint32).reshape(-1, 2)
+        out7["inter_text"] = np.array([t[6] for t in lines])
+        print("inter-chr default filter:", len(lines), "pairs")
         out7["settings"] = np.array(["%s|%s" % (kb, cnt or "") for kb, cnt in settings])
         np.savez_compressed(os.path.join(HERE, "pgen", "vcor_windows.npz"), **out7)
     finally:

@@ -324,3 +324,30 @@ def test_vcor_values_oracle_plus_formatter_reproduce_reference_text(cli, tmp_pat
     assert len(got) == len(want) > 30000
     bad = [(w, g) for w, g in zip(want, got) if w != g]
     assert not bad, bad[:5]
+
+
+def test_inter_chr_filter_and_order_from_oracle_values(cli, tmp_path):
+    """--r2-unphased inter-chr with the default filter: the pairs the reference wrote, in its order, are exactly the
+    pairs A < B (any chromosomes) whose oracle r^2 is >= 0.2 * (1 - 2^-44), A-major; texts through the formatter."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "pgen", "vcor_windows.npz"))
+    raw = z["raw"]
+    m, n = raw.shape
+    inv, mf, _ = T.oracle_prepare(raw)
+    hom, r2h, vaggs = T.oracle_split(inv, n)
+    thr = 0.2 * (1 - T.K_SMALL_EPSILON)
+    pairs, bits = [], []
+    for i in range(m):
+        for j in range(i + 1, m):
+            st = T.oracle_pair_stats(hom, r2h, vaggs, n, i, j)
+            cov, v1, v2 = T.oracle_r2(st)
+            if st.nm == 0 or v1 * v2 == 0.0:
+                continue
+            r2 = cov * cov / (v1 * v2)
+            if r2 >= thr:
+                pairs.append((i, j))
+                bits.append(np.float64(r2).view(np.uint64))
+    assert pairs == [(int(a), int(b)) for a, b in z["inter_pairs"]]
+    path = tmp_path / "bits.txt"
+    open(path, "w").write("".join("%016x\n" % int(b) for b in bits))
+    out = subprocess.run([cli, "--debug-format-g6", str(path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert out.stdout.split("\n")[:-1] == [str(t) for t in z["inter_text"]]
