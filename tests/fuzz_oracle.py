@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """CPU-only randomised check of the test ORACLE (oracle/ldoracle.c) against the reference binary (oracle/_ref/plink2):
 --indep-pairwise on .bed / fixed-width .pgen and --indep-pairphase on phased variable-width .pgen, random shapes,
+chrX/chrY/MT sample layouts with random sexes and non-founders (ldtools.sex_chromosome_rows),
 windows, thresholds, scan orders, missing rates.  No GPU involved: this pins the checker the GPU parity tests use.
     python tests/fuzz_oracle.py [--cases 100] [--seed 1]"""
 import argparse
@@ -15,7 +16,71 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 import ldtools as T  # noqa: E402
 
 
+def sexed_case(rng, idx, tmp):
+    """autosomes + chrX + chrY + MT, random sexes and non-founders, both prune commands on one phased fileset"""
+    n = int(rng.choice([60, 97, 130]))
+    m = int(rng.integers(120, 400))
+    raw, pp, pi = T.synth_phased(m, n, int(rng.integers(1, 1 << 30)), missing_rate=float(rng.choice([0.0, 0.03])), redraw=float(rng.choice([0.05, 0.2])))
+    names = ["1", "3", "X", "Y", "MT"]
+    cuts = np.sort(rng.integers(0, m, size=len(names) - 1))
+    sizes = np.diff(np.concatenate([[0], cuts, [m]]))
+    chroms, bps = [], []
+    for name, cnt in zip(names, sizes):
+        chroms += [name] * int(cnt)
+        bps += list((3000000 if name == "X" else 1) + np.sort(rng.integers(1, 60000, size=int(cnt))))
+    bps = np.array(bps, dtype=np.uint32)
+    sexes = rng.choice([0, 1, 2], size=n, p=[0.1, 0.45, 0.45])
+    parents = [("s0", "s1") if (s > 1 and rng.random() < 0.06) else ("0", "0") for s in range(n)]
+    founders = np.array([p == ("0", "0") for p in parents])
+    while T.ref_pairphase_chrx_is_unreliable(sexes, founders):
+        sexes[np.flatnonzero(founders & (sexes != 1))[0]] = 1
+    if rng.random() < 0.5:
+        kb = int(rng.choice([1, 3, 10]))
+        wargs, window, step, is_bp = ["%dkb" % kb], int(kb * 1000 * (1 + T.K_SMALL_EPSILON)), 1, True
+    else:
+        window = int(rng.integers(2, 120))
+        step = int(rng.integers(1, max(2, window)))
+        wargs, is_bp = [str(window), str(step)], False
+    r2 = float(rng.choice([0.1, 0.2, 0.5, 0.8]))
+    order = int(rng.integers(1, 3))
+    mode = "phase" if rng.random() < 0.5 else "wise"
+    d = os.path.join(tmp, "c%d" % idx)
+    os.makedirs(d)
+    ids = T.write_pgen_phased(os.path.join(d, "d"), raw, pi, chroms, bps, sexes=sexes, parents=parents)
+    kept, removed, _ = T.ref_indep_pairwise(os.path.join(d, "d"), wargs, r2, order=order, mode=mode, threads=2)
+    want = np.isin(np.array(ids), np.array(removed))
+    got = np.zeros(m, dtype=bool)
+    n_f = int(founders.sum())
+    for name in dict.fromkeys(chroms):
+        vs = np.array([i for i, c in enumerate(chroms) if c == name])
+        if not len(vs):
+            continue
+        zeros = np.zeros(len(vs), dtype=np.uint32)
+        if name in ("X", "Y", "MT"):
+            codes, mf = T.sex_chromosome_rows(raw[vs], founders, sexes, name, phaseinfo=pi[vs] if (mode == "phase" and name == "X") else None)
+            if codes.shape[1] < 2:
+                return True, "case %d: too few usable founders on chr%s (skipped)" % (idx, name)
+            if mode == "phase":
+                res, _ = T.oracle_indep_pairphase(T.haploid_codes_to_hap_rows(codes), codes.shape[1], zeros, bps[vs], mf, window, step, is_bp, r2, order)
+            else:
+                res, _ = T.oracle_indep_pairwise(T.pack_2bit(codes), codes.shape[1], zeros, bps[vs], mf, window, step, is_bp, r2, order)
+        elif mode == "phase":
+            rows, mf, unphased, hap_ct = T.oracle_hapsplit(raw[vs][:, founders], (raw[vs][:, founders] == 1).astype(np.uint8), pi[vs][:, founders])
+            res, _ = T.oracle_indep_pairphase(rows, hap_ct, zeros, bps[vs], mf, window, step, is_bp, r2, order)
+        else:
+            inv, mf, _ = T.oracle_prepare(raw[vs][:, founders])
+            res, _ = T.oracle_indep_pairwise(inv, n_f, zeros, bps[vs], mf, window, step, is_bp, r2, order)
+        got[vs] = res
+    desc = "case %d: sexed pair%s n=%d m=%d %s r2=%g order=%d removed=%d" % (idx, mode, n, m, " ".join(wargs), r2, order, int(want.sum()))
+    if not np.array_equal(got, want):
+        bad = np.flatnonzero(got != want)
+        desc += " MISMATCH on " + ",".join(sorted({chroms[b] for b in bad}))
+    return bool(np.array_equal(got, want)), desc
+
+
 def one_case(rng, idx, tmp):
+    if rng.random() < 0.3:
+        return sexed_case(rng, idx, tmp)
     n = int(rng.choice([50, 64, 97, 130, 257, 513]))
     m = int(rng.integers(60, 400))
     miss = float(rng.choice([0.0, 0.0, 0.01, 0.05, 0.2]))
