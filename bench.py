@@ -230,12 +230,13 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    kernel_ms, prep_ms, replay_ms = [], [], []
+    kernel_ms, prep_ms, replay_ms, mfma_ms = [], [], [], []
     removed = None
     for _ in range(args.steps):
         removed = step()
         c = eng.counters()
-        kernel_ms.append(c["ms_pair_general"] if args.missing_rate > 0 else c["ms_pair_fast"])
+        kernel_ms.append(c["ms_pair_kernel"])
+        mfma_ms.append(c["ms_pair_mfma"])
         prep_ms.append(c["ms_prepare"])
         replay_ms.append(c["ms_replay"])
     sync()
@@ -304,7 +305,8 @@ def main():
                                  "ceiling of that op mix",
                          "valu_lane_ops_per_pair_dword": ops_per_pair_dword, "valu_lane_ops_per_s": (executed_lane_ops / (kms * 1e-3)) if kms > 0 else 0.0, "valu_mix_peak": valu_mix_peak,
                          "valu_frac": (executed_lane_ops / (kms * 1e-3)) / valu_mix_peak if kms > 0 else 0.0},
-            "stage_ms": {"prepare_kernel": float(np.mean(prep_ms)), "pair_kernel": kms, "host_replay": float(np.mean(replay_ms))},
+            "stage_ms": {"prepare_kernel": float(np.mean(prep_ms)), "pair_kernel": kms, "pair_mfma_kernel": float(np.mean(mfma_ms)),
+                         "host_replay": float(np.mean(replay_ms))},
             "early_termination": {"tile_unit_chunks": ctr["tile_unit_chunks"], "skipped_unit_chunks": ctr["early_exit_unit_chunks"],
                                   "skipped_frac": (ctr["early_exit_unit_chunks"] / ctr["tile_unit_chunks"]) if ctr["tile_unit_chunks"] else 0.0},
         }

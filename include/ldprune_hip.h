@@ -121,6 +121,8 @@ typedef struct {
   uint32_t window_max;       /* as LdPruneSubcontigSplitAll reports it */
   uint64_t tile_unit_chunks;       /* pair-kernel work of the last run in (8-distance unit x k-chunk) steps ... */
   uint64_t early_exit_unit_chunks; /* ... and how many of them early termination skipped (provably sub-threshold tiles) */
+  double ms_pair_mfma;             /* device time of pair_mfma_kernel (matrix-pipe tiles, complete data) in the last run */
+  uint64_t mfma_block_products;    /* 32 x 32 block products of the matrix-pipe plan (0 when that path is off) */
 } ldp_counters;
 
 /* ---- lifecycle ---- */
@@ -184,6 +186,11 @@ int ldp_pair_stats(ldp_engine* e, uint32_t n_pairs, const uint32_t* first, const
  * touched: this is how the host logic is tested on a CPU-only machine. */
 int ldp_debug_set_variant_recs(ldp_engine* e, const ldp_variant_rec* recs);
 int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first, const uint32_t* second, uint64_t* removed);
+/* Host-only view of the matrix-pipe work plan (csrc/ldp_device.h: MfmaWG) in the engine's shard-local variant
+ * indices, for the CPU test that every candidate pair is owned by exactly one 32 x 32 block product.  Per workgroup
+ * 63 words: n_rb, j_lo, j_hi, rb[16], then per wave jv, vv, jend, prod_mask, slot[7].  lo_local (optional, *local_ct
+ * entries) receives the window starts in the same index space.  words == NULL only counts. */
+int ldp_debug_mfma_plan(const ldp_engine* e, uint32_t* wg_count, uint32_t* words, uint64_t capacity_words, uint32_t* lo_local, uint32_t* local_ct);
 
 /* ---- --r2-unphased matrices (Vcor / VcorMatrix, plink2_ld.cc:12050,9766; ComputeR2 :6654-6682) ---- */
 /* All-pairs plan over variant_ct variants (inter-chromosomal pairs included, as the matrix shapes of

@@ -63,7 +63,8 @@ class ldp_counters(ctypes.Structure):
                 ("ms_replay", ctypes.c_double), ("ms_run_total", ctypes.c_double),
                 ("pair_kernel_launches", ctypes.c_uint32), ("subcontig_ct", ctypes.c_uint32),
                 ("owned_subcontig_ct", ctypes.c_uint32), ("window_max", ctypes.c_uint32),
-                ("tile_unit_chunks", ctypes.c_uint64), ("early_exit_unit_chunks", ctypes.c_uint64)]
+                ("tile_unit_chunks", ctypes.c_uint64), ("early_exit_unit_chunks", ctypes.c_uint64),
+                ("ms_pair_mfma", ctypes.c_double), ("mfma_block_products", ctypes.c_uint64)]
 
     def asdict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
@@ -78,7 +79,7 @@ VARIANT_REC_DTYPE = np.dtype([("nm_ct", "<u4"), ("sum", "<i4"), ("ssq", "<u4"), 
 CABI_SYMBOLS = [
     "ldp_create", "ldp_destroy", "ldp_last_error", "ldp_device_count", "ldp_set_variants", "ldp_get_subcontigs",
     "ldp_set_shard", "ldp_get_band", "ldp_load_genotypes", "ldp_set_maj_freqs", "ldp_set_preferred", "ldp_run",
-    "ldp_run_with_stats", "ldp_pair_stats", "ldp_debug_set_variant_recs", "ldp_debug_replay_pairs",
+    "ldp_run_with_stats", "ldp_pair_stats", "ldp_debug_set_variant_recs", "ldp_debug_replay_pairs", "ldp_debug_mfma_plan",
     "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
     "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_r2_unphased_hits", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
@@ -87,7 +88,7 @@ CABI_SYMBOLS = [
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_synth.hip", "ldp_engine.cpp", "ldp_pgen.cpp")]
+    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_pair_mfma.hip", "ldp_synth.hip", "ldp_engine.cpp", "ldp_pgen.cpp")]
 
 
 def _stale(target, deps):
@@ -100,7 +101,7 @@ def _stale(target, deps):
 def build_library(force=False, verbose=False):
     """Compile the HIP kernels + host runtime into lib/libldprune_hip.so for gfx950 (hipcc cross-compiles
     without a GPU).  In-tree so the .so travels with the repo snapshot."""
-    deps = _sources() + [os.path.join(CSRC, "ldp_device.h"), os.path.join(REPO, "include", "ldprune_hip.h")]
+    deps = _sources() + [os.path.join(CSRC, "ldp_device.h"), os.path.join(CSRC, "ldp_pair_device.h"), os.path.join(REPO, "include", "ldprune_hip.h")]
     if force or _stale(LIB_PATH, deps):
         os.makedirs(LIB_DIR, exist_ok=True)
         cmd = ["hipcc"] + HIPCC_FLAGS + ["-shared", "-o", LIB_PATH] + _sources()
@@ -163,6 +164,7 @@ def lib():
     L.ldp_pair_stats.argtypes = [vp, ctypes.c_uint32, u32p, u32p, vp]
     L.ldp_debug_set_variant_recs.argtypes = [vp, vp]
     L.ldp_debug_replay_pairs.argtypes = [vp, ctypes.c_uint64, u32p, u32p, u64p]
+    L.ldp_debug_mfma_plan.argtypes = [vp, u32p, u32p, ctypes.c_uint64, u32p, u32p]
     L.ldp_get_variant_recs.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp]
     L.ldp_get_maj_freqs.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, f64p]
     L.ldp_get_planes.argtypes = [vp, ctypes.c_uint32, u32p, u32p]
@@ -519,6 +521,17 @@ class LdPruneEngine:
         self._ck(self._L.ldp_debug_replay_pairs(self._h, len(first), _ptr(first, ctypes.c_uint32), _ptr(second, ctypes.c_uint32),
                                                 _ptr(bm, ctypes.c_uint64)))
         return self._to_bool(bm)
+
+    def debug_mfma_plan(self):
+        """(workgroups as an (n, 63) uint32 array, lo in shard-local indices) -- see ldp_debug_mfma_plan."""
+        n = ctypes.c_uint32(0)
+        lc = ctypes.c_uint32(0)
+        self._ck(self._L.ldp_debug_mfma_plan(self._h, ctypes.byref(n), None, 0, None, ctypes.byref(lc)))
+        words = np.zeros((max(n.value, 1), 63), dtype=np.uint32)
+        lo = np.zeros(max(lc.value, 1), dtype=np.uint32)
+        self._ck(self._L.ldp_debug_mfma_plan(self._h, ctypes.byref(n), _ptr(words, ctypes.c_uint32), words.size, _ptr(lo, ctypes.c_uint32),
+                                             ctypes.byref(lc)))
+        return words[:n.value], lo[:lc.value]
 
     # ---- inspection
     def variant_recs(self, first=0, n=None):

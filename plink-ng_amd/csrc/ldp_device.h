@@ -64,6 +64,37 @@ struct cp_gen_slot {
   uint32_t pad;
 };
 
+// ---- matrix-pipe pair tiles (ldp_pair_mfma.hip) -------------------------------------------------------------
+// The complete-data dot product sum x_i x_j, x in {-1, 0, +1}, is an integer matrix product over the samples.  It runs
+// on the MFMA pipe as FP4 (E2M1: +-1 and 0 are exact) with f32 accumulation, which is integer-exact below 2^24.
+// Work is cut into row-blocks of kMfBlock consecutive variants, aligned to the subcontig start.  A WAVE owns one
+// "parallelogram": second-variant blocks J0, J1 = J0 + 32 and first-variant blocks V0..V4 (consecutive), products
+//   (J0, V0) (J0, V1) (J0, V2) (J0, V3)   and   (J1, V1) (J1, V2) (J1, V3) (J1, V4),
+// i.e. both J blocks against the same four block distances; on the diagonal V3 = J0 and V4 = J1.  A workgroup of four
+// waves stages the union of its waves' row-blocks (<= kMfMaxRowBlocks) through LDS, kMfStageSamples samples at a time.
+constexpr int kMfBlock = 32;
+constexpr int kMfMaxRowBlocks = 16;
+constexpr int kMfStageSamples = 256;        // 8 hom + 8 ref2het dwords per row and stage = 4 slots of 16 B
+constexpr int kMfStageRowDwords = 16;
+constexpr int kMfWaves = 4;
+constexpr int kMfMaxDmaPerWave = (2 * kMfMaxRowBlocks + kMfWaves - 1) / kMfWaves;  // 64 slots per DMA instruction
+constexpr uint32_t kMfMaxFounders = 16000000;  // f32 accumulators stay integer-exact
+
+struct MfmaWaveItem {
+  int32_t jv;        // first variant of J0 (J1 = jv + 32); < 0: the wave has nothing to do
+  int32_t vv;        // first variant of V0 (may lie before the subcontig: such rows hold no candidate pair)
+  uint32_t jend;     // second variants >= jend belong to the next subcontig (its own blocks own their pairs)
+  uint8_t slot[7];   // LDS row-block slot of J0, J1, V0..V4
+  uint8_t prod_mask; // products (bit p; p < 4: (J0, V_p), p >= 4: (J1, V_{p-3})) that hold candidate pairs
+};
+struct MfmaWG {
+  uint32_t rb[kMfMaxRowBlocks];  // first variant of each staged row-block
+  uint32_t n_rb;
+  uint32_t j_lo, j_hi;           // second variants the workgroup's waves own: [j_lo, j_hi)
+  uint32_t pad;
+  MfmaWaveItem w[kMfWaves];
+};
+
 struct PairKernelArgs {
   const uint32_t* planes;        // [variant][chunk][2][kChunkDwords]
   uint64_t row_dwords;           // dwords per variant row = chunks * kRowChunkDwords
@@ -99,6 +130,14 @@ struct PairKernelArgs {
   ldp_r2_hit* r2_hits;
   uint64_t r2_hit_capacity;
   double r2_min;
+  // matrix-pipe tiles (launch_pair_mfma); any_missing (one word, written by prepare_kernel) routes a whole launch:
+  // non-zero -> the popcount kernels do the work, zero -> the matrix-pipe kernel does (when mf_active)
+  const MfmaWG* mf_wgs;
+  uint32_t n_mf_wgs;
+  uint32_t n_local;              // rows in `planes`
+  uint32_t mf_stages;            // ceil(founder_ct / kMfStageSamples)
+  uint32_t mf_active;            // the launch also carries matrix-pipe work items
+  const uint32_t* any_missing;
 };
 
 struct PrepareArgs {
@@ -116,6 +155,7 @@ struct PrepareArgs {
   double cp_tv_scale;            // sqrt(sqrt(thresh) * (1 - 1e-6))
   uint32_t checkpoint_chunk[kCheckpoints];
   uint32_t n_checkpoints;
+  uint32_t* any_missing;         // set to 1 when a converted row has missing calls (may be nullptr)
 };
 
 hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream);
@@ -125,6 +165,8 @@ hipError_t launch_pair_stats_ref(const uint32_t* planes, uint64_t row_dwords, ui
                                  const uint32_t* first, const uint32_t* second, uint32_t n_pairs,
                                  ldp_pair_stats_t* out, hipStream_t stream);
 size_t pair_tiles_lds_bytes(uint32_t max_rows);
+// ev[0..1] (optional): recorded before/after the kernel
+hipError_t launch_pair_mfma(const PairKernelArgs& a, hipStream_t stream, hipEvent_t* ev);
 
 // LDS rows of a work item that stages `units` 8-distance units starting at distance d0 (make_geom in the kernel)
 inline uint32_t tile_rows(uint32_t d0, uint32_t units) {

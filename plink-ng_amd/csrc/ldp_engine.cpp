@@ -113,12 +113,17 @@ struct ldp_engine {
     uint32_t item_first = 0, item_ct = 0;
     uint32_t need_end = 0;               // local variants [0, need_end) must be loaded
     uint64_t word_first = 0, word_end = 0;  // predicate words the group's J-tiles own
+    uint32_t mf_first = 0, mf_ct = 0;    // the same J range as matrix-pipe workgroups (mf_wgs)
     bool launched = false;
     hipEvent_t ev_ready = nullptr;
     hipEvent_t ev_done = nullptr;         // kernels finished and the group's predicate words are back on the host
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // popcount fast / general, matrix pipe
   };
   std::vector<PairGroup> groups;
+  // Matrix-pipe plan of the same band (ldp_pair_mfma.hip): used for complete data, founder_ct <= kMfMaxFounders
+  bool mf_enabled = false;
+  std::vector<MfmaWG> mf_wgs;
+  uint64_t mf_products = 0;               // 32 x 32 block products of the plan
   uint32_t next_group = 0;                 // groups before this one are launched for the current load epoch
   uint32_t loaded_prefix = 0;              // local variants [0, loaded_prefix) were loaded in the current epoch
   uint32_t load_epoch = 1;
@@ -147,6 +152,8 @@ struct ldp_engine {
   unsigned long long* d_counters = nullptr;
   cp_slot* d_cp_stats = nullptr;           // per-variant checkpoint statistics (early termination)
   cp_gen_slot* d_cp_gen = nullptr;         // ... for tiles with missing calls
+  MfmaWG* d_mf_wgs = nullptr;
+  uint32_t* d_any_missing = nullptr;       // [0]: a row converted in this load epoch has missing calls; [1 + g]: its value when group g was queued
   uint32_t checkpoint_chunk[kCheckpoints];
   uint32_t n_checkpoints = 0;
   uint32_t* h_pred = nullptr;  // pinned
@@ -238,6 +245,10 @@ void free_device(ldp_engine* e) {
   (void)hipFree(e->d_counters);
   (void)hipFree(e->d_cp_stats);
   (void)hipFree(e->d_cp_gen);
+  (void)hipFree(e->d_mf_wgs);
+  (void)hipFree(e->d_any_missing);
+  e->d_mf_wgs = nullptr;
+  e->d_any_missing = nullptr;
   if (e->h_pred) {
     (void)hipHostFree(e->h_pred);
   }
@@ -272,7 +283,7 @@ void free_device(ldp_engine* e) {
       g.ev_ready = nullptr;
       g.ev_done = nullptr;
     }
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 6; ++q) {
       if (g.ev[q]) {
         (void)hipEventDestroy(g.ev[q]);
         g.ev[q] = nullptr;
@@ -460,6 +471,164 @@ int checkpoint_fractions(double r2_param, double* frac) {
   return n;
 }
 
+// ---- matrix-pipe plan (ldp_device.h: MfmaWG) ------------------------------------------------------------------
+// Row-blocks of 32 variants aligned to the subcontig start; per pair of second-variant blocks (J0, J1) one wave item
+// ("parallelogram") for every four block distances the band reaches; wave items are packed four to a workgroup as
+// long as the union of their row-blocks fits the LDS ring (J quads x distance pairs for wide bands, four
+// neighbouring J pairs for narrow ones).
+bool mfma_requested() {
+  const char* m = getenv("LDP_PAIR_MFMA");
+  return !(m && (strcmp(m, "0") == 0));
+}
+
+void plan_mfma(ldp_engine* e) {
+  e->mf_wgs.clear();
+  e->mf_products = 0;
+  struct Wave {
+    int32_t jv, vv;
+    uint32_t jend;
+    uint8_t mask;
+    uint32_t blocks[7];
+    uint8_t used;  // bit u: blocks[u] is read
+  };
+  std::vector<Wave> pending;
+  std::vector<uint32_t> uni;
+  auto flush = [&]() {
+    if (pending.empty()) {
+      return;
+    }
+    MfmaWG wg;
+    memset(&wg, 0, sizeof(wg));
+    std::sort(uni.begin(), uni.end());
+    wg.n_rb = static_cast<uint32_t>(uni.size());
+    for (uint32_t k = 0; k < wg.n_rb; ++k) {
+      wg.rb[k] = uni[k];
+    }
+    for (uint32_t k = wg.n_rb; k < kMfMaxRowBlocks; ++k) {
+      wg.rb[k] = uni[0];
+    }
+    wg.j_lo = 0xffffffffu;
+    wg.j_hi = 0;
+    for (uint32_t w = 0; w < kMfWaves; ++w) {
+      MfmaWaveItem& wi = wg.w[w];
+      if (w >= pending.size()) {
+        wi.jv = -1;
+        wi.vv = 0;
+        wi.jend = 0;
+        wi.prod_mask = 0;
+        continue;
+      }
+      const Wave& pw = pending[w];
+      wi.jv = pw.jv;
+      wi.vv = pw.vv;
+      wi.jend = pw.jend;
+      wi.prod_mask = pw.mask;
+      for (int u = 0; u < 7; ++u) {
+        wi.slot[u] = 0;
+        if (pw.used & (1u << u)) {
+          wi.slot[u] = static_cast<uint8_t>(std::lower_bound(uni.begin(), uni.end(), pw.blocks[u]) - uni.begin());
+        }
+      }
+      wg.j_lo = std::min(wg.j_lo, static_cast<uint32_t>(pw.jv));
+      wg.j_hi = std::max(wg.j_hi, pw.jend);
+      e->mf_products += static_cast<uint64_t>(__builtin_popcount(pw.mask));
+    }
+    e->mf_wgs.push_back(wg);
+    pending.clear();
+    uni.clear();
+  };
+  auto add = [&](const Wave& w) {
+    std::vector<uint32_t> merged = uni;
+    for (int u = 0; u < 7; ++u) {
+      if ((w.used & (1u << u)) && (std::find(merged.begin(), merged.end(), w.blocks[u]) == merged.end())) {
+        merged.push_back(w.blocks[u]);
+      }
+    }
+    if ((pending.size() == kMfWaves) || (merged.size() > kMfMaxRowBlocks)) {
+      flush();
+      merged.clear();
+      for (int u = 0; u < 7; ++u) {
+        if ((w.used & (1u << u)) && (std::find(merged.begin(), merged.end(), w.blocks[u]) == merged.end())) {
+          merged.push_back(w.blocks[u]);
+        }
+      }
+    }
+    uni.swap(merged);
+    pending.push_back(w);
+  };
+  for (uint32_t sk : e->owned) {
+    const Subcontig& s = e->subs[sk];
+    const uint32_t sfirst = s.local_first;
+    const uint32_t nb = (s.len + kMfBlock - 1) / kMfBlock;
+    // farthest block distance any second variant of a block reaches (-1: the block holds no candidate pair)
+    std::vector<int32_t> reach(nb, -1);
+    for (uint32_t v = 0; v < s.len; ++v) {
+      const uint32_t j = sfirst + v;
+      const uint32_t lo = e->lo_local[j];
+      if (lo < j) {
+        const int32_t d = static_cast<int32_t>(v / kMfBlock) - static_cast<int32_t>((lo - sfirst) / kMfBlock);
+        reach[v / kMfBlock] = std::max(reach[v / kMfBlock], d);
+      }
+    }
+    auto reach_of = [&](uint32_t b) { return (b < nb) ? reach[b] : -1; };
+    auto make = [&](uint32_t a, uint32_t p, Wave* out) {
+      Wave w;
+      memset(&w, 0, sizeof(w));
+      w.jv = static_cast<int32_t>(sfirst + kMfBlock * a);
+      w.vv = w.jv - static_cast<int32_t>(kMfBlock * (4 * p + 3));
+      w.jend = std::min(sfirst + s.len, static_cast<uint32_t>(w.jv) + 2 * kMfBlock);
+      const bool diag = (p == 0);
+      w.blocks[0] = sfirst + kMfBlock * a;
+      w.blocks[1] = sfirst + kMfBlock * (a + 1);
+      for (int k = 0; k < 4; ++k) {
+        const int32_t off = static_cast<int32_t>(4 * p + 3) - k;  // block distance of both (J0, V_k) and (J1, V_{k+1})
+        if ((reach_of(a) >= off) && (static_cast<int32_t>(a) >= off)) {
+          w.mask |= static_cast<uint8_t>(1u << k);
+          w.used |= 1u;
+          if (diag && (k == 3)) {
+            // (J0, J0)
+          } else {
+            w.used |= static_cast<uint8_t>(1u << (2 + k));
+            w.blocks[2 + k] = sfirst + kMfBlock * (a - static_cast<uint32_t>(off));
+          }
+        }
+        if ((reach_of(a + 1) >= off) && (static_cast<int32_t>(a + 1) >= off)) {
+          w.mask |= static_cast<uint8_t>(1u << (4 + k));
+          w.used |= 2u;
+          if (diag && (k >= 2)) {
+            w.used |= (k == 2) ? 1u : 0u;  // (J1, J0) reads J0 as its V block; (J1, J1) only J1
+          } else {
+            w.used |= static_cast<uint8_t>(1u << (3 + k));
+            w.blocks[3 + k] = sfirst + kMfBlock * (a + 1 - static_cast<uint32_t>(off));
+          }
+        }
+      }
+      *out = w;
+      return w.mask != 0;
+    };
+    for (uint32_t a = 0; a < nb; a += 4) {
+      const int32_t r0 = std::max(reach_of(a), reach_of(a + 1));
+      const int32_t r1 = std::max(reach_of(a + 2), reach_of(a + 3));
+      const uint32_t p0 = (r0 >= 0) ? static_cast<uint32_t>(r0) / 4 + 1 : 0;
+      const uint32_t p1 = (r1 >= 0) ? static_cast<uint32_t>(r1) / 4 + 1 : 0;
+      for (uint32_t p = 0; p < std::max(p0, p1); p += 2) {
+        Wave w;
+        for (uint32_t q = 0; q < 2; ++q) {
+          if ((p + q < p0) && make(a, p + q, &w)) {
+            add(w);
+          }
+        }
+        for (uint32_t q = 0; q < 2; ++q) {
+          if ((p + q < p1) && make(a + 2, p + q, &w)) {
+            add(w);
+          }
+        }
+      }
+    }
+  }
+  flush();
+}
+
 void build_shard(ldp_engine* e) {
   // local index space
   e->owned.clear();
@@ -553,6 +722,27 @@ void build_shard(ldp_engine* e) {
     }
   }
   free_device(e);
+  e->mf_enabled = mfma_requested() && (!e->matrix_mode) && (!e->band_r2_mode) && (e->P.founder_ct <= kMfMaxFounders);
+  e->mf_wgs.clear();
+  // second variants at which a launch group may end: every matrix-pipe workgroup lies on one side
+  std::vector<uint32_t> safe_cut;
+  if (e->mf_enabled) {
+    plan_mfma(e);
+    uint32_t hi = 0;
+    for (size_t k = 0; k + 1 < e->mf_wgs.size(); ++k) {
+      hi = std::max(hi, e->mf_wgs[k].j_hi);
+      if (e->mf_wgs[k + 1].j_lo >= hi) {
+        safe_cut.push_back(e->mf_wgs[k + 1].j_lo);
+      }
+    }
+  }
+  auto cut_ok = [&](uint32_t prev_j0, uint32_t next_j0) {
+    if (!e->mf_enabled) {
+      return true;
+    }
+    const auto it = std::upper_bound(safe_cut.begin(), safe_cut.end(), prev_j0);
+    return (it != safe_cut.end()) && (*it <= next_j0);
+  };
   // launch groups: ~kTargetGroups runs of whole J-tiles (a J-tile's blocks share predicate rows)
   e->groups.clear();
   {
@@ -569,7 +759,7 @@ void build_shard(ldp_engine* e) {
       const double share = (k < kTargetGroups) ? (kTargetGroups - k) / weight_sum : 1.0;
       const uint32_t want = std::max<uint32_t>(512, static_cast<uint32_t>(n_items * share));
       uint32_t i1 = ((k + 1 >= kTargetGroups) || (n_items - i0 <= want)) ? n_items : i0 + want;
-      while ((i1 < n_items) && (e->items[i1].j0 == e->items[i1 - 1].j0)) {
+      while ((i1 < n_items) && ((e->items[i1].j0 == e->items[i1 - 1].j0) || !cut_ok(e->items[i1 - 1].j0, e->items[i1].j0))) {
         ++i1;
       }
       ldp_engine::PairGroup g;
@@ -580,6 +770,20 @@ void build_shard(ldp_engine* e) {
       g.word_end = e->row_off[e->items[i1 - 1].jend];
       e->groups.push_back(g);
       i0 = i1;
+    }
+    // the same J ranges as runs of matrix-pipe workgroups
+    uint32_t w0 = 0;
+    for (size_t gi = 0; gi < e->groups.size(); ++gi) {
+      ldp_engine::PairGroup& g = e->groups[gi];
+      const uint32_t j_end = (gi + 1 < e->groups.size()) ? e->items[e->groups[gi + 1].item_first].j0 : 0xffffffffu;
+      uint32_t w1 = w0;
+      while ((w1 < e->mf_wgs.size()) && (e->mf_wgs[w1].j_lo < j_end)) {
+        g.need_end = std::max(g.need_end, e->mf_wgs[w1].j_hi);
+        ++w1;
+      }
+      g.mf_first = w0;
+      g.mf_ct = w1 - w0;
+      w0 = w1;
     }
   }
   e->load_tag.assign(local, 0);
@@ -653,6 +857,12 @@ int ensure_device_plan(ldp_engine* e) {
   HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
   HIP_TRY(e, hipMalloc(&e->d_cp_stats, n * kCpSlots * sizeof(cp_slot)));
   HIP_TRY(e, hipMalloc(&e->d_cp_gen, n * kCheckpoints * sizeof(cp_gen_slot)));
+  HIP_TRY(e, hipMalloc(&e->d_mf_wgs, std::max<size_t>(e->mf_wgs.size(), 1) * sizeof(MfmaWG)));
+  HIP_TRY(e, hipMalloc(&e->d_any_missing, (e->groups.size() + 2) * sizeof(uint32_t)));
+  HIP_TRY(e, hipMemsetAsync(e->d_any_missing, 0, (e->groups.size() + 2) * sizeof(uint32_t), e->stream));
+  if (!e->mf_wgs.empty()) {
+    HIP_TRY(e, hipMemcpyAsync(e->d_mf_wgs, e->mf_wgs.data(), e->mf_wgs.size() * sizeof(MfmaWG), hipMemcpyHostToDevice, e->stream));
+  }
   // checkpoints for early termination
   e->n_checkpoints = 0;
   for (int k = 0; k < kCheckpoints; ++k) {
@@ -687,7 +897,7 @@ int ensure_device_plan(ldp_engine* e) {
   for (ldp_engine::PairGroup& g : e->groups) {
     HIP_TRY(e, hipEventCreateWithFlags(&g.ev_ready, hipEventDisableTiming));
     HIP_TRY(e, hipEventCreateWithFlags(&g.ev_done, hipEventDisableTiming));
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 6; ++q) {
       HIP_TRY(e, hipEventCreate(&g.ev[q]));
     }
   }
@@ -1060,6 +1270,13 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.r2_row_end = 0;
   A.r2_band_base = 0;
   A.r2_float = 0;
+  // matrix-pipe work is attached per launch (launch_group / the inspection run); r^2 launches stay on the popcount kernels
+  A.mf_wgs = nullptr;
+  A.n_mf_wgs = 0;
+  A.n_local = e->local_ct;
+  A.mf_stages = (e->P.founder_ct + kMfStageSamples - 1) / kMfStageSamples;
+  A.mf_active = 0;
+  A.any_missing = nullptr;
 }
 
 // A new load epoch begins (variants are being loaded again): whatever the pair streams still run belongs to the
@@ -1072,6 +1289,7 @@ int begin_load_epoch(ldp_engine* e) {
     }
   }
   HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->d_any_missing, 0, sizeof(uint32_t), e->stream));
   ++e->load_epoch;
   e->loaded_prefix = 0;
   e->next_group = 0;
@@ -1096,9 +1314,24 @@ int launch_group(ldp_engine* e, uint32_t gi) {
   A.items = e->d_items + g.item_first;
   A.item_general = e->d_item_general + g.item_first;
   A.n_items = g.item_ct;
-  const hipError_t krc = launch_pair_tiles(A, e->max_rows, ps, g.ev);
+  if (e->mf_enabled) {
+    // Which kernel family owns the group is decided on the device, once per group: a snapshot of the missing-calls flag
+    // (all of the group's rows are converted by now) that every kernel of the group reads.
+    HIP_TRY(e, hipMemcpyAsync(e->d_any_missing + 1 + gi, e->d_any_missing, sizeof(uint32_t), hipMemcpyDeviceToDevice, ps));
+    A.mf_active = 1;
+    A.any_missing = e->d_any_missing + 1 + gi;
+    A.mf_wgs = e->d_mf_wgs + g.mf_first;
+    A.n_mf_wgs = g.mf_ct;
+  }
+  hipError_t krc = launch_pair_tiles(A, e->max_rows, ps, g.ev);
   if (krc != hipSuccess) {
     return hipfail(e, krc, "pair_tiles_kernel launch");
+  }
+  if (e->mf_enabled) {
+    krc = launch_pair_mfma(A, ps, g.ev + 4);
+    if (krc != hipSuccess) {
+      return hipfail(e, krc, "pair_mfma_kernel launch");
+    }
   }
   if (g.word_end > g.word_first) {
     HIP_TRY(e, hipMemcpyAsync(e->h_pred + g.word_first, e->d_pred + g.word_first, (g.word_end - g.word_first) * sizeof(uint32_t), hipMemcpyDeviceToHost, ps));
@@ -1155,7 +1388,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   HIP_TRY(e, hipSetDevice(e->device));
   DevBuf stats_buf;
   ldp_pair_stats_t* d_stats = nullptr;
-  float kms = 0.f, kms_fast = 0.f, kms_general = 0.f;
+  float kms = 0.f, kms_fast = 0.f, kms_general = 0.f, kms_mfma = 0.f;
   uint32_t launches = 0;
   std::vector<double> mf_scratch;
   const double* mf = nullptr;
@@ -1184,13 +1417,27 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     PairKernelArgs A;
     fill_pair_args(e, &A, false);
     A.stats = d_stats;
-    hipEvent_t evk[4];
-    for (int q = 0; q < 4; ++q) {
+    hipEvent_t evk[6];
+    for (int q = 0; q < 6; ++q) {
       HIP_TRY(e, hipEventCreate(&evk[q]));
     }
-    const hipError_t krc = launch_pair_tiles(A, e->max_rows, e->stream, evk);
+    if (e->mf_enabled) {
+      const size_t slot = 1 + e->groups.size();
+      HIP_TRY(e, hipMemcpyAsync(e->d_any_missing + slot, e->d_any_missing, sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
+      A.mf_active = 1;
+      A.any_missing = e->d_any_missing + slot;
+      A.mf_wgs = e->d_mf_wgs;
+      A.n_mf_wgs = static_cast<uint32_t>(e->mf_wgs.size());
+    }
+    hipError_t krc = launch_pair_tiles(A, e->max_rows, e->stream, evk);
     if (krc != hipSuccess) {
       return hipfail(e, krc, "pair_tiles_kernel launch");
+    }
+    if (e->mf_enabled) {
+      krc = launch_pair_mfma(A, e->stream, evk + 4);
+      if (krc != hipSuccess) {
+        return hipfail(e, krc, "pair_mfma_kernel launch");
+      }
     }
     if (e->pred_words) {
       HIP_TRY(e, hipMemcpyAsync(e->h_pred, e->d_pred, e->pred_words * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
@@ -1207,9 +1454,12 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     if (!e->items.empty()) {
       HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
       HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[2], evk[3]));
+      if (e->mf_enabled && !e->mf_wgs.empty()) {
+        HIP_TRY(e, hipEventElapsedTime(&kms_mfma, evk[4], evk[5]));
+      }
       launches = 1;
     }
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 6; ++q) {
       (void)hipEventDestroy(evk[q]);
     }
     // the next plain run recomputes with the production settings
@@ -1277,6 +1527,11 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
       float f = 0.f, gen = 0.f;
       HIP_TRY(e, hipEventElapsedTime(&f, g.ev[0], g.ev[1]));
       HIP_TRY(e, hipEventElapsedTime(&gen, g.ev[2], g.ev[3]));
+      if (e->mf_enabled && g.mf_ct) {
+        float mf = 0.f;
+        HIP_TRY(e, hipEventElapsedTime(&mf, g.ev[4], g.ev[5]));
+        kms_mfma += mf;
+      }
       kms_fast += f;
       kms_general += gen;
       ++launches;
@@ -1287,7 +1542,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   for (int q = 0; q < 4; ++q) {
     h_counters[q] = e->h_counters_pin[q];  // (the stream that carried the copy has been synchronised in both branches)
   }
-  kms = kms_fast + kms_general;
+  kms = kms_fast + kms_general + kms_mfma;
   if (!replayed) {
     rc = prepare_mf(e, &mf_scratch, &mf);
     if (rc) {
@@ -1313,6 +1568,8 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   e->ctr.ms_pair_kernel = kms;
   e->ctr.ms_pair_fast = kms_fast;
   e->ctr.ms_pair_general = kms_general;
+  e->ctr.ms_pair_mfma = kms_mfma;
+  e->ctr.mfma_block_products = e->mf_enabled ? e->mf_products : 0;
   e->ctr.ms_replay = replayed ? replay_busy_ms : (t_end - t_replay);  // (time spent replaying, not waiting for groups)
   e->ctr.ms_run_total = t_end - t_start;
   e->ctr.pair_kernel_launches = launches;
@@ -2052,6 +2309,7 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
         PA.checkpoint_chunk[k] = e->checkpoint_chunk[k];
       }
       PA.n_checkpoints = e->n_checkpoints;
+      PA.any_missing = e->d_any_missing;
       if (!e->prep_pending) {
         HIP_TRY(e, hipEventRecord(e->prep_ev0, e->stream));
         e->prep_pending = true;
@@ -2231,6 +2489,44 @@ int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first
   replay(e, pred.data(), mf, R, &replay_pairs);
   e->ctr.replay_pairs = replay_pairs;
   return finish_removed(e, R, removed);
+}
+
+int ldp_debug_mfma_plan(const ldp_engine* e, uint32_t* wg_count, uint32_t* words, uint64_t capacity_words, uint32_t* lo_local, uint32_t* local_ct) {
+  if (!e || !e->planned || !wg_count) {
+    return LDP_ERR_INVALID;
+  }
+  *wg_count = static_cast<uint32_t>(e->mf_wgs.size());
+  if (local_ct) {
+    *local_ct = e->local_ct;
+  }
+  if (lo_local) {
+    std::copy(e->lo_local.begin(), e->lo_local.end(), lo_local);
+  }
+  if (!words) {
+    return LDP_OK;
+  }
+  constexpr uint32_t kWords = 3 + kMfMaxRowBlocks + kMfWaves * 11;
+  if (capacity_words < static_cast<uint64_t>(kWords) * e->mf_wgs.size()) {
+    return LDP_ERR_INVALID;
+  }
+  for (const MfmaWG& wg : e->mf_wgs) {
+    *words++ = wg.n_rb;
+    *words++ = wg.j_lo;
+    *words++ = wg.j_hi;
+    for (uint32_t k = 0; k < kMfMaxRowBlocks; ++k) {
+      *words++ = wg.rb[k];
+    }
+    for (uint32_t w = 0; w < kMfWaves; ++w) {
+      *words++ = static_cast<uint32_t>(wg.w[w].jv);
+      *words++ = static_cast<uint32_t>(wg.w[w].vv);
+      *words++ = wg.w[w].jend;
+      *words++ = wg.w[w].prod_mask;
+      for (int u = 0; u < 7; ++u) {
+        *words++ = wg.w[w].slot[u];
+      }
+    }
+  }
+  return LDP_OK;
 }
 
 int ldp_get_variant_recs(ldp_engine* e, uint32_t first_variant, uint32_t n, ldp_variant_rec* out) {

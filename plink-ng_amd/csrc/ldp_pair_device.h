@@ -1,0 +1,112 @@
+// ldp_pair_device.h -- device-side pieces shared by the two pair kernels (ldp_kernels.hip: popcount tiles,
+// ldp_pair_mfma.hip: matrix-pipe tiles): the FP64 prune predicate, the r^2 of --r2-unphased, the per-pair output
+// step and the early-termination bound.  Device code only (included by .hip translation units).
+#ifndef LDP_PAIR_DEVICE_H
+#define LDP_PAIR_DEVICE_H
+
+#include "ldp_device.h"
+
+namespace ldp {
+
+__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    v += __shfl_down(v, off, 64);
+  }
+  return v;
+}
+
+// Wait until at most `allowed` of this wave's memory operations are still in flight (they complete in order, so
+// everything older has landed), then the workgroup barrier.  Hand-written because __syncthreads() always drains
+// to zero, which would serialise the ring.  The "memory" clobber keeps LDS reads and DMA issues on their side.
+__device__ __forceinline__ void wait_dma_then_barrier(uint32_t allowed) {
+#define LDP_WAIT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory"); break;
+  switch (allowed) {
+    LDP_WAIT_CASE(1) LDP_WAIT_CASE(2) LDP_WAIT_CASE(3) LDP_WAIT_CASE(4) LDP_WAIT_CASE(5) LDP_WAIT_CASE(6) LDP_WAIT_CASE(7)
+    LDP_WAIT_CASE(8) LDP_WAIT_CASE(9) LDP_WAIT_CASE(10) LDP_WAIT_CASE(11) LDP_WAIT_CASE(12) LDP_WAIT_CASE(13) LDP_WAIT_CASE(14)
+    default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+  }
+#undef LDP_WAIT_CASE
+}
+
+// plink2_ld.cc:1085-1090, no FMA contraction possible (multiplies only); var1 belongs to the FIRST variant.
+__device__ __forceinline__ bool exceeds(const ldp_pair_stats_t& s, double thresh) {
+  const double cov12 = static_cast<double>(static_cast<int64_t>(s.dot) * static_cast<int64_t>(s.nm) - static_cast<int64_t>(s.sum1) * static_cast<int64_t>(s.sum2));
+  const double var1 = static_cast<double>(static_cast<int64_t>(s.ssq1) * static_cast<int64_t>(s.nm) - static_cast<int64_t>(s.sum1) * static_cast<int64_t>(s.sum1));
+  const double var2 = static_cast<double>(static_cast<int64_t>(s.ssq2) * static_cast<int64_t>(s.nm) - static_cast<int64_t>(s.sum2) * static_cast<int64_t>(s.sum2));
+  return __dmul_rn(cov12, cov12) > __dmul_rn(__dmul_rn(thresh, var1), var2);
+}
+
+// r^2 of --r2-unphased exactly as ComputeR2 writes it (plink2_ld.cc:6654-6682): NaN when there is no joint
+// observation or a zero variance product, else cov01*cov01 / (double(var0)*double(var1)).  The NaN bit
+// patterns are the ones the reference's `0.0 / 0.0` produces on x86 (sign bit set).
+__device__ __forceinline__ double r2_unphased(const ldp_pair_stats_t& s) {
+  const double nan_ref = __longlong_as_double(static_cast<long long>(0xfff8000000000000ull));
+  if (!s.nm) {
+    return nan_ref;
+  }
+  const int64_t var0 = static_cast<int64_t>(s.ssq1) * static_cast<int64_t>(s.nm) - static_cast<int64_t>(s.sum1) * static_cast<int64_t>(s.sum1);
+  const int64_t var1 = static_cast<int64_t>(s.ssq2) * static_cast<int64_t>(s.nm) - static_cast<int64_t>(s.sum2) * static_cast<int64_t>(s.sum2);
+  const double variance_prod = __dmul_rn(static_cast<double>(var0), static_cast<double>(var1));
+  if (variance_prod == 0.0) {
+    return nan_ref;
+  }
+  const double cov01 = static_cast<double>(static_cast<int64_t>(s.dot) * static_cast<int64_t>(s.nm) - static_cast<int64_t>(s.sum1) * static_cast<int64_t>(s.sum2));
+  return __ddiv_rn(__dmul_rn(cov01, cov01), variance_prod);
+}
+
+// returns true when the prune predicate holds (the caller counts)
+__device__ __forceinline__ bool emit_pair(const PairKernelArgs& A, uint32_t i, uint32_t j, uint32_t lo_j, const ldp_pair_stats_t& st) {
+  if (A.stats) {
+    A.stats[A.pair_off[j] + (i - lo_j)] = st;
+  }
+  if (A.r2_out || A.r2_hits) {
+    if ((j < A.r2_row_first) || (j >= A.r2_row_end)) {
+      return false;  // a J-tile can straddle the edge of the requested rows
+    }
+    const double r2 = r2_unphased(st);
+    if (A.r2_hits) {
+      if (fabs(r2) >= A.r2_min) {  // (false for NaN)
+        const unsigned long long slot = atomicAdd(&A.counters[3], 1ull);
+        if (slot < A.r2_hit_capacity) {
+          ldp_r2_hit h;
+          h.first = i;
+          h.second = j;
+          h.r2 = r2;
+          A.r2_hits[slot] = h;
+        }
+      }
+      return false;
+    }
+    // dense rows of the lower triangle (matrix shapes), or the band itself (windowed table)
+    const uint64_t idx = A.r2_ld ? (static_cast<uint64_t>(j - A.r2_row_first) * A.r2_ld + i) : (A.pair_off[j] - A.r2_band_base + (i - lo_j));
+    if (A.r2_float) {
+      const float f = (r2 != r2) ? __uint_as_float(0xffc00000u) : static_cast<float>(r2);
+      static_cast<float*>(A.r2_out)[idx] = f;
+    } else {
+      static_cast<double*>(A.r2_out)[idx] = r2;
+    }
+    return false;
+  }
+  if (exceeds(st, A.thresh)) {
+    atomicOr(&A.pred[A.row_off[j] + ((i >> 5) - (lo_j >> 5))], 1u << (i & 31));
+    return true;
+  }
+  return false;
+}
+
+// Early termination test, complete data (see ldp_device.h).  After the chunks before checkpoint `cp` the partial dot
+// product of pair (i,j) is dot_p = acc[0] - 2*acc[1].  |N*dot - S_i*S_j| <= |c0| + B with
+//   c0 = N*dot_p + a_i*a_j - S_i*S_j,  B = b_i*b_j   (a, b = the checkpoint slot of each variant)
+// and the pair cannot reach the threshold when |c0| + B + 1 < t_i*t_j (t = the scaled sqrt(variance numerator);
+// the +1 and the 1e-6 folded into t dwarf every FP64 rounding error here).
+__device__ __forceinline__ bool pair_hopeless(const PairKernelArgs& A, const uint32_t (&c)[2], const cp_slot& ci, const cp_slot& gi, const cp_slot& cj,
+                                              const cp_slot& gj) {
+  const double dot_p = static_cast<double>(static_cast<int32_t>(c[0] - 2 * c[1]));
+  const double c0 = fma(static_cast<double>(A.founder_ct), dot_p, fma(ci.a, cj.a, -(gi.a * gj.a)));
+  const double bound = fabs(c0) + fma(ci.b, cj.b, 1.0);
+  return bound < gi.b * gj.b;
+}
+
+}  // namespace ldp
+#endif

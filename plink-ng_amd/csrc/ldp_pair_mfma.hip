@@ -1,0 +1,310 @@
+// ldp_pair_mfma.hip -- the complete-data pair statistics on the matrix pipe (gfx950 / CDNA4).
+//
+// DotprodWords (plink2_ld.cc:235-251) computes dot = sum_s x_i[s] * x_j[s] with x in {-1, 0, +1} (0 = het or missing)
+// as popcnt(hom_i & hom_j) - 2 popcnt(hom_i & hom_j & (r2h_i ^ r2h_j)).  The same integer is a matrix product over the
+// samples, and CDNA4's v_mfma_scale_f32_32x32x64_f8f6f4 contracts 64 samples of a 32 x 32 block of pairs per
+// instruction with FP4 (E2M1) operands: +-1 and 0 are exact codes, products are +-1 / 0, and the f32 accumulators hold
+// integers exactly below 2^24 (kMfMaxFounders).  Per 32 samples of one variant the two plane dwords (hom, ref2het)
+// expand to 32 E2M1 nibbles (magnitude bit = hom, sign bit = ref2het; the sign of a zero is irrelevant) in 10 VALU
+// operations, once per row-block and k-step, shared by the 32 x 32 pairs of every product the block takes part in --
+// against 4 VALU lane-operations per pair and 32 samples on the popcount path (tools/mfma_probe.hip measures both the
+// facts about the instruction this file relies on and the rates).  The expansion cannot live in HBM (4 bits per
+// genotype: 312 GB per GPU at BASELINE config 3), so rows are staged as bit-planes and expanded in registers.
+//
+// The sample order inside a fragment is free as long as both operands use the same one (a dot product is
+// order-invariant); every row goes through the same fp4_of_planes(), so it is.
+//
+// Results are the integers the popcount kernels produce (the parity tests compare every candidate pair's 6-tuple);
+// the per-pair epilogue (FP64 predicate, r^2, predicate bits) is shared (ldp_pair_device.h).
+#include "ldp_device.h"
+#include "ldp_pair_device.h"
+
+#include <cstdlib>
+
+namespace ldp {
+
+typedef int mf_v8i __attribute__((ext_vector_type(8)));
+typedef float mf_v16f __attribute__((ext_vector_type(16)));
+
+struct Frag {
+  uint32_t d[4];  // 32 E2M1 values: one lane's share (one row, 32 samples) of a 32 x 64 operand
+};
+
+// 32 samples: plane dwords H (hom: |x| = 1) and R (ref2het: the sign; x = +1 <=> hom & ref2het, i.e. the nibble codes
+// -x, the same for both operands) -> nibble (R << 3) | (H << 1).  Output dword q, nibble p = sample 4p + q.
+__device__ __forceinline__ void fp4_of_planes(uint32_t H, uint32_t R, Frag& f) {
+  uint32_t t0 = (H & 0x33333333u) | ((R << 2) & 0xccccccccu);  // per nibble: H[4p], H[4p+1], R[4p], R[4p+1]
+  uint32_t t1 = ((H >> 2) & 0x33333333u) | (R & 0xccccccccu);  //             H[4p+2], H[4p+3], R[4p+2], R[4p+3]
+  asm("" : "+v"(t0), "+v"(t1));  // (keeps the two-step form: 2 shifts + 2 v_bfi, then 2 shifts + 4 ands)
+  f.d[0] = (t0 << 1) & 0xaaaaaaaau;
+  f.d[1] = t0 & 0xaaaaaaaau;
+  f.d[2] = (t1 << 1) & 0xaaaaaaaau;
+  f.d[3] = t1 & 0xaaaaaaaau;
+}
+
+// C[row of a][column of b] += sum over 64 samples; E8M0 scale 0x7f = 1.0 for both operands
+__device__ __forceinline__ mf_v16f mfma_fp4(const Frag& a, const Frag& b, mf_v16f c) {
+  const mf_v8i A = {static_cast<int>(a.d[0]), static_cast<int>(a.d[1]), static_cast<int>(a.d[2]), static_cast<int>(a.d[3]), 0, 0, 0, 0};
+  const mf_v8i B = {static_cast<int>(b.d[0]), static_cast<int>(b.d[1]), static_cast<int>(b.d[2]), static_cast<int>(b.d[3]), 0, 0, 0, 0};
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
+__device__ __forceinline__ uint32_t comp(const uint4& v, int k) { return (k == 0) ? v.x : ((k == 1) ? v.y : ((k == 2) ? v.z : v.w)); }
+
+constexpr uint32_t kMfBlockStageDwords = kMfBlock * kMfStageRowDwords;  // 512 dwords = 2 KiB per row-block and stage
+constexpr uint32_t kMfEpiProducts = 4;                                  // products per epilogue round
+constexpr uint32_t kMfEpiWaveDwords = kMfEpiProducts * 16 * 64;
+constexpr uint32_t kMfLdsDwords = kMfWaves * kMfEpiWaveDwords;          // 64 KiB: epilogue scratch == staging ring
+constexpr uint32_t kMfMaxStages = 4;
+
+// One stage (kMfStageSamples samples) of a wave's parallelogram.  (st4 is __restrict__ on purpose: without it hipcc
+// assumes the LDS-DMA in flight may alias these reads and drains it with s_waitcnt vmcnt(0) in front of every one.)
+__device__ __forceinline__ void mfma_stage(const uint4* __restrict__ st4, const uint32_t (&slot_off)[7], uint32_t oH, uint32_t oR, uint32_t need,
+                                           uint32_t live, bool diag, mf_v16f (&acc)[8]) {
+  // J fragments of all four k-steps stay in registers; the V blocks stream past them one at a time (two b128 LDS
+  // reads -> 4 fragments -> 4 or 8 MFMAs), so only one V block's raw dwords are live next to the 128 accumulators.
+  Frag fj0[4], fj1[4];
+  if (need & 1u) {
+    const uint4 H = st4[slot_off[0] + oH], R = st4[slot_off[0] + oR];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fp4_of_planes(comp(H, ks), comp(R, ks), fj0[ks]);
+    }
+  }
+  if (need & 2u) {
+    const uint4 H = st4[slot_off[1] + oH], R = st4[slot_off[1] + oR];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fp4_of_planes(comp(H, ks), comp(R, ks), fj1[ks]);
+    }
+  }
+  // rows of C = first variant (A operand: a V block), columns = second variant (B operand: a J block)
+#define LDP_MF_VBLOCK(u, P0, P1)                                                           \
+  if (need & (1u << (u))) {                                                                \
+    const uint4 H = st4[slot_off[u] + oH], R = st4[slot_off[u] + oR];                      \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                     \
+      Frag fv;                                                                             \
+      fp4_of_planes(comp(H, ks), comp(R, ks), fv);                                         \
+      if ((P0 >= 0) && (live & (1u << (P0 & 7)))) acc[P0 & 7] = mfma_fp4(fv, fj0[ks], acc[P0 & 7]); \
+      if ((P1 >= 0) && (live & (1u << (P1 & 7)))) acc[P1 & 7] = mfma_fp4(fv, fj1[ks], acc[P1 & 7]); \
+    }                                                                                      \
+  }
+  LDP_MF_VBLOCK(2, 0, -1)
+  LDP_MF_VBLOCK(3, 1, 4)
+  LDP_MF_VBLOCK(4, 2, 5)
+  if (diag) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (live & 0x08u) acc[3] = mfma_fp4(fj0[ks], fj0[ks], acc[3]);
+      if (live & 0x40u) acc[6] = mfma_fp4(fj0[ks], fj1[ks], acc[6]);
+      if (live & 0x80u) acc[7] = mfma_fp4(fj1[ks], fj1[ks], acc[7]);
+    }
+  } else {
+    LDP_MF_VBLOCK(5, 3, 6)
+    LDP_MF_VBLOCK(6, -1, 7)
+  }
+#undef LDP_MF_VBLOCK
+}
+
+// LDS image of a stage: row-block slot b, row r, 16-byte piece c (0, 1 = hom dwords 0-3, 4-7 of the stage; 2, 3 =
+// ref2het) sits at 16-byte slot (32 b + r) * 4 + (c ^ ((r >> 2) & 3)).  The XOR makes the 16 lanes of every
+// ds_read_b128 group (rows r, r + 1, ... of one piece) hit 16 distinct 4-bank groups without padding, and the DMA
+// (lane-linear in LDS, free per-lane global address) simply fetches the piece that belongs in its slot.
+__global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ uint32_t s_src_off[kMfMaxDmaPerWave * kMfWaves * 64];
+  if (*A.any_missing) {
+    return;  // rows with missing calls: the popcount kernels own this launch (7 counts per pair)
+  }
+  const uint32_t per_xcd = (A.n_mf_wgs + 7) / 8;
+  const uint32_t item_idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // XCD-aware, as pair_tiles_kernel
+  if (item_idx >= A.n_mf_wgs) {
+    return;
+  }
+  const MfmaWG* __restrict__ wg = A.mf_wgs + item_idx;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lane = tid & 63;
+  const uint32_t r = lane & 31;
+  const uint32_t h = lane >> 5;
+
+  const uint32_t n_rb = __builtin_amdgcn_readfirstlane(wg->n_rb);
+  const uint32_t n_instr = 2 * n_rb;  // DMA wave-instructions per stage (64 slots of 16 B each)
+  const uint32_t mine = (n_instr > wave) ? (n_instr - wave + kMfWaves - 1) / kMfWaves : 0;
+  const uint32_t stage_dwords = n_rb * kMfBlockStageDwords;
+  uint32_t stages = A.lds_dwords / stage_dwords;
+  stages = (stages > kMfMaxStages) ? kMfMaxStages : stages;
+  const uint32_t row_bytes = static_cast<uint32_t>(A.row_dwords * sizeof(uint32_t));
+  const uint32_t n_stages = A.mf_stages;
+
+  // ---- DMA plan: per-lane source offsets (LDS) and per-instruction row-block bases (uniform) ----
+  const uint8_t* base_t[kMfMaxDmaPerWave];
+#pragma unroll
+  for (int t = 0; t < kMfMaxDmaPerWave; ++t) {
+    const uint32_t T = wave + kMfWaves * t;
+    base_t[t] = reinterpret_cast<const uint8_t*>(A.planes);
+    if (T < n_instr) {
+      const uint32_t first = __builtin_amdgcn_readfirstlane(wg->rb[T >> 1]);
+      base_t[t] += static_cast<uint64_t>(first) * row_bytes;
+      const uint32_t L = T * 64 + lane;
+      const uint32_t rr = (L >> 2) & 31;
+      const uint32_t col = (L & 3) ^ ((rr >> 2) & 3);
+      uint32_t var = first + rr;
+      var = (var < A.n_local) ? var : (A.n_local - 1);
+      s_src_off[t * (kMfWaves * 64) + tid] = (var - first) * row_bytes + (col & 1) * 16 + (col >> 1) * 64;
+    }
+  }
+
+  // ---- this wave's parallelogram ----
+  const MfmaWaveItem* __restrict__ wi = wg->w + wave;
+  const int32_t jv = __builtin_amdgcn_readfirstlane(wi->jv);
+  const int32_t vv = __builtin_amdgcn_readfirstlane(wi->vv);
+  const uint32_t jend = __builtin_amdgcn_readfirstlane(wi->jend);
+  const uint32_t live = (jv >= 0) ? __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wi->prod_mask)) : 0u;
+  const bool diag = (vv + 3 * kMfBlock == jv);
+  uint32_t slot_off[7];  // uint4 index of the row-block's first slot
+#pragma unroll
+  for (int u = 0; u < 7; ++u) {
+    slot_off[u] = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wi->slot[u])) * (kMfBlock * 4);
+  }
+  // which row-blocks the live products read (on the diagonal V3 / V4 are J0 / J1)
+  uint32_t need = ((live & 0x0fu) ? 1u : 0u) | ((live & 0xf0u) ? 2u : 0u);
+  need |= (live & 0x01u) ? 4u : 0u;
+  need |= (live & 0x12u) ? 8u : 0u;
+  need |= (live & 0x24u) ? 16u : 0u;
+  if (!diag) {
+    need |= (live & 0x48u) ? 32u : 0u;
+    need |= (live & 0x80u) ? 64u : 0u;
+  } else {
+    need |= (live & 0x48u) ? 1u : 0u;  // V3 is J0
+    need |= (live & 0x80u) ? 2u : 0u;  // V4 is J1
+  }
+  const uint32_t sw = (r >> 2) & 3;
+  const uint32_t oH = r * 4 + (h ^ sw);
+  const uint32_t oR = r * 4 + ((2 + h) ^ sw);
+
+  mf_v16f acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      acc[p][g] = 0.f;
+    }
+  }
+
+  auto dma_stage = [&](uint32_t s, uint32_t buf) {
+    const uint32_t kbyte = (s >> 1) * (kRowChunkDwords * 4) + (s & 1) * 32;
+    uint32_t* dst = lds + buf * stage_dwords;
+#pragma unroll
+    for (int t = 0; t < kMfMaxDmaPerWave; ++t) {
+      const uint32_t T = wave + kMfWaves * t;
+      if (T < n_instr) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_t[t] + kbyte + s_src_off[t * (kMfWaves * 64) + tid]),
+                                         (__attribute__((address_space(3))) void*)(dst + T * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  __syncthreads();  // (s_src_off is complete)
+  // ---- k-loop over stages of kMfStageSamples samples, ring of `stages` LDS buffers ----
+  uint32_t issued = 0, issue_buf = 0, read_buf = 0;
+  while ((issued < n_stages) && (issued + 1 < stages)) {
+    dma_stage(issued, issue_buf);
+    ++issued;
+    issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
+  }
+  for (uint32_t kc = 0; kc < n_stages; ++kc) {
+    wait_dma_then_barrier(mine * (issued - kc - 1));
+    if (issued < n_stages) {
+      dma_stage(issued, issue_buf);  // (reuses the buffer every wave finished reading before the barrier)
+      ++issued;
+      issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
+    }
+    const uint4* __restrict__ st4 = reinterpret_cast<const uint4*>(lds + read_buf * stage_dwords);
+    read_buf = (read_buf + 1 == stages) ? 0 : read_buf + 1;
+    if (!live) {
+      continue;
+    }
+    mfma_stage(st4, slot_off, oH, oR, need, live, diag, acc);
+  }
+  __syncthreads();  // staging is over: LDS becomes the epilogue's scratch (a private region per wave)
+
+  // ---- epilogue: accumulators through LDS so the per-pair code is a rolled loop ----
+  // lane l, register g of a product holds first variant (g & 3) + 8 (g >> 2) + 4 (l >> 5) of the V block, second variant
+  // l & 31 of the J block (tools/mfma_probe.hip, fact 1)
+  uint32_t* epi = lds + wave * kMfEpiWaveDwords;
+  uint32_t n_true = 0;
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    if (!(live & (0xfu << (4 * round)))) {
+      continue;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) {
+      if (live & (1u << (4 * round + pl))) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          epi[(pl * 16 + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>(acc[4 * round + pl][g]));
+        }
+      }
+    }
+    const int64_t j64 = static_cast<int64_t>(jv) + kMfBlock * round + r;
+    if (j64 < static_cast<int64_t>(jend)) {
+      const uint32_t j = static_cast<uint32_t>(j64);
+      const uint32_t lo_j = A.lo[j];
+      if (lo_j < j) {
+        const int32_t sum_j = A.recs[j].sum;
+        const uint32_t ssq_j = A.recs[j].ssq;
+#pragma unroll 1
+        for (uint32_t pl = 0; pl < 4; ++pl) {
+          if (!(live & (1u << (4 * round + pl)))) {
+            continue;
+          }
+          const int64_t vfirst = static_cast<int64_t>(vv) + kMfBlock * (pl + round) + 4 * h;
+#pragma unroll 1
+          for (uint32_t g = 0; g < 16; ++g) {
+            const int64_t i64 = vfirst + (g & 3) + 8 * (g >> 2);
+            if ((i64 < static_cast<int64_t>(lo_j)) || (i64 >= j64)) {
+              continue;
+            }
+            const uint32_t i = static_cast<uint32_t>(i64);
+            ldp_pair_stats_t ps;
+            ps.dot = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]);
+            ps.nm = A.founder_ct;
+            ps.sum1 = A.recs[i].sum;
+            ps.ssq1 = A.recs[i].ssq;
+            ps.sum2 = sum_j;
+            ps.ssq2 = ssq_j;
+            n_true += emit_pair(A, i, j, lo_j, ps) ? 1 : 0;
+          }
+        }
+      }
+    }
+  }
+  n_true = wave_reduce_add(n_true);
+  if ((lane == 0) && n_true) {
+    atomicAdd(A.counters, static_cast<unsigned long long>(n_true));
+  }
+}
+
+hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipEvent_t* ev) {
+  if (!a_in.n_mf_wgs) {
+    return hipSuccess;
+  }
+  PairKernelArgs a = a_in;
+  const size_t lds = static_cast<size_t>(kMfLdsDwords) * sizeof(uint32_t);
+  a.lds_dwords = kMfLdsDwords;
+  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMfLdsDwords * sizeof(uint32_t)));
+  (void)attr_rc;
+  const uint32_t per_xcd = (a.n_mf_wgs + 7) / 8;
+  if (ev) {
+    (void)hipEventRecord(ev[0], stream);
+  }
+  hipLaunchKernelGGL(pair_mfma_kernel, dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
+  if (ev) {
+    (void)hipEventRecord(ev[1], stream);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace ldp

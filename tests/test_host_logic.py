@@ -218,3 +218,73 @@ def test_vcor_window_plan_matches_reference_pair_set(pkg):
             st = T.oracle_pair_stats(hom, r2h, vaggs, n, i, j)
             cov, v1, v2 = T.oracle_r2(st)
             assert (st.nm == 0) or (v1 * v2 == 0.0), (k, i, j)  # ComputeR2: undefined -> NaN -> not written
+
+
+def _mfma_plan_coverage(pkg, m, nchr, seed, window, step, is_bp, spacing, rank=0, world=1):
+    """Every candidate pair must be owned by exactly one live 32 x 32 block product of the matrix-pipe plan, row-block
+    slots must point at the blocks the products read, and a workgroup stages at most 16 distinct row-blocks."""
+    chr_idx, bps = make_positions(m, nchr, seed, spacing=spacing)
+    eng = pkg.LdPruneEngine(100, window, step, is_bp, 0.2, device=-1)
+    eng.set_variants(chr_idx, bps)
+    if world > 1:
+        eng.set_shard(rank, world)
+    wgs, lo = eng.debug_mfma_plan()
+    eng.close()
+    n_local = len(lo)
+    span = np.arange(n_local, dtype=np.int64) - lo.astype(np.int64)
+    pair_off = np.concatenate([[0], np.cumsum(np.maximum(span, 0))])
+    count = np.zeros(int(pair_off[-1]), dtype=np.int32)
+    prev_hi = 0
+    for wg in wgs:
+        n_rb, j_lo, j_hi = int(wg[0]), int(wg[1]), int(wg[2])
+        rb = wg[3:19].astype(np.int64)
+        assert 1 <= n_rb <= 16
+        assert np.all(np.diff(rb[:n_rb]) > 0)
+        assert np.all(rb[:n_rb] < n_local)
+        assert j_lo < j_hi <= n_local
+        for w in range(4):
+            base = 19 + 11 * w
+            jv, vv, jend, mask = int(np.int32(wg[base])), int(np.int32(wg[base + 1])), int(wg[base + 2]), int(wg[base + 3])
+            slot = wg[base + 4:base + 11].astype(np.int64)
+            if jv < 0:
+                assert mask == 0 or True
+                continue
+            assert mask != 0 and j_lo <= jv < jend <= j_hi
+            diag = (vv + 96 == jv)
+            for p in range(8):
+                if not (mask >> p) & 1:
+                    continue
+                q, k = p >> 2, (p & 3) + (p >> 2)
+                jfirst, vfirst = jv + 32 * q, vv + 32 * k
+                assert rb[slot[q]] == jfirst
+                assert vfirst >= 0
+                if diag and k >= 3:
+                    assert vfirst == jv + 32 * (k - 3)  # the kernel takes J0 / J1's fragments for V3 / V4
+                    assert rb[slot[k - 3]] == vfirst
+                else:
+                    assert rb[slot[2 + k]] == vfirst and slot[2 + k] < n_rb
+                for j in range(jfirst, min(jfirst + 32, jend)):
+                    a, b = max(vfirst, int(lo[j])), min(vfirst + 32, j)
+                    if a < b:
+                        count[pair_off[j] + a - lo[j]:pair_off[j] + b - lo[j]] += 1
+        prev_hi = max(prev_hi, j_hi)
+    assert np.all(count == 1), "pairs covered %d..%d times" % (count.min() if len(count) else 1, count.max() if len(count) else 1)
+    return len(wgs), len(count)
+
+
+@pytest.mark.parametrize("m,nchr,seed,window,step,is_bp,spacing", [
+    (3000, 3, 1, 20000, 1, True, 300),      # ~67 variants per window: narrow band, diagonal parallelograms only
+    (5000, 2, 2, 200000, 1, True, 300),     # ~670 per window: wide band, several parallelograms per J pair
+    (2000, 7, 3, 50, 5, False, 300),        # count windows with a step
+    (1500, 40, 4, 15000, 1, True, 200),     # many short subcontigs
+    (700, 1, 5, 1000000, 1, True, 100),     # one window spans everything
+    (33, 1, 6, 1000, 1, True, 100), (64, 1, 7, 100000, 1, True, 100), (65, 2, 8, 100000, 1, True, 100),
+])
+def test_mfma_plan_covers_every_candidate_pair_once(pkg, m, nchr, seed, window, step, is_bp, spacing):
+    n_wg, n_pairs = _mfma_plan_coverage(pkg, m, nchr, seed, window, step, is_bp, spacing)
+    assert n_pairs == 0 or n_wg > 0
+
+
+def test_mfma_plan_covers_a_shard(pkg):
+    for rank in range(2):
+        _mfma_plan_coverage(pkg, 4000, 6, 9, 30000, 1, True, 300, rank=rank, world=2)

@@ -1,0 +1,326 @@
+// mfma_probe.hip -- facts about v_mfma_scale_f32_32x32x64_f8f6f4 (FP4 operands) that pair_mfma_kernel relies on,
+// measured on the box instead of assumed:
+//   1. C/D layout: lane l, register g  ->  (row of A, column of B)
+//   2. K consistency: the same (lane half, VGPR, nibble) position of A and B meets in the contraction
+//   3. E2M1 codes: 0x2 = +1, 0xA = -1, 0x0 / 0x8 = 0; E8M0 scale 0x7F = 1
+//   4. integer exactness of the f32 accumulation right up to 2^24
+//   5. issue rate of the instruction alone, and with the bit-plane -> FP4 unpack beside it
+// Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_probe.hip -o tools/_bin/mfma_probe
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+#define CHECK(x)                                                                  \
+  do {                                                                            \
+    hipError_t e__ = (x);                                                         \
+    if (e__ != hipSuccess) {                                                      \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e__), __FILE__, __LINE__); \
+      exit(1);                                                                    \
+    }                                                                             \
+  } while (0)
+
+__device__ __forceinline__ v16f mfma_fp4(const uint32_t (&a)[4], const uint32_t (&b)[4], v16f c) {
+  const v8i A = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], 0, 0, 0, 0};
+  const v8i B = {(int)b[0], (int)b[1], (int)b[2], (int)b[3], 0, 0, 0, 0};
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
+// one wave: a[lane][4], b[lane][4], cin[lane][16] -> cout[lane][16]
+__global__ void one_mfma(const uint32_t* a, const uint32_t* b, const float* cin, float* cout) {
+  const int l = threadIdx.x;
+  uint32_t A[4], B[4];
+  v16f C;
+  for (int q = 0; q < 4; ++q) {
+    A[q] = a[l * 4 + q];
+    B[q] = b[l * 4 + q];
+  }
+  for (int g = 0; g < 16; ++g) {
+    C[g] = cin[l * 16 + g];
+  }
+  C = mfma_fp4(A, B, C);
+  for (int g = 0; g < 16; ++g) {
+    cout[l * 16 + g] = C[g];
+  }
+}
+
+// bit-planes -> FP4: 32 samples (hom dword H, sign dword R) -> 4 dwords of E2M1 nibbles (bit 1 = H, bit 3 = R)
+__device__ __forceinline__ void unpack32(uint32_t H, uint32_t R, uint32_t (&o)[4]) {
+  const uint32_t t0 = (H & 0x33333333u) | ((R << 2) & 0xccccccccu);
+  const uint32_t t1 = ((H >> 2) & 0x33333333u) | (R & 0xccccccccu);
+  o[0] = (t0 << 1) & 0xaaaaaaaau;
+  o[1] = t0 & 0xaaaaaaaau;
+  o[2] = (t1 << 1) & 0xaaaaaaaau;
+  o[3] = t1 & 0xaaaaaaaau;
+}
+
+// rate: NACC independent accumulators, `iters` rounds; mode 0 = MFMA only, 1 = + one unpack32 per MFMA (VALU beside it),
+// 2 = 7 unpacks per 8 MFMAs with operands read from LDS (the shape of pair_mfma_kernel's k-step)
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void rate_kernel(const uint32_t* src, float* out, int iters) {
+  __shared__ uint32_t lds[8192];
+  const int l = threadIdx.x;
+  for (int q = l; q < 8192; q += 256) {
+    lds[q] = src[q];
+  }
+  __syncthreads();
+  v16f acc[8];
+  for (int p = 0; p < 8; ++p) {
+    for (int g = 0; g < 16; ++g) {
+      acc[p][g] = 0.f;
+    }
+  }
+  uint32_t fa[4] = {src[l], src[l + 256], src[l + 512], src[l + 768]};
+  uint32_t fb[4] = {src[l + 1024], src[l + 1280], src[l + 1536], src[l + 1792]};
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 0) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        acc[p] = mfma_fp4(fa, fb, acc[p]);
+      }
+    } else if (MODE == 1) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        uint32_t f[4];
+        unpack32(fa[p & 3] + it, fb[p & 3] ^ it, f);
+        acc[p] = mfma_fp4(f, fb, acc[p]);
+      }
+    } else {
+      const uint4* l4 = reinterpret_cast<const uint4*>(lds);
+      const int base = ((it & 7) * 7) * 64 + (l & 63);
+      uint32_t fr[7][4];
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        const uint4 hv = l4[base + u * 64];
+        unpack32(hv.x, hv.y, fr[u]);
+      }
+      acc[0] = mfma_fp4(fr[2], fr[0], acc[0]);
+      acc[1] = mfma_fp4(fr[3], fr[0], acc[1]);
+      acc[2] = mfma_fp4(fr[4], fr[0], acc[2]);
+      acc[3] = mfma_fp4(fr[5], fr[0], acc[3]);
+      acc[4] = mfma_fp4(fr[3], fr[1], acc[4]);
+      acc[5] = mfma_fp4(fr[4], fr[1], acc[5]);
+      acc[6] = mfma_fp4(fr[5], fr[1], acc[6]);
+      acc[7] = mfma_fp4(fr[6], fr[1], acc[7]);
+    }
+  }
+  float s = 0.f;
+  for (int p = 0; p < 8; ++p) {
+    for (int g = 0; g < 16; ++g) {
+      s += acc[p][g];
+    }
+  }
+  out[blockIdx.x * 256 + l] = s;
+}
+
+static void run_one(const std::vector<uint32_t>& a, const std::vector<uint32_t>& b, const std::vector<float>& cin, std::vector<float>& cout,
+                    uint32_t* da, uint32_t* db, float* dc, float* dd) {
+  CHECK(hipMemcpy(da, a.data(), 256 * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(db, b.data(), 256 * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(dc, cin.data(), 1024 * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(one_mfma, dim3(1), dim3(64), 0, 0, da, db, dc, dd);
+  CHECK(hipDeviceSynchronize());
+  cout.resize(1024);
+  CHECK(hipMemcpy(cout.data(), dd, 1024 * 4, hipMemcpyDeviceToHost));
+}
+
+int main() {
+  uint32_t *da, *db;
+  float *dc, *dd;
+  CHECK(hipMalloc(&da, 1024));
+  CHECK(hipMalloc(&db, 1024));
+  CHECK(hipMalloc(&dc, 4096));
+  CHECK(hipMalloc(&dd, 4096));
+  std::vector<uint32_t> a(256), b(256);
+  std::vector<float> cin(1024, 0.f), c;
+  int bad = 0;
+
+  // 1. layout: A row r = all (+1) in every k for lanes with (l & 31) == r; B all ones.  C[l][g] = 64 iff row(l, g) == r.
+  std::vector<int> row_of(1024, -1), col_of(1024, -1);
+  for (int r = 0; r < 32; ++r) {
+    for (int l = 0; l < 64; ++l) {
+      for (int q = 0; q < 4; ++q) {
+        a[l * 4 + q] = ((l & 31) == r) ? 0x22222222u : 0u;
+        b[l * 4 + q] = 0x22222222u;
+      }
+    }
+    run_one(a, b, cin, c, da, db, dc, dd);
+    for (int e = 0; e < 1024; ++e) {
+      if (c[e] == 64.f) {
+        row_of[e] = r;
+      } else if (c[e] != 0.f) {
+        printf("layout(row): unexpected value %g at lane %d reg %d\n", c[e], e / 16, e % 16);
+        ++bad;
+      }
+    }
+    for (int l = 0; l < 64; ++l) {
+      for (int q = 0; q < 4; ++q) {
+        a[l * 4 + q] = 0x22222222u;
+        b[l * 4 + q] = ((l & 31) == r) ? 0x22222222u : 0u;
+      }
+    }
+    run_one(a, b, cin, c, da, db, dc, dd);
+    for (int e = 0; e < 1024; ++e) {
+      if (c[e] == 64.f) {
+        col_of[e] = r;
+      }
+    }
+  }
+  int layout_ok = 1;
+  for (int l = 0; l < 64; ++l) {
+    for (int g = 0; g < 16; ++g) {
+      const int want_row = (g & 3) + 8 * (g >> 2) + 4 * (l >> 5);
+      const int want_col = l & 31;
+      if ((row_of[l * 16 + g] != want_row) || (col_of[l * 16 + g] != want_col)) {
+        layout_ok = 0;
+      }
+    }
+  }
+  printf("1. C/D layout row=(g&3)+8*(g>>2)+4*(l>>5) [A operand's lane&31], col=l&31 [B operand's lane&31]: %s\n", layout_ok ? "CONFIRMED" : "DIFFERENT");
+  if (!layout_ok) {
+    ++bad;
+    for (int l = 0; l < 64; l += 9) {
+      printf("   lane %2d:", l);
+      for (int g = 0; g < 16; ++g) {
+        printf(" (%d,%d)", row_of[l * 16 + g], col_of[l * 16 + g]);
+      }
+      printf("\n");
+    }
+  }
+
+  // 2. K consistency: one-hot nibble at position pa of A row 0, pb of B col 0 (position = half*32 + vgpr*8 + nibble)
+  int k_ok = 1, k_pairs = 0;
+  for (int pa = 0; pa < 64; ++pa) {
+    for (int pb = 0; pb < 64; ++pb) {
+      if ((pa != pb) && ((pa * 7 + pb * 3) % 5)) {
+        continue;  // all equal positions + a fifth of the unequal ones
+      }
+      std::fill(a.begin(), a.end(), 0u);
+      std::fill(b.begin(), b.end(), 0u);
+      a[((pa >> 5) * 32 + 0) * 4 + ((pa >> 3) & 3)] = 0x2u << (4 * (pa & 7));
+      b[((pb >> 5) * 32 + 0) * 4 + ((pb >> 3) & 3)] = 0x2u << (4 * (pb & 7));
+      run_one(a, b, cin, c, da, db, dc, dd);
+      const float want = (pa == pb) ? 1.f : 0.f;
+      if (c[0] != want) {
+        if (k_ok) {
+          printf("   K mismatch: A position %d x B position %d -> %g (expected %g)\n", pa, pb, c[0], want);
+        }
+        k_ok = 0;
+      }
+      ++k_pairs;
+    }
+  }
+  printf("2. K consistency (same lane half / VGPR / nibble of A and B contract), %d position pairs: %s\n", k_pairs, k_ok ? "CONFIRMED" : "DIFFERENT");
+  bad += !k_ok;
+
+  // 3. code table
+  {
+    const uint32_t codes[6] = {0x0, 0x2, 0xA, 0x8, 0x1, 0x4};
+    const float vals[6] = {0.f, 1.f, -1.f, 0.f, 0.5f, 2.f};
+    int ok = 1;
+    for (int x = 0; x < 6; ++x) {
+      for (int y = 0; y < 6; ++y) {
+        std::fill(a.begin(), a.end(), 0u);
+        std::fill(b.begin(), b.end(), 0u);
+        a[0] = codes[x];
+        b[0] = codes[y];
+        run_one(a, b, cin, c, da, db, dc, dd);
+        if (c[0] != vals[x] * vals[y]) {
+          printf("   code 0x%x x 0x%x -> %g, expected %g\n", codes[x], codes[y], c[0], vals[x] * vals[y]);
+          ok = 0;
+        }
+      }
+    }
+    printf("3. E2M1 codes 0x2=+1 0xA=-1 0x0/0x8=0 (0x1=0.5 0x4=2), scale 0x7F=1: %s\n", ok ? "CONFIRMED" : "DIFFERENT");
+    bad += !ok;
+  }
+
+  // 4. exactness near 2^24: C0 + 64 * (+1) and C0 - 64, mixed signs
+  {
+    int ok = 1;
+    const float starts[4] = {16777216.f - 64.f, -(16777216.f - 64.f), 16777000.f, 8388607.f};
+    for (int t = 0; t < 4; ++t) {
+      for (int sign = 0; sign < 2; ++sign) {
+        for (int l = 0; l < 64; ++l) {
+          for (int q = 0; q < 4; ++q) {
+            a[l * 4 + q] = 0x22222222u;
+            b[l * 4 + q] = sign ? 0xaaaaaaaau : 0x22222222u;
+          }
+        }
+        std::vector<float> c0(1024, starts[t]);
+        run_one(a, b, c0, c, da, db, dc, dd);
+        const double want = (double)starts[t] + (sign ? -64.0 : 64.0);
+        if ((double)c[5] != want) {
+          if (fabs(want) <= 16777216.0) {
+            printf("   %.1f %c 64 -> %.1f (expected %.1f)\n", starts[t], sign ? '-' : '+', c[5], want);
+            ok = 0;
+          }
+        }
+      }
+    }
+    // alternating signs inside one instruction: 32 x (+1) and 32 x (-1) on top of a large C
+    for (int l = 0; l < 64; ++l) {
+      for (int q = 0; q < 4; ++q) {
+        a[l * 4 + q] = 0x22222222u;
+        b[l * 4 + q] = (l < 32) ? 0x22222222u : 0xaaaaaaaau;
+      }
+    }
+    std::vector<float> c0(1024, 16777215.f);
+    run_one(a, b, c0, c, da, db, dc, dd);
+    if (c[7] != 16777215.f) {
+      printf("   16777215 + 32 - 32 -> %.1f\n", c[7]);
+      ok = 0;
+    }
+    printf("4. integer-exact accumulation up to 2^24: %s\n", ok ? "CONFIRMED" : "DIFFERENT");
+    bad += !ok;
+  }
+
+  // 5. rates
+  {
+    uint32_t* src;
+    float* out;
+    CHECK(hipMalloc(&src, 8192 * 4));
+    std::vector<uint32_t> h(8192);
+    for (int q = 0; q < 8192; ++q) {
+      h[q] = 0x9e3779b9u * (q + 1);
+    }
+    CHECK(hipMemcpy(src, h.data(), 8192 * 4, hipMemcpyHostToDevice));
+    const int blocks = 256 * 2 * 8;
+    CHECK(hipMalloc(&out, blocks * 256 * 4));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    const int iters = 2000;
+    for (int mode = 0; mode < 3; ++mode) {
+      for (int rep = 0; rep < 2; ++rep) {
+        CHECK(hipEventRecord(e0, 0));
+        if (mode == 0) {
+          hipLaunchKernelGGL(rate_kernel<0>, dim3(blocks), dim3(256), 0, 0, src, out, iters);
+        } else if (mode == 1) {
+          hipLaunchKernelGGL(rate_kernel<1>, dim3(blocks), dim3(256), 0, 0, src, out, iters);
+        } else {
+          hipLaunchKernelGGL(rate_kernel<2>, dim3(blocks), dim3(256), 0, 0, src, out, iters);
+        }
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) {
+          const double mfmas = (double)blocks * 4 * iters * 8;
+          const double macs = mfmas * 65536.0;
+          printf("5. mode %d (%s): %.3f ms, %.3e MAC/s = %.2f PFLOP/s, %.1f cycles/MFMA/SIMD at 2.4 GHz\n", mode,
+                 mode == 0 ? "MFMA only" : (mode == 1 ? "1 unpack per MFMA" : "LDS read + 7 unpacks per 8 MFMAs"), ms, macs / (ms * 1e-3),
+                 2 * macs / (ms * 1e-3) / 1e15, (ms * 1e-3) * 2.4e9 / (mfmas / 1024.0));
+        }
+      }
+    }
+  }
+  printf("probe: %s\n", bad ? "SOMETHING DIFFERS" : "all assumptions hold");
+  return bad ? 1 : 0;
+}
