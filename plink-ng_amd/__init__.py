@@ -64,7 +64,8 @@ class ldp_counters(ctypes.Structure):
                 ("pair_kernel_launches", ctypes.c_uint32), ("subcontig_ct", ctypes.c_uint32),
                 ("owned_subcontig_ct", ctypes.c_uint32), ("window_max", ctypes.c_uint32),
                 ("tile_unit_chunks", ctypes.c_uint64), ("early_exit_unit_chunks", ctypes.c_uint64),
-                ("ms_pair_mfma", ctypes.c_double), ("mfma_block_products", ctypes.c_uint64)]
+                ("ms_pair_mfma", ctypes.c_double), ("mfma_block_products", ctypes.c_uint64),
+                ("mfma_product_stages", ctypes.c_uint64), ("mfma_skipped_product_stages", ctypes.c_uint64)]
 
     def asdict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

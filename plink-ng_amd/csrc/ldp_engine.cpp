@@ -577,30 +577,19 @@ void plan_mfma(ldp_engine* e) {
       w.jv = static_cast<int32_t>(sfirst + kMfBlock * a);
       w.vv = w.jv - static_cast<int32_t>(kMfBlock * (4 * p + 3));
       w.jend = std::min(sfirst + s.len, static_cast<uint32_t>(w.jv) + 2 * kMfBlock);
-      const bool diag = (p == 0);
       w.blocks[0] = sfirst + kMfBlock * a;
       w.blocks[1] = sfirst + kMfBlock * (a + 1);
       for (int k = 0; k < 4; ++k) {
         const int32_t off = static_cast<int32_t>(4 * p + 3) - k;  // block distance of both (J0, V_k) and (J1, V_{k+1})
         if ((reach_of(a) >= off) && (static_cast<int32_t>(a) >= off)) {
           w.mask |= static_cast<uint8_t>(1u << k);
-          w.used |= 1u;
-          if (diag && (k == 3)) {
-            // (J0, J0)
-          } else {
-            w.used |= static_cast<uint8_t>(1u << (2 + k));
-            w.blocks[2 + k] = sfirst + kMfBlock * (a - static_cast<uint32_t>(off));
-          }
+          w.used |= static_cast<uint8_t>(1u | (1u << (2 + k)));
+          w.blocks[2 + k] = sfirst + kMfBlock * (a - static_cast<uint32_t>(off));  // (on the diagonal V3 is J0 itself)
         }
         if ((reach_of(a + 1) >= off) && (static_cast<int32_t>(a + 1) >= off)) {
           w.mask |= static_cast<uint8_t>(1u << (4 + k));
-          w.used |= 2u;
-          if (diag && (k >= 2)) {
-            w.used |= (k == 2) ? 1u : 0u;  // (J1, J0) reads J0 as its V block; (J1, J1) only J1
-          } else {
-            w.used |= static_cast<uint8_t>(1u << (3 + k));
-            w.blocks[3 + k] = sfirst + kMfBlock * (a + 1 - static_cast<uint32_t>(off));
-          }
+          w.used |= static_cast<uint8_t>(2u | (1u << (3 + k)));
+          w.blocks[3 + k] = sfirst + kMfBlock * (a + 1 - static_cast<uint32_t>(off));
         }
       }
       *out = w;
@@ -1570,6 +1559,8 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   e->ctr.ms_pair_general = kms_general;
   e->ctr.ms_pair_mfma = kms_mfma;
   e->ctr.mfma_block_products = e->mf_enabled ? e->mf_products : 0;
+  e->ctr.mfma_product_stages = e->ctr.mfma_block_products * ((e->P.founder_ct + kMfStageSamples - 1) / kMfStageSamples);
+  e->ctr.mfma_skipped_product_stages = h_counters[2];
   e->ctr.ms_replay = replayed ? replay_busy_ms : (t_end - t_replay);  // (time spent replaying, not waiting for groups)
   e->ctr.ms_run_total = t_end - t_start;
   e->ctr.pair_kernel_launches = launches;
@@ -2010,6 +2001,7 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
     HIP_TRY(e, hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, e->stream));
   }
   PairKernelArgs A;
+  fill_pair_args(e, &A, false);  // (defaults, incl. "no matrix-pipe work attached"; the matrix-mode fields follow)
   A.planes = e->d_planes;
   A.row_dwords = e->row_dwords;
   A.chunks = e->chunks;

@@ -19,6 +19,7 @@
 #include "ldp_device.h"
 #include "ldp_pair_device.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace ldp {
@@ -59,10 +60,16 @@ constexpr uint32_t kMfMaxStages = 4;
 
 // One stage (kMfStageSamples samples) of a wave's parallelogram.  (st4 is __restrict__ on purpose: without it hipcc
 // assumes the LDS-DMA in flight may alias these reads and drains it with s_waitcnt vmcnt(0) in front of every one.)
+// J fragments of all four k-steps stay in registers; the V blocks stream past them one at a time (two b128 LDS reads ->
+// 4 fragments -> 4 or 8 MFMAs), the next block's reads in flight while the current one is multiplied, so only two V
+// blocks' raw dwords are live next to the 128 accumulators.
 __device__ __forceinline__ void mfma_stage(const uint4* __restrict__ st4, const uint32_t (&slot_off)[7], uint32_t oH, uint32_t oR, uint32_t need,
-                                           uint32_t live, bool diag, mf_v16f (&acc)[8]) {
-  // J fragments of all four k-steps stay in registers; the V blocks stream past them one at a time (two b128 LDS
-  // reads -> 4 fragments -> 4 or 8 MFMAs), so only one V block's raw dwords are live next to the 128 accumulators.
+                                           uint32_t live, mf_v16f (&acc)[8]) {
+  uint4 vH[2], vR[2];
+  if (need & 4u) {
+    vH[0] = st4[slot_off[2] + oH];
+    vR[0] = st4[slot_off[2] + oR];
+  }
   Frag fj0[4], fj1[4];
   if (need & 1u) {
     const uint4 H = st4[slot_off[0] + oH], R = st4[slot_off[0] + oR];
@@ -79,31 +86,38 @@ __device__ __forceinline__ void mfma_stage(const uint4* __restrict__ st4, const 
     }
   }
   // rows of C = first variant (A operand: a V block), columns = second variant (B operand: a J block)
-#define LDP_MF_VBLOCK(u, P0, P1)                                                           \
+#define LDP_MF_VBLOCK(u, B, P0, P1)                                                        \
+  if (((u) < 6) && (need & (2u << (u)))) {                                                  \
+    vH[(B) ^ 1] = st4[slot_off[((u) < 6) ? (u) + 1 : 6] + oH];                              \
+    vR[(B) ^ 1] = st4[slot_off[((u) < 6) ? (u) + 1 : 6] + oR];                              \
+  }                                                                                        \
   if (need & (1u << (u))) {                                                                \
-    const uint4 H = st4[slot_off[u] + oH], R = st4[slot_off[u] + oR];                      \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                     \
       Frag fv;                                                                             \
-      fp4_of_planes(comp(H, ks), comp(R, ks), fv);                                         \
+      fp4_of_planes(comp(vH[B], ks), comp(vR[B], ks), fv);                                 \
       if ((P0 >= 0) && (live & (1u << (P0 & 7)))) acc[P0 & 7] = mfma_fp4(fv, fj0[ks], acc[P0 & 7]); \
       if ((P1 >= 0) && (live & (1u << (P1 & 7)))) acc[P1 & 7] = mfma_fp4(fv, fj1[ks], acc[P1 & 7]); \
     }                                                                                      \
   }
-  LDP_MF_VBLOCK(2, 0, -1)
-  LDP_MF_VBLOCK(3, 1, 4)
-  LDP_MF_VBLOCK(4, 2, 5)
-  if (diag) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (live & 0x08u) acc[3] = mfma_fp4(fj0[ks], fj0[ks], acc[3]);
-      if (live & 0x40u) acc[6] = mfma_fp4(fj0[ks], fj1[ks], acc[6]);
-      if (live & 0x80u) acc[7] = mfma_fp4(fj1[ks], fj1[ks], acc[7]);
-    }
-  } else {
-    LDP_MF_VBLOCK(5, 3, 6)
-    LDP_MF_VBLOCK(6, -1, 7)
-  }
+  LDP_MF_VBLOCK(2, 0, 0, -1)
+  LDP_MF_VBLOCK(3, 1, 1, 4)
+  LDP_MF_VBLOCK(4, 0, 2, 5)
+  LDP_MF_VBLOCK(5, 1, 3, 6)
+  LDP_MF_VBLOCK(6, 0, -1, 7)
 #undef LDP_MF_VBLOCK
+}
+
+// Row-blocks the live products of a wave read: bit u of the result = J0, J1, V0..V4.  (On the diagonal V3 / V4 are the
+// rows of J0 / J1 again and are simply expanded twice: a special case for them cost more in register copies around
+// the branches than the 2 of 7 expansions it saved.)
+__device__ __forceinline__ uint32_t blocks_needed(uint32_t live) {
+  uint32_t need = ((live & 0x0fu) ? 1u : 0u) | ((live & 0xf0u) ? 2u : 0u);
+  need |= (live & 0x01u) ? 4u : 0u;
+  need |= (live & 0x12u) ? 8u : 0u;
+  need |= (live & 0x24u) ? 16u : 0u;
+  need |= (live & 0x48u) ? 32u : 0u;
+  need |= (live & 0x80u) ? 64u : 0u;
+  return need;
 }
 
 // LDS image of a stage: row-block slot b, row r, 16-byte piece c (0, 1 = hom dwords 0-3, 4-7 of the stage; 2, 3 =
@@ -113,6 +127,7 @@ __device__ __forceinline__ void mfma_stage(const uint4* __restrict__ st4, const 
 __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_src_off[kMfMaxDmaPerWave * kMfWaves * 64];
+  __shared__ uint32_t s_need[kMfWaves];
   if (*A.any_missing) {
     return;  // rows with missing calls: the popcount kernels own this launch (7 counts per pair)
   }
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
 
   const uint32_t n_rb = __builtin_amdgcn_readfirstlane(wg->n_rb);
   const uint32_t n_instr = 2 * n_rb;  // DMA wave-instructions per stage (64 slots of 16 B each)
-  const uint32_t mine = (n_instr > wave) ? (n_instr - wave + kMfWaves - 1) / kMfWaves : 0;
+  uint32_t mine = (n_instr > wave) ? (n_instr - wave + kMfWaves - 1) / kMfWaves : 0;  // ... of which this wave issues
   const uint32_t stage_dwords = n_rb * kMfBlockStageDwords;
   uint32_t stages = A.lds_dwords / stage_dwords;
   stages = (stages > kMfMaxStages) ? kMfMaxStages : stages;
@@ -160,25 +175,13 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   const int32_t jv = __builtin_amdgcn_readfirstlane(wi->jv);
   const int32_t vv = __builtin_amdgcn_readfirstlane(wi->vv);
   const uint32_t jend = __builtin_amdgcn_readfirstlane(wi->jend);
-  const uint32_t live = (jv >= 0) ? __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wi->prod_mask)) : 0u;
-  const bool diag = (vv + 3 * kMfBlock == jv);
+  uint32_t live = (jv >= 0) ? __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wi->prod_mask)) : 0u;
   uint32_t slot_off[7];  // uint4 index of the row-block's first slot
 #pragma unroll
   for (int u = 0; u < 7; ++u) {
     slot_off[u] = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wi->slot[u])) * (kMfBlock * 4);
   }
-  // which row-blocks the live products read (on the diagonal V3 / V4 are J0 / J1)
-  uint32_t need = ((live & 0x0fu) ? 1u : 0u) | ((live & 0xf0u) ? 2u : 0u);
-  need |= (live & 0x01u) ? 4u : 0u;
-  need |= (live & 0x12u) ? 8u : 0u;
-  need |= (live & 0x24u) ? 16u : 0u;
-  if (!diag) {
-    need |= (live & 0x48u) ? 32u : 0u;
-    need |= (live & 0x80u) ? 64u : 0u;
-  } else {
-    need |= (live & 0x48u) ? 1u : 0u;  // V3 is J0
-    need |= (live & 0x80u) ? 2u : 0u;  // V4 is J1
-  }
+  uint32_t need = blocks_needed(live);
   const uint32_t sw = (r >> 2) & 3;
   const uint32_t oH = r * 4 + (h ^ sw);
   const uint32_t oR = r * 4 + ((2 + h) ^ sw);
@@ -192,13 +195,16 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
     }
   }
 
+  uint32_t wg_need = (1u << n_rb) - 1;  // row-block slots some wave still reads (all of them until a checkpoint says otherwise)
+  uint32_t next_cp = 0;
+  const uint32_t n_cp = A.cp_stats ? A.n_checkpoints : 0;
   auto dma_stage = [&](uint32_t s, uint32_t buf) {
     const uint32_t kbyte = (s >> 1) * (kRowChunkDwords * 4) + (s & 1) * 32;
     uint32_t* dst = lds + buf * stage_dwords;
 #pragma unroll
     for (int t = 0; t < kMfMaxDmaPerWave; ++t) {
       const uint32_t T = wave + kMfWaves * t;
-      if (T < n_instr) {
+      if ((T < n_instr) && ((wg_need >> (T >> 1)) & 1u)) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_t[t] + kbyte + s_src_off[t * (kMfWaves * 64) + tid]),
                                          (__attribute__((address_space(3))) void*)(dst + T * 256), 16, 0, 0);
       }
@@ -206,16 +212,121 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   };
 
   __syncthreads();  // (s_src_off is complete)
+  uint32_t* epi = lds + wave * kMfEpiWaveDwords;  // this wave's scratch whenever the ring is empty (checkpoints, epilogue)
+  // accumulators of the live products among 4 * round .. 4 * round + 3 -> epi[(pl * 16 + g) * 64 + lane], as integers
+  auto dump_round = [&](int round) {
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) {
+      if (live & (1u << (4 * round + pl))) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          epi[(pl * 16 + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>((round ? acc[4 + pl] : acc[pl])[g]));
+        }
+      }
+    }
+  };
   // ---- k-loop over stages of kMfStageSamples samples, ring of `stages` LDS buffers ----
-  uint32_t issued = 0, issue_buf = 0, read_buf = 0;
-  while ((issued < n_stages) && (issued + 1 < stages)) {
-    dma_stage(issued, issue_buf);
-    ++issued;
-    issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
-  }
+  // The ring never runs past the next checkpoint: when one fires every queued chunk has been consumed and the whole
+  // LDS is free for the checkpoint's scratch (the accumulators go through it so the bound is a rolled loop).
+  uint32_t issued = 0, issue_buf = 0, read_buf = 0, issued_base = 0;
+  uint32_t issue_limit = (next_cp < n_cp) ? 2 * A.checkpoint_chunk[next_cp] : n_stages;
+  issue_limit = (issue_limit < n_stages) ? issue_limit : n_stages;
+  auto ring_fill = [&]() {
+    issue_buf = 0;
+    read_buf = 0;
+    while ((issued < issue_limit) && (issued + 1 < issued_base + stages)) {
+      dma_stage(issued, issue_buf);
+      ++issued;
+      issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
+    }
+  };
+  ring_fill();
   for (uint32_t kc = 0; kc < n_stages; ++kc) {
+    if ((next_cp < n_cp) && (kc == 2 * A.checkpoint_chunk[next_cp])) {  // (block-uniform; issued == kc here)
+      // ---- checkpoint (ldp_device.h): drop the products whose candidate pairs are all provably below the threshold ----
+      __syncthreads();  // every wave is done with the last stage: LDS is scratch now
+      if (live) {
+        uint32_t keep = 0;
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+          if (!(live & (0xfu << (4 * round)))) {
+            continue;
+          }
+          dump_round(round);
+          const int64_t j64 = static_cast<int64_t>(jv) + kMfBlock * round + r;
+          const bool jvalid = (j64 < static_cast<int64_t>(jend));
+          const uint32_t j = jvalid ? static_cast<uint32_t>(j64) : static_cast<uint32_t>(jv);
+          const int64_t lo_j = jvalid ? static_cast<int64_t>(A.lo[j]) : j64;
+          const cp_slot cj = A.cp_stats[static_cast<uint64_t>(j) * kCpSlots + next_cp];
+          const cp_slot gj = A.cp_stats[static_cast<uint64_t>(j) * kCpSlots + kCheckpoints];
+#pragma unroll 1
+          for (uint32_t pl = 0; pl < 4; ++pl) {
+            if (!(live & (1u << (4 * round + pl)))) {
+              continue;
+            }
+            bool hopeless = true;
+            const int64_t vfirst = static_cast<int64_t>(vv) + kMfBlock * (pl + round) + 4 * h;
+#pragma unroll 2
+            for (uint32_t g = 0; g < 16; ++g) {
+              const int64_t i64 = vfirst + (g & 3) + 8 * (g >> 2);
+              if (jvalid && (i64 >= lo_j) && (i64 < j64)) {
+                const cp_slot ci = A.cp_stats[static_cast<uint64_t>(i64) * kCpSlots + next_cp];
+                const cp_slot gi = A.cp_stats[static_cast<uint64_t>(i64) * kCpSlots + kCheckpoints];
+                // |N dot - S_i S_j| <= |c0| + B, see pair_hopeless() in ldp_pair_device.h (dot_p is the partial dot product)
+                const double dot_p = static_cast<double>(static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]));
+                const double c0 = fma(static_cast<double>(A.founder_ct), dot_p, fma(ci.a, cj.a, -(gi.a * gj.a)));
+                const double bound = fabs(c0) + fma(ci.b, cj.b, 1.0);
+                hopeless = hopeless && (bound < gi.b * gj.b);
+              }
+            }
+            if (!__all(hopeless)) {
+              keep |= 1u << (4 * round + pl);
+            }
+          }
+        }
+        keep = __builtin_amdgcn_readfirstlane(keep);
+        if (keep != live) {
+          if (lane == 0) {
+            atomicAdd(A.counters + 2, static_cast<unsigned long long>(n_stages - kc) * __builtin_popcount(live & ~keep));
+          }
+          live = keep;
+          need = blocks_needed(live);
+        }
+      }
+      ++next_cp;
+      // which staged row-blocks does the workgroup still read?  Dead ones are no longer fetched.
+      if (lane == 0) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+          if (need & (1u << u)) {
+            m |= 1u << (slot_off[u] / (kMfBlock * 4));
+          }
+        }
+        s_need[wave] = m;
+      }
+      __syncthreads();
+      const uint32_t all_need = s_need[0] | s_need[1] | s_need[2] | s_need[3];
+      __syncthreads();  // (s_need is rewritten at the next checkpoint; the scratch reads above are over as well)
+      if (!all_need) {
+        break;  // nothing left that could reach the threshold
+      }
+      if (all_need != wg_need) {
+        wg_need = __builtin_amdgcn_readfirstlane(all_need);
+        mine = 0;
+#pragma unroll
+        for (int t = 0; t < kMfMaxDmaPerWave; ++t) {
+          const uint32_t T = wave + kMfWaves * t;
+          mine += ((T < n_instr) && ((wg_need >> (T >> 1)) & 1u)) ? 1u : 0u;
+        }
+      }
+      issue_limit = (next_cp < n_cp) ? 2 * A.checkpoint_chunk[next_cp] : n_stages;
+      issue_limit = (issue_limit < n_stages) ? issue_limit : n_stages;
+      issued_base = kc;
+      ring_fill();  // restart the ring at this stage
+    }
     wait_dma_then_barrier(mine * (issued - kc - 1));
-    if (issued < n_stages) {
+    if (issued < issue_limit) {
       dma_stage(issued, issue_buf);  // (reuses the buffer every wave finished reading before the barrier)
       ++issued;
       issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
@@ -225,29 +336,20 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
     if (!live) {
       continue;
     }
-    mfma_stage(st4, slot_off, oH, oR, need, live, diag, acc);
+    mfma_stage(st4, slot_off, oH, oR, need, live, acc);
   }
   __syncthreads();  // staging is over: LDS becomes the epilogue's scratch (a private region per wave)
 
   // ---- epilogue: accumulators through LDS so the per-pair code is a rolled loop ----
   // lane l, register g of a product holds first variant (g & 3) + 8 (g >> 2) + 4 (l >> 5) of the V block, second variant
   // l & 31 of the J block (tools/mfma_probe.hip, fact 1)
-  uint32_t* epi = lds + wave * kMfEpiWaveDwords;
   uint32_t n_true = 0;
 #pragma unroll
   for (int round = 0; round < 2; ++round) {
     if (!(live & (0xfu << (4 * round)))) {
       continue;
     }
-#pragma unroll
-    for (int pl = 0; pl < 4; ++pl) {
-      if (live & (1u << (4 * round + pl))) {
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          epi[(pl * 16 + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>(acc[4 * round + pl][g]));
-        }
-      }
-    }
+    dump_round(round);
     const int64_t j64 = static_cast<int64_t>(jv) + kMfBlock * round + r;
     if (j64 < static_cast<int64_t>(jend)) {
       const uint32_t j = static_cast<uint32_t>(j64);
@@ -292,10 +394,16 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
     return hipSuccess;
   }
   PairKernelArgs a = a_in;
-  const size_t lds = static_cast<size_t>(kMfLdsDwords) * sizeof(uint32_t);
-  a.lds_dwords = kMfLdsDwords;
-  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kMfLdsDwords * sizeof(uint32_t)));
-  (void)attr_rc;
+  // 64 KiB (+ 8 KiB static) lets two workgroups share a CU; LDP_DEBUG_MFMA_LDS_KB trades that for a deeper ring (tuning aid)
+  static const size_t lds = []() {
+    size_t bytes = static_cast<size_t>(kMfLdsDwords) * sizeof(uint32_t);
+    if (const char* kb = getenv("LDP_DEBUG_MFMA_LDS_KB")) {
+      bytes = std::max<size_t>(bytes, std::min<size_t>(static_cast<size_t>(atoi(kb)), 150) * 1024);
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    return bytes;
+  }();
+  a.lds_dwords = static_cast<uint32_t>(lds / sizeof(uint32_t));
   const uint32_t per_xcd = (a.n_mf_wgs + 7) / 8;
   if (ev) {
     (void)hipEventRecord(ev[0], stream);

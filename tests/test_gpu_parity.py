@@ -292,12 +292,13 @@ def test_early_termination_is_invisible(gpu_pkg, n, r2, order, miss):
     packed = T.pack_2bit(raw)
     off, c0 = _run_early_exit(gpu_pkg, packed, n, chr_idx, bps, 150, 1, False, r2, order, False)
     on, c1 = _run_early_exit(gpu_pkg, packed, n, chr_idx, bps, 150, 1, False, r2, order, True)
-    assert c0["early_exit_unit_chunks"] == 0
+    assert c0["early_exit_unit_chunks"] == 0 and c0["mfma_skipped_product_stages"] == 0
     assert np.array_equal(on, off)
     assert c1["pred_true"] == c0["pred_true"]
     assert c1["tile_unit_chunks"] == c0["tile_unit_chunks"] > 0
     if r2 >= 0.5 and miss <= 0.01:
-        assert c1["early_exit_unit_chunks"] > 0  # unrelated pairs are provably hopeless early on
+        # unrelated pairs are provably hopeless early on (whichever kernel family owned the tiles)
+        assert c1["early_exit_unit_chunks"] + c1["mfma_skipped_product_stages"] > 0
     inv, mf, _ = T.oracle_prepare(raw)
     want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 150, 1, False, r2, order)
     assert np.array_equal(on, want)
@@ -373,7 +374,10 @@ def test_early_termination_wide_window(gpu_pkg, miss):
     assert np.array_equal(off, want)
     assert np.array_equal(on, want)
     assert c1["pred_true"] == c0["pred_true"]
-    assert c1["early_exit_unit_chunks"] > 0.3 * c1["tile_unit_chunks"]
+    if c1["mfma_product_stages"] and miss == 0.0:   # complete data runs on the matrix-pipe kernel (block products x stages)
+        assert c1["mfma_skipped_product_stages"] > 0.3 * c1["mfma_product_stages"]
+    else:
+        assert c1["early_exit_unit_chunks"] > 0.3 * c1["tile_unit_chunks"]
 
 
 def test_randomised_differential(gpu_pkg):

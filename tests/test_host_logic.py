@@ -258,11 +258,7 @@ def _mfma_plan_coverage(pkg, m, nchr, seed, window, step, is_bp, spacing, rank=0
                 jfirst, vfirst = jv + 32 * q, vv + 32 * k
                 assert rb[slot[q]] == jfirst
                 assert vfirst >= 0
-                if diag and k >= 3:
-                    assert vfirst == jv + 32 * (k - 3)  # the kernel takes J0 / J1's fragments for V3 / V4
-                    assert rb[slot[k - 3]] == vfirst
-                else:
-                    assert rb[slot[2 + k]] == vfirst and slot[2 + k] < n_rb
+                assert rb[slot[2 + k]] == vfirst and slot[2 + k] < n_rb  # (on the diagonal V3 / V4 are J0 / J1 again)
                 for j in range(jfirst, min(jfirst + 32, jend)):
                     a, b = max(vfirst, int(lo[j])), min(vfirst + 32, j)
                     if a < b:
