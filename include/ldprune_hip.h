@@ -123,7 +123,7 @@ typedef struct {
   uint64_t early_exit_unit_chunks; /* ... and how many of them early termination skipped (provably sub-threshold tiles) */
   double ms_pair_mfma;             /* device time of pair_mfma_kernel (matrix-pipe tiles, complete data) in the last run */
   uint64_t mfma_block_products;    /* 32 x 32 block products of the matrix-pipe plan (0 when that path is off) */
-  uint64_t mfma_product_stages;    /* ... times the 256-sample stages of a row: the matrix-pipe work of an exhaustive run */
+  uint64_t mfma_product_stages;    /* ... times the 64-sample k-steps of a row: the MFMA instructions of an exhaustive run */
   uint64_t mfma_skipped_product_stages; /* ... and how much of it early termination skipped in the last run */
 } ldp_counters;
 

@@ -71,13 +71,11 @@ struct cp_gen_slot {
 // "parallelogram": second-variant blocks J0, J1 = J0 + 32 and first-variant blocks V0..V4 (consecutive), products
 //   (J0, V0) (J0, V1) (J0, V2) (J0, V3)   and   (J1, V1) (J1, V2) (J1, V3) (J1, V4),
 // i.e. both J blocks against the same four block distances; on the diagonal V3 = J0 and V4 = J1.  A workgroup of four
-// waves stages the union of its waves' row-blocks (<= kMfMaxRowBlocks) through LDS, kMfStageSamples samples at a time.
+// waves stages the union of its waves' row-blocks (<= kMfMaxRowBlocks) through LDS, 128 or 256 samples at a time.
 constexpr int kMfBlock = 32;
 constexpr int kMfMaxRowBlocks = 16;
-constexpr int kMfStageSamples = 256;        // 8 hom + 8 ref2het dwords per row and stage = 4 slots of 16 B
-constexpr int kMfStageRowDwords = 16;
 constexpr int kMfWaves = 4;
-constexpr int kMfMaxDmaPerWave = (2 * kMfMaxRowBlocks + kMfWaves - 1) / kMfWaves;  // 64 slots per DMA instruction
+constexpr int kMfMaxDmaPerWave = (2 * kMfMaxRowBlocks + kMfWaves - 1) / kMfWaves;  // (256-sample stages: two DMA instructions of 64 slots per row-block)
 constexpr uint32_t kMfMaxFounders = 16000000;  // f32 accumulators stay integer-exact
 
 struct MfmaWaveItem {
@@ -135,7 +133,6 @@ struct PairKernelArgs {
   const MfmaWG* mf_wgs;
   uint32_t n_mf_wgs;
   uint32_t n_local;              // rows in `planes`
-  uint32_t mf_stages;            // ceil(founder_ct / kMfStageSamples)
   uint32_t mf_active;            // the launch also carries matrix-pipe work items
   const uint32_t* any_missing;
 };
@@ -167,6 +164,7 @@ hipError_t launch_pair_stats_ref(const uint32_t* planes, uint64_t row_dwords, ui
 size_t pair_tiles_lds_bytes(uint32_t max_rows);
 // ev[0..1] (optional): recorded before/after the kernel
 hipError_t launch_pair_mfma(const PairKernelArgs& a, hipStream_t stream, hipEvent_t* ev);
+uint32_t pair_mfma_ksteps(uint32_t founder_ct);  // 64-sample k-steps per row (the unit of counters[2])
 
 // LDS rows of a work item that stages `units` 8-distance units starting at distance d0 (make_geom in the kernel)
 inline uint32_t tile_rows(uint32_t d0, uint32_t units) {

@@ -1263,7 +1263,6 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.mf_wgs = nullptr;
   A.n_mf_wgs = 0;
   A.n_local = e->local_ct;
-  A.mf_stages = (e->P.founder_ct + kMfStageSamples - 1) / kMfStageSamples;
   A.mf_active = 0;
   A.any_missing = nullptr;
 }
@@ -1559,7 +1558,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   e->ctr.ms_pair_general = kms_general;
   e->ctr.ms_pair_mfma = kms_mfma;
   e->ctr.mfma_block_products = e->mf_enabled ? e->mf_products : 0;
-  e->ctr.mfma_product_stages = e->ctr.mfma_block_products * ((e->P.founder_ct + kMfStageSamples - 1) / kMfStageSamples);
+  e->ctr.mfma_product_stages = e->ctr.mfma_block_products * pair_mfma_ksteps(e->P.founder_ct);
   e->ctr.mfma_skipped_product_stages = h_counters[2];
   e->ctr.ms_replay = replayed ? replay_busy_ms : (t_end - t_replay);  // (time spent replaying, not waiting for groups)
   e->ctr.ms_run_total = t_end - t_start;

@@ -24,6 +24,8 @@ __device__ __forceinline__ void wait_dma_then_barrier(uint32_t allowed) {
   switch (allowed) {
     LDP_WAIT_CASE(1) LDP_WAIT_CASE(2) LDP_WAIT_CASE(3) LDP_WAIT_CASE(4) LDP_WAIT_CASE(5) LDP_WAIT_CASE(6) LDP_WAIT_CASE(7)
     LDP_WAIT_CASE(8) LDP_WAIT_CASE(9) LDP_WAIT_CASE(10) LDP_WAIT_CASE(11) LDP_WAIT_CASE(12) LDP_WAIT_CASE(13) LDP_WAIT_CASE(14)
+    LDP_WAIT_CASE(15) LDP_WAIT_CASE(16) LDP_WAIT_CASE(17) LDP_WAIT_CASE(18) LDP_WAIT_CASE(19) LDP_WAIT_CASE(20) LDP_WAIT_CASE(21)
+    LDP_WAIT_CASE(22) LDP_WAIT_CASE(23) LDP_WAIT_CASE(24) LDP_WAIT_CASE(25) LDP_WAIT_CASE(26) LDP_WAIT_CASE(27) LDP_WAIT_CASE(28)
     default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
   }
 #undef LDP_WAIT_CASE

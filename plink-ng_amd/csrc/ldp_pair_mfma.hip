@@ -50,81 +50,148 @@ __device__ __forceinline__ mf_v16f mfma_fp4(const Frag& a, const Frag& b, mf_v16
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 
-__device__ __forceinline__ uint32_t comp(const uint4& v, int k) { return (k == 0) ? v.x : ((k == 1) ? v.y : ((k == 2) ? v.z : v.w)); }
+typedef uint32_t mf_u4 __attribute__((ext_vector_type(4)));  // (a native vector: usable as an inline-asm operand)
 
-constexpr uint32_t kMfBlockStageDwords = kMfBlock * kMfStageRowDwords;  // 512 dwords = 2 KiB per row-block and stage
 constexpr uint32_t kMfEpiProducts = 4;                                  // products per epilogue round
 constexpr uint32_t kMfEpiWaveDwords = kMfEpiProducts * 16 * 64;
 constexpr uint32_t kMfLdsDwords = kMfWaves * kMfEpiWaveDwords;          // 64 KiB: epilogue scratch == staging ring
-constexpr uint32_t kMfMaxStages = 4;
+constexpr uint32_t kMfMaxStages = 6;
+// checkpoint scratch: two products' accumulators per wave in the lower half, the staged rows' cp_slot pairs behind them
+constexpr uint32_t kMfCpWaveDwords = 2 * 16 * 64;
+constexpr uint32_t kMfCpScratchDwords = kMfWaves * kMfCpWaveDwords;  // 32 KiB in; kMfMaxRowBlocks * 32 rows * 32 B = 16 KiB follow
 
-// One stage (kMfStageSamples samples) of a wave's parallelogram.  (st4 is __restrict__ on purpose: without it hipcc
-// assumes the LDS-DMA in flight may alias these reads and drains it with s_waitcnt vmcnt(0) in front of every one.)
-// J fragments of all four k-steps stay in registers; the V blocks stream past them one at a time (two b128 LDS reads ->
-// 4 fragments -> 4 or 8 MFMAs), the next block's reads in flight while the current one is multiplied, so only two V
-// blocks' raw dwords are live next to the 128 accumulators.
-__device__ __forceinline__ void mfma_stage(const uint4* __restrict__ st4, const uint32_t (&slot_off)[7], uint32_t oH, uint32_t oR, uint32_t need,
-                                           uint32_t live, mf_v16f (&acc)[8]) {
-  uint4 vH[2], vR[2];
+// ---- geometry of a stage, by k-steps per stage (KS = 4: 256 samples, KS = 2: 128 samples) -------------------------
+// A k-step is one MFMA per product: 64 samples, lane half h supplying 32 of them (one dword of each plane).
+// LDS image of a stage: row-block slot b, row r, KS 16-byte pieces per row.
+//   KS = 4: pieces 0, 1 = hom dwords 0-3 / 4-7 of the stage, 2, 3 = ref2het; piece c sits at slot (32 b + r) * 4 +
+//           (c ^ ((r >> 2) & 3)); lane half h reads pieces h and 2 + h (its own 4 dwords = 4 k-steps).
+//   KS = 2: piece 0 = hom dwords 0-3, piece 1 = ref2het; slot (32 b + r) * 2 + (c ^ ((r >> 3) & 1)); both lane halves
+//           read both pieces (same address: a broadcast) and half h takes dwords 2h, 2h + 1.
+// The XOR makes the 16 lanes of every ds_read_b128 group hit 16 distinct 4-bank groups without padding, and the DMA
+// (lane-linear in LDS, free per-lane global address) simply fetches the piece that belongs in its slot.  Smaller
+// stages mean a deeper ring in the same LDS (more bytes in flight per CU) for one more barrier per 128 samples.
+template <int KS>
+struct StageGeom {
+  static constexpr uint32_t kRowSlots = KS;                       // 16-byte slots per row
+  static constexpr uint32_t kBlockSlots = kMfBlock * KS;          // per row-block (uint4 units)
+  static constexpr uint32_t kBlockDwords = kBlockSlots * 4;
+  static constexpr uint32_t kInstrPerBlock2 = KS;                 // DMA instructions per TWO row-blocks (64 slots each)
+  static constexpr uint32_t kStageSamples = 64 * KS;
+  static constexpr uint32_t kStagesPerChunk = (kChunkDwords * 32) / kStageSamples;
+  __device__ static uint32_t n_instr(uint32_t n_rb) { return (n_rb * KS + 1) / 2; }
+  __device__ static uint32_t block_of_instr(uint32_t T) { return (KS == 4) ? (T >> 1) : T; }
+  __device__ static uint32_t swizzle(uint32_t rr) { return (KS == 4) ? ((rr >> 2) & 3) : ((rr >> 3) & 1); }
+  // byte offset of piece `col` inside a row's 128-byte k-chunk, for the first stage of the chunk
+  __device__ static uint32_t piece_byte(uint32_t col) { return (KS == 4) ? ((col & 1) * 16 + (col >> 1) * 64) : (col * 64); }
+  __device__ static uint32_t stage_byte(uint32_t s) {
+    return (KS == 4) ? ((s >> 1) * (kRowChunkDwords * 4) + (s & 1) * 32) : ((s >> 2) * (kRowChunkDwords * 4) + (s & 3) * 16);
+  }
+};
+
+// (Keeps hipcc from folding what follows into the LDS reads that produced a and b: a select between two dwords of a
+// loaded vector is otherwise re-written into loads that have lost the __restrict__ information, and each of them then
+// waits for the whole DMA ring, see mfma_stage.)
+__device__ __forceinline__ void opaque(mf_u4& a, mf_u4& b) { asm("" : "+v"(a), "+v"(b)); }
+
+// One lane's two plane dwords of k-step ks from the raw LDS reads
+template <int KS>
+__device__ __forceinline__ void kstep_dwords(const mf_u4& H, const mf_u4& R, int ks, uint32_t h, uint32_t* hd, uint32_t* rd) {
+  if constexpr (KS == 4) {
+    *hd = H[ks];
+    *rd = R[ks];
+  } else {
+    *hd = h ? H[2 + ks] : H[ks];
+    *rd = h ? R[2 + ks] : R[ks];
+  }
+}
+
+// One stage of a wave's parallelogram.  (st4 is __restrict__ on purpose: without it hipcc assumes the LDS-DMA in flight
+// may alias these reads and drains it with s_waitcnt vmcnt(0) in front of every one.)
+// J fragments of all k-steps of the stage stay in registers; the V blocks stream past them one at a time (two b128 LDS
+// reads -> KS fragments -> KS or 2 KS MFMAs), the next block's reads in flight while the current one is multiplied, so
+// only two V blocks' raw dwords are live next to the 128 accumulators.  On the diagonal (V3 = J0, V4 = J1) the last
+// two blocks take the J fragments instead of reading and expanding the same rows again; the MFMAs themselves are the
+// same instructions either way (a branch around them costs a register copy of every accumulator it touches).
+template <int KS>
+__device__ __forceinline__ void mfma_stage(const mf_u4* __restrict__ st4, const uint32_t (&slot_off)[7], uint32_t oH, uint32_t oR, uint32_t h, uint32_t need,
+                                           uint32_t live, bool diag, mf_v16f (&acc)[8]) {
+  mf_u4 vH[2], vR[2];
   if (need & 4u) {
     vH[0] = st4[slot_off[2] + oH];
     vR[0] = st4[slot_off[2] + oR];
   }
-  Frag fj0[4], fj1[4];
+  Frag fj0[KS], fj1[KS];
   if (need & 1u) {
-    const uint4 H = st4[slot_off[0] + oH], R = st4[slot_off[0] + oR];
+    mf_u4 H = st4[slot_off[0] + oH], R = st4[slot_off[0] + oR];
+    opaque(H, R);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      fp4_of_planes(comp(H, ks), comp(R, ks), fj0[ks]);
+    for (int ks = 0; ks < KS; ++ks) {
+      uint32_t hd, rd;
+      kstep_dwords<KS>(H, R, ks, h, &hd, &rd);
+      fp4_of_planes(hd, rd, fj0[ks]);
     }
   }
   if (need & 2u) {
-    const uint4 H = st4[slot_off[1] + oH], R = st4[slot_off[1] + oR];
+    mf_u4 H = st4[slot_off[1] + oH], R = st4[slot_off[1] + oR];
+    opaque(H, R);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      fp4_of_planes(comp(H, ks), comp(R, ks), fj1[ks]);
+    for (int ks = 0; ks < KS; ++ks) {
+      uint32_t hd, rd;
+      kstep_dwords<KS>(H, R, ks, h, &hd, &rd);
+      fp4_of_planes(hd, rd, fj1[ks]);
     }
   }
   // rows of C = first variant (A operand: a V block), columns = second variant (B operand: a J block)
-#define LDP_MF_VBLOCK(u, B, P0, P1)                                                        \
+  // u: row-block (2..6 = V0..V4), B: raw buffer, PM: the products that read it, P0 / P1: its product with J0 / J1 (-1: none),
+  // ALIAS: on the diagonal the block IS J0 (0) / J1 (1) (-1: never)
+#define LDP_MF_VBLOCK(u, B, PM, P0, P1, ALIAS)                                             \
   if (((u) < 6) && (need & (2u << (u)))) {                                                  \
     vH[(B) ^ 1] = st4[slot_off[((u) < 6) ? (u) + 1 : 6] + oH];                              \
     vR[(B) ^ 1] = st4[slot_off[((u) < 6) ? (u) + 1 : 6] + oR];                              \
   }                                                                                        \
-  if (need & (1u << (u))) {                                                                \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                     \
+  if (live & (PM)) {                                                                       \
+    opaque(vH[B], vR[B]);                                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                    \
       Frag fv;                                                                             \
-      fp4_of_planes(comp(vH[B], ks), comp(vR[B], ks), fv);                                 \
+      if (((ALIAS) >= 0) && diag) {                                                        \
+        fv = ((ALIAS) == 1) ? fj1[ks] : fj0[ks];                                           \
+      } else {                                                                             \
+        uint32_t hd, rd;                                                                   \
+        kstep_dwords<KS>(vH[B], vR[B], ks, h, &hd, &rd);                                   \
+        fp4_of_planes(hd, rd, fv);                                                         \
+      }                                                                                    \
       if ((P0 >= 0) && (live & (1u << (P0 & 7)))) acc[P0 & 7] = mfma_fp4(fv, fj0[ks], acc[P0 & 7]); \
       if ((P1 >= 0) && (live & (1u << (P1 & 7)))) acc[P1 & 7] = mfma_fp4(fv, fj1[ks], acc[P1 & 7]); \
     }                                                                                      \
   }
-  LDP_MF_VBLOCK(2, 0, 0, -1)
-  LDP_MF_VBLOCK(3, 1, 1, 4)
-  LDP_MF_VBLOCK(4, 0, 2, 5)
-  LDP_MF_VBLOCK(5, 1, 3, 6)
-  LDP_MF_VBLOCK(6, 0, -1, 7)
+  LDP_MF_VBLOCK(2, 0, 0x01u, 0, -1, -1)
+  LDP_MF_VBLOCK(3, 1, 0x12u, 1, 4, -1)
+  LDP_MF_VBLOCK(4, 0, 0x24u, 2, 5, -1)
+  LDP_MF_VBLOCK(5, 1, 0x48u, 3, 6, 0)
+  LDP_MF_VBLOCK(6, 0, 0x80u, -1, 7, 1)
 #undef LDP_MF_VBLOCK
 }
 
-// Row-blocks the live products of a wave read: bit u of the result = J0, J1, V0..V4.  (On the diagonal V3 / V4 are the
-// rows of J0 / J1 again and are simply expanded twice: a special case for them cost more in register copies around
-// the branches than the 2 of 7 expansions it saved.)
-__device__ __forceinline__ uint32_t blocks_needed(uint32_t live) {
+// Row-blocks whose LDS rows the live products of a wave read: bit u of the result = J0, J1, V0..V4 (on the diagonal V3 /
+// V4 are J0 / J1 and are not read a second time)
+__device__ __forceinline__ uint32_t blocks_needed(uint32_t live, bool diag) {
   uint32_t need = ((live & 0x0fu) ? 1u : 0u) | ((live & 0xf0u) ? 2u : 0u);
   need |= (live & 0x01u) ? 4u : 0u;
   need |= (live & 0x12u) ? 8u : 0u;
   need |= (live & 0x24u) ? 16u : 0u;
-  need |= (live & 0x48u) ? 32u : 0u;
-  need |= (live & 0x80u) ? 64u : 0u;
+  if (diag) {
+    need |= (live & 0x48u) ? 1u : 0u;
+    need |= (live & 0x80u) ? 2u : 0u;
+  } else {
+    need |= (live & 0x48u) ? 32u : 0u;
+    need |= (live & 0x80u) ? 64u : 0u;
+  }
   return need;
 }
 
-// LDS image of a stage: row-block slot b, row r, 16-byte piece c (0, 1 = hom dwords 0-3, 4-7 of the stage; 2, 3 =
-// ref2het) sits at 16-byte slot (32 b + r) * 4 + (c ^ ((r >> 2) & 3)).  The XOR makes the 16 lanes of every
-// ds_read_b128 group (rows r, r + 1, ... of one piece) hit 16 distinct 4-bank groups without padding, and the DMA
-// (lane-linear in LDS, free per-lane global address) simply fetches the piece that belongs in its slot.
+template <int KS>
 __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelArgs A) {
+  using G = StageGeom<KS>;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_src_off[kMfMaxDmaPerWave * kMfWaves * 64];
   __shared__ uint32_t s_need[kMfWaves];
@@ -144,13 +211,13 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   const uint32_t h = lane >> 5;
 
   const uint32_t n_rb = __builtin_amdgcn_readfirstlane(wg->n_rb);
-  const uint32_t n_instr = 2 * n_rb;  // DMA wave-instructions per stage (64 slots of 16 B each)
+  const uint32_t n_instr = G::n_instr(n_rb);  // DMA wave-instructions per stage (64 slots of 16 B each)
   uint32_t mine = (n_instr > wave) ? (n_instr - wave + kMfWaves - 1) / kMfWaves : 0;  // ... of which this wave issues
-  const uint32_t stage_dwords = n_rb * kMfBlockStageDwords;
+  const uint32_t stage_dwords = n_instr * 256;
   uint32_t stages = A.lds_dwords / stage_dwords;
   stages = (stages > kMfMaxStages) ? kMfMaxStages : stages;
   const uint32_t row_bytes = static_cast<uint32_t>(A.row_dwords * sizeof(uint32_t));
-  const uint32_t n_stages = A.mf_stages;
+  const uint32_t n_stages = (A.founder_ct + G::kStageSamples - 1) / G::kStageSamples;
 
   // ---- DMA plan: per-lane source offsets (LDS) and per-instruction row-block bases (uniform) ----
   const uint8_t* base_t[kMfMaxDmaPerWave];
@@ -159,14 +226,15 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
     const uint32_t T = wave + kMfWaves * t;
     base_t[t] = reinterpret_cast<const uint8_t*>(A.planes);
     if (T < n_instr) {
-      const uint32_t first = __builtin_amdgcn_readfirstlane(wg->rb[T >> 1]);
+      const uint32_t blk = G::block_of_instr(T);
+      const uint32_t first = __builtin_amdgcn_readfirstlane(wg->rb[(blk < n_rb) ? blk : (n_rb - 1)]);
       base_t[t] += static_cast<uint64_t>(first) * row_bytes;
       const uint32_t L = T * 64 + lane;
-      const uint32_t rr = (L >> 2) & 31;
-      const uint32_t col = (L & 3) ^ ((rr >> 2) & 3);
+      const uint32_t rr = (L / KS) & 31;
+      const uint32_t col = (L % KS) ^ G::swizzle(rr);
       uint32_t var = first + rr;
       var = (var < A.n_local) ? var : (A.n_local - 1);
-      s_src_off[t * (kMfWaves * 64) + tid] = (var - first) * row_bytes + (col & 1) * 16 + (col >> 1) * 64;
+      s_src_off[t * (kMfWaves * 64) + tid] = (var - first) * row_bytes + G::piece_byte(col);
     }
   }
 
@@ -176,15 +244,33 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   const int32_t vv = __builtin_amdgcn_readfirstlane(wi->vv);
   const uint32_t jend = __builtin_amdgcn_readfirstlane(wi->jend);
   uint32_t live = (jv >= 0) ? __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wi->prod_mask)) : 0u;
+  const bool diag = (vv + 3 * kMfBlock == jv);
   uint32_t slot_off[7];  // uint4 index of the row-block's first slot
 #pragma unroll
   for (int u = 0; u < 7; ++u) {
-    slot_off[u] = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wi->slot[u])) * (kMfBlock * 4);
+    slot_off[u] = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wi->slot[u])) * G::kBlockSlots;
   }
-  uint32_t need = blocks_needed(live);
-  const uint32_t sw = (r >> 2) & 3;
-  const uint32_t oH = r * 4 + (h ^ sw);
-  const uint32_t oR = r * 4 + ((2 + h) ^ sw);
+  uint32_t need = blocks_needed(live, diag);
+  // window starts of this lane's two second variants (J0 + r, J1 + r), fetched here: the k-loop must not hold ordinary
+  // global loads (see the checkpoint)
+  uint32_t lo_j2[2] = {0xffffffffu, 0xffffffffu};  // (lo >= j: no candidate pair)
+  if (jv >= 0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t j = static_cast<uint32_t>(jv) + kMfBlock * q + r;
+      if (j < jend) {
+        lo_j2[q] = A.lo[j];
+      }
+    }
+  }
+  uint32_t slots_packed = 0;  // LDS row-block slot of J0, J1, V0..V4, 4 bits each (for the checkpoint's rolled loops)
+#pragma unroll
+  for (int u = 0; u < 7; ++u) {
+    slots_packed |= (slot_off[u] / G::kBlockSlots) << (4 * u);
+  }
+  const uint32_t sw = G::swizzle(r);
+  const uint32_t oH = (KS == 4) ? (r * 4 + (h ^ sw)) : (r * 2 + sw);
+  const uint32_t oR = (KS == 4) ? (r * 4 + ((2 + h) ^ sw)) : (r * 2 + (1 ^ sw));
 
   mf_v16f acc[8];
 #pragma unroll
@@ -199,16 +285,29 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   uint32_t next_cp = 0;
   const uint32_t n_cp = A.cp_stats ? A.n_checkpoints : 0;
   auto dma_stage = [&](uint32_t s, uint32_t buf) {
-    const uint32_t kbyte = (s >> 1) * (kRowChunkDwords * 4) + (s & 1) * 32;
+    const uint32_t kbyte = G::stage_byte(s);
     uint32_t* dst = lds + buf * stage_dwords;
 #pragma unroll
     for (int t = 0; t < kMfMaxDmaPerWave; ++t) {
       const uint32_t T = wave + kMfWaves * t;
-      if ((T < n_instr) && ((wg_need >> (T >> 1)) & 1u)) {
+      if ((T < n_instr) && ((wg_need >> G::block_of_instr(T)) & 1u)) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_t[t] + kbyte + s_src_off[t * (kMfWaves * 64) + tid]),
                                          (__attribute__((address_space(3))) void*)(dst + T * 256), 16, 0, 0);
       }
     }
+  };
+  auto count_mine = [&]() {
+    uint32_t m = 0;
+#pragma unroll
+    for (int t = 0; t < kMfMaxDmaPerWave; ++t) {
+      const uint32_t T = wave + kMfWaves * t;
+      m += ((T < n_instr) && ((wg_need >> G::block_of_instr(T)) & 1u)) ? 1u : 0u;
+    }
+    return m;
+  };
+  auto checkpoint_stage = [&](uint32_t cp) {
+    const uint32_t s = A.checkpoint_chunk[cp] * G::kStagesPerChunk;
+    return (s < n_stages) ? s : n_stages;
   };
 
   __syncthreads();  // (s_src_off is complete)
@@ -225,12 +324,11 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
       }
     }
   };
-  // ---- k-loop over stages of kMfStageSamples samples, ring of `stages` LDS buffers ----
+  // ---- k-loop over stages, ring of `stages` LDS buffers ----
   // The ring never runs past the next checkpoint: when one fires every queued chunk has been consumed and the whole
   // LDS is free for the checkpoint's scratch (the accumulators go through it so the bound is a rolled loop).
   uint32_t issued = 0, issue_buf = 0, read_buf = 0, issued_base = 0;
-  uint32_t issue_limit = (next_cp < n_cp) ? 2 * A.checkpoint_chunk[next_cp] : n_stages;
-  issue_limit = (issue_limit < n_stages) ? issue_limit : n_stages;
+  uint32_t issue_limit = (next_cp < n_cp) ? checkpoint_stage(next_cp) : n_stages;
   auto ring_fill = [&]() {
     issue_buf = 0;
     read_buf = 0;
@@ -242,55 +340,89 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   };
   ring_fill();
   for (uint32_t kc = 0; kc < n_stages; ++kc) {
-    if ((next_cp < n_cp) && (kc == 2 * A.checkpoint_chunk[next_cp])) {  // (block-uniform; issued == kc here)
+    if ((next_cp < n_cp) && (kc == checkpoint_stage(next_cp))) {  // (block-uniform; issued == kc here)
       // ---- checkpoint (ldp_device.h): drop the products whose candidate pairs are all provably below the threshold ----
       __syncthreads();  // every wave is done with the last stage: LDS is scratch now
+      // The checkpoint statistics (ldp_device.h: cp_slot) of every staged row come in by LDS-DMA as well, slot next_cp and
+      // the whole-row slot, 32 bytes per row behind the accumulator scratch.  Ordinary global loads inside the k-loop
+      // would make hipcc drain the ring (s_waitcnt vmcnt(0)) in front of EVERY LDS read of the loop, not just here.
+      {
+        const uint8_t* cps = reinterpret_cast<const uint8_t*>(A.cp_stats);
+#pragma unroll
+        for (int t = 0; t < kMfMaxDmaPerWave; ++t) {
+          const uint32_t T = wave + kMfWaves * t;  // row-block slot T: 32 rows x 2 pieces
+          if (T < n_rb) {
+            const uint32_t first = __builtin_amdgcn_readfirstlane(wg->rb[T]);
+            uint32_t var = first + (lane >> 1);
+            var = (var < A.n_local) ? var : (A.n_local - 1);
+            const uint64_t off = static_cast<uint64_t>(var) * (kCpSlots * sizeof(cp_slot)) + ((lane & 1) ? kCheckpoints : next_cp) * sizeof(cp_slot);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cps + off),
+                                             (__attribute__((address_space(3))) void*)(lds + kMfCpScratchDwords + T * 256), 16, 0, 0);
+          }
+        }
+      }
+      __syncthreads();  // (drains the DMA: the slots are in LDS)
+      const cp_slot* __restrict__ cpl = reinterpret_cast<const cp_slot*>(lds + kMfCpScratchDwords);  // [row-block slot][row][2]
       if (live) {
         uint32_t keep = 0;
+        uint32_t* cp_epi = lds + wave * kMfCpWaveDwords;  // two products per round
 #pragma unroll
-        for (int round = 0; round < 2; ++round) {
-          if (!(live & (0xfu << (4 * round)))) {
+        for (int round = 0; round < 4; ++round) {
+          if (!(live & (0x3u << (2 * round)))) {
             continue;
           }
-          dump_round(round);
-          const int64_t j64 = static_cast<int64_t>(jv) + kMfBlock * round + r;
-          const bool jvalid = (j64 < static_cast<int64_t>(jend));
-          const uint32_t j = jvalid ? static_cast<uint32_t>(j64) : static_cast<uint32_t>(jv);
-          const int64_t lo_j = jvalid ? static_cast<int64_t>(A.lo[j]) : j64;
-          const cp_slot cj = A.cp_stats[static_cast<uint64_t>(j) * kCpSlots + next_cp];
-          const cp_slot gj = A.cp_stats[static_cast<uint64_t>(j) * kCpSlots + kCheckpoints];
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            if (live & (1u << (2 * round + pl))) {
+#pragma unroll
+              for (int g = 0; g < 16; ++g) {
+                cp_epi[(pl * 16 + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>(acc[2 * round + pl][g]));
+              }
+            }
+          }
+          const int q = (round >= 2) ? 1 : 0;
+          const int64_t j64 = static_cast<int64_t>(jv) + kMfBlock * q + r;
+          const int64_t lo_j = lo_j2[q];
+          const uint32_t jslot = (slots_packed >> (4 * q)) & 15u;
+          const cp_slot cj = cpl[(jslot * kMfBlock + r) * 2];
+          const cp_slot gj = cpl[(jslot * kMfBlock + r) * 2 + 1];
 #pragma unroll 1
-          for (uint32_t pl = 0; pl < 4; ++pl) {
-            if (!(live & (1u << (4 * round + pl)))) {
+          for (uint32_t pl = 0; pl < 2; ++pl) {
+            const uint32_t p = 2 * round + pl;
+            if (!(live & (1u << p))) {
               continue;
             }
+            const uint32_t k = (p & 3) + q;  // V block of the product
+            const uint32_t vslot = (slots_packed >> (4 * (2 + k))) & 15u;
             bool hopeless = true;
-            const int64_t vfirst = static_cast<int64_t>(vv) + kMfBlock * (pl + round) + 4 * h;
+            const int64_t vfirst = static_cast<int64_t>(vv) + kMfBlock * k + 4 * h;
 #pragma unroll 2
             for (uint32_t g = 0; g < 16; ++g) {
-              const int64_t i64 = vfirst + (g & 3) + 8 * (g >> 2);
-              if (jvalid && (i64 >= lo_j) && (i64 < j64)) {
-                const cp_slot ci = A.cp_stats[static_cast<uint64_t>(i64) * kCpSlots + next_cp];
-                const cp_slot gi = A.cp_stats[static_cast<uint64_t>(i64) * kCpSlots + kCheckpoints];
+              const uint32_t row = (g & 3) + 8 * (g >> 2) + 4 * h;
+              const int64_t i64 = static_cast<int64_t>(vv) + kMfBlock * k + row;
+              if ((i64 >= lo_j) && (i64 < j64)) {
+                const cp_slot ci = cpl[(vslot * kMfBlock + row) * 2];
+                const cp_slot gi = cpl[(vslot * kMfBlock + row) * 2 + 1];
                 // |N dot - S_i S_j| <= |c0| + B, see pair_hopeless() in ldp_pair_device.h (dot_p is the partial dot product)
-                const double dot_p = static_cast<double>(static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]));
+                const double dot_p = static_cast<double>(static_cast<int32_t>(cp_epi[(pl * 16 + g) * 64 + lane]));
                 const double c0 = fma(static_cast<double>(A.founder_ct), dot_p, fma(ci.a, cj.a, -(gi.a * gj.a)));
                 const double bound = fabs(c0) + fma(ci.b, cj.b, 1.0);
                 hopeless = hopeless && (bound < gi.b * gj.b);
               }
             }
+            (void)vfirst;
             if (!__all(hopeless)) {
-              keep |= 1u << (4 * round + pl);
+              keep |= 1u << p;
             }
           }
         }
         keep = __builtin_amdgcn_readfirstlane(keep);
         if (keep != live) {
           if (lane == 0) {
-            atomicAdd(A.counters + 2, static_cast<unsigned long long>(n_stages - kc) * __builtin_popcount(live & ~keep));
+            atomicAdd(A.counters + 2, static_cast<unsigned long long>(n_stages - kc) * KS * __builtin_popcount(live & ~keep));
           }
           live = keep;
-          need = blocks_needed(live);
+          need = blocks_needed(live, diag);
         }
       }
       ++next_cp;
@@ -300,7 +432,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
           if (need & (1u << u)) {
-            m |= 1u << (slot_off[u] / (kMfBlock * 4));
+            m |= 1u << (slot_off[u] / G::kBlockSlots);
           }
         }
         s_need[wave] = m;
@@ -313,15 +445,9 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
       }
       if (all_need != wg_need) {
         wg_need = __builtin_amdgcn_readfirstlane(all_need);
-        mine = 0;
-#pragma unroll
-        for (int t = 0; t < kMfMaxDmaPerWave; ++t) {
-          const uint32_t T = wave + kMfWaves * t;
-          mine += ((T < n_instr) && ((wg_need >> (T >> 1)) & 1u)) ? 1u : 0u;
-        }
+        mine = count_mine();
       }
-      issue_limit = (next_cp < n_cp) ? 2 * A.checkpoint_chunk[next_cp] : n_stages;
-      issue_limit = (issue_limit < n_stages) ? issue_limit : n_stages;
+      issue_limit = (next_cp < n_cp) ? checkpoint_stage(next_cp) : n_stages;
       issued_base = kc;
       ring_fill();  // restart the ring at this stage
     }
@@ -331,12 +457,12 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
       ++issued;
       issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
     }
-    const uint4* __restrict__ st4 = reinterpret_cast<const uint4*>(lds + read_buf * stage_dwords);
+    const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * stage_dwords);
     read_buf = (read_buf + 1 == stages) ? 0 : read_buf + 1;
     if (!live) {
       continue;
     }
-    mfma_stage(st4, slot_off, oH, oR, need, live, acc);
+    mfma_stage<KS>(st4, slot_off, oH, oR, h, need, live, diag, acc);
   }
   __syncthreads();  // staging is over: LDS becomes the epilogue's scratch (a private region per wave)
 
@@ -353,7 +479,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
     const int64_t j64 = static_cast<int64_t>(jv) + kMfBlock * round + r;
     if (j64 < static_cast<int64_t>(jend)) {
       const uint32_t j = static_cast<uint32_t>(j64);
-      const uint32_t lo_j = A.lo[j];
+      const uint32_t lo_j = lo_j2[round];
       if (lo_j < j) {
         const int32_t sum_j = A.recs[j].sum;
         const uint32_t ssq_j = A.recs[j].ssq;
@@ -394,13 +520,20 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
     return hipSuccess;
   }
   PairKernelArgs a = a_in;
+  // 128-sample stages by default: config 2's workgroups stage 11 row-blocks, 22 KiB per 256 samples, i.e. two ring buffers
+  // in the 64 KiB that let two workgroups share a CU -- too few bytes in flight for HBM (measured, profiles/).
+  static const int ks = []() {
+    const char* k = getenv("LDP_DEBUG_MFMA_KS");
+    return (k && (atoi(k) == 4)) ? 4 : 2;
+  }();
   // 64 KiB (+ 8 KiB static) lets two workgroups share a CU; LDP_DEBUG_MFMA_LDS_KB trades that for a deeper ring (tuning aid)
   static const size_t lds = []() {
     size_t bytes = static_cast<size_t>(kMfLdsDwords) * sizeof(uint32_t);
     if (const char* kb = getenv("LDP_DEBUG_MFMA_LDS_KB")) {
       bytes = std::max<size_t>(bytes, std::min<size_t>(static_cast<size_t>(atoi(kb)), 150) * 1024);
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
     return bytes;
   }();
   a.lds_dwords = static_cast<uint32_t>(lds / sizeof(uint32_t));
@@ -408,11 +541,22 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
   if (ev) {
     (void)hipEventRecord(ev[0], stream);
   }
-  hipLaunchKernelGGL(pair_mfma_kernel, dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
+  if (ks == 4) {
+    hipLaunchKernelGGL(pair_mfma_kernel<4>, dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
+  } else {
+    hipLaunchKernelGGL(pair_mfma_kernel<2>, dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
+  }
   if (ev) {
     (void)hipEventRecord(ev[1], stream);
   }
   return hipGetLastError();
+}
+
+// 64-sample k-steps per row as the kernel counts them (counters[2] is in product x k-step units)
+uint32_t pair_mfma_ksteps(uint32_t founder_ct) {
+  const char* k = getenv("LDP_DEBUG_MFMA_KS");
+  const uint32_t ks = (k && (atoi(k) == 4)) ? 4 : 2;
+  return ((founder_ct + 64 * ks - 1) / (64 * ks)) * ks;
 }
 
 }  // namespace ldp
