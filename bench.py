@@ -305,7 +305,7 @@ def main():
                                  "ceiling of that op mix",
                          "valu_lane_ops_per_pair_dword": ops_per_pair_dword, "valu_lane_ops_per_s": (executed_lane_ops / (kms * 1e-3)) if kms > 0 else 0.0, "valu_mix_peak": valu_mix_peak,
                          "valu_frac": (executed_lane_ops / (kms * 1e-3)) / valu_mix_peak if kms > 0 else 0.0},
-            "stage_ms": {"prepare_kernel": float(np.mean(prep_ms)), "pair_kernel": kms, "pair_mfma_kernel": float(np.mean(mfma_ms)),
+            "stage_ms": {"prepare_kernel": float(np.mean(prep_ms)), "pair_kernel": kms, "pair_mfma_kernel": float(np.mean(mfma_ms)), "pair_mfma_general_kernel": ctr["ms_pair_mfma_general"],
                          "host_replay": float(np.mean(replay_ms))},
             "early_termination": {"tile_unit_chunks": ctr["tile_unit_chunks"], "skipped_unit_chunks": ctr["early_exit_unit_chunks"],
                                   "skipped_frac": (ctr["early_exit_unit_chunks"] / ctr["tile_unit_chunks"]) if ctr["tile_unit_chunks"] else 0.0},

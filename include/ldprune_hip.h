@@ -125,6 +125,7 @@ typedef struct {
   uint64_t mfma_block_products;    /* 32 x 32 block products of the matrix-pipe plan (0 when that path is off) */
   uint64_t mfma_product_stages;    /* ... times the 64-sample k-steps of a row: the MFMA instructions of an exhaustive run */
   uint64_t mfma_skipped_product_stages; /* ... and how much of it early termination skipped in the last run */
+  double ms_pair_mfma_general;     /* device time of pair_mfma_general_kernel (matrix-pipe tiles with missing calls) */
 } ldp_counters;
 
 /* ---- lifecycle ---- */

@@ -65,7 +65,8 @@ class ldp_counters(ctypes.Structure):
                 ("owned_subcontig_ct", ctypes.c_uint32), ("window_max", ctypes.c_uint32),
                 ("tile_unit_chunks", ctypes.c_uint64), ("early_exit_unit_chunks", ctypes.c_uint64),
                 ("ms_pair_mfma", ctypes.c_double), ("mfma_block_products", ctypes.c_uint64),
-                ("mfma_product_stages", ctypes.c_uint64), ("mfma_skipped_product_stages", ctypes.c_uint64)]
+                ("mfma_product_stages", ctypes.c_uint64), ("mfma_skipped_product_stages", ctypes.c_uint64),
+                ("ms_pair_mfma_general", ctypes.c_double)]
 
     def asdict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -129,7 +129,8 @@ struct PairKernelArgs {
   uint64_t r2_hit_capacity;
   double r2_min;
   // matrix-pipe tiles (launch_pair_mfma); any_missing (one word, written by prepare_kernel) routes a whole launch:
-  // non-zero -> the popcount kernels do the work, zero -> the matrix-pipe kernel does (when mf_active)
+  // zero -> pair_mfma_kernel (complete data), non-zero -> pair_mfma_general_kernel; mf_active = 1: the popcount
+  // kernels of the launch only run for non-zero (the general matrix-pipe kernel is off), 2: they never run
   const MfmaWG* mf_wgs;
   uint32_t n_mf_wgs;
   uint32_t n_local;              // rows in `planes`
@@ -162,9 +163,10 @@ hipError_t launch_pair_stats_ref(const uint32_t* planes, uint64_t row_dwords, ui
                                  const uint32_t* first, const uint32_t* second, uint32_t n_pairs,
                                  ldp_pair_stats_t* out, hipStream_t stream);
 size_t pair_tiles_lds_bytes(uint32_t max_rows);
-// ev[0..1] (optional): recorded before/after the kernel
+// ev[0..2] (optional): recorded before the complete-data kernel, between it and the missing-calls kernel, and after
 hipError_t launch_pair_mfma(const PairKernelArgs& a, hipStream_t stream, hipEvent_t* ev);
-uint32_t pair_mfma_ksteps(uint32_t founder_ct);  // 64-sample k-steps per row (the unit of counters[2])
+uint32_t pair_mfma_ksteps(uint32_t founder_ct);
+bool pair_mfma_general_enabled();  // missing-calls tiles on the matrix pipe too (else: popcount kernels)  // 64-sample k-steps per row (the unit of counters[2])
 
 // LDS rows of a work item that stages `units` 8-distance units starting at distance d0 (make_geom in the kernel)
 inline uint32_t tile_rows(uint32_t d0, uint32_t units) {

@@ -117,7 +117,7 @@ struct ldp_engine {
     bool launched = false;
     hipEvent_t ev_ready = nullptr;
     hipEvent_t ev_done = nullptr;         // kernels finished and the group's predicate words are back on the host
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // popcount fast / general, matrix pipe
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // popcount fast / general, matrix pipe complete | general
   };
   std::vector<PairGroup> groups;
   // Matrix-pipe plan of the same band (ldp_pair_mfma.hip): used for complete data, founder_ct <= kMfMaxFounders
@@ -283,7 +283,7 @@ void free_device(ldp_engine* e) {
       g.ev_ready = nullptr;
       g.ev_done = nullptr;
     }
-    for (int q = 0; q < 6; ++q) {
+    for (int q = 0; q < 7; ++q) {
       if (g.ev[q]) {
         (void)hipEventDestroy(g.ev[q]);
         g.ev[q] = nullptr;
@@ -886,7 +886,7 @@ int ensure_device_plan(ldp_engine* e) {
   for (ldp_engine::PairGroup& g : e->groups) {
     HIP_TRY(e, hipEventCreateWithFlags(&g.ev_ready, hipEventDisableTiming));
     HIP_TRY(e, hipEventCreateWithFlags(&g.ev_done, hipEventDisableTiming));
-    for (int q = 0; q < 6; ++q) {
+    for (int q = 0; q < 7; ++q) {
       HIP_TRY(e, hipEventCreate(&g.ev[q]));
     }
   }
@@ -1306,7 +1306,7 @@ int launch_group(ldp_engine* e, uint32_t gi) {
     // Which kernel family owns the group is decided on the device, once per group: a snapshot of the missing-calls flag
     // (all of the group's rows are converted by now) that every kernel of the group reads.
     HIP_TRY(e, hipMemcpyAsync(e->d_any_missing + 1 + gi, e->d_any_missing, sizeof(uint32_t), hipMemcpyDeviceToDevice, ps));
-    A.mf_active = 1;
+    A.mf_active = pair_mfma_general_enabled() ? 2 : 1;
     A.any_missing = e->d_any_missing + 1 + gi;
     A.mf_wgs = e->d_mf_wgs + g.mf_first;
     A.n_mf_wgs = g.mf_ct;
@@ -1376,7 +1376,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   HIP_TRY(e, hipSetDevice(e->device));
   DevBuf stats_buf;
   ldp_pair_stats_t* d_stats = nullptr;
-  float kms = 0.f, kms_fast = 0.f, kms_general = 0.f, kms_mfma = 0.f;
+  float kms = 0.f, kms_fast = 0.f, kms_general = 0.f, kms_mfma = 0.f, kms_mfma_general = 0.f;
   uint32_t launches = 0;
   std::vector<double> mf_scratch;
   const double* mf = nullptr;
@@ -1405,14 +1405,14 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     PairKernelArgs A;
     fill_pair_args(e, &A, false);
     A.stats = d_stats;
-    hipEvent_t evk[6];
-    for (int q = 0; q < 6; ++q) {
+    hipEvent_t evk[7];
+    for (int q = 0; q < 7; ++q) {
       HIP_TRY(e, hipEventCreate(&evk[q]));
     }
     if (e->mf_enabled) {
       const size_t slot = 1 + e->groups.size();
       HIP_TRY(e, hipMemcpyAsync(e->d_any_missing + slot, e->d_any_missing, sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
-      A.mf_active = 1;
+      A.mf_active = pair_mfma_general_enabled() ? 2 : 1;
       A.any_missing = e->d_any_missing + slot;
       A.mf_wgs = e->d_mf_wgs;
       A.n_mf_wgs = static_cast<uint32_t>(e->mf_wgs.size());
@@ -1444,10 +1444,11 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
       HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[2], evk[3]));
       if (e->mf_enabled && !e->mf_wgs.empty()) {
         HIP_TRY(e, hipEventElapsedTime(&kms_mfma, evk[4], evk[5]));
+        HIP_TRY(e, hipEventElapsedTime(&kms_mfma_general, evk[5], evk[6]));
       }
       launches = 1;
     }
-    for (int q = 0; q < 6; ++q) {
+    for (int q = 0; q < 7; ++q) {
       (void)hipEventDestroy(evk[q]);
     }
     // the next plain run recomputes with the production settings
@@ -1516,9 +1517,11 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
       HIP_TRY(e, hipEventElapsedTime(&f, g.ev[0], g.ev[1]));
       HIP_TRY(e, hipEventElapsedTime(&gen, g.ev[2], g.ev[3]));
       if (e->mf_enabled && g.mf_ct) {
-        float mf = 0.f;
+        float mf = 0.f, mfg = 0.f;
         HIP_TRY(e, hipEventElapsedTime(&mf, g.ev[4], g.ev[5]));
+        HIP_TRY(e, hipEventElapsedTime(&mfg, g.ev[5], g.ev[6]));
         kms_mfma += mf;
+        kms_mfma_general += mfg;
       }
       kms_fast += f;
       kms_general += gen;
@@ -1530,7 +1533,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   for (int q = 0; q < 4; ++q) {
     h_counters[q] = e->h_counters_pin[q];  // (the stream that carried the copy has been synchronised in both branches)
   }
-  kms = kms_fast + kms_general + kms_mfma;
+  kms = kms_fast + kms_general + kms_mfma + kms_mfma_general;
   if (!replayed) {
     rc = prepare_mf(e, &mf_scratch, &mf);
     if (rc) {
@@ -1557,6 +1560,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   e->ctr.ms_pair_fast = kms_fast;
   e->ctr.ms_pair_general = kms_general;
   e->ctr.ms_pair_mfma = kms_mfma;
+  e->ctr.ms_pair_mfma_general = kms_mfma_general;
   e->ctr.mfma_block_products = e->mf_enabled ? e->mf_products : 0;
   e->ctr.mfma_product_stages = e->ctr.mfma_block_products * pair_mfma_ksteps(e->P.founder_ct);
   e->ctr.mfma_skipped_product_stages = h_counters[2];

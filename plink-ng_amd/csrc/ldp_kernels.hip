@@ -908,8 +908,8 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_ker
   if (item_idx >= A.n_items) {
     return;
   }
-  if (A.mf_active && !*A.any_missing) {
-    return;  // complete data everywhere: pair_mfma_kernel owns this launch (ldp_pair_mfma.hip)
+  if ((A.mf_active == 2) || (A.mf_active && !*A.any_missing)) {
+    return;  // the matrix-pipe kernels own this launch (ldp_pair_mfma.hip)
   }
   const uint32_t item_class = A.item_general[item_idx];  // classify_items_kernel: 0 complete, 1 / 2 missing calls
   if ((item_class != 0) != GENERAL) {

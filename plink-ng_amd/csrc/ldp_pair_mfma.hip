@@ -515,6 +515,198 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   }
 }
 
+// ================================================================================================
+// tiles with missing calls: all six statistics of ComputeIndepPairwiseR2Components on the matrix pipe
+// ================================================================================================
+// With missing calls the statistics run over the pairwise-complete samples (plink2_ld.cc:699-723, SumSsqWords :317-335,
+// SumSsqNmWords :578-602).  Per variant three vectors over the samples: x in {-1, 0, +1} as above, n = 1 where the call
+// is present (hom | ref2het), h = x^2 (hom).  For first variant i and second variant j:
+//   dot = x_i.x_j   nm = n_i.n_j   ssq2 = n_i.h_j   sum2 = n_i.x_j   ssq1 = h_i.n_j   sum1 = x_i.n_j
+// six integer matrix products instead of one, against seven popcounts instead of two on the VALU path.  (The nibble
+// code of x is -x, see fp4_of_planes: dot is unaffected, the two sums come out negated and are flipped in the epilogue.)
+// A workgroup owns ONE second-variant block of a wave item and its (up to) four first-variant blocks, one product per
+// wave: 6 x 16 accumulator registers, the J block's three fragment sets of the stage kept in registers.
+__device__ __forceinline__ void fp4_nh_of_planes(uint32_t H, uint32_t R, const Frag& fx, Frag& fn, Frag& fh) {
+  const uint32_t N = H | R;  // call present
+  fn.d[0] = (N << 1) & 0x22222222u;
+  fn.d[1] = N & 0x22222222u;
+  fn.d[2] = (N >> 1) & 0x22222222u;
+  fn.d[3] = (N >> 2) & 0x22222222u;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    fh.d[q] = fx.d[q] & 0x22222222u;  // |x|
+  }
+}
+
+constexpr uint32_t kMfGenRowBlocks = 5;  // J, V0..V3 of the workgroup
+constexpr uint32_t kMfGenInstr = kMfGenRowBlocks * 2;
+constexpr uint32_t kMfGenDmaPerWave = (kMfGenInstr + kMfWaves - 1) / kMfWaves;
+
+__global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_general_kernel(PairKernelArgs A) {
+  using G = StageGeom<4>;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ uint32_t s_src_off[kMfGenDmaPerWave * kMfWaves * 64];
+  if (!*A.any_missing) {
+    return;  // complete data: pair_mfma_kernel owns this launch
+  }
+  const uint32_t n_blocks = A.n_mf_wgs * 8;  // workgroup x wave item x J block
+  const uint32_t per_xcd = (n_blocks + 7) / 8;
+  const uint32_t idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (idx >= n_blocks) {
+    return;
+  }
+  const MfmaWG* __restrict__ wg = A.mf_wgs + (idx >> 3);
+  const MfmaWaveItem* __restrict__ wi = wg->w + ((idx >> 1) & 3);
+  const uint32_t q = idx & 1;
+  const int32_t jv0 = wi->jv;
+  if (jv0 < 0) {
+    return;
+  }
+  const uint32_t mask4 = (static_cast<uint32_t>(wi->prod_mask) >> (4 * q)) & 0xfu;
+  if (!mask4) {
+    return;
+  }
+  const uint32_t tid = threadIdx.x;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lane = tid & 63;
+  const uint32_t r = lane & 31;
+  const uint32_t h = lane >> 5;
+  const int32_t jfirst = jv0 + static_cast<int32_t>(kMfBlock * q);
+  const int32_t vv = wi->vv;
+  const uint32_t jend = wi->jend;
+  const bool live = (mask4 >> wave) & 1u;  // this wave's product: (J_q, V_{q + wave})
+  const int32_t vfirst_blk = vv + static_cast<int32_t>(kMfBlock * (q + wave));
+  const uint32_t row_bytes = static_cast<uint32_t>(A.row_dwords * sizeof(uint32_t));
+  const uint32_t n_stages = (A.founder_ct + G::kStageSamples - 1) / G::kStageSamples;
+  const uint32_t stage_dwords = kMfGenInstr * 256;
+  uint32_t stages = A.lds_dwords / stage_dwords;
+  stages = (stages > kMfMaxStages) ? kMfMaxStages : stages;
+  const uint32_t mine = (kMfGenInstr > wave) ? (kMfGenInstr - wave + kMfWaves - 1) / kMfWaves : 0;
+
+  // ---- DMA plan: row-block slot 0 = the J block, 1 + t = V_{q + t} (a block without candidate pairs is not read: its slot
+  // simply fetches the J rows again)
+  const uint8_t* base_t[kMfGenDmaPerWave];
+#pragma unroll
+  for (int t = 0; t < static_cast<int>(kMfGenDmaPerWave); ++t) {
+    const uint32_t T = wave + kMfWaves * t;
+    base_t[t] = reinterpret_cast<const uint8_t*>(A.planes);
+    if (T < kMfGenInstr) {
+      const uint32_t blk = T >> 1;
+      int32_t first = jfirst;
+      if ((blk > 0) && ((mask4 >> (blk - 1)) & 1u)) {
+        first = vv + static_cast<int32_t>(kMfBlock * (q + blk - 1));
+      }
+      first = __builtin_amdgcn_readfirstlane(first);
+      base_t[t] += static_cast<uint64_t>(static_cast<uint32_t>(first)) * row_bytes;
+      const uint32_t L = T * 64 + lane;
+      const uint32_t rr = (L >> 2) & 31;
+      const uint32_t col = (L & 3) ^ G::swizzle(rr);
+      uint32_t var = static_cast<uint32_t>(first) + rr;
+      var = (var < A.n_local) ? var : (A.n_local - 1);
+      s_src_off[t * (kMfWaves * 64) + tid] = (var - static_cast<uint32_t>(first)) * row_bytes + G::piece_byte(col);
+    }
+  }
+  auto dma_stage = [&](uint32_t s, uint32_t buf) {
+    const uint32_t kbyte = G::stage_byte(s);
+    uint32_t* dst = lds + buf * stage_dwords;
+#pragma unroll
+    for (int t = 0; t < static_cast<int>(kMfGenDmaPerWave); ++t) {
+      const uint32_t T = wave + kMfWaves * t;
+      if (T < kMfGenInstr) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_t[t] + kbyte + s_src_off[t * (kMfWaves * 64) + tid]),
+                                         (__attribute__((address_space(3))) void*)(dst + T * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  // window start, subcontig end of this lane's second variant
+  const int64_t j64 = static_cast<int64_t>(jfirst) + r;
+  uint32_t lo_j = 0xffffffffu;
+  if (j64 < static_cast<int64_t>(jend)) {
+    lo_j = A.lo[static_cast<uint32_t>(j64)];
+  }
+  const uint32_t sw = G::swizzle(r);
+  const uint32_t oH = r * 4 + (h ^ sw);
+  const uint32_t oR = r * 4 + ((2 + h) ^ sw);
+  const uint32_t v_slot = (1 + wave) * G::kBlockSlots;
+
+  mf_v16f acc[6];  // [0] x.x  [1] n.n  [2] n_i.h_j  [3] n_i.x_j  [4] h_i.n_j  [5] x_i.n_j
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      acc[c][g] = 0.f;
+    }
+  }
+  __syncthreads();  // (s_src_off is complete)
+  uint32_t issued = 0, issue_buf = 0, read_buf = 0;
+  while ((issued < n_stages) && (issued + 1 < stages)) {
+    dma_stage(issued, issue_buf);
+    ++issued;
+    issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
+  }
+  for (uint32_t kc = 0; kc < n_stages; ++kc) {
+    wait_dma_then_barrier(mine * (issued - kc - 1));
+    if (issued < n_stages) {
+      dma_stage(issued, issue_buf);
+      ++issued;
+      issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
+    }
+    const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * stage_dwords);
+    read_buf = (read_buf + 1 == stages) ? 0 : read_buf + 1;
+    if (!live) {
+      continue;
+    }
+    mf_u4 jH = st4[oH], jR = st4[oR];
+    mf_u4 vH = st4[v_slot + oH], vR = st4[v_slot + oR];
+    opaque(jH, jR);
+    Frag jx[4], jn[4], jh[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fp4_of_planes(jH[ks], jR[ks], jx[ks]);
+      fp4_nh_of_planes(jH[ks], jR[ks], jx[ks], jn[ks], jh[ks]);
+    }
+    opaque(vH, vR);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      Frag vx, vn, vh;
+      fp4_of_planes(vH[ks], vR[ks], vx);
+      fp4_nh_of_planes(vH[ks], vR[ks], vx, vn, vh);
+      // rows of C = first variant i (A operand: the V block), columns = second variant j (B operand: the J block)
+      acc[0] = mfma_fp4(vx, jx[ks], acc[0]);
+      acc[1] = mfma_fp4(vn, jn[ks], acc[1]);
+      acc[2] = mfma_fp4(vn, jh[ks], acc[2]);
+      acc[3] = mfma_fp4(vn, jx[ks], acc[3]);
+      acc[4] = mfma_fp4(vh, jn[ks], acc[4]);
+      acc[5] = mfma_fp4(vx, jn[ks], acc[5]);
+    }
+  }
+  // ---- epilogue: straight from the registers (one product per wave) ----
+  uint32_t n_true = 0;
+  if (live && (lo_j != 0xffffffffu) && (static_cast<int64_t>(lo_j) < j64)) {
+    const uint32_t j = static_cast<uint32_t>(j64);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int64_t i64 = static_cast<int64_t>(vfirst_blk) + (g & 3) + 8 * (g >> 2) + 4 * h;
+      if ((i64 >= static_cast<int64_t>(lo_j)) && (i64 < j64)) {
+        ldp_pair_stats_t ps;
+        ps.dot = static_cast<int32_t>(acc[0][g]);
+        ps.nm = static_cast<uint32_t>(static_cast<int32_t>(acc[1][g]));
+        ps.ssq2 = static_cast<uint32_t>(static_cast<int32_t>(acc[2][g]));
+        ps.sum2 = -static_cast<int32_t>(acc[3][g]);
+        ps.ssq1 = static_cast<uint32_t>(static_cast<int32_t>(acc[4][g]));
+        ps.sum1 = -static_cast<int32_t>(acc[5][g]);
+        n_true += emit_pair(A, static_cast<uint32_t>(i64), j, lo_j, ps) ? 1 : 0;
+      }
+    }
+  }
+  n_true = wave_reduce_add(n_true);
+  if ((lane == 0) && n_true) {
+    atomicAdd(A.counters, static_cast<unsigned long long>(n_true));
+  }
+}
+
+
 hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipEvent_t* ev) {
   if (!a_in.n_mf_wgs) {
     return hipSuccess;
@@ -549,7 +741,31 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
   if (ev) {
     (void)hipEventRecord(ev[1], stream);
   }
+  // the same plan for launches whose rows have missing calls: one workgroup per (wave item, second-variant block)
+  static const bool general_on = []() {
+    const char* g = getenv("LDP_PAIR_MFMA_GENERAL");
+    return !(g && (atoi(g) == 0));
+  }();
+  if (general_on) {
+    static const size_t glds = []() {
+      const size_t bytes = static_cast<size_t>(kMfLdsDwords) * sizeof(uint32_t);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+      return bytes;
+    }();
+    PairKernelArgs g = a_in;
+    g.lds_dwords = static_cast<uint32_t>(glds / sizeof(uint32_t));
+    const uint32_t gper_xcd = (g.n_mf_wgs * 8 + 7) / 8;
+    hipLaunchKernelGGL(pair_mfma_general_kernel, dim3(gper_xcd * 8), dim3(kMfWaves * 64), glds, stream, g);
+  }
+  if (ev) {
+    (void)hipEventRecord(ev[2], stream);
+  }
   return hipGetLastError();
+}
+
+bool pair_mfma_general_enabled() {
+  const char* g = getenv("LDP_PAIR_MFMA_GENERAL");
+  return !(g && (atoi(g) == 0));
 }
 
 // 64-sample k-steps per row as the kernel counts them (counters[2] is in product x k-step units)
