@@ -154,6 +154,7 @@ struct PrepareArgs {
   uint32_t checkpoint_chunk[kCheckpoints];
   uint32_t n_checkpoints;
   uint32_t* any_missing;         // set to 1 when a converted row has missing calls (may be nullptr)
+  bool fix_cp_gen;               // redo cp_gen for rows with missing calls (cp_gen_fix_kernel)
 };
 
 hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream);

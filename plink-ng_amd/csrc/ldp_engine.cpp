@@ -737,7 +737,10 @@ void build_shard(ldp_engine* e) {
   {
     // ~4 groups of decreasing size (40/30/20/10 %): what is exposed after the last kernel is that group's copy back
     // and replay, so it should be the small one
-    uint32_t kTargetGroups = 4;
+    // (the matrix-pipe kernel runs ~4,000 workgroups of four waves at config 2 on 512 resident slots: small groups leave
+    // the chip half empty at their tails -- 1 / 2 / 4 groups: 4.25 / 4.6 / 5.0 ms of kernel, 10.84 / 10.87 / 11.17 ms per
+    // step with the replay of all but the last group hidden)
+    uint32_t kTargetGroups = e->mf_enabled ? 2 : 4;
     if (const char* tg = getenv("LDP_DEBUG_GROUPS")) {
       kTargetGroups = std::max(1, atoi(tg));
     }
@@ -2305,6 +2308,7 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
       }
       PA.n_checkpoints = e->n_checkpoints;
       PA.any_missing = e->d_any_missing;
+      PA.fix_cp_gen = !(e->mf_enabled && pair_mfma_general_enabled());  // (only the popcount kernel's interval bound reads cp_gen)
       if (!e->prep_pending) {
         HIP_TRY(e, hipEventRecord(e->prep_ev0, e->stream));
         e->prep_pending = true;

@@ -488,7 +488,7 @@ hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream) {
     LDP_PREP(1024, 0);
   }
 #undef LDP_PREP
-  if (a.cp_stats && a.n_checkpoints) {
+  if (a.cp_stats && a.n_checkpoints && a.fix_cp_gen) {
     hipLaunchKernelGGL(cp_gen_fix_kernel, dim3((a.n_variants + 3) / 4), dim3(256), 0, stream, a);
   }
   return hipGetLastError();

@@ -712,11 +712,12 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
     return hipSuccess;
   }
   PairKernelArgs a = a_in;
-  // 128-sample stages by default: config 2's workgroups stage 11 row-blocks, 22 KiB per 256 samples, i.e. two ring buffers
-  // in the 64 KiB that let two workgroups share a CU -- too few bytes in flight for HBM (measured, profiles/).
+  // 256-sample stages (four k-steps between barriers).  128-sample stages double the ring depth in the same LDS but were
+  // measured slower everywhere (config 2: 7.4 vs 5.0 ms, config-3 density: 80 vs 53 ms; profiles/): the extra barrier and
+  // the lane-half select cost more than the deeper ring buys.  LDP_DEBUG_MFMA_KS=2 selects them (tuning aid).
   static const int ks = []() {
     const char* k = getenv("LDP_DEBUG_MFMA_KS");
-    return (k && (atoi(k) == 4)) ? 4 : 2;
+    return (k && (atoi(k) == 2)) ? 2 : 4;
   }();
   // 64 KiB (+ 8 KiB static) lets two workgroups share a CU; LDP_DEBUG_MFMA_LDS_KB trades that for a deeper ring (tuning aid)
   static const size_t lds = []() {
@@ -771,7 +772,7 @@ bool pair_mfma_general_enabled() {
 // 64-sample k-steps per row as the kernel counts them (counters[2] is in product x k-step units)
 uint32_t pair_mfma_ksteps(uint32_t founder_ct) {
   const char* k = getenv("LDP_DEBUG_MFMA_KS");
-  const uint32_t ks = (k && (atoi(k) == 4)) ? 4 : 2;
+  const uint32_t ks = (k && (atoi(k) == 2)) ? 2 : 4;
   return ((founder_ct + 64 * ks - 1) / (64 * ks)) * ks;
 }
 
