@@ -1,0 +1,72 @@
+"""Parity at BASELINE configs 3 and 5's sample count (N = 500,000), where the covariance numerators reach ~6e22 and the
+FP64 predicate (plink2_ld.cc:1085-1090) works on 2^53-scale integers: `plink2-hip --indep-pairwise 500kb 0.2` against the
+reference binary on a 20,020-variant x 500,000-sample slice of the benchmark generator (22 chromosomes, 300 bp spacing, the
+window reaches ~1,667 variants: the same band density as config 3), complete data, 0.1 % and 5 % missing calls
+(configs 3 / 5).  Files must be byte-identical.  Also: bench.py's own step under torch.distributed.run with one rank, so
+that init_process_group("nccl") and the RCCL all_gather of the prune bitmask run on whatever GPU box runs the suite."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(REPO, "oracle", "_ref", "plink2")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("miss", [0.0, 0.001, 0.05])
+def test_config3_sample_count_files_identical_to_reference(gpu_pkg, tmp_path, miss):
+    import torch
+    import bench
+    if not os.path.exists(REF):
+        pytest.fail("oracle/_ref/plink2 is missing (build() makes it where /root/reference exists; it travels with the snapshot)")
+    cli = gpu_pkg.build_cli()
+    n, m = 500000, 20020
+    chr_idx, bps = bench.genome_layout(m, 1, 300)
+    stride = (n + 3) // 4
+    buf = torch.empty((m, stride), dtype=torch.uint8, device="cuda")
+    gpu_pkg.synth_genotypes_device(bench.SEED + 1, 0, m, n, miss, buf.data_ptr(), stride)
+    torch.cuda.synchronize()
+    host = buf.cpu().numpy()
+    del buf
+    torch.cuda.empty_cache()
+    prefix = str(tmp_path / "c3")
+    bench.write_plink1_fileset(prefix, host, n, chr_idx, bps)
+    del host
+    cores = os.cpu_count() or 1
+    ref = subprocess.run([REF, "--bfile", "c3", "--indep-pairwise", "500kb", "0.2", "--threads", str(cores), "--out", "ref"], cwd=str(tmp_path),
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert ref.returncode == 0, ref.stdout[-1500:]
+    hip = subprocess.run([cli, "--bfile", "c3", "--indep-pairwise", "500kb", "0.2", "--out", "hip"], cwd=str(tmp_path),
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert hip.returncode == 0, hip.stdout[-1500:]
+    for ext in (".prune.in", ".prune.out"):
+        a = open(os.path.join(str(tmp_path), "ref" + ext), "rb").read()
+        b = open(os.path.join(str(tmp_path), "hip" + ext), "rb").read()
+        assert a == b, "%s differs (%d vs %d bytes)" % (ext, len(a), len(b))
+    removed = len(open(os.path.join(str(tmp_path), "ref.prune.out")).read().split())
+    assert 0.1 * m < removed < 0.9 * m  # the slice really is pruned (LD chains of the generator)
+    os.remove(prefix + ".bed")
+
+
+@pytest.mark.gpu
+def test_bench_step_under_torchrun_initialises_rccl(gpu_pkg, tmp_path):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29577",
+           os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--variants", "60000", "--samples", "20000",
+           "--no-cpu-baseline", "--no-legs"]
+    cp = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["config"]["variants_removed"] > 0
+    # the same workload without a process group must prune the same variants (the exchange is an identity at one rank)
+    cp2 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "0", "--variants", "60000", "--samples", "20000",
+                          "--no-cpu-baseline", "--no-legs"], cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert cp2.returncode == 0, cp2.stderr[-2000:]
+    j2 = json.loads([ln for ln in cp2.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j2["config"]["variants_removed"] == j["config"]["variants_removed"]
