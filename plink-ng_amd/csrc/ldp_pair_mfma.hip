@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace ldp {
 
@@ -112,9 +113,16 @@ __device__ __forceinline__ void kstep_dwords(const mf_u4& H, const mf_u4& R, int
 // only two V blocks' raw dwords are live next to the 128 accumulators.  On the diagonal (V3 = J0, V4 = J1) the last
 // two blocks take the J fragments instead of reading and expanding the same rows again; the MFMAs themselves are the
 // same instructions either way (a branch around them costs a register copy of every accumulator it touches).
-template <int KS>
+template <int KS, bool ALL>
 __device__ __forceinline__ void mfma_stage(const mf_u4* __restrict__ st4, const uint32_t (&slot_off)[7], uint32_t oH, uint32_t oR, uint32_t h, uint32_t need,
                                            uint32_t live, bool diag, mf_v16f (&acc)[8]) {
+  // ALL: every product is live and no block is aliased (the common state before the first checkpoint of a wide band):
+  // the same code without a single test or branch -- 7 SALU instructions per MFMA in the masked form (profiles/)
+  if constexpr (ALL) {
+    need = 0x7fu;
+    live = 0xffu;
+    diag = false;
+  }
   mf_u4 vH[2], vR[2];
   if (need & 4u) {
     vH[0] = st4[slot_off[2] + oH];
@@ -339,130 +347,146 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
     }
   };
   ring_fill();
-  for (uint32_t kc = 0; kc < n_stages; ++kc) {
-    if ((next_cp < n_cp) && (kc == checkpoint_stage(next_cp))) {  // (block-uniform; issued == kc here)
-      // ---- checkpoint (ldp_device.h): drop the products whose candidate pairs are all provably below the threshold ----
-      __syncthreads();  // every wave is done with the last stage: LDS is scratch now
-      // The checkpoint statistics (ldp_device.h: cp_slot) of every staged row come in by LDS-DMA as well, slot next_cp and
-      // the whole-row slot, 32 bytes per row behind the accumulator scratch.  Ordinary global loads inside the k-loop
-      // would make hipcc drain the ring (s_waitcnt vmcnt(0)) in front of EVERY LDS read of the loop, not just here.
-      {
-        const uint8_t* cps = reinterpret_cast<const uint8_t*>(A.cp_stats);
+  // The stages between two checkpoints, with the product / block tests either compiled in (masked) or not (ALL); the
+  // choice is made per segment, outside the loop, so that neither form pays register copies for the other's branches.
+  auto run_segment = [&](auto all_tag, uint32_t kc, uint32_t kc_end) {
+    constexpr bool ALL = decltype(all_tag)::value;
+    for (; kc < kc_end; ++kc) {
+      wait_dma_then_barrier(mine * (issued - kc - 1));
+      if (issued < issue_limit) {
+        dma_stage(issued, issue_buf);  // (reuses the buffer every wave finished reading before the barrier)
+        ++issued;
+        issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
+      }
+      const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * stage_dwords);
+      read_buf = (read_buf + 1 == stages) ? 0 : read_buf + 1;
+      if (ALL || live) {
+        mfma_stage<KS, ALL>(st4, slot_off, oH, oR, h, need, live, diag, acc);
+      }
+    }
+  };
+  for (uint32_t kc = 0; kc < n_stages;) {
+    const uint32_t kc_end = issue_limit;  // the next checkpoint (or the end of the rows)
+    if ((live == 0xffu) && !diag) {
+      run_segment(std::true_type(), kc, kc_end);
+    } else {
+      run_segment(std::false_type(), kc, kc_end);
+    }
+    kc = kc_end;
+    if (kc >= n_stages) {
+      break;
+    }
+    {  // (block-uniform; issued == kc here)
+    // ---- checkpoint (ldp_device.h): drop the products whose candidate pairs are all provably below the threshold ----
+    __syncthreads();  // every wave is done with the last stage: LDS is scratch now
+    // The checkpoint statistics (ldp_device.h: cp_slot) of every staged row come in by LDS-DMA as well, slot next_cp and
+    // the whole-row slot, 32 bytes per row behind the accumulator scratch.  Ordinary global loads inside the k-loop
+    // would make hipcc drain the ring (s_waitcnt vmcnt(0)) in front of EVERY LDS read of the loop, not just here.
+    {
+      const uint8_t* cps = reinterpret_cast<const uint8_t*>(A.cp_stats);
 #pragma unroll
-        for (int t = 0; t < kMfMaxDmaPerWave; ++t) {
-          const uint32_t T = wave + kMfWaves * t;  // row-block slot T: 32 rows x 2 pieces
-          if (T < n_rb) {
-            const uint32_t first = __builtin_amdgcn_readfirstlane(wg->rb[T]);
-            uint32_t var = first + (lane >> 1);
-            var = (var < A.n_local) ? var : (A.n_local - 1);
-            const uint64_t off = static_cast<uint64_t>(var) * (kCpSlots * sizeof(cp_slot)) + ((lane & 1) ? kCheckpoints : next_cp) * sizeof(cp_slot);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cps + off),
-                                             (__attribute__((address_space(3))) void*)(lds + kMfCpScratchDwords + T * 256), 16, 0, 0);
-          }
+      for (int t = 0; t < kMfMaxDmaPerWave; ++t) {
+        const uint32_t T = wave + kMfWaves * t;  // row-block slot T: 32 rows x 2 pieces
+        if (T < n_rb) {
+          const uint32_t first = __builtin_amdgcn_readfirstlane(wg->rb[T]);
+          uint32_t var = first + (lane >> 1);
+          var = (var < A.n_local) ? var : (A.n_local - 1);
+          const uint64_t off = static_cast<uint64_t>(var) * (kCpSlots * sizeof(cp_slot)) + ((lane & 1) ? kCheckpoints : next_cp) * sizeof(cp_slot);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cps + off),
+                                           (__attribute__((address_space(3))) void*)(lds + kMfCpScratchDwords + T * 256), 16, 0, 0);
         }
       }
-      __syncthreads();  // (drains the DMA: the slots are in LDS)
-      const cp_slot* __restrict__ cpl = reinterpret_cast<const cp_slot*>(lds + kMfCpScratchDwords);  // [row-block slot][row][2]
-      if (live) {
-        uint32_t keep = 0;
-        uint32_t* cp_epi = lds + wave * kMfCpWaveDwords;  // two products per round
+    }
+    __syncthreads();  // (drains the DMA: the slots are in LDS)
+    const cp_slot* __restrict__ cpl = reinterpret_cast<const cp_slot*>(lds + kMfCpScratchDwords);  // [row-block slot][row][2]
+    if (live) {
+      uint32_t keep = 0;
+      uint32_t* cp_epi = lds + wave * kMfCpWaveDwords;  // two products per round
 #pragma unroll
-        for (int round = 0; round < 4; ++round) {
-          if (!(live & (0x3u << (2 * round)))) {
+      for (int round = 0; round < 4; ++round) {
+        if (!(live & (0x3u << (2 * round)))) {
+          continue;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          if (live & (1u << (2 * round + pl))) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+              cp_epi[(pl * 16 + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>(acc[2 * round + pl][g]));
+            }
+          }
+        }
+        const int q = (round >= 2) ? 1 : 0;
+        const int64_t j64 = static_cast<int64_t>(jv) + kMfBlock * q + r;
+        const int64_t lo_j = lo_j2[q];
+        const uint32_t jslot = (slots_packed >> (4 * q)) & 15u;
+        const cp_slot cj = cpl[(jslot * kMfBlock + r) * 2];
+        const cp_slot gj = cpl[(jslot * kMfBlock + r) * 2 + 1];
+#pragma unroll 1
+        for (uint32_t pl = 0; pl < 2; ++pl) {
+          const uint32_t p = 2 * round + pl;
+          if (!(live & (1u << p))) {
             continue;
           }
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl) {
-            if (live & (1u << (2 * round + pl))) {
-#pragma unroll
-              for (int g = 0; g < 16; ++g) {
-                cp_epi[(pl * 16 + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>(acc[2 * round + pl][g]));
-              }
-            }
-          }
-          const int q = (round >= 2) ? 1 : 0;
-          const int64_t j64 = static_cast<int64_t>(jv) + kMfBlock * q + r;
-          const int64_t lo_j = lo_j2[q];
-          const uint32_t jslot = (slots_packed >> (4 * q)) & 15u;
-          const cp_slot cj = cpl[(jslot * kMfBlock + r) * 2];
-          const cp_slot gj = cpl[(jslot * kMfBlock + r) * 2 + 1];
-#pragma unroll 1
-          for (uint32_t pl = 0; pl < 2; ++pl) {
-            const uint32_t p = 2 * round + pl;
-            if (!(live & (1u << p))) {
-              continue;
-            }
-            const uint32_t k = (p & 3) + q;  // V block of the product
-            const uint32_t vslot = (slots_packed >> (4 * (2 + k))) & 15u;
-            bool hopeless = true;
-            const int64_t vfirst = static_cast<int64_t>(vv) + kMfBlock * k + 4 * h;
+          const uint32_t k = (p & 3) + q;  // V block of the product
+          const uint32_t vslot = (slots_packed >> (4 * (2 + k))) & 15u;
+          bool hopeless = true;
+          const int64_t vfirst = static_cast<int64_t>(vv) + kMfBlock * k + 4 * h;
 #pragma unroll 2
-            for (uint32_t g = 0; g < 16; ++g) {
-              const uint32_t row = (g & 3) + 8 * (g >> 2) + 4 * h;
-              const int64_t i64 = static_cast<int64_t>(vv) + kMfBlock * k + row;
-              if ((i64 >= lo_j) && (i64 < j64)) {
-                const cp_slot ci = cpl[(vslot * kMfBlock + row) * 2];
-                const cp_slot gi = cpl[(vslot * kMfBlock + row) * 2 + 1];
-                // |N dot - S_i S_j| <= |c0| + B, see pair_hopeless() in ldp_pair_device.h (dot_p is the partial dot product)
-                const double dot_p = static_cast<double>(static_cast<int32_t>(cp_epi[(pl * 16 + g) * 64 + lane]));
-                const double c0 = fma(static_cast<double>(A.founder_ct), dot_p, fma(ci.a, cj.a, -(gi.a * gj.a)));
-                const double bound = fabs(c0) + fma(ci.b, cj.b, 1.0);
-                hopeless = hopeless && (bound < gi.b * gj.b);
-              }
-            }
-            (void)vfirst;
-            if (!__all(hopeless)) {
-              keep |= 1u << p;
+          for (uint32_t g = 0; g < 16; ++g) {
+            const uint32_t row = (g & 3) + 8 * (g >> 2) + 4 * h;
+            const int64_t i64 = static_cast<int64_t>(vv) + kMfBlock * k + row;
+            if ((i64 >= lo_j) && (i64 < j64)) {
+              const cp_slot ci = cpl[(vslot * kMfBlock + row) * 2];
+              const cp_slot gi = cpl[(vslot * kMfBlock + row) * 2 + 1];
+              // |N dot - S_i S_j| <= |c0| + B, see pair_hopeless() in ldp_pair_device.h (dot_p is the partial dot product)
+              const double dot_p = static_cast<double>(static_cast<int32_t>(cp_epi[(pl * 16 + g) * 64 + lane]));
+              const double c0 = fma(static_cast<double>(A.founder_ct), dot_p, fma(ci.a, cj.a, -(gi.a * gj.a)));
+              const double bound = fabs(c0) + fma(ci.b, cj.b, 1.0);
+              hopeless = hopeless && (bound < gi.b * gj.b);
             }
           }
-        }
-        keep = __builtin_amdgcn_readfirstlane(keep);
-        if (keep != live) {
-          if (lane == 0) {
-            atomicAdd(A.counters + 2, static_cast<unsigned long long>(n_stages - kc) * KS * __builtin_popcount(live & ~keep));
+          (void)vfirst;
+          if (!__all(hopeless)) {
+            keep |= 1u << p;
           }
-          live = keep;
-          need = blocks_needed(live, diag);
         }
       }
-      ++next_cp;
-      // which staged row-blocks does the workgroup still read?  Dead ones are no longer fetched.
-      if (lane == 0) {
-        uint32_t m = 0;
+      keep = __builtin_amdgcn_readfirstlane(keep);
+      if (keep != live) {
+        if (lane == 0) {
+          atomicAdd(A.counters + 2, static_cast<unsigned long long>(n_stages - kc) * KS * __builtin_popcount(live & ~keep));
+        }
+        live = keep;
+        need = blocks_needed(live, diag);
+      }
+    }
+    ++next_cp;
+    // which staged row-blocks does the workgroup still read?  Dead ones are no longer fetched.
+    if (lane == 0) {
+      uint32_t m = 0;
 #pragma unroll
-        for (int u = 0; u < 7; ++u) {
-          if (need & (1u << u)) {
-            m |= 1u << (slot_off[u] / G::kBlockSlots);
-          }
+      for (int u = 0; u < 7; ++u) {
+        if (need & (1u << u)) {
+          m |= 1u << (slot_off[u] / G::kBlockSlots);
         }
-        s_need[wave] = m;
       }
-      __syncthreads();
-      const uint32_t all_need = s_need[0] | s_need[1] | s_need[2] | s_need[3];
-      __syncthreads();  // (s_need is rewritten at the next checkpoint; the scratch reads above are over as well)
-      if (!all_need) {
-        break;  // nothing left that could reach the threshold
-      }
-      if (all_need != wg_need) {
-        wg_need = __builtin_amdgcn_readfirstlane(all_need);
-        mine = count_mine();
-      }
-      issue_limit = (next_cp < n_cp) ? checkpoint_stage(next_cp) : n_stages;
-      issued_base = kc;
-      ring_fill();  // restart the ring at this stage
+      s_need[wave] = m;
     }
-    wait_dma_then_barrier(mine * (issued - kc - 1));
-    if (issued < issue_limit) {
-      dma_stage(issued, issue_buf);  // (reuses the buffer every wave finished reading before the barrier)
-      ++issued;
-      issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
+    __syncthreads();
+    const uint32_t all_need = s_need[0] | s_need[1] | s_need[2] | s_need[3];
+    __syncthreads();  // (s_need is rewritten at the next checkpoint; the scratch reads above are over as well)
+    if (!all_need) {
+      break;  // nothing left that could reach the threshold
     }
-    const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * stage_dwords);
-    read_buf = (read_buf + 1 == stages) ? 0 : read_buf + 1;
-    if (!live) {
-      continue;
+    if (all_need != wg_need) {
+      wg_need = __builtin_amdgcn_readfirstlane(all_need);
+      mine = count_mine();
     }
-    mfma_stage<KS>(st4, slot_off, oH, oR, h, need, live, diag, acc);
+    issue_limit = (next_cp < n_cp) ? checkpoint_stage(next_cp) : n_stages;
+    issued_base = kc;
+    ring_fill();  // restart the ring at this stage
+    }
   }
   __syncthreads();  // staging is over: LDS becomes the epilogue's scratch (a private region per wave)
 

@@ -37,16 +37,26 @@ def main():
     out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in pmc.items() if "ldp::" in k}
     n_disp = {k: max(len(v) for v in cs.values()) for k, cs in pmc.items() if "ldp::" in k}  # PMC passes run ONE bench step
     json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
+    samples = int(os.environ.get("LDP_PROF_SAMPLES", "50000"))
+    variants = int(os.environ.get("LDP_PROF_VARIANTS", "1000000"))
+    window_kb = float(os.environ.get("LDP_PROF_WINDOW_KB", "200"))
+    best = None
     for k, cs in out.items():
-        if "pair_tiles_kernel<false>" in k and "FETCH_SIZE" in cs:
-            read_b = cs["FETCH_SIZE"] * 1024 * 2
-            write_b = cs.get("WRITE_SIZE", 0.0) * 1024
-            json.dump({"kernel": k, "samples": 50000, "variants": 1000000, "window_kb": 200.0,
-                       "hbm_bytes_per_launch": read_b + write_b, "launches_per_step": n_disp[k],
-                       "hbm_bytes_per_step": (read_b + write_b) * n_disp[k],
-                       "fetch_size_kib": cs["FETCH_SIZE"], "write_size_kib": cs.get("WRITE_SIZE"),
-                       "note": "FETCH_SIZE x 1024 x 2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE x 1024",
-                       "tag": tag}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+        if (("pair_mfma_kernel" in k) or ("pair_mfma_general_kernel" in k) or ("pair_tiles_kernel" in k)) and "FETCH_SIZE" in cs:
+            # the pair kernel that did the work of this run = the one that fetched the most
+            if (best is None) or (cs["FETCH_SIZE"] > out[best]["FETCH_SIZE"]):
+                best = k
+    if best:
+        cs = out[best]
+        read_b = cs["FETCH_SIZE"] * 1024 * 2
+        write_b = cs.get("WRITE_SIZE", 0.0) * 1024
+        short = best.split("(")[0].replace("void ", "").replace("ldp::", "")
+        json.dump({"kernel": short, "samples": samples, "variants": variants, "window_kb": window_kb,
+                   "hbm_bytes_per_launch": read_b + write_b, "launches_per_step": n_disp[best],
+                   "hbm_bytes_per_step": (read_b + write_b) * n_disp[best],
+                   "fetch_size_kib": cs["FETCH_SIZE"], "write_size_kib": cs.get("WRITE_SIZE"),
+                   "note": "FETCH_SIZE x 1024 x 2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE x 1024",
+                   "tag": tag}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
     print(open(os.path.join(dst, tag + "_kernel_stats.csv")).read())
 
 
