@@ -351,3 +351,17 @@ def test_inter_chr_filter_and_order_from_oracle_values(cli, tmp_path):
     open(path, "w").write("".join("%016x\n" % int(b) for b in bits))
     out = subprocess.run([cli, "--debug-format-g6", str(path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert out.stdout.split("\n")[:-1] == [str(t) for t in z["inter_text"]]
+
+
+@pytest.mark.gpu
+def test_cli_two_gpus_match_one(gpu_pkg, cli, tmp_path):
+    """`plink2-hip --gpus 2`: subcontigs LPT-sharded over two devices, bitmaps OR-ed; same files as one device.  Needs a box
+    with two visible devices (the gpurun boxes have one: skipped there, runs wherever the driver has a multi-GPU node)."""
+    if gpu_pkg.device_count() < 2:
+        pytest.skip("only %d HIP device(s) visible" % gpu_pkg.device_count())
+    prefix, raw, chr_idx, bps = small_fileset(tmp_path, m=900, n=200, seed=21)
+    one = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "30kb", "0.3", "--out", "one"], str(tmp_path))
+    two = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "30kb", "0.3", "--gpus", "2", "--out", "two"], str(tmp_path))
+    assert one.returncode == 0 and two.returncode == 0, two.stdout
+    for ext in (".prune.in", ".prune.out"):
+        assert filecmp.cmp(str(tmp_path / ("one" + ext)), str(tmp_path / ("two" + ext)), shallow=False)

@@ -1,0 +1,82 @@
+"""The in-process seam exercised from the reference's own LdPrune(): oracle/_ref/plink2_hipld is the
+reference binary with tests/integration/indep_pairwise_hip.cc linked in and the IndepPairwise() call inside LdPrune()
+(plink2_ld.cc:2700) redirected to it at build time (oracle/Makefile, target ref_hip).  Its output files must be
+byte-identical to the stock reference's."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ldtools as T
+from test_cli import small_fileset
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STOCK = os.path.join(REPO, "oracle", "_ref", "plink2")
+PATCHED = os.path.join(REPO, "oracle", "_ref", "plink2_hipld")
+
+CASES = [
+    (["--bfile", "d", "--indep-pairwise", "50", "5", "0.2"], {}),
+    (["--bfile", "d", "--indep-pairwise", "20kb", "0.5"], {}),
+    (["--pfile", "d", "--indep-pairwise", "30", "1", "0.3", "--indep-order", "1"], {}),
+    (["--bfile", "d", "--indep-pairwise", "15kb", "0.1"], {"nonfounders": 7}),
+    (["--bfile", "d", "--indep-pairwise", "40", "3", "0.4"], {"chr0": 3}),
+    (["--bfile", "d", "--indep-pairwise", "25kb", "0.2", "--indep-preferred", "pref.txt"], {}),
+]
+
+
+def run(binary, args, cwd, out):
+    return subprocess.run([binary] + args + ["--bad-ld", "--out", out], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+
+
+def both(tmp_path, args, kw, seed):
+    prefix, raw, chr_idx, bps = small_fileset(tmp_path, m=400, n=90, seed=seed, **kw)
+    if "--indep-preferred" in args:
+        with open(str(tmp_path / "pref.txt"), "w") as f:
+            f.write("".join("snp%d\n" % i for i in range(0, 400, 7)))
+    a = run(STOCK, args, str(tmp_path), "stock")
+    b = run(PATCHED, args, str(tmp_path), "hipld")
+    assert a.returncode == 0, a.stdout[-1500:]
+    assert b.returncode == 0, b.stdout[-1500:]
+    for ext in (".prune.in", ".prune.out"):
+        assert open(str(tmp_path / ("stock" + ext)), "rb").read() == open(str(tmp_path / ("hipld" + ext)), "rb").read(), ext
+    return b.stdout
+
+
+@pytest.mark.skipif(not (os.path.exists(STOCK) and os.path.exists(PATCHED)), reason="oracle/_ref binaries not built (make -C oracle ref ref_hip)")
+def test_patched_reference_runs_its_own_path_without_a_gpu(pkg, tmp_path):
+    """Plumbing only (no GPU here): with no HIP device IndepPairwiseHip() hands the job to the reference's IndepPairwise()."""
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the gpu test")
+    out = both(tmp_path, CASES[0][0], CASES[0][1], 3)
+    assert "--indep-pairwise (HIP" not in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_reference_ldprune_through_the_c_abi_matches_stock_reference(gpu_pkg, tmp_path, case):
+    assert os.path.exists(STOCK) and os.path.exists(PATCHED), "oracle/_ref/plink2{,_hipld} missing: build() makes them where /root/reference exists"
+    args, kw = CASES[case]
+    out = both(tmp_path, args, kw, 11 + case)
+    assert "--indep-pairwise (HIP" in out  # the engine really ran
+
+
+@pytest.mark.gpu
+def test_sex_chromosomes_fall_back_to_the_reference_path(gpu_pkg, tmp_path):
+    """chrX in the include set: the binding leaves the whole job to IndepPairwise() (its sample-mapped rows are a caller's
+    job); PLINK2_HIP_LDPRUNE=0 does the same for any input."""
+    m, n = 300, 80
+    raw = T.synth_raw_codes(m, n, 5, missing_rate=0.02)
+    chroms = ["1"] * 150 + ["X"] * 150
+    bps = np.concatenate([1000 + 200 * np.arange(150), 1000 + 200 * np.arange(150)]).astype(np.uint32)
+    T.write_bed(str(tmp_path / "d"), raw, chroms, bps)
+    a = run(STOCK, ["--bfile", "d", "--indep-pairwise", "20kb", "0.3"], str(tmp_path), "stock")
+    b = run(PATCHED, ["--bfile", "d", "--indep-pairwise", "20kb", "0.3"], str(tmp_path), "hipld")
+    assert a.returncode == 0 and b.returncode == 0, b.stdout[-1000:]
+    assert "--indep-pairwise (HIP" not in b.stdout
+    for ext in (".prune.in", ".prune.out"):
+        assert open(str(tmp_path / ("stock" + ext)), "rb").read() == open(str(tmp_path / ("hipld" + ext)), "rb").read()
+    env = dict(os.environ, PLINK2_HIP_LDPRUNE="0")
+    c = subprocess.run([PATCHED, "--bfile", "d", "--chr", "1", "--indep-pairwise", "20kb", "0.3", "--out", "off"], cwd=str(tmp_path), env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert c.returncode == 0 and "--indep-pairwise (HIP" not in c.stdout
