@@ -248,6 +248,11 @@ int ldp_get_counters(const ldp_engine* e, ldp_counters* out);
 typedef struct ldp_pgen ldp_pgen;
 int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct_hint, ldp_pgen** out);
 int ldp_pgen_info(const ldp_pgen* p, uint32_t* variant_ct, uint32_t* sample_ct, int* storage_mode, int* row_encoding, int* has_multiallelic);
+/* 1 when some variant record carries a dosage track (vrtype bits 5-6).  The reader decodes hardcalls only; the reference
+ * derives allele frequencies -- hence the major allele and the prune tie-break -- from dosages when they exist
+ * (plink2_data.cc:2424-2566), so a caller that wants the reference's prune list must either refuse such files (plink2-hip
+ * does) or supply dosage-based frequencies through ldp_set_maj_freqs(). */
+int ldp_pgen_has_dosage(const ldp_pgen* p);
 /* fixed-width modes only: pointer to row 0 inside the file mapping (zero-copy), NULL for variable-width files */
 const void* ldp_pgen_direct_rows(const ldp_pgen* p, uint64_t* stride_bytes);
 /* decode rows [first_variant, first_variant+n) into out_rows; 64k-variant blocks decode on up to `threads` host threads (0 = all) */

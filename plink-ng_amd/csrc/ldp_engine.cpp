@@ -318,10 +318,18 @@ void free_device(ldp_engine* e) {
 
 // LdPruneSubcontigSplitAll, plink2_ld.cc:2165-2268 (every variant included).
 void subcontig_split(const uint32_t* chr_idx, const uint32_t* bps, uint32_t variant_ct, uint32_t window, std::vector<Subcontig>* subs, uint32_t* window_max_out) {
+  // What LdPruneSubcontigSplitAll (plink2_ld.cc:2165-2268) produces, derived from its definition rather than its loop:
+  //   * a subcontig is a maximal run of variants of one chromosome in which consecutive positions are at most `window`
+  //     apart (bp windows; no two variants further apart can ever share a window), or the whole chromosome (count windows);
+  //     runs of a single variant are never loaded and do not appear;
+  //   * window_max = the largest number of variants any window can hold: for bp windows the longest run
+  //     {w .. v} with bps[w] >= bps[v] - window inside one chromosome (at least 1), for count windows the largest
+  //     chromosome capped at the window size.
   subs->clear();
-  uint32_t window_max = bps ? 1 : 0;
-  uint32_t vidx0 = 0;
   auto push = [&](uint32_t first, uint32_t len) {
+    if (len < 2) {
+      return;
+    }
     Subcontig s;
     s.len = len;
     s.first = first;
@@ -329,57 +337,40 @@ void subcontig_split(const uint32_t* chr_idx, const uint32_t* bps, uint32_t vari
     s.local_first = 0;
     subs->push_back(s);
   };
-  while (vidx0 < variant_ct) {
-    uint32_t chr_end = vidx0 + 1;
-    while ((chr_end < variant_ct) && (chr_idx[chr_end] == chr_idx[vidx0])) {
+  uint32_t window_max = bps ? 1 : 0;
+  for (uint32_t chr_first = 0; chr_first < variant_ct;) {
+    uint32_t chr_end = chr_first + 1;
+    while ((chr_end < variant_ct) && (chr_idx[chr_end] == chr_idx[chr_first])) {
       ++chr_end;
     }
-    const uint32_t chr_variant_ct = chr_end - vidx0;
-    if (chr_variant_ct > 1) {
-      if (bps) {
-        uint32_t sub_first = vidx0;
-        uint32_t win_first = vidx0;
-        uint32_t win_pos_first = bps[vidx0];
-        uint32_t prev_pos = win_pos_first;
-        uint32_t v = vidx0 + 1;
-        do {
-          uint32_t bp_thresh = bps[v];
-          if (bp_thresh < window) {
-            prev_pos = bp_thresh;
-            bp_thresh = 0;
-          } else {
-            if (bp_thresh - window > prev_pos) {  // gap wider than the window: new subcontig (:2200)
-              if (v > sub_first + 1) {
-                push(sub_first, v - sub_first);
-              }
-              sub_first = v;
-            }
-            prev_pos = bp_thresh;
-            bp_thresh -= window;
-          }
-          if (bp_thresh > win_pos_first) {
-            do {
-              ++win_first;
-              win_pos_first = bps[win_first];
-            } while (bp_thresh > win_pos_first);
-          } else if (v - win_first == window_max) {
-            ++window_max;
-          }
-        } while (++v < chr_end);
-        if (v > sub_first + 1) {
-          push(sub_first, v - sub_first);
+    if (!bps) {
+      push(chr_first, chr_end - chr_first);
+      if (chr_end - chr_first > 1) {
+        window_max = std::max(window_max, std::min(chr_end - chr_first, window));
+      }
+    } else {
+      // runs between gaps wider than the window
+      uint32_t run_first = chr_first;
+      for (uint32_t v = chr_first + 1; v < chr_end; ++v) {
+        if (bps[v] - bps[v - 1] > window) {
+          push(run_first, v - run_first);
+          run_first = v;
         }
-      } else {
-        push(vidx0, chr_variant_ct);
-        if ((window_max < window) && (chr_variant_ct > window_max)) {
-          window_max = chr_variant_ct;
+      }
+      push(run_first, chr_end - run_first);
+      // widest window: two pointers over the chromosome (a chromosome of one variant leaves window_max alone)
+      if (chr_end - chr_first > 1) {
+        uint32_t w = chr_first;
+        for (uint32_t v = chr_first; v < chr_end; ++v) {
+          const uint32_t reach = (bps[v] > window) ? (bps[v] - window) : 0;
+          while (bps[w] < reach) {
+            ++w;
+          }
+          window_max = std::max(window_max, v - w + 1);
         }
       }
     }
-    vidx0 = chr_end;
-  }
-  if ((!bps) && (window_max > window)) {
-    window_max = window;
+    chr_first = chr_end;
   }
   *window_max_out = window_max;
 }
@@ -1408,7 +1399,17 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     PairKernelArgs A;
     fill_pair_args(e, &A, false);
     A.stats = d_stats;
-    hipEvent_t evk[7];
+    struct EventSet {  // released on every exit path
+      hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+      ~EventSet() {
+        for (hipEvent_t x : ev) {
+          if (x) {
+            (void)hipEventDestroy(x);
+          }
+        }
+      }
+    } evset;
+    hipEvent_t* evk = evset.ev;
     for (int q = 0; q < 7; ++q) {
       HIP_TRY(e, hipEventCreate(&evk[q]));
     }
@@ -1450,9 +1451,6 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
         HIP_TRY(e, hipEventElapsedTime(&kms_mfma_general, evk[5], evk[6]));
       }
       launches = 1;
-    }
-    for (int q = 0; q < 7; ++q) {
-      (void)hipEventDestroy(evk[q]);
     }
     // the next plain run recomputes with the production settings
     for (ldp_engine::PairGroup& g : e->groups) {

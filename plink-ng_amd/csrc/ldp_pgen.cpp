@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -26,6 +27,7 @@
 
 struct ldp_pgen {
   std::string err;
+  std::mutex err_mutex;
   int fd = -1;
   const uint8_t* map = nullptr;
   uint64_t size = 0;
@@ -38,14 +40,19 @@ struct ldp_pgen {
   std::vector<uint8_t> vrtype;  // per variant
   std::vector<uint64_t> fpos;   // variant_ct + 1 record offsets
   bool any_multiallelic = false;
+  bool any_dosage = false;        // some record carries a dosage track (skipped by this reader)
 };
 
 namespace {
 
 constexpr uint32_t kBlockVariants = 65536;
 
+// (readers may call the per-record functions on one handle from several threads: the message is the first failure's)
 int pfail(ldp_pgen* p, int code, const std::string& msg) {
-  p->err = msg;
+  std::lock_guard<std::mutex> lock(p->err_mutex);
+  if (p->err.empty()) {
+    p->err = msg;
+  }
   return code;
 }
 
@@ -381,6 +388,9 @@ int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct
       if (t & 8) {
         P->any_multiallelic = true;
       }
+      if (t & 0x60) {
+        P->any_dosage = true;  // (bits 5-6: a dosage track follows the hardcalls; bit 7, phased dosage, implies one)
+      }
       uint32_t len = 0;
       memcpy(&len, lens + static_cast<uint64_t>(k) * len_bytes, len_bytes);
       P->fpos[v] = rec;
@@ -411,6 +421,8 @@ int ldp_pgen_info(const ldp_pgen* P, uint32_t* variant_ct, uint32_t* sample_ct, 
   if (has_multiallelic) *has_multiallelic = P->any_multiallelic ? 1 : 0;
   return LDP_OK;
 }
+
+int ldp_pgen_has_dosage(const ldp_pgen* P) { return (P && P->any_dosage) ? 1 : 0; }
 
 const void* ldp_pgen_direct_rows(const ldp_pgen* P, uint64_t* stride_bytes) {
   if (!P || (P->mode != 0x01 && P->mode != 0x02)) {

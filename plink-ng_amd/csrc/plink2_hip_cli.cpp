@@ -1288,6 +1288,12 @@ int main(int argc, char** argv) {
   }
   int storage_mode = 0, encoding = LDP_GENO_REF, has_multiallelic = 0;
   ldp_pgen_info(pg, nullptr, nullptr, &storage_mode, &encoding, &has_multiallelic);
+  if (ldp_pgen_has_dosage(pg)) {
+    // The reference takes allele frequencies (major allele, tie-break of the prune; the r^2 of dosage data) from the dosages
+    // when a file has them; this front-end reads hardcalls only and would silently write a different list.
+    ldp_pgen_close(pg);
+    die(9, "Error: %s holds dosage data, which plink2-hip does not read yet (allele frequencies and r^2 would be\ncomputed from hardcalls only, unlike plink2).  Use plink2 --make-pgen erase-dosage first.\n", gpath.c_str());
+  }
   uint64_t rec_bytes = (static_cast<uint64_t>(raw_sample_ct) + 3) / 4;
   const uint8_t* direct_rows = static_cast<const uint8_t*>(ldp_pgen_direct_rows(pg, &rec_bytes));  // NULL for variable-width
 

@@ -365,3 +365,23 @@ def test_cli_two_gpus_match_one(gpu_pkg, cli, tmp_path):
     assert one.returncode == 0 and two.returncode == 0, two.stdout
     for ext in (".prune.in", ".prune.out"):
         assert filecmp.cmp(str(tmp_path / ("one" + ext)), str(tmp_path / ("two" + ext)), shallow=False)
+
+
+def test_cli_refuses_dosage_pgen(cli, tmp_path):
+    """A .pgen with dosage tracks: the reference derives allele frequencies (major allele, prune tie-break) from the dosages
+    (plink2_data.cc:2424-2566); plink2-hip reads hardcalls only, so it must refuse instead of writing a different list."""
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "plink2")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/plink2 not built")
+    cp = subprocess.run([ref, "--dummy", "60", "200", "dosage-freq=0.3", "--seed", "3", "--threads", "2", "--make-pgen", "--out", "dos"], cwd=str(tmp_path),
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert cp.returncode == 0, cp.stdout
+    out = run_cli(cli, ["--pfile", "dos", "--indep-pairwise", "50", "5", "0.2", "--out", "o"], str(tmp_path))
+    assert out.returncode == 9 and "dosage" in out.stdout
+    assert not os.path.exists(str(tmp_path / "o.prune.in"))
+    # without the dosages the same data is accepted (up to the point where a GPU is needed)
+    cp = subprocess.run([ref, "--pfile", "dos", "--make-pgen", "erase-dosage", "--out", "hard"], cwd=str(tmp_path),
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert cp.returncode == 0, cp.stdout
+    out = run_cli(cli, ["--pfile", "hard", "--indep-pairwise", "50", "5", "0.2", "--dry-run", "--out", "o"], str(tmp_path))
+    assert out.returncode == 0, out.stdout
