@@ -472,9 +472,13 @@ bool mfma_requested() {
   return !(m && (strcmp(m, "0") == 0));
 }
 
-void plan_mfma(ldp_engine* e) {
-  e->mf_wgs.clear();
-  e->mf_products = 0;
+// runs: (first local variant, length) of the row ranges blocks are aligned to (the owned subcontigs; one run over
+// everything for the all-pairs plan of --r2-unphased); lo: window start per local variant (nullptr: 0, every earlier
+// variant is a partner); only second variants in [j_first, j_end) get products (a row chunk of an r^2 matrix).
+void plan_mfma_generic(const std::vector<std::pair<uint32_t, uint32_t>>& runs, const uint32_t* lo_of, uint32_t j_first, uint32_t j_end,
+                       std::vector<MfmaWG>* out_wgs, uint64_t* out_products) {
+  out_wgs->clear();
+  *out_products = 0;
   struct Wave {
     int32_t jv, vv;
     uint32_t jend;
@@ -522,9 +526,9 @@ void plan_mfma(ldp_engine* e) {
       }
       wg.j_lo = std::min(wg.j_lo, static_cast<uint32_t>(pw.jv));
       wg.j_hi = std::max(wg.j_hi, pw.jend);
-      e->mf_products += static_cast<uint64_t>(__builtin_popcount(pw.mask));
+      *out_products += static_cast<uint64_t>(__builtin_popcount(pw.mask));
     }
-    e->mf_wgs.push_back(wg);
+    out_wgs->push_back(wg);
     pending.clear();
     uni.clear();
   };
@@ -547,15 +551,20 @@ void plan_mfma(ldp_engine* e) {
     uni.swap(merged);
     pending.push_back(w);
   };
-  for (uint32_t sk : e->owned) {
-    const Subcontig& s = e->subs[sk];
-    const uint32_t sfirst = s.local_first;
+  for (const std::pair<uint32_t, uint32_t>& run : runs) {
+    struct {
+      uint32_t len;
+    } s = {run.second};
+    const uint32_t sfirst = run.first;
     const uint32_t nb = (s.len + kMfBlock - 1) / kMfBlock;
     // farthest block distance any second variant of a block reaches (-1: the block holds no candidate pair)
     std::vector<int32_t> reach(nb, -1);
     for (uint32_t v = 0; v < s.len; ++v) {
       const uint32_t j = sfirst + v;
-      const uint32_t lo = e->lo_local[j];
+      if ((j < j_first) || (j >= j_end)) {
+        continue;
+      }
+      const uint32_t lo = lo_of ? lo_of[j] : sfirst;
       if (lo < j) {
         const int32_t d = static_cast<int32_t>(v / kMfBlock) - static_cast<int32_t>((lo - sfirst) / kMfBlock);
         reach[v / kMfBlock] = std::max(reach[v / kMfBlock], d);
@@ -607,6 +616,14 @@ void plan_mfma(ldp_engine* e) {
     }
   }
   flush();
+}
+
+void plan_mfma(ldp_engine* e) {
+  std::vector<std::pair<uint32_t, uint32_t>> runs;
+  for (uint32_t sk : e->owned) {
+    runs.emplace_back(e->subs[sk].local_first, e->subs[sk].len);
+  }
+  plan_mfma_generic(runs, e->lo_local.data(), 0, e->local_ct, &e->mf_wgs, &e->mf_products);
 }
 
 void build_shard(ldp_engine* e) {
@@ -1787,6 +1804,28 @@ int ldp_set_variants_vcor(ldp_engine* e, uint32_t variant_ct, const uint32_t* ch
 }  // extern "C"
 
 namespace {
+// --r2-unphased requests on the matrix pipe: plan the requested second variants' block products (ldp_device.h: MfmaWG),
+// upload the plan and attach it to the launch.  The r^2 epilogue is emit_pair()'s, shared with the popcount kernels.
+bool r2_on_matrix_pipe(const ldp_engine* e) { return mfma_requested() && (e->P.founder_ct <= kMfMaxFounders); }
+
+int attach_mfma_plan(ldp_engine* e, PairKernelArgs* A, const std::vector<std::pair<uint32_t, uint32_t>>& runs, const uint32_t* lo, uint32_t j_first,
+                     uint32_t j_end, DevBuf* buf, uint64_t* products) {
+  std::vector<MfmaWG> wgs;
+  plan_mfma_generic(runs, lo, j_first, j_end, &wgs, products);
+  A->n_mf_wgs = static_cast<uint32_t>(wgs.size());
+  if (wgs.empty()) {
+    return LDP_OK;
+  }
+  HIP_TRY(e, hipMalloc(&buf->p, wgs.size() * sizeof(MfmaWG)));
+  HIP_TRY(e, hipMemcpy(buf->p, wgs.data(), wgs.size() * sizeof(MfmaWG), hipMemcpyHostToDevice));
+  const size_t slot = 1 + e->groups.size();  // (the snapshot slot of launches outside the launch groups)
+  HIP_TRY(e, hipMemcpyAsync(e->d_any_missing + slot, e->d_any_missing, sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
+  A->mf_wgs = buf->as<MfmaWG>();
+  A->mf_active = 2;
+  A->any_missing = e->d_any_missing + slot;
+  return LDP_OK;
+}
+
 struct HitRequest {
   double min_r2;
   ldp_r2_hit* out;
@@ -1881,9 +1920,26 @@ int r2_band_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
   for (int q = 0; q < 4; ++q) {
     HIP_TRY(e, hipEventCreate(&evk[q]));
   }
-  const hipError_t krc = launch_pair_tiles(A, e->max_rows, e->stream, evk);
+  DevBuf mf_buf;
+  uint64_t mf_products = 0;
+  const bool on_mfma = r2_on_matrix_pipe(e);
+  hipError_t krc;
+  if (on_mfma) {
+    std::vector<std::pair<uint32_t, uint32_t>> runs;
+    for (uint32_t sk : e->owned) {
+      runs.emplace_back(e->subs[sk].local_first, e->subs[sk].len);
+    }
+    rc = attach_mfma_plan(e, &A, runs, e->lo_local.data(), l_first, l_end, &mf_buf, &mf_products);
+    if (rc) {
+      return rc;
+    }
+    krc = launch_pair_mfma(A, e->stream, evk);  // evk[0..2]: complete-data kernel | missing-calls kernel
+    (void)hipEventRecord(evk[3], e->stream);
+  } else {
+    krc = launch_pair_tiles(A, e->max_rows, e->stream, evk);
+  }
   if (krc != hipSuccess) {
-    return hipfail(e, krc, "pair_tiles_kernel launch");
+    return hipfail(e, krc, "pair kernel launch");
   }
   if (hits) {
     HIP_TRY(e, hipMemcpyAsync(e->h_counters_pin, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
@@ -1903,7 +1959,12 @@ int r2_band_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
     HIP_TRY(e, hipStreamSynchronize(e->stream));
   }
   float kms_fast = 0.f, kms_general = 0.f;
-  if (A.n_items) {
+  if (on_mfma) {
+    if (A.n_mf_wgs) {
+      HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
+      HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[1], evk[2]));
+    }
+  } else if (A.n_items) {
     HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
     HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[2], evk[3]));
   }
@@ -2041,9 +2102,24 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
   for (int q = 0; q < 4; ++q) {
     HIP_TRY(e, hipEventCreate(&evk[q]));
   }
-  hipError_t krc = launch_pair_tiles(A, std::max<uint32_t>(max_rows, kTileJ + 8), e->stream, evk);
+  DevBuf mf_buf;
+  uint64_t mf_products = 0;
+  const bool on_mfma = r2_on_matrix_pipe(e);
+  hipError_t krc;
+  if (on_mfma) {
+    const std::vector<std::pair<uint32_t, uint32_t>> runs(1, std::make_pair(0u, e->local_ct));
+    rc = attach_mfma_plan(e, &A, runs, nullptr, row_first, row_end, &mf_buf, &mf_products);
+    if (rc) {
+      return rc;
+    }
+    krc = launch_pair_mfma(A, e->stream, evk);  // evk[0..2]: complete-data kernel | missing-calls kernel
+    (void)hipEventRecord(evk[3], e->stream);
+    computed = mf_products * kMfBlock * kMfBlock;
+  } else {
+    krc = launch_pair_tiles(A, std::max<uint32_t>(max_rows, kTileJ + 8), e->stream, evk);
+  }
   if (krc != hipSuccess) {
-    return hipfail(e, krc, "pair_tiles_kernel launch");
+    return hipfail(e, krc, "pair kernel launch");
   }
   if (hits) {
     HIP_TRY(e, hipMemcpyAsync(e->h_counters_pin, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
@@ -2063,7 +2139,12 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
     HIP_TRY(e, hipStreamSynchronize(e->stream));
   }
   float kms_fast = 0.f, kms_general = 0.f;
-  if (!items.empty()) {
+  if (on_mfma) {
+    if (A.n_mf_wgs) {
+      HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
+      HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[1], evk[2]));
+    }
+  } else if (!items.empty()) {
     HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
     HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[2], evk[3]));
   }
