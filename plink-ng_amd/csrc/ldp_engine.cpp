@@ -539,7 +539,12 @@ void plan_mfma_generic(const std::vector<std::pair<uint32_t, uint32_t>>& runs, c
         merged.push_back(w.blocks[u]);
       }
     }
-    if ((pending.size() == kMfWaves) || (merged.size() > kMfMaxRowBlocks)) {
+    static const size_t max_waves = []() {  // tuning aid: fewer wave items per workgroup = fewer row-blocks = a deeper ring
+      const char* w = getenv("LDP_DEBUG_MFMA_WAVES");
+      const int v = w ? atoi(w) : kMfWaves;
+      return static_cast<size_t>(std::min(std::max(v, 1), kMfWaves));
+    }();
+    if ((pending.size() == max_waves) || (merged.size() > kMfMaxRowBlocks)) {
       flush();
       merged.clear();
       for (int u = 0; u < 7; ++u) {
