@@ -217,6 +217,15 @@ typedef struct {
   double r2;
 } ldp_r2_hit;
 int ldp_r2_unphased_hits(ldp_engine* e, uint32_t row_first, uint32_t row_ct, double min_r2, ldp_r2_hit* out, uint64_t capacity, uint64_t* count);
+/* Column blocks of the same all-pairs matrix, for the reference's `--parallel k n` decomposition of the r^2 outputs
+ * (VcorMatrix plink2_ld.cc:9800-9824, VcorTable :11157-11168) and for sharding them over devices: only pairs first < second
+ * with second in [row_first, row_first+row_ct) AND first in [col_first, col_first+col_ct).  Dense form: out[(second -
+ * row_first) * ld_elems + (first - col_first)], the diagonal element included when it lies in the block; hit form as above.
+ * Only the block products that touch the column range are computed. */
+int ldp_r2_unphased_block(ldp_engine* e, uint32_t row_first, uint32_t row_ct, uint32_t col_first, uint32_t col_ct, int as_float, void* out,
+                          uint64_t ld_elems);
+int ldp_r2_unphased_block_hits(ldp_engine* e, uint32_t row_first, uint32_t row_ct, uint32_t col_first, uint32_t col_ct, double min_r2, ldp_r2_hit* out,
+                               uint64_t capacity, uint64_t* count);
 
 /* ---- --r2-unphased table (VcorTable, plink2_ld.cc:11025; window: UpdateVcorWindow :10984-11023) ---- */
 /* Windowed plan: variant B is paired with the earlier variants A of its chromosome with bp[B] - bp[A] <= bp_radius

@@ -83,7 +83,7 @@ CABI_SYMBOLS = [
     "ldp_set_shard", "ldp_get_band", "ldp_load_genotypes", "ldp_set_maj_freqs", "ldp_set_preferred", "ldp_run",
     "ldp_run_with_stats", "ldp_pair_stats", "ldp_debug_set_variant_recs", "ldp_debug_replay_pairs", "ldp_debug_mfma_plan",
     "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
-    "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_r2_unphased_hits", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
+    "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_r2_unphased_hits", "ldp_r2_unphased_block", "ldp_r2_unphased_block_hits", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_has_dosage", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
     "ldp_pgen_variant_is_multiallelic", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_subset_samples", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
 ]
@@ -176,6 +176,9 @@ def lib():
     L.ldp_set_variants_matrix.argtypes = [vp, ctypes.c_uint32]
     L.ldp_r2_unphased_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, vp, ctypes.c_uint64]
     L.ldp_r2_unphased_hits.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+    L.ldp_r2_unphased_block.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, vp, ctypes.c_uint64]
+    L.ldp_r2_unphased_block_hits.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, vp, ctypes.c_uint64,
+                                             ctypes.POINTER(ctypes.c_uint64)]
     L.ldp_set_variants_vcor.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
                                         ctypes.c_uint32, ctypes.c_uint32]
     L.ldp_r2_unphased_band_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, vp, ctypes.c_uint64]
@@ -408,6 +411,21 @@ class LdPruneEngine:
         out = np.zeros((row_ct, ld), dtype=np.float32 if as_float else np.float64)
         self._ck(self._L.ldp_r2_unphased_rows(self._h, row_first, row_ct, 1 if as_float else 0, out.ctypes.data_as(ctypes.c_void_p), ld))
         return out
+
+    def r2_unphased_block(self, row_first, row_ct, col_first, col_ct, as_float=False):
+        """Column block of the same rows: (row_ct, col_ct) array, element [j - row_first, i - col_first] for i < j (and the
+        diagonal where it falls inside the block); everything else 0."""
+        out = np.zeros((row_ct, col_ct), dtype=np.float32 if as_float else np.float64)
+        self._ck(self._L.ldp_r2_unphased_block(self._h, row_first, row_ct, col_first, col_ct, 1 if as_float else 0, out.ctypes.data_as(ctypes.c_void_p), col_ct))
+        return out
+
+    def r2_unphased_block_hits(self, min_r2, row_first, row_ct, col_first, col_ct, capacity=1 << 20):
+        out = np.zeros(max(capacity, 1), dtype=R2_HIT_DTYPE)
+        found = ctypes.c_uint64()
+        self._ck(self._L.ldp_r2_unphased_block_hits(self._h, row_first, row_ct, col_first, col_ct, float(min_r2), out.ctypes.data_as(ctypes.c_void_p), capacity,
+                                                    ctypes.byref(found)))
+        got = out[:min(found.value, capacity)]
+        return np.sort(got, order=["first", "second"]), found.value
 
     def r2_unphased_hits(self, min_r2, row_first=0, row_ct=None, capacity=1 << 20):
         """Pairs first < second (second among the rows) with |r^2| >= min_r2, filtered on the device; sorted here by

@@ -121,6 +121,8 @@ struct PairKernelArgs {
   uint64_t r2_ld;
   uint32_t r2_row_first;         // only second variants j in [r2_row_first, r2_row_end) are stored
   uint32_t r2_row_end;
+  uint32_t r2_col_first;         // ... and only first variants i in [r2_col_first, r2_col_end) (a column block of the matrix);
+  uint32_t r2_col_end;           //     dense rows then start at column r2_col_first: element (j - r2_row_first) * r2_ld + (i - r2_col_first)
   uint64_t r2_band_base;         // r2_ld == 0: band layout, element pair_off[j] - r2_band_base + (i - lo[j])
   uint32_t r2_float;
   // device-side filter (ldp_r2_unphased_hits): with r2_hits != nullptr a pair with |r^2| >= r2_min is appended at

@@ -476,7 +476,9 @@ bool mfma_requested() {
 // everything for the all-pairs plan of --r2-unphased); lo: window start per local variant (nullptr: 0, every earlier
 // variant is a partner); only second variants in [j_first, j_end) get products (a row chunk of an r^2 matrix).
 void plan_mfma_generic(const std::vector<std::pair<uint32_t, uint32_t>>& runs, const uint32_t* lo_of, uint32_t j_first, uint32_t j_end,
-                       std::vector<MfmaWG>* out_wgs, uint64_t* out_products) {
+                       std::vector<MfmaWG>* out_wgs, uint64_t* out_products, uint32_t i_first = 0, uint32_t i_end = 0xffffffffu) {
+  // (i_first / i_end: only first variants in [i_first, i_end) are wanted -- a column block of an r^2 matrix; products whose V
+  // block lies outside it are not planned)
   out_wgs->clear();
   *out_products = 0;
   struct Wave {
@@ -586,12 +588,16 @@ void plan_mfma_generic(const std::vector<std::pair<uint32_t, uint32_t>>& runs, c
       w.blocks[1] = sfirst + kMfBlock * (a + 1);
       for (int k = 0; k < 4; ++k) {
         const int32_t off = static_cast<int32_t>(4 * p + 3) - k;  // block distance of both (J0, V_k) and (J1, V_{k+1})
-        if ((reach_of(a) >= off) && (static_cast<int32_t>(a) >= off)) {
+        const auto v_wanted = [&](uint32_t vblock) {  // does row-block `vblock` of the run hold a wanted first variant?
+          const uint64_t v0 = static_cast<uint64_t>(sfirst) + static_cast<uint64_t>(kMfBlock) * vblock;
+          return (v0 < i_end) && (v0 + kMfBlock > i_first);
+        };
+        if ((reach_of(a) >= off) && (static_cast<int32_t>(a) >= off) && v_wanted(a - static_cast<uint32_t>(off))) {
           w.mask |= static_cast<uint8_t>(1u << k);
           w.used |= static_cast<uint8_t>(1u | (1u << (2 + k)));
           w.blocks[2 + k] = sfirst + kMfBlock * (a - static_cast<uint32_t>(off));  // (on the diagonal V3 is J0 itself)
         }
-        if ((reach_of(a + 1) >= off) && (static_cast<int32_t>(a + 1) >= off)) {
+        if ((reach_of(a + 1) >= off) && (static_cast<int32_t>(a + 1) >= off) && v_wanted(a + 1 - static_cast<uint32_t>(off))) {
           w.mask |= static_cast<uint8_t>(1u << (4 + k));
           w.used |= static_cast<uint8_t>(2u | (1u << (3 + k)));
           w.blocks[3 + k] = sfirst + kMfBlock * (a + 1 - static_cast<uint32_t>(off));
@@ -1273,6 +1279,8 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.r2_ld = 0;
   A.r2_row_first = 0;
   A.r2_row_end = 0;
+  A.r2_col_first = 0;
+  A.r2_col_end = 0xffffffffu;
   A.r2_band_base = 0;
   A.r2_float = 0;
   // matrix-pipe work is attached per launch (launch_group / the inspection run); r^2 launches stay on the popcount kernels
@@ -1814,9 +1822,9 @@ namespace {
 bool r2_on_matrix_pipe(const ldp_engine* e) { return mfma_requested() && (e->P.founder_ct <= kMfMaxFounders); }
 
 int attach_mfma_plan(ldp_engine* e, PairKernelArgs* A, const std::vector<std::pair<uint32_t, uint32_t>>& runs, const uint32_t* lo, uint32_t j_first,
-                     uint32_t j_end, DevBuf* buf, uint64_t* products) {
+                     uint32_t j_end, DevBuf* buf, uint64_t* products, uint32_t i_first = 0, uint32_t i_end = 0xffffffffu) {
   std::vector<MfmaWG> wgs;
-  plan_mfma_generic(runs, lo, j_first, j_end, &wgs, products);
+  plan_mfma_generic(runs, lo, j_first, j_end, &wgs, products, i_first, i_end);
   A->n_mf_wgs = static_cast<uint32_t>(wgs.size());
   if (wgs.empty()) {
     return LDP_OK;
@@ -1986,7 +1994,8 @@ int r2_band_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
 }
 
 // rows [row_first, row_first+row_ct) of the all-pairs plan: dense into `out` (hits == nullptr) or filtered into hits->out
-int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t ld_elems, const HitRequest* hits) {
+int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t ld_elems, const HitRequest* hits,
+                 uint32_t col_first = 0, uint32_t col_end = 0xffffffffu) {
   if (!e) {
     return LDP_ERR_INVALID;
   }
@@ -1998,7 +2007,8 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
       return fail(e, LDP_ERR_INVALID, "row range / hit buffer out of bounds");
     }
     *hits->count = 0;
-  } else if ((static_cast<uint64_t>(row_first) + row_ct > e->variant_ct) || (row_ct && !out) || (ld_elems < static_cast<uint64_t>(row_first) + row_ct)) {
+  } else if ((static_cast<uint64_t>(row_first) + row_ct > e->variant_ct) || (row_ct && !out) || (col_first > col_end) ||
+             (ld_elems + col_first < std::min<uint64_t>(static_cast<uint64_t>(row_first) + row_ct, col_end))) {
     return fail(e, LDP_ERR_INVALID, "row range / leading dimension out of bounds");
   }
   int rc = ensure_device_plan(e);
@@ -2024,7 +2034,8 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
     const uint32_t jend = std::min(j0 + kTileJ, row_end);
     const uint32_t dmax = jend - 1;
     for (uint32_t j = j0; j < jend; ++j) {
-      cand += j;
+      const uint32_t hi = std::min(j, col_end);
+      cand += (hi > col_first) ? (hi - col_first) : 0;
     }
     if (!dmax) {
       continue;
@@ -2101,6 +2112,8 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
   A.r2_ld = ld_elems;
   A.r2_row_first = row_first;
   A.r2_row_end = row_end;
+  A.r2_col_first = col_first;
+  A.r2_col_end = col_end;
   A.r2_band_base = 0;
   A.r2_float = as_float ? 1 : 0;
   hipEvent_t evk[4];
@@ -2113,7 +2126,7 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
   hipError_t krc;
   if (on_mfma) {
     const std::vector<std::pair<uint32_t, uint32_t>> runs(1, std::make_pair(0u, e->local_ct));
-    rc = attach_mfma_plan(e, &A, runs, nullptr, row_first, row_end, &mf_buf, &mf_products);
+    rc = attach_mfma_plan(e, &A, runs, nullptr, row_first, row_end, &mf_buf, &mf_products, col_first, col_end);
     if (rc) {
       return rc;
     }
@@ -2158,10 +2171,13 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
   }
   // diagonal: r^2(v, v) through the same formula = 1.0, or NaN when the variant has no variance
   for (uint32_t j = row_first; (!hits) && (j < row_end); ++j) {
+    if ((j < col_first) || (j >= col_end)) {
+      continue;
+    }
     const ldp_variant_rec& r = e->recs[j];
     const int64_t var = static_cast<int64_t>(r.ssq) * static_cast<int64_t>(r.nm_ct) - static_cast<int64_t>(r.sum) * static_cast<int64_t>(r.sum);
     const bool defined = r.nm_ct && (static_cast<double>(var) * static_cast<double>(var) != 0.0);
-    const uint64_t idx = static_cast<uint64_t>(j - row_first) * ld_elems + j;
+    const uint64_t idx = static_cast<uint64_t>(j - row_first) * ld_elems + (j - col_first);
     if (as_float) {
       const uint32_t bits = defined ? 0x3f800000u : 0xffc00000u;
       memcpy(static_cast<float*>(out) + idx, &bits, 4);
@@ -2184,6 +2200,16 @@ extern "C" {
 
 int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t ld_elems) {
   return r2_rows_impl(e, row_first, row_ct, as_float, out, ld_elems, nullptr);
+}
+
+int ldp_r2_unphased_block(ldp_engine* e, uint32_t row_first, uint32_t row_ct, uint32_t col_first, uint32_t col_ct, int as_float, void* out, uint64_t ld_elems) {
+  return r2_rows_impl(e, row_first, row_ct, as_float, out, ld_elems, nullptr, col_first, col_first + col_ct);
+}
+
+int ldp_r2_unphased_block_hits(ldp_engine* e, uint32_t row_first, uint32_t row_ct, uint32_t col_first, uint32_t col_ct, double min_r2, ldp_r2_hit* out,
+                               uint64_t capacity, uint64_t* count) {
+  HitRequest hr{min_r2, out, capacity, count};
+  return r2_rows_impl(e, row_first, row_ct, 0, nullptr, static_cast<uint64_t>(row_first) + row_ct, &hr, col_first, col_first + col_ct);
 }
 
 int ldp_r2_unphased_hits(ldp_engine* e, uint32_t row_first, uint32_t row_ct, double min_r2, ldp_r2_hit* out, uint64_t capacity, uint64_t* count) {

@@ -63,8 +63,8 @@ __device__ __forceinline__ bool emit_pair(const PairKernelArgs& A, uint32_t i, u
     A.stats[A.pair_off[j] + (i - lo_j)] = st;
   }
   if (A.r2_out || A.r2_hits) {
-    if ((j < A.r2_row_first) || (j >= A.r2_row_end)) {
-      return false;  // a J-tile can straddle the edge of the requested rows
+    if ((j < A.r2_row_first) || (j >= A.r2_row_end) || (i < A.r2_col_first) || (i >= A.r2_col_end)) {
+      return false;  // a tile can straddle the edge of the requested rows / columns
     }
     const double r2 = r2_unphased(st);
     if (A.r2_hits) {
@@ -81,7 +81,7 @@ __device__ __forceinline__ bool emit_pair(const PairKernelArgs& A, uint32_t i, u
       return false;
     }
     // dense rows of the lower triangle (matrix shapes), or the band itself (windowed table)
-    const uint64_t idx = A.r2_ld ? (static_cast<uint64_t>(j - A.r2_row_first) * A.r2_ld + i) : (A.pair_off[j] - A.r2_band_base + (i - lo_j));
+    const uint64_t idx = A.r2_ld ? (static_cast<uint64_t>(j - A.r2_row_first) * A.r2_ld + (i - A.r2_col_first)) : (A.pair_off[j] - A.r2_band_base + (i - lo_j));
     if (A.r2_float) {
       const float f = (r2 != r2) ? __uint_as_float(0xffc00000u) : static_cast<float>(r2);
       static_cast<float*>(A.r2_out)[idx] = f;

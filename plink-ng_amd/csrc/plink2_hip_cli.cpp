@@ -377,6 +377,7 @@ struct Args {
   std::string preferred;
   int gpus = 1;
   bool have_r2 = false;
+  uint32_t parallel_idx = 0, parallel_tot = 1;  // --parallel k n (0-based index inside, plink2.cc:10109-10117)
   int r2_shape = -1;      // 0 square, 1 square0, 2 triangle
   int r2_float = -1;      // 1 bin4, 0 bin
   bool yes_really = false;
@@ -648,6 +649,20 @@ Args parse_args(int argc, char** argv) {
       }
       of.close();
       exit(0);
+    } else if (f == "--parallel") {
+      need(i, 2, "--parallel");
+      char* end = nullptr;
+      const long k = strtol(argv[i + 1], &end, 10);
+      if ((*end) || (k < 1) || (k > 32768)) {
+        die(5, "Error: Invalid --parallel job index '%s'.\n", argv[i + 1]);
+      }
+      const long n = strtol(argv[i + 2], &end, 10);
+      if ((*end) || (n < 2) || (n > 32768) || (n < k)) {
+        die(5, "Error: Invalid --parallel total job count '%s'.\n", argv[i + 2]);
+      }
+      A.parallel_idx = static_cast<uint32_t>(k - 1);
+      A.parallel_tot = static_cast<uint32_t>(n);
+      i += 2;
     } else if (f == "--gpus") {
       need(i, 1, "--gpus");
       A.gpus = atoi(argv[++i]);
@@ -660,6 +675,9 @@ Args parse_args(int argc, char** argv) {
   }
   if (!A.have_prune && !A.have_r2) {
     die(5, "Error: no command given (plink2-hip implements --indep-pairwise and --r2-unphased matrices).\n");
+  }
+  if (A.have_prune && (A.parallel_tot != 1)) {
+    die(9, "Error: --parallel only distributes the --r2-unphased outputs in plink2-hip (the prune shards by --gpus).\n");
   }
   if (A.have_prune && A.have_r2) {
     die(5, "Error: run --indep-pairwise and --r2-unphased separately.\n");
@@ -1374,7 +1392,7 @@ int main(int argc, char** argv) {
 
   if (A.have_r2) {
     // ---- --r2-unphased {square|square0|triangle} {bin|bin4}: every variant, every pair (Vcor, plink2_ld.cc:12050)
-    if ((!A.r2_table) && variant_ct > 400000 && !A.yes_really) {  // plink2_ld.cc:9788
+    if ((!A.r2_table) && variant_ct > 400000 && (A.parallel_tot == 1) && !A.yes_really) {  // plink2_ld.cc:9788
       die(7, "Error: Gigantic (over 400k variants) --r2-unphased unfiltered, non-distributed\ncomputation.  Rerun with the 'yes-really' modifier if you are SURE you have enough\nhard drive space and want to do this.\n");
     }
     ldp_params RP;
@@ -1399,7 +1417,7 @@ int main(int argc, char** argv) {
         }
       }
     }
-    if (A.r2_inter && (A.ld_min_r2 <= 0.0) && (variant_ct > 400000) && !A.yes_really) {  // plink2_ld.cc:11087
+    if (A.r2_inter && (A.ld_min_r2 <= 0.0) && (variant_ct > 400000) && (A.parallel_tot == 1) && !A.yes_really) {  // plink2_ld.cc:11087
       die(7, "Error: Gigantic (over 400k variants) --r2-unphased unfiltered, non-distributed\ncomputation.  Rerun with the 'yes-really' modifier if you are SURE you have enough\nhard drive space and want to do this.\n");
     }
     if ((A.r2_table && !A.r2_inter) ? ldp_set_variants_vcor(e, variant_ct, chr_idx.data(), bps.data(), A.ld_bp_radius, A.ld_var_ct_radius)
@@ -1407,12 +1425,48 @@ int main(int argc, char** argv) {
       die(12, "Error: engine setup failed: %s\n", ldp_last_error(e));
     }
     const std::string base = A.out + (A.r2_text ? ".unphased.vcor2" : ".unphased.vcor2.bin");
-    if (!A.r2_table) {
+    // --parallel k n: the reference's row shards.  Matrix (VcorMatrix, plink2_ld.cc:9800-9824): `square` takes rows
+    // [M k / n, M (k+1) / n); the triangular shapes take ParallelBounds() rows (equal numbers of lower-triangle entries) and
+    // a piece that does not reach the last row behaves as if the later variants did not exist (its .vars file, written by piece
+    // 1 only, lists just the variants before its last row; square0's zero padding still runs to the full width).  Table
+    // (VcorTable, :11157-11168): first variants [M k / n, M (k+1) / n); the header goes to piece 1.  Pieces are named
+    // <file>.<k> and concatenate to the undistributed output.
+    uint32_t shard_first = 0, shard_end = variant_ct, vars_ct = variant_ct;
+    const std::string piece_suffix = (A.parallel_tot == 1) ? std::string() : ("." + std::to_string(A.parallel_idx + 1));
+    if (A.parallel_tot != 1) {
+      if ((!A.r2_table) && (variant_ct < 2 * A.parallel_tot)) {
+        die(7, "Error: Too few variants in --r2-unphased run for --parallel %u %u.\n", A.parallel_idx + 1, A.parallel_tot);
+      }
+      if ((!A.r2_table) && (A.r2_shape != 0)) {
+        // smallest v with v (v + 1) >= x (TriangleDivide, plink2_common.cc:4936, modif = 1)
+        auto tri = [](uint64_t x) {
+          if (!x) {
+            return static_cast<uint64_t>(0);
+          }
+          uint64_t v = static_cast<uint64_t>(sqrt(static_cast<double>(x)));
+          while ((v >= 1) && ((v - 1) * v >= x)) {
+            --v;
+          }
+          while (v * (v + 1) < x) {
+            ++v;
+          }
+          return v;
+        };
+        const uint64_t tot = static_cast<uint64_t>(variant_ct) * (static_cast<uint64_t>(variant_ct) + 1);
+        shard_first = static_cast<uint32_t>(tri(tot * A.parallel_idx / A.parallel_tot));
+        shard_end = static_cast<uint32_t>(tri(tot * (A.parallel_idx + 1) / A.parallel_tot));
+        vars_ct = shard_end;
+      } else {
+        shard_first = static_cast<uint32_t>(static_cast<uint64_t>(variant_ct) * A.parallel_idx / A.parallel_tot);
+        shard_end = static_cast<uint32_t>(static_cast<uint64_t>(variant_ct) * (A.parallel_idx + 1) / A.parallel_tot);
+      }
+    }
+    if ((!A.r2_table) && (A.parallel_idx == 0)) {
       FILE* vf = fopen((base + ".vars").c_str(), "wb");
       if (!vf) {
         die(2, "Error: Failed to open %s.vars for writing.\n", base.c_str());
       }
-      for (uint32_t k = 0; k < variant_ct; ++k) {
+      for (uint32_t k = 0; k < vars_ct; ++k) {
         fputs(V.id[inc[k]].c_str(), vf);
         fputc('\n', vf);
       }
@@ -1536,11 +1590,13 @@ int main(int argc, char** argv) {
         if (ieq(name.c_str(), "PAR2")) return std::string("PAR2");
         return name;
       };
-      const std::string tpath = A.out + (A.r2_zs ? ".vcor.zst" : ".vcor");
+      const std::string tpath = A.out + ".vcor" + piece_suffix + (A.r2_zs ? ".zst" : "");
       OutFile tf;
       tf.open(tpath, A.r2_zs);
       static const char kVcorHeader[] = "#CHROM_A\tPOS_A\tID_A\tCHROM_B\tPOS_B\tID_B\tUNPHASED_R2\n";
-      tf.write(kVcorHeader, sizeof(kVcorHeader) - 1);
+      if (A.parallel_idx == 0) {
+        tf.write(kVcorHeader, sizeof(kVcorHeader) - 1);
+      }
       const double thresh = A.ld_min_r2;
       if (A.r2_inter || (thresh > 0.0)) {
         // ---- inter-chr: every pair A < B of the whole variant set, chromosome 0 included (plink2_ld.cc:11082-11116).
@@ -1559,14 +1615,17 @@ int main(int argc, char** argv) {
         const bool device_filter = (thresh > 0.0);
         std::vector<ldp_r2_hit> dev_hits(device_filter ? (1u << 24) : 0);
         uint32_t big_rows = 65536;
-        for (uint32_t r0 = 0; r0 < variant_ct;) {
+        // (a shard owns the pairs whose FIRST variant lies in [shard_first, shard_end): second variants from shard_first + 1 on)
+        for (uint32_t r0 = (A.parallel_tot == 1) ? 0 : shard_first; r0 < variant_ct;) {
           uint32_t rows = static_cast<uint32_t>(std::max<uint64_t>(32, (1ull << 28) / (static_cast<uint64_t>(r0 + 4096) * 8)));
           rows = std::min(std::min(rows, variant_ct - r0), 65536u);
           if (device_filter) {
             const uint32_t big = A.r2_inter ? std::min(std::min<uint32_t>(rows * 16, variant_ct - r0), 65536u)  // (no dense buffer to size)
                                             : std::min(big_rows, variant_ct - r0);
             uint64_t found = 0;
-            if (ldp_r2_unphased_hits(e, r0, big, thresh, dev_hits.data(), dev_hits.size(), &found)) {
+            if ((A.r2_inter && (A.parallel_tot != 1))
+                    ? ldp_r2_unphased_block_hits(e, r0, big, shard_first, shard_end - shard_first, thresh, dev_hits.data(), dev_hits.size(), &found)
+                    : ldp_r2_unphased_hits(e, r0, big, thresh, dev_hits.data(), dev_hits.size(), &found)) {
               die(12, "Error: %s\n", ldp_last_error(e));
             }
             if (found <= dev_hits.size()) {
@@ -1574,7 +1633,9 @@ int main(int argc, char** argv) {
                 return (a.second != b.second) ? (a.second < b.second) : (a.first < b.first);
               });
               for (uint64_t q = 0; q < found; ++q) {
-                hits.push_back({dev_hits[q].first, dev_hits[q].second, dev_hits[q].r2});
+                if ((dev_hits[q].first >= shard_first) && (dev_hits[q].first < shard_end)) {
+                  hits.push_back({dev_hits[q].first, dev_hits[q].second, dev_hits[q].r2});
+                }
               }
               r0 += big;
               continue;
@@ -1601,7 +1662,7 @@ int main(int argc, char** argv) {
               for (uint32_t q = q0; q < q1; ++q) {
                 const uint32_t j = r0 + q;
                 const double* row = chunk.data() + static_cast<uint64_t>(q) * ld;
-                for (uint32_t i = 0; i < j; ++i) {
+                for (uint32_t i = shard_first; (i < j) && (i < shard_end); ++i) {
                   const double r2 = row[i];
                   if ((thresh >= 0.0) && (!(fabs(r2) >= thresh))) {  // VcorTableWriteThread :10816-10821
                     continue;
@@ -1683,12 +1744,12 @@ int main(int argc, char** argv) {
       uint32_t chr_a_idx = 0xffffffffu;
       uint64_t written = 0;
       const uint64_t kMaxPairs = 1ull << 25;  // 256 MiB of doubles per chunk
-      for (uint32_t a0 = 0; a0 < variant_ct;) {
+      for (uint32_t a0 = shard_first; a0 < shard_end;) {
         // first variants [a0, a1): their partners are the second variants (a0, hi[a1-1]]
         uint32_t a1 = a0;
         uint64_t pairs = 0;
         uint32_t row_end = a0 + 1;
-        while (a1 < variant_ct) {
+        while (a1 < shard_end) {
           const uint32_t new_end = std::max(row_end, hi[a1] + 1);
           uint64_t add = 0;
           for (uint32_t j = row_end; j < new_end; ++j) {
@@ -1756,19 +1817,22 @@ int main(int argc, char** argv) {
       return 0;
     }
     const size_t esz = A.r2_float ? 4 : 8;
-    const std::string mpath = base + ((A.r2_text && A.r2_zs) ? ".zst" : "");
+    const std::string mpath = base + piece_suffix + ((A.r2_text && A.r2_zs) ? ".zst" : "");
     OutFile mf;
     mf.open(mpath, A.r2_text && A.r2_zs);
-    std::vector<uint8_t> full;  // square needs the mirrored upper triangle: whole matrix in host memory
+    // square needs the mirrored upper triangle: the shard's rows, full width, in host memory.  The lower part of row j comes
+    // from the engine's row j; the upper part (columns i > j) from the column block [shard rows] of the later rows i.
+    const uint32_t piece_rows = shard_end - shard_first;
+    std::vector<uint8_t> full;
     if (A.r2_shape == 0) {
-      full.assign(static_cast<size_t>(variant_ct) * variant_ct * esz, 0);
+      full.assign(static_cast<size_t>(piece_rows) * variant_ct * esz, 0);
     }
     std::vector<uint8_t> chunk;
     std::string textbuf;
-    for (uint32_t r0 = 0; r0 < variant_ct;) {
+    for (uint32_t r0 = shard_first; r0 < shard_end;) {
       // rows per chunk: about 1 GiB of output
       uint32_t rows = static_cast<uint32_t>(std::max<uint64_t>(32, (1ull << 30) / (static_cast<uint64_t>(r0 + 4096) * esz)));
-      rows = std::min(std::min(rows, variant_ct - r0), 65536u);
+      rows = std::min(std::min(rows, shard_end - r0), 65536u);
       const uint64_t ld = static_cast<uint64_t>(r0) + rows;
       chunk.assign(static_cast<size_t>(rows) * ld * esz, 0);
       if (ldp_r2_unphased_rows(e, r0, rows, A.r2_float, chunk.data(), ld)) {
@@ -1804,19 +1868,42 @@ int main(int argc, char** argv) {
             left -= w;
           }
         } else {
-          memcpy(full.data() + static_cast<uint64_t>(j) * variant_ct * esz, row, (static_cast<size_t>(j) + 1) * esz);
-          for (uint32_t i = 0; i < j; ++i) {
-            memcpy(full.data() + (static_cast<uint64_t>(i) * variant_ct + j) * esz, row + static_cast<uint64_t>(i) * esz, esz);
-          }
+          memcpy(full.data() + static_cast<uint64_t>(j - shard_first) * variant_ct * esz, row, (static_cast<size_t>(j) + 1) * esz);
         }
       }
       r0 += rows;
     }
     if (A.r2_shape == 0 && !full.empty()) {
+      if (piece_rows == variant_ct) {
+        // the whole matrix is here: mirror it
+        for (uint32_t j = 1; j < variant_ct; ++j) {
+          for (uint32_t i = 0; i < j; ++i) {
+            memcpy(full.data() + (static_cast<uint64_t>(i) * variant_ct + j) * esz, full.data() + (static_cast<uint64_t>(j) * variant_ct + i) * esz, esz);
+          }
+        }
+      }
+      // upper parts of a shard: second variants i in (shard_first, M), first variants = the shard's rows
+      for (uint32_t r0 = (piece_rows == variant_ct) ? variant_ct : (shard_first + 1); r0 < variant_ct;) {
+        uint32_t rows = static_cast<uint32_t>(std::max<uint64_t>(32, (1ull << 29) / (static_cast<uint64_t>(piece_rows) * esz)));
+        rows = std::min(std::min(rows, variant_ct - r0), 65536u);
+        chunk.assign(static_cast<size_t>(rows) * piece_rows * esz, 0);
+        if (ldp_r2_unphased_block(e, r0, rows, shard_first, piece_rows, A.r2_float, chunk.data(), piece_rows)) {
+          die(12, "Error: %s\n", ldp_last_error(e));
+        }
+        for (uint32_t q = 0; q < rows; ++q) {
+          const uint32_t i = r0 + q;  // second variant
+          const uint32_t jmax = std::min(i, shard_end);  // first variants j in [shard_first, jmax)
+          const uint8_t* brow = chunk.data() + static_cast<uint64_t>(q) * piece_rows * esz;
+          for (uint32_t j = shard_first; j < jmax; ++j) {
+            memcpy(full.data() + (static_cast<uint64_t>(j - shard_first) * variant_ct + i) * esz, brow + static_cast<uint64_t>(j - shard_first) * esz, esz);
+          }
+        }
+        r0 += rows;
+      }
       if (A.r2_text) {
         const double* dm = reinterpret_cast<const double*>(full.data());
         char num[40];
-        for (uint32_t j = 0; j < variant_ct; ++j) {
+        for (uint32_t j = 0; j < piece_rows; ++j) {
           textbuf.clear();
           for (uint32_t i = 0; i < variant_ct; ++i) {
             textbuf.append(num, format_g6(dm[static_cast<uint64_t>(j) * variant_ct + i], num) - num);
@@ -1830,7 +1917,7 @@ int main(int argc, char** argv) {
       }
     }
     mf.close();
-    logprintf("--r2-unphased: Matrix written to %s .\n", mpath.c_str());
+    logprintf("--r2-unphased: Matrix%s written to %s .\n", (A.parallel_tot == 1) ? "" : " piece", mpath.c_str());
     ldp_destroy(e);
     ldp_pgen_close(pg);
     if (g_log) {

@@ -12,6 +12,8 @@ import pytest
 import ldtools as T
 from test_golden import GOLDEN, load
 
+REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "plink2")
+
 pytestmark = pytest.mark.gpu
 
 
@@ -311,3 +313,83 @@ def test_cli_r2_multiallelic_variants_match_reference(gpu_pkg, tmp_path):
         ref, got = both(args)
         assert ref.returncode == 0 and got.returncode == 0, (args, ref.stdout[-300:], got.stdout[-300:])
         assert filecmp.cmp(os.path.join(tmp, "ref" + ext), os.path.join(tmp, "hip" + ext), shallow=False), args
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,miss", [(260, 90, 0.0), (333, 70, 0.04)])
+def test_matrix_column_blocks_match_the_rows(gpu_pkg, m, n, miss):
+    """ldp_r2_unphased_block / _block_hits (the pieces of `--parallel k n` and of a device shard): every block of the lower
+    triangle equals the same entries of the full rows; hits of a block = the full hit list restricted to it."""
+    pkg = gpu_pkg
+    raw = T.synth_raw_codes(m, n, seed=3 * m + n, missing_rate=miss)
+    eng = pkg.LdPruneEngine(n, 2, 1, False, 0.5, device=0)
+    eng.set_variants_matrix(m)
+    eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+    full = eng.r2_unphased_rows()
+    hits_all, found_all = eng.r2_unphased_hits(0.05)
+    assert found_all == len(hits_all)
+    for (r0, rc, c0, cc) in [(0, m, 0, m), (100, 60, 37, 50), (200, m - 200, 0, 33), (64, 64, 64, 64), (5, 20, 100, 40), (130, 70, 96, 64)]:
+        blk = eng.r2_unphased_block(r0, rc, c0, cc)
+        want = np.zeros_like(blk)
+        for j in range(r0, r0 + rc):
+            hi = min(j + 1, c0 + cc)
+            if hi > c0:
+                want[j - r0, :hi - c0] = full[j, c0:hi]
+        assert np.array_equal(np.isnan(blk), np.isnan(want))
+        assert np.array_equal(blk[~np.isnan(blk)], want[~np.isnan(want)])
+        h, found = eng.r2_unphased_block_hits(0.05, r0, rc, c0, cc)
+        sel = hits_all[(hits_all["second"] >= r0) & (hits_all["second"] < r0 + rc) & (hits_all["first"] >= c0) & (hits_all["first"] < c0 + cc)]
+        assert found == len(sel) and np.array_equal(h, np.sort(sel, order=["first", "second"]))
+    eng.close()
+
+
+def _concat(paths):
+    return b"".join(open(p, "rb").read() for p in paths)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mods", [["square0", "bin"], ["triangle", "bin4"], ["square", "bin"], ["triangle"], ["square0"], ["square", "bin4"]])
+def test_cli_matrix_parallel_pieces_match_reference(gpu_pkg, tmp_path, mods):
+    """`--parallel k n` for the matrix shapes (VcorMatrix, plink2_ld.cc:9800-9824): every piece byte-identical to the
+    reference's piece, .vars written by piece 1 only, and the pieces concatenate to the undistributed file."""
+    cli = gpu_pkg.build_cli()
+    m, n = 157, 120
+    raw = T.synth_raw_codes(m, n, seed=77, missing_rate=0.03)
+    chroms = ["1"] * 80 + ["2"] * (m - 80)
+    bps = (1000 + 137 * np.arange(m)).astype(np.uint32)
+    T.write_bed(str(tmp_path / "d"), raw, chroms, bps)
+    ext = ".unphased.vcor2" + (".bin" if ("bin" in mods or "bin4" in mods) else "")
+    for k in (1, 2, 3):
+        a = subprocess.run([REF, "--bfile", "d", "--r2-unphased"] + mods + ["--parallel", str(k), "3", "--out", "ref"], cwd=str(tmp_path),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        b = subprocess.run([cli, "--bfile", "d", "--r2-unphased"] + mods + ["--parallel", str(k), "3", "--out", "hip"], cwd=str(tmp_path),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert a.returncode == 0, a.stdout[-800:]
+        assert b.returncode == 0, b.stdout[-800:]
+        assert open(str(tmp_path / ("ref%s.%d" % (ext, k))), "rb").read() == open(str(tmp_path / ("hip%s.%d" % (ext, k))), "rb").read(), (mods, k)
+    assert open(str(tmp_path / ("ref%s.vars" % ext)), "rb").read() == open(str(tmp_path / ("hip%s.vars" % ext)), "rb").read()
+    whole = subprocess.run([cli, "--bfile", "d", "--r2-unphased"] + mods + ["--out", "all"], cwd=str(tmp_path), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert whole.returncode == 0, whole.stdout[-800:]
+    assert _concat([str(tmp_path / ("hip%s.%d" % (ext, k))) for k in (1, 2, 3)]) == open(str(tmp_path / ("all" + ext)), "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mods,extra", [(["inter-chr"], ["--ld-window-r2", "0.1"]), (["inter-chr"], ["--ld-window-r2", "0"]),
+                                        ([], ["--ld-window-kb", "5", "--ld-window-r2", "0.05"]), ([], ["--ld-window-kb", "3", "--ld-window-r2", "0"])])
+def test_cli_table_parallel_pieces_match_reference(gpu_pkg, tmp_path, mods, extra):
+    """`--parallel k n` for the .vcor tables (VcorTable, plink2_ld.cc:11157-11168): shards by first variant, header in piece 1."""
+    cli = gpu_pkg.build_cli()
+    m, n = 211, 100
+    raw = T.synth_raw_codes(m, n, seed=91, missing_rate=0.02)
+    chroms = ["1"] * 100 + ["3"] * (m - 100)
+    bps = (500 + 97 * np.arange(m)).astype(np.uint32)
+    T.write_bed(str(tmp_path / "d"), raw, chroms, bps)
+    for k in (1, 2, 3, 4):
+        a = subprocess.run([REF, "--bfile", "d", "--r2-unphased"] + mods + extra + ["--parallel", str(k), "4", "--out", "ref"], cwd=str(tmp_path),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        b = subprocess.run([cli, "--bfile", "d", "--r2-unphased"] + mods + extra + ["--parallel", str(k), "4", "--out", "hip"], cwd=str(tmp_path),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert a.returncode == 0, a.stdout[-800:]
+        assert b.returncode == 0, b.stdout[-800:]
+        assert open(str(tmp_path / ("ref.vcor.%d" % k)), "rb").read() == open(str(tmp_path / ("hip.vcor.%d" % k)), "rb").read(), (mods, extra, k)
