@@ -603,6 +603,12 @@ void plan_mfma_generic(const std::vector<std::pair<uint32_t, uint32_t>>& runs, c
           w.blocks[3 + k] = sfirst + kMfBlock * (a + 1 - static_cast<uint32_t>(off));
         }
       }
+      if (p == 0) {
+        // on the diagonal the kernel takes V3 / V4 from the J0 / J1 fragments: those blocks must be staged (and have a slot)
+        // even when none of their own products is wanted (a column block, or a J0 block whose variants have no partner)
+        w.used |= (w.mask & 0x48u) ? 1u : 0u;
+        w.used |= (w.mask & 0x80u) ? 2u : 0u;
+      }
       *out = w;
       return w.mask != 0;
     };

@@ -251,6 +251,9 @@ def _mfma_plan_coverage(pkg, m, nchr, seed, window, step, is_bp, spacing, rank=0
                 continue
             assert mask != 0 and j_lo <= jv < jend <= j_hi
             diag = (vv + 96 == jv)
+            if diag:  # the kernel reads V3 / V4 through the J0 / J1 slots there
+                assert (not mask & 0x48) or rb[slot[0]] == jv
+                assert (not mask & 0x80) or rb[slot[1]] == jv + 32
             for p in range(8):
                 if not (mask >> p) & 1:
                     continue
