@@ -566,7 +566,7 @@ constexpr uint32_t kMfGenRowBlocks = 5;  // J, V0..V3 of the workgroup
 constexpr uint32_t kMfGenInstr = kMfGenRowBlocks * 2;
 constexpr uint32_t kMfGenDmaPerWave = (kMfGenInstr + kMfWaves - 1) / kMfWaves;
 
-__global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_general_kernel(PairKernelArgs A) {
+__global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(PairKernelArgs A) {
   using G = StageGeom<4>;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_src_off[kMfGenDmaPerWave * kMfWaves * 64];
@@ -773,7 +773,12 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
   }();
   if (general_on) {
     static const size_t glds = []() {
-      const size_t bytes = static_cast<size_t>(kMfLdsDwords) * sizeof(uint32_t);
+      // 5 row-blocks = 10 KiB per stage: a ring of five in 50 KiB (+ 3 KiB static) lets THREE workgroups share a CU (138 VGPRs
+      // allow three waves per SIMD); LDP_DEBUG_MFMA_GEN_LDS_KB overrides (tuning aid)
+      size_t bytes = 50 * 1024;
+      if (const char* kb = getenv("LDP_DEBUG_MFMA_GEN_LDS_KB")) {
+        bytes = std::min<size_t>(std::max<size_t>(static_cast<size_t>(atoi(kb)), 20), 150) * 1024;
+      }
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
       return bytes;
     }();

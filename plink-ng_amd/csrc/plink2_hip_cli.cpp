@@ -33,10 +33,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cfloat>
 #include <fstream>
+#include <functional>
 #include <sstream>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -390,6 +393,17 @@ struct Args {
   uint32_t ld_var_ct_radius = 0x7fffffff;  // --ld-window N: N - 1
   uint32_t ld_bp_radius = 0xffffffffu;     // --ld-window-kb; UINT32_MAX = not given (table default 1000 kb)
   double ld_min_r2 = 2.0;                  // --ld-window-r2 (after the reference's epsilon); 2.0 = not given
+  // --clump (InitClump, plink2_ld.cc:62-78; parsing plink2.cc:4960-5120)
+  bool have_clump = false;
+  std::string clump_file;
+  bool clump_unphased = false;
+  bool clump_no_test = false;
+  std::vector<std::string> clump_id_field, clump_p_field, clump_test_field, clump_test;
+  double clump_ln_p1 = 2.3025850929940457 * -4.0 * (1.0 - kSmallEpsilon);
+  double clump_ln_p2 = 2.3025850929940457 * -2.0 * (1.0 - kSmallEpsilon);
+  double clump_r2_raw = 0.5;
+  double clump_r2 = 0.5 * (1.0 + kSmallEpsilon);
+  uint32_t clump_bp_radius = 249999;
   bool timing = false;    // --timing: print per-phase wall times
   bool dry_run = false;  // parse + plan only, print the parameters exactly (%a) and exit: used by the CPU tests
 };
@@ -421,6 +435,8 @@ bool ieq(const char* a, const char* b) {
   }
   return !*a && !*b;
 }
+
+const char* scan_ln(const char* s, double* ln_out);  // (--clump section below)
 
 Args parse_args(int argc, char** argv) {
   Args A;
@@ -567,6 +583,64 @@ Args parse_args(int argc, char** argv) {
         A.r2_float = 0;  // computed as doubles, printed with 6 significant digits
       }
       A.have_r2 = true;
+    } else if (f == "--clump") {  // plink2.cc:4861-4958
+      need(i, 1, "--clump");
+      if ((i + 2 < argc) && (argv[i + 2][0] != '-')) {
+        die(9, "Error: plink2-hip's --clump takes one report file and the default column set.\n");
+      }
+      A.clump_file = argv[++i];
+      A.have_clump = true;
+    } else if (f == "--clump-unphased") {
+      A.clump_unphased = true;
+    } else if ((f == "--clump-p1") || (f == "--clump-p2")) {  // plink2.cc:5015-5046
+      need(i, 1, f.c_str());
+      const std::string v = argv[++i];
+      double ln;
+      const char* endp = scan_ln(v.c_str(), &ln);
+      if (!endp || *endp || (ln > 0.0)) {
+        die(5, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
+      }
+      ((f == "--clump-p1") ? A.clump_ln_p1 : A.clump_ln_p2) = ln * (1.0 - kSmallEpsilon);
+    } else if (f == "--clump-r2") {  // plink2.cc:5047-5059
+      need(i, 1, "--clump-r2");
+      const std::string v = argv[++i];
+      double d;
+      const char* endp;
+      if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || (d >= 1.0 - kSmallEpsilon)) {
+        die(5, "Error: Invalid --clump-r2 argument '%s'.\n", v.c_str());
+      }
+      A.clump_r2_raw = d;
+      A.clump_r2 = d * (1.0 + kSmallEpsilon);
+    } else if (f == "--clump-kb") {  // plink2.cc:4960-4978
+      need(i, 1, "--clump-kb");
+      const std::string v = argv[++i];
+      double d;
+      const char* endp;
+      if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || (d < 0.001)) {
+        die(5, "Error: Invalid --clump-kb argument '%s'.\n", v.c_str());
+      }
+      d *= 1000;
+      A.clump_bp_radius = (d > 2147483647.0) ? 0x7ffffffeu : static_cast<uint32_t>(static_cast<int32_t>(d * (1.0 + kSmallEpsilon) - 1));
+    } else if ((f == "--clump-id-field") || (f == "--clump-snp-field") || (f == "--clump-p-field") || (f == "--clump-field") ||
+               (f == "--clump-test-field") || (f == "--clump-test")) {
+      // one or more names, highest priority first; --clump-test[-field] without arguments turns the TEST filter off
+      std::vector<std::string> names;
+      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+        names.push_back(argv[++i]);
+      }
+      if ((f == "--clump-test") || (f == "--clump-test-field")) {
+        if (names.empty()) {
+          A.clump_no_test = true;
+        }
+        ((f == "--clump-test") ? A.clump_test : A.clump_test_field) = names;
+      } else {
+        if (names.empty()) {
+          die(5, "Error: %s needs at least one column name.\n", f.c_str());
+        }
+        (((f == "--clump-p-field") || (f == "--clump-field")) ? A.clump_p_field : A.clump_id_field) = names;
+      }
+    } else if (f.compare(0, 7, "--clump") == 0) {
+      die(9, "Error: %s is not supported by plink2-hip's --clump yet.\n", f.c_str());
     } else if (f == "--ld-window") {  // plink2.cc:7908-7920
       need(i, 1, "--ld-window");
       const std::string v = argv[++i];
@@ -672,6 +746,23 @@ Args parse_args(int argc, char** argv) {
     } else {
       die(5, "Error: Unrecognized flag ('%s').  plink2-hip implements the --indep-pairwise path only.\n", f.c_str());
     }
+  }
+  if (A.have_clump) {
+    if (A.have_prune || A.have_r2) {
+      die(5, "Error: run --clump on its own.\n");
+    }
+    if (!A.clump_unphased) {
+      // (without it the reference uses phased-hardcall / EM haplotype-frequency r^2, ComputeR2 :6490-6650: not this path)
+      die(9, "Error: plink2-hip's --clump computes unphased hardcall r^2 only: add --clump-unphased.\n");
+    }
+    if (A.parallel_tot != 1) {
+      die(5, "Error: --parallel has no effect on --clump.\n");
+    }
+    // the rest of the program sees a windowed r^2 run: chromosome 0 stripped, sorted positions required
+    A.have_r2 = true;
+    A.r2_table = true;
+  } else if (A.clump_unphased) {
+    die(5, "Error: --clump-unphased must be used with --clump.\n");
   }
   if (!A.have_prune && !A.have_r2) {
     die(5, "Error: no command given (plink2-hip implements --indep-pairwise and --r2-unphased matrices).\n");
@@ -1236,6 +1327,654 @@ void fetch_raw_row(ldp_pgen* pg, int storage_mode, uint32_t raw_variant, uint32_
   }
 }
 
+// ---- --clump (ClumpReports, plink2_ld.cc:7506-9480) --------------------------------------------------------------
+// What plink2-hip covers: one association report, biallelic diploid variants, --clump-unphased (the hardcall r^2 of
+// ComputeR2, plink2_ld.cc:6654-6682 -- the quantity the matrix-pipe kernels produce), default column set, and the
+// --clump-p1/-p2/-r2/-kb/-id-field/-p-field/-test/-test-field settings.  The reference walks the index candidates in
+// p-value order and, for each one still unclumped, computes r^2 against the unclumped variants of its window.  Here
+// the r^2 > threshold pairs of the WHOLE band (every observed variant against its +-kb neighbours) come from one pass
+// of the windowed-table kernels, filtered in the kernel epilogue; the rank-ordered greedy assignment then runs on the
+// host over that sparse pair list.  The pair set tested is a superset of the reference's, each r^2 is the same
+// double, and the greedy pass only ever looks at (index, window member) pairs, so the clumps are identical.
+
+const double kLn10 = 2.3025850929940457;
+const double kRecipLn10 = 0.43429448190325176;
+
+// ln of a nonnegative decimal number, as ScanadvLn (include/plink2_string.cc:1530-1760) derives it: up to ~17
+// significant digits accumulate in an integer, the rest only move the decimal exponent, and ln = log(digits) +
+// e10 * ln(10) -- so "1e-400" works, and the doubles (hence the candidate order and the bins) match the reference's.
+// Returns the end of the number, or nullptr when there is none; zero gives -DBL_MAX.
+const char* scan_ln(const char* s, double* ln_out) {
+  const bool neg = (*s == '-');
+  if (neg || (*s == '+')) {
+    ++s;
+  }
+  int64_t digits = 0;
+  long e10 = 0;
+  bool any = false;
+  bool full = false;  // 10^16 reached: later digits are not read
+  for (; (*s >= '0') && (*s <= '9'); ++s) {
+    any = true;
+    if (!full) {
+      digits = digits * 10 + (*s - '0');
+      full = (digits >= 10000000000000000LL);
+    } else {
+      ++e10;
+    }
+  }
+  if (*s == '.') {
+    ++s;
+    if ((!any) && !((*s >= '0') && (*s <= '9'))) {
+      return nullptr;
+    }
+    for (; (*s >= '0') && (*s <= '9'); ++s) {
+      any = true;
+      if (!full) {
+        digits = digits * 10 + (*s - '0');
+        --e10;
+        full = (digits >= 10000000000000000LL);
+      }
+    }
+  }
+  if (!any || (neg && digits)) {
+    return nullptr;
+  }
+  if ((*s == 'e') || (*s == 'E')) {
+    ++s;
+    const bool eneg = (*s == '-');
+    if (eneg || (*s == '+')) {
+      ++s;
+    }
+    long ex = 0;
+    for (; (*s >= '0') && (*s <= '9'); ++s) {
+      if (ex >= 107374182) {
+        if (!eneg) {
+          return nullptr;
+        }
+        while ((*s >= '0') && (*s <= '9')) {
+          ++s;
+        }
+        *ln_out = -DBL_MAX;
+        return s;
+      }
+      ex = ex * 10 + (*s - '0');
+    }
+    e10 += eneg ? -ex : ex;
+  }
+  if (!digits) {
+    *ln_out = -DBL_MAX;
+    return s;
+  }
+  double ln = log(static_cast<double>(digits));
+  if (e10) {
+    ln += static_cast<double>(e10) * kLn10;
+  }
+  *ln_out = ln;
+  return s;
+}
+
+// exp(ln_val) with 6 significant digits, as lntoa_g prints p-values (include/plink2_string.cc:2876-2946): plain
+// decimals down to 1e-4, d.ddddde-XX below, mantissa and exponent taken from the logarithm so that values under
+// DBL_MIN still print.
+char* format_ln_g6(double ln_val, char* out) {
+  if (ln_val < 13.81551005796414) {
+    if (ln_val > -9.210340871976317) {
+      if (ln_val > -5.000001349509205e-7) {
+        if (ln_val < 4.999987599993995e-6) {
+          *out++ = '1';
+          return out;
+        }
+        return format_g6(exp(ln_val), out);
+      }
+      double x = exp(ln_val);
+      *out++ = '0';
+      *out++ = '.';
+      if (x < 9.9999949999999e-3) {
+        x *= 100;
+        *out++ = '0';
+        *out++ = '0';
+      }
+      if (x < 9.9999949999999e-2) {
+        x *= 10;
+        *out++ = '0';
+      }
+      return put_digits_trimmed(banker_round(x * 1000000), 6, 1, out);
+    }
+    if (ln_val < 2147483643.0 * (-kLn10)) {
+      *out++ = '0';
+      return out;
+    }
+  } else if (ln_val > 2147483643.0 * kLn10) {
+    memcpy(out, "inf", 3);
+    return out + 3;
+  }
+  int32_t xp10 = static_cast<int32_t>(fma(ln_val, kRecipLn10, 5.000001349509205e-7 * kRecipLn10));
+  double mantissa = exp(fma(static_cast<double>(xp10), -kLn10, ln_val));
+  if (mantissa < 0.99999949999999) {
+    mantissa *= 10;
+    xp10 -= 1;
+  } else if (mantissa > 9.9999949999999) {
+    mantissa *= 0.1;
+    xp10 += 1;
+  }
+  const uint32_t t = banker_round(mantissa * 100000);
+  *out++ = static_cast<char>('0' + t / 100000);
+  if (t % 100000) {
+    *out++ = '.';
+    out = put_digits_trimmed(t % 100000, 5, 1, out);
+  }
+  *out++ = 'e';
+  *out++ = (xp10 < 0) ? '-' : '+';
+  const uint32_t ax = static_cast<uint32_t>((xp10 < 0) ? -xp10 : xp10);
+  if (ax < 10) {
+    *out++ = '0';
+  }
+  return out + snprintf(out, 12, "%u", ax);
+}
+
+// digit runs compare as numbers, everything else bytewise (the order NsortDedupAndWrite gives the .missing_id list)
+bool natural_less(const std::string& a, const std::string& b) {
+  size_t i = 0, j = 0;
+  while ((i < a.size()) && (j < b.size())) {
+    const bool da = (a[i] >= '0') && (a[i] <= '9'), db = (b[j] >= '0') && (b[j] <= '9');
+    if (da && db) {
+      size_t i1 = i, j1 = j;
+      while ((i1 < a.size()) && (a[i1] == '0')) {
+        ++i1;
+      }
+      while ((j1 < b.size()) && (b[j1] == '0')) {
+        ++j1;
+      }
+      size_t i2 = i1, j2 = j1;
+      while ((i2 < a.size()) && (a[i2] >= '0') && (a[i2] <= '9')) {
+        ++i2;
+      }
+      while ((j2 < b.size()) && (b[j2] >= '0') && (b[j2] <= '9')) {
+        ++j2;
+      }
+      if ((i2 - i1) != (j2 - j1)) {
+        return (i2 - i1) < (j2 - j1);
+      }
+      const int c = a.compare(i1, i2 - i1, b, j1, j2 - j1);
+      if (c) {
+        return c < 0;
+      }
+      i = i2;
+      j = j2;
+      continue;
+    }
+    if (a[i] != b[j]) {
+      return static_cast<unsigned char>(a[i]) < static_cast<unsigned char>(b[j]);
+    }
+    ++i;
+    ++j;
+  }
+  if ((i == a.size()) != (j == b.size())) {
+    return i == a.size();
+  }
+  return a < b;
+}
+
+// bin boundaries of the default 'bins' column set (kClumpDefaultLnBinBounds, plink2_ld.cc:7498): ln of 1e-4, 1e-3, 1e-2, 0.05
+const double kClumpLnBins[4] = {-9.210340371976706, -6.907755278982529, -4.605170185988353, -2.995732273554161};
+
+struct ClumpData {
+  // per dataset variant (index into the caller's included-variant list)
+  std::vector<double> best_ln;                // lowest ln p among the lines at or below the load threshold; 0 without one
+  std::vector<uint32_t> nonsig;               // lines above every bin boundary
+  std::vector<std::vector<uint8_t>> entries;  // one per loaded line: (bin << 1) | (ln p > ln p2)
+  std::vector<uint8_t> observed;
+  std::vector<std::string> missing_ids;       // top (p <= p1) IDs absent from the dataset
+};
+
+uint32_t clump_bin(double ln_pval) {  // LowerBoundNonemptyD: boundaries strictly below
+  uint32_t b = 0;
+  while ((b < 4) && (ln_pval > kClumpLnBins[b])) {
+    ++b;
+  }
+  return b;
+}
+
+// The report -> per-variant p-value lists (plink2_ld.cc:7667-7858).
+void clump_load_report(const Args& A, const Variants& V, const std::vector<uint32_t>& inc, ClumpData* D) {
+  const uint32_t variant_ct = static_cast<uint32_t>(inc.size());
+  D->best_ln.assign(variant_ct, 0.0);
+  D->nonsig.assign(variant_ct, 0);
+  D->entries.assign(variant_ct, std::vector<uint8_t>());
+  D->observed.assign(variant_ct, 0);
+  // ID -> included-variant index; kDup marks IDs the dataset holds more than once (an error only when the report names one)
+  const uint32_t kDup = 0xffffffffu;
+  std::unordered_map<std::string, uint32_t> by_id;
+  by_id.reserve(static_cast<size_t>(variant_ct) * 2);
+  for (uint32_t k = 0; k < variant_ct; ++k) {
+    auto it = by_id.emplace(V.id[inc[k]], k);
+    if (!it.second) {
+      it.first->second = kDup;
+    }
+  }
+  const double ln_p1 = A.clump_ln_p1, ln_p2 = A.clump_ln_p2;
+  const double load_thresh = std::max(std::max(ln_p1, ln_p2), kClumpLnBins[3]);
+  const std::string text = slurp(A.clump_file);
+  const char* p = text.c_str();
+  const char* const end = p + text.size();
+  size_t line_idx = 0;
+  auto next_line = [&](const char** ls, const char** le) {
+    if (p >= end) {
+      return false;
+    }
+    ++line_idx;
+    *ls = p;
+    const char* nl = static_cast<const char*>(memchr(p, '\n', end - p));
+    *le = nl ? nl : end;
+    p = nl ? nl + 1 : end;
+    while ((*ls < *le) && ((**ls == ' ') || (**ls == '\t'))) {
+      ++*ls;
+    }
+    return true;
+  };
+  auto tokens_of = [](const char* ls, const char* le, std::vector<std::pair<const char*, uint32_t>>* out) {
+    out->clear();
+    while (ls < le) {
+      while ((ls < le) && ((*ls == ' ') || (*ls == '\t') || (*ls == '\r'))) {
+        ++ls;
+      }
+      const char* t0 = ls;
+      while ((ls < le) && (*ls != ' ') && (*ls != '\t') && (*ls != '\r')) {
+        ++ls;
+      }
+      if (ls > t0) {
+        out->emplace_back(t0, static_cast<uint32_t>(ls - t0));
+      }
+    }
+  };
+  const char* ls;
+  const char* le;
+  std::vector<std::pair<const char*, uint32_t>> toks;
+  // The first nonblank line is the header.  (The reference means to skip '##' lines first, but its test compares three
+  // bytes -- "##" and a terminator, plink2_ld.cc:7680 -- which no line of a text file matches; a '##' line is
+  // therefore read as the header there, and here.)
+  do {
+    if (!next_line(&ls, &le)) {
+      die(3, "Error: %s is empty.\n", A.clump_file.c_str());
+    }
+  } while (ls == le);  // (the reference's text reader skips blank lines)
+  if (*ls == '#') {
+    ++ls;
+  }
+  tokens_of(ls, le, &toks);
+  // column search (SearchHeaderLine, plink2_cmdline.cc:4270): per field a priority list of names
+  std::vector<std::string> want[3];
+  want[0] = A.clump_id_field.empty() ? std::vector<std::string>{"ID", "SNP"} : A.clump_id_field;
+  if (!A.clump_no_test) {
+    want[1] = A.clump_test_field.empty() ? std::vector<std::string>{"TEST"} : A.clump_test_field;
+  }
+  want[2] = A.clump_p_field.empty() ? std::vector<std::string>{"P"} : A.clump_p_field;
+  int col[3] = {-1, -1, -1};
+  size_t prio[3] = {~size_t(0), ~size_t(0), ~size_t(0)};
+  for (size_t c = 0; c < toks.size(); ++c) {
+    const std::string name(toks[c].first, toks[c].second);
+    for (int t = 0; t < 3; ++t) {
+      for (size_t q = 0; q < want[t].size(); ++q) {
+        if (want[t][q] == name && prio[t] >= q) {
+          if (prio[t] == q) {
+            die(3, "Error: Duplicate column header '%s' in --clump file.\n", name.c_str());
+          }
+          prio[t] = q;
+          col[t] = static_cast<int>(c);
+        }
+      }
+    }
+  }
+  if ((col[0] < 0) || (col[2] < 0)) {
+    die(7, "Error: --clump requires ID and P columns.\n");
+  }
+  const int last_col = std::max(col[0], std::max(col[1], col[2]));
+  const std::vector<std::string> test_names = A.clump_test.empty() ? std::vector<std::string>{"ADD"} : A.clump_test;
+  while (next_line(&ls, &le)) {
+    if (ls == le) {
+      continue;
+    }
+    tokens_of(ls, le, &toks);
+    if (toks.empty()) {
+      continue;
+    }
+    if (static_cast<int>(toks.size()) <= last_col) {
+      die(7, "Error: Line %zu of %s has fewer tokens than expected.\n", line_idx, A.clump_file.c_str());
+    }
+    if (col[1] >= 0) {
+      const std::string t(toks[col[1]].first, toks[col[1]].second);
+      if (std::find(test_names.begin(), test_names.end(), t) == test_names.end()) {
+        continue;
+      }
+    }
+    const std::string ptok(toks[col[2]].first, toks[col[2]].second);
+    double ln_pval;
+    const char* pe = scan_ln(ptok.c_str(), &ln_pval);
+    if (!pe || *pe) {
+      std::string low = ptok;
+      for (char& ch : low) {
+        ch = static_cast<char>(tolower(static_cast<unsigned char>(ch)));
+      }
+      if ((low == "na") || (low == "nan")) {
+        continue;
+      }
+      if (ptok == "INF") {  // PLINK 1.x underflow
+        ln_pval = -708.3964185322641;
+      } else {
+        die(7, "Error: Invalid p-value on line %zu of %s.\n", line_idx, A.clump_file.c_str());
+      }
+    }
+    const std::string id(toks[col[0]].first, toks[col[0]].second);
+    const auto it = by_id.find(id);
+    if (it == by_id.end()) {
+      if (ln_pval <= ln_p1) {
+        D->missing_ids.push_back(id);
+      }
+      continue;
+    }
+    if (it->second == kDup) {
+      die(7, "Error: --clump variant ID '%s' appears multiple times in main dataset.\n", id.c_str());
+    }
+    const uint32_t k = it->second;
+    if (ln_pval > load_thresh) {
+      if (ln_pval > 0.0) {
+        die(3, "Error: p-value > 1 on line %zu of %s.\n", line_idx, A.clump_file.c_str());
+      }
+      if (ln_pval > kClumpLnBins[3]) {
+        D->nonsig[k] += 1;
+        D->observed[k] = 1;
+      }
+      continue;
+    }
+    if (D->best_ln[k] >= ln_pval) {
+      D->best_ln[k] = ln_pval;
+    }
+    D->observed[k] = 1;
+    D->entries[k].push_back(static_cast<uint8_t>((clump_bin(ln_pval) << 1) | (ln_pval > ln_p2)));
+  }
+}
+
+// feed(engine, raw file indices in engine order): the caller's genotype-row feeder
+int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>& inc, const std::vector<uint32_t>& chr_idx,
+                  const std::vector<uint32_t>& bps, uint32_t founder_ct,
+                  const std::function<void(ldp_engine*, const std::vector<uint32_t>&)>& feed) {
+  if (founder_ct < 2) {
+    die(7, "Error: --clump requires at least two founders.  (--make-founders may come in handy\nhere.)\n");
+  }
+  const double t_start = now_s();
+  ClumpData D;
+  clump_load_report(A, V, inc, &D);
+  if (!D.missing_ids.empty()) {  // natural-sorted, deduplicated (plink2_ld.cc:7909-7931)
+    std::sort(D.missing_ids.begin(), D.missing_ids.end(), natural_less);
+    D.missing_ids.erase(std::unique(D.missing_ids.begin(), D.missing_ids.end()), D.missing_ids.end());
+    const std::string path = A.out + ".clumps.missing_id";
+    OutFile mf;
+    mf.open(path, false);
+    for (const std::string& s : D.missing_ids) {
+      mf.write(s.data(), s.size());
+      mf.write("\n", 1);
+    }
+    mf.close();
+    const size_t n = D.missing_ids.size();
+    logprintf("Warning: %zu top variant ID%s in --clump file missing from main dataset.  ID%s written to %s .\n", n, (n == 1) ? "" : "s",
+              (n == 1) ? "" : "s", path.c_str());
+  }
+  // observed variants (named by a usable report line) in dataset order, and the index candidates among them:
+  // best p <= p1, ranked by (ln p, position in the dataset) (ClumpPvalCmp; plink2_ld.cc:7996-8040)
+  std::vector<uint32_t> obs;  // -> index into inc[]
+  for (uint32_t k = 0; k < D.observed.size(); ++k) {
+    if (D.observed[k]) {
+      obs.push_back(k);
+    }
+  }
+  const uint32_t n_obs = static_cast<uint32_t>(obs.size());
+  std::vector<uint32_t> cand;  // -> observed index, rank order
+  for (uint32_t o = 0; o < n_obs; ++o) {
+    if (D.best_ln[obs[o]] <= A.clump_ln_p1) {
+      cand.push_back(o);
+    }
+  }
+  if (cand.empty()) {
+    logprintf("Warning: No significant --clump results.  Skipping.\n");
+    return 0;
+  }
+  std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) {
+    const double la = D.best_ln[obs[a]], lb = D.best_ln[obs[b]];
+    return (la != lb) ? (la < lb) : (a < b);
+  });
+  const uint32_t cand_ct = static_cast<uint32_t>(cand.size());
+  std::vector<uint8_t> is_cand(n_obs, 0);
+  for (uint32_t o : cand) {
+    is_cand[o] = 1;
+  }
+
+  // r^2 > threshold pairs within +-bp_radius, one endpoint an index candidate: the windowed-table kernels with the
+  // filter in their epilogue.  The kernel keeps r^2 >= the number the user gave; the reference's test is r^2 >
+  // that number * (1 + 2^-44) (plink2.cc:5059, ClumpHighmemR2 plink2_ld.cc:7352), applied here on the same doubles.
+  std::vector<std::pair<uint32_t, uint32_t>> links;  // (candidate, partner), observed indices
+  double t_rows = t_start, t_pairs = t_start;
+  // Only observed variants within the radius of some index candidate can ever be tested (the reference's islands,
+  // GetNextIslandIdxs plink2_ld.cc:5642, make the same cut): the engine holds those, in dataset order.
+  std::vector<uint32_t> o_chr(n_obs), o_bp(n_obs);
+  for (uint32_t o = 0; o < n_obs; ++o) {
+    o_chr[o] = chr_idx[obs[o]];
+    o_bp[o] = bps[obs[o]];
+  }
+  std::vector<int32_t> cover(static_cast<size_t>(n_obs) + 1, 0);
+  bool any_pair = false;
+  for (uint32_t o : cand) {
+    uint32_t lo = o, hi = o;
+    for (uint32_t step = 1; step;) {  // galloping search on both sides
+      step = 0;
+      uint32_t jump = 1;
+      while ((lo >= jump) && (o_chr[lo - jump] == o_chr[o]) && (o_bp[o] - o_bp[lo - jump] <= A.clump_bp_radius)) {
+        lo -= jump;
+        jump *= 2;
+        step = 1;
+      }
+      jump = 1;
+      while ((hi + jump < n_obs) && (o_chr[hi + jump] == o_chr[o]) && (o_bp[hi + jump] - o_bp[o] <= A.clump_bp_radius)) {
+        hi += jump;
+        jump *= 2;
+        step = 1;
+      }
+    }
+    any_pair |= (hi > lo);
+    ++cover[lo];
+    --cover[hi + 1];
+  }
+  std::vector<uint32_t> sub;  // engine row -> observed index
+  {
+    int32_t depth = 0;
+    for (uint32_t o = 0; o < n_obs; ++o) {
+      depth += cover[o];
+      if (depth > 0) {
+        sub.push_back(o);
+      }
+    }
+  }
+  const uint32_t n_sub = static_cast<uint32_t>(sub.size());
+  if (any_pair) {
+    ldp_params RP;
+    memset(&RP, 0, sizeof(RP));
+    RP.founder_ct = founder_ct;
+    RP.prune_window_size = 2;
+    RP.prune_window_incr = 1;
+    RP.prune_last_param = 0.5;
+    RP.device = 0;
+    if (ldp_device_count() < 1) {
+      die(12, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
+    }
+    ldp_engine* e = nullptr;
+    if (ldp_create(&RP, &e)) {
+      die(12, "Error: engine setup failed.\n");
+    }
+    std::vector<uint32_t> s_chr(n_sub), s_bp(n_sub), s_raw(n_sub);
+    for (uint32_t q = 0; q < n_sub; ++q) {
+      s_chr[q] = o_chr[sub[q]];
+      s_bp[q] = o_bp[sub[q]];
+      s_raw[q] = inc[obs[sub[q]]];
+    }
+    if (ldp_set_variants_vcor(e, n_sub, s_chr.data(), s_bp.data(), A.clump_bp_radius, 0xffffffffu)) {
+      die(12, "Error: engine setup failed: %s\n", ldp_last_error(e));
+    }
+    feed(e, s_raw);
+    t_rows = now_s();
+    std::vector<ldp_r2_hit> hits(1u << 24);
+    const double min_r2 = std::max(A.clump_r2_raw, 0.0);
+    uint32_t rows_per_call = 65536;
+    for (uint32_t r0 = 0; r0 < n_sub;) {
+      const uint32_t rows = std::min(rows_per_call, n_sub - r0);
+      uint64_t found = 0;
+      if (ldp_r2_unphased_hits(e, r0, rows, min_r2, hits.data(), hits.size(), &found)) {
+        die(12, "Error: %s\n", ldp_last_error(e));
+      }
+      if (found > hits.size()) {
+        if (rows == 1) {
+          die(8, "Error: one variant has more --clump-r2 partners than the filter buffer holds.\n");
+        }
+        rows_per_call = std::max(1u, rows / 2);
+        continue;
+      }
+      for (uint64_t q = 0; q < found; ++q) {
+        const ldp_r2_hit& h = hits[q];
+        if (!(h.r2 > A.clump_r2)) {
+          continue;
+        }
+        const uint32_t a = sub[h.first], b = sub[h.second];
+        if (is_cand[a]) {
+          links.emplace_back(a, b);
+        }
+        if (is_cand[b]) {
+          links.emplace_back(b, a);
+        }
+      }
+      r0 += rows;
+    }
+    ldp_destroy(e);
+    t_pairs = now_s();
+  }
+  std::sort(links.begin(), links.end());
+  std::vector<uint64_t> link_off(static_cast<size_t>(n_obs) + 1, 0);
+  for (const auto& l : links) {
+    ++link_off[l.first + 1];
+  }
+  for (uint32_t o = 0; o < n_obs; ++o) {
+    link_off[o + 1] += link_off[o];
+  }
+
+  // the greedy pass (plink2_ld.cc:8610-8700): candidates in rank order; one already inside a clump is skipped, the
+  // others take every still-unclumped window member above the threshold
+  const uint32_t kNone = 0xffffffffu;
+  std::vector<uint32_t> clump_of(n_obs, kNone);  // -> rank of the clump's index variant
+  uint32_t clump_ct = 0;
+  for (uint32_t r = 0; r < cand_ct; ++r) {
+    const uint32_t o = cand[r];
+    if (clump_of[o] != kNone) {
+      continue;
+    }
+    ++clump_ct;
+    clump_of[o] = r;
+    for (uint64_t q = link_off[o]; q < link_off[o + 1]; ++q) {
+      const uint32_t m = links[q].second;
+      if (clump_of[m] == kNone) {
+        clump_of[m] = r;
+      }
+    }
+  }
+  logprintf("--clump: %u clump%s formed from %u index candidate%s.\n", clump_ct, (clump_ct == 1) ? "" : "s", cand_ct, (cand_ct == 1) ? "" : "s");
+
+  // members of each clump in dataset order (ordered_members, plink2_ld.cc:8936-8970)
+  std::vector<uint64_t> mem_off(static_cast<size_t>(cand_ct) + 1, 0);
+  for (uint32_t o = 0; o < n_obs; ++o) {
+    if (clump_of[o] != kNone) {
+      ++mem_off[clump_of[o] + 1];
+    }
+  }
+  for (uint32_t r = 0; r < cand_ct; ++r) {
+    mem_off[r + 1] += mem_off[r];
+  }
+  std::vector<uint32_t> members(mem_off[cand_ct]);
+  {
+    std::vector<uint64_t> fill(mem_off.begin(), mem_off.end() - 1);
+    for (uint32_t o = 0; o < n_obs; ++o) {
+      if (clump_of[o] != kNone) {
+        members[fill[clump_of[o]]++] = o;
+      }
+    }
+  }
+
+  // <out>.clumps, default columns (plink2_ld.cc:9003-9405): chrom pos | total | bins | sp2
+  const std::string path = A.out + ".clumps";
+  OutFile f;
+  f.open(path, false);
+  std::string buf = "#CHROM\tPOS\tID\tP\tTOTAL\tNONSIG\tS0.05\tS0.01\tS0.001\tS0.0001\tSP2\n";
+  char num[64];
+  for (uint32_t r = 0; r < cand_ct; ++r) {
+    if (mem_off[r] == mem_off[r + 1]) {
+      continue;
+    }
+    const uint32_t io = cand[r];
+    const uint32_t iv = inc[obs[io]];
+    const double index_ln = D.best_ln[obs[io]];
+    buf += V.chrom[iv];
+    buf += '\t';
+    buf += std::to_string(V.bp[iv]);
+    buf += '\t';
+    buf += V.id[iv];
+    buf += '\t';
+    buf.append(num, format_ln_g6(index_ln, num) - num);
+    uint64_t bins[5] = {0, 0, 0, 0, 0};
+    for (uint64_t q = mem_off[r]; q < mem_off[r + 1]; ++q) {
+      const uint32_t k = obs[members[q]];
+      bins[4] += D.nonsig[k];
+      for (uint8_t en : D.entries[k]) {
+        ++bins[en >> 1];
+      }
+    }
+    --bins[clump_bin(index_ln)];
+    buf += '\t';
+    buf += std::to_string(bins[0] + bins[1] + bins[2] + bins[3] + bins[4]);
+    for (int b = 4; b >= 0; --b) {
+      buf += '\t';
+      buf += std::to_string(bins[b]);
+    }
+    buf += '\t';
+    bool nonempty = false;
+    for (uint64_t q = mem_off[r]; q < mem_off[r + 1]; ++q) {
+      const uint32_t m = members[q];
+      if (m == io) {
+        continue;
+      }
+      for (uint8_t en : D.entries[obs[m]]) {
+        if (!(en & 1)) {
+          buf += V.id[inc[obs[m]]];
+          buf += ',';
+          nonempty = true;
+        }
+      }
+    }
+    if (nonempty) {
+      buf.pop_back();
+    } else {
+      buf += '.';
+    }
+    buf += '\n';
+    if (buf.size() > (1u << 20)) {
+      f.write(buf.data(), buf.size());
+      buf.clear();
+    }
+  }
+  f.write(buf.data(), buf.size());
+  f.close();
+  logprintf("Results written to %s .\n", path.c_str());
+  if (A.timing) {
+    fprintf(stderr, "[timing] clump: %u observed variants (%u near an index candidate), %u index candidates, %zu links; report+rows %.3f s, pair kernels %.3f s, greedy+write %.3f s\n",
+            n_obs, n_sub, cand_ct, links.size(), t_rows - t_start, t_pairs - t_rows, now_s() - t_pairs);
+  }
+  return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -1362,7 +2101,7 @@ int main(int argc, char** argv) {
     }
   }
   if (skipped) {
-    logprintf("--%s: Ignoring %u chromosome 0 variant%s.\n", A.have_prune ? (A.pairphase ? "indep-pairphase" : "indep-pairwise") : "r2-unphased", skipped, skipped == 1 ? "" : "s");
+    logprintf("--%s: Ignoring %u chromosome 0 variant%s.\n", A.have_prune ? (A.pairphase ? "indep-pairphase" : "indep-pairwise") : (A.have_clump ? "clump" : "r2-unphased"), skipped, skipped == 1 ? "" : "s");
   }
   const uint32_t variant_ct = static_cast<uint32_t>(inc.size());
   if (A.window_is_bp || A.r2_table) {
@@ -1370,6 +2109,9 @@ int main(int argc, char** argv) {
       if (chr_idx[k] == chr_idx[k - 1] && bps[k] < bps[k - 1]) {
         if (A.have_prune) {  // plink2.cc:2926-2929
           die(3, "Error: When the window size is in kb units, LD-based pruning requires a sorted\n.pvar/.bim.  Retry this command after using --make-pgen/--make-bed +\n--sort-vars to sort your data.\n");
+        }
+        if (A.have_clump) {  // plink2.cc:2998-3001
+          die(7, "Error: --clump requires a sorted .pvar/.bim.  Retry this command after using\n--make-pgen/--make-bed + --sort-vars to sort your data.\n");
         }
         die(3, "Error: --r[2]-[un]phased runs require a sorted .pvar/.bim.  Retry this command\nafter using --make-pgen/--make-bed + --sort-vars to sort your data.\n");  // plink2.cc:2944-2947
       }
@@ -1394,6 +2136,69 @@ int main(int argc, char** argv) {
     // ---- --r2-unphased {square|square0|triangle} {bin|bin4}: every variant, every pair (Vcor, plink2_ld.cc:12050)
     if ((!A.r2_table) && variant_ct > 400000 && (A.parallel_tot == 1) && !A.yes_really) {  // plink2_ld.cc:9788
       die(7, "Error: Gigantic (over 400k variants) --r2-unphased unfiltered, non-distributed\ncomputation.  Rerun with the 'yes-really' modifier if you are SURE you have enough\nhard drive space and want to do this.\n");
+    }
+    // host rows of the listed variants (raw file indices, in engine order) -> engine: decode / direct rows, founder columns
+    auto feed_rows = [&](ldp_engine* eng, const std::vector<uint32_t>& incl) {
+      const uint32_t n_incl = static_cast<uint32_t>(incl.size());
+      const bool all_founders = (founder_ct == raw_sample_ct);
+      const uint64_t out_rec = (static_cast<uint64_t>(founder_ct) + 3) / 4;
+      std::vector<uint32_t> founder_idx;
+      for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+        if (is_founder[sx]) {
+          founder_idx.push_back(sx);
+        }
+      }
+      const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((1024ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
+      std::vector<uint8_t> decoded, gather;
+      std::vector<uint8_t> founder_mask((static_cast<size_t>(raw_sample_ct) + 7) / 8, 0);
+      for (uint32_t sidx : founder_idx) {
+        founder_mask[sidx >> 3] |= static_cast<uint8_t>(1u << (sidx & 7));
+      }
+      for (uint32_t k = 0; k < n_incl;) {
+        // a run of included variants that are consecutive in the file (chromosome 0 is stripped in table mode)
+        const uint32_t raw_first = incl[k];
+        uint32_t run = 1;
+        while ((run < kChunk) && (k + run < n_incl) && (incl[k + run] == raw_first + run)) {
+          ++run;
+        }
+        const uint8_t* src;
+        uint64_t stride = rec_bytes;
+        if (direct_rows) {
+          src = direct_rows + static_cast<uint64_t>(raw_first) * rec_bytes;
+        } else {
+          decoded.resize(static_cast<size_t>(run) * rec_bytes);
+          if (ldp_pgen_read(pg, raw_first, run, decoded.data(), rec_bytes, 0)) {
+            die(3, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+          }
+          src = decoded.data();
+        }
+        if (!all_founders) {
+          // the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185)
+          gather.resize(static_cast<size_t>(run) * out_rec);
+          if (ldp_subset_samples(src, rec_bytes, run, raw_sample_ct, founder_mask.data(), gather.data(), out_rec, 0, 0)) {
+            die(12, "Error: founder subsetting failed.\n");
+          }
+          src = gather.data();
+          stride = out_rec;
+        }
+        if (ldp_load_genotypes(eng, k, run, src, stride, LDP_MEM_HOST, encoding)) {
+          die(12, "Error: %s\n", ldp_last_error(eng));
+        }
+        k += run;
+      }
+    };
+    if (A.have_clump) {
+      for (uint32_t k = 0; k < variant_ct; ++k) {
+        if (V.alt_ct[inc[k]] > 1) {  // (the reference clumps (variant, A1 allele) pairs there, plink2_ld.cc:7776-7817)
+          die(9, "Error: multiallelic variant '%s': plink2-hip's --clump handles biallelic variants only.\n", V.id[inc[k]].c_str());
+        }
+      }
+      join_hip();
+      const int rc = clump_reports(A, V, inc, chr_idx, bps, founder_ct, feed_rows);
+      if (g_log) {
+        fclose(g_log);
+      }
+      return rc;
     }
     ldp_params RP;
     memset(&RP, 0, sizeof(RP));
@@ -1475,51 +2280,13 @@ int main(int argc, char** argv) {
     }
     // genotype rows -> engine (same feeder as the prune path)
     {
-      const bool all_founders = (founder_ct == raw_sample_ct);
+      feed_rows(e, inc);
       const uint64_t out_rec = (static_cast<uint64_t>(founder_ct) + 3) / 4;
       std::vector<uint32_t> founder_idx;
       for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
         if (is_founder[sx]) {
           founder_idx.push_back(sx);
         }
-      }
-      const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((1024ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
-      std::vector<uint8_t> decoded, gather;
-      std::vector<uint8_t> founder_mask((static_cast<size_t>(raw_sample_ct) + 7) / 8, 0);
-      for (uint32_t sidx : founder_idx) {
-        founder_mask[sidx >> 3] |= static_cast<uint8_t>(1u << (sidx & 7));
-      }
-      for (uint32_t k = 0; k < variant_ct;) {
-        // a run of included variants that are consecutive in the file (chromosome 0 is stripped in table mode)
-        const uint32_t raw_first = inc[k];
-        uint32_t run = 1;
-        while ((run < kChunk) && (k + run < variant_ct) && (inc[k + run] == raw_first + run)) {
-          ++run;
-        }
-        const uint8_t* src;
-        uint64_t stride = rec_bytes;
-        if (direct_rows) {
-          src = direct_rows + static_cast<uint64_t>(raw_first) * rec_bytes;
-        } else {
-          decoded.resize(static_cast<size_t>(run) * rec_bytes);
-          if (ldp_pgen_read(pg, raw_first, run, decoded.data(), rec_bytes, 0)) {
-            die(3, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
-          }
-          src = decoded.data();
-        }
-        if (!all_founders) {
-          // the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185)
-          gather.resize(static_cast<size_t>(run) * out_rec);
-          if (ldp_subset_samples(src, rec_bytes, run, raw_sample_ct, founder_mask.data(), gather.data(), out_rec, 0, 0)) {
-            die(12, "Error: founder subsetting failed.\n");
-          }
-          src = gather.data();
-          stride = out_rec;
-        }
-        if (ldp_load_genotypes(e, k, run, src, stride, LDP_MEM_HOST, encoding)) {
-          die(12, "Error: %s\n", ldp_last_error(e));
-        }
-        k += run;
       }
       // Multiallelic variants (R2NondosageVariant works on PgrGetInv1(major allele) rows, plink2_ld.cc:6039-6048):
       // collapsed major-vs-rest on the host, as for the prune.  With 'ref-based' the collapse is REF-vs-rest, which

@@ -1,0 +1,166 @@
+"""plink2-hip --clump against the reference binary (ClumpReports, plink2_ld.cc:7506-9480): the .clumps report and the
+.clumps.missing_id list must be the same bytes.  The report handling (p-value parsing through logarithms, TEST filter,
+column search, bins, TOTAL, SP2, the p-value formatter) is exercised on the CPU with a window that pairs nothing; the
+r^2 membership runs on the GPU."""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+import ldtools as T
+from test_cli import cli, run_cli  # noqa: F401  (fixture)
+
+P_FORMATS = ["%.3g", "%.6e", "%.2e", "%.8f", "%.1e", "%g"]
+
+
+def clump_fileset(tmp_path, m, n, seed, missing_rate=0.02, n_chr=3, spacing=900):
+    raw = T.synth_raw_codes(m, n, seed, missing_rate=missing_rate, ld_copy_prob=0.7, redraw=0.04)
+    rng = np.random.default_rng(seed + 17)
+    per = m // n_chr
+    chroms, bps = [], []
+    for c in range(n_chr):
+        cnt = per if c < n_chr - 1 else m - per * (n_chr - 1)
+        pos = np.cumsum(rng.integers(1, spacing, size=cnt)) + 1000  # strictly increasing: no shared positions
+        chroms += [str(c + 1)] * cnt
+        bps += [int(x) for x in pos]
+    prefix = str(tmp_path / "d")
+    T.write_bed(prefix, raw, chroms, bps)
+    T.write_pgen_fixed(prefix, raw, chroms, bps)
+    return prefix, raw, chroms, bps
+
+
+def write_report(path, m, seed, header=("#CHROM", "POS", "ID", "TEST", "OBS_CT", "P"), sig_rate=0.06, with_test=True, id_name="ID", p_name="P"):
+    """A --glm-like report: mostly unremarkable p-values, a few strong ones, odd spellings, repeated and unknown IDs."""
+    rng = np.random.default_rng(seed)
+    lines = []
+    cols = [h for h in header]
+    cols = [id_name if h == "ID" else (p_name if h == "P" else h) for h in cols]
+    if not with_test:
+        cols = [h for h in cols if h != "TEST"]
+    lines.append("\t".join(cols))
+    odd = ["NA", "nan", "0", "1", "1e-320", "4.9e-324", "INF", ".05", "5E-9", "0.0001", "1e-4", "0.01", "1.00e-02", "+0.05", "0.001",
+           "0.05000000000000001", "9.9999949e-5", "9.99999501e-5", "0.99999951", "12345678901234567890e-25", "0.000100000000000000000001"]
+    ids = ["snp%d" % v for v in range(m)]
+    order = rng.permutation(m)
+    for v in order:
+        reps = 1 + (rng.random() < 0.05) + (rng.random() < 0.01)
+        for _ in range(reps):
+            u = rng.random()
+            if u < sig_rate:
+                p = 10.0 ** (-rng.uniform(4, 40))
+            elif u < 3 * sig_rate:
+                p = 10.0 ** (-rng.uniform(1, 4.3))
+            else:
+                p = rng.random()
+            ptxt = P_FORMATS[rng.integers(len(P_FORMATS))] % p
+            if rng.random() < 0.03:
+                ptxt = odd[rng.integers(len(odd))]
+            tests = ["ADD"] if with_test else [None]
+            if with_test and rng.random() < 0.2:
+                tests = ["ADD", "DOMDEV"] if rng.random() < 0.5 else ["GENO_2DF"]
+            for t in tests:
+                row = {"#CHROM": "1", "POS": "1", "ID": ids[v], "TEST": t, "OBS_CT": "100",
+                       "P": ptxt if t == "ADD" or t is None else "%.3g" % rng.random()}
+                lines.append("\t".join(row[h] for h in header if (h != "TEST" or with_test)))
+    for k in range(25):  # IDs the dataset does not have: the significant ones go to .clumps.missing_id
+        p = 10.0 ** (-rng.uniform(0, 9))
+        row = {"#CHROM": "1", "POS": "1", "ID": "rs%d_%d" % (rng.integers(1, 300), k % 3), "TEST": "ADD", "OBS_CT": "100", "P": "%.3g" % p}
+        lines.append("\t".join(row[h] for h in header if (h != "TEST" or with_test)))
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def compare_runs(cli, tmp_path, common):
+    ref = T.run_ref(common + ["--threads", "4", "--out", "ref"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    got = run_cli(cli, common + ["--out", "hip"], str(tmp_path))
+    assert got.returncode == 0, got.stdout
+    if not os.path.exists(str(tmp_path / "ref.clumps")):
+        assert "No significant --clump results" in ref.stdout
+        assert "No significant --clump results" in got.stdout
+        assert not os.path.exists(str(tmp_path / "hip.clumps"))
+        return ref, got
+    want = open(str(tmp_path / "ref.clumps")).read()
+    have = open(str(tmp_path / "hip.clumps")).read()
+    if want != have:
+        wl, hl = want.split("\n"), have.split("\n")
+        bad = [(a, b) for a, b in zip(wl, hl) if a != b]
+        raise AssertionError("%d/%d lines differ, first: %r" % (len(bad) + abs(len(wl) - len(hl)), len(wl), bad[:2]))
+    for ext in (".clumps.missing_id",):
+        a, b = str(tmp_path / ("ref" + ext)), str(tmp_path / ("hip" + ext))
+        assert os.path.exists(a) == os.path.exists(b)
+        if os.path.exists(a):
+            assert filecmp.cmp(a, b, shallow=False), ext
+    line = [l for l in ref.stdout.split("\n") if "formed from" in l]
+    assert line and line[0].strip() in got.stdout
+    return ref, got
+
+
+needs_ref = pytest.mark.skipif(not T.have_ref(), reason="oracle/_ref/plink2 not built")
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,extra", [
+    (1, []),
+    (2, ["--clump-p1", "1e-3", "--clump-p2", "0.04"]),
+    (3, ["--clump-p1", "0.2", "--clump-p2", "0.5"]),          # thresholds above the last bin boundary
+    (4, ["--clump-p1", "1e-9", "--clump-p2", "1e-12"]),       # p2 < p1
+    (5, ["--clump-p1", "1e-300"]),                               # nothing significant
+])
+def test_clump_report_handling_matches_reference(cli, tmp_path, seed, extra):
+    """A 1-bp radius over distinct positions pairs nothing, so every index candidate is a clump of its own and no GPU
+    is needed: what is compared is the report parsing, ranking, binning and printing."""
+    m = 1500
+    clump_fileset(tmp_path, m, 40, seed)
+    write_report(str(tmp_path / "assoc.txt"), m, seed)
+    common = ["--bfile", "d", "--clump", "assoc.txt", "--clump-unphased", "--clump-kb", "0.001"] + extra
+    compare_runs(cli, tmp_path, common)
+
+
+@needs_ref
+def test_clump_column_search_and_test_filter(cli, tmp_path):
+    m = 600
+    clump_fileset(tmp_path, m, 40, 9)
+    write_report(str(tmp_path / "a.txt"), m, 21, header=("ID", "TEST", "P", "#CHROM"), id_name="SNP", p_name="PVAL")
+    base = ["--bfile", "d", "--clump-unphased", "--clump-kb", "0.001", "--clump-p1", "0.01"]
+    compare_runs(cli, tmp_path, base + ["--clump", "a.txt", "--clump-p-field", "PVAL"])
+    compare_runs(cli, tmp_path, base + ["--clump", "a.txt", "--clump-p-field", "P", "PVAL", "--clump-test", "ADD", "DOMDEV"])
+    write_report(str(tmp_path / "b.txt"), m, 22, with_test=False)
+    compare_runs(cli, tmp_path, base + ["--clump", "b.txt"])
+
+
+def test_clump_flag_rules(cli, tmp_path):
+    clump_fileset(tmp_path, 60, 20, 3)
+    write_report(str(tmp_path / "a.txt"), 60, 1)
+    r = run_cli(cli, ["--bfile", "d", "--clump", "a.txt"], str(tmp_path))
+    assert r.returncode == 9 and "--clump-unphased" in r.stdout
+    r = run_cli(cli, ["--bfile", "d", "--clump", "a.txt", "--clump-unphased", "--clump-r2", "1.0"], str(tmp_path))
+    assert r.returncode == 5 and "Invalid --clump-r2" in r.stdout
+    r = run_cli(cli, ["--bfile", "d", "--clump", "a.txt", "--clump-unphased", "--clump-allow-overlap"], str(tmp_path))
+    assert r.returncode == 9
+    r = run_cli(cli, ["--bfile", "d", "--clump-unphased"], str(tmp_path))
+    assert r.returncode == 5
+
+
+CLUMP_CASES = [
+    # fmt, m, n, missing, extra
+    ("bfile", 3000, 200, 0.0, []),
+    ("pfile", 3000, 333, 0.03, ["--clump-r2", "0.2", "--clump-kb", "60"]),
+    ("bfile", 5000, 150, 0.01, ["--clump-r2", "0.8", "--clump-p1", "1e-3", "--clump-p2", "0.05", "--clump-kb", "1000"]),
+    ("pfile", 2500, 97, 0.05, ["--clump-r2", "0", "--clump-kb", "20"]),
+    ("pfile", 4000, 1200, 0.002, ["--clump-r2", "0.35", "--clump-p1", "0.05", "--clump-p2", "0.5"]),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CLUMP_CASES)
+def test_clump_matches_reference(gpu_pkg, cli, tmp_path, case):
+    fmt, m, n, miss, extra = case
+    assert T.have_ref(), "reference binary oracle/_ref/plink2 must travel with the repo snapshot"
+    clump_fileset(tmp_path, m, n, m + n, missing_rate=miss, spacing=400)
+    write_report(str(tmp_path / "assoc.txt"), m, n)
+    common = ["--" + fmt, "d", "--clump", "assoc.txt", "--clump-unphased"] + extra
+    ref, got = compare_runs(cli, tmp_path, common)
+    body = open(str(tmp_path / "hip.clumps")).read().split("\n")[1:-1]
+    assert any(l.split("\t")[-1] != "." for l in body), "the case must form multi-variant clumps"
