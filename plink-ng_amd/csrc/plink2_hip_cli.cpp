@@ -1975,11 +1975,47 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
   return 0;
 }
 
-}  // namespace
+// Everything the commands share: the parsed command line, the variant and sample tables, the open genotype file and the
+// included-variant index (chromosome 0 stripped where the reference strips it).  load_inputs() fills it; run_r2() (the
+// --r2-unphased outputs and --clump) and run_prune() (--indep-pairwise / --indep-pairphase) consume it.
+struct Session {
+  double t_begin = 0.0, t_hip_init = 0.0, t_parse = 0.0, t_joined = 0.0;
+  Args A;
+  Variants V;
+  std::thread t_hip;  // HIP runtime start-up, beside the file parsing; joined where the first engine is created, or on the way out
+  std::vector<uint8_t> is_founder, sex;
+  uint32_t raw_sample_ct = 0, founder_ct = 0, raw_variant_ct = 0;
+  bool is_bed = false;
+  std::string gpath;
+  ldp_pgen* pg = nullptr;
+  int storage_mode = 0, encoding = LDP_GENO_REF, has_multiallelic = 0;
+  uint64_t rec_bytes = 0;
+  const uint8_t* direct_rows = nullptr;  // NULL for variable-width files
+  std::vector<uint32_t> inc;             // raw index of every included variant
+  std::vector<uint32_t> chr_idx, bps;
+  std::vector<uint8_t> vcls;             // per included variant: 0 diploid, 3 chrX, 4 chrY, 5 MT
+  uint32_t variant_ct = 0;
+  std::vector<uint32_t> mk, xk, yk, tk;  // indices into inc[]: main engine, chrX, chrY, MT under --indep-pairphase
+  uint32_t m_ct = 0;
+  std::vector<uint32_t> m_chr, m_bps;
+  void join_hip() {
+    if (t_hip.joinable()) {
+      t_hip.join();
+      t_joined = now_s();
+    }
+  }
+  ~Session() {
+    if (t_hip.joinable()) {
+      t_hip.join();
+    }
+  }
+};
 
-int main(int argc, char** argv) {
-  const double t_begin = now_s();
-  Args A = parse_args(argc, argv);
+void load_inputs(Session& S, int argc, char** argv) {
+  S.t_begin = now_s();
+  S.A = parse_args(argc, argv);
+  const Args& A = S.A;
+  const double t_begin = S.t_begin;
   g_log = fopen((A.out + ".log").c_str(), "w");
   logprintf("plink2-hip: MI355X-native --indep-pairwise (drop-in for that path of PLINK v2.0)\n");
   logprintf("Options in effect:\n ");
@@ -1990,40 +2026,23 @@ int main(int argc, char** argv) {
 
   // the variant table parses on its own thread and the HIP runtime initialises on another while the
   // sample file is read
-  Variants V;
+  Variants& V = S.V;
   std::thread t_variants([&]() { load_variants(A, &V); });
-  double t_hip_init = 0.0, t_parse = 0.0;
-  std::thread t_hip([&]() { const double t0 = now_s(); (void)ldp_device_count(); t_hip_init = now_s() - t0; });
-  // joined where the first engine is created (HIP context creation is the longest setup item; the variant-table
-  // passes and the ID check below run beside it), or on the way out
-  struct Joiner {
-    std::thread& t;
-    ~Joiner() {
-      if (t.joinable()) {
-        t.join();
-      }
-    }
-  } hip_guard{t_hip};
-  double t_joined = 0.0;
-  auto join_hip = [&]() {
-    if (t_hip.joinable()) {
-      t_hip.join();
-      t_joined = now_s();
-    }
-  };
-  std::vector<uint8_t> is_founder;
-  std::vector<uint8_t> sex;
-  load_samples(A, &is_founder, &sex);
+  S.t_hip = std::thread([&S]() { const double t0 = now_s(); (void)ldp_device_count(); S.t_hip_init = now_s() - t0; });
+  std::vector<uint8_t>& is_founder = S.is_founder;
+  load_samples(A, &S.is_founder, &S.sex);
   t_variants.join();
-  t_parse = now_s() - t_begin;
-  const uint32_t raw_sample_ct = static_cast<uint32_t>(is_founder.size());
-  uint32_t founder_ct = 0;
+  S.t_parse = now_s() - t_begin;
+  S.raw_sample_ct = static_cast<uint32_t>(is_founder.size());
+  const uint32_t raw_sample_ct = S.raw_sample_ct;
+  uint32_t& founder_ct = S.founder_ct;
   for (uint8_t f : is_founder) {
     founder_ct += f;
   }
   logprintf("%u sample%s loaded from %s (%u founder%s).\n", raw_sample_ct, raw_sample_ct == 1 ? "" : "s",
             (A.psam.empty() ? A.fam : A.psam).c_str(), founder_ct, founder_ct == 1 ? "" : "s");
-  const uint32_t raw_variant_ct = static_cast<uint32_t>(V.id.size());
+  S.raw_variant_ct = static_cast<uint32_t>(V.id.size());
+  const uint32_t raw_variant_ct = S.raw_variant_ct;
   logprintf("%u variant%s loaded from %s.\n", raw_variant_ct, raw_variant_ct == 1 ? "" : "s", (A.pvar.empty() ? A.bim : A.pvar).c_str());
 
   if (A.have_prune && founder_ct < 50 && !A.bad_ld) {  // plink2.cc:2063-2071
@@ -2037,27 +2056,28 @@ int main(int argc, char** argv) {
   }
 
   // ---- genotype file (.bed / fixed-width .pgen / standard variable-width .pgen)
-  const bool is_bed = !A.bed.empty();
-  const std::string& gpath = is_bed ? A.bed : A.pgen;
-  ldp_pgen* pg = nullptr;
+  S.is_bed = !A.bed.empty();
+  S.gpath = S.is_bed ? A.bed : A.pgen;
+  const std::string& gpath = S.gpath;
+  ldp_pgen*& pg = S.pg;
   if (ldp_pgen_open(gpath.c_str(), raw_sample_ct, raw_variant_ct, &pg)) {
     die(3, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
   }
-  int storage_mode = 0, encoding = LDP_GENO_REF, has_multiallelic = 0;
-  ldp_pgen_info(pg, nullptr, nullptr, &storage_mode, &encoding, &has_multiallelic);
+  ldp_pgen_info(pg, nullptr, nullptr, &S.storage_mode, &S.encoding, &S.has_multiallelic);
   if (ldp_pgen_has_dosage(pg)) {
     // The reference takes allele frequencies (major allele, tie-break of the prune; the r^2 of dosage data) from the dosages
     // when a file has them; this front-end reads hardcalls only and would silently write a different list.
     ldp_pgen_close(pg);
     die(9, "Error: %s holds dosage data, which plink2-hip does not read yet (allele frequencies and r^2 would be\ncomputed from hardcalls only, unlike plink2).  Use plink2 --make-pgen erase-dosage first.\n", gpath.c_str());
   }
-  uint64_t rec_bytes = (static_cast<uint64_t>(raw_sample_ct) + 3) / 4;
-  const uint8_t* direct_rows = static_cast<const uint8_t*>(ldp_pgen_direct_rows(pg, &rec_bytes));  // NULL for variable-width
+  S.rec_bytes = (static_cast<uint64_t>(raw_sample_ct) + 3) / 4;
+  S.direct_rows = static_cast<const uint8_t*>(ldp_pgen_direct_rows(pg, &S.rec_bytes));  // NULL for variable-width
 
   // ---- variant table: strip chromosome 0, chromosome order index, sortedness, unique IDs
-  std::vector<uint32_t> inc;  // raw index of every included variant
-  std::vector<uint32_t> chr_idx, bps;
-  std::vector<uint8_t> vcls;  // per included variant: 0 diploid, 3 chrX, 4 chrY, 5 MT
+  std::vector<uint32_t>& inc = S.inc;
+  std::vector<uint32_t>& chr_idx = S.chr_idx;
+  std::vector<uint32_t>& bps = S.bps;
+  std::vector<uint8_t>& vcls = S.vcls;
   uint32_t skipped = 0;
   {
     std::unordered_set<std::string> seen_chr;
@@ -2103,7 +2123,8 @@ int main(int argc, char** argv) {
   if (skipped) {
     logprintf("--%s: Ignoring %u chromosome 0 variant%s.\n", A.have_prune ? (A.pairphase ? "indep-pairphase" : "indep-pairwise") : (A.have_clump ? "clump" : "r2-unphased"), skipped, skipped == 1 ? "" : "s");
   }
-  const uint32_t variant_ct = static_cast<uint32_t>(inc.size());
+  S.variant_ct = static_cast<uint32_t>(inc.size());
+  const uint32_t variant_ct = S.variant_ct;
   if (A.window_is_bp || A.r2_table) {
     for (uint32_t k = 1; k < variant_ct; ++k) {
       if (chr_idx[k] == chr_idx[k - 1] && bps[k] < bps[k - 1]) {
@@ -2121,461 +2142,403 @@ int main(int argc, char** argv) {
   // chrX and chrY variants run on engines of their own (different sample sets); MT stays with the autosomes --
   // except under --indep-pairphase, where the autosomes carry two haplotypes per founder and MT one
   // (IndepPairphaseUpdateSubcontig, plink2_ld.cc:1491-1511)
-  std::vector<uint32_t> mk, xk, yk, tk;  // indices into inc[]
+  std::vector<uint32_t>&mk = S.mk, &xk = S.xk, &yk = S.yk, &tk = S.tk;
   for (uint32_t k = 0; k < variant_ct; ++k) {
     (vcls[k] == 3 ? xk : (vcls[k] == 4 ? yk : ((vcls[k] == 5 && A.pairphase) ? tk : mk))).push_back(k);
   }
-  const uint32_t m_ct = static_cast<uint32_t>(mk.size());
-  std::vector<uint32_t> m_chr(m_ct), m_bps(m_ct);
+  S.m_ct = static_cast<uint32_t>(mk.size());
+  const uint32_t m_ct = S.m_ct;
+  std::vector<uint32_t>&m_chr = S.m_chr, &m_bps = S.m_bps;
+  m_chr.resize(m_ct);
+  m_bps.resize(m_ct);
   for (uint32_t q = 0; q < m_ct; ++q) {
     m_chr[q] = chr_idx[mk[q]];
     m_bps[q] = bps[mk[q]];
   }
+}
 
-  if (A.have_r2) {
-    // ---- --r2-unphased {square|square0|triangle} {bin|bin4}: every variant, every pair (Vcor, plink2_ld.cc:12050)
-    if ((!A.r2_table) && variant_ct > 400000 && (A.parallel_tot == 1) && !A.yes_really) {  // plink2_ld.cc:9788
-      die(7, "Error: Gigantic (over 400k variants) --r2-unphased unfiltered, non-distributed\ncomputation.  Rerun with the 'yes-really' modifier if you are SURE you have enough\nhard drive space and want to do this.\n");
-    }
-    // host rows of the listed variants (raw file indices, in engine order) -> engine: decode / direct rows, founder columns
-    auto feed_rows = [&](ldp_engine* eng, const std::vector<uint32_t>& incl) {
-      const uint32_t n_incl = static_cast<uint32_t>(incl.size());
-      const bool all_founders = (founder_ct == raw_sample_ct);
-      const uint64_t out_rec = (static_cast<uint64_t>(founder_ct) + 3) / 4;
-      std::vector<uint32_t> founder_idx;
-      for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
-        if (is_founder[sx]) {
-          founder_idx.push_back(sx);
-        }
-      }
-      const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((1024ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
-      std::vector<uint8_t> decoded, gather;
-      std::vector<uint8_t> founder_mask((static_cast<size_t>(raw_sample_ct) + 7) / 8, 0);
-      for (uint32_t sidx : founder_idx) {
-        founder_mask[sidx >> 3] |= static_cast<uint8_t>(1u << (sidx & 7));
-      }
-      for (uint32_t k = 0; k < n_incl;) {
-        // a run of included variants that are consecutive in the file (chromosome 0 is stripped in table mode)
-        const uint32_t raw_first = incl[k];
-        uint32_t run = 1;
-        while ((run < kChunk) && (k + run < n_incl) && (incl[k + run] == raw_first + run)) {
-          ++run;
-        }
-        const uint8_t* src;
-        uint64_t stride = rec_bytes;
-        if (direct_rows) {
-          src = direct_rows + static_cast<uint64_t>(raw_first) * rec_bytes;
-        } else {
-          decoded.resize(static_cast<size_t>(run) * rec_bytes);
-          if (ldp_pgen_read(pg, raw_first, run, decoded.data(), rec_bytes, 0)) {
-            die(3, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
-          }
-          src = decoded.data();
-        }
-        if (!all_founders) {
-          // the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185)
-          gather.resize(static_cast<size_t>(run) * out_rec);
-          if (ldp_subset_samples(src, rec_bytes, run, raw_sample_ct, founder_mask.data(), gather.data(), out_rec, 0, 0)) {
-            die(12, "Error: founder subsetting failed.\n");
-          }
-          src = gather.data();
-          stride = out_rec;
-        }
-        if (ldp_load_genotypes(eng, k, run, src, stride, LDP_MEM_HOST, encoding)) {
-          die(12, "Error: %s\n", ldp_last_error(eng));
-        }
-        k += run;
-      }
-    };
-    if (A.have_clump) {
-      for (uint32_t k = 0; k < variant_ct; ++k) {
-        if (V.alt_ct[inc[k]] > 1) {  // (the reference clumps (variant, A1 allele) pairs there, plink2_ld.cc:7776-7817)
-          die(9, "Error: multiallelic variant '%s': plink2-hip's --clump handles biallelic variants only.\n", V.id[inc[k]].c_str());
-        }
-      }
-      join_hip();
-      const int rc = clump_reports(A, V, inc, chr_idx, bps, founder_ct, feed_rows);
-      if (g_log) {
-        fclose(g_log);
-      }
-      return rc;
-    }
-    ldp_params RP;
-    memset(&RP, 0, sizeof(RP));
-    RP.founder_ct = founder_ct;
-    RP.prune_window_size = 2;
-    RP.prune_window_incr = 1;
-    RP.prune_last_param = 0.5;
-    RP.device = 0;
-    join_hip();
-    if (ldp_device_count() < 1) {
-      die(12, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
-    }
-    ldp_engine* e = nullptr;
-    if (ldp_create(&RP, &e)) {
-      die(12, "Error: engine setup failed.\n");
-    }
-    if (A.r2_table && !A.r2_allow_ambiguous) {  // plink2_ld.cc:11063-11072 (the default column set has no allele columns)
-      for (uint32_t k = 0; k < variant_ct; ++k) {
-        if (V.alt_ct[inc[k]] > 1) {
-          die(7, "Error: --r2-unphased column-set doesn't include allele columns which clarify\nwhich calculation is being performed at multiallelic variants. Either filter\nout multiallelic variants, revise the column-set (with e.g. \"cols=+%s\"), or\nuse the 'allow-ambiguous-allele' modifier to override this error.\n", A.r2_ref_based ? "ref" : "maj");
-        }
+// ---- the r^2 outputs: --r2-unphased matrices and tables, --clump ----
+int run_r2(Session& S) {
+  const Args& A = S.A;
+  const Variants& V = S.V;
+  const double t_begin = S.t_begin;
+  const std::vector<uint8_t>& is_founder = S.is_founder;
+  const std::vector<uint8_t>& sex = S.sex;
+  const uint32_t raw_sample_ct = S.raw_sample_ct, founder_ct = S.founder_ct, raw_variant_ct = S.raw_variant_ct;
+  const std::string& gpath = S.gpath;
+  ldp_pgen* const pg = S.pg;
+  const int storage_mode = S.storage_mode, encoding = S.encoding, has_multiallelic = S.has_multiallelic;
+  const uint64_t rec_bytes = S.rec_bytes;
+  const uint8_t* const direct_rows = S.direct_rows;
+  const std::vector<uint32_t>&inc = S.inc, &chr_idx = S.chr_idx, &bps = S.bps;
+  const std::vector<uint8_t>& vcls = S.vcls;
+  const uint32_t variant_ct = S.variant_ct, m_ct = S.m_ct;
+  const std::vector<uint32_t>&mk = S.mk, &xk = S.xk, &yk = S.yk, &tk = S.tk, &m_chr = S.m_chr, &m_bps = S.m_bps;
+  auto join_hip = [&S]() { S.join_hip(); };
+  const double &t_hip_init = S.t_hip_init, &t_parse = S.t_parse, &t_joined = S.t_joined;
+  // ---- --r2-unphased {square|square0|triangle} {bin|bin4}: every variant, every pair (Vcor, plink2_ld.cc:12050)
+  if ((!A.r2_table) && variant_ct > 400000 && (A.parallel_tot == 1) && !A.yes_really) {  // plink2_ld.cc:9788
+    die(7, "Error: Gigantic (over 400k variants) --r2-unphased unfiltered, non-distributed\ncomputation.  Rerun with the 'yes-really' modifier if you are SURE you have enough\nhard drive space and want to do this.\n");
+  }
+  // host rows of the listed variants (raw file indices, in engine order) -> engine: decode / direct rows, founder columns
+  auto feed_rows = [&](ldp_engine* eng, const std::vector<uint32_t>& incl) {
+    const uint32_t n_incl = static_cast<uint32_t>(incl.size());
+    const bool all_founders = (founder_ct == raw_sample_ct);
+    const uint64_t out_rec = (static_cast<uint64_t>(founder_ct) + 3) / 4;
+    std::vector<uint32_t> founder_idx;
+    for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+      if (is_founder[sx]) {
+        founder_idx.push_back(sx);
       }
     }
-    if (A.r2_inter && (A.ld_min_r2 <= 0.0) && (variant_ct > 400000) && (A.parallel_tot == 1) && !A.yes_really) {  // plink2_ld.cc:11087
-      die(7, "Error: Gigantic (over 400k variants) --r2-unphased unfiltered, non-distributed\ncomputation.  Rerun with the 'yes-really' modifier if you are SURE you have enough\nhard drive space and want to do this.\n");
+    const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((1024ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
+    std::vector<uint8_t> decoded, gather;
+    std::vector<uint8_t> founder_mask((static_cast<size_t>(raw_sample_ct) + 7) / 8, 0);
+    for (uint32_t sidx : founder_idx) {
+      founder_mask[sidx >> 3] |= static_cast<uint8_t>(1u << (sidx & 7));
     }
-    if ((A.r2_table && !A.r2_inter) ? ldp_set_variants_vcor(e, variant_ct, chr_idx.data(), bps.data(), A.ld_bp_radius, A.ld_var_ct_radius)
-                                    : ldp_set_variants_matrix(e, variant_ct)) {
-      die(12, "Error: engine setup failed: %s\n", ldp_last_error(e));
-    }
-    const std::string base = A.out + (A.r2_text ? ".unphased.vcor2" : ".unphased.vcor2.bin");
-    // --parallel k n: the reference's row shards.  Matrix (VcorMatrix, plink2_ld.cc:9800-9824): `square` takes rows
-    // [M k / n, M (k+1) / n); the triangular shapes take ParallelBounds() rows (equal numbers of lower-triangle entries) and
-    // a piece that does not reach the last row behaves as if the later variants did not exist (its .vars file, written by piece
-    // 1 only, lists just the variants before its last row; square0's zero padding still runs to the full width).  Table
-    // (VcorTable, :11157-11168): first variants [M k / n, M (k+1) / n); the header goes to piece 1.  Pieces are named
-    // <file>.<k> and concatenate to the undistributed output.
-    uint32_t shard_first = 0, shard_end = variant_ct, vars_ct = variant_ct;
-    const std::string piece_suffix = (A.parallel_tot == 1) ? std::string() : ("." + std::to_string(A.parallel_idx + 1));
-    if (A.parallel_tot != 1) {
-      if ((!A.r2_table) && (variant_ct < 2 * A.parallel_tot)) {
-        die(7, "Error: Too few variants in --r2-unphased run for --parallel %u %u.\n", A.parallel_idx + 1, A.parallel_tot);
+    for (uint32_t k = 0; k < n_incl;) {
+      // a run of included variants that are consecutive in the file (chromosome 0 is stripped in table mode)
+      const uint32_t raw_first = incl[k];
+      uint32_t run = 1;
+      while ((run < kChunk) && (k + run < n_incl) && (incl[k + run] == raw_first + run)) {
+        ++run;
       }
-      if ((!A.r2_table) && (A.r2_shape != 0)) {
-        // smallest v with v (v + 1) >= x (TriangleDivide, plink2_common.cc:4936, modif = 1)
-        auto tri = [](uint64_t x) {
-          if (!x) {
-            return static_cast<uint64_t>(0);
-          }
-          uint64_t v = static_cast<uint64_t>(sqrt(static_cast<double>(x)));
-          while ((v >= 1) && ((v - 1) * v >= x)) {
-            --v;
-          }
-          while (v * (v + 1) < x) {
-            ++v;
-          }
-          return v;
-        };
-        const uint64_t tot = static_cast<uint64_t>(variant_ct) * (static_cast<uint64_t>(variant_ct) + 1);
-        shard_first = static_cast<uint32_t>(tri(tot * A.parallel_idx / A.parallel_tot));
-        shard_end = static_cast<uint32_t>(tri(tot * (A.parallel_idx + 1) / A.parallel_tot));
-        vars_ct = shard_end;
+      const uint8_t* src;
+      uint64_t stride = rec_bytes;
+      if (direct_rows) {
+        src = direct_rows + static_cast<uint64_t>(raw_first) * rec_bytes;
       } else {
-        shard_first = static_cast<uint32_t>(static_cast<uint64_t>(variant_ct) * A.parallel_idx / A.parallel_tot);
-        shard_end = static_cast<uint32_t>(static_cast<uint64_t>(variant_ct) * (A.parallel_idx + 1) / A.parallel_tot);
+        decoded.resize(static_cast<size_t>(run) * rec_bytes);
+        if (ldp_pgen_read(pg, raw_first, run, decoded.data(), rec_bytes, 0)) {
+          die(3, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+        }
+        src = decoded.data();
+      }
+      if (!all_founders) {
+        // the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185)
+        gather.resize(static_cast<size_t>(run) * out_rec);
+        if (ldp_subset_samples(src, rec_bytes, run, raw_sample_ct, founder_mask.data(), gather.data(), out_rec, 0, 0)) {
+          die(12, "Error: founder subsetting failed.\n");
+        }
+        src = gather.data();
+        stride = out_rec;
+      }
+      if (ldp_load_genotypes(eng, k, run, src, stride, LDP_MEM_HOST, encoding)) {
+        die(12, "Error: %s\n", ldp_last_error(eng));
+      }
+      k += run;
+    }
+  };
+  if (A.have_clump) {
+    for (uint32_t k = 0; k < variant_ct; ++k) {
+      if (V.alt_ct[inc[k]] > 1) {  // (the reference clumps (variant, A1 allele) pairs there, plink2_ld.cc:7776-7817)
+        die(9, "Error: multiallelic variant '%s': plink2-hip's --clump handles biallelic variants only.\n", V.id[inc[k]].c_str());
       }
     }
-    if ((!A.r2_table) && (A.parallel_idx == 0)) {
-      FILE* vf = fopen((base + ".vars").c_str(), "wb");
-      if (!vf) {
-        die(2, "Error: Failed to open %s.vars for writing.\n", base.c_str());
-      }
-      for (uint32_t k = 0; k < vars_ct; ++k) {
-        fputs(V.id[inc[k]].c_str(), vf);
-        fputc('\n', vf);
-      }
-      fclose(vf);
-      logprintf("--r2-unphased: Variant IDs written to %s.vars .\n", base.c_str());
+    join_hip();
+    const int rc = clump_reports(A, V, inc, chr_idx, bps, founder_ct, feed_rows);
+    if (g_log) {
+      fclose(g_log);
     }
-    // genotype rows -> engine (same feeder as the prune path)
-    {
-      feed_rows(e, inc);
-      const uint64_t out_rec = (static_cast<uint64_t>(founder_ct) + 3) / 4;
-      std::vector<uint32_t> founder_idx;
-      for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
-        if (is_founder[sx]) {
-          founder_idx.push_back(sx);
-        }
-      }
-      // Multiallelic variants (R2NondosageVariant works on PgrGetInv1(major allele) rows, plink2_ld.cc:6039-6048):
-      // collapsed major-vs-rest on the host, as for the prune.  With 'ref-based' the collapse is REF-vs-rest, which
-      // is what the main track's codes already are.
-      if (!A.r2_ref_based) {
-        std::vector<uint8_t> lo(raw_sample_ct), hi(raw_sample_ct), inv_row(out_rec);
-        for (uint32_t k = 0; k < variant_ct; ++k) {
-          const uint32_t alts = V.alt_ct[inc[k]];
-          if (alts < 2) {
-            continue;
-          }
-          if (storage_mode == 0x01) {
-            die(3, "Error: multiallelic variant in a .bim/.bed fileset.\n");
-          }
-          double mf = 0.0;
-          multiallelic_inverse_row(pg, inc[k], alts, founder_idx, &lo, &hi, inv_row.data(), out_rec, &mf);
-          if (ldp_load_genotypes(e, k, 1, inv_row.data(), out_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) || ldp_set_maj_freqs(e, k, 1, &mf)) {
-            die(12, "Error: %s\n", ldp_last_error(e));
-          }
-        }
+    return rc;
+  }
+  ldp_params RP;
+  memset(&RP, 0, sizeof(RP));
+  RP.founder_ct = founder_ct;
+  RP.prune_window_size = 2;
+  RP.prune_window_incr = 1;
+  RP.prune_last_param = 0.5;
+  RP.device = 0;
+  join_hip();
+  if (ldp_device_count() < 1) {
+    die(12, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
+  }
+  ldp_engine* e = nullptr;
+  if (ldp_create(&RP, &e)) {
+    die(12, "Error: engine setup failed.\n");
+  }
+  if (A.r2_table && !A.r2_allow_ambiguous) {  // plink2_ld.cc:11063-11072 (the default column set has no allele columns)
+    for (uint32_t k = 0; k < variant_ct; ++k) {
+      if (V.alt_ct[inc[k]] > 1) {
+        die(7, "Error: --r2-unphased column-set doesn't include allele columns which clarify\nwhich calculation is being performed at multiallelic variants. Either filter\nout multiallelic variants, revise the column-set (with e.g. \"cols=+%s\"), or\nuse the 'allow-ambiguous-allele' modifier to override this error.\n", A.r2_ref_based ? "ref" : "maj");
       }
     }
-    if (A.r2_table) {
-      // ---- windowed table (VcorTable, plink2_ld.cc:11025): one line per pair A < B inside the window whose r^2 passes
-      //      --ld-window-r2, A-major; default column set (plink2_ld.h:101)
-      std::vector<uint32_t> lo(std::max<uint32_t>(variant_ct, 1));
-      uint64_t cand = 0;
-      if (!A.r2_inter) {
-        ldp_get_band(e, lo.data(), &cand);
-      }
-      // hi[i] = last second variant paired with i (lo is nondecreasing inside a chromosome and == j outside windows)
-      std::vector<uint32_t> hi(variant_ct);
-      if (!A.r2_inter) {
-        uint32_t j = 0;
-        for (uint32_t i = 0; i < variant_ct; ++i) {
-          j = std::max(j, i);
-          while ((j + 1 < variant_ct) && (lo[j + 1] <= i) && (chr_idx[j + 1] == chr_idx[i])) {
-            ++j;
-          }
-          hi[i] = j;
+  }
+  if (A.r2_inter && (A.ld_min_r2 <= 0.0) && (variant_ct > 400000) && (A.parallel_tot == 1) && !A.yes_really) {  // plink2_ld.cc:11087
+    die(7, "Error: Gigantic (over 400k variants) --r2-unphased unfiltered, non-distributed\ncomputation.  Rerun with the 'yes-really' modifier if you are SURE you have enough\nhard drive space and want to do this.\n");
+  }
+  if ((A.r2_table && !A.r2_inter) ? ldp_set_variants_vcor(e, variant_ct, chr_idx.data(), bps.data(), A.ld_bp_radius, A.ld_var_ct_radius)
+                                  : ldp_set_variants_matrix(e, variant_ct)) {
+    die(12, "Error: engine setup failed: %s\n", ldp_last_error(e));
+  }
+  const std::string base = A.out + (A.r2_text ? ".unphased.vcor2" : ".unphased.vcor2.bin");
+  // --parallel k n: the reference's row shards.  Matrix (VcorMatrix, plink2_ld.cc:9800-9824): `square` takes rows
+  // [M k / n, M (k+1) / n); the triangular shapes take ParallelBounds() rows (equal numbers of lower-triangle entries) and
+  // a piece that does not reach the last row behaves as if the later variants did not exist (its .vars file, written by piece
+  // 1 only, lists just the variants before its last row; square0's zero padding still runs to the full width).  Table
+  // (VcorTable, :11157-11168): first variants [M k / n, M (k+1) / n); the header goes to piece 1.  Pieces are named
+  // <file>.<k> and concatenate to the undistributed output.
+  uint32_t shard_first = 0, shard_end = variant_ct, vars_ct = variant_ct;
+  const std::string piece_suffix = (A.parallel_tot == 1) ? std::string() : ("." + std::to_string(A.parallel_idx + 1));
+  if (A.parallel_tot != 1) {
+    if ((!A.r2_table) && (variant_ct < 2 * A.parallel_tot)) {
+      die(7, "Error: Too few variants in --r2-unphased run for --parallel %u %u.\n", A.parallel_idx + 1, A.parallel_tot);
+    }
+    if ((!A.r2_table) && (A.r2_shape != 0)) {
+      // smallest v with v (v + 1) >= x (TriangleDivide, plink2_common.cc:4936, modif = 1)
+      auto tri = [](uint64_t x) {
+        if (!x) {
+          return static_cast<uint64_t>(0);
         }
-      }
-      // names as the reference prints them (chrtoa with the default --output-chr: bare numbers, XY/PAR1/PAR2, contig names)
-      auto chrom_out = [&](const std::string& raw) {
-        std::string name = raw;
-        if (name.size() > 3 && (name[0] | 32) == 'c' && (name[1] | 32) == 'h' && (name[2] | 32) == 'r') {
-          bool zero = false;
-          const std::string rest = name.substr(3);
-          bool numeric = !rest.empty();
-          for (char c : rest) {
-            numeric = numeric && (c >= '0' && c <= '9');
-          }
-          if (numeric || ieq(rest.c_str(), "XY") || ieq(rest.c_str(), "PAR1") || ieq(rest.c_str(), "PAR2")) {
-            name = rest;
-          }
-          (void)zero;
+        uint64_t v = static_cast<uint64_t>(sqrt(static_cast<double>(x)));
+        while ((v >= 1) && ((v - 1) * v >= x)) {
+          --v;
         }
-        bool numeric = !name.empty();
-        for (char c : name) {
-          numeric = numeric && (c >= '0' && c <= '9');
+        while (v * (v + 1) < x) {
+          ++v;
         }
-        if (numeric) {
-          const long v = strtol(name.c_str(), nullptr, 10);
-          return (v == 25) ? std::string("XY") : std::to_string(v);
-        }
-        if (ieq(name.c_str(), "XY")) return std::string("XY");
-        if (ieq(name.c_str(), "PAR1")) return std::string("PAR1");
-        if (ieq(name.c_str(), "PAR2")) return std::string("PAR2");
-        return name;
+        return v;
       };
-      const std::string tpath = A.out + ".vcor" + piece_suffix + (A.r2_zs ? ".zst" : "");
-      OutFile tf;
-      tf.open(tpath, A.r2_zs);
-      static const char kVcorHeader[] = "#CHROM_A\tPOS_A\tID_A\tCHROM_B\tPOS_B\tID_B\tUNPHASED_R2\n";
-      if (A.parallel_idx == 0) {
-        tf.write(kVcorHeader, sizeof(kVcorHeader) - 1);
+      const uint64_t tot = static_cast<uint64_t>(variant_ct) * (static_cast<uint64_t>(variant_ct) + 1);
+      shard_first = static_cast<uint32_t>(tri(tot * A.parallel_idx / A.parallel_tot));
+      shard_end = static_cast<uint32_t>(tri(tot * (A.parallel_idx + 1) / A.parallel_tot));
+      vars_ct = shard_end;
+    } else {
+      shard_first = static_cast<uint32_t>(static_cast<uint64_t>(variant_ct) * A.parallel_idx / A.parallel_tot);
+      shard_end = static_cast<uint32_t>(static_cast<uint64_t>(variant_ct) * (A.parallel_idx + 1) / A.parallel_tot);
+    }
+  }
+  if ((!A.r2_table) && (A.parallel_idx == 0)) {
+    FILE* vf = fopen((base + ".vars").c_str(), "wb");
+    if (!vf) {
+      die(2, "Error: Failed to open %s.vars for writing.\n", base.c_str());
+    }
+    for (uint32_t k = 0; k < vars_ct; ++k) {
+      fputs(V.id[inc[k]].c_str(), vf);
+      fputc('\n', vf);
+    }
+    fclose(vf);
+    logprintf("--r2-unphased: Variant IDs written to %s.vars .\n", base.c_str());
+  }
+  // genotype rows -> engine (same feeder as the prune path)
+  {
+    feed_rows(e, inc);
+    const uint64_t out_rec = (static_cast<uint64_t>(founder_ct) + 3) / 4;
+    std::vector<uint32_t> founder_idx;
+    for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+      if (is_founder[sx]) {
+        founder_idx.push_back(sx);
       }
-      const double thresh = A.ld_min_r2;
-      if (A.r2_inter || (thresh > 0.0)) {
-        // ---- inter-chr: every pair A < B of the whole variant set, chromosome 0 included (plink2_ld.cc:11082-11116).
-        // The r^2 values come row chunk by row chunk (second variant B) from the all-pairs plan; pairs that pass
-        // --ld-window-r2 are kept as (A, B, r^2) and bucketed by A afterwards, which gives the file's A-major order.
-        // ---- windowed table with a positive threshold (the default): the same, over the band's pairs.
-        struct Hit {
-          uint32_t i, j;
-          double r2;
-        };
-        std::vector<Hit> hits;
-        std::vector<double> chunk;
-        const uint32_t nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-        // With a positive threshold the filter runs in the kernel's epilogue (ldp_r2_unphased_hits) and only the
-        // passing pairs cross PCIe; a row chunk whose hits overflow the buffer is redone through the dense path below.
-        const bool device_filter = (thresh > 0.0);
-        std::vector<ldp_r2_hit> dev_hits(device_filter ? (1u << 24) : 0);
-        uint32_t big_rows = 65536;
-        // (a shard owns the pairs whose FIRST variant lies in [shard_first, shard_end): second variants from shard_first + 1 on)
-        for (uint32_t r0 = (A.parallel_tot == 1) ? 0 : shard_first; r0 < variant_ct;) {
-          uint32_t rows = static_cast<uint32_t>(std::max<uint64_t>(32, (1ull << 28) / (static_cast<uint64_t>(r0 + 4096) * 8)));
-          rows = std::min(std::min(rows, variant_ct - r0), 65536u);
-          if (device_filter) {
-            const uint32_t big = A.r2_inter ? std::min(std::min<uint32_t>(rows * 16, variant_ct - r0), 65536u)  // (no dense buffer to size)
-                                            : std::min(big_rows, variant_ct - r0);
-            uint64_t found = 0;
-            if ((A.r2_inter && (A.parallel_tot != 1))
-                    ? ldp_r2_unphased_block_hits(e, r0, big, shard_first, shard_end - shard_first, thresh, dev_hits.data(), dev_hits.size(), &found)
-                    : ldp_r2_unphased_hits(e, r0, big, thresh, dev_hits.data(), dev_hits.size(), &found)) {
-              die(12, "Error: %s\n", ldp_last_error(e));
-            }
-            if (found <= dev_hits.size()) {
-              std::sort(dev_hits.begin(), dev_hits.begin() + found, [](const ldp_r2_hit& a, const ldp_r2_hit& b) {
-                return (a.second != b.second) ? (a.second < b.second) : (a.first < b.first);
-              });
-              for (uint64_t q = 0; q < found; ++q) {
-                if ((dev_hits[q].first >= shard_first) && (dev_hits[q].first < shard_end)) {
-                  hits.push_back({dev_hits[q].first, dev_hits[q].second, dev_hits[q].r2});
-                }
-              }
-              r0 += big;
-              continue;
-            }
-            if (!A.r2_inter) {
-              if (big == 1) {
-                die(8, "Error: one variant has more passing partners than the filter buffer holds.\n");
-              }
-              big_rows = std::max(1u, big / 2);  // more hits than the buffer holds: fewer second variants per call
-              continue;
-            }
-          }
-          const uint64_t ld = static_cast<uint64_t>(r0) + rows;
-          chunk.assign(static_cast<size_t>(rows) * ld, 0.0);
-          if (ldp_r2_unphased_rows(e, r0, rows, 0, chunk.data(), ld)) {
-            die(12, "Error: %s\n", ldp_last_error(e));
-          }
-          std::vector<std::vector<Hit>> part(nthreads);
-          std::vector<std::thread> pool;
-          for (uint32_t t = 0; t < nthreads; ++t) {
-            pool.emplace_back([&, t]() {
-              const uint32_t q0 = static_cast<uint32_t>(static_cast<uint64_t>(rows) * t / nthreads);
-              const uint32_t q1 = static_cast<uint32_t>(static_cast<uint64_t>(rows) * (t + 1) / nthreads);
-              for (uint32_t q = q0; q < q1; ++q) {
-                const uint32_t j = r0 + q;
-                const double* row = chunk.data() + static_cast<uint64_t>(q) * ld;
-                for (uint32_t i = shard_first; (i < j) && (i < shard_end); ++i) {
-                  const double r2 = row[i];
-                  if ((thresh >= 0.0) && (!(fabs(r2) >= thresh))) {  // VcorTableWriteThread :10816-10821
-                    continue;
-                  }
-                  part[t].push_back({i, j, r2});
-                }
-              }
-            });
-          }
-          for (std::thread& th : pool) {
-            th.join();
-          }
-          for (const std::vector<Hit>& v : part) {
-            hits.insert(hits.end(), v.begin(), v.end());
-          }
-          r0 += rows;
+    }
+    // Multiallelic variants (R2NondosageVariant works on PgrGetInv1(major allele) rows, plink2_ld.cc:6039-6048):
+    // collapsed major-vs-rest on the host, as for the prune.  With 'ref-based' the collapse is REF-vs-rest, which
+    // is what the main track's codes already are.
+    if (!A.r2_ref_based) {
+      std::vector<uint8_t> lo(raw_sample_ct), hi(raw_sample_ct), inv_row(out_rec);
+      for (uint32_t k = 0; k < variant_ct; ++k) {
+        const uint32_t alts = V.alt_ct[inc[k]];
+        if (alts < 2) {
+          continue;
         }
-        // stable bucket by first variant (second variants arrive in increasing order)
-        std::vector<uint64_t> start(static_cast<size_t>(variant_ct) + 1, 0);
-        for (const Hit& h : hits) {
-          ++start[h.i + 1];
+        if (storage_mode == 0x01) {
+          die(3, "Error: multiallelic variant in a .bim/.bed fileset.\n");
         }
-        for (uint32_t i = 0; i < variant_ct; ++i) {
-          start[i + 1] += start[i];
-        }
-        std::vector<Hit> sorted(hits.size());
-        {
-          std::vector<uint64_t> cursor(start.begin(), start.end() - 1);
-          for (const Hit& h : hits) {
-            sorted[cursor[h.i]++] = h;
-          }
-        }
-        std::vector<Hit>().swap(hits);
-        std::vector<std::string> chr_name;  // by chromosome order index
-        for (uint32_t k = 0; k < variant_ct; ++k) {
-          if (chr_idx[k] >= chr_name.size()) {
-            chr_name.resize(chr_idx[k] + 1);
-            chr_name[chr_idx[k]] = chrom_out(V.chrom[inc[k]]);
-          }
-        }
-        std::string out;
-        out.reserve(1 << 22);
-        char num[40];
-        for (const Hit& h : sorted) {
-          out += chr_name[chr_idx[h.i]];
-          out += '\t';
-          out += std::to_string(bps[h.i]);
-          out += '\t';
-          out += V.id[inc[h.i]];
-          out += '\t';
-          out += chr_name[chr_idx[h.j]];
-          out += '\t';
-          out += std::to_string(bps[h.j]);
-          out += '\t';
-          out += V.id[inc[h.j]];
-          out += '\t';
-          out.append(num, format_g6(h.r2, num) - num);
-          out += '\n';
-          if (out.size() > (1u << 21)) {
-            tf.write(out.data(), out.size());
-            out.clear();
-          }
-        }
-        tf.write(out.data(), out.size());
-        tf.close();
-        logprintf("--r2-unphased: %llu variant pair%s written to %s .\n", static_cast<unsigned long long>(sorted.size()), sorted.size() == 1 ? "" : "s", tpath.c_str());
-        ldp_destroy(e);
-        ldp_pgen_close(pg);
-        if (g_log) {
-          fclose(g_log);
-        }
-        return 0;
-      }
-      std::vector<double> band;
-      std::vector<uint64_t> off;
-      std::string linebuf;
-      linebuf.reserve(1 << 22);
-      std::string chr_a_name;
-      uint32_t chr_a_idx = 0xffffffffu;
-      uint64_t written = 0;
-      const uint64_t kMaxPairs = 1ull << 25;  // 256 MiB of doubles per chunk
-      for (uint32_t a0 = shard_first; a0 < shard_end;) {
-        // first variants [a0, a1): their partners are the second variants (a0, hi[a1-1]]
-        uint32_t a1 = a0;
-        uint64_t pairs = 0;
-        uint32_t row_end = a0 + 1;
-        while (a1 < shard_end) {
-          const uint32_t new_end = std::max(row_end, hi[a1] + 1);
-          uint64_t add = 0;
-          for (uint32_t j = row_end; j < new_end; ++j) {
-            add += j - lo[j];
-          }
-          if ((a1 > a0) && (pairs + add > kMaxPairs)) {
-            break;
-          }
-          pairs += add;
-          row_end = new_end;
-          ++a1;
-        }
-        const uint32_t row_first = a0;
-        const uint32_t row_ct = row_end - row_first;
-        off.assign(static_cast<size_t>(row_ct) + 1, 0);
-        for (uint32_t q = 0; q < row_ct; ++q) {
-          off[q + 1] = off[q] + ((row_first + q) - lo[row_first + q]);
-        }
-        band.resize(std::max<uint64_t>(off[row_ct], 1));
-        if (off[row_ct] && ldp_r2_unphased_band_rows(e, row_first, row_ct, 0, band.data(), off[row_ct])) {
+        double mf = 0.0;
+        multiallelic_inverse_row(pg, inc[k], alts, founder_idx, &lo, &hi, inv_row.data(), out_rec, &mf);
+        if (ldp_load_genotypes(e, k, 1, inv_row.data(), out_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) || ldp_set_maj_freqs(e, k, 1, &mf)) {
           die(12, "Error: %s\n", ldp_last_error(e));
         }
-        char num[40];
-        for (uint32_t i = a0; i < a1; ++i) {
-          if (chr_idx[i] != chr_a_idx) {
-            chr_a_idx = chr_idx[i];
-            chr_a_name = chrom_out(V.chrom[inc[i]]);
+      }
+    }
+  }
+  if (A.r2_table) {
+    // ---- windowed table (VcorTable, plink2_ld.cc:11025): one line per pair A < B inside the window whose r^2 passes
+    //      --ld-window-r2, A-major; default column set (plink2_ld.h:101)
+    std::vector<uint32_t> lo(std::max<uint32_t>(variant_ct, 1));
+    uint64_t cand = 0;
+    if (!A.r2_inter) {
+      ldp_get_band(e, lo.data(), &cand);
+    }
+    // hi[i] = last second variant paired with i (lo is nondecreasing inside a chromosome and == j outside windows)
+    std::vector<uint32_t> hi(variant_ct);
+    if (!A.r2_inter) {
+      uint32_t j = 0;
+      for (uint32_t i = 0; i < variant_ct; ++i) {
+        j = std::max(j, i);
+        while ((j + 1 < variant_ct) && (lo[j + 1] <= i) && (chr_idx[j + 1] == chr_idx[i])) {
+          ++j;
+        }
+        hi[i] = j;
+      }
+    }
+    // names as the reference prints them (chrtoa with the default --output-chr: bare numbers, XY/PAR1/PAR2, contig names)
+    auto chrom_out = [&](const std::string& raw) {
+      std::string name = raw;
+      if (name.size() > 3 && (name[0] | 32) == 'c' && (name[1] | 32) == 'h' && (name[2] | 32) == 'r') {
+        bool zero = false;
+        const std::string rest = name.substr(3);
+        bool numeric = !rest.empty();
+        for (char c : rest) {
+          numeric = numeric && (c >= '0' && c <= '9');
+        }
+        if (numeric || ieq(rest.c_str(), "XY") || ieq(rest.c_str(), "PAR1") || ieq(rest.c_str(), "PAR2")) {
+          name = rest;
+        }
+        (void)zero;
+      }
+      bool numeric = !name.empty();
+      for (char c : name) {
+        numeric = numeric && (c >= '0' && c <= '9');
+      }
+      if (numeric) {
+        const long v = strtol(name.c_str(), nullptr, 10);
+        return (v == 25) ? std::string("XY") : std::to_string(v);
+      }
+      if (ieq(name.c_str(), "XY")) return std::string("XY");
+      if (ieq(name.c_str(), "PAR1")) return std::string("PAR1");
+      if (ieq(name.c_str(), "PAR2")) return std::string("PAR2");
+      return name;
+    };
+    const std::string tpath = A.out + ".vcor" + piece_suffix + (A.r2_zs ? ".zst" : "");
+    OutFile tf;
+    tf.open(tpath, A.r2_zs);
+    static const char kVcorHeader[] = "#CHROM_A\tPOS_A\tID_A\tCHROM_B\tPOS_B\tID_B\tUNPHASED_R2\n";
+    if (A.parallel_idx == 0) {
+      tf.write(kVcorHeader, sizeof(kVcorHeader) - 1);
+    }
+    const double thresh = A.ld_min_r2;
+    if (A.r2_inter || (thresh > 0.0)) {
+      // ---- inter-chr: every pair A < B of the whole variant set, chromosome 0 included (plink2_ld.cc:11082-11116).
+      // The r^2 values come row chunk by row chunk (second variant B) from the all-pairs plan; pairs that pass
+      // --ld-window-r2 are kept as (A, B, r^2) and bucketed by A afterwards, which gives the file's A-major order.
+      // ---- windowed table with a positive threshold (the default): the same, over the band's pairs.
+      struct Hit {
+        uint32_t i, j;
+        double r2;
+      };
+      std::vector<Hit> hits;
+      std::vector<double> chunk;
+      const uint32_t nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+      // With a positive threshold the filter runs in the kernel's epilogue (ldp_r2_unphased_hits) and only the
+      // passing pairs cross PCIe; a row chunk whose hits overflow the buffer is redone through the dense path below.
+      const bool device_filter = (thresh > 0.0);
+      std::vector<ldp_r2_hit> dev_hits(device_filter ? (1u << 24) : 0);
+      uint32_t big_rows = 65536;
+      // (a shard owns the pairs whose FIRST variant lies in [shard_first, shard_end): second variants from shard_first + 1 on)
+      for (uint32_t r0 = (A.parallel_tot == 1) ? 0 : shard_first; r0 < variant_ct;) {
+        uint32_t rows = static_cast<uint32_t>(std::max<uint64_t>(32, (1ull << 28) / (static_cast<uint64_t>(r0 + 4096) * 8)));
+        rows = std::min(std::min(rows, variant_ct - r0), 65536u);
+        if (device_filter) {
+          const uint32_t big = A.r2_inter ? std::min(std::min<uint32_t>(rows * 16, variant_ct - r0), 65536u)  // (no dense buffer to size)
+                                          : std::min(big_rows, variant_ct - r0);
+          uint64_t found = 0;
+          if ((A.r2_inter && (A.parallel_tot != 1))
+                  ? ldp_r2_unphased_block_hits(e, r0, big, shard_first, shard_end - shard_first, thresh, dev_hits.data(), dev_hits.size(), &found)
+                  : ldp_r2_unphased_hits(e, r0, big, thresh, dev_hits.data(), dev_hits.size(), &found)) {
+            die(12, "Error: %s\n", ldp_last_error(e));
           }
-          for (uint32_t j = i + 1; j <= hi[i]; ++j) {
-            const double r2 = band[off[j - row_first] + (i - lo[j])];
-            if ((thresh >= 0.0) && (!(fabs(r2) >= thresh))) {  // VcorTableWriteThread :10816-10821 (NaN never passes)
-              continue;
+          if (found <= dev_hits.size()) {
+            std::sort(dev_hits.begin(), dev_hits.begin() + found, [](const ldp_r2_hit& a, const ldp_r2_hit& b) {
+              return (a.second != b.second) ? (a.second < b.second) : (a.first < b.first);
+            });
+            for (uint64_t q = 0; q < found; ++q) {
+              if ((dev_hits[q].first >= shard_first) && (dev_hits[q].first < shard_end)) {
+                hits.push_back({dev_hits[q].first, dev_hits[q].second, dev_hits[q].r2});
+              }
             }
-            linebuf += chr_a_name;
-            linebuf += '\t';
-            linebuf += std::to_string(bps[i]);
-            linebuf += '\t';
-            linebuf += V.id[inc[i]];
-            linebuf += '\t';
-            linebuf += chr_a_name;  // same chromosome: the table never pairs across chromosomes without inter-chr
-            linebuf += '\t';
-            linebuf += std::to_string(bps[j]);
-            linebuf += '\t';
-            linebuf += V.id[inc[j]];
-            linebuf += '\t';
-            linebuf.append(num, format_g6(r2, num) - num);
-            linebuf += '\n';
-            ++written;
+            r0 += big;
+            continue;
           }
-          if (linebuf.size() > (1u << 21)) {
-            tf.write(linebuf.data(), linebuf.size());
-            linebuf.clear();
+          if (!A.r2_inter) {
+            if (big == 1) {
+              die(8, "Error: one variant has more passing partners than the filter buffer holds.\n");
+            }
+            big_rows = std::max(1u, big / 2);  // more hits than the buffer holds: fewer second variants per call
+            continue;
           }
         }
-        a0 = a1;
+        const uint64_t ld = static_cast<uint64_t>(r0) + rows;
+        chunk.assign(static_cast<size_t>(rows) * ld, 0.0);
+        if (ldp_r2_unphased_rows(e, r0, rows, 0, chunk.data(), ld)) {
+          die(12, "Error: %s\n", ldp_last_error(e));
+        }
+        std::vector<std::vector<Hit>> part(nthreads);
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < nthreads; ++t) {
+          pool.emplace_back([&, t]() {
+            const uint32_t q0 = static_cast<uint32_t>(static_cast<uint64_t>(rows) * t / nthreads);
+            const uint32_t q1 = static_cast<uint32_t>(static_cast<uint64_t>(rows) * (t + 1) / nthreads);
+            for (uint32_t q = q0; q < q1; ++q) {
+              const uint32_t j = r0 + q;
+              const double* row = chunk.data() + static_cast<uint64_t>(q) * ld;
+              for (uint32_t i = shard_first; (i < j) && (i < shard_end); ++i) {
+                const double r2 = row[i];
+                if ((thresh >= 0.0) && (!(fabs(r2) >= thresh))) {  // VcorTableWriteThread :10816-10821
+                  continue;
+                }
+                part[t].push_back({i, j, r2});
+              }
+            }
+          });
+        }
+        for (std::thread& th : pool) {
+          th.join();
+        }
+        for (const std::vector<Hit>& v : part) {
+          hits.insert(hits.end(), v.begin(), v.end());
+        }
+        r0 += rows;
       }
-      tf.write(linebuf.data(), linebuf.size());
+      // stable bucket by first variant (second variants arrive in increasing order)
+      std::vector<uint64_t> start(static_cast<size_t>(variant_ct) + 1, 0);
+      for (const Hit& h : hits) {
+        ++start[h.i + 1];
+      }
+      for (uint32_t i = 0; i < variant_ct; ++i) {
+        start[i + 1] += start[i];
+      }
+      std::vector<Hit> sorted(hits.size());
+      {
+        std::vector<uint64_t> cursor(start.begin(), start.end() - 1);
+        for (const Hit& h : hits) {
+          sorted[cursor[h.i]++] = h;
+        }
+      }
+      std::vector<Hit>().swap(hits);
+      std::vector<std::string> chr_name;  // by chromosome order index
+      for (uint32_t k = 0; k < variant_ct; ++k) {
+        if (chr_idx[k] >= chr_name.size()) {
+          chr_name.resize(chr_idx[k] + 1);
+          chr_name[chr_idx[k]] = chrom_out(V.chrom[inc[k]]);
+        }
+      }
+      std::string out;
+      out.reserve(1 << 22);
+      char num[40];
+      for (const Hit& h : sorted) {
+        out += chr_name[chr_idx[h.i]];
+        out += '\t';
+        out += std::to_string(bps[h.i]);
+        out += '\t';
+        out += V.id[inc[h.i]];
+        out += '\t';
+        out += chr_name[chr_idx[h.j]];
+        out += '\t';
+        out += std::to_string(bps[h.j]);
+        out += '\t';
+        out += V.id[inc[h.j]];
+        out += '\t';
+        out.append(num, format_g6(h.r2, num) - num);
+        out += '\n';
+        if (out.size() > (1u << 21)) {
+          tf.write(out.data(), out.size());
+          out.clear();
+        }
+      }
+      tf.write(out.data(), out.size());
       tf.close();
-      logprintf("--r2-unphased: %llu variant pair%s written to %s .\n", static_cast<unsigned long long>(written), written == 1 ? "" : "s", tpath.c_str());
+      logprintf("--r2-unphased: %llu variant pair%s written to %s .\n", static_cast<unsigned long long>(sorted.size()), sorted.size() == 1 ? "" : "s", tpath.c_str());
       ldp_destroy(e);
       ldp_pgen_close(pg);
       if (g_log) {
@@ -2583,108 +2546,79 @@ int main(int argc, char** argv) {
       }
       return 0;
     }
-    const size_t esz = A.r2_float ? 4 : 8;
-    const std::string mpath = base + piece_suffix + ((A.r2_text && A.r2_zs) ? ".zst" : "");
-    OutFile mf;
-    mf.open(mpath, A.r2_text && A.r2_zs);
-    // square needs the mirrored upper triangle: the shard's rows, full width, in host memory.  The lower part of row j comes
-    // from the engine's row j; the upper part (columns i > j) from the column block [shard rows] of the later rows i.
-    const uint32_t piece_rows = shard_end - shard_first;
-    std::vector<uint8_t> full;
-    if (A.r2_shape == 0) {
-      full.assign(static_cast<size_t>(piece_rows) * variant_ct * esz, 0);
-    }
-    std::vector<uint8_t> chunk;
-    std::string textbuf;
-    for (uint32_t r0 = shard_first; r0 < shard_end;) {
-      // rows per chunk: about 1 GiB of output
-      uint32_t rows = static_cast<uint32_t>(std::max<uint64_t>(32, (1ull << 30) / (static_cast<uint64_t>(r0 + 4096) * esz)));
-      rows = std::min(std::min(rows, shard_end - r0), 65536u);
-      const uint64_t ld = static_cast<uint64_t>(r0) + rows;
-      chunk.assign(static_cast<size_t>(rows) * ld * esz, 0);
-      if (ldp_r2_unphased_rows(e, r0, rows, A.r2_float, chunk.data(), ld)) {
+    std::vector<double> band;
+    std::vector<uint64_t> off;
+    std::string linebuf;
+    linebuf.reserve(1 << 22);
+    std::string chr_a_name;
+    uint32_t chr_a_idx = 0xffffffffu;
+    uint64_t written = 0;
+    const uint64_t kMaxPairs = 1ull << 25;  // 256 MiB of doubles per chunk
+    for (uint32_t a0 = shard_first; a0 < shard_end;) {
+      // first variants [a0, a1): their partners are the second variants (a0, hi[a1-1]]
+      uint32_t a1 = a0;
+      uint64_t pairs = 0;
+      uint32_t row_end = a0 + 1;
+      while (a1 < shard_end) {
+        const uint32_t new_end = std::max(row_end, hi[a1] + 1);
+        uint64_t add = 0;
+        for (uint32_t j = row_end; j < new_end; ++j) {
+          add += j - lo[j];
+        }
+        if ((a1 > a0) && (pairs + add > kMaxPairs)) {
+          break;
+        }
+        pairs += add;
+        row_end = new_end;
+        ++a1;
+      }
+      const uint32_t row_first = a0;
+      const uint32_t row_ct = row_end - row_first;
+      off.assign(static_cast<size_t>(row_ct) + 1, 0);
+      for (uint32_t q = 0; q < row_ct; ++q) {
+        off[q + 1] = off[q] + ((row_first + q) - lo[row_first + q]);
+      }
+      band.resize(std::max<uint64_t>(off[row_ct], 1));
+      if (off[row_ct] && ldp_r2_unphased_band_rows(e, row_first, row_ct, 0, band.data(), off[row_ct])) {
         die(12, "Error: %s\n", ldp_last_error(e));
       }
-      for (uint32_t q = 0; q < rows; ++q) {
-        const uint32_t j = r0 + q;
-        const uint8_t* row = chunk.data() + static_cast<uint64_t>(q) * ld * esz;
-        if (A.r2_text && (A.r2_shape != 0)) {
-          // VcorMatrixWriteThread :9733-9752: dtoa_g values, tab-separated, square0 padded with "0" entries
-          const double* drow = reinterpret_cast<const double*>(row);
-          textbuf.clear();
-          char num[40];
-          for (uint32_t i = 0; i <= j; ++i) {
-            textbuf.append(num, format_g6(drow[i], num) - num);
-            textbuf += '\t';
+      char num[40];
+      for (uint32_t i = a0; i < a1; ++i) {
+        if (chr_idx[i] != chr_a_idx) {
+          chr_a_idx = chr_idx[i];
+          chr_a_name = chrom_out(V.chrom[inc[i]]);
+        }
+        for (uint32_t j = i + 1; j <= hi[i]; ++j) {
+          const double r2 = band[off[j - row_first] + (i - lo[j])];
+          if ((thresh >= 0.0) && (!(fabs(r2) >= thresh))) {  // VcorTableWriteThread :10816-10821 (NaN never passes)
+            continue;
           }
-          if (A.r2_shape == 1) {
-            for (uint32_t i = j + 1; i < variant_ct; ++i) {
-              textbuf += "0\t";
-            }
-          }
-          textbuf.back() = '\n';
-          mf.write(textbuf.data(), textbuf.size());
-        } else if (A.r2_shape == 2) {
-          mf.write(row, esz * (static_cast<size_t>(j) + 1));
-        } else if (A.r2_shape == 1) {
-          mf.write(row, esz * (static_cast<size_t>(j) + 1));
-          static const std::vector<uint8_t> zeros(1 << 20, 0);
-          for (uint64_t left = (static_cast<uint64_t>(variant_ct) - j - 1) * esz; left;) {
-            const size_t w = static_cast<size_t>(std::min<uint64_t>(left, zeros.size()));
-            mf.write(zeros.data(), w);
-            left -= w;
-          }
-        } else {
-          memcpy(full.data() + static_cast<uint64_t>(j - shard_first) * variant_ct * esz, row, (static_cast<size_t>(j) + 1) * esz);
+          linebuf += chr_a_name;
+          linebuf += '\t';
+          linebuf += std::to_string(bps[i]);
+          linebuf += '\t';
+          linebuf += V.id[inc[i]];
+          linebuf += '\t';
+          linebuf += chr_a_name;  // same chromosome: the table never pairs across chromosomes without inter-chr
+          linebuf += '\t';
+          linebuf += std::to_string(bps[j]);
+          linebuf += '\t';
+          linebuf += V.id[inc[j]];
+          linebuf += '\t';
+          linebuf.append(num, format_g6(r2, num) - num);
+          linebuf += '\n';
+          ++written;
+        }
+        if (linebuf.size() > (1u << 21)) {
+          tf.write(linebuf.data(), linebuf.size());
+          linebuf.clear();
         }
       }
-      r0 += rows;
+      a0 = a1;
     }
-    if (A.r2_shape == 0 && !full.empty()) {
-      if (piece_rows == variant_ct) {
-        // the whole matrix is here: mirror it
-        for (uint32_t j = 1; j < variant_ct; ++j) {
-          for (uint32_t i = 0; i < j; ++i) {
-            memcpy(full.data() + (static_cast<uint64_t>(i) * variant_ct + j) * esz, full.data() + (static_cast<uint64_t>(j) * variant_ct + i) * esz, esz);
-          }
-        }
-      }
-      // upper parts of a shard: second variants i in (shard_first, M), first variants = the shard's rows
-      for (uint32_t r0 = (piece_rows == variant_ct) ? variant_ct : (shard_first + 1); r0 < variant_ct;) {
-        uint32_t rows = static_cast<uint32_t>(std::max<uint64_t>(32, (1ull << 29) / (static_cast<uint64_t>(piece_rows) * esz)));
-        rows = std::min(std::min(rows, variant_ct - r0), 65536u);
-        chunk.assign(static_cast<size_t>(rows) * piece_rows * esz, 0);
-        if (ldp_r2_unphased_block(e, r0, rows, shard_first, piece_rows, A.r2_float, chunk.data(), piece_rows)) {
-          die(12, "Error: %s\n", ldp_last_error(e));
-        }
-        for (uint32_t q = 0; q < rows; ++q) {
-          const uint32_t i = r0 + q;  // second variant
-          const uint32_t jmax = std::min(i, shard_end);  // first variants j in [shard_first, jmax)
-          const uint8_t* brow = chunk.data() + static_cast<uint64_t>(q) * piece_rows * esz;
-          for (uint32_t j = shard_first; j < jmax; ++j) {
-            memcpy(full.data() + (static_cast<uint64_t>(j - shard_first) * variant_ct + i) * esz, brow + static_cast<uint64_t>(j - shard_first) * esz, esz);
-          }
-        }
-        r0 += rows;
-      }
-      if (A.r2_text) {
-        const double* dm = reinterpret_cast<const double*>(full.data());
-        char num[40];
-        for (uint32_t j = 0; j < piece_rows; ++j) {
-          textbuf.clear();
-          for (uint32_t i = 0; i < variant_ct; ++i) {
-            textbuf.append(num, format_g6(dm[static_cast<uint64_t>(j) * variant_ct + i], num) - num);
-            textbuf += '\t';
-          }
-          textbuf.back() = '\n';
-          mf.write(textbuf.data(), textbuf.size());
-        }
-      } else {
-        mf.write(full.data(), full.size());
-      }
-    }
-    mf.close();
-    logprintf("--r2-unphased: Matrix%s written to %s .\n", (A.parallel_tot == 1) ? "" : " piece", mpath.c_str());
+    tf.write(linebuf.data(), linebuf.size());
+    tf.close();
+    logprintf("--r2-unphased: %llu variant pair%s written to %s .\n", static_cast<unsigned long long>(written), written == 1 ? "" : "s", tpath.c_str());
     ldp_destroy(e);
     ldp_pgen_close(pg);
     if (g_log) {
@@ -2692,6 +2626,135 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  const size_t esz = A.r2_float ? 4 : 8;
+  const std::string mpath = base + piece_suffix + ((A.r2_text && A.r2_zs) ? ".zst" : "");
+  OutFile mf;
+  mf.open(mpath, A.r2_text && A.r2_zs);
+  // square needs the mirrored upper triangle: the shard's rows, full width, in host memory.  The lower part of row j comes
+  // from the engine's row j; the upper part (columns i > j) from the column block [shard rows] of the later rows i.
+  const uint32_t piece_rows = shard_end - shard_first;
+  std::vector<uint8_t> full;
+  if (A.r2_shape == 0) {
+    full.assign(static_cast<size_t>(piece_rows) * variant_ct * esz, 0);
+  }
+  std::vector<uint8_t> chunk;
+  std::string textbuf;
+  for (uint32_t r0 = shard_first; r0 < shard_end;) {
+    // rows per chunk: about 1 GiB of output
+    uint32_t rows = static_cast<uint32_t>(std::max<uint64_t>(32, (1ull << 30) / (static_cast<uint64_t>(r0 + 4096) * esz)));
+    rows = std::min(std::min(rows, shard_end - r0), 65536u);
+    const uint64_t ld = static_cast<uint64_t>(r0) + rows;
+    chunk.assign(static_cast<size_t>(rows) * ld * esz, 0);
+    if (ldp_r2_unphased_rows(e, r0, rows, A.r2_float, chunk.data(), ld)) {
+      die(12, "Error: %s\n", ldp_last_error(e));
+    }
+    for (uint32_t q = 0; q < rows; ++q) {
+      const uint32_t j = r0 + q;
+      const uint8_t* row = chunk.data() + static_cast<uint64_t>(q) * ld * esz;
+      if (A.r2_text && (A.r2_shape != 0)) {
+        // VcorMatrixWriteThread :9733-9752: dtoa_g values, tab-separated, square0 padded with "0" entries
+        const double* drow = reinterpret_cast<const double*>(row);
+        textbuf.clear();
+        char num[40];
+        for (uint32_t i = 0; i <= j; ++i) {
+          textbuf.append(num, format_g6(drow[i], num) - num);
+          textbuf += '\t';
+        }
+        if (A.r2_shape == 1) {
+          for (uint32_t i = j + 1; i < variant_ct; ++i) {
+            textbuf += "0\t";
+          }
+        }
+        textbuf.back() = '\n';
+        mf.write(textbuf.data(), textbuf.size());
+      } else if (A.r2_shape == 2) {
+        mf.write(row, esz * (static_cast<size_t>(j) + 1));
+      } else if (A.r2_shape == 1) {
+        mf.write(row, esz * (static_cast<size_t>(j) + 1));
+        static const std::vector<uint8_t> zeros(1 << 20, 0);
+        for (uint64_t left = (static_cast<uint64_t>(variant_ct) - j - 1) * esz; left;) {
+          const size_t w = static_cast<size_t>(std::min<uint64_t>(left, zeros.size()));
+          mf.write(zeros.data(), w);
+          left -= w;
+        }
+      } else {
+        memcpy(full.data() + static_cast<uint64_t>(j - shard_first) * variant_ct * esz, row, (static_cast<size_t>(j) + 1) * esz);
+      }
+    }
+    r0 += rows;
+  }
+  if (A.r2_shape == 0 && !full.empty()) {
+    if (piece_rows == variant_ct) {
+      // the whole matrix is here: mirror it
+      for (uint32_t j = 1; j < variant_ct; ++j) {
+        for (uint32_t i = 0; i < j; ++i) {
+          memcpy(full.data() + (static_cast<uint64_t>(i) * variant_ct + j) * esz, full.data() + (static_cast<uint64_t>(j) * variant_ct + i) * esz, esz);
+        }
+      }
+    }
+    // upper parts of a shard: second variants i in (shard_first, M), first variants = the shard's rows
+    for (uint32_t r0 = (piece_rows == variant_ct) ? variant_ct : (shard_first + 1); r0 < variant_ct;) {
+      uint32_t rows = static_cast<uint32_t>(std::max<uint64_t>(32, (1ull << 29) / (static_cast<uint64_t>(piece_rows) * esz)));
+      rows = std::min(std::min(rows, variant_ct - r0), 65536u);
+      chunk.assign(static_cast<size_t>(rows) * piece_rows * esz, 0);
+      if (ldp_r2_unphased_block(e, r0, rows, shard_first, piece_rows, A.r2_float, chunk.data(), piece_rows)) {
+        die(12, "Error: %s\n", ldp_last_error(e));
+      }
+      for (uint32_t q = 0; q < rows; ++q) {
+        const uint32_t i = r0 + q;  // second variant
+        const uint32_t jmax = std::min(i, shard_end);  // first variants j in [shard_first, jmax)
+        const uint8_t* brow = chunk.data() + static_cast<uint64_t>(q) * piece_rows * esz;
+        for (uint32_t j = shard_first; j < jmax; ++j) {
+          memcpy(full.data() + (static_cast<uint64_t>(j - shard_first) * variant_ct + i) * esz, brow + static_cast<uint64_t>(j - shard_first) * esz, esz);
+        }
+      }
+      r0 += rows;
+    }
+    if (A.r2_text) {
+      const double* dm = reinterpret_cast<const double*>(full.data());
+      char num[40];
+      for (uint32_t j = 0; j < piece_rows; ++j) {
+        textbuf.clear();
+        for (uint32_t i = 0; i < variant_ct; ++i) {
+          textbuf.append(num, format_g6(dm[static_cast<uint64_t>(j) * variant_ct + i], num) - num);
+          textbuf += '\t';
+        }
+        textbuf.back() = '\n';
+        mf.write(textbuf.data(), textbuf.size());
+      }
+    } else {
+      mf.write(full.data(), full.size());
+    }
+  }
+  mf.close();
+  logprintf("--r2-unphased: Matrix%s written to %s .\n", (A.parallel_tot == 1) ? "" : " piece", mpath.c_str());
+  ldp_destroy(e);
+  ldp_pgen_close(pg);
+  if (g_log) {
+    fclose(g_log);
+  }
+  return 0;
+}
+
+// ---- --indep-pairwise / --indep-pairphase ----
+int run_prune(Session& S) {
+  const Args& A = S.A;
+  const Variants& V = S.V;
+  const double t_begin = S.t_begin;
+  const std::vector<uint8_t>& is_founder = S.is_founder;
+  const std::vector<uint8_t>& sex = S.sex;
+  const uint32_t raw_sample_ct = S.raw_sample_ct, founder_ct = S.founder_ct, raw_variant_ct = S.raw_variant_ct;
+  const std::string& gpath = S.gpath;
+  ldp_pgen* const pg = S.pg;
+  const int storage_mode = S.storage_mode, encoding = S.encoding, has_multiallelic = S.has_multiallelic;
+  const uint64_t rec_bytes = S.rec_bytes;
+  const uint8_t* const direct_rows = S.direct_rows;
+  const std::vector<uint32_t>&inc = S.inc, &chr_idx = S.chr_idx, &bps = S.bps;
+  const std::vector<uint8_t>& vcls = S.vcls;
+  const uint32_t variant_ct = S.variant_ct, m_ct = S.m_ct;
+  const std::vector<uint32_t>&mk = S.mk, &xk = S.xk, &yk = S.yk, &tk = S.tk, &m_chr = S.m_chr, &m_bps = S.m_bps;
+  auto join_hip = [&S]() { S.join_hip(); };
+  const double &t_hip_init = S.t_hip_init, &t_parse = S.t_parse, &t_joined = S.t_joined;
 
   ldp_params P;
   memset(&P, 0, sizeof(P));
@@ -2955,11 +3018,43 @@ int main(int argc, char** argv) {
         uint32_t multi_unphased = UINT32_MAX;
         SexPlan mt_plan;
         mt_plan.part1 = founder_idx;
+        // A multiallelic variant whose REF allele is the major one needs nothing: the main track already counts REF
+        // copies (0/1/2 non-REF alleles = 0/1/2 non-major ones), and GetMajIdxMulti's first test (plink2_common.cc:1042,
+        // freq[REF] >= 0.5 with freq = count * (1 / total), plink2_filter.cc:2137-2147) is the biallelic rule the
+        // conversion kernel applied to the bulk-loaded row.  Its genotype counts say which variants those are.
+        std::vector<uint8_t> ref_is_major;
+        uint32_t multi_skipped = 0;
+        if (!A.pairphase) {
+          bool any_multi = false;
+          for (uint32_t qq = 0; (qq < m_ct) && !any_multi; ++qq) {
+            any_multi = (V.alt_ct[inc[mk[qq]]] > 1) && (vcls[mk[qq]] != 5);
+          }
+          if (any_multi) {
+            ref_is_major.assign(m_ct, 0);
+            std::vector<ldp_variant_rec> recs(m_ct);
+            for (int r = 0; r < world; ++r) {  // (a variant's counts are zero on the engines that do not own it)
+              if (ldp_get_variant_recs(eng[r], 0, m_ct, recs.data())) {
+                die(12, "\nError: %s\n", ldp_last_error(eng[r]));
+              }
+              for (uint32_t qq = 0; qq < m_ct; ++qq) {
+                const uint64_t ref_ct = 2ull * recs[qq].n_homref + recs[qq].n_het;
+                const uint64_t tot = 2ull * (static_cast<uint64_t>(recs[qq].n_homref) + recs[qq].n_het + recs[qq].n_homalt);
+                if (tot && (static_cast<double>(ref_ct) * (1.0 / static_cast<double>(tot)) >= 0.5)) {
+                  ref_is_major[qq] = 1;
+                }
+              }
+            }
+          }
+        }
         for (uint32_t qq = 0; qq < m_ct; ++qq) {
           const uint32_t raw_v = inc[mk[qq]];
           const uint32_t alts = V.alt_ct[raw_v];
           const bool is_mt = (vcls[mk[qq]] == 5);
           if (alts < 2 && !is_mt) {
+            continue;
+          }
+          if ((!is_mt) && (!ref_is_major.empty()) && ref_is_major[qq]) {
+            ++multi_skipped;
             continue;
           }
           double mf = 0.0;
@@ -2992,8 +3087,9 @@ int main(int argc, char** argv) {
         if (std::min(multi_unphased, pending_unphased) != UINT32_MAX) {
           die_unphased(std::min(multi_unphased, pending_unphased));
         }
-        if ((multi_ct || mt_ct) && A.timing) {
-          logprintf("\n[timing] host-built rows: %u multiallelic, %u MT\n", multi_ct, mt_ct);
+        if ((multi_ct || mt_ct || multi_skipped) && A.timing) {
+          logprintf("\n[timing] host-built rows: %u multiallelic (%u more have REF as the major allele: main track as loaded), %u MT\n", multi_ct,
+                    multi_skipped, mt_ct);
         }
       }
       t_load1 = now_s();
@@ -3159,4 +3255,13 @@ int main(int argc, char** argv) {
   fflush(nullptr);
   // everything is on disk; releasing tens of GB of device memory and unmapping the input only costs time
   _exit(0);
+}
+
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  Session S;
+  load_inputs(S, argc, argv);
+  return S.A.have_r2 ? run_r2(S) : run_prune(S);
 }
