@@ -2355,6 +2355,14 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
   }
   static const bool eager_always = (getenv("LDP_EAGER_PAIRS") != nullptr) && (strcmp(getenv("LDP_EAGER_PAIRS"), "1") == 0);
   const bool eager = (!e->matrix_mode) && (!e->band_r2_mode) && ((location == LDP_MEM_HOST) || eager_always);
+  static const uint32_t copy_threads = []() {
+    const char* c = getenv("LDP_DEBUG_COPY_THREADS");
+    return (c && atoi(c) > 0) ? static_cast<uint32_t>(atoi(c)) : 16u;
+  }();
+  static const uint64_t copy_task_bytes = []() {
+    const char* c = getenv("LDP_DEBUG_COPY_TASK_KB");
+    return (c && atoi(c) > 0) ? (static_cast<uint64_t>(atoi(c)) << 10) : (4ull << 20);
+  }();
   uint32_t slot = 0;
   uint32_t g = first_variant;
   const uint32_t gend = first_variant + n;
@@ -2386,9 +2394,9 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
         HIP_TRY(e, hipEventSynchronize(e->stage_done[slot]));  // slot free again?
         uint8_t* pin = e->h_stage[slot];
         const uint8_t* from = src + static_cast<uint64_t>(g + done - first_variant) * stride_bytes;
-        const uint32_t kRowsPerTask = std::max<uint32_t>(1, static_cast<uint32_t>((4ull << 20) / pack_stride));
+        const uint32_t kRowsPerTask = std::max<uint32_t>(1, static_cast<uint32_t>((copy_task_bytes) / pack_stride));
         const uint32_t tasks = (cnt + kRowsPerTask - 1) / kRowsPerTask;
-        parallel_for(tasks, 16, [&](uint32_t t) {
+        parallel_for(tasks, copy_threads, [&](uint32_t t) {
           const uint32_t r0 = t * kRowsPerTask;
           const uint32_t r1 = std::min(cnt, r0 + kRowsPerTask);
           if (stride_bytes == pack_stride) {

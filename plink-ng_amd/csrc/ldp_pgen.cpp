@@ -305,7 +305,7 @@ int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct
     return pfail(P, LDP_ERR_INVALID, std::string(path) + " is too small to be a PLINK genotype file.");
   }
   P->size = static_cast<uint64_t>(st.st_size);
-  void* m = mmap(nullptr, P->size, PROT_READ, MAP_PRIVATE, P->fd, 0);
+  void* m = mmap(nullptr, P->size, PROT_READ, MAP_PRIVATE | (getenv("LDP_DEBUG_MAP_POPULATE") ? MAP_POPULATE : 0), P->fd, 0);
   if (m == MAP_FAILED) {
     return pfail(P, LDP_ERR_NOMEM, std::string("Failed to map ") + path + ".");
   }

@@ -2937,8 +2937,10 @@ int run_prune(Session& S) {
       // ldp_pgen_read) while the engine takes the current one, two buffers alternating; small enough that the
       // buffers' first-touch page faults are paid once, large enough for ~60 decode tasks per chunk.
       const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((direct ? (1024ull << 20) : (256ull << 20)) / std::max<uint64_t>(in_rec, 1)));
+      // two buffers of one chunk each, malloc'ed (a vector would zero-fill them on this thread: 2 x 256 MiB of page faults and
+      // memset before the first record is decoded; this way the decoder's threads touch the pages first, in parallel) and
       // never freed: returning ~0.5 GiB of touched pages to the kernel costs tens of ms and the process exits soon
-      std::vector<uint8_t>* decoded = new std::vector<uint8_t>[2];
+      uint8_t* decoded[2] = {nullptr, nullptr};
       std::vector<uint8_t> gather;
       // the runs (maximal stretches of included variants that are contiguous in the file, capped at kChunk)
       struct Run {
@@ -2955,6 +2957,10 @@ int run_prune(Session& S) {
         q += run;
       }
       std::thread decoder;
+      // The decoder runs beside the engine's copy threads (ldp_load_genotypes: 16 of them feeding the pinned ring); a record
+      // takes microseconds, so a few dozen threads keep ahead of PCIe and more only get in the copies' way.
+      const uint32_t decode_threads = getenv("LDP_DEBUG_DECODE_THREADS") ? static_cast<uint32_t>(atoi(getenv("LDP_DEBUG_DECODE_THREADS"))) : 32;
+      double t_wait_decode = 0.0, t_load_calls = 0.0;
       int decode_rc = 0;
       uint32_t unphased_at = 0;
       uint32_t pending_unphased = UINT32_MAX;
@@ -2962,11 +2968,19 @@ int run_prune(Session& S) {
         if (direct || k >= runs.size()) {
           return;
         }
-        std::vector<uint8_t>& buf = decoded[k & 1];
-        buf.resize(static_cast<size_t>(runs[k].n) * in_rec);
+        if (!decoded[k & 1]) {
+          uint32_t longest = 0;
+          for (const Run& rn : runs) {
+            longest = std::max(longest, rn.n);
+          }
+          decoded[k & 1] = static_cast<uint8_t*>(malloc(static_cast<size_t>(longest) * in_rec + 64));
+          if (!decoded[k & 1]) {
+            die(8, "\nError: Out of memory.\n");
+          }
+        }
         decoder = std::thread([&, k]() {
-          decode_rc = A.pairphase ? ldp_pgen_read_phased(pg, runs[k].raw0, runs[k].n, decoded[k & 1].data(), in_rec, founder_mask.data(), 0, &unphased_at)
-                                  : ldp_pgen_read(pg, runs[k].raw0, runs[k].n, decoded[k & 1].data(), rec_bytes, 0);
+          decode_rc = A.pairphase ? ldp_pgen_read_phased(pg, runs[k].raw0, runs[k].n, decoded[k & 1], in_rec, founder_mask.data(), decode_threads, &unphased_at)
+                                  : ldp_pgen_read(pg, runs[k].raw0, runs[k].n, decoded[k & 1], rec_bytes, decode_threads);
         });
       };
       start_decode(0);
@@ -2979,7 +2993,9 @@ int run_prune(Session& S) {
         if (direct) {
           src = direct + static_cast<uint64_t>(raw0) * rec_bytes;
         } else {
+          const double tw0 = now_s();
           decoder.join();
+          t_wait_decode += now_s() - tw0;
           if (decode_rc == LDP_ERR_UNPHASED) {
             pending_unphased = unphased_at;  // reported below, unless a multiallelic variant before it is unphased too
             break;
@@ -2987,7 +3003,7 @@ int run_prune(Session& S) {
           if (decode_rc) {
             die(3, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
           }
-          src = decoded[k & 1].data();
+          src = decoded[k & 1];
           start_decode(k + 1);
         }
         if (!all_founders) {
@@ -3000,12 +3016,18 @@ int run_prune(Session& S) {
           src = gather.data();
           stride = out_rec;
         }
+        const double tl0 = now_s();
         for (int r = 0; r < world; ++r) {
           const int rc = ldp_load_genotypes(eng[r], q, run, src, stride, LDP_MEM_HOST, load_encoding);
           if (rc) {
             die(12, "Error: %s\n", ldp_last_error(eng[r]));
           }
         }
+        t_load_calls += now_s() - tl0;
+      }
+      if (A.timing && !direct) {
+        logprintf("\n[timing] variable-width records: %zu chunks, waited %.3f s for the decoder, %.3f s inside ldp_load_genotypes\n", runs.size(), t_wait_decode,
+                  t_load_calls);
       }
       // rows that need host treatment overwrite their bulk-loaded versions: variants with more than one ALT
       // allele (collapsed major-vs-rest) and MT variants (hets -> missing, plink2_ld.cc:1362-1364)
@@ -3247,7 +3269,9 @@ int run_prune(Session& S) {
   }
   logprintf("Variant lists written to %s.prune.in and %s.prune.out .\n", A.out.c_str(), A.out.c_str());
   if (A.timing) {
-    logprintf("[timing] total %.3f s\n", now_s() - t_begin);
+    // (wall-clock stamps: what a caller's stopwatch sees beyond `total` is process start-up before main() and teardown after _exit)
+    const double unix_now = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+    logprintf("[timing] total %.3f s (main() entered at unix time %.3f, leaving at %.3f)\n", now_s() - t_begin, unix_now - (now_s() - t_begin), unix_now);
   }
   if (g_log) {
     fclose(g_log);
