@@ -61,7 +61,10 @@ enum {
    * phased one, missing -> both missing); haplotype h in {0,1} is carried as the genotype code 2h, whose
    * pair statistics are exactly 4 x the reference's cov12 / variance1 / variance2 (ldp_kernels.hip), so the prune
    * decision is the same bit. */
-  LDP_GENO_PHASED = 4
+  LDP_GENO_PHASED = 4,
+  /* OR this into LDP_GENO_REF or LDP_GENO_BED: the rows hold the samples of the FILE (raw_sample_ct of
+     ldp_set_sample_map()) and the engine gathers its founder_ct columns from them on the device. */
+  LDP_GENO_MAPPED = 8
 };
 /* bytes of one LDP_GENO_PHASED row / offset of its phaseinfo bits, for hap_ct haplotypes (= the engine's founder_ct) */
 uint64_t ldp_phased_row_bytes(uint32_t hap_ct);
@@ -164,6 +167,15 @@ int ldp_get_band(const ldp_engine* e, uint32_t* lo, uint64_t* candidate_pairs);
  * Loading a variant again (a new pass over the data) simply starts over. */
 int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* geno, uint64_t stride_bytes,
                        int location, int encoding);
+/* Sample-mapped rows: the rows the reference assembles per variant on chrX, chrY and MT before LdPrune's pair loop
+ * (plink2_ld.cc:1356-1388: founder subset, SetHetMissing on the haploid samples, on chrX the males once and the non-males
+ * as two pseudo-samples -- DESIGN.md section 7), built on the device.  Column f of an engine row is sample src_sample[f] of
+ * the loaded row; with het_to_missing[f] != 0 a heterozygous call there becomes missing.  The allele counts that decide
+ * the major allele (and give maj_freq) are taken over the columns BEFORE that substitution, one allele pair per column,
+ * which is the reference's chrX / haploid frequency arithmetic (plink2_filter.cc:2137-2147 with the male / non-male
+ * weights of :2096-2112) when the non-male columns appear twice.  src_sample, het_to_missing: founder_ct entries each.
+ * Rows loaded with LDP_GENO_MAPPED are then raw_sample_ct samples wide (ceil(raw_sample_ct / 4) bytes). */
+int ldp_set_sample_map(ldp_engine* e, uint32_t raw_sample_ct, const uint32_t* src_sample, const uint8_t* het_to_missing);
 /* major-allele frequencies (GetAlleleFreq(..., maj_alleles[v]), plink2_ld.cc:915) for LDP_GENO_INVERSE
  * input; for REF/BED input the engine derives them itself and this call overrides them. */
 int ldp_set_maj_freqs(ldp_engine* e, uint32_t first_variant, uint32_t n, const double* maj_freqs);

@@ -25,6 +25,7 @@ CLI_PATH = os.path.join(BIN_DIR, "plink2-hip")
 LDP_OK, LDP_ERR_INVALID, LDP_ERR_NOMEM, LDP_ERR_GPU, LDP_ERR_STATE, LDP_ERR_UNSUPPORTED = range(6)
 LDP_GENO_INVERSE, LDP_GENO_REF, LDP_GENO_BED = 0, 1, 2
 LDP_GENO_PHASED = 4  # OR into INVERSE / REF: --indep-pairphase rows (include/ldprune_hip.h)
+LDP_GENO_MAPPED = 8  # OR into REF / BED: file-wide rows, columns gathered on the device (ldp_set_sample_map)
 LDP_ERR_UNPHASED = 6
 LDP_MEM_HOST, LDP_MEM_DEVICE = 0, 1
 
@@ -80,7 +81,7 @@ VARIANT_REC_DTYPE = np.dtype([("nm_ct", "<u4"), ("sum", "<i4"), ("ssq", "<u4"), 
 # Every symbol include/ldprune_hip.h declares (checked by tests/test_cabi_symbols.py).
 CABI_SYMBOLS = [
     "ldp_create", "ldp_destroy", "ldp_last_error", "ldp_device_count", "ldp_set_variants", "ldp_get_subcontigs",
-    "ldp_set_shard", "ldp_get_band", "ldp_load_genotypes", "ldp_set_maj_freqs", "ldp_set_preferred", "ldp_run",
+    "ldp_set_shard", "ldp_get_band", "ldp_load_genotypes", "ldp_set_sample_map", "ldp_set_maj_freqs", "ldp_set_preferred", "ldp_run",
     "ldp_run_with_stats", "ldp_pair_stats", "ldp_debug_set_variant_recs", "ldp_debug_replay_pairs", "ldp_debug_mfma_plan",
     "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
     "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_r2_unphased_hits", "ldp_r2_unphased_block", "ldp_r2_unphased_block_hits", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
@@ -160,6 +161,7 @@ def lib():
     L.ldp_get_band.argtypes = [vp, u32p, u64p]
     L.ldp_load_genotypes.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]
     L.ldp_set_maj_freqs.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, f64p]
+    L.ldp_set_sample_map.argtypes = [vp, ctypes.c_uint32, u32p, ctypes.POINTER(ctypes.c_uint8)]
     L.ldp_set_preferred.argtypes = [vp, u64p]
     L.ldp_run.argtypes = [vp, u64p]
     L.ldp_run_with_stats.argtypes = [vp, u64p, vp, ctypes.c_uint64]
@@ -485,6 +487,13 @@ class LdPruneEngine:
     def load_genotypes_device(self, first_variant, n, device_ptr, stride_bytes, encoding=LDP_GENO_INVERSE):
         self._ck(self._L.ldp_load_genotypes(self._h, first_variant, n, ctypes.c_void_p(device_ptr), stride_bytes,
                                             LDP_MEM_DEVICE, encoding))
+
+    def set_sample_map(self, raw_sample_ct, src_sample, het_to_missing=None):
+        """Column f of the engine's rows = sample src_sample[f] of rows loaded with LDP_GENO_MAPPED; het_to_missing[f] != 0
+        turns a het call there into a missing one (chrX males, chrY, MT)."""
+        src = np.ascontiguousarray(src_sample, dtype=np.uint32)
+        het = None if het_to_missing is None else np.ascontiguousarray(het_to_missing, dtype=np.uint8)
+        self._ck(self._L.ldp_set_sample_map(self._h, raw_sample_ct, _ptr(src, ctypes.c_uint32), None if het is None else _ptr(het, ctypes.c_uint8)))
 
     def set_maj_freqs(self, first_variant, freqs):
         freqs = np.ascontiguousarray(freqs, dtype=np.float64)

@@ -156,10 +156,15 @@ struct PrepareArgs {
   uint32_t checkpoint_chunk[kCheckpoints];
   uint32_t n_checkpoints;
   uint32_t* any_missing;         // set to 1 when a converted row has missing calls (may be nullptr)
+  const uint32_t* extra_het;     // per variant: het calls the sample map turned into missing ones (allele counts only); may be nullptr
   bool fix_cp_gen;               // redo cp_gen for rows with missing calls (cp_gen_fix_kernel)
 };
 
 hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream);
+// Sample-mapped rows (ldp_set_sample_map): out row v = 2-bit REF codes of columns map[f] & 0x7fffffff of in row v, hets of
+// columns with bit 31 set replaced by missing and counted into extra_het[v]; in rows are .pgen- or .bed-coded.
+hipError_t launch_gather_rows(const uint8_t* in, uint64_t in_stride, uint32_t n_variants, int in_is_bed, const uint32_t* map, uint32_t out_ct, uint8_t* out,
+                              uint64_t out_stride, uint32_t* extra_het, hipStream_t stream);
 // ev[0..3] (optional): recorded before/after the complete-data kernel and before/after the general kernel
 hipError_t launch_pair_tiles(const PairKernelArgs& a, uint32_t max_rows, hipStream_t stream, hipEvent_t* ev);
 hipError_t launch_pair_stats_ref(const uint32_t* planes, uint64_t row_dwords, uint32_t chunks, uint32_t plane_base_variant,

@@ -171,6 +171,14 @@ struct ldp_engine {
   uint8_t* d_stage[3] = {nullptr, nullptr, nullptr};
   hipEvent_t stage_done[3] = {nullptr, nullptr, nullptr};
   bool prep_pending = false;
+  // sample-mapped rows (ldp_set_sample_map): column f <- sample (map & 0x7fffffff), bit 31 = het becomes missing
+  std::vector<uint32_t> sample_map;
+  uint32_t map_raw_sample_ct = 0;
+  uint32_t* d_sample_map = nullptr;
+  uint8_t* d_gather = nullptr;      // gathered 2-bit rows of one conversion launch
+  size_t gather_bytes = 0;
+  uint32_t* d_extra_het = nullptr;  // per variant of that launch
+  size_t extra_het_cap = 0;
 
   ldp_counters ctr;
 
@@ -270,6 +278,14 @@ void free_device(ldp_engine* e) {
       e->stage_done[k] = nullptr;
     }
   }
+  (void)hipFree(e->d_sample_map);
+  (void)hipFree(e->d_gather);
+  (void)hipFree(e->d_extra_het);
+  e->d_sample_map = nullptr;
+  e->d_gather = nullptr;
+  e->d_extra_het = nullptr;
+  e->gather_bytes = 0;
+  e->extra_het_cap = 0;
   if (e->prep_ev0) {
     (void)hipEventDestroy(e->prep_ev0);
     (void)hipEventDestroy(e->prep_ev1);
@@ -2309,10 +2325,14 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
     return fail(e, LDP_ERR_STATE, "ldp_set_variants() first");
   }
   const bool phased = (encoding & LDP_GENO_PHASED) != 0;
-  const int base_encoding = encoding & ~LDP_GENO_PHASED;
+  const bool mapped = (encoding & LDP_GENO_MAPPED) != 0;
+  const int base_encoding = encoding & ~(LDP_GENO_PHASED | LDP_GENO_MAPPED);
   if ((base_encoding < LDP_GENO_INVERSE) || (base_encoding > LDP_GENO_BED) || (phased && (base_encoding == LDP_GENO_BED)) ||
       ((location != LDP_MEM_HOST) && (location != LDP_MEM_DEVICE))) {
     return fail(e, LDP_ERR_INVALID, "bad encoding/location");
+  }
+  if (mapped && (phased || (base_encoding == LDP_GENO_INVERSE) || e->sample_map.empty())) {
+    return fail(e, LDP_ERR_INVALID, "LDP_GENO_MAPPED needs ldp_set_sample_map() and LDP_GENO_REF or LDP_GENO_BED rows");
   }
   if (phased && (e->P.founder_ct & 1)) {
     return fail(e, LDP_ERR_INVALID, "LDP_GENO_PHASED rows need an even founder_ct (haplotype count = 2 x samples)");
@@ -2320,7 +2340,8 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
   if ((static_cast<uint64_t>(first_variant) + n > e->variant_ct) || (n && !geno)) {
     return fail(e, LDP_ERR_INVALID, "variant range out of bounds");
   }
-  const uint64_t row_bytes = phased ? ldp_phased_row_bytes(e->P.founder_ct) : ((static_cast<uint64_t>(e->P.founder_ct) + 3) / 4);
+  const uint64_t row_bytes = mapped ? ((static_cast<uint64_t>(e->map_raw_sample_ct) + 3) / 4)
+                                    : (phased ? ldp_phased_row_bytes(e->P.founder_ct) : ((static_cast<uint64_t>(e->P.founder_ct) + 3) / 4));
   if (stride_bytes < row_bytes) {
     return fail(e, LDP_ERR_INVALID, "stride smaller than a genotype row");
   }
@@ -2341,6 +2362,30 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
       return rc;
     }
     stage_rows = std::max<size_t>(1, kStageBytes / pack_stride);
+  }
+  const uint64_t gather_stride = ((static_cast<uint64_t>(e->P.founder_ct) + 3) / 4 + 3) & ~static_cast<uint64_t>(3);
+  size_t gather_rows = 0;
+  if (mapped) {
+    gather_rows = std::max<size_t>(1, std::max<size_t>(stage_rows, kStageBytes / gather_stride));
+    if (location == LDP_MEM_HOST) {
+      gather_rows = stage_rows;
+    }
+    if (e->gather_bytes < gather_rows * gather_stride) {
+      HIP_TRY(e, hipStreamSynchronize(e->stream));
+      (void)hipFree(e->d_gather);
+      e->d_gather = nullptr;
+      e->gather_bytes = 0;
+      HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_gather), gather_rows * gather_stride));
+      e->gather_bytes = gather_rows * gather_stride;
+    }
+    if (e->extra_het_cap < gather_rows) {
+      HIP_TRY(e, hipStreamSynchronize(e->stream));
+      (void)hipFree(e->d_extra_het);
+      e->d_extra_het = nullptr;
+      e->extra_het_cap = 0;
+      HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_extra_het), gather_rows * sizeof(uint32_t)));
+      e->extra_het_cap = gather_rows;
+    }
   }
   // loading a variant a second time since the last epoch began starts a new epoch (see begin_load_epoch)
   for (uint32_t q = first_variant; q < first_variant + n; ++q) {
@@ -2379,6 +2424,9 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
     uint32_t done = 0;
     while (done < run) {
       uint32_t cnt = run - done;
+      if (mapped) {
+        cnt = static_cast<uint32_t>(std::min<size_t>(cnt, gather_rows));  // (one gather buffer, reused in stream order)
+      }
       const uint32_t l0 = static_cast<uint32_t>(e->global_to_local[g + done]);
       // end the conversion launch where the next pair group becomes ready, so that group starts behind it
       if (eager && (e->next_group < e->groups.size())) {
@@ -2415,11 +2463,25 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
         d_src = src + static_cast<uint64_t>(g + done - first_variant) * stride_bytes;
       }
       PrepareArgs PA;
+      PA.extra_het = nullptr;
+      int prep_encoding = encoding;
+      if (mapped) {
+        // the engine's columns out of the file's rows: gather_rows_kernel, then the ordinary conversion on its output
+        const hipError_t grc = launch_gather_rows(d_src, d_stride, cnt, base_encoding == LDP_GENO_BED, e->d_sample_map, e->P.founder_ct, e->d_gather, gather_stride,
+                                                   e->d_extra_het, e->stream);
+        if (grc != hipSuccess) {
+          return hipfail(e, grc, "gather_rows_kernel launch");
+        }
+        d_src = e->d_gather;
+        d_stride = gather_stride;
+        prep_encoding = LDP_GENO_REF;
+        PA.extra_het = e->d_extra_het;
+      }
       PA.geno = d_src;
       PA.stride_bytes = d_stride;
       PA.n_variants = cnt;
       PA.founder_ct = e->P.founder_ct;
-      PA.encoding = encoding;
+      PA.encoding = prep_encoding;
       PA.planes = e->d_planes + static_cast<uint64_t>(l0) * e->row_dwords;
       PA.row_dwords = e->row_dwords;
       PA.chunks = e->chunks;
@@ -2471,6 +2533,35 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
   if (location == LDP_MEM_HOST) {
     HIP_TRY(e, hipStreamSynchronize(e->stream));  // the caller may reuse its buffer once we return
   }
+  return LDP_OK;
+}
+
+int ldp_set_sample_map(ldp_engine* e, uint32_t raw_sample_ct, const uint32_t* src_sample, const uint8_t* het_to_missing) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  if (!raw_sample_ct || !src_sample || (raw_sample_ct > 0x7fffffffu)) {
+    return fail(e, LDP_ERR_INVALID, "sample map: raw_sample_ct / src_sample");
+  }
+  bind_gpu(e);
+  if (!e->gpu_ok) {
+    return fail(e, LDP_ERR_GPU, "no usable HIP device");
+  }
+  HIP_TRY(e, hipSetDevice(e->device));
+  std::vector<uint32_t> m(e->P.founder_ct);
+  for (uint32_t f = 0; f < e->P.founder_ct; ++f) {
+    if (src_sample[f] >= raw_sample_ct) {
+      return fail(e, LDP_ERR_INVALID, "sample map: source sample out of range");
+    }
+    m[f] = src_sample[f] | ((het_to_missing && het_to_missing[f]) ? 0x80000000u : 0u);
+  }
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (!e->d_sample_map) {
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_sample_map), m.size() * sizeof(uint32_t)));
+  }
+  HIP_TRY(e, hipMemcpy(e->d_sample_map, m.data(), m.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  e->sample_map.swap(m);
+  e->map_raw_sample_ct = raw_sample_ct;
   return LDP_OK;
 }
 

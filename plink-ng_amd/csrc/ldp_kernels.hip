@@ -290,6 +290,8 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
     const uint32_t n0 = both_ct;
     const uint32_t n1 = r2h_ct - both_ct;
     const uint32_t n2 = hom_ct - both_ct;
+    // (sample-mapped rows: the het calls that were made missing still count as one allele each)
+    const uint32_t n1_alleles = n1 + (A.extra_het ? A.extra_het[v] : 0u);
     uint32_t alt_major = 0;
     ldp_variant_rec rec;
     rec.n_homref = 0;
@@ -299,8 +301,8 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
     if ((A.encoding & 3) != LDP_GENO_INVERSE) {
       // plink2_filter.cc:2137-2147: freq = ref * (1 / tot), 1/2 when nothing is observed;
       // major = REF iff freq >= 0.5 (plink2_common.h:559-567)
-      const uint64_t ref_ct = 2ull * n0 + n1;
-      const uint64_t alt_ct = 2ull * n2 + n1;
+      const uint64_t ref_ct = 2ull * n0 + n1_alleles;
+      const uint64_t alt_ct = 2ull * n2 + n1_alleles;
       const uint64_t tot = ref_ct + alt_ct;
       double ref_freq = 0.5;
       if (tot) {
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
       }
       alt_major = !(ref_freq >= 0.5);
       rec.n_homref = n0;
-      rec.n_het = n1;
+      rec.n_het = n1_alleles;
       rec.n_homalt = n2;
     }
     // after the (optional) 0<->2 inversion
@@ -458,6 +460,56 @@ __global__ __launch_bounds__(256) void cp_gen_fix_kernel(PrepareArgs A) {
       }
     }
   }
+}
+
+// Sample-mapped rows (ldp_set_sample_map): one block per variant gathers the engine's columns from the file's row.
+// The input row (<= a few hundred KB) is read through L2 by every thread of its block; the map is shared by all blocks.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restrict__ in, uint64_t in_stride, int in_is_bed, const uint32_t* __restrict__ map,
+                                                          uint32_t out_ct, uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ extra_het) {
+  __shared__ uint32_t red[4];
+  const uint32_t v = blockIdx.x;
+  const uint8_t* row = in + static_cast<uint64_t>(v) * in_stride;
+  uint32_t* orow = reinterpret_cast<uint32_t*>(out + static_cast<uint64_t>(v) * out_stride);
+  const uint32_t out_dwords = static_cast<uint32_t>(out_stride / 4);
+  uint32_t made_missing = 0;
+  for (uint32_t d = threadIdx.x; d < out_dwords; d += 256) {
+    uint32_t w = 0;
+#pragma unroll 4
+    for (uint32_t k = 0; k < 16; ++k) {
+      const uint32_t f = d * 16 + k;
+      if (f < out_ct) {
+        const uint32_t m = map[f];
+        const uint32_t src = m & 0x7fffffffu;
+        uint32_t c = (static_cast<uint32_t>(row[src >> 2]) >> (2 * (src & 3))) & 3u;
+        if (in_is_bed) {
+          c = (0x1eu >> (2 * c)) & 3u;  // .bed 0,1,2,3 -> .pgen 2,3,1,0 (pgenlib_read.cc:2157)
+        }
+        if ((m >> 31) && (c == 1)) {
+          c = 3;
+          ++made_missing;
+        }
+        w |= c << (2 * k);
+      }
+    }
+    orow[d] = w;
+  }
+  made_missing = wave_reduce_add(made_missing);
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = made_missing;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    extra_het[v] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+hipError_t launch_gather_rows(const uint8_t* in, uint64_t in_stride, uint32_t n_variants, int in_is_bed, const uint32_t* map, uint32_t out_ct, uint8_t* out,
+                              uint64_t out_stride, uint32_t* extra_het, hipStream_t stream) {
+  if (!n_variants) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(n_variants), dim3(256), 0, stream, in, in_stride, in_is_bed, map, out_ct, out, out_stride, extra_het);
+  return hipGetLastError();
 }
 
 hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream) {

@@ -3191,7 +3191,52 @@ int run_prune(Session& S) {
       std::vector<uint8_t> rows;
       std::vector<double> mfs;
       std::atomic<uint32_t> x_unphased(UINT32_MAX);
-      for (uint32_t w0 = 0; w0 < ks.size(); w0 += chunk) {
+      if (!x_phased) {
+        // The rows are built on the device (ldp_set_sample_map): the file's rows go up as they are, in runs of variants
+        // that are consecutive in the file, and a conversion-time gather picks the founders -- the haploid ones first, with
+        // their het calls made missing, then (chrX) the others twice.  The host used to do this per sample and variant.
+        std::vector<uint32_t> src_sample;
+        std::vector<uint8_t> het_missing;
+        src_sample.reserve(fct);
+        het_missing.reserve(fct);
+        for (uint32_t sidx : sp.part1) {
+          src_sample.push_back(sidx);
+          het_missing.push_back(1);
+        }
+        for (int rep = 0; rep < 2; ++rep) {
+          for (uint32_t sidx : sp.part2) {
+            src_sample.push_back(sidx);
+            het_missing.push_back(0);
+          }
+        }
+        if (ldp_set_sample_map(se, raw_sample_ct, src_sample.data(), het_missing.data())) {
+          die(12, "\nError: %s\n", ldp_last_error(se));
+        }
+        const uint32_t max_run = std::max<uint32_t>(1, static_cast<uint32_t>((256ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
+        std::vector<uint8_t> decoded;
+        for (uint32_t w0 = 0; w0 < ks.size();) {
+          const uint32_t raw0 = inc[ks[w0]];
+          uint32_t run = 1;
+          while ((w0 + run < ks.size()) && (inc[ks[w0 + run]] == raw0 + run) && (run < max_run)) {
+            ++run;
+          }
+          const uint8_t* rows_at = nullptr;
+          if (direct_rows) {
+            rows_at = direct_rows + static_cast<uint64_t>(raw0) * rec_bytes;
+          } else {
+            decoded.resize(static_cast<size_t>(run) * rec_bytes);
+            if (ldp_pgen_read(pg, raw0, run, decoded.data(), rec_bytes, 0)) {
+              die(3, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+            }
+            rows_at = decoded.data();
+          }
+          if (ldp_load_genotypes(se, w0, run, rows_at, rec_bytes, LDP_MEM_HOST, encoding | LDP_GENO_MAPPED)) {
+            die(12, "\nError: %s\n", ldp_last_error(se));
+          }
+          w0 += run;
+        }
+      }
+      for (uint32_t w0 = 0; x_phased && (w0 < ks.size()); w0 += chunk) {
         const uint32_t cnt = std::min<uint32_t>(chunk, static_cast<uint32_t>(ks.size()) - w0);
         rows.assign(static_cast<size_t>(cnt) * s_rec, 0);
         mfs.assign(cnt, 0.0);
