@@ -474,6 +474,41 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restr
   uint32_t made_missing = 0;
   for (uint32_t d = threadIdx.x; d < out_dwords; d += 256) {
     uint32_t w = 0;
+    // sixteen columns that are neighbours in the file too (a founder subset with few gaps, a block of one sex): one
+    // unaligned 32-bit window of the input row instead of sixteen byte loads
+    if (d * 16 + 15 < out_ct) {
+      const uint32_t m0 = map[d * 16], m15 = map[d * 16 + 15];
+      if (((m15 & 0x7fffffffu) - (m0 & 0x7fffffffu) == 15) && ((m0 >> 31) == (m15 >> 31))) {
+        bool run = true;
+#pragma unroll
+        for (uint32_t k = 1; k < 15; ++k) {
+          run = run && (map[d * 16 + k] == m0 + k);
+        }
+        if (run) {
+          const uint32_t src = m0 & 0x7fffffffu;
+          const uint8_t* at = row + (src >> 2);
+          // (the row is read bytewise: no alignment or over-read assumptions about the caller's stride)
+          uint64_t bits = 0;
+#pragma unroll
+          for (uint32_t b = 0; b < 5; ++b) {
+            bits |= static_cast<uint64_t>(at[(b < 4 || (src & 3)) ? b : 0]) << (8 * b);
+          }
+          w = static_cast<uint32_t>(bits >> (2 * (src & 3)));
+          if (in_is_bed) {
+            // .bed -> .pgen codes, sixteen at a time: 00 -> 10, 01 -> 11, 10 -> 01, 11 -> 00
+            const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
+            w = ((hi ^ 0x55555555u) << 1) | (lo ^ hi);
+          }
+          if (m0 >> 31) {
+            const uint32_t hets = (w & 0x55555555u) & ~((w >> 1) & 0x55555555u);
+            w |= hets * 3u;
+            made_missing += __popc(hets);
+          }
+          orow[d] = w;
+          continue;
+        }
+      }
+    }
 #pragma unroll 4
     for (uint32_t k = 0; k < 16; ++k) {
       const uint32_t f = d * 16 + k;

@@ -2184,7 +2184,6 @@ int run_r2(Session& S) {
   auto feed_rows = [&](ldp_engine* eng, const std::vector<uint32_t>& incl) {
     const uint32_t n_incl = static_cast<uint32_t>(incl.size());
     const bool all_founders = (founder_ct == raw_sample_ct);
-    const uint64_t out_rec = (static_cast<uint64_t>(founder_ct) + 3) / 4;
     std::vector<uint32_t> founder_idx;
     for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
       if (is_founder[sx]) {
@@ -2192,10 +2191,9 @@ int run_r2(Session& S) {
       }
     }
     const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((1024ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
-    std::vector<uint8_t> decoded, gather;
-    std::vector<uint8_t> founder_mask((static_cast<size_t>(raw_sample_ct) + 7) / 8, 0);
-    for (uint32_t sidx : founder_idx) {
-      founder_mask[sidx >> 3] |= static_cast<uint8_t>(1u << (sidx & 7));
+    std::vector<uint8_t> decoded;
+    if ((!all_founders) && ldp_set_sample_map(eng, raw_sample_ct, founder_idx.data(), nullptr)) {
+      die(12, "Error: %s\n", ldp_last_error(eng));
     }
     for (uint32_t k = 0; k < n_incl;) {
       // a run of included variants that are consecutive in the file (chromosome 0 is stripped in table mode)
@@ -2215,16 +2213,8 @@ int run_r2(Session& S) {
         }
         src = decoded.data();
       }
-      if (!all_founders) {
-        // the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185)
-        gather.resize(static_cast<size_t>(run) * out_rec);
-        if (ldp_subset_samples(src, rec_bytes, run, raw_sample_ct, founder_mask.data(), gather.data(), out_rec, 0, 0)) {
-          die(12, "Error: founder subsetting failed.\n");
-        }
-        src = gather.data();
-        stride = out_rec;
-      }
-      if (ldp_load_genotypes(eng, k, run, src, stride, LDP_MEM_HOST, encoding)) {
+      // (the founder columns, CopyNyparrNonemptySubset pgenlib_misc.cc:32,185, are picked on the device)
+      if (ldp_load_genotypes(eng, k, run, src, stride, LDP_MEM_HOST, encoding | (all_founders ? 0 : LDP_GENO_MAPPED))) {
         die(12, "Error: %s\n", ldp_last_error(eng));
       }
       k += run;
@@ -2886,9 +2876,8 @@ int run_prune(Session& S) {
                 t_parse, t_tables_done - t_begin, t_planned - t_begin, t_hip_init, t_joined - t_begin);
     }
 
-    // ---- genotype rows of the diploid (+MT) variants -> engines.  All-founder files go straight from the
-    // mapping; otherwise the founder columns are gathered on the host first (CopyNyparrNonemptySubset,
-    // pgenlib_misc.cc:32,185).
+    // ---- genotype rows of the diploid (+MT) variants -> engines, straight from the mapping (or the decoder's buffers);
+    // the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185) are picked on the device.
     const bool all_founders = (founder_ct == raw_sample_ct);
     // --indep-pairphase rows: 2-bit codes, padding to a dword, phaseinfo bits (LDP_GENO_PHASED, ldprune_hip.h)
     const uint64_t in_rec = A.pairphase ? ldp_phased_row_bytes(2 * raw_sample_ct) : rec_bytes;
@@ -2956,6 +2945,16 @@ int run_prune(Session& S) {
         runs.push_back({q, raw0, run});
         q += run;
       }
+      // Non-founders in the file: the engines pick the founder columns themselves while converting (ldp_set_sample_map), so the
+      // rows go up as the file has them.  (--indep-pairphase rows carry phase bits the gather does not move: host subset.)
+      const bool device_subset = (!all_founders) && !A.pairphase;
+      if (device_subset) {
+        for (int r = 0; r < world; ++r) {
+          if (ldp_set_sample_map(eng[r], raw_sample_ct, founder_idx.data(), nullptr)) {
+            die(12, "\nError: %s\n", ldp_last_error(eng[r]));
+          }
+        }
+      }
       std::thread decoder;
       // The decoder runs beside the engine's copy threads (ldp_load_genotypes: 16 of them feeding the pinned ring); a record
       // takes microseconds, so a few dozen threads keep ahead of PCIe and more only get in the copies' way.
@@ -3006,7 +3005,7 @@ int run_prune(Session& S) {
           src = decoded[k & 1];
           start_decode(k + 1);
         }
-        if (!all_founders) {
+        if ((!all_founders) && !device_subset) {
           // gather the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185)
           // (+ CopyBitarrSubset of phaseinfo under --indep-pairphase, plink2_ld.cc:2075), all host threads
           gather.resize(static_cast<size_t>(run) * out_rec);
@@ -3018,7 +3017,7 @@ int run_prune(Session& S) {
         }
         const double tl0 = now_s();
         for (int r = 0; r < world; ++r) {
-          const int rc = ldp_load_genotypes(eng[r], q, run, src, stride, LDP_MEM_HOST, load_encoding);
+          const int rc = ldp_load_genotypes(eng[r], q, run, src, stride, LDP_MEM_HOST, load_encoding | (device_subset ? LDP_GENO_MAPPED : 0));
           if (rc) {
             die(12, "Error: %s\n", ldp_last_error(eng[r]));
           }

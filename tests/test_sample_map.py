@@ -88,3 +88,36 @@ def test_mapped_rows_need_a_map(gpu_pkg):
     with pytest.raises(pkg.LdpError):
         e.set_sample_map(8, np.arange(10, dtype=np.uint32), None)  # sources beyond the file's samples
     e.close()
+
+
+@pytest.mark.parametrize("n_raw,keep,flag,enc", [(1000, 0.95, 0, "ref"), (1000, 0.9, 1, "bed"), (4099, 0.99, 0, "bed"), (4099, 1.0, 1, "ref"), (50, 0.8, 0, "ref")])
+def test_mapped_subset_with_long_runs(gpu_pkg, n_raw, keep, flag, enc):
+    """A founder subset with few gaps (or all samples, hets -> missing): the gather's sixteen-neighbours fast path, both
+    encodings, window offsets 0..3 within a byte."""
+    pkg = gpu_pkg
+    rng = np.random.default_rng(n_raw + flag)
+    m = 300
+    raw = T.synth_raw_codes(m, n_raw, seed=n_raw + 3, missing_rate=0.05)
+    raw[1] = 1
+    src = np.flatnonzero(rng.random(n_raw) < keep).astype(np.uint32)
+    het = np.full(len(src), flag, np.uint8)
+    chr_idx, bps = make_positions(m, 2, 9)
+    rows, mf, alt_major = host_rows(raw, src, het)
+    a = pkg.LdPruneEngine(len(src), 30, 1, False, 0.3, device=0)
+    a.set_variants(chr_idx, None)
+    a.load_genotypes_host(0, T.pack_2bit(rows), pkg.LDP_GENO_INVERSE)
+    a.set_maj_freqs(0, mf)
+    b = pkg.LdPruneEngine(len(src), 30, 1, False, 0.3, device=0)
+    b.set_variants(chr_idx, None)
+    b.set_sample_map(n_raw, src, het)
+    rec = (n_raw + 3) // 4
+    codes = raw if enc == "ref" else np.array([3, 2, 0, 1], dtype=np.uint8)[raw]
+    packed = np.ascontiguousarray(T.pack_2bit(codes).view(np.uint8).reshape(m, -1)[:, :rec])
+    b.load_genotypes_host(0, packed, (pkg.LDP_GENO_REF if enc == "ref" else pkg.LDP_GENO_BED) | pkg.LDP_GENO_MAPPED)
+    for v in range(m):
+        assert np.array_equal(a.planes(v)[0], b.planes(v)[0]), (v, "hom plane")
+        assert np.array_equal(a.planes(v)[1], b.planes(v)[1]), (v, "ref2het plane")
+    assert np.array_equal(b.maj_freqs(), mf)
+    assert np.array_equal(a.run(), b.run())
+    a.close()
+    b.close()
