@@ -393,6 +393,10 @@ struct Args {
   uint32_t ld_var_ct_radius = 0x7fffffff;  // --ld-window N: N - 1
   uint32_t ld_bp_radius = 0xffffffffu;     // --ld-window-kb; UINT32_MAX = not given (table default 1000 kb)
   double ld_min_r2 = 2.0;                  // --ld-window-r2 (after the reference's epsilon); 2.0 = not given
+  // --ld-snp / --ld-snps / --ld-snp-list (plink2.cc:7966-8003): the table's row variants.  ld_snps: (first, second) ID pairs,
+  // second empty for a single ID, otherwise the range first..second in file order
+  std::vector<std::pair<std::string, std::string>> ld_snps;
+  std::string ld_snp_list;
   // --clump (InitClump, plink2_ld.cc:62-78; parsing plink2.cc:4960-5120)
   bool have_clump = false;
   std::string clump_file;
@@ -641,6 +645,43 @@ Args parse_args(int argc, char** argv) {
       }
     } else if (f.compare(0, 7, "--clump") == 0) {
       die(9, "Error: %s is not supported by plink2-hip's --clump yet.\n", f.c_str());
+    } else if (f == "--ld-snp") {
+      need(i, 1, "--ld-snp");
+      if (!A.ld_snps.empty() || !A.ld_snp_list.empty()) {
+        die(5, "Error: --ld-snp cannot be used with --ld-snps or --ld-snp-list.\n");
+      }
+      A.ld_snps.emplace_back(argv[++i], "");
+    } else if (f == "--ld-snps") {  // ParseNameRanges, plink2_cmdline.cc:2247: comma-separated IDs and first-last ranges
+      if (!A.ld_snps.empty() || !A.ld_snp_list.empty()) {
+        die(5, "Error: --ld-snps cannot be used with --ld-snp or --ld-snp-list.\n");
+      }
+      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+        const std::string arg = argv[++i];
+        size_t p0 = 0;
+        while (p0 <= arg.size()) {
+          const size_t p1 = std::min(arg.find(',', p0), arg.size());
+          const std::string piece = arg.substr(p0, p1 - p0);
+          const size_t dash = piece.find('-');
+          if (piece.empty() || (dash == 0) || (dash + 1 == piece.size())) {
+            die(5, "Error: Invalid --ld-snps argument '%s'.\n", arg.c_str());
+          }
+          if (dash == std::string::npos) {
+            A.ld_snps.emplace_back(piece, "");
+          } else {
+            A.ld_snps.emplace_back(piece.substr(0, dash), piece.substr(dash + 1));
+          }
+          p0 = p1 + 1;
+        }
+      }
+      if (A.ld_snps.empty()) {
+        die(5, "Error: --ld-snps requires at least one value.\n");
+      }
+    } else if (f == "--ld-snp-list") {
+      need(i, 1, "--ld-snp-list");
+      if (!A.ld_snps.empty()) {
+        die(5, "Error: --ld-snp-list cannot be used with --ld-snp.\n");
+      }
+      A.ld_snp_list = argv[++i];
     } else if (f == "--ld-window") {  // plink2.cc:7908-7920
       need(i, 1, "--ld-window");
       const std::string v = argv[++i];
@@ -774,6 +815,23 @@ Args parse_args(int argc, char** argv) {
     die(5, "Error: run --indep-pairwise and --r2-unphased separately.\n");
   }
   const bool ld_window_given = (A.ld_var_ct_radius != 0x7fffffff) || (A.ld_bp_radius != 0xffffffffu);
+  const bool ld_snp_given = (!A.ld_snps.empty()) || (!A.ld_snp_list.empty());
+  if (ld_snp_given && (!A.have_r2 || A.have_clump)) {
+    die(5, "Error: --ld-window.../--ld-snp... must be used with --r[2]-[un]phased.\n");  // plink2.cc:12960
+  }
+  if (ld_snp_given && A.have_r2 && (!A.r2_table)) {  // plink2.cc:11186-11191
+    die(5, "Error: Matrix-only and table-only --r2-unphased settings cannot be used together.\n");
+  }
+  if (ld_snp_given && (A.ld_var_ct_radius != 0x7fffffff)) {
+    // With a variant-count window the reference's row windows are irregular: its second pass restarts each chromosome's window
+    // search at a position its first pass has already cleared, and FindNth1BitFrom (UpdateVcorWindow, plink2_ld.cc:10997-11001)
+    // then keeps one variant more on the leading side for the rows that follow (snp101,snp103 with --ld-window 3 pairs snp103
+    // with snp100).  Not reproduced.
+    die(9, "Error: --ld-window together with --ld-snp/--ld-snps/--ld-snp-list is not supported by plink2-hip (--ld-window-kb is).\n");
+  }
+  if (ld_snp_given && (A.parallel_tot != 1)) {
+    die(9, "Error: --parallel with --ld-snp/--ld-snps/--ld-snp-list is not supported by plink2-hip yet.\n");
+  }
   if ((ld_window_given || A.ld_min_r2 != 2.0) && !A.have_r2) {
     die(5, "Error: --ld-window.../--ld-snp... must be used with --r[2]-[un]phased.\n");  // plink2.cc:12960
   }
@@ -2398,7 +2456,76 @@ int run_r2(Session& S) {
       tf.write(kVcorHeader, sizeof(kVcorHeader) - 1);
     }
     const double thresh = A.ld_min_r2;
-    if (A.r2_inter || (thresh > 0.0)) {
+    // --ld-snp / --ld-snps / --ld-snp-list (VcorTable, plink2_ld.cc:11083-11150): the row variants.  A row variant is
+    // reported against every variant of its window, on both sides (UpdateVcorWindow :10984 with row_snp_subset), as the
+    // A of the line; a pair of two row variants appears once, lower index first (:10806-10815).
+    std::vector<uint8_t> is_row;
+    if ((!A.ld_snps.empty()) || (!A.ld_snp_list.empty())) {
+      if (thresh < 0.0) {
+        die(9, "Error: a negative --ld-window-r2 with --ld-snp/--ld-snps/--ld-snp-list is not supported by plink2-hip.\n");
+      }
+      is_row.assign(variant_ct, 0);
+      std::unordered_map<std::string, std::vector<uint32_t>> by_id;
+      by_id.reserve(static_cast<size_t>(variant_ct) * 2);
+      for (uint32_t k = 0; k < variant_ct; ++k) {
+        by_id[V.id[inc[k]]].push_back(k);
+      }
+      if (!A.ld_snp_list.empty()) {  // (TokenExtractExclude, plink2_filter.cc: unknown IDs are skipped, repeated dataset IDs are an error)
+        const std::string text = slurp(A.ld_snp_list);
+        std::vector<std::string> ids;
+        for (size_t p0 = 0; p0 < text.size();) {
+          while ((p0 < text.size()) && (static_cast<unsigned char>(text[p0]) <= ' ')) {
+            ++p0;
+          }
+          size_t p1 = p0;
+          while ((p1 < text.size()) && (static_cast<unsigned char>(text[p1]) > ' ')) {
+            ++p1;
+          }
+          if (p1 > p0) {
+            ids.emplace_back(text, p0, p1 - p0);
+          }
+          p0 = p1;
+        }
+        for (const std::string& id : ids) {
+          const auto it = by_id.find(id);
+          if (it == by_id.end()) {
+            continue;
+          }
+          if (it->second.size() > 1) {
+            die(3, "Error: Variant '%s' in --ld-snp-list file appears multiple times in dataset.\n", id.c_str());
+          }
+          is_row[it->second[0]] = 1;
+        }
+      }
+      for (const auto& pr : A.ld_snps) {  // (InterpretVariantRangeList, plink2_filter.cc:216-271)
+        const auto a = by_id.find(pr.first);
+        if (a == by_id.end()) {
+          die(7, "Error: --ld-snps variant '%s' not found.\n", pr.first.c_str());
+        }
+        if (pr.second.empty()) {
+          for (uint32_t k : a->second) {
+            is_row[k] = 1;
+          }
+          continue;
+        }
+        if (a->second.size() > 1) {
+          die(7, "Error: --ld-snps range-starting variant ID '%s' appears multiple times.\n", pr.first.c_str());
+        }
+        const auto b = by_id.find(pr.second);
+        if (b == by_id.end()) {
+          die(7, "Error: --ld-snps variant '%s' not found.\n", pr.second.c_str());
+        }
+        if (b->second.size() > 1) {
+          die(7, "Error: --ld-snps range-ending variant ID '%s' appears multiple times.\n", pr.second.c_str());
+        }
+        const uint32_t k0 = std::min(a->second[0], b->second[0]), k1 = std::max(a->second[0], b->second[0]);
+        for (uint32_t k = k0; k <= k1; ++k) {
+          is_row[k] = 1;
+        }
+      }
+    }
+    const bool row_subset = !is_row.empty();
+    if (A.r2_inter || (thresh > 0.0) || row_subset) {
       // ---- inter-chr: every pair A < B of the whole variant set, chromosome 0 included (plink2_ld.cc:11082-11116).
       // The r^2 values come row chunk by row chunk (second variant B) from the all-pairs plan; pairs that pass
       // --ld-window-r2 are kept as (A, B, r^2) and bucketed by A afterwards, which gives the file's A-major order.
@@ -2412,7 +2539,7 @@ int run_r2(Session& S) {
       const uint32_t nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
       // With a positive threshold the filter runs in the kernel's epilogue (ldp_r2_unphased_hits) and only the
       // passing pairs cross PCIe; a row chunk whose hits overflow the buffer is redone through the dense path below.
-      const bool device_filter = (thresh > 0.0);
+      const bool device_filter = (thresh > 0.0) || row_subset;  // (threshold 0: every defined r^2 passes, NaN does not, :10816)
       std::vector<ldp_r2_hit> dev_hits(device_filter ? (1u << 24) : 0);
       uint32_t big_rows = 65536;
       // (a shard owns the pairs whose FIRST variant lies in [shard_first, shard_end): second variants from shard_first + 1 on)
@@ -2479,6 +2606,19 @@ int run_r2(Session& S) {
           hits.insert(hits.end(), v.begin(), v.end());
         }
         r0 += rows;
+      }
+      if (row_subset) {
+        // the row variant becomes the A of each line; pairs without one drop out; lines run by (A, B)
+        size_t kept = 0;
+        for (const Hit& h : hits) {
+          if (is_row[h.i]) {
+            hits[kept++] = h;
+          } else if (is_row[h.j]) {
+            hits[kept++] = {h.j, h.i, h.r2};
+          }
+        }
+        hits.resize(kept);
+        std::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) { return (a.i != b.i) ? (a.i < b.i) : (a.j < b.j); });
       }
       // stable bucket by first variant (second variants arrive in increasing order)
       std::vector<uint64_t> start(static_cast<size_t>(variant_ct) + 1, 0);

@@ -393,3 +393,64 @@ def test_cli_table_parallel_pieces_match_reference(gpu_pkg, tmp_path, mods, extr
         assert a.returncode == 0, a.stdout[-800:]
         assert b.returncode == 0, b.stdout[-800:]
         assert open(str(tmp_path / ("ref.vcor.%d" % k)), "rb").read() == open(str(tmp_path / ("hip.vcor.%d" % k)), "rb").read(), (mods, extra, k)
+
+
+LD_SNP_CASES = [
+    ["--ld-snp", "snp200"],
+    ["--ld-snp", "snp200", "--ld-window-r2", "0", "--ld-window-kb", "3"],
+    ["--ld-snps", "snp100-snp140,snp7", "snp650", "--ld-window-r2", "0.05"],
+    ["--ld-snps", "snp140-snp100", "--ld-window-kb", "1.5", "--ld-window-r2", "0"],
+    ["--ld-snp-list", "rows.txt", "--ld-window-r2", "0.1"],
+    ["--ld-snp-list", "rows.txt", "--ld-window-kb", "2", "--ld-window-r2", "0"],
+    ["inter-chr", "--ld-snp-list", "rows.txt", "--ld-window-r2", "0.3"],
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", LD_SNP_CASES)
+def test_cli_vcor_row_variants_match_reference(gpu_pkg, tmp_path, extra):
+    """--ld-snp / --ld-snps / --ld-snp-list: the row variants lead their lines and see both sides of their windows."""
+    assert T.have_ref()
+    cli = gpu_pkg.build_cli()
+    m, n = 900, 160
+    raw = T.synth_raw_codes(m, n, seed=23, missing_rate=0.02)
+    raw[12] = 2
+    chroms = ["0"] * 4 + ["1"] * 500 + ["3"] * 1 + ["7"] * 395
+    rng = np.random.default_rng(9)
+    pos = np.concatenate([np.arange(4) + 1, np.sort(rng.integers(1, 60000, 500)), [5], np.sort(rng.integers(1, 2000000, 395))])
+    T.write_pgen_fixed(str(tmp_path / "d"), raw, chroms, pos)
+    with open(str(tmp_path / "rows.txt"), "w") as f:
+        f.write("snp2 snp30\nsnp31 nosuchid snp32\nsnp504\nsnp505 snp899 snp506\n")   # snp2 sits on chromosome 0
+    mods = [x for x in extra if not x.startswith("--") and x == "inter-chr"]
+    rest = [x for x in extra if x != "inter-chr"]
+    ref = T.run_ref(["--pfile", "d", "--r2-unphased"] + mods + rest + ["--out", "ref"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    got = subprocess.run([cli, "--pfile", "d", "--r2-unphased"] + mods + rest + ["--out", "hip"], cwd=str(tmp_path), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert got.returncode == 0, got.stdout
+    want = open(str(tmp_path / "ref.vcor")).read()
+    have = open(str(tmp_path / "hip.vcor")).read()
+    assert want.count("\n") >= 2
+    if want != have:
+        wl, hl = want.split("\n"), have.split("\n")
+        bad = [(a, b) for a, b in zip(wl, hl) if a != b]
+        raise AssertionError("%d vs %d lines, first difference %r" % (len(wl), len(hl), bad[:2]))
+
+
+def test_cli_ld_snp_flag_rules(tmp_path):
+    import __graft_entry__ as ge
+    cli = ge.load_package().build_cli()
+    raw = T.synth_raw_codes(60, 30, seed=2)
+    T.write_pgen_fixed(str(tmp_path / "d"), raw, ["1"] * 60, np.arange(60) * 10 + 1)
+    def run(args):
+        return subprocess.run([cli, "--pfile", "d"] + args, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    r = run(["--r2-unphased", "square", "--ld-snp", "snp3"])
+    assert r.returncode == 5 and "Matrix-only and table-only" in r.stdout
+    r = run(["--r2-unphased", "--ld-snp", "snp3", "--ld-snps", "snp4"])
+    assert r.returncode == 5 and "cannot be used with" in r.stdout
+    r = run(["--indep-pairwise", "50", "5", "0.2", "--ld-snp", "snp3"])
+    assert r.returncode == 5
+    r = run(["--r2-unphased", "--ld-snps", "snp3-"])
+    assert r.returncode == 5 and "Invalid --ld-snps" in r.stdout
+    r = run(["--r2-unphased", "--ld-snp", "snp3", "--ld-window", "5"])
+    assert r.returncode == 9
