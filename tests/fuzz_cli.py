@@ -2,7 +2,8 @@
 """Randomised end-to-end comparison on the GPU box: plink2-hip against the reference binary (oracle/_ref/plink2) on
 random small filesets -- .bed or fixed-width .pgen, chromosome 0 rows, non-founders, missing calls, kb / count windows,
 both scan orders -- for --indep-pairwise (.prune.in/.prune.out), --indep-pairphase on phased variable-width .pgen
-(autosomes, chrX/chrY/MT with random sexes, non-founders) and the --r2-unphased table (.vcor).  Files must be
+(autosomes, chrX/chrY/MT with random sexes, non-founders), the --r2-unphased table (.vcor, with --ld-snp / --ld-snps /
+--ld-snp-list row variants) and --clump (.clumps).  Files must be
 byte-identical.
     python tests/fuzz_cli.py [--cases 40] [--seed 1]"""
 import argparse
@@ -140,14 +141,41 @@ def one_case(cli, ref, rng, idx, tmp, execute=True, mode="all"):
     else:
         T.write_pgen_fixed(os.path.join(d, "d"), raw, names, pos)
         inp = ["--pfile", "d"]
-    if rng.random() < 0.6:
+    # some samples with parents in the file (non-founders): the engines pick the founder columns themselves
+    founders = n
+    if rng.random() < 0.4:
+        nonf = np.sort(rng.choice(np.arange(2, n), size=int(rng.integers(1, max(2, n // 5))), replace=False))
+        founders = n - len(nonf)
+        if use_bed:
+            lines = open(os.path.join(d, "d.fam")).read().splitlines()
+            for sidx in nonf:
+                t = lines[sidx].split()
+                t[2], t[3] = "s0", "s1"
+                lines[sidx] = " ".join(t)
+            open(os.path.join(d, "d.fam"), "w").write("\n".join(lines) + "\n")
+        else:
+            isnf = np.zeros(n, dtype=bool)
+            isnf[nonf] = True
+            with open(os.path.join(d, "d.psam"), "w") as f:
+                f.write("#IID\tPAT\tMAT\tSEX\n")
+                for sidx in range(n):
+                    f.write("s%d\t%s\t%s\t2\n" % (sidx, "s0" if isnf[sidx] else "0", "s1" if isnf[sidx] else "0"))
+    kind = rng.random()
+    if kind < 0.12:
+        # --clump on a random report (unknown IDs, repeated lines, odd p-value spellings come from tests/test_clump.py)
+        import test_clump as TC
+        TC.write_report(os.path.join(d, "assoc.txt"), m, int(rng.integers(1, 1 << 30)), sig_rate=float(rng.choice([0.02, 0.06, 0.2])))
+        args = inp + ["--clump", "assoc.txt", "--clump-unphased", "--clump-r2", str(rng.choice([0, 0.1, 0.5, 0.8])), "--clump-kb", str(rng.choice([1, 10, 250])),
+                      "--clump-p1", str(rng.choice(["1e-4", "1e-2", "0.3"])), "--clump-p2", str(rng.choice(["1e-2", "0.05", "1e-6"]))]
+        outs = [".clumps"]
+    elif kind < 0.6:
         if rng.random() < 0.5:
             win = ["%gkb" % float(rng.choice([0.5, 2, 7.5, 20]))]
         else:
             w = int(rng.integers(2, 120))
             win = [str(w), str(int(rng.integers(1, max(2, w))))]
         args = inp + ["--indep-pairwise"] + win + [str(rng.choice([0.1, 0.2, 0.3, 0.5, 0.8])), "--indep-order", str(int(rng.integers(1, 3)))]
-        if n < 50:
+        if founders < 50:
             args.append("--bad-ld")
         outs = [".prune.in", ".prune.out"]
     else:
@@ -157,6 +185,19 @@ def one_case(cli, ref, rng, idx, tmp, execute=True, mode="all"):
             args = inp + ["--r2-unphased", "--ld-window-kb", str(rng.choice([1, 5, 30])), "--ld-window-r2", str(rng.choice([0, 0.05, 0.2, 0.6]))]
             if rng.random() < 0.5:
                 args += ["--ld-window", str(int(rng.integers(2, 40)))]
+        if ("--ld-window" not in args) and (rng.random() < 0.35):
+            # row variants: a single ID, ranges, or a list file with an unknown ID in it
+            pick = sorted(int(x) for x in rng.choice(np.arange(n_zero, m), size=int(rng.integers(1, 6)), replace=False))
+            how = rng.random()
+            if how < 0.3:
+                args += ["--ld-snp", "snp%d" % pick[0]]
+            elif how < 0.65:
+                toks = ["snp%d" % v for v in pick[:-2]] + (["snp%d-snp%d" % (pick[-2], pick[-1])] if len(pick) >= 2 else ["snp%d" % pick[0]])
+                args += ["--ld-snps", ",".join(toks)]
+            else:
+                with open(os.path.join(d, "rows.txt"), "w") as f:
+                    f.write(" ".join("snp%d" % v for v in pick) + "\nnot_there\n")
+                args += ["--ld-snp-list", "rows.txt"]
         outs = [".vcor"]
     if not execute:
         return True, "case %d skipped" % idx
@@ -167,8 +208,11 @@ def one_case(cli, ref, rng, idx, tmp, execute=True, mode="all"):
     if r.returncode != 0:
         return True, "case %d: both refuse (%s)" % (idx, " ".join(args))
     for e in outs:
-        if not filecmp.cmp(os.path.join(d, "ref" + e), os.path.join(d, "hip" + e), shallow=False):
-            return False, "case %d: %s differs: %s (n=%d m=%d miss=%g %s)" % (idx, e, " ".join(args), n, m, miss, "bed" if use_bed else "pgen")
+        have_ref, have_hip = os.path.exists(os.path.join(d, "ref" + e)), os.path.exists(os.path.join(d, "hip" + e))
+        if (e == ".clumps") and (not have_ref) and (not have_hip):
+            continue  # (nothing significant: both skip the file)
+        if (have_ref != have_hip) or not filecmp.cmp(os.path.join(d, "ref" + e), os.path.join(d, "hip" + e), shallow=False):
+            return False, "case %d: %s differs: %s (n=%d m=%d miss=%g %s, %d founders)" % (idx, e, " ".join(args), n, m, miss, "bed" if use_bed else "pgen", founders)
     return True, "case %d ok: %s" % (idx, " ".join(args))
 
 
