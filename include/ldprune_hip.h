@@ -62,8 +62,9 @@ enum {
    * pair statistics are exactly 4 x the reference's cov12 / variance1 / variance2 (ldp_kernels.hip), so the prune
    * decision is the same bit. */
   LDP_GENO_PHASED = 4,
-  /* OR this into LDP_GENO_REF or LDP_GENO_BED: the rows hold the samples of the FILE (raw_sample_ct of
-     ldp_set_sample_map()) and the engine gathers its founder_ct columns from them on the device. */
+  /* OR this into LDP_GENO_REF, LDP_GENO_BED or LDP_GENO_INVERSE: the rows hold the samples of the FILE (raw_sample_ct
+     of ldp_set_sample_map()) and the engine gathers its founder_ct columns from them on the device.  With
+     LDP_GENO_INVERSE the caller has already counted against the major allele and supplies maj_freq as usual. */
   LDP_GENO_MAPPED = 8
 };
 /* bytes of one LDP_GENO_PHASED row / offset of its phaseinfo bits, for hap_ct haplotypes (= the engine's founder_ct) */

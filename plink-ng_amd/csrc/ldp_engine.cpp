@@ -2331,8 +2331,8 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
       ((location != LDP_MEM_HOST) && (location != LDP_MEM_DEVICE))) {
     return fail(e, LDP_ERR_INVALID, "bad encoding/location");
   }
-  if (mapped && (phased || (base_encoding == LDP_GENO_INVERSE) || e->sample_map.empty())) {
-    return fail(e, LDP_ERR_INVALID, "LDP_GENO_MAPPED needs ldp_set_sample_map() and LDP_GENO_REF or LDP_GENO_BED rows");
+  if (mapped && (phased || e->sample_map.empty())) {
+    return fail(e, LDP_ERR_INVALID, "LDP_GENO_MAPPED needs ldp_set_sample_map() and unphased rows");
   }
   if (phased && (e->P.founder_ct & 1)) {
     return fail(e, LDP_ERR_INVALID, "LDP_GENO_PHASED rows need an even founder_ct (haplotype count = 2 x samples)");
@@ -2474,8 +2474,12 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
         }
         d_src = e->d_gather;
         d_stride = gather_stride;
-        prep_encoding = LDP_GENO_REF;
-        PA.extra_het = e->d_extra_het;
+        if (base_encoding == LDP_GENO_INVERSE) {
+          prep_encoding = LDP_GENO_INVERSE;  // (the caller decided the major allele and supplies maj_freq: nothing to count)
+        } else {
+          prep_encoding = LDP_GENO_REF;
+          PA.extra_het = e->d_extra_het;
+        }
       }
       PA.geno = d_src;
       PA.stride_bytes = d_stride;

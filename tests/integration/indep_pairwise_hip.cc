@@ -8,11 +8,15 @@
 //
 // IndepPairwiseHip() follows the convention of the reference's existing GPU seam (2.0/cuda/plink2_matrix_cuda.h:24-104, failure
 // mapping plink2_matrix_calc.cc:9632-9635): plain C calls, int codes, kPglRetGpuFail + "Error: GPU operation failure." on
-// any device-side failure.  It keeps the reference's loader (PgrGetInv1 with the founder subset, plink2_ld.cc:1357) and its
-// major-allele frequencies (GetAlleleFreq, :915) and hands them to the engine as LDP_GENO_INVERSE rows; the engine returns
-// removed_variants_collapsed (:2555, :1424).  Chromosomes the engine's autosomal-diploid path does not cover (chrX, chrY,
-// MT, other haploid contigs: the sample-mapped rows of DESIGN.md section 7 are the caller's job) go to the reference's own
-// IndepPairwise(), as does everything when PLINK2_HIP_LDPRUNE=0 is set in the environment.
+// any device-side failure.  It keeps the reference's decoder (PgrGetInv1, plink2_ld.cc:1357,1363: counts of the non-major
+// allele) and its major-allele frequencies (GetAlleleFreq, :915) and hands the rows to the engines as they come out of the
+// file -- all samples, LDP_GENO_INVERSE | LDP_GENO_MAPPED -- with one sample map per chromosome class doing what the
+// reference's loader does on the host at :1357-1388: the founder subset for the diploid chromosomes; the same with
+// SetHetMissing for haploid ones (MT, ...); on chrX the male founders (hets missing) followed by the others, which the
+// engine sees twice (their 2x weight); on chrY the non-female founders, hets missing.  Each class runs
+// on an engine of its own (different column sets); the bits come back in include-order and are merged into
+// removed_variants_collapsed (:2555, :1424).  PLINK2_HIP_LDPRUNE=0 in the environment sends everything to the reference's
+// own IndepPairwise().
 #include "plink2_ld.h"
 
 #include <stdlib.h>
@@ -51,136 +55,193 @@ PglErr IndepPairwiseHip(const uintptr_t* variant_include, const ChrInfo* cip, co
   const uint32_t raw_variant_ct = cip->chr_fo_vidx_start[cip->chr_ct];
   const uint32_t raw_variant_ctl = BitCtToWordCt(raw_variant_ct);
   const uint32_t variant_ct = PopcountWords(variant_include, raw_variant_ctl);
+  const uint32_t founder_nonmale_ct = founder_ct - founder_male_ct;
   // ---- who runs it ----
   const char* off = getenv("PLINK2_HIP_LDPRUNE");
-  bool use_hip = !(off && (!strcmp(off, "0"))) && (ldp_device_count() > 0) && variant_ct;
-  if (use_hip) {
-    // any included variant on a haploid / sex chromosome -> the reference's own path (whole job: the result bitmap is one)
-    for (uint32_t chr_fo_idx = 0; chr_fo_idx != cip->chr_ct; ++chr_fo_idx) {
-      const uint32_t vstart = cip->chr_fo_vidx_start[chr_fo_idx];
-      const uint32_t vend = cip->chr_fo_vidx_start[chr_fo_idx + 1];
-      if ((vstart != vend) && PopcountBitRange(variant_include, vstart, vend) && IsSet(cip->haploid_mask, cip->chr_file_order[chr_fo_idx])) {
-        use_hip = false;
-        break;
-      }
-    }
-  }
+  const bool use_hip = !(off && (!strcmp(off, "0"))) && (ldp_device_count() > 0) && variant_ct;
   if (!use_hip) {
     return IndepPairwise(variant_include, cip, variant_bps, allele_idx_offsets, maj_alleles, allele_freqs, founder_info, founder_info_cumulative_popcounts, founder_nonmale, founder_male, founder_nonfemale, ldip, preferred_variants, subcontig_info, subcontig_thread_assignments, raw_sample_ct, founder_ct, founder_male_ct, founder_nonfemale_ct, subcontig_ct, window_max, calc_thread_ct, max_load, simple_pgrp, removed_variants_collapsed);
   }
 
-  ldp_params p;
-  memset(&p, 0, sizeof(p));
-  p.founder_ct = founder_ct;
-  p.prune_window_size = ldip->prune_window_size;
-  p.prune_window_incr = ldip->prune_window_incr;
-  p.window_is_bp = (ldip->prune_flags / kfLdPruneWindowBp) & 1;
-  p.plink1_order = (ldip->prune_flags / kfLdPrunePlink1Order) & 1;
-  p.prune_last_param = ldip->prune_last_param;  // (the engine applies *(1 + kSmallEpsilon) itself, cf. plink2_ld.cc:1255)
-  p.device = -1;
-  p.stream = nullptr;
-  ldp_engine* eng = nullptr;
-  int rc = ldp_create(&p, &eng);
-  if (rc) {
-    return MapLdpError(rc, nullptr);
+  // ---- the variant table in include-order, and each variant's chromosome class (plink2_ld.cc:1325-1334) ----
+  enum { kDiploid = 0, kHaploid = 1, kChrX = 2, kChrY = 3, kClassCt = 4 };
+  const uint32_t all_haploid = IsSet(cip->haploid_mask, 0);  // :1258
+  const uint32_t x_code = cip->xymt_codes[kChrOffsetX];
+  const uint32_t y_code = cip->xymt_codes[kChrOffsetY];
+  std::vector<uint32_t> chr_fo(variant_ct), bps(variant_ct), uidxs(variant_ct);
+  std::vector<uint32_t> members[kClassCt];  // include-order indices
+  {
+    uintptr_t variant_uidx_base = 0;
+    uintptr_t cur_bits = variant_include[0];
+    uint32_t chr_fo_idx = 0;
+    uint32_t chr_end = cip->chr_fo_vidx_start[1];
+    for (uint32_t variant_idx = 0; variant_idx != variant_ct; ++variant_idx) {
+      const uint32_t variant_uidx = BitIter1(variant_include, &variant_uidx_base, &cur_bits);
+      while (variant_uidx >= chr_end) {
+        ++chr_fo_idx;
+        chr_end = cip->chr_fo_vidx_start[chr_fo_idx + 1];
+      }
+      uidxs[variant_idx] = variant_uidx;
+      chr_fo[variant_idx] = chr_fo_idx;
+      bps[variant_idx] = variant_bps? variant_bps[variant_uidx] : 0;
+      const uint32_t chr_idx = cip->chr_file_order[chr_fo_idx];
+      const uint32_t is_x = (chr_idx == x_code);
+      const uint32_t is_y = (chr_idx == y_code);
+      uint32_t cls = kDiploid;
+      if (is_x && founder_nonmale_ct) {
+        cls = kChrX;
+      } else if (is_x || is_y) {
+        cls = kChrY;  // (chrX without a single non-male founder takes the chrY branch, :1332,1379-1384)
+      } else if (IsSet(cip->haploid_mask, chr_idx)) {
+        cls = kHaploid;
+      }
+      members[cls].push_back(variant_idx);
+    }
   }
-  PglErr reterr = kPglRetSuccess;
-  logprintf("--indep-pairwise (HIP, %d device%s visible): ", ldp_device_count(), (ldp_device_count() == 1)? "" : "s");
-  fflush(stdout);
-  do {
-    // 1. the variant table in include-order: chromosome file-order index and position (what LdPruneSubcontigSplitAll reads)
-    std::vector<uint32_t> chr_fo(variant_ct), bps(variant_ct), uidxs(variant_ct);
-    {
-      uintptr_t variant_uidx_base = 0;
-      uintptr_t cur_bits = variant_include[0];
-      uint32_t chr_fo_idx = 0;
-      uint32_t chr_end = cip->chr_fo_vidx_start[1];
-      for (uint32_t variant_idx = 0; variant_idx != variant_ct; ++variant_idx) {
-        const uint32_t variant_uidx = BitIter1(variant_include, &variant_uidx_base, &cur_bits);
-        while (variant_uidx >= chr_end) {
-          ++chr_fo_idx;
-          chr_end = cip->chr_fo_vidx_start[chr_fo_idx + 1];
-        }
-        uidxs[variant_idx] = variant_uidx;
-        chr_fo[variant_idx] = chr_fo_idx;
-        bps[variant_idx] = variant_bps? variant_bps[variant_uidx] : 0;
+  // column lists: sample indices of the file, bit 31 = a het call becomes missing (SetHetMissing)
+  auto columns_of = [&](const uintptr_t* sample_set, uint32_t het_missing, std::vector<uint32_t>* src, std::vector<unsigned char>* het) {
+    for (uint32_t sample_idx = 0; sample_idx != raw_sample_ct; ++sample_idx) {
+      if (IsSet(sample_set, sample_idx)) {
+        src->push_back(sample_idx);
+        het->push_back(het_missing);
       }
     }
-    rc = ldp_set_variants(eng, variant_ct, chr_fo.data(), (p.window_is_bp && variant_bps)? bps.data() : nullptr);
+  };
+  const uint32_t removed_wordct = BitCtToWordCt(variant_ct);
+  ZeroWArr(removed_wordct, removed_variants_collapsed);
+  logprintf("--indep-pairwise (HIP, %d device%s visible): ", ldp_device_count(), (ldp_device_count() == 1)? "" : "s");
+  fflush(stdout);
+  PglErr reterr = kPglRetSuccess;
+  PgrSampleSubsetIndex pssi;
+  PgrClearSampleSubsetIndex(simple_pgrp, &pssi);  // rows of ALL samples: the engines pick their columns
+  const uintptr_t row_bytes = NypCtToVecCt(raw_sample_ct) * kBytesPerVec;  // PgrGetInv1 writes whole vectors
+  const uint32_t batch = 1 + (256 * 1048576 / row_bytes);
+  unsigned char* rows;
+  if (cachealigned_malloc(batch * row_bytes, &rows)) {
+    return kPglRetNomem;
+  }
+  std::vector<double> maj_freqs(batch);
+  for (uint32_t cls = 0; (cls != kClassCt) && (!reterr); ++cls) {
+    const std::vector<uint32_t>& mem = members[cls];
+    const uint32_t cls_variant_ct = mem.size();
+    if (!cls_variant_ct) {
+      continue;
+    }
+    std::vector<uint32_t> src;
+    std::vector<unsigned char> het;
+    if (cls == kDiploid) {
+      columns_of(founder_info, 0, &src, &het);
+    } else if (cls == kHaploid) {
+      columns_of(founder_info, 1, &src, &het);
+    } else if (cls == kChrX) {
+      columns_of(founder_male, 1, &src, &het);
+      for (uint32_t rep = 0; rep != 2; ++rep) {
+        columns_of(founder_nonmale, all_haploid, &src, &het);
+      }
+    } else {
+      columns_of(founder_nonfemale, 1, &src, &het);
+    }
+    if (src.size() < 2) {
+      continue;  // (nothing to correlate: the reference's loop leaves these variants alone as well)
+    }
+    ldp_params p;
+    memset(&p, 0, sizeof(p));
+    p.founder_ct = src.size();
+    p.prune_window_size = ldip->prune_window_size;
+    p.prune_window_incr = ldip->prune_window_incr;
+    p.window_is_bp = (ldip->prune_flags / kfLdPruneWindowBp) & 1;
+    p.plink1_order = (ldip->prune_flags / kfLdPrunePlink1Order) & 1;
+    p.prune_last_param = ldip->prune_last_param;  // (the engine applies *(1 + kSmallEpsilon) itself, cf. plink2_ld.cc:1255)
+    p.device = -1;
+    p.stream = nullptr;
+    ldp_engine* eng = nullptr;
+    int rc = ldp_create(&p, &eng);
     if (rc) {
-      reterr = MapLdpError(rc, eng);
+      reterr = MapLdpError(rc, nullptr);
       break;
     }
-    // 2. genotypes: the reference's own decode (PgrGetInv1 on the founder subset: 2-bit counts of the non-major allele),
-    //    a batch of rows at a time, with the frequencies the scan compares (GetAlleleFreq of the major allele)
-    PgrSampleSubsetIndex pssi;
-    PgrSetSampleSubsetIndex(founder_info_cumulative_popcounts, simple_pgrp, &pssi);
-    const uintptr_t row_bytes = NypCtToVecCt(founder_ct) * kBytesPerVec;  // PgrGetInv1 writes whole vectors
-    const uint32_t batch = 1 + (256 * 1048576 / row_bytes);
-    unsigned char* rows;
-    if (cachealigned_malloc(batch * row_bytes, &rows)) {
-      reterr = kPglRetNomem;
-      break;
-    }
-    std::vector<double> maj_freqs(batch);
-    uint32_t cur_allele_ct = 2;
-    for (uint32_t batch_start = 0; (batch_start < variant_ct) && (!reterr); batch_start += batch) {
-      const uint32_t n = (variant_ct - batch_start < batch)? (variant_ct - batch_start) : batch;
-      for (uint32_t k = 0; k != n; ++k) {
-        const uint32_t variant_uidx = uidxs[batch_start + k];
-        reterr = PgrGetInv1(founder_info, pssi, founder_ct, variant_uidx, maj_alleles[variant_uidx], simple_pgrp, R_CAST(uintptr_t*, &(rows[k * row_bytes])));
-        if (unlikely(reterr)) {
-          PgenErrPrintNV(reterr, variant_uidx);
+    do {
+      std::vector<uint32_t> cls_chr(cls_variant_ct), cls_bps(cls_variant_ct);
+      for (uint32_t k = 0; k != cls_variant_ct; ++k) {
+        cls_chr[k] = chr_fo[mem[k]];
+        cls_bps[k] = bps[mem[k]];
+      }
+      rc = ldp_set_variants(eng, cls_variant_ct, cls_chr.data(), (p.window_is_bp && variant_bps)? cls_bps.data() : nullptr);
+      if (!rc) {
+        rc = ldp_set_sample_map(eng, raw_sample_ct, src.data(), het.data());
+      }
+      if (rc) {
+        reterr = MapLdpError(rc, eng);
+        break;
+      }
+      // genotypes: the reference's own decode, a batch of rows at a time, with the frequencies the scan compares
+      uint32_t cur_allele_ct = 2;
+      for (uint32_t batch_start = 0; (batch_start < cls_variant_ct) && (!reterr); batch_start += batch) {
+        const uint32_t n = (cls_variant_ct - batch_start < batch)? (cls_variant_ct - batch_start) : batch;
+        for (uint32_t k = 0; k != n; ++k) {
+          const uint32_t variant_uidx = uidxs[mem[batch_start + k]];
+          reterr = PgrGetInv1(nullptr, pssi, raw_sample_ct, variant_uidx, maj_alleles[variant_uidx], simple_pgrp, R_CAST(uintptr_t*, &(rows[k * row_bytes])));
+          if (unlikely(reterr)) {
+            PgenErrPrintNV(reterr, variant_uidx);
+            break;
+          }
+          uintptr_t allele_idx_base;
+          if (!allele_idx_offsets) {
+            allele_idx_base = variant_uidx;
+          } else {
+            allele_idx_base = allele_idx_offsets[variant_uidx];
+            cur_allele_ct = allele_idx_offsets[variant_uidx + 1] - allele_idx_base;
+            allele_idx_base -= variant_uidx;
+          }
+          maj_freqs[k] = GetAlleleFreq(&(allele_freqs[allele_idx_base]), maj_alleles[variant_uidx], cur_allele_ct);
+        }
+        if (reterr) {
           break;
         }
-        uintptr_t allele_idx_base;
-        if (!allele_idx_offsets) {
-          allele_idx_base = variant_uidx;
-        } else {
-          allele_idx_base = allele_idx_offsets[variant_uidx];
-          cur_allele_ct = allele_idx_offsets[variant_uidx + 1] - allele_idx_base;
-          allele_idx_base -= variant_uidx;
+        rc = ldp_load_genotypes(eng, batch_start, n, rows, row_bytes, LDP_MEM_HOST, LDP_GENO_INVERSE | LDP_GENO_MAPPED);
+        if (!rc) {
+          rc = ldp_set_maj_freqs(eng, batch_start, n, maj_freqs.data());
         }
-        maj_freqs[k] = GetAlleleFreq(&(allele_freqs[allele_idx_base]), maj_alleles[variant_uidx], cur_allele_ct);
+        if (rc) {
+          reterr = MapLdpError(rc, eng);
+        }
       }
       if (reterr) {
         break;
       }
-      rc = ldp_load_genotypes(eng, batch_start, n, rows, row_bytes, LDP_MEM_HOST, LDP_GENO_INVERSE);
-      if (!rc) {
-        rc = ldp_set_maj_freqs(eng, batch_start, n, maj_freqs.data());
-      }
-      if (rc) {
-        reterr = MapLdpError(rc, eng);
-      }
-    }
-    aligned_free(rows);
-    if (reterr) {
-      break;
-    }
-    // 3. --indep-preferred: raw-index bitmap -> include-order bitmap
-    if (preferred_variants) {
-      std::vector<uint64_t> pref((variant_ct + 63) / 64, 0);
-      for (uint32_t variant_idx = 0; variant_idx != variant_ct; ++variant_idx) {
-        if (IsSet(preferred_variants, uidxs[variant_idx])) {
-          pref[variant_idx / 64] |= 1ULL << (variant_idx % 64);
+      // --indep-preferred: raw-index bitmap -> this engine's bitmap
+      if (preferred_variants) {
+        std::vector<uint64_t> pref((cls_variant_ct + 63) / 64, 0);
+        for (uint32_t k = 0; k != cls_variant_ct; ++k) {
+          if (IsSet(preferred_variants, uidxs[mem[k]])) {
+            pref[k / 64] |= 1ULL << (k % 64);
+          }
+        }
+        rc = ldp_set_preferred(eng, pref.data());
+        if (rc) {
+          reterr = MapLdpError(rc, eng);
+          break;
         }
       }
-      rc = ldp_set_preferred(eng, pref.data());
+      // bit k set <=> the class's k-th variant is removed: into the include-order bitmap
+      std::vector<uint64_t> removed((cls_variant_ct + 63) / 64 + 1, 0);
+      rc = ldp_run(eng, removed.data());
       if (rc) {
         reterr = MapLdpError(rc, eng);
         break;
       }
-    }
-    // 4. bit i set <=> i-th included variant removed
-    rc = ldp_run(eng, R_CAST(uint64_t*, removed_variants_collapsed));
-    if (rc) {
-      reterr = MapLdpError(rc, eng);
-      break;
-    }
+      for (uint32_t k = 0; k != cls_variant_ct; ++k) {
+        if ((removed[k / 64] >> (k % 64)) & 1) {
+          SetBit(mem[k], removed_variants_collapsed);
+        }
+      }
+    } while (0);
+    ldp_destroy(eng);
+  }
+  aligned_free(rows);
+  if (!reterr) {
     fputs("done.\n", stdout);
-  } while (0);
-  ldp_destroy(eng);
+  }
   return reterr;
 }
 

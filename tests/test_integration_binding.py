@@ -62,21 +62,41 @@ def test_reference_ldprune_through_the_c_abi_matches_stock_reference(gpu_pkg, tm
 
 
 @pytest.mark.gpu
-def test_sex_chromosomes_fall_back_to_the_reference_path(gpu_pkg, tmp_path):
-    """chrX in the include set: the binding leaves the whole job to IndepPairwise() (its sample-mapped rows are a caller's
-    job); PLINK2_HIP_LDPRUNE=0 does the same for any input."""
+@pytest.mark.parametrize("fmt,wargs,unknown,all_male", [("pfile", ["40kb", "0.3"], True, False), ("bfile", ["70", "9", "0.2"], True, False),
+                                                         ("pfile", ["100", "1", "0.4", "--indep-order", "1"], False, False), ("bfile", ["30kb", "0.3"], False, True)])
+def test_sex_chromosomes_through_the_c_abi(gpu_pkg, tmp_path, fmt, wargs, unknown, all_male):
+    """chrX / chrY / MT in the include set: the binding loads PgrGetInv1 rows of all samples and lets one sample map per
+    chromosome class do the reference loader's founder / sex subsetting and SetHetMissing (plink2_ld.cc:1357-1388) on the
+    device.  Male, female and unknown-sex samples, non-founders; also a file without a single non-male founder (chrX then
+    takes the reference's chrY branch)."""
+    from test_cli import sexed_fileset
+    prefix = sexed_fileset(tmp_path, m=900, n=140, seed=5 + len(wargs), nonfounders=6, unknown_sex=unknown)
+    if all_male:
+        if fmt == "bfile":
+            lines = [l.split() for l in open(prefix + ".fam").read().splitlines()]
+            for t in lines:
+                t[4] = "1"
+            open(prefix + ".fam", "w").write("\n".join(" ".join(t) for t in lines) + "\n")
+        else:
+            pytest.skip("all-male variant runs on the .fam fileset")
+    args = ["--" + fmt, "sx", "--indep-pairwise"] + wargs
+    a = run(STOCK, args, str(tmp_path), "stock")
+    b = run(PATCHED, args, str(tmp_path), "hipld")
+    assert a.returncode == 0, a.stdout[-1500:]
+    assert b.returncode == 0, b.stdout[-1500:]
+    assert "--indep-pairwise (HIP" in b.stdout
+    for ext in (".prune.in", ".prune.out"):
+        assert open(str(tmp_path / ("stock" + ext)), "rb").read() == open(str(tmp_path / ("hipld" + ext)), "rb").read(), ext
+    removed = open(str(tmp_path / "stock.prune.out")).read().split()
+    assert len(removed) > 20
+
+
+@pytest.mark.gpu
+def test_environment_switch_sends_the_job_to_the_reference_path(gpu_pkg, tmp_path):
     m, n = 300, 80
     raw = T.synth_raw_codes(m, n, 5, missing_rate=0.02)
-    chroms = ["1"] * 150 + ["X"] * 150
-    bps = np.concatenate([1000 + 200 * np.arange(150), 1000 + 200 * np.arange(150)]).astype(np.uint32)
-    T.write_bed(str(tmp_path / "d"), raw, chroms, bps)
-    a = run(STOCK, ["--bfile", "d", "--indep-pairwise", "20kb", "0.3"], str(tmp_path), "stock")
-    b = run(PATCHED, ["--bfile", "d", "--indep-pairwise", "20kb", "0.3"], str(tmp_path), "hipld")
-    assert a.returncode == 0 and b.returncode == 0, b.stdout[-1000:]
-    assert "--indep-pairwise (HIP" not in b.stdout
-    for ext in (".prune.in", ".prune.out"):
-        assert open(str(tmp_path / ("stock" + ext)), "rb").read() == open(str(tmp_path / ("hipld" + ext)), "rb").read()
+    T.write_bed(str(tmp_path / "d"), raw, ["1"] * m, (1000 + 200 * np.arange(m)).astype(np.uint32))
     env = dict(os.environ, PLINK2_HIP_LDPRUNE="0")
-    c = subprocess.run([PATCHED, "--bfile", "d", "--chr", "1", "--indep-pairwise", "20kb", "0.3", "--out", "off"], cwd=str(tmp_path), env=env,
+    c = subprocess.run([PATCHED, "--bfile", "d", "--indep-pairwise", "20kb", "0.3", "--out", "off"], cwd=str(tmp_path), env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert c.returncode == 0 and "--indep-pairwise (HIP" not in c.stdout

@@ -121,3 +121,35 @@ def test_mapped_subset_with_long_runs(gpu_pkg, n_raw, keep, flag, enc):
     assert np.array_equal(a.run(), b.run())
     a.close()
     b.close()
+
+
+def test_mapped_inverse_rows(gpu_pkg):
+    """LDP_GENO_INVERSE | LDP_GENO_MAPPED: what the reference-side binding loads (PgrGetInv1 rows of all samples)."""
+    pkg = gpu_pkg
+    n_raw, m = 301, 400
+    rng = np.random.default_rng(5)
+    inv_all = T.synth_raw_codes(m, n_raw, seed=77, missing_rate=0.05)   # read as counts of the non-major allele
+    males = np.sort(rng.choice(n_raw, size=120, replace=False))
+    others = np.setdiff1d(np.arange(n_raw), males)[:150]
+    src = np.concatenate([males, others, others]).astype(np.uint32)
+    het = np.concatenate([np.ones(len(males), np.uint8), np.zeros(2 * len(others), np.uint8)])
+    cols = inv_all[:, src].copy()
+    cols[(cols == 1) & (het[None, :] != 0)] = 3
+    mf = 0.5 + 0.5 * rng.random(m)
+    chr_idx, _ = make_positions(m, 2, 3)
+    a = pkg.LdPruneEngine(len(src), 25, 1, False, 0.2, device=0)
+    a.set_variants(chr_idx, None)
+    a.load_genotypes_host(0, T.pack_2bit(cols), pkg.LDP_GENO_INVERSE)
+    a.set_maj_freqs(0, mf)
+    b = pkg.LdPruneEngine(len(src), 25, 1, False, 0.2, device=0)
+    b.set_variants(chr_idx, None)
+    b.set_sample_map(n_raw, src, het)
+    rec = (n_raw + 3) // 4
+    b.load_genotypes_host(0, np.ascontiguousarray(T.pack_2bit(inv_all).view(np.uint8).reshape(m, -1)[:, :rec]), pkg.LDP_GENO_INVERSE | pkg.LDP_GENO_MAPPED)
+    b.set_maj_freqs(0, mf)
+    for v in range(0, m, 7):
+        assert np.array_equal(a.planes(v)[0], b.planes(v)[0]) and np.array_equal(a.planes(v)[1], b.planes(v)[1]), v
+    ra, rb = a.run(), b.run()
+    assert np.array_equal(ra, rb) and 0 < int(ra.sum()) < m
+    a.close()
+    b.close()
