@@ -31,6 +31,8 @@ namespace plink2 {
 // plink2_ld.cc: not static, not in the header
 PglErr IndepPairwise(const uintptr_t* variant_include, const ChrInfo* cip, const uint32_t* variant_bps, const uintptr_t* allele_idx_offsets, const AlleleCode* maj_alleles, const double* allele_freqs, const uintptr_t* founder_info, const uint32_t* founder_info_cumulative_popcounts, const uintptr_t* founder_nonmale, const uintptr_t* founder_male, const uintptr_t* founder_nonfemale, const LdInfo* ldip, const uintptr_t* preferred_variants, const uint32_t* subcontig_info, const uint32_t* subcontig_thread_assignments, uint32_t raw_sample_ct, uint32_t founder_ct, uint32_t founder_male_ct, uint32_t founder_nonfemale_ct, uint32_t subcontig_ct, uintptr_t window_max, uint32_t calc_thread_ct, uint32_t max_load, PgenReader* simple_pgrp, uintptr_t* removed_variants_collapsed);
 
+PglErr IndepPairphase(const uintptr_t* variant_include, const ChrInfo* cip, const uint32_t* variant_bps, const uintptr_t* allele_idx_offsets, const AlleleCode* maj_alleles, const double* allele_freqs, const uintptr_t* founder_info, const uint32_t* founder_info_cumulative_popcounts, const uintptr_t* founder_nonmale, const uintptr_t* founder_male, const uintptr_t* founder_nonfemale, const LdInfo* ldip, const uintptr_t* preferred_variants, const uint32_t* subcontig_info, const uint32_t* subcontig_thread_assignments, uint32_t raw_sample_ct, uint32_t founder_ct, uint32_t founder_male_ct, uint32_t founder_nonfemale_ct, uint32_t subcontig_ct, uintptr_t window_max, uint32_t calc_thread_ct, uint32_t max_load, PgenReader* simple_pgrp, uintptr_t* removed_variants_collapsed);
+
 namespace {
 
 PglErr MapLdpError(int rc, const ldp_engine* eng) {
@@ -242,6 +244,180 @@ PglErr IndepPairwiseHip(const uintptr_t* variant_include, const ChrInfo* cip, co
   if (!reterr) {
     fputs("done.\n", stdout);
   }
+  return reterr;
+}
+
+// --indep-pairphase (IndepPairphase, plink2_ld.cc:1802; the call at :2698 is redirected the same way).  Diploid chromosomes:
+// PgrGetInv1P on the founder subset (:2039) gives counts of the non-major allele plus phasepresent / phaseinfo; a het call
+// without phase is the reference's "not fully phased" error (:2044-2048, HapsplitMustPhased); the rows go to an engine of
+// 2 x founder_ct haplotypes as LDP_GENO_INVERSE | LDP_GENO_PHASED, where the conversion kernel does the haplotype split.
+// Jobs that include chrX / chrY / MT or another haploid contig go to the reference's own IndepPairphase().
+PglErr IndepPairphaseHip(const uintptr_t* variant_include, const ChrInfo* cip, const uint32_t* variant_bps, const uintptr_t* allele_idx_offsets, const AlleleCode* maj_alleles, const double* allele_freqs, const uintptr_t* founder_info, const uint32_t* founder_info_cumulative_popcounts, const uintptr_t* founder_nonmale, const uintptr_t* founder_male, const uintptr_t* founder_nonfemale, const LdInfo* ldip, const uintptr_t* preferred_variants, const uint32_t* subcontig_info, const uint32_t* subcontig_thread_assignments, uint32_t raw_sample_ct, uint32_t founder_ct, uint32_t founder_male_ct, uint32_t founder_nonfemale_ct, uint32_t subcontig_ct, uintptr_t window_max, uint32_t calc_thread_ct, uint32_t max_load, PgenReader* simple_pgrp, uintptr_t* removed_variants_collapsed) {
+  const uint32_t raw_variant_ct = cip->chr_fo_vidx_start[cip->chr_ct];
+  const uint32_t raw_variant_ctl = BitCtToWordCt(raw_variant_ct);
+  const uint32_t variant_ct = PopcountWords(variant_include, raw_variant_ctl);
+  const char* off = getenv("PLINK2_HIP_LDPRUNE");
+  bool use_hip = !(off && (!strcmp(off, "0"))) && (ldp_device_count() > 0) && variant_ct;
+  if (use_hip) {
+    for (uint32_t chr_fo_idx = 0; chr_fo_idx != cip->chr_ct; ++chr_fo_idx) {
+      const uint32_t vstart = cip->chr_fo_vidx_start[chr_fo_idx];
+      const uint32_t vend = cip->chr_fo_vidx_start[chr_fo_idx + 1];
+      if ((vstart != vend) && PopcountBitRange(variant_include, vstart, vend) && IsSet(cip->haploid_mask, cip->chr_file_order[chr_fo_idx])) {
+        use_hip = false;
+        break;
+      }
+    }
+  }
+  if (!use_hip) {
+    return IndepPairphase(variant_include, cip, variant_bps, allele_idx_offsets, maj_alleles, allele_freqs, founder_info, founder_info_cumulative_popcounts, founder_nonmale, founder_male, founder_nonfemale, ldip, preferred_variants, subcontig_info, subcontig_thread_assignments, raw_sample_ct, founder_ct, founder_male_ct, founder_nonfemale_ct, subcontig_ct, window_max, calc_thread_ct, max_load, simple_pgrp, removed_variants_collapsed);
+  }
+  ldp_params p;
+  memset(&p, 0, sizeof(p));
+  p.founder_ct = 2 * founder_ct;  // haplotypes (plink2_ld.cc:1506)
+  p.prune_window_size = ldip->prune_window_size;
+  p.prune_window_incr = ldip->prune_window_incr;
+  p.window_is_bp = (ldip->prune_flags / kfLdPruneWindowBp) & 1;
+  p.plink1_order = (ldip->prune_flags / kfLdPrunePlink1Order) & 1;
+  p.prune_last_param = ldip->prune_last_param;
+  p.device = -1;
+  p.stream = nullptr;
+  ldp_engine* eng = nullptr;
+  int rc = ldp_create(&p, &eng);
+  if (rc) {
+    return MapLdpError(rc, nullptr);
+  }
+  PglErr reterr = kPglRetSuccess;
+  logprintf("--indep-pairphase (HIP, %d device%s visible): ", ldp_device_count(), (ldp_device_count() == 1)? "" : "s");
+  fflush(stdout);
+  uintptr_t* genovec = nullptr;
+  uintptr_t* phasepresent = nullptr;
+  uintptr_t* phaseinfo = nullptr;
+  unsigned char* rows = nullptr;
+  do {
+    std::vector<uint32_t> chr_fo(variant_ct), bps(variant_ct), uidxs(variant_ct);
+    {
+      uintptr_t variant_uidx_base = 0;
+      uintptr_t cur_bits = variant_include[0];
+      uint32_t chr_fo_idx = 0;
+      uint32_t chr_end = cip->chr_fo_vidx_start[1];
+      for (uint32_t variant_idx = 0; variant_idx != variant_ct; ++variant_idx) {
+        const uint32_t variant_uidx = BitIter1(variant_include, &variant_uidx_base, &cur_bits);
+        while (variant_uidx >= chr_end) {
+          ++chr_fo_idx;
+          chr_end = cip->chr_fo_vidx_start[chr_fo_idx + 1];
+        }
+        uidxs[variant_idx] = variant_uidx;
+        chr_fo[variant_idx] = chr_fo_idx;
+        bps[variant_idx] = variant_bps? variant_bps[variant_uidx] : 0;
+      }
+    }
+    rc = ldp_set_variants(eng, variant_ct, chr_fo.data(), (p.window_is_bp && variant_bps)? bps.data() : nullptr);
+    if (rc) {
+      reterr = MapLdpError(rc, eng);
+      break;
+    }
+    PgrSampleSubsetIndex pssi;
+    PgrSetSampleSubsetIndex(founder_info_cumulative_popcounts, simple_pgrp, &pssi);
+    const uintptr_t code_bytes = NypCtToByteCt(founder_ct);
+    const uintptr_t phase_off = ldp_phased_phase_offset(p.founder_ct);
+    const uintptr_t phase_bytes = DivUp(founder_ct, 8);
+    const uintptr_t row_bytes = (ldp_phased_row_bytes(p.founder_ct) + 3) & (~S_CAST(uintptr_t, 3));
+    const uint32_t batch = 1 + (256 * 1048576 / row_bytes);
+    if (cachealigned_malloc(NypCtToVecCt(founder_ct) * kBytesPerVec, &genovec) ||
+        cachealigned_malloc(BitCtToVecCt(founder_ct) * kBytesPerVec, &phasepresent) ||
+        cachealigned_malloc(BitCtToVecCt(founder_ct) * kBytesPerVec, &phaseinfo) ||
+        cachealigned_malloc(batch * row_bytes, &rows)) {
+      reterr = kPglRetNomem;
+      break;
+    }
+    std::vector<double> maj_freqs(batch);
+    uint32_t cur_allele_ct = 2;
+    const uint32_t founder_ctl = BitCtToWordCt(founder_ct);
+    const uint32_t founder_ctl2 = NypCtToWordCt(founder_ct);
+    for (uint32_t batch_start = 0; (batch_start < variant_ct) && (!reterr); batch_start += batch) {
+      const uint32_t n = (variant_ct - batch_start < batch)? (variant_ct - batch_start) : batch;
+      for (uint32_t k = 0; k != n; ++k) {
+        const uint32_t variant_uidx = uidxs[batch_start + k];
+        uint32_t phasepresent_ct;
+        reterr = PgrGetInv1P(founder_info, pssi, founder_ct, variant_uidx, maj_alleles[variant_uidx], simple_pgrp, genovec, phasepresent, phaseinfo, &phasepresent_ct);
+        if (unlikely(reterr)) {
+          PgenErrPrintNV(reterr, variant_uidx);
+          break;
+        }
+        ZeroTrailingNyps(founder_ct, genovec);
+        if (!phasepresent_ct) {
+          ZeroWArr(founder_ctl, phasepresent);
+        }
+        // every het call must carry phase (HapsplitMustPhased, pgenlib_misc.cc:1887-1921)
+        uintptr_t unphased = 0;
+        const Halfword* phasepresent_hw = DowncastKWToHW(phasepresent);
+        for (uint32_t widx = 0; widx != founder_ctl2; ++widx) {
+          const uintptr_t geno_word = genovec[widx];
+          const uintptr_t het_word = geno_word & (~(geno_word >> 1)) & kMask5555;
+          unphased |= het_word & (~UnpackHalfwordToWord(phasepresent_hw[widx]));
+        }
+        if (unlikely(unphased)) {
+          logputs("\n");
+          logerrprintf("Error: --indep-pairphase: 0-based variant #%u is not fully phased.\n", variant_uidx);
+          reterr = kPglRetInconsistentInput;
+          break;
+        }
+        unsigned char* row = &(rows[k * row_bytes]);
+        memcpy(row, genovec, code_bytes);
+        memset(&(row[code_bytes]), 0, phase_off - code_bytes);
+        BitvecAnd(phasepresent, founder_ctl, phaseinfo);
+        ZeroTrailingBits(founder_ct, phaseinfo);
+        memcpy(&(row[phase_off]), phaseinfo, phase_bytes);
+        memset(&(row[phase_off + phase_bytes]), 0, row_bytes - phase_off - phase_bytes);
+        uintptr_t allele_idx_base;
+        if (!allele_idx_offsets) {
+          allele_idx_base = variant_uidx;
+        } else {
+          allele_idx_base = allele_idx_offsets[variant_uidx];
+          cur_allele_ct = allele_idx_offsets[variant_uidx + 1] - allele_idx_base;
+          allele_idx_base -= variant_uidx;
+        }
+        maj_freqs[k] = GetAlleleFreq(&(allele_freqs[allele_idx_base]), maj_alleles[variant_uidx], cur_allele_ct);
+      }
+      if (reterr) {
+        break;
+      }
+      rc = ldp_load_genotypes(eng, batch_start, n, rows, row_bytes, LDP_MEM_HOST, LDP_GENO_INVERSE | LDP_GENO_PHASED);
+      if (!rc) {
+        rc = ldp_set_maj_freqs(eng, batch_start, n, maj_freqs.data());
+      }
+      if (rc) {
+        reterr = MapLdpError(rc, eng);
+      }
+    }
+    if (reterr) {
+      break;
+    }
+    if (preferred_variants) {
+      std::vector<uint64_t> pref((variant_ct + 63) / 64, 0);
+      for (uint32_t variant_idx = 0; variant_idx != variant_ct; ++variant_idx) {
+        if (IsSet(preferred_variants, uidxs[variant_idx])) {
+          pref[variant_idx / 64] |= 1ULL << (variant_idx % 64);
+        }
+      }
+      rc = ldp_set_preferred(eng, pref.data());
+      if (rc) {
+        reterr = MapLdpError(rc, eng);
+        break;
+      }
+    }
+    rc = ldp_run(eng, R_CAST(uint64_t*, removed_variants_collapsed));
+    if (rc) {
+      reterr = MapLdpError(rc, eng);
+      break;
+    }
+    fputs("done.\n", stdout);
+  } while (0);
+  aligned_free_cond(rows);
+  aligned_free_cond(phaseinfo);
+  aligned_free_cond(phasepresent);
+  aligned_free_cond(genovec);
+  ldp_destroy(eng);
   return reterr;
 }
 

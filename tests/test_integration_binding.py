@@ -100,3 +100,36 @@ def test_environment_switch_sends_the_job_to_the_reference_path(gpu_pkg, tmp_pat
     c = subprocess.run([PATCHED, "--bfile", "d", "--indep-pairwise", "20kb", "0.3", "--out", "off"], cwd=str(tmp_path), env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert c.returncode == 0 and "--indep-pairwise (HIP" not in c.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wargs,nonfounders", [(["30kb", "0.5"], 0), (["60", "7", "0.2", "--indep-order", "1"], 5), (["100", "1", "0.8"], 5)])
+def test_reference_pairphase_through_the_c_abi_matches_stock_reference(gpu_pkg, tmp_path, wargs, nonfounders):
+    """IndepPairphase() redirected the same way (plink2_ld.cc:2698): PgrGetInv1P rows + phase bits as LDP_GENO_INVERSE |
+    LDP_GENO_PHASED on a 2 x founders haplotype engine."""
+    from test_pairphase import _phased_fileset
+    tmp = str(tmp_path)
+    _phased_fileset(tmp, 700, 131, seed=17 + nonfounders, chrom_plan=[("0", 3), ("1", 300), ("2", 250), ("7", 147)], nonfounders=nonfounders)
+    args = ["--pfile", "p", "--indep-pairphase"] + wargs
+    a = run(STOCK, args, tmp, "stock")
+    b = run(PATCHED, args, tmp, "hipld")
+    assert a.returncode == 0, a.stdout[-1500:]
+    assert b.returncode == 0, b.stdout[-1500:]
+    assert "--indep-pairphase (HIP" in b.stdout
+    for ext in (".prune.in", ".prune.out"):
+        assert open(os.path.join(tmp, "stock" + ext), "rb").read() == open(os.path.join(tmp, "hipld" + ext), "rb").read(), ext
+    assert 0 < len(open(os.path.join(tmp, "stock.prune.out")).read().split()) < 697
+
+
+@pytest.mark.gpu
+def test_reference_pairphase_binding_reports_unphased_hets_like_the_reference(gpu_pkg, tmp_path):
+    from test_pairphase import _phased_fileset
+    tmp = str(tmp_path)
+    _phased_fileset(tmp, 300, 90, seed=31, chrom_plan=[("1", 300)], unphased_rate=0.2)
+    args = ["--pfile", "p", "--indep-pairphase", "50", "5", "0.5"]
+    a = run(STOCK, args, tmp, "stock")
+    b = run(PATCHED, args, tmp, "hipld")
+    assert a.returncode == b.returncode == 7, (a.returncode, b.returncode, b.stdout[-800:])
+    ea = [ln for ln in a.stdout.splitlines() if ln.startswith("Error")]
+    eb = [ln for ln in b.stdout.splitlines() if ln.startswith("Error")]
+    assert ea == eb and "is not fully phased" in eb[0]
