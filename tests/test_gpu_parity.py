@@ -392,3 +392,38 @@ def test_randomised_differential(gpu_pkg):
     for k in range(80):
         ok, desc = fz.one_case(gpu_pkg, rng, k)
         assert ok, desc
+
+
+@pytest.mark.parametrize("n,missing", [(16000000, 0.0), (16000001, 0.0), (16000257, 0.01)])
+def test_sample_counts_around_the_matrix_pipe_limit(gpu_pkg, n, missing):
+    """f32 accumulators stay integer-exact up to kMfMaxFounders = 16,000,000 samples; beyond that the popcount kernels take the
+    pairs.  Either side of the limit the tile kernels' six-tuples must equal the one-wave-per-pair reference kernel's
+    (ldp_pair_stats: an independent, trivially simple kernel), and the counters must say which family ran."""
+    import torch
+    pkg = gpu_pkg
+    m = 40
+    stride = (n + 3) // 4
+    buf = torch.empty((m, stride), dtype=torch.uint8, device="cuda")
+    pkg.synth_genotypes_device(77, 0, m, n, missing, buf.data_ptr(), stride)
+    torch.cuda.synchronize()
+    eng = pkg.LdPruneEngine(n, 12, 1, False, 0.2, device=0)
+    eng.set_variants(np.zeros(m, dtype=np.uint32), None)
+    eng.load_genotypes_device(0, m, buf.data_ptr(), stride, pkg.LDP_GENO_REF)
+    removed, stats = eng.run_with_stats()
+    lo, cand = eng.band()
+    first, second = [], []
+    for j in range(m):
+        for i in range(int(lo[j]), j):
+            first.append(i)
+            second.append(j)
+    assert len(first) == cand == len(stats)
+    ref = eng.pair_stats(first, second)
+    assert np.array_equal(stats, ref)
+    assert int(stats["nm"].max()) <= n and int(stats["nm"].min()) > 0.9 * n
+    ctr = eng.counters()
+    if n <= 16000000:
+        assert ctr["mfma_block_products"] > 0
+    else:
+        assert ctr["mfma_block_products"] == 0
+    eng.close()
+    del buf
