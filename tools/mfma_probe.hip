@@ -63,8 +63,8 @@ __device__ __forceinline__ void unpack32(uint32_t H, uint32_t R, uint32_t (&o)[4
 
 // rate: NACC independent accumulators, `iters` rounds; mode 0 = MFMA only, 1 = + one unpack32 per MFMA (VALU beside it),
 // 2 = 7 unpacks per 8 MFMAs with operands read from LDS (the shape of pair_mfma_kernel's k-step)
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void rate_kernel(const uint32_t* src, float* out, int iters) {
+template <int MODE, int PAT = 0>
+__global__ __launch_bounds__(256, 2) void rate_kernel(const uint32_t* src, float* out, int iters, const uint32_t* big = nullptr, size_t big_rows = 1) {
   __shared__ uint32_t lds[8192];
   const int l = threadIdx.x;
   for (int q = l; q < 8192; q += 256) {
@@ -91,6 +91,57 @@ __global__ __launch_bounds__(256, 2) void rate_kernel(const uint32_t* src, float
         uint32_t f[4];
         unpack32(fa[p & 3] + it, fb[p & 3] ^ it, f);
         acc[p] = mfma_fp4(f, fb, acc[p]);
+      }
+    } else if (MODE >= 3) {
+      // the shape of pair_mfma_kernel's stage: (MODE 4, 5) this wave's share of the next stage's LDS-DMA (22 KiB per stage and
+      // workgroup = 5.5 x 1 KiB per wave, from a 12.5 GB-like strided source), a counted vmcnt wait, one s_barrier, then 20
+      // unpacks and 32 MFMAs from the ring.  MODE 3: barrier only.  MODE 5: the DMA without the barrier (unsafe, rate only).
+      uint32_t* ring = lds;  // 2 x 16 KiB halves
+      const int half = it & 1;
+      if (MODE >= 4) {
+        const uint8_t* g = reinterpret_cast<const uint8_t*>(big);
+        // DMA instruction (t, wave) = 1 KiB of this stage for rows of 12,544 bytes, as pair_mfma_kernel issues them.
+        // PAT 0: 16 rows x (32 B of the hom half-chunk + 32 B of the ref2het half-chunk, 64 B apart: the committed layout)
+        // PAT 1: 16 rows x 64 contiguous bytes     PAT 2: 8 rows x 128 contiguous bytes (a full line per row)
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+          const int lane = l & 63;
+          const int per_row = (PAT == 2) ? 8 : 4;
+          const size_t row = (static_cast<size_t>(blockIdx.x) * 352 + static_cast<size_t>(t * 4 + (l >> 6)) * 16 + lane / per_row) % big_rows;
+          const int pc = lane % per_row;
+          size_t off;
+          if (PAT == 0) {
+            off = static_cast<size_t>(it / 2 % 98) * 128 + (it & 1) * 32 + (pc >> 1) * 64 + (pc & 1) * 16;
+          } else if (PAT == 1) {
+            off = static_cast<size_t>(it % 196) * 64 + pc * 16;
+          } else {
+            off = static_cast<size_t>(it % 98) * 128 + pc * 16;
+          }
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + row * 12544 + off),
+                                           (__attribute__((address_space(3))) void*)(ring + (half ^ 1) * 4096 + ((t * 4 + (l >> 6)) % 16) * 256), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      }
+      if (MODE != 5) {
+        __builtin_amdgcn_s_barrier();
+      }
+      const uint4* l4 = reinterpret_cast<const uint4*>(ring + half * 4096);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        uint32_t fr[5][4];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const uint4 hv = l4[((u * 4 + ks) * 64 + (l & 63)) & 1023];
+          unpack32(hv.x, hv.y, fr[u]);
+        }
+        acc[0] = mfma_fp4(fr[2], fr[0], acc[0]);
+        acc[1] = mfma_fp4(fr[3], fr[0], acc[1]);
+        acc[2] = mfma_fp4(fr[4], fr[0], acc[2]);
+        acc[3] = mfma_fp4(fr[0], fr[0], acc[3]);
+        acc[4] = mfma_fp4(fr[3], fr[1], acc[4]);
+        acc[5] = mfma_fp4(fr[4], fr[1], acc[5]);
+        acc[6] = mfma_fp4(fr[0], fr[1], acc[6]);
+        acc[7] = mfma_fp4(fr[1], fr[1], acc[7]);
       }
     } else {
       const uint4* l4 = reinterpret_cast<const uint4*>(lds);
@@ -305,6 +356,40 @@ int main(int argc, char** argv) {
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     const int iters = 2000;
+    uint32_t* big = nullptr;
+    const size_t big_rows = 400000;  // 5 GB of 12,544-byte rows: the DMA of modes 4 and 5 streams from HBM like the kernel's
+    CHECK(hipMalloc(&big, big_rows * 12544));
+    CHECK(hipMemset(big, 0x5a, big_rows * 12544));
+    for (int mode = 3; mode < 8; ++mode) {
+      for (int rep = 0; rep < 2; ++rep) {
+        const int stages = 196;
+        CHECK(hipEventRecord(e0, 0));
+        if (mode == 3) {
+          hipLaunchKernelGGL((rate_kernel<3, 0>), dim3(blocks), dim3(256), 0, 0, src, out, stages, big, big_rows);
+        } else if (mode == 4) {
+          hipLaunchKernelGGL((rate_kernel<4, 0>), dim3(blocks), dim3(256), 0, 0, src, out, stages, big, big_rows);
+        } else if (mode == 5) {
+          hipLaunchKernelGGL((rate_kernel<5, 0>), dim3(blocks), dim3(256), 0, 0, src, out, stages, big, big_rows);
+        } else if (mode == 6) {
+          hipLaunchKernelGGL((rate_kernel<4, 1>), dim3(blocks), dim3(256), 0, 0, src, out, stages, big, big_rows);
+        } else {
+          hipLaunchKernelGGL((rate_kernel<4, 2>), dim3(blocks), dim3(256), 0, 0, src, out, stages, big, big_rows);
+        }
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) {
+          static const char* kName[5] = {"stage shape, barrier only", "stage shape, LDS-DMA ring (2 x 32 B per row, committed layout) + barrier",
+                                         "the same without the barrier", "LDS-DMA ring, 64 contiguous bytes per row", "LDS-DMA ring, 128 contiguous bytes per row"};
+          const double mfmas = (double)blocks * 4 * stages * 32;
+          const double macs = mfmas * 65536.0;
+          printf("5. mode %d (%s): %.3f ms, %.2f PFLOP/s, %.1f cycles/MFMA/SIMD at 2.4 GHz, %.2f us per stage and CU, DMA %.2f TB/s\n", mode, kName[mode - 3], ms,
+                 2 * macs / (ms * 1e-3) / 1e15, (ms * 1e-3) * 2.4e9 / (mfmas / 1024.0), (ms * 1e-3) / (blocks / 512.0) / stages * 1e6,
+                 (mode == 3) ? 0.0 : (double)blocks * stages * 24576.0 / (ms * 1e-3) / 1e12);
+        }
+      }
+    }
     for (int mode = 0; mode < 3; ++mode) {
       for (int rep = 0; rep < 2; ++rep) {
         CHECK(hipEventRecord(e0, 0));
