@@ -393,6 +393,12 @@ struct Args {
   uint32_t ld_var_ct_radius = 0x7fffffff;  // --ld-window N: N - 1
   uint32_t ld_bp_radius = 0xffffffffu;     // --ld-window-kb; UINT32_MAX = not given (table default 1000 kb)
   double ld_min_r2 = 2.0;                  // --ld-window-r2 (after the reference's epsilon); 2.0 = not given
+  // variant / sample filters applied before the command (the reference's variant_include / sample_include):
+  // --chr / --not-chr (codes and code ranges, or names), --autosome, --extract / --exclude (variant ID lists),
+  // --keep / --remove (sample ID lists: "FID IID", "IID", or a #FID / #IID header line)
+  std::vector<std::string> chr_keep, chr_drop;
+  bool autosome = false;
+  std::vector<std::string> extract_files, exclude_files, keep_files, remove_files;
   // --ld-snp / --ld-snps / --ld-snp-list (plink2.cc:7966-8003): the table's row variants.  ld_snps: (first, second) ID pairs,
   // second empty for a single ID, otherwise the range first..second in file order
   std::vector<std::pair<std::string, std::string>> ld_snps;
@@ -645,6 +651,35 @@ Args parse_args(int argc, char** argv) {
       }
     } else if (f.compare(0, 7, "--clump") == 0) {
       die(9, "Error: %s is not supported by plink2-hip's --clump yet.\n", f.c_str());
+    } else if ((f == "--chr") || (f == "--not-chr")) {  // ParseChrRanges, plink2_cmdline.cc: "1-4, 22, X" in one or several arguments
+      std::vector<std::string>& dst = (f == "--chr") ? A.chr_keep : A.chr_drop;
+      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+        const std::string arg = argv[++i];
+        size_t p0 = 0;
+        while (p0 < arg.size()) {
+          const size_t p1 = std::min(arg.find(',', p0), arg.size());
+          if (p1 > p0) {
+            dst.push_back(arg.substr(p0, p1 - p0));
+          }
+          p0 = p1 + 1;
+        }
+      }
+      if (dst.empty()) {
+        die(5, "Error: %s requires at least one value.\n", f.c_str());
+      }
+    } else if (f == "--autosome") {
+      A.autosome = true;
+    } else if ((f == "--extract") || (f == "--exclude") || (f == "--keep") || (f == "--remove")) {
+      std::vector<std::string>& dst = (f == "--extract") ? A.extract_files : ((f == "--exclude") ? A.exclude_files : ((f == "--keep") ? A.keep_files : A.remove_files));
+      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+        dst.push_back(argv[++i]);
+      }
+      if (dst.empty()) {
+        die(5, "Error: %s requires at least one filename.\n", f.c_str());
+      }
+      if (((f == "--extract") || (f == "--exclude")) && ((dst[0] == "range") || (dst[0] == "bed0") || (dst[0] == "bed1") || (dst[0] == "intersect"))) {
+        die(9, "Error: the '%s' mode of %s is not supported by plink2-hip.\n", dst[0].c_str(), f.c_str());
+      }
     } else if (f == "--ld-snp") {
       need(i, 1, "--ld-snp");
       if (!A.ld_snps.empty() || !A.ld_snp_list.empty()) {
@@ -861,7 +896,7 @@ Args parse_args(int argc, char** argv) {
 
 // founder <=> PAT and MAT are both exactly "0" (plink2_psam.cc:804-806); absent columns => founder
 // sex: 1 = male, 2 = female, anything else = unknown (plink2_psam.cc:808-813)
-void load_samples(const Args& A, std::vector<uint8_t>* is_founder, std::vector<uint8_t>* sex) {
+void load_samples(const Args& A, std::vector<uint8_t>* is_founder, std::vector<uint8_t>* sex, std::vector<std::string>* fid_iid = nullptr) {
   const bool psam = !A.psam.empty();
   const std::string& path = psam ? A.psam : A.fam;
   std::ifstream in(path);
@@ -869,8 +904,8 @@ void load_samples(const Args& A, std::vector<uint8_t>* is_founder, std::vector<u
     die(2, "Error: Failed to open %s.\n", path.c_str());
   }
   std::string line;
-  int pat_col = -1, mat_col = -1, sex_col = -1;
-  bool header_seen = false;
+  int pat_col = -1, mat_col = -1, sex_col = -1, iid_col = 0;
+  bool header_seen = false, has_fid = false;
   while (std::getline(in, line)) {
     if (line.empty()) {
       continue;
@@ -883,6 +918,8 @@ void load_samples(const Args& A, std::vector<uint8_t>* is_founder, std::vector<u
           if (cols[c] == "MAT") mat_col = static_cast<int>(c);
           if (cols[c] == "SEX") sex_col = static_cast<int>(c);
         }
+        has_fid = (cols[0] == "#FID");
+        iid_col = has_fid ? 1 : 0;
         header_seen = true;
       }
       continue;
@@ -897,6 +934,9 @@ void load_samples(const Args& A, std::vector<uint8_t>* is_founder, std::vector<u
         die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
       }
       is_founder->push_back((t[2] == "0") && (t[3] == "0"));
+      if (fid_iid) {
+        fid_iid->push_back(t[0] + "\t" + t[1]);
+      }
       const std::string& v = t[4];  // CharToSex on a one-character token (plink2_psam.cc:505-509), for .fam as for .psam
       sex->push_back((v == "1" || v == "M" || v == "m") ? 1 : ((v == "2" || v == "F" || v == "f") ? 2 : 0));
     } else {
@@ -908,6 +948,12 @@ void load_samples(const Args& A, std::vector<uint8_t>* is_founder, std::vector<u
         founder = (t[pat_col] == "0") && (t[mat_col] == "0");
       }
       is_founder->push_back(founder);
+      if (fid_iid) {  // (no FID column: FID "0", as the reference keys its samples)
+        if (static_cast<size_t>(iid_col) >= t.size()) {
+          die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
+        }
+        fid_iid->push_back((has_fid ? t[0] : std::string("0")) + "\t" + t[iid_col]);
+      }
       uint8_t sx = 0;
       if (sex_col >= 0 && static_cast<size_t>(sex_col) < t.size()) {
         const std::string& v = t[sex_col];
@@ -2033,6 +2079,131 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
   return 0;
 }
 
+// --chr / --not-chr / --autosome: a chromosome's numeric code (1..22, X 23, Y 24, XY 25, MT 26, 0; -1 for other names)
+int chrom_code(const std::string& name_in) {
+  std::string name = name_in;
+  if (name.size() > 3 && (name[0] | 32) == 'c' && (name[1] | 32) == 'h' && (name[2] | 32) == 'r') {
+    name = name.substr(3);
+  }
+  bool numeric = !name.empty();
+  for (char c : name) {
+    numeric = numeric && (c >= '0' && c <= '9');
+  }
+  if (numeric) {
+    const long v = strtol(name.c_str(), nullptr, 10);
+    return (v <= 26) ? static_cast<int>(v) : -1;
+  }
+  if (ieq(name.c_str(), "X")) return 23;
+  if (ieq(name.c_str(), "Y")) return 24;
+  if (ieq(name.c_str(), "XY")) return 25;
+  if (ieq(name.c_str(), "MT") || ieq(name.c_str(), "M")) return 26;
+  return -1;
+}
+
+// is chromosome `name` named by one of the --chr style terms ("7", "chr7", "3-9", "X", "contig_12")?
+bool chrom_listed(const std::vector<std::string>& terms, const std::string& name) {
+  const int code = chrom_code(name);
+  std::string bare = name;
+  if (bare.size() > 3 && (bare[0] | 32) == 'c' && (bare[1] | 32) == 'h' && (bare[2] | 32) == 'r') {
+    bare = bare.substr(3);
+  }
+  for (const std::string& t : terms) {
+    const size_t dash = t.find('-');
+    if ((dash != std::string::npos) && (dash > 0) && (dash + 1 < t.size())) {
+      const int lo = chrom_code(t.substr(0, dash)), hi = chrom_code(t.substr(dash + 1));
+      if ((lo >= 0) && (hi >= lo)) {
+        if ((code >= lo) && (code <= hi)) {
+          return true;
+        }
+        continue;
+      }
+    }
+    const int tc = chrom_code(t);
+    if (tc >= 0) {
+      if (tc == code) {
+        return true;
+      }
+      continue;
+    }
+    std::string tb = t;
+    if (tb.size() > 3 && (tb[0] | 32) == 'c' && (tb[1] | 32) == 'h' && (tb[2] | 32) == 'r') {
+      tb = tb.substr(3);
+    }
+    if (tb == bare) {
+      return true;
+    }
+  }
+  return false;
+}
+
+std::vector<std::string> tokens_of_file(const std::string& path) {
+  const std::string text = slurp(path);
+  std::vector<std::string> out;
+  for (size_t p0 = 0; p0 < text.size();) {
+    while ((p0 < text.size()) && (static_cast<unsigned char>(text[p0]) <= ' ')) {
+      ++p0;
+    }
+    size_t p1 = p0;
+    while ((p1 < text.size()) && (static_cast<unsigned char>(text[p1]) > ' ')) {
+      ++p1;
+    }
+    if (p1 > p0) {
+      out.emplace_back(text, p0, p1 - p0);
+    }
+    p0 = p1;
+  }
+  return out;
+}
+
+// --keep / --remove files (LoadXidHeader + LoadSampleIds, plink2_common.cc:1313,1707): "FID<tab>IID" keys.  A header line
+// "#FID IID ..." or "#IID ..." names the columns; without one, a line of two or more tokens is FID IID and a line of one is
+// an IID with FID "0".
+void load_sample_id_list(const std::string& path, const char* flag, std::vector<std::string>* keys) {
+  std::ifstream in(path);
+  if (!in) {
+    die(2, "Error: Failed to open %s.\n", path.c_str());
+  }
+  std::string line;
+  int mode = 0;  // 0: no header (FID IID or IID), 1: #FID IID, 2: #IID
+  bool first = true;
+  size_t line_idx = 0;
+  while (std::getline(in, line)) {
+    ++line_idx;
+    std::vector<std::string> t = split_ws(line);
+    if (t.empty()) {
+      continue;
+    }
+    if (t[0][0] == '#') {
+      if (first && ((t[0] == "#FID") || (t[0] == "#IID"))) {
+        first = false;
+        if (t[0] == "#FID") {
+          if ((t.size() < 2) || (t[1] != "IID")) {
+            die(3, "Error: No IID column on line %zu of --%s file.\n", line_idx, flag);
+          }
+          mode = 1;
+        } else {
+          mode = 2;
+        }
+        if ((t.size() > static_cast<size_t>(3 - mode)) && (t[3 - mode] == "SID")) {
+          die(9, "Error: SID columns in --%s files are not supported by plink2-hip.\n", flag);
+        }
+      }
+      continue;  // (other '#' lines before the data are comments)
+    }
+    first = false;
+    if (mode == 2) {
+      keys->push_back("0\t" + t[0]);
+    } else if ((mode == 1) || (t.size() >= 2)) {
+      if (t.size() < 2) {
+        die(3, "Error: Line %zu of --%s file has fewer tokens than expected.\n", line_idx, flag);
+      }
+      keys->push_back(t[0] + "\t" + t[1]);
+    } else {
+      keys->push_back("0\t" + t[0]);
+    }
+  }
+}
+
 // Everything the commands share: the parsed command line, the variant and sample tables, the open genotype file and the
 // included-variant index (chromosome 0 stripped where the reference strips it).  load_inputs() fills it; run_r2() (the
 // --r2-unphased outputs and --clump) and run_prune() (--indep-pairwise / --indep-pairphase) consume it.
@@ -2041,7 +2212,7 @@ struct Session {
   Args A;
   Variants V;
   std::thread t_hip;  // HIP runtime start-up, beside the file parsing; joined where the first engine is created, or on the way out
-  std::vector<uint8_t> is_founder, sex;
+  std::vector<uint8_t> is_founder, sex;  // (a sample --keep / --remove drops is no founder from here on)
   uint32_t raw_sample_ct = 0, founder_ct = 0, raw_variant_ct = 0;
   bool is_bed = false;
   std::string gpath;
@@ -2088,7 +2259,41 @@ void load_inputs(Session& S, int argc, char** argv) {
   std::thread t_variants([&]() { load_variants(A, &V); });
   S.t_hip = std::thread([&S]() { const double t0 = now_s(); (void)ldp_device_count(); S.t_hip_init = now_s() - t0; });
   std::vector<uint8_t>& is_founder = S.is_founder;
-  load_samples(A, &S.is_founder, &S.sex);
+  std::vector<std::string> sample_keys;
+  const bool sample_filter = (!A.keep_files.empty()) || (!A.remove_files.empty());
+  load_samples(A, &S.is_founder, &S.sex, sample_filter ? &sample_keys : nullptr);
+  if (sample_filter) {  // KeepOrRemove, plink2_filter.cc:1227-1261 (--keep first, then --remove, plink2.cc)
+    std::vector<uint8_t> in(S.is_founder.size(), 1);
+    for (int pass = 0; pass < 2; ++pass) {
+      const std::vector<std::string>& files = pass ? A.remove_files : A.keep_files;
+      if (files.empty()) {
+        continue;
+      }
+      const char* flag = pass ? "remove" : "keep";
+      std::vector<std::string> keys;
+      for (const std::string& fn : files) {
+        load_sample_id_list(fn, flag, &keys);
+      }
+      std::unordered_set<std::string> listed;
+      size_t dups = 0;
+      for (std::string& k : keys) {
+        dups += listed.insert(std::move(k)).second ? 0 : 1;
+      }
+      uint32_t remaining = 0;
+      for (size_t sx = 0; sx < in.size(); ++sx) {
+        const bool hit = listed.count(sample_keys[sx]) != 0;
+        in[sx] = static_cast<uint8_t>(in[sx] && (pass ? !hit : hit));
+        remaining += in[sx];
+      }
+      logprintf("--%s: %u sample%s remaining.\n", flag, remaining, (remaining == 1) ? "" : "s");
+      if (dups) {
+        logprintf("Warning: At least %zu duplicate ID%s in --%s file(s).\n", dups, (dups == 1) ? "" : "s", flag);
+      }
+    }
+    for (size_t sx = 0; sx < in.size(); ++sx) {
+      S.is_founder[sx] = static_cast<uint8_t>(S.is_founder[sx] && in[sx]);
+    }
+  }
   t_variants.join();
   S.t_parse = now_s() - t_begin;
   S.raw_sample_ct = static_cast<uint32_t>(is_founder.size());
@@ -2137,12 +2342,28 @@ void load_inputs(Session& S, int argc, char** argv) {
   std::vector<uint32_t>& bps = S.bps;
   std::vector<uint8_t>& vcls = S.vcls;
   uint32_t skipped = 0;
+  // variant filters: --chr / --not-chr / --autosome by chromosome, then --extract, then --exclude by ID
+  // (TokenExtractExclude, plink2_filter.cc:367: every variant carrying a listed ID, unknown IDs ignored)
+  std::unordered_set<std::string> extract_ids, exclude_ids;
+  for (const std::string& fn : A.extract_files) {
+    for (std::string& t : tokens_of_file(fn)) {
+      extract_ids.insert(std::move(t));
+    }
+  }
+  for (const std::string& fn : A.exclude_files) {
+    for (std::string& t : tokens_of_file(fn)) {
+      exclude_ids.insert(std::move(t));
+    }
+  }
+  const bool chr_filter = (!A.chr_keep.empty()) || (!A.chr_drop.empty()) || A.autosome;
+  uint32_t after_extract = 0, after_exclude = 0;
   {
     std::unordered_set<std::string> seen_chr;
     std::string cur;
     uint32_t fo = 0;
     bool first = true;
     bool zero = false;
+    bool chr_out = false;
     int cls = 0;
     inc.reserve(raw_variant_ct);
     chr_idx.reserve(raw_variant_ct);
@@ -2158,7 +2379,24 @@ void load_inputs(Session& S, int argc, char** argv) {
         }
         first = false;
         cls = chrom_class(cur, A.allow_extra_chr, &zero);
+        chr_out = false;
+        if (chr_filter) {
+          const int code = chrom_code(cur);
+          chr_out = ((!A.chr_keep.empty()) && !chrom_listed(A.chr_keep, cur)) || ((!A.chr_drop.empty()) && chrom_listed(A.chr_drop, cur)) ||
+                    (A.autosome && !((code >= 1) && (code <= 22)));
+        }
       }
+      if (chr_out) {
+        continue;
+      }
+      if ((!A.extract_files.empty()) && !extract_ids.count(V.id[v])) {
+        continue;
+      }
+      ++after_extract;
+      if ((!A.exclude_files.empty()) && exclude_ids.count(V.id[v])) {
+        continue;
+      }
+      ++after_exclude;
       if (zero && (A.have_prune || (A.r2_table && !A.r2_inter))) {  // (the all-pairs modes keep chromosome 0)
         ++skipped;
         continue;
@@ -2177,6 +2415,12 @@ void load_inputs(Session& S, int argc, char** argv) {
       chr_idx.push_back(fo);
       bps.push_back(V.bp[v]);
     }
+  }
+  if (!A.extract_files.empty()) {
+    logprintf("--extract: %u variant%s remaining.\n", after_extract, (after_extract == 1) ? "" : "s");
+  }
+  if (!A.exclude_files.empty()) {
+    logprintf("--exclude: %u variant%s remaining.\n", after_exclude, (after_exclude == 1) ? "" : "s");
   }
   if (skipped) {
     logprintf("--%s: Ignoring %u chromosome 0 variant%s.\n", A.have_prune ? (A.pairphase ? "indep-pairphase" : "indep-pairwise") : (A.have_clump ? "clump" : "r2-unphased"), skipped, skipped == 1 ? "" : "s");
@@ -2470,7 +2714,7 @@ int run_r2(Session& S) {
       for (uint32_t k = 0; k < variant_ct; ++k) {
         by_id[V.id[inc[k]]].push_back(k);
       }
-      if (!A.ld_snp_list.empty()) {  // (TokenExtractExclude, plink2_filter.cc: unknown IDs are skipped, repeated dataset IDs are an error)
+      if (!A.ld_snp_list.empty()) {  // (TokenExtractExclude, plink2_filter.cc:367: unknown IDs are skipped, every variant carrying a listed ID counts)
         const std::string text = slurp(A.ld_snp_list);
         std::vector<std::string> ids;
         for (size_t p0 = 0; p0 < text.size();) {
@@ -2491,10 +2735,9 @@ int run_r2(Session& S) {
           if (it == by_id.end()) {
             continue;
           }
-          if (it->second.size() > 1) {
-            die(3, "Error: Variant '%s' in --ld-snp-list file appears multiple times in dataset.\n", id.c_str());
+          for (uint32_t k : it->second) {
+            is_row[k] = 1;
           }
-          is_row[it->second[0]] = 1;
         }
       }
       for (const auto& pr : A.ld_snps) {  // (InterpretVariantRangeList, plink2_filter.cc:216-271)

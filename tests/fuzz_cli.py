@@ -160,6 +160,21 @@ def one_case(cli, ref, rng, idx, tmp, execute=True, mode="all"):
                 f.write("#IID\tPAT\tMAT\tSEX\n")
                 for sidx in range(n):
                     f.write("s%d\t%s\t%s\t2\n" % (sidx, "s0" if isnf[sidx] else "0", "s1" if isnf[sidx] else "0"))
+    # filters in front of the command: a chromosome subset, an ID list to drop, a sample list to keep
+    if rng.random() < 0.3:
+        how = rng.random()
+        if (how < 0.4) and (chr_ct > 1):
+            inp = inp + ["--chr", ",".join(labels[:max(1, chr_ct - 1)])]
+        elif how < 0.7:
+            with open(os.path.join(d, "drop.txt"), "w") as f:
+                f.write("\n".join("snp%d" % v for v in rng.choice(m, size=max(1, m // 7), replace=False)) + "\nnone_such\n")
+            inp = inp + ["--exclude", "drop.txt"]
+        elif founders == n:
+            keep = np.sort(rng.choice(n, size=max(55, n * 3 // 4), replace=False))
+            with open(os.path.join(d, "keep.txt"), "w") as f:
+                f.write("".join(("s%d s%d\n" % (s, s)) if use_bed else ("s%d\n" % s) for s in keep))
+            inp = inp + ["--keep", "keep.txt"]
+            founders = len(keep)
     kind = rng.random()
     if kind < 0.12:
         # --clump on a random report (unknown IDs, repeated lines, odd p-value spellings come from tests/test_clump.py)

@@ -1,0 +1,96 @@
+"""Variant and sample filters in front of the commands (--chr / --not-chr / --autosome, --extract / --exclude, --keep /
+--remove): plink2-hip's output files against the reference binary's on the same command line."""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+import ldtools as T
+from test_cli import cli, run_cli  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def fileset(tmp_path, m=1200, n=150, seed=3, with_x=True):
+    raw = T.synth_raw_codes(m, n, seed, missing_rate=0.02, ld_copy_prob=0.6, redraw=0.05)
+    names = ["0"] * 5 + ["1"] * 400 + ["2"] * 300 + ["3"] * 200 + ["7"] * 145 + (["X"] * 150 if with_x else ["9"] * 150)
+    assert len(names) == m
+    rng = np.random.default_rng(seed)
+    pos = np.zeros(m, dtype=np.int64)
+    start = 0
+    for cnt in (5, 400, 300, 200, 145, 150):
+        pos[start:start + cnt] = np.sort(rng.choice(np.arange(3000000, 3400000), size=cnt, replace=False))
+        start += cnt
+    sexes = rng.choice([1, 2], size=n)
+    prefix = str(tmp_path / "d")
+    T.write_bed(prefix, raw, names, pos)
+    T.write_pgen_fixed(prefix, raw, names, pos, sexes=sexes)
+    fam = ["f%d s%d %s %s %d -9" % (s // 3, s, "s0" if s % 13 == 5 else "0", "s1" if s % 13 == 5 else "0", sexes[s]) for s in range(n)]
+    open(prefix + ".fam", "w").write("\n".join(fam) + "\n")
+    psam = ["#IID\tPAT\tMAT\tSEX"] + ["s%d\t%s\t%s\t%d" % (s, "s0" if s % 13 == 5 else "0", "s1" if s % 13 == 5 else "0", sexes[s]) for s in range(n)]
+    open(prefix + ".psam", "w").write("\n".join(psam) + "\n")
+    with open(str(tmp_path / "vars.txt"), "w") as f:
+        f.write("\n".join("snp%d" % v for v in rng.choice(m, size=m // 2, replace=False)) + "\nnot_in_the_file\n")
+    with open(str(tmp_path / "vars2.txt"), "w") as f:
+        f.write(" ".join("snp%d" % v for v in rng.choice(m, size=m // 6, replace=False)) + "\n")
+    pick = rng.choice(n, size=n * 2 // 3, replace=False)
+    with open(str(tmp_path / "keep_fam.txt"), "w") as f:          # FID IID, no header
+        f.write("".join("f%d s%d\n" % (s // 3, s) for s in pick) + "f999 nobody\nf0 s0\nf0 s0\n")
+    with open(str(tmp_path / "keep_iid.txt"), "w") as f:          # IID only, no header (matches FID 0: the .psam has no FID column)
+        f.write("".join("s%d\n" % s for s in pick))
+    with open(str(tmp_path / "rm_hdr.txt"), "w") as f:            # header line naming the columns
+        f.write("#IID\tNOTE\n" + "".join("s%d\tx\n" % s for s in pick[:40]))
+    with open(str(tmp_path / "rm_fam_hdr.txt"), "w") as f:
+        f.write("# a comment\n#FID\tIID\n" + "".join("f%d\ts%d\n" % (s // 3, s) for s in pick[:40]))
+    return prefix
+
+
+def compare(cli, tmp_path, args, exts):
+    ref = T.run_ref(args + ["--threads", "4", "--out", "ref"], str(tmp_path))
+    got = run_cli(cli, args + ["--out", "hip"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout[-1500:]
+    assert got.returncode == 0, got.stdout[-1500:]
+    for e in exts:
+        a, b = str(tmp_path / ("ref" + e)), str(tmp_path / ("hip" + e))
+        assert os.path.getsize(a) > 20, e
+        assert filecmp.cmp(a, b, shallow=False), (e, " ".join(args))
+    return ref, got
+
+
+PRUNE = ["--indep-pairwise", "60kb", "0.3", "--bad-ld"]
+CASES = [
+    (["--bfile", "d", "--chr", "1,3"] + PRUNE, None),
+    (["--bfile", "d", "--chr", "1-2,", "7"] + PRUNE, None),
+    (["--pfile", "d", "--chr", "chr2", "X"] + PRUNE, None),
+    (["--bfile", "d", "--not-chr", "2", "X"] + PRUNE, None),
+    (["--pfile", "d", "--autosome"] + PRUNE, None),
+    (["--bfile", "d", "--extract", "vars.txt"] + PRUNE, "--extract:"),
+    (["--pfile", "d", "--exclude", "vars.txt"] + PRUNE, "--exclude:"),
+    (["--bfile", "d", "--extract", "vars.txt", "--exclude", "vars2.txt", "--chr", "1-3"] + PRUNE, "--exclude:"),
+    (["--bfile", "d", "--keep", "keep_fam.txt"] + PRUNE, "--keep:"),
+    (["--pfile", "d", "--keep", "keep_iid.txt"] + PRUNE, "--keep:"),
+    (["--pfile", "d", "--remove", "rm_hdr.txt"] + PRUNE, "--remove:"),
+    (["--bfile", "d", "--remove", "rm_fam_hdr.txt", "--keep", "keep_fam.txt", "--not-chr", "X"] + PRUNE, "--remove:"),
+]
+
+
+@pytest.mark.parametrize("args,log_key", CASES)
+def test_filters_in_front_of_the_prune(gpu_pkg, cli, tmp_path, args, log_key):
+    assert T.have_ref()
+    fileset(tmp_path)
+    ref, got = compare(cli, tmp_path, args, [".prune.in", ".prune.out"])
+    if log_key:
+        want = [l.strip() for l in ref.stdout.split("\n") if l.startswith(log_key)]
+        assert want and want[0] in got.stdout, (want, got.stdout[-600:])
+
+
+def test_filters_in_front_of_the_r2_table_and_clump(gpu_pkg, cli, tmp_path):
+    assert T.have_ref()
+    fileset(tmp_path, with_x=False)
+    compare(cli, tmp_path, ["--bfile", "d", "--chr", "2-7", "--exclude", "vars2.txt", "--keep", "keep_fam.txt", "--r2-unphased", "--ld-window-kb", "40",
+                            "--ld-window-r2", "0.1"], [".vcor"])
+    import test_clump as TC
+    TC.write_report(str(tmp_path / "assoc.txt"), 1200, 5, sig_rate=0.1)
+    compare(cli, tmp_path, ["--pfile", "d", "--extract", "vars.txt", "--remove", "rm_hdr.txt", "--clump", "assoc.txt", "--clump-unphased", "--clump-r2", "0.2",
+                            "--clump-kb", "100", "--clump-p1", "0.01"], [".clumps"])
