@@ -398,6 +398,9 @@ struct Args {
   // --keep / --remove (sample ID lists: "FID IID", "IID", or a #FID / #IID header line)
   std::vector<std::string> chr_keep, chr_drop;
   bool autosome = false;
+  // --maf / --max-maf (nonmajor-allele frequency over the founders) and --geno (missing-call rate over the samples), as the
+  // reference enforces them (EnforceFreqConstraints plink2_filter.cc:3791, EnforceGenoThresh :3498); 0 / 1 / 1 = not given
+  double min_maf = 0.0, max_maf = 1.0, geno = 1.0;
   std::vector<std::string> extract_files, exclude_files, keep_files, remove_files;
   // --ld-snp / --ld-snps / --ld-snp-list (plink2.cc:7966-8003): the table's row variants.  ld_snps: (first, second) ID pairs,
   // second empty for a single ID, otherwise the range first..second in file order
@@ -669,6 +672,30 @@ Args parse_args(int argc, char** argv) {
       }
     } else if (f == "--autosome") {
       A.autosome = true;
+    } else if ((f == "--maf") || (f == "--max-maf") || (f == "--geno")) {  // plink2.cc:8690-8742, 8745-8790, 6487-6516
+      double d = (f == "--maf") ? 0.01 : 0.1;
+      if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+        const std::string v = argv[++i];
+        const char* endp;
+        if (!scan_double_plink(v.c_str(), &d, &endp) || *endp) {
+          if (*endp == ':' || !((v[0] >= '0' && v[0] <= '9') || v[0] == '.')) {
+            die(9, "Error: %s modifiers ('%s') are not supported by plink2-hip.\n", f.c_str(), v.c_str());
+          }
+          die(5, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
+        }
+        if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+          die(9, "Error: %s modifiers ('%s') are not supported by plink2-hip.\n", f.c_str(), argv[i + 1]);
+        }
+        if (d < 0.0) {
+          die(5, "Error: %s argument '%s' too small (must be >= 0).\n", f.c_str(), v.c_str());
+        }
+        if ((f == "--max-maf") ? (d >= 1.0) : (d > 1.0)) {
+          die(5, "Error: %s argument '%s' too large (must be %s 1).\n", f.c_str(), v.c_str(), (f == "--max-maf") ? "<" : "<=");
+        }
+      } else if (f == "--max-maf") {
+        die(5, "Error: --max-maf requires a value.\n");
+      }
+      ((f == "--maf") ? A.min_maf : ((f == "--max-maf") ? A.max_maf : A.geno)) = d;
     } else if ((f == "--extract") || (f == "--exclude") || (f == "--keep") || (f == "--remove")) {
       std::vector<std::string>& dst = (f == "--extract") ? A.extract_files : ((f == "--exclude") ? A.exclude_files : ((f == "--keep") ? A.keep_files : A.remove_files));
       while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
@@ -2204,6 +2231,46 @@ void load_sample_id_list(const std::string& path, const char* flag, std::vector<
   }
 }
 
+// Genotype counts of rows for --maf / --max-maf / --geno: per row the hom-REF / het / hom-ALT calls among the founders and the
+// missing calls among all kept samples.  m_f / m_s: one bit pair (01) per founder / kept sample, 32 samples per word.
+struct RowCounts {
+  uint32_t ref2, het, alt2;  // founders
+  uint32_t missing;          // kept samples
+};
+void count_rows(const uint8_t* rows, uint64_t stride, uint32_t n_rows, bool bed, uint32_t raw_sample_ct, const std::vector<uint64_t>& m_f,
+                const std::vector<uint64_t>& m_s, RowCounts* out) {
+  const uint64_t kLo = 0x5555555555555555ull;
+  const uint64_t row_bytes = (static_cast<uint64_t>(raw_sample_ct) + 3) / 4;
+  const size_t words = m_f.size();
+  for (uint32_t r = 0; r < n_rows; ++r) {
+    const uint8_t* row = rows + static_cast<uint64_t>(r) * stride;
+    uint32_t c00 = 0, c01 = 0, c10 = 0, miss = 0;
+    for (size_t w = 0; w < words; ++w) {
+      uint64_t x = 0;
+      const uint64_t left = row_bytes - 8 * w;
+      memcpy(&x, row + 8 * w, (left < 8) ? left : 8);
+      const uint64_t lo = x & kLo, hi = (x >> 1) & kLo;
+      const uint64_t b00 = ~(lo | hi) & kLo, b01 = lo & ~hi, b10 = hi & ~lo, b11 = lo & hi;
+      c00 += static_cast<uint32_t>(__builtin_popcountll(b00 & m_f[w]));
+      c01 += static_cast<uint32_t>(__builtin_popcountll(b01 & m_f[w]));
+      c10 += static_cast<uint32_t>(__builtin_popcountll(b10 & m_f[w]));
+      miss += static_cast<uint32_t>(__builtin_popcountll((bed ? b01 : b11) & m_s[w]));
+    }
+    if (bed) {  // 00 hom-ALT, 01 missing, 10 het, 11 hom-REF (pgenlib_read.cc:2157)
+      uint32_t c11 = 0;
+      for (size_t w = 0; w < words; ++w) {
+        uint64_t x = 0;
+        const uint64_t left = row_bytes - 8 * w;
+        memcpy(&x, row + 8 * w, (left < 8) ? left : 8);
+        c11 += static_cast<uint32_t>(__builtin_popcountll(x & (x >> 1) & kLo & m_f[w]));
+      }
+      out[r] = {c11, c10, c00, miss};
+    } else {    // 00 hom-REF, 01 het, 10 hom-ALT, 11 missing
+      out[r] = {c00, c01, c10, miss};
+    }
+  }
+}
+
 // Everything the commands share: the parsed command line, the variant and sample tables, the open genotype file and the
 // included-variant index (chromosome 0 stripped where the reference strips it).  load_inputs() fills it; run_r2() (the
 // --r2-unphased outputs and --clump) and run_prune() (--indep-pairwise / --indep-pairphase) consume it.
@@ -2213,6 +2280,7 @@ struct Session {
   Variants V;
   std::thread t_hip;  // HIP runtime start-up, beside the file parsing; joined where the first engine is created, or on the way out
   std::vector<uint8_t> is_founder, sex;  // (a sample --keep / --remove drops is no founder from here on)
+  std::vector<uint8_t> sample_kept;      // empty: no sample filter
   uint32_t raw_sample_ct = 0, founder_ct = 0, raw_variant_ct = 0;
   bool is_bed = false;
   std::string gpath;
@@ -2293,6 +2361,7 @@ void load_inputs(Session& S, int argc, char** argv) {
     for (size_t sx = 0; sx < in.size(); ++sx) {
       S.is_founder[sx] = static_cast<uint8_t>(S.is_founder[sx] && in[sx]);
     }
+    S.sample_kept = in;
   }
   t_variants.join();
   S.t_parse = now_s() - t_begin;
@@ -2357,6 +2426,124 @@ void load_inputs(Session& S, int argc, char** argv) {
   }
   const bool chr_filter = (!A.chr_keep.empty()) || (!A.chr_drop.empty()) || A.autosome;
   uint32_t after_extract = 0, after_exclude = 0;
+  // --geno / --maf / --max-maf need genotype counts before the variant list is final: one multi-threaded pass over the rows of
+  // the variants the table filters leave (host popcounts; the rows are read again when they go to the device)
+  std::vector<uint8_t> drop_by_counts;
+  if ((A.min_maf != 0.0) || (A.max_maf != 1.0) || (A.geno != 1.0)) {
+    std::unordered_map<std::string, uint8_t> chr_state;  // 1 = filtered out by chromosome
+    std::vector<uint32_t> todo;
+    for (uint32_t v = 0; v < raw_variant_ct; ++v) {
+      auto it = chr_state.find(V.chrom[v]);
+      if (it == chr_state.end()) {
+        const std::string& cur = V.chrom[v];
+        const int code = chrom_code(cur);
+        const bool out = chr_filter && (((!A.chr_keep.empty()) && !chrom_listed(A.chr_keep, cur)) || ((!A.chr_drop.empty()) && chrom_listed(A.chr_drop, cur)) ||
+                                         (A.autosome && !((code >= 1) && (code <= 22))));
+        bool zero = false;
+        const int cls = chrom_class(cur, A.allow_extra_chr, &zero);
+        if ((!out) && (cls >= 3)) {
+          die(9, "Error: --maf / --max-maf / --geno on chrX, chrY or MT ('%s') are not supported by plink2-hip: filter them out (--autosome, --chr) or pre-filter with plink2.\n", cur.c_str());
+        }
+        it = chr_state.emplace(cur, static_cast<uint8_t>(out)).first;
+      }
+      if (it->second || ((!A.extract_files.empty()) && !extract_ids.count(V.id[v])) || ((!A.exclude_files.empty()) && exclude_ids.count(V.id[v]))) {
+        continue;
+      }
+      if (V.alt_ct[v] > 1) {
+        die(9, "Error: --maf / --max-maf / --geno with multiallelic variants ('%s') are not supported by plink2-hip.\n", V.id[v].c_str());
+      }
+      todo.push_back(v);
+    }
+    const size_t words = (static_cast<size_t>(raw_sample_ct) + 31) / 32;
+    std::vector<uint64_t> m_f(words, 0), m_s(words, 0);
+    uint32_t kept_samples = 0;
+    for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+      if (S.sample_kept.empty() || S.sample_kept[sx]) {
+        m_s[sx >> 5] |= 1ull << (2 * (sx & 31));
+        ++kept_samples;
+      }
+      if (is_founder[sx]) {
+        m_f[sx >> 5] |= 1ull << (2 * (sx & 31));
+      }
+    }
+    std::vector<RowCounts> counts(todo.size());
+    const bool bed = (S.storage_mode == 0x01);
+    const uint32_t nthreads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    if (S.direct_rows) {
+      std::atomic<size_t> next(0);
+      const size_t kTask = 2048;
+      std::vector<std::thread> pool;
+      for (uint32_t t = 0; t < nthreads; ++t) {
+        pool.emplace_back([&]() {
+          for (size_t q0 = next.fetch_add(kTask); q0 < todo.size(); q0 = next.fetch_add(kTask)) {
+            const size_t q1 = std::min(todo.size(), q0 + kTask);
+            for (size_t q = q0; q < q1; ++q) {
+              count_rows(S.direct_rows + static_cast<uint64_t>(todo[q]) * S.rec_bytes, S.rec_bytes, 1, bed, raw_sample_ct, m_f, m_s, &counts[q]);
+            }
+          }
+        });
+      }
+      for (std::thread& th : pool) {
+        th.join();
+      }
+    } else {
+      // variable-width records: decode runs of file-consecutive variants (all host threads), then count them
+      const uint32_t max_run = std::max<uint32_t>(1, static_cast<uint32_t>((256ull << 20) / std::max<uint64_t>(S.rec_bytes, 1)));
+      std::vector<uint8_t> decoded;
+      for (size_t q0 = 0; q0 < todo.size();) {
+        uint32_t run = 1;
+        while ((q0 + run < todo.size()) && (todo[q0 + run] == todo[q0] + run) && (run < max_run)) {
+          ++run;
+        }
+        decoded.resize(static_cast<size_t>(run) * S.rec_bytes);
+        if (ldp_pgen_read(pg, todo[q0], run, decoded.data(), S.rec_bytes, 0)) {
+          die(3, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+        }
+        std::atomic<uint32_t> next(0);
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < nthreads; ++t) {
+          pool.emplace_back([&]() {
+            for (uint32_t r0 = next.fetch_add(256); r0 < run; r0 = next.fetch_add(256)) {
+              const uint32_t n = std::min(256u, run - r0);
+              count_rows(decoded.data() + static_cast<uint64_t>(r0) * S.rec_bytes, S.rec_bytes, n, bed, raw_sample_ct, m_f, m_s, &counts[q0 + r0]);
+            }
+          });
+        }
+        for (std::thread& th : pool) {
+          th.join();
+        }
+        q0 += run;
+      }
+    }
+    drop_by_counts.assign(raw_variant_ct, 0);
+    uint32_t geno_removed = 0, freq_removed = 0;
+    const uint32_t missing_max = static_cast<uint32_t>(static_cast<int32_t>(A.geno * (1 + kSmallEpsilon) * static_cast<double>(kept_samples)));
+    const double min_maf = A.min_maf * (1.0 - kSmallEpsilon), max_maf = A.max_maf * (1.0 + kSmallEpsilon);
+    for (size_t q = 0; q < todo.size(); ++q) {
+      const RowCounts& c = counts[q];
+      if ((A.geno != 1.0) && (c.missing > missing_max)) {
+        drop_by_counts[todo[q]] = 1;
+        ++geno_removed;
+        continue;
+      }
+      if ((A.min_maf != 0.0) || (A.max_maf != 1.0)) {
+        const uint64_t ref_ct = 2ull * c.ref2 + c.het, alt_ct = 2ull * c.alt2 + c.het, tot = ref_ct + alt_ct;
+        const double ref_freq = tot ? (static_cast<double>(ref_ct) * (1.0 / static_cast<double>(tot))) : 0.5;  // plink2_filter.cc:2137-2147
+        const double nonref_freq = 1.0 - ref_freq;
+        const double typed = (nonref_freq < ref_freq) ? nonref_freq : ref_freq;  // GetTypedFreq, nonmajor mode, two alleles (:3715-3723)
+        if (((A.min_maf != 0.0) && (typed < min_maf)) || ((A.max_maf < 1.0) && (typed > max_maf))) {
+          drop_by_counts[todo[q]] = 1;
+          ++freq_removed;
+        }
+      }
+    }
+    if (A.geno != 1.0) {
+      logprintf("--geno: %u variant%s removed due to missing genotype data.\n", geno_removed, (geno_removed == 1) ? "" : "s");
+    }
+    if ((A.min_maf != 0.0) || (A.max_maf != 1.0)) {
+      logprintf("%u variant%s removed due to allele frequency threshold(s)\n(--maf/--max-maf/--mac/--max-mac).\n", freq_removed, (freq_removed == 1) ? "" : "s");
+    }
+  }
   {
     std::unordered_set<std::string> seen_chr;
     std::string cur;
@@ -2397,6 +2584,9 @@ void load_inputs(Session& S, int argc, char** argv) {
         continue;
       }
       ++after_exclude;
+      if ((!drop_by_counts.empty()) && drop_by_counts[v]) {
+        continue;
+      }
       if (zero && (A.have_prune || (A.r2_table && !A.r2_inter))) {  // (the all-pairs modes keep chromosome 0)
         ++skipped;
         continue;

@@ -175,6 +175,8 @@ def one_case(cli, ref, rng, idx, tmp, execute=True, mode="all"):
                 f.write("".join(("s%d s%d\n" % (s, s)) if use_bed else ("s%d\n" % s) for s in keep))
             inp = inp + ["--keep", "keep.txt"]
             founders = len(keep)
+    if rng.random() < 0.2:
+        inp = inp + [str(rng.choice(["--maf", "--geno"])), str(rng.choice([0.01, 0.02, 0.05, 0.1, 0.3]))]
     kind = rng.random()
     if kind < 0.12:
         # --clump on a random report (unknown IDs, repeated lines, odd p-value spellings come from tests/test_clump.py)

@@ -94,3 +94,40 @@ def test_filters_in_front_of_the_r2_table_and_clump(gpu_pkg, cli, tmp_path):
     TC.write_report(str(tmp_path / "assoc.txt"), 1200, 5, sig_rate=0.1)
     compare(cli, tmp_path, ["--pfile", "d", "--extract", "vars.txt", "--remove", "rm_hdr.txt", "--clump", "assoc.txt", "--clump-unphased", "--clump-r2", "0.2",
                             "--clump-kb", "100", "--clump-p1", "0.01"], [".clumps"])
+
+
+COUNT_CASES = [
+    (["--bfile", "d", "--maf", "0.05"] + PRUNE, "removed due to allele frequency"),
+    (["--pfile", "d", "--maf"] + PRUNE, "removed due to allele frequency"),
+    (["--bfile", "d", "--geno", "0.02"] + PRUNE, "--geno:"),
+    (["--pfile", "d", "--geno", "0.017", "--maf", "0.1", "--max-maf", "0.4"] + PRUNE, "removed due to allele frequency"),
+    (["--bfile", "d", "--keep", "keep_fam.txt", "--geno", "0.02", "--maf", "0.03", "--chr", "1-3"] + PRUNE, "--geno:"),
+    (["--pfile", "v", "--maf", "0.2", "--geno"] + PRUNE, "--geno:"),   # variable-width records: decoded for the counts
+]
+
+
+@pytest.mark.parametrize("args,log_key", COUNT_CASES)
+def test_count_based_filters(gpu_pkg, cli, tmp_path, args, log_key):
+    """--maf / --max-maf (founders' nonmajor-allele frequency) and --geno (kept samples' missing-call rate): the thresholds with
+    the reference's epsilons, on data whose frequencies and missing rates straddle them."""
+    assert T.have_ref()
+    fileset(tmp_path, with_x=False)
+    if "v" in args:
+        mk = T.run_ref(["--pfile", "d", "--make-pgen", "--out", "v"], str(tmp_path))
+        assert mk.returncode == 0, mk.stdout
+    ref, got = compare(cli, tmp_path, args, [".prune.in", ".prune.out"])
+    want = [l.strip() for l in ref.stdout.split("\n") if log_key in l]
+    assert want and want[0] in got.stdout, (want, got.stdout[-800:])
+    n_in = len(open(str(tmp_path / "ref.prune.in")).read().split())
+    n_out = len(open(str(tmp_path / "ref.prune.out")).read().split())
+    assert 50 < n_in + n_out < 1195   # the filters removed something and left something
+
+
+def test_count_based_filters_refuse_what_they_do_not_cover(gpu_pkg, cli, tmp_path):
+    fileset(tmp_path)
+    r = run_cli(cli, ["--bfile", "d", "--maf", "0.05"] + PRUNE, str(tmp_path))
+    assert r.returncode == 9 and "chrX" in r.stdout
+    r = run_cli(cli, ["--bfile", "d", "--maf", "0.05:minor"] + PRUNE, str(tmp_path))
+    assert r.returncode == 9
+    r = run_cli(cli, ["--bfile", "d", "--maf", "1.5"] + PRUNE, str(tmp_path))
+    assert r.returncode == 5
