@@ -401,6 +401,7 @@ struct Args {
   // --maf / --max-maf (nonmajor-allele frequency over the founders) and --geno (missing-call rate over the samples), as the
   // reference enforces them (EnforceFreqConstraints plink2_filter.cc:3791, EnforceGenoThresh :3498); 0 / 1 / 1 = not given
   double min_maf = 0.0, max_maf = 1.0, geno = 1.0;
+  uint32_t max_alleles = 0xffffffffu;  // --max-alleles N (applied while the variant table loads, LoadPvar)
   std::vector<std::string> extract_files, exclude_files, keep_files, remove_files;
   // --ld-snp / --ld-snps / --ld-snp-list (plink2.cc:7966-8003): the table's row variants.  ld_snps: (first, second) ID pairs,
   // second empty for a single ID, otherwise the range first..second in file order
@@ -670,6 +671,15 @@ Args parse_args(int argc, char** argv) {
       if (dst.empty()) {
         die(5, "Error: %s requires at least one value.\n", f.c_str());
       }
+    } else if (f == "--max-alleles") {  // plink2.cc:9340-9360
+      need(i, 1, "--max-alleles");
+      const std::string v = argv[++i];
+      char* endp;
+      const unsigned long n = strtoul(v.c_str(), &endp, 10);
+      if (v.empty() || *endp || (n < 2) || (n > 0x7fffffffUL)) {
+        die(5, "Error: Invalid --max-alleles argument '%s'.\n", v.c_str());
+      }
+      A.max_alleles = static_cast<uint32_t>(n);
     } else if (f == "--autosome") {
       A.autosome = true;
     } else if ((f == "--maf") || (f == "--max-maf") || (f == "--geno")) {  // plink2.cc:8690-8742, 8745-8790, 6487-6516
@@ -2449,6 +2459,9 @@ void load_inputs(Session& S, int argc, char** argv) {
       if (it->second || ((!A.extract_files.empty()) && !extract_ids.count(V.id[v])) || ((!A.exclude_files.empty()) && exclude_ids.count(V.id[v]))) {
         continue;
       }
+      if (static_cast<uint32_t>(V.alt_ct[v]) + 1 > A.max_alleles) {
+        continue;
+      }
       if (V.alt_ct[v] > 1) {
         die(9, "Error: --maf / --max-maf / --geno with multiallelic variants ('%s') are not supported by plink2-hip.\n", V.id[v].c_str());
       }
@@ -2573,7 +2586,7 @@ void load_inputs(Session& S, int argc, char** argv) {
                     (A.autosome && !((code >= 1) && (code <= 22)));
         }
       }
-      if (chr_out) {
+      if (chr_out || (static_cast<uint32_t>(V.alt_ct[v]) + 1 > A.max_alleles)) {
         continue;
       }
       if ((!A.extract_files.empty()) && !extract_ids.count(V.id[v])) {
