@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Pair-kernel counters of one synthetic shape on the GPU box: tools/pair_counters.py SAMPLES VARIANTS MISSING_RATE WINDOW_KB R2 [SPACING_BP]
+(candidate pairs, kernel milliseconds, block products, product k-steps run and skipped).  Used for profiles/r02_experiments.md."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
