@@ -409,7 +409,7 @@ struct Args {
   std::string ld_snp_list;
   // --clump (InitClump, plink2_ld.cc:62-78; parsing plink2.cc:4960-5120)
   bool have_clump = false;
-  std::string clump_file;
+  std::vector<std::string> clump_files;  // one or more reports (plink2.cc:4861-4958: comma- or space-separated)
   bool clump_unphased = false;
   bool clump_no_test = false;
   std::vector<std::string> clump_id_field, clump_p_field, clump_test_field, clump_test;
@@ -599,10 +599,20 @@ Args parse_args(int argc, char** argv) {
       A.have_r2 = true;
     } else if (f == "--clump") {  // plink2.cc:4861-4958
       need(i, 1, "--clump");
-      if ((i + 2 < argc) && (argv[i + 2][0] != '-')) {
-        die(9, "Error: plink2-hip's --clump takes one report file and the default column set.\n");
+      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+        const std::string arg = argv[++i];
+        if ((arg == "zs") || (arg.compare(0, 5, "cols=") == 0)) {
+          die(9, "Error: the '%s' modifier of --clump is not supported by plink2-hip.\n", arg.c_str());
+        }
+        size_t p0 = 0;
+        while (p0 <= arg.size()) {
+          const size_t p1 = std::min(arg.find(',', p0), arg.size());
+          if (p1 > p0) {
+            A.clump_files.push_back(arg.substr(p0, p1 - p0));
+          }
+          p0 = p1 + 1;
+        }
       }
-      A.clump_file = argv[++i];
       A.have_clump = true;
     } else if (f == "--clump-unphased") {
       A.clump_unphased = true;
@@ -1663,7 +1673,8 @@ struct ClumpData {
   // per dataset variant (index into the caller's included-variant list)
   std::vector<double> best_ln;                // lowest ln p among the lines at or below the load threshold; 0 without one
   std::vector<uint32_t> nonsig;               // lines above every bin boundary
-  std::vector<std::vector<uint8_t>> entries;  // one per loaded line: (bin << 1) | (ln p > ln p2)
+  std::vector<std::vector<uint16_t>> entries; // one per loaded line, in the order read (last report first): (file << 4) | (bin << 1) | (ln p > ln p2)
+  std::vector<uint16_t> best_file;            // report (1-based) the best p-value came from; ties go to the first report
   std::vector<uint8_t> observed;
   std::vector<std::string> missing_ids;       // top (p <= p1) IDs absent from the dataset
 };
@@ -1681,7 +1692,8 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
   const uint32_t variant_ct = static_cast<uint32_t>(inc.size());
   D->best_ln.assign(variant_ct, 0.0);
   D->nonsig.assign(variant_ct, 0);
-  D->entries.assign(variant_ct, std::vector<uint8_t>());
+  D->entries.assign(variant_ct, std::vector<uint16_t>());
+  D->best_file.assign(variant_ct, 1);
   D->observed.assign(variant_ct, 0);
   // ID -> included-variant index; kDup marks IDs the dataset holds more than once (an error only when the report names one)
   const uint32_t kDup = 0xffffffffu;
@@ -1695,143 +1707,150 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
   }
   const double ln_p1 = A.clump_ln_p1, ln_p2 = A.clump_ln_p2;
   const double load_thresh = std::max(std::max(ln_p1, ln_p2), kClumpLnBins[3]);
-  const std::string text = slurp(A.clump_file);
-  const char* p = text.c_str();
-  const char* const end = p + text.size();
-  size_t line_idx = 0;
-  auto next_line = [&](const char** ls, const char** le) {
-    if (p >= end) {
-      return false;
-    }
-    ++line_idx;
-    *ls = p;
-    const char* nl = static_cast<const char*>(memchr(p, '\n', end - p));
-    *le = nl ? nl : end;
-    p = nl ? nl + 1 : end;
-    while ((*ls < *le) && ((**ls == ' ') || (**ls == '\t'))) {
-      ++*ls;
-    }
-    return true;
-  };
-  auto tokens_of = [](const char* ls, const char* le, std::vector<std::pair<const char*, uint32_t>>* out) {
-    out->clear();
-    while (ls < le) {
-      while ((ls < le) && ((*ls == ' ') || (*ls == '\t') || (*ls == '\r'))) {
-        ++ls;
-      }
-      const char* t0 = ls;
-      while ((ls < le) && (*ls != ' ') && (*ls != '\t') && (*ls != '\r')) {
-        ++ls;
-      }
-      if (ls > t0) {
-        out->emplace_back(t0, static_cast<uint32_t>(ls - t0));
-      }
-    }
-  };
-  const char* ls;
-  const char* le;
-  std::vector<std::pair<const char*, uint32_t>> toks;
-  // The first nonblank line is the header.  (The reference means to skip '##' lines first, but its test compares three
-  // bytes -- "##" and a terminator, plink2_ld.cc:7680 -- which no line of a text file matches; a '##' line is
-  // therefore read as the header there, and here.)
-  do {
-    if (!next_line(&ls, &le)) {
-      die(3, "Error: %s is empty.\n", A.clump_file.c_str());
-    }
-  } while (ls == le);  // (the reference's text reader skips blank lines)
-  if (*ls == '#') {
-    ++ls;
+  if (A.clump_files.size() > 4000) {
+    die(9, "Error: too many --clump reports.\n");
   }
-  tokens_of(ls, le, &toks);
-  // column search (SearchHeaderLine, plink2_cmdline.cc:4270): per field a priority list of names
-  std::vector<std::string> want[3];
-  want[0] = A.clump_id_field.empty() ? std::vector<std::string>{"ID", "SNP"} : A.clump_id_field;
-  if (!A.clump_no_test) {
-    want[1] = A.clump_test_field.empty() ? std::vector<std::string>{"TEST"} : A.clump_test_field;
-  }
-  want[2] = A.clump_p_field.empty() ? std::vector<std::string>{"P"} : A.clump_p_field;
-  int col[3] = {-1, -1, -1};
-  size_t prio[3] = {~size_t(0), ~size_t(0), ~size_t(0)};
-  for (size_t c = 0; c < toks.size(); ++c) {
-    const std::string name(toks[c].first, toks[c].second);
-    for (int t = 0; t < 3; ++t) {
-      for (size_t q = 0; q < want[t].size(); ++q) {
-        if (want[t][q] == name && prio[t] >= q) {
-          if (prio[t] == q) {
-            die(3, "Error: Duplicate column header '%s' in --clump file.\n", name.c_str());
+  for (size_t file_idx1 = A.clump_files.size(); file_idx1; --file_idx1) {  // last report first (plink2_ld.cc:7644-7654)
+    const std::string& fname = A.clump_files[file_idx1 - 1];
+    const std::string text = slurp(fname);
+    const char* p = text.c_str();
+    const char* const end = p + text.size();
+    size_t line_idx = 0;
+    auto next_line = [&](const char** ls, const char** le) {
+      if (p >= end) {
+        return false;
+      }
+      ++line_idx;
+      *ls = p;
+      const char* nl = static_cast<const char*>(memchr(p, '\n', end - p));
+      *le = nl ? nl : end;
+      p = nl ? nl + 1 : end;
+      while ((*ls < *le) && ((**ls == ' ') || (**ls == '\t'))) {
+        ++*ls;
+      }
+      return true;
+    };
+    auto tokens_of = [](const char* ls, const char* le, std::vector<std::pair<const char*, uint32_t>>* out) {
+      out->clear();
+      while (ls < le) {
+        while ((ls < le) && ((*ls == ' ') || (*ls == '\t') || (*ls == '\r'))) {
+          ++ls;
+        }
+        const char* t0 = ls;
+        while ((ls < le) && (*ls != ' ') && (*ls != '\t') && (*ls != '\r')) {
+          ++ls;
+        }
+        if (ls > t0) {
+          out->emplace_back(t0, static_cast<uint32_t>(ls - t0));
+        }
+      }
+    };
+    const char* ls;
+    const char* le;
+    std::vector<std::pair<const char*, uint32_t>> toks;
+    // The first nonblank line is the header.  (The reference means to skip '##' lines first, but its test compares three
+    // bytes -- "##" and a terminator, plink2_ld.cc:7680 -- which no line of a text file matches; a '##' line is
+    // therefore read as the header there, and here.)
+    do {
+      if (!next_line(&ls, &le)) {
+        die(3, "Error: %s is empty.\n", fname.c_str());
+      }
+    } while (ls == le);  // (the reference's text reader skips blank lines)
+    if (*ls == '#') {
+      ++ls;
+    }
+    tokens_of(ls, le, &toks);
+    // column search (SearchHeaderLine, plink2_cmdline.cc:4270): per field a priority list of names
+    std::vector<std::string> want[3];
+    want[0] = A.clump_id_field.empty() ? std::vector<std::string>{"ID", "SNP"} : A.clump_id_field;
+    if (!A.clump_no_test) {
+      want[1] = A.clump_test_field.empty() ? std::vector<std::string>{"TEST"} : A.clump_test_field;
+    }
+    want[2] = A.clump_p_field.empty() ? std::vector<std::string>{"P"} : A.clump_p_field;
+    int col[3] = {-1, -1, -1};
+    size_t prio[3] = {~size_t(0), ~size_t(0), ~size_t(0)};
+    for (size_t c = 0; c < toks.size(); ++c) {
+      const std::string name(toks[c].first, toks[c].second);
+      for (int t = 0; t < 3; ++t) {
+        for (size_t q = 0; q < want[t].size(); ++q) {
+          if (want[t][q] == name && prio[t] >= q) {
+            if (prio[t] == q) {
+              die(3, "Error: Duplicate column header '%s' in --clump file.\n", name.c_str());
+            }
+            prio[t] = q;
+            col[t] = static_cast<int>(c);
           }
-          prio[t] = q;
-          col[t] = static_cast<int>(c);
         }
       }
     }
-  }
-  if ((col[0] < 0) || (col[2] < 0)) {
-    die(7, "Error: --clump requires ID and P columns.\n");
-  }
-  const int last_col = std::max(col[0], std::max(col[1], col[2]));
-  const std::vector<std::string> test_names = A.clump_test.empty() ? std::vector<std::string>{"ADD"} : A.clump_test;
-  while (next_line(&ls, &le)) {
-    if (ls == le) {
-      continue;
+    if ((col[0] < 0) || (col[2] < 0)) {
+      die(7, "Error: --clump requires ID and P columns.\n");
     }
-    tokens_of(ls, le, &toks);
-    if (toks.empty()) {
-      continue;
-    }
-    if (static_cast<int>(toks.size()) <= last_col) {
-      die(7, "Error: Line %zu of %s has fewer tokens than expected.\n", line_idx, A.clump_file.c_str());
-    }
-    if (col[1] >= 0) {
-      const std::string t(toks[col[1]].first, toks[col[1]].second);
-      if (std::find(test_names.begin(), test_names.end(), t) == test_names.end()) {
+    const int last_col = std::max(col[0], std::max(col[1], col[2]));
+    const std::vector<std::string> test_names = A.clump_test.empty() ? std::vector<std::string>{"ADD"} : A.clump_test;
+    while (next_line(&ls, &le)) {
+      if (ls == le) {
         continue;
       }
-    }
-    const std::string ptok(toks[col[2]].first, toks[col[2]].second);
-    double ln_pval;
-    const char* pe = scan_ln(ptok.c_str(), &ln_pval);
-    if (!pe || *pe) {
-      std::string low = ptok;
-      for (char& ch : low) {
-        ch = static_cast<char>(tolower(static_cast<unsigned char>(ch)));
-      }
-      if ((low == "na") || (low == "nan")) {
+      tokens_of(ls, le, &toks);
+      if (toks.empty()) {
         continue;
       }
-      if (ptok == "INF") {  // PLINK 1.x underflow
-        ln_pval = -708.3964185322641;
-      } else {
-        die(7, "Error: Invalid p-value on line %zu of %s.\n", line_idx, A.clump_file.c_str());
+      if (static_cast<int>(toks.size()) <= last_col) {
+        die(7, "Error: Line %zu of %s has fewer tokens than expected.\n", line_idx, fname.c_str());
       }
-    }
-    const std::string id(toks[col[0]].first, toks[col[0]].second);
-    const auto it = by_id.find(id);
-    if (it == by_id.end()) {
-      if (ln_pval <= ln_p1) {
-        D->missing_ids.push_back(id);
+      if (col[1] >= 0) {
+        const std::string t(toks[col[1]].first, toks[col[1]].second);
+        if (std::find(test_names.begin(), test_names.end(), t) == test_names.end()) {
+          continue;
+        }
       }
-      continue;
-    }
-    if (it->second == kDup) {
-      die(7, "Error: --clump variant ID '%s' appears multiple times in main dataset.\n", id.c_str());
-    }
-    const uint32_t k = it->second;
-    if (ln_pval > load_thresh) {
-      if (ln_pval > 0.0) {
-        die(3, "Error: p-value > 1 on line %zu of %s.\n", line_idx, A.clump_file.c_str());
+      const std::string ptok(toks[col[2]].first, toks[col[2]].second);
+      double ln_pval;
+      const char* pe = scan_ln(ptok.c_str(), &ln_pval);
+      if (!pe || *pe) {
+        std::string low = ptok;
+        for (char& ch : low) {
+          ch = static_cast<char>(tolower(static_cast<unsigned char>(ch)));
+        }
+        if ((low == "na") || (low == "nan")) {
+          continue;
+        }
+        if (ptok == "INF") {  // PLINK 1.x underflow
+          ln_pval = -708.3964185322641;
+        } else {
+          die(7, "Error: Invalid p-value on line %zu of %s.\n", line_idx, fname.c_str());
+        }
       }
-      if (ln_pval > kClumpLnBins[3]) {
-        D->nonsig[k] += 1;
-        D->observed[k] = 1;
+      const std::string id(toks[col[0]].first, toks[col[0]].second);
+      const auto it = by_id.find(id);
+      if (it == by_id.end()) {
+        if (ln_pval <= ln_p1) {
+          D->missing_ids.push_back(id);
+        }
+        continue;
       }
-      continue;
+      if (it->second == kDup) {
+        die(7, "Error: --clump variant ID '%s' appears multiple times in main dataset.\n", id.c_str());
+      }
+      const uint32_t k = it->second;
+      if (ln_pval > load_thresh) {
+        if (ln_pval > 0.0) {
+          die(3, "Error: p-value > 1 on line %zu of %s.\n", line_idx, fname.c_str());
+        }
+        if (ln_pval > kClumpLnBins[3]) {
+          D->nonsig[k] += 1;
+          D->observed[k] = 1;
+        }
+        continue;
+      }
+      if (D->best_ln[k] >= ln_pval) {  // (>=: the reports are read last to first, so ties end up with the first one, :7833)
+        D->best_ln[k] = ln_pval;
+        D->best_file[k] = static_cast<uint16_t>(file_idx1);
+      }
+      D->observed[k] = 1;
+      D->entries[k].push_back(static_cast<uint16_t>((file_idx1 << 4) | (clump_bin(ln_pval) << 1) | (ln_pval > ln_p2)));
     }
-    if (D->best_ln[k] >= ln_pval) {
-      D->best_ln[k] = ln_pval;
-    }
-    D->observed[k] = 1;
-    D->entries[k].push_back(static_cast<uint8_t>((clump_bin(ln_pval) << 1) | (ln_pval > ln_p2)));
   }
 }
 
@@ -1857,8 +1876,8 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
     }
     mf.close();
     const size_t n = D.missing_ids.size();
-    logprintf("Warning: %zu top variant ID%s in --clump file missing from main dataset.  ID%s written to %s .\n", n, (n == 1) ? "" : "s",
-              (n == 1) ? "" : "s", path.c_str());
+    logprintf("Warning: %zu top variant ID%s in --clump file%s missing from main dataset.  ID%s written to %s .\n", n, (n == 1) ? "" : "s",
+              (A.clump_files.size() == 1) ? "" : "s", (n == 1) ? "" : "s", path.c_str());
   }
   // observed variants (named by a usable report line) in dataset order, and the index candidates among them:
   // best p <= p1, ranked by (ln p, position in the dataset) (ClumpPvalCmp; plink2_ld.cc:7996-8040)
@@ -2049,7 +2068,10 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
   const std::string path = A.out + ".clumps";
   OutFile f;
   f.open(path, false);
-  std::string buf = "#CHROM\tPOS\tID\tP\tTOTAL\tNONSIG\tS0.05\tS0.01\tS0.001\tS0.0001\tSP2\n";
+  // (several reports: an F column names the report of the index variant's best p-value, and SP2 entries carry theirs)
+  const bool multi = (A.clump_files.size() > 1);
+  std::string buf = multi ? "#CHROM\tPOS\tID\tF\tP\tTOTAL\tNONSIG\tS0.05\tS0.01\tS0.001\tS0.0001\tSP2\n"
+                          : "#CHROM\tPOS\tID\tP\tTOTAL\tNONSIG\tS0.05\tS0.01\tS0.001\tS0.0001\tSP2\n";
   char num[64];
   for (uint32_t r = 0; r < cand_ct; ++r) {
     if (mem_off[r] == mem_off[r + 1]) {
@@ -2064,13 +2086,18 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
     buf += '\t';
     buf += V.id[iv];
     buf += '\t';
+    const uint32_t index_file = D.best_file[obs[io]];
+    if (multi) {
+      buf += std::to_string(index_file);
+      buf += '\t';
+    }
     buf.append(num, format_ln_g6(index_ln, num) - num);
     uint64_t bins[5] = {0, 0, 0, 0, 0};
     for (uint64_t q = mem_off[r]; q < mem_off[r + 1]; ++q) {
       const uint32_t k = obs[members[q]];
       bins[4] += D.nonsig[k];
-      for (uint8_t en : D.entries[k]) {
-        ++bins[en >> 1];
+      for (uint16_t en : D.entries[k]) {
+        ++bins[(en >> 1) & 7];
       }
     }
     --bins[clump_bin(index_ln)];
@@ -2084,15 +2111,23 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
     bool nonempty = false;
     for (uint64_t q = mem_off[r]; q < mem_off[r + 1]; ++q) {
       const uint32_t m = members[q];
-      if (m == io) {
-        continue;
-      }
-      for (uint8_t en : D.entries[obs[m]]) {
-        if (!(en & 1)) {
-          buf += V.id[inc[obs[m]]];
-          buf += ',';
-          nonempty = true;
+      // a member's lines, latest read first (the reference walks its linked list from the head, :7851,9330): report 1's
+      // lines bottom-up, then report 2's, ...; the index variant's own line in its own report is the clump itself
+      const std::vector<uint16_t>& ent = D.entries[obs[m]];
+      for (size_t x = ent.size(); x; --x) {
+        const uint16_t en = ent[x - 1];
+        const uint32_t file = en >> 4;
+        if ((en & 1) || ((m == io) && (file == index_file))) {
+          continue;
         }
+        buf += V.id[inc[obs[m]]];
+        if (multi) {
+          buf += '(';
+          buf += std::to_string(file);
+          buf += ')';
+        }
+        buf += ',';
+        nonempty = true;
       }
     }
     if (nonempty) {

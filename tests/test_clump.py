@@ -130,6 +130,21 @@ def test_clump_column_search_and_test_filter(cli, tmp_path):
     compare_runs(cli, tmp_path, base + ["--clump", "b.txt"])
 
 
+@needs_ref
+@pytest.mark.parametrize("how", ["space", "comma"])
+def test_clump_several_reports_without_ld(cli, tmp_path, how):
+    """Three reports: the F column, ties between reports (the first wins), a variant's lines from other reports in SP2."""
+    m = 900
+    clump_fileset(tmp_path, m, 40, 12)
+    write_report(str(tmp_path / "a.txt"), m, 31)
+    write_report(str(tmp_path / "b.txt"), m, 32, sig_rate=0.1)
+    write_report(str(tmp_path / "c.txt"), m, 31)          # the same p-values as a.txt: every best p-value is a tie
+    files = ["a.txt", "b.txt", "c.txt"] if how == "space" else ["a.txt,b.txt,c.txt"]
+    compare_runs(cli, tmp_path, ["--bfile", "d", "--clump"] + files + ["--clump-unphased", "--clump-kb", "0.001", "--clump-p1", "0.001", "--clump-p2", "0.05"])
+    body = open(str(tmp_path / "hip.clumps")).read().split("\n")
+    assert body[0].split("\t")[3] == "F" and any("(" in l for l in body[1:])
+
+
 def test_clump_flag_rules(cli, tmp_path):
     clump_fileset(tmp_path, 60, 20, 3)
     write_report(str(tmp_path / "a.txt"), 60, 1)
@@ -141,6 +156,18 @@ def test_clump_flag_rules(cli, tmp_path):
     assert r.returncode == 9
     r = run_cli(cli, ["--bfile", "d", "--clump-unphased"], str(tmp_path))
     assert r.returncode == 5
+
+
+@pytest.mark.gpu
+def test_clump_several_reports_match_reference(gpu_pkg, cli, tmp_path):
+    assert T.have_ref()
+    m = 3000
+    clump_fileset(tmp_path, m, 210, 3, spacing=400)
+    write_report(str(tmp_path / "a.txt"), m, 5)
+    write_report(str(tmp_path / "b.txt"), m, 6, sig_rate=0.03)
+    compare_runs(cli, tmp_path, ["--pfile", "d", "--clump", "a.txt", "b.txt", "--clump-unphased", "--clump-r2", "0.3", "--clump-kb", "80"])
+    body = open(str(tmp_path / "hip.clumps")).read().split("\n")[1:-1]
+    assert any(l.split("\t")[-1] != "." for l in body)
 
 
 CLUMP_CASES = [
