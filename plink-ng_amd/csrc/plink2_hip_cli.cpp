@@ -411,6 +411,7 @@ struct Args {
   bool have_clump = false;
   std::vector<std::string> clump_files;  // one or more reports (plink2.cc:4861-4958: comma- or space-separated)
   bool clump_unphased = false;
+  bool clump_allow_overlap = false;
   bool clump_no_test = false;
   std::vector<std::string> clump_id_field, clump_p_field, clump_test_field, clump_test;
   double clump_ln_p1 = 2.3025850929940457 * -4.0 * (1.0 - kSmallEpsilon);
@@ -616,6 +617,8 @@ Args parse_args(int argc, char** argv) {
       A.have_clump = true;
     } else if (f == "--clump-unphased") {
       A.clump_unphased = true;
+    } else if (f == "--clump-allow-overlap") {
+      A.clump_allow_overlap = true;
     } else if ((f == "--clump-p1") || (f == "--clump-p2")) {  // plink2.cc:5015-5046
       need(i, 1, f.c_str());
       const std::string v = argv[++i];
@@ -2024,45 +2027,40 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
   }
 
   // the greedy pass (plink2_ld.cc:8610-8700): candidates in rank order; one already inside a clump is skipped, the
-  // others take every still-unclumped window member above the threshold
-  const uint32_t kNone = 0xffffffffu;
-  std::vector<uint32_t> clump_of(n_obs, kNone);  // -> rank of the clump's index variant
+  // others take every still-unclumped window member above the threshold.  --clump-allow-overlap (:8135-8141,7471-7490): a
+  // member stays available to later clumps -- only index variants leave the pool -- but joining a clump still takes a
+  // candidate off the list of future index variants.
+  std::vector<uint64_t> mem_off(static_cast<size_t>(cand_ct) + 1, 0);
+  std::vector<uint32_t> members;
   uint32_t clump_ct = 0;
-  for (uint32_t r = 0; r < cand_ct; ++r) {
-    const uint32_t o = cand[r];
-    if (clump_of[o] != kNone) {
-      continue;
-    }
-    ++clump_ct;
-    clump_of[o] = r;
-    for (uint64_t q = link_off[o]; q < link_off[o + 1]; ++q) {
-      const uint32_t m = links[q].second;
-      if (clump_of[m] == kNone) {
-        clump_of[m] = r;
+  {
+    std::vector<uint8_t> in_pool(n_obs, 1), may_lead(n_obs, 1);
+    std::vector<uint32_t> cur;
+    for (uint32_t r = 0; r < cand_ct; ++r) {
+      const uint32_t o = cand[r];
+      mem_off[r] = members.size();
+      if (!(A.clump_allow_overlap ? may_lead[o] : in_pool[o])) {
+        continue;
       }
+      ++clump_ct;
+      in_pool[o] = 0;
+      cur.assign(1, o);
+      for (uint64_t q = link_off[o]; q < link_off[o + 1]; ++q) {
+        const uint32_t m = links[q].second;
+        if (in_pool[m]) {
+          cur.push_back(m);
+          may_lead[m] = 0;
+          if (!A.clump_allow_overlap) {
+            in_pool[m] = 0;
+          }
+        }
+      }
+      std::sort(cur.begin(), cur.end());  // members in dataset order (ordered_members, :8936-8970)
+      members.insert(members.end(), cur.begin(), cur.end());
     }
+    mem_off[cand_ct] = members.size();
   }
   logprintf("--clump: %u clump%s formed from %u index candidate%s.\n", clump_ct, (clump_ct == 1) ? "" : "s", cand_ct, (cand_ct == 1) ? "" : "s");
-
-  // members of each clump in dataset order (ordered_members, plink2_ld.cc:8936-8970)
-  std::vector<uint64_t> mem_off(static_cast<size_t>(cand_ct) + 1, 0);
-  for (uint32_t o = 0; o < n_obs; ++o) {
-    if (clump_of[o] != kNone) {
-      ++mem_off[clump_of[o] + 1];
-    }
-  }
-  for (uint32_t r = 0; r < cand_ct; ++r) {
-    mem_off[r + 1] += mem_off[r];
-  }
-  std::vector<uint32_t> members(mem_off[cand_ct]);
-  {
-    std::vector<uint64_t> fill(mem_off.begin(), mem_off.end() - 1);
-    for (uint32_t o = 0; o < n_obs; ++o) {
-      if (clump_of[o] != kNone) {
-        members[fill[clump_of[o]]++] = o;
-      }
-    }
-  }
 
   // <out>.clumps, default columns (plink2_ld.cc:9003-9405): chrom pos | total | bins | sp2
   const std::string path = A.out + ".clumps";

@@ -184,6 +184,12 @@ def one_case(cli, ref, rng, idx, tmp, execute=True, mode="all"):
         TC.write_report(os.path.join(d, "assoc.txt"), m, int(rng.integers(1, 1 << 30)), sig_rate=float(rng.choice([0.02, 0.06, 0.2])))
         args = inp + ["--clump", "assoc.txt", "--clump-unphased", "--clump-r2", str(rng.choice([0, 0.1, 0.5, 0.8])), "--clump-kb", str(rng.choice([1, 10, 250])),
                       "--clump-p1", str(rng.choice(["1e-4", "1e-2", "0.3"])), "--clump-p2", str(rng.choice(["1e-2", "0.05", "1e-6"]))]
+        if rng.random() < 0.4:
+            args.append("--clump-allow-overlap")
+        if rng.random() < 0.3:
+            TC.write_report(os.path.join(d, "assoc2.txt"), m, int(rng.integers(1, 1 << 30)), sig_rate=0.05)
+            k = args.index("assoc.txt")
+            args.insert(k + 1, "assoc2.txt")
         outs = [".clumps"]
     elif kind < 0.6:
         if rng.random() < 0.5:

@@ -152,7 +152,7 @@ def test_clump_flag_rules(cli, tmp_path):
     assert r.returncode == 9 and "--clump-unphased" in r.stdout
     r = run_cli(cli, ["--bfile", "d", "--clump", "a.txt", "--clump-unphased", "--clump-r2", "1.0"], str(tmp_path))
     assert r.returncode == 5 and "Invalid --clump-r2" in r.stdout
-    r = run_cli(cli, ["--bfile", "d", "--clump", "a.txt", "--clump-unphased", "--clump-allow-overlap"], str(tmp_path))
+    r = run_cli(cli, ["--bfile", "d", "--clump", "a.txt", "--clump-unphased", "--clump-range", "genes.txt"], str(tmp_path))
     assert r.returncode == 9
     r = run_cli(cli, ["--bfile", "d", "--clump-unphased"], str(tmp_path))
     assert r.returncode == 5
@@ -177,6 +177,8 @@ CLUMP_CASES = [
     ("bfile", 5000, 150, 0.01, ["--clump-r2", "0.8", "--clump-p1", "1e-3", "--clump-p2", "0.05", "--clump-kb", "1000"]),
     ("pfile", 2500, 97, 0.05, ["--clump-r2", "0", "--clump-kb", "20"]),
     ("pfile", 4000, 1200, 0.002, ["--clump-r2", "0.35", "--clump-p1", "0.05", "--clump-p2", "0.5"]),
+    ("bfile", 3000, 200, 0.01, ["--clump-allow-overlap", "--clump-r2", "0.15", "--clump-p1", "0.01", "--clump-p2", "0.1", "--clump-kb", "100"]),
+    ("pfile", 2500, 120, 0.0, ["--clump-allow-overlap", "--clump-r2", "0.05", "--clump-p1", "0.05", "--clump-kb", "30"]),
 ]
 
 
