@@ -2405,6 +2405,9 @@ void load_inputs(Session& S, int argc, char** argv) {
       S.is_founder[sx] = static_cast<uint8_t>(S.is_founder[sx] && in[sx]);
     }
     S.sample_kept = in;
+    if (std::find(in.begin(), in.end(), 1) == in.end()) {  // plink2.cc:1836-1838
+      die(13, "Error: No samples remaining after main filters.\n");
+    }
   }
   t_variants.join();
   S.t_parse = now_s() - t_begin;
@@ -2657,6 +2660,38 @@ void load_inputs(Session& S, int argc, char** argv) {
   }
   if (!A.exclude_files.empty()) {
     logprintf("--exclude: %u variant%s remaining.\n", after_exclude, (after_exclude == 1) ? "" : "s");
+  }
+  // filters applied while the variant table loads (--autosome / --chr / --not-chr / --max-alleles) that leave nothing:
+  // plink2.cc:1025-1050, kPglRetInconsistentInput, flag names in kLoadFilterLogFlagnames order
+  if ((chr_filter || (A.max_alleles != 0xffffffffu)) && raw_variant_ct) {
+    bool any_loaded = false;
+    std::unordered_map<std::string, uint8_t> chr_state;
+    for (uint32_t v = 0; (v < raw_variant_ct) && !any_loaded; ++v) {
+      auto it = chr_state.find(V.chrom[v]);
+      if (it == chr_state.end()) {
+        const std::string& cur = V.chrom[v];
+        const int code = chrom_code(cur);
+        const bool out = chr_filter && (((!A.chr_keep.empty()) && !chrom_listed(A.chr_keep, cur)) || ((!A.chr_drop.empty()) && chrom_listed(A.chr_drop, cur)) ||
+                                         (A.autosome && !((code >= 1) && (code <= 22))));
+        it = chr_state.emplace(cur, static_cast<uint8_t>(out)).first;
+      }
+      any_loaded = (!it->second) && (static_cast<uint32_t>(V.alt_ct[v]) + 1 <= A.max_alleles);
+    }
+    if (!any_loaded) {
+      std::string flags;
+      for (const char* nm : {A.autosome ? "autosome" : "", A.chr_keep.empty() ? "" : "chr", A.chr_drop.empty() ? "" : "not-chr",
+                             (A.max_alleles != 0xffffffffu) ? "max-alleles" : ""}) {
+        if (*nm) {
+          flags += (flags.empty() ? "--" : " + --");
+          flags += nm;
+        }
+      }
+      die(7, "Error: All %u variant%s in %s excluded by %s.\n", raw_variant_ct, (raw_variant_ct == 1) ? "" : "s", (A.pvar.empty() ? A.bim : A.pvar).c_str(), flags.c_str());
+    }
+  }
+  const bool any_main_filter = chr_filter || (!A.extract_files.empty()) || (!A.exclude_files.empty()) || (!drop_by_counts.empty()) || (A.max_alleles != 0xffffffffu);
+  if (any_main_filter && inc.empty() && (!skipped)) {  // plink2.cc:2484-2487 (kPglRetDegenerateData)
+    die(13, "Error: No variants remaining after main filters.\n");
   }
   if (skipped) {
     logprintf("--%s: Ignoring %u chromosome 0 variant%s.\n", A.have_prune ? (A.pairphase ? "indep-pairphase" : "indep-pairwise") : (A.have_clump ? "clump" : "r2-unphased"), skipped, skipped == 1 ? "" : "s");

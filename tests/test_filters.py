@@ -148,3 +148,20 @@ def test_max_alleles_filter(gpu_pkg, cli, tmp_path, extra):
         assert got.returncode == 9 and "multiallelic" in got.stdout   # count filters with a triallelic site left: refused
         return
     compare(cli, tmp_path, args, [".prune.in", ".prune.out"])
+
+
+def test_filters_that_leave_nothing(gpu_pkg, cli, tmp_path):
+    """kPglRetDegenerateData (exit 13) with the reference's messages."""
+    fileset(tmp_path, with_x=False)
+    open(str(tmp_path / "unknown.txt"), "w").write("rs1 rs2\n")
+    for args, msg in ((["--bfile", "d", "--extract", "unknown.txt"] + PRUNE, "No variants remaining after main filters"),
+                      (["--bfile", "d", "--chr", "21", "--max-alleles", "2"] + PRUNE, "excluded by --chr + --max-alleles."),
+                      (["--bfile", "d", "--chr", "21"] + PRUNE, "excluded by --chr.")):
+        ref = T.run_ref(args + ["--out", "ref"], str(tmp_path))
+        got = run_cli(cli, args + ["--out", "hip"], str(tmp_path))
+        assert ref.returncode == got.returncode and ref.returncode in (7, 13), (ref.returncode, got.returncode, got.stdout[-400:])
+        assert msg in ref.stdout.replace("\n", " ") and msg in got.stdout, (msg, ref.stdout[-300:], got.stdout[-300:])
+    open(str(tmp_path / "nobody.txt"), "w").write("x y\n")
+    ref = T.run_ref(["--bfile", "d", "--keep", "nobody.txt"] + PRUNE + ["--out", "ref"], str(tmp_path))
+    got = run_cli(cli, ["--bfile", "d", "--keep", "nobody.txt"] + PRUNE + ["--out", "hip"], str(tmp_path))
+    assert ref.returncode == got.returncode == 13 and "No samples remaining after main filters" in got.stdout
