@@ -67,7 +67,7 @@ class ldp_counters(ctypes.Structure):
                 ("tile_unit_chunks", ctypes.c_uint64), ("early_exit_unit_chunks", ctypes.c_uint64),
                 ("ms_pair_mfma", ctypes.c_double), ("mfma_block_products", ctypes.c_uint64),
                 ("mfma_product_stages", ctypes.c_uint64), ("mfma_skipped_product_stages", ctypes.c_uint64),
-                ("ms_pair_mfma_general", ctypes.c_double)]
+                ("ms_pair_mfma_general", ctypes.c_double), ("sparse_exact_pairs", ctypes.c_uint64)]
 
     def asdict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

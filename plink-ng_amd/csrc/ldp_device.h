@@ -137,7 +137,8 @@ struct PairKernelArgs {
   uint32_t n_mf_wgs;
   uint32_t n_local;              // rows in `planes`
   uint32_t mf_active;            // the launch also carries matrix-pipe work items
-  const uint32_t* any_missing;
+  const uint32_t* any_missing;   // 0: complete data; otherwise the largest number of missing calls in a row converted so far
+  uint32_t sparse_max;           // prune runs: up to this many missing calls per row pair_mfma_kernel keeps the launch (4.1d); 0 = never
 };
 
 struct PrepareArgs {

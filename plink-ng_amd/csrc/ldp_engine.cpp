@@ -483,6 +483,20 @@ int checkpoint_fractions(double r2_param, double* frac) {
 // ("parallelogram") for every four block distances the band reaches; wave items are packed four to a workgroup as
 // long as the union of their row-blocks fits the LDS ring (J quads x distance pairs for wide bands, four
 // neighbouring J pairs for narrow ones).
+// Rows with at most this many missing calls leave a prune launch with pair_mfma_kernel and its interval epilogue (DESIGN.md
+// 4.1d): 0.3 % of the samples by default (beyond that the pairs the intervals leave open cost more than the six-product
+// kernel); LDP_PAIR_SPARSE=0 turns the path off, LDP_DEBUG_SPARSE_FRAC sets the fraction.
+uint32_t sparse_missing_limit(uint32_t founder_ct) {
+  // (read per launch, like LDP_EARLY_EXIT: the tests switch it between engines of one process)
+  const char* off = getenv("LDP_PAIR_SPARSE");
+  if (off && (strcmp(off, "0") == 0)) {
+    return 0;
+  }
+  const char* f = getenv("LDP_DEBUG_SPARSE_FRAC");
+  const double frac = f ? atof(f) : 0.003;
+  return static_cast<uint32_t>(frac * static_cast<double>(founder_ct));
+}
+
 bool mfma_requested() {
   const char* m = getenv("LDP_PAIR_MFMA");
   return !(m && (strcmp(m, "0") == 0));
@@ -1311,6 +1325,7 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.n_local = e->local_ct;
   A.mf_active = 0;
   A.any_missing = nullptr;
+  A.sparse_max = 0;
 }
 
 // A new load epoch begins (variants are being loaded again): whatever the pair streams still run belongs to the
@@ -1356,6 +1371,7 @@ int launch_group(ldp_engine* e, uint32_t gi) {
     A.any_missing = e->d_any_missing + 1 + gi;
     A.mf_wgs = e->d_mf_wgs + g.mf_first;
     A.n_mf_wgs = g.mf_ct;
+    A.sparse_max = ((A.mf_active == 2) && !A.stats) ? sparse_missing_limit(e->P.founder_ct) : 0;
   }
   hipError_t krc = launch_pair_tiles(A, e->max_rows, ps, g.ev);
   if (krc != hipSuccess) {
@@ -1617,6 +1633,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   e->ctr.mfma_block_products = e->mf_enabled ? e->mf_products : 0;
   e->ctr.mfma_product_stages = e->ctr.mfma_block_products * pair_mfma_ksteps(e->P.founder_ct);
   e->ctr.mfma_skipped_product_stages = h_counters[2];
+  e->ctr.sparse_exact_pairs = h_counters[3];
   e->ctr.ms_replay = replayed ? replay_busy_ms : (t_end - t_replay);  // (time spent replaying, not waiting for groups)
   e->ctr.ms_run_total = t_end - t_start;
   e->ctr.pair_kernel_launches = launches;

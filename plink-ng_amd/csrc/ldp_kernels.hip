@@ -325,7 +325,13 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
     rec.flags = alt_major | (mono << 1) | ((nm_ct != A.founder_ct) ? 4u : 0u);
     A.recs[v] = rec;
     if (A.any_missing && (nm_ct != A.founder_ct)) {
-      *A.any_missing = 1;  // (plain store: every writer stores the same value) -> the popcount kernels take the pair work
+      // the largest number of missing calls in a row: zero routes a launch to the complete-data kernel, a small value to its
+      // interval epilogue (ldp_pair_mfma.hip), anything else to the six-product kernel.  (Read first: the maximum settles
+      // after a few rows and the atomic is then skipped.)
+      const uint32_t miss = A.founder_ct - nm_ct;
+      if (miss > *static_cast<volatile uint32_t*>(A.any_missing)) {
+        atomicMax(A.any_missing, miss);
+      }
     }
     s_alt_major = alt_major;
     s_sum = rec.sum;

@@ -197,14 +197,161 @@ __device__ __forceinline__ uint32_t blocks_needed(uint32_t live, bool diag) {
   return need;
 }
 
-template <int KS>
+// ---- a few missing calls per row (4.1d) -------------------------------------------------------------------------
+// x = 0 where a call is missing, so the dot product of the complete-data kernel is already the exact `dot` of
+// ComputeIndepPairwiseR2Components; what the missing calls leave open are the five pairwise-complete counts.  With M_i, M_j
+// missing calls in the two rows they are confined to intervals that per-variant numbers pin down:
+//   nm   in [N - M_i - M_j, N - max(M_i, M_j)]
+//   sum1 in [S_i - k1, S_i + k1],  ssq1 in [Q_i - k1, Q_i],  k1 = min(M_j, Q_i)   (the calls of i that j's missing calls remove)
+//   sum2, ssq2 the same with k2 = min(M_i, Q_j)
+// and interval arithmetic on cov = dot nm - sum1 sum2, var = ssq nm - sum^2 decides the predicate cov^2 > thresh var1 var2
+// for every pair that is not close to the threshold (1e-9 relative slack covers the FP64 rounding of the bounds).  The
+// few pairs left open are resolved exactly on the spot: the whole wave counts the five statistics of one such pair from
+// the two rows' bit-planes (lanes across plane dwords, as pair_stats_ref_kernel does) and the exact predicate decides.
+// Returns 0 below, 1 above, 2 open.
+__device__ __forceinline__ int classify_sparse(const PairKernelArgs& A, double dot, const ldp_variant_rec& ri, const ldp_variant_rec& rj) {
+  const double N = static_cast<double>(A.founder_ct);
+  const double Mi = N - static_cast<double>(ri.nm_ct), Mj = N - static_cast<double>(rj.nm_ct);
+  const double nm_lo = fmax(N - Mi - Mj, 0.0), nm_hi = N - fmax(Mi, Mj);
+  const double Si = ri.sum, Sj = rj.sum, Qi = ri.ssq, Qj = rj.ssq;
+  const double k1 = fmin(Mj, Qi), k2 = fmin(Mi, Qj);
+  const double s1_lo = Si - k1, s1_hi = Si + k1, s2_lo = Sj - k2, s2_hi = Sj + k2;
+  // cov = dot nm - sum1 sum2
+  const double a0 = dot * nm_lo, a1 = dot * nm_hi;
+  const double a_lo = fmin(a0, a1), a_hi = fmax(a0, a1);
+  const double p0 = s1_lo * s2_lo, p1 = s1_lo * s2_hi, p2 = s1_hi * s2_lo, p3 = s1_hi * s2_hi;
+  const double b_lo = fmin(fmin(p0, p1), fmin(p2, p3)), b_hi = fmax(fmax(p0, p1), fmax(p2, p3));
+  const double c_lo = a_lo - b_hi, c_hi = a_hi - b_lo;
+  const double c2_hi = fmax(c_lo * c_lo, c_hi * c_hi);
+  const double c2_lo = ((c_lo <= 0.0) && (c_hi >= 0.0)) ? 0.0 : fmin(c_lo * c_lo, c_hi * c_hi);
+  // var = ssq nm - sum^2 (never negative for the true values)
+  const double q1_hi = fmax(s1_lo * s1_lo, s1_hi * s1_hi), q1_lo = ((s1_lo <= 0.0) && (s1_hi >= 0.0)) ? 0.0 : fmin(s1_lo * s1_lo, s1_hi * s1_hi);
+  const double q2_hi = fmax(s2_lo * s2_lo, s2_hi * s2_hi), q2_lo = ((s2_lo <= 0.0) && (s2_hi >= 0.0)) ? 0.0 : fmin(s2_lo * s2_lo, s2_hi * s2_hi);
+  const double v1_lo = fmax((Qi - k1) * nm_lo - q1_hi, 0.0), v1_hi = fmax(Qi * nm_hi - q1_lo, 0.0);
+  const double v2_lo = fmax((Qj - k2) * nm_lo - q2_hi, 0.0), v2_hi = fmax(Qj * nm_hi - q2_lo, 0.0);
+  const double rhs_lo = A.thresh * v1_lo * v2_lo, rhs_hi = A.thresh * v1_hi * v2_hi;
+  if (c2_lo > rhs_hi * (1.0 + 1e-9) + 1.0) {
+    return 1;
+  }
+  if (c2_hi * (1.0 + 1e-9) + 1.0 < rhs_lo) {
+    return 0;
+  }
+  return 2;
+}
+
+// the five pairwise-complete counts of (i, j) by the whole wave; every lane returns the same tuple (dot is the caller's)
+__device__ __forceinline__ ldp_pair_stats_t wave_pair_counts(const PairKernelArgs& A, uint32_t i, uint32_t j, int32_t dot, uint32_t lane) {
+  const uint32_t* __restrict__ r1 = A.planes + static_cast<uint64_t>(i) * A.row_dwords;
+  const uint32_t* __restrict__ r2 = A.planes + static_cast<uint64_t>(j) * A.row_dwords;
+  const uint32_t plane_dwords = A.chunks * kChunkDwords;
+  uint32_t c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0;
+  for (uint32_t p = lane; p < plane_dwords; p += 64) {
+    const uint32_t off = (p / kChunkDwords) * kRowChunkDwords + (p % kChunkDwords);
+    const uint32_t h1 = r1[off], q1 = r1[off + kChunkDwords];
+    const uint32_t h2 = r2[off], q2 = r2[off + kChunkDwords];
+    const uint32_t n1 = h1 | q1, n2 = h2 | q2;
+    c2 += __popc(n1 & n2);
+    c3 += __popc(n1 & h2);
+    c4 += __popc(n1 & h2 & q2);
+    c5 += __popc(n2 & h1);
+    c6 += __popc(n2 & h1 & q1);
+  }
+  c2 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c2));  // (the sum lands in lane 0)
+  c3 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c3));  // (the sum lands in lane 0)
+  c4 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c4));  // (the sum lands in lane 0)
+  c5 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c5));  // (the sum lands in lane 0)
+  c6 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c6));  // (the sum lands in lane 0)
+  ldp_pair_stats_t st;
+  st.nm = c2;
+  st.ssq2 = c3;
+  st.sum2 = static_cast<int32_t>(2 * c4 - c3);
+  st.ssq1 = c5;
+  st.sum1 = static_cast<int32_t>(2 * c6 - c5);
+  st.dot = dot;
+  return st;
+}
+
+// One round (the four products of one J block, already dumped to this wave's LDS scratch).
+__device__ __forceinline__ uint32_t sparse_round(const PairKernelArgs& A, const uint32_t* epi, uint32_t lane, int32_t jv, int32_t vv, uint32_t jend,
+                                                          uint32_t live, uint32_t lo_j, int round) {
+  const uint32_t r = lane & 31, h = lane >> 5;
+  uint32_t n_true = 0, n_open = 0;
+  const int64_t j64 = static_cast<int64_t>(jv) + kMfBlock * round + r;
+  const bool j_ok = (j64 < static_cast<int64_t>(jend)) && (static_cast<int64_t>(lo_j) < j64);
+  const uint32_t j = j_ok ? static_cast<uint32_t>(j64) : 0u;
+  ldp_variant_rec rj;
+  rj.nm_ct = 0;
+  rj.sum = 0;
+  rj.ssq = 0;
+  rj.flags = 0;
+  if (j_ok) {
+    rj = A.recs[j];
+  }
+#pragma unroll 1
+  for (uint32_t pl = 0; pl < 4; ++pl) {
+    if (!(live & (1u << (4 * round + pl)))) {
+      continue;  // (wave-uniform)
+    }
+    const int64_t vfirst = static_cast<int64_t>(vv) + kMfBlock * (pl + round) + 4 * h;
+#pragma unroll 1
+    for (uint32_t g = 0; g < 16; ++g) {
+      const int64_t i64 = vfirst + (g & 3) + 8 * (g >> 2);
+      const bool valid = j_ok && (i64 >= static_cast<int64_t>(lo_j)) && (i64 < j64);
+      const uint32_t i = valid ? static_cast<uint32_t>(i64) : 0u;
+      const int32_t dot = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]);
+      int cls = 0;
+      if (valid) {
+        cls = classify_sparse(A, static_cast<double>(dot), A.recs[i], rj);
+        if (cls == 1) {
+          atomicOr(&A.pred[A.row_off[j] + ((i >> 5) - (lo_j >> 5))], 1u << (i & 31));
+          ++n_true;
+        }
+      }
+      // the pairs left open, one after the other, each by the whole wave
+      unsigned long long open = __ballot(cls == 2);
+      while (open) {
+        const int l = __builtin_ctzll(open);
+        open &= open - 1;
+        const uint32_t ii = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(i), l));
+        const uint32_t jj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(j), l));
+        const int32_t dd = __builtin_amdgcn_readlane(dot, l);
+        const ldp_pair_stats_t st = wave_pair_counts(A, ii, jj, dd, lane);
+        if ((static_cast<int>(lane) == l) && exceeds(st, A.thresh)) {
+          atomicOr(&A.pred[A.row_off[j] + ((i >> 5) - (lo_j >> 5))], 1u << (i & 31));
+          ++n_true;
+        }
+        n_open += (lane == 0) ? 1u : 0u;
+      }
+    }
+  }
+  if ((lane == 0) && n_open) {
+    atomicAdd(A.counters + 3, static_cast<unsigned long long>(n_open));
+  }
+  return n_true;
+}
+
+// SPARSE: the instantiation that takes launches whose rows have a few missing calls (4.1d): the same stage loops without
+// checkpoints, and the interval epilogue.  A kernel of its own rather than a branch in the epilogue: with the interval code
+// inside it hipcc re-allocates the complete-data kernel's registers and spills inside the stage loop (inlined), or keeps
+// half of them in scratch across the call (out of line).  Both instantiations are launched; the one the data does not
+// call for leaves at once.
+template <int KS, bool SPARSE>
 __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelArgs A) {
   using G = StageGeom<KS>;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_src_off[kMfMaxDmaPerWave * kMfWaves * 64];
   __shared__ uint32_t s_need[kMfWaves];
-  if (*A.any_missing) {
-    return;  // rows with missing calls: the popcount kernels own this launch (7 counts per pair)
+  // 0: complete data.  1 .. sparse_max missing calls in the worst row: this kernel keeps the launch and its epilogue sorts
+  // the pairs with interval arithmetic (sparse_epilogue below).  More: pair_mfma_general_kernel owns the launch.
+  const uint32_t miss_max = *A.any_missing;
+  if constexpr (!SPARSE) {
+    if (miss_max) {
+      return;
+    }
+  } else {
+    if ((!miss_max) || !(A.sparse_max && (miss_max <= A.sparse_max))) {
+      return;
+    }
   }
   const uint32_t per_xcd = (A.n_mf_wgs + 7) / 8;
   const uint32_t item_idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // XCD-aware, as pair_tiles_kernel
@@ -291,7 +438,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
 
   uint32_t wg_need = (1u << n_rb) - 1;  // row-block slots some wave still reads (all of them until a checkpoint says otherwise)
   uint32_t next_cp = 0;
-  const uint32_t n_cp = A.cp_stats ? A.n_checkpoints : 0;
+  const uint32_t n_cp = (A.cp_stats && !SPARSE) ? A.n_checkpoints : 0;  // (the checkpoint bound assumes complete rows)
   auto dma_stage = [&](uint32_t s, uint32_t buf) {
     const uint32_t kbyte = G::stage_byte(s);
     uint32_t* dst = lds + buf * stage_dwords;
@@ -494,6 +641,20 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   // lane l, register g of a product holds first variant (g & 3) + 8 (g >> 2) + 4 (l >> 5) of the V block, second variant
   // l & 31 of the J block (tools/mfma_probe.hip, fact 1)
   uint32_t n_true = 0;
+  if constexpr (SPARSE) {
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      if (live & (0xfu << (4 * round))) {
+        dump_round(round);
+        n_true += sparse_round(A, epi, lane, jv, vv, jend, live, lo_j2[round], round);
+      }
+    }
+    n_true = wave_reduce_add(n_true);
+    if ((lane == 0) && n_true) {
+      atomicAdd(A.counters, static_cast<unsigned long long>(n_true));
+    }
+    return;
+  }
 #pragma unroll
   for (int round = 0; round < 2; ++round) {
     if (!(live & (0xfu << (4 * round)))) {
@@ -570,8 +731,11 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
   using G = StageGeom<4>;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_src_off[kMfGenDmaPerWave * kMfWaves * 64];
-  if (!*A.any_missing) {
-    return;  // complete data: pair_mfma_kernel owns this launch
+  {
+    const uint32_t miss_max = *A.any_missing;
+    if ((!miss_max) || (A.sparse_max && (miss_max <= A.sparse_max))) {
+      return;  // complete data, or few enough missing calls for its interval epilogue: pair_mfma_kernel owns this launch
+    }
   }
   const uint32_t n_blocks = A.n_mf_wgs * 8;  // workgroup x wave item x J block
   const uint32_t per_xcd = (n_blocks + 7) / 8;
@@ -749,8 +913,10 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
     if (const char* kb = getenv("LDP_DEBUG_MFMA_LDS_KB")) {
       bytes = std::max<size_t>(bytes, std::min<size_t>(static_cast<size_t>(atoi(kb)), 150) * 1024);
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
     return bytes;
   }();
   a.lds_dwords = static_cast<uint32_t>(lds / sizeof(uint32_t));
@@ -759,9 +925,15 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
     (void)hipEventRecord(ev[0], stream);
   }
   if (ks == 4) {
-    hipLaunchKernelGGL(pair_mfma_kernel<4>, dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
+    hipLaunchKernelGGL((pair_mfma_kernel<4, false>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
+    if (a.sparse_max) {
+      hipLaunchKernelGGL((pair_mfma_kernel<4, true>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
+    }
   } else {
-    hipLaunchKernelGGL(pair_mfma_kernel<2>, dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
+    hipLaunchKernelGGL((pair_mfma_kernel<2, false>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
+    if (a.sparse_max) {
+      hipLaunchKernelGGL((pair_mfma_kernel<2, true>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
+    }
   }
   if (ev) {
     (void)hipEventRecord(ev[1], stream);

@@ -79,7 +79,10 @@ void logprintf(const char* fmt, ...) {
     fputs(buf, g_log);
     fclose(g_log);
   }
-  exit(code);
+  // (not exit(): loader threads may still be running, and static destructors under their feet end in a crash instead of
+  // the exit code)
+  fflush(nullptr);
+  _exit(code);
 }
 
 // The reference's decimal scanner: up to 16-17 significant digits accumulated in an int64, then ONE

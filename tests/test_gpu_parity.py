@@ -305,6 +305,59 @@ def test_early_termination_is_invisible(gpu_pkg, n, r2, order, miss):
     assert np.array_equal(on, want)
 
 
+def _run_sparse(pkg, packed, n, chr_idx, bps, r2, env):
+    keys = ("LDP_PAIR_SPARSE", "LDP_DEBUG_SPARSE_FRAC")
+    old = {k: os.environ.get(k) for k in keys}
+    for k in keys:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    try:
+        eng = pkg.LdPruneEngine(n, 150, 1, False, r2, order=2, device=0)
+        eng.set_variants(chr_idx, bps)
+        eng.load_genotypes_host(0, packed, pkg.LDP_GENO_REF)
+        removed = eng.run()
+        ctr = eng.counters()
+        eng.close()
+    finally:
+        for k in keys:
+            os.environ.pop(k, None)
+            if old[k] is not None:
+                os.environ[k] = old[k]
+    return removed, ctr
+
+
+@pytest.mark.parametrize("n,miss,r2,redraw,frac", [
+    (20000, 0.001, 0.5, 0.05, None),    # the default limit (0.3 % of the samples): nearly every pair is settled by its intervals
+    (20000, 0.0003, 0.5, 0.29, None),   # planted r^2 ~ 0.504: a crowd of pairs next to the threshold
+    (50000, 0.0015, 0.2, 0.55, None),
+    (9000, 0.001, 0.8, 0.1, None),
+    (6000, 0.02, 0.5, 0.29, "0.08"),    # a limit far beyond the useful one: wide intervals, most pairs resolved exactly
+    (3000, 0.05, 0.1, 0.68, "0.2"),
+])
+def test_rows_with_a_few_missing_calls(gpu_pkg, n, miss, r2, redraw, frac):
+    """launches whose rows miss only a few calls stay with the complete-data matrix kernel; per-variant
+    counts confine the pairwise-complete statistics to intervals, interval arithmetic settles the predicate of the
+    clear pairs and the rest are counted exactly.  Same prune set as the six-product kernel and as the oracle."""
+    m = 700
+    raw = T.synth_raw_codes(m, n, seed=n % 89 + 3, missing_rate=miss, ld_copy_prob=0.7, redraw=redraw)
+    chr_idx, bps = make_positions(m, 2, 5)
+    packed = T.pack_2bit(raw)
+    env = {} if frac is None else {"LDP_DEBUG_SPARSE_FRAC": frac}
+    got, c1 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, env)
+    six, c0 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, {"LDP_PAIR_SPARSE": "0"})
+    assert c0["sparse_exact_pairs"] == 0 and c0["ms_pair_mfma_general"] > 0
+    assert c1["ms_pair_mfma_general"] < 0.5 * c0["ms_pair_mfma_general"], "the launches must have taken the interval path"
+    assert np.array_equal(got, six)
+    assert c1["pred_true"] == c0["pred_true"] > 0
+    if frac is None:
+        assert c1["sparse_exact_pairs"] < 0.2 * c1["candidate_pairs"]
+    else:
+        assert c1["sparse_exact_pairs"] > 0.03 * c1["candidate_pairs"]
+    inv, mf, _ = T.oracle_prepare(raw)
+    want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 150, 1, False, r2, 2)
+    assert np.array_equal(got, want)
+
+
 def test_early_termination_late_correlation(gpu_pkg):
     """Adversarial layout: pairs that look unrelated over the first 45 % of the samples and are identical over
     the rest.  A bound that extrapolated from the visited samples would drop them; the remainder bound keeps them."""
