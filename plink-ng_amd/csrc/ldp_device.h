@@ -130,16 +130,34 @@ struct PairKernelArgs {
   ldp_r2_hit* r2_hits;
   uint64_t r2_hit_capacity;
   double r2_min;
-  // matrix-pipe tiles (launch_pair_mfma); any_missing (one word, written by prepare_kernel) routes a whole launch:
-  // zero -> pair_mfma_kernel (complete data), non-zero -> pair_mfma_general_kernel; mf_active = 1: the popcount
+  // matrix-pipe tiles (launch_pair_mfma); `route` (one word, written by route_kernel from what prepare_kernel saw of the
+  // rows converted so far) sends a whole launch to one kernel: kRouteComplete -> pair_mfma_kernel, kRouteSparse -> its
+  // interval-epilogue instantiation (4.1d), kRouteGeneral -> pair_mfma_general_kernel; mf_active = 1: the popcount
   // kernels of the launch only run for non-zero (the general matrix-pipe kernel is off), 2: they never run
   const MfmaWG* mf_wgs;
   uint32_t n_mf_wgs;
   uint32_t n_local;              // rows in `planes`
   uint32_t mf_active;            // the launch also carries matrix-pipe work items
-  const uint32_t* any_missing;   // 0: complete data; otherwise the largest number of missing calls in a row converted so far
-  uint32_t sparse_max;           // prune runs: up to this many missing calls per row pair_mfma_kernel keeps the launch (4.1d); 0 = never
+  const uint32_t* route;         // kRoute*
+  uint32_t sparse_ok;            // the route may be kRouteSparse (prune launches): launch that instantiation as well
 };
+
+constexpr uint32_t kRouteComplete = 0, kRouteSparse = 1, kRouteGeneral = 2;
+
+// What prepare_kernel records about missing calls, per load epoch: the largest count in a row, and striped over
+// kMissStripes words (by variant index; one atomic per row with missing calls) the total of missing calls and the number
+// of rows beyond `miss_high` of them.
+constexpr uint32_t kMissStripes = 64;
+struct MissStats {
+  uint32_t max_missing;
+  uint32_t pad;
+  unsigned long long total[kMissStripes];
+  unsigned long long high_rows[kMissStripes];
+};
+// *route_out = kRouteComplete when no row had a missing call, kRouteSparse when the total is at most total_limit and the
+// high rows at most high_limit (both 0: never), else kRouteGeneral
+hipError_t launch_route(const MissStats* stats, unsigned long long total_limit, unsigned long long high_limit, int allow_sparse, uint32_t* route_out,
+                        hipStream_t stream);
 
 struct PrepareArgs {
   const uint8_t* geno;           // row 0 = variant `first`
@@ -156,7 +174,8 @@ struct PrepareArgs {
   double cp_tv_scale;            // sqrt(sqrt(thresh) * (1 - 1e-6))
   uint32_t checkpoint_chunk[kCheckpoints];
   uint32_t n_checkpoints;
-  uint32_t* any_missing;         // set to 1 when a converted row has missing calls (may be nullptr)
+  MissStats* miss_stats;         // what the rows' missing calls add up to (may be nullptr)
+  uint32_t miss_high;            // rows with more missing calls than this count as high rows
   const uint32_t* extra_het;     // per variant: het calls the sample map turned into missing ones (allele counts only); may be nullptr
   bool fix_cp_gen;               // redo cp_gen for rows with missing calls (cp_gen_fix_kernel)
 };

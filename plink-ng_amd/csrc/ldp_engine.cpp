@@ -153,7 +153,8 @@ struct ldp_engine {
   cp_slot* d_cp_stats = nullptr;           // per-variant checkpoint statistics (early termination)
   cp_gen_slot* d_cp_gen = nullptr;         // ... for tiles with missing calls
   MfmaWG* d_mf_wgs = nullptr;
-  uint32_t* d_any_missing = nullptr;       // [0]: a row converted in this load epoch has missing calls; [1 + g]: its value when group g was queued
+  MissStats* d_miss_stats = nullptr;       // missing calls of the rows converted in this load epoch (prepare_kernel)
+  uint32_t* d_route = nullptr;             // [g]: which matrix-pipe kernel owns launch group g (route_kernel, when the group is queued); [groups]: other launches
   uint32_t checkpoint_chunk[kCheckpoints];
   uint32_t n_checkpoints = 0;
   uint32_t* h_pred = nullptr;  // pinned
@@ -254,9 +255,11 @@ void free_device(ldp_engine* e) {
   (void)hipFree(e->d_cp_stats);
   (void)hipFree(e->d_cp_gen);
   (void)hipFree(e->d_mf_wgs);
-  (void)hipFree(e->d_any_missing);
+  (void)hipFree(e->d_miss_stats);
+  (void)hipFree(e->d_route);
   e->d_mf_wgs = nullptr;
-  e->d_any_missing = nullptr;
+  e->d_miss_stats = nullptr;
+  e->d_route = nullptr;
   if (e->h_pred) {
     (void)hipHostFree(e->h_pred);
   }
@@ -483,18 +486,19 @@ int checkpoint_fractions(double r2_param, double* frac) {
 // ("parallelogram") for every four block distances the band reaches; wave items are packed four to a workgroup as
 // long as the union of their row-blocks fits the LDS ring (J quads x distance pairs for wide bands, four
 // neighbouring J pairs for narrow ones).
-// Rows with at most this many missing calls leave a prune launch with pair_mfma_kernel and its interval epilogue (DESIGN.md
-// 4.1d): 0.3 % of the samples by default (beyond that the pairs the intervals leave open cost more than the six-product
-// kernel); LDP_PAIR_SPARSE=0 turns the path off, LDP_DEBUG_SPARSE_FRAC sets the fraction.
-uint32_t sparse_missing_limit(uint32_t founder_ct) {
-  // (read per launch, like LDP_EARLY_EXIT: the tests switch it between engines of one process)
+// Prune launches whose rows miss on average at most this fraction of their calls stay with pair_mfma_kernel and its interval
+// epilogue: 0.5 % by default -- on the benchmark generator the pairs the intervals leave open cost as much as
+// the six-product kernel at 0.65 % (profiles/r02_experiments.md).  Rows with more than twice the fraction count as high rows,
+// and more than 2 % of those route the launch to the six-product kernel as well (their pairs are mostly open).
+// LDP_PAIR_SPARSE=0 turns the path off, LDP_DEBUG_SPARSE_FRAC sets the fraction (read per call, like LDP_EARLY_EXIT: the
+// tests switch it between engines of one process).
+double sparse_missing_fraction() {
   const char* off = getenv("LDP_PAIR_SPARSE");
   if (off && (strcmp(off, "0") == 0)) {
-    return 0;
+    return 0.0;
   }
   const char* f = getenv("LDP_DEBUG_SPARSE_FRAC");
-  const double frac = f ? atof(f) : 0.003;
-  return static_cast<uint32_t>(frac * static_cast<double>(founder_ct));
+  return f ? atof(f) : 0.005;
 }
 
 bool mfma_requested() {
@@ -905,8 +909,10 @@ int ensure_device_plan(ldp_engine* e) {
   HIP_TRY(e, hipMalloc(&e->d_cp_stats, n * kCpSlots * sizeof(cp_slot)));
   HIP_TRY(e, hipMalloc(&e->d_cp_gen, n * kCheckpoints * sizeof(cp_gen_slot)));
   HIP_TRY(e, hipMalloc(&e->d_mf_wgs, std::max<size_t>(e->mf_wgs.size(), 1) * sizeof(MfmaWG)));
-  HIP_TRY(e, hipMalloc(&e->d_any_missing, (e->groups.size() + 2) * sizeof(uint32_t)));
-  HIP_TRY(e, hipMemsetAsync(e->d_any_missing, 0, (e->groups.size() + 2) * sizeof(uint32_t), e->stream));
+  HIP_TRY(e, hipMalloc(&e->d_miss_stats, sizeof(MissStats)));
+  HIP_TRY(e, hipMemsetAsync(e->d_miss_stats, 0, sizeof(MissStats), e->stream));
+  HIP_TRY(e, hipMalloc(&e->d_route, (e->groups.size() + 1) * sizeof(uint32_t)));
+  HIP_TRY(e, hipMemsetAsync(e->d_route, 0, (e->groups.size() + 1) * sizeof(uint32_t), e->stream));
   if (!e->mf_wgs.empty()) {
     HIP_TRY(e, hipMemcpyAsync(e->d_mf_wgs, e->mf_wgs.data(), e->mf_wgs.size() * sizeof(MfmaWG), hipMemcpyHostToDevice, e->stream));
   }
@@ -1324,8 +1330,8 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.n_mf_wgs = 0;
   A.n_local = e->local_ct;
   A.mf_active = 0;
-  A.any_missing = nullptr;
-  A.sparse_max = 0;
+  A.route = nullptr;
+  A.sparse_ok = 0;
 }
 
 // A new load epoch begins (variants are being loaded again): whatever the pair streams still run belongs to the
@@ -1338,7 +1344,7 @@ int begin_load_epoch(ldp_engine* e) {
     }
   }
   HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
-  HIP_TRY(e, hipMemsetAsync(e->d_any_missing, 0, sizeof(uint32_t), e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->d_miss_stats, 0, sizeof(MissStats), e->stream));
   ++e->load_epoch;
   e->loaded_prefix = 0;
   e->next_group = 0;
@@ -1346,6 +1352,17 @@ int begin_load_epoch(ldp_engine* e) {
     g.launched = false;
   }
   return LDP_OK;
+}
+
+// Decide on the device which matrix-pipe kernel owns the launches queued next on `stream` (slot of d_route): everything the
+// stream holds so far -- the conversions of the rows those launches read -- has added to d_miss_stats by then.
+hipError_t queue_route(ldp_engine* e, size_t slot, hipStream_t stream, int allow_sparse) {
+  const double rows = static_cast<double>(std::max<uint32_t>(e->loaded_prefix, 1));
+  const double frac = allow_sparse ? sparse_missing_fraction() : 0.0;
+  const double total_limit = frac * static_cast<double>(e->P.founder_ct) * rows;  // (< 2^64: 16M samples x 2^32 rows)
+  const double high_limit = 0.02 * rows;
+  return launch_route(e->d_miss_stats, static_cast<unsigned long long>(total_limit), static_cast<unsigned long long>(high_limit), allow_sparse && (frac > 0.0),
+                      e->d_route + slot, stream);
 }
 
 // Queue group gi behind everything the main stream holds right now (the prepare kernels it depends on).
@@ -1366,12 +1383,12 @@ int launch_group(ldp_engine* e, uint32_t gi) {
   if (e->mf_enabled) {
     // Which kernel family owns the group is decided on the device, once per group: a snapshot of the missing-calls flag
     // (all of the group's rows are converted by now) that every kernel of the group reads.
-    HIP_TRY(e, hipMemcpyAsync(e->d_any_missing + 1 + gi, e->d_any_missing, sizeof(uint32_t), hipMemcpyDeviceToDevice, ps));
     A.mf_active = pair_mfma_general_enabled() ? 2 : 1;
-    A.any_missing = e->d_any_missing + 1 + gi;
+    A.sparse_ok = ((A.mf_active == 2) && !A.stats && (sparse_missing_fraction() > 0.0)) ? 1 : 0;
+    HIP_TRY(e, queue_route(e, gi, ps, A.sparse_ok));
+    A.route = e->d_route + gi;
     A.mf_wgs = e->d_mf_wgs + g.mf_first;
     A.n_mf_wgs = g.mf_ct;
-    A.sparse_max = ((A.mf_active == 2) && !A.stats) ? sparse_missing_limit(e->P.founder_ct) : 0;
   }
   hipError_t krc = launch_pair_tiles(A, e->max_rows, ps, g.ev);
   if (krc != hipSuccess) {
@@ -1482,10 +1499,10 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
       HIP_TRY(e, hipEventCreate(&evk[q]));
     }
     if (e->mf_enabled) {
-      const size_t slot = 1 + e->groups.size();
-      HIP_TRY(e, hipMemcpyAsync(e->d_any_missing + slot, e->d_any_missing, sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
+      const size_t slot = e->groups.size();
+      HIP_TRY(e, queue_route(e, slot, e->stream, 0));
       A.mf_active = pair_mfma_general_enabled() ? 2 : 1;
-      A.any_missing = e->d_any_missing + slot;
+      A.route = e->d_route + slot;
       A.mf_wgs = e->d_mf_wgs;
       A.n_mf_wgs = static_cast<uint32_t>(e->mf_wgs.size());
     }
@@ -1870,11 +1887,11 @@ int attach_mfma_plan(ldp_engine* e, PairKernelArgs* A, const std::vector<std::pa
   }
   HIP_TRY(e, hipMalloc(&buf->p, wgs.size() * sizeof(MfmaWG)));
   HIP_TRY(e, hipMemcpy(buf->p, wgs.data(), wgs.size() * sizeof(MfmaWG), hipMemcpyHostToDevice));
-  const size_t slot = 1 + e->groups.size();  // (the snapshot slot of launches outside the launch groups)
-  HIP_TRY(e, hipMemcpyAsync(e->d_any_missing + slot, e->d_any_missing, sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
+  const size_t slot = e->groups.size();  // (the route slot of launches outside the launch groups)
+  HIP_TRY(e, queue_route(e, slot, e->stream, 0));
   A->mf_wgs = buf->as<MfmaWG>();
   A->mf_active = 2;
-  A->any_missing = e->d_any_missing + slot;
+  A->route = e->d_route + slot;
   return LDP_OK;
 }
 
@@ -2514,7 +2531,8 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
         PA.checkpoint_chunk[k] = e->checkpoint_chunk[k];
       }
       PA.n_checkpoints = e->n_checkpoints;
-      PA.any_missing = e->d_any_missing;
+      PA.miss_stats = e->d_miss_stats;
+      PA.miss_high = static_cast<uint32_t>(std::min(2.0 * sparse_missing_fraction() * static_cast<double>(e->P.founder_ct), 4294967295.0));
       PA.fix_cp_gen = !(e->mf_enabled && pair_mfma_general_enabled());  // (only the popcount kernel's interval bound reads cp_gen)
       if (!e->prep_pending) {
         HIP_TRY(e, hipEventRecord(e->prep_ev0, e->stream));

@@ -324,15 +324,6 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
     const uint32_t mono = ((!plus_ct) && (!minus_ct)) || (plus_ct == nm_ct) || (minus_ct == nm_ct);  // plink2_ld.cc:902
     rec.flags = alt_major | (mono << 1) | ((nm_ct != A.founder_ct) ? 4u : 0u);
     A.recs[v] = rec;
-    if (A.any_missing && (nm_ct != A.founder_ct)) {
-      // the largest number of missing calls in a row: zero routes a launch to the complete-data kernel, a small value to its
-      // interval epilogue (ldp_pair_mfma.hip), anything else to the six-product kernel.  (Read first: the maximum settles
-      // after a few rows and the atomic is then skipped.)
-      const uint32_t miss = A.founder_ct - nm_ct;
-      if (miss > *static_cast<volatile uint32_t*>(A.any_missing)) {
-        atomicMax(A.any_missing, miss);
-      }
-    }
     s_alt_major = alt_major;
     s_sum = rec.sum;
   }
@@ -553,6 +544,73 @@ hipError_t launch_gather_rows(const uint8_t* in, uint64_t in_stride, uint32_t n_
   return hipGetLastError();
 }
 
+// What the rows of one conversion launch add to MissStats (ldp_device.h).  A kernel of its own behind prepare_kernel: one
+// atomic per row from inside it costs 16 ns each -- they serialise at the memory side -- and quadrupled the conversion.
+__global__ __launch_bounds__(256) void miss_stats_kernel(const ldp_variant_rec* __restrict__ recs, uint32_t n, uint32_t founder_ct, uint32_t miss_high,
+                                                         MissStats* __restrict__ stats) {
+  unsigned long long total = 0;
+  uint32_t high = 0, mx = 0;
+  for (uint32_t v = blockIdx.x * 256 + threadIdx.x; v < n; v += gridDim.x * 256) {
+    const uint32_t miss = founder_ct - recs[v].nm_ct;
+    total += miss;
+    high += (miss > miss_high) ? 1u : 0u;
+    mx = max(mx, miss);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    total += __shfl_down(total, off, 64);
+    high += __shfl_down(high, off, 64);
+    mx = max(mx, static_cast<uint32_t>(__shfl_down(mx, off, 64)));
+  }
+  __shared__ unsigned long long s_total[4];
+  __shared__ uint32_t s_high[4], s_max[4];
+  const uint32_t wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_total[wave] = total;
+    s_high[wave] = high;
+    s_max[wave] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    total = s_total[0] + s_total[1] + s_total[2] + s_total[3];
+    high = s_high[0] + s_high[1] + s_high[2] + s_high[3];
+    mx = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    if (mx) {
+      atomicMax(&stats->max_missing, mx);
+      atomicAdd(&stats->total[blockIdx.x % kMissStripes], total);
+      if (high) {
+        atomicAdd(&stats->high_rows[blockIdx.x % kMissStripes], static_cast<unsigned long long>(high));
+      }
+    }
+  }
+}
+
+// One wave: which kernel takes the launches queued behind this point (ldp_device.h: kRoute*).
+__global__ __launch_bounds__(64) void route_kernel(const MissStats* __restrict__ stats, unsigned long long total_limit, unsigned long long high_limit,
+                                                   int allow_sparse, uint32_t* __restrict__ route_out) {
+  const uint32_t lane = threadIdx.x;
+  unsigned long long total = stats->total[lane], high = stats->high_rows[lane];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    total += __shfl_down(total, off, 64);
+    high += __shfl_down(high, off, 64);
+  }
+  if (lane == 0) {
+    uint32_t route = kRouteComplete;
+    if (stats->max_missing) {
+      route = (allow_sparse && (total <= total_limit) && (high <= high_limit)) ? kRouteSparse : kRouteGeneral;
+    }
+    *route_out = route;
+  }
+}
+
+hipError_t launch_route(const MissStats* stats, unsigned long long total_limit, unsigned long long high_limit, int allow_sparse, uint32_t* route_out,
+                        hipStream_t stream) {
+  static_assert(kMissStripes == 64, "one lane per stripe");
+  hipLaunchKernelGGL(route_kernel, dim3(1), dim3(64), 0, stream, stats, total_limit, high_limit, allow_sparse, route_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream) {
   if (!a.n_variants) {
     return hipSuccess;
@@ -581,6 +639,10 @@ hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream) {
     LDP_PREP(1024, 0);
   }
 #undef LDP_PREP
+  if (a.miss_stats) {
+    hipLaunchKernelGGL(miss_stats_kernel, dim3(std::min<uint32_t>((a.n_variants + 255) / 256, 256)), dim3(256), 0, stream, a.recs, a.n_variants, a.founder_ct,
+                       a.miss_high, a.miss_stats);
+  }
   if (a.cp_stats && a.n_checkpoints && a.fix_cp_gen) {
     hipLaunchKernelGGL(cp_gen_fix_kernel, dim3((a.n_variants + 3) / 4), dim3(256), 0, stream, a);
   }
@@ -1001,7 +1063,7 @@ __global__ __launch_bounds__(kBlockThreads, GENERAL ? 2 : 4) void pair_tiles_ker
   if (item_idx >= A.n_items) {
     return;
   }
-  if ((A.mf_active == 2) || (A.mf_active && !*A.any_missing)) {
+  if ((A.mf_active == 2) || (A.mf_active && (*A.route == kRouteComplete))) {
     return;  // the matrix-pipe kernels own this launch (ldp_pair_mfma.hip)
   }
   const uint32_t item_class = A.item_general[item_idx];  // classify_items_kernel: 0 complete, 1 / 2 missing calls

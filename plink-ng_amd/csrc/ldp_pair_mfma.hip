@@ -241,20 +241,43 @@ __device__ __forceinline__ int classify_sparse(const PairKernelArgs& A, double d
 
 // the five pairwise-complete counts of (i, j) by the whole wave; every lane returns the same tuple (dot is the caller's)
 __device__ __forceinline__ ldp_pair_stats_t wave_pair_counts(const PairKernelArgs& A, uint32_t i, uint32_t j, int32_t dot, uint32_t lane) {
-  const uint32_t* __restrict__ r1 = A.planes + static_cast<uint64_t>(i) * A.row_dwords;
-  const uint32_t* __restrict__ r2 = A.planes + static_cast<uint64_t>(j) * A.row_dwords;
-  const uint32_t plane_dwords = A.chunks * kChunkDwords;
+  // 16-byte loads, two per row and plane in flight (a lone wave is latency-bound here): quad q of a plane = dwords 4 (q & 3) ..
+  // of chunk q >> 2; a row chunk is 8 quads, hom first
+  const uint4* __restrict__ r1 = reinterpret_cast<const uint4*>(A.planes + static_cast<uint64_t>(i) * A.row_dwords);
+  const uint4* __restrict__ r2 = reinterpret_cast<const uint4*>(A.planes + static_cast<uint64_t>(j) * A.row_dwords);
+  const uint32_t n_quads = A.chunks * (kChunkDwords / 4);
   uint32_t c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0;
-  for (uint32_t p = lane; p < plane_dwords; p += 64) {
-    const uint32_t off = (p / kChunkDwords) * kRowChunkDwords + (p % kChunkDwords);
-    const uint32_t h1 = r1[off], q1 = r1[off + kChunkDwords];
-    const uint32_t h2 = r2[off], q2 = r2[off + kChunkDwords];
-    const uint32_t n1 = h1 | q1, n2 = h2 | q2;
-    c2 += __popc(n1 & n2);
-    c3 += __popc(n1 & h2);
-    c4 += __popc(n1 & h2 & q2);
-    c5 += __popc(n2 & h1);
-    c6 += __popc(n2 & h1 & q1);
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  for (uint32_t q = lane; q < n_quads; q += 128) {
+    const uint32_t qb = q + 64;
+    const bool two = qb < n_quads;
+    const uint32_t ia = (q >> 2) * 8 + (q & 3), ib = two ? ((qb >> 2) * 8 + (qb & 3)) : ia;
+    const uint4 h1a = r1[ia], q1a = r1[ia + 4], h2a = r2[ia], q2a = r2[ia + 4];
+    uint4 h1b = r1[ib], q1b = r1[ib + 4], h2b = r2[ib], q2b = r2[ib + 4];
+    if (!two) {
+      h1b = zero;
+      q1b = zero;
+      h2b = zero;
+      q2b = zero;
+    }
+#define LDP_SPARSE_COUNT(H1, Q1, H2, Q2)               \
+  {                                                    \
+    const uint32_t n1 = (H1) | (Q1), n2 = (H2) | (Q2); \
+    c2 += __popc(n1 & n2);                             \
+    c3 += __popc(n1 & (H2));                           \
+    c4 += __popc(n1 & (H2) & (Q2));                    \
+    c5 += __popc(n2 & (H1));                           \
+    c6 += __popc(n2 & (H1) & (Q1));                    \
+  }
+    LDP_SPARSE_COUNT(h1a.x, q1a.x, h2a.x, q2a.x)
+    LDP_SPARSE_COUNT(h1a.y, q1a.y, h2a.y, q2a.y)
+    LDP_SPARSE_COUNT(h1a.z, q1a.z, h2a.z, q2a.z)
+    LDP_SPARSE_COUNT(h1a.w, q1a.w, h2a.w, q2a.w)
+    LDP_SPARSE_COUNT(h1b.x, q1b.x, h2b.x, q2b.x)
+    LDP_SPARSE_COUNT(h1b.y, q1b.y, h2b.y, q2b.y)
+    LDP_SPARSE_COUNT(h1b.z, q1b.z, h2b.z, q2b.z)
+    LDP_SPARSE_COUNT(h1b.w, q1b.w, h2b.w, q2b.w)
+#undef LDP_SPARSE_COUNT
   }
   c2 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c2));  // (the sum lands in lane 0)
   c3 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c3));  // (the sum lands in lane 0)
@@ -341,17 +364,9 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_src_off[kMfMaxDmaPerWave * kMfWaves * 64];
   __shared__ uint32_t s_need[kMfWaves];
-  // 0: complete data.  1 .. sparse_max missing calls in the worst row: this kernel keeps the launch and its epilogue sorts
-  // the pairs with interval arithmetic (sparse_epilogue below).  More: pair_mfma_general_kernel owns the launch.
-  const uint32_t miss_max = *A.any_missing;
-  if constexpr (!SPARSE) {
-    if (miss_max) {
-      return;
-    }
-  } else {
-    if ((!miss_max) || !(A.sparse_max && (miss_max <= A.sparse_max))) {
-      return;
-    }
+  // route_kernel decided which of the three matrix-pipe kernels owns the launch (ldp_device.h); the others leave at once
+  if (*A.route != (SPARSE ? kRouteSparse : kRouteComplete)) {
+    return;
   }
   const uint32_t per_xcd = (A.n_mf_wgs + 7) / 8;
   const uint32_t item_idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // XCD-aware, as pair_tiles_kernel
@@ -732,8 +747,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_src_off[kMfGenDmaPerWave * kMfWaves * 64];
   {
-    const uint32_t miss_max = *A.any_missing;
-    if ((!miss_max) || (A.sparse_max && (miss_max <= A.sparse_max))) {
+    if (*A.route != kRouteGeneral) {
       return;  // complete data, or few enough missing calls for its interval epilogue: pair_mfma_kernel owns this launch
     }
   }
@@ -926,12 +940,12 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
   }
   if (ks == 4) {
     hipLaunchKernelGGL((pair_mfma_kernel<4, false>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
-    if (a.sparse_max) {
+    if (a.sparse_ok) {
       hipLaunchKernelGGL((pair_mfma_kernel<4, true>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
     }
   } else {
     hipLaunchKernelGGL((pair_mfma_kernel<2, false>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
-    if (a.sparse_max) {
+    if (a.sparse_ok) {
       hipLaunchKernelGGL((pair_mfma_kernel<2, true>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
     }
   }

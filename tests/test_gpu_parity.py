@@ -327,9 +327,9 @@ def _run_sparse(pkg, packed, n, chr_idx, bps, r2, env):
 
 
 @pytest.mark.parametrize("n,miss,r2,redraw,frac", [
-    (20000, 0.001, 0.5, 0.05, None),    # the default limit (0.3 % of the samples): nearly every pair is settled by its intervals
+    (20000, 0.001, 0.5, 0.05, None),    # the default limit (0.5 % of the calls): nearly every pair is settled by its intervals
     (20000, 0.0003, 0.5, 0.29, None),   # planted r^2 ~ 0.504: a crowd of pairs next to the threshold
-    (50000, 0.0015, 0.2, 0.55, None),
+    (50000, 0.003, 0.2, 0.55, None),
     (9000, 0.001, 0.8, 0.1, None),
     (6000, 0.02, 0.5, 0.29, "0.08"),    # a limit far beyond the useful one: wide intervals, most pairs resolved exactly
     (3000, 0.05, 0.1, 0.68, "0.2"),
@@ -356,6 +356,29 @@ def test_rows_with_a_few_missing_calls(gpu_pkg, n, miss, r2, redraw, frac):
     inv, mf, _ = T.oracle_prepare(raw)
     want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 150, 1, False, r2, 2)
     assert np.array_equal(got, want)
+
+
+def test_route_follows_the_mean_not_the_worst_row(gpu_pkg):
+    """A handful of rows with many missing calls among rows with few: the launch still takes the interval path (its
+    pairs with those rows are counted exactly); when such rows are common it goes to the six-product kernel."""
+    n, m = 20000, 700
+    rng = np.random.default_rng(5)
+    chr_idx, bps = make_positions(m, 2, 5)
+    for n_bad, sparse in ((6, True), (80, False)):
+        raw = T.synth_raw_codes(m, n, seed=41, missing_rate=0.0005, ld_copy_prob=0.7, redraw=0.1)
+        for v in rng.choice(m, size=n_bad, replace=False):
+            raw[v, rng.random(n) < 0.07] = 3
+        packed = T.pack_2bit(raw)
+        got, c1 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, 0.5, {})
+        six, c0 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, 0.5, {"LDP_PAIR_SPARSE": "0"})
+        assert np.array_equal(got, six) and c1["pred_true"] == c0["pred_true"]
+        if sparse:
+            assert c1["ms_pair_mfma_general"] < 0.5 * c0["ms_pair_mfma_general"] and c1["sparse_exact_pairs"] > 0
+        else:
+            assert c1["sparse_exact_pairs"] == 0
+        inv, mf, _ = T.oracle_prepare(raw)
+        want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 150, 1, False, 0.5, 2)
+        assert np.array_equal(got, want)
 
 
 def test_early_termination_late_correlation(gpu_pkg):

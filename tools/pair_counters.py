@@ -18,5 +18,5 @@ for it in range(2):
     eng.load_genotypes_device(0, m, buf.data_ptr(), stride, pkg.LDP_GENO_REF)
     rem = eng.run()
 c = eng.counters()
-keys = ["candidate_pairs", "ms_pair_mfma", "ms_pair_mfma_general", "mfma_block_products", "mfma_product_stages", "mfma_skipped_product_stages", "ms_prepare"]
+keys = ["candidate_pairs", "ms_pair_mfma", "ms_pair_mfma_general", "mfma_block_products", "mfma_product_stages", "mfma_skipped_product_stages", "ms_prepare", "sparse_exact_pairs", "pred_true"]
 print(json.dumps({k: c.get(k) for k in keys if k in c}), int(rem.sum()))
