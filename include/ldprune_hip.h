@@ -261,6 +261,7 @@ int ldp_get_maj_freqs(ldp_engine* e, uint32_t first_variant, uint32_t n, double*
 int ldp_get_planes(ldp_engine* e, uint32_t variant, uint32_t* hom, uint32_t* ref2het);
 int ldp_get_counters(const ldp_engine* e, ldp_counters* out);
 
+
 /* ---- genotype file reader (host-side I/O edge; no GPU involved) ---- */
 /* Main-track reader for PLINK binary genotype files: .bed (storage mode 0x01), fixed-width .pgen (0x02) and
  * standard variable-width .pgen (0x10: raw / one-bit / LD-compressed / difflist records).  Replaces, for this
@@ -271,6 +272,10 @@ int ldp_get_counters(const ldp_engine* e, ldp_counters* out);
 typedef struct ldp_pgen ldp_pgen;
 int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct_hint, ldp_pgen** out);
 int ldp_pgen_info(const ldp_pgen* p, uint32_t* variant_ct, uint32_t* sample_ct, int* storage_mode, int* row_encoding, int* has_multiallelic);
+/* Which REF alleles are provisional (PgfiInitPhase1 / Phase2, pgenlib_read.cc:790,872-877: control bits 6-7 of the header):
+ * returns 0 = the .pgen does not say (the .pvar's INFO/PR does), 1 = none, 2 = all (always for a .bed), 3 = per variant, and
+ * then bit v of bits[] (up to bits_bytes bytes, may be NULL) is set when variant v's REF is provisional; -1 on a NULL handle. */
+int ldp_pgen_provisional_ref(const ldp_pgen* p, uint8_t* bits, uint64_t bits_bytes);
 /* 1 when some variant record carries a dosage track (vrtype bits 5-6).  The reader decodes hardcalls only; the reference
  * derives allele frequencies -- hence the major allele and the prune tie-break -- from dosages when they exist
  * (plink2_data.cc:2424-2566), so a caller that wants the reference's prune list must either refuse such files (plink2-hip

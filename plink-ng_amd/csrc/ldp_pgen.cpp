@@ -41,6 +41,8 @@ struct ldp_pgen {
   std::vector<uint64_t> fpos;   // variant_ct + 1 record offsets
   bool any_multiallelic = false;
   bool any_dosage = false;        // some record carries a dosage track (skipped by this reader)
+  int nonref_storage = 0;         // control bits 6-7: 0 see the .pvar, 1 every REF trusted, 2 every REF provisional, 3 nonref_bits
+  std::vector<uint8_t> nonref_bits;  // storage 3: bit v = variant v's REF allele is provisional
 };
 
 namespace {
@@ -337,11 +339,18 @@ int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct
   P->rec_bytes = (static_cast<uint64_t>(P->sample_ct) + 3) / 4;
   const uint8_t ctrl = P->map[11];
   const uint32_t nonref_storage = ctrl >> 6;
+  P->nonref_storage = static_cast<int>(nonref_storage);
+  if (nonref_storage == 3) {
+    P->nonref_bits.assign((static_cast<size_t>(P->variant_ct) + 7) / 8, 0);
+  }
   if (P->mode == 0x02) {
     if (ctrl & 63) {
       return pfail(P, LDP_ERR_INVALID, "fixed-width .pgen with a variable-width control byte.");
     }
     P->data_off = 12 + ((nonref_storage == 3) ? (static_cast<uint64_t>(P->variant_ct) + 7) / 8 : 0);
+    if ((nonref_storage == 3) && (P->size >= P->data_off)) {
+      memcpy(P->nonref_bits.data(), P->map + 12, P->nonref_bits.size());
+    }
     if (P->size != P->data_off + P->rec_bytes * P->variant_ct) {
       return pfail(P, LDP_ERR_INVALID, "Unexpected .pgen file size (expected " + std::to_string(P->data_off + P->rec_bytes * P->variant_ct) + " bytes).");
     }
@@ -402,12 +411,28 @@ int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct
     if (b + 1 == B) {
       P->fpos[M] = rec;
     }
+    if (nonref_storage == 3) {  // (the block's flags close its header section; 65,536 variants per block: byte-aligned)
+      memcpy(P->nonref_bits.data() + static_cast<size_t>(b) * (kBlockVariants / 8), P->map + pos + need - (cnt + 7) / 8, (cnt + 7) / 8);
+    }
     pos += need;
   }
   if (!M) {
     P->fpos[0] = pos;
   }
   return LDP_OK;
+}
+
+int ldp_pgen_provisional_ref(const ldp_pgen* P, uint8_t* bits, uint64_t bits_bytes) {
+  if (!P) {
+    return -1;
+  }
+  if (P->mode == 0x01) {
+    return 2;  // a .bed has no notion of REF: every A2 allele is provisional (pgenlib_read.cc:790)
+  }
+  if ((P->nonref_storage == 3) && bits) {
+    memcpy(bits, P->nonref_bits.data(), std::min<uint64_t>(bits_bytes, P->nonref_bits.size()));
+  }
+  return P->nonref_storage;
 }
 
 int ldp_pgen_info(const ldp_pgen* P, uint32_t* variant_ct, uint32_t* sample_ct, int* storage_mode, int* row_encoding, int* has_multiallelic) {

@@ -292,32 +292,32 @@ class OutFile {
     path_ = path;
     f_ = fopen(path.c_str(), "wb");
     if (!f_) {
-      die(2, "Error: Failed to open %s for writing.\n", path.c_str());
+      die(3, "Error: Failed to open %s for writing.\n", path.c_str());
     }
     if (!zs) {
       return;
     }
     void* lib = dlopen("libzstd.so.1", RTLD_NOW);
     if (!lib) {
-      die(9, "Error: 'zs' output needs libzstd.so.1, which could not be loaded.\n");
+      die(63, "Error: 'zs' output needs libzstd.so.1, which could not be loaded.\n");
     }
     create_ = reinterpret_cast<void* (*)()>(dlsym(lib, "ZSTD_createCCtx"));
     destroy_ = reinterpret_cast<size_t (*)(void*)>(dlsym(lib, "ZSTD_freeCCtx"));
     step_ = reinterpret_cast<size_t (*)(void*, Buf*, CBuf*, int)>(dlsym(lib, "ZSTD_compressStream2"));
     is_error_ = reinterpret_cast<unsigned (*)(size_t)>(dlsym(lib, "ZSTD_isError"));
     if (!create_ || !destroy_ || !step_ || !is_error_) {
-      die(9, "Error: libzstd.so.1 lacks the streaming compression API.\n");
+      die(63, "Error: libzstd.so.1 lacks the streaming compression API.\n");
     }
     ctx_ = create_();
     if (!ctx_) {
-      die(8, "Error: Out of memory.\n");
+      die(2, "Error: Out of memory.\n");
     }
     obuf_.resize(1 << 20);
   }
   void write(const void* p, size_t n) {
     if (!ctx_) {
       if (n && (fwrite(p, 1, n, f_) != n)) {
-        die(2, "Error: File write failure: %s.\n", path_.c_str());
+        die(5, "Error: File write failure: %s.\n", path_.c_str());
       }
       return;
     }
@@ -330,7 +330,7 @@ class OutFile {
       ctx_ = nullptr;
     }
     if (fclose(f_)) {
-      die(2, "Error: File write failure: %s.\n", path_.c_str());
+      die(5, "Error: File write failure: %s.\n", path_.c_str());
     }
     f_ = nullptr;
   }
@@ -350,10 +350,10 @@ class OutFile {
       Buf out{obuf_.data(), obuf_.size(), 0};
       const size_t left = step_(ctx_, &out, &in, end_op);
       if (is_error_(left)) {
-        die(2, "Error: zstd compression failure: %s.\n", path_.c_str());
+        die(5, "Error: zstd compression failure: %s.\n", path_.c_str());
       }
       if (out.pos && (fwrite(obuf_.data(), 1, out.pos, f_) != out.pos)) {
-        die(2, "Error: File write failure: %s.\n", path_.c_str());
+        die(5, "Error: File write failure: %s.\n", path_.c_str());
       }
       if (end_op ? (left == 0) : (in.pos == in.size)) {
         break;
@@ -390,6 +390,9 @@ struct Args {
   bool r2_table = false;   // --r2-unphased without a matrix shape: windowed .vcor table
   bool r2_ref_based = false;
   bool r2_allow_ambiguous = false;
+  uint32_t r2_cols = 0;            // kVcorCol* (set after the modifiers are read: plink2.cc:11158-11207)
+  std::string r2_cols_desc;        // the text behind cols=
+  bool r2_cols_given = false;
   bool r2_zs = false;      // 'zs': Zstandard-compressed table / text matrix
   bool r2_inter = false;   // 'inter-chr': the table over ALL pairs, chromosome 0 included (plink2_ld.cc:11082-11116)
   bool r2_text = false;    // matrix shape without bin/bin4: text matrix
@@ -456,11 +459,68 @@ bool ieq(const char* a, const char* b) {
 
 const char* scan_ln(const char* s, double* ln_out);  // (--clump section below)
 
+// ---- --r2-unphased cols= (plink2_ld.h:87-101, ParseColDescriptor plink2_cmdline.cc:4375) ----
+enum : uint32_t {
+  kVcorColChrom = 1u << 0, kVcorColPos = 1u << 1, kVcorColId = 1u << 2, kVcorColRef = 1u << 3, kVcorColAlt1 = 1u << 4, kVcorColAlt = 1u << 5,
+  kVcorColMaybeprovref = 1u << 6, kVcorColProvref = 1u << 7, kVcorColMaj = 1u << 8, kVcorColNonmaj = 1u << 9, kVcorColFreq = 1u << 10,
+  kVcorColD = 1u << 11, kVcorColDprime = 1u << 12, kVcorColDprimeAbs = 1u << 13,
+  kVcorColDefault = kVcorColChrom | kVcorColPos | kVcorColId | kVcorColMaybeprovref
+};
+
+// A column-set descriptor: either a plain list (exactly these columns) or +name / -name edits of the default set, never
+// both; "-x" also removes "maybex" when x itself is not set.
+uint32_t parse_col_descriptor(const std::string& desc, const std::vector<std::string>& names, uint32_t default_cols, const char* flag) {
+  auto find = [&](const std::string& id) {
+    for (size_t k = 0; k < names.size(); ++k) {
+      if (names[k] == id) {
+        return static_cast<int>(k);
+      }
+    }
+    return -1;
+  };
+  uint32_t result = 0;
+  if (desc.empty()) {
+    return result;
+  }
+  const bool edits = (desc[0] == '+') || (desc[0] == '-');
+  if (edits) {
+    result = default_cols;
+  }
+  for (size_t p0 = 0; p0 <= desc.size();) {
+    const size_t p1 = std::min(desc.find(',', p0), desc.size());
+    std::string tok = desc.substr(p0, p1 - p0);
+    const bool signed_tok = (!tok.empty()) && ((tok[0] == '+') || (tok[0] == '-'));
+    if (signed_tok != edits) {
+      die(8, "Error: Invalid --%s column set descriptor (either all column set IDs must be\npreceded by +/-, or none of them can be).\n", flag);
+    }
+    const char sign = edits ? tok[0] : '+';
+    if (edits) {
+      tok.erase(0, 1);
+    }
+    const int k = find(tok);
+    if (k < 0) {
+      die(8, "Error: Unrecognized ID '%s' in --%s column set descriptor.\n", tok.c_str(), flag);
+    }
+    if (sign == '+') {
+      result |= 1u << k;
+    } else if (result & (1u << k)) {
+      result -= 1u << k;
+    } else {
+      const int mk = find("maybe" + tok);
+      if (mk >= 0) {
+        result &= ~(1u << mk);
+      }
+    }
+    p0 = p1 + 1;
+  }
+  return result;
+}
+
 Args parse_args(int argc, char** argv) {
   Args A;
   auto need = [&](int i, int n, const char* flag) {
     if (i + n >= argc) {
-      die(5, "Error: Missing argument for %s.\n", flag);
+      die(8, "Error: Missing argument for %s.\n", flag);
     }
   };
   for (int i = 1; i < argc; ++i) {
@@ -500,7 +560,7 @@ Args parse_args(int argc, char** argv) {
       else A.preferred = v;
     } else if (f == "--indep-pairwise" || f == "--indep-pairphase") {
       if (A.have_prune) {
-        die(5, "Error: --indep-pairwise and --indep-pairphase cannot be used together.\n");
+        die(8, "Error: --indep-pairwise and --indep-pairphase cannot be used together.\n");
       }
       A.pairphase = (f == "--indep-pairphase");
       const char* fl = f.c_str();
@@ -510,19 +570,19 @@ Args parse_args(int argc, char** argv) {
         par.emplace_back(argv[++i]);
       }
       if (par.size() < 2 || par.size() > 4) {
-        die(5, "Error: %s accepts 2-4 arguments.\n", fl);
+        die(8, "Error: %s accepts 2-4 arguments.\n", fl);
       }
       double first;
       const char* endp;
       if (!scan_double_plink(par[0].c_str(), &first, &endp) || first < 0.0) {
-        die(5, "Error: Invalid %s window size '%s'.\n", fl, par[0].c_str());
+        die(8, "Error: Invalid %s window size '%s'.\n", fl, par[0].c_str());
       }
       size_t next = 1;
       bool is_kb = false;
       if (ieq(endp, "kb")) {
         is_kb = true;
       } else if (*endp) {
-        die(5, "Error: Invalid %s window size '%s'.\n", fl, par[0].c_str());
+        die(8, "Error: Invalid %s window size '%s'.\n", fl, par[0].c_str());
       } else if (ieq(par[1].c_str(), "kb")) {
         is_kb = true;
         next = 2;
@@ -534,7 +594,7 @@ Args parse_args(int argc, char** argv) {
         } else {
           const int32_t w = static_cast<int32_t>(first * 1000 * (1 + kSmallEpsilon));
           if (w < 2) {
-            die(5, "Error: %s window size cannot be smaller than 2.\n", fl);
+            die(8, "Error: %s window size cannot be smaller than 2.\n", fl);
           }
           A.window = w;
         }
@@ -546,23 +606,23 @@ Args parse_args(int argc, char** argv) {
         char* e2;
         const long st = strtol(par[next].c_str(), &e2, 10);
         if (*e2 || st < 1 || st > 2147483646) {
-          die(5, "Error: Invalid %s window-increment '%s'.\n", fl, par[next].c_str());
+          die(8, "Error: Invalid %s window-increment '%s'.\n", fl, par[next].c_str());
         }
         A.step = static_cast<uint32_t>(st);
         if (!is_kb) {
           if (A.step > A.window) {
-            die(5, "Error: %s window-increment cannot be larger than window size.\n", fl);
+            die(8, "Error: %s window-increment cannot be larger than window size.\n", fl);
           }
         } else if (A.step != 1) {
-          die(5, "Error: %s window-increment must be 1 when window size is in\nkilobase units.\n", fl);
+          die(8, "Error: %s window-increment must be 1 when window size is in\nkilobase units.\n", fl);
         }
         ++next;
       } else if (next + 1 != par.size()) {
-        die(5, "Error: Invalid %s argument sequence.\n", fl);
+        die(8, "Error: Invalid %s argument sequence.\n", fl);
       }
       const char* e3;
       if (!scan_double_plink(par[next].c_str(), &A.r2, &e3) || *e3 || A.r2 < 0.0 || A.r2 >= 1.0) {
-        die(5, "Error: Invalid %s r^2 threshold '%s'.\n", fl, par[next].c_str());
+        die(8, "Error: Invalid %s r^2 threshold '%s'.\n", fl, par[next].c_str());
       }
       A.have_prune = true;
     } else if (f == "--r2-unphased") {
@@ -572,10 +632,10 @@ Args parse_args(int argc, char** argv) {
         const bool is_shape = (m == "square") || (m == "square0") || (m == "triangle");
         const bool is_encoding = (m == "bin") || (m == "bin4") || (m == "zs");
         if (is_shape && (A.r2_shape >= 0)) {
-          die(5, "Error: Multiple --r2-unphased shape modifiers.\n");  // plink2.cc:11068-11090
+          die(8, "Error: Multiple --r2-unphased shape modifiers.\n");  // plink2.cc:11068-11090
         }
         if (is_encoding && ((A.r2_float >= 0) || A.r2_zs)) {
-          die(5, "Error: Multiple --r2-unphased encoding modifiers.\n");  // plink2.cc:11106-11118
+          die(8, "Error: Multiple --r2-unphased encoding modifiers.\n");  // plink2.cc:11106-11118
         }
         if (m == "square") A.r2_shape = 0;
         else if (m == "square0") A.r2_shape = 1;
@@ -587,13 +647,31 @@ Args parse_args(int argc, char** argv) {
         else if (m == "yes-really") A.yes_really = true;
         else if (m == "ref-based") A.r2_ref_based = true;          // multiallelic variants: REF vs the rest instead of major vs the rest
         else if (m == "allow-ambiguous-allele") A.r2_allow_ambiguous = true;
-        else die(9, "Error: --r2-unphased modifier '%s' is not supported by plink2-hip (matrix shapes with bin/bin4, or the default-column table).\n", m.c_str());
+        else if (m.compare(0, 5, "cols=") == 0) {
+          if (A.r2_cols_given) {
+            die(8, "Error: Multiple --r2-unphased cols= modifiers.\n");
+          }
+          A.r2_cols_given = true;
+          A.r2_cols_desc = m.substr(5);
+        }
+        else if ((m == "d") || (m == "dprime") || (m == "dprime-signed")) {
+          die(8, "Error: --r2-unphased does not support computation of D or D'. Use --r2-phased\nwith 'cols=+%s' instead.\n", (m == "d") ? "d" : ((m == "dprime") ? "dprimeabs" : "dprime"));
+        }
+        else die(63, "Error: --r2-unphased modifier '%s' is not supported by plink2-hip (matrix shapes with bin/bin4, or the default-column table).\n", m.c_str());
       }
       if ((A.r2_shape < 0) && (A.r2_float >= 0)) {
         A.r2_shape = 0;  // an encoding without a shape: square (plink2_help.cc:1015-1017)
       }
-      if (A.r2_inter && (A.r2_shape >= 0)) {
-        die(5, "Error: Matrix-only and table-only --r2-unphased settings cannot be used together.\n");  // plink2.cc:11187-11191
+      A.r2_cols = kVcorColDefault;
+      if (A.r2_cols_given) {  // plink2.cc:11158-11172
+        A.r2_cols = parse_col_descriptor(A.r2_cols_desc, {"chrom", "pos", "id", "ref", "alt1", "alt", "maybeprovref", "provref", "maj", "nonmaj", "freq", "d", "dprime", "dprimeabs"},
+                                         kVcorColDefault, "r2-unphased");
+        if (A.r2_cols & (kVcorColD | kVcorColDprime | kVcorColDprimeAbs)) {
+          die(8, "Error: --r2-unphased does not support computation of D or D'. Use --r2-phased\ninstead.\n");
+        }
+      }
+      if ((A.r2_inter || A.r2_cols_given) && (A.r2_shape >= 0)) {
+        die(8, "Error: Matrix-only and table-only --r2-unphased settings cannot be used together.\n");  // plink2.cc:11187-11191
       }
       A.r2_table = (A.r2_shape < 0);
       A.r2_text = (A.r2_shape >= 0) && (A.r2_float < 0);  // shape without bin/bin4: tab-delimited text matrix
@@ -606,7 +684,7 @@ Args parse_args(int argc, char** argv) {
       while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
         const std::string arg = argv[++i];
         if ((arg == "zs") || (arg.compare(0, 5, "cols=") == 0)) {
-          die(9, "Error: the '%s' modifier of --clump is not supported by plink2-hip.\n", arg.c_str());
+          die(63, "Error: the '%s' modifier of --clump is not supported by plink2-hip.\n", arg.c_str());
         }
         size_t p0 = 0;
         while (p0 <= arg.size()) {
@@ -628,7 +706,7 @@ Args parse_args(int argc, char** argv) {
       double ln;
       const char* endp = scan_ln(v.c_str(), &ln);
       if (!endp || *endp || (ln > 0.0)) {
-        die(5, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
+        die(8, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
       }
       ((f == "--clump-p1") ? A.clump_ln_p1 : A.clump_ln_p2) = ln * (1.0 - kSmallEpsilon);
     } else if (f == "--clump-r2") {  // plink2.cc:5047-5059
@@ -637,7 +715,7 @@ Args parse_args(int argc, char** argv) {
       double d;
       const char* endp;
       if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || (d >= 1.0 - kSmallEpsilon)) {
-        die(5, "Error: Invalid --clump-r2 argument '%s'.\n", v.c_str());
+        die(8, "Error: Invalid --clump-r2 argument '%s'.\n", v.c_str());
       }
       A.clump_r2_raw = d;
       A.clump_r2 = d * (1.0 + kSmallEpsilon);
@@ -647,7 +725,7 @@ Args parse_args(int argc, char** argv) {
       double d;
       const char* endp;
       if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || (d < 0.001)) {
-        die(5, "Error: Invalid --clump-kb argument '%s'.\n", v.c_str());
+        die(8, "Error: Invalid --clump-kb argument '%s'.\n", v.c_str());
       }
       d *= 1000;
       A.clump_bp_radius = (d > 2147483647.0) ? 0x7ffffffeu : static_cast<uint32_t>(static_cast<int32_t>(d * (1.0 + kSmallEpsilon) - 1));
@@ -665,12 +743,12 @@ Args parse_args(int argc, char** argv) {
         ((f == "--clump-test") ? A.clump_test : A.clump_test_field) = names;
       } else {
         if (names.empty()) {
-          die(5, "Error: %s needs at least one column name.\n", f.c_str());
+          die(8, "Error: %s needs at least one column name.\n", f.c_str());
         }
         (((f == "--clump-p-field") || (f == "--clump-field")) ? A.clump_p_field : A.clump_id_field) = names;
       }
     } else if (f.compare(0, 7, "--clump") == 0) {
-      die(9, "Error: %s is not supported by plink2-hip's --clump yet.\n", f.c_str());
+      die(63, "Error: %s is not supported by plink2-hip's --clump yet.\n", f.c_str());
     } else if ((f == "--chr") || (f == "--not-chr")) {  // ParseChrRanges, plink2_cmdline.cc: "1-4, 22, X" in one or several arguments
       std::vector<std::string>& dst = (f == "--chr") ? A.chr_keep : A.chr_drop;
       while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
@@ -685,7 +763,7 @@ Args parse_args(int argc, char** argv) {
         }
       }
       if (dst.empty()) {
-        die(5, "Error: %s requires at least one value.\n", f.c_str());
+        die(8, "Error: %s requires at least one value.\n", f.c_str());
       }
     } else if (f == "--max-alleles") {  // plink2.cc:9340-9360
       need(i, 1, "--max-alleles");
@@ -693,7 +771,7 @@ Args parse_args(int argc, char** argv) {
       char* endp;
       const unsigned long n = strtoul(v.c_str(), &endp, 10);
       if (v.empty() || *endp || (n < 2) || (n > 0x7fffffffUL)) {
-        die(5, "Error: Invalid --max-alleles argument '%s'.\n", v.c_str());
+        die(8, "Error: Invalid --max-alleles argument '%s'.\n", v.c_str());
       }
       A.max_alleles = static_cast<uint32_t>(n);
     } else if (f == "--autosome") {
@@ -705,21 +783,21 @@ Args parse_args(int argc, char** argv) {
         const char* endp;
         if (!scan_double_plink(v.c_str(), &d, &endp) || *endp) {
           if (*endp == ':' || !((v[0] >= '0' && v[0] <= '9') || v[0] == '.')) {
-            die(9, "Error: %s modifiers ('%s') are not supported by plink2-hip.\n", f.c_str(), v.c_str());
+            die(63, "Error: %s modifiers ('%s') are not supported by plink2-hip.\n", f.c_str(), v.c_str());
           }
-          die(5, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
+          die(8, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
         }
         if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
-          die(9, "Error: %s modifiers ('%s') are not supported by plink2-hip.\n", f.c_str(), argv[i + 1]);
+          die(63, "Error: %s modifiers ('%s') are not supported by plink2-hip.\n", f.c_str(), argv[i + 1]);
         }
         if (d < 0.0) {
-          die(5, "Error: %s argument '%s' too small (must be >= 0).\n", f.c_str(), v.c_str());
+          die(8, "Error: %s argument '%s' too small (must be >= 0).\n", f.c_str(), v.c_str());
         }
         if ((f == "--max-maf") ? (d >= 1.0) : (d > 1.0)) {
-          die(5, "Error: %s argument '%s' too large (must be %s 1).\n", f.c_str(), v.c_str(), (f == "--max-maf") ? "<" : "<=");
+          die(8, "Error: %s argument '%s' too large (must be %s 1).\n", f.c_str(), v.c_str(), (f == "--max-maf") ? "<" : "<=");
         }
       } else if (f == "--max-maf") {
-        die(5, "Error: --max-maf requires a value.\n");
+        die(8, "Error: --max-maf requires a value.\n");
       }
       ((f == "--maf") ? A.min_maf : ((f == "--max-maf") ? A.max_maf : A.geno)) = d;
     } else if ((f == "--extract") || (f == "--exclude") || (f == "--keep") || (f == "--remove")) {
@@ -728,20 +806,20 @@ Args parse_args(int argc, char** argv) {
         dst.push_back(argv[++i]);
       }
       if (dst.empty()) {
-        die(5, "Error: %s requires at least one filename.\n", f.c_str());
+        die(8, "Error: %s requires at least one filename.\n", f.c_str());
       }
       if (((f == "--extract") || (f == "--exclude")) && ((dst[0] == "range") || (dst[0] == "bed0") || (dst[0] == "bed1") || (dst[0] == "intersect"))) {
-        die(9, "Error: the '%s' mode of %s is not supported by plink2-hip.\n", dst[0].c_str(), f.c_str());
+        die(63, "Error: the '%s' mode of %s is not supported by plink2-hip.\n", dst[0].c_str(), f.c_str());
       }
     } else if (f == "--ld-snp") {
       need(i, 1, "--ld-snp");
       if (!A.ld_snps.empty() || !A.ld_snp_list.empty()) {
-        die(5, "Error: --ld-snp cannot be used with --ld-snps or --ld-snp-list.\n");
+        die(8, "Error: --ld-snp cannot be used with --ld-snps or --ld-snp-list.\n");
       }
       A.ld_snps.emplace_back(argv[++i], "");
     } else if (f == "--ld-snps") {  // ParseNameRanges, plink2_cmdline.cc:2247: comma-separated IDs and first-last ranges
       if (!A.ld_snps.empty() || !A.ld_snp_list.empty()) {
-        die(5, "Error: --ld-snps cannot be used with --ld-snp or --ld-snp-list.\n");
+        die(8, "Error: --ld-snps cannot be used with --ld-snp or --ld-snp-list.\n");
       }
       while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
         const std::string arg = argv[++i];
@@ -751,7 +829,7 @@ Args parse_args(int argc, char** argv) {
           const std::string piece = arg.substr(p0, p1 - p0);
           const size_t dash = piece.find('-');
           if (piece.empty() || (dash == 0) || (dash + 1 == piece.size())) {
-            die(5, "Error: Invalid --ld-snps argument '%s'.\n", arg.c_str());
+            die(8, "Error: Invalid --ld-snps argument '%s'.\n", arg.c_str());
           }
           if (dash == std::string::npos) {
             A.ld_snps.emplace_back(piece, "");
@@ -762,12 +840,12 @@ Args parse_args(int argc, char** argv) {
         }
       }
       if (A.ld_snps.empty()) {
-        die(5, "Error: --ld-snps requires at least one value.\n");
+        die(8, "Error: --ld-snps requires at least one value.\n");
       }
     } else if (f == "--ld-snp-list") {
       need(i, 1, "--ld-snp-list");
       if (!A.ld_snps.empty()) {
-        die(5, "Error: --ld-snp-list cannot be used with --ld-snp.\n");
+        die(8, "Error: --ld-snp-list cannot be used with --ld-snp.\n");
       }
       A.ld_snp_list = argv[++i];
     } else if (f == "--ld-window") {  // plink2.cc:7908-7920
@@ -776,7 +854,7 @@ Args parse_args(int argc, char** argv) {
       char* endp;
       const unsigned long n = strtoul(v.c_str(), &endp, 10);
       if (v.empty() || *endp || n < 2 || n > 0x7ffffffeul) {
-        die(5, "Error: Invalid --ld-window argument '%s'.\n", v.c_str());
+        die(8, "Error: Invalid --ld-window argument '%s'.\n", v.c_str());
       }
       A.ld_var_ct_radius = static_cast<uint32_t>(n) - 1;
     } else if (f == "--ld-window-kb") {  // plink2.cc:7921-7937
@@ -785,7 +863,7 @@ Args parse_args(int argc, char** argv) {
       double d;
       const char* endp;
       if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || d < 0) {
-        die(5, "Error: Invalid --ld-window-kb argument '%s'.\n", v.c_str());
+        die(8, "Error: Invalid --ld-window-kb argument '%s'.\n", v.c_str());
       }
       d *= 1000 * (1 + kSmallEpsilon);
       A.ld_bp_radius = (d > 2147483646) ? 2147483646u : static_cast<uint32_t>(static_cast<int32_t>(d));
@@ -795,20 +873,20 @@ Args parse_args(int argc, char** argv) {
       double d;
       const char* endp;
       if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || d > 1.0) {
-        die(5, "Error: Invalid --ld-window-r2 argument '%s'.\n", v.c_str());
+        die(8, "Error: Invalid --ld-window-r2 argument '%s'.\n", v.c_str());
       }
       if (d > 0.0) {
         d *= 1 - kSmallEpsilon;
       }
       A.ld_min_r2 = d;
     } else if (f == "--ld-window-cm" || f == "--ld-snp" || f == "--ld-snps" || f == "--ld-snp-list") {
-      die(9, "Error: %s is not supported by plink2-hip.\n", f.c_str());
+      die(63, "Error: %s is not supported by plink2-hip.\n", f.c_str());
     } else if (f == "--indep-order") {
       need(i, 1, "--indep-order");
       std::string v = argv[++i];
       if (v == "1") A.order = 1;
       else if (v == "2") A.order = 2;
-      else die(5, "Error: Invalid --indep-order mode '%s' ('1' or '2' expected).\n", v.c_str());
+      else die(8, "Error: Invalid --indep-order mode '%s' ('1' or '2' expected).\n", v.c_str());
     } else if (f == "--bad-ld") {
       A.bad_ld = true;
     } else if (f == "--allow-extra-chr") {
@@ -822,7 +900,7 @@ Args parse_args(int argc, char** argv) {
       need(i, 1, "--debug-format-g6");
       FILE* df = fopen(argv[++i], "r");
       if (!df) {
-        die(2, "Error: Failed to open %s.\n", argv[i]);
+        die(3, "Error: Failed to open %s.\n", argv[i]);
       }
       char line[64], num[40];
       while (fgets(line, sizeof(line), df)) {
@@ -839,7 +917,7 @@ Args parse_args(int argc, char** argv) {
       need(i, 2, "--debug-zstd");
       std::ifstream in(argv[i + 1], std::ios::binary);
       if (!in) {
-        die(2, "Error: Failed to open %s.\n", argv[i + 1]);
+        die(3, "Error: Failed to open %s.\n", argv[i + 1]);
       }
       std::stringstream ss;
       ss << in.rdbuf();
@@ -857,11 +935,11 @@ Args parse_args(int argc, char** argv) {
       char* end = nullptr;
       const long k = strtol(argv[i + 1], &end, 10);
       if ((*end) || (k < 1) || (k > 32768)) {
-        die(5, "Error: Invalid --parallel job index '%s'.\n", argv[i + 1]);
+        die(8, "Error: Invalid --parallel job index '%s'.\n", argv[i + 1]);
       }
       const long n = strtol(argv[i + 2], &end, 10);
       if ((*end) || (n < 2) || (n > 32768) || (n < k)) {
-        die(5, "Error: Invalid --parallel total job count '%s'.\n", argv[i + 2]);
+        die(8, "Error: Invalid --parallel total job count '%s'.\n", argv[i + 2]);
       }
       A.parallel_idx = static_cast<uint32_t>(k - 1);
       A.parallel_tot = static_cast<uint32_t>(n);
@@ -873,64 +951,64 @@ Args parse_args(int argc, char** argv) {
       need(i, 1, f.c_str());
       ++i;  // accepted for command-line compatibility; the work runs on the GPU(s)
     } else {
-      die(5, "Error: Unrecognized flag ('%s').  plink2-hip implements the --indep-pairwise path only.\n", f.c_str());
+      die(8, "Error: Unrecognized flag ('%s').  plink2-hip implements the --indep-pairwise path only.\n", f.c_str());
     }
   }
   if (A.have_clump) {
     if (A.have_prune || A.have_r2) {
-      die(5, "Error: run --clump on its own.\n");
+      die(8, "Error: run --clump on its own.\n");
     }
     if (!A.clump_unphased) {
       // (without it the reference uses phased-hardcall / EM haplotype-frequency r^2, ComputeR2 :6490-6650: not this path)
-      die(9, "Error: plink2-hip's --clump computes unphased hardcall r^2 only: add --clump-unphased.\n");
+      die(63, "Error: plink2-hip's --clump computes unphased hardcall r^2 only: add --clump-unphased.\n");
     }
     if (A.parallel_tot != 1) {
-      die(5, "Error: --parallel has no effect on --clump.\n");
+      die(8, "Error: --parallel has no effect on --clump.\n");
     }
     // the rest of the program sees a windowed r^2 run: chromosome 0 stripped, sorted positions required
     A.have_r2 = true;
     A.r2_table = true;
   } else if (A.clump_unphased) {
-    die(5, "Error: --clump-unphased must be used with --clump.\n");
+    die(8, "Error: --clump-unphased must be used with --clump.\n");
   }
   if (!A.have_prune && !A.have_r2) {
-    die(5, "Error: no command given (plink2-hip implements --indep-pairwise and --r2-unphased matrices).\n");
+    die(8, "Error: no command given (plink2-hip implements --indep-pairwise and --r2-unphased matrices).\n");
   }
   if (A.have_prune && (A.parallel_tot != 1)) {
-    die(9, "Error: --parallel only distributes the --r2-unphased outputs in plink2-hip (the prune shards by --gpus).\n");
+    die(63, "Error: --parallel only distributes the --r2-unphased outputs in plink2-hip (the prune shards by --gpus).\n");
   }
   if (A.have_prune && A.have_r2) {
-    die(5, "Error: run --indep-pairwise and --r2-unphased separately.\n");
+    die(8, "Error: run --indep-pairwise and --r2-unphased separately.\n");
   }
   const bool ld_window_given = (A.ld_var_ct_radius != 0x7fffffff) || (A.ld_bp_radius != 0xffffffffu);
   const bool ld_snp_given = (!A.ld_snps.empty()) || (!A.ld_snp_list.empty());
   if (ld_snp_given && (!A.have_r2 || A.have_clump)) {
-    die(5, "Error: --ld-window.../--ld-snp... must be used with --r[2]-[un]phased.\n");  // plink2.cc:12960
+    die(8, "Error: --ld-window.../--ld-snp... must be used with --r[2]-[un]phased.\n");  // plink2.cc:12960
   }
   if (ld_snp_given && A.have_r2 && (!A.r2_table)) {  // plink2.cc:11186-11191
-    die(5, "Error: Matrix-only and table-only --r2-unphased settings cannot be used together.\n");
+    die(8, "Error: Matrix-only and table-only --r2-unphased settings cannot be used together.\n");
   }
   if (ld_snp_given && (A.ld_var_ct_radius != 0x7fffffff)) {
     // With a variant-count window the reference's row windows are irregular: its second pass restarts each chromosome's window
     // search at a position its first pass has already cleared, and FindNth1BitFrom (UpdateVcorWindow, plink2_ld.cc:10997-11001)
     // then keeps one variant more on the leading side for the rows that follow (snp101,snp103 with --ld-window 3 pairs snp103
     // with snp100).  Not reproduced.
-    die(9, "Error: --ld-window together with --ld-snp/--ld-snps/--ld-snp-list is not supported by plink2-hip (--ld-window-kb is).\n");
+    die(63, "Error: --ld-window together with --ld-snp/--ld-snps/--ld-snp-list is not supported by plink2-hip (--ld-window-kb is).\n");
   }
   if (ld_snp_given && (A.parallel_tot != 1)) {
-    die(9, "Error: --parallel with --ld-snp/--ld-snps/--ld-snp-list is not supported by plink2-hip yet.\n");
+    die(63, "Error: --parallel with --ld-snp/--ld-snps/--ld-snp-list is not supported by plink2-hip yet.\n");
   }
   if ((ld_window_given || A.ld_min_r2 != 2.0) && !A.have_r2) {
-    die(5, "Error: --ld-window.../--ld-snp... must be used with --r[2]-[un]phased.\n");  // plink2.cc:12960
+    die(8, "Error: --ld-window.../--ld-snp... must be used with --r[2]-[un]phased.\n");  // plink2.cc:12960
   }
   if (A.have_r2 && ((!A.r2_table) || A.r2_inter)) {
     if (ld_window_given) {  // plink2.cc:11175-11179
-      die(5, "Error: All-pairs --r2-unphased settings cannot be used with --ld-window/--ld-window-kb/--ld-window-cm.\n");
+      die(8, "Error: All-pairs --r2-unphased settings cannot be used with --ld-window/--ld-window-kb/--ld-window-cm.\n");
     }
   }
   if (A.have_r2 && !A.r2_table) {
     if (A.ld_min_r2 != 2.0) {  // plink2.cc:11186-11191
-      die(5, "Error: Matrix-only and table-only --r2-unphased settings cannot be used together.\n");
+      die(8, "Error: Matrix-only and table-only --r2-unphased settings cannot be used together.\n");
     }
   }
   if (A.r2_table) {  // table defaults, plink2.cc:11181-11205
@@ -942,7 +1020,7 @@ Args parse_args(int argc, char** argv) {
     }
   }
   if (A.gpus < 1) {
-    die(5, "Error: --gpus must be positive.\n");
+    die(8, "Error: --gpus must be positive.\n");
   }
   return A;
 }
@@ -954,7 +1032,7 @@ void load_samples(const Args& A, std::vector<uint8_t>* is_founder, std::vector<u
   const std::string& path = psam ? A.psam : A.fam;
   std::ifstream in(path);
   if (!in) {
-    die(2, "Error: Failed to open %s.\n", path.c_str());
+    die(3, "Error: Failed to open %s.\n", path.c_str());
   }
   std::string line;
   int pat_col = -1, mat_col = -1, sex_col = -1, iid_col = 0;
@@ -984,7 +1062,7 @@ void load_samples(const Args& A, std::vector<uint8_t>* is_founder, std::vector<u
     if (!psam || !header_seen) {
       // .fam layout: FID IID PAT MAT SEX PHENO
       if (t.size() < 5) {
-        die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
+        die(6, "Error: Fewer tokens than expected in %s.\n", path.c_str());
       }
       is_founder->push_back((t[2] == "0") && (t[3] == "0"));
       if (fid_iid) {
@@ -996,14 +1074,14 @@ void load_samples(const Args& A, std::vector<uint8_t>* is_founder, std::vector<u
       bool founder = true;
       if (pat_col >= 0 && mat_col >= 0) {
         if (static_cast<size_t>(std::max(pat_col, mat_col)) >= t.size()) {
-          die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
+          die(6, "Error: Fewer tokens than expected in %s.\n", path.c_str());
         }
         founder = (t[pat_col] == "0") && (t[mat_col] == "0");
       }
       is_founder->push_back(founder);
       if (fid_iid) {  // (no FID column: FID "0", as the reference keys its samples)
         if (static_cast<size_t>(iid_col) >= t.size()) {
-          die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
+          die(6, "Error: Fewer tokens than expected in %s.\n", path.c_str());
         }
         fid_iid->push_back((has_fid ? t[0] : std::string("0")) + "\t" + t[iid_col]);
       }
@@ -1021,13 +1099,15 @@ struct Variants {
   std::vector<std::string> chrom, id;
   std::vector<uint32_t> bp;
   std::vector<uint8_t> alt_ct;  // number of ALT alleles (1 for biallelic / .bim), capped at 255
+  std::vector<std::string> ref, alt;  // allele text (ALT comma-separated as in the file); only kept for --r2-unphased allele columns
+  bool info_pr_header = false;        // the .pvar declares INFO/PR (provisional REF alleles are flagged per variant there)
 };
 
 // whole file -> memory; the variant/sample tables are a few tens of MB even at 10M variants
 std::string slurp(const std::string& path) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) {
-    die(2, "Error: Failed to open %s.\n", path.c_str());
+    die(3, "Error: Failed to open %s.\n", path.c_str());
   }
   std::string buf;
   fseek(f, 0, SEEK_END);
@@ -1035,7 +1115,7 @@ std::string slurp(const std::string& path) {
   fseek(f, 0, SEEK_SET);
   buf.resize(sz > 0 ? static_cast<size_t>(sz) : 0);
   if (sz > 0 && fread(&buf[0], 1, buf.size(), f) != buf.size()) {
-    die(2, "Error: Failed to read %s.\n", path.c_str());
+    die(4, "Error: Failed to read %s.\n", path.c_str());
   }
   fclose(f);
   return buf;
@@ -1054,7 +1134,7 @@ std::string slurp_zst(const std::string& path) {
   };
   void* lib = dlopen("libzstd.so.1", RTLD_NOW);
   if (!lib) {
-    die(9, "Error: %s is zstd-compressed and libzstd.so.1 could not be loaded (%s).\n", path.c_str(), dlerror());
+    die(63, "Error: %s is zstd-compressed and libzstd.so.1 could not be loaded (%s).\n", path.c_str(), dlerror());
   }
   auto create = reinterpret_cast<void* (*)()>(dlsym(lib, "ZSTD_createDStream"));
   auto destroy = reinterpret_cast<size_t (*)(void*)>(dlsym(lib, "ZSTD_freeDStream"));
@@ -1062,12 +1142,12 @@ std::string slurp_zst(const std::string& path) {
   auto step = reinterpret_cast<size_t (*)(void*, OutBuf*, InBuf*)>(dlsym(lib, "ZSTD_decompressStream"));
   auto is_error = reinterpret_cast<unsigned (*)(size_t)>(dlsym(lib, "ZSTD_isError"));
   if (!create || !destroy || !init || !step || !is_error) {
-    die(9, "Error: libzstd.so.1 lacks the streaming decompression API.\n");
+    die(63, "Error: libzstd.so.1 lacks the streaming decompression API.\n");
   }
   const std::string in = slurp(path);
   void* ds = create();
   if (!ds || is_error(init(ds))) {
-    die(9, "Error: zstd decompressor setup failed.\n");
+    die(63, "Error: zstd decompressor setup failed.\n");
   }
   std::string out;
   std::vector<char> chunk(4u << 20);
@@ -1077,7 +1157,7 @@ std::string slurp_zst(const std::string& path) {
     OutBuf ob = {chunk.data(), chunk.size(), 0};
     last = step(ds, &ob, &ib);
     if (is_error(last)) {
-      die(3, "Error: %s is not a valid zstd stream.\n", path.c_str());
+      die(6, "Error: %s is not a valid zstd stream.\n", path.c_str());
     }
     out.append(chunk.data(), ob.pos);
   }
@@ -1086,11 +1166,11 @@ std::string slurp_zst(const std::string& path) {
     InBuf none = {in.data(), ib.size, ib.size};
     last = step(ds, &ob, &none);
     if (is_error(last)) {
-      die(3, "Error: %s is not a valid zstd stream.\n", path.c_str());
+      die(6, "Error: %s is not a valid zstd stream.\n", path.c_str());
     }
     out.append(chunk.data(), ob.pos);
     if (!ob.pos && last) {
-      die(3, "Error: %s ends inside a zstd frame.\n", path.c_str());
+      die(6, "Error: %s ends inside a zstd frame.\n", path.c_str());
     }
   }
   destroy(ds);
@@ -1133,7 +1213,8 @@ void load_variants(const Args& A, Variants* V) {
   const bool zst = (path.size() > 4) && (path.compare(path.size() - 4, 4, ".zst") == 0);
   const std::string buf = zst ? slurp_zst(path) : slurp(path);
   bool header = false;
-  int c_chrom = 0, c_pos = 3, c_id = 1, c_alt = -1;
+  int c_chrom = 0, c_pos = 3, c_id = 1, c_alt = -1, c_ref = -1;
+  const bool keep_alleles = A.have_r2 && (A.r2_cols & (kVcorColRef | kVcorColAlt1 | kVcorColAlt | kVcorColMaj | kVcorColNonmaj));
   constexpr int kCap = 64;
   Tok t[kCap];
   const char* p = buf.data();
@@ -1161,11 +1242,14 @@ void load_variants(const Args& A, Variants* V) {
           if (t[c].eq("POS")) c_pos = c;
           if (t[c].eq("ID")) c_id = c;
           if (t[c].eq("ALT")) c_alt = c;
+          if (t[c].eq("REF")) c_ref = c;
         }
         if (c_pos < 0 || c_id < 0) {
-          die(3, "Error: %s header lacks POS/ID.\n", path.c_str());
+          die(6, "Error: %s header lacks POS/ID.\n", path.c_str());
         }
         header = true;
+      } else if ((eol - line) >= 14 && !memcmp(line, "##INFO=<ID=PR,", 14)) {
+        V->info_pr_header = true;
       }
       continue;
     }
@@ -1178,35 +1262,44 @@ void load_variants(const Args& A, Variants* V) {
       if (nt == 5) {
         c_pos = 2;
       } else if (nt < 6) {
-        die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
+        die(6, "Error: Fewer tokens than expected in %s.\n", path.c_str());
       }
     }
     if (std::max(std::max(c_chrom, c_pos), c_id) >= std::min(nt, kCap)) {
-      die(3, "Error: Fewer tokens than expected in %s.\n", path.c_str());
+      die(6, "Error: Fewer tokens than expected in %s.\n", path.c_str());
     }
     uint32_t alts = 1;
     if (c_alt >= 0 && c_alt < std::min(nt, kCap)) {
       alts += static_cast<uint32_t>(std::count(t[c_alt].p, t[c_alt].p + t[c_alt].n, ','));
     }
     if (alts > 254) {
-      die(9, "Error: variant '%.*s' has more than 254 ALT alleles, which plink2-hip does not support.\n", static_cast<int>(t[c_id].n), t[c_id].p);
+      die(63, "Error: variant '%.*s' has more than 254 ALT alleles, which plink2-hip does not support.\n", static_cast<int>(t[c_id].n), t[c_id].p);
     }
     V->alt_ct.push_back(static_cast<uint8_t>(alts));
+    if (keep_alleles) {
+      // .bim: ... A1 A2 with A1 -> ALT, A2 -> REF (LoadPvar, plink2_pvar.cc:1434-1450)
+      const int k_ref = header ? c_ref : ((nt == 5) ? 4 : 5), k_alt = header ? c_alt : ((nt == 5) ? 3 : 4);
+      if ((k_ref < 0) || (k_alt < 0) || (std::max(k_ref, k_alt) >= std::min(nt, kCap))) {
+        die(6, "Error: %s has no REF/ALT columns.\n", path.c_str());
+      }
+      V->ref.emplace_back(t[k_ref].p, t[k_ref].n);
+      V->alt.emplace_back(t[k_alt].p, t[k_alt].n);
+    }
     V->chrom.emplace_back(t[c_chrom].p, t[c_chrom].n);
     V->id.emplace_back(t[c_id].p, t[c_id].n);
     uint64_t pos = 0;
     const Tok& tp = t[c_pos];
     if (!tp.n || tp.n > 10) {
-      die(3, "Error: Invalid bp coordinate in %s.\n", path.c_str());
+      die(6, "Error: Invalid bp coordinate in %s.\n", path.c_str());
     }
     for (size_t k = 0; k < tp.n; ++k) {
       if (tp.p[k] < '0' || tp.p[k] > '9') {
-        die(3, "Error: Invalid bp coordinate in %s.\n", path.c_str());
+        die(6, "Error: Invalid bp coordinate in %s.\n", path.c_str());
       }
       pos = pos * 10 + static_cast<uint64_t>(tp.p[k] - '0');
     }
     if (pos > 0x7ffffffe) {
-      die(3, "Error: Invalid bp coordinate in %s.\n", path.c_str());
+      die(6, "Error: Invalid bp coordinate in %s.\n", path.c_str());
     }
     V->bp.push_back(static_cast<uint32_t>(pos));
   }
@@ -1266,17 +1359,17 @@ int chrom_class(const std::string& name_in, bool allow_extra, bool* is_zero) {
 // VCF-imported data, tests/test_pairphase.py).  *unphased: a collapsed het (one major allele) without phase.
 void multiallelic_inverse_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_ct, const std::vector<uint32_t>& founder_idx,
                               std::vector<uint8_t>* lo, std::vector<uint8_t>* hi, uint8_t* out_row, uint64_t out_rec, double* maj_freq,
-                              uint8_t* phase = nullptr, uint64_t phase_bytes = 0, bool* unphased = nullptr) {
+                              uint8_t* phase = nullptr, uint64_t phase_bytes = 0, bool* unphased = nullptr, uint32_t* maj_idx = nullptr) {
   if (phase ? ldp_pgen_read_alleles_phased(pg, raw_variant, alt_ct, lo->data(), hi->data(), phase, phase + phase_bytes)
             : ldp_pgen_read_alleles(pg, raw_variant, alt_ct, lo->data(), hi->data())) {
-    die(3, "\nError: %s\n", ldp_pgen_last_error(pg));
+    die(6, "\nError: %s\n", ldp_pgen_last_error(pg));
   }
   const uint32_t allele_ct = alt_ct + 1;
   std::vector<uint64_t> cnt(allele_ct, 0);
   for (uint32_t s : founder_idx) {
     if ((*lo)[s] != 255) {
       if ((*lo)[s] >= allele_ct || (*hi)[s] >= allele_ct) {
-        die(3, "\nError: allele index out of range in multiallelic record.\n");
+        die(6, "\nError: allele index out of range in multiallelic record.\n");
       }
       ++cnt[(*lo)[s]];
       ++cnt[(*hi)[s]];
@@ -1327,6 +1420,9 @@ void multiallelic_inverse_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_c
         maj = allele_ct - 1;
       }
     }
+  }
+  if (maj_idx) {
+    *maj_idx = maj;
   }
   if (maj + 1 < allele_ct) {
     *maj_freq = freq[maj];
@@ -1471,7 +1567,7 @@ void build_sex_row(const SexPlan& sp, const uint8_t* raw_row, uint8_t* out_row, 
 // raw REF-coded row of one variant (decoding / .bed recoding as needed) into `buf`
 void fetch_raw_row(ldp_pgen* pg, int storage_mode, uint32_t raw_variant, uint32_t raw_sample_ct, uint64_t rec_bytes, uint8_t* buf) {
   if (ldp_pgen_read(pg, raw_variant, 1, buf, rec_bytes, 1)) {
-    die(3, "\nError: %s\n", ldp_pgen_last_error(pg));
+    die(6, "\nError: %s\n", ldp_pgen_last_error(pg));
   }
   if (storage_mode == 0x01) {
     static const uint8_t conv[4] = {2, 3, 1, 0};  // .bed -> pgen codes (pgenlib_read.cc:2157)
@@ -1714,7 +1810,7 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
   const double ln_p1 = A.clump_ln_p1, ln_p2 = A.clump_ln_p2;
   const double load_thresh = std::max(std::max(ln_p1, ln_p2), kClumpLnBins[3]);
   if (A.clump_files.size() > 4000) {
-    die(9, "Error: too many --clump reports.\n");
+    die(63, "Error: too many --clump reports.\n");
   }
   for (size_t file_idx1 = A.clump_files.size(); file_idx1; --file_idx1) {  // last report first (plink2_ld.cc:7644-7654)
     const std::string& fname = A.clump_files[file_idx1 - 1];
@@ -1759,7 +1855,7 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
     // therefore read as the header there, and here.)
     do {
       if (!next_line(&ls, &le)) {
-        die(3, "Error: %s is empty.\n", fname.c_str());
+        die(6, "Error: %s is empty.\n", fname.c_str());
       }
     } while (ls == le);  // (the reference's text reader skips blank lines)
     if (*ls == '#') {
@@ -1781,7 +1877,7 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
         for (size_t q = 0; q < want[t].size(); ++q) {
           if (want[t][q] == name && prio[t] >= q) {
             if (prio[t] == q) {
-              die(3, "Error: Duplicate column header '%s' in --clump file.\n", name.c_str());
+              die(6, "Error: Duplicate column header '%s' in --clump file.\n", name.c_str());
             }
             prio[t] = q;
             col[t] = static_cast<int>(c);
@@ -1842,7 +1938,7 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
       const uint32_t k = it->second;
       if (ln_pval > load_thresh) {
         if (ln_pval > 0.0) {
-          die(3, "Error: p-value > 1 on line %zu of %s.\n", line_idx, fname.c_str());
+          die(6, "Error: p-value > 1 on line %zu of %s.\n", line_idx, fname.c_str());
         }
         if (ln_pval > kClumpLnBins[3]) {
           D->nonsig[k] += 1;
@@ -1969,11 +2065,11 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
     RP.prune_last_param = 0.5;
     RP.device = 0;
     if (ldp_device_count() < 1) {
-      die(12, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
+      die(16, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
     }
     ldp_engine* e = nullptr;
     if (ldp_create(&RP, &e)) {
-      die(12, "Error: engine setup failed.\n");
+      die(16, "Error: engine setup failed.\n");
     }
     std::vector<uint32_t> s_chr(n_sub), s_bp(n_sub), s_raw(n_sub);
     for (uint32_t q = 0; q < n_sub; ++q) {
@@ -1982,7 +2078,7 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
       s_raw[q] = inc[obs[sub[q]]];
     }
     if (ldp_set_variants_vcor(e, n_sub, s_chr.data(), s_bp.data(), A.clump_bp_radius, 0xffffffffu)) {
-      die(12, "Error: engine setup failed: %s\n", ldp_last_error(e));
+      die(16, "Error: engine setup failed: %s\n", ldp_last_error(e));
     }
     feed(e, s_raw);
     t_rows = now_s();
@@ -1993,11 +2089,11 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
       const uint32_t rows = std::min(rows_per_call, n_sub - r0);
       uint64_t found = 0;
       if (ldp_r2_unphased_hits(e, r0, rows, min_r2, hits.data(), hits.size(), &found)) {
-        die(12, "Error: %s\n", ldp_last_error(e));
+        die(16, "Error: %s\n", ldp_last_error(e));
       }
       if (found > hits.size()) {
         if (rows == 1) {
-          die(8, "Error: one variant has more --clump-r2 partners than the filter buffer holds.\n");
+          die(2, "Error: one variant has more --clump-r2 partners than the filter buffer holds.\n");
         }
         rows_per_call = std::max(1u, rows / 2);
         continue;
@@ -2234,7 +2330,7 @@ std::vector<std::string> tokens_of_file(const std::string& path) {
 void load_sample_id_list(const std::string& path, const char* flag, std::vector<std::string>* keys) {
   std::ifstream in(path);
   if (!in) {
-    die(2, "Error: Failed to open %s.\n", path.c_str());
+    die(3, "Error: Failed to open %s.\n", path.c_str());
   }
   std::string line;
   int mode = 0;  // 0: no header (FID IID or IID), 1: #FID IID, 2: #IID
@@ -2251,14 +2347,14 @@ void load_sample_id_list(const std::string& path, const char* flag, std::vector<
         first = false;
         if (t[0] == "#FID") {
           if ((t.size() < 2) || (t[1] != "IID")) {
-            die(3, "Error: No IID column on line %zu of --%s file.\n", line_idx, flag);
+            die(6, "Error: No IID column on line %zu of --%s file.\n", line_idx, flag);
           }
           mode = 1;
         } else {
           mode = 2;
         }
         if ((t.size() > static_cast<size_t>(3 - mode)) && (t[3 - mode] == "SID")) {
-          die(9, "Error: SID columns in --%s files are not supported by plink2-hip.\n", flag);
+          die(63, "Error: SID columns in --%s files are not supported by plink2-hip.\n", flag);
         }
       }
       continue;  // (other '#' lines before the data are comments)
@@ -2268,7 +2364,7 @@ void load_sample_id_list(const std::string& path, const char* flag, std::vector<
       keys->push_back("0\t" + t[0]);
     } else if ((mode == 1) || (t.size() >= 2)) {
       if (t.size() < 2) {
-        die(3, "Error: Line %zu of --%s file has fewer tokens than expected.\n", line_idx, flag);
+        die(6, "Error: Line %zu of --%s file has fewer tokens than expected.\n", line_idx, flag);
       }
       keys->push_back(t[0] + "\t" + t[1]);
     } else {
@@ -2442,14 +2538,14 @@ void load_inputs(Session& S, int argc, char** argv) {
   const std::string& gpath = S.gpath;
   ldp_pgen*& pg = S.pg;
   if (ldp_pgen_open(gpath.c_str(), raw_sample_ct, raw_variant_ct, &pg)) {
-    die(3, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+    die(6, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
   }
   ldp_pgen_info(pg, nullptr, nullptr, &S.storage_mode, &S.encoding, &S.has_multiallelic);
   if (ldp_pgen_has_dosage(pg)) {
     // The reference takes allele frequencies (major allele, tie-break of the prune; the r^2 of dosage data) from the dosages
     // when a file has them; this front-end reads hardcalls only and would silently write a different list.
     ldp_pgen_close(pg);
-    die(9, "Error: %s holds dosage data, which plink2-hip does not read yet (allele frequencies and r^2 would be\ncomputed from hardcalls only, unlike plink2).  Use plink2 --make-pgen erase-dosage first.\n", gpath.c_str());
+    die(63, "Error: %s holds dosage data, which plink2-hip does not read yet (allele frequencies and r^2 would be\ncomputed from hardcalls only, unlike plink2).  Use plink2 --make-pgen erase-dosage first.\n", gpath.c_str());
   }
   S.rec_bytes = (static_cast<uint64_t>(raw_sample_ct) + 3) / 4;
   S.direct_rows = static_cast<const uint8_t*>(ldp_pgen_direct_rows(pg, &S.rec_bytes));  // NULL for variable-width
@@ -2491,7 +2587,7 @@ void load_inputs(Session& S, int argc, char** argv) {
         bool zero = false;
         const int cls = chrom_class(cur, A.allow_extra_chr, &zero);
         if ((!out) && (cls >= 3)) {
-          die(9, "Error: --maf / --max-maf / --geno on chrX, chrY or MT ('%s') are not supported by plink2-hip: filter them out (--autosome, --chr) or pre-filter with plink2.\n", cur.c_str());
+          die(63, "Error: --maf / --max-maf / --geno on chrX, chrY or MT ('%s') are not supported by plink2-hip: filter them out (--autosome, --chr) or pre-filter with plink2.\n", cur.c_str());
         }
         it = chr_state.emplace(cur, static_cast<uint8_t>(out)).first;
       }
@@ -2502,7 +2598,7 @@ void load_inputs(Session& S, int argc, char** argv) {
         continue;
       }
       if (V.alt_ct[v] > 1) {
-        die(9, "Error: --maf / --max-maf / --geno with multiallelic variants ('%s') are not supported by plink2-hip.\n", V.id[v].c_str());
+        die(63, "Error: --maf / --max-maf / --geno with multiallelic variants ('%s') are not supported by plink2-hip.\n", V.id[v].c_str());
       }
       todo.push_back(v);
     }
@@ -2549,7 +2645,7 @@ void load_inputs(Session& S, int argc, char** argv) {
         }
         decoded.resize(static_cast<size_t>(run) * S.rec_bytes);
         if (ldp_pgen_read(pg, todo[q0], run, decoded.data(), S.rec_bytes, 0)) {
-          die(3, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+          die(6, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
         }
         std::atomic<uint32_t> next(0);
         std::vector<std::thread> pool;
@@ -2610,7 +2706,7 @@ void load_inputs(Session& S, int argc, char** argv) {
     for (uint32_t v = 0; v < raw_variant_ct; ++v) {
       if (first || V.chrom[v] != cur) {
         if (!seen_chr.insert(V.chrom[v]).second) {
-          die(3, "Error: %s has a split chromosome. Use --make-pgen + --sort-vars to remedy this.\n", (A.pvar.empty() ? A.bim : A.pvar).c_str());
+          die(6, "Error: %s has a split chromosome. Use --make-pgen + --sort-vars to remedy this.\n", (A.pvar.empty() ? A.bim : A.pvar).c_str());
         }
         cur = V.chrom[v];
         if (!first) {
@@ -2644,13 +2740,13 @@ void load_inputs(Session& S, int argc, char** argv) {
         continue;
       }
       if (cls >= 3 && A.have_r2) {
-        die(9, "Error: chromosome '%s': chrX/chrY/MT are not supported yet by --r2-unphased in plink2-hip.\n", cur.c_str());
+        die(63, "Error: chromosome '%s': chrX/chrY/MT are not supported yet by --r2-unphased in plink2-hip.\n", cur.c_str());
       }
       if (cls == 2) {
-        die(3, "Error: Invalid chromosome code '%s'. (Use --allow-extra-chr to force it to be accepted.)\n", cur.c_str());
+        die(6, "Error: Invalid chromosome code '%s'. (Use --allow-extra-chr to force it to be accepted.)\n", cur.c_str());
       }
       if (cls >= 3 && V.alt_ct[v] > 1) {
-        die(9, "Error: multiallelic variant '%s' on chrX/chrY/MT is not supported yet by plink2-hip.\n", V.id[v].c_str());
+        die(63, "Error: multiallelic variant '%s' on chrX/chrY/MT is not supported yet by plink2-hip.\n", V.id[v].c_str());
       }
       vcls.push_back(static_cast<uint8_t>(cls));
       inc.push_back(v);
@@ -2705,12 +2801,12 @@ void load_inputs(Session& S, int argc, char** argv) {
     for (uint32_t k = 1; k < variant_ct; ++k) {
       if (chr_idx[k] == chr_idx[k - 1] && bps[k] < bps[k - 1]) {
         if (A.have_prune) {  // plink2.cc:2926-2929
-          die(3, "Error: When the window size is in kb units, LD-based pruning requires a sorted\n.pvar/.bim.  Retry this command after using --make-pgen/--make-bed +\n--sort-vars to sort your data.\n");
+          die(6, "Error: When the window size is in kb units, LD-based pruning requires a sorted\n.pvar/.bim.  Retry this command after using --make-pgen/--make-bed +\n--sort-vars to sort your data.\n");
         }
         if (A.have_clump) {  // plink2.cc:2998-3001
           die(7, "Error: --clump requires a sorted .pvar/.bim.  Retry this command after using\n--make-pgen/--make-bed + --sort-vars to sort your data.\n");
         }
-        die(3, "Error: --r[2]-[un]phased runs require a sorted .pvar/.bim.  Retry this command\nafter using --make-pgen/--make-bed + --sort-vars to sort your data.\n");  // plink2.cc:2944-2947
+        die(6, "Error: --r[2]-[un]phased runs require a sorted .pvar/.bim.  Retry this command\nafter using --make-pgen/--make-bed + --sort-vars to sort your data.\n");  // plink2.cc:2944-2947
       }
     }
   }
@@ -2769,7 +2865,7 @@ int run_r2(Session& S) {
     const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((1024ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
     std::vector<uint8_t> decoded;
     if ((!all_founders) && ldp_set_sample_map(eng, raw_sample_ct, founder_idx.data(), nullptr)) {
-      die(12, "Error: %s\n", ldp_last_error(eng));
+      die(16, "Error: %s\n", ldp_last_error(eng));
     }
     for (uint32_t k = 0; k < n_incl;) {
       // a run of included variants that are consecutive in the file (chromosome 0 is stripped in table mode)
@@ -2785,13 +2881,13 @@ int run_r2(Session& S) {
       } else {
         decoded.resize(static_cast<size_t>(run) * rec_bytes);
         if (ldp_pgen_read(pg, raw_first, run, decoded.data(), rec_bytes, 0)) {
-          die(3, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+          die(6, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
         }
         src = decoded.data();
       }
       // (the founder columns, CopyNyparrNonemptySubset pgenlib_misc.cc:32,185, are picked on the device)
       if (ldp_load_genotypes(eng, k, run, src, stride, LDP_MEM_HOST, encoding | (all_founders ? 0 : LDP_GENO_MAPPED))) {
-        die(12, "Error: %s\n", ldp_last_error(eng));
+        die(16, "Error: %s\n", ldp_last_error(eng));
       }
       k += run;
     }
@@ -2799,7 +2895,7 @@ int run_r2(Session& S) {
   if (A.have_clump) {
     for (uint32_t k = 0; k < variant_ct; ++k) {
       if (V.alt_ct[inc[k]] > 1) {  // (the reference clumps (variant, A1 allele) pairs there, plink2_ld.cc:7776-7817)
-        die(9, "Error: multiallelic variant '%s': plink2-hip's --clump handles biallelic variants only.\n", V.id[inc[k]].c_str());
+        die(63, "Error: multiallelic variant '%s': plink2-hip's --clump handles biallelic variants only.\n", V.id[inc[k]].c_str());
       }
     }
     join_hip();
@@ -2818,14 +2914,15 @@ int run_r2(Session& S) {
   RP.device = 0;
   join_hip();
   if (ldp_device_count() < 1) {
-    die(12, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
+    die(16, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
   }
   ldp_engine* e = nullptr;
   if (ldp_create(&RP, &e)) {
-    die(12, "Error: engine setup failed.\n");
+    die(16, "Error: engine setup failed.\n");
   }
-  if (A.r2_table && !A.r2_allow_ambiguous) {  // plink2_ld.cc:11063-11072 (the default column set has no allele columns)
-    for (uint32_t k = 0; k < variant_ct; ++k) {
+  if (A.r2_table && !A.r2_allow_ambiguous) {  // plink2_ld.cc:11063-11072
+    const bool ambiguous = A.r2_ref_based ? !(A.r2_cols & (kVcorColRef | kVcorColAlt)) : !(A.r2_cols & (kVcorColMaj | kVcorColNonmaj));
+    for (uint32_t k = 0; ambiguous && (k < variant_ct); ++k) {
       if (V.alt_ct[inc[k]] > 1) {
         die(7, "Error: --r2-unphased column-set doesn't include allele columns which clarify\nwhich calculation is being performed at multiallelic variants. Either filter\nout multiallelic variants, revise the column-set (with e.g. \"cols=+%s\"), or\nuse the 'allow-ambiguous-allele' modifier to override this error.\n", A.r2_ref_based ? "ref" : "maj");
       }
@@ -2836,7 +2933,7 @@ int run_r2(Session& S) {
   }
   if ((A.r2_table && !A.r2_inter) ? ldp_set_variants_vcor(e, variant_ct, chr_idx.data(), bps.data(), A.ld_bp_radius, A.ld_var_ct_radius)
                                   : ldp_set_variants_matrix(e, variant_ct)) {
-    die(12, "Error: engine setup failed: %s\n", ldp_last_error(e));
+    die(16, "Error: engine setup failed: %s\n", ldp_last_error(e));
   }
   const std::string base = A.out + (A.r2_text ? ".unphased.vcor2" : ".unphased.vcor2.bin");
   // --parallel k n: the reference's row shards.  Matrix (VcorMatrix, plink2_ld.cc:9800-9824): `square` takes rows
@@ -2878,7 +2975,7 @@ int run_r2(Session& S) {
   if ((!A.r2_table) && (A.parallel_idx == 0)) {
     FILE* vf = fopen((base + ".vars").c_str(), "wb");
     if (!vf) {
-      die(2, "Error: Failed to open %s.vars for writing.\n", base.c_str());
+      die(3, "Error: Failed to open %s.vars for writing.\n", base.c_str());
     }
     for (uint32_t k = 0; k < vars_ct; ++k) {
       fputs(V.id[inc[k]].c_str(), vf);
@@ -2888,6 +2985,7 @@ int run_r2(Session& S) {
     logprintf("--r2-unphased: Variant IDs written to %s.vars .\n", base.c_str());
   }
   // genotype rows -> engine (same feeder as the prune path)
+  std::unordered_map<uint32_t, std::pair<uint32_t, double>> multi_maj;  // multiallelic variant -> (major allele, its frequency), for the MAJ / NONMAJ / NONMAJ_FREQ columns
   {
     feed_rows(e, inc);
     const uint64_t out_rec = (static_cast<uint64_t>(founder_ct) + 3) / 4;
@@ -2900,7 +2998,8 @@ int run_r2(Session& S) {
     // Multiallelic variants (R2NondosageVariant works on PgrGetInv1(major allele) rows, plink2_ld.cc:6039-6048):
     // collapsed major-vs-rest on the host, as for the prune.  With 'ref-based' the collapse is REF-vs-rest, which
     // is what the main track's codes already are.
-    if (!A.r2_ref_based) {
+    const bool want_maj = A.r2_table && (A.r2_cols & (kVcorColMaj | kVcorColNonmaj | kVcorColFreq));
+    if ((!A.r2_ref_based) || want_maj) {
       std::vector<uint8_t> lo(raw_sample_ct), hi(raw_sample_ct), inv_row(out_rec);
       for (uint32_t k = 0; k < variant_ct; ++k) {
         const uint32_t alts = V.alt_ct[inc[k]];
@@ -2908,12 +3007,19 @@ int run_r2(Session& S) {
           continue;
         }
         if (storage_mode == 0x01) {
-          die(3, "Error: multiallelic variant in a .bim/.bed fileset.\n");
+          die(6, "Error: multiallelic variant in a .bim/.bed fileset.\n");
         }
         double mf = 0.0;
-        multiallelic_inverse_row(pg, inc[k], alts, founder_idx, &lo, &hi, inv_row.data(), out_rec, &mf);
+        uint32_t maj = 0;
+        multiallelic_inverse_row(pg, inc[k], alts, founder_idx, &lo, &hi, inv_row.data(), out_rec, &mf, nullptr, 0, nullptr, &maj);
+        if (want_maj) {
+          multi_maj[k] = std::make_pair(maj, mf);
+        }
+        if (A.r2_ref_based) {
+          continue;  // (the main track's REF-vs-rest codes are the rows; only the major allele and its frequency were wanted)
+        }
         if (ldp_load_genotypes(e, k, 1, inv_row.data(), out_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) || ldp_set_maj_freqs(e, k, 1, &mf)) {
-          die(12, "Error: %s\n", ldp_last_error(e));
+          die(16, "Error: %s\n", ldp_last_error(e));
         }
       }
     }
@@ -2969,9 +3075,136 @@ int run_r2(Session& S) {
     const std::string tpath = A.out + ".vcor" + piece_suffix + (A.r2_zs ? ".zst" : "");
     OutFile tf;
     tf.open(tpath, A.r2_zs);
-    static const char kVcorHeader[] = "#CHROM_A\tPOS_A\tID_A\tCHROM_B\tPOS_B\tID_B\tUNPHASED_R2\n";
+    // ---- the column set (VcorTable :11250-11390, VcorTableWriteThread :10836-10960)
+    const uint32_t cols = A.r2_cols;
+    std::vector<uint8_t> prov_bits;
+    bool prov_all = false, provref_col = false;
+    if (cols & kVcorColRef) {  // ProvrefCol (plink2_common.h:1549): 'provref' always, 'maybeprovref' when some included variant is flagged
+      prov_bits.assign((static_cast<size_t>(raw_variant_ct) + 7) / 8, 0);
+      const int storage = ldp_pgen_provisional_ref(pg, prov_bits.data(), prov_bits.size());
+      if ((storage == 0) && V.info_pr_header && (cols & (kVcorColProvref | kVcorColMaybeprovref))) {
+        die(63, "Error: provisional-REF flags kept in the .pvar's INFO/PR are not supported by plink2-hip (--r2-unphased 'ref' column).\n");
+      }
+      prov_all = (storage == 2);
+      if (cols & kVcorColProvref) {
+        provref_col = true;
+      } else if (cols & kVcorColMaybeprovref) {
+        provref_col = prov_all;
+        for (uint32_t k = 0; (storage == 3) && (!provref_col) && (k < variant_ct); ++k) {
+          provref_col = (prov_bits[inc[k] >> 3] >> (inc[k] & 7)) & 1;
+        }
+      }
+    }
+    // major allele and non-major frequency per variant (the allele-frequency pass: plink2_filter.cc:2137-2147, GetMajIdx)
+    std::vector<uint8_t> maj_allele;
+    std::vector<double> nonmaj_freq;
+    if (cols & (kVcorColMaj | kVcorColNonmaj | kVcorColFreq)) {
+      std::vector<ldp_variant_rec> recs(variant_ct);
+      if (variant_ct && ldp_get_variant_recs(e, 0, variant_ct, recs.data())) {
+        die(16, "Error: %s\n", ldp_last_error(e));
+      }
+      maj_allele.assign(variant_ct, 0);
+      nonmaj_freq.assign(variant_ct, 0.0);
+      for (uint32_t k = 0; k < variant_ct; ++k) {
+        const auto it = multi_maj.find(k);
+        double maj_freq;
+        if (it != multi_maj.end()) {
+          maj_allele[k] = static_cast<uint8_t>(it->second.first);
+          maj_freq = it->second.second;
+        } else {
+          const uint64_t ref_ct = 2ull * recs[k].n_homref + recs[k].n_het, alt_ct = 2ull * recs[k].n_homalt + recs[k].n_het, tot = ref_ct + alt_ct;
+          double ref_freq = 0.5;
+          if (tot) {
+            ref_freq = static_cast<double>(ref_ct) * (1.0 / static_cast<double>(tot));
+          }
+          maj_allele[k] = (ref_freq >= 0.5) ? 0 : 1;
+          maj_freq = maj_allele[k] ? (1.0 - ref_freq) : ref_freq;  // GetAlleleFreq: the last allele's frequency is 1 - the others
+        }
+        nonmaj_freq[k] = 1.0 - maj_freq;
+      }
+    }
+    auto allele_text = [&](uint32_t k, uint32_t allele, std::string* out) {
+      const uint32_t v = inc[k];
+      if (!allele) {
+        *out += V.ref[v];
+        return;
+      }
+      const std::string& alt = V.alt[v];
+      size_t p0 = 0;
+      for (uint32_t a = 1; a < allele; ++a) {
+        p0 = alt.find(',', p0) + 1;
+      }
+      out->append(alt, p0, std::min(alt.find(',', p0), alt.size()) - p0);
+    };
+    // one variant's columns, each followed by a tab
+    auto put_variant = [&](uint32_t k, const std::string& chr_name, std::string* out) {
+      char num[40];
+      if (cols & kVcorColChrom) {
+        *out += chr_name;
+        *out += '\t';
+      }
+      if (cols & kVcorColPos) {
+        *out += std::to_string(bps[k]);
+        *out += '\t';
+      }
+      if (cols & kVcorColId) {
+        *out += V.id[inc[k]];
+        *out += '\t';
+      }
+      if (cols & kVcorColRef) {
+        *out += V.ref[inc[k]];
+        *out += '\t';
+      }
+      if (cols & kVcorColAlt1) {
+        allele_text(k, 1, out);
+        *out += '\t';
+      }
+      if (cols & kVcorColAlt) {
+        *out += V.alt[inc[k]];
+        *out += '\t';
+      }
+      if (provref_col) {
+        *out += (prov_all || ((!prov_bits.empty()) && ((prov_bits[inc[k] >> 3] >> (inc[k] & 7)) & 1))) ? 'Y' : 'N';
+        *out += '\t';
+      }
+      if (cols & kVcorColMaj) {
+        allele_text(k, maj_allele[k], out);
+        *out += '\t';
+      }
+      if (cols & kVcorColNonmaj) {
+        const uint32_t allele_ct = static_cast<uint32_t>(V.alt_ct[inc[k]]) + 1;
+        for (uint32_t a = 0; a < allele_ct; ++a) {
+          if (a != maj_allele[k]) {
+            allele_text(k, a, out);
+            *out += ',';
+          }
+        }
+        out->back() = '\t';
+      }
+      if (cols & kVcorColFreq) {
+        out->append(num, format_g6(nonmaj_freq[k], num) - num);
+        *out += '\t';
+      }
+    };
     if (A.parallel_idx == 0) {
-      tf.write(kVcorHeader, sizeof(kVcorHeader) - 1);
+      std::string hdr = "#";
+      for (const char side : {'A', 'B'}) {
+        const std::pair<uint32_t, const char*> names[] = {{kVcorColChrom, "CHROM_"}, {kVcorColPos, "POS_"}, {kVcorColId, "ID_"}, {kVcorColRef, "REF_"},
+                                                          {kVcorColAlt1, "ALT1_"}, {kVcorColAlt, "ALT_"}, {0, "PROVISIONAL_REF_"}, {kVcorColMaj, "MAJ_"},
+                                                          {kVcorColNonmaj, "NONMAJ_"}, {kVcorColFreq, "NONMAJ_FREQ_"}};
+        for (const auto& nm : names) {
+          if (nm.first ? ((cols & nm.first) != 0) : provref_col) {
+            hdr += nm.second;
+            hdr += side;
+            if (!nm.first) {
+              hdr += '?';
+            }
+            hdr += '\t';
+          }
+        }
+      }
+      hdr += "UNPHASED_R2\n";
+      tf.write(hdr.data(), hdr.size());
     }
     const double thresh = A.ld_min_r2;
     // --ld-snp / --ld-snps / --ld-snp-list (VcorTable, plink2_ld.cc:11083-11150): the row variants.  A row variant is
@@ -2980,7 +3213,7 @@ int run_r2(Session& S) {
     std::vector<uint8_t> is_row;
     if ((!A.ld_snps.empty()) || (!A.ld_snp_list.empty())) {
       if (thresh < 0.0) {
-        die(9, "Error: a negative --ld-window-r2 with --ld-snp/--ld-snps/--ld-snp-list is not supported by plink2-hip.\n");
+        die(63, "Error: a negative --ld-window-r2 with --ld-snp/--ld-snps/--ld-snp-list is not supported by plink2-hip.\n");
       }
       is_row.assign(variant_ct, 0);
       std::unordered_map<std::string, std::vector<uint32_t>> by_id;
@@ -3070,7 +3303,7 @@ int run_r2(Session& S) {
           if ((A.r2_inter && (A.parallel_tot != 1))
                   ? ldp_r2_unphased_block_hits(e, r0, big, shard_first, shard_end - shard_first, thresh, dev_hits.data(), dev_hits.size(), &found)
                   : ldp_r2_unphased_hits(e, r0, big, thresh, dev_hits.data(), dev_hits.size(), &found)) {
-            die(12, "Error: %s\n", ldp_last_error(e));
+            die(16, "Error: %s\n", ldp_last_error(e));
           }
           if (found <= dev_hits.size()) {
             std::sort(dev_hits.begin(), dev_hits.begin() + found, [](const ldp_r2_hit& a, const ldp_r2_hit& b) {
@@ -3086,7 +3319,7 @@ int run_r2(Session& S) {
           }
           if (!A.r2_inter) {
             if (big == 1) {
-              die(8, "Error: one variant has more passing partners than the filter buffer holds.\n");
+              die(2, "Error: one variant has more passing partners than the filter buffer holds.\n");
             }
             big_rows = std::max(1u, big / 2);  // more hits than the buffer holds: fewer second variants per call
             continue;
@@ -3095,7 +3328,7 @@ int run_r2(Session& S) {
         const uint64_t ld = static_cast<uint64_t>(r0) + rows;
         chunk.assign(static_cast<size_t>(rows) * ld, 0.0);
         if (ldp_r2_unphased_rows(e, r0, rows, 0, chunk.data(), ld)) {
-          die(12, "Error: %s\n", ldp_last_error(e));
+          die(16, "Error: %s\n", ldp_last_error(e));
         }
         std::vector<std::vector<Hit>> part(nthreads);
         std::vector<std::thread> pool;
@@ -3164,18 +3397,8 @@ int run_r2(Session& S) {
       out.reserve(1 << 22);
       char num[40];
       for (const Hit& h : sorted) {
-        out += chr_name[chr_idx[h.i]];
-        out += '\t';
-        out += std::to_string(bps[h.i]);
-        out += '\t';
-        out += V.id[inc[h.i]];
-        out += '\t';
-        out += chr_name[chr_idx[h.j]];
-        out += '\t';
-        out += std::to_string(bps[h.j]);
-        out += '\t';
-        out += V.id[inc[h.j]];
-        out += '\t';
+        put_variant(h.i, chr_name[chr_idx[h.i]], &out);
+        put_variant(h.j, chr_name[chr_idx[h.j]], &out);
         out.append(num, format_g6(h.r2, num) - num);
         out += '\n';
         if (out.size() > (1u << 21)) {
@@ -3227,7 +3450,7 @@ int run_r2(Session& S) {
       }
       band.resize(std::max<uint64_t>(off[row_ct], 1));
       if (off[row_ct] && ldp_r2_unphased_band_rows(e, row_first, row_ct, 0, band.data(), off[row_ct])) {
-        die(12, "Error: %s\n", ldp_last_error(e));
+        die(16, "Error: %s\n", ldp_last_error(e));
       }
       char num[40];
       for (uint32_t i = a0; i < a1; ++i) {
@@ -3240,18 +3463,8 @@ int run_r2(Session& S) {
           if ((thresh >= 0.0) && (!(fabs(r2) >= thresh))) {  // VcorTableWriteThread :10816-10821 (NaN never passes)
             continue;
           }
-          linebuf += chr_a_name;
-          linebuf += '\t';
-          linebuf += std::to_string(bps[i]);
-          linebuf += '\t';
-          linebuf += V.id[inc[i]];
-          linebuf += '\t';
-          linebuf += chr_a_name;  // same chromosome: the table never pairs across chromosomes without inter-chr
-          linebuf += '\t';
-          linebuf += std::to_string(bps[j]);
-          linebuf += '\t';
-          linebuf += V.id[inc[j]];
-          linebuf += '\t';
+          put_variant(i, chr_a_name, &linebuf);
+          put_variant(j, chr_a_name, &linebuf);  // same chromosome: the table never pairs across chromosomes without inter-chr
           linebuf.append(num, format_g6(r2, num) - num);
           linebuf += '\n';
           ++written;
@@ -3293,7 +3506,7 @@ int run_r2(Session& S) {
     const uint64_t ld = static_cast<uint64_t>(r0) + rows;
     chunk.assign(static_cast<size_t>(rows) * ld * esz, 0);
     if (ldp_r2_unphased_rows(e, r0, rows, A.r2_float, chunk.data(), ld)) {
-      die(12, "Error: %s\n", ldp_last_error(e));
+      die(16, "Error: %s\n", ldp_last_error(e));
     }
     for (uint32_t q = 0; q < rows; ++q) {
       const uint32_t j = r0 + q;
@@ -3345,7 +3558,7 @@ int run_r2(Session& S) {
       rows = std::min(std::min(rows, variant_ct - r0), 65536u);
       chunk.assign(static_cast<size_t>(rows) * piece_rows * esz, 0);
       if (ldp_r2_unphased_block(e, r0, rows, shard_first, piece_rows, A.r2_float, chunk.data(), piece_rows)) {
-        die(12, "Error: %s\n", ldp_last_error(e));
+        die(16, "Error: %s\n", ldp_last_error(e));
       }
       for (uint32_t q = 0; q < rows; ++q) {
         const uint32_t i = r0 + q;  // second variant
@@ -3417,7 +3630,7 @@ int run_prune(Session& S) {
     join_hip();
     const double t_plan0 = now_s();
     if (ldp_create(&P, &e) || ldp_set_variants(e, m_ct, m_chr.data(), A.window_is_bp ? m_bps.data() : nullptr)) {
-      die(12, "Error: planning failed.\n");
+      die(16, "Error: planning failed.\n");
     }
     if (A.timing) {
       logprintf("[timing] table parse %.3f s, joined at %.3f s, variant table passes %.3f s, engine plan %.3f s\n", t_parse, t_joined - t_begin,
@@ -3470,7 +3683,7 @@ int run_prune(Session& S) {
     join_hip();
     const int ndev = ldp_device_count();
     if (ndev < 1) {
-      die(12, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
+      die(16, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
     }
     world = std::min(A.gpus, ndev);
   }
@@ -3480,24 +3693,24 @@ int run_prune(Session& S) {
     P.device = r;
     int rc = ldp_create(&P, &eng[r]);
     if (rc) {
-      die(12, "Error: ldp_create failed (%d).\n", rc);
+      die(16, "Error: ldp_create failed (%d).\n", rc);
     }
     rc = ldp_set_variants(eng[r], m_ct, m_chr.data(), A.window_is_bp ? m_bps.data() : nullptr);
     if (rc) {
-      die(12, "Error: %s\n", ldp_last_error(eng[r]));
+      die(16, "Error: %s\n", ldp_last_error(eng[r]));
     }
     ldp_get_subcontigs(eng[r], &subcontig_ct, nullptr, 0);
     if (world > 1) {
       rc = ldp_set_shard(eng[r], r, world, nullptr);
       if (rc) {
-        die(12, "Error: %s\n", ldp_last_error(eng[r]));
+        die(16, "Error: %s\n", ldp_last_error(eng[r]));
       }
     }
   }
   const double t_planned = now_s();
   join_hip();
   if (ldp_device_count() < 1) {
-    die(12, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
+    die(16, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
   }
   std::vector<uint64_t> removed((static_cast<size_t>(variant_ct) + 63) / 64 + 1, 0);
   if (subcontig_ct || !xk.empty() || !yk.empty() || !tk.empty()) {
@@ -3509,7 +3722,7 @@ int run_prune(Session& S) {
       std::unordered_set<std::string> want;
       std::ifstream pin(A.preferred);
       if (!pin) {
-        die(2, "Error: Failed to open %s.\n", A.preferred.c_str());
+        die(3, "Error: Failed to open %s.\n", A.preferred.c_str());
       }
       std::string tok;
       while (pin >> tok) {
@@ -3608,7 +3821,7 @@ int run_prune(Session& S) {
       if (device_subset) {
         for (int r = 0; r < world; ++r) {
           if (ldp_set_sample_map(eng[r], raw_sample_ct, founder_idx.data(), nullptr)) {
-            die(12, "\nError: %s\n", ldp_last_error(eng[r]));
+            die(16, "\nError: %s\n", ldp_last_error(eng[r]));
           }
         }
       }
@@ -3631,7 +3844,7 @@ int run_prune(Session& S) {
           }
           decoded[k & 1] = static_cast<uint8_t*>(malloc(static_cast<size_t>(longest) * in_rec + 64));
           if (!decoded[k & 1]) {
-            die(8, "\nError: Out of memory.\n");
+            die(2, "\nError: Out of memory.\n");
           }
         }
         decoder = std::thread([&, k]() {
@@ -3657,7 +3870,7 @@ int run_prune(Session& S) {
             break;
           }
           if (decode_rc) {
-            die(3, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+            die(6, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
           }
           src = decoded[k & 1];
           start_decode(k + 1);
@@ -3667,7 +3880,7 @@ int run_prune(Session& S) {
           // (+ CopyBitarrSubset of phaseinfo under --indep-pairphase, plink2_ld.cc:2075), all host threads
           gather.resize(static_cast<size_t>(run) * out_rec);
           if (ldp_subset_samples(src, direct ? rec_bytes : in_rec, run, raw_sample_ct, founder_mask.data(), gather.data(), out_rec, A.pairphase ? 1 : 0, 0)) {
-            die(12, "\nError: founder subsetting failed.\n");
+            die(16, "\nError: founder subsetting failed.\n");
           }
           src = gather.data();
           stride = out_rec;
@@ -3676,7 +3889,7 @@ int run_prune(Session& S) {
         for (int r = 0; r < world; ++r) {
           const int rc = ldp_load_genotypes(eng[r], q, run, src, stride, LDP_MEM_HOST, load_encoding | (device_subset ? LDP_GENO_MAPPED : 0));
           if (rc) {
-            die(12, "Error: %s\n", ldp_last_error(eng[r]));
+            die(16, "Error: %s\n", ldp_last_error(eng[r]));
           }
         }
         t_load_calls += now_s() - tl0;
@@ -3712,7 +3925,7 @@ int run_prune(Session& S) {
             std::vector<ldp_variant_rec> recs(m_ct);
             for (int r = 0; r < world; ++r) {  // (a variant's counts are zero on the engines that do not own it)
               if (ldp_get_variant_recs(eng[r], 0, m_ct, recs.data())) {
-                die(12, "\nError: %s\n", ldp_last_error(eng[r]));
+                die(16, "\nError: %s\n", ldp_last_error(eng[r]));
               }
               for (uint32_t qq = 0; qq < m_ct; ++qq) {
                 const uint64_t ref_ct = 2ull * recs[qq].n_homref + recs[qq].n_het;
@@ -3742,7 +3955,7 @@ int run_prune(Session& S) {
             ++mt_ct;
           } else {
             if (storage_mode == 0x01) {
-              die(3, "\nError: multiallelic variant in a .bim/.bed fileset.\n");
+              die(6, "\nError: multiallelic variant in a .bim/.bed fileset.\n");
             }
             if (A.pairphase) {
               bool unphased = false;
@@ -3758,7 +3971,7 @@ int run_prune(Session& S) {
           for (int r = 0; r < world; ++r) {
             if (ldp_load_genotypes(eng[r], qq, 1, inv_row.data(), host_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) ||
                 ldp_set_maj_freqs(eng[r], qq, 1, &mf)) {
-              die(12, "\nError: %s\n", ldp_last_error(eng[r]));
+              die(16, "\nError: %s\n", ldp_last_error(eng[r]));
             }
           }
         }
@@ -3789,7 +4002,7 @@ int run_prune(Session& S) {
       }
       for (int r = 0; r < world; ++r) {
         if (rcs[r]) {
-          die(12, "\nError: %s\n", ldp_last_error(eng[r]));
+          die(16, "\nError: %s\n", ldp_last_error(eng[r]));
         }
         scatter(part[r], mk);
       }
@@ -3828,7 +4041,7 @@ int run_prune(Session& S) {
       }
       const uint32_t fct = sp.out_ct();
       if (fct < 2) {
-        die(9, "\nError: fewer than two usable founders on chr%s; not supported by plink2-hip.\n", kSexName[which]);
+        die(63, "\nError: fewer than two usable founders on chr%s; not supported by plink2-hip.\n", kSexName[which]);
       }
       ldp_params SP = P;
       SP.founder_ct = fct;
@@ -3840,7 +4053,7 @@ int run_prune(Session& S) {
         s_bps[w] = bps[ks[w]];
       }
       if (ldp_create(&SP, &se) || ldp_set_variants(se, static_cast<uint32_t>(ks.size()), s_chr.data(), A.window_is_bp ? s_bps.data() : nullptr)) {
-        die(12, "\nError: chr%s engine setup failed.\n", kSexName[which]);
+        die(16, "\nError: chr%s engine setup failed.\n", kSexName[which]);
       }
       const uint64_t s_rec = (static_cast<uint64_t>(fct) + 3) / 4;
       const uint32_t chunk = std::max<uint32_t>(1, static_cast<uint32_t>((256ull << 20) / std::max<uint64_t>(s_rec, 1)));
@@ -3866,7 +4079,7 @@ int run_prune(Session& S) {
           }
         }
         if (ldp_set_sample_map(se, raw_sample_ct, src_sample.data(), het_missing.data())) {
-          die(12, "\nError: %s\n", ldp_last_error(se));
+          die(16, "\nError: %s\n", ldp_last_error(se));
         }
         const uint32_t max_run = std::max<uint32_t>(1, static_cast<uint32_t>((256ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
         std::vector<uint8_t> decoded;
@@ -3882,12 +4095,12 @@ int run_prune(Session& S) {
           } else {
             decoded.resize(static_cast<size_t>(run) * rec_bytes);
             if (ldp_pgen_read(pg, raw0, run, decoded.data(), rec_bytes, 0)) {
-              die(3, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+              die(6, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
             }
             rows_at = decoded.data();
           }
           if (ldp_load_genotypes(se, w0, run, rows_at, rec_bytes, LDP_MEM_HOST, encoding | LDP_GENO_MAPPED)) {
-            die(12, "\nError: %s\n", ldp_last_error(se));
+            die(16, "\nError: %s\n", ldp_last_error(se));
           }
           w0 += run;
         }
@@ -3913,7 +4126,7 @@ int run_prune(Session& S) {
                   continue;
                 }
                 if (prc) {
-                  die(3, "\nError: %s\n", ldp_pgen_last_error(pg));
+                  die(6, "\nError: %s\n", ldp_pgen_last_error(pg));
                 }
                 build_sex_row(sp, raw_row.data(), rows.data() + static_cast<uint64_t>(w) * s_rec, s_rec, &mfs[w], raw_row.data() + in_phase_off);
                 continue;
@@ -3930,7 +4143,7 @@ int run_prune(Session& S) {
           die_unphased(x_unphased.load());
         }
         if (ldp_load_genotypes(se, w0, cnt, rows.data(), s_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) || ldp_set_maj_freqs(se, w0, cnt, mfs.data())) {
-          die(12, "\nError: %s\n", ldp_last_error(se));
+          die(16, "\nError: %s\n", ldp_last_error(se));
         }
       }
       const std::vector<uint64_t> pref_s = sub_preferred(ks);
@@ -3939,7 +4152,7 @@ int run_prune(Session& S) {
       }
       std::vector<uint64_t> bm((ks.size() + 63) / 64 + 1, 0);
       if (ldp_run(se, bm.data())) {
-        die(12, "\nError: %s\n", ldp_last_error(se));
+        die(16, "\nError: %s\n", ldp_last_error(se));
       }
       scatter(bm, ks);
       ldp_destroy(se);
@@ -3955,7 +4168,7 @@ int run_prune(Session& S) {
     const std::string path = A.out + (pass ? ".prune.out" : ".prune.in");
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) {
-      die(2, "Error: Failed to open %s for writing.\n", path.c_str());
+      die(3, "Error: Failed to open %s for writing.\n", path.c_str());
     }
     for (uint32_t k = 0; k < variant_ct; ++k) {
       const bool rem = (removed[k >> 6] >> (k & 63)) & 1;
@@ -3965,7 +4178,7 @@ int run_prune(Session& S) {
       }
     }
     if (fclose(f)) {
-      die(2, "Error: File write failure: %s.\n", path.c_str());
+      die(5, "Error: File write failure: %s.\n", path.c_str());
     }
   }
   logprintf("Variant lists written to %s.prune.in and %s.prune.out .\n", A.out.c_str(), A.out.c_str());

@@ -100,7 +100,7 @@ def test_cli_refuses_to_compute_without_gpu(cli, pkg, tmp_path):
         pytest.skip("GPU present")
     small_fileset(tmp_path)
     cp = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "50", "5", "0.2", "--out", "o"], str(tmp_path))
-    assert cp.returncode == 12 and "no usable HIP device" in cp.stdout
+    assert cp.returncode == 16 and "no usable HIP device" in cp.stdout
     assert not os.path.exists(str(tmp_path / "o.prune.in"))
 
 
@@ -377,7 +377,7 @@ def test_cli_refuses_dosage_pgen(cli, tmp_path):
                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert cp.returncode == 0, cp.stdout
     out = run_cli(cli, ["--pfile", "dos", "--indep-pairwise", "50", "5", "0.2", "--out", "o"], str(tmp_path))
-    assert out.returncode == 9 and "dosage" in out.stdout
+    assert out.returncode == 63 and "dosage" in out.stdout
     assert not os.path.exists(str(tmp_path / "o.prune.in"))
     # without the dosages the same data is accepted (up to the point where a GPU is needed)
     cp = subprocess.run([ref, "--pfile", "dos", "--make-pgen", "erase-dosage", "--out", "hard"], cwd=str(tmp_path),

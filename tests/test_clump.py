@@ -149,13 +149,13 @@ def test_clump_flag_rules(cli, tmp_path):
     clump_fileset(tmp_path, 60, 20, 3)
     write_report(str(tmp_path / "a.txt"), 60, 1)
     r = run_cli(cli, ["--bfile", "d", "--clump", "a.txt"], str(tmp_path))
-    assert r.returncode == 9 and "--clump-unphased" in r.stdout
+    assert r.returncode == 63 and "--clump-unphased" in r.stdout
     r = run_cli(cli, ["--bfile", "d", "--clump", "a.txt", "--clump-unphased", "--clump-r2", "1.0"], str(tmp_path))
-    assert r.returncode == 5 and "Invalid --clump-r2" in r.stdout
+    assert r.returncode == 8 and "Invalid --clump-r2" in r.stdout
     r = run_cli(cli, ["--bfile", "d", "--clump", "a.txt", "--clump-unphased", "--clump-range", "genes.txt"], str(tmp_path))
-    assert r.returncode == 9
+    assert r.returncode == 63
     r = run_cli(cli, ["--bfile", "d", "--clump-unphased"], str(tmp_path))
-    assert r.returncode == 5
+    assert r.returncode == 8
 
 
 @pytest.mark.gpu

@@ -126,11 +126,11 @@ def test_count_based_filters(gpu_pkg, cli, tmp_path, args, log_key):
 def test_count_based_filters_refuse_what_they_do_not_cover(gpu_pkg, cli, tmp_path):
     fileset(tmp_path)
     r = run_cli(cli, ["--bfile", "d", "--maf", "0.05"] + PRUNE, str(tmp_path))
-    assert r.returncode == 9 and "chrX" in r.stdout
+    assert r.returncode == 63 and "chrX" in r.stdout
     r = run_cli(cli, ["--bfile", "d", "--maf", "0.05:minor"] + PRUNE, str(tmp_path))
-    assert r.returncode == 9
+    assert r.returncode == 63
     r = run_cli(cli, ["--bfile", "d", "--maf", "1.5"] + PRUNE, str(tmp_path))
-    assert r.returncode == 5
+    assert r.returncode == 8
 
 
 @pytest.mark.parametrize("extra", [["--max-alleles", "2"], ["--max-alleles", "3", "--geno", "0.08"], ["--max-alleles", "2", "--maf", "0.1"]])
@@ -145,7 +145,7 @@ def test_max_alleles_filter(gpu_pkg, cli, tmp_path, extra):
     args = ["--pfile", "mv"] + extra + ["--indep-pairwise", "40kb", "0.2"]
     if "3" in extra:
         got = run_cli(cli, args + ["--out", "hip"], str(tmp_path))
-        assert got.returncode == 9 and "multiallelic" in got.stdout   # count filters with a triallelic site left: refused
+        assert got.returncode == 63 and "multiallelic" in got.stdout   # count filters with a triallelic site left: refused
         return
     compare(cli, tmp_path, args, [".prune.in", ".prune.out"])
 

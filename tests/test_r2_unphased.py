@@ -445,12 +445,115 @@ def test_cli_ld_snp_flag_rules(tmp_path):
     def run(args):
         return subprocess.run([cli, "--pfile", "d"] + args, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     r = run(["--r2-unphased", "square", "--ld-snp", "snp3"])
-    assert r.returncode == 5 and "Matrix-only and table-only" in r.stdout
+    assert r.returncode == 8 and "Matrix-only and table-only" in r.stdout
     r = run(["--r2-unphased", "--ld-snp", "snp3", "--ld-snps", "snp4"])
-    assert r.returncode == 5 and "cannot be used with" in r.stdout
+    assert r.returncode == 8 and "cannot be used with" in r.stdout
     r = run(["--indep-pairwise", "50", "5", "0.2", "--ld-snp", "snp3"])
-    assert r.returncode == 5
+    assert r.returncode == 8
     r = run(["--r2-unphased", "--ld-snps", "snp3-"])
-    assert r.returncode == 5 and "Invalid --ld-snps" in r.stdout
+    assert r.returncode == 8 and "Invalid --ld-snps" in r.stdout
     r = run(["--r2-unphased", "--ld-snp", "snp3", "--ld-window", "5"])
-    assert r.returncode == 9
+    assert r.returncode == 63
+
+
+COLS_CASES = [
+    ("pfile", ["cols=chrom,id,ref,alt"], []),
+    ("pfile", ["cols=+maj,+nonmaj,+freq"], ["--ld-window-r2", "0.05"]),
+    ("bfile", ["cols=-chrom,-pos,+ref,+alt1"], []),                    # a .bed's REF alleles are provisional: the column appears
+    ("bfile", ["cols=+ref,-maybeprovref"], []),
+    ("pfile", ["cols=pos,provref,ref"], ["--ld-window-kb", "3"]),
+    ("pfile", ["cols=id"], ["--ld-window-r2", "0.5"]),
+    ("pfile", ["cols=+freq,-id", "inter-chr"], ["--ld-window-r2", "0.3"]),
+    ("bfile", ["cols=maj,nonmaj,freq", "zs"], ["--ld-window-r2", "0"]),
+    ("mkpgen", ["cols=+ref,+alt,+maj"], []),                            # written by the reference from the .bed: every REF provisional
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,mods,extra", COLS_CASES)
+def test_cli_vcor_column_sets_match_reference(gpu_pkg, tmp_path, fmt, mods, extra):
+    """--r2-unphased cols=: the .vcor table with other column sets (VcorTableWriteThread, plink2_ld.cc:10836-10960)."""
+    assert T.have_ref()
+    cli = gpu_pkg.build_cli()
+    tmp = str(tmp_path)
+    m, n = 500, 120
+    raw = T.synth_raw_codes(m, n, seed=23, missing_rate=0.03)
+    raw[7] = 0                                   # monomorphic: frequency 0, NaN r^2
+    raw[8, :] = 3                                # nothing observed: frequency 0.5 by convention
+    chroms = ["1"] * 300 + ["4"] * 200
+    rng = np.random.default_rng(4)
+    pos = np.concatenate([np.sort(rng.integers(1, 40000, 300)), np.sort(rng.integers(1, 40000, 200))])
+    T.write_pgen_fixed(os.path.join(tmp, "d"), raw, chroms, pos)
+    T.write_bed(os.path.join(tmp, "d"), raw, chroms, pos)
+    src = ["--" + fmt, "d"]
+    if fmt == "mkpgen":
+        mk = T.run_ref(["--bfile", "d", "--make-pgen", "--out", "e"], tmp)
+        assert mk.returncode == 0, mk.stdout
+        src = ["--pfile", "e"]
+    ref = T.run_ref(src + ["--r2-unphased"] + mods + extra + ["--out", "ref"], tmp)
+    assert ref.returncode == 0, ref.stdout
+    got = subprocess.run([cli] + src + ["--r2-unphased"] + mods + extra + ["--out", "hip"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         text=True, timeout=600)
+    assert got.returncode == 0, got.stdout
+    ext = ".vcor.zst" if "zs" in mods else ".vcor"
+    if ext.endswith(".zst"):
+        a = subprocess.run([T.REF_BIN, "--zst-decompress", os.path.join(tmp, "ref" + ext)], stdout=subprocess.PIPE).stdout
+        b = subprocess.run([T.REF_BIN, "--zst-decompress", os.path.join(tmp, "hip" + ext)], stdout=subprocess.PIPE).stdout
+        assert len(a) > 100 and a == b
+    else:
+        want, have = open(os.path.join(tmp, "ref" + ext)).read(), open(os.path.join(tmp, "hip" + ext)).read()
+        assert len(want) > 100
+        if want != have:
+            wl, hl = want.split("\n"), have.split("\n")
+            bad = [(a, b) for a, b in zip(wl, hl) if a != b]
+            raise AssertionError("%d vs %d lines, first difference %r" % (len(wl), len(hl), bad[:2]))
+
+
+@pytest.mark.gpu
+def test_cli_vcor_column_sets_at_multiallelic_variants(gpu_pkg, tmp_path):
+    """Allele columns lift the ambiguity guard: MAJ / NONMAJ / NONMAJ_FREQ of multiallelic variants, REF / ALT with 'ref-based'."""
+    assert T.have_ref()
+    cli = gpu_pkg.build_cli()
+    tmp = str(tmp_path)
+    m, n = 260, 110
+    first, second, alt_ct = T.synth_multiallelic_haps(m, n, seed=5, max_alt=4, multi_rate=0.4)
+    T.write_vcf_haps(os.path.join(tmp, "d.vcf"), first, second, alt_ct, ["1"] * 150 + ["6"] * 110, np.concatenate([np.arange(150), np.arange(110)]) * 211 + 1,
+                     unphased=np.ones(first.shape, dtype=bool))
+    T.ref_import_vcf(os.path.join(tmp, "d.vcf"), os.path.join(tmp, "d"))
+    for mods in (["cols=+maj,+nonmaj,+freq"], ["cols=+ref,+alt", "ref-based"], ["cols=+maj,+alt1"], ["cols=+ref,+alt,+maj,+freq", "ref-based"],
+                 ["cols=+nonmaj", "inter-chr"]):
+        args = ["--pfile", "d", "--r2-unphased"] + mods + ["--ld-window-r2", "0.05"]
+        ref = T.run_ref(args + ["--out", "ref"], tmp)
+        got = subprocess.run([cli] + args + ["--out", "hip"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert ref.returncode == 0 and got.returncode == 0, (mods, ref.stdout[-300:], got.stdout[-300:])
+        assert filecmp.cmp(os.path.join(tmp, "ref.vcor"), os.path.join(tmp, "hip.vcor"), shallow=False), mods
+    # the guard itself: 'ref-based' wants ref or alt, the default wants maj or nonmaj
+    for mods in (["cols=+ref"], ["cols=+maj", "ref-based"]):
+        args = ["--pfile", "d", "--r2-unphased"] + mods
+        ref = T.run_ref(args + ["--out", "ref"], tmp)
+        got = subprocess.run([cli] + args + ["--out", "hip"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert ref.returncode == got.returncode == 7, mods
+
+
+def test_cli_cols_flag_rules(tmp_path):
+    import __graft_entry__ as ge
+    cli = ge.load_package().build_cli()
+    raw = T.synth_raw_codes(60, 30, seed=2)
+    T.write_pgen_fixed(str(tmp_path / "d"), raw, ["1"] * 60, np.arange(60) * 10 + 1)
+    def run(args):
+        return subprocess.run([cli, "--pfile", "d"] + args, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    r = run(["--r2-unphased", "cols=+nonsense"])
+    assert r.returncode == 8 and "Unrecognized ID 'nonsense' in --r2-unphased column set descriptor." in r.stdout
+    r = run(["--r2-unphased", "cols=+maj,freq"])
+    assert r.returncode == 8 and "either all column set IDs must be" in r.stdout
+    r = run(["--r2-unphased", "cols=+d"])
+    assert r.returncode == 8 and "does not support computation of D or D'" in r.stdout
+    r = run(["--r2-unphased", "square", "cols=+maj"])
+    assert r.returncode == 8 and "Matrix-only and table-only" in r.stdout
+    r = run(["--r2-unphased", "cols=+maj", "cols=+freq"])
+    assert r.returncode == 8 and "Multiple --r2-unphased cols= modifiers." in r.stdout
+    if T.have_ref():
+        for args in (["--r2-unphased", "cols=+nonsense"], ["--r2-unphased", "cols=+maj,freq"], ["--r2-unphased", "cols=+d"], ["--r2-unphased", "dprime"]):
+            ref = T.run_ref(["--pfile", "d"] + args + ["--out", "ref"], str(tmp_path))
+            got = run(args)
+            assert ref.returncode == got.returncode, (args, ref.returncode, got.returncode)
