@@ -253,6 +253,11 @@ int ldp_set_variants_vcor(ldp_engine* e, uint32_t variant_ct, const uint32_t* ch
  * (bin) / floats (bin4) as ldp_r2_unphased_rows, NaN included; filtering (--ld-window-r2) and the A-major order of the
  * .vcor file are the caller's (VcorTableWriteThread :10680-10950).  `out` is host memory of capacity_elems elements. */
 int ldp_r2_unphased_band_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t capacity_elems);
+/* --r-unphased (ComputeR2 + the callers' sqrt, plink2_ld.cc:6654-6682, :9633-9641, :10640-10647): mode 1 makes every
+ * ldp_r2_unphased_* call return r = +-sqrt(r^2), negative when the covariance of the two variants' major-allele-oriented
+ * codes is; mode 2 orients both variants to REF instead ('ref-based'); 0 (default) returns r^2.  The hit filter then
+ * compares |r| with min_r2, so pass sqrt(threshold).  NaN where r^2 is undefined, as before. */
+int ldp_set_r_signed(ldp_engine* e, int mode);
 
 /* ---- inspection ---- */
 int ldp_get_variant_recs(ldp_engine* e, uint32_t first_variant, uint32_t n, ldp_variant_rec* out);

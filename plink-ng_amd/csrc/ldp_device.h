@@ -125,6 +125,8 @@ struct PairKernelArgs {
   uint32_t r2_col_end;           //     dense rows then start at column r2_col_first: element (j - r2_row_first) * r2_ld + (i - r2_col_first)
   uint64_t r2_band_base;         // r2_ld == 0: band layout, element pair_off[j] - r2_band_base + (i - lo[j])
   uint32_t r2_float;
+  uint32_t r_signed;             // 0: r^2; 1: r = +-sqrt(r^2), sign of the covariance of the rows as stored (major-allele orientation);
+                                 // 2: the same in REF orientation (the sign flips when exactly one row was inverted by prepare_kernel)
   // device-side filter (ldp_r2_unphased_hits): with r2_hits != nullptr a pair with |r^2| >= r2_min is appended at
   // slot atomicAdd(counters[3]) when that is below r2_hit_capacity, and nothing is stored to r2_out
   ldp_r2_hit* r2_hits;

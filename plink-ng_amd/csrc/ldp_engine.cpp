@@ -122,6 +122,7 @@ struct ldp_engine {
   std::vector<PairGroup> groups;
   // Matrix-pipe plan of the same band (ldp_pair_mfma.hip): used for complete data, founder_ct <= kMfMaxFounders
   bool mf_enabled = false;
+  uint32_t r_signed = 0;                  // ldp_set_r_signed
   std::vector<MfmaWG> mf_wgs;
   uint64_t mf_products = 0;               // 32 x 32 block products of the plan
   uint32_t next_group = 0;                 // groups before this one are launched for the current load epoch
@@ -1325,6 +1326,7 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.r2_col_end = 0xffffffffu;
   A.r2_band_base = 0;
   A.r2_float = 0;
+  A.r_signed = e->r_signed;
   // matrix-pipe work is attached per launch (launch_group / the inspection run); r^2 launches stay on the popcount kernels
   A.mf_wgs = nullptr;
   A.n_mf_wgs = 0;
@@ -2253,6 +2255,17 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
 }  // namespace
 
 extern "C" {
+
+int ldp_set_r_signed(ldp_engine* e, int mode) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  if ((mode < 0) || (mode > 2)) {
+    return fail(e, LDP_ERR_INVALID, "ldp_set_r_signed: mode must be 0 (r^2), 1 (r, major-allele orientation) or 2 (r, REF orientation)");
+  }
+  e->r_signed = static_cast<uint32_t>(mode);
+  return LDP_OK;
+}
 
 int ldp_r2_unphased_rows(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t ld_elems) {
   return r2_rows_impl(e, row_first, row_ct, as_float, out, ld_elems, nullptr);

@@ -66,7 +66,19 @@ __device__ __forceinline__ bool emit_pair(const PairKernelArgs& A, uint32_t i, u
     if ((j < A.r2_row_first) || (j >= A.r2_row_end) || (i < A.r2_col_first) || (i >= A.r2_col_end)) {
       return false;  // a tile can straddle the edge of the requested rows / columns
     }
-    const double r2 = r2_unphased(st);
+    double r2 = r2_unphased(st);
+    if (A.r_signed && (r2 == r2)) {
+      // --r-unphased (plink2_ld.cc:9633-9641, :10640-10647): sqrt of the same quotient, negative when the covariance is
+      r2 = __dsqrt_rn(r2);
+      const int64_t cov = static_cast<int64_t>(st.dot) * static_cast<int64_t>(st.nm) - static_cast<int64_t>(st.sum1) * static_cast<int64_t>(st.sum2);
+      bool neg = cov < 0;
+      if ((A.r_signed == 2) && cov) {  // (a zero covariance stays +0 in either orientation)
+        neg ^= ((A.recs[i].flags ^ A.recs[j].flags) & 1u) != 0;
+      }
+      if (neg) {
+        r2 = -r2;
+      }
+    }
     if (A.r2_hits) {
       if (fabs(r2) >= A.r2_min) {  // (false for NaN)
         const unsigned long long slot = atomicAdd(&A.counters[3], 1ull);

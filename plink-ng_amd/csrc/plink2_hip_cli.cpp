@@ -13,11 +13,12 @@
 // the <50-founders guard (plink2.cc:2063-2071) and the output writer.
 // Multiallelic variants are collapsed major-vs-rest on the host (Get1Multiallelic semantics); chrX / chrY / MT get
 // their sample-mapped rows (males het->missing, non-males x2, ...) built on the host as well.
-// --r2-unphased: the matrix shapes (square/square0/triangle as bin, bin4 or text) and the windowed .vcor table with the
-// default columns (--ld-window, --ld-window-kb, --ld-window-r2), number formatting restated from dtoa_g.
-// Not yet supported (reported as such, never silently mis-handled): external-index .pgen (modes
-// 0x20/0x21), more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, chrX/Y/MT and multiallelic sites in
-// --r2-unphased, its cols=/zs/inter-chr modifiers, --ld-snp*, --ld-window-cm.
+// --r2-unphased / --r-unphased: the matrix shapes (square/square0/triangle as bin, bin4 or text, zs), the windowed and the
+// inter-chr .vcor table with cols=, --ld-window, --ld-window-kb, --ld-window-r2, --ld-snp / --ld-snps / --ld-snp-list,
+// --parallel; number formatting restated from dtoa_g.  --clump (several reports, --clump-allow-overlap).
+// Not yet supported (reported as such with exit 63, never silently mis-handled): external-index .pgen (modes 0x20/0x21),
+// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, chrX/Y/MT in the r^2 outputs and --clump, --ld-window-cm,
+// --clump-range.
 #include <dlfcn.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -49,6 +50,18 @@ namespace {
 
 constexpr double kSmallEpsilon = 0.00000000000005684341886080801486968994140625;  // 2^-44
 FILE* g_log = nullptr;
+bool g_r_unsquared = false;  // --r-unphased: the messages below name that flag where they say --r2-unphased
+
+// (--r-unphased shares every code path with --r2-unphased; the reference prints the flag actually given)
+void name_the_flag(char* buf) {
+  if (!g_r_unsquared) {
+    return;
+  }
+  static const char kFrom[] = "--r2-unphased";
+  for (char* p = strstr(buf, kFrom); p; p = strstr(p, kFrom)) {
+    memmove(p + 3, p + 4, strlen(p + 4) + 1);  // "--r2-..." -> "--r-..."
+  }
+}
 
 double now_s() {
   using namespace std::chrono;
@@ -61,6 +74,7 @@ void logprintf(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
+  name_the_flag(buf);
   fputs(buf, stdout);
   if (g_log) {
     fputs(buf, g_log);
@@ -73,6 +87,7 @@ void logprintf(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
+  name_the_flag(buf);
   fflush(stdout);
   fputs(buf, stderr);
   if (g_log) {
@@ -390,6 +405,7 @@ struct Args {
   bool r2_table = false;   // --r2-unphased without a matrix shape: windowed .vcor table
   bool r2_ref_based = false;
   bool r2_allow_ambiguous = false;
+  bool r_unsquared = false;        // --r-unphased: r = +-sqrt(r^2) with the sign of the covariance
   uint32_t r2_cols = 0;            // kVcorCol* (set after the modifiers are read: plink2.cc:11158-11207)
   std::string r2_cols_desc;        // the text behind cols=
   bool r2_cols_given = false;
@@ -625,7 +641,12 @@ Args parse_args(int argc, char** argv) {
         die(8, "Error: Invalid %s r^2 threshold '%s'.\n", fl, par[next].c_str());
       }
       A.have_prune = true;
-    } else if (f == "--r2-unphased") {
+    } else if ((f == "--r2-unphased") || (f == "--r-unphased")) {
+      if (A.have_r2) {
+        die(8, "Error: --r-phased, --r-unphased, --r2-phased, and --r2-unphased are mutually\nexclusive.\n");
+      }
+      A.r_unsquared = (f == "--r-unphased");
+      g_r_unsquared = A.r_unsquared;
       // [{square | square0 | triangle | inter-chr}] ['yes-really'] [{zs | bin | bin4}] ... (plink2.cc:11090-11210)
       while (i + 1 < argc && !(argv[i + 1][0] == '-' && argv[i + 1][1] == '-')) {
         std::string m = argv[++i];
@@ -662,12 +683,14 @@ Args parse_args(int argc, char** argv) {
       if ((A.r2_shape < 0) && (A.r2_float >= 0)) {
         A.r2_shape = 0;  // an encoding without a shape: square (plink2_help.cc:1015-1017)
       }
-      A.r2_cols = kVcorColDefault;
+      // (r's sign needs an allele to refer to: its default set adds MAJ, or REF with 'ref-based'; plink2.cc:11158-11162, :11196-11203)
+      const uint32_t default_cols = kVcorColDefault | (A.r_unsquared ? (A.r2_ref_based ? kVcorColRef : kVcorColMaj) : 0u);
+      A.r2_cols = default_cols;
       if (A.r2_cols_given) {  // plink2.cc:11158-11172
         A.r2_cols = parse_col_descriptor(A.r2_cols_desc, {"chrom", "pos", "id", "ref", "alt1", "alt", "maybeprovref", "provref", "maj", "nonmaj", "freq", "d", "dprime", "dprimeabs"},
-                                         kVcorColDefault, "r2-unphased");
+                                         default_cols, A.r_unsquared ? "r-unphased" : "r2-unphased");
         if (A.r2_cols & (kVcorColD | kVcorColDprime | kVcorColDprimeAbs)) {
-          die(8, "Error: --r2-unphased does not support computation of D or D'. Use --r2-phased\ninstead.\n");
+          die(8, "Error: --r2-unphased does not support computation of D or D'. Use --r%s-phased\ninstead.\n", A.r_unsquared ? "" : "2");
         }
       }
       if ((A.r2_inter || A.r2_cols_given) && (A.r2_shape >= 0)) {
@@ -2920,10 +2943,33 @@ int run_r2(Session& S) {
   if (ldp_create(&RP, &e)) {
     die(16, "Error: engine setup failed.\n");
   }
-  if (A.r2_table && !A.r2_allow_ambiguous) {  // plink2_ld.cc:11063-11072
-    const bool ambiguous = A.r2_ref_based ? !(A.r2_cols & (kVcorColRef | kVcorColAlt)) : !(A.r2_cols & (kVcorColMaj | kVcorColNonmaj));
-    for (uint32_t k = 0; ambiguous && (k < variant_ct); ++k) {
-      if (V.alt_ct[inc[k]] > 1) {
+  if (ldp_set_r_signed(e, A.r_unsquared ? (A.r2_ref_based ? 2 : 1) : 0)) {
+    die(16, "Error: %s\n", ldp_last_error(e));
+  }
+  if (A.r2_table && !A.r2_allow_ambiguous) {  // plink2_ld.cc:11042-11074
+    bool multiallelic = false;
+    for (uint32_t k = 0; (!multiallelic) && (k < variant_ct); ++k) {
+      multiallelic = V.alt_ct[inc[k]] > 1;
+    }
+    if (A.r_unsquared) {
+      // the sign of r refers to an allele: some column has to name it
+      bool ambiguous = false;
+      if (!A.r2_ref_based) {
+        ambiguous = !(A.r2_cols & (kVcorColMaj | kVcorColNonmaj));
+      } else {
+        const uint32_t relevant = A.r2_cols & (kVcorColRef | kVcorColAlt1 | kVcorColAlt);
+        if (relevant != kVcorColAlt1) {
+          ambiguous = !relevant;
+        } else if (multiallelic) {
+          die(7, "Error: The meaning of r's sign cannot be consistently inferred from just the\n--r2-unphased 'alt1' column-set at multiallelic variants. Either filter out\nmultiallelic variants, revise the column-set, or use the\n'allow-ambiguous-allele' modifier to override this error.\n");
+        }
+      }
+      if (ambiguous) {
+        die(7, "Error: --r2-unphased column-set doesn't include allele columns which clarify\nthe meaning of r's sign. Either switch to --r2-unphased, add a disambiguating\ncolumn-set, or use the 'allow-ambiguous-allele' modifier to override this\nerror.\n");
+      }
+    } else {
+      const bool ambiguous = A.r2_ref_based ? !(A.r2_cols & (kVcorColRef | kVcorColAlt)) : !(A.r2_cols & (kVcorColMaj | kVcorColNonmaj));
+      if (ambiguous && multiallelic) {
         die(7, "Error: --r2-unphased column-set doesn't include allele columns which clarify\nwhich calculation is being performed at multiallelic variants. Either filter\nout multiallelic variants, revise the column-set (with e.g. \"cols=+%s\"), or\nuse the 'allow-ambiguous-allele' modifier to override this error.\n", A.r2_ref_based ? "ref" : "maj");
       }
     }
@@ -2935,7 +2981,7 @@ int run_r2(Session& S) {
                                   : ldp_set_variants_matrix(e, variant_ct)) {
     die(16, "Error: engine setup failed: %s\n", ldp_last_error(e));
   }
-  const std::string base = A.out + (A.r2_text ? ".unphased.vcor2" : ".unphased.vcor2.bin");
+  const std::string base = A.out + ".unphased.vcor" + (A.r_unsquared ? "1" : "2") + (A.r2_text ? "" : ".bin");  // (VcorMatrix :9849-9857)
   // --parallel k n: the reference's row shards.  Matrix (VcorMatrix, plink2_ld.cc:9800-9824): `square` takes rows
   // [M k / n, M (k+1) / n); the triangular shapes take ParallelBounds() rows (equal numbers of lower-triangle entries) and
   // a piece that does not reach the last row behaves as if the later variants did not exist (its .vars file, written by piece
@@ -3203,10 +3249,11 @@ int run_r2(Session& S) {
           }
         }
       }
-      hdr += "UNPHASED_R2\n";
+      hdr += A.r_unsquared ? "UNPHASED_R\n" : "UNPHASED_R2\n";
       tf.write(hdr.data(), hdr.size());
     }
-    const double thresh = A.ld_min_r2;
+    // (--r-unphased filters |r| against the root of --ld-window-r2: VcorTable :11575-11579)
+    const double thresh = A.r_unsquared ? ((A.ld_min_r2 < 0.0) ? -1.0 : sqrt(A.ld_min_r2)) : A.ld_min_r2;
     // --ld-snp / --ld-snps / --ld-snp-list (VcorTable, plink2_ld.cc:11083-11150): the row variants.  A row variant is
     // reported against every variant of its window, on both sides (UpdateVcorWindow :10984 with row_snp_subset), as the
     // A of the line; a pair of two row variants appears once, lower index first (:10806-10815).

@@ -557,3 +557,80 @@ def test_cli_cols_flag_rules(tmp_path):
             ref = T.run_ref(["--pfile", "d"] + args + ["--out", "ref"], str(tmp_path))
             got = run(args)
             assert ref.returncode == got.returncode, (args, ref.returncode, got.returncode)
+
+
+R_CASES = [
+    # fmt, modifiers, extra flags, output extension
+    ("pfile", [], [], ".vcor"),                                                        # default columns: MAJ names the allele r's sign refers to
+    ("bfile", ["ref-based"], ["--ld-window-r2", "0.04"], ".vcor"),                    # REF orientation (+ PROVISIONAL_REF? for a .bed)
+    ("pfile", ["cols=+nonmaj,+freq,-maj"], ["--ld-window-r2", "0"], ".vcor"),
+    ("pfile", ["inter-chr", "cols=id,maj"], ["--ld-window-r2", "0.25"], ".vcor"),
+    ("pfile", ["ref-based", "cols=id,alt1", "allow-ambiguous-allele"], ["--ld-window-kb", "4"], ".vcor"),
+    ("pfile", ["square", "bin"], [], ".unphased.vcor1.bin"),
+    ("bfile", ["triangle", "bin4"], [], ".unphased.vcor1.bin"),
+    ("pfile", ["square0", "bin", "ref-based"], [], ".unphased.vcor1.bin"),
+    ("pfile", ["triangle"], [], ".unphased.vcor1"),
+    ("pfile", ["square", "ref-based"], [], ".unphased.vcor1"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,mods,extra,ext", R_CASES)
+def test_cli_r_unphased_matches_reference(gpu_pkg, tmp_path, fmt, mods, extra, ext):
+    """--r-unphased: r = +-sqrt(r^2) with the sign of the covariance (plink2_ld.cc:9633-9641, :10640-10647), in major-allele
+    or REF orientation; tables, binary and text matrices."""
+    assert T.have_ref()
+    cli = gpu_pkg.build_cli()
+    tmp = str(tmp_path)
+    m, n = 420, 130
+    raw = T.synth_raw_codes(m, n, seed=31, missing_rate=0.03, ld_copy_prob=0.7)
+    rng = np.random.default_rng(2)
+    for v in rng.choice(m, size=m // 3, replace=False):   # negative correlations: flip a third of the variants
+        raw[v] = np.where(raw[v] < 3, 2 - raw[v], 3)
+    raw[5] = 0
+    chroms = ["2"] * 250 + ["9"] * 170
+    pos = np.concatenate([np.sort(rng.integers(1, 30000, 250)), np.sort(rng.integers(1, 30000, 170))])
+    T.write_pgen_fixed(os.path.join(tmp, "d"), raw, chroms, pos)
+    T.write_bed(os.path.join(tmp, "d"), raw, chroms, pos)
+    args = ["--" + fmt, "d", "--r-unphased"] + mods + extra
+    ref = T.run_ref(args + ["--out", "ref"], tmp)
+    assert ref.returncode == 0, ref.stdout
+    got = subprocess.run([cli] + args + ["--out", "hip"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert got.returncode == 0, got.stdout
+    want, have = open(os.path.join(tmp, "ref" + ext), "rb").read(), open(os.path.join(tmp, "hip" + ext), "rb").read()
+    assert len(want) > 100
+    if ext == ".vcor":
+        assert b"-0." in want, "the case must contain negative correlations"
+        if want != have:
+            wl, hl = want.split(b"\n"), have.split(b"\n")
+            bad = [(a, b) for a, b in zip(wl, hl) if a != b]
+            raise AssertionError("%d vs %d lines, first difference %r" % (len(wl), len(hl), bad[:2]))
+    assert want == have
+    if ext.endswith("vcor1.bin") or ext.endswith("vcor1"):
+        assert open(os.path.join(tmp, "ref" + ext + ".vars")).read() == open(os.path.join(tmp, "hip" + ext + ".vars")).read()
+
+
+@pytest.mark.gpu
+def test_cli_r_unphased_guards_and_multiallelic(gpu_pkg, tmp_path):
+    assert T.have_ref()
+    cli = gpu_pkg.build_cli()
+    tmp = str(tmp_path)
+    m, n = 200, 100
+    first, second, alt_ct = T.synth_multiallelic_haps(m, n, seed=8, max_alt=3, multi_rate=0.3)
+    T.write_vcf_haps(os.path.join(tmp, "d.vcf"), first, second, alt_ct, ["1"] * m, np.arange(m) * 180 + 1, unphased=np.ones(first.shape, dtype=bool))
+    T.ref_import_vcf(os.path.join(tmp, "d.vcf"), os.path.join(tmp, "d"))
+
+    def both(mods):
+        args = ["--pfile", "d", "--r-unphased"] + mods
+        ref = T.run_ref(args + ["--out", "ref"], tmp)
+        got = subprocess.run([cli] + args + ["--out", "hip"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        return ref, got
+
+    for mods in ([], ["ref-based", "cols=+alt"], ["cols=+nonmaj,-maj"], ["ref-based", "cols=+alt1", "allow-ambiguous-allele"], ["square", "bin"]):
+        ref, got = both(mods)
+        assert ref.returncode == 0 and got.returncode == 0, (mods, ref.stdout[-300:], got.stdout[-300:])
+        ext = ".unphased.vcor1.bin" if "square" in mods else ".vcor"
+        assert filecmp.cmp(os.path.join(tmp, "ref" + ext), os.path.join(tmp, "hip" + ext), shallow=False), mods
+    for mods in (["cols=-maj"], ["ref-based", "cols=-ref"], ["ref-based", "cols=-ref,+alt1"]):   # nothing names the allele / alt1 alone at multiallelic sites
+        ref, got = both(mods)
+        assert ref.returncode == got.returncode == 7, (mods, ref.returncode, got.returncode, got.stdout[-300:])
