@@ -248,6 +248,10 @@ int ldp_r2_unphased_block_hits(ldp_engine* e, uint32_t row_first, uint32_t row_c
  * ldp_get_band() returns lo[] (first partner of each second variant). */
 int ldp_set_variants_vcor(ldp_engine* e, uint32_t variant_ct, const uint32_t* chr_idx, const uint32_t* bps, uint32_t bp_radius,
                           uint32_t var_ct_radius);
+/* The same with --ld-window-cm (UpdateVcorWindow :11008-11013): cms[] are the variants' centimorgan positions, nondecreasing
+ * inside a chromosome; B > A also has to satisfy cms[B] < cms[A] + cm_radius.  cms == NULL: no centimorgan window. */
+int ldp_set_variants_vcor_cm(ldp_engine* e, uint32_t variant_ct, const uint32_t* chr_idx, const uint32_t* bps, const double* cms, uint32_t bp_radius,
+                             double cm_radius, uint32_t var_ct_radius);
 /* r^2 of every candidate pair whose SECOND variant j lies in [row_first, row_first+row_ct), band order: the pairs of j
  * start at element sum_{row_first <= j' < j} (j' - lo[j']) and run over first variants i = lo[j] .. j-1.  Same doubles
  * (bin) / floats (bin4) as ldp_r2_unphased_rows, NaN included; filtering (--ld-window-r2) and the A-major order of the

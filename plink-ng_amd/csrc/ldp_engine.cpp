@@ -1810,6 +1810,11 @@ int ldp_set_variants_matrix(ldp_engine* e, uint32_t variant_ct) {
 // Window of the --r2-unphased table (UpdateVcorWindow, plink2_ld.cc:10984-11023): second variant B is paired with
 // the earlier variants A of its chromosome that are at most var_ct_radius variants and bp_radius base pairs away.
 int ldp_set_variants_vcor(ldp_engine* e, uint32_t variant_ct, const uint32_t* chr_idx, const uint32_t* bps, uint32_t bp_radius, uint32_t var_ct_radius) {
+  return ldp_set_variants_vcor_cm(e, variant_ct, chr_idx, bps, nullptr, bp_radius, -1.0, var_ct_radius);
+}
+
+int ldp_set_variants_vcor_cm(ldp_engine* e, uint32_t variant_ct, const uint32_t* chr_idx, const uint32_t* bps, const double* cms, uint32_t bp_radius,
+                             double cm_radius, uint32_t var_ct_radius) {
   if (!e) {
     return LDP_ERR_INVALID;
   }
@@ -1840,7 +1845,9 @@ int ldp_set_variants_vcor(ldp_engine* e, uint32_t variant_ct, const uint32_t* ch
     }
     uint32_t lo = c0;
     for (uint32_t j = c0; j < c1; ++j) {
-      while ((bps[j] - bps[lo] > bp_radius) || (j - lo > var_ct_radius)) {
+      // (the centimorgan window is open at the far end: B belongs to A's window while cm_B < cm_A + radius, the sum as
+      // UpdateVcorWindow forms it, plink2_ld.cc:11010-11013)
+      while ((bps[j] - bps[lo] > bp_radius) || (j - lo > var_ct_radius) || (cms && (lo < j) && !(cms[j] < cms[lo] + cm_radius))) {
         ++lo;
       }
       e->lo_global[j] = lo;

@@ -14,10 +14,10 @@
 // Multiallelic variants are collapsed major-vs-rest on the host (Get1Multiallelic semantics); chrX / chrY / MT get
 // their sample-mapped rows (males het->missing, non-males x2, ...) built on the host as well.
 // --r2-unphased / --r-unphased: the matrix shapes (square/square0/triangle as bin, bin4 or text, zs), the windowed and the
-// inter-chr .vcor table with cols=, --ld-window, --ld-window-kb, --ld-window-r2, --ld-snp / --ld-snps / --ld-snp-list,
+// inter-chr .vcor table with cols=, --ld-window, --ld-window-kb, --ld-window-cm, --ld-window-r2, --ld-snp / --ld-snps / --ld-snp-list,
 // --parallel; number formatting restated from dtoa_g.  --clump (several reports, --clump-allow-overlap).
 // Not yet supported (reported as such with exit 63, never silently mis-handled): external-index .pgen (modes 0x20/0x21),
-// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, chrX/Y/MT in the r^2 outputs and --clump, --ld-window-cm,
+// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, chrX/Y/MT in the r^2 outputs and --clump,
 // --clump-range.
 #include <dlfcn.h>
 #include <sys/mman.h>
@@ -414,6 +414,7 @@ struct Args {
   bool r2_text = false;    // matrix shape without bin/bin4: text matrix
   uint32_t ld_var_ct_radius = 0x7fffffff;  // --ld-window N: N - 1
   uint32_t ld_bp_radius = 0xffffffffu;     // --ld-window-kb; UINT32_MAX = not given (table default 1000 kb)
+  double ld_cm_radius = -1.0;              // --ld-window-cm; -1 = not given
   double ld_min_r2 = 2.0;                  // --ld-window-r2 (after the reference's epsilon); 2.0 = not given
   // variant / sample filters applied before the command (the reference's variant_include / sample_include):
   // --chr / --not-chr (codes and code ranges, or names), --autosome, --extract / --exclude (variant ID lists),
@@ -890,6 +891,15 @@ Args parse_args(int argc, char** argv) {
       }
       d *= 1000 * (1 + kSmallEpsilon);
       A.ld_bp_radius = (d > 2147483646) ? 2147483646u : static_cast<uint32_t>(static_cast<int32_t>(d));
+    } else if (f == "--ld-window-cm") {  // plink2.cc:7938-7949
+      need(i, 1, "--ld-window-cm");
+      const std::string v = argv[++i];
+      double d;
+      const char* endp;
+      if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || d < 0) {
+        die(8, "Error: Invalid --ld-window-cm argument '%s'.\n", v.c_str());
+      }
+      A.ld_cm_radius = d * (1 + kSmallEpsilon);
     } else if (f == "--ld-window-r2") {  // plink2.cc:7950-7964
       need(i, 1, "--ld-window-r2");
       const std::string v = argv[++i];
@@ -1003,7 +1013,7 @@ Args parse_args(int argc, char** argv) {
   if (A.have_prune && A.have_r2) {
     die(8, "Error: run --indep-pairwise and --r2-unphased separately.\n");
   }
-  const bool ld_window_given = (A.ld_var_ct_radius != 0x7fffffff) || (A.ld_bp_radius != 0xffffffffu);
+  const bool ld_window_given = (A.ld_var_ct_radius != 0x7fffffff) || (A.ld_bp_radius != 0xffffffffu) || (A.ld_cm_radius != -1.0);
   const bool ld_snp_given = (!A.ld_snps.empty()) || (!A.ld_snp_list.empty());
   if (ld_snp_given && (!A.have_r2 || A.have_clump)) {
     die(8, "Error: --ld-window.../--ld-snp... must be used with --r[2]-[un]phased.\n");  // plink2.cc:12960
@@ -1017,6 +1027,11 @@ Args parse_args(int argc, char** argv) {
     // then keeps one variant more on the leading side for the rows that follow (snp101,snp103 with --ld-window 3 pairs snp103
     // with snp100).  Not reproduced.
     die(63, "Error: --ld-window together with --ld-snp/--ld-snps/--ld-snp-list is not supported by plink2-hip (--ld-window-kb is).\n");
+  }
+  if (ld_snp_given && (A.ld_cm_radius != -1.0)) {
+    // (the leading side of a row variant's window keeps cm >= center - radius, the trailing side cm < center + radius,
+    // UpdateVcorWindow :10991-10994 / :11010-11013: not the same band seen from the two ends)
+    die(63, "Error: --ld-window-cm together with --ld-snp/--ld-snps/--ld-snp-list is not supported by plink2-hip.\n");
   }
   if (ld_snp_given && (A.parallel_tot != 1)) {
     die(63, "Error: --parallel with --ld-snp/--ld-snps/--ld-snp-list is not supported by plink2-hip yet.\n");
@@ -1124,6 +1139,9 @@ struct Variants {
   std::vector<uint8_t> alt_ct;  // number of ALT alleles (1 for biallelic / .bim), capped at 255
   std::vector<std::string> ref, alt;  // allele text (ALT comma-separated as in the file); only kept for --r2-unphased allele columns
   bool info_pr_header = false;        // the .pvar declares INFO/PR (provisional REF alleles are flagged per variant there)
+  std::vector<double> cm;             // centimorgan positions; only kept for --ld-window-cm (empty when the file has no CM column)
+  bool cm_unsorted = false;           // some chromosome's CM values decrease (LoadPvar, plink2_pvar.cc:2121-2134)
+  bool cm_any_nonzero = false;
 };
 
 // whole file -> memory; the variant/sample tables are a few tens of MB even at 10M variants
@@ -1236,7 +1254,10 @@ void load_variants(const Args& A, Variants* V) {
   const bool zst = (path.size() > 4) && (path.compare(path.size() - 4, 4, ".zst") == 0);
   const std::string buf = zst ? slurp_zst(path) : slurp(path);
   bool header = false;
-  int c_chrom = 0, c_pos = 3, c_id = 1, c_alt = -1, c_ref = -1;
+  int c_chrom = 0, c_pos = 3, c_id = 1, c_alt = -1, c_ref = -1, c_cm = -1;
+  const bool keep_cm = A.have_r2 && (A.ld_cm_radius != -1.0);
+  double last_cm = -1.7976931348623157e308;
+  std::string last_cm_chrom;
   const bool keep_alleles = A.have_r2 && (A.r2_cols & (kVcorColRef | kVcorColAlt1 | kVcorColAlt | kVcorColMaj | kVcorColNonmaj));
   constexpr int kCap = 64;
   Tok t[kCap];
@@ -1266,6 +1287,7 @@ void load_variants(const Args& A, Variants* V) {
           if (t[c].eq("ID")) c_id = c;
           if (t[c].eq("ALT")) c_alt = c;
           if (t[c].eq("REF")) c_ref = c;
+          if (t[c].eq("CM")) c_cm = c;
         }
         if (c_pos < 0 || c_id < 0) {
           die(6, "Error: %s header lacks POS/ID.\n", path.c_str());
@@ -1307,6 +1329,30 @@ void load_variants(const Args& A, Variants* V) {
       }
       V->ref.emplace_back(t[k_ref].p, t[k_ref].n);
       V->alt.emplace_back(t[k_alt].p, t[k_alt].n);
+    }
+    if (keep_cm) {
+      const int k_cm = header ? c_cm : ((nt == 5) ? -1 : 2);
+      double cur_cm = 0.0;
+      if ((k_cm >= 0) && (k_cm < std::min(nt, kCap))) {
+        if ((t[c_chrom].n != last_cm_chrom.size()) || memcmp(t[c_chrom].p, last_cm_chrom.data(), t[c_chrom].n)) {
+          last_cm_chrom.assign(t[c_chrom].p, t[c_chrom].n);
+          last_cm = -1.7976931348623157e308;
+        }
+        if (!((t[k_cm].n == 1) && (t[k_cm].p[0] == '0'))) {  // (a bare "0" is taken as is, without the order check)
+          const std::string tok(t[k_cm].p, t[k_cm].n);
+          const char* endp;
+          if (!scan_double_plink(tok.c_str(), &cur_cm, &endp) || *endp) {
+            die(6, "Error: Invalid centimorgan position in %s.\n", path.c_str());
+          }
+          if (cur_cm < last_cm) {
+            V->cm_unsorted = true;
+          } else {
+            last_cm = cur_cm;
+          }
+          V->cm_any_nonzero = V->cm_any_nonzero || (cur_cm != 0.0);
+        }
+      }
+      V->cm.push_back(cur_cm);
     }
     V->chrom.emplace_back(t[c_chrom].p, t[c_chrom].n);
     V->id.emplace_back(t[c_id].p, t[c_id].n);
@@ -2977,7 +3023,20 @@ int run_r2(Session& S) {
   if (A.r2_inter && (A.ld_min_r2 <= 0.0) && (variant_ct > 400000) && (A.parallel_tot == 1) && !A.yes_really) {  // plink2_ld.cc:11087
     die(7, "Error: Gigantic (over 400k variants) --r2-unphased unfiltered, non-distributed\ncomputation.  Rerun with the 'yes-really' modifier if you are SURE you have enough\nhard drive space and want to do this.\n");
   }
-  if ((A.r2_table && !A.r2_inter) ? ldp_set_variants_vcor(e, variant_ct, chr_idx.data(), bps.data(), A.ld_bp_radius, A.ld_var_ct_radius)
+  std::vector<double> cms;  // --ld-window-cm (a file without non-zero CM values has no CM window: Vcor hands UpdateVcorWindow a null array)
+  if (A.r2_table && (!A.r2_inter) && (A.ld_cm_radius != -1.0)) {
+    if (V.cm_unsorted) {  // plink2.cc:2948-2951
+      die(7, "Error: --ld-window-cm requires nondecreasing CM values on each chromosome.\nRetry this command after regenerating your CM coordinates.\n");
+    }
+    if (V.cm_any_nonzero) {
+      cms.resize(variant_ct);
+      for (uint32_t k = 0; k < variant_ct; ++k) {
+        cms[k] = V.cm[inc[k]];
+      }
+    }
+  }
+  if ((A.r2_table && !A.r2_inter) ? ldp_set_variants_vcor_cm(e, variant_ct, chr_idx.data(), bps.data(), cms.empty() ? nullptr : cms.data(), A.ld_bp_radius,
+                                                             A.ld_cm_radius, A.ld_var_ct_radius)
                                   : ldp_set_variants_matrix(e, variant_ct)) {
     die(16, "Error: engine setup failed: %s\n", ldp_last_error(e));
   }

@@ -634,3 +634,74 @@ def test_cli_r_unphased_guards_and_multiallelic(gpu_pkg, tmp_path):
     for mods in (["cols=-maj"], ["ref-based", "cols=-ref"], ["ref-based", "cols=-ref,+alt1"]):   # nothing names the allele / alt1 alone at multiallelic sites
         ref, got = both(mods)
         assert ref.returncode == got.returncode == 7, (mods, ref.returncode, got.returncode, got.stdout[-300:])
+
+
+def _rewrite_cm(bim_path, cms):
+    rows = [ln.split("\t") for ln in open(bim_path).read().splitlines()]
+    assert len(rows) == len(cms) and len(rows[0]) == 6
+    with open(bim_path, "w") as f:
+        for r, c in zip(rows, cms):
+            r[2] = c
+            f.write("\t".join(r) + "\n")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--ld-window-cm", "0.5"], ["--ld-window-cm", "0.05", "--ld-window-r2", "0"], ["--ld-window-cm", "2", "--ld-window-kb", "8"],
+                                   ["--ld-window-cm", "1", "--ld-window", "6", "--ld-window-r2", "0.01"], ["--ld-window-cm", "0"],
+                                   ["--ld-window-cm", "0.25", "--r-unphased"]])
+def test_cli_ld_window_cm_matches_reference(gpu_pkg, tmp_path, extra):
+    """--ld-window-cm: the centimorgan window of UpdateVcorWindow (open at the far end, intersected with the kb and count windows)."""
+    assert T.have_ref()
+    cli = gpu_pkg.build_cli()
+    tmp = str(tmp_path)
+    m, n = 600, 100
+    raw = T.synth_raw_codes(m, n, seed=37, missing_rate=0.02, ld_copy_prob=0.7)
+    chroms = ["1"] * 350 + ["5"] * 250
+    rng = np.random.default_rng(6)
+    pos = np.concatenate([np.sort(rng.integers(1, 60000, 350)), np.sort(rng.integers(1, 60000, 250))])
+    T.write_bed(os.path.join(tmp, "d"), raw, chroms, pos)
+    # quarter-centimorgan grid with repeats: plenty of pairs exactly one radius apart
+    steps = rng.choice([0.0, 0.25, 0.25, 0.5, 0.05], size=m)
+    cm = np.concatenate([np.cumsum(steps[:350]), np.cumsum(steps[350:])])
+    _rewrite_cm(os.path.join(tmp, "d.bim"), ["%g" % c for c in cm])
+    flag = ["--r-unphased"] if "--r-unphased" in extra else ["--r2-unphased"]
+    extra = [x for x in extra if x != "--r-unphased"]
+    args = ["--bfile", "d"] + flag + extra
+    ref = T.run_ref(args + ["--out", "ref"], tmp)
+    assert ref.returncode == 0, ref.stdout
+    got = subprocess.run([cli] + args + ["--out", "hip"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert got.returncode == 0, got.stdout
+    want, have = open(os.path.join(tmp, "ref.vcor")).read(), open(os.path.join(tmp, "hip.vcor")).read()
+    if want != have:
+        wl, hl = want.split("\n"), have.split("\n")
+        bad = [(a, b) for a, b in zip(wl, hl) if a != b]
+        raise AssertionError("%d vs %d lines, first difference %r" % (len(wl), len(hl), bad[:2]))
+    if extra[1] != "0":
+        assert len(want) > 200
+
+
+@pytest.mark.gpu
+def test_cli_ld_window_cm_edge_cases(gpu_pkg, tmp_path):
+    assert T.have_ref()
+    cli = gpu_pkg.build_cli()
+    tmp = str(tmp_path)
+    m, n = 120, 60
+    raw = T.synth_raw_codes(m, n, seed=3, ld_copy_prob=0.8)
+    T.write_bed(os.path.join(tmp, "d"), raw, ["2"] * m, np.arange(m) * 50 + 1)
+
+    def both(args):
+        ref = T.run_ref(["--bfile", "d", "--r2-unphased"] + args + ["--out", "ref"], tmp)
+        got = subprocess.run([cli, "--bfile", "d", "--r2-unphased"] + args + ["--out", "hip"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        return ref, got
+
+    # a file without centimorgan positions: the flag has nothing to act on
+    ref, got = both(["--ld-window-cm", "0.001"])
+    assert ref.returncode == got.returncode == 0 and filecmp.cmp(os.path.join(tmp, "ref.vcor"), os.path.join(tmp, "hip.vcor"), shallow=False)
+    # decreasing positions
+    _rewrite_cm(os.path.join(tmp, "d.bim"), ["%g" % (10 - 0.01 * k) for k in range(m)])
+    ref, got = both(["--ld-window-cm", "1"])
+    assert ref.returncode == got.returncode == 7 and "nondecreasing CM values" in got.stdout
+    ref, got = both(["square", "--ld-window-cm", "1"])
+    assert ref.returncode == got.returncode == 8
+    ref, got = both(["--ld-window-cm", "-1"])
+    assert ref.returncode == got.returncode == 8 and "Invalid --ld-window-cm argument" in got.stdout
