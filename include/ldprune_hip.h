@@ -280,6 +280,10 @@ int ldp_get_counters(const ldp_engine* e, ldp_counters* out);
  * for .bed (dimensions live in .fam/.bim), cross-checked against the header otherwise (0 = no check). */
 typedef struct ldp_pgen ldp_pgen;
 int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct_hint, ldp_pgen** out);
+/* The same with the name of the index file of an external-index .pgen (storage mode 0x20: the .pgen holds the records,
+ * "<path>.pgi" -- or pgi_path, the reference's --pgi -- the header; PgfiInitPhase1, pgenlib_read.cc:800-840).  pgi_path may
+ * be NULL; it is ignored for files that carry their own header. */
+int ldp_pgen_open_indexed(const char* path, const char* pgi_path, uint32_t sample_ct_hint, uint32_t variant_ct_hint, ldp_pgen** out);
 int ldp_pgen_info(const ldp_pgen* p, uint32_t* variant_ct, uint32_t* sample_ct, int* storage_mode, int* row_encoding, int* has_multiallelic);
 /* Which REF alleles are provisional (PgfiInitPhase1 / Phase2, pgenlib_read.cc:790,872-877: control bits 6-7 of the header):
  * returns 0 = the .pgen does not say (the .pvar's INFO/PR does), 1 = none, 2 = all (always for a .bed), 3 = per variant, and

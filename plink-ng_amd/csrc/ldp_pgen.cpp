@@ -32,6 +32,10 @@ struct ldp_pgen {
   const uint8_t* map = nullptr;
   uint64_t size = 0;
   int mode = 0;
+  int file_mode = 0;            // the storage-mode byte of the file when it differs from `mode` (0x20: external index)
+  int index_fd = -1;            // .pgen.pgi of the external-index modes
+  const uint8_t* index_map = nullptr;
+  uint64_t index_size = 0;
   uint32_t variant_ct = 0;
   uint32_t sample_ct = 0;
   uint64_t rec_bytes = 0;       // ceil(sample_ct / 4)
@@ -290,6 +294,10 @@ inline uint32_t packed_get(const uint8_t* base, uint64_t idx, uint32_t width_bit
 extern "C" {
 
 int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct_hint, ldp_pgen** out) {
+  return ldp_pgen_open_indexed(path, nullptr, sample_ct_hint, variant_ct_hint, out);
+}
+
+int ldp_pgen_open_indexed(const char* path, const char* pgi_path, uint32_t sample_ct_hint, uint32_t variant_ct_hint, ldp_pgen** out) {
   if (!path || !out) {
     return LDP_ERR_INVALID;
   }
@@ -327,17 +335,48 @@ int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct
     }
     return LDP_OK;
   }
-  if (P->size < 12) {
+  // The header: the file's own first bytes, or for the external-index modes the .pgen.pgi beside it (pgen_spec.tex:149-170:
+  // "formatted just like a PGEN header", third byte 0x30; block offsets still point into the .pgen)
+  const uint8_t* H = P->map;
+  uint64_t Hsize = P->size;
+  if ((P->mode & 0xfe) == 0x20) {
+    if (P->mode == 0x21) {
+      return pfail(P, LDP_ERR_UNSUPPORTED, ".pgen storage mode 0x21 (external index with header extensions) is not supported.");
+    }
+    const std::string ipath = (pgi_path && pgi_path[0]) ? std::string(pgi_path) : (std::string(path) + ".pgi");
+    P->index_fd = open(ipath.c_str(), O_RDONLY);
+    if (P->index_fd < 0) {
+      return pfail(P, LDP_ERR_INVALID, "Failed to open " + ipath + ".");
+    }
+    struct stat ist;
+    if (fstat(P->index_fd, &ist) || ist.st_size < 12) {
+      return pfail(P, LDP_ERR_INVALID, ipath + " is too small to be a .pgen.pgi file.");
+    }
+    P->index_size = static_cast<uint64_t>(ist.st_size);
+    void* im = mmap(nullptr, P->index_size, PROT_READ, MAP_PRIVATE, P->index_fd, 0);
+    if (im == MAP_FAILED) {
+      return pfail(P, LDP_ERR_NOMEM, "Failed to map " + ipath + ".");
+    }
+    P->index_map = static_cast<const uint8_t*>(im);
+    if ((P->index_map[0] != 0x6c) || (P->index_map[1] != 0x1b) || (P->index_map[2] != 0x30)) {
+      return pfail(P, LDP_ERR_INVALID, ipath + " is not a .pgen.pgi file (first three bytes don't match the magic number).");
+    }
+    H = P->index_map;
+    Hsize = P->index_size;
+    P->file_mode = P->mode;
+    P->mode = 0x10;  // (from here on an ordinary variable-width file whose header lives elsewhere)
+  }
+  if (Hsize < 12) {
     return pfail(P, LDP_ERR_INVALID, std::string(path) + " is too small to be a .pgen file.");
   }
-  memcpy(&P->variant_ct, P->map + 3, 4);
-  memcpy(&P->sample_ct, P->map + 7, 4);
+  memcpy(&P->variant_ct, H + 3, 4);
+  memcpy(&P->sample_ct, H + 7, 4);
   if ((sample_ct_hint && sample_ct_hint != P->sample_ct) || (variant_ct_hint && variant_ct_hint != P->variant_ct)) {
     return pfail(P, LDP_ERR_INVALID, ".pgen header (" + std::to_string(P->variant_ct) + " variants, " + std::to_string(P->sample_ct) +
                                          " samples) does not match the variant/sample files.");
   }
   P->rec_bytes = (static_cast<uint64_t>(P->sample_ct) + 3) / 4;
-  const uint8_t ctrl = P->map[11];
+  const uint8_t ctrl = H[11];
   const uint32_t nonref_storage = ctrl >> 6;
   P->nonref_storage = static_cast<int>(nonref_storage);
   if (nonref_storage == 3) {
@@ -358,7 +397,7 @@ int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct
   }
   if (P->mode != 0x10) {
     char buf[160];
-    snprintf(buf, sizeof(buf), ".pgen storage mode 0x%02x is not supported (supported: 0x01 .bed, 0x02 fixed-width, 0x10 standard).", P->mode);
+    snprintf(buf, sizeof(buf), ".pgen storage mode 0x%02x is not supported (supported: 0x01 .bed, 0x02 fixed-width, 0x10 standard, 0x20 standard with an external index).", P->mode);
     return pfail(P, LDP_ERR_UNSUPPORTED, buf);
   }
   // ---- standard variable-width header (pgen_spec.tex:160-235)
@@ -372,7 +411,7 @@ int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct
   const uint32_t M = P->variant_ct;
   const uint32_t B = (M + kBlockVariants - 1) / kBlockVariants;
   uint64_t pos = 12 + 8ull * B;
-  if (pos > P->size) {
+  if (pos > Hsize) {
     return pfail(P, LDP_ERR_INVALID, "truncated .pgen header.");
   }
   P->vrtype.resize(M);
@@ -380,14 +419,14 @@ int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct
   for (uint32_t b = 0; b < B; ++b) {
     const uint32_t cnt = std::min(kBlockVariants, M - b * kBlockVariants);
     uint64_t block_off;
-    memcpy(&block_off, P->map + 12 + 8ull * b, 8);
+    memcpy(&block_off, H + 12 + 8ull * b, 8);
     const uint64_t types_bytes = (type_bits == 4) ? (cnt + 1) / 2 : cnt;
     const uint64_t need = types_bytes + static_cast<uint64_t>(cnt) * len_bytes + static_cast<uint64_t>(cnt) * ac_bytes +
                           ((nonref_storage == 3) ? (cnt + 7) / 8 : 0);
-    if (pos + need > P->size) {
+    if (pos + need > Hsize) {
       return pfail(P, LDP_ERR_INVALID, "truncated .pgen header.");
     }
-    const uint8_t* types = P->map + pos;
+    const uint8_t* types = H + pos;
     const uint8_t* lens = types + types_bytes;
     uint64_t rec = block_off;
     for (uint32_t k = 0; k < cnt; ++k) {
@@ -412,12 +451,12 @@ int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct
       P->fpos[M] = rec;
     }
     if (nonref_storage == 3) {  // (the block's flags close its header section; 65,536 variants per block: byte-aligned)
-      memcpy(P->nonref_bits.data() + static_cast<size_t>(b) * (kBlockVariants / 8), P->map + pos + need - (cnt + 7) / 8, (cnt + 7) / 8);
+      memcpy(P->nonref_bits.data() + static_cast<size_t>(b) * (kBlockVariants / 8), H + pos + need - (cnt + 7) / 8, (cnt + 7) / 8);
     }
     pos += need;
   }
   if (!M) {
-    P->fpos[0] = pos;
+    P->fpos[0] = (H == P->map) ? pos : 3;
   }
   return LDP_OK;
 }
@@ -441,7 +480,7 @@ int ldp_pgen_info(const ldp_pgen* P, uint32_t* variant_ct, uint32_t* sample_ct, 
   }
   if (variant_ct) *variant_ct = P->variant_ct;
   if (sample_ct) *sample_ct = P->sample_ct;
-  if (storage_mode) *storage_mode = P->mode;
+  if (storage_mode) *storage_mode = P->mode;  // (0x10 for an external-index file as well: the records are the same)
   if (row_encoding) *row_encoding = (P->mode == 0x01) ? LDP_GENO_BED : LDP_GENO_REF;
   if (has_multiallelic) *has_multiallelic = P->any_multiallelic ? 1 : 0;
   return LDP_OK;
@@ -1122,6 +1161,12 @@ void ldp_pgen_close(ldp_pgen* P) {
   }
   if (P->fd >= 0) {
     close(P->fd);
+  }
+  if (P->index_map) {
+    munmap(const_cast<uint8_t*>(P->index_map), P->index_size);
+  }
+  if (P->index_fd >= 0) {
+    close(P->index_fd);
   }
   delete P;
 }

@@ -16,7 +16,7 @@
 // --r2-unphased / --r-unphased: the matrix shapes (square/square0/triangle as bin, bin4 or text, zs), the windowed and the
 // inter-chr .vcor table with cols=, --ld-window, --ld-window-kb, --ld-window-cm, --ld-window-r2, --ld-snp / --ld-snps / --ld-snp-list,
 // --parallel; number formatting restated from dtoa_g.  --clump (several reports, --clump-allow-overlap).
-// Not yet supported (reported as such with exit 63, never silently mis-handled): external-index .pgen (modes 0x20/0x21),
+// Not yet supported (reported as such with exit 63, never silently mis-handled): .pgen header extensions (modes 0x11/0x21),
 // more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, chrX/Y/MT in the r^2 outputs and --clump,
 // --clump-range.
 #include <dlfcn.h>
@@ -386,7 +386,7 @@ class OutFile {
 };
 
 struct Args {
-  std::string bed, bim, fam, pgen, pvar, psam, out = "plink2";
+  std::string bed, bim, fam, pgen, pgi, pvar, psam, out = "plink2";
   bool have_prune = false;
   bool pairphase = false;  // --indep-pairphase instead of --indep-pairwise
   uint32_t window = 0, step = 1;
@@ -564,13 +564,14 @@ Args parse_args(int argc, char** argv) {
         A.bim = pre + ".bim" + vz;
         A.fam = pre + ".fam";
       }
-    } else if (f == "--bed" || f == "--bim" || f == "--fam" || f == "--pgen" || f == "--pvar" || f == "--psam" || f == "--out" || f == "--indep-preferred") {
+    } else if (f == "--bed" || f == "--bim" || f == "--fam" || f == "--pgen" || f == "--pgi" || f == "--pvar" || f == "--psam" || f == "--out" || f == "--indep-preferred") {
       need(i, 1, f.c_str());
       std::string v = argv[++i];
       if (f == "--bed") A.bed = v;
       else if (f == "--bim") A.bim = v;
       else if (f == "--fam") A.fam = v;
       else if (f == "--pgen") A.pgen = v;
+      else if (f == "--pgi") A.pgi = v;  // (external-index .pgen: plink2.cc:10572-10590)
       else if (f == "--pvar") A.pvar = v;
       else if (f == "--psam") A.psam = v;
       else if (f == "--out") A.out = v;
@@ -2606,7 +2607,7 @@ void load_inputs(Session& S, int argc, char** argv) {
   S.gpath = S.is_bed ? A.bed : A.pgen;
   const std::string& gpath = S.gpath;
   ldp_pgen*& pg = S.pg;
-  if (ldp_pgen_open(gpath.c_str(), raw_sample_ct, raw_variant_ct, &pg)) {
+  if (ldp_pgen_open_indexed(gpath.c_str(), A.pgi.empty() ? nullptr : A.pgi.c_str(), raw_sample_ct, raw_variant_ct, &pg)) {
     die(6, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
   }
   ldp_pgen_info(pg, nullptr, nullptr, &S.storage_mode, &S.encoding, &S.has_multiallelic);

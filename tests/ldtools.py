@@ -682,3 +682,22 @@ def ref_indep_pairwise(prefix, window_args, r2, order=2, threads=2, bad_ld=True,
     if cp.returncode != 0:
         raise RuntimeError("reference plink2 failed:\n" + cp.stdout)
     return read_id_list(out + ".prune.in"), read_id_list(out + ".prune.out"), cp.stdout
+
+
+def split_pgen_index(pgen_path, out_pgen, out_pgi):
+    """A standard (0x10) .pgen rewritten as an external-index pair (pgen_spec.tex:149-170): the header becomes the .pgen.pgi
+    (third byte 0x30, block offsets re-based), the records follow a bare three-byte .pgen header (mode 0x20)."""
+    data = open(pgen_path, "rb").read()
+    assert data[:3] == bytes([0x6C, 0x1B, 0x10])
+    m = int.from_bytes(data[3:7], "little")
+    n_blocks = (m + 65535) // 65536
+    offs = [int.from_bytes(data[12 + 8 * b:20 + 8 * b], "little") for b in range(n_blocks)]
+    header_len = offs[0]
+    hdr = bytearray(data[:header_len])
+    hdr[2] = 0x30
+    for b, o in enumerate(offs):
+        hdr[12 + 8 * b:20 + 8 * b] = (o - header_len + 3).to_bytes(8, "little")
+    with open(out_pgi, "wb") as f:
+        f.write(bytes(hdr))
+    with open(out_pgen, "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x20]) + data[header_len:])

@@ -87,12 +87,13 @@ def test_founder_guard_and_format_errors(cli, tmp_path):
         f.write(b"\0")
     cp = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "50", "5", "0.2", "--bad-ld", "--dry-run", "--out", "o"], str(tmp_path))
     assert cp.returncode != 0 and "Unexpected" in cp.stdout
-    # external-index .pgen is refused, not mis-read
-    with open(str(tmp_path / "d.pgen"), "r+b") as f:
-        f.seek(2)
-        f.write(bytes([0x20]))
-    cp = run_cli(cli, ["--pfile", "d", "--indep-pairwise", "50", "5", "0.2", "--bad-ld", "--dry-run", "--out", "o"], str(tmp_path))
-    assert cp.returncode != 0 and "storage mode 0x20 is not supported" in cp.stdout
+    # an external-index .pgen without its index, and the extension modes: refused, not mis-read
+    for mode, needle in ((0x20, "d.pgen.pgi"), (0x21, "storage mode 0x21"), (0x11, "storage mode 0x11 is not supported")):
+        with open(str(tmp_path / "d.pgen"), "r+b") as f:
+            f.seek(2)
+            f.write(bytes([mode]))
+        cp = run_cli(cli, ["--pfile", "d", "--indep-pairwise", "50", "5", "0.2", "--bad-ld", "--dry-run", "--out", "o"], str(tmp_path))
+        assert cp.returncode != 0 and needle in cp.stdout, cp.stdout
 
 
 def test_cli_refuses_to_compute_without_gpu(cli, pkg, tmp_path):
@@ -114,6 +115,7 @@ CLI_CASES = [
     ("pfile", ["100", "10"], "0.4", 2, 0, 0, True),
     ("vpfile", ["20kb"], "0.2", 2, 0, 0, False),     # standard variable-width .pgen written by the reference
     ("vpfile", ["60", "3"], "0.5", 1, 9, 4, False),
+    ("xpfile", ["25kb"], "0.3", 2, 4, 2, False),      # the same with the index split off into a .pgen.pgi (mode 0x20), named by --pgi
 ]
 
 
@@ -129,6 +131,11 @@ def test_cli_byte_identical_to_reference(gpu_pkg, cli, tmp_path, case):
         assert mk.returncode == 0, mk.stdout
         assert open(str(tmp_path / "v.pgen"), "rb").read(3)[2] == 0x10
         common = ["--pfile", "v", "--indep-pairwise"] + wargs + [r2]
+    elif fmt == "xpfile":
+        mk = T.run_ref(["--pfile", "d", "--make-pgen", "--out", "v"], str(tmp_path))
+        assert mk.returncode == 0, mk.stdout
+        T.split_pgen_index(str(tmp_path / "v.pgen"), str(tmp_path / "x.pgen"), str(tmp_path / "x.index"))
+        common = ["--pgen", "x.pgen", "--pgi", "x.index", "--pvar", "v.pvar", "--psam", "v.psam", "--indep-pairwise"] + wargs + [r2]
     else:
         common = ["--" + fmt, "d", "--indep-pairwise"] + wargs + [r2]
     if order == 1:

@@ -79,6 +79,57 @@ def test_committed_variable_width_file(pkg):
     f.close()
 
 
+def test_external_index_file(pkg, tmp_path):
+    """Storage mode 0x20: the records in the .pgen, the header in the .pgen.pgi beside it (or wherever --pgi says)."""
+    import ctypes
+    z = np.load(os.path.join(GOLD, "varwidth_small_codes.npz"))
+    want = T.unpack_2bit(z["raw_packed"].reshape(int(z["m"]), -1).view(np.uint64), int(z["n"]))
+    T.split_pgen_index(os.path.join(GOLD, "varwidth_small.pgen"), str(tmp_path / "x.pgen"), str(tmp_path / "x.pgen.pgi"))
+    f = pkg.PgenFile(str(tmp_path / "x.pgen"))
+    assert f.mode == 0x10 and (f.variant_ct, f.sample_ct) == (int(z["m"]), int(z["n"]))
+    assert np.array_equal(codes(f.read(), f.sample_ct), want)
+    assert np.array_equal(codes(f.read(120, 33), f.sample_ct), want[120:153])
+    f.close()
+    # the index under another name
+    os.rename(str(tmp_path / "x.pgen.pgi"), str(tmp_path / "elsewhere.idx"))
+    with pytest.raises(pkg.LdpError):
+        pkg.PgenFile(str(tmp_path / "x.pgen"))
+    L = pkg.lib()
+    h = ctypes.c_void_p()
+    L.ldp_pgen_open_indexed.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+    assert L.ldp_pgen_open_indexed(str(tmp_path / "x.pgen").encode(), str(tmp_path / "elsewhere.idx").encode(), 0, 0, ctypes.byref(h)) == 0
+    L.ldp_pgen_close.argtypes = [ctypes.c_void_p]
+    L.ldp_pgen_close(h)
+    # a .pgi is not a .pgen; an index with the wrong magic is refused
+    with pytest.raises(pkg.LdpError):
+        pkg.PgenFile(str(tmp_path / "elsewhere.idx"))
+    bad = bytearray(open(str(tmp_path / "elsewhere.idx"), "rb").read())
+    bad[2] = 0x10
+    open(str(tmp_path / "x.pgen.pgi"), "wb").write(bytes(bad))
+    with pytest.raises(pkg.LdpError):
+        pkg.PgenFile(str(tmp_path / "x.pgen"))
+
+
+@pytest.mark.skipif(not T.have_ref(), reason="reference binary not built")
+def test_external_index_file_is_what_the_reference_reads(pkg, tmp_path):
+    """The split file is a valid external-index fileset by the reference's own reader: it prunes it to the same lists."""
+    m, n = 600, 80
+    raw = structured_codes(m, n, 5)
+    T.write_pgen_fixed(str(tmp_path / "f"), raw, ["1"] * m, np.arange(m) * 100 + 1)
+    cp = T.run_ref(["--pfile", "f", "--make-pgen", "--out", "v"], str(tmp_path))
+    assert cp.returncode == 0, cp.stdout
+    T.split_pgen_index(str(tmp_path / "v.pgen"), str(tmp_path / "x.pgen"), str(tmp_path / "x.pgen.pgi"))
+    for ext in (".pvar", ".psam"):
+        os.link(str(tmp_path / ("v" + ext)), str(tmp_path / ("x" + ext)))
+    a = T.run_ref(["--pfile", "v", "--indep-pairwise", "50", "5", "0.3", "--out", "a"], str(tmp_path))
+    b = T.run_ref(["--pfile", "x", "--indep-pairwise", "50", "5", "0.3", "--out", "b"], str(tmp_path))
+    assert a.returncode == 0 and b.returncode == 0, b.stdout
+    assert open(str(tmp_path / "a.prune.in")).read() == open(str(tmp_path / "b.prune.in")).read()
+    f = pkg.PgenFile(str(tmp_path / "x.pgen"))
+    assert np.array_equal(codes(f.read(threads=3), n), raw)
+    f.close()
+
+
 @pytest.mark.skipif(not T.have_ref(), reason="reference binary not built")
 @pytest.mark.parametrize("m,n,seed", [(400, 50, 1), (900, 300, 2), (70000, 40, 3), (300, 70000, 4)])
 def test_roundtrip_through_reference_writer(pkg, tmp_path, m, n, seed):
