@@ -339,10 +339,14 @@ int ldp_pgen_open_indexed(const char* path, const char* pgi_path, uint32_t sampl
   // "formatted just like a PGEN header", third byte 0x30; block offsets still point into the .pgen)
   const uint8_t* H = P->map;
   uint64_t Hsize = P->size;
+  // 0x11 / 0x21 are 0x10 / 0x20 with "ignorable extensions" (pgen_spec.tex:237-270): bytes behind the header body and
+  // possibly behind the last record.  Every record is located through the block offsets and record lengths, so ignoring
+  // them takes no parsing at all.
+  if (P->mode == 0x11) {
+    P->file_mode = P->mode;
+    P->mode = 0x10;
+  }
   if ((P->mode & 0xfe) == 0x20) {
-    if (P->mode == 0x21) {
-      return pfail(P, LDP_ERR_UNSUPPORTED, ".pgen storage mode 0x21 (external index with header extensions) is not supported.");
-    }
     const std::string ipath = (pgi_path && pgi_path[0]) ? std::string(pgi_path) : (std::string(path) + ".pgi");
     P->index_fd = open(ipath.c_str(), O_RDONLY);
     if (P->index_fd < 0) {
@@ -358,7 +362,7 @@ int ldp_pgen_open_indexed(const char* path, const char* pgi_path, uint32_t sampl
       return pfail(P, LDP_ERR_NOMEM, "Failed to map " + ipath + ".");
     }
     P->index_map = static_cast<const uint8_t*>(im);
-    if ((P->index_map[0] != 0x6c) || (P->index_map[1] != 0x1b) || (P->index_map[2] != 0x30)) {
+    if ((P->index_map[0] != 0x6c) || (P->index_map[1] != 0x1b) || (P->index_map[2] != (P->mode | 0x10))) {
       return pfail(P, LDP_ERR_INVALID, ipath + " is not a .pgen.pgi file (first three bytes don't match the magic number).");
     }
     H = P->index_map;
@@ -397,7 +401,7 @@ int ldp_pgen_open_indexed(const char* path, const char* pgi_path, uint32_t sampl
   }
   if (P->mode != 0x10) {
     char buf[160];
-    snprintf(buf, sizeof(buf), ".pgen storage mode 0x%02x is not supported (supported: 0x01 .bed, 0x02 fixed-width, 0x10 standard, 0x20 standard with an external index).", P->mode);
+    snprintf(buf, sizeof(buf), ".pgen storage mode 0x%02x is not supported (supported: 0x01 .bed, 0x02 fixed-width, 0x10 / 0x11 standard, 0x20 / 0x21 standard with an external index).", P->mode);
     return pfail(P, LDP_ERR_UNSUPPORTED, buf);
   }
   // ---- standard variable-width header (pgen_spec.tex:160-235)

@@ -16,7 +16,7 @@
 // --r2-unphased / --r-unphased: the matrix shapes (square/square0/triangle as bin, bin4 or text, zs), the windowed and the
 // inter-chr .vcor table with cols=, --ld-window, --ld-window-kb, --ld-window-cm, --ld-window-r2, --ld-snp / --ld-snps / --ld-snp-list,
 // --parallel; number formatting restated from dtoa_g.  --clump (several reports, --clump-allow-overlap).
-// Not yet supported (reported as such with exit 63, never silently mis-handled): .pgen header extensions (modes 0x11/0x21),
+// Not yet supported (reported as such with exit 63, never silently mis-handled): dosage tracks,
 // more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, chrX/Y/MT in the r^2 outputs and --clump,
 // --clump-range.
 #include <dlfcn.h>

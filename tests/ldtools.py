@@ -701,3 +701,21 @@ def split_pgen_index(pgen_path, out_pgen, out_pgi):
         f.write(bytes(hdr))
     with open(out_pgen, "wb") as f:
         f.write(bytes([0x6C, 0x1B, 0x20]) + data[header_len:])
+
+
+def add_pgen_header_extension(pgen_path, out_path, writer_id=b"ldtools test writer"):
+    """A standard (0x10) .pgen rewritten with an ignorable header extension (mode 0x11, pgen_spec.tex:237-270): header flag
+    varint 0x2 (writer identifier), no footer extensions, the body's length, the body; block offsets shifted accordingly."""
+    data = open(pgen_path, "rb").read()
+    assert data[:3] == bytes([0x6C, 0x1B, 0x10]) and len(writer_id) < 128
+    m = int.from_bytes(data[3:7], "little")
+    n_blocks = (m + 65535) // 65536
+    offs = [int.from_bytes(data[12 + 8 * b:20 + 8 * b], "little") for b in range(n_blocks)]
+    header_len = offs[0]
+    ext = bytes([0x02, 0x00, len(writer_id)]) + writer_id
+    hdr = bytearray(data[:header_len])
+    hdr[2] = 0x11
+    for b, o in enumerate(offs):
+        hdr[12 + 8 * b:20 + 8 * b] = (o + len(ext)).to_bytes(8, "little")
+    with open(out_path, "wb") as f:
+        f.write(bytes(hdr) + ext + data[header_len:])

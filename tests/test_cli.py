@@ -88,7 +88,7 @@ def test_founder_guard_and_format_errors(cli, tmp_path):
     cp = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "50", "5", "0.2", "--bad-ld", "--dry-run", "--out", "o"], str(tmp_path))
     assert cp.returncode != 0 and "Unexpected" in cp.stdout
     # an external-index .pgen without its index, and the extension modes: refused, not mis-read
-    for mode, needle in ((0x20, "d.pgen.pgi"), (0x21, "storage mode 0x21"), (0x11, "storage mode 0x11 is not supported")):
+    for mode, needle in ((0x20, "d.pgen.pgi"), (0x21, "d.pgen.pgi"), (0x12, "storage mode 0x12 is not supported")):
         with open(str(tmp_path / "d.pgen"), "r+b") as f:
             f.seek(2)
             f.write(bytes([mode]))

@@ -128,6 +128,25 @@ def test_external_index_file_is_what_the_reference_reads(pkg, tmp_path):
     f = pkg.PgenFile(str(tmp_path / "x.pgen"))
     assert np.array_equal(codes(f.read(threads=3), n), raw)
     f.close()
+    # ignorable header extensions (0x11), alone and with the external index (0x21 / 0x31)
+    T.add_pgen_header_extension(str(tmp_path / "v.pgen"), str(tmp_path / "e.pgen"))
+    for ext in (".pvar", ".psam"):
+        os.link(str(tmp_path / ("v" + ext)), str(tmp_path / ("e" + ext)))
+    c = T.run_ref(["--pfile", "e", "--indep-pairwise", "50", "5", "0.3", "--out", "c"], str(tmp_path))
+    assert c.returncode == 0, c.stdout
+    assert open(str(tmp_path / "a.prune.in")).read() == open(str(tmp_path / "c.prune.in")).read()
+    f = pkg.PgenFile(str(tmp_path / "e.pgen"))
+    assert np.array_equal(codes(f.read(threads=2), n), raw)
+    f.close()
+    pgi = bytearray(open(str(tmp_path / "x.pgen.pgi"), "rb").read())
+    pgi[2] = 0x31
+    open(str(tmp_path / "y.pgen.pgi"), "wb").write(bytes(pgi) + bytes([0x00, 0x00]))   # (no extensions present)
+    body = bytearray(open(str(tmp_path / "x.pgen"), "rb").read())
+    body[2] = 0x21
+    open(str(tmp_path / "y.pgen"), "wb").write(bytes(body))
+    f = pkg.PgenFile(str(tmp_path / "y.pgen"))
+    assert np.array_equal(codes(f.read(), n), raw)
+    f.close()
 
 
 @pytest.mark.skipif(not T.have_ref(), reason="reference binary not built")
@@ -153,7 +172,10 @@ def test_malformed_files_are_rejected(pkg, tmp_path):
     open(bad, "wb").write(src[:len(src) // 2])            # truncated records
     with pytest.raises(pkg.LdpError):
         pkg.PgenFile(bad).read()
-    open(bad, "wb").write(src[:2] + bytes([0x21]) + src[3:])  # external-index mode: unsupported
+    open(bad, "wb").write(src[:2] + bytes([0x21]) + src[3:])  # external-index mode without its index
+    with pytest.raises(pkg.LdpError):
+        pkg.PgenFile(bad)
+    open(bad, "wb").write(src[:2] + bytes([0x03]) + src[3:])  # fixed-width dosage: unsupported
     with pytest.raises(pkg.LdpError) as ei:
         pkg.PgenFile(bad)
     assert ei.value.code == pkg.LDP_ERR_UNSUPPORTED
