@@ -17,7 +17,7 @@
 // inter-chr .vcor table with cols=, --ld-window, --ld-window-kb, --ld-window-cm, --ld-window-r2, --ld-snp / --ld-snps / --ld-snp-list,
 // --parallel; number formatting restated from dtoa_g.  --clump (several reports, --clump-allow-overlap).
 // Not yet supported (reported as such with exit 63, never silently mis-handled): dosage tracks,
-// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, chrX/Y/MT in the r^2 outputs and --clump,
+// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, chrY/MT in the r^2 outputs, chrX/Y/MT in --clump,
 // --clump-range.
 #include <dlfcn.h>
 #include <sys/mman.h>
@@ -2809,8 +2809,8 @@ void load_inputs(Session& S, int argc, char** argv) {
         ++skipped;
         continue;
       }
-      if (cls >= 3 && A.have_r2) {
-        die(63, "Error: chromosome '%s': chrX/chrY/MT are not supported yet by --r2-unphased in plink2-hip.\n", cur.c_str());
+      if ((cls >= 4 && A.have_r2) || (cls == 3 && A.have_clump)) {
+        die(63, "Error: chromosome '%s': chrY/MT are not supported yet by --r2-unphased, and chrX/chrY/MT not by --clump, in plink2-hip.\n", cur.c_str());
       }
       if (cls == 2) {
         die(6, "Error: Invalid chromosome code '%s'. (Use --allow-extra-chr to force it to be accepted.)\n", cur.c_str());
@@ -2923,13 +2923,18 @@ int run_r2(Session& S) {
     die(7, "Error: Gigantic (over 400k variants) --r2-unphased unfiltered, non-distributed\ncomputation.  Rerun with the 'yes-really' modifier if you are SURE you have enough\nhard drive space and want to do this.\n");
   }
   // host rows of the listed variants (raw file indices, in engine order) -> engine: decode / direct rows, founder columns
-  auto feed_rows = [&](ldp_engine* eng, const std::vector<uint32_t>& incl) {
+  // cols: the sample columns the engine keeps (nullptr: the founders)
+  auto feed_rows_cols = [&](ldp_engine* eng, const std::vector<uint32_t>& incl, const std::vector<uint32_t>* cols) {
     const uint32_t n_incl = static_cast<uint32_t>(incl.size());
-    const bool all_founders = (founder_ct == raw_sample_ct);
+    const bool all_founders = (!cols) && (founder_ct == raw_sample_ct);
     std::vector<uint32_t> founder_idx;
-    for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
-      if (is_founder[sx]) {
-        founder_idx.push_back(sx);
+    if (cols) {
+      founder_idx = *cols;
+    } else {
+      for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+        if (is_founder[sx]) {
+          founder_idx.push_back(sx);
+        }
       }
     }
     const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((1024ull << 20) / std::max<uint64_t>(rec_bytes, 1)));
@@ -2962,6 +2967,7 @@ int run_r2(Session& S) {
       k += run;
     }
   };
+  auto feed_rows = [&](ldp_engine* eng, const std::vector<uint32_t>& incl) { feed_rows_cols(eng, incl, nullptr); };
   if (A.have_clump) {
     for (uint32_t k = 0; k < variant_ct; ++k) {
       if (V.alt_ct[inc[k]] > 1) {  // (the reference clumps (variant, A1 allele) pairs there, plink2_ld.cc:7776-7817)
@@ -3130,6 +3136,187 @@ int run_r2(Session& S) {
       }
     }
   }
+  // ---- chrX (ComputeXR2, plink2_ld.cc:7122-7190): a pair with a chrX variant weighs the male founders down --
+  // by 1/2 when both variants are on chrX, by 1 - sqrt(2)/2 when one is -- in all six sums before the same quotient.  The
+  // kernels' values for such pairs are replaced on the host: two integer 6-tuples per pair (all founders from the main
+  // engine, male founders from a second engine fed the same rows through a sample map; ldp_pair_stats), turned from the
+  // engines' +-1 coding and orientation into the reference's counts of the non-major (non-REF with 'ref-based') allele --
+  // exactly, in integers -- and then the reference's doubles, fma for fma (the reference documents an -mfma build).
+  std::vector<uint8_t> is_x(variant_ct, 0);
+  bool any_x = false;
+  for (uint32_t k = 0; k < variant_ct; ++k) {
+    is_x[k] = (vcls[k] == 3);
+    any_x = any_x || is_x[k];
+  }
+  ldp_engine* e_male = nullptr;
+  std::vector<uint8_t> x_flip_all, x_flip_male, x_maj_alt;  // (x_maj_alt: the chrX-aware major allele, for the MAJ / NONMAJ columns)
+  struct EngineGuard {
+    ldp_engine** p;
+    ~EngineGuard() {
+      if (*p) {
+        ldp_destroy(*p);
+      }
+    }
+  } male_guard{&e_male};
+  std::vector<double> x_maj_freq;
+  if (any_x) {
+    std::vector<uint32_t> male_cols;
+    for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+      if (is_founder[sx] && (sex[sx] == 1)) {
+        male_cols.push_back(sx);
+      }
+    }
+    std::vector<ldp_variant_rec> recs_all(variant_ct), recs_male(variant_ct);
+    memset(recs_male.data(), 0, recs_male.size() * sizeof(ldp_variant_rec));
+    if (ldp_get_variant_recs(e, 0, variant_ct, recs_all.data())) {
+      die(16, "Error: %s\n", ldp_last_error(e));
+    }
+    if (!male_cols.empty()) {
+      ldp_params MP = RP;
+      MP.founder_ct = static_cast<uint32_t>(male_cols.size());
+      if (ldp_create(&MP, &e_male) || ldp_set_variants_matrix(e_male, variant_ct)) {
+        die(16, "Error: engine setup failed.\n");
+      }
+      feed_rows_cols(e_male, inc, &male_cols);
+      if (ldp_get_variant_recs(e_male, 0, variant_ct, recs_male.data())) {
+        die(16, "Error: %s\n", ldp_last_error(e_male));
+      }
+    }
+    x_flip_all.assign(variant_ct, 0);
+    x_flip_male.assign(variant_ct, 0);
+    x_maj_alt.assign(variant_ct, 0);
+    x_maj_freq.assign(variant_ct, 0.0);
+    for (uint32_t k = 0; k < variant_ct; ++k) {
+      uint32_t target_alt = recs_all[k].flags & 1u;  // the engine's own choice: diploid allele counts over the founders
+      if (is_x[k]) {
+        // the allele-frequency pass on chrX counts a male once (the arithmetic of build_sex_row above)
+        const uint64_t g1 = recs_all[k].n_het, g2 = recs_all[k].n_homalt, n_all = static_cast<uint64_t>(recs_all[k].n_homref) + g1 + g2;
+        const uint64_t m1 = recs_male[k].n_het, m2 = recs_male[k].n_homalt, n_male = static_cast<uint64_t>(recs_male[k].n_homref) + m1 + m2;
+        const uint64_t alt_ct = 4 * g2 + 2 * g1 - 2 * m2 - m1, tot = 2 * (2 * n_all - n_male), ref_ct = tot - alt_ct;
+        double ref_freq = 0.5;
+        if (tot) {
+          ref_freq = static_cast<double>(ref_ct) * (1.0 / static_cast<double>(tot));
+        }
+        target_alt = (ref_freq >= 0.5) ? 0 : 1;
+        x_maj_freq[k] = target_alt ? (1.0 - ref_freq) : ref_freq;
+      }
+      x_maj_alt[k] = static_cast<uint8_t>(target_alt);
+      if (A.r2_ref_based) {
+        target_alt = 0;
+      }
+      x_flip_all[k] = static_cast<uint8_t>((recs_all[k].flags & 1u) ^ target_alt);
+      x_flip_male[k] = static_cast<uint8_t>((recs_male[k].flags & 1u) ^ target_alt);
+    }
+  }
+  // r^2 (or r) of the listed pairs, each with at least one chrX variant
+  auto x_pairs_r2 = [&](const std::vector<uint32_t>& first, const std::vector<uint32_t>& second, std::vector<double>* out) {
+    const size_t n = first.size();
+    out->resize(n);
+    std::vector<ldp_pair_stats_t> ta, tm;
+    struct G {
+      int64_t n, g1, q1, g2, q2, d;
+    };
+    auto counts = [](const ldp_pair_stats_t& t, bool flip1, bool flip2) {
+      G c;
+      c.n = t.nm;
+      c.g1 = c.n - t.sum1;
+      c.q1 = c.n - 2 * static_cast<int64_t>(t.sum1) + t.ssq1;
+      c.g2 = c.n - t.sum2;
+      c.q2 = c.n - 2 * static_cast<int64_t>(t.sum2) + t.ssq2;
+      c.d = c.n - t.sum1 - t.sum2 + t.dot;
+      if (flip1) {  // g -> 2 - g
+        c.q1 = 4 * c.n - 4 * c.g1 + c.q1;
+        c.g1 = 2 * c.n - c.g1;
+        c.d = 2 * c.g2 - c.d;
+      }
+      if (flip2) {
+        c.q2 = 4 * c.n - 4 * c.g2 + c.q2;
+        c.g2 = 2 * c.n - c.g2;
+        c.d = 2 * c.g1 - c.d;
+      }
+      return c;
+    };
+    double nan_ref;  // (the bits the reference's `0.0 / 0.0` has on x86: sign set)
+    {
+      const uint64_t bits = 0xfff8000000000000ull;
+      memcpy(&nan_ref, &bits, 8);
+    }
+    for (size_t p0 = 0; p0 < n; p0 += (1u << 21)) {
+      const uint32_t cnt = static_cast<uint32_t>(std::min<size_t>(n - p0, 1u << 21));
+      ta.resize(cnt);
+      tm.assign(cnt, ldp_pair_stats_t{0, 0, 0, 0, 0, 0});
+      if (ldp_pair_stats(e, cnt, first.data() + p0, second.data() + p0, ta.data()) ||
+          (e_male && ldp_pair_stats(e_male, cnt, first.data() + p0, second.data() + p0, tm.data()))) {
+        die(16, "Error: %s\n", ldp_last_error(e));
+      }
+      for (uint32_t q = 0; q < cnt; ++q) {
+        const uint32_t i = first[p0 + q], j = second[p0 + q];
+        const G a = counts(ta[q], x_flip_all[i], x_flip_all[j]);
+        double r = nan_ref;
+        if (a.n) {
+          const G m = e_male ? counts(tm[q], x_flip_male[i], x_flip_male[j]) : G{0, 0, 0, 0, 0, 0};
+          const double male_downwt = (is_x[i] && is_x[j]) ? 0.5 : (1.0 - 0.5 * 1.4142135623730951);
+          const double w_obs = fma(-male_downwt, static_cast<double>(m.n), static_cast<double>(a.n));
+          const double w_g1 = fma(-male_downwt, static_cast<double>(m.g1), static_cast<double>(a.g1));
+          const double w_g2 = fma(-male_downwt, static_cast<double>(m.g2), static_cast<double>(a.g2));
+          const double w_q1 = fma(-male_downwt, static_cast<double>(m.q1), static_cast<double>(a.q1));
+          const double w_q2 = fma(-male_downwt, static_cast<double>(m.q2), static_cast<double>(a.q2));
+          const double w_d = fma(-male_downwt, static_cast<double>(m.d), static_cast<double>(a.d));
+          const double var1 = fma(w_q1, w_obs, -w_g1 * w_g1);
+          const double var2 = fma(w_q2, w_obs, -w_g2 * w_g2);
+          if ((var1 > 0.0) && (var2 > 0.0)) {
+            const double var_prod = var1 * var2;
+            const double cov = fma(w_d, w_obs, -w_g1 * w_g2);
+            const double q = cov * cov / var_prod;
+            r = (1.0 < q) ? 1.0 : q;
+            if (A.r_unsquared) {
+              r = sqrt(r);
+              if (cov < 0.0) {
+                r = -r;
+              }
+            }
+          }
+        }
+        (*out)[p0 + q] = r;
+      }
+    }
+  };
+  // the entries of dense rows [r0, r0 + rows) x columns [c0, c0 + cols) (second variant j = row, first variant i = column,
+  // i < j) that involve chrX, recomputed in place
+  auto x_fix_dense = [&](void* buf, bool as_float, uint32_t r0, uint32_t rows, uint32_t c0, uint32_t cols, uint64_t ld) {
+    if (!any_x) {
+      return;
+    }
+    std::vector<uint32_t> fi, se;
+    std::vector<double> vals;
+    auto flush = [&]() {
+      x_pairs_r2(fi, se, &vals);
+      for (size_t q = 0; q < fi.size(); ++q) {
+        const uint64_t idx = static_cast<uint64_t>(se[q] - r0) * ld + (fi[q] - c0);
+        if (as_float) {
+          static_cast<float*>(buf)[idx] = static_cast<float>(vals[q]);
+        } else {
+          static_cast<double*>(buf)[idx] = vals[q];
+        }
+      }
+      fi.clear();
+      se.clear();
+    };
+    for (uint32_t q = 0; q < rows; ++q) {
+      const uint32_t j = r0 + q;
+      const uint32_t i_end = std::min(j, c0 + cols);
+      for (uint32_t i = c0; i < i_end; ++i) {
+        if (is_x[i] || is_x[j]) {
+          fi.push_back(i);
+          se.push_back(j);
+        }
+      }
+      if (fi.size() > (1u << 22)) {
+        flush();
+      }
+    }
+    flush();
+  };
   if (A.r2_table) {
     // ---- windowed table (VcorTable, plink2_ld.cc:11025): one line per pair A < B inside the window whose r^2 passes
     //      --ld-window-r2, A-major; default column set (plink2_ld.h:101)
@@ -3214,7 +3401,10 @@ int run_r2(Session& S) {
       for (uint32_t k = 0; k < variant_ct; ++k) {
         const auto it = multi_maj.find(k);
         double maj_freq;
-        if (it != multi_maj.end()) {
+        if (is_x[k]) {
+          maj_allele[k] = x_maj_alt[k];
+          maj_freq = x_maj_freq[k];
+        } else if (it != multi_maj.end()) {
           maj_allele[k] = static_cast<uint8_t>(it->second.first);
           maj_freq = it->second.second;
         } else {
@@ -3413,14 +3603,35 @@ int run_r2(Session& S) {
             die(16, "Error: %s\n", ldp_last_error(e));
           }
           if (found <= dev_hits.size()) {
-            std::sort(dev_hits.begin(), dev_hits.begin() + found, [](const ldp_r2_hit& a, const ldp_r2_hit& b) {
-              return (a.second != b.second) ? (a.second < b.second) : (a.first < b.first);
-            });
+            std::vector<Hit> fresh;
             for (uint64_t q = 0; q < found; ++q) {
-              if ((dev_hits[q].first >= shard_first) && (dev_hits[q].first < shard_end)) {
-                hits.push_back({dev_hits[q].first, dev_hits[q].second, dev_hits[q].r2});
+              if ((dev_hits[q].first >= shard_first) && (dev_hits[q].first < shard_end) && !(is_x[dev_hits[q].first] || is_x[dev_hits[q].second])) {
+                fresh.push_back({dev_hits[q].first, dev_hits[q].second, dev_hits[q].r2});
               }
             }
+            if (any_x) {  // the chunk's pairs with a chrX variant: values and filter on the host
+              std::vector<uint32_t> fi, se;
+              std::vector<double> vals;
+              for (uint32_t j = r0; j < r0 + big; ++j) {
+                const uint32_t i0 = A.r2_inter ? shard_first : std::max(lo[j], shard_first);
+                const uint32_t i1 = std::min(j, shard_end);
+                for (uint32_t i = i0; i < i1; ++i) {
+                  if (is_x[i] || is_x[j]) {
+                    fi.push_back(i);
+                    se.push_back(j);
+                  }
+                }
+              }
+              x_pairs_r2(fi, se, &vals);
+              for (size_t q = 0; q < fi.size(); ++q) {
+                if ((thresh >= 0.0) && (!(fabs(vals[q]) >= thresh))) {
+                  continue;
+                }
+                fresh.push_back({fi[q], se[q], vals[q]});
+              }
+            }
+            std::sort(fresh.begin(), fresh.end(), [](const Hit& a, const Hit& b) { return (a.j != b.j) ? (a.j < b.j) : (a.i < b.i); });
+            hits.insert(hits.end(), fresh.begin(), fresh.end());
             r0 += big;
             continue;
           }
@@ -3437,6 +3648,7 @@ int run_r2(Session& S) {
         if (ldp_r2_unphased_rows(e, r0, rows, 0, chunk.data(), ld)) {
           die(16, "Error: %s\n", ldp_last_error(e));
         }
+        x_fix_dense(chunk.data(), false, r0, rows, 0, static_cast<uint32_t>(ld), ld);
         std::vector<std::vector<Hit>> part(nthreads);
         std::vector<std::thread> pool;
         for (uint32_t t = 0; t < nthreads; ++t) {
@@ -3559,6 +3771,21 @@ int run_r2(Session& S) {
       if (off[row_ct] && ldp_r2_unphased_band_rows(e, row_first, row_ct, 0, band.data(), off[row_ct])) {
         die(16, "Error: %s\n", ldp_last_error(e));
       }
+      if (any_x) {  // (a window never leaves its chromosome: the pairs of the chrX rows)
+        std::vector<uint32_t> fi, se;
+        std::vector<double> vals;
+        for (uint32_t q = 0; q < row_ct; ++q) {
+          const uint32_t j = row_first + q;
+          for (uint32_t i = lo[j]; is_x[j] && (i < j); ++i) {
+            fi.push_back(i);
+            se.push_back(j);
+          }
+        }
+        x_pairs_r2(fi, se, &vals);
+        for (size_t q = 0; q < fi.size(); ++q) {
+          band[off[se[q] - row_first] + (fi[q] - lo[se[q]])] = vals[q];
+        }
+      }
       char num[40];
       for (uint32_t i = a0; i < a1; ++i) {
         if (chr_idx[i] != chr_a_idx) {
@@ -3615,6 +3842,7 @@ int run_r2(Session& S) {
     if (ldp_r2_unphased_rows(e, r0, rows, A.r2_float, chunk.data(), ld)) {
       die(16, "Error: %s\n", ldp_last_error(e));
     }
+    x_fix_dense(chunk.data(), A.r2_float != 0, r0, rows, 0, static_cast<uint32_t>(ld), ld);
     for (uint32_t q = 0; q < rows; ++q) {
       const uint32_t j = r0 + q;
       const uint8_t* row = chunk.data() + static_cast<uint64_t>(q) * ld * esz;
@@ -3667,6 +3895,7 @@ int run_r2(Session& S) {
       if (ldp_r2_unphased_block(e, r0, rows, shard_first, piece_rows, A.r2_float, chunk.data(), piece_rows)) {
         die(16, "Error: %s\n", ldp_last_error(e));
       }
+      x_fix_dense(chunk.data(), A.r2_float != 0, r0, rows, shard_first, piece_rows, piece_rows);
       for (uint32_t q = 0; q < rows; ++q) {
         const uint32_t i = r0 + q;  // second variant
         const uint32_t jmax = std::min(i, shard_end);  // first variants j in [shard_first, jmax)

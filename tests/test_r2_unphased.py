@@ -705,3 +705,92 @@ def test_cli_ld_window_cm_edge_cases(gpu_pkg, tmp_path):
     assert ref.returncode == got.returncode == 8
     ref, got = both(["--ld-window-cm", "-1"])
     assert ref.returncode == got.returncode == 8 and "Invalid --ld-window-cm argument" in got.stdout
+
+
+def _x_fileset(tmp_path, m=360, n=150, seed=7, unknown_sex=True, nonfounders=5):
+    """chr1 + chrX + chr5 (chrX in the middle of the file), males / females / unknown sex, some non-founders."""
+    raw = T.synth_raw_codes(m, n, seed, missing_rate=0.04, ld_copy_prob=0.7)
+    per = m // 3
+    chroms = ["1"] * per + ["X"] * per + ["5"] * (m - 2 * per)
+    rng = np.random.default_rng(seed)
+    bps = np.concatenate([np.sort(rng.integers(1, 50000, per)), np.sort(rng.integers(1, 50000, per)), np.sort(rng.integers(1, 50000, m - 2 * per))]).astype(np.uint32)
+    sexes = rng.choice([1, 2, 0] if unknown_sex else [1, 2], size=n, p=[0.5, 0.4, 0.1] if unknown_sex else [0.5, 0.5])
+    male = np.flatnonzero(sexes == 1)
+    for v in range(per, 2 * per):                 # hemizygous males: hets are rare there, not absent
+        het = raw[v, male] == 1
+        keep = rng.random(het.sum()) < 0.1
+        vals = raw[v, male]
+        vals[np.flatnonzero(het)[~keep]] = 2 * rng.integers(0, 2, size=int((~keep).sum()))
+        raw[v, male] = vals
+    prefix = str(tmp_path / "sx")
+    T.write_pgen_fixed(prefix, raw, chroms, bps, sexes=sexes)
+    T.write_bed(prefix, raw, chroms, bps)
+    fam, psam = [], ["#IID\tPAT\tMAT\tSEX"]
+    for s_ in range(n):
+        nf = (s_ % 11 == 3) and (s_ // 11 < nonfounders)
+        fam.append("s%d s%d %s %s %d -9" % (s_, s_, "s0" if nf else "0", "s1" if nf else "0", sexes[s_]))
+        psam.append("s%d\t%s\t%s\t%s" % (s_, "s0" if nf else "0", "s1" if nf else "0", "NA" if sexes[s_] == 0 else str(sexes[s_])))
+    open(prefix + ".fam", "w").write("\n".join(fam) + "\n")
+    open(prefix + ".psam", "w").write("\n".join(psam) + "\n")
+    return prefix
+
+
+X_CASES = [
+    ("pfile", "--r2-unphased", [], [], ".vcor"),
+    ("bfile", "--r2-unphased", [], ["--ld-window-r2", "0", "--ld-window-kb", "6"], ".vcor"),
+    ("pfile", "--r2-unphased", ["inter-chr"], ["--ld-window-r2", "0.04"], ".vcor"),
+    ("pfile", "--r2-unphased", ["inter-chr"], ["--ld-window-r2", "0"], ".vcor"),
+    ("bfile", "--r2-unphased", ["cols=+maj,+nonmaj,+freq"], ["--ld-window-r2", "0.1"], ".vcor"),
+    ("pfile", "--r2-unphased", ["square", "bin"], [], ".unphased.vcor2.bin"),
+    ("pfile", "--r2-unphased", ["triangle", "bin4"], [], ".unphased.vcor2.bin"),
+    ("bfile", "--r2-unphased", ["square0"], [], ".unphased.vcor2"),
+    ("pfile", "--r-unphased", [], ["--ld-window-r2", "0.02"], ".vcor"),
+    ("pfile", "--r-unphased", ["ref-based", "inter-chr"], ["--ld-window-r2", "0.05"], ".vcor"),
+    ("pfile", "--r-unphased", ["triangle", "bin", "ref-based"], [], ".unphased.vcor1.bin"),
+    ("pfile", "--r2-unphased", [], ["--ld-snps", "snp130-snp150,snp40", "--ld-window-kb", "8"], ".vcor"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,flag,mods,extra,ext", X_CASES)
+def test_cli_r2_with_chrx_matches_reference(gpu_pkg, tmp_path, fmt, flag, mods, extra, ext):
+    """Pairs with a chrX variant: the male founders weighted down in all six sums (ComputeXR2, plink2_ld.cc:7122-7190) -- by
+    1/2 inside chrX, by 1 - sqrt(2)/2 against an autosome -- with the chrX-aware major allele where the orientation matters."""
+    assert T.have_ref()
+    cli = gpu_pkg.build_cli()
+    tmp = str(tmp_path)
+    _x_fileset(tmp_path)
+    args = ["--" + fmt, "sx", flag] + mods + extra
+    ref = T.run_ref(args + ["--out", "ref"], tmp)
+    assert ref.returncode == 0, ref.stdout
+    got = subprocess.run([cli] + args + ["--out", "hip"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert got.returncode == 0, got.stdout
+    want, have = open(os.path.join(tmp, "ref" + ext), "rb").read(), open(os.path.join(tmp, "hip" + ext), "rb").read()
+    assert len(want) > 200
+    if ext == ".vcor" or ext.endswith("vcor2"):
+        if want != have:
+            wl, hl = want.split(b"\n"), have.split(b"\n")
+            bad = [(a, b) for a, b in zip(wl, hl) if a != b]
+            raise AssertionError("%d vs %d lines, first difference %r" % (len(wl), len(hl), bad[:2]))
+    elif want != have:
+        dt = np.float32 if "bin4" in mods else np.float64
+        a, b = np.frombuffer(want, dtype=dt), np.frombuffer(have, dtype=dt)
+        ai, bi = a.view(np.uint32 if "bin4" in mods else np.uint64), b.view(np.uint32 if "bin4" in mods else np.uint64)
+        bad = np.flatnonzero(ai != bi)
+        raise AssertionError("%d of %d elements differ, first at %d: %r (%x) vs %r (%x)" % (len(bad), len(a), bad[0], a[bad[0]], ai[bad[0]], b[bad[0]], bi[bad[0]]))
+
+
+@pytest.mark.gpu
+def test_cli_r2_chrx_without_male_founders_and_refusals(gpu_pkg, tmp_path):
+    assert T.have_ref()
+    cli = gpu_pkg.build_cli()
+    tmp = str(tmp_path)
+    prefix = _x_fileset(tmp_path, unknown_sex=False)
+    # every sample female: the male terms vanish but the chrX formula (clamp at 1, variance guard) stays
+    lines = open(prefix + ".fam").read().splitlines()
+    open(prefix + ".fam", "w").write("\n".join(" ".join(ln.split()[:4] + ["2", "-9"]) for ln in lines) + "\n")
+    args = ["--bfile", "sx", "--r2-unphased", "--ld-window-r2", "0.05"]
+    ref = T.run_ref(args + ["--out", "ref"], tmp)
+    got = subprocess.run([cli] + args + ["--out", "hip"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert ref.returncode == 0 and got.returncode == 0, (ref.stdout[-300:], got.stdout[-300:])
+    assert filecmp.cmp(os.path.join(tmp, "ref.vcor"), os.path.join(tmp, "hip.vcor"), shallow=False)
