@@ -17,7 +17,7 @@
 // inter-chr .vcor table with cols=, --ld-window, --ld-window-kb, --ld-window-cm, --ld-window-r2, --ld-snp / --ld-snps / --ld-snp-list,
 // --parallel; number formatting restated from dtoa_g.  --clump (several reports, --clump-allow-overlap).
 // Not yet supported (reported as such with exit 63, never silently mis-handled): dosage tracks,
-// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, chrY/MT in the r^2 outputs, chrX/Y/MT in --clump,
+// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, major-allele-oriented outputs on chrY/MT, chrX/Y/MT in --clump,
 // --clump-range.
 #include <dlfcn.h>
 #include <sys/mman.h>
@@ -2809,8 +2809,8 @@ void load_inputs(Session& S, int argc, char** argv) {
         ++skipped;
         continue;
       }
-      if ((cls >= 4 && A.have_r2) || (cls == 3 && A.have_clump)) {
-        die(63, "Error: chromosome '%s': chrY/MT are not supported yet by --r2-unphased, and chrX/chrY/MT not by --clump, in plink2-hip.\n", cur.c_str());
+      if (cls >= 3 && A.have_clump) {
+        die(63, "Error: chromosome '%s': chrX/chrY/MT are not supported yet by --clump in plink2-hip.\n", cur.c_str());
       }
       if (cls == 2) {
         die(6, "Error: Invalid chromosome code '%s'. (Use --allow-extra-chr to force it to be accepted.)\n", cur.c_str());
@@ -3143,10 +3143,59 @@ int run_r2(Session& S) {
   // engines' +-1 coding and orientation into the reference's counts of the non-major (non-REF with 'ref-based') allele --
   // exactly, in integers -- and then the reference's doubles, fma for fma (the reference documents an -mfma build).
   std::vector<uint8_t> is_x(variant_ct, 0);
-  bool any_x = false;
+  bool any_x = false, any_ymt = false;
   for (uint32_t k = 0; k < variant_ct; ++k) {
     is_x[k] = (vcls[k] == 3);
     any_x = any_x || is_x[k];
+    any_ymt = any_ymt || (vcls[k] >= 4);
+  }
+  // chrY: the female founders' calls count as missing (InterleavedSetMissing, VcorMatrix :10290 / VcorTable :11845), unless
+  // every founder is male or none is female (:10025-10043); MT rows are ordinary.  What would need the haploid
+  // allele-frequency arithmetic of these chromosomes is the major allele: the sign of a major-oriented r, the MAJ / NONMAJ /
+  // NONMAJ_FREQ columns, and the rounding of the chrX-weighted sums when a chrX variant is paired with them.
+  uint32_t founder_male_ct = 0, founder_female_ct = 0;
+  for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+    founder_male_ct += is_founder[sx] && (sex[sx] == 1);
+    founder_female_ct += is_founder[sx] && (sex[sx] == 2);
+  }
+  if (founder_female_ct && (founder_male_ct != founder_ct)) {
+    std::vector<uint8_t> row(rec_bytes);
+    const uint8_t missing_code = (encoding == LDP_GENO_BED) ? 1 : 3;
+    for (uint32_t k = 0; k < variant_ct; ++k) {
+      if (vcls[k] != 4) {
+        continue;
+      }
+      if (direct_rows) {
+        memcpy(row.data(), direct_rows + static_cast<uint64_t>(inc[k]) * rec_bytes, rec_bytes);
+      } else if (ldp_pgen_read(pg, inc[k], 1, row.data(), rec_bytes, 0)) {
+        die(6, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+      }
+      for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+        if (is_founder[sx] && (sex[sx] == 2)) {
+          uint8_t& b = row[sx >> 2];
+          b = static_cast<uint8_t>((b & ~(3u << (2 * (sx & 3)))) | (missing_code << (2 * (sx & 3))));
+        }
+      }
+      if (ldp_load_genotypes(e, k, 1, row.data(), rec_bytes, LDP_MEM_HOST, encoding | ((founder_ct == raw_sample_ct) ? 0 : LDP_GENO_MAPPED))) {
+        die(16, "Error: %s\n", ldp_last_error(e));
+      }
+    }
+  }
+  // chrX is only special when the founders are of both kinds (:9946-9951, :11470-11480)
+  if ((!founder_male_ct) || (founder_male_ct == founder_ct)) {
+    any_x = false;
+    std::fill(is_x.begin(), is_x.end(), 0);
+  }
+  if (any_ymt) {
+    if (A.r_unsquared && !A.r2_ref_based) {
+      die(63, "Error: --r-unphased on chrY/MT variants needs 'ref-based' in plink2-hip.\n");
+    }
+    if (A.r2_table && (A.r2_cols & (kVcorColMaj | kVcorColNonmaj | kVcorColFreq))) {
+      die(63, "Error: the maj/nonmaj/freq columns of chrY/MT variants are not supported by plink2-hip.\n");
+    }
+    if (any_x && (!A.r2_ref_based) && (A.r2_inter || !A.r2_table)) {
+      die(63, "Error: all-pairs --r2-unphased over chrX together with chrY/MT needs 'ref-based' in plink2-hip.\n");
+    }
   }
   ldp_engine* e_male = nullptr;
   std::vector<uint8_t> x_flip_all, x_flip_male, x_maj_alt;  // (x_maj_alt: the chrX-aware major allele, for the MAJ / NONMAJ columns)

@@ -788,9 +788,42 @@ def test_cli_r2_chrx_without_male_founders_and_refusals(gpu_pkg, tmp_path):
     prefix = _x_fileset(tmp_path, unknown_sex=False)
     # every sample female: the male terms vanish but the chrX formula (clamp at 1, variance guard) stays
     lines = open(prefix + ".fam").read().splitlines()
-    open(prefix + ".fam", "w").write("\n".join(" ".join(ln.split()[:4] + ["2", "-9"]) for ln in lines) + "\n")
-    args = ["--bfile", "sx", "--r2-unphased", "--ld-window-r2", "0.05"]
+    for sex_code in ("2", "1"):     # ... and with male founders only chrX is not special at all (Vcor :9946-9951)
+        open(prefix + ".fam", "w").write("\n".join(" ".join(ln.split()[:4] + [sex_code, "-9"]) for ln in lines) + "\n")
+        for args in (["--bfile", "sx", "--r2-unphased", "--ld-window-r2", "0.05"], ["--bfile", "sx", "--r2-unphased", "inter-chr", "--ld-window-r2", "0.05"]):
+            ref = T.run_ref(args + ["--out", "ref"], tmp)
+            got = subprocess.run([cli] + args + ["--out", "hip"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+            assert ref.returncode == 0 and got.returncode == 0, (ref.stdout[-300:], got.stdout[-300:])
+            assert filecmp.cmp(os.path.join(tmp, "ref.vcor"), os.path.join(tmp, "hip.vcor"), shallow=False), (sex_code, args)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,flag,mods,extra,ext", [
+    ("pfile", "--r2-unphased", [], ["--ld-window-r2", "0.03"], ".vcor"),
+    ("bfile", "--r2-unphased", ["ref-based", "cols=+ref,+alt1"], ["--ld-window-kb", "4", "--ld-window-r2", "0"], ".vcor"),
+    ("pfile", "--r-unphased", ["ref-based", "inter-chr"], ["--ld-window-r2", "0.03"], ".vcor"),
+    ("pfile", "--r2-unphased", ["square", "bin", "ref-based"], [], ".unphased.vcor2.bin"),
+])
+def test_cli_r2_whole_genome_layout_matches_reference(gpu_pkg, tmp_path, fmt, flag, mods, extra, ext):
+    """Autosomes, chrX, chrY and MT in one fileset (only chrX is special in the unphased statistics, Vcor :9611-9632)."""
+    assert T.have_ref()
+    from test_cli import sexed_fileset
+    cli = gpu_pkg.build_cli()
+    tmp = str(tmp_path)
+    sexed_fileset(tmp_path, m=500, n=130)
+    args = ["--" + fmt, "sx", flag] + mods + extra
     ref = T.run_ref(args + ["--out", "ref"], tmp)
+    assert ref.returncode == 0, ref.stdout
     got = subprocess.run([cli] + args + ["--out", "hip"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
-    assert ref.returncode == 0 and got.returncode == 0, (ref.stdout[-300:], got.stdout[-300:])
-    assert filecmp.cmp(os.path.join(tmp, "ref.vcor"), os.path.join(tmp, "hip.vcor"), shallow=False)
+    assert got.returncode == 0, got.stdout
+    want, have = open(os.path.join(tmp, "ref" + ext), "rb").read(), open(os.path.join(tmp, "hip" + ext), "rb").read()
+    assert len(want) > 200
+    if ext == ".vcor" and want != have:
+        wl, hl = want.split(b"\n"), have.split(b"\n")
+        bad = [(a, b) for a, b in zip(wl, hl) if a != b]
+        raise AssertionError("%d vs %d lines, first difference %r" % (len(wl), len(hl), bad[:2]))
+    assert want == have
+    # what needs the haploid chromosomes' major allele is refused
+    for bad_args in (["--r-unphased"], ["--r2-unphased", "cols=+maj"], ["--r2-unphased", "inter-chr"]):
+        r = subprocess.run([cli, "--pfile", "sx"] + bad_args + ["--out", "hip2"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 63, (bad_args, r.stdout[-300:])
