@@ -2,9 +2,9 @@
 """Randomised end-to-end comparison on the GPU box: plink2-hip against the reference binary (oracle/_ref/plink2) on
 random small filesets -- .bed or fixed-width .pgen, chromosome 0 rows, non-founders, missing calls, kb / count windows,
 both scan orders -- for --indep-pairwise (.prune.in/.prune.out), --indep-pairphase on phased variable-width .pgen
-(autosomes, chrX/chrY/MT with random sexes, non-founders), the --r2-unphased table (.vcor, with --ld-snp / --ld-snps /
---ld-snp-list row variants) and --clump (.clumps).  Files must be
-byte-identical.
+(autosomes, chrX/chrY/MT with random sexes, non-founders), the --r2-unphased / --r-unphased table (.vcor: windowed incl.
+--ld-window-cm, inter-chr, 'ref-based', cols= sets, --ld-snp / --ld-snps / --ld-snp-list row variants, a chrX with random
+sexes now and then) and --clump (.clumps).  Files must be byte-identical.
     python tests/fuzz_cli.py [--cases 40] [--seed 1]"""
 import argparse
 import filecmp
@@ -126,6 +126,12 @@ def one_case(cli, ref, rng, idx, tmp, execute=True, mode="all"):
     per = np.sort(rng.integers(0, chr_ct, size=m - n_zero))
     labels = [str(c) for c in rng.choice(np.arange(1, 23), size=chr_ct, replace=False)]
     labels.sort(key=int)
+    kind = rng.random()
+    # the r^2 outputs also get a chrX now and then (male founders weighted down, ComputeXR2), with random sexes
+    with_x = (kind >= 0.6) and (rng.random() < 0.3)
+    sexes = rng.choice([1, 2, 0], size=n, p=[0.45, 0.45, 0.1]) if with_x else np.full(n, 2)
+    if with_x:
+        labels[-1] = "X"
     names += [labels[c] for c in per]
     pos = np.zeros(m, dtype=np.int64)
     pos[:n_zero] = np.arange(n_zero) + 1
@@ -138,8 +144,11 @@ def one_case(cli, ref, rng, idx, tmp, execute=True, mode="all"):
     if use_bed:
         T.write_bed(os.path.join(d, "d"), raw, names, pos)
         inp = ["--bfile", "d"]
+        if with_x:
+            lines = open(os.path.join(d, "d.fam")).read().splitlines()
+            open(os.path.join(d, "d.fam"), "w").write("\n".join(" ".join(ln.split()[:4] + [str(sexes[k]), "-9"]) for k, ln in enumerate(lines)) + "\n")
     else:
-        T.write_pgen_fixed(os.path.join(d, "d"), raw, names, pos)
+        T.write_pgen_fixed(os.path.join(d, "d"), raw, names, pos, sexes=sexes if with_x else None)
         inp = ["--pfile", "d"]
     # some samples with parents in the file (non-founders): the engines pick the founder columns themselves
     founders = n
@@ -159,7 +168,7 @@ def one_case(cli, ref, rng, idx, tmp, execute=True, mode="all"):
             with open(os.path.join(d, "d.psam"), "w") as f:
                 f.write("#IID\tPAT\tMAT\tSEX\n")
                 for sidx in range(n):
-                    f.write("s%d\t%s\t%s\t2\n" % (sidx, "s0" if isnf[sidx] else "0", "s1" if isnf[sidx] else "0"))
+                    f.write("s%d\t%s\t%s\t%s\n" % (sidx, "s0" if isnf[sidx] else "0", "s1" if isnf[sidx] else "0", "NA" if sexes[sidx] == 0 else str(sexes[sidx])))
     # filters in front of the command: a chromosome subset, an ID list to drop, a sample list to keep
     if rng.random() < 0.3:
         how = rng.random()
@@ -175,9 +184,8 @@ def one_case(cli, ref, rng, idx, tmp, execute=True, mode="all"):
                 f.write("".join(("s%d s%d\n" % (s, s)) if use_bed else ("s%d\n" % s) for s in keep))
             inp = inp + ["--keep", "keep.txt"]
             founders = len(keep)
-    if rng.random() < 0.2:
+    if (rng.random() < 0.2) and not with_x:
         inp = inp + [str(rng.choice(["--maf", "--geno"])), str(rng.choice([0.01, 0.02, 0.05, 0.1, 0.3]))]
-    kind = rng.random()
     if kind < 0.12:
         # --clump on a random report (unknown IDs, repeated lines, odd p-value spellings come from tests/test_clump.py)
         import test_clump as TC
@@ -202,13 +210,29 @@ def one_case(cli, ref, rng, idx, tmp, execute=True, mode="all"):
             args.append("--bad-ld")
         outs = [".prune.in", ".prune.out"]
     else:
+        # r^2 or signed r, orientation, column set
+        flag = ["--r-unphased"] if rng.random() < 0.3 else ["--r2-unphased"]
+        mods = ["ref-based"] if rng.random() < 0.3 else []
+        if rng.random() < 0.4:
+            mods.append(str(rng.choice(["cols=+maj,+nonmaj,+freq", "cols=+ref,+alt1,+alt", "cols=-chrom,-pos,+maj,+ref", "cols=id,ref,maj,freq", "cols=+provref,+ref"])))
         if rng.random() < 0.25:
-            args = inp + ["--r2-unphased", "inter-chr", "--ld-window-r2", str(rng.choice([0, 0.05, 0.2, 0.6]))]
+            args = inp + flag + ["inter-chr"] + mods + ["--ld-window-r2", str(rng.choice([0, 0.05, 0.2, 0.6]))]
         else:
-            args = inp + ["--r2-unphased", "--ld-window-kb", str(rng.choice([1, 5, 30])), "--ld-window-r2", str(rng.choice([0, 0.05, 0.2, 0.6]))]
+            args = inp + flag + mods + ["--ld-window-kb", str(rng.choice([1, 5, 30])), "--ld-window-r2", str(rng.choice([0, 0.05, 0.2, 0.6]))]
             if rng.random() < 0.5:
                 args += ["--ld-window", str(int(rng.integers(2, 40)))]
-        if ("--ld-window" not in args) and (rng.random() < 0.35):
+            elif use_bed and (rng.random() < 0.4):
+                # centimorgan positions on a coarse grid (pairs exactly one radius apart) and a centimorgan window
+                rows = [ln.split("\t") for ln in open(os.path.join(d, "d.bim")).read().splitlines()]
+                cm, last = 0.0, None
+                for r_ in rows:
+                    if r_[0] != last:
+                        cm, last = 0.0, r_[0]
+                    cm += float(rng.choice([0.0, 0.125, 0.25, 0.5]))
+                    r_[2] = "%g" % cm
+                open(os.path.join(d, "d.bim"), "w").write("\n".join("\t".join(r_) for r_ in rows) + "\n")
+                args += ["--ld-window-cm", str(rng.choice([0.25, 0.5, 1, 3]))]
+        if ("--ld-window" not in args) and ("--ld-window-cm" not in args) and (rng.random() < 0.35):
             # row variants: a single ID, ranges, or a list file with an unknown ID in it
             pick = sorted(int(x) for x in rng.choice(np.arange(n_zero, m), size=int(rng.integers(1, 6)), replace=False))
             how = rng.random()
