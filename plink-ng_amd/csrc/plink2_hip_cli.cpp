@@ -17,8 +17,7 @@
 // inter-chr .vcor table with cols=, --ld-window, --ld-window-kb, --ld-window-cm, --ld-window-r2, --ld-snp / --ld-snps / --ld-snp-list,
 // --parallel; number formatting restated from dtoa_g.  --clump (several reports, --clump-allow-overlap).
 // Not yet supported (reported as such with exit 63, never silently mis-handled): dosage tracks,
-// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, major-allele-oriented outputs on chrY/MT, chrX/Y/MT in --clump,
-// --clump-range.
+// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, major-allele-oriented r^2 outputs on chrY/MT, --clump-range.
 #include <dlfcn.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -2027,9 +2026,109 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
 }
 
 // feed(engine, raw file indices in engine order): the caller's genotype-row feeder
+// ---- chrX pairs of the r^2 outputs and --clump (ComputeXR2, plink2_ld.cc:7122-7190) ----
+// A pair with a chrX variant weighs the male founders down in all six sums -- by 1/2 when both variants are on chrX, by
+// 1 - sqrt(2)/2 when one is -- before the same quotient.  Two integer 6-tuples per pair (all founders from `all`, male
+// founders from `male`, an engine fed the same rows through a sample map; ldp_pair_stats) are turned from the engines' +-1
+// coding and orientation into the reference's counts of the non-major (non-REF) allele -- exactly, in integers -- and
+// then the reference's doubles follow, fma for fma (the documented AVX2 build defines FP_FAST_FMA).  Inside chrX the weight
+// is dyadic and every sum exact, so WHICH orientation is the target only matters for pairs with an autosome -- but the two
+// tuples of a pair must agree on one (each engine picks its major alleles from its own samples).
+struct XWeighted {
+  ldp_engine* all = nullptr;
+  ldp_engine* male = nullptr;             // nullptr: no male founders
+  std::vector<uint8_t> is_x;               // per engine row
+  std::vector<uint8_t> flip_all, flip_male;  // per engine row: the engine's orientation differs from the target's
+  bool unsquared = false;
+  struct G {
+    int64_t n, g1, q1, g2, q2, d;
+  };
+  static G counts(const ldp_pair_stats_t& t, bool flip1, bool flip2) {
+    G c;
+    c.n = t.nm;
+    c.g1 = c.n - t.sum1;
+    c.q1 = c.n - 2 * static_cast<int64_t>(t.sum1) + t.ssq1;
+    c.g2 = c.n - t.sum2;
+    c.q2 = c.n - 2 * static_cast<int64_t>(t.sum2) + t.ssq2;
+    c.d = c.n - t.sum1 - t.sum2 + t.dot;
+    if (flip1) {  // g -> 2 - g
+      c.q1 = 4 * c.n - 4 * c.g1 + c.q1;
+      c.g1 = 2 * c.n - c.g1;
+      c.d = 2 * c.g2 - c.d;
+    }
+    if (flip2) {
+      c.q2 = 4 * c.n - 4 * c.g2 + c.q2;
+      c.g2 = 2 * c.n - c.g2;
+      c.d = 2 * c.g1 - c.d;
+    }
+    return c;
+  }
+  // r^2 (or r) of the listed pairs, each with at least one chrX variant; NaN where the reference's is undefined
+  void pairs(const std::vector<uint32_t>& first, const std::vector<uint32_t>& second, std::vector<double>* out) const {
+    const size_t n = first.size();
+    out->resize(n);
+    std::vector<ldp_pair_stats_t> ta, tm;
+    double nan_ref;  // (the bits the reference's `0.0 / 0.0` has on x86: sign set)
+    {
+      const uint64_t bits = 0xfff8000000000000ull;
+      memcpy(&nan_ref, &bits, 8);
+    }
+    for (size_t p0 = 0; p0 < n; p0 += (1u << 21)) {
+      const uint32_t cnt = static_cast<uint32_t>(std::min<size_t>(n - p0, 1u << 21));
+      ta.resize(cnt);
+      tm.assign(cnt, ldp_pair_stats_t{0, 0, 0, 0, 0, 0});
+      if (ldp_pair_stats(all, cnt, first.data() + p0, second.data() + p0, ta.data())) {
+        die(16, "Error: %s\n", ldp_last_error(all));
+      }
+      if (male && ldp_pair_stats(male, cnt, first.data() + p0, second.data() + p0, tm.data())) {
+        die(16, "Error: %s\n", ldp_last_error(male));
+      }
+      for (uint32_t q = 0; q < cnt; ++q) {
+        const uint32_t i = first[p0 + q], j = second[p0 + q];
+        const G a = counts(ta[q], (!flip_all.empty()) && flip_all[i], (!flip_all.empty()) && flip_all[j]);
+        double r = nan_ref;
+        if (a.n) {
+          const G m = male ? counts(tm[q], (!flip_male.empty()) && flip_male[i], (!flip_male.empty()) && flip_male[j]) : G{0, 0, 0, 0, 0, 0};
+          const double male_downwt = (is_x[i] && is_x[j]) ? 0.5 : (1.0 - 0.5 * 1.4142135623730951);
+          const double w_obs = fma(-male_downwt, static_cast<double>(m.n), static_cast<double>(a.n));
+          const double w_g1 = fma(-male_downwt, static_cast<double>(m.g1), static_cast<double>(a.g1));
+          const double w_g2 = fma(-male_downwt, static_cast<double>(m.g2), static_cast<double>(a.g2));
+          const double w_q1 = fma(-male_downwt, static_cast<double>(m.q1), static_cast<double>(a.q1));
+          const double w_q2 = fma(-male_downwt, static_cast<double>(m.q2), static_cast<double>(a.q2));
+          const double w_d = fma(-male_downwt, static_cast<double>(m.d), static_cast<double>(a.d));
+          const double var1 = fma(w_q1, w_obs, -w_g1 * w_g1);
+          const double var2 = fma(w_q2, w_obs, -w_g2 * w_g2);
+          if ((var1 > 0.0) && (var2 > 0.0)) {
+            const double var_prod = var1 * var2;
+            const double cov = fma(w_d, w_obs, -w_g1 * w_g2);
+            const double quot = cov * cov / var_prod;
+            r = (1.0 < quot) ? 1.0 : quot;
+            if (unsquared) {
+              r = sqrt(r);
+              if (cov < 0.0) {
+                r = -r;
+              }
+            }
+          }
+        }
+        (*out)[p0 + q] = r;
+      }
+    }
+  }
+};
+
+// what --clump needs to know about sex chromosomes (ClumpReports :8150-8215, :8460-8482)
+struct ClumpSex {
+  const std::vector<uint8_t>* vcls = nullptr;  // per included variant: 3 chrX, 4 chrY
+  std::vector<uint32_t> male_cols;             // raw sample indices of the male founders
+  uint32_t founder_male_ct = 0, founder_female_ct = 0, founder_nosex_ct = 0;
+  std::function<void(ldp_engine*, const std::vector<uint32_t>&, const std::vector<uint32_t>*)> feed_cols;
+  std::function<void(ldp_engine*, uint32_t, uint32_t)> females_missing;
+};
+
 int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>& inc, const std::vector<uint32_t>& chr_idx,
                   const std::vector<uint32_t>& bps, uint32_t founder_ct,
-                  const std::function<void(ldp_engine*, const std::vector<uint32_t>&)>& feed) {
+                  const std::function<void(ldp_engine*, const std::vector<uint32_t>&)>& feed, const ClumpSex& SX) {
   if (founder_ct < 2) {
     die(7, "Error: --clump requires at least two founders.  (--make-founders may come in handy\nhere.)\n");
   }
@@ -2151,6 +2250,55 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
       die(16, "Error: engine setup failed: %s\n", ldp_last_error(e));
     }
     feed(e, s_raw);
+    // sex chromosomes: chrY rows with the female founders' calls missing; chrX pairs through the male-weighted sums when the
+    // founders are of both kinds (is_x, :8472-8481), their own engine for the male founders' tuples
+    std::vector<uint8_t> s_is_x(n_sub, 0);
+    bool any_x = false, any_y = false;
+    for (uint32_t q = 0; q < n_sub; ++q) {
+      const uint8_t cls = (*SX.vcls)[obs[sub[q]]];
+      any_y = any_y || (cls == 4);
+      if ((cls == 3) && SX.founder_male_ct && (SX.founder_male_ct != founder_ct)) {
+        s_is_x[q] = 1;
+        any_x = true;
+      }
+    }
+    if (any_y) {
+      if (!(SX.founder_male_ct + SX.founder_nosex_ct)) {  // :8162-8166 (there: an index variant on chrY; here: any chrY row that can be tested)
+        die(7, "Error: --clump: chrY index variant(s) are present, but all founders in the main\ndataset are females.\n");
+      }
+      if (SX.founder_male_ct + SX.founder_nosex_ct != founder_ct) {
+        for (uint32_t q = 0; q < n_sub; ++q) {
+          if ((*SX.vcls)[obs[sub[q]]] == 4) {
+            SX.females_missing(e, q, s_raw[q]);
+          }
+        }
+      }
+    }
+    XWeighted xw;
+    std::vector<uint32_t> band_lo;
+    if (any_x) {
+      ldp_params MP = RP;
+      MP.founder_ct = SX.founder_male_ct;
+      if (ldp_create(&MP, &xw.male) || ldp_set_variants_matrix(xw.male, n_sub)) {
+        die(16, "Error: engine setup failed.\n");
+      }
+      SX.feed_cols(xw.male, s_raw, &SX.male_cols);
+      xw.all = e;
+      xw.is_x = s_is_x;
+      // one orientation for both tuples of a pair: the main engine's (the male engine chose its major alleles from the male
+      // founders alone).  Which one it is does not matter inside chrX: the weight is dyadic and every sum exact.
+      std::vector<ldp_variant_rec> ra(n_sub), rm(n_sub);
+      if (ldp_get_variant_recs(e, 0, n_sub, ra.data()) || ldp_get_variant_recs(xw.male, 0, n_sub, rm.data())) {
+        die(16, "Error: %s\n", ldp_last_error(e));
+      }
+      xw.flip_male.resize(n_sub);
+      for (uint32_t q = 0; q < n_sub; ++q) {
+        xw.flip_male[q] = static_cast<uint8_t>((ra[q].flags ^ rm[q].flags) & 1u);
+      }
+      band_lo.resize(n_sub);
+      uint64_t cand_pairs = 0;
+      ldp_get_band(e, band_lo.data(), &cand_pairs);
+    }
     t_rows = now_s();
     std::vector<ldp_r2_hit> hits(1u << 24);
     const double min_r2 = std::max(A.clump_r2_raw, 0.0);
@@ -2168,20 +2316,44 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
         rows_per_call = std::max(1u, rows / 2);
         continue;
       }
-      for (uint64_t q = 0; q < found; ++q) {
-        const ldp_r2_hit& h = hits[q];
-        if (!(h.r2 > A.clump_r2)) {
-          continue;
-        }
-        const uint32_t a = sub[h.first], b = sub[h.second];
+      auto link = [&](uint32_t first, uint32_t second) {
+        const uint32_t a = sub[first], b = sub[second];
         if (is_cand[a]) {
           links.emplace_back(a, b);
         }
         if (is_cand[b]) {
           links.emplace_back(b, a);
         }
+      };
+      for (uint64_t q = 0; q < found; ++q) {
+        const ldp_r2_hit& h = hits[q];
+        if ((!(h.r2 > A.clump_r2)) || s_is_x[h.second]) {  // (a window never leaves its chromosome: chrX rows pair with chrX rows)
+          continue;
+        }
+        link(h.first, h.second);
+      }
+      if (any_x) {
+        std::vector<uint32_t> fi, se;
+        std::vector<double> vals;
+        for (uint32_t j = r0; j < r0 + rows; ++j) {
+          for (uint32_t i = band_lo[j]; s_is_x[j] && (i < j); ++i) {
+            if (is_cand[sub[i]] || is_cand[sub[j]]) {
+              fi.push_back(i);
+              se.push_back(j);
+            }
+          }
+        }
+        xw.pairs(fi, se, &vals);
+        for (size_t q = 0; q < fi.size(); ++q) {
+          if (vals[q] > A.clump_r2) {
+            link(fi[q], se[q]);
+          }
+        }
       }
       r0 += rows;
+    }
+    if (xw.male) {
+      ldp_destroy(xw.male);
     }
     ldp_destroy(e);
     t_pairs = now_s();
@@ -2809,9 +2981,6 @@ void load_inputs(Session& S, int argc, char** argv) {
         ++skipped;
         continue;
       }
-      if (cls >= 3 && A.have_clump) {
-        die(63, "Error: chromosome '%s': chrX/chrY/MT are not supported yet by --clump in plink2-hip.\n", cur.c_str());
-      }
       if (cls == 2) {
         die(6, "Error: Invalid chromosome code '%s'. (Use --allow-extra-chr to force it to be accepted.)\n", cur.c_str());
       }
@@ -2968,6 +3137,26 @@ int run_r2(Session& S) {
     }
   };
   auto feed_rows = [&](ldp_engine* eng, const std::vector<uint32_t>& incl) { feed_rows_cols(eng, incl, nullptr); };
+  // chrY rows of the r^2 outputs and --clump: the female founders' calls count as missing (InterleavedSetMissing, plink2_ld.cc
+  // :8833, :10290, :11845).  Reloads engine row `row` from raw variant `raw` that way.
+  auto females_missing = [&](ldp_engine* eng, uint32_t row_idx, uint32_t raw) {
+    std::vector<uint8_t> row(rec_bytes);
+    const uint8_t missing_code = (encoding == LDP_GENO_BED) ? 1 : 3;
+    if (direct_rows) {
+      memcpy(row.data(), direct_rows + static_cast<uint64_t>(raw) * rec_bytes, rec_bytes);
+    } else if (ldp_pgen_read(pg, raw, 1, row.data(), rec_bytes, 0)) {
+      die(6, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+    }
+    for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+      if (is_founder[sx] && (sex[sx] == 2)) {
+        uint8_t& b = row[sx >> 2];
+        b = static_cast<uint8_t>((b & ~(3u << (2 * (sx & 3)))) | (missing_code << (2 * (sx & 3))));
+      }
+    }
+    if (ldp_load_genotypes(eng, row_idx, 1, row.data(), rec_bytes, LDP_MEM_HOST, encoding | ((founder_ct == raw_sample_ct) ? 0 : LDP_GENO_MAPPED))) {
+      die(16, "Error: %s\n", ldp_last_error(eng));
+    }
+  };
   if (A.have_clump) {
     for (uint32_t k = 0; k < variant_ct; ++k) {
       if (V.alt_ct[inc[k]] > 1) {  // (the reference clumps (variant, A1 allele) pairs there, plink2_ld.cc:7776-7817)
@@ -2975,7 +3164,21 @@ int run_r2(Session& S) {
       }
     }
     join_hip();
-    const int rc = clump_reports(A, V, inc, chr_idx, bps, founder_ct, feed_rows);
+    ClumpSex SX;
+    SX.vcls = &vcls;
+    for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+      if (is_founder[sx]) {
+        SX.founder_male_ct += (sex[sx] == 1);
+        SX.founder_female_ct += (sex[sx] == 2);
+        SX.founder_nosex_ct += (sex[sx] != 1) && (sex[sx] != 2);
+        if (sex[sx] == 1) {
+          SX.male_cols.push_back(sx);
+        }
+      }
+    }
+    SX.feed_cols = feed_rows_cols;
+    SX.females_missing = females_missing;
+    const int rc = clump_reports(A, V, inc, chr_idx, bps, founder_ct, feed_rows, SX);
     if (g_log) {
       fclose(g_log);
     }
@@ -3136,12 +3339,7 @@ int run_r2(Session& S) {
       }
     }
   }
-  // ---- chrX (ComputeXR2, plink2_ld.cc:7122-7190): a pair with a chrX variant weighs the male founders down --
-  // by 1/2 when both variants are on chrX, by 1 - sqrt(2)/2 when one is -- in all six sums before the same quotient.  The
-  // kernels' values for such pairs are replaced on the host: two integer 6-tuples per pair (all founders from the main
-  // engine, male founders from a second engine fed the same rows through a sample map; ldp_pair_stats), turned from the
-  // engines' +-1 coding and orientation into the reference's counts of the non-major (non-REF with 'ref-based') allele --
-  // exactly, in integers -- and then the reference's doubles, fma for fma (the reference documents an -mfma build).
+  // ---- chrX: the kernels' values of pairs with a chrX variant are replaced on the host (XWeighted above) ----
   std::vector<uint8_t> is_x(variant_ct, 0);
   bool any_x = false, any_ymt = false;
   for (uint32_t k = 0; k < variant_ct; ++k) {
@@ -3159,25 +3357,9 @@ int run_r2(Session& S) {
     founder_female_ct += is_founder[sx] && (sex[sx] == 2);
   }
   if (founder_female_ct && (founder_male_ct != founder_ct)) {
-    std::vector<uint8_t> row(rec_bytes);
-    const uint8_t missing_code = (encoding == LDP_GENO_BED) ? 1 : 3;
     for (uint32_t k = 0; k < variant_ct; ++k) {
-      if (vcls[k] != 4) {
-        continue;
-      }
-      if (direct_rows) {
-        memcpy(row.data(), direct_rows + static_cast<uint64_t>(inc[k]) * rec_bytes, rec_bytes);
-      } else if (ldp_pgen_read(pg, inc[k], 1, row.data(), rec_bytes, 0)) {
-        die(6, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
-      }
-      for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
-        if (is_founder[sx] && (sex[sx] == 2)) {
-          uint8_t& b = row[sx >> 2];
-          b = static_cast<uint8_t>((b & ~(3u << (2 * (sx & 3)))) | (missing_code << (2 * (sx & 3))));
-        }
-      }
-      if (ldp_load_genotypes(e, k, 1, row.data(), rec_bytes, LDP_MEM_HOST, encoding | ((founder_ct == raw_sample_ct) ? 0 : LDP_GENO_MAPPED))) {
-        die(16, "Error: %s\n", ldp_last_error(e));
+      if (vcls[k] == 4) {
+        females_missing(e, k, inc[k]);
       }
     }
   }
@@ -3257,79 +3439,14 @@ int run_r2(Session& S) {
       x_flip_male[k] = static_cast<uint8_t>((recs_male[k].flags & 1u) ^ target_alt);
     }
   }
-  // r^2 (or r) of the listed pairs, each with at least one chrX variant
-  auto x_pairs_r2 = [&](const std::vector<uint32_t>& first, const std::vector<uint32_t>& second, std::vector<double>* out) {
-    const size_t n = first.size();
-    out->resize(n);
-    std::vector<ldp_pair_stats_t> ta, tm;
-    struct G {
-      int64_t n, g1, q1, g2, q2, d;
-    };
-    auto counts = [](const ldp_pair_stats_t& t, bool flip1, bool flip2) {
-      G c;
-      c.n = t.nm;
-      c.g1 = c.n - t.sum1;
-      c.q1 = c.n - 2 * static_cast<int64_t>(t.sum1) + t.ssq1;
-      c.g2 = c.n - t.sum2;
-      c.q2 = c.n - 2 * static_cast<int64_t>(t.sum2) + t.ssq2;
-      c.d = c.n - t.sum1 - t.sum2 + t.dot;
-      if (flip1) {  // g -> 2 - g
-        c.q1 = 4 * c.n - 4 * c.g1 + c.q1;
-        c.g1 = 2 * c.n - c.g1;
-        c.d = 2 * c.g2 - c.d;
-      }
-      if (flip2) {
-        c.q2 = 4 * c.n - 4 * c.g2 + c.q2;
-        c.g2 = 2 * c.n - c.g2;
-        c.d = 2 * c.g1 - c.d;
-      }
-      return c;
-    };
-    double nan_ref;  // (the bits the reference's `0.0 / 0.0` has on x86: sign set)
-    {
-      const uint64_t bits = 0xfff8000000000000ull;
-      memcpy(&nan_ref, &bits, 8);
-    }
-    for (size_t p0 = 0; p0 < n; p0 += (1u << 21)) {
-      const uint32_t cnt = static_cast<uint32_t>(std::min<size_t>(n - p0, 1u << 21));
-      ta.resize(cnt);
-      tm.assign(cnt, ldp_pair_stats_t{0, 0, 0, 0, 0, 0});
-      if (ldp_pair_stats(e, cnt, first.data() + p0, second.data() + p0, ta.data()) ||
-          (e_male && ldp_pair_stats(e_male, cnt, first.data() + p0, second.data() + p0, tm.data()))) {
-        die(16, "Error: %s\n", ldp_last_error(e));
-      }
-      for (uint32_t q = 0; q < cnt; ++q) {
-        const uint32_t i = first[p0 + q], j = second[p0 + q];
-        const G a = counts(ta[q], x_flip_all[i], x_flip_all[j]);
-        double r = nan_ref;
-        if (a.n) {
-          const G m = e_male ? counts(tm[q], x_flip_male[i], x_flip_male[j]) : G{0, 0, 0, 0, 0, 0};
-          const double male_downwt = (is_x[i] && is_x[j]) ? 0.5 : (1.0 - 0.5 * 1.4142135623730951);
-          const double w_obs = fma(-male_downwt, static_cast<double>(m.n), static_cast<double>(a.n));
-          const double w_g1 = fma(-male_downwt, static_cast<double>(m.g1), static_cast<double>(a.g1));
-          const double w_g2 = fma(-male_downwt, static_cast<double>(m.g2), static_cast<double>(a.g2));
-          const double w_q1 = fma(-male_downwt, static_cast<double>(m.q1), static_cast<double>(a.q1));
-          const double w_q2 = fma(-male_downwt, static_cast<double>(m.q2), static_cast<double>(a.q2));
-          const double w_d = fma(-male_downwt, static_cast<double>(m.d), static_cast<double>(a.d));
-          const double var1 = fma(w_q1, w_obs, -w_g1 * w_g1);
-          const double var2 = fma(w_q2, w_obs, -w_g2 * w_g2);
-          if ((var1 > 0.0) && (var2 > 0.0)) {
-            const double var_prod = var1 * var2;
-            const double cov = fma(w_d, w_obs, -w_g1 * w_g2);
-            const double q = cov * cov / var_prod;
-            r = (1.0 < q) ? 1.0 : q;
-            if (A.r_unsquared) {
-              r = sqrt(r);
-              if (cov < 0.0) {
-                r = -r;
-              }
-            }
-          }
-        }
-        (*out)[p0 + q] = r;
-      }
-    }
-  };
+  XWeighted xw;
+  xw.all = e;
+  xw.male = e_male;
+  xw.is_x = is_x;
+  xw.flip_all = x_flip_all;
+  xw.flip_male = x_flip_male;
+  xw.unsquared = A.r_unsquared;
+  auto x_pairs_r2 = [&](const std::vector<uint32_t>& first, const std::vector<uint32_t>& second, std::vector<double>* out) { xw.pairs(first, second, out); };
   // the entries of dense rows [r0, r0 + rows) x columns [c0, c0 + cols) (second variant j = row, first variant i = column,
   // i < j) that involve chrX, recomputed in place
   auto x_fix_dense = [&](void* buf, bool as_float, uint32_t r0, uint32_t rows, uint32_t c0, uint32_t cols, uint64_t ld) {

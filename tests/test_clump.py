@@ -193,3 +193,27 @@ def test_clump_matches_reference(gpu_pkg, cli, tmp_path, case):
     ref, got = compare_runs(cli, tmp_path, common)
     body = open(str(tmp_path / "hip.clumps")).read().split("\n")[1:-1]
     assert any(l.split("\t")[-1] != "." for l in body), "the case must form multi-variant clumps"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,unknown,extra", [
+    ("pfile", True, ["--clump-r2", "0.2", "--clump-kb", "30", "--clump-p1", "0.01", "--clump-p2", "0.2"]),
+    ("bfile", False, ["--clump-r2", "0.05", "--clump-kb", "100", "--clump-p1", "0.05", "--clump-p2", "0.5", "--clump-allow-overlap"]),
+    ("pfile", True, ["--clump-r2", "0.5", "--clump-kb", "15", "--clump-p1", "0.001"]),
+])
+def test_clump_with_sex_chromosomes_matches_reference(gpu_pkg, cli, tmp_path, fmt, unknown, extra):
+    """chrX windows through the male-weighted sums (ComputeXR2 with both variants on chrX), chrY rows with the female founders'
+    calls missing, MT as it is (ClumpReports, plink2_ld.cc:8150-8215, :8460-8482, :8823-8835)."""
+    assert T.have_ref()
+    from test_cli import sexed_fileset
+    m = 900
+    sexed_fileset(tmp_path, m=m, n=140, seed=11, unknown_sex=unknown)
+    write_report(str(tmp_path / "assoc.txt"), m, 3, sig_rate=0.1)
+    common = ["--" + fmt, "sx", "--clump", "assoc.txt", "--clump-unphased"] + extra
+    compare_runs(cli, tmp_path, common)
+    body = open(str(tmp_path / "hip.clumps")).read().split("\n")[1:-1]
+    by_chr = {}
+    for l in body:
+        f = l.split("\t")
+        by_chr.setdefault(f[0], []).append(f[-1] != ".")
+    assert any(by_chr.get("X", [])) and any(by_chr.get("Y", [])), "multi-variant clumps on chrX and chrY must be formed"
