@@ -128,7 +128,7 @@ def one_case(cli, ref, rng, idx, tmp, execute=True, mode="all"):
     labels.sort(key=int)
     kind = rng.random()
     # the r^2 outputs also get a chrX now and then (male founders weighted down, ComputeXR2), with random sexes
-    with_x = (kind >= 0.6) and (rng.random() < 0.3)
+    with_x = ((kind >= 0.6) or (kind < 0.12)) and (rng.random() < 0.3)   # (also for --clump)
     sexes = rng.choice([1, 2, 0], size=n, p=[0.45, 0.45, 0.1]) if with_x else np.full(n, 2)
     if with_x:
         labels[-1] = "X"
