@@ -1088,20 +1088,25 @@ inline uint32_t next_clear(const std::vector<uint32_t>& bm, uint32_t from, uint3
 // The greedy scan of IndepPairwiseThread (plink2_ld.cc:931-1100) for one subcontig, replayed from
 // predicate bits.  R = removed bitmap over local indices (u32 words).  pred row j: bit i of word
 // (i>>5)-(lo[j]>>5).
+// Resumable at batch boundaries (what carries over is R and first_unchecked): *cursor (nullptr: the subcontig's start) is the
+// first variant not replayed yet, and only batches whose variants all lie below `covered` -- complete predicate rows -- run.
 uint64_t replay_subcontig(const ldp_engine* e, uint32_t k, const uint32_t* pred, const double* mf, std::vector<uint32_t>& R,
-                          std::vector<uint32_t>& first_unchecked) {
+                          std::vector<uint32_t>& first_unchecked, uint32_t* cursor = nullptr, uint32_t covered = 0xffffffffu) {
   uint64_t replay_pairs = 0;
   const bool plink1 = e->P.plink1_order != 0;
   const Subcontig& s = e->subs[k];
   const uint32_t sfirst = s.local_first;
   const uint32_t send = s.local_first + s.len;
-  uint32_t ns = sfirst;
+  uint32_t ns = cursor ? *cursor : sfirst;
   while (ns < send) {
     uint32_t ne = ns;
     while (!e->batch_end[s.first + (ne - sfirst)]) {
       ++ne;
     }
     ++ne;
+    if (ne > covered) {
+      break;
+    }
     const uint32_t lo = e->lo_local[ns];
     // load-time removal of monomorphic variants (:902-904)
     for (uint32_t j = ns; j < ne; ++j) {
@@ -1187,45 +1192,86 @@ uint64_t replay_subcontig(const ldp_engine* e, uint32_t k, const uint32_t* pred,
     }
     ns = ne;
   }
+  if (cursor) {
+    *cursor = ns;
+  }
   return replay_pairs;
 }
 
 // Replay as the launch groups come back: group g is waited for, then every subcontig whose variants all lie below
 // its need_end is replayed (concurrently) while the GPU works on the later groups.
 int replay_progressive(ldp_engine* e, const uint32_t* pred, const double* mf, std::vector<uint32_t>& R, uint64_t* replay_pairs_out, double* busy_ms_out) {
-  double busy_ms = 0.0;
   std::vector<uint32_t> first_unchecked;
   if (e->P.plink1_order) {
     first_unchecked.assign(e->local_ct, 0);
   }
+  // One worker per owned subcontig (up to 64), started while the GPU still computes: a worker replays its subcontig batch by
+  // batch as far as the predicate rows are complete (`covered`, advanced by this thread as each group's copy lands) and waits
+  // for more.  What is left after the last kernel is the last group's share of one subcontig -- no thread start-up, no
+  // whole chromosomes.
+  const uint32_t n_owned = static_cast<uint32_t>(e->owned.size());
+  const uint32_t nt = std::max(1u, std::min(std::min(std::thread::hardware_concurrency(), 64u), n_owned));
+  std::atomic<uint32_t> covered(0), next(0);
   std::atomic<uint64_t> total(0);
-  size_t si = 0;  // e->owned is in local order
-  std::vector<uint32_t> batch;
-  const size_t n_groups = e->groups.size();
-  for (size_t gi = 0; gi <= n_groups; ++gi) {
-    uint32_t covered = e->local_ct;
-    if (gi < n_groups) {
-      HIP_TRY(e, hipEventSynchronize(e->groups[gi].ev_done));
-      // take along every later group that has finished in the meantime: one wide batch instead of several narrow ones
-      while ((gi + 1 < n_groups) && (hipEventQuery(e->groups[gi + 1].ev_done) == hipSuccess)) {
-        ++gi;
+  std::atomic<bool> give_up(false);
+  std::vector<std::thread> pool;
+  pool.reserve(nt);
+  for (uint32_t w = 0; w < nt; ++w) {
+    pool.emplace_back([&]() {
+      for (uint32_t idx = next.fetch_add(1); idx < n_owned; idx = next.fetch_add(1)) {
+        const uint32_t k = e->owned[idx];
+        const uint32_t send = e->subs[k].local_first + e->subs[k].len;
+        uint32_t cursor = e->subs[k].local_first;
+        uint32_t seen = covered.load(std::memory_order_acquire);
+        while (true) {
+          total.fetch_add(replay_subcontig(e, k, pred, mf, R, first_unchecked, &cursor, seen));
+          if (cursor >= send) {
+            break;
+          }
+          uint32_t spins = 0;
+          uint32_t now = covered.load(std::memory_order_acquire);
+          while ((now == seen) && !give_up.load(std::memory_order_relaxed)) {
+            if (++spins > 64) {
+              std::this_thread::sleep_for(std::chrono::microseconds(10));
+            } else {
+              std::this_thread::yield();
+            }
+            now = covered.load(std::memory_order_acquire);
+          }
+          if (give_up.load(std::memory_order_relaxed)) {
+            return;
+          }
+          seen = now;
+        }
       }
-      (void)hipGetLastError();  // (hipErrorNotReady from the query is not an error)
-      covered = (gi + 1 < n_groups) ? e->groups[gi].need_end : e->local_ct;
-    }
-    batch.clear();
-    while ((si < e->owned.size()) && (e->subs[e->owned[si]].local_first + e->subs[e->owned[si]].len <= covered)) {
-      batch.push_back(e->owned[si++]);
-    }
-    std::stable_sort(batch.begin(), batch.end(), [&](uint32_t a, uint32_t b) { return e->subs[a].len > e->subs[b].len; });
-    const double t0 = now_ms();
-    parallel_for(static_cast<uint32_t>(batch.size()), 64, [&](uint32_t t) {
-      total.fetch_add(replay_subcontig(e, batch[t], pred, mf, R, first_unchecked));
     });
-    busy_ms += now_ms() - t0;
+  }
+  double t_first = 0.0;
+  hipError_t herr = hipSuccess;
+  const size_t n_groups = e->groups.size();
+  for (size_t gi = 0; gi < n_groups; ++gi) {
+    herr = hipEventSynchronize(e->groups[gi].ev_done);
+    if (herr != hipSuccess) {
+      break;
+    }
+    if (!gi) {
+      t_first = now_ms();
+    }
+    covered.store((gi + 1 < n_groups) ? e->groups[gi].need_end : e->local_ct, std::memory_order_release);
+  }
+  if (herr != hipSuccess) {
+    give_up.store(true);
+  } else {
+    covered.store(e->local_ct, std::memory_order_release);  // (no groups at all: nothing to wait for)
+  }
+  for (std::thread& th : pool) {
+    th.join();
+  }
+  if (herr != hipSuccess) {
+    return hipfail(e, herr, "waiting for a launch group");
   }
   *replay_pairs_out = total.load();
-  *busy_ms_out = busy_ms;
+  *busy_ms_out = t_first ? (now_ms() - t_first) : 0.0;
   return LDP_OK;
 }
 
