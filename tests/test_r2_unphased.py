@@ -437,25 +437,6 @@ def test_cli_vcor_row_variants_match_reference(gpu_pkg, tmp_path, extra):
         raise AssertionError("%d vs %d lines, first difference %r" % (len(wl), len(hl), bad[:2]))
 
 
-def test_cli_ld_snp_flag_rules(tmp_path):
-    import __graft_entry__ as ge
-    cli = ge.load_package().build_cli()
-    raw = T.synth_raw_codes(60, 30, seed=2)
-    T.write_pgen_fixed(str(tmp_path / "d"), raw, ["1"] * 60, np.arange(60) * 10 + 1)
-    def run(args):
-        return subprocess.run([cli, "--pfile", "d"] + args, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
-    r = run(["--r2-unphased", "square", "--ld-snp", "snp3"])
-    assert r.returncode == 8 and "Matrix-only and table-only" in r.stdout
-    r = run(["--r2-unphased", "--ld-snp", "snp3", "--ld-snps", "snp4"])
-    assert r.returncode == 8 and "cannot be used with" in r.stdout
-    r = run(["--indep-pairwise", "50", "5", "0.2", "--ld-snp", "snp3"])
-    assert r.returncode == 8
-    r = run(["--r2-unphased", "--ld-snps", "snp3-"])
-    assert r.returncode == 8 and "Invalid --ld-snps" in r.stdout
-    r = run(["--r2-unphased", "--ld-snp", "snp3", "--ld-window", "5"])
-    assert r.returncode == 63
-
-
 COLS_CASES = [
     ("pfile", ["cols=chrom,id,ref,alt"], []),
     ("pfile", ["cols=+maj,+nonmaj,+freq"], ["--ld-window-r2", "0.05"]),
@@ -533,30 +514,6 @@ def test_cli_vcor_column_sets_at_multiallelic_variants(gpu_pkg, tmp_path):
         ref = T.run_ref(args + ["--out", "ref"], tmp)
         got = subprocess.run([cli] + args + ["--out", "hip"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert ref.returncode == got.returncode == 7, mods
-
-
-def test_cli_cols_flag_rules(tmp_path):
-    import __graft_entry__ as ge
-    cli = ge.load_package().build_cli()
-    raw = T.synth_raw_codes(60, 30, seed=2)
-    T.write_pgen_fixed(str(tmp_path / "d"), raw, ["1"] * 60, np.arange(60) * 10 + 1)
-    def run(args):
-        return subprocess.run([cli, "--pfile", "d"] + args, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
-    r = run(["--r2-unphased", "cols=+nonsense"])
-    assert r.returncode == 8 and "Unrecognized ID 'nonsense' in --r2-unphased column set descriptor." in r.stdout
-    r = run(["--r2-unphased", "cols=+maj,freq"])
-    assert r.returncode == 8 and "either all column set IDs must be" in r.stdout
-    r = run(["--r2-unphased", "cols=+d"])
-    assert r.returncode == 8 and "does not support computation of D or D'" in r.stdout
-    r = run(["--r2-unphased", "square", "cols=+maj"])
-    assert r.returncode == 8 and "Matrix-only and table-only" in r.stdout
-    r = run(["--r2-unphased", "cols=+maj", "cols=+freq"])
-    assert r.returncode == 8 and "Multiple --r2-unphased cols= modifiers." in r.stdout
-    if T.have_ref():
-        for args in (["--r2-unphased", "cols=+nonsense"], ["--r2-unphased", "cols=+maj,freq"], ["--r2-unphased", "cols=+d"], ["--r2-unphased", "dprime"]):
-            ref = T.run_ref(["--pfile", "d"] + args + ["--out", "ref"], str(tmp_path))
-            got = run(args)
-            assert ref.returncode == got.returncode, (args, ref.returncode, got.returncode)
 
 
 R_CASES = [
