@@ -436,6 +436,10 @@ struct Args {
   bool clump_allow_overlap = false;
   bool clump_no_test = false;
   std::vector<std::string> clump_id_field, clump_p_field, clump_test_field, clump_test;
+  uint32_t clump_cols = 0;                 // kClumpCol* (plink2_ld.h:51-67), set after the modifiers are read
+  std::string clump_cols_desc;
+  bool clump_cols_given = false;
+  std::vector<double> clump_ln_bins;       // --clump-bins: ln of the boundaries, each times (1 + 2^-44); empty: the default four
   double clump_ln_p1 = 2.3025850929940457 * -4.0 * (1.0 - kSmallEpsilon);
   double clump_ln_p2 = 2.3025850929940457 * -2.0 * (1.0 - kSmallEpsilon);
   double clump_r2_raw = 0.5;
@@ -481,6 +485,15 @@ enum : uint32_t {
   kVcorColMaybeprovref = 1u << 6, kVcorColProvref = 1u << 7, kVcorColMaj = 1u << 8, kVcorColNonmaj = 1u << 9, kVcorColFreq = 1u << 10,
   kVcorColD = 1u << 11, kVcorColDprime = 1u << 12, kVcorColDprimeAbs = 1u << 13,
   kVcorColDefault = kVcorColChrom | kVcorColPos | kVcorColId | kVcorColMaybeprovref
+};
+
+enum : uint32_t {
+  kClumpColChrom = 1u << 0, kClumpColPos = 1u << 1, kClumpColRef = 1u << 2, kClumpColAlt1 = 1u << 3, kClumpColAlt = 1u << 4,
+  kClumpColMaybeprovref = 1u << 5, kClumpColProvref = 1u << 6, kClumpColMaybeA1 = 1u << 7, kClumpColA1 = 1u << 8, kClumpColMaybeF = 1u << 9,
+  kClumpColF = 1u << 10, kClumpColTotal = 1u << 11, kClumpColMaybeBounds = 1u << 12, kClumpColBounds = 1u << 13, kClumpColBins = 1u << 14,
+  kClumpColSp2 = 1u << 15,
+  kClumpColDefault = kClumpColChrom | kClumpColPos | kClumpColMaybeprovref | kClumpColMaybeA1 | kClumpColMaybeF | kClumpColTotal | kClumpColMaybeBounds |
+                     kClumpColBins | kClumpColSp2
 };
 
 // A column-set descriptor: either a plain list (exactly these columns) or +name / -name edits of the default set, never
@@ -707,8 +720,19 @@ Args parse_args(int argc, char** argv) {
       need(i, 1, "--clump");
       while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
         const std::string arg = argv[++i];
-        if ((arg == "zs") || (arg.compare(0, 5, "cols=") == 0)) {
+        if (arg == "zs") {
           die(63, "Error: the '%s' modifier of --clump is not supported by plink2-hip.\n", arg.c_str());
+        }
+        if (arg.compare(0, 5, "cols=") == 0) {  // plink2.cc:4900-4925
+          if (!A.clump_files.empty()) {
+            die(8, "Error: Invalid --clump argument sequence ('cols=' must come before\nfilename(s)).\n");
+          }
+          if (A.clump_cols_given) {
+            die(8, "Error: Multiple --clump cols= modifiers.\n");
+          }
+          A.clump_cols_given = true;
+          A.clump_cols_desc = arg.substr(5);
+          continue;
         }
         size_t p0 = 0;
         while (p0 <= arg.size()) {
@@ -720,6 +744,40 @@ Args parse_args(int argc, char** argv) {
         }
       }
       A.have_clump = true;
+      A.clump_cols = kClumpColDefault;
+      if (A.clump_cols_given) {
+        A.clump_cols = parse_col_descriptor(A.clump_cols_desc, {"chrom", "pos", "ref", "alt1", "alt", "maybeprovref", "provref", "maybea1", "a1", "maybef", "f", "total",
+                                                                "maybebounds", "bounds", "bins", "sp2"}, kClumpColDefault, "clump");
+      }
+    } else if (f == "--clump-bins") {  // plink2.cc:5139-5192
+      need(i, 1, "--clump-bins");
+      double prev_ln = -1.7976931348623157e308;
+      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+        const std::string arg = argv[++i];
+        const char* it = arg.c_str();
+        while (true) {
+          double cur_ln;
+          it = scan_ln(it, &cur_ln);
+          if ((!it) || ((*it != '\0') && (*it != ','))) {
+            die(8, "Error: Invalid --clump-bins argument '%s'.\n", arg.c_str());
+          }
+          if (cur_ln <= prev_ln) {  // (the reference means to refuse these too, plink2.cc:5178, but never advances its prev_ln)
+            die(8, "Error: --clump-bins values are not in increasing order.\n");
+          }
+          if (cur_ln >= 0.0) {
+            die(8, "Error: --clump-bins values >= 1 do not make sense.\n");
+          }
+          prev_ln = cur_ln;
+          A.clump_ln_bins.push_back(cur_ln * (1.0 + kSmallEpsilon));
+          if (*it == '\0') {
+            break;
+          }
+          ++it;
+        }
+      }
+      if (A.clump_ln_bins.size() > 2000) {
+        die(63, "Error: more than 2000 --clump-bins boundaries are not supported by plink2-hip.\n");
+      }
     } else if (f == "--clump-unphased") {
       A.clump_unphased = true;
     } else if (f == "--clump-allow-overlap") {
@@ -1013,6 +1071,14 @@ Args parse_args(int argc, char** argv) {
   if (A.have_prune && A.have_r2) {
     die(8, "Error: run --indep-pairwise and --r2-unphased separately.\n");
   }
+  if (!A.clump_ln_bins.empty()) {  // plink2.cc:5139-5147
+    if (!A.have_clump) {
+      die(8, "Error: --clump-bins must be used with --clump.\n");
+    }
+    if (!(A.clump_cols & kClumpColBins)) {
+      die(8, "Error: --clump-bins does not make sense when --clump 'bins' column set has been\nexcluded.\n");
+    }
+  }
   const bool ld_window_given = (A.ld_var_ct_radius != 0x7fffffff) || (A.ld_bp_radius != 0xffffffffu) || (A.ld_cm_radius != -1.0);
   const bool ld_snp_given = (!A.ld_snps.empty()) || (!A.ld_snp_list.empty());
   if (ld_snp_given && (!A.have_r2 || A.have_clump)) {
@@ -1258,7 +1324,8 @@ void load_variants(const Args& A, Variants* V) {
   const bool keep_cm = A.have_r2 && (A.ld_cm_radius != -1.0);
   double last_cm = -1.7976931348623157e308;
   std::string last_cm_chrom;
-  const bool keep_alleles = A.have_r2 && (A.r2_cols & (kVcorColRef | kVcorColAlt1 | kVcorColAlt | kVcorColMaj | kVcorColNonmaj));
+  const bool keep_alleles = (A.have_r2 && (A.r2_cols & (kVcorColRef | kVcorColAlt1 | kVcorColAlt | kVcorColMaj | kVcorColNonmaj))) ||
+                            (A.have_clump && (A.clump_cols & (kClumpColRef | kClumpColAlt1 | kClumpColAlt)));
   constexpr int kCap = 64;
   Tok t[kCap];
   const char* p = buf.data();
@@ -1844,15 +1911,16 @@ struct ClumpData {
   // per dataset variant (index into the caller's included-variant list)
   std::vector<double> best_ln;                // lowest ln p among the lines at or below the load threshold; 0 without one
   std::vector<uint32_t> nonsig;               // lines above every bin boundary
-  std::vector<std::vector<uint16_t>> entries; // one per loaded line, in the order read (last report first): (file << 4) | (bin << 1) | (ln p > ln p2)
+  std::vector<std::vector<uint32_t>> entries; // one per loaded line, in the order read (last report first): (file << 12) | (bin << 1) | (ln p > ln p2)
+  std::vector<double> ln_bins;                // bin boundaries in use (empty: the 'bins' column set is off)
   std::vector<uint16_t> best_file;            // report (1-based) the best p-value came from; ties go to the first report
   std::vector<uint8_t> observed;
   std::vector<std::string> missing_ids;       // top (p <= p1) IDs absent from the dataset
 };
 
-uint32_t clump_bin(double ln_pval) {  // LowerBoundNonemptyD: boundaries strictly below
+uint32_t clump_bin(const std::vector<double>& ln_bins, double ln_pval) {  // LowerBoundNonemptyD: boundaries strictly below
   uint32_t b = 0;
-  while ((b < 4) && (ln_pval > kClumpLnBins[b])) {
+  while ((b < ln_bins.size()) && (ln_pval > ln_bins[b])) {
     ++b;
   }
   return b;
@@ -1863,7 +1931,7 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
   const uint32_t variant_ct = static_cast<uint32_t>(inc.size());
   D->best_ln.assign(variant_ct, 0.0);
   D->nonsig.assign(variant_ct, 0);
-  D->entries.assign(variant_ct, std::vector<uint16_t>());
+  D->entries.assign(variant_ct, std::vector<uint32_t>());
   D->best_file.assign(variant_ct, 1);
   D->observed.assign(variant_ct, 0);
   // ID -> included-variant index; kDup marks IDs the dataset holds more than once (an error only when the report names one)
@@ -1876,8 +1944,21 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
       it.first->second = kDup;
     }
   }
-  const double ln_p1 = A.clump_ln_p1, ln_p2 = A.clump_ln_p2;
-  const double load_thresh = std::max(std::max(ln_p1, ln_p2), kClumpLnBins[3]);
+  // what is kept of a line depends on the column set (:7577-7612): bins and their boundaries, p2 only when SP2 or the bounds
+  // want it, entries at all only for total / bins / SP2 / bounds, the above-every-boundary counts only for total / bins
+  D->ln_bins.clear();
+  if (A.clump_cols & kClumpColBins) {
+    D->ln_bins = A.clump_ln_bins.empty() ? std::vector<double>(kClumpLnBins, kClumpLnBins + 4) : A.clump_ln_bins;
+  }
+  const bool bounds_col = (A.clump_cols & kClumpColBounds) != 0;  // ('maybebounds' needs --clump-range)
+  const bool sp2_col = (A.clump_cols & kClumpColSp2) != 0;
+  const double ln_p1 = A.clump_ln_p1, ln_p2 = (sp2_col || bounds_col) ? A.clump_ln_p2 : -1.7976931348623157e308;
+  double load_thresh = std::max(ln_p1, ln_p2);
+  if ((!D->ln_bins.empty()) && (load_thresh < D->ln_bins.back())) {
+    load_thresh = D->ln_bins.back();
+  }
+  const bool keep_entries = (A.clump_cols & (kClumpColTotal | kClumpColBins | kClumpColSp2)) || bounds_col;
+  const bool nonsig_needed = (A.clump_cols & (kClumpColTotal | kClumpColBins)) && (load_thresh < 0.0);
   if (A.clump_files.size() > 4000) {
     die(63, "Error: too many --clump reports.\n");
   }
@@ -2009,7 +2090,7 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
         if (ln_pval > 0.0) {
           die(6, "Error: p-value > 1 on line %zu of %s.\n", line_idx, fname.c_str());
         }
-        if (ln_pval > kClumpLnBins[3]) {
+        if (nonsig_needed && (D->ln_bins.empty() || (ln_pval > D->ln_bins.back()))) {
           D->nonsig[k] += 1;
           D->observed[k] = 1;
         }
@@ -2020,7 +2101,9 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
         D->best_file[k] = static_cast<uint16_t>(file_idx1);
       }
       D->observed[k] = 1;
-      D->entries[k].push_back(static_cast<uint16_t>((file_idx1 << 4) | (clump_bin(ln_pval) << 1) | (ln_pval > ln_p2)));
+      if (keep_entries) {
+        D->entries[k].push_back(static_cast<uint32_t>((file_idx1 << 12) | (clump_bin(D->ln_bins, ln_pval) << 1) | (ln_pval > ln_p2)));
+      }
     }
   }
 }
@@ -2122,6 +2205,8 @@ struct ClumpSex {
   const std::vector<uint8_t>* vcls = nullptr;  // per included variant: 3 chrX, 4 chrY
   std::vector<uint32_t> male_cols;             // raw sample indices of the male founders
   uint32_t founder_male_ct = 0, founder_female_ct = 0, founder_nosex_ct = 0;
+  int prov_storage = 1;                        // ldp_pgen_provisional_ref
+  std::vector<uint8_t> prov_bits;
   std::function<void(ldp_engine*, const std::vector<uint32_t>&, const std::vector<uint32_t>*)> feed_cols;
   std::function<void(ldp_engine*, uint32_t, uint32_t)> females_missing;
 };
@@ -2403,15 +2488,57 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
   }
   logprintf("--clump: %u clump%s formed from %u index candidate%s.\n", clump_ct, (clump_ct == 1) ? "" : "s", cand_ct, (cand_ct == 1) ? "" : "s");
 
-  // <out>.clumps, default columns (plink2_ld.cc:9003-9405): chrom pos | total | bins | sp2
+  // <out>.clumps (plink2_ld.cc:9003-9405): [chrom pos] ID [ref alt1 alt provref a1 f] P [total] [bounds] [bins] [sp2]
   const std::string path = A.out + ".clumps";
   OutFile f;
   f.open(path, false);
   // (several reports: an F column names the report of the index variant's best p-value, and SP2 entries carry theirs)
   const bool multi = (A.clump_files.size() > 1);
-  std::string buf = multi ? "#CHROM\tPOS\tID\tF\tP\tTOTAL\tNONSIG\tS0.05\tS0.01\tS0.001\tS0.0001\tSP2\n"
-                          : "#CHROM\tPOS\tID\tP\tTOTAL\tNONSIG\tS0.05\tS0.01\tS0.001\tS0.0001\tSP2\n";
+  const uint32_t cols = A.clump_cols;
+  const bool f_col = (cols & kClumpColF) || ((cols & kClumpColMaybeF) && multi);
+  const bool sp2_col = (cols & kClumpColSp2) != 0;
+  const bool f_in_sp2 = sp2_col && ((cols & kClumpColF) || multi);
+  const bool bounds_col = (cols & kClumpColBounds) != 0;
+  const bool a1_col = (cols & kClumpColA1) != 0;  // ('maybea1' wants a multiallelic variant in the dataset: those are refused above)
+  const size_t bin_bound_ct = D.ln_bins.size();
+  bool provref_col = false;
+  if (cols & kClumpColRef) {  // ProvrefCol (plink2_common.h:1549)
+    if ((SX.prov_storage == 0) && V.info_pr_header && (cols & (kClumpColProvref | kClumpColMaybeprovref))) {
+      die(63, "Error: provisional-REF flags kept in the .pvar's INFO/PR are not supported by plink2-hip (--clump 'ref' column).\n");
+    }
+    if (cols & kClumpColProvref) {
+      provref_col = true;
+    } else if (cols & kClumpColMaybeprovref) {
+      provref_col = (SX.prov_storage == 2);
+      for (size_t k = 0; (SX.prov_storage == 3) && (!provref_col) && (k < inc.size()); ++k) {
+        provref_col = (SX.prov_bits[inc[k] >> 3] >> (inc[k] & 7)) & 1;
+      }
+    }
+  }
   char num[64];
+  std::string buf = "#";
+  if (cols & kClumpColChrom) buf += "CHROM\t";
+  if (cols & kClumpColPos) buf += "POS\t";
+  buf += "ID\t";
+  if (cols & kClumpColRef) buf += "REF\t";
+  if (cols & kClumpColAlt1) buf += "ALT1\t";
+  if (cols & kClumpColAlt) buf += "ALT\t";
+  if (provref_col) buf += "PROVISIONAL_REF?\t";
+  if (a1_col) buf += "A1\t";
+  if (f_col) buf += "F\t";
+  buf += "P";
+  if (cols & kClumpColTotal) buf += "\tTOTAL";
+  if (bounds_col) buf += "\tCLUMP_FIRST_POS\tCLUMP_LAST_POS";
+  if (bin_bound_ct) {
+    buf += "\tNONSIG";
+    for (size_t b = bin_bound_ct; b; --b) {
+      buf += "\tS";
+      buf.append(num, format_ln_g6(D.ln_bins[b - 1], num) - num);
+    }
+  }
+  if (sp2_col) buf += "\tSP2";
+  buf += '\n';
+  std::vector<uint64_t> bins(bin_bound_ct + 1);
   for (uint32_t r = 0; r < cand_ct; ++r) {
     if (mem_off[r] == mem_off[r + 1]) {
       continue;
@@ -2419,32 +2546,98 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
     const uint32_t io = cand[r];
     const uint32_t iv = inc[obs[io]];
     const double index_ln = D.best_ln[obs[io]];
-    buf += V.chrom[iv];
-    buf += '\t';
-    buf += std::to_string(V.bp[iv]);
-    buf += '\t';
+    if (cols & kClumpColChrom) {
+      buf += V.chrom[iv];
+      buf += '\t';
+    }
+    if (cols & kClumpColPos) {
+      buf += std::to_string(V.bp[iv]);
+      buf += '\t';
+    }
     buf += V.id[iv];
     buf += '\t';
+    if (cols & kClumpColRef) {
+      buf += V.ref[iv];
+      buf += '\t';
+    }
+    if (cols & kClumpColAlt1) {
+      buf.append(V.alt[iv], 0, std::min(V.alt[iv].find(','), V.alt[iv].size()));
+      buf += '\t';
+    }
+    if (cols & kClumpColAlt) {
+      buf += V.alt[iv];
+      buf += '\t';
+    }
+    if (provref_col) {
+      buf += ((SX.prov_storage == 2) || ((SX.prov_storage == 3) && ((SX.prov_bits[iv >> 3] >> (iv & 7)) & 1))) ? 'Y' : 'N';
+      buf += '\t';
+    }
+    if (a1_col) {
+      buf += ".\t";  // (a biallelic variant without --clump-force-a1, :9186-9196)
+    }
     const uint32_t index_file = D.best_file[obs[io]];
-    if (multi) {
+    if (f_col) {
       buf += std::to_string(index_file);
       buf += '\t';
     }
     buf.append(num, format_ln_g6(index_ln, num) - num);
-    uint64_t bins[5] = {0, 0, 0, 0, 0};
-    for (uint64_t q = mem_off[r]; q < mem_off[r + 1]; ++q) {
-      const uint32_t k = obs[members[q]];
-      bins[4] += D.nonsig[k];
-      for (uint16_t en : D.entries[k]) {
-        ++bins[(en >> 1) & 7];
+    if ((cols & kClumpColTotal) || bin_bound_ct) {
+      uint64_t total = 0;
+      std::fill(bins.begin(), bins.end(), 0);
+      for (uint64_t q = mem_off[r]; q < mem_off[r + 1]; ++q) {
+        const uint32_t k = obs[members[q]];
+        bins[bin_bound_ct] += D.nonsig[k];
+        for (uint32_t en : D.entries[k]) {
+          ++bins[bin_bound_ct ? ((en >> 1) & 2047) : 0];
+        }
+      }
+      // (the index variant's own line is the clump, not one of its members: with bins it leaves its bin, without them the
+      // plain count, :9240-9262)
+      --bins[bin_bound_ct ? clump_bin(D.ln_bins, index_ln) : 0];
+      for (uint64_t b : bins) {
+        total += b;
+      }
+      if (cols & kClumpColTotal) {
+        buf += '\t';
+        buf += std::to_string(total);
       }
     }
-    --bins[clump_bin(index_ln)];
-    buf += '\t';
-    buf += std::to_string(bins[0] + bins[1] + bins[2] + bins[3] + bins[4]);
-    for (int b = 4; b >= 0; --b) {
+    if (bounds_col) {
+      // bp range of the members with a line at or below p2 (:9270-9311)
+      uint32_t first_bp = 0xffffffffu, last_bp = 0;
+      for (uint64_t q = mem_off[r]; q < mem_off[r + 1]; ++q) {
+        const uint32_t k = obs[members[q]];
+        bool hit = false;
+        for (uint32_t en : D.entries[k]) {
+          hit = hit || !(en & 1);
+        }
+        if (hit) {
+          if (first_bp == 0xffffffffu) {
+            first_bp = V.bp[inc[k]];
+          }
+          last_bp = V.bp[inc[k]];
+        }
+      }
       buf += '\t';
-      buf += std::to_string(bins[b]);
+      if (first_bp != 0xffffffffu) {
+        buf += std::to_string(first_bp);
+        buf += '\t';
+        buf += std::to_string(last_bp);
+      } else {
+        buf += ".\t.";
+      }
+    }
+    for (size_t b = bin_bound_ct + 1; bin_bound_ct && b; --b) {
+      buf += '\t';
+      buf += std::to_string(bins[b - 1]);
+    }
+    if (!sp2_col) {
+      buf += '\n';
+      if (buf.size() > (1u << 20)) {
+        f.write(buf.data(), buf.size());
+        buf.clear();
+      }
+      continue;
     }
     buf += '\t';
     bool nonempty = false;
@@ -2452,15 +2645,15 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
       const uint32_t m = members[q];
       // a member's lines, latest read first (the reference walks its linked list from the head, :7851,9330): report 1's
       // lines bottom-up, then report 2's, ...; the index variant's own line in its own report is the clump itself
-      const std::vector<uint16_t>& ent = D.entries[obs[m]];
+      const std::vector<uint32_t>& ent = D.entries[obs[m]];
       for (size_t x = ent.size(); x; --x) {
-        const uint16_t en = ent[x - 1];
-        const uint32_t file = en >> 4;
+        const uint32_t en = ent[x - 1];
+        const uint32_t file = en >> 12;
         if ((en & 1) || ((m == io) && (file == index_file))) {
           continue;
         }
         buf += V.id[inc[obs[m]]];
-        if (multi) {
+        if (f_in_sp2) {
           buf += '(';
           buf += std::to_string(file);
           buf += ')';
@@ -3176,6 +3369,8 @@ int run_r2(Session& S) {
         }
       }
     }
+    SX.prov_bits.assign((static_cast<size_t>(raw_variant_ct) + 7) / 8, 0);
+    SX.prov_storage = ldp_pgen_provisional_ref(pg, SX.prov_bits.data(), SX.prov_bits.size());
     SX.feed_cols = feed_rows_cols;
     SX.females_missing = females_missing;
     const int rc = clump_reports(A, V, inc, chr_idx, bps, founder_ct, feed_rows, SX);

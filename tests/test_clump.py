@@ -145,6 +145,44 @@ def test_clump_several_reports_without_ld(cli, tmp_path, how):
     assert body[0].split("\t")[3] == "F" and any("(" in l for l in body[1:])
 
 
+@needs_ref
+@pytest.mark.parametrize("fmt,extra", [
+    ("bfile", ["cols=-chrom,-pos"]),
+    ("bfile", ["cols=+ref,+alt1,+alt"]),                       # a .bed's REF alleles are provisional: the column appears
+    ("pfile", ["cols=+ref,+alt,+provref"]),
+    ("pfile", ["cols=+bounds", "--clump-p1", "1e-3", "--clump-p2", "1e-5"]),   # index variants above p2: '.' bounds
+    ("pfile", ["cols=+bounds,+f,+a1"]),
+    ("pfile", ["cols=-bins"]),
+    ("bfile", ["cols=-total,-bins"]),
+    ("pfile", ["cols=sp2"]),
+    ("pfile", ["cols=total"]),
+    ("bfile", ["cols=chrom,pos"]),
+    ("pfile", ["--clump-bins", "0.001,0.01", "0.2"]),
+    ("bfile", ["--clump-bins", "1e-5", "--clump-p1", "0.05"]),
+    ("pfile", ["--clump-bins", "1e-6,0.0001,0.02,0.3,0.9", "cols=+bounds"]),
+])
+def test_clump_column_sets_and_bins_match_reference(cli, tmp_path, fmt, extra):
+    """cols= and --clump-bins (plink2_ld.cc:7577-7612, :9003-9360): what is kept of a report line -- and with it which variants
+    count as observed -- depends on the column set."""
+    m = 1200
+    clump_fileset(tmp_path, m, 40, 8)
+    write_report(str(tmp_path / "assoc.txt"), m, 5)
+    mods = [x for x in extra if x.startswith("cols=")]
+    rest = [x for x in extra if not x.startswith("cols=")]
+    common = ["--" + fmt, "d", "--clump"] + mods + ["assoc.txt", "--clump-unphased", "--clump-kb", "0.001"] + rest
+    compare_runs(cli, tmp_path, common)
+
+
+@needs_ref
+def test_clump_column_sets_with_two_reports(cli, tmp_path):
+    m = 700
+    clump_fileset(tmp_path, m, 40, 2)
+    write_report(str(tmp_path / "a.txt"), m, 11)
+    write_report(str(tmp_path / "b.txt"), m, 12, sig_rate=0.1)
+    for mods in (["cols=-maybef"], ["cols=+f,-sp2"], ["cols=+bounds,-total"]):
+        compare_runs(cli, tmp_path, ["--bfile", "d", "--clump"] + mods + ["a.txt", "b.txt", "--clump-unphased", "--clump-kb", "0.001", "--clump-p1", "0.001"])
+
+
 def test_clump_flag_rules(cli, tmp_path):
     clump_fileset(tmp_path, 60, 20, 3)
     write_report(str(tmp_path / "a.txt"), 60, 1)
@@ -156,6 +194,17 @@ def test_clump_flag_rules(cli, tmp_path):
     assert r.returncode == 63
     r = run_cli(cli, ["--bfile", "d", "--clump-unphased"], str(tmp_path))
     assert r.returncode == 8
+    for args, needle in ((["--clump-bins", "0.01,0.001"], "not in increasing order"), (["--clump-bins", "0.5,1"], "values >= 1"),
+                         (["--clump-bins", "0.01x"], "Invalid --clump-bins argument"), (["cols=-bins", "--clump-bins", "0.01"], "has been excluded"),
+                         (["cols=+nope"], "Unrecognized ID 'nope' in --clump column set descriptor.")):
+        mods = [x for x in args if x.startswith("cols=")]
+        rest = [x for x in args if not x.startswith("cols=")]
+        r = run_cli(cli, ["--bfile", "d", "--clump"] + mods + ["a.txt", "--clump-unphased"] + rest, str(tmp_path))
+        assert r.returncode == 8 and needle in r.stdout.replace("\n", " "), (args, r.returncode, r.stdout[-300:])
+        if T.have_ref() and "increasing" not in needle:   # (the reference's order check never updates its running value: it lets these through)
+            assert T.run_ref(["--bfile", "d", "--clump"] + mods + ["a.txt", "--clump-unphased"] + rest + ["--out", "ref"], str(tmp_path)).returncode == 8, args
+    r = run_cli(cli, ["--bfile", "d", "--clump", "a.txt", "cols=+f", "--clump-unphased"], str(tmp_path))
+    assert r.returncode == 8 and "must come before" in r.stdout
 
 
 @pytest.mark.gpu
