@@ -436,6 +436,8 @@ struct Args {
   bool clump_allow_overlap = false;
   bool clump_no_test = false;
   std::vector<std::string> clump_id_field, clump_p_field, clump_test_field, clump_test;
+  bool clump_in_log10 = false, clump_out_log10 = false;  // --clump-log10 ['input-only' | 'output-only']
+  bool clump_log10_p1 = false, clump_log10_p2 = false, clump_plain_p1 = false, clump_plain_p2 = false;
   uint32_t clump_cols = 0;                 // kClumpCol* (plink2_ld.h:51-67), set after the modifiers are read
   std::string clump_cols_desc;
   bool clump_cols_given = false;
@@ -782,7 +784,30 @@ Args parse_args(int argc, char** argv) {
       A.clump_unphased = true;
     } else if (f == "--clump-allow-overlap") {
       A.clump_allow_overlap = true;
+    } else if (f == "--clump-log10") {  // plink2.cc:5211-5232
+      A.clump_in_log10 = A.clump_out_log10 = true;
+      if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+        const std::string v = argv[++i];
+        if (v == "input-only") {
+          A.clump_out_log10 = false;
+        } else if (v == "output-only") {
+          A.clump_in_log10 = false;
+        } else {
+          die(8, "Error: Invalid --clump-log10 argument '%s'.\n", v.c_str());
+        }
+      }
+    } else if ((f == "--clump-log10-p1") || (f == "--clump-log10-p2")) {  // plink2.cc:4979-5008
+      need(i, 1, f.c_str());
+      const std::string v = argv[++i];
+      double d;
+      const char* endp;
+      if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || (d < 0.0)) {
+        die(8, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
+      }
+      ((f == "--clump-log10-p1") ? A.clump_ln_p1 : A.clump_ln_p2) = d * (-2.3025850929940457 * (1.0 - kSmallEpsilon));
+      ((f == "--clump-log10-p1") ? A.clump_log10_p1 : A.clump_log10_p2) = true;
     } else if ((f == "--clump-p1") || (f == "--clump-p2")) {  // plink2.cc:5015-5046
+      ((f == "--clump-p1") ? A.clump_plain_p1 : A.clump_plain_p2) = true;
       need(i, 1, f.c_str());
       const std::string v = argv[++i];
       double ln;
@@ -1070,6 +1095,12 @@ Args parse_args(int argc, char** argv) {
   }
   if (A.have_prune && A.have_r2) {
     die(8, "Error: run --indep-pairwise and --r2-unphased separately.\n");
+  }
+  if ((A.clump_plain_p1 && A.clump_log10_p1) || (A.clump_plain_p2 && A.clump_log10_p2)) {  // plink2.cc:5014-5016, :5032-5034
+    die(8, "Error: --clump-p%d cannot be used with --clump-log10-p%d.\n", (A.clump_plain_p1 && A.clump_log10_p1) ? 1 : 2, (A.clump_plain_p1 && A.clump_log10_p1) ? 1 : 2);
+  }
+  if ((A.clump_in_log10 || A.clump_out_log10 || A.clump_log10_p1 || A.clump_log10_p2) && !A.have_clump) {
+    die(8, "Error: --clump-log10 must be used with --clump.\n");
   }
   if (!A.clump_ln_bins.empty()) {  // plink2.cc:5139-5147
     if (!A.have_clump) {
@@ -2018,7 +2049,8 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
     if (!A.clump_no_test) {
       want[1] = A.clump_test_field.empty() ? std::vector<std::string>{"TEST"} : A.clump_test_field;
     }
-    want[2] = A.clump_p_field.empty() ? std::vector<std::string>{"P"} : A.clump_p_field;
+    want[2] = A.clump_p_field.empty() ? (A.clump_in_log10 ? std::vector<std::string>{"LOG10_P", "NEG_LOG10_P", "P"} : std::vector<std::string>{"P"})
+                                      : A.clump_p_field;  // (:7631)
     int col[3] = {-1, -1, -1};
     size_t prio[3] = {~size_t(0), ~size_t(0), ~size_t(0)};
     for (size_t c = 0; c < toks.size(); ++c) {
@@ -2058,9 +2090,23 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
         }
       }
       const std::string ptok(toks[col[2]].first, toks[col[2]].second);
-      double ln_pval;
-      const char* pe = scan_ln(ptok.c_str(), &ln_pval);
-      if (!pe || *pe) {
+      double ln_pval = 0.0;
+      bool scanned;
+      if (!A.clump_in_log10) {
+        const char* pe = scan_ln(ptok.c_str(), &ln_pval);
+        scanned = pe && !*pe;
+      } else {  // -log10(p) (:7744-7752)
+        double neglog10;
+        const char* pe;
+        scanned = scan_double_plink(ptok.c_str(), &neglog10, &pe) && !*pe;
+        if (scanned) {
+          ln_pval = neglog10 * -2.3025850929940457;
+          if (ln_pval > 0.0) {
+            die(7, "Error: Invalid p-value on line %zu of %s.\n", line_idx, fname.c_str());
+          }
+        }
+      }
+      if (!scanned) {
         std::string low = ptok;
         for (char& ch : low) {
           ch = static_cast<char>(tolower(static_cast<unsigned char>(ch)));
@@ -2068,7 +2114,7 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
         if ((low == "na") || (low == "nan")) {
           continue;
         }
-        if (ptok == "INF") {  // PLINK 1.x underflow
+        if ((ptok == "INF") || (A.clump_in_log10 && (ptok == "inf"))) {  // PLINK 1.x underflow
           ln_pval = -708.3964185322641;
         } else {
           die(7, "Error: Invalid p-value on line %zu of %s.\n", line_idx, fname.c_str());
@@ -2526,7 +2572,7 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
   if (provref_col) buf += "PROVISIONAL_REF?\t";
   if (a1_col) buf += "A1\t";
   if (f_col) buf += "F\t";
-  buf += "P";
+  buf += A.clump_out_log10 ? "NEG_LOG10_P" : "P";
   if (cols & kClumpColTotal) buf += "\tTOTAL";
   if (bounds_col) buf += "\tCLUMP_FIRST_POS\tCLUMP_LAST_POS";
   if (bin_bound_ct) {
@@ -2580,7 +2626,11 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
       buf += std::to_string(index_file);
       buf += '\t';
     }
-    buf.append(num, format_ln_g6(index_ln, num) - num);
+    if (A.clump_out_log10) {
+      buf.append(num, format_g6(-0.43429448190325176 * index_ln, num) - num);  // (:9214-9216)
+    } else {
+      buf.append(num, format_ln_g6(index_ln, num) - num);
+    }
     if ((cols & kClumpColTotal) || bin_bound_ct) {
       uint64_t total = 0;
       std::fill(bins.begin(), bins.end(), 0);

@@ -183,6 +183,39 @@ def test_clump_column_sets_with_two_reports(cli, tmp_path):
         compare_runs(cli, tmp_path, ["--bfile", "d", "--clump"] + mods + ["a.txt", "b.txt", "--clump-unphased", "--clump-kb", "0.001", "--clump-p1", "0.001"])
 
 
+@needs_ref
+@pytest.mark.parametrize("mode,pname,extra", [
+    ([], "LOG10_P", []),
+    (["input-only"], "NEG_LOG10_P", ["--clump-log10-p1", "2.5", "--clump-log10-p2", "1"]),
+    (["output-only"], "P", ["--clump-p1", "0.003"]),
+    ([], "P", ["--clump-log10-p1", "3"]),                       # 'P' is the last name tried for a -log10 column
+])
+def test_clump_log10_matches_reference(cli, tmp_path, mode, pname, extra):
+    """--clump-log10 and --clump-log10-p1/-p2 (plink2.cc:4979-5008, :5211-5232; ClumpReports :7631, :7744-7752, :9214)."""
+    import math
+    m = 900
+    clump_fileset(tmp_path, m, 40, 6)
+    write_report(str(tmp_path / "plain.txt"), m, 7)
+    rng = np.random.default_rng(3)
+    lines = open(str(tmp_path / "plain.txt")).read().splitlines()
+    hdr = lines[0].split("\t")
+    pc = hdr.index("P")
+    as_log = mode != ["output-only"]
+    out = ["\t".join(pname if h == "P" else h for h in hdr)]
+    for ln in lines[1:]:
+        f = ln.split("\t")
+        if as_log:
+            try:
+                v = float(f[pc])
+                f[pc] = ("inf" if rng.random() < 0.3 else "INF") if v == 0.0 else ("%.6g" % -math.log10(v)) if (0 < v <= 1) else f[pc]
+            except ValueError:
+                pass
+        out.append("\t".join(f))
+    open(str(tmp_path / "assoc.txt"), "w").write("\n".join(out) + "\n")
+    common = ["--bfile", "d", "--clump", "assoc.txt", "--clump-unphased", "--clump-kb", "0.001", "--clump-log10"] + mode + extra
+    compare_runs(cli, tmp_path, common)
+
+
 def test_clump_flag_rules(cli, tmp_path):
     clump_fileset(tmp_path, 60, 20, 3)
     write_report(str(tmp_path / "a.txt"), 60, 1)
@@ -203,6 +236,11 @@ def test_clump_flag_rules(cli, tmp_path):
         assert r.returncode == 8 and needle in r.stdout.replace("\n", " "), (args, r.returncode, r.stdout[-300:])
         if T.have_ref() and "increasing" not in needle:   # (the reference's order check never updates its running value: it lets these through)
             assert T.run_ref(["--bfile", "d", "--clump"] + mods + ["a.txt", "--clump-unphased"] + rest + ["--out", "ref"], str(tmp_path)).returncode == 8, args
+    for args in (["--clump-log10", "sideways"], ["--clump-p1", "0.01", "--clump-log10-p1", "2"], ["--clump-log10-p2", "-1"]):
+        r = run_cli(cli, ["--bfile", "d", "--clump", "a.txt", "--clump-unphased"] + args, str(tmp_path))
+        assert r.returncode == 8, (args, r.returncode, r.stdout[-200:])
+        if T.have_ref():
+            assert T.run_ref(["--bfile", "d", "--clump", "a.txt", "--clump-unphased"] + args + ["--out", "ref"], str(tmp_path)).returncode == 8, args
     r = run_cli(cli, ["--bfile", "d", "--clump", "a.txt", "cols=+f", "--clump-unphased"], str(tmp_path))
     assert r.returncode == 8 and "must come before" in r.stdout
 
