@@ -3312,6 +3312,79 @@ void load_inputs(Session& S, int argc, char** argv) {
 }
 
 // ---- the r^2 outputs: --r2-unphased matrices and tables, --clump ----
+// --ld-snp / --ld-snps / --ld-snp-list (VcorTable, plink2_ld.cc:11083-11150): the row variants.  A row variant is
+// reported against every variant of its window, on both sides (UpdateVcorWindow :10984 with row_snp_subset), as the
+// A of the line; a pair of two row variants appears once, lower index first (:10806-10815).
+// Returns one flag per included variant (empty: no row subset).
+std::vector<uint8_t> vcor_row_variants(const Args& A, const Variants& V, const std::vector<uint32_t>& inc, uint32_t variant_ct, double thresh) {
+  std::vector<uint8_t> is_row;
+  if (A.ld_snps.empty() && A.ld_snp_list.empty()) {
+    return is_row;
+  }
+  if (thresh < 0.0) {
+    die(63, "Error: a negative --ld-window-r2 with --ld-snp/--ld-snps/--ld-snp-list is not supported by plink2-hip.\n");
+  }
+  is_row.assign(variant_ct, 0);
+  std::unordered_map<std::string, std::vector<uint32_t>> by_id;
+  by_id.reserve(static_cast<size_t>(variant_ct) * 2);
+  for (uint32_t k = 0; k < variant_ct; ++k) {
+    by_id[V.id[inc[k]]].push_back(k);
+  }
+  if (!A.ld_snp_list.empty()) {  // (TokenExtractExclude, plink2_filter.cc:367: unknown IDs are skipped, every variant carrying a listed ID counts)
+    const std::string text = slurp(A.ld_snp_list);
+    std::vector<std::string> ids;
+    for (size_t p0 = 0; p0 < text.size();) {
+      while ((p0 < text.size()) && (static_cast<unsigned char>(text[p0]) <= ' ')) {
+        ++p0;
+      }
+      size_t p1 = p0;
+      while ((p1 < text.size()) && (static_cast<unsigned char>(text[p1]) > ' ')) {
+        ++p1;
+      }
+      if (p1 > p0) {
+        ids.emplace_back(text, p0, p1 - p0);
+      }
+      p0 = p1;
+    }
+    for (const std::string& id : ids) {
+      const auto it = by_id.find(id);
+      if (it == by_id.end()) {
+        continue;
+      }
+      for (uint32_t k : it->second) {
+        is_row[k] = 1;
+      }
+    }
+  }
+  for (const auto& pr : A.ld_snps) {  // (InterpretVariantRangeList, plink2_filter.cc:216-271)
+    const auto a = by_id.find(pr.first);
+    if (a == by_id.end()) {
+      die(7, "Error: --ld-snps variant '%s' not found.\n", pr.first.c_str());
+    }
+    if (pr.second.empty()) {
+      for (uint32_t k : a->second) {
+        is_row[k] = 1;
+      }
+      continue;
+    }
+    if (a->second.size() > 1) {
+      die(7, "Error: --ld-snps range-starting variant ID '%s' appears multiple times.\n", pr.first.c_str());
+    }
+    const auto b = by_id.find(pr.second);
+    if (b == by_id.end()) {
+      die(7, "Error: --ld-snps variant '%s' not found.\n", pr.second.c_str());
+    }
+    if (b->second.size() > 1) {
+      die(7, "Error: --ld-snps range-ending variant ID '%s' appears multiple times.\n", pr.second.c_str());
+    }
+    const uint32_t k0 = std::min(a->second[0], b->second[0]), k1 = std::max(a->second[0], b->second[0]);
+    for (uint32_t k = k0; k <= k1; ++k) {
+      is_row[k] = 1;
+    }
+  }
+  return is_row;
+}
+
 // What the two writers of the r^2 outputs share (run_r2 sets it up: engine planned and fed, sex chromosomes prepared)
 struct R2Job {
   Session& S;
@@ -3360,6 +3433,160 @@ struct R2Job {
       }
     }
     flush();
+  }
+};
+
+// The column set of the .vcor table (VcorTable :11250-11390, VcorTableWriteThread :10836-10960): what each variant prints
+// in front of the r^2, and the header line.
+struct VcorColumns {
+  const R2Job& J;
+  const Args& A;
+  const Variants& V;
+  const std::vector<uint32_t>& inc;
+  const std::vector<uint32_t>& bps;
+  uint32_t cols = 0;
+  std::vector<uint8_t> prov_bits;
+  bool prov_all = false, provref_col = false;
+  std::vector<uint8_t> maj_allele;
+  std::vector<double> nonmaj_freq;
+  explicit VcorColumns(const R2Job& job) : J(job), A(job.S.A), V(job.S.V), inc(job.S.inc), bps(job.S.bps) {
+    ldp_engine* const e = J.e;
+    ldp_pgen* const pg = J.S.pg;
+    const uint32_t variant_ct = J.S.variant_ct, raw_variant_ct = J.S.raw_variant_ct;
+    const std::vector<uint8_t>& is_x = J.is_x;
+    const auto& multi_maj = J.multi_maj;
+    const std::vector<uint8_t>& x_maj_alt = J.x_maj_alt;
+    const std::vector<double>& x_maj_freq = J.x_maj_freq;
+    cols = A.r2_cols;
+    if (cols & kVcorColRef) {  // ProvrefCol (plink2_common.h:1549): 'provref' always, 'maybeprovref' when some included variant is flagged
+      prov_bits.assign((static_cast<size_t>(raw_variant_ct) + 7) / 8, 0);
+      const int storage = ldp_pgen_provisional_ref(pg, prov_bits.data(), prov_bits.size());
+      if ((storage == 0) && V.info_pr_header && (cols & (kVcorColProvref | kVcorColMaybeprovref))) {
+        die(63, "Error: provisional-REF flags kept in the .pvar's INFO/PR are not supported by plink2-hip (--r2-unphased 'ref' column).\n");
+      }
+      prov_all = (storage == 2);
+      if (cols & kVcorColProvref) {
+        provref_col = true;
+      } else if (cols & kVcorColMaybeprovref) {
+        provref_col = prov_all;
+        for (uint32_t k = 0; (storage == 3) && (!provref_col) && (k < variant_ct); ++k) {
+          provref_col = (prov_bits[inc[k] >> 3] >> (inc[k] & 7)) & 1;
+        }
+      }
+    }
+    // major allele and non-major frequency per variant (the allele-frequency pass: plink2_filter.cc:2137-2147, GetMajIdx)
+    if (cols & (kVcorColMaj | kVcorColNonmaj | kVcorColFreq)) {
+      std::vector<ldp_variant_rec> recs(variant_ct);
+      if (variant_ct && ldp_get_variant_recs(e, 0, variant_ct, recs.data())) {
+        die(16, "Error: %s\n", ldp_last_error(e));
+      }
+      maj_allele.assign(variant_ct, 0);
+      nonmaj_freq.assign(variant_ct, 0.0);
+      for (uint32_t k = 0; k < variant_ct; ++k) {
+        const auto it = multi_maj.find(k);
+        double maj_freq;
+        if (is_x[k]) {
+          maj_allele[k] = x_maj_alt[k];
+          maj_freq = x_maj_freq[k];
+        } else if (it != multi_maj.end()) {
+          maj_allele[k] = static_cast<uint8_t>(it->second.first);
+          maj_freq = it->second.second;
+        } else {
+          const uint64_t ref_ct = 2ull * recs[k].n_homref + recs[k].n_het, alt_ct = 2ull * recs[k].n_homalt + recs[k].n_het, tot = ref_ct + alt_ct;
+          double ref_freq = 0.5;
+          if (tot) {
+            ref_freq = static_cast<double>(ref_ct) * (1.0 / static_cast<double>(tot));
+          }
+          maj_allele[k] = (ref_freq >= 0.5) ? 0 : 1;
+          maj_freq = maj_allele[k] ? (1.0 - ref_freq) : ref_freq;  // GetAlleleFreq: the last allele's frequency is 1 - the others
+        }
+        nonmaj_freq[k] = 1.0 - maj_freq;
+      }
+    }
+    // one variant's columns, each followed by a tab
+  }
+  void allele_text(uint32_t k, uint32_t allele, std::string* out) const {
+    const uint32_t v = inc[k];
+    if (!allele) {
+      *out += V.ref[v];
+      return;
+    }
+    const std::string& alt = V.alt[v];
+    size_t p0 = 0;
+    for (uint32_t a = 1; a < allele; ++a) {
+      p0 = alt.find(',', p0) + 1;
+    }
+    out->append(alt, p0, std::min(alt.find(',', p0), alt.size()) - p0);
+  }
+  // one variant's columns, each followed by a tab
+  void put(uint32_t k, const std::string& chr_name, std::string* out) const {
+    char num[40];
+    if (cols & kVcorColChrom) {
+      *out += chr_name;
+      *out += '\t';
+    }
+    if (cols & kVcorColPos) {
+      *out += std::to_string(bps[k]);
+      *out += '\t';
+    }
+    if (cols & kVcorColId) {
+      *out += V.id[inc[k]];
+      *out += '\t';
+    }
+    if (cols & kVcorColRef) {
+      *out += V.ref[inc[k]];
+      *out += '\t';
+    }
+    if (cols & kVcorColAlt1) {
+      allele_text(k, 1, out);
+      *out += '\t';
+    }
+    if (cols & kVcorColAlt) {
+      *out += V.alt[inc[k]];
+      *out += '\t';
+    }
+    if (provref_col) {
+      *out += (prov_all || ((!prov_bits.empty()) && ((prov_bits[inc[k] >> 3] >> (inc[k] & 7)) & 1))) ? 'Y' : 'N';
+      *out += '\t';
+    }
+    if (cols & kVcorColMaj) {
+      allele_text(k, maj_allele[k], out);
+      *out += '\t';
+    }
+    if (cols & kVcorColNonmaj) {
+      const uint32_t allele_ct = static_cast<uint32_t>(V.alt_ct[inc[k]]) + 1;
+      for (uint32_t a = 0; a < allele_ct; ++a) {
+        if (a != maj_allele[k]) {
+          allele_text(k, a, out);
+          *out += ',';
+        }
+      }
+      out->back() = '\t';
+    }
+    if (cols & kVcorColFreq) {
+      out->append(num, format_g6(nonmaj_freq[k], num) - num);
+      *out += '\t';
+    }
+  }
+  std::string header() const {
+  std::string hdr = "#";
+  for (const char side : {'A', 'B'}) {
+    const std::pair<uint32_t, const char*> names[] = {{kVcorColChrom, "CHROM_"}, {kVcorColPos, "POS_"}, {kVcorColId, "ID_"}, {kVcorColRef, "REF_"},
+                                                      {kVcorColAlt1, "ALT1_"}, {kVcorColAlt, "ALT_"}, {0, "PROVISIONAL_REF_"}, {kVcorColMaj, "MAJ_"},
+                                                      {kVcorColNonmaj, "NONMAJ_"}, {kVcorColFreq, "NONMAJ_FREQ_"}};
+    for (const auto& nm : names) {
+      if (nm.first ? ((cols & nm.first) != 0) : provref_col) {
+        hdr += nm.second;
+        hdr += side;
+        if (!nm.first) {
+          hdr += '?';
+        }
+        hdr += '\t';
+      }
+    }
+  }
+  hdr += A.r_unsquared ? "UNPHASED_R\n" : "UNPHASED_R2\n";
+    return hdr;
   }
 };
 
@@ -3434,209 +3661,15 @@ int write_vcor_table(R2Job& J) {
   const std::string tpath = A.out + ".vcor" + piece_suffix + (A.r2_zs ? ".zst" : "");
   OutFile tf;
   tf.open(tpath, A.r2_zs);
-  // ---- the column set (VcorTable :11250-11390, VcorTableWriteThread :10836-10960)
-  const uint32_t cols = A.r2_cols;
-  std::vector<uint8_t> prov_bits;
-  bool prov_all = false, provref_col = false;
-  if (cols & kVcorColRef) {  // ProvrefCol (plink2_common.h:1549): 'provref' always, 'maybeprovref' when some included variant is flagged
-    prov_bits.assign((static_cast<size_t>(raw_variant_ct) + 7) / 8, 0);
-    const int storage = ldp_pgen_provisional_ref(pg, prov_bits.data(), prov_bits.size());
-    if ((storage == 0) && V.info_pr_header && (cols & (kVcorColProvref | kVcorColMaybeprovref))) {
-      die(63, "Error: provisional-REF flags kept in the .pvar's INFO/PR are not supported by plink2-hip (--r2-unphased 'ref' column).\n");
-    }
-    prov_all = (storage == 2);
-    if (cols & kVcorColProvref) {
-      provref_col = true;
-    } else if (cols & kVcorColMaybeprovref) {
-      provref_col = prov_all;
-      for (uint32_t k = 0; (storage == 3) && (!provref_col) && (k < variant_ct); ++k) {
-        provref_col = (prov_bits[inc[k] >> 3] >> (inc[k] & 7)) & 1;
-      }
-    }
-  }
-  // major allele and non-major frequency per variant (the allele-frequency pass: plink2_filter.cc:2137-2147, GetMajIdx)
-  std::vector<uint8_t> maj_allele;
-  std::vector<double> nonmaj_freq;
-  if (cols & (kVcorColMaj | kVcorColNonmaj | kVcorColFreq)) {
-    std::vector<ldp_variant_rec> recs(variant_ct);
-    if (variant_ct && ldp_get_variant_recs(e, 0, variant_ct, recs.data())) {
-      die(16, "Error: %s\n", ldp_last_error(e));
-    }
-    maj_allele.assign(variant_ct, 0);
-    nonmaj_freq.assign(variant_ct, 0.0);
-    for (uint32_t k = 0; k < variant_ct; ++k) {
-      const auto it = multi_maj.find(k);
-      double maj_freq;
-      if (is_x[k]) {
-        maj_allele[k] = x_maj_alt[k];
-        maj_freq = x_maj_freq[k];
-      } else if (it != multi_maj.end()) {
-        maj_allele[k] = static_cast<uint8_t>(it->second.first);
-        maj_freq = it->second.second;
-      } else {
-        const uint64_t ref_ct = 2ull * recs[k].n_homref + recs[k].n_het, alt_ct = 2ull * recs[k].n_homalt + recs[k].n_het, tot = ref_ct + alt_ct;
-        double ref_freq = 0.5;
-        if (tot) {
-          ref_freq = static_cast<double>(ref_ct) * (1.0 / static_cast<double>(tot));
-        }
-        maj_allele[k] = (ref_freq >= 0.5) ? 0 : 1;
-        maj_freq = maj_allele[k] ? (1.0 - ref_freq) : ref_freq;  // GetAlleleFreq: the last allele's frequency is 1 - the others
-      }
-      nonmaj_freq[k] = 1.0 - maj_freq;
-    }
-  }
-  auto allele_text = [&](uint32_t k, uint32_t allele, std::string* out) {
-    const uint32_t v = inc[k];
-    if (!allele) {
-      *out += V.ref[v];
-      return;
-    }
-    const std::string& alt = V.alt[v];
-    size_t p0 = 0;
-    for (uint32_t a = 1; a < allele; ++a) {
-      p0 = alt.find(',', p0) + 1;
-    }
-    out->append(alt, p0, std::min(alt.find(',', p0), alt.size()) - p0);
-  };
-  // one variant's columns, each followed by a tab
-  auto put_variant = [&](uint32_t k, const std::string& chr_name, std::string* out) {
-    char num[40];
-    if (cols & kVcorColChrom) {
-      *out += chr_name;
-      *out += '\t';
-    }
-    if (cols & kVcorColPos) {
-      *out += std::to_string(bps[k]);
-      *out += '\t';
-    }
-    if (cols & kVcorColId) {
-      *out += V.id[inc[k]];
-      *out += '\t';
-    }
-    if (cols & kVcorColRef) {
-      *out += V.ref[inc[k]];
-      *out += '\t';
-    }
-    if (cols & kVcorColAlt1) {
-      allele_text(k, 1, out);
-      *out += '\t';
-    }
-    if (cols & kVcorColAlt) {
-      *out += V.alt[inc[k]];
-      *out += '\t';
-    }
-    if (provref_col) {
-      *out += (prov_all || ((!prov_bits.empty()) && ((prov_bits[inc[k] >> 3] >> (inc[k] & 7)) & 1))) ? 'Y' : 'N';
-      *out += '\t';
-    }
-    if (cols & kVcorColMaj) {
-      allele_text(k, maj_allele[k], out);
-      *out += '\t';
-    }
-    if (cols & kVcorColNonmaj) {
-      const uint32_t allele_ct = static_cast<uint32_t>(V.alt_ct[inc[k]]) + 1;
-      for (uint32_t a = 0; a < allele_ct; ++a) {
-        if (a != maj_allele[k]) {
-          allele_text(k, a, out);
-          *out += ',';
-        }
-      }
-      out->back() = '\t';
-    }
-    if (cols & kVcorColFreq) {
-      out->append(num, format_g6(nonmaj_freq[k], num) - num);
-      *out += '\t';
-    }
-  };
+  const VcorColumns columns(J);
+  auto put_variant = [&](uint32_t k, const std::string& chr_name, std::string* out) { columns.put(k, chr_name, out); };
   if (A.parallel_idx == 0) {
-    std::string hdr = "#";
-    for (const char side : {'A', 'B'}) {
-      const std::pair<uint32_t, const char*> names[] = {{kVcorColChrom, "CHROM_"}, {kVcorColPos, "POS_"}, {kVcorColId, "ID_"}, {kVcorColRef, "REF_"},
-                                                        {kVcorColAlt1, "ALT1_"}, {kVcorColAlt, "ALT_"}, {0, "PROVISIONAL_REF_"}, {kVcorColMaj, "MAJ_"},
-                                                        {kVcorColNonmaj, "NONMAJ_"}, {kVcorColFreq, "NONMAJ_FREQ_"}};
-      for (const auto& nm : names) {
-        if (nm.first ? ((cols & nm.first) != 0) : provref_col) {
-          hdr += nm.second;
-          hdr += side;
-          if (!nm.first) {
-            hdr += '?';
-          }
-          hdr += '\t';
-        }
-      }
-    }
-    hdr += A.r_unsquared ? "UNPHASED_R\n" : "UNPHASED_R2\n";
+    const std::string hdr = columns.header();
     tf.write(hdr.data(), hdr.size());
   }
   // (--r-unphased filters |r| against the root of --ld-window-r2: VcorTable :11575-11579)
   const double thresh = A.r_unsquared ? ((A.ld_min_r2 < 0.0) ? -1.0 : sqrt(A.ld_min_r2)) : A.ld_min_r2;
-  // --ld-snp / --ld-snps / --ld-snp-list (VcorTable, plink2_ld.cc:11083-11150): the row variants.  A row variant is
-  // reported against every variant of its window, on both sides (UpdateVcorWindow :10984 with row_snp_subset), as the
-  // A of the line; a pair of two row variants appears once, lower index first (:10806-10815).
-  std::vector<uint8_t> is_row;
-  if ((!A.ld_snps.empty()) || (!A.ld_snp_list.empty())) {
-    if (thresh < 0.0) {
-      die(63, "Error: a negative --ld-window-r2 with --ld-snp/--ld-snps/--ld-snp-list is not supported by plink2-hip.\n");
-    }
-    is_row.assign(variant_ct, 0);
-    std::unordered_map<std::string, std::vector<uint32_t>> by_id;
-    by_id.reserve(static_cast<size_t>(variant_ct) * 2);
-    for (uint32_t k = 0; k < variant_ct; ++k) {
-      by_id[V.id[inc[k]]].push_back(k);
-    }
-    if (!A.ld_snp_list.empty()) {  // (TokenExtractExclude, plink2_filter.cc:367: unknown IDs are skipped, every variant carrying a listed ID counts)
-      const std::string text = slurp(A.ld_snp_list);
-      std::vector<std::string> ids;
-      for (size_t p0 = 0; p0 < text.size();) {
-        while ((p0 < text.size()) && (static_cast<unsigned char>(text[p0]) <= ' ')) {
-          ++p0;
-        }
-        size_t p1 = p0;
-        while ((p1 < text.size()) && (static_cast<unsigned char>(text[p1]) > ' ')) {
-          ++p1;
-        }
-        if (p1 > p0) {
-          ids.emplace_back(text, p0, p1 - p0);
-        }
-        p0 = p1;
-      }
-      for (const std::string& id : ids) {
-        const auto it = by_id.find(id);
-        if (it == by_id.end()) {
-          continue;
-        }
-        for (uint32_t k : it->second) {
-          is_row[k] = 1;
-        }
-      }
-    }
-    for (const auto& pr : A.ld_snps) {  // (InterpretVariantRangeList, plink2_filter.cc:216-271)
-      const auto a = by_id.find(pr.first);
-      if (a == by_id.end()) {
-        die(7, "Error: --ld-snps variant '%s' not found.\n", pr.first.c_str());
-      }
-      if (pr.second.empty()) {
-        for (uint32_t k : a->second) {
-          is_row[k] = 1;
-        }
-        continue;
-      }
-      if (a->second.size() > 1) {
-        die(7, "Error: --ld-snps range-starting variant ID '%s' appears multiple times.\n", pr.first.c_str());
-      }
-      const auto b = by_id.find(pr.second);
-      if (b == by_id.end()) {
-        die(7, "Error: --ld-snps variant '%s' not found.\n", pr.second.c_str());
-      }
-      if (b->second.size() > 1) {
-        die(7, "Error: --ld-snps range-ending variant ID '%s' appears multiple times.\n", pr.second.c_str());
-      }
-      const uint32_t k0 = std::min(a->second[0], b->second[0]), k1 = std::max(a->second[0], b->second[0]);
-      for (uint32_t k = k0; k <= k1; ++k) {
-        is_row[k] = 1;
-      }
-    }
-  }
+  const std::vector<uint8_t> is_row = vcor_row_variants(A, V, inc, variant_ct, thresh);
   const bool row_subset = !is_row.empty();
   if (A.r2_inter || (thresh > 0.0) || row_subset) {
     // ---- inter-chr: every pair A < B of the whole variant set, chromosome 0 included (plink2_ld.cc:11082-11116).
