@@ -2545,6 +2545,7 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
   const bool sp2_col = (cols & kClumpColSp2) != 0;
   const bool f_in_sp2 = sp2_col && ((cols & kClumpColF) || multi);
   const bool bounds_col = (cols & kClumpColBounds) != 0;
+  const bool f_in_sp2_files = multi && sp2_col;  // (save_all_fidxs, :7633)
   const bool a1_col = (cols & kClumpColA1) != 0;  // ('maybea1' wants a multiallelic variant in the dataset: those are refused above)
   const size_t bin_bound_ct = D.ln_bins.size();
   bool provref_col = false;
@@ -2657,7 +2658,9 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
       uint32_t first_bp = 0xffffffffu, last_bp = 0;
       for (uint64_t q = mem_off[r]; q < mem_off[r + 1]; ++q) {
         const uint32_t k = obs[members[q]];
-        bool hit = false;
+        // (with several reports and SP2 the reference keeps a report number behind every entry and this scan, :9271-9279, does not
+        // step over it: the number's low bit is clear, so any member with a kept line counts.  Reproduced.)
+        bool hit = f_in_sp2_files && !D.entries[k].empty();
         for (uint32_t en : D.entries[k]) {
           hit = hit || !(en & 1);
         }

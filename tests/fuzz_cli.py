@@ -4,7 +4,8 @@ random small filesets -- .bed or fixed-width .pgen, chromosome 0 rows, non-found
 both scan orders -- for --indep-pairwise (.prune.in/.prune.out), --indep-pairphase on phased variable-width .pgen
 (autosomes, chrX/chrY/MT with random sexes, non-founders), the --r2-unphased / --r-unphased table (.vcor: windowed incl.
 --ld-window-cm, inter-chr, 'ref-based', cols= sets, --ld-snp / --ld-snps / --ld-snp-list row variants, a chrX with random
-sexes now and then) and --clump (.clumps).  Files must be byte-identical.
+sexes now and then) and --clump (.clumps: several reports, --clump-allow-overlap, column sets, --clump-bins, -log10
+output).  Files must be byte-identical.
     python tests/fuzz_cli.py [--cases 40] [--seed 1]"""
 import argparse
 import filecmp
@@ -127,6 +128,8 @@ def one_case(cli, ref, rng, idx, tmp, execute=True, mode="all"):
     labels = [str(c) for c in rng.choice(np.arange(1, 23), size=chr_ct, replace=False)]
     labels.sort(key=int)
     kind = rng.random()
+    if mode == "clump":
+        kind = 0.05
     # the r^2 outputs also get a chrX now and then (male founders weighted down, ComputeXR2), with random sexes
     with_x = ((kind >= 0.6) or (kind < 0.12)) and (rng.random() < 0.3)   # (also for --clump)
     sexes = rng.choice([1, 2, 0], size=n, p=[0.45, 0.45, 0.1]) if with_x else np.full(n, 2)
@@ -194,6 +197,13 @@ def one_case(cli, ref, rng, idx, tmp, execute=True, mode="all"):
                       "--clump-p1", str(rng.choice(["1e-4", "1e-2", "0.3"])), "--clump-p2", str(rng.choice(["1e-2", "0.05", "1e-6"]))]
         if rng.random() < 0.4:
             args.append("--clump-allow-overlap")
+        if rng.random() < 0.4:   # column sets decide what is kept of a report line (and which variants count as observed)
+            k = args.index("assoc.txt")
+            args.insert(k, str(rng.choice(["cols=+bounds", "cols=-bins", "cols=-total,-bins", "cols=sp2", "cols=+ref,+alt1,+f", "cols=chrom,pos,total,bounds"])))
+        if (rng.random() < 0.3) and not any(a in ("cols=-bins", "cols=-total,-bins", "cols=sp2", "cols=chrom,pos,total,bounds") for a in args):
+            args += ["--clump-bins", str(rng.choice(["0.001,0.01", "1e-6,1e-3,0.05,0.5", "0.2"]))]
+        if rng.random() < 0.2:
+            args += ["--clump-log10", "output-only"]
         if rng.random() < 0.3:
             TC.write_report(os.path.join(d, "assoc2.txt"), m, int(rng.integers(1, 1 << 30)), sig_rate=0.05)
             k = args.index("assoc.txt")
@@ -267,7 +277,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--mode", default="all", choices=["all", "pairphase"])
+    ap.add_argument("--mode", default="all", choices=["all", "pairphase", "clump"])
     ap.add_argument("--only", type=int, default=None, help="replay the random stream but execute only this case")
     ap.add_argument("--keep", default=None, help="directory to keep the case files in (default: a temporary directory)")
     args = ap.parse_args()

@@ -181,6 +181,12 @@ def test_clump_column_sets_with_two_reports(cli, tmp_path):
     write_report(str(tmp_path / "b.txt"), m, 12, sig_rate=0.1)
     for mods in (["cols=-maybef"], ["cols=+f,-sp2"], ["cols=+bounds,-total"]):
         compare_runs(cli, tmp_path, ["--bfile", "d", "--clump"] + mods + ["a.txt", "b.txt", "--clump-unphased", "--clump-kb", "0.001", "--clump-p1", "0.001"])
+    # index variants above p2: '.' bounds -- except that with several reports and SP2 the reference's scan trips over the report
+    # numbers it keeps and counts every member with a kept line (plink2_ld.cc:9271-9279); without SP2 it does not
+    for mods in (["cols=+bounds"], ["cols=+bounds,-sp2"]):
+        compare_runs(cli, tmp_path, ["--bfile", "d", "--clump"] + mods + ["a.txt", "b.txt", "--clump-unphased", "--clump-kb", "0.001", "--clump-p1", "0.05", "--clump-p2", "1e-5"])
+        body = open(str(tmp_path / "hip.clumps")).read()
+        assert ("\t.\t." in body) == ("-sp2" in mods[0])
 
 
 @needs_ref
