@@ -15,9 +15,10 @@
 // their sample-mapped rows (males het->missing, non-males x2, ...) built on the host as well.
 // --r2-unphased / --r-unphased: the matrix shapes (square/square0/triangle as bin, bin4 or text, zs), the windowed and the
 // inter-chr .vcor table with cols=, --ld-window, --ld-window-kb, --ld-window-cm, --ld-window-r2, --ld-snp / --ld-snps / --ld-snp-list,
-// --parallel; number formatting restated from dtoa_g.  --clump (several reports, --clump-allow-overlap).
+// --parallel; number formatting restated from dtoa_g.  --clump (several reports, --clump-allow-overlap, cols=, bins, -log10,
+// ranges, sex chromosomes).
 // Not yet supported (reported as such with exit 63, never silently mis-handled): dosage tracks,
-// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT, major-allele-oriented r^2 outputs on chrY/MT, --clump-range.
+// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT and in --clump, major-allele-oriented r^2 outputs on chrY/MT.
 #include <dlfcn.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -37,6 +38,7 @@
 #include <fstream>
 #include <functional>
 #include <sstream>
+#include <map>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -436,6 +438,10 @@ struct Args {
   bool clump_allow_overlap = false;
   bool clump_no_test = false;
   std::vector<std::string> clump_id_field, clump_p_field, clump_test_field, clump_test;
+  std::string clump_range;                 // --clump-range / --clump-range0 <file>: regions to report overlaps with
+  bool clump_range0 = false;
+  uint32_t clump_range_border = 0;         // --clump-range-border <kb>, in bp
+  bool clump_range_border_given = false;
   bool clump_in_log10 = false, clump_out_log10 = false;  // --clump-log10 ['input-only' | 'output-only']
   bool clump_log10_p1 = false, clump_log10_p2 = false, clump_plain_p1 = false, clump_plain_p2 = false;
   uint32_t clump_cols = 0;                 // kClumpCol* (plink2_ld.h:51-67), set after the modifiers are read
@@ -784,6 +790,23 @@ Args parse_args(int argc, char** argv) {
       A.clump_unphased = true;
     } else if (f == "--clump-allow-overlap") {
       A.clump_allow_overlap = true;
+    } else if ((f == "--clump-range") || (f == "--clump-range0")) {  // plink2.cc:5092-5120
+      need(i, 1, f.c_str());
+      if (!A.clump_range.empty()) {
+        die(8, "Error: --clump-range and --clump-range0 cannot be used together.\n");
+      }
+      A.clump_range = argv[++i];
+      A.clump_range0 = (f == "--clump-range0");
+    } else if (f == "--clump-range-border") {  // plink2.cc:5121-5138
+      need(i, 1, "--clump-range-border");
+      const std::string v = argv[++i];
+      double d;
+      const char* endp;
+      if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || (d < 0.0)) {
+        die(8, "Error: Invalid --clump-range-border argument '%s'.\n", v.c_str());
+      }
+      A.clump_range_border = (d > 2147483.646) ? 0x7ffffffeu : static_cast<uint32_t>(static_cast<int32_t>(d * 1000 * (1 + kSmallEpsilon)));
+      A.clump_range_border_given = true;
     } else if (f == "--clump-log10") {  // plink2.cc:5211-5232
       A.clump_in_log10 = A.clump_out_log10 = true;
       if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
@@ -1101,6 +1124,14 @@ Args parse_args(int argc, char** argv) {
   }
   if ((A.clump_in_log10 || A.clump_out_log10 || A.clump_log10_p1 || A.clump_log10_p2) && !A.have_clump) {
     die(8, "Error: --clump-log10 must be used with --clump.\n");
+  }
+  // (the reference reads its flags in sorted order, and "clump-range-border" sorts before "clump-range0": with --clump-range0 the
+  // border flag finds no range file yet, plink2.cc:5122-5125)
+  if (A.clump_range_border_given && (A.clump_range.empty() || A.clump_range0)) {
+    die(8, "Error: --clump-range-border must be used with --clump-range[0].\n");
+  }
+  if ((!A.clump_range.empty()) && !A.have_clump) {
+    die(8, "Error: --clump-range must be used with --clump.\n");
   }
   if (!A.clump_ln_bins.empty()) {  // plink2.cc:5139-5147
     if (!A.have_clump) {
@@ -1981,14 +2012,15 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
   if (A.clump_cols & kClumpColBins) {
     D->ln_bins = A.clump_ln_bins.empty() ? std::vector<double>(kClumpLnBins, kClumpLnBins + 4) : A.clump_ln_bins;
   }
-  const bool bounds_col = (A.clump_cols & kClumpColBounds) != 0;  // ('maybebounds' needs --clump-range)
+  const bool ranges_col = !A.clump_range.empty();
+  const bool bounds_col = (A.clump_cols & kClumpColBounds) || ((A.clump_cols & kClumpColMaybeBounds) && ranges_col);
   const bool sp2_col = (A.clump_cols & kClumpColSp2) != 0;
-  const double ln_p1 = A.clump_ln_p1, ln_p2 = (sp2_col || bounds_col) ? A.clump_ln_p2 : -1.7976931348623157e308;
+  const double ln_p1 = A.clump_ln_p1, ln_p2 = (sp2_col || bounds_col || ranges_col) ? A.clump_ln_p2 : -1.7976931348623157e308;
   double load_thresh = std::max(ln_p1, ln_p2);
   if ((!D->ln_bins.empty()) && (load_thresh < D->ln_bins.back())) {
     load_thresh = D->ln_bins.back();
   }
-  const bool keep_entries = (A.clump_cols & (kClumpColTotal | kClumpColBins | kClumpColSp2)) || bounds_col;
+  const bool keep_entries = (A.clump_cols & (kClumpColTotal | kClumpColBins | kClumpColSp2)) || bounds_col || ranges_col;
   const bool nonsig_needed = (A.clump_cols & (kClumpColTotal | kClumpColBins)) && (load_thresh < 0.0);
   if (A.clump_files.size() > 4000) {
     die(63, "Error: too many --clump reports.\n");
@@ -2243,6 +2275,121 @@ struct XWeighted {
         (*out)[p0 + q] = r;
       }
     }
+  }
+};
+
+// --clump-range[0] (LoadAndSortIntervalBed / LoadIntervalBed, plink2_set.cc:39-330, :495-638): lines `chrom first last name`;
+// per chromosome the names in natural order, each with its intervals -- stretched by the border, half-open, sorted, merged.
+int chrom_code(const std::string& name_in);
+struct ClumpRanges {
+  // chromosome key (the numeric code of a standard name, else the name itself) -> (name, flattened [start, end) pairs)
+  std::map<std::string, std::vector<std::pair<std::string, std::vector<uint32_t>>>> by_chr;
+  static std::string key_of(const std::string& chrom) {
+    const int code = chrom_code(chrom);
+    return (code >= 0) ? std::to_string(code) : chrom;
+  }
+  void load(const Args& A, const Variants& V, const std::vector<uint32_t>& inc) {
+    std::unordered_set<std::string> known;  // chromosomes the dataset names (an unknown non-standard name is an error there)
+    for (uint32_t v : inc) {
+      known.insert(key_of(V.chrom[v]));
+    }
+    const std::string text = slurp(A.clump_range);
+    std::map<std::string, std::map<std::string, std::vector<std::pair<uint32_t, uint32_t>>, bool (*)(const std::string&, const std::string&)>> raw;
+    size_t line_idx = 0;
+    for (size_t p0 = 0; p0 < text.size();) {
+      size_t p1 = text.find('\n', p0);
+      if (p1 == std::string::npos) {
+        p1 = text.size();
+      }
+      ++line_idx;
+      std::vector<std::string> tok;
+      for (size_t q = p0; q < p1;) {
+        while ((q < p1) && (static_cast<unsigned char>(text[q]) <= ' ')) {
+          ++q;
+        }
+        size_t q1 = q;
+        while ((q1 < p1) && (static_cast<unsigned char>(text[q1]) > ' ')) {
+          ++q1;
+        }
+        if (q1 > q) {
+          tok.emplace_back(text, q, q1 - q);
+        }
+        q = q1;
+      }
+      p0 = p1 + 1;
+      if (tok.empty()) {
+        continue;
+      }
+      if (tok.size() < 4) {
+        die(6, "Error: Line %zu of %s has fewer tokens than expected.\n", line_idx, A.clump_range.c_str());
+      }
+      const std::string key = key_of(tok[0]);
+      if ((chrom_code(tok[0]) < 0) && !known.count(key)) {
+        die(6, "Error: Invalid chromosome code on line %zu of %s.\n", line_idx, A.clump_range.c_str());
+      }
+      uint64_t first = 0, last = 0;
+      for (int w = 1; w <= 2; ++w) {
+        uint64_t val = 0;
+        bool ok = !tok[w].empty();
+        for (char ch : tok[w]) {
+          ok = ok && (ch >= '0') && (ch <= '9') && (val < 0x7fffffffull);
+          val = val * 10 + static_cast<uint64_t>(ch - '0');
+        }
+        if ((!ok) || (val > 0x7ffffffeull)) {
+          die(6, "Error: Invalid range %s position on line %zu of %s.\n", (w == 1) ? "start" : "end", line_idx, A.clump_range.c_str());
+        }
+        ((w == 1) ? first : last) = val;
+      }
+      first += A.clump_range0 ? 1 : 0;
+      if (last < first) {
+        die(6, "Error: Range end position smaller than range start on line %zu of %s.\n", line_idx, A.clump_range.c_str());
+      }
+      first = (A.clump_range_border > first) ? 0 : (first - A.clump_range_border);
+      last += A.clump_range_border;
+      auto it = raw.find(key);
+      if (it == raw.end()) {
+        it = raw.emplace(key, std::map<std::string, std::vector<std::pair<uint32_t, uint32_t>>, bool (*)(const std::string&, const std::string&)>(natural_less)).first;
+      }
+      it->second[tok[3]].emplace_back(static_cast<uint32_t>(first), static_cast<uint32_t>(last + 1));
+    }
+    for (auto& chr : raw) {
+      auto& out = by_chr[chr.first];
+      for (auto& g : chr.second) {
+        std::sort(g.second.begin(), g.second.end());
+        std::vector<uint32_t> flat;
+        for (const auto& iv : g.second) {
+          if ((!flat.empty()) && (iv.first <= flat.back())) {
+            flat.back() = std::max(flat.back(), iv.second);
+          } else {
+            flat.push_back(iv.first);
+            flat.push_back(iv.second);
+          }
+        }
+        out.emplace_back(g.first, std::move(flat));
+      }
+    }
+  }
+  // names of `chrom` with an interval meeting [first_bp, end_bp), comma-separated (empty: none)
+  std::string overlaps(const std::string& chrom, uint32_t first_bp, uint32_t end_bp) const {
+    std::string names;
+    const auto it = by_chr.find(key_of(chrom));
+    if (it == by_chr.end()) {
+      return names;
+    }
+    for (const auto& g : it->second) {
+      bool hit = false;
+      for (size_t k = 0; (k < g.second.size()) && !hit; k += 2) {
+        hit = (g.second[k] < end_bp) && (g.second[k + 1] > first_bp);
+      }
+      if (hit) {
+        names += g.first;
+        names += ',';
+      }
+    }
+    if (!names.empty()) {
+      names.pop_back();
+    }
+    return names;
   }
 };
 
@@ -2544,7 +2691,12 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
   const bool f_col = (cols & kClumpColF) || ((cols & kClumpColMaybeF) && multi);
   const bool sp2_col = (cols & kClumpColSp2) != 0;
   const bool f_in_sp2 = sp2_col && ((cols & kClumpColF) || multi);
-  const bool bounds_col = (cols & kClumpColBounds) != 0;
+  const bool ranges_col = !A.clump_range.empty();
+  ClumpRanges ranges;
+  if (ranges_col) {
+    ranges.load(A, V, inc);
+  }
+  const bool bounds_col = (cols & kClumpColBounds) || ((cols & kClumpColMaybeBounds) && ranges_col);
   const bool f_in_sp2_files = multi && sp2_col;  // (save_all_fidxs, :7633)
   const bool a1_col = (cols & kClumpColA1) != 0;  // ('maybea1' wants a multiallelic variant in the dataset: those are refused above)
   const size_t bin_bound_ct = D.ln_bins.size();
@@ -2584,6 +2736,7 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
     }
   }
   if (sp2_col) buf += "\tSP2";
+  if (ranges_col) buf += "\tRANGES";
   buf += '\n';
   std::vector<uint64_t> bins(bin_bound_ct + 1);
   for (uint32_t r = 0; r < cand_ct; ++r) {
@@ -2653,9 +2806,9 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
         buf += std::to_string(total);
       }
     }
-    if (bounds_col) {
+    uint32_t first_bp = 0xffffffffu, last_bp = 0;
+    if (bounds_col || ranges_col) {
       // bp range of the members with a line at or below p2 (:9270-9311)
-      uint32_t first_bp = 0xffffffffu, last_bp = 0;
       for (uint64_t q = mem_off[r]; q < mem_off[r + 1]; ++q) {
         const uint32_t k = obs[members[q]];
         // (with several reports and SP2 the reference keeps a report number behind every entry and this scan, :9271-9279, does not
@@ -2671,6 +2824,8 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
           last_bp = V.bp[inc[k]];
         }
       }
+    }
+    if (bounds_col) {
       buf += '\t';
       if (first_bp != 0xffffffffu) {
         buf += std::to_string(first_bp);
@@ -2684,17 +2839,11 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
       buf += '\t';
       buf += std::to_string(bins[b - 1]);
     }
-    if (!sp2_col) {
-      buf += '\n';
-      if (buf.size() > (1u << 20)) {
-        f.write(buf.data(), buf.size());
-        buf.clear();
-      }
-      continue;
-    }
-    buf += '\t';
     bool nonempty = false;
-    for (uint64_t q = mem_off[r]; q < mem_off[r + 1]; ++q) {
+    if (sp2_col) {
+      buf += '\t';
+    }
+    for (uint64_t q = mem_off[r]; sp2_col && (q < mem_off[r + 1]); ++q) {
       const uint32_t m = members[q];
       // a member's lines, latest read first (the reference walks its linked list from the head, :7851,9330): report 1's
       // lines bottom-up, then report 2's, ...; the index variant's own line in its own report is the clump itself
@@ -2715,10 +2864,17 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
         nonempty = true;
       }
     }
-    if (nonempty) {
-      buf.pop_back();
-    } else {
-      buf += '.';
+    if (sp2_col) {
+      if (nonempty) {
+        buf.pop_back();
+      } else {
+        buf += '.';
+      }
+    }
+    if (ranges_col) {  // (:9377-9400)
+      const std::string names = (first_bp != 0xffffffffu) ? ranges.overlaps(V.chrom[iv], first_bp, last_bp + 1) : std::string();
+      buf += '\t';
+      buf += names.empty() ? std::string(".") : names;
     }
     buf += '\n';
     if (buf.size() > (1u << 20)) {

@@ -222,6 +222,48 @@ def test_clump_log10_matches_reference(cli, tmp_path, mode, pname, extra):
     compare_runs(cli, tmp_path, common)
 
 
+def write_ranges(path, chroms, bps, seed, zero_based=False):
+    """Regions around some variants: several pieces per name, names that sort differently naturally and bytewise, one name on
+    two chromosomes, lines on a chromosome the dataset does not have."""
+    rng = np.random.default_rng(seed)
+    lines = []
+    m = len(bps)
+    for g in range(60):
+        v = int(rng.integers(0, m))
+        name = "gene%d" % (g % 37) if g % 5 else "%dorf%d" % (g % 7, g)
+        for _ in range(int(rng.integers(1, 4))):
+            a = max(1, int(bps[v]) - int(rng.integers(0, 3000)))
+            b = a + int(rng.integers(0, 6000))
+            lines.append("%s %d %d %s" % (chroms[v], a - (1 if zero_based else 0), b, name))
+    lines.append("22 1 1000000 elsewhere")
+    lines.append("%s 1 2 tiny" % chroms[0])
+    rng.shuffle(lines)
+    open(path, "w").write("\n".join(lines) + "\n")
+
+
+@needs_ref
+@pytest.mark.parametrize("flag,extra", [
+    ("--clump-range", []),
+    ("--clump-range0", []),
+    ("--clump-range", ["--clump-range-border", "2.5"]),
+    ("--clump-range", ["--clump-range-border", "40", "--clump-p1", "0.01", "--clump-p2", "1e-6"]),   # index variants above p2: no bounds, no ranges
+    ("--clump-range", ["cols=-maybebounds,-sp2,-bins"]),
+])
+def test_clump_ranges_match_reference(cli, tmp_path, flag, extra):
+    """--clump-range[0] / --clump-range-border: the RANGES column and the bounds that come with it (plink2_set.cc:39-330, :495-638;
+    plink2_ld.cc:9265-9400)."""
+    m = 1000
+    prefix, raw, chroms, bps = clump_fileset(tmp_path, m, 40, 4)
+    write_report(str(tmp_path / "assoc.txt"), m, 9)
+    write_ranges(str(tmp_path / "genes.txt"), chroms, bps, 1, zero_based=(flag == "--clump-range0"))
+    mods = [x for x in extra if x.startswith("cols=")]
+    rest = [x for x in extra if not x.startswith("cols=")]
+    common = ["--bfile", "d", "--clump"] + mods + ["assoc.txt", "--clump-unphased", "--clump-kb", "0.001", flag, "genes.txt"] + rest
+    compare_runs(cli, tmp_path, common)
+    body = open(str(tmp_path / "hip.clumps")).read().split("\n")
+    assert body[0].endswith("RANGES") and any(("," in l.split("\t")[-1]) for l in body[1:-1]), "some clump must meet several regions"
+
+
 def test_clump_flag_rules(cli, tmp_path):
     clump_fileset(tmp_path, 60, 20, 3)
     write_report(str(tmp_path / "a.txt"), 60, 1)
@@ -229,8 +271,11 @@ def test_clump_flag_rules(cli, tmp_path):
     assert r.returncode == 63 and "--clump-unphased" in r.stdout
     r = run_cli(cli, ["--bfile", "d", "--clump", "a.txt", "--clump-unphased", "--clump-r2", "1.0"], str(tmp_path))
     assert r.returncode == 8 and "Invalid --clump-r2" in r.stdout
-    r = run_cli(cli, ["--bfile", "d", "--clump", "a.txt", "--clump-unphased", "--clump-range", "genes.txt"], str(tmp_path))
-    assert r.returncode == 63
+    for args in (["--clump-range-border", "5"], ["--clump-range0", "a.txt", "--clump-range-border", "5"]):
+        r = run_cli(cli, ["--bfile", "d", "--clump", "a.txt", "--clump-unphased"] + args, str(tmp_path))
+        assert r.returncode == 8 and "must be used with --clump-range" in r.stdout
+        if T.have_ref():
+            assert T.run_ref(["--bfile", "d", "--clump", "a.txt", "--clump-unphased"] + args + ["--out", "ref"], str(tmp_path)).returncode == 8
     r = run_cli(cli, ["--bfile", "d", "--clump-unphased"], str(tmp_path))
     assert r.returncode == 8
     for args, needle in ((["--clump-bins", "0.01,0.001"], "not in increasing order"), (["--clump-bins", "0.5,1"], "values >= 1"),
