@@ -46,6 +46,37 @@ assert out.returncode == 0 and out.stdout.split("\n")[:-1] == [str(t) for t in g
 open(T + "/in.txt", "w").write("line\n" * 200000)
 z = subprocess.run([T + "/cli", "--debug-zstd", T + "/in.txt", T + "/out.zst"], stderr=subprocess.PIPE, text=True)
 assert z.returncode == 0, z.stderr[-400:]
+# the host-only command paths: table parsing (alleles, centimorgans), filters, the --clump report handling with column
+# sets / bins / ranges (a 1-bp radius pairs nothing, so no device is needed), and the command-line refusals
+sys.path.insert(0, R + "/tests")
+import os
+import ldtools as L
+import test_clump as TC
+d = T + "/fs"
+os.makedirs(d)
+m = 400
+raw = L.synth_raw_codes(m, 40, seed=3, missing_rate=0.02)
+chroms = ["1"] * 150 + ["2"] * 150 + ["X"] * 100
+bps = np.concatenate([np.arange(150), np.arange(150), np.arange(100)]) * 1000 + 1000
+L.write_bed(d + "/d", raw, chroms, bps)
+L.write_pgen_fixed(d + "/d", raw, chroms, bps)
+TC.write_report(d + "/a.txt", m, 5)
+TC.write_report(d + "/b.txt", m, 6, sig_rate=0.1)
+TC.write_ranges(d + "/genes.txt", chroms, bps, 2)
+open(d + "/drop.txt", "w").write("snp3 snp77\nsnp200\nnone_such\n")
+runs = [
+    (["--bfile", "d", "--clump", "cols=+ref,+alt1,+alt,+bounds,+f,+a1", "a.txt", "b.txt", "--clump-unphased", "--clump-kb", "0.001", "--clump-bins", "1e-5,0.001", "0.2",
+      "--clump-range", "genes.txt", "--clump-range-border", "3"], 0),
+    (["--pfile", "d", "--clump", "cols=sp2", "a.txt", "--clump-unphased", "--clump-kb", "0.001", "--clump-log10", "output-only", "--clump-p1", "0.3", "--clump-p2", "1e-7"], 0),
+    (["--bfile", "d", "--chr", "1,X", "--exclude", "drop.txt", "--indep-pairwise", "50", "5", "0.2", "--bad-ld", "--dry-run"], 0),
+    (["--bfile", "d", "--r-unphased", "cols=+nope"], 8),
+    (["--bfile", "d", "--r2-unphased", "square", "--ld-window-cm", "1"], 8),
+    (["--bfile", "d", "--clump", "a.txt", "cols=+f", "--clump-unphased"], 8),
+    (["--pgen", "d.pgen", "--pgi", "nowhere.pgi", "--pvar", "d.pvar", "--psam", "d.psam", "--indep-pairwise", "50", "5", "0.2", "--bad-ld", "--dry-run"], 0),
+]
+for args, want in runs:
+    r = subprocess.run([T + "/cli"] + args + ["--out", "o"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == want and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (args, r.returncode, r.stdout[-300:], r.stderr[-800:])
 print("plink2-hip host paths: clean")
 PY
 fi
@@ -53,7 +84,7 @@ if command -v hipcc > /dev/null; then
   # the engine's host logic (window planning in all three modes, sharding, greedy replay in both orders) on random
   # variant tables; the HIP runtime is linked but never finds a device here
   hipcc -std=c++17 -g -O1 --offload-arch=gfx950 -fsanitize=address,undefined -fno-omit-frame-pointer -fno-gpu-sanitize -I"$R/include" \
-      "$R/tests/sanitize/engine_host_harness.cpp" "$R/plink-ng_amd/csrc/ldp_engine.cpp" "$R/plink-ng_amd/csrc/ldp_kernels.hip" \
+      "$R/tests/sanitize/engine_host_harness.cpp" "$R/plink-ng_amd/csrc/ldp_engine.cpp" "$R/plink-ng_amd/csrc/ldp_kernels.hip" "$R/plink-ng_amd/csrc/ldp_pair_mfma.hip" \
       "$R/plink-ng_amd/csrc/ldp_synth.hip" "$R/plink-ng_amd/csrc/ldp_pgen.cpp" -o "$T/engine" -lpthread 2> "$T/engine_build.log" || { tail -5 "$T/engine_build.log"; exit 1; }
   ASAN_OPTIONS=detect_leaks=0 "$T/engine"
 fi
