@@ -2224,6 +2224,35 @@ struct XWeighted {
     }
     return c;
   }
+  // the reference's doubles from the two count tuples (ComputeXR2 :7160-7185)
+  static double weighted(const G& a, const G& m, bool both_x, bool unsquared, double nan_ref) {
+    if (!a.n) {
+      return nan_ref;
+    }
+    const double male_downwt = both_x ? 0.5 : (1.0 - 0.5 * 1.4142135623730951);
+    const double w_obs = fma(-male_downwt, static_cast<double>(m.n), static_cast<double>(a.n));
+    const double w_g1 = fma(-male_downwt, static_cast<double>(m.g1), static_cast<double>(a.g1));
+    const double w_g2 = fma(-male_downwt, static_cast<double>(m.g2), static_cast<double>(a.g2));
+    const double w_q1 = fma(-male_downwt, static_cast<double>(m.q1), static_cast<double>(a.q1));
+    const double w_q2 = fma(-male_downwt, static_cast<double>(m.q2), static_cast<double>(a.q2));
+    const double w_d = fma(-male_downwt, static_cast<double>(m.d), static_cast<double>(a.d));
+    const double var1 = fma(w_q1, w_obs, -w_g1 * w_g1);
+    const double var2 = fma(w_q2, w_obs, -w_g2 * w_g2);
+    if (!((var1 > 0.0) && (var2 > 0.0))) {
+      return nan_ref;
+    }
+    const double var_prod = var1 * var2;
+    const double cov = fma(w_d, w_obs, -w_g1 * w_g2);
+    const double quot = cov * cov / var_prod;
+    double r = (1.0 < quot) ? 1.0 : quot;
+    if (unsquared) {
+      r = sqrt(r);
+      if (cov < 0.0) {
+        r = -r;
+      }
+    }
+    return r;
+  }
   // r^2 (or r) of the listed pairs, each with at least one chrX variant; NaN where the reference's is undefined
   void pairs(const std::vector<uint32_t>& first, const std::vector<uint32_t>& second, std::vector<double>* out) const {
     const size_t n = first.size();
@@ -2247,31 +2276,8 @@ struct XWeighted {
       for (uint32_t q = 0; q < cnt; ++q) {
         const uint32_t i = first[p0 + q], j = second[p0 + q];
         const G a = counts(ta[q], (!flip_all.empty()) && flip_all[i], (!flip_all.empty()) && flip_all[j]);
-        double r = nan_ref;
-        if (a.n) {
-          const G m = male ? counts(tm[q], (!flip_male.empty()) && flip_male[i], (!flip_male.empty()) && flip_male[j]) : G{0, 0, 0, 0, 0, 0};
-          const double male_downwt = (is_x[i] && is_x[j]) ? 0.5 : (1.0 - 0.5 * 1.4142135623730951);
-          const double w_obs = fma(-male_downwt, static_cast<double>(m.n), static_cast<double>(a.n));
-          const double w_g1 = fma(-male_downwt, static_cast<double>(m.g1), static_cast<double>(a.g1));
-          const double w_g2 = fma(-male_downwt, static_cast<double>(m.g2), static_cast<double>(a.g2));
-          const double w_q1 = fma(-male_downwt, static_cast<double>(m.q1), static_cast<double>(a.q1));
-          const double w_q2 = fma(-male_downwt, static_cast<double>(m.q2), static_cast<double>(a.q2));
-          const double w_d = fma(-male_downwt, static_cast<double>(m.d), static_cast<double>(a.d));
-          const double var1 = fma(w_q1, w_obs, -w_g1 * w_g1);
-          const double var2 = fma(w_q2, w_obs, -w_g2 * w_g2);
-          if ((var1 > 0.0) && (var2 > 0.0)) {
-            const double var_prod = var1 * var2;
-            const double cov = fma(w_d, w_obs, -w_g1 * w_g2);
-            const double quot = cov * cov / var_prod;
-            r = (1.0 < quot) ? 1.0 : quot;
-            if (unsquared) {
-              r = sqrt(r);
-              if (cov < 0.0) {
-                r = -r;
-              }
-            }
-          }
-        }
+        const G m = male ? counts(tm[q], (!flip_male.empty()) && flip_male[i], (!flip_male.empty()) && flip_male[j]) : G{0, 0, 0, 0, 0, 0};
+        const double r = weighted(a, m, is_x[i] && is_x[j], unsquared, nan_ref);
         (*out)[p0 + q] = r;
       }
     }
@@ -5206,7 +5212,41 @@ int run_prune(Session& S) {
 
 }  // namespace
 
+// test hook (no GPU needed): lines `both_x unsquared flip1 flip2 mflip1 mflip2  nm sum1 ssq1 sum2 ssq2 dot  (the same six for the male
+// founders)` in, the chrX-weighted r^2 (or r) out as the hex bits of the double -- XWeighted's arithmetic against values the
+// reference computed (tests/test_r2_flags.py)
+int debug_xweighted(const char* path) {
+  FILE* df = fopen(path, "r");
+  if (!df) {
+    die(3, "Error: Failed to open %s.\n", path);
+  }
+  double nan_ref;
+  {
+    const uint64_t bits = 0xfff8000000000000ull;
+    memcpy(&nan_ref, &bits, 8);
+  }
+  int bx, us, f1, f2, g1, g2;
+  long long v[12];
+  while (fscanf(df, "%d %d %d %d %d %d %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld", &bx, &us, &f1, &f2, &g1, &g2, &v[0], &v[1], &v[2], &v[3], &v[4], &v[5],
+                &v[6], &v[7], &v[8], &v[9], &v[10], &v[11]) == 18) {
+    ldp_pair_stats_t ta, tm;
+    ta.nm = static_cast<uint32_t>(v[0]); ta.sum1 = static_cast<int32_t>(v[1]); ta.ssq1 = static_cast<uint32_t>(v[2]);
+    ta.sum2 = static_cast<int32_t>(v[3]); ta.ssq2 = static_cast<uint32_t>(v[4]); ta.dot = static_cast<int32_t>(v[5]);
+    tm.nm = static_cast<uint32_t>(v[6]); tm.sum1 = static_cast<int32_t>(v[7]); tm.ssq1 = static_cast<uint32_t>(v[8]);
+    tm.sum2 = static_cast<int32_t>(v[9]); tm.ssq2 = static_cast<uint32_t>(v[10]); tm.dot = static_cast<int32_t>(v[11]);
+    const double r = XWeighted::weighted(XWeighted::counts(ta, f1 != 0, f2 != 0), XWeighted::counts(tm, g1 != 0, g2 != 0), bx != 0, us != 0, nan_ref);
+    uint64_t bits;
+    memcpy(&bits, &r, 8);
+    printf("%016llx\n", static_cast<unsigned long long>(bits));
+  }
+  fclose(df);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if ((argc == 3) && (strcmp(argv[1], "--debug-xweighted") == 0)) {
+    return debug_xweighted(argv[2]);
+  }
   Session S;
   load_inputs(S, argc, argv);
   return S.A.have_r2 ? run_r2(S) : run_prune(S);
