@@ -1280,6 +1280,22 @@ void replay(ldp_engine* e, const uint32_t* pred, const double* mf, std::vector<u
   if (e->P.plink1_order) {
     first_unchecked.assign(e->local_ct, 0);
   }
+  // LDP_DEBUG_REPLAY_STEPS=k (test hook): every subcontig in k instalments, the way the streaming replay of a run advances
+  // through it as the launch groups land
+  if (const char* st = getenv("LDP_DEBUG_REPLAY_STEPS")) {
+    const uint32_t steps = static_cast<uint32_t>(std::max(1, atoi(st)));
+    uint64_t total = 0;
+    for (uint32_t k : e->owned) {
+      const Subcontig& sub = e->subs[k];
+      uint32_t cursor = sub.local_first;
+      for (uint32_t q = 1; q <= steps; ++q) {
+        const uint32_t covered = (q == steps) ? (sub.local_first + sub.len) : (sub.local_first + static_cast<uint32_t>(static_cast<uint64_t>(sub.len) * q / steps));
+        total += replay_subcontig(e, k, pred, mf, R, first_unchecked, &cursor, covered);
+      }
+    }
+    *replay_pairs_out = total;
+    return;
+  }
   // longest subcontig first
   std::vector<uint32_t> order(e->owned);
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return e->subs[a].len > e->subs[b].len; });

@@ -80,8 +80,16 @@ def test_replay_matches_oracle(pkg, case):
     eng.debug_set_variant_recs(recs_from_vaggs(pkg, vaggs, n, m))
     eng.set_maj_freqs(0, mf)
     got = eng.debug_replay_pairs(first, second)
-    eng.close()
     assert np.array_equal(got, want), "removed sets differ: %d vs %d" % (got.sum(), want.sum())
+    # the same in instalments (the streaming replay of a run resumes every subcontig at window-batch boundaries)
+    for steps in ("2", "7", "1000"):
+        os.environ["LDP_DEBUG_REPLAY_STEPS"] = steps
+        try:
+            again = eng.debug_replay_pairs(first, second)
+        finally:
+            del os.environ["LDP_DEBUG_REPLAY_STEPS"]
+        assert np.array_equal(again, want), steps
+    eng.close()
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
