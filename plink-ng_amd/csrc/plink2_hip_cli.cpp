@@ -438,6 +438,8 @@ struct Args {
   bool clump_allow_overlap = false;
   bool clump_no_test = false;
   std::vector<std::string> clump_id_field, clump_p_field, clump_test_field, clump_test;
+  bool clump_force_a1 = false, clump_no_a1 = false;  // --clump-force-a1; --clump-a1-field without names
+  std::vector<std::string> clump_a1_field;
   std::string clump_range;                 // --clump-range / --clump-range0 <file>: regions to report overlaps with
   bool clump_range0 = false;
   uint32_t clump_range_border = 0;         // --clump-range-border <kb>, in bp
@@ -790,6 +792,13 @@ Args parse_args(int argc, char** argv) {
       A.clump_unphased = true;
     } else if (f == "--clump-allow-overlap") {
       A.clump_allow_overlap = true;
+    } else if (f == "--clump-force-a1") {  // plink2.cc:5200-5210
+      A.clump_force_a1 = true;
+    } else if (f == "--clump-a1-field") {  // plink2.cc:5059-5071
+      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+        A.clump_a1_field.push_back(argv[++i]);
+      }
+      A.clump_no_a1 = A.clump_a1_field.empty();
     } else if ((f == "--clump-range") || (f == "--clump-range0")) {  // plink2.cc:5092-5120
       need(i, 1, f.c_str());
       if (!A.clump_range.empty()) {
@@ -1127,6 +1136,12 @@ Args parse_args(int argc, char** argv) {
   }
   // (the reference reads its flags in sorted order, and "clump-range-border" sorts before "clump-range0": with --clump-range0 the
   // border flag finds no range file yet, plink2.cc:5122-5125)
+  if (A.clump_force_a1 && A.clump_no_a1) {
+    die(8, "Error: --clump-force-a1 does not make sense with empty --clump-a1-field\nargument.\n");
+  }
+  if ((A.clump_force_a1 || A.clump_no_a1 || !A.clump_a1_field.empty()) && !A.have_clump) {
+    die(8, "Error: --clump-force-a1 must be used with --clump.\n");
+  }
   if (A.clump_range_border_given && (A.clump_range.empty() || A.clump_range0)) {
     die(8, "Error: --clump-range-border must be used with --clump-range[0].\n");
   }
@@ -1387,7 +1402,7 @@ void load_variants(const Args& A, Variants* V) {
   double last_cm = -1.7976931348623157e308;
   std::string last_cm_chrom;
   const bool keep_alleles = (A.have_r2 && (A.r2_cols & (kVcorColRef | kVcorColAlt1 | kVcorColAlt | kVcorColMaj | kVcorColNonmaj))) ||
-                            (A.have_clump && (A.clump_cols & (kClumpColRef | kClumpColAlt1 | kClumpColAlt)));
+                            (A.have_clump && ((A.clump_cols & (kClumpColRef | kClumpColAlt1 | kClumpColAlt)) || A.clump_force_a1));
   constexpr int kCap = 64;
   Tok t[kCap];
   const char* p = buf.data();
@@ -1975,6 +1990,8 @@ struct ClumpData {
   std::vector<uint32_t> nonsig;               // lines above every bin boundary
   std::vector<std::vector<uint32_t>> entries; // one per loaded line, in the order read (last report first): (file << 12) | (bin << 1) | (ln p > ln p2)
   std::vector<double> ln_bins;                // bin boundaries in use (empty: the 'bins' column set is off)
+  std::vector<uint8_t> best_a1;               // --clump-force-a1: the best line's A1 is the ALT allele
+  std::vector<std::string> missing_pairs;     // top (ID, A1) pairs whose allele the dataset's variant does not have
   std::vector<uint16_t> best_file;            // report (1-based) the best p-value came from; ties go to the first report
   std::vector<uint8_t> observed;
   std::vector<std::string> missing_ids;       // top (p <= p1) IDs absent from the dataset
@@ -1995,6 +2012,7 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
   D->nonsig.assign(variant_ct, 0);
   D->entries.assign(variant_ct, std::vector<uint32_t>());
   D->best_file.assign(variant_ct, 1);
+  D->best_a1.assign(variant_ct, 0);
   D->observed.assign(variant_ct, 0);
   // ID -> included-variant index; kDup marks IDs the dataset holds more than once (an error only when the report names one)
   const uint32_t kDup = 0xffffffffu;
@@ -2083,10 +2101,22 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
     }
     want[2] = A.clump_p_field.empty() ? (A.clump_in_log10 ? std::vector<std::string>{"LOG10_P", "NEG_LOG10_P", "P"} : std::vector<std::string>{"P"})
                                       : A.clump_p_field;  // (:7631)
+    const std::vector<std::string> want_a1 = A.clump_force_a1 ? (A.clump_a1_field.empty() ? std::vector<std::string>{"A1"} : A.clump_a1_field) : std::vector<std::string>();
+    int col_a1 = -1;
+    size_t prio_a1 = ~size_t(0);
     int col[3] = {-1, -1, -1};
     size_t prio[3] = {~size_t(0), ~size_t(0), ~size_t(0)};
     for (size_t c = 0; c < toks.size(); ++c) {
       const std::string name(toks[c].first, toks[c].second);
+      for (size_t q = 0; q < want_a1.size(); ++q) {
+        if ((want_a1[q] == name) && (prio_a1 >= q)) {
+          if (prio_a1 == q) {
+            die(6, "Error: Duplicate column header '%s' in --clump file.\n", name.c_str());
+          }
+          prio_a1 = q;
+          col_a1 = static_cast<int>(c);
+        }
+      }
       for (int t = 0; t < 3; ++t) {
         for (size_t q = 0; q < want[t].size(); ++q) {
           if (want[t][q] == name && prio[t] >= q) {
@@ -2102,7 +2132,7 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
     if ((col[0] < 0) || (col[2] < 0)) {
       die(7, "Error: --clump requires ID and P columns.\n");
     }
-    const int last_col = std::max(col[0], std::max(col[1], col[2]));
+    const int last_col = std::max(std::max(col[0], col_a1), std::max(col[1], col[2]));
     const std::vector<std::string> test_names = A.clump_test.empty() ? std::vector<std::string>{"ADD"} : A.clump_test;
     while (next_line(&ls, &le)) {
       if (ls == le) {
@@ -2164,6 +2194,23 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
         die(7, "Error: --clump variant ID '%s' appears multiple times in main dataset.\n", id.c_str());
       }
       const uint32_t k = it->second;
+      uint32_t a1_alt = 0;
+      if (A.clump_force_a1) {  // (:7783-7818)
+        if (col_a1 < 0) {
+          die(7, "Error: Variant ID on line %zu of %s is multiallelic, but there is no A1 column.\n", line_idx, fname.c_str());
+        }
+        const std::string a1(toks[col_a1].first, toks[col_a1].second);
+        if (a1 == V.ref[inc[k]]) {
+          a1_alt = 0;
+        } else if (a1 == V.alt[inc[k]]) {
+          a1_alt = 1;
+        } else {
+          if (ln_pval <= ln_p1) {
+            D->missing_pairs.push_back(id + "\t" + a1);
+          }
+          continue;
+        }
+      }
       if (ln_pval > load_thresh) {
         if (ln_pval > 0.0) {
           die(6, "Error: p-value > 1 on line %zu of %s.\n", line_idx, fname.c_str());
@@ -2177,10 +2224,11 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
       if (D->best_ln[k] >= ln_pval) {  // (>=: the reports are read last to first, so ties end up with the first one, :7833)
         D->best_ln[k] = ln_pval;
         D->best_file[k] = static_cast<uint16_t>(file_idx1);
+        D->best_a1[k] = static_cast<uint8_t>(a1_alt);
       }
       D->observed[k] = 1;
       if (keep_entries) {
-        D->entries[k].push_back(static_cast<uint32_t>((file_idx1 << 12) | (clump_bin(D->ln_bins, ln_pval) << 1) | (ln_pval > ln_p2)));
+        D->entries[k].push_back(static_cast<uint32_t>((a1_alt << 30) | (file_idx1 << 12) | (clump_bin(D->ln_bins, ln_pval) << 1) | (ln_pval > ln_p2)));
       }
     }
   }
@@ -2433,6 +2481,21 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
     const size_t n = D.missing_ids.size();
     logprintf("Warning: %zu top variant ID%s in --clump file%s missing from main dataset.  ID%s written to %s .\n", n, (n == 1) ? "" : "s",
               (A.clump_files.size() == 1) ? "" : "s", (n == 1) ? "" : "s", path.c_str());
+  }
+  if (!D.missing_pairs.empty()) {  // (:7933-7952)
+    std::sort(D.missing_pairs.begin(), D.missing_pairs.end(), natural_less);
+    D.missing_pairs.erase(std::unique(D.missing_pairs.begin(), D.missing_pairs.end()), D.missing_pairs.end());
+    const std::string path = A.out + ".clumps.missing_allele";
+    OutFile mf;
+    mf.open(path, false);
+    for (const std::string& s : D.missing_pairs) {
+      mf.write(s.data(), s.size());
+      mf.write("\n", 1);
+    }
+    mf.close();
+    const size_t n = D.missing_pairs.size();
+    logprintf("Warning: %zu top (variant ID, A1 allele) pair%s in --clump file%s missing from main dataset due to allele rather than variant ID.  (Variant ID, A1 allele) pair%s written to %s .\n",
+              n, (n == 1) ? "" : "s", (A.clump_files.size() == 1) ? "" : "s", (n == 1) ? "" : "s", path.c_str());
   }
   // observed variants (named by a usable report line) in dataset order, and the index candidates among them:
   // best p <= p1, ranked by (ln p, position in the dataset) (ClumpPvalCmp; plink2_ld.cc:7996-8040)
@@ -2703,7 +2766,7 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
     ranges.load(A, V, inc);
   }
   const bool bounds_col = (cols & kClumpColBounds) || ((cols & kClumpColMaybeBounds) && ranges_col);
-  const bool f_in_sp2_files = multi && sp2_col;  // (save_all_fidxs, :7633)
+  const bool save_all_fidxs = (multi || A.clump_force_a1) && sp2_col;  // (:7633)
   const bool a1_col = (cols & kClumpColA1) != 0;  // ('maybea1' wants a multiallelic variant in the dataset: those are refused above)
   const size_t bin_bound_ct = D.ln_bins.size();
   bool provref_col = false;
@@ -2778,8 +2841,13 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
       buf += ((SX.prov_storage == 2) || ((SX.prov_storage == 3) && ((SX.prov_bits[iv >> 3] >> (iv & 7)) & 1))) ? 'Y' : 'N';
       buf += '\t';
     }
-    if (a1_col) {
-      buf += ".\t";  // (a biallelic variant without --clump-force-a1, :9186-9196)
+    if (a1_col) {  // (a biallelic variant: the best line's A1 with --clump-force-a1, else '.', :9186-9196)
+      if (A.clump_force_a1) {
+        buf += D.best_a1[obs[io]] ? V.alt[iv] : V.ref[iv];
+        buf += '\t';
+      } else {
+        buf += ".\t";
+      }
     }
     const uint32_t index_file = D.best_file[obs[io]];
     if (f_col) {
@@ -2817,11 +2885,14 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
       // bp range of the members with a line at or below p2 (:9270-9311)
       for (uint64_t q = mem_off[r]; q < mem_off[r + 1]; ++q) {
         const uint32_t k = obs[members[q]];
-        // (with several reports and SP2 the reference keeps a report number behind every entry and this scan, :9271-9279, does not
-        // step over it: the number's low bit is clear, so any member with a kept line counts.  Reproduced.)
-        bool hit = f_in_sp2_files && !D.entries[k].empty();
-        for (uint32_t en : D.entries[k]) {
-          hit = hit || !(en & 1);
+        // (with several reports -- or --clump-force-a1 -- and SP2 the reference keeps a word behind every entry, report number
+        // times two plus the forced-A1 bit, and this scan, :9271-9279, does not step over it: it tests that word's low bit like
+        // an entry's.  Reproduced: entries are walked the way its list is, latest read first.)
+        bool hit = false;
+        const std::vector<uint32_t>& ent_k = D.entries[k];
+        for (size_t x = ent_k.size(); x && !hit; --x) {
+          const uint32_t en = ent_k[x - 1];
+          hit = (!(en & 1)) || (save_all_fidxs && !((en >> 30) & 1));
         }
         if (hit) {
           if (first_bp == 0xffffffffu) {
@@ -2856,11 +2927,16 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
       const std::vector<uint32_t>& ent = D.entries[obs[m]];
       for (size_t x = ent.size(); x; --x) {
         const uint32_t en = ent[x - 1];
-        const uint32_t file = en >> 12;
+        const uint32_t file = (en >> 12) & 0x3ffff;
         if ((en & 1) || ((m == io) && (file == index_file))) {
           continue;
         }
         buf += V.id[inc[obs[m]]];
+        if (A.clump_force_a1) {  // (:9355-9358)
+          buf += '(';
+          buf += ((en >> 30) & 1) ? V.alt[inc[obs[m]]] : V.ref[inc[obs[m]]];
+          buf += ')';
+        }
         if (f_in_sp2) {
           buf += '(';
           buf += std::to_string(file);

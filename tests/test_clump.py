@@ -87,7 +87,7 @@ def compare_runs(cli, tmp_path, common):
         wl, hl = want.split("\n"), have.split("\n")
         bad = [(a, b) for a, b in zip(wl, hl) if a != b]
         raise AssertionError("%d/%d lines differ, first: %r" % (len(bad) + abs(len(wl) - len(hl)), len(wl), bad[:2]))
-    for ext in (".clumps.missing_id",):
+    for ext in (".clumps.missing_id", ".clumps.missing_allele"):
         a, b = str(tmp_path / ("ref" + ext)), str(tmp_path / ("hip" + ext))
         assert os.path.exists(a) == os.path.exists(b)
         if os.path.exists(a):
@@ -262,6 +262,56 @@ def test_clump_ranges_match_reference(cli, tmp_path, flag, extra):
     compare_runs(cli, tmp_path, common)
     body = open(str(tmp_path / "hip.clumps")).read().split("\n")
     assert body[0].endswith("RANGES") and any(("," in l.split("\t")[-1]) for l in body[1:-1]), "some clump must meet several regions"
+
+
+def add_a1_column(src, dst, seed, name="A1"):
+    """An allele column behind the report's columns: mostly the dataset's ALT (C) or REF (A), now and then neither."""
+    rng = np.random.default_rng(seed)
+    lines = open(src).read().splitlines()
+    out = [lines[0] + "\t" + name]
+    for ln in lines[1:]:
+        out.append(ln + "\t" + str(rng.choice(["C", "A", "T", "AC"], p=[0.55, 0.35, 0.07, 0.03])))
+    open(dst, "w").write("\n".join(out) + "\n")
+
+
+@needs_ref
+@pytest.mark.parametrize("mods,extra,two", [
+    ([], [], False),
+    (["cols=+a1,+bounds"], ["--clump-p1", "0.01", "--clump-p2", "1e-4"], False),     # the bounds scan reads the forced-A1 bit too
+    (["cols=+a1,+f"], [], True),
+    (["cols=+bounds,-total"], ["--clump-p1", "0.05", "--clump-p2", "1e-5"], True),
+    (["cols=-sp2,+a1"], [], False),
+])
+def test_clump_force_a1_matches_reference(cli, tmp_path, mods, extra, two):
+    """--clump-force-a1 on a biallelic dataset (ClumpReports :7783-7818, :9186-9196, :9355-9358): lines whose A1 is neither allele
+    drop out (the top ones into .clumps.missing_allele), the A1 column and the SP2 suffixes carry the allele."""
+    m = 900
+    clump_fileset(tmp_path, m, 40, 10)
+    write_report(str(tmp_path / "p.txt"), m, 21)
+    add_a1_column(str(tmp_path / "p.txt"), str(tmp_path / "a.txt"), 1)
+    files = ["a.txt"]
+    if two:
+        write_report(str(tmp_path / "q.txt"), m, 22, sig_rate=0.1)
+        add_a1_column(str(tmp_path / "q.txt"), str(tmp_path / "b.txt"), 2)
+        files.append("b.txt")
+    common = ["--bfile", "d", "--clump"] + mods + files + ["--clump-unphased", "--clump-kb", "0.001", "--clump-force-a1"] + extra
+    compare_runs(cli, tmp_path, common)
+    assert os.path.exists(str(tmp_path / "hip.clumps.missing_allele"))
+
+
+@needs_ref
+def test_clump_a1_field_rules(cli, tmp_path):
+    m = 300
+    clump_fileset(tmp_path, m, 40, 3)
+    write_report(str(tmp_path / "p.txt"), m, 4)
+    add_a1_column(str(tmp_path / "p.txt"), str(tmp_path / "a.txt"), 5, name="EFFECT")
+    base = ["--bfile", "d", "--clump", "a.txt", "--clump-unphased", "--clump-kb", "0.001"]
+    compare_runs(cli, tmp_path, base + ["--clump-force-a1", "--clump-a1-field", "ALLELE", "EFFECT"])
+    compare_runs(cli, tmp_path, base + ["--clump-a1-field", "EFFECT"])                     # without the force flag a biallelic dataset ignores it
+    for args, code in ((["--clump-force-a1"], 7), (["--clump-force-a1", "--clump-a1-field"], 8)):
+        ref = T.run_ref(base + args + ["--out", "ref"], str(tmp_path))
+        got = run_cli(cli, base + args + ["--out", "hip"], str(tmp_path))
+        assert ref.returncode == got.returncode == code, (args, ref.returncode, got.returncode, got.stdout[-300:])
 
 
 def test_clump_flag_rules(cli, tmp_path):
