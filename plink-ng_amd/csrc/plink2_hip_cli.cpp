@@ -438,6 +438,7 @@ struct Args {
   bool clump_allow_overlap = false;
   bool clump_no_test = false;
   std::vector<std::string> clump_id_field, clump_p_field, clump_test_field, clump_test;
+  bool clump_zs = false;
   bool clump_force_a1 = false, clump_no_a1 = false;  // --clump-force-a1; --clump-a1-field without names
   std::vector<std::string> clump_a1_field;
   std::string clump_range;                 // --clump-range / --clump-range0 <file>: regions to report overlaps with
@@ -730,8 +731,12 @@ Args parse_args(int argc, char** argv) {
       need(i, 1, "--clump");
       while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
         const std::string arg = argv[++i];
-        if (arg == "zs") {
-          die(63, "Error: the '%s' modifier of --clump is not supported by plink2-hip.\n", arg.c_str());
+        if (arg == "zs") {  // (.clumps and the missing-ID lists through the zstd writer, OutnameZstSet :7920, :7944, :9004)
+          if (!A.clump_files.empty()) {
+            die(8, "Error: Invalid --clump argument sequence ('zs' must come before\nfilename(s)).\n");
+          }
+          A.clump_zs = true;
+          continue;
         }
         if (arg.compare(0, 5, "cols=") == 0) {  // plink2.cc:4900-4925
           if (!A.clump_files.empty()) {
@@ -2470,9 +2475,9 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
   if (!D.missing_ids.empty()) {  // natural-sorted, deduplicated (plink2_ld.cc:7909-7931)
     std::sort(D.missing_ids.begin(), D.missing_ids.end(), natural_less);
     D.missing_ids.erase(std::unique(D.missing_ids.begin(), D.missing_ids.end()), D.missing_ids.end());
-    const std::string path = A.out + ".clumps.missing_id";
+    const std::string path = A.out + ".clumps.missing_id" + (A.clump_zs ? ".zst" : "");
     OutFile mf;
-    mf.open(path, false);
+    mf.open(path, A.clump_zs);
     for (const std::string& s : D.missing_ids) {
       mf.write(s.data(), s.size());
       mf.write("\n", 1);
@@ -2485,9 +2490,9 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
   if (!D.missing_pairs.empty()) {  // (:7933-7952)
     std::sort(D.missing_pairs.begin(), D.missing_pairs.end(), natural_less);
     D.missing_pairs.erase(std::unique(D.missing_pairs.begin(), D.missing_pairs.end()), D.missing_pairs.end());
-    const std::string path = A.out + ".clumps.missing_allele";
+    const std::string path = A.out + ".clumps.missing_allele" + (A.clump_zs ? ".zst" : "");
     OutFile mf;
-    mf.open(path, false);
+    mf.open(path, A.clump_zs);
     for (const std::string& s : D.missing_pairs) {
       mf.write(s.data(), s.size());
       mf.write("\n", 1);
@@ -2751,9 +2756,9 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
   logprintf("--clump: %u clump%s formed from %u index candidate%s.\n", clump_ct, (clump_ct == 1) ? "" : "s", cand_ct, (cand_ct == 1) ? "" : "s");
 
   // <out>.clumps (plink2_ld.cc:9003-9405): [chrom pos] ID [ref alt1 alt provref a1 f] P [total] [bounds] [bins] [sp2]
-  const std::string path = A.out + ".clumps";
+  const std::string path = A.out + ".clumps" + (A.clump_zs ? ".zst" : "");
   OutFile f;
-  f.open(path, false);
+  f.open(path, A.clump_zs);
   // (several reports: an F column names the report of the index variant's best p-value, and SP2 entries carry theirs)
   const bool multi = (A.clump_files.size() > 1);
   const uint32_t cols = A.clump_cols;

@@ -314,6 +314,22 @@ def test_clump_a1_field_rules(cli, tmp_path):
         assert ref.returncode == got.returncode == code, (args, ref.returncode, got.returncode, got.stdout[-300:])
 
 
+@needs_ref
+def test_clump_zs_outputs_decompress_to_the_reference_text(cli, tmp_path):
+    import subprocess
+    m = 800
+    clump_fileset(tmp_path, m, 40, 14)
+    write_report(str(tmp_path / "assoc.txt"), m, 15)
+    common = ["--bfile", "d", "--clump", "zs", "cols=+bounds", "assoc.txt", "--clump-unphased", "--clump-kb", "0.001"]
+    ref = T.run_ref(common + ["--out", "ref"], str(tmp_path))
+    got = run_cli(cli, common + ["--out", "hip"], str(tmp_path))
+    assert ref.returncode == 0 and got.returncode == 0, (ref.stdout[-300:], got.stdout[-300:])
+    for ext in (".clumps.zst", ".clumps.missing_id.zst"):
+        a = subprocess.run([T.REF_BIN, "--zst-decompress", str(tmp_path / ("ref" + ext))], stdout=subprocess.PIPE).stdout
+        b = subprocess.run([T.REF_BIN, "--zst-decompress", str(tmp_path / ("hip" + ext))], stdout=subprocess.PIPE).stdout
+        assert len(a) > 50 and a == b, ext
+
+
 def test_clump_flag_rules(cli, tmp_path):
     clump_fileset(tmp_path, 60, 20, 3)
     write_report(str(tmp_path / "a.txt"), 60, 1)
