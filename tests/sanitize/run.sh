@@ -64,11 +64,13 @@ TC.write_report(d + "/a.txt", m, 5)
 TC.write_report(d + "/b.txt", m, 6, sig_rate=0.1)
 TC.write_ranges(d + "/genes.txt", chroms, bps, 2)
 open(d + "/drop.txt", "w").write("snp3 snp77\nsnp200\nnone_such\n")
+TC.add_a1_column(d + "/a.txt", d + "/a1.txt", 3)
 runs = [
     (["--bfile", "d", "--clump", "cols=+ref,+alt1,+alt,+bounds,+f,+a1", "a.txt", "b.txt", "--clump-unphased", "--clump-kb", "0.001", "--clump-bins", "1e-5,0.001", "0.2",
       "--clump-range", "genes.txt", "--clump-range-border", "3"], 0),
     (["--pfile", "d", "--clump", "cols=sp2", "a.txt", "--clump-unphased", "--clump-kb", "0.001", "--clump-log10", "output-only", "--clump-p1", "0.3", "--clump-p2", "1e-7"], 0),
     (["--bfile", "d", "--chr", "1,X", "--exclude", "drop.txt", "--indep-pairwise", "50", "5", "0.2", "--bad-ld", "--dry-run"], 0),
+    (["--bfile", "d", "--clump", "zs", "cols=+a1,+bounds", "a1.txt", "--clump-unphased", "--clump-kb", "0.001", "--clump-force-a1", "--clump-p1", "0.05", "--clump-p2", "1e-4"], 0),
     (["--bfile", "d", "--r-unphased", "cols=+nope"], 8),
     (["--bfile", "d", "--r2-unphased", "square", "--ld-window-cm", "1"], 8),
     (["--bfile", "d", "--clump", "a.txt", "cols=+f", "--clump-unphased"], 8),
