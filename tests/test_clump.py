@@ -330,6 +330,35 @@ def test_clump_zs_outputs_decompress_to_the_reference_text(cli, tmp_path):
         assert len(a) > 50 and a == b, ext
 
 
+@needs_ref
+@pytest.mark.parametrize("storage", [1, 2, 3])
+def test_provisional_ref_column_follows_the_pgen_header(cli, pkg, tmp_path, storage):
+    """PROVISIONAL_REF? ('maybeprovref' with a REF column): the .pgen header says none / all / these (control bits 6-7 and the
+    flag array behind the header, pgen_spec.tex:196-206) -- through the reader's ldp_pgen_provisional_ref and the column writer."""
+    m = 300
+    prefix, raw, chroms, bps = clump_fileset(tmp_path, m, 40, 6)
+    rng = np.random.default_rng(storage)
+    flags = rng.random(m) < 0.3
+    data = open(prefix + ".pgen", "rb").read()
+    assert data[:3] == bytes([0x6C, 0x1B, 0x02]) and data[11] == 0x40
+    body = data[12:]
+    bits = np.packbits(flags, bitorder="little").tobytes() if storage == 3 else b""
+    open(prefix + ".pgen", "wb").write(data[:11] + bytes([storage << 6]) + bits + body)
+    write_report(str(tmp_path / "assoc.txt"), m, 2)
+    f = pkg.PgenFile(prefix + ".pgen")
+    got_bits = np.zeros((m + 7) // 8, dtype=np.uint8)
+    import ctypes
+    L = pkg.lib()
+    L.ldp_pgen_provisional_ref.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_uint64]
+    assert L.ldp_pgen_provisional_ref(f._h, got_bits.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), len(got_bits)) == storage
+    if storage == 3:
+        assert np.array_equal(np.unpackbits(got_bits, bitorder="little")[:m].astype(bool), flags)
+    f.close()
+    compare_runs(cli, tmp_path, ["--pfile", "d", "--clump", "cols=+ref", "assoc.txt", "--clump-unphased", "--clump-kb", "0.001", "--clump-p1", "0.05"])
+    hdr = open(str(tmp_path / "hip.clumps")).readline()
+    assert ("PROVISIONAL_REF?" in hdr) == (storage != 1)
+
+
 def test_clump_flag_rules(cli, tmp_path):
     clump_fileset(tmp_path, 60, 20, 3)
     write_report(str(tmp_path / "a.txt"), 60, 1)
