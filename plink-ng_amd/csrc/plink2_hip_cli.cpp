@@ -1286,7 +1286,8 @@ struct Variants {
   std::vector<uint32_t> bp;
   std::vector<uint8_t> alt_ct;  // number of ALT alleles (1 for biallelic / .bim), capped at 255
   std::vector<std::string> ref, alt;  // allele text (ALT comma-separated as in the file); only kept for --r2-unphased allele columns
-  bool info_pr_header = false;        // the .pvar declares INFO/PR (provisional REF alleles are flagged per variant there)
+  bool info_pr_header = false;        // the .pvar declares INFO/PR as a flag (provisional REF alleles are marked per variant there)
+  std::vector<uint8_t> info_pr;       // bit v: variant v's INFO carries PR (PrInInfo, plink2_pvar.cc:561); kept when a REF column is printed
   std::vector<double> cm;             // centimorgan positions; only kept for --ld-window-cm (empty when the file has no CM column)
   bool cm_unsorted = false;           // some chromosome's CM values decrease (LoadPvar, plink2_pvar.cc:2121-2134)
   bool cm_any_nonzero = false;
@@ -1402,7 +1403,8 @@ void load_variants(const Args& A, Variants* V) {
   const bool zst = (path.size() > 4) && (path.compare(path.size() - 4, 4, ".zst") == 0);
   const std::string buf = zst ? slurp_zst(path) : slurp(path);
   bool header = false;
-  int c_chrom = 0, c_pos = 3, c_id = 1, c_alt = -1, c_ref = -1, c_cm = -1;
+  int c_chrom = 0, c_pos = 3, c_id = 1, c_alt = -1, c_ref = -1, c_cm = -1, c_info = -1;
+  const bool keep_pr = (A.have_r2 && (A.r2_cols & kVcorColRef)) || (A.have_clump && (A.clump_cols & kClumpColRef));
   const bool keep_cm = A.have_r2 && (A.ld_cm_radius != -1.0);
   double last_cm = -1.7976931348623157e308;
   std::string last_cm_chrom;
@@ -1437,13 +1439,17 @@ void load_variants(const Args& A, Variants* V) {
           if (t[c].eq("ALT")) c_alt = c;
           if (t[c].eq("REF")) c_ref = c;
           if (t[c].eq("CM")) c_cm = c;
+          if (t[c].eq("INFO")) c_info = c;
         }
         if (c_pos < 0 || c_id < 0) {
           die(6, "Error: %s header lacks POS/ID.\n", path.c_str());
         }
         header = true;
       } else if ((eol - line) >= 14 && !memcmp(line, "##INFO=<ID=PR,", 14)) {
-        V->info_pr_header = true;
+        // (only a Flag definition counts, plink2_pvar.cc:1254-1259)
+        const std::string hl(line, static_cast<size_t>(eol - line));
+        const size_t tp = hl.find("Type=");
+        V->info_pr_header = (tp != std::string::npos) && (hl.compare(tp + 5, 4, "Flag") == 0) && ((tp + 9 >= hl.size()) || (hl[tp + 9] == ',') || (hl[tp + 9] == '>'));
       }
       continue;
     }
@@ -1502,6 +1508,18 @@ void load_variants(const Args& A, Variants* V) {
         }
       }
       V->cm.push_back(cur_cm);
+    }
+    if (keep_pr && V->info_pr_header && header && (c_info >= 0) && (c_info < std::min(nt, kCap))) {
+      const std::string info(t[c_info].p, t[c_info].n);
+      const bool pr = (info == "PR") || (info.compare(0, 3, "PR;") == 0) || ((info.size() >= 3) && (info.compare(info.size() - 3, 3, ";PR") == 0)) ||
+                      (info.find(";PR;") != std::string::npos);
+      const size_t vi = V->chrom.size();
+      if (pr) {
+        if (V->info_pr.size() <= (vi >> 3)) {
+          V->info_pr.resize((vi >> 3) + 1024, 0);
+        }
+        V->info_pr[vi >> 3] |= static_cast<uint8_t>(1u << (vi & 7));
+      }
     }
     V->chrom.emplace_back(t[c_chrom].p, t[c_chrom].n);
     V->id.emplace_back(t[c_id].p, t[c_id].n);
@@ -2776,9 +2794,7 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
   const size_t bin_bound_ct = D.ln_bins.size();
   bool provref_col = false;
   if (cols & kClumpColRef) {  // ProvrefCol (plink2_common.h:1549)
-    if ((SX.prov_storage == 0) && V.info_pr_header && (cols & (kClumpColProvref | kClumpColMaybeprovref))) {
-      die(63, "Error: provisional-REF flags kept in the .pvar's INFO/PR are not supported by plink2-hip (--clump 'ref' column).\n");
-    }
+
     if (cols & kClumpColProvref) {
       provref_col = true;
     } else if (cols & kClumpColMaybeprovref) {
@@ -3706,9 +3722,10 @@ struct VcorColumns {
     cols = A.r2_cols;
     if (cols & kVcorColRef) {  // ProvrefCol (plink2_common.h:1549): 'provref' always, 'maybeprovref' when some included variant is flagged
       prov_bits.assign((static_cast<size_t>(raw_variant_ct) + 7) / 8, 0);
-      const int storage = ldp_pgen_provisional_ref(pg, prov_bits.data(), prov_bits.size());
-      if ((storage == 0) && V.info_pr_header && (cols & (kVcorColProvref | kVcorColMaybeprovref))) {
-        die(63, "Error: provisional-REF flags kept in the .pvar's INFO/PR are not supported by plink2-hip (--r2-unphased 'ref' column).\n");
+      int storage = ldp_pgen_provisional_ref(pg, prov_bits.data(), prov_bits.size());
+      if ((storage == 0) && V.info_pr_header) {  // the .pgen leaves it to the .pvar's INFO/PR
+        storage = 3;
+        std::copy(V.info_pr.begin(), V.info_pr.begin() + std::min(V.info_pr.size(), prov_bits.size()), prov_bits.begin());
       }
       prov_all = (storage == 2);
       if (cols & kVcorColProvref) {
@@ -4408,6 +4425,10 @@ int run_r2(Session& S) {
     }
     SX.prov_bits.assign((static_cast<size_t>(raw_variant_ct) + 7) / 8, 0);
     SX.prov_storage = ldp_pgen_provisional_ref(pg, SX.prov_bits.data(), SX.prov_bits.size());
+    if ((SX.prov_storage == 0) && V.info_pr_header) {  // the .pgen leaves it to the .pvar's INFO/PR
+      SX.prov_storage = 3;
+      std::copy(V.info_pr.begin(), V.info_pr.begin() + std::min(V.info_pr.size(), SX.prov_bits.size()), SX.prov_bits.begin());
+    }
     SX.feed_cols = feed_rows_cols;
     SX.females_missing = females_missing;
     const int rc = clump_reports(A, V, inc, chr_idx, bps, founder_ct, feed_rows, SX);

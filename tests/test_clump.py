@@ -359,6 +359,30 @@ def test_provisional_ref_column_follows_the_pgen_header(cli, pkg, tmp_path, stor
     assert ("PROVISIONAL_REF?" in hdr) == (storage != 1)
 
 
+@needs_ref
+@pytest.mark.parametrize("with_header", [True, False])
+def test_provisional_ref_column_from_the_pvar_info(cli, tmp_path, with_header):
+    """A .pgen that leaves the provisional-REF flags to the .pvar (control bits 6-7 = 0): INFO/PR marks the variants -- PR alone, first,
+    last, or in the middle of the INFO keys (PrInInfo, plink2_pvar.cc:561) -- when the header declares the flag."""
+    m = 300
+    prefix, raw, chroms, bps = clump_fileset(tmp_path, m, 40, 7)
+    data = open(prefix + ".pgen", "rb").read()
+    open(prefix + ".pgen", "wb").write(data[:11] + bytes([0x00]) + data[12:])
+    rng = np.random.default_rng(9)
+    infos = ["PR", "PR;AC=3", "AC=3;PR", "AC=3;PR;DP=9", "AC=3", ".", "APR;DP=2", "DP=2;PRX", "XPR"]
+    lines = open(prefix + ".pvar").read().splitlines()
+    out = ['##INFO=<ID=PR,Number=0,Type=Flag,Description="Provisional reference allele, may not be based on real reference genome">'] if with_header else []
+    out.append(lines[0] + "\tQUAL\tFILTER\tINFO")
+    for ln in lines[1:]:
+        out.append(ln + "\t.\t.\t" + infos[int(rng.integers(len(infos)))])
+    open(prefix + ".pvar", "w").write("\n".join(out) + "\n")
+    write_report(str(tmp_path / "assoc.txt"), m, 3)
+    for mods in (["cols=+ref"], ["cols=+ref,+provref"]):
+        compare_runs(cli, tmp_path, ["--pfile", "d", "--clump"] + mods + ["assoc.txt", "--clump-unphased", "--clump-kb", "0.001", "--clump-p1", "0.05"])
+    body = open(str(tmp_path / "hip.clumps")).read()
+    assert ("\tY\t" in body) == with_header
+
+
 def test_clump_flag_rules(cli, tmp_path):
     clump_fileset(tmp_path, 60, 20, 3)
     write_report(str(tmp_path / "a.txt"), 60, 1)
