@@ -438,6 +438,7 @@ struct Args {
   bool clump_allow_overlap = false;
   bool clump_no_test = false;
   std::vector<std::string> clump_id_field, clump_p_field, clump_test_field, clump_test;
+  bool make_founders = false, make_founders_require2 = false, make_founders_first = false;  // --make-founders ['require-2-missing'] ['first']
   bool clump_zs = false;
   bool clump_force_a1 = false, clump_no_a1 = false;  // --clump-force-a1; --clump-a1-field without names
   std::vector<std::string> clump_a1_field;
@@ -797,6 +798,18 @@ Args parse_args(int argc, char** argv) {
       A.clump_unphased = true;
     } else if (f == "--clump-allow-overlap") {
       A.clump_allow_overlap = true;
+    } else if (f == "--make-founders") {  // plink2.cc:9555-9575
+      A.make_founders = true;
+      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+        const std::string v = argv[++i];
+        if (v == "require-2-missing") {
+          A.make_founders_require2 = true;
+        } else if (v == "first") {
+          A.make_founders_first = true;
+        } else {
+          die(8, "Error: Invalid --make-founders argument '%s'.\n", v.c_str());
+        }
+      }
     } else if (f == "--clump-force-a1") {  // plink2.cc:5200-5210
       A.clump_force_a1 = true;
     } else if (f == "--clump-a1-field") {  // plink2.cc:5059-5071
@@ -1213,7 +1226,8 @@ Args parse_args(int argc, char** argv) {
 
 // founder <=> PAT and MAT are both exactly "0" (plink2_psam.cc:804-806); absent columns => founder
 // sex: 1 = male, 2 = female, anything else = unknown (plink2_psam.cc:808-813)
-void load_samples(const Args& A, std::vector<uint8_t>* is_founder, std::vector<uint8_t>* sex, std::vector<std::string>* fid_iid = nullptr) {
+void load_samples(const Args& A, std::vector<uint8_t>* is_founder, std::vector<uint8_t>* sex, std::vector<std::string>* fid_iid = nullptr,
+                  std::vector<std::pair<std::string, std::string>>* parents = nullptr) {
   const bool psam = !A.psam.empty();
   const std::string& path = psam ? A.psam : A.fam;
   std::ifstream in(path);
@@ -1254,6 +1268,9 @@ void load_samples(const Args& A, std::vector<uint8_t>* is_founder, std::vector<u
       if (fid_iid) {
         fid_iid->push_back(t[0] + "\t" + t[1]);
       }
+      if (parents) {
+        parents->emplace_back(t[0] + "\t" + t[2], t[0] + "\t" + t[3]);
+      }
       const std::string& v = t[4];  // CharToSex on a one-character token (plink2_psam.cc:505-509), for .fam as for .psam
       sex->push_back((v == "1" || v == "M" || v == "m") ? 1 : ((v == "2" || v == "F" || v == "f") ? 2 : 0));
     } else {
@@ -1265,6 +1282,10 @@ void load_samples(const Args& A, std::vector<uint8_t>* is_founder, std::vector<u
         founder = (t[pat_col] == "0") && (t[mat_col] == "0");
       }
       is_founder->push_back(founder);
+      if (parents) {
+        const std::string fid = has_fid ? t[0] : std::string("0");
+        parents->emplace_back(fid + "\t" + ((pat_col >= 0) ? t[pat_col] : std::string("0")), fid + "\t" + ((mat_col >= 0) ? t[mat_col] : std::string("0")));
+      }
       if (fid_iid) {  // (no FID column: FID "0", as the reference keys its samples)
         if (static_cast<size_t>(iid_col) >= t.size()) {
           die(6, "Error: Fewer tokens than expected in %s.\n", path.c_str());
@@ -3218,7 +3239,39 @@ void load_inputs(Session& S, int argc, char** argv) {
   std::vector<uint8_t>& is_founder = S.is_founder;
   std::vector<std::string> sample_keys;
   const bool sample_filter = (!A.keep_files.empty()) || (!A.remove_files.empty());
-  load_samples(A, &S.is_founder, &S.sex, sample_filter ? &sample_keys : nullptr);
+  std::vector<std::pair<std::string, std::string>> parent_keys;
+  load_samples(A, &S.is_founder, &S.sex, (sample_filter || A.make_founders) ? &sample_keys : nullptr, A.make_founders ? &parent_keys : nullptr);
+  // --make-founders (MakeFounders, plink2_filter.cc:4372-4443): a non-founder with a parent (both, with 'require-2-missing') that
+  // is not among the samples in play becomes a founder; 'first' applies it before --keep / --remove, else after them
+  auto make_founders = [&](const std::vector<uint8_t>* included) {
+    std::unordered_set<std::string> present;
+    bool any_nonfounder = false;
+    for (size_t sx = 0; sx < sample_keys.size(); ++sx) {
+      if ((!included) || (*included)[sx]) {
+        present.insert(sample_keys[sx]);
+        any_nonfounder = any_nonfounder || !S.is_founder[sx];
+      }
+    }
+    if (!any_nonfounder) {
+      logprintf("Note: Skipping --make-founders since there are no nonfounders.\n");
+      return;
+    }
+    uint32_t affected = 0;
+    for (size_t sx = 0; sx < sample_keys.size(); ++sx) {
+      if (S.is_founder[sx] || (included && !(*included)[sx])) {
+        continue;
+      }
+      const uint32_t missing = (present.count(parent_keys[sx].first) ? 0u : 1u) + (present.count(parent_keys[sx].second) ? 0u : 1u);
+      if (missing > (A.make_founders_require2 ? 1u : 0u)) {
+        S.is_founder[sx] = 1;
+        ++affected;
+      }
+    }
+    logprintf("--make-founders: %u sample%s affected.\n", affected, (affected == 1) ? "" : "s");
+  };
+  if (A.make_founders && A.make_founders_first) {
+    make_founders(nullptr);
+  }
   if (sample_filter) {  // KeepOrRemove, plink2_filter.cc:1227-1261 (--keep first, then --remove, plink2.cc)
     std::vector<uint8_t> in(S.is_founder.size(), 1);
     for (int pass = 0; pass < 2; ++pass) {
@@ -3254,6 +3307,9 @@ void load_inputs(Session& S, int argc, char** argv) {
     if (std::find(in.begin(), in.end(), 1) == in.end()) {  // plink2.cc:1836-1838
       die(13, "Error: No samples remaining after main filters.\n");
     }
+  }
+  if (A.make_founders && !A.make_founders_first) {
+    make_founders(S.sample_kept.empty() ? nullptr : &S.sample_kept);
   }
   t_variants.join();
   S.t_parse = now_s() - t_begin;

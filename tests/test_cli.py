@@ -392,3 +392,37 @@ def test_cli_refuses_dosage_pgen(cli, tmp_path):
     assert cp.returncode == 0, cp.stdout
     out = run_cli(cli, ["--pfile", "hard", "--indep-pairwise", "50", "5", "0.2", "--dry-run", "--out", "o"], str(tmp_path))
     assert out.returncode == 0, out.stdout
+
+
+def test_make_founders_counts_match_reference(cli, tmp_path):
+    """--make-founders ['require-2-missing'] ['first'] (MakeFounders, plink2_filter.cc:4372-4443): which samples become founders,
+    judged by both binaries' own log lines (no GPU: --dry-run here, an unrelated cheap command there)."""
+    if not T.have_ref():
+        pytest.skip("oracle/_ref/plink2 not built")
+    m, n = 80, 70
+    raw = T.synth_raw_codes(m, n, seed=2)
+    T.write_bed(str(tmp_path / "d"), raw, ["1"] * m, np.arange(m) * 100 + 1)
+    rng = np.random.default_rng(5)
+    lines = []
+    for s_ in range(n):
+        kind = rng.integers(0, 5)
+        pat, mat = "0", "0"
+        if kind == 1:
+            pat, mat = "s%d" % rng.integers(0, n), "s%d" % rng.integers(0, n)      # both parents in the file
+        elif kind == 2:
+            pat, mat = "s%d" % rng.integers(0, n), "gone%d" % s_                    # one parent absent
+        elif kind == 3:
+            pat, mat = "gone%da" % s_, "gone%db" % s_                               # both absent
+        elif kind == 4:
+            pat, mat = "0", "s%d" % rng.integers(0, n)                              # one parent unknown
+        lines.append("s%d s%d %s %s 2 -9" % (s_, s_, pat, mat))
+    open(str(tmp_path / "d.fam"), "w").write("\n".join(lines) + "\n")
+    open(str(tmp_path / "keep.txt"), "w").write("".join("s%d s%d\n" % (k, k) for k in range(0, n, 2)))
+    for mods in ([], ["require-2-missing"], ["first"], ["require-2-missing", "first"]):
+        for flt in ([], ["--keep", "keep.txt"]):
+            ref = T.run_ref(["--bfile", "d"] + flt + ["--make-founders"] + mods + ["--freq", "--out", "ref"], str(tmp_path))
+            got = run_cli(cli, ["--bfile", "d"] + flt + ["--make-founders"] + mods + ["--indep-pairwise", "50", "5", "0.2", "--bad-ld", "--dry-run", "--out", "hip"], str(tmp_path))
+            assert ref.returncode == 0 and got.returncode == 0, (mods, flt, ref.stdout[-300:], got.stdout[-300:])
+            want = [l.strip() for l in ref.stdout.split("\n") if l.startswith("--make-founders:") or "Skipping --make-founders" in l]
+            have = [l.strip() for l in got.stdout.split("\n") if l.startswith("--make-founders:") or "Skipping --make-founders" in l]
+            assert want and want == have, (mods, flt, want, have)

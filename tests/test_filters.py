@@ -165,3 +165,21 @@ def test_filters_that_leave_nothing(gpu_pkg, cli, tmp_path):
     ref = T.run_ref(["--bfile", "d", "--keep", "nobody.txt"] + PRUNE + ["--out", "ref"], str(tmp_path))
     got = run_cli(cli, ["--bfile", "d", "--keep", "nobody.txt"] + PRUNE + ["--out", "hip"], str(tmp_path))
     assert ref.returncode == got.returncode == 13 and "No samples remaining after main filters" in got.stdout
+
+
+def test_make_founders_prune_matches_reference(gpu_pkg, cli, tmp_path):
+    """Samples whose parents are not in the file become founders: the prune then runs over them too."""
+    m, n = 400, 120
+    raw = T.synth_raw_codes(m, n, seed=9, missing_rate=0.02)
+    T.write_bed(str(tmp_path / "d"), raw, ["1"] * 200 + ["2"] * 200, np.concatenate([np.arange(200), np.arange(200)]) * 150 + 1)
+    lines = []
+    for s_ in range(n):
+        pat, mat = ("0", "0") if s_ % 3 else (("s%d" % ((s_ + 1) % n), "s%d" % ((s_ + 2) % n)) if s_ % 2 else ("gone", "s%d" % ((s_ + 5) % n)))
+        lines.append("s%d s%d %s %s 1 -9" % (s_, s_, pat, mat))
+    open(str(tmp_path / "d.fam"), "w").write("\n".join(lines) + "\n")
+    for mods in ([], ["require-2-missing"]):
+        common = ["--bfile", "d", "--make-founders"] + mods + ["--indep-pairwise", "30kb", "0.2"]
+        ref = T.run_ref(common + ["--out", "ref"], str(tmp_path))
+        got = run_cli(cli, common + ["--out", "hip"], str(tmp_path))
+        assert ref.returncode == 0 and got.returncode == 0, (ref.stdout[-300:], got.stdout[-300:])
+        assert filecmp.cmp(str(tmp_path / "ref.prune.in"), str(tmp_path / "hip.prune.in"), shallow=False), mods
