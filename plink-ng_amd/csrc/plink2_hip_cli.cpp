@@ -51,6 +51,7 @@ namespace {
 
 constexpr double kSmallEpsilon = 0.00000000000005684341886080801486968994140625;  // 2^-44
 FILE* g_log = nullptr;
+bool g_silent = false;       // --silent: the log file still gets every line, the terminal only errors
 bool g_r_unsquared = false;  // --r-unphased: the messages below name that flag where they say --r2-unphased
 
 // (--r-unphased shares every code path with --r2-unphased; the reference prints the flag actually given)
@@ -76,7 +77,9 @@ void logprintf(const char* fmt, ...) {
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
   name_the_flag(buf);
-  fputs(buf, stdout);
+  if (!g_silent) {
+    fputs(buf, stdout);
+  }
   if (g_log) {
     fputs(buf, g_log);
   }
@@ -798,6 +801,8 @@ Args parse_args(int argc, char** argv) {
       A.clump_unphased = true;
     } else if (f == "--clump-allow-overlap") {
       A.clump_allow_overlap = true;
+    } else if (f == "--silent") {
+      g_silent = true;
     } else if (f == "--make-founders") {  // plink2.cc:9555-9575
       A.make_founders = true;
       while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
