@@ -429,6 +429,7 @@ struct Args {
   // reference enforces them (EnforceFreqConstraints plink2_filter.cc:3791, EnforceGenoThresh :3498); 0 / 1 / 1 = not given
   double min_maf = 0.0, max_maf = 1.0, geno = 1.0;
   uint32_t max_alleles = 0xffffffffu;  // --max-alleles N (applied while the variant table loads, LoadPvar)
+  bool snps_only = false, snps_only_acgt = false;  // --snps-only ['just-acgt'] (another load-time filter)
   std::vector<std::string> extract_files, exclude_files, keep_files, remove_files;
   // --ld-snp / --ld-snps / --ld-snp-list (plink2.cc:7966-8003): the table's row variants.  ld_snps: (first, second) ID pairs,
   // second empty for a single ID, otherwise the range first..second in file order
@@ -801,6 +802,15 @@ Args parse_args(int argc, char** argv) {
       A.clump_unphased = true;
     } else if (f == "--clump-allow-overlap") {
       A.clump_allow_overlap = true;
+    } else if (f == "--snps-only") {  // plink2.cc:11437-11453
+      A.snps_only = true;
+      if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+        const std::string v = argv[++i];
+        if (v != "just-acgt") {
+          die(8, "Error: Invalid --snps-only argument '%s'.\n", v.c_str());
+        }
+        A.snps_only_acgt = true;
+      }
     } else if (f == "--silent") {
       g_silent = true;
     } else if (f == "--make-founders") {  // plink2.cc:9555-9575
@@ -1311,6 +1321,7 @@ struct Variants {
   std::vector<std::string> chrom, id;
   std::vector<uint32_t> bp;
   std::vector<uint8_t> alt_ct;  // number of ALT alleles (1 for biallelic / .bim), capped at 255
+  std::vector<uint8_t> not_snp; // --snps-only: an allele longer than one character (or, with 'just-acgt', outside ACGT / missing)
   std::vector<std::string> ref, alt;  // allele text (ALT comma-separated as in the file); only kept for --r2-unphased allele columns
   bool info_pr_header = false;        // the .pvar declares INFO/PR as a flag (provisional REF alleles are marked per variant there)
   std::vector<uint8_t> info_pr;       // bit v: variant v's INFO carries PR (PrInInfo, plink2_pvar.cc:561); kept when a REF column is printed
@@ -1502,6 +1513,18 @@ void load_variants(const Args& A, Variants* V) {
       die(63, "Error: variant '%.*s' has more than 254 ALT alleles, which plink2-hip does not support.\n", static_cast<int>(t[c_id].n), t[c_id].p);
     }
     V->alt_ct.push_back(static_cast<uint8_t>(alts));
+    if (A.snps_only) {  // LoadPvar, plink2_pvar.cc:1917-1932
+      const int k_ref = header ? c_ref : ((nt == 5) ? 4 : 5), k_alt = header ? c_alt : ((nt == 5) ? 3 : 4);
+      bool snp = (k_ref >= 0) && (k_alt >= 0) && (std::max(k_ref, k_alt) < std::min(nt, kCap)) && (t[k_ref].n == 1) && (t[k_alt].n == 2 * (alts - 1) + 1);
+      if (snp && A.snps_only_acgt) {
+        auto acgtm = [](char ch) { return (ch == 'A') || (ch == 'C') || (ch == 'G') || (ch == 'T') || (ch == 'a') || (ch == 'c') || (ch == 'g') || (ch == 't') || (ch == '.'); };
+        snp = acgtm(t[k_ref].p[0]);
+        for (uint32_t a = 0; snp && (a < alts); ++a) {
+          snp = acgtm(t[k_alt].p[2 * a]);
+        }
+      }
+      V->not_snp.push_back(snp ? 0 : 1);
+    }
     if (keep_alleles) {
       // .bim: ... A1 A2 with A1 -> ALT, A2 -> REF (LoadPvar, plink2_pvar.cc:1434-1450)
       const int k_ref = header ? c_ref : ((nt == 5) ? 4 : 5), k_alt = header ? c_alt : ((nt == 5) ? 3 : 4);
@@ -3402,7 +3425,7 @@ void load_inputs(Session& S, int argc, char** argv) {
       if (it->second || ((!A.extract_files.empty()) && !extract_ids.count(V.id[v])) || ((!A.exclude_files.empty()) && exclude_ids.count(V.id[v]))) {
         continue;
       }
-      if (static_cast<uint32_t>(V.alt_ct[v]) + 1 > A.max_alleles) {
+      if ((static_cast<uint32_t>(V.alt_ct[v]) + 1 > A.max_alleles) || (A.snps_only && V.not_snp[v])) {
         continue;
       }
       if (V.alt_ct[v] > 1) {
@@ -3529,7 +3552,7 @@ void load_inputs(Session& S, int argc, char** argv) {
                     (A.autosome && !((code >= 1) && (code <= 22)));
         }
       }
-      if (chr_out || (static_cast<uint32_t>(V.alt_ct[v]) + 1 > A.max_alleles)) {
+      if (chr_out || ((static_cast<uint32_t>(V.alt_ct[v]) + 1 > A.max_alleles) || (A.snps_only && V.not_snp[v]))) {
         continue;
       }
       if ((!A.extract_files.empty()) && !extract_ids.count(V.id[v])) {
@@ -3567,7 +3590,7 @@ void load_inputs(Session& S, int argc, char** argv) {
   }
   // filters applied while the variant table loads (--autosome / --chr / --not-chr / --max-alleles) that leave nothing:
   // plink2.cc:1025-1050, kPglRetInconsistentInput, flag names in kLoadFilterLogFlagnames order
-  if ((chr_filter || (A.max_alleles != 0xffffffffu)) && raw_variant_ct) {
+  if ((chr_filter || (A.max_alleles != 0xffffffffu) || A.snps_only) && raw_variant_ct) {
     bool any_loaded = false;
     std::unordered_map<std::string, uint8_t> chr_state;
     for (uint32_t v = 0; (v < raw_variant_ct) && !any_loaded; ++v) {
@@ -3579,12 +3602,12 @@ void load_inputs(Session& S, int argc, char** argv) {
                                          (A.autosome && !((code >= 1) && (code <= 22))));
         it = chr_state.emplace(cur, static_cast<uint8_t>(out)).first;
       }
-      any_loaded = (!it->second) && (static_cast<uint32_t>(V.alt_ct[v]) + 1 <= A.max_alleles);
+      any_loaded = (!it->second) && (static_cast<uint32_t>(V.alt_ct[v]) + 1 <= A.max_alleles) && !(A.snps_only && V.not_snp[v]);
     }
     if (!any_loaded) {
       std::string flags;
       for (const char* nm : {A.autosome ? "autosome" : "", A.chr_keep.empty() ? "" : "chr", A.chr_drop.empty() ? "" : "not-chr",
-                             (A.max_alleles != 0xffffffffu) ? "max-alleles" : ""}) {
+                             (A.max_alleles != 0xffffffffu) ? "max-alleles" : "", A.snps_only ? "snps-only" : ""}) {
         if (*nm) {
           flags += (flags.empty() ? "--" : " + --");
           flags += nm;
@@ -3593,7 +3616,7 @@ void load_inputs(Session& S, int argc, char** argv) {
       die(7, "Error: All %u variant%s in %s excluded by %s.\n", raw_variant_ct, (raw_variant_ct == 1) ? "" : "s", (A.pvar.empty() ? A.bim : A.pvar).c_str(), flags.c_str());
     }
   }
-  const bool any_main_filter = chr_filter || (!A.extract_files.empty()) || (!A.exclude_files.empty()) || (!drop_by_counts.empty()) || (A.max_alleles != 0xffffffffu);
+  const bool any_main_filter = chr_filter || (!A.extract_files.empty()) || (!A.exclude_files.empty()) || (!drop_by_counts.empty()) || (A.max_alleles != 0xffffffffu) || A.snps_only;
   if (any_main_filter && inc.empty() && (!skipped)) {  // plink2.cc:2484-2487 (kPglRetDegenerateData)
     die(13, "Error: No variants remaining after main filters.\n");
   }

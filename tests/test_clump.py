@@ -383,6 +383,23 @@ def test_provisional_ref_column_from_the_pvar_info(cli, tmp_path, with_header):
     assert ("\tY\t" in body) == with_header
 
 
+@needs_ref
+@pytest.mark.parametrize("mods", [[], ["just-acgt"]])
+def test_snps_only_in_front_of_the_command(cli, tmp_path, mods):
+    """--snps-only ['just-acgt'] drops variants while the table loads (LoadPvar, plink2_pvar.cc:1917-1932): seen here through
+    --clump, whose report then names IDs the dataset no longer has."""
+    m = 400
+    prefix, raw, chroms, bps = clump_fileset(tmp_path, m, 40, 12)
+    rng = np.random.default_rng(1)
+    rows = [ln.split("\t") for ln in open(prefix + ".bim").read().splitlines()]
+    for r_ in rows:
+        r_[4], r_[5] = [("C", "A"), ("CT", "A"), ("C", "AG"), ("N", "A"), ("c", "t"), (".", "G"), ("<DEL>", "A"), ("*", "T")][int(rng.choice(8, p=[0.6, 0.07, 0.07, 0.06, 0.05, 0.05, 0.05, 0.05]))]
+    open(prefix + ".bim", "w").write("\n".join("\t".join(r_) for r_ in rows) + "\n")
+    write_report(str(tmp_path / "assoc.txt"), m, 13)
+    compare_runs(cli, tmp_path, ["--bfile", "d", "--snps-only"] + mods + ["--clump", "assoc.txt", "--clump-unphased", "--clump-kb", "0.001", "--clump-p1", "0.01"])
+    assert os.path.getsize(str(tmp_path / "hip.clumps.missing_id")) > 0
+
+
 def test_clump_flag_rules(cli, tmp_path):
     clump_fileset(tmp_path, 60, 20, 3)
     write_report(str(tmp_path / "a.txt"), 60, 1)
