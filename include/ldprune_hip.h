@@ -131,6 +131,13 @@ typedef struct {
   uint64_t mfma_skipped_product_stages; /* ... and how much of it early termination skipped in the last run */
   double ms_pair_mfma_general;     /* device time of pair_mfma_general_kernel (matrix-pipe tiles with missing calls) */
   uint64_t sparse_exact_pairs;     /* few missing calls: pairs the interval test left open and the kernel resolved exactly */
+  /* Which matrix-pipe kernel the device-side route gave the pair launches of the last run (one word per launch group, written by
+   * route_kernel from the rows' missing-call totals): complete data -> pair_mfma_kernel, a few missing calls -> its interval
+   * epilogue, otherwise the six-product kernel.  All zero when the popcount kernels own the run. */
+  uint32_t route_complete_launches;
+  uint32_t route_sparse_launches;
+  uint32_t route_general_launches;
+  uint32_t reserved0;
 } ldp_counters;
 
 /* ---- lifecycle ---- */
@@ -139,6 +146,9 @@ void ldp_destroy(ldp_engine* e);
 const char* ldp_last_error(const ldp_engine* e);
 /* number of usable HIP devices (0 when there is none); never fails */
 int ldp_device_count(void);
+/* Largest founder_ct whose pair statistics run on the matrix pipe (FP4 operands, f32 accumulators that hold the integers
+ * exactly); larger jobs run on the popcount kernels.  Same results either way. */
+uint32_t ldp_matrix_pipe_max_founders(void);
 
 /* ---- planning (host only; usable without a GPU) ---- */
 /* variant_ct included variants in file order with chr0/unplaced already stripped (StripUnplacedK,
@@ -203,6 +213,13 @@ int ldp_pair_stats(ldp_engine* e, uint32_t n_pairs, const uint32_t* first, const
  * touched: this is how the host logic is tested on a CPU-only machine. */
 int ldp_debug_set_variant_recs(ldp_engine* e, const ldp_variant_rec* recs);
 int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first, const uint32_t* second, uint64_t* removed);
+/* Kernel-selection switches of ONE engine, for tests and measurements (the defaults are what production runs use; they can also
+ * be preset from the environment at ldp_create(): LDP_EARLY_EXIT, LDP_PAIR_MFMA, LDP_PAIR_MFMA_GENERAL, LDP_PAIR_SPARSE,
+ * LDP_DEBUG_SPARSE_FRAC).  name: "early_exit" (0/1: checkpoints that drop provably sub-threshold products), "pair_mfma" (0/1:
+ * matrix-pipe kernels; 0 = the popcount kernels -- set before ldp_set_variants*()), "mfma_general" (0/1: rows with missing calls
+ * on the matrix pipe), "pair_sparse" (0/1: the interval epilogue for rows with a few missing calls), "sparse_frac" (mean
+ * missing fraction up to which a launch takes it).  Results never depend on these.  Unknown name: LDP_ERR_INVALID. */
+int ldp_debug_set_option(ldp_engine* e, const char* name, double value);
 /* Host-only view of the matrix-pipe work plan (csrc/ldp_device.h: MfmaWG) in the engine's shard-local variant
  * indices, for the CPU test that every candidate pair is owned by exactly one 32 x 32 block product.  Per workgroup
  * 63 words: n_rb, j_lo, j_hi, rb[16], then per wave jv, vv, jend, prod_mask, slot[7].  lo_local (optional, *local_ct

@@ -67,7 +67,9 @@ class ldp_counters(ctypes.Structure):
                 ("tile_unit_chunks", ctypes.c_uint64), ("early_exit_unit_chunks", ctypes.c_uint64),
                 ("ms_pair_mfma", ctypes.c_double), ("mfma_block_products", ctypes.c_uint64),
                 ("mfma_product_stages", ctypes.c_uint64), ("mfma_skipped_product_stages", ctypes.c_uint64),
-                ("ms_pair_mfma_general", ctypes.c_double), ("sparse_exact_pairs", ctypes.c_uint64)]
+                ("ms_pair_mfma_general", ctypes.c_double), ("sparse_exact_pairs", ctypes.c_uint64),
+                ("route_complete_launches", ctypes.c_uint32), ("route_sparse_launches", ctypes.c_uint32),
+                ("route_general_launches", ctypes.c_uint32), ("reserved0", ctypes.c_uint32)]
 
     def asdict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
@@ -87,6 +89,7 @@ CABI_SYMBOLS = [
     "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_r2_unphased_hits", "ldp_r2_unphased_block", "ldp_r2_unphased_block_hits", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_has_dosage", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
     "ldp_pgen_variant_is_multiallelic", "ldp_pgen_provisional_ref", "ldp_pgen_open_indexed", "ldp_set_r_signed", "ldp_set_variants_vcor_cm", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_subset_samples", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
+    "ldp_debug_set_option", "ldp_matrix_pipe_max_founders",
 ]
 
 
@@ -168,6 +171,9 @@ def lib():
     L.ldp_pair_stats.argtypes = [vp, ctypes.c_uint32, u32p, u32p, vp]
     L.ldp_debug_set_variant_recs.argtypes = [vp, vp]
     L.ldp_debug_replay_pairs.argtypes = [vp, ctypes.c_uint64, u32p, u32p, u64p]
+    L.ldp_matrix_pipe_max_founders.argtypes = []
+    L.ldp_matrix_pipe_max_founders.restype = ctypes.c_uint32
+    L.ldp_debug_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_double]
     L.ldp_debug_mfma_plan.argtypes = [vp, u32p, u32p, ctypes.c_uint64, u32p, u32p]
     L.ldp_get_variant_recs.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp]
     L.ldp_get_maj_freqs.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, f64p]
@@ -207,6 +213,11 @@ def lib():
     L.ldp_pgen_close.restype = None
     _lib = L
     return L
+
+
+def matrix_pipe_max_founders():
+    """Largest founder_ct the matrix-pipe kernels take (f32 accumulators integer-exact); beyond it the popcount kernels run."""
+    return int(lib().ldp_matrix_pipe_max_founders())
 
 
 def device_count():
@@ -391,6 +402,12 @@ class LdPruneEngine:
     def _ck(self, rc):
         if rc != LDP_OK:
             raise LdpError(rc, self._L.ldp_last_error(self._h).decode())
+
+    def set_option(self, name, value):
+        """Kernel-selection switch of this engine (ldp_debug_set_option): 'early_exit', 'pair_mfma' (before set_variants),
+        'mfma_general', 'pair_sparse', 'sparse_frac'.  Results never depend on them."""
+        self._ck(self._L.ldp_debug_set_option(self._h, name.encode(), float(value)))
+        return self
 
     # ---- planning
     def set_variants(self, chr_idx, bps=None):

@@ -146,9 +146,8 @@ struct PairKernelArgs {
 
 constexpr uint32_t kRouteComplete = 0, kRouteSparse = 1, kRouteGeneral = 2;
 
-// What prepare_kernel records about missing calls, per load epoch: the largest count in a row, and striped over
-// kMissStripes words (by variant index; one atomic per row with missing calls) the total of missing calls and the number
-// of rows beyond `miss_high` of them.
+// What the rows a launch reads miss (miss_stats_kernel over their records, when the launch is queued): the largest count in a
+// row, and striped over kMissStripes words the total of missing calls and the number of rows beyond `miss_high` of them.
 constexpr uint32_t kMissStripes = 64;
 struct MissStats {
   uint32_t max_missing;
@@ -158,6 +157,8 @@ struct MissStats {
 };
 // *route_out = kRouteComplete when no row had a missing call, kRouteSparse when the total is at most total_limit and the
 // high rows at most high_limit (both 0: never), else kRouteGeneral
+// adds the missing calls of recs[0, n) to *stats (block reductions, a handful of atomics)
+hipError_t launch_miss_stats(const ldp_variant_rec* recs, uint32_t n, uint32_t founder_ct, uint32_t miss_high, MissStats* stats, hipStream_t stream);
 hipError_t launch_route(const MissStats* stats, unsigned long long total_limit, unsigned long long high_limit, int allow_sparse, uint32_t* route_out,
                         hipStream_t stream);
 
@@ -195,8 +196,7 @@ hipError_t launch_pair_stats_ref(const uint32_t* planes, uint64_t row_dwords, ui
 size_t pair_tiles_lds_bytes(uint32_t max_rows);
 // ev[0..2] (optional): recorded before the complete-data kernel, between it and the missing-calls kernel, and after
 hipError_t launch_pair_mfma(const PairKernelArgs& a, hipStream_t stream, hipEvent_t* ev);
-uint32_t pair_mfma_ksteps(uint32_t founder_ct);
-bool pair_mfma_general_enabled();  // missing-calls tiles on the matrix pipe too (else: popcount kernels)  // 64-sample k-steps per row (the unit of counters[2])
+uint32_t pair_mfma_ksteps(uint32_t founder_ct);  // 64-sample k-steps per row (the unit of counters[2])
 
 // LDS rows of a work item that stages `units` 8-distance units starting at distance d0 (make_geom in the kernel)
 inline uint32_t tile_rows(uint32_t d0, uint32_t units) {

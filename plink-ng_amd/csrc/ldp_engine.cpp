@@ -72,8 +72,18 @@ void parallel_for(uint32_t n, uint32_t max_threads, F fn) {
 
 constexpr int kPairStreams = 1;
 
+// Kernel-selection switches of one engine.  Defaults come from the environment when the engine is created (tuning from a
+// shell); ldp_debug_set_option() overrides them per engine, which is what the tests use -- no process-global state.
+struct EngineOptions {
+  bool early_exit = true;     // LDP_EARLY_EXIT=0: exhaustive pair kernels
+  bool pair_mfma = true;      // LDP_PAIR_MFMA=0: popcount kernels instead of the matrix pipe
+  bool mfma_general = true;   // LDP_PAIR_MFMA_GENERAL=0: rows with missing calls go to the popcount kernel
+  double sparse_frac = 0.005; // LDP_PAIR_SPARSE=0 -> 0; LDP_DEBUG_SPARSE_FRAC
+};
+
 struct ldp_engine {
   ldp_params P;
+  EngineOptions opt;
   int device = -1;
   bool gpu_ok = false;
   bool gpu_probed = false;  // bind_gpu() ran (it runs at the first device use, not in ldp_create)
@@ -154,7 +164,7 @@ struct ldp_engine {
   cp_slot* d_cp_stats = nullptr;           // per-variant checkpoint statistics (early termination)
   cp_gen_slot* d_cp_gen = nullptr;         // ... for tiles with missing calls
   MfmaWG* d_mf_wgs = nullptr;
-  MissStats* d_miss_stats = nullptr;       // missing calls of the rows converted in this load epoch (prepare_kernel)
+  MissStats* d_miss_stats = nullptr;       // [slot of d_route]: missing calls of the resident rows a launch reads (summed from the records when the launch is queued)
   uint32_t* d_route = nullptr;             // [g]: which matrix-pipe kernel owns launch group g (route_kernel, when the group is queued); [groups]: other launches
   uint32_t checkpoint_chunk[kCheckpoints];
   uint32_t n_checkpoints = 0;
@@ -225,6 +235,33 @@ int hipfail(ldp_engine* e, hipError_t rc, const char* what) {
 
 constexpr uint32_t kStageSlots = 3;
 constexpr size_t kStageBytes = 64ull << 20;
+
+// timing events of one launch, released on every exit path
+template <int N>
+struct EventSet {
+  hipEvent_t ev[N];
+  EventSet() {
+    for (hipEvent_t& x : ev) {
+      x = nullptr;
+    }
+  }
+  ~EventSet() {
+    for (hipEvent_t x : ev) {
+      if (x) {
+        (void)hipEventDestroy(x);
+      }
+    }
+  }
+  hipError_t create() {
+    for (hipEvent_t& x : ev) {
+      const hipError_t rc = hipEventCreate(&x);
+      if (rc != hipSuccess) {
+        return rc;
+      }
+    }
+    return hipSuccess;
+  }
+};
 
 // temporary device allocation released on every exit path
 struct DevBuf {
@@ -452,9 +489,18 @@ void plan_subcontig(const ldp_engine* e, const Subcontig& s, std::vector<uint32_
 // ---- early termination planning (ldp_device.h) -----------------------------------------------------------
 // A pair of unrelated variants becomes provably hopeless once the unvisited share of the samples drops below
 // ~sqrt(thresh): checkpoint fractions start just past 1 - sqrt(thresh) and spread out from there.
-bool early_exit_requested() {
+EngineOptions options_from_env() {
+  EngineOptions o;
   const char* ee = getenv("LDP_EARLY_EXIT");
-  return !(ee && (strcmp(ee, "0") == 0));
+  o.early_exit = !(ee && (strcmp(ee, "0") == 0));
+  const char* m = getenv("LDP_PAIR_MFMA");
+  o.pair_mfma = !(m && (strcmp(m, "0") == 0));
+  const char* g = getenv("LDP_PAIR_MFMA_GENERAL");
+  o.mfma_general = !(g && (atoi(g) == 0));
+  const char* off = getenv("LDP_PAIR_SPARSE");
+  const char* f = getenv("LDP_DEBUG_SPARSE_FRAC");
+  o.sparse_frac = (off && (strcmp(off, "0") == 0)) ? 0.0 : (f ? atof(f) : 0.005);
+  return o;
 }
 
 int checkpoint_fractions(double r2_param, double* frac) {
@@ -491,22 +537,8 @@ int checkpoint_fractions(double r2_param, double* frac) {
 // epilogue: 0.5 % by default -- on the benchmark generator the pairs the intervals leave open cost as much as
 // the six-product kernel at 0.65 % (profiles/r02_experiments.md).  Rows with more than twice the fraction count as high rows,
 // and more than 2 % of those route the launch to the six-product kernel as well (their pairs are mostly open).
-// LDP_PAIR_SPARSE=0 turns the path off, LDP_DEBUG_SPARSE_FRAC sets the fraction (read per call, like LDP_EARLY_EXIT: the
-// tests switch it between engines of one process).
-double sparse_missing_fraction() {
-  const char* off = getenv("LDP_PAIR_SPARSE");
-  if (off && (strcmp(off, "0") == 0)) {
-    return 0.0;
-  }
-  const char* f = getenv("LDP_DEBUG_SPARSE_FRAC");
-  return f ? atof(f) : 0.005;
-}
-
-bool mfma_requested() {
-  const char* m = getenv("LDP_PAIR_MFMA");
-  return !(m && (strcmp(m, "0") == 0));
-}
-
+// ldp_debug_set_option("pair_sparse", 0) turns the path off, "sparse_frac" sets the fraction (defaults from LDP_PAIR_SPARSE /
+// LDP_DEBUG_SPARSE_FRAC at engine creation).
 // runs: (first local variant, length) of the row ranges blocks are aligned to (the owned subcontigs; one run over
 // everything for the all-pairs plan of --r2-unphased); lo: window start per local variant (nullptr: 0, every earlier
 // variant is a partner); only second variants in [j_first, j_end) get products (a row chunk of an r^2 matrix).
@@ -771,7 +803,7 @@ void build_shard(ldp_engine* e) {
     }
   }
   free_device(e);
-  e->mf_enabled = mfma_requested() && (!e->matrix_mode) && (!e->band_r2_mode) && (e->P.founder_ct <= kMfMaxFounders);
+  e->mf_enabled = e->opt.pair_mfma && (!e->matrix_mode) && (!e->band_r2_mode) && (e->P.founder_ct <= kMfMaxFounders);
   e->mf_wgs.clear();
   // second variants at which a launch group may end: every matrix-pipe workgroup lies on one side
   std::vector<uint32_t> safe_cut;
@@ -910,8 +942,8 @@ int ensure_device_plan(ldp_engine* e) {
   HIP_TRY(e, hipMalloc(&e->d_cp_stats, n * kCpSlots * sizeof(cp_slot)));
   HIP_TRY(e, hipMalloc(&e->d_cp_gen, n * kCheckpoints * sizeof(cp_gen_slot)));
   HIP_TRY(e, hipMalloc(&e->d_mf_wgs, std::max<size_t>(e->mf_wgs.size(), 1) * sizeof(MfmaWG)));
-  HIP_TRY(e, hipMalloc(&e->d_miss_stats, sizeof(MissStats)));
-  HIP_TRY(e, hipMemsetAsync(e->d_miss_stats, 0, sizeof(MissStats), e->stream));
+  HIP_TRY(e, hipMalloc(&e->d_miss_stats, (e->groups.size() + 1) * sizeof(MissStats)));
+  HIP_TRY(e, hipMemsetAsync(e->d_miss_stats, 0, (e->groups.size() + 1) * sizeof(MissStats), e->stream));
   HIP_TRY(e, hipMalloc(&e->d_route, (e->groups.size() + 1) * sizeof(uint32_t)));
   HIP_TRY(e, hipMemsetAsync(e->d_route, 0, (e->groups.size() + 1) * sizeof(uint32_t), e->stream));
   if (!e->mf_wgs.empty()) {
@@ -933,7 +965,8 @@ int ensure_device_plan(ldp_engine* e) {
     }
   }
   HIP_TRY(e, hipHostMalloc(&e->h_pred, std::max<size_t>(e->pred_words, 1) * sizeof(uint32_t), hipHostMallocDefault));
-  HIP_TRY(e, hipHostMalloc(&e->h_counters_pin, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+  // (4 counters, then the route words of the launch groups + the inspection launch)
+  HIP_TRY(e, hipHostMalloc(&e->h_counters_pin, 4 * sizeof(unsigned long long) + (e->groups.size() + 1) * sizeof(uint32_t), hipHostMallocDefault));
   if (e->local_ct) {
     HIP_TRY(e, hipMemcpyAsync(e->d_lo, e->lo_local.data(), e->local_ct * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->d_row_off, e->row_off.data(), (e->local_ct + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
@@ -1370,7 +1403,7 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.counters = e->d_counters;
   A.item_general = e->d_item_general;
   // early termination is off when the caller wants every pair's integers (parity runs) or LDP_EARLY_EXIT=0
-  A.cp_stats = (with_early_exit && early_exit_requested() && e->n_checkpoints) ? e->d_cp_stats : nullptr;
+  A.cp_stats = (with_early_exit && e->opt.early_exit && e->n_checkpoints) ? e->d_cp_stats : nullptr;
   A.cp_gen = A.cp_stats ? e->d_cp_gen : nullptr;
   for (int k = 0; k < kCheckpoints; ++k) {
     A.checkpoint_chunk[k] = e->checkpoint_chunk[k];
@@ -1408,7 +1441,6 @@ int begin_load_epoch(ldp_engine* e) {
     }
   }
   HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
-  HIP_TRY(e, hipMemsetAsync(e->d_miss_stats, 0, sizeof(MissStats), e->stream));
   ++e->load_epoch;
   e->loaded_prefix = 0;
   e->next_group = 0;
@@ -1418,14 +1450,26 @@ int begin_load_epoch(ldp_engine* e) {
   return LDP_OK;
 }
 
-// Decide on the device which matrix-pipe kernel owns the launches queued next on `stream` (slot of d_route): everything the
-// stream holds so far -- the conversions of the rows those launches read -- has added to d_miss_stats by then.
-hipError_t queue_route(ldp_engine* e, size_t slot, hipStream_t stream, int allow_sparse) {
-  const double rows = static_cast<double>(std::max<uint32_t>(e->loaded_prefix, 1));
-  const double frac = allow_sparse ? sparse_missing_fraction() : 0.0;
+// Decide on the device which matrix-pipe kernel owns the launches queued next on `stream` (slot of d_route).  The decision is
+// taken from the records of ALL the rows the launches read, local rows [0, row_end), as they are resident when the stream gets
+// there -- whichever load call, of whichever load epoch, put them there (a caller may re-load a few rows only; plink2-hip does
+// for multiallelic and MT rows, and a record kept per epoch would forget the missing calls of the rows that stayed).
+hipError_t queue_route(ldp_engine* e, size_t slot, hipStream_t stream, int allow_sparse, uint32_t row_end) {
+  const double rows = static_cast<double>(std::max<uint32_t>(row_end, 1));
+  const double frac = allow_sparse ? e->opt.sparse_frac : 0.0;
   const double total_limit = frac * static_cast<double>(e->P.founder_ct) * rows;  // (< 2^64: 16M samples x 2^32 rows)
   const double high_limit = 0.02 * rows;
-  return launch_route(e->d_miss_stats, static_cast<unsigned long long>(total_limit), static_cast<unsigned long long>(high_limit), allow_sparse && (frac > 0.0),
+  const uint32_t miss_high = static_cast<uint32_t>(std::min(2.0 * e->opt.sparse_frac * static_cast<double>(e->P.founder_ct), 4294967295.0));
+  MissStats* ms = e->d_miss_stats + slot;
+  hipError_t rc = hipMemsetAsync(ms, 0, sizeof(MissStats), stream);
+  if (rc != hipSuccess) {
+    return rc;
+  }
+  rc = launch_miss_stats(e->d_recs, row_end, e->P.founder_ct, miss_high, ms, stream);
+  if (rc != hipSuccess) {
+    return rc;
+  }
+  return launch_route(ms, static_cast<unsigned long long>(total_limit), static_cast<unsigned long long>(high_limit), allow_sparse && (frac > 0.0),
                       e->d_route + slot, stream);
 }
 
@@ -1447,9 +1491,9 @@ int launch_group(ldp_engine* e, uint32_t gi) {
   if (e->mf_enabled) {
     // Which kernel family owns the group is decided on the device, once per group: a snapshot of the missing-calls flag
     // (all of the group's rows are converted by now) that every kernel of the group reads.
-    A.mf_active = pair_mfma_general_enabled() ? 2 : 1;
-    A.sparse_ok = ((A.mf_active == 2) && !A.stats && (sparse_missing_fraction() > 0.0)) ? 1 : 0;
-    HIP_TRY(e, queue_route(e, gi, ps, A.sparse_ok));
+    A.mf_active = e->opt.mfma_general ? 2 : 1;
+    A.sparse_ok = ((A.mf_active == 2) && !A.stats && (e->opt.sparse_frac > 0.0)) ? 1 : 0;
+    HIP_TRY(e, queue_route(e, gi, ps, A.sparse_ok, g.need_end));
     A.route = e->d_route + gi;
     A.mf_wgs = e->d_mf_wgs + g.mf_first;
     A.n_mf_wgs = g.mf_ct;
@@ -1548,24 +1592,13 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     PairKernelArgs A;
     fill_pair_args(e, &A, false);
     A.stats = d_stats;
-    struct EventSet {  // released on every exit path
-      hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-      ~EventSet() {
-        for (hipEvent_t x : ev) {
-          if (x) {
-            (void)hipEventDestroy(x);
-          }
-        }
-      }
-    } evset;
+    EventSet<7> evset;
     hipEvent_t* evk = evset.ev;
-    for (int q = 0; q < 7; ++q) {
-      HIP_TRY(e, hipEventCreate(&evk[q]));
-    }
+    HIP_TRY(e, evset.create());
     if (e->mf_enabled) {
       const size_t slot = e->groups.size();
-      HIP_TRY(e, queue_route(e, slot, e->stream, 0));
-      A.mf_active = pair_mfma_general_enabled() ? 2 : 1;
+      HIP_TRY(e, queue_route(e, slot, e->stream, 0, e->local_ct));
+      A.mf_active = e->opt.mfma_general ? 2 : 1;
       A.route = e->d_route + slot;
       A.mf_wgs = e->d_mf_wgs;
       A.n_mf_wgs = static_cast<uint32_t>(e->mf_wgs.size());
@@ -1584,6 +1617,9 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
       HIP_TRY(e, hipMemcpyAsync(e->h_pred, e->d_pred, e->pred_words * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     }
     HIP_TRY(e, hipMemcpyAsync(e->h_counters_pin, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    if (e->mf_enabled) {
+      HIP_TRY(e, hipMemcpyAsync(e->h_counters_pin + 4, e->d_route, (e->groups.size() + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    }
     if (d_stats) {
       HIP_TRY(e, hipMemcpyAsync(stats, d_stats, e->cand_pairs * sizeof(ldp_pair_stats_t), hipMemcpyDeviceToHost, e->stream));
     }
@@ -1640,6 +1676,9 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     }
     tl[0] = now_ms();
     HIP_TRY(e, hipMemcpyAsync(e->h_counters_pin, e->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    if (e->mf_enabled) {
+      HIP_TRY(e, hipMemcpyAsync(e->h_counters_pin + 4, e->d_route, (e->groups.size() + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    }
     // 2. ... meanwhile the per-variant records come back on the copy stream and the host derives the
     //    major-allele frequencies the replay needs ...
     rc = fetch_recs(e);
@@ -1684,6 +1723,20 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     h_counters[q] = e->h_counters_pin[q];  // (the stream that carried the copy has been synchronised in both branches)
   }
   kms = kms_fast + kms_general + kms_mfma + kms_mfma_general;
+  // which matrix-pipe kernel route_kernel gave each launch of this run (deterministic evidence of the path taken)
+  uint32_t route_ct[3] = {0, 0, 0};
+  if (e->mf_enabled && !e->mf_wgs.empty()) {
+    const uint32_t* h_route = reinterpret_cast<const uint32_t*>(e->h_counters_pin + 4);
+    if (stats) {
+      ++route_ct[std::min<uint32_t>(h_route[e->groups.size()], 2)];
+    } else {
+      for (size_t gi = 0; gi < e->groups.size(); ++gi) {
+        if (e->groups[gi].mf_ct) {
+          ++route_ct[std::min<uint32_t>(h_route[gi], 2)];
+        }
+      }
+    }
+  }
   if (!replayed) {
     rc = prepare_mf(e, &mf_scratch, &mf);
     if (rc) {
@@ -1715,6 +1768,9 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   e->ctr.mfma_product_stages = e->ctr.mfma_block_products * pair_mfma_ksteps(e->P.founder_ct);
   e->ctr.mfma_skipped_product_stages = h_counters[2];
   e->ctr.sparse_exact_pairs = h_counters[3];
+  e->ctr.route_complete_launches = route_ct[0];
+  e->ctr.route_sparse_launches = route_ct[1];
+  e->ctr.route_general_launches = route_ct[2];
   e->ctr.ms_replay = replayed ? replay_busy_ms : (t_end - t_replay);  // (time spent replaying, not waiting for groups)
   e->ctr.ms_run_total = t_end - t_start;
   e->ctr.pair_kernel_launches = launches;
@@ -1736,6 +1792,8 @@ int ldp_device_count(void) {
   }
   return n;
 }
+
+uint32_t ldp_matrix_pipe_max_founders(void) { return kMfMaxFounders; }
 
 int ldp_create(const ldp_params* params, ldp_engine** out) {
   if (!params || !out) {
@@ -1763,6 +1821,7 @@ int ldp_create(const ldp_params* params, ldp_engine** out) {
     return LDP_ERR_NOMEM;
   }
   e->P = *params;
+  e->opt = options_from_env();
   e->ctr = ldp_counters();
   *out = e;
   return LDP_OK;
@@ -1946,7 +2005,7 @@ int ldp_set_variants_vcor_cm(ldp_engine* e, uint32_t variant_ct, const uint32_t*
 namespace {
 // --r2-unphased requests on the matrix pipe: plan the requested second variants' block products (ldp_device.h: MfmaWG),
 // upload the plan and attach it to the launch.  The r^2 epilogue is emit_pair()'s, shared with the popcount kernels.
-bool r2_on_matrix_pipe(const ldp_engine* e) { return mfma_requested() && (e->P.founder_ct <= kMfMaxFounders); }
+bool r2_on_matrix_pipe(const ldp_engine* e) { return e->opt.pair_mfma && (e->P.founder_ct <= kMfMaxFounders); }
 
 int attach_mfma_plan(ldp_engine* e, PairKernelArgs* A, const std::vector<std::pair<uint32_t, uint32_t>>& runs, const uint32_t* lo, uint32_t j_first,
                      uint32_t j_end, DevBuf* buf, uint64_t* products, uint32_t i_first = 0, uint32_t i_end = 0xffffffffu) {
@@ -1959,7 +2018,7 @@ int attach_mfma_plan(ldp_engine* e, PairKernelArgs* A, const std::vector<std::pa
   HIP_TRY(e, hipMalloc(&buf->p, wgs.size() * sizeof(MfmaWG)));
   HIP_TRY(e, hipMemcpy(buf->p, wgs.data(), wgs.size() * sizeof(MfmaWG), hipMemcpyHostToDevice));
   const size_t slot = e->groups.size();  // (the route slot of launches outside the launch groups)
-  HIP_TRY(e, queue_route(e, slot, e->stream, 0));
+  HIP_TRY(e, queue_route(e, slot, e->stream, 0, e->local_ct));
   A->mf_wgs = buf->as<MfmaWG>();
   A->mf_active = 2;
   A->route = e->d_route + slot;
@@ -2056,10 +2115,9 @@ int r2_band_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
   A.r2_row_end = l_end;
   A.r2_band_base = e->pair_off[l_first];
   A.r2_float = as_float ? 1 : 0;
-  hipEvent_t evk[4];
-  for (int q = 0; q < 4; ++q) {
-    HIP_TRY(e, hipEventCreate(&evk[q]));
-  }
+  EventSet<4> evset;
+  hipEvent_t* evk = evset.ev;
+  HIP_TRY(e, evset.create());
   DevBuf mf_buf;
   uint64_t mf_products = 0;
   const bool on_mfma = r2_on_matrix_pipe(e);
@@ -2108,9 +2166,6 @@ int r2_band_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
     HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
     HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[2], evk[3]));
   }
-  for (int q = 0; q < 4; ++q) {
-    (void)hipEventDestroy(evk[q]);
-  }
   e->ctr.candidate_pairs = n_elems;
   e->ctr.ms_pair_fast = kms_fast;
   e->ctr.ms_pair_general = kms_general;
@@ -2157,6 +2212,7 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
   uint32_t max_rows = 0;
   uint64_t computed = 0, cand = 0;
   const uint32_t row_end = row_first + row_ct;
+  const bool on_mfma = r2_on_matrix_pipe(e);  // (then the popcount work items are never launched: not built, not uploaded)
   for (uint32_t j0 = row_first; j0 < row_end; j0 += kTileJ) {
     const uint32_t jend = std::min(j0 + kTileJ, row_end);
     const uint32_t dmax = jend - 1;
@@ -2164,7 +2220,7 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
       const uint32_t hi = std::min(j, col_end);
       cand += (hi > col_first) ? (hi - col_first) : 0;
     }
-    if (!dmax) {
+    if ((!dmax) || on_mfma) {
       continue;
     }
     const uint32_t units = (dmax + 7) / 8;
@@ -2243,13 +2299,11 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
   A.r2_col_end = col_end;
   A.r2_band_base = 0;
   A.r2_float = as_float ? 1 : 0;
-  hipEvent_t evk[4];
-  for (int q = 0; q < 4; ++q) {
-    HIP_TRY(e, hipEventCreate(&evk[q]));
-  }
+  EventSet<4> evset;
+  hipEvent_t* evk = evset.ev;
+  HIP_TRY(e, evset.create());
   DevBuf mf_buf;
   uint64_t mf_products = 0;
-  const bool on_mfma = r2_on_matrix_pipe(e);
   hipError_t krc;
   if (on_mfma) {
     const std::vector<std::pair<uint32_t, uint32_t>> runs(1, std::make_pair(0u, e->local_ct));
@@ -2292,9 +2346,6 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
   } else if (!items.empty()) {
     HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
     HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[2], evk[3]));
-  }
-  for (int q = 0; q < 4; ++q) {
-    (void)hipEventDestroy(evk[q]);
   }
   // diagonal: r^2(v, v) through the same formula = 1.0, or NaN when the variant has no variance
   for (uint32_t j = row_first; (!hits) && (j < row_end); ++j) {
@@ -2613,9 +2664,9 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
         PA.checkpoint_chunk[k] = e->checkpoint_chunk[k];
       }
       PA.n_checkpoints = e->n_checkpoints;
-      PA.miss_stats = e->d_miss_stats;
-      PA.miss_high = static_cast<uint32_t>(std::min(2.0 * sparse_missing_fraction() * static_cast<double>(e->P.founder_ct), 4294967295.0));
-      PA.fix_cp_gen = !(e->mf_enabled && pair_mfma_general_enabled());  // (only the popcount kernel's interval bound reads cp_gen)
+      PA.miss_stats = nullptr;  // (the route is taken from the records when a launch is queued: queue_route)
+      PA.miss_high = static_cast<uint32_t>(std::min(2.0 * e->opt.sparse_frac * static_cast<double>(e->P.founder_ct), 4294967295.0));
+      PA.fix_cp_gen = !(e->mf_enabled && e->opt.mfma_general);  // (only the popcount kernel's interval bound reads cp_gen)
       if (!e->prep_pending) {
         HIP_TRY(e, hipEventRecord(e->prep_ev0, e->stream));
         e->prep_pending = true;
@@ -2776,6 +2827,37 @@ int ldp_pair_stats(ldp_engine* e, uint32_t n_pairs, const uint32_t* first, const
   }
   HIP_TRY(e, hipMemcpyAsync(out, d_out, static_cast<size_t>(n_pairs) * sizeof(ldp_pair_stats_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return LDP_OK;
+}
+
+int ldp_debug_set_option(ldp_engine* e, const char* name, double value) {
+  if (!e || !name) {
+    return LDP_ERR_INVALID;
+  }
+  const std::string n(name);
+  if (n == "early_exit") {
+    e->opt.early_exit = (value != 0.0);
+  } else if (n == "pair_mfma") {
+    if (e->planned) {
+      return fail(e, LDP_ERR_STATE, "pair_mfma must be set before ldp_set_variants()");
+    }
+    e->opt.pair_mfma = (value != 0.0);
+  } else if (n == "mfma_general") {
+    e->opt.mfma_general = (value != 0.0);
+  } else if (n == "pair_sparse") {
+    if (value == 0.0) {
+      e->opt.sparse_frac = 0.0;
+    } else if (e->opt.sparse_frac == 0.0) {
+      e->opt.sparse_frac = 0.005;
+    }
+  } else if (n == "sparse_frac") {
+    if (!(value >= 0.0) || !(value <= 1.0)) {
+      return fail(e, LDP_ERR_INVALID, "sparse_frac must lie in [0, 1]");
+    }
+    e->opt.sparse_frac = value;
+  } else {
+    return fail(e, LDP_ERR_INVALID, "unknown option: " + n);
+  }
   return LDP_OK;
 }
 

@@ -604,6 +604,14 @@ __global__ __launch_bounds__(64) void route_kernel(const MissStats* __restrict__
   }
 }
 
+hipError_t launch_miss_stats(const ldp_variant_rec* recs, uint32_t n, uint32_t founder_ct, uint32_t miss_high, MissStats* stats, hipStream_t stream) {
+  if (!n) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(miss_stats_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 256)), dim3(256), 0, stream, recs, n, founder_ct, miss_high, stats);
+  return hipGetLastError();
+}
+
 hipError_t launch_route(const MissStats* stats, unsigned long long total_limit, unsigned long long high_limit, int allow_sparse, uint32_t* route_out,
                         hipStream_t stream) {
   static_assert(kMissStripes == 64, "one lane per stripe");

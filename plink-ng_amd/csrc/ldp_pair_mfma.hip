@@ -953,11 +953,7 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
     (void)hipEventRecord(ev[1], stream);
   }
   // the same plan for launches whose rows have missing calls: one workgroup per (wave item, second-variant block)
-  static const bool general_on = []() {
-    const char* g = getenv("LDP_PAIR_MFMA_GENERAL");
-    return !(g && (atoi(g) == 0));
-  }();
-  if (general_on) {
+  if (a_in.mf_active == 2) {  // (1: rows with missing calls stay on the popcount kernel, EngineOptions::mfma_general)
     static const size_t glds = []() {
       // 5 row-blocks = 10 KiB per stage: a ring of five in 50 KiB (+ 3 KiB static) lets THREE workgroups share a CU (138 VGPRs
       // allow three waves per SIMD); LDP_DEBUG_MFMA_GEN_LDS_KB overrides (tuning aid)
@@ -977,11 +973,6 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
     (void)hipEventRecord(ev[2], stream);
   }
   return hipGetLastError();
-}
-
-bool pair_mfma_general_enabled() {
-  const char* g = getenv("LDP_PAIR_MFMA_GENERAL");
-  return !(g && (atoi(g) == 0));
 }
 
 // 64-sample k-steps per row as the kernel counts them (counters[2] is in product x k-step units)

@@ -362,7 +362,7 @@ int ldp_pgen_open_indexed(const char* path, const char* pgi_path, uint32_t sampl
       return pfail(P, LDP_ERR_NOMEM, "Failed to map " + ipath + ".");
     }
     P->index_map = static_cast<const uint8_t*>(im);
-    if ((P->index_map[0] != 0x6c) || (P->index_map[1] != 0x1b) || (P->index_map[2] != (P->mode | 0x10))) {
+    if ((P->index_map[0] != 0x6c) || (P->index_map[1] != 0x1b) || ((P->index_map[2] & 0xfe) != 0x30)) {  // (either index flavour for either .pgen mode, as PgfiInitPhase1 accepts: pgenlib_read.cc:836)
       return pfail(P, LDP_ERR_INVALID, ipath + " is not a .pgen.pgi file (first three bytes don't match the magic number).");
     }
     H = P->index_map;

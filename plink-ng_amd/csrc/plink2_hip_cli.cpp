@@ -1321,6 +1321,7 @@ struct Variants {
   std::vector<std::string> chrom, id;
   std::vector<uint32_t> bp;
   std::vector<uint8_t> alt_ct;  // number of ALT alleles (1 for biallelic / .bim), capped at 255
+  std::vector<uint8_t> alt_missing;  // --max-alleles: the single ALT is a missing code ('.' or '0'), which counts as ONE allele (plink2_pvar.cc:1940-1948); empty unless the filter is on
   std::vector<uint8_t> not_snp; // --snps-only: an allele longer than one character (or, with 'just-acgt', outside ACGT / missing)
   std::vector<std::string> ref, alt;  // allele text (ALT comma-separated as in the file); only kept for --r2-unphased allele columns
   bool info_pr_header = false;        // the .pvar declares INFO/PR as a flag (provisional REF alleles are marked per variant there)
@@ -1329,6 +1330,11 @@ struct Variants {
   bool cm_unsorted = false;           // some chromosome's CM values decrease (LoadPvar, plink2_pvar.cc:2121-2134)
   bool cm_any_nonzero = false;
 };
+
+// allele count as --max-alleles sees it (LoadPvar, plink2_pvar.cc:1937-1953): a lone ALT that is a missing code counts as one allele
+inline uint32_t allele_ct_for_filter(const Variants& V, size_t v) {
+  return ((v < V.alt_missing.size()) && V.alt_missing[v]) ? 1u : (static_cast<uint32_t>(V.alt_ct[v]) + 1);
+}
 
 // whole file -> memory; the variant/sample tables are a few tens of MB even at 10M variants
 std::string slurp(const std::string& path) {
@@ -1513,11 +1519,17 @@ void load_variants(const Args& A, Variants* V) {
       die(63, "Error: variant '%.*s' has more than 254 ALT alleles, which plink2-hip does not support.\n", static_cast<int>(t[c_id].n), t[c_id].p);
     }
     V->alt_ct.push_back(static_cast<uint8_t>(alts));
+    if (A.max_alleles != 0xffffffffu) {
+      // ('0' is the reference's default --input-missing-genotype character, plink2.cc:4033)
+      const int k_alt1 = header ? c_alt : ((nt == 5) ? 3 : 4);
+      const bool miss = (alts == 1) && (k_alt1 >= 0) && (k_alt1 < std::min(nt, kCap)) && (t[k_alt1].n == 1) && ((t[k_alt1].p[0] == '.') || (t[k_alt1].p[0] == '0'));
+      V->alt_missing.push_back(miss ? 1 : 0);
+    }
     if (A.snps_only) {  // LoadPvar, plink2_pvar.cc:1917-1932
       const int k_ref = header ? c_ref : ((nt == 5) ? 4 : 5), k_alt = header ? c_alt : ((nt == 5) ? 3 : 4);
       bool snp = (k_ref >= 0) && (k_alt >= 0) && (std::max(k_ref, k_alt) < std::min(nt, kCap)) && (t[k_ref].n == 1) && (t[k_alt].n == 2 * (alts - 1) + 1);
       if (snp && A.snps_only_acgt) {
-        auto acgtm = [](char ch) { return (ch == 'A') || (ch == 'C') || (ch == 'G') || (ch == 'T') || (ch == 'a') || (ch == 'c') || (ch == 'g') || (ch == 't') || (ch == '.'); };
+        auto acgtm = [](char ch) { return (ch == 'A') || (ch == 'C') || (ch == 'G') || (ch == 'T') || (ch == 'a') || (ch == 'c') || (ch == 'g') || (ch == 't') || (ch == '.') || (ch == '0'); };  // (acgtm_table incl. the default missing-genotype character '0', plink2_pvar.cc:1631)
         snp = acgtm(t[k_ref].p[0]);
         for (uint32_t a = 0; snp && (a < alts); ++a) {
           snp = acgtm(t[k_alt].p[2 * a]);
@@ -3425,7 +3437,7 @@ void load_inputs(Session& S, int argc, char** argv) {
       if (it->second || ((!A.extract_files.empty()) && !extract_ids.count(V.id[v])) || ((!A.exclude_files.empty()) && exclude_ids.count(V.id[v]))) {
         continue;
       }
-      if ((static_cast<uint32_t>(V.alt_ct[v]) + 1 > A.max_alleles) || (A.snps_only && V.not_snp[v])) {
+      if ((allele_ct_for_filter(V, v) > A.max_alleles) || (A.snps_only && V.not_snp[v])) {
         continue;
       }
       if (V.alt_ct[v] > 1) {
@@ -3552,7 +3564,7 @@ void load_inputs(Session& S, int argc, char** argv) {
                     (A.autosome && !((code >= 1) && (code <= 22)));
         }
       }
-      if (chr_out || ((static_cast<uint32_t>(V.alt_ct[v]) + 1 > A.max_alleles) || (A.snps_only && V.not_snp[v]))) {
+      if (chr_out || ((allele_ct_for_filter(V, v) > A.max_alleles) || (A.snps_only && V.not_snp[v]))) {
         continue;
       }
       if ((!A.extract_files.empty()) && !extract_ids.count(V.id[v])) {
@@ -3602,7 +3614,7 @@ void load_inputs(Session& S, int argc, char** argv) {
                                          (A.autosome && !((code >= 1) && (code <= 22))));
         it = chr_state.emplace(cur, static_cast<uint8_t>(out)).first;
       }
-      any_loaded = (!it->second) && (static_cast<uint32_t>(V.alt_ct[v]) + 1 <= A.max_alleles) && !(A.snps_only && V.not_snp[v]);
+      any_loaded = (!it->second) && (allele_ct_for_filter(V, v) <= A.max_alleles) && !(A.snps_only && V.not_snp[v]);
     }
     if (!any_loaded) {
       std::string flags;

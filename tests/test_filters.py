@@ -183,3 +183,32 @@ def test_make_founders_prune_matches_reference(gpu_pkg, cli, tmp_path):
         got = run_cli(cli, common + ["--out", "hip"], str(tmp_path))
         assert ref.returncode == 0 and got.returncode == 0, (ref.stdout[-300:], got.stdout[-300:])
         assert filecmp.cmp(str(tmp_path / "ref.prune.in"), str(tmp_path / "hip.prune.in"), shallow=False), mods
+
+
+@pytest.mark.parametrize("extra", [["--snps-only", "just-acgt"], ["--max-alleles", "1"], ["--snps-only"]])
+def test_missing_code_alleles_in_a_bim(gpu_pkg, cli, tmp_path, extra):
+    """A .bim whose A1 is '0' (monomorphic PLINK 1 data) or '.': '0' is the reference's default missing-genotype character, so
+    `--snps-only just-acgt` keeps such variants (acgtm_table, plink2_pvar.cc:1631) and `--max-alleles` counts the lone ALT as
+    no allele at all (allele_ct = 1, plink2_pvar.cc:1940-1948)."""
+    assert T.have_ref()
+    m, n = 500, 130
+    raw = T.synth_raw_codes(m, n, seed=21, missing_rate=0.01, ld_copy_prob=0.6, redraw=0.05)
+    raw[::7][raw[::7] == 2] = 0                         # (rows with A1 = 0 carry no A1 allele)
+    raw[::7][raw[::7] == 1] = 0
+    prefix = str(tmp_path / "d")
+    T.write_bed(prefix, raw, ["1"] * 250 + ["2"] * 250, np.concatenate([np.arange(250), np.arange(250)]) * 200 + 1)
+    lines = open(prefix + ".bim").read().splitlines()
+    for v in range(0, m, 7):
+        f = lines[v].split("\t")
+        f[4] = "0" if (v % 14) else "."
+        lines[v] = "\t".join(f)
+    for v in range(3, m, 11):
+        f = lines[v].split("\t")
+        f[4] = "N"                                      # neither ACGT nor a missing code
+        lines[v] = "\t".join(f)
+    for v in range(5, m, 13):
+        f = lines[v].split("\t")
+        f[5] = "CT"                                     # not a SNP
+        lines[v] = "\t".join(f)
+    open(prefix + ".bim", "w").write("\n".join(lines) + "\n")
+    compare(cli, tmp_path, ["--bfile", "d"] + extra + ["--indep-pairwise", "30kb", "0.2"], [".prune.in", ".prune.out"])

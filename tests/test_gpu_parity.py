@@ -182,6 +182,53 @@ def test_mixed_missingness_tiles(gpu_pkg):
     check_run(gpu_pkg, raw, chr_idx, bps, 40, 3, False, 0.2, 2)
 
 
+def test_partial_reload_keeps_the_route_of_the_resident_rows(gpu_pkg):
+    """Rows with missing calls are loaded in bulk, then a few complete rows are loaded AGAIN one at a time (what plink2-hip does
+    with multiallelic and MT rows).  The kernel choice must still know about the missing calls of the rows that stayed resident:
+    a route derived from the last load alone would send the launch to the complete-data kernel, which takes nm = founder_ct."""
+    pkg = gpu_pkg
+    m, n = 300, 900
+    raw = T.synth_raw_codes(m, n, seed=77, missing_rate=0.04, ld_copy_prob=0.6, redraw=0.05)
+    redo = [5, 130, 131, 299]
+    for v in redo:
+        raw[v] = np.where(raw[v] == 3, 0, raw[v])      # the re-loaded rows are complete
+    chr_idx, bps = make_positions(m, 2, 91)
+    inv, mf, altmaj, hom, r2h, vaggs = oracle_recs(raw, n)
+    want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 40, 1, False, 0.2, 2)
+    eng = pkg.LdPruneEngine(n, 40, 1, False, 0.2, order=2, device=0)
+    eng.set_variants(chr_idx, bps)
+    eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+    for v in redo:                                       # host-built rows in the caller's own orientation, like the CLI's
+        eng.load_genotypes_host(v, np.ascontiguousarray(inv[v:v + 1]), pkg.LDP_GENO_INVERSE)
+        eng.set_maj_freqs(v, mf[v:v + 1])
+    got = eng.run()
+    c = eng.counters()
+    assert c["route_complete_launches"] == 0 and c["route_general_launches"] + c["route_sparse_launches"] > 0
+    assert np.array_equal(got, want)
+    removed, stats = eng.run_with_stats()
+    lo, _ = eng.band()
+    k = 0
+    for j in range(m):
+        for i in range(int(lo[j]), j):
+            assert tuple(int(x) for x in stats[k]) == T.oracle_pair_stats(hom, r2h, vaggs, n, i, j).astuple(), (i, j)
+            k += 1
+    eng.close()
+    # the same through the r^2 rows of --r2-unphased (all-pairs plan)
+    eng = pkg.LdPruneEngine(n, 40, 1, False, 0.2, order=2, device=0)
+    eng.set_variants_matrix(m)
+    eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+    for v in redo:
+        eng.load_genotypes_host(v, np.ascontiguousarray(inv[v:v + 1]), pkg.LDP_GENO_INVERSE)
+    r2 = eng.r2_unphased_rows()
+    eng.close()
+    for (i, j) in ((4, 5), (5, 130), (129, 131), (7, 299), (130, 131)):
+        st = T.oracle_pair_stats(hom, r2h, vaggs, n, i, j)
+        nm, s1, q1, s2, q2, dot = st.astuple()
+        cov = float(dot * nm - s1 * s2)
+        vp = float(q1 * nm - s1 * s1) * float(q2 * nm - s2 * s2)
+        assert r2[j, i] == (cov * cov) / vp, (i, j)
+
+
 def test_device_pointer_input(gpu_pkg):
     m, n = 300, 257
     raw = T.synth_raw_codes(m, n, seed=31, missing_rate=0.02)
@@ -262,20 +309,13 @@ def test_config2_sample_count(gpu_pkg):
 
 
 def _run_early_exit(pkg, packed, n, chr_idx, bps, window, step, is_bp, r2, order, enabled):
-    old = os.environ.get("LDP_EARLY_EXIT")
-    os.environ["LDP_EARLY_EXIT"] = "1" if enabled else "0"
-    try:
-        eng = pkg.LdPruneEngine(n, window, step, is_bp, r2, order=order, device=0)
-        eng.set_variants(chr_idx, bps)
-        eng.load_genotypes_host(0, packed, pkg.LDP_GENO_REF)
-        removed = eng.run()
-        ctr = eng.counters()
-        eng.close()
-    finally:
-        if old is None:
-            del os.environ["LDP_EARLY_EXIT"]
-        else:
-            os.environ["LDP_EARLY_EXIT"] = old
+    eng = pkg.LdPruneEngine(n, window, step, is_bp, r2, order=order, device=0)
+    eng.set_option("early_exit", 1 if enabled else 0)  # (a switch of this engine, not of the process)
+    eng.set_variants(chr_idx, bps)
+    eng.load_genotypes_host(0, packed, pkg.LDP_GENO_REF)
+    removed = eng.run()
+    ctr = eng.counters()
+    eng.close()
     return removed, ctr
 
 
@@ -299,30 +339,21 @@ def test_early_termination_is_invisible(gpu_pkg, n, r2, order, miss):
     if r2 >= 0.5 and miss <= 0.01:
         # unrelated pairs are provably hopeless early on (whichever kernel family owned the tiles; the matrix-pipe kernel
         # for tiles with missing calls has no early termination yet)
-        assert c1["early_exit_unit_chunks"] + c1["mfma_skipped_product_stages"] > 0 or c1["ms_pair_mfma_general"] > 0
+        assert c1["early_exit_unit_chunks"] + c1["mfma_skipped_product_stages"] > 0 or c1["route_general_launches"] > 0
     inv, mf, _ = T.oracle_prepare(raw)
     want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 150, 1, False, r2, order)
     assert np.array_equal(on, want)
 
 
-def _run_sparse(pkg, packed, n, chr_idx, bps, r2, env):
-    keys = ("LDP_PAIR_SPARSE", "LDP_DEBUG_SPARSE_FRAC")
-    old = {k: os.environ.get(k) for k in keys}
-    for k in keys:
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    try:
-        eng = pkg.LdPruneEngine(n, 150, 1, False, r2, order=2, device=0)
-        eng.set_variants(chr_idx, bps)
-        eng.load_genotypes_host(0, packed, pkg.LDP_GENO_REF)
-        removed = eng.run()
-        ctr = eng.counters()
-        eng.close()
-    finally:
-        for k in keys:
-            os.environ.pop(k, None)
-            if old[k] is not None:
-                os.environ[k] = old[k]
+def _run_sparse(pkg, packed, n, chr_idx, bps, r2, options):
+    eng = pkg.LdPruneEngine(n, 150, 1, False, r2, order=2, device=0)
+    for name, value in options.items():
+        eng.set_option(name, value)
+    eng.set_variants(chr_idx, bps)
+    eng.load_genotypes_host(0, packed, pkg.LDP_GENO_REF)
+    removed = eng.run()
+    ctr = eng.counters()
+    eng.close()
     return removed, ctr
 
 
@@ -331,8 +362,8 @@ def _run_sparse(pkg, packed, n, chr_idx, bps, r2, env):
     (20000, 0.0003, 0.5, 0.29, None),   # planted r^2 ~ 0.504: a crowd of pairs next to the threshold
     (50000, 0.003, 0.2, 0.55, None),
     (9000, 0.001, 0.8, 0.1, None),
-    (6000, 0.02, 0.5, 0.29, "0.08"),    # a limit far beyond the useful one: wide intervals, most pairs resolved exactly
-    (3000, 0.05, 0.1, 0.68, "0.2"),
+    (6000, 0.02, 0.5, 0.29, 0.08),    # a limit far beyond the useful one: wide intervals, most pairs resolved exactly
+    (3000, 0.05, 0.1, 0.68, 0.2),
 ])
 def test_rows_with_a_few_missing_calls(gpu_pkg, n, miss, r2, redraw, frac):
     """launches whose rows miss only a few calls stay with the complete-data matrix kernel; per-variant
@@ -342,11 +373,12 @@ def test_rows_with_a_few_missing_calls(gpu_pkg, n, miss, r2, redraw, frac):
     raw = T.synth_raw_codes(m, n, seed=n % 89 + 3, missing_rate=miss, ld_copy_prob=0.7, redraw=redraw)
     chr_idx, bps = make_positions(m, 2, 5)
     packed = T.pack_2bit(raw)
-    env = {} if frac is None else {"LDP_DEBUG_SPARSE_FRAC": frac}
-    got, c1 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, env)
-    six, c0 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, {"LDP_PAIR_SPARSE": "0"})
-    assert c0["sparse_exact_pairs"] == 0 and c0["ms_pair_mfma_general"] > 0
-    assert c1["ms_pair_mfma_general"] < 0.5 * c0["ms_pair_mfma_general"], "the launches must have taken the interval path"
+    opts = {} if frac is None else {"sparse_frac": frac}
+    got, c1 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, opts)
+    six, c0 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, {"pair_sparse": 0})
+    # which kernel owned the launches is read from the route words the device wrote, not from timings
+    assert c0["sparse_exact_pairs"] == 0 and c0["route_general_launches"] > 0 and c0["route_sparse_launches"] == 0 and c0["route_complete_launches"] == 0
+    assert c1["route_sparse_launches"] > 0 and c1["route_general_launches"] == 0 and c1["route_complete_launches"] == 0, "the launches must have taken the interval path"
     assert np.array_equal(got, six)
     assert c1["pred_true"] == c0["pred_true"] > 0
     if frac is None:
@@ -370,12 +402,13 @@ def test_route_follows_the_mean_not_the_worst_row(gpu_pkg):
             raw[v, rng.random(n) < 0.07] = 3
         packed = T.pack_2bit(raw)
         got, c1 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, 0.5, {})
-        six, c0 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, 0.5, {"LDP_PAIR_SPARSE": "0"})
+        six, c0 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, 0.5, {"pair_sparse": 0})
         assert np.array_equal(got, six) and c1["pred_true"] == c0["pred_true"]
+        assert c0["route_general_launches"] > 0 and c0["route_sparse_launches"] == 0
         if sparse:
-            assert c1["ms_pair_mfma_general"] < 0.5 * c0["ms_pair_mfma_general"] and c1["sparse_exact_pairs"] > 0
+            assert c1["route_sparse_launches"] > 0 and c1["route_general_launches"] == 0 and c1["sparse_exact_pairs"] > 0
         else:
-            assert c1["sparse_exact_pairs"] == 0
+            assert c1["route_general_launches"] > 0 and c1["route_sparse_launches"] == 0 and c1["sparse_exact_pairs"] == 0
         inv, mf, _ = T.oracle_prepare(raw)
         want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 150, 1, False, 0.5, 2)
         assert np.array_equal(got, want)
@@ -453,7 +486,7 @@ def test_early_termination_wide_window(gpu_pkg, miss):
     assert c1["pred_true"] == c0["pred_true"]
     if c1["mfma_product_stages"] and miss == 0.0:   # complete data runs on the matrix-pipe kernel (block products x stages)
         assert c1["mfma_skipped_product_stages"] > 0.3 * c1["mfma_product_stages"]
-    elif not c1["ms_pair_mfma_general"] > 0:
+    elif not c1["route_general_launches"] > 0:
         assert c1["early_exit_unit_chunks"] > 0.3 * c1["tile_unit_chunks"]
 
 
@@ -470,13 +503,15 @@ def test_randomised_differential(gpu_pkg):
         assert ok, desc
 
 
-@pytest.mark.parametrize("n,missing", [(16000000, 0.0), (16000001, 0.0), (16000257, 0.01)])
-def test_sample_counts_around_the_matrix_pipe_limit(gpu_pkg, n, missing):
-    """f32 accumulators stay integer-exact up to kMfMaxFounders = 16,000,000 samples; beyond that the popcount kernels take the
-    pairs.  Either side of the limit the tile kernels' six-tuples must equal the one-wave-per-pair reference kernel's
+@pytest.mark.parametrize("beyond,missing", [(0, 0.0), (1, 0.0), (257, 0.01)])
+def test_sample_counts_around_the_matrix_pipe_limit(gpu_pkg, beyond, missing):
+    """f32 accumulators stay integer-exact up to kMfMaxFounders samples (ldp_matrix_pipe_max_founders()); beyond that the popcount
+    kernels take the pairs.  Either side of the limit the tile kernels' six-tuples must equal the one-wave-per-pair reference kernel's
     (ldp_pair_stats: an independent, trivially simple kernel), and the counters must say which family ran."""
     import torch
     pkg = gpu_pkg
+    limit = pkg.matrix_pipe_max_founders()
+    n = limit + beyond
     m = 40
     stride = (n + 3) // 4
     buf = torch.empty((m, stride), dtype=torch.uint8, device="cuda")
@@ -497,7 +532,7 @@ def test_sample_counts_around_the_matrix_pipe_limit(gpu_pkg, n, missing):
     assert np.array_equal(stats, ref)
     assert int(stats["nm"].max()) <= n and int(stats["nm"].min()) > 0.9 * n
     ctr = eng.counters()
-    if n <= 16000000:
+    if n <= limit:
         assert ctr["mfma_block_products"] > 0
     else:
         assert ctr["mfma_block_products"] == 0
