@@ -19,6 +19,18 @@ constexpr int kChunkDwords = 16;                 // plane dwords per k-chunk (51
 constexpr int kRowChunkDwords = 2 * kChunkDwords; // hom + ref2het = 128 B
 constexpr int kLdsRowDwords = kRowChunkDwords + 4; // 36: odd number (9) of 16-B slots -> conflict-free b128 reads
 
+// ---- HBM layout of the 2-bit code image (the resident format of the matrix-pipe kernels) ------------------------
+// One variant = one row of 2-bit genotype codes as the .pgen main track / PgrGetInv1 has them (00 hom-REF -- or hom-major for
+// LDP_GENO_INVERSE input --, 01 het, 10 hom-ALT, 11 missing; sample s at bits 2 (s % 16) of dword s / 16), kCodeStageBytes
+// (= 256 samples) at a time: the row stride is a whole number of stages and the samples beyond founder_ct are coded 11
+// ("missing": no contribution to any count), so the kernels never mask.  The image is NOT re-oriented to the major allele: the
+// prune predicate cov^2 > thr var1 var2 does not depend on the orientation, and where a sign does (the reported sums and dot
+// product, --r-unphased) the epilogue takes it from the records' ALT-major flags.  Same bytes per variant as the input: rows that
+// already are REF- / INVERSE-coded in the engine's image (ldp_map_rows) are counted in place, nothing is rewritten.
+constexpr uint32_t kCodeStageSamples = 256;
+constexpr uint32_t kCodeStageBytes = kCodeStageSamples / 4;  // 64
+inline uint64_t code_row_bytes_of(uint32_t founder_ct) { return static_cast<uint64_t>((founder_ct + kCodeStageSamples - 1) / kCodeStageSamples) * kCodeStageBytes; }
+
 // ---- pair-tile geometry -------------------------------------------------------------------------
 // A block owns kTileJ consecutive "second" variants j and a run of distances d = j - i in units of 8.  Wave w owns
 // second-variant group w (lane (tx = lane&7, ty = lane>>3): j = j0 + tx + 8w) of ALL the block's units
@@ -94,7 +106,9 @@ struct MfmaWG {
 };
 
 struct PairKernelArgs {
-  const uint32_t* planes;        // [variant][chunk][2][kChunkDwords]
+  const uint32_t* planes;        // [variant][chunk][2][kChunkDwords]  (popcount kernels; nullptr when the code image is resident)
+  const uint8_t* codes;          // [variant][code_row_bytes]          (matrix-pipe kernels; nullptr when the bit-planes are)
+  uint64_t code_row_bytes;
   uint64_t row_dwords;           // dwords per variant row = chunks * kRowChunkDwords
   uint32_t chunks;
   uint32_t founder_ct;
@@ -177,6 +191,8 @@ struct PrepareArgs {
   double cp_tv_scale;            // sqrt(sqrt(thresh) * (1 - 1e-6))
   uint32_t checkpoint_chunk[kCheckpoints];
   uint32_t n_checkpoints;
+  uint8_t* codes_out;            // code image rows (row 0 = variant `first`), code_row_bytes apart; launch_codes() only.  When it
+  uint64_t code_row_bytes;       //   equals `geno` (and the strides agree) the rows are counted in place and only their padding is written
   MissStats* miss_stats;         // what the rows' missing calls add up to (may be nullptr)
   uint32_t miss_high;            // rows with more missing calls than this count as high rows
   const uint32_t* extra_het;     // per variant: het calls the sample map turned into missing ones (allele counts only); may be nullptr
@@ -184,6 +200,12 @@ struct PrepareArgs {
 };
 
 hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream);
+// the same for the code image: rows of any accepted encoding -> REF- (or INVERSE-) coded 2-bit rows + the per-variant records and
+// checkpoint statistics (in the image's own orientation); no bit-planes
+hipError_t launch_codes(const PrepareArgs& a, hipStream_t stream);
+// arbitrary pairs from the code image (the integers in major-allele orientation, like launch_pair_stats_ref)
+hipError_t launch_pair_stats_ref_codes(const uint8_t* codes, uint64_t code_row_bytes, const ldp_variant_rec* recs, const uint32_t* first, const uint32_t* second,
+                                       uint32_t n_pairs, ldp_pair_stats_t* out, hipStream_t stream);
 // Sample-mapped rows (ldp_set_sample_map): out row v = 2-bit REF codes of columns map[f] & 0x7fffffff of in row v, hets of
 // columns with bit 31 set replaced by missing and counted into extra_het[v]; in rows are .pgen- or .bed-coded.
 hipError_t launch_gather_rows(const uint8_t* in, uint64_t in_stride, uint32_t n_variants, int in_is_bed, const uint32_t* map, uint32_t out_ct, uint8_t* out,

@@ -1,18 +1,21 @@
-// ldp_pair_mfma.hip -- the complete-data pair statistics on the matrix pipe (gfx950 / CDNA4).
+// ldp_pair_mfma.hip -- the pair statistics on the matrix pipe (gfx950 / CDNA4).
 //
 // DotprodWords (plink2_ld.cc:235-251) computes dot = sum_s x_i[s] * x_j[s] with x in {-1, 0, +1} (0 = het or missing)
 // as popcnt(hom_i & hom_j) - 2 popcnt(hom_i & hom_j & (r2h_i ^ r2h_j)).  The same integer is a matrix product over the
 // samples, and CDNA4's v_mfma_scale_f32_32x32x64_f8f6f4 contracts 64 samples of a 32 x 32 block of pairs per
-// instruction with FP4 (E2M1) operands: +-1 and 0 are exact codes, products are +-1 / 0, and the f32 accumulators hold
-// integers exactly below 2^24 (kMfMaxFounders).  Per 32 samples of one variant the two plane dwords (hom, ref2het)
-// expand to 32 E2M1 nibbles (magnitude bit = hom, sign bit = ref2het; the sign of a zero is irrelevant) in 10 VALU
-// operations, once per row-block and k-step, shared by the 32 x 32 pairs of every product the block takes part in --
-// against 4 VALU lane-operations per pair and 32 samples on the popcount path (tools/mfma_probe.hip measures both the
-// facts about the instruction this file relies on and the rates).  The expansion cannot live in HBM (4 bits per
-// genotype: 312 GB per GPU at BASELINE config 3), so rows are staged as bit-planes and expanded in registers.
+// instruction with FP4 (E2M1) operands: +-2 and 0 are exact codes, the E8M0 block scale 1/2 on both operands makes every
+// product +-1 / 0, and the f32 accumulators hold integers exactly below 2^24 (kMfMaxFounders).
+//
+// Operands are expanded straight from the 2-bit genotype codes of the resident image (ldp_device.h): per 16 samples (one
+// dword) two v_bitop3_b32 and a shift give sixteen E2M1 nibbles -- magnitude bit 2 = !b0 (homozygous), sign bit 3 = b1
+// (hom-ALT) -- once per row-block and k-step, shared by the 32 x 32 pairs of every product the block takes part in
+// (tools/mfma_probe.hip checks the instruction facts this relies on, fact 6 the expansion itself).  There is no bit-plane
+// image and no conversion pass in front of these kernels: the count pass (ldp_codes.hip) only reads.
 //
 // The sample order inside a fragment is free as long as both operands use the same one (a dot product is
-// order-invariant); every row goes through the same fp4_of_planes(), so it is.
+// order-invariant); every row goes through the same fp4_of_codes(), so it is.  The image keeps the rows' own orientation
+// (REF-based): the prune predicate does not depend on it, and the reported integers / --r-unphased take the sign from the
+// records' ALT-major flags in the epilogue.
 //
 // Results are the integers the popcount kernels produce (the parity tests compare every candidate pair's 6-tuple);
 // the per-pair epilogue (FP64 predicate, r^2, predicate bits) is shared (ldp_pair_device.h).
@@ -32,23 +35,27 @@ struct Frag {
   uint32_t d[4];  // 32 E2M1 values: one lane's share (one row, 32 samples) of a 32 x 64 operand
 };
 
-// 32 samples: plane dwords H (hom: |x| = 1) and R (ref2het: the sign; x = +1 <=> hom & ref2het, i.e. the nibble codes
-// -x, the same for both operands) -> nibble (R << 3) | (H << 1).  Output dword q, nibble p = sample 4p + q.
-__device__ __forceinline__ void fp4_of_planes(uint32_t H, uint32_t R, Frag& f) {
-  uint32_t t0 = (H & 0x33333333u) | ((R << 2) & 0xccccccccu);  // per nibble: H[4p], H[4p+1], R[4p], R[4p+1]
-  uint32_t t1 = ((H >> 2) & 0x33333333u) | (R & 0xccccccccu);  //             H[4p+2], H[4p+3], R[4p+2], R[4p+3]
-  asm("" : "+v"(t0), "+v"(t1));  // (keeps the two-step form: 2 shifts + 2 v_bfi, then 2 shifts + 4 ands)
-  f.d[0] = (t0 << 1) & 0xaaaaaaaau;
-  f.d[1] = t0 & 0xaaaaaaaau;
-  f.d[2] = (t1 << 1) & 0xaaaaaaaau;
-  f.d[3] = t1 & 0xaaaaaaaau;
+// 16 samples of 2-bit codes (00 hom-REF, 01 het, 10 hom-ALT, 11 missing; sample s at bits 2s, 2s+1) -> the E2M1 nibbles of
+// the odd samples of X: magnitude at nibble bit 2 (value 2.0) = !b0, sign at bit 3 = b1, i.e. x = +2 / 0 / -2 / -0.
+// f(X) = (X ^ 0x44444444) & 0xCCCCCCCC; the even samples are the odd ones of X << 2.  One v_bitop3_b32 each.
+__device__ __forceinline__ uint32_t fp4_x(uint32_t X) { return __builtin_amdgcn_bitop3_b32(X, 0x44444444u, 0xccccccccu, 0x28); }  // (a ^ b) & c
+// call present (n = !(b0 & b1)) and homozygous (h = !b0 = |x|), both as 2.0 at nibble bit 2
+__device__ __forceinline__ uint32_t fp4_n(uint32_t X) { return __builtin_amdgcn_bitop3_b32(X, X >> 1, 0x44444444u, 0x2a); }  // !(a & b) & c
+
+// 32 samples (two code dwords) of one variant -> one lane's share of a 32 x 64 operand
+__device__ __forceinline__ void fp4_of_codes(uint32_t c0, uint32_t c1, Frag& f) {
+  f.d[0] = fp4_x(c0);
+  f.d[1] = fp4_x(c0 << 2);
+  f.d[2] = fp4_x(c1);
+  f.d[3] = fp4_x(c1 << 2);
 }
 
-// C[row of a][column of b] += sum over 64 samples; E8M0 scale 0x7f = 1.0 for both operands
+// C[row of a][column of b] += sum over 64 samples.  E8M0 scale 0x7e = 1/2 for both operands: (+-2 / 2) (+-2 / 2) = +-1.
+constexpr int kFp4Scale = 0x7e7e7e7e;
 __device__ __forceinline__ mf_v16f mfma_fp4(const Frag& a, const Frag& b, mf_v16f c) {
   const mf_v8i A = {static_cast<int>(a.d[0]), static_cast<int>(a.d[1]), static_cast<int>(a.d[2]), static_cast<int>(a.d[3]), 0, 0, 0, 0};
   const mf_v8i B = {static_cast<int>(b.d[0]), static_cast<int>(b.d[1]), static_cast<int>(b.d[2]), static_cast<int>(b.d[3]), 0, 0, 0, 0};
-  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, kFp4Scale, 0, kFp4Scale);
 }
 
 typedef uint32_t mf_u4 __attribute__((ext_vector_type(4)));  // (a native vector: usable as an inline-asm operand)
@@ -61,18 +68,16 @@ constexpr uint32_t kMfMaxStages = 6;
 constexpr uint32_t kMfCpWaveDwords = 2 * 16 * 64;
 constexpr uint32_t kMfCpScratchDwords = kMfWaves * kMfCpWaveDwords;  // 32 KiB in; kMfMaxRowBlocks * 32 rows * 32 B = 16 KiB follow
 
-// ---- geometry of a stage, by k-steps per stage (KS = 4: 256 samples, KS = 2: 128 samples) -------------------------
-// A k-step is one MFMA per product: 64 samples, lane half h supplying 32 of them (one dword of each plane).
-// LDS image of a stage: row-block slot b, row r, KS 16-byte pieces per row.
-//   KS = 4: pieces 0, 1 = hom dwords 0-3 / 4-7 of the stage, 2, 3 = ref2het; piece c sits at slot (32 b + r) * 4 +
-//           (c ^ ((r >> 2) & 3)); lane half h reads pieces h and 2 + h (its own 4 dwords = 4 k-steps).
-//   KS = 2: piece 0 = hom dwords 0-3, piece 1 = ref2het; slot (32 b + r) * 2 + (c ^ ((r >> 3) & 1)); both lane halves
-//           read both pieces (same address: a broadcast) and half h takes dwords 2h, 2h + 1.
-// The XOR makes the 16 lanes of every ds_read_b128 group hit 16 distinct 4-bank groups without padding, and the DMA
-// (lane-linear in LDS, free per-lane global address) simply fetches the piece that belongs in its slot.  Smaller
-// stages mean a deeper ring in the same LDS (more bytes in flight per CU) for one more barrier per 128 samples.
+// ---- geometry of a stage: four k-steps = 256 samples = kCodeStageBytes contiguous bytes of a row ---------------------
+// A k-step is one MFMA per product: 64 samples, lane half h supplying 32 of them (two code dwords).
+// LDS image of a stage: row-block slot b, row r, four 16-byte pieces per row (piece c = bytes 16 c .. of the row's stage);
+// piece c sits at slot (32 b + r) * 4 + (c ^ ((r >> 2) & 3)); lane half h reads pieces h and 2 + h: its k-step ks is dword ks of
+// each.  The XOR makes the 16 lanes of every ds_read_b128 group hit 16 distinct 4-bank groups without padding, and the DMA
+// (lane-linear in LDS, free per-lane global address) simply fetches the piece that belongs in its slot.
+// (128-sample stages -- twice the ring depth in the same LDS -- were measured slower everywhere in round 2 and are gone.)
 template <int KS>
 struct StageGeom {
+  static_assert(KS == 4, "256-sample stages");
   static constexpr uint32_t kRowSlots = KS;                       // 16-byte slots per row
   static constexpr uint32_t kBlockSlots = kMfBlock * KS;          // per row-block (uint4 units)
   static constexpr uint32_t kBlockDwords = kBlockSlots * 4;
@@ -80,13 +85,11 @@ struct StageGeom {
   static constexpr uint32_t kStageSamples = 64 * KS;
   static constexpr uint32_t kStagesPerChunk = (kChunkDwords * 32) / kStageSamples;
   __device__ static uint32_t n_instr(uint32_t n_rb) { return (n_rb * KS + 1) / 2; }
-  __device__ static uint32_t block_of_instr(uint32_t T) { return (KS == 4) ? (T >> 1) : T; }
-  __device__ static uint32_t swizzle(uint32_t rr) { return (KS == 4) ? ((rr >> 2) & 3) : ((rr >> 3) & 1); }
-  // byte offset of piece `col` inside a row's 128-byte k-chunk, for the first stage of the chunk
-  __device__ static uint32_t piece_byte(uint32_t col) { return (KS == 4) ? ((col & 1) * 16 + (col >> 1) * 64) : (col * 64); }
-  __device__ static uint32_t stage_byte(uint32_t s) {
-    return (KS == 4) ? ((s >> 1) * (kRowChunkDwords * 4) + (s & 1) * 32) : ((s >> 2) * (kRowChunkDwords * 4) + (s & 3) * 16);
-  }
+  __device__ static uint32_t block_of_instr(uint32_t T) { return T >> 1; }
+  __device__ static uint32_t swizzle(uint32_t rr) { return (rr >> 2) & 3; }
+  // byte offset of piece `col` inside a row's stage, and of stage s inside the row
+  __device__ static uint32_t piece_byte(uint32_t col) { return col * 16; }
+  __device__ static uint32_t stage_byte(uint32_t s) { return s * kCodeStageBytes; }
 };
 
 // (Keeps hipcc from folding what follows into the LDS reads that produced a and b: a select between two dwords of a
@@ -94,16 +97,12 @@ struct StageGeom {
 // waits for the whole DMA ring, see mfma_stage.)
 __device__ __forceinline__ void opaque(mf_u4& a, mf_u4& b) { asm("" : "+v"(a), "+v"(b)); }
 
-// One lane's two plane dwords of k-step ks from the raw LDS reads
+// One lane's two code dwords of k-step ks from the raw LDS reads
 template <int KS>
 __device__ __forceinline__ void kstep_dwords(const mf_u4& H, const mf_u4& R, int ks, uint32_t h, uint32_t* hd, uint32_t* rd) {
-  if constexpr (KS == 4) {
-    *hd = H[ks];
-    *rd = R[ks];
-  } else {
-    *hd = h ? H[2 + ks] : H[ks];
-    *rd = h ? R[2 + ks] : R[ks];
-  }
+  (void)h;
+  *hd = H[ks];
+  *rd = R[ks];
 }
 
 // One stage of a wave's parallelogram.  (st4 is __restrict__ on purpose: without it hipcc assumes the LDS-DMA in flight
@@ -136,7 +135,7 @@ __device__ __forceinline__ void mfma_stage(const mf_u4* __restrict__ st4, const 
     for (int ks = 0; ks < KS; ++ks) {
       uint32_t hd, rd;
       kstep_dwords<KS>(H, R, ks, h, &hd, &rd);
-      fp4_of_planes(hd, rd, fj0[ks]);
+      fp4_of_codes(hd, rd, fj0[ks]);
     }
   }
   if (need & 2u) {
@@ -146,7 +145,7 @@ __device__ __forceinline__ void mfma_stage(const mf_u4* __restrict__ st4, const 
     for (int ks = 0; ks < KS; ++ks) {
       uint32_t hd, rd;
       kstep_dwords<KS>(H, R, ks, h, &hd, &rd);
-      fp4_of_planes(hd, rd, fj1[ks]);
+      fp4_of_codes(hd, rd, fj1[ks]);
     }
   }
   // rows of C = first variant (A operand: a V block), columns = second variant (B operand: a J block)
@@ -166,7 +165,7 @@ __device__ __forceinline__ void mfma_stage(const mf_u4* __restrict__ st4, const 
       } else {                                                                             \
         uint32_t hd, rd;                                                                   \
         kstep_dwords<KS>(vH[B], vR[B], ks, h, &hd, &rd);                                   \
-        fp4_of_planes(hd, rd, fv);                                                         \
+        fp4_of_codes(hd, rd, fv);                                                          \
       }                                                                                    \
       if ((P0 >= 0) && (live & (1u << (P0 & 7)))) acc[P0 & 7] = mfma_fp4(fv, fj0[ks], acc[P0 & 7]); \
       if ((P1 >= 0) && (live & (1u << (P1 & 7)))) acc[P1 & 7] = mfma_fp4(fv, fj1[ks], acc[P1 & 7]); \

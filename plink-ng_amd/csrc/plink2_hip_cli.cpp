@@ -942,7 +942,7 @@ Args parse_args(int argc, char** argv) {
       const std::string v = argv[++i];
       char* endp;
       const unsigned long n = strtoul(v.c_str(), &endp, 10);
-      if (v.empty() || *endp || (n < 2) || (n > 0x7fffffffUL)) {
+      if (v.empty() || *endp || (n < 1) || (n > 0x7fffffffUL)) {  // (ScanPosintDefcapx: any positive integer)
         die(8, "Error: Invalid --max-alleles argument '%s'.\n", v.c_str());
       }
       A.max_alleles = static_cast<uint32_t>(n);

@@ -5,6 +5,10 @@
 //   3. E2M1 codes: 0x2 = +1, 0xA = -1, 0x0 / 0x8 = 0; E8M0 scale 0x7F = 1
 //   4. integer exactness of the f32 accumulation right up to 2^24
 //   5. issue rate of the instruction alone, and with the bit-plane -> FP4 unpack beside it
+//   6. 2-bit genotype codes -> FP4 directly (3 VALU per 16 samples, v_bitop3_b32), magnitude 2.0 with E8M0 scale 0x7E = 1/2
+//      on both operands: the six products of the pair statistics equal the CPU's integer counts
+//   7. the instruction's ceiling by operand data and occupancy (zero / random operands, 2 / 4 waves per SIMD) with the
+//      effective shader clock of each run: the datasheet rate needs low-toggle operands
 // Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_probe.hip -o tools/_bin/mfma_probe
 #include <hip/hip_runtime.h>
 
@@ -31,6 +35,94 @@ __device__ __forceinline__ v16f mfma_fp4(const uint32_t (&a)[4], const uint32_t 
   const v8i A = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], 0, 0, 0, 0};
   const v8i B = {(int)b[0], (int)b[1], (int)b[2], (int)b[3], 0, 0, 0, 0};
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
+// 16 samples of 2-bit codes (00 hom-REF, 01 het, 10 hom-ALT, 11 missing; sample s at bits 2s, 2s+1) -> two dwords of E2M1
+// nibbles: magnitude at nibble bit 2 (value 2.0) = !b0, sign at bit 3 = b1, i.e. x = +2 / 0 / -2 / -0.  f(X) = (X ^ 0x44444444) &
+// 0xCCCCCCCC picks the odd samples of X; the even ones are the odd ones of X << 2.  One v_bitop3_b32 each.
+__device__ __forceinline__ uint32_t fp4_x(uint32_t X) { return __builtin_amdgcn_bitop3_b32(X, 0x44444444u, 0xccccccccu, 0x28); }  // (a ^ b) & c
+// call present (n = !(b0 & b1)) and homozygous (h = !b0 = |x|), both as 2.0 at nibble bit 2
+__device__ __forceinline__ uint32_t fp4_n(uint32_t X) { return __builtin_amdgcn_bitop3_b32(X, X >> 1, 0x44444444u, 0x2a); }  // !(a & b) & c
+__device__ __forceinline__ uint32_t fp4_h(uint32_t X) { return __builtin_amdgcn_bitop3_b32(X, 0x44444444u, 0x44444444u, 0x28); }  // (a ^ b) & c = !b0 at bit 2
+
+__device__ __forceinline__ v16f mfma_fp4_half(const uint32_t (&a)[4], const uint32_t (&b)[4], v16f c, int scale) {
+  const v8i A = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], 0, 0, 0, 0};
+  const v8i B = {(int)b[0], (int)b[1], (int)b[2], (int)b[3], 0, 0, 0, 0};
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, scale, 0, scale);
+}
+
+// one wave: codes a[lane][2], b[lane][2] (32 samples each) -> the six products, out[p][lane][16]
+__global__ void codes_mfma(const uint32_t* a, const uint32_t* b, float* out, int scale) {
+  const int l = threadIdx.x;
+  uint32_t ax[4], an[4], ah[4], bx[4], bn[4], bh[4];
+  for (int q = 0; q < 2; ++q) {
+    const uint32_t ca = a[l * 2 + q], cb = b[l * 2 + q];
+    ax[2 * q] = fp4_x(ca);
+    ax[2 * q + 1] = fp4_x(ca << 2);
+    an[2 * q] = fp4_n(ca);
+    an[2 * q + 1] = fp4_n(ca << 2);
+    ah[2 * q] = fp4_h(ca);
+    ah[2 * q + 1] = fp4_h(ca << 2);
+    bx[2 * q] = fp4_x(cb);
+    bx[2 * q + 1] = fp4_x(cb << 2);
+    bn[2 * q] = fp4_n(cb);
+    bn[2 * q + 1] = fp4_n(cb << 2);
+    bh[2 * q] = fp4_h(cb);
+    bh[2 * q + 1] = fp4_h(cb << 2);
+  }
+  v16f z;
+  for (int g = 0; g < 16; ++g) {
+    z[g] = 0.f;
+  }
+  const v16f c0 = mfma_fp4_half(ax, bx, z, scale);  // x_i . x_j
+  const v16f c1 = mfma_fp4_half(an, bn, z, scale);  // n_i . n_j
+  const v16f c2 = mfma_fp4_half(an, bh, z, scale);  // n_i . h_j
+  const v16f c3 = mfma_fp4_half(an, bx, z, scale);  // n_i . x_j
+  const v16f c4 = mfma_fp4_half(ah, bn, z, scale);  // h_i . n_j
+  const v16f c5 = mfma_fp4_half(ax, bn, z, scale);  // x_i . n_j
+  for (int g = 0; g < 16; ++g) {
+    out[(0 * 64 + l) * 16 + g] = c0[g];
+    out[(1 * 64 + l) * 16 + g] = c1[g];
+    out[(2 * 64 + l) * 16 + g] = c2[g];
+    out[(3 * 64 + l) * 16 + g] = c3[g];
+    out[(4 * 64 + l) * 16 + g] = c4[g];
+    out[(5 * 64 + l) * 16 + g] = c5[g];
+  }
+}
+
+// 7: the instruction alone, NACC independent accumulators, W waves per SIMD; clk[0..1] = shader-clock / 100 MHz wall-clock ticks of block 0
+template <int NACC, int W>
+__global__ __launch_bounds__(256, W) void peak_kernel(const uint32_t* src, float* out, int iters, unsigned long long* clk) {
+  const int l = threadIdx.x;
+  v16f acc[NACC];
+  for (int p = 0; p < NACC; ++p) {
+    for (int g = 0; g < 16; ++g) {
+      acc[p][g] = 0.f;
+    }
+  }
+  const uint32_t fa[4] = {src[l], src[l + 256], src[l + 512], src[l + 768]};
+  const uint32_t fb[4] = {src[l + 1024], src[l + 1280], src[l + 1536], src[l + 1792]};
+  const unsigned long long t0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int p = 0; p < NACC; ++p) {
+      const v8i A = {(int)fa[0], (int)fa[1], (int)fa[2], (int)fa[3], 0, 0, 0, 0};
+      const v8i B = {(int)fb[0], (int)fb[1], (int)fb[2], (int)fb[3], 0, 0, 0, 0};
+      acc[p] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc[p], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+  }
+  const unsigned long long t1 = clock64(), w1 = wall_clock64();
+  float sum = 0.f;
+  for (int p = 0; p < NACC; ++p) {
+    for (int g = 0; g < 16; ++g) {
+      sum += acc[p][g];
+    }
+  }
+  out[blockIdx.x * 256 + l] = sum;
+  if ((blockIdx.x == 0) && (l == 0)) {
+    clk[0] = t1 - t0;
+    clk[1] = w1 - w0;
+  }
 }
 
 // one wave: a[lane][4], b[lane][4], cin[lane][16] -> cout[lane][16]
@@ -339,6 +431,126 @@ int main(int argc, char** argv) {
     bad += !ok;
   }
 
+  // 6. 2-bit codes -> FP4 (3 VALU per 16 samples), six products against CPU counts, scale 0x7E (and 0x7F for the record)
+  {
+    uint32_t *dca, *dcb;
+    float* dout;
+    CHECK(hipMalloc(&dca, 64 * 2 * 4));
+    CHECK(hipMalloc(&dcb, 64 * 2 * 4));
+    CHECK(hipMalloc(&dout, 6 * 1024 * 4));
+    std::vector<uint32_t> ca(128), cb(128);
+    uint64_t rng = 88172645463325252ull;
+    auto next = [&]() {
+      rng ^= rng << 13;
+      rng ^= rng >> 7;
+      rng ^= rng << 17;
+      return static_cast<uint32_t>(rng >> 16);
+    };
+    int ok7e = 1, ok7f = 1;
+    for (int trial = 0; trial < 8; ++trial) {
+      for (int q = 0; q < 128; ++q) {
+        ca[q] = next();
+        cb[q] = next();
+        if (trial == 0) {
+          ca[q] = 0;           // every call hom-REF: x = +1 everywhere
+          cb[q] = 0xaaaaaaaau; // every call hom-ALT: x = -1
+        }
+      }
+      CHECK(hipMemcpy(dca, ca.data(), 512, hipMemcpyHostToDevice));
+      CHECK(hipMemcpy(dcb, cb.data(), 512, hipMemcpyHostToDevice));
+      for (int pass = 0; pass < 2; ++pass) {
+        const int scale = pass ? 0x7f7f7f7f : 0x7e7e7e7e;
+        hipLaunchKernelGGL(codes_mfma, dim3(1), dim3(64), 0, 0, dca, dcb, dout, scale);
+        CHECK(hipDeviceSynchronize());
+        std::vector<float> o(6 * 1024);
+        CHECK(hipMemcpy(o.data(), dout, 6 * 1024 * 4, hipMemcpyDeviceToHost));
+        // row r of an operand = lanes r (half 0) and 32 + r (half 1), 32 samples each
+        auto code = [&](const std::vector<uint32_t>& c, int r, int s) {  // s < 64
+          const int lane = (s >> 5) * 32 + r;
+          const int t = s & 31;
+          return (c[lane * 2 + (t >> 4)] >> (2 * (t & 15))) & 3u;
+        };
+        for (int l = 0; l < 64; ++l) {
+          for (int g = 0; g < 16; ++g) {
+            const int i = (g & 3) + 8 * (g >> 2) + 4 * (l >> 5), j = l & 31;  // i: A row, j: B row
+            int want[6] = {0, 0, 0, 0, 0, 0};
+            for (int sidx = 0; sidx < 64; ++sidx) {
+              const uint32_t gi = code(ca, i, sidx), gj = code(cb, j, sidx);
+              const int xi = (gi == 0) ? 1 : ((gi == 2) ? -1 : 0), xj = (gj == 0) ? 1 : ((gj == 2) ? -1 : 0);
+              const int ni = (gi != 3), nj = (gj != 3), hi = xi * xi, hj = xj * xj;
+              want[0] += xi * xj;
+              want[1] += ni * nj;
+              want[2] += ni * hj;
+              want[3] += ni * xj;
+              want[4] += hi * nj;
+              want[5] += xi * nj;
+            }
+            for (int p = 0; p < 6; ++p) {
+              const float got = o[(p * 64 + l) * 16 + g];
+              const float exp = static_cast<float>(want[p]) * (pass ? 4.f : 1.f);
+              if (got != exp) {
+                if ((pass ? ok7f : ok7e)) {
+                  printf("   codes: product %d pair (%d,%d) scale 0x%02x -> %g, expected %g\n", p, i, j, scale & 0xff, got, exp);
+                }
+                (pass ? ok7f : ok7e) = 0;
+              }
+            }
+          }
+        }
+      }
+    }
+    printf("6. 2-bit codes -> FP4 (magnitude 2.0), six products == CPU counts with E8M0 scale 0x7E (x 1/2 per operand): %s; with 0x7F they are 4x: %s\n",
+           ok7e ? "CONFIRMED" : "DIFFERENT", ok7f ? "CONFIRMED" : "DIFFERENT");
+    bad += !ok7e;
+    CHECK(hipFree(dca));
+    CHECK(hipFree(dcb));
+    CHECK(hipFree(dout));
+  }
+
+  }
+  // 7. the instruction's ceiling by operand data and occupancy
+  {
+    uint32_t* src;
+    float* out;
+    unsigned long long* clk;
+    CHECK(hipMalloc(&src, 2048 * 4));
+    const int blocks = 256 * 4 * 8;
+    CHECK(hipMalloc(&out, blocks * 256 * 4));
+    CHECK(hipMalloc(&clk, 16));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int data = 0; data < 3; ++data) {
+      std::vector<uint32_t> h(2048);
+      for (int q = 0; q < 2048; ++q) {
+        h[q] = (data == 0) ? 0u : ((data == 1) ? 0x22222222u : (0x9e3779b9u * (q + 1)));
+      }
+      CHECK(hipMemcpy(src, h.data(), 2048 * 4, hipMemcpyHostToDevice));
+      for (int w = 0; w < 2; ++w) {
+        float ms = 0.f;
+        const int iters = 4000;
+        for (int rep = 0; rep < 2; ++rep) {
+          CHECK(hipEventRecord(e0, 0));
+          if (w == 0) {
+            hipLaunchKernelGGL((peak_kernel<8, 2>), dim3(blocks), dim3(256), 0, 0, src, out, iters / 2, clk);
+          } else {
+            hipLaunchKernelGGL((peak_kernel<4, 4>), dim3(blocks), dim3(256), 0, 0, src, out, iters, clk);
+          }
+          CHECK(hipEventRecord(e1, 0));
+          CHECK(hipEventSynchronize(e1));
+          CHECK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        unsigned long long hc[2];
+        CHECK(hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost));
+        const double mfmas = (double)blocks * 4 * iters * 4;
+        printf("7. peak (%s operands, %d waves per SIMD, %d accumulators): %.3f ms = %.2f PFLOP/s; shader clock %.0f MHz (clock64 / wall_clock64 of block 0)\n",
+               data == 0 ? "zero" : (data == 1 ? "all +1" : "random"), w ? 4 : 2, w ? 4 : 8, ms, 2 * mfmas * 65536.0 / (ms * 1e-3) / 1e15,
+               hc[1] ? (double)hc[0] / (double)hc[1] * 100.0 : 0.0);
+      }
+    }
+    CHECK(hipFree(src));
+    CHECK(hipFree(out));
+    CHECK(hipFree(clk));
   }
   // 5. rates
   {
