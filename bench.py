@@ -4,28 +4,35 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload at N = 1 (BASELINE.json configs[1]): synthetic 50,000 samples x 1,000,000 biallelic variants, 22 autosomes with
-variant counts proportional to GRCh38 lengths at uniform 2,875 bp spacing, `--indep-pairwise 200kb 0.5`.
-With N GPUs the default is weak scaling on ONE genome: 22 autosomes holding N x 1,000,000 variants, the chromosomes (the
-subcontigs) LPT-sharded over the ranks exactly as `ldp_set_shard` does it, so the load imbalance of 22 unequal
-chromosomes on N ranks is part of the number.  `--strong` keeps the total at --variants whatever N is.  There is no
-data-path collective; the prune bitmask is exchanged once per step with an RCCL all_gather.
+Workloads (synthetic; 22 autosomes with variant counts proportional to GRCh38 lengths, uniform spacing):
+  N = 1   BASELINE.json configs[1]: 50,000 samples x 1,000,000 biallelic variants at 2,875 bp, `--indep-pairwise 200kb 0.5`
+          (the largest named configuration that fits one GPU; the metric's 500k x 10M is 1.25 TB).
+  N >= 2  BASELINE.json configs[2], the configuration the metric is quoted on, STRONG scaling: 500,000 samples x 10,000,000
+          variants at 290 bp, `--indep-pairwise 500kb 0.2`, the 22 chromosomes (the subcontigs) LPT-sharded over the ranks exactly
+          as `ldp_set_shard` does it, so the imbalance of 22 unequal chromosomes on N ranks is part of the number.  A rank's share
+          is resident in HBM at N = 8 (1.25M variants = 156 GB); at N = 2 / 4 it exceeds 288 GB and the rank works through its
+          chromosomes one engine at a time, generating each chromosome's rows inside the step (said so in config.workload).
+  `--workload config2|config3`, `--samples/--variants/--spacing/--window-kb/--r2`, `--strong/--weak` override all of this.
+There is no data-path collective; the prune bitmask is exchanged once per step with an RCCL all_gather.
 
-A "step" is one pass of the hot path over the HBM-resident packed 2-bit genotype matrix: bit-plane split + per-variant
-aggregates + allele counts (prepare_kernel), the banded pair statistics / prune predicate (pair_mfma_kernel for complete
-data, pair_mfma_general_kernel when rows have missing calls), the host replay of the greedy scan, and the bitmask exchange.
-`value` = candidate variant pairs decided per second over all ranks.
+A "step" is one pass of the hot path over the HBM-resident 2-bit genotype image: the count pass (codes_kernel: per-variant
+aggregates, allele counts, major allele, checkpoint statistics -- a read of N/4 bytes per variant, nothing is rewritten: the pair
+kernels expand the 2-bit codes themselves), the banded pair statistics / prune predicate on the matrix pipe (pair_mfma_kernel
+for complete data, its interval epilogue for rows with a few missing calls, pair_mfma_general_kernel otherwise), the host replay
+of the greedy scan, and the bitmask exchange.  The rows are generated straight into the engine's image (ldp_map_rows), so they
+are resident when the timed region starts.  `value` = candidate variant pairs decided per second over all ranks.
 
 One JSON line is printed by rank 0.
   roofline      the pair kernel of the run against BOTH ceilings it can meet, the larger fraction named as `bound`:
                 mfma  executed FP4 MFMA flops (instructions the kernel really issued: plan x k-steps - early termination)
-                      / summed kernel time, against the guide's dense FP4 peak (10 PFLOP/s) and against the rate
-                      tools/mfma_probe.hip measures on this box in this run;
-                hbm   compulsory bytes (every owned bit-plane row once: variants x N/4) / summed kernel time against 8 TB/s,
-                      and the streaming-read rate tools/ubench_copy.hip measures in this run.
+                      / summed kernel time, against the guide's dense FP4 peak (10 PFLOP/s);
+                hbm   compulsory bytes (every owned row once: variants x N/4) / summed kernel time against 8 TB/s.
                 `traffic` (HBM bytes per step from PMC counters) is replayed from profiles/ when the workload matches
                 and says so; the effective stream rate of SURVEY 8(d) (pairs x N/2 bytes) is a named side field.
-  legs          the same step with early termination off, and with 0.1 % / 1 % missing calls (interval epilogue / six-product kernel)
+  legs          (N = 1) the same step with early termination off, with 0.1 % / 1 % missing calls, and the north-star shapes at
+                one GPU: `config3_density` / `config5_density` = 500,000 samples x 120,000 variants at 290 bp, `500kb 0.2`,
+                complete data / 5 % missing calls, each with its kernel time, executed-MFMA fraction, replayed PMC traffic and
+                traffic / compulsory, and a prune-set comparison with reference plink2 on a slice.
   cpu_baseline  reference plink2 (oracle/_ref/plink2, AVX2, all host threads) on a bounded sample of the same generator,
                 prune set compared with the HIP path's; plus both binaries end to end on the sample's files.
 """
@@ -48,21 +55,25 @@ GRCH38_MB = [248.96, 242.19, 198.30, 190.21, 181.54, 170.81, 159.35, 145.14, 138
 SEED = 20260925 + 2
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP4_PEAK_TFLOPS = 10000.0  # MI355X_MICROARCH.md: ~10 PFLOP/s dense FP4 MFMA (AMD's 20 PF figure is 2:1 sparse)
+CONFIGS = {
+    "config2": dict(samples=50000, variants=1000000, spacing=2875, window_kb=200.0, r2=0.5),
+    "config3": dict(samples=500000, variants=10000000, spacing=290, window_kb=500.0, r2=0.2),
+}
+HBM_BYTES = 288e9
 
 
-def genome_layout(variants, genomes, spacing):
-    """chr_idx / bp arrays for `genomes` copies of a 22-autosome genome of `variants` variants each."""
+def genome_layout(variants, spacing):
+    """chr_idx / bp arrays of one 22-autosome genome holding `variants` variants."""
     tot = sum(GRCH38_MB)
     counts = [int(variants * mb / tot) for mb in GRCH38_MB]
     counts[0] += variants - sum(counts)
-    chr_idx = np.empty(variants * genomes, dtype=np.uint32)
-    bps = np.empty(variants * genomes, dtype=np.uint32)
+    chr_idx = np.empty(variants, dtype=np.uint32)
+    bps = np.empty(variants, dtype=np.uint32)
     pos = 0
-    for g in range(genomes):
-        for c, n in enumerate(counts):
-            chr_idx[pos:pos + n] = g * 22 + c
-            bps[pos:pos + n] = 10000 + spacing * np.arange(n, dtype=np.uint32)
-            pos += n
+    for c, n in enumerate(counts):
+        chr_idx[pos:pos + n] = c
+        bps[pos:pos + n] = 10000 + spacing * np.arange(n, dtype=np.uint32)
+        pos += n
     return chr_idx, bps
 
 
@@ -101,7 +112,7 @@ def host_description():
     return {"cpu_model": model, "nproc": os.cpu_count() or 0}
 
 
-def cpu_baseline(pkg, torch, args, founder_ct, spacing, window_bp, r2, missing_rate):
+def cpu_baseline(pkg, torch, founder_ct, m, spacing, window_kb, r2, missing_rate, cli_compare=True):
     """Reference plink2 (all host cores) on a bounded sample of the same generator; also a parity check."""
     ref_bin = os.path.join(REPO, "oracle", "_ref", "plink2")
     base = {"value": None, "unit": "variant-pairs/s", "cores": 0, "kind": "reference", **host_description()}
@@ -109,15 +120,13 @@ def cpu_baseline(pkg, torch, args, founder_ct, spacing, window_bp, r2, missing_r
         return {**base, "sample": "oracle/_ref/plink2 not built"}
     if "avx2" not in open("/proc/cpuinfo").read():
         return {**base, "sample": "host CPU lacks AVX2"}
-    m = args.cpu_sample_variants
-    if m <= 0:
-        m = 440000 if founder_ct <= 100000 else 22000  # ~2-20 s of reference time either way
-    chr_idx, bps = genome_layout(m, 1, spacing)
+    window_bp = pkg.kb_window(window_kb)
+    chr_idx, bps = genome_layout(m, spacing)
     stride = (founder_ct + 3) // 4
     buf = torch.empty((m, stride), dtype=torch.uint8, device="cuda")
     pkg.synth_genotypes_device(SEED, 0, m, founder_ct, missing_rate, buf.data_ptr(), stride)
     torch.cuda.synchronize()
-    # HIP path on the sample
+    # HIP path on the sample (rows from a caller-owned device buffer: copied into the image, then as in the timed step)
     eng = pkg.LdPruneEngine(founder_ct, window_bp, 1, True, r2, device=torch.cuda.current_device())
     eng.set_variants(chr_idx, bps)
     eng.load_genotypes_device(0, m, buf.data_ptr(), stride, pkg.LDP_GENO_REF)
@@ -131,7 +140,7 @@ def cpu_baseline(pkg, torch, args, founder_ct, spacing, window_bp, r2, missing_r
         prefix = os.path.join(tmp, "sample")
         write_plink1_fileset(prefix, host, founder_ct, chr_idx, bps)
         cores = os.cpu_count() or 1
-        kb = "%gkb" % (window_bp / 1000.0)
+        kb = "%gkb" % window_kb
         cmd = [ref_bin, "--bfile", "sample", "--indep-pairwise", kb, repr(r2), "--threads", str(cores), "--out", "ref"]
         t0 = time.perf_counter()
         cp = subprocess.run(cmd, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
@@ -142,7 +151,7 @@ def cpu_baseline(pkg, torch, args, founder_ct, spacing, window_bp, r2, missing_r
         removed_ref = np.array([("snp%d" % i) in removed_ids for i in range(m)])
         cli = {}
         cli_bin = os.path.join(REPO, "plink-ng_amd", "bin", "plink2-hip")
-        if (not args.no_cli_compare) and os.path.exists(cli_bin):
+        if cli_compare and os.path.exists(cli_bin):
             # the process-level drop-in on the same files (file mapping + H2D + kernels + replay + writer)
             t1 = time.perf_counter()
             cc = subprocess.run([cli_bin, "--bfile", "sample", "--indep-pairwise", kb, repr(r2), "--out", "hip"],
@@ -174,12 +183,21 @@ def measured_ceilings():
     probe = os.path.join(REPO, "tools", "_bin", "mfma_probe")
     if os.path.exists(probe):
         try:
-            txt = subprocess.run([probe, "--rates"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120).stdout
-            rates = [float(x) for x in re.findall(r"= ([0-9.]+) PFLOP/s", txt)]
-            if len(rates) >= 3:
-                out["mfma_fp4_tflops_instruction_alone"] = rates[0] * 1000.0
-                out["mfma_fp4_tflops_with_plane_expansion"] = rates[2] * 1000.0
-                out["mfma_source"] = "tools/mfma_probe.hip --rates (v_mfma_scale_f32_32x32x64_f8f6f4, random operands, 2 waves per SIMD; mode 2 = LDS read + 7 bit-plane expansions per 8 MFMAs)"
+            txt = subprocess.run([probe, "--rates"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=180).stdout
+            peak = {}
+            for mt in re.finditer(r"^7\. peak \((\S+(?: \+1)?) operands, (\d) waves per SIMD.*?= ([0-9.]+) PFLOP/s; shader clock (\d+) MHz", txt, re.M):
+                peak["%s_operands_%sw" % (mt.group(1).replace(" ", ""), mt.group(2))] = {"tflops": float(mt.group(3)) * 1000.0, "shader_mhz": int(mt.group(4))}
+            if peak:
+                out["mfma_fp4_instruction_alone"] = peak
+                best = max(v["tflops"] for v in peak.values())
+                rnd = max((v["tflops"] for k, v in peak.items() if k.startswith("random")), default=None)
+                out["mfma_fp4_tflops_best"] = best
+                out["mfma_fp4_tflops_random_operands"] = rnd
+            m2 = re.search(r"^5\. mode 2 .*?= ([0-9.]+) PFLOP/s", txt, re.M)
+            if m2:
+                out["mfma_fp4_tflops_with_plane_expansion"] = float(m2.group(1)) * 1000.0
+            out["mfma_source"] = ("tools/mfma_probe.hip --rates (v_mfma_scale_f32_32x32x64_f8f6f4 alone: constant operands reach the datasheet rate, "
+                                  "random operands clock down -- the shader clock of each run is printed beside it)")
         except Exception as e:  # pragma: no cover
             out["mfma_error"] = str(e)
     copy = os.path.join(REPO, "tools", "_bin", "ubench_copy")
@@ -198,31 +216,174 @@ def measured_ceilings():
     return out
 
 
+class Workload:
+    """One rank's share of a genome: engines planned up front (host work), rows generated straight into an engine's resident
+    image.  `resident`: one engine holds the whole share and its rows stay in HBM across steps.  Otherwise the share does not
+    fit HBM and the rank works through its chromosomes one engine at a time, generating each chromosome's rows inside the step."""
+
+    def __init__(self, pkg, torch, cfg, missing_rate, rank, world, device, options=None):
+        self.pkg, self.torch, self.cfg, self.missing_rate = pkg, torch, cfg, missing_rate
+        self.rank, self.world, self.device = rank, world, device
+        self.options = options or {}
+        self.founder_ct = cfg["samples"]
+        self.window_bp = pkg.kb_window(cfg["window_kb"])
+        self.m_total = cfg["variants"]
+        self.chr_idx, self.bps = genome_layout(self.m_total, cfg["spacing"])
+        planner = self._engine()
+        planner.set_variants(self.chr_idx, self.bps)
+        self.subs = planner.subcontigs()
+        self.owner = planner.set_shard(rank, world) if world > 1 else np.zeros(len(self.subs), dtype=np.uint32)
+        self.owned = [(ln, first) for (ln, first), o in zip(self.subs, self.owner) if o == rank]
+        self.local_ct = sum(ln for ln, _ in self.owned)
+        row_bytes = ((self.founder_ct + 255) // 256) * 64
+        self.image_bytes = self.local_ct * row_bytes
+        self.resident = self.image_bytes * 1.06 + 6e9 < HBM_BYTES
+        self.engines = []
+        if self.resident:
+            self.engines.append((planner, self.owned))
+        else:
+            planner.close()
+            for ln, first in self.owned:  # one engine per owned chromosome, planned now, device memory only while it is worked on
+                e = self._engine()
+                sel = slice(first, first + ln)
+                e.set_variants(self.chr_idx[sel], self.bps[sel])
+                self.engines.append((e, [(ln, first)]))
+        self.segs = {}
+        if self.resident:
+            self._generate(planner, self.owned, 0)
+        torch.cuda.synchronize()
+
+    def _engine(self):
+        e = self.pkg.LdPruneEngine(self.founder_ct, self.window_bp, 1, True, self.cfg["r2"], device=self.device)
+        for k, v in self.options.items():
+            e.set_option(k, v)
+        return e
+
+    def _generate(self, eng, runs, base):
+        """rows of `runs` (global variant ranges) generated into eng's image; eng's variant 0 = global variant `base`"""
+        segs = []
+        for ln, first in runs:
+            ptr, stride = eng.map_rows(first - base, ln)
+            self.pkg.synth_genotypes_device(SEED, first, ln, self.founder_ct, self.missing_rate, ptr, stride)
+            segs.append((first - base, ln, ptr, stride))
+        self.torch.cuda.synchronize()  # (the generator runs on the null stream, the engine on its own: order them)
+        self.segs[id(eng)] = segs
+
+    def step(self):
+        """one pass; returns (global removed bitmap as uint64 words, [counters per engine])"""
+        words = np.zeros((self.m_total + 63) // 64, dtype=np.uint64)
+        ctrs = []
+        for eng, runs in self.engines:
+            base = 0 if self.resident else runs[0][1]
+            if not self.resident:
+                self._generate(eng, runs, base)
+            for first, ln, ptr, stride in self.segs[id(eng)]:
+                eng.load_genotypes_device(first, ln, ptr, stride, self.pkg.LDP_GENO_REF)
+            bm = eng.run_bitmap()  # uint64 words over the engine's variants; only this rank's bits are set
+            ctrs.append(eng.counters())
+            if self.resident:
+                words = bm
+            else:
+                mask = np.unpackbits(bm.view(np.uint8), bitorder="little")[:runs[0][0]]
+                full = np.zeros(self.m_total, dtype=np.uint8)
+                full[base:base + runs[0][0]] = mask
+                words |= np.packbits(np.pad(full, (0, len(words) * 64 - self.m_total)), bitorder="little").view(np.uint64)
+                eng.release_device()
+        return words, ctrs
+
+    def close(self):
+        for eng, _ in self.engines:
+            eng.close()
+        self.engines = []
+        self.torch.cuda.empty_cache()
+
+
+def sum_counters(ctrs):
+    keys = ("candidate_pairs", "pred_true", "replay_pairs", "ms_prepare", "ms_pair_kernel", "ms_pair_mfma", "ms_pair_mfma_general", "ms_pair_fast",
+            "ms_pair_general", "ms_replay", "pair_kernel_launches", "mfma_block_products", "mfma_product_stages", "mfma_skipped_product_stages",
+            "sparse_exact_pairs", "route_complete_launches", "route_sparse_launches", "route_general_launches")
+    return {k: sum(c[k] for c in ctrs) for k in keys}
+
+
+def pmc_traffic(founder_ct, variants, window_kb, missing_rate):
+    """HBM bytes per step from PMC counters, replayed from profiles/ (collected by tools/profile.sh on the same workload)."""
+    for name in sorted(os.listdir(os.path.join(REPO, "profiles")), reverse=True):
+        if not (name.endswith("pmc_traffic.json") and name.startswith("r03")):
+            continue
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", name)))
+        except Exception:
+            continue
+        if (tj.get("samples") == founder_ct and tj.get("variants") == variants and tj.get("window_kb") == window_kb
+                and abs(tj.get("missing_rate", 0.0) - missing_rate) < 1e-12):
+            return tj.get("hbm_bytes_per_step"), "profiles/%s (replayed: PMC passes of tools/profile.sh, tag %s; not measured in this run)" % (name, tj.get("tag")), tj
+    return None, None, None
+
+
+def pair_roofline(c, founder_ct, local_ct, missing_rate, variants, window_kb):
+    kms_mfma, kms_gen = c["ms_pair_mfma"], c["ms_pair_mfma_general"]
+    general = c["route_general_launches"] > 0
+    kms_valu = c["ms_pair_fast"] + c["ms_pair_general"]
+    on_matrix_pipe = (kms_mfma + kms_gen) > kms_valu
+    kernel = ("pair_mfma_general_kernel" if general else "pair_mfma_kernel") if on_matrix_pipe else ("pair_tiles_kernel<true>" if general else "pair_tiles_kernel<false>")
+    kms = (kms_mfma + kms_gen) if on_matrix_pipe else kms_valu
+    launches = max(int(c["pair_kernel_launches"]), 1)
+    # MFMA side: instructions the kernel really issued.  One block product = 32 x 32 pairs; one k-step = one
+    # v_mfma_scale_f32_32x32x64_f8f6f4 = 65,536 MACs; the general kernel issues six per block product and k-step.
+    executed = max(c["mfma_product_stages"] - c["mfma_skipped_product_stages"], 0) * (6 if general else 1)
+    mfma_tflops = (executed * 65536 * 2.0 / (kms * 1e-3)) / 1e12 if (kms > 0 and on_matrix_pipe) else 0.0
+    # HBM side: every owned row must be read once (N/4 bytes per variant, rows padded to 64 bytes)
+    compulsory = local_ct * ((founder_ct + 255) // 256) * 64.0
+    hbm_gbs = (compulsory / (kms * 1e-3)) / 1e9 if kms > 0 else 0.0
+    traffic, traffic_src, tj = pmc_traffic(founder_ct, variants, window_kb, missing_rate)
+    mfma_frac, hbm_frac = mfma_tflops / FP4_PEAK_TFLOPS, hbm_gbs / HBM_PEAK_GBS
+    by_mfma = mfma_frac >= hbm_frac
+    return {
+        "bound": "mfma" if by_mfma else "hbm",
+        "achieved": mfma_tflops if by_mfma else hbm_gbs, "peak": FP4_PEAK_TFLOPS if by_mfma else HBM_PEAK_GBS,
+        "unit": "TFLOP/s" if by_mfma else "GB/s", "frac": mfma_frac if by_mfma else hbm_frac,
+        "traffic": traffic, "traffic_source": traffic_src,
+        "traffic_over_compulsory": (traffic / compulsory) if (traffic and compulsory) else None,
+        "kernel": kernel, "kernel_ms_per_launch": kms / launches, "launches_per_step": launches, "kernel_ms_per_step": kms,
+        "mfma": {"executed_tflops": mfma_tflops, "peak_tflops": FP4_PEAK_TFLOPS, "frac_of_peak": mfma_frac,
+                 "mfma_instructions_per_step": executed, "block_products": c["mfma_block_products"],
+                 "plan_efficiency": (c["candidate_pairs"] / (c["mfma_block_products"] * 1024.0)) if c["mfma_block_products"] else None,
+                 "early_termination_skipped_frac": (c["mfma_skipped_product_stages"] / c["mfma_product_stages"]) if c["mfma_product_stages"] else 0.0},
+        "hbm": {"compulsory_bytes_per_step": compulsory, "compulsory_gbs": hbm_gbs, "peak_gbs": HBM_PEAK_GBS, "frac_of_peak": hbm_frac},
+        "effective_stream_gbs": (c["candidate_pairs"] * (founder_ct / 2.0) / (kms * 1e-3)) / 1e9 if kms > 0 else 0.0,
+        "routes": {"complete": c["route_complete_launches"], "sparse": c["route_sparse_launches"], "general": c["route_general_launches"]},
+        "note": "frac is against the datasheet peak of the named bound.  effective_stream_gbs is SURVEY 8(d)'s pairs x N/2 bytes figure: "
+                "tiling makes it exceed any physical rate, it is not a roofline fraction.",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--samples", type=int, default=50000)
-    ap.add_argument("--variants", type=int, default=1000000, help="variants per GPU (total with --strong)")
-    ap.add_argument("--window-kb", type=float, default=200.0)
-    ap.add_argument("--r2", type=float, default=0.5)
+    ap.add_argument("--workload", choices=sorted(CONFIGS), default=None, help="default: config2 at one GPU, config3 (the metric's) at several")
+    ap.add_argument("--samples", type=int, default=None)
+    ap.add_argument("--variants", type=int, default=None, help="variants of the genome (total with --strong, per GPU with --weak)")
+    ap.add_argument("--window-kb", type=float, default=None)
+    ap.add_argument("--r2", type=float, default=None)
+    ap.add_argument("--spacing", type=int, default=None, help="bp between consecutive variants")
     ap.add_argument("--missing-rate", type=float, default=0.0)
-    ap.add_argument("--spacing", type=int, default=2875, help="bp between consecutive variants")
-    ap.add_argument("--strong", action="store_true", help="strong scaling: --variants is the whole genome, sharded over the ranks")
-    ap.add_argument("--cpu-sample-variants", type=int, default=0, help="0 = 440,000 up to 100k samples, 22,000 beyond")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: the genome is fixed, sharded over the ranks (default for config3)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: --variants per GPU on one genome (default for config2)")
+    ap.add_argument("--cpu-sample-variants", type=int, default=0, help="0 = 440,000 up to 100k samples, 11,000 beyond")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-legs", action="store_true", help="skip the exhaustive / missing-calls legs and the ceiling microbenchmarks")
-    ap.add_argument("--resident-planes", action="store_true",
-                    help="for shapes whose 2-bit input and bit-planes do not fit HBM together (config 3: 156 GB each): convert once, "
-                         "chunk by chunk, outside the timed region; a step is then the pair kernel + replay only (said so in config.workload)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the exhaustive / missing-calls / north-star-shape legs and the ceiling microbenchmarks")
     ap.add_argument("--no-cli-compare", action="store_true", help="do not time plink2-hip end-to-end on the CPU-baseline sample files")
+    ap.add_argument("--leg-variants", type=int, default=120000, help="variants of the config3/5-density legs")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
     pkg = ge.load_package()
+    import importlib
+    distmod = importlib.import_module("plink_ng_amd.dist")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -239,57 +400,14 @@ def main():
     if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    founder_ct = args.samples
-    spacing = args.spacing
-    window_bp = pkg.kb_window(args.window_kb)
-    m_total = args.variants if args.strong else args.variants * world
-    chr_idx, bps = genome_layout(m_total, 1, spacing)  # ONE genome, whatever the rank count
-
-    def build_engine(missing_rate):
-        eng = pkg.LdPruneEngine(founder_ct, window_bp, 1, True, args.r2, device=local_rank)
-        eng.set_variants(chr_idx, bps)
-        subs = eng.subcontigs()
-        owner = eng.set_shard(rank, world) if world > 1 else np.zeros(len(subs), dtype=np.uint32)
-        owned = [(ln, first) for (ln, first), o in zip(subs, owner) if o == rank]
-        local_ct = sum(ln for ln, _ in owned)
-        # synthetic REF-coded genotypes of the owned subcontigs, resident in HBM before timing starts
-        stride = (founder_ct + 3) // 4
-        seg, geno = [], None
-        if args.resident_planes:
-            chunk_rows = max(1, (8 << 30) // stride)
-            chunk = torch.empty((chunk_rows, stride), dtype=torch.uint8, device="cuda")
-            for ln, first in owned:
-                for c0 in range(0, ln, chunk_rows):
-                    cnt = min(chunk_rows, ln - c0)
-                    pkg.synth_genotypes_device(SEED, first + c0, cnt, founder_ct, missing_rate, chunk.data_ptr(), stride)
-                    torch.cuda.synchronize()  # the generator runs on the null stream, the engine on its own: order them
-                    eng.load_genotypes_device(first + c0, cnt, chunk.data_ptr(), stride, pkg.LDP_GENO_REF)
-                    torch.cuda.synchronize()  # ... and the chunk buffer is reused
-            del chunk
-            torch.cuda.empty_cache()
-        else:
-            geno = torch.empty((max(local_ct, 1), stride), dtype=torch.uint8, device="cuda")
-            off = 0
-            for ln, first in owned:
-                pkg.synth_genotypes_device(SEED, first, ln, founder_ct, missing_rate, geno.data_ptr() + off * stride, stride)
-                seg.append((first, ln, off))
-                off += ln
-        torch.cuda.synchronize()
-        return eng, geno, seg, stride, local_ct, len(subs)
-
-    import importlib
-    distmod = importlib.import_module("plink_ng_amd.dist")
-
-    def make_step(eng, geno, seg, stride):
-        def step():
-            for first, ln, o in seg:
-                eng.load_genotypes_device(first, ln, geno.data_ptr() + o * stride, stride, pkg.LDP_GENO_REF)
-            bm = eng.run_bitmap()  # uint64 words over all variants; only this rank's bits are set
-            if use_dist:
-                # the one exchange step: all_gather of the per-rank removed bitmaps (RCCL over xGMI), OR-ed on the device
-                return distmod.allgather_bitmaps(bm, world, device="cuda")
-            return bm
-        return step
+    name = args.workload or ("config2" if world == 1 else "config3")
+    cfg = dict(CONFIGS[name])
+    for k, v in (("samples", args.samples), ("variants", args.variants), ("window_kb", args.window_kb), ("r2", args.r2), ("spacing", args.spacing)):
+        if v is not None:
+            cfg[k] = v
+    strong = args.strong or ((name == "config3") and not args.weak)
+    if not strong:
+        cfg["variants"] = cfg["variants"] * world
 
     def sync():
         torch.cuda.synchronize()
@@ -297,23 +415,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(step, eng, steps, warmup):
+    def timed(wl, steps, warmup):
+        def one():
+            words, ctrs = wl.step()
+            if use_dist:
+                # the one exchange step: all_gather of the per-rank removed bitmaps (RCCL over xGMI), OR-ed on the device
+                return distmod.allgather_bitmaps(words, world, device="cuda"), ctrs
+            return words, ctrs
         for _ in range(warmup):
-            step()
+            one()
         sync()
         t0 = time.perf_counter()
         ks, removed = [], None
         for _ in range(steps):
-            removed = step()
-            ks.append(eng.counters())
+            removed, ctrs = one()
+            ks.append(sum_counters(ctrs))
         sync()
         return time.perf_counter() - t0, ks, removed
 
-    eng, geno, seg, stride, local_ct, n_subs = build_engine(args.missing_rate)
-    step = make_step(eng, geno, seg, stride)
-    elapsed, ks, removed = timed(step, eng, args.steps, args.warmup)
+    wl = Workload(pkg, torch, cfg, args.missing_rate, rank, world, local_rank)
+    elapsed, ks, removed = timed(wl, args.steps, args.warmup)
     ctr = ks[-1]
-    removed = distmod.bitmap_to_mask(removed.cpu().numpy() if use_dist else removed, m_total)
+    removed = distmod.bitmap_to_mask(removed.cpu().numpy() if use_dist else removed, cfg["variants"])
     per_rank_pairs = [ctr["candidate_pairs"]]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -328,123 +451,93 @@ def main():
     out = None
     if rank == 0:
         mean = lambda key: float(np.mean([k[key] for k in ks])) if ks else 0.0
+        cmean = {k: mean(k) for k in ks[-1]}
         ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
         value = total_pairs * args.steps / elapsed
-        kms_mfma, kms_mfma_gen = mean("ms_pair_mfma"), mean("ms_pair_mfma_general")
-        # (rows with only a few missing calls stay with pair_mfma_kernel and its interval epilogue: DESIGN 4.1d)
-        general = (args.missing_rate > 0) and not (kms_mfma > kms_mfma_gen)
-        kms_valu = mean("ms_pair_fast") + mean("ms_pair_general")
-        on_matrix_pipe = (kms_mfma + kms_mfma_gen) > kms_valu
-        kernel = ("pair_mfma_general_kernel" if general else "pair_mfma_kernel") if on_matrix_pipe else \
-                 ("pair_tiles_kernel<true>" if general else "pair_tiles_kernel<false>")
-        kms = (kms_mfma_gen if general else kms_mfma) if on_matrix_pipe else kms_valu
-        launches = max(int(ctr["pair_kernel_launches"]), 1)
-        # --- MFMA side: instructions the kernel really issued.  One block product = 32 x 32 pairs; one k-step = one
-        # v_mfma_scale_f32_32x32x64_f8f6f4 = 65,536 MACs; the general kernel issues six per block product and k-step.
-        executed_ksteps = max(ctr["mfma_product_stages"] - ctr["mfma_skipped_product_stages"], 0) * (6 if general else 1)
-        mfma_flops = executed_ksteps * 65536 * 2.0
-        mfma_tflops = (mfma_flops / (kms * 1e-3)) / 1e12 if (kms > 0 and on_matrix_pipe) else 0.0
-        # --- HBM side: every owned bit-plane row must be read once (N/4 bytes per variant)
-        compulsory = local_ct * ((founder_ct + 511) // 512) * 128.0
-        hbm_gbs = (compulsory / (kms * 1e-3)) / 1e9 if kms > 0 else 0.0
-        traffic, traffic_src = None, None
-        tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if (tj.get("samples") == founder_ct and tj.get("variants") == args.variants and tj.get("window_kb") == args.window_kb
-                        and tj.get("kernel", "").startswith(kernel.split("<")[0]) and not general and world == 1):
-                    traffic = tj.get("hbm_bytes_per_step")
-                    traffic_src = "profiles/pmc_traffic.json (replayed: PMC passes of tools/profile.sh, tag %s; not measured in this run)" % tj.get("tag")
-            except Exception:
-                traffic = None
-        mfma_frac, hbm_frac = mfma_tflops / FP4_PEAK_TFLOPS, hbm_gbs / HBM_PEAK_GBS
-        by_mfma = mfma_frac >= hbm_frac
-        roofline = {
-            "bound": "mfma" if by_mfma else "hbm",
-            "achieved": mfma_tflops if by_mfma else hbm_gbs, "peak": FP4_PEAK_TFLOPS if by_mfma else HBM_PEAK_GBS,
-            "unit": "TFLOP/s" if by_mfma else "GB/s", "frac": mfma_frac if by_mfma else hbm_frac,
-            "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel,
-            "kernel_ms_per_launch": kms / launches, "launches_per_step": launches, "kernel_ms_per_step": kms,
-            "mfma": {"executed_tflops": mfma_tflops, "peak_tflops": FP4_PEAK_TFLOPS, "frac_of_peak": mfma_frac,
-                     "mfma_instructions_per_step": executed_ksteps, "block_products": ctr["mfma_block_products"],
-                     "plan_efficiency": (ctr["candidate_pairs"] / (ctr["mfma_block_products"] * 1024.0)) if ctr["mfma_block_products"] else None,
-                     "early_termination_skipped_frac": (ctr["mfma_skipped_product_stages"] / ctr["mfma_product_stages"]) if ctr["mfma_product_stages"] else 0.0},
-            "hbm": {"compulsory_bytes_per_step": compulsory, "compulsory_gbs": hbm_gbs, "peak_gbs": HBM_PEAK_GBS, "frac_of_peak": hbm_frac},
-            "effective_stream_gbs": (ctr["candidate_pairs"] * (founder_ct / 2.0) / (kms * 1e-3)) / 1e9 if kms > 0 else 0.0,
-            "note": "frac is against the datasheet peak of the named bound; measured_ceilings (same run, same box) give the same "
-                    "fractions against what this box delivers.  effective_stream_gbs is SURVEY 8(d)'s pairs x N/2 bytes figure: "
-                    "tiling makes it exceed any physical rate, it is not a roofline fraction.",
-        }
+        roofline = pair_roofline(cmean, cfg["samples"], wl.local_ct, args.missing_rate, cfg["variants"], cfg["window_kb"])
+        on_matrix_pipe = roofline["kernel"].startswith("pair_mfma")
         out = {
             "metric": "variant-pairs/s (--indep-pairwise, whole job)", "value": value, "unit": "variant-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
-            "dtype": "fp4 (E2M1: exact -1/0/+1) x fp4 -> f32 integer-exact MFMA accumulation + f64 predicate" if on_matrix_pipe
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "fp4 (E2M1: exact -2/0/+2, block scale 1/2) x fp4 -> f32 integer-exact MFMA accumulation + f64 predicate" if on_matrix_pipe
                      else "u32 popcount + f64 predicate",
             "data": "synthetic",
-            "config": {"workload": "synthetic %d samples x %d biallelic variants (%s), one genome of 22 autosomes at %d bp spacing, "
-                                   "--indep-pairwise %gkb %g, missing rate %g, chromosomes LPT-sharded over %d rank(s)%s" %
-                                   (founder_ct, m_total, "total, strong scaling" if args.strong else "%d per GPU, weak scaling" % args.variants,
-                                    spacing, args.window_kb, args.r2, args.missing_rate, world,
-                                    "; bit-planes resident, conversion outside the timed step" if args.resident_planes else ""),
-                       "samples": founder_ct, "variants_total": m_total, "variants_rank0": local_ct, "window_kb": args.window_kb, "r2": args.r2,
-                       "subcontigs": n_subs, "candidate_pairs_total": total_pairs, "candidate_pairs_per_rank": per_rank_pairs,
+            "config": {"workload": "%s: synthetic %d samples x %d biallelic variants (%s), one genome of 22 autosomes at %d bp spacing, "
+                                   "--indep-pairwise %gkb %g, missing rate %g, chromosomes LPT-sharded over %d rank(s); %s" %
+                                   (name, cfg["samples"], cfg["variants"], "total, strong scaling" if strong else "%d per GPU, weak scaling" % (cfg["variants"] // world),
+                                    cfg["spacing"], cfg["window_kb"], cfg["r2"], args.missing_rate, world,
+                                    "2-bit rows resident in HBM, counted in place each step (no conversion pass, no second image)" if wl.resident else
+                                    "a rank's share (%.0f GB) exceeds HBM: one engine per chromosome, each chromosome's rows generated inside the step" % (wl.image_bytes / 1e9)),
+                       "samples": cfg["samples"], "variants_total": cfg["variants"], "variants_rank0": wl.local_ct, "window_kb": cfg["window_kb"], "r2": cfg["r2"],
+                       "subcontigs": len(wl.subs), "candidate_pairs_total": total_pairs, "candidate_pairs_per_rank": per_rank_pairs,
                        "shard_imbalance_max_over_mean": (max(per_rank_pairs) / (total_pairs / world)) if total_pairs else 1.0,
                        "pairs_above_threshold_rank0": ctr["pred_true"], "above_threshold_pairs_consumed_by_replay_rank0": ctr["replay_pairs"],
-                       "variants_removed": int(removed.sum())},
+                       "variants_removed": int(removed.sum()), "resident": bool(wl.resident)},
             "roofline": roofline,
-            "stage_ms": {"prepare_kernel": mean("ms_prepare"), "pair_kernels": mean("ms_pair_kernel"), "pair_mfma_kernel": kms_mfma,
-                         "pair_mfma_general_kernel": kms_mfma_gen, "pair_tiles_kernels_popcount": kms_valu, "host_replay": mean("ms_replay"),
-                         "note": "prepare_kernel (HBM-bound: reads N/4, writes N/4 bytes per variant) and the pair kernel run back to back"},
+            "stage_ms": {"count_pass_codes_kernel": mean("ms_prepare"), "pair_kernels": mean("ms_pair_kernel"), "pair_mfma_kernel": mean("ms_pair_mfma"),
+                         "pair_mfma_general_kernel": mean("ms_pair_mfma_general"), "pair_tiles_kernels_popcount": mean("ms_pair_fast") + mean("ms_pair_general"),
+                         "host_replay": mean("ms_replay"),
+                         "note": "the count pass (HBM-bound: reads N/4 bytes per variant, writes only the records) and the pair kernel run back to back; "
+                                 "count pass: %.0f GB/s" % ((wl.image_bytes / (mean("ms_prepare") * 1e-3) / 1e9) if mean("ms_prepare") > 0 else 0.0)},
         }
-    eng.close()
-    del geno
-    torch.cuda.empty_cache()
+    wl.close()
 
-    if rank == 0 and world == 1 and not args.no_legs and not args.resident_planes:
+    if rank == 0 and world == 1 and not args.no_legs:
         legs = {}
+        half = max(2, args.steps // 2)
+
+        def leg(cfg_l, missing, options, steps):
+            w = Workload(pkg, torch, cfg_l, missing, 0, 1, local_rank, options)
+            el, kk, rem = timed(w, steps, 1)
+            c = {k: float(np.mean([q[k] for q in kk])) for k in kk[-1]}
+            r = pair_roofline(c, cfg_l["samples"], w.local_ct, missing, cfg_l["variants"], cfg_l["window_kb"])
+            res = {"ms_per_step": 1000.0 * el / steps, "count_pass_ms": c["ms_prepare"], "pair_kernels_ms": c["ms_pair_kernel"], "kernel": r["kernel"],
+                   "routes": r["routes"], "pairs_counted_exactly": int(c["sparse_exact_pairs"]), "candidate_pairs": int(c["candidate_pairs"]),
+                   "variants_removed": int(distmod.bitmap_to_mask(rem, cfg_l["variants"]).sum()), "roofline": r}
+            w.close()
+            return res
+
         # (a) the same step with early termination off: every block product walks every sample
-        os.environ["LDP_EARLY_EXIT"] = "0"
-        e2, g2, s2, st2, _, _ = build_engine(args.missing_rate)
-        el, k2, _ = timed(make_step(e2, g2, s2, st2), e2, max(2, args.steps // 2), 1)
-        legs["exhaustive"] = {"ms_per_step": 1000.0 * el / max(2, args.steps // 2), "pair_kernels_ms": float(np.mean([k["ms_pair_kernel"] for k in k2])),
-                              "what": "LDP_EARLY_EXIT=0"}
-        e2.close()
-        del g2
-        os.environ.pop("LDP_EARLY_EXIT")
-        torch.cuda.empty_cache()
+        legs["exhaustive"] = leg(cfg, args.missing_rate, {"early_exit": 0}, half)
+        legs["exhaustive"]["what"] = "early termination off (ldp_debug_set_option early_exit 0)"
         # (b) missing calls in every variant: 0.1 % (the complete-data kernel with the interval epilogue) and
         # 1 % (the six-product kernel)
         if args.missing_rate == 0.0:
             for rate in (0.001, 0.01):
-                e3, g3, s3, st3, _, _ = build_engine(rate)
-                el, k3, _ = timed(make_step(e3, g3, s3, st3), e3, max(2, args.steps // 2), 1)
-                c3 = e3.counters()
-                last = k3[-1]
-                kern = max((("pair_mfma_kernel", last["ms_pair_mfma"]), ("pair_mfma_general_kernel", last["ms_pair_mfma_general"]),
-                            ("pair_tiles_kernel<true>", last["ms_pair_general"])), key=lambda kv: kv[1])[0]
-                legs["missing_rate_%g" % rate] = {"ms_per_step": 1000.0 * el / max(2, args.steps // 2),
-                                                  "pair_kernels_ms": float(np.mean([k["ms_pair_kernel"] for k in k3])),
-                                                  "prepare_ms": float(np.mean([k["ms_prepare"] for k in k3])),
-                                                  "kernel": kern,
-                                                  "pairs_counted_exactly": int(c3.get("sparse_exact_pairs", 0)),
-                                                  "vs_complete_data_step": (1000.0 * el / max(2, args.steps // 2)) / out["ms_per_step"]}
-                e3.close()
-                del g3
+                legs["missing_rate_%g" % rate] = leg(cfg, rate, {}, half)
+                legs["missing_rate_%g" % rate]["vs_complete_data_step"] = legs["missing_rate_%g" % rate]["ms_per_step"] / out["ms_per_step"]
+        # (c) the north-star shapes at one GPU: config 3's / config 5's density on a slice of the genome that fits
+        if name == "config2" and args.leg_variants > 0:
+            c3 = dict(CONFIGS["config3"], variants=args.leg_variants)
+            for key, rate in (("config3_density", 0.0), ("config5_density", 0.05)):
+                try:
+                    L = leg(c3, rate, {}, 3)
+                    L["what"] = ("%d samples x %d variants at %d bp, --indep-pairwise %gkb %g, %s; rows resident, count pass inside the step" %
+                                 (c3["samples"], c3["variants"], c3["spacing"], c3["window_kb"], c3["r2"],
+                                  "complete data" if rate == 0.0 else "5 % missing calls in every variant (config 5's multiallelic sites reach the pair kernels as "
+                                  "ordinary 2-bit rows -- the major-vs-rest collapse happens where the record is decoded, DESIGN 7 -- and are modelled as such)"))
+                    if not args.no_cpu_baseline:
+                        m_slice = args.cpu_sample_variants or 11000
+                        cb = cpu_baseline(pkg, torch, c3["samples"], m_slice, c3["spacing"], c3["window_kb"], c3["r2"], rate, cli_compare=False)
+                        L["reference_slice"] = {k: cb.get(k) for k in ("prune_set_identical_to_hip", "removed", "wall_s", "value", "cores", "sample")}
+                    legs[key] = L
+                except Exception as e:  # pragma: no cover  (e.g. a smaller GPU)
+                    legs[key] = {"error": str(e)[:300]}
                 torch.cuda.empty_cache()
         out["legs"] = legs
         ceil = measured_ceilings()
         out["roofline"]["measured_ceilings"] = ceil
-        if ceil.get("mfma_fp4_tflops_instruction_alone"):
-            out["roofline"]["mfma"]["frac_of_measured_instruction_rate"] = out["roofline"]["mfma"]["executed_tflops"] / ceil["mfma_fp4_tflops_instruction_alone"]
-            out["roofline"]["mfma"]["frac_of_measured_rate_with_expansion"] = out["roofline"]["mfma"]["executed_tflops"] / ceil["mfma_fp4_tflops_with_plane_expansion"]
+        if ceil.get("mfma_fp4_tflops_random_operands"):
+            out["roofline"]["mfma"]["frac_of_measured_rate_random_operands"] = out["roofline"]["mfma"]["executed_tflops"] / ceil["mfma_fp4_tflops_random_operands"]
         if ceil.get("hbm_read_gbs"):
             out["roofline"]["hbm"]["frac_of_measured_read_rate"] = out["roofline"]["hbm"]["compulsory_gbs"] / ceil["hbm_read_gbs"]
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, torch, args, founder_ct, spacing, window_bp, args.r2, args.missing_rate)
+            m = args.cpu_sample_variants or (440000 if cfg["samples"] <= 100000 else 11000)  # ~2-20 s of reference time either way
+            out["cpu_baseline"] = cpu_baseline(pkg, torch, cfg["samples"], m, cfg["spacing"], cfg["window_kb"], cfg["r2"], args.missing_rate,
+                                               cli_compare=not args.no_cli_compare)
         else:
             out["cpu_baseline"] = {"value": None, "unit": "variant-pairs/s", "cores": 0, "kind": "reference",
                                    "sample": "measured at N=1 only", **host_description()}

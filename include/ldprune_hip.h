@@ -179,6 +179,21 @@ int ldp_get_band(const ldp_engine* e, uint32_t* lo, uint64_t* candidate_pairs);
  * Loading a variant again (a new pass over the data) simply starts over. */
 int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* geno, uint64_t stride_bytes,
                        int location, int encoding);
+/* Zero-copy loading.  The engine keeps the genotypes as one resident image of 2-bit rows -- the same codes, the same N/4 bytes
+ * per variant as the input -- and a producer that runs on the device (a decoder, a generator) can write its rows straight into
+ * it: *device_rows receives the device address of the image row of first_variant, *stride_bytes the distance between rows
+ * (ceil(founder_ct / 4) rounded up to a multiple of 64: write the ceil(founder_ct / 4) meaningful bytes of each row, the engine
+ * fills the padding).  Then call ldp_load_genotypes() with exactly this pointer, stride and range, LDP_MEM_DEVICE and
+ * LDP_GENO_REF or LDP_GENO_INVERSE: the rows are counted where they are (one read of the data, no copy, no conversion pass).
+ * This is the role of the raw_tgenovecs buffers the reference's main thread decodes into for its workers (plink2_ld.cc:1206,
+ * 1357).  The variants must be consecutive owned rows (one subcontig run at a time).  Rows loaded from any other buffer are
+ * copied into the image as before.  LDP_ERR_UNSUPPORTED when the engine keeps bit-planes instead (more founders than
+ * ldp_matrix_pipe_max_founders()): load from your own buffer then. */
+int ldp_map_rows(ldp_engine* e, uint32_t first_variant, uint32_t n, void** device_rows, uint64_t* stride_bytes);
+/* Give the engine's device memory back (image, records, predicate rows, staging) while keeping its plan: for a caller that works
+ * through more data than fits HBM, one engine (chromosome) after the other.  The next ldp_load_genotypes() / ldp_map_rows()
+ * allocates again; every row has to be loaded again before the next ldp_run(). */
+int ldp_release_device(ldp_engine* e);
 /* Sample-mapped rows: the rows the reference assembles per variant on chrX, chrY and MT before LdPrune's pair loop
  * (plink2_ld.cc:1356-1388: founder subset, SetHetMissing on the haploid samples, on chrX the males once and the non-males
  * as two pseudo-samples -- DESIGN.md section 7), built on the device.  Column f of an engine row is sample src_sample[f] of
@@ -214,10 +229,9 @@ int ldp_pair_stats(ldp_engine* e, uint32_t n_pairs, const uint32_t* first, const
 int ldp_debug_set_variant_recs(ldp_engine* e, const ldp_variant_rec* recs);
 int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first, const uint32_t* second, uint64_t* removed);
 /* Kernel-selection switches of ONE engine, for tests and measurements (the defaults are what production runs use; they can also
- * be preset from the environment at ldp_create(): LDP_EARLY_EXIT, LDP_PAIR_MFMA, LDP_PAIR_MFMA_GENERAL, LDP_PAIR_SPARSE,
+ * be preset from the environment at ldp_create(): LDP_EARLY_EXIT, LDP_PAIR_MFMA, LDP_PAIR_SPARSE,
  * LDP_DEBUG_SPARSE_FRAC).  name: "early_exit" (0/1: checkpoints that drop provably sub-threshold products), "pair_mfma" (0/1:
- * matrix-pipe kernels; 0 = the popcount kernels -- set before ldp_set_variants*()), "mfma_general" (0/1: rows with missing calls
- * on the matrix pipe), "pair_sparse" (0/1: the interval epilogue for rows with a few missing calls), "sparse_frac" (mean
+ * matrix-pipe kernels; 0 = the popcount kernels -- set before ldp_set_variants*()), "pair_sparse" (0/1: the interval epilogue for rows with a few missing calls), "sparse_frac" (mean
  * missing fraction up to which a launch takes it).  Results never depend on these.  Unknown name: LDP_ERR_INVALID. */
 int ldp_debug_set_option(ldp_engine* e, const char* name, double value);
 /* Host-only view of the matrix-pipe work plan (csrc/ldp_device.h: MfmaWG) in the engine's shard-local variant

@@ -89,12 +89,12 @@ CABI_SYMBOLS = [
     "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_r2_unphased_hits", "ldp_r2_unphased_block", "ldp_r2_unphased_block_hits", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_has_dosage", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
     "ldp_pgen_variant_is_multiallelic", "ldp_pgen_provisional_ref", "ldp_pgen_open_indexed", "ldp_set_r_signed", "ldp_set_variants_vcor_cm", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_subset_samples", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
-    "ldp_debug_set_option", "ldp_matrix_pipe_max_founders",
+    "ldp_debug_set_option", "ldp_matrix_pipe_max_founders", "ldp_map_rows", "ldp_release_device",
 ]
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_pair_mfma.hip", "ldp_synth.hip", "ldp_engine.cpp", "ldp_pgen.cpp")]
+    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_codes.hip", "ldp_pair_mfma.hip", "ldp_synth.hip", "ldp_engine.cpp", "ldp_pgen.cpp")]
 
 
 def _stale(target, deps):
@@ -171,6 +171,8 @@ def lib():
     L.ldp_pair_stats.argtypes = [vp, ctypes.c_uint32, u32p, u32p, vp]
     L.ldp_debug_set_variant_recs.argtypes = [vp, vp]
     L.ldp_debug_replay_pairs.argtypes = [vp, ctypes.c_uint64, u32p, u32p, u64p]
+    L.ldp_map_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp), u64p]
+    L.ldp_release_device.argtypes = [vp]
     L.ldp_matrix_pipe_max_founders.argtypes = []
     L.ldp_matrix_pipe_max_founders.restype = ctypes.c_uint32
     L.ldp_debug_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_double]
@@ -213,6 +215,15 @@ def lib():
     L.ldp_pgen_close.restype = None
     _lib = L
     return L
+
+
+def hip_memcpy_dtod(dst_ptr, src_ptr, nbytes):
+    """hipMemcpy device -> device through the process's HIP runtime (test / benchmark plumbing: fills mapped image rows from a
+    torch tensor)."""
+    lib()
+    rt = ctypes.CDLL("libamdhip64.so", mode=ctypes.RTLD_GLOBAL)
+    rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    return int(rt.hipMemcpy(ctypes.c_void_p(dst_ptr), ctypes.c_void_p(src_ptr), ctypes.c_size_t(nbytes), 3))  # 3 = hipMemcpyDeviceToDevice
 
 
 def matrix_pipe_max_founders():
@@ -509,6 +520,19 @@ class LdPruneEngine:
     def load_genotypes_device(self, first_variant, n, device_ptr, stride_bytes, encoding=LDP_GENO_INVERSE):
         self._ck(self._L.ldp_load_genotypes(self._h, first_variant, n, ctypes.c_void_p(device_ptr), stride_bytes,
                                             LDP_MEM_DEVICE, encoding))
+
+    def map_rows(self, first_variant, n):
+        """(device pointer, stride in bytes) of the engine's own image rows of variants [first_variant, first_variant + n): write
+        REF- or INVERSE-coded 2-bit rows there and pass the same pointer / stride to load_genotypes_device() -- they are counted in
+        place, nothing is copied (ldp_map_rows)."""
+        ptr = ctypes.c_void_p()
+        stride = ctypes.c_uint64()
+        self._ck(self._L.ldp_map_rows(self._h, int(first_variant), int(n), ctypes.byref(ptr), ctypes.byref(stride)))
+        return int(ptr.value), int(stride.value)
+
+    def release_device(self):
+        """Free the engine's device memory, keep its plan (ldp_release_device)."""
+        self._ck(self._L.ldp_release_device(self._h))
 
     def set_sample_map(self, raw_sample_ct, src_sample, het_to_missing=None):
         """Column f of the engine's rows = sample src_sample[f] of rows loaded with LDP_GENO_MAPPED; het_to_missing[f] != 0

@@ -113,8 +113,13 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
     }
     if (phased) {
       const uint32_t ph = src_dword(row + phase_off, phase_bytes, u, aligned4);
-      hap_codes_of_16(src_dword(row, code_bytes, 2 * u, aligned4), ph, &w.x, &w.y);
-      hap_codes_of_16(src_dword(row, code_bytes, 2 * u + 1, aligned4), ph >> 16, &w.z, &w.w);
+      uint32_t o0, o1, o2, o3;
+      hap_codes_of_16(src_dword(row, code_bytes, 2 * u, aligned4), ph, &o0, &o1);
+      hap_codes_of_16(src_dword(row, code_bytes, 2 * u + 1, aligned4), ph >> 16, &o2, &o3);
+      w.x = o0;
+      w.y = o1;
+      w.z = o2;
+      w.w = o3;
     } else {
       if (aligned4 && (16u * u + 16u <= code_bytes)) {
         // streamed once: non-temporal (global_load_dwordx4 only needs dword alignment on gfx950, all a packed row guarantees)

@@ -77,7 +77,6 @@ constexpr int kPairStreams = 1;
 struct EngineOptions {
   bool early_exit = true;     // LDP_EARLY_EXIT=0: exhaustive pair kernels
   bool pair_mfma = true;      // LDP_PAIR_MFMA=0: popcount kernels instead of the matrix pipe
-  bool mfma_general = true;   // LDP_PAIR_MFMA_GENERAL=0: rows with missing calls go to the popcount kernel
   double sparse_frac = 0.005; // LDP_PAIR_SPARSE=0 -> 0; LDP_DEBUG_SPARSE_FRAC
 };
 
@@ -152,6 +151,11 @@ struct ldp_engine {
   std::vector<uint64_t> preferred;        // global bitmap (may be empty)
 
   // ---- device ----
+  // The resident genotype image: 2-bit codes for the matrix-pipe kernels (ldp_device.h; the default), hom / ref2het bit-planes
+  // for the popcount kernels (more than kMfMaxFounders founders, or pair_mfma switched off).  Exactly one of the two exists.
+  bool codes_format = false;
+  uint8_t* d_codes = nullptr;
+  uint64_t code_row_bytes = 0;
   uint32_t* d_planes = nullptr;
   ldp_variant_rec* d_recs = nullptr;
   uint32_t* d_lo = nullptr;
@@ -282,6 +286,8 @@ void free_device(ldp_engine* e) {
     return;
   }
   (void)hipFree(e->d_planes);
+  (void)hipFree(e->d_codes);
+  e->d_codes = nullptr;
   (void)hipFree(e->d_recs);
   (void)hipFree(e->d_lo);
   (void)hipFree(e->d_row_off);
@@ -495,8 +501,6 @@ EngineOptions options_from_env() {
   o.early_exit = !(ee && (strcmp(ee, "0") == 0));
   const char* m = getenv("LDP_PAIR_MFMA");
   o.pair_mfma = !(m && (strcmp(m, "0") == 0));
-  const char* g = getenv("LDP_PAIR_MFMA_GENERAL");
-  o.mfma_general = !(g && (atoi(g) == 0));
   const char* off = getenv("LDP_PAIR_SPARSE");
   const char* f = getenv("LDP_DEBUG_SPARSE_FRAC");
   o.sparse_frac = (off && (strcmp(off, "0") == 0)) ? 0.0 : (f ? atof(f) : 0.005);
@@ -929,7 +933,13 @@ int ensure_device_plan(ldp_engine* e) {
   e->chunks = (plane_dwords + kChunkDwords - 1) / kChunkDwords;
   e->row_dwords = static_cast<uint64_t>(e->chunks) * kRowChunkDwords;
   const size_t n = std::max<size_t>(e->local_ct, 1);
-  HIP_TRY(e, hipMalloc(&e->d_planes, n * e->row_dwords * sizeof(uint32_t)));
+  e->codes_format = e->opt.pair_mfma && (e->P.founder_ct <= kMfMaxFounders);
+  e->code_row_bytes = code_row_bytes_of(e->P.founder_ct);
+  if (e->codes_format) {
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_codes), n * e->code_row_bytes));
+  } else {
+    HIP_TRY(e, hipMalloc(&e->d_planes, n * e->row_dwords * sizeof(uint32_t)));
+  }
   HIP_TRY(e, hipMalloc(&e->d_recs, n * sizeof(ldp_variant_rec)));
   HIP_TRY(e, hipMalloc(&e->d_lo, n * sizeof(uint32_t)));
   HIP_TRY(e, hipMalloc(&e->d_row_off, (n + 1) * sizeof(uint64_t)));
@@ -972,7 +982,7 @@ int ensure_device_plan(ldp_engine* e) {
     HIP_TRY(e, hipMemcpyAsync(e->d_row_off, e->row_off.data(), (e->local_ct + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->d_pair_off, e->pair_off.data(), (e->local_ct + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
   }
-  if (!e->items.empty()) {
+  if ((!e->items.empty()) && !e->codes_format) {  // (the popcount work items: host-side bookkeeping only when the matrix pipe runs)
     HIP_TRY(e, hipMemcpyAsync(e->d_items, e->items.data(), e->items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, e->stream));
   }
   if (e->local_ct) {
@@ -1387,6 +1397,8 @@ int prepare_mf(ldp_engine* e, std::vector<double>* scratch, const double** mf_ou
 void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_exit) {
   PairKernelArgs& A = *out;
   A.planes = e->d_planes;
+  A.codes = e->d_codes;
+  A.code_row_bytes = e->code_row_bytes;
   A.row_dwords = e->row_dwords;
   A.chunks = e->chunks;
   A.founder_ct = e->P.founder_ct;
@@ -1395,7 +1407,7 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.row_off = e->d_row_off;
   A.pred = e->d_pred;
   A.items = e->d_items;
-  A.n_items = static_cast<uint32_t>(e->items.size());
+  A.n_items = e->codes_format ? 0u : static_cast<uint32_t>(e->items.size());
   A.plane_base_variant = 0;
   A.thresh = e->P.prune_last_param * (1 + kSmallEpsilon);  // plink2_ld.cc:1255
   A.stats = nullptr;
@@ -1487,11 +1499,11 @@ int launch_group(ldp_engine* e, uint32_t gi) {
   fill_pair_args(e, &A, true);
   A.items = e->d_items + g.item_first;
   A.item_general = e->d_item_general + g.item_first;
-  A.n_items = g.item_ct;
+  A.n_items = e->codes_format ? 0u : g.item_ct;
   if (e->mf_enabled) {
     // Which kernel family owns the group is decided on the device, once per group: a snapshot of the missing-calls flag
     // (all of the group's rows are converted by now) that every kernel of the group reads.
-    A.mf_active = e->opt.mfma_general ? 2 : 1;
+    A.mf_active = 2;
     A.sparse_ok = ((A.mf_active == 2) && !A.stats && (e->opt.sparse_frac > 0.0)) ? 1 : 0;
     HIP_TRY(e, queue_route(e, gi, ps, A.sparse_ok, g.need_end));
     A.route = e->d_route + gi;
@@ -1598,7 +1610,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     if (e->mf_enabled) {
       const size_t slot = e->groups.size();
       HIP_TRY(e, queue_route(e, slot, e->stream, 0, e->local_ct));
-      A.mf_active = e->opt.mfma_general ? 2 : 1;
+      A.mf_active = 2;
       A.route = e->d_route + slot;
       A.mf_wgs = e->d_mf_wgs;
       A.n_mf_wgs = static_cast<uint32_t>(e->mf_wgs.size());
@@ -1629,8 +1641,10 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     }
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (!e->items.empty()) {
-      HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
-      HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[2], evk[3]));
+      if (!e->codes_format) {  // (the popcount kernels were launched)
+        HIP_TRY(e, hipEventElapsedTime(&kms_fast, evk[0], evk[1]));
+        HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[2], evk[3]));
+      }
       if (e->mf_enabled && !e->mf_wgs.empty()) {
         HIP_TRY(e, hipEventElapsedTime(&kms_mfma, evk[4], evk[5]));
         HIP_TRY(e, hipEventElapsedTime(&kms_mfma_general, evk[5], evk[6]));
@@ -1703,8 +1717,10 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     tl[4] = now_ms();
     for (ldp_engine::PairGroup& g : e->groups) {
       float f = 0.f, gen = 0.f;
-      HIP_TRY(e, hipEventElapsedTime(&f, g.ev[0], g.ev[1]));
-      HIP_TRY(e, hipEventElapsedTime(&gen, g.ev[2], g.ev[3]));
+      if (!e->codes_format) {  // (the popcount kernels were launched)
+        HIP_TRY(e, hipEventElapsedTime(&f, g.ev[0], g.ev[1]));
+        HIP_TRY(e, hipEventElapsedTime(&gen, g.ev[2], g.ev[3]));
+      }
       if (e->mf_enabled && g.mf_ct) {
         float mf = 0.f, mfg = 0.f;
         HIP_TRY(e, hipEventElapsedTime(&mf, g.ev[4], g.ev[5]));
@@ -2005,7 +2021,7 @@ int ldp_set_variants_vcor_cm(ldp_engine* e, uint32_t variant_ct, const uint32_t*
 namespace {
 // --r2-unphased requests on the matrix pipe: plan the requested second variants' block products (ldp_device.h: MfmaWG),
 // upload the plan and attach it to the launch.  The r^2 epilogue is emit_pair()'s, shared with the popcount kernels.
-bool r2_on_matrix_pipe(const ldp_engine* e) { return e->opt.pair_mfma && (e->P.founder_ct <= kMfMaxFounders); }
+bool r2_on_matrix_pipe(const ldp_engine* e) { return e->codes_format; }  // (set by ensure_device_plan: the matrix-pipe kernels read the code image)
 
 int attach_mfma_plan(ldp_engine* e, PairKernelArgs* A, const std::vector<std::pair<uint32_t, uint32_t>>& runs, const uint32_t* lo, uint32_t j_first,
                      uint32_t j_end, DevBuf* buf, uint64_t* products, uint32_t i_first = 0, uint32_t i_end = 0xffffffffu) {
@@ -2533,6 +2549,10 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
   const uint64_t gather_stride = ((static_cast<uint64_t>(e->P.founder_ct) + 3) / 4 + 3) & ~static_cast<uint64_t>(3);
   size_t gather_rows = 0;
   if (mapped) {
+    if (!e->d_sample_map) {  // (the device copy went with a re-plan or ldp_release_device(): the host copy is the master)
+      HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_sample_map), e->sample_map.size() * sizeof(uint32_t)));
+      HIP_TRY(e, hipMemcpy(e->d_sample_map, e->sample_map.data(), e->sample_map.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     gather_rows = std::max<size_t>(1, std::max<size_t>(stage_rows, kStageBytes / gather_stride));
     if (location == LDP_MEM_HOST) {
       gather_rows = stage_rows;
@@ -2653,7 +2673,20 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
       PA.n_variants = cnt;
       PA.founder_ct = e->P.founder_ct;
       PA.encoding = prep_encoding;
-      PA.planes = e->d_planes + static_cast<uint64_t>(l0) * e->row_dwords;
+      PA.codes_out = nullptr;
+      PA.code_row_bytes = e->code_row_bytes;
+      if (e->codes_format) {
+        PA.codes_out = e->d_codes + static_cast<uint64_t>(l0) * e->code_row_bytes;
+        // Rows the caller filled in the image itself (ldp_map_rows) are counted where they are; any other pointer into the image
+        // would be read while it is being written.
+        const uint8_t* img_end = e->d_codes + static_cast<uint64_t>(e->local_ct) * e->code_row_bytes;
+        if ((location == LDP_MEM_DEVICE) && (!mapped) && (d_src + static_cast<uint64_t>(cnt - 1) * d_stride + row_bytes > e->d_codes) && (d_src < img_end)) {
+          if ((d_src != PA.codes_out) || (d_stride != e->code_row_bytes) || phased || (base_encoding == LDP_GENO_BED)) {
+            return fail(e, LDP_ERR_INVALID, "rows inside the engine's image must be the mapped rows themselves (ldp_map_rows: same variants, same stride, REF or INVERSE codes)");
+          }
+        }
+      }
+      PA.planes = e->codes_format ? nullptr : (e->d_planes + static_cast<uint64_t>(l0) * e->row_dwords);
       PA.row_dwords = e->row_dwords;
       PA.chunks = e->chunks;
       PA.recs = e->d_recs + l0;
@@ -2666,14 +2699,14 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
       PA.n_checkpoints = e->n_checkpoints;
       PA.miss_stats = nullptr;  // (the route is taken from the records when a launch is queued: queue_route)
       PA.miss_high = static_cast<uint32_t>(std::min(2.0 * e->opt.sparse_frac * static_cast<double>(e->P.founder_ct), 4294967295.0));
-      PA.fix_cp_gen = !(e->mf_enabled && e->opt.mfma_general);  // (only the popcount kernel's interval bound reads cp_gen)
+      PA.fix_cp_gen = !e->mf_enabled;  // (only the popcount kernel's interval bound reads cp_gen)
       if (!e->prep_pending) {
         HIP_TRY(e, hipEventRecord(e->prep_ev0, e->stream));
         e->prep_pending = true;
       }
-      hipError_t krc = launch_prepare(PA, e->stream);
+      hipError_t krc = e->codes_format ? launch_codes(PA, e->stream) : launch_prepare(PA, e->stream);
       if (krc != hipSuccess) {
-        return hipfail(e, krc, "prepare_kernel launch");
+        return hipfail(e, krc, e->codes_format ? "codes_kernel launch" : "prepare_kernel launch");
       }
       HIP_TRY(e, hipEventRecord(e->prep_ev1, e->stream));
       if (location == LDP_MEM_HOST) {
@@ -2705,6 +2738,68 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
   if (location == LDP_MEM_HOST) {
     HIP_TRY(e, hipStreamSynchronize(e->stream));  // the caller may reuse its buffer once we return
   }
+  return LDP_OK;
+}
+
+int ldp_map_rows(ldp_engine* e, uint32_t first_variant, uint32_t n, void** device_rows, uint64_t* stride_bytes) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  if (!device_rows || !stride_bytes) {
+    return fail(e, LDP_ERR_INVALID, "null output pointer");
+  }
+  *device_rows = nullptr;
+  *stride_bytes = 0;
+  if (!e->planned) {
+    return fail(e, LDP_ERR_STATE, "ldp_set_variants() first");
+  }
+  if ((!n) || (static_cast<uint64_t>(first_variant) + n > e->variant_ct)) {
+    return fail(e, LDP_ERR_INVALID, "variant range out of bounds");
+  }
+  const int rc = ensure_device_plan(e);
+  if (rc) {
+    return rc;
+  }
+  if (!e->codes_format) {
+    return fail(e, LDP_ERR_UNSUPPORTED, "this engine keeps bit-planes (more founders than the matrix pipe takes, or pair_mfma off): load from your own buffer");
+  }
+  const int64_t l0 = e->global_to_local[first_variant];
+  if (l0 < 0) {
+    return fail(e, LDP_ERR_INVALID, "the first variant is not owned by this engine (ldp_set_shard / a subcontig of length one)");
+  }
+  for (uint32_t q = 1; q < n; ++q) {
+    if (e->global_to_local[first_variant + q] != l0 + q) {
+      return fail(e, LDP_ERR_INVALID, "the variants are not consecutive rows of this engine (map one owned run at a time: ldp_get_subcontigs)");
+    }
+  }
+  *device_rows = e->d_codes + static_cast<uint64_t>(l0) * e->code_row_bytes;
+  *stride_bytes = e->code_row_bytes;
+  return LDP_OK;
+}
+
+int ldp_release_device(ldp_engine* e) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  if (!e->gpu_ok || !e->plan_uploaded) {
+    return LDP_OK;
+  }
+  HIP_TRY(e, hipSetDevice(e->device));
+  for (int k = 0; k < kPairStreams; ++k) {
+    HIP_TRY(e, hipStreamSynchronize(e->pair_stream[k]));
+  }
+  HIP_TRY(e, hipStreamSynchronize(e->copy_stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  free_device(e);
+  // the rows are gone with the image: everything has to be loaded again before the next run
+  std::fill(e->loaded.begin(), e->loaded.end(), 0);
+  std::fill(e->load_tag.begin(), e->load_tag.end(), 0);
+  for (uint8_t& m : e->mf_set) {
+    m = (m == 1) ? 1 : 0;  // (caller-supplied frequencies stay)
+  }
+  e->load_epoch = 1;
+  e->recs_host_valid = false;
+  e->recs_copy_queued = false;
   return LDP_OK;
 }
 
@@ -2821,7 +2916,8 @@ int ldp_pair_stats(ldp_engine* e, uint32_t n_pairs, const uint32_t* first, const
   ldp_pair_stats_t* d_out = out_buf.as<ldp_pair_stats_t>();
   HIP_TRY(e, hipMemcpyAsync(d_idx, lf.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(d_idx + n_pairs, ls.data(), n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-  hipError_t krc = launch_pair_stats_ref(e->d_planes, e->row_dwords, e->chunks, 0, d_idx, d_idx + n_pairs, n_pairs, d_out, e->stream);
+  hipError_t krc = e->codes_format ? launch_pair_stats_ref_codes(e->d_codes, e->code_row_bytes, e->d_recs, d_idx, d_idx + n_pairs, n_pairs, d_out, e->stream)
+                                   : launch_pair_stats_ref(e->d_planes, e->row_dwords, e->chunks, 0, d_idx, d_idx + n_pairs, n_pairs, d_out, e->stream);
   if (krc != hipSuccess) {
     return hipfail(e, krc, "pair_stats_ref launch");
   }
@@ -2842,8 +2938,6 @@ int ldp_debug_set_option(ldp_engine* e, const char* name, double value) {
       return fail(e, LDP_ERR_STATE, "pair_mfma must be set before ldp_set_variants()");
     }
     e->opt.pair_mfma = (value != 0.0);
-  } else if (n == "mfma_general") {
-    e->opt.mfma_general = (value != 0.0);
   } else if (n == "pair_sparse") {
     if (value == 0.0) {
       e->opt.sparse_frac = 0.0;
@@ -3009,9 +3103,32 @@ int ldp_get_planes(ldp_engine* e, uint32_t variant, uint32_t* hom, uint32_t* ref
   if (rc) {
     return rc;
   }
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  const uint32_t plane_dwords = (e->P.founder_ct + 31) / 32;
+  if (e->codes_format) {
+    // the planes SplitHomRef2het (pgenlib_misc.cc:1797) would make of the major-allele-oriented row, from the image's codes:
+    // hom = !b0, ref2het = !b1, and ref2het ^= hom when the row is ALT-major (the 0 <-> 2 inversion the image does not carry)
+    std::vector<uint32_t> codes(e->code_row_bytes / 4);
+    ldp_variant_rec rec;
+    HIP_TRY(e, hipMemcpy(codes.data(), e->d_codes + static_cast<uint64_t>(l) * e->code_row_bytes, e->code_row_bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(&rec, e->d_recs + l, sizeof(rec), hipMemcpyDeviceToHost));
+    for (uint32_t p = 0; p < plane_dwords; ++p) {
+      uint32_t h = 0, r = 0;
+      for (uint32_t half = 0; half < 2; ++half) {
+        const uint32_t w = codes[2 * p + half];
+        for (uint32_t t = 0; t < 16; ++t) {
+          const uint32_t c = (w >> (2 * t)) & 3u;
+          h |= ((c & 1u) ^ 1u) << (16 * half + t);
+          r |= ((c >> 1) ^ 1u) << (16 * half + t);
+        }
+      }
+      hom[p] = h;
+      ref2het[p] = (rec.flags & 1u) ? (r ^ h) : r;
+    }
+    return LDP_OK;
+  }
   std::vector<uint32_t> row(e->row_dwords);
   HIP_TRY(e, hipMemcpy(row.data(), e->d_planes + static_cast<uint64_t>(l) * e->row_dwords, e->row_dwords * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  const uint32_t plane_dwords = (e->P.founder_ct + 31) / 32;
   for (uint32_t p = 0; p < plane_dwords; ++p) {
     const uint32_t off = (p / kChunkDwords) * kRowChunkDwords + (p % kChunkDwords);
     hom[p] = row[off];

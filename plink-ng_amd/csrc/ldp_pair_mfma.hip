@@ -238,44 +238,45 @@ __device__ __forceinline__ int classify_sparse(const PairKernelArgs& A, double d
   return 2;
 }
 
-// the five pairwise-complete counts of (i, j) by the whole wave; every lane returns the same tuple (dot is the caller's)
-__device__ __forceinline__ ldp_pair_stats_t wave_pair_counts(const PairKernelArgs& A, uint32_t i, uint32_t j, int32_t dot, uint32_t lane) {
-  // 16-byte loads, two per row and plane in flight (a lone wave is latency-bound here): quad q of a plane = dwords 4 (q & 3) ..
-  // of chunk q >> 2; a row chunk is 8 quads, hom first
-  const uint4* __restrict__ r1 = reinterpret_cast<const uint4*>(A.planes + static_cast<uint64_t>(i) * A.row_dwords);
-  const uint4* __restrict__ r2 = reinterpret_cast<const uint4*>(A.planes + static_cast<uint64_t>(j) * A.row_dwords);
-  const uint32_t n_quads = A.chunks * (kChunkDwords / 4);
+// the five pairwise-complete counts of (i, j) by the whole wave, from the two rows of the code image; every lane returns the
+// same tuple (dot is the caller's).  The integers are in major-allele orientation, like the records: si / sj = the rows'
+// ALT-major flags.
+__device__ __forceinline__ ldp_pair_stats_t wave_pair_counts(const PairKernelArgs& A, uint32_t i, uint32_t j, int32_t dot, uint32_t lane, bool alt_i, bool alt_j) {
+  // 16-byte loads, two per row in flight (a lone wave is latency-bound here)
+  const uint4* __restrict__ r1 = reinterpret_cast<const uint4*>(A.codes + static_cast<uint64_t>(i) * A.code_row_bytes);
+  const uint4* __restrict__ r2 = reinterpret_cast<const uint4*>(A.codes + static_cast<uint64_t>(j) * A.code_row_bytes);
+  const uint32_t n_quads = static_cast<uint32_t>(A.code_row_bytes / 16);
   uint32_t c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0;
-  const uint4 zero = make_uint4(0, 0, 0, 0);
+  const uint4 pad = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);  // "missing": counts nothing
   for (uint32_t q = lane; q < n_quads; q += 128) {
     const uint32_t qb = q + 64;
     const bool two = qb < n_quads;
-    const uint32_t ia = (q >> 2) * 8 + (q & 3), ib = two ? ((qb >> 2) * 8 + (qb & 3)) : ia;
-    const uint4 h1a = r1[ia], q1a = r1[ia + 4], h2a = r2[ia], q2a = r2[ia + 4];
-    uint4 h1b = r1[ib], q1b = r1[ib + 4], h2b = r2[ib], q2b = r2[ib + 4];
+    const uint4 w1a = r1[q], w2a = r2[q];
+    uint4 w1b = r1[two ? qb : q], w2b = r2[two ? qb : q];
     if (!two) {
-      h1b = zero;
-      q1b = zero;
-      h2b = zero;
-      q2b = zero;
+      w1b = pad;
+      w2b = pad;
     }
-#define LDP_SPARSE_COUNT(H1, Q1, H2, Q2)               \
-  {                                                    \
-    const uint32_t n1 = (H1) | (Q1), n2 = (H2) | (Q2); \
-    c2 += __popc(n1 & n2);                             \
-    c3 += __popc(n1 & (H2));                           \
-    c4 += __popc(n1 & (H2) & (Q2));                    \
-    c5 += __popc(n2 & (H1));                           \
-    c6 += __popc(n2 & (H1) & (Q1));                    \
+    // sixteen samples per dword at the even bit positions: h = homozygous, p = hom-REF (x = +1), n = call present
+#define LDP_SPARSE_COUNT(W1, W2)                                                                  \
+  {                                                                                               \
+    const uint32_t h1 = ~(W1) & 0x55555555u, h2 = ~(W2) & 0x55555555u;                             \
+    const uint32_t p1 = h1 & ~((W1) >> 1), p2 = h2 & ~((W2) >> 1);                                 \
+    const uint32_t n1 = ~((W1) & ((W1) >> 1)) & 0x55555555u, n2 = ~((W2) & ((W2) >> 1)) & 0x55555555u; \
+    c2 += __popc(n1 & n2);                                                                        \
+    c3 += __popc(n1 & h2);                                                                        \
+    c4 += __popc(n1 & p2);                                                                        \
+    c5 += __popc(n2 & h1);                                                                        \
+    c6 += __popc(n2 & p1);                                                                        \
   }
-    LDP_SPARSE_COUNT(h1a.x, q1a.x, h2a.x, q2a.x)
-    LDP_SPARSE_COUNT(h1a.y, q1a.y, h2a.y, q2a.y)
-    LDP_SPARSE_COUNT(h1a.z, q1a.z, h2a.z, q2a.z)
-    LDP_SPARSE_COUNT(h1a.w, q1a.w, h2a.w, q2a.w)
-    LDP_SPARSE_COUNT(h1b.x, q1b.x, h2b.x, q2b.x)
-    LDP_SPARSE_COUNT(h1b.y, q1b.y, h2b.y, q2b.y)
-    LDP_SPARSE_COUNT(h1b.z, q1b.z, h2b.z, q2b.z)
-    LDP_SPARSE_COUNT(h1b.w, q1b.w, h2b.w, q2b.w)
+    LDP_SPARSE_COUNT(w1a.x, w2a.x)
+    LDP_SPARSE_COUNT(w1a.y, w2a.y)
+    LDP_SPARSE_COUNT(w1a.z, w2a.z)
+    LDP_SPARSE_COUNT(w1a.w, w2a.w)
+    LDP_SPARSE_COUNT(w1b.x, w2b.x)
+    LDP_SPARSE_COUNT(w1b.y, w2b.y)
+    LDP_SPARSE_COUNT(w1b.z, w2b.z)
+    LDP_SPARSE_COUNT(w1b.w, w2b.w)
 #undef LDP_SPARSE_COUNT
   }
   c2 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c2));  // (the sum lands in lane 0)
@@ -286,9 +287,9 @@ __device__ __forceinline__ ldp_pair_stats_t wave_pair_counts(const PairKernelArg
   ldp_pair_stats_t st;
   st.nm = c2;
   st.ssq2 = c3;
-  st.sum2 = static_cast<int32_t>(2 * c4 - c3);
+  st.sum2 = static_cast<int32_t>(2 * c4 - c3) * (alt_j ? -1 : 1);
   st.ssq1 = c5;
-  st.sum1 = static_cast<int32_t>(2 * c6 - c5);
+  st.sum1 = static_cast<int32_t>(2 * c6 - c5) * (alt_i ? -1 : 1);
   st.dot = dot;
   return st;
 }
@@ -320,10 +321,14 @@ __device__ __forceinline__ uint32_t sparse_round(const PairKernelArgs& A, const 
       const int64_t i64 = vfirst + (g & 3) + 8 * (g >> 2);
       const bool valid = j_ok && (i64 >= static_cast<int64_t>(lo_j)) && (i64 < j64);
       const uint32_t i = valid ? static_cast<uint32_t>(i64) : 0u;
-      const int32_t dot = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]);
+      int32_t dot = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]);
       int cls = 0;
+      uint32_t alt_ij = 0;  // bit 0: row i is ALT-major, bit 1: row j
       if (valid) {
-        cls = classify_sparse(A, static_cast<double>(dot), A.recs[i], rj);
+        const ldp_variant_rec ri = A.recs[i];
+        alt_ij = (ri.flags & 1u) | ((rj.flags & 1u) << 1);
+        dot = ((alt_ij == 1u) || (alt_ij == 2u)) ? -dot : dot;  // the image's orientation -> the records' (major allele)
+        cls = classify_sparse(A, static_cast<double>(dot), ri, rj);
         if (cls == 1) {
           atomicOr(&A.pred[A.row_off[j] + ((i >> 5) - (lo_j >> 5))], 1u << (i & 31));
           ++n_true;
@@ -337,7 +342,8 @@ __device__ __forceinline__ uint32_t sparse_round(const PairKernelArgs& A, const 
         const uint32_t ii = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(i), l));
         const uint32_t jj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(j), l));
         const int32_t dd = __builtin_amdgcn_readlane(dot, l);
-        const ldp_pair_stats_t st = wave_pair_counts(A, ii, jj, dd, lane);
+        const uint32_t aa = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(alt_ij), l));
+        const ldp_pair_stats_t st = wave_pair_counts(A, ii, jj, dd, lane, (aa & 1u) != 0, (aa & 2u) != 0);
         if ((static_cast<int>(lane) == l) && exceeds(st, A.thresh)) {
           atomicOr(&A.pred[A.row_off[j] + ((i >> 5) - (lo_j >> 5))], 1u << (i & 31));
           ++n_true;
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   const uint32_t stage_dwords = n_instr * 256;
   uint32_t stages = A.lds_dwords / stage_dwords;
   stages = (stages > kMfMaxStages) ? kMfMaxStages : stages;
-  const uint32_t row_bytes = static_cast<uint32_t>(A.row_dwords * sizeof(uint32_t));
+  const uint32_t row_bytes = static_cast<uint32_t>(A.code_row_bytes);
   const uint32_t n_stages = (A.founder_ct + G::kStageSamples - 1) / G::kStageSamples;
 
   // ---- DMA plan: per-lane source offsets (LDS) and per-instruction row-block bases (uniform) ----
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
 #pragma unroll
   for (int t = 0; t < kMfMaxDmaPerWave; ++t) {
     const uint32_t T = wave + kMfWaves * t;
-    base_t[t] = reinterpret_cast<const uint8_t*>(A.planes);
+    base_t[t] = A.codes;
     if (T < n_instr) {
       const uint32_t blk = G::block_of_instr(T);
       const uint32_t first = __builtin_amdgcn_readfirstlane(wg->rb[(blk < n_rb) ? blk : (n_rb - 1)]);
@@ -682,6 +688,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
       if (lo_j < j) {
         const int32_t sum_j = A.recs[j].sum;
         const uint32_t ssq_j = A.recs[j].ssq;
+        const uint32_t flags_j = A.recs[j].flags;
 #pragma unroll 1
         for (uint32_t pl = 0; pl < 4; ++pl) {
           if (!(live & (1u << (4 * round + pl)))) {
@@ -695,11 +702,13 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
               continue;
             }
             const uint32_t i = static_cast<uint32_t>(i64);
+            const ldp_variant_rec ri = A.recs[i];
             ldp_pair_stats_t ps;
-            ps.dot = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]);
+            const int32_t dot_img = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]);
+            ps.dot = ((ri.flags ^ flags_j) & 1u) ? -dot_img : dot_img;  // the image's orientation -> the records' (major allele)
             ps.nm = A.founder_ct;
-            ps.sum1 = A.recs[i].sum;
-            ps.ssq1 = A.recs[i].ssq;
+            ps.sum1 = ri.sum;
+            ps.ssq1 = ri.ssq;
             ps.sum2 = sum_j;
             ps.ssq2 = ssq_j;
             n_true += emit_pair(A, i, j, lo_j, ps) ? 1 : 0;
@@ -721,19 +730,19 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
 // SumSsqNmWords :578-602).  Per variant three vectors over the samples: x in {-1, 0, +1} as above, n = 1 where the call
 // is present (hom | ref2het), h = x^2 (hom).  For first variant i and second variant j:
 //   dot = x_i.x_j   nm = n_i.n_j   ssq2 = n_i.h_j   sum2 = n_i.x_j   ssq1 = h_i.n_j   sum1 = x_i.n_j
-// six integer matrix products instead of one, against seven popcounts instead of two on the VALU path.  (The nibble
-// code of x is -x, see fp4_of_planes: dot is unaffected, the two sums come out negated and are flipped in the epilogue.)
+// six integer matrix products instead of one, against seven popcounts instead of two on the VALU path.  All three vectors are
+// coded 2.0 at nibble bit 2 (x with its sign at bit 3) and every product carries the 1/2 x 1/2 block scale.  x is in the
+// image's orientation: dot and the two sums take their signs from the records' ALT-major flags in the epilogue.
 // A workgroup owns ONE second-variant block of a wave item and its (up to) four first-variant blocks, one product per
 // wave: 6 x 16 accumulator registers, the J block's three fragment sets of the stage kept in registers.
-__device__ __forceinline__ void fp4_nh_of_planes(uint32_t H, uint32_t R, const Frag& fx, Frag& fn, Frag& fh) {
-  const uint32_t N = H | R;  // call present
-  fn.d[0] = (N << 1) & 0x22222222u;
-  fn.d[1] = N & 0x22222222u;
-  fn.d[2] = (N >> 1) & 0x22222222u;
-  fn.d[3] = (N >> 2) & 0x22222222u;
+__device__ __forceinline__ void fp4_nh_of_codes(uint32_t c0, uint32_t c1, const Frag& fx, Frag& fn, Frag& fh) {
+  fn.d[0] = fp4_n(c0);
+  fn.d[1] = fp4_n(c0 << 2);
+  fn.d[2] = fp4_n(c1);
+  fn.d[3] = fp4_n(c1 << 2);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    fh.d[q] = fx.d[q] & 0x22222222u;  // |x|
+    fh.d[q] = fx.d[q] & 0x44444444u;  // |x|
   }
 }
 
@@ -777,7 +786,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
   const uint32_t jend = wi->jend;
   const bool live = (mask4 >> wave) & 1u;  // this wave's product: (J_q, V_{q + wave})
   const int32_t vfirst_blk = vv + static_cast<int32_t>(kMfBlock * (q + wave));
-  const uint32_t row_bytes = static_cast<uint32_t>(A.row_dwords * sizeof(uint32_t));
+  const uint32_t row_bytes = static_cast<uint32_t>(A.code_row_bytes);
   const uint32_t n_stages = (A.founder_ct + G::kStageSamples - 1) / G::kStageSamples;
   const uint32_t stage_dwords = kMfGenInstr * 256;
   uint32_t stages = A.lds_dwords / stage_dwords;
@@ -790,7 +799,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
 #pragma unroll
   for (int t = 0; t < static_cast<int>(kMfGenDmaPerWave); ++t) {
     const uint32_t T = wave + kMfWaves * t;
-    base_t[t] = reinterpret_cast<const uint8_t*>(A.planes);
+    base_t[t] = A.codes;
     if (T < kMfGenInstr) {
       const uint32_t blk = T >> 1;
       int32_t first = jfirst;
@@ -864,15 +873,15 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
     Frag jx[4], jn[4], jh[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      fp4_of_planes(jH[ks], jR[ks], jx[ks]);
-      fp4_nh_of_planes(jH[ks], jR[ks], jx[ks], jn[ks], jh[ks]);
+      fp4_of_codes(jH[ks], jR[ks], jx[ks]);
+      fp4_nh_of_codes(jH[ks], jR[ks], jx[ks], jn[ks], jh[ks]);
     }
     opaque(vH, vR);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       Frag vx, vn, vh;
-      fp4_of_planes(vH[ks], vR[ks], vx);
-      fp4_nh_of_planes(vH[ks], vR[ks], vx, vn, vh);
+      fp4_of_codes(vH[ks], vR[ks], vx);
+      fp4_nh_of_codes(vH[ks], vR[ks], vx, vn, vh);
       // rows of C = first variant i (A operand: the V block), columns = second variant j (B operand: the J block)
       acc[0] = mfma_fp4(vx, jx[ks], acc[0]);
       acc[1] = mfma_fp4(vn, jn[ks], acc[1]);
@@ -886,17 +895,21 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
   uint32_t n_true = 0;
   if (live && (lo_j != 0xffffffffu) && (static_cast<int64_t>(lo_j) < j64)) {
     const uint32_t j = static_cast<uint32_t>(j64);
+    const bool alt_j = (A.recs[j].flags & 1u) != 0;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int64_t i64 = static_cast<int64_t>(vfirst_blk) + (g & 3) + 8 * (g >> 2) + 4 * h;
       if ((i64 >= static_cast<int64_t>(lo_j)) && (i64 < j64)) {
+        // the image's orientation -> the records' (major allele): x_i, x_j change sign with their row's ALT-major flag
+        const bool alt_i = (A.recs[static_cast<uint32_t>(i64)].flags & 1u) != 0;
         ldp_pair_stats_t ps;
-        ps.dot = static_cast<int32_t>(acc[0][g]);
+        const int32_t d = static_cast<int32_t>(acc[0][g]), s2 = static_cast<int32_t>(acc[3][g]), s1 = static_cast<int32_t>(acc[5][g]);
+        ps.dot = (alt_i != alt_j) ? -d : d;
         ps.nm = static_cast<uint32_t>(static_cast<int32_t>(acc[1][g]));
         ps.ssq2 = static_cast<uint32_t>(static_cast<int32_t>(acc[2][g]));
-        ps.sum2 = -static_cast<int32_t>(acc[3][g]);
+        ps.sum2 = alt_j ? -s2 : s2;
         ps.ssq1 = static_cast<uint32_t>(static_cast<int32_t>(acc[4][g]));
-        ps.sum1 = -static_cast<int32_t>(acc[5][g]);
+        ps.sum1 = alt_i ? -s1 : s1;
         n_true += emit_pair(A, static_cast<uint32_t>(i64), j, lo_j, ps) ? 1 : 0;
       }
     }
@@ -913,22 +926,13 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
     return hipSuccess;
   }
   PairKernelArgs a = a_in;
-  // 256-sample stages (four k-steps between barriers).  128-sample stages double the ring depth in the same LDS but were
-  // measured slower everywhere (config 2: 7.4 vs 5.0 ms, config-3 density: 80 vs 53 ms; profiles/): the extra barrier and
-  // the lane-half select cost more than the deeper ring buys.  LDP_DEBUG_MFMA_KS=2 selects them (tuning aid).
-  static const int ks = []() {
-    const char* k = getenv("LDP_DEBUG_MFMA_KS");
-    return (k && (atoi(k) == 2)) ? 2 : 4;
-  }();
   // 64 KiB (+ 8 KiB static) lets two workgroups share a CU; LDP_DEBUG_MFMA_LDS_KB trades that for a deeper ring (tuning aid)
   static const size_t lds = []() {
     size_t bytes = static_cast<size_t>(kMfLdsDwords) * sizeof(uint32_t);
     if (const char* kb = getenv("LDP_DEBUG_MFMA_LDS_KB")) {
       bytes = std::max<size_t>(bytes, std::min<size_t>(static_cast<size_t>(atoi(kb)), 150) * 1024);
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
     return bytes;
   }();
@@ -937,16 +941,9 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
   if (ev) {
     (void)hipEventRecord(ev[0], stream);
   }
-  if (ks == 4) {
-    hipLaunchKernelGGL((pair_mfma_kernel<4, false>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
-    if (a.sparse_ok) {
-      hipLaunchKernelGGL((pair_mfma_kernel<4, true>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
-    }
-  } else {
-    hipLaunchKernelGGL((pair_mfma_kernel<2, false>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
-    if (a.sparse_ok) {
-      hipLaunchKernelGGL((pair_mfma_kernel<2, true>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
-    }
+  hipLaunchKernelGGL((pair_mfma_kernel<4, false>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
+  if (a.sparse_ok) {
+    hipLaunchKernelGGL((pair_mfma_kernel<4, true>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
   }
   if (ev) {
     (void)hipEventRecord(ev[1], stream);
@@ -975,10 +972,6 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
 }
 
 // 64-sample k-steps per row as the kernel counts them (counters[2] is in product x k-step units)
-uint32_t pair_mfma_ksteps(uint32_t founder_ct) {
-  const char* k = getenv("LDP_DEBUG_MFMA_KS");
-  const uint32_t ks = (k && (atoi(k) == 2)) ? 2 : 4;
-  return ((founder_ct + 64 * ks - 1) / (64 * ks)) * ks;
-}
+uint32_t pair_mfma_ksteps(uint32_t founder_ct) { return ((founder_ct + 255) / 256) * 4; }
 
 }  // namespace ldp

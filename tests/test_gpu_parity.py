@@ -229,6 +229,87 @@ def test_partial_reload_keeps_the_route_of_the_resident_rows(gpu_pkg):
         assert r2[j, i] == (cov * cov) / vp, (i, j)
 
 
+@pytest.mark.parametrize("n,miss", [(3, 0.0), (64, 0.0), (255, 0.02), (256, 0.0), (257, 0.05), (1000, 0.0), (1021, 0.01), (4099, 0.0), (50000, 0.001)])
+def test_rows_written_into_the_engines_image_are_counted_in_place(gpu_pkg, n, miss):
+    """ldp_map_rows: a device-side producer writes REF-coded rows straight into the resident image (its trailing bits and the
+    padding up to the stage boundary left as garbage) and ldp_load_genotypes() counts them where they are.  Records, planes,
+    every candidate pair's integers and the prune set equal those of the same rows loaded from host memory, and the oracle's."""
+    import torch
+    pkg = gpu_pkg
+    m = 150
+    raw = T.synth_raw_codes(m, n, seed=n + 7, missing_rate=miss, ld_copy_prob=0.6, redraw=0.1)
+    chr_idx, bps = make_positions(m, 2, 60 + n % 7)
+    inv, mf, altmaj, hom, r2h, vaggs = oracle_recs(raw, n)
+    want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 30, 1, False, 0.3, 2)
+    packed = np.ascontiguousarray(T.pack_2bit(raw).view(np.uint8).reshape(m, -1)[:, :(n + 3) // 4])
+    if n % 4:
+        packed[:, -1] |= np.uint8((0xff << (2 * (n % 4))) & 0xaa)   # garbage in the trailing bit pairs of the last byte
+    eng = pkg.LdPruneEngine(n, 30, 1, False, 0.3, order=2, device=0)
+    eng.set_variants(chr_idx, bps)
+    subs = eng.subcontigs()
+    assert sum(ln for ln, _ in subs) == m
+    for ln, first in subs:
+        ptr, stride = eng.map_rows(first, ln)
+        assert stride % 64 == 0 and stride >= (n + 3) // 4
+        img = torch.full((ln, stride), 0x5a, dtype=torch.uint8, device="cuda")          # (0x5a: not a valid padding)
+        img[:, :packed.shape[1]] = torch.from_numpy(packed[first:first + ln]).cuda()
+        torch.cuda.synchronize()
+        assert pkg.hip_memcpy_dtod(ptr, img.data_ptr(), ln * stride) == 0
+        torch.cuda.synchronize()
+        eng.load_genotypes_device(first, ln, ptr, stride, pkg.LDP_GENO_REF)
+    recs = eng.variant_recs()
+    w32 = (n + 31) // 32
+    for v in range(m):
+        gh, gr = eng.planes(v)
+        assert np.array_equal(gh, hom[v].view(np.uint32)[:w32]) and np.array_equal(gr, r2h[v].view(np.uint32)[:w32]), v
+        assert (recs[v]["nm_ct"], recs[v]["sum"], recs[v]["ssq"]) == (vaggs[v].nm_ct, vaggs[v].sum, vaggs[v].ssq)
+        assert bool(recs[v]["flags"] & 1) == bool(altmaj[v])
+    assert np.array_equal(eng.maj_freqs(), mf)
+    got = eng.run()
+    assert np.array_equal(got, want)
+    removed, stats = eng.run_with_stats()
+    lo, _ = eng.band()
+    k = 0
+    for j in range(m):
+        for i in range(int(lo[j]), j):
+            assert tuple(int(x) for x in stats[k]) == T.oracle_pair_stats(hom, r2h, vaggs, n, i, j).astuple(), (i, j)
+            k += 1
+    # a second pass over the same rows (what a benchmark step does) gives the same answer: the padding fix is idempotent
+    for ln, first in subs:
+        ptr, stride = eng.map_rows(first, ln)
+        eng.load_genotypes_device(first, ln, ptr, stride, pkg.LDP_GENO_REF)
+    assert np.array_equal(eng.run(), want)
+    # a pointer into the image that is not the mapped row itself is refused, not read while it is written
+    ptr, stride = eng.map_rows(subs[0][1], subs[0][0])
+    with pytest.raises(pkg.LdpError):
+        eng.load_genotypes_device(subs[0][1] + 1, 1, ptr, stride, pkg.LDP_GENO_REF)
+    eng.close()
+
+
+@pytest.mark.parametrize("n,miss", [(300, 0.0), (2100, 0.03)])
+def test_popcount_kernels_on_bit_planes_agree_with_the_matrix_pipe(gpu_pkg, n, miss):
+    """The two resident formats (2-bit code image + matrix pipe, bit-planes + popcount kernels) give the same integers."""
+    pkg = gpu_pkg
+    m = 260
+    raw = T.synth_raw_codes(m, n, seed=n, missing_rate=miss, ld_copy_prob=0.6, redraw=0.1)
+    chr_idx, bps = make_positions(m, 2, 9)
+    out = []
+    for mfma in (1, 0):
+        eng = pkg.LdPruneEngine(n, 40, 1, False, 0.3, order=2, device=0)
+        eng.set_option("pair_mfma", mfma)
+        eng.set_variants(chr_idx, bps)
+        eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+        removed, stats = eng.run_with_stats()
+        c = eng.counters()
+        assert (c["mfma_block_products"] > 0) == bool(mfma)
+        planes = [eng.planes(v) for v in (0, 7, m - 1)]
+        out.append((removed, stats, planes, eng.run()))
+        eng.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][3], out[1][3])
+    for a, b in zip(out[0][2], out[1][2]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_device_pointer_input(gpu_pkg):
     m, n = 300, 257
     raw = T.synth_raw_codes(m, n, seed=31, missing_rate=0.02)
