@@ -75,8 +75,10 @@ __device__ __forceinline__ void hap_codes_of_16(uint32_t w, uint32_t phase16, ui
   *out1 = spread_to_nibbles(miss >> 16) * 5u | (spread_to_nibbles(b1_first >> 16) << 1) | (spread_to_nibbles(b1_second >> 16) << 3);
 }
 
-// One block per variant, one 16-byte unit of the image row (64 samples) per thread and iteration.
-template <int THREADS>
+// One block per variant, one 16-byte unit of the image row (64 samples) per thread and iteration.  ITERS > 0: the iterations
+// are unrolled with all of a thread's loads issued up front (few threads with many 16-byte loads in flight each beat many
+// threads with few, as in prepare_kernel); ITERS == 0: a rolled loop for rows beyond the register budget.
+template <int THREADS, int ITERS>
 __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
   constexpr int kWaves = THREADS / 64;
   __shared__ uint32_t red[kWaves][3 + 2 * kCheckpoints];
@@ -95,6 +97,8 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
   const uint32_t code_bytes = (samples + 3) >> 2;
   const uint32_t phase_off = (code_bytes + 3) & ~3u;
   const uint32_t phase_bytes = (samples + 7) >> 3;
+  // units that are whole 16-byte pieces of a plain source row: one vector load, no tail, no padding
+  const uint32_t n_fast = (phased || !aligned4) ? 0u : (A.founder_ct / 64);
 
   uint32_t hom_ct = 0, r2h_ct = 0, both_ct = 0;
   uint32_t rest[kCheckpoints];  // hom calls | code-0 calls << 16 in k-chunks >= checkpoint k (a thread's share stays below 2^16)
@@ -102,14 +106,12 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
   for (int k = 0; k < kCheckpoints; ++k) {
     rest[k] = 0;
   }
-#pragma unroll 4
-  for (uint32_t u = tid; u < n_units; u += THREADS) {
+  // everything a unit needs besides a plain vector load: phased rows, unaligned rows, the tail of the row and its padding
+  auto slow_unit = [&](uint32_t u, u32x4& w) {
     const uint32_t s0 = u * 64;  // first sample (haplotype) of the unit
-    u32x4 w;
     if (s0 >= A.founder_ct) {
       w.x = w.y = w.z = w.w = 0xffffffffu;  // padding up to the stage boundary: "missing"
-      __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(out_row + 16ull * u));
-      continue;
+      return;
     }
     if (phased) {
       const uint32_t ph = src_dword(row + phase_off, phase_bytes, u, aligned4);
@@ -121,19 +123,10 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
       w.z = o2;
       w.w = o3;
     } else {
-      if (aligned4 && (16u * u + 16u <= code_bytes)) {
-        // streamed once: non-temporal (global_load_dwordx4 only needs dword alignment on gfx950, all a packed row guarantees)
-        const u32x4_a4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4*>(row + 16ull * u));
-        w.x = t.x;
-        w.y = t.y;
-        w.z = t.z;
-        w.w = t.w;
-      } else {
-        w.x = src_dword(row, code_bytes, 4 * u, aligned4);
-        w.y = src_dword(row, code_bytes, 4 * u + 1, aligned4);
-        w.z = src_dword(row, code_bytes, 4 * u + 2, aligned4);
-        w.w = src_dword(row, code_bytes, 4 * u + 3, aligned4);
-      }
+      w.x = src_dword(row, code_bytes, 4 * u, aligned4);
+      w.y = src_dword(row, code_bytes, 4 * u + 1, aligned4);
+      w.z = src_dword(row, code_bytes, 4 * u + 2, aligned4);
+      w.w = src_dword(row, code_bytes, 4 * u + 3, aligned4);
       if (bed) {
         w.x = pgen_of_bed(w.x);
         w.y = pgen_of_bed(w.y);
@@ -141,8 +134,7 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
         w.w = pgen_of_bed(w.w);
       }
     }
-    const bool tail = (s0 + 64 > A.founder_ct);
-    if (tail) {
+    if (s0 + 64 > A.founder_ct) {
       // samples >= founder_ct: coded missing, whatever the caller's trailing bits were
       const uint32_t left = A.founder_ct - s0;  // 1..63
 #pragma unroll
@@ -157,22 +149,74 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
         w[d] |= m;
       }
     }
-    if ((!in_place) || tail) {
-      __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(out_row + 16ull * u));
-    }
-    // counts, 32 samples per operation: lo / hi = the low / high code bits of two dwords interleaved (any sample order will do)
+  };
+  auto count_unit = [&](uint32_t u, const u32x4& w) {
+    // 32 samples per operation: lo / hi = the low / high code bits of two dwords interleaved (any sample order will do)
     const uint32_t lo0 = (w.x & 0x55555555u) | ((w.y & 0x55555555u) << 1), hi0 = ((w.x >> 1) & 0x55555555u) | (w.y & 0xaaaaaaaau);
     const uint32_t lo1 = (w.z & 0x55555555u) | ((w.w & 0x55555555u) << 1), hi1 = ((w.z >> 1) & 0x55555555u) | (w.w & 0xaaaaaaaau);
-    const uint32_t hc = __popc(~lo0) + __popc(~lo1);           // homozygous calls (codes 00, 10)
+    const uint32_t hc = __popc(~lo0) + __popc(~lo1);                  // homozygous calls (codes 00, 10)
     const uint32_t bc = __popc(~(lo0 | hi0)) + __popc(~(lo1 | hi1));  // code 00
     hom_ct += hc;
-    r2h_ct += __popc(~hi0) + __popc(~hi1);                      // codes 00, 01
+    r2h_ct += __popc(~hi0) + __popc(~hi1);                            // codes 00, 01
     both_ct += bc;
-    const uint32_t chunk = u / (kChunkDwords * 32 / 64);        // 512-sample k-chunk
+    const uint32_t chunk = u / (kChunkDwords * 32 / 64);              // 512-sample k-chunk
     const uint32_t packed = hc | (bc << 16);
 #pragma unroll
     for (int k = 0; k < kCheckpoints; ++k) {
       rest[k] += (chunk >= A.checkpoint_chunk[k]) ? packed : 0;
+    }
+  };
+  uint32_t slow_first = 0;  // units from here on go through slow_unit()
+  if constexpr (ITERS > 0) {
+    u32x4 w[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const uint32_t u = tid + it * THREADS;
+      if (u < n_fast) {
+        const u32x4_a4 t = *reinterpret_cast<const u32x4_a4*>(row + 16ull * u);
+        w[it].x = t.x;
+        w[it].y = t.y;
+        w[it].z = t.z;
+        w[it].w = t.w;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const uint32_t u = tid + it * THREADS;
+      if (u < n_fast) {
+        if (bed) {
+          w[it].x = pgen_of_bed(w[it].x);
+          w[it].y = pgen_of_bed(w[it].y);
+          w[it].z = pgen_of_bed(w[it].z);
+          w[it].w = pgen_of_bed(w[it].w);
+        }
+        if (!in_place) {
+          __builtin_nontemporal_store(w[it], reinterpret_cast<u32x4*>(out_row + 16ull * u));
+        }
+        count_unit(u, w[it]);
+      }
+    }
+    slow_first = (n_fast < static_cast<uint32_t>(ITERS * THREADS)) ? n_fast : static_cast<uint32_t>(ITERS * THREADS);
+  }
+  // what is left: all of a phased / unaligned / very long row; otherwise the tail unit and the padding
+  for (uint32_t u = slow_first + tid; u < n_units; u += THREADS) {
+    u32x4 w;
+    bool store = !in_place;
+    if (u < n_fast) {
+      const u32x4_a4 t = *reinterpret_cast<const u32x4_a4*>(row + 16ull * u);
+      w.x = bed ? pgen_of_bed(t.x) : t.x;
+      w.y = bed ? pgen_of_bed(t.y) : t.y;
+      w.z = bed ? pgen_of_bed(t.z) : t.z;
+      w.w = bed ? pgen_of_bed(t.w) : t.w;
+    } else {
+      slow_unit(u, w);
+      store = store || (u * 64 + 64 > A.founder_ct);  // (the tail and the padding are the engine's to write, in place too)
+    }
+    if (store) {
+      __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(out_row + 16ull * u));
+    }
+    if (u * 64 < A.founder_ct) {
+      count_unit(u, w);
     }
   }
   hom_ct = wave_reduce_add(hom_ct);
@@ -327,16 +371,28 @@ hipError_t launch_codes(const PrepareArgs& a, hipStream_t stream) {
     return hipSuccess;
   }
   const uint64_t units = a.code_row_bytes / 16;
-  // few threads with several 16-byte loads in flight each (as prepare_kernel: config 2's rows ran best at 128 threads)
-  if (units <= 128 * 16) {
-    hipLaunchKernelGGL((codes_kernel<128>), dim3(a.n_variants), dim3(128), 0, stream, a);
-  } else if (units <= 256 * 32) {
-    hipLaunchKernelGGL((codes_kernel<256>), dim3(a.n_variants), dim3(256), 0, stream, a);
-  } else if (units <= 512 * 64) {
-    hipLaunchKernelGGL((codes_kernel<512>), dim3(a.n_variants), dim3(512), 0, stream, a);
+  // the geometry prepare_kernel was tuned to (config 2: 128 x 7 best; N = 500,000: 512 x 16), a unit = 64 samples in both
+#define LDP_CODES(T, I) hipLaunchKernelGGL((codes_kernel<T, I>), dim3(a.n_variants), dim3(T), 0, stream, a)
+  if (units <= 128 * 2) {
+    LDP_CODES(128, 2);
+  } else if (units <= 128 * 4) {
+    LDP_CODES(128, 4);
+  } else if (units <= 128 * 7) {
+    LDP_CODES(128, 7);
+  } else if (units <= 128 * 8) {
+    LDP_CODES(128, 8);
+  } else if (units <= 128 * 16) {
+    LDP_CODES(128, 16);
+  } else if (units <= 256 * 16) {
+    LDP_CODES(256, 16);
+  } else if (units <= 512 * 16) {
+    LDP_CODES(512, 16);
+  } else if (units <= 1024 * 16) {
+    LDP_CODES(1024, 16);
   } else {
-    hipLaunchKernelGGL((codes_kernel<1024>), dim3(a.n_variants), dim3(1024), 0, stream, a);
+    LDP_CODES(1024, 0);
   }
+#undef LDP_CODES
   return hipGetLastError();
 }
 
