@@ -301,7 +301,7 @@ class Workload:
 def sum_counters(ctrs):
     keys = ("candidate_pairs", "pred_true", "replay_pairs", "ms_prepare", "ms_pair_kernel", "ms_pair_mfma", "ms_pair_mfma_general", "ms_pair_fast",
             "ms_pair_general", "ms_replay", "pair_kernel_launches", "mfma_block_products", "mfma_product_stages", "mfma_skipped_product_stages",
-            "sparse_exact_pairs", "route_complete_launches", "route_sparse_launches", "route_general_launches")
+            "sparse_exact_pairs", "route_complete_launches", "route_sparse_launches", "route_general_launches", "mfma_extra_product_stages", "wide_tiles")
     return {k: sum(c[k] for c in ctrs) for k in keys}
 
 
@@ -330,7 +330,7 @@ def pair_roofline(c, founder_ct, local_ct, missing_rate, variants, window_kb):
     launches = max(int(c["pair_kernel_launches"]), 1)
     # MFMA side: instructions the kernel really issued.  One block product = 32 x 32 pairs; one k-step = one
     # v_mfma_scale_f32_32x32x64_f8f6f4 = 65,536 MACs; the general kernel issues six per block product and k-step.
-    executed = max(c["mfma_product_stages"] - c["mfma_skipped_product_stages"], 0) * (6 if general else 1)
+    executed = (max(c["mfma_product_stages"] - c["mfma_skipped_product_stages"], 0) + c["mfma_extra_product_stages"]) * (6 if general else 1)
     mfma_tflops = (executed * 65536 * 2.0 / (kms * 1e-3)) / 1e12 if (kms > 0 and on_matrix_pipe) else 0.0
     # HBM side: every owned row must be read once (N/4 bytes per variant, rows padded to 64 bytes)
     compulsory = local_ct * ((founder_ct + 255) // 256) * 64.0
@@ -348,7 +348,9 @@ def pair_roofline(c, founder_ct, local_ct, missing_rate, variants, window_kb):
         "mfma": {"executed_tflops": mfma_tflops, "peak_tflops": FP4_PEAK_TFLOPS, "frac_of_peak": mfma_frac,
                  "mfma_instructions_per_step": executed, "block_products": c["mfma_block_products"],
                  "plan_efficiency": (c["candidate_pairs"] / (c["mfma_block_products"] * 1024.0)) if c["mfma_block_products"] else None,
-                 "early_termination_skipped_frac": (c["mfma_skipped_product_stages"] / c["mfma_product_stages"]) if c["mfma_product_stages"] else 0.0},
+                 "early_termination_skipped_frac": (c["mfma_skipped_product_stages"] / c["mfma_product_stages"]) if c["mfma_product_stages"] else 0.0,
+                 "computed_beyond_plan_frac": (c["mfma_extra_product_stages"] / c["mfma_product_stages"]) if c["mfma_product_stages"] else 0.0,
+                 "wide_tiles": c["wide_tiles"]},
         "hbm": {"compulsory_bytes_per_step": compulsory, "compulsory_gbs": hbm_gbs, "peak_gbs": HBM_PEAK_GBS, "frac_of_peak": hbm_frac},
         "effective_stream_gbs": (c["candidate_pairs"] * (founder_ct / 2.0) / (kms * 1e-3)) / 1e9 if kms > 0 else 0.0,
         "routes": {"complete": c["route_complete_launches"], "sparse": c["route_sparse_launches"], "general": c["route_general_launches"]},

@@ -137,7 +137,9 @@ typedef struct {
   uint32_t route_complete_launches;
   uint32_t route_sparse_launches;
   uint32_t route_general_launches;
-  uint32_t reserved0;
+  uint32_t wide_tiles;             /* 8 x 8 block tiles of the plan (wide-band subcontigs, complete-data launches) */
+  uint64_t mfma_extra_product_stages; /* product x k-step units the wide-band kernel computed beyond the plan (its waves run all eight
+                                         products of their rectangle or none): executed MFMA = stages - skipped + extra */
 } ldp_counters;
 
 /* ---- lifecycle ---- */
@@ -229,16 +231,27 @@ int ldp_pair_stats(ldp_engine* e, uint32_t n_pairs, const uint32_t* first, const
 int ldp_debug_set_variant_recs(ldp_engine* e, const ldp_variant_rec* recs);
 int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first, const uint32_t* second, uint64_t* removed);
 /* Kernel-selection switches of ONE engine, for tests and measurements (the defaults are what production runs use; they can also
- * be preset from the environment at ldp_create(): LDP_EARLY_EXIT, LDP_PAIR_MFMA, LDP_PAIR_SPARSE,
- * LDP_DEBUG_SPARSE_FRAC).  name: "early_exit" (0/1: checkpoints that drop provably sub-threshold products), "pair_mfma" (0/1:
- * matrix-pipe kernels; 0 = the popcount kernels -- set before ldp_set_variants*()), "pair_sparse" (0/1: the interval epilogue for rows with a few missing calls), "sparse_frac" (mean
- * missing fraction up to which a launch takes it).  Results never depend on these.  Unknown name: LDP_ERR_INVALID. */
+ * be preset from the environment at ldp_create(): LDP_EARLY_EXIT, LDP_PAIR_MFMA, LDP_PAIR_SPARSE, LDP_DEBUG_SPARSE_FRAC,
+ * LDP_DEBUG_WIDE_MIN_REACH).  name:
+ *   "early_exit"      0/1: checkpoints that drop provably sub-threshold products
+ *   "pair_mfma"       0/1: matrix-pipe kernels on the 2-bit code image; 0 = the popcount kernels on bit-planes (before ldp_set_variants*())
+ *   "pair_sparse"     0/1: the interval epilogue for rows with a few missing calls
+ *   "sparse_frac"     mean missing fraction up to which a launch takes it
+ *   "wide_min_reach"  row-blocks a subcontig's band must reach to take the 8 x 8 tile plan of the wide-band kernel; 0 = always,
+ *                     a huge value = never (before ldp_set_variants())
+ * Results never depend on these.  Unknown name: LDP_ERR_INVALID. */
 int ldp_debug_set_option(ldp_engine* e, const char* name, double value);
 /* Host-only view of the matrix-pipe work plan (csrc/ldp_device.h: MfmaWG) in the engine's shard-local variant
  * indices, for the CPU test that every candidate pair is owned by exactly one 32 x 32 block product.  Per workgroup
- * 63 words: n_rb, j_lo, j_hi, rb[16], then per wave jv, vv, jend, prod_mask, slot[7].  lo_local (optional, *local_ct
+ * 63 words: n_rb (bit 31: see ldp_debug_wide_plan), j_lo, j_hi, rb[16], then per wave jv, vv, jend, prod_mask, slot[7].  lo_local (optional, *local_ct
  * entries) receives the window starts in the same index space.  words == NULL only counts. */
 int ldp_debug_mfma_plan(const ldp_engine* e, uint32_t* wg_count, uint32_t* words, uint64_t capacity_words, uint32_t* lo_local, uint32_t* local_ct);
+
+/* The wide-band plan (csrc/ldp_device.h: MfmaTile; subcontigs whose band reaches the "wide_min_reach" option in row-blocks): per
+ * tile 5 words: jv, vv, jend, mask bits 0-31, mask bits 32-63 (bit 8 a + b: the product of J block a and V block b).  The
+ * workgroups of ldp_debug_mfma_plan() that belong to such subcontigs carry bit 31 in their first word; complete-data launches
+ * leave those to the tiles.  words == NULL only counts. */
+int ldp_debug_wide_plan(const ldp_engine* e, uint32_t* tile_count, uint32_t* words, uint64_t capacity_words);
 
 /* ---- --r2-unphased matrices (Vcor / VcorMatrix, plink2_ld.cc:12050,9766; ComputeR2 :6654-6682) ---- */
 /* All-pairs plan over variant_ct variants (inter-chromosomal pairs included, as the matrix shapes of

@@ -69,7 +69,8 @@ class ldp_counters(ctypes.Structure):
                 ("mfma_product_stages", ctypes.c_uint64), ("mfma_skipped_product_stages", ctypes.c_uint64),
                 ("ms_pair_mfma_general", ctypes.c_double), ("sparse_exact_pairs", ctypes.c_uint64),
                 ("route_complete_launches", ctypes.c_uint32), ("route_sparse_launches", ctypes.c_uint32),
-                ("route_general_launches", ctypes.c_uint32), ("reserved0", ctypes.c_uint32)]
+                ("route_general_launches", ctypes.c_uint32), ("wide_tiles", ctypes.c_uint32),
+                ("mfma_extra_product_stages", ctypes.c_uint64)]
 
     def asdict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
@@ -89,12 +90,12 @@ CABI_SYMBOLS = [
     "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_r2_unphased_hits", "ldp_r2_unphased_block", "ldp_r2_unphased_block_hits", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_has_dosage", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
     "ldp_pgen_variant_is_multiallelic", "ldp_pgen_provisional_ref", "ldp_pgen_open_indexed", "ldp_set_r_signed", "ldp_set_variants_vcor_cm", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_subset_samples", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
-    "ldp_debug_set_option", "ldp_matrix_pipe_max_founders", "ldp_map_rows", "ldp_release_device",
+    "ldp_debug_set_option", "ldp_matrix_pipe_max_founders", "ldp_map_rows", "ldp_release_device", "ldp_debug_wide_plan",
 ]
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_codes.hip", "ldp_pair_mfma.hip", "ldp_synth.hip", "ldp_engine.cpp", "ldp_pgen.cpp")]
+    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_codes.hip", "ldp_pair_mfma.hip", "ldp_pair_wide.hip", "ldp_synth.hip", "ldp_engine.cpp", "ldp_pgen.cpp")]
 
 
 def _stale(target, deps):
@@ -107,7 +108,7 @@ def _stale(target, deps):
 def build_library(force=False, verbose=False):
     """Compile the HIP kernels + host runtime into lib/libldprune_hip.so for gfx950 (hipcc cross-compiles
     without a GPU).  In-tree so the .so travels with the repo snapshot."""
-    deps = _sources() + [os.path.join(CSRC, "ldp_device.h"), os.path.join(CSRC, "ldp_pair_device.h"), os.path.join(REPO, "include", "ldprune_hip.h")]
+    deps = _sources() + [os.path.join(CSRC, "ldp_device.h"), os.path.join(CSRC, "ldp_pair_device.h"), os.path.join(CSRC, "ldp_mfma_device.h"), os.path.join(REPO, "include", "ldprune_hip.h")]
     if force or _stale(LIB_PATH, deps):
         os.makedirs(LIB_DIR, exist_ok=True)
         cmd = ["hipcc"] + HIPCC_FLAGS + ["-shared", "-o", LIB_PATH] + _sources()
@@ -173,6 +174,7 @@ def lib():
     L.ldp_debug_replay_pairs.argtypes = [vp, ctypes.c_uint64, u32p, u32p, u64p]
     L.ldp_map_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp), u64p]
     L.ldp_release_device.argtypes = [vp]
+    L.ldp_debug_wide_plan.argtypes = [vp, u32p, u32p, ctypes.c_uint64]
     L.ldp_matrix_pipe_max_founders.argtypes = []
     L.ldp_matrix_pipe_max_founders.restype = ctypes.c_uint32
     L.ldp_debug_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_double]
@@ -607,6 +609,14 @@ class LdPruneEngine:
         self._ck(self._L.ldp_debug_mfma_plan(self._h, ctypes.byref(n), _ptr(words, ctypes.c_uint32), words.size, _ptr(lo, ctypes.c_uint32),
                                              ctypes.byref(lc)))
         return words[:n.value], lo[:lc.value]
+
+    def debug_wide_plan(self):
+        """tiles of the wide-band plan as an (n, 5) uint32 array: jv, vv, jend, mask low / high word (ldp_debug_wide_plan)."""
+        n = ctypes.c_uint32(0)
+        self._ck(self._L.ldp_debug_wide_plan(self._h, ctypes.byref(n), None, 0))
+        words = np.zeros((max(n.value, 1), 5), dtype=np.uint32)
+        self._ck(self._L.ldp_debug_wide_plan(self._h, ctypes.byref(n), _ptr(words, ctypes.c_uint32), words.size))
+        return words[:n.value]
 
     # ---- inspection
     def variant_recs(self, first=0, n=None):

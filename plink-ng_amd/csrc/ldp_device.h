@@ -101,8 +101,26 @@ struct MfmaWG {
   uint32_t rb[kMfMaxRowBlocks];  // first variant of each staged row-block
   uint32_t n_rb;
   uint32_t j_lo, j_hi;           // second variants the workgroup's waves own: [j_lo, j_hi)
-  uint32_t pad;
+  uint32_t pad;                  // 1: the subcontig also has a wide plan (MfmaTile), which owns it on complete-data launches
   MfmaWaveItem w[kMfWaves];
+};
+
+// Wide bands (config 3: ~1,700 variants = 54 row-blocks per window): a workgroup of EIGHT waves owns a square tile of 8 second-variant
+// blocks x 8 first-variant blocks, 64 block products for 16 staged row-blocks -- twice the products per staged byte of the
+// parallelogram plan above (32 for 15), which is what a band this wide is short of (profiles/r02_c3shape_pmc_traffic.json: the
+// narrow plan re-fetched every row ~12 times from HBM).  Wave w owns J blocks 2 (w & 3), + 1 and V blocks 4 (w >> 2) .. + 3.
+// Tiles are aligned to the subcontig start in both directions, so on the diagonal the V tile IS the J tile (8 row-blocks staged).
+constexpr int kWdWaves = 8;
+constexpr int kWdTile = 8;                       // row-blocks per tile side
+constexpr int kWdRowBlocks = 2 * kWdTile;        // staged row-blocks: slots 0..7 the J blocks, 8..15 the V blocks
+constexpr int kWdDmaPerWave = (2 * kWdRowBlocks) / kWdWaves;  // 256-sample stages: two DMA instructions of 64 slots per row-block
+constexpr uint32_t kWdMinReach = 12;             // a subcontig whose band reaches this many row-blocks takes the wide plan
+struct MfmaTile {
+  int32_t jv;        // first variant of J block 0 (J block a = jv + 32 a)
+  int32_t vv;        // first variant of V block 0 (V block b = vv + 32 b); == jv on the diagonal
+  uint32_t jend;     // second variants >= jend belong to the next subcontig
+  uint32_t pad;
+  uint64_t mask;     // bit 8 a + b: product (J_a, V_b) holds candidate pairs
 };
 
 struct PairKernelArgs {
@@ -156,6 +174,11 @@ struct PairKernelArgs {
   uint32_t mf_active;            // the launch also carries matrix-pipe work items
   const uint32_t* route;         // kRoute*
   uint32_t sparse_ok;            // the route may be kRouteSparse (prune launches): launch that instantiation as well
+  // wide-band tiles (launch_pair_wide): complete-data launches only; the workgroups of mf_wgs whose MfmaWG::pad is 1 cover the
+  // same subcontigs for the other two routes and are skipped by pair_mfma_kernel<., false> when wd_active is set
+  const MfmaTile* wd_tiles;
+  uint32_t n_wd_tiles;
+  uint32_t wd_active;
 };
 
 constexpr uint32_t kRouteComplete = 0, kRouteSparse = 1, kRouteGeneral = 2;
@@ -218,6 +241,8 @@ hipError_t launch_pair_stats_ref(const uint32_t* planes, uint64_t row_dwords, ui
 size_t pair_tiles_lds_bytes(uint32_t max_rows);
 // ev[0..2] (optional): recorded before the complete-data kernel, between it and the missing-calls kernel, and after
 hipError_t launch_pair_mfma(const PairKernelArgs& a, hipStream_t stream, hipEvent_t* ev);
+// the wide-band tiles of the launch (complete-data route); queued between ev[0] and ev[1] of launch_pair_mfma by the caller's order
+hipError_t launch_pair_wide(const PairKernelArgs& a, hipStream_t stream);
 uint32_t pair_mfma_ksteps(uint32_t founder_ct);  // 64-sample k-steps per row (the unit of counters[2])
 
 // LDS rows of a work item that stages `units` 8-distance units starting at distance d0 (make_geom in the kernel)

@@ -78,6 +78,7 @@ struct EngineOptions {
   bool early_exit = true;     // LDP_EARLY_EXIT=0: exhaustive pair kernels
   bool pair_mfma = true;      // LDP_PAIR_MFMA=0: popcount kernels instead of the matrix pipe
   double sparse_frac = 0.005; // LDP_PAIR_SPARSE=0 -> 0; LDP_DEBUG_SPARSE_FRAC
+  uint32_t wide_min_reach = kWdMinReach;  // band reach (row-blocks) from which a subcontig takes the 8 x 8 tile plan; LDP_DEBUG_WIDE_MIN_REACH
 };
 
 struct ldp_engine {
@@ -123,6 +124,7 @@ struct ldp_engine {
     uint32_t need_end = 0;               // local variants [0, need_end) must be loaded
     uint64_t word_first = 0, word_end = 0;  // predicate words the group's J-tiles own
     uint32_t mf_first = 0, mf_ct = 0;    // the same J range as matrix-pipe workgroups (mf_wgs)
+    uint32_t wd_first = 0, wd_ct = 0;    // ... and as wide-band tiles (wd_tiles)
     bool launched = false;
     hipEvent_t ev_ready = nullptr;
     hipEvent_t ev_done = nullptr;         // kernels finished and the group's predicate words are back on the host
@@ -133,6 +135,7 @@ struct ldp_engine {
   bool mf_enabled = false;
   uint32_t r_signed = 0;                  // ldp_set_r_signed
   std::vector<MfmaWG> mf_wgs;
+  std::vector<MfmaTile> wd_tiles;         // the 8 x 8 tile plan of the wide-band subcontigs (ldp_pair_wide.hip), in J order
   uint64_t mf_products = 0;               // 32 x 32 block products of the plan
   uint32_t next_group = 0;                 // groups before this one are launched for the current load epoch
   uint32_t loaded_prefix = 0;              // local variants [0, loaded_prefix) were loaded in the current epoch
@@ -168,6 +171,7 @@ struct ldp_engine {
   cp_slot* d_cp_stats = nullptr;           // per-variant checkpoint statistics (early termination)
   cp_gen_slot* d_cp_gen = nullptr;         // ... for tiles with missing calls
   MfmaWG* d_mf_wgs = nullptr;
+  MfmaTile* d_wd_tiles = nullptr;
   MissStats* d_miss_stats = nullptr;       // [slot of d_route]: missing calls of the resident rows a launch reads (summed from the records when the launch is queued)
   uint32_t* d_route = nullptr;             // [g]: which matrix-pipe kernel owns launch group g (route_kernel, when the group is queued); [groups]: other launches
   uint32_t checkpoint_chunk[kCheckpoints];
@@ -299,6 +303,8 @@ void free_device(ldp_engine* e) {
   (void)hipFree(e->d_cp_stats);
   (void)hipFree(e->d_cp_gen);
   (void)hipFree(e->d_mf_wgs);
+  (void)hipFree(e->d_wd_tiles);
+  e->d_wd_tiles = nullptr;
   (void)hipFree(e->d_miss_stats);
   (void)hipFree(e->d_route);
   e->d_mf_wgs = nullptr;
@@ -504,6 +510,9 @@ EngineOptions options_from_env() {
   const char* off = getenv("LDP_PAIR_SPARSE");
   const char* f = getenv("LDP_DEBUG_SPARSE_FRAC");
   o.sparse_frac = (off && (strcmp(off, "0") == 0)) ? 0.0 : (f ? atof(f) : 0.005);
+  if (const char* w = getenv("LDP_DEBUG_WIDE_MIN_REACH")) {
+    o.wide_min_reach = static_cast<uint32_t>(std::max(0, atoi(w)));
+  }
   return o;
 }
 
@@ -546,12 +555,19 @@ int checkpoint_fractions(double r2_param, double* frac) {
 // runs: (first local variant, length) of the row ranges blocks are aligned to (the owned subcontigs; one run over
 // everything for the all-pairs plan of --r2-unphased); lo: window start per local variant (nullptr: 0, every earlier
 // variant is a partner); only second variants in [j_first, j_end) get products (a row chunk of an r^2 matrix).
+// out_tiles (optional): runs whose band reaches wide_min_reach row-blocks ALSO get the wide plan of ldp_pair_wide.hip -- 8 x 8
+// block tiles aligned to the run start, J tile by J tile with the V tiles of a J tile consecutive -- and their workgroups here
+// are marked (MfmaWG::pad) so that complete-data launches leave them to the tiles.
 void plan_mfma_generic(const std::vector<std::pair<uint32_t, uint32_t>>& runs, const uint32_t* lo_of, uint32_t j_first, uint32_t j_end,
-                       std::vector<MfmaWG>* out_wgs, uint64_t* out_products, uint32_t i_first = 0, uint32_t i_end = 0xffffffffu) {
+                       std::vector<MfmaWG>* out_wgs, uint64_t* out_products, uint32_t i_first = 0, uint32_t i_end = 0xffffffffu,
+                       std::vector<MfmaTile>* out_tiles = nullptr, uint32_t wide_min_reach = kWdMinReach) {
   // (i_first / i_end: only first variants in [i_first, i_end) are wanted -- a column block of an r^2 matrix; products whose V
   // block lies outside it are not planned)
   out_wgs->clear();
   *out_products = 0;
+  if (out_tiles) {
+    out_tiles->clear();
+  }
   struct Wave {
     int32_t jv, vv;
     uint32_t jend;
@@ -649,6 +665,49 @@ void plan_mfma_generic(const std::vector<std::pair<uint32_t, uint32_t>>& runs, c
       }
     }
     auto reach_of = [&](uint32_t b) { return (b < nb) ? reach[b] : -1; };
+    const size_t run_wg_first = out_wgs->size();
+    bool wide_run = false;
+    if (out_tiles) {
+      flush();  // (a workgroup never mixes wave items of two runs when some runs are wide: the mark below is per workgroup)
+      const int32_t max_reach = reach.empty() ? -1 : *std::max_element(reach.begin(), reach.end());
+      wide_run = (max_reach >= static_cast<int32_t>(wide_min_reach));
+    }
+    if (wide_run) {
+      const uint32_t nt = (nb + kWdTile - 1) / kWdTile;
+      for (uint32_t T = 0; T < nt; ++T) {
+        // first V tile any J block of the tile reaches
+        int32_t t_lo = static_cast<int32_t>(T);
+        for (uint32_t a = 0; a < static_cast<uint32_t>(kWdTile); ++a) {
+          const uint32_t ja = T * kWdTile + a;
+          if (reach_of(ja) >= 0) {
+            t_lo = std::min(t_lo, (static_cast<int32_t>(ja) - reach_of(ja)) / static_cast<int32_t>(kWdTile));
+          }
+        }
+        for (int32_t t = std::max(t_lo, 0); t <= static_cast<int32_t>(T); ++t) {
+          MfmaTile tl;
+          tl.jv = static_cast<int32_t>(sfirst + kMfBlock * kWdTile * T);
+          tl.vv = static_cast<int32_t>(sfirst + kMfBlock * kWdTile * static_cast<uint32_t>(t));
+          tl.jend = sfirst + s.len;
+          tl.pad = 0;
+          tl.mask = 0;
+          for (uint32_t a = 0; a < static_cast<uint32_t>(kWdTile); ++a) {
+            const uint32_t ja = T * kWdTile + a;
+            if (reach_of(ja) < 0) {
+              continue;
+            }
+            for (uint32_t b = 0; b < static_cast<uint32_t>(kWdTile); ++b) {
+              const uint32_t vb = static_cast<uint32_t>(t) * kWdTile + b;
+              if ((vb <= ja) && (static_cast<int32_t>(ja - vb) <= reach_of(ja))) {
+                tl.mask |= 1ull << (8 * a + b);
+              }
+            }
+          }
+          if (tl.mask) {
+            out_tiles->push_back(tl);
+          }
+        }
+      }
+    }
     auto make = [&](uint32_t a, uint32_t p, Wave* out) {
       Wave w;
       memset(&w, 0, sizeof(w));
@@ -702,6 +761,12 @@ void plan_mfma_generic(const std::vector<std::pair<uint32_t, uint32_t>>& runs, c
         }
       }
     }
+    if (out_tiles) {
+      flush();
+      for (size_t k = run_wg_first; k < out_wgs->size(); ++k) {
+        (*out_wgs)[k].pad = wide_run ? 1u : 0u;
+      }
+    }
   }
   flush();
 }
@@ -711,7 +776,7 @@ void plan_mfma(ldp_engine* e) {
   for (uint32_t sk : e->owned) {
     runs.emplace_back(e->subs[sk].local_first, e->subs[sk].len);
   }
-  plan_mfma_generic(runs, e->lo_local.data(), 0, e->local_ct, &e->mf_wgs, &e->mf_products);
+  plan_mfma_generic(runs, e->lo_local.data(), 0, e->local_ct, &e->mf_wgs, &e->mf_products, 0, 0xffffffffu, &e->wd_tiles, e->opt.wide_min_reach);
 }
 
 void build_shard(ldp_engine* e) {
@@ -809,14 +874,31 @@ void build_shard(ldp_engine* e) {
   free_device(e);
   e->mf_enabled = e->opt.pair_mfma && (!e->matrix_mode) && (!e->band_r2_mode) && (e->P.founder_ct <= kMfMaxFounders);
   e->mf_wgs.clear();
-  // second variants at which a launch group may end: every matrix-pipe workgroup lies on one side
+  e->wd_tiles.clear();
+  // second variants at which a launch group may end: every matrix-pipe workgroup (and every wide-band tile) lies on one side
   std::vector<uint32_t> safe_cut;
   if (e->mf_enabled) {
     plan_mfma(e);
+    // J ranges of the wide tiles (the V tiles of one J tile share theirs), ascending
+    std::vector<std::pair<uint32_t, uint32_t>> tile_j;
+    for (const MfmaTile& t : e->wd_tiles) {
+      const uint32_t lo = static_cast<uint32_t>(t.jv), hi = std::min(lo + kMfBlock * kWdTile, t.jend);
+      if (tile_j.empty() || (tile_j.back().first != lo)) {
+        tile_j.emplace_back(lo, hi);
+      }
+    }
+    auto inside_a_tile = [&](uint32_t c) {
+      auto it = std::upper_bound(tile_j.begin(), tile_j.end(), std::make_pair(c, 0xffffffffu));
+      if (it == tile_j.begin()) {
+        return false;
+      }
+      --it;
+      return (it->first < c) && (c < it->second);
+    };
     uint32_t hi = 0;
     for (size_t k = 0; k + 1 < e->mf_wgs.size(); ++k) {
       hi = std::max(hi, e->mf_wgs[k].j_hi);
-      if (e->mf_wgs[k + 1].j_lo >= hi) {
+      if ((e->mf_wgs[k + 1].j_lo >= hi) && !inside_a_tile(e->mf_wgs[k + 1].j_lo)) {
         safe_cut.push_back(e->mf_wgs[k + 1].j_lo);
       }
     }
@@ -872,6 +954,19 @@ void build_shard(ldp_engine* e) {
       g.mf_first = w0;
       g.mf_ct = w1 - w0;
       w0 = w1;
+    }
+    uint32_t t0 = 0;
+    for (size_t gi = 0; gi < e->groups.size(); ++gi) {
+      ldp_engine::PairGroup& g = e->groups[gi];
+      const uint32_t j_end = (gi + 1 < e->groups.size()) ? e->items[e->groups[gi + 1].item_first].j0 : 0xffffffffu;
+      uint32_t t1 = t0;
+      while ((t1 < e->wd_tiles.size()) && (static_cast<uint32_t>(e->wd_tiles[t1].jv) < j_end)) {
+        g.need_end = std::max(g.need_end, std::min(static_cast<uint32_t>(e->wd_tiles[t1].jv) + kMfBlock * kWdTile, e->wd_tiles[t1].jend));
+        ++t1;
+      }
+      g.wd_first = t0;
+      g.wd_ct = t1 - t0;
+      t0 = t1;
     }
   }
   e->load_tag.assign(local, 0);
@@ -958,6 +1053,10 @@ int ensure_device_plan(ldp_engine* e) {
   HIP_TRY(e, hipMemsetAsync(e->d_route, 0, (e->groups.size() + 1) * sizeof(uint32_t), e->stream));
   if (!e->mf_wgs.empty()) {
     HIP_TRY(e, hipMemcpyAsync(e->d_mf_wgs, e->mf_wgs.data(), e->mf_wgs.size() * sizeof(MfmaWG), hipMemcpyHostToDevice, e->stream));
+  }
+  HIP_TRY(e, hipMalloc(&e->d_wd_tiles, std::max<size_t>(e->wd_tiles.size(), 1) * sizeof(MfmaTile)));
+  if (!e->wd_tiles.empty()) {
+    HIP_TRY(e, hipMemcpyAsync(e->d_wd_tiles, e->wd_tiles.data(), e->wd_tiles.size() * sizeof(MfmaTile), hipMemcpyHostToDevice, e->stream));
   }
   // checkpoints for early termination
   e->n_checkpoints = 0;
@@ -1441,6 +1540,9 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.mf_active = 0;
   A.route = nullptr;
   A.sparse_ok = 0;
+  A.wd_tiles = nullptr;
+  A.n_wd_tiles = 0;
+  A.wd_active = 0;
 }
 
 // A new load epoch begins (variants are being loaded again): whatever the pair streams still run belongs to the
@@ -1509,6 +1611,9 @@ int launch_group(ldp_engine* e, uint32_t gi) {
     A.route = e->d_route + gi;
     A.mf_wgs = e->d_mf_wgs + g.mf_first;
     A.n_mf_wgs = g.mf_ct;
+    A.wd_tiles = e->d_wd_tiles + g.wd_first;
+    A.n_wd_tiles = g.wd_ct;
+    A.wd_active = e->wd_tiles.empty() ? 0u : 1u;
   }
   hipError_t krc = launch_pair_tiles(A, e->max_rows, ps, g.ev);
   if (krc != hipSuccess) {
@@ -1614,6 +1719,9 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
       A.route = e->d_route + slot;
       A.mf_wgs = e->d_mf_wgs;
       A.n_mf_wgs = static_cast<uint32_t>(e->mf_wgs.size());
+      A.wd_tiles = e->d_wd_tiles;
+      A.n_wd_tiles = static_cast<uint32_t>(e->wd_tiles.size());
+      A.wd_active = e->wd_tiles.empty() ? 0u : 1u;
     }
     hipError_t krc = launch_pair_tiles(A, e->max_rows, e->stream, evk);
     if (krc != hipSuccess) {
@@ -1773,7 +1881,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   e->ctr.computed_pairs = e->computed_pairs;
   e->ctr.replay_pairs = replay_pairs;
   e->ctr.pred_true = h_counters[0];
-  e->ctr.early_exit_unit_chunks = h_counters[1] / 4;  // the kernel counts quarter units (one second-variant group)
+  e->ctr.early_exit_unit_chunks = e->codes_format ? 0 : (h_counters[1] / 4);  // the popcount kernel counts quarter units (one second-variant group)
   e->ctr.tile_unit_chunks = (e->computed_pairs / (8 * kTileJ)) * e->chunks;
   e->ctr.ms_pair_kernel = kms;
   e->ctr.ms_pair_fast = kms_fast;
@@ -1783,6 +1891,8 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   e->ctr.mfma_block_products = e->mf_enabled ? e->mf_products : 0;
   e->ctr.mfma_product_stages = e->ctr.mfma_block_products * pair_mfma_ksteps(e->P.founder_ct);
   e->ctr.mfma_skipped_product_stages = h_counters[2];
+  e->ctr.mfma_extra_product_stages = e->codes_format ? h_counters[1] : 0;
+  e->ctr.wide_tiles = e->mf_enabled ? static_cast<uint32_t>(e->wd_tiles.size()) : 0;
   e->ctr.sparse_exact_pairs = h_counters[3];
   e->ctr.route_complete_launches = route_ct[0];
   e->ctr.route_sparse_launches = route_ct[1];
@@ -2938,6 +3048,11 @@ int ldp_debug_set_option(ldp_engine* e, const char* name, double value) {
       return fail(e, LDP_ERR_STATE, "pair_mfma must be set before ldp_set_variants()");
     }
     e->opt.pair_mfma = (value != 0.0);
+  } else if (n == "wide_min_reach") {
+    if (e->planned) {
+      return fail(e, LDP_ERR_STATE, "wide_min_reach must be set before ldp_set_variants()");
+    }
+    e->opt.wide_min_reach = (value >= 4294967295.0) ? 0xffffffffu : static_cast<uint32_t>(std::max(0.0, value));
   } else if (n == "pair_sparse") {
     if (value == 0.0) {
       e->opt.sparse_frac = 0.0;
@@ -3021,7 +3136,7 @@ int ldp_debug_mfma_plan(const ldp_engine* e, uint32_t* wg_count, uint32_t* words
     return LDP_ERR_INVALID;
   }
   for (const MfmaWG& wg : e->mf_wgs) {
-    *words++ = wg.n_rb;
+    *words++ = wg.n_rb | (wg.pad ? 0x80000000u : 0u);  // (bit 31: the subcontig also has the wide plan)
     *words++ = wg.j_lo;
     *words++ = wg.j_hi;
     for (uint32_t k = 0; k < kMfMaxRowBlocks; ++k) {
@@ -3036,6 +3151,27 @@ int ldp_debug_mfma_plan(const ldp_engine* e, uint32_t* wg_count, uint32_t* words
         *words++ = wg.w[w].slot[u];
       }
     }
+  }
+  return LDP_OK;
+}
+
+int ldp_debug_wide_plan(const ldp_engine* e, uint32_t* tile_count, uint32_t* words, uint64_t capacity_words) {
+  if (!e || !e->planned || !tile_count) {
+    return LDP_ERR_INVALID;
+  }
+  *tile_count = static_cast<uint32_t>(e->wd_tiles.size());
+  if (!words) {
+    return LDP_OK;
+  }
+  if (capacity_words < 5ull * e->wd_tiles.size()) {
+    return LDP_ERR_INVALID;
+  }
+  for (const MfmaTile& t : e->wd_tiles) {
+    *words++ = static_cast<uint32_t>(t.jv);
+    *words++ = static_cast<uint32_t>(t.vv);
+    *words++ = t.jend;
+    *words++ = static_cast<uint32_t>(t.mask);
+    *words++ = static_cast<uint32_t>(t.mask >> 32);
   }
   return LDP_OK;
 }

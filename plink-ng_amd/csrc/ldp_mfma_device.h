@@ -1,0 +1,73 @@
+// ldp_mfma_device.h -- device-side pieces shared by the matrix-pipe pair kernels (ldp_pair_mfma.hip: parallelogram wave items for
+// narrow bands, ldp_pair_wide.hip: 8 x 8 block tiles for wide ones): the FP4 expansion of the 2-bit genotype codes, the MFMA
+// wrapper and the geometry of a staged 256-sample slice.  Device code only.
+#ifndef LDP_MFMA_DEVICE_H
+#define LDP_MFMA_DEVICE_H
+
+#include "ldp_device.h"
+
+namespace ldp {
+
+typedef int mf_v8i __attribute__((ext_vector_type(8)));
+typedef float mf_v16f __attribute__((ext_vector_type(16)));
+
+struct Frag {
+  uint32_t d[4];  // 32 E2M1 values: one lane's share (one row, 32 samples) of a 32 x 64 operand
+};
+
+// 16 samples of 2-bit codes (00 hom-REF, 01 het, 10 hom-ALT, 11 missing; sample s at bits 2s, 2s+1) -> the E2M1 nibbles of
+// the odd samples of X: magnitude at nibble bit 2 (value 2.0) = !b0, sign at bit 3 = b1, i.e. x = +2 / 0 / -2 / -0.
+// f(X) = (X ^ 0x44444444) & 0xCCCCCCCC; the even samples are the odd ones of X << 2.  One v_bitop3_b32 each.
+__device__ __forceinline__ uint32_t fp4_x(uint32_t X) { return __builtin_amdgcn_bitop3_b32(X, 0x44444444u, 0xccccccccu, 0x28); }  // (a ^ b) & c
+// call present (n = !(b0 & b1)) and homozygous (h = !b0 = |x|), both as 2.0 at nibble bit 2
+__device__ __forceinline__ uint32_t fp4_n(uint32_t X) { return __builtin_amdgcn_bitop3_b32(X, X >> 1, 0x44444444u, 0x2a); }  // !(a & b) & c
+
+// 32 samples (two code dwords) of one variant -> one lane's share of a 32 x 64 operand
+__device__ __forceinline__ void fp4_of_codes(uint32_t c0, uint32_t c1, Frag& f) {
+  f.d[0] = fp4_x(c0);
+  f.d[1] = fp4_x(c0 << 2);
+  f.d[2] = fp4_x(c1);
+  f.d[3] = fp4_x(c1 << 2);
+}
+
+// C[row of a][column of b] += sum over 64 samples.  E8M0 scale 0x7e = 1/2 for both operands: (+-2 / 2) (+-2 / 2) = +-1.
+constexpr int kFp4Scale = 0x7e7e7e7e;
+__device__ __forceinline__ mf_v16f mfma_fp4(const Frag& a, const Frag& b, mf_v16f c) {
+  const mf_v8i A = {static_cast<int>(a.d[0]), static_cast<int>(a.d[1]), static_cast<int>(a.d[2]), static_cast<int>(a.d[3]), 0, 0, 0, 0};
+  const mf_v8i B = {static_cast<int>(b.d[0]), static_cast<int>(b.d[1]), static_cast<int>(b.d[2]), static_cast<int>(b.d[3]), 0, 0, 0, 0};
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, kFp4Scale, 0, kFp4Scale);
+}
+
+typedef uint32_t mf_u4 __attribute__((ext_vector_type(4)));  // (a native vector: usable as an inline-asm operand)
+
+// ---- geometry of a stage: four k-steps = 256 samples = kCodeStageBytes contiguous bytes of a row ---------------------
+// A k-step is one MFMA per product: 64 samples, lane half h supplying 32 of them (two code dwords).
+// LDS image of a stage: row-block slot b, row r, four 16-byte pieces per row (piece c = bytes 16 c .. of the row's stage);
+// piece c sits at slot (32 b + r) * 4 + (c ^ ((r >> 2) & 3)); lane half h reads pieces h and 2 + h: its k-step ks is dword ks of
+// each.  The XOR makes the 16 lanes of every ds_read_b128 group hit 16 distinct 4-bank groups without padding, and the DMA
+// (lane-linear in LDS, free per-lane global address) simply fetches the piece that belongs in its slot.
+// (128-sample stages -- twice the ring depth in the same LDS -- were measured slower everywhere in round 2 and are gone.)
+template <int KS>
+struct StageGeom {
+  static_assert(KS == 4, "256-sample stages");
+  static constexpr uint32_t kRowSlots = KS;                       // 16-byte slots per row
+  static constexpr uint32_t kBlockSlots = kMfBlock * KS;          // per row-block (uint4 units)
+  static constexpr uint32_t kBlockDwords = kBlockSlots * 4;
+  static constexpr uint32_t kInstrPerBlock2 = KS;                 // DMA instructions per TWO row-blocks (64 slots each)
+  static constexpr uint32_t kStageSamples = 64 * KS;
+  static constexpr uint32_t kStagesPerChunk = (kChunkDwords * 32) / kStageSamples;
+  __device__ static uint32_t n_instr(uint32_t n_rb) { return (n_rb * KS + 1) / 2; }
+  __device__ static uint32_t block_of_instr(uint32_t T) { return T >> 1; }
+  __device__ static uint32_t swizzle(uint32_t rr) { return (rr >> 2) & 3; }
+  // byte offset of piece `col` inside a row's stage, and of stage s inside the row
+  __device__ static uint32_t piece_byte(uint32_t col) { return col * 16; }
+  __device__ static uint32_t stage_byte(uint32_t s) { return s * kCodeStageBytes; }
+};
+
+// (Keeps hipcc from folding what follows into the LDS reads that produced a and b: a select between two dwords of a
+// loaded vector is otherwise re-written into loads that have lost the __restrict__ information, and each of them then
+// waits for the whole DMA ring, see mfma_stage.)
+__device__ __forceinline__ void opaque(mf_u4& a, mf_u4& b) { asm("" : "+v"(a), "+v"(b)); }
+
+}  // namespace ldp
+#endif

@@ -1,0 +1,448 @@
+// ldp_pair_wide.hip -- the complete-data pair statistics of WIDE bands on the matrix pipe: 8 x 8 block tiles, eight waves.
+//
+// Same arithmetic as pair_mfma_kernel (ldp_pair_mfma.hip: DotprodWords, plink2_ld.cc:235-251, as FP4 matrix products over the
+// samples, expanded from the resident 2-bit codes), a different work decomposition.  At BASELINE config 3's density a window
+// holds ~1,700 variants = 54 row-blocks, and the parallelogram plan's 32 block products per 15 staged row-blocks made the
+// kernel wait for HBM: every row was fetched ~12 times (profiles/r02_c3shape_pmc_traffic.json).  Here a workgroup owns a
+// SQUARE of 8 second-variant blocks x 8 first-variant blocks: 64 products for 16 staged row-blocks (32 KiB per 256-sample
+// stage), i.e. half the bytes per product, and one workgroup per CU with a four-stage ring in 128 KiB of LDS.  Wave w owns
+// the 2 x 4 sub-rectangle J blocks 2 (w & 3), + 1 x V blocks 4 (w >> 2) .. + 3: eight accumulator sets, six row-block reads
+// and expansions per stage (the parallelogram needs seven).  Tiles are aligned to the subcontig start in both directions;
+// on the diagonal the V tile is the J tile (8 row-blocks staged) and the products above it are simply not live.
+// Workgroups are ordered J tile by J tile with all V tiles of a J tile consecutive, and the launch hands consecutive
+// workgroups to one XCD: neighbours share their eight J row-blocks (and overlapping V ranges) through that XCD's L2.
+// Early termination as in pair_mfma_kernel: at a checkpoint a wave drops the products that provably hold no pair above the
+// threshold, row-blocks nobody reads any more are no longer fetched, a workgroup with nothing left leaves.
+#include "ldp_device.h"
+#include "ldp_pair_device.h"
+#include "ldp_mfma_device.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+namespace ldp {
+
+namespace {
+
+using WG = StageGeom<4>;
+constexpr uint32_t kWdStageDwords = kWdRowBlocks * WG::kBlockDwords;  // 8,192 dwords = 32 KiB
+constexpr uint32_t kWdMaxStages = 4;
+constexpr uint32_t kWdEpiWaveDwords = 4 * 16 * 64;                    // four products per epilogue round: 16 KiB per wave
+constexpr uint32_t kWdLdsDwords = kWdWaves * kWdEpiWaveDwords;        // 128 KiB: epilogue scratch == four-stage ring
+constexpr uint32_t kWdCpWaveDwords = 2 * 16 * 64;                     // checkpoint: two products per wave and round
+constexpr uint32_t kWdCpScratchDwords = kWdWaves * kWdCpWaveDwords;   // 64 KiB in; 16 row-blocks x 32 rows x 32 B = 16 KiB follow
+static_assert(kWdStageDwords * kWdMaxStages <= kWdLdsDwords, "ring fits the epilogue scratch");
+
+// One stage of a wave's 2 x 4 rectangle: J fragments of all four k-steps in registers, the four V blocks streamed past them
+// (two b128 LDS reads -> 4 fragments -> 8 MFMAs, the next block's reads in flight).  There is ONE form of this loop body, without
+// a test or a branch: a wave computes all eight of its products as long as one of them is live and stops altogether once none is.
+// (A masked form -- one branch per product or per V block -- costs register copies of every accumulator at each branch; with
+// eight waves' worth of state hipcc spilled inside the stage loop for it, and a scratch reload's vmcnt wait drains the DMA
+// ring.  A wave's eight products sit next to each other in distance, so they mostly die together anyway; the products of a
+// partly live wave that hold no candidate pair accumulate numbers nobody reads.)
+__device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const uint32_t (&joff)[2], const uint32_t (&voff)[4], uint32_t oH, uint32_t oR,
+                                           mf_v16f (&acc)[8]) {
+  mf_u4 vH[2], vR[2];
+  vH[0] = st4[voff[0] + oH];
+  vR[0] = st4[voff[0] + oR];
+  Frag fj0[4], fj1[4];
+  {
+    mf_u4 H = st4[joff[0] + oH], R = st4[joff[0] + oR];
+    opaque(H, R);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fp4_of_codes(H[ks], R[ks], fj0[ks]);
+    }
+  }
+  {
+    mf_u4 H = st4[joff[1] + oH], R = st4[joff[1] + oR];
+    opaque(H, R);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fp4_of_codes(H[ks], R[ks], fj1[ks]);
+    }
+  }
+  // rows of C = first variant (A operand: a V block), columns = second variant (B operand: a J block)
+  // b: V block of the wave (0..3), B: its raw buffer; products b (with J0) and 4 + b (with J1)
+#define LDP_WD_VBLOCK(b, B)                                    \
+  if ((b) < 3) {                                               \
+    vH[(B) ^ 1] = st4[voff[((b) < 3) ? (b) + 1 : 3] + oH];     \
+    vR[(B) ^ 1] = st4[voff[((b) < 3) ? (b) + 1 : 3] + oR];     \
+  }                                                            \
+  opaque(vH[B], vR[B]);                                        \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {           \
+    Frag fv;                                                   \
+    fp4_of_codes(vH[B][ks], vR[B][ks], fv);                    \
+    acc[b] = mfma_fp4(fv, fj0[ks], acc[b]);                    \
+    acc[4 + (b)] = mfma_fp4(fv, fj1[ks], acc[4 + (b)]);        \
+  }
+  LDP_WD_VBLOCK(0, 0)
+  LDP_WD_VBLOCK(1, 1)
+  LDP_WD_VBLOCK(2, 0)
+  LDP_WD_VBLOCK(3, 1)
+#undef LDP_WD_VBLOCK
+}
+
+// row-block slots (bit s: slot s of the stage) a wave with a live product reads: its two J blocks and its four V blocks
+__device__ __forceinline__ uint32_t wide_slots_needed(uint32_t live, uint32_t a0, uint32_t vslot0) {
+  return live ? ((3u << a0) | (0xfu << vslot0)) : 0u;
+}
+
+__global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKernelArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ uint32_t s_src_off[kWdDmaPerWave * kWdWaves * 64];
+  __shared__ uint32_t s_need[kWdWaves];
+  if (*A.route != kRouteComplete) {
+    return;  // rows with missing calls: the parallelogram plan's kernels own the launch (ldp_pair_mfma.hip)
+  }
+  const uint32_t per_xcd = (A.n_wd_tiles + 7) / 8;
+  const uint32_t idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // consecutive tiles on one XCD
+  if (idx >= A.n_wd_tiles) {
+    return;
+  }
+  const MfmaTile* __restrict__ tile = A.wd_tiles + idx;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lane = tid & 63;
+  const uint32_t r = lane & 31;
+  const uint32_t h = lane >> 5;
+  const int32_t jv0 = __builtin_amdgcn_readfirstlane(tile->jv);
+  const int32_t vv0 = __builtin_amdgcn_readfirstlane(tile->vv);
+  const uint32_t jend = __builtin_amdgcn_readfirstlane(tile->jend);
+  const uint32_t mask_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tile->mask));
+  const uint32_t mask_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tile->mask >> 32));
+  const bool diag = (jv0 == vv0);
+  const uint32_t row_bytes = static_cast<uint32_t>(A.code_row_bytes);
+  const uint32_t n_stages = (A.founder_ct + WG::kStageSamples - 1) / WG::kStageSamples;
+  const uint32_t stage_dwords = kWdStageDwords;
+  uint32_t stages = A.lds_dwords / stage_dwords;
+  stages = (stages > kWdMaxStages) ? kWdMaxStages : stages;
+
+  // ---- this wave's rectangle: J blocks a0, a0 + 1, V blocks b0 .. b0 + 3 ----
+  const uint32_t a0 = 2 * (wave & 3), b0 = 4 * (wave >> 2);
+  const uint32_t vslot0 = (diag ? 0u : static_cast<uint32_t>(kWdTile)) + b0;
+  auto mask_row = [&](uint32_t a) { return ((a < 4) ? (mask_lo >> (8 * a)) : (mask_hi >> (8 * (a - 4)))) & 0xffu; };
+  uint32_t live = ((mask_row(a0) >> b0) & 0xfu) | (((mask_row(a0 + 1) >> b0) & 0xfu) << 4);
+  live = __builtin_amdgcn_readfirstlane(live);
+  // row-block slots the workgroup reads: the rectangles of the waves that own a live product
+  uint32_t wg_need = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < static_cast<uint32_t>(kWdWaves); ++w) {
+    const uint32_t wa = 2 * (w & 3), wb = 4 * (w >> 2);
+    const uint32_t wl = ((mask_row(wa) | mask_row(wa + 1)) >> wb) & 0xfu;
+    wg_need |= wide_slots_needed(wl, wa, (diag ? 0u : static_cast<uint32_t>(kWdTile)) + wb);
+  }
+  wg_need = __builtin_amdgcn_readfirstlane(wg_need);
+  auto slot_first = [&](uint32_t s) { return (s < static_cast<uint32_t>(kWdTile)) ? (jv0 + static_cast<int32_t>(kMfBlock * s)) : (vv0 + static_cast<int32_t>(kMfBlock * (s - kWdTile))); };
+
+  // ---- DMA plan: per-lane source offsets (LDS) and per-instruction row-block bases (uniform) ----
+  const uint8_t* base_t[kWdDmaPerWave];
+#pragma unroll
+  for (int t = 0; t < kWdDmaPerWave; ++t) {
+    const uint32_t T = wave + kWdWaves * t;  // instruction T of the stage: half of row-block slot T >> 1
+    const uint32_t slot = T >> 1;
+    uint32_t first = static_cast<uint32_t>(slot_first(slot));
+    first = (first < A.n_local) ? first : (A.n_local - 1);  // (a block beyond the rows is never live; keep its address legal anyway)
+    first = __builtin_amdgcn_readfirstlane(first);
+    base_t[t] = A.codes + static_cast<uint64_t>(first) * row_bytes;
+    const uint32_t L = T * 64 + lane;
+    const uint32_t rr = (L / 4) & 31;
+    const uint32_t col = (L % 4) ^ WG::swizzle(rr);
+    uint32_t var = first + rr;
+    var = (var < A.n_local) ? var : (A.n_local - 1);
+    s_src_off[t * (kWdWaves * 64) + tid] = (var - first) * row_bytes + WG::piece_byte(col);
+  }
+  auto count_mine = [&]() {
+    uint32_t m = 0;
+#pragma unroll
+    for (int t = 0; t < kWdDmaPerWave; ++t) {
+      m += ((wg_need >> ((wave + kWdWaves * t) >> 1)) & 1u) ? 1u : 0u;
+    }
+    return m;
+  };
+  uint32_t mine = count_mine();  // DMA wave-instructions per stage this wave issues
+
+  uint32_t joff[2], voff[4];  // uint4 index of the row-block's first slot
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    joff[q] = (a0 + q) * WG::kBlockSlots;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    voff[b] = (vslot0 + b) * WG::kBlockSlots;
+  }
+  uint32_t need = wide_slots_needed(live, a0, vslot0);
+  // window starts of this lane's two second variants (J0 + r, J1 + r), fetched here: the k-loop must not hold ordinary
+  // global loads (hipcc would drain the DMA ring in front of every LDS read of the loop)
+  uint32_t lo_j2[2] = {0xffffffffu, 0xffffffffu};  // (lo >= j: no candidate pair)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint32_t j = static_cast<uint32_t>(jv0) + kMfBlock * (a0 + q) + r;
+    if (j < jend) {
+      lo_j2[q] = A.lo[j];
+    }
+  }
+  const uint32_t sw = WG::swizzle(r);
+  const uint32_t oH = r * 4 + (h ^ sw);
+  const uint32_t oR = r * 4 + ((2 + h) ^ sw);
+
+  mf_v16f acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      acc[p][g] = 0.f;
+    }
+  }
+
+  uint32_t next_cp = 0;
+  const uint32_t n_cp = A.cp_stats ? A.n_checkpoints : 0;
+  const uint32_t live0 = live;        // the products of the plan
+  uint32_t stop_stage = n_stages;     // stages this wave computes (it stops as a whole, at a checkpoint)
+  auto dma_stage = [&](uint32_t s, uint32_t buf) {
+    const uint32_t kbyte = WG::stage_byte(s);
+    uint32_t* dst = lds + buf * stage_dwords;
+#pragma unroll
+    for (int t = 0; t < kWdDmaPerWave; ++t) {
+      const uint32_t T = wave + kWdWaves * t;
+      if ((wg_need >> (T >> 1)) & 1u) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_t[t] + kbyte + s_src_off[t * (kWdWaves * 64) + tid]),
+                                         (__attribute__((address_space(3))) void*)(dst + T * 256), 16, 0, 0);
+      }
+    }
+  };
+  auto checkpoint_stage = [&](uint32_t cp) {
+    const uint32_t s = A.checkpoint_chunk[cp] * WG::kStagesPerChunk;
+    return (s < n_stages) ? s : n_stages;
+  };
+
+  __syncthreads();  // (s_src_off is complete)
+  uint32_t* epi = lds + wave * kWdEpiWaveDwords;  // this wave's scratch whenever the ring is empty (epilogue)
+  // ---- k-loop over stages, ring of `stages` LDS buffers; the ring never runs past the next checkpoint ----
+  uint32_t issued = 0, issue_buf = 0, read_buf = 0, issued_base = 0;
+  uint32_t issue_limit = (next_cp < n_cp) ? checkpoint_stage(next_cp) : n_stages;
+  auto ring_fill = [&]() {
+    issue_buf = 0;
+    read_buf = 0;
+    while ((issued < issue_limit) && (issued + 1 < issued_base + stages)) {
+      dma_stage(issued, issue_buf);
+      ++issued;
+      issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
+    }
+  };
+  ring_fill();
+  for (uint32_t kc = 0; kc < n_stages;) {
+    const uint32_t kc_end = issue_limit;  // the next checkpoint (or the end of the rows)
+    for (; kc < kc_end; ++kc) {
+      wait_dma_then_barrier(mine * (issued - kc - 1));
+      if (issued < issue_limit) {
+        dma_stage(issued, issue_buf);  // (reuses the buffer every wave finished reading before the barrier)
+        ++issued;
+        issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
+      }
+      const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * stage_dwords);
+      read_buf = (read_buf + 1 == stages) ? 0 : read_buf + 1;
+      if (live) {
+        wide_stage(st4, joff, voff, oH, oR, acc);
+      }
+    }
+    if (kc >= n_stages) {
+      break;
+    }
+    // ---- checkpoint (ldp_device.h): drop the products whose candidate pairs are all provably below the threshold ----
+    __syncthreads();  // every wave is done with the last stage: LDS is scratch now
+    {
+      // the checkpoint statistics of every staged row by LDS-DMA too: slot next_cp and the whole-row slot, 32 bytes per row
+      const uint8_t* cps = reinterpret_cast<const uint8_t*>(A.cp_stats);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint32_t T = wave + kWdWaves * t;  // row-block slot T: 32 rows x 2 pieces
+        if ((wg_need >> T) & 1u) {
+          uint32_t first = static_cast<uint32_t>(slot_first(T));
+          first = (first < A.n_local) ? first : (A.n_local - 1);
+          uint32_t var = first + (lane >> 1);
+          var = (var < A.n_local) ? var : (A.n_local - 1);
+          const uint64_t off = static_cast<uint64_t>(var) * (kCpSlots * sizeof(cp_slot)) + ((lane & 1) ? kCheckpoints : next_cp) * sizeof(cp_slot);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cps + off),
+                                           (__attribute__((address_space(3))) void*)(lds + kWdCpScratchDwords + T * 256), 16, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // (drains the DMA: the slots are in LDS)
+    const cp_slot* __restrict__ cpl = reinterpret_cast<const cp_slot*>(lds + kWdCpScratchDwords);  // [row-block slot][row][2]
+    if (live) {
+      uint32_t keep = 0;
+      uint32_t* cp_epi = lds + wave * kWdCpWaveDwords;  // two products per round
+#pragma unroll
+      for (int round = 0; round < 4; ++round) {
+        if (!(live & (0x3u << (2 * round)))) {
+          continue;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          if (live & (1u << (2 * round + pl))) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+              cp_epi[(pl * 16 + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>(acc[2 * round + pl][g]));
+            }
+          }
+        }
+        const int q = (round >= 2) ? 1 : 0;  // products 0..3: J0, 4..7: J1
+        const int64_t j64 = static_cast<int64_t>(jv0) + kMfBlock * (a0 + q) + r;
+        const int64_t lo_j = lo_j2[q];
+        const uint32_t jslot = a0 + q;
+        const cp_slot cj = cpl[(jslot * kMfBlock + r) * 2];
+        const cp_slot gj = cpl[(jslot * kMfBlock + r) * 2 + 1];
+#pragma unroll 1
+        for (uint32_t pl = 0; pl < 2; ++pl) {
+          const uint32_t p = 2 * round + pl;
+          if (!(live & (1u << p))) {
+            continue;
+          }
+          const uint32_t b = p & 3;  // V block of the product
+          const uint32_t vslot = vslot0 + b;
+          bool hopeless = true;
+#pragma unroll 2
+          for (uint32_t g = 0; g < 16; ++g) {
+            const uint32_t row = (g & 3) + 8 * (g >> 2) + 4 * h;
+            const int64_t i64 = static_cast<int64_t>(vv0) + kMfBlock * (b0 + b) + row;
+            if ((i64 >= lo_j) && (i64 < j64)) {
+              const cp_slot ci = cpl[(vslot * kMfBlock + row) * 2];
+              const cp_slot gi = cpl[(vslot * kMfBlock + row) * 2 + 1];
+              // |N dot - S_i S_j| <= |c0| + B, see pair_hopeless() in ldp_pair_device.h (dot_p is the partial dot product)
+              const double dot_p = static_cast<double>(static_cast<int32_t>(cp_epi[(pl * 16 + g) * 64 + lane]));
+              const double c0 = fma(static_cast<double>(A.founder_ct), dot_p, fma(ci.a, cj.a, -(gi.a * gj.a)));
+              const double bound = fabs(c0) + fma(ci.b, cj.b, 1.0);
+              hopeless = hopeless && (bound < gi.b * gj.b);
+            }
+          }
+          if (!__all(hopeless)) {
+            keep |= 1u << p;
+          }
+        }
+      }
+      keep = __builtin_amdgcn_readfirstlane(keep);
+      if (keep != live) {
+        live = keep;
+        need = wide_slots_needed(live, a0, vslot0);
+        if (!live) {
+          stop_stage = kc;  // the wave computes nothing from here on
+        }
+      }
+    }
+    ++next_cp;
+    // which staged row-blocks does the workgroup still read?  Dead ones are no longer fetched.
+    if (lane == 0) {
+      s_need[wave] = need;
+    }
+    __syncthreads();
+    uint32_t all_need = 0;
+#pragma unroll
+    for (int w = 0; w < kWdWaves; ++w) {
+      all_need |= s_need[w];
+    }
+    __syncthreads();  // (s_need is rewritten at the next checkpoint; the scratch reads above are over as well)
+    if (!all_need) {
+      break;  // nothing left that could reach the threshold
+    }
+    if (all_need != wg_need) {
+      wg_need = __builtin_amdgcn_readfirstlane(all_need);
+      mine = count_mine();
+    }
+    issue_limit = (next_cp < n_cp) ? checkpoint_stage(next_cp) : n_stages;
+    issued_base = kc;
+    ring_fill();  // restart the ring at this stage
+  }
+  __syncthreads();  // staging is over: LDS becomes the epilogue's scratch (a private region per wave)
+  if ((lane == 0) && live0) {
+    // bookkeeping in product x k-step units (one MFMA each): what early termination saved of the plan's products, and what the
+    // single-form stage loop computed beyond the plan (the products of this wave's rectangle that hold no candidate pair)
+    const uint32_t planned = __builtin_popcount(live0);
+    if (stop_stage < n_stages) {
+      atomicAdd(A.counters + 2, static_cast<unsigned long long>(n_stages - stop_stage) * 4 * planned);
+    }
+    if (planned < 8) {
+      atomicAdd(A.counters + 1, static_cast<unsigned long long>(stop_stage) * 4 * (8 - planned));
+    }
+  }
+
+  // ---- epilogue: accumulators through LDS so the per-pair code is a rolled loop ----
+  // lane l, register g of a product holds first variant (g & 3) + 8 (g >> 2) + 4 (l >> 5) of the V block, second variant
+  // l & 31 of the J block (tools/mfma_probe.hip, fact 1)
+  uint32_t n_true = 0;
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    if (!(live & (0xfu << (4 * round)))) {
+      continue;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) {
+      if (live & (1u << (4 * round + pl))) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          epi[(pl * 16 + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>((round ? acc[4 + pl] : acc[pl])[g]));
+        }
+      }
+    }
+    const int64_t j64 = static_cast<int64_t>(jv0) + kMfBlock * (a0 + round) + r;
+    if (j64 < static_cast<int64_t>(jend)) {
+      const uint32_t j = static_cast<uint32_t>(j64);
+      const uint32_t lo_j = lo_j2[round];
+      if (lo_j < j) {
+        const int32_t sum_j = A.recs[j].sum;
+        const uint32_t ssq_j = A.recs[j].ssq;
+        const uint32_t flags_j = A.recs[j].flags;
+#pragma unroll 1
+        for (uint32_t pl = 0; pl < 4; ++pl) {
+          if (!(live & (1u << (4 * round + pl)))) {
+            continue;
+          }
+          const int64_t vfirst = static_cast<int64_t>(vv0) + kMfBlock * (b0 + pl) + 4 * h;
+#pragma unroll 1
+          for (uint32_t g = 0; g < 16; ++g) {
+            const int64_t i64 = vfirst + (g & 3) + 8 * (g >> 2);
+            if ((i64 < static_cast<int64_t>(lo_j)) || (i64 >= j64)) {
+              continue;
+            }
+            const uint32_t i = static_cast<uint32_t>(i64);
+            const ldp_variant_rec ri = A.recs[i];
+            ldp_pair_stats_t ps;
+            const int32_t dot_img = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]);
+            ps.dot = ((ri.flags ^ flags_j) & 1u) ? -dot_img : dot_img;  // the image's orientation -> the records' (major allele)
+            ps.nm = A.founder_ct;
+            ps.sum1 = ri.sum;
+            ps.ssq1 = ri.ssq;
+            ps.sum2 = sum_j;
+            ps.ssq2 = ssq_j;
+            n_true += emit_pair(A, i, j, lo_j, ps) ? 1 : 0;
+          }
+        }
+      }
+    }
+  }
+  n_true = wave_reduce_add(n_true);
+  if ((lane == 0) && n_true) {
+    atomicAdd(A.counters, static_cast<unsigned long long>(n_true));
+  }
+}
+
+}  // namespace
+
+hipError_t launch_pair_wide(const PairKernelArgs& a_in, hipStream_t stream) {
+  if (!a_in.n_wd_tiles) {
+    return hipSuccess;
+  }
+  PairKernelArgs a = a_in;
+  static const size_t lds = []() {
+    const size_t bytes = static_cast<size_t>(kWdLdsDwords) * sizeof(uint32_t);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    return bytes;
+  }();
+  a.lds_dwords = static_cast<uint32_t>(lds / sizeof(uint32_t));
+  const uint32_t per_xcd = (a.n_wd_tiles + 7) / 8;
+  hipLaunchKernelGGL(pair_mfma_wide_kernel, dim3(per_xcd * 8), dim3(kWdWaves * 64), lds, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace ldp

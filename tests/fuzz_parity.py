@@ -52,6 +52,9 @@ def one_case(pkg, rng, idx):
     inv, mf, _ = T.oracle_prepare(raw)
     want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, window, step, is_bp, r2, order)
     eng = pkg.LdPruneEngine(n, window, step, is_bp, r2, order=order, device=0)
+    wide = int(rng.choice([-1, -1, 0, 1, 3]))  # (drawn for every case, so that the sequence of cases stays the same)
+    if wide >= 0:
+        eng.set_option("wide_min_reach", wide)  # send narrower bands through the 8 x 8 tile plan of the wide-band kernel too
     eng.set_variants(chr_idx, bps)
     packed = T.pack_2bit(raw)
     if rng.random() < 0.5:
@@ -64,9 +67,9 @@ def one_case(pkg, rng, idx):
     ctr = eng.counters()
     eng.close()
     ok = np.array_equal(got, want)
-    desc = "case %d: n=%d m=%d miss=%g %s window=%d step=%d r2=%g order=%d chr=%d removed=%d skipped=%.2f" % (
-        idx, n, m, miss, "bp" if is_bp else "count", window, step, r2, order, n_chr, int(want.sum()),
-        (ctr["early_exit_unit_chunks"] / ctr["tile_unit_chunks"]) if ctr["tile_unit_chunks"] else 0.0)
+    desc = "case %d: n=%d m=%d miss=%g %s window=%d step=%d r2=%g order=%d chr=%d wide_min_reach=%d tiles=%d removed=%d skipped=%.2f" % (
+        idx, n, m, miss, "bp" if is_bp else "count", window, step, r2, order, n_chr, wide, ctr["wide_tiles"], int(want.sum()),
+        (ctr["mfma_skipped_product_stages"] / ctr["mfma_product_stages"]) if ctr["mfma_product_stages"] else 0.0)
     return ok, desc
 
 

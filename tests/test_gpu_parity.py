@@ -310,6 +310,81 @@ def test_popcount_kernels_on_bit_planes_agree_with_the_matrix_pipe(gpu_pkg, n, m
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+WIDE_CASES = [
+    # m, n, seed, window, step, is_bp, r2, order, min_reach
+    (900, 300, 1, 500, 1, False, 0.2, 2, 12),       # 16 row-blocks of reach: the tile plan by itself
+    (1300, 3000, 2, 400, 7, False, 0.5, 2, 12),     # count window with a step, two subcontigs
+    (1000, 1100, 3, 90000, 1, True, 0.3, 1, 12),    # kb windows with gaps: subcontigs of every length, some wide
+    (700, 70, 4, 50, 5, False, 0.2, 2, 0),          # a narrow band forced through the tiles (diagonal tiles only)
+    (520, 513, 5, 519, 1, False, 0.1, 2, 0),        # one window spans everything: three J tiles, the last one ragged
+    (257, 40, 6, 256, 1, False, 0.4, 2, 0),         # a J tile of one variant
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_wide_band_tiles_match_oracle(gpu_pkg, case):
+    """pair_mfma_wide_kernel (8 x 8 block tiles, eight waves: the plan of wide bands such as config 3's): every candidate
+    pair's integers and the prune set against the oracle, and early termination -- whole waves stopping at checkpoints --
+    invisible in the result."""
+    pkg = gpu_pkg
+    m, n, seed, window, step, is_bp, r2, order, min_reach = case
+    raw = T.synth_raw_codes(m, n, seed, missing_rate=0.0, ld_copy_prob=0.6, redraw=0.08)
+    chr_idx, bps = make_positions(m, 2, seed + 40) if is_bp else (np.repeat(np.arange(2, dtype=np.uint32), (m + 1) // 2)[:m], None)
+    inv, mf, altmaj, hom, r2h, vaggs = oracle_recs(raw, n)
+    want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps if bps is not None else np.arange(m, dtype=np.uint32), mf, window, step, is_bp, r2, order)
+    res = {}
+    for ee in (1, 0):
+        eng = pkg.LdPruneEngine(n, window, step, is_bp, r2, order=order, device=0)
+        eng.set_option("wide_min_reach", min_reach)
+        eng.set_option("early_exit", ee)
+        eng.set_variants(chr_idx, bps)
+        eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+        got = eng.run()
+        c = eng.counters()
+        assert c["wide_tiles"] > 0 and c["route_complete_launches"] > 0
+        assert np.array_equal(got, want), (ee, int(got.sum()), int(want.sum()))
+        res[ee] = c
+        if ee == 0:
+            removed, stats = eng.run_with_stats()
+            lo, _ = eng.band()
+            k = 0
+            for j in range(m):
+                for i in range(int(lo[j]), j):
+                    assert tuple(int(x) for x in stats[k]) == T.oracle_pair_stats(hom, r2h, vaggs, n, i, j).astuple(), (i, j)
+                    k += 1
+            assert np.array_equal(removed, want)
+        eng.close()
+    assert res[0]["mfma_skipped_product_stages"] == 0 and res[1]["pred_true"] == res[0]["pred_true"]
+    # the same rows through the parallelogram plan alone
+    eng = pkg.LdPruneEngine(n, window, step, is_bp, r2, order=order, device=0)
+    eng.set_option("wide_min_reach", 1e9)
+    eng.set_variants(chr_idx, bps)
+    eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+    assert np.array_equal(eng.run(), want) and eng.counters()["wide_tiles"] == 0
+    eng.close()
+
+
+def test_wide_band_with_missing_calls_falls_back_to_the_parallelogram_kernels(gpu_pkg):
+    """The tile kernel takes complete-data launches only; rows with missing calls send the launch to the interval epilogue or the
+    six-product kernel over the parallelogram plan of the same subcontigs."""
+    pkg = gpu_pkg
+    m, n = 800, 900
+    for miss, route in ((0.001, "route_sparse_launches"), (0.05, "route_general_launches")):
+        raw = T.synth_raw_codes(m, n, 17, missing_rate=miss, ld_copy_prob=0.6, redraw=0.08)
+        chr_idx = np.zeros(m, dtype=np.uint32)
+        bps = np.arange(m, dtype=np.uint32)
+        inv, mf, _ = T.oracle_prepare(raw)
+        want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 450, 1, False, 0.3, 2)
+        eng = pkg.LdPruneEngine(n, 450, 1, False, 0.3, order=2, device=0)
+        eng.set_variants(chr_idx, None)
+        eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+        got = eng.run()
+        c = eng.counters()
+        eng.close()
+        assert c["wide_tiles"] > 0 and c[route] > 0 and c["route_complete_launches"] == 0
+        assert np.array_equal(got, want)
+
+
 def test_device_pointer_input(gpu_pkg):
     m, n = 300, 257
     raw = T.synth_raw_codes(m, n, seed=31, missing_rate=0.02)

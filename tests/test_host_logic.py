@@ -244,7 +244,7 @@ def _mfma_plan_coverage(pkg, m, nchr, seed, window, step, is_bp, spacing, rank=0
     count = np.zeros(int(pair_off[-1]), dtype=np.int32)
     prev_hi = 0
     for wg in wgs:
-        n_rb, j_lo, j_hi = int(wg[0]), int(wg[1]), int(wg[2])
+        n_rb, j_lo, j_hi = int(wg[0]) & 0x7fffffff, int(wg[1]), int(wg[2])
         rb = wg[3:19].astype(np.int64)
         assert 1 <= n_rb <= 16
         assert np.all(np.diff(rb[:n_rb]) > 0)
@@ -277,6 +277,78 @@ def _mfma_plan_coverage(pkg, m, nchr, seed, window, step, is_bp, spacing, rank=0
         prev_hi = max(prev_hi, j_hi)
     assert np.all(count == 1), "pairs covered %d..%d times" % (count.min() if len(count) else 1, count.max() if len(count) else 1)
     return len(wgs), len(count)
+
+
+def _wide_plan_coverage(pkg, m, nchr, seed, window, step, is_bp, spacing, min_reach, rank=0, world=1, big_gap_prob=0.01):
+    """The 8 x 8 tile plan of the wide-band kernel (ldp_pair_wide.hip): over the subcontigs that take it every candidate pair is
+    owned by exactly one live product of exactly one tile, tiles are aligned to the subcontig start in both directions, and the
+    parallelogram workgroups of those subcontigs are marked as standing by."""
+    chr_idx, bps = make_positions(m, nchr, seed, spacing=spacing, big_gap_prob=big_gap_prob)
+    eng = pkg.LdPruneEngine(100, window, step, is_bp, 0.2, device=-1)
+    eng.set_option("wide_min_reach", min_reach)
+    eng.set_variants(chr_idx, bps)
+    if world > 1:
+        eng.set_shard(rank, world)
+    wgs, lo = eng.debug_mfma_plan()
+    tiles = eng.debug_wide_plan()
+    eng.close()
+    n_local = len(lo)
+    span = np.arange(n_local, dtype=np.int64) - lo.astype(np.int64)
+    pair_off = np.concatenate([[0], np.cumsum(np.maximum(span, 0))])
+    count = np.zeros(int(pair_off[-1]), dtype=np.int32)
+    wide_j = np.zeros(n_local, dtype=bool)   # second variants whose subcontig has the wide plan
+    for wg in wgs:
+        if int(wg[0]) >> 31:
+            wide_j[int(wg[1]):int(wg[2])] = True
+    prev = (-1, -1)
+    for jv, vv, jend, mlo, mhi in tiles.astype(np.int64):
+        mask = int(mlo) | (int(mhi) << 32)
+        assert mask and 0 <= vv <= jv < jend <= n_local and (jv - vv) % 256 == 0
+        assert (jv, vv) > prev   # J tile by J tile, V tiles ascending
+        prev = (jv, vv)
+        for a in range(8):
+            for b in range(8):
+                if not (mask >> (8 * a + b)) & 1:
+                    continue
+                jfirst, vfirst = jv + 32 * a, vv + 32 * b
+                assert vfirst <= jfirst
+                for j in range(jfirst, min(jfirst + 32, jend)):
+                    assert wide_j[j]
+                    x, y = max(vfirst, int(lo[j])), min(vfirst + 32, j)
+                    if x < y:
+                        count[pair_off[j] + x - lo[j]:pair_off[j] + y - lo[j]] += 1
+    for j in range(n_local):
+        if span[j] > 0:
+            want = 1 if wide_j[j] else 0
+            assert np.all(count[pair_off[j]:pair_off[j + 1]] == want), (j, want)
+    return len(tiles), int(wide_j.sum())
+
+
+@pytest.mark.parametrize("m,nchr,seed,window,step,is_bp,spacing,min_reach,gap_prob,expect", [
+    (5000, 2, 2, 200000, 1, True, 300, 12, 0.0, "all"),    # ~670 per window = 21 row-blocks: both subcontigs wide
+    (9000, 3, 11, 520000, 1, True, 300, 12, 0.0, "all"),   # config 3's density: ~1,730 per window = 54 row-blocks
+    (5000, 2, 2, 200000, 1, True, 300, 12, 0.01, None),    # the same density cut into subcontigs of every length by gaps
+    (3000, 3, 1, 20000, 1, True, 300, 12, 0.01, "none"),   # ~67 per window: nothing is wide
+    (3000, 3, 1, 20000, 1, True, 300, 0, 0.01, "all"),     # ... unless forced: narrow bands through the tile plan
+    (2000, 7, 3, 50, 5, False, 300, 1, 0.01, None),        # count windows with a step
+    (1500, 40, 4, 15000, 1, True, 200, 2, 0.01, None),     # many short subcontigs, some wide by this measure, some not
+    (700, 1, 5, 1000000, 1, True, 100, 12, 0.0, "all"),    # one window spans everything
+    (257, 1, 6, 100000, 1, True, 100, 0, 0.0, "all"), (256, 1, 7, 100000, 1, True, 100, 0, 0.0, "all"), (33, 1, 8, 100000, 1, True, 100, 0, 0.0, "all"),
+])
+def test_wide_plan_covers_every_candidate_pair_once(pkg, m, nchr, seed, window, step, is_bp, spacing, min_reach, gap_prob, expect):
+    n_tiles, n_wide = _wide_plan_coverage(pkg, m, nchr, seed, window, step, is_bp, spacing, min_reach, big_gap_prob=gap_prob)
+    if expect == "none":
+        assert n_tiles == 0 and n_wide == 0
+    elif expect == "all":
+        assert n_tiles > 0 and (n_wide == m or (gap_prob > 0 and n_wide > 0.95 * m))  # (variants alone in a subcontig are in no plan)
+    # the parallelogram plan still covers everything (it owns the launches whose rows have missing calls)
+    _mfma_plan_coverage(pkg, m, nchr, seed, window, step, is_bp, spacing)
+
+
+def test_wide_plan_covers_a_shard(pkg):
+    for rank in range(2):
+        n_tiles, _ = _wide_plan_coverage(pkg, 6000, 6, 9, 300000, 1, True, 300, 12, rank=rank, world=2, big_gap_prob=0.0)
+        assert n_tiles > 0
 
 
 @pytest.mark.parametrize("m,nchr,seed,window,step,is_bp,spacing", [
