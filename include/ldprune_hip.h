@@ -164,6 +164,17 @@ int ldp_get_subcontigs(const ldp_engine* e, uint32_t* ct, uint32_t* info, uint32
  * cf. plink2_ld.cc:2686-2694).  Only owned variants need genotype rows; ldp_run() reports bits for
  * owned variants only.  owner[k] (optional, subcontig_ct entries) receives the rank of subcontig k. */
 int ldp_set_shard(ldp_engine* e, uint32_t rank, uint32_t world, uint32_t* owner);
+/* The one exchange step of a multi-GPU prune, for a C/C++ host (one process or one process per GPU): every rank contributes the
+ * removed bits of ITS variants, packed in shard order, and ONE ncclAllGather over device buffers (RCCL over xGMI; segments padded
+ * to the longest: the allgatherv) gives every rank every segment; they are then stitched into global variant order -- what
+ * IndepPairwise does with its threads' bit ranges (plink2_ld.cc:1418-1426).  comm: an ncclComm_t whose size and rank equal
+ * ldp_set_shard()'s world and rank.  removed_local: the bitmap ldp_run() produced on this rank; removed_global (out):
+ * (variant_ct + 63) / 64 words, identical on every rank.  RCCL is bound at run time (librccl.so.1): LDP_ERR_UNSUPPORTED where it
+ * is not installed.  ldp_comm_init_all() / ldp_comm_destroy() wrap ncclCommInitAll / ncclCommDestroy for hosts that drive
+ * several devices from one process (plink2-hip --gpus N) and do not want RCCL's header. */
+int ldp_allgather_removed(ldp_engine* e, void* nccl_comm, const uint64_t* removed_local, uint64_t* removed_global);
+int ldp_comm_init_all(int n, const int* devices, void** comms);
+void ldp_comm_destroy(void* comm);
 /* per-variant window start lo[v] (first candidate partner index) and candidate pair total */
 int ldp_get_band(const ldp_engine* e, uint32_t* lo, uint64_t* candidate_pairs);
 
@@ -243,7 +254,7 @@ int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first
 int ldp_debug_set_option(ldp_engine* e, const char* name, double value);
 /* Host-only view of the matrix-pipe work plan (csrc/ldp_device.h: MfmaWG) in the engine's shard-local variant
  * indices, for the CPU test that every candidate pair is owned by exactly one 32 x 32 block product.  Per workgroup
- * 63 words: n_rb (bit 31: see ldp_debug_wide_plan), j_lo, j_hi, rb[16], then per wave jv, vv, jend, prod_mask, slot[7].  lo_local (optional, *local_ct
+ * 63 words: n_rb (bit 31: see ldp_debug_wide_plan; bit 30: every wave item is diagonal), j_lo, j_hi, rb[16], then per wave jv, vv, jend, prod_mask, slot[7].  lo_local (optional, *local_ct
  * entries) receives the window starts in the same index space.  words == NULL only counts. */
 int ldp_debug_mfma_plan(const ldp_engine* e, uint32_t* wg_count, uint32_t* words, uint64_t capacity_words, uint32_t* lo_local, uint32_t* local_ct);
 

@@ -91,6 +91,7 @@ CABI_SYMBOLS = [
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_has_dosage", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
     "ldp_pgen_variant_is_multiallelic", "ldp_pgen_provisional_ref", "ldp_pgen_open_indexed", "ldp_set_r_signed", "ldp_set_variants_vcor_cm", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_subset_samples", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
     "ldp_debug_set_option", "ldp_matrix_pipe_max_founders", "ldp_map_rows", "ldp_release_device", "ldp_debug_wide_plan",
+    "ldp_allgather_removed", "ldp_comm_init_all", "ldp_comm_destroy",
 ]
 
 
@@ -174,6 +175,10 @@ def lib():
     L.ldp_debug_replay_pairs.argtypes = [vp, ctypes.c_uint64, u32p, u32p, u64p]
     L.ldp_map_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp), u64p]
     L.ldp_release_device.argtypes = [vp]
+    L.ldp_allgather_removed.argtypes = [vp, vp, u64p, u64p]
+    L.ldp_comm_init_all.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(vp)]
+    L.ldp_comm_destroy.argtypes = [vp]
+    L.ldp_comm_destroy.restype = None
     L.ldp_debug_wide_plan.argtypes = [vp, u32p, u32p, ctypes.c_uint64]
     L.ldp_matrix_pipe_max_founders.argtypes = []
     L.ldp_matrix_pipe_max_founders.restype = ctypes.c_uint32
@@ -226,6 +231,21 @@ def hip_memcpy_dtod(dst_ptr, src_ptr, nbytes):
     rt = ctypes.CDLL("libamdhip64.so", mode=ctypes.RTLD_GLOBAL)
     rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     return int(rt.hipMemcpy(ctypes.c_void_p(dst_ptr), ctypes.c_void_p(src_ptr), ctypes.c_size_t(nbytes), 3))  # 3 = hipMemcpyDeviceToDevice
+
+
+def comm_init_all(devices):
+    """ncclCommInitAll over `devices` through the C ABI (ldp_comm_init_all): a list of ncclComm_t handles (integers)."""
+    n = len(devices)
+    devs = (ctypes.c_int * n)(*devices)
+    comms = (ctypes.c_void_p * n)()
+    rc = lib().ldp_comm_init_all(n, devs, comms)
+    if rc != LDP_OK:
+        raise LdpError(rc, "ldp_comm_init_all failed")
+    return [int(c) for c in comms]
+
+
+def comm_destroy(comm):
+    lib().ldp_comm_destroy(ctypes.c_void_p(comm))
 
 
 def matrix_pipe_max_founders():
@@ -531,6 +551,14 @@ class LdPruneEngine:
         stride = ctypes.c_uint64()
         self._ck(self._L.ldp_map_rows(self._h, int(first_variant), int(n), ctypes.byref(ptr), ctypes.byref(stride)))
         return int(ptr.value), int(stride.value)
+
+    def allgather_removed(self, comm, removed_bitmap_words):
+        """ldp_allgather_removed: this rank's bitmap (uint64 words over all variants) -> the global one, through ONE ncclAllGather
+        of shard-order segments on the communicator `comm` (an ncclComm_t as an integer / c_void_p)."""
+        words = np.ascontiguousarray(removed_bitmap_words, dtype=np.uint64)
+        out = np.zeros((self.variant_ct + 63) // 64 + 1, dtype=np.uint64)
+        self._ck(self._L.ldp_allgather_removed(self._h, ctypes.c_void_p(comm), _ptr(words, ctypes.c_uint64), _ptr(out, ctypes.c_uint64)))
+        return out
 
     def release_device(self):
         """Free the engine's device memory, keep its plan (ldp_release_device)."""

@@ -101,7 +101,8 @@ struct MfmaWG {
   uint32_t rb[kMfMaxRowBlocks];  // first variant of each staged row-block
   uint32_t n_rb;
   uint32_t j_lo, j_hi;           // second variants the workgroup's waves own: [j_lo, j_hi)
-  uint32_t pad;                  // 1: the subcontig also has a wide plan (MfmaTile), which owns it on complete-data launches
+  uint32_t pad;                  // bit 0: the subcontig also has a wide plan (MfmaTile), which owns it on complete-data launches;
+                                 // bit 1: every wave item is diagonal (V3 = J0, V4 = J1): the single-form kernel's workgroup
   MfmaWaveItem w[kMfWaves];
 };
 
@@ -170,6 +171,7 @@ struct PairKernelArgs {
   // kernels of the launch only run for non-zero (the general matrix-pipe kernel is off), 2: they never run
   const MfmaWG* mf_wgs;
   uint32_t n_mf_wgs;
+  uint32_t mf_diag_ct;           // the first mf_diag_ct workgroups of mf_wgs are all-diagonal (MfmaWG::pad bit 1): pair_mfma_kernel's DIAGFORM instantiation
   uint32_t n_local;              // rows in `planes`
   uint32_t mf_active;            // the launch also carries matrix-pipe work items
   const uint32_t* route;         // kRoute*

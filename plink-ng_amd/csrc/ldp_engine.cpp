@@ -23,6 +23,9 @@
 
 #include "ldp_device.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 using namespace ldp;
 
 namespace {
@@ -123,7 +126,8 @@ struct ldp_engine {
     uint32_t item_first = 0, item_ct = 0;
     uint32_t need_end = 0;               // local variants [0, need_end) must be loaded
     uint64_t word_first = 0, word_end = 0;  // predicate words the group's J-tiles own
-    uint32_t mf_first = 0, mf_ct = 0;    // the same J range as matrix-pipe workgroups (mf_wgs)
+    uint32_t mf_first = 0, mf_ct = 0;    // the same J range as matrix-pipe workgroups (mf_wgs) ...
+    uint32_t mf_diag_ct = 0;             // ... of which the first mf_diag_ct are all-diagonal (partition_diag)
     uint32_t wd_first = 0, wd_ct = 0;    // ... and as wide-band tiles (wd_tiles)
     bool launched = false;
     hipEvent_t ev_ready = nullptr;
@@ -593,6 +597,11 @@ void plan_mfma_generic(const std::vector<std::pair<uint32_t, uint32_t>>& runs, c
     }
     wg.j_lo = 0xffffffffu;
     wg.j_hi = 0;
+    bool all_diag = true;
+    for (const Wave& pw : pending) {
+      all_diag = all_diag && (pw.vv + static_cast<int32_t>(3 * kMfBlock) == pw.jv);
+    }
+    wg.pad = all_diag ? 2u : 0u;
     for (uint32_t w = 0; w < kMfWaves; ++w) {
       MfmaWaveItem& wi = wg.w[w];
       if (w >= pending.size()) {
@@ -764,11 +773,19 @@ void plan_mfma_generic(const std::vector<std::pair<uint32_t, uint32_t>>& runs, c
     if (out_tiles) {
       flush();
       for (size_t k = run_wg_first; k < out_wgs->size(); ++k) {
-        (*out_wgs)[k].pad = wide_run ? 1u : 0u;
+        (*out_wgs)[k].pad = ((*out_wgs)[k].pad & 2u) | (wide_run ? 1u : 0u);
       }
     }
   }
   flush();
+}
+
+// The workgroups [first, first + ct) with the all-diagonal ones (MfmaWG::pad bit 1) first, J order kept inside either run:
+// launch_pair_mfma hands the first run to the single-form instantiation of pair_mfma_kernel and the rest to the general one.
+uint32_t partition_diag(std::vector<MfmaWG>* wgs, size_t first, size_t ct) {
+  const auto b = wgs->begin() + static_cast<std::ptrdiff_t>(first);
+  const auto mid = std::stable_partition(b, b + static_cast<std::ptrdiff_t>(ct), [](const MfmaWG& w) { return (w.pad & 2u) != 0; });
+  return static_cast<uint32_t>(mid - b);
 }
 
 void plan_mfma(ldp_engine* e) {
@@ -954,6 +971,9 @@ void build_shard(ldp_engine* e) {
       g.mf_first = w0;
       g.mf_ct = w1 - w0;
       w0 = w1;
+    }
+    for (ldp_engine::PairGroup& g : e->groups) {
+      g.mf_diag_ct = partition_diag(&e->mf_wgs, g.mf_first, g.mf_ct);
     }
     uint32_t t0 = 0;
     for (size_t gi = 0; gi < e->groups.size(); ++gi) {
@@ -1536,6 +1556,7 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   // matrix-pipe work is attached per launch (launch_group / the inspection run); r^2 launches stay on the popcount kernels
   A.mf_wgs = nullptr;
   A.n_mf_wgs = 0;
+  A.mf_diag_ct = 0;
   A.n_local = e->local_ct;
   A.mf_active = 0;
   A.route = nullptr;
@@ -1611,6 +1632,7 @@ int launch_group(ldp_engine* e, uint32_t gi) {
     A.route = e->d_route + gi;
     A.mf_wgs = e->d_mf_wgs + g.mf_first;
     A.n_mf_wgs = g.mf_ct;
+    A.mf_diag_ct = g.mf_diag_ct;
     A.wd_tiles = e->d_wd_tiles + g.wd_first;
     A.n_wd_tiles = g.wd_ct;
     A.wd_active = e->wd_tiles.empty() ? 0u : 1u;
@@ -1728,9 +1750,18 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
       return hipfail(e, krc, "pair_tiles_kernel launch");
     }
     if (e->mf_enabled) {
-      krc = launch_pair_mfma(A, e->stream, evk + 4);
-      if (krc != hipSuccess) {
-        return hipfail(e, krc, "pair_mfma_kernel launch");
+      // group by group (each group's workgroups are ordered [all-diagonal | others] for the two instantiations), one route
+      for (const ldp_engine::PairGroup& g : e->groups) {
+        PairKernelArgs G = A;
+        G.mf_wgs = e->d_mf_wgs + g.mf_first;
+        G.n_mf_wgs = g.mf_ct;
+        G.mf_diag_ct = g.mf_diag_ct;
+        G.wd_tiles = e->d_wd_tiles + g.wd_first;
+        G.n_wd_tiles = g.wd_ct;
+        krc = launch_pair_mfma(G, e->stream, evk + 4);
+        if (krc != hipSuccess) {
+          return hipfail(e, krc, "pair_mfma_kernel launch");
+        }
       }
     }
     if (e->pred_words) {
@@ -2141,6 +2172,7 @@ int attach_mfma_plan(ldp_engine* e, PairKernelArgs* A, const std::vector<std::pa
   if (wgs.empty()) {
     return LDP_OK;
   }
+  A->mf_diag_ct = partition_diag(&wgs, 0, wgs.size());
   HIP_TRY(e, hipMalloc(&buf->p, wgs.size() * sizeof(MfmaWG)));
   HIP_TRY(e, hipMemcpy(buf->p, wgs.data(), wgs.size() * sizeof(MfmaWG), hipMemcpyHostToDevice));
   const size_t slot = e->groups.size();  // (the route slot of launches outside the launch groups)
@@ -2587,6 +2619,135 @@ int ldp_set_shard(ldp_engine* e, uint32_t rank, uint32_t world, uint32_t* owner)
   e->world = world;
   build_shard(e);
   e->ctr.owned_subcontig_ct = static_cast<uint32_t>(e->owned.size());
+  return LDP_OK;
+}
+
+// ---- the one exchange step of a multi-GPU prune, from the C/C++ host: RCCL, bound at run time -----------------------
+// (dlopen: the library also has to load where no RCCL is installed, and inside a process that brought its own copy)
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+const Rccl& rccl() {
+  static const Rccl R = []() {
+    Rccl r;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) {
+        break;
+      }
+    }
+    if (r.lib) {
+      r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+      r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
+      r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.lib, "ncclCommUserRank"));
+      r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
+      r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+      r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+      r.ok = r.AllGather && r.CommCount && r.CommUserRank && r.CommInitAll && r.CommDestroy;
+    }
+    return r;
+  }();
+  return R;
+}
+}  // namespace
+
+int ldp_comm_init_all(int n, const int* devices, void** comms) {
+  if ((n < 1) || !comms) {
+    return LDP_ERR_INVALID;
+  }
+  const Rccl& R = rccl();
+  if (!R.ok) {
+    return LDP_ERR_UNSUPPORTED;
+  }
+  std::vector<ncclComm_t> c(n, nullptr);
+  if (R.CommInitAll(c.data(), n, devices) != ncclSuccess) {
+    return LDP_ERR_GPU;
+  }
+  for (int k = 0; k < n; ++k) {
+    comms[k] = c[k];
+  }
+  return LDP_OK;
+}
+
+void ldp_comm_destroy(void* comm) {
+  if (comm && rccl().ok) {
+    (void)rccl().CommDestroy(static_cast<ncclComm_t>(comm));
+  }
+}
+
+int ldp_allgather_removed(ldp_engine* e, void* comm, const uint64_t* removed_local, uint64_t* removed_global) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  if (!e->planned || e->matrix_mode || e->band_r2_mode) {
+    return fail(e, LDP_ERR_STATE, "ldp_set_variants() (+ ldp_set_shard) first");
+  }
+  if (!comm || !removed_local || !removed_global) {
+    return fail(e, LDP_ERR_INVALID, "null argument");
+  }
+  const Rccl& R = rccl();
+  if (!R.ok) {
+    return fail(e, LDP_ERR_UNSUPPORTED, "RCCL (librccl.so.1) is not available");
+  }
+  bind_gpu(e);
+  if (!e->gpu_ok) {
+    return fail(e, LDP_ERR_GPU, "no usable HIP device");
+  }
+  ncclComm_t c = static_cast<ncclComm_t>(comm);
+  int count = 0, urank = -1;
+  if ((R.CommCount(c, &count) != ncclSuccess) || (R.CommUserRank(c, &urank) != ncclSuccess)) {
+    return fail(e, LDP_ERR_GPU, "ncclCommCount / ncclCommUserRank failed");
+  }
+  if ((static_cast<uint32_t>(count) != e->world) || (static_cast<uint32_t>(urank) != e->rank)) {
+    return fail(e, LDP_ERR_INVALID, "the communicator's size / rank differ from ldp_set_shard()'s");
+  }
+  // every rank knows every rank's segment: the owned subcontigs in file order (the LPT assignment is deterministic)
+  std::vector<uint64_t> seg_bits(e->world, 0);
+  for (const Subcontig& s : e->subs) {
+    seg_bits[s.owner] += s.len;
+  }
+  const uint64_t words = std::max<uint64_t>((*std::max_element(seg_bits.begin(), seg_bits.end()) + 63) / 64, 1);  // the longest segment: a padded all-gather is the allgatherv
+  std::vector<uint64_t> mine(words, 0);
+  for (uint32_t l = 0; l < e->local_ct; ++l) {
+    const uint32_t g = e->local_to_global[l];
+    if ((removed_local[g >> 6] >> (g & 63)) & 1ull) {
+      mine[l >> 6] |= 1ull << (l & 63);
+    }
+  }
+  HIP_TRY(e, hipSetDevice(e->device));
+  DevBuf send, recv;
+  HIP_TRY(e, hipMalloc(&send.p, words * sizeof(uint64_t)));
+  HIP_TRY(e, hipMalloc(&recv.p, words * sizeof(uint64_t) * e->world));
+  HIP_TRY(e, hipMemcpyAsync(send.p, mine.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+  const ncclResult_t nrc = R.AllGather(send.p, recv.p, words, ncclUint64, c, e->stream);
+  if (nrc != ncclSuccess) {
+    return fail(e, LDP_ERR_GPU, std::string("ncclAllGather: ") + (R.GetErrorString ? R.GetErrorString(nrc) : "failed"));
+  }
+  std::vector<uint64_t> all(words * e->world);
+  HIP_TRY(e, hipMemcpyAsync(all.data(), recv.p, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  // the stitch (plink2_ld.cc:1418-1426, CopyBitarrRange per thread): segment bits -> global variant order
+  const size_t gwords = (static_cast<size_t>(e->variant_ct) + 63) / 64;
+  std::fill(removed_global, removed_global + gwords, 0ull);
+  std::vector<uint64_t> pos(e->world, 0);
+  for (const Subcontig& s : e->subs) {
+    const uint64_t* seg = all.data() + static_cast<size_t>(s.owner) * words;
+    uint64_t& p = pos[s.owner];
+    for (uint32_t v = 0; v < s.len; ++v, ++p) {
+      if ((seg[p >> 6] >> (p & 63)) & 1ull) {
+        const uint32_t g = s.first + v;
+        removed_global[g >> 6] |= 1ull << (g & 63);
+      }
+    }
+  }
   return LDP_OK;
 }
 
@@ -3136,7 +3297,7 @@ int ldp_debug_mfma_plan(const ldp_engine* e, uint32_t* wg_count, uint32_t* words
     return LDP_ERR_INVALID;
   }
   for (const MfmaWG& wg : e->mf_wgs) {
-    *words++ = wg.n_rb | (wg.pad ? 0x80000000u : 0u);  // (bit 31: the subcontig also has the wide plan)
+    *words++ = wg.n_rb | ((wg.pad & 1u) ? 0x80000000u : 0u) | ((wg.pad & 2u) ? 0x40000000u : 0u);  // (bit 31: the subcontig also has the wide plan; bit 30: all-diagonal)
     *words++ = wg.j_lo;
     *words++ = wg.j_hi;
     for (uint32_t k = 0; k < kMfMaxRowBlocks; ++k) {

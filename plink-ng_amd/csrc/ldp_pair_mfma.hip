@@ -119,6 +119,60 @@ __device__ __forceinline__ void mfma_stage(const mf_u4* __restrict__ st4, const 
 #undef LDP_MF_VBLOCK
 }
 
+// The stage of a DIAGONAL wave item (V3 = J0, V4 = J1: every wave item of a band narrower than four row-blocks, i.e. all of
+// BASELINE config 2) in ONE form: five row-block reads issued together, five expansions, all eight products, no test, no branch.
+// The masked form above reads a block, waits, expands and multiplies, block after block, behind a branch each -- with two waves
+// per SIMD the LDS latencies and the accumulator copies at the branches add up to most of a stage (profiles/r03_experiments.md).
+// Here a wave computes all eight products while one of them is live and nothing once none is; products that hold no candidate
+// pair accumulate numbers nobody reads (their row-blocks may not even be staged: the read then hits some other block's rows).
+// MFMAs on one accumulator never follow each other directly: V0's single product alternates with V4's.
+template <int KS>
+__device__ __forceinline__ void mfma_stage_diag(const mf_u4* __restrict__ st4, const uint32_t (&slot_off)[7], uint32_t oH, uint32_t oR, mf_v16f (&acc)[8]) {
+  mf_u4 jH0 = st4[slot_off[0] + oH], jR0 = st4[slot_off[0] + oR];
+  mf_u4 jH1 = st4[slot_off[1] + oH], jR1 = st4[slot_off[1] + oR];
+  mf_u4 vH0 = st4[slot_off[2] + oH], vR0 = st4[slot_off[2] + oR];
+  mf_u4 vH1 = st4[slot_off[3] + oH], vR1 = st4[slot_off[3] + oR];
+  mf_u4 vH2 = st4[slot_off[4] + oH], vR2 = st4[slot_off[4] + oR];
+  opaque(jH0, jR0);
+  opaque(jH1, jR1);
+  Frag fj0[KS], fj1[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    fp4_of_codes(jH0[ks], jR0[ks], fj0[ks]);
+    fp4_of_codes(jH1[ks], jR1[ks], fj1[ks]);
+  }
+  // rows of C = first variant (A operand: a V block), columns = second variant (B operand: a J block)
+  opaque(vH0, vR0);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    Frag fv;
+    fp4_of_codes(vH0[ks], vR0[ks], fv);
+    acc[0] = mfma_fp4(fv, fj0[ks], acc[0]);           // (J0, V0)
+    acc[7] = mfma_fp4(fj1[ks], fj1[ks], acc[7]);      // (J1, V4 = J1)
+  }
+  opaque(vH1, vR1);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    Frag fv;
+    fp4_of_codes(vH1[ks], vR1[ks], fv);
+    acc[1] = mfma_fp4(fv, fj0[ks], acc[1]);           // (J0, V1)
+    acc[4] = mfma_fp4(fv, fj1[ks], acc[4]);           // (J1, V1)
+  }
+  opaque(vH2, vR2);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    Frag fv;
+    fp4_of_codes(vH2[ks], vR2[ks], fv);
+    acc[2] = mfma_fp4(fv, fj0[ks], acc[2]);           // (J0, V2)
+    acc[5] = mfma_fp4(fv, fj1[ks], acc[5]);           // (J1, V2)
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    acc[3] = mfma_fp4(fj0[ks], fj0[ks], acc[3]);      // (J0, V3 = J0)
+    acc[6] = mfma_fp4(fj0[ks], fj1[ks], acc[6]);      // (J1, V3 = J0)
+  }
+}
+
 // Row-blocks whose LDS rows the live products of a wave read: bit u of the result = J0, J1, V0..V4 (on the diagonal V3 /
 // V4 are J0 / J1 and are not read a second time)
 __device__ __forceinline__ uint32_t blocks_needed(uint32_t live, bool diag) {
@@ -303,7 +357,10 @@ __device__ __forceinline__ uint32_t sparse_round(const PairKernelArgs& A, const 
 // inside it hipcc re-allocates the complete-data kernel's registers and spills inside the stage loop (inlined), or keeps
 // half of them in scratch across the call (out of line).  Both instantiations are launched; the one the data does not
 // call for leaves at once.
-template <int KS, bool SPARSE>
+// DIAGFORM: the instantiation that takes the workgroups whose wave items are all diagonal (MfmaWG::pad bit 1), with the single
+// branch-free stage loop of mfma_stage_diag and early termination by whole waves; the other instantiation keeps the general
+// forms for everything else.  Separate kernels because a third loop form in one kernel sends hipcc into hundreds of spills.
+template <int KS, bool SPARSE, bool DIAGFORM>
 __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelArgs A) {
   using G = StageGeom<KS>;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -319,8 +376,14 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
     return;
   }
   const MfmaWG* __restrict__ wg = A.mf_wgs + item_idx;
-  if ((!SPARSE) && A.wd_active && wg->pad) {
-    return;  // a subcontig with a wide band: its complete-data launches belong to pair_mfma_wide_kernel's tiles (ldp_pair_wide.hip)
+  {
+    const uint32_t kind = wg->pad;
+    if ((!SPARSE) && A.wd_active && (kind & 1u)) {
+      return;  // a subcontig with a wide band: its complete-data launches belong to pair_mfma_wide_kernel's tiles (ldp_pair_wide.hip)
+    }
+    if (((kind & 2u) != 0) != DIAGFORM) {
+      return;  // the other instantiation's workgroup
+    }
   }
   const uint32_t tid = threadIdx.x;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -369,6 +432,8 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
     slot_off[u] = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wi->slot[u])) * G::kBlockSlots;
   }
   uint32_t need = blocks_needed(live, diag);
+  const uint32_t live0 = live, need0 = need;  // (DIAGFORM: the plan's products; a wave runs all of them until none is live)
+  uint32_t stop_stage = 0xffffffffu;         // (DIAGFORM: the stage at which the wave stopped computing)
   // window starts of this lane's two second variants (J0 + r, J1 + r), fetched here: the k-loop must not hold ordinary
   // global loads (see the checkpoint)
   uint32_t lo_j2[2] = {0xffffffffu, 0xffffffffu};  // (lo >= j: no candidate pair)
@@ -477,7 +542,21 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   };
   for (uint32_t kc = 0; kc < n_stages;) {
     const uint32_t kc_end = issue_limit;  // the next checkpoint (or the end of the rows)
-    if ((live == 0xffu) && !diag) {
+    if constexpr (DIAGFORM) {
+      for (uint32_t k2 = kc; k2 < kc_end; ++k2) {
+        wait_dma_then_barrier(mine * (issued - k2 - 1));
+        if (issued < issue_limit) {
+          dma_stage(issued, issue_buf);  // (reuses the buffer every wave finished reading before the barrier)
+          ++issued;
+          issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
+        }
+        const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * stage_dwords);
+        read_buf = (read_buf + 1 == stages) ? 0 : read_buf + 1;
+        if (live) {
+          mfma_stage_diag<KS>(st4, slot_off, oH, oR, acc);
+        }
+      }
+    } else if ((live == 0xffu) && !diag) {
       run_segment(std::true_type(), kc, kc_end);
     } else {
       run_segment(std::false_type(), kc, kc_end);
@@ -564,11 +643,19 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
       }
       keep = __builtin_amdgcn_readfirstlane(keep);
       if (keep != live) {
-        if (lane == 0) {
-          atomicAdd(A.counters + 2, static_cast<unsigned long long>(n_stages - kc) * KS * __builtin_popcount(live & ~keep));
+        if constexpr (DIAGFORM) {
+          live = keep;
+          need = live ? need0 : 0u;  // (the single-form loop reads all of the wave's planned blocks while it runs at all)
+          if (!live) {
+            stop_stage = kc;
+          }
+        } else {
+          if (lane == 0) {
+            atomicAdd(A.counters + 2, static_cast<unsigned long long>(n_stages - kc) * KS * __builtin_popcount(live & ~keep));
+          }
+          live = keep;
+          need = blocks_needed(live, diag);
         }
-        live = keep;
-        need = blocks_needed(live, diag);
       }
     }
     ++next_cp;
@@ -599,6 +686,20 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
     }
   }
   __syncthreads();  // staging is over: LDS becomes the epilogue's scratch (a private region per wave)
+  if constexpr (DIAGFORM) {
+    if ((lane == 0) && live0) {
+      // bookkeeping in product x k-step units (one MFMA each): what early termination saved of the plan's products, and what
+      // the single-form loop computed beyond the plan (products of the wave item that hold no candidate pair)
+      const uint32_t planned = __builtin_popcount(live0);
+      const uint32_t ran = (stop_stage < n_stages) ? stop_stage : n_stages;
+      if (ran < n_stages) {
+        atomicAdd(A.counters + 2, static_cast<unsigned long long>(n_stages - ran) * KS * planned);
+      }
+      if (planned < 8) {
+        atomicAdd(A.counters + 1, static_cast<unsigned long long>(ran) * KS * (8 - planned));
+      }
+    }
+  }
 
   // ---- epilogue: accumulators through LDS so the per-pair code is a rolled loop ----
   // lane l, register g of a product holds first variant (g & 3) + 8 (g >> 2) + 4 (l >> 5) of the V block, second variant
@@ -875,16 +976,28 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
     if (const char* kb = getenv("LDP_DEBUG_MFMA_LDS_KB")) {
       bytes = std::max<size_t>(bytes, std::min<size_t>(static_cast<size_t>(atoi(kb)), 150) * 1024);
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<4, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<4, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
     return bytes;
   }();
   a.lds_dwords = static_cast<uint32_t>(lds / sizeof(uint32_t));
-  const uint32_t per_xcd = (a.n_mf_wgs + 7) / 8;
   if (ev) {
     (void)hipEventRecord(ev[0], stream);
   }
-  hipLaunchKernelGGL((pair_mfma_kernel<4, false>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
+  // the workgroups of the launch in two runs: [0, mf_diag_ct) all-diagonal ones (single-form kernel), the rest (general forms)
+  const uint32_t n_diag = a_in.mf_diag_ct, n_rest = a_in.n_mf_wgs - a_in.mf_diag_ct;
+  PairKernelArgs ad = a, ar = a;
+  ad.n_mf_wgs = n_diag;
+  ar.mf_wgs = a.mf_wgs + n_diag;
+  ar.n_mf_wgs = n_rest;
+  if (n_diag) {
+    hipLaunchKernelGGL((pair_mfma_kernel<4, false, true>), dim3(((n_diag + 7) / 8) * 8), dim3(kMfWaves * 64), lds, stream, ad);
+  }
+  if (n_rest) {
+    hipLaunchKernelGGL((pair_mfma_kernel<4, false, false>), dim3(((n_rest + 7) / 8) * 8), dim3(kMfWaves * 64), lds, stream, ar);
+  }
   if (a.wd_active) {
     const hipError_t wrc = launch_pair_wide(a_in, stream);  // the wide-band subcontigs of the same launch (complete data)
     if (wrc != hipSuccess) {
@@ -892,7 +1005,12 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
     }
   }
   if (a.sparse_ok) {
-    hipLaunchKernelGGL((pair_mfma_kernel<4, true>), dim3(per_xcd * 8), dim3(kMfWaves * 64), lds, stream, a);
+    if (n_diag) {
+      hipLaunchKernelGGL((pair_mfma_kernel<4, true, true>), dim3(((n_diag + 7) / 8) * 8), dim3(kMfWaves * 64), lds, stream, ad);
+    }
+    if (n_rest) {
+      hipLaunchKernelGGL((pair_mfma_kernel<4, true, false>), dim3(((n_rest + 7) / 8) * 8), dim3(kMfWaves * 64), lds, stream, ar);
+    }
   }
   if (ev) {
     (void)hipEventRecord(ev[1], stream);

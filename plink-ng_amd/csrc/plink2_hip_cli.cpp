@@ -5200,6 +5200,21 @@ int run_prune(Session& S) {
       const size_t m_words = (static_cast<size_t>(m_ct) + 63) / 64 + 1;
       std::vector<std::vector<uint64_t>> part(world, std::vector<uint64_t>(m_words, 0));
       std::vector<int> rcs(world, 0);
+      // several devices: the shards' results meet in ONE RCCL all-gather of their removed-bit segments (ldp_allgather_removed:
+      // the cross-device form of the stitch at plink2_ld.cc:1418-1426); without RCCL the host ORs the bitmaps
+      std::vector<void*> comms(world, nullptr);
+      std::vector<std::vector<uint64_t>> full;
+      bool use_rccl = false;
+      if (world > 1) {
+        std::vector<int> devs(world);
+        for (int r = 0; r < world; ++r) {
+          devs[r] = r;
+        }
+        use_rccl = (ldp_comm_init_all(world, devs.data(), comms.data()) == 0);
+        if (use_rccl) {
+          full.assign(world, std::vector<uint64_t>(m_words, 0));
+        }
+      }
       std::vector<std::thread> th;
       for (int r = 0; r < world; ++r) {
         th.emplace_back([&, r]() {
@@ -5207,16 +5222,33 @@ int run_prune(Session& S) {
             ldp_set_preferred(eng[r], pref_m.data());
           }
           rcs[r] = ldp_run(eng[r], part[r].data());
+          if (use_rccl) {
+            // (every rank enters the collective, also one whose run failed: the others would wait for it forever otherwise)
+            const int arc = ldp_allgather_removed(eng[r], comms[r], part[r].data(), full[r].data());
+            if (!rcs[r]) {
+              rcs[r] = arc;
+            }
+          }
         });
       }
       for (std::thread& t : th) {
         t.join();
       }
       for (int r = 0; r < world; ++r) {
+        if (comms[r]) {
+          ldp_comm_destroy(comms[r]);
+        }
+      }
+      for (int r = 0; r < world; ++r) {
         if (rcs[r]) {
           die(16, "\nError: %s\n", ldp_last_error(eng[r]));
         }
-        scatter(part[r], mk);
+        if (!use_rccl) {
+          scatter(part[r], mk);
+        }
+      }
+      if (use_rccl) {
+        scatter(full[0], mk);  // (every rank holds the same global bitmap)
       }
       t_run1 = now_s();
     }

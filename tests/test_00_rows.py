@@ -107,6 +107,15 @@ def test_matrix_pipe_exactness_limit(gpu_pkg):
     P.test_sample_counts_around_the_matrix_pipe_limit(gpu_pkg, 257, 0.01)
 
 
+def test_row_e_rccl_allgather_from_the_c_abi(gpu_pkg):
+    P.test_rccl_allgather_from_the_c_abi_with_one_rank(gpu_pkg)
+
+
+def test_row_a12_wide_band_tiles(gpu_pkg):
+    """config 3's band shape (a window of many row-blocks): the 8 x 8 tile kernel against the oracle"""
+    P.test_wide_band_tiles_match_oracle(gpu_pkg, P.WIDE_CASES[0])
+
+
 def test_row_e_bench_step_under_torchrun(gpu_pkg, tmp_path):
     """One rank under torch.distributed.run: RCCL is initialised and the bitmap exchange runs (an identity at one rank)."""
     import test_config3_parity as C3

@@ -314,7 +314,7 @@ WIDE_CASES = [
     # m, n, seed, window, step, is_bp, r2, order, min_reach
     (900, 300, 1, 500, 1, False, 0.2, 2, 12),       # 16 row-blocks of reach: the tile plan by itself
     (1300, 3000, 2, 400, 7, False, 0.5, 2, 12),     # count window with a step, two subcontigs
-    (1000, 1100, 3, 90000, 1, True, 0.3, 1, 12),    # kb windows with gaps: subcontigs of every length, some wide
+    (1000, 1100, 3, 150000, 1, True, 0.3, 1, 6),    # kb windows with gaps: subcontigs of every length, some wide by this measure
     (700, 70, 4, 50, 5, False, 0.2, 2, 0),          # a narrow band forced through the tiles (diagonal tiles only)
     (520, 513, 5, 519, 1, False, 0.1, 2, 0),        # one window spans everything: three J tiles, the last one ragged
     (257, 40, 6, 256, 1, False, 0.4, 2, 0),         # a J tile of one variant
@@ -383,6 +383,41 @@ def test_wide_band_with_missing_calls_falls_back_to_the_parallelogram_kernels(gp
         eng.close()
         assert c["wide_tiles"] > 0 and c[route] > 0 and c["route_complete_launches"] == 0
         assert np.array_equal(got, want)
+
+
+def test_rccl_allgather_from_the_c_abi_with_one_rank(gpu_pkg):
+    """ldp_allgather_removed: the one exchange step of a multi-GPU prune driven from a C/C++ host -- segments in shard order,
+    ONE ncclAllGather on device buffers, stitched into global variant order.  One rank here (the box has one GPU): RCCL is
+    bound and initialised, the collective runs, and the result is the rank's own bitmap.  (The two-rank stitch is covered on
+    the CPU: tests/test_distributed_gloo.py.)"""
+    pkg = gpu_pkg
+    m, n = 900, 200
+    raw = T.synth_raw_codes(m, n, seed=5, missing_rate=0.01)
+    chr_idx, bps = make_positions(m, 5, 3)
+    eng = pkg.LdPruneEngine(n, 20000, 1, True, 0.2, device=0)
+    eng.set_variants(chr_idx, bps)
+    eng.set_shard(0, 1)
+    eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+    words = eng.run_bitmap()
+    comm = pkg.comm_init_all([0])[0]
+    try:
+        out = eng.allgather_removed(comm, words)
+    finally:
+        pkg.comm_destroy(comm)
+    nw = (m + 63) // 64
+    assert np.array_equal(out[:nw], words[:nw]) and int(np.unpackbits(words[:nw].view(np.uint8)).sum()) > 50
+    # a communicator whose size does not match the shard is refused
+    eng2 = pkg.LdPruneEngine(n, 20000, 1, True, 0.2, device=0)
+    eng2.set_variants(chr_idx, bps)
+    eng2.set_shard(1, 2)
+    comm = pkg.comm_init_all([0])[0]
+    try:
+        with pytest.raises(pkg.LdpError):
+            eng2.allgather_removed(comm, words)
+    finally:
+        pkg.comm_destroy(comm)
+    eng.close()
+    eng2.close()
 
 
 def test_device_pointer_input(gpu_pkg):

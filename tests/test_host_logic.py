@@ -244,7 +244,8 @@ def _mfma_plan_coverage(pkg, m, nchr, seed, window, step, is_bp, spacing, rank=0
     count = np.zeros(int(pair_off[-1]), dtype=np.int32)
     prev_hi = 0
     for wg in wgs:
-        n_rb, j_lo, j_hi = int(wg[0]) & 0x7fffffff, int(wg[1]), int(wg[2])
+        n_rb, j_lo, j_hi = int(wg[0]) & 0x3fffffff, int(wg[1]), int(wg[2])
+        all_diag = bool((int(wg[0]) >> 30) & 1)
         rb = wg[3:19].astype(np.int64)
         assert 1 <= n_rb <= 16
         assert np.all(np.diff(rb[:n_rb]) > 0)
@@ -259,6 +260,7 @@ def _mfma_plan_coverage(pkg, m, nchr, seed, window, step, is_bp, spacing, rank=0
                 continue
             assert mask != 0 and j_lo <= jv < jend <= j_hi
             diag = (vv + 96 == jv)
+            assert diag or not all_diag   # (the single-form kernel's workgroups hold diagonal wave items only)
             if diag:  # the kernel reads V3 / V4 through the J0 / J1 slots there
                 assert (not mask & 0x48) or rb[slot[0]] == jv
                 assert (not mask & 0x80) or rb[slot[1]] == jv + 32

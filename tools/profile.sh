@@ -4,7 +4,7 @@
 # MI355X_MICROARCH.md prescribes), and writes the raw CSVs under gpurun_out/prof_<tag>/ plus the summaries
 # tools/summarize_prof.py derives under gpurun_out/profiles_<tag>/ (copy those into profiles/).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT

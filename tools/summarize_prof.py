@@ -2,7 +2,7 @@
 """Condense the rocprofv3 CSVs tools/profile.sh collected into the small files kept under profiles/:
   <tag>_kernel_stats.csv   per-kernel calls / total / average / min / max duration (from kernel_trace)
   <tag>_pmc.json           per-kernel mean counter values (one dispatch = one launch)
-  pmc_traffic.json         HBM bytes per pair_tiles_kernel launch, read by bench.py as roofline.traffic
+  <tag>_pmc_traffic.json   HBM bytes per step of the pair kernels, read by bench.py as roofline.traffic
 HBM bytes follow MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 reports half of the bytes of a wide coalesced streaming read, so the read side is doubled."""
 import collections
@@ -40,23 +40,28 @@ def main():
     samples = int(os.environ.get("LDP_PROF_SAMPLES", "50000"))
     variants = int(os.environ.get("LDP_PROF_VARIANTS", "1000000"))
     window_kb = float(os.environ.get("LDP_PROF_WINDOW_KB", "200"))
-    best = None
+    missing_rate = float(os.environ.get("LDP_PROF_MISSING", "0"))
+    # every pair kernel that did work in the step (a launch can carry the wide-band tiles AND the parallelogram workgroups)
+    per_kernel, total_b, total_read, total_write = {}, 0.0, 0.0, 0.0
     for k, cs in out.items():
-        if (("pair_mfma_kernel" in k) or ("pair_mfma_general_kernel" in k) or ("pair_tiles_kernel" in k)) and "FETCH_SIZE" in cs:
-            # the pair kernel that did the work of this run = the one that fetched the most
-            if (best is None) or (cs["FETCH_SIZE"] > out[best]["FETCH_SIZE"]):
-                best = k
-    if best:
-        cs = out[best]
-        read_b = cs["FETCH_SIZE"] * 1024 * 2
-        write_b = cs.get("WRITE_SIZE", 0.0) * 1024
-        short = best.split("(")[0].replace("void ", "").replace("ldp::", "")
-        json.dump({"kernel": short, "samples": samples, "variants": variants, "window_kb": window_kb,
-                   "hbm_bytes_per_launch": read_b + write_b, "launches_per_step": n_disp[best],
-                   "hbm_bytes_per_step": (read_b + write_b) * n_disp[best],
-                   "fetch_size_kib": cs["FETCH_SIZE"], "write_size_kib": cs.get("WRITE_SIZE"),
-                   "note": "FETCH_SIZE x 1024 x 2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE x 1024",
-                   "tag": tag}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+        if (("pair_mfma" in k) or ("pair_tiles_kernel" in k)) and "FETCH_SIZE" in cs:
+            read_b = cs["FETCH_SIZE"] * 1024 * 2 * n_disp[k]
+            write_b = cs.get("WRITE_SIZE", 0.0) * 1024 * n_disp[k]
+            short = k.split("(")[0].replace("void ", "").replace("ldp::", "").replace("(anonymous namespace)::", "")
+            per_kernel[short] = {"launches_per_step": n_disp[k], "hbm_read_bytes_per_step": read_b, "hbm_write_bytes_per_step": write_b,
+                                 "l2_hit_rate": (cs["TCC_HIT_sum"] / (cs["TCC_HIT_sum"] + cs["TCC_MISS_sum"])) if cs.get("TCC_HIT_sum") is not None and (cs.get("TCC_HIT_sum", 0) + cs.get("TCC_MISS_sum", 0)) > 0 else None}
+            total_b += read_b + write_b
+            total_read += read_b
+            total_write += write_b
+    if per_kernel:
+        main_kernel = max(per_kernel, key=lambda k: per_kernel[k]["hbm_read_bytes_per_step"])
+        rows_bytes = ((samples + 255) // 256) * 64
+        json.dump({"kernel": main_kernel, "samples": samples, "variants": variants, "window_kb": window_kb, "missing_rate": missing_rate,
+                   "hbm_bytes_per_step": total_b, "hbm_read_bytes_per_step": total_read, "hbm_write_bytes_per_step": total_write,
+                   "compulsory_bytes_per_step": float(variants) * rows_bytes, "traffic_over_compulsory": total_b / (float(variants) * rows_bytes),
+                   "pair_kernels": per_kernel,
+                   "note": "sum over the pair kernels of the step of FETCH_SIZE x 1024 x 2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE x 1024",
+                   "tag": tag}, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
     print(open(os.path.join(dst, tag + "_kernel_stats.csv")).read())
 
 
