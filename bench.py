@@ -235,7 +235,7 @@ class Workload:
         self.owner = planner.set_shard(rank, world) if world > 1 else np.zeros(len(self.subs), dtype=np.uint32)
         self.owned = [(ln, first) for (ln, first), o in zip(self.subs, self.owner) if o == rank]
         self.local_ct = sum(ln for ln, _ in self.owned)
-        row_bytes = ((self.founder_ct + 255) // 256) * 64
+        row_bytes = ((self.founder_ct + 511) // 512) * 128
         self.image_bytes = self.local_ct * row_bytes
         self.resident = self.image_bytes * 1.06 + 6e9 < HBM_BYTES
         self.engines = []
@@ -333,7 +333,7 @@ def pair_roofline(c, founder_ct, local_ct, missing_rate, variants, window_kb):
     executed = (max(c["mfma_product_stages"] - c["mfma_skipped_product_stages"], 0) + c["mfma_extra_product_stages"]) * (6 if general else 1)
     mfma_tflops = (executed * 65536 * 2.0 / (kms * 1e-3)) / 1e12 if (kms > 0 and on_matrix_pipe) else 0.0
     # HBM side: every owned row must be read once (N/4 bytes per variant, rows padded to 64 bytes)
-    compulsory = local_ct * ((founder_ct + 255) // 256) * 64.0
+    compulsory = local_ct * ((founder_ct + 511) // 512) * 128.0
     hbm_gbs = (compulsory / (kms * 1e-3)) / 1e9 if kms > 0 else 0.0
     traffic, traffic_src, tj = pmc_traffic(founder_ct, variants, window_kb, missing_rate)
     mfma_frac, hbm_frac = mfma_tflops / FP4_PEAK_TFLOPS, hbm_gbs / HBM_PEAK_GBS

@@ -29,7 +29,8 @@ constexpr int kLdsRowDwords = kRowChunkDwords + 4; // 36: odd number (9) of 16-B
 // already are REF- / INVERSE-coded in the engine's image (ldp_map_rows) are counted in place, nothing is rewritten.
 constexpr uint32_t kCodeStageSamples = 256;
 constexpr uint32_t kCodeStageBytes = kCodeStageSamples / 4;  // 64
-inline uint64_t code_row_bytes_of(uint32_t founder_ct) { return static_cast<uint64_t>((founder_ct + kCodeStageSamples - 1) / kCodeStageSamples) * kCodeStageBytes; }
+// (rows are whole 512-sample k-chunks long -- 128 bytes, a cache line -- so that the wide-band kernel's stages never straddle a row end)
+inline uint64_t code_row_bytes_of(uint32_t founder_ct) { return static_cast<uint64_t>((founder_ct + 511) / 512) * 128; }
 
 // ---- pair-tile geometry -------------------------------------------------------------------------
 // A block owns kTileJ consecutive "second" variants j and a run of distances d = j - i in units of 8.  Wave w owns
@@ -114,7 +115,6 @@ struct MfmaWG {
 constexpr int kWdWaves = 8;
 constexpr int kWdTile = 8;                       // row-blocks per tile side
 constexpr int kWdRowBlocks = 2 * kWdTile;        // staged row-blocks: slots 0..7 the J blocks, 8..15 the V blocks
-constexpr int kWdDmaPerWave = (2 * kWdRowBlocks) / kWdWaves;  // 256-sample stages: two DMA instructions of 64 slots per row-block
 constexpr uint32_t kWdMinReach = 12;             // a subcontig whose band reaches this many row-blocks takes the wide plan
 struct MfmaTile {
   int32_t jv;        // first variant of J block 0 (J block a = jv + 32 a)

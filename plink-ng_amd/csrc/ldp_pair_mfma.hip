@@ -173,6 +173,32 @@ __device__ __forceinline__ void mfma_stage_diag(const mf_u4* __restrict__ st4, c
   }
 }
 
+// ... and once the four FAR products of a diagonal wave item -- (J0, V0) (J0, V1) (J1, V1) (J1, V2): block distances 2 and 3 -- are
+// provably below the threshold (on real data they are the first to go: LD decays with distance), the NEAR half alone:
+// (J0, V2) (J0, J0) (J1, J0) (J1, J1), three row-block reads and sixteen MFMAs per stage instead of five and thirty-two, and the
+// workgroup stops fetching V0 / V1 blocks nobody reads any more.
+constexpr uint32_t kDiagFar = 0x33u, kDiagNear = 0xccu;
+template <int KS>
+__device__ __forceinline__ void mfma_stage_near(const mf_u4* __restrict__ st4, const uint32_t (&slot_off)[7], uint32_t oH, uint32_t oR, mf_v16f (&acc)[8]) {
+  mf_u4 jH0 = st4[slot_off[0] + oH], jR0 = st4[slot_off[0] + oR];
+  mf_u4 jH1 = st4[slot_off[1] + oH], jR1 = st4[slot_off[1] + oR];
+  mf_u4 vH2 = st4[slot_off[4] + oH], vR2 = st4[slot_off[4] + oR];
+  opaque(jH0, jR0);
+  opaque(jH1, jR1);
+  opaque(vH2, vR2);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    Frag f0, f1, fv;
+    fp4_of_codes(jH0[ks], jR0[ks], f0);
+    fp4_of_codes(jH1[ks], jR1[ks], f1);
+    fp4_of_codes(vH2[ks], vR2[ks], fv);
+    acc[2] = mfma_fp4(fv, f0, acc[2]);   // (J0, V2)
+    acc[3] = mfma_fp4(f0, f0, acc[3]);   // (J0, V3 = J0)
+    acc[6] = mfma_fp4(f0, f1, acc[6]);   // (J1, V3 = J0)
+    acc[7] = mfma_fp4(f1, f1, acc[7]);   // (J1, V4 = J1)
+  }
+}
+
 // Row-blocks whose LDS rows the live products of a wave read: bit u of the result = J0, J1, V0..V4 (on the diagonal V3 /
 // V4 are J0 / J1 and are not read a second time)
 __device__ __forceinline__ uint32_t blocks_needed(uint32_t live, bool diag) {
@@ -433,7 +459,8 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   }
   uint32_t need = blocks_needed(live, diag);
   const uint32_t live0 = live, need0 = need;  // (DIAGFORM: the plan's products; a wave runs all of them until none is live)
-  uint32_t stop_stage = 0xffffffffu;         // (DIAGFORM: the stage at which the wave stopped computing)
+  uint32_t stop_stage = 0xffffffffu;         // (DIAGFORM: the stage at which the wave stopped computing ...
+  uint32_t far_stop = 0xffffffffu;           //  ... and the one at which it dropped its FAR products)
   // window starts of this lane's two second variants (J0 + r, J1 + r), fetched here: the k-loop must not hold ordinary
   // global loads (see the checkpoint)
   uint32_t lo_j2[2] = {0xffffffffu, 0xffffffffu};  // (lo >= j: no candidate pair)
@@ -543,7 +570,9 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   for (uint32_t kc = 0; kc < n_stages;) {
     const uint32_t kc_end = issue_limit;  // the next checkpoint (or the end of the rows)
     if constexpr (DIAGFORM) {
-      for (uint32_t k2 = kc; k2 < kc_end; ++k2) {
+      // one of three branch-free forms per segment (between two checkpoints), chosen out here: all eight products while a FAR one
+      // is live, the NEAR four afterwards, nothing once none is (the wave still issues its share of the DMA and meets the barriers)
+      auto advance = [&](uint32_t k2) {
         wait_dma_then_barrier(mine * (issued - k2 - 1));
         if (issued < issue_limit) {
           dma_stage(issued, issue_buf);  // (reuses the buffer every wave finished reading before the barrier)
@@ -552,8 +581,21 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
         }
         const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * stage_dwords);
         read_buf = (read_buf + 1 == stages) ? 0 : read_buf + 1;
-        if (live) {
+        return st4;
+      };
+      if (live & kDiagFar) {
+        for (uint32_t k2 = kc; k2 < kc_end; ++k2) {
+          const mf_u4* __restrict__ st4 = advance(k2);
           mfma_stage_diag<KS>(st4, slot_off, oH, oR, acc);
+        }
+      } else if (live) {
+        for (uint32_t k2 = kc; k2 < kc_end; ++k2) {
+          const mf_u4* __restrict__ st4 = advance(k2);
+          mfma_stage_near<KS>(st4, slot_off, oH, oR, acc);
+        }
+      } else {
+        for (uint32_t k2 = kc; k2 < kc_end; ++k2) {
+          (void)advance(k2);
         }
       }
     } else if ((live == 0xffu) && !diag) {
@@ -644,8 +686,12 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
       keep = __builtin_amdgcn_readfirstlane(keep);
       if (keep != live) {
         if constexpr (DIAGFORM) {
+          if ((live & kDiagFar) && !(keep & kDiagFar)) {
+            far_stop = kc;   // from here on the NEAR form (or nothing)
+          }
           live = keep;
-          need = live ? need0 : 0u;  // (the single-form loop reads all of the wave's planned blocks while it runs at all)
+          // (a form reads all of its planned blocks while it runs at all: J0, J1, V0..V2 -- or J0, J1, V2 alone)
+          need = (live & kDiagFar) ? need0 : (live ? (need0 & 0x13u) : 0u);
           if (!live) {
             stop_stage = kc;
           }
@@ -689,14 +735,17 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   if constexpr (DIAGFORM) {
     if ((lane == 0) && live0) {
       // bookkeeping in product x k-step units (one MFMA each): what early termination saved of the plan's products, and what
-      // the single-form loop computed beyond the plan (products of the wave item that hold no candidate pair)
-      const uint32_t planned = __builtin_popcount(live0);
-      const uint32_t ran = (stop_stage < n_stages) ? stop_stage : n_stages;
-      if (ran < n_stages) {
-        atomicAdd(A.counters + 2, static_cast<unsigned long long>(n_stages - ran) * KS * planned);
+      // the branch-free forms computed beyond the plan (products of the wave item that hold no candidate pair)
+      const uint32_t ran = (stop_stage < n_stages) ? stop_stage : n_stages;          // stages with any form
+      const uint32_t ran_far = (live0 & kDiagFar) ? ((far_stop < ran) ? far_stop : ran) : 0u;  // stages with the full form
+      const uint32_t plan_far = __builtin_popcount(live0 & kDiagFar), plan_near = __builtin_popcount(live0 & kDiagNear);
+      const unsigned long long saved = static_cast<unsigned long long>(n_stages - ran_far) * plan_far + static_cast<unsigned long long>(n_stages - ran) * plan_near;
+      const unsigned long long extra = static_cast<unsigned long long>(ran_far) * (4 - plan_far) + static_cast<unsigned long long>(ran) * (4 - plan_near);
+      if (saved) {
+        atomicAdd(A.counters + 2, saved * KS);
       }
-      if (planned < 8) {
-        atomicAdd(A.counters + 1, static_cast<unsigned long long>(ran) * KS * (8 - planned));
+      if (extra) {
+        atomicAdd(A.counters + 1, extra * KS);
       }
     }
   }
@@ -1039,6 +1088,6 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
 }
 
 // 64-sample k-steps per row as the kernel counts them (counters[2] is in product x k-step units)
-uint32_t pair_mfma_ksteps(uint32_t founder_ct) { return ((founder_ct + 255) / 256) * 4; }
+uint32_t pair_mfma_ksteps(uint32_t founder_ct) { return ((founder_ct + 511) / 512) * 8; }  // (whole 512-sample k-chunks: the wide-band kernel's stages; the others stop at most four k-steps of padding earlier)
 
 }  // namespace ldp

@@ -25,16 +25,30 @@ namespace ldp {
 
 namespace {
 
-using WG = StageGeom<4>;
-constexpr uint32_t kWdStageDwords = kWdRowBlocks * WG::kBlockDwords;  // 8,192 dwords = 32 KiB
-constexpr uint32_t kWdMaxStages = 4;
+// ---- geometry: a stage is 512 samples = 128 contiguous bytes of a row (one cache line), two half-stages of four k-steps ----
+// LDS image of a stage: row-block slot b, row r, eight 16-byte pieces per row (piece c = bytes 16 c .. of the row's stage) at
+// unit (32 b + r) * 8 + (c ^ ((r >> 1) & 7)); in half-stage hs lane half h reads pieces 4 hs + h and 4 hs + 2 + h: its k-step
+// ks is dword ks of each.  The XOR spreads the 16 lanes of every ds_read_b128 group over the 16 four-bank groups (rows two apart
+// share banks at this row pitch), and the DMA (lane-linear in LDS, free per-lane global address) fetches the piece that belongs
+// in its unit.  Twice the samples per barrier of pair_mfma_kernel's stages: with ONE workgroup per CU nothing else fills the
+// bubble behind a barrier (all eight waves read and expand before the first MFMA), so there should be few of them.
+constexpr uint32_t kWdStageSamples = 512;
+constexpr uint32_t kWdRowStageBytes = kWdStageSamples / 4;             // 128
+constexpr uint32_t kWdPieces = kWdRowStageBytes / 16;                  // 8
+constexpr uint32_t kWdBlockUnits = kMfBlock * kWdPieces;               // 16-byte units per row-block and stage: 256
+constexpr uint32_t kWdStageDwords = kWdRowBlocks * kWdBlockUnits * 4;  // 16,384 dwords = 64 KiB
+constexpr uint32_t kWdMaxStages = 2;
+constexpr uint32_t kWdInstrPerBlock = kWdBlockUnits / 64;              // DMA wave-instructions per row-block and stage: 4
+constexpr uint32_t kWdDma = (kWdRowBlocks * kWdInstrPerBlock) / kWdWaves;  // per wave and stage: 8
+constexpr uint32_t kWdKsteps = kWdStageSamples / 64;                   // MFMAs per product and stage: 8
 constexpr uint32_t kWdEpiWaveDwords = 4 * 16 * 64;                    // four products per epilogue round: 16 KiB per wave
-constexpr uint32_t kWdLdsDwords = kWdWaves * kWdEpiWaveDwords;        // 128 KiB: epilogue scratch == four-stage ring
+constexpr uint32_t kWdLdsDwords = kWdWaves * kWdEpiWaveDwords;        // 128 KiB: epilogue scratch == two-stage ring
 constexpr uint32_t kWdCpWaveDwords = 2 * 16 * 64;                     // checkpoint: two products per wave and round
 constexpr uint32_t kWdCpScratchDwords = kWdWaves * kWdCpWaveDwords;   // 64 KiB in; 16 row-blocks x 32 rows x 32 B = 16 KiB follow
 static_assert(kWdStageDwords * kWdMaxStages <= kWdLdsDwords, "ring fits the epilogue scratch");
+__device__ __forceinline__ uint32_t wd_swizzle(uint32_t row) { return (row >> 1) & 7u; }
 
-// One stage of a wave's 2 x 4 rectangle: J fragments of all four k-steps in registers, the four V blocks streamed past them
+// One HALF-stage (256 samples) of a wave's 2 x 4 rectangle: J fragments of all four k-steps in registers, the four V blocks streamed past them
 // (two b128 LDS reads -> 4 fragments -> 8 MFMAs, the next block's reads in flight).  There is ONE form of this loop body, without
 // a test or a branch: a wave computes all eight of its products as long as one of them is live and stops altogether once none is.
 // (A masked form -- one branch per product or per V block -- costs register copies of every accumulator at each branch; with
@@ -91,7 +105,6 @@ __device__ __forceinline__ uint32_t wide_slots_needed(uint32_t live, uint32_t a0
 
 __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKernelArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  __shared__ uint32_t s_src_off[kWdDmaPerWave * kWdWaves * 64];
   __shared__ uint32_t s_need[kWdWaves];
   if (*A.route != kRouteComplete) {
     return;  // rows with missing calls: the parallelogram plan's kernels own the launch (ldp_pair_mfma.hip)
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
   const uint32_t mask_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tile->mask >> 32));
   const bool diag = (jv0 == vv0);
   const uint32_t row_bytes = static_cast<uint32_t>(A.code_row_bytes);
-  const uint32_t n_stages = (A.founder_ct + WG::kStageSamples - 1) / WG::kStageSamples;
+  const uint32_t n_stages = (A.founder_ct + kWdStageSamples - 1) / kWdStageSamples;  // (the image's rows are whole stages long: ldp_device.h)
   const uint32_t stage_dwords = kWdStageDwords;
   uint32_t stages = A.lds_dwords / stage_dwords;
   stages = (stages > kWdMaxStages) ? kWdMaxStages : stages;
@@ -136,28 +149,29 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
   wg_need = __builtin_amdgcn_readfirstlane(wg_need);
   auto slot_first = [&](uint32_t s) { return (s < static_cast<uint32_t>(kWdTile)) ? (jv0 + static_cast<int32_t>(kMfBlock * s)) : (vv0 + static_cast<int32_t>(kMfBlock * (s - kWdTile))); };
 
-  // ---- DMA plan: per-lane source offsets (LDS) and per-instruction row-block bases (uniform) ----
-  const uint8_t* base_t[kWdDmaPerWave];
+  // ---- DMA plan: per-lane source offsets (registers) and per-instruction row-block bases (uniform) ----
+  // instruction T of a stage = a quarter of row-block slot T >> 2: eight rows x eight 16-byte pieces
+  const uint8_t* base_t[kWdDma];
+  uint32_t src_off[kWdDma];
 #pragma unroll
-  for (int t = 0; t < kWdDmaPerWave; ++t) {
-    const uint32_t T = wave + kWdWaves * t;  // instruction T of the stage: half of row-block slot T >> 1
-    const uint32_t slot = T >> 1;
+  for (int t = 0; t < static_cast<int>(kWdDma); ++t) {
+    const uint32_t T = wave + kWdWaves * t;
+    const uint32_t slot = T / kWdInstrPerBlock;
     uint32_t first = static_cast<uint32_t>(slot_first(slot));
     first = (first < A.n_local) ? first : (A.n_local - 1);  // (a block beyond the rows is never live; keep its address legal anyway)
     first = __builtin_amdgcn_readfirstlane(first);
     base_t[t] = A.codes + static_cast<uint64_t>(first) * row_bytes;
-    const uint32_t L = T * 64 + lane;
-    const uint32_t rr = (L / 4) & 31;
-    const uint32_t col = (L % 4) ^ WG::swizzle(rr);
+    const uint32_t rr = (T % kWdInstrPerBlock) * 8 + (lane >> 3);
+    const uint32_t col = (lane & 7) ^ wd_swizzle(rr);
     uint32_t var = first + rr;
     var = (var < A.n_local) ? var : (A.n_local - 1);
-    s_src_off[t * (kWdWaves * 64) + tid] = (var - first) * row_bytes + WG::piece_byte(col);
+    src_off[t] = (var - first) * row_bytes + col * 16;
   }
   auto count_mine = [&]() {
     uint32_t m = 0;
 #pragma unroll
-    for (int t = 0; t < kWdDmaPerWave; ++t) {
-      m += ((wg_need >> ((wave + kWdWaves * t) >> 1)) & 1u) ? 1u : 0u;
+    for (int t = 0; t < static_cast<int>(kWdDma); ++t) {
+      m += ((wg_need >> ((wave + kWdWaves * t) / kWdInstrPerBlock)) & 1u) ? 1u : 0u;
     }
     return m;
   };
@@ -166,11 +180,11 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
   uint32_t joff[2], voff[4];  // uint4 index of the row-block's first slot
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    joff[q] = (a0 + q) * WG::kBlockSlots;
+    joff[q] = (a0 + q) * kWdBlockUnits;
   }
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    voff[b] = (vslot0 + b) * WG::kBlockSlots;
+    voff[b] = (vslot0 + b) * kWdBlockUnits;
   }
   uint32_t need = wide_slots_needed(live, a0, vslot0);
   // window starts of this lane's two second variants (J0 + r, J1 + r), fetched here: the k-loop must not hold ordinary
@@ -183,9 +197,10 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
       lo_j2[q] = A.lo[j];
     }
   }
-  const uint32_t sw = WG::swizzle(r);
-  const uint32_t oH = r * 4 + (h ^ sw);
-  const uint32_t oR = r * 4 + ((2 + h) ^ sw);
+  const uint32_t sw = wd_swizzle(r);
+  // unit offsets of this lane's two pieces inside a row-block, for the two half-stages
+  const uint32_t oH0 = r * kWdPieces + (h ^ sw), oR0 = r * kWdPieces + ((2 + h) ^ sw);
+  const uint32_t oH1 = r * kWdPieces + ((4 + h) ^ sw), oR1 = r * kWdPieces + ((6 + h) ^ sw);
 
   mf_v16f acc[8];
 #pragma unroll
@@ -201,23 +216,22 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
   const uint32_t live0 = live;        // the products of the plan
   uint32_t stop_stage = n_stages;     // stages this wave computes (it stops as a whole, at a checkpoint)
   auto dma_stage = [&](uint32_t s, uint32_t buf) {
-    const uint32_t kbyte = WG::stage_byte(s);
+    const uint32_t kbyte = s * kWdRowStageBytes;
     uint32_t* dst = lds + buf * stage_dwords;
 #pragma unroll
-    for (int t = 0; t < kWdDmaPerWave; ++t) {
+    for (int t = 0; t < static_cast<int>(kWdDma); ++t) {
       const uint32_t T = wave + kWdWaves * t;
-      if ((wg_need >> (T >> 1)) & 1u) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_t[t] + kbyte + s_src_off[t * (kWdWaves * 64) + tid]),
+      if ((wg_need >> (T / kWdInstrPerBlock)) & 1u) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_t[t] + kbyte + src_off[t]),
                                          (__attribute__((address_space(3))) void*)(dst + T * 256), 16, 0, 0);
       }
     }
   };
   auto checkpoint_stage = [&](uint32_t cp) {
-    const uint32_t s = A.checkpoint_chunk[cp] * WG::kStagesPerChunk;
+    const uint32_t s = A.checkpoint_chunk[cp];  // (a stage is a 512-sample k-chunk here)
     return (s < n_stages) ? s : n_stages;
   };
 
-  __syncthreads();  // (s_src_off is complete)
   uint32_t* epi = lds + wave * kWdEpiWaveDwords;  // this wave's scratch whenever the ring is empty (epilogue)
   // ---- k-loop over stages, ring of `stages` LDS buffers; the ring never runs past the next checkpoint ----
   uint32_t issued = 0, issue_buf = 0, read_buf = 0, issued_base = 0;
@@ -244,7 +258,8 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
       const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * stage_dwords);
       read_buf = (read_buf + 1 == stages) ? 0 : read_buf + 1;
       if (live) {
-        wide_stage(st4, joff, voff, oH, oR, acc);
+        wide_stage(st4, joff, voff, oH0, oR0, acc);
+        wide_stage(st4, joff, voff, oH1, oR1, acc);
       }
     }
     if (kc >= n_stages) {
@@ -360,10 +375,10 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
     // single-form stage loop computed beyond the plan (the products of this wave's rectangle that hold no candidate pair)
     const uint32_t planned = __builtin_popcount(live0);
     if (stop_stage < n_stages) {
-      atomicAdd(A.counters + 2, static_cast<unsigned long long>(n_stages - stop_stage) * 4 * planned);
+      atomicAdd(A.counters + 2, static_cast<unsigned long long>(n_stages - stop_stage) * kWdKsteps * planned);
     }
     if (planned < 8) {
-      atomicAdd(A.counters + 1, static_cast<unsigned long long>(stop_stage) * 4 * (8 - planned));
+      atomicAdd(A.counters + 1, static_cast<unsigned long long>(stop_stage) * kWdKsteps * (8 - planned));
     }
   }
 

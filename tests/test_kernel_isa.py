@@ -43,7 +43,7 @@ def test_pair_mfma_kernel_keeps_its_dma_ring_running(tmp_path):
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
 def test_wide_band_kernel_has_one_branch_free_stage_loop_and_no_scratch(tmp_path):
-    """pair_mfma_wide_kernel (ldp_pair_wide.hip): the stage loop exists in ONE form -- 32 MFMAs behind 12 LDS reads, no branch, no
+    """pair_mfma_wide_kernel (ldp_pair_wide.hip): the stage loop exists in ONE form -- 64 MFMAs behind 24 LDS reads, no branch, no
     accumulator copy -- and the kernel uses no scratch at all (a masked form made hipcc spill inside the loop: DESIGN.md 4.1e)."""
     src = os.path.join(REPO, "plink-ng_amd", "csrc", "ldp_pair_wide.hip")
     out = tmp_path / "wd.s"
@@ -55,10 +55,10 @@ def test_wide_band_kernel_has_one_branch_free_stage_loop_and_no_scratch(tmp_path
     assert [int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", cp.stdout)] == [2]
     lines = open(out).read().splitlines()
     mf = [k for k, ln in enumerate(lines) if "v_mfma_scale_f32_32x32x64_f8f6f4" in ln]
-    assert len(mf) == 32                       # one copy of the stage body
+    assert len(mf) == 64                       # one copy of the stage body: two half-stages of 32
     body = lines[mf[0]:mf[-1] + 1]
     assert not any(("s_cbranch" in ln) or ("scratch_" in ln) or ("v_accvgpr" in ln) for ln in body)
-    assert sum("v_bitop3_b32" in ln for ln in lines[mf[0] - 60:mf[-1]]) == 96   # 6 row-blocks x 4 k-steps x 4 dwords, one operation each
+    assert sum("v_bitop3_b32" in ln for ln in lines[mf[0] - 60:mf[-1]]) == 192  # 2 half-stages x 6 row-blocks x 4 k-steps x 4 dwords, one operation each
     for k, ln in enumerate(lines):
         if "ds_read_b128" in ln:
             before = [x for x in lines[max(0, k - 6):k] if not x.strip().startswith(";")]

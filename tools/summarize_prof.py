@@ -47,7 +47,7 @@ def main():
         if (("pair_mfma" in k) or ("pair_tiles_kernel" in k)) and "FETCH_SIZE" in cs:
             read_b = cs["FETCH_SIZE"] * 1024 * 2 * n_disp[k]
             write_b = cs.get("WRITE_SIZE", 0.0) * 1024 * n_disp[k]
-            short = k.split("(")[0].replace("void ", "").replace("ldp::", "").replace("(anonymous namespace)::", "")
+            short = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("ldp::", "")
             per_kernel[short] = {"launches_per_step": n_disp[k], "hbm_read_bytes_per_step": read_b, "hbm_write_bytes_per_step": write_b,
                                  "l2_hit_rate": (cs["TCC_HIT_sum"] / (cs["TCC_HIT_sum"] + cs["TCC_MISS_sum"])) if cs.get("TCC_HIT_sum") is not None and (cs.get("TCC_HIT_sum", 0) + cs.get("TCC_MISS_sum", 0)) > 0 else None}
             total_b += read_b + write_b
@@ -55,7 +55,7 @@ def main():
             total_write += write_b
     if per_kernel:
         main_kernel = max(per_kernel, key=lambda k: per_kernel[k]["hbm_read_bytes_per_step"])
-        rows_bytes = ((samples + 255) // 256) * 64
+        rows_bytes = ((samples + 511) // 512) * 128
         json.dump({"kernel": main_kernel, "samples": samples, "variants": variants, "window_kb": window_kb, "missing_rate": missing_rate,
                    "hbm_bytes_per_step": total_b, "hbm_read_bytes_per_step": total_read, "hbm_write_bytes_per_step": total_write,
                    "compulsory_bytes_per_step": float(variants) * rows_bytes, "traffic_over_compulsory": total_b / (float(variants) * rows_bytes),
