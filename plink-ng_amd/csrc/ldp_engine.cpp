@@ -936,6 +936,18 @@ void build_shard(ldp_engine* e) {
     // the chip half empty at their tails -- 1 / 2 / 4 groups: 4.25 / 4.6 / 5.0 ms of kernel, 10.84 / 10.87 / 11.17 ms per
     // step with the replay of all but the last group hidden)
     uint32_t kTargetGroups = e->mf_enabled ? 2 : 4;
+    if (e->mf_enabled && !e->wd_tiles.empty()) {
+      // Wide bands: a tile runs for the whole length of the rows (2.5 ms at config 3's density, a dozen rounds of them in a
+      // 120,000-variant slice), so every launch ends in a tail of most of a round, while the replay of such a share takes well
+      // under a millisecond per 100,000 variants: one launch (config-3 slice: 30.6 ms of kernel against 32.3 with two, 34.2 with three)
+      uint64_t wide_products = 0;
+      for (const MfmaTile& t : e->wd_tiles) {
+        wide_products += static_cast<uint64_t>(__builtin_popcountll(t.mask));
+      }
+      if (2 * wide_products >= e->mf_products) {
+        kTargetGroups = 1;
+      }
+    }
     if (const char* tg = getenv("LDP_DEBUG_GROUPS")) {
       kTargetGroups = std::max(1, atoi(tg));
     }

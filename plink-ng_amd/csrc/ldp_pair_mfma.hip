@@ -493,7 +493,15 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
 
   uint32_t wg_need = (1u << n_rb) - 1;  // row-block slots some wave still reads (all of them until a checkpoint says otherwise)
   uint32_t next_cp = 0;
-  const uint32_t n_cp = (A.cp_stats && !SPARSE) ? A.n_checkpoints : 0;  // (the checkpoint bound assumes complete rows)
+  // (the checkpoint bound assumes complete rows.  DIAGFORM: ONE checkpoint, the second of the list (a fraction 1 - sqrt(r2) + 0.04
+  // of the samples): from about 0.02 behind 1 - sqrt(r2) the four FAR products of nearly every wave item are provably hopeless
+  // -- a third of the plan's MFMAs at config 2 -- and nothing earlier is (r2 0.5: at 0.30 a quarter, at 0.31 a third).  Each
+  // further checkpoint costs a drained ring, three barriers and a restart for nothing: config 2 with 1 / 2 / 5 checkpoints
+  // 3.50 / 3.73 / 4.32 ms, none 3.91; profiles/r03_experiments.md)
+  const uint32_t cp_all = (A.cp_stats && !SPARSE) ? A.n_checkpoints : 0;
+  const uint32_t first_cp = (DIAGFORM && (cp_all >= 2)) ? 1u : 0u;
+  const uint32_t n_cp = DIAGFORM ? ((cp_all > first_cp) ? first_cp + 1 : cp_all) : cp_all;
+  next_cp = first_cp;
   auto dma_stage = [&](uint32_t s, uint32_t buf) {
     const uint32_t kbyte = G::stage_byte(s);
     uint32_t* dst = lds + buf * stage_dwords;
