@@ -62,8 +62,10 @@ CONFIGS = {
 HBM_BYTES = 288e9
 
 
-def genome_layout(variants, spacing):
-    """chr_idx / bp arrays of one 22-autosome genome holding `variants` variants."""
+def genome_layout(variants, genomes, spacing):
+    """chr_idx / bp arrays of one 22-autosome genome holding `variants` variants (`genomes` is 1: one genome whatever the rank
+    count; the argument is kept for the tests and tools that share this generator)."""
+    assert genomes == 1
     tot = sum(GRCH38_MB)
     counts = [int(variants * mb / tot) for mb in GRCH38_MB]
     counts[0] += variants - sum(counts)
@@ -121,7 +123,7 @@ def cpu_baseline(pkg, torch, founder_ct, m, spacing, window_kb, r2, missing_rate
     if "avx2" not in open("/proc/cpuinfo").read():
         return {**base, "sample": "host CPU lacks AVX2"}
     window_bp = pkg.kb_window(window_kb)
-    chr_idx, bps = genome_layout(m, spacing)
+    chr_idx, bps = genome_layout(m, 1, spacing)
     stride = (founder_ct + 3) // 4
     buf = torch.empty((m, stride), dtype=torch.uint8, device="cuda")
     pkg.synth_genotypes_device(SEED, 0, m, founder_ct, missing_rate, buf.data_ptr(), stride)
@@ -228,12 +230,20 @@ class Workload:
         self.founder_ct = cfg["samples"]
         self.window_bp = pkg.kb_window(cfg["window_kb"])
         self.m_total = cfg["variants"]
-        self.chr_idx, self.bps = genome_layout(self.m_total, cfg["spacing"])
+        self.chr_idx, self.bps = genome_layout(self.m_total, 1, cfg["spacing"])
         planner = self._engine()
         planner.set_variants(self.chr_idx, self.bps)
         self.subs = planner.subcontigs()
         self.owner = planner.set_shard(rank, world) if world > 1 else np.zeros(len(self.subs), dtype=np.uint32)
-        self.owned = [(ln, first) for (ln, first), o in zip(self.subs, self.owner) if o == rank]
+        self.owned_subs = [(ln, first) for (ln, first), o in zip(self.subs, self.owner) if o == rank]
+        self.owned = []
+        for (ln, first), o in zip(self.subs, self.owner):
+            if o != rank:
+                continue
+            if self.owned and (self.owned[-1][1] + self.owned[-1][0] == first):
+                self.owned[-1] = (self.owned[-1][0] + ln, self.owned[-1][1])  # adjacent subcontigs: one run of image rows, one load call
+            else:
+                self.owned.append((ln, first))
         self.local_ct = sum(ln for ln, _ in self.owned)
         row_bytes = ((self.founder_ct + 511) // 512) * 128
         self.image_bytes = self.local_ct * row_bytes
@@ -243,7 +253,7 @@ class Workload:
             self.engines.append((planner, self.owned))
         else:
             planner.close()
-            for ln, first in self.owned:  # one engine per owned chromosome, planned now, device memory only while it is worked on
+            for ln, first in self.owned_subs:  # one engine per owned chromosome, planned now, device memory only while it is worked on
                 e = self._engine()
                 sel = slice(first, first + ln)
                 e.set_variants(self.chr_idx[sel], self.bps[sel])

@@ -12,6 +12,8 @@
 #include "ldp_pair_device.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <string>
 
 namespace ldp {
 
@@ -78,7 +80,7 @@ __device__ __forceinline__ void hap_codes_of_16(uint32_t w, uint32_t phase16, ui
 // One block per variant, one 16-byte unit of the image row (64 samples) per thread and iteration.  ITERS > 0: the iterations
 // are unrolled with all of a thread's loads issued up front (few threads with many 16-byte loads in flight each beat many
 // threads with few, as in prepare_kernel); ITERS == 0: a rolled loop for rows beyond the register budget.
-template <int THREADS, int ITERS>
+template <int THREADS, int ITERS, bool NT = false>
 __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
   constexpr int kWaves = THREADS / 64;
   __shared__ uint32_t red[kWaves][3 + 2 * kCheckpoints];
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
     for (int it = 0; it < ITERS; ++it) {
       const uint32_t u = tid + it * THREADS;
       if (u < n_fast) {
-        const u32x4_a4 t = *reinterpret_cast<const u32x4_a4*>(row + 16ull * u);
+        const u32x4_a4 t = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4*>(row + 16ull * u)) : *reinterpret_cast<const u32x4_a4*>(row + 16ull * u);
         w[it].x = t.x;
         w[it].y = t.y;
         w[it].z = t.z;
@@ -373,6 +375,25 @@ hipError_t launch_codes(const PrepareArgs& a, hipStream_t stream) {
   const uint64_t units = a.code_row_bytes / 16;
   // the geometry prepare_kernel was tuned to (config 2: 128 x 7 best; N = 500,000: 512 x 16), a unit = 64 samples in both
 #define LDP_CODES(T, I) hipLaunchKernelGGL((codes_kernel<T, I>), dim3(a.n_variants), dim3(T), 0, stream, a)
+  if (const char* shape = getenv("LDP_DEBUG_CODES_SHAPE")) {  // tuning aid: "64x13", "128x7nt", "256x4", "256x4nt"
+    const std::string sh(shape);
+    if ((sh == "64x13") && (units <= 64 * 13)) {
+      hipLaunchKernelGGL((codes_kernel<64, 13>), dim3(a.n_variants), dim3(64), 0, stream, a);
+      return hipGetLastError();
+    }
+    if ((sh == "128x7nt") && (units <= 128 * 7)) {
+      hipLaunchKernelGGL((codes_kernel<128, 7, true>), dim3(a.n_variants), dim3(128), 0, stream, a);
+      return hipGetLastError();
+    }
+    if ((sh == "256x4") && (units <= 256 * 4)) {
+      hipLaunchKernelGGL((codes_kernel<256, 4>), dim3(a.n_variants), dim3(256), 0, stream, a);
+      return hipGetLastError();
+    }
+    if ((sh == "256x4nt") && (units <= 256 * 4)) {
+      hipLaunchKernelGGL((codes_kernel<256, 4, true>), dim3(a.n_variants), dim3(256), 0, stream, a);
+      return hipGetLastError();
+    }
+  }
   if (units <= 128 * 2) {
     LDP_CODES(128, 2);
   } else if (units <= 128 * 4) {
