@@ -203,6 +203,33 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
  * copied into the image as before.  LDP_ERR_UNSUPPORTED when the engine keeps bit-planes instead (more founders than
  * ldp_matrix_pipe_max_founders()): load from your own buffer then. */
 int ldp_map_rows(ldp_engine* e, uint32_t first_variant, uint32_t n, void** device_rows, uint64_t* stride_bytes);
+/* Variant records of a variable-width .pgen file, decoded ON THE DEVICE from the file's own bytes and loaded: what the reference's
+ * reader thread does one variant at a time before LdPrune's pair loop (plink2_ld.cc:1345-1390 PgrGetInv1 ->
+ * ReadGenovecSubsetUnsafe, pgenlib_read.cc:2849-2912: plain 2-bit, one-bit + exceptions, difflists, LD-compressed chains,
+ * pgenlib_read.cc:2186-2760; and for variants with more than one ALT allele Get1Multiallelic, pgenlib_read.cc:5417-5563, with
+ * the major allele chosen as ComputeAlleleFreqs / GetMajIdxMulti do, plink2_filter.cc:2113-2153, plink2_common.cc:1042-1070).
+ * Only the main track and auxiliary track 1 are read; phase and dosage tracks behind them are ignored.
+ *   recs[q]      record of variant first_variant + q inside `bytes` (host or device memory, `location`): offset, length, the
+ *                file's variant record type byte, and the allele count from the .pvar (ldp_pgen_record_index() fills the first
+ *                three from a file's index).  Variants this engine does not own are decoded too (LD chains run through them).
+ *   ld_base      optional: the record that stands alone (not LD-compressed) on which recs[0], if it is LD-compressed, builds,
+ *                when that record is not part of this call.  Without it an LD-compressed first record builds on the last
+ *                stand-alone record of the previous call, provided this call starts where that one ended.
+ *   raw_sample_ct  samples of the file = the engine's founder_ct, or the raw count of ldp_set_sample_map() (the engine then
+ *                gathers its columns as for LDP_GENO_MAPPED rows; variants with allele_ct > 2 are refused in that case, since
+ *                their major allele is counted over the columns of the file).
+ *   major_allele_out  optional, n entries: the major allele of the variants with allele_ct > 2 (their maj_freq is set as by
+ *                ldp_set_maj_freqs), UINT32_MAX for the others (decided by the count pass: ldp_get_variant_recs).
+ * LDP_ERR_INVALID for a malformed record (no row of the call counts as loaded then). */
+typedef struct ldp_pgen_rec {
+  uint64_t offset;
+  uint32_t length;
+  uint8_t vrtype;
+  uint8_t allele_ct; /* 2..255 */
+  uint16_t reserved;
+} ldp_pgen_rec;
+int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* bytes, uint64_t n_bytes, int location, const ldp_pgen_rec* recs,
+                          const ldp_pgen_rec* ld_base, uint32_t raw_sample_ct, uint32_t* major_allele_out);
 /* Give the engine's device memory back (image, records, predicate rows, staging) while keeping its plan: for a caller that works
  * through more data than fits HBM, one engine (chromosome) after the other.  The next ldp_load_genotypes() / ldp_map_rows()
  * allocates again; every row has to be loaded again before the next ldp_run(). */
@@ -351,6 +378,12 @@ int ldp_pgen_provisional_ref(const ldp_pgen* p, uint8_t* bits, uint64_t bits_byt
 int ldp_pgen_has_dosage(const ldp_pgen* p);
 /* fixed-width modes only: pointer to row 0 inside the file mapping (zero-copy), NULL for variable-width files */
 const void* ldp_pgen_direct_rows(const ldp_pgen* p, uint64_t* stride_bytes);
+/* For ldp_load_pgen_records(): the file's bytes (the reader's mapping) and the index entries of variants [first_variant, +n) --
+ * offset, length, record type; allele_ct is set to 2 (the .pvar knows better).  *ld_base_variant (optional): the variant whose
+ * record the first one builds on when it is LD-compressed (GetLdbaseVidx, pgenlib_read.cc:1848), UINT32_MAX otherwise.
+ * Fixed-width .pgen files yield plain 2-bit records; LDP_ERR_UNSUPPORTED for a .bed (its rows are not .pgen codes). */
+const void* ldp_pgen_file_bytes(const ldp_pgen* p, uint64_t* n_bytes);
+int ldp_pgen_record_index(const ldp_pgen* p, uint32_t first_variant, uint32_t n, ldp_pgen_rec* out, uint32_t* ld_base_variant);
 /* decode rows [first_variant, first_variant+n) into out_rows; 64k-variant blocks decode on up to `threads` host threads (0 = all) */
 int ldp_pgen_read(ldp_pgen* p, uint32_t first_variant, uint32_t n, void* out_rows, uint64_t stride_bytes, uint32_t threads);
 /* Multiallelic hard-call track (pgen_spec.tex:469-540; what Get1Multiallelic, pgenlib_read.cc:5417, consumes):

@@ -56,6 +56,11 @@ class ldp_variant_rec(ctypes.Structure):
                 ("n_homalt", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
+class ldp_pgen_rec(ctypes.Structure):
+    _fields_ = [("offset", ctypes.c_uint64), ("length", ctypes.c_uint32), ("vrtype", ctypes.c_uint8), ("allele_ct", ctypes.c_uint8),
+                ("reserved", ctypes.c_uint16)]
+
+
 class ldp_counters(ctypes.Structure):
     _fields_ = [("candidate_pairs", ctypes.c_uint64), ("computed_pairs", ctypes.c_uint64),
                 ("replay_pairs", ctypes.c_uint64), ("pred_true", ctypes.c_uint64),
@@ -91,12 +96,12 @@ CABI_SYMBOLS = [
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_has_dosage", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
     "ldp_pgen_variant_is_multiallelic", "ldp_pgen_provisional_ref", "ldp_pgen_open_indexed", "ldp_set_r_signed", "ldp_set_variants_vcor_cm", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_subset_samples", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
     "ldp_debug_set_option", "ldp_matrix_pipe_max_founders", "ldp_map_rows", "ldp_release_device", "ldp_debug_wide_plan",
-    "ldp_allgather_removed", "ldp_comm_init_all", "ldp_comm_destroy",
+    "ldp_allgather_removed", "ldp_comm_init_all", "ldp_comm_destroy", "ldp_load_pgen_records", "ldp_pgen_file_bytes", "ldp_pgen_record_index",
 ]
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_codes.hip", "ldp_pair_mfma.hip", "ldp_pair_wide.hip", "ldp_synth.hip", "ldp_engine.cpp", "ldp_pgen.cpp")]
+    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_codes.hip", "ldp_pair_mfma.hip", "ldp_pair_wide.hip", "ldp_pgen_decode.hip", "ldp_synth.hip", "ldp_engine.cpp", "ldp_pgen.cpp")]
 
 
 def _stale(target, deps):
@@ -175,6 +180,11 @@ def lib():
     L.ldp_debug_replay_pairs.argtypes = [vp, ctypes.c_uint64, u32p, u32p, u64p]
     L.ldp_map_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp), u64p]
     L.ldp_release_device.argtypes = [vp]
+    L.ldp_load_pgen_records.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ldp_pgen_rec),
+                                        ctypes.POINTER(ldp_pgen_rec), ctypes.c_uint32, u32p]
+    L.ldp_pgen_file_bytes.argtypes = [vp, u64p]
+    L.ldp_pgen_file_bytes.restype = ctypes.c_void_p
+    L.ldp_pgen_record_index.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ldp_pgen_rec), u32p]
     L.ldp_allgather_removed.argtypes = [vp, vp, u64p, u64p]
     L.ldp_comm_init_all.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(vp)]
     L.ldp_comm_destroy.argtypes = [vp]
@@ -330,6 +340,26 @@ class PgenFile:
         if rc != LDP_OK:
             raise LdpError(rc, self._L.ldp_pgen_last_error(self._h).decode())
         return out
+
+    def file_bytes(self):
+        """(host pointer, byte count) of the reader's mapping of the file (ldp_pgen_file_bytes)."""
+        nb = ctypes.c_uint64()
+        p = self._L.ldp_pgen_file_bytes(self._h, ctypes.byref(nb))
+        return int(p), int(nb.value)
+
+    def record_index(self, first=0, n=None, allele_cts=None):
+        """(ctypes array of ldp_pgen_rec for variants [first, first + n), the variant the first record's LD chain builds on or None);
+        allele_cts (optional, per variant) overrides the default of 2."""
+        n = self.variant_ct - first if n is None else n
+        recs = (ldp_pgen_rec * max(n, 1))()
+        base = ctypes.c_uint32()
+        rc = self._L.ldp_pgen_record_index(self._h, first, n, recs, ctypes.byref(base))
+        if rc != LDP_OK:
+            raise LdpError(rc, "ldp_pgen_record_index failed")
+        if allele_cts is not None:
+            for q in range(n):
+                recs[q].allele_ct = int(allele_cts[q])
+        return recs, (None if base.value == 0xffffffff else int(base.value))
 
     def read_phased(self, first=0, n=None, sample_mask=None, threads=0):
         """Rows in the LDP_GENO_REF | LDP_GENO_PHASED layout (2-bit codes, padding to a dword, phaseinfo bits).
@@ -542,6 +572,24 @@ class LdPruneEngine:
     def load_genotypes_device(self, first_variant, n, device_ptr, stride_bytes, encoding=LDP_GENO_INVERSE):
         self._ck(self._L.ldp_load_genotypes(self._h, first_variant, n, ctypes.c_void_p(device_ptr), stride_bytes,
                                             LDP_MEM_DEVICE, encoding))
+
+    def load_pgen_records(self, first_variant, pgen, raw_first=None, n=None, allele_cts=None, location=LDP_MEM_HOST, device_bytes=None):
+        """ldp_load_pgen_records: variants [first_variant, +n) of the engine <- records [raw_first, +n) of the PgenFile `pgen`, decoded
+        on the device.  device_bytes: device pointer of a copy of the whole file (location = LDP_MEM_DEVICE).  Returns the major
+        alleles (uint32 array; 0xffffffff for variants with one ALT allele)."""
+        raw_first = first_variant if raw_first is None else raw_first
+        n = pgen.variant_ct - raw_first if n is None else n
+        recs, base = pgen.record_index(raw_first, n, allele_cts)
+        base_rec = None
+        if base is not None:
+            base_rec = pgen.record_index(base, 1)[0]
+        ptr, nbytes = pgen.file_bytes()
+        if location == LDP_MEM_DEVICE:
+            ptr = int(device_bytes)
+        maj = np.zeros(max(n, 1), dtype=np.uint32)
+        self._ck(self._L.ldp_load_pgen_records(self._h, int(first_variant), int(n), ctypes.c_void_p(ptr), nbytes, location, recs,
+                                               base_rec if base_rec is not None else None, pgen.sample_ct, _ptr(maj, ctypes.c_uint32)))
+        return maj[:n]
 
     def map_rows(self, first_variant, n):
         """(device pointer, stride in bytes) of the engine's own image rows of variants [first_variant, first_variant + n): write

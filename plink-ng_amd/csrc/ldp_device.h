@@ -216,6 +216,7 @@ struct PrepareArgs {
   double cp_tv_scale;            // sqrt(sqrt(thresh) * (1 - 1e-6))
   uint32_t checkpoint_chunk[kCheckpoints];
   uint32_t n_checkpoints;
+  const uint8_t* row_inverse;    // optional, entry 0 = variant `first`: nonzero = this row is LDP_GENO_INVERSE whatever `encoding` says
   uint8_t* codes_out;            // code image rows (row 0 = variant `first`), code_row_bytes apart; launch_codes() only.  When it
   uint64_t code_row_bytes;       //   equals `geno` (and the strides agree) the rows are counted in place and only their padding is written
   MissStats* miss_stats;         // what the rows' missing calls add up to (may be nullptr)
@@ -231,6 +232,40 @@ hipError_t launch_codes(const PrepareArgs& a, hipStream_t stream);
 // arbitrary pairs from the code image (the integers in major-allele orientation, like launch_pair_stats_ref)
 hipError_t launch_pair_stats_ref_codes(const uint8_t* codes, uint64_t code_row_bytes, const ldp_variant_rec* recs, const uint32_t* first, const uint32_t* second,
                                        uint32_t n_pairs, ldp_pair_stats_t* out, hipStream_t stream);
+constexpr double kSmallEpsilon = 0.00000000000005684341886080801486968994140625;  // 2^-44 (plink2_float.h:119)
+
+// ---- .pgen records decoded on the device (ldp_pgen_decode.hip) ----------------------------------------------------
+constexpr uint32_t kPgenBaseCarried = 0xfffffffeu;  // PgenRecDesc::base: the row the engine kept from the previous launch
+constexpr uint32_t kPgenNoBase = 0xffffffffu;
+struct PgenRecDesc {
+  uint64_t off;        // first byte of the record in the launch's byte buffer
+  uint32_t len;        // bytes
+  uint32_t base;       // LD-compressed records (types 2, 3): row of this launch that holds their base, or kPgenBaseCarried
+  uint32_t allele_ct;  // from the .pvar (2 = one ALT allele)
+  uint32_t vrtype;     // the file's variant record type byte
+};
+struct PgenDecodeArgs {
+  const uint8_t* bytes;         // the records' bytes
+  const PgenRecDesc* recs;
+  uint32_t n;                   // records = rows of this launch
+  uint32_t sample_ct;           // samples of the FILE
+  uint8_t* rows;                // out: 2-bit rows, ceil(sample_ct / 4) bytes used, the rest of the stride zero
+  uint64_t stride;              // multiple of 16
+  const uint8_t* carried_base;  // the most recent non-LD row before this launch, or nullptr
+  uint64_t* main_end;           // out, per record: offset in `bytes` of the first byte behind the main track
+  int* error;                   // out: 0, or 1 + the index of a malformed record
+  int pass;                     // (set by the launcher)
+  int any_ld;                   // some record is LD-compressed
+  // variants with more than one ALT allele: their records, and what the collapse decides
+  const uint32_t* multi_rec;    // record indices
+  uint32_t n_multi;
+  double* maj_freq;             // out, per entry of multi_rec: GetAlleleFreq of the major allele
+  uint32_t* maj_idx;            // out: the major allele
+  uint8_t* row_inverse;         // out, per RECORD: 1 = the row now counts copies of non-major alleles (LDP_GENO_INVERSE)
+};
+hipError_t launch_pgen_main(const PgenDecodeArgs& a, hipStream_t stream);
+hipError_t launch_pgen_aux1(const PgenDecodeArgs& a, hipStream_t stream);
+
 // Sample-mapped rows (ldp_set_sample_map): out row v = 2-bit REF codes of columns map[f] & 0x7fffffff of in row v, hets of
 // columns with bit 31 set replaced by missing and counted into extra_het[v]; in rows are .pgen- or .bed-coded.
 hipError_t launch_gather_rows(const uint8_t* in, uint64_t in_stride, uint32_t n_variants, int in_is_bed, const uint32_t* map, uint32_t out_ct, uint8_t* out,

@@ -30,7 +30,6 @@ using namespace ldp;
 
 namespace {
 
-constexpr double kSmallEpsilon = 0.00000000000005684341886080801486968994140625;  // 2^-44 (plink2_float.h:119)
 
 struct Subcontig {
   uint32_t len;
@@ -203,6 +202,16 @@ struct ldp_engine {
   size_t gather_bytes = 0;
   uint32_t* d_extra_het = nullptr;  // per variant of that launch
   size_t extra_het_cap = 0;
+  // ldp_load_pgen_records(): device scratch of one launch (bytes, record descriptors, decoded rows, per-record outputs) and the
+  // most recent non-LD row, kept for a call that continues where this one stopped
+  struct DecodeScratch {
+    void* ptr[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  } dec;
+  uint8_t* d_ld_base = nullptr;
+  size_t ld_base_cap = 0;
+  bool ld_base_valid = false;
+  uint32_t dec_next_variant = 0;  // the call that may use d_ld_base starts here
 
   ldp_counters ctr;
 
@@ -335,6 +344,15 @@ void free_device(ldp_engine* e) {
       e->stage_done[k] = nullptr;
     }
   }
+  for (int k = 0; k < 8; ++k) {
+    (void)hipFree(e->dec.ptr[k]);
+    e->dec.ptr[k] = nullptr;
+    e->dec.cap[k] = 0;
+  }
+  (void)hipFree(e->d_ld_base);
+  e->d_ld_base = nullptr;
+  e->ld_base_cap = 0;
+  e->ld_base_valid = false;
   (void)hipFree(e->d_sample_map);
   (void)hipFree(e->d_gather);
   (void)hipFree(e->d_extra_het);
@@ -2783,7 +2801,11 @@ int ldp_get_band(const ldp_engine* e, uint32_t* lo, uint64_t* candidate_pairs) {
 uint64_t ldp_phased_phase_offset(uint32_t hap_ct) { return ((static_cast<uint64_t>(hap_ct / 2) + 3) / 4 + 3) & ~static_cast<uint64_t>(3); }
 uint64_t ldp_phased_row_bytes(uint32_t hap_ct) { return ldp_phased_phase_offset(hap_ct) + (static_cast<uint64_t>(hap_ct / 2) + 7) / 8; }
 
-int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* geno, uint64_t stride_bytes, int location, int encoding) {
+namespace {
+// ldp_load_genotypes(); d_row_inverse / h_row_inverse (optional, device and host copies of the same n bytes): rows that are
+// LDP_GENO_INVERSE whatever `encoding` says (the collapsed multiallelic rows of ldp_load_pgen_records)
+int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* geno, uint64_t stride_bytes, int location, int encoding,
+                   const uint8_t* d_row_inverse, const uint8_t* h_row_inverse) {
   if (!e) {
     return LDP_ERR_INVALID;
   }
@@ -2951,6 +2973,7 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
           PA.extra_het = e->d_extra_het;
         }
       }
+      PA.row_inverse = d_row_inverse ? (d_row_inverse + (g + done - first_variant)) : nullptr;
       PA.geno = d_src;
       PA.stride_bytes = d_stride;
       PA.n_variants = cnt;
@@ -2999,7 +3022,7 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
       for (uint32_t q = 0; q < cnt; ++q) {
         e->loaded[l0 + q] = 1;
         e->load_tag[l0 + q] = e->load_epoch;
-        if (base_encoding != LDP_GENO_INVERSE) {
+        if ((base_encoding != LDP_GENO_INVERSE) && !(h_row_inverse && h_row_inverse[g + done + q - first_variant])) {
           e->mf_set[l0 + q] = 2;  // derived from the device's allele counts at the next ldp_run()
         }
       }
@@ -3022,6 +3045,248 @@ int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const 
     HIP_TRY(e, hipStreamSynchronize(e->stream));  // the caller may reuse its buffer once we return
   }
   return LDP_OK;
+}
+}  // namespace
+
+int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* geno, uint64_t stride_bytes, int location, int encoding) {
+  return load_rows_impl(e, first_variant, n, geno, stride_bytes, location, encoding, nullptr, nullptr);
+}
+
+namespace {
+// slot k of the decode scratch, at least `bytes` large (contents are not kept when it grows)
+int dec_reserve(ldp_engine* e, int k, size_t bytes, void** out) {
+  if (e->dec.cap[k] < bytes) {
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    (void)hipFree(e->dec.ptr[k]);
+    e->dec.ptr[k] = nullptr;
+    e->dec.cap[k] = 0;
+    const size_t want = bytes + bytes / 4 + 256;
+    HIP_TRY(e, hipMalloc(&e->dec.ptr[k], want));
+    e->dec.cap[k] = want;
+  }
+  *out = e->dec.ptr[k];
+  return LDP_OK;
+}
+}  // namespace
+
+// Variant records of a variable-width .pgen, decoded on the device (ldp_pgen_decode.hip) into rows of the FILE's samples and
+// loaded from there like any device-resident rows.  What the reference does per variant on its one reader thread
+// (PgrGetInv1 -> ReadGenovecSubsetUnsafe, plink2_ld.cc:1345-1390 / pgenlib_read.cc:2849-2912, 5417-5563).
+int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* bytes, uint64_t n_bytes, int location, const ldp_pgen_rec* recs,
+                          const ldp_pgen_rec* ld_base, uint32_t raw_sample_ct, uint32_t* major_allele_out) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  if (!e->planned) {
+    return fail(e, LDP_ERR_STATE, "ldp_set_variants() first");
+  }
+  if ((static_cast<uint64_t>(first_variant) + n > e->variant_ct) || (n && (!bytes || !recs)) || ((location != LDP_MEM_HOST) && (location != LDP_MEM_DEVICE))) {
+    return fail(e, LDP_ERR_INVALID, "variant range out of bounds / null input / bad location");
+  }
+  const bool mapped = !e->sample_map.empty();
+  if (mapped ? (raw_sample_ct != e->map_raw_sample_ct) : (raw_sample_ct != e->P.founder_ct)) {
+    return fail(e, LDP_ERR_INVALID, "the records' sample count is neither the engine's founder count nor the sample map's raw count");
+  }
+  if (!n) {
+    return LDP_OK;
+  }
+  // the byte span the records cover (only that much goes to the device), every record inside the buffer
+  uint64_t span_lo = UINT64_MAX, span_hi = 0;
+  auto cover = [&](const ldp_pgen_rec& r) {
+    if ((r.offset > n_bytes) || (r.length > n_bytes - r.offset)) {
+      return false;
+    }
+    span_lo = std::min<uint64_t>(span_lo, r.offset);
+    span_hi = std::max<uint64_t>(span_hi, r.offset + r.length);
+    return true;
+  };
+  bool any_multi = false, any_ld = false;
+  for (uint32_t q = 0; q < n; ++q) {
+    if (!cover(recs[q])) {
+      return fail(e, LDP_ERR_INVALID, "a record lies outside the byte buffer");
+    }
+    if ((recs[q].allele_ct < 2) || (recs[q].allele_ct > 255)) {
+      return fail(e, LDP_ERR_INVALID, "allele_ct must lie in [2, 255]");
+    }
+    any_multi = any_multi || (recs[q].allele_ct > 2);
+    const uint32_t type = recs[q].vrtype & 7u;
+    any_ld = any_ld || (type == 2) || (type == 3);
+  }
+  if (any_multi && mapped) {
+    return fail(e, LDP_ERR_UNSUPPORTED, "variants with more than one ALT allele are collapsed over the file's samples: not with a sample map (collapse them on the host, LDP_GENO_INVERSE)");
+  }
+  if (ld_base) {
+    const uint32_t type = ld_base->vrtype & 7u;
+    if ((type == 2) || (type == 3) || !cover(*ld_base)) {
+      return fail(e, LDP_ERR_INVALID, "ld_base must be a record that stands alone, inside the byte buffer");
+    }
+  }
+  int rc = ensure_device_plan(e);
+  if (rc) {
+    return rc;
+  }
+  HIP_TRY(e, hipSetDevice(e->device));
+  const uint64_t stride = ((static_cast<uint64_t>(raw_sample_ct) + 3) / 4 + 15) & ~static_cast<uint64_t>(15);
+  // ---- the bytes
+  const uint8_t* d_bytes;
+  if (location == LDP_MEM_HOST) {
+    void* p = nullptr;
+    rc = dec_reserve(e, 0, span_hi - span_lo + 16, &p);
+    if (rc) {
+      return rc;
+    }
+    HIP_TRY(e, hipMemcpyAsync(p, static_cast<const uint8_t*>(bytes) + span_lo, span_hi - span_lo, hipMemcpyHostToDevice, e->stream));
+    d_bytes = static_cast<const uint8_t*>(p) - span_lo;  // (record offsets stay as the caller gave them)
+  } else {
+    d_bytes = static_cast<const uint8_t*>(bytes);
+  }
+  if (e->ld_base_cap < stride) {
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    (void)hipFree(e->d_ld_base);
+    e->d_ld_base = nullptr;
+    e->ld_base_cap = 0;
+    e->ld_base_valid = false;
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_ld_base), stride));
+    e->ld_base_cap = stride;
+  }
+  bool have_carried = e->ld_base_valid && (e->dec_next_variant == first_variant);
+  // ---- in launches of at most ~256 MiB of rows
+  const uint32_t rows_per_launch = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / stride)));
+  std::vector<ldp::PgenRecDesc> descs;
+  std::vector<uint32_t> multi;
+  std::vector<uint8_t> h_inverse;
+  std::vector<double> h_maj_freq;
+  std::vector<uint32_t> h_maj_idx;
+  int status = LDP_OK;
+  for (uint32_t q0 = 0; (q0 < n) && (status == LDP_OK); q0 += rows_per_launch) {
+    const uint32_t cnt = std::min(rows_per_launch, n - q0);
+    const bool with_base_rec = (q0 == 0) && (ld_base != nullptr);
+    const uint32_t rows = cnt + (with_base_rec ? 1u : 0u);  // (the caller's ld_base record is decoded as an extra row behind the others)
+    descs.assign(rows, ldp::PgenRecDesc());
+    multi.clear();
+    uint32_t last_alone = with_base_rec ? cnt : (have_carried ? kPgenBaseCarried : kPgenNoBase);
+    int64_t last_alone_row = -1;
+    for (uint32_t q = 0; q < cnt; ++q) {
+      const ldp_pgen_rec& r = recs[q0 + q];
+      ldp::PgenRecDesc& d = descs[q];
+      d.off = r.offset;
+      d.len = r.length;
+      d.allele_ct = r.allele_ct;
+      d.vrtype = r.vrtype;
+      d.base = kPgenNoBase;
+      const uint32_t type = r.vrtype & 7u;
+      if ((type == 2) || (type == 3)) {
+        if (last_alone == kPgenNoBase) {
+          return fail(e, LDP_ERR_INVALID, "an LD-compressed record whose base is neither in this call, nor ld_base, nor the last record of the previous call");
+        }
+        d.base = last_alone;
+      } else {
+        last_alone = q;
+        last_alone_row = q;
+      }
+      if (r.allele_ct > 2) {
+        multi.push_back(q);
+      }
+    }
+    if (with_base_rec) {
+      ldp::PgenRecDesc& d = descs[cnt];
+      d.off = ld_base->offset;
+      d.len = ld_base->length;
+      d.allele_ct = 2;
+      d.vrtype = ld_base->vrtype;
+      d.base = kPgenNoBase;
+    }
+    void *p_recs = nullptr, *p_rows = nullptr, *p_end = nullptr, *p_multi = nullptr, *p_mf = nullptr, *p_mi = nullptr, *p_inv = nullptr;
+    if ((rc = dec_reserve(e, 1, rows * sizeof(ldp::PgenRecDesc), &p_recs)) || (rc = dec_reserve(e, 2, static_cast<size_t>(rows) * stride, &p_rows)) ||
+        (rc = dec_reserve(e, 3, rows * sizeof(uint64_t), &p_end)) || (rc = dec_reserve(e, 4, (multi.size() + 1) * sizeof(uint32_t), &p_multi)) ||
+        (rc = dec_reserve(e, 5, (multi.size() + 1) * sizeof(double), &p_mf)) || (rc = dec_reserve(e, 6, (multi.size() + 1) * sizeof(uint32_t) + sizeof(int), &p_mi)) ||
+        (rc = dec_reserve(e, 7, rows, &p_inv))) {
+      return rc;
+    }
+    int* d_err = reinterpret_cast<int*>(static_cast<uint32_t*>(p_mi) + multi.size() + 1);
+    HIP_TRY(e, hipMemcpyAsync(p_recs, descs.data(), rows * sizeof(ldp::PgenRecDesc), hipMemcpyHostToDevice, e->stream));
+    if (!multi.empty()) {
+      HIP_TRY(e, hipMemcpyAsync(p_multi, multi.data(), multi.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    }
+    HIP_TRY(e, hipMemsetAsync(d_err, 0, sizeof(int), e->stream));
+    HIP_TRY(e, hipMemsetAsync(p_inv, 0, rows, e->stream));
+    ldp::PgenDecodeArgs DA;
+    DA.bytes = d_bytes;
+    DA.recs = static_cast<const ldp::PgenRecDesc*>(p_recs);
+    DA.n = rows;
+    DA.sample_ct = raw_sample_ct;
+    DA.rows = static_cast<uint8_t*>(p_rows);
+    DA.stride = stride;
+    DA.carried_base = have_carried ? e->d_ld_base : nullptr;
+    DA.main_end = static_cast<uint64_t*>(p_end);
+    DA.error = d_err;
+    DA.pass = 0;
+    DA.any_ld = any_ld ? 1 : 0;
+    DA.multi_rec = static_cast<const uint32_t*>(p_multi);
+    DA.n_multi = static_cast<uint32_t>(multi.size());
+    DA.maj_freq = static_cast<double*>(p_mf);
+    DA.maj_idx = static_cast<uint32_t*>(p_mi);
+    DA.row_inverse = static_cast<uint8_t*>(p_inv);
+    hipError_t krc = launch_pgen_main(DA, e->stream);
+    if (krc != hipSuccess) {
+      return hipfail(e, krc, "pgen_main_kernel launch");
+    }
+    // the row the next launch's LD-compressed records may build on (taken BEFORE the multiallelic collapse rewrites rows:
+    // an LD base is the main track as stored)
+    if (last_alone_row >= 0) {
+      HIP_TRY(e, hipMemcpyAsync(e->d_ld_base, DA.rows + static_cast<uint64_t>(last_alone_row) * stride, stride, hipMemcpyDeviceToDevice, e->stream));
+      have_carried = true;
+    } else if (with_base_rec) {
+      HIP_TRY(e, hipMemcpyAsync(e->d_ld_base, DA.rows + static_cast<uint64_t>(cnt) * stride, stride, hipMemcpyDeviceToDevice, e->stream));
+      have_carried = true;
+    }
+    krc = launch_pgen_aux1(DA, e->stream);
+    if (krc != hipSuccess) {
+      return hipfail(e, krc, "pgen_aux1_kernel launch");
+    }
+    int h_err = 0;
+    h_inverse.assign(cnt, 0);
+    h_maj_freq.assign(multi.size(), 0.0);
+    h_maj_idx.assign(multi.size(), 0);
+    HIP_TRY(e, hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    if (!multi.empty()) {
+      HIP_TRY(e, hipMemcpyAsync(h_maj_freq.data(), p_mf, multi.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(e, hipMemcpyAsync(h_maj_idx.data(), p_mi, multi.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (h_err) {
+      e->ld_base_valid = false;
+      const uint32_t bad = static_cast<uint32_t>(h_err - 1);
+      return fail(e, LDP_ERR_INVALID, "malformed variant record in .pgen data (variant " + std::to_string((bad < cnt) ? (first_variant + q0 + bad) : first_variant) + ((bad < cnt) ? ")" : ": its LD base)"));
+    }
+    for (size_t k = 0; k < multi.size(); ++k) {
+      h_inverse[multi[k]] = 1;
+      if (major_allele_out) {
+        major_allele_out[q0 + multi[k]] = h_maj_idx[k];
+      }
+    }
+    if (major_allele_out) {
+      for (uint32_t q = 0; q < cnt; ++q) {
+        if (!h_inverse[q]) {
+          major_allele_out[q0 + q] = UINT32_MAX;  // one ALT allele: the count pass decides (ldp_get_variant_recs: flags bit 0)
+        }
+      }
+    }
+    status = load_rows_impl(e, first_variant + q0, cnt, DA.rows, stride, LDP_MEM_DEVICE, LDP_GENO_REF | (mapped ? LDP_GENO_MAPPED : 0), multi.empty() ? nullptr : DA.row_inverse,
+                            multi.empty() ? nullptr : h_inverse.data());
+    if (status == LDP_OK) {
+      for (size_t k = 0; k < multi.size(); ++k) {
+        const int64_t l = e->global_to_local[first_variant + q0 + multi[k]];
+        if (l >= 0) {
+          e->maj_freq[l] = h_maj_freq[k];
+          e->mf_set[l] = 1;
+        }
+      }
+    }
+  }
+  e->ld_base_valid = have_carried && (status == LDP_OK);
+  e->dec_next_variant = first_variant + n;
+  return status;
 }
 
 int ldp_map_rows(ldp_engine* e, uint32_t first_variant, uint32_t n, void** device_rows, uint64_t* stride_bytes) {

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
     rec.n_het = 0;
     rec.n_homalt = 0;
     rec.reserved = 0;
-    if ((A.encoding & 3) != LDP_GENO_INVERSE) {
+    if (((A.encoding & 3) != LDP_GENO_INVERSE) && !(A.row_inverse && A.row_inverse[v])) {
       // plink2_filter.cc:2137-2147: freq = ref * (1 / tot), 1/2 when nothing is observed;
       // major = REF iff freq >= 0.5 (plink2_common.h:559-567)
       const uint64_t ref_ct = 2ull * n0 + n1_alleles;

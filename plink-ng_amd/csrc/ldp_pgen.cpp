@@ -492,6 +492,49 @@ int ldp_pgen_info(const ldp_pgen* P, uint32_t* variant_ct, uint32_t* sample_ct, 
 
 int ldp_pgen_has_dosage(const ldp_pgen* P) { return (P && P->any_dosage) ? 1 : 0; }
 
+const void* ldp_pgen_file_bytes(const ldp_pgen* P, uint64_t* n_bytes) {
+  if (!P || !P->map) {
+    return nullptr;
+  }
+  if (n_bytes) {
+    *n_bytes = P->size;
+  }
+  return P->map;
+}
+
+int ldp_pgen_record_index(const ldp_pgen* P, uint32_t first_variant, uint32_t n, ldp_pgen_rec* out, uint32_t* ld_base_variant) {
+  if (!P || (n && !out) || (static_cast<uint64_t>(first_variant) + n > P->variant_ct)) {
+    return LDP_ERR_INVALID;
+  }
+  if (ld_base_variant) {
+    *ld_base_variant = UINT32_MAX;
+  }
+  if (P->mode == 0x01) {
+    return LDP_ERR_UNSUPPORTED;
+  }
+  const bool fixed = (P->mode == 0x02);
+  for (uint32_t q = 0; q < n; ++q) {
+    const uint32_t v = first_variant + q;
+    out[q].offset = fixed ? (P->data_off + static_cast<uint64_t>(v) * P->rec_bytes) : P->fpos[v];
+    out[q].length = static_cast<uint32_t>(fixed ? P->rec_bytes : (P->fpos[v + 1] - P->fpos[v]));
+    out[q].vrtype = fixed ? 0 : P->vrtype[v];
+    out[q].allele_ct = 2;
+    out[q].reserved = 0;
+  }
+  if (ld_base_variant && n && (!fixed) && ((P->vrtype[first_variant] & 6) == 2)) {
+    const uint32_t blk_first = (first_variant / kBlockVariants) * kBlockVariants;
+    uint32_t b = first_variant;
+    while ((b > blk_first) && ((P->vrtype[b] & 6) == 2)) {
+      --b;
+    }
+    if ((P->vrtype[b] & 6) == 2) {
+      return LDP_ERR_INVALID;  // (a block that opens with an LD-compressed record)
+    }
+    *ld_base_variant = b;
+  }
+  return LDP_OK;
+}
+
 const void* ldp_pgen_direct_rows(const ldp_pgen* P, uint64_t* stride_bytes) {
   if (!P || (P->mode != 0x01 && P->mode != 0x02)) {
     return nullptr;

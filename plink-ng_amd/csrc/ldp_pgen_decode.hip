@@ -1,0 +1,713 @@
+// ldp_pgen_decode.hip -- variant records of a variable-width .pgen file decoded ON THE DEVICE, straight from the file's bytes
+// into 2-bit genotype rows (what ReadGenovecSubsetUnsafe produces, 2.0/include/pgenlib_read.cc:2849-2912, and -- for variants
+// with more than one ALT allele -- what PgrGetInv1 produces for the major allele, pgenlib_read.cc:5417-5563).
+//
+//   pgen_main_kernel   one workgroup per record, main track: type 0 (plain 2-bit), 1 (one bit per sample + exceptions,
+//                      pgenlib_read.cc:2186-2303 Parse1or2bitGenovec / ParseOnebitUnsafe), 4 / 6 / 7 (difflist against an all-0 /
+//                      all-2 / all-missing row, :2436-2532 ParseAndApplyDifflist), 2 / 3 (difflist against the most recent
+//                      non-LD record, type 3 then inverted 0 <-> 2, :2687-2760 LdLoadAndCopyGenovecSubsetIfNecessary).  Two
+//                      launches: the records that stand alone, then the LD-compressed ones on top of their finished bases.
+//   pgen_aux1_kernel   one workgroup per variant with more than one ALT allele: auxiliary track 1 (pgen_spec.tex:469-540;
+//                      Get1Multiallelic pgenlib_read.cc:5417-5563: aux1a = REF/ALTx with x >= 2, aux1b = ALTx/ALTy other than
+//                      ALT1/ALT1, each as a bit array over the main track's category or as a sample-id list, then packed
+//                      allele codes), allele counts over the samples, the major allele in the reference's arithmetic
+//                      (plink2_filter.cc:2113-2153 freq = count * (1 / total); GetMajIdxMulti plink2_common.cc:1042-1070;
+//                      GetAlleleFreq plink2_common.h:584-593), and the row rewritten as copies of NON-major alleles.
+//
+// A difflist (pgen_spec.tex:367-430) is entries in groups of 64: per group the first sample id, per group but the last the
+// byte size of its delta stream, [2-bit values for all entries,] then the varint deltas.  The groups are independent once the
+// sizes are summed, so a workgroup's threads each take a run of groups; entries touch distinct samples, so their 2-bit fields
+// go in with atomics on the row's dwords.  Malformed input never reads outside the record: every byte access is checked
+// against the record's end, and a violation raises the launch's error word (1 + record index) instead of a row.
+#include "ldp_device.h"
+#include "ldp_pair_device.h"
+
+namespace ldp {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct ByteCursor {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool ok;
+  __device__ __forceinline__ uint32_t u8() {
+    if (p >= end) {
+      ok = false;
+      return 0;
+    }
+    return *p++;
+  }
+  __device__ __forceinline__ uint32_t varint() {
+    uint32_t v = 0;
+    for (int shift = 0; shift < 35; shift += 7) {
+      const uint32_t b = u8();
+      if (!ok) {
+        return 0;
+      }
+      v |= (b & 0x7fu) << shift;
+      if (!(b & 0x80u)) {
+        return v;
+      }
+    }
+    ok = false;
+    return 0;
+  }
+  __device__ __forceinline__ bool skip(uint64_t n) {
+    if (static_cast<uint64_t>(end - p) < n) {
+      ok = false;
+      return false;
+    }
+    p += n;
+    return true;
+  }
+};
+
+__device__ __forceinline__ uint32_t id_width(uint32_t sample_ct) { return (sample_ct <= 256) ? 1 : ((sample_ct <= 65536) ? 2 : ((sample_ct <= 16777216) ? 3 : 4)); }
+
+__device__ __forceinline__ uint32_t read_le(const uint8_t* p, uint32_t nbytes) {
+  uint32_t v = 0;
+  for (uint32_t k = 0; k < nbytes; ++k) {
+    v |= static_cast<uint32_t>(p[k]) << (8 * k);
+  }
+  return v;
+}
+
+// dword d of a byte string of nbytes (bytes past the end read as zero)
+__device__ __forceinline__ uint32_t dword_of_bytes(const uint8_t* p, uint64_t nbytes, uint64_t d) {
+  const uint64_t off = d * 4;
+  uint32_t w = 0;
+  for (uint32_t k = 0; k < 4; ++k) {
+    if (off + k < nbytes) {
+      w |= static_cast<uint32_t>(p[off + k]) << (8 * k);
+    }
+  }
+  return w;
+}
+
+// the 16 low bits of x -> the even bit positions of a dword
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {
+  uint32_t t = x & 0xffffu;
+  t = (t | (t << 8)) & 0x00ff00ffu;
+  t = (t | (t << 4)) & 0x0f0f0f0fu;
+  t = (t | (t << 2)) & 0x33333333u;
+  t = (t | (t << 1)) & 0x55555555u;
+  return t;
+}
+
+__device__ __forceinline__ void set_field(uint32_t* row, uint32_t sample, uint32_t code) {
+  const uint32_t sh = 2 * (sample & 15);
+  atomicAnd(row + (sample >> 4), ~(3u << sh));
+  atomicOr(row + (sample >> 4), code << sh);
+}
+
+// exclusive prefix of one number per thread (and the total), through LDS
+__device__ __forceinline__ uint32_t block_exclusive(uint32_t mine, uint32_t* s_tmp, uint32_t tid, uint32_t* total) {
+  __syncthreads();  // (s_tmp may still be read from the previous use)
+  s_tmp[tid] = mine;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+  for (uint32_t t = 0; t < kThreads; ++t) {
+    const uint32_t x = s_tmp[t];
+    before += (t < tid) ? x : 0;
+    all += x;
+  }
+  *total = all;
+  return before;
+}
+
+// The header of a difflist, parsed by every thread; the thread's share of the groups and where its delta bytes start.
+struct Difflist {
+  uint32_t L, G, idw;
+  const uint8_t* first_ids;
+  const uint8_t* sizes;
+  const uint8_t* vals;  // nullptr: ids only
+  const uint8_t* deltas;
+  uint32_t g0, g1;      // this thread's groups
+  const uint8_t* mine;  // its first delta byte
+};
+
+// false: malformed (or L == 0: then c.p is the list's end and D.L == 0)
+__device__ __forceinline__ bool difflist_open(ByteCursor& c, uint32_t sample_ct, bool with_values, uint32_t* s_tmp, uint32_t tid, Difflist* D) {
+  D->L = c.varint();
+  D->G = 0;
+  D->g0 = D->g1 = 0;
+  if ((!c.ok) || (D->L > sample_ct)) {
+    c.ok = false;
+    return false;
+  }
+  if (!D->L) {
+    return true;
+  }
+  D->G = (D->L + 63) / 64;
+  D->idw = id_width(sample_ct);
+  D->first_ids = c.p;
+  if (!c.skip(static_cast<uint64_t>(D->G) * D->idw)) {
+    return false;
+  }
+  D->sizes = c.p;
+  if (!c.skip(D->G - 1)) {
+    return false;
+  }
+  D->vals = nullptr;
+  if (with_values) {
+    D->vals = c.p;
+    if (!c.skip((D->L + 3) / 4)) {
+      return false;
+    }
+  }
+  D->deltas = c.p;
+  const uint32_t gpt = (D->G + kThreads - 1) / kThreads;
+  D->g0 = (tid * gpt < D->G) ? tid * gpt : D->G;
+  D->g1 = (D->g0 + gpt < D->G) ? D->g0 + gpt : D->G;
+  uint32_t bytes = 0;
+  for (uint32_t g = D->g0; g < D->g1; ++g) {
+    if (g + 1 < D->G) {
+      bytes += static_cast<uint32_t>(D->sizes[g]) + 63u;
+    }
+  }
+  uint32_t total;
+  const uint32_t before = block_exclusive(bytes, s_tmp, tid, &total);
+  if (static_cast<uint64_t>(c.end - D->deltas) < total) {
+    c.ok = false;
+    return false;
+  }
+  D->mine = D->deltas + before;
+  return true;
+}
+
+// f(sample id, entry index) for the entries of this thread's groups.  Returns false on malformed input.  *list_end (written by
+// the thread that owns the last group) = first byte behind the list.
+template <class F>
+__device__ __forceinline__ bool difflist_walk(const Difflist& D, const uint8_t* rec_end, uint32_t sample_ct, const uint8_t** list_end, F f) {
+  ByteCursor q{D.mine, rec_end, true};
+  for (uint32_t g = D.g0; g < D.g1; ++g) {
+    uint32_t id = read_le(D.first_ids + static_cast<uint64_t>(g) * D.idw, D.idw);
+    const uint32_t k0 = g * 64;
+    const uint32_t kend = (D.L < k0 + 64) ? D.L : (k0 + 64);
+    const uint8_t* gstart = q.p;
+    for (uint32_t k = k0; k < kend; ++k) {
+      if (k != k0) {
+        id += q.varint();
+        if (!q.ok) {
+          return false;
+        }
+      }
+      if (id >= sample_ct) {
+        return false;
+      }
+      f(id, k);
+    }
+    if (g + 1 < D.G) {
+      if (static_cast<uint32_t>(q.p - gstart) != static_cast<uint32_t>(D.sizes[g]) + 63u) {
+        return false;  // (the size bytes are what lets the groups be read independently: they have to be right)
+      }
+    } else {
+      *list_end = q.p;
+    }
+  }
+  return true;
+}
+
+__device__ __forceinline__ uint32_t packed_get(const uint8_t* base, uint64_t idx, uint32_t width_bits) {
+  if (!width_bits) {
+    return 0;
+  }
+  if (width_bits == 8) {
+    return base[idx];
+  }
+  const uint64_t bit = idx * width_bits;
+  return (static_cast<uint32_t>(base[bit >> 3]) >> (bit & 7)) & ((1u << width_bits) - 1u);
+}
+
+__global__ __launch_bounds__(kThreads) void pgen_main_kernel(PgenDecodeArgs A) {
+  __shared__ uint32_t s_tmp[kThreads];
+  __shared__ int s_bad;
+  const uint32_t v = blockIdx.x;
+  const PgenRecDesc R = A.recs[v];
+  const uint32_t type = R.vrtype & 7u;
+  const bool is_ld = (type == 2) || (type == 3);
+  if (is_ld != (A.pass == 1)) {
+    return;
+  }
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) {
+    s_bad = 0;
+  }
+  uint32_t* out = reinterpret_cast<uint32_t*>(A.rows + static_cast<uint64_t>(v) * A.stride);
+  const uint32_t row_dwords = static_cast<uint32_t>(A.stride / 4);
+  const uint32_t n = A.sample_ct;
+  const uint64_t nb = (static_cast<uint64_t>(n) + 3) / 4;
+  ByteCursor c{A.bytes + R.off, A.bytes + R.off + R.len, true};
+  bool bad = false;
+  bool has_list = false;
+  switch (type) {
+    case 0:
+      if (R.len < nb) {
+        bad = true;
+        break;
+      }
+      for (uint32_t d = tid; d < row_dwords; d += kThreads) {
+        out[d] = dword_of_bytes(c.p, nb, d);
+      }
+      c.p += nb;
+      break;
+    case 1: {
+      // one bit per sample: byte 0 = 4 * low code + (high - low); a set bit = the high code (pgen_spec.tex:437-452)
+      const uint32_t code = c.u8();
+      const uint32_t low = code >> 2;
+      const uint32_t high = low + (code & 3u);
+      const uint64_t bit_bytes = (static_cast<uint64_t>(n) + 7) / 8;
+      if ((!c.ok) || (high > 3) || (high == low) || (static_cast<uint64_t>(c.end - c.p) < bit_bytes)) {
+        bad = true;
+        break;
+      }
+      for (uint32_t d = tid; d < row_dwords; d += kThreads) {
+        uint32_t bits = 0;
+        if (2ull * d < bit_bytes) {
+          bits = c.p[2ull * d];
+          if (2ull * d + 1 < bit_bytes) {
+            bits |= static_cast<uint32_t>(c.p[2ull * d + 1]) << 8;
+          }
+        }
+        out[d] = low * 0x55555555u + spread16(bits) * (high - low);
+      }
+      c.p += bit_bytes;
+      has_list = true;
+      break;
+    }
+    case 2:
+    case 3: {
+      const uint32_t* base = nullptr;
+      if (R.base == kPgenBaseCarried) {
+        base = reinterpret_cast<const uint32_t*>(A.carried_base);
+      } else if (R.base < A.n) {
+        base = reinterpret_cast<const uint32_t*>(A.rows + static_cast<uint64_t>(R.base) * A.stride);
+      }
+      if (!base) {
+        bad = true;
+        break;
+      }
+      for (uint32_t d = tid; d < row_dwords; d += kThreads) {
+        out[d] = base[d];
+      }
+      has_list = true;
+      break;
+    }
+    case 4:
+    case 6:
+    case 7: {
+      const uint32_t fill = ((type == 4) ? 0u : ((type == 6) ? 2u : 3u)) * 0x55555555u;
+      for (uint32_t d = tid; d < row_dwords; d += kThreads) {
+        out[d] = fill;
+      }
+      has_list = true;
+      break;
+    }
+    default:  // 5: reserved; the reference decodes it as all hom-REF (pgenlib_read.cc:2740-2742)
+      for (uint32_t d = tid; d < row_dwords; d += kThreads) {
+        out[d] = 0;
+      }
+      break;
+  }
+  __syncthreads();  // (the row's plain stores are visible to the workgroup's atomics; s_bad is initialised)
+  const uint8_t* main_end = c.p;
+  bool owns_end = (tid == 0);
+  if (has_list && !bad) {
+    Difflist D;
+    if (!difflist_open(c, n, true, s_tmp, tid, &D)) {
+      bad = true;
+    } else if (D.L) {
+      owns_end = (D.g0 < D.g1) && (D.g1 == D.G);
+      const uint8_t* vals = D.vals;
+      if (!difflist_walk(D, c.end, n, &main_end, [&](uint32_t id, uint32_t k) { set_field(out, id, (static_cast<uint32_t>(vals[k >> 2]) >> (2 * (k & 3))) & 3u); })) {
+        bad = true;
+      }
+    } else {
+      main_end = c.p;
+    }
+  }
+  if (bad) {
+    s_bad = 1;
+  }
+  __syncthreads();
+  if (s_bad) {
+    if (tid == 0) {
+      atomicCAS(A.error, 0, static_cast<int>(v) + 1);
+    }
+    return;
+  }
+  if (owns_end) {
+    A.main_end[v] = static_cast<uint64_t>(main_end - A.bytes);
+  }
+  // 0 <-> 2 for type 3 (GenovecInvertUnsafe), then the bits behind the last sample are cleared whatever the record said
+  for (uint32_t d = tid; d < row_dwords; d += kThreads) {
+    uint32_t w = out[d];
+    if (type == 3) {
+      w ^= ((~w) << 1) & 0xaaaaaaaau;
+    }
+    const uint64_t s0 = 16ull * d;
+    if (s0 >= n) {
+      w = 0;
+    } else if (s0 + 16 > n) {
+      w &= (1u << (2 * (n - static_cast<uint32_t>(s0)))) - 1u;
+    }
+    out[d] = w;
+  }
+}
+
+// ---- auxiliary track 1 ------------------------------------------------------------------------------------------
+// One patch set of the track (category 1: the main track's code-1 samples, REF/ALT1 -> REF/ALTx; category 2: its code-2
+// samples, ALT1/ALT1 -> ALTx/ALTy), located and ready to be walked by the workgroup.
+struct PatchSet {
+  uint32_t fmt;           // 0 bit array over the category's samples, 1 sample-id list, 15 none
+  const uint8_t* bits;    // fmt 0
+  uint32_t k_first;       // fmt 0: index (within the category) of this thread's first category sample ...
+  uint32_t rank_first;    // ... and how many patched samples precede it
+  Difflist D;             // fmt 1
+  uint32_t patched;       // entries
+  const uint8_t* vals;    // the packed allele codes behind the set
+};
+
+struct Alleles {
+  uint32_t lo, hi;
+};
+
+__device__ __forceinline__ Alleles patch_alleles(const PatchSet& S, uint32_t cat, uint32_t allele_ct, uint32_t idx) {
+  const uint32_t alt_ct = allele_ct - 1;
+  Alleles a;
+  if (cat == 1) {
+    const uint32_t w = (alt_ct == 2) ? 0u : ((alt_ct == 3) ? 1u : ((alt_ct <= 5) ? 2u : ((alt_ct <= 17) ? 4u : 8u)));
+    a.lo = 0;
+    a.hi = 2 + packed_get(S.vals, idx, w);
+  } else if (alt_ct == 2) {
+    const uint32_t both = (static_cast<uint32_t>(S.vals[idx >> 3]) >> (idx & 7)) & 1u;
+    a.lo = both ? 2u : 1u;
+    a.hi = 2;
+  } else {
+    const uint32_t w = (alt_ct <= 4) ? 2u : ((alt_ct <= 16) ? 4u : 8u);
+    a.lo = 1 + packed_get(S.vals, 2ull * idx, w);
+    a.hi = 1 + packed_get(S.vals, 2ull * idx + 1, w);
+  }
+  return a;
+}
+
+__device__ __forceinline__ uint64_t patch_value_bytes(uint32_t cat, uint32_t allele_ct, uint32_t patched) {
+  const uint32_t alt_ct = allele_ct - 1;
+  if (cat == 1) {
+    const uint32_t w = (alt_ct == 2) ? 0u : ((alt_ct == 3) ? 1u : ((alt_ct <= 5) ? 2u : ((alt_ct <= 17) ? 4u : 8u)));
+    return (static_cast<uint64_t>(patched) * w + 7) / 8;
+  }
+  if (alt_ct == 2) {
+    return (static_cast<uint64_t>(patched) + 7) / 8;
+  }
+  const uint32_t w = (alt_ct <= 4) ? 2u : ((alt_ct <= 16) ? 4u : 8u);
+  return (static_cast<uint64_t>(patched) * 2 * w + 7) / 8;
+}
+
+// category mask of a dword of main-track codes: bit 2 s set iff sample s has code `cat` (1 or 2)
+__device__ __forceinline__ uint32_t cat_mask(uint32_t w, uint32_t cat) {
+  const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
+  return (cat == 1) ? (lo & ~hi) : (hi & ~lo);
+}
+
+__global__ __launch_bounds__(kThreads) void pgen_aux1_kernel(PgenDecodeArgs A) {
+  __shared__ uint32_t s_tmp[kThreads];
+  __shared__ int s_cnt[256];
+  __shared__ int s_bad;
+  __shared__ const uint8_t* s_ptr;
+  __shared__ uint32_t s_maj;
+  const uint32_t m = blockIdx.x;
+  const uint32_t v = A.multi_rec[m];
+  const PgenRecDesc R = A.recs[v];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n = A.sample_ct;
+  const uint32_t allele_ct = R.allele_ct;
+  uint32_t* row = reinterpret_cast<uint32_t*>(A.rows + static_cast<uint64_t>(v) * A.stride);
+  const uint32_t n_dwords = (n + 15) / 16;
+  const uint32_t dpt = (n_dwords + kThreads - 1) / kThreads;
+  const uint32_t d0 = (tid * dpt < n_dwords) ? tid * dpt : n_dwords;
+  const uint32_t d1 = (d0 + dpt < n_dwords) ? d0 + dpt : n_dwords;
+  if (tid == 0) {
+    s_bad = 0;
+  }
+  s_cnt[tid] = 0;
+  // ---- the main track's categories: counts, and each thread's rank among them
+  uint32_t my1 = 0, my2 = 0, my3 = 0;
+  for (uint32_t d = d0; d < d1; ++d) {
+    const uint32_t w = row[d];
+    my1 += __popc(cat_mask(w, 1));
+    my2 += __popc(cat_mask(w, 2));
+    my3 += __popc(w & (w >> 1) & 0x55555555u);
+  }
+  uint32_t n1, n2, n3;
+  const uint32_t pre1 = block_exclusive(my1, s_tmp, tid, &n1);
+  const uint32_t pre2 = block_exclusive(my2, s_tmp, tid, &n2);
+  (void)block_exclusive(my3, s_tmp, tid, &n3);
+  const uint32_t n0 = n - n1 - n2 - n3;
+  bool bad = (allele_ct < 3) || (allele_ct > 255);
+  // ---- locate the two patch sets
+  PatchSet S[2];
+  S[0].fmt = S[1].fmt = 15;
+  S[0].patched = S[1].patched = 0;
+  const uint8_t* rec_end = A.bytes + R.off + R.len;
+  if ((R.vrtype & 8u) && !bad) {
+    ByteCursor c{A.bytes + A.main_end[v], rec_end, true};
+    const uint32_t fmt = c.u8();
+    bad = !c.ok;
+    for (uint32_t cat = 1; (cat <= 2) && !bad; ++cat) {
+      PatchSet& P = S[cat - 1];
+      P.fmt = (cat == 1) ? (fmt & 15u) : (fmt >> 4);
+      const uint32_t ncat = (cat == 1) ? n1 : n2;
+      const uint32_t pre = (cat == 1) ? pre1 : pre2;
+      const uint32_t mine = (cat == 1) ? my1 : my2;
+      if (P.fmt == 15) {
+        continue;
+      }
+      if (P.fmt == 0) {
+        P.bits = c.p;
+        if (!c.skip((static_cast<uint64_t>(ncat) + 7) / 8)) {
+          bad = true;
+          break;
+        }
+        uint32_t set = 0;
+        for (uint32_t k = pre; k < pre + mine; ++k) {
+          set += (static_cast<uint32_t>(P.bits[k >> 3]) >> (k & 7)) & 1u;
+        }
+        P.k_first = pre;
+        P.rank_first = block_exclusive(set, s_tmp, tid, &P.patched);
+      } else if (P.fmt == 1) {
+        if (!difflist_open(c, n, false, s_tmp, tid, &P.D)) {
+          bad = true;
+          break;
+        }
+        P.patched = P.D.L;
+        if (P.D.L) {
+          // where the list ends only the walk of its last group tells
+          const uint8_t* list_end = nullptr;
+          const bool last = (P.D.g0 < P.D.g1) && (P.D.g1 == P.D.G);
+          Difflist tail = P.D;
+          bool walked = true;
+          if (last) {
+            // this thread's earlier groups have known sizes: skip to the last one
+            for (uint32_t g = tail.g0; g + 1 < tail.g1; ++g) {
+              tail.mine += static_cast<uint32_t>(tail.sizes[g]) + 63u;
+            }
+            tail.g0 = tail.g1 - 1;
+            walked = difflist_walk(tail, rec_end, n, &list_end, [](uint32_t, uint32_t) {});
+          }
+          __syncthreads();
+          if (last) {
+            s_ptr = walked ? list_end : nullptr;
+          }
+          __syncthreads();
+          if (!s_ptr) {
+            bad = true;
+            break;
+          }
+          c.p = s_ptr;
+        }
+      } else {
+        bad = true;  // reserved format
+        break;
+      }
+      P.vals = c.p;
+      if (!c.skip(patch_value_bytes(cat, allele_ct, P.patched))) {
+        bad = true;
+      }
+    }
+  }
+  if (bad) {
+    s_bad = 1;
+  }
+  __syncthreads();
+  if (s_bad) {
+    if (tid == 0) {
+      atomicCAS(A.error, 0, static_cast<int>(v) + 1);
+    }
+    return;
+  }
+  // f(sample, category, alleles) over this thread's share of the patches of both sets; `codes` = the main-track dword of the
+  // sample for the bit-array form (its own), looked up for the list form
+  auto for_each_patch = [&](bool lists, auto f) -> bool {
+    bool ok = true;
+    for (uint32_t cat = 1; cat <= 2; ++cat) {
+      const PatchSet& P = S[cat - 1];
+      if ((P.fmt == 1) && lists && P.D.L) {
+        const uint8_t* unused = nullptr;
+        ok = difflist_walk(P.D, rec_end, n, &unused, [&](uint32_t id, uint32_t k) { f(id, cat, patch_alleles(P, cat, allele_ct, k)); }) && ok;
+      }
+    }
+    return ok;
+  };
+  // ---- pass 1: allele counts.  Main track: 2 n0 + n1 REF copies, n1 + 2 n2 ALT1 copies; a category-1 patch turns one ALT1
+  // copy into ALTx, a category-2 patch turns two into ALTx + ALTy.
+  auto count_patch = [&](uint32_t /*sample*/, uint32_t cat, Alleles a) {
+    if ((a.hi >= allele_ct) || (a.lo >= allele_ct)) {
+      s_bad = 1;
+      return;
+    }
+    if (cat == 1) {
+      atomicAdd(&s_cnt[1], -1);
+      atomicAdd(&s_cnt[a.hi], 1);
+    } else {
+      atomicAdd(&s_cnt[1], -2);
+      atomicAdd(&s_cnt[a.lo], 1);
+      atomicAdd(&s_cnt[a.hi], 1);
+    }
+  };
+  // bit-array sets: the thread's own dwords, samples in order
+  auto walk_bits = [&](uint32_t d, uint32_t w, uint32_t (&k)[2], uint32_t (&rank)[2], auto f) {
+    for (uint32_t cat = 1; cat <= 2; ++cat) {
+      const PatchSet& P = S[cat - 1];
+      if (P.fmt != 0) {
+        continue;
+      }
+      uint32_t mask = cat_mask(w, cat);
+      while (mask) {
+        const uint32_t b = __builtin_ctz(mask);
+        mask &= mask - 1;
+        const uint32_t kk = k[cat - 1]++;
+        if ((static_cast<uint32_t>(P.bits[kk >> 3]) >> (kk & 7)) & 1u) {
+          f(16 * d + (b >> 1), cat, patch_alleles(P, cat, allele_ct, rank[cat - 1]++));
+        }
+      }
+    }
+  };
+  {
+    uint32_t k[2] = {S[0].k_first, S[1].k_first}, rank[2] = {S[0].rank_first, S[1].rank_first};
+    for (uint32_t d = d0; d < d1; ++d) {
+      walk_bits(d, row[d], k, rank, count_patch);
+    }
+    // list sets: the sample must be in the set's category (checked while the row still holds the main track)
+    const bool ok = for_each_patch(true, [&](uint32_t id, uint32_t cat, Alleles a) {
+      const uint32_t code = (row[id >> 4] >> (2 * (id & 15))) & 3u;
+      if (code != cat) {
+        s_bad = 1;
+      }
+      count_patch(id, cat, a);
+    });
+    if (!ok) {
+      s_bad = 1;
+    }
+  }
+  __syncthreads();
+  if (s_bad) {
+    if (tid == 0) {
+      atomicCAS(A.error, 0, static_cast<int>(v) + 1);
+    }
+    return;
+  }
+  if (tid == 0) {
+    // ComputeAlleleFreqs (plink2_filter.cc:2113-2153): freq[a] = count[a] * (1 / total) for all alleles but the last, 1 / k each
+    // when nothing is observed; GetMajIdxMulti (plink2_common.cc:1042-1070); GetAlleleFreq (plink2_common.h:584-593)
+    const uint64_t c_ref = 2ull * n0 + n1;
+    const int64_t c_alt1 = static_cast<int64_t>(n1) + 2ll * n2 + s_cnt[1];
+    auto count_of = [&](uint32_t a) -> uint64_t { return (a == 0) ? c_ref : ((a == 1) ? static_cast<uint64_t>(c_alt1) : static_cast<uint64_t>(s_cnt[a])); };
+    const uint64_t tot = 2ull * (static_cast<uint64_t>(n0) + n1 + n2);
+    const double tot_recip = tot ? __ddiv_rn(1.0, static_cast<double>(tot)) : 0.0;
+    const double none = __ddiv_rn(1.0, static_cast<double>(allele_ct));
+    auto freq_of = [&](uint32_t a) -> double { return tot ? __dmul_rn(static_cast<double>(count_of(a)), tot_recip) : none; };
+    uint32_t maj;
+    const double ref_freq = freq_of(0);
+    if (ref_freq >= 0.5) {
+      maj = 0;
+    } else {
+      const double alt1_freq = freq_of(1);
+      if (alt1_freq >= 0.5) {
+        maj = 1;
+      } else {
+        maj = 1;
+        double max_freq = alt1_freq;
+        if (ref_freq >= alt1_freq) {
+          maj = 0;
+          max_freq = ref_freq;
+        }
+        double tot_nonlast = __dadd_rn(ref_freq, alt1_freq);
+        for (uint32_t a = 2; a + 1 < allele_ct; ++a) {
+          const double f = freq_of(a);
+          if (f > max_freq) {
+            maj = a;
+            max_freq = f;
+          }
+          tot_nonlast = __dadd_rn(tot_nonlast, f);
+        }
+        if (__dadd_rn(max_freq, tot_nonlast) < 1.0 - kSmallEpsilon) {
+          maj = allele_ct - 1;
+        }
+      }
+    }
+    double mf;
+    if (maj + 1 < allele_ct) {
+      mf = freq_of(maj);
+    } else {
+      double last = __dsub_rn(1.0, freq_of(0));
+      for (uint32_t a = 1; a + 1 < allele_ct; ++a) {
+        last = __dsub_rn(last, freq_of(a));
+      }
+      mf = (last > 0.0) ? last : 0.0;
+    }
+    s_maj = maj;
+    A.maj_idx[m] = maj;
+    A.maj_freq[m] = mf;
+    A.row_inverse[v] = 1;
+  }
+  __syncthreads();
+  const uint32_t maj = s_maj;
+  if (maj == 0) {
+    return;  // REF is the major allele: the main track already counts the copies of the others
+  }
+  // ---- pass 2: the row as copies of non-major alleles.  Main-track codes first (major = ALT1: 2 - code; a later ALT: every
+  // call is two non-major copies), then the patched samples.
+  auto code_of = [&](Alleles a) -> uint32_t { return 2u - ((a.lo == maj) ? 1u : 0u) - ((a.hi == maj) ? 1u : 0u); };
+  {
+    uint32_t k[2] = {S[0].k_first, S[1].k_first}, rank[2] = {S[0].rank_first, S[1].rank_first};
+    for (uint32_t d = d0; d < d1; ++d) {
+      const uint32_t w = row[d];
+      uint32_t t;
+      if (maj == 1) {
+        t = w ^ (((~w) << 1) & 0xaaaaaaaau);
+      } else {
+        t = 0xaaaaaaaau | (w & (w >> 1) & 0x55555555u);
+      }
+      walk_bits(d, w, k, rank, [&](uint32_t sample, uint32_t /*cat*/, Alleles a) {
+        const uint32_t sh = 2 * (sample & 15);
+        t = (t & ~(3u << sh)) | (code_of(a) << sh);
+      });
+      const uint64_t s0 = 16ull * d;
+      if (s0 + 16 > n) {
+        t &= (1u << (2 * (n - static_cast<uint32_t>(s0)))) - 1u;
+      }
+      row[d] = t;
+    }
+  }
+  __syncthreads();
+  (void)for_each_patch(true, [&](uint32_t id, uint32_t /*cat*/, Alleles a) { set_field(row, id, code_of(a)); });
+}
+
+}  // namespace
+
+hipError_t launch_pgen_main(const PgenDecodeArgs& a, hipStream_t stream) {
+  if (!a.n) {
+    return hipSuccess;
+  }
+  PgenDecodeArgs p = a;
+  p.pass = 0;
+  hipLaunchKernelGGL(pgen_main_kernel, dim3(a.n), dim3(kThreads), 0, stream, p);
+  if (a.any_ld) {
+    p.pass = 1;
+    hipLaunchKernelGGL(pgen_main_kernel, dim3(a.n), dim3(kThreads), 0, stream, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_pgen_aux1(const PgenDecodeArgs& a, hipStream_t stream) {
+  if (!a.n_multi) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(pgen_aux1_kernel, dim3(a.n_multi), dim3(kThreads), 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace ldp

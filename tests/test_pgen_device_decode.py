@@ -1,0 +1,253 @@
+"""ldp_load_pgen_records: variant records of a variable-width .pgen decoded on the device (ldp_pgen_decode.hip) -- every
+main-track record type, LD-compressed chains across calls, auxiliary track 1 with the major-vs-rest collapse -- against the
+host reader (itself pinned to the reference's writer and to VCF input in test_pgen_reader.py) and against numpy restatements of
+Get1Multiallelic / GetMajIdxMulti.  Rows are compared bit for bit (ldp_get_planes), records and major-allele frequencies
+exactly, and the prune set with the one of the same rows loaded from host memory."""
+import os
+
+import numpy as np
+import pytest
+
+import ldtools as T
+from test_pgen_reader import GOLD, codes, make_multiallelic_vcf, structured_codes
+
+pytestmark = pytest.mark.gpu
+
+
+def positions(m, spacing=1000):
+    return np.zeros(m, dtype=np.uint32), (np.arange(m, dtype=np.uint32) + 1) * spacing
+
+
+def engine(pkg, n, m, window=40, r2=0.3):
+    eng = pkg.LdPruneEngine(n, window, 1, False, r2, order=2, device=0)
+    chr_idx, bps = positions(m)
+    eng.set_variants(chr_idx, bps)
+    return eng
+
+
+def assert_same_rows(a, b, m):
+    ra, rb = a.variant_recs(), b.variant_recs()
+    for name in ("nm_ct", "sum", "ssq", "flags", "n_homref", "n_het", "n_homalt"):
+        assert np.array_equal(ra[name], rb[name]), name
+    for v in range(m):
+        ha, xa = a.planes(v)
+        hb, xb = b.planes(v)
+        assert np.array_equal(ha, hb) and np.array_equal(xa, xb), v
+    assert np.array_equal(a.maj_freqs(), b.maj_freqs())
+
+
+def test_committed_variable_width_file(gpu_pkg):
+    pkg = gpu_pkg
+    f = pkg.PgenFile(os.path.join(GOLD, "varwidth_small.pgen"))
+    z = np.load(os.path.join(GOLD, "varwidth_small_codes.npz"))
+    m, n = f.variant_ct, f.sample_ct
+    want = T.unpack_2bit(z["raw_packed"].reshape(int(z["m"]), -1).view(np.uint64), int(z["n"]))
+    rows = f.read()
+    assert np.array_equal(codes(rows, n), want)
+    host = engine(pkg, n, m)
+    host.load_genotypes_host(0, rows, pkg.LDP_GENO_REF)
+    dev = engine(pkg, n, m)
+    maj = dev.load_pgen_records(0, f)
+    assert np.all(maj == 0xffffffff)
+    assert_same_rows(host, dev, m)
+    assert np.array_equal(host.run(), dev.run())
+    f.close()
+
+
+@pytest.mark.skipif(not T.have_ref(), reason="reference binary not built")
+@pytest.mark.parametrize("m,n,seed", [(400, 50, 1), (900, 300, 2), (3000, 1237, 5), (300, 70000, 4)])
+def test_every_record_type_of_the_reference_writer(gpu_pkg, tmp_path, m, n, seed):
+    pkg = gpu_pkg
+    raw = structured_codes(m, n, seed)
+    T.write_pgen_fixed(str(tmp_path / "f"), raw, ["1"] * m, np.arange(m) + 1)
+    cp = T.run_ref(["--pfile", "f", "--make-pgen", "--out", "v"], str(tmp_path))
+    assert cp.returncode == 0, cp.stdout
+    f = pkg.PgenFile(str(tmp_path / "v.pgen"))
+    assert f.mode == 0x10
+    recs, _ = f.record_index()
+    types = {int(recs[q].vrtype) & 7 for q in range(m)}
+    assert types & {2, 3} and types & {4, 6, 7} and (1 in types), types   # (LD-compressed, difflist and one-bit records are all there)
+    rows = f.read(threads=4)
+    host = engine(pkg, n, m)
+    host.load_genotypes_host(0, rows, pkg.LDP_GENO_REF)
+    # one call
+    dev = engine(pkg, n, m)
+    dev.load_pgen_records(0, f)
+    assert_same_rows(host, dev, m)
+    # several calls that cut LD chains: the engine carries the base over
+    dev2 = engine(pkg, n, m)
+    cuts = [0, 1, 7, m // 3, m // 3 + 1, (2 * m) // 3, m]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        dev2.load_pgen_records(a, f, a, b - a)
+    assert_same_rows(host, dev2, m)
+    # a call that starts inside a chain without its predecessor: ld_base names the record
+    ld = [q for q in range(1, m) if (int(recs[q].vrtype) & 6) == 2 and (int(recs[q - 1].vrtype) & 6) == 2]
+    if ld:
+        q = ld[len(ld) // 2]
+        dev3 = engine(pkg, n, m)
+        dev3.load_pgen_records(q, f, q, m - q)
+        dev3.load_pgen_records(0, f, 0, q)
+        assert_same_rows(host, dev3, m)
+    # the file's bytes already on the device
+    import torch
+    ptr, nbytes = f.file_bytes()
+    buf = torch.from_numpy(np.ctypeslib.as_array((pkg.ctypes.c_uint8 * nbytes).from_address(ptr)).copy()).cuda()
+    dev4 = engine(pkg, n, m)
+    dev4.load_pgen_records(0, f, location=pkg.LDP_MEM_DEVICE, device_bytes=buf.data_ptr())
+    assert_same_rows(host, dev4, m)
+    assert np.array_equal(host.run(), dev4.run())
+    f.close()
+
+
+def collapse(lo, hi, alt_ct):
+    """Get1Multiallelic + GetMajIdxMulti in numpy: (INVERSE-coded codes, major allele, its frequency) of one variant."""
+    called = lo != 255
+    cnt = np.zeros(alt_ct + 1, dtype=np.int64)
+    np.add.at(cnt, lo[called], 1)
+    np.add.at(cnt, hi[called], 1)
+    maj, mf = T.major_allele_multi(cnt)
+    c = np.where(called, (lo != maj).astype(np.uint8) + (hi != maj).astype(np.uint8), 3).astype(np.uint8)
+    return c, maj, mf
+
+
+@pytest.mark.skipif(not T.have_ref(), reason="reference binary not built")
+@pytest.mark.parametrize("m,n,seed,max_alt", [(120, 90, 1, 2), (150, 300, 2, 5), (80, 70, 3, 17), (60, 40, 4, 18), (60, 5000, 6, 4), (40, 3000, 7, 2)])
+def test_multiallelic_records_are_collapsed_on_the_device(gpu_pkg, tmp_path, m, n, seed, max_alt):
+    pkg = gpu_pkg
+    alt_ct, lo, hi = make_multiallelic_vcf(str(tmp_path / "m.vcf"), m, n, seed, max_alt=max_alt, missing=0.03 if n < 1000 else 0.002)
+    if n >= 1000:
+        # rare third alleles: the patch sets become sample-id lists instead of bit arrays
+        rng = np.random.default_rng(seed)
+        with open(str(tmp_path / "m.vcf")) as fh:
+            lines = fh.read().split("\n")
+        out = []
+        v = 0
+        for line in lines:
+            if line.startswith("#") or not line:
+                out.append(line)
+                continue
+            parts = line.split("\t")
+            k = int(alt_ct[v])
+            if k >= 2 and v % 2 == 0:
+                l = np.where(rng.random(n) < 0.3, 1, 0).astype(np.uint8)
+                h = np.maximum(l, np.where(rng.random(n) < 0.3, 1, 0)).astype(np.uint8)
+                l, h = np.minimum(l, h), np.maximum(l, h)
+                rare = rng.choice(n, size=7, replace=False)
+                h[rare[:4]] = k
+                l[rare[4:]] = np.minimum(l[rare[4:]], 1)
+                h[rare[4:]] = k
+                l[rare[2:4]] = k if k >= 2 else l[rare[2:4]]
+                l, h = np.minimum(l, h), np.maximum(l, h)
+                lo[v], hi[v] = l, h
+                parts[9:] = ["%d/%d" % (l[s], h[s]) for s in range(n)]
+            out.append("\t".join(parts))
+            v += 1
+        open(str(tmp_path / "m.vcf"), "w").write("\n".join(out))
+    cp = T.run_ref(["--vcf", "m.vcf", "--make-pgen", "--out", "mv"], str(tmp_path))
+    assert cp.returncode == 0, cp.stdout
+    f = pkg.PgenFile(str(tmp_path / "mv.pgen"))
+    assert f.has_multiallelic
+    # host path: main track for one ALT allele, numpy collapse of the reader's allele pairs for the others
+    rows = f.read()
+    host = engine(pkg, n, m)
+    host.load_genotypes_host(0, rows, pkg.LDP_GENO_REF)
+    want_maj = np.full(m, 0xffffffff, dtype=np.uint32)
+    for v in range(m):
+        if alt_ct[v] > 1:
+            glo, ghi = f.read_alleles(v, int(alt_ct[v]))
+            assert np.array_equal(glo, lo[v]) and np.array_equal(ghi, hi[v])
+            c, maj, mf = collapse(glo, ghi, int(alt_ct[v]))
+            want_maj[v] = maj
+            packed = np.ascontiguousarray(T.pack_2bit(c[None, :]).view(np.uint8).reshape(1, -1)[:, :(n + 3) // 4])
+            host.load_genotypes_host(v, packed, pkg.LDP_GENO_INVERSE)
+            host.set_maj_freqs(v, np.array([mf]))
+    dev = engine(pkg, n, m)
+    got_maj = dev.load_pgen_records(0, f, allele_cts=alt_ct + 1)
+    assert np.array_equal(got_maj, want_maj)
+    assert len(set(want_maj[alt_ct > 1].tolist())) >= 2   # (REF, ALT1 and later alleles all occur as the major one over the cases)
+    assert_same_rows(host, dev, m)
+    assert np.array_equal(host.run(), dev.run())
+    # in pieces (the collapse must not disturb LD bases: a base is the main track as stored)
+    dev2 = engine(pkg, n, m)
+    for a, b in [(0, 5), (5, m // 2), (m // 2, m)]:
+        dev2.load_pgen_records(a, f, a, b - a, allele_cts=(alt_ct + 1)[a:b])
+    assert_same_rows(host, dev2, m)
+    f.close()
+
+
+@pytest.mark.skipif(not T.have_ref(), reason="reference binary not built")
+def test_records_of_a_file_with_more_samples_than_founders(gpu_pkg, tmp_path):
+    """With a sample map the decoded rows are the file's and the engine gathers its columns (LDP_GENO_MAPPED)."""
+    pkg = gpu_pkg
+    m, raw_n = 500, 333
+    raw = structured_codes(m, raw_n, 11)
+    T.write_pgen_fixed(str(tmp_path / "f"), raw, ["1"] * m, np.arange(m) + 1)
+    cp = T.run_ref(["--pfile", "f", "--make-pgen", "--out", "v"], str(tmp_path))
+    assert cp.returncode == 0, cp.stdout
+    f = pkg.PgenFile(str(tmp_path / "v.pgen"))
+    keep = np.flatnonzero(np.random.default_rng(3).random(raw_n) < 0.7).astype(np.uint32)
+    n = len(keep)
+    sub = np.ascontiguousarray(T.pack_2bit(raw[:, keep]).view(np.uint8).reshape(m, -1)[:, :(n + 3) // 4])
+    host = engine(pkg, n, m)
+    host.load_genotypes_host(0, sub, pkg.LDP_GENO_REF)
+    dev = engine(pkg, n, m)
+    dev.set_sample_map(raw_n, keep)
+    dev.load_pgen_records(0, f)
+    assert_same_rows(host, dev, m)
+    assert np.array_equal(host.run(), dev.run())
+    # allele_ct > 2 needs the file's samples to be the engine's
+    with pytest.raises(pkg.LdpError) as ei:
+        dev.load_pgen_records(0, f, allele_cts=np.full(m, 3))
+    assert ei.value.code == pkg.LDP_ERR_UNSUPPORTED
+    f.close()
+
+
+def test_malformed_records_are_refused(gpu_pkg, tmp_path):
+    pkg = gpu_pkg
+    src = open(os.path.join(GOLD, "varwidth_small.pgen"), "rb").read()
+    f = pkg.PgenFile(os.path.join(GOLD, "varwidth_small.pgen"))
+    m, n = f.variant_ct, f.sample_ct
+    recs, _ = f.record_index()
+    ptr, nbytes = f.file_bytes()
+    data = np.frombuffer(src, dtype=np.uint8).copy()
+    rng = np.random.default_rng(5)
+    refused = 0
+    for trial in range(40):
+        bad = data.copy()
+        q = int(rng.integers(0, m))
+        r = recs[q]
+        if (int(r.vrtype) & 7) == 0 or r.length < 3:
+            continue
+        mode = trial % 3
+        cut = (pkg.ldp_pgen_rec * m)()
+        for k in range(m):
+            cut[k].offset, cut[k].length, cut[k].vrtype, cut[k].allele_ct = recs[k].offset, recs[k].length, recs[k].vrtype, 2
+        if mode == 0:
+            cut[q].length = int(rng.integers(1, r.length))          # truncated record
+        elif mode == 1:
+            bad[r.offset + int(rng.integers(0, r.length))] ^= 0xff   # a flipped byte
+        else:
+            bad[r.offset:r.offset + r.length] = rng.integers(0, 256, size=r.length, dtype=np.uint8)
+        eng = engine(pkg, n, m)
+        maj = np.zeros(m, dtype=np.uint32)
+        rc = eng._L.ldp_load_pgen_records(eng._h, 0, m, bad.ctypes.data_as(pkg.ctypes.c_void_p), len(bad), pkg.LDP_MEM_HOST, cut, None, n,
+                                          maj.ctypes.data_as(pkg.ctypes.POINTER(pkg.ctypes.c_uint32)))
+        # a damaged record is either refused or decodes to SOME row (a flipped genotype value is not detectable); it never crashes,
+        # and a refused call leaves the engine usable
+        assert rc in (pkg.LDP_OK, pkg.LDP_ERR_INVALID)
+        if rc == pkg.LDP_ERR_INVALID:
+            refused += 1
+            eng.load_pgen_records(0, f)
+            eng.run()
+    assert refused >= 5
+    # records outside the buffer, LD-compressed first record without a base
+    eng = engine(pkg, n, m)
+    with pytest.raises(pkg.LdpError):
+        eng._ck(eng._L.ldp_load_pgen_records(eng._h, 0, m, pkg.ctypes.c_void_p(ptr), 10, pkg.LDP_MEM_HOST, recs, None, n, None))
+    ld = [q for q in range(m) if (int(recs[q].vrtype) & 6) == 2]
+    if ld:
+        one = (pkg.ldp_pgen_rec * 1)()
+        one[0].offset, one[0].length, one[0].vrtype, one[0].allele_ct = recs[ld[0]].offset, recs[ld[0]].length, recs[ld[0]].vrtype, 2
+        with pytest.raises(pkg.LdpError):
+            eng._ck(eng._L.ldp_load_pgen_records(eng._h, ld[0], 1, pkg.ctypes.c_void_p(ptr), nbytes, pkg.LDP_MEM_HOST, one, None, n, None))
+    f.close()
