@@ -5037,6 +5037,14 @@ int run_prune(Session& S) {
           }
         }
       }
+      // Variable-width records are decoded ON THE DEVICE from the file's own bytes (ldp_load_pgen_records: main track of every
+      // record type, LD-compressed chains, and -- when the engine's samples are the file's -- the collapse of variants with more
+      // than one ALT allele); --indep-pairphase rows (phase track) and LDP_DEBUG_HOST_DECODE=1 take the host decoder below.
+      const bool device_decode = (!direct) && (!A.pairphase) && (storage_mode != 0x01) && (storage_mode != 0x02) && (getenv("LDP_DEBUG_HOST_DECODE") == nullptr);
+      const bool device_multi = device_decode && all_founders;
+      uint64_t file_size = 0;
+      const void* file_bytes = device_decode ? ldp_pgen_file_bytes(pg, &file_size) : nullptr;
+      std::vector<ldp_pgen_rec> rec_index;
       std::thread decoder;
       // The decoder runs beside the engine's copy threads (ldp_load_genotypes: 16 of them feeding the pinned ring); a record
       // takes microseconds, so a few dozen threads keep ahead of PCIe and more only get in the copies' way.
@@ -5046,7 +5054,7 @@ int run_prune(Session& S) {
       uint32_t unphased_at = 0;
       uint32_t pending_unphased = UINT32_MAX;
       auto start_decode = [&](size_t k) {
-        if (direct || k >= runs.size()) {
+        if (direct || device_decode || k >= runs.size()) {
           return;
         }
         if (!decoded[k & 1]) {
@@ -5071,6 +5079,35 @@ int run_prune(Session& S) {
         const uint32_t run = runs[k].n;
         const uint8_t* src;
         uint64_t stride = in_rec;
+        if (device_decode) {
+          rec_index.resize(run);
+          uint32_t base_v = UINT32_MAX;
+          ldp_pgen_rec base_rec;
+          if (ldp_pgen_record_index(pg, raw0, run, rec_index.data(), &base_v) || ((base_v != UINT32_MAX) && ldp_pgen_record_index(pg, base_v, 1, &base_rec, nullptr))) {
+            die(6, "\nError: %s: malformed variant record index.\n", gpath.c_str());
+          }
+          if (device_multi) {
+            for (uint32_t t = 0; t < run; ++t) {
+              const uint32_t alts = V.alt_ct[raw0 + t];
+              if ((alts > 1) && (vcls[mk[q + t]] != 5)) {
+                if (alts > 254) {
+                  die(63, "\nError: variant '%s' has more than 254 ALT alleles: not supported by plink2-hip.\n", V.id[raw0 + t].c_str());
+                }
+                rec_index[t].allele_ct = static_cast<uint8_t>(alts + 1);
+              }
+            }
+          }
+          const double tl0 = now_s();
+          for (int r = 0; r < world; ++r) {
+            const int rc = ldp_load_pgen_records(eng[r], q, run, file_bytes, file_size, LDP_MEM_HOST, rec_index.data(), (base_v != UINT32_MAX) ? &base_rec : nullptr,
+                                                 raw_sample_ct, nullptr);
+            if (rc) {
+              die((rc == LDP_ERR_INVALID) ? 6 : 16, "\nError: %s: %s\n", gpath.c_str(), ldp_last_error(eng[r]));
+            }
+          }
+          t_load_calls += now_s() - tl0;
+          continue;
+        }
         if (direct) {
           src = direct + static_cast<uint64_t>(raw0) * rec_bytes;
         } else {
@@ -5113,7 +5150,7 @@ int run_prune(Session& S) {
       // rows that need host treatment overwrite their bulk-loaded versions: variants with more than one ALT
       // allele (collapsed major-vs-rest) and MT variants (hets -> missing, plink2_ld.cc:1362-1364)
       {
-        uint32_t multi_ct = 0, mt_ct = 0;
+        uint32_t multi_ct = 0, mt_ct = 0, multi_device = 0;
         // (--indep-pairphase: a multiallelic row is 2 haplotypes per founder as plain 2-bit codes on the 2N-haplotype engine)
         const uint64_t host_rec = A.pairphase ? ((2ull * founder_ct + 3) / 4) : out_rec;
         const uint64_t raw_phase_bytes = (static_cast<uint64_t>(raw_sample_ct) + 7) / 8;
@@ -5127,7 +5164,7 @@ int run_prune(Session& S) {
         // conversion kernel applied to the bulk-loaded row.  Its genotype counts say which variants those are.
         std::vector<uint8_t> ref_is_major;
         uint32_t multi_skipped = 0;
-        if (!A.pairphase) {
+        if ((!A.pairphase) && !device_multi) {
           bool any_multi = false;
           for (uint32_t qq = 0; (qq < m_ct) && !any_multi; ++qq) {
             any_multi = (V.alt_ct[inc[mk[qq]]] > 1) && (vcls[mk[qq]] != 5);
@@ -5154,6 +5191,10 @@ int run_prune(Session& S) {
           const uint32_t alts = V.alt_ct[raw_v];
           const bool is_mt = (vcls[mk[qq]] == 5);
           if (alts < 2 && !is_mt) {
+            continue;
+          }
+          if (device_multi && !is_mt) {
+            ++multi_device;  // (collapsed by ldp_load_pgen_records)
             continue;
           }
           if ((!is_mt) && (!ref_is_major.empty()) && ref_is_major[qq]) {
@@ -5190,9 +5231,9 @@ int run_prune(Session& S) {
         if (std::min(multi_unphased, pending_unphased) != UINT32_MAX) {
           die_unphased(std::min(multi_unphased, pending_unphased));
         }
-        if ((multi_ct || mt_ct || multi_skipped) && A.timing) {
-          logprintf("\n[timing] host-built rows: %u multiallelic (%u more have REF as the major allele: main track as loaded), %u MT\n", multi_ct,
-                    multi_skipped, mt_ct);
+        if ((multi_ct || mt_ct || multi_skipped || multi_device) && A.timing) {
+          logprintf("\n[timing] host-built rows: %u multiallelic (%u more have REF as the major allele: main track as loaded; %u collapsed on the device), %u MT\n",
+                    multi_ct, multi_skipped, multi_device, mt_ct);
         }
       }
       t_load1 = now_s();
