@@ -14,6 +14,7 @@ import test_golden as GOLD
 import test_gpu_parity as P
 import test_integration_binding as BIND
 import test_pairphase as PH
+import test_pgen_device_decode as DEC
 import test_r2_unphased as R2
 import test_sample_map as SM
 from test_cli import cli  # noqa: F401  (fixture)
@@ -61,6 +62,14 @@ def test_rows_a1_a2_a18_cli_files_byte_identical(gpu_pkg, cli, tmp_path):
 
 def test_row_f1_variable_width_pgen(gpu_pkg, cli, tmp_path):
     CLI.test_cli_byte_identical_to_reference(gpu_pkg, cli, tmp_path, CLI.CLI_CASES[7])
+
+
+def test_row_f1_records_decoded_on_the_device(gpu_pkg, tmp_path):
+    """ldp_load_pgen_records: the committed reference-written file (every main-track record type) and a VCF-imported multiallelic
+    fileset (aux track 1, major-vs-rest collapse) against the host reader."""
+    DEC.test_committed_variable_width_file(gpu_pkg)
+    if T.have_ref():
+        DEC.test_multiallelic_records_are_collapsed_on_the_device(gpu_pkg, tmp_path, 150, 300, 2, 5)
 
 
 def test_row_a20_r2_matrix(gpu_pkg, tmp_path):
