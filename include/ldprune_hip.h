@@ -269,12 +269,14 @@ int ldp_pair_stats(ldp_engine* e, uint32_t n_pairs, const uint32_t* first, const
 int ldp_debug_set_variant_recs(ldp_engine* e, const ldp_variant_rec* recs);
 int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first, const uint32_t* second, uint64_t* removed);
 /* Kernel-selection switches of ONE engine, for tests and measurements (the defaults are what production runs use; they can also
- * be preset from the environment at ldp_create(): LDP_EARLY_EXIT, LDP_PAIR_MFMA, LDP_PAIR_SPARSE, LDP_DEBUG_SPARSE_FRAC,
+ * be preset from the environment at ldp_create(): LDP_EARLY_EXIT, LDP_PAIR_MFMA, LDP_PAIR_SPARSE, LDP_PAIR_FOUR, LDP_DEBUG_SPARSE_FRAC,
  * LDP_DEBUG_WIDE_MIN_REACH).  name:
  *   "early_exit"      0/1: checkpoints that drop provably sub-threshold products
  *   "pair_mfma"       0/1: matrix-pipe kernels on the 2-bit code image; 0 = the popcount kernels on bit-planes (before ldp_set_variants*())
  *   "pair_sparse"     0/1: the interval epilogue for rows with a few missing calls
  *   "sparse_frac"     mean missing fraction up to which a launch takes it
+ *   "pair_four"       0/1: prune launches over rows with more missing calls than that multiply four products per pair and take the
+ *                     two sums of squares from per-variant intervals (exact count for the few pairs they leave open); 0 = all six
  *   "wide_min_reach"  row-blocks a subcontig's band must reach to take the 8 x 8 tile plan of the wide-band kernel; 0 = always,
  *                     a huge value = never (before ldp_set_variants())
  * Results never depend on these.  Unknown name: LDP_ERR_INVALID. */

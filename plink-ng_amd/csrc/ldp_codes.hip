@@ -83,7 +83,8 @@ __device__ __forceinline__ void hap_codes_of_16(uint32_t w, uint32_t phase16, ui
 template <int THREADS, int ITERS, bool NT = false>
 __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
   constexpr int kWaves = THREADS / 64;
-  __shared__ uint32_t red[kWaves][3 + 2 * kCheckpoints];
+  __shared__ uint32_t red[kWaves][3 + 2 * kCheckpoints + kGenCheckpoints];
+  __shared__ uint32_t s_alt_major;
   __shared__ int32_t s_sum;
   const uint32_t v = blockIdx.x;
   const uint32_t tid = threadIdx.x;
@@ -104,9 +105,14 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
 
   uint32_t hom_ct = 0, r2h_ct = 0, both_ct = 0;
   uint32_t rest[kCheckpoints];  // hom calls | code-0 calls << 16 in k-chunks >= checkpoint k (a thread's share stays below 2^16)
+  uint32_t rest_nm[kGenCheckpoints];  // missing calls (+ padding) there, for the checkpoints the six-product kernel uses (its bound: cp_gen)
 #pragma unroll
   for (int k = 0; k < kCheckpoints; ++k) {
     rest[k] = 0;
+  }
+#pragma unroll
+  for (int k = 0; k < kGenCheckpoints; ++k) {
+    rest_nm[k] = 0;
   }
   // everything a unit needs besides a plain vector load: phased rows, unaligned rows, the tail of the row and its padding
   auto slow_unit = [&](uint32_t u, u32x4& w) {
@@ -168,6 +174,17 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
       rest[k] += (chunk >= A.checkpoint_chunk[k]) ? packed : 0;
     }
   };
+  // missing calls (and the padding behind the last sample, coded the same) per remainder, for the six-product kernel's bound: only
+  // threads that met one come back for this
+  auto count_missing = [&](uint32_t u, const u32x4& w) {
+    const uint32_t mc = __popc(w.x & (w.x >> 1) & 0x55555555u) + __popc(w.y & (w.y >> 1) & 0x55555555u) + __popc(w.z & (w.z >> 1) & 0x55555555u) +
+                        __popc(w.w & (w.w >> 1) & 0x55555555u);
+    const uint32_t chunk = u / (kChunkDwords * 32 / 64);
+#pragma unroll
+    for (int k = 0; k < kGenCheckpoints; ++k) {
+      rest_nm[k] += (chunk >= A.checkpoint_chunk[kGenCheckpointFirst + k]) ? mc : 0;
+    }
+  };
   uint32_t slow_first = 0;  // units from here on go through slow_unit()
   if constexpr (ITERS > 0) {
     u32x4 w[ITERS];
@@ -198,6 +215,21 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
         count_unit(u, w[it]);
       }
     }
+    // (calls present = codes 0, 1, 2 = hom + (codes 0 or 1) - code 0: a thread whose units are all calls skips this)
+    uint32_t my_units = 0;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      my_units += (tid + it * THREADS < n_fast) ? 1u : 0u;
+    }
+    if (hom_ct + r2h_ct - both_ct != 64 * my_units) {
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const uint32_t u = tid + it * THREADS;
+        if (u < n_fast) {
+          count_missing(u, w[it]);
+        }
+      }
+    }
     slow_first = (n_fast < static_cast<uint32_t>(ITERS * THREADS)) ? n_fast : static_cast<uint32_t>(ITERS * THREADS);
   }
   // what is left: all of a phased / unaligned / very long row; otherwise the tail unit and the padding
@@ -218,7 +250,11 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
       __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(out_row + 16ull * u));
     }
     if (u * 64 < A.founder_ct) {
+      const uint32_t calls_before = hom_ct + r2h_ct - both_ct;
       count_unit(u, w);
+      if (hom_ct + r2h_ct - both_ct != calls_before + 64) {
+        count_missing(u, w);
+      }
     }
   }
   hom_ct = wave_reduce_add(hom_ct);
@@ -230,6 +266,12 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
     rest_both[k] = wave_reduce_add(rest[k] >> 16);
     rest[k] = wave_reduce_add(rest[k] & 0xffffu);
   }
+  if (__any((rest_nm[0] | rest_nm[kGenCheckpoints - 1]) != 0)) {  // (a later remainder's count is part of an earlier one's)
+#pragma unroll
+    for (int k = 0; k < kGenCheckpoints; ++k) {
+      rest_nm[k] = wave_reduce_add(rest_nm[k]);
+    }
+  }
   if ((tid & 63) == 0) {
     red[tid >> 6][0] = hom_ct;
     red[tid >> 6][1] = r2h_ct;
@@ -238,6 +280,10 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
     for (int k = 0; k < kCheckpoints; ++k) {
       red[tid >> 6][3 + k] = rest[k];
       red[tid >> 6][3 + kCheckpoints + k] = rest_both[k];
+    }
+#pragma unroll
+    for (int k = 0; k < kGenCheckpoints; ++k) {
+      red[tid >> 6][3 + 2 * kCheckpoints + k] = rest_nm[k];
     }
   }
   __syncthreads();
@@ -289,13 +335,22 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
     const uint32_t mono = ((!plus_ct) && (!minus_ct)) || (plus_ct == nm_ct) || (minus_ct == nm_ct);  // plink2_ld.cc:902
     rec.flags = alt_major | (mono << 1) | ((nm_ct != A.founder_ct) ? 4u : 0u);
     A.recs[v] = rec;
+    s_alt_major = alt_major;
     s_sum = static_cast<int32_t>(n0 - n2);  // the sum in the IMAGE's orientation: what the checkpoint bound pairs with the kernel's partial dot products
   }
   __syncthreads();
-  if (A.cp_stats && (tid < kCpSlots)) {
-    // early-termination statistics (layout: ldp_device.h), in the orientation of the image; only read for complete-data rows
+  // (the six-product kernel's slots by the LAST wave, beside the first one's: the tail of a block is a chain of latencies)
+  constexpr uint32_t kGenTid0 = (kWaves > 1) ? (kWaves - 1) * 64 : kCpSlots;
+  const bool cp_thread = tid < kCpSlots, gen_thread = (tid >= kGenTid0) && (tid < kGenTid0 + 1 + kGenCheckpoints);
+  if (A.cp_stats && (cp_thread || gen_thread)) {
+    // early-termination statistics (layout: ldp_device.h), in the orientation of the image: one 16-byte slot per thread, one
+    // contiguous 144-byte record per variant
     const double N = static_cast<double>(A.founder_ct);
-    cp_slot slot;
+    union {
+      cp_slot cp;
+      cp_gen_slot gen;
+      u32x4 raw;
+    } slot;
     if (tid < kCheckpoints) {
       uint32_t hom_r = 0, both_r = 0;
       for (int w = 0; w < kWaves; ++w) {
@@ -306,18 +361,49 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
       const uint64_t seen = static_cast<uint64_t>(A.checkpoint_chunk[tid]) * (kChunkDwords * 32);
       const double n_r = (seen < A.founder_ct) ? static_cast<double>(A.founder_ct - seen) : 1.0;
       const double v_r = fmax(static_cast<double>(hom_r) - s_r * s_r / n_r, 0.0);
-      slot.a = s_r * sqrt(N / n_r);
-      slot.b = sqrt(N * v_r);
-    } else {
+      slot.cp.a = s_r * sqrt(N / n_r);
+      slot.cp.b = sqrt(N * v_r);
+    } else if (cp_thread) {
       uint32_t hom_all = 0;
       for (int w = 0; w < kWaves; ++w) {
         hom_all += red[w][0];
       }
       const double S = static_cast<double>(s_sum);
-      slot.a = S;
-      slot.b = sqrt(fmax(N * static_cast<double>(hom_all) - S * S, 0.0)) * A.cp_tv_scale;
+      slot.cp.a = S;
+      slot.cp.b = sqrt(fmax(N * static_cast<double>(hom_all) - S * S, 0.0)) * A.cp_tv_scale;
+    } else {
+      // the six-product kernel's slots, in z = 1 - x (0 = code 0, 1 = het, 2 = code 2) over the variant's own calls:
+      // sum z = hets + 2 code-2 calls, sum z^2 = hets + 4 code-2 calls
+      uint32_t hom = 0, both = 0, nm = 0;
+      uint32_t flag = 0;
+      if (tid == kGenTid0) {  // the whole row (calls = codes 0, 1, 2 = hom + (codes 0 or 1) - code 0), with the ALT-major flag
+        uint32_t r2h = 0;
+        for (int w = 0; w < kWaves; ++w) {
+          hom += red[w][0];
+          r2h += red[w][1];
+          both += red[w][2];
+        }
+        nm = hom + r2h - both;
+        flag = s_alt_major;
+      } else {
+        const uint32_t k = tid - kGenTid0 - 1, cp = kGenCheckpointFirst + k;
+        uint32_t miss_r = 0;
+        for (int w = 0; w < kWaves; ++w) {
+          hom += red[w][3 + cp];
+          both += red[w][3 + kCheckpoints + cp];
+          miss_r += red[w][3 + 2 * kCheckpoints + k];
+        }
+        // calls = the counted samples of the remainder (whole 64-sample units: the last one's padding is coded missing) - missing
+        const uint64_t seen64 = static_cast<uint64_t>(A.checkpoint_chunk[cp]) * (kChunkDwords * 32);
+        const uint64_t counted = (static_cast<uint64_t>(A.founder_ct) + 63) & ~static_cast<uint64_t>(63);
+        nm = (seen64 < counted) ? static_cast<uint32_t>(counted - seen64) - miss_r : 0u;
+      }
+      slot.gen.nm_r = nm;
+      slot.gen.zs_r = nm + hom - 2 * both;
+      slot.gen.zq_r = nm + 3 * hom - 4 * both;
+      slot.gen.pad = flag;
     }
-    A.cp_stats[static_cast<uint64_t>(v) * kCpSlots + tid] = slot;
+    reinterpret_cast<u32x4*>(A.cp_stats)[static_cast<uint64_t>(v) * kCpStride + (cp_thread ? tid : (kCpSlots + tid - kGenTid0))] = slot.raw;
   }
 }
 

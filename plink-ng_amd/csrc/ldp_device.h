@@ -64,12 +64,20 @@ struct WorkItem {
 // Results are unchanged: only pairs whose predicate is provably false are skipped.
 constexpr int kCheckpoints = 5;
 constexpr int kCpSlots = kCheckpoints + 1;
+// ... followed, in the same per-variant record, by what the six-product kernel's bound needs (cp_gen_slot below, written by the
+// code image's count pass only): the whole row, then the remainders behind checkpoints kGenCheckpointFirst .. + kGenCheckpoints - 1
+// (0.08 and 0.16 behind 1 - sqrt(r2) of the samples: where that kernel stops).  One contiguous 144-byte store per variant.
+constexpr int kGenCheckpointFirst = 2;
+constexpr int kGenCheckpoints = 2;
+constexpr int kCpStride = kCpSlots + 1 + kGenCheckpoints;
 struct cp_slot {
   double a, b;
 };
 // Tiles with missing calls: the pair statistics run over the pairwise-complete samples, which no per-variant number
 // pins down, so the bound works on intervals.  Per variant and checkpoint, over the not-yet-visited samples R where
 // the variant itself is called, in z = 1 - x (0 = homozygous major, 1 = het, 2 = homozygous minor):
+// (in the code image's cp_stats records: slot kCpSlots = the WHOLE row -- its calls, sum z, sum z^2, and in pad its ALT-major
+// flag --, slots kCpSlots + 1 + k = the remainder behind checkpoint kGenCheckpointFirst + k)
 struct cp_gen_slot {
   uint32_t nm_r;  // calls
   uint32_t zs_r;  // sum z
@@ -145,7 +153,7 @@ struct PairKernelArgs {
   uint8_t* item_general;         // per work item: 1 = some row has missing calls -> general kernel
   // --r2-unphased matrix mode: when r2_out != nullptr the epilogue stores r^2 of pair (i<j) at
   // r2_out[(j - r2_row_first) * r2_ld + i] (float or double) instead of predicate bits
-  const cp_slot* cp_stats;       // [variant][kCpSlots]; nullptr disables early termination
+  const cp_slot* cp_stats;       // [variant][kCpStride]; nullptr disables early termination
   const cp_gen_slot* cp_gen;     // [variant][kCheckpoints]: the same for tiles with missing calls
   uint32_t checkpoint_chunk[kCheckpoints];  // ascending; a checkpoint fires after chunk (value - 1) is consumed
   uint32_t n_checkpoints;
@@ -175,6 +183,7 @@ struct PairKernelArgs {
   uint32_t n_local;              // rows in `planes`
   uint32_t mf_active;            // the launch also carries matrix-pipe work items
   const uint32_t* route;         // kRoute*
+  uint32_t mf_four;              // prune launches on the six-product route may use its four-product form (EngineOptions::pair_four)
   uint32_t sparse_ok;            // the route may be kRouteSparse (prune launches): launch that instantiation as well
   // wide-band tiles (launch_pair_wide): complete-data launches only; the workgroups of mf_wgs whose MfmaWG::pad is 1 cover the
   // same subcontigs for the other two routes and are skipped by pair_mfma_kernel<., false> when wd_active is set
@@ -211,7 +220,7 @@ struct PrepareArgs {
   uint64_t row_dwords;
   uint32_t chunks;
   ldp_variant_rec* recs;         // entry 0 = variant `first`
-  cp_slot* cp_stats;             // entry 0 = variant `first`, kCpSlots each; may be nullptr
+  cp_slot* cp_stats;             // entry 0 = variant `first`, kCpStride each; may be nullptr
   cp_gen_slot* cp_gen;           // entry 0 = variant `first`, kCheckpoints each (written iff cp_stats is)
   double cp_tv_scale;            // sqrt(sqrt(thresh) * (1 - 1e-6))
   uint32_t checkpoint_chunk[kCheckpoints];

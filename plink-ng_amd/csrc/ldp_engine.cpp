@@ -81,6 +81,7 @@ struct EngineOptions {
   bool pair_mfma = true;      // LDP_PAIR_MFMA=0: popcount kernels instead of the matrix pipe
   double sparse_frac = 0.005; // LDP_PAIR_SPARSE=0 -> 0; LDP_DEBUG_SPARSE_FRAC
   uint32_t wide_min_reach = kWdMinReach;  // band reach (row-blocks) from which a subcontig takes the 8 x 8 tile plan; LDP_DEBUG_WIDE_MIN_REACH
+  bool pair_four = true;      // LDP_PAIR_FOUR=0: rows with missing calls always take all six products (prune launches otherwise four)
 };
 
 struct ldp_engine {
@@ -532,6 +533,8 @@ EngineOptions options_from_env() {
   const char* off = getenv("LDP_PAIR_SPARSE");
   const char* f = getenv("LDP_DEBUG_SPARSE_FRAC");
   o.sparse_frac = (off && (strcmp(off, "0") == 0)) ? 0.0 : (f ? atof(f) : 0.005);
+  const char* four = getenv("LDP_PAIR_FOUR");
+  o.pair_four = !(four && (strcmp(four, "0") == 0));
   if (const char* w = getenv("LDP_DEBUG_WIDE_MIN_REACH")) {
     o.wide_min_reach = static_cast<uint32_t>(std::max(0, atoi(w)));
   }
@@ -1094,7 +1097,7 @@ int ensure_device_plan(ldp_engine* e) {
   HIP_TRY(e, hipMalloc(&e->d_item_general, std::max<size_t>(e->items.size(), 1)));
   HIP_TRY(e, hipMalloc(&e->d_counters, 4 * sizeof(unsigned long long)));
   HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
-  HIP_TRY(e, hipMalloc(&e->d_cp_stats, n * kCpSlots * sizeof(cp_slot)));
+  HIP_TRY(e, hipMalloc(&e->d_cp_stats, n * kCpStride * sizeof(cp_slot)));
   HIP_TRY(e, hipMalloc(&e->d_cp_gen, n * kCheckpoints * sizeof(cp_gen_slot)));
   HIP_TRY(e, hipMalloc(&e->d_mf_wgs, std::max<size_t>(e->mf_wgs.size(), 1) * sizeof(MfmaWG)));
   HIP_TRY(e, hipMalloc(&e->d_miss_stats, (e->groups.size() + 1) * sizeof(MissStats)));
@@ -1591,6 +1594,7 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.mf_active = 0;
   A.route = nullptr;
   A.sparse_ok = 0;
+  A.mf_four = e->opt.pair_four ? 1u : 0u;
   A.wd_tiles = nullptr;
   A.n_wd_tiles = 0;
   A.wd_active = 0;
@@ -2996,7 +3000,7 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
       PA.row_dwords = e->row_dwords;
       PA.chunks = e->chunks;
       PA.recs = e->d_recs + l0;
-      PA.cp_stats = e->d_cp_stats + static_cast<uint64_t>(l0) * kCpSlots;
+      PA.cp_stats = e->d_cp_stats + static_cast<uint64_t>(l0) * kCpStride;
       PA.cp_gen = e->d_cp_gen + static_cast<uint64_t>(l0) * kCheckpoints;
       PA.cp_tv_scale = sqrt(sqrt(e->P.prune_last_param * (1 + kSmallEpsilon)) * (1.0 - 1e-6));
       for (int k = 0; k < kCheckpoints; ++k) {
@@ -3491,6 +3495,8 @@ int ldp_debug_set_option(ldp_engine* e, const char* name, double value) {
       return fail(e, LDP_ERR_STATE, "wide_min_reach must be set before ldp_set_variants()");
     }
     e->opt.wide_min_reach = (value >= 4294967295.0) ? 0xffffffffu : static_cast<uint32_t>(std::max(0.0, value));
+  } else if (n == "pair_four") {
+    e->opt.pair_four = (value != 0.0);
   } else if (n == "pair_sparse") {
     if (value == 0.0) {
       e->opt.sparse_frac = 0.0;

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(PrepareArgs A) {
       slot.a = S;
       slot.b = sqrt(fmax(N * static_cast<double>(hom_all) - S * S, 0.0)) * A.cp_tv_scale;
     }
-    A.cp_stats[static_cast<uint64_t>(v) * kCpSlots + tid] = slot;
+    A.cp_stats[static_cast<uint64_t>(v) * kCpStride + tid] = slot;
   }
   uint32_t* out_row = A.planes + static_cast<uint64_t>(v) * A.row_dwords;
   if constexpr (MAXIT > 0) {
@@ -954,8 +954,8 @@ __device__ __forceinline__ uint32_t live_units(const PairKernelArgs& A, uint32_t
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      const cp_slot cj = A.cp_stats[static_cast<uint64_t>(j) * kCpSlots + cp];
-      const cp_slot gj = A.cp_stats[static_cast<uint64_t>(j) * kCpSlots + kCheckpoints];
+      const cp_slot cj = A.cp_stats[static_cast<uint64_t>(j) * kCpStride + cp];
+      const cp_slot gj = A.cp_stats[static_cast<uint64_t>(j) * kCpStride + kCheckpoints];
 #pragma unroll
       for (int a0 = 0; a0 < NA; a0 += 4) {
         cp_slot ci[4], gi[4];
@@ -963,8 +963,8 @@ __device__ __forceinline__ uint32_t live_units(const PairKernelArgs& A, uint32_t
         for (int q = 0; q < 4; ++q) {
           const uint32_t d = d_first + ty + 8 * (a0 + q);
           const uint64_t i = (d <= j) ? (j - d) : 0;
-          ci[q] = A.cp_stats[i * kCpSlots + cp];
-          gi[q] = A.cp_stats[i * kCpSlots + kCheckpoints];
+          ci[q] = A.cp_stats[i * kCpStride + cp];
+          gi[q] = A.cp_stats[i * kCpStride + kCheckpoints];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

@@ -39,6 +39,16 @@ __device__ __forceinline__ bool exceeds(const ldp_pair_stats_t& s, double thresh
   return __dmul_rn(cov12, cov12) > __dmul_rn(__dmul_rn(thresh, var1), var2);
 }
 
+// the same with negative variances read as zero (hypothetical sums of squares below what the sums allow: the low end of an
+// interval; true variances are never negative, and the right-hand side is monotone in each of them from zero upwards)
+__device__ __forceinline__ bool exceeds_clamped(const ldp_pair_stats_t& s, double thresh) {
+  const double cov12 = static_cast<double>(static_cast<int64_t>(s.dot) * static_cast<int64_t>(s.nm) - static_cast<int64_t>(s.sum1) * static_cast<int64_t>(s.sum2));
+  const int64_t v1 = static_cast<int64_t>(s.ssq1) * static_cast<int64_t>(s.nm) - static_cast<int64_t>(s.sum1) * static_cast<int64_t>(s.sum1);
+  const int64_t v2 = static_cast<int64_t>(s.ssq2) * static_cast<int64_t>(s.nm) - static_cast<int64_t>(s.sum2) * static_cast<int64_t>(s.sum2);
+  const double var1 = static_cast<double>((v1 > 0) ? v1 : 0), var2 = static_cast<double>((v2 > 0) ? v2 : 0);
+  return __dmul_rn(cov12, cov12) > __dmul_rn(__dmul_rn(thresh, var1), var2);
+}
+
 // r^2 of --r2-unphased exactly as ComputeR2 writes it (plink2_ld.cc:6654-6682): NaN when there is no joint
 // observation or a zero variance product, else cov01*cov01 / (double(var0)*double(var1)).  The NaN bit
 // patterns are the ones the reference's `0.0 / 0.0` produces on x86 (sign bit set).

@@ -630,7 +630,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
           const uint32_t first = __builtin_amdgcn_readfirstlane(wg->rb[T]);
           uint32_t var = first + (lane >> 1);
           var = (var < A.n_local) ? var : (A.n_local - 1);
-          const uint64_t off = static_cast<uint64_t>(var) * (kCpSlots * sizeof(cp_slot)) + ((lane & 1) ? kCheckpoints : next_cp) * sizeof(cp_slot);
+          const uint64_t off = static_cast<uint64_t>(var) * (kCpStride * sizeof(cp_slot)) + ((lane & 1) ? kCheckpoints : next_cp) * sizeof(cp_slot);
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cps + off),
                                            (__attribute__((address_space(3))) void*)(lds + kMfCpScratchDwords + T * 256), 16, 0, 0);
         }
@@ -847,33 +847,153 @@ __device__ __forceinline__ void fp4_nh_of_codes(uint32_t c0, uint32_t c1, const 
   }
 }
 
-constexpr uint32_t kMfGenRowBlocks = 5;  // J, V0..V3 of the workgroup
+constexpr uint32_t kMfGenRowBlocks = 5;  // J0, J1 and the three V blocks of the workgroup's half
 constexpr uint32_t kMfGenInstr = kMfGenRowBlocks * 2;
 constexpr uint32_t kMfGenDmaPerWave = (kMfGenInstr + kMfWaves - 1) / kMfWaves;
+constexpr uint32_t kMfGenCpRound = 4;                                      // accumulator rows per checkpoint round
+constexpr uint32_t kMfGenCpWaveDwords = 6 * kMfGenCpRound * 64;            // this wave's scratch for one round (6 KiB)
+constexpr uint32_t kMfGenCpRowDwords = kMfBlock * (10 * 8 / 4);              // ... and its V block's rows, prepared (2 KiB)
+constexpr uint32_t kMfGenCpStatDwords = kMfWaves * (kMfGenCpWaveDwords + kMfGenCpRowDwords);  // the rows' cp_gen slots follow (5 x 1 KiB)
 
+// ---- can a pair still reach the threshold? (the six-product kernel's checkpoints) ----------------------------------------
+// With missing calls the statistics run over the pairwise-complete samples C = C_P (visited, known exactly from the six partial
+// sums) + C_R (the rest), and C_R is not pinned down by per-variant numbers: of variant i's own calls in the remainder R at most
+// dmax_i = min(partner's missing calls in R, own calls in R) drop out.  The popcount kernel's bound (ldp_kernels.hip:
+// pair_hopeless) puts every sum into an interval and multiplies the intervals, which at 1 % missing calls already loses the
+// 25 % of headroom the complete-data bound has when it fires.  This one removes the dependence first:
+//   * each variant is turned to its MINOR allele (z = copies of it: 0, 1, 2; r^2 is invariant) and CENTRED at its own mean
+//     alpha over all its calls: z' = z - alpha.  cov = n sum z'w' - sum z' sum w' and var = n sum z'^2 - (sum z')^2 hold for any
+//     shift, and with this one the sums of z' are small numbers (sampling noise plus what drops out), so the products of sums
+//     -- where interval arithmetic loses most -- hardly matter;
+//   * |sum over C_R of z'w'| <= sqrt(sum_{R, i called} z'^2 . sum_{R, j called} w'^2) (Cauchy-Schwarz; a sum of squares only grows
+//     with its index set), whatever drops out;
+//   * what drops out of a sum is at most its dmax largest (for the lower end: most negative) terms, and the remainder's calls
+//     are known by value: c0, c1, c2 of them have z = 0, 1, 2 (from its calls, sum z and sum z^2).
+// The pair is hopeless when (n_hi (|ZW'_P| + CS) + |Zs'|max |Ws'|max + 1)^2 (1 + 1e-6) < thresh (1 - 1e-6) var1_lo var2_lo with
+// var_lo = n_lo Q'_lo - |Zs'|max^2.  On the bench generator (50,000 samples, r^2 0.5, 1 % missing calls) 97 % of unrelated pairs
+// are hopeless 0.08 behind 1 - sqrt(r2) of the samples and all of them at 0.16; the interval product: 11 % and about half.
+struct GenRow {
+  double sgn;         // -1: the image's x counts the major allele's copies with +1
+  double alpha;       // mean of z over the variant's calls
+  double nr;          // its calls in the remainder
+  double a, b;        // sum of z', of z'^2 over them
+  double c0, c1, c2;  // how many of them have z = 0, 1, 2
+  double hom_p;       // its homozygous calls in the visited part
+  double miss_p;      // its missing calls there
+};
+__device__ __forceinline__ GenRow gen_row(const cp_gen_slot& cp, const cp_gen_slot& whole, double seen) {
+  GenRow g;
+  const bool flip = whole.pad != 0;
+  const double nr = cp.nm_r, nt = whole.nm_r;
+  double a = cp.zs_r, b = cp.zq_r, zt = whole.zs_r;
+  // homozygous calls = sum z^2 - 2 sum z + calls (z in {0, 2} <-> (z - 1)^2 = 1), whichever allele z counts
+  g.hom_p = (static_cast<double>(whole.zq_r) - 2.0 * whole.zs_r + nt) - (b - 2.0 * a + nr);
+  g.miss_p = fmax(seen - (nt - nr), 0.0);
+  if (flip) {  // z -> 2 - z
+    b = 4.0 * nr - 4.0 * a + b;
+    a = 2.0 * nr - a;
+    zt = 2.0 * nt - zt;
+  }
+  g.sgn = flip ? -1.0 : 1.0;
+  g.alpha = (nt > 0.0) ? zt / nt : 0.0;
+  g.nr = nr;
+  g.c2 = 0.5 * (b - a);
+  g.c1 = a - 2.0 * g.c2;
+  g.c0 = nr - g.c1 - g.c2;
+  g.a = a - g.alpha * nr;
+  g.b = fmax(b - 2.0 * g.alpha * a + g.alpha * g.alpha * nr, 0.0);
+  return g;
+}
+// the most that dropping at most d of the remainder's calls can take from sum z' (hi), add to it (lo), take from sum z'^2 (q);
+// alpha in [0, 1] (checked by the caller)
+__device__ __forceinline__ void gen_drops(const GenRow& g, double d, double* hi, double* lo, double* q) {
+  const double al = g.alpha;
+  const double k2 = fmin(d, g.c2), k1 = fmin(d - k2, g.c1);
+  *hi = (2.0 - al) * k2 + (1.0 - al) * k1;  // (the terms z' = 2 - alpha, then 1 - alpha >= 0)
+  *lo = al * fmin(d, g.c0);                  // (the terms z' = -alpha)
+  // squares: (2 - alpha)^2 first, then the larger of (1 - alpha)^2 and alpha^2
+  const bool one_first = (1.0 - al) >= al;
+  const double va = one_first ? (1.0 - al) * (1.0 - al) : al * al, ca = one_first ? g.c1 : g.c0;
+  const double vb = one_first ? al * al : (1.0 - al) * (1.0 - al), cb = one_first ? g.c0 : g.c1;
+  const double ka = fmin(d - k2, ca), kb = fmin(d - k2 - ka, cb);
+  *q = (2.0 - al) * (2.0 - al) * k2 + va * ka + vb * kb;
+}
+// SIX = false (the four-product form has no partial sums of squares): q1 >= max(|s1|, i's homozygous calls in the visited part - j's
+// missing calls there), which only lowers the variance bound.
+template <bool SIX>
+__device__ __forceinline__ bool pair_hopeless_centred(double thresh, double n_p, double s1, double q1, double s2, double q2, double dot, const GenRow& I,
+                                                      const GenRow& J, double rs) {
+  if constexpr (!SIX) {
+    q1 = fmax(fabs(s1), I.hom_p - J.miss_p);
+    q2 = fmax(fabs(s2), J.hom_p - I.miss_p);
+  }
+  s1 *= I.sgn;
+  s2 *= J.sgn;
+  dot *= I.sgn * J.sgn;
+  const double al = I.alpha, be = J.alpha;
+  // visited part, exact, in z = 1 - x and centred
+  const double zs_p = n_p - s1, zq_p = n_p - 2.0 * s1 + q1;
+  const double ws_p = n_p - s2, wq_p = n_p - 2.0 * s2 + q2;
+  const double zw_p = n_p - s1 - s2 + dot;
+  const double Zs = zs_p - al * n_p, Ws = ws_p - be * n_p;
+  const double Zq = fmax(zq_p - 2.0 * al * zs_p + al * al * n_p, 0.0), Wq = fmax(wq_p - 2.0 * be * ws_p + be * be * n_p, 0.0);
+  const double ZW = zw_p - al * ws_p - be * zs_p + al * be * n_p;
+  const double dmax_i = fmin(rs - J.nr, I.nr), dmax_j = fmin(rs - I.nr, J.nr);
+  const double n_lo = n_p + fmax(I.nr - dmax_i, J.nr - dmax_j);
+  const double n_hi = n_p + fmin(I.nr, J.nr);
+  double hi_i, lo_i, dq_i, hi_j, lo_j, dq_j;
+  gen_drops(I, dmax_i, &hi_i, &lo_i, &dq_i);
+  gen_drops(J, dmax_j, &hi_j, &lo_j, &dq_j);
+  const double zsm = fmax(fabs(Zs + I.a + lo_i), fabs(Zs + I.a - hi_i));
+  const double wsm = fmax(fabs(Ws + J.a + lo_j), fabs(Ws + J.a - hi_j));
+  const double q1lo = fmax(Zq + I.b - dq_i, Zq), q2lo = fmax(Wq + J.b - dq_j, Wq);
+  const double cmax = n_hi * (fabs(ZW) + sqrt(I.b * J.b) * (1.0 + 1e-9)) + zsm * wsm + 1.0;
+  const double var1_lo = n_lo * q1lo - zsm * zsm;
+  const double var2_lo = n_lo * q2lo - wsm * wsm;
+  return (al <= 1.0) && (be <= 1.0) && (var1_lo > 0.0) && (var2_lo > 0.0) && (cmax * cmax * (1.0 + 1e-6) < thresh * (1.0 - 1e-6) * var1_lo * var2_lo);
+}
+
+// A workgroup owns one HALF of a wave item -- its four products at block distances {0, 1} (half 1: on the diagonal the blocks
+// next to it, which hold the pairs in LD) or {2, 3} (half 0: the far end of the window) -- one product per wave:
+// wave w = (J_q, V_{q + t}), q = w >> 1, t = 2 half + (w & 1).  Both halves stage five row-blocks (J0, J1, three V blocks).
+// Early termination is by whole workgroups: at a checkpoint every wave bounds its 1,024 pairs with pair_hopeless_centred(); a wave
+// whose pairs are all hopeless stops multiplying, and when that is all four the workgroup leaves and the CU takes the next
+// one.  (Round 2's layout -- one J block against its four distances per workgroup -- retired the far waves of EVERY workgroup,
+// which emptied two SIMDs of each CU and gained no time; here the far products of a window sit in workgroups of their own.)
+// SIX = false, prune launches (only the predicate is wanted): FOUR products -- dot, nm, sum1, sum2 -- and the two sums of squares
+// from per-variant numbers: ssq1 = (i's homozygous calls) - hm, hm = those of them where j is missing.  There are
+// R = M_j - (calls missing in both) = M_j - (nm + M_i + M_j - N) samples where j is missing and i is not, the x_i over them sum to
+// S_i - sum1 =: xm, so hm lies in [|xm|, R] with the parity of xm.  The predicate cov^2 > thresh var1 var2 is monotone in ssq1 and
+// ssq2 (the reference's own rounding included: products of non-negative doubles), so it is decided whenever both ends of the
+// intervals agree; the few pairs left open are counted exactly on the spot by the whole wave (wave_pair_counts, as in 4.1d).
+template <bool SIX>
 __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(PairKernelArgs A) {
   using G = StageGeom<4>;
+  constexpr int NP = SIX ? 6 : 4;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_src_off[kMfGenDmaPerWave * kMfWaves * 64];
+  __shared__ uint32_t s_live_waves;
   {
     if (*A.route != kRouteGeneral) {
       return;  // complete data, or few enough missing calls for its interval epilogue: pair_mfma_kernel owns this launch
     }
   }
-  const uint32_t n_blocks = A.n_mf_wgs * 8;  // workgroup x wave item x J block
-  const uint32_t per_xcd = (n_blocks + 7) / 8;
+  const uint32_t n_units = A.n_mf_wgs * 8;  // workgroup x wave item x half
+  const uint32_t per_xcd = (n_units + 7) / 8;
   const uint32_t idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (idx >= n_blocks) {
+  if (idx >= n_units) {
     return;
   }
   const MfmaWG* __restrict__ wg = A.mf_wgs + (idx >> 3);
   const MfmaWaveItem* __restrict__ wi = wg->w + ((idx >> 1) & 3);
-  const uint32_t q = idx & 1;
+  const uint32_t half = idx & 1;
   const int32_t jv0 = wi->jv;
   if (jv0 < 0) {
     return;
   }
-  const uint32_t mask4 = (static_cast<uint32_t>(wi->prod_mask) >> (4 * q)) & 0xfu;
+  const uint32_t mask8 = wi->prod_mask;
+  // bit w = the product of wave w
+  const uint32_t mask4 = ((mask8 >> (2 * half)) & 3u) | (((mask8 >> (4 + 2 * half)) & 3u) << 2);
   if (!mask4) {
     return;
   }
@@ -882,11 +1002,13 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
   const uint32_t lane = tid & 63;
   const uint32_t r = lane & 31;
   const uint32_t h = lane >> 5;
+  const uint32_t q = wave >> 1;
+  const uint32_t vk = q + (wave & 1);  // V block of this wave's product among the half's three: V_{2 half + vk}
   const int32_t jfirst = jv0 + static_cast<int32_t>(kMfBlock * q);
   const int32_t vv = wi->vv;
   const uint32_t jend = wi->jend;
-  const bool live = (mask4 >> wave) & 1u;  // this wave's product: (J_q, V_{q + wave})
-  const int32_t vfirst_blk = vv + static_cast<int32_t>(kMfBlock * (q + wave));
+  bool live = (mask4 >> wave) & 1u;
+  const int32_t vfirst_blk = vv + static_cast<int32_t>(kMfBlock * (2 * half + vk));
   const uint32_t row_bytes = static_cast<uint32_t>(A.code_row_bytes);
   const uint32_t n_stages = (A.founder_ct + G::kStageSamples - 1) / G::kStageSamples;
   const uint32_t stage_dwords = kMfGenInstr * 256;
@@ -894,20 +1016,24 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
   stages = (stages > kMfMaxStages) ? kMfMaxStages : stages;
   const uint32_t mine = (kMfGenInstr > wave) ? (kMfGenInstr - wave + kMfWaves - 1) / kMfWaves : 0;
 
-  // ---- DMA plan: row-block slot 0 = the J block, 1 + t = V_{q + t} (a block without candidate pairs is not read: its slot
-  // simply fetches the J rows again)
+  // ---- DMA plan: row-block slots 0, 1 = J0, J1; 2 + k = V_{2 half + k}.  A block no live product reads is not fetched: its slot
+  // simply fetches the rows of the first block that is.
+  const uint32_t need_j = ((mask4 & 3u) ? 1u : 0u) | ((mask4 & 12u) ? 2u : 0u);
+  const uint32_t need_v = ((mask4 & 1u) ? 1u : 0u) | ((mask4 & 6u) ? 2u : 0u) | ((mask4 & 8u) ? 4u : 0u);  // (V_k: wave 0 reads 0, waves 1 and 2 read 1, wave 3 reads 2)
+  const int32_t first_needed = jv0 + static_cast<int32_t>((need_j & 1u) ? 0 : kMfBlock);
+  auto slot_first = [&](uint32_t blk) -> int32_t {
+    if (blk < 2) {
+      return ((need_j >> blk) & 1u) ? (jv0 + static_cast<int32_t>(kMfBlock * blk)) : first_needed;
+    }
+    return ((need_v >> (blk - 2)) & 1u) ? (vv + static_cast<int32_t>(kMfBlock * (2 * half + blk - 2))) : first_needed;
+  };
   const uint8_t* base_t[kMfGenDmaPerWave];
 #pragma unroll
   for (int t = 0; t < static_cast<int>(kMfGenDmaPerWave); ++t) {
     const uint32_t T = wave + kMfWaves * t;
     base_t[t] = A.codes;
     if (T < kMfGenInstr) {
-      const uint32_t blk = T >> 1;
-      int32_t first = jfirst;
-      if ((blk > 0) && ((mask4 >> (blk - 1)) & 1u)) {
-        first = vv + static_cast<int32_t>(kMfBlock * (q + blk - 1));
-      }
-      first = __builtin_amdgcn_readfirstlane(first);
+      const int32_t first = __builtin_amdgcn_readfirstlane(slot_first(T >> 1));
       base_t[t] += static_cast<uint64_t>(static_cast<uint32_t>(first)) * row_bytes;
       const uint32_t L = T * 64 + lane;
       const uint32_t rr = (L >> 2) & 31;
@@ -937,82 +1063,284 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
     lo_j = A.lo[static_cast<uint32_t>(j64)];
   }
   const uint32_t sw = G::swizzle(r);
+  const uint32_t j_slot = q * G::kBlockSlots;
   const uint32_t oH = r * 4 + (h ^ sw);
   const uint32_t oR = r * 4 + ((2 + h) ^ sw);
-  const uint32_t v_slot = (1 + wave) * G::kBlockSlots;
+  const uint32_t v_slot = (2 + vk) * G::kBlockSlots;
 
-  mf_v16f acc[6];  // [0] x.x  [1] n.n  [2] n_i.h_j  [3] n_i.x_j  [4] h_i.n_j  [5] x_i.n_j
+  mf_v16f acc[NP];  // [0] x.x  [1] n.n  [2] n_i.x_j  [3] x_i.n_j  [4] n_i.h_j  [5] h_i.n_j
 #pragma unroll
-  for (int c = 0; c < 6; ++c) {
+  for (int c = 0; c < NP; ++c) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       acc[c][g] = 0.f;
     }
   }
+  // ---- checkpoints: the far half of every wave item, and both halves away from the diagonal.  Two of the list's five (the
+  // second and third: 0.04 and 0.08 behind 1 - sqrt(r2)): each costs a drained ring and ~1,000 FP64 operations per lane.
+  const bool diag = (vv + 3 * static_cast<int32_t>(kMfBlock) == jv0);
+  const uint32_t cp_all = (A.cp_stats && ((half == 0) || !diag)) ? A.n_checkpoints : 0;
+  const uint32_t n_cp = (cp_all >= kGenCheckpointFirst + kGenCheckpoints) ? kGenCheckpoints : ((cp_all > kGenCheckpointFirst) ? (cp_all - kGenCheckpointFirst) : 0u);
+  auto cp_of = [&](uint32_t k) { return kGenCheckpointFirst + k; };
+  auto checkpoint_stage = [&](uint32_t cp) {
+    const uint32_t s = A.checkpoint_chunk[cp] * G::kStagesPerChunk;
+    return (s < n_stages) ? s : n_stages;
+  };
   __syncthreads();  // (s_src_off is complete)
-  uint32_t issued = 0, issue_buf = 0, read_buf = 0;
-  while ((issued < n_stages) && (issued + 1 < stages)) {
-    dma_stage(issued, issue_buf);
-    ++issued;
-    issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
-  }
-  for (uint32_t kc = 0; kc < n_stages; ++kc) {
-    wait_dma_then_barrier(mine * (issued - kc - 1));
-    if (issued < n_stages) {
+  uint32_t issued = 0, issue_buf = 0, read_buf = 0, issued_base = 0;
+  uint32_t next_cp = 0;
+  uint32_t issue_limit = (next_cp < n_cp) ? checkpoint_stage(cp_of(next_cp)) : n_stages;
+  auto ring_fill = [&]() {
+    issue_buf = 0;
+    read_buf = 0;
+    while ((issued < issue_limit) && (issued + 1 < issued_base + stages)) {
       dma_stage(issued, issue_buf);
       ++issued;
       issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
     }
-    const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * stage_dwords);
-    read_buf = (read_buf + 1 == stages) ? 0 : read_buf + 1;
-    if (!live) {
-      continue;
-    }
-    mf_u4 jH = st4[oH], jR = st4[oR];
-    mf_u4 vH = st4[v_slot + oH], vR = st4[v_slot + oR];
-    opaque(jH, jR);
-    Frag jx[4], jn[4], jh[4];
+  };
+  ring_fill();
+  uint32_t stop_stage = n_stages;  // where this wave's product was retired (bookkeeping)
+  for (uint32_t kc = 0; kc < n_stages;) {
+    const uint32_t kc_end = issue_limit;
+    for (; kc < kc_end; ++kc) {
+      wait_dma_then_barrier(mine * (issued - kc - 1));
+      if (issued < issue_limit) {
+        dma_stage(issued, issue_buf);
+        ++issued;
+        issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
+      }
+      const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * stage_dwords);
+      read_buf = (read_buf + 1 == stages) ? 0 : read_buf + 1;
+      if (!live) {
+        continue;
+      }
+      mf_u4 jH = st4[j_slot + oH], jR = st4[j_slot + oR];
+      mf_u4 vH = st4[v_slot + oH], vR = st4[v_slot + oR];
+      opaque(jH, jR);
+      Frag jx[4], jn[4], jh[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      fp4_of_codes(jH[ks], jR[ks], jx[ks]);
-      fp4_nh_of_codes(jH[ks], jR[ks], jx[ks], jn[ks], jh[ks]);
-    }
-    opaque(vH, vR);
+      for (int ks = 0; ks < 4; ++ks) {
+        fp4_of_codes(jH[ks], jR[ks], jx[ks]);
+        fp4_nh_of_codes(jH[ks], jR[ks], jx[ks], jn[ks], jh[ks]);
+      }
+      opaque(vH, vR);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      Frag vx, vn, vh;
-      fp4_of_codes(vH[ks], vR[ks], vx);
-      fp4_nh_of_codes(vH[ks], vR[ks], vx, vn, vh);
-      // rows of C = first variant i (A operand: the V block), columns = second variant j (B operand: the J block)
-      acc[0] = mfma_fp4(vx, jx[ks], acc[0]);
-      acc[1] = mfma_fp4(vn, jn[ks], acc[1]);
-      acc[2] = mfma_fp4(vn, jh[ks], acc[2]);
-      acc[3] = mfma_fp4(vn, jx[ks], acc[3]);
-      acc[4] = mfma_fp4(vh, jn[ks], acc[4]);
-      acc[5] = mfma_fp4(vx, jn[ks], acc[5]);
+      for (int ks = 0; ks < 4; ++ks) {
+        Frag vx, vn, vh;
+        fp4_of_codes(vH[ks], vR[ks], vx);
+        fp4_nh_of_codes(vH[ks], vR[ks], vx, vn, vh);
+        // rows of C = first variant i (A operand: the V block), columns = second variant j (B operand: the J block)
+        acc[0] = mfma_fp4(vx, jx[ks], acc[0]);
+        acc[1] = mfma_fp4(vn, jn[ks], acc[1]);
+        acc[2] = mfma_fp4(vn, jx[ks], acc[2]);
+        acc[3] = mfma_fp4(vx, jn[ks], acc[3]);
+        if constexpr (SIX) {
+          acc[4] = mfma_fp4(vn, jh[ks], acc[4]);
+          acc[5] = mfma_fp4(vh, jn[ks], acc[5]);
+        }
+      }
     }
+    if (kc >= n_stages) {
+      break;
+    }
+    // ---- checkpoint (block-uniform; issued == kc: the ring is empty and the LDS is scratch) ----
+    __syncthreads();
+    if (tid == 0) {
+      s_live_waves = 0;
+    }
+    {
+      // the rows' remainder statistics (cp_gen_slot, 16 bytes) come in by LDS-DMA like the rows themselves: row-block slot T by
+      // wave T & 3, lanes 0..31 = its rows' slots of this checkpoint, lanes 32..63 = their whole-row slots
+      const uint8_t* cpg = reinterpret_cast<const uint8_t*>(A.cp_stats);
+      const uint32_t gen_slot = kCpSlots + 1 + next_cp;  // (the remainder behind checkpoint kGenCheckpointFirst + next_cp)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint32_t T = wave + kMfWaves * t;
+        if (T < kMfGenRowBlocks) {
+          const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(slot_first(T)));
+          uint32_t var = first + r;
+          var = (var < A.n_local) ? var : (A.n_local - 1);
+          const uint64_t off = (static_cast<uint64_t>(var) * kCpStride + (h ? static_cast<uint32_t>(kCpSlots) : gen_slot)) * sizeof(cp_gen_slot);  // lanes 32..63: the whole-row slot
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cpg + off),
+                                           (__attribute__((address_space(3))) void*)(lds + kMfGenCpStatDwords + T * 256), 16, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // (drains the DMA: the slots are in LDS; s_live_waves is zero)
+    if (live) {
+      const cp_gen_slot* __restrict__ cpl = reinterpret_cast<const cp_gen_slot*>(lds + kMfGenCpStatDwords);  // [row-block slot][64 lanes]
+      const uint64_t seen = static_cast<uint64_t>(kc) * G::kStageSamples;
+      const double seen_d = static_cast<double>((seen < A.founder_ct) ? seen : A.founder_ct);
+      const GenRow gj = gen_row(cpl[q * 64 + r], cpl[q * 64 + 32 + r], seen_d);
+      uint32_t* mine_epi = lds + wave * (kMfGenCpWaveDwords + kMfGenCpRowDwords);
+      GenRow* rows_i = reinterpret_cast<GenRow*>(mine_epi + kMfGenCpWaveDwords);
+      if (h == 0) {
+        rows_i[r] = gen_row(cpl[(2 + vk) * 64 + r], cpl[(2 + vk) * 64 + 32 + r], seen_d);  // (read back by other lanes of this wave only)
+      }
+      const double rs = (seen < A.founder_ct) ? static_cast<double>(A.founder_ct - seen) : 1.0;
+      bool hopeless = true;
+#pragma unroll
+      for (int round = 0; round < 16 / static_cast<int>(kMfGenCpRound); ++round) {
+        if (__all(hopeless)) {  // (one pair that may still reach the threshold keeps the product: no need to look at the rest)
+#pragma unroll
+          for (int c = 0; c < NP; ++c) {
+#pragma unroll
+            for (int g = 0; g < static_cast<int>(kMfGenCpRound); ++g) {
+              mine_epi[(c * kMfGenCpRound + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>(acc[c][round * kMfGenCpRound + g]));
+            }
+          }
+#pragma unroll 1
+          for (uint32_t gg = 0; gg < kMfGenCpRound; ++gg) {
+            const uint32_t g = round * kMfGenCpRound + gg;
+            const uint32_t row = (g & 3) + 8 * (g >> 2) + 4 * h;
+            const int64_t i64 = static_cast<int64_t>(vfirst_blk) + row;
+            if ((lo_j != 0xffffffffu) && (i64 >= static_cast<int64_t>(lo_j)) && (i64 < j64)) {
+              const GenRow gi = rows_i[row];
+              auto val = [&](uint32_t c) { return static_cast<double>(static_cast<int32_t>(mine_epi[(c * kMfGenCpRound + gg) * 64 + lane])); };
+              hopeless = hopeless && pair_hopeless_centred<SIX>(A.thresh, val(1), val(3), SIX ? val(5) : 0.0, val(2), SIX ? val(4) : 0.0, val(0), gi, gj, rs);
+            }
+          }
+        }
+      }
+      if (__all(hopeless)) {
+        live = false;
+        stop_stage = kc;
+      } else if (lane == 0) {
+        atomicAdd(&s_live_waves, 1u);
+      }
+    }
+    __syncthreads();
+    if (!s_live_waves) {
+      break;  // nothing left for this workgroup
+    }
+    ++next_cp;
+    issued_base = kc;
+    issue_limit = (next_cp < n_cp) ? checkpoint_stage(cp_of(next_cp)) : n_stages;
+    ring_fill();
+  }
+  if ((lane == 0) && (stop_stage < n_stages) && ((mask4 >> wave) & 1u)) {
+    atomicAdd(A.counters + 2, static_cast<unsigned long long>(n_stages - stop_stage) * 4ull);  // product x 64-sample k-steps not multiplied
   }
   // ---- epilogue: straight from the registers (one product per wave) ----
   uint32_t n_true = 0;
-  if (live && (lo_j != 0xffffffffu) && (static_cast<int64_t>(lo_j) < j64)) {
-    const uint32_t j = static_cast<uint32_t>(j64);
-    const bool alt_j = (A.recs[j].flags & 1u) != 0;
+  if constexpr (SIX) {
+    if (live && (lo_j != 0xffffffffu) && (static_cast<int64_t>(lo_j) < j64)) {
+      const uint32_t j = static_cast<uint32_t>(j64);
+      const bool alt_j = (A.recs[j].flags & 1u) != 0;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int64_t i64 = static_cast<int64_t>(vfirst_blk) + (g & 3) + 8 * (g >> 2) + 4 * h;
-      if ((i64 >= static_cast<int64_t>(lo_j)) && (i64 < j64)) {
-        // the image's orientation -> the records' (major allele): x_i, x_j change sign with their row's ALT-major flag
-        const bool alt_i = (A.recs[static_cast<uint32_t>(i64)].flags & 1u) != 0;
-        ldp_pair_stats_t ps;
-        const int32_t d = static_cast<int32_t>(acc[0][g]), s2 = static_cast<int32_t>(acc[3][g]), s1 = static_cast<int32_t>(acc[5][g]);
-        ps.dot = (alt_i != alt_j) ? -d : d;
-        ps.nm = static_cast<uint32_t>(static_cast<int32_t>(acc[1][g]));
-        ps.ssq2 = static_cast<uint32_t>(static_cast<int32_t>(acc[2][g]));
-        ps.sum2 = alt_j ? -s2 : s2;
-        ps.ssq1 = static_cast<uint32_t>(static_cast<int32_t>(acc[4][g]));
-        ps.sum1 = alt_i ? -s1 : s1;
-        n_true += emit_pair(A, static_cast<uint32_t>(i64), j, lo_j, ps) ? 1 : 0;
+      for (int g = 0; g < 16; ++g) {
+        const int64_t i64 = static_cast<int64_t>(vfirst_blk) + (g & 3) + 8 * (g >> 2) + 4 * h;
+        if ((i64 >= static_cast<int64_t>(lo_j)) && (i64 < j64)) {
+          // the image's orientation -> the records' (major allele): x_i, x_j change sign with their row's ALT-major flag
+          const bool alt_i = (A.recs[static_cast<uint32_t>(i64)].flags & 1u) != 0;
+          ldp_pair_stats_t ps;
+          const int32_t d = static_cast<int32_t>(acc[0][g]), s2 = static_cast<int32_t>(acc[2][g]), s1 = static_cast<int32_t>(acc[3][g]);
+          ps.dot = (alt_i != alt_j) ? -d : d;
+          ps.nm = static_cast<uint32_t>(static_cast<int32_t>(acc[1][g]));
+          ps.ssq2 = static_cast<uint32_t>(static_cast<int32_t>(acc[SIX ? 4 : 0][g]));
+          ps.sum2 = alt_j ? -s2 : s2;
+          ps.ssq1 = static_cast<uint32_t>(static_cast<int32_t>(acc[SIX ? 5 : 0][g]));
+          ps.sum1 = alt_i ? -s1 : s1;
+          n_true += emit_pair(A, static_cast<uint32_t>(i64), j, lo_j, ps) ? 1 : 0;
+        }
       }
+    }
+  } else {
+    __syncthreads();  // (every wave is past its last stage: the ring is this epilogue's scratch)
+  }
+  if constexpr (!SIX) if (live) {  // (wave-uniform: the exact route below needs the whole wave)
+    // the accumulators go through LDS, eight rows at a time, so that the classification is ONE rolled loop: unrolled sixteen
+    // times next to 64 live accumulators it made hipcc spill three of them inside the stage loop
+    uint32_t* epi4 = lds + wave * (4 * 8 * 64);
+    const bool j_ok = (lo_j != 0xffffffffu) && (static_cast<int64_t>(lo_j) < j64);
+    const uint32_t j = j_ok ? static_cast<uint32_t>(j64) : 0u;
+    ldp_variant_rec rj;
+    rj.nm_ct = 0;
+    rj.sum = 0;
+    rj.ssq = 0;
+    rj.flags = 0;
+    if (j_ok) {
+      rj = A.recs[j];
+    }
+    const bool alt_j = (rj.flags & 1u) != 0;
+    const int64_t N = static_cast<int64_t>(A.founder_ct);
+    uint32_t n_open = 0;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) {
+          epi4[(c * 8 + g8) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>(acc[c][round * 8 + g8]));
+        }
+      }
+#pragma unroll 1
+    for (uint32_t g8 = 0; g8 < 8; ++g8) {
+      const uint32_t g = round * 8 + g8;
+      const int64_t i64 = static_cast<int64_t>(vfirst_blk) + (g & 3) + 8 * (g >> 2) + 4 * h;
+      const bool valid = j_ok && (i64 >= static_cast<int64_t>(lo_j)) && (i64 < j64);
+      const uint32_t i = valid ? static_cast<uint32_t>(i64) : 0u;
+      ldp_pair_stats_t ps;
+      ps.dot = 0;
+      int cls = 0;
+      uint32_t alt_ij = 0;
+      if (valid) {
+        const ldp_variant_rec ri = A.recs[i];
+        const bool alt_i = (ri.flags & 1u) != 0;
+        alt_ij = (alt_i ? 1u : 0u) | (alt_j ? 2u : 0u);
+        const int32_t d = static_cast<int32_t>(epi4[(0 * 8 + g8) * 64 + lane]), s2 = static_cast<int32_t>(epi4[(2 * 8 + g8) * 64 + lane]),
+                      s1 = static_cast<int32_t>(epi4[(3 * 8 + g8) * 64 + lane]);
+        ps.dot = (alt_i != alt_j) ? -d : d;
+        ps.nm = epi4[(1 * 8 + g8) * 64 + lane];
+        ps.sum2 = alt_j ? -s2 : s2;
+        ps.sum1 = alt_i ? -s1 : s1;
+        const int64_t Mi = N - ri.nm_ct, Mj = N - rj.nm_ct;
+        const int64_t mm = static_cast<int64_t>(ps.nm) + Mi + Mj - N;  // missing in both
+        const int64_t R1 = Mj - mm, R2 = Mi - mm;                      // j missing and i called; i missing and j called
+        int64_t xm1 = static_cast<int64_t>(ri.sum) - ps.sum1, xm2 = static_cast<int64_t>(rj.sum) - ps.sum2;
+        xm1 = (xm1 < 0) ? -xm1 : xm1;
+        xm2 = (xm2 < 0) ? -xm2 : xm2;
+        const int64_t hm1_hi = R1 - ((R1 - xm1) & 1), hm2_hi = R2 - ((R2 - xm2) & 1);
+        ldp_pair_stats_t hi = ps, lo = ps;
+        hi.ssq1 = static_cast<uint32_t>(static_cast<int64_t>(ri.ssq) - xm1);
+        hi.ssq2 = static_cast<uint32_t>(static_cast<int64_t>(rj.ssq) - xm2);
+        const int64_t l1 = static_cast<int64_t>(ri.ssq) - hm1_hi, l2 = static_cast<int64_t>(rj.ssq) - hm2_hi;
+        lo.ssq1 = static_cast<uint32_t>((l1 > 0) ? l1 : 0);
+        lo.ssq2 = static_cast<uint32_t>((l2 > 0) ? l2 : 0);
+        // (a consistent pair of inputs has 0 <= xm <= R; anything else is left to the exact route)
+        const bool sane = (mm >= 0) && (xm1 <= R1) && (xm2 <= R2) && (xm1 <= static_cast<int64_t>(ri.ssq)) && (xm2 <= static_cast<int64_t>(rj.ssq));
+        if (sane && exceeds(hi, A.thresh)) {
+          cls = 1;
+        } else if (sane && !exceeds_clamped(lo, A.thresh)) {
+          cls = 0;
+        } else {
+          cls = 2;
+        }
+        if (cls == 1) {
+          atomicOr(&A.pred[A.row_off[j] + ((i >> 5) - (lo_j >> 5))], 1u << (i & 31));
+          ++n_true;
+        }
+      }
+      unsigned long long open = __ballot(cls == 2);
+      while (open) {
+        const int l = __builtin_ctzll(open);
+        open &= open - 1;
+        const uint32_t ii = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(i), l));
+        const uint32_t jj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(j), l));
+        const int32_t dd = __builtin_amdgcn_readlane(ps.dot, l);
+        const uint32_t aa = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(alt_ij), l));
+        const ldp_pair_stats_t st = wave_pair_counts(A, ii, jj, dd, lane, (aa & 1u) != 0, (aa & 2u) != 0);
+        if ((static_cast<int>(lane) == l) && exceeds(st, A.thresh)) {
+          atomicOr(&A.pred[A.row_off[j] + ((i >> 5) - (lo_j >> 5))], 1u << (i & 31));
+          ++n_true;
+        }
+        n_open += (lane == 0) ? 1u : 0u;
+      }
+    }
+    }
+    if ((lane == 0) && n_open) {
+      atomicAdd(A.counters + 3, static_cast<unsigned long long>(n_open));
     }
   }
   n_true = wave_reduce_add(n_true);
@@ -1081,13 +1409,19 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
       if (const char* kb = getenv("LDP_DEBUG_MFMA_GEN_LDS_KB")) {
         bytes = std::min<size_t>(std::max<size_t>(static_cast<size_t>(atoi(kb)), 20), 150) * 1024;
       }
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_general_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_general_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
       return bytes;
     }();
     PairKernelArgs g = a_in;
     g.lds_dwords = static_cast<uint32_t>(glds / sizeof(uint32_t));
     const uint32_t gper_xcd = (g.n_mf_wgs * 8 + 7) / 8;
-    hipLaunchKernelGGL(pair_mfma_general_kernel, dim3(gper_xcd * 8), dim3(kMfWaves * 64), glds, stream, g);
+    // only the predicate is wanted (no integers, no r^2 values): the four-product form
+    if (a_in.mf_four && !a_in.stats && !a_in.r2_out && !a_in.r2_hits) {
+      hipLaunchKernelGGL(pair_mfma_general_kernel<false>, dim3(gper_xcd * 8), dim3(kMfWaves * 64), glds, stream, g);
+    } else {
+      hipLaunchKernelGGL(pair_mfma_general_kernel<true>, dim3(gper_xcd * 8), dim3(kMfWaves * 64), glds, stream, g);
+    }
   }
   if (ev) {
     (void)hipEventRecord(ev[2], stream);

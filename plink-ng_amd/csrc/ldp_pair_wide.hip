@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
           first = (first < A.n_local) ? first : (A.n_local - 1);
           uint32_t var = first + (lane >> 1);
           var = (var < A.n_local) ? var : (A.n_local - 1);
-          const uint64_t off = static_cast<uint64_t>(var) * (kCpSlots * sizeof(cp_slot)) + ((lane & 1) ? kCheckpoints : next_cp) * sizeof(cp_slot);
+          const uint64_t off = static_cast<uint64_t>(var) * (kCpStride * sizeof(cp_slot)) + ((lane & 1) ? kCheckpoints : next_cp) * sizeof(cp_slot);
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cps + off),
                                            (__attribute__((address_space(3))) void*)(lds + kWdCpScratchDwords + T * 256), 16, 0, 0);
         }

@@ -55,6 +55,10 @@ def one_case(pkg, rng, idx):
     wide = int(rng.choice([-1, -1, 0, 1, 3]))  # (drawn for every case, so that the sequence of cases stays the same)
     if wide >= 0:
         eng.set_option("wide_min_reach", wide)  # send narrower bands through the 8 x 8 tile plan of the wide-band kernel too
+    if idx % 3 == 2:
+        eng.set_option("pair_four", 0)   # the six-product form of the missing-call kernel (prune launches default to four)
+    if idx % 5 == 4:
+        eng.set_option("pair_sparse", 0)  # rows with a few missing calls through the missing-call kernel too
     eng.set_variants(chr_idx, bps)
     packed = T.pack_2bit(raw)
     if rng.random() < 0.5:

@@ -566,9 +566,15 @@ def test_rows_with_a_few_missing_calls(gpu_pkg, n, miss, r2, redraw, frac):
     packed = T.pack_2bit(raw)
     opts = {} if frac is None else {"sparse_frac": frac}
     got, c1 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, opts)
-    six, c0 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, {"pair_sparse": 0})
+    six, c0 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, {"pair_sparse": 0, "pair_four": 0})
     # which kernel owned the launches is read from the route words the device wrote, not from timings
     assert c0["sparse_exact_pairs"] == 0 and c0["route_general_launches"] > 0 and c0["route_sparse_launches"] == 0 and c0["route_complete_launches"] == 0
+    # ... and the four-product form of that kernel (two sums of squares from per-variant intervals): the same set,
+    # nearly every pair settled without a recount
+    four, c4 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, {"pair_sparse": 0})
+    assert c4["route_general_launches"] > 0 and c4["route_sparse_launches"] == 0
+    assert np.array_equal(four, six) and c4["pred_true"] == c0["pred_true"]
+    assert c4["sparse_exact_pairs"] < (0.05 if frac is None else 0.5) * c4["candidate_pairs"]
     assert c1["route_sparse_launches"] > 0 and c1["route_general_launches"] == 0 and c1["route_complete_launches"] == 0, "the launches must have taken the interval path"
     assert np.array_equal(got, six)
     assert c1["pred_true"] == c0["pred_true"] > 0
@@ -579,6 +585,39 @@ def test_rows_with_a_few_missing_calls(gpu_pkg, n, miss, r2, redraw, frac):
     inv, mf, _ = T.oracle_prepare(raw)
     want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 150, 1, False, r2, 2)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n,miss,r2,redraw", [
+    (20000, 0.01, 0.5, 0.05),
+    (20000, 0.05, 0.2, 0.55),     # config 5's rate and threshold, with planted pairs around it
+    (6000, 0.2, 0.5, 0.29),       # wide intervals next to a crowd of pairs at r^2 ~ 0.5: many recounts, same set
+    (3001, 0.6, 0.1, 0.3),        # most calls missing
+    (50000, 0.02, 0.8, 0.1),
+])
+def test_four_product_form_of_the_missing_call_kernel(gpu_pkg, n, miss, r2, redraw):
+    """prune launches over rows with missing calls multiply four products per pair (dot, nm, the two sums); the sums of
+    squares come from per-variant intervals -- ssq1 = hom_i - hm, |S_i - sum1| <= hm <= #(j missing, i called), same parity -- and the
+    predicate, monotone in both, is decided where the ends agree; the rest is recounted exactly.  Same prune set and the same
+    number of true predicates as the six-product form and the oracle, with and without early termination, also when some rows are
+    complete and some are mostly missing."""
+    m = 700
+    raw = T.synth_raw_codes(m, n, seed=n % 97 + 11, missing_rate=miss, ld_copy_prob=0.7, redraw=redraw)
+    rng = np.random.default_rng(n)
+    raw[rng.choice(m, size=40, replace=False)] = np.where(raw[0] == 3, 0, raw[0])[None, :]   # some complete rows (copies: in LD with each other)
+    for v in rng.choice(m, size=20, replace=False):
+        raw[v, rng.random(n) < 0.7] = 3                                                        # and some that are mostly missing
+    chr_idx, bps = make_positions(m, 2, 5)
+    packed = T.pack_2bit(raw)
+    six, c6 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, {"pair_sparse": 0, "pair_four": 0})
+    four, c4 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, {"pair_sparse": 0})
+    four_x, c4x = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, {"pair_sparse": 0, "early_exit": 0})
+    assert c6["route_general_launches"] > 0 and c4["route_general_launches"] > 0 and c6["sparse_exact_pairs"] == 0
+    assert np.array_equal(four, six) and np.array_equal(four_x, six)
+    assert c4x["pred_true"] == c6["pred_true"] > 0 and c4["pred_true"] <= c4x["pred_true"]   # (a retired product's pairs are false)
+    assert c4x["mfma_skipped_product_stages"] == 0
+    inv, mf, _ = T.oracle_prepare(raw)
+    want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 150, 1, False, r2, 2)
+    assert np.array_equal(four, want)
 
 
 def test_route_follows_the_mean_not_the_worst_row(gpu_pkg):
@@ -593,13 +632,14 @@ def test_route_follows_the_mean_not_the_worst_row(gpu_pkg):
             raw[v, rng.random(n) < 0.07] = 3
         packed = T.pack_2bit(raw)
         got, c1 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, 0.5, {})
-        six, c0 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, 0.5, {"pair_sparse": 0})
+        six, c0 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, 0.5, {"pair_sparse": 0, "pair_four": 0})
         assert np.array_equal(got, six) and c1["pred_true"] == c0["pred_true"]
         assert c0["route_general_launches"] > 0 and c0["route_sparse_launches"] == 0
         if sparse:
             assert c1["route_sparse_launches"] > 0 and c1["route_general_launches"] == 0 and c1["sparse_exact_pairs"] > 0
         else:
-            assert c1["route_general_launches"] > 0 and c1["route_sparse_launches"] == 0 and c1["sparse_exact_pairs"] == 0
+            assert c1["route_general_launches"] > 0 and c1["route_sparse_launches"] == 0
+            assert c1["sparse_exact_pairs"] < 0.01 * c1["candidate_pairs"]   # (the four-product form recounts what its intervals leave open)
         inv, mf, _ = T.oracle_prepare(raw)
         want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 150, 1, False, 0.5, 2)
         assert np.array_equal(got, want)
