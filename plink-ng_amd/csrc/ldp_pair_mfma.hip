@@ -960,6 +960,33 @@ __device__ __forceinline__ bool pair_hopeless_centred(double thresh, double n_p,
 // whose pairs are all hopeless stops multiplying, and when that is all four the workgroup leaves and the CU takes the next
 // one.  (Round 2's layout -- one J block against its four distances per workgroup -- retired the far waves of EVERY workgroup,
 // which emptied two SIMDs of each CU and gained no time; here the far products of a window sit in workgroups of their own.)
+// The four-product forms' decision for one pair from dot, nm, sum1, sum2 (in ps, major-allele orientation) and the two variants'
+// records: 1 = the predicate holds, 0 = it does not, 2 = open (recount).  See the comment on pair_mfma_general_kernel.
+__device__ __forceinline__ int classify_four(const ldp_pair_stats_t& ps, const ldp_variant_rec& ri, const ldp_variant_rec& rj, int64_t N, double thresh) {
+  const int64_t Mi = N - ri.nm_ct, Mj = N - rj.nm_ct;
+  const int64_t mm = static_cast<int64_t>(ps.nm) + Mi + Mj - N;  // missing in both
+  const int64_t R1 = Mj - mm, R2 = Mi - mm;                      // j missing and i called; i missing and j called
+  int64_t xm1 = static_cast<int64_t>(ri.sum) - ps.sum1, xm2 = static_cast<int64_t>(rj.sum) - ps.sum2;
+  xm1 = (xm1 < 0) ? -xm1 : xm1;
+  xm2 = (xm2 < 0) ? -xm2 : xm2;
+  const int64_t hm1_hi = R1 - ((R1 - xm1) & 1), hm2_hi = R2 - ((R2 - xm2) & 1);
+  ldp_pair_stats_t hi = ps, lo = ps;
+  hi.ssq1 = static_cast<uint32_t>(static_cast<int64_t>(ri.ssq) - xm1);
+  hi.ssq2 = static_cast<uint32_t>(static_cast<int64_t>(rj.ssq) - xm2);
+  const int64_t l1 = static_cast<int64_t>(ri.ssq) - hm1_hi, l2 = static_cast<int64_t>(rj.ssq) - hm2_hi;
+  lo.ssq1 = static_cast<uint32_t>((l1 > 0) ? l1 : 0);
+  lo.ssq2 = static_cast<uint32_t>((l2 > 0) ? l2 : 0);
+  // (a consistent pair of inputs has 0 <= xm <= R; anything else is left to the exact route)
+  const bool sane = (mm >= 0) && (xm1 <= R1) && (xm2 <= R2) && (xm1 <= static_cast<int64_t>(ri.ssq)) && (xm2 <= static_cast<int64_t>(rj.ssq));
+  if (sane && exceeds(hi, thresh)) {
+    return 1;
+  }
+  if (sane && !exceeds_clamped(lo, thresh)) {
+    return 0;
+  }
+  return 2;
+}
+
 // SIX = false, prune launches (only the predicate is wanted): FOUR products -- dot, nm, sum1, sum2 -- and the two sums of squares
 // from per-variant numbers: ssq1 = (i's homozygous calls) - hm, hm = those of them where j is missing.  There are
 // R = M_j - (calls missing in both) = M_j - (nm + M_i + M_j - N) samples where j is missing and i is not, the x_i over them sum to
@@ -1295,28 +1322,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
         ps.nm = epi4[(1 * 8 + g8) * 64 + lane];
         ps.sum2 = alt_j ? -s2 : s2;
         ps.sum1 = alt_i ? -s1 : s1;
-        const int64_t Mi = N - ri.nm_ct, Mj = N - rj.nm_ct;
-        const int64_t mm = static_cast<int64_t>(ps.nm) + Mi + Mj - N;  // missing in both
-        const int64_t R1 = Mj - mm, R2 = Mi - mm;                      // j missing and i called; i missing and j called
-        int64_t xm1 = static_cast<int64_t>(ri.sum) - ps.sum1, xm2 = static_cast<int64_t>(rj.sum) - ps.sum2;
-        xm1 = (xm1 < 0) ? -xm1 : xm1;
-        xm2 = (xm2 < 0) ? -xm2 : xm2;
-        const int64_t hm1_hi = R1 - ((R1 - xm1) & 1), hm2_hi = R2 - ((R2 - xm2) & 1);
-        ldp_pair_stats_t hi = ps, lo = ps;
-        hi.ssq1 = static_cast<uint32_t>(static_cast<int64_t>(ri.ssq) - xm1);
-        hi.ssq2 = static_cast<uint32_t>(static_cast<int64_t>(rj.ssq) - xm2);
-        const int64_t l1 = static_cast<int64_t>(ri.ssq) - hm1_hi, l2 = static_cast<int64_t>(rj.ssq) - hm2_hi;
-        lo.ssq1 = static_cast<uint32_t>((l1 > 0) ? l1 : 0);
-        lo.ssq2 = static_cast<uint32_t>((l2 > 0) ? l2 : 0);
-        // (a consistent pair of inputs has 0 <= xm <= R; anything else is left to the exact route)
-        const bool sane = (mm >= 0) && (xm1 <= R1) && (xm2 <= R2) && (xm1 <= static_cast<int64_t>(ri.ssq)) && (xm2 <= static_cast<int64_t>(rj.ssq));
-        if (sane && exceeds(hi, A.thresh)) {
-          cls = 1;
-        } else if (sane && !exceeds_clamped(lo, A.thresh)) {
-          cls = 0;
-        } else {
-          cls = 2;
-        }
+        cls = classify_four(ps, ri, rj, N, A.thresh);
         if (cls == 1) {
           atomicOr(&A.pred[A.row_off[j] + ((i >> 5) - (lo_j >> 5))], 1u << (i & 31));
           ++n_true;
