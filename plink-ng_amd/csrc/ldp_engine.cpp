@@ -111,6 +111,10 @@ struct ldp_engine {
   std::vector<uint32_t> owned;            // subcontig ids
   std::vector<uint32_t> local_to_global;
   std::vector<int64_t> global_to_local;   // -1 = not owned
+  struct OwnedRun {
+    uint32_t g_first, g_end;  // global variants [g_first, g_end): owned, consecutive locally too
+  };
+  std::vector<OwnedRun> owned_runs;        // sorted; what a load call walks instead of the variants
   std::vector<uint32_t> lo_local;
   std::vector<uint64_t> row_off;          // local_ct + 1
   std::vector<uint64_t> pair_off;         // local_ct + 1
@@ -822,6 +826,7 @@ void build_shard(ldp_engine* e) {
   e->owned.clear();
   e->local_to_global.clear();
   e->global_to_local.assign(e->variant_ct, -1);
+  e->owned_runs.clear();
   uint32_t local = 0;
   for (uint32_t k = 0; k < e->subs.size(); ++k) {
     Subcontig& s = e->subs[k];
@@ -830,6 +835,11 @@ void build_shard(ldp_engine* e) {
     }
     s.local_first = local;
     e->owned.push_back(k);
+    if ((!e->owned_runs.empty()) && (e->owned_runs.back().g_end == s.first)) {
+      e->owned_runs.back().g_end = s.first + s.len;
+    } else if (s.len) {
+      e->owned_runs.push_back({s.first, s.first + s.len});
+    }
     for (uint32_t v = 0; v < s.len; ++v) {
       e->global_to_local[s.first + v] = local + v;
       e->local_to_global.push_back(s.first + v);
@@ -1444,10 +1454,15 @@ int replay_progressive(ldp_engine* e, const uint32_t* pred, const double* mf, st
   double t_first = 0.0;
   hipError_t herr = hipSuccess;
   const size_t n_groups = e->groups.size();
+  const bool timeline = getenv("LDP_DEBUG_TIMELINE") != nullptr;
+  const double t_enter = now_ms();
   for (size_t gi = 0; gi < n_groups; ++gi) {
     herr = hipEventSynchronize(e->groups[gi].ev_done);
     if (herr != hipSuccess) {
       break;
+    }
+    if (timeline) {
+      fprintf(stderr, "replay: group %zu back %.2f ms after the replay threads started\n", gi, now_ms() - t_enter);
     }
     if (!gi) {
       t_first = now_ms();
@@ -1461,6 +1476,9 @@ int replay_progressive(ldp_engine* e, const uint32_t* pred, const double* mf, st
   }
   for (std::thread& th : pool) {
     th.join();
+  }
+  if (timeline) {
+    fprintf(stderr, "replay: workers joined %.2f ms after they started\n", now_ms() - t_enter);
   }
   if (herr != hipSuccess) {
     return hipfail(e, herr, "waiting for a launch group");
@@ -2908,15 +2926,14 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
   uint32_t g = first_variant;
   const uint32_t gend = first_variant + n;
   while (g < gend) {
-    if (e->global_to_local[g] < 0) {
-      ++g;
+    // maximal run of owned variants consecutive both globally and locally (owned_runs: a million-variant call is one or a few
+    // of them, and walking the variants instead kept the count pass from starting for most of a millisecond)
+    auto it = std::upper_bound(e->owned_runs.begin(), e->owned_runs.end(), g, [](uint32_t v, const ldp_engine::OwnedRun& r) { return v < r.g_first; });
+    if ((it == e->owned_runs.begin()) || (g >= (it - 1)->g_end)) {
+      g = (it == e->owned_runs.end()) ? gend : std::min(gend, it->g_first);  // not owned: on to the next run
       continue;
     }
-    // maximal run of owned variants consecutive both globally and locally
-    uint32_t run = 1;
-    while ((g + run < gend) && (e->global_to_local[g + run] == e->global_to_local[g] + run)) {
-      ++run;
-    }
+    const uint32_t run = std::min(gend, (it - 1)->g_end) - g;
     uint32_t done = 0;
     while (done < run) {
       uint32_t cnt = run - done;
@@ -3023,11 +3040,18 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
         HIP_TRY(e, hipEventRecord(e->stage_done[slot], e->stream));
         slot = (slot + 1) % kStageSlots;
       }
-      for (uint32_t q = 0; q < cnt; ++q) {
-        e->loaded[l0 + q] = 1;
-        e->load_tag[l0 + q] = e->load_epoch;
-        if ((base_encoding != LDP_GENO_INVERSE) && !(h_row_inverse && h_row_inverse[g + done + q - first_variant])) {
-          e->mf_set[l0 + q] = 2;  // derived from the device's allele counts at the next ldp_run()
+      std::fill(e->loaded.begin() + l0, e->loaded.begin() + l0 + cnt, static_cast<uint8_t>(1));
+      std::fill(e->load_tag.begin() + l0, e->load_tag.begin() + l0 + cnt, e->load_epoch);
+      if (base_encoding != LDP_GENO_INVERSE) {
+        // derived from the device's allele counts at the next ldp_run()
+        if (!h_row_inverse) {
+          std::fill(e->mf_set.begin() + l0, e->mf_set.begin() + l0 + cnt, static_cast<uint8_t>(2));
+        } else {
+          for (uint32_t q = 0; q < cnt; ++q) {
+            if (!h_row_inverse[g + done + q - first_variant]) {
+              e->mf_set[l0 + q] = 2;
+            }
+          }
         }
       }
       // Pair tiles whose variants are all converted start right away when the input comes over PCIe (the GPU is
