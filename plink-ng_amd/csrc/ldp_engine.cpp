@@ -3179,7 +3179,10 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
   }
   bool have_carried = e->ld_base_valid && (e->dec_next_variant == first_variant);
   // ---- in launches of at most ~256 MiB of rows
-  const uint32_t rows_per_launch = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / stride)));
+  uint32_t rows_per_launch = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / stride)));
+  if (const char* dbg = getenv("LDP_DEBUG_DECODE_ROWS")) {  // (test hook: many small launches, LD chains cut everywhere)
+    rows_per_launch = static_cast<uint32_t>(std::max(1, atoi(dbg)));
+  }
   std::vector<ldp::PgenRecDesc> descs;
   std::vector<uint32_t> multi;
   std::vector<uint8_t> h_inverse;

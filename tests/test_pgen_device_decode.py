@@ -99,6 +99,45 @@ def test_every_record_type_of_the_reference_writer(gpu_pkg, tmp_path, m, n, seed
     f.close()
 
 
+@pytest.mark.skipif(not T.have_ref(), reason="reference binary not built")
+def test_small_launches_and_sharded_engines(gpu_pkg, tmp_path, monkeypatch):
+    """The call's own split into launches (here forced to 5 rows: every LD chain is cut) and engines that own only some of the
+    subcontigs (LD chains run through records the engine does not keep): the union of two shards equals the unsharded result."""
+    pkg = gpu_pkg
+    m, n = 1200, 700
+    raw = structured_codes(m, n, 21)
+    T.write_pgen_fixed(str(tmp_path / "f"), raw, ["1"] * m, np.arange(m) + 1)
+    cp = T.run_ref(["--pfile", "f", "--make-pgen", "--out", "v"], str(tmp_path))
+    assert cp.returncode == 0, cp.stdout
+    f = pkg.PgenFile(str(tmp_path / "v.pgen"))
+    rows = f.read()
+    host = engine(pkg, n, m)
+    host.load_genotypes_host(0, rows, pkg.LDP_GENO_REF)
+    want = host.run()
+    monkeypatch.setenv("LDP_DEBUG_DECODE_ROWS", "5")
+    dev = engine(pkg, n, m)
+    dev.load_pgen_records(0, f)
+    assert_same_rows(host, dev, m)
+    monkeypatch.delenv("LDP_DEBUG_DECODE_ROWS")
+    # four chromosomes, two shards on the same device
+    chr_idx = (np.arange(m) * 4 // m).astype(np.uint32)
+    bps = (np.arange(m, dtype=np.uint32) + 1) * 1000
+    whole = pkg.LdPruneEngine(n, 40, 1, False, 0.3, order=2, device=0)
+    whole.set_variants(chr_idx, bps)
+    whole.load_genotypes_host(0, rows, pkg.LDP_GENO_REF)
+    want4 = whole.run()
+    got = np.zeros(m, dtype=bool)
+    for rank in range(2):
+        eng = pkg.LdPruneEngine(n, 40, 1, False, 0.3, order=2, device=0)
+        eng.set_variants(chr_idx, bps)
+        eng.set_shard(rank, 2)
+        for a, b in [(0, 333), (333, 901), (901, m)]:
+            eng.load_pgen_records(a, f, a, b - a)
+        got |= eng.run()
+    assert np.array_equal(got, want4) and want4.sum() > 0 and want.sum() > 0
+    f.close()
+
+
 def collapse(lo, hi, alt_ct):
     """Get1Multiallelic + GetMajIdxMulti in numpy: (INVERSE-coded codes, major allele, its frequency) of one variant."""
     called = lo != 255
