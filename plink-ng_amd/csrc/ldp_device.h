@@ -246,6 +246,7 @@ constexpr double kSmallEpsilon = 0.00000000000005684341886080801486968994140625;
 // ---- .pgen records decoded on the device (ldp_pgen_decode.hip) ----------------------------------------------------
 constexpr uint32_t kPgenBaseCarried = 0xfffffffeu;  // PgenRecDesc::base: the row the engine kept from the previous launch
 constexpr uint32_t kPgenNoBase = 0xffffffffu;
+constexpr uint64_t kPgenLdsRowBytes = 128 * 1024;   // rows up to this size (524,288 samples) are assembled in LDS
 struct PgenRecDesc {
   uint64_t off;        // first byte of the record in the launch's byte buffer
   uint32_t len;        // bytes

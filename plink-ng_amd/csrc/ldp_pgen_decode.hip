@@ -22,6 +22,8 @@
 #include "ldp_device.h"
 #include "ldp_pair_device.h"
 
+#include <cstdlib>
+
 namespace ldp {
 
 namespace {
@@ -96,10 +98,20 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x) {
   return t;
 }
 
+// a load that sees what the atomics of other waves (performed at the L2) have done to a row: not through this CU's L1
+__device__ __forceinline__ uint32_t load_l2(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The 2-bit field of `sample` becomes `code`.  Entries of a list touch distinct samples, so the field still holds what the row was
+// filled with whatever the neighbours in its dword are doing: one read, and ONE atomic that flips the bits that differ (none when
+// the list repeats the row's value) -- the lists of a reference-written file are a few hundred million entries per million
+// variants, and two atomics each was what the kernel spent its time on.
 __device__ __forceinline__ void set_field(uint32_t* row, uint32_t sample, uint32_t code) {
   const uint32_t sh = 2 * (sample & 15);
-  atomicAnd(row + (sample >> 4), ~(3u << sh));
-  atomicOr(row + (sample >> 4), code << sh);
+  uint32_t* w = row + (sample >> 4);
+  const uint32_t old = (load_l2(w) >> sh) & 3u;
+  if (old != code) {
+    atomicXor(w, (old ^ code) << sh);
+  }
 }
 
 // exclusive prefix of one number per thread (and the total), through LDS
@@ -221,7 +233,20 @@ __device__ __forceinline__ uint32_t packed_get(const uint8_t* base, uint64_t idx
   return (static_cast<uint32_t>(base[bit >> 3]) >> (bit & 7)) & ((1u << width_bits) - 1u);
 }
 
+// ... the same on a row staged in LDS (rows of up to kPgenLdsRowBytes: the record is assembled there, its list goes in with LDS
+// atomics -- two orders of magnitude cheaper than atomics at the L2 -- and the finished row is written out once, coalesced)
+__device__ __forceinline__ void set_field_lds(uint32_t* row, uint32_t sample, uint32_t code) {
+  const uint32_t sh = 2 * (sample & 15);
+  uint32_t* w = row + (sample >> 4);
+  const uint32_t old = (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> sh) & 3u;
+  if (old != code) {
+    __hip_atomic_fetch_xor(w, (old ^ code) << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+
+template <bool LDS>
 __global__ __launch_bounds__(kThreads) void pgen_main_kernel(PgenDecodeArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t row_lds[];
   __shared__ uint32_t s_tmp[kThreads];
   __shared__ int s_bad;
   const uint32_t v = blockIdx.x;
@@ -235,7 +260,8 @@ __global__ __launch_bounds__(kThreads) void pgen_main_kernel(PgenDecodeArgs A) {
   if (tid == 0) {
     s_bad = 0;
   }
-  uint32_t* out = reinterpret_cast<uint32_t*>(A.rows + static_cast<uint64_t>(v) * A.stride);
+  uint32_t* gout = reinterpret_cast<uint32_t*>(A.rows + static_cast<uint64_t>(v) * A.stride);
+  uint32_t* out = LDS ? row_lds : gout;  // where the row is assembled
   const uint32_t row_dwords = static_cast<uint32_t>(A.stride / 4);
   const uint32_t n = A.sample_ct;
   const uint64_t nb = (static_cast<uint64_t>(n) + 3) / 4;
@@ -321,7 +347,14 @@ __global__ __launch_bounds__(kThreads) void pgen_main_kernel(PgenDecodeArgs A) {
     } else if (D.L) {
       owns_end = (D.g0 < D.g1) && (D.g1 == D.G);
       const uint8_t* vals = D.vals;
-      if (!difflist_walk(D, c.end, n, &main_end, [&](uint32_t id, uint32_t k) { set_field(out, id, (static_cast<uint32_t>(vals[k >> 2]) >> (2 * (k & 3))) & 3u); })) {
+      if (!difflist_walk(D, c.end, n, &main_end, [&](uint32_t id, uint32_t k) {
+            const uint32_t code = (static_cast<uint32_t>(vals[k >> 2]) >> (2 * (k & 3))) & 3u;
+            if constexpr (LDS) {
+              set_field_lds(row_lds, id, code);
+            } else {
+              set_field(gout, id, code);
+            }
+          })) {
         bad = true;
       }
     } else {
@@ -343,7 +376,7 @@ __global__ __launch_bounds__(kThreads) void pgen_main_kernel(PgenDecodeArgs A) {
   }
   // 0 <-> 2 for type 3 (GenovecInvertUnsafe), then the bits behind the last sample are cleared whatever the record said
   for (uint32_t d = tid; d < row_dwords; d += kThreads) {
-    uint32_t w = out[d];
+    uint32_t w = LDS ? row_lds[d] : load_l2(gout + d);
     if (type == 3) {
       w ^= ((~w) << 1) & 0xaaaaaaaau;
     }
@@ -353,7 +386,7 @@ __global__ __launch_bounds__(kThreads) void pgen_main_kernel(PgenDecodeArgs A) {
     } else if (s0 + 16 > n) {
       w &= (1u << (2 * (n - static_cast<uint32_t>(s0)))) - 1u;
     }
-    out[d] = w;
+    gout[d] = w;
   }
 }
 
@@ -693,11 +726,18 @@ hipError_t launch_pgen_main(const PgenDecodeArgs& a, hipStream_t stream) {
     return hipSuccess;
   }
   PgenDecodeArgs p = a;
-  p.pass = 0;
-  hipLaunchKernelGGL(pgen_main_kernel, dim3(a.n), dim3(kThreads), 0, stream, p);
-  if (a.any_ld) {
-    p.pass = 1;
-    hipLaunchKernelGGL(pgen_main_kernel, dim3(a.n), dim3(kThreads), 0, stream, p);
+  // rows that fit the LDS beside a few other workgroups are assembled there
+  static const bool lds_ok = []() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pgen_main_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kPgenLdsRowBytes)) == hipSuccess;
+  }();
+  const bool in_lds = lds_ok && (a.stride <= kPgenLdsRowBytes) && (getenv("LDP_DEBUG_DECODE_NO_LDS") == nullptr);
+  for (int pass = 0; pass < (a.any_ld ? 2 : 1); ++pass) {
+    p.pass = pass;
+    if (in_lds) {
+      hipLaunchKernelGGL(pgen_main_kernel<true>, dim3(a.n), dim3(kThreads), static_cast<size_t>(a.stride), stream, p);
+    } else {
+      hipLaunchKernelGGL(pgen_main_kernel<false>, dim3(a.n), dim3(kThreads), 0, stream, p);
+    }
   }
   return hipGetLastError();
 }

@@ -119,6 +119,12 @@ def test_small_launches_and_sharded_engines(gpu_pkg, tmp_path, monkeypatch):
     dev.load_pgen_records(0, f)
     assert_same_rows(host, dev, m)
     monkeypatch.delenv("LDP_DEBUG_DECODE_ROWS")
+    # rows assembled in global memory (what rows beyond 128 KiB take) instead of LDS
+    monkeypatch.setenv("LDP_DEBUG_DECODE_NO_LDS", "1")
+    dev_g = engine(pkg, n, m)
+    dev_g.load_pgen_records(0, f)
+    assert_same_rows(host, dev_g, m)
+    monkeypatch.delenv("LDP_DEBUG_DECODE_NO_LDS")
     # four chromosomes, two shards on the same device
     chr_idx = (np.arange(m) * 4 // m).astype(np.uint32)
     bps = (np.arange(m, dtype=np.uint32) + 1) * 1000
