@@ -698,6 +698,54 @@ def test_early_termination_missing_calls_adversarial(gpu_pkg):
         assert c1["pred_true"] == c0["pred_true"]
 
 
+@pytest.mark.parametrize("n,r2,miss", [(20000, 0.5, 0.002), (20000, 0.5, 0.0045), (9000, 0.2, 0.001), (50000, 0.7, 0.003)])
+def test_early_termination_with_a_few_missing_calls(gpu_pkg, n, r2, miss):
+    """Narrow bands (config 2's shape: ~70 variants per window) whose rows miss a few calls take the single-form kernel with the
+    interval epilogue (4.1d).  Same prune set and true-predicate count with early termination on and off, as the six-product
+    kernel (which does stop at checkpoints) and as the oracle -- with pairs that only become correlated in the last 40 % of the
+    samples, and with the missing calls of some rows sitting on their partners' rare carriers."""
+    pkg = gpu_pkg
+    m = 1500
+    rng = np.random.default_rng(n + int(1000 * r2))
+    raw = T.synth_raw_codes(m, n, seed=n % 89 + 5, missing_rate=miss, ld_copy_prob=0.6, redraw=0.08)
+    cut = int(0.6 * n)
+    for v in range(10, m, 9):          # late LD: unrelated over the first 60 %, a copy of the neighbour afterwards
+        raw[v, :cut] = rng.permutation(raw[v, :cut])
+        raw[v, cut:] = raw[v - 1, cut:]
+    tail = np.arange(int(0.75 * n), n)
+    for v in range(5, m - 2, 37):      # a rare variant whose carriers come late, a partner missing on a handful of them
+        raw[v] = 0
+        carriers = rng.choice(tail, size=30, replace=False)
+        raw[v, carriers] = 1
+        raw[v + 1] = raw[v]
+        raw[v + 1, carriers[:4]] = 3
+    chr_idx = (np.arange(m) // 750).astype(np.uint32)
+    bps = (10000 + 2875 * (np.arange(m) % 750)).astype(np.uint32)
+    packed = T.pack_2bit(raw)
+    on, c1 = _run_early_exit(pkg, packed, n, chr_idx, bps, 200000, 1, True, r2, 2, True)
+    off, c0 = _run_early_exit(pkg, packed, n, chr_idx, bps, 200000, 1, True, r2, 2, False)
+    assert c1["route_sparse_launches"] > 0 and c1["route_general_launches"] == 0 and c1["route_complete_launches"] == 0
+    assert c0["mfma_skipped_product_stages"] == 0
+    assert np.array_equal(on, off) and c1["pred_true"] == c0["pred_true"] > 0
+    six, c6 = _run_sparse_bp(pkg, packed, n, chr_idx, bps, r2)
+    assert np.array_equal(on, six) and c6["route_general_launches"] > 0
+    inv, mf, _ = T.oracle_prepare(raw)
+    want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 200000, 1, True, r2, 2)
+    assert np.array_equal(on, want)
+
+
+def _run_sparse_bp(pkg, packed, n, chr_idx, bps, r2):
+    eng = pkg.LdPruneEngine(n, 200000, 1, True, r2, order=2, device=0)
+    eng.set_option("pair_sparse", 0)
+    eng.set_option("pair_four", 0)
+    eng.set_variants(chr_idx, bps)
+    eng.load_genotypes_host(0, packed, pkg.LDP_GENO_REF)
+    removed = eng.run()
+    ctr = eng.counters()
+    eng.close()
+    return removed, ctr
+
+
 @pytest.mark.parametrize("miss", [0.0, 0.003])
 def test_early_termination_wide_window(gpu_pkg, miss):
     """A 400-variant window: five blocks per J-tile, the far ones (their own second-variant rows, d0 >= 32) stop at the
