@@ -37,6 +37,7 @@ One JSON line is printed by rank 0.
                 prune set compared with the HIP path's; plus both binaries end to end on the sample's files.
 """
 import argparse
+import ctypes
 import json
 import os
 import re
@@ -223,8 +224,9 @@ class Workload:
     image.  `resident`: one engine holds the whole share and its rows stay in HBM across steps.  Otherwise the share does not
     fit HBM and the rank works through its chromosomes one engine at a time, generating each chromosome's rows inside the step."""
 
-    def __init__(self, pkg, torch, cfg, missing_rate, rank, world, device, options=None):
+    def __init__(self, pkg, torch, cfg, missing_rate, rank, world, device, options=None, multiallelic=None):
         self.pkg, self.torch, self.cfg, self.missing_rate = pkg, torch, cfg, missing_rate
+        self.multi = None
         self.rank, self.world, self.device = rank, world, device
         self.options = options or {}
         self.founder_ct = cfg["samples"]
@@ -261,7 +263,65 @@ class Workload:
         self.segs = {}
         if self.resident:
             self._generate(planner, self.owned, 0)
+            if multiallelic:
+                self._make_multiallelic(planner, *multiallelic)
         torch.cuda.synchronize()
+
+    def _make_multiallelic(self, eng, n_runs, run_len):
+        """Config 5's multiallelic sites: n_runs stretches of run_len variants get a second ALT allele and arrive, inside every step,
+        as .pgen variant records resident in HBM -- plain main track + auxiliary track 1 (both patch sets as bit arrays: a tenth of the
+        het / hom-ALT calls carry ALT2) -- that ldp_load_pgen_records decodes and collapses major-vs-rest on the device.
+        The records are built once, here, from the generated rows."""
+        pkg, torch, n = self.pkg, self.torch, self.founder_ct
+        first0, ln0, ptr0, stride = self.segs[id(eng)][0]
+        nb = (n + 3) // 4
+        rng = np.random.default_rng(7)
+        starts = [first0 + int((k + 0.5) * ln0 / n_runs) for k in range(n_runs)]
+        blobs, runs, offset, checks = [], [], 0, []
+        shifts = np.array([0, 2, 4, 6], dtype=np.uint8)
+        for st in starts:
+            rows = torch.empty((run_len, stride), dtype=torch.uint8, device="cuda")
+            assert pkg.hip_memcpy_dtod(rows.data_ptr(), ptr0 + (st - first0) * stride, run_len * stride) == 0
+            torch.cuda.synchronize()
+            host = rows.cpu().numpy()
+            recs = (pkg.ldp_pgen_rec * run_len)()
+            for q in range(run_len):
+                codes = ((host[q, :nb, None] >> shifts) & 3).reshape(-1)[:n]
+                main = host[q, :nb].copy()
+                if n % 4:
+                    main[-1] &= (1 << (2 * (n % 4))) - 1
+                i1, i2 = np.flatnonzero(codes == 1), np.flatnonzero(codes == 2)
+                b1, b2 = rng.random(len(i1)) < 0.1, rng.random(len(i2)) < 0.1
+                both = rng.random(int(b2.sum())) < 0.5                      # ALT2/ALT2 (else ALT1/ALT2)
+                rec = np.concatenate([main, np.array([0], dtype=np.uint8), np.packbits(b1, bitorder="little"), np.packbits(b2, bitorder="little"),
+                                      np.packbits(both, bitorder="little")])
+                recs[q].offset, recs[q].length, recs[q].vrtype, recs[q].allele_ct = offset, len(rec), 0x08, 3
+                offset += len(rec)
+                blobs.append(rec)
+                if q == 0:   # expected record of the collapsed row, for the parity flag below
+                    lo = np.where(codes == 3, 255, np.where(codes == 2, 1, 0)).astype(np.int64)
+                    hi = np.where(codes == 3, 255, np.where(codes == 0, 0, 1)).astype(np.int64)
+                    hi[i1[b1]] = 2
+                    k2 = i2[b2]
+                    lo[k2] = np.where(both, 2, 1)
+                    hi[k2] = 2
+                    called = codes != 3
+                    cnt = np.bincount(np.concatenate([lo[called], hi[called]]), minlength=3)[:3]
+                    f0, f1 = cnt[0] * (1.0 / cnt.sum()), cnt[1] * (1.0 / cnt.sum())
+                    maj = 0 if f0 >= 0.5 else (1 if f1 >= 0.5 else (2 if (cnt[2] > max(cnt[0], cnt[1])) else (0 if f0 >= f1 else 1)))
+                    nonmaj = (lo[called] != maj).astype(np.int64) + (hi[called] != maj)
+                    checks.append((st, int(called.sum()), int((nonmaj == 0).sum()) - int((nonmaj == 2).sum()), int((nonmaj != 1).sum())))
+            runs.append((st, run_len, recs))
+        data = np.concatenate(blobs)
+        self.multi = {"runs": runs, "bytes": torch.from_numpy(data).cuda(), "nbytes": int(len(data)), "variants": n_runs * run_len, "checks": checks,
+                      "ms_calls": []}
+
+    def _load_multiallelic(self, eng):
+        t0 = time.perf_counter()
+        for st, ln, recs in self.multi["runs"]:
+            eng._ck(eng._L.ldp_load_pgen_records(eng._h, st, ln, ctypes.c_void_p(self.multi["bytes"].data_ptr()), self.multi["nbytes"], self.pkg.LDP_MEM_DEVICE,
+                                                  recs, None, self.founder_ct, None))
+        self.multi["ms_calls"].append(1e3 * (time.perf_counter() - t0))
 
     def _engine(self):
         e = self.pkg.LdPruneEngine(self.founder_ct, self.window_bp, 1, True, self.cfg["r2"], device=self.device)
@@ -289,6 +349,8 @@ class Workload:
                 self._generate(eng, runs, base)
             for first, ln, ptr, stride in self.segs[id(eng)]:
                 eng.load_genotypes_device(first, ln, ptr, stride, self.pkg.LDP_GENO_REF)
+            if self.multi:
+                self._load_multiallelic(eng)
             bm = eng.run_bitmap()  # uint64 words over the engine's variants; only this rank's bits are set
             ctrs.append(eng.counters())
             if self.resident:
@@ -499,14 +561,25 @@ def main():
         legs = {}
         half = max(2, args.steps // 2)
 
-        def leg(cfg_l, missing, options, steps):
-            w = Workload(pkg, torch, cfg_l, missing, 0, 1, local_rank, options)
+        def leg(cfg_l, missing, options, steps, multiallelic=None):
+            w = Workload(pkg, torch, cfg_l, missing, 0, 1, local_rank, options, multiallelic)
             el, kk, rem = timed(w, steps, 1)
             c = {k: float(np.mean([q[k] for q in kk])) for k in kk[-1]}
             r = pair_roofline(c, cfg_l["samples"], w.local_ct, missing, cfg_l["variants"], cfg_l["window_kb"])
             res = {"ms_per_step": 1000.0 * el / steps, "count_pass_ms": c["ms_prepare"], "pair_kernels_ms": c["ms_pair_kernel"], "kernel": r["kernel"],
                    "routes": r["routes"], "pairs_counted_exactly": int(c["sparse_exact_pairs"]), "candidate_pairs": int(c["candidate_pairs"]),
                    "variants_removed": int(distmod.bitmap_to_mask(rem, cfg_l["variants"]).sum()), "roofline": r}
+            if w.multi:
+                eng = w.engines[0][0]
+                ok = True
+                for st, nm, sm, sq in w.multi["checks"]:
+                    rec = eng.variant_recs(st, 1)[0]
+                    ok = ok and (int(rec["nm_ct"]), int(rec["sum"]), int(rec["ssq"])) == (nm, sm, sq)
+                res["multiallelic"] = {"variants": w.multi["variants"], "runs": len(w.multi["runs"]), "record_bytes": w.multi["nbytes"],
+                                       "ms_per_step_in_ldp_load_pgen_records": float(np.mean(w.multi["ms_calls"][1:] or w.multi["ms_calls"])),
+                                       "records_match_numpy_collapse": bool(ok),
+                                       "what": "variants with two ALT alleles arriving as .pgen records resident in HBM (main track + aux track 1), decoded and "
+                                               "collapsed major-vs-rest on the device inside every step (ldp_load_pgen_records, one call per run of consecutive variants)"}
             w.close()
             return res
 
@@ -524,11 +597,13 @@ def main():
             c3 = dict(CONFIGS["config3"], variants=args.leg_variants)
             for key, rate in (("config3_density", 0.0), ("config5_density", 0.05)):
                 try:
-                    L = leg(c3, rate, {}, 3)
+                    # config 5: 2 % of the variants are multiallelic (runs of 400 consecutive variants, one ldp_load_pgen_records call each:
+                    # a loader hands over records in batches, and a call costs ~0.8 ms of latency whatever it holds up to a few hundred)
+                    L = leg(c3, rate, {}, 3, None if rate == 0.0 else (max(1, c3["variants"] // 20000), 400))
                     L["what"] = ("%d samples x %d variants at %d bp, --indep-pairwise %gkb %g, %s; rows resident, count pass inside the step" %
                                  (c3["samples"], c3["variants"], c3["spacing"], c3["window_kb"], c3["r2"],
-                                  "complete data" if rate == 0.0 else "5 % missing calls in every variant (config 5's multiallelic sites reach the pair kernels as "
-                                  "ordinary 2-bit rows -- the major-vs-rest collapse happens where the record is decoded, DESIGN 7 -- and are modelled as such)"))
+                                  "complete data" if rate == 0.0 else "5 % missing calls in every variant, 2 % of the variants multiallelic (see `multiallelic`; the "
+                                  "reference slice below is the same generator without the second ALT allele)"))
                     if not args.no_cpu_baseline:
                         m_slice = args.cpu_sample_variants or 11000
                         cb = cpu_baseline(pkg, torch, c3["samples"], m_slice, c3["spacing"], c3["window_kb"], c3["r2"], rate, cli_compare=False)

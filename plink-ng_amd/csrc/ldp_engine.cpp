@@ -213,6 +213,8 @@ struct ldp_engine {
     void* ptr[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   } dec;
+  uint8_t* h_dec_pin = nullptr;  // pinned: the launch's descriptors going up, its per-record results coming down (pageable copies cost ~0.2 ms each)
+  size_t dec_pin_cap = 0;
   uint8_t* d_ld_base = nullptr;
   size_t ld_base_cap = 0;
   bool ld_base_valid = false;
@@ -358,6 +360,11 @@ void free_device(ldp_engine* e) {
   e->d_ld_base = nullptr;
   e->ld_base_cap = 0;
   e->ld_base_valid = false;
+  if (e->h_dec_pin) {
+    (void)hipHostFree(e->h_dec_pin);
+    e->h_dec_pin = nullptr;
+    e->dec_pin_cap = 0;
+  }
   (void)hipFree(e->d_sample_map);
   (void)hipFree(e->d_gather);
   (void)hipFree(e->d_extra_het);
@@ -3183,17 +3190,38 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
   if (const char* dbg = getenv("LDP_DEBUG_DECODE_ROWS")) {  // (test hook: many small launches, LD chains cut everywhere)
     rows_per_launch = static_cast<uint32_t>(std::max(1, atoi(dbg)));
   }
-  std::vector<ldp::PgenRecDesc> descs;
   std::vector<uint32_t> multi;
   std::vector<uint8_t> h_inverse;
-  std::vector<double> h_maj_freq;
-  std::vector<uint32_t> h_maj_idx;
   int status = LDP_OK;
+  // pinned staging for one launch: descriptors | multiallelic record indices | major-allele frequencies | major alleles | error word
+  {
+    const size_t rows_max = static_cast<size_t>(rows_per_launch) + 1;
+    const size_t want = rows_max * (sizeof(ldp::PgenRecDesc) + sizeof(uint32_t) + sizeof(double) + sizeof(uint32_t)) + 64;
+    if (e->dec_pin_cap < want) {
+      HIP_TRY(e, hipStreamSynchronize(e->stream));
+      if (e->h_dec_pin) {
+        (void)hipHostFree(e->h_dec_pin);
+        e->h_dec_pin = nullptr;
+        e->dec_pin_cap = 0;
+      }
+      HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_dec_pin), want, hipHostMallocDefault));
+      e->dec_pin_cap = want;
+    }
+  }
+  const size_t rows_cap = static_cast<size_t>(rows_per_launch) + 1;
+  ldp::PgenRecDesc* descs = reinterpret_cast<ldp::PgenRecDesc*>(e->h_dec_pin);
+  double* h_maj_freq = reinterpret_cast<double*>(e->h_dec_pin + rows_cap * sizeof(ldp::PgenRecDesc));
+  uint32_t* h_multi = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(h_maj_freq) + rows_cap * sizeof(double));
+  uint32_t* h_maj_idx = h_multi + rows_cap;
+  int* h_err_pin = reinterpret_cast<int*>(h_maj_idx + rows_cap);
   for (uint32_t q0 = 0; (q0 < n) && (status == LDP_OK); q0 += rows_per_launch) {
+    const double t_call = now_ms();
     const uint32_t cnt = std::min(rows_per_launch, n - q0);
     const bool with_base_rec = (q0 == 0) && (ld_base != nullptr);
     const uint32_t rows = cnt + (with_base_rec ? 1u : 0u);  // (the caller's ld_base record is decoded as an extra row behind the others)
-    descs.assign(rows, ldp::PgenRecDesc());
+    for (uint32_t q = 0; q < rows; ++q) {
+      descs[q] = ldp::PgenRecDesc();
+    }
     multi.clear();
     uint32_t last_alone = with_base_rec ? cnt : (have_carried ? kPgenBaseCarried : kPgenNoBase);
     int64_t last_alone_row = -1;
@@ -3235,9 +3263,10 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
       return rc;
     }
     int* d_err = reinterpret_cast<int*>(static_cast<uint32_t*>(p_mi) + multi.size() + 1);
-    HIP_TRY(e, hipMemcpyAsync(p_recs, descs.data(), rows * sizeof(ldp::PgenRecDesc), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(p_recs, descs, rows * sizeof(ldp::PgenRecDesc), hipMemcpyHostToDevice, e->stream));
     if (!multi.empty()) {
-      HIP_TRY(e, hipMemcpyAsync(p_multi, multi.data(), multi.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+      memcpy(h_multi, multi.data(), multi.size() * sizeof(uint32_t));
+      HIP_TRY(e, hipMemcpyAsync(p_multi, h_multi, multi.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     }
     HIP_TRY(e, hipMemsetAsync(d_err, 0, sizeof(int), e->stream));
     HIP_TRY(e, hipMemsetAsync(p_inv, 0, rows, e->stream));
@@ -3275,16 +3304,17 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
     if (krc != hipSuccess) {
       return hipfail(e, krc, "pgen_aux1_kernel launch");
     }
-    int h_err = 0;
     h_inverse.assign(cnt, 0);
-    h_maj_freq.assign(multi.size(), 0.0);
-    h_maj_idx.assign(multi.size(), 0);
-    HIP_TRY(e, hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    *h_err_pin = 0;
+    HIP_TRY(e, hipMemcpyAsync(h_err_pin, d_err, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     if (!multi.empty()) {
-      HIP_TRY(e, hipMemcpyAsync(h_maj_freq.data(), p_mf, multi.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-      HIP_TRY(e, hipMemcpyAsync(h_maj_idx.data(), p_mi, multi.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(e, hipMemcpyAsync(h_maj_freq, p_mf, multi.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(e, hipMemcpyAsync(h_maj_idx, p_mi, multi.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     }
+    const double t_q = now_ms();
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const double t_s = now_ms();
+    const int h_err = *h_err_pin;
     if (h_err) {
       e->ld_base_valid = false;
       const uint32_t bad = static_cast<uint32_t>(h_err - 1);
@@ -3305,6 +3335,9 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
     }
     status = load_rows_impl(e, first_variant + q0, cnt, DA.rows, stride, LDP_MEM_DEVICE, LDP_GENO_REF | (mapped ? LDP_GENO_MAPPED : 0), multi.empty() ? nullptr : DA.row_inverse,
                             multi.empty() ? nullptr : h_inverse.data());
+    if (getenv("LDP_DEBUG_TIMELINE")) {
+      fprintf(stderr, "decode launch of %u rows: queued in %.3f ms, device done %.3f ms later, rows loaded %.3f ms after that\n", rows, t_q - t_call, t_s - t_q, now_ms() - t_s);
+    }
     if (status == LDP_OK) {
       for (size_t k = 0; k < multi.size(); ++k) {
         const int64_t l = e->global_to_local[first_variant + q0 + multi[k]];

@@ -29,6 +29,7 @@ namespace ldp {
 namespace {
 
 constexpr int kThreads = 256;
+constexpr uint32_t kChunk = 8;  // dwords of a row a thread handles together in the auxiliary-track kernel: their bit-array windows are loaded together
 
 struct ByteCursor {
   const uint8_t* p;
@@ -76,9 +77,14 @@ __device__ __forceinline__ uint32_t read_le(const uint8_t* p, uint32_t nbytes) {
   return v;
 }
 
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+
 // dword d of a byte string of nbytes (bytes past the end read as zero)
 __device__ __forceinline__ uint32_t dword_of_bytes(const uint8_t* p, uint64_t nbytes, uint64_t d) {
   const uint64_t off = d * 4;
+  if (off + 4 <= nbytes) {
+    return *reinterpret_cast<const u32_unaligned*>(p + off);  // (records start at any byte: one unaligned load, not four byte loads)
+  }
   uint32_t w = 0;
   for (uint32_t k = 0; k < 4; ++k) {
     if (off + k < nbytes) {
@@ -274,6 +280,7 @@ __global__ __launch_bounds__(kThreads) void pgen_main_kernel(PgenDecodeArgs A) {
         bad = true;
         break;
       }
+#pragma unroll 4
       for (uint32_t d = tid; d < row_dwords; d += kThreads) {
         out[d] = dword_of_bytes(c.p, nb, d);
       }
@@ -439,13 +446,30 @@ __device__ __forceinline__ uint64_t patch_value_bytes(uint32_t cat, uint32_t all
   return (static_cast<uint64_t>(patched) * 2 * w + 7) / 8;
 }
 
+// bits [k, k + nb) of a bit array (nb <= 16), read as ONE (unaligned) dword where the record has four bytes left, byte by byte
+// at its very end: the category samples of a dword of the row own consecutive bits of the patch set's array
+__device__ __forceinline__ uint32_t bit_window(const uint8_t* bits, const uint8_t* rec_end, uint32_t k, uint32_t nb) {
+  const uint8_t* p = bits + (k >> 3);
+  uint32_t w = 0;
+  if (p + 4 <= rec_end) {
+    w = *reinterpret_cast<const u32_unaligned*>(p);
+  } else {
+    for (uint32_t b = 0; (b < 4) && (p + b < rec_end); ++b) {
+      w |= static_cast<uint32_t>(p[b]) << (8 * b);
+    }
+  }
+  return (w >> (k & 7)) & ((1u << nb) - 1u);
+}
+
 // category mask of a dword of main-track codes: bit 2 s set iff sample s has code `cat` (1 or 2)
 __device__ __forceinline__ uint32_t cat_mask(uint32_t w, uint32_t cat) {
   const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
   return (cat == 1) ? (lo & ~hi) : (hi & ~lo);
 }
 
+template <bool LDS>
 __global__ __launch_bounds__(kThreads) void pgen_aux1_kernel(PgenDecodeArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t main_lds[];  // LDS: the main track, read five times below, staged once
   __shared__ uint32_t s_tmp[kThreads];
   __shared__ int s_cnt[256];
   __shared__ int s_bad;
@@ -466,10 +490,31 @@ __global__ __launch_bounds__(kThreads) void pgen_aux1_kernel(PgenDecodeArgs A) {
     s_bad = 0;
   }
   s_cnt[tid] = 0;
+  // Every thread owns a contiguous run of the row's dwords (the rank of a sample within its category runs along the row), which
+  // makes its reads of the row from global memory a chain of latencies; from LDS they are not.
+  const uint32_t* mtrack = row;
+  if constexpr (LDS) {
+    // (one wave per SIMD: nothing hides a load's latency but the thread's own other loads -- eight in flight)
+    for (uint32_t d = tid; d < n_dwords; d += 8 * kThreads) {
+      uint32_t v8[8];
+#pragma unroll
+      for (uint32_t i = 0; i < 8; ++i) {
+        v8[i] = (d + i * kThreads < n_dwords) ? row[d + i * kThreads] : 0u;
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < 8; ++i) {
+        if (d + i * kThreads < n_dwords) {
+          main_lds[d + i * kThreads] = v8[i];
+        }
+      }
+    }
+    __syncthreads();
+    mtrack = main_lds;
+  }
   // ---- the main track's categories: counts, and each thread's rank among them
   uint32_t my1 = 0, my2 = 0, my3 = 0;
   for (uint32_t d = d0; d < d1; ++d) {
-    const uint32_t w = row[d];
+    const uint32_t w = mtrack[d];
     my1 += __popc(cat_mask(w, 1));
     my2 += __popc(cat_mask(w, 2));
     my3 += __popc(w & (w >> 1) & 0x55555555u);
@@ -489,7 +534,11 @@ __global__ __launch_bounds__(kThreads) void pgen_aux1_kernel(PgenDecodeArgs A) {
     ByteCursor c{A.bytes + A.main_end[v], rec_end, true};
     const uint32_t fmt = c.u8();
     bad = !c.ok;
-    for (uint32_t cat = 1; (cat <= 2) && !bad; ++cat) {
+#pragma unroll
+    for (uint32_t cat = 1; cat <= 2; ++cat) {
+      if (bad) {
+        break;
+      }
       PatchSet& P = S[cat - 1];
       P.fmt = (cat == 1) ? (fmt & 15u) : (fmt >> 4);
       const uint32_t ncat = (cat == 1) ? n1 : n2;
@@ -504,9 +553,23 @@ __global__ __launch_bounds__(kThreads) void pgen_aux1_kernel(PgenDecodeArgs A) {
           bad = true;
           break;
         }
+        // how many of this thread's category samples are patched: per dword of the row one window of the bit array
         uint32_t set = 0;
-        for (uint32_t k = pre; k < pre + mine; ++k) {
-          set += (static_cast<uint32_t>(P.bits[k >> 3]) >> (k & 7)) & 1u;
+        {
+          uint32_t k = pre;
+          for (uint32_t d = d0; d < d1; d += kChunk) {
+            uint32_t kk[kChunk], nbits[kChunk];
+#pragma unroll
+            for (uint32_t i = 0; i < kChunk; ++i) {
+              nbits[i] = (d + i < d1) ? __popc(cat_mask(mtrack[d + i], cat)) : 0u;
+              kk[i] = k;
+              k += nbits[i];
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < kChunk; ++i) {  // (independent loads: in flight together)
+              set += nbits[i] ? __popc(bit_window(P.bits, rec_end, kk[i], nbits[i])) : 0u;
+            }
+          }
         }
         P.k_first = pre;
         P.rank_first = block_exclusive(set, s_tmp, tid, &P.patched);
@@ -565,6 +628,7 @@ __global__ __launch_bounds__(kThreads) void pgen_aux1_kernel(PgenDecodeArgs A) {
   // sample for the bit-array form (its own), looked up for the list form
   auto for_each_patch = [&](bool lists, auto f) -> bool {
     bool ok = true;
+#pragma unroll
     for (uint32_t cat = 1; cat <= 2; ++cat) {
       const PatchSet& P = S[cat - 1];
       if ((P.fmt == 1) && lists && P.D.L) {
@@ -576,46 +640,88 @@ __global__ __launch_bounds__(kThreads) void pgen_aux1_kernel(PgenDecodeArgs A) {
   };
   // ---- pass 1: allele counts.  Main track: 2 n0 + n1 REF copies, n1 + 2 n2 ALT1 copies; a category-1 patch turns one ALT1
   // copy into ALTx, a category-2 patch turns two into ALTx + ALTy.
+  // (the first four alleles are counted in registers and added to the workgroup's histogram once per thread: tens of thousands of
+  // LDS atomics on the one or two addresses nearly every patch names were most of this kernel's time)
+  int local_cnt0 = 0, local_cnt1 = 0, local_cnt2 = 0, local_cnt3 = 0;
+  auto bump = [&](uint32_t a, int delta) {
+    if (a == 1) {
+      local_cnt1 += delta;
+    } else if (a == 2) {
+      local_cnt2 += delta;
+    } else if (a == 3) {
+      local_cnt3 += delta;
+    } else if (a == 0) {
+      local_cnt0 += delta;
+    } else {
+      atomicAdd(&s_cnt[a], delta);
+    }
+  };
   auto count_patch = [&](uint32_t /*sample*/, uint32_t cat, Alleles a) {
     if ((a.hi >= allele_ct) || (a.lo >= allele_ct)) {
       s_bad = 1;
       return;
     }
     if (cat == 1) {
-      atomicAdd(&s_cnt[1], -1);
-      atomicAdd(&s_cnt[a.hi], 1);
+      bump(1, -1);
+      bump(a.hi, 1);
     } else {
-      atomicAdd(&s_cnt[1], -2);
-      atomicAdd(&s_cnt[a.lo], 1);
-      atomicAdd(&s_cnt[a.hi], 1);
+      bump(1, -2);
+      bump(a.lo, 1);
+      bump(a.hi, 1);
     }
   };
-  // bit-array sets: the thread's own dwords, samples in order
-  auto walk_bits = [&](uint32_t d, uint32_t w, uint32_t (&k)[2], uint32_t (&rank)[2], auto f) {
+  // bit-array sets: the thread's own dwords, kChunk at a time (w[i] = main-track dword d + i, cnt of them valid), samples in order;
+  // f(i, sample, category, alleles)
+  auto walk_chunk = [&](uint32_t d, const uint32_t (&w)[kChunk], uint32_t cnt, uint32_t (&k)[2], uint32_t (&rank)[2], auto f) {
+    uint32_t msk[2][kChunk], win[2][kChunk];
+#pragma unroll
     for (uint32_t cat = 1; cat <= 2; ++cat) {
       const PatchSet& P = S[cat - 1];
-      if (P.fmt != 0) {
-        continue;
+      uint32_t kk[kChunk], nbits[kChunk];
+#pragma unroll
+      for (uint32_t i = 0; i < kChunk; ++i) {
+        msk[cat - 1][i] = ((P.fmt == 0) && (i < cnt)) ? cat_mask(w[i], cat) : 0u;
+        nbits[i] = __popc(msk[cat - 1][i]);
+        kk[i] = k[cat - 1];
+        k[cat - 1] += nbits[i];
       }
-      uint32_t mask = cat_mask(w, cat);
-      while (mask) {
-        const uint32_t b = __builtin_ctz(mask);
-        mask &= mask - 1;
-        const uint32_t kk = k[cat - 1]++;
-        if ((static_cast<uint32_t>(P.bits[kk >> 3]) >> (kk & 7)) & 1u) {
-          f(16 * d + (b >> 1), cat, patch_alleles(P, cat, allele_ct, rank[cat - 1]++));
+#pragma unroll
+      for (uint32_t i = 0; i < kChunk; ++i) {  // bit t of a window: the dword's t-th sample of the category is patched
+        win[cat - 1][i] = nbits[i] ? bit_window(P.bits, rec_end, kk[i], nbits[i]) : 0u;
+      }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kChunk; ++i) {
+#pragma unroll
+      for (uint32_t cat = 1; cat <= 2; ++cat) {
+        const PatchSet& P = S[cat - 1];
+        uint32_t wv = win[cat - 1][i];
+        while (wv) {
+          const uint32_t t = __builtin_ctz(wv);
+          wv &= wv - 1;
+          uint32_t mm = msk[cat - 1][i];
+          for (uint32_t j = 0; j < t; ++j) {
+            mm &= mm - 1;
+          }
+          f(i, 16 * (d + i) + (__builtin_ctz(mm) >> 1), cat, patch_alleles(P, cat, allele_ct, rank[cat - 1]++));
         }
       }
     }
   };
   {
     uint32_t k[2] = {S[0].k_first, S[1].k_first}, rank[2] = {S[0].rank_first, S[1].rank_first};
-    for (uint32_t d = d0; d < d1; ++d) {
-      walk_bits(d, row[d], k, rank, count_patch);
+    for (uint32_t d = d0; d < d1; d += kChunk) {
+      uint32_t w[kChunk];
+      const uint32_t cnt = (d1 - d < kChunk) ? (d1 - d) : kChunk;
+#pragma unroll
+      for (uint32_t i = 0; i < kChunk; ++i) {
+        w[i] = (i < cnt) ? mtrack[d + i] : 0u;
+      }
+      walk_chunk(d, w, cnt, k, rank, [&](uint32_t /*i*/, uint32_t sample, uint32_t cat, Alleles a) { count_patch(sample, cat, a); });
     }
     // list sets: the sample must be in the set's category (checked while the row still holds the main track)
     const bool ok = for_each_patch(true, [&](uint32_t id, uint32_t cat, Alleles a) {
-      const uint32_t code = (row[id >> 4] >> (2 * (id & 15))) & 3u;
+      const uint32_t code = (mtrack[id >> 4] >> (2 * (id & 15))) & 3u;
       if (code != cat) {
         s_bad = 1;
       }
@@ -623,6 +729,18 @@ __global__ __launch_bounds__(kThreads) void pgen_aux1_kernel(PgenDecodeArgs A) {
     });
     if (!ok) {
       s_bad = 1;
+    }
+    if (local_cnt0) {
+      atomicAdd(&s_cnt[0], local_cnt0);
+    }
+    if (local_cnt1) {
+      atomicAdd(&s_cnt[1], local_cnt1);
+    }
+    if (local_cnt2) {
+      atomicAdd(&s_cnt[2], local_cnt2);
+    }
+    if (local_cnt3) {
+      atomicAdd(&s_cnt[3], local_cnt3);
     }
   }
   __syncthreads();
@@ -696,23 +814,34 @@ __global__ __launch_bounds__(kThreads) void pgen_aux1_kernel(PgenDecodeArgs A) {
   auto code_of = [&](Alleles a) -> uint32_t { return 2u - ((a.lo == maj) ? 1u : 0u) - ((a.hi == maj) ? 1u : 0u); };
   {
     uint32_t k[2] = {S[0].k_first, S[1].k_first}, rank[2] = {S[0].rank_first, S[1].rank_first};
-    for (uint32_t d = d0; d < d1; ++d) {
-      const uint32_t w = row[d];
-      uint32_t t;
-      if (maj == 1) {
-        t = w ^ (((~w) << 1) & 0xaaaaaaaau);
-      } else {
-        t = 0xaaaaaaaau | (w & (w >> 1) & 0x55555555u);
+    for (uint32_t d = d0; d < d1; d += kChunk) {
+      uint32_t w[kChunk], t[kChunk];
+      const uint32_t cnt = (d1 - d < kChunk) ? (d1 - d) : kChunk;
+#pragma unroll
+      for (uint32_t i = 0; i < kChunk; ++i) {
+        w[i] = (i < cnt) ? mtrack[d + i] : 0u;
+        t[i] = (maj == 1) ? (w[i] ^ (((~w[i]) << 1) & 0xaaaaaaaau)) : (0xaaaaaaaau | (w[i] & (w[i] >> 1) & 0x55555555u));
       }
-      walk_bits(d, w, k, rank, [&](uint32_t sample, uint32_t /*cat*/, Alleles a) {
+      walk_chunk(d, w, cnt, k, rank, [&](uint32_t i, uint32_t sample, uint32_t /*cat*/, Alleles a) {
         const uint32_t sh = 2 * (sample & 15);
-        t = (t & ~(3u << sh)) | (code_of(a) << sh);
+#pragma unroll
+        for (uint32_t j = 0; j < kChunk; ++j) {  // (i is not a compile-time index)
+          if (j == i) {
+            t[j] = (t[j] & ~(3u << sh)) | (code_of(a) << sh);
+          }
+        }
       });
-      const uint64_t s0 = 16ull * d;
-      if (s0 + 16 > n) {
-        t &= (1u << (2 * (n - static_cast<uint32_t>(s0)))) - 1u;
+#pragma unroll
+      for (uint32_t i = 0; i < kChunk; ++i) {
+        if (i < cnt) {
+          const uint64_t s0 = 16ull * (d + i);
+          uint32_t tv = t[i];
+          if (s0 + 16 > n) {
+            tv &= (1u << (2 * (n - static_cast<uint32_t>(s0)))) - 1u;
+          }
+          row[d + i] = tv;
+        }
       }
-      row[d] = t;
     }
   }
   __syncthreads();
@@ -746,7 +875,14 @@ hipError_t launch_pgen_aux1(const PgenDecodeArgs& a, hipStream_t stream) {
   if (!a.n_multi) {
     return hipSuccess;
   }
-  hipLaunchKernelGGL(pgen_aux1_kernel, dim3(a.n_multi), dim3(kThreads), 0, stream, a);
+  static const bool lds_ok = []() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pgen_aux1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kPgenLdsRowBytes)) == hipSuccess;
+  }();
+  if (lds_ok && (a.stride <= kPgenLdsRowBytes) && (getenv("LDP_DEBUG_DECODE_NO_LDS") == nullptr)) {
+    hipLaunchKernelGGL(pgen_aux1_kernel<true>, dim3(a.n_multi), dim3(kThreads), static_cast<size_t>(a.stride), stream, a);
+  } else {
+    hipLaunchKernelGGL(pgen_aux1_kernel<false>, dim3(a.n_multi), dim3(kThreads), 0, stream, a);
+  }
   return hipGetLastError();
 }
 
