@@ -29,6 +29,7 @@ namespace ldp {
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kAuxThreads = 1024;  // the auxiliary-track kernel: a thread's share of a row is a chain of latencies, so more, shorter ones
 constexpr uint32_t kChunk = 8;  // dwords of a row a thread handles together in the auxiliary-track kernel: their bit-array windows are loaded together
 
 struct ByteCursor {
@@ -121,14 +122,26 @@ __device__ __forceinline__ void set_field(uint32_t* row, uint32_t sample, uint32
 }
 
 // exclusive prefix of one number per thread (and the total), through LDS
+template <int NT>
 __device__ __forceinline__ uint32_t block_exclusive(uint32_t mine, uint32_t* s_tmp, uint32_t tid, uint32_t* total) {
+  // inclusive scan inside the wave (shuffles), the waves' totals through LDS
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  uint32_t incl = mine;
+#pragma unroll
+  for (uint32_t off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(incl, off, 64);
+    incl += (lane >= off) ? y : 0u;
+  }
   __syncthreads();  // (s_tmp may still be read from the previous use)
-  s_tmp[tid] = mine;
+  if (lane == 63) {
+    s_tmp[wave] = incl;
+  }
   __syncthreads();
-  uint32_t before = 0, all = 0;
-  for (uint32_t t = 0; t < kThreads; ++t) {
-    const uint32_t x = s_tmp[t];
-    before += (t < tid) ? x : 0;
+  uint32_t before = incl - mine, all = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < NT / 64; ++w) {
+    const uint32_t x = s_tmp[w];
+    before += (w < wave) ? x : 0u;
     all += x;
   }
   *total = all;
@@ -147,6 +160,7 @@ struct Difflist {
 };
 
 // false: malformed (or L == 0: then c.p is the list's end and D.L == 0)
+template <int NT>
 __device__ __forceinline__ bool difflist_open(ByteCursor& c, uint32_t sample_ct, bool with_values, uint32_t* s_tmp, uint32_t tid, Difflist* D) {
   D->L = c.varint();
   D->G = 0;
@@ -176,7 +190,7 @@ __device__ __forceinline__ bool difflist_open(ByteCursor& c, uint32_t sample_ct,
     }
   }
   D->deltas = c.p;
-  const uint32_t gpt = (D->G + kThreads - 1) / kThreads;
+  const uint32_t gpt = (D->G + NT - 1) / NT;
   D->g0 = (tid * gpt < D->G) ? tid * gpt : D->G;
   D->g1 = (D->g0 + gpt < D->G) ? D->g0 + gpt : D->G;
   uint32_t bytes = 0;
@@ -186,7 +200,7 @@ __device__ __forceinline__ bool difflist_open(ByteCursor& c, uint32_t sample_ct,
     }
   }
   uint32_t total;
-  const uint32_t before = block_exclusive(bytes, s_tmp, tid, &total);
+  const uint32_t before = block_exclusive<NT>(bytes, s_tmp, tid, &total);
   if (static_cast<uint64_t>(c.end - D->deltas) < total) {
     c.ok = false;
     return false;
@@ -349,7 +363,7 @@ __global__ __launch_bounds__(kThreads) void pgen_main_kernel(PgenDecodeArgs A) {
   bool owns_end = (tid == 0);
   if (has_list && !bad) {
     Difflist D;
-    if (!difflist_open(c, n, true, s_tmp, tid, &D)) {
+    if (!difflist_open<kThreads>(c, n, true, s_tmp, tid, &D)) {
       bad = true;
     } else if (D.L) {
       owns_end = (D.g0 < D.g1) && (D.g1 == D.G);
@@ -468,9 +482,9 @@ __device__ __forceinline__ uint32_t cat_mask(uint32_t w, uint32_t cat) {
 }
 
 template <bool LDS>
-__global__ __launch_bounds__(kThreads) void pgen_aux1_kernel(PgenDecodeArgs A) {
+__global__ __launch_bounds__(kAuxThreads) void pgen_aux1_kernel(PgenDecodeArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t main_lds[];  // LDS: the main track, read five times below, staged once
-  __shared__ uint32_t s_tmp[kThreads];
+  __shared__ uint32_t s_tmp[kAuxThreads];
   __shared__ int s_cnt[256];
   __shared__ int s_bad;
   __shared__ const uint8_t* s_ptr;
@@ -483,28 +497,30 @@ __global__ __launch_bounds__(kThreads) void pgen_aux1_kernel(PgenDecodeArgs A) {
   const uint32_t allele_ct = R.allele_ct;
   uint32_t* row = reinterpret_cast<uint32_t*>(A.rows + static_cast<uint64_t>(v) * A.stride);
   const uint32_t n_dwords = (n + 15) / 16;
-  const uint32_t dpt = (n_dwords + kThreads - 1) / kThreads;
+  const uint32_t dpt = (n_dwords + kAuxThreads - 1) / kAuxThreads;
   const uint32_t d0 = (tid * dpt < n_dwords) ? tid * dpt : n_dwords;
   const uint32_t d1 = (d0 + dpt < n_dwords) ? d0 + dpt : n_dwords;
   if (tid == 0) {
     s_bad = 0;
   }
-  s_cnt[tid] = 0;
+  if (tid < 256) {
+    s_cnt[tid] = 0;
+  }
   // Every thread owns a contiguous run of the row's dwords (the rank of a sample within its category runs along the row), which
   // makes its reads of the row from global memory a chain of latencies; from LDS they are not.
   const uint32_t* mtrack = row;
   if constexpr (LDS) {
     // (one wave per SIMD: nothing hides a load's latency but the thread's own other loads -- eight in flight)
-    for (uint32_t d = tid; d < n_dwords; d += 8 * kThreads) {
+    for (uint32_t d = tid; d < n_dwords; d += 8 * kAuxThreads) {
       uint32_t v8[8];
 #pragma unroll
       for (uint32_t i = 0; i < 8; ++i) {
-        v8[i] = (d + i * kThreads < n_dwords) ? row[d + i * kThreads] : 0u;
+        v8[i] = (d + i * kAuxThreads < n_dwords) ? row[d + i * kAuxThreads] : 0u;
       }
 #pragma unroll
       for (uint32_t i = 0; i < 8; ++i) {
-        if (d + i * kThreads < n_dwords) {
-          main_lds[d + i * kThreads] = v8[i];
+        if (d + i * kAuxThreads < n_dwords) {
+          main_lds[d + i * kAuxThreads] = v8[i];
         }
       }
     }
@@ -520,9 +536,9 @@ __global__ __launch_bounds__(kThreads) void pgen_aux1_kernel(PgenDecodeArgs A) {
     my3 += __popc(w & (w >> 1) & 0x55555555u);
   }
   uint32_t n1, n2, n3;
-  const uint32_t pre1 = block_exclusive(my1, s_tmp, tid, &n1);
-  const uint32_t pre2 = block_exclusive(my2, s_tmp, tid, &n2);
-  (void)block_exclusive(my3, s_tmp, tid, &n3);
+  const uint32_t pre1 = block_exclusive<kAuxThreads>(my1, s_tmp, tid, &n1);
+  const uint32_t pre2 = block_exclusive<kAuxThreads>(my2, s_tmp, tid, &n2);
+  (void)block_exclusive<kAuxThreads>(my3, s_tmp, tid, &n3);
   const uint32_t n0 = n - n1 - n2 - n3;
   bool bad = (allele_ct < 3) || (allele_ct > 255);
   // ---- locate the two patch sets
@@ -572,9 +588,9 @@ __global__ __launch_bounds__(kThreads) void pgen_aux1_kernel(PgenDecodeArgs A) {
           }
         }
         P.k_first = pre;
-        P.rank_first = block_exclusive(set, s_tmp, tid, &P.patched);
+        P.rank_first = block_exclusive<kAuxThreads>(set, s_tmp, tid, &P.patched);
       } else if (P.fmt == 1) {
-        if (!difflist_open(c, n, false, s_tmp, tid, &P.D)) {
+        if (!difflist_open<kAuxThreads>(c, n, false, s_tmp, tid, &P.D)) {
           bad = true;
           break;
         }
@@ -879,9 +895,9 @@ hipError_t launch_pgen_aux1(const PgenDecodeArgs& a, hipStream_t stream) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&pgen_aux1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kPgenLdsRowBytes)) == hipSuccess;
   }();
   if (lds_ok && (a.stride <= kPgenLdsRowBytes) && (getenv("LDP_DEBUG_DECODE_NO_LDS") == nullptr)) {
-    hipLaunchKernelGGL(pgen_aux1_kernel<true>, dim3(a.n_multi), dim3(kThreads), static_cast<size_t>(a.stride), stream, a);
+    hipLaunchKernelGGL(pgen_aux1_kernel<true>, dim3(a.n_multi), dim3(kAuxThreads), static_cast<size_t>(a.stride), stream, a);
   } else {
-    hipLaunchKernelGGL(pgen_aux1_kernel<false>, dim3(a.n_multi), dim3(kThreads), 0, stream, a);
+    hipLaunchKernelGGL(pgen_aux1_kernel<false>, dim3(a.n_multi), dim3(kAuxThreads), 0, stream, a);
   }
   return hipGetLastError();
 }

@@ -144,6 +144,27 @@ def test_small_launches_and_sharded_engines(gpu_pkg, tmp_path, monkeypatch):
     f.close()
 
 
+def test_records_into_an_engine_that_keeps_bit_planes(gpu_pkg):
+    """pair_mfma 0 (what engines beyond 16,000,000 founders do): the decoded rows go through prepare_kernel instead of the count
+    pass of the code image; same records, planes and prune set as host-loaded rows."""
+    pkg = gpu_pkg
+    f = pkg.PgenFile(os.path.join(GOLD, "varwidth_small.pgen"))
+    m, n = f.variant_ct, f.sample_ct
+    rows = f.read()
+    engines = []
+    for _ in range(2):
+        eng = pkg.LdPruneEngine(n, 40, 1, False, 0.3, order=2, device=0)
+        eng.set_option("pair_mfma", 0)
+        chr_idx, bps = positions(m)
+        eng.set_variants(chr_idx, bps)
+        engines.append(eng)
+    engines[0].load_genotypes_host(0, rows, pkg.LDP_GENO_REF)
+    engines[1].load_pgen_records(0, f)
+    assert_same_rows(engines[0], engines[1], m)
+    assert np.array_equal(engines[0].run(), engines[1].run())
+    f.close()
+
+
 def collapse(lo, hi, alt_ct):
     """Get1Multiallelic + GetMajIdxMulti in numpy: (INVERSE-coded codes, major allele, its frequency) of one variant."""
     called = lo != 255
