@@ -11,7 +11,8 @@ Workloads (synthetic; 22 autosomes with variant counts proportional to GRCh38 le
           variants at 290 bp, `--indep-pairwise 500kb 0.2`, the 22 chromosomes (the subcontigs) LPT-sharded over the ranks exactly
           as `ldp_set_shard` does it, so the imbalance of 22 unequal chromosomes on N ranks is part of the number.  A rank's share
           is resident in HBM at N = 8 (1.25M variants = 156 GB); at N = 2 / 4 it exceeds 288 GB and the rank works through its
-          chromosomes one engine at a time, generating each chromosome's rows inside the step (said so in config.workload).
+          chromosomes one engine at a time, copying each chromosome's rows inside the step from one resident chromosome's worth of
+          generated rows (said so in config.workload).
   `--workload config2|config3`, `--samples/--variants/--spacing/--window-kb/--r2`, `--strong/--weak` override all of this.
 There is no data-path collective; the prune bitmask is exchanged once per step with an RCCL all_gather.
 
@@ -60,7 +61,7 @@ CONFIGS = {
     "config2": dict(samples=50000, variants=1000000, spacing=2875, window_kb=200.0, r2=0.5),
     "config3": dict(samples=500000, variants=10000000, spacing=290, window_kb=500.0, r2=0.2),
 }
-HBM_BYTES = 288e9
+HBM_BYTES = float(os.environ.get("LDP_BENCH_HBM_GB", "288")) * 1e9  # (the override forces the non-resident mode at small sizes: tests)
 
 
 def genome_layout(variants, genomes, spacing):
@@ -222,7 +223,8 @@ def measured_ceilings():
 class Workload:
     """One rank's share of a genome: engines planned up front (host work), rows generated straight into an engine's resident
     image.  `resident`: one engine holds the whole share and its rows stay in HBM across steps.  Otherwise the share does not
-    fit HBM and the rank works through its chromosomes one engine at a time, generating each chromosome's rows inside the step."""
+    fit HBM and the rank works through its chromosomes one engine at a time, copying each chromosome's rows inside the step from one
+    resident chromosome's worth of generated rows."""
 
     def __init__(self, pkg, torch, cfg, missing_rate, rank, world, device, options=None, multiallelic=None):
         self.pkg, self.torch, self.cfg, self.missing_rate = pkg, torch, cfg, missing_rate
@@ -261,10 +263,22 @@ class Workload:
                 e.set_variants(self.chr_idx[sel], self.bps[sel])
                 self.engines.append((e, [(ln, first)]))
         self.segs = {}
+        self.master = None
         if self.resident:
             self._generate(planner, self.owned, 0)
             if multiallelic:
                 self._make_multiallelic(planner, *multiallelic)
+        elif self.owned_subs:
+            # The share does not fit: its chromosomes are worked through one engine at a time, and what an engine counts has to be
+            # resident when the step begins -- not produced by the synthetic generator inside it (32 GB/s: it would be most of the
+            # step).  ONE chromosome's worth of rows is generated here, once, and every chromosome of the share takes its rows from
+            # that buffer by a device-to-device copy into its engine's image (the longest owned chromosome's rows; shorter ones take a
+            # prefix).  The chromosomes of a non-resident share therefore hold the same genotypes; shapes, windows and work are the
+            # genome's.
+            ln_max = max(ln for ln, _ in self.owned_subs)
+            first = [f for ln, f in self.owned_subs if ln == ln_max][0]
+            self.master = torch.empty((ln_max, row_bytes), dtype=torch.uint8, device="cuda")
+            pkg.synth_genotypes_device(SEED, first, ln_max, self.founder_ct, self.missing_rate, self.master.data_ptr(), row_bytes)
         torch.cuda.synchronize()
 
     def _make_multiallelic(self, eng, n_runs, run_len):
@@ -346,7 +360,14 @@ class Workload:
         for eng, runs in self.engines:
             base = 0 if self.resident else runs[0][1]
             if not self.resident:
-                self._generate(eng, runs, base)
+                segs = []
+                for ln, first in runs:
+                    ptr, stride = eng.map_rows(first - base, ln)
+                    assert stride == self.master.shape[1]
+                    assert self.pkg.hip_memcpy_dtod(ptr, self.master.data_ptr(), ln * stride) == 0
+                    segs.append((first - base, ln, ptr, stride))
+                self.torch.cuda.synchronize()
+                self.segs[id(eng)] = segs
             for first, ln, ptr, stride in self.segs[id(eng)]:
                 eng.load_genotypes_device(first, ln, ptr, stride, self.pkg.LDP_GENO_REF)
             if self.multi:
@@ -542,7 +563,8 @@ def main():
                                    (name, cfg["samples"], cfg["variants"], "total, strong scaling" if strong else "%d per GPU, weak scaling" % (cfg["variants"] // world),
                                     cfg["spacing"], cfg["window_kb"], cfg["r2"], args.missing_rate, world,
                                     "2-bit rows resident in HBM, counted in place each step (no conversion pass, no second image)" if wl.resident else
-                                    "a rank's share (%.0f GB) exceeds HBM: one engine per chromosome, each chromosome's rows generated inside the step" % (wl.image_bytes / 1e9)),
+                                    "a rank's share (%.0f GB) exceeds HBM: one engine per chromosome, each chromosome's rows copied inside the step from ONE resident chromosome's "
+                                    "worth of generated rows (every chromosome of the share holds the same genotypes)" % (wl.image_bytes / 1e9)),
                        "samples": cfg["samples"], "variants_total": cfg["variants"], "variants_rank0": wl.local_ct, "window_kb": cfg["window_kb"], "r2": cfg["r2"],
                        "subcontigs": len(wl.subs), "candidate_pairs_total": total_pairs, "candidate_pairs_per_rank": per_rank_pairs,
                        "shard_imbalance_max_over_mean": (max(per_rank_pairs) / (total_pairs / world)) if total_pairs else 1.0,

@@ -70,3 +70,21 @@ def test_bench_step_under_torchrun_initialises_rccl(gpu_pkg, tmp_path):
     assert cp2.returncode == 0, cp2.stderr[-2000:]
     j2 = json.loads([ln for ln in cp2.stdout.splitlines() if ln.startswith("{")][-1])
     assert j2["config"]["variants_removed"] == j["config"]["variants_removed"]
+
+
+@pytest.mark.gpu
+def test_bench_share_that_does_not_fit_hbm(gpu_pkg):
+    """bench.py's non-resident mode (a rank's share of config 3 at N = 2 / 4 exceeds HBM): forced here with a small HBM limit.
+    One engine per chromosome, rows copied from one resident chromosome's worth of generated rows inside the step; every chromosome
+    then prunes like the master chromosome does on its own."""
+    env = dict(os.environ, LDP_BENCH_HBM_GB="6.2")
+    args = ["--workload", "config3", "--samples", "20000", "--variants", "44000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-legs"]
+    cp = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    j = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["config"]["resident"] is False and j["value"] > 0
+    assert 0.1 * 44000 < j["config"]["variants_removed"] < 0.9 * 44000
+    cp2 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert cp2.returncode == 0, cp2.stderr[-2000:]
+    j2 = json.loads([ln for ln in cp2.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j2["config"]["resident"] is True and j2["config"]["candidate_pairs_total"] == j["config"]["candidate_pairs_total"]
