@@ -280,3 +280,48 @@ def test_subset_samples_property(pkg):
         assert np.array_equal(got, want)
 
     check()
+
+
+def test_record_index_and_file_bytes(pkg, tmp_path):
+    """What ldp_load_pgen_records is fed from: the reader's mapping and its index entries (no GPU needed).  Records tile the file's
+    record area in order, types are the header's, and the LD base of an LD-compressed record is the closest earlier record that is
+    not LD-compressed; a fixed-width file yields plain records, a .bed is refused."""
+    path = os.path.join(GOLD, "varwidth_small.pgen")
+    f = pkg.PgenFile(path)
+    m = f.variant_ct
+    raw = open(path, "rb").read()
+    ptr, nbytes = f.file_bytes()
+    assert nbytes == len(raw)
+    assert bytes((pkg.ctypes.c_uint8 * 16).from_address(ptr)) == raw[:16]
+    recs, base = f.record_index()
+    assert base is None
+    offs = [recs[q].offset for q in range(m)]
+    lens = [recs[q].length for q in range(m)]
+    assert all(offs[q] + lens[q] == offs[q + 1] for q in range(m - 1)) and offs[-1] + lens[-1] == len(raw)
+    assert all(recs[q].allele_ct == 2 for q in range(m))
+    types = [recs[q].vrtype & 7 for q in range(m)]
+    assert types[0] not in (2, 3)
+    ld = [q for q in range(m) if types[q] in (2, 3)]
+    assert ld
+    for q in ld[:: max(1, len(ld) // 20)]:
+        _, b = f.record_index(q, 1)
+        want = max(k for k in range(q) if types[k] not in (2, 3))
+        assert b == want
+        assert f.record_index(want, 1)[1] is None
+    # allele counts from the caller
+    recs2, _ = f.record_index(3, 4, allele_cts=[2, 3, 5, 2])
+    assert [recs2[q].allele_ct for q in range(4)] == [2, 3, 5, 2] and recs2[0].offset == offs[3]
+    f.close()
+    # fixed-width .pgen: plain records; .bed: refused
+    rawc = T.synth_raw_codes(30, 41, 3, missing_rate=0.05)
+    T.write_pgen_fixed(str(tmp_path / "fx"), rawc, ["1"] * 30, np.arange(30) + 1)
+    g = pkg.PgenFile(str(tmp_path / "fx.pgen"))
+    rg, bg = g.record_index()
+    assert bg is None and all((rg[q].vrtype, rg[q].length) == (0, (41 + 3) // 4) for q in range(30)) and rg[1].offset - rg[0].offset == 11
+    g.close()
+    T.write_bed(str(tmp_path / "b"), rawc, ["1"] * 30, np.arange(30) + 1)
+    h = pkg.PgenFile(str(tmp_path / "b.bed"), sample_ct_hint=41, variant_ct_hint=30)
+    with pytest.raises(pkg.LdpError) as ei:
+        h.record_index()
+    assert ei.value.code == pkg.LDP_ERR_UNSUPPORTED
+    h.close()
