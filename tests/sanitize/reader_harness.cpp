@@ -20,6 +20,26 @@ int main(int argc, char** argv) {
       int rc = ldp_pgen_read(pg, 0, m, rows.data(), rec, th);
       if (rc) { printf("read rc %d\n", rc); }
     }
+    // the record index ldp_load_pgen_records is fed from: whole file, ragged pieces, every record inside the mapping
+    {
+      uint64_t nbytes = 0;
+      const uint8_t* bytes = static_cast<const uint8_t*>(ldp_pgen_file_bytes(pg, &nbytes));
+      std::vector<ldp_pgen_rec> idx(m);
+      uint32_t base = 0;
+      if (ldp_pgen_record_index(pg, 0, m, idx.data(), &base) == 0) {
+        uint64_t sum = 0;
+        for (uint32_t v = 0; v < m; ++v) {
+          if (idx[v].offset + idx[v].length > nbytes) { printf("record %u outside the file\n", v); return 1; }
+          sum += bytes[idx[v].offset] + bytes[idx[v].offset + idx[v].length - 1];
+        }
+        for (uint32_t v = 0; v < m; v += 5) {
+          ldp_pgen_rec one_rec;
+          ldp_pgen_record_index(pg, v, 1, &one_rec, &base);
+          if ((base != 0xffffffffu) && (base >= v)) { printf("LD base %u of %u\n", base, v); return 1; }
+        }
+        (void)sum;
+      }
+    }
     // ragged single reads
     std::vector<uint8_t> one(rec);
     for (uint32_t v = 0; v < m; v += 7) ldp_pgen_read(pg, v, 1, one.data(), rec, 1);
