@@ -394,7 +394,7 @@ class Workload:
 def sum_counters(ctrs):
     keys = ("candidate_pairs", "pred_true", "replay_pairs", "ms_prepare", "ms_pair_kernel", "ms_pair_mfma", "ms_pair_mfma_general", "ms_pair_fast",
             "ms_pair_general", "ms_replay", "pair_kernel_launches", "mfma_block_products", "mfma_product_stages", "mfma_skipped_product_stages",
-            "sparse_exact_pairs", "route_complete_launches", "route_sparse_launches", "route_general_launches", "mfma_extra_product_stages", "wide_tiles")
+            "sparse_exact_pairs", "route_complete_launches", "route_sparse_launches", "route_general_launches", "mfma_extra_product_stages", "wide_tiles", "four_tile_launches")
     return {k: sum(c[k] for c in ctrs) for k in keys}
 
 
@@ -418,12 +418,15 @@ def pair_roofline(c, founder_ct, local_ct, missing_rate, variants, window_kb):
     general = c["route_general_launches"] > 0
     kms_valu = c["ms_pair_fast"] + c["ms_pair_general"]
     on_matrix_pipe = (kms_mfma + kms_gen) > kms_valu
-    kernel = ("pair_mfma_general_kernel" if general else "pair_mfma_kernel") if on_matrix_pipe else ("pair_tiles_kernel<true>" if general else "pair_tiles_kernel<false>")
+    four_tiles = c.get("four_tile_launches", 0) > 0   # wide bands: the four-product form runs on quarter tiles
+    kernel = (("pair_mfma_tile4_kernel" if four_tiles else "pair_mfma_general_kernel") if general else "pair_mfma_kernel") if on_matrix_pipe else ("pair_tiles_kernel<true>" if general else "pair_tiles_kernel<false>")
     kms = (kms_mfma + kms_gen) if on_matrix_pipe else kms_valu
     launches = max(int(c["pair_kernel_launches"]), 1)
     # MFMA side: instructions the kernel really issued.  One block product = 32 x 32 pairs; one k-step = one
-    # v_mfma_scale_f32_32x32x64_f8f6f4 = 65,536 MACs; the general kernel issues six per block product and k-step.
-    executed = (max(c["mfma_product_stages"] - c["mfma_skipped_product_stages"], 0) + c["mfma_extra_product_stages"]) * (6 if general else 1)
+    # v_mfma_scale_f32_32x32x64_f8f6f4 = 65,536 MACs; the missing-call kernels issue four per block product and k-step on prune
+    # launches (six with LDP_PAIR_FOUR=0).
+    per_product = (6 if os.environ.get("LDP_PAIR_FOUR") == "0" else 4) if general else 1
+    executed = (max(c["mfma_product_stages"] - c["mfma_skipped_product_stages"], 0) + c["mfma_extra_product_stages"]) * per_product
     mfma_tflops = (executed * 65536 * 2.0 / (kms * 1e-3)) / 1e12 if (kms > 0 and on_matrix_pipe) else 0.0
     # HBM side: every owned row must be read once (N/4 bytes per variant, rows padded to 64 bytes)
     compulsory = local_ct * ((founder_ct + 511) // 512) * 128.0

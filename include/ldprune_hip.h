@@ -140,6 +140,9 @@ typedef struct {
   uint32_t wide_tiles;             /* 8 x 8 block tiles of the plan (wide-band subcontigs, complete-data launches) */
   uint64_t mfma_extra_product_stages; /* product x k-step units the wide-band kernel computed beyond the plan (its waves run all eight
                                          products of their rectangle or none): executed MFMA = stages - skipped + extra */
+  uint32_t four_tile_launches;     /* launches of the last run whose tiles went to pair_mfma_tile4_kernel (wide bands, rows with missing
+                                      calls, four-product form) */
+  uint32_t reserved0;
 } ldp_counters;
 
 /* ---- lifecycle ---- */
@@ -269,7 +272,7 @@ int ldp_pair_stats(ldp_engine* e, uint32_t n_pairs, const uint32_t* first, const
 int ldp_debug_set_variant_recs(ldp_engine* e, const ldp_variant_rec* recs);
 int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first, const uint32_t* second, uint64_t* removed);
 /* Kernel-selection switches of ONE engine, for tests and measurements (the defaults are what production runs use; they can also
- * be preset from the environment at ldp_create(): LDP_EARLY_EXIT, LDP_PAIR_MFMA, LDP_PAIR_SPARSE, LDP_PAIR_FOUR, LDP_DEBUG_SPARSE_FRAC,
+ * be preset from the environment at ldp_create(): LDP_EARLY_EXIT, LDP_PAIR_MFMA, LDP_PAIR_SPARSE, LDP_PAIR_FOUR, LDP_PAIR_FOUR_TILES, LDP_DEBUG_SPARSE_FRAC,
  * LDP_DEBUG_WIDE_MIN_REACH).  name:
  *   "early_exit"      0/1: checkpoints that drop provably sub-threshold products
  *   "pair_mfma"       0/1: matrix-pipe kernels on the 2-bit code image; 0 = the popcount kernels on bit-planes (before ldp_set_variants*())
@@ -277,6 +280,8 @@ int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first
  *   "sparse_frac"     mean missing fraction up to which a launch takes it
  *   "pair_four"       0/1: prune launches over rows with more missing calls than that multiply four products per pair and take the
  *                     two sums of squares from per-variant intervals (exact count for the few pairs they leave open); 0 = all six
+ *   "pair_four_tiles" 0/1: ... and in wide bands (subcontigs with the tile plan) that form runs over quarter tiles instead of the
+ *                     parallelogram plan (default 1)
  *   "wide_min_reach"  row-blocks a subcontig's band must reach to take the 8 x 8 tile plan of the wide-band kernel; 0 = always,
  *                     a huge value = never (before ldp_set_variants())
  * Results never depend on these.  Unknown name: LDP_ERR_INVALID. */

@@ -183,6 +183,7 @@ struct PairKernelArgs {
   uint32_t n_local;              // rows in `planes`
   uint32_t mf_active;            // the launch also carries matrix-pipe work items
   const uint32_t* route;         // kRoute*
+  uint32_t wd_general;           // (set by the launcher) the tile plan's subcontigs are taken by pair_mfma_tile4_kernel: the missing-call kernel skips their workgroups
   uint32_t mf_four;              // prune launches on the six-product route may use its four-product form (EngineOptions::pair_four)
   uint32_t sparse_ok;            // the route may be kRouteSparse (prune launches): launch that instantiation as well
   // wide-band tiles (launch_pair_wide): complete-data launches only; the workgroups of mf_wgs whose MfmaWG::pad is 1 cover the

@@ -82,6 +82,7 @@ struct EngineOptions {
   double sparse_frac = 0.005; // LDP_PAIR_SPARSE=0 -> 0; LDP_DEBUG_SPARSE_FRAC
   uint32_t wide_min_reach = kWdMinReach;  // band reach (row-blocks) from which a subcontig takes the 8 x 8 tile plan; LDP_DEBUG_WIDE_MIN_REACH
   bool pair_four = true;      // LDP_PAIR_FOUR=0: rows with missing calls always take all six products (prune launches otherwise four)
+  bool four_tiles = true;     // LDP_PAIR_FOUR_TILES=0: the four-product form stays on the parallelogram plan in wide bands too
 };
 
 struct ldp_engine {
@@ -133,6 +134,7 @@ struct ldp_engine {
     uint32_t mf_first = 0, mf_ct = 0;    // the same J range as matrix-pipe workgroups (mf_wgs) ...
     uint32_t mf_diag_ct = 0;             // ... of which the first mf_diag_ct are all-diagonal (partition_diag)
     uint32_t wd_first = 0, wd_ct = 0;    // ... and as wide-band tiles (wd_tiles)
+    bool four_tiles = false;             // the group's last launch queued pair_mfma_tile4_kernel for them
     bool launched = false;
     hipEvent_t ev_ready = nullptr;
     hipEvent_t ev_done = nullptr;         // kernels finished and the group's predicate words are back on the host
@@ -546,6 +548,8 @@ EngineOptions options_from_env() {
   o.sparse_frac = (off && (strcmp(off, "0") == 0)) ? 0.0 : (f ? atof(f) : 0.005);
   const char* four = getenv("LDP_PAIR_FOUR");
   o.pair_four = !(four && (strcmp(four, "0") == 0));
+  const char* ft = getenv("LDP_PAIR_FOUR_TILES");
+  o.four_tiles = !(ft && (strcmp(ft, "0") == 0));
   if (const char* w = getenv("LDP_DEBUG_WIDE_MIN_REACH")) {
     o.wide_min_reach = static_cast<uint32_t>(std::max(0, atoi(w)));
   }
@@ -1620,6 +1624,7 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.route = nullptr;
   A.sparse_ok = 0;
   A.mf_four = e->opt.pair_four ? 1u : 0u;
+  A.wd_general = 0;
   A.wd_tiles = nullptr;
   A.n_wd_tiles = 0;
   A.wd_active = 0;
@@ -1695,6 +1700,9 @@ int launch_group(ldp_engine* e, uint32_t gi) {
     A.wd_tiles = e->d_wd_tiles + g.wd_first;
     A.n_wd_tiles = g.wd_ct;
     A.wd_active = e->wd_tiles.empty() ? 0u : 1u;
+    // prune launches over rows with missing calls: the four-product form takes the tile plan's subcontigs in quarter tiles
+    A.wd_general = (A.mf_four && e->opt.four_tiles && !A.stats && !A.r2_out && !A.r2_hits && A.n_wd_tiles) ? 1u : 0u;
+    g.four_tiles = (A.wd_general != 0);
   }
   hipError_t krc = launch_pair_tiles(A, e->max_rows, ps, g.ev);
   if (krc != hipSuccess) {
@@ -1939,6 +1947,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   kms = kms_fast + kms_general + kms_mfma + kms_mfma_general;
   // which matrix-pipe kernel route_kernel gave each launch of this run (deterministic evidence of the path taken)
   uint32_t route_ct[3] = {0, 0, 0};
+  uint32_t four_tile_launches = 0;
   if (e->mf_enabled && !e->mf_wgs.empty()) {
     const uint32_t* h_route = reinterpret_cast<const uint32_t*>(e->h_counters_pin + 4);
     if (stats) {
@@ -1947,6 +1956,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
       for (size_t gi = 0; gi < e->groups.size(); ++gi) {
         if (e->groups[gi].mf_ct) {
           ++route_ct[std::min<uint32_t>(h_route[gi], 2)];
+          four_tile_launches += ((h_route[gi] >= 2) && e->groups[gi].four_tiles) ? 1u : 0u;
         }
       }
     }
@@ -1987,6 +1997,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   e->ctr.route_complete_launches = route_ct[0];
   e->ctr.route_sparse_launches = route_ct[1];
   e->ctr.route_general_launches = route_ct[2];
+  e->ctr.four_tile_launches = four_tile_launches;
   e->ctr.ms_replay = replayed ? replay_busy_ms : (t_end - t_replay);  // (time spent replaying, not waiting for groups)
   e->ctr.ms_run_total = t_end - t_start;
   e->ctr.pair_kernel_launches = launches;
@@ -3557,6 +3568,8 @@ int ldp_debug_set_option(ldp_engine* e, const char* name, double value) {
     e->opt.wide_min_reach = (value >= 4294967295.0) ? 0xffffffffu : static_cast<uint32_t>(std::max(0.0, value));
   } else if (n == "pair_four") {
     e->opt.pair_four = (value != 0.0);
+  } else if (n == "pair_four_tiles") {
+    e->opt.four_tiles = (value != 0.0);
   } else if (n == "pair_sparse") {
     if (value == 0.0) {
       e->opt.sparse_frac = 0.0;

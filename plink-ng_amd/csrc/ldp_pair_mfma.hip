@@ -1012,6 +1012,9 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
     return;
   }
   const MfmaWG* __restrict__ wg = A.mf_wgs + (idx >> 3);
+  if (A.wd_general && (wg->pad & 1u)) {
+    return;  // the subcontig has the tile plan: pair_mfma_tile4_kernel owns its pairs in this launch
+  }
   const MfmaWaveItem* __restrict__ wi = wg->w + ((idx >> 1) & 3);
   const uint32_t half = idx & 1;
   const int32_t jv0 = wi->jv;
@@ -1356,6 +1359,411 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
 }
 
 
+// ---- the four-product form on the TILE plan of wide bands ------------------------------------------------------------------
+// At config 5's density the kernel above fetches 37 x its compulsory bytes (profiles/r03_c5shape_pmc_traffic.json): half a wave
+// item stages five row-blocks for four block products, and a row-block is 4 MB at 500,000 samples.  Subcontigs that have the
+// wide plan (MfmaTile: 8 x 8 row-blocks, ldp_pair_wide.hip) are therefore taken in QUARTER tiles here: a workgroup of eight
+// waves stages 4 J + 4 V row-blocks (0.5 per product), wave w owns J block w & 3 against V blocks 2 (w >> 2), + 1 -- two
+// products that share the expanded J operand, 2 x 4 x 16 accumulators, two waves per SIMD.  Stages, checkpoints (whole waves
+// retire, the workgroup leaves when all have) and the interval epilogue are those of pair_mfma_general_kernel<false>.
+constexpr uint32_t kT4Waves = 8;
+constexpr uint32_t kT4Blocks = 8;                      // staged row-blocks: slots 0..3 = J, 4..7 = V
+constexpr uint32_t kT4Instr = kT4Blocks * 2;           // DMA instructions per 256-sample stage
+constexpr uint32_t kT4DmaPerWave = kT4Instr / kT4Waves;
+constexpr uint32_t kT4StageDwords = kT4Instr * 256;    // 16 KiB
+constexpr uint32_t kT4CpWaveDwords = 4 * kMfGenCpRound * 64 + kMfGenCpRowDwords;  // a wave's checkpoint scratch: four sums x rows, its V block's rows prepared
+constexpr uint32_t kT4CpStatDwords = kT4Waves * kT4CpWaveDwords;                  // the rows' slots follow (8 x 1 KiB)
+constexpr uint32_t kT4LdsDwords = 6 * kT4StageDwords;  // 96 KiB: a ring of six stages (one workgroup per CU: 256 registers a wave); the epilogue's scratch is 64 KiB of it
+
+__global__ __launch_bounds__(kT4Waves * 64, 2) void pair_mfma_tile4_kernel(PairKernelArgs A) {
+  using G = StageGeom<4>;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ uint32_t s_src_off[kT4Instr * 64];
+  __shared__ uint32_t s_live_waves;
+  __shared__ uint32_t s_need;
+  {
+    if (*A.route != kRouteGeneral) {
+      return;
+    }
+  }
+  const uint32_t n_units = A.n_wd_tiles * 4;  // tile x quarter
+  const uint32_t per_xcd = (n_units + 7) / 8;
+  const uint32_t idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (idx >= n_units) {
+    return;
+  }
+  const MfmaTile* __restrict__ tile = A.wd_tiles + (idx >> 2);
+  const uint32_t qj = (idx >> 1) & 1u, qv = idx & 1u;
+  const int32_t jv0 = __builtin_amdgcn_readfirstlane(tile->jv) + static_cast<int32_t>(kMfBlock * 4 * qj);
+  const int32_t vv0 = __builtin_amdgcn_readfirstlane(tile->vv) + static_cast<int32_t>(kMfBlock * 4 * qv);
+  const uint32_t jend = __builtin_amdgcn_readfirstlane(tile->jend);
+  const unsigned long long tmask = tile->mask;
+  // bit 4 a + b: product (J block a, V block b) of this quarter holds candidate pairs
+  uint32_t mask16 = 0;
+#pragma unroll
+  for (uint32_t a = 0; a < 4; ++a) {
+    mask16 |= (static_cast<uint32_t>(tmask >> (8 * (4 * qj + a) + 4 * qv)) & 0xfu) << (4 * a);
+  }
+  mask16 = __builtin_amdgcn_readfirstlane(mask16);
+  if (!mask16) {
+    return;
+  }
+  const uint32_t tid = threadIdx.x;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lane = tid & 63;
+  const uint32_t r = lane & 31;
+  const uint32_t h = lane >> 5;
+  const uint32_t ja = wave & 3, vb0 = 2 * (wave >> 2);
+  uint32_t live = (mask16 >> (4 * ja + vb0)) & 3u;  // bit p: (J block ja, V block vb0 + p)
+  const uint32_t mine_products = live;
+  const int32_t jfirst = jv0 + static_cast<int32_t>(kMfBlock * ja);
+  const int32_t vfirst0 = vv0 + static_cast<int32_t>(kMfBlock * vb0);
+  const uint32_t row_bytes = static_cast<uint32_t>(A.code_row_bytes);
+  // stages are taken in PAIRS (one barrier per 512 samples, as in the wide-band kernel: the image's rows are whole 512-sample
+  // k-chunks long, padded with missing calls, and the checkpoints sit on chunk boundaries)
+  const uint32_t n_stages = 2 * ((A.founder_ct + 2 * G::kStageSamples - 1) / (2 * G::kStageSamples));
+  uint32_t stages = A.lds_dwords / kT4StageDwords;
+  stages = (stages > kMfMaxStages) ? kMfMaxStages : stages;
+  stages &= ~1u;  // (launch_pair_mfma gives six)
+
+  // ---- DMA plan: row-block slot s (0..3 J, 4..7 V) is fetched while bit s of `need` is set: some live product reads it.  The
+  // set shrinks at the checkpoints (s_need); a wave issues instructions wave and wave + 8 of a stage, i.e. half of J block
+  // wave >> 1 and half of V block wave >> 1.
+  uint32_t need = 0;
+#pragma unroll
+  for (uint32_t a = 0; a < 4; ++a) {
+    const uint32_t rowm = (mask16 >> (4 * a)) & 0xfu;
+    need |= (rowm ? (1u << a) : 0u) | (rowm << 4);
+  }
+  auto slot_first = [&](uint32_t slot) -> int32_t {
+    return (slot < 4) ? (jv0 + static_cast<int32_t>(kMfBlock * slot)) : (vv0 + static_cast<int32_t>(kMfBlock * (slot - 4)));
+  };
+  const uint32_t my_j_bit = 1u << (wave >> 1), my_v_bit = 16u << (wave >> 1);
+  uint32_t mine = ((need & my_j_bit) ? 1u : 0u) + ((need & my_v_bit) ? 1u : 0u);  // DMA instructions per stage this wave issues
+  const uint8_t* base_t[kT4DmaPerWave];
+#pragma unroll
+  for (int t = 0; t < static_cast<int>(kT4DmaPerWave); ++t) {
+    const uint32_t T = wave + kT4Waves * t;
+    uint32_t first = static_cast<uint32_t>(slot_first(T >> 1));
+    first = (first < A.n_local) ? first : (A.n_local - 1);
+    first = __builtin_amdgcn_readfirstlane(first);
+    base_t[t] = A.codes + static_cast<uint64_t>(first) * row_bytes;
+    const uint32_t L = T * 64 + lane;
+    const uint32_t rr = (L >> 2) & 31;
+    const uint32_t col = (L & 3) ^ G::swizzle(rr);
+    uint32_t var = first + rr;
+    var = (var < A.n_local) ? var : (A.n_local - 1);
+    s_src_off[t * (kT4Waves * 64) + tid] = (var - first) * row_bytes + G::piece_byte(col);
+  }
+  auto dma_stage = [&](uint32_t s, uint32_t buf) {
+    const uint32_t kbyte = G::stage_byte(s);
+    uint32_t* dst = lds + buf * kT4StageDwords;
+#pragma unroll
+    for (int t = 0; t < static_cast<int>(kT4DmaPerWave); ++t) {
+      const uint32_t T = wave + kT4Waves * t;
+      if (need & (t ? my_v_bit : my_j_bit)) {  // (wave-uniform)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_t[t] + kbyte + s_src_off[t * (kT4Waves * 64) + tid]),
+                                         (__attribute__((address_space(3))) void*)(dst + T * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  const int64_t j64 = static_cast<int64_t>(jfirst) + r;
+  uint32_t lo_j = 0xffffffffu;
+  if ((j64 >= 0) && (j64 < static_cast<int64_t>(jend))) {
+    lo_j = A.lo[static_cast<uint32_t>(j64)];
+  }
+  const uint32_t sw = G::swizzle(r);
+  const uint32_t j_slot = ja * G::kBlockSlots;
+  const uint32_t oH = r * 4 + (h ^ sw);
+  const uint32_t oR = r * 4 + ((2 + h) ^ sw);
+  const uint32_t v_slot0 = (4 + vb0) * G::kBlockSlots, v_slot1 = (5 + vb0) * G::kBlockSlots;
+
+  mf_v16f acc[2][4];  // [product][0 x.x  1 n.n  2 n_i.x_j  3 x_i.n_j]
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        acc[p][c][g] = 0.f;
+      }
+    }
+  }
+  const uint32_t cp_all = A.cp_stats ? A.n_checkpoints : 0;
+  const uint32_t n_cp = (cp_all >= kGenCheckpointFirst + kGenCheckpoints) ? kGenCheckpoints : ((cp_all > kGenCheckpointFirst) ? (cp_all - kGenCheckpointFirst) : 0u);
+  auto checkpoint_stage = [&](uint32_t cp) {
+    const uint32_t s = A.checkpoint_chunk[cp] * G::kStagesPerChunk;
+    return (s < n_stages) ? s : n_stages;
+  };
+  __syncthreads();  // (s_src_off is complete)
+  uint32_t issued = 0, issue_buf = 0, read_buf = 0, issued_base = 0;
+  uint32_t next_cp = 0;
+  uint32_t issue_limit = (next_cp < n_cp) ? checkpoint_stage(kGenCheckpointFirst + next_cp) : n_stages;
+  auto ring_fill = [&]() {
+    issue_buf = 0;
+    read_buf = 0;
+    while ((issued < issue_limit) && (issued + 2 < issued_base + stages)) {
+      dma_stage(issued, issue_buf);
+      ++issued;
+      issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
+    }
+  };
+  ring_fill();
+  // both stages of pair kc, kc + 1 have landed and every wave is done with the pair before: two more stages go into its buffers
+  auto advance = [&](uint32_t kc) {
+    wait_dma_then_barrier(mine * (issued - kc - 2));
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (issued < issue_limit) {
+        dma_stage(issued, issue_buf);
+        ++issued;
+        issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
+      }
+    }
+    const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * kT4StageDwords);
+    read_buf = (read_buf + 2 == stages) ? 0 : read_buf + 2;
+    return st4;
+  };
+  // ONE form of the stage (both products whenever the wave has a live one: a retired or never-wanted product accumulates numbers
+  // nobody reads -- several forms chosen per segment made hipcc keep a copy of the accumulators per form and spill)
+  uint32_t stop_stage[2] = {n_stages, n_stages};
+  for (uint32_t kc = 0; kc < n_stages;) {
+    const uint32_t kc_end = issue_limit;
+    for (; kc < kc_end; kc += 2) {
+      const mf_u4* __restrict__ st4 = advance(kc);
+      if (!live) {
+        continue;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const mf_u4* __restrict__ sq = st4 + q * (kT4StageDwords / 4);
+        mf_u4 jH = sq[j_slot + oH], jR = sq[j_slot + oR];
+        mf_u4 aH = sq[v_slot0 + oH], aR = sq[v_slot0 + oR];
+        mf_u4 bH = sq[v_slot1 + oH], bR = sq[v_slot1 + oR];
+        opaque(jH, jR);
+        opaque(aH, aR);
+        opaque(bH, bR);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          // the J operand of the k-step, expanded once for both products
+          Frag jx, jn, unused;
+          fp4_of_codes(jH[ks], jR[ks], jx);
+          fp4_nh_of_codes(jH[ks], jR[ks], jx, jn, unused);
+          {
+            Frag vx, vn;
+            fp4_of_codes(aH[ks], aR[ks], vx);
+            fp4_nh_of_codes(aH[ks], aR[ks], vx, vn, unused);
+            acc[0][0] = mfma_fp4(vx, jx, acc[0][0]);
+            acc[0][1] = mfma_fp4(vn, jn, acc[0][1]);
+            acc[0][2] = mfma_fp4(vn, jx, acc[0][2]);
+            acc[0][3] = mfma_fp4(vx, jn, acc[0][3]);
+          }
+          {
+            Frag vx, vn;
+            fp4_of_codes(bH[ks], bR[ks], vx);
+            fp4_nh_of_codes(bH[ks], bR[ks], vx, vn, unused);
+            acc[1][0] = mfma_fp4(vx, jx, acc[1][0]);
+            acc[1][1] = mfma_fp4(vn, jn, acc[1][1]);
+            acc[1][2] = mfma_fp4(vn, jx, acc[1][2]);
+            acc[1][3] = mfma_fp4(vx, jn, acc[1][3]);
+          }
+        }
+      }
+    }
+    if (kc >= n_stages) {
+      break;
+    }
+    // ---- checkpoint (block-uniform; the ring is empty and the LDS is scratch) ----
+    __syncthreads();
+    if (tid == 0) {
+      s_live_waves = 0;
+      s_need = 0;
+    }
+    {
+      // row-block slot `wave` by this wave: lanes 0..31 = its rows' remainder slots, lanes 32..63 = their whole-row slots
+      const uint8_t* cpg = reinterpret_cast<const uint8_t*>(A.cp_stats);
+      const uint32_t gen_slot = kCpSlots + 1 + next_cp;
+      uint32_t first = static_cast<uint32_t>(slot_first(wave));
+      first = (first < A.n_local) ? first : (A.n_local - 1);
+      first = __builtin_amdgcn_readfirstlane(first);
+      uint32_t var = first + r;
+      var = (var < A.n_local) ? var : (A.n_local - 1);
+      const uint64_t off = (static_cast<uint64_t>(var) * kCpStride + (h ? static_cast<uint32_t>(kCpSlots) : gen_slot)) * sizeof(cp_gen_slot);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cpg + off),
+                                       (__attribute__((address_space(3))) void*)(lds + kT4CpStatDwords + wave * 256), 16, 0, 0);
+    }
+    __syncthreads();  // (drains the DMA; s_live_waves is zero)
+    if (live) {
+      const cp_gen_slot* __restrict__ cpl = reinterpret_cast<const cp_gen_slot*>(lds + kT4CpStatDwords);
+      const uint64_t seen = static_cast<uint64_t>(kc) * G::kStageSamples;
+      const double seen_d = static_cast<double>((seen < A.founder_ct) ? seen : A.founder_ct);
+      const double rs = (seen < A.founder_ct) ? static_cast<double>(A.founder_ct - seen) : 1.0;
+      const GenRow gj = gen_row(cpl[ja * 64 + r], cpl[ja * 64 + 32 + r], seen_d);
+      uint32_t* mine_epi = lds + wave * kT4CpWaveDwords;
+      GenRow* rows_i = reinterpret_cast<GenRow*>(mine_epi + 4 * kMfGenCpRound * 64);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        if (!(live & (1u << p))) {
+          continue;
+        }
+        if (h == 0) {
+          rows_i[r] = gen_row(cpl[(4 + vb0 + p) * 64 + r], cpl[(4 + vb0 + p) * 64 + 32 + r], seen_d);
+        }
+        bool hopeless = true;
+#pragma unroll
+        for (int round = 0; round < 16 / static_cast<int>(kMfGenCpRound); ++round) {
+          if (__all(hopeless)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+              for (int g = 0; g < static_cast<int>(kMfGenCpRound); ++g) {
+                mine_epi[(c * kMfGenCpRound + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>(acc[p][c][round * kMfGenCpRound + g]));
+              }
+            }
+#pragma unroll 1
+            for (uint32_t gg = 0; gg < kMfGenCpRound; ++gg) {
+              const uint32_t g = round * kMfGenCpRound + gg;
+              const uint32_t row = (g & 3) + 8 * (g >> 2) + 4 * h;
+              const int64_t i64 = static_cast<int64_t>(vfirst0) + kMfBlock * p + row;
+              if ((lo_j != 0xffffffffu) && (i64 >= static_cast<int64_t>(lo_j)) && (i64 < j64)) {
+                const GenRow gi = rows_i[row];
+                auto val = [&](uint32_t c) { return static_cast<double>(static_cast<int32_t>(mine_epi[(c * kMfGenCpRound + gg) * 64 + lane])); };
+                hopeless = hopeless && pair_hopeless_centred<false>(A.thresh, val(1), val(3), 0.0, val(2), 0.0, val(0), gi, gj, rs);
+              }
+            }
+          }
+        }
+        if (__all(hopeless)) {
+          live &= ~(1u << p);
+          stop_stage[p] = kc;
+        }
+      }
+      if (live && (lane == 0)) {
+        atomicAdd(&s_live_waves, 1u);
+        atomicOr(&s_need, (1u << ja) | (live << (4 + vb0)));
+      }
+    }
+    __syncthreads();
+    if (!s_live_waves) {
+      break;
+    }
+    need = __builtin_amdgcn_readfirstlane(s_need);
+    mine = ((need & my_j_bit) ? 1u : 0u) + ((need & my_v_bit) ? 1u : 0u);
+    ++next_cp;
+    issued_base = kc;
+    issue_limit = (next_cp < n_cp) ? checkpoint_stage(kGenCheckpointFirst + next_cp) : n_stages;
+    ring_fill();
+  }
+  if (lane == 0) {
+    unsigned long long skipped = 0;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if ((mine_products >> p) & 1u) {
+        skipped += static_cast<unsigned long long>(n_stages - stop_stage[p]) * 4ull;
+      }
+    }
+    if (skipped) {
+      atomicAdd(A.counters + 2, skipped);
+    }
+  }
+  // ---- epilogue: intervals for the two sums of squares, exact recount where they leave the predicate open ----
+  __syncthreads();  // (every wave is past its last stage: the ring is scratch)
+  uint32_t n_true = 0, n_open = 0;
+  uint32_t* epi4 = lds + wave * (4 * 8 * 64);
+  // (what the epilogue needs per lane is derived again here rather than kept in registers across the stage loops, where hipcc
+  // parks such values in scratch and reloads them on every trip)
+  {
+  uint32_t tid_e = threadIdx.x;
+  asm volatile("" : "+v"(tid_e));
+  const uint32_t lane = tid_e & 63, r = lane & 31, h = lane >> 5;
+  const int64_t j64 = static_cast<int64_t>(jfirst) + r;
+  uint32_t lo_j = 0xffffffffu;
+  if ((j64 >= 0) && (j64 < static_cast<int64_t>(jend))) {
+    lo_j = A.lo[static_cast<uint32_t>(j64)];
+  }
+  const bool j_ok = (lo_j != 0xffffffffu) && (static_cast<int64_t>(lo_j) < j64);
+  const uint32_t j = j_ok ? static_cast<uint32_t>(j64) : 0u;
+  ldp_variant_rec rj;
+  rj.nm_ct = 0;
+  rj.sum = 0;
+  rj.ssq = 0;
+  rj.flags = 0;
+  if (j_ok && live) {
+    rj = A.recs[j];
+  }
+  const bool alt_j = (rj.flags & 1u) != 0;
+  const int64_t N = static_cast<int64_t>(A.founder_ct);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (!(live & (1u << p))) {  // (wave-uniform)
+      continue;
+    }
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) {
+          epi4[(c * 8 + g8) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>(acc[p][c][round * 8 + g8]));
+        }
+      }
+#pragma unroll 1
+      for (uint32_t g8 = 0; g8 < 8; ++g8) {
+        const uint32_t g = round * 8 + g8;
+        const int64_t i64 = static_cast<int64_t>(vfirst0) + kMfBlock * p + (g & 3) + 8 * (g >> 2) + 4 * h;
+        const bool valid = j_ok && (i64 >= static_cast<int64_t>(lo_j)) && (i64 < j64);
+        const uint32_t i = valid ? static_cast<uint32_t>(i64) : 0u;
+        int32_t dot_major = 0;
+        uint32_t alt_ij = 0;
+        int cls = 0;
+        if (valid) {
+          const ldp_variant_rec ri = A.recs[i];
+          const bool alt_i = (ri.flags & 1u) != 0;
+          alt_ij = (alt_i ? 1u : 0u) | (alt_j ? 2u : 0u);
+          ldp_pair_stats_t ps;
+          const int32_t d = static_cast<int32_t>(epi4[(0 * 8 + g8) * 64 + lane]), s2 = static_cast<int32_t>(epi4[(2 * 8 + g8) * 64 + lane]),
+                        s1 = static_cast<int32_t>(epi4[(3 * 8 + g8) * 64 + lane]);
+          ps.dot = (alt_i != alt_j) ? -d : d;
+          ps.nm = epi4[(1 * 8 + g8) * 64 + lane];
+          ps.sum2 = alt_j ? -s2 : s2;
+          ps.sum1 = alt_i ? -s1 : s1;
+          dot_major = ps.dot;
+          cls = classify_four(ps, ri, rj, N, A.thresh);
+          if (cls == 1) {
+            atomicOr(&A.pred[A.row_off[j] + ((i >> 5) - (lo_j >> 5))], 1u << (i & 31));
+            ++n_true;
+          }
+        }
+        unsigned long long open = __ballot(cls == 2);
+        while (open) {
+          const int l = __builtin_ctzll(open);
+          open &= open - 1;
+          const uint32_t ii = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(i), l));
+          const uint32_t jj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(j), l));
+          const int32_t dd = __builtin_amdgcn_readlane(dot_major, l);
+          const uint32_t aa = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(alt_ij), l));
+          const ldp_pair_stats_t st = wave_pair_counts(A, ii, jj, dd, lane, (aa & 1u) != 0, (aa & 2u) != 0);
+          if ((static_cast<int>(lane) == l) && exceeds(st, A.thresh)) {
+            atomicOr(&A.pred[A.row_off[j] + ((i >> 5) - (lo_j >> 5))], 1u << (i & 31));
+            ++n_true;
+          }
+          n_open += (lane == 0) ? 1u : 0u;
+        }
+      }
+    }
+  }
+  if ((lane == 0) && n_open) {
+    atomicAdd(A.counters + 3, static_cast<unsigned long long>(n_open));
+  }
+  n_true = wave_reduce_add(n_true);
+  if ((lane == 0) && n_true) {
+    atomicAdd(A.counters, static_cast<unsigned long long>(n_true));
+  }
+  }
+}
+
+
 hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipEvent_t* ev) {
   if (!a_in.n_mf_wgs) {
     return hipSuccess;
@@ -1421,6 +1829,19 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
     }();
     PairKernelArgs g = a_in;
     g.lds_dwords = static_cast<uint32_t>(glds / sizeof(uint32_t));
+    // prune launches over subcontigs with the tile plan: quarter tiles (four products); the parallelogram workgroups of those
+    // subcontigs then stay out (wd_general)
+    if (a_in.wd_general) {
+      static const size_t t4lds = []() {
+        const size_t bytes = static_cast<size_t>(kT4LdsDwords) * sizeof(uint32_t);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_tile4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        return bytes;
+      }();
+      PairKernelArgs t4 = a_in;
+      t4.lds_dwords = static_cast<uint32_t>(t4lds / sizeof(uint32_t));
+      const uint32_t t4_per_xcd = (a_in.n_wd_tiles * 4 + 7) / 8;
+      hipLaunchKernelGGL(pair_mfma_tile4_kernel, dim3(t4_per_xcd * 8), dim3(kT4Waves * 64), t4lds, stream, t4);
+    }
     const uint32_t gper_xcd = (g.n_mf_wgs * 8 + 7) / 8;
     // only the predicate is wanted (no integers, no r^2 values): the four-product form
     if (a_in.mf_four && !a_in.stats && !a_in.r2_out && !a_in.r2_hits) {

@@ -620,6 +620,58 @@ def test_four_product_form_of_the_missing_call_kernel(gpu_pkg, n, miss, r2, redr
     assert np.array_equal(four, want)
 
 
+def _run_wide(pkg, packed, n, chr_idx, window, r2, options):
+    eng = pkg.LdPruneEngine(n, window, 1, False, r2, order=2, device=0)
+    for name, value in options.items():
+        eng.set_option(name, value)
+    eng.set_variants(chr_idx, None)
+    eng.load_genotypes_host(0, packed, pkg.LDP_GENO_REF)
+    removed = eng.run()
+    ctr = eng.counters()
+    eng.close()
+    return removed, ctr
+
+
+@pytest.mark.parametrize("n,m,window,miss,r2", [
+    (20000, 1500, 600, 0.05, 0.2),     # config 5's rate and threshold; 19 row-blocks of reach
+    (6000, 1100, 1000, 0.02, 0.5),     # the window is most of the chromosome: diagonal and far tiles, ragged last J tile
+    (900, 1300, 420, 0.3, 0.1),        # four stages, no checkpoint reached; wide intervals, many recounts
+    (50000, 900, 450, 0.01, 0.7),
+])
+def test_four_product_form_on_quarter_tiles_of_wide_bands(gpu_pkg, n, m, window, miss, r2):
+    """subcontigs that have the 8 x 8 tile plan take the four-product form in QUARTER tiles (pair_mfma_tile4_kernel: eight
+    waves, 4 J x 4 V row-blocks per stage, two products per wave) instead of the parallelogram plan.  Same prune set and the same
+    number of true predicates as that plan, the six-product form and the oracle, with and without early termination -- with pairs
+    that only become correlated in the last 40 % of the samples, and rows that are complete or mostly missing among the others."""
+    pkg = gpu_pkg
+    rng = np.random.default_rng(n + m)
+    raw = T.synth_raw_codes(m, n, seed=n % 83 + 3, missing_rate=miss, ld_copy_prob=0.6, redraw=0.1)
+    cut = int(0.6 * n)
+    for v in range(40, m, 11):             # late LD with a variant 37 rows back (another row-block, often another quarter tile)
+        raw[v, :cut] = rng.permutation(raw[v, :cut])
+        raw[v, cut:] = raw[v - 37, cut:]
+    raw[rng.choice(m, size=30, replace=False)] = np.where(raw[3] == 3, 0, raw[3])[None, :]
+    for v in rng.choice(m, size=15, replace=False):
+        raw[v, rng.random(n) < 0.7] = 3
+    chr_idx = (np.arange(m) >= m - 200).astype(np.uint32)   # a second, short chromosome (narrow plan) behind the wide one
+    packed = T.pack_2bit(raw)
+    tiles, ct = _run_wide(pkg, packed, n, chr_idx, window, r2, {"pair_sparse": 0})
+    tiles_x, ctx = _run_wide(pkg, packed, n, chr_idx, window, r2, {"pair_sparse": 0, "early_exit": 0})
+    plan, cp = _run_wide(pkg, packed, n, chr_idx, window, r2, {"pair_sparse": 0, "pair_four_tiles": 0})
+    six, c6 = _run_wide(pkg, packed, n, chr_idx, window, r2, {"pair_sparse": 0, "pair_four": 0, "early_exit": 0})
+    assert ct["wide_tiles"] > 0 and ct["four_tile_launches"] > 0 and ctx["four_tile_launches"] > 0
+    assert cp["four_tile_launches"] == 0 and c6["four_tile_launches"] == 0 and c6["route_general_launches"] > 0
+    assert np.array_equal(tiles, six) and np.array_equal(tiles_x, six) and np.array_equal(plan, six)
+    assert ctx["pred_true"] == c6["pred_true"] > 0 and ct["pred_true"] <= ctx["pred_true"]
+    assert ctx["mfma_skipped_product_stages"] == 0
+    if n >= 6000:
+        assert ct["mfma_skipped_product_stages"] > 0
+    if n <= 6000:
+        inv, mf, _ = T.oracle_prepare(raw)
+        want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, np.arange(m, dtype=np.uint32), mf, window, 1, False, r2, 2)
+        assert np.array_equal(tiles, want)
+
+
 def test_route_follows_the_mean_not_the_worst_row(gpu_pkg):
     """A handful of rows with many missing calls among rows with few: the launch still takes the interval path (its
     pairs with those rows are counted exactly); when such rows are common it goes to the six-product kernel."""

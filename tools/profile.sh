@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --no-cpu-baseline --no-legs ${LDP_PROF_ARGS:-}"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --steps 5 --warmup 1 > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --steps ${LDP_PROF_TRACE_STEPS:-5} --warmup 1 > $OUT/trace.log 2>&1
 tail -1 $OUT/trace.log
 i=0
 for P in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
@@ -19,6 +19,7 @@ for P in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VA
          "FETCH_SIZE" \
          "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
+  if [ -n "${LDP_PROF_TRAFFIC_ONLY:-}" ] && [ $i -lt 4 ]; then continue; fi   # (only the two passes roofline.traffic comes from)
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pmc$i -- $BENCH --steps 1 --warmup 0 > $OUT/pmc$i.log 2>&1
 done
 python $R/tools/summarize_prof.py $OUT $R/gpurun_out/profiles_$TAG $TAG
