@@ -1366,19 +1366,29 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
 // waves stages 4 J + 4 V row-blocks (0.5 per product), wave w owns J block w & 3 against V blocks 2 (w >> 2), + 1 -- two
 // products that share the expanded J operand, 2 x 4 x 16 accumulators, two waves per SIMD.  Stages, checkpoints (whole waves
 // retire, the workgroup leaves when all have) and the interval epilogue are those of pair_mfma_general_kernel<false>.
-constexpr uint32_t kT4Waves = 8;
-constexpr uint32_t kT4Blocks = 8;                      // staged row-blocks: slots 0..3 = J, 4..7 = V
-constexpr uint32_t kT4Instr = kT4Blocks * 2;           // DMA instructions per 256-sample stage
-constexpr uint32_t kT4DmaPerWave = kT4Instr / kT4Waves;
-constexpr uint32_t kT4StageDwords = kT4Instr * 256;    // 16 KiB
-constexpr uint32_t kT4CpWaveDwords = 4 * kMfGenCpRound * 64 + kMfGenCpRowDwords;  // a wave's checkpoint scratch: four sums x rows, its V block's rows prepared
-constexpr uint32_t kT4CpStatDwords = kT4Waves * kT4CpWaveDwords;                  // the rows' slots follow (8 x 1 KiB)
-constexpr uint32_t kT4LdsDwords = 6 * kT4StageDwords;  // 96 KiB: a ring of six stages (one workgroup per CU: 256 registers a wave); the epilogue's scratch is 64 KiB of it
+template <int JB>
+struct T4 {  // JB J row-blocks x 4 V row-blocks per workgroup, 2 JB waves
+  static_assert((JB == 2) || (JB == 4), "half or quarter of a tile's J blocks");
+  static constexpr uint32_t kWaves = 2 * JB;
+  static constexpr uint32_t kBlocks = JB + 4;                   // staged row-blocks: slots 0 .. JB - 1 = J, the next four = V
+  static constexpr uint32_t kInstr = kBlocks * 2;               // DMA instructions per 256-sample stage
+  static constexpr uint32_t kDmaPerWave = kInstr / kWaves;      // 2 (JB = 4), 3 (JB = 2)
+  static constexpr uint32_t kStageDwords = kInstr * 256;        // 16 / 12 KiB
+  static constexpr uint32_t kCpWaveDwords = 4 * kMfGenCpRound * 64 + kMfGenCpRowDwords;  // a wave's checkpoint scratch: four sums x rows, its V block's rows prepared
+  static constexpr uint32_t kCpStatDwords = kWaves * kCpWaveDwords;                      // the rows' slots follow (1 KiB per row-block)
+  static constexpr uint32_t kLdsDwords = 6 * kStageDwords;      // a ring of six stages: 96 KiB, one workgroup per CU (JB = 4) / 72 KiB, two (JB = 2)
+  static constexpr uint32_t kUnits = 2 * (8 / JB);              // workgroups per tile
+  static_assert(kInstr % kWaves == 0, "whole instructions per wave");
+  static_assert(kCpStatDwords + kBlocks * 256 <= kLdsDwords, "checkpoint scratch inside the ring");
+  static_assert(kWaves * 4 * 8 * 64 <= kLdsDwords, "epilogue scratch inside the ring");
+};
 
-__global__ __launch_bounds__(kT4Waves * 64, 2) void pair_mfma_tile4_kernel(PairKernelArgs A) {
+template <int JB>
+__global__ __launch_bounds__(T4<JB>::kWaves * 64, 2) void pair_mfma_tile4_kernel(PairKernelArgs A) {
   using G = StageGeom<4>;
+  using C = T4<JB>;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  __shared__ uint32_t s_src_off[kT4Instr * 64];
+  __shared__ uint32_t s_src_off[C::kInstr * 64];
   __shared__ uint32_t s_live_waves;
   __shared__ uint32_t s_need;
   {
@@ -1386,23 +1396,23 @@ __global__ __launch_bounds__(kT4Waves * 64, 2) void pair_mfma_tile4_kernel(PairK
       return;
     }
   }
-  const uint32_t n_units = A.n_wd_tiles * 4;  // tile x quarter
+  const uint32_t n_units = A.n_wd_tiles * C::kUnits;
   const uint32_t per_xcd = (n_units + 7) / 8;
   const uint32_t idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (idx >= n_units) {
     return;
   }
-  const MfmaTile* __restrict__ tile = A.wd_tiles + (idx >> 2);
-  const uint32_t qj = (idx >> 1) & 1u, qv = idx & 1u;
-  const int32_t jv0 = __builtin_amdgcn_readfirstlane(tile->jv) + static_cast<int32_t>(kMfBlock * 4 * qj);
+  const MfmaTile* __restrict__ tile = A.wd_tiles + (idx / C::kUnits);
+  const uint32_t qj = (idx % C::kUnits) >> 1, qv = idx & 1u;  // J blocks JB qj .., V blocks 4 qv ..
+  const int32_t jv0 = __builtin_amdgcn_readfirstlane(tile->jv) + static_cast<int32_t>(kMfBlock * JB * qj);
   const int32_t vv0 = __builtin_amdgcn_readfirstlane(tile->vv) + static_cast<int32_t>(kMfBlock * 4 * qv);
   const uint32_t jend = __builtin_amdgcn_readfirstlane(tile->jend);
   const unsigned long long tmask = tile->mask;
-  // bit 4 a + b: product (J block a, V block b) of this quarter holds candidate pairs
+  // bit 4 a + b: product (J block a, V block b) of this part of the tile holds candidate pairs
   uint32_t mask16 = 0;
 #pragma unroll
-  for (uint32_t a = 0; a < 4; ++a) {
-    mask16 |= (static_cast<uint32_t>(tmask >> (8 * (4 * qj + a) + 4 * qv)) & 0xfu) << (4 * a);
+  for (uint32_t a = 0; a < static_cast<uint32_t>(JB); ++a) {
+    mask16 |= (static_cast<uint32_t>(tmask >> (8 * (JB * qj + a) + 4 * qv)) & 0xfu) << (4 * a);
   }
   mask16 = __builtin_amdgcn_readfirstlane(mask16);
   if (!mask16) {
@@ -1413,7 +1423,7 @@ __global__ __launch_bounds__(kT4Waves * 64, 2) void pair_mfma_tile4_kernel(PairK
   const uint32_t lane = tid & 63;
   const uint32_t r = lane & 31;
   const uint32_t h = lane >> 5;
-  const uint32_t ja = wave & 3, vb0 = 2 * (wave >> 2);
+  const uint32_t ja = wave % JB, vb0 = 2 * (wave / JB);
   uint32_t live = (mask16 >> (4 * ja + vb0)) & 3u;  // bit p: (J block ja, V block vb0 + p)
   const uint32_t mine_products = live;
   const int32_t jfirst = jv0 + static_cast<int32_t>(kMfBlock * ja);
@@ -1422,28 +1432,36 @@ __global__ __launch_bounds__(kT4Waves * 64, 2) void pair_mfma_tile4_kernel(PairK
   // stages are taken in PAIRS (one barrier per 512 samples, as in the wide-band kernel: the image's rows are whole 512-sample
   // k-chunks long, padded with missing calls, and the checkpoints sit on chunk boundaries)
   const uint32_t n_stages = 2 * ((A.founder_ct + 2 * G::kStageSamples - 1) / (2 * G::kStageSamples));
-  uint32_t stages = A.lds_dwords / kT4StageDwords;
+  uint32_t stages = A.lds_dwords / C::kStageDwords;
   stages = (stages > kMfMaxStages) ? kMfMaxStages : stages;
   stages &= ~1u;  // (launch_pair_mfma gives six)
 
-  // ---- DMA plan: row-block slot s (0..3 J, 4..7 V) is fetched while bit s of `need` is set: some live product reads it.  The
-  // set shrinks at the checkpoints (s_need); a wave issues instructions wave and wave + 8 of a stage, i.e. half of J block
-  // wave >> 1 and half of V block wave >> 1.
+  // ---- DMA plan: row-block slot s (J first, then V) is fetched while bit s of `need` is set: some live product reads it.  The
+  // set shrinks at the checkpoints (s_need); a wave issues instructions wave, wave + kWaves, .. of a stage (instruction T = half of
+  // row-block slot T >> 1).
   uint32_t need = 0;
 #pragma unroll
-  for (uint32_t a = 0; a < 4; ++a) {
+  for (uint32_t a = 0; a < static_cast<uint32_t>(JB); ++a) {
     const uint32_t rowm = (mask16 >> (4 * a)) & 0xfu;
-    need |= (rowm ? (1u << a) : 0u) | (rowm << 4);
+    need |= (rowm ? (1u << a) : 0u) | (rowm << JB);
   }
   auto slot_first = [&](uint32_t slot) -> int32_t {
-    return (slot < 4) ? (jv0 + static_cast<int32_t>(kMfBlock * slot)) : (vv0 + static_cast<int32_t>(kMfBlock * (slot - 4)));
+    return (slot < static_cast<uint32_t>(JB)) ? (jv0 + static_cast<int32_t>(kMfBlock * slot)) : (vv0 + static_cast<int32_t>(kMfBlock * (slot - JB)));
   };
-  const uint32_t my_j_bit = 1u << (wave >> 1), my_v_bit = 16u << (wave >> 1);
-  uint32_t mine = ((need & my_j_bit) ? 1u : 0u) + ((need & my_v_bit) ? 1u : 0u);  // DMA instructions per stage this wave issues
-  const uint8_t* base_t[kT4DmaPerWave];
+  auto my_bit = [&](int t) { return 1u << ((wave + C::kWaves * static_cast<uint32_t>(t)) >> 1); };
+  auto count_mine = [&]() {
+    uint32_t m = 0;
 #pragma unroll
-  for (int t = 0; t < static_cast<int>(kT4DmaPerWave); ++t) {
-    const uint32_t T = wave + kT4Waves * t;
+    for (int t = 0; t < static_cast<int>(C::kDmaPerWave); ++t) {
+      m += (need & my_bit(t)) ? 1u : 0u;
+    }
+    return m;
+  };
+  uint32_t mine = count_mine();  // DMA instructions per stage this wave issues
+  const uint8_t* base_t[C::kDmaPerWave];
+#pragma unroll
+  for (int t = 0; t < static_cast<int>(C::kDmaPerWave); ++t) {
+    const uint32_t T = wave + C::kWaves * t;
     uint32_t first = static_cast<uint32_t>(slot_first(T >> 1));
     first = (first < A.n_local) ? first : (A.n_local - 1);
     first = __builtin_amdgcn_readfirstlane(first);
@@ -1453,16 +1471,16 @@ __global__ __launch_bounds__(kT4Waves * 64, 2) void pair_mfma_tile4_kernel(PairK
     const uint32_t col = (L & 3) ^ G::swizzle(rr);
     uint32_t var = first + rr;
     var = (var < A.n_local) ? var : (A.n_local - 1);
-    s_src_off[t * (kT4Waves * 64) + tid] = (var - first) * row_bytes + G::piece_byte(col);
+    s_src_off[t * (C::kWaves * 64) + tid] = (var - first) * row_bytes + G::piece_byte(col);
   }
   auto dma_stage = [&](uint32_t s, uint32_t buf) {
     const uint32_t kbyte = G::stage_byte(s);
-    uint32_t* dst = lds + buf * kT4StageDwords;
+    uint32_t* dst = lds + buf * C::kStageDwords;
 #pragma unroll
-    for (int t = 0; t < static_cast<int>(kT4DmaPerWave); ++t) {
-      const uint32_t T = wave + kT4Waves * t;
-      if (need & (t ? my_v_bit : my_j_bit)) {  // (wave-uniform)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_t[t] + kbyte + s_src_off[t * (kT4Waves * 64) + tid]),
+    for (int t = 0; t < static_cast<int>(C::kDmaPerWave); ++t) {
+      const uint32_t T = wave + C::kWaves * t;
+      if (need & my_bit(t)) {  // (wave-uniform)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_t[t] + kbyte + s_src_off[t * (C::kWaves * 64) + tid]),
                                          (__attribute__((address_space(3))) void*)(dst + T * 256), 16, 0, 0);
       }
     }
@@ -1477,7 +1495,7 @@ __global__ __launch_bounds__(kT4Waves * 64, 2) void pair_mfma_tile4_kernel(PairK
   const uint32_t j_slot = ja * G::kBlockSlots;
   const uint32_t oH = r * 4 + (h ^ sw);
   const uint32_t oR = r * 4 + ((2 + h) ^ sw);
-  const uint32_t v_slot0 = (4 + vb0) * G::kBlockSlots, v_slot1 = (5 + vb0) * G::kBlockSlots;
+  const uint32_t v_slot0 = (JB + vb0) * G::kBlockSlots, v_slot1 = (JB + 1 + vb0) * G::kBlockSlots;
 
   mf_v16f acc[2][4];  // [product][0 x.x  1 n.n  2 n_i.x_j  3 x_i.n_j]
 #pragma unroll
@@ -1521,7 +1539,7 @@ __global__ __launch_bounds__(kT4Waves * 64, 2) void pair_mfma_tile4_kernel(PairK
         issue_buf = (issue_buf + 1 == stages) ? 0 : issue_buf + 1;
       }
     }
-    const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * kT4StageDwords);
+    const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * C::kStageDwords);
     read_buf = (read_buf + 2 == stages) ? 0 : read_buf + 2;
     return st4;
   };
@@ -1537,7 +1555,7 @@ __global__ __launch_bounds__(kT4Waves * 64, 2) void pair_mfma_tile4_kernel(PairK
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const mf_u4* __restrict__ sq = st4 + q * (kT4StageDwords / 4);
+        const mf_u4* __restrict__ sq = st4 + q * (C::kStageDwords / 4);
         mf_u4 jH = sq[j_slot + oH], jR = sq[j_slot + oR];
         mf_u4 aH = sq[v_slot0 + oH], aR = sq[v_slot0 + oR];
         mf_u4 bH = sq[v_slot1 + oH], bR = sq[v_slot1 + oR];
@@ -1581,26 +1599,32 @@ __global__ __launch_bounds__(kT4Waves * 64, 2) void pair_mfma_tile4_kernel(PairK
       s_need = 0;
     }
     {
-      // row-block slot `wave` by this wave: lanes 0..31 = its rows' remainder slots, lanes 32..63 = their whole-row slots
+      // row-block slot T by wave T % kWaves: lanes 0..31 = its rows' remainder slots, lanes 32..63 = their whole-row slots
       const uint8_t* cpg = reinterpret_cast<const uint8_t*>(A.cp_stats);
       const uint32_t gen_slot = kCpSlots + 1 + next_cp;
-      uint32_t first = static_cast<uint32_t>(slot_first(wave));
-      first = (first < A.n_local) ? first : (A.n_local - 1);
-      first = __builtin_amdgcn_readfirstlane(first);
-      uint32_t var = first + r;
-      var = (var < A.n_local) ? var : (A.n_local - 1);
-      const uint64_t off = (static_cast<uint64_t>(var) * kCpStride + (h ? static_cast<uint32_t>(kCpSlots) : gen_slot)) * sizeof(cp_gen_slot);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cpg + off),
-                                       (__attribute__((address_space(3))) void*)(lds + kT4CpStatDwords + wave * 256), 16, 0, 0);
+#pragma unroll
+      for (uint32_t t = 0; t < (C::kBlocks + C::kWaves - 1) / C::kWaves; ++t) {
+        const uint32_t T = wave + C::kWaves * t;
+        if (T < C::kBlocks) {
+          uint32_t first = static_cast<uint32_t>(slot_first(T));
+          first = (first < A.n_local) ? first : (A.n_local - 1);
+          first = __builtin_amdgcn_readfirstlane(first);
+          uint32_t var = first + r;
+          var = (var < A.n_local) ? var : (A.n_local - 1);
+          const uint64_t off = (static_cast<uint64_t>(var) * kCpStride + (h ? static_cast<uint32_t>(kCpSlots) : gen_slot)) * sizeof(cp_gen_slot);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cpg + off),
+                                           (__attribute__((address_space(3))) void*)(lds + C::kCpStatDwords + T * 256), 16, 0, 0);
+        }
+      }
     }
     __syncthreads();  // (drains the DMA; s_live_waves is zero)
     if (live) {
-      const cp_gen_slot* __restrict__ cpl = reinterpret_cast<const cp_gen_slot*>(lds + kT4CpStatDwords);
+      const cp_gen_slot* __restrict__ cpl = reinterpret_cast<const cp_gen_slot*>(lds + C::kCpStatDwords);
       const uint64_t seen = static_cast<uint64_t>(kc) * G::kStageSamples;
       const double seen_d = static_cast<double>((seen < A.founder_ct) ? seen : A.founder_ct);
       const double rs = (seen < A.founder_ct) ? static_cast<double>(A.founder_ct - seen) : 1.0;
       const GenRow gj = gen_row(cpl[ja * 64 + r], cpl[ja * 64 + 32 + r], seen_d);
-      uint32_t* mine_epi = lds + wave * kT4CpWaveDwords;
+      uint32_t* mine_epi = lds + wave * C::kCpWaveDwords;
       GenRow* rows_i = reinterpret_cast<GenRow*>(mine_epi + 4 * kMfGenCpRound * 64);
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
@@ -1608,7 +1632,7 @@ __global__ __launch_bounds__(kT4Waves * 64, 2) void pair_mfma_tile4_kernel(PairK
           continue;
         }
         if (h == 0) {
-          rows_i[r] = gen_row(cpl[(4 + vb0 + p) * 64 + r], cpl[(4 + vb0 + p) * 64 + 32 + r], seen_d);
+          rows_i[r] = gen_row(cpl[(JB + vb0 + p) * 64 + r], cpl[(JB + vb0 + p) * 64 + 32 + r], seen_d);
         }
         bool hopeless = true;
 #pragma unroll
@@ -1641,7 +1665,7 @@ __global__ __launch_bounds__(kT4Waves * 64, 2) void pair_mfma_tile4_kernel(PairK
       }
       if (live && (lane == 0)) {
         atomicAdd(&s_live_waves, 1u);
-        atomicOr(&s_need, (1u << ja) | (live << (4 + vb0)));
+        atomicOr(&s_need, (1u << ja) | (live << (JB + vb0)));
       }
     }
     __syncthreads();
@@ -1649,7 +1673,7 @@ __global__ __launch_bounds__(kT4Waves * 64, 2) void pair_mfma_tile4_kernel(PairK
       break;
     }
     need = __builtin_amdgcn_readfirstlane(s_need);
-    mine = ((need & my_j_bit) ? 1u : 0u) + ((need & my_v_bit) ? 1u : 0u);
+    mine = count_mine();
     ++next_cp;
     issued_base = kc;
     issue_limit = (next_cp < n_cp) ? checkpoint_stage(kGenCheckpointFirst + next_cp) : n_stages;
@@ -1832,15 +1856,16 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
     // prune launches over subcontigs with the tile plan: quarter tiles (four products); the parallelogram workgroups of those
     // subcontigs then stay out (wd_general)
     if (a_in.wd_general) {
+      // quarter tiles: JB = 4 (half tiles of J, two workgroups of four waves per CU, measured the same: profiles/r03_experiments.md)
       static const size_t t4lds = []() {
-        const size_t bytes = static_cast<size_t>(kT4LdsDwords) * sizeof(uint32_t);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_tile4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        const size_t bytes = static_cast<size_t>(T4<4>::kLdsDwords) * sizeof(uint32_t);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_tile4_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
         return bytes;
       }();
       PairKernelArgs t4 = a_in;
-      t4.lds_dwords = static_cast<uint32_t>(t4lds / sizeof(uint32_t));
-      const uint32_t t4_per_xcd = (a_in.n_wd_tiles * 4 + 7) / 8;
-      hipLaunchKernelGGL(pair_mfma_tile4_kernel, dim3(t4_per_xcd * 8), dim3(kT4Waves * 64), t4lds, stream, t4);
+      t4.lds_dwords = T4<4>::kLdsDwords;
+      const uint32_t per_xcd = (a_in.n_wd_tiles * T4<4>::kUnits + 7) / 8;
+      hipLaunchKernelGGL(pair_mfma_tile4_kernel<4>, dim3(per_xcd * 8), dim3(T4<4>::kWaves * 64), t4lds, stream, t4);
     }
     const uint32_t gper_xcd = (g.n_mf_wgs * 8 + 7) / 8;
     // only the predicate is wanted (no integers, no r^2 values): the four-product form

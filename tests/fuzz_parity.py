@@ -57,6 +57,8 @@ def one_case(pkg, rng, idx):
         eng.set_option("wide_min_reach", wide)  # send narrower bands through the 8 x 8 tile plan of the wide-band kernel too
     if idx % 3 == 2:
         eng.set_option("pair_four", 0)   # the six-product form of the missing-call kernel (prune launches default to four)
+    if idx % 4 == 3:
+        eng.set_option("pair_four_tiles", 0)  # ... on the parallelogram plan in wide bands too (default: quarter tiles of the tile plan)
     if idx % 5 == 4:
         eng.set_option("pair_sparse", 0)  # rows with a few missing calls through the missing-call kernel too
     eng.set_variants(chr_idx, bps)
@@ -71,8 +73,8 @@ def one_case(pkg, rng, idx):
     ctr = eng.counters()
     eng.close()
     ok = np.array_equal(got, want)
-    desc = "case %d: n=%d m=%d miss=%g %s window=%d step=%d r2=%g order=%d chr=%d wide_min_reach=%d tiles=%d removed=%d skipped=%.2f" % (
-        idx, n, m, miss, "bp" if is_bp else "count", window, step, r2, order, n_chr, wide, ctr["wide_tiles"], int(want.sum()),
+    desc = "case %d: n=%d m=%d miss=%g %s window=%d step=%d r2=%g order=%d chr=%d wide_min_reach=%d tiles=%d four_tile_launches=%d removed=%d skipped=%.2f" % (
+        idx, n, m, miss, "bp" if is_bp else "count", window, step, r2, order, n_chr, wide, ctr["wide_tiles"], ctr["four_tile_launches"], int(want.sum()),
         (ctr["mfma_skipped_product_stages"] / ctr["mfma_product_stages"]) if ctr["mfma_product_stages"] else 0.0)
     return ok, desc
 

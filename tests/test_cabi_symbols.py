@@ -27,7 +27,7 @@ def test_struct_layouts_match_the_header(pkg):
     assert ctypes.sizeof(pkg.ldp_pair_stats_t) == 24 == pkg.PAIR_STATS_DTYPE.itemsize
     assert ctypes.sizeof(pkg.ldp_variant_rec) == 32 == pkg.VARIANT_REC_DTYPE.itemsize
     assert ctypes.sizeof(pkg.ldp_params) == 48
-    assert ctypes.sizeof(pkg.ldp_counters) == 184
+    assert ctypes.sizeof(pkg.ldp_counters) == 192
 
 
 def test_device_count_never_fails(pkg):

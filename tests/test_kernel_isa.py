@@ -66,3 +66,32 @@ def test_wide_band_kernel_has_one_branch_free_stage_loop_and_no_scratch(tmp_path
         if "ds_read_b128" in ln:
             before = [x for x in lines[max(0, k - 6):k] if not x.strip().startswith(";")]
             assert "vmcnt(0)" not in "\n".join(before[-3:]), "s_waitcnt vmcnt(0) in front of a stage read:\n" + "\n".join(lines[k - 6:k + 1])
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+def test_quarter_tile_kernel_has_one_stage_loop_without_scratch(tmp_path):
+    """pair_mfma_tile4_kernel: ONE form of the stage loop -- two 256-sample stages, 2 products x 4 sums x 4 k-steps x 2
+    = 64 MFMAs behind 12 LDS reads -- with no scratch access and no accumulator copy inside (three forms chosen per segment made
+    hipcc spill an address inside the loop, whose reload drained the DMA ring every stage), two waves per SIMD."""
+    src = os.path.join(REPO, "plink-ng_amd", "csrc", "ldp_pair_mfma.hip")
+    out = tmp_path / "mf.s"
+    cp = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--cuda-device-only", "-S",
+                         src, "-o", str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert cp.returncode == 0, cp.stdout[-2000:]
+    text = open(out).read()
+    m = re.search(r"^(_ZN3ldp22pair_mfma_tile4_kernel\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M)
+    assert m, "kernel not found"
+    lines = m.group(2).splitlines()
+    assert re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2)) and int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2)).group(1)) <= 256
+    labels = {mm.group(1): k for k, ln in enumerate(lines) for mm in [re.match(r"^(\.LBB\d+_\d+):", ln)] if mm}
+    loops = []
+    for k, ln in enumerate(lines):
+        mm = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", ln)
+        if mm and mm.group(1) in labels and labels[mm.group(1)] < k:
+            body = lines[labels[mm.group(1)]:k]
+            loops.append((sum("v_mfma_scale_f32_32x32x64_f8f6f4" in x for x in body), body))
+    inner = min((lp for lp in loops if lp[0] > 0), key=lambda lp: len(lp[1]))
+    assert inner[0] == 64
+    assert not any(("scratch_" in x) or ("v_accvgpr" in x) for x in inner[1])
+    assert sum("ds_read_b128" in x for x in inner[1]) == 12
+    assert sum("v_mfma_scale_f32_32x32x64_f8f6f4" in x for x in lines) == 64   # no second copy of the stage anywhere
