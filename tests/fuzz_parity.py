@@ -18,10 +18,12 @@ import ldtools as T  # noqa: E402
 import __graft_entry__ as ge  # noqa: E402
 
 
-def one_case(pkg, rng, idx):
+def one_case(pkg, rng, idx, wide_missing=False):
     n = int(rng.choice([33, 64, 100, 511, 512, 513, 1000, 1536, 2047, 2049, 3000, 5000, 9000]))
     m = int(rng.integers(40, 700 if n <= 3000 else 350))
     miss = float(rng.choice([0.0, 0.0, 0.0, 0.001, 0.003, 0.01, 0.05, 0.2]))
+    if wide_missing:
+        miss = float(rng.choice([0.01, 0.05, 0.2]))   # --wide-missing: every case on the missing-call kernels ...
     raw = T.synth_raw_codes(m, n, seed=int(rng.integers(1, 1 << 30)), missing_rate=miss)
     # sprinkle structure: copies with noise (LD), monomorphic rows, an all-missing row, rare variants
     for _ in range(m // 6):
@@ -53,6 +55,8 @@ def one_case(pkg, rng, idx):
     want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, window, step, is_bp, r2, order)
     eng = pkg.LdPruneEngine(n, window, step, is_bp, r2, order=order, device=0)
     wide = int(rng.choice([-1, -1, 0, 1, 3]))  # (drawn for every case, so that the sequence of cases stays the same)
+    if wide_missing:
+        wide = int(idx % 3)                        # ... over the tile plan (quarter tiles of the four-product form unless switched off below)
     if wide >= 0:
         eng.set_option("wide_min_reach", wide)  # send narrower bands through the 8 x 8 tile plan of the wide-band kernel too
     if idx % 3 == 2:
@@ -83,13 +87,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--wide-missing", action="store_true", help="every case has missing calls and takes the wide-band tile plan (pair_mfma_tile4_kernel)")
     args = ap.parse_args()
     pkg = ge.load_package()
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
     skipped_any = 0
     for k in range(args.cases):
-        ok, desc = one_case(pkg, rng, k)
+        ok, desc = one_case(pkg, rng, k, args.wide_missing)
         if "skipped=0.00" not in desc:
             skipped_any += 1
         if not ok:
