@@ -383,6 +383,14 @@ int ldp_pgen_provisional_ref(const ldp_pgen* p, uint8_t* bits, uint64_t bits_byt
  * (plink2_data.cc:2424-2566), so a caller that wants the reference's prune list must either refuse such files (plink2-hip
  * does) or supply dosage-based frequencies through ldp_set_maj_freqs(). */
 int ldp_pgen_has_dosage(const ldp_pgen* p);
+/* ... and whether this variant's record does; its two allele dosage sums over the samples of sample_mask (bit s of byte s >> 3;
+ * NULL = all), in the reference's units -- 16384 per ALT allele copy, so a diploid sample adds 32768 to ref + alt -- exactly
+ * as GetBasicGenotypeCountsAndDosage16s (pgenlib_read.cc:7917) forms them: a sample's dosage where it has one, its hardcall
+ * otherwise.  Also defined for records without a dosage track and for .bed rows (hardcalls only).  From these the reference's
+ * allele frequency is ref * (1 / (ref + alt)) (ComputeAlleleFreqs, plink2_filter.cc:2113-2153).  LDP_ERR_UNSUPPORTED for a
+ * multiallelic record. */
+int ldp_pgen_variant_has_dosage(const ldp_pgen* p, uint32_t variant);
+int ldp_pgen_dosage_sums(ldp_pgen* p, uint32_t variant, const uint8_t* sample_mask, uint64_t* ref_dosage, uint64_t* alt_dosage);
 /* fixed-width modes only: pointer to row 0 inside the file mapping (zero-copy), NULL for variable-width files */
 const void* ldp_pgen_direct_rows(const ldp_pgen* p, uint64_t* stride_bytes);
 /* For ldp_load_pgen_records(): the file's bytes (the reader's mapping) and the index entries of variants [first_variant, +n) --

@@ -94,7 +94,7 @@ CABI_SYMBOLS = [
     "ldp_run_with_stats", "ldp_pair_stats", "ldp_debug_set_variant_recs", "ldp_debug_replay_pairs", "ldp_debug_mfma_plan",
     "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
     "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_r2_unphased_hits", "ldp_r2_unphased_block", "ldp_r2_unphased_block_hits", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
-    "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_has_dosage", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
+    "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_has_dosage", "ldp_pgen_variant_has_dosage", "ldp_pgen_dosage_sums", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
     "ldp_pgen_variant_is_multiallelic", "ldp_pgen_provisional_ref", "ldp_pgen_open_indexed", "ldp_set_r_signed", "ldp_set_variants_vcor_cm", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_subset_samples", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
     "ldp_debug_set_option", "ldp_matrix_pipe_max_founders", "ldp_map_rows", "ldp_release_device", "ldp_debug_wide_plan",
     "ldp_allgather_removed", "ldp_comm_init_all", "ldp_comm_destroy", "ldp_load_pgen_records", "ldp_pgen_file_bytes", "ldp_pgen_record_index",
@@ -216,6 +216,8 @@ def lib():
     L.ldp_pgen_direct_rows.restype = ctypes.c_void_p
     L.ldp_pgen_read.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.c_uint32]
     L.ldp_pgen_variant_is_multiallelic.argtypes = [vp, ctypes.c_uint32]
+    L.ldp_pgen_variant_has_dosage.argtypes = [vp, ctypes.c_uint32]
+    L.ldp_pgen_dosage_sums.argtypes = [vp, ctypes.c_uint32, vp, u64p, u64p]
     L.ldp_phased_row_bytes.argtypes = [ctypes.c_uint32]
     L.ldp_phased_row_bytes.restype = ctypes.c_uint64
     L.ldp_phased_phase_offset.argtypes = [ctypes.c_uint32]
@@ -405,6 +407,25 @@ class PgenFile:
 
     def is_multiallelic(self, variant):
         return bool(self._L.ldp_pgen_variant_is_multiallelic(self._h, variant))
+
+    def has_dosage(self, variant=None):
+        """some record of the file (variant None) / this variant's record carries a dosage track"""
+        if variant is None:
+            return bool(self._L.ldp_pgen_has_dosage(self._h))
+        return bool(self._L.ldp_pgen_variant_has_dosage(self._h, variant))
+
+    def dosage_sums(self, variant, sample_mask=None):
+        """(ref, alt) allele dosage sums of a biallelic variant in the reference's units (16384 per ALT allele copy) over the
+        samples whose bit is set in sample_mask (bool array over the file's samples; None = all)"""
+        ref, alt = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        mask = None
+        if sample_mask is not None:
+            mask = np.packbits(np.asarray(sample_mask, dtype=bool), bitorder="little")
+        rc = self._L.ldp_pgen_dosage_sums(self._h, variant, mask.ctypes.data_as(ctypes.c_void_p) if mask is not None else None,
+                                          ctypes.byref(ref), ctypes.byref(alt))
+        if rc != LDP_OK:
+            raise LdpError(rc, self._L.ldp_pgen_last_error(self._h).decode())
+        return int(ref.value), int(alt.value)
 
     def close(self):
         if self._h:

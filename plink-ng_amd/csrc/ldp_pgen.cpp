@@ -399,9 +399,34 @@ int ldp_pgen_open_indexed(const char* path, const char* pgi_path, uint32_t sampl
     }
     return LDP_OK;
   }
+  if ((P->mode == 0x03) || (P->mode == 0x04)) {
+    // Fixed-width records with dosages (PgfiInitPhase1, pgenlib_read.cc:885-913): every record is the 2-bit hardcalls followed by
+    // one 16-bit dosage per sample (record type 0x40, "unconditional dosage") and, in mode 4, one 16-bit phased-dosage
+    // difference per sample (0xc0).  Represented here as a variable-width file whose records happen to have one length.
+    if (ctrl & 63) {
+      return pfail(P, LDP_ERR_INVALID, "fixed-width .pgen with a variable-width control byte.");
+    }
+    const uint64_t off = 12 + ((nonref_storage == 3) ? (static_cast<uint64_t>(P->variant_ct) + 7) / 8 : 0);
+    const uint64_t width = P->rec_bytes + static_cast<uint64_t>(P->sample_ct) * ((P->mode == 0x03) ? 2 : 4);
+    if ((nonref_storage == 3) && (P->size >= off)) {
+      memcpy(P->nonref_bits.data(), P->map + 12, P->nonref_bits.size());
+    }
+    if (P->size != off + width * P->variant_ct) {
+      return pfail(P, LDP_ERR_INVALID, "Unexpected .pgen file size (expected " + std::to_string(off + width * P->variant_ct) + " bytes).");
+    }
+    P->vrtype.assign(P->variant_ct, static_cast<uint8_t>((P->mode == 0x03) ? 0x40 : 0xc0));
+    P->fpos.resize(static_cast<size_t>(P->variant_ct) + 1);
+    for (uint64_t v = 0; v <= P->variant_ct; ++v) {
+      P->fpos[v] = off + v * width;
+    }
+    P->any_dosage = (P->variant_ct != 0);
+    P->file_mode = P->mode;
+    P->mode = 0x10;
+    return LDP_OK;
+  }
   if (P->mode != 0x10) {
-    char buf[160];
-    snprintf(buf, sizeof(buf), ".pgen storage mode 0x%02x is not supported (supported: 0x01 .bed, 0x02 fixed-width, 0x10 / 0x11 standard, 0x20 / 0x21 standard with an external index).", P->mode);
+    char buf[200];
+    snprintf(buf, sizeof(buf), ".pgen storage mode 0x%02x is not supported (supported: 0x01 .bed, 0x02-0x04 fixed-width, 0x10 / 0x11 standard, 0x20 / 0x21 standard with an external index).", P->mode);
     return pfail(P, LDP_ERR_UNSUPPORTED, buf);
   }
   // ---- standard variable-width header (pgen_spec.tex:160-235)
@@ -836,6 +861,163 @@ int ldp_pgen_read(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_row
 int ldp_pgen_read_phased(ldp_pgen* P, uint32_t first_variant, uint32_t n, void* out_rows, uint64_t stride_bytes,
                          const uint8_t* sample_mask, uint32_t threads, uint32_t* unphased_variant) {
   return read_impl(P, first_variant, n, out_rows, stride_bytes, threads, true, sample_mask, unphased_variant);
+}
+
+int ldp_pgen_variant_has_dosage(const ldp_pgen* P, uint32_t variant) {
+  if (!P || variant >= P->variant_ct || P->mode != 0x10) {
+    return 0;
+  }
+  return (P->vrtype[variant] & 0x60) ? 1 : 0;
+}
+
+// The two allele dosage sums of a biallelic variant over the samples of sample_mask, as GetBasicGenotypeCountsAndDosage16s
+// computes them (pgenlib_read.cc:7917-8190): a sample with a dosage contributes it (16384 per ALT copy, 32768 - that to REF),
+// any other sample its hardcall, a sample with neither nothing.
+int ldp_pgen_dosage_sums(ldp_pgen* P, uint32_t variant, const uint8_t* sample_mask, uint64_t* ref_dosage, uint64_t* alt_dosage) {
+  if (!P || !ref_dosage || !alt_dosage) {
+    return LDP_ERR_INVALID;
+  }
+  if (variant >= P->variant_ct) {
+    return pfail(P, LDP_ERR_INVALID, "variant index out of range");
+  }
+  const uint32_t n = P->sample_ct;
+  std::vector<uint8_t> row(P->rec_bytes + 8, 0);
+  const uint8_t* aux = nullptr;
+  uint32_t vrtype = 0;
+  if (P->mode == 0x01 || P->mode == 0x02) {
+    const int rc = ldp_pgen_read(P, variant, 1, row.data(), P->rec_bytes, 1);
+    if (rc) {
+      return rc;
+    }
+    if (P->mode == 0x01) {  // .bed -> pgen codes
+      static const uint8_t conv[4] = {2, 3, 1, 0};
+      for (uint32_t s = 0; s < n; ++s) {
+        set_code(row.data(), s, conv[(row[s >> 2] >> (2 * (s & 3))) & 3]);
+      }
+    }
+  } else {
+    vrtype = P->vrtype[variant];
+    if (vrtype & 8) {
+      return pfail(P, LDP_ERR_UNSUPPORTED, "dosage sums of a multiallelic record (the reference has none either: pgenlib_read.cc:8036)");
+    }
+    const uint32_t blk_first = (variant / kBlockVariants) * kBlockVariants;
+    uint32_t start = variant;
+    while (start > blk_first && ((P->vrtype[start] & 6) == 2)) {
+      --start;
+    }
+    std::vector<uint8_t> base(P->rec_bytes + 8, 0);
+    bool have_base = false;
+    for (uint32_t v = start; v <= variant; ++v) {
+      const bool is_ld = ((P->vrtype[v] & 6) == 2);
+      if (v < variant && is_ld) {
+        continue;
+      }
+      if (!decode_record(P, v, have_base ? base.data() : nullptr, row.data(), (v == variant) ? &aux : nullptr)) {
+        return pfail(P, LDP_ERR_INVALID, "malformed variant record in .pgen file");
+      }
+      if (!is_ld) {
+        memcpy(base.data(), row.data(), P->rec_bytes);
+        have_base = true;
+      }
+    }
+  }
+  auto in_mask = [&](uint32_t s) { return (!sample_mask) || ((sample_mask[s >> 3] >> (s & 7)) & 1); };
+  auto code_of = [&](uint32_t s) { return (row[s >> 2] >> (2 * (s & 3))) & 3u; };
+  // hardcall counts of the subset; of the raw file (the phase track's length is a function of every sample's het calls)
+  uint64_t geno[4] = {0, 0, 0, 0};
+  uint32_t raw_het_ct = 0;
+  for (uint32_t s = 0; s < n; ++s) {
+    const uint32_t c = code_of(s);
+    raw_het_ct += (c == 1) ? 1u : 0u;
+    if (in_mask(s)) {
+      ++geno[c];
+    }
+  }
+  uint64_t alt = 0, dosage_ct = 0;
+  uint64_t replaced[4] = {0, 0, 0, 0};
+  if (vrtype & 0x60) {
+    Cursor c{aux, P->map + P->fpos[variant + 1]};
+    if (vrtype & 0x10) {
+      // the phase track (aux 2, pgen_spec.tex:541-562) sits in front: 1 + het_ct bits, then -- when bit 0 says the phase of some
+      // het calls is absent -- one phaseinfo bit per het call that has one
+      const uint64_t first = 1 + raw_het_ct / 8;
+      if (static_cast<uint64_t>(c.end - c.p) < first) {
+        return pfail(P, LDP_ERR_INVALID, "truncated phase track");
+      }
+      uint64_t skip = first;
+      if (c.p[0] & 1) {
+        uint32_t present = 0;
+        for (uint64_t b = 0; b < first; ++b) {
+          present += static_cast<uint32_t>(__builtin_popcount(c.p[b]));
+        }
+        skip += (present - 1 + 7) / 8;
+      }
+      if (!c.skip(skip)) {
+        return pfail(P, LDP_ERR_INVALID, "truncated phase track");
+      }
+    }
+    if ((vrtype & 0x60) == 0x40) {
+      // one value per sample, 65535 = none (and then no hardcall either: pgen_spec.tex:601-604)
+      const uint8_t* vals = c.p;
+      if (!c.skip(2ull * n)) {
+        return pfail(P, LDP_ERR_INVALID, "truncated dosage track");
+      }
+      for (uint32_t s = 0; s < n; ++s) {
+        if (!in_mask(s)) {
+          continue;
+        }
+        uint16_t d;
+        memcpy(&d, vals + 2ull * s, 2);
+        if (d != 65535) {
+          alt += d;
+          ++dosage_ct;
+        }
+      }
+      // (every called sample has a dosage: the hardcalls are all replaced)
+      for (int q = 0; q < 3; ++q) {
+        replaced[q] = geno[q];
+      }
+    } else {
+      std::vector<uint32_t> ids;  // track 3: who has a dosage (pgen_spec.tex:598-606) -- a list of sample ids or a bit per sample
+      if ((vrtype & 0x60) == 0x20) {
+        if (!read_id_difflist(c, n, &ids)) {
+          return pfail(P, LDP_ERR_INVALID, "malformed dosage list");
+        }
+      } else {
+        const uint8_t* bits = c.p;
+        if (!c.skip((static_cast<uint64_t>(n) + 7) / 8)) {
+          return pfail(P, LDP_ERR_INVALID, "truncated dosage track");
+        }
+        for (uint32_t s = 0; s < n; ++s) {
+          if ((bits[s >> 3] >> (s & 7)) & 1) {
+            ids.push_back(s);
+          }
+        }
+      }
+      const uint8_t* vals = c.p;
+      if (!c.skip(2ull * ids.size())) {
+        return pfail(P, LDP_ERR_INVALID, "truncated dosage track");
+      }
+      for (size_t k = 0; k < ids.size(); ++k) {
+        const uint32_t s = ids[k];
+        if (!in_mask(s)) {
+          continue;
+        }
+        uint16_t d;
+        memcpy(&d, vals + 2 * k, 2);
+        alt += d;
+        ++dosage_ct;
+        ++replaced[code_of(s)];
+      }
+    }
+  }
+  const uint64_t replaced_ct = replaced[0] + replaced[1] + replaced[2];
+  const uint64_t remaining_het = geno[1] - replaced[1], remaining_homalt = geno[2] - replaced[2];
+  alt += (2 * remaining_homalt + remaining_het) * 16384ull;
+  const uint64_t nondosage_nm = (geno[0] + geno[1] + geno[2]) - replaced_ct;
+  *alt_dosage = alt;
+  *ref_dosage = (dosage_ct + nondosage_nm) * 32768ull - alt;
+  return LDP_OK;
 }
 
 int ldp_pgen_variant_is_multiallelic(const ldp_pgen* P, uint32_t variant) {

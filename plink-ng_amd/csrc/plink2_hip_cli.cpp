@@ -3236,6 +3236,7 @@ struct Session {
   std::string gpath;
   ldp_pgen* pg = nullptr;
   int storage_mode = 0, encoding = LDP_GENO_REF, has_multiallelic = 0;
+  bool has_dosage = false;  // some record carries a dosage track: --indep-pairwise takes the allele frequencies from them
   uint64_t rec_bytes = 0;
   const uint8_t* direct_rows = nullptr;  // NULL for variable-width files
   std::vector<uint32_t> inc;             // raw index of every included variant
@@ -3384,11 +3385,17 @@ void load_inputs(Session& S, int argc, char** argv) {
     die(6, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
   }
   ldp_pgen_info(pg, nullptr, nullptr, &S.storage_mode, &S.encoding, &S.has_multiallelic);
-  if (ldp_pgen_has_dosage(pg)) {
-    // The reference takes allele frequencies (major allele, tie-break of the prune; the r^2 of dosage data) from the dosages
-    // when a file has them; this front-end reads hardcalls only and would silently write a different list.
-    ldp_pgen_close(pg);
-    die(63, "Error: %s holds dosage data, which plink2-hip does not read yet (allele frequencies and r^2 would be\ncomputed from hardcalls only, unlike plink2).  Use plink2 --make-pgen erase-dosage first.\n", gpath.c_str());
+  S.has_dosage = ldp_pgen_has_dosage(pg) != 0;
+  if (S.has_dosage) {
+    // The reference takes allele frequencies from the dosages when a file has them (plink2_data.cc:2421-2443).  For
+    // --indep-pairwise that is the major allele's frequency in the tie-break -- r^2 itself is computed from the hardcalls
+    // (plink2_ld.cc:699-723) --, which run_prune() reproduces (ldp_pgen_dosage_sums).  Everything else that would read dosages
+    // (the r^2 of --r2-unphased / --clump, phased dosages, frequency filters) is refused rather than computed from hardcalls.
+    const char* what = A.have_r2 ? "--r2-unphased / --clump" : (A.pairphase ? "--indep-pairphase" : (((A.min_maf != 0.0) || (A.max_maf != 1.0)) ? "--maf / --max-maf" : nullptr));
+    if (what) {
+      ldp_pgen_close(pg);
+      die(63, "Error: %s holds dosage data, which plink2-hip reads for --indep-pairwise only (%s would be\ncomputed from hardcalls, unlike plink2).  Use plink2 --make-pgen erase-dosage first.\n", gpath.c_str(), what);
+    }
   }
   S.rec_bytes = (static_cast<uint64_t>(raw_sample_ct) + 3) / 4;
   S.direct_rows = static_cast<const uint8_t*>(ldp_pgen_direct_rows(pg, &S.rec_bytes));  // NULL for variable-width
@@ -4929,6 +4936,16 @@ int run_prune(Session& S) {
     if (duplicate_ids) {  // plink2_ld.cc:2590-2592
       die(7, "Error: --indep-pair%s requires unique variant IDs. (--set-all-var-ids and/or --rm-dup may help.)\n", A.pairphase ? "phase" : "wise");
     }
+    if (S.has_dosage) {
+      // chrX / chrY / MT: the reference's dosage-aware counts weigh males and females differently there (plink2_data.cc:2467-2620)
+      for (const std::vector<uint32_t>* ks : {&xk, &yk, &tk}) {
+        for (uint32_t k : *ks) {
+          if (ldp_pgen_variant_has_dosage(pg, inc[k])) {
+            die(63, "Error: variant '%s' on a sex chromosome or chrM has dosages, which plink2-hip reads on the autosomes only.\n", V.id[inc[k]].c_str());
+          }
+        }
+      }
+    }
     std::vector<uint64_t> preferred;
     if (!A.preferred.empty()) {
       std::unordered_set<std::string> want;
@@ -5234,6 +5251,64 @@ int run_prune(Session& S) {
         if ((multi_ct || mt_ct || multi_skipped || multi_device) && A.timing) {
           logprintf("\n[timing] host-built rows: %u multiallelic (%u more have REF as the major allele: main track as loaded; %u collapsed on the device), %u MT\n",
                     multi_ct, multi_skipped, multi_device, mt_ct);
+        }
+      }
+      // Variants whose records carry dosages: the major allele's frequency comes from the founders' dosage sums (a sample's
+      // dosage where it has one, its hardcall otherwise: ldp_pgen_dosage_sums), in ComputeAlleleFreqs' arithmetic
+      // (plink2_filter.cc:2137-2147: ref * (1 / (ref + alt)); the factor 2 of the diploid case cancels exactly) with
+      // GetMajIdx's rule (REF unless its frequency is below 0.5).  The rows themselves stay the hardcalls.
+      if (S.has_dosage) {
+        std::vector<uint32_t> todo;
+        for (uint32_t qq = 0; qq < m_ct; ++qq) {
+          const uint32_t raw_v = inc[mk[qq]];
+          if (!ldp_pgen_variant_has_dosage(pg, raw_v)) {
+            continue;
+          }
+          if ((V.alt_ct[raw_v] > 1) || (vcls[mk[qq]] == 5)) {
+            die(63, "\nError: variant '%s' has dosages and %s, which plink2-hip does not read yet.\n", V.id[raw_v].c_str(),
+                (vcls[mk[qq]] == 5) ? "lies on chrM" : "several ALT alleles");
+          }
+          todo.push_back(qq);
+        }
+        std::vector<double> mfs(todo.size(), 0.0);
+        std::atomic<uint32_t> next(0);
+        std::atomic<int> bad(0);
+        const uint8_t* mask = all_founders ? nullptr : founder_mask.data();
+        auto worker = [&]() {
+          for (uint32_t t = next.fetch_add(64); (t < todo.size()) && !bad.load(); t = next.fetch_add(64)) {
+            for (uint32_t q = t; q < std::min<size_t>(todo.size(), t + 64); ++q) {
+              uint64_t ref_dd = 0, alt_dd = 0;
+              if (ldp_pgen_dosage_sums(pg, inc[mk[todo[q]]], mask, &ref_dd, &alt_dd)) {
+                bad.store(1);
+                return;
+              }
+              const uint64_t tot = ref_dd + alt_dd;
+              const double ref_freq = tot ? (static_cast<double>(static_cast<int64_t>(ref_dd)) * (1.0 / static_cast<double>(static_cast<int64_t>(tot)))) : 0.5;
+              mfs[q] = (ref_freq < 0.5) ? (1.0 - ref_freq) : ref_freq;
+            }
+          }
+        };
+        const uint32_t nthreads = std::max<uint32_t>(1, std::min<uint32_t>({32u, std::thread::hardware_concurrency(), static_cast<uint32_t>((todo.size() + 63) / 64)}));
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < nthreads; ++t) {
+          pool.emplace_back(worker);
+        }
+        worker();
+        for (std::thread& t : pool) {
+          t.join();
+        }
+        if (bad.load()) {
+          die(6, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+        }
+        for (size_t q = 0; q < todo.size(); ++q) {
+          for (int r = 0; r < world; ++r) {
+            if (ldp_set_maj_freqs(eng[r], todo[q], 1, &mfs[q])) {
+              die(16, "\nError: %s\n", ldp_last_error(eng[r]));
+            }
+          }
+        }
+        if (A.timing) {
+          logprintf("\n[timing] allele frequencies of %zu variants from their dosages\n", todo.size());
         }
       }
       t_load1 = now_s();

@@ -355,8 +355,14 @@ def phased_pgen_records(raw_codes, phaseinfo):
 def write_pgen_phased(prefix, raw_codes, phaseinfo, chroms, bps, ids=None, sexes=None, parents=None):
     """Standard variable-width .pgen (storage mode 0x10, 8-bit record types, 3-byte record lengths;
     pgen_spec.tex:160-235) whose records carry the hardcall-phase track, + .pvar + .psam."""
-    m, n = raw_codes.shape
     records, vrtypes = phased_pgen_records(raw_codes, phaseinfo)
+    return write_pgen_records(prefix, records, vrtypes, raw_codes.shape[1], chroms, bps, ids, sexes, parents)
+
+
+def write_pgen_records(prefix, records, vrtypes, n, chroms, bps, ids=None, sexes=None, parents=None):
+    """... from ready-made record bytes and their 8-bit record types."""
+    m = len(records)
+    vrtypes = np.asarray(vrtypes, dtype=np.uint8)
     blocks = (m + 65535) // 65536
     header_len = 12 + 8 * blocks + sum(min(65536, m - b * 65536) * 4 for b in range(blocks))
     with open(prefix + ".pgen", "wb") as f:

@@ -374,24 +374,77 @@ def test_cli_two_gpus_match_one(gpu_pkg, cli, tmp_path):
         assert filecmp.cmp(str(tmp_path / ("one" + ext)), str(tmp_path / ("two" + ext)), shallow=False)
 
 
-def test_cli_refuses_dosage_pgen(cli, tmp_path):
+def dummy_dosage_fileset(tmp_path, name, n, m, freq, seed):
+    """a fileset with dosage tracks written by the reference itself"""
+    cp = T.run_ref(["--dummy", str(n), str(m), "dosage-freq=%g" % freq, "--seed", str(seed), "--threads", "2", "--make-pgen", "--out", name], str(tmp_path))
+    assert cp.returncode == 0, cp.stdout
+
+
+def test_cli_dosage_pgen_rules(cli, pkg, tmp_path):
     """A .pgen with dosage tracks: the reference derives allele frequencies (major allele, prune tie-break) from the dosages
-    (plink2_data.cc:2424-2566); plink2-hip reads hardcalls only, so it must refuse instead of writing a different list."""
-    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "plink2")
-    if not os.path.exists(ref):
+    (plink2_data.cc:2421-2443).  --indep-pairwise reproduces that (ldp_pgen_dosage_sums); what would need dosages elsewhere -- the
+    r^2 of --r2-unphased / --clump, phased dosages, frequency filters -- is refused instead of being computed from hardcalls."""
+    if not T.have_ref():
         pytest.skip("oracle/_ref/plink2 not built")
-    cp = subprocess.run([ref, "--dummy", "60", "200", "dosage-freq=0.3", "--seed", "3", "--threads", "2", "--make-pgen", "--out", "dos"], cwd=str(tmp_path),
-                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
-    assert cp.returncode == 0, cp.stdout
-    out = run_cli(cli, ["--pfile", "dos", "--indep-pairwise", "50", "5", "0.2", "--out", "o"], str(tmp_path))
-    assert out.returncode == 63 and "dosage" in out.stdout
+    dummy_dosage_fileset(tmp_path, "dos", 60, 200, 0.3, 3)
+    for args in (["--r2-unphased", "--ld-window-r2", "0.2"], ["--indep-pairphase", "50", "5", "0.2"], ["--indep-pairwise", "50", "5", "0.2", "--maf", "0.05"]):
+        out = run_cli(cli, ["--pfile", "dos"] + args + ["--out", "o"], str(tmp_path))
+        assert out.returncode == 63 and "dosage" in out.stdout, out.stdout
     assert not os.path.exists(str(tmp_path / "o.prune.in"))
-    # without the dosages the same data is accepted (up to the point where a GPU is needed)
-    cp = subprocess.run([ref, "--pfile", "dos", "--make-pgen", "erase-dosage", "--out", "hard"], cwd=str(tmp_path),
-                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
-    assert cp.returncode == 0, cp.stdout
-    out = run_cli(cli, ["--pfile", "hard", "--indep-pairwise", "50", "5", "0.2", "--dry-run", "--out", "o"], str(tmp_path))
+    out = run_cli(cli, ["--pfile", "dos", "--indep-pairwise", "50", "5", "0.2", "--dry-run", "--out", "o"], str(tmp_path))
     assert out.returncode == 0, out.stdout
+    if pkg.device_count() == 0:   # the prune itself gets as far as the device
+        out = run_cli(cli, ["--pfile", "dos", "--indep-pairwise", "50", "5", "0.2", "--out", "o"], str(tmp_path))
+        assert out.returncode == 16 and "no usable HIP device" in out.stdout
+    # the reader's sums over the reference's own records (dosage lists, bit arrays) against its --freq
+    f = pkg.PgenFile(str(tmp_path / "dos.pgen"))
+    assert f.has_dosage()
+    cp = T.run_ref(["--pfile", "dos", "--freq", "--out", "fr"], str(tmp_path))
+    assert cp.returncode == 0, cp.stdout
+    rows = [ln.split() for ln in open(str(tmp_path / "fr.afreq")) if not ln.startswith("#")]
+    with_track = 0
+    for v in range(f.variant_ct):
+        ref_dd, alt_dd = f.dosage_sums(v)
+        with_track += f.has_dosage(v)
+        x = alt_dd / (ref_dd + alt_dd)
+        assert int(rows[v][5]) == (ref_dd + alt_dd) // 16384
+        assert abs(float(rows[v][4]) - x) <= (0.6 * 10.0 ** (np.floor(np.log10(x)) - 5) if x else 0.0), (v, rows[v], x)
+    assert with_track > 100
+    f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("freq,order,wargs,nonfounders", [(0.3, 2, ["60", "4"], 0), (0.95, 1, ["200kb"], 0), (0.05, 2, ["100", "1"], 9)])
+def test_cli_dosage_frequencies_match_reference(gpu_pkg, cli, tmp_path, freq, order, wargs, nonfounders):
+    """--indep-pairwise on files with dosage tracks: r^2 from the hardcalls, the tie-break's allele frequencies from the dosages --
+    byte-identical lists.  Random genotypes at a low threshold: a third of the variants go, and which one of a pair goes is decided
+    by frequencies that differ between hardcalls and dosages in the second digit."""
+    assert T.have_ref(), "reference binary oracle/_ref/plink2 must travel with the repo snapshot"
+    dummy_dosage_fileset(tmp_path, "dos", 130, 1500, freq, int(100 * freq) + order)
+    if nonfounders:
+        # (--dummy writes "#IID SEX PHENO1": give a few samples parents, so that the founders are a subset of the file's samples)
+        lines = open(str(tmp_path / "dos.psam")).read().splitlines()
+        assert lines[0].split("\t") == ["#IID", "SEX", "PHENO1"]
+        out = ["#IID\tPAT\tMAT\tSEX\tPHENO1"]
+        for k, ln in enumerate(lines[1:]):
+            iid, sex, ph = ln.split("\t")
+            out.append("\t".join([iid] + (["per0", "per1"] if (3 <= k < 3 + nonfounders) else ["0", "0"]) + [sex, ph]))
+        open(str(tmp_path / "dos.psam"), "w").write("\n".join(out) + "\n")
+    common = ["--pfile", "dos", "--indep-pairwise"] + wargs + ["0.03"] + (["--indep-order", "1"] if order == 1 else [])
+    ref = T.run_ref(common + ["--threads", "4", "--out", "ref"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    got = run_cli(cli, common + ["--out", "hip"], str(tmp_path))
+    assert got.returncode == 0, got.stdout
+    assert filecmp.cmp(str(tmp_path / "ref.prune.in"), str(tmp_path / "hip.prune.in"), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "ref.prune.out"), str(tmp_path / "hip.prune.out"), shallow=False)
+    assert re.findall(r"\d+/\d+ variants removed\.", ref.stdout)[-1] in got.stdout
+    # ... and the dosages matter: the hardcalls of the same file give another list
+    hard = T.run_ref(["--pfile", "dos", "--make-pgen", "erase-dosage", "--out", "hard"], str(tmp_path))
+    assert hard.returncode == 0, hard.stdout
+    ref2 = T.run_ref(["--pfile", "hard", "--indep-pairwise"] + wargs + ["0.03"] + (["--indep-order", "1"] if order == 1 else []) + ["--threads", "4", "--out", "ref2"], str(tmp_path))
+    assert ref2.returncode == 0, ref2.stdout
+    if freq >= 0.3:
+        assert not filecmp.cmp(str(tmp_path / "ref.prune.in"), str(tmp_path / "ref2.prune.in"), shallow=False)
 
 
 def test_make_founders_counts_match_reference(cli, tmp_path):

@@ -175,10 +175,14 @@ def test_malformed_files_are_rejected(pkg, tmp_path):
     open(bad, "wb").write(src[:2] + bytes([0x21]) + src[3:])  # external-index mode without its index
     with pytest.raises(pkg.LdpError):
         pkg.PgenFile(bad)
-    open(bad, "wb").write(src[:2] + bytes([0x03]) + src[3:])  # fixed-width dosage: unsupported
+    open(bad, "wb").write(src[:2] + bytes([0x05]) + src[3:])  # no such storage mode
     with pytest.raises(pkg.LdpError) as ei:
         pkg.PgenFile(bad)
     assert ei.value.code == pkg.LDP_ERR_UNSUPPORTED
+    open(bad, "wb").write(src[:2] + bytes([0x03]) + src[3:])  # fixed-width dosage mode over a variable-width header
+    with pytest.raises(pkg.LdpError) as ei:
+        pkg.PgenFile(bad)
+    assert ei.value.code == pkg.LDP_ERR_INVALID
     open(bad, "wb").write(b"\x00\x01\x02")
     with pytest.raises(pkg.LdpError):
         pkg.PgenFile(bad)
