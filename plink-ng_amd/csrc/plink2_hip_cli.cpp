@@ -17,7 +17,7 @@
 // inter-chr .vcor table with cols=, --ld-window, --ld-window-kb, --ld-window-cm, --ld-window-r2, --ld-snp / --ld-snps / --ld-snp-list,
 // --parallel; number formatting restated from dtoa_g.  --clump (several reports, --clump-allow-overlap, cols=, bins, -log10,
 // ranges, sex chromosomes).
-// Not yet supported (reported as such with exit 63, never silently mis-handled): dosage tracks,
+// Not yet supported (reported as such with exit 63, never silently mis-handled): dosage data outside --indep-pairwise on the autosomes,
 // more than 254 ALT alleles, multiallelic sites on chrX/Y/MT and in --clump, major-allele-oriented r^2 outputs on chrY/MT.
 #include <dlfcn.h>
 #include <sys/mman.h>

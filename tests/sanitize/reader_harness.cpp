@@ -56,6 +56,18 @@ int main(int argc, char** argv) {
         ldp_pgen_read_alleles_phased(pg, v, alts, lo.data(), hi.data(), pp.data(), pi.data());
       }
     }
+    // dosage tracks: sums over everybody and over a subset
+    {
+      std::vector<uint8_t> third((n + 7) / 8, 0);
+      for (uint32_t s = 0; s < n; s += 3) third[s >> 3] |= 1u << (s & 7);
+      uint64_t rd = 0, ad = 0, with_track = 0, failed = 0;
+      for (uint32_t v = 0; v < m; ++v) {
+        with_track += ldp_pgen_variant_has_dosage(pg, v);
+        failed += ldp_pgen_dosage_sums(pg, v, nullptr, &rd, &ad) != 0;
+        failed += ldp_pgen_dosage_sums(pg, v, third.data(), &rd, &ad) != 0;
+      }
+      printf("dosage: file %d, records with a track %llu, failed calls %llu\n", ldp_pgen_has_dosage(pg), (unsigned long long)with_track, (unsigned long long)failed);
+    }
     // subset
     std::vector<uint8_t> keep((n + 7) / 8, 0);
     uint32_t kept = 0;

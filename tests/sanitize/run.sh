@@ -1,6 +1,6 @@
 #!/bin/bash
 # AddressSanitizer + UndefinedBehaviorSanitizer over the host-side file reader (ldp_pgen.cpp: main track, phase track,
-# multiallelic + phase, sample subsetting) on every committed golden .pgen, and over plink2-hip's host-only paths
+# multiallelic + phase, dosage tracks, sample subsetting) on every committed golden .pgen, and over plink2-hip's host-only paths
 # (the .vcor number formatter, the zstd output stream), and over the engine's host logic.  No GPU involved.
 #   bash tests/sanitize/run.sh
 set -eu
@@ -11,15 +11,15 @@ SAN="-std=c++17 -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -fno
 g++ $SAN -I"$R/include" -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ "$R/tests/sanitize/reader_harness.cpp" "$R/tests/sanitize/geometry_stub.cpp" \
     "$R/plink-ng_amd/csrc/ldp_pgen.cpp" -o "$T/reader" -lpthread
 G="$R/tests/golden/pgen"
-"$T/reader" "$G/varwidth_small.pgen" 1 "$G/phased_small.pgen" 1 "$G/phased_partial.pgen" 1 "$G/phased_multi.pgen" 4 "$G/phased_multi_partial.pgen" 4
+"$T/reader" "$G/varwidth_small.pgen" 1 "$G/phased_small.pgen" 1 "$G/phased_partial.pgen" 1 "$G/phased_multi.pgen" 4 "$G/phased_multi_partial.pgen" 4 "$G/dosage_small.pgen" 1
 LDP_PGEN_NO_BMI2=1 "$T/reader" "$G/phased_partial.pgen" 1 "$G/phased_multi.pgen" 4 > /dev/null
 # malformed input: byte flips / truncation of the golden files must end in an error code, never in a sanitizer report
 python3 - "$T" "$G" <<'PY'
 import sys, subprocess, numpy as np
 T, G = sys.argv[1], sys.argv[2]
 rng = np.random.default_rng(1)
-files = [("varwidth_small.pgen", 1), ("phased_small.pgen", 1), ("phased_multi.pgen", 4), ("phased_multi_partial.pgen", 4)]
-for it in range(120):
+files = [("varwidth_small.pgen", 1), ("phased_small.pgen", 1), ("phased_multi.pgen", 4), ("phased_multi_partial.pgen", 4), ("dosage_small.pgen", 1)]
+for it in range(150):
     name, alts = files[it % len(files)]
     data = bytearray(open(G + "/" + name, "rb").read())
     kind = int(rng.integers(0, 3))
@@ -31,7 +31,7 @@ for it in range(120):
     open(T + "/mut.pgen", "wb").write(data)
     r = subprocess.run([T + "/reader", T + "/mut.pgen", str(alts)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert r.returncode in (0, 1) and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (it, name, kind, r.stderr[-800:])
-print("reader on 120 corrupted files: errors only, no sanitizer report")
+print("reader on 150 corrupted files: errors only, no sanitizer report")
 PY
 if [ -f "$R/plink-ng_amd/lib/libldprune_hip.so" ]; then
   g++ $SAN -I/opt/rocm/include "$R/plink-ng_amd/csrc/plink2_hip_cli.cpp" -o "$T/cli" -L"$R/plink-ng_amd/lib" -lldprune_hip -Wl,-rpath,"$R/plink-ng_amd/lib" -lpthread -ldl

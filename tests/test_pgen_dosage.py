@@ -244,3 +244,33 @@ def test_oracle_prune_with_dosage_frequencies_reproduces_the_reference(pkg, tmp_
     if freq >= 0.3:
         hard, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf_hard, window, step, is_bp, 0.03, order)
         assert not np.array_equal(hard, want)
+
+
+def test_golden_dosage_file(pkg):
+    """tests/golden/pgen/dosage_small.*: a file the reference's --dummy wrote, its --freq and two of its --indep-pairwise lists
+    (tests/golden/make_golden_dosage.py) -- pins the dosage reader and the frequency arithmetic where the reference binary is absent."""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pgen")
+    g = np.load(os.path.join(gold, "dosage_small.npz"))
+    n, m = int(g["n"]), int(g["m"])
+    f = pkg.PgenFile(os.path.join(gold, "dosage_small.pgen"))
+    assert (f.variant_ct, f.sample_ct) == (m, n) and f.has_dosage()
+    rows = f.read()
+    pad = (-rows.shape[1]) % 8
+    raw = T.unpack_2bit(np.ascontiguousarray(np.pad(rows, ((0, 0), (0, pad)))).view(np.uint64), n)
+    mf = np.zeros(m)
+    kinds = set()
+    for v in range(m):
+        ref_dd, alt_dd = f.dosage_sums(v)
+        tot = ref_dd + alt_dd
+        assert tot // 16384 == int(g["obs_ct"][v]) and freq_agrees(str(g["alt_freq_text"][v]), alt_dd / tot)
+        ref_freq = float(ref_dd) * (1.0 / float(tot))
+        mf[v] = (1.0 - ref_freq) if ref_freq < 0.5 else ref_freq
+        kinds.add(int(f.record_index(v, 1)[0][0].vrtype) & 0x60)
+    assert {0x20, 0x60} <= kinds   # dosage lists and bit arrays both occur
+    f.close()
+    inv, _, _ = T.oracle_prepare(raw)
+    chr_idx, bps = np.zeros(m, dtype=np.uint32), np.arange(m, dtype=np.uint32)
+    got, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 50, 5, False, 0.3, 2)
+    assert np.array_equal(got, g["removed_count_o2"])
+    got, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 30000, 1, True, 0.45, 1)
+    assert np.array_equal(got, g["removed_kb_o1"])
