@@ -3237,6 +3237,10 @@ struct Session {
   ldp_pgen* pg = nullptr;
   int storage_mode = 0, encoding = LDP_GENO_REF, has_multiallelic = 0;
   bool has_dosage = false;  // some record carries a dosage track: --indep-pairwise takes the allele frequencies from them
+  // founders' (ref, alt) dosage sums of the variants that have a dosage track (ldp_pgen_dosage_sums), computed once: the
+  // frequency filters and the prune's tie-break both want them
+  std::unordered_map<uint32_t, std::pair<uint64_t, uint64_t>> dosage_sums;
+  void need_dosage_sums(const std::vector<uint32_t>& raw_variants);
   uint64_t rec_bytes = 0;
   const uint8_t* direct_rows = nullptr;  // NULL for variable-width files
   std::vector<uint32_t> inc;             // raw index of every included variant
@@ -3389,9 +3393,10 @@ void load_inputs(Session& S, int argc, char** argv) {
   if (S.has_dosage) {
     // The reference takes allele frequencies from the dosages when a file has them (plink2_data.cc:2421-2443).  For
     // --indep-pairwise that is the major allele's frequency in the tie-break -- r^2 itself is computed from the hardcalls
-    // (plink2_ld.cc:699-723) --, which run_prune() reproduces (ldp_pgen_dosage_sums).  Everything else that would read dosages
-    // (the r^2 of --r2-unphased / --clump, phased dosages, frequency filters) is refused rather than computed from hardcalls.
-    const char* what = A.have_r2 ? "--r2-unphased / --clump" : (A.pairphase ? "--indep-pairphase" : (((A.min_maf != 0.0) || (A.max_maf != 1.0)) ? "--maf / --max-maf" : nullptr));
+    // (plink2_ld.cc:699-723) --, which run_prune() reproduces (ldp_pgen_dosage_sums); --maf / --max-maf compare the same
+    // frequencies.  Everything else that would read dosages (the r^2 of --r2-unphased / --clump, phased dosages) is refused
+    // rather than computed from hardcalls.
+    const char* what = A.have_r2 ? "--r2-unphased / --clump" : (A.pairphase ? "--indep-pairphase" : nullptr);
     if (what) {
       ldp_pgen_close(pg);
       die(63, "Error: %s holds dosage data, which plink2-hip reads for --indep-pairwise only (%s would be\ncomputed from hardcalls, unlike plink2).  Use plink2 --make-pgen erase-dosage first.\n", gpath.c_str(), what);
@@ -3513,6 +3518,15 @@ void load_inputs(Session& S, int argc, char** argv) {
         q0 += run;
       }
     }
+    if (S.has_dosage && ((A.min_maf != 0.0) || (A.max_maf != 1.0))) {
+      std::vector<uint32_t> with_track;
+      for (uint32_t v : todo) {
+        if (ldp_pgen_variant_has_dosage(pg, v)) {
+          with_track.push_back(v);
+        }
+      }
+      S.need_dosage_sums(with_track);
+    }
     drop_by_counts.assign(raw_variant_ct, 0);
     uint32_t geno_removed = 0, freq_removed = 0;
     const uint32_t missing_max = static_cast<uint32_t>(static_cast<int32_t>(A.geno * (1 + kSmallEpsilon) * static_cast<double>(kept_samples)));
@@ -3525,7 +3539,13 @@ void load_inputs(Session& S, int argc, char** argv) {
         continue;
       }
       if ((A.min_maf != 0.0) || (A.max_maf != 1.0)) {
-        const uint64_t ref_ct = 2ull * c.ref2 + c.het, alt_ct = 2ull * c.alt2 + c.het, tot = ref_ct + alt_ct;
+        uint64_t ref_ct = 2ull * c.ref2 + c.het, alt_ct = 2ull * c.alt2 + c.het;
+        const auto dd = S.dosage_sums.find(todo[q]);
+        if (dd != S.dosage_sums.end()) {  // a record with dosages: the founders' dosage sums (units cancel: both are scaled by 16384)
+          ref_ct = dd->second.first;
+          alt_ct = dd->second.second;
+        }
+        const uint64_t tot = ref_ct + alt_ct;
         const double ref_freq = tot ? (static_cast<double>(ref_ct) * (1.0 / static_cast<double>(tot))) : 0.5;  // plink2_filter.cc:2137-2147
         const double nonref_freq = 1.0 - ref_freq;
         const double typed = (nonref_freq < ref_freq) ? nonref_freq : ref_freq;  // GetTypedFreq, nonmajor mode, two alleles (:3715-3723)
@@ -4816,6 +4836,53 @@ int run_r2(Session& S) {
 }
 
 // ---- --indep-pairwise / --indep-pairphase ----
+void Session::need_dosage_sums(const std::vector<uint32_t>& raw_variants) {
+  std::vector<uint32_t> todo;
+  for (uint32_t v : raw_variants) {
+    if (!dosage_sums.count(v)) {
+      todo.push_back(v);
+    }
+  }
+  if (todo.empty()) {
+    return;
+  }
+  std::vector<uint8_t> founder_mask((static_cast<size_t>(raw_sample_ct) + 7) / 8, 0);
+  for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+    if (is_founder[sx]) {
+      founder_mask[sx >> 3] |= static_cast<uint8_t>(1u << (sx & 7));
+    }
+  }
+  const uint8_t* mask = (founder_ct == raw_sample_ct) ? nullptr : founder_mask.data();
+  std::vector<std::pair<uint64_t, uint64_t>> out(todo.size());
+  std::atomic<uint32_t> next(0);
+  std::atomic<int> bad(0);
+  auto worker = [&]() {
+    for (uint32_t t = next.fetch_add(64); (t < todo.size()) && !bad.load(); t = next.fetch_add(64)) {
+      for (uint32_t q = t; q < std::min<size_t>(todo.size(), t + 64); ++q) {
+        if (ldp_pgen_dosage_sums(pg, todo[q], mask, &out[q].first, &out[q].second)) {
+          bad.store(1);
+          return;
+        }
+      }
+    }
+  };
+  const uint32_t nthreads = std::max<uint32_t>(1, std::min<uint32_t>({32u, std::thread::hardware_concurrency(), static_cast<uint32_t>((todo.size() + 63) / 64)}));
+  std::vector<std::thread> pool;
+  for (uint32_t t = 1; t < nthreads; ++t) {
+    pool.emplace_back(worker);
+  }
+  worker();
+  for (std::thread& t : pool) {
+    t.join();
+  }
+  if (bad.load()) {
+    die(6, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+  }
+  for (size_t q = 0; q < todo.size(); ++q) {
+    dosage_sums[todo[q]] = out[q];
+  }
+}
+
 int run_prune(Session& S) {
   const Args& A = S.A;
   const Variants& V = S.V;
@@ -5271,34 +5338,18 @@ int run_prune(Session& S) {
           todo.push_back(qq);
         }
         std::vector<double> mfs(todo.size(), 0.0);
-        std::atomic<uint32_t> next(0);
-        std::atomic<int> bad(0);
-        const uint8_t* mask = all_founders ? nullptr : founder_mask.data();
-        auto worker = [&]() {
-          for (uint32_t t = next.fetch_add(64); (t < todo.size()) && !bad.load(); t = next.fetch_add(64)) {
-            for (uint32_t q = t; q < std::min<size_t>(todo.size(), t + 64); ++q) {
-              uint64_t ref_dd = 0, alt_dd = 0;
-              if (ldp_pgen_dosage_sums(pg, inc[mk[todo[q]]], mask, &ref_dd, &alt_dd)) {
-                bad.store(1);
-                return;
-              }
-              const uint64_t tot = ref_dd + alt_dd;
-              const double ref_freq = tot ? (static_cast<double>(static_cast<int64_t>(ref_dd)) * (1.0 / static_cast<double>(static_cast<int64_t>(tot)))) : 0.5;
-              mfs[q] = (ref_freq < 0.5) ? (1.0 - ref_freq) : ref_freq;
-            }
+        {
+          std::vector<uint32_t> raw_todo(todo.size());
+          for (size_t q = 0; q < todo.size(); ++q) {
+            raw_todo[q] = inc[mk[todo[q]]];
           }
-        };
-        const uint32_t nthreads = std::max<uint32_t>(1, std::min<uint32_t>({32u, std::thread::hardware_concurrency(), static_cast<uint32_t>((todo.size() + 63) / 64)}));
-        std::vector<std::thread> pool;
-        for (uint32_t t = 1; t < nthreads; ++t) {
-          pool.emplace_back(worker);
-        }
-        worker();
-        for (std::thread& t : pool) {
-          t.join();
-        }
-        if (bad.load()) {
-          die(6, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+          S.need_dosage_sums(raw_todo);
+          for (size_t q = 0; q < todo.size(); ++q) {
+            const std::pair<uint64_t, uint64_t>& dd = S.dosage_sums[raw_todo[q]];
+            const uint64_t tot = dd.first + dd.second;
+            const double ref_freq = tot ? (static_cast<double>(static_cast<int64_t>(dd.first)) * (1.0 / static_cast<double>(static_cast<int64_t>(tot)))) : 0.5;
+            mfs[q] = (ref_freq < 0.5) ? (1.0 - ref_freq) : ref_freq;
+          }
         }
         for (size_t q = 0; q < todo.size(); ++q) {
           for (int r = 0; r < world; ++r) {

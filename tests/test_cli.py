@@ -387,12 +387,24 @@ def test_cli_dosage_pgen_rules(cli, pkg, tmp_path):
     if not T.have_ref():
         pytest.skip("oracle/_ref/plink2 not built")
     dummy_dosage_fileset(tmp_path, "dos", 60, 200, 0.3, 3)
-    for args in (["--r2-unphased", "--ld-window-r2", "0.2"], ["--indep-pairphase", "50", "5", "0.2"], ["--indep-pairwise", "50", "5", "0.2", "--maf", "0.05"]):
+    for args in (["--r2-unphased", "--ld-window-r2", "0.2"], ["--indep-pairphase", "50", "5", "0.2"]):
         out = run_cli(cli, ["--pfile", "dos"] + args + ["--out", "o"], str(tmp_path))
         assert out.returncode == 63 and "dosage" in out.stdout, out.stdout
     assert not os.path.exists(str(tmp_path / "o.prune.in"))
     out = run_cli(cli, ["--pfile", "dos", "--indep-pairwise", "50", "5", "0.2", "--dry-run", "--out", "o"], str(tmp_path))
     assert out.returncode == 0, out.stdout
+    # --maf / --max-maf compare the dosage-based frequencies, as the reference's do: same number of variants filtered out, and
+    # another number than on the hardcalls of the same file
+    flt = ["--maf", "0.3", "--max-maf", "0.47", "--indep-pairwise", "50", "5", "0.2"]
+    ref = T.run_ref(["--pfile", "dos"] + flt + ["--out", "rf"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    line = re.findall(r"\d+ variants? removed due to allele frequency threshold", ref.stdout)[-1]
+    out = run_cli(cli, ["--pfile", "dos"] + flt + ["--dry-run", "--out", "o"], str(tmp_path))
+    assert out.returncode == 0 and line in out.stdout, (line, out.stdout)
+    hard = T.run_ref(["--pfile", "dos", "--make-pgen", "erase-dosage", "--out", "hard"], str(tmp_path))
+    assert hard.returncode == 0, hard.stdout
+    out = run_cli(cli, ["--pfile", "hard"] + flt + ["--dry-run", "--out", "o"], str(tmp_path))
+    assert out.returncode == 0 and line not in out.stdout
     if pkg.device_count() == 0:   # the prune itself gets as far as the device
         out = run_cli(cli, ["--pfile", "dos", "--indep-pairwise", "50", "5", "0.2", "--out", "o"], str(tmp_path))
         assert out.returncode == 16 and "no usable HIP device" in out.stdout
@@ -414,7 +426,8 @@ def test_cli_dosage_pgen_rules(cli, pkg, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("freq,order,wargs,nonfounders", [(0.3, 2, ["60", "4"], 0), (0.95, 1, ["200kb"], 0), (0.05, 2, ["100", "1"], 9)])
+@pytest.mark.parametrize("freq,order,wargs,nonfounders", [(0.3, 2, ["60", "4"], 0), (0.95, 1, ["200kb"], 0), (0.05, 2, ["100", "1"], 9),
+                                                          (0.5, 2, ["80", "2", "--maf", "0.2", "--max-maf", "0.48"], 5)])
 def test_cli_dosage_frequencies_match_reference(gpu_pkg, cli, tmp_path, freq, order, wargs, nonfounders):
     """--indep-pairwise on files with dosage tracks: r^2 from the hardcalls, the tie-break's allele frequencies from the dosages --
     byte-identical lists.  Random genotypes at a low threshold: a third of the variants go, and which one of a pair goes is decided
@@ -430,7 +443,9 @@ def test_cli_dosage_frequencies_match_reference(gpu_pkg, cli, tmp_path, freq, or
             iid, sex, ph = ln.split("\t")
             out.append("\t".join([iid] + (["per0", "per1"] if (3 <= k < 3 + nonfounders) else ["0", "0"]) + [sex, ph]))
         open(str(tmp_path / "dos.psam"), "w").write("\n".join(out) + "\n")
-    common = ["--pfile", "dos", "--indep-pairwise"] + wargs + ["0.03"] + (["--indep-order", "1"] if order == 1 else [])
+    k = wargs.index("--maf") if "--maf" in wargs else len(wargs)
+    wargs, filters = wargs[:k], wargs[k:]          # (frequency filters: the dosage-based frequencies again)
+    common = ["--pfile", "dos", "--indep-pairwise"] + wargs + ["0.03"] + filters + (["--indep-order", "1"] if order == 1 else [])
     ref = T.run_ref(common + ["--threads", "4", "--out", "ref"], str(tmp_path))
     assert ref.returncode == 0, ref.stdout
     got = run_cli(cli, common + ["--out", "hip"], str(tmp_path))
@@ -441,7 +456,7 @@ def test_cli_dosage_frequencies_match_reference(gpu_pkg, cli, tmp_path, freq, or
     # ... and the dosages matter: the hardcalls of the same file give another list
     hard = T.run_ref(["--pfile", "dos", "--make-pgen", "erase-dosage", "--out", "hard"], str(tmp_path))
     assert hard.returncode == 0, hard.stdout
-    ref2 = T.run_ref(["--pfile", "hard", "--indep-pairwise"] + wargs + ["0.03"] + (["--indep-order", "1"] if order == 1 else []) + ["--threads", "4", "--out", "ref2"], str(tmp_path))
+    ref2 = T.run_ref(["--pfile", "hard", "--indep-pairwise"] + wargs + ["0.03"] + filters + (["--indep-order", "1"] if order == 1 else []) + ["--threads", "4", "--out", "ref2"], str(tmp_path))
     assert ref2.returncode == 0, ref2.stdout
     if freq >= 0.3:
         assert not filecmp.cmp(str(tmp_path / "ref.prune.in"), str(tmp_path / "ref2.prune.in"), shallow=False)
