@@ -921,17 +921,50 @@ int ldp_pgen_dosage_sums(ldp_pgen* P, uint32_t variant, const uint8_t* sample_ma
       }
     }
   }
-  auto in_mask = [&](uint32_t s) { return (!sample_mask) || ((sample_mask[s >> 3] >> (s & 7)) & 1); };
-  auto code_of = [&](uint32_t s) { return (row[s >> 2] >> (2 * (s & 3))) & 3u; };
+  // 32 samples at a time: one 64-bit word of codes, the sample mask and the dosage-presence bits spread to the codes' even bit
+  // positions, category counts as popcounts (a record is ~1 MB at 500,000 samples: this pass has to stream)
+  const uint64_t m5 = 0x5555555555555555ull;
+  const uint32_t nblk = (n + 31) / 32;
+  const uint64_t nbits_bytes = (static_cast<uint64_t>(n) + 7) / 8;
+  auto spread32 = [](uint32_t x) {
+    uint64_t v = x;
+    v = (v | (v << 16)) & 0x0000ffff0000ffffull;
+    v = (v | (v << 8)) & 0x00ff00ff00ff00ffull;
+    v = (v | (v << 4)) & 0x0f0f0f0f0f0f0f0full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & m5;
+    return v;
+  };
+  auto valid32 = [&](uint32_t blk) { return (n - 32 * blk >= 32) ? 0xffffffffu : ((1u << (n - 32 * blk)) - 1u); };
+  auto bits32 = [&](const uint8_t* bits, uint32_t blk) {  // bits == nullptr: everybody
+    uint32_t w = 0xffffffffu;
+    if (bits) {
+      w = 0;
+      memcpy(&w, bits + 4ull * blk, static_cast<size_t>(std::min<uint64_t>(4, nbits_bytes - 4ull * blk)));
+    }
+    return w & valid32(blk);
+  };
+  struct Cats {
+    uint64_t homref, het, homalt, missing;
+  };
+  auto cats_of = [&](uint32_t blk) {
+    uint64_t g = 0;
+    memcpy(&g, row.data() + 8ull * blk, 8);  // (the buffer is rec_bytes + 8 long, zero behind the row)
+    const uint64_t lo = g & m5, hi = (g >> 1) & m5;
+    return Cats{~(lo | hi) & m5, lo & ~hi, hi & ~lo, lo & hi};
+  };
+  typedef uint16_t u16u __attribute__((aligned(1)));
   // hardcall counts of the subset; of the raw file (the phase track's length is a function of every sample's het calls)
   uint64_t geno[4] = {0, 0, 0, 0};
   uint32_t raw_het_ct = 0;
-  for (uint32_t s = 0; s < n; ++s) {
-    const uint32_t c = code_of(s);
-    raw_het_ct += (c == 1) ? 1u : 0u;
-    if (in_mask(s)) {
-      ++geno[c];
-    }
+  for (uint32_t blk = 0; blk < nblk; ++blk) {
+    const Cats c = cats_of(blk);
+    const uint64_t V = spread32(valid32(blk)), M = spread32(bits32(sample_mask, blk));
+    raw_het_ct += static_cast<uint32_t>(__builtin_popcountll(c.het & V));
+    geno[0] += static_cast<uint64_t>(__builtin_popcountll(c.homref & M));
+    geno[1] += static_cast<uint64_t>(__builtin_popcountll(c.het & M));
+    geno[2] += static_cast<uint64_t>(__builtin_popcountll(c.homalt & M));
+    geno[3] += static_cast<uint64_t>(__builtin_popcountll(c.missing & M));
   }
   uint64_t alt = 0, dosage_ct = 0;
   uint64_t replaced[4] = {0, 0, 0, 0};
@@ -958,56 +991,98 @@ int ldp_pgen_dosage_sums(ldp_pgen* P, uint32_t variant, const uint8_t* sample_ma
     }
     if ((vrtype & 0x60) == 0x40) {
       // one value per sample, 65535 = none (and then no hardcall either: pgen_spec.tex:601-604)
-      const uint8_t* vals = c.p;
+      const u16u* vals = reinterpret_cast<const u16u*>(c.p);
       if (!c.skip(2ull * n)) {
         return pfail(P, LDP_ERR_INVALID, "truncated dosage track");
       }
-      for (uint32_t s = 0; s < n; ++s) {
-        if (!in_mask(s)) {
-          continue;
-        }
-        uint16_t d;
-        memcpy(&d, vals + 2ull * s, 2);
-        if (d != 65535) {
-          alt += d;
-          ++dosage_ct;
+      for (uint32_t blk = 0; blk < nblk; ++blk) {
+        const uint32_t mw = bits32(sample_mask, blk), s0 = 32 * blk;
+        if (mw == valid32(blk)) {
+          const uint32_t cnt = std::min(32u, n - s0);
+          uint32_t sum = 0, have = 0;
+          for (uint32_t k = 0; k < cnt; ++k) {
+            const uint32_t d = vals[s0 + k];
+            sum += (d != 65535u) ? d : 0u;
+            have += (d != 65535u) ? 1u : 0u;
+          }
+          alt += sum;
+          dosage_ct += have;
+        } else {
+          for (uint32_t w = mw; w; w &= w - 1) {
+            const uint32_t d = vals[s0 + static_cast<uint32_t>(__builtin_ctz(w))];
+            if (d != 65535u) {
+              alt += d;
+              ++dosage_ct;
+            }
+          }
         }
       }
       // (every called sample has a dosage: the hardcalls are all replaced)
       for (int q = 0; q < 3; ++q) {
         replaced[q] = geno[q];
       }
-    } else {
-      std::vector<uint32_t> ids;  // track 3: who has a dosage (pgen_spec.tex:598-606) -- a list of sample ids or a bit per sample
-      if ((vrtype & 0x60) == 0x20) {
-        if (!read_id_difflist(c, n, &ids)) {
-          return pfail(P, LDP_ERR_INVALID, "malformed dosage list");
+    } else if ((vrtype & 0x60) == 0x60) {
+      // track 3: one presence bit per sample (pgen_spec.tex:605-606); track 4: the values of the samples that have one, in order
+      const uint8_t* bits = c.p;
+      if (!c.skip(nbits_bytes)) {
+        return pfail(P, LDP_ERR_INVALID, "truncated dosage track");
+      }
+      uint64_t total = 0;
+      for (uint32_t blk = 0; blk < nblk; ++blk) {
+        total += static_cast<uint64_t>(__builtin_popcount(bits32(bits, blk)));
+      }
+      const u16u* vals = reinterpret_cast<const u16u*>(c.p);
+      if (!c.skip(2ull * total)) {
+        return pfail(P, LDP_ERR_INVALID, "truncated dosage track");
+      }
+      uint64_t k = 0;
+      for (uint32_t blk = 0; blk < nblk; ++blk) {
+        const uint32_t pw = bits32(bits, blk);
+        if (!pw) {
+          continue;
         }
-      } else {
-        const uint8_t* bits = c.p;
-        if (!c.skip((static_cast<uint64_t>(n) + 7) / 8)) {
-          return pfail(P, LDP_ERR_INVALID, "truncated dosage track");
-        }
-        for (uint32_t s = 0; s < n; ++s) {
-          if ((bits[s >> 3] >> (s & 7)) & 1) {
-            ids.push_back(s);
+        const uint32_t mw = bits32(sample_mask, blk), cnt = static_cast<uint32_t>(__builtin_popcount(pw));
+        if (!(pw & ~mw)) {
+          uint32_t sum = 0;
+          for (uint32_t q = 0; q < cnt; ++q) {
+            sum += vals[k + q];
+          }
+          alt += sum;
+          dosage_ct += cnt;
+        } else {
+          uint32_t q = 0;
+          for (uint32_t w = pw; w; w &= w - 1, ++q) {
+            if ((mw >> __builtin_ctz(w)) & 1u) {
+              alt += vals[k + q];
+              ++dosage_ct;
+            }
           }
         }
+        k += cnt;
+        const Cats cc = cats_of(blk);
+        const uint64_t PM = spread32(pw & mw);
+        replaced[0] += static_cast<uint64_t>(__builtin_popcountll(cc.homref & PM));
+        replaced[1] += static_cast<uint64_t>(__builtin_popcountll(cc.het & PM));
+        replaced[2] += static_cast<uint64_t>(__builtin_popcountll(cc.homalt & PM));
       }
-      const uint8_t* vals = c.p;
+    } else {
+      // track 3: the ids of the samples that have a dosage (pgen_spec.tex:598-600)
+      std::vector<uint32_t> ids;
+      if (!read_id_difflist(c, n, &ids)) {
+        return pfail(P, LDP_ERR_INVALID, "malformed dosage list");
+      }
+      const u16u* vals = reinterpret_cast<const u16u*>(c.p);
       if (!c.skip(2ull * ids.size())) {
         return pfail(P, LDP_ERR_INVALID, "truncated dosage track");
       }
-      for (size_t k = 0; k < ids.size(); ++k) {
-        const uint32_t s = ids[k];
-        if (!in_mask(s)) {
+      for (size_t q = 0; q < ids.size(); ++q) {
+        const uint32_t sx = ids[q];
+        if (sample_mask && !((sample_mask[sx >> 3] >> (sx & 7)) & 1)) {
           continue;
         }
-        uint16_t d;
-        memcpy(&d, vals + 2 * k, 2);
-        alt += d;
+        alt += vals[q];
         ++dosage_ct;
-        ++replaced[code_of(s)];
+        ++replaced[(row[sx >> 2] >> (2 * (sx & 3))) & 3u];
       }
     }
   }

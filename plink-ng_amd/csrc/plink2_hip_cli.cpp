@@ -4866,7 +4866,7 @@ void Session::need_dosage_sums(const std::vector<uint32_t>& raw_variants) {
       }
     }
   };
-  const uint32_t nthreads = std::max<uint32_t>(1, std::min<uint32_t>({32u, std::thread::hardware_concurrency(), static_cast<uint32_t>((todo.size() + 63) / 64)}));
+  const uint32_t nthreads = std::max<uint32_t>(1, std::min<uint32_t>({64u, std::thread::hardware_concurrency(), static_cast<uint32_t>((todo.size() + 63) / 64)}));
   std::vector<std::thread> pool;
   for (uint32_t t = 1; t < nthreads; ++t) {
     pool.emplace_back(worker);
