@@ -428,6 +428,8 @@ struct Args {
   // --maf / --max-maf (nonmajor-allele frequency over the founders) and --geno (missing-call rate over the samples), as the
   // reference enforces them (EnforceFreqConstraints plink2_filter.cc:3791, EnforceGenoThresh :3498); 0 / 1 / 1 = not given
   double min_maf = 0.0, max_maf = 1.0, geno = 1.0;
+  uint64_t min_allele_ddosage = 0, max_allele_ddosage = ~0ull;  // --mac / --max-mac in 32768ths of an allele copy (plink2.cc:8785-8867)
+  bool ac_founders = false;
   uint32_t max_alleles = 0xffffffffu;  // --max-alleles N (applied while the variant table loads, LoadPvar)
   bool snps_only = false, snps_only_acgt = false;  // --snps-only ['just-acgt'] (another load-time filter)
   std::vector<std::string> extract_files, exclude_files, keep_files, remove_files;
@@ -972,6 +974,39 @@ Args parse_args(int argc, char** argv) {
         die(8, "Error: --max-maf requires a value.\n");
       }
       ((f == "--maf") ? A.min_maf : ((f == "--max-maf") ? A.max_maf : A.geno)) = d;
+    } else if ((f == "--mac") || (f == "--max-mac")) {  // plink2.cc:8785-8867 (default mode: the non-major allele's dosage sum over the founders)
+      if ((i + 1 >= argc) || (argv[i + 1][0] == '-')) {
+        die(8, "Error: %s requires a value.\n", f.c_str());
+      }
+      const std::string v = argv[++i];
+      double d = 0.0;
+      const char* endp;
+      if (!scan_double_plink(v.c_str(), &d, &endp) || *endp) {
+        if (*endp == ':') {
+          die(63, "Error: %s modifiers ('%s') are not supported by plink2-hip.\n", f.c_str(), v.c_str());
+        }
+        die(8, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
+      }
+      if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+        die(63, "Error: %s modifiers ('%s') are not supported by plink2-hip.\n", f.c_str(), argv[i + 1]);
+      }
+      if ((d < 0.0) || (d > 2147483646.0)) {
+        die(8, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
+      }
+      if (f == "--mac") {
+        if (d > 0.0) {  // round up, but keep as much precision as possible
+          const int32_t int_part = static_cast<int32_t>(d);
+          d -= int_part;
+          A.min_allele_ddosage = static_cast<uint64_t>(int_part) * 32768ull;
+          if (d > 0.0) {
+            A.min_allele_ddosage += 1 + static_cast<uint64_t>(d * (32768 * (1 - kSmallEpsilon)));
+          }
+        }
+      } else {
+        A.max_allele_ddosage = static_cast<uint64_t>(static_cast<int64_t>(d * 32768));  // round down
+      }
+    } else if (f == "--ac-founders") {
+      A.ac_founders = true;
     } else if ((f == "--extract") || (f == "--exclude") || (f == "--keep") || (f == "--remove")) {
       std::vector<std::string>& dst = (f == "--extract") ? A.extract_files : ((f == "--exclude") ? A.exclude_files : ((f == "--keep") ? A.keep_files : A.remove_files));
       while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
@@ -3429,7 +3464,19 @@ void load_inputs(Session& S, int argc, char** argv) {
   // --geno / --maf / --max-maf need genotype counts before the variant list is final: one multi-threaded pass over the rows of
   // the variants the table filters leave (host popcounts; the rows are read again when they go to the device)
   std::vector<uint8_t> drop_by_counts;
-  if ((A.min_maf != 0.0) || (A.max_maf != 1.0) || (A.geno != 1.0)) {
+  const bool mac_filter = (A.min_allele_ddosage != 0) || (A.max_allele_ddosage != ~0ull);
+  const bool freq_filter = (A.min_maf != 0.0) || (A.max_maf != 1.0) || mac_filter;
+  if (mac_filter && (!A.ac_founders)) {
+    // (plink2.cc:2102-2105; plink2-hip counts alleles over the founders: the --nonfounders alternative is not offered)
+    uint32_t kept = 0;
+    for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+      kept += (S.sample_kept.empty() || S.sample_kept[sx]) ? 1u : 0u;
+    }
+    if (kept != founder_ct) {
+      die(7, "Error: --mac/--max-mac/\"--freq counts\" specified, but with neither\n--ac-founders nor --nonfounders; and nonfounders are present.\n");
+    }
+  }
+  if (freq_filter || (A.geno != 1.0)) {
     std::unordered_map<std::string, uint8_t> chr_state;  // 1 = filtered out by chromosome
     std::vector<uint32_t> todo;
     for (uint32_t v = 0; v < raw_variant_ct; ++v) {
@@ -3442,7 +3489,7 @@ void load_inputs(Session& S, int argc, char** argv) {
         bool zero = false;
         const int cls = chrom_class(cur, A.allow_extra_chr, &zero);
         if ((!out) && (cls >= 3)) {
-          die(63, "Error: --maf / --max-maf / --geno on chrX, chrY or MT ('%s') are not supported by plink2-hip: filter them out (--autosome, --chr) or pre-filter with plink2.\n", cur.c_str());
+          die(63, "Error: --maf / --max-maf / --mac / --max-mac / --geno on chrX, chrY or MT ('%s') are not supported by plink2-hip: filter them out (--autosome, --chr) or pre-filter with plink2.\n", cur.c_str());
         }
         it = chr_state.emplace(cur, static_cast<uint8_t>(out)).first;
       }
@@ -3453,7 +3500,7 @@ void load_inputs(Session& S, int argc, char** argv) {
         continue;
       }
       if (V.alt_ct[v] > 1) {
-        die(63, "Error: --maf / --max-maf / --geno with multiallelic variants ('%s') are not supported by plink2-hip.\n", V.id[v].c_str());
+        die(63, "Error: --maf / --max-maf / --mac / --max-mac / --geno with multiallelic variants ('%s') are not supported by plink2-hip.\n", V.id[v].c_str());
       }
       todo.push_back(v);
     }
@@ -3518,7 +3565,7 @@ void load_inputs(Session& S, int argc, char** argv) {
         q0 += run;
       }
     }
-    if (S.has_dosage && ((A.min_maf != 0.0) || (A.max_maf != 1.0))) {
+    if (S.has_dosage && freq_filter) {
       std::vector<uint32_t> with_track;
       for (uint32_t v : todo) {
         if (ldp_pgen_variant_has_dosage(pg, v)) {
@@ -3538,18 +3585,29 @@ void load_inputs(Session& S, int argc, char** argv) {
         ++geno_removed;
         continue;
       }
-      if ((A.min_maf != 0.0) || (A.max_maf != 1.0)) {
-        uint64_t ref_ct = 2ull * c.ref2 + c.het, alt_ct = 2ull * c.alt2 + c.het;
+      if (freq_filter) {
+        // allele counts in 16384ths of a copy: the hardcalls', or -- a record with dosages -- the founders' dosage sums
+        uint64_t ref_ct = (2ull * c.ref2 + c.het) * 16384ull, alt_ct = (2ull * c.alt2 + c.het) * 16384ull;
         const auto dd = S.dosage_sums.find(todo[q]);
-        if (dd != S.dosage_sums.end()) {  // a record with dosages: the founders' dosage sums (units cancel: both are scaled by 16384)
+        if (dd != S.dosage_sums.end()) {
           ref_ct = dd->second.first;
           alt_ct = dd->second.second;
         }
         const uint64_t tot = ref_ct + alt_ct;
+        if (mac_filter) {
+          // GetTypedDdosage, nonmajor mode, two alleles (plink2_filter.cc:3765-3767) on allele_ddosages = 2 x these sums
+          // (plink2_data.cc:2441-2442)
+          const uint64_t typed_dd = 2 * std::min(ref_ct, alt_ct);
+          if ((typed_dd < A.min_allele_ddosage) || (typed_dd > A.max_allele_ddosage)) {
+            drop_by_counts[todo[q]] = 1;
+            ++freq_removed;
+            continue;
+          }
+        }
         const double ref_freq = tot ? (static_cast<double>(ref_ct) * (1.0 / static_cast<double>(tot))) : 0.5;  // plink2_filter.cc:2137-2147
         const double nonref_freq = 1.0 - ref_freq;
         const double typed = (nonref_freq < ref_freq) ? nonref_freq : ref_freq;  // GetTypedFreq, nonmajor mode, two alleles (:3715-3723)
-        if (((A.min_maf != 0.0) && (typed < min_maf)) || ((A.max_maf < 1.0) && (typed > max_maf))) {
+        if ((((A.min_maf != 0.0) || (A.max_maf != 1.0))) && (((A.min_maf != 0.0) && (typed < min_maf)) || ((A.max_maf < 1.0) && (typed > max_maf)))) {
           drop_by_counts[todo[q]] = 1;
           ++freq_removed;
         }
@@ -3558,7 +3616,7 @@ void load_inputs(Session& S, int argc, char** argv) {
     if (A.geno != 1.0) {
       logprintf("--geno: %u variant%s removed due to missing genotype data.\n", geno_removed, (geno_removed == 1) ? "" : "s");
     }
-    if ((A.min_maf != 0.0) || (A.max_maf != 1.0)) {
+    if (freq_filter) {
       logprintf("%u variant%s removed due to allele frequency threshold(s)\n(--maf/--max-maf/--mac/--max-mac).\n", freq_removed, (freq_removed == 1) ? "" : "s");
     }
   }

@@ -462,6 +462,42 @@ def test_cli_dosage_frequencies_match_reference(gpu_pkg, cli, tmp_path, freq, or
         assert not filecmp.cmp(str(tmp_path / "ref.prune.in"), str(tmp_path / "ref2.prune.in"), shallow=False)
 
 
+@pytest.mark.parametrize("dosage", [False, True])
+def test_mac_filters_count_like_the_reference(cli, tmp_path, dosage):
+    """--mac / --max-mac (plink2.cc:8785-8867, EnforceFreqConstraints plink2_filter.cc:3791): the non-major allele's count over the
+    founders -- its dosage sum where records carry dosages -- against thresholds kept in 32768ths of an allele copy, fractional
+    arguments rounded as the reference rounds them.  Same number of variants filtered out (the filter runs before a GPU is needed)."""
+    if not T.have_ref():
+        pytest.skip("oracle/_ref/plink2 not built")
+    args = ["--dummy", "90", "400"] + (["dosage-freq=0.4"] if dosage else []) + ["--seed", "21", "--threads", "2", "--make-pgen", "--out", "d"]
+    cp = T.run_ref(args, str(tmp_path))
+    assert cp.returncode == 0, cp.stdout
+    seen = set()
+    for flt in (["--mac", "70"], ["--max-mac", "80"], ["--mac", "66.5", "--max-mac", "84.25"], ["--mac", "72", "--maf", "0.42"], ["--mac", "0"]):
+        ref = T.run_ref(["--pfile", "d"] + flt + ["--indep-pairwise", "50", "5", "0.2", "--out", "r"], str(tmp_path))
+        assert ref.returncode == 0, ref.stdout
+        lines = re.findall(r"\d+ variants? removed due to allele frequency threshold", ref.stdout)
+        got = run_cli(cli, ["--pfile", "d"] + flt + ["--indep-pairwise", "50", "5", "0.2", "--dry-run", "--out", "o"], str(tmp_path))
+        assert got.returncode == 0, got.stdout
+        if lines:
+            assert lines[-1] in got.stdout, (flt, lines[-1], got.stdout)
+            seen.add(lines[-1])
+        else:
+            assert "removed due to allele frequency" not in got.stdout
+    assert len(seen) >= 3
+    # nonfounders present: the reference wants to be told whose alleles to count
+    lines = open(str(tmp_path / "d.psam")).read().splitlines()
+    out = ["#IID\tPAT\tMAT\tSEX\tPHENO1"] + ["\t".join([ln.split("\t")[0]] + (["per0", "per1"] if k in (5, 6) else ["0", "0"]) + ln.split("\t")[1:]) for k, ln in enumerate(lines[1:])]
+    open(str(tmp_path / "d.psam"), "w").write("\n".join(out) + "\n")
+    ref = T.run_ref(["--pfile", "d", "--mac", "70", "--indep-pairwise", "50", "5", "0.2", "--out", "r"], str(tmp_path))
+    got = run_cli(cli, ["--pfile", "d", "--mac", "70", "--indep-pairwise", "50", "5", "0.2", "--dry-run", "--out", "o"], str(tmp_path))
+    assert ref.returncode != 0 and got.returncode == 7 and "--ac-founders nor --nonfounders" in ref.stdout.replace("\n", " ") and "--ac-founders nor --nonfounders" in got.stdout.replace("\n", " ")
+    ref = T.run_ref(["--pfile", "d", "--mac", "70", "--ac-founders", "--indep-pairwise", "50", "5", "0.2", "--out", "r"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    got = run_cli(cli, ["--pfile", "d", "--mac", "70", "--ac-founders", "--indep-pairwise", "50", "5", "0.2", "--dry-run", "--out", "o"], str(tmp_path))
+    assert got.returncode == 0 and re.findall(r"\d+ variants? removed due to allele frequency threshold", ref.stdout)[-1] in got.stdout
+
+
 def test_make_founders_counts_match_reference(cli, tmp_path):
     """--make-founders ['require-2-missing'] ['first'] (MakeFounders, plink2_filter.cc:4372-4443): which samples become founders,
     judged by both binaries' own log lines (no GPU: --dry-run here, an unrelated cheap command there)."""
