@@ -4,38 +4,42 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workloads (synthetic; 22 autosomes with variant counts proportional to GRCh38 lengths, uniform spacing):
-  N = 1   BASELINE.json configs[1]: 50,000 samples x 1,000,000 biallelic variants at 2,875 bp, `--indep-pairwise 200kb 0.5`
-          (the largest named configuration that fits one GPU; the metric's 500k x 10M is 1.25 TB).
-  N >= 2  BASELINE.json configs[2], the configuration the metric is quoted on, STRONG scaling: 500,000 samples x 10,000,000
-          variants at 290 bp, `--indep-pairwise 500kb 0.2`, the 22 chromosomes (the subcontigs) LPT-sharded over the ranks exactly
-          as `ldp_set_shard` does it, so the imbalance of 22 unequal chromosomes on N ranks is part of the number.  A rank's share
-          is resident in HBM at N = 8 (1.25M variants = 156 GB); at N = 2 / 4 it exceeds 288 GB and the rank works through its
-          chromosomes one engine at a time, copying each chromosome's rows inside the step from one resident chromosome's worth of
-          generated rows (said so in config.workload).
-  `--workload config2|config3`, `--samples/--variants/--spacing/--window-kb/--r2`, `--strong/--weak` override all of this.
+ONE workload family at every N (synthetic; one genome of 22 autosomes with variant counts proportional to GRCh38 lengths, uniform
+spacing, chromosomes = subcontigs LPT-sharded over the ranks exactly as `ldp_set_shard` does it):
+  default   BASELINE.json configs[2]'s density, WEAK scaling: 500,000 samples, 290 bp spacing, `--indep-pairwise 500kb 0.2`,
+            1,250,000 variants PER GPU (156 GB of 2-bit rows, resident in HBM) -- the real per-GPU share of the metric's 500k x 10M at
+            N = 8, where this line IS config 3; at N = 1 it is the largest slice of it that fits one GPU.
+  --strong  the metric's 10M variants in total whatever N.  A rank's share is resident only at N = 8; at N = 2 / 4 it exceeds HBM, the
+            rank works through its chromosomes one engine at a time with every chromosome's rows copied inside the step from ONE
+            generated chromosome, and the line says `"data": "model ..."`: a model of the workload, not a measurement of it.
+  `--workload config2` (50,000 x 1,000,000 at 2,875 bp, `200kb 0.5`: BASELINE.json configs[1]; weak: that many variants per GPU),
+  `--samples/--variants/--spacing/--window-kb/--r2` override all of this.
 There is no data-path collective; the prune bitmask is exchanged once per step with an RCCL all_gather.
 
 A "step" is one pass of the hot path over the HBM-resident 2-bit genotype image: the count pass (codes_kernel: per-variant
 aggregates, allele counts, major allele, checkpoint statistics -- a read of N/4 bytes per variant, nothing is rewritten: the pair
-kernels expand the 2-bit codes themselves), the banded pair statistics / prune predicate on the matrix pipe (pair_mfma_kernel
-for complete data, its interval epilogue for rows with a few missing calls, pair_mfma_general_kernel otherwise), the host replay
-of the greedy scan, and the bitmask exchange.  The rows are generated straight into the engine's image (ldp_map_rows), so they
-are resident when the timed region starts.  `value` = candidate variant pairs decided per second over all ranks.
+kernels expand the 2-bit codes themselves), the banded pair statistics / prune predicate on the matrix pipe (pair_mfma_wide_kernel
+on 8 x 8 block tiles for wide bands, pair_mfma_kernel for narrow ones, the interval epilogue / four-product kernels for rows with
+missing calls), the host replay of the greedy scan, and the bitmask exchange.  The rows are generated straight into the engine's
+image (ldp_map_rows), so they are resident when the timed region starts.  `value` = candidate variant pairs decided per second over
+all ranks.
 
 One JSON line is printed by rank 0.
   roofline      the pair kernel of the run against BOTH ceilings it can meet, the larger fraction named as `bound`:
                 mfma  executed FP4 MFMA flops (instructions the kernel really issued: plan x k-steps - early termination)
                       / summed kernel time, against the guide's dense FP4 peak (10 PFLOP/s);
                 hbm   compulsory bytes (every owned row once: variants x N/4) / summed kernel time against 8 TB/s.
-                `traffic` (HBM bytes per step from PMC counters) is replayed from profiles/ when the workload matches
-                and says so; the effective stream rate of SURVEY 8(d) (pairs x N/2 bytes) is a named side field.
-  legs          (N = 1) the same step with early termination off, with 0.1 % / 1 % missing calls, and the north-star shapes at
-                one GPU: `config3_density` / `config5_density` = 500,000 samples x 120,000 variants at 290 bp, `500kb 0.2`,
-                complete data / 5 % missing calls, each with its kernel time, executed-MFMA fraction, replayed PMC traffic and
-                traffic / compulsory, and a prune-set comparison with reference plink2 on a slice.
+                `traffic` (HBM bytes per step from PMC counters) is replayed from profiles/*_pmc_traffic.json ONLY when the workload
+                matches AND the kernel sources that file was profiled on hash to what this tree holds (`traffic_source` "stale"
+                otherwise); the effective stream rate of SURVEY 8(d) (pairs x N/2 bytes) is a named side field.
+  legs          (N = 1) `config2` (BASELINE.json configs[1]: the step, its roofline, early termination off, 0.1 % / 1 % missing calls,
+                the reference on a 440,000-variant sample with both binaries end to end), `config5_density` (500,000 x 120,000, 5 %
+                missing calls, 2 % multiallelic records decoded inside the step), `config4_tiles` (--r2-unphased inter-chr: a 65,536 x
+                65,536 cross-chromosome tile set at 500,000 samples, device-side filter, with plink2-hip against the reference on a
+                slice), each with kernel time, roofline and a reference comparison.
   cpu_baseline  reference plink2 (oracle/_ref/plink2, AVX2, all host threads) on a bounded sample of the same generator,
-                prune set compared with the HIP path's; plus both binaries end to end on the sample's files.
+                prune set compared with the HIP path's; plink2-hip end to end on the same files beside it, and both walls
+                extrapolated linearly to a chr22-sized slice of the metric's genome.
 """
 import argparse
 import ctypes
@@ -61,6 +65,11 @@ CONFIGS = {
     "config2": dict(samples=50000, variants=1000000, spacing=2875, window_kb=200.0, r2=0.5),
     "config3": dict(samples=500000, variants=10000000, spacing=290, window_kb=500.0, r2=0.2),
 }
+PER_GPU_VARIANTS = {"config2": 1000000, "config3": 1250000}  # weak scaling: the share of one GPU (config 3: 10M / 8)
+CHR22_FRACTION = GRCH38_MB[21] / sum(GRCH38_MB)               # end-to-end runs materialise <= one chr22-sized chromosome
+# the kernel sources a PMC profile is valid for (roofline.traffic is replayed only when their hashes match this tree)
+KERNEL_SOURCES = ["plink-ng_amd/csrc/" + f for f in ("ldp_pair_wide.hip", "ldp_pair_mfma.hip", "ldp_mfma_device.h", "ldp_pair_device.h", "ldp_device.h",
+                                                      "ldp_codes.hip", "ldp_engine.cpp")]
 HBM_BYTES = float(os.environ.get("LDP_BENCH_HBM_GB", "288")) * 1e9  # (the override forces the non-resident mode at small sizes: tests)
 
 
@@ -116,7 +125,7 @@ def host_description():
     return {"cpu_model": model, "nproc": os.cpu_count() or 0}
 
 
-def cpu_baseline(pkg, torch, founder_ct, m, spacing, window_kb, r2, missing_rate, cli_compare=True):
+def cpu_baseline(pkg, torch, founder_ct, m, spacing, window_kb, r2, missing_rate, cli_compare=True, full_variants=0):
     """Reference plink2 (all host cores) on a bounded sample of the same generator; also a parity check."""
     ref_bin = os.path.join(REPO, "oracle", "_ref", "plink2")
     base = {"value": None, "unit": "variant-pairs/s", "cores": 0, "kind": "reference", **host_description()}
@@ -166,6 +175,26 @@ def cpu_baseline(pkg, torch, founder_ct, m, spacing, window_kb, r2, missing_rate
             cli = {"e2e_wall_s": {"reference_plink2": wall, "plink2_hip": cli_wall, "speedup": wall / cli_wall if cli_wall > 0 else None,
                                   "what": "process start to exit on the sample's .bed/.bim/.fam (page cache warm), same command line"},
                    "plink2_hip_files_identical": bool(same), "plink2_hip_rc": cc.returncode}
+            if full_variants and full_variants > m:
+                # "materialise <= 1 chromosome (chr22-sized) ... and extrapolate -- say so".  Both walls scale with the
+                # variant count once the fixed parts are taken out: the reference's load + frequency + prune passes are all linear in
+                # variants at a fixed window; plink2-hip's fixed part is the HIP context + table start-up (measured on an empty run).
+                chr22 = int(round(full_variants * CHR22_FRACTION))
+                t2 = time.perf_counter()
+                subprocess.run([cli_bin, "--bfile", "sample", "--indep-pairwise", kb, repr(r2), "--dry-run", "--out", "dry"], cwd=tmp, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True, timeout=600)
+                dry_wall = time.perf_counter() - t2
+                hip_fixed = min(dry_wall, cli_wall)
+                scale = chr22 / float(m)
+                ref_x = wall * scale
+                hip_x = hip_fixed + max(cli_wall - hip_fixed, 0.0) * scale
+                cli["e2e_chr22_extrapolation"] = {
+                    "variants_chr22_sized": chr22, "of_genome_variants": full_variants, "scale_from_sample": scale,
+                    "reference_plink2_s": ref_x, "plink2_hip_s": hip_x, "speedup": (ref_x / hip_x) if hip_x > 0 else None,
+                    "plink2_hip_fixed_s": hip_fixed,
+                    "how": "LINEAR extrapolation of the two measured walls from the %d-variant sample to a chr22-sized chromosome of the genome (%d variants = %.2f %% of "
+                           "%d): reference wall x scale; plink2-hip = its variant-independent part (HIP context + tables: a --dry-run on the same files) + the rest x scale.  "
+                           "An extrapolation, not a measurement (SURVEY 8(d))" % (m, chr22, 100.0 * CHR22_FRACTION, full_variants)}
         mt = re.search(r"\((\d+) compute thread", cp.stdout)
         compute_threads = int(mt.group(1)) if mt else 0
         used = (compute_threads + 1) if mt else cores  # LD compute threads + the decode/main thread
@@ -398,18 +427,41 @@ def sum_counters(ctrs):
     return {k: sum(c[k] for c in ctrs) for k in keys}
 
 
+def source_hashes():
+    """git blob hashes (sha1 of "blob <len>\\0" + content) of the kernel sources, computed from the working tree"""
+    import hashlib
+    out = {}
+    for rel in KERNEL_SOURCES:
+        try:
+            data = open(os.path.join(REPO, rel), "rb").read()
+        except OSError:
+            out[rel] = None
+            continue
+        out[rel] = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    return out
+
+
 def pmc_traffic(founder_ct, variants, window_kb, missing_rate):
-    """HBM bytes per step from PMC counters, replayed from profiles/ (collected by tools/profile.sh on the same workload)."""
+    """HBM bytes per step from PMC counters, replayed from profiles/ (collected by tools/profile.sh on the same workload) -- only
+    from a file whose recorded kernel-source hashes equal this tree's: a kernel edit makes every older profile "stale"."""
+    now = source_hashes()
+    stale = None
     for name in sorted(os.listdir(os.path.join(REPO, "profiles")), reverse=True):
-        if not (name.endswith("pmc_traffic.json") and name.startswith("r03")):
+        if not name.endswith("pmc_traffic.json"):
             continue
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", name)))
         except Exception:
             continue
-        if (tj.get("samples") == founder_ct and tj.get("variants") == variants and tj.get("window_kb") == window_kb
+        if not (tj.get("samples") == founder_ct and tj.get("variants") == variants and tj.get("window_kb") == window_kb
                 and abs(tj.get("missing_rate", 0.0) - missing_rate) < 1e-12):
-            return tj.get("hbm_bytes_per_step"), "profiles/%s (replayed: PMC passes of tools/profile.sh, tag %s; not measured in this run)" % (name, tj.get("tag")), tj
+            continue
+        if tj.get("sources") != now:
+            stale = stale or name
+            continue
+        return tj.get("hbm_bytes_per_step"), "profiles/%s (replayed: PMC passes of tools/profile.sh, tag %s, kernel sources identical to this tree's; not measured in this run)" % (name, tj.get("tag")), tj
+    if stale:
+        return None, "stale (profiles/%s was collected on other kernel sources than this tree's)" % stale, None
     return None, None, None
 
 
@@ -419,7 +471,8 @@ def pair_roofline(c, founder_ct, local_ct, missing_rate, variants, window_kb):
     kms_valu = c["ms_pair_fast"] + c["ms_pair_general"]
     on_matrix_pipe = (kms_mfma + kms_gen) > kms_valu
     four_tiles = c.get("four_tile_launches", 0) > 0   # wide bands: the four-product form runs on quarter tiles
-    kernel = (("pair_mfma_tile4_kernel" if four_tiles else "pair_mfma_general_kernel") if general else "pair_mfma_kernel") if on_matrix_pipe else ("pair_tiles_kernel<true>" if general else "pair_tiles_kernel<false>")
+    wide = c.get("wide_tiles", 0) > 0 and c["route_complete_launches"] > 0   # complete-data launches of wide-band subcontigs: the 8 x 8 tile kernel
+    kernel = (("pair_mfma_tile4_kernel" if four_tiles else "pair_mfma_general_kernel") if general else ("pair_mfma_wide_kernel" if wide else "pair_mfma_kernel")) if on_matrix_pipe else ("pair_tiles_kernel<true>" if general else "pair_tiles_kernel<false>")
     kms = (kms_mfma + kms_gen) if on_matrix_pipe else kms_valu
     launches = max(int(c["pair_kernel_launches"]), 1)
     # MFMA side: instructions the kernel really issued.  One block product = 32 x 32 pairs; one k-step = one
@@ -455,25 +508,116 @@ def pair_roofline(c, founder_ct, local_ct, missing_rate, variants, window_kb):
     }
 
 
+def config4_tiles_leg(pkg, torch, device, samples, tile, ref_slice_variants, no_cpu):
+    """BASELINE config 4 (`--r2-unphased inter-chr`, plink2_ld.cc:11082-11116; VcorMatrixThread :9518-9652) as SURVEY 8(d) sizes it: a
+    fixed tile x tile CROSS-chromosome tile set -- `tile` variants of one chromosome against `tile` variants of another, every pair
+    -- at `samples` founders, through the all-pairs plan's column-block call with the table writer's filter in the kernel epilogue
+    (r^2 >= 0.2 (1 - 2^-44), the command's default), so that only the pairs that would be written leave the device."""
+    n, m = samples, 2 * tile
+    eng = pkg.LdPruneEngine(n, 2, 1, False, 0.5, device=device)
+    eng.set_variants_matrix(m)
+    # rows [0, tile): the first `tile` variants of chromosome 1; rows [tile, 2 tile): the first of chromosome 2 (generator indices far
+    # apart: the planted LD never links the two sets, as on two real chromosomes)
+    far = 5000000
+    ptr, stride = eng.map_rows(0, m)
+    pkg.synth_genotypes_device(SEED + 2, 0, tile, n, 0.0, ptr, stride)
+    pkg.synth_genotypes_device(SEED + 2, far, tile, n, 0.0, ptr + tile * stride, stride)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.load_genotypes_device(0, m, ptr, stride, pkg.LDP_GENO_REF)
+    count_ms = eng.counters()["ms_prepare"]
+    thr = 0.2 * (1.0 - 2.0 ** -44)
+    rows_per_call = 8192
+    eng.r2_unphased_block_hits(thr, tile, 64, 0, tile, capacity=1 << 16)  # warm-up (plan upload, kernel load)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    pairs, kms, hits, products = 0, 0.0, 0, 0
+    for r0 in range(tile, m, rows_per_call):
+        h = eng.r2_unphased_block_hits(thr, r0, min(rows_per_call, m - r0), 0, tile, capacity=1 << 22)
+        c = eng.counters()
+        pairs += c["candidate_pairs"]
+        kms += c["ms_pair_kernel"]
+        products += c["computed_pairs"] // 1024
+        hits += len(h)
+    wall = time.perf_counter() - t1
+    ksteps = (n + 63) // 64
+    row_bytes = ((n + 511) // 512) * 128
+    mfma_tflops = products * ksteps * 65536 * 2.0 / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+    compulsory = m * float(row_bytes)
+    traffic, traffic_src, _ = pmc_traffic(n, m, 0.0, 0.0)
+    res = {"what": "--r2-unphased inter-chr tile set: %d x %d cross-chromosome variant pairs at %d samples (complete data), every pair's r^2 computed, the default "
+                   "--ld-window-r2 0.2 filter applied in the kernel epilogue (ldp_r2_unphased_block_hits, %d rows of second variants per call); rows resident, "
+                   "count pass %.1f ms outside the timed region" % (tile, tile, n, rows_per_call, count_ms),
+           "pairs": int(pairs), "pairs_passing_filter": int(hits), "wall_s": wall, "pairs_per_s_wall": pairs / wall if wall > 0 else None,
+           "kernel_ms": kms, "pairs_per_s_kernel": pairs / (kms * 1e-3) if kms > 0 else None,
+           "roofline": {"bound": "mfma", "achieved": mfma_tflops, "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mfma_tflops / FP4_PEAK_TFLOPS,
+                        "traffic": traffic, "traffic_source": traffic_src,
+                        "traffic_over_compulsory": (traffic / compulsory) if traffic else None,
+                        "mfma_instructions": int(products * ksteps), "block_products": int(products),
+                        "plan_efficiency": pairs / (products * 1024.0) if products else None,
+                        "hbm": {"compulsory_bytes": compulsory, "compulsory_gbs": compulsory / (kms * 1e-3) / 1e9 if kms > 0 else 0.0, "peak_gbs": HBM_PEAK_GBS},
+                        "effective_stream_gbs": pairs * (n / 2.0) / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
+                        "kernel": "pair_mfma_wide_kernel / pair_mfma_kernel with the r^2 epilogue (one product per pair: complete data)"}}
+    eng.close()
+    torch.cuda.empty_cache()
+    # the same command, both binaries end to end, on a slice the reference finishes in seconds: two chromosomes x ref_slice_variants / 2
+    ref_bin = os.path.join(REPO, "oracle", "_ref", "plink2")
+    cli_bin = os.path.join(REPO, "plink-ng_amd", "bin", "plink2-hip")
+    if (not no_cpu) and os.path.exists(ref_bin) and os.path.exists(cli_bin) and ref_slice_variants >= 4:
+        half = ref_slice_variants // 2
+        buf = torch.empty((2 * half, (n + 3) // 4), dtype=torch.uint8, device="cuda")
+        pkg.synth_genotypes_device(SEED + 2, 0, half, n, 0.0, buf.data_ptr(), buf.shape[1])
+        pkg.synth_genotypes_device(SEED + 2, far, half, n, 0.0, buf.data_ptr() + half * buf.shape[1], buf.shape[1])
+        torch.cuda.synchronize()
+        host = buf.cpu().numpy()
+        del buf
+        chr_idx = np.repeat(np.arange(2, dtype=np.uint32), half)
+        bps = np.tile(10000 + 290 * np.arange(half, dtype=np.uint32), 2)
+        tmp = tempfile.mkdtemp(prefix="ldbench4_")
+        try:
+            write_plink1_fileset(os.path.join(tmp, "sample"), host, n, chr_idx, bps)
+            cores = os.cpu_count() or 1
+            walls, outs = {}, {}
+            for name, cmd in (("reference_plink2", [ref_bin, "--bfile", "sample", "--r2-unphased", "inter-chr", "--threads", str(cores), "--out", "ref"]),
+                              ("plink2_hip", [cli_bin, "--bfile", "sample", "--r2-unphased", "inter-chr", "--out", "hip"])):
+                t2 = time.perf_counter()
+                cp = subprocess.run(cmd, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+                walls[name] = time.perf_counter() - t2
+                outs[name] = cp.returncode
+            same = False
+            if outs["reference_plink2"] == 0 and outs["plink2_hip"] == 0:
+                same = open(os.path.join(tmp, "ref.vcor"), "rb").read() == open(os.path.join(tmp, "hip.vcor"), "rb").read()
+            sl_pairs = (2 * half) * (2 * half - 1) // 2
+            res["reference_slice"] = {"variants": 2 * half, "samples": n, "pairs": sl_pairs, "vcor_files_identical": bool(same), "rc": outs,
+                                      "e2e_wall_s": walls, "reference_pairs_per_s": sl_pairs / walls["reference_plink2"], "cores": cores,
+                                      "what": "both binaries, `--r2-unphased inter-chr` (default filter) on two chromosomes x %d variants of the same generator, "
+                                              "byte comparison of the .vcor tables" % half}
+        finally:
+            subprocess.call(["rm", "-rf", tmp])
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=sorted(CONFIGS), default=None, help="default: config2 at one GPU, config3 (the metric's) at several")
+    ap.add_argument("--workload", choices=sorted(CONFIGS), default="config3", help="default: config3's density (the metric's), weak scaling at 1.25M variants per GPU")
     ap.add_argument("--samples", type=int, default=None)
-    ap.add_argument("--variants", type=int, default=None, help="variants of the genome (total with --strong, per GPU with --weak)")
+    ap.add_argument("--variants", type=int, default=None, help="variants of the genome (total with --strong, per GPU otherwise)")
     ap.add_argument("--window-kb", type=float, default=None)
     ap.add_argument("--r2", type=float, default=None)
     ap.add_argument("--spacing", type=int, default=None, help="bp between consecutive variants")
     ap.add_argument("--missing-rate", type=float, default=0.0)
-    ap.add_argument("--strong", action="store_true", help="strong scaling: the genome is fixed, sharded over the ranks (default for config3)")
-    ap.add_argument("--weak", action="store_true", help="weak scaling: --variants per GPU on one genome (default for config2)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: the named configuration's genome in total, sharded over the ranks")
+    ap.add_argument("--weak", action="store_true", help="weak scaling (the default): --variants per GPU on one genome")
     ap.add_argument("--cpu-sample-variants", type=int, default=0, help="0 = 440,000 up to 100k samples, 11,000 beyond")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-legs", action="store_true", help="skip the exhaustive / missing-calls / north-star-shape legs and the ceiling microbenchmarks")
+    ap.add_argument("--no-legs", action="store_true", help="skip the config2 / config5-density / config4-tiles legs and the ceiling microbenchmarks")
     ap.add_argument("--no-cli-compare", action="store_true", help="do not time plink2-hip end-to-end on the CPU-baseline sample files")
-    ap.add_argument("--leg-variants", type=int, default=120000, help="variants of the config3/5-density legs")
+    ap.add_argument("--leg-variants", type=int, default=120000, help="variants of the config5-density leg")
+    ap.add_argument("--tile", type=int, default=65536, help="side of the config4_tiles leg's cross-chromosome tile set")
+    ap.add_argument("--option", action="append", default=[], help="name=value: a per-engine kernel switch (ldp_debug_set_option) for the main workload, for experiments")
     args = ap.parse_args()
 
     import torch
@@ -498,14 +642,21 @@ def main():
     if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    name = args.workload or ("config2" if world == 1 else "config3")
+    name = args.workload
     cfg = dict(CONFIGS[name])
+    strong = args.strong and not args.weak
+    if not strong:
+        cfg["variants"] = PER_GPU_VARIANTS[name]
     for k, v in (("samples", args.samples), ("variants", args.variants), ("window_kb", args.window_kb), ("r2", args.r2), ("spacing", args.spacing)):
         if v is not None:
             cfg[k] = v
-    strong = args.strong or ((name == "config3") and not args.weak)
+    per_gpu_variants = cfg["variants"] if not strong else None
     if not strong:
         cfg["variants"] = cfg["variants"] * world
+    main_options = {}
+    for kv in args.option:
+        k, v = kv.split("=", 1)
+        main_options[k] = float(v)
 
     def sync():
         torch.cuda.synchronize()
@@ -531,7 +682,18 @@ def main():
         sync()
         return time.perf_counter() - t0, ks, removed
 
-    wl = Workload(pkg, torch, cfg, args.missing_rate, rank, world, local_rank)
+    def dtype_of(roofline):
+        return ("fp4 (E2M1: exact -2/0/+2, block scale 1/2) x fp4 -> f32 integer-exact MFMA accumulation + f64 predicate" if roofline["kernel"].startswith("pair_mfma")
+                else "u32 popcount + f64 predicate")
+
+    def stage_ms(cmean, image_bytes):
+        return {"count_pass_codes_kernel": cmean["ms_prepare"], "pair_kernels": cmean["ms_pair_kernel"], "pair_mfma_kernels": cmean["ms_pair_mfma"],
+                "pair_mfma_missing_call_kernels": cmean["ms_pair_mfma_general"], "pair_tiles_kernels_popcount": cmean["ms_pair_fast"] + cmean["ms_pair_general"],
+                "host_replay": cmean["ms_replay"],
+                "note": "the count pass (HBM-bound: reads N/4 bytes per variant, writes only the records) and the pair kernels run back to back; "
+                        "count pass: %.0f GB/s" % ((image_bytes / (cmean["ms_prepare"] * 1e-3) / 1e9) if cmean["ms_prepare"] > 0 else 0.0)}
+
+    wl = Workload(pkg, torch, cfg, args.missing_rate, rank, world, local_rank, main_options)
     elapsed, ks, removed = timed(wl, args.steps, args.warmup)
     ctr = ks[-1]
     removed = distmod.bitmap_to_mask(removed.cpu().numpy() if use_dist else removed, cfg["variants"])
@@ -552,48 +714,46 @@ def main():
         cmean = {k: mean(k) for k in ks[-1]}
         ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
         value = total_pairs * args.steps / elapsed
-        roofline = pair_roofline(cmean, cfg["samples"], wl.local_ct, args.missing_rate, cfg["variants"], cfg["window_kb"])
-        on_matrix_pipe = roofline["kernel"].startswith("pair_mfma")
+        roofline = pair_roofline(cmean, cfg["samples"], wl.local_ct, args.missing_rate, wl.local_ct, cfg["window_kb"])
         out = {
             "metric": "variant-pairs/s (--indep-pairwise, whole job)", "value": value, "unit": "variant-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "fp4 (E2M1: exact -2/0/+2, block scale 1/2) x fp4 -> f32 integer-exact MFMA accumulation + f64 predicate" if on_matrix_pipe
-                     else "u32 popcount + f64 predicate",
-            "data": "synthetic",
+            "dtype": dtype_of(roofline),
+            "data": "synthetic" if wl.resident else "model (synthetic shapes; a rank's share exceeds HBM, so every chromosome of it is a copy of ONE generated chromosome: NOT a measurement "
+                                                    "of the named workload)",
             "config": {"workload": "%s: synthetic %d samples x %d biallelic variants (%s), one genome of 22 autosomes at %d bp spacing, "
                                    "--indep-pairwise %gkb %g, missing rate %g, chromosomes LPT-sharded over %d rank(s); %s" %
-                                   (name, cfg["samples"], cfg["variants"], "total, strong scaling" if strong else "%d per GPU, weak scaling" % (cfg["variants"] // world),
+                                   (name, cfg["samples"], cfg["variants"], "total, strong scaling" if strong else "%d per GPU, weak scaling" % per_gpu_variants,
                                     cfg["spacing"], cfg["window_kb"], cfg["r2"], args.missing_rate, world,
                                     "2-bit rows resident in HBM, counted in place each step (no conversion pass, no second image)" if wl.resident else
                                     "a rank's share (%.0f GB) exceeds HBM: one engine per chromosome, each chromosome's rows copied inside the step from ONE resident chromosome's "
                                     "worth of generated rows (every chromosome of the share holds the same genotypes)" % (wl.image_bytes / 1e9)),
+                       "family": "every --gpus N of this default reports the SAME workload: BASELINE.json configs[2]'s samples / density / window / threshold at %s; at N = 8 "
+                                 "the weak line is configs[2] itself (10M variants)" % ("the metric's 10,000,000 variants in total" if strong else "1,250,000 variants per GPU"),
                        "samples": cfg["samples"], "variants_total": cfg["variants"], "variants_rank0": wl.local_ct, "window_kb": cfg["window_kb"], "r2": cfg["r2"],
                        "subcontigs": len(wl.subs), "candidate_pairs_total": total_pairs, "candidate_pairs_per_rank": per_rank_pairs,
                        "shard_imbalance_max_over_mean": (max(per_rank_pairs) / (total_pairs / world)) if total_pairs else 1.0,
                        "pairs_above_threshold_rank0": ctr["pred_true"], "above_threshold_pairs_consumed_by_replay_rank0": ctr["replay_pairs"],
-                       "variants_removed": int(removed.sum()), "resident": bool(wl.resident)},
+                       "variants_removed": int(removed.sum()), "resident": bool(wl.resident), "image_gb_rank0": wl.image_bytes / 1e9,
+                       "engine_options": main_options},
             "roofline": roofline,
-            "stage_ms": {"count_pass_codes_kernel": mean("ms_prepare"), "pair_kernels": mean("ms_pair_kernel"), "pair_mfma_kernel": mean("ms_pair_mfma"),
-                         "pair_mfma_general_kernel": mean("ms_pair_mfma_general"), "pair_tiles_kernels_popcount": mean("ms_pair_fast") + mean("ms_pair_general"),
-                         "host_replay": mean("ms_replay"),
-                         "note": "the count pass (HBM-bound: reads N/4 bytes per variant, writes only the records) and the pair kernel run back to back; "
-                                 "count pass: %.0f GB/s" % ((wl.image_bytes / (mean("ms_prepare") * 1e-3) / 1e9) if mean("ms_prepare") > 0 else 0.0)},
+            "stage_ms": stage_ms(cmean, wl.image_bytes),
         }
     wl.close()
 
     if rank == 0 and world == 1 and not args.no_legs:
         legs = {}
-        half = max(2, args.steps // 2)
+        half = max(2, min(args.steps, 10) // 2)
 
         def leg(cfg_l, missing, options, steps, multiallelic=None):
             w = Workload(pkg, torch, cfg_l, missing, 0, 1, local_rank, options, multiallelic)
             el, kk, rem = timed(w, steps, 1)
             c = {k: float(np.mean([q[k] for q in kk])) for k in kk[-1]}
             r = pair_roofline(c, cfg_l["samples"], w.local_ct, missing, cfg_l["variants"], cfg_l["window_kb"])
-            res = {"ms_per_step": 1000.0 * el / steps, "count_pass_ms": c["ms_prepare"], "pair_kernels_ms": c["ms_pair_kernel"], "kernel": r["kernel"],
-                   "routes": r["routes"], "pairs_counted_exactly": int(c["sparse_exact_pairs"]), "candidate_pairs": int(c["candidate_pairs"]),
-                   "variants_removed": int(distmod.bitmap_to_mask(rem, cfg_l["variants"]).sum()), "roofline": r}
+            res = {"ms_per_step": 1000.0 * el / steps, "pairs_per_s": c["candidate_pairs"] * steps / el, "count_pass_ms": c["ms_prepare"], "pair_kernels_ms": c["ms_pair_kernel"],
+                   "kernel": r["kernel"], "routes": r["routes"], "pairs_counted_exactly": int(c["sparse_exact_pairs"]), "candidate_pairs": int(c["candidate_pairs"]),
+                   "variants_removed": int(distmod.bitmap_to_mask(rem, cfg_l["variants"]).sum()), "roofline": r, "stage_ms": stage_ms(c, w.image_bytes)}
             if w.multi:
                 eng = w.engines[0][0]
                 ok = True
@@ -604,39 +764,61 @@ def main():
                                        "ms_per_step_in_ldp_load_pgen_records": float(np.mean(w.multi["ms_calls"][1:] or w.multi["ms_calls"])),
                                        "records_match_numpy_collapse": bool(ok),
                                        "what": "variants with two ALT alleles arriving as .pgen records resident in HBM (main track + aux track 1), decoded and "
-                                               "collapsed major-vs-rest on the device inside every step (ldp_load_pgen_records, one call per run of consecutive variants)"}
+                                               "collapsed major-vs-rest on the device inside every step (ldp_load_pgen_records, one call per run of consecutive variants); their "
+                                               "records are checked against a numpy restatement of the collapse here -- the comparison of the collapse with the REFERENCE lives in "
+                                               "tests/test_cli.py::test_cli_multiallelic_collapse_matches_reference and tests/test_pgen_device_decode.py"}
             w.close()
             return res
 
-        # (a) the same step with early termination off: every block product walks every sample
-        legs["exhaustive"] = leg(cfg, args.missing_rate, {"early_exit": 0}, half)
-        legs["exhaustive"]["what"] = "early termination off (ldp_debug_set_option early_exit 0)"
-        # (b) missing calls in every variant: 0.1 % (the complete-data kernel with the interval epilogue) and
-        # 1 % (the six-product kernel)
-        if args.missing_rate == 0.0:
+        # (a) BASELINE.json configs[1] (the narrow-band shape): 50,000 x 1,000,000, 200kb 0.5, with its own roofline, early termination
+        # off, rows with 0.1 % / 1 % missing calls, and the reference on a 440,000-variant sample (both binaries end to end)
+        try:
+            c2 = dict(CONFIGS["config2"])
+            steps2 = max(5, min(args.steps, 20))
+            L = leg(c2, 0.0, {}, steps2)
+            L["what"] = "BASELINE.json configs[1]: %d samples x %d variants at %d bp, --indep-pairwise %gkb %g; rows resident, count pass inside the step" % (
+                c2["samples"], c2["variants"], c2["spacing"], c2["window_kb"], c2["r2"])
+            L["exhaustive"] = {k: v for k, v in leg(c2, 0.0, {"early_exit": 0}, half).items() if k in ("ms_per_step", "pair_kernels_ms", "kernel")}
+            L["exhaustive"]["what"] = "early termination off (ldp_debug_set_option early_exit 0)"
             for rate in (0.001, 0.01):
-                legs["missing_rate_%g" % rate] = leg(cfg, rate, {}, half)
-                legs["missing_rate_%g" % rate]["vs_complete_data_step"] = legs["missing_rate_%g" % rate]["ms_per_step"] / out["ms_per_step"]
-        # (c) the north-star shapes at one GPU: config 3's / config 5's density on a slice of the genome that fits
-        if name == "config2" and args.leg_variants > 0:
-            c3 = dict(CONFIGS["config3"], variants=args.leg_variants)
-            for key, rate in (("config3_density", 0.0), ("config5_density", 0.05)):
-                try:
-                    # config 5: 2 % of the variants are multiallelic (runs of 400 consecutive variants, one ldp_load_pgen_records call each:
-                    # a loader hands over records in batches, and a call costs ~0.8 ms of latency whatever it holds up to a few hundred)
-                    L = leg(c3, rate, {}, 3, None if rate == 0.0 else (max(1, c3["variants"] // 20000), 400))
-                    L["what"] = ("%d samples x %d variants at %d bp, --indep-pairwise %gkb %g, %s; rows resident, count pass inside the step" %
-                                 (c3["samples"], c3["variants"], c3["spacing"], c3["window_kb"], c3["r2"],
-                                  "complete data" if rate == 0.0 else "5 % missing calls in every variant, 2 % of the variants multiallelic (see `multiallelic`; the "
-                                  "reference slice below is the same generator without the second ALT allele)"))
-                    if not args.no_cpu_baseline:
-                        m_slice = args.cpu_sample_variants or 11000
-                        cb = cpu_baseline(pkg, torch, c3["samples"], m_slice, c3["spacing"], c3["window_kb"], c3["r2"], rate, cli_compare=False)
-                        L["reference_slice"] = {k: cb.get(k) for k in ("prune_set_identical_to_hip", "removed", "wall_s", "value", "cores", "sample")}
-                    legs[key] = L
-                except Exception as e:  # pragma: no cover  (e.g. a smaller GPU)
-                    legs[key] = {"error": str(e)[:300]}
-                torch.cuda.empty_cache()
+                M = leg(c2, rate, {}, half)
+                L["missing_rate_%g" % rate] = {k: M[k] for k in ("ms_per_step", "pair_kernels_ms", "kernel", "routes", "pairs_counted_exactly", "variants_removed")}
+                L["missing_rate_%g" % rate]["vs_complete_data_step"] = M["ms_per_step"] / L["ms_per_step"]
+                L["missing_rate_%g" % rate]["mfma"] = M["roofline"]["mfma"]
+            if not args.no_cpu_baseline:
+                L["cpu_baseline"] = cpu_baseline(pkg, torch, c2["samples"], 440000, c2["spacing"], c2["window_kb"], c2["r2"], 0.0, cli_compare=not args.no_cli_compare)
+            legs["config2"] = L
+        except Exception as e:  # pragma: no cover
+            legs["config2"] = {"error": str(e)[:300]}
+        torch.cuda.empty_cache()
+        # (b) config 5's density on a slice: 5 % missing calls in every variant, 2 % of the variants multiallelic (runs of 400 consecutive
+        # variants, one ldp_load_pgen_records call each: a loader hands over records in batches)
+        if args.leg_variants > 0 and name == "config3":
+            c5 = dict(CONFIGS["config3"], variants=args.leg_variants)
+            try:
+                L = leg(c5, 0.05, {}, 3, (max(1, c5["variants"] // 20000), 400))
+                L["what"] = ("%d samples x %d variants at %d bp, --indep-pairwise %gkb %g, 5 %% missing calls in every variant, 2 %% of the variants multiallelic (see "
+                             "`multiallelic`); rows resident, count pass inside the step" % (c5["samples"], c5["variants"], c5["spacing"], c5["window_kb"], c5["r2"]))
+                C = leg(c5, 0.0, {}, 3)
+                L["vs_complete_data_step_of_the_same_slice"] = L["ms_per_step"] / C["ms_per_step"]
+                L["complete_data_step_of_the_same_slice"] = {k: C[k] for k in ("ms_per_step", "pair_kernels_ms", "kernel", "variants_removed")}
+                L["complete_data_step_of_the_same_slice"]["roofline"] = {k: C["roofline"][k] for k in ("bound", "achieved", "frac", "traffic", "traffic_source", "traffic_over_compulsory")}
+                if not args.no_cpu_baseline:
+                    cb = cpu_baseline(pkg, torch, c5["samples"], args.cpu_sample_variants or 11000, c5["spacing"], c5["window_kb"], c5["r2"], 0.05, cli_compare=False)
+                    L["reference_slice"] = {k: cb.get(k) for k in ("prune_set_identical_to_hip", "removed", "wall_s", "value", "cores", "sample")}
+                    L["reference_slice"]["note"] = ("the same generator at 5 % missing calls WITHOUT the second ALT allele: the reference comparison of the multiallelic collapse is "
+                                                    "tests/test_cli.py::test_cli_multiallelic_collapse_matches_reference, not this leg")
+                legs["config5_density"] = L
+            except Exception as e:  # pragma: no cover  (e.g. a smaller GPU)
+                legs["config5_density"] = {"error": str(e)[:300]}
+            torch.cuda.empty_cache()
+        # (c) config 4: the cross-chromosome tile set of --r2-unphased inter-chr
+        if args.tile > 0:
+            try:
+                legs["config4_tiles"] = config4_tiles_leg(pkg, torch, local_rank, CONFIGS["config3"]["samples"], args.tile, 1024, args.no_cpu_baseline)
+            except Exception as e:  # pragma: no cover
+                legs["config4_tiles"] = {"error": str(e)[:300]}
+            torch.cuda.empty_cache()
         out["legs"] = legs
         ceil = measured_ceilings()
         out["roofline"]["measured_ceilings"] = ceil
@@ -649,7 +831,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             m = args.cpu_sample_variants or (440000 if cfg["samples"] <= 100000 else 11000)  # ~2-20 s of reference time either way
             out["cpu_baseline"] = cpu_baseline(pkg, torch, cfg["samples"], m, cfg["spacing"], cfg["window_kb"], cfg["r2"], args.missing_rate,
-                                               cli_compare=not args.no_cli_compare)
+                                               cli_compare=not args.no_cli_compare, full_variants=CONFIGS[name]["variants"])
         else:
             out["cpu_baseline"] = {"value": None, "unit": "variant-pairs/s", "cores": 0, "kind": "reference",
                                    "sample": "measured at N=1 only", **host_description()}

@@ -174,10 +174,22 @@ int ldp_set_shard(ldp_engine* e, uint32_t rank, uint32_t world, uint32_t* owner)
  * ldp_set_shard()'s world and rank.  removed_local: the bitmap ldp_run() produced on this rank; removed_global (out):
  * (variant_ct + 63) / 64 words, identical on every rank.  RCCL is bound at run time (librccl.so.1): LDP_ERR_UNSUPPORTED where it
  * is not installed.  ldp_comm_init_all() / ldp_comm_destroy() wrap ncclCommInitAll / ncclCommDestroy for hosts that drive
- * several devices from one process (plink2-hip --gpus N) and do not want RCCL's header. */
+ * several devices from one process (plink2-hip --gpus N) and do not want RCCL's header.
+ * A rank that cannot enter the collective (bad arguments, no device, allocation failure) calls ncclCommAbort on its communicator
+ * before it returns the error, so that its peers come back from the all-gather with an error instead of waiting for it forever;
+ * after a nonzero return the communicator must not be used or destroyed again.  A host whose rank failed BEFORE the exchange
+ * (ldp_run() returned an error) should not enter it at all -- abort or simply drop the communicators, as plink2-hip does. */
 int ldp_allgather_removed(ldp_engine* e, void* nccl_comm, const uint64_t* removed_local, uint64_t* removed_global);
 int ldp_comm_init_all(int n, const int* devices, void** comms);
 void ldp_comm_destroy(void* comm);
+/* The same exchange in its three steps, for hosts with another transport (MPI, a host-side copy between engines of one process --
+ * plink2-hip where RCCL is absent or refuses the device set): ldp_shard_segment_words() = 64-bit words of one padded segment (the
+ * longest shard's bits, at least one word; the same on every rank); ldp_pack_removed_segment() = this rank's removed bits in shard
+ * order (its owned subcontigs in file order), `segment` holding that many words; ldp_stitch_removed_segments() = world x words
+ * words, rank-major, back into global variant order (removed_global: (variant_ct + 63) / 64 words).  Host-only, no GPU touched. */
+int ldp_shard_segment_words(const ldp_engine* e, uint64_t* words);
+int ldp_pack_removed_segment(const ldp_engine* e, const uint64_t* removed_local, uint64_t* segment);
+int ldp_stitch_removed_segments(const ldp_engine* e, const uint64_t* segments, uint64_t* removed_global);
 /* per-variant window start lo[v] (first candidate partner index) and candidate pair total */
 int ldp_get_band(const ldp_engine* e, uint32_t* lo, uint64_t* candidate_pairs);
 

@@ -97,7 +97,7 @@ CABI_SYMBOLS = [
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_has_dosage", "ldp_pgen_variant_has_dosage", "ldp_pgen_dosage_sums", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
     "ldp_pgen_variant_is_multiallelic", "ldp_pgen_provisional_ref", "ldp_pgen_open_indexed", "ldp_set_r_signed", "ldp_set_variants_vcor_cm", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_subset_samples", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
     "ldp_debug_set_option", "ldp_matrix_pipe_max_founders", "ldp_map_rows", "ldp_release_device", "ldp_debug_wide_plan",
-    "ldp_allgather_removed", "ldp_comm_init_all", "ldp_comm_destroy", "ldp_load_pgen_records", "ldp_pgen_file_bytes", "ldp_pgen_record_index",
+    "ldp_allgather_removed", "ldp_comm_init_all", "ldp_comm_destroy", "ldp_shard_segment_words", "ldp_pack_removed_segment", "ldp_stitch_removed_segments", "ldp_load_pgen_records", "ldp_pgen_file_bytes", "ldp_pgen_record_index",
 ]
 
 
@@ -114,11 +114,34 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=False):
     """Compile the HIP kernels + host runtime into lib/libldprune_hip.so for gfx950 (hipcc cross-compiles
-    without a GPU).  In-tree so the .so travels with the repo snapshot."""
-    deps = _sources() + [os.path.join(CSRC, "ldp_device.h"), os.path.join(CSRC, "ldp_pair_device.h"), os.path.join(CSRC, "ldp_mfma_device.h"), os.path.join(REPO, "include", "ldprune_hip.h")]
-    if force or _stale(LIB_PATH, deps):
-        os.makedirs(LIB_DIR, exist_ok=True)
-        cmd = ["hipcc"] + HIPCC_FLAGS + ["-shared", "-o", LIB_PATH] + _sources()
+    without a GPU).  In-tree so the .so travels with the repo snapshot.  One object per source under lib/_obj/, stale ones
+    recompiled in parallel, then one link."""
+    headers = [os.path.join(CSRC, "ldp_device.h"), os.path.join(CSRC, "ldp_pair_device.h"), os.path.join(CSRC, "ldp_mfma_device.h"),
+               os.path.join(REPO, "include", "ldprune_hip.h"), os.path.join(REPO, "include", "ldprune_hip_debug.h")]
+    headers = [h for h in headers if os.path.exists(h)]
+    if not force and not _stale(LIB_PATH, _sources() + headers):
+        return LIB_PATH  # (a snapshot on the GPU box carries the library but not the objects: nothing to do there)
+    obj_dir = os.path.join(LIB_DIR, "_obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    objs, todo = [], []
+    for src in _sources():
+        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            todo.append((src, obj))
+
+    def compile_one(job):
+        cmd = ["hipcc"] + HIPCC_FLAGS + ["-c", job[0], "-o", job[1]]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    if todo:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1)) as pool:
+            list(pool.map(compile_one, todo))
+    if todo or force or _stale(LIB_PATH, objs):
+        cmd = ["hipcc"] + HIPCC_FLAGS + ["-shared", "-o", LIB_PATH] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -188,6 +211,9 @@ def lib():
     L.ldp_pgen_record_index.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ldp_pgen_rec), u32p]
     L.ldp_allgather_removed.argtypes = [vp, vp, u64p, u64p]
     L.ldp_comm_init_all.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(vp)]
+    L.ldp_shard_segment_words.argtypes = [vp, u64p]
+    L.ldp_pack_removed_segment.argtypes = [vp, u64p, u64p]
+    L.ldp_stitch_removed_segments.argtypes = [vp, u64p, u64p]
     L.ldp_comm_destroy.argtypes = [vp]
     L.ldp_comm_destroy.restype = None
     L.ldp_debug_wide_plan.argtypes = [vp, u32p, u32p, ctypes.c_uint64]
@@ -628,6 +654,26 @@ class LdPruneEngine:
         words = np.ascontiguousarray(removed_bitmap_words, dtype=np.uint64)
         out = np.zeros((self.variant_ct + 63) // 64 + 1, dtype=np.uint64)
         self._ck(self._L.ldp_allgather_removed(self._h, ctypes.c_void_p(comm), _ptr(words, ctypes.c_uint64), _ptr(out, ctypes.c_uint64)))
+        return out
+
+    def segment_words(self):
+        """64-bit words of one padded shard segment (ldp_shard_segment_words)."""
+        w = ctypes.c_uint64()
+        self._ck(self._L.ldp_shard_segment_words(self._h, ctypes.byref(w)))
+        return int(w.value)
+
+    def pack_removed_segment(self, removed_bitmap_words):
+        """This rank's removed bits in shard order (ldp_pack_removed_segment): segment_words() uint64 words."""
+        words = np.ascontiguousarray(removed_bitmap_words, dtype=np.uint64)
+        seg = np.zeros(self.segment_words(), dtype=np.uint64)
+        self._ck(self._L.ldp_pack_removed_segment(self._h, _ptr(words, ctypes.c_uint64), _ptr(seg, ctypes.c_uint64)))
+        return seg
+
+    def stitch_removed_segments(self, segments):
+        """world x segment_words() words, rank-major -> the global removed bitmap (ldp_stitch_removed_segments)."""
+        segs = np.ascontiguousarray(segments, dtype=np.uint64).reshape(-1)
+        out = np.zeros((self.variant_ct + 63) // 64 + 1, dtype=np.uint64)
+        self._ck(self._L.ldp_stitch_removed_segments(self._h, _ptr(segs, ctypes.c_uint64), _ptr(out, ctypes.c_uint64)))
         return out
 
     def release_device(self):

@@ -2702,6 +2702,7 @@ struct Rccl {
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
 };
@@ -2720,6 +2721,7 @@ const Rccl& rccl() {
       r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.lib, "ncclCommUserRank"));
       r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
       r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+      r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.lib, "ncclCommAbort"));
       r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
       r.ok = r.AllGather && r.CommCount && r.CommUserRank && r.CommInitAll && r.CommDestroy;
     }
@@ -2753,63 +2755,60 @@ void ldp_comm_destroy(void* comm) {
   }
 }
 
-int ldp_allgather_removed(ldp_engine* e, void* comm, const uint64_t* removed_local, uint64_t* removed_global) {
-  if (!e) {
-    return LDP_ERR_INVALID;
-  }
-  if (!e->planned || e->matrix_mode || e->band_r2_mode) {
-    return fail(e, LDP_ERR_STATE, "ldp_set_variants() (+ ldp_set_shard) first");
-  }
-  if (!comm || !removed_local || !removed_global) {
-    return fail(e, LDP_ERR_INVALID, "null argument");
-  }
-  const Rccl& R = rccl();
-  if (!R.ok) {
-    return fail(e, LDP_ERR_UNSUPPORTED, "RCCL (librccl.so.1) is not available");
-  }
-  bind_gpu(e);
-  if (!e->gpu_ok) {
-    return fail(e, LDP_ERR_GPU, "no usable HIP device");
-  }
-  ncclComm_t c = static_cast<ncclComm_t>(comm);
-  int count = 0, urank = -1;
-  if ((R.CommCount(c, &count) != ncclSuccess) || (R.CommUserRank(c, &urank) != ncclSuccess)) {
-    return fail(e, LDP_ERR_GPU, "ncclCommCount / ncclCommUserRank failed");
-  }
-  if ((static_cast<uint32_t>(count) != e->world) || (static_cast<uint32_t>(urank) != e->rank)) {
-    return fail(e, LDP_ERR_INVALID, "the communicator's size / rank differ from ldp_set_shard()'s");
-  }
-  // every rank knows every rank's segment: the owned subcontigs in file order (the LPT assignment is deterministic)
-  std::vector<uint64_t> seg_bits(e->world, 0);
+// ---- the exchange in three separable steps: pack (host), transport, stitch (host) ---------------------------------------
+// Every rank knows every rank's segment: its owned subcontigs in file order (the LPT assignment is deterministic).  A segment
+// is padded to the longest one, so that ONE all-gather of equal pieces is the allgatherv.
+namespace {
+uint64_t shard_segment_words(const ldp_engine* e) {
+  std::vector<uint64_t> seg_bits(std::max<uint32_t>(e->world, 1), 0);
   for (const Subcontig& s : e->subs) {
     seg_bits[s.owner] += s.len;
   }
-  const uint64_t words = std::max<uint64_t>((*std::max_element(seg_bits.begin(), seg_bits.end()) + 63) / 64, 1);  // the longest segment: a padded all-gather is the allgatherv
-  std::vector<uint64_t> mine(words, 0);
+  return std::max<uint64_t>((*std::max_element(seg_bits.begin(), seg_bits.end()) + 63) / 64, 1);
+}
+bool shard_ready(const ldp_engine* e) { return e && e->planned && !e->matrix_mode && !e->band_r2_mode; }
+}  // namespace
+
+int ldp_shard_segment_words(const ldp_engine* e, uint64_t* words) {
+  if (!shard_ready(e) || !words) {
+    return e ? LDP_ERR_STATE : LDP_ERR_INVALID;
+  }
+  *words = shard_segment_words(e);
+  return LDP_OK;
+}
+
+int ldp_pack_removed_segment(const ldp_engine* e, const uint64_t* removed_local, uint64_t* segment) {
+  if (!shard_ready(e)) {
+    return e ? LDP_ERR_STATE : LDP_ERR_INVALID;
+  }
+  if (!removed_local || !segment) {
+    return LDP_ERR_INVALID;
+  }
+  const uint64_t words = shard_segment_words(e);
+  std::fill(segment, segment + words, 0ull);
   for (uint32_t l = 0; l < e->local_ct; ++l) {
     const uint32_t g = e->local_to_global[l];
     if ((removed_local[g >> 6] >> (g & 63)) & 1ull) {
-      mine[l >> 6] |= 1ull << (l & 63);
+      segment[l >> 6] |= 1ull << (l & 63);
     }
   }
-  HIP_TRY(e, hipSetDevice(e->device));
-  DevBuf send, recv;
-  HIP_TRY(e, hipMalloc(&send.p, words * sizeof(uint64_t)));
-  HIP_TRY(e, hipMalloc(&recv.p, words * sizeof(uint64_t) * e->world));
-  HIP_TRY(e, hipMemcpyAsync(send.p, mine.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
-  const ncclResult_t nrc = R.AllGather(send.p, recv.p, words, ncclUint64, c, e->stream);
-  if (nrc != ncclSuccess) {
-    return fail(e, LDP_ERR_GPU, std::string("ncclAllGather: ") + (R.GetErrorString ? R.GetErrorString(nrc) : "failed"));
+  return LDP_OK;
+}
+
+// the stitch (plink2_ld.cc:1418-1426, CopyBitarrRange per thread): segment bits -> global variant order
+int ldp_stitch_removed_segments(const ldp_engine* e, const uint64_t* segments, uint64_t* removed_global) {
+  if (!shard_ready(e)) {
+    return e ? LDP_ERR_STATE : LDP_ERR_INVALID;
   }
-  std::vector<uint64_t> all(words * e->world);
-  HIP_TRY(e, hipMemcpyAsync(all.data(), recv.p, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  // the stitch (plink2_ld.cc:1418-1426, CopyBitarrRange per thread): segment bits -> global variant order
+  if (!segments || !removed_global) {
+    return LDP_ERR_INVALID;
+  }
+  const uint64_t words = shard_segment_words(e);
   const size_t gwords = (static_cast<size_t>(e->variant_ct) + 63) / 64;
   std::fill(removed_global, removed_global + gwords, 0ull);
-  std::vector<uint64_t> pos(e->world, 0);
+  std::vector<uint64_t> pos(std::max<uint32_t>(e->world, 1), 0);
   for (const Subcontig& s : e->subs) {
-    const uint64_t* seg = all.data() + static_cast<size_t>(s.owner) * words;
+    const uint64_t* seg = segments + static_cast<size_t>(s.owner) * words;
     uint64_t& p = pos[s.owner];
     for (uint32_t v = 0; v < s.len; ++v, ++p) {
       if ((seg[p >> 6] >> (p & 63)) & 1ull) {
@@ -2819,6 +2818,67 @@ int ldp_allgather_removed(ldp_engine* e, void* comm, const uint64_t* removed_loc
     }
   }
   return LDP_OK;
+}
+
+int ldp_allgather_removed(ldp_engine* e, void* comm, const uint64_t* removed_local, uint64_t* removed_global) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  // A rank that cannot enter the collective must not leave its peers waiting in it: every exit before the ncclAllGather
+  // is enqueued aborts the communicator (ncclCommAbort wakes the other ranks with an error instead of a hang).
+  const Rccl& R = rccl();
+  ncclComm_t c = static_cast<ncclComm_t>(comm);
+  auto leave = [&](int code, const std::string& msg) {
+    if (c && R.ok && R.CommAbort) {
+      (void)R.CommAbort(c);
+    }
+    return fail(e, code, msg);
+  };
+  if (!shard_ready(e)) {
+    return leave(LDP_ERR_STATE, "ldp_set_variants() (+ ldp_set_shard) first");
+  }
+  if (!comm || !removed_local || !removed_global) {
+    return leave(LDP_ERR_INVALID, "null argument");
+  }
+  if (!R.ok) {
+    return fail(e, LDP_ERR_UNSUPPORTED, "RCCL (librccl.so.1) is not available");
+  }
+  bind_gpu(e);
+  if (!e->gpu_ok) {
+    return leave(LDP_ERR_GPU, "no usable HIP device");
+  }
+  int count = 0, urank = -1;
+  if ((R.CommCount(c, &count) != ncclSuccess) || (R.CommUserRank(c, &urank) != ncclSuccess)) {
+    return leave(LDP_ERR_GPU, "ncclCommCount / ncclCommUserRank failed");
+  }
+  if ((static_cast<uint32_t>(count) != e->world) || (static_cast<uint32_t>(urank) != e->rank)) {
+    return leave(LDP_ERR_INVALID, "the communicator's size / rank differ from ldp_set_shard()'s");
+  }
+  const uint64_t words = shard_segment_words(e);
+  std::vector<uint64_t> mine(words, 0);
+  (void)ldp_pack_removed_segment(e, removed_local, mine.data());
+  DevBuf send, recv;
+  hipError_t hrc = hipSetDevice(e->device);
+  if (hrc == hipSuccess) {
+    hrc = hipMalloc(&send.p, words * sizeof(uint64_t));
+  }
+  if (hrc == hipSuccess) {
+    hrc = hipMalloc(&recv.p, words * sizeof(uint64_t) * e->world);
+  }
+  if (hrc == hipSuccess) {
+    hrc = hipMemcpyAsync(send.p, mine.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream);
+  }
+  if (hrc != hipSuccess) {
+    return leave(LDP_ERR_GPU, std::string("setup of the all-gather buffers: ") + hipGetErrorString(hrc));
+  }
+  const ncclResult_t nrc = R.AllGather(send.p, recv.p, words, ncclUint64, c, e->stream);
+  if (nrc != ncclSuccess) {
+    return leave(LDP_ERR_GPU, std::string("ncclAllGather: ") + (R.GetErrorString ? R.GetErrorString(nrc) : "failed"));
+  }
+  std::vector<uint64_t> all(words * e->world);
+  HIP_TRY(e, hipMemcpyAsync(all.data(), recv.p, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return ldp_stitch_removed_segments(e, all.data(), removed_global);
 }
 
 int ldp_get_band(const ldp_engine* e, uint32_t* lo, uint64_t* candidate_pairs) {

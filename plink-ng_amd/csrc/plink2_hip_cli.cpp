@@ -5022,19 +5022,25 @@ int run_prune(Session& S) {
   const double t_tables_done = now_s();
   // One GPU: the engine is created and planned (host work: ldp_create binds the device lazily) while the HIP runtime
   // is still starting; several GPUs: the device count decides how many engines there are, so wait for it first.
-  int world = 1;
+  int world = 1, n_devices = 1;
+  bool alias_devices = false;
   if (A.gpus > 1) {
     join_hip();
     const int ndev = ldp_device_count();
     if (ndev < 1) {
       die(16, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
     }
-    world = std::min(A.gpus, ndev);
+    // LDP_DEBUG_ALIAS_DEVICES=1 (tests, one-GPU boxes): as many engines as --gpus asks for, dealt round-robin onto the devices
+    // there are -- every host-side step of the N-device run (shard plan, per-engine loads, one thread per engine, segment pack /
+    // exchange / stitch) then runs on a single device; RCCL refuses a device twice, so the exchange is the host transport.
+    alias_devices = (getenv("LDP_DEBUG_ALIAS_DEVICES") != nullptr) && (atoi(getenv("LDP_DEBUG_ALIAS_DEVICES")) != 0);
+    n_devices = ndev;
+    world = alias_devices ? A.gpus : std::min(A.gpus, ndev);
   }
   std::vector<ldp_engine*> eng(world, nullptr);
   uint32_t subcontig_ct = 0;
   for (int r = 0; r < world; ++r) {
-    P.device = r;
+    P.device = r % n_devices;
     int rc = ldp_create(&P, &eng[r]);
     if (rc) {
       die(16, "Error: ldp_create failed (%d).\n", rc);
@@ -5425,21 +5431,10 @@ int run_prune(Session& S) {
       const size_t m_words = (static_cast<size_t>(m_ct) + 63) / 64 + 1;
       std::vector<std::vector<uint64_t>> part(world, std::vector<uint64_t>(m_words, 0));
       std::vector<int> rcs(world, 0);
-      // several devices: the shards' results meet in ONE RCCL all-gather of their removed-bit segments (ldp_allgather_removed:
-      // the cross-device form of the stitch at plink2_ld.cc:1418-1426); without RCCL the host ORs the bitmaps
-      std::vector<void*> comms(world, nullptr);
-      std::vector<std::vector<uint64_t>> full;
-      bool use_rccl = false;
-      if (world > 1) {
-        std::vector<int> devs(world);
-        for (int r = 0; r < world; ++r) {
-          devs[r] = r;
-        }
-        use_rccl = (ldp_comm_init_all(world, devs.data(), comms.data()) == 0);
-        if (use_rccl) {
-          full.assign(world, std::vector<uint64_t>(m_words, 0));
-        }
-      }
+      // several devices: every engine prunes its shard on a host thread of its own; the shards' results then meet in ONE RCCL
+      // all-gather of their removed-bit segments (ldp_allgather_removed: the cross-device form of the stitch at
+      // plink2_ld.cc:1418-1426).  Without RCCL -- or with engines that share a device -- the same segments are packed, copied
+      // between the engines by the host and stitched by every rank (ldp_pack_removed_segment / ldp_stitch_removed_segments).
       std::vector<std::thread> th;
       for (int r = 0; r < world; ++r) {
         th.emplace_back([&, r]() {
@@ -5447,33 +5442,73 @@ int run_prune(Session& S) {
             ldp_set_preferred(eng[r], pref_m.data());
           }
           rcs[r] = ldp_run(eng[r], part[r].data());
-          if (use_rccl) {
-            // (every rank enters the collective, also one whose run failed: the others would wait for it forever otherwise)
-            const int arc = ldp_allgather_removed(eng[r], comms[r], part[r].data(), full[r].data());
-            if (!rcs[r]) {
-              rcs[r] = arc;
-            }
-          }
         });
       }
       for (std::thread& t : th) {
         t.join();
       }
-      for (int r = 0; r < world; ++r) {
-        if (comms[r]) {
-          ldp_comm_destroy(comms[r]);
-        }
-      }
+      th.clear();
+      // (a rank whose run failed must not leave the others waiting in a collective: nobody enters it then)
       for (int r = 0; r < world; ++r) {
         if (rcs[r]) {
           die(16, "\nError: %s\n", ldp_last_error(eng[r]));
         }
-        if (!use_rccl) {
-          scatter(part[r], mk);
-        }
       }
-      if (use_rccl) {
-        scatter(full[0], mk);  // (every rank holds the same global bitmap)
+      if (world == 1) {
+        scatter(part[0], mk);
+      } else {
+        std::vector<void*> comms(world, nullptr);
+        std::vector<std::vector<uint64_t>> full(world, std::vector<uint64_t>(m_words, 0));
+        bool use_rccl = false;
+        if (!alias_devices) {
+          std::vector<int> devs(world);
+          for (int r = 0; r < world; ++r) {
+            devs[r] = r;
+          }
+          use_rccl = (ldp_comm_init_all(world, devs.data(), comms.data()) == 0);
+        }
+        if (use_rccl) {
+          for (int r = 0; r < world; ++r) {
+            th.emplace_back([&, r]() { rcs[r] = ldp_allgather_removed(eng[r], comms[r], part[r].data(), full[r].data()); });
+          }
+          for (std::thread& t : th) {
+            t.join();
+          }
+          for (int r = 0; r < world; ++r) {
+            if (rcs[r]) {  // (the failing rank aborted its communicator; the process ends here, nothing is destroyed twice)
+              die(16, "\nError: %s\n", ldp_last_error(eng[r]));
+            }
+          }
+          for (int r = 0; r < world; ++r) {
+            ldp_comm_destroy(comms[r]);
+          }
+        } else {
+          uint64_t seg_words = 0;
+          if (ldp_shard_segment_words(eng[0], &seg_words)) {
+            die(16, "\nError: %s\n", ldp_last_error(eng[0]));
+          }
+          std::vector<uint64_t> segs(static_cast<size_t>(seg_words) * world, 0);
+          for (int r = 0; r < world; ++r) {
+            if (ldp_pack_removed_segment(eng[r], part[r].data(), segs.data() + static_cast<size_t>(r) * seg_words)) {
+              die(16, "\nError: packing the removed bits of shard %d failed.\n", r);
+            }
+          }
+          for (int r = 0; r < world; ++r) {
+            if (ldp_stitch_removed_segments(eng[r], segs.data(), full[r].data())) {
+              die(16, "\nError: stitching the removed bits on shard %d failed.\n", r);
+            }
+          }
+        }
+        for (int r = 1; r < world; ++r) {  // every rank holds the same global bitmap
+          if (memcmp(full[r].data(), full[0].data(), ((static_cast<size_t>(m_ct) + 63) / 64) * sizeof(uint64_t)) != 0) {
+            die(16, "\nError: the shards disagree about the stitched prune bitmap (rank %d).\n", r);
+          }
+        }
+        scatter(full[0], mk);
+        if (A.timing) {
+          logprintf("\n[timing] %d engines on %d device%s, exchange: %s\n", world, std::min(world, n_devices), (std::min(world, n_devices) == 1) ? "" : "s",
+                    use_rccl ? "RCCL all-gather" : "host transport");
+        }
       }
       t_run1 = now_s();
     }

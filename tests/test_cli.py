@@ -361,17 +361,35 @@ def test_inter_chr_filter_and_order_from_oracle_values(cli, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_two_gpus_match_one(gpu_pkg, cli, tmp_path):
-    """`plink2-hip --gpus 2`: subcontigs LPT-sharded over two devices, bitmaps OR-ed; same files as one device.  Needs a box
-    with two visible devices (the gpurun boxes have one: skipped there, runs wherever the driver has a multi-GPU node)."""
-    if gpu_pkg.device_count() < 2:
-        pytest.skip("only %d HIP device(s) visible" % gpu_pkg.device_count())
-    prefix, raw, chr_idx, bps = small_fileset(tmp_path, m=900, n=200, seed=21)
-    one = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "30kb", "0.3", "--out", "one"], str(tmp_path))
-    two = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "30kb", "0.3", "--gpus", "2", "--out", "two"], str(tmp_path))
-    assert one.returncode == 0 and two.returncode == 0, two.stdout
+@pytest.mark.parametrize("engines,fmt,order", [(2, "bfile", 2), (3, "pfile", 2), (8, "bfile", 1), (8, "vpfile", 2)])
+def test_cli_n_engines_match_reference(gpu_pkg, cli, tmp_path, engines, fmt, order):
+    """`plink2-hip --gpus N`: the subcontigs LPT-sharded over N engines (ldp_set_shard), every engine loading from the same file
+    calls, one host thread per engine, and the shards' removed bits packed, exchanged and stitched (plink2_ld.cc:2686-2694 shard,
+    :1418-1426 stitch).  With N devices the exchange is one RCCL all-gather; on a box with fewer, LDP_DEBUG_ALIAS_DEVICES=1 deals
+    the engines onto the devices there are and the host carries the segments (RCCL refuses a device twice): every other step is
+    the N-device run's.  Byte-identical to the reference and to one engine; N = 8 leaves some engines without a subcontig."""
+    assert T.have_ref(), "reference binary oracle/_ref/plink2 must travel with the repo snapshot"
+    prefix, raw, chr_idx, bps = small_fileset(tmp_path, m=1500, n=200, seed=21 + engines, nonfounders=(3 if fmt == "pfile" else 0), chr0=4)
+    src = ["--" + fmt, "d"]
+    if fmt == "vpfile":
+        mk = T.run_ref(["--pfile", "d", "--make-pgen", "--out", "v"], str(tmp_path))
+        assert mk.returncode == 0, mk.stdout
+        src = ["--pfile", "v"]
+    common = src + ["--indep-pairwise", "30kb", "0.3"] + (["--indep-order", "1"] if order == 1 else [])
+    ref = T.run_ref(common + ["--threads", "4", "--out", "ref"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    one = run_cli(cli, common + ["--out", "one"], str(tmp_path))
+    assert one.returncode == 0, one.stdout
+    env = dict(os.environ)
+    if gpu_pkg.device_count() < engines:
+        env["LDP_DEBUG_ALIAS_DEVICES"] = "1"
+    many = subprocess.run([cli] + common + ["--gpus", str(engines), "--timing", "--out", "many"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                          text=True, timeout=600, env=env)
+    assert many.returncode == 0, many.stdout
+    assert "(%d GPUs)" % engines in many.stdout and ("%d engines on" % engines) in many.stdout, many.stdout
     for ext in (".prune.in", ".prune.out"):
-        assert filecmp.cmp(str(tmp_path / ("one" + ext)), str(tmp_path / ("two" + ext)), shallow=False)
+        assert filecmp.cmp(str(tmp_path / ("ref" + ext)), str(tmp_path / ("many" + ext)), shallow=False)
+        assert filecmp.cmp(str(tmp_path / ("one" + ext)), str(tmp_path / ("many" + ext)), shallow=False)
 
 
 def dummy_dosage_fileset(tmp_path, name, n, m, freq, seed):

@@ -57,7 +57,7 @@ def test_bench_step_under_torchrun_initialises_rccl(gpu_pkg, tmp_path):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29577",
-           os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--variants", "60000", "--samples", "20000",
+           os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "config2", "--variants", "60000", "--samples", "20000",
            "--no-cpu-baseline", "--no-legs"]
     cp = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert cp.returncode == 0, cp.stderr[-2000:]
@@ -65,7 +65,7 @@ def test_bench_step_under_torchrun_initialises_rccl(gpu_pkg, tmp_path):
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["config"]["variants_removed"] > 0
     # the same workload without a process group must prune the same variants (the exchange is an identity at one rank)
-    cp2 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "0", "--variants", "60000", "--samples", "20000",
+    cp2 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "0", "--workload", "config2", "--variants", "60000", "--samples", "20000",
                           "--no-cpu-baseline", "--no-legs"], cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert cp2.returncode == 0, cp2.stderr[-2000:]
     j2 = json.loads([ln for ln in cp2.stdout.splitlines() if ln.startswith("{")][-1])
@@ -83,8 +83,10 @@ def test_bench_share_that_does_not_fit_hbm(gpu_pkg):
     assert cp.returncode == 0, cp.stderr[-2000:]
     j = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
     assert j["config"]["resident"] is False and j["value"] > 0
+    assert j["data"].startswith("model")   # a share that does not fit is a model of the workload and the line says so
     assert 0.1 * 44000 < j["config"]["variants_removed"] < 0.9 * 44000
     cp2 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert cp2.returncode == 0, cp2.stderr[-2000:]
     j2 = json.loads([ln for ln in cp2.stdout.splitlines() if ln.startswith("{")][-1])
     assert j2["config"]["resident"] is True and j2["config"]["candidate_pairs_total"] == j["config"]["candidate_pairs_total"]
+    assert j2["data"] == "synthetic" and j2["scaling"] == "weak"

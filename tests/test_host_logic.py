@@ -369,3 +369,46 @@ def test_mfma_plan_covers_every_candidate_pair_once(pkg, m, nchr, seed, window, 
 def test_mfma_plan_covers_a_shard(pkg):
     for rank in range(2):
         _mfma_plan_coverage(pkg, 4000, 6, 9, 30000, 1, True, 300, rank=rank, world=2)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8, 40])
+def test_segment_pack_and_stitch_of_the_c_abi(pkg, world):
+    """The exchange of a multi-device prune in its host steps (ldp_pack_removed_segment / ldp_stitch_removed_segments): each rank
+    packs the removed bits of its own subcontigs in shard order, the padded segments -- whatever carried them -- stitch back to
+    the global bitmap on every rank (plink2_ld.cc:1418-1426).  Against plink_ng_amd.dist's numpy form of the same layout, which is
+    what the gloo / RCCL all_gather of bench.py moves; more ranks than subcontigs leaves empty shards."""
+    import importlib
+    distmod = importlib.import_module("plink_ng_amd.dist")
+    m = 5000
+    rng = np.random.default_rng(world)
+    chr_idx, bps = make_positions(m, 22, 7 + world)
+    engines, owners = [], None
+    for r in range(world):
+        eng = pkg.LdPruneEngine(50, 20000, 1, True, 0.5)
+        eng.set_variants(chr_idx, bps)
+        owners = eng.set_shard(r, world)
+        engines.append(eng)
+    subs = engines[0].subcontigs()
+    covered = np.zeros(m, dtype=bool)   # (a variant alone in its stretch belongs to no subcontig: never pruned, never exchanged)
+    for ln, f0 in subs:
+        covered[f0:f0 + ln] = True
+    truth = (rng.random(m) < 0.4) & covered
+    words = engines[0].segment_words()
+    assert words == max(1, distmod.segment_words(subs, owners, world))
+    segs = np.zeros((world, words), dtype=np.uint64)
+    for r, eng in enumerate(engines):
+        assert eng.segment_words() == words
+        owned = np.zeros(m, dtype=bool)
+        for (ln, f0), o in zip(subs, owners):
+            if o == r:
+                owned[f0:f0 + ln] = True
+        mine = truth & owned
+        bm = np.zeros((m + 63) // 64 + 1, dtype=np.uint64)
+        pb = np.packbits(mine, bitorder="little")
+        bm.view(np.uint8)[:len(pb)] = pb
+        segs[r] = eng.pack_removed_segment(bm)
+        assert np.array_equal(segs[r].view(np.int64), distmod.pack_local_bits(mine, subs, owners, r, words))
+    for eng in engines:
+        full = eng.stitch_removed_segments(segs)
+        assert np.array_equal(distmod.bitmap_to_mask(full, m), truth)
+        eng.close()

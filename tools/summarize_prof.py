@@ -37,10 +37,24 @@ def main():
     out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in pmc.items() if "ldp::" in k}
     n_disp = {k: max(len(v) for v in cs.values()) for k, cs in pmc.items() if "ldp::" in k}  # PMC passes run ONE bench step
     json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
-    samples = int(os.environ.get("LDP_PROF_SAMPLES", "50000"))
-    variants = int(os.environ.get("LDP_PROF_VARIANTS", "1000000"))
-    window_kb = float(os.environ.get("LDP_PROF_WINDOW_KB", "200"))
-    missing_rate = float(os.environ.get("LDP_PROF_MISSING", "0"))
+    # the workload: from the bench line the traced run printed (trace.log), so that the file can never be labelled with another
+    # shape than the one that ran; the kernel sources it ran on: git blob hashes of this snapshot (bench.py replays the traffic only
+    # while they equal the tree's)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    line = None
+    for ln in open(os.path.join(src, "trace.log"), errors="ignore"):
+        if ln.startswith("{") and '"metric"' in ln:
+            line = json.loads(ln)
+    cfgj = (line or {}).get("config", {})
+    samples = int(cfgj.get("samples", os.environ.get("LDP_PROF_SAMPLES", "0")))
+    variants = int(cfgj.get("variants_rank0", os.environ.get("LDP_PROF_VARIANTS", "0")))
+    window_kb = float(cfgj.get("window_kb", os.environ.get("LDP_PROF_WINDOW_KB", "0")))
+    m = None
+    if line:
+        import re
+        m = re.search(r"missing rate ([0-9.e+-]+)", cfgj.get("workload", ""))
+    missing_rate = float(m.group(1).rstrip(",")) if m else float(os.environ.get("LDP_PROF_MISSING", "0"))
     # every pair kernel that did work in the step (a launch can carry the wide-band tiles AND the parallelogram workgroups)
     per_kernel, total_b, total_read, total_write = {}, 0.0, 0.0, 0.0
     for k, cs in out.items():
@@ -61,7 +75,8 @@ def main():
                    "compulsory_bytes_per_step": float(variants) * rows_bytes, "traffic_over_compulsory": total_b / (float(variants) * rows_bytes),
                    "pair_kernels": per_kernel,
                    "note": "sum over the pair kernels of the step of FETCH_SIZE x 1024 x 2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE x 1024",
-                   "tag": tag}, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
+                   "tag": tag, "sources": bench.source_hashes(),
+                   "bench_line_of_the_traced_run": {k: (line or {}).get(k) for k in ("value", "ms_per_step", "steps")}}, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
     print(open(os.path.join(dst, tag + "_kernel_stats.csv")).read())
 
 
