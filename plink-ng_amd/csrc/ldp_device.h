@@ -97,7 +97,7 @@ constexpr int kMfBlock = 32;
 constexpr int kMfMaxRowBlocks = 16;
 constexpr int kMfWaves = 4;
 constexpr int kMfMaxDmaPerWave = (2 * kMfMaxRowBlocks + kMfWaves - 1) / kMfWaves;  // (256-sample stages: two DMA instructions of 64 slots per row-block)
-constexpr uint32_t kMfMaxFounders = 16000000;  // f32 accumulators stay integer-exact
+constexpr uint32_t kMfMaxFounders = 4000000;   // f32 accumulators stay integer-exact: complete rows accumulate sum g_i g_j <= 4 N (ldp_mfma_device.h)
 
 struct MfmaWaveItem {
   int32_t jv;        // first variant of J0 (J1 = jv + 32); < 0: the wave has nothing to do

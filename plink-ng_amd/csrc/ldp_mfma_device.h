@@ -38,6 +38,55 @@ __device__ __forceinline__ mf_v16f mfma_fp4(const Frag& a, const Frag& b, mf_v16
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, kFp4Scale, 0, kFp4Scale);
 }
 
+// ---- complete data: the ALLELE-COUNT coding ---------------------------------------------------------------------------
+// The pair kernels run at the socket's power cap (profiles/r04_power_during_step.txt: 1,330-1,380 W of 1,400 W, the shader clock
+// pulled from 2.4 to ~2.1 GHz), so what an MFMA costs is its energy, and that depends on the operand VALUES: on genotype data
+// tools/energy_probe.hip measures the instruction 8-11 % cheaper with hom-REF = 0 (most products 0 x 0) than with hom-REF = +2
+// (profiles/r04_energy_probe.txt).  A 2-bit code IS an E2M1 value when it sits in the low half of a nibble: 00 -> 0, 01 -> 0.5,
+// 10 -> 1.0 (11 -> 1.5), i.e. g / 2 with g = the count of the coded allele; E8M0 block scale 0x80 = 2 on both operands makes every
+// product g_i g_j.  Even samples: X & 0x33333333; odd samples: (X >> 2) & 0x33333333 -- the same three VALU per 16 samples as the
+// +-2 coding.  For COMPLETE rows x = 1 - g, so the statistic the reference wants (DotprodWords, plink2_ld.cc:235-251) follows
+// exactly from G = sum g_i g_j and the rows' own sums: dot = N - sum g_i - sum g_j + G = G - N + S_i + S_j (S = the row's sum of x
+// in the image's orientation).  Padding samples are coded 11 and add 9 each to every G: a constant of the launch (g_bias below).
+// Rows with missing calls never come here: code 11 would count as 3 (the SPARSE instantiation and the missing-call kernels keep
+// the +-2 coding, where a missing call is 0).  Integer-exact while 4 N + 9 * 511 < 2^24 (kMfMaxFounders).
+constexpr int kFp4ScaleG = static_cast<int>(0x80808080u);
+__device__ __forceinline__ void fp4_g_of_codes(uint32_t c0, uint32_t c1, Frag& f) {
+  f.d[0] = c0 & 0x33333333u;
+  f.d[1] = (c0 >> 2) & 0x33333333u;
+  f.d[2] = c1 & 0x33333333u;
+  f.d[3] = (c1 >> 2) & 0x33333333u;
+}
+__device__ __forceinline__ mf_v16f mfma_fp4g(const Frag& a, const Frag& b, mf_v16f c) {
+  const mf_v8i A = {static_cast<int>(a.d[0]), static_cast<int>(a.d[1]), static_cast<int>(a.d[2]), static_cast<int>(a.d[3]), 0, 0, 0, 0};
+  const mf_v8i B = {static_cast<int>(b.d[0]), static_cast<int>(b.d[1]), static_cast<int>(b.d[2]), static_cast<int>(b.d[3]), 0, 0, 0, 0};
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, kFp4ScaleG, 0, kFp4ScaleG);
+}
+// GC = true: allele-count coding (complete data); false: the +-2 coding (a missing call is 0)
+template <bool GC>
+__device__ __forceinline__ void fp4_expand(uint32_t c0, uint32_t c1, Frag& f) {
+  if constexpr (GC) {
+    fp4_g_of_codes(c0, c1, f);
+  } else {
+    fp4_of_codes(c0, c1, f);
+  }
+}
+template <bool GC>
+__device__ __forceinline__ mf_v16f mfma_pair(const Frag& a, const Frag& b, mf_v16f c) {
+  if constexpr (GC) {
+    return mfma_fp4g(a, b, c);
+  } else {
+    return mfma_fp4(a, b, c);
+  }
+}
+// what a launch subtracts from G: N for the shift x = 1 - g, 9 per padding sample of a row (rows are whole 512-sample chunks)
+__device__ __forceinline__ int32_t g_bias_of(uint32_t founder_ct) {
+  const uint32_t padded = ((founder_ct + 511u) / 512u) * 512u;
+  return static_cast<int32_t>(founder_ct + 9u * (padded - founder_ct));
+}
+// a record's sum of x in the IMAGE's orientation (the record itself is in major-allele orientation; flags bit 0 = they differ)
+__device__ __forceinline__ int32_t sum_img_of(const ldp_variant_rec& r) { return (r.flags & 1u) ? -r.sum : r.sum; }
+
 typedef uint32_t mf_u4 __attribute__((ext_vector_type(4)));  // (a native vector: usable as an inline-asm operand)
 
 // ---- geometry of a stage: four k-steps = 256 samples = kCodeStageBytes contiguous bytes of a row ---------------------

@@ -52,7 +52,7 @@ __device__ __forceinline__ void kstep_dwords(const mf_u4& H, const mf_u4& R, int
 // only two V blocks' raw dwords are live next to the 128 accumulators.  On the diagonal (V3 = J0, V4 = J1) the last
 // two blocks take the J fragments instead of reading and expanding the same rows again; the MFMAs themselves are the
 // same instructions either way (a branch around them costs a register copy of every accumulator it touches).
-template <int KS, bool ALL>
+template <int KS, bool ALL, bool GC>
 __device__ __forceinline__ void mfma_stage(const mf_u4* __restrict__ st4, const uint32_t (&slot_off)[7], uint32_t oH, uint32_t oR, uint32_t h, uint32_t need,
                                            uint32_t live, bool diag, mf_v16f (&acc)[8]) {
   // ALL: every product is live and no block is aliased (the common state before the first checkpoint of a wide band):
@@ -75,7 +75,7 @@ __device__ __forceinline__ void mfma_stage(const mf_u4* __restrict__ st4, const 
     for (int ks = 0; ks < KS; ++ks) {
       uint32_t hd, rd;
       kstep_dwords<KS>(H, R, ks, h, &hd, &rd);
-      fp4_of_codes(hd, rd, fj0[ks]);
+      fp4_expand<GC>(hd, rd, fj0[ks]);
     }
   }
   if (need & 2u) {
@@ -85,7 +85,7 @@ __device__ __forceinline__ void mfma_stage(const mf_u4* __restrict__ st4, const 
     for (int ks = 0; ks < KS; ++ks) {
       uint32_t hd, rd;
       kstep_dwords<KS>(H, R, ks, h, &hd, &rd);
-      fp4_of_codes(hd, rd, fj1[ks]);
+      fp4_expand<GC>(hd, rd, fj1[ks]);
     }
   }
   // rows of C = first variant (A operand: a V block), columns = second variant (B operand: a J block)
@@ -105,10 +105,10 @@ __device__ __forceinline__ void mfma_stage(const mf_u4* __restrict__ st4, const 
       } else {                                                                             \
         uint32_t hd, rd;                                                                   \
         kstep_dwords<KS>(vH[B], vR[B], ks, h, &hd, &rd);                                   \
-        fp4_of_codes(hd, rd, fv);                                                          \
+        fp4_expand<GC>(hd, rd, fv);                                                          \
       }                                                                                    \
-      if ((P0 >= 0) && (live & (1u << (P0 & 7)))) acc[P0 & 7] = mfma_fp4(fv, fj0[ks], acc[P0 & 7]); \
-      if ((P1 >= 0) && (live & (1u << (P1 & 7)))) acc[P1 & 7] = mfma_fp4(fv, fj1[ks], acc[P1 & 7]); \
+      if ((P0 >= 0) && (live & (1u << (P0 & 7)))) acc[P0 & 7] = mfma_pair<GC>(fv, fj0[ks], acc[P0 & 7]); \
+      if ((P1 >= 0) && (live & (1u << (P1 & 7)))) acc[P1 & 7] = mfma_pair<GC>(fv, fj1[ks], acc[P1 & 7]); \
     }                                                                                      \
   }
   LDP_MF_VBLOCK(2, 0, 0x01u, 0, -1, -1)
@@ -126,7 +126,7 @@ __device__ __forceinline__ void mfma_stage(const mf_u4* __restrict__ st4, const 
 // Here a wave computes all eight products while one of them is live and nothing once none is; products that hold no candidate
 // pair accumulate numbers nobody reads (their row-blocks may not even be staged: the read then hits some other block's rows).
 // MFMAs on one accumulator never follow each other directly: V0's single product alternates with V4's.
-template <int KS>
+template <int KS, bool GC>
 __device__ __forceinline__ void mfma_stage_diag(const mf_u4* __restrict__ st4, const uint32_t (&slot_off)[7], uint32_t oH, uint32_t oR, mf_v16f (&acc)[8]) {
   mf_u4 jH0 = st4[slot_off[0] + oH], jR0 = st4[slot_off[0] + oR];
   mf_u4 jH1 = st4[slot_off[1] + oH], jR1 = st4[slot_off[1] + oR];
@@ -138,38 +138,38 @@ __device__ __forceinline__ void mfma_stage_diag(const mf_u4* __restrict__ st4, c
   Frag fj0[KS], fj1[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    fp4_of_codes(jH0[ks], jR0[ks], fj0[ks]);
-    fp4_of_codes(jH1[ks], jR1[ks], fj1[ks]);
+    fp4_expand<GC>(jH0[ks], jR0[ks], fj0[ks]);
+    fp4_expand<GC>(jH1[ks], jR1[ks], fj1[ks]);
   }
   // rows of C = first variant (A operand: a V block), columns = second variant (B operand: a J block)
   opaque(vH0, vR0);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     Frag fv;
-    fp4_of_codes(vH0[ks], vR0[ks], fv);
-    acc[0] = mfma_fp4(fv, fj0[ks], acc[0]);           // (J0, V0)
-    acc[7] = mfma_fp4(fj1[ks], fj1[ks], acc[7]);      // (J1, V4 = J1)
+    fp4_expand<GC>(vH0[ks], vR0[ks], fv);
+    acc[0] = mfma_pair<GC>(fv, fj0[ks], acc[0]);           // (J0, V0)
+    acc[7] = mfma_pair<GC>(fj1[ks], fj1[ks], acc[7]);      // (J1, V4 = J1)
   }
   opaque(vH1, vR1);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     Frag fv;
-    fp4_of_codes(vH1[ks], vR1[ks], fv);
-    acc[1] = mfma_fp4(fv, fj0[ks], acc[1]);           // (J0, V1)
-    acc[4] = mfma_fp4(fv, fj1[ks], acc[4]);           // (J1, V1)
+    fp4_expand<GC>(vH1[ks], vR1[ks], fv);
+    acc[1] = mfma_pair<GC>(fv, fj0[ks], acc[1]);           // (J0, V1)
+    acc[4] = mfma_pair<GC>(fv, fj1[ks], acc[4]);           // (J1, V1)
   }
   opaque(vH2, vR2);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     Frag fv;
-    fp4_of_codes(vH2[ks], vR2[ks], fv);
-    acc[2] = mfma_fp4(fv, fj0[ks], acc[2]);           // (J0, V2)
-    acc[5] = mfma_fp4(fv, fj1[ks], acc[5]);           // (J1, V2)
+    fp4_expand<GC>(vH2[ks], vR2[ks], fv);
+    acc[2] = mfma_pair<GC>(fv, fj0[ks], acc[2]);           // (J0, V2)
+    acc[5] = mfma_pair<GC>(fv, fj1[ks], acc[5]);           // (J1, V2)
   }
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    acc[3] = mfma_fp4(fj0[ks], fj0[ks], acc[3]);      // (J0, V3 = J0)
-    acc[6] = mfma_fp4(fj0[ks], fj1[ks], acc[6]);      // (J1, V3 = J0)
+    acc[3] = mfma_pair<GC>(fj0[ks], fj0[ks], acc[3]);      // (J0, V3 = J0)
+    acc[6] = mfma_pair<GC>(fj0[ks], fj1[ks], acc[6]);      // (J1, V3 = J0)
   }
 }
 
@@ -178,7 +178,7 @@ __device__ __forceinline__ void mfma_stage_diag(const mf_u4* __restrict__ st4, c
 // (J0, V2) (J0, J0) (J1, J0) (J1, J1), three row-block reads and sixteen MFMAs per stage instead of five and thirty-two, and the
 // workgroup stops fetching V0 / V1 blocks nobody reads any more.
 constexpr uint32_t kDiagFar = 0x33u, kDiagNear = 0xccu;
-template <int KS>
+template <int KS, bool GC>
 __device__ __forceinline__ void mfma_stage_near(const mf_u4* __restrict__ st4, const uint32_t (&slot_off)[7], uint32_t oH, uint32_t oR, mf_v16f (&acc)[8]) {
   mf_u4 jH0 = st4[slot_off[0] + oH], jR0 = st4[slot_off[0] + oR];
   mf_u4 jH1 = st4[slot_off[1] + oH], jR1 = st4[slot_off[1] + oR];
@@ -189,13 +189,13 @@ __device__ __forceinline__ void mfma_stage_near(const mf_u4* __restrict__ st4, c
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     Frag f0, f1, fv;
-    fp4_of_codes(jH0[ks], jR0[ks], f0);
-    fp4_of_codes(jH1[ks], jR1[ks], f1);
-    fp4_of_codes(vH2[ks], vR2[ks], fv);
-    acc[2] = mfma_fp4(fv, f0, acc[2]);   // (J0, V2)
-    acc[3] = mfma_fp4(f0, f0, acc[3]);   // (J0, V3 = J0)
-    acc[6] = mfma_fp4(f0, f1, acc[6]);   // (J1, V3 = J0)
-    acc[7] = mfma_fp4(f1, f1, acc[7]);   // (J1, V4 = J1)
+    fp4_expand<GC>(jH0[ks], jR0[ks], f0);
+    fp4_expand<GC>(jH1[ks], jR1[ks], f1);
+    fp4_expand<GC>(vH2[ks], vR2[ks], fv);
+    acc[2] = mfma_pair<GC>(fv, f0, acc[2]);   // (J0, V2)
+    acc[3] = mfma_pair<GC>(f0, f0, acc[3]);   // (J0, V3 = J0)
+    acc[6] = mfma_pair<GC>(f0, f1, acc[6]);   // (J1, V3 = J0)
+    acc[7] = mfma_pair<GC>(f1, f1, acc[7]);   // (J1, V4 = J1)
   }
 }
 
@@ -389,6 +389,13 @@ __device__ __forceinline__ uint32_t sparse_round(const PairKernelArgs& A, const 
 template <int KS, bool SPARSE, bool DIAGFORM>
 __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelArgs A) {
   using G = StageGeom<KS>;
+  // complete data: the allele-count coding (ldp_mfma_device.h), the accumulators hold G = sum g_i g_j; the SPARSE instantiation (rows
+  // with a few missing calls) keeps the +-2 coding, where a missing call contributes 0 and the accumulators hold the dot product
+  // (The masked instantiation <., false, false> -- bands of 4-11 row-blocks, ragged workgroups, the windowed r^2 plans -- keeps the
+  // +-2 coding as well: it sits at 254 registers, and with the checkpoint's conversion beside its branches hipcc parks an accumulator
+  // in scratch INSIDE the stage loop, whose reload drains the DMA ring every k-step; tests/test_kernel_isa.py.)
+  constexpr bool GC = (!SPARSE) && DIAGFORM;
+  const int32_t g_bias = g_bias_of(A.founder_ct);
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_src_off[kMfMaxDmaPerWave * kMfWaves * 64];
   __shared__ uint32_t s_need[kMfWaves];
@@ -571,7 +578,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
       const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * stage_dwords);
       read_buf = (read_buf + 1 == stages) ? 0 : read_buf + 1;
       if (ALL || live) {
-        mfma_stage<KS, ALL>(st4, slot_off, oH, oR, h, need, live, diag, acc);
+        mfma_stage<KS, ALL, GC>(st4, slot_off, oH, oR, h, need, live, diag, acc);
       }
     }
   };
@@ -594,12 +601,12 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
       if (live & kDiagFar) {
         for (uint32_t k2 = kc; k2 < kc_end; ++k2) {
           const mf_u4* __restrict__ st4 = advance(k2);
-          mfma_stage_diag<KS>(st4, slot_off, oH, oR, acc);
+          mfma_stage_diag<KS, GC>(st4, slot_off, oH, oR, acc);
         }
       } else if (live) {
         for (uint32_t k2 = kc; k2 < kc_end; ++k2) {
           const mf_u4* __restrict__ st4 = advance(k2);
-          mfma_stage_near<KS>(st4, slot_off, oH, oR, acc);
+          mfma_stage_near<KS, GC>(st4, slot_off, oH, oR, acc);
         }
       } else {
         for (uint32_t k2 = kc; k2 < kc_end; ++k2) {
@@ -638,6 +645,20 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
     }
     __syncthreads();  // (drains the DMA: the slots are in LDS)
     const cp_slot* __restrict__ cpl = reinterpret_cast<const cp_slot*>(lds + kMfCpScratchDwords);  // [row-block slot][row][2]
+    // GC: the accumulators hold G_P = sum over the samples visited of g_i g_j; the partial dot product of x = 1 - g is
+    // G_P - n_P + sP_i + sP_j with sP = the row's sum of x over the samples visited, an INTEGER: S - s_R, where s_R is
+    // a * sqrt(n_R / N) to the nearest integer (cp_slot: a = s_R * sqrt(N / n_R) as the count pass rounded it; n_P samples visited,
+    // no padding among them: a checkpoint sits in front of the last k-chunk).  One integer per staged row, behind the slots.
+    int32_t* __restrict__ sp = reinterpret_cast<int32_t*>(lds + kMfCpScratchDwords + kMfMaxRowBlocks * kMfBlock * 8);
+    const int32_t cp_seen = static_cast<int32_t>(kc * G::kStageSamples);
+    if constexpr (GC) {
+      const double n_all = static_cast<double>(A.founder_ct);
+      const double kappa = sqrt(((static_cast<double>(cp_seen) < n_all) ? (n_all - static_cast<double>(cp_seen)) : 1.0) / n_all);
+      for (uint32_t q = tid; q < n_rb * kMfBlock; q += kMfWaves * 64) {
+        sp[q] = static_cast<int32_t>(cpl[2 * q + 1].a) - static_cast<int32_t>(rint(cpl[2 * q].a * kappa));
+      }
+      __syncthreads();
+    }
     if (live) {
       uint32_t keep = 0;
       uint32_t* cp_epi = lds + wave * kMfCpWaveDwords;  // two products per round
@@ -661,6 +682,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
         const uint32_t jslot = (slots_packed >> (4 * q)) & 15u;
         const cp_slot cj = cpl[(jslot * kMfBlock + r) * 2];
         const cp_slot gj = cpl[(jslot * kMfBlock + r) * 2 + 1];
+        const int32_t tj = GC ? (sp[jslot * kMfBlock + r] - cp_seen) : 0;
 #pragma unroll 1
         for (uint32_t pl = 0; pl < 2; ++pl) {
           const uint32_t p = 2 * round + pl;
@@ -679,7 +701,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
               const cp_slot ci = cpl[(vslot * kMfBlock + row) * 2];
               const cp_slot gi = cpl[(vslot * kMfBlock + row) * 2 + 1];
               // |N dot - S_i S_j| <= |c0| + B, see pair_hopeless() in ldp_pair_device.h (dot_p is the partial dot product)
-              const double dot_p = static_cast<double>(static_cast<int32_t>(cp_epi[(pl * 16 + g) * 64 + lane]));
+              const double dot_p = static_cast<double>(static_cast<int32_t>(cp_epi[(pl * 16 + g) * 64 + lane]) + (GC ? (tj + sp[vslot * kMfBlock + row]) : 0));
               const double c0 = fma(static_cast<double>(A.founder_ct), dot_p, fma(ci.a, cj.a, -(gi.a * gj.a)));
               const double bound = fabs(c0) + fma(ci.b, cj.b, 1.0);
               hopeless = hopeless && (bound < gi.b * gj.b);
@@ -790,6 +812,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
         const int32_t sum_j = A.recs[j].sum;
         const uint32_t ssq_j = A.recs[j].ssq;
         const uint32_t flags_j = A.recs[j].flags;
+        const int32_t sum_img_j = (flags_j & 1u) ? -sum_j : sum_j;
 #pragma unroll 1
         for (uint32_t pl = 0; pl < 4; ++pl) {
           if (!(live & (1u << (4 * round + pl)))) {
@@ -805,7 +828,10 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
             const uint32_t i = static_cast<uint32_t>(i64);
             const ldp_variant_rec ri = A.recs[i];
             ldp_pair_stats_t ps;
-            const int32_t dot_img = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]);
+            int32_t dot_img = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]);
+            if constexpr (GC) {
+              dot_img += sum_img_of(ri) + sum_img_j - g_bias;  // G -> the dot product of x = 1 - g (ldp_mfma_device.h)
+            }
             ps.dot = ((ri.flags ^ flags_j) & 1u) ? -dot_img : dot_img;  // the image's orientation -> the records' (major allele)
             ps.nm = A.founder_ct;
             ps.sum1 = ri.sum;

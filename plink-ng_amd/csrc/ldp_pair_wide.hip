@@ -66,7 +66,7 @@ __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const 
     opaque(H, R);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      fp4_of_codes(H[ks], R[ks], fj0[ks]);
+      fp4_expand<true>(H[ks], R[ks], fj0[ks]);
     }
   }
   {
@@ -74,7 +74,7 @@ __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const 
     opaque(H, R);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      fp4_of_codes(H[ks], R[ks], fj1[ks]);
+      fp4_expand<true>(H[ks], R[ks], fj1[ks]);
     }
   }
   // rows of C = first variant (A operand: a V block), columns = second variant (B operand: a J block)
@@ -87,9 +87,9 @@ __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const 
   opaque(vH[B], vR[B]);                                        \
   _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {           \
     Frag fv;                                                   \
-    fp4_of_codes(vH[B][ks], vR[B][ks], fv);                    \
-    acc[b] = mfma_fp4(fv, fj0[ks], acc[b]);                    \
-    acc[4 + (b)] = mfma_fp4(fv, fj1[ks], acc[4 + (b)]);        \
+    fp4_expand<true>(vH[B][ks], vR[B][ks], fv);                    \
+    acc[b] = mfma_pair<true>(fv, fj0[ks], acc[b]);                    \
+    acc[4 + (b)] = mfma_pair<true>(fv, fj1[ks], acc[4 + (b)]);        \
   }
   LDP_WD_VBLOCK(0, 0)
   LDP_WD_VBLOCK(1, 1)
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
   const uint32_t mask_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tile->mask));
   const uint32_t mask_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tile->mask >> 32));
   const bool diag = (jv0 == vv0);
+  const int32_t g_bias = g_bias_of(A.founder_ct);
   const uint32_t row_bytes = static_cast<uint32_t>(A.code_row_bytes);
   const uint32_t n_stages = (A.founder_ct + kWdStageSamples - 1) / kWdStageSamples;  // (the image's rows are whole stages long: ldp_device.h)
   const uint32_t stage_dwords = kWdStageDwords;
@@ -286,6 +287,20 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
     }
     __syncthreads();  // (drains the DMA: the slots are in LDS)
     const cp_slot* __restrict__ cpl = reinterpret_cast<const cp_slot*>(lds + kWdCpScratchDwords);  // [row-block slot][row][2]
+    // allele-count coding (ldp_mfma_device.h): the accumulators hold G_P = sum over the samples visited of g_i g_j; the partial dot
+    // product of x = 1 - g is G_P - n_P + sP_i + sP_j with sP = the row's sum of x over the samples visited, an INTEGER: S - s_R,
+    // where s_R is a * sqrt(n_R / N) to the nearest integer (cp_slot: a = s_R * sqrt(N / n_R) as the count pass rounded it; n_P
+    // samples visited, no padding among them: a checkpoint sits in front of the last k-chunk).  One integer per staged row, behind the slots.
+    int32_t* __restrict__ sp = reinterpret_cast<int32_t*>(lds + kWdCpScratchDwords + kWdRowBlocks * kMfBlock * 8);
+    const int32_t cp_seen = static_cast<int32_t>(kc * kWdStageSamples);
+    {
+      const double n_all = static_cast<double>(A.founder_ct);
+      const double kappa = sqrt(((static_cast<double>(cp_seen) < n_all) ? (n_all - static_cast<double>(cp_seen)) : 1.0) / n_all);
+      for (uint32_t q = tid; q < kWdRowBlocks * kMfBlock; q += kWdWaves * 64) {
+        sp[q] = static_cast<int32_t>(cpl[2 * q + 1].a) - static_cast<int32_t>(rint(cpl[2 * q].a * kappa));
+      }
+      __syncthreads();
+    }
     if (live) {
       uint32_t keep = 0;
       uint32_t* cp_epi = lds + wave * kWdCpWaveDwords;  // two products per round
@@ -309,6 +324,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
         const uint32_t jslot = a0 + q;
         const cp_slot cj = cpl[(jslot * kMfBlock + r) * 2];
         const cp_slot gj = cpl[(jslot * kMfBlock + r) * 2 + 1];
+        const int32_t tj = sp[jslot * kMfBlock + r] - cp_seen;
 #pragma unroll 1
         for (uint32_t pl = 0; pl < 2; ++pl) {
           const uint32_t p = 2 * round + pl;
@@ -326,7 +342,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
               const cp_slot ci = cpl[(vslot * kMfBlock + row) * 2];
               const cp_slot gi = cpl[(vslot * kMfBlock + row) * 2 + 1];
               // |N dot - S_i S_j| <= |c0| + B, see pair_hopeless() in ldp_pair_device.h (dot_p is the partial dot product)
-              const double dot_p = static_cast<double>(static_cast<int32_t>(cp_epi[(pl * 16 + g) * 64 + lane]));
+              const double dot_p = static_cast<double>(static_cast<int32_t>(cp_epi[(pl * 16 + g) * 64 + lane]) + tj + sp[vslot * kMfBlock + row]);
               const double c0 = fma(static_cast<double>(A.founder_ct), dot_p, fma(ci.a, cj.a, -(gi.a * gj.a)));
               const double bound = fabs(c0) + fma(ci.b, cj.b, 1.0);
               hopeless = hopeless && (bound < gi.b * gj.b);
@@ -408,6 +424,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
         const int32_t sum_j = A.recs[j].sum;
         const uint32_t ssq_j = A.recs[j].ssq;
         const uint32_t flags_j = A.recs[j].flags;
+        const int32_t sum_img_j = (flags_j & 1u) ? -sum_j : sum_j;
 #pragma unroll 1
         for (uint32_t pl = 0; pl < 4; ++pl) {
           if (!(live & (1u << (4 * round + pl)))) {
@@ -423,7 +440,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
             const uint32_t i = static_cast<uint32_t>(i64);
             const ldp_variant_rec ri = A.recs[i];
             ldp_pair_stats_t ps;
-            const int32_t dot_img = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]);
+            const int32_t dot_img = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]) + sum_img_of(ri) + sum_img_j - g_bias;  // G -> dot of x = 1 - g
             ps.dot = ((ri.flags ^ flags_j) & 1u) ? -dot_img : dot_img;  // the image's orientation -> the records' (major allele)
             ps.nm = A.founder_ct;
             ps.sum1 = ri.sum;

@@ -61,7 +61,10 @@ def test_wide_band_kernel_has_one_branch_free_stage_loop_and_no_scratch(tmp_path
     assert len(mf) == 64                       # one copy of the stage body: two half-stages of 32
     body = lines[mf[0]:mf[-1] + 1]
     assert not any(("s_cbranch" in ln) or ("scratch_" in ln) or ("v_accvgpr" in ln) for ln in body)
-    assert sum("v_bitop3_b32" in ln for ln in lines[mf[0] - 60:mf[-1]]) == 192  # 2 half-stages x 6 row-blocks x 4 k-steps x 4 dwords, one operation each
+    # the allele-count expansion (ldp_mfma_device.h): 2 half-stages x 6 row-blocks x 4 k-steps x 4 fragment dwords, one v_and each, and a
+    # shift for every second one (the odd samples of a code dword) -- three VALU per 16 samples
+    assert sum(("v_and_b32" in ln) and ("0x33333333" in ln) for ln in lines[mf[0] - 80:mf[-1]]) == 192
+    assert sum("v_lshrrev_b32" in ln for ln in lines[mf[0] - 80:mf[-1]]) == 96
     for k, ln in enumerate(lines):
         if "ds_read_b128" in ln:
             before = [x for x in lines[max(0, k - 6):k] if not x.strip().startswith(";")]
