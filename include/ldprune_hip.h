@@ -177,7 +177,7 @@ int ldp_set_shard(ldp_engine* e, uint32_t rank, uint32_t world, uint32_t* owner)
  * several devices from one process (plink2-hip --gpus N) and do not want RCCL's header.
  * A rank that cannot enter the collective (bad arguments, no device, allocation failure) calls ncclCommAbort on its communicator
  * before it returns the error, so that its peers come back from the all-gather with an error instead of waiting for it forever;
- * after a nonzero return the communicator must not be used or destroyed again.  A host whose rank failed BEFORE the exchange
+ * after a nonzero return the communicator is gone: do not use it again (ldp_comm_destroy() on it is a harmless no-op).  A host whose rank failed BEFORE the exchange
  * (ldp_run() returned an error) should not enter it at all -- abort or simply drop the communicators, as plink2-hip does. */
 int ldp_allgather_removed(ldp_engine* e, void* nccl_comm, const uint64_t* removed_local, uint64_t* removed_global);
 int ldp_comm_init_all(int n, const int* devices, void** comms);

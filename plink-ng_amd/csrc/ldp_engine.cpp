@@ -17,6 +17,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -717,6 +719,10 @@ void plan_mfma_generic(const std::vector<std::pair<uint32_t, uint32_t>>& runs, c
       const int32_t max_reach = reach.empty() ? -1 : *std::max_element(reach.begin(), reach.end());
       wide_run = (max_reach >= static_cast<int32_t>(wide_min_reach));
     }
+    const auto block_wanted = [&](uint32_t vblock) {  // does row-block `vblock` of the run hold a wanted first variant?
+      const uint64_t v0 = static_cast<uint64_t>(sfirst) + static_cast<uint64_t>(kMfBlock) * vblock;
+      return (v0 < i_end) && (v0 + kMfBlock > i_first);
+    };
     if (wide_run) {
       const uint32_t nt = (nb + kWdTile - 1) / kWdTile;
       for (uint32_t T = 0; T < nt; ++T) {
@@ -742,7 +748,7 @@ void plan_mfma_generic(const std::vector<std::pair<uint32_t, uint32_t>>& runs, c
             }
             for (uint32_t b = 0; b < static_cast<uint32_t>(kWdTile); ++b) {
               const uint32_t vb = static_cast<uint32_t>(t) * kWdTile + b;
-              if ((vb <= ja) && (static_cast<int32_t>(ja - vb) <= reach_of(ja))) {
+              if ((vb <= ja) && (static_cast<int32_t>(ja - vb) <= reach_of(ja)) && block_wanted(vb)) {
                 tl.mask |= 1ull << (8 * a + b);
               }
             }
@@ -763,10 +769,7 @@ void plan_mfma_generic(const std::vector<std::pair<uint32_t, uint32_t>>& runs, c
       w.blocks[1] = sfirst + kMfBlock * (a + 1);
       for (int k = 0; k < 4; ++k) {
         const int32_t off = static_cast<int32_t>(4 * p + 3) - k;  // block distance of both (J0, V_k) and (J1, V_{k+1})
-        const auto v_wanted = [&](uint32_t vblock) {  // does row-block `vblock` of the run hold a wanted first variant?
-          const uint64_t v0 = static_cast<uint64_t>(sfirst) + static_cast<uint64_t>(kMfBlock) * vblock;
-          return (v0 < i_end) && (v0 + kMfBlock > i_first);
-        };
+        const auto& v_wanted = block_wanted;
         if ((reach_of(a) >= off) && (static_cast<int32_t>(a) >= off) && v_wanted(a - static_cast<uint32_t>(off))) {
           w.mask |= static_cast<uint8_t>(1u << k);
           w.used |= static_cast<uint8_t>(1u | (1u << (2 + k)));
@@ -2234,10 +2237,15 @@ namespace {
 // upload the plan and attach it to the launch.  The r^2 epilogue is emit_pair()'s, shared with the popcount kernels.
 bool r2_on_matrix_pipe(const ldp_engine* e) { return e->codes_format; }  // (set by ensure_device_plan: the matrix-pipe kernels read the code image)
 
+// tile_buf (optional): runs whose band is wide ALSO get the 8 x 8 tile plan of ldp_pair_wide.hip -- the all-pairs rows of the r^2
+// matrices and of `inter-chr` (BASELINE config 4) are nothing but wide bands --, which owns them on complete-data launches (the
+// marked parallelogram workgroups stand by for rows with missing calls, as in the prune).
 int attach_mfma_plan(ldp_engine* e, PairKernelArgs* A, const std::vector<std::pair<uint32_t, uint32_t>>& runs, const uint32_t* lo, uint32_t j_first,
-                     uint32_t j_end, DevBuf* buf, uint64_t* products, uint32_t i_first = 0, uint32_t i_end = 0xffffffffu) {
+                     uint32_t j_end, DevBuf* buf, uint64_t* products, uint32_t i_first = 0, uint32_t i_end = 0xffffffffu, DevBuf* tile_buf = nullptr,
+                     uint64_t* tile_products = nullptr) {
   std::vector<MfmaWG> wgs;
-  plan_mfma_generic(runs, lo, j_first, j_end, &wgs, products, i_first, i_end);
+  std::vector<MfmaTile> tiles;
+  plan_mfma_generic(runs, lo, j_first, j_end, &wgs, products, i_first, i_end, tile_buf ? &tiles : nullptr, e->opt.wide_min_reach);
   A->n_mf_wgs = static_cast<uint32_t>(wgs.size());
   if (wgs.empty()) {
     return LDP_OK;
@@ -2245,6 +2253,19 @@ int attach_mfma_plan(ldp_engine* e, PairKernelArgs* A, const std::vector<std::pa
   A->mf_diag_ct = partition_diag(&wgs, 0, wgs.size());
   HIP_TRY(e, hipMalloc(&buf->p, wgs.size() * sizeof(MfmaWG)));
   HIP_TRY(e, hipMemcpy(buf->p, wgs.data(), wgs.size() * sizeof(MfmaWG), hipMemcpyHostToDevice));
+  if (!tiles.empty()) {
+    HIP_TRY(e, hipMalloc(&tile_buf->p, tiles.size() * sizeof(MfmaTile)));
+    HIP_TRY(e, hipMemcpy(tile_buf->p, tiles.data(), tiles.size() * sizeof(MfmaTile), hipMemcpyHostToDevice));
+    A->wd_tiles = tile_buf->as<MfmaTile>();
+    A->n_wd_tiles = static_cast<uint32_t>(tiles.size());
+    A->wd_active = 1;
+    if (tile_products) {
+      *tile_products = 0;
+      for (const MfmaTile& t : tiles) {
+        *tile_products += static_cast<uint64_t>(__builtin_popcountll(t.mask));
+      }
+    }
+  }
   const size_t slot = e->groups.size();  // (the route slot of launches outside the launch groups)
   HIP_TRY(e, queue_route(e, slot, e->stream, 0, e->local_ct));
   A->mf_wgs = buf->as<MfmaWG>();
@@ -2530,18 +2551,18 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
   EventSet<4> evset;
   hipEvent_t* evk = evset.ev;
   HIP_TRY(e, evset.create());
-  DevBuf mf_buf;
-  uint64_t mf_products = 0;
+  DevBuf mf_buf, tile_buf;
+  uint64_t mf_products = 0, tile_products = 0;
   hipError_t krc;
   if (on_mfma) {
     const std::vector<std::pair<uint32_t, uint32_t>> runs(1, std::make_pair(0u, e->local_ct));
-    rc = attach_mfma_plan(e, &A, runs, nullptr, row_first, row_end, &mf_buf, &mf_products, col_first, col_end);
+    rc = attach_mfma_plan(e, &A, runs, nullptr, row_first, row_end, &mf_buf, &mf_products, col_first, col_end, &tile_buf, &tile_products);
     if (rc) {
       return rc;
     }
-    krc = launch_pair_mfma(A, e->stream, evk);  // evk[0..2]: complete-data kernel | missing-calls kernel
+    krc = launch_pair_mfma(A, e->stream, evk);  // evk[0..2]: complete-data kernels (tiles + parallelogram workgroups) | missing-calls kernel
     (void)hipEventRecord(evk[3], e->stream);
-    computed = mf_products * kMfBlock * kMfBlock;
+    computed = (tile_products ? tile_products : mf_products) * kMfBlock * kMfBlock;  // (what a complete-data launch multiplies: the tiles' products where there are tiles)
   } else {
     krc = launch_pair_tiles(A, std::max<uint32_t>(max_rows, kTileJ + 8), e->stream, evk);
   }
@@ -2749,8 +2770,20 @@ int ldp_comm_init_all(int n, const int* devices, void** comms) {
   return LDP_OK;
 }
 
+namespace {
+// communicators ldp_allgather_removed() had to abort: ncclCommAbort has already released them, a later ldp_comm_destroy() is a no-op
+std::mutex g_aborted_mu;
+std::set<void*> g_aborted;
+}  // namespace
+
 void ldp_comm_destroy(void* comm) {
   if (comm && rccl().ok) {
+    {
+      std::lock_guard<std::mutex> lk(g_aborted_mu);
+      if (g_aborted.erase(comm)) {
+        return;
+      }
+    }
     (void)rccl().CommDestroy(static_cast<ncclComm_t>(comm));
   }
 }
@@ -2831,6 +2864,8 @@ int ldp_allgather_removed(ldp_engine* e, void* comm, const uint64_t* removed_loc
   auto leave = [&](int code, const std::string& msg) {
     if (c && R.ok && R.CommAbort) {
       (void)R.CommAbort(c);
+      std::lock_guard<std::mutex> lk(g_aborted_mu);
+      g_aborted.insert(c);
     }
     return fail(e, code, msg);
   };

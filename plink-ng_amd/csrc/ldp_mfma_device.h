@@ -79,10 +79,11 @@ __device__ __forceinline__ mf_v16f mfma_pair(const Frag& a, const Frag& b, mf_v1
     return mfma_fp4(a, b, c);
   }
 }
-// what a launch subtracts from G: N for the shift x = 1 - g, 9 per padding sample of a row (rows are whole 512-sample chunks)
-__device__ __forceinline__ int32_t g_bias_of(uint32_t founder_ct) {
-  const uint32_t padded = ((founder_ct + 511u) / 512u) * 512u;
-  return static_cast<int32_t>(founder_ct + 9u * (padded - founder_ct));
+// what a launch subtracts from G: N for the shift x = 1 - g, 9 per padding sample the kernel walks over (it visits whole stages of
+// stage_samples; the image's rows are whole 512-sample chunks with every sample beyond founder_ct coded 11)
+__device__ __forceinline__ int32_t g_bias_of(uint32_t founder_ct, uint32_t stage_samples) {
+  const uint32_t visited = ((founder_ct + stage_samples - 1u) / stage_samples) * stage_samples;
+  return static_cast<int32_t>(founder_ct + 9u * (visited - founder_ct));
 }
 // a record's sum of x in the IMAGE's orientation (the record itself is in major-allele orientation; flags bit 0 = they differ)
 __device__ __forceinline__ int32_t sum_img_of(const ldp_variant_rec& r) { return (r.flags & 1u) ? -r.sum : r.sum; }

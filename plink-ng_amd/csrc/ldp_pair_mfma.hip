@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   // +-2 coding as well: it sits at 254 registers, and with the checkpoint's conversion beside its branches hipcc parks an accumulator
   // in scratch INSIDE the stage loop, whose reload drains the DMA ring every k-step; tests/test_kernel_isa.py.)
   constexpr bool GC = (!SPARSE) && DIAGFORM;
-  const int32_t g_bias = g_bias_of(A.founder_ct);
+  const int32_t g_bias = g_bias_of(A.founder_ct, G::kStageSamples);
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_src_off[kMfMaxDmaPerWave * kMfWaves * 64];
   __shared__ uint32_t s_need[kMfWaves];

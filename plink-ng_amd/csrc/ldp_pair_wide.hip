@@ -55,8 +55,16 @@ __device__ __forceinline__ uint32_t wd_swizzle(uint32_t row) { return (row >> 1)
 // eight waves' worth of state hipcc spilled inside the stage loop for it, and a scratch reload's vmcnt wait drains the DMA
 // ring.  A wave's eight products sit next to each other in distance, so they mostly die together anyway; the products of a
 // partly live wave that hold no candidate pair accumulate numbers nobody reads.)
+// ABL (measurement only, tools/profile notes in profiles/r04_experiments.md; results are WRONG for ABL != 0): bit 1 = expand only the
+// first k-step's operands and reuse them (a quarter of the VALU work, the same operand statistics), bit 2 = no LDS reads in the loop
+// (every lane multiplies what the first stage left in its registers' place: constants of the launch)
+template <int ABL>
 __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const uint32_t (&joff)[2], const uint32_t (&voff)[4], uint32_t oH, uint32_t oR,
                                            mf_v16f (&acc)[8]) {
+  if constexpr ((ABL & 4) != 0) {
+    // (handled by wide_stage_kept below)
+    return;
+  }
   mf_u4 vH[2], vR[2];
   vH[0] = st4[voff[0] + oH];
   vR[0] = st4[voff[0] + oR];
@@ -66,7 +74,11 @@ __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const 
     opaque(H, R);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      fp4_expand<true>(H[ks], R[ks], fj0[ks]);
+      if ((ABL & 2) && ks) {
+        fj0[ks] = fj0[0];
+      } else {
+        fp4_expand<true>(H[ks], R[ks], fj0[ks]);
+      }
     }
   }
   {
@@ -74,7 +86,11 @@ __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const 
     opaque(H, R);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      fp4_expand<true>(H[ks], R[ks], fj1[ks]);
+      if ((ABL & 2) && ks) {
+        fj1[ks] = fj1[0];
+      } else {
+        fp4_expand<true>(H[ks], R[ks], fj1[ks]);
+      }
     }
   }
   // rows of C = first variant (A operand: a V block), columns = second variant (B operand: a J block)
@@ -87,7 +103,11 @@ __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const 
   opaque(vH[B], vR[B]);                                        \
   _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {           \
     Frag fv;                                                   \
-    fp4_expand<true>(vH[B][ks], vR[B][ks], fv);                    \
+    if ((ABL & 2) && ks) {                                     \
+      fv = fj1[(ks + (b)) & 3];                                \
+    } else {                                                   \
+      fp4_expand<true>(vH[B][ks], vR[B][ks], fv);              \
+    }                                                          \
     acc[b] = mfma_pair<true>(fv, fj0[ks], acc[b]);                    \
     acc[4 + (b)] = mfma_pair<true>(fv, fj1[ks], acc[4 + (b)]);        \
   }
@@ -98,11 +118,46 @@ __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const 
 #undef LDP_WD_VBLOCK
 }
 
+// ABL bit 2: the stage without LDS reads -- every row-block's codes are the two pieces this lane read ONCE (real genotypes of the first
+// stage, the dwords rotated per block and k-step so that consecutive MFMAs still see different operands)
+template <int ABL>
+__device__ __forceinline__ void wide_stage_kept(mf_u4 H, mf_u4 R, mf_v16f (&acc)[8]) {
+  opaque(H, R);
+  Frag fj0[4], fj1[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    if ((ABL & 2) && ks) {
+      fj0[ks] = fj0[0];
+      fj1[ks] = fj1[0];
+    } else {
+      fp4_expand<true>(H[ks], R[ks], fj0[ks]);
+      fp4_expand<true>(R[ks], H[(ks + 1) & 3], fj1[ks]);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    mf_u4 vH = {H[b & 3], H[(b + 1) & 3], H[(b + 2) & 3], H[(b + 3) & 3]}, vR = {R[(b + 2) & 3], R[(b + 3) & 3], R[b & 3], R[(b + 1) & 3]};
+    opaque(vH, vR);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      Frag fv;
+      if ((ABL & 2) && ks) {
+        fv = fj1[(ks + b) & 3];
+      } else {
+        fp4_expand<true>(vH[ks], vR[ks], fv);
+      }
+      acc[b] = mfma_pair<true>(fv, fj0[ks], acc[b]);
+      acc[4 + b] = mfma_pair<true>(fv, fj1[ks], acc[4 + b]);
+    }
+  }
+}
+
 // row-block slots (bit s: slot s of the stage) a wave with a live product reads: its two J blocks and its four V blocks
 __device__ __forceinline__ uint32_t wide_slots_needed(uint32_t live, uint32_t a0, uint32_t vslot0) {
   return live ? ((3u << a0) | (0xfu << vslot0)) : 0u;
 }
 
+template <int ABL>
 __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKernelArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_need[kWdWaves];
@@ -126,7 +181,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
   const uint32_t mask_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tile->mask));
   const uint32_t mask_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tile->mask >> 32));
   const bool diag = (jv0 == vv0);
-  const int32_t g_bias = g_bias_of(A.founder_ct);
+  const int32_t g_bias = g_bias_of(A.founder_ct, kWdStageSamples);
   const uint32_t row_bytes = static_cast<uint32_t>(A.code_row_bytes);
   const uint32_t n_stages = (A.founder_ct + kWdStageSamples - 1) / kWdStageSamples;  // (the image's rows are whole stages long: ldp_device.h)
   const uint32_t stage_dwords = kWdStageDwords;
@@ -176,7 +231,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
     }
     return m;
   };
-  uint32_t mine = count_mine();  // DMA wave-instructions per stage this wave issues
+  uint32_t mine = (ABL & 1) ? 0u : count_mine();  // DMA wave-instructions per stage this wave issues
 
   uint32_t joff[2], voff[4];  // uint4 index of the row-block's first slot
 #pragma unroll
@@ -212,6 +267,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
     }
   }
 
+  mf_u4 keptH = {0, 0, 0, 0}, keptR = {0, 0, 0, 0};  // (ABL bit 2 only)
   uint32_t next_cp = 0;
   const uint32_t n_cp = A.cp_stats ? A.n_checkpoints : 0;
   const uint32_t live0 = live;        // the products of the plan
@@ -222,7 +278,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
 #pragma unroll
     for (int t = 0; t < static_cast<int>(kWdDma); ++t) {
       const uint32_t T = wave + kWdWaves * t;
-      if ((wg_need >> (T / kWdInstrPerBlock)) & 1u) {
+      if (((wg_need >> (T / kWdInstrPerBlock)) & 1u) && (!(ABL & 1) || (s < kWdMaxStages))) {  // (ABL bit 0: only the ring's first fill leaves HBM: what the DMA costs)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_t[t] + kbyte + src_off[t]),
                                          (__attribute__((address_space(3))) void*)(dst + T * 256), 16, 0, 0);
       }
@@ -258,9 +314,18 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
       }
       const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * stage_dwords);
       read_buf = (read_buf + 1 == stages) ? 0 : read_buf + 1;
-      if (live) {
-        wide_stage(st4, joff, voff, oH0, oR0, acc);
-        wide_stage(st4, joff, voff, oH1, oR1, acc);
+      if constexpr ((ABL & 4) != 0) {
+        if (kc == 0) {
+          keptH = st4[joff[0] + oH0];
+          keptR = st4[joff[0] + oR0];
+        }
+        if (live) {
+          wide_stage_kept<ABL>(keptH, keptR, acc);
+          wide_stage_kept<ABL>(keptR, keptH, acc);
+        }
+      } else if (live) {
+        wide_stage<ABL>(st4, joff, voff, oH0, oR0, acc);
+        wide_stage<ABL>(st4, joff, voff, oH1, oR1, acc);
       }
     }
     if (kc >= n_stages) {
@@ -379,7 +444,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
     }
     if (all_need != wg_need) {
       wg_need = __builtin_amdgcn_readfirstlane(all_need);
-      mine = count_mine();
+      mine = (ABL & 1) ? 0u : count_mine();
     }
     issue_limit = (next_cp < n_cp) ? checkpoint_stage(next_cp) : n_stages;
     issued_base = kc;
@@ -466,14 +531,30 @@ hipError_t launch_pair_wide(const PairKernelArgs& a_in, hipStream_t stream) {
     return hipSuccess;
   }
   PairKernelArgs a = a_in;
+  // LDP_DEBUG_WIDE_ABLATE (measurement only, WRONG results): 1 = no DMA, 2 = a quarter of the operand expansions, 4 = no LDS reads, 7 = all
+  static const int ablate = []() {
+    const char* v = getenv("LDP_DEBUG_WIDE_ABLATE");
+    return v ? atoi(v) : 0;
+  }();
   static const size_t lds = []() {
     const size_t bytes = static_cast<size_t>(kWdLdsDwords) * sizeof(uint32_t);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
     return bytes;
   }();
   a.lds_dwords = static_cast<uint32_t>(lds / sizeof(uint32_t));
   const uint32_t per_xcd = (a.n_wd_tiles + 7) / 8;
-  hipLaunchKernelGGL(pair_mfma_wide_kernel, dim3(per_xcd * 8), dim3(kWdWaves * 64), lds, stream, a);
+  const dim3 grid(per_xcd * 8), block(kWdWaves * 64);
+  switch (ablate) {
+    case 1: hipLaunchKernelGGL(pair_mfma_wide_kernel<1>, grid, block, lds, stream, a); break;
+    case 2: hipLaunchKernelGGL(pair_mfma_wide_kernel<2>, grid, block, lds, stream, a); break;
+    case 4: hipLaunchKernelGGL(pair_mfma_wide_kernel<4>, grid, block, lds, stream, a); break;
+    case 7: hipLaunchKernelGGL(pair_mfma_wide_kernel<7>, grid, block, lds, stream, a); break;
+    default: hipLaunchKernelGGL(pair_mfma_wide_kernel<0>, grid, block, lds, stream, a); break;
+  }
   return hipGetLastError();
 }
 

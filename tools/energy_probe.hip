@@ -90,6 +90,65 @@ __global__ __launch_bounds__(256, 2) void probe_kernel(const uint32_t* __restric
   }
 }
 
+// the same contraction as v_mfma_scale_f32_16x16x128_f8f6f4: half the multiply-adds per instruction (16 x 16 pairs x 128 samples), a
+// quarter of the accumulator registers (4 per lane): 16 accumulators here, two instructions for the work of one 32x32x64
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int K>
+__global__ __launch_bounds__(256, 2) void probe16_kernel(const uint32_t* __restrict__ src, float* out, int iters, unsigned long long* clk) {
+  const int l = threadIdx.x;
+  v4f acc[16];
+  for (int p = 0; p < 16; ++p) {
+    for (int g = 0; g < 4; ++g) {
+      acc[p][g] = 0.f;
+    }
+  }
+  uint32_t f[8][4];
+  for (int q = 0; q < 8; ++q) {
+    for (int d = 0; d < 4; ++d) {
+      f[q][d] = src[(q * 4 + d) * 256 + l];
+    }
+  }
+  uint32_t dummy[6];
+  for (int q = 0; q < 6; ++q) {
+    dummy[q] = src[q * 256 + l] ^ (0x9e3779b9u * (q + 1));
+  }
+  const unsigned long long t0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const int a = 2 * round + (p & 1), b = 4 + 2 * round + ((p >> 1) & 1);
+        const v8i A = {(int)f[a][0], (int)f[a][1], (int)f[a][2], (int)f[a][3], 0, 0, 0, 0};
+        const v8i B = {(int)f[b][0], (int)f[b][1], (int)f[b][2], (int)f[b][3], 0, 0, 0, 0};
+        acc[p] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, acc[p], 4, 4, 0, 0x7e7e7e7e, 0, 0x7e7e7e7e);
+        if (p & 1) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            dummy[k] = __builtin_amdgcn_bitop3_b32(dummy[k], 0x44444444u + it, 0xccccccccu, 0x28);
+          }
+        }
+      }
+    }
+  }
+  const unsigned long long t1 = clock64(), w1 = wall_clock64();
+  float sum = 0.f;
+  for (int p = 0; p < 16; ++p) {
+    for (int g = 0; g < 4; ++g) {
+      sum += acc[p][g];
+    }
+  }
+  uint32_t x = 0;
+  for (int q = 0; q < 6; ++q) {
+    x ^= dummy[q];
+  }
+  out[blockIdx.x * 256 + l] = sum + static_cast<float>(x & 1);
+  if ((blockIdx.x == 0) && (l == 0)) {
+    clk[0] = t1 - t0;
+    clk[1] = w1 - w0;
+  }
+}
+
 enum { kZero = 0, kRandom, kX, kG, kMix, kGminor, kNData };
 static const char* const kDataName[kNData] = {"all zero", "uniform random nibbles", "genotypes, x coding (+2 / 0 / -2)", "genotypes, g coding (0 / 0.5 / 1)",
                                                "genotypes, MFMAs alternate x / g coding", "genotypes, g coding of the MINOR allele, MAF ~ U(0.01, 0.2)"};
@@ -191,6 +250,32 @@ int main() {
     for (int k = 0; k < 7; ++k) {
       printf("B. %-40s + %d v_bitop3 per MFMA: %7.3f ms = %5.2f PFLOP/s at %4.0f MHz, time per MFMA x %.3f (vs x coding alone)\n", kDataName[data], k, ms[k],
              2 * mfmas * 65536.0 / (ms[k] * 1e-3) / 1e15, mhz[k], base > 0 ? ms[k] / base : 0.0);
+    }
+  }
+  // C. the 16x16x128 form: two instructions per 65,536 multiply-adds, 4 accumulator registers per lane instead of 16
+  for (int data : {kX, kG}) {
+    fill(h, data, rng);
+    CHECK(hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int k : {0, 3}) {
+      float ms = 0.f;
+      for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipEventRecord(e0, 0));
+        if (k == 0) {
+          hipLaunchKernelGGL((probe16_kernel<0>), dim3(blocks), dim3(256), 0, 0, src, out, iters, clk);
+        } else {
+          hipLaunchKernelGGL((probe16_kernel<3>), dim3(blocks), dim3(256), 0, 0, src, out, iters, clk);
+        }
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+      }
+      unsigned long long hc[2];
+      CHECK(hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost));
+      printf("C. 16x16x128, %-40s + %d v_bitop3 per 65,536 multiply-adds: %7.3f ms = %5.2f PFLOP/s at %4.0f MHz, time per 65,536 multiply-adds x %.3f (vs 32x32x64, x coding alone)\n",
+             kDataName[data], k, ms, 2 * mfmas * 65536.0 / (ms * 1e-3) / 1e15, hc[1] ? (double)hc[0] / (double)hc[1] * 100.0 : 0.0, base > 0 ? ms / base : 0.0);
     }
   }
   CHECK(hipFree(src));
