@@ -113,23 +113,23 @@ typedef struct {
   uint64_t computed_pairs;   /* pair slots the kernel actually evaluated (tile padding included) */
   uint64_t replay_pairs;     /* predicate bits the greedy replay consumed */
   uint64_t pred_true;        /* candidate pairs above threshold */
-  double ms_prepare;         /* device time of the split/count kernels in the last ldp_load_genotypes() (HIP events) */
+  double ms_prepare;         /* device time of the count pass (codes_kernel; prepare_kernel on bit-plane engines) in the last ldp_load_genotypes() (HIP events) */
   double ms_pair_kernel;     /* device time of all pair-kernel launches in the last ldp_run() (HIP events on the engine stream) */
-  double ms_pair_fast;       /* ... of pair_tiles_kernel<false> (complete-data tiles) alone */
-  double ms_pair_general;    /* ... of pair_tiles_kernel<true> (tiles with missing calls) alone */
+  double ms_pair_fast;       /* ... of the popcount fallback pair_tiles_kernel<false> (bit-plane engines: > 4,000,000 founders or pair_mfma off) alone */
+  double ms_pair_general;    /* ... of pair_tiles_kernel<true> (the same fallback, tiles with missing calls) alone */
   double ms_replay;          /* host wall time of the replay in the last ldp_run() */
   double ms_run_total;       /* host wall time of the last ldp_run() */
   uint32_t pair_kernel_launches;
   uint32_t subcontig_ct;
   uint32_t owned_subcontig_ct;
   uint32_t window_max;       /* as LdPruneSubcontigSplitAll reports it */
-  uint64_t tile_unit_chunks;       /* pair-kernel work of the last run in (8-distance unit x k-chunk) steps ... */
+  uint64_t tile_unit_chunks;       /* popcount fallback only: its work in the last run in (8-distance unit x k-chunk) steps ... */
   uint64_t early_exit_unit_chunks; /* ... and how many of them early termination skipped (provably sub-threshold tiles) */
-  double ms_pair_mfma;             /* device time of pair_mfma_kernel (matrix-pipe tiles, complete data) in the last run */
+  double ms_pair_mfma;             /* device time of the complete-data matrix-pipe kernels (pair_mfma_kernel, pair_mfma_wide_kernel) in the last run */
   uint64_t mfma_block_products;    /* 32 x 32 block products of the matrix-pipe plan (0 when that path is off) */
   uint64_t mfma_product_stages;    /* ... times the 64-sample k-steps of a row: the MFMA instructions of an exhaustive run */
   uint64_t mfma_skipped_product_stages; /* ... and how much of it early termination skipped in the last run */
-  double ms_pair_mfma_general;     /* device time of pair_mfma_general_kernel (matrix-pipe tiles with missing calls) */
+  double ms_pair_mfma_general;     /* device time of the missing-call matrix-pipe kernels (pair_mfma_general_kernel, pair_mfma_tile4_kernel) */
   uint64_t sparse_exact_pairs;     /* few missing calls: pairs the interval test left open and the kernel resolved exactly */
   /* Which matrix-pipe kernel the device-side route gave the pair launches of the last run (one word per launch group, written by
    * route_kernel from the rows' missing-call totals): complete data -> pair_mfma_kernel, a few missing calls -> its interval
@@ -277,39 +277,6 @@ int ldp_run(ldp_engine* e, uint64_t* removed);
 int ldp_run_with_stats(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t stats_capacity);
 /* Arbitrary pairs (first[k] < second[k] not required) through the reference kernel (one wave per pair). */
 int ldp_pair_stats(ldp_engine* e, uint32_t n_pairs, const uint32_t* first, const uint32_t* second, ldp_pair_stats_t* out);
-/* Host-only replay of the greedy scan (plink2_ld.cc:931-1100) from a caller-supplied list of the candidate
- * pairs whose predicate is TRUE (global variant indices, first < second, each inside the band).  Needs
- * variant records (ldp_debug_set_variant_recs, for the monomorphic flags) and maj_freqs.  No GPU is
- * touched: this is how the host logic is tested on a CPU-only machine. */
-int ldp_debug_set_variant_recs(ldp_engine* e, const ldp_variant_rec* recs);
-int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first, const uint32_t* second, uint64_t* removed);
-/* Kernel-selection switches of ONE engine, for tests and measurements (the defaults are what production runs use; they can also
- * be preset from the environment at ldp_create(): LDP_EARLY_EXIT, LDP_PAIR_MFMA, LDP_PAIR_SPARSE, LDP_PAIR_FOUR, LDP_PAIR_FOUR_TILES, LDP_DEBUG_SPARSE_FRAC,
- * LDP_DEBUG_WIDE_MIN_REACH).  name:
- *   "early_exit"      0/1: checkpoints that drop provably sub-threshold products
- *   "pair_mfma"       0/1: matrix-pipe kernels on the 2-bit code image; 0 = the popcount kernels on bit-planes (before ldp_set_variants*())
- *   "pair_sparse"     0/1: the interval epilogue for rows with a few missing calls
- *   "sparse_frac"     mean missing fraction up to which a launch takes it
- *   "pair_four"       0/1: prune launches over rows with more missing calls than that multiply four products per pair and take the
- *                     two sums of squares from per-variant intervals (exact count for the few pairs they leave open); 0 = all six
- *   "pair_four_tiles" 0/1: ... and in wide bands (subcontigs with the tile plan) that form runs over quarter tiles instead of the
- *                     parallelogram plan (default 1)
- *   "wide_min_reach"  row-blocks a subcontig's band must reach to take the 8 x 8 tile plan of the wide-band kernel; 0 = always,
- *                     a huge value = never (before ldp_set_variants())
- * Results never depend on these.  Unknown name: LDP_ERR_INVALID. */
-int ldp_debug_set_option(ldp_engine* e, const char* name, double value);
-/* Host-only view of the matrix-pipe work plan (csrc/ldp_device.h: MfmaWG) in the engine's shard-local variant
- * indices, for the CPU test that every candidate pair is owned by exactly one 32 x 32 block product.  Per workgroup
- * 63 words: n_rb (bit 31: see ldp_debug_wide_plan; bit 30: every wave item is diagonal), j_lo, j_hi, rb[16], then per wave jv, vv, jend, prod_mask, slot[7].  lo_local (optional, *local_ct
- * entries) receives the window starts in the same index space.  words == NULL only counts. */
-int ldp_debug_mfma_plan(const ldp_engine* e, uint32_t* wg_count, uint32_t* words, uint64_t capacity_words, uint32_t* lo_local, uint32_t* local_ct);
-
-/* The wide-band plan (csrc/ldp_device.h: MfmaTile; subcontigs whose band reaches the "wide_min_reach" option in row-blocks): per
- * tile 5 words: jv, vv, jend, mask bits 0-31, mask bits 32-63 (bit 8 a + b: the product of J block a and V block b).  The
- * workgroups of ldp_debug_mfma_plan() that belong to such subcontigs carry bit 31 in their first word; complete-data launches
- * leave those to the tiles.  words == NULL only counts. */
-int ldp_debug_wide_plan(const ldp_engine* e, uint32_t* tile_count, uint32_t* words, uint64_t capacity_words);
-
 /* ---- --r2-unphased matrices (Vcor / VcorMatrix, plink2_ld.cc:12050,9766; ComputeR2 :6654-6682) ---- */
 /* All-pairs plan over variant_ct variants (inter-chromosomal pairs included, as the matrix shapes of
  * --r2-unphased do): use instead of ldp_set_variants(), then ldp_load_genotypes() as usual. */
@@ -443,13 +410,7 @@ int ldp_subset_samples(const void* in_rows, uint64_t in_stride, uint32_t n_rows,
 const char* ldp_pgen_last_error(const ldp_pgen* p);
 void ldp_pgen_close(ldp_pgen* p);
 
-/* ---- synthetic workload (benchmark / test support, not part of the reference seam) ---- */
-/* Deterministic genotype generator for the SURVEY.md 8(d) workload: rows [first_variant, +n_variants) of
- * REF-based codes (LDP_GENO_REF) written to `out` (host or device memory), each genotype a pure function of
- * (seed, variant index, sample index).  LD is planted like the reference's --dummy
- * (plink2_import.cc:16387-16432).  `stream` is a hipStream_t (device output only; may be NULL). */
-int ldp_synth_genotypes(uint64_t seed, uint64_t first_variant, uint32_t n_variants, uint32_t founder_ct, double missing_rate,
-                        void* out, uint64_t stride_bytes, int location, void* stream);
+/* Test hooks, kernel-selection switches and the benchmark's synthetic generator are NOT part of this boundary: ldprune_hip_debug.h. */
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "../../include/ldprune_hip.h"
+#include "../../include/ldprune_hip_debug.h"
 
 namespace ldp {
 

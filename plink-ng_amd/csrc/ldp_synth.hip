@@ -10,7 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/ldprune_hip.h"
+#include "../../include/ldprune_hip_debug.h"
 
 namespace {
 

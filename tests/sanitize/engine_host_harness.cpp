@@ -3,7 +3,7 @@
 #include <cstring>
 #include <vector>
 #include <random>
-#include "ldprune_hip.h"
+#include "ldprune_hip_debug.h"
 int main() {
   std::mt19937 rng(7);
   for (int iter = 0; iter < 60; ++iter) {

@@ -7,9 +7,18 @@ import re
 
 def declared_symbols():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    text = open(os.path.join(repo, "include", "ldprune_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ldp_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    for hdr in ("ldprune_hip.h", "ldprune_hip_debug.h"):   # the boundary, and the test / measurement hooks kept out of it
+        text = open(os.path.join(repo, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(ldp_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_the_boundary_header_carries_no_test_hooks():
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(repo, "include", "ldprune_hip.h")).read(), flags=re.S)
+    assert "ldp_debug_" not in text and "ldp_synth_" not in text
 
 
 def test_header_and_binding_agree(pkg):
