@@ -151,6 +151,10 @@ void ldp_destroy(ldp_engine* e);
 const char* ldp_last_error(const ldp_engine* e);
 /* number of usable HIP devices (0 when there is none); never fails */
 int ldp_device_count(void);
+/* Optional: create the device's context now (first stream, first pinned allocation, first copy), from any thread, so that the first
+ * ldp_load_genotypes() of an engine on that device does not pay for it (tens to hundreds of milliseconds).  LDP_ERR_GPU without
+ * such a device. */
+int ldp_prewarm(int device);
 /* Largest founder_ct whose pair statistics run on the matrix pipe (FP4 operands, f32 accumulators that hold the integers
  * exactly); larger jobs run on the popcount kernels.  Same results either way. */
 uint32_t ldp_matrix_pipe_max_founders(void);
@@ -207,6 +211,12 @@ int ldp_get_band(const ldp_engine* e, uint32_t* lo, uint64_t* candidate_pairs);
  * Loading a variant again (a new pass over the data) simply starts over. */
 int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* geno, uint64_t stride_bytes,
                        int location, int encoding);
+/* The same for rows that lie in a FILE as fixed-width records (a .bed, a fixed-width .pgen: the main-thread read loop of
+ * plink2_ld.cc:1345-1390 for those formats): row of variant first_variant + k at file_offset + k * stride_bytes of the open
+ * descriptor fd.  The rows are pread() straight into the pinned staging ring by the engine's copy threads -- the page cache is
+ * copied out in large runs, where a memcpy out of a mapping of the file first pays a minor page fault per 4 KiB -- and cross PCIe
+ * from there.  The descriptor is only read (pread: its file position is untouched) and may be closed once the call returns. */
+int ldp_load_genotypes_fd(ldp_engine* e, uint32_t first_variant, uint32_t n, int fd, uint64_t file_offset, uint64_t stride_bytes, int encoding);
 /* Zero-copy loading.  The engine keeps the genotypes as one resident image of 2-bit rows -- the same codes, the same N/4 bytes
  * per variant as the input -- and a producer that runs on the device (a decoder, a generator) can write its rows straight into
  * it: *device_rows receives the device address of the image row of first_variant, *stride_bytes the distance between rows
@@ -245,6 +255,16 @@ typedef struct ldp_pgen_rec {
 } ldp_pgen_rec;
 int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* bytes, uint64_t n_bytes, int location, const ldp_pgen_rec* recs,
                           const ldp_pgen_rec* ld_base, uint32_t raw_sample_ct, uint32_t* major_allele_out);
+/* The same for --indep-pairphase (plink2_ld.cc:1449-2163; loader :2040-2052): the records' main tracks AND their hardcall-phase tracks
+ * (auxiliary track 2, pgen_spec "Phased heterozygous hard-calls"; ReadGenovecHphaseSubsetUnsafe pgenlib_read.cc:6704, what
+ * PgrGetInv1P :7016 hands HapsplitMustPhased pgenlib_misc.cc:1887) are decoded on the device into LDP_GENO_PHASED rows and loaded;
+ * the engine's founder_ct is the haplotype count, 2 x raw_sample_ct, and every sample of the file is used (no sample map).  Every
+ * heterozygous call must be phased, as the reference demands of its founders (plink2_ld.cc:2045-2049): otherwise nothing of the
+ * offending launch is loaded, the call returns LDP_ERR_UNPHASED and *unphased_variant (optional) receives the lowest variant of the
+ * call with such a het call (UINT32_MAX when there is none).  Records with more than one ALT allele are refused
+ * (LDP_ERR_UNSUPPORTED: their phase refers to allele pairs, Get1MP pgenlib_read.cc:6962 -- build those rows on the host). */
+int ldp_load_pgen_records_phased(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* bytes, uint64_t n_bytes, int location, const ldp_pgen_rec* recs,
+                                 const ldp_pgen_rec* ld_base, uint32_t raw_sample_ct, uint32_t* unphased_variant);
 /* Give the engine's device memory back (image, records, predicate rows, staging) while keeping its plan: for a caller that works
  * through more data than fits HBM, one engine (chromosome) after the other.  The next ldp_load_genotypes() / ldp_map_rows()
  * allocates again; every row has to be loaded again before the next ldp_run(). */
@@ -372,6 +392,9 @@ int ldp_pgen_variant_has_dosage(const ldp_pgen* p, uint32_t variant);
 int ldp_pgen_dosage_sums(ldp_pgen* p, uint32_t variant, const uint8_t* sample_mask, uint64_t* ref_dosage, uint64_t* alt_dosage);
 /* fixed-width modes only: pointer to row 0 inside the file mapping (zero-copy), NULL for variable-width files */
 const void* ldp_pgen_direct_rows(const ldp_pgen* p, uint64_t* stride_bytes);
+/* ... and the same rows as (descriptor, offset of row 0, stride) for ldp_load_genotypes_fd(); -1 for variable-width files.  The
+ * descriptor stays the reader's (do not close it). */
+int ldp_pgen_direct_fd(const ldp_pgen* p, uint64_t* first_row_offset, uint64_t* stride_bytes);
 /* For ldp_load_pgen_records(): the file's bytes (the reader's mapping) and the index entries of variants [first_variant, +n) --
  * offset, length, record type; allele_ct is set to 2 (the .pvar knows better).  *ld_base_variant (optional): the variant whose
  * record the first one builds on when it is LD-compressed (GetLdbaseVidx, pgenlib_read.cc:1848), UINT32_MAX otherwise.

@@ -89,15 +89,15 @@ VARIANT_REC_DTYPE = np.dtype([("nm_ct", "<u4"), ("sum", "<i4"), ("ssq", "<u4"), 
 
 # Every symbol include/ldprune_hip.h declares (checked by tests/test_cabi_symbols.py).
 CABI_SYMBOLS = [
-    "ldp_create", "ldp_destroy", "ldp_last_error", "ldp_device_count", "ldp_set_variants", "ldp_get_subcontigs",
-    "ldp_set_shard", "ldp_get_band", "ldp_load_genotypes", "ldp_set_sample_map", "ldp_set_maj_freqs", "ldp_set_preferred", "ldp_run",
+    "ldp_create", "ldp_destroy", "ldp_last_error", "ldp_device_count", "ldp_prewarm", "ldp_set_variants", "ldp_get_subcontigs",
+    "ldp_set_shard", "ldp_get_band", "ldp_load_genotypes", "ldp_load_genotypes_fd", "ldp_set_sample_map", "ldp_set_maj_freqs", "ldp_set_preferred", "ldp_run",
     "ldp_run_with_stats", "ldp_pair_stats", "ldp_debug_set_variant_recs", "ldp_debug_replay_pairs", "ldp_debug_mfma_plan",
     "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
     "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_r2_unphased_hits", "ldp_r2_unphased_block", "ldp_r2_unphased_block_hits", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
-    "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_has_dosage", "ldp_pgen_variant_has_dosage", "ldp_pgen_dosage_sums", "ldp_pgen_direct_rows", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
+    "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_has_dosage", "ldp_pgen_variant_has_dosage", "ldp_pgen_dosage_sums", "ldp_pgen_direct_rows", "ldp_pgen_direct_fd", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
     "ldp_pgen_variant_is_multiallelic", "ldp_pgen_provisional_ref", "ldp_pgen_open_indexed", "ldp_set_r_signed", "ldp_set_variants_vcor_cm", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_subset_samples", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
     "ldp_debug_set_option", "ldp_matrix_pipe_max_founders", "ldp_map_rows", "ldp_release_device", "ldp_debug_wide_plan",
-    "ldp_allgather_removed", "ldp_comm_init_all", "ldp_comm_destroy", "ldp_shard_segment_words", "ldp_pack_removed_segment", "ldp_stitch_removed_segments", "ldp_load_pgen_records", "ldp_pgen_file_bytes", "ldp_pgen_record_index",
+    "ldp_allgather_removed", "ldp_comm_init_all", "ldp_comm_destroy", "ldp_shard_segment_words", "ldp_pack_removed_segment", "ldp_stitch_removed_segments", "ldp_load_pgen_records", "ldp_load_pgen_records_phased", "ldp_pgen_file_bytes", "ldp_pgen_record_index",
 ]
 
 
@@ -206,11 +206,14 @@ def lib():
     L.ldp_release_device.argtypes = [vp]
     L.ldp_load_pgen_records.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ldp_pgen_rec),
                                         ctypes.POINTER(ldp_pgen_rec), ctypes.c_uint32, u32p]
+    L.ldp_load_pgen_records_phased.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ldp_pgen_rec),
+                                               ctypes.POINTER(ldp_pgen_rec), ctypes.c_uint32, u32p]
     L.ldp_pgen_file_bytes.argtypes = [vp, u64p]
     L.ldp_pgen_file_bytes.restype = ctypes.c_void_p
     L.ldp_pgen_record_index.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ldp_pgen_rec), u32p]
     L.ldp_allgather_removed.argtypes = [vp, vp, u64p, u64p]
     L.ldp_comm_init_all.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(vp)]
+    L.ldp_load_genotypes_fd.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
     L.ldp_shard_segment_words.argtypes = [vp, u64p]
     L.ldp_pack_removed_segment.argtypes = [vp, u64p, u64p]
     L.ldp_stitch_removed_segments.argtypes = [vp, u64p, u64p]
@@ -617,6 +620,10 @@ class LdPruneEngine:
         self._ck(self._L.ldp_load_genotypes(self._h, first_variant, rows.shape[0], rows.ctypes.data_as(ctypes.c_void_p),
                                             stride, LDP_MEM_HOST, encoding))
 
+    def load_genotypes_fd(self, first_variant, n, fd, file_offset, stride_bytes, encoding=LDP_GENO_REF):
+        """Fixed-width rows straight from an open file descriptor (ldp_load_genotypes_fd): pread into the pinned ring."""
+        self._ck(self._L.ldp_load_genotypes_fd(self._h, int(first_variant), int(n), int(fd), int(file_offset), int(stride_bytes), int(encoding)))
+
     def load_genotypes_device(self, first_variant, n, device_ptr, stride_bytes, encoding=LDP_GENO_INVERSE):
         self._ck(self._L.ldp_load_genotypes(self._h, first_variant, n, ctypes.c_void_p(device_ptr), stride_bytes,
                                             LDP_MEM_DEVICE, encoding))
@@ -638,6 +645,23 @@ class LdPruneEngine:
         self._ck(self._L.ldp_load_pgen_records(self._h, int(first_variant), int(n), ctypes.c_void_p(ptr), nbytes, location, recs,
                                                base_rec if base_rec is not None else None, pgen.sample_ct, _ptr(maj, ctypes.c_uint32)))
         return maj[:n]
+
+    def load_pgen_records_phased(self, first_variant, pgen, raw_first=None, n=None):
+        """ldp_load_pgen_records_phased (--indep-pairphase): main + hardcall-phase tracks of records [raw_first, +n) decoded on the device
+        into the engine's haplotype rows (founder_ct = 2 x the file's samples).  Raises LdpError(LDP_ERR_UNPHASED) with `.variant` = the
+        lowest variant that has a het call without phase."""
+        raw_first = first_variant if raw_first is None else raw_first
+        n = pgen.variant_ct - raw_first if n is None else n
+        recs, base = pgen.record_index(raw_first, n, None)
+        base_rec = pgen.record_index(base, 1)[0] if base is not None else None
+        ptr, nbytes = pgen.file_bytes()
+        bad = ctypes.c_uint32(0xffffffff)
+        rc = self._L.ldp_load_pgen_records_phased(self._h, int(first_variant), int(n), ctypes.c_void_p(ptr), nbytes, LDP_MEM_HOST, recs,
+                                                  base_rec if base_rec is not None else None, pgen.sample_ct, ctypes.byref(bad))
+        if rc != LDP_OK:
+            err = LdpError(rc, self._L.ldp_last_error(self._h).decode())
+            err.variant = int(bad.value)
+            raise err
 
     def map_rows(self, first_variant, n):
         """(device pointer, stride in bytes) of the engine's own image rows of variants [first_variant, first_variant + n): write

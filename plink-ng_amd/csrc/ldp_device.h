@@ -274,8 +274,13 @@ struct PgenDecodeArgs {
   double* maj_freq;             // out, per entry of multi_rec: GetAlleleFreq of the major allele
   uint32_t* maj_idx;            // out: the major allele
   uint8_t* row_inverse;         // out, per RECORD: 1 = the row now counts copies of non-major alleles (LDP_GENO_INVERSE)
+  // --indep-pairphase: the hardcall-phase track decoded into the rows' second part (LDP_GENO_PHASED layout); 0 = not wanted
+  uint64_t phase_off;           // byte offset of the phase bits inside a row (a multiple of 4, < stride)
+  uint32_t* unphased;           // out: lowest record index with a het call that has no phase (atomicMin; preset to UINT32_MAX)
 };
 hipError_t launch_pgen_main(const PgenDecodeArgs& a, hipStream_t stream);
+// the phase tracks of records [0, n_records) on top of their decoded main tracks (after launch_pgen_main on the same stream)
+hipError_t launch_pgen_phase(const PgenDecodeArgs& a, uint32_t n_records, hipStream_t stream);
 hipError_t launch_pgen_aux1(const PgenDecodeArgs& a, hipStream_t stream);
 
 // Sample-mapped rows (ldp_set_sample_map): out row v = 2-bit REF codes of columns map[f] & 0x7fffffff of in row v, hets of

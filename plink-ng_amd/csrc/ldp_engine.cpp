@@ -26,6 +26,8 @@
 #include "ldp_device.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
+#include <cerrno>
 #include <rccl/rccl.h>
 
 using namespace ldp;
@@ -86,6 +88,8 @@ struct EngineOptions {
   bool pair_four = true;      // LDP_PAIR_FOUR=0: rows with missing calls always take all six products (prune launches otherwise four)
   bool four_tiles = true;     // LDP_PAIR_FOUR_TILES=0: the four-product form stays on the parallelogram plan in wide bands too
 };
+
+constexpr uint32_t kStageSlots = 4;  // pinned staging ring of host-memory input
 
 struct ldp_engine {
   ldp_params P;
@@ -199,9 +203,11 @@ struct ldp_engine {
   hipStream_t pair_stream[kPairStreams] = {nullptr};
   hipEvent_t pair_tail[kPairStreams] = {nullptr};  // last thing queued on each pair stream
   bool pair_tail_set[kPairStreams] = {false};
-  uint8_t* h_stage[3] = {nullptr, nullptr, nullptr};  // pinned staging ring for host-memory genotype input
-  uint8_t* d_stage[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t stage_done[3] = {nullptr, nullptr, nullptr};
+  uint8_t* h_stage[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging ring for host-memory genotype input
+  uint8_t* d_stage[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t stage_done[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t h2d_stream[2] = {nullptr, nullptr};   // H2D copies of alternate slots (two SDMA queues: one tops out near 30 GB/s)
+  hipEvent_t copied[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
   bool prep_pending = false;
   // sample-mapped rows (ldp_set_sample_map): column f <- sample (map & 0x7fffffff), bit 31 = het becomes missing
   std::vector<uint32_t> sample_map;
@@ -265,8 +271,7 @@ int hipfail(ldp_engine* e, hipError_t rc, const char* what) {
     }                                                 \
   } while (0)
 
-constexpr uint32_t kStageSlots = 3;
-constexpr size_t kStageBytes = 64ull << 20;
+constexpr size_t kStageBytes = 16ull << 20;  // per slot: pinning host memory costs ~0.3 ms per MiB on the GPU box, and a 16 MiB copy is 0.3 ms of PCIe
 
 // timing events of one launch, released on every exit path
 template <int N>
@@ -345,14 +350,24 @@ void free_device(ldp_engine* e) {
     (void)hipHostUnregister(e->recs.data());
     e->recs_registered = false;
   }
+  for (int k = 0; k < 2; ++k) {
+    if (e->h2d_stream[k]) {
+      (void)hipStreamDestroy(e->h2d_stream[k]);
+      e->h2d_stream[k] = nullptr;
+    }
+  }
   for (uint32_t k = 0; k < kStageSlots; ++k) {
     if (e->h_stage[k]) {
       (void)hipHostFree(e->h_stage[k]);
       (void)hipFree(e->d_stage[k]);
       (void)hipEventDestroy(e->stage_done[k]);
+      if (e->copied[k]) {
+        (void)hipEventDestroy(e->copied[k]);
+      }
       e->h_stage[k] = nullptr;
       e->d_stage[k] = nullptr;
       e->stage_done[k] = nullptr;
+      e->copied[k] = nullptr;
     }
   }
   for (int k = 0; k < 8; ++k) {
@@ -1101,6 +1116,15 @@ int ensure_device_plan(ldp_engine* e) {
     return LDP_OK;
   }
   HIP_TRY(e, hipSetDevice(e->device));
+  static const bool plan_timing = getenv("LDP_DEBUG_LOAD_TIMING") != nullptr;
+  double t_mark = now_ms();
+  auto mark = [&](const char* what) {
+    if (plan_timing) {
+      const double t = now_ms();
+      fprintf(stderr, "[plan timing] %-28s %.1f ms\n", what, t - t_mark);
+      t_mark = t;
+    }
+  };
   const uint32_t plane_dwords = (e->P.founder_ct + 31) / 32;
   e->chunks = (plane_dwords + kChunkDwords - 1) / kChunkDwords;
   e->row_dwords = static_cast<uint64_t>(e->chunks) * kRowChunkDwords;
@@ -1112,6 +1136,7 @@ int ensure_device_plan(ldp_engine* e) {
   } else {
     HIP_TRY(e, hipMalloc(&e->d_planes, n * e->row_dwords * sizeof(uint32_t)));
   }
+  mark("image hipMalloc");
   HIP_TRY(e, hipMalloc(&e->d_recs, n * sizeof(ldp_variant_rec)));
   HIP_TRY(e, hipMalloc(&e->d_lo, n * sizeof(uint32_t)));
   HIP_TRY(e, hipMalloc(&e->d_row_off, (n + 1) * sizeof(uint64_t)));
@@ -1135,6 +1160,7 @@ int ensure_device_plan(ldp_engine* e) {
   if (!e->wd_tiles.empty()) {
     HIP_TRY(e, hipMemcpyAsync(e->d_wd_tiles, e->wd_tiles.data(), e->wd_tiles.size() * sizeof(MfmaTile), hipMemcpyHostToDevice, e->stream));
   }
+  mark("other hipMallocs + uploads");
   // checkpoints for early termination
   e->n_checkpoints = 0;
   for (int k = 0; k < kCheckpoints; ++k) {
@@ -1153,6 +1179,7 @@ int ensure_device_plan(ldp_engine* e) {
   HIP_TRY(e, hipHostMalloc(&e->h_pred, std::max<size_t>(e->pred_words, 1) * sizeof(uint32_t), hipHostMallocDefault));
   // (4 counters, then the route words of the launch groups + the inspection launch)
   HIP_TRY(e, hipHostMalloc(&e->h_counters_pin, 4 * sizeof(unsigned long long) + (e->groups.size() + 1) * sizeof(uint32_t), hipHostMallocDefault));
+  mark("pinned host buffers");
   if (e->local_ct) {
     HIP_TRY(e, hipMemcpyAsync(e->d_lo, e->lo_local.data(), e->local_ct * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemcpyAsync(e->d_row_off, e->row_off.data(), (e->local_ct + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
@@ -1161,10 +1188,12 @@ int ensure_device_plan(ldp_engine* e) {
   if ((!e->items.empty()) && !e->codes_format) {  // (the popcount work items: host-side bookkeeping only when the matrix pipe runs)
     HIP_TRY(e, hipMemcpyAsync(e->d_items, e->items.data(), e->items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, e->stream));
   }
+  mark("plan arrays H2D");
   if (e->local_ct) {
     HIP_TRY(e, hipHostRegister(e->recs.data(), e->recs.size() * sizeof(ldp_variant_rec), hipHostRegisterDefault));
     e->recs_registered = true;
   }
+  mark("hipHostRegister(recs)");
   HIP_TRY(e, hipEventCreate(&e->prep_ev0));
   HIP_TRY(e, hipEventCreate(&e->prep_ev1));
   for (ldp_engine::PairGroup& g : e->groups) {
@@ -1177,7 +1206,9 @@ int ensure_device_plan(ldp_engine* e) {
   for (int k = 0; k < kPairStreams; ++k) {
     HIP_TRY(e, hipEventCreateWithFlags(&e->pair_tail[k], hipEventDisableTiming));
   }
+  mark("events");
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  mark("stream sync");
   e->plan_uploaded = true;
   return LDP_OK;
 }
@@ -1223,6 +1254,10 @@ int ensure_staging(ldp_engine* e) {
     HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_stage[k]), bytes));
     HIP_TRY(e, hipEventCreate(&e->stage_done[k]));
     HIP_TRY(e, hipEventRecord(e->stage_done[k], e->stream));
+    HIP_TRY(e, hipEventCreateWithFlags(&e->copied[k], hipEventDisableTiming));
+  }
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(e, hipStreamCreateWithFlags(&e->h2d_stream[k], hipStreamNonBlocking));
   }
   return LDP_OK;
 }
@@ -2021,6 +2056,39 @@ int ldp_device_count(void) {
     return 0;
   }
   return n;
+}
+
+// The first real use of a device creates its context and queues: 40-90 ms on the GPU box (up to half a second on a cold one), which
+// an engine otherwise pays inside its first ldp_load_genotypes().  A host that has other start-up work to do (plink2-hip: the variant
+// and sample tables) calls this on a side thread first.  Creates a stream and a small pinned allocation and frees both.
+int ldp_prewarm(int device) {
+  if ((device < 0) || (device >= ldp_device_count())) {
+    return LDP_ERR_GPU;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    (void)hipGetLastError();
+    return LDP_ERR_GPU;
+  }
+  hipStream_t st = nullptr;
+  void* pin = nullptr;
+  void* dev = nullptr;
+  const bool ok = (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) && (hipHostMalloc(&pin, 1 << 20, hipHostMallocDefault) == hipSuccess) &&
+                  (hipMalloc(&dev, 1 << 20) == hipSuccess) && (hipMemcpyAsync(dev, pin, 1 << 20, hipMemcpyHostToDevice, st) == hipSuccess) &&
+                  (hipStreamSynchronize(st) == hipSuccess);
+  if (dev) {
+    (void)hipFree(dev);
+  }
+  if (pin) {
+    (void)hipHostFree(pin);
+  }
+  if (st) {
+    (void)hipStreamDestroy(st);
+  }
+  if (!ok) {
+    (void)hipGetLastError();
+    return LDP_ERR_GPU;
+  }
+  return LDP_OK;
 }
 
 uint32_t ldp_matrix_pipe_max_founders(void) { return kMfMaxFounders; }
@@ -2939,8 +3007,10 @@ uint64_t ldp_phased_row_bytes(uint32_t hap_ct) { return ldp_phased_phase_offset(
 namespace {
 // ldp_load_genotypes(); d_row_inverse / h_row_inverse (optional, device and host copies of the same n bytes): rows that are
 // LDP_GENO_INVERSE whatever `encoding` says (the collapsed multiallelic rows of ldp_load_pgen_records)
+// src_fd >= 0: the rows are read from that file descriptor at src_off + (variant - first_variant) * stride_bytes (pread straight into
+// the pinned ring; `geno` is unused and location is LDP_MEM_HOST)
 int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* geno, uint64_t stride_bytes, int location, int encoding,
-                   const uint8_t* d_row_inverse, const uint8_t* h_row_inverse) {
+                   const uint8_t* d_row_inverse, const uint8_t* h_row_inverse, int src_fd = -1, uint64_t src_off = 0) {
   if (!e) {
     return LDP_ERR_INVALID;
   }
@@ -2960,7 +3030,7 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
   if (phased && (e->P.founder_ct & 1)) {
     return fail(e, LDP_ERR_INVALID, "LDP_GENO_PHASED rows need an even founder_ct (haplotype count = 2 x samples)");
   }
-  if ((static_cast<uint64_t>(first_variant) + n > e->variant_ct) || (n && !geno)) {
+  if ((static_cast<uint64_t>(first_variant) + n > e->variant_ct) || (n && !geno && (src_fd < 0))) {
     return fail(e, LDP_ERR_INVALID, "variant range out of bounds");
   }
   const uint64_t row_bytes = mapped ? ((static_cast<uint64_t>(e->map_raw_sample_ct) + 3) / 4)
@@ -2968,10 +3038,12 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
   if (stride_bytes < row_bytes) {
     return fail(e, LDP_ERR_INVALID, "stride smaller than a genotype row");
   }
+  const double t_entry = now_ms();
   int rc = ensure_device_plan(e);
   if (rc) {
     return rc;
   }
+  const double t_planned = now_ms();
   HIP_TRY(e, hipSetDevice(e->device));
   const uint8_t* src = static_cast<const uint8_t*>(geno);
   // Host input goes through a 3-deep ring of pinned staging buffers: host threads gather rows into
@@ -3035,6 +3107,10 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
     const char* c = getenv("LDP_DEBUG_COPY_TASK_KB");
     return (c && atoi(c) > 0) ? (static_cast<uint64_t>(atoi(c)) << 10) : (4ull << 20);
   }();
+  static const bool load_timing = getenv("LDP_DEBUG_LOAD_TIMING") != nullptr;  // host side of the file -> HBM leg, on stderr
+  double t_wait_slot = 0.0, t_copy = 0.0;
+  uint32_t n_slots = 0;
+  const double t_call0 = now_ms();
   uint32_t slot = 0;
   uint32_t g = first_variant;
   const uint32_t gend = first_variant + n;
@@ -3065,14 +3141,46 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
       uint64_t d_stride = stride_bytes;
       if (location == LDP_MEM_HOST) {
         cnt = static_cast<uint32_t>(std::min<size_t>(cnt, stage_rows));
+        const double tw0 = load_timing ? now_ms() : 0.0;
         HIP_TRY(e, hipEventSynchronize(e->stage_done[slot]));  // slot free again?
+        const double tw1 = load_timing ? now_ms() : 0.0;
+        t_wait_slot += tw1 - tw0;
         uint8_t* pin = e->h_stage[slot];
         const uint8_t* from = src + static_cast<uint64_t>(g + done - first_variant) * stride_bytes;
         const uint32_t kRowsPerTask = std::max<uint32_t>(1, static_cast<uint32_t>((copy_task_bytes) / pack_stride));
         const uint32_t tasks = (cnt + kRowsPerTask - 1) / kRowsPerTask;
+        std::atomic<int> read_failed(0);
         parallel_for(tasks, copy_threads, [&](uint32_t t) {
           const uint32_t r0 = t * kRowsPerTask;
           const uint32_t r1 = std::min(cnt, r0 + kRowsPerTask);
+          if (src_fd >= 0) {
+            // file -> pinned memory with pread: the kernel copies out of the page cache in large runs and no page of a 12 GB mapping
+            // has to be faulted in first (a memcpy out of an mmap pays one minor fault per 4 KiB: ~28 GB/s on 16 threads, measured)
+            const uint64_t base = src_off + static_cast<uint64_t>(g + done - first_variant) * stride_bytes;
+            auto read_all = [&](uint8_t* dst, uint64_t off, uint64_t len) {
+              while (len) {
+                const ssize_t got = pread(src_fd, dst, len, static_cast<off_t>(off));
+                if (got <= 0) {
+                  if ((got < 0) && (errno == EINTR)) {
+                    continue;
+                  }
+                  read_failed.store(1);
+                  return;
+                }
+                dst += got;
+                off += static_cast<uint64_t>(got);
+                len -= static_cast<uint64_t>(got);
+              }
+            };
+            if (stride_bytes == pack_stride) {
+              read_all(pin + static_cast<uint64_t>(r0) * pack_stride, base + static_cast<uint64_t>(r0) * stride_bytes, static_cast<uint64_t>(r1 - r0 - 1) * pack_stride + row_bytes);
+            } else {
+              for (uint32_t r = r0; r < r1; ++r) {
+                read_all(pin + static_cast<uint64_t>(r) * pack_stride, base + static_cast<uint64_t>(r) * stride_bytes, row_bytes);
+              }
+            }
+            return;
+          }
           if (stride_bytes == pack_stride) {
             const uint64_t len = static_cast<uint64_t>(r1 - r0 - 1) * pack_stride + row_bytes;  // the last row may end at the caller's buffer end
             memcpy(pin + static_cast<uint64_t>(r0) * pack_stride, from + static_cast<uint64_t>(r0) * pack_stride, len);
@@ -3082,8 +3190,33 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
             }
           }
         });
-        HIP_TRY(e, hipMemcpyAsync(e->d_stage[slot], pin, static_cast<size_t>(cnt) * pack_stride, hipMemcpyHostToDevice, e->stream));
-        d_src = e->d_stage[slot];
+        if (read_failed.load()) {
+          return fail(e, LDP_ERR_INVALID, "reading the genotype rows from the file descriptor failed (short file or I/O error)");
+        }
+        if (load_timing) {
+          t_copy += now_ms() - tw1;
+          ++n_slots;
+        }
+        // file -> HBM: the pinned slot crosses PCIe (a) by an SDMA copy on one of TWO copy streams, alternating, which the engine's
+        // stream then waits for (one copy queue tops out near 30 GB/s on this host; the staged rows are read by the count pass), or
+        // (b) LDP_DEBUG_H2D_MODE=2: not at all -- the count pass reads the pinned rows over PCIe itself (host memory is
+        // device-accessible), or (c) =0: the single in-order copy of rounds 1-3.
+        static const int h2d_mode = []() {
+          const char* m = getenv("LDP_DEBUG_H2D_MODE");
+          return m ? atoi(m) : 1;
+        }();
+        if (h2d_mode == 2) {
+          d_src = pin;
+        } else if (h2d_mode == 1) {
+          hipStream_t cs = e->h2d_stream[slot & 1];
+          HIP_TRY(e, hipMemcpyAsync(e->d_stage[slot], pin, static_cast<size_t>(cnt) * pack_stride, hipMemcpyHostToDevice, cs));
+          HIP_TRY(e, hipEventRecord(e->copied[slot], cs));
+          HIP_TRY(e, hipStreamWaitEvent(e->stream, e->copied[slot], 0));
+          d_src = e->d_stage[slot];
+        } else {
+          HIP_TRY(e, hipMemcpyAsync(e->d_stage[slot], pin, static_cast<size_t>(cnt) * pack_stride, hipMemcpyHostToDevice, e->stream));
+          d_src = e->d_stage[slot];
+        }
         d_stride = pack_stride;
       } else {
         d_src = src + static_cast<uint64_t>(g + done - first_variant) * stride_bytes;
@@ -3183,7 +3316,17 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
   e->recs_host_valid = false;
   e->recs_copy_queued = false;
   if (location == LDP_MEM_HOST) {
-    HIP_TRY(e, hipStreamSynchronize(e->stream));  // the caller may reuse its buffer once we return
+    const double ts0 = now_ms();
+    // (No stream synchronisation here: the caller's rows have been copied into the engine's own pinned slots by the time the copy
+    // threads return, so its buffer is free, and the slots' reuse waits on their events.  Draining the ring at the end of every call
+    // cost 3.4 ms per 1 GB call of plink2-hip: profiles/r04_experiments.md.)
+    if (load_timing) {
+      fprintf(stderr, "[load timing] %u rows in %u slots: %.1f ms in all = %.1f waiting for a free slot + %.1f copying into pinned memory (%s) + %.1f other; before that %.1f ms "
+                      "device plan / image allocation + %.1f ms staging ring\n", n,
+              n_slots, now_ms() - t_call0, t_wait_slot, t_copy, (src_fd >= 0) ? "pread" : "memcpy", (now_ms() - t_call0) - t_wait_slot - t_copy, t_planned - t_entry,
+              t_call0 - t_planned);
+      (void)ts0;
+    }
   }
   return LDP_OK;
 }
@@ -3191,6 +3334,13 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
 
 int ldp_load_genotypes(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* geno, uint64_t stride_bytes, int location, int encoding) {
   return load_rows_impl(e, first_variant, n, geno, stride_bytes, location, encoding, nullptr, nullptr);
+}
+
+int ldp_load_genotypes_fd(ldp_engine* e, uint32_t first_variant, uint32_t n, int fd, uint64_t file_offset, uint64_t stride_bytes, int encoding) {
+  if (fd < 0) {
+    return e ? fail(e, LDP_ERR_INVALID, "bad file descriptor") : LDP_ERR_INVALID;
+  }
+  return load_rows_impl(e, first_variant, n, nullptr, stride_bytes, LDP_MEM_HOST, encoding, nullptr, nullptr, fd, file_offset);
 }
 
 namespace {
@@ -3213,8 +3363,27 @@ int dec_reserve(ldp_engine* e, int k, size_t bytes, void** out) {
 // Variant records of a variable-width .pgen, decoded on the device (ldp_pgen_decode.hip) into rows of the FILE's samples and
 // loaded from there like any device-resident rows.  What the reference does per variant on its one reader thread
 // (PgrGetInv1 -> ReadGenovecSubsetUnsafe, plink2_ld.cc:1345-1390 / pgenlib_read.cc:2849-2912, 5417-5563).
+namespace {
+int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* bytes, uint64_t n_bytes, int location, const ldp_pgen_rec* recs,
+                           const ldp_pgen_rec* ld_base, uint32_t raw_sample_ct, uint32_t* major_allele_out, bool phased, uint32_t* unphased_variant);
+}  // namespace
+
 int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* bytes, uint64_t n_bytes, int location, const ldp_pgen_rec* recs,
                           const ldp_pgen_rec* ld_base, uint32_t raw_sample_ct, uint32_t* major_allele_out) {
+  return load_pgen_records_impl(e, first_variant, n, bytes, n_bytes, location, recs, ld_base, raw_sample_ct, major_allele_out, false, nullptr);
+}
+
+int ldp_load_pgen_records_phased(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* bytes, uint64_t n_bytes, int location, const ldp_pgen_rec* recs,
+                                 const ldp_pgen_rec* ld_base, uint32_t raw_sample_ct, uint32_t* unphased_variant) {
+  if (unphased_variant) {
+    *unphased_variant = UINT32_MAX;
+  }
+  return load_pgen_records_impl(e, first_variant, n, bytes, n_bytes, location, recs, ld_base, raw_sample_ct, nullptr, true, unphased_variant);
+}
+
+namespace {
+int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* bytes, uint64_t n_bytes, int location, const ldp_pgen_rec* recs,
+                           const ldp_pgen_rec* ld_base, uint32_t raw_sample_ct, uint32_t* major_allele_out, bool phased, uint32_t* unphased_variant) {
   if (!e) {
     return LDP_ERR_INVALID;
   }
@@ -3225,7 +3394,12 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
     return fail(e, LDP_ERR_INVALID, "variant range out of bounds / null input / bad location");
   }
   const bool mapped = !e->sample_map.empty();
-  if (mapped ? (raw_sample_ct != e->map_raw_sample_ct) : (raw_sample_ct != e->P.founder_ct)) {
+  if (phased) {
+    // --indep-pairphase: the engine's founder_ct is the haplotype count, two per sample of the file (LDP_GENO_PHASED)
+    if (mapped || (static_cast<uint64_t>(raw_sample_ct) * 2 != e->P.founder_ct)) {
+      return fail(e, LDP_ERR_INVALID, "phased records: the engine's founder_ct must be twice the file's sample count, without a sample map");
+    }
+  } else if (mapped ? (raw_sample_ct != e->map_raw_sample_ct) : (raw_sample_ct != e->P.founder_ct)) {
     return fail(e, LDP_ERR_INVALID, "the records' sample count is neither the engine's founder count nor the sample map's raw count");
   }
   if (!n) {
@@ -3253,6 +3427,9 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
     const uint32_t type = recs[q].vrtype & 7u;
     any_ld = any_ld || (type == 2) || (type == 3);
   }
+  if (any_multi && phased) {
+    return fail(e, LDP_ERR_UNSUPPORTED, "phased records with more than one ALT allele: their phase refers to allele pairs (Get1MP, pgenlib_read.cc:6962): build those rows on the host");
+  }
   if (any_multi && mapped) {
     return fail(e, LDP_ERR_UNSUPPORTED, "variants with more than one ALT allele are collapsed over the file's samples: not with a sample map (collapse them on the host, LDP_GENO_INVERSE)");
   }
@@ -3267,7 +3444,10 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
     return rc;
   }
   HIP_TRY(e, hipSetDevice(e->device));
-  const uint64_t stride = ((static_cast<uint64_t>(raw_sample_ct) + 3) / 4 + 15) & ~static_cast<uint64_t>(15);
+  // (phased: a row is codes, padding to a dword, then 16 phase bits per code dword -- the LDP_GENO_PHASED layout the count pass splits)
+  const uint64_t phase_off = phased ? ldp_phased_phase_offset(2 * raw_sample_ct) : 0;
+  const uint64_t stride = phased ? ((phase_off + 2ull * ((static_cast<uint64_t>(raw_sample_ct) + 15) / 16) + 15) & ~static_cast<uint64_t>(15))
+                                 : (((static_cast<uint64_t>(raw_sample_ct) + 3) / 4 + 15) & ~static_cast<uint64_t>(15));
   // ---- the bytes
   const uint8_t* d_bytes;
   if (location == LDP_MEM_HOST) {
@@ -3302,7 +3482,7 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
   // pinned staging for one launch: descriptors | multiallelic record indices | major-allele frequencies | major alleles | error word
   {
     const size_t rows_max = static_cast<size_t>(rows_per_launch) + 1;
-    const size_t want = rows_max * (sizeof(ldp::PgenRecDesc) + sizeof(uint32_t) + sizeof(double) + sizeof(uint32_t)) + 64;
+    const size_t want = rows_max * (sizeof(ldp::PgenRecDesc) + sizeof(uint32_t) + sizeof(double) + sizeof(uint32_t)) + 64;  // (+ the error word and the unphased record behind them)
     if (e->dec_pin_cap < want) {
       HIP_TRY(e, hipStreamSynchronize(e->stream));
       if (e->h_dec_pin) {
@@ -3365,10 +3545,11 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
     if ((rc = dec_reserve(e, 1, rows * sizeof(ldp::PgenRecDesc), &p_recs)) || (rc = dec_reserve(e, 2, static_cast<size_t>(rows) * stride, &p_rows)) ||
         (rc = dec_reserve(e, 3, rows * sizeof(uint64_t), &p_end)) || (rc = dec_reserve(e, 4, (multi.size() + 1) * sizeof(uint32_t), &p_multi)) ||
         (rc = dec_reserve(e, 5, (multi.size() + 1) * sizeof(double), &p_mf)) || (rc = dec_reserve(e, 6, (multi.size() + 1) * sizeof(uint32_t) + sizeof(int), &p_mi)) ||
-        (rc = dec_reserve(e, 7, rows, &p_inv))) {
+        (rc = dec_reserve(e, 7, rows + 8, &p_inv))) {
       return rc;
     }
     int* d_err = reinterpret_cast<int*>(static_cast<uint32_t*>(p_mi) + multi.size() + 1);
+    uint32_t* d_unphased = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(p_inv) + ((static_cast<size_t>(rows) + 3) & ~static_cast<size_t>(3)));  // (behind the row flags)
     HIP_TRY(e, hipMemcpyAsync(p_recs, descs, rows * sizeof(ldp::PgenRecDesc), hipMemcpyHostToDevice, e->stream));
     if (!multi.empty()) {
       memcpy(h_multi, multi.data(), multi.size() * sizeof(uint32_t));
@@ -3376,6 +3557,7 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
     }
     HIP_TRY(e, hipMemsetAsync(d_err, 0, sizeof(int), e->stream));
     HIP_TRY(e, hipMemsetAsync(p_inv, 0, rows, e->stream));
+    HIP_TRY(e, hipMemsetAsync(d_unphased, 0xff, sizeof(uint32_t), e->stream));
     ldp::PgenDecodeArgs DA;
     DA.bytes = d_bytes;
     DA.recs = static_cast<const ldp::PgenRecDesc*>(p_recs);
@@ -3393,9 +3575,17 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
     DA.maj_freq = static_cast<double*>(p_mf);
     DA.maj_idx = static_cast<uint32_t*>(p_mi);
     DA.row_inverse = static_cast<uint8_t*>(p_inv);
+    DA.phase_off = phase_off;
+    DA.unphased = d_unphased;
     hipError_t krc = launch_pgen_main(DA, e->stream);
     if (krc != hipSuccess) {
       return hipfail(e, krc, "pgen_main_kernel launch");
+    }
+    if (phased) {
+      krc = launch_pgen_phase(DA, cnt, e->stream);  // (not the caller's ld_base row behind them: only its codes are a base)
+      if (krc != hipSuccess) {
+        return hipfail(e, krc, "pgen_phase_kernel launch");
+      }
     }
     // the row the next launch's LD-compressed records may build on (taken BEFORE the multiallelic collapse rewrites rows:
     // an LD base is the main track as stored)
@@ -3413,6 +3603,10 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
     h_inverse.assign(cnt, 0);
     *h_err_pin = 0;
     HIP_TRY(e, hipMemcpyAsync(h_err_pin, d_err, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    h_err_pin[1] = -1;
+    if (phased) {
+      HIP_TRY(e, hipMemcpyAsync(h_err_pin + 1, d_unphased, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    }
     if (!multi.empty()) {
       HIP_TRY(e, hipMemcpyAsync(h_maj_freq, p_mf, multi.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
       HIP_TRY(e, hipMemcpyAsync(h_maj_idx, p_mi, multi.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
@@ -3425,6 +3619,14 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
       e->ld_base_valid = false;
       const uint32_t bad = static_cast<uint32_t>(h_err - 1);
       return fail(e, LDP_ERR_INVALID, "malformed variant record in .pgen data (variant " + std::to_string((bad < cnt) ? (first_variant + q0 + bad) : first_variant) + ((bad < cnt) ? ")" : ": its LD base)"));
+    }
+    if (phased && (static_cast<uint32_t>(h_err_pin[1]) != UINT32_MAX)) {
+      // a het call without phase: the reference's "variant #k is not fully phased" (plink2_ld.cc:2045-2049); nothing of this launch is loaded
+      e->ld_base_valid = false;
+      if (unphased_variant) {
+        *unphased_variant = first_variant + q0 + static_cast<uint32_t>(h_err_pin[1]);
+      }
+      return fail(e, LDP_ERR_UNPHASED, "a heterozygous call has no phase (variant " + std::to_string(first_variant + q0 + static_cast<uint32_t>(h_err_pin[1])) + ")");
     }
     for (size_t k = 0; k < multi.size(); ++k) {
       h_inverse[multi[k]] = 1;
@@ -3439,8 +3641,8 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
         }
       }
     }
-    status = load_rows_impl(e, first_variant + q0, cnt, DA.rows, stride, LDP_MEM_DEVICE, LDP_GENO_REF | (mapped ? LDP_GENO_MAPPED : 0), multi.empty() ? nullptr : DA.row_inverse,
-                            multi.empty() ? nullptr : h_inverse.data());
+    status = load_rows_impl(e, first_variant + q0, cnt, DA.rows, stride, LDP_MEM_DEVICE, LDP_GENO_REF | (mapped ? LDP_GENO_MAPPED : 0) | (phased ? LDP_GENO_PHASED : 0),
+                            multi.empty() ? nullptr : DA.row_inverse, multi.empty() ? nullptr : h_inverse.data());
     if (getenv("LDP_DEBUG_TIMELINE")) {
       fprintf(stderr, "decode launch of %u rows: queued in %.3f ms, device done %.3f ms later, rows loaded %.3f ms after that\n", rows, t_q - t_call, t_s - t_q, now_ms() - t_s);
     }
@@ -3458,6 +3660,7 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
   e->dec_next_variant = first_variant + n;
   return status;
 }
+}  // namespace
 
 int ldp_map_rows(ldp_engine* e, uint32_t first_variant, uint32_t n, void** device_rows, uint64_t* stride_bytes) {
   if (!e) {

@@ -560,6 +560,19 @@ int ldp_pgen_record_index(const ldp_pgen* P, uint32_t first_variant, uint32_t n,
   return LDP_OK;
 }
 
+int ldp_pgen_direct_fd(const ldp_pgen* P, uint64_t* first_row_offset, uint64_t* stride_bytes) {
+  if (!P || (P->mode != 0x01 && P->mode != 0x02) || (P->fd < 0)) {
+    return -1;
+  }
+  if (first_row_offset) {
+    *first_row_offset = P->data_off;
+  }
+  if (stride_bytes) {
+    *stride_bytes = P->rec_bytes;
+  }
+  return P->fd;
+}
+
 const void* ldp_pgen_direct_rows(const ldp_pgen* P, uint64_t* stride_bytes) {
   if (!P || (P->mode != 0x01 && P->mode != 0x02)) {
     return nullptr;

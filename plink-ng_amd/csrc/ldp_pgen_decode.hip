@@ -864,7 +864,132 @@ __global__ __launch_bounds__(kAuxThreads) void pgen_aux1_kernel(PgenDecodeArgs A
   (void)for_each_patch(true, [&](uint32_t id, uint32_t /*cat*/, Alleles a) { set_field(row, id, code_of(a)); });
 }
 
+// ---- auxiliary track 2: phased heterozygous hard-calls (--indep-pairphase) ------------------------------------------------
+// pgen_spec.tex "Phased heterozygous hard-calls"; ReadGenovecHphaseSubsetUnsafe, pgenlib_read.cc:6704; what PgrGetInv1P hands
+// HapsplitMustPhased (pgenlib_read.cc:7016, pgenlib_misc.cc:1887).  Behind the main track of a record whose type byte has bit 4
+// set: bit 0 of the first byte says whether a "phasepresent" bit per heterozygous call follows (bits 1 .. H of the same bytes;
+// otherwise every het call is phased); then one "phaseinfo" bit per PHASED het call (set = the ALT allele on the first haplotype,
+// "1|0") -- from the next byte boundary when phasepresent is stored, from bit 1 of the first byte when not.  One workgroup per
+// record: count the het calls of the decoded row (a block scan gives every thread the rank of its first one), the phased ones
+// among them likewise, then every thread sets the phase bits of its own samples: the row's second part (LDP_GENO_PHASED layout,
+// ldprune_hip.h: phase bit of sample s = bit s % 8 of byte phase_off + s / 8), all of it written (zero where there is no het).
+// A het call without phase -- no track at all, or a clear phasepresent bit -- reports its record: A.unphased <- the lowest index.
+__device__ __forceinline__ uint32_t track_bit(const uint8_t* p, const uint8_t* end, uint64_t idx, bool* bad) {
+  const uint8_t* q = p + (idx >> 3);
+  if (q >= end) {
+    *bad = true;
+    return 0;
+  }
+  return (static_cast<uint32_t>(*q) >> (idx & 7)) & 1u;
+}
+// number of set bits among bits [b0, b0 + n) of the track
+__device__ __forceinline__ uint32_t track_popcount(const uint8_t* p, const uint8_t* end, uint64_t b0, uint32_t n, bool* bad) {
+  uint32_t ct = 0;
+  uint64_t b = b0;
+  const uint64_t b1 = b0 + n;
+  while ((b < b1) && (b & 7)) {
+    ct += track_bit(p, end, b++, bad);
+  }
+  while (b + 8 <= b1) {
+    const uint8_t* q = p + (b >> 3);
+    if (q >= end) {
+      *bad = true;
+      return ct;
+    }
+    ct += __builtin_popcount(static_cast<uint32_t>(*q));
+    b += 8;
+  }
+  while (b < b1) {
+    ct += track_bit(p, end, b++, bad);
+  }
+  return ct;
+}
+
+__global__ __launch_bounds__(kThreads) void pgen_phase_kernel(PgenDecodeArgs A) {
+  __shared__ uint32_t s_tmp[kThreads];
+  const uint32_t v = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const PgenRecDesc R = A.recs[v];
+  const uint32_t n = A.sample_ct;
+  uint8_t* rowb = A.rows + static_cast<uint64_t>(v) * A.stride;
+  const uint32_t* row = reinterpret_cast<const uint32_t*>(rowb);
+  uint16_t* phase = reinterpret_cast<uint16_t*>(rowb + A.phase_off);  // 16 samples (one code dword) per entry
+  const uint32_t n_dw = (n + 15) / 16;
+  const uint32_t per = (n_dw + kThreads - 1) / kThreads;
+  const uint32_t d0 = min(tid * per, n_dw), d1 = min(d0 + per, n_dw);
+  uint32_t hets = 0;
+  for (uint32_t d = d0; d < d1; ++d) {
+    const uint32_t w = row[d];
+    hets += __builtin_popcount(w & ~(w >> 1) & 0x55555555u);
+  }
+  uint32_t het_ct = 0;
+  const uint32_t het_before = block_exclusive<kThreads>(hets, s_tmp, tid, &het_ct);
+  const bool has_track = (R.vrtype & 0x10u) != 0;
+  const uint8_t* rec_end = A.bytes + R.off + R.len;
+  const uint8_t* aux2 = A.bytes + A.main_end[v];
+  bool bad = false, unphased = false;
+  bool explicit_present = false;
+  const uint8_t* info = aux2;
+  uint64_t info_bit = 1;
+  uint32_t present_before = het_before;
+  if (has_track && het_ct) {
+    if ((aux2 < A.bytes + R.off) || (aux2 >= rec_end)) {
+      bad = true;
+    } else {
+      explicit_present = (aux2[0] & 1u) != 0;
+    }
+    if (explicit_present) {
+      const uint32_t mine = track_popcount(aux2, rec_end, 1ull + het_before, hets, &bad);
+      uint32_t present_ct = 0;
+      present_before = block_exclusive<kThreads>(mine, s_tmp, tid, &present_ct);
+      info = aux2 + 1 + het_ct / 8;
+      info_bit = 0;
+      if ((!present_ct) || (info + (present_ct + 7) / 8 > rec_end)) {
+        bad = true;
+      }
+    } else if (aux2 + 1 + het_ct / 8 > rec_end) {
+      bad = true;
+    }
+  } else if (het_ct && !has_track) {
+    unphased = true;  // het calls and no phase track at all
+  }
+  uint32_t k = het_before, r = present_before;
+  for (uint32_t d = d0; d < d1; ++d) {
+    const uint32_t w = row[d];
+    uint32_t h = w & ~(w >> 1) & 0x55555555u;
+    uint32_t bits16 = 0;
+    while (h && has_track && !bad) {
+      const uint32_t pos = static_cast<uint32_t>(__builtin_ctz(h)) >> 1;
+      h &= h - 1;
+      const bool present = explicit_present ? (track_bit(aux2, rec_end, 1ull + k, &bad) != 0) : true;
+      ++k;
+      if (present) {
+        bits16 |= track_bit(info, rec_end, info_bit + r, &bad) << pos;
+        ++r;
+      } else {
+        unphased = true;
+      }
+    }
+    phase[d] = static_cast<uint16_t>(bits16);
+  }
+  // (the padding between the codes and the phase bits, and the phase bytes behind the last code dword's two, stay as the main
+  // track's kernel left them: zero)
+  if (bad) {
+    atomicCAS(A.error, 0, static_cast<int>(v) + 1);
+  } else if (unphased && A.unphased) {
+    atomicMin(A.unphased, v);
+  }
+}
+
 }  // namespace
+
+hipError_t launch_pgen_phase(const PgenDecodeArgs& a, uint32_t n_records, hipStream_t stream) {
+  if (!n_records || !a.phase_off) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(pgen_phase_kernel, dim3(n_records), dim3(kThreads), 0, stream, a);
+  return hipGetLastError();
+}
 
 hipError_t launch_pgen_main(const PgenDecodeArgs& a, hipStream_t stream) {
   if (!a.n) {

@@ -3315,7 +3315,8 @@ void load_inputs(Session& S, int argc, char** argv) {
   // sample file is read
   Variants& V = S.V;
   std::thread t_variants([&]() { load_variants(A, &V); });
-  S.t_hip = std::thread([&S]() { const double t0 = now_s(); (void)ldp_device_count(); S.t_hip_init = now_s() - t0; });
+  // (the HIP runtime start-up AND the context of device 0 -- its queues, the first pinned allocation -- beside the table parsing)
+  S.t_hip = std::thread([&S]() { const double t0 = now_s(); if (ldp_device_count() > 0) { (void)ldp_prewarm(0); } S.t_hip_init = now_s() - t0; });
   std::vector<uint8_t>& is_founder = S.is_founder;
   std::vector<std::string> sample_keys;
   const bool sample_filter = (!A.keep_files.empty()) || (!A.remove_files.empty());
@@ -5115,6 +5116,10 @@ int run_prune(Session& S) {
     const uint64_t out_rec = A.pairphase ? ldp_phased_row_bytes(2 * founder_ct) : ((static_cast<uint64_t>(founder_ct) + 3) / 4);
     const int load_encoding = A.pairphase ? (LDP_GENO_REF | LDP_GENO_PHASED) : encoding;
     const uint8_t* direct = A.pairphase ? nullptr : direct_rows;  // phased rows always come through the decoder
+    uint64_t direct_off = 0;
+    // (LDP_DEBUG_LOAD_FD=1: pread() into the pinned ring instead of a memcpy out of the mapping -- measured SLOWER on the GPU box's
+    // host, 32-40 against 53 GB/s per 1 GB call with the page cache warm, so the mapping stays the default)
+    const int direct_fd = (direct && getenv("LDP_DEBUG_LOAD_FD")) ? ldp_pgen_direct_fd(pg, &direct_off, nullptr) : -1;
     std::vector<uint8_t> founder_mask((static_cast<size_t>(raw_sample_ct) + 7) / 8, 0);
     for (uint32_t sidx = 0; sidx < raw_sample_ct; ++sidx) {
       if (is_founder[sidx]) {
@@ -5188,8 +5193,12 @@ int run_prune(Session& S) {
       // Variable-width records are decoded ON THE DEVICE from the file's own bytes (ldp_load_pgen_records: main track of every
       // record type, LD-compressed chains, and -- when the engine's samples are the file's -- the collapse of variants with more
       // than one ALT allele); --indep-pairphase rows (phase track) and LDP_DEBUG_HOST_DECODE=1 take the host decoder below.
-      const bool device_decode = (!direct) && (!A.pairphase) && (storage_mode != 0x01) && (storage_mode != 0x02) && (getenv("LDP_DEBUG_HOST_DECODE") == nullptr);
-      const bool device_multi = device_decode && all_founders;
+      // --indep-pairphase: main AND phase track on the device (ldp_load_pgen_records_phased) when every sample is a founder and no
+      // variant has more than one ALT allele (whose phase refers to allele pairs: host rows, below); otherwise the host decoder.
+      const bool device_phase = A.pairphase && all_founders && (!has_multiallelic) && (storage_mode != 0x01) && (storage_mode != 0x02) &&
+                                (getenv("LDP_DEBUG_HOST_DECODE") == nullptr);
+      const bool device_decode = (!direct) && ((!A.pairphase) || device_phase) && (storage_mode != 0x01) && (storage_mode != 0x02) && (getenv("LDP_DEBUG_HOST_DECODE") == nullptr);
+      const bool device_multi = device_decode && all_founders && !A.pairphase;
       uint64_t file_size = 0;
       const void* file_bytes = device_decode ? ldp_pgen_file_bytes(pg, &file_size) : nullptr;
       std::vector<ldp_pgen_rec> rec_index;
@@ -5247,8 +5256,14 @@ int run_prune(Session& S) {
           }
           const double tl0 = now_s();
           for (int r = 0; r < world; ++r) {
-            const int rc = ldp_load_pgen_records(eng[r], q, run, file_bytes, file_size, LDP_MEM_HOST, rec_index.data(), (base_v != UINT32_MAX) ? &base_rec : nullptr,
-                                                 raw_sample_ct, nullptr);
+            uint32_t bad_q = UINT32_MAX;
+            const int rc = device_phase ? ldp_load_pgen_records_phased(eng[r], q, run, file_bytes, file_size, LDP_MEM_HOST, rec_index.data(),
+                                                                       (base_v != UINT32_MAX) ? &base_rec : nullptr, raw_sample_ct, &bad_q)
+                                        : ldp_load_pgen_records(eng[r], q, run, file_bytes, file_size, LDP_MEM_HOST, rec_index.data(),
+                                                                (base_v != UINT32_MAX) ? &base_rec : nullptr, raw_sample_ct, nullptr);
+            if ((rc == LDP_ERR_UNPHASED) && (bad_q != UINT32_MAX)) {
+              die_unphased(inc[mk[bad_q]]);  // (chunks and launches run in variant order: the first one to fail holds the lowest variant)
+            }
             if (rc) {
               die((rc == LDP_ERR_INVALID) ? 6 : 16, "\nError: %s: %s\n", gpath.c_str(), ldp_last_error(eng[r]));
             }
@@ -5284,7 +5299,12 @@ int run_prune(Session& S) {
         }
         const double tl0 = now_s();
         for (int r = 0; r < world; ++r) {
-          const int rc = ldp_load_genotypes(eng[r], q, run, src, stride, LDP_MEM_HOST, load_encoding | (device_subset ? LDP_GENO_MAPPED : 0));
+          // fixed-width rows as the file has them: out of the mapping, or (LDP_DEBUG_LOAD_FD=1) with pread() straight into the engine's
+          // pinned ring (ldp_load_genotypes_fd)
+          const bool from_fd = direct && (src == direct + static_cast<uint64_t>(raw0) * rec_bytes) && (direct_fd >= 0);
+          const int rc = from_fd ? ldp_load_genotypes_fd(eng[r], q, run, direct_fd, direct_off + static_cast<uint64_t>(raw0) * rec_bytes, stride,
+                                                         load_encoding | (device_subset ? LDP_GENO_MAPPED : 0))
+                                 : ldp_load_genotypes(eng[r], q, run, src, stride, LDP_MEM_HOST, load_encoding | (device_subset ? LDP_GENO_MAPPED : 0));
           if (rc) {
             die(16, "Error: %s\n", ldp_last_error(eng[r]));
           }

@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--window-kb", type=float, default=200.0)
     ap.add_argument("--r2", type=float, default=0.5)
     ap.add_argument("--no-ref", action="store_true")
+    ap.add_argument("--h2d-modes", default="", help="comma-separated LDP_DEBUG_H2D_MODE values to time plink2-hip with (measurement)")
     ap.add_argument("--pgen", action="store_true", help="convert the .bed with the reference's --make-pgen first (variable-width .pgen) and time both tools on that")
     ap.add_argument("--phased", action="store_true", help="--indep-pairphase on a phased variable-width .pgen (haplotypes = the synthetic generator's pseudo-samples, paired up)")
     ap.add_argument("--inter-chr", action="store_true", help="time --r2-unphased inter-chr --ld-window-r2 <--r2> (all pairs; keep --variants small)")
@@ -154,13 +155,18 @@ def main():
                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         print("reference --make-pgen rc", cp.returncode, "wall %.1f s, .pgen %.2f GB" % (time.perf_counter() - t0, os.path.getsize(os.path.join(tmp, "s.pgen")) / 1e9))
         common = ["--pfile", "s"] + common[2:]
-    for rep in range(2):
-        t0 = time.perf_counter()
-        cp = subprocess.run([os.path.join(REPO, "plink-ng_amd", "bin", "plink2-hip")] + common + ["--timing", "--out", "hip"], cwd=tmp,
-                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        t_hip = time.perf_counter() - t0
-        print("plink2-hip rc", cp.returncode, "wall %.3f s" % t_hip)
-        print("\n".join(ln for ln in cp.stdout.splitlines() if "timing" in ln or "removed" in ln or "written" in ln or "Error" in ln or "timeline" in ln or "recs copy" in ln))
+    for mode in (args.h2d_modes.split(",") if args.h2d_modes else [None]):
+        env = dict(os.environ)
+        if mode is not None:
+            env["LDP_DEBUG_H2D_MODE"] = mode   # 0: one in-order copy stream, 1: two copy streams (default), 2: the count pass reads the pinned rows itself
+            print("--- LDP_DEBUG_H2D_MODE=%s" % mode)
+        for rep in range(2):
+            t0 = time.perf_counter()
+            cp = subprocess.run([os.path.join(REPO, "plink-ng_amd", "bin", "plink2-hip")] + common + ["--timing", "--out", "hip"], cwd=tmp,
+                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+            t_hip = time.perf_counter() - t0
+            print("plink2-hip rc", cp.returncode, "wall %.3f s" % t_hip)
+            print("\n".join(ln for ln in cp.stdout.splitlines() if "timing" in ln or "removed" in ln or "written" in ln or "Error" in ln or "timeline" in ln or "recs copy" in ln))
     if not args.no_ref:
         t0 = time.perf_counter()
         cp = subprocess.run([os.path.join(REPO, "oracle", "_ref", "plink2")] + common + ["--threads", str(os.cpu_count()), "--out", "ref"], cwd=tmp,

@@ -869,3 +869,48 @@ def test_sample_counts_around_the_matrix_pipe_limit(gpu_pkg, beyond, missing):
         assert ctr["mfma_block_products"] == 0
     eng.close()
     del buf
+
+
+@pytest.mark.parametrize("n,offset", [(1000, 3), (1001, 0), (50000, 12)])
+def test_rows_read_from_a_file_descriptor(gpu_pkg, tmp_path, n, offset):
+    """ldp_load_genotypes_fd: fixed-width rows pread() straight from a file into the pinned ring -- the same records, maj_freq and
+    prune set as the same rows handed over in host memory (row lengths that are and are not a multiple of four bytes; a header in
+    front of row 0, as a .bed / fixed-width .pgen has)."""
+    pkg = gpu_pkg
+    m = 700
+    raw = T.synth_raw_codes(m, n, seed=n + offset, missing_rate=0.01)
+    chr_idx, bps = make_positions(m, 3, 11)
+    packed = T.pack_2bit(raw)
+    rb = (n + 3) // 4                                   # rows as a .bed / fixed-width .pgen stores them: ceil(n / 4) bytes, no padding
+    rows = np.ascontiguousarray(packed.view(np.uint8).reshape(m, -1)[:, :rb])
+    path = str(tmp_path / "rows.bin")
+    with open(path, "wb") as f:
+        f.write(b"\x6c" * offset)
+        f.write(rows.tobytes())
+    res = []
+    for via_fd in (False, True):
+        eng = pkg.LdPruneEngine(n, 20000, 1, True, 0.3, device=0)
+        eng.set_variants(chr_idx, bps)
+        if via_fd:
+            fd = os.open(path, os.O_RDONLY)
+            try:
+                eng.load_genotypes_fd(0, 300, fd, offset, rb, pkg.LDP_GENO_REF)   # two calls: the second starts mid-file
+                eng.load_genotypes_fd(300, m - 300, fd, offset + 300 * rb, rb, pkg.LDP_GENO_REF)
+            finally:
+                os.close(fd)
+        else:
+            eng.load_genotypes_host(0, packed, pkg.LDP_GENO_REF)
+        res.append((eng.variant_recs().copy(), eng.maj_freqs().copy(), eng.run().copy()))
+        eng.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert res[0][2].sum() > 10
+    # a file that ends early is an error, not a short read silently taken for rows
+    eng = pkg.LdPruneEngine(n, 20000, 1, True, 0.3, device=0)
+    eng.set_variants(chr_idx, bps)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        with pytest.raises(pkg.LdpError):
+            eng.load_genotypes_fd(0, m, fd, offset + 64 * rb, rb, pkg.LDP_GENO_REF)
+    finally:
+        os.close(fd)
+    eng.close()

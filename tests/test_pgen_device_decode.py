@@ -317,3 +317,93 @@ def test_malformed_records_are_refused(gpu_pkg, tmp_path):
         with pytest.raises(pkg.LdpError):
             eng._ck(eng._L.ldp_load_pgen_records(eng._h, ld[0], 1, pkg.ctypes.c_void_p(ptr), nbytes, pkg.LDP_MEM_HOST, one, None, n, None))
     f.close()
+
+
+def phased_engine(pkg, n, m, window=40, r2=0.3):
+    eng = pkg.LdPruneEngine(2 * n, window, 1, False, r2, order=2, device=0)   # haplotypes: two per sample of the file
+    chr_idx, bps = positions(m)
+    eng.set_variants(chr_idx, bps)
+    return eng
+
+
+def test_phase_track_decoded_on_the_device(gpu_pkg):
+    """ldp_load_pgen_records_phased (--indep-pairphase): the hardcall-phase track (auxiliary track 2) of a reference-written,
+    fully phased VCF import decoded on the device -- against the host reader's LDP_GENO_PHASED rows (test_pairphase.py pins those to
+    the reference) loaded from host memory: haplotype rows bit for bit, records, frequencies, prune set; in one call and in calls
+    that cut the LD chains."""
+    pkg = gpu_pkg
+    f = pkg.PgenFile(os.path.join(GOLD, "phased_small.pgen"))
+    m, n = f.variant_ct, f.sample_ct
+    rows = f.read_phased()
+    host = phased_engine(pkg, n, m)
+    host.load_genotypes_host(0, rows, pkg.LDP_GENO_REF | pkg.LDP_GENO_PHASED)
+    dev = phased_engine(pkg, n, m)
+    dev.load_pgen_records_phased(0, f)
+    assert_same_rows(host, dev, m)
+    assert np.array_equal(host.run(), dev.run()) and host.run().sum() > 0
+    dev2 = phased_engine(pkg, n, m)
+    cuts = [0, 1, 5, m // 3, m // 3 + 1, (2 * m) // 3, m]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        dev2.load_pgen_records_phased(a, f, a, b - a)
+    assert_same_rows(host, dev2, m)
+    for e in (host, dev, dev2):
+        e.close()
+    f.close()
+
+
+def test_device_phase_decode_reports_the_first_unphased_variant(gpu_pkg):
+    """A partially phased file (the reference: "variant #40 is not fully phased", plink2_ld.cc:2045-2049): the fully phased head loads,
+    a call that reaches variant 40 returns LDP_ERR_UNPHASED with that variant, whatever the launch size, and the engine stays usable."""
+    pkg = gpu_pkg
+    f = pkg.PgenFile(os.path.join(GOLD, "phased_partial.pgen"))
+    m, n = f.variant_ct, f.sample_ct
+    z = np.load(os.path.join(GOLD, "phased_partial.npz"))
+    first_bad = int(np.argmax(((z["raw"] == 1) & (z["phasepresent"] == 0)).any(axis=1)))
+    assert first_bad == 40
+    dev = phased_engine(pkg, n, m)
+    dev.load_pgen_records_phased(0, f, 0, first_bad)
+    host = phased_engine(pkg, n, m)
+    host.load_genotypes_host(0, f.read_phased(0, first_bad), pkg.LDP_GENO_REF | pkg.LDP_GENO_PHASED)
+    for v in range(first_bad):
+        assert all(np.array_equal(a, b) for a, b in zip(host.planes(v), dev.planes(v)))
+    for rows_per_launch in (None, "7"):
+        if rows_per_launch:
+            os.environ["LDP_DEBUG_DECODE_ROWS"] = rows_per_launch
+        try:
+            with pytest.raises(pkg.LdpError) as ei:
+                dev.load_pgen_records_phased(0, f)
+        finally:
+            os.environ.pop("LDP_DEBUG_DECODE_ROWS", None)
+        assert ei.value.code == pkg.LDP_ERR_UNPHASED and ei.value.variant == first_bad
+    dev.load_pgen_records_phased(0, f, 0, first_bad)   # still usable
+    dev.close()
+    host.close()
+    f.close()
+
+
+@pytest.mark.skipif(not T.have_ref(), reason="reference binary not built")
+@pytest.mark.parametrize("m,n,seed,miss", [(300, 40, 1, 0.0), (700, 1000, 2, 0.02), (120, 70001, 3, 0.01)])
+def test_phase_tracks_of_reference_imported_vcfs(gpu_pkg, tmp_path, m, n, seed, miss):
+    """Phased VCFs imported by the reference (--vcf ... --make-pgen: phase tracks with and without explicit phasepresent beside
+    every main-track record type), decoded on the device against the host reader; up to 70,001 samples (rows assembled outside LDS)."""
+    pkg = gpu_pkg
+    raw, pp, pi = T.synth_phased(m, n, seed=seed, missing_rate=miss)
+    T.write_vcf(str(tmp_path / "p.vcf"), raw, ["1"] * m, np.arange(m) + 1, phasepresent=(raw == 1), phaseinfo=pi)
+    cp = T.run_ref(["--vcf", "p.vcf", "--make-pgen", "--out", "p"], str(tmp_path))
+    assert cp.returncode == 0, cp.stdout
+    f = pkg.PgenFile(str(tmp_path / "p.pgen"))
+    assert (f.variant_ct, f.sample_ct) == (m, n)
+    host = phased_engine(pkg, n, m)
+    host.load_genotypes_host(0, f.read_phased(threads=4), pkg.LDP_GENO_REF | pkg.LDP_GENO_PHASED)
+    dev = phased_engine(pkg, n, m)
+    dev.load_pgen_records_phased(0, f)
+    ra, rb = host.variant_recs(), dev.variant_recs()
+    for name in ("nm_ct", "sum", "ssq", "flags"):
+        assert np.array_equal(ra[name], rb[name]), name
+    for v in range(0, m, max(1, m // 40)):
+        assert all(np.array_equal(a, b) for a, b in zip(host.planes(v), dev.planes(v))), v
+    assert np.array_equal(host.maj_freqs(), dev.maj_freqs())
+    assert np.array_equal(host.run(), dev.run())
+    host.close()
+    dev.close()
+    f.close()
