@@ -17,6 +17,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <set>
 #include <string>
@@ -73,6 +75,80 @@ void parallel_for(uint32_t n, uint32_t max_threads, F fn) {
     th.join();
   }
 }
+
+// The same on threads that stay: the file -> pinned-memory copies of ldp_load_genotypes() come as hundreds of short batches (one per
+// 16 MiB slot), and spawning sixteen threads for each cost as much as the copy itself.  One pool per process, created at first use;
+// run() is called from one thread at a time per pool user (the engines of a multi-device process take turns through the mutex).
+class CopyPool {
+ public:
+  static CopyPool& get() {
+    static CopyPool* pool = new CopyPool();  // (never destroyed: its threads may outlive main()'s statics)
+    return *pool;
+  }
+  template <class F>
+  void run(uint32_t n, uint32_t max_threads, F fn) {
+    if (n <= 1 || workers_.empty()) {
+      for (uint32_t t = 0; t < n; ++t) {
+        fn(t);
+      }
+      return;
+    }
+    std::lock_guard<std::mutex> user(user_mu_);
+    std::function<void(uint32_t)> f = fn;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &f;
+      n_ = n;
+      next_.store(0);
+      done_ = 0;
+      active_ = std::min<uint32_t>(std::min<uint32_t>(max_threads, static_cast<uint32_t>(workers_.size())), n);
+      ++epoch_;
+    }
+    cv_.notify_all();
+    for (uint32_t t = next_.fetch_add(1); t < n; t = next_.fetch_add(1)) {  // (the caller works too)
+      f(t);
+    }
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&]() { return done_ == active_; });
+    fn_ = nullptr;
+  }
+
+ private:
+  CopyPool() {
+    const uint32_t nt = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    for (uint32_t w = 0; w + 1 < nt; ++w) {
+      workers_.emplace_back([this, w]() {
+        uint64_t seen = 0;
+        for (;;) {
+          std::function<void(uint32_t)>* f;
+          uint32_t n;
+          {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&]() { return (epoch_ != seen) && (w < active_); });
+            seen = epoch_;
+            f = fn_;
+            n = n_;
+          }
+          for (uint32_t t = next_.fetch_add(1); t < n; t = next_.fetch_add(1)) {
+            (*f)(t);
+          }
+          std::lock_guard<std::mutex> lk(mu_);
+          if (++done_ == active_) {
+            cv_done_.notify_one();
+          }
+        }
+      });
+      workers_.back().detach();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_, user_mu_;
+  std::condition_variable cv_, cv_done_;
+  std::function<void(uint32_t)>* fn_ = nullptr;
+  uint32_t n_ = 0, active_ = 0, done_ = 0;
+  uint64_t epoch_ = 0;
+  std::atomic<uint32_t> next_{0};
+};
 
 }  // namespace
 
@@ -3105,7 +3181,7 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
   }();
   static const uint64_t copy_task_bytes = []() {
     const char* c = getenv("LDP_DEBUG_COPY_TASK_KB");
-    return (c && atoi(c) > 0) ? (static_cast<uint64_t>(atoi(c)) << 10) : (4ull << 20);
+    return (c && atoi(c) > 0) ? (static_cast<uint64_t>(atoi(c)) << 10) : (1ull << 20);
   }();
   static const bool load_timing = getenv("LDP_DEBUG_LOAD_TIMING") != nullptr;  // host side of the file -> HBM leg, on stderr
   double t_wait_slot = 0.0, t_copy = 0.0;
@@ -3150,7 +3226,7 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
         const uint32_t kRowsPerTask = std::max<uint32_t>(1, static_cast<uint32_t>((copy_task_bytes) / pack_stride));
         const uint32_t tasks = (cnt + kRowsPerTask - 1) / kRowsPerTask;
         std::atomic<int> read_failed(0);
-        parallel_for(tasks, copy_threads, [&](uint32_t t) {
+        CopyPool::get().run(tasks, copy_threads, [&](uint32_t t) {
           const uint32_t r0 = t * kRowsPerTask;
           const uint32_t r1 = std::min(cnt, r0 + kRowsPerTask);
           if (src_fd >= 0) {
