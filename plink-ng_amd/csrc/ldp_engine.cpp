@@ -163,6 +163,7 @@ struct EngineOptions {
   uint32_t wide_min_reach = kWdMinReach;  // band reach (row-blocks) from which a subcontig takes the 8 x 8 tile plan; LDP_DEBUG_WIDE_MIN_REACH
   bool pair_four = true;      // LDP_PAIR_FOUR=0: rows with missing calls always take all six products (prune launches otherwise four)
   bool four_tiles = true;     // LDP_PAIR_FOUR_TILES=0: the four-product form stays on the parallelogram plan in wide bands too
+  bool wide_diag_last = true; // LDP_DEBUG_WIDE_DIAG_LAST=0: the tiles of a launch in plain J order (diagonal tiles among the others)
 };
 
 constexpr uint32_t kStageSlots = 4;  // pinned staging ring of host-memory input
@@ -216,6 +217,7 @@ struct ldp_engine {
     uint32_t mf_first = 0, mf_ct = 0;    // the same J range as matrix-pipe workgroups (mf_wgs) ...
     uint32_t mf_diag_ct = 0;             // ... of which the first mf_diag_ct are all-diagonal (partition_diag)
     uint32_t wd_first = 0, wd_ct = 0;    // ... and as wide-band tiles (wd_tiles)
+    uint32_t wl_first = 0, wl_ct = 0;    // ... in launch order (wd_launch: eight XCD streams, padded to equal length)
     bool four_tiles = false;             // the group's last launch queued pair_mfma_tile4_kernel for them
     bool launched = false;
     hipEvent_t ev_ready = nullptr;
@@ -228,6 +230,7 @@ struct ldp_engine {
   uint32_t r_signed = 0;                  // ldp_set_r_signed
   std::vector<MfmaWG> mf_wgs;
   std::vector<MfmaTile> wd_tiles;         // the 8 x 8 tile plan of the wide-band subcontigs (ldp_pair_wide.hip), in J order
+  std::vector<MfmaTile> wd_launch;        // the same tiles as the device gets them: per launch group eight XCD streams (see build_shard)
   uint64_t mf_products = 0;               // 32 x 32 block products of the plan
   uint32_t next_group = 0;                 // groups before this one are launched for the current load epoch
   uint32_t loaded_prefix = 0;              // local variants [0, loaded_prefix) were loaded in the current epoch
@@ -643,6 +646,8 @@ EngineOptions options_from_env() {
   o.pair_four = !(four && (strcmp(four, "0") == 0));
   const char* ft = getenv("LDP_PAIR_FOUR_TILES");
   o.four_tiles = !(ft && (strcmp(ft, "0") == 0));
+  const char* dl = getenv("LDP_DEBUG_WIDE_DIAG_LAST");
+  o.wide_diag_last = !(dl && (strcmp(dl, "0") == 0));
   if (const char* w = getenv("LDP_DEBUG_WIDE_MIN_REACH")) {
     o.wide_min_reach = static_cast<uint32_t>(std::max(0, atoi(w)));
   }
@@ -1136,6 +1141,48 @@ void build_shard(ldp_engine* e) {
       g.wd_ct = t1 - t0;
       t0 = t1;
     }
+    // Launch order of the tiles.  The kernels hand workgroup b to XCD b % 8 and give XCD x the tiles [x per, (x + 1) per) of the
+    // launch's array, in order, so that the tiles running together on an XCD are neighbours and share row-blocks through its L2.
+    // That only works while they also walk the samples together -- a (row-block, stage) unit lives in the 4 MB L2 for about two
+    // stages -- and tiles of equal length started together do: a laggard hits what the leaders fetched and catches up.  DIAGONAL
+    // tiles break it: their near products are the pairs in LD, they run to the end of the rows (1.0 against ~0.6 of the others at
+    // r^2 0.2), one in eight tiles, and behind the first of them a stream never re-aligns (profiles/r04_pmc_traffic.json: 6.1 x
+    // the compulsory bytes over 148 rounds of config 3's share, L2 hit rate 31 %).  So every stream gets its off-diagonal tiles
+    // first, J tile by J tile, and its diagonal tiles at the end.  Streams are padded to equal length with empty tiles (mask 0).
+    e->wd_launch.clear();
+    for (ldp_engine::PairGroup& g : e->groups) {
+      g.wl_first = static_cast<uint32_t>(e->wd_launch.size());
+      g.wl_ct = 0;
+      if (!g.wd_ct) {
+        continue;
+      }
+      std::vector<uint32_t> off, diag;
+      for (uint32_t t = g.wd_first; t < g.wd_first + g.wd_ct; ++t) {
+        ((e->opt.wide_diag_last && (e->wd_tiles[t].jv == e->wd_tiles[t].vv)) ? diag : off).push_back(t);
+      }
+      auto chunk = [](size_t n, uint32_t x) { return std::make_pair(n * x / 8, n * (x + 1) / 8); };
+      size_t per = 0;
+      for (uint32_t x = 0; x < 8; ++x) {
+        const auto co = chunk(off.size(), x), cd = chunk(diag.size(), x);
+        per = std::max(per, (co.second - co.first) + (cd.second - cd.first));
+      }
+      MfmaTile empty;
+      memset(&empty, 0, sizeof(empty));
+      for (uint32_t x = 0; x < 8; ++x) {
+        const auto co = chunk(off.size(), x), cd = chunk(diag.size(), x);
+        size_t k = 0;
+        for (size_t q = co.first; q < co.second; ++q, ++k) {
+          e->wd_launch.push_back(e->wd_tiles[off[q]]);
+        }
+        for (size_t q = cd.first; q < cd.second; ++q, ++k) {
+          e->wd_launch.push_back(e->wd_tiles[diag[q]]);
+        }
+        for (; k < per; ++k) {
+          e->wd_launch.push_back(empty);
+        }
+      }
+      g.wl_ct = static_cast<uint32_t>(8 * per);
+    }
   }
   e->load_tag.assign(local, 0);
   e->load_epoch = 1;
@@ -1232,9 +1279,9 @@ int ensure_device_plan(ldp_engine* e) {
   if (!e->mf_wgs.empty()) {
     HIP_TRY(e, hipMemcpyAsync(e->d_mf_wgs, e->mf_wgs.data(), e->mf_wgs.size() * sizeof(MfmaWG), hipMemcpyHostToDevice, e->stream));
   }
-  HIP_TRY(e, hipMalloc(&e->d_wd_tiles, std::max<size_t>(e->wd_tiles.size(), 1) * sizeof(MfmaTile)));
-  if (!e->wd_tiles.empty()) {
-    HIP_TRY(e, hipMemcpyAsync(e->d_wd_tiles, e->wd_tiles.data(), e->wd_tiles.size() * sizeof(MfmaTile), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMalloc(&e->d_wd_tiles, std::max<size_t>(e->wd_launch.size(), 1) * sizeof(MfmaTile)));
+  if (!e->wd_launch.empty()) {
+    HIP_TRY(e, hipMemcpyAsync(e->d_wd_tiles, e->wd_launch.data(), e->wd_launch.size() * sizeof(MfmaTile), hipMemcpyHostToDevice, e->stream));
   }
   mark("other hipMallocs + uploads");
   // checkpoints for early termination
@@ -1811,8 +1858,8 @@ int launch_group(ldp_engine* e, uint32_t gi) {
     A.mf_wgs = e->d_mf_wgs + g.mf_first;
     A.n_mf_wgs = g.mf_ct;
     A.mf_diag_ct = g.mf_diag_ct;
-    A.wd_tiles = e->d_wd_tiles + g.wd_first;
-    A.n_wd_tiles = g.wd_ct;
+    A.wd_tiles = e->d_wd_tiles + g.wl_first;
+    A.n_wd_tiles = g.wl_ct;
     A.wd_active = e->wd_tiles.empty() ? 0u : 1u;
     // prune launches over rows with missing calls: the four-product form takes the tile plan's subcontigs in quarter tiles
     A.wd_general = (A.mf_four && e->opt.four_tiles && !A.stats && !A.r2_out && !A.r2_hits && A.n_wd_tiles) ? 1u : 0u;
@@ -1923,7 +1970,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
       A.mf_wgs = e->d_mf_wgs;
       A.n_mf_wgs = static_cast<uint32_t>(e->mf_wgs.size());
       A.wd_tiles = e->d_wd_tiles;
-      A.n_wd_tiles = static_cast<uint32_t>(e->wd_tiles.size());
+      A.n_wd_tiles = static_cast<uint32_t>(e->wd_launch.size());
       A.wd_active = e->wd_tiles.empty() ? 0u : 1u;
     }
     hipError_t krc = launch_pair_tiles(A, e->max_rows, e->stream, evk);
@@ -1937,8 +1984,8 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
         G.mf_wgs = e->d_mf_wgs + g.mf_first;
         G.n_mf_wgs = g.mf_ct;
         G.mf_diag_ct = g.mf_diag_ct;
-        G.wd_tiles = e->d_wd_tiles + g.wd_first;
-        G.n_wd_tiles = g.wd_ct;
+        G.wd_tiles = e->d_wd_tiles + g.wl_first;
+        G.n_wd_tiles = g.wl_ct;
         krc = launch_pair_mfma(G, e->stream, evk + 4);
         if (krc != hipSuccess) {
           return hipfail(e, krc, "pair_mfma_kernel launch");
@@ -3226,7 +3273,8 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
         const uint32_t kRowsPerTask = std::max<uint32_t>(1, static_cast<uint32_t>((copy_task_bytes) / pack_stride));
         const uint32_t tasks = (cnt + kRowsPerTask - 1) / kRowsPerTask;
         std::atomic<int> read_failed(0);
-        CopyPool::get().run(tasks, copy_threads, [&](uint32_t t) {
+        static const bool use_pool = !(getenv("LDP_DEBUG_COPY_POOL") && (atoi(getenv("LDP_DEBUG_COPY_POOL")) == 0));
+        auto copy_task = [&](uint32_t t) {
           const uint32_t r0 = t * kRowsPerTask;
           const uint32_t r1 = std::min(cnt, r0 + kRowsPerTask);
           if (src_fd >= 0) {
@@ -3265,7 +3313,12 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
               memcpy(pin + static_cast<uint64_t>(r) * pack_stride, from + static_cast<uint64_t>(r) * stride_bytes, row_bytes);
             }
           }
-        });
+        };
+        if (use_pool) {
+          CopyPool::get().run(tasks, copy_threads, copy_task);
+        } else {
+          parallel_for(tasks, copy_threads, copy_task);
+        }
         if (read_failed.load()) {
           return fail(e, LDP_ERR_INVALID, "reading the genotype rows from the file descriptor failed (short file or I/O error)");
         }
@@ -3942,6 +3995,11 @@ int ldp_debug_set_option(ldp_engine* e, const char* name, double value) {
     e->opt.wide_min_reach = (value >= 4294967295.0) ? 0xffffffffu : static_cast<uint32_t>(std::max(0.0, value));
   } else if (n == "pair_four") {
     e->opt.pair_four = (value != 0.0);
+  } else if (n == "wide_diag_last") {
+    if (e->planned) {
+      return fail(e, LDP_ERR_STATE, "wide_diag_last must be set before ldp_set_variants()");
+    }
+    e->opt.wide_diag_last = (value != 0.0);
   } else if (n == "pair_four_tiles") {
     e->opt.four_tiles = (value != 0.0);
   } else if (n == "pair_sparse") {

@@ -180,6 +180,9 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
   const uint32_t jend = __builtin_amdgcn_readfirstlane(tile->jend);
   const uint32_t mask_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tile->mask));
   const uint32_t mask_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tile->mask >> 32));
+  if (!(mask_lo | mask_hi)) {
+    return;  // (padding of an XCD's stream: the launch's streams are of equal length, ldp_engine.cpp build_shard)
+  }
   const bool diag = (jv0 == vv0);
   const int32_t g_bias = g_bias_of(A.founder_ct, kWdStageSamples);
   const uint32_t row_bytes = static_cast<uint32_t>(A.code_row_bytes);
