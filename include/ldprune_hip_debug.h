@@ -30,8 +30,9 @@ int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first
  *                     two sums of squares from per-variant intervals (exact count for the few pairs they leave open); 0 = all six
  *   "pair_four_tiles" 0/1: ... and in wide bands (subcontigs with the tile plan) that form runs over quarter tiles instead of the
  *                     parallelogram plan (default 1)
- *   "wide_diag_last"  0/1: within a launch every XCD's stream of 8 x 8 tiles runs its off-diagonal tiles first and its diagonal tiles
- *                     (the long ones: their near products hold the pairs in LD) at the end (default 1; before ldp_set_variants())
+ *   "wide_diag_last"  k: within a launch every XCD's stream of 8 x 8 tiles runs its far tiles first and the tiles fewer than k tile
+ *                     distances from the diagonal (the long ones: they hold the pairs in LD) at the end; 0 = plain J order (default 2;
+ *                     before ldp_set_variants())
  *   "wide_min_reach"  row-blocks a subcontig's band must reach to take the 8 x 8 tile plan of the wide-band kernel; 0 = always,
  *                     a huge value = never (before ldp_set_variants())
  * Results never depend on these.  Unknown name: LDP_ERR_INVALID. */

@@ -163,7 +163,7 @@ struct EngineOptions {
   uint32_t wide_min_reach = kWdMinReach;  // band reach (row-blocks) from which a subcontig takes the 8 x 8 tile plan; LDP_DEBUG_WIDE_MIN_REACH
   bool pair_four = true;      // LDP_PAIR_FOUR=0: rows with missing calls always take all six products (prune launches otherwise four)
   bool four_tiles = true;     // LDP_PAIR_FOUR_TILES=0: the four-product form stays on the parallelogram plan in wide bands too
-  bool wide_diag_last = true; // LDP_DEBUG_WIDE_DIAG_LAST=0: the tiles of a launch in plain J order (diagonal tiles among the others)
+  uint32_t wide_diag_last = 2; // LDP_DEBUG_WIDE_DIAG_LAST=k: tiles fewer than k tile distances from the diagonal run at the end of their XCD stream (0: plain J order)
 };
 
 constexpr uint32_t kStageSlots = 4;  // pinned staging ring of host-memory input
@@ -647,7 +647,7 @@ EngineOptions options_from_env() {
   const char* ft = getenv("LDP_PAIR_FOUR_TILES");
   o.four_tiles = !(ft && (strcmp(ft, "0") == 0));
   const char* dl = getenv("LDP_DEBUG_WIDE_DIAG_LAST");
-  o.wide_diag_last = !(dl && (strcmp(dl, "0") == 0));
+  o.wide_diag_last = dl ? static_cast<uint32_t>(std::max(0, atoi(dl))) : 2u;
   if (const char* w = getenv("LDP_DEBUG_WIDE_MIN_REACH")) {
     o.wide_min_reach = static_cast<uint32_t>(std::max(0, atoi(w)));
   }
@@ -1147,8 +1147,10 @@ void build_shard(ldp_engine* e) {
     // stages -- and tiles of equal length started together do: a laggard hits what the leaders fetched and catches up.  DIAGONAL
     // tiles break it: their near products are the pairs in LD, they run to the end of the rows (1.0 against ~0.6 of the others at
     // r^2 0.2), one in eight tiles, and behind the first of them a stream never re-aligns (profiles/r04_pmc_traffic.json: 6.1 x
-    // the compulsory bytes over 148 rounds of config 3's share, L2 hit rate 31 %).  So every stream gets its off-diagonal tiles
-    // first, J tile by J tile, and its diagonal tiles at the end.  Streams are padded to equal length with empty tiles (mask 0).
+    // the compulsory bytes over 148 rounds of config 3's share, L2 hit rate 31 %).  So every stream gets its far tiles first, J tile
+    // by J tile, and the tiles next to the diagonal at the end -- the diagonal ones and their first neighbours, which hold the rest
+    // of the pairs in LD (config 3's share, kernel ms with the last 0 / 1 / 2 / 3 / 4 tile distances deferred: 330 / 302 / 296 / 297 /
+    // 319; HBM traffic 6.1 -> 5.3 x compulsory with 1).  Streams are padded to equal length with empty tiles (mask 0).
     e->wd_launch.clear();
     for (ldp_engine::PairGroup& g : e->groups) {
       g.wl_first = static_cast<uint32_t>(e->wd_launch.size());
@@ -1158,7 +1160,8 @@ void build_shard(ldp_engine* e) {
       }
       std::vector<uint32_t> off, diag;
       for (uint32_t t = g.wd_first; t < g.wd_first + g.wd_ct; ++t) {
-        ((e->opt.wide_diag_last && (e->wd_tiles[t].jv == e->wd_tiles[t].vv)) ? diag : off).push_back(t);
+        const uint32_t dist = static_cast<uint32_t>(e->wd_tiles[t].jv - e->wd_tiles[t].vv) / (kMfBlock * kWdTile);
+        ((dist < e->opt.wide_diag_last) ? diag : off).push_back(t);
       }
       auto chunk = [](size_t n, uint32_t x) { return std::make_pair(n * x / 8, n * (x + 1) / 8); };
       size_t per = 0;
@@ -3999,7 +4002,7 @@ int ldp_debug_set_option(ldp_engine* e, const char* name, double value) {
     if (e->planned) {
       return fail(e, LDP_ERR_STATE, "wide_diag_last must be set before ldp_set_variants()");
     }
-    e->opt.wide_diag_last = (value != 0.0);
+    e->opt.wide_diag_last = static_cast<uint32_t>(std::max(0.0, value));
   } else if (n == "pair_four_tiles") {
     e->opt.four_tiles = (value != 0.0);
   } else if (n == "pair_sparse") {
