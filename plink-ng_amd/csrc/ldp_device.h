@@ -189,9 +189,13 @@ struct PairKernelArgs {
   uint32_t sparse_ok;            // the route may be kRouteSparse (prune launches): launch that instantiation as well
   // wide-band tiles (launch_pair_wide): complete-data launches only; the workgroups of mf_wgs whose MfmaWG::pad is 1 cover the
   // same subcontigs for the other two routes and are skipped by pair_mfma_kernel<., false> when wd_active is set
-  const MfmaTile* wd_tiles;
+  const MfmaTile* wd_tiles;      // in launch order (eight XCD streams of equal length, far tiles first; ldp_engine.cpp build_shard)
   uint32_t n_wd_tiles;
   uint32_t wd_active;
+  // the same tiles in plain J order, for pair_mfma_tile4_kernel: its quarter tiles stop at their own checkpoints, workgroup by
+  // workgroup, and the deferred order costs it 3 % (config 5's density: 115.1 against 118.3 ms); nullptr: wd_tiles serves both
+  const MfmaTile* wd_tiles_plain;
+  uint32_t n_wd_tiles_plain;
 };
 
 constexpr uint32_t kRouteComplete = 0, kRouteSparse = 1, kRouteGeneral = 2;

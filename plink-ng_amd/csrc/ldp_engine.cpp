@@ -266,7 +266,8 @@ struct ldp_engine {
   cp_slot* d_cp_stats = nullptr;           // per-variant checkpoint statistics (early termination)
   cp_gen_slot* d_cp_gen = nullptr;         // ... for tiles with missing calls
   MfmaWG* d_mf_wgs = nullptr;
-  MfmaTile* d_wd_tiles = nullptr;
+  MfmaTile* d_wd_tiles = nullptr;          // wd_launch
+  MfmaTile* d_wd_tiles_plain = nullptr;    // wd_tiles (J order), when the two differ
   MissStats* d_miss_stats = nullptr;       // [slot of d_route]: missing calls of the resident rows a launch reads (summed from the records when the launch is queued)
   uint32_t* d_route = nullptr;             // [g]: which matrix-pipe kernel owns launch group g (route_kernel, when the group is queued); [groups]: other launches
   uint32_t checkpoint_chunk[kCheckpoints];
@@ -413,6 +414,8 @@ void free_device(ldp_engine* e) {
   (void)hipFree(e->d_mf_wgs);
   (void)hipFree(e->d_wd_tiles);
   e->d_wd_tiles = nullptr;
+  (void)hipFree(e->d_wd_tiles_plain);
+  e->d_wd_tiles_plain = nullptr;
   (void)hipFree(e->d_miss_stats);
   (void)hipFree(e->d_route);
   e->d_mf_wgs = nullptr;
@@ -1285,6 +1288,10 @@ int ensure_device_plan(ldp_engine* e) {
   HIP_TRY(e, hipMalloc(&e->d_wd_tiles, std::max<size_t>(e->wd_launch.size(), 1) * sizeof(MfmaTile)));
   if (!e->wd_launch.empty()) {
     HIP_TRY(e, hipMemcpyAsync(e->d_wd_tiles, e->wd_launch.data(), e->wd_launch.size() * sizeof(MfmaTile), hipMemcpyHostToDevice, e->stream));
+    if (e->opt.wide_diag_last) {
+      HIP_TRY(e, hipMalloc(&e->d_wd_tiles_plain, e->wd_tiles.size() * sizeof(MfmaTile)));
+      HIP_TRY(e, hipMemcpyAsync(e->d_wd_tiles_plain, e->wd_tiles.data(), e->wd_tiles.size() * sizeof(MfmaTile), hipMemcpyHostToDevice, e->stream));
+    }
   }
   mark("other hipMallocs + uploads");
   // checkpoints for early termination
@@ -1792,6 +1799,8 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.wd_tiles = nullptr;
   A.n_wd_tiles = 0;
   A.wd_active = 0;
+  A.wd_tiles_plain = nullptr;
+  A.n_wd_tiles_plain = 0;
 }
 
 // A new load epoch begins (variants are being loaded again): whatever the pair streams still run belongs to the
@@ -1864,6 +1873,10 @@ int launch_group(ldp_engine* e, uint32_t gi) {
     A.wd_tiles = e->d_wd_tiles + g.wl_first;
     A.n_wd_tiles = g.wl_ct;
     A.wd_active = e->wd_tiles.empty() ? 0u : 1u;
+    if (e->d_wd_tiles_plain) {
+      A.wd_tiles_plain = e->d_wd_tiles_plain + g.wd_first;
+      A.n_wd_tiles_plain = g.wd_ct;
+    }
     // prune launches over rows with missing calls: the four-product form takes the tile plan's subcontigs in quarter tiles
     A.wd_general = (A.mf_four && e->opt.four_tiles && !A.stats && !A.r2_out && !A.r2_hits && A.n_wd_tiles) ? 1u : 0u;
     g.four_tiles = (A.wd_general != 0);
@@ -1989,6 +2002,10 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
         G.mf_diag_ct = g.mf_diag_ct;
         G.wd_tiles = e->d_wd_tiles + g.wl_first;
         G.n_wd_tiles = g.wl_ct;
+        if (e->d_wd_tiles_plain) {
+          G.wd_tiles_plain = e->d_wd_tiles_plain + g.wd_first;
+          G.n_wd_tiles_plain = g.wd_ct;
+        }
         krc = launch_pair_mfma(G, e->stream, evk + 4);
         if (krc != hipSuccess) {
           return hipfail(e, krc, "pair_mfma_kernel launch");

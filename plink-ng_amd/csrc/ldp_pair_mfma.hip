@@ -1422,13 +1422,14 @@ __global__ __launch_bounds__(T4<JB>::kWaves * 64, 2) void pair_mfma_tile4_kernel
       return;
     }
   }
-  const uint32_t n_units = A.n_wd_tiles * C::kUnits;
+  const MfmaTile* __restrict__ tiles = A.wd_tiles_plain ? A.wd_tiles_plain : A.wd_tiles;  // (J order: ldp_device.h)
+  const uint32_t n_units = (A.wd_tiles_plain ? A.n_wd_tiles_plain : A.n_wd_tiles) * C::kUnits;
   const uint32_t per_xcd = (n_units + 7) / 8;
   const uint32_t idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (idx >= n_units) {
     return;
   }
-  const MfmaTile* __restrict__ tile = A.wd_tiles + (idx / C::kUnits);
+  const MfmaTile* __restrict__ tile = tiles + (idx / C::kUnits);
   const uint32_t qj = (idx % C::kUnits) >> 1, qv = idx & 1u;  // J blocks JB qj .., V blocks 4 qv ..
   const int32_t jv0 = __builtin_amdgcn_readfirstlane(tile->jv) + static_cast<int32_t>(kMfBlock * JB * qj);
   const int32_t vv0 = __builtin_amdgcn_readfirstlane(tile->vv) + static_cast<int32_t>(kMfBlock * 4 * qv);
@@ -1890,7 +1891,7 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
       }();
       PairKernelArgs t4 = a_in;
       t4.lds_dwords = T4<4>::kLdsDwords;
-      const uint32_t per_xcd = (a_in.n_wd_tiles * T4<4>::kUnits + 7) / 8;
+      const uint32_t per_xcd = ((a_in.wd_tiles_plain ? a_in.n_wd_tiles_plain : a_in.n_wd_tiles) * T4<4>::kUnits + 7) / 8;
       hipLaunchKernelGGL(pair_mfma_tile4_kernel<4>, dim3(per_xcd * 8), dim3(T4<4>::kWaves * 64), t4lds, stream, t4);
     }
     const uint32_t gper_xcd = (g.n_mf_wgs * 8 + 7) / 8;
