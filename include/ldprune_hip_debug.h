@@ -28,6 +28,8 @@ int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first
  *   "sparse_frac"     mean missing fraction up to which a launch takes it
  *   "pair_four"       0/1: prune launches over rows with more missing calls than that multiply four products per pair and take the
  *                     two sums of squares from per-variant intervals (exact count for the few pairs they leave open); 0 = all six
+ *   "pair_gu"         0/1: the four-product form's operands are allele counts and missing flags (default 1; exact up to 1,800,000
+ *                     founders, engines with more use 0 by themselves); 0 = the +-2 coded x and the call flags n of rounds 2-3
  *   "pair_four_tiles" 0/1: ... and in wide bands (subcontigs with the tile plan) that form runs over quarter tiles instead of the
  *                     parallelogram plan (default 1)
  *   "wide_diag_last"  k: within a launch every XCD's stream of 8 x 8 tiles runs its far tiles first and the tiles fewer than k tile

@@ -99,6 +99,7 @@ constexpr int kMfMaxRowBlocks = 16;
 constexpr int kMfWaves = 4;
 constexpr int kMfMaxDmaPerWave = (2 * kMfMaxRowBlocks + kMfWaves - 1) / kMfWaves;  // (256-sample stages: two DMA instructions of 64 slots per row-block)
 constexpr uint32_t kMfMaxFounders = 4000000;   // f32 accumulators stay integer-exact: complete rows accumulate sum g_i g_j <= 4 N (ldp_mfma_device.h)
+constexpr uint32_t kMfGuMaxFounders = 1800000;  // ... and the four-product form's allele-count / missing-flag operands while 9 N < 2^24 (ldp_mfma_device.h)
 
 struct MfmaWaveItem {
   int32_t jv;        // first variant of J0 (J1 = jv + 32); < 0: the wave has nothing to do
@@ -186,6 +187,7 @@ struct PairKernelArgs {
   const uint32_t* route;         // kRoute*
   uint32_t wd_general;           // (set by the launcher) the tile plan's subcontigs are taken by pair_mfma_tile4_kernel: the missing-call kernel skips their workgroups
   uint32_t mf_four;              // prune launches on the six-product route may use its four-product form (EngineOptions::pair_four)
+  uint32_t mf_gu;                // ... with allele counts g' and missing flags u as operands (ldp_mfma_device.h; founder_ct <= kMfGuMaxFounders)
   uint32_t sparse_ok;            // the route may be kRouteSparse (prune launches): launch that instantiation as well
   // wide-band tiles (launch_pair_wide): complete-data launches only; the workgroups of mf_wgs whose MfmaWG::pad is 1 cover the
   // same subcontigs for the other two routes and are skipped by pair_mfma_kernel<., false> when wd_active is set

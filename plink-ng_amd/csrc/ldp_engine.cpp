@@ -162,6 +162,7 @@ struct EngineOptions {
   double sparse_frac = 0.005; // LDP_PAIR_SPARSE=0 -> 0; LDP_DEBUG_SPARSE_FRAC
   uint32_t wide_min_reach = kWdMinReach;  // band reach (row-blocks) from which a subcontig takes the 8 x 8 tile plan; LDP_DEBUG_WIDE_MIN_REACH
   bool pair_four = true;      // LDP_PAIR_FOUR=0: rows with missing calls always take all six products (prune launches otherwise four)
+  bool pair_gu = true;        // option "pair_gu" 0: the four-product form multiplies x and n (rounds 2-3) instead of allele counts and missing flags
   bool four_tiles = true;     // LDP_PAIR_FOUR_TILES=0: the four-product form stays on the parallelogram plan in wide bands too
   uint32_t wide_diag_last = 2; // LDP_DEBUG_WIDE_DIAG_LAST=k: tiles fewer than k tile distances from the diagonal run at the end of their XCD stream (0: plain J order)
 };
@@ -309,6 +310,7 @@ struct ldp_engine {
   size_t ld_base_cap = 0;
   bool ld_base_valid = false;
   uint32_t dec_next_variant = 0;  // the call that may use d_ld_base starts here
+  uint64_t dec_next_offset = 0;        // ... and the file offset right behind that call's last record
 
   ldp_counters ctr;
 
@@ -1795,6 +1797,7 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.route = nullptr;
   A.sparse_ok = 0;
   A.mf_four = e->opt.pair_four ? 1u : 0u;
+  A.mf_gu = (e->opt.pair_gu && (e->P.founder_ct <= kMfGuMaxFounders)) ? 1u : 0u;
   A.wd_general = 0;
   A.wd_tiles = nullptr;
   A.n_wd_tiles = 0;
@@ -2938,7 +2941,7 @@ struct Rccl {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
 };
-const Rccl& rccl() {
+static const Rccl& rccl() {
   static const Rccl R = []() {
     Rccl r;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
@@ -3619,7 +3622,9 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
     HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_ld_base), stride));
     e->ld_base_cap = stride;
   }
-  bool have_carried = e->ld_base_valid && (e->dec_next_variant == first_variant);
+  // (the carried base is the record that PRECEDES this call's first one in the file: same engine position AND same file position --
+  // a caller that loads non-adjacent file ranges into adjacent engine indices gets LDP_ERR_INVALID below instead of a wrong row)
+  bool have_carried = e->ld_base_valid && (e->dec_next_variant == first_variant) && (e->dec_next_offset == recs[0].offset);
   // ---- in launches of at most ~256 MiB of rows
   uint32_t rows_per_launch = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / stride)));
   if (const char* dbg = getenv("LDP_DEBUG_DECODE_ROWS")) {  // (test hook: many small launches, LD chains cut everywhere)
@@ -3807,6 +3812,7 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
   }
   e->ld_base_valid = have_carried && (status == LDP_OK);
   e->dec_next_variant = first_variant + n;
+  e->dec_next_offset = recs[n - 1].offset + recs[n - 1].length;
   return status;
 }
 }  // namespace
@@ -4015,6 +4021,8 @@ int ldp_debug_set_option(ldp_engine* e, const char* name, double value) {
     e->opt.wide_min_reach = (value >= 4294967295.0) ? 0xffffffffu : static_cast<uint32_t>(std::max(0.0, value));
   } else if (n == "pair_four") {
     e->opt.pair_four = (value != 0.0);
+  } else if (n == "pair_gu") {
+    e->opt.pair_gu = (value != 0.0);
   } else if (n == "wide_diag_last") {
     if (e->planned) {
       return fail(e, LDP_ERR_STATE, "wide_diag_last must be set before ldp_set_variants()");

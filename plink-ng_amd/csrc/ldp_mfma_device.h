@@ -79,6 +79,45 @@ __device__ __forceinline__ mf_v16f mfma_pair(const Frag& a, const Frag& b, mf_v1
     return mfma_fp4(a, b, c);
   }
 }
+// ---- rows with missing calls, prune launches: allele counts g' and the MISSING flag u ----------------------------------------------
+// The four-product form of the missing-call kernels (ldp_pair_mfma.hip) multiplied x (+-2 coding, 0 at a missing call) and n (call
+// present: 2.0 almost everywhere).  At the power cap the operand values are what an MFMA costs (above), so since round 4 the vectors are
+//   g' = the 2-bit code itself as an allele count (0, 1, 2 -- and 3 at a missing call: the code is not touched, three VALU per dword)
+//   u  = 1 at a missing call (5 % of the genotypes at config 5, none elsewhere: four VALU per dword; seven in all, as x and n cost)
+// both as E2M1 in the low half of a nibble (g' / 2, u / 2 = 0.5) with block scale 2.  The four products
+//   P1 = g'_i.g'_j   P4 = u_i.u_j   P3 = u_i.g'_j   P2 = g'_i.u_j
+// give, with z = g' - 3 u (the allele count with a missing call as 0): z.z = P1 - 3 P2 - 3 P3 + 9 P4, z_i.u_j = P2 - 3 P4,
+// u_i.z_j = P3 - 3 P4, u.u = P4, and with each row's own U = its missing calls and Z = its sum of z over the same samples (from the
+// records / the checkpoint slots) everything ComputeIndepPairwiseR2Components wants over the pairwise-complete samples, exactly, in
+// integers (x = 1 - z on called samples): nm = n - U_i - U_j + u.u,  S1 = Z_i - z_i.u_j,  S2 = Z_j - u_i.z_j,
+//   sum1 = nm - S1   sum2 = nm - S2   dot = nm - S1 - S2 + z.z         (image orientation, as before).
+// Padding samples are coded 11 in every row: they drop out of z.z, z.u and u.z by themselves and add n_pad to u.u.
+// Exact while 9 N < 2^24: kMfGuMaxFounders (ldp_device.h); engines with more founders keep the x / n operands.
+__device__ __forceinline__ void fp4_gu_of_dword(uint32_t X, uint32_t* g_even, uint32_t* g_odd, uint32_t* u_even, uint32_t* u_odd) {
+  const uint32_t Xs = X >> 2;
+  *g_even = X & 0x33333333u;
+  *g_odd = Xs & 0x33333333u;
+  *u_even = __builtin_amdgcn_bitop3_b32(X, X >> 1, 0x11111111u, 0x80);   // a & b & c
+  *u_odd = __builtin_amdgcn_bitop3_b32(Xs, Xs >> 1, 0x11111111u, 0x80);
+}
+__device__ __forceinline__ void fp4_gu_of_codes(uint32_t c0, uint32_t c1, Frag& fg, Frag& fu) {
+  fp4_gu_of_dword(c0, &fg.d[0], &fg.d[1], &fu.d[0], &fu.d[1]);
+  fp4_gu_of_dword(c1, &fg.d[2], &fg.d[3], &fu.d[2], &fu.d[3]);
+}
+// accumulators (P1, P4, P3, P2) of a pair over n_vis real samples (+ n_pad padding samples) and the two rows' (U, Z) over the same
+// samples -> dot, nm, sum2, sum1
+__device__ __forceinline__ void x_from_gu(int32_t P1, int32_t P4, int32_t P3, int32_t P2, int32_t Ui, int32_t Zi, int32_t Uj, int32_t Zj, int32_t n_vis, int32_t n_pad,
+                                          int32_t* dot, int32_t* nm, int32_t* sum2, int32_t* sum1) {
+  const int32_t uu = P4 - n_pad;
+  const int32_t zu = P2 - 3 * P4, uz = P3 - 3 * P4;
+  const int32_t zz = P1 - 3 * P2 - 3 * P3 + 9 * P4;
+  const int32_t n = n_vis - Ui - Uj + uu;
+  const int32_t S1 = Zi - zu, S2 = Zj - uz;
+  *nm = n;
+  *sum1 = n - S1;
+  *sum2 = n - S2;
+  *dot = n - S1 - S2 + zz;
+}
 // what a launch subtracts from G: N for the shift x = 1 - g, 9 per padding sample the kernel walks over (it visits whole stages of
 // stage_samples; the image's rows are whole 512-sample chunks with every sample beyond founder_ct coded 11)
 __device__ __forceinline__ int32_t g_bias_of(uint32_t founder_ct, uint32_t stage_samples) {
@@ -87,6 +126,12 @@ __device__ __forceinline__ int32_t g_bias_of(uint32_t founder_ct, uint32_t stage
 }
 // a record's sum of x in the IMAGE's orientation (the record itself is in major-allele orientation; flags bit 0 = they differ)
 __device__ __forceinline__ int32_t sum_img_of(const ldp_variant_rec& r) { return (r.flags & 1u) ? -r.sum : r.sum; }
+
+// a record's (U, Z) over the whole row: missing calls, and the sum of the allele count over its calls (image orientation)
+__device__ __forceinline__ void uz_of_rec(const ldp_variant_rec& r, uint32_t founder_ct, int32_t* U, int32_t* Z) {
+  *U = static_cast<int32_t>(founder_ct - r.nm_ct);
+  *Z = static_cast<int32_t>(r.nm_ct) - sum_img_of(r);
+}
 
 typedef uint32_t mf_u4 __attribute__((ext_vector_type(4)));  // (a native vector: usable as an inline-asm operand)
 

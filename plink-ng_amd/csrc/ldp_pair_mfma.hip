@@ -1019,10 +1019,14 @@ __device__ __forceinline__ int classify_four(const ldp_pair_stats_t& ps, const l
 // S_i - sum1 =: xm, so hm lies in [|xm|, R] with the parity of xm.  The predicate cov^2 > thresh var1 var2 is monotone in ssq1 and
 // ssq2 (the reference's own rounding included: products of non-negative doubles), so it is decided whenever both ends of the
 // intervals agree; the few pairs left open are counted exactly on the spot by the whole wave (wave_pair_counts, as in 4.1d).
-template <bool SIX>
+template <bool SIX, bool GU>
 __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(PairKernelArgs A) {
   using G = StageGeom<4>;
   constexpr int NP = SIX ? 6 : 4;
+  // GU (four-product form, founder_ct <= kMfGuMaxFounders): the operands are the allele counts g' and the missing flags u
+  // (ldp_mfma_device.h): accumulators (P1, P4, P3, P2), turned into (dot, nm, sum2, sum1) where they are read; otherwise x, n (, h)
+  static_assert(!(SIX && GU), "the six-product form keeps x, n, h");
+  constexpr bool ZC = GU;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_src_off[kMfGenDmaPerWave * kMfWaves * 64];
   __shared__ uint32_t s_live_waves;
@@ -1174,23 +1178,31 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
       mf_u4 jH = st4[j_slot + oH], jR = st4[j_slot + oR];
       mf_u4 vH = st4[v_slot + oH], vR = st4[v_slot + oR];
       opaque(jH, jR);
-      Frag jx[4], jn[4], jh[4];
+      Frag jx[4], jn[4], jh[4];  // (ZC: jx holds z)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        fp4_of_codes(jH[ks], jR[ks], jx[ks]);
-        fp4_nh_of_codes(jH[ks], jR[ks], jx[ks], jn[ks], jh[ks]);
+        if constexpr (ZC) {
+          fp4_gu_of_codes(jH[ks], jR[ks], jx[ks], jn[ks]);  // (jx = g', jn = u)
+        } else {
+          fp4_of_codes(jH[ks], jR[ks], jx[ks]);
+          fp4_nh_of_codes(jH[ks], jR[ks], jx[ks], jn[ks], jh[ks]);
+        }
       }
       opaque(vH, vR);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         Frag vx, vn, vh;
-        fp4_of_codes(vH[ks], vR[ks], vx);
-        fp4_nh_of_codes(vH[ks], vR[ks], vx, vn, vh);
+        if constexpr (ZC) {
+          fp4_gu_of_codes(vH[ks], vR[ks], vx, vn);
+        } else {
+          fp4_of_codes(vH[ks], vR[ks], vx);
+          fp4_nh_of_codes(vH[ks], vR[ks], vx, vn, vh);
+        }
         // rows of C = first variant i (A operand: the V block), columns = second variant j (B operand: the J block)
-        acc[0] = mfma_fp4(vx, jx[ks], acc[0]);
-        acc[1] = mfma_fp4(vn, jn[ks], acc[1]);
-        acc[2] = mfma_fp4(vn, jx[ks], acc[2]);
-        acc[3] = mfma_fp4(vx, jn[ks], acc[3]);
+        acc[0] = mfma_pair<ZC>(vx, jx[ks], acc[0]);
+        acc[1] = mfma_pair<ZC>(vn, jn[ks], acc[1]);
+        acc[2] = mfma_pair<ZC>(vn, jx[ks], acc[2]);
+        acc[3] = mfma_pair<ZC>(vx, jn[ks], acc[3]);
         if constexpr (SIX) {
           acc[4] = mfma_fp4(vn, jh[ks], acc[4]);
           acc[5] = mfma_fp4(vh, jn[ks], acc[5]);
@@ -1229,6 +1241,8 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
       const uint64_t seen = static_cast<uint64_t>(kc) * G::kStageSamples;
       const double seen_d = static_cast<double>((seen < A.founder_ct) ? seen : A.founder_ct);
       const GenRow gj = gen_row(cpl[q * 64 + r], cpl[q * 64 + 32 + r], seen_d);
+      const int32_t uj_p = static_cast<int32_t>(seen_d) - static_cast<int32_t>(cpl[q * 64 + 32 + r].nm_r - cpl[q * 64 + r].nm_r);
+      const int32_t zj_p = static_cast<int32_t>(cpl[q * 64 + 32 + r].zs_r - cpl[q * 64 + r].zs_r);
       uint32_t* mine_epi = lds + wave * (kMfGenCpWaveDwords + kMfGenCpRowDwords);
       GenRow* rows_i = reinterpret_cast<GenRow*>(mine_epi + kMfGenCpWaveDwords);
       if (h == 0) {
@@ -1253,8 +1267,19 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
             const int64_t i64 = static_cast<int64_t>(vfirst_blk) + row;
             if ((lo_j != 0xffffffffu) && (i64 >= static_cast<int64_t>(lo_j)) && (i64 < j64)) {
               const GenRow gi = rows_i[row];
-              auto val = [&](uint32_t c) { return static_cast<double>(static_cast<int32_t>(mine_epi[(c * kMfGenCpRound + gg) * 64 + lane])); };
-              hopeless = hopeless && pair_hopeless_centred<SIX>(A.thresh, val(1), val(3), SIX ? val(5) : 0.0, val(2), SIX ? val(4) : 0.0, val(0), gi, gj, rs);
+              auto raw = [&](uint32_t c) { return static_cast<int32_t>(mine_epi[(c * kMfGenCpRound + gg) * 64 + lane]); };
+              int32_t dot_p = raw(0), nm_p = raw(1), s2_p = raw(2), s1_p = raw(3);
+              if constexpr (ZC) {
+                // the rows' missing calls and allele-count sums over the samples visited (cp_gen_slot: calls and sum z of the whole row
+                // and of the remainder, image orientation; no padding among the samples visited)
+                const cp_gen_slot ci = cpl[(2 + vk) * 64 + row], wi = cpl[(2 + vk) * 64 + 32 + row];
+                const int32_t n_vis = static_cast<int32_t>(seen_d);
+                x_from_gu(raw(0), raw(1), raw(2), raw(3), n_vis - static_cast<int32_t>(wi.nm_r - ci.nm_r), static_cast<int32_t>(wi.zs_r - ci.zs_r), uj_p, zj_p, n_vis, 0, &dot_p, &nm_p,
+                          &s2_p, &s1_p);
+              }
+              auto val = [&](uint32_t c) { return static_cast<double>(raw(c)); };
+              hopeless = hopeless && pair_hopeless_centred<SIX>(A.thresh, static_cast<double>(nm_p), static_cast<double>(s1_p), SIX ? val(5) : 0.0, static_cast<double>(s2_p),
+                                                                SIX ? val(4) : 0.0, static_cast<double>(dot_p), gi, gj, rs);
             }
           }
         }
@@ -1345,10 +1370,16 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
         const ldp_variant_rec ri = A.recs[i];
         const bool alt_i = (ri.flags & 1u) != 0;
         alt_ij = (alt_i ? 1u : 0u) | (alt_j ? 2u : 0u);
-        const int32_t d = static_cast<int32_t>(epi4[(0 * 8 + g8) * 64 + lane]), s2 = static_cast<int32_t>(epi4[(2 * 8 + g8) * 64 + lane]),
-                      s1 = static_cast<int32_t>(epi4[(3 * 8 + g8) * 64 + lane]);
+        int32_t d = static_cast<int32_t>(epi4[(0 * 8 + g8) * 64 + lane]), s2 = static_cast<int32_t>(epi4[(2 * 8 + g8) * 64 + lane]),
+                s1 = static_cast<int32_t>(epi4[(3 * 8 + g8) * 64 + lane]), nm = static_cast<int32_t>(epi4[(1 * 8 + g8) * 64 + lane]);
+        if constexpr (ZC) {
+          int32_t Ui, Zi, Uj, Zj;
+          uz_of_rec(ri, A.founder_ct, &Ui, &Zi);
+          uz_of_rec(rj, A.founder_ct, &Uj, &Zj);
+          x_from_gu(d, nm, s2, s1, Ui, Zi, Uj, Zj, static_cast<int32_t>(A.founder_ct), static_cast<int32_t>(n_stages * G::kStageSamples - A.founder_ct), &d, &nm, &s2, &s1);
+        }
+        ps.nm = static_cast<uint32_t>(nm);
         ps.dot = (alt_i != alt_j) ? -d : d;
-        ps.nm = epi4[(1 * 8 + g8) * 64 + lane];
         ps.sum2 = alt_j ? -s2 : s2;
         ps.sum1 = alt_i ? -s1 : s1;
         cls = classify_four(ps, ri, rj, N, A.thresh);
@@ -1409,7 +1440,7 @@ struct T4 {  // JB J row-blocks x 4 V row-blocks per workgroup, 2 JB waves
   static_assert(kWaves * 4 * 8 * 64 <= kLdsDwords, "epilogue scratch inside the ring");
 };
 
-template <int JB>
+template <int JB, bool GU>
 __global__ __launch_bounds__(T4<JB>::kWaves * 64, 2) void pair_mfma_tile4_kernel(PairKernelArgs A) {
   using G = StageGeom<4>;
   using C = T4<JB>;
@@ -1524,7 +1555,7 @@ __global__ __launch_bounds__(T4<JB>::kWaves * 64, 2) void pair_mfma_tile4_kernel
   const uint32_t oR = r * 4 + ((2 + h) ^ sw);
   const uint32_t v_slot0 = (JB + vb0) * G::kBlockSlots, v_slot1 = (JB + 1 + vb0) * G::kBlockSlots;
 
-  mf_v16f acc[2][4];  // [product][0 x.x  1 n.n  2 n_i.x_j  3 x_i.n_j]
+  mf_v16f acc[2][4];  // [product][0 x.x  1 n.n  2 n_i.x_j  3 x_i.n_j]; GU: [0 g'.g'  1 u.u  2 u_i.g'_j  3 g'_i.u_j], turned into dot, nm, sum2, sum1 where they are read
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
 #pragma unroll
@@ -1592,26 +1623,39 @@ __global__ __launch_bounds__(T4<JB>::kWaves * 64, 2) void pair_mfma_tile4_kernel
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           // the J operand of the k-step, expanded once for both products
+          // the J operand of the k-step, expanded once for both products (GU: jx = g', jn = u, ldp_mfma_device.h; otherwise x, n)
           Frag jx, jn, unused;
-          fp4_of_codes(jH[ks], jR[ks], jx);
-          fp4_nh_of_codes(jH[ks], jR[ks], jx, jn, unused);
-          {
-            Frag vx, vn;
-            fp4_of_codes(aH[ks], aR[ks], vx);
-            fp4_nh_of_codes(aH[ks], aR[ks], vx, vn, unused);
-            acc[0][0] = mfma_fp4(vx, jx, acc[0][0]);
-            acc[0][1] = mfma_fp4(vn, jn, acc[0][1]);
-            acc[0][2] = mfma_fp4(vn, jx, acc[0][2]);
-            acc[0][3] = mfma_fp4(vx, jn, acc[0][3]);
+          if constexpr (GU) {
+            fp4_gu_of_codes(jH[ks], jR[ks], jx, jn);
+          } else {
+            fp4_of_codes(jH[ks], jR[ks], jx);
+            fp4_nh_of_codes(jH[ks], jR[ks], jx, jn, unused);
           }
           {
             Frag vx, vn;
-            fp4_of_codes(bH[ks], bR[ks], vx);
-            fp4_nh_of_codes(bH[ks], bR[ks], vx, vn, unused);
-            acc[1][0] = mfma_fp4(vx, jx, acc[1][0]);
-            acc[1][1] = mfma_fp4(vn, jn, acc[1][1]);
-            acc[1][2] = mfma_fp4(vn, jx, acc[1][2]);
-            acc[1][3] = mfma_fp4(vx, jn, acc[1][3]);
+            if constexpr (GU) {
+              fp4_gu_of_codes(aH[ks], aR[ks], vx, vn);
+            } else {
+              fp4_of_codes(aH[ks], aR[ks], vx);
+              fp4_nh_of_codes(aH[ks], aR[ks], vx, vn, unused);
+            }
+            acc[0][0] = mfma_pair<GU>(vx, jx, acc[0][0]);
+            acc[0][1] = mfma_pair<GU>(vn, jn, acc[0][1]);
+            acc[0][2] = mfma_pair<GU>(vn, jx, acc[0][2]);
+            acc[0][3] = mfma_pair<GU>(vx, jn, acc[0][3]);
+          }
+          {
+            Frag vx, vn;
+            if constexpr (GU) {
+              fp4_gu_of_codes(bH[ks], bR[ks], vx, vn);
+            } else {
+              fp4_of_codes(bH[ks], bR[ks], vx);
+              fp4_nh_of_codes(bH[ks], bR[ks], vx, vn, unused);
+            }
+            acc[1][0] = mfma_pair<GU>(vx, jx, acc[1][0]);
+            acc[1][1] = mfma_pair<GU>(vn, jn, acc[1][1]);
+            acc[1][2] = mfma_pair<GU>(vn, jx, acc[1][2]);
+            acc[1][3] = mfma_pair<GU>(vx, jn, acc[1][3]);
           }
         }
       }
@@ -1651,6 +1695,8 @@ __global__ __launch_bounds__(T4<JB>::kWaves * 64, 2) void pair_mfma_tile4_kernel
       const double seen_d = static_cast<double>((seen < A.founder_ct) ? seen : A.founder_ct);
       const double rs = (seen < A.founder_ct) ? static_cast<double>(A.founder_ct - seen) : 1.0;
       const GenRow gj = gen_row(cpl[ja * 64 + r], cpl[ja * 64 + 32 + r], seen_d);
+      const int32_t uj_p = static_cast<int32_t>(seen_d) - static_cast<int32_t>(cpl[ja * 64 + 32 + r].nm_r - cpl[ja * 64 + r].nm_r);
+      const int32_t zj_p = static_cast<int32_t>(cpl[ja * 64 + 32 + r].zs_r - cpl[ja * 64 + r].zs_r);
       uint32_t* mine_epi = lds + wave * C::kCpWaveDwords;
       GenRow* rows_i = reinterpret_cast<GenRow*>(mine_epi + 4 * kMfGenCpRound * 64);
 #pragma unroll
@@ -1679,8 +1725,16 @@ __global__ __launch_bounds__(T4<JB>::kWaves * 64, 2) void pair_mfma_tile4_kernel
               const int64_t i64 = static_cast<int64_t>(vfirst0) + kMfBlock * p + row;
               if ((lo_j != 0xffffffffu) && (i64 >= static_cast<int64_t>(lo_j)) && (i64 < j64)) {
                 const GenRow gi = rows_i[row];
-                auto val = [&](uint32_t c) { return static_cast<double>(static_cast<int32_t>(mine_epi[(c * kMfGenCpRound + gg) * 64 + lane])); };
-                hopeless = hopeless && pair_hopeless_centred<false>(A.thresh, val(1), val(3), 0.0, val(2), 0.0, val(0), gi, gj, rs);
+                auto raw = [&](uint32_t c) { return static_cast<int32_t>(mine_epi[(c * kMfGenCpRound + gg) * 64 + lane]); };
+                int32_t dot_p = raw(0), nm_p = raw(1), s2_p = raw(2), s1_p = raw(3);
+                if constexpr (GU) {
+                  const cp_gen_slot ci = cpl[(JB + vb0 + p) * 64 + row], wi = cpl[(JB + vb0 + p) * 64 + 32 + row];
+                  const int32_t n_vis = static_cast<int32_t>(seen_d);
+                  x_from_gu(raw(0), raw(1), raw(2), raw(3), n_vis - static_cast<int32_t>(wi.nm_r - ci.nm_r), static_cast<int32_t>(wi.zs_r - ci.zs_r), uj_p, zj_p, n_vis, 0, &dot_p,
+                            &nm_p, &s2_p, &s1_p);
+                }
+                hopeless = hopeless && pair_hopeless_centred<false>(A.thresh, static_cast<double>(nm_p), static_cast<double>(s1_p), 0.0, static_cast<double>(s2_p), 0.0,
+                                                                    static_cast<double>(dot_p), gi, gj, rs);
               }
             }
           }
@@ -1773,10 +1827,16 @@ __global__ __launch_bounds__(T4<JB>::kWaves * 64, 2) void pair_mfma_tile4_kernel
           const bool alt_i = (ri.flags & 1u) != 0;
           alt_ij = (alt_i ? 1u : 0u) | (alt_j ? 2u : 0u);
           ldp_pair_stats_t ps;
-          const int32_t d = static_cast<int32_t>(epi4[(0 * 8 + g8) * 64 + lane]), s2 = static_cast<int32_t>(epi4[(2 * 8 + g8) * 64 + lane]),
-                        s1 = static_cast<int32_t>(epi4[(3 * 8 + g8) * 64 + lane]);
+          int32_t d = static_cast<int32_t>(epi4[(0 * 8 + g8) * 64 + lane]), s2 = static_cast<int32_t>(epi4[(2 * 8 + g8) * 64 + lane]),
+                  s1 = static_cast<int32_t>(epi4[(3 * 8 + g8) * 64 + lane]), nm = static_cast<int32_t>(epi4[(1 * 8 + g8) * 64 + lane]);
+          if constexpr (GU) {
+            int32_t Ui, Zi, Uj, Zj;
+            uz_of_rec(ri, A.founder_ct, &Ui, &Zi);
+            uz_of_rec(rj, A.founder_ct, &Uj, &Zj);
+            x_from_gu(d, nm, s2, s1, Ui, Zi, Uj, Zj, static_cast<int32_t>(A.founder_ct), static_cast<int32_t>(n_stages * G::kStageSamples - A.founder_ct), &d, &nm, &s2, &s1);
+          }
+          ps.nm = static_cast<uint32_t>(nm);
           ps.dot = (alt_i != alt_j) ? -d : d;
-          ps.nm = epi4[(1 * 8 + g8) * 64 + lane];
           ps.sum2 = alt_j ? -s2 : s2;
           ps.sum1 = alt_i ? -s1 : s1;
           dot_major = ps.dot;
@@ -1874,32 +1934,44 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
       if (const char* kb = getenv("LDP_DEBUG_MFMA_GEN_LDS_KB")) {
         bytes = std::min<size_t>(std::max<size_t>(static_cast<size_t>(atoi(kb)), 20), 150) * 1024;
       }
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_general_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_general_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_general_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_general_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_general_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
       return bytes;
     }();
     PairKernelArgs g = a_in;
     g.lds_dwords = static_cast<uint32_t>(glds / sizeof(uint32_t));
+    // the four-product forms' operands: allele counts and missing flags while 9 N stays exact in f32 (ldp_mfma_device.h), x and n otherwise
+    const bool gu = (a_in.mf_gu != 0) && (a_in.founder_ct <= kMfGuMaxFounders);
     // prune launches over subcontigs with the tile plan: quarter tiles (four products); the parallelogram workgroups of those
     // subcontigs then stay out (wd_general)
     if (a_in.wd_general) {
       // quarter tiles: JB = 4 (half tiles of J, two workgroups of four waves per CU, measured the same: profiles/r03_experiments.md)
       static const size_t t4lds = []() {
         const size_t bytes = static_cast<size_t>(T4<4>::kLdsDwords) * sizeof(uint32_t);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_tile4_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_tile4_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_tile4_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
         return bytes;
       }();
       PairKernelArgs t4 = a_in;
       t4.lds_dwords = T4<4>::kLdsDwords;
       const uint32_t per_xcd = ((a_in.wd_tiles_plain ? a_in.n_wd_tiles_plain : a_in.n_wd_tiles) * T4<4>::kUnits + 7) / 8;
-      hipLaunchKernelGGL(pair_mfma_tile4_kernel<4>, dim3(per_xcd * 8), dim3(T4<4>::kWaves * 64), t4lds, stream, t4);
+      if (gu) {
+        hipLaunchKernelGGL((pair_mfma_tile4_kernel<4, true>), dim3(per_xcd * 8), dim3(T4<4>::kWaves * 64), t4lds, stream, t4);
+      } else {
+        hipLaunchKernelGGL((pair_mfma_tile4_kernel<4, false>), dim3(per_xcd * 8), dim3(T4<4>::kWaves * 64), t4lds, stream, t4);
+      }
     }
     const uint32_t gper_xcd = (g.n_mf_wgs * 8 + 7) / 8;
     // only the predicate is wanted (no integers, no r^2 values): the four-product form
     if (a_in.mf_four && !a_in.stats && !a_in.r2_out && !a_in.r2_hits) {
-      hipLaunchKernelGGL(pair_mfma_general_kernel<false>, dim3(gper_xcd * 8), dim3(kMfWaves * 64), glds, stream, g);
+      if (gu) {
+        hipLaunchKernelGGL((pair_mfma_general_kernel<false, true>), dim3(gper_xcd * 8), dim3(kMfWaves * 64), glds, stream, g);
+      } else {
+        hipLaunchKernelGGL((pair_mfma_general_kernel<false, false>), dim3(gper_xcd * 8), dim3(kMfWaves * 64), glds, stream, g);
+      }
     } else {
-      hipLaunchKernelGGL(pair_mfma_general_kernel<true>, dim3(gper_xcd * 8), dim3(kMfWaves * 64), glds, stream, g);
+      hipLaunchKernelGGL((pair_mfma_general_kernel<true, false>), dim3(gper_xcd * 8), dim3(kMfWaves * 64), glds, stream, g);
     }
   }
   if (ev) {

@@ -980,7 +980,7 @@ Args parse_args(int argc, char** argv) {
       }
       const std::string v = argv[++i];
       double d = 0.0;
-      const char* endp;
+      const char* endp = v.c_str();  // (scan_double_plink leaves it alone when there is no number at all)
       if (!scan_double_plink(v.c_str(), &d, &endp) || *endp) {
         if (*endp == ':') {
           die(63, "Error: %s modifiers ('%s') are not supported by plink2-hip.\n", f.c_str(), v.c_str());

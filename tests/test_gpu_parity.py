@@ -611,8 +611,11 @@ def test_four_product_form_of_the_missing_call_kernel(gpu_pkg, n, miss, r2, redr
     six, c6 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, {"pair_sparse": 0, "pair_four": 0})
     four, c4 = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, {"pair_sparse": 0})
     four_x, c4x = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, {"pair_sparse": 0, "early_exit": 0})
+    # ... and with the operands of engines beyond 1,800,000 founders (x and n instead of allele counts and missing flags)
+    four_xn, c4n = _run_sparse(gpu_pkg, packed, n, chr_idx, bps, r2, {"pair_sparse": 0, "pair_gu": 0})
     assert c6["route_general_launches"] > 0 and c4["route_general_launches"] > 0 and c6["sparse_exact_pairs"] == 0
-    assert np.array_equal(four, six) and np.array_equal(four_x, six)
+    assert np.array_equal(four, six) and np.array_equal(four_x, six) and np.array_equal(four_xn, six)
+    assert c4n["pred_true"] == c4["pred_true"] and c4n["mfma_skipped_product_stages"] == c4["mfma_skipped_product_stages"]
     assert c4x["pred_true"] == c6["pred_true"] > 0 and c4["pred_true"] <= c4x["pred_true"]   # (a retired product's pairs are false)
     assert c4x["mfma_skipped_product_stages"] == 0
     inv, mf, _ = T.oracle_prepare(raw)
@@ -658,6 +661,9 @@ def test_four_product_form_on_quarter_tiles_of_wide_bands(gpu_pkg, n, m, window,
     tiles, ct = _run_wide(pkg, packed, n, chr_idx, window, r2, {"pair_sparse": 0})
     tiles_x, ctx = _run_wide(pkg, packed, n, chr_idx, window, r2, {"pair_sparse": 0, "early_exit": 0})
     plan, cp = _run_wide(pkg, packed, n, chr_idx, window, r2, {"pair_sparse": 0, "pair_four_tiles": 0})
+    tiles_xn, ctn = _run_wide(pkg, packed, n, chr_idx, window, r2, {"pair_sparse": 0, "pair_gu": 0})
+    assert np.array_equal(tiles_xn, tiles) and ctn["pred_true"] == ct["pred_true"] and ctn["four_tile_launches"] > 0
+    assert ctn["mfma_skipped_product_stages"] == ct["mfma_skipped_product_stages"]
     six, c6 = _run_wide(pkg, packed, n, chr_idx, window, r2, {"pair_sparse": 0, "pair_four": 0, "early_exit": 0})
     assert ct["wide_tiles"] > 0 and ct["four_tile_launches"] > 0 and ctx["four_tile_launches"] > 0
     assert cp["four_tile_launches"] == 0 and c6["four_tile_launches"] == 0 and c6["route_general_launches"] > 0
