@@ -3557,16 +3557,8 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
   if (!n) {
     return LDP_OK;
   }
-  // the byte span the records cover (only that much goes to the device), every record inside the buffer
-  uint64_t span_lo = UINT64_MAX, span_hi = 0;
-  auto cover = [&](const ldp_pgen_rec& r) {
-    if ((r.offset > n_bytes) || (r.length > n_bytes - r.offset)) {
-      return false;
-    }
-    span_lo = std::min<uint64_t>(span_lo, r.offset);
-    span_hi = std::max<uint64_t>(span_hi, r.offset + r.length);
-    return true;
-  };
+  // every record inside the buffer
+  auto cover = [&](const ldp_pgen_rec& r) { return (r.offset <= n_bytes) && (r.length <= n_bytes - r.offset); };
   bool any_multi = false, any_ld = false;
   for (uint32_t q = 0; q < n; ++q) {
     if (!cover(recs[q])) {
@@ -3601,18 +3593,9 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
   const uint64_t stride = phased ? ((phase_off + 2ull * ((static_cast<uint64_t>(raw_sample_ct) + 15) / 16) + 15) & ~static_cast<uint64_t>(15))
                                  : (((static_cast<uint64_t>(raw_sample_ct) + 3) / 4 + 15) & ~static_cast<uint64_t>(15));
   // ---- the bytes
-  const uint8_t* d_bytes;
-  if (location == LDP_MEM_HOST) {
-    void* p = nullptr;
-    rc = dec_reserve(e, 0, span_hi - span_lo + 16, &p);
-    if (rc) {
-      return rc;
-    }
-    HIP_TRY(e, hipMemcpyAsync(p, static_cast<const uint8_t*>(bytes) + span_lo, span_hi - span_lo, hipMemcpyHostToDevice, e->stream));
-    d_bytes = static_cast<const uint8_t*>(p) - span_lo;  // (record offsets stay as the caller gave them)
-  } else {
-    d_bytes = static_cast<const uint8_t*>(bytes);
-  }
+  // (host bytes go to the device launch by launch, below: only the span of that launch's records, so that the first decode does not wait
+  // for the whole call's upload and a call over a file with long dosage tracks does not need one allocation for all of them)
+  const uint8_t* d_bytes = (location == LDP_MEM_HOST) ? nullptr : static_cast<const uint8_t*>(bytes);
   if (e->ld_base_cap < stride) {
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     (void)hipFree(e->d_ld_base);
@@ -3694,6 +3677,19 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
       d.allele_ct = 2;
       d.vrtype = ld_base->vrtype;
       d.base = kPgenNoBase;
+    }
+    if (location == LDP_MEM_HOST) {
+      uint64_t lo = UINT64_MAX, hi = 0;
+      for (uint32_t q = 0; q < rows; ++q) {
+        lo = std::min<uint64_t>(lo, descs[q].off);
+        hi = std::max<uint64_t>(hi, descs[q].off + descs[q].len);
+      }
+      void* p = nullptr;
+      if ((rc = dec_reserve(e, 0, hi - lo + 16, &p))) {
+        return rc;
+      }
+      HIP_TRY(e, hipMemcpyAsync(p, static_cast<const uint8_t*>(bytes) + lo, hi - lo, hipMemcpyHostToDevice, e->stream));
+      d_bytes = static_cast<const uint8_t*>(p) - lo;  // (record offsets stay as the caller gave them)
     }
     void *p_recs = nullptr, *p_rows = nullptr, *p_end = nullptr, *p_multi = nullptr, *p_mf = nullptr, *p_mi = nullptr, *p_inv = nullptr;
     if ((rc = dec_reserve(e, 1, rows * sizeof(ldp::PgenRecDesc), &p_recs)) || (rc = dec_reserve(e, 2, static_cast<size_t>(rows) * stride, &p_rows)) ||
