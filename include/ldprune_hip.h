@@ -328,6 +328,22 @@ int ldp_r2_unphased_block(ldp_engine* e, uint32_t row_first, uint32_t row_ct, ui
                           uint64_t ld_elems);
 int ldp_r2_unphased_block_hits(ldp_engine* e, uint32_t row_first, uint32_t row_ct, uint32_t col_first, uint32_t col_ct, double min_r2, ldp_r2_hit* out,
                                uint64_t capacity, uint64_t* count);
+/* chrX pairs of the same block (ComputeXR2, plink2_ld.cc:7122-7190; is_x :9946-9951): a pair with a chrX variant weighs the male
+ * founders down in all six sums -- by 1/2 when both variants are on chrX, by 1 - sqrt(2)/2 when one is -- before the quotient
+ * (clamped at 1; NaN when a weighted variance is not positive).  `e` holds all founders, `male` (NULL: there are none) the same
+ * variants through a sample map of the male founders, on the same device; is_x[variant_ct] marks the chrX rows; flip_all /
+ * flip_male[variant_ct] (NULL: none) mark the rows whose engine orientation (ldp_variant_rec.flags bit 0) differs from the one the
+ * values are wanted in -- with the irrational weight the rounding depends on it.  Both engines' six integers of every such pair
+ * come from the pair kernels and are combined on the device, the reference's doubles fma for fma.
+ * Dense form: `out` is the block ldp_r2_unphased_block() filled (same layout, host memory); only the elements of pairs (i < j) with
+ * a chrX variant are overwritten, with r^2 or (unsquared != 0) r.  Hit form: those pairs with |value| >= min_r2, as above. */
+int ldp_r2_unphased_block_x(ldp_engine* e, ldp_engine* male, const uint8_t* is_x, const uint8_t* flip_all, const uint8_t* flip_male, uint32_t row_first,
+                            uint32_t row_ct, uint32_t col_first, uint32_t col_ct, int as_float, int unsquared, void* out, uint64_t ld_elems);
+int ldp_r2_unphased_block_x_hits(ldp_engine* e, ldp_engine* male, const uint8_t* is_x, const uint8_t* flip_all, const uint8_t* flip_male, uint32_t row_first,
+                                 uint32_t row_ct, uint32_t col_first, uint32_t col_ct, int unsquared, double min_r2, ldp_r2_hit* out, uint64_t capacity,
+                                 uint64_t* count);
+/* The six integers themselves (ldp_pair_stats_t, the engine's orientation) of the pairs i < j of the block, same layout; zero elsewhere. */
+int ldp_pair_stats_block(ldp_engine* e, uint32_t row_first, uint32_t row_ct, uint32_t col_first, uint32_t col_ct, ldp_pair_stats_t* out, uint64_t ld_elems);
 
 /* ---- --r2-unphased table (VcorTable, plink2_ld.cc:11025; window: UpdateVcorWindow :10984-11023) ---- */
 /* Windowed plan: variant B is paired with the earlier variants A of its chromosome with bp[B] - bp[A] <= bp_radius

@@ -93,7 +93,7 @@ CABI_SYMBOLS = [
     "ldp_set_shard", "ldp_get_band", "ldp_load_genotypes", "ldp_load_genotypes_fd", "ldp_set_sample_map", "ldp_set_maj_freqs", "ldp_set_preferred", "ldp_run",
     "ldp_run_with_stats", "ldp_pair_stats", "ldp_debug_set_variant_recs", "ldp_debug_replay_pairs", "ldp_debug_mfma_plan",
     "ldp_get_variant_recs", "ldp_get_maj_freqs", "ldp_get_planes", "ldp_get_counters", "ldp_synth_genotypes",
-    "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_r2_unphased_hits", "ldp_r2_unphased_block", "ldp_r2_unphased_block_hits", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
+    "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_r2_unphased_hits", "ldp_r2_unphased_block", "ldp_r2_unphased_block_hits", "ldp_r2_unphased_block_x", "ldp_r2_unphased_block_x_hits", "ldp_pair_stats_block", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_has_dosage", "ldp_pgen_variant_has_dosage", "ldp_pgen_dosage_sums", "ldp_pgen_direct_rows", "ldp_pgen_direct_fd", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
     "ldp_pgen_variant_is_multiallelic", "ldp_pgen_provisional_ref", "ldp_pgen_open_indexed", "ldp_set_r_signed", "ldp_set_variants_vcor_cm", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_subset_samples", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
     "ldp_debug_set_option", "ldp_matrix_pipe_max_founders", "ldp_map_rows", "ldp_release_device", "ldp_debug_wide_plan",
@@ -236,6 +236,12 @@ def lib():
     L.ldp_r2_unphased_block.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, vp, ctypes.c_uint64]
     L.ldp_r2_unphased_block_hits.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, vp, ctypes.c_uint64,
                                              ctypes.POINTER(ctypes.c_uint64)]
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    L.ldp_r2_unphased_block_x.argtypes = [vp, vp, u8p, u8p, u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, vp,
+                                          ctypes.c_uint64]
+    L.ldp_r2_unphased_block_x_hits.argtypes = [vp, vp, u8p, u8p, u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_double,
+                                               vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+    L.ldp_pair_stats_block.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint64]
     L.ldp_set_variants_vcor.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
                                         ctypes.c_uint32, ctypes.c_uint32]
     L.ldp_r2_unphased_band_rows.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, vp, ctypes.c_uint64]
@@ -565,6 +571,40 @@ class LdPruneEngine:
         got = out[:min(found.value, capacity)]
         return np.sort(got, order=["first", "second"]), found.value
 
+    def pair_stats_block(self, row_first, row_ct, col_first, col_ct):
+        """ldp_pair_stats_block: the six integers of the pairs i < j of a dense block from the pair kernels, (row_ct, col_ct) structured array."""
+        out = np.zeros((row_ct, col_ct), dtype=PAIR_STATS_DTYPE)
+        self._ck(self._L.ldp_pair_stats_block(self._h, row_first, row_ct, col_first, col_ct, out.ctypes.data_as(ctypes.c_void_p), col_ct))
+        return out
+
+    @staticmethod
+    def _flags(a):
+        if a is None:
+            return None, None
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+    def r2_unphased_block_x(self, block, male, is_x, row_first, col_first, flip_all=None, flip_male=None, unsquared=False):
+        """ldp_r2_unphased_block_x: overwrites, in `block` (what r2_unphased_block returned for the same rows / columns), the elements of
+        the pairs with a chrX variant by their male-weighted r^2 (or r); `male` = the male founders' engine or None."""
+        k1, p1 = self._flags(is_x)
+        k2, p2 = self._flags(flip_all)
+        k3, p3 = self._flags(flip_male)
+        self._ck(self._L.ldp_r2_unphased_block_x(self._h, male._h if male is not None else None, p1, p2, p3, row_first, block.shape[0], col_first, block.shape[1],
+                                                 1 if block.dtype == np.float32 else 0, 1 if unsquared else 0, block.ctypes.data_as(ctypes.c_void_p), block.shape[1]))
+        return block
+
+    def r2_unphased_block_x_hits(self, male, is_x, min_r2, row_first, row_ct, col_first, col_ct, flip_all=None, flip_male=None, unsquared=False, capacity=1 << 20):
+        k1, p1 = self._flags(is_x)
+        k2, p2 = self._flags(flip_all)
+        k3, p3 = self._flags(flip_male)
+        out = np.zeros(max(capacity, 1), dtype=R2_HIT_DTYPE)
+        found = ctypes.c_uint64()
+        self._ck(self._L.ldp_r2_unphased_block_x_hits(self._h, male._h if male is not None else None, p1, p2, p3, row_first, row_ct, col_first, col_ct,
+                                                      1 if unsquared else 0, float(min_r2), out.ctypes.data_as(ctypes.c_void_p), capacity, ctypes.byref(found)))
+        got = out[:min(found.value, capacity)]
+        return np.sort(got, order=["first", "second"]), found.value
+
     def r2_unphased_hits(self, min_r2, row_first=0, row_ct=None, capacity=1 << 20):
         """Pairs first < second (second among the rows) with |r^2| >= min_r2, filtered on the device; sorted here by
         (first, second).  Returns (structured array, total found) -- found > len(array) means the buffer was too small."""
@@ -646,7 +686,7 @@ class LdPruneEngine:
                                                base_rec if base_rec is not None else None, pgen.sample_ct, _ptr(maj, ctypes.c_uint32)))
         return maj[:n]
 
-    def load_pgen_records_phased(self, first_variant, pgen, raw_first=None, n=None):
+    def load_pgen_records_phased(self, first_variant, pgen, raw_first=None, n=None, location=LDP_MEM_HOST, device_bytes=None):
         """ldp_load_pgen_records_phased (--indep-pairphase): main + hardcall-phase tracks of records [raw_first, +n) decoded on the device
         into the engine's haplotype rows (founder_ct = 2 x the file's samples).  Raises LdpError(LDP_ERR_UNPHASED) with `.variant` = the
         lowest variant that has a het call without phase."""
@@ -655,8 +695,10 @@ class LdPruneEngine:
         recs, base = pgen.record_index(raw_first, n, None)
         base_rec = pgen.record_index(base, 1)[0] if base is not None else None
         ptr, nbytes = pgen.file_bytes()
+        if location == LDP_MEM_DEVICE:
+            ptr = int(device_bytes)   # (the whole file's bytes, resident in HBM)
         bad = ctypes.c_uint32(0xffffffff)
-        rc = self._L.ldp_load_pgen_records_phased(self._h, int(first_variant), int(n), ctypes.c_void_p(ptr), nbytes, LDP_MEM_HOST, recs,
+        rc = self._L.ldp_load_pgen_records_phased(self._h, int(first_variant), int(n), ctypes.c_void_p(ptr), nbytes, location, recs,
                                                   base_rec if base_rec is not None else None, pgen.sample_ct, ctypes.byref(bad))
         if rc != LDP_OK:
             err = LdpError(rc, self._L.ldp_last_error(self._h).decode())

@@ -167,7 +167,7 @@ struct PairKernelArgs {
   uint32_t r2_col_first;         // ... and only first variants i in [r2_col_first, r2_col_end) (a column block of the matrix);
   uint32_t r2_col_end;           //     dense rows then start at column r2_col_first: element (j - r2_row_first) * r2_ld + (i - r2_col_first)
   uint64_t r2_band_base;         // r2_ld == 0: band layout, element pair_off[j] - r2_band_base + (i - lo[j])
-  uint32_t r2_float;
+  uint32_t r2_float;             // 0: doubles, 1: floats, 2: ldp_pair_stats_t (the six integers of every pair instead of their r^2; dense layouts only)
   uint32_t r_signed;             // 0: r^2; 1: r = +-sqrt(r^2), sign of the covariance of the rows as stored (major-allele orientation);
                                  // 2: the same in REF orientation (the sign flips when exactly one row was inverted by prepare_kernel)
   // device-side filter (ldp_r2_unphased_hits): with r2_hits != nullptr a pair with |r^2| >= r2_min is appended at
@@ -301,6 +301,26 @@ hipError_t launch_pair_stats_ref(const uint32_t* planes, uint64_t row_dwords, ui
 size_t pair_tiles_lds_bytes(uint32_t max_rows);
 // ev[0..2] (optional): recorded before the complete-data kernel, between it and the missing-calls kernel, and after
 hipError_t launch_pair_mfma(const PairKernelArgs& a, hipStream_t stream, hipEvent_t* ev);
+// chrX pairs of the r^2 outputs (ldp_kernels.hip: x_weighted_kernel): the two engines' six integers of every pair of a dense block
+// (row q = second variant row_first + q, column c = first variant col_first + c, c < cols) -> the male-weighted r^2 (or r)
+struct XWeightedArgs {
+  const ldp_pair_stats_t* all;   // [rows][cols], all founders
+  const ldp_pair_stats_t* male;  // the same over the male founders; nullptr: none
+  uint32_t rows, cols;
+  uint32_t row_first, col_first;
+  const uint8_t* is_x;           // per engine row (variant): on chrX
+  const uint8_t* flip_all;       // per engine row: the engine's orientation differs from the target's; nullptr: never
+  const uint8_t* flip_male;
+  uint32_t unsquared;            // r instead of r^2
+  uint32_t as_float;
+  void* out;                     // dense: element q * out_ld + c, written only where the pair involves chrX (c + col_first < q + row_first)
+  uint64_t out_ld;
+  ldp_r2_hit* hits;              // != nullptr: pairs with |value| >= min_r2 appended at atomicAdd(hit_count) while below hit_capacity; `out` unused
+  uint64_t hit_capacity;
+  unsigned long long* hit_count;
+  double min_r2;
+};
+hipError_t launch_x_weighted(const XWeightedArgs& a, hipStream_t stream);
 // the wide-band tiles of the launch (complete-data route); queued between ev[0] and ev[1] of launch_pair_mfma by the caller's order
 hipError_t launch_pair_wide(const PairKernelArgs& a, hipStream_t stream);
 uint32_t pair_mfma_ksteps(uint32_t founder_ct);  // 64-sample k-steps per row (the unit of counters[2])

@@ -2639,8 +2639,10 @@ int r2_band_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
 }
 
 // rows [row_first, row_first+row_ct) of the all-pairs plan: dense into `out` (hits == nullptr) or filtered into hits->out
+// as_float 2: the six integers of every pair (ldp_pair_stats_t) instead of their r^2; out_on_device: `out` is device memory of this
+// engine's device (left there, no diagonal: the chrX-weighted r^2 below combines two engines' tuples on the device)
 int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_float, void* out, uint64_t ld_elems, const HitRequest* hits,
-                 uint32_t col_first = 0, uint32_t col_end = 0xffffffffu) {
+                 uint32_t col_first = 0, uint32_t col_end = 0xffffffffu, bool out_on_device = false) {
   if (!e) {
     return LDP_ERR_INVALID;
   }
@@ -2706,7 +2708,7 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
       d0 += 8 * u;
     }
   }
-  const size_t esz = as_float ? sizeof(float) : sizeof(double);
+  const size_t esz = (as_float == 2) ? sizeof(ldp_pair_stats_t) : (as_float ? sizeof(float) : sizeof(double));
   const uint64_t out_elems = hits ? 0 : (static_cast<uint64_t>(row_ct) * ld_elems);
   DevBuf out_buf, items_buf, general_buf;
   void* d_out = nullptr;
@@ -2714,8 +2716,12 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
     HIP_TRY(e, hipMalloc(&out_buf.p, std::max<uint64_t>(hits->capacity, 1) * sizeof(ldp_r2_hit)));
     HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
   } else {
-    HIP_TRY(e, hipMalloc(&out_buf.p, out_elems * esz));
-    d_out = out_buf.p;
+    if (out_on_device) {
+      d_out = out;
+    } else {
+      HIP_TRY(e, hipMalloc(&out_buf.p, out_elems * esz));
+      d_out = out_buf.p;
+    }
     HIP_TRY(e, hipMemsetAsync(d_out, 0, out_elems * esz, e->stream));
   }
   WorkItem* d_items = nullptr;
@@ -2761,7 +2767,7 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
   A.r2_col_first = col_first;
   A.r2_col_end = col_end;
   A.r2_band_base = 0;
-  A.r2_float = as_float ? 1 : 0;
+  A.r2_float = static_cast<uint32_t>(as_float);
   EventSet<4> evset;
   hipEvent_t* evk = evset.ev;
   HIP_TRY(e, evset.create());
@@ -2792,6 +2798,8 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
     if (stored) {
       HIP_TRY(e, hipMemcpy(hits->out, out_buf.p, stored * sizeof(ldp_r2_hit), hipMemcpyDeviceToHost));
     }
+  } else if (out_on_device) {
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
   } else {
     HIP_TRY(e, hipMemcpyAsync(out, d_out, out_elems * esz, hipMemcpyDeviceToHost, e->stream));
     rc = fetch_recs(e);  // diagonal needs each variant's own variance
@@ -2811,7 +2819,7 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
     HIP_TRY(e, hipEventElapsedTime(&kms_general, evk[2], evk[3]));
   }
   // diagonal: r^2(v, v) through the same formula = 1.0, or NaN when the variant has no variance
-  for (uint32_t j = row_first; (!hits) && (j < row_end); ++j) {
+  for (uint32_t j = row_first; (!hits) && (as_float != 2) && (!out_on_device) && (j < row_end); ++j) {
     if ((j < col_first) || (j >= col_end)) {
       continue;
     }
@@ -2835,9 +2843,173 @@ int r2_rows_impl(ldp_engine* e, uint32_t row_first, uint32_t row_ct, int as_floa
   e->ctr.ms_run_total = now_ms() - t_start;
   return LDP_OK;
 }
+
+// chrX pairs of a dense block (ComputeXR2, plink2_ld.cc:7122-7190): both engines' tuples from the pair kernels, combined on the device
+// (x_weighted_kernel).  Only the rectangles that hold such pairs are computed: the chrX rows against all columns, the other rows
+// against the chrX columns.
+int r2_x_block_impl(ldp_engine* e, ldp_engine* male, const uint8_t* is_x, const uint8_t* flip_all, const uint8_t* flip_male, uint32_t row_first, uint32_t row_ct,
+                    uint32_t col_first, uint32_t col_ct, int as_float, int unsquared, void* out, uint64_t ld_elems, const HitRequest* hits) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  if (!e->planned || !e->matrix_mode || (male && (!male->planned || !male->matrix_mode))) {
+    return fail(e, LDP_ERR_STATE, "ldp_set_variants_matrix() first (both engines)");
+  }
+  if (male && ((male->variant_ct != e->variant_ct) || (male->device != e->device))) {
+    return fail(e, LDP_ERR_INVALID, "the male founders' engine must hold the same variants on the same device");
+  }
+  if (!is_x || (static_cast<uint64_t>(row_first) + row_ct > e->variant_ct) || (static_cast<uint64_t>(col_first) + col_ct > e->variant_ct) ||
+      (hits ? ((hits->capacity && !hits->out) || !hits->count) : ((row_ct && col_ct && !out) || (ld_elems < col_ct)))) {
+    return fail(e, LDP_ERR_INVALID, "is_x missing / block or output out of bounds");
+  }
+  if (hits) {
+    *hits->count = 0;
+  }
+  if (!row_ct || !col_ct) {
+    return LDP_OK;
+  }
+  int rc = ensure_device_plan(e);
+  if (rc) {
+    return rc;
+  }
+  HIP_TRY(e, hipSetDevice(e->device));
+  const uint32_t m = e->variant_ct, col_end = col_first + col_ct, row_end = row_first + row_ct;
+  // the chrX columns of the block
+  uint32_t xc_lo = col_end, xc_hi = col_first;
+  for (uint32_t i = col_first; i < col_end; ++i) {
+    if (is_x[i]) {
+      xc_lo = std::min(xc_lo, i);
+      xc_hi = i + 1;
+    }
+  }
+  DevBuf flags_buf, ta_buf, tm_buf, val_buf, hit_buf, ctr_buf;
+  HIP_TRY(e, hipMalloc(&flags_buf.p, 3ull * m));
+  uint8_t* d_is_x = flags_buf.as<uint8_t>();
+  uint8_t* d_flip_all = flip_all ? d_is_x + m : nullptr;
+  uint8_t* d_flip_male = (male && flip_male) ? d_is_x + 2ull * m : nullptr;
+  HIP_TRY(e, hipMemcpyAsync(d_is_x, is_x, m, hipMemcpyHostToDevice, e->stream));
+  if (d_flip_all) {
+    HIP_TRY(e, hipMemcpyAsync(d_flip_all, flip_all, m, hipMemcpyHostToDevice, e->stream));
+  }
+  if (d_flip_male) {
+    HIP_TRY(e, hipMemcpyAsync(d_flip_male, flip_male, m, hipMemcpyHostToDevice, e->stream));
+  }
+  if (hits) {
+    HIP_TRY(e, hipMalloc(&hit_buf.p, std::max<uint64_t>(hits->capacity, 1) * sizeof(ldp_r2_hit)));
+    HIP_TRY(e, hipMalloc(&ctr_buf.p, sizeof(unsigned long long)));
+    HIP_TRY(e, hipMemsetAsync(ctr_buf.p, 0, sizeof(unsigned long long), e->stream));
+  }
+  // row chunks of at most ~1 GiB of tuples per engine
+  const size_t esz = as_float ? sizeof(float) : sizeof(double);
+  uint32_t rows_per = static_cast<uint32_t>(std::max<uint64_t>(32, ((1ull << 30) / sizeof(ldp_pair_stats_t)) / col_ct) & ~31ull);
+  if (const char* dbg = getenv("LDP_DEBUG_X_ROWS")) {  // (test hook: many small chunks)
+    rows_per = static_cast<uint32_t>(std::max(1, atoi(dbg)));
+  }
+  HIP_TRY(e, hipMalloc(&ta_buf.p, static_cast<uint64_t>(std::min(rows_per, row_ct)) * col_ct * sizeof(ldp_pair_stats_t)));
+  if (male) {
+    HIP_TRY(e, hipMalloc(&tm_buf.p, static_cast<uint64_t>(std::min(rows_per, row_ct)) * col_ct * sizeof(ldp_pair_stats_t)));
+  }
+  std::vector<uint8_t> h_val;
+  if (!hits) {
+    HIP_TRY(e, hipMalloc(&val_buf.p, static_cast<uint64_t>(std::min(rows_per, row_ct)) * col_ct * esz));
+  }
+  for (uint32_t r0 = row_first; r0 < row_end; r0 += rows_per) {
+    const uint32_t rows = std::min(rows_per, row_end - r0);
+    bool any_x_row = false;
+    for (uint32_t j = r0; j < r0 + rows; ++j) {
+      any_x_row = any_x_row || (is_x[j] != 0);
+    }
+    // (a chunk without a chrX row only needs the chrX columns; pairs are i < j: nothing right of the chunk's last row either)
+    const uint32_t c0 = any_x_row ? col_first : xc_lo;
+    const uint32_t c1 = std::min(any_x_row ? col_end : xc_hi, r0 + rows - 1);
+    if (c0 >= c1) {
+      continue;
+    }
+    const uint32_t cols = c1 - c0;
+    if ((rc = r2_rows_impl(e, r0, rows, 2, ta_buf.p, cols, nullptr, c0, c1, true))) {
+      return rc;
+    }
+    if (male && (rc = r2_rows_impl(male, r0, rows, 2, tm_buf.p, cols, nullptr, c0, c1, true))) {
+      return fail(e, rc, std::string("male founders' engine: ") + ldp_last_error(male));
+    }
+    XWeightedArgs X;
+    X.all = ta_buf.as<ldp_pair_stats_t>();
+    X.male = male ? tm_buf.as<ldp_pair_stats_t>() : nullptr;
+    X.rows = rows;
+    X.cols = cols;
+    X.row_first = r0;
+    X.col_first = c0;
+    X.is_x = d_is_x;
+    X.flip_all = d_flip_all;
+    X.flip_male = d_flip_male;
+    X.unsquared = unsquared ? 1u : 0u;
+    X.as_float = as_float ? 1u : 0u;
+    X.out = val_buf.p;
+    X.out_ld = cols;
+    X.hits = hits ? hit_buf.as<ldp_r2_hit>() : nullptr;
+    X.hit_capacity = hits ? hits->capacity : 0;
+    X.hit_count = static_cast<unsigned long long*>(ctr_buf.p);
+    X.min_r2 = hits ? hits->min_r2 : 0.0;
+    const hipError_t krc = launch_x_weighted(X, e->stream);
+    if (krc != hipSuccess) {
+      return hipfail(e, krc, "x_weighted_kernel launch");
+    }
+    if (hits) {
+      HIP_TRY(e, hipStreamSynchronize(e->stream));  // (the next chunk's tuples overwrite these from the engines' own streams)
+      continue;
+    }
+    // the chunk's values back, and the pairs with a chrX variant into the caller's block (everything else stays as it was)
+    h_val.resize(static_cast<size_t>(rows) * cols * esz);
+    HIP_TRY(e, hipMemcpyAsync(h_val.data(), val_buf.p, h_val.size(), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    for (uint32_t q = 0; q < rows; ++q) {
+      const uint32_t j = r0 + q;
+      const uint32_t i_end = std::min(c1, j);
+      uint8_t* dst = static_cast<uint8_t*>(out) + (static_cast<uint64_t>(j - row_first) * ld_elems) * esz;
+      const uint8_t* src = h_val.data() + static_cast<size_t>(q) * cols * esz;
+      if (is_x[j]) {
+        if (i_end > c0) {
+          memcpy(dst + static_cast<size_t>(c0 - col_first) * esz, src, static_cast<size_t>(i_end - c0) * esz);
+        }
+      } else {
+        for (uint32_t i = std::max(c0, xc_lo); i < std::min(i_end, xc_hi); ++i) {
+          if (is_x[i]) {
+            memcpy(dst + static_cast<size_t>(i - col_first) * esz, src + static_cast<size_t>(i - c0) * esz, esz);
+          }
+        }
+      }
+    }
+  }
+  if (hits) {
+    unsigned long long found = 0;
+    HIP_TRY(e, hipMemcpyAsync(&found, ctr_buf.p, sizeof(found), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    *hits->count = found;
+    const uint64_t stored = std::min<uint64_t>(found, hits->capacity);
+    if (stored) {
+      HIP_TRY(e, hipMemcpy(hits->out, hit_buf.p, stored * sizeof(ldp_r2_hit), hipMemcpyDeviceToHost));
+    }
+  }
+  return LDP_OK;
+}
 }  // namespace
 
 extern "C" {
+
+int ldp_r2_unphased_block_x(ldp_engine* e, ldp_engine* male, const uint8_t* is_x, const uint8_t* flip_all, const uint8_t* flip_male, uint32_t row_first, uint32_t row_ct,
+                            uint32_t col_first, uint32_t col_ct, int as_float, int unsquared, void* out, uint64_t ld_elems) {
+  return r2_x_block_impl(e, male, is_x, flip_all, flip_male, row_first, row_ct, col_first, col_ct, as_float, unsquared, out, ld_elems, nullptr);
+}
+
+int ldp_r2_unphased_block_x_hits(ldp_engine* e, ldp_engine* male, const uint8_t* is_x, const uint8_t* flip_all, const uint8_t* flip_male, uint32_t row_first,
+                                 uint32_t row_ct, uint32_t col_first, uint32_t col_ct, int unsquared, double min_r2, ldp_r2_hit* out, uint64_t capacity, uint64_t* count) {
+  HitRequest hr{min_r2, out, capacity, count};
+  return r2_x_block_impl(e, male, is_x, flip_all, flip_male, row_first, row_ct, col_first, col_ct, 0, unsquared, nullptr, 0, &hr);
+}
+
+int ldp_pair_stats_block(ldp_engine* e, uint32_t row_first, uint32_t row_ct, uint32_t col_first, uint32_t col_ct, ldp_pair_stats_t* out, uint64_t ld_elems) {
+  return r2_rows_impl(e, row_first, row_ct, 2, out, ld_elems, nullptr, col_first, col_first + col_ct);
+}
 
 int ldp_set_r_signed(ldp_engine* e, int mode) {
   if (!e) {

@@ -1214,6 +1214,111 @@ size_t pair_tiles_lds_bytes(uint32_t max_rows) {
   return (2 * stage > epi) ? 2 * stage : epi;
 }
 
+// ---- chrX pairs of the r^2 outputs (ComputeXR2, plink2_ld.cc:7122-7190) ----------------------------------------------------------
+// A pair with a chrX variant weighs the male founders down in all six sums -- by 1/2 when both variants are on chrX, by
+// 1 - sqrt(2)/2 when one is -- before the usual quotient (clamped at 1; undefined when a weighted variance is not positive).
+// The engines' tuples (+-1 coding, each engine's own major-allele orientation) become the reference's counts of the target
+// orientation's allele exactly, in integers; then the reference's doubles, fma for fma (its documented AVX2 build defines
+// FP_FAST_FMA; v_fma_f64 is the same operation, the build has -ffp-contract=off).
+namespace {
+struct XCounts {
+  int64_t n, g1, q1, g2, q2, d;
+};
+__device__ __forceinline__ XCounts x_counts(const ldp_pair_stats_t& t, bool flip1, bool flip2) {
+  XCounts c;
+  c.n = t.nm;
+  c.g1 = c.n - t.sum1;
+  c.q1 = c.n - 2 * static_cast<int64_t>(t.sum1) + t.ssq1;
+  c.g2 = c.n - t.sum2;
+  c.q2 = c.n - 2 * static_cast<int64_t>(t.sum2) + t.ssq2;
+  c.d = c.n - t.sum1 - t.sum2 + t.dot;
+  if (flip1) {  // g -> 2 - g
+    c.q1 = 4 * c.n - 4 * c.g1 + c.q1;
+    c.g1 = 2 * c.n - c.g1;
+    c.d = 2 * c.g2 - c.d;
+  }
+  if (flip2) {
+    c.q2 = 4 * c.n - 4 * c.g2 + c.q2;
+    c.g2 = 2 * c.n - c.g2;
+    c.d = 2 * c.g1 - c.d;
+  }
+  return c;
+}
+__global__ __launch_bounds__(256) void x_weighted_kernel(XWeightedArgs A) {
+  const uint64_t idx = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= static_cast<uint64_t>(A.rows) * A.cols) {
+    return;
+  }
+  const uint32_t q = static_cast<uint32_t>(idx / A.cols), c = static_cast<uint32_t>(idx % A.cols);
+  const uint32_t j = A.row_first + q, i = A.col_first + c;
+  if (i >= j) {
+    return;
+  }
+  const bool xi = A.is_x[i] != 0, xj = A.is_x[j] != 0;
+  if (!(xi || xj)) {
+    return;
+  }
+  const double nan_ref = __longlong_as_double(static_cast<long long>(0xfff8000000000000ull));  // (the reference's 0.0 / 0.0 on x86)
+  const XCounts a = x_counts(A.all[idx], A.flip_all && A.flip_all[i], A.flip_all && A.flip_all[j]);
+  XCounts m = {0, 0, 0, 0, 0, 0};
+  if (A.male) {
+    m = x_counts(A.male[idx], A.flip_male && A.flip_male[i], A.flip_male && A.flip_male[j]);
+  }
+  double r = nan_ref;
+  if (a.n) {
+    const double male_downwt = (xi && xj) ? 0.5 : (1.0 - 0.5 * 1.4142135623730951);
+    const double w_obs = fma(-male_downwt, static_cast<double>(m.n), static_cast<double>(a.n));
+    const double w_g1 = fma(-male_downwt, static_cast<double>(m.g1), static_cast<double>(a.g1));
+    const double w_g2 = fma(-male_downwt, static_cast<double>(m.g2), static_cast<double>(a.g2));
+    const double w_q1 = fma(-male_downwt, static_cast<double>(m.q1), static_cast<double>(a.q1));
+    const double w_q2 = fma(-male_downwt, static_cast<double>(m.q2), static_cast<double>(a.q2));
+    const double w_d = fma(-male_downwt, static_cast<double>(m.d), static_cast<double>(a.d));
+    const double var1 = fma(w_q1, w_obs, -__dmul_rn(w_g1, w_g1));
+    const double var2 = fma(w_q2, w_obs, -__dmul_rn(w_g2, w_g2));
+    if ((var1 > 0.0) && (var2 > 0.0)) {
+      const double var_prod = __dmul_rn(var1, var2);
+      const double cov = fma(w_d, w_obs, -__dmul_rn(w_g1, w_g2));
+      const double quot = __ddiv_rn(__dmul_rn(cov, cov), var_prod);
+      r = (1.0 < quot) ? 1.0 : quot;
+      if (A.unsquared) {
+        r = __dsqrt_rn(r);
+        if (cov < 0.0) {
+          r = -r;
+        }
+      }
+    }
+  }
+  if (A.hits) {
+    if (fabs(r) >= A.min_r2) {  // (false for NaN)
+      const unsigned long long slot = atomicAdd(A.hit_count, 1ull);
+      if (slot < A.hit_capacity) {
+        ldp_r2_hit h;
+        h.first = i;
+        h.second = j;
+        h.r2 = r;
+        A.hits[slot] = h;
+      }
+    }
+    return;
+  }
+  const uint64_t o = static_cast<uint64_t>(q) * A.out_ld + c;
+  if (A.as_float) {
+    static_cast<float*>(A.out)[o] = (r != r) ? __uint_as_float(0xffc00000u) : static_cast<float>(r);
+  } else {
+    static_cast<double*>(A.out)[o] = r;
+  }
+}
+}  // namespace
+
+hipError_t launch_x_weighted(const XWeightedArgs& a, hipStream_t stream) {
+  const uint64_t n = static_cast<uint64_t>(a.rows) * a.cols;
+  if (!n) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(x_weighted_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_pair_tiles(const PairKernelArgs& a_in, uint32_t max_rows, hipStream_t stream, hipEvent_t* ev) {
   if (!a_in.n_items) {
     return hipSuccess;

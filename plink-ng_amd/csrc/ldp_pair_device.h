@@ -76,6 +76,11 @@ __device__ __forceinline__ bool emit_pair(const PairKernelArgs& A, uint32_t i, u
     if ((j < A.r2_row_first) || (j >= A.r2_row_end) || (i < A.r2_col_first) || (i >= A.r2_col_end)) {
       return false;  // a tile can straddle the edge of the requested rows / columns
     }
+    if (A.r2_float == 2) {
+      // the pair's six integers themselves, dense layout (r2_tuples_impl: the chrX-weighted r^2 combines two engines' tuples)
+      static_cast<ldp_pair_stats_t*>(A.r2_out)[static_cast<uint64_t>(j - A.r2_row_first) * A.r2_ld + (i - A.r2_col_first)] = st;
+      return false;
+    }
     double r2 = r2_unphased(st);
     if (A.r_signed && (r2 == r2)) {
       // --r-unphased (plink2_ld.cc:9633-9641, :10640-10647): sqrt of the same quotient, negative when the covariance is

@@ -3848,9 +3848,18 @@ struct R2Job {
     if (!any_x) {
       return;
     }
-    std::vector<uint32_t> fi, se;
-    std::vector<double> vals;
-    auto flush = [&]() {
+    if (getenv("LDP_DEBUG_X_HOST")) {  // (test hook: pair lists through ldp_pair_stats and the host arithmetic, as the band writers do)
+      std::vector<uint32_t> fi, se;
+      std::vector<double> vals;
+      for (uint32_t q = 0; q < rows; ++q) {
+        const uint32_t j = r0 + q;
+        for (uint32_t i = c0; i < std::min(j, c0 + cols); ++i) {
+          if (is_x[i] || is_x[j]) {
+            fi.push_back(i);
+            se.push_back(j);
+          }
+        }
+      }
       xw.pairs(fi, se, &vals);
       for (size_t q = 0; q < fi.size(); ++q) {
         const uint64_t idx = static_cast<uint64_t>(se[q] - r0) * ld + (fi[q] - c0);
@@ -3860,23 +3869,13 @@ struct R2Job {
           static_cast<double*>(buf)[idx] = vals[q];
         }
       }
-      fi.clear();
-      se.clear();
-    };
-    for (uint32_t q = 0; q < rows; ++q) {
-      const uint32_t j = r0 + q;
-      const uint32_t i_end = std::min(j, c0 + cols);
-      for (uint32_t i = c0; i < i_end; ++i) {
-        if (is_x[i] || is_x[j]) {
-          fi.push_back(i);
-          se.push_back(j);
-        }
-      }
-      if (fi.size() > (1u << 22)) {
-        flush();
-      }
+      return;
     }
-    flush();
+    // both engines' tuples of the block's chrX rows / columns from the pair kernels, combined on the device (ldp_r2_unphased_block_x)
+    if (ldp_r2_unphased_block_x(xw.all, xw.male, xw.is_x.data(), xw.flip_all.empty() ? nullptr : xw.flip_all.data(), xw.flip_male.empty() ? nullptr : xw.flip_male.data(),
+                                r0, rows, c0, cols, as_float ? 1 : 0, xw.unsquared ? 1 : 0, buf, ld)) {
+      die(16, "Error: %s\n", ldp_last_error(xw.all));
+    }
   }
 };
 
@@ -4153,7 +4152,25 @@ int write_vcor_table(R2Job& J) {
               fresh.push_back({dev_hits[q].first, dev_hits[q].second, dev_hits[q].r2});
             }
           }
-          if (any_x) {  // the chunk's pairs with a chrX variant: values and filter on the host
+          bool x_done = false;
+          if (any_x && A.r2_inter && (thresh >= 0.0) && !getenv("LDP_DEBUG_X_HOST")) {
+            // all-pairs plan: the chunk's pairs with a chrX variant from the pair kernels too, weighted and filtered on the device
+            // (a chunk whose passing pairs do not fit the buffer goes through the lists below)
+            uint64_t x_found = 0;
+            const XWeighted& xw = J.xw;
+            if (ldp_r2_unphased_block_x_hits(xw.all, xw.male, xw.is_x.data(), xw.flip_all.empty() ? nullptr : xw.flip_all.data(),
+                                             xw.flip_male.empty() ? nullptr : xw.flip_male.data(), r0, big, shard_first, shard_end - shard_first, xw.unsquared ? 1 : 0,
+                                             thresh, dev_hits.data(), dev_hits.size(), &x_found)) {
+              die(16, "Error: %s\n", ldp_last_error(xw.all));
+            }
+            if (x_found <= dev_hits.size()) {
+              for (uint64_t q = 0; q < x_found; ++q) {
+                fresh.push_back({dev_hits[q].first, dev_hits[q].second, dev_hits[q].r2});
+              }
+              x_done = true;
+            }
+          }
+          if (any_x && !x_done) {  // the chunk's pairs with a chrX variant: values and filter on the host
             std::vector<uint32_t> fi, se;
             std::vector<double> vals;
             for (uint32_t j = r0; j < r0 + big; ++j) {

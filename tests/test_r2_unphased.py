@@ -343,6 +343,147 @@ def test_matrix_column_blocks_match_the_rows(gpu_pkg, m, n, miss):
     eng.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,miss,mfma", [(260, 90, 0.0, 1), (333, 70, 0.04, 1), (200, 1100, 0.01, 1), (150, 130, 0.1, 0)])
+def test_pair_tuples_of_dense_blocks_from_the_pair_kernels(gpu_pkg, m, n, miss, mfma):
+    """ldp_pair_stats_block: the six integers of every pair of a block, written by the tile kernels' epilogue instead of the r^2 they would
+    form from them -- equal to the one-wave-per-pair reference kernel's (ldp_pair_stats), on complete rows, rows with missing calls,
+    monomorphic and all-missing rows, on the matrix pipe and on the popcount kernels."""
+    pkg = gpu_pkg
+    raw = T.synth_raw_codes(m, n, seed=5 * m + n, missing_rate=miss)
+    raw[3] = 0
+    raw[5] = 3
+    eng = pkg.LdPruneEngine(n, 2, 1, False, 0.5, device=0)
+    eng.set_option("pair_mfma", mfma)
+    eng.set_variants_matrix(m)
+    eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+    for (r0, rc, c0, cc) in [(0, m, 0, m), (100, 45, 37, 50), (64, 64, 64, 64), (130, m - 130, 96, 54)]:
+        blk = eng.pair_stats_block(r0, rc, c0, cc)
+        first, second = [], []
+        for j in range(r0, r0 + rc):
+            for i in range(c0, min(j, c0 + cc)):
+                first.append(i)
+                second.append(j)
+        ref = eng.pair_stats(first, second)
+        got = blk[np.array(second) - r0, np.array(first) - c0]
+        assert np.array_equal(got, ref)
+        mask = np.ones(blk.shape, dtype=bool)
+        mask[np.array(second) - r0, np.array(first) - c0] = False
+        assert not blk[mask].view(np.uint32).any()      # nothing outside the pairs i < j
+    eng.close()
+
+
+def _x_weighted_numpy(ta, tm, fa_i, fa_j, fm_i, fm_j, both_x, unsquared):
+    """ComputeXR2's arithmetic (plink2_ld.cc:7160-7185) for one pair in numpy longdouble: every fma of the reference is one rounding of
+    an exactly representable product-sum here as long as the 64-bit significand holds it -- the caller only asks for the value where
+    double arithmetic cannot be on a rounding boundary (tolerance 2 ulp), bit-exactness is the CLI tests' business (vs the reference)."""
+    def counts(t, f1, f2):
+        n = int(t["nm"]); g1 = n - int(t["sum1"]); q1 = n - 2 * int(t["sum1"]) + int(t["ssq1"])
+        g2 = n - int(t["sum2"]); q2 = n - 2 * int(t["sum2"]) + int(t["ssq2"]); d = n - int(t["sum1"]) - int(t["sum2"]) + int(t["dot"])
+        if f1:
+            q1 = 4 * n - 4 * g1 + q1; g1 = 2 * n - g1; d = 2 * g2 - d
+        if f2:
+            q2 = 4 * n - 4 * g2 + q2; g2 = 2 * n - g2; d = 2 * g1 - d
+        return n, g1, q1, g2, q2, d
+    a = counts(ta, fa_i, fa_j)
+    mm = counts(tm, fm_i, fm_j) if tm is not None else (0,) * 6
+    if not a[0]:
+        return np.nan
+    w = 0.5 if both_x else (1.0 - 0.5 * 1.4142135623730951)
+    L = np.longdouble
+    wn, g1, q1, g2, q2, d = [np.float64(L(x) - L(w) * L(y)) for x, y in zip(a, mm)]
+    var1 = np.float64(L(q1) * L(wn) - L(np.float64(g1 * g1)))
+    var2 = np.float64(L(q2) * L(wn) - L(np.float64(g2 * g2)))
+    if not (var1 > 0 and var2 > 0):
+        return np.nan
+    cov = np.float64(L(d) * L(wn) - L(np.float64(g1 * g2)))
+    r = min(1.0, float(cov * cov / (var1 * var2)))
+    if unsquared:
+        r = np.sqrt(r) * (-1.0 if cov < 0 else 1.0)
+    return r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("unsquared,as_float", [(False, False), (True, False), (False, True)])
+def test_chrx_weighted_blocks_on_the_device(gpu_pkg, monkeypatch, unsquared, as_float):
+    """ldp_r2_unphased_block_x / _x_hits (ComputeXR2): the all-founder and the male-founder engines' tuples from the pair kernels, combined
+    by x_weighted_kernel -- only the pairs with a chrX variant are touched; values against the same arithmetic in numpy; one chunk or
+    many; hits = the dense values filtered."""
+    pkg = gpu_pkg
+    m, n = 300, 160
+    rng = np.random.default_rng(11)
+    raw = T.synth_raw_codes(m, n, seed=21, missing_rate=0.03, ld_copy_prob=0.7)
+    is_x = np.zeros(m, dtype=np.uint8)
+    is_x[100:190] = 1
+    male = np.flatnonzero(rng.random(n) < 0.45)
+    flip_all = (rng.random(m) < 0.3).astype(np.uint8)
+    flip_male = (rng.random(m) < 0.3).astype(np.uint8)
+    e_all = pkg.LdPruneEngine(n, 2, 1, False, 0.5, device=0)
+    e_all.set_variants_matrix(m)
+    e_all.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+    e_m = pkg.LdPruneEngine(len(male), 2, 1, False, 0.5, device=0)
+    e_m.set_variants_matrix(m)
+    e_m.load_genotypes_host(0, T.pack_2bit(raw[:, male]), pkg.LDP_GENO_REF)
+    for (r0, rc, c0, cc) in [(0, m, 0, m), (90, 120, 50, 100), (200, 100, 0, 96), (200, 100, 150, 64)]:
+        base = e_all.r2_unphased_block(r0, rc, c0, cc, as_float=as_float)
+        ta, tm = e_all.pair_stats_block(r0, rc, c0, cc), e_m.pair_stats_block(r0, rc, c0, cc)
+        outs = []
+        for rows_env in (None, "7"):
+            if rows_env:
+                monkeypatch.setenv("LDP_DEBUG_X_ROWS", rows_env)
+            else:
+                monkeypatch.delenv("LDP_DEBUG_X_ROWS", raising=False)
+            outs.append(e_all.r2_unphased_block_x(base.copy(), e_m, is_x, r0, c0, flip_all, flip_male, unsquared))
+        monkeypatch.delenv("LDP_DEBUG_X_ROWS", raising=False)
+        got = outs[0]
+        assert same_bits(outs[0], outs[1])
+        touched = np.zeros(got.shape, dtype=bool)
+        for j in range(r0, r0 + rc):
+            for i in range(c0, min(j, c0 + cc)):
+                if is_x[i] or is_x[j]:
+                    touched[j - r0, i - c0] = True
+                    want = _x_weighted_numpy(ta[j - r0, i - c0], tm[j - r0, i - c0], flip_all[i], flip_all[j], flip_male[i], flip_male[j], bool(is_x[i] and is_x[j]), unsquared)
+                    g = float(got[j - r0, i - c0])
+                    assert (np.isnan(want) and np.isnan(g)) or abs(g - want) <= (2e-7 if as_float else 5e-16) * max(1.0, abs(want)), (i, j, g, want)
+        assert (touched.any() or (r0, c0) == (200, 0)) and same_bits(got[~touched], base[~touched])   # (one block has no chrX row or column)
+        if not as_float:
+            assert set(got[touched][np.isnan(got[touched])].view(np.uint64)) <= {0xfff8000000000000}
+            hits, found = e_all.r2_unphased_block_x_hits(e_m, is_x, 0.05, r0, rc, c0, cc, flip_all, flip_male, unsquared)
+            jj, ii = np.nonzero(touched & (np.abs(got) >= 0.05))
+            want_hits = sorted((int(i) + c0, int(j) + r0) for j, i in zip(jj, ii))
+            assert found == len(want_hits) and [(int(h["first"]), int(h["second"])) for h in hits] == want_hits
+            assert same_bits(np.array([h["r2"] for h in hits]), np.array([got[j - r0, i - c0] for i, j in want_hits]))
+    # without male founders the weights drop out but the formula (clamp, variance guard) stays
+    base = e_all.r2_unphased_block(0, m, 0, m)
+    none = e_all.r2_unphased_block_x(base.copy(), None, is_x, 0, 0, None, None, unsquared)
+    ta = e_all.pair_stats_block(0, m, 0, m)
+    for (i, j) in [(120, 150), (5, 130), (150, 250)]:
+        want = _x_weighted_numpy(ta[j, i], None, 0, 0, 0, 0, bool(is_x[i] and is_x[j]), unsquared)
+        assert (np.isnan(want) and np.isnan(none[j, i])) or abs(none[j, i] - want) <= 5e-16 * max(1.0, abs(want))
+    e_all.close()
+    e_m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mods,extra,ext", [(["inter-chr"], ["--ld-window-r2", "0.02"], ".vcor"), (["square", "bin"], [], ".unphased.vcor2.bin"),
+                                            (["inter-chr", "ref-based"], ["--ld-window-r2", "0"], ".vcor")])
+def test_cli_chrx_device_path_equals_the_pair_lists(gpu_pkg, tmp_path, mods, extra, ext):
+    """plink2-hip's chrX values of dense rows and of the inter-chr table come from ldp_r2_unphased_block_x[_hits]; LDP_DEBUG_X_HOST=1
+    takes the same pairs as lists through the one-wave-per-pair kernel and the host arithmetic (what the band writers do, pinned to the
+    reference in test_cli_r2_with_chrx_matches_reference): byte-identical files, also when the device path works in many row chunks."""
+    cli = gpu_pkg.build_cli()
+    tmp = str(tmp_path)
+    _x_fileset(tmp_path, m=900, n=210, seed=13)
+    flag = "--r-unphased" if "ref-based" in mods else "--r2-unphased"
+    outs = []
+    for tag, env in (("dev", {}), ("chunks", {"LDP_DEBUG_X_ROWS": "50"}), ("host", {"LDP_DEBUG_X_HOST": "1"})):
+        got = subprocess.run([cli, "--pfile", "sx", flag] + mods + extra + ["--out", tag], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                             timeout=900, env={**os.environ, **env})
+        assert got.returncode == 0, got.stdout
+        outs.append(open(os.path.join(tmp, tag + ext), "rb").read())
+    assert len(outs[0]) > 10000 and outs[0] == outs[2] and outs[1] == outs[2]
+
+
 def _concat(paths):
     return b"".join(open(p, "rb").read() for p in paths)
 

@@ -97,6 +97,66 @@ def measure(pkg, torch, path, allele_cts, label, extra):
     return res
 
 
+def measure_phased(pkg, torch, path, label, extra):
+    """--indep-pairphase's load: main + hardcall-phase tracks -> haplotype rows (ldp_load_pgen_records_phased) against the host reader
+    (ldp_pgen_read_phased) followed by the same engine's load of its rows."""
+    f = pkg.PgenFile(path)
+    m, n = f.variant_ct, f.sample_ct
+    ptr, nbytes = f.file_bytes()
+    host_bytes = np.ctypeslib.as_array((pkg.ctypes.c_uint8 * nbytes).from_address(ptr))
+    dev_bytes = torch.from_numpy(host_bytes.copy()).cuda()
+    res = {"file": label, "samples": n, "variants": m, "file_bytes": nbytes, "haplotype_row_bytes": m * pkg.phased_row_bytes(2 * n), **extra}
+    eng = pkg.LdPruneEngine(2 * n, 200, 1, True, 0.5, order=2, device=0)
+    chr_idx, bps = bench.genome_layout(m, 1, 2875)
+    eng.set_variants(chr_idx, bps)
+
+    def dev_call():
+        eng.load_pgen_records_phased(0, f, location=pkg.LDP_MEM_DEVICE, device_bytes=dev_bytes.data_ptr())
+        eng.variant_recs(0, 1)
+
+    dev_call()
+    res["device_decode_plus_count_ms"] = 1e3 * best_of(dev_call)
+    want = eng.variant_recs().copy()
+
+    def host_bytes_call():
+        eng.load_pgen_records_phased(0, f)
+        eng.variant_recs(0, 1)
+
+    res["same_call_bytes_in_host_memory_ms"] = 1e3 * best_of(host_bytes_call)
+    rows_host = f.read_phased(threads=0)
+    res["host_decoder_all_threads_ms"] = 1e3 * best_of(lambda: f.read_phased(threads=0), reps=2)
+    res["host_decoder_one_thread_ms"] = 1e3 * best_of(lambda: f.read_phased(threads=1), reps=1)
+    rows_dev = torch.from_numpy(rows_host).cuda()
+
+    def count_only():
+        eng.load_genotypes_device(0, m, rows_dev.data_ptr(), rows_host.shape[1], pkg.LDP_GENO_REF | pkg.LDP_GENO_PHASED)
+        eng.variant_recs(0, 1)
+
+    count_only()
+    res["count_pass_on_decoded_rows_ms"] = 1e3 * best_of(count_only)
+    got = eng.variant_recs()
+    res["records_identical_to_host_decoded_rows"] = bool(all(np.array_equal(got[k], want[k]) for k in ("nm_ct", "sum", "ssq", "flags")))
+    dec = res["device_decode_plus_count_ms"] - res["count_pass_on_decoded_rows_ms"]
+    res["device_decode_ms"] = dec
+    res["device_decode_rows_GBps"] = res["haplotype_row_bytes"] / max(dec, 1e-6) / 1e6
+    eng.close()
+    f.close()
+    return res
+
+
+def write_phased_vcf(path, codes, rng):
+    """codes: (m, n) genotype codes 0/1/2/3; every het gets a random phase, everything is written with '|' (a fully phased file)."""
+    m, n = codes.shape
+    table = np.array(["0|0", "0|1", "1|1", ".|.", "1|0"])
+    with open(path, "w") as fh:
+        fh.write("##fileformat=VCFv4.2\n##contig=<ID=1>\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"GT\">\n")
+        fh.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join("s%d" % s for s in range(n)) + "\n")
+        for v in range(m):
+            c = codes[v].astype(np.int64)
+            c = np.where((c == 1) & (rng.random(n) < 0.5), 4, c)
+            fh.write("1\t%d\tp%d\tA\tC\t.\t.\t.\tGT\t%s\n" % (1000 + 2875 * v, v, "\t".join(table[c])))
+
+
 def write_multiallelic_vcf(path, codes, rng, third_rate):
     """codes: (m, n) int8 genotype codes 0/1/2/3 from the bench generator; some ALT copies become ALT2 (every variant has two ALT
     alleles in the header)."""
@@ -118,6 +178,8 @@ def main():
     ap.add_argument("--samples", type=int, default=50000)
     ap.add_argument("--variants", type=int, default=200000)
     ap.add_argument("--multi-variants", type=int, default=1500)
+    ap.add_argument("--phased-variants", type=int, default=4000)
+    ap.add_argument("--phased-samples", type=int, default=20000)
     ap.add_argument("--missing-rate", type=float, default=0.001)
     ap.add_argument("--out", default="")
     args = ap.parse_args()
@@ -149,6 +211,15 @@ def main():
             assert cp.returncode == 0, cp.stdout[-500:]
             lines.append(measure(pkg, torch, os.path.join(tmp, "mv.pgen"), np.full(mm, 3), "reference --vcf import, two ALT alleles per variant (aux track 1)",
                                  {"missing_rate": args.missing_rate}))
+        pm, pn = min(args.phased_variants, m), min(args.phased_samples, n)
+        if pm:
+            shifts = np.array([0, 2, 4, 6], dtype=np.uint8)
+            codes = ((host[:pm, :(pn + 3) // 4, None] >> shifts) & 3).reshape(pm, -1)[:, :pn]
+            write_phased_vcf(os.path.join(tmp, "p.vcf"), codes, np.random.default_rng(2))
+            cp = subprocess.run([ref_bin, "--vcf", "p.vcf", "--make-pgen", "--out", "pv"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            assert cp.returncode == 0, cp.stdout[-500:]
+            lines.append(measure_phased(pkg, torch, os.path.join(tmp, "pv.pgen"), "reference --vcf import of a fully phased file (hardcall-phase track)",
+                                        {"missing_rate": args.missing_rate}))
     finally:
         subprocess.call(["rm", "-rf", tmp])
     for r in lines:
