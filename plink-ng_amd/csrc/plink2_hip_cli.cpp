@@ -563,426 +563,439 @@ uint32_t parse_col_descriptor(const std::string& desc, const std::vector<std::st
   return result;
 }
 
-Args parse_args(int argc, char** argv) {
-  Args A;
-  auto need = [&](int i, int n, const char* flag) {
-    if (i + n >= argc) {
-      die(8, "Error: Missing argument for %s.\n", flag);
+// ---- command line ----
+// parse_args(): one pass over argv, each flag offered to the families below in turn (a family returns false for a flag that is not its
+// own), then the checks between flags (check_flag_combinations).  Inside a family `i` is the cursor into argv, as in the loop.
+struct ArgCursor {
+  int argc;
+  char** argv;
+  int i;
+};
+#define LDP_ARG_FAMILY_PROLOGUE                                   \
+  int& i = c.i;                                                   \
+  const int argc = c.argc;                                        \
+  char** const argv = c.argv;                                     \
+  auto need = [&](int at, int n, const char* flag) {             \
+    if (at + n >= argc) {                                         \
+      die(8, "Error: Missing argument for %s.\n", flag);         \
+    }                                                             \
+  };                                                              \
+  (void)need;                                                     \
+  (void)argv
+
+// the fileset and output names
+bool parse_input_flags(Args& A, ArgCursor& c, const std::string& f) {
+  LDP_ARG_FAMILY_PROLOGUE;
+  if (f == "--bfile" || f == "--pfile" || f == "--bpfile") {
+    need(i, 1, f.c_str());
+    std::string pre = argv[++i];
+    // optional 'vzs' modifier: the variant table is zstd-compressed (<prefix>.pvar.zst / .bim.zst)
+    std::string vz;
+    if (i + 1 < argc && std::string(argv[i + 1]) == "vzs") {
+      vz = ".zst";
+      ++i;
     }
-  };
-  for (int i = 1; i < argc; ++i) {
-    std::string f = argv[i];
-    if (f == "--bfile" || f == "--pfile" || f == "--bpfile") {
-      need(i, 1, f.c_str());
-      std::string pre = argv[++i];
-      // optional 'vzs' modifier: the variant table is zstd-compressed (<prefix>.pvar.zst / .bim.zst)
-      std::string vz;
-      if (i + 1 < argc && std::string(argv[i + 1]) == "vzs") {
-        vz = ".zst";
-        ++i;
-      }
-      if (f == "--bfile") {
-        A.bed = pre + ".bed";
-        A.bim = pre + ".bim" + vz;
-        A.fam = pre + ".fam";
-      } else if (f == "--pfile") {
-        A.pgen = pre + ".pgen";
-        A.pvar = pre + ".pvar" + vz;
-        A.psam = pre + ".psam";
+    if (f == "--bfile") {
+      A.bed = pre + ".bed";
+      A.bim = pre + ".bim" + vz;
+      A.fam = pre + ".fam";
+    } else if (f == "--pfile") {
+      A.pgen = pre + ".pgen";
+      A.pvar = pre + ".pvar" + vz;
+      A.psam = pre + ".psam";
+    } else {
+      A.pgen = pre + ".pgen";
+      A.bim = pre + ".bim" + vz;
+      A.fam = pre + ".fam";
+    }
+  } else if (f == "--bed" || f == "--bim" || f == "--fam" || f == "--pgen" || f == "--pgi" || f == "--pvar" || f == "--psam" || f == "--out" || f == "--indep-preferred") {
+    need(i, 1, f.c_str());
+    std::string v = argv[++i];
+    if (f == "--bed") A.bed = v;
+    else if (f == "--bim") A.bim = v;
+    else if (f == "--fam") A.fam = v;
+    else if (f == "--pgen") A.pgen = v;
+    else if (f == "--pgi") A.pgi = v;  // (external-index .pgen: plink2.cc:10572-10590)
+    else if (f == "--pvar") A.pvar = v;
+    else if (f == "--psam") A.psam = v;
+    else if (f == "--out") A.out = v;
+    else A.preferred = v;
+  } else {
+    return false;
+  }
+  return true;
+}
+
+// --indep-pairwise / --indep-pairphase / --r2-unphased / --r-unphased and their modifiers
+bool parse_command_flags(Args& A, ArgCursor& c, const std::string& f) {
+  LDP_ARG_FAMILY_PROLOGUE;
+  if (f == "--indep-pairwise" || f == "--indep-pairphase") {
+    if (A.have_prune) {
+      die(8, "Error: --indep-pairwise and --indep-pairphase cannot be used together.\n");
+    }
+    A.pairphase = (f == "--indep-pairphase");
+    const char* fl = f.c_str();
+    // <window size>['kb'] [step size (variant ct)] <unphased-hardcall-r^2 threshold>   (plink2.cc:7238-7313)
+    std::vector<std::string> par;
+    while (i + 1 < argc && !(argv[i + 1][0] == '-' && argv[i + 1][1] == '-')) {
+      par.emplace_back(argv[++i]);
+    }
+    if (par.size() < 2 || par.size() > 4) {
+      die(8, "Error: %s accepts 2-4 arguments.\n", fl);
+    }
+    double first;
+    const char* endp;
+    if (!scan_double_plink(par[0].c_str(), &first, &endp) || first < 0.0) {
+      die(8, "Error: Invalid %s window size '%s'.\n", fl, par[0].c_str());
+    }
+    size_t next = 1;
+    bool is_kb = false;
+    if (ieq(endp, "kb")) {
+      is_kb = true;
+    } else if (*endp) {
+      die(8, "Error: Invalid %s window size '%s'.\n", fl, par[0].c_str());
+    } else if (ieq(par[1].c_str(), "kb")) {
+      is_kb = true;
+      next = 2;
+    }
+    if (is_kb) {
+      A.window_is_bp = true;
+      if (first > 2147483.646) {
+        A.window = 2147483646;
       } else {
-        A.pgen = pre + ".pgen";
-        A.bim = pre + ".bim" + vz;
-        A.fam = pre + ".fam";
-      }
-    } else if (f == "--bed" || f == "--bim" || f == "--fam" || f == "--pgen" || f == "--pgi" || f == "--pvar" || f == "--psam" || f == "--out" || f == "--indep-preferred") {
-      need(i, 1, f.c_str());
-      std::string v = argv[++i];
-      if (f == "--bed") A.bed = v;
-      else if (f == "--bim") A.bim = v;
-      else if (f == "--fam") A.fam = v;
-      else if (f == "--pgen") A.pgen = v;
-      else if (f == "--pgi") A.pgi = v;  // (external-index .pgen: plink2.cc:10572-10590)
-      else if (f == "--pvar") A.pvar = v;
-      else if (f == "--psam") A.psam = v;
-      else if (f == "--out") A.out = v;
-      else A.preferred = v;
-    } else if (f == "--indep-pairwise" || f == "--indep-pairphase") {
-      if (A.have_prune) {
-        die(8, "Error: --indep-pairwise and --indep-pairphase cannot be used together.\n");
-      }
-      A.pairphase = (f == "--indep-pairphase");
-      const char* fl = f.c_str();
-      // <window size>['kb'] [step size (variant ct)] <unphased-hardcall-r^2 threshold>   (plink2.cc:7238-7313)
-      std::vector<std::string> par;
-      while (i + 1 < argc && !(argv[i + 1][0] == '-' && argv[i + 1][1] == '-')) {
-        par.emplace_back(argv[++i]);
-      }
-      if (par.size() < 2 || par.size() > 4) {
-        die(8, "Error: %s accepts 2-4 arguments.\n", fl);
-      }
-      double first;
-      const char* endp;
-      if (!scan_double_plink(par[0].c_str(), &first, &endp) || first < 0.0) {
-        die(8, "Error: Invalid %s window size '%s'.\n", fl, par[0].c_str());
-      }
-      size_t next = 1;
-      bool is_kb = false;
-      if (ieq(endp, "kb")) {
-        is_kb = true;
-      } else if (*endp) {
-        die(8, "Error: Invalid %s window size '%s'.\n", fl, par[0].c_str());
-      } else if (ieq(par[1].c_str(), "kb")) {
-        is_kb = true;
-        next = 2;
-      }
-      if (is_kb) {
-        A.window_is_bp = true;
-        if (first > 2147483.646) {
-          A.window = 2147483646;
-        } else {
-          const int32_t w = static_cast<int32_t>(first * 1000 * (1 + kSmallEpsilon));
-          if (w < 2) {
-            die(8, "Error: %s window size cannot be smaller than 2.\n", fl);
-          }
-          A.window = w;
+        const int32_t w = static_cast<int32_t>(first * 1000 * (1 + kSmallEpsilon));
+        if (w < 2) {
+          die(8, "Error: %s window size cannot be smaller than 2.\n", fl);
         }
+        A.window = w;
+      }
+    } else {
+      A.window = (first > 2147483647) ? 2147483647u : static_cast<uint32_t>(static_cast<int32_t>(first));
+    }
+    if (next + 2 == par.size()) {
+      // explicit step size
+      char* e2;
+      const long st = strtol(par[next].c_str(), &e2, 10);
+      if (*e2 || st < 1 || st > 2147483646) {
+        die(8, "Error: Invalid %s window-increment '%s'.\n", fl, par[next].c_str());
+      }
+      A.step = static_cast<uint32_t>(st);
+      if (!is_kb) {
+        if (A.step > A.window) {
+          die(8, "Error: %s window-increment cannot be larger than window size.\n", fl);
+        }
+      } else if (A.step != 1) {
+        die(8, "Error: %s window-increment must be 1 when window size is in\nkilobase units.\n", fl);
+      }
+      ++next;
+    } else if (next + 1 != par.size()) {
+      die(8, "Error: Invalid %s argument sequence.\n", fl);
+    }
+    const char* e3;
+    if (!scan_double_plink(par[next].c_str(), &A.r2, &e3) || *e3 || A.r2 < 0.0 || A.r2 >= 1.0) {
+      die(8, "Error: Invalid %s r^2 threshold '%s'.\n", fl, par[next].c_str());
+    }
+    A.have_prune = true;
+  } else if ((f == "--r2-unphased") || (f == "--r-unphased")) {
+    if (A.have_r2) {
+      die(8, "Error: --r-phased, --r-unphased, --r2-phased, and --r2-unphased are mutually\nexclusive.\n");
+    }
+    A.r_unsquared = (f == "--r-unphased");
+    g_r_unsquared = A.r_unsquared;
+    // [{square | square0 | triangle | inter-chr}] ['yes-really'] [{zs | bin | bin4}] ... (plink2.cc:11090-11210)
+    while (i + 1 < argc && !(argv[i + 1][0] == '-' && argv[i + 1][1] == '-')) {
+      std::string m = argv[++i];
+      const bool is_shape = (m == "square") || (m == "square0") || (m == "triangle");
+      const bool is_encoding = (m == "bin") || (m == "bin4") || (m == "zs");
+      if (is_shape && (A.r2_shape >= 0)) {
+        die(8, "Error: Multiple --r2-unphased shape modifiers.\n");  // plink2.cc:11068-11090
+      }
+      if (is_encoding && ((A.r2_float >= 0) || A.r2_zs)) {
+        die(8, "Error: Multiple --r2-unphased encoding modifiers.\n");  // plink2.cc:11106-11118
+      }
+      if (m == "square") A.r2_shape = 0;
+      else if (m == "square0") A.r2_shape = 1;
+      else if (m == "triangle") A.r2_shape = 2;
+      else if (m == "inter-chr") A.r2_inter = true;
+      else if (m == "bin") A.r2_float = 0;
+      else if (m == "bin4") A.r2_float = 1;
+      else if (m == "zs") A.r2_zs = true;
+      else if (m == "yes-really") A.yes_really = true;
+      else if (m == "ref-based") A.r2_ref_based = true;          // multiallelic variants: REF vs the rest instead of major vs the rest
+      else if (m == "allow-ambiguous-allele") A.r2_allow_ambiguous = true;
+      else if (m.compare(0, 5, "cols=") == 0) {
+        if (A.r2_cols_given) {
+          die(8, "Error: Multiple --r2-unphased cols= modifiers.\n");
+        }
+        A.r2_cols_given = true;
+        A.r2_cols_desc = m.substr(5);
+      }
+      else if ((m == "d") || (m == "dprime") || (m == "dprime-signed")) {
+        die(8, "Error: --r2-unphased does not support computation of D or D'. Use --r2-phased\nwith 'cols=+%s' instead.\n", (m == "d") ? "d" : ((m == "dprime") ? "dprimeabs" : "dprime"));
+      }
+      else die(63, "Error: --r2-unphased modifier '%s' is not supported by plink2-hip (matrix shapes with bin/bin4, or the default-column table).\n", m.c_str());
+    }
+    if ((A.r2_shape < 0) && (A.r2_float >= 0)) {
+      A.r2_shape = 0;  // an encoding without a shape: square (plink2_help.cc:1015-1017)
+    }
+    // (r's sign needs an allele to refer to: its default set adds MAJ, or REF with 'ref-based'; plink2.cc:11158-11162, :11196-11203)
+    const uint32_t default_cols = kVcorColDefault | (A.r_unsquared ? (A.r2_ref_based ? kVcorColRef : kVcorColMaj) : 0u);
+    A.r2_cols = default_cols;
+    if (A.r2_cols_given) {  // plink2.cc:11158-11172
+      A.r2_cols = parse_col_descriptor(A.r2_cols_desc, {"chrom", "pos", "id", "ref", "alt1", "alt", "maybeprovref", "provref", "maj", "nonmaj", "freq", "d", "dprime", "dprimeabs"},
+                                       default_cols, A.r_unsquared ? "r-unphased" : "r2-unphased");
+      if (A.r2_cols & (kVcorColD | kVcorColDprime | kVcorColDprimeAbs)) {
+        die(8, "Error: --r2-unphased does not support computation of D or D'. Use --r%s-phased\ninstead.\n", A.r_unsquared ? "" : "2");
+      }
+    }
+    if ((A.r2_inter || A.r2_cols_given) && (A.r2_shape >= 0)) {
+      die(8, "Error: Matrix-only and table-only --r2-unphased settings cannot be used together.\n");  // plink2.cc:11187-11191
+    }
+    A.r2_table = (A.r2_shape < 0);
+    A.r2_text = (A.r2_shape >= 0) && (A.r2_float < 0);  // shape without bin/bin4: tab-delimited text matrix
+    if (A.r2_text) {
+      A.r2_float = 0;  // computed as doubles, printed with 6 significant digits
+    }
+    A.have_r2 = true;
+  } else {
+    return false;
+  }
+  return true;
+}
+
+// --clump and its companions (plink2.cc:4861-5232)
+bool parse_clump_flags(Args& A, ArgCursor& c, const std::string& f) {
+  LDP_ARG_FAMILY_PROLOGUE;
+  if (f == "--clump") {  // plink2.cc:4861-4958
+    need(i, 1, "--clump");
+    while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+      const std::string arg = argv[++i];
+      if (arg == "zs") {  // (.clumps and the missing-ID lists through the zstd writer, OutnameZstSet :7920, :7944, :9004)
+        if (!A.clump_files.empty()) {
+          die(8, "Error: Invalid --clump argument sequence ('zs' must come before\nfilename(s)).\n");
+        }
+        A.clump_zs = true;
+        continue;
+      }
+      if (arg.compare(0, 5, "cols=") == 0) {  // plink2.cc:4900-4925
+        if (!A.clump_files.empty()) {
+          die(8, "Error: Invalid --clump argument sequence ('cols=' must come before\nfilename(s)).\n");
+        }
+        if (A.clump_cols_given) {
+          die(8, "Error: Multiple --clump cols= modifiers.\n");
+        }
+        A.clump_cols_given = true;
+        A.clump_cols_desc = arg.substr(5);
+        continue;
+      }
+      size_t p0 = 0;
+      while (p0 <= arg.size()) {
+        const size_t p1 = std::min(arg.find(',', p0), arg.size());
+        if (p1 > p0) {
+          A.clump_files.push_back(arg.substr(p0, p1 - p0));
+        }
+        p0 = p1 + 1;
+      }
+    }
+    A.have_clump = true;
+    A.clump_cols = kClumpColDefault;
+    if (A.clump_cols_given) {
+      A.clump_cols = parse_col_descriptor(A.clump_cols_desc, {"chrom", "pos", "ref", "alt1", "alt", "maybeprovref", "provref", "maybea1", "a1", "maybef", "f", "total",
+                                                              "maybebounds", "bounds", "bins", "sp2"}, kClumpColDefault, "clump");
+    }
+  } else if (f == "--clump-bins") {  // plink2.cc:5139-5192
+    need(i, 1, "--clump-bins");
+    double prev_ln = -1.7976931348623157e308;
+    while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+      const std::string arg = argv[++i];
+      const char* it = arg.c_str();
+      while (true) {
+        double cur_ln;
+        it = scan_ln(it, &cur_ln);
+        if ((!it) || ((*it != '\0') && (*it != ','))) {
+          die(8, "Error: Invalid --clump-bins argument '%s'.\n", arg.c_str());
+        }
+        if (cur_ln <= prev_ln) {  // (the reference means to refuse these too, plink2.cc:5178, but never advances its prev_ln)
+          die(8, "Error: --clump-bins values are not in increasing order.\n");
+        }
+        if (cur_ln >= 0.0) {
+          die(8, "Error: --clump-bins values >= 1 do not make sense.\n");
+        }
+        prev_ln = cur_ln;
+        A.clump_ln_bins.push_back(cur_ln * (1.0 + kSmallEpsilon));
+        if (*it == '\0') {
+          break;
+        }
+        ++it;
+      }
+    }
+    if (A.clump_ln_bins.size() > 2000) {
+      die(63, "Error: more than 2000 --clump-bins boundaries are not supported by plink2-hip.\n");
+    }
+  } else if (f == "--clump-unphased") {
+    A.clump_unphased = true;
+  } else if (f == "--clump-allow-overlap") {
+    A.clump_allow_overlap = true;
+  } else if (f == "--clump-force-a1") {  // plink2.cc:5200-5210
+    A.clump_force_a1 = true;
+  } else if (f == "--clump-a1-field") {  // plink2.cc:5059-5071
+    while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+      A.clump_a1_field.push_back(argv[++i]);
+    }
+    A.clump_no_a1 = A.clump_a1_field.empty();
+  } else if ((f == "--clump-range") || (f == "--clump-range0")) {  // plink2.cc:5092-5120
+    need(i, 1, f.c_str());
+    if (!A.clump_range.empty()) {
+      die(8, "Error: --clump-range and --clump-range0 cannot be used together.\n");
+    }
+    A.clump_range = argv[++i];
+    A.clump_range0 = (f == "--clump-range0");
+  } else if (f == "--clump-range-border") {  // plink2.cc:5121-5138
+    need(i, 1, "--clump-range-border");
+    const std::string v = argv[++i];
+    double d;
+    const char* endp;
+    if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || (d < 0.0)) {
+      die(8, "Error: Invalid --clump-range-border argument '%s'.\n", v.c_str());
+    }
+    A.clump_range_border = (d > 2147483.646) ? 0x7ffffffeu : static_cast<uint32_t>(static_cast<int32_t>(d * 1000 * (1 + kSmallEpsilon)));
+    A.clump_range_border_given = true;
+  } else if (f == "--clump-log10") {  // plink2.cc:5211-5232
+    A.clump_in_log10 = A.clump_out_log10 = true;
+    if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+      const std::string v = argv[++i];
+      if (v == "input-only") {
+        A.clump_out_log10 = false;
+      } else if (v == "output-only") {
+        A.clump_in_log10 = false;
       } else {
-        A.window = (first > 2147483647) ? 2147483647u : static_cast<uint32_t>(static_cast<int32_t>(first));
+        die(8, "Error: Invalid --clump-log10 argument '%s'.\n", v.c_str());
       }
-      if (next + 2 == par.size()) {
-        // explicit step size
-        char* e2;
-        const long st = strtol(par[next].c_str(), &e2, 10);
-        if (*e2 || st < 1 || st > 2147483646) {
-          die(8, "Error: Invalid %s window-increment '%s'.\n", fl, par[next].c_str());
-        }
-        A.step = static_cast<uint32_t>(st);
-        if (!is_kb) {
-          if (A.step > A.window) {
-            die(8, "Error: %s window-increment cannot be larger than window size.\n", fl);
-          }
-        } else if (A.step != 1) {
-          die(8, "Error: %s window-increment must be 1 when window size is in\nkilobase units.\n", fl);
-        }
-        ++next;
-      } else if (next + 1 != par.size()) {
-        die(8, "Error: Invalid %s argument sequence.\n", fl);
+    }
+  } else if ((f == "--clump-log10-p1") || (f == "--clump-log10-p2")) {  // plink2.cc:4979-5008
+    need(i, 1, f.c_str());
+    const std::string v = argv[++i];
+    double d;
+    const char* endp;
+    if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || (d < 0.0)) {
+      die(8, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
+    }
+    ((f == "--clump-log10-p1") ? A.clump_ln_p1 : A.clump_ln_p2) = d * (-2.3025850929940457 * (1.0 - kSmallEpsilon));
+    ((f == "--clump-log10-p1") ? A.clump_log10_p1 : A.clump_log10_p2) = true;
+  } else if ((f == "--clump-p1") || (f == "--clump-p2")) {  // plink2.cc:5015-5046
+    ((f == "--clump-p1") ? A.clump_plain_p1 : A.clump_plain_p2) = true;
+    need(i, 1, f.c_str());
+    const std::string v = argv[++i];
+    double ln;
+    const char* endp = scan_ln(v.c_str(), &ln);
+    if (!endp || *endp || (ln > 0.0)) {
+      die(8, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
+    }
+    ((f == "--clump-p1") ? A.clump_ln_p1 : A.clump_ln_p2) = ln * (1.0 - kSmallEpsilon);
+  } else if (f == "--clump-r2") {  // plink2.cc:5047-5059
+    need(i, 1, "--clump-r2");
+    const std::string v = argv[++i];
+    double d;
+    const char* endp;
+    if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || (d >= 1.0 - kSmallEpsilon)) {
+      die(8, "Error: Invalid --clump-r2 argument '%s'.\n", v.c_str());
+    }
+    A.clump_r2_raw = d;
+    A.clump_r2 = d * (1.0 + kSmallEpsilon);
+  } else if (f == "--clump-kb") {  // plink2.cc:4960-4978
+    need(i, 1, "--clump-kb");
+    const std::string v = argv[++i];
+    double d;
+    const char* endp;
+    if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || (d < 0.001)) {
+      die(8, "Error: Invalid --clump-kb argument '%s'.\n", v.c_str());
+    }
+    d *= 1000;
+    A.clump_bp_radius = (d > 2147483647.0) ? 0x7ffffffeu : static_cast<uint32_t>(static_cast<int32_t>(d * (1.0 + kSmallEpsilon) - 1));
+  } else if ((f == "--clump-id-field") || (f == "--clump-snp-field") || (f == "--clump-p-field") || (f == "--clump-field") ||
+             (f == "--clump-test-field") || (f == "--clump-test")) {
+    // one or more names, highest priority first; --clump-test[-field] without arguments turns the TEST filter off
+    std::vector<std::string> names;
+    while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+      names.push_back(argv[++i]);
+    }
+    if ((f == "--clump-test") || (f == "--clump-test-field")) {
+      if (names.empty()) {
+        A.clump_no_test = true;
       }
-      const char* e3;
-      if (!scan_double_plink(par[next].c_str(), &A.r2, &e3) || *e3 || A.r2 < 0.0 || A.r2 >= 1.0) {
-        die(8, "Error: Invalid %s r^2 threshold '%s'.\n", fl, par[next].c_str());
+      ((f == "--clump-test") ? A.clump_test : A.clump_test_field) = names;
+    } else {
+      if (names.empty()) {
+        die(8, "Error: %s needs at least one column name.\n", f.c_str());
       }
-      A.have_prune = true;
-    } else if ((f == "--r2-unphased") || (f == "--r-unphased")) {
-      if (A.have_r2) {
-        die(8, "Error: --r-phased, --r-unphased, --r2-phased, and --r2-unphased are mutually\nexclusive.\n");
-      }
-      A.r_unsquared = (f == "--r-unphased");
-      g_r_unsquared = A.r_unsquared;
-      // [{square | square0 | triangle | inter-chr}] ['yes-really'] [{zs | bin | bin4}] ... (plink2.cc:11090-11210)
-      while (i + 1 < argc && !(argv[i + 1][0] == '-' && argv[i + 1][1] == '-')) {
-        std::string m = argv[++i];
-        const bool is_shape = (m == "square") || (m == "square0") || (m == "triangle");
-        const bool is_encoding = (m == "bin") || (m == "bin4") || (m == "zs");
-        if (is_shape && (A.r2_shape >= 0)) {
-          die(8, "Error: Multiple --r2-unphased shape modifiers.\n");  // plink2.cc:11068-11090
-        }
-        if (is_encoding && ((A.r2_float >= 0) || A.r2_zs)) {
-          die(8, "Error: Multiple --r2-unphased encoding modifiers.\n");  // plink2.cc:11106-11118
-        }
-        if (m == "square") A.r2_shape = 0;
-        else if (m == "square0") A.r2_shape = 1;
-        else if (m == "triangle") A.r2_shape = 2;
-        else if (m == "inter-chr") A.r2_inter = true;
-        else if (m == "bin") A.r2_float = 0;
-        else if (m == "bin4") A.r2_float = 1;
-        else if (m == "zs") A.r2_zs = true;
-        else if (m == "yes-really") A.yes_really = true;
-        else if (m == "ref-based") A.r2_ref_based = true;          // multiallelic variants: REF vs the rest instead of major vs the rest
-        else if (m == "allow-ambiguous-allele") A.r2_allow_ambiguous = true;
-        else if (m.compare(0, 5, "cols=") == 0) {
-          if (A.r2_cols_given) {
-            die(8, "Error: Multiple --r2-unphased cols= modifiers.\n");
-          }
-          A.r2_cols_given = true;
-          A.r2_cols_desc = m.substr(5);
-        }
-        else if ((m == "d") || (m == "dprime") || (m == "dprime-signed")) {
-          die(8, "Error: --r2-unphased does not support computation of D or D'. Use --r2-phased\nwith 'cols=+%s' instead.\n", (m == "d") ? "d" : ((m == "dprime") ? "dprimeabs" : "dprime"));
-        }
-        else die(63, "Error: --r2-unphased modifier '%s' is not supported by plink2-hip (matrix shapes with bin/bin4, or the default-column table).\n", m.c_str());
-      }
-      if ((A.r2_shape < 0) && (A.r2_float >= 0)) {
-        A.r2_shape = 0;  // an encoding without a shape: square (plink2_help.cc:1015-1017)
-      }
-      // (r's sign needs an allele to refer to: its default set adds MAJ, or REF with 'ref-based'; plink2.cc:11158-11162, :11196-11203)
-      const uint32_t default_cols = kVcorColDefault | (A.r_unsquared ? (A.r2_ref_based ? kVcorColRef : kVcorColMaj) : 0u);
-      A.r2_cols = default_cols;
-      if (A.r2_cols_given) {  // plink2.cc:11158-11172
-        A.r2_cols = parse_col_descriptor(A.r2_cols_desc, {"chrom", "pos", "id", "ref", "alt1", "alt", "maybeprovref", "provref", "maj", "nonmaj", "freq", "d", "dprime", "dprimeabs"},
-                                         default_cols, A.r_unsquared ? "r-unphased" : "r2-unphased");
-        if (A.r2_cols & (kVcorColD | kVcorColDprime | kVcorColDprimeAbs)) {
-          die(8, "Error: --r2-unphased does not support computation of D or D'. Use --r%s-phased\ninstead.\n", A.r_unsquared ? "" : "2");
-        }
-      }
-      if ((A.r2_inter || A.r2_cols_given) && (A.r2_shape >= 0)) {
-        die(8, "Error: Matrix-only and table-only --r2-unphased settings cannot be used together.\n");  // plink2.cc:11187-11191
-      }
-      A.r2_table = (A.r2_shape < 0);
-      A.r2_text = (A.r2_shape >= 0) && (A.r2_float < 0);  // shape without bin/bin4: tab-delimited text matrix
-      if (A.r2_text) {
-        A.r2_float = 0;  // computed as doubles, printed with 6 significant digits
-      }
-      A.have_r2 = true;
-    } else if (f == "--clump") {  // plink2.cc:4861-4958
-      need(i, 1, "--clump");
-      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
-        const std::string arg = argv[++i];
-        if (arg == "zs") {  // (.clumps and the missing-ID lists through the zstd writer, OutnameZstSet :7920, :7944, :9004)
-          if (!A.clump_files.empty()) {
-            die(8, "Error: Invalid --clump argument sequence ('zs' must come before\nfilename(s)).\n");
-          }
-          A.clump_zs = true;
-          continue;
-        }
-        if (arg.compare(0, 5, "cols=") == 0) {  // plink2.cc:4900-4925
-          if (!A.clump_files.empty()) {
-            die(8, "Error: Invalid --clump argument sequence ('cols=' must come before\nfilename(s)).\n");
-          }
-          if (A.clump_cols_given) {
-            die(8, "Error: Multiple --clump cols= modifiers.\n");
-          }
-          A.clump_cols_given = true;
-          A.clump_cols_desc = arg.substr(5);
-          continue;
-        }
-        size_t p0 = 0;
-        while (p0 <= arg.size()) {
-          const size_t p1 = std::min(arg.find(',', p0), arg.size());
-          if (p1 > p0) {
-            A.clump_files.push_back(arg.substr(p0, p1 - p0));
-          }
-          p0 = p1 + 1;
-        }
-      }
-      A.have_clump = true;
-      A.clump_cols = kClumpColDefault;
-      if (A.clump_cols_given) {
-        A.clump_cols = parse_col_descriptor(A.clump_cols_desc, {"chrom", "pos", "ref", "alt1", "alt", "maybeprovref", "provref", "maybea1", "a1", "maybef", "f", "total",
-                                                                "maybebounds", "bounds", "bins", "sp2"}, kClumpColDefault, "clump");
-      }
-    } else if (f == "--clump-bins") {  // plink2.cc:5139-5192
-      need(i, 1, "--clump-bins");
-      double prev_ln = -1.7976931348623157e308;
-      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
-        const std::string arg = argv[++i];
-        const char* it = arg.c_str();
-        while (true) {
-          double cur_ln;
-          it = scan_ln(it, &cur_ln);
-          if ((!it) || ((*it != '\0') && (*it != ','))) {
-            die(8, "Error: Invalid --clump-bins argument '%s'.\n", arg.c_str());
-          }
-          if (cur_ln <= prev_ln) {  // (the reference means to refuse these too, plink2.cc:5178, but never advances its prev_ln)
-            die(8, "Error: --clump-bins values are not in increasing order.\n");
-          }
-          if (cur_ln >= 0.0) {
-            die(8, "Error: --clump-bins values >= 1 do not make sense.\n");
-          }
-          prev_ln = cur_ln;
-          A.clump_ln_bins.push_back(cur_ln * (1.0 + kSmallEpsilon));
-          if (*it == '\0') {
-            break;
-          }
-          ++it;
-        }
-      }
-      if (A.clump_ln_bins.size() > 2000) {
-        die(63, "Error: more than 2000 --clump-bins boundaries are not supported by plink2-hip.\n");
-      }
-    } else if (f == "--clump-unphased") {
-      A.clump_unphased = true;
-    } else if (f == "--clump-allow-overlap") {
-      A.clump_allow_overlap = true;
-    } else if (f == "--snps-only") {  // plink2.cc:11437-11453
-      A.snps_only = true;
-      if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
-        const std::string v = argv[++i];
-        if (v != "just-acgt") {
-          die(8, "Error: Invalid --snps-only argument '%s'.\n", v.c_str());
-        }
-        A.snps_only_acgt = true;
-      }
-    } else if (f == "--silent") {
-      g_silent = true;
-    } else if (f == "--make-founders") {  // plink2.cc:9555-9575
-      A.make_founders = true;
-      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
-        const std::string v = argv[++i];
-        if (v == "require-2-missing") {
-          A.make_founders_require2 = true;
-        } else if (v == "first") {
-          A.make_founders_first = true;
-        } else {
-          die(8, "Error: Invalid --make-founders argument '%s'.\n", v.c_str());
-        }
-      }
-    } else if (f == "--clump-force-a1") {  // plink2.cc:5200-5210
-      A.clump_force_a1 = true;
-    } else if (f == "--clump-a1-field") {  // plink2.cc:5059-5071
-      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
-        A.clump_a1_field.push_back(argv[++i]);
-      }
-      A.clump_no_a1 = A.clump_a1_field.empty();
-    } else if ((f == "--clump-range") || (f == "--clump-range0")) {  // plink2.cc:5092-5120
-      need(i, 1, f.c_str());
-      if (!A.clump_range.empty()) {
-        die(8, "Error: --clump-range and --clump-range0 cannot be used together.\n");
-      }
-      A.clump_range = argv[++i];
-      A.clump_range0 = (f == "--clump-range0");
-    } else if (f == "--clump-range-border") {  // plink2.cc:5121-5138
-      need(i, 1, "--clump-range-border");
+      (((f == "--clump-p-field") || (f == "--clump-field")) ? A.clump_p_field : A.clump_id_field) = names;
+    }
+  } else if (f.compare(0, 7, "--clump") == 0) {
+    die(63, "Error: %s is not supported by plink2-hip's --clump yet.\n", f.c_str());
+  } else {
+    return false;
+  }
+  return true;
+}
+
+// variant and sample filters
+bool parse_filter_flags(Args& A, ArgCursor& c, const std::string& f) {
+  LDP_ARG_FAMILY_PROLOGUE;
+  if (f == "--snps-only") {  // plink2.cc:11437-11453
+    A.snps_only = true;
+    if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
       const std::string v = argv[++i];
-      double d;
-      const char* endp;
-      if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || (d < 0.0)) {
-        die(8, "Error: Invalid --clump-range-border argument '%s'.\n", v.c_str());
+      if (v != "just-acgt") {
+        die(8, "Error: Invalid --snps-only argument '%s'.\n", v.c_str());
       }
-      A.clump_range_border = (d > 2147483.646) ? 0x7ffffffeu : static_cast<uint32_t>(static_cast<int32_t>(d * 1000 * (1 + kSmallEpsilon)));
-      A.clump_range_border_given = true;
-    } else if (f == "--clump-log10") {  // plink2.cc:5211-5232
-      A.clump_in_log10 = A.clump_out_log10 = true;
-      if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
-        const std::string v = argv[++i];
-        if (v == "input-only") {
-          A.clump_out_log10 = false;
-        } else if (v == "output-only") {
-          A.clump_in_log10 = false;
-        } else {
-          die(8, "Error: Invalid --clump-log10 argument '%s'.\n", v.c_str());
-        }
-      }
-    } else if ((f == "--clump-log10-p1") || (f == "--clump-log10-p2")) {  // plink2.cc:4979-5008
-      need(i, 1, f.c_str());
+      A.snps_only_acgt = true;
+    }
+  } else if (f == "--make-founders") {  // plink2.cc:9555-9575
+    A.make_founders = true;
+    while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
       const std::string v = argv[++i];
-      double d;
-      const char* endp;
-      if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || (d < 0.0)) {
-        die(8, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
-      }
-      ((f == "--clump-log10-p1") ? A.clump_ln_p1 : A.clump_ln_p2) = d * (-2.3025850929940457 * (1.0 - kSmallEpsilon));
-      ((f == "--clump-log10-p1") ? A.clump_log10_p1 : A.clump_log10_p2) = true;
-    } else if ((f == "--clump-p1") || (f == "--clump-p2")) {  // plink2.cc:5015-5046
-      ((f == "--clump-p1") ? A.clump_plain_p1 : A.clump_plain_p2) = true;
-      need(i, 1, f.c_str());
-      const std::string v = argv[++i];
-      double ln;
-      const char* endp = scan_ln(v.c_str(), &ln);
-      if (!endp || *endp || (ln > 0.0)) {
-        die(8, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
-      }
-      ((f == "--clump-p1") ? A.clump_ln_p1 : A.clump_ln_p2) = ln * (1.0 - kSmallEpsilon);
-    } else if (f == "--clump-r2") {  // plink2.cc:5047-5059
-      need(i, 1, "--clump-r2");
-      const std::string v = argv[++i];
-      double d;
-      const char* endp;
-      if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || (d >= 1.0 - kSmallEpsilon)) {
-        die(8, "Error: Invalid --clump-r2 argument '%s'.\n", v.c_str());
-      }
-      A.clump_r2_raw = d;
-      A.clump_r2 = d * (1.0 + kSmallEpsilon);
-    } else if (f == "--clump-kb") {  // plink2.cc:4960-4978
-      need(i, 1, "--clump-kb");
-      const std::string v = argv[++i];
-      double d;
-      const char* endp;
-      if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || (d < 0.001)) {
-        die(8, "Error: Invalid --clump-kb argument '%s'.\n", v.c_str());
-      }
-      d *= 1000;
-      A.clump_bp_radius = (d > 2147483647.0) ? 0x7ffffffeu : static_cast<uint32_t>(static_cast<int32_t>(d * (1.0 + kSmallEpsilon) - 1));
-    } else if ((f == "--clump-id-field") || (f == "--clump-snp-field") || (f == "--clump-p-field") || (f == "--clump-field") ||
-               (f == "--clump-test-field") || (f == "--clump-test")) {
-      // one or more names, highest priority first; --clump-test[-field] without arguments turns the TEST filter off
-      std::vector<std::string> names;
-      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
-        names.push_back(argv[++i]);
-      }
-      if ((f == "--clump-test") || (f == "--clump-test-field")) {
-        if (names.empty()) {
-          A.clump_no_test = true;
-        }
-        ((f == "--clump-test") ? A.clump_test : A.clump_test_field) = names;
+      if (v == "require-2-missing") {
+        A.make_founders_require2 = true;
+      } else if (v == "first") {
+        A.make_founders_first = true;
       } else {
-        if (names.empty()) {
-          die(8, "Error: %s needs at least one column name.\n", f.c_str());
+        die(8, "Error: Invalid --make-founders argument '%s'.\n", v.c_str());
+      }
+    }
+  } else if ((f == "--chr") || (f == "--not-chr")) {  // ParseChrRanges, plink2_cmdline.cc: "1-4, 22, X" in one or several arguments
+    std::vector<std::string>& dst = (f == "--chr") ? A.chr_keep : A.chr_drop;
+    while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+      const std::string arg = argv[++i];
+      size_t p0 = 0;
+      while (p0 < arg.size()) {
+        const size_t p1 = std::min(arg.find(',', p0), arg.size());
+        if (p1 > p0) {
+          dst.push_back(arg.substr(p0, p1 - p0));
         }
-        (((f == "--clump-p-field") || (f == "--clump-field")) ? A.clump_p_field : A.clump_id_field) = names;
+        p0 = p1 + 1;
       }
-    } else if (f.compare(0, 7, "--clump") == 0) {
-      die(63, "Error: %s is not supported by plink2-hip's --clump yet.\n", f.c_str());
-    } else if ((f == "--chr") || (f == "--not-chr")) {  // ParseChrRanges, plink2_cmdline.cc: "1-4, 22, X" in one or several arguments
-      std::vector<std::string>& dst = (f == "--chr") ? A.chr_keep : A.chr_drop;
-      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
-        const std::string arg = argv[++i];
-        size_t p0 = 0;
-        while (p0 < arg.size()) {
-          const size_t p1 = std::min(arg.find(',', p0), arg.size());
-          if (p1 > p0) {
-            dst.push_back(arg.substr(p0, p1 - p0));
-          }
-          p0 = p1 + 1;
-        }
-      }
-      if (dst.empty()) {
-        die(8, "Error: %s requires at least one value.\n", f.c_str());
-      }
-    } else if (f == "--max-alleles") {  // plink2.cc:9340-9360
-      need(i, 1, "--max-alleles");
+    }
+    if (dst.empty()) {
+      die(8, "Error: %s requires at least one value.\n", f.c_str());
+    }
+  } else if (f == "--max-alleles") {  // plink2.cc:9340-9360
+    need(i, 1, "--max-alleles");
+    const std::string v = argv[++i];
+    char* endp;
+    const unsigned long n = strtoul(v.c_str(), &endp, 10);
+    if (v.empty() || *endp || (n < 1) || (n > 0x7fffffffUL)) {  // (ScanPosintDefcapx: any positive integer)
+      die(8, "Error: Invalid --max-alleles argument '%s'.\n", v.c_str());
+    }
+    A.max_alleles = static_cast<uint32_t>(n);
+  } else if (f == "--autosome") {
+    A.autosome = true;
+  } else if ((f == "--maf") || (f == "--max-maf") || (f == "--geno")) {  // plink2.cc:8690-8742, 8745-8790, 6487-6516
+    double d = (f == "--maf") ? 0.01 : 0.1;
+    if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
       const std::string v = argv[++i];
-      char* endp;
-      const unsigned long n = strtoul(v.c_str(), &endp, 10);
-      if (v.empty() || *endp || (n < 1) || (n > 0x7fffffffUL)) {  // (ScanPosintDefcapx: any positive integer)
-        die(8, "Error: Invalid --max-alleles argument '%s'.\n", v.c_str());
-      }
-      A.max_alleles = static_cast<uint32_t>(n);
-    } else if (f == "--autosome") {
-      A.autosome = true;
-    } else if ((f == "--maf") || (f == "--max-maf") || (f == "--geno")) {  // plink2.cc:8690-8742, 8745-8790, 6487-6516
-      double d = (f == "--maf") ? 0.01 : 0.1;
-      if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
-        const std::string v = argv[++i];
-        const char* endp;
-        if (!scan_double_plink(v.c_str(), &d, &endp) || *endp) {
-          if (*endp == ':' || !((v[0] >= '0' && v[0] <= '9') || v[0] == '.')) {
-            die(63, "Error: %s modifiers ('%s') are not supported by plink2-hip.\n", f.c_str(), v.c_str());
-          }
-          die(8, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
-        }
-        if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
-          die(63, "Error: %s modifiers ('%s') are not supported by plink2-hip.\n", f.c_str(), argv[i + 1]);
-        }
-        if (d < 0.0) {
-          die(8, "Error: %s argument '%s' too small (must be >= 0).\n", f.c_str(), v.c_str());
-        }
-        if ((f == "--max-maf") ? (d >= 1.0) : (d > 1.0)) {
-          die(8, "Error: %s argument '%s' too large (must be %s 1).\n", f.c_str(), v.c_str(), (f == "--max-maf") ? "<" : "<=");
-        }
-      } else if (f == "--max-maf") {
-        die(8, "Error: --max-maf requires a value.\n");
-      }
-      ((f == "--maf") ? A.min_maf : ((f == "--max-maf") ? A.max_maf : A.geno)) = d;
-    } else if ((f == "--mac") || (f == "--max-mac")) {  // plink2.cc:8785-8867 (default mode: the non-major allele's dosage sum over the founders)
-      if ((i + 1 >= argc) || (argv[i + 1][0] == '-')) {
-        die(8, "Error: %s requires a value.\n", f.c_str());
-      }
-      const std::string v = argv[++i];
-      double d = 0.0;
-      const char* endp = v.c_str();  // (scan_double_plink leaves it alone when there is no number at all)
+      const char* endp;
       if (!scan_double_plink(v.c_str(), &d, &endp) || *endp) {
-        if (*endp == ':') {
+        if (*endp == ':' || !((v[0] >= '0' && v[0] <= '9') || v[0] == '.')) {
           die(63, "Error: %s modifiers ('%s') are not supported by plink2-hip.\n", f.c_str(), v.c_str());
         }
         die(8, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
@@ -990,186 +1003,238 @@ Args parse_args(int argc, char** argv) {
       if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
         die(63, "Error: %s modifiers ('%s') are not supported by plink2-hip.\n", f.c_str(), argv[i + 1]);
       }
-      if ((d < 0.0) || (d > 2147483646.0)) {
-        die(8, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
+      if (d < 0.0) {
+        die(8, "Error: %s argument '%s' too small (must be >= 0).\n", f.c_str(), v.c_str());
       }
-      if (f == "--mac") {
-        if (d > 0.0) {  // round up, but keep as much precision as possible
-          const int32_t int_part = static_cast<int32_t>(d);
-          d -= int_part;
-          A.min_allele_ddosage = static_cast<uint64_t>(int_part) * 32768ull;
-          if (d > 0.0) {
-            A.min_allele_ddosage += 1 + static_cast<uint64_t>(d * (32768 * (1 - kSmallEpsilon)));
-          }
-        }
-      } else {
-        A.max_allele_ddosage = static_cast<uint64_t>(static_cast<int64_t>(d * 32768));  // round down
+      if ((f == "--max-maf") ? (d >= 1.0) : (d > 1.0)) {
+        die(8, "Error: %s argument '%s' too large (must be %s 1).\n", f.c_str(), v.c_str(), (f == "--max-maf") ? "<" : "<=");
       }
-    } else if (f == "--ac-founders") {
-      A.ac_founders = true;
-    } else if ((f == "--extract") || (f == "--exclude") || (f == "--keep") || (f == "--remove")) {
-      std::vector<std::string>& dst = (f == "--extract") ? A.extract_files : ((f == "--exclude") ? A.exclude_files : ((f == "--keep") ? A.keep_files : A.remove_files));
-      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
-        dst.push_back(argv[++i]);
-      }
-      if (dst.empty()) {
-        die(8, "Error: %s requires at least one filename.\n", f.c_str());
-      }
-      if (((f == "--extract") || (f == "--exclude")) && ((dst[0] == "range") || (dst[0] == "bed0") || (dst[0] == "bed1") || (dst[0] == "intersect"))) {
-        die(63, "Error: the '%s' mode of %s is not supported by plink2-hip.\n", dst[0].c_str(), f.c_str());
-      }
-    } else if (f == "--ld-snp") {
-      need(i, 1, "--ld-snp");
-      if (!A.ld_snps.empty() || !A.ld_snp_list.empty()) {
-        die(8, "Error: --ld-snp cannot be used with --ld-snps or --ld-snp-list.\n");
-      }
-      A.ld_snps.emplace_back(argv[++i], "");
-    } else if (f == "--ld-snps") {  // ParseNameRanges, plink2_cmdline.cc:2247: comma-separated IDs and first-last ranges
-      if (!A.ld_snps.empty() || !A.ld_snp_list.empty()) {
-        die(8, "Error: --ld-snps cannot be used with --ld-snp or --ld-snp-list.\n");
-      }
-      while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
-        const std::string arg = argv[++i];
-        size_t p0 = 0;
-        while (p0 <= arg.size()) {
-          const size_t p1 = std::min(arg.find(',', p0), arg.size());
-          const std::string piece = arg.substr(p0, p1 - p0);
-          const size_t dash = piece.find('-');
-          if (piece.empty() || (dash == 0) || (dash + 1 == piece.size())) {
-            die(8, "Error: Invalid --ld-snps argument '%s'.\n", arg.c_str());
-          }
-          if (dash == std::string::npos) {
-            A.ld_snps.emplace_back(piece, "");
-          } else {
-            A.ld_snps.emplace_back(piece.substr(0, dash), piece.substr(dash + 1));
-          }
-          p0 = p1 + 1;
-        }
-      }
-      if (A.ld_snps.empty()) {
-        die(8, "Error: --ld-snps requires at least one value.\n");
-      }
-    } else if (f == "--ld-snp-list") {
-      need(i, 1, "--ld-snp-list");
-      if (!A.ld_snps.empty()) {
-        die(8, "Error: --ld-snp-list cannot be used with --ld-snp.\n");
-      }
-      A.ld_snp_list = argv[++i];
-    } else if (f == "--ld-window") {  // plink2.cc:7908-7920
-      need(i, 1, "--ld-window");
-      const std::string v = argv[++i];
-      char* endp;
-      const unsigned long n = strtoul(v.c_str(), &endp, 10);
-      if (v.empty() || *endp || n < 2 || n > 0x7ffffffeul) {
-        die(8, "Error: Invalid --ld-window argument '%s'.\n", v.c_str());
-      }
-      A.ld_var_ct_radius = static_cast<uint32_t>(n) - 1;
-    } else if (f == "--ld-window-kb") {  // plink2.cc:7921-7937
-      need(i, 1, "--ld-window-kb");
-      const std::string v = argv[++i];
-      double d;
-      const char* endp;
-      if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || d < 0) {
-        die(8, "Error: Invalid --ld-window-kb argument '%s'.\n", v.c_str());
-      }
-      d *= 1000 * (1 + kSmallEpsilon);
-      A.ld_bp_radius = (d > 2147483646) ? 2147483646u : static_cast<uint32_t>(static_cast<int32_t>(d));
-    } else if (f == "--ld-window-cm") {  // plink2.cc:7938-7949
-      need(i, 1, "--ld-window-cm");
-      const std::string v = argv[++i];
-      double d;
-      const char* endp;
-      if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || d < 0) {
-        die(8, "Error: Invalid --ld-window-cm argument '%s'.\n", v.c_str());
-      }
-      A.ld_cm_radius = d * (1 + kSmallEpsilon);
-    } else if (f == "--ld-window-r2") {  // plink2.cc:7950-7964
-      need(i, 1, "--ld-window-r2");
-      const std::string v = argv[++i];
-      double d;
-      const char* endp;
-      if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || d > 1.0) {
-        die(8, "Error: Invalid --ld-window-r2 argument '%s'.\n", v.c_str());
-      }
-      if (d > 0.0) {
-        d *= 1 - kSmallEpsilon;
-      }
-      A.ld_min_r2 = d;
-    } else if (f == "--ld-window-cm" || f == "--ld-snp" || f == "--ld-snps" || f == "--ld-snp-list") {
-      die(63, "Error: %s is not supported by plink2-hip.\n", f.c_str());
-    } else if (f == "--indep-order") {
-      need(i, 1, "--indep-order");
-      std::string v = argv[++i];
-      if (v == "1") A.order = 1;
-      else if (v == "2") A.order = 2;
-      else die(8, "Error: Invalid --indep-order mode '%s' ('1' or '2' expected).\n", v.c_str());
-    } else if (f == "--bad-ld") {
-      A.bad_ld = true;
-    } else if (f == "--allow-extra-chr") {
-      A.allow_extra_chr = true;
-    } else if (f == "--timing") {
-      A.timing = true;
-    } else if (f == "--dry-run") {
-      A.dry_run = true;
-    } else if (f == "--debug-format-g6") {
-      // test hook (no GPU needed): one hex bit pattern of a double per line in, the .vcor number formatting out
-      need(i, 1, "--debug-format-g6");
-      FILE* df = fopen(argv[++i], "r");
-      if (!df) {
-        die(3, "Error: Failed to open %s.\n", argv[i]);
-      }
-      char line[64], num[40];
-      while (fgets(line, sizeof(line), df)) {
-        const unsigned long long bits = strtoull(line, nullptr, 16);
-        double d;
-        memcpy(&d, &bits, sizeof(d));
-        *format_g6(d, num) = '\0';
-        puts(num);
-      }
-      fclose(df);
-      exit(0);
-    } else if (f == "--debug-zstd") {
-      // test hook (no GPU needed): <in> <out.zst> through the 'zs' output writer, in odd-sized pieces
-      need(i, 2, "--debug-zstd");
-      std::ifstream in(argv[i + 1], std::ios::binary);
-      if (!in) {
-        die(3, "Error: Failed to open %s.\n", argv[i + 1]);
-      }
-      std::stringstream ss;
-      ss << in.rdbuf();
-      const std::string data = ss.str();
-      OutFile of;
-      of.open(argv[i + 2], true);
-      for (size_t pos = 0, piece = 1; pos < data.size(); pos += piece, piece = piece * 3 + 1) {
-        piece = std::min(piece, data.size() - pos);
-        of.write(data.data() + pos, piece);
-      }
-      of.close();
-      exit(0);
-    } else if (f == "--parallel") {
-      need(i, 2, "--parallel");
-      char* end = nullptr;
-      const long k = strtol(argv[i + 1], &end, 10);
-      if ((*end) || (k < 1) || (k > 32768)) {
-        die(8, "Error: Invalid --parallel job index '%s'.\n", argv[i + 1]);
-      }
-      const long n = strtol(argv[i + 2], &end, 10);
-      if ((*end) || (n < 2) || (n > 32768) || (n < k)) {
-        die(8, "Error: Invalid --parallel total job count '%s'.\n", argv[i + 2]);
-      }
-      A.parallel_idx = static_cast<uint32_t>(k - 1);
-      A.parallel_tot = static_cast<uint32_t>(n);
-      i += 2;
-    } else if (f == "--gpus") {
-      need(i, 1, "--gpus");
-      A.gpus = atoi(argv[++i]);
-    } else if (f == "--threads" || f == "--memory" || f == "--seed") {
-      need(i, 1, f.c_str());
-      ++i;  // accepted for command-line compatibility; the work runs on the GPU(s)
-    } else {
-      die(8, "Error: Unrecognized flag ('%s').  plink2-hip implements the --indep-pairwise path only.\n", f.c_str());
+    } else if (f == "--max-maf") {
+      die(8, "Error: --max-maf requires a value.\n");
     }
+    ((f == "--maf") ? A.min_maf : ((f == "--max-maf") ? A.max_maf : A.geno)) = d;
+  } else if ((f == "--mac") || (f == "--max-mac")) {  // plink2.cc:8785-8867 (default mode: the non-major allele's dosage sum over the founders)
+    if ((i + 1 >= argc) || (argv[i + 1][0] == '-')) {
+      die(8, "Error: %s requires a value.\n", f.c_str());
+    }
+    const std::string v = argv[++i];
+    double d = 0.0;
+    const char* endp = v.c_str();  // (scan_double_plink leaves it alone when there is no number at all)
+    if (!scan_double_plink(v.c_str(), &d, &endp) || *endp) {
+      if (*endp == ':') {
+        die(63, "Error: %s modifiers ('%s') are not supported by plink2-hip.\n", f.c_str(), v.c_str());
+      }
+      die(8, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
+    }
+    if ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+      die(63, "Error: %s modifiers ('%s') are not supported by plink2-hip.\n", f.c_str(), argv[i + 1]);
+    }
+    if ((d < 0.0) || (d > 2147483646.0)) {
+      die(8, "Error: Invalid %s argument '%s'.\n", f.c_str(), v.c_str());
+    }
+    if (f == "--mac") {
+      if (d > 0.0) {  // round up, but keep as much precision as possible
+        const int32_t int_part = static_cast<int32_t>(d);
+        d -= int_part;
+        A.min_allele_ddosage = static_cast<uint64_t>(int_part) * 32768ull;
+        if (d > 0.0) {
+          A.min_allele_ddosage += 1 + static_cast<uint64_t>(d * (32768 * (1 - kSmallEpsilon)));
+        }
+      }
+    } else {
+      A.max_allele_ddosage = static_cast<uint64_t>(static_cast<int64_t>(d * 32768));  // round down
+    }
+  } else if (f == "--ac-founders") {
+    A.ac_founders = true;
+  } else if ((f == "--extract") || (f == "--exclude") || (f == "--keep") || (f == "--remove")) {
+    std::vector<std::string>& dst = (f == "--extract") ? A.extract_files : ((f == "--exclude") ? A.exclude_files : ((f == "--keep") ? A.keep_files : A.remove_files));
+    while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+      dst.push_back(argv[++i]);
+    }
+    if (dst.empty()) {
+      die(8, "Error: %s requires at least one filename.\n", f.c_str());
+    }
+    if (((f == "--extract") || (f == "--exclude")) && ((dst[0] == "range") || (dst[0] == "bed0") || (dst[0] == "bed1") || (dst[0] == "intersect"))) {
+      die(63, "Error: the '%s' mode of %s is not supported by plink2-hip.\n", dst[0].c_str(), f.c_str());
+    }
+  } else {
+    return false;
   }
+  return true;
+}
+
+// --ld-window* / --ld-snp* of the r^2 table
+bool parse_ldwindow_flags(Args& A, ArgCursor& c, const std::string& f) {
+  LDP_ARG_FAMILY_PROLOGUE;
+  if (f == "--ld-snp") {
+    need(i, 1, "--ld-snp");
+    if (!A.ld_snps.empty() || !A.ld_snp_list.empty()) {
+      die(8, "Error: --ld-snp cannot be used with --ld-snps or --ld-snp-list.\n");
+    }
+    A.ld_snps.emplace_back(argv[++i], "");
+  } else if (f == "--ld-snps") {  // ParseNameRanges, plink2_cmdline.cc:2247: comma-separated IDs and first-last ranges
+    if (!A.ld_snps.empty() || !A.ld_snp_list.empty()) {
+      die(8, "Error: --ld-snps cannot be used with --ld-snp or --ld-snp-list.\n");
+    }
+    while ((i + 1 < argc) && (argv[i + 1][0] != '-')) {
+      const std::string arg = argv[++i];
+      size_t p0 = 0;
+      while (p0 <= arg.size()) {
+        const size_t p1 = std::min(arg.find(',', p0), arg.size());
+        const std::string piece = arg.substr(p0, p1 - p0);
+        const size_t dash = piece.find('-');
+        if (piece.empty() || (dash == 0) || (dash + 1 == piece.size())) {
+          die(8, "Error: Invalid --ld-snps argument '%s'.\n", arg.c_str());
+        }
+        if (dash == std::string::npos) {
+          A.ld_snps.emplace_back(piece, "");
+        } else {
+          A.ld_snps.emplace_back(piece.substr(0, dash), piece.substr(dash + 1));
+        }
+        p0 = p1 + 1;
+      }
+    }
+    if (A.ld_snps.empty()) {
+      die(8, "Error: --ld-snps requires at least one value.\n");
+    }
+  } else if (f == "--ld-snp-list") {
+    need(i, 1, "--ld-snp-list");
+    if (!A.ld_snps.empty()) {
+      die(8, "Error: --ld-snp-list cannot be used with --ld-snp.\n");
+    }
+    A.ld_snp_list = argv[++i];
+  } else if (f == "--ld-window") {  // plink2.cc:7908-7920
+    need(i, 1, "--ld-window");
+    const std::string v = argv[++i];
+    char* endp;
+    const unsigned long n = strtoul(v.c_str(), &endp, 10);
+    if (v.empty() || *endp || n < 2 || n > 0x7ffffffeul) {
+      die(8, "Error: Invalid --ld-window argument '%s'.\n", v.c_str());
+    }
+    A.ld_var_ct_radius = static_cast<uint32_t>(n) - 1;
+  } else if (f == "--ld-window-kb") {  // plink2.cc:7921-7937
+    need(i, 1, "--ld-window-kb");
+    const std::string v = argv[++i];
+    double d;
+    const char* endp;
+    if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || d < 0) {
+      die(8, "Error: Invalid --ld-window-kb argument '%s'.\n", v.c_str());
+    }
+    d *= 1000 * (1 + kSmallEpsilon);
+    A.ld_bp_radius = (d > 2147483646) ? 2147483646u : static_cast<uint32_t>(static_cast<int32_t>(d));
+  } else if (f == "--ld-window-cm") {  // plink2.cc:7938-7949
+    need(i, 1, "--ld-window-cm");
+    const std::string v = argv[++i];
+    double d;
+    const char* endp;
+    if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || d < 0) {
+      die(8, "Error: Invalid --ld-window-cm argument '%s'.\n", v.c_str());
+    }
+    A.ld_cm_radius = d * (1 + kSmallEpsilon);
+  } else if (f == "--ld-window-r2") {  // plink2.cc:7950-7964
+    need(i, 1, "--ld-window-r2");
+    const std::string v = argv[++i];
+    double d;
+    const char* endp;
+    if (!scan_double_plink(v.c_str(), &d, &endp) || *endp || d > 1.0) {
+      die(8, "Error: Invalid --ld-window-r2 argument '%s'.\n", v.c_str());
+    }
+    if (d > 0.0) {
+      d *= 1 - kSmallEpsilon;
+    }
+    A.ld_min_r2 = d;
+  } else if (f == "--ld-window-cm" || f == "--ld-snp" || f == "--ld-snps" || f == "--ld-snp-list") {
+    die(63, "Error: %s is not supported by plink2-hip.\n", f.c_str());
+  } else {
+    return false;
+  }
+  return true;
+}
+
+// everything else (order, threads, debugging aids)
+bool parse_misc_flags(Args& A, ArgCursor& c, const std::string& f) {
+  LDP_ARG_FAMILY_PROLOGUE;
+  if (f == "--silent") {
+    g_silent = true;
+  } else if (f == "--indep-order") {
+    need(i, 1, "--indep-order");
+    std::string v = argv[++i];
+    if (v == "1") A.order = 1;
+    else if (v == "2") A.order = 2;
+    else die(8, "Error: Invalid --indep-order mode '%s' ('1' or '2' expected).\n", v.c_str());
+  } else if (f == "--bad-ld") {
+    A.bad_ld = true;
+  } else if (f == "--allow-extra-chr") {
+    A.allow_extra_chr = true;
+  } else if (f == "--timing") {
+    A.timing = true;
+  } else if (f == "--dry-run") {
+    A.dry_run = true;
+  } else if (f == "--debug-format-g6") {
+    // test hook (no GPU needed): one hex bit pattern of a double per line in, the .vcor number formatting out
+    need(i, 1, "--debug-format-g6");
+    FILE* df = fopen(argv[++i], "r");
+    if (!df) {
+      die(3, "Error: Failed to open %s.\n", argv[i]);
+    }
+    char line[64], num[40];
+    while (fgets(line, sizeof(line), df)) {
+      const unsigned long long bits = strtoull(line, nullptr, 16);
+      double d;
+      memcpy(&d, &bits, sizeof(d));
+      *format_g6(d, num) = '\0';
+      puts(num);
+    }
+    fclose(df);
+    exit(0);
+  } else if (f == "--debug-zstd") {
+    // test hook (no GPU needed): <in> <out.zst> through the 'zs' output writer, in odd-sized pieces
+    need(i, 2, "--debug-zstd");
+    std::ifstream in(argv[i + 1], std::ios::binary);
+    if (!in) {
+      die(3, "Error: Failed to open %s.\n", argv[i + 1]);
+    }
+    std::stringstream ss;
+    ss << in.rdbuf();
+    const std::string data = ss.str();
+    OutFile of;
+    of.open(argv[i + 2], true);
+    for (size_t pos = 0, piece = 1; pos < data.size(); pos += piece, piece = piece * 3 + 1) {
+      piece = std::min(piece, data.size() - pos);
+      of.write(data.data() + pos, piece);
+    }
+    of.close();
+    exit(0);
+  } else if (f == "--parallel") {
+    need(i, 2, "--parallel");
+    char* end = nullptr;
+    const long k = strtol(argv[i + 1], &end, 10);
+    if ((*end) || (k < 1) || (k > 32768)) {
+      die(8, "Error: Invalid --parallel job index '%s'.\n", argv[i + 1]);
+    }
+    const long n = strtol(argv[i + 2], &end, 10);
+    if ((*end) || (n < 2) || (n > 32768) || (n < k)) {
+      die(8, "Error: Invalid --parallel total job count '%s'.\n", argv[i + 2]);
+    }
+    A.parallel_idx = static_cast<uint32_t>(k - 1);
+    A.parallel_tot = static_cast<uint32_t>(n);
+    i += 2;
+  } else if (f == "--gpus") {
+    need(i, 1, "--gpus");
+    A.gpus = atoi(argv[++i]);
+  } else if (f == "--threads" || f == "--memory" || f == "--seed") {
+    need(i, 1, f.c_str());
+    ++i;  // accepted for command-line compatibility; the work runs on the GPU(s)
+  } else {
+    return false;
+  }
+  return true;
+}
+
+#undef LDP_ARG_FAMILY_PROLOGUE
+
+// what the reference checks between flags once all of them are read
+void check_flag_combinations(Args& A) {
   if (A.have_clump) {
     if (A.have_prune || A.have_r2) {
       die(8, "Error: run --clump on its own.\n");
@@ -1271,6 +1336,19 @@ Args parse_args(int argc, char** argv) {
   if (A.gpus < 1) {
     die(8, "Error: --gpus must be positive.\n");
   }
+}
+
+Args parse_args(int argc, char** argv) {
+  Args A;
+  ArgCursor c{argc, argv, 1};
+  for (; c.i < argc; ++c.i) {
+    const std::string f = argv[c.i];
+    if (!(parse_input_flags(A, c, f) || parse_command_flags(A, c, f) || parse_clump_flags(A, c, f) || parse_filter_flags(A, c, f) || parse_ldwindow_flags(A, c, f) ||
+          parse_misc_flags(A, c, f))) {
+      die(8, "Error: Unrecognized flag ('%s').  plink2-hip implements the --indep-pairwise path only.\n", f.c_str());
+    }
+  }
+  check_flag_combinations(A);
   return A;
 }
 
@@ -4959,10 +5037,13 @@ void Session::need_dosage_sums(const std::vector<uint32_t>& raw_variants) {
   }
 }
 
-int run_prune(Session& S) {
+// --indep-pairwise / --indep-pairphase: one run, phase by phase in the order run() calls them (LdPrune, plink2_ld.cc:2530-2720;
+// IndepPairwise / IndepPairphase :1284-1450, :2020-2330; LdPruneWrite :2464-2528).  The members are what the phases share.
+struct PruneJob {
+  Session& S;
   const Args& A = S.A;
   const Variants& V = S.V;
-  const double t_begin = S.t_begin;
+  const double t_begin;
   const std::vector<uint8_t>& is_founder = S.is_founder;
   const std::vector<uint8_t>& sex = S.sex;
   const uint32_t raw_sample_ct = S.raw_sample_ct, founder_ct = S.founder_ct, raw_variant_ct = S.raw_variant_ct;
@@ -4975,21 +5056,70 @@ int run_prune(Session& S) {
   const std::vector<uint8_t>& vcls = S.vcls;
   const uint32_t variant_ct = S.variant_ct, m_ct = S.m_ct;
   const std::vector<uint32_t>&mk = S.mk, &xk = S.xk, &yk = S.yk, &tk = S.tk, &m_chr = S.m_chr, &m_bps = S.m_bps;
-  auto join_hip = [&S]() { S.join_hip(); };
   const double &t_hip_init = S.t_hip_init, &t_parse = S.t_parse, &t_joined = S.t_joined;
 
   ldp_params P;
-  memset(&P, 0, sizeof(P));
-  P.founder_ct = A.pairphase ? 2 * founder_ct : founder_ct;  // --indep-pairphase: haplotypes (plink2_ld.cc:1506)
-  P.prune_window_size = A.window;
-  P.prune_window_incr = A.step;
-  P.window_is_bp = A.window_is_bp;
-  P.plink1_order = (A.order == 1);
-  P.prune_last_param = A.r2;
-  if (A.dry_run) {
+  bool duplicate_ids = false;
+  double t_tables_done = 0, t_planned = 0, t_load0 = 0, t_load1 = 0, t_run1 = 0;
+  int world = 1, n_devices = 1;
+  bool alias_devices = false;
+  std::vector<ldp_engine*> eng;
+  uint32_t subcontig_ct = 0;
+  std::vector<uint64_t> removed;    // bit k: variant k (include order) is pruned
+  std::vector<uint64_t> preferred;  // --indep-preferred, same indexing; empty: none
+  std::vector<uint8_t> founder_mask;
+  std::vector<uint32_t> founder_idx;
+  // geometry of the rows on their way to the engines (set_row_geometry)
+  bool all_founders = false;
+  uint64_t in_rec = 0, in_phase_off = 0, out_rec = 0, direct_off = 0;
+  int load_encoding = 0, direct_fd = -1;
+  const uint8_t* direct = nullptr;
+  // what the bulk load leaves for the host-built rows
+  bool device_multi = false;
+  uint32_t pending_unphased = UINT32_MAX;
+
+  explicit PruneJob(Session& s) : S(s), t_begin(s.t_begin) {}
+
+  [[noreturn]] void die_unphased(uint32_t raw_v) const {
+    die(7, "\nError: --indep-pairphase: 0-based variant #%u is not fully phased.\n", raw_v);  // plink2_ld.cc:2047
+  }
+  // --indep-preferred bits of a subset of the variants (ks: include-order indices, in the subset's engine order)
+  std::vector<uint64_t> sub_preferred(const std::vector<uint32_t>& ks) const {
+      std::vector<uint64_t> out;
+      if (!preferred.empty()) {
+        out.assign((ks.size() + 63) / 64 + 1, 0);
+        for (size_t q = 0; q < ks.size(); ++q) {
+          if ((preferred[ks[q] >> 6] >> (ks[q] & 63)) & 1) {
+            out[q >> 6] |= 1ull << (q & 63);
+          }
+        }
+      }
+      return out;
+  }
+  // an engine's removed bits (its own variant order) into the run's bitmap
+  void scatter(const std::vector<uint64_t>& bm, const std::vector<uint32_t>& ks) {
+      for (size_t q = 0; q < ks.size(); ++q) {
+        if ((bm[q >> 6] >> (q & 63)) & 1) {
+          removed[ks[q] >> 6] |= 1ull << (ks[q] & 63);
+        }
+      }
+  }
+
+  void set_params() {
+    memset(&P, 0, sizeof(P));
+    P.founder_ct = A.pairphase ? 2 * founder_ct : founder_ct;  // --indep-pairphase: haplotypes (plink2_ld.cc:1506)
+    P.prune_window_size = A.window;
+    P.prune_window_incr = A.step;
+    P.window_is_bp = A.window_is_bp;
+    P.plink1_order = (A.order == 1);
+    P.prune_last_param = A.r2;
+  }
+
+  // --dry-run: the plan only (no device)
+  int dry_run() {
     ldp_engine* e = nullptr;
     P.device = -1;
-    join_hip();
+    S.join_hip();
     const double t_plan0 = now_s();
     if (ldp_create(&P, &e) || ldp_set_variants(e, m_ct, m_chr.data(), A.window_is_bp ? m_bps.data() : nullptr)) {
       die(16, "Error: planning failed.\n");
@@ -5010,78 +5140,74 @@ int run_prune(Session& S) {
     ldp_destroy(e);
     return 0;
   }
+
   // unique IDs (plink2_ld.cc:2573-2592): checked here, beside the HIP start-up, reported where the reference does
-  bool duplicate_ids = false;
-  {
-    // open-addressing table of variant indices keyed by a 64-bit FNV-1a hash of the ID
-    uint32_t bits = 4;
-    while ((1ull << bits) < 2ull * variant_ct) {
-      ++bits;
-    }
-    const uint64_t mask = (1ull << bits) - 1;
-    std::vector<uint32_t> table(static_cast<size_t>(1) << bits, 0xffffffffu);
-    for (uint32_t k = 0; (k < variant_ct) && !duplicate_ids; ++k) {
-      const std::string& id = V.id[inc[k]];
-      uint64_t h = 0xcbf29ce484222325ull;
-      for (unsigned char ch : id) {
-        h = (h ^ ch) * 0x100000001b3ull;
+  void check_unique_ids() {
+    {
+      // open-addressing table of variant indices keyed by a 64-bit FNV-1a hash of the ID
+      uint32_t bits = 4;
+      while ((1ull << bits) < 2ull * variant_ct) {
+        ++bits;
       }
-      uint64_t slot = (h ^ (h >> 29)) & mask;
-      while (table[slot] != 0xffffffffu) {
-        if (V.id[inc[table[slot]]] == id) {
-          duplicate_ids = true;
-          break;
+      const uint64_t mask = (1ull << bits) - 1;
+      std::vector<uint32_t> table(static_cast<size_t>(1) << bits, 0xffffffffu);
+      for (uint32_t k = 0; (k < variant_ct) && !duplicate_ids; ++k) {
+        const std::string& id = V.id[inc[k]];
+        uint64_t h = 0xcbf29ce484222325ull;
+        for (unsigned char ch : id) {
+          h = (h ^ ch) * 0x100000001b3ull;
         }
-        slot = (slot + 1) & mask;
+        uint64_t slot = (h ^ (h >> 29)) & mask;
+        while (table[slot] != 0xffffffffu) {
+          if (V.id[inc[table[slot]]] == id) {
+            duplicate_ids = true;
+            break;
+          }
+          slot = (slot + 1) & mask;
+        }
+        table[slot] = k;
       }
-      table[slot] = k;
     }
   }
-  const double t_tables_done = now_s();
+
   // One GPU: the engine is created and planned (host work: ldp_create binds the device lazily) while the HIP runtime
   // is still starting; several GPUs: the device count decides how many engines there are, so wait for it first.
-  int world = 1, n_devices = 1;
-  bool alias_devices = false;
-  if (A.gpus > 1) {
-    join_hip();
-    const int ndev = ldp_device_count();
-    if (ndev < 1) {
-      die(16, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
+  void plan_engines() {
+    if (A.gpus > 1) {
+      S.join_hip();
+      const int ndev = ldp_device_count();
+      if (ndev < 1) {
+        die(16, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
+      }
+      // LDP_DEBUG_ALIAS_DEVICES=1 (tests, one-GPU boxes): as many engines as --gpus asks for, dealt round-robin onto the devices
+      // there are -- every host-side step of the N-device run (shard plan, per-engine loads, one thread per engine, segment pack /
+      // exchange / stitch) then runs on a single device; RCCL refuses a device twice, so the exchange is the host transport.
+      alias_devices = (getenv("LDP_DEBUG_ALIAS_DEVICES") != nullptr) && (atoi(getenv("LDP_DEBUG_ALIAS_DEVICES")) != 0);
+      n_devices = ndev;
+      world = alias_devices ? A.gpus : std::min(A.gpus, ndev);
     }
-    // LDP_DEBUG_ALIAS_DEVICES=1 (tests, one-GPU boxes): as many engines as --gpus asks for, dealt round-robin onto the devices
-    // there are -- every host-side step of the N-device run (shard plan, per-engine loads, one thread per engine, segment pack /
-    // exchange / stitch) then runs on a single device; RCCL refuses a device twice, so the exchange is the host transport.
-    alias_devices = (getenv("LDP_DEBUG_ALIAS_DEVICES") != nullptr) && (atoi(getenv("LDP_DEBUG_ALIAS_DEVICES")) != 0);
-    n_devices = ndev;
-    world = alias_devices ? A.gpus : std::min(A.gpus, ndev);
-  }
-  std::vector<ldp_engine*> eng(world, nullptr);
-  uint32_t subcontig_ct = 0;
-  for (int r = 0; r < world; ++r) {
-    P.device = r % n_devices;
-    int rc = ldp_create(&P, &eng[r]);
-    if (rc) {
-      die(16, "Error: ldp_create failed (%d).\n", rc);
-    }
-    rc = ldp_set_variants(eng[r], m_ct, m_chr.data(), A.window_is_bp ? m_bps.data() : nullptr);
-    if (rc) {
-      die(16, "Error: %s\n", ldp_last_error(eng[r]));
-    }
-    ldp_get_subcontigs(eng[r], &subcontig_ct, nullptr, 0);
-    if (world > 1) {
-      rc = ldp_set_shard(eng[r], r, world, nullptr);
+    eng.assign(world, nullptr);
+    for (int r = 0; r < world; ++r) {
+      P.device = r % n_devices;
+      int rc = ldp_create(&P, &eng[r]);
+      if (rc) {
+        die(16, "Error: ldp_create failed (%d).\n", rc);
+      }
+      rc = ldp_set_variants(eng[r], m_ct, m_chr.data(), A.window_is_bp ? m_bps.data() : nullptr);
       if (rc) {
         die(16, "Error: %s\n", ldp_last_error(eng[r]));
       }
+      ldp_get_subcontigs(eng[r], &subcontig_ct, nullptr, 0);
+      if (world > 1) {
+        rc = ldp_set_shard(eng[r], r, world, nullptr);
+        if (rc) {
+          die(16, "Error: %s\n", ldp_last_error(eng[r]));
+        }
+      }
     }
   }
-  const double t_planned = now_s();
-  join_hip();
-  if (ldp_device_count() < 1) {
-    die(16, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
-  }
-  std::vector<uint64_t> removed((static_cast<size_t>(variant_ct) + 63) / 64 + 1, 0);
-  if (subcontig_ct || !xk.empty() || !yk.empty() || !tk.empty()) {
+
+  void check_before_loading() {
     if (duplicate_ids) {  // plink2_ld.cc:2590-2592
       die(7, "Error: --indep-pair%s requires unique variant IDs. (--set-all-var-ids and/or --rm-dup may help.)\n", A.pairphase ? "phase" : "wise");
     }
@@ -5095,7 +5221,10 @@ int run_prune(Session& S) {
         }
       }
     }
-    std::vector<uint64_t> preferred;
+  }
+
+  // --indep-preferred (plink2_ld.cc:2594-2640)
+  void read_preferred() {
     if (!A.preferred.empty()) {
       std::unordered_set<std::string> want;
       std::ifstream pin(A.preferred);
@@ -5116,447 +5245,432 @@ int run_prune(Session& S) {
       }
       logprintf("--indep-preferred: %u variant%s loaded.\n", ct, ct == 1 ? "" : "s");
     }
-    logprintf("--indep-pair%s (%d GPU%s): ", A.pairphase ? "phase" : "wise", world, world == 1 ? "" : "s");
-    fflush(stdout);
-    const double t_load0 = now_s();
-    if (A.timing) {
-      logprintf("\n[timing] table parse %.3f s, variant-table passes + ID check done at %.3f s, engine planned at %.3f s, HIP init %.3f s (concurrent; joined at %.3f s)\n",
-                t_parse, t_tables_done - t_begin, t_planned - t_begin, t_hip_init, t_joined - t_begin);
-    }
+  }
 
-    // ---- genotype rows of the diploid (+MT) variants -> engines, straight from the mapping (or the decoder's buffers);
-    // the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185) are picked on the device.
-    const bool all_founders = (founder_ct == raw_sample_ct);
+  // ---- genotype rows of the diploid (+MT) variants -> engines, straight from the mapping (or the decoder's buffers);
+  // the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185) are picked on the device.
+  void set_row_geometry() {
+    all_founders = (founder_ct == raw_sample_ct);
     // --indep-pairphase rows: 2-bit codes, padding to a dword, phaseinfo bits (LDP_GENO_PHASED, ldprune_hip.h)
-    const uint64_t in_rec = A.pairphase ? ldp_phased_row_bytes(2 * raw_sample_ct) : rec_bytes;
-    const uint64_t in_phase_off = ldp_phased_phase_offset(2 * raw_sample_ct);
-    const uint64_t out_rec = A.pairphase ? ldp_phased_row_bytes(2 * founder_ct) : ((static_cast<uint64_t>(founder_ct) + 3) / 4);
-    const int load_encoding = A.pairphase ? (LDP_GENO_REF | LDP_GENO_PHASED) : encoding;
-    const uint8_t* direct = A.pairphase ? nullptr : direct_rows;  // phased rows always come through the decoder
-    uint64_t direct_off = 0;
+    in_rec = A.pairphase ? ldp_phased_row_bytes(2 * raw_sample_ct) : rec_bytes;
+    in_phase_off = ldp_phased_phase_offset(2 * raw_sample_ct);
+    out_rec = A.pairphase ? ldp_phased_row_bytes(2 * founder_ct) : ((static_cast<uint64_t>(founder_ct) + 3) / 4);
+    load_encoding = A.pairphase ? (LDP_GENO_REF | LDP_GENO_PHASED) : encoding;
+    direct = A.pairphase ? nullptr : direct_rows;  // phased rows always come through the decoder
+    direct_off = 0;
     // (LDP_DEBUG_LOAD_FD=1: pread() into the pinned ring instead of a memcpy out of the mapping -- measured SLOWER on the GPU box's
     // host, 32-40 against 53 GB/s per 1 GB call with the page cache warm, so the mapping stays the default)
-    const int direct_fd = (direct && getenv("LDP_DEBUG_LOAD_FD")) ? ldp_pgen_direct_fd(pg, &direct_off, nullptr) : -1;
-    std::vector<uint8_t> founder_mask((static_cast<size_t>(raw_sample_ct) + 7) / 8, 0);
+    direct_fd = (direct && getenv("LDP_DEBUG_LOAD_FD")) ? ldp_pgen_direct_fd(pg, &direct_off, nullptr) : -1;
+    founder_mask.assign((static_cast<size_t>(raw_sample_ct) + 7) / 8, 0);
     for (uint32_t sidx = 0; sidx < raw_sample_ct; ++sidx) {
       if (is_founder[sidx]) {
         founder_mask[sidx >> 3] |= static_cast<uint8_t>(1u << (sidx & 7));
       }
     }
-    auto die_unphased = [&](uint32_t raw_v) {
-      die(7, "\nError: --indep-pairphase: 0-based variant #%u is not fully phased.\n", raw_v);  // plink2_ld.cc:2047
-    };
-    std::vector<uint32_t> founder_idx;
+    founder_idx.clear();
     for (uint32_t s = 0; s < raw_sample_ct; ++s) {
       if (is_founder[s]) {
         founder_idx.push_back(s);
       }
     }
-    auto sub_preferred = [&](const std::vector<uint32_t>& ks) {
-      std::vector<uint64_t> out;
-      if (!preferred.empty()) {
-        out.assign((ks.size() + 63) / 64 + 1, 0);
-        for (size_t q = 0; q < ks.size(); ++q) {
-          if ((preferred[ks[q] >> 6] >> (ks[q] & 63)) & 1) {
-            out[q >> 6] |= 1ull << (q & 63);
+  }
+
+  // the diploid (+MT) variants' rows, file -> engines (the loop of IndepPairwise, plink2_ld.cc:1345-1390)
+  void load_diploid_rows() {
+    // Chunks of ~256 MiB of decoded rows.  Variable-width .pgen: the next chunk is decoded (all host threads, see
+    // ldp_pgen_read) while the engine takes the current one, two buffers alternating; small enough that the
+    // buffers' first-touch page faults are paid once, large enough for ~60 decode tasks per chunk.
+    const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((direct ? (1024ull << 20) : (256ull << 20)) / std::max<uint64_t>(in_rec, 1)));
+    // two buffers of one chunk each, malloc'ed (a vector would zero-fill them on this thread: 2 x 256 MiB of page faults and
+    // memset before the first record is decoded; this way the decoder's threads touch the pages first, in parallel) and
+    // never freed: returning ~0.5 GiB of touched pages to the kernel costs tens of ms and the process exits soon
+    uint8_t* decoded[2] = {nullptr, nullptr};
+    std::vector<uint8_t> gather;
+    // the runs (maximal stretches of included variants that are contiguous in the file, capped at kChunk)
+    struct Run {
+      uint32_t q, raw0, n;
+    };
+    std::vector<Run> runs;
+    for (uint32_t q = 0; q < m_ct;) {
+      const uint32_t raw0 = inc[mk[q]];
+      uint32_t run = 1;
+      while (q + run < m_ct && inc[mk[q + run]] == raw0 + run && run < kChunk) {
+        ++run;
+      }
+      runs.push_back({q, raw0, run});
+      q += run;
+    }
+    // Non-founders in the file: the engines pick the founder columns themselves while converting (ldp_set_sample_map), so the
+    // rows go up as the file has them.  (--indep-pairphase rows carry phase bits the gather does not move: host subset.)
+    const bool device_subset = (!all_founders) && !A.pairphase;
+    if (device_subset) {
+      for (int r = 0; r < world; ++r) {
+        if (ldp_set_sample_map(eng[r], raw_sample_ct, founder_idx.data(), nullptr)) {
+          die(16, "\nError: %s\n", ldp_last_error(eng[r]));
+        }
+      }
+    }
+    // Variable-width records are decoded ON THE DEVICE from the file's own bytes (ldp_load_pgen_records: main track of every
+    // record type, LD-compressed chains, and -- when the engine's samples are the file's -- the collapse of variants with more
+    // than one ALT allele); --indep-pairphase rows (phase track) and LDP_DEBUG_HOST_DECODE=1 take the host decoder below.
+    // --indep-pairphase: main AND phase track on the device (ldp_load_pgen_records_phased) when every sample is a founder and no
+    // variant has more than one ALT allele (whose phase refers to allele pairs: host rows, below); otherwise the host decoder.
+    const bool device_phase = A.pairphase && all_founders && (!has_multiallelic) && (storage_mode != 0x01) && (storage_mode != 0x02) &&
+                              (getenv("LDP_DEBUG_HOST_DECODE") == nullptr);
+    const bool device_decode = (!direct) && ((!A.pairphase) || device_phase) && (storage_mode != 0x01) && (storage_mode != 0x02) && (getenv("LDP_DEBUG_HOST_DECODE") == nullptr);
+    device_multi = device_decode && all_founders && !A.pairphase;
+    uint64_t file_size = 0;
+    const void* file_bytes = device_decode ? ldp_pgen_file_bytes(pg, &file_size) : nullptr;
+    std::vector<ldp_pgen_rec> rec_index;
+    std::thread decoder;
+    // The decoder runs beside the engine's copy threads (ldp_load_genotypes: 16 of them feeding the pinned ring); a record
+    // takes microseconds, so a few dozen threads keep ahead of PCIe and more only get in the copies' way.
+    const uint32_t decode_threads = getenv("LDP_DEBUG_DECODE_THREADS") ? static_cast<uint32_t>(atoi(getenv("LDP_DEBUG_DECODE_THREADS"))) : 32;
+    double t_wait_decode = 0.0, t_load_calls = 0.0;
+    int decode_rc = 0;
+    uint32_t unphased_at = 0;
+    pending_unphased = UINT32_MAX;
+    auto start_decode = [&](size_t k) {
+      if (direct || device_decode || k >= runs.size()) {
+        return;
+      }
+      if (!decoded[k & 1]) {
+        uint32_t longest = 0;
+        for (const Run& rn : runs) {
+          longest = std::max(longest, rn.n);
+        }
+        decoded[k & 1] = static_cast<uint8_t*>(malloc(static_cast<size_t>(longest) * in_rec + 64));
+        if (!decoded[k & 1]) {
+          die(2, "\nError: Out of memory.\n");
+        }
+      }
+      decoder = std::thread([&, k]() {
+        decode_rc = A.pairphase ? ldp_pgen_read_phased(pg, runs[k].raw0, runs[k].n, decoded[k & 1], in_rec, founder_mask.data(), decode_threads, &unphased_at)
+                                : ldp_pgen_read(pg, runs[k].raw0, runs[k].n, decoded[k & 1], rec_bytes, decode_threads);
+      });
+    };
+    start_decode(0);
+    for (size_t k = 0; k < runs.size(); ++k) {
+      const uint32_t q = runs[k].q;
+      const uint32_t raw0 = runs[k].raw0;
+      const uint32_t run = runs[k].n;
+      const uint8_t* src;
+      uint64_t stride = in_rec;
+      if (device_decode) {
+        rec_index.resize(run);
+        uint32_t base_v = UINT32_MAX;
+        ldp_pgen_rec base_rec;
+        if (ldp_pgen_record_index(pg, raw0, run, rec_index.data(), &base_v) || ((base_v != UINT32_MAX) && ldp_pgen_record_index(pg, base_v, 1, &base_rec, nullptr))) {
+          die(6, "\nError: %s: malformed variant record index.\n", gpath.c_str());
+        }
+        if (device_multi) {
+          for (uint32_t t = 0; t < run; ++t) {
+            const uint32_t alts = V.alt_ct[raw0 + t];
+            if ((alts > 1) && (vcls[mk[q + t]] != 5)) {
+              if (alts > 254) {
+                die(63, "\nError: variant '%s' has more than 254 ALT alleles: not supported by plink2-hip.\n", V.id[raw0 + t].c_str());
+              }
+              rec_index[t].allele_ct = static_cast<uint8_t>(alts + 1);
+            }
+          }
+        }
+        const double tl0 = now_s();
+        for (int r = 0; r < world; ++r) {
+          uint32_t bad_q = UINT32_MAX;
+          const int rc = device_phase ? ldp_load_pgen_records_phased(eng[r], q, run, file_bytes, file_size, LDP_MEM_HOST, rec_index.data(),
+                                                                     (base_v != UINT32_MAX) ? &base_rec : nullptr, raw_sample_ct, &bad_q)
+                                      : ldp_load_pgen_records(eng[r], q, run, file_bytes, file_size, LDP_MEM_HOST, rec_index.data(),
+                                                              (base_v != UINT32_MAX) ? &base_rec : nullptr, raw_sample_ct, nullptr);
+          if ((rc == LDP_ERR_UNPHASED) && (bad_q != UINT32_MAX)) {
+            die_unphased(inc[mk[bad_q]]);  // (chunks and launches run in variant order: the first one to fail holds the lowest variant)
+          }
+          if (rc) {
+            die((rc == LDP_ERR_INVALID) ? 6 : 16, "\nError: %s: %s\n", gpath.c_str(), ldp_last_error(eng[r]));
+          }
+        }
+        t_load_calls += now_s() - tl0;
+        continue;
+      }
+      if (direct) {
+        src = direct + static_cast<uint64_t>(raw0) * rec_bytes;
+      } else {
+        const double tw0 = now_s();
+        decoder.join();
+        t_wait_decode += now_s() - tw0;
+        if (decode_rc == LDP_ERR_UNPHASED) {
+          pending_unphased = unphased_at;  // reported below, unless a multiallelic variant before it is unphased too
+          break;
+        }
+        if (decode_rc) {
+          die(6, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+        }
+        src = decoded[k & 1];
+        start_decode(k + 1);
+      }
+      if ((!all_founders) && !device_subset) {
+        // gather the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185)
+        // (+ CopyBitarrSubset of phaseinfo under --indep-pairphase, plink2_ld.cc:2075), all host threads
+        gather.resize(static_cast<size_t>(run) * out_rec);
+        if (ldp_subset_samples(src, direct ? rec_bytes : in_rec, run, raw_sample_ct, founder_mask.data(), gather.data(), out_rec, A.pairphase ? 1 : 0, 0)) {
+          die(16, "\nError: founder subsetting failed.\n");
+        }
+        src = gather.data();
+        stride = out_rec;
+      }
+      const double tl0 = now_s();
+      for (int r = 0; r < world; ++r) {
+        // fixed-width rows as the file has them: out of the mapping, or (LDP_DEBUG_LOAD_FD=1) with pread() straight into the engine's
+        // pinned ring (ldp_load_genotypes_fd)
+        const bool from_fd = direct && (src == direct + static_cast<uint64_t>(raw0) * rec_bytes) && (direct_fd >= 0);
+        const int rc = from_fd ? ldp_load_genotypes_fd(eng[r], q, run, direct_fd, direct_off + static_cast<uint64_t>(raw0) * rec_bytes, stride,
+                                                       load_encoding | (device_subset ? LDP_GENO_MAPPED : 0))
+                               : ldp_load_genotypes(eng[r], q, run, src, stride, LDP_MEM_HOST, load_encoding | (device_subset ? LDP_GENO_MAPPED : 0));
+        if (rc) {
+          die(16, "Error: %s\n", ldp_last_error(eng[r]));
+        }
+      }
+      t_load_calls += now_s() - tl0;
+    }
+    if (A.timing && !direct) {
+      logprintf("\n[timing] variable-width records: %zu chunks, waited %.3f s for the decoder, %.3f s inside ldp_load_genotypes\n", runs.size(), t_wait_decode,
+                t_load_calls);
+    }
+  }
+
+  // rows that need host treatment overwrite their bulk-loaded versions: variants with more than one ALT
+  // allele (collapsed major-vs-rest) and MT variants (hets -> missing, plink2_ld.cc:1362-1364)
+  void patch_host_built_rows() {
+    uint32_t multi_ct = 0, mt_ct = 0, multi_device = 0;
+    // (--indep-pairphase: a multiallelic row is 2 haplotypes per founder as plain 2-bit codes on the 2N-haplotype engine)
+    const uint64_t host_rec = A.pairphase ? ((2ull * founder_ct + 3) / 4) : out_rec;
+    const uint64_t raw_phase_bytes = (static_cast<uint64_t>(raw_sample_ct) + 7) / 8;
+    std::vector<uint8_t> lo(raw_sample_ct), hi(raw_sample_ct), inv_row(host_rec), raw_row(rec_bytes + 8), phase_buf(2 * raw_phase_bytes);
+    uint32_t multi_unphased = UINT32_MAX;
+    SexPlan mt_plan;
+    mt_plan.part1 = founder_idx;
+    // A multiallelic variant whose REF allele is the major one needs nothing: the main track already counts REF
+    // copies (0/1/2 non-REF alleles = 0/1/2 non-major ones), and GetMajIdxMulti's first test (plink2_common.cc:1042,
+    // freq[REF] >= 0.5 with freq = count * (1 / total), plink2_filter.cc:2137-2147) is the biallelic rule the
+    // conversion kernel applied to the bulk-loaded row.  Its genotype counts say which variants those are.
+    std::vector<uint8_t> ref_is_major;
+    uint32_t multi_skipped = 0;
+    if ((!A.pairphase) && !device_multi) {
+      bool any_multi = false;
+      for (uint32_t qq = 0; (qq < m_ct) && !any_multi; ++qq) {
+        any_multi = (V.alt_ct[inc[mk[qq]]] > 1) && (vcls[mk[qq]] != 5);
+      }
+      if (any_multi) {
+        ref_is_major.assign(m_ct, 0);
+        std::vector<ldp_variant_rec> recs(m_ct);
+        for (int r = 0; r < world; ++r) {  // (a variant's counts are zero on the engines that do not own it)
+          if (ldp_get_variant_recs(eng[r], 0, m_ct, recs.data())) {
+            die(16, "\nError: %s\n", ldp_last_error(eng[r]));
+          }
+          for (uint32_t qq = 0; qq < m_ct; ++qq) {
+            const uint64_t ref_ct = 2ull * recs[qq].n_homref + recs[qq].n_het;
+            const uint64_t tot = 2ull * (static_cast<uint64_t>(recs[qq].n_homref) + recs[qq].n_het + recs[qq].n_homalt);
+            if (tot && (static_cast<double>(ref_ct) * (1.0 / static_cast<double>(tot)) >= 0.5)) {
+              ref_is_major[qq] = 1;
+            }
           }
         }
       }
-      return out;
-    };
-    auto scatter = [&](const std::vector<uint64_t>& bm, const std::vector<uint32_t>& ks) {
-      for (size_t q = 0; q < ks.size(); ++q) {
-        if ((bm[q >> 6] >> (q & 63)) & 1) {
-          removed[ks[q] >> 6] |= 1ull << (ks[q] & 63);
+    }
+    for (uint32_t qq = 0; qq < m_ct; ++qq) {
+      const uint32_t raw_v = inc[mk[qq]];
+      const uint32_t alts = V.alt_ct[raw_v];
+      const bool is_mt = (vcls[mk[qq]] == 5);
+      if (alts < 2 && !is_mt) {
+        continue;
+      }
+      if (device_multi && !is_mt) {
+        ++multi_device;  // (collapsed by ldp_load_pgen_records)
+        continue;
+      }
+      if ((!is_mt) && (!ref_is_major.empty()) && ref_is_major[qq]) {
+        ++multi_skipped;
+        continue;
+      }
+      double mf = 0.0;
+      if (is_mt) {
+        fetch_raw_row(pg, storage_mode, raw_v, raw_sample_ct, rec_bytes, raw_row.data());
+        build_sex_row(mt_plan, raw_row.data(), inv_row.data(), out_rec, &mf);
+        ++mt_ct;
+      } else {
+        if (storage_mode == 0x01) {
+          die(6, "\nError: multiallelic variant in a .bim/.bed fileset.\n");
+        }
+        if (A.pairphase) {
+          bool unphased = false;
+          multiallelic_inverse_row(pg, raw_v, alts, founder_idx, &lo, &hi, inv_row.data(), host_rec, &mf, phase_buf.data(), raw_phase_bytes, &unphased);
+          if (unphased) {
+            multi_unphased = std::min(multi_unphased, raw_v);
+          }
+        } else {
+          multiallelic_inverse_row(pg, raw_v, alts, founder_idx, &lo, &hi, inv_row.data(), out_rec, &mf);
+        }
+        ++multi_ct;
+      }
+      for (int r = 0; r < world; ++r) {
+        if (ldp_load_genotypes(eng[r], qq, 1, inv_row.data(), host_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) ||
+            ldp_set_maj_freqs(eng[r], qq, 1, &mf)) {
+          die(16, "\nError: %s\n", ldp_last_error(eng[r]));
         }
       }
-    };
-    double t_load1 = now_s();
-    double t_run1 = 0;
-    if (subcontig_ct) {
-      // Chunks of ~256 MiB of decoded rows.  Variable-width .pgen: the next chunk is decoded (all host threads, see
-      // ldp_pgen_read) while the engine takes the current one, two buffers alternating; small enough that the
-      // buffers' first-touch page faults are paid once, large enough for ~60 decode tasks per chunk.
-      const uint32_t kChunk = std::max<uint32_t>(1, static_cast<uint32_t>((direct ? (1024ull << 20) : (256ull << 20)) / std::max<uint64_t>(in_rec, 1)));
-      // two buffers of one chunk each, malloc'ed (a vector would zero-fill them on this thread: 2 x 256 MiB of page faults and
-      // memset before the first record is decoded; this way the decoder's threads touch the pages first, in parallel) and
-      // never freed: returning ~0.5 GiB of touched pages to the kernel costs tens of ms and the process exits soon
-      uint8_t* decoded[2] = {nullptr, nullptr};
-      std::vector<uint8_t> gather;
-      // the runs (maximal stretches of included variants that are contiguous in the file, capped at kChunk)
-      struct Run {
-        uint32_t q, raw0, n;
-      };
-      std::vector<Run> runs;
-      for (uint32_t q = 0; q < m_ct;) {
-        const uint32_t raw0 = inc[mk[q]];
-        uint32_t run = 1;
-        while (q + run < m_ct && inc[mk[q + run]] == raw0 + run && run < kChunk) {
-          ++run;
+    }
+    if (std::min(multi_unphased, pending_unphased) != UINT32_MAX) {
+      die_unphased(std::min(multi_unphased, pending_unphased));
+    }
+    if ((multi_ct || mt_ct || multi_skipped || multi_device) && A.timing) {
+      logprintf("\n[timing] host-built rows: %u multiallelic (%u more have REF as the major allele: main track as loaded; %u collapsed on the device), %u MT\n",
+                multi_ct, multi_skipped, multi_device, mt_ct);
+    }
+  }
+
+  // Variants whose records carry dosages: the major allele's frequency comes from the founders' dosage sums (a sample's
+  // dosage where it has one, its hardcall otherwise: ldp_pgen_dosage_sums), in ComputeAlleleFreqs' arithmetic
+  // (plink2_filter.cc:2137-2147: ref * (1 / (ref + alt)); the factor 2 of the diploid case cancels exactly) with
+  // GetMajIdx's rule (REF unless its frequency is below 0.5).  The rows themselves stay the hardcalls.
+  void set_dosage_frequencies() {
+    if (S.has_dosage) {
+      std::vector<uint32_t> todo;
+      for (uint32_t qq = 0; qq < m_ct; ++qq) {
+        const uint32_t raw_v = inc[mk[qq]];
+        if (!ldp_pgen_variant_has_dosage(pg, raw_v)) {
+          continue;
         }
-        runs.push_back({q, raw0, run});
-        q += run;
+        if ((V.alt_ct[raw_v] > 1) || (vcls[mk[qq]] == 5)) {
+          die(63, "\nError: variant '%s' has dosages and %s, which plink2-hip does not read yet.\n", V.id[raw_v].c_str(),
+              (vcls[mk[qq]] == 5) ? "lies on chrM" : "several ALT alleles");
+        }
+        todo.push_back(qq);
       }
-      // Non-founders in the file: the engines pick the founder columns themselves while converting (ldp_set_sample_map), so the
-      // rows go up as the file has them.  (--indep-pairphase rows carry phase bits the gather does not move: host subset.)
-      const bool device_subset = (!all_founders) && !A.pairphase;
-      if (device_subset) {
+      std::vector<double> mfs(todo.size(), 0.0);
+      {
+        std::vector<uint32_t> raw_todo(todo.size());
+        for (size_t q = 0; q < todo.size(); ++q) {
+          raw_todo[q] = inc[mk[todo[q]]];
+        }
+        S.need_dosage_sums(raw_todo);
+        for (size_t q = 0; q < todo.size(); ++q) {
+          const std::pair<uint64_t, uint64_t>& dd = S.dosage_sums[raw_todo[q]];
+          const uint64_t tot = dd.first + dd.second;
+          const double ref_freq = tot ? (static_cast<double>(static_cast<int64_t>(dd.first)) * (1.0 / static_cast<double>(static_cast<int64_t>(tot)))) : 0.5;
+          mfs[q] = (ref_freq < 0.5) ? (1.0 - ref_freq) : ref_freq;
+        }
+      }
+      for (size_t q = 0; q < todo.size(); ++q) {
         for (int r = 0; r < world; ++r) {
-          if (ldp_set_sample_map(eng[r], raw_sample_ct, founder_idx.data(), nullptr)) {
+          if (ldp_set_maj_freqs(eng[r], todo[q], 1, &mfs[q])) {
             die(16, "\nError: %s\n", ldp_last_error(eng[r]));
           }
         }
       }
-      // Variable-width records are decoded ON THE DEVICE from the file's own bytes (ldp_load_pgen_records: main track of every
-      // record type, LD-compressed chains, and -- when the engine's samples are the file's -- the collapse of variants with more
-      // than one ALT allele); --indep-pairphase rows (phase track) and LDP_DEBUG_HOST_DECODE=1 take the host decoder below.
-      // --indep-pairphase: main AND phase track on the device (ldp_load_pgen_records_phased) when every sample is a founder and no
-      // variant has more than one ALT allele (whose phase refers to allele pairs: host rows, below); otherwise the host decoder.
-      const bool device_phase = A.pairphase && all_founders && (!has_multiallelic) && (storage_mode != 0x01) && (storage_mode != 0x02) &&
-                                (getenv("LDP_DEBUG_HOST_DECODE") == nullptr);
-      const bool device_decode = (!direct) && ((!A.pairphase) || device_phase) && (storage_mode != 0x01) && (storage_mode != 0x02) && (getenv("LDP_DEBUG_HOST_DECODE") == nullptr);
-      const bool device_multi = device_decode && all_founders && !A.pairphase;
-      uint64_t file_size = 0;
-      const void* file_bytes = device_decode ? ldp_pgen_file_bytes(pg, &file_size) : nullptr;
-      std::vector<ldp_pgen_rec> rec_index;
-      std::thread decoder;
-      // The decoder runs beside the engine's copy threads (ldp_load_genotypes: 16 of them feeding the pinned ring); a record
-      // takes microseconds, so a few dozen threads keep ahead of PCIe and more only get in the copies' way.
-      const uint32_t decode_threads = getenv("LDP_DEBUG_DECODE_THREADS") ? static_cast<uint32_t>(atoi(getenv("LDP_DEBUG_DECODE_THREADS"))) : 32;
-      double t_wait_decode = 0.0, t_load_calls = 0.0;
-      int decode_rc = 0;
-      uint32_t unphased_at = 0;
-      uint32_t pending_unphased = UINT32_MAX;
-      auto start_decode = [&](size_t k) {
-        if (direct || device_decode || k >= runs.size()) {
-          return;
+      if (A.timing) {
+        logprintf("\n[timing] allele frequencies of %zu variants from their dosages\n", todo.size());
+      }
+    }
+  }
+
+  // every engine prunes its shard; several engines: their removed-bit segments meet (stitch, plink2_ld.cc:1418-1426)
+  void run_diploid_engines() {
+    t_load1 = now_s();
+    const std::vector<uint64_t> pref_m = sub_preferred(mk);
+    const size_t m_words = (static_cast<size_t>(m_ct) + 63) / 64 + 1;
+    std::vector<std::vector<uint64_t>> part(world, std::vector<uint64_t>(m_words, 0));
+    std::vector<int> rcs(world, 0);
+    // several devices: every engine prunes its shard on a host thread of its own; the shards' results then meet in ONE RCCL
+    // all-gather of their removed-bit segments (ldp_allgather_removed: the cross-device form of the stitch at
+    // plink2_ld.cc:1418-1426).  Without RCCL -- or with engines that share a device -- the same segments are packed, copied
+    // between the engines by the host and stitched by every rank (ldp_pack_removed_segment / ldp_stitch_removed_segments).
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; ++r) {
+      th.emplace_back([&, r]() {
+        if (!pref_m.empty()) {
+          ldp_set_preferred(eng[r], pref_m.data());
         }
-        if (!decoded[k & 1]) {
-          uint32_t longest = 0;
-          for (const Run& rn : runs) {
-            longest = std::max(longest, rn.n);
-          }
-          decoded[k & 1] = static_cast<uint8_t*>(malloc(static_cast<size_t>(longest) * in_rec + 64));
-          if (!decoded[k & 1]) {
-            die(2, "\nError: Out of memory.\n");
-          }
-        }
-        decoder = std::thread([&, k]() {
-          decode_rc = A.pairphase ? ldp_pgen_read_phased(pg, runs[k].raw0, runs[k].n, decoded[k & 1], in_rec, founder_mask.data(), decode_threads, &unphased_at)
-                                  : ldp_pgen_read(pg, runs[k].raw0, runs[k].n, decoded[k & 1], rec_bytes, decode_threads);
-        });
-      };
-      start_decode(0);
-      for (size_t k = 0; k < runs.size(); ++k) {
-        const uint32_t q = runs[k].q;
-        const uint32_t raw0 = runs[k].raw0;
-        const uint32_t run = runs[k].n;
-        const uint8_t* src;
-        uint64_t stride = in_rec;
-        if (device_decode) {
-          rec_index.resize(run);
-          uint32_t base_v = UINT32_MAX;
-          ldp_pgen_rec base_rec;
-          if (ldp_pgen_record_index(pg, raw0, run, rec_index.data(), &base_v) || ((base_v != UINT32_MAX) && ldp_pgen_record_index(pg, base_v, 1, &base_rec, nullptr))) {
-            die(6, "\nError: %s: malformed variant record index.\n", gpath.c_str());
-          }
-          if (device_multi) {
-            for (uint32_t t = 0; t < run; ++t) {
-              const uint32_t alts = V.alt_ct[raw0 + t];
-              if ((alts > 1) && (vcls[mk[q + t]] != 5)) {
-                if (alts > 254) {
-                  die(63, "\nError: variant '%s' has more than 254 ALT alleles: not supported by plink2-hip.\n", V.id[raw0 + t].c_str());
-                }
-                rec_index[t].allele_ct = static_cast<uint8_t>(alts + 1);
-              }
-            }
-          }
-          const double tl0 = now_s();
-          for (int r = 0; r < world; ++r) {
-            uint32_t bad_q = UINT32_MAX;
-            const int rc = device_phase ? ldp_load_pgen_records_phased(eng[r], q, run, file_bytes, file_size, LDP_MEM_HOST, rec_index.data(),
-                                                                       (base_v != UINT32_MAX) ? &base_rec : nullptr, raw_sample_ct, &bad_q)
-                                        : ldp_load_pgen_records(eng[r], q, run, file_bytes, file_size, LDP_MEM_HOST, rec_index.data(),
-                                                                (base_v != UINT32_MAX) ? &base_rec : nullptr, raw_sample_ct, nullptr);
-            if ((rc == LDP_ERR_UNPHASED) && (bad_q != UINT32_MAX)) {
-              die_unphased(inc[mk[bad_q]]);  // (chunks and launches run in variant order: the first one to fail holds the lowest variant)
-            }
-            if (rc) {
-              die((rc == LDP_ERR_INVALID) ? 6 : 16, "\nError: %s: %s\n", gpath.c_str(), ldp_last_error(eng[r]));
-            }
-          }
-          t_load_calls += now_s() - tl0;
-          continue;
-        }
-        if (direct) {
-          src = direct + static_cast<uint64_t>(raw0) * rec_bytes;
-        } else {
-          const double tw0 = now_s();
-          decoder.join();
-          t_wait_decode += now_s() - tw0;
-          if (decode_rc == LDP_ERR_UNPHASED) {
-            pending_unphased = unphased_at;  // reported below, unless a multiallelic variant before it is unphased too
-            break;
-          }
-          if (decode_rc) {
-            die(6, "\nError: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
-          }
-          src = decoded[k & 1];
-          start_decode(k + 1);
-        }
-        if ((!all_founders) && !device_subset) {
-          // gather the founder columns (CopyNyparrNonemptySubset, pgenlib_misc.cc:32,185)
-          // (+ CopyBitarrSubset of phaseinfo under --indep-pairphase, plink2_ld.cc:2075), all host threads
-          gather.resize(static_cast<size_t>(run) * out_rec);
-          if (ldp_subset_samples(src, direct ? rec_bytes : in_rec, run, raw_sample_ct, founder_mask.data(), gather.data(), out_rec, A.pairphase ? 1 : 0, 0)) {
-            die(16, "\nError: founder subsetting failed.\n");
-          }
-          src = gather.data();
-          stride = out_rec;
-        }
-        const double tl0 = now_s();
+        rcs[r] = ldp_run(eng[r], part[r].data());
+      });
+    }
+    for (std::thread& t : th) {
+      t.join();
+    }
+    th.clear();
+    // (a rank whose run failed must not leave the others waiting in a collective: nobody enters it then)
+    for (int r = 0; r < world; ++r) {
+      if (rcs[r]) {
+        die(16, "\nError: %s\n", ldp_last_error(eng[r]));
+      }
+    }
+    if (world == 1) {
+      scatter(part[0], mk);
+    } else {
+      std::vector<void*> comms(world, nullptr);
+      std::vector<std::vector<uint64_t>> full(world, std::vector<uint64_t>(m_words, 0));
+      bool use_rccl = false;
+      if (!alias_devices) {
+        std::vector<int> devs(world);
         for (int r = 0; r < world; ++r) {
-          // fixed-width rows as the file has them: out of the mapping, or (LDP_DEBUG_LOAD_FD=1) with pread() straight into the engine's
-          // pinned ring (ldp_load_genotypes_fd)
-          const bool from_fd = direct && (src == direct + static_cast<uint64_t>(raw0) * rec_bytes) && (direct_fd >= 0);
-          const int rc = from_fd ? ldp_load_genotypes_fd(eng[r], q, run, direct_fd, direct_off + static_cast<uint64_t>(raw0) * rec_bytes, stride,
-                                                         load_encoding | (device_subset ? LDP_GENO_MAPPED : 0))
-                                 : ldp_load_genotypes(eng[r], q, run, src, stride, LDP_MEM_HOST, load_encoding | (device_subset ? LDP_GENO_MAPPED : 0));
-          if (rc) {
-            die(16, "Error: %s\n", ldp_last_error(eng[r]));
-          }
+          devs[r] = r;
         }
-        t_load_calls += now_s() - tl0;
+        use_rccl = (ldp_comm_init_all(world, devs.data(), comms.data()) == 0);
       }
-      if (A.timing && !direct) {
-        logprintf("\n[timing] variable-width records: %zu chunks, waited %.3f s for the decoder, %.3f s inside ldp_load_genotypes\n", runs.size(), t_wait_decode,
-                  t_load_calls);
-      }
-      // rows that need host treatment overwrite their bulk-loaded versions: variants with more than one ALT
-      // allele (collapsed major-vs-rest) and MT variants (hets -> missing, plink2_ld.cc:1362-1364)
-      {
-        uint32_t multi_ct = 0, mt_ct = 0, multi_device = 0;
-        // (--indep-pairphase: a multiallelic row is 2 haplotypes per founder as plain 2-bit codes on the 2N-haplotype engine)
-        const uint64_t host_rec = A.pairphase ? ((2ull * founder_ct + 3) / 4) : out_rec;
-        const uint64_t raw_phase_bytes = (static_cast<uint64_t>(raw_sample_ct) + 7) / 8;
-        std::vector<uint8_t> lo(raw_sample_ct), hi(raw_sample_ct), inv_row(host_rec), raw_row(rec_bytes + 8), phase_buf(2 * raw_phase_bytes);
-        uint32_t multi_unphased = UINT32_MAX;
-        SexPlan mt_plan;
-        mt_plan.part1 = founder_idx;
-        // A multiallelic variant whose REF allele is the major one needs nothing: the main track already counts REF
-        // copies (0/1/2 non-REF alleles = 0/1/2 non-major ones), and GetMajIdxMulti's first test (plink2_common.cc:1042,
-        // freq[REF] >= 0.5 with freq = count * (1 / total), plink2_filter.cc:2137-2147) is the biallelic rule the
-        // conversion kernel applied to the bulk-loaded row.  Its genotype counts say which variants those are.
-        std::vector<uint8_t> ref_is_major;
-        uint32_t multi_skipped = 0;
-        if ((!A.pairphase) && !device_multi) {
-          bool any_multi = false;
-          for (uint32_t qq = 0; (qq < m_ct) && !any_multi; ++qq) {
-            any_multi = (V.alt_ct[inc[mk[qq]]] > 1) && (vcls[mk[qq]] != 5);
-          }
-          if (any_multi) {
-            ref_is_major.assign(m_ct, 0);
-            std::vector<ldp_variant_rec> recs(m_ct);
-            for (int r = 0; r < world; ++r) {  // (a variant's counts are zero on the engines that do not own it)
-              if (ldp_get_variant_recs(eng[r], 0, m_ct, recs.data())) {
-                die(16, "\nError: %s\n", ldp_last_error(eng[r]));
-              }
-              for (uint32_t qq = 0; qq < m_ct; ++qq) {
-                const uint64_t ref_ct = 2ull * recs[qq].n_homref + recs[qq].n_het;
-                const uint64_t tot = 2ull * (static_cast<uint64_t>(recs[qq].n_homref) + recs[qq].n_het + recs[qq].n_homalt);
-                if (tot && (static_cast<double>(ref_ct) * (1.0 / static_cast<double>(tot)) >= 0.5)) {
-                  ref_is_major[qq] = 1;
-                }
-              }
-            }
+      if (use_rccl) {
+        for (int r = 0; r < world; ++r) {
+          th.emplace_back([&, r]() { rcs[r] = ldp_allgather_removed(eng[r], comms[r], part[r].data(), full[r].data()); });
+        }
+        for (std::thread& t : th) {
+          t.join();
+        }
+        for (int r = 0; r < world; ++r) {
+          if (rcs[r]) {  // (the failing rank aborted its communicator; the process ends here, nothing is destroyed twice)
+            die(16, "\nError: %s\n", ldp_last_error(eng[r]));
           }
         }
-        for (uint32_t qq = 0; qq < m_ct; ++qq) {
-          const uint32_t raw_v = inc[mk[qq]];
-          const uint32_t alts = V.alt_ct[raw_v];
-          const bool is_mt = (vcls[mk[qq]] == 5);
-          if (alts < 2 && !is_mt) {
-            continue;
-          }
-          if (device_multi && !is_mt) {
-            ++multi_device;  // (collapsed by ldp_load_pgen_records)
-            continue;
-          }
-          if ((!is_mt) && (!ref_is_major.empty()) && ref_is_major[qq]) {
-            ++multi_skipped;
-            continue;
-          }
-          double mf = 0.0;
-          if (is_mt) {
-            fetch_raw_row(pg, storage_mode, raw_v, raw_sample_ct, rec_bytes, raw_row.data());
-            build_sex_row(mt_plan, raw_row.data(), inv_row.data(), out_rec, &mf);
-            ++mt_ct;
-          } else {
-            if (storage_mode == 0x01) {
-              die(6, "\nError: multiallelic variant in a .bim/.bed fileset.\n");
-            }
-            if (A.pairphase) {
-              bool unphased = false;
-              multiallelic_inverse_row(pg, raw_v, alts, founder_idx, &lo, &hi, inv_row.data(), host_rec, &mf, phase_buf.data(), raw_phase_bytes, &unphased);
-              if (unphased) {
-                multi_unphased = std::min(multi_unphased, raw_v);
-              }
-            } else {
-              multiallelic_inverse_row(pg, raw_v, alts, founder_idx, &lo, &hi, inv_row.data(), out_rec, &mf);
-            }
-            ++multi_ct;
-          }
-          for (int r = 0; r < world; ++r) {
-            if (ldp_load_genotypes(eng[r], qq, 1, inv_row.data(), host_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) ||
-                ldp_set_maj_freqs(eng[r], qq, 1, &mf)) {
-              die(16, "\nError: %s\n", ldp_last_error(eng[r]));
-            }
-          }
+        for (int r = 0; r < world; ++r) {
+          ldp_comm_destroy(comms[r]);
         }
-        if (std::min(multi_unphased, pending_unphased) != UINT32_MAX) {
-          die_unphased(std::min(multi_unphased, pending_unphased));
-        }
-        if ((multi_ct || mt_ct || multi_skipped || multi_device) && A.timing) {
-          logprintf("\n[timing] host-built rows: %u multiallelic (%u more have REF as the major allele: main track as loaded; %u collapsed on the device), %u MT\n",
-                    multi_ct, multi_skipped, multi_device, mt_ct);
-        }
-      }
-      // Variants whose records carry dosages: the major allele's frequency comes from the founders' dosage sums (a sample's
-      // dosage where it has one, its hardcall otherwise: ldp_pgen_dosage_sums), in ComputeAlleleFreqs' arithmetic
-      // (plink2_filter.cc:2137-2147: ref * (1 / (ref + alt)); the factor 2 of the diploid case cancels exactly) with
-      // GetMajIdx's rule (REF unless its frequency is below 0.5).  The rows themselves stay the hardcalls.
-      if (S.has_dosage) {
-        std::vector<uint32_t> todo;
-        for (uint32_t qq = 0; qq < m_ct; ++qq) {
-          const uint32_t raw_v = inc[mk[qq]];
-          if (!ldp_pgen_variant_has_dosage(pg, raw_v)) {
-            continue;
-          }
-          if ((V.alt_ct[raw_v] > 1) || (vcls[mk[qq]] == 5)) {
-            die(63, "\nError: variant '%s' has dosages and %s, which plink2-hip does not read yet.\n", V.id[raw_v].c_str(),
-                (vcls[mk[qq]] == 5) ? "lies on chrM" : "several ALT alleles");
-          }
-          todo.push_back(qq);
-        }
-        std::vector<double> mfs(todo.size(), 0.0);
-        {
-          std::vector<uint32_t> raw_todo(todo.size());
-          for (size_t q = 0; q < todo.size(); ++q) {
-            raw_todo[q] = inc[mk[todo[q]]];
-          }
-          S.need_dosage_sums(raw_todo);
-          for (size_t q = 0; q < todo.size(); ++q) {
-            const std::pair<uint64_t, uint64_t>& dd = S.dosage_sums[raw_todo[q]];
-            const uint64_t tot = dd.first + dd.second;
-            const double ref_freq = tot ? (static_cast<double>(static_cast<int64_t>(dd.first)) * (1.0 / static_cast<double>(static_cast<int64_t>(tot)))) : 0.5;
-            mfs[q] = (ref_freq < 0.5) ? (1.0 - ref_freq) : ref_freq;
-          }
-        }
-        for (size_t q = 0; q < todo.size(); ++q) {
-          for (int r = 0; r < world; ++r) {
-            if (ldp_set_maj_freqs(eng[r], todo[q], 1, &mfs[q])) {
-              die(16, "\nError: %s\n", ldp_last_error(eng[r]));
-            }
-          }
-        }
-        if (A.timing) {
-          logprintf("\n[timing] allele frequencies of %zu variants from their dosages\n", todo.size());
-        }
-      }
-      t_load1 = now_s();
-      const std::vector<uint64_t> pref_m = sub_preferred(mk);
-      const size_t m_words = (static_cast<size_t>(m_ct) + 63) / 64 + 1;
-      std::vector<std::vector<uint64_t>> part(world, std::vector<uint64_t>(m_words, 0));
-      std::vector<int> rcs(world, 0);
-      // several devices: every engine prunes its shard on a host thread of its own; the shards' results then meet in ONE RCCL
-      // all-gather of their removed-bit segments (ldp_allgather_removed: the cross-device form of the stitch at
-      // plink2_ld.cc:1418-1426).  Without RCCL -- or with engines that share a device -- the same segments are packed, copied
-      // between the engines by the host and stitched by every rank (ldp_pack_removed_segment / ldp_stitch_removed_segments).
-      std::vector<std::thread> th;
-      for (int r = 0; r < world; ++r) {
-        th.emplace_back([&, r]() {
-          if (!pref_m.empty()) {
-            ldp_set_preferred(eng[r], pref_m.data());
-          }
-          rcs[r] = ldp_run(eng[r], part[r].data());
-        });
-      }
-      for (std::thread& t : th) {
-        t.join();
-      }
-      th.clear();
-      // (a rank whose run failed must not leave the others waiting in a collective: nobody enters it then)
-      for (int r = 0; r < world; ++r) {
-        if (rcs[r]) {
-          die(16, "\nError: %s\n", ldp_last_error(eng[r]));
-        }
-      }
-      if (world == 1) {
-        scatter(part[0], mk);
       } else {
-        std::vector<void*> comms(world, nullptr);
-        std::vector<std::vector<uint64_t>> full(world, std::vector<uint64_t>(m_words, 0));
-        bool use_rccl = false;
-        if (!alias_devices) {
-          std::vector<int> devs(world);
-          for (int r = 0; r < world; ++r) {
-            devs[r] = r;
-          }
-          use_rccl = (ldp_comm_init_all(world, devs.data(), comms.data()) == 0);
+        uint64_t seg_words = 0;
+        if (ldp_shard_segment_words(eng[0], &seg_words)) {
+          die(16, "\nError: %s\n", ldp_last_error(eng[0]));
         }
-        if (use_rccl) {
-          for (int r = 0; r < world; ++r) {
-            th.emplace_back([&, r]() { rcs[r] = ldp_allgather_removed(eng[r], comms[r], part[r].data(), full[r].data()); });
-          }
-          for (std::thread& t : th) {
-            t.join();
-          }
-          for (int r = 0; r < world; ++r) {
-            if (rcs[r]) {  // (the failing rank aborted its communicator; the process ends here, nothing is destroyed twice)
-              die(16, "\nError: %s\n", ldp_last_error(eng[r]));
-            }
-          }
-          for (int r = 0; r < world; ++r) {
-            ldp_comm_destroy(comms[r]);
-          }
-        } else {
-          uint64_t seg_words = 0;
-          if (ldp_shard_segment_words(eng[0], &seg_words)) {
-            die(16, "\nError: %s\n", ldp_last_error(eng[0]));
-          }
-          std::vector<uint64_t> segs(static_cast<size_t>(seg_words) * world, 0);
-          for (int r = 0; r < world; ++r) {
-            if (ldp_pack_removed_segment(eng[r], part[r].data(), segs.data() + static_cast<size_t>(r) * seg_words)) {
-              die(16, "\nError: packing the removed bits of shard %d failed.\n", r);
-            }
-          }
-          for (int r = 0; r < world; ++r) {
-            if (ldp_stitch_removed_segments(eng[r], segs.data(), full[r].data())) {
-              die(16, "\nError: stitching the removed bits on shard %d failed.\n", r);
-            }
+        std::vector<uint64_t> segs(static_cast<size_t>(seg_words) * world, 0);
+        for (int r = 0; r < world; ++r) {
+          if (ldp_pack_removed_segment(eng[r], part[r].data(), segs.data() + static_cast<size_t>(r) * seg_words)) {
+            die(16, "\nError: packing the removed bits of shard %d failed.\n", r);
           }
         }
-        for (int r = 1; r < world; ++r) {  // every rank holds the same global bitmap
-          if (memcmp(full[r].data(), full[0].data(), ((static_cast<size_t>(m_ct) + 63) / 64) * sizeof(uint64_t)) != 0) {
-            die(16, "\nError: the shards disagree about the stitched prune bitmap (rank %d).\n", r);
+        for (int r = 0; r < world; ++r) {
+          if (ldp_stitch_removed_segments(eng[r], segs.data(), full[r].data())) {
+            die(16, "\nError: stitching the removed bits on shard %d failed.\n", r);
           }
-        }
-        scatter(full[0], mk);
-        if (A.timing) {
-          logprintf("\n[timing] %d engines on %d device%s, exchange: %s\n", world, std::min(world, n_devices), (std::min(world, n_devices) == 1) ? "" : "s",
-                    use_rccl ? "RCCL all-gather" : "host transport");
         }
       }
-      t_run1 = now_s();
+      for (int r = 1; r < world; ++r) {  // every rank holds the same global bitmap
+        if (memcmp(full[r].data(), full[0].data(), ((static_cast<size_t>(m_ct) + 63) / 64) * sizeof(uint64_t)) != 0) {
+          die(16, "\nError: the shards disagree about the stitched prune bitmap (rank %d).\n", r);
+        }
+      }
+      scatter(full[0], mk);
+      if (A.timing) {
+        logprintf("\n[timing] %d engines on %d device%s, exchange: %s\n", world, std::min(world, n_devices), (std::min(world, n_devices) == 1) ? "" : "s",
+                  use_rccl ? "RCCL all-gather" : "host transport");
+      }
     }
-    if (A.timing) {
-      ldp_counters c;
-      ldp_get_counters(eng[0], &c);
-      logprintf("\n[timing] setup+parse %.3f s | genotype load (file -> HBM bit-planes) %.3f s | run %.3f s (pair kernel %.1f ms, replay %.1f ms; %llu candidate pairs) | buffer release %.3f s\n",
-                t_load0 - t_begin, t_load1 - t_load0, (t_run1 ? t_run1 : now_s()) - t_load1, c.ms_pair_kernel, c.ms_replay, static_cast<unsigned long long>(c.candidate_pairs), t_run1 ? now_s() - t_run1 : 0.0);
-    }
-    // ---- chrX, chrY: their own sample sets, rows built on the host, one engine each on device 0
-    // (--indep-pairphase: MT too, one haplotype per founder with hets missing -- HapsplitHaploid, plink2_ld.cc:2051)
+    t_run1 = now_s();
+  }
+
+  void report_load_and_run() {
+    ldp_counters c;
+    ldp_get_counters(eng[0], &c);
+    logprintf("\n[timing] setup+parse %.3f s | genotype load (file -> HBM bit-planes) %.3f s | run %.3f s (pair kernel %.1f ms, replay %.1f ms; %llu candidate pairs) | buffer release %.3f s\n",
+              t_load0 - t_begin, t_load1 - t_load0, (t_run1 ? t_run1 : now_s()) - t_load1, c.ms_pair_kernel, c.ms_replay, static_cast<unsigned long long>(c.candidate_pairs), t_run1 ? now_s() - t_run1 : 0.0);
+  }
+
+  // ---- chrX, chrY: their own sample sets, rows built on the host, one engine each on device 0
+  // (--indep-pairphase: MT too, one haplotype per founder with hets missing -- HapsplitHaploid, plink2_ld.cc:2051)
+  void run_sex_chromosomes() {
     for (int which = 0; which < 3; ++which) {
       const std::vector<uint32_t>& ks = (which == 0) ? xk : ((which == 1) ? yk : tk);
       if (ks.empty()) {
@@ -5699,41 +5813,94 @@ int run_prune(Session& S) {
       ldp_destroy(se);
     }
   }
-  uint32_t removed_ct = 0;
-  for (uint64_t w : removed) {
-    removed_ct += static_cast<uint32_t>(__builtin_popcountll(w));
-  }
-  logprintf("%u/%u variants removed.\n", removed_ct, variant_ct);  // plink2_ld.cc:2707
-  // LdPruneWrite, plink2_ld.cc:2464-2528
-  for (int pass = 0; pass < 2; ++pass) {
-    const std::string path = A.out + (pass ? ".prune.out" : ".prune.in");
-    FILE* f = fopen(path.c_str(), "wb");
-    if (!f) {
-      die(3, "Error: Failed to open %s for writing.\n", path.c_str());
+
+  void write_lists() {
+    uint32_t removed_ct = 0;
+    for (uint64_t w : removed) {
+      removed_ct += static_cast<uint32_t>(__builtin_popcountll(w));
     }
-    for (uint32_t k = 0; k < variant_ct; ++k) {
-      const bool rem = (removed[k >> 6] >> (k & 63)) & 1;
-      if (rem == static_cast<bool>(pass)) {
-        fputs(V.id[inc[k]].c_str(), f);
-        fputc('\n', f);
+    logprintf("%u/%u variants removed.\n", removed_ct, variant_ct);  // plink2_ld.cc:2707
+    // LdPruneWrite, plink2_ld.cc:2464-2528
+    for (int pass = 0; pass < 2; ++pass) {
+      const std::string path = A.out + (pass ? ".prune.out" : ".prune.in");
+      FILE* f = fopen(path.c_str(), "wb");
+      if (!f) {
+        die(3, "Error: Failed to open %s for writing.\n", path.c_str());
+      }
+      for (uint32_t k = 0; k < variant_ct; ++k) {
+        const bool rem = (removed[k >> 6] >> (k & 63)) & 1;
+        if (rem == static_cast<bool>(pass)) {
+          fputs(V.id[inc[k]].c_str(), f);
+          fputc('\n', f);
+        }
+      }
+      if (fclose(f)) {
+        die(5, "Error: File write failure: %s.\n", path.c_str());
       }
     }
-    if (fclose(f)) {
-      die(5, "Error: File write failure: %s.\n", path.c_str());
+    logprintf("Variant lists written to %s.prune.in and %s.prune.out .\n", A.out.c_str(), A.out.c_str());
+  }
+
+  [[noreturn]] void finish() {
+    if (A.timing) {
+      // (wall-clock stamps: what a caller's stopwatch sees beyond `total` is process start-up before main() and teardown after _exit)
+      const double unix_now = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+      logprintf("[timing] total %.3f s (main() entered at unix time %.3f, leaving at %.3f)\n", now_s() - t_begin, unix_now - (now_s() - t_begin), unix_now);
     }
+    if (g_log) {
+      fclose(g_log);
+    }
+    fflush(nullptr);
+    // everything is on disk; releasing tens of GB of device memory and unmapping the input only costs time
+    _exit(0);
   }
-  logprintf("Variant lists written to %s.prune.in and %s.prune.out .\n", A.out.c_str(), A.out.c_str());
-  if (A.timing) {
-    // (wall-clock stamps: what a caller's stopwatch sees beyond `total` is process start-up before main() and teardown after _exit)
-    const double unix_now = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
-    logprintf("[timing] total %.3f s (main() entered at unix time %.3f, leaving at %.3f)\n", now_s() - t_begin, unix_now - (now_s() - t_begin), unix_now);
+
+  int run() {
+    set_params();
+    if (A.dry_run) {
+      return dry_run();
+    }
+    check_unique_ids();
+    t_tables_done = now_s();
+    plan_engines();
+    t_planned = now_s();
+    S.join_hip();
+    if (ldp_device_count() < 1) {
+      die(16, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
+    }
+    removed.assign((static_cast<size_t>(variant_ct) + 63) / 64 + 1, 0);
+    if (subcontig_ct || !xk.empty() || !yk.empty() || !tk.empty()) {
+      check_before_loading();
+      read_preferred();
+      logprintf("--indep-pair%s (%d GPU%s): ", A.pairphase ? "phase" : "wise", world, world == 1 ? "" : "s");
+      fflush(stdout);
+      t_load0 = now_s();
+      if (A.timing) {
+        logprintf("\n[timing] table parse %.3f s, variant-table passes + ID check done at %.3f s, engine planned at %.3f s, HIP init %.3f s (concurrent; joined at %.3f s)\n",
+                  t_parse, t_tables_done - t_begin, t_planned - t_begin, t_hip_init, t_joined - t_begin);
+      }
+      set_row_geometry();
+      t_load1 = now_s();
+      t_run1 = 0;
+      if (subcontig_ct) {
+        load_diploid_rows();
+        patch_host_built_rows();
+        set_dosage_frequencies();
+        run_diploid_engines();
+      }
+      if (A.timing) {
+        report_load_and_run();
+      }
+      run_sex_chromosomes();
+    }
+    write_lists();
+    finish();
   }
-  if (g_log) {
-    fclose(g_log);
-  }
-  fflush(nullptr);
-  // everything is on disk; releasing tens of GB of device memory and unmapping the input only costs time
-  _exit(0);
+};
+
+int run_prune(Session& S) {
+  PruneJob job(S);
+  return job.run();
 }
 
 
