@@ -69,7 +69,7 @@ PER_GPU_VARIANTS = {"config2": 1000000, "config3": 1250000}  # weak scaling: the
 CHR22_FRACTION = GRCH38_MB[21] / sum(GRCH38_MB)               # end-to-end runs materialise <= one chr22-sized chromosome
 # the kernel sources a PMC profile is valid for (roofline.traffic is replayed only when their hashes match this tree)
 KERNEL_SOURCES = ["plink-ng_amd/csrc/" + f for f in ("ldp_pair_wide.hip", "ldp_pair_mfma.hip", "ldp_mfma_device.h", "ldp_pair_device.h", "ldp_device.h",
-                                                      "ldp_codes.hip", "ldp_engine.cpp")]
+                                                      "ldp_codes.hip", "ldp_engine.cpp", "ldp_engine_run.cpp", "ldp_engine_internal.h")]
 HBM_BYTES = float(os.environ.get("LDP_BENCH_HBM_GB", "288")) * 1e9  # (the override forces the non-resident mode at small sizes: tests)
 
 

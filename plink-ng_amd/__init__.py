@@ -102,7 +102,8 @@ CABI_SYMBOLS = [
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_codes.hip", "ldp_pair_mfma.hip", "ldp_pair_wide.hip", "ldp_pgen_decode.hip", "ldp_synth.hip", "ldp_engine.cpp", "ldp_pgen.cpp")]
+    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_codes.hip", "ldp_pair_mfma.hip", "ldp_pair_wide.hip", "ldp_pgen_decode.hip", "ldp_synth.hip", "ldp_engine.cpp", "ldp_engine_run.cpp", "ldp_engine_r2.cpp",
+                                          "ldp_engine_load.cpp", "ldp_engine_shard.cpp", "ldp_pgen.cpp")]
 
 
 def _stale(target, deps):

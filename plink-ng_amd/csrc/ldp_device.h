@@ -1,5 +1,5 @@
 // ldp_device.h -- layout constants and launch-side declarations shared by the HIP kernels
-// (ldp_kernels.hip) and the host runtime (ldp_engine.cpp).
+// (ldp_kernels.hip) and the host runtime (ldp_engine*.cpp).
 #ifndef LDP_DEVICE_H
 #define LDP_DEVICE_H
 
