@@ -59,6 +59,8 @@ sys.path.insert(0, REPO)
 GRCH38_MB = [248.96, 242.19, 198.30, 190.21, 181.54, 170.81, 159.35, 145.14, 138.39, 133.80, 135.09, 133.28,
              114.36, 107.04, 101.99, 90.34, 83.26, 80.37, 58.62, 64.44, 46.71, 50.82]
 SEED = 20260925 + 2
+if os.environ.get("LDP_BENCH_ALT_MINOR"):   # measurement aid (profiles/r04_experiments.md): ALT is the minor allele of every synthetic variant
+    SEED |= 1 << 63
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP4_PEAK_TFLOPS = 10000.0  # MI355X_MICROARCH.md: ~10 PFLOP/s dense FP4 MFMA (AMD's 20 PF figure is 2:1 sparse)
 CONFIGS = {

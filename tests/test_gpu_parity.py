@@ -877,6 +877,35 @@ def test_sample_counts_around_the_matrix_pipe_limit(gpu_pkg, beyond, missing):
     del buf
 
 
+def test_four_product_operands_at_their_founder_limit(gpu_pkg):
+    """The allele-count / missing-flag operands of the four-product form are exact while 9 N < 2^24 (kMfGuMaxFounders = 1,800,000,
+    ldp_mfma_device.h); engines with more founders multiply x and n.  At the limit and just beyond it: the same prune set and the same
+    number of true predicates as the six-product form, from rows with 3 % missing calls and planted LD."""
+    import torch
+    pkg = gpu_pkg
+    m = 96
+    for n in (1800000, 1800001):
+        stride = (n + 3) // 4
+        buf = torch.empty((m, stride), dtype=torch.uint8, device="cuda")
+        pkg.synth_genotypes_device(91, 0, m, n, 0.03, buf.data_ptr(), stride)
+        torch.cuda.synchronize()
+        outs = []
+        for opts in ({"pair_sparse": 0}, {"pair_sparse": 0, "pair_gu": 0}, {"pair_sparse": 0, "pair_four": 0}):
+            eng = pkg.LdPruneEngine(n, 40, 1, False, 0.2, order=2, device=0)
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            eng.set_variants(np.zeros(m, dtype=np.uint32), None)
+            eng.load_genotypes_device(0, m, buf.data_ptr(), stride, pkg.LDP_GENO_REF)
+            removed = eng.run()
+            ctr = eng.counters()
+            outs.append((removed, ctr["pred_true"], ctr["route_general_launches"]))
+            eng.close()
+        assert outs[0][2] > 0 and outs[0][1] > 0 and removed.sum() > 0
+        assert np.array_equal(outs[0][0], outs[2][0]) and np.array_equal(outs[1][0], outs[2][0])
+        assert outs[0][1] <= outs[2][1] and outs[0][1] == outs[1][1]     # (early termination retires products whose pairs are false; both operand sets alike)
+        del buf
+
+
 @pytest.mark.parametrize("n,offset", [(1000, 3), (1001, 0), (50000, 12)])
 def test_rows_read_from_a_file_descriptor(gpu_pkg, tmp_path, n, offset):
     """ldp_load_genotypes_fd: fixed-width rows pread() straight from a file into the pinned ring -- the same records, maj_freq and
