@@ -99,14 +99,19 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
   }
   static const bool eager_always = (getenv("LDP_EAGER_PAIRS") != nullptr) && (strcmp(getenv("LDP_EAGER_PAIRS"), "1") == 0);
   const bool eager = (!e->matrix_mode) && (!e->band_r2_mode) && ((location == LDP_MEM_HOST) || eager_always);
-  static const uint32_t copy_threads = []() {
+  // host threads per 16 MiB slot and bytes per task: a memcpy out of a mapping runs at its best on 16 threads; pread() calls (the file
+  // descriptor form, what plink2-hip uses for fixed-width rows) want more, smaller ones -- 32 x 256 KiB: 0.36-0.38 s for config 2's
+  // 12.5 GB on a host where the mapping took 0.35-0.97 s from run to run (profiles/r04_experiments.md)
+  static const uint32_t copy_threads_env = []() {
     const char* c = getenv("LDP_DEBUG_COPY_THREADS");
-    return (c && atoi(c) > 0) ? static_cast<uint32_t>(atoi(c)) : 16u;
+    return (c && atoi(c) > 0) ? static_cast<uint32_t>(atoi(c)) : 0u;
   }();
-  static const uint64_t copy_task_bytes = []() {
+  static const uint64_t copy_task_env = []() {
     const char* c = getenv("LDP_DEBUG_COPY_TASK_KB");
-    return (c && atoi(c) > 0) ? (static_cast<uint64_t>(atoi(c)) << 10) : (1ull << 20);
+    return (c && atoi(c) > 0) ? (static_cast<uint64_t>(atoi(c)) << 10) : 0ull;
   }();
+  const uint32_t copy_threads = copy_threads_env ? copy_threads_env : ((src_fd >= 0) ? 32u : 16u);
+  const uint64_t copy_task_bytes = copy_task_env ? copy_task_env : ((src_fd >= 0) ? (256ull << 10) : (1ull << 20));
   static const bool load_timing = getenv("LDP_DEBUG_LOAD_TIMING") != nullptr;  // host side of the file -> HBM leg, on stderr
   double t_wait_slot = 0.0, t_copy = 0.0;
   uint32_t n_slots = 0;

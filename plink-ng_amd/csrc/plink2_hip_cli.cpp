@@ -5258,9 +5258,10 @@ struct PruneJob {
     load_encoding = A.pairphase ? (LDP_GENO_REF | LDP_GENO_PHASED) : encoding;
     direct = A.pairphase ? nullptr : direct_rows;  // phased rows always come through the decoder
     direct_off = 0;
-    // (LDP_DEBUG_LOAD_FD=1: pread() into the pinned ring instead of a memcpy out of the mapping -- measured SLOWER on the GPU box's
-    // host, 32-40 against 53 GB/s per 1 GB call with the page cache warm, so the mapping stays the default)
-    direct_fd = (direct && getenv("LDP_DEBUG_LOAD_FD")) ? ldp_pgen_direct_fd(pg, &direct_off, nullptr) : -1;
+    // Fixed-width rows go from the file to the engine's pinned ring with pread() (ldp_load_genotypes_fd), not by memcpy out of the
+    // mapping: a 12 GB mapping is faulted in page run by page run, and what that costs swung between 0.35 and 0.97 s from one run to
+    // the next on the same host, while 32 readers take 0.36-0.38 s every time (LDP_DEBUG_LOAD_FD=0: the mapping)
+    direct_fd = (direct && !(getenv("LDP_DEBUG_LOAD_FD") && (atoi(getenv("LDP_DEBUG_LOAD_FD")) == 0))) ? ldp_pgen_direct_fd(pg, &direct_off, nullptr) : -1;
     founder_mask.assign((static_cast<size_t>(raw_sample_ct) + 7) / 8, 0);
     for (uint32_t sidx = 0; sidx < raw_sample_ct; ++sidx) {
       if (is_founder[sidx]) {
@@ -5419,7 +5420,7 @@ struct PruneJob {
       }
       const double tl0 = now_s();
       for (int r = 0; r < world; ++r) {
-        // fixed-width rows as the file has them: out of the mapping, or (LDP_DEBUG_LOAD_FD=1) with pread() straight into the engine's
+        // fixed-width rows as the file has them: with pread() straight into the engine's
         // pinned ring (ldp_load_genotypes_fd)
         const bool from_fd = direct && (src == direct + static_cast<uint64_t>(raw0) * rec_bytes) && (direct_fd >= 0);
         const int rc = from_fd ? ldp_load_genotypes_fd(eng[r], q, run, direct_fd, direct_off + static_cast<uint64_t>(raw0) * rec_bytes, stride,

@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--r2", type=float, default=0.5)
     ap.add_argument("--no-ref", action="store_true")
     ap.add_argument("--h2d-modes", default="", help="comma-separated LDP_DEBUG_H2D_MODE values to time plink2-hip with (measurement)")
+    ap.add_argument("--env-sets", default="", help="semicolon-separated sets of NAME=VALUE,NAME=VALUE to time plink2-hip with on the same fileset (measurement)")
+    ap.add_argument("--reps", type=int, default=3, help="plink2-hip runs per setting; the reported speed-up uses the BEST wall of each tool (HIP start-up "
+                    "varies by 0.1-0.3 s from run to run on one box), all walls are printed")
     ap.add_argument("--pgen", action="store_true", help="convert the .bed with the reference's --make-pgen first (variable-width .pgen) and time both tools on that")
     ap.add_argument("--phased", action="store_true", help="--indep-pairphase on a phased variable-width .pgen (haplotypes = the synthetic generator's pseudo-samples, paired up)")
     ap.add_argument("--inter-chr", action="store_true", help="time --r2-unphased inter-chr --ld-window-r2 <--r2> (all pairs; keep --variants small)")
@@ -155,24 +158,36 @@ def main():
                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         print("reference --make-pgen rc", cp.returncode, "wall %.1f s, .pgen %.2f GB" % (time.perf_counter() - t0, os.path.getsize(os.path.join(tmp, "s.pgen")) / 1e9))
         common = ["--pfile", "s"] + common[2:]
-    for mode in (args.h2d_modes.split(",") if args.h2d_modes else [None]):
+    settings = [("LDP_DEBUG_H2D_MODE=" + mode) for mode in args.h2d_modes.split(",")] if args.h2d_modes else [""]
+    if args.env_sets:
+        settings = args.env_sets.split(";")
+    t_hip = None
+    for setting in settings:
         env = dict(os.environ)
-        if mode is not None:
-            env["LDP_DEBUG_H2D_MODE"] = mode   # 0: one in-order copy stream, 1: two copy streams (default), 2: the count pass reads the pinned rows itself
-            print("--- LDP_DEBUG_H2D_MODE=%s" % mode)
-        for rep in range(2):
+        for kv in filter(None, setting.split(",")):
+            name, _, value = kv.partition("=")
+            env[name] = value
+        if setting:
+            print("--- " + setting)
+        walls = []
+        for rep in range(max(1, args.reps)):
             t0 = time.perf_counter()
             cp = subprocess.run([os.path.join(REPO, "plink-ng_amd", "bin", "plink2-hip")] + common + ["--timing", "--out", "hip"], cwd=tmp,
                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
-            t_hip = time.perf_counter() - t0
-            print("plink2-hip rc", cp.returncode, "wall %.3f s" % t_hip)
+            walls.append(time.perf_counter() - t0)
+            print("plink2-hip rc", cp.returncode, "wall %.3f s" % walls[-1])
             print("\n".join(ln for ln in cp.stdout.splitlines() if "timing" in ln or "removed" in ln or "written" in ln or "Error" in ln or "timeline" in ln or "recs copy" in ln))
+        print("plink2-hip walls:", " ".join("%.3f" % w for w in walls), "best %.3f median %.3f" % (min(walls), sorted(walls)[len(walls) // 2]))
+        t_hip = min(walls) if t_hip is None else t_hip   # (the speed-up line is the first setting's)
     if not args.no_ref:
-        t0 = time.perf_counter()
-        cp = subprocess.run([os.path.join(REPO, "oracle", "_ref", "plink2")] + common + ["--threads", str(os.cpu_count()), "--out", "ref"], cwd=tmp,
-                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        t_ref = time.perf_counter() - t0
-        print("reference rc", cp.returncode, "wall %.3f s" % t_ref, "speedup %.1fx" % (t_ref / t_hip))
+        ref_walls = []
+        for rep in range(2):
+            t0 = time.perf_counter()
+            cp = subprocess.run([os.path.join(REPO, "oracle", "_ref", "plink2")] + common + ["--threads", str(os.cpu_count()), "--out", "ref"], cwd=tmp,
+                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            ref_walls.append(time.perf_counter() - t0)
+        t_ref = min(ref_walls)
+        print("reference rc", cp.returncode, "walls", " ".join("%.3f" % w for w in ref_walls), "best %.3f s" % t_ref, "speedup (best / best) %.1fx" % (t_ref / t_hip))
         same = all(open(os.path.join(tmp, "hip" + e)).read() == open(os.path.join(tmp, "ref" + e)).read() for e in outs)
         print("files identical:", same)
     subprocess.call(["rm", "-rf", tmp])
