@@ -438,6 +438,34 @@ int r2_x_block_impl(ldp_engine* e, ldp_engine* male, const uint8_t* is_x, const 
       xc_hi = i + 1;
     }
   }
+  // row chunks of at most ~1 GiB of tuples per engine; a chunk without a chrX row only needs the chrX columns (pairs are i < j: nothing
+  // right of the chunk's last row either).  Blocks without any chrX pair -- most chunks of a genome-wide table -- cost nothing.
+  const size_t esz = as_float ? sizeof(float) : sizeof(double);
+  uint32_t rows_per = static_cast<uint32_t>(std::max<uint64_t>(32, ((1ull << 30) / sizeof(ldp_pair_stats_t)) / col_ct) & ~31ull);
+  if (const char* dbg = getenv("LDP_DEBUG_X_ROWS")) {  // (test hook: many small chunks)
+    rows_per = static_cast<uint32_t>(std::max(1, atoi(dbg)));
+  }
+  struct Chunk {
+    uint32_t r0, rows, c0, c1;
+  };
+  std::vector<Chunk> chunks;
+  uint64_t max_elems = 0;
+  for (uint32_t r0 = row_first; r0 < row_end; r0 += rows_per) {
+    const uint32_t rows = std::min(rows_per, row_end - r0);
+    bool any_x_row = false;
+    for (uint32_t j = r0; j < r0 + rows; ++j) {
+      any_x_row = any_x_row || (is_x[j] != 0);
+    }
+    const uint32_t c0 = any_x_row ? col_first : xc_lo;
+    const uint32_t c1 = std::min(any_x_row ? col_end : xc_hi, r0 + rows - 1);
+    if (c0 < c1) {
+      chunks.push_back({r0, rows, c0, c1});
+      max_elems = std::max(max_elems, static_cast<uint64_t>(rows) * (c1 - c0));
+    }
+  }
+  if (chunks.empty()) {
+    return LDP_OK;
+  }
   DevBuf flags_buf, ta_buf, tm_buf, val_buf, hit_buf, ctr_buf;
   HIP_TRY(e, hipMalloc(&flags_buf.p, 3ull * m));
   uint8_t* d_is_x = flags_buf.as<uint8_t>();
@@ -455,32 +483,16 @@ int r2_x_block_impl(ldp_engine* e, ldp_engine* male, const uint8_t* is_x, const 
     HIP_TRY(e, hipMalloc(&ctr_buf.p, sizeof(unsigned long long)));
     HIP_TRY(e, hipMemsetAsync(ctr_buf.p, 0, sizeof(unsigned long long), e->stream));
   }
-  // row chunks of at most ~1 GiB of tuples per engine
-  const size_t esz = as_float ? sizeof(float) : sizeof(double);
-  uint32_t rows_per = static_cast<uint32_t>(std::max<uint64_t>(32, ((1ull << 30) / sizeof(ldp_pair_stats_t)) / col_ct) & ~31ull);
-  if (const char* dbg = getenv("LDP_DEBUG_X_ROWS")) {  // (test hook: many small chunks)
-    rows_per = static_cast<uint32_t>(std::max(1, atoi(dbg)));
-  }
-  HIP_TRY(e, hipMalloc(&ta_buf.p, static_cast<uint64_t>(std::min(rows_per, row_ct)) * col_ct * sizeof(ldp_pair_stats_t)));
+  HIP_TRY(e, hipMalloc(&ta_buf.p, max_elems * sizeof(ldp_pair_stats_t)));
   if (male) {
-    HIP_TRY(e, hipMalloc(&tm_buf.p, static_cast<uint64_t>(std::min(rows_per, row_ct)) * col_ct * sizeof(ldp_pair_stats_t)));
+    HIP_TRY(e, hipMalloc(&tm_buf.p, max_elems * sizeof(ldp_pair_stats_t)));
   }
   std::vector<uint8_t> h_val;
   if (!hits) {
-    HIP_TRY(e, hipMalloc(&val_buf.p, static_cast<uint64_t>(std::min(rows_per, row_ct)) * col_ct * esz));
+    HIP_TRY(e, hipMalloc(&val_buf.p, max_elems * esz));
   }
-  for (uint32_t r0 = row_first; r0 < row_end; r0 += rows_per) {
-    const uint32_t rows = std::min(rows_per, row_end - r0);
-    bool any_x_row = false;
-    for (uint32_t j = r0; j < r0 + rows; ++j) {
-      any_x_row = any_x_row || (is_x[j] != 0);
-    }
-    // (a chunk without a chrX row only needs the chrX columns; pairs are i < j: nothing right of the chunk's last row either)
-    const uint32_t c0 = any_x_row ? col_first : xc_lo;
-    const uint32_t c1 = std::min(any_x_row ? col_end : xc_hi, r0 + rows - 1);
-    if (c0 >= c1) {
-      continue;
-    }
+  for (const Chunk& ch : chunks) {
+    const uint32_t r0 = ch.r0, rows = ch.rows, c0 = ch.c0, c1 = ch.c1;
     const uint32_t cols = c1 - c0;
     if ((rc = r2_rows_impl(e, r0, rows, 2, ta_buf.p, cols, nullptr, c0, c1, true))) {
       return rc;
