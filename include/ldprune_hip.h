@@ -241,8 +241,10 @@ int ldp_map_rows(ldp_engine* e, uint32_t first_variant, uint32_t n, void** devic
  *                when that record is not part of this call.  Without it an LD-compressed first record builds on the last
  *                stand-alone record of the previous call, provided this call starts where that one ended.
  *   raw_sample_ct  samples of the file = the engine's founder_ct, or the raw count of ldp_set_sample_map() (the engine then
- *                gathers its columns as for LDP_GENO_MAPPED rows; variants with allele_ct > 2 are refused in that case, since
- *                their major allele is counted over the columns of the file).
+ *                gathers its columns as for LDP_GENO_MAPPED rows; the major allele of a variant with allele_ct > 2 is counted
+ *                over the map's samples when the map is a plain subset of the file's -- every sample at most once, no het ->
+ *                missing: the founders among non-founders, plink2_filter.cc:2113-2153 --, and such variants are refused,
+ *                LDP_ERR_UNSUPPORTED, under any other map: the chrX / chrY layouts weigh samples).
  *   major_allele_out  optional, n entries: the major allele of the variants with allele_ct > 2 (their maj_freq is set as by
  *                ldp_set_maj_freqs), UINT32_MAX for the others (decided by the count pass: ldp_get_variant_recs).
  * LDP_ERR_INVALID for a malformed record (no row of the call counts as loaded then). */

@@ -280,6 +280,8 @@ struct PgenDecodeArgs {
   double* maj_freq;             // out, per entry of multi_rec: GetAlleleFreq of the major allele
   uint32_t* maj_idx;            // out: the major allele
   uint8_t* row_inverse;         // out, per RECORD: 1 = the row now counts copies of non-major alleles (LDP_GENO_INVERSE)
+  const uint32_t* sample_mask;  // optional bitmap over the file's samples: the ones whose alleles count (a subset sample map: the founders)
+  uint32_t mask_ct;             // ... and how many they are
   // --indep-pairphase: the hardcall-phase track decoded into the rows' second part (LDP_GENO_PHASED layout); 0 = not wanted
   uint64_t phase_off;           // byte offset of the phase bits inside a row (a multiple of 4, < stride)
   uint32_t* unphased;           // out: lowest record index with a het call that has no phase (atomicMin; preset to UINT32_MAX)

@@ -48,6 +48,8 @@ void free_device(ldp_engine* e) {
   (void)hipFree(e->d_planes);
   (void)hipFree(e->d_codes);
   e->d_codes = nullptr;
+  (void)hipFree(e->d_map_mask);
+  e->d_map_mask = nullptr;
   (void)hipFree(e->d_recs);
   (void)hipFree(e->d_lo);
   (void)hipFree(e->d_row_off);
@@ -1440,6 +1442,24 @@ int ldp_set_sample_map(ldp_engine* e, uint32_t raw_sample_ct, const uint32_t* sr
     HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_sample_map), m.size() * sizeof(uint32_t)));
   }
   HIP_TRY(e, hipMemcpy(e->d_sample_map, m.data(), m.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  // a plain subset?  (then records with several ALT alleles can be collapsed on the device: ldp_load_pgen_records)
+  std::vector<uint32_t> mask((static_cast<size_t>(raw_sample_ct) + 31) / 32 + 1, 0);
+  bool subset = true;
+  for (uint32_t f = 0; f < e->P.founder_ct; ++f) {
+    const uint32_t sidx = m[f] & 0x7fffffffu;
+    if ((m[f] >> 31) || ((mask[sidx >> 5] >> (sidx & 31)) & 1u)) {
+      subset = false;
+      break;
+    }
+    mask[sidx >> 5] |= 1u << (sidx & 31);
+  }
+  (void)hipFree(e->d_map_mask);
+  e->d_map_mask = nullptr;
+  e->map_is_subset = subset;
+  if (subset) {
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_map_mask), mask.size() * sizeof(uint32_t)));
+    HIP_TRY(e, hipMemcpy(e->d_map_mask, mask.data(), mask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   e->sample_map.swap(m);
   e->map_raw_sample_ct = raw_sample_ct;
   return LDP_OK;

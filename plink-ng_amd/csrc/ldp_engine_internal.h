@@ -289,6 +289,10 @@ struct ldp_engine {
   std::vector<uint32_t> sample_map;
   uint32_t map_raw_sample_ct = 0;
   uint32_t* d_sample_map = nullptr;
+  // the map is a plain SUBSET of the file's samples (each at most once, no het -> missing: founders among non-founders): then the
+  // device-side multiallelic collapse counts alleles over exactly these samples (bitmap over the file's samples)
+  bool map_is_subset = false;
+  uint32_t* d_map_mask = nullptr;
   uint8_t* d_gather = nullptr;      // gathered 2-bit rows of one conversion launch
   size_t gather_bytes = 0;
   uint32_t* d_extra_het = nullptr;  // per variant of that launch

@@ -433,8 +433,8 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
   if (any_multi && phased) {
     return fail(e, LDP_ERR_UNSUPPORTED, "phased records with more than one ALT allele: their phase refers to allele pairs (Get1MP, pgenlib_read.cc:6962): build those rows on the host");
   }
-  if (any_multi && mapped) {
-    return fail(e, LDP_ERR_UNSUPPORTED, "variants with more than one ALT allele are collapsed over the file's samples: not with a sample map (collapse them on the host, LDP_GENO_INVERSE)");
+  if (any_multi && mapped && !e->map_is_subset) {
+    return fail(e, LDP_ERR_UNSUPPORTED, "variants with more than one ALT allele are collapsed over the file's samples or a plain subset of them: not with a sample map that repeats samples or turns het calls missing (collapse them on the host, LDP_GENO_INVERSE)");
   }
   if (ld_base) {
     const uint32_t type = ld_base->vrtype & 7u;
@@ -584,6 +584,17 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
     DA.maj_freq = static_cast<double*>(p_mf);
     DA.maj_idx = static_cast<uint32_t*>(p_mi);
     DA.row_inverse = static_cast<uint8_t*>(p_inv);
+    if (mapped && e->map_is_subset && (!e->d_map_mask) && !multi.empty()) {
+      // (the device copy went with a re-plan or ldp_release_device(): the host's sample map is the master)
+      std::vector<uint32_t> mask((static_cast<size_t>(e->map_raw_sample_ct) + 31) / 32 + 1, 0);
+      for (uint32_t sm : e->sample_map) {
+        mask[(sm & 0x7fffffffu) >> 5] |= 1u << (sm & 31);
+      }
+      HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_map_mask), mask.size() * sizeof(uint32_t)));
+      HIP_TRY(e, hipMemcpy(e->d_map_mask, mask.data(), mask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    DA.sample_mask = (mapped && e->map_is_subset) ? e->d_map_mask : nullptr;  // (a subset map: the alleles of its samples decide the major allele)
+    DA.mask_ct = e->P.founder_ct;
     DA.phase_off = phase_off;
     DA.unphased = d_unphased;
     hipError_t krc = launch_pgen_main(DA, e->stream);

@@ -528,18 +528,41 @@ __global__ __launch_bounds__(kAuxThreads) void pgen_aux1_kernel(PgenDecodeArgs A
     mtrack = main_lds;
   }
   // ---- the main track's categories: counts, and each thread's rank among them
-  uint32_t my1 = 0, my2 = 0, my3 = 0;
+  // (A.sample_mask, optional: the engine's samples are a SUBSET of the file's -- the founders --, and the allele counts that choose the
+  // major allele run over them alone (the allele-frequency pass, plink2_filter.cc:2113-2153, counts founders); the ranks that locate
+  // a sample's patch run over all of the file's samples either way)
+  const uint32_t* __restrict__ smask = A.sample_mask;
+  auto mask_of_dword = [&](uint32_t d) -> uint32_t {  // the 16 samples of code dword d, one bit each in the even positions
+    return smask ? spread16(smask[d >> 1] >> (16 * (d & 1))) : 0x55555555u;
+  };
+  auto in_mask = [&](uint32_t sample) -> bool { return (!smask) || ((smask[sample >> 5] >> (sample & 31)) & 1u); };
+  uint32_t my1 = 0, my2 = 0, my3 = 0, mk1 = 0, mk2 = 0, mk3 = 0;
   for (uint32_t d = d0; d < d1; ++d) {
     const uint32_t w = mtrack[d];
-    my1 += __popc(cat_mask(w, 1));
-    my2 += __popc(cat_mask(w, 2));
-    my3 += __popc(w & (w >> 1) & 0x55555555u);
+    const uint32_t c1 = cat_mask(w, 1), c2 = cat_mask(w, 2), c3 = w & (w >> 1) & 0x55555555u;
+    my1 += __popc(c1);
+    my2 += __popc(c2);
+    my3 += __popc(c3);
+    if (smask) {
+      const uint32_t mm = mask_of_dword(d);
+      mk1 += __popc(c1 & mm);
+      mk2 += __popc(c2 & mm);
+      mk3 += __popc(c3 & mm);
+    }
   }
   uint32_t n1, n2, n3;
   const uint32_t pre1 = block_exclusive<kAuxThreads>(my1, s_tmp, tid, &n1);
   const uint32_t pre2 = block_exclusive<kAuxThreads>(my2, s_tmp, tid, &n2);
   (void)block_exclusive<kAuxThreads>(my3, s_tmp, tid, &n3);
-  const uint32_t n0 = n - n1 - n2 - n3;
+  // genotype counts over the samples that count: f0 hom-REF, f1 REF/ALT1 (or a patched het), f2 ALT1/ALT1 (or patched)
+  uint32_t f1 = n1, f2 = n2, f3 = n3, f_all = n;
+  if (smask) {
+    (void)block_exclusive<kAuxThreads>(mk1, s_tmp, tid, &f1);
+    (void)block_exclusive<kAuxThreads>(mk2, s_tmp, tid, &f2);
+    (void)block_exclusive<kAuxThreads>(mk3, s_tmp, tid, &f3);
+    f_all = A.mask_ct;
+  }
+  const uint32_t f0 = f_all - f1 - f2 - f3;
   bool bad = (allele_ct < 3) || (allele_ct > 255);
   // ---- locate the two patch sets
   PatchSet S[2];
@@ -672,10 +695,13 @@ __global__ __launch_bounds__(kAuxThreads) void pgen_aux1_kernel(PgenDecodeArgs A
       atomicAdd(&s_cnt[a], delta);
     }
   };
-  auto count_patch = [&](uint32_t /*sample*/, uint32_t cat, Alleles a) {
+  auto count_patch = [&](uint32_t sample, uint32_t cat, Alleles a) {
     if ((a.hi >= allele_ct) || (a.lo >= allele_ct)) {
       s_bad = 1;
       return;
+    }
+    if (!in_mask(sample)) {
+      return;  // (checked, not counted)
     }
     if (cat == 1) {
       bump(1, -1);
@@ -769,10 +795,10 @@ __global__ __launch_bounds__(kAuxThreads) void pgen_aux1_kernel(PgenDecodeArgs A
   if (tid == 0) {
     // ComputeAlleleFreqs (plink2_filter.cc:2113-2153): freq[a] = count[a] * (1 / total) for all alleles but the last, 1 / k each
     // when nothing is observed; GetMajIdxMulti (plink2_common.cc:1042-1070); GetAlleleFreq (plink2_common.h:584-593)
-    const uint64_t c_ref = 2ull * n0 + n1;
-    const int64_t c_alt1 = static_cast<int64_t>(n1) + 2ll * n2 + s_cnt[1];
+    const uint64_t c_ref = 2ull * f0 + f1;
+    const int64_t c_alt1 = static_cast<int64_t>(f1) + 2ll * f2 + s_cnt[1];
     auto count_of = [&](uint32_t a) -> uint64_t { return (a == 0) ? c_ref : ((a == 1) ? static_cast<uint64_t>(c_alt1) : static_cast<uint64_t>(s_cnt[a])); };
-    const uint64_t tot = 2ull * (static_cast<uint64_t>(n0) + n1 + n2);
+    const uint64_t tot = 2ull * (static_cast<uint64_t>(f0) + f1 + f2);
     const double tot_recip = tot ? __ddiv_rn(1.0, static_cast<double>(tot)) : 0.0;
     const double none = __ddiv_rn(1.0, static_cast<double>(allele_ct));
     auto freq_of = [&](uint32_t a) -> double { return tot ? __dmul_rn(static_cast<double>(count_of(a)), tot_recip) : none; };

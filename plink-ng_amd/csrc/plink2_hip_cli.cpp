@@ -5319,7 +5319,9 @@ struct PruneJob {
     const bool device_phase = A.pairphase && all_founders && (!has_multiallelic) && (storage_mode != 0x01) && (storage_mode != 0x02) &&
                               (getenv("LDP_DEBUG_HOST_DECODE") == nullptr);
     const bool device_decode = (!direct) && ((!A.pairphase) || device_phase) && (storage_mode != 0x01) && (storage_mode != 0x02) && (getenv("LDP_DEBUG_HOST_DECODE") == nullptr);
-    device_multi = device_decode && all_founders && !A.pairphase;
+    // (records with several ALT alleles are collapsed on the device as well: over the file's samples, or over the founders when the
+    // engines pick those through a subset sample map)
+    device_multi = device_decode && (all_founders || device_subset) && !A.pairphase;
     uint64_t file_size = 0;
     const void* file_bytes = device_decode ? ldp_pgen_file_bytes(pg, &file_size) : nullptr;
     std::vector<ldp_pgen_rec> rec_index;

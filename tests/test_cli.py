@@ -193,6 +193,36 @@ def test_cli_multiallelic_collapse_matches_reference(gpu_pkg, cli, tmp_path, max
     assert 0 < len(open(str(tmp_path / "hip.prune.out")).read().split()) < m
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_alt,wargs,nonfounder_every", [(3, ["30kb"], 3), (6, ["60", "5"], 2), (2, ["20kb"], 7)])
+def test_cli_multiallelic_collapse_over_the_founders_matches_reference(gpu_pkg, cli, tmp_path, max_alt, wargs, nonfounder_every):
+    """The same with non-founders in the file: the engines pick the founder columns through a subset sample map and the collapse's
+    allele counts run over the founders -- on the device (pgen_aux1_kernel with the map's mask; `--timing` says how many variants took
+    which way), byte-identical lists to the reference's."""
+    from test_pgen_reader import make_multiallelic_vcf
+    assert T.have_ref()
+    m, n = 600, 170
+    make_multiallelic_vcf(str(tmp_path / "m.vcf"), m, n, seed=10 + max_alt, max_alt=max_alt, missing=0.04)
+    mk = T.run_ref(["--vcf", "m.vcf", "--make-pgen", "--out", "mv"], str(tmp_path))
+    assert mk.returncode == 0, mk.stdout
+    psam = ["#IID\tPAT\tMAT\tSEX"]
+    for s_ in range(n):
+        nf = (s_ % nonfounder_every == 1) and s_ > 3
+        psam.append("s%d\t%s\t%s\t%d" % (s_, "s0" if nf else "0", "s2" if nf else "0", 1 + (s_ % 2)))
+    open(str(tmp_path / "mv.psam"), "w").write("\n".join(psam) + "\n")
+    common = ["--pfile", "mv", "--indep-pairwise"] + wargs + ["0.1"]
+    ref = T.run_ref(common + ["--threads", "2", "--out", "ref"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    got = run_cli(cli, common + ["--timing", "--out", "hip"], str(tmp_path))
+    assert got.returncode == 0, got.stdout
+    assert filecmp.cmp(str(tmp_path / "ref.prune.in"), str(tmp_path / "hip.prune.in"), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "ref.prune.out"), str(tmp_path / "hip.prune.out"), shallow=False)
+    assert 0 < len(open(str(tmp_path / "hip.prune.out")).read().split()) < m
+    import re
+    line = re.search(r"host-built rows: (\d+) multiallelic \((\d+) more have REF as the major allele: main track as loaded; (\d+) collapsed on the device\)", got.stdout)
+    assert line and int(line.group(1)) == 0 and int(line.group(3)) > 50, got.stdout[-600:]
+
+
 def sexed_fileset(tmp_path, m=900, n=140, seed=5, nonfounders=6, unknown_sex=True):
     """Autosomes + chrX + chrY + MT, males/females/unknown sex, a few non-founders."""
     raw = T.synth_raw_codes(m, n, seed, missing_rate=0.04)

@@ -261,10 +261,60 @@ def test_records_of_a_file_with_more_samples_than_founders(gpu_pkg, tmp_path):
     dev.load_pgen_records(0, f)
     assert_same_rows(host, dev, m)
     assert np.array_equal(host.run(), dev.run())
-    # allele_ct > 2 needs the file's samples to be the engine's
+    # allele_ct > 2 under a map that is not a plain subset of the file's samples (a sample twice: the chrX layouts): refused
+    twice = engine(pkg, n + 1, m)
+    twice.set_sample_map(raw_n, np.concatenate([keep, keep[:1]]).astype(np.uint32))
     with pytest.raises(pkg.LdpError) as ei:
-        dev.load_pgen_records(0, f, allele_cts=np.full(m, 3))
+        twice.load_pgen_records(0, f, allele_cts=np.full(m, 3))
     assert ei.value.code == pkg.LDP_ERR_UNSUPPORTED
+    f.close()
+
+
+@pytest.mark.skipif(not T.have_ref(), reason="reference binary not built")
+@pytest.mark.parametrize("m,raw_n,seed,max_alt,keep_frac", [(120, 130, 21, 3, 0.7), (90, 400, 22, 6, 0.5), (60, 5000, 23, 4, 0.9), (70, 64, 24, 2, 0.3)])
+def test_multiallelic_collapse_over_a_subset_of_the_files_samples(gpu_pkg, tmp_path, m, raw_n, seed, max_alt, keep_frac):
+    """Founders among non-founders: the engine's samples are a subset of the file's (ldp_set_sample_map without repeats), and the allele
+    counts that choose a multiallelic variant's major allele run over THEM (the allele-frequency pass counts founders,
+    plink2_filter.cc:2113-2153) -- pgen_aux1_kernel with a sample mask, against the numpy collapse of the reader's allele pairs over
+    the same samples; the major allele differs from the whole file's for some variants by construction (a small subset)."""
+    pkg = gpu_pkg
+    alt_ct, lo, hi = make_multiallelic_vcf(str(tmp_path / "m.vcf"), m, raw_n, seed, max_alt=max_alt, missing=0.03 if raw_n < 1000 else 0.002)
+    cp = T.run_ref(["--vcf", "m.vcf", "--make-pgen", "--out", "mv"], str(tmp_path))
+    assert cp.returncode == 0, cp.stdout
+    f = pkg.PgenFile(str(tmp_path / "mv.pgen"))
+    keep = np.flatnonzero(np.random.default_rng(seed).random(raw_n) < keep_frac).astype(np.uint32)
+    n = len(keep)
+    rows = f.read()
+    host = engine(pkg, n, m)
+    want_maj = np.full(m, 0xffffffff, dtype=np.uint32)
+    whole_maj = np.full(m, 0xffffffff, dtype=np.uint32)
+    for v in range(m):
+        glo, ghi = f.read_alleles(v, int(alt_ct[v])) if alt_ct[v] > 1 else (None, None)
+        if alt_ct[v] > 1:
+            c, maj, mf = collapse(glo[keep], ghi[keep], int(alt_ct[v]))
+            want_maj[v] = maj
+            whole_maj[v] = collapse(glo, ghi, int(alt_ct[v]))[1]
+            packed = np.ascontiguousarray(T.pack_2bit(c[None, :]).view(np.uint8).reshape(1, -1)[:, :(n + 3) // 4])
+            host.load_genotypes_host(v, packed, pkg.LDP_GENO_INVERSE)
+            host.set_maj_freqs(v, np.array([mf]))
+        else:
+            codes = ((rows[v][:, None] >> np.array([0, 2, 4, 6], dtype=np.uint8)) & 3).reshape(-1)[:raw_n][keep].astype(np.uint8)
+            packed = np.ascontiguousarray(T.pack_2bit(codes[None, :]).view(np.uint8).reshape(1, -1)[:, :(n + 3) // 4])
+            host.load_genotypes_host(v, packed, pkg.LDP_GENO_REF)
+    dev = engine(pkg, n, m)
+    dev.set_sample_map(raw_n, keep)
+    got_maj = dev.load_pgen_records(0, f, allele_cts=alt_ct + 1)
+    assert np.array_equal(got_maj, want_maj)
+    if keep_frac <= 0.5:
+        assert (want_maj != whole_maj).any()          # (the subset's major allele is not always the file's)
+    assert_same_rows(host, dev, m)
+    assert np.array_equal(host.run(), dev.run())
+    # in pieces, and after the device copies were released (the mask is rebuilt from the host's map)
+    dev2 = engine(pkg, n, m)
+    dev2.set_sample_map(raw_n, keep)
+    for a, b in [(0, 7), (7, m // 2), (m // 2, m)]:
+        dev2.load_pgen_records(a, f, a, b - a, allele_cts=(alt_ct + 1)[a:b])
+    assert_same_rows(host, dev2, m)
     f.close()
 
 
