@@ -787,6 +787,8 @@ def main():
                 L["missing_rate_%g" % rate] = {k: M[k] for k in ("ms_per_step", "pair_kernels_ms", "kernel", "routes", "pairs_counted_exactly", "variants_removed")}
                 L["missing_rate_%g" % rate]["vs_complete_data_step"] = M["ms_per_step"] / L["ms_per_step"]
                 L["missing_rate_%g" % rate]["mfma"] = M["roofline"]["mfma"]
+                for key in ("traffic", "traffic_over_compulsory", "traffic_source"):   # (replayed like the main leg's: profiles/*_pmc_traffic.json of this workload)
+                    L["missing_rate_%g" % rate][key] = M["roofline"][key]
             if not args.no_cpu_baseline:
                 L["cpu_baseline"] = cpu_baseline(pkg, torch, c2["samples"], 440000, c2["spacing"], c2["window_kb"], c2["r2"], 0.0, cli_compare=not args.no_cli_compare)
             legs["config2"] = L
