@@ -637,12 +637,22 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback exists for the hot path)")
+    # LDP_BENCH_ALIAS_DEVICES=1 (tests, one-GPU boxes): the N ranks of `--gpus N` share the devices there are, and the exchange goes
+    # over gloo (RCCL refuses a device twice) -- the rank / shard / exchange code of the N-GPU line runs, its numbers are NOT a
+    # measurement of N GPUs and the line says so
+    alias = bool(os.environ.get("LDP_BENCH_ALIAS_DEVICES")) and (world > 1)
+    if alias:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     # under torch.distributed.run the RCCL path is used even for a single rank, so the exchange code is
     # exercised on a 1-GPU box as well
     use_dist = (world > 1) or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    coll_device = "cpu" if alias else "cuda"
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if alias:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     name = args.workload
     cfg = dict(CONFIGS[name])
@@ -671,7 +681,7 @@ def main():
             words, ctrs = wl.step()
             if use_dist:
                 # the one exchange step: all_gather of the per-rank removed bitmaps (RCCL over xGMI), OR-ed on the device
-                return distmod.allgather_bitmaps(words, world, device="cuda"), ctrs
+                return distmod.allgather_bitmaps(words, world, device=coll_device), ctrs
             return words, ctrs
         for _ in range(warmup):
             one()
@@ -701,10 +711,10 @@ def main():
     removed = distmod.bitmap_to_mask(removed.cpu().numpy() if use_dist else removed, cfg["variants"])
     per_rank_pairs = [ctr["candidate_pairs"]]
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mine = torch.tensor([ctr["candidate_pairs"]], dtype=torch.int64, device="cuda")
+        mine = torch.tensor([ctr["candidate_pairs"]], dtype=torch.int64, device=coll_device)
         allp = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allp, mine)
         per_rank_pairs = [int(x.item()) for x in allp]
@@ -722,8 +732,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": dtype_of(roofline),
-            "data": "synthetic" if wl.resident else "model (synthetic shapes; a rank's share exceeds HBM, so every chromosome of it is a copy of ONE generated chromosome: NOT a measurement "
-                                                    "of the named workload)",
+            "data": ("model (LDP_BENCH_ALIAS_DEVICES: %d ranks share %d device(s), gloo exchange: the N-rank code path runs, its numbers are NOT a measurement of %d GPUs)"
+                     % (world, torch.cuda.device_count(), world)) if alias else
+                    ("synthetic" if wl.resident else "model (synthetic shapes; a rank's share exceeds HBM, so every chromosome of it is a copy of ONE generated chromosome: NOT a "
+                                                     "measurement of the named workload)"),
             "config": {"workload": "%s: synthetic %d samples x %d biallelic variants (%s), one genome of 22 autosomes at %d bp spacing, "
                                    "--indep-pairwise %gkb %g, missing rate %g, chromosomes LPT-sharded over %d rank(s); %s" %
                                    (name, cfg["samples"], cfg["variants"], "total, strong scaling" if strong else "%d per GPU, weak scaling" % per_gpu_variants,

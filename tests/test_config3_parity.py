@@ -73,6 +73,28 @@ def test_bench_step_under_torchrun_initialises_rccl(gpu_pkg, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_n_ranks_on_one_device(gpu_pkg, tmp_path, world):
+    """bench.py's own N-rank line on a one-GPU box (LDP_BENCH_ALIAS_DEVICES=1: the ranks share the device, gloo carries the exchange): the
+    rank / LPT shard / all-gather code of `--gpus N` runs under torch.distributed.run, the line is labelled a model, and the stitched
+    prune set has as many variants as the single-rank run over the same total workload (strong scaling: the same genome)."""
+    env = dict(os.environ, LDP_BENCH_ALIAS_DEVICES="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    common = ["--steps", "2", "--warmup", "1", "--workload", "config2", "--variants", "90000", "--samples", "20000", "--strong", "--no-cpu-baseline", "--no-legs"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(29590 + world),
+           os.path.join(REPO, "bench.py"), "--gpus", str(world)] + common
+    cp = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    j = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == world and j["scaling"] == "strong" and j["value"] > 0 and j["data"].startswith("model (LDP_BENCH_ALIAS_DEVICES")
+    cp1 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + common, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert cp1.returncode == 0, cp1.stderr[-2000:]
+    j1 = json.loads([ln for ln in cp1.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j1["n_gpus"] == 1 and j1["config"]["variants_removed"] == j["config"]["variants_removed"] > 0
+    assert j["config"]["candidate_pairs_total"] == j1["config"]["candidate_pairs_total"] and len(j["config"]["candidate_pairs_per_rank"]) == world
+
+
+@pytest.mark.gpu
 def test_bench_share_that_does_not_fit_hbm(gpu_pkg):
     """bench.py's non-resident mode (a rank's share of config 3 at N = 2 / 4 exceeds HBM): forced here with a small HBM limit.
     One engine per chromosome, rows copied from one resident chromosome's worth of generated rows inside the step; every chromosome
