@@ -385,39 +385,69 @@ def test_wide_band_with_missing_calls_falls_back_to_the_parallelogram_kernels(gp
         assert np.array_equal(got, want)
 
 
+_RCCL_ONE_RANK = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {repo!r})
+sys.path.insert(0, {tests!r})
+import __graft_entry__ as ge
+import ldtools as T
+from test_host_logic import make_positions
+pkg = ge.load_package()
+m, n = 900, 200
+raw = T.synth_raw_codes(m, n, seed=5, missing_rate=0.01)
+chr_idx, bps = make_positions(m, 5, 3)
+eng = pkg.LdPruneEngine(n, 20000, 1, True, 0.2, device=0)
+eng.set_variants(chr_idx, bps)
+eng.set_shard(0, 1)
+eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+words = eng.run_bitmap()
+comm = pkg.comm_init_all([0])[0]
+try:
+    out = eng.allgather_removed(comm, words)
+finally:
+    pkg.comm_destroy(comm)
+nw = (m + 63) // 64
+assert np.array_equal(out[:nw], words[:nw]) and int(np.unpackbits(words[:nw].view(np.uint8)).sum()) > 50
+# a communicator whose size does not match the shard is refused (and aborted: a rank that cannot enter the collective must not leave
+# its peers waiting)
+eng2 = pkg.LdPruneEngine(n, 20000, 1, True, 0.2, device=0)
+eng2.set_variants(chr_idx, bps)
+eng2.set_shard(1, 2)
+comm = pkg.comm_init_all([0])[0]
+refused = False
+try:
+    eng2.allgather_removed(comm, words)
+except pkg.LdpError:
+    refused = True
+finally:
+    pkg.comm_destroy(comm)   # (a no-op on the aborted communicator)
+assert refused
+# ... and RCCL still works afterwards in the same process
+comm = pkg.comm_init_all([0])[0]
+out = eng.allgather_removed(comm, words)
+pkg.comm_destroy(comm)
+assert np.array_equal(out[:nw], words[:nw])
+eng.close()
+eng2.close()
+print("rccl one rank: ok")
+"""
+
+
 def test_rccl_allgather_from_the_c_abi_with_one_rank(gpu_pkg):
     """ldp_allgather_removed: the one exchange step of a multi-GPU prune driven from a C/C++ host -- segments in shard order,
     ONE ncclAllGather on device buffers, stitched into global variant order.  One rank here (the box has one GPU): RCCL is
-    bound and initialised, the collective runs, and the result is the rank's own bitmap.  (The two-rank stitch is covered on
-    the CPU: tests/test_distributed_gloo.py.)"""
-    pkg = gpu_pkg
-    m, n = 900, 200
-    raw = T.synth_raw_codes(m, n, seed=5, missing_rate=0.01)
-    chr_idx, bps = make_positions(m, 5, 3)
-    eng = pkg.LdPruneEngine(n, 20000, 1, True, 0.2, device=0)
-    eng.set_variants(chr_idx, bps)
-    eng.set_shard(0, 1)
-    eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
-    words = eng.run_bitmap()
-    comm = pkg.comm_init_all([0])[0]
-    try:
-        out = eng.allgather_removed(comm, words)
-    finally:
-        pkg.comm_destroy(comm)
-    nw = (m + 63) // 64
-    assert np.array_equal(out[:nw], words[:nw]) and int(np.unpackbits(words[:nw].view(np.uint8)).sum()) > 50
-    # a communicator whose size does not match the shard is refused
-    eng2 = pkg.LdPruneEngine(n, 20000, 1, True, 0.2, device=0)
-    eng2.set_variants(chr_idx, bps)
-    eng2.set_shard(1, 2)
-    comm = pkg.comm_init_all([0])[0]
-    try:
-        with pytest.raises(pkg.LdpError):
-            eng2.allgather_removed(comm, words)
-    finally:
-        pkg.comm_destroy(comm)
-    eng.close()
-    eng2.close()
+    bound and initialised, the collective runs, and the result is the rank's own bitmap; a mismatched communicator is refused and
+    aborted.  (The two-rank stitch is covered on the CPU: tests/test_distributed_gloo.py.)  In a process of its own: an aborted
+    communicator's helper threads have no business inside the test runner."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cp = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK.format(repo=os.path.dirname(here), tests=here)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                        timeout=600, env=env)
+    assert cp.returncode == 0 and "rccl one rank: ok" in cp.stdout, (cp.stdout[-500:], cp.stderr[-1500:])
 
 
 def test_device_pointer_input(gpu_pkg):
