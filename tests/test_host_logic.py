@@ -412,3 +412,43 @@ def test_segment_pack_and_stitch_of_the_c_abi(pkg, world):
         full = eng.stitch_removed_segments(segs)
         assert np.array_equal(distmod.bitmap_to_mask(full, m), truth)
         eng.close()
+
+
+def test_operand_coding_identities_of_the_matrix_pipe_kernels():
+    """The integer identities the FP4 operand codings rest on (plink-ng_amd/csrc/ldp_mfma_device.h), restated in numpy on random
+    rows -- the kernels themselves are pinned on the GPU, this pins the algebra where no GPU is needed.
+    Complete rows: G = sum g_i g_j over the samples VISITED (padding coded 11 = 3) gives dot = G - g_bias + S_i + S_j with
+    g_bias = N + 9 (visited - N).  Rows with missing calls: the accumulators of g' (the code, 3 at a missing call) and u (missing flag)
+    give dot, nm, sum1, sum2 over the pairwise-complete samples through x_from_gu."""
+    rng = np.random.default_rng(17)
+    for n, stage in [(1000, 256), (513, 512), (77, 256), (4096, 512)]:
+        visited = ((n + stage - 1) // stage) * stage
+        # ---- complete rows
+        gi = rng.integers(0, 3, size=n)
+        gj = np.where(rng.random(n) < 0.6, gi, rng.integers(0, 3, size=n))
+        pad = np.full(visited - n, 3)
+        G = int(np.dot(np.concatenate([gi, pad]), np.concatenate([gj, pad])))
+        xi, xj = 1 - gi, 1 - gj
+        g_bias = n + 9 * (visited - n)
+        assert G - g_bias + int(xi.sum()) + int(xj.sum()) == int(np.dot(xi, xj))
+        # ---- rows with missing calls (code 3): g' = code, u = (code == 3)
+        ci = np.where(rng.random(n) < 0.07, 3, gi)
+        cj = np.where(rng.random(n) < 0.05, 3, gj)
+        gpi, gpj = np.concatenate([ci, pad]), np.concatenate([cj, pad])
+        ui, uj = (gpi == 3).astype(np.int64), (gpj == 3).astype(np.int64)
+        P1, P4, P3, P2 = int(np.dot(gpi, gpj)), int(np.dot(ui, uj)), int(np.dot(ui, gpj)), int(np.dot(gpi, uj))
+        n_pad = visited - n
+        # each row's own missing count U and allele sum Z over its calls among the n real samples
+        Ui, Uj = int((ci == 3).sum()), int((cj == 3).sum())
+        Zi, Zj = int(ci[ci != 3].sum()), int(cj[cj != 3].sum())
+        uu = P4 - n_pad
+        zu, uz = P2 - 3 * P4, P3 - 3 * P4
+        zz = P1 - 3 * P2 - 3 * P3 + 9 * P4
+        nm = n - Ui - Uj + uu
+        S1, S2 = Zi - zu, Zj - uz
+        sum1, sum2, dot = nm - S1, nm - S2, nm - S1 - S2 + zz
+        both = (ci != 3) & (cj != 3)
+        x1, x2 = (1 - ci)[both], (1 - cj)[both]
+        assert (nm, sum1, sum2, dot) == (int(both.sum()), int(x1.sum()), int(x2.sum()), int(np.dot(x1, x2)))
+        # exactness in f32 accumulators: the largest accumulator stays below 2^24 at the engine limits
+    assert 4 * 4000000 + 9 * 511 < 2 ** 24 and 9 * (1800000 + 511) < 2 ** 24
