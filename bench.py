@@ -467,7 +467,7 @@ def pmc_traffic(founder_ct, variants, window_kb, missing_rate):
     return None, None, None
 
 
-def pair_roofline(c, founder_ct, local_ct, missing_rate, variants, window_kb):
+def pair_roofline(c, founder_ct, local_ct, missing_rate, variants, window_kb, options=None):
     kms_mfma, kms_gen = c["ms_pair_mfma"], c["ms_pair_mfma_general"]
     general = c["route_general_launches"] > 0
     kms_valu = c["ms_pair_fast"] + c["ms_pair_general"]
@@ -479,8 +479,8 @@ def pair_roofline(c, founder_ct, local_ct, missing_rate, variants, window_kb):
     launches = max(int(c["pair_kernel_launches"]), 1)
     # MFMA side: instructions the kernel really issued.  One block product = 32 x 32 pairs; one k-step = one
     # v_mfma_scale_f32_32x32x64_f8f6f4 = 65,536 MACs; the missing-call kernels issue four per block product and k-step on prune
-    # launches (six with LDP_PAIR_FOUR=0).
-    per_product = (6 if os.environ.get("LDP_PAIR_FOUR") == "0" else 4) if general else 1
+    # launches (six with the engine option pair_four = 0).
+    per_product = (6 if (options or {}).get("pair_four", 1) == 0 else 4) if general else 1
     executed = (max(c["mfma_product_stages"] - c["mfma_skipped_product_stages"], 0) + c["mfma_extra_product_stages"]) * per_product
     mfma_tflops = (executed * 65536 * 2.0 / (kms * 1e-3)) / 1e12 if (kms > 0 and on_matrix_pipe) else 0.0
     # HBM side: every owned row must be read once (N/4 bytes per variant, rows padded to 64 bytes)
@@ -726,7 +726,7 @@ def main():
         cmean = {k: mean(k) for k in ks[-1]}
         ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
         value = total_pairs * args.steps / elapsed
-        roofline = pair_roofline(cmean, cfg["samples"], wl.local_ct, args.missing_rate, wl.local_ct, cfg["window_kb"])
+        roofline = pair_roofline(cmean, cfg["samples"], wl.local_ct, args.missing_rate, wl.local_ct, cfg["window_kb"], main_options)
         out = {
             "metric": "variant-pairs/s (--indep-pairwise, whole job)", "value": value, "unit": "variant-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -764,7 +764,7 @@ def main():
             w = Workload(pkg, torch, cfg_l, missing, 0, 1, local_rank, options, multiallelic)
             el, kk, rem = timed(w, steps, 1)
             c = {k: float(np.mean([q[k] for q in kk])) for k in kk[-1]}
-            r = pair_roofline(c, cfg_l["samples"], w.local_ct, missing, cfg_l["variants"], cfg_l["window_kb"])
+            r = pair_roofline(c, cfg_l["samples"], w.local_ct, missing, cfg_l["variants"], cfg_l["window_kb"], options)
             res = {"ms_per_step": 1000.0 * el / steps, "pairs_per_s": c["candidate_pairs"] * steps / el, "count_pass_ms": c["ms_prepare"], "pair_kernels_ms": c["ms_pair_kernel"],
                    "kernel": r["kernel"], "routes": r["routes"], "pairs_counted_exactly": int(c["sparse_exact_pairs"]), "candidate_pairs": int(c["candidate_pairs"]),
                    "variants_removed": int(distmod.bitmap_to_mask(rem, cfg_l["variants"]).sum()), "roofline": r, "stage_ms": stage_ms(c, w.image_bytes)}

@@ -19,9 +19,9 @@ extern "C" {
  * touched: this is how the host logic is tested on a CPU-only machine. */
 int ldp_debug_set_variant_recs(ldp_engine* e, const ldp_variant_rec* recs);
 int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first, const uint32_t* second, uint64_t* removed);
-/* Kernel-selection switches of ONE engine, for tests and measurements (the defaults are what production runs use; they can also
- * be preset from the environment at ldp_create(): LDP_EARLY_EXIT, LDP_PAIR_MFMA, LDP_PAIR_SPARSE, LDP_PAIR_FOUR, LDP_PAIR_FOUR_TILES, LDP_DEBUG_SPARSE_FRAC,
- * LDP_DEBUG_WIDE_MIN_REACH).  name:
+/* Kernel-selection switches of ONE engine, for tests and measurements (the defaults are what production runs use).  The shipped
+ * library reads NO environment variable (csrc/ldp_env.h): this call is the only way to switch anything, engine by engine; only the
+ * measurement build (-DLDP_MEASURE, lib/libldprune_hip_measure.so, tools/) presets them from LDP_* variables.  name:
  *   "early_exit"      0/1: checkpoints that drop provably sub-threshold products
  *   "pair_mfma"       0/1: matrix-pipe kernels on the 2-bit code image; 0 = the popcount kernels on bit-planes (before ldp_set_variants*())
  *   "pair_sparse"     0/1: the interval epilogue for rows with a few missing calls
@@ -37,8 +37,15 @@ int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first
  *                     before ldp_set_variants())
  *   "wide_min_reach"  row-blocks a subcontig's band must reach to take the 8 x 8 tile plan of the wide-band kernel; 0 = always,
  *                     a huge value = never (before ldp_set_variants())
+ *   "replay_steps"    k: ldp_debug_replay_pairs() walks every subcontig in k instalments, the way the streaming replay of a run advances
+ *   "decode_rows"     k: ldp_load_pgen_records*() decode in launches of k rows (LD chains cut everywhere)
+ *   "decode_no_lds"   0/1: decoded rows are assembled in global memory (what rows beyond 128 KiB take) instead of LDS
+ *   "x_rows"          k: ldp_r2_unphased_block_x*() work in chunks of k rows
  * Results never depend on these.  Unknown name: LDP_ERR_INVALID. */
 int ldp_debug_set_option(ldp_engine* e, const char* name, double value);
+/* The .pgen reader's phase / subset routines use pext / pdep where the host has BMI2; on != 0 forces the portable loops for the whole
+ * process (a test hook: both give the same bytes). */
+int ldp_pgen_debug_force_portable(int on);
 /* Host-only view of the matrix-pipe work plan (csrc/ldp_device.h: MfmaWG) in the engine's shard-local variant
  * indices, for the CPU test that every candidate pair is owned by exactly one 32 x 32 block product.  Per workgroup
  * 63 words: n_rb (bit 31: see ldp_debug_wide_plan; bit 30: every wave item is diagonal), j_lo, j_hi, rb[16], then per wave jv, vv, jend, prod_mask, slot[7].  lo_local (optional, *local_ct

@@ -20,6 +20,9 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 BIN_DIR = os.path.join(_HERE, "bin")
 LIB_PATH = os.path.join(LIB_DIR, "libldprune_hip.so")
+# the measurement build (-DLDP_MEASURE, csrc/ldp_env.h): environment presets, timing prints and the ablation kernels of tools/ --
+# never loaded by tests/, bench.py's default run or plink2-hip; LDP_LIB_MEASURE=1 makes lib() load it (tools/attribution.py)
+MEASURE_LIB_PATH = os.path.join(LIB_DIR, "libldprune_hip_measure.so")
 CLI_PATH = os.path.join(BIN_DIR, "plink2-hip")
 
 LDP_OK, LDP_ERR_INVALID, LDP_ERR_NOMEM, LDP_ERR_GPU, LDP_ERR_STATE, LDP_ERR_UNSUPPORTED = range(6)
@@ -96,7 +99,7 @@ CABI_SYMBOLS = [
     "ldp_set_variants_matrix", "ldp_r2_unphased_rows", "ldp_r2_unphased_hits", "ldp_r2_unphased_block", "ldp_r2_unphased_block_hits", "ldp_r2_unphased_block_x", "ldp_r2_unphased_block_x_hits", "ldp_pair_stats_block", "ldp_set_variants_vcor", "ldp_r2_unphased_band_rows",
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_has_dosage", "ldp_pgen_variant_has_dosage", "ldp_pgen_dosage_sums", "ldp_pgen_direct_rows", "ldp_pgen_direct_fd", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
     "ldp_pgen_variant_is_multiallelic", "ldp_pgen_provisional_ref", "ldp_pgen_open_indexed", "ldp_set_r_signed", "ldp_set_variants_vcor_cm", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_subset_samples", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
-    "ldp_debug_set_option", "ldp_matrix_pipe_max_founders", "ldp_map_rows", "ldp_release_device", "ldp_debug_wide_plan",
+    "ldp_debug_set_option", "ldp_pgen_debug_force_portable", "ldp_matrix_pipe_max_founders", "ldp_map_rows", "ldp_release_device", "ldp_debug_wide_plan",
     "ldp_allgather_removed", "ldp_comm_init_all", "ldp_comm_destroy", "ldp_shard_segment_words", "ldp_pack_removed_segment", "ldp_stitch_removed_segments", "ldp_load_pgen_records", "ldp_load_pgen_records_phased", "ldp_pgen_file_bytes", "ldp_pgen_record_index",
 ]
 
@@ -113,16 +116,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
+def build_library(force=False, verbose=False, measure=False):
     """Compile the HIP kernels + host runtime into lib/libldprune_hip.so for gfx950 (hipcc cross-compiles
     without a GPU).  In-tree so the .so travels with the repo snapshot.  One object per source under lib/_obj/, stale ones
-    recompiled in parallel, then one link."""
+    recompiled in parallel, then one link.  measure=True: the measurement build, lib/libldprune_hip_measure.so (-DLDP_MEASURE)."""
     headers = [os.path.join(CSRC, "ldp_device.h"), os.path.join(CSRC, "ldp_pair_device.h"), os.path.join(CSRC, "ldp_mfma_device.h"),
+               os.path.join(CSRC, "ldp_env.h"), os.path.join(CSRC, "ldp_engine_internal.h"),
                os.path.join(REPO, "include", "ldprune_hip.h"), os.path.join(REPO, "include", "ldprune_hip_debug.h")]
     headers = [h for h in headers if os.path.exists(h)]
-    if not force and not _stale(LIB_PATH, _sources() + headers):
-        return LIB_PATH  # (a snapshot on the GPU box carries the library but not the objects: nothing to do there)
-    obj_dir = os.path.join(LIB_DIR, "_obj")
+    lib_path = MEASURE_LIB_PATH if measure else LIB_PATH
+    flags = HIPCC_FLAGS + (["-DLDP_MEASURE"] if measure else [])
+    if not force and not _stale(lib_path, _sources() + headers):
+        return lib_path  # (a snapshot on the GPU box carries the library but not the objects: nothing to do there)
+    obj_dir = os.path.join(LIB_DIR, "_obj_measure" if measure else "_obj")
     os.makedirs(obj_dir, exist_ok=True)
     objs, todo = [], []
     for src in _sources():
@@ -132,7 +138,7 @@ def build_library(force=False, verbose=False):
             todo.append((src, obj))
 
     def compile_one(job):
-        cmd = ["hipcc"] + HIPCC_FLAGS + ["-c", job[0], "-o", job[1]]
+        cmd = ["hipcc"] + flags + ["-c", job[0], "-o", job[1]]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -141,12 +147,12 @@ def build_library(force=False, verbose=False):
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1)) as pool:
             list(pool.map(compile_one, todo))
-    if todo or force or _stale(LIB_PATH, objs):
-        cmd = ["hipcc"] + HIPCC_FLAGS + ["-shared", "-o", LIB_PATH] + objs
+    if todo or force or _stale(lib_path, objs):
+        cmd = ["hipcc"] + flags + ["-shared", "-o", lib_path] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib_path
 
 
 def build_cli(force=False, verbose=False):
@@ -173,13 +179,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise LdpError(LDP_ERR_GPU, "HIP extension %s is missing; run __graft_entry__.build()" % LIB_PATH)
+    path = MEASURE_LIB_PATH if os.environ.get("LDP_LIB_MEASURE") == "1" else LIB_PATH
+    if not os.path.exists(path):
+        raise LdpError(LDP_ERR_GPU, "HIP extension %s is missing; run __graft_entry__.build()" % path)
     try:
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is optional plumbing
         pass
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(path)
     vp = ctypes.c_void_p
     u32p = ctypes.POINTER(ctypes.c_uint32)
     u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -224,6 +231,7 @@ def lib():
     L.ldp_matrix_pipe_max_founders.argtypes = []
     L.ldp_matrix_pipe_max_founders.restype = ctypes.c_uint32
     L.ldp_debug_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_double]
+    L.ldp_pgen_debug_force_portable.argtypes = [ctypes.c_int]
     L.ldp_debug_mfma_plan.argtypes = [vp, u32p, u32p, ctypes.c_uint64, u32p, u32p]
     L.ldp_get_variant_recs.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, vp]
     L.ldp_get_maj_freqs.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, f64p]
@@ -526,7 +534,8 @@ class LdPruneEngine:
 
     def set_option(self, name, value):
         """Kernel-selection switch of this engine (ldp_debug_set_option): 'early_exit', 'pair_mfma' (before set_variants),
-        'mfma_general', 'pair_sparse', 'sparse_frac'.  Results never depend on them."""
+        'pair_sparse', 'sparse_frac', ... and the test hooks 'replay_steps', 'decode_rows', 'decode_no_lds', 'x_rows' (include/ldprune_hip_debug.h).
+        Results never depend on them."""
         self._ck(self._L.ldp_debug_set_option(self._h, name.encode(), float(value)))
         return self
 

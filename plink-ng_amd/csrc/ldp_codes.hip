@@ -461,7 +461,7 @@ hipError_t launch_codes(const PrepareArgs& a, hipStream_t stream) {
   const uint64_t units = a.code_row_bytes / 16;
   // the geometry prepare_kernel was tuned to (config 2: 128 x 7 best; N = 500,000: 512 x 16), a unit = 64 samples in both
 #define LDP_CODES(T, I) hipLaunchKernelGGL((codes_kernel<T, I>), dim3(a.n_variants), dim3(T), 0, stream, a)
-  if (const char* shape = getenv("LDP_DEBUG_CODES_SHAPE")) {  // tuning aid: "64x13", "128x7nt", "256x4", "256x4nt"
+  if (const char* shape = LDP_ENV("LDP_DEBUG_CODES_SHAPE")) {  // tuning aid: "64x13", "128x7nt", "256x4", "256x4nt"
     const std::string sh(shape);
     if ((sh == "64x13") && (units <= 64 * 13)) {
       hipLaunchKernelGGL((codes_kernel<64, 13>), dim3(a.n_variants), dim3(64), 0, stream, a);

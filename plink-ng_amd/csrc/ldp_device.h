@@ -8,6 +8,7 @@
 
 #include "../../include/ldprune_hip.h"
 #include "../../include/ldprune_hip_debug.h"
+#include "ldp_env.h"
 
 namespace ldp {
 
@@ -285,6 +286,7 @@ struct PgenDecodeArgs {
   // --indep-pairphase: the hardcall-phase track decoded into the rows' second part (LDP_GENO_PHASED layout); 0 = not wanted
   uint64_t phase_off;           // byte offset of the phase bits inside a row (a multiple of 4, < stride)
   uint32_t* unphased;           // out: lowest record index with a het call that has no phase (atomicMin; preset to UINT32_MAX)
+  int no_lds;                   // (test hook, option "decode_no_lds") assemble rows in global memory whatever their size
 };
 hipError_t launch_pgen_main(const PgenDecodeArgs& a, hipStream_t stream);
 // the phase tracks of records [0, n_records) on top of their decoded main tracks (after launch_pgen_main on the same stream)

@@ -19,7 +19,7 @@ namespace ldph LDP_HIDDEN {
 // they are through the sooner the host has the per-variant records it needs to start replaying finished groups.
 hipError_t create_stream(hipStream_t* out, bool high_priority) {
   int lo = 0, hi = 0;
-  static const bool flat = (getenv("LDP_STREAM_PRIORITY") != nullptr) && (strcmp(getenv("LDP_STREAM_PRIORITY"), "0") == 0);
+  static const bool flat = (LDP_ENV("LDP_STREAM_PRIORITY") != nullptr) && (strcmp(LDP_ENV("LDP_STREAM_PRIORITY"), "0") == 0);
   if (flat || (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) || (lo == hi)) {
     (void)hipGetLastError();
     return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
@@ -287,20 +287,20 @@ void plan_subcontig(const ldp_engine* e, const Subcontig& s, std::vector<uint32_
 // ~sqrt(thresh): checkpoint fractions start just past 1 - sqrt(thresh) and spread out from there.
 EngineOptions options_from_env() {
   EngineOptions o;
-  const char* ee = getenv("LDP_EARLY_EXIT");
+  const char* ee = LDP_ENV("LDP_EARLY_EXIT");
   o.early_exit = !(ee && (strcmp(ee, "0") == 0));
-  const char* m = getenv("LDP_PAIR_MFMA");
+  const char* m = LDP_ENV("LDP_PAIR_MFMA");
   o.pair_mfma = !(m && (strcmp(m, "0") == 0));
-  const char* off = getenv("LDP_PAIR_SPARSE");
-  const char* f = getenv("LDP_DEBUG_SPARSE_FRAC");
+  const char* off = LDP_ENV("LDP_PAIR_SPARSE");
+  const char* f = LDP_ENV("LDP_DEBUG_SPARSE_FRAC");
   o.sparse_frac = (off && (strcmp(off, "0") == 0)) ? 0.0 : (f ? atof(f) : 0.005);
-  const char* four = getenv("LDP_PAIR_FOUR");
+  const char* four = LDP_ENV("LDP_PAIR_FOUR");
   o.pair_four = !(four && (strcmp(four, "0") == 0));
-  const char* ft = getenv("LDP_PAIR_FOUR_TILES");
+  const char* ft = LDP_ENV("LDP_PAIR_FOUR_TILES");
   o.four_tiles = !(ft && (strcmp(ft, "0") == 0));
-  const char* dl = getenv("LDP_DEBUG_WIDE_DIAG_LAST");
+  const char* dl = LDP_ENV("LDP_DEBUG_WIDE_DIAG_LAST");
   o.wide_diag_last = dl ? static_cast<uint32_t>(std::max(0, atoi(dl))) : 2u;
-  if (const char* w = getenv("LDP_DEBUG_WIDE_MIN_REACH")) {
+  if (const char* w = LDP_ENV("LDP_DEBUG_WIDE_MIN_REACH")) {
     o.wide_min_reach = static_cast<uint32_t>(std::max(0, atoi(w)));
   }
   return o;
@@ -310,7 +310,7 @@ int checkpoint_fractions(double r2_param, double* frac) {
   static const double kStep[kCheckpoints] = {0.012, 0.04, 0.08, 0.16, 0.36};  // (tuned on config 2: an earlier first checkpoint pays, a failed one costs little)
   const double f0 = 1.0 - sqrt(r2_param);
   int n = 0;
-  if (const char* dbg = getenv("LDP_DEBUG_CP_FRACS")) {  // tuning aid: comma-separated absolute fractions
+  if (const char* dbg = LDP_ENV("LDP_DEBUG_CP_FRACS")) {  // tuning aid: comma-separated absolute fractions
     while (*dbg && (n < kCheckpoints)) {
       char* end;
       const double f = strtod(dbg, &end);
@@ -424,7 +424,7 @@ void plan_mfma_generic(const std::vector<std::pair<uint32_t, uint32_t>>& runs, c
       }
     }
     static const size_t max_waves = []() {  // tuning aid: fewer wave items per workgroup = fewer row-blocks = a deeper ring
-      const char* w = getenv("LDP_DEBUG_MFMA_WAVES");
+      const char* w = LDP_ENV("LDP_DEBUG_MFMA_WAVES");
       const int v = w ? atoi(w) : kMfWaves;
       return static_cast<size_t>(std::min(std::max(v, 1), kMfWaves));
     }();
@@ -657,7 +657,7 @@ void build_shard(ldp_engine* e) {
       }
       const uint32_t units = (dmax + 7) / 8;
       static const uint32_t max_units = []() {  // tuning aid: blocks of fewer units than the kernel's limit
-        const char* mu = getenv("LDP_DEBUG_MAX_UNITS");
+        const char* mu = LDP_ENV("LDP_DEBUG_MAX_UNITS");
         const int v = mu ? atoi(mu) : kMaxUnitsPerBlock;
         return static_cast<uint32_t>(std::min(std::max(v, 1), kMaxUnitsPerBlock));
       }();
@@ -741,7 +741,7 @@ void build_shard(ldp_engine* e) {
         kTargetGroups = 1;
       }
     }
-    if (const char* tg = getenv("LDP_DEBUG_GROUPS")) {
+    if (const char* tg = LDP_ENV("LDP_DEBUG_GROUPS")) {
       kTargetGroups = std::max(1, atoi(tg));
     }
     const uint32_t n_items = static_cast<uint32_t>(e->items.size());
@@ -894,7 +894,7 @@ int ensure_device_plan(ldp_engine* e) {
     return LDP_OK;
   }
   HIP_TRY(e, hipSetDevice(e->device));
-  static const bool plan_timing = getenv("LDP_DEBUG_LOAD_TIMING") != nullptr;
+  static const bool plan_timing = LDP_ENV("LDP_DEBUG_LOAD_TIMING") != nullptr;
   double t_mark = now_ms();
   auto mark = [&](const char* what) {
     if (plan_timing) {
@@ -1070,7 +1070,7 @@ int fetch_recs(ldp_engine* e) {
     }
     const double t0 = now_ms();
     HIP_TRY(e, hipStreamSynchronize(e->copy_stream));
-    if (getenv("LDP_DEBUG_TIMELINE")) {
+    if (LDP_ENV("LDP_DEBUG_TIMELINE")) {
       fprintf(stderr, "recs copy: waited %.2f ms\n", now_ms() - t0);
     }
     e->recs_copy_queued = false;
@@ -1533,6 +1533,14 @@ int ldp_debug_set_option(ldp_engine* e, const char* name, double value) {
       return fail(e, LDP_ERR_INVALID, "sparse_frac must lie in [0, 1]");
     }
     e->opt.sparse_frac = value;
+  } else if (n == "replay_steps") {
+    e->opt.replay_steps = static_cast<uint32_t>(std::max(0.0, value));
+  } else if (n == "decode_rows") {
+    e->opt.decode_rows = static_cast<uint32_t>(std::max(0.0, value));
+  } else if (n == "decode_no_lds") {
+    e->opt.decode_no_lds = (value != 0.0);
+  } else if (n == "x_rows") {
+    e->opt.x_rows = static_cast<uint32_t>(std::max(0.0, value));
   } else {
     return fail(e, LDP_ERR_INVALID, "unknown option: " + n);
   }

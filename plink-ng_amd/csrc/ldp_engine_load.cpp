@@ -97,22 +97,22 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
       break;
     }
   }
-  static const bool eager_always = (getenv("LDP_EAGER_PAIRS") != nullptr) && (strcmp(getenv("LDP_EAGER_PAIRS"), "1") == 0);
+  static const bool eager_always = (LDP_ENV("LDP_EAGER_PAIRS") != nullptr) && (strcmp(LDP_ENV("LDP_EAGER_PAIRS"), "1") == 0);
   const bool eager = (!e->matrix_mode) && (!e->band_r2_mode) && ((location == LDP_MEM_HOST) || eager_always);
   // host threads per 16 MiB slot and bytes per task: a memcpy out of a mapping runs at its best on 16 threads; pread() calls (the file
   // descriptor form, what plink2-hip uses for fixed-width rows) want more, smaller ones -- 32 x 256 KiB: 0.36-0.38 s for config 2's
   // 12.5 GB on a host where the mapping took 0.35-0.97 s from run to run (profiles/r04_experiments.md)
   static const uint32_t copy_threads_env = []() {
-    const char* c = getenv("LDP_DEBUG_COPY_THREADS");
+    const char* c = LDP_ENV("LDP_DEBUG_COPY_THREADS");
     return (c && atoi(c) > 0) ? static_cast<uint32_t>(atoi(c)) : 0u;
   }();
   static const uint64_t copy_task_env = []() {
-    const char* c = getenv("LDP_DEBUG_COPY_TASK_KB");
+    const char* c = LDP_ENV("LDP_DEBUG_COPY_TASK_KB");
     return (c && atoi(c) > 0) ? (static_cast<uint64_t>(atoi(c)) << 10) : 0ull;
   }();
   const uint32_t copy_threads = copy_threads_env ? copy_threads_env : ((src_fd >= 0) ? 32u : 16u);
   const uint64_t copy_task_bytes = copy_task_env ? copy_task_env : ((src_fd >= 0) ? (256ull << 10) : (1ull << 20));
-  static const bool load_timing = getenv("LDP_DEBUG_LOAD_TIMING") != nullptr;  // host side of the file -> HBM leg, on stderr
+  static const bool load_timing = LDP_ENV("LDP_DEBUG_LOAD_TIMING") != nullptr;  // host side of the file -> HBM leg, on stderr
   double t_wait_slot = 0.0, t_copy = 0.0;
   uint32_t n_slots = 0;
   const double t_call0 = now_ms();
@@ -155,7 +155,7 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
         const uint32_t kRowsPerTask = std::max<uint32_t>(1, static_cast<uint32_t>((copy_task_bytes) / pack_stride));
         const uint32_t tasks = (cnt + kRowsPerTask - 1) / kRowsPerTask;
         std::atomic<int> read_failed(0);
-        static const bool use_pool = !(getenv("LDP_DEBUG_COPY_POOL") && (atoi(getenv("LDP_DEBUG_COPY_POOL")) == 0));
+        static const bool use_pool = !(LDP_ENV("LDP_DEBUG_COPY_POOL") && (atoi(LDP_ENV("LDP_DEBUG_COPY_POOL")) == 0));
         auto copy_task = [&](uint32_t t) {
           const uint32_t r0 = t * kRowsPerTask;
           const uint32_t r1 = std::min(cnt, r0 + kRowsPerTask);
@@ -213,7 +213,7 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
         // (b) LDP_DEBUG_H2D_MODE=2: not at all -- the count pass reads the pinned rows over PCIe itself (host memory is
         // device-accessible), or (c) =0: the single in-order copy of rounds 1-3.
         static const int h2d_mode = []() {
-          const char* m = getenv("LDP_DEBUG_H2D_MODE");
+          const char* m = LDP_ENV("LDP_DEBUG_H2D_MODE");
           return m ? atoi(m) : 1;
         }();
         if (h2d_mode == 2) {
@@ -469,8 +469,8 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
   bool have_carried = e->ld_base_valid && (e->dec_next_variant == first_variant) && (e->dec_next_offset == recs[0].offset);
   // ---- in launches of at most ~256 MiB of rows
   uint32_t rows_per_launch = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / stride)));
-  if (const char* dbg = getenv("LDP_DEBUG_DECODE_ROWS")) {  // (test hook: many small launches, LD chains cut everywhere)
-    rows_per_launch = static_cast<uint32_t>(std::max(1, atoi(dbg)));
+  if (e->opt.decode_rows) {  // (test hook, option "decode_rows": many small launches, LD chains cut everywhere)
+    rows_per_launch = e->opt.decode_rows;
   }
   std::vector<uint32_t> multi;
   std::vector<uint8_t> h_inverse;
@@ -579,6 +579,7 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
     DA.error = d_err;
     DA.pass = 0;
     DA.any_ld = any_ld ? 1 : 0;
+    DA.no_lds = e->opt.decode_no_lds ? 1 : 0;
     DA.multi_rec = static_cast<const uint32_t*>(p_multi);
     DA.n_multi = static_cast<uint32_t>(multi.size());
     DA.maj_freq = static_cast<double*>(p_mf);
@@ -663,7 +664,7 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
     }
     status = load_rows_impl(e, first_variant + q0, cnt, DA.rows, stride, LDP_MEM_DEVICE, LDP_GENO_REF | (mapped ? LDP_GENO_MAPPED : 0) | (phased ? LDP_GENO_PHASED : 0),
                             multi.empty() ? nullptr : DA.row_inverse, multi.empty() ? nullptr : h_inverse.data());
-    if (getenv("LDP_DEBUG_TIMELINE")) {
+    if (LDP_ENV("LDP_DEBUG_TIMELINE")) {
       fprintf(stderr, "decode launch of %u rows: queued in %.3f ms, device done %.3f ms later, rows loaded %.3f ms after that\n", rows, t_q - t_call, t_s - t_q, now_ms() - t_s);
     }
     if (status == LDP_OK) {

@@ -442,8 +442,8 @@ int r2_x_block_impl(ldp_engine* e, ldp_engine* male, const uint8_t* is_x, const 
   // right of the chunk's last row either).  Blocks without any chrX pair -- most chunks of a genome-wide table -- cost nothing.
   const size_t esz = as_float ? sizeof(float) : sizeof(double);
   uint32_t rows_per = static_cast<uint32_t>(std::max<uint64_t>(32, ((1ull << 30) / sizeof(ldp_pair_stats_t)) / col_ct) & ~31ull);
-  if (const char* dbg = getenv("LDP_DEBUG_X_ROWS")) {  // (test hook: many small chunks)
-    rows_per = static_cast<uint32_t>(std::max(1, atoi(dbg)));
+  if (e->opt.x_rows) {  // (test hook, option "x_rows": many small chunks)
+    rows_per = e->opt.x_rows;
   }
   struct Chunk {
     uint32_t r0, rows, c0, c1;

@@ -185,7 +185,7 @@ int replay_progressive(ldp_engine* e, const uint32_t* pred, const double* mf, st
   double t_first = 0.0;
   hipError_t herr = hipSuccess;
   const size_t n_groups = e->groups.size();
-  const bool timeline = getenv("LDP_DEBUG_TIMELINE") != nullptr;
+  const bool timeline = LDP_ENV("LDP_DEBUG_TIMELINE") != nullptr;
   const double t_enter = now_ms();
   for (size_t gi = 0; gi < n_groups; ++gi) {
     herr = hipEventSynchronize(e->groups[gi].ev_done);
@@ -224,10 +224,10 @@ void replay(ldp_engine* e, const uint32_t* pred, const double* mf, std::vector<u
   if (e->P.plink1_order) {
     first_unchecked.assign(e->local_ct, 0);
   }
-  // LDP_DEBUG_REPLAY_STEPS=k (test hook): every subcontig in k instalments, the way the streaming replay of a run advances
+  // option "replay_steps" k (test hook): every subcontig in k instalments, the way the streaming replay of a run advances
   // through it as the launch groups land
-  if (const char* st = getenv("LDP_DEBUG_REPLAY_STEPS")) {
-    const uint32_t steps = static_cast<uint32_t>(std::max(1, atoi(st)));
+  if (e->opt.replay_steps) {
+    const uint32_t steps = e->opt.replay_steps;
     uint64_t total = 0;
     for (uint32_t k : e->owned) {
       const Subcontig& sub = e->subs[k];
@@ -703,7 +703,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   }
   finish_removed(e, R, removed);
   const double t_end = now_ms();
-  if (getenv("LDP_DEBUG_TIMELINE")) {
+  if (LDP_ENV("LDP_DEBUG_TIMELINE")) {
     fprintf(stderr, "run timeline (ms since entry): queued %.2f recs %.2f mf %.2f replayed %.2f synced %.2f end %.2f\n", tl[0] - t_start, tl[1] - t_start,
             tl[2] - t_start, tl[3] - t_start, tl[4] - t_start, t_end - t_start);
   }

@@ -1326,7 +1326,7 @@ hipError_t launch_pair_tiles(const PairKernelArgs& a_in, uint32_t max_rows, hipS
   PairKernelArgs a = a_in;
   const uint32_t per_xcd = (a.n_items + 7) / 8;
   size_t lds = pair_tiles_lds_bytes(max_rows);
-  if (const char* pad = getenv("LDP_DEBUG_LDS_KB")) {  // tuning aid: force fewer resident blocks per CU
+  if (const char* pad = LDP_ENV("LDP_DEBUG_LDS_KB")) {  // tuning aid: force fewer resident blocks per CU
     lds = std::max<size_t>(lds, static_cast<size_t>(atoi(pad)) * 1024);
   }
   a.lds_dwords = static_cast<uint32_t>(lds / sizeof(uint32_t));

@@ -1883,7 +1883,7 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
   // 64 KiB (+ 8 KiB static) lets two workgroups share a CU; LDP_DEBUG_MFMA_LDS_KB trades that for a deeper ring (tuning aid)
   static const size_t lds = []() {
     size_t bytes = static_cast<size_t>(kMfLdsDwords) * sizeof(uint32_t);
-    if (const char* kb = getenv("LDP_DEBUG_MFMA_LDS_KB")) {
+    if (const char* kb = LDP_ENV("LDP_DEBUG_MFMA_LDS_KB")) {
       bytes = std::max<size_t>(bytes, std::min<size_t>(static_cast<size_t>(atoi(kb)), 150) * 1024);
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<4, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
@@ -1931,7 +1931,7 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
       // 5 row-blocks = 10 KiB per stage: a ring of five in 50 KiB (+ 3 KiB static) lets THREE workgroups share a CU (138 VGPRs
       // allow three waves per SIMD); LDP_DEBUG_MFMA_GEN_LDS_KB overrides (tuning aid)
       size_t bytes = 50 * 1024;
-      if (const char* kb = getenv("LDP_DEBUG_MFMA_GEN_LDS_KB")) {
+      if (const char* kb = LDP_ENV("LDP_DEBUG_MFMA_GEN_LDS_KB")) {
         bytes = std::min<size_t>(std::max<size_t>(static_cast<size_t>(atoi(kb)), 20), 150) * 1024;
       }
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_general_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));

@@ -5,12 +5,13 @@
 // holds ~1,700 variants = 54 row-blocks, and the parallelogram plan's 32 block products per 15 staged row-blocks made the
 // kernel wait for HBM: every row was fetched ~12 times (profiles/r02_c3shape_pmc_traffic.json).  Here a workgroup owns a
 // SQUARE of 8 second-variant blocks x 8 first-variant blocks: 64 products for 16 staged row-blocks (32 KiB per 256-sample
-// stage), i.e. half the bytes per product, and one workgroup per CU with a four-stage ring in 128 KiB of LDS.  Wave w owns
+// stage), i.e. half the bytes per product, and one workgroup per CU with a two-stage ring of 512-sample stages in 128 KiB of LDS.  Wave w owns
 // the 2 x 4 sub-rectangle J blocks 2 (w & 3), + 1 x V blocks 4 (w >> 2) .. + 3: eight accumulator sets, six row-block reads
 // and expansions per stage (the parallelogram needs seven).  Tiles are aligned to the subcontig start in both directions;
 // on the diagonal the V tile is the J tile (8 row-blocks staged) and the products above it are simply not live.
-// Workgroups are ordered J tile by J tile with all V tiles of a J tile consecutive, and the launch hands consecutive
-// workgroups to one XCD: neighbours share their eight J row-blocks (and overlapping V ranges) through that XCD's L2.
+// The launch is eight streams of tiles of equal length, one per XCD (ldp_engine.cpp build_shard): the far tiles of a stream first,
+// J tile by J tile, its tiles next to the diagonal (the long ones) at the end; workgroup b runs tile (b & 7) * per_xcd + (b >> 3), so
+// the tiles that run together on an XCD are neighbours and share row-blocks through that XCD's L2.
 // Early termination as in pair_mfma_kernel: at a checkpoint a wave drops the products that provably hold no pair above the
 // threshold, row-blocks nobody reads any more are no longer fetched, a workgroup with nothing left leaves.
 #include "ldp_device.h"
@@ -55,9 +56,13 @@ __device__ __forceinline__ uint32_t wd_swizzle(uint32_t row) { return (row >> 1)
 // eight waves' worth of state hipcc spilled inside the stage loop for it, and a scratch reload's vmcnt wait drains the DMA
 // ring.  A wave's eight products sit next to each other in distance, so they mostly die together anyway; the products of a
 // partly live wave that hold no candidate pair accumulate numbers nobody reads.)
-// ABL (measurement only, tools/profile notes in profiles/r04_experiments.md; results are WRONG for ABL != 0): bit 1 = expand only the
-// first k-step's operands and reuse them (a quarter of the VALU work, the same operand statistics), bit 2 = no LDS reads in the loop
-// (every lane multiplies what the first stage left in its registers' place: constants of the launch)
+// ABL != 0 exists in the MEASUREMENT build only (-DLDP_MEASURE, csrc/ldp_env.h; the shipped library instantiates <0> and nothing
+// else): ablations for the attribution tables of profiles/r04_experiments.md and r05_experiments.md.  Bits 0-3 make the results
+// WRONG by construction.  Bit 0 (value 1) = no DMA after the ring's first fill, bit 1 (2) = expand only the first k-step's operands
+// and reuse them (a quarter of the VALU work, the same operand statistics), bit 2 (4) = no LDS reads in the loop (every lane
+// multiplies what the first stage left in its registers' place), bit 3 (8) = no s_waitcnt vmcnt / s_barrier in the stage loop (the
+// waves run free), bit 4 (16) = no per-pair epilogue, bit 5 (32) = time stamps around the phases of every wave (results right:
+// where the cycles go), summed into g_wide_measure.
 template <int ABL>
 __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const uint32_t (&joff)[2], const uint32_t (&voff)[4], uint32_t oH, uint32_t oR,
                                            mf_v16f (&acc)[8]) {
@@ -152,6 +157,20 @@ __device__ __forceinline__ void wide_stage_kept(mf_u4 H, mf_u4 R, mf_v16f (&acc)
   }
 }
 
+#ifdef LDP_MEASURE
+// what the waves of the measured launches spent where (shader cycles, summed over waves; ABL bit 5 fills 0-5 and 9-10, every measured
+// instantiation 6-8): [0] s_waitcnt vmcnt in front of the stage barrier, [1] the stage barrier itself, [2] stages of waves with a live
+// product (DMA issue + LDS reads + expansions + MFMA issue), [3] stages of waves with none, [4] checkpoints, [5] epilogue, [6] entry to
+// exit, [7] waves, [8] entry to exit in 100 MHz wall ticks (shader clock = 100 MHz x [6] / [8]), [9] / [10] stage visits live / dead
+__device__ unsigned long long g_wide_measure[16];
+__device__ __forceinline__ unsigned long long wd_clk() {
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long t = __builtin_readcyclecounter();
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#endif
+
 // row-block slots (bit s: slot s of the stage) a wave with a live product reads: its two J blocks and its four V blocks
 __device__ __forceinline__ uint32_t wide_slots_needed(uint32_t live, uint32_t a0, uint32_t vslot0) {
   return live ? ((3u << a0) | (0xfu << vslot0)) : 0u;
@@ -170,6 +189,10 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
     return;
   }
   const MfmaTile* __restrict__ tile = A.wd_tiles + idx;
+#ifdef LDP_MEASURE
+  unsigned long long m_t[6] = {0, 0, 0, 0, 0, 0}, m_visits[2] = {0, 0};
+  const unsigned long long m_clk0 = wd_clk(), m_wall0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const uint32_t tid = threadIdx.x;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t lane = tid & 63;
@@ -309,7 +332,23 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
   for (uint32_t kc = 0; kc < n_stages;) {
     const uint32_t kc_end = issue_limit;  // the next checkpoint (or the end of the rows)
     for (; kc < kc_end; ++kc) {
+#ifdef LDP_MEASURE
+      unsigned long long m_s0 = 0;
+      if constexpr ((ABL & 32) != 0) {
+        // (a two-stage ring: the stage about to be read is the only one in flight, the wait is always vmcnt(0))
+        const unsigned long long a0 = wd_clk();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long a1 = wd_clk();
+        asm volatile("s_barrier" ::: "memory");
+        m_s0 = wd_clk();
+        m_t[0] += a1 - a0;
+        m_t[1] += m_s0 - a1;
+      } else if constexpr ((ABL & 8) == 0) {
+        wait_dma_then_barrier(mine * (issued - kc - 1));
+      }
+#else
       wait_dma_then_barrier(mine * (issued - kc - 1));
+#endif
       if (issued < issue_limit) {
         dma_stage(issued, issue_buf);  // (reuses the buffer every wave finished reading before the barrier)
         ++issued;
@@ -330,10 +369,19 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
         wide_stage<ABL>(st4, joff, voff, oH0, oR0, acc);
         wide_stage<ABL>(st4, joff, voff, oH1, oR1, acc);
       }
+#ifdef LDP_MEASURE
+      if constexpr ((ABL & 32) != 0) {
+        m_t[live ? 2 : 3] += wd_clk() - m_s0;
+        m_visits[live ? 0 : 1] += 1;
+      }
+#endif
     }
     if (kc >= n_stages) {
       break;
     }
+#ifdef LDP_MEASURE
+    const unsigned long long m_c0 = ((ABL & 32) != 0) ? wd_clk() : 0ull;
+#endif
     // ---- checkpoint (ldp_device.h): drop the products whose candidate pairs are all provably below the threshold ----
     __syncthreads();  // every wave is done with the last stage: LDS is scratch now
     {
@@ -452,6 +500,11 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
     issue_limit = (next_cp < n_cp) ? checkpoint_stage(next_cp) : n_stages;
     issued_base = kc;
     ring_fill();  // restart the ring at this stage
+#ifdef LDP_MEASURE
+    if constexpr ((ABL & 32) != 0) {
+      m_t[4] += wd_clk() - m_c0;
+    }
+#endif
   }
   __syncthreads();  // staging is over: LDS becomes the epilogue's scratch (a private region per wave)
   if ((lane == 0) && live0) {
@@ -470,6 +523,12 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
   // lane l, register g of a product holds first variant (g & 3) + 8 (g >> 2) + 4 (l >> 5) of the V block, second variant
   // l & 31 of the J block (tools/mfma_probe.hip, fact 1)
   uint32_t n_true = 0;
+#ifdef LDP_MEASURE
+  const unsigned long long m_e0 = wd_clk();
+  if constexpr ((ABL & 16) != 0) {
+    live = 0;  // (no per-pair epilogue: what it costs)
+  }
+#endif
 #pragma unroll
   for (int round = 0; round < 2; ++round) {
     if (!(live & (0xfu << (4 * round)))) {
@@ -525,6 +584,25 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
   if ((lane == 0) && n_true) {
     atomicAdd(A.counters, static_cast<unsigned long long>(n_true));
   }
+#ifdef LDP_MEASURE
+  {
+    const unsigned long long m_clk1 = wd_clk(), m_wall1 = __builtin_amdgcn_s_memrealtime();
+    m_t[5] = m_clk1 - m_e0;
+    if (lane == 0) {
+      if constexpr ((ABL & 32) != 0) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          atomicAdd(&g_wide_measure[q], m_t[q]);
+        }
+        atomicAdd(&g_wide_measure[9], m_visits[0]);
+        atomicAdd(&g_wide_measure[10], m_visits[1]);
+      }
+      atomicAdd(&g_wide_measure[6], m_clk1 - m_clk0);
+      atomicAdd(&g_wide_measure[7], 1ull);
+      atomicAdd(&g_wide_measure[8], m_wall1 - m_wall0);
+    }
+  }
+#endif
 }
 
 }  // namespace
@@ -534,31 +612,51 @@ hipError_t launch_pair_wide(const PairKernelArgs& a_in, hipStream_t stream) {
     return hipSuccess;
   }
   PairKernelArgs a = a_in;
-  // LDP_DEBUG_WIDE_ABLATE (measurement only, WRONG results): 1 = no DMA, 2 = a quarter of the operand expansions, 4 = no LDS reads, 7 = all
-  static const int ablate = []() {
-    const char* v = getenv("LDP_DEBUG_WIDE_ABLATE");
-    return v ? atoi(v) : 0;
-  }();
-  static const size_t lds = []() {
-    const size_t bytes = static_cast<size_t>(kWdLdsDwords) * sizeof(uint32_t);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-    return bytes;
-  }();
+  const size_t lds = static_cast<size_t>(kWdLdsDwords) * sizeof(uint32_t);
   a.lds_dwords = static_cast<uint32_t>(lds / sizeof(uint32_t));
   const uint32_t per_xcd = (a.n_wd_tiles + 7) / 8;
   const dim3 grid(per_xcd * 8), block(kWdWaves * 64);
+#ifdef LDP_MEASURE
+  // LDP_DEBUG_WIDE_ABLATE (measurement build only; bits 0-3 give WRONG results): see wide_stage.  Read at every launch.
+  const char* v = LDP_ENV("LDP_DEBUG_WIDE_ABLATE");
+  const int ablate = v ? atoi(v) : 0;
+#define LDP_WD_CASE(n)                                                                                                                                        \
+  case n:                                                                                                                                                     \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<n>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+    hipLaunchKernelGGL(pair_mfma_wide_kernel<n>, grid, block, lds, stream, a);                                                                                \
+    break;
   switch (ablate) {
-    case 1: hipLaunchKernelGGL(pair_mfma_wide_kernel<1>, grid, block, lds, stream, a); break;
-    case 2: hipLaunchKernelGGL(pair_mfma_wide_kernel<2>, grid, block, lds, stream, a); break;
-    case 4: hipLaunchKernelGGL(pair_mfma_wide_kernel<4>, grid, block, lds, stream, a); break;
-    case 7: hipLaunchKernelGGL(pair_mfma_wide_kernel<7>, grid, block, lds, stream, a); break;
-    default: hipLaunchKernelGGL(pair_mfma_wide_kernel<0>, grid, block, lds, stream, a); break;
+    LDP_WD_CASE(1) LDP_WD_CASE(2) LDP_WD_CASE(4) LDP_WD_CASE(7) LDP_WD_CASE(8) LDP_WD_CASE(9) LDP_WD_CASE(15) LDP_WD_CASE(16) LDP_WD_CASE(25) LDP_WD_CASE(31) LDP_WD_CASE(32)
+    default:
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      hipLaunchKernelGGL(pair_mfma_wide_kernel<0>, grid, block, lds, stream, a);
+      break;
   }
+#undef LDP_WD_CASE
+#else
+  static const bool attr_set = []() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kWdLdsDwords * sizeof(uint32_t))) == hipSuccess;
+  }();
+  (void)attr_set;
+  hipLaunchKernelGGL(pair_mfma_wide_kernel<0>, grid, block, lds, stream, a);
+#endif
   return hipGetLastError();
 }
+
+#ifdef LDP_MEASURE
+// (measurement build only) the sums of g_wide_measure since the last reset
+extern "C" int ldp_measure_wide_counters(unsigned long long* out16, int reset) {
+  if (out16 && (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wide_measure), 16 * sizeof(unsigned long long)) != hipSuccess)) {
+    return 1;
+  }
+  if (reset) {
+    const unsigned long long zero[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wide_measure), zero, sizeof(zero)) != hipSuccess) {
+      return 1;
+    }
+  }
+  return 0;
+}
+#endif
 
 }  // namespace ldp

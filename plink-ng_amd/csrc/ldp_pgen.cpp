@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/ldprune_hip.h"
+#include "ldp_env.h"
 
 struct ldp_pgen {
   std::string err;
@@ -52,6 +53,7 @@ struct ldp_pgen {
 namespace {
 
 constexpr uint32_t kBlockVariants = 65536;
+std::atomic<bool> g_force_portable(false);  // ldp_pgen_debug_force_portable(): the bit-deposit loops instead of pext / pdep (a test hook)
 
 // (readers may call the per-record functions on one handle from several threads: the message is the first failure's)
 int pfail(ldp_pgen* p, int code, const std::string& msg) {
@@ -293,6 +295,11 @@ inline uint32_t packed_get(const uint8_t* base, uint64_t idx, uint32_t width_bit
 
 extern "C" {
 
+int ldp_pgen_debug_force_portable(int on) {
+  g_force_portable.store(on != 0);
+  return LDP_OK;
+}
+
 int ldp_pgen_open(const char* path, uint32_t sample_ct_hint, uint32_t variant_ct_hint, ldp_pgen** out) {
   return ldp_pgen_open_indexed(path, nullptr, sample_ct_hint, variant_ct_hint, out);
 }
@@ -315,7 +322,7 @@ int ldp_pgen_open_indexed(const char* path, const char* pgi_path, uint32_t sampl
     return pfail(P, LDP_ERR_INVALID, std::string(path) + " is too small to be a PLINK genotype file.");
   }
   P->size = static_cast<uint64_t>(st.st_size);
-  void* m = mmap(nullptr, P->size, PROT_READ, MAP_PRIVATE | (getenv("LDP_DEBUG_MAP_POPULATE") ? MAP_POPULATE : 0), P->fd, 0);
+  void* m = mmap(nullptr, P->size, PROT_READ, MAP_PRIVATE | (LDP_ENV("LDP_DEBUG_MAP_POPULATE") ? MAP_POPULATE : 0), P->fd, 0);
   if (m == MAP_FAILED) {
     return pfail(P, LDP_ERR_NOMEM, std::string("Failed to map ") + path + ".");
   }
@@ -710,7 +717,8 @@ bool decode_phase_impl(const ldp_pgen* P, uint32_t v, const uint8_t* row, const 
 // carries no phase.
 bool decode_phase(const ldp_pgen* P, uint32_t v, const uint8_t* row, const uint8_t* aux2, const uint8_t* sample_mask, uint8_t* phase, bool* unphased) {
 #if defined(__x86_64__)
-  static const bool have_bmi2 = __builtin_cpu_supports("bmi2") && !getenv("LDP_PGEN_NO_BMI2");  // (the variable: tests of the portable path)
+  static const bool cpu_bmi2 = __builtin_cpu_supports("bmi2");
+  const bool have_bmi2 = cpu_bmi2 && !g_force_portable.load(std::memory_order_relaxed);  // (ldp_pgen_debug_force_portable: tests of the portable path)
   if (have_bmi2) {
     return decode_phase_impl<true>(P, v, row, aux2, sample_mask, phase, unphased);
   }
@@ -1408,7 +1416,8 @@ int ldp_subset_samples(const void* in_rows, uint64_t in_stride, uint32_t n_rows,
   }
   (void)m5;
 #if defined(__x86_64__)
-  static const bool have_bmi2 = __builtin_cpu_supports("bmi2") && !getenv("LDP_PGEN_NO_BMI2");
+  static const bool cpu_bmi2 = __builtin_cpu_supports("bmi2");
+  const bool have_bmi2 = cpu_bmi2 && !g_force_portable.load(std::memory_order_relaxed);
 #else
   static const bool have_bmi2 = false;
 #endif

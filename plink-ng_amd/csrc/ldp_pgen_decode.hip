@@ -1026,7 +1026,7 @@ hipError_t launch_pgen_main(const PgenDecodeArgs& a, hipStream_t stream) {
   static const bool lds_ok = []() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&pgen_main_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kPgenLdsRowBytes)) == hipSuccess;
   }();
-  const bool in_lds = lds_ok && (a.stride <= kPgenLdsRowBytes) && (getenv("LDP_DEBUG_DECODE_NO_LDS") == nullptr);
+  const bool in_lds = lds_ok && (a.stride <= kPgenLdsRowBytes) && !a.no_lds;
   for (int pass = 0; pass < (a.any_ld ? 2 : 1); ++pass) {
     p.pass = pass;
     if (in_lds) {
@@ -1045,7 +1045,7 @@ hipError_t launch_pgen_aux1(const PgenDecodeArgs& a, hipStream_t stream) {
   static const bool lds_ok = []() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&pgen_aux1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kPgenLdsRowBytes)) == hipSuccess;
   }();
-  if (lds_ok && (a.stride <= kPgenLdsRowBytes) && (getenv("LDP_DEBUG_DECODE_NO_LDS") == nullptr)) {
+  if (lds_ok && (a.stride <= kPgenLdsRowBytes) && !a.no_lds) {
     hipLaunchKernelGGL(pgen_aux1_kernel<true>, dim3(a.n_multi), dim3(kAuxThreads), static_cast<size_t>(a.stride), stream, a);
   } else {
     hipLaunchKernelGGL(pgen_aux1_kernel<false>, dim3(a.n_multi), dim3(kAuxThreads), 0, stream, a);

@@ -46,6 +46,7 @@
 #include <vector>
 
 #include "../../include/ldprune_hip.h"
+#include "../../include/ldprune_hip_debug.h"  // (only for the --debug-* test hooks)
 
 namespace {
 
@@ -1151,6 +1152,12 @@ bool parse_ldwindow_flags(Args& A, ArgCursor& c, const std::string& f) {
   return true;
 }
 
+// test / measurement hooks of the front-end (hidden --debug-* flags; the library itself reads no environment, csrc/ldp_env.h)
+struct DebugHooks {
+  bool alias_devices = false, x_host = false, host_decode = false, load_map = false;
+  uint32_t x_rows = 0, decode_threads = 0;
+} g_dbg;
+
 // everything else (order, threads, debugging aids)
 bool parse_misc_flags(Args& A, ArgCursor& c, const std::string& f) {
   LDP_ARG_FAMILY_PROLOGUE;
@@ -1170,6 +1177,21 @@ bool parse_misc_flags(Args& A, ArgCursor& c, const std::string& f) {
     A.timing = true;
   } else if (f == "--dry-run") {
     A.dry_run = true;
+  } else if (f == "--debug-alias-devices") {
+    g_dbg.alias_devices = true;   // (test hook: the N engines of --gpus N dealt onto the devices there are, host transport for the exchange)
+  } else if (f == "--debug-x-host") {
+    g_dbg.x_host = true;          // (test hook: chrX pairs as lists through ldp_pair_stats and the host arithmetic)
+  } else if (f == "--debug-host-decode") {
+    g_dbg.host_decode = true;     // (measurement / test hook: variable-width records decoded by the host reader)
+  } else if (f == "--debug-load-map") {
+    g_dbg.load_map = true;        // (measurement: fixed-width rows copied out of the mapping instead of pread())
+  } else if ((f == "--debug-x-rows") || (f == "--debug-decode-threads")) {
+    need(i, 1, f.c_str());
+    const int v = atoi(argv[++i]);
+    if (v < 1) {
+      die(8, "Error: Invalid %s argument '%s'.\n", f.c_str(), argv[i]);
+    }
+    ((f == "--debug-x-rows") ? g_dbg.x_rows : g_dbg.decode_threads) = static_cast<uint32_t>(v);
   } else if (f == "--debug-format-g6") {
     // test hook (no GPU needed): one hex bit pattern of a double per line in, the .vcor number formatting out
     need(i, 1, "--debug-format-g6");
@@ -3926,7 +3948,7 @@ struct R2Job {
     if (!any_x) {
       return;
     }
-    if (getenv("LDP_DEBUG_X_HOST")) {  // (test hook: pair lists through ldp_pair_stats and the host arithmetic, as the band writers do)
+    if (g_dbg.x_host) {  // (test hook --debug-x-host: pair lists through ldp_pair_stats and the host arithmetic, as the band writers do)
       std::vector<uint32_t> fi, se;
       std::vector<double> vals;
       for (uint32_t q = 0; q < rows; ++q) {
@@ -4231,7 +4253,7 @@ int write_vcor_table(R2Job& J) {
             }
           }
           bool x_done = false;
-          if (any_x && A.r2_inter && (thresh >= 0.0) && !getenv("LDP_DEBUG_X_HOST")) {
+          if (any_x && A.r2_inter && (thresh >= 0.0) && !g_dbg.x_host) {
             // all-pairs plan: the chunk's pairs with a chrX variant from the pair kernels too, weighted and filtered on the device
             // (a chunk whose passing pairs do not fit the buffer goes through the lists below)
             uint64_t x_found = 0;
@@ -4729,6 +4751,9 @@ int run_r2(Session& S) {
   if (ldp_create(&RP, &e)) {
     die(16, "Error: engine setup failed.\n");
   }
+  if (g_dbg.x_rows) {
+    (void)ldp_debug_set_option(e, "x_rows", static_cast<double>(g_dbg.x_rows));
+  }
   if (ldp_set_r_signed(e, A.r_unsquared ? (A.r2_ref_based ? 2 : 1) : 0)) {
     die(16, "Error: %s\n", ldp_last_error(e));
   }
@@ -5179,10 +5204,10 @@ struct PruneJob {
       if (ndev < 1) {
         die(16, "Error: no usable HIP device (plink2-hip has no CPU compute path).\n");
       }
-      // LDP_DEBUG_ALIAS_DEVICES=1 (tests, one-GPU boxes): as many engines as --gpus asks for, dealt round-robin onto the devices
+      // --debug-alias-devices (tests, one-GPU boxes): as many engines as --gpus asks for, dealt round-robin onto the devices
       // there are -- every host-side step of the N-device run (shard plan, per-engine loads, one thread per engine, segment pack /
       // exchange / stitch) then runs on a single device; RCCL refuses a device twice, so the exchange is the host transport.
-      alias_devices = (getenv("LDP_DEBUG_ALIAS_DEVICES") != nullptr) && (atoi(getenv("LDP_DEBUG_ALIAS_DEVICES")) != 0);
+      alias_devices = g_dbg.alias_devices;
       n_devices = ndev;
       world = alias_devices ? A.gpus : std::min(A.gpus, ndev);
     }
@@ -5260,8 +5285,8 @@ struct PruneJob {
     direct_off = 0;
     // Fixed-width rows go from the file to the engine's pinned ring with pread() (ldp_load_genotypes_fd), not by memcpy out of the
     // mapping: a 12 GB mapping is faulted in page run by page run, and what that costs swung between 0.35 and 0.97 s from one run to
-    // the next on the same host, while 32 readers take 0.36-0.38 s every time (LDP_DEBUG_LOAD_FD=0: the mapping)
-    direct_fd = (direct && !(getenv("LDP_DEBUG_LOAD_FD") && (atoi(getenv("LDP_DEBUG_LOAD_FD")) == 0))) ? ldp_pgen_direct_fd(pg, &direct_off, nullptr) : -1;
+    // the next on the same host, while 32 readers take 0.36-0.38 s every time (--debug-load-map: the mapping)
+    direct_fd = (direct && !g_dbg.load_map) ? ldp_pgen_direct_fd(pg, &direct_off, nullptr) : -1;
     founder_mask.assign((static_cast<size_t>(raw_sample_ct) + 7) / 8, 0);
     for (uint32_t sidx = 0; sidx < raw_sample_ct; ++sidx) {
       if (is_founder[sidx]) {
@@ -5313,12 +5338,12 @@ struct PruneJob {
     }
     // Variable-width records are decoded ON THE DEVICE from the file's own bytes (ldp_load_pgen_records: main track of every
     // record type, LD-compressed chains, and -- when the engine's samples are the file's -- the collapse of variants with more
-    // than one ALT allele); --indep-pairphase rows (phase track) and LDP_DEBUG_HOST_DECODE=1 take the host decoder below.
+    // than one ALT allele); --indep-pairphase rows (phase track) and --debug-host-decode take the host decoder below.
     // --indep-pairphase: main AND phase track on the device (ldp_load_pgen_records_phased) when every sample is a founder and no
     // variant has more than one ALT allele (whose phase refers to allele pairs: host rows, below); otherwise the host decoder.
     const bool device_phase = A.pairphase && all_founders && (!has_multiallelic) && (storage_mode != 0x01) && (storage_mode != 0x02) &&
-                              (getenv("LDP_DEBUG_HOST_DECODE") == nullptr);
-    const bool device_decode = (!direct) && ((!A.pairphase) || device_phase) && (storage_mode != 0x01) && (storage_mode != 0x02) && (getenv("LDP_DEBUG_HOST_DECODE") == nullptr);
+                              (!g_dbg.host_decode);
+    const bool device_decode = (!direct) && ((!A.pairphase) || device_phase) && (storage_mode != 0x01) && (storage_mode != 0x02) && (!g_dbg.host_decode);
     // (records with several ALT alleles are collapsed on the device as well: over the file's samples, or over the founders when the
     // engines pick those through a subset sample map)
     device_multi = device_decode && (all_founders || device_subset) && !A.pairphase;
@@ -5328,7 +5353,7 @@ struct PruneJob {
     std::thread decoder;
     // The decoder runs beside the engine's copy threads (ldp_load_genotypes: 16 of them feeding the pinned ring); a record
     // takes microseconds, so a few dozen threads keep ahead of PCIe and more only get in the copies' way.
-    const uint32_t decode_threads = getenv("LDP_DEBUG_DECODE_THREADS") ? static_cast<uint32_t>(atoi(getenv("LDP_DEBUG_DECODE_THREADS"))) : 32;
+    const uint32_t decode_threads = g_dbg.decode_threads ? g_dbg.decode_threads : 32;
     double t_wait_decode = 0.0, t_load_calls = 0.0;
     int decode_rc = 0;
     uint32_t unphased_at = 0;

@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--window-kb", type=float, default=200.0)
     ap.add_argument("--r2", type=float, default=0.5)
     ap.add_argument("--no-ref", action="store_true")
-    ap.add_argument("--h2d-modes", default="", help="comma-separated LDP_DEBUG_H2D_MODE values to time plink2-hip with (measurement)")
+    ap.add_argument("--h2d-modes", default="", help="comma-separated LDP_DEBUG_H2D_MODE values to time plink2-hip with (they only reach a plink2-hip linked against the measurement build, -DLDP_MEASURE)")
     ap.add_argument("--env-sets", default="", help="semicolon-separated sets of NAME=VALUE,NAME=VALUE to time plink2-hip with on the same fileset (measurement)")
     ap.add_argument("--reps", type=int, default=3, help="plink2-hip runs per setting; the reported speed-up uses the BEST wall of each tool (HIP start-up "
                     "varies by 0.1-0.3 s from run to run on one box), all walls are printed")

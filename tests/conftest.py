@@ -19,6 +19,8 @@ def pkg():
     p = ge.load_package()
     if not os.path.exists(p.LIB_PATH):
         p.build_library()
+    if os.environ.get("LDTEST_PGEN_PORTABLE"):   # (tests/test_pairphase.py::test_portable_bit_deposit_path re-runs the reader tests this way)
+        assert p.lib().ldp_pgen_debug_force_portable(1) == 0
     return p
 
 

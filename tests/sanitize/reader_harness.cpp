@@ -3,7 +3,12 @@
 #include <cstring>
 #include <vector>
 #include "ldprune_hip.h"
+extern "C" int ldp_pgen_debug_force_portable(int on);
+
 int main(int argc, char** argv) {
+  if (getenv("LDTEST_PGEN_PORTABLE")) {  // (the harness is test infrastructure: the library itself reads no environment)
+    ldp_pgen_debug_force_portable(1);
+  }
   for (int a = 1; a + 1 < argc; a += 2) {
     ldp_pgen* pg = nullptr;
     if (ldp_pgen_open(argv[a], 0, 0, &pg)) {

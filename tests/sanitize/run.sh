@@ -12,7 +12,7 @@ g++ $SAN -I"$R/include" -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ "$R/tests/san
     "$R/plink-ng_amd/csrc/ldp_pgen.cpp" -o "$T/reader" -lpthread
 G="$R/tests/golden/pgen"
 "$T/reader" "$G/varwidth_small.pgen" 1 "$G/phased_small.pgen" 1 "$G/phased_partial.pgen" 1 "$G/phased_multi.pgen" 4 "$G/phased_multi_partial.pgen" 4 "$G/dosage_small.pgen" 1
-LDP_PGEN_NO_BMI2=1 "$T/reader" "$G/phased_partial.pgen" 1 "$G/phased_multi.pgen" 4 > /dev/null
+LDTEST_PGEN_PORTABLE=1 "$T/reader" "$G/phased_partial.pgen" 1 "$G/phased_multi.pgen" 4 > /dev/null
 # malformed input: byte flips / truncation of the golden files must end in an error code, never in a sanitizer report
 python3 - "$T" "$G" <<'PY'
 import sys, subprocess, numpy as np

@@ -31,6 +31,21 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(L, name), "missing export: " + name
 
 
+def test_the_shipped_library_reads_no_environment(pkg):
+    """No LDP_* variable can change which kernel runs or what it computes: the names do not even reach the binary (csrc/ldp_env.h; the
+    measurement build -DLDP_MEASURE, lib/libldprune_hip_measure.so, is the one that knows them), and neither does an ablation kernel."""
+    blob = open(pkg.LIB_PATH, "rb").read()
+    for marker in (b"LDP_DEBUG", b"LDP_PAIR_", b"LDP_EARLY", b"LDP_EAGER", b"LDP_STREAM", b"LDP_PGEN_", b"ldp_measure_"):
+        assert marker not in blob, marker
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(repo, "plink-ng_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".cpp", ".hip", ".h")) and f not in ("ldp_env.h", "plink2_hip_cli.cpp"):
+            assert "getenv(" not in open(os.path.join(csrc, f)).read(), f + ": the library's environment goes through LDP_ENV (ldp_env.h)"
+    # ... and the front-end takes its test hooks as --debug-* flags
+    assert "getenv(\"LDP_" not in open(os.path.join(csrc, "plink2_hip_cli.cpp")).read()
+
+
 def test_struct_layouts_match_the_header(pkg):
     # sizes the C side was compiled with (plain C structs, natural alignment)
     assert ctypes.sizeof(pkg.ldp_pair_stats_t) == 24 == pkg.PAIR_STATS_DTYPE.itemsize

@@ -395,7 +395,7 @@ def test_inter_chr_filter_and_order_from_oracle_values(cli, tmp_path):
 def test_cli_n_engines_match_reference(gpu_pkg, cli, tmp_path, engines, fmt, order):
     """`plink2-hip --gpus N`: the subcontigs LPT-sharded over N engines (ldp_set_shard), every engine loading from the same file
     calls, one host thread per engine, and the shards' removed bits packed, exchanged and stitched (plink2_ld.cc:2686-2694 shard,
-    :1418-1426 stitch).  With N devices the exchange is one RCCL all-gather; on a box with fewer, LDP_DEBUG_ALIAS_DEVICES=1 deals
+    :1418-1426 stitch).  With N devices the exchange is one RCCL all-gather; on a box with fewer, --debug-alias-devices deals
     the engines onto the devices there are and the host carries the segments (RCCL refuses a device twice): every other step is
     the N-device run's.  Byte-identical to the reference and to one engine; N = 8 leaves some engines without a subcontig."""
     assert T.have_ref(), "reference binary oracle/_ref/plink2 must travel with the repo snapshot"
@@ -410,11 +410,9 @@ def test_cli_n_engines_match_reference(gpu_pkg, cli, tmp_path, engines, fmt, ord
     assert ref.returncode == 0, ref.stdout
     one = run_cli(cli, common + ["--out", "one"], str(tmp_path))
     assert one.returncode == 0, one.stdout
-    env = dict(os.environ)
-    if gpu_pkg.device_count() < engines:
-        env["LDP_DEBUG_ALIAS_DEVICES"] = "1"
-    many = subprocess.run([cli] + common + ["--gpus", str(engines), "--timing", "--out", "many"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                          text=True, timeout=600, env=env)
+    alias = ["--debug-alias-devices"] if gpu_pkg.device_count() < engines else []
+    many = subprocess.run([cli] + common + alias + ["--gpus", str(engines), "--timing", "--out", "many"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                          text=True, timeout=600)
     assert many.returncode == 0, many.stdout
     assert "(%d GPUs)" % engines in many.stdout and ("%d engines on" % engines) in many.stdout, many.stdout
     for ext in (".prune.in", ".prune.out"):

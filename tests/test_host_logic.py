@@ -82,13 +82,11 @@ def test_replay_matches_oracle(pkg, case):
     got = eng.debug_replay_pairs(first, second)
     assert np.array_equal(got, want), "removed sets differ: %d vs %d" % (got.sum(), want.sum())
     # the same in instalments (the streaming replay of a run resumes every subcontig at window-batch boundaries)
-    for steps in ("2", "7", "1000"):
-        os.environ["LDP_DEBUG_REPLAY_STEPS"] = steps
-        try:
-            again = eng.debug_replay_pairs(first, second)
-        finally:
-            del os.environ["LDP_DEBUG_REPLAY_STEPS"]
+    for steps in (2, 7, 1000):
+        eng.set_option("replay_steps", steps)
+        again = eng.debug_replay_pairs(first, second)
         assert np.array_equal(again, want), steps
+    eng.set_option("replay_steps", 0)
     eng.close()
 
 

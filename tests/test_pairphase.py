@@ -244,9 +244,10 @@ def test_oracle_sex_chromosome_layouts_match_reference_golden():
 
 
 def test_portable_bit_deposit_path():
-    """the phase decoder uses pext/pdep when the host has BMI2; LDP_PGEN_NO_BMI2 forces the portable loops"""
+    """the phase decoder uses pext/pdep when the host has BMI2; ldp_pgen_debug_force_portable(1) -- which tests/conftest.py calls when
+    LDTEST_PGEN_PORTABLE is set: the library itself reads no environment -- forces the portable loops"""
     import sys
-    env = dict(os.environ, LDP_PGEN_NO_BMI2="1")
+    env = dict(os.environ, LDTEST_PGEN_PORTABLE="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "not gpu", "-k", "reader", "-p", "no:cacheprovider"],
                        env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-800:]

@@ -114,17 +114,15 @@ def test_small_launches_and_sharded_engines(gpu_pkg, tmp_path, monkeypatch):
     host = engine(pkg, n, m)
     host.load_genotypes_host(0, rows, pkg.LDP_GENO_REF)
     want = host.run()
-    monkeypatch.setenv("LDP_DEBUG_DECODE_ROWS", "5")
     dev = engine(pkg, n, m)
+    dev.set_option("decode_rows", 5)
     dev.load_pgen_records(0, f)
     assert_same_rows(host, dev, m)
-    monkeypatch.delenv("LDP_DEBUG_DECODE_ROWS")
     # rows assembled in global memory (what rows beyond 128 KiB take) instead of LDS
-    monkeypatch.setenv("LDP_DEBUG_DECODE_NO_LDS", "1")
     dev_g = engine(pkg, n, m)
+    dev_g.set_option("decode_no_lds", 1)
     dev_g.load_pgen_records(0, f)
     assert_same_rows(host, dev_g, m)
-    monkeypatch.delenv("LDP_DEBUG_DECODE_NO_LDS")
     # four chromosomes, two shards on the same device
     chr_idx = (np.arange(m) * 4 // m).astype(np.uint32)
     bps = (np.arange(m, dtype=np.uint32) + 1) * 1000
@@ -416,15 +414,12 @@ def test_device_phase_decode_reports_the_first_unphased_variant(gpu_pkg):
     host.load_genotypes_host(0, f.read_phased(0, first_bad), pkg.LDP_GENO_REF | pkg.LDP_GENO_PHASED)
     for v in range(first_bad):
         assert all(np.array_equal(a, b) for a, b in zip(host.planes(v), dev.planes(v)))
-    for rows_per_launch in (None, "7"):
-        if rows_per_launch:
-            os.environ["LDP_DEBUG_DECODE_ROWS"] = rows_per_launch
-        try:
-            with pytest.raises(pkg.LdpError) as ei:
-                dev.load_pgen_records_phased(0, f)
-        finally:
-            os.environ.pop("LDP_DEBUG_DECODE_ROWS", None)
+    for rows_per_launch in (0, 7):
+        dev.set_option("decode_rows", rows_per_launch)
+        with pytest.raises(pkg.LdpError) as ei:
+            dev.load_pgen_records_phased(0, f)
         assert ei.value.code == pkg.LDP_ERR_UNPHASED and ei.value.variant == first_bad
+    dev.set_option("decode_rows", 0)
     dev.load_pgen_records_phased(0, f, 0, first_bad)   # still usable
     dev.close()
     host.close()

@@ -428,13 +428,10 @@ def test_chrx_weighted_blocks_on_the_device(gpu_pkg, monkeypatch, unsquared, as_
         base = e_all.r2_unphased_block(r0, rc, c0, cc, as_float=as_float)
         ta, tm = e_all.pair_stats_block(r0, rc, c0, cc), e_m.pair_stats_block(r0, rc, c0, cc)
         outs = []
-        for rows_env in (None, "7"):
-            if rows_env:
-                monkeypatch.setenv("LDP_DEBUG_X_ROWS", rows_env)
-            else:
-                monkeypatch.delenv("LDP_DEBUG_X_ROWS", raising=False)
+        for x_rows in (0, 7):
+            e_all.set_option("x_rows", x_rows)
             outs.append(e_all.r2_unphased_block_x(base.copy(), e_m, is_x, r0, c0, flip_all, flip_male, unsquared))
-        monkeypatch.delenv("LDP_DEBUG_X_ROWS", raising=False)
+        e_all.set_option("x_rows", 0)
         got = outs[0]
         assert same_bits(outs[0], outs[1])
         touched = np.zeros(got.shape, dtype=bool)
@@ -468,7 +465,7 @@ def test_chrx_weighted_blocks_on_the_device(gpu_pkg, monkeypatch, unsquared, as_
 @pytest.mark.parametrize("mods,extra,ext", [(["inter-chr"], ["--ld-window-r2", "0.02"], ".vcor"), (["square", "bin"], [], ".unphased.vcor2.bin"),
                                             (["inter-chr", "ref-based"], ["--ld-window-r2", "0"], ".vcor")])
 def test_cli_chrx_device_path_equals_the_pair_lists(gpu_pkg, tmp_path, mods, extra, ext):
-    """plink2-hip's chrX values of dense rows and of the inter-chr table come from ldp_r2_unphased_block_x[_hits]; LDP_DEBUG_X_HOST=1
+    """plink2-hip's chrX values of dense rows and of the inter-chr table come from ldp_r2_unphased_block_x[_hits]; --debug-x-host
     takes the same pairs as lists through the one-wave-per-pair kernel and the host arithmetic (what the band writers do, pinned to the
     reference in test_cli_r2_with_chrx_matches_reference): byte-identical files, also when the device path works in many row chunks."""
     cli = gpu_pkg.build_cli()
@@ -476,9 +473,9 @@ def test_cli_chrx_device_path_equals_the_pair_lists(gpu_pkg, tmp_path, mods, ext
     _x_fileset(tmp_path, m=900, n=210, seed=13)
     flag = "--r-unphased" if "ref-based" in mods else "--r2-unphased"
     outs = []
-    for tag, env in (("dev", {}), ("chunks", {"LDP_DEBUG_X_ROWS": "50"}), ("host", {"LDP_DEBUG_X_HOST": "1"})):
-        got = subprocess.run([cli, "--pfile", "sx", flag] + mods + extra + ["--out", tag], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                             timeout=900, env={**os.environ, **env})
+    for tag, hook in (("dev", []), ("chunks", ["--debug-x-rows", "50"]), ("host", ["--debug-x-host"])):
+        got = subprocess.run([cli, "--pfile", "sx", flag] + mods + extra + hook + ["--out", tag], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                             timeout=900)
         assert got.returncode == 0, got.stdout
         outs.append(open(os.path.join(tmp, tag + ext), "rb").read())
     assert len(outs[0]) > 10000 and outs[0] == outs[2] and outs[1] == outs[2]
