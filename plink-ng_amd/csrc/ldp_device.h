@@ -199,6 +199,7 @@ struct PairKernelArgs {
   // workgroup, and the deferred order costs it 3 % (config 5's density: 115.1 against 118.3 ms); nullptr: wd_tiles serves both
   const MfmaTile* wd_tiles_plain;
   uint32_t n_wd_tiles_plain;
+  uint32_t wd_async;             // the tiles run on pair_mfma_wide_async_kernel (no workgroup barrier in the stage loop; EngineOptions::wide_async)
 };
 
 constexpr uint32_t kRouteComplete = 0, kRouteSparse = 1, kRouteGeneral = 2;

@@ -300,6 +300,9 @@ EngineOptions options_from_env() {
   o.four_tiles = !(ft && (strcmp(ft, "0") == 0));
   const char* dl = LDP_ENV("LDP_DEBUG_WIDE_DIAG_LAST");
   o.wide_diag_last = dl ? static_cast<uint32_t>(std::max(0, atoi(dl))) : 2u;
+  if (const char* wa = LDP_ENV("LDP_DEBUG_WIDE_ASYNC")) {
+    o.wide_async = (atoi(wa) != 0);
+  }
   if (const char* w = LDP_ENV("LDP_DEBUG_WIDE_MIN_REACH")) {
     o.wide_min_reach = static_cast<uint32_t>(std::max(0, atoi(w)));
   }
@@ -1533,6 +1536,8 @@ int ldp_debug_set_option(ldp_engine* e, const char* name, double value) {
       return fail(e, LDP_ERR_INVALID, "sparse_frac must lie in [0, 1]");
     }
     e->opt.sparse_frac = value;
+  } else if (n == "wide_async") {
+    e->opt.wide_async = (value != 0.0);
   } else if (n == "replay_steps") {
     e->opt.replay_steps = static_cast<uint32_t>(std::max(0.0, value));
   } else if (n == "decode_rows") {

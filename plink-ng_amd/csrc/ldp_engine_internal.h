@@ -160,6 +160,7 @@ struct EngineOptions {
   bool pair_gu = true;        // option "pair_gu" 0: the four-product form multiplies x and n (rounds 2-3) instead of allele counts and missing flags
   bool four_tiles = true;     // LDP_PAIR_FOUR_TILES=0: the four-product form stays on the parallelogram plan in wide bands too
   uint32_t wide_diag_last = 2; // LDP_DEBUG_WIDE_DIAG_LAST=k: tiles fewer than k tile distances from the diagonal run at the end of their XCD stream (0: plain J order)
+  bool wide_async = false;     // option "wide_async": the 8 x 8 tiles on pair_mfma_wide_async_kernel (flags instead of a workgroup barrier per stage)
   // test hooks (ldp_debug_set_option only; 0 = off): results never depend on them
   uint32_t replay_steps = 0;   // "replay_steps" k: ldp_debug_replay_pairs() walks every subcontig in k instalments, as the streaming replay of a run does
   uint32_t decode_rows = 0;    // "decode_rows" k: record decode in launches of k rows (LD chains cut everywhere)

@@ -351,6 +351,7 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.wd_active = 0;
   A.wd_tiles_plain = nullptr;
   A.n_wd_tiles_plain = 0;
+  A.wd_async = e->opt.wide_async ? 1u : 0u;
 }
 
 // A new load epoch begins (variants are being loaded again): whatever the pair streams still run belongs to the

@@ -605,6 +605,498 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
 #endif
 }
 
+
+// ================================================================================================================================
+// pair_mfma_wide_async_kernel -- the same tiles, the same arithmetic, NO workgroup barrier in the stage loop (round 5).
+//
+// With s_barrier at every stage the eight waves of the one workgroup a CU holds move in lock-step: after a barrier all of them issue
+// their DMA share, read LDS and expand before the first MFMA, so the two waves of a SIMD meet their bubbles together and the matrix
+// pipe idles (profiles/r05_experiments.md: the attribution).  Here the waves only exchange two counters each through LDS:
+//   s_flags[w]      stages whose DMA share of wave w has landed  (wave w: s_waitcnt vmcnt, then the store)
+//   s_flags[8 + w]  stages wave w has finished reading
+// A stage is 256 samples (32 KiB for the 16 row-blocks), the ring holds FOUR: the one being multiplied, the next one (landed), and
+// two in flight -- the same 64 KiB in flight and the same two stage-times (4,096 matrix-pipe cycles per SIMD) for a load to land as
+// the two-stage ring of 512-sample stages above.  Wave w, stage s:
+//   top     wait until every wave's share of stage s has landed (s_flags[0..7] > s)            -- normally true for a stage already
+//   issue   its share of stage s + 3 into the buffer of stage s - 1, once every wave has finished that one (s_flags[8..15] >= s);
+//           not yet?  then after the stage (the wave is ahead of the others: nothing is late)
+//   multiply stage s (wide_stage, as above)
+//   end     store "finished s"; s_waitcnt vmcnt until its share of stage s + 2 has landed (issued two stages ago), store that
+// so a wave may run a whole stage ahead of or behind any other without anybody waiting, and the two waves of a SIMD drift out of
+// phase: one multiplies while the other reads and expands.  LDS executes a wave's operations in order, so "data read, then flag
+// stored" and "flag seen, then data read" need no more than program order (compiler fences only).  A spin that never ends would be a
+// bug in this protocol: it traps after ~2^22 polls instead of hanging the device.
+// Checkpoints, epilogue, plan and counters are those of the kernel above; the two are interchangeable launch by launch
+// (PairKernelArgs::wd_async, engine option "wide_async") and the parity tests run both.
+constexpr uint32_t kWaStageSamples = 256;
+constexpr uint32_t kWaPieces = 4;                                        // 16-byte pieces per row and stage
+constexpr uint32_t kWaBlockUnits = kMfBlock * kWaPieces;                 // 128
+constexpr uint32_t kWaStageDwords = kWdRowBlocks * kWaBlockUnits * 4;    // 8,192 dwords = 32 KiB
+constexpr uint32_t kWaRing = 4;
+constexpr uint32_t kWaInstrPerBlock = kWaBlockUnits / 64;                // 2
+constexpr uint32_t kWaDma = (kWdRowBlocks * kWaInstrPerBlock) / kWdWaves;  // DMA wave-instructions per wave and stage: 4
+constexpr uint32_t kWaKsteps = kWaStageSamples / 64;                     // 4
+static_assert(kWaStageDwords * kWaRing <= kWdLdsDwords, "ring fits the epilogue scratch");
+__device__ __forceinline__ uint32_t wa_swizzle(uint32_t row) { return (row >> 2) & 3u; }  // (StageGeom<4>'s: 64-byte row pitch)
+
+// wait until at most `allowed` of this wave's loads are in flight (no barrier)
+__device__ __forceinline__ void wait_dma_only(uint32_t allowed) {
+#define LDP_WAIT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+  switch (allowed) {
+    LDP_WAIT_CASE(1) LDP_WAIT_CASE(2) LDP_WAIT_CASE(3) LDP_WAIT_CASE(4) LDP_WAIT_CASE(5) LDP_WAIT_CASE(6) LDP_WAIT_CASE(7) LDP_WAIT_CASE(8)
+    LDP_WAIT_CASE(9) LDP_WAIT_CASE(10) LDP_WAIT_CASE(11) LDP_WAIT_CASE(12)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef LDP_WAIT_CASE
+}
+
+// The counters are read and written by hand-placed LDS instructions: through a pointer hipcc would either take the generic address
+// space (flat_load: it counts against vmcnt AND lgkmcnt) or, seeing an LDS read behind an LDS-DMA it cannot tell apart from it, put
+// `s_waitcnt vmcnt(0)` in front of every poll -- and drain the ring.  (An LDS operation the compiler does not know about only makes
+// its own lgkmcnt waits more conservative: LDS returns in order.)
+__device__ __forceinline__ uint32_t wa_flag_read(uint32_t lds_byte_addr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_byte_addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void wa_flag_write(uint32_t lds_byte_addr, uint32_t value) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(lds_byte_addr), "v"(value) : "memory");
+}
+
+template <int ABL>
+__global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_async_kernel(PairKernelArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ uint32_t s_need[kWdWaves];
+  __shared__ uint32_t s_flags[2 * kWdWaves];
+  if (*A.route != kRouteComplete) {
+    return;
+  }
+  const uint32_t per_xcd = (A.n_wd_tiles + 7) / 8;
+  const uint32_t idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (idx >= A.n_wd_tiles) {
+    return;
+  }
+  const MfmaTile* __restrict__ tile = A.wd_tiles + idx;
+#ifdef LDP_MEASURE
+  unsigned long long m_t[3] = {0, 0, 0};
+  const unsigned long long m_clk0 = wd_clk(), m_wall0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  const uint32_t tid = threadIdx.x;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lane = tid & 63;
+  const uint32_t r = lane & 31;
+  const uint32_t h = lane >> 5;
+  const int32_t jv0 = __builtin_amdgcn_readfirstlane(tile->jv);
+  const int32_t vv0 = __builtin_amdgcn_readfirstlane(tile->vv);
+  const uint32_t jend = __builtin_amdgcn_readfirstlane(tile->jend);
+  const uint32_t mask_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tile->mask));
+  const uint32_t mask_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tile->mask >> 32));
+  if (!(mask_lo | mask_hi)) {
+    return;
+  }
+  if (tid < 2 * kWdWaves) {
+    s_flags[tid] = 0;
+  }
+  __syncthreads();
+  const uint32_t flags_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t*)s_flags));
+  const uint32_t poll_addr = flags_addr + 4 * (lane & 15);
+  const bool diag = (jv0 == vv0);
+  const int32_t g_bias = g_bias_of(A.founder_ct, kWdStageSamples);   // (whole 512-sample chunks are visited, as above)
+  const uint32_t row_bytes = static_cast<uint32_t>(A.code_row_bytes);
+  const uint32_t n_stages = 2 * ((A.founder_ct + kWdStageSamples - 1) / kWdStageSamples);
+
+  const uint32_t a0 = 2 * (wave & 3), b0 = 4 * (wave >> 2);
+  const uint32_t vslot0 = (diag ? 0u : static_cast<uint32_t>(kWdTile)) + b0;
+  auto mask_row = [&](uint32_t a) { return ((a < 4) ? (mask_lo >> (8 * a)) : (mask_hi >> (8 * (a - 4)))) & 0xffu; };
+  uint32_t live = ((mask_row(a0) >> b0) & 0xfu) | (((mask_row(a0 + 1) >> b0) & 0xfu) << 4);
+  live = __builtin_amdgcn_readfirstlane(live);
+  uint32_t wg_need = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < static_cast<uint32_t>(kWdWaves); ++w) {
+    const uint32_t wa = 2 * (w & 3), wb = 4 * (w >> 2);
+    const uint32_t wl = ((mask_row(wa) | mask_row(wa + 1)) >> wb) & 0xfu;
+    wg_need |= wide_slots_needed(wl, wa, (diag ? 0u : static_cast<uint32_t>(kWdTile)) + wb);
+  }
+  wg_need = __builtin_amdgcn_readfirstlane(wg_need);
+  auto slot_first = [&](uint32_t s) { return (s < static_cast<uint32_t>(kWdTile)) ? (jv0 + static_cast<int32_t>(kMfBlock * s)) : (vv0 + static_cast<int32_t>(kMfBlock * (s - kWdTile))); };
+
+  // ---- DMA plan: instruction T of a stage = half of row-block slot T >> 1: sixteen rows x four 16-byte pieces ----
+  const uint8_t* base_t[kWaDma];
+  uint32_t src_off[kWaDma];
+#pragma unroll
+  for (int t = 0; t < static_cast<int>(kWaDma); ++t) {
+    const uint32_t T = wave + kWdWaves * t;
+    const uint32_t slot = T / kWaInstrPerBlock;
+    uint32_t first = static_cast<uint32_t>(slot_first(slot));
+    first = (first < A.n_local) ? first : (A.n_local - 1);
+    first = __builtin_amdgcn_readfirstlane(first);
+    base_t[t] = A.codes + static_cast<uint64_t>(first) * row_bytes;
+    const uint32_t rr = (T % kWaInstrPerBlock) * 16 + (lane >> 2);
+    const uint32_t col = (lane & 3) ^ wa_swizzle(rr);
+    uint32_t var = first + rr;
+    var = (var < A.n_local) ? var : (A.n_local - 1);
+    src_off[t] = (var - first) * row_bytes + col * 16;
+  }
+  auto count_mine = [&]() {
+    uint32_t m = 0;
+#pragma unroll
+    for (int t = 0; t < static_cast<int>(kWaDma); ++t) {
+      m += ((wg_need >> ((wave + kWdWaves * t) / kWaInstrPerBlock)) & 1u) ? 1u : 0u;
+    }
+    return m;
+  };
+  uint32_t mine = count_mine();
+
+  uint32_t joff[2], voff[4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    joff[q] = (a0 + q) * kWaBlockUnits;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    voff[b] = (vslot0 + b) * kWaBlockUnits;
+  }
+  uint32_t need = wide_slots_needed(live, a0, vslot0);
+  uint32_t lo_j2[2] = {0xffffffffu, 0xffffffffu};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint32_t j = static_cast<uint32_t>(jv0) + kMfBlock * (a0 + q) + r;
+    if (j < jend) {
+      lo_j2[q] = A.lo[j];
+    }
+  }
+  const uint32_t sw = wa_swizzle(r);
+  const uint32_t oH = r * kWaPieces + (h ^ sw), oR = r * kWaPieces + ((2 + h) ^ sw);
+
+  mf_v16f acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      acc[p][g] = 0.f;
+    }
+  }
+
+  uint32_t next_cp = 0;
+  const uint32_t n_cp = A.cp_stats ? A.n_checkpoints : 0;
+  const uint32_t live0 = live;
+  uint32_t stop_stage = n_stages;
+  auto dma_stage = [&](uint32_t s) {
+    const uint32_t kbyte = s * (kWaStageSamples / 4);
+    uint32_t* dst = lds + (s & (kWaRing - 1)) * kWaStageDwords;
+#pragma unroll
+    for (int t = 0; t < static_cast<int>(kWaDma); ++t) {
+      const uint32_t T = wave + kWdWaves * t;
+      if ((wg_need >> (T / kWaInstrPerBlock)) & 1u) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_t[t] + kbyte + src_off[t]),
+                                         (__attribute__((address_space(3))) void*)(dst + T * 256), 16, 0, 0);
+      }
+    }
+  };
+  auto checkpoint_stage = [&](uint32_t cp) {
+    const uint32_t s = 2 * A.checkpoint_chunk[cp];  // (checkpoints sit on 512-sample chunk boundaries)
+    return (s < n_stages) ? s : n_stages;
+  };
+  // poll the sixteen counters: has every wave's share of stage `s_landed` landed, has every wave finished stage `s_done`?
+  // (s_done < 0: nothing to wait for)
+  auto poll = [&](uint32_t need_landed, uint32_t need_done, bool* landed_ok, bool* done_ok) {
+    const uint32_t v = wa_flag_read(poll_addr);
+    *landed_ok = __all((lane & 8) || (v >= need_landed));
+    *done_ok = __all(!(lane & 8) || (v >= need_done));
+  };
+  auto spin_fail = [&]() { __builtin_trap(); };
+
+  uint32_t* epi = lds + wave * kWdEpiWaveDwords;
+  uint32_t issued = 0, confirmed = 0;
+  uint32_t issue_limit = (next_cp < n_cp) ? checkpoint_stage(next_cp) : n_stages;
+  auto ring_fill = [&](uint32_t base) {  // (every buffer is free: the kernel's start, or behind a checkpoint's barriers)
+    while ((issued < issue_limit) && (issued < base + kWaRing - 1)) {
+      dma_stage(issued);
+      ++issued;
+    }
+  };
+  // this wave's share of every stage <= c has landed: tell the others
+  auto confirm = [&](uint32_t c) {
+    wait_dma_only(mine * (issued - c - 1));
+    wa_flag_write(flags_addr + 4 * wave, c + 1);
+    confirmed = c + 1;
+  };
+  ring_fill(0);
+  for (uint32_t kc = 0; kc < n_stages;) {
+    const uint32_t kc_end = issue_limit;
+    for (; kc < kc_end; ++kc) {
+      if (confirmed <= kc) {
+        confirm(kc);  // (only behind a ring_fill)
+      }
+#ifdef LDP_MEASURE
+      const unsigned long long m_p0 = ((ABL & 32) != 0) ? wd_clk() : 0ull;
+#endif
+      // buffer of the stage to issue next (stage `issued`, buffer of stage issued - 4): free once every wave has finished that stage
+      const bool want_issue = (issued < issue_limit);
+      const uint32_t need_done = (issued >= kWaRing) ? (issued - kWaRing + 1) : 0u;
+      bool landed_ok, done_ok;
+      poll(kc + 1, need_done, &landed_ok, &done_ok);
+      if (live) {
+        for (uint32_t spin = 0; !landed_ok; ++spin) {
+          __builtin_amdgcn_s_sleep(1);
+          poll(kc + 1, need_done, &landed_ok, &done_ok);
+          if (spin > (1u << 22)) {
+            spin_fail();
+          }
+        }
+      }
+      bool pending = false;
+      if (want_issue) {
+        if (done_ok) {
+          dma_stage(issued);
+          ++issued;
+        } else {
+          pending = true;
+        }
+      }
+#ifdef LDP_MEASURE
+      if constexpr ((ABL & 32) != 0) {
+        m_t[0] += wd_clk() - m_p0;
+      }
+#endif
+      if (live) {
+        const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + (kc & (kWaRing - 1)) * kWaStageDwords);
+        wide_stage<0>(st4, joff, voff, oH, oR, acc);
+      }
+      wa_flag_write(flags_addr + 4 * (kWdWaves + wave), kc + 1);  // finished reading stage kc (LDS runs this wave's reads before this store)
+#ifdef LDP_MEASURE
+      const unsigned long long m_q0 = ((ABL & 32) != 0) ? wd_clk() : 0ull;
+#endif
+      if (pending) {
+        for (uint32_t spin = 0;; ++spin) {
+          poll(0, need_done, &landed_ok, &done_ok);
+          if (done_ok) {
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          if (spin > (1u << 22)) {
+            spin_fail();
+          }
+        }
+        dma_stage(issued);
+        ++issued;
+      }
+#ifdef LDP_MEASURE
+      const unsigned long long m_q1 = ((ABL & 32) != 0) ? wd_clk() : 0ull;
+#endif
+      // the share issued two stages ago must have landed by now: the others will want it a stage from here
+      {
+        const uint32_t c = (kc + 2 < issued) ? (kc + 2) : (issued - 1);
+        if (confirmed <= c) {
+          confirm(c);
+        }
+      }
+#ifdef LDP_MEASURE
+      if constexpr ((ABL & 32) != 0) {
+        m_t[1] += m_q1 - m_q0;
+        m_t[2] += wd_clk() - m_q1;
+      }
+#endif
+    }
+    if (kc >= n_stages) {
+      break;
+    }
+    // ---- checkpoint (as in the kernel above; a stage is 256 samples here) ----
+    __syncthreads();
+    {
+      const uint8_t* cps = reinterpret_cast<const uint8_t*>(A.cp_stats);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint32_t T = wave + kWdWaves * t;
+        if ((wg_need >> T) & 1u) {
+          uint32_t first = static_cast<uint32_t>(slot_first(T));
+          first = (first < A.n_local) ? first : (A.n_local - 1);
+          uint32_t var = first + (lane >> 1);
+          var = (var < A.n_local) ? var : (A.n_local - 1);
+          const uint64_t off = static_cast<uint64_t>(var) * (kCpStride * sizeof(cp_slot)) + ((lane & 1) ? kCheckpoints : next_cp) * sizeof(cp_slot);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cps + off),
+                                           (__attribute__((address_space(3))) void*)(lds + kWdCpScratchDwords + T * 256), 16, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    const cp_slot* __restrict__ cpl = reinterpret_cast<const cp_slot*>(lds + kWdCpScratchDwords);
+    int32_t* __restrict__ sp = reinterpret_cast<int32_t*>(lds + kWdCpScratchDwords + kWdRowBlocks * kMfBlock * 8);
+    const int32_t cp_seen = static_cast<int32_t>(kc * kWaStageSamples);
+    {
+      const double n_all = static_cast<double>(A.founder_ct);
+      const double kappa = sqrt(((static_cast<double>(cp_seen) < n_all) ? (n_all - static_cast<double>(cp_seen)) : 1.0) / n_all);
+      for (uint32_t q = tid; q < kWdRowBlocks * kMfBlock; q += kWdWaves * 64) {
+        sp[q] = static_cast<int32_t>(cpl[2 * q + 1].a) - static_cast<int32_t>(rint(cpl[2 * q].a * kappa));
+      }
+      __syncthreads();
+    }
+    if (live) {
+      uint32_t keep = 0;
+      uint32_t* cp_epi = lds + wave * kWdCpWaveDwords;
+#pragma unroll
+      for (int round = 0; round < 4; ++round) {
+        if (!(live & (0x3u << (2 * round)))) {
+          continue;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          if (live & (1u << (2 * round + pl))) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+              cp_epi[(pl * 16 + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>(acc[2 * round + pl][g]));
+            }
+          }
+        }
+        const int q = (round >= 2) ? 1 : 0;
+        const int64_t j64 = static_cast<int64_t>(jv0) + kMfBlock * (a0 + q) + r;
+        const int64_t lo_j = lo_j2[q];
+        const uint32_t jslot = a0 + q;
+        const cp_slot cj = cpl[(jslot * kMfBlock + r) * 2];
+        const cp_slot gj = cpl[(jslot * kMfBlock + r) * 2 + 1];
+        const int32_t tj = sp[jslot * kMfBlock + r] - cp_seen;
+#pragma unroll 1
+        for (uint32_t pl = 0; pl < 2; ++pl) {
+          const uint32_t p = 2 * round + pl;
+          if (!(live & (1u << p))) {
+            continue;
+          }
+          const uint32_t b = p & 3;
+          const uint32_t vslot = vslot0 + b;
+          bool hopeless = true;
+#pragma unroll 2
+          for (uint32_t g = 0; g < 16; ++g) {
+            const uint32_t row = (g & 3) + 8 * (g >> 2) + 4 * h;
+            const int64_t i64 = static_cast<int64_t>(vv0) + kMfBlock * (b0 + b) + row;
+            if ((i64 >= lo_j) && (i64 < j64)) {
+              const cp_slot ci = cpl[(vslot * kMfBlock + row) * 2];
+              const cp_slot gi = cpl[(vslot * kMfBlock + row) * 2 + 1];
+              const double dot_p = static_cast<double>(static_cast<int32_t>(cp_epi[(pl * 16 + g) * 64 + lane]) + tj + sp[vslot * kMfBlock + row]);
+              const double c0 = fma(static_cast<double>(A.founder_ct), dot_p, fma(ci.a, cj.a, -(gi.a * gj.a)));
+              const double bound = fabs(c0) + fma(ci.b, cj.b, 1.0);
+              hopeless = hopeless && (bound < gi.b * gj.b);
+            }
+          }
+          if (!__all(hopeless)) {
+            keep |= 1u << p;
+          }
+        }
+      }
+      keep = __builtin_amdgcn_readfirstlane(keep);
+      if (keep != live) {
+        live = keep;
+        need = wide_slots_needed(live, a0, vslot0);
+        if (!live) {
+          stop_stage = kc;
+        }
+      }
+    }
+    ++next_cp;
+    if (lane == 0) {
+      s_need[wave] = need;
+    }
+    __syncthreads();
+    uint32_t all_need = 0;
+#pragma unroll
+    for (int w = 0; w < kWdWaves; ++w) {
+      all_need |= s_need[w];
+    }
+    __syncthreads();
+    if (!all_need) {
+      break;
+    }
+    if (all_need != wg_need) {
+      wg_need = __builtin_amdgcn_readfirstlane(all_need);
+      mine = count_mine();
+    }
+    issue_limit = (next_cp < n_cp) ? checkpoint_stage(next_cp) : n_stages;
+    ring_fill(kc);
+  }
+  __syncthreads();
+  if ((lane == 0) && live0) {
+    const uint32_t planned = __builtin_popcount(live0);
+    if (stop_stage < n_stages) {
+      atomicAdd(A.counters + 2, static_cast<unsigned long long>(n_stages - stop_stage) * kWaKsteps * planned);
+    }
+    if (planned < 8) {
+      atomicAdd(A.counters + 1, static_cast<unsigned long long>(stop_stage) * kWaKsteps * (8 - planned));
+    }
+  }
+
+  // ---- epilogue (as above) ----
+  uint32_t n_true = 0;
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    if (!(live & (0xfu << (4 * round)))) {
+      continue;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) {
+      if (live & (1u << (4 * round + pl))) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          epi[(pl * 16 + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>((round ? acc[4 + pl] : acc[pl])[g]));
+        }
+      }
+    }
+    const int64_t j64 = static_cast<int64_t>(jv0) + kMfBlock * (a0 + round) + r;
+    if (j64 < static_cast<int64_t>(jend)) {
+      const uint32_t j = static_cast<uint32_t>(j64);
+      const uint32_t lo_j = lo_j2[round];
+      if (lo_j < j) {
+        const int32_t sum_j = A.recs[j].sum;
+        const uint32_t ssq_j = A.recs[j].ssq;
+        const uint32_t flags_j = A.recs[j].flags;
+        const int32_t sum_img_j = (flags_j & 1u) ? -sum_j : sum_j;
+#pragma unroll 1
+        for (uint32_t pl = 0; pl < 4; ++pl) {
+          if (!(live & (1u << (4 * round + pl)))) {
+            continue;
+          }
+          const int64_t vfirst = static_cast<int64_t>(vv0) + kMfBlock * (b0 + pl) + 4 * h;
+#pragma unroll 1
+          for (uint32_t g = 0; g < 16; ++g) {
+            const int64_t i64 = vfirst + (g & 3) + 8 * (g >> 2);
+            if ((i64 < static_cast<int64_t>(lo_j)) || (i64 >= j64)) {
+              continue;
+            }
+            const uint32_t i = static_cast<uint32_t>(i64);
+            const ldp_variant_rec ri = A.recs[i];
+            ldp_pair_stats_t ps;
+            const int32_t dot_img = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]) + sum_img_of(ri) + sum_img_j - g_bias;
+            ps.dot = ((ri.flags ^ flags_j) & 1u) ? -dot_img : dot_img;
+            ps.nm = A.founder_ct;
+            ps.sum1 = ri.sum;
+            ps.ssq1 = ri.ssq;
+            ps.sum2 = sum_j;
+            ps.ssq2 = ssq_j;
+            n_true += emit_pair(A, i, j, lo_j, ps) ? 1 : 0;
+          }
+        }
+      }
+    }
+  }
+  n_true = wave_reduce_add(n_true);
+  if ((lane == 0) && n_true) {
+    atomicAdd(A.counters, static_cast<unsigned long long>(n_true));
+  }
+#ifdef LDP_MEASURE
+  {
+    const unsigned long long m_clk1 = wd_clk(), m_wall1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      if constexpr ((ABL & 32) != 0) {
+        atomicAdd(&g_wide_measure[11], m_t[0]);  // top-of-stage polls (+ the DMA issue behind them)
+        atomicAdd(&g_wide_measure[12], m_t[1]);  // deferred issues
+        atomicAdd(&g_wide_measure[13], m_t[2]);  // s_waitcnt vmcnt of the confirmations
+      }
+      atomicAdd(&g_wide_measure[6], m_clk1 - m_clk0);
+      atomicAdd(&g_wide_measure[7], 1ull);
+      atomicAdd(&g_wide_measure[8], m_wall1 - m_wall0);
+    }
+  }
+#endif
+}
+
 }  // namespace
 
 hipError_t launch_pair_wide(const PairKernelArgs& a_in, hipStream_t stream) {
@@ -620,6 +1112,16 @@ hipError_t launch_pair_wide(const PairKernelArgs& a_in, hipStream_t stream) {
   // LDP_DEBUG_WIDE_ABLATE (measurement build only; bits 0-3 give WRONG results): see wide_stage.  Read at every launch.
   const char* v = LDP_ENV("LDP_DEBUG_WIDE_ABLATE");
   const int ablate = v ? atoi(v) : 0;
+  if (a.wd_async) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_async_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_async_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (ablate & 32) {
+      hipLaunchKernelGGL(pair_mfma_wide_async_kernel<32>, grid, block, lds, stream, a);
+    } else {
+      hipLaunchKernelGGL(pair_mfma_wide_async_kernel<0>, grid, block, lds, stream, a);
+    }
+    return hipGetLastError();
+  }
 #define LDP_WD_CASE(n)                                                                                                                                        \
   case n:                                                                                                                                                     \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<n>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
@@ -635,10 +1137,16 @@ hipError_t launch_pair_wide(const PairKernelArgs& a_in, hipStream_t stream) {
 #undef LDP_WD_CASE
 #else
   static const bool attr_set = []() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kWdLdsDwords * sizeof(uint32_t))) == hipSuccess;
+    const int bytes = static_cast<int>(kWdLdsDwords * sizeof(uint32_t));
+    return (hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) &&
+           (hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_async_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess);
   }();
   (void)attr_set;
-  hipLaunchKernelGGL(pair_mfma_wide_kernel<0>, grid, block, lds, stream, a);
+  if (a.wd_async) {
+    hipLaunchKernelGGL(pair_mfma_wide_async_kernel<0>, grid, block, lds, stream, a);
+  } else {
+    hipLaunchKernelGGL(pair_mfma_wide_kernel<0>, grid, block, lds, stream, a);
+  }
 #endif
   return hipGetLastError();
 }

@@ -136,3 +136,38 @@ def test_config3_sample_count_against_oracle(gpu_pkg):
         assert eng.counters()["window_max"] > 128
         eng.close()
         assert np.array_equal(got, want)
+
+
+def test_three_kernel_families_agree_at_config3_density(gpu_pkg):
+    """N = 500,000 samples, 6,000 variants of the benchmark generator at config 3's density (290 bp, 500kb 0.2: the band reaches 54
+    row-blocks, the 8 x 8 tile plan): the tile kernel with a workgroup barrier per stage, the barrier-free one (pair_mfma_wide_async_kernel)
+    and the popcount kernels on bit-planes (another plan, another arithmetic: no matrix pipe, no early termination) must remove the same
+    variants and find the same number of pairs above the threshold; the two tile kernels must also retire the same work."""
+    import torch
+    import bench
+    pkg = gpu_pkg
+    n, m = 500000, 6000
+    chr_idx, bps = bench.genome_layout(m, 1, 290)
+    stride = (n + 3) // 4
+    buf = torch.empty((m, stride), dtype=torch.uint8, device="cuda")
+    pkg.synth_genotypes_device(bench.SEED, 0, m, n, 0.0, buf.data_ptr(), stride)
+    torch.cuda.synchronize()
+    got = {}
+    for name, opts in (("barrier", {}), ("async", {"wide_async": 1}), ("async_exhaustive", {"wide_async": 1, "early_exit": 0}),
+                       ("popcount", {"pair_mfma": 0, "early_exit": 0})):
+        eng = pkg.LdPruneEngine(n, pkg.kb_window(500.0), 1, True, 0.2, device=0)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        eng.set_variants(chr_idx, bps)
+        eng.load_genotypes_device(0, m, buf.data_ptr(), stride, pkg.LDP_GENO_REF)
+        got[name] = (eng.run(), eng.counters())
+        eng.close()
+    base, cb = got["barrier"]
+    assert cb["wide_tiles"] > 0 and cb["mfma_skipped_product_stages"] > 0 and 0.1 * m < base.sum() < 0.9 * m
+    for name in ("async", "async_exhaustive", "popcount"):
+        r, c = got[name]
+        assert np.array_equal(r, base), name
+        assert c["pred_true"] == cb["pred_true"], name
+    ca = got["async"][1]
+    assert ca["wide_tiles"] == cb["wide_tiles"] and ca["mfma_skipped_product_stages"] == cb["mfma_skipped_product_stages"]
+    assert got["popcount"][1]["mfma_block_products"] == 0

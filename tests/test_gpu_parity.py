@@ -333,17 +333,24 @@ def test_wide_band_tiles_match_oracle(gpu_pkg, case):
     inv, mf, altmaj, hom, r2h, vaggs = oracle_recs(raw, n)
     want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps if bps is not None else np.arange(m, dtype=np.uint32), mf, window, step, is_bp, r2, order)
     res = {}
-    for ee in (1, 0):
+    # both forms of the tile kernel: a workgroup barrier per 512-sample stage ("wide_async" 0) and the barrier-free one whose waves
+    # exchange counters through LDS (256-sample stages, pair_mfma_wide_async_kernel)
+    for ee, wa in ((1, 0), (0, 0), (1, 1), (0, 1)):
         eng = pkg.LdPruneEngine(n, window, step, is_bp, r2, order=order, device=0)
         eng.set_option("wide_min_reach", min_reach)
         eng.set_option("early_exit", ee)
+        eng.set_option("wide_async", wa)
         eng.set_variants(chr_idx, bps)
         eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
         got = eng.run()
         c = eng.counters()
         assert c["wide_tiles"] > 0 and c["route_complete_launches"] > 0
-        assert np.array_equal(got, want), (ee, int(got.sum()), int(want.sum()))
-        res[ee] = c
+        assert np.array_equal(got, want), (ee, wa, int(got.sum()), int(want.sum()))
+        if wa:
+            assert (c["pred_true"], c["mfma_skipped_product_stages"], c["mfma_extra_product_stages"]) == \
+                   (res[ee]["pred_true"], res[ee]["mfma_skipped_product_stages"], res[ee]["mfma_extra_product_stages"]), (ee, "the two forms retire the same work")
+        else:
+            res[ee] = c
         if ee == 0:
             removed, stats = eng.run_with_stats()
             lo, _ = eng.band()
