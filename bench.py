@@ -38,8 +38,12 @@ One JSON line is printed by rank 0.
                 65,536 cross-chromosome tile set at 500,000 samples, device-side filter, with plink2-hip against the reference on a
                 slice), each with kernel time, roofline and a reference comparison.
   cpu_baseline  reference plink2 (oracle/_ref/plink2, AVX2, all host threads) on a bounded sample of the same generator,
-                prune set compared with the HIP path's; plink2-hip end to end on the same files beside it, and both walls
-                extrapolated linearly to a chr22-sized slice of the metric's genome.
+                prune set compared with the HIP path's; and, at the metric's sample count, BOTH binaries end to end on a chr22-sized
+                share of the metric's genome (176,765 variants x 500,000 samples, a 22 GB fixed-width .pgen: SURVEY 8(d)) --
+                `cpu_baseline.e2e_wall_s`, measured walls, plink2-hip's phase split and file -> HBM rate beside them.
+  headline_bits_check  one chromosome of the timed share re-run alone on the popcount kernels (no matrix pipe, no early termination):
+                its removed bits must equal the timed run's.
+  power_and_clock      socket power / shader clock (rocm-smi) sampled during the timed steps.
 """
 import argparse
 import ctypes
@@ -115,6 +119,168 @@ def write_plink1_fileset(prefix, host_codes, founder_ct, chr_idx, bps):
         f.write("".join("s%d s%d 0 0 2 -9\n" % (s, s) for s in range(founder_ct)))
 
 
+class SmiSampler:
+    """Socket power (W) and shader clock (MHz) as `rocm-smi -P -g --json` reports them, polled on a thread as fast as it answers (a few
+    samples per second) while a tagged window is open: tells a kernel at the socket's power cap (clock pulled below 2.4 GHz) from an
+    issue- or latency-bound one.  Reported, never used for a decision."""
+
+    def __init__(self):
+        import threading
+        self.samples, self.window, self._stop = [], None, False
+        self.cap_w = None
+        try:
+            out = subprocess.run(["/opt/rocm/bin/rocm-smi", "-M", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20).stdout
+            card = next(iter(json.loads(out).values()))
+            caps = [float(v) for k, v in card.items() if "(W)" in k]
+            self.cap_w = caps[0] if caps else None
+        except Exception:
+            pass
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        while not self._stop:
+            if self.window is None:
+                time.sleep(0.02)
+                continue
+            try:
+                out = subprocess.run(["/opt/rocm/bin/rocm-smi", "-P", "-g", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10).stdout
+                card = next(iter(json.loads(out).values()))
+                watts = [float(v) for k, v in card.items() if "ower" in k and "(W)" in k]
+                mhz = [float(mt.group(1)) for k, v in card.items() if "sclk" in k.lower() for mt in [re.search(r"(\d+)\s*Mhz", str(v))] if mt]
+                if self.window is not None:
+                    self.samples.append((self.window, watts[0] if watts else None, mhz[0] if mhz else None))
+            except Exception:
+                time.sleep(0.05)
+
+    def stop(self):
+        self._stop = True
+
+    def summary(self, tag):
+        rows = [r for r in self.samples if r[0] == tag]
+        w = sorted(r[1] for r in rows if r[1] is not None)
+        c = sorted(r[2] for r in rows if r[2] is not None)
+        med = lambda v: v[len(v) // 2] if v else None
+        return {"source": "rocm-smi -P -g polled during the timed steps (%d samples)" % len(rows), "socket_power_w_median": med(w), "socket_power_w_max": w[-1] if w else None,
+                "socket_power_cap_w": self.cap_w, "shader_clock_mhz_median": med(c), "shader_clock_mhz_min": c[0] if c else None, "shader_clock_mhz_max": c[-1] if c else None}
+
+
+class E2EChr22:
+    """BASELINE.json's second metric -- `--indep-pairwise` WALL-CLOCK -- measured, not extrapolated, at the metric's sample count on the
+    largest fileset SURVEY 8(d) allows to be materialised: a chr22-sized share of the metric's genome (176,765 of 10,000,000 variants x
+    500,000 samples, 22 chromosomes at the metric's density), written by the device generator as a fixed-width .pgen (22 GB, page cache
+    or tmpfs).  start() materialises it and starts reference plink2 (all host threads it can use) in the background, so that its
+    minutes run beside the GPU legs of this script; finish() joins it, then runs plink2-hip on the same files with the GPU idle
+    (`--timing`: its own phase split), and compares the two pairs of output files byte for byte."""
+
+    def __init__(self, pkg, torch, cfg, variants, ref_timeout_s=900):
+        self.pkg, self.torch, self.cfg, self.m, self.ref_timeout_s = pkg, torch, cfg, variants, ref_timeout_s
+        self.tmp, self.ref_proc, self.res = None, None, {}
+
+    def start(self):
+        pkg, torch, cfg, m = self.pkg, self.torch, self.cfg, self.m
+        n = cfg["samples"]
+        stride = (n + 3) // 4
+        need = m * stride * 1.15 + 2e9
+        ref_bin = os.path.join(REPO, "oracle", "_ref", "plink2")
+        if not (os.path.exists(ref_bin) and os.access(ref_bin, os.X_OK)):
+            self.res = {"skipped": "oracle/_ref/plink2 not built"}
+            return self
+        where = None
+        for d in ("/dev/shm", tempfile.gettempdir()):
+            try:
+                st = os.statvfs(d)
+                if st.f_bavail * st.f_frsize > need:
+                    where = d
+                    break
+            except OSError:
+                continue
+        if where is None:
+            self.res = {"skipped": "no %.0f GB of scratch space for the fileset" % (need / 1e9)}
+            return self
+        self.tmp = tempfile.mkdtemp(prefix="ldbench_e2e_", dir=where)
+        chr_idx, bps = genome_layout(m, 1, cfg["spacing"])
+        t0 = time.perf_counter()
+        rows_per = max(1, (1 << 30) // stride)
+        dev = torch.empty((rows_per, stride), dtype=torch.uint8, device="cuda")
+        pin = [torch.empty((rows_per, stride), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        with open(os.path.join(self.tmp, "g.pgen"), "wb") as f:
+            f.write(bytes([0x6C, 0x1B, 0x02]) + np.uint32(m).tobytes() + np.uint32(n).tobytes() + bytes([0x40]))   # fixed-width .pgen (pgenlib_read.cc:881-911)
+            k = 0
+            for r0 in range(0, m, rows_per):
+                cnt = min(rows_per, m - r0)
+                pkg.synth_genotypes_device(SEED, r0, cnt, n, 0.0, dev.data_ptr(), stride)
+                torch.cuda.synchronize()
+                pin[k & 1][:cnt].copy_(dev[:cnt])
+                torch.cuda.synchronize()
+                f.write(memoryview(pin[k & 1].numpy()[:cnt]))
+                k += 1
+        del dev, pin
+        torch.cuda.empty_cache()
+        with open(os.path.join(self.tmp, "g.pvar"), "w") as f:
+            f.write("#CHROM\tPOS\tID\tREF\tALT\n" + "".join("%d\t%d\tsnp%d\tA\tC\n" % (chr_idx[i] + 1, bps[i], i) for i in range(m)))
+        with open(os.path.join(self.tmp, "g.psam"), "w") as f:
+            f.write("#IID\tSEX\n" + "".join("s%d\t2\n" % q for q in range(n)))
+        self.file_bytes = 12 + m * stride
+        self.res = {"variants": m, "samples": n, "fileset": "fixed-width .pgen + .pvar + .psam under %s (%.1f GB, written by the device generator in %.1f s)" %
+                    (where, self.file_bytes / 1e9, time.perf_counter() - t0)}
+        self.cores = os.cpu_count() or 1
+        self.kb = "%gkb" % cfg["window_kb"]
+        self.ref_t0 = time.perf_counter()
+        self.ref_proc = subprocess.Popen([ref_bin, "--pfile", "g", "--indep-pairwise", self.kb, repr(cfg["r2"]), "--threads", str(self.cores), "--out", "ref"],
+                                         cwd=self.tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        return self
+
+    def finish(self):
+        if not self.tmp:
+            return self.res
+        try:
+            res = self.res
+            try:
+                ref_out, _ = self.ref_proc.communicate(timeout=self.ref_timeout_s)
+                ref_wall = time.perf_counter() - self.ref_t0
+                ref_rc = self.ref_proc.returncode
+            except subprocess.TimeoutExpired:
+                self.ref_proc.kill()
+                ref_out, ref_wall, ref_rc = "", None, -9
+            mt = re.search(r"\((\d+) compute thread", ref_out or "")
+            res["reference_plink2"] = {"wall_s": ref_wall, "rc": ref_rc, "threads_requested": self.cores, "compute_threads": int(mt.group(1)) if mt else None,
+                                       "note": "started right after the fileset was written and timed to its exit; it ran BESIDE this script's GPU legs (it uses a dozen host "
+                                               "threads, the legs one), so its wall is if anything pessimistic by the legs' host work"}
+            cli_bin = os.path.join(REPO, "plink-ng_amd", "bin", "plink2-hip")
+            self.torch.cuda.synchronize()
+            walls, phases, rc, txt = [], None, None, ""
+            for _ in range(2):   # (the second run: page cache and HIP code objects warm on both sides alike -- the reference ran once, cold HIP start-up is in run 1)
+                t1 = time.perf_counter()
+                cc = subprocess.run([cli_bin, "--pfile", "g", "--indep-pairwise", self.kb, repr(self.cfg["r2"]), "--timing", "--out", "hip"], cwd=self.tmp,
+                                    stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+                walls.append(time.perf_counter() - t1)
+                rc, txt = cc.returncode, cc.stdout
+            ph = re.search(r"setup\+parse ([0-9.]+) s \| genotype load[^|]*?([0-9.]+) s \| run ([0-9.]+) s \(pair kernel ([0-9.]+) ms, replay ([0-9.]+) ms; (\d+) candidate pairs\)", txt)
+            tot = re.search(r"\[timing\] total ([0-9.]+) s", txt)
+            if ph:
+                load_s = float(ph.group(2))
+                phases = {"setup_and_table_parse_s": float(ph.group(1)), "file_to_hbm_s": load_s, "file_to_hbm_gbs": self.file_bytes / load_s / 1e9 if load_s > 0 else None,
+                          "run_s": float(ph.group(3)), "pair_kernels_ms": float(ph.group(4)), "host_replay_ms": float(ph.group(5)), "candidate_pairs": int(ph.group(6)),
+                          "main_total_s": float(tot.group(1)) if tot else None,
+                          "note": "plink2-hip --timing, second run; file_to_hbm covers pread() of the .pgen rows into the pinned ring, H2D and the count pass (they overlap); "
+                                  "run = pair kernels + replay behind the load; the rest of the wall is process start-up, HIP context, list writing and exit"}
+            same = False
+            if rc == 0 and ref_rc == 0:
+                same = all(open(os.path.join(self.tmp, "hip" + e), "rb").read() == open(os.path.join(self.tmp, "ref" + e), "rb").read() for e in (".prune.in", ".prune.out"))
+            res["plink2_hip"] = {"wall_s": min(walls), "wall_s_runs": walls, "rc": rc, "phases": phases}
+            res["files_identical"] = bool(same)
+            res["speedup"] = (ref_wall / min(walls)) if (ref_wall and walls and rc == 0 and ref_rc == 0) else None
+            if ph and ref_wall:
+                res["reference_candidate_pairs_per_s"] = int(ph.group(6)) / ref_wall
+            res["what"] = ("MEASURED end-to-end walls, process start to exit, same command line (--indep-pairwise %s %g) on the same fileset: %d variants (a chr22-sized share "
+                           "of the metric's 10M-variant genome: 22 chromosomes at %d bp) x %d samples" % (self.kb, self.cfg["r2"], self.m, self.cfg["spacing"], self.cfg["samples"]))
+            return res
+        finally:
+            subprocess.call(["rm", "-rf", self.tmp])
+            self.tmp = None
+
+
 def host_description():
     model = ""
     try:
@@ -177,26 +343,6 @@ def cpu_baseline(pkg, torch, founder_ct, m, spacing, window_kb, r2, missing_rate
             cli = {"e2e_wall_s": {"reference_plink2": wall, "plink2_hip": cli_wall, "speedup": wall / cli_wall if cli_wall > 0 else None,
                                   "what": "process start to exit on the sample's .bed/.bim/.fam (page cache warm), same command line"},
                    "plink2_hip_files_identical": bool(same), "plink2_hip_rc": cc.returncode}
-            if full_variants and full_variants > m:
-                # "materialise <= 1 chromosome (chr22-sized) ... and extrapolate -- say so".  Both walls scale with the
-                # variant count once the fixed parts are taken out: the reference's load + frequency + prune passes are all linear in
-                # variants at a fixed window; plink2-hip's fixed part is the HIP context + table start-up (measured on an empty run).
-                chr22 = int(round(full_variants * CHR22_FRACTION))
-                t2 = time.perf_counter()
-                subprocess.run([cli_bin, "--bfile", "sample", "--indep-pairwise", kb, repr(r2), "--dry-run", "--out", "dry"], cwd=tmp, stdout=subprocess.PIPE,
-                               stderr=subprocess.STDOUT, text=True, timeout=600)
-                dry_wall = time.perf_counter() - t2
-                hip_fixed = min(dry_wall, cli_wall)
-                scale = chr22 / float(m)
-                ref_x = wall * scale
-                hip_x = hip_fixed + max(cli_wall - hip_fixed, 0.0) * scale
-                cli["e2e_chr22_extrapolation"] = {
-                    "variants_chr22_sized": chr22, "of_genome_variants": full_variants, "scale_from_sample": scale,
-                    "reference_plink2_s": ref_x, "plink2_hip_s": hip_x, "speedup": (ref_x / hip_x) if hip_x > 0 else None,
-                    "plink2_hip_fixed_s": hip_fixed,
-                    "how": "LINEAR extrapolation of the two measured walls from the %d-variant sample to a chr22-sized chromosome of the genome (%d variants = %.2f %% of "
-                           "%d): reference wall x scale; plink2-hip = its variant-independent part (HIP context + tables: a --dry-run on the same files) + the rest x scale.  "
-                           "An extrapolation, not a measurement (SURVEY 8(d))" % (m, chr22, 100.0 * CHR22_FRACTION, full_variants)}
         mt = re.search(r"\((\d+) compute thread", cp.stdout)
         compute_threads = int(mt.group(1)) if mt else 0
         used = (compute_threads + 1) if mt else cores  # LD compute threads + the decode/main thread
@@ -210,6 +356,39 @@ def cpu_baseline(pkg, torch, founder_ct, m, spacing, window_kb, r2, missing_rate
                 "removed": int(removed_ref.sum())}
     finally:
         subprocess.call(["rm", "-rf", tmp])
+
+
+def headline_bits_check(pkg, torch, wl, removed_mask):
+    """The bits of the headline run, checked: one whole chromosome of the rank's share (the last owned subcontig: chr21 / chr22, ~20,000
+    variants) runs ALONE through a second engine that shares nothing with the timed one but the rows -- the popcount kernels on bit-planes
+    (no matrix pipe, no FP4 operands), no early termination, its own plan -- and its removed bits must equal the big run's for that
+    subcontig.  (Subcontigs are independent: plink2_ld.cc:2686-2694.)"""
+    if not (wl.resident and wl.owned_subs and wl.engines):
+        return {"checked": False, "why": "share not resident"}
+    eng0 = wl.engines[0][0]
+    ln, first = wl.owned_subs[-1]
+    seg = None
+    for sfirst, sln, ptr, stride in wl.segs[id(eng0)]:
+        if sfirst <= first and first + ln <= sfirst + sln:
+            seg = (ptr + (first - sfirst) * stride, stride)
+    if seg is None:
+        return {"checked": False, "why": "subcontig not inside one mapped run"}
+    t0 = time.perf_counter()
+    e = pkg.LdPruneEngine(wl.founder_ct, wl.window_bp, 1, True, wl.cfg["r2"], device=wl.device)
+    e.set_option("pair_mfma", 0)
+    e.set_option("early_exit", 0)
+    sel = slice(first, first + ln)
+    e.set_variants(wl.chr_idx[sel], wl.bps[sel])
+    e.load_genotypes_device(0, ln, seg[0], seg[1], pkg.LDP_GENO_REF)
+    got = e.run()
+    c = e.counters()
+    e.close()
+    torch.cuda.empty_cache()
+    want = np.asarray(removed_mask[sel], dtype=bool)
+    return {"checked": True, "identical": bool(np.array_equal(np.asarray(got, dtype=bool), want)), "subcontig_first_variant": int(first), "variants": int(ln),
+            "removed": int(want.sum()), "candidate_pairs": int(c["candidate_pairs"]), "seconds": time.perf_counter() - t0,
+            "independent_engine": "popcount kernels on bit-planes (pair_mfma 0: ms_pair_mfma %.1f, popcount ms %.1f), early termination off, planned alone" %
+                                  (c["ms_pair_mfma"], c["ms_pair_fast"] + c["ms_pair_general"])}
 
 
 def measured_ceilings():
@@ -617,6 +796,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the config2 / config5-density / config4-tiles legs and the ceiling microbenchmarks")
     ap.add_argument("--no-cli-compare", action="store_true", help="do not time plink2-hip end-to-end on the CPU-baseline sample files")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the measured chr22-sized end-to-end run of both binaries (22 GB fileset, minutes of reference time)")
+    ap.add_argument("--e2e-variants", type=int, default=0, help="variants of that fileset (0 = a chr22-sized share of the named genome: 176,765 of 10M)")
     ap.add_argument("--leg-variants", type=int, default=120000, help="variants of the config5-density leg")
     ap.add_argument("--tile", type=int, default=65536, help="side of the config4_tiles leg's cross-chromosome tile set")
     ap.add_argument("--option", action="append", default=[], help="name=value: a per-engine kernel switch (ldp_debug_set_option) for the main workload, for experiments")
@@ -676,7 +857,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(wl, steps, warmup):
+    def timed(wl, steps, warmup, on_start=None):
         def one():
             words, ctrs = wl.step()
             if use_dist:
@@ -686,6 +867,8 @@ def main():
         for _ in range(warmup):
             one()
         sync()
+        if on_start:
+            on_start()
         t0 = time.perf_counter()
         ks, removed = [], None
         for _ in range(steps):
@@ -706,7 +889,15 @@ def main():
                         "count pass: %.0f GB/s" % ((image_bytes / (cmean["ms_prepare"] * 1e-3) / 1e9) if cmean["ms_prepare"] > 0 else 0.0)}
 
     wl = Workload(pkg, torch, cfg, args.missing_rate, rank, world, local_rank, main_options)
-    elapsed, ks, removed = timed(wl, args.steps, args.warmup)
+    smi = SmiSampler() if rank == 0 else None
+
+    def open_window():
+        if smi:
+            smi.window = "main"   # (the sampler's window covers the timed steps only)
+    elapsed, ks, removed = timed(wl, args.steps, args.warmup, open_window)
+    if smi:
+        smi.window = None
+        smi.stop()
     ctr = ks[-1]
     removed = distmod.bitmap_to_mask(removed.cpu().numpy() if use_dist else removed, cfg["variants"])
     per_rank_pairs = [ctr["candidate_pairs"]]
@@ -719,6 +910,23 @@ def main():
         dist.all_gather(allp, mine)
         per_rank_pairs = [int(x.item()) for x in allp]
     total_pairs = sum(per_rank_pairs)
+    # ---- self-check of an N-rank run (every rank takes part; rank 0 reports): the world really has N ranks, every rank sits on a
+    # device of its own, and the collective backend saw every rank
+    selfcheck = None
+    if use_dist:
+        props = torch.cuda.get_device_properties(local_rank)
+        ident = "%s/%s" % (getattr(props, "uuid", None) or getattr(props, "pci_bus_id", local_rank), getattr(props, "pci_device_id", ""))
+        ids = [None] * world
+        dist.all_gather_object(ids, (rank, local_rank, str(ident)))
+        seen = torch.zeros(world, dtype=torch.int64, device=coll_device)
+        seen[rank] = 1
+        dist.all_reduce(seen)   # (through the collective backend of the timed exchange: RCCL, or gloo under LDP_BENCH_ALIAS_DEVICES)
+        selfcheck = {"world_size": dist.get_world_size(), "world_size_is_n_gpus": bool(dist.get_world_size() == args.gpus),
+                     "backend": dist.get_backend(), "rccl_ranks_seen": int((seen > 0).sum().item()), "ranks": [list(x) for x in ids],
+                     "device_ordinals_distinct": bool(len({x[1] for x in ids}) == world), "devices_distinct": bool(len({x[2] for x in ids}) == world)}
+        if not alias:
+            assert selfcheck["world_size_is_n_gpus"] and selfcheck["rccl_ranks_seen"] == world, selfcheck
+            assert selfcheck["device_ordinals_distinct"], "two ranks share a device ordinal: %r" % (ids,)
 
     out = None
     if rank == 0:
@@ -753,8 +961,50 @@ def main():
                        "engine_options": main_options},
             "roofline": roofline,
             "stage_ms": stage_ms(cmean, wl.image_bytes),
+            "power_and_clock": smi.summary("main") if smi else None,
         }
+        if world == 1:
+            try:
+                out["headline_bits_check"] = headline_bits_check(pkg, torch, wl, removed)
+            except Exception as ex:  # pragma: no cover
+                out["headline_bits_check"] = {"checked": False, "why": str(ex)[:300]}
+        if selfcheck is not None:
+            out["multi_rank_selfcheck"] = selfcheck
+    subset = None
+    if rank == 0 and world > 1:
+        subset = (wl.founder_ct, wl.window_bp, cfg["r2"], wl.chr_idx, wl.bps, wl.m_total)
     wl.close()
+    if subset is not None:
+        # ... and the combined bitmap of the N shards equals ONE engine's result on the last three chromosomes (chr20-22: a contiguous
+        # range of the genome, 5 % of it; subcontigs are independent), computed here on rank 0 after its own share has left the device
+        try:
+            n_f, w_bp, r2v, chr_all, bps_all, m_tot = subset
+            first = int(np.searchsorted(chr_all, 19, side="left"))
+            ln = m_tot - first
+            t0 = time.perf_counter()
+            e1 = pkg.LdPruneEngine(n_f, w_bp, 1, True, r2v, device=local_rank)
+            e1.set_variants(chr_all[first:], bps_all[first:])
+            ptr, stride = e1.map_rows(0, ln)
+            pkg.synth_genotypes_device(SEED, first, ln, n_f, args.missing_rate, ptr, stride)
+            torch.cuda.synchronize()
+            e1.load_genotypes_device(0, ln, ptr, stride, pkg.LDP_GENO_REF)
+            one = np.asarray(e1.run(), dtype=bool)
+            e1.close()
+            torch.cuda.empty_cache()
+            out["multi_rank_selfcheck"]["three_chromosome_subset"] = {
+                "first_variant": first, "variants": int(ln), "identical_to_single_engine": bool(np.array_equal(one, np.asarray(removed[first:], dtype=bool))),
+                "removed": int(one.sum()), "seconds": time.perf_counter() - t0,
+                "what": "chr20-22 of the genome run alone through ONE engine on rank 0 against the stitched bitmap of the %d ranks" % world}
+        except Exception as ex:  # pragma: no cover
+            out["multi_rank_selfcheck"]["three_chromosome_subset"] = {"error": str(ex)[:300]}
+    e2e = None
+    if rank == 0 and world == 1 and (not args.no_cpu_baseline) and (not args.no_e2e) and (not args.no_cli_compare) and cfg["samples"] > 100000:
+        # the metric's wall-clock leg: materialise the chr22-sized fileset now and let the reference run beside the GPU legs below
+        try:
+            e2e = E2EChr22(pkg, torch, cfg, args.e2e_variants or int(round(CONFIGS[name]["variants"] * CHR22_FRACTION))).start()
+        except Exception as ex:  # pragma: no cover
+            e2e = None
+            out["e2e_error"] = str(ex)[:300]
 
     if rank == 0 and world == 1 and not args.no_legs:
         legs = {}
@@ -846,8 +1096,29 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             m = args.cpu_sample_variants or (440000 if cfg["samples"] <= 100000 else 11000)  # ~2-20 s of reference time either way
-            out["cpu_baseline"] = cpu_baseline(pkg, torch, cfg["samples"], m, cfg["spacing"], cfg["window_kb"], cfg["r2"], args.missing_rate,
-                                               cli_compare=not args.no_cli_compare, full_variants=CONFIGS[name]["variants"])
+            cb = cpu_baseline(pkg, torch, cfg["samples"], m, cfg["spacing"], cfg["window_kb"], cfg["r2"], args.missing_rate, cli_compare=not args.no_cli_compare)
+            if e2e is not None:
+                # the wall-clock half of the metric, measured on the chr22-sized fileset; the small slice above stays as the parity check of the
+                # timed engine's generator (prune_set_identical_to_hip) and moves to `slice`
+                big = e2e.finish()
+                ref = big.get("reference_plink2") or {}
+                hip = big.get("plink2_hip") or {}
+                if ref.get("wall_s") and hip.get("wall_s") and ref.get("rc") == 0 and hip.get("rc") == 0:
+                    cb["slice"] = {k: cb.pop(k) for k in ("e2e_wall_s", "sample", "wall_s", "value", "removed") if k in cb}
+                    cb["e2e_wall_s"] = {"reference_plink2": ref["wall_s"], "plink2_hip": hip["wall_s"], "speedup": big.get("speedup"), "variants": big["variants"],
+                                        "samples": big["samples"], "files_identical": big.get("files_identical"), "plink2_hip_phases": hip.get("phases"),
+                                        "plink2_hip_wall_s_runs": hip.get("wall_s_runs"), "reference_compute_threads": ref.get("compute_threads"),
+                                        "fileset": big.get("fileset"), "what": big.get("what"), "reference_note": ref.get("note")}
+                    cb["value"] = big.get("reference_candidate_pairs_per_s")
+                    cb["wall_s"] = ref["wall_s"]
+                    if ref.get("compute_threads"):
+                        cb["cores"] = ref["compute_threads"] + 1
+                    cb["sample"] = ("%d variants x %d samples of the same generator as a fixed-width .pgen (a chr22-sized share of the metric's genome, %s): reference plink2 "
+                                    "AVX2 end-to-end wall %.1f s, %d candidate pairs" % (big["variants"], big["samples"], big.get("fileset", ""), ref["wall_s"],
+                                                                                         (hip.get("phases") or {}).get("candidate_pairs", 0)))
+                else:
+                    cb["e2e_chr22_measurement"] = big   # (incomplete: keep what there is, the slice's numbers stay in place)
+            out["cpu_baseline"] = cb
         else:
             out["cpu_baseline"] = {"value": None, "unit": "variant-pairs/s", "cores": 0, "kind": "reference",
                                    "sample": "measured at N=1 only", **host_description()}

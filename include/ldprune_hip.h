@@ -200,9 +200,9 @@ int ldp_get_band(const ldp_engine* e, uint32_t* lo, uint64_t* candidate_pairs);
 /* ---- data ---- */
 /* Rows [first_variant, first_variant+n) of the variant table.  `geno` points at row first_variant;
  * rows are stride_bytes apart.  location: LDP_MEM_HOST or LDP_MEM_DEVICE.  Rows outside this
- * engine's shard are ignored.  The engine converts to bit-planes resident in HBM, computes the
- * per-variant aggregates (FillVaggs, plink2_ld.cc:725) and, for REF/BED encodings, the allele counts,
- * major allele and inversion.  Host buffers may be reused as soon as the call returns (rows travel through a
+ * engine's shard are ignored.  The engine keeps them as 2-bit REF- / INVERSE-coded rows resident in HBM (bit-planes only with more
+ * founders than ldp_matrix_pipe_max_founders()), computes the per-variant aggregates (FillVaggs, plink2_ld.cc:725) and, for
+ * REF/BED encodings, the allele counts and the major allele (rows are not re-oriented: the records carry the flag).  Host buffers may be reused as soon as the call returns (rows travel through a
  * pinned staging ring).  Device buffers are read asynchronously on the engine's stream: the data must be
  * complete before the call (synchronise the producing stream) and must stay valid until the next ldp_run() /
  * ldp_get_* call returns.
@@ -239,7 +239,12 @@ int ldp_map_rows(ldp_engine* e, uint32_t first_variant, uint32_t n, void** devic
  *                three from a file's index).  Variants this engine does not own are decoded too (LD chains run through them).
  *   ld_base      optional: the record that stands alone (not LD-compressed) on which recs[0], if it is LD-compressed, builds,
  *                when that record is not part of this call.  Without it an LD-compressed first record builds on the last
- *                stand-alone record of the previous call, provided this call starts where that one ended.
+ *                stand-alone record of the previous call, provided this call starts where that one ended -- in the engine
+ *                (first_variant) AND in the file: recs[0].offset must equal the previous call's last offset + length.  Record
+ *                offsets of consecutive calls must therefore live in ONE address space (whole-file offsets, as
+ *                ldp_pgen_record_index() gives them), whatever `bytes` points at; a caller that hands over every chunk in a
+ *                buffer of its own with offsets restarting at 0 passes ld_base (or cuts its chunks at stand-alone records),
+ *                otherwise LDP_ERR_INVALID.
  *   raw_sample_ct  samples of the file = the engine's founder_ct, or the raw count of ldp_set_sample_map() (the engine then
  *                gathers its columns as for LDP_GENO_MAPPED rows; the major allele of a variant with allele_ct > 2 is counted
  *                over the map's samples when the map is a plain subset of the file's -- every sample at most once, no het ->

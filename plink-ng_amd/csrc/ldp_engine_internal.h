@@ -81,13 +81,20 @@ class CopyPool {
   }
   template <class F>
   void run(uint32_t n, uint32_t max_threads, F fn) {
-    if (n <= 1 || workers_.empty()) {
+    // (a forked child inherits the object but none of its threads: it works on its own)
+    if (n <= 1 || workers_.empty() || (getpid() != pid_)) {
       for (uint32_t t = 0; t < n; ++t) {
         fn(t);
       }
       return;
     }
-    std::lock_guard<std::mutex> user(user_mu_);
+    // one user at a time; an engine that finds the pool busy (several engines loading from their own host threads: plink2-hip --gpus N)
+    // does not queue up behind the others' copies but spawns threads for this batch, as every call did before the pool existed
+    std::unique_lock<std::mutex> user(user_mu_, std::try_to_lock);
+    if (!user.owns_lock()) {
+      parallel_for(n, max_threads, fn);
+      return;
+    }
     std::function<void(uint32_t)> f = fn;
     {
       std::lock_guard<std::mutex> lk(mu_);
@@ -136,6 +143,7 @@ class CopyPool {
     }
   }
   std::vector<std::thread> workers_;
+  const pid_t pid_ = getpid();
   std::mutex mu_, user_mu_;
   std::condition_variable cv_, cv_done_;
   std::function<void(uint32_t)>* fn_ = nullptr;

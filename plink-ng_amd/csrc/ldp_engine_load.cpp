@@ -538,17 +538,27 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
       d.base = kPgenNoBase;
     }
     if (location == LDP_MEM_HOST) {
+      // the span of THIS launch's own records goes up in one copy; the caller's ld_base record -- which may lie anywhere before them
+      // (variant filters, a run that starts late in a 64k-variant block: the gap can be gigabytes) -- in a copy of its own behind it
       uint64_t lo = UINT64_MAX, hi = 0;
-      for (uint32_t q = 0; q < rows; ++q) {
+      for (uint32_t q = 0; q < cnt; ++q) {
         lo = std::min<uint64_t>(lo, descs[q].off);
         hi = std::max<uint64_t>(hi, descs[q].off + descs[q].len);
       }
+      const uint64_t span = (hi - lo + 15) & ~static_cast<uint64_t>(15);
+      const uint64_t base_len = with_base_rec ? ld_base->length : 0;
       void* p = nullptr;
-      if ((rc = dec_reserve(e, 0, hi - lo + 16, &p))) {
+      if ((rc = dec_reserve(e, 0, span + base_len + 32, &p))) {
         return rc;
       }
       HIP_TRY(e, hipMemcpyAsync(p, static_cast<const uint8_t*>(bytes) + lo, hi - lo, hipMemcpyHostToDevice, e->stream));
-      d_bytes = static_cast<const uint8_t*>(p) - lo;  // (record offsets stay as the caller gave them)
+      if (with_base_rec) {
+        HIP_TRY(e, hipMemcpyAsync(static_cast<uint8_t*>(p) + span, static_cast<const uint8_t*>(bytes) + ld_base->offset, base_len, hipMemcpyHostToDevice, e->stream));
+        descs[cnt].off = lo + span;  // (where the kernels find it: d_bytes + off)
+      }
+      // record offsets stay as the caller gave them: the kernels add them to this base (an address computed as an integer: `p - lo` need
+      // not lie inside the allocation)
+      d_bytes = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(p) - static_cast<uintptr_t>(lo));
     }
     void *p_recs = nullptr, *p_rows = nullptr, *p_end = nullptr, *p_multi = nullptr, *p_mf = nullptr, *p_mi = nullptr, *p_inv = nullptr;
     if ((rc = dec_reserve(e, 1, rows * sizeof(ldp::PgenRecDesc), &p_recs)) || (rc = dec_reserve(e, 2, static_cast<size_t>(rows) * stride, &p_rows)) ||

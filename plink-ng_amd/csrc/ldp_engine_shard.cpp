@@ -79,6 +79,12 @@ static const Rccl& rccl() {
 }
 }  // namespace ldph
 
+namespace ldph LDP_HIDDEN {
+// communicators ldp_allgather_removed() had to abort: ncclCommAbort has already released them, a later ldp_comm_destroy() is a no-op
+std::mutex g_aborted_mu;
+std::set<void*> g_aborted;
+}  // namespace ldph
+
 int ldp_comm_init_all(int n, const int* devices, void** comms) {
   if ((n < 1) || !comms) {
     return LDP_ERR_INVALID;
@@ -91,17 +97,18 @@ int ldp_comm_init_all(int n, const int* devices, void** comms) {
   if (R.CommInitAll(c.data(), n, devices) != ncclSuccess) {
     return LDP_ERR_GPU;
   }
+  {
+    // (a fresh communicator may live at the address of one that was aborted and never passed to ldp_comm_destroy)
+    std::lock_guard<std::mutex> lk(g_aborted_mu);
+    for (int k = 0; k < n; ++k) {
+      g_aborted.erase(c[k]);
+    }
+  }
   for (int k = 0; k < n; ++k) {
     comms[k] = c[k];
   }
   return LDP_OK;
 }
-
-namespace ldph LDP_HIDDEN {
-// communicators ldp_allgather_removed() had to abort: ncclCommAbort has already released them, a later ldp_comm_destroy() is a no-op
-std::mutex g_aborted_mu;
-std::set<void*> g_aborted;
-}  // namespace ldph
 
 void ldp_comm_destroy(void* comm) {
   if (comm && rccl().ok) {
@@ -188,8 +195,11 @@ int ldp_allgather_removed(ldp_engine* e, void* comm, const uint64_t* removed_loc
   // is enqueued aborts the communicator (ncclCommAbort wakes the other ranks with an error instead of a hang).
   const Rccl& R = rccl();
   ncclComm_t c = static_cast<ncclComm_t>(comm);
+  // (only a handle RCCL itself has answered for is aborted: ncclCommCount on it comes first, before any other reason to leave)
+  int count = 0, urank = -1;
+  const bool handle_ok = c && R.ok && (R.CommCount(c, &count) == ncclSuccess) && (R.CommUserRank(c, &urank) == ncclSuccess);
   auto leave = [&](int code, const std::string& msg) {
-    if (c && R.ok && R.CommAbort) {
+    if (handle_ok && R.CommAbort) {
       (void)R.CommAbort(c);
       std::lock_guard<std::mutex> lk(g_aborted_mu);
       g_aborted.insert(c);
@@ -209,9 +219,8 @@ int ldp_allgather_removed(ldp_engine* e, void* comm, const uint64_t* removed_loc
   if (!e->gpu_ok) {
     return leave(LDP_ERR_GPU, "no usable HIP device");
   }
-  int count = 0, urank = -1;
-  if ((R.CommCount(c, &count) != ncclSuccess) || (R.CommUserRank(c, &urank) != ncclSuccess)) {
-    return leave(LDP_ERR_GPU, "ncclCommCount / ncclCommUserRank failed");
+  if (!handle_ok) {
+    return fail(e, LDP_ERR_GPU, "ncclCommCount / ncclCommUserRank failed: not a live communicator");
   }
   if ((static_cast<uint32_t>(count) != e->world) || (static_cast<uint32_t>(urank) != e->rank)) {
     return leave(LDP_ERR_INVALID, "the communicator's size / rank differ from ldp_set_shard()'s");
@@ -237,9 +246,17 @@ int ldp_allgather_removed(ldp_engine* e, void* comm, const uint64_t* removed_loc
   if (nrc != ncclSuccess) {
     return leave(LDP_ERR_GPU, std::string("ncclAllGather: ") + (R.GetErrorString ? R.GetErrorString(nrc) : "failed"));
   }
+  // (from here on the collective is in flight: the buffers it reads and writes are released only behind a synchronised stream, or --
+  // when that fails too -- behind an aborted communicator)
   std::vector<uint64_t> all(words * e->world);
-  HIP_TRY(e, hipMemcpyAsync(all.data(), recv.p, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  hrc = hipMemcpyAsync(all.data(), recv.p, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream);
+  const hipError_t src = hipStreamSynchronize(e->stream);
+  if ((hrc != hipSuccess) || (src != hipSuccess)) {
+    if (src != hipSuccess) {
+      return leave(LDP_ERR_GPU, std::string("all-gather of the removed bits: ") + hipGetErrorString(src));
+    }
+    return fail(e, LDP_ERR_GPU, std::string("copy of the gathered segments: ") + hipGetErrorString(hrc));
+  }
   return ldp_stitch_removed_segments(e, all.data(), removed_global);
 }
 

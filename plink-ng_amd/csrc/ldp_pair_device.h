@@ -127,8 +127,19 @@ __device__ __forceinline__ bool emit_pair(const PairKernelArgs& A, uint32_t i, u
 // Early termination test, complete data (see ldp_device.h).  After the chunks before checkpoint `cp` the partial dot
 // product of pair (i,j) is dot_p = acc[0] - 2*acc[1].  |N*dot - S_i*S_j| <= |c0| + B with
 //   c0 = N*dot_p + a_i*a_j - S_i*S_j,  B = b_i*b_j   (a, b = the checkpoint slot of each variant)
-// and the pair cannot reach the threshold when |c0| + B + 1 < t_i*t_j (t = the scaled sqrt(variance numerator);
-// the +1 and the 1e-6 folded into t dwarf every FP64 rounding error here).
+// and the pair cannot reach the threshold when |c0| + B + 1 < t_i*t_j (t = the scaled sqrt(variance numerator)).
+// FP64 error budget, for every founder count the matrix pipe accepts (N <= kMfMaxFounders = 4,000,000; the same test serves the
+// tile kernels' checkpoints, ldp_pair_wide.hip):
+//   * every integer here is below N^2 = 1.6e13 < 2^53: N*dot_p and S_i*S_j are exact, the two fma of c0 round once each at a
+//     magnitude <= 4.8e13 (half an ulp there: 2^-8), and the stored slots a = s_R*sqrt(N/n_R), b = sqrt(N*(q_R - s_R^2/n_R)) carry
+//     a few ulp of relative error at a magnitude <= N, i.e. <= 2e-9 each, <= 0.02 in a_i*a_j or b_i*b_j.  |c0| + B as computed is
+//     therefore within 0.05 of its real value: the "+ 1" on the left is twenty times that.
+//   * the right side is scaled by (1 - 1e-6) (cp_tv_scale), ten orders of magnitude more than the ~1e-15 relative rounding of t_i*t_j
+//     AND of the reference's own predicate cov^2 > thr*var1*var2 (three multiplications, plink2_ld.cc:1085-1090): a pair dropped
+//     here has |cov| < (1 - 1e-6) sqrt(thr var1 var2) - 0.95 in exact arithmetic, which no rounding of that predicate can turn true.
+//   * the partial sums a checkpoint needs (s_R back from a * sqrt(n_R / N)) are integers recovered by rint() from a value that is off
+//     by <= 4e6 * 5e-16: exact.
+// The budget would hold up to N ~ 3e7 (N^2 < 2^53 / 8); the accumulators' own limit (4 N < 2^24) is what sets kMfMaxFounders.
 __device__ __forceinline__ bool pair_hopeless(const PairKernelArgs& A, const uint32_t (&c)[2], const cp_slot& ci, const cp_slot& gi, const cp_slot& cj,
                                               const cp_slot& gj) {
   const double dot_p = static_cast<double>(static_cast<int32_t>(c[0] - 2 * c[1]));

@@ -73,7 +73,7 @@ def test_bench_step_under_torchrun_initialises_rccl(gpu_pkg, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_bench_n_ranks_on_one_device(gpu_pkg, tmp_path, world):
     """bench.py's own N-rank line on a one-GPU box (LDP_BENCH_ALIAS_DEVICES=1: the ranks share the device, gloo carries the exchange): the
     rank / LPT shard / all-gather code of `--gpus N` runs under torch.distributed.run, the line is labelled a model, and the stitched
@@ -92,6 +92,11 @@ def test_bench_n_ranks_on_one_device(gpu_pkg, tmp_path, world):
     j1 = json.loads([ln for ln in cp1.stdout.splitlines() if ln.startswith("{")][-1])
     assert j1["n_gpus"] == 1 and j1["config"]["variants_removed"] == j["config"]["variants_removed"] > 0
     assert j["config"]["candidate_pairs_total"] == j1["config"]["candidate_pairs_total"] and len(j["config"]["candidate_pairs_per_rank"]) == world
+    # the N-rank line checks itself: world size, ranks seen by the collective backend, and the stitched bitmap against ONE engine on chr20-22
+    sc = j["multi_rank_selfcheck"]
+    assert sc["world_size"] == world and sc["world_size_is_n_gpus"] and sc["rccl_ranks_seen"] == world and len(sc["ranks"]) == world
+    assert sc["three_chromosome_subset"]["identical_to_single_engine"] is True and sc["three_chromosome_subset"]["variants"] > 1000
+    assert sc["devices_distinct"] is False   # (this box: the ranks share its one device, and the line says so)
 
 
 @pytest.mark.gpu
