@@ -800,6 +800,7 @@ def main():
     ap.add_argument("--e2e-variants", type=int, default=0, help="variants of that fileset (0 = a chr22-sized share of the named genome: 176,765 of 10M)")
     ap.add_argument("--leg-variants", type=int, default=120000, help="variants of the config5-density leg")
     ap.add_argument("--tile", type=int, default=65536, help="side of the config4_tiles leg's cross-chromosome tile set")
+    ap.add_argument("--only-config4", action="store_true", help="run the config4_tiles leg alone and print it as the line (the PMC profile of that shape: tools/profile.sh)")
     ap.add_argument("--option", action="append", default=[], help="name=value: a per-engine kernel switch (ldp_debug_set_option) for the main workload, for experiments")
     args = ap.parse_args()
 
@@ -835,6 +836,14 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.only_config4:
+        res = config4_tiles_leg(pkg, torch, local_rank, CONFIGS["config3"]["samples"], args.tile, 0, True)
+        print(json.dumps({"metric": "variant-pairs/s (--r2-unphased inter-chr tile set, kernel)", "value": res["pairs_per_s_kernel"], "unit": "variant-pairs/s", "n_gpus": 1,
+                          "steps": 1, "warmup": 0, "ms_per_step": res["kernel_ms"], "higher_is_better": True, "data": "synthetic",
+                          "config": {"workload": "config4_tiles: %s; missing rate 0" % res["what"], "samples": CONFIGS["config3"]["samples"], "variants_rank0": 2 * args.tile,
+                                     "window_kb": 0.0},
+                          "roofline": res["roofline"], "legs": {"config4_tiles": res}}))
+        return
     name = args.workload
     cfg = dict(CONFIGS[name])
     strong = args.strong and not args.weak

@@ -62,7 +62,8 @@ __device__ __forceinline__ uint32_t wd_swizzle(uint32_t row) { return (row >> 1)
 // and reuse them (a quarter of the VALU work, the same operand statistics), bit 2 (4) = no LDS reads in the loop (every lane
 // multiplies what the first stage left in its registers' place), bit 3 (8) = no s_waitcnt vmcnt / s_barrier in the stage loop (the
 // waves run free), bit 4 (16) = no per-pair epilogue, bit 5 (32) = time stamps around the phases of every wave (results right:
-// where the cycles go), summed into g_wide_measure.
+// where the cycles go), summed into g_wide_measure, bit 6 (64) = every tile stages the same 512 rows (wrong results; all of the DMA's
+// requests hit the L2: what the HBM leg of the traffic costs).
 template <int ABL>
 __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const uint32_t (&joff)[2], const uint32_t (&voff)[4], uint32_t oH, uint32_t oR,
                                            mf_v16f (&acc)[8]) {
@@ -240,6 +241,9 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
     const uint32_t T = wave + kWdWaves * t;
     const uint32_t slot = T / kWdInstrPerBlock;
     uint32_t first = static_cast<uint32_t>(slot_first(slot));
+    if constexpr ((ABL & 64) != 0) {
+      first = slot * kMfBlock;  // (measurement: every tile of the launch stages the SAME 512 rows -- the DMA's L2 -> LDS leg without its HBM leg)
+    }
     first = (first < A.n_local) ? first : (A.n_local - 1);  // (a block beyond the rows is never live; keep its address legal anyway)
     first = __builtin_amdgcn_readfirstlane(first);
     base_t[t] = A.codes + static_cast<uint64_t>(first) * row_bytes;
@@ -1128,7 +1132,7 @@ hipError_t launch_pair_wide(const PairKernelArgs& a_in, hipStream_t stream) {
     hipLaunchKernelGGL(pair_mfma_wide_kernel<n>, grid, block, lds, stream, a);                                                                                \
     break;
   switch (ablate) {
-    LDP_WD_CASE(1) LDP_WD_CASE(2) LDP_WD_CASE(4) LDP_WD_CASE(7) LDP_WD_CASE(8) LDP_WD_CASE(9) LDP_WD_CASE(15) LDP_WD_CASE(16) LDP_WD_CASE(25) LDP_WD_CASE(31) LDP_WD_CASE(32)
+    LDP_WD_CASE(1) LDP_WD_CASE(2) LDP_WD_CASE(4) LDP_WD_CASE(7) LDP_WD_CASE(8) LDP_WD_CASE(9) LDP_WD_CASE(15) LDP_WD_CASE(16) LDP_WD_CASE(25) LDP_WD_CASE(31) LDP_WD_CASE(32) LDP_WD_CASE(64)
     default:
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
       hipLaunchKernelGGL(pair_mfma_wide_kernel<0>, grid, block, lds, stream, a);

@@ -15,44 +15,11 @@ import os
 import re
 import subprocess
 import sys
-import threading
 import time
 
 os.environ["LDP_LIB_MEASURE"] = "1"
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-
-
-class SmiSampler(threading.Thread):
-    """socket power (W) and shader clock (MHz) as rocm-smi reports them, as fast as it answers"""
-
-    def __init__(self):
-        super().__init__(daemon=True)
-        self.samples, self.stop_flag, self.window = [], False, None
-
-    def run(self):
-        while not self.stop_flag:
-            try:
-                out = subprocess.run(["/opt/rocm/bin/rocm-smi", "-P", "-g", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10).stdout
-                card = next(iter(json.loads(out).values()))
-                watts = [float(v) for k, v in card.items() if "ower" in k and "(W)" in k]
-                mhz = []
-                for k, v in card.items():
-                    mt = re.search(r"(\d+)\s*Mhz", str(v)) if "sclk" in k.lower() else None
-                    if mt:
-                        mhz.append(float(mt.group(1)))
-                if self.window is not None:
-                    self.samples.append((time.perf_counter(), watts[0] if watts else None, mhz[0] if mhz else None, self.window))
-            except Exception:
-                time.sleep(0.05)
-
-    def summary(self, tag):
-        rows = [s for s in self.samples if s[3] == tag]
-        w = sorted(s[1] for s in rows if s[1] is not None)
-        c = sorted(s[2] for s in rows if s[2] is not None)
-        med = lambda v: v[len(v) // 2] if v else None
-        return {"smi_samples": len(rows), "smi_power_w_median": med(w), "smi_power_w_max": w[-1] if w else None, "smi_sclk_mhz_median": med(c),
-                "smi_sclk_mhz_min": c[0] if c else None}
 
 
 def main():
@@ -62,6 +29,7 @@ def main():
     ap.add_argument("--ablations", default="0,32,1,7,8,9,15,16,25")
     ap.add_argument("--modes", default="exhaustive,early")
     ap.add_argument("--option", action="append", default=[])
+    ap.add_argument("--probe", action="store_true", help="instead: tools/_bin/energy_probe, one configuration at a time for a few seconds each, with the same power / clock sampling")
     args = ap.parse_args()
 
     import torch
@@ -71,8 +39,28 @@ def main():
     L = pkg.lib()
     L.ldp_measure_wide_counters.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     torch.cuda.set_device(0)
-    smi = SmiSampler()
-    smi.start()
+    smi = bench.SmiSampler()
+
+    def smi_summary(tag):
+        q = smi.summary(tag)
+        return {"smi_samples": int(re.search(r"(\d+) samples", q["source"]).group(1)), "smi_power_w_median": q["socket_power_w_median"], "smi_power_w_max": q["socket_power_w_max"],
+                "smi_sclk_mhz_median": q["shader_clock_mhz_median"], "smi_sclk_mhz_min": q["shader_clock_mhz_min"], "smi_power_cap_w": q["socket_power_cap_w"]}
+    if args.probe:
+        # the instruction alone, by operand data (0 zero, 1 random nibbles, 2 genotypes +-2 coded, 3 genotypes as allele counts) and VALU beside it
+        exe = os.path.join(REPO, "tools", "_bin", "energy_probe")
+        for data, k in ((3, 0), (3, 3), (3, 6), (2, 0), (0, 0), (1, 0)):
+            tag = "probe/%d/%d" % (data, k)
+            smi.window = tag
+            out = subprocess.run([exe, "long", str(data), str(k), "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120).stdout
+            smi.window = None
+            try:
+                rec = json.loads(out.strip().splitlines()[-1])
+            except Exception:
+                rec = {"probe_output": out[-300:]}
+            rec.update(smi_summary(tag))
+            print(json.dumps(rec), flush=True)
+        smi.stop()
+        return
     cfg = dict(bench.CONFIGS["config3"], variants=args.variants)
     extra = {}
     for kv in args.option:
@@ -120,11 +108,11 @@ def main():
                 rec["stage_visits_live_dead"] = [m[9], m[10]]
                 if m[11] or m[12] or m[13]:   # the barrier-free kernel: polls at the top of a stage, deferred DMA issues, s_waitcnt vmcnt of the confirmations
                     rec["async_frac_of_wave_cycles"] = {"top_poll_and_issue": m[11] / tot, "deferred_issue_poll": m[12] / tot, "confirm_vmcnt": m[13] / tot}
-            rec.update(smi.summary(tag))
+            rec.update(smi_summary(tag))
             print(json.dumps(rec), flush=True)
         os.environ.pop("LDP_DEBUG_WIDE_ABLATE", None)
         wl.close()
-    smi.stop_flag = True
+    smi.stop()
 
 
 if __name__ == "__main__":

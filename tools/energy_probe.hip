@@ -16,6 +16,7 @@
 #include <stdio.h>
 
 #include <random>
+#include <string>
 #include <vector>
 
 typedef int v8i __attribute__((ext_vector_type(8)));
@@ -211,7 +212,56 @@ static int run(const uint32_t* src, float* out, unsigned long long* clk, int blo
   return 0;
 }
 
-int main() {
+// `energy_probe long <data 0..5> <K 0|3|6> <seconds>`: ONE configuration launched back to back for a few seconds, so that a power
+// sampler beside it (tools/attribution.py --probe: rocm-smi at a few Hz) sees that configuration alone; prints the rate and the in-kernel clock
+static int long_run(int data, int K, double seconds) {
+  uint32_t* src;
+  float* out;
+  unsigned long long* clk;
+  const int blocks = 256 * 2 * 8, iters = 1500;
+  CHECK(hipMalloc(&src, 8 * 4 * 256 * 4));
+  CHECK(hipMalloc(&out, blocks * 256 * 4));
+  CHECK(hipMalloc(&clk, 16));
+  std::mt19937 rng(12345);
+  std::vector<uint32_t> h(8 * 4 * 256);
+  fill(h, data, rng);
+  CHECK(hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  const double mfmas = (double)blocks * 4 * iters * 16;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  double total_ms = 0.0, mhz_sum = 0.0;
+  int launches = 0;
+  while (total_ms < seconds * 1e3) {
+    CHECK(hipEventRecord(e0, 0));
+    for (int rep = 0; rep < 20; ++rep) {
+      if (K == 0) {
+        hipLaunchKernelGGL((probe_kernel<0>), dim3(blocks), dim3(256), 0, 0, src, out, iters, clk);
+      } else if (K == 3) {
+        hipLaunchKernelGGL((probe_kernel<3>), dim3(blocks), dim3(256), 0, 0, src, out, iters, clk);
+      } else {
+        hipLaunchKernelGGL((probe_kernel<6>), dim3(blocks), dim3(256), 0, 0, src, out, iters, clk);
+      }
+    }
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long hc[2];
+    CHECK(hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost));
+    total_ms += ms;
+    launches += 20;
+    mhz_sum += hc[1] ? (double)hc[0] / (double)hc[1] * 100.0 : 0.0;
+  }
+  printf("{\"probe\": \"%s\", \"valu_per_mfma\": %d, \"seconds\": %.2f, \"mfma_instructions_per_s\": %.4e, \"pflops\": %.3f, \"in_kernel_mhz\": %.0f}\n", kDataName[data], K,
+         total_ms / 1e3, mfmas * launches / (total_ms * 1e-3), 2 * mfmas * 65536.0 * launches / (total_ms * 1e-3) / 1e15, mhz_sum / (launches / 20));
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if ((argc == 5) && (std::string(argv[1]) == "long")) {
+    return long_run(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
+  }
   uint32_t* src;
   float* out;
   unsigned long long* clk;
