@@ -25,7 +25,7 @@ except Exception as e:
     print("bench_full failed", e)
 PY
 timeout 1200 python -m pytest tests -x -q -m gpu > $O/gpu_suite.txt 2>&1; tail -4 $O/gpu_suite.txt
-timeout 400 python tools/attribution.py --steps 40 --ablations 0,2,4,64,65 --modes exhaustive > $O/attr_more.jsonl 2> $O/attr_more.err
+timeout 400 python tools/attribution.py --steps 40 --ablations 0,2,4,64 --modes exhaustive > $O/attr_more.jsonl 2> $O/attr_more.err
 timeout 200 python tools/attribution.py --probe > $O/attr_probe.jsonl 2> $O/attr_probe.err
 cut -c1-420 $O/attr_more.jsonl; cat $O/attr_probe.jsonl
 for SET in "" "LDP_EAGER_PAIRS=1" "LDP_EAGER_PAIRS=1 LDP_DEBUG_GROUPS=4" "LDP_EAGER_PAIRS=1 LDP_DEBUG_GROUPS=8" "LDP_DEBUG_GROUPS=1"; do
