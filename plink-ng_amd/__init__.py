@@ -155,14 +155,20 @@ def build_library(force=False, verbose=False, measure=False):
     return lib_path
 
 
+def cli_sources():
+    """the front-end's translation units: main() + one unit per concern (csrc/p2h_cli.h is what they share)"""
+    return [os.path.join(CSRC, f) for f in ("plink2_hip_cli.cpp", "p2h_util.cpp", "p2h_args.cpp", "p2h_tables.cpp", "p2h_inputs.cpp", "p2h_clump.cpp", "p2h_r2.cpp",
+                                            "p2h_prune.cpp")]
+
+
 def build_cli(force=False, verbose=False):
-    src = os.path.join(CSRC, "plink2_hip_cli.cpp")
-    if not os.path.exists(src):
+    srcs = cli_sources()
+    if not os.path.exists(srcs[0]):
         return None
-    deps = [src, LIB_PATH, os.path.join(REPO, "include", "ldprune_hip.h")]
+    deps = srcs + [LIB_PATH, os.path.join(CSRC, "p2h_cli.h"), os.path.join(REPO, "include", "ldprune_hip.h"), os.path.join(REPO, "include", "ldprune_hip_debug.h")]
     if force or _stale(CLI_PATH, deps):
         os.makedirs(BIN_DIR, exist_ok=True)
-        cmd = ["hipcc", "-O2", "-std=c++17", "-ffp-contract=off", "-o", CLI_PATH, src, "-L" + LIB_DIR, "-lldprune_hip",
+        cmd = ["hipcc", "-O2", "-std=c++17", "-ffp-contract=off", "-o", CLI_PATH] + srcs + ["-L" + LIB_DIR, "-lldprune_hip",
                "-Wl,-rpath,$ORIGIN/../lib", "-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd))

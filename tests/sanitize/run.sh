@@ -34,7 +34,7 @@ for it in range(150):
 print("reader on 150 corrupted files: errors only, no sanitizer report")
 PY
 if [ -f "$R/plink-ng_amd/lib/libldprune_hip.so" ]; then
-  g++ $SAN -I/opt/rocm/include "$R/plink-ng_amd/csrc/plink2_hip_cli.cpp" -o "$T/cli" -L"$R/plink-ng_amd/lib" -lldprune_hip -Wl,-rpath,"$R/plink-ng_amd/lib" -lpthread -ldl
+  g++ $SAN -I/opt/rocm/include "$R"/plink-ng_amd/csrc/plink2_hip_cli.cpp "$R"/plink-ng_amd/csrc/p2h_*.cpp -o "$T/cli" -L"$R/plink-ng_amd/lib" -lldprune_hip -Wl,-rpath,"$R/plink-ng_amd/lib" -lpthread -ldl
   export ASAN_OPTIONS=detect_leaks=0
   python3 - "$T" "$R" <<'PY'
 import sys, subprocess, numpy as np
