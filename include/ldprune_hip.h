@@ -142,7 +142,7 @@ typedef struct {
                                          products of their rectangle or none): executed MFMA = stages - skipped + extra */
   uint32_t four_tile_launches;     /* launches of the last run whose tiles went to pair_mfma_tile4_kernel (wide bands, rows with missing
                                       calls, four-product form) */
-  uint32_t reserved0;
+  uint32_t decoded_in_place_rows; /* variant records ldp_load_pgen_records() decoded straight into the image (no scratch row, no copy) since ldp_create() */
 } ldp_counters;
 
 /* ---- lifecycle ---- */

@@ -455,14 +455,17 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
   // (host bytes go to the device launch by launch, below: only the span of that launch's records, so that the first decode does not wait
   // for the whole call's upload and a call over a file with long dosage tracks does not need one allocation for all of them)
   const uint8_t* d_bytes = (location == LDP_MEM_HOST) ? nullptr : static_cast<const uint8_t*>(bytes);
-  if (e->ld_base_cap < stride) {
+  // (a launch that decodes straight into the image -- below -- reads and writes rows at the image's pitch: the carried base too)
+  const uint64_t base_cap = std::max<uint64_t>(stride, e->codes_format ? e->code_row_bytes : 0);
+  if (e->ld_base_cap < base_cap) {
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     (void)hipFree(e->d_ld_base);
     e->d_ld_base = nullptr;
     e->ld_base_cap = 0;
     e->ld_base_valid = false;
-    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_ld_base), stride));
-    e->ld_base_cap = stride;
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_ld_base), base_cap));
+    HIP_TRY(e, hipMemsetAsync(e->d_ld_base, 0, base_cap, e->stream));
+    e->ld_base_cap = base_cap;
   }
   // (the carried base is the record that PRECEDES this call's first one in the file: same engine position AND same file position --
   // a caller that loads non-adjacent file ranges into adjacent engine indices gets LDP_ERR_INVALID below instead of a wrong row)
@@ -560,8 +563,34 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
       // not lie inside the allocation)
       d_bytes = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(p) - static_cast<uintptr_t>(lo));
     }
+    // Rows of variants this engine owns back to back are decoded STRAIGHT INTO ITS IMAGE (round 5) and counted there by the load below --
+    // what ReadGenovecSubsetUnsafe does when it writes its caller's buffer (pgenlib_read.cc:2849-2912): no scratch row, no second copy.
+    // Not with a sample map or phase bits (those rows are re-laid out on the way), not for the launch that carries the caller's ld_base
+    // record as an extra row, not on bit-plane engines.
+    int64_t l_first = -1;
+    bool into_image = e->codes_format && (!mapped) && (!phased) && (!with_base_rec) && (stride <= e->code_row_bytes);
+    if (into_image) {
+      l_first = e->global_to_local[first_variant + q0];
+      into_image = (l_first >= 0);
+      for (uint32_t q = 1; into_image && (q < cnt); ++q) {
+        into_image = (e->global_to_local[first_variant + q0 + q] == l_first + static_cast<int64_t>(q));
+      }
+    }
+    if (into_image) {
+      // (rows about to be overwritten may belong to launches of the current load epoch: the same rule as in load_rows_impl)
+      for (uint32_t q = 0; q < cnt; ++q) {
+        if (e->load_tag[static_cast<size_t>(l_first) + q] == e->load_epoch) {
+          if ((rc = begin_load_epoch(e))) {
+            return rc;
+          }
+          break;
+        }
+      }
+    }
+    const uint64_t lstride = into_image ? e->code_row_bytes : stride;
     void *p_recs = nullptr, *p_rows = nullptr, *p_end = nullptr, *p_multi = nullptr, *p_mf = nullptr, *p_mi = nullptr, *p_inv = nullptr;
-    if ((rc = dec_reserve(e, 1, rows * sizeof(ldp::PgenRecDesc), &p_recs)) || (rc = dec_reserve(e, 2, static_cast<size_t>(rows) * stride, &p_rows)) ||
+    if ((rc = dec_reserve(e, 1, rows * sizeof(ldp::PgenRecDesc), &p_recs)) ||
+        (into_image ? 0 : (rc = dec_reserve(e, 2, static_cast<size_t>(rows) * stride, &p_rows))) ||
         (rc = dec_reserve(e, 3, rows * sizeof(uint64_t), &p_end)) || (rc = dec_reserve(e, 4, (multi.size() + 1) * sizeof(uint32_t), &p_multi)) ||
         (rc = dec_reserve(e, 5, (multi.size() + 1) * sizeof(double), &p_mf)) || (rc = dec_reserve(e, 6, (multi.size() + 1) * sizeof(uint32_t) + sizeof(int), &p_mi)) ||
         (rc = dec_reserve(e, 7, rows + 8, &p_inv))) {
@@ -582,8 +611,8 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
     DA.recs = static_cast<const ldp::PgenRecDesc*>(p_recs);
     DA.n = rows;
     DA.sample_ct = raw_sample_ct;
-    DA.rows = static_cast<uint8_t*>(p_rows);
-    DA.stride = stride;
+    DA.rows = into_image ? (e->d_codes + static_cast<uint64_t>(l_first) * e->code_row_bytes) : static_cast<uint8_t*>(p_rows);
+    DA.stride = lstride;
     DA.carried_base = have_carried ? e->d_ld_base : nullptr;
     DA.main_end = static_cast<uint64_t*>(p_end);
     DA.error = d_err;
@@ -621,10 +650,10 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
     // the row the next launch's LD-compressed records may build on (taken BEFORE the multiallelic collapse rewrites rows:
     // an LD base is the main track as stored)
     if (last_alone_row >= 0) {
-      HIP_TRY(e, hipMemcpyAsync(e->d_ld_base, DA.rows + static_cast<uint64_t>(last_alone_row) * stride, stride, hipMemcpyDeviceToDevice, e->stream));
+      HIP_TRY(e, hipMemcpyAsync(e->d_ld_base, DA.rows + static_cast<uint64_t>(last_alone_row) * lstride, stride, hipMemcpyDeviceToDevice, e->stream));
       have_carried = true;
     } else if (with_base_rec) {
-      HIP_TRY(e, hipMemcpyAsync(e->d_ld_base, DA.rows + static_cast<uint64_t>(cnt) * stride, stride, hipMemcpyDeviceToDevice, e->stream));
+      HIP_TRY(e, hipMemcpyAsync(e->d_ld_base, DA.rows + static_cast<uint64_t>(cnt) * lstride, stride, hipMemcpyDeviceToDevice, e->stream));
       have_carried = true;
     }
     krc = launch_pgen_aux1(DA, e->stream);
@@ -648,6 +677,10 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
     const int h_err = *h_err_pin;
     if (h_err) {
       e->ld_base_valid = false;
+      if (into_image) {
+        // (the malformed call wrote into the image: whatever those rows held before is gone, and they do not count as loaded)
+        std::fill(e->loaded.begin() + l_first, e->loaded.begin() + l_first + cnt, static_cast<uint8_t>(0));
+      }
       const uint32_t bad = static_cast<uint32_t>(h_err - 1);
       return fail(e, LDP_ERR_INVALID, "malformed variant record in .pgen data (variant " + std::to_string((bad < cnt) ? (first_variant + q0 + bad) : first_variant) + ((bad < cnt) ? ")" : ": its LD base)"));
     }
@@ -672,7 +705,10 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
         }
       }
     }
-    status = load_rows_impl(e, first_variant + q0, cnt, DA.rows, stride, LDP_MEM_DEVICE, LDP_GENO_REF | (mapped ? LDP_GENO_MAPPED : 0) | (phased ? LDP_GENO_PHASED : 0),
+    if (into_image) {
+      e->ctr.decoded_in_place_rows += cnt;
+    }
+    status = load_rows_impl(e, first_variant + q0, cnt, DA.rows, lstride, LDP_MEM_DEVICE, LDP_GENO_REF | (mapped ? LDP_GENO_MAPPED : 0) | (phased ? LDP_GENO_PHASED : 0),
                             multi.empty() ? nullptr : DA.row_inverse, multi.empty() ? nullptr : h_inverse.data());
     if (LDP_ENV("LDP_DEBUG_TIMELINE")) {
       fprintf(stderr, "decode launch of %u rows: queued in %.3f ms, device done %.3f ms later, rows loaded %.3f ms after that\n", rows, t_q - t_call, t_s - t_q, now_ms() - t_s);

@@ -75,6 +75,33 @@ def test_wide_band_kernel_has_one_branch_free_stage_loop_and_no_scratch(tmp_path
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+def test_barrier_free_tile_kernel_polls_lds_counters_and_never_drains_its_ring(tmp_path):
+    """pair_mfma_wide_async_kernel (ldp_pair_wide.hip, round 5's experiment): one copy of the 256-sample stage (32 MFMAs), the waves'
+    counters read by hand-placed ds_read_b32 -- no flat access (a volatile pointer made hipcc take the generic address space, which counts
+    against vmcnt AND lgkmcnt) and no `s_waitcnt vmcnt(0)` in front of a poll or a stage read (it would drain the four-stage ring) --, spins
+    that sleep, a trap behind them, no s_barrier between the polls and the matrix instructions, no scratch."""
+    src = os.path.join(REPO, "plink-ng_amd", "csrc", "ldp_pair_wide.hip")
+    out = tmp_path / "wa.s"
+    cp = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--cuda-device-only", "-S", src, "-o", str(out)],
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert cp.returncode == 0, cp.stdout[-2000:]
+    m = re.search(r"^(_ZN3ldp\w*pair_mfma_wide_async_kernelILi0E\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel", open(out).read(), re.S | re.M)
+    assert m, "pair_mfma_wide_async_kernel<0> not found"
+    lines = m.group(2).splitlines()
+    mf = [k for k, ln in enumerate(lines) if "v_mfma_scale_f32_32x32x64_f8f6f4" in ln]
+    assert len(mf) == 32
+    assert not any(("flat_load" in ln) or ("flat_store" in ln) or ("scratch_" in ln) for ln in lines)
+    polls = [k for k, ln in enumerate(lines) if "ds_read_b32" in ln]
+    assert len(polls) >= 3 and any("s_sleep" in ln for ln in lines) and any("s_trap" in ln for ln in lines)
+    for k in polls + [k for k, ln in enumerate(lines) if ("ds_read_b128" in ln) and (mf[0] - 60 < k < mf[-1])]:
+        before = [x for x in lines[max(0, k - 6):k] if not x.strip().startswith(";")]
+        assert "vmcnt(0)" not in "\n".join(before[-3:]), "the ring is drained in front of line %d:\n%s" % (k, "\n".join(lines[k - 6:k + 1]))
+    # from the first poll in front of the stage to its last matrix instruction: no workgroup barrier
+    first_poll = max(k for k in polls if k < mf[0])
+    assert not any("s_barrier" in ln for ln in lines[first_poll:mf[-1] + 1])
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
 def test_quarter_tile_kernel_has_one_stage_loop_without_scratch(tmp_path):
     """pair_mfma_tile4_kernel: ONE form of the stage loop -- two 256-sample stages, 2 products x 4 sums x 4 k-steps x 2
     = 64 MFMAs behind 12 LDS reads -- with no scratch access and no accumulator copy inside (three forms chosen per segment made

@@ -49,6 +49,7 @@ def test_committed_variable_width_file(gpu_pkg):
     dev = engine(pkg, n, m)
     maj = dev.load_pgen_records(0, f)
     assert np.all(maj == 0xffffffff)
+    assert dev.counters()["decoded_in_place_rows"] == m   # (straight into the engine's image: no scratch row, no copy)
     assert_same_rows(host, dev, m)
     assert np.array_equal(host.run(), dev.run())
     f.close()
@@ -73,6 +74,7 @@ def test_every_record_type_of_the_reference_writer(gpu_pkg, tmp_path, m, n, seed
     # one call
     dev = engine(pkg, n, m)
     dev.load_pgen_records(0, f)
+    assert dev.counters()["decoded_in_place_rows"] == m
     assert_same_rows(host, dev, m)
     # several calls that cut LD chains: the engine carries the base over
     dev2 = engine(pkg, n, m)
@@ -88,6 +90,7 @@ def test_every_record_type_of_the_reference_writer(gpu_pkg, tmp_path, m, n, seed
         dev3.load_pgen_records(q, f, q, m - q)
         dev3.load_pgen_records(0, f, 0, q)
         assert_same_rows(host, dev3, m)
+        assert 0 < dev3.counters()["decoded_in_place_rows"] <= m   # (the launch that carries the ld_base record as an extra row takes the scratch)
     # the file's bytes already on the device
     import torch
     ptr, nbytes = f.file_bytes()
