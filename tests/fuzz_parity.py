@@ -18,10 +18,12 @@ import ldtools as T  # noqa: E402
 import __graft_entry__ as ge  # noqa: E402
 
 
-def one_case(pkg, rng, idx, wide_missing=False):
+def one_case(pkg, rng, idx, wide_missing=False, wide_async=False):
     n = int(rng.choice([33, 64, 100, 511, 512, 513, 1000, 1536, 2047, 2049, 3000, 5000, 9000]))
     m = int(rng.integers(40, 700 if n <= 3000 else 350))
     miss = float(rng.choice([0.0, 0.0, 0.0, 0.001, 0.003, 0.01, 0.05, 0.2]))
+    if wide_async:
+        miss = 0.0                                    # --wide-async: complete data through the tile plan on the barrier-free kernel
     if wide_missing:
         miss = float(rng.choice([0.01, 0.05, 0.2]))   # --wide-missing: every case on the missing-call kernels ...
     raw = T.synth_raw_codes(m, n, seed=int(rng.integers(1, 1 << 30)), missing_rate=miss)
@@ -57,6 +59,9 @@ def one_case(pkg, rng, idx, wide_missing=False):
     wide = int(rng.choice([-1, -1, 0, 1, 3]))  # (drawn for every case, so that the sequence of cases stays the same)
     if wide_missing:
         wide = int(idx % 3)                        # ... over the tile plan (quarter tiles of the four-product form unless switched off below)
+    if wide_async:
+        wide = int(idx % 3)
+        eng.set_option("wide_async", 1)
     if wide >= 0:
         eng.set_option("wide_min_reach", wide)  # send narrower bands through the 8 x 8 tile plan of the wide-band kernel too
     if idx % 3 == 2:
@@ -88,13 +93,14 @@ def main():
     ap.add_argument("--cases", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--wide-missing", action="store_true", help="every case has missing calls and takes the wide-band tile plan (pair_mfma_tile4_kernel)")
+    ap.add_argument("--wide-async", action="store_true", help="every case is complete data on the tile plan, run by pair_mfma_wide_async_kernel (engine option wide_async)")
     args = ap.parse_args()
     pkg = ge.load_package()
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
     skipped_any = 0
     for k in range(args.cases):
-        ok, desc = one_case(pkg, rng, k, args.wide_missing)
+        ok, desc = one_case(pkg, rng, k, args.wide_missing, args.wide_async)
         if "skipped=0.00" not in desc:
             skipped_any += 1
         if not ok:
