@@ -509,7 +509,10 @@ struct PruneJob {
         continue;
       }
       double mf = 0.0;
-      if (is_mt) {
+      if (is_mt && (alts >= 2)) {
+        multiallelic_sex_row(pg, raw_v, alts, mt_plan, &lo, &hi, inv_row.data(), out_rec, &mf);
+        ++mt_ct;
+      } else if (is_mt) {
         fetch_raw_row(pg, storage_mode, raw_v, raw_sample_ct, rec_bytes, raw_row.data());
         build_sex_row(mt_plan, raw_row.data(), inv_row.data(), out_rec, &mf);
         ++mt_ct;
@@ -775,6 +778,25 @@ struct PruneJob {
             die(16, "\nError: %s\n", ldp_last_error(se));
           }
           w0 += run;
+        }
+        // variants with several ALT alleles: their rows (collapsed on the major allele of the chromosome's own allele-frequency rule) are
+        // built here and replace the mapped main tracks
+        std::vector<uint8_t> lo_a, hi_a, m_row;
+        for (uint32_t w = 0; w < ks.size(); ++w) {
+          const uint32_t raw_v = inc[ks[w]];
+          if (V.alt_ct[raw_v] < 2) {
+            continue;
+          }
+          if (lo_a.empty()) {
+            lo_a.resize(raw_sample_ct);
+            hi_a.resize(raw_sample_ct);
+            m_row.resize(s_rec);
+          }
+          double mf = 0.0;
+          multiallelic_sex_row(pg, raw_v, V.alt_ct[raw_v], sp, &lo_a, &hi_a, m_row.data(), s_rec, &mf);
+          if (ldp_load_genotypes(se, w, 1, m_row.data(), s_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) || ldp_set_maj_freqs(se, w, 1, &mf)) {
+            die(16, "\nError: %s\n", ldp_last_error(se));
+          }
         }
       }
       for (uint32_t w0 = 0; x_phased && (w0 < ks.size()); w0 += chunk) {

@@ -388,38 +388,10 @@ int chrom_class(const std::string& name_in, bool allow_extra, bool* is_zero) {
   return allow_extra ? 0 : 2;
 }
 
-// Multiallelic variant on the host (rare: a few percent of sites): founder allele counts -> allele frequencies in
-// the reference's arithmetic (ComputeAlleleFreqs, plink2_filter.cc:2113-2153: freq[a] = count[a] * (1/total), 1/k
-// when nothing is observed) -> major allele (GetMajIdx / GetMajIdxMulti, plink2_common.h:559-567,
-// plink2_common.cc:1042-1070) -> its frequency (GetAlleleFreq, plink2_common.h:584-593) -> the 2-bit row
-// PgrGetInv1 would return for that allele (pgenlib_read.cc:5544-5563): copies of non-major alleles, 3 = missing.
-//
-// phase != nullptr (--indep-pairphase; two byte buffers of ceil(raw samples / 8), phasepresent then phaseinfo): the row
-// holds two haplotypes per founder instead (haplotype = genotype code 2h, h = carries a non-major allele; index 2f =
-// the second haplotype of the file, 2f+1 the first, as the conversion kernel lays out LDP_GENO_PHASED rows), following
-// PgrGetInv1P -> Get1MP (pgenlib_read.cc:7016,6962) -> HapsplitMustPhased.  Get1MP hands the file's phaseinfo through
-// unchanged, which means "the HIGHER allele of the het is on the first haplotype"; read as "the counted allele is"
-// it is off by a swap whenever the major allele is the LOWER allele of a multiallelic het (1|2 with major = 1).  The
-// reference prunes with that assignment (reproduced here; the physically right one gives different lists on
-// VCF-imported data, tests/test_pairphase.py).  *unphased: a collapsed het (one major allele) without phase.
-void multiallelic_inverse_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_ct, const std::vector<uint32_t>& founder_idx,
-                              std::vector<uint8_t>* lo, std::vector<uint8_t>* hi, uint8_t* out_row, uint64_t out_rec, double* maj_freq,
-                              uint8_t* phase, uint64_t phase_bytes, bool* unphased, uint32_t* maj_idx) {
-  if (phase ? ldp_pgen_read_alleles_phased(pg, raw_variant, alt_ct, lo->data(), hi->data(), phase, phase + phase_bytes)
-            : ldp_pgen_read_alleles(pg, raw_variant, alt_ct, lo->data(), hi->data())) {
-    die(6, "\nError: %s\n", ldp_pgen_last_error(pg));
-  }
-  const uint32_t allele_ct = alt_ct + 1;
-  std::vector<uint64_t> cnt(allele_ct, 0);
-  for (uint32_t s : founder_idx) {
-    if ((*lo)[s] != 255) {
-      if ((*lo)[s] >= allele_ct || (*hi)[s] >= allele_ct) {
-        die(6, "\nError: allele index out of range in multiallelic record.\n");
-      }
-      ++cnt[(*lo)[s]];
-      ++cnt[(*hi)[s]];
-    }
-  }
+// allele counts -> allele frequencies (ComputeAlleleFreqs, plink2_filter.cc:2113-2153: count * (1 / total), 1 / allele_ct each when nothing
+// is observed) -> the major allele (GetMajIdxMulti, plink2_common.cc:1042-1070) and its frequency (GetAlleleFreq, plink2_common.h:584-593)
+uint32_t pick_major_allele(const std::vector<uint64_t>& cnt, double* maj_freq) {
+  const uint32_t allele_ct = static_cast<uint32_t>(cnt.size());
   uint64_t tot = 0;
   for (uint64_t c : cnt) {
     tot += c;
@@ -466,9 +438,6 @@ void multiallelic_inverse_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_c
       }
     }
   }
-  if (maj_idx) {
-    *maj_idx = maj;
-  }
   if (maj + 1 < allele_ct) {
     *maj_freq = freq[maj];
   } else {
@@ -477,6 +446,45 @@ void multiallelic_inverse_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_c
       last -= freq[a];
     }
     *maj_freq = (last > 0.0) ? last : 0.0;
+  }
+  return maj;
+}
+
+// Multiallelic variant on the host (rare: a few percent of sites): founder allele counts -> allele frequencies in
+// the reference's arithmetic (ComputeAlleleFreqs, plink2_filter.cc:2113-2153: freq[a] = count[a] * (1/total), 1/k
+// when nothing is observed) -> major allele (GetMajIdx / GetMajIdxMulti, plink2_common.h:559-567,
+// plink2_common.cc:1042-1070) -> its frequency (GetAlleleFreq, plink2_common.h:584-593) -> the 2-bit row
+// PgrGetInv1 would return for that allele (pgenlib_read.cc:5544-5563): copies of non-major alleles, 3 = missing.
+//
+// phase != nullptr (--indep-pairphase; two byte buffers of ceil(raw samples / 8), phasepresent then phaseinfo): the row
+// holds two haplotypes per founder instead (haplotype = genotype code 2h, h = carries a non-major allele; index 2f =
+// the second haplotype of the file, 2f+1 the first, as the conversion kernel lays out LDP_GENO_PHASED rows), following
+// PgrGetInv1P -> Get1MP (pgenlib_read.cc:7016,6962) -> HapsplitMustPhased.  Get1MP hands the file's phaseinfo through
+// unchanged, which means "the HIGHER allele of the het is on the first haplotype"; read as "the counted allele is"
+// it is off by a swap whenever the major allele is the LOWER allele of a multiallelic het (1|2 with major = 1).  The
+// reference prunes with that assignment (reproduced here; the physically right one gives different lists on
+// VCF-imported data, tests/test_pairphase.py).  *unphased: a collapsed het (one major allele) without phase.
+void multiallelic_inverse_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_ct, const std::vector<uint32_t>& founder_idx,
+                              std::vector<uint8_t>* lo, std::vector<uint8_t>* hi, uint8_t* out_row, uint64_t out_rec, double* maj_freq,
+                              uint8_t* phase, uint64_t phase_bytes, bool* unphased, uint32_t* maj_idx) {
+  if (phase ? ldp_pgen_read_alleles_phased(pg, raw_variant, alt_ct, lo->data(), hi->data(), phase, phase + phase_bytes)
+            : ldp_pgen_read_alleles(pg, raw_variant, alt_ct, lo->data(), hi->data())) {
+    die(6, "\nError: %s\n", ldp_pgen_last_error(pg));
+  }
+  const uint32_t allele_ct = alt_ct + 1;
+  std::vector<uint64_t> cnt(allele_ct, 0);
+  for (uint32_t s : founder_idx) {
+    if ((*lo)[s] != 255) {
+      if ((*lo)[s] >= allele_ct || (*hi)[s] >= allele_ct) {
+        die(6, "\nError: allele index out of range in multiallelic record.\n");
+      }
+      ++cnt[(*lo)[s]];
+      ++cnt[(*hi)[s]];
+    }
+  }
+  const uint32_t maj = pick_major_allele(cnt, maj_freq);
+  if (maj_idx) {
+    *maj_idx = maj;
   }
   memset(out_row, 0, out_rec);
   uint32_t f = 0;
@@ -588,6 +596,51 @@ void build_sex_row(const SexPlan& sp, const uint8_t* raw_row, uint8_t* out_row, 
       uint32_t c = code_at(raw_row, s);
       c = alt_major ? inv[c] : c;
       out_row[f >> 2] |= static_cast<uint8_t>(c << (2 * (f & 3)));
+      ++f;
+    }
+  }
+}
+
+// A variant with several ALT alleles on chrX / chrY / MT (--indep-pairwise): the allele counts that choose its major allele weigh the
+// founders as the reference's allele-frequency pass does (LoadAlleleAndGenoCountsThread, plink2_data.cc:2840-2895: chrX "double all counts,
+// then subtract male counts" -- a non-male's allele copy counts 2, a male's 1, a male het half / half --; chrY / MT diploid-style counts over the
+// plan's founders, :2752-2835), the row is PgrGetInv1's collapse on that allele (copies of non-major alleles, pgenlib_read.cc:5544-5563) in the
+// plan's layout: part 1 once with "one major + one other allele" made missing (plink2_ld.cc:1362-1388), part 2 twice.
+void multiallelic_sex_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_ct, const SexPlan& sp, std::vector<uint8_t>* lo, std::vector<uint8_t>* hi, uint8_t* out_row,
+                          uint64_t out_rec, double* maj_freq) {
+  if (ldp_pgen_read_alleles(pg, raw_variant, alt_ct, lo->data(), hi->data())) {
+    die(6, "\nError: %s\n", ldp_pgen_last_error(pg));
+  }
+  const uint32_t allele_ct = alt_ct + 1;
+  std::vector<uint64_t> cnt(allele_ct, 0);
+  auto add = [&](uint32_t s, uint64_t w) {
+    if ((*lo)[s] != 255) {
+      if ((*lo)[s] >= allele_ct || (*hi)[s] >= allele_ct) {
+        die(6, "\nError: allele index out of range in multiallelic record.\n");
+      }
+      cnt[(*lo)[s]] += w;
+      cnt[(*hi)[s]] += w;
+    }
+  };
+  for (uint32_t s : sp.part1) {
+    add(s, 1);
+  }
+  for (uint32_t s : sp.part2) {
+    add(s, 2);
+  }
+  const uint32_t maj = pick_major_allele(cnt, maj_freq);
+  memset(out_row, 0, out_rec);
+  uint32_t f = 0;
+  auto code_of = [&](uint32_t s) { return ((*lo)[s] == 255) ? 3u : (static_cast<uint32_t>((*lo)[s] != maj) + static_cast<uint32_t>((*hi)[s] != maj)); };
+  for (uint32_t s : sp.part1) {
+    uint32_t c = code_of(s);
+    c = (c == 1) ? 3u : c;
+    out_row[f >> 2] |= static_cast<uint8_t>(c << (2 * (f & 3)));
+    ++f;
+  }
+  for (int rep = 0; rep < 2; ++rep) {
+    for (uint32_t s : sp.part2) {
+      out_row[f >> 2] |= static_cast<uint8_t>(code_of(s) << (2 * (f & 3)));
       ++f;
     }
   }

@@ -18,7 +18,8 @@
 // --parallel; number formatting restated from dtoa_g.  --clump (several reports, --clump-allow-overlap, cols=, bins, -log10,
 // ranges, sex chromosomes).
 // Not yet supported (reported as such with exit 63, never silently mis-handled): dosage data outside --indep-pairwise on the autosomes,
-// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT and in --clump, major-allele-oriented r^2 outputs on chrY/MT.
+// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT outside --indep-pairwise (round 5 built those) and in --clump, major-allele-oriented
+// r^2 outputs on chrY/MT.
 // The front-end is split into translation units of one concern each (p2h_cli.h: what they share): p2h_util.cpp (logging, number
 // scanning / formatting), p2h_args.cpp (command line), p2h_tables.cpp (.psam / .pvar tables, host-built rows), p2h_inputs.cpp (filters,
 // load_inputs), p2h_clump.cpp (--clump), p2h_r2.cpp (--r2-unphased outputs), p2h_prune.cpp (--indep-pairwise / --indep-pairphase); this file

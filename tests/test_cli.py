@@ -267,6 +267,57 @@ def test_cli_sex_chromosomes_match_reference(gpu_pkg, cli, tmp_path, fmt, wargs,
     assert filecmp.cmp(str(tmp_path / "ref.prune.out"), str(tmp_path / "hip.prune.out"), shallow=False)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_alt,wargs,order,unknown", [(3, ["40kb"], 2, True), (6, ["80", "7"], 1, False)])
+def test_cli_multiallelic_variants_on_sex_chromosomes_match_reference(gpu_pkg, cli, tmp_path, max_alt, wargs, order, unknown):
+    """Variants with several ALT alleles on chrX / chrY / MT under --indep-pairwise (round 5; refused before): the major allele from the
+    chromosome's own allele-frequency rule (plink2_data.cc:2752-2895: chrX non-males' copies count double, chrY / MT diploid-style over
+    their founders), PgrGetInv1's collapse on it, then the chromosome's sample layout -- byte-identical lists to the reference's, with
+    non-founders and unknown-sex samples in the file."""
+    from test_pgen_reader import make_multiallelic_vcf
+    assert T.have_ref()
+    m, n = 800, 150
+    make_multiallelic_vcf(str(tmp_path / "m.vcf"), m, n, seed=20 + max_alt, max_alt=max_alt, missing=0.04)
+    mk = T.run_ref(["--vcf", "m.vcf", "--make-pgen", "--out", "mv"], str(tmp_path))
+    assert mk.returncode == 0, mk.stdout
+    # the same records, re-labelled: a quarter each on chromosome 1, X, Y and MT
+    out = []
+    k = 0
+    for ln in open(str(tmp_path / "mv.pvar")):
+        if ln.startswith("#"):
+            out.append(ln)
+            continue
+        f = ln.rstrip("\n").split("\t")
+        f[0] = ["1", "X", "Y", "MT"][min(3, (4 * k) // m)]
+        out.append("\t".join(f) + "\n")
+        k += 1
+    open(str(tmp_path / "mv.pvar"), "w").write("".join(out))
+    rng = np.random.default_rng(max_alt)
+    sexes = rng.choice([1, 2, 0] if unknown else [1, 2], size=n, p=[0.45, 0.45, 0.1] if unknown else [0.5, 0.5])
+    psam = ["#IID\tPAT\tMAT\tSEX"]
+    for s_ in range(n):
+        nf = (s_ % 9 == 4) and s_ > 9
+        psam.append("s%d\t%s\t%s\t%s" % (s_, "s0" if nf else "0", "s1" if nf else "0", "NA" if sexes[s_] == 0 else str(sexes[s_])))
+    open(str(tmp_path / "mv.psam"), "w").write("\n".join(psam) + "\n")
+    common = ["--pfile", "mv", "--indep-pairwise"] + wargs + ["0.1"]
+    if order == 1:
+        common += ["--indep-order", "1"]
+    ref = T.run_ref(common + ["--threads", "3", "--out", "ref"], str(tmp_path))
+    assert ref.returncode == 0, ref.stdout
+    got = run_cli(cli, common + ["--out", "hip"], str(tmp_path))
+    assert got.returncode == 0, got.stdout
+    ref_out = open(str(tmp_path / "ref.prune.out")).read().split()
+    hip_out = open(str(tmp_path / "hip.prune.out")).read().split()
+    diff = sorted(set(ref_out) ^ set(hip_out), key=lambda x: int(x[3:]))
+    assert not diff, "differs on %d variants, e.g. %s" % (len(diff), diff[:10])
+    assert filecmp.cmp(str(tmp_path / "ref.prune.in"), str(tmp_path / "hip.prune.in"), shallow=False)
+    assert filecmp.cmp(str(tmp_path / "ref.prune.out"), str(tmp_path / "hip.prune.out"), shallow=False)
+    assert 0 < len(hip_out) < m
+    # --indep-pairphase and the r^2 outputs still refuse them, loudly
+    r = run_cli(cli, ["--pfile", "mv", "--r2-unphased", "--out", "no"], str(tmp_path))
+    assert r.returncode == 63 and "multiallelic" in r.stdout
+
+
 def test_vcor_number_formatting_matches_reference(cli, tmp_path):
     """The .vcor writer's 6-significant-digit formatter against 26k (double, text) pairs recorded from the
     reference's own table output (tests/golden/make_golden_vcor.py).  No GPU involved."""
