@@ -36,6 +36,7 @@ def main():
     import bench
     import __graft_entry__ as ge
     pkg = ge.load_package()
+    pkg.build_library(measure=True)   # lib/libldprune_hip_measure.so (-DLDP_MEASURE): a no-op when it is newer than the sources
     L = pkg.lib()
     L.ldp_measure_wide_counters.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     torch.cuda.set_device(0)
