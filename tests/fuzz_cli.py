@@ -60,6 +60,60 @@ def pairphase_multiallelic_case(cli, ref, rng, idx, tmp, execute=True):
     return True, "case %d ok: %s (multiallelic VCF import)" % (idx, " ".join(args))
 
 
+def sex_multiallelic_case(cli, ref, rng, idx, tmp, execute=True):
+    """--indep-pairwise over variants with several ALT alleles on chromosome 1, X, Y and MT (a VCF imported by the reference, its .pvar
+    re-labelled), random sexes incl. unknown, non-founders: the sex-weighted allele counts choose the major allele (round 5)"""
+    from test_pgen_reader import make_multiallelic_vcf
+    n = int(rng.choice([40, 77, 150]))
+    m = int(rng.integers(120, 500))
+    d = os.path.join(tmp, "c%d" % idx)
+    os.makedirs(d)
+    seed = int(rng.integers(1, 1 << 30))
+    max_alt = int(rng.integers(2, 7))
+    miss = float(rng.choice([0.0, 0.03, 0.1]))
+    names = [str(x) for x in rng.permutation(["1", "X", "Y", "MT"])[:int(rng.integers(2, 5))]]
+    order_of = {"1": 0, "X": 1, "Y": 2, "MT": 3}
+    names.sort(key=lambda c: order_of[c])
+    cuts = np.sort(rng.integers(1, m, size=len(names) - 1))
+    sexes = rng.choice([1, 2, 0], size=n, p=[0.45, 0.4, 0.15])
+    nonfounder = rng.random(n) < float(rng.choice([0.0, 0.1]))
+    nonfounder[:3] = False
+    if rng.random() < 0.5:
+        win = ["%gkb" % float(rng.choice([5, 20, 60]))]
+    else:
+        w = int(rng.integers(2, 150))
+        win = [str(w), str(int(rng.integers(1, max(2, w))))]
+    args = ["--pfile", "d", "--indep-pairwise"] + win + [str(rng.choice([0.05, 0.1, 0.3, 0.6])), "--indep-order", str(int(rng.integers(1, 3)))]
+    if not execute:
+        return True, "case %d skipped" % idx
+    make_multiallelic_vcf(os.path.join(d, "d.vcf"), m, n, seed=seed, max_alt=max_alt, missing=miss)
+    T.ref_import_vcf(os.path.join(d, "d.vcf"), os.path.join(d, "d"))
+    out, k = [], 0
+    for ln in open(os.path.join(d, "d.pvar")):
+        if ln.startswith("#"):
+            out.append(ln)
+            continue
+        f = ln.rstrip("\n").split("\t")
+        f[0] = names[int(np.searchsorted(cuts, k, side="right"))]
+        out.append("\t".join(f) + "\n")
+        k += 1
+    open(os.path.join(d, "d.pvar"), "w").write("".join(out))
+    psam = ["#IID\tPAT\tMAT\tSEX"]
+    for q in range(n):
+        psam.append("s%d\t%s\t%s\t%s" % (q, "s0" if nonfounder[q] else "0", "s1" if nonfounder[q] else "0", "NA" if sexes[q] == 0 else str(sexes[q])))
+    open(os.path.join(d, "d.psam"), "w").write("\n".join(psam) + "\n")
+    r = run([ref] + args + ["--threads", "2", "--out", "ref"], d)
+    g = run([cli] + args + ["--out", "hip"], d)
+    if r.returncode != g.returncode:
+        return False, "case %d: exit codes differ (ref %d, hip %d): %s\n%s\n%s" % (idx, r.returncode, g.returncode, " ".join(args), r.stdout[-300:], g.stdout[-400:])
+    if r.returncode != 0:
+        return True, "case %d: both refuse (%s)" % (idx, " ".join(args))
+    for e in (".prune.in", ".prune.out"):
+        if not filecmp.cmp(os.path.join(d, "ref" + e), os.path.join(d, "hip" + e), shallow=False):
+            return False, "case %d: %s differs: %s (multiallelic on %s, n=%d m=%d seed=%d max_alt=%d)" % (idx, e, " ".join(args), "/".join(names), n, m, seed, max_alt)
+    return True, "case %d ok: %s (multiallelic on %s)" % (idx, " ".join(args), "/".join(names))
+
+
 def pairphase_case(cli, ref, rng, idx, tmp, execute=True):
     if rng.random() < 0.25:
         return pairphase_multiallelic_case(cli, ref, rng, idx, tmp, execute)
@@ -277,7 +331,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--mode", default="all", choices=["all", "pairphase", "clump"])
+    ap.add_argument("--mode", default="all", choices=["all", "pairphase", "clump", "sexmulti"])
     ap.add_argument("--only", type=int, default=None, help="replay the random stream but execute only this case")
     ap.add_argument("--keep", default=None, help="directory to keep the case files in (default: a temporary directory)")
     args = ap.parse_args()
@@ -292,7 +346,10 @@ def main():
         if args.keep:
             os.makedirs(tmp, exist_ok=True)
         for k in range(args.cases):
-            ok, desc = one_case(cli, ref, rng, k, tmp, execute=(args.only is None or k == args.only), mode=args.mode)
+            if args.mode == "sexmulti":
+                ok, desc = sex_multiallelic_case(cli, ref, rng, k, tmp, execute=(args.only is None or k == args.only))
+            else:
+                ok, desc = one_case(cli, ref, rng, k, tmp, execute=(args.only is None or k == args.only), mode=args.mode)
             if not ok:
                 print("MISMATCH", desc, "(--seed %d)" % args.seed)
                 sys.exit(1)
