@@ -279,9 +279,9 @@ void load_inputs(Session& S, int argc, char** argv) {
 
   if (A.have_prune && founder_ct < 50 && !A.bad_ld) {  // plink2.cc:2063-2071
     if (raw_sample_ct < 50) {
-      die(7, "Error: This run estimates linkage disequilibrium between variants, but there\nare less than 50 samples to estimate from.  You should perform this operation\non a larger dataset.\n(Strictly speaking, you can also override this error with --bad-ld, but this is\nalmost always a bad idea.)\n");
+      die(13, "Error: This run estimates linkage disequilibrium between variants, but there\nare less than 50 samples to estimate from.  You should perform this operation\non a larger dataset.\n(Strictly speaking, you can also override this error with --bad-ld, but this is\nalmost always a bad idea.)\n");
     }
-    die(7, "Error: This run estimates linkage disequilibrium between variants, but there\nare less than 50 founders to estimate from.  --make-founders may help.\n(Strictly speaking, you can also override this error with --bad-ld, but this is\nalmost always a bad idea.)\n");
+    die(13, "Error: This run estimates linkage disequilibrium between variants, but there\nare less than 50 founders to estimate from.  --make-founders may help.\n(Strictly speaking, you can also override this error with --bad-ld, but this is\nalmost always a bad idea.)\n");
   }
   if (founder_ct < 2) {
     die(7, "Error: %s requires at least two founders. (--make-founders may come in handy here.)\n", A.have_prune ? (A.pairphase ? "--indep-pairphase" : "--indep-pairwise") : "--r2-unphased");

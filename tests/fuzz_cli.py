@@ -84,6 +84,8 @@ def sex_multiallelic_case(cli, ref, rng, idx, tmp, execute=True):
         w = int(rng.integers(2, 150))
         win = [str(w), str(int(rng.integers(1, max(2, w))))]
     args = ["--pfile", "d", "--indep-pairwise"] + win + [str(rng.choice([0.05, 0.1, 0.3, 0.6])), "--indep-order", str(int(rng.integers(1, 3)))]
+    if (n < 60) and (rng.random() < 0.8):
+        args.append("--bad-ld")   # (fewer than 50 founders: without it both tools must refuse, with the same exit code)
     if not execute:
         return True, "case %d skipped" % idx
     make_multiallelic_vcf(os.path.join(d, "d.vcf"), m, n, seed=seed, max_alt=max_alt, missing=miss)

@@ -79,7 +79,10 @@ def test_argument_errors(cli, tmp_path, args, needle):
 def test_founder_guard_and_format_errors(cli, tmp_path):
     small_fileset(tmp_path, n=30)
     cp = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "50", "5", "0.2", "--dry-run", "--out", "o"], str(tmp_path))
-    assert cp.returncode != 0 and "less than 50 samples" in cp.stdout
+    assert cp.returncode == 13 and "less than 50 samples" in cp.stdout   # kPglRetDegenerateData (plink2.cc:2065-2071), as the reference exits:
+    if T.have_ref():
+        ref = T.run_ref(["--bfile", "d", "--indep-pairwise", "50", "5", "0.2", "--out", "r"], str(tmp_path))
+        assert ref.returncode == cp.returncode == 13 and "less than 50" in ref.stdout
     cp = run_cli(cli, ["--bfile", "d", "--indep-pairwise", "50", "5", "0.2", "--bad-ld", "--dry-run", "--out", "o"], str(tmp_path))
     assert cp.returncode == 0
     # wrong .bed size
