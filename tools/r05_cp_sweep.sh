@@ -11,7 +11,7 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print('$1 [$2]', round(d['ms_per_step'],2), round(r['kernel_ms_per_step'],2), round(r['mfma']['early_termination_skipped_frac'],4), d['config']['variants_removed'])"
 }
-for F in "" "0.573,0.593,0.633,0.713,0.913" "0.578,0.603,0.643,0.713,0.913" "0.570,0.580,0.593,0.633,0.753" "0.575,0.585,0.600,0.640,0.760" "0.580,0.590,0.610,0.650,0.800" "0.583,0.620,0.700,0.850" "0.570,0.576,0.584,0.600,0.680"; do
+for F in "" "0.561,0.575,0.600,0.650,0.800" "0.558,0.566,0.580,0.620,0.750" "0.563,0.570,0.590,0.630,0.750" "0.565,0.575,0.593,0.633,0.753" "0.565,0.580,0.600,0.640,0.760" "0.560,0.570,0.585,0.620,0.750" "0.565,0.593,0.633,0.713,0.913"; do
   run slice "$F" "--variants 120000" 12
-done > $O/cp_sweep.txt 2>&1
-cat $O/cp_sweep.txt
+done > $O/cp_sweep2.txt 2>&1
+cat $O/cp_sweep2.txt
