@@ -735,7 +735,7 @@ def pmc_traffic(founder_ct, variants, window_kb, missing_rate):
     return None, None, None
 
 
-def pmc_traffic_in_run(argv_workload, timeout_s=240):
+def pmc_traffic_in_run(argv_workload, timeout_s=150):
     """HBM bytes of ONE step of the named workload measured NOW, on this box: two rocprofv3 passes over a one-step child run of this script
     (`--kernel-trace --pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: separate passes, as MI355X_MICROARCH.md's HBM section prescribes), summed over
     the pair kernels' dispatches; FETCH_SIZE / WRITE_SIZE are in KiB and gfx950's FETCH_SIZE reports half of a wide streaming read (x 2).
