@@ -173,7 +173,7 @@ class E2EChr22:
     minutes run beside the GPU legs of this script; finish() joins it, then runs plink2-hip on the same files with the GPU idle
     (`--timing`: its own phase split), and compares the two pairs of output files byte for byte."""
 
-    def __init__(self, pkg, torch, cfg, variants, ref_timeout_s=900):
+    def __init__(self, pkg, torch, cfg, variants, ref_timeout_s=420):
         self.pkg, self.torch, self.cfg, self.m, self.ref_timeout_s = pkg, torch, cfg, variants, ref_timeout_s
         self.tmp, self.ref_proc, self.res = None, None, {}
 
