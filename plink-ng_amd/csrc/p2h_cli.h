@@ -397,7 +397,10 @@ struct ClumpSex {
   int prov_storage = 1;                        // ldp_pgen_provisional_ref
   std::vector<uint8_t> prov_bits;
   std::function<void(ldp_engine*, const std::vector<uint32_t>&, const std::vector<uint32_t>*)> feed_cols;
-  std::function<void(ldp_engine*, uint32_t, uint32_t)> females_missing;
+  uint32_t raw_sample_ct = 0;
+  // reloads engine row `row` from raw variant `raw`: the main track (aidx < 0) or the copies-of-the-other-alleles row of allele `aidx` of a
+  // multiallelic variant; females_missing: the female founders' calls become missing (chrY); mapped: the engine picks its sample columns itself
+  std::function<void(ldp_engine*, uint32_t row, uint32_t raw, int32_t aidx, bool females_missing, bool mapped)> allele_row;
 };
 
 int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>& inc, const std::vector<uint32_t>& chr_idx,

@@ -194,13 +194,58 @@ bool natural_less(const std::string& a, const std::string& b) {
 // bin boundaries of the default 'bins' column set (kClumpDefaultLnBinBounds, plink2_ld.cc:7498): ln of 1e-4, 1e-3, 1e-2, 0.05
 const double kClumpLnBins[4] = {-9.210340371976706, -6.907755278982529, -4.605170185988353, -2.995732273554161};
 
+// What the reference keys by "allele index" (plink2_ld.cc:7776-7819): a biallelic variant is ONE entity whatever the report's A1 says
+// (--clump-force-a1 only remembers which allele the best line named), a variant with several ALT alleles is one entity PER ALLELE, REF
+// included -- each with its own p-values, its own rank among the index candidates and its own genotype row (copies of that allele).  A slot
+// here is that entity: slot_base[k] .. slot_base[k + 1] are the slots of included variant k (one, or allele count many), in dataset order.
+struct ClumpSlots {
+  std::vector<uint32_t> base;  // per included variant (+ 1)
+  std::vector<uint32_t> var;   // slot -> included variant
+  bool any_multiallelic = false;
+  void build(const Variants& V, const std::vector<uint32_t>& inc) {
+    base.assign(inc.size() + 1, 0);
+    for (size_t k = 0; k < inc.size(); ++k) {
+      const uint32_t n = (V.alt_ct[inc[k]] > 1) ? (static_cast<uint32_t>(V.alt_ct[inc[k]]) + 1) : 1u;
+      any_multiallelic = any_multiallelic || (n > 1);
+      base[k + 1] = base[k] + n;
+    }
+    var.resize(base.back());
+    for (size_t k = 0; k < inc.size(); ++k) {
+      for (uint32_t q = base[k]; q < base[k + 1]; ++q) {
+        var[q] = static_cast<uint32_t>(k);
+      }
+    }
+  }
+  uint32_t count() const { return base.back(); }
+  bool multiallelic(uint32_t slot) const { return base[var[slot] + 1] - base[var[slot]] > 1; }
+  uint32_t aidx(uint32_t slot) const { return slot - base[var[slot]]; }
+};
+
+// allele `idx` of raw variant v as the reference's flat allele table holds it (REF, then the ALT alleles): one past the last allele is the
+// next variant's REF -- which is what its SP2 printer reads when a stale forced-A1 bit rides on a multiallelic entry (clump_load_report)
+std::string allele_text(const Variants& V, uint32_t v, uint32_t idx) {
+  if (idx == 0) {
+    return V.ref[v];
+  }
+  const std::string& alt = V.alt[v];
+  size_t pos = 0;
+  for (uint32_t a = 1; a <= V.alt_ct[v]; ++a) {
+    const size_t comma = std::min(alt.find(',', pos), alt.size());
+    if (a == idx) {
+      return alt.substr(pos, comma - pos);
+    }
+    pos = comma + 1;
+  }
+  return (static_cast<size_t>(v) + 1 < V.ref.size()) ? V.ref[v + 1] : std::string();
+}
+
 struct ClumpData {
-  // per dataset variant (index into the caller's included-variant list)
+  // per slot (ClumpSlots)
   std::vector<double> best_ln;                // lowest ln p among the lines at or below the load threshold; 0 without one
   std::vector<uint32_t> nonsig;               // lines above every bin boundary
   std::vector<std::vector<uint32_t>> entries; // one per loaded line, in the order read (last report first): (file << 12) | (bin << 1) | (ln p > ln p2)
   std::vector<double> ln_bins;                // bin boundaries in use (empty: the 'bins' column set is off)
-  std::vector<uint8_t> best_a1;               // --clump-force-a1: the best line's A1 is the ALT allele
+  std::vector<uint8_t> best_a1;               // --clump-force-a1: the best line's A1 is the ALT allele (a biallelic variant's slot)
   std::vector<std::string> missing_pairs;     // top (ID, A1) pairs whose allele the dataset's variant does not have
   std::vector<uint16_t> best_file;            // report (1-based) the best p-value came from; ties go to the first report
   std::vector<uint8_t> observed;
@@ -216,15 +261,24 @@ uint32_t clump_bin(const std::vector<double>& ln_bins, double ln_pval) {  // Low
 }
 
 // The report -> per-variant p-value lists (plink2_ld.cc:7667-7858).
-void clump_load_report(const Args& A, const Variants& V, const std::vector<uint32_t>& inc, ClumpData* D) {
+void clump_load_report(const Args& A, const Variants& V, const std::vector<uint32_t>& inc, const ClumpSlots& SL, ClumpData* D) {
   const uint32_t variant_ct = static_cast<uint32_t>(inc.size());
-  D->best_ln.assign(variant_ct, 0.0);
-  D->nonsig.assign(variant_ct, 0);
-  D->entries.assign(variant_ct, std::vector<uint32_t>());
-  D->best_file.assign(variant_ct, 1);
-  D->best_a1.assign(variant_ct, 0);
-  D->observed.assign(variant_ct, 0);
+  const uint32_t slot_ct = SL.count();
+  D->best_ln.assign(slot_ct, 0.0);
+  D->nonsig.assign(slot_ct, 0);
+  D->entries.assign(slot_ct, std::vector<uint32_t>());
+  D->best_file.assign(slot_ct, 1);
+  D->best_a1.assign(slot_ct, 0);
+  D->observed.assign(slot_ct, 0);
   // ID -> included-variant index; kDup marks IDs the dataset holds more than once (an error only when the report names one)
+  bool pvar_multiallelic = false;
+  for (size_t v = 0; (!pvar_multiallelic) && (v < V.alt_ct.size()); ++v) {
+    pvar_multiallelic = V.alt_ct[v] > 1;
+  }
+  // the forced-A1 bit of the latest line of a BIALLELIC variant (biallelic_forced_a1_alt, :7646): the reference declares it outside the loops
+  // over reports and lines and writes it on biallelic lines only, so an entry of a multiallelic variant's allele carries whatever the
+  // previous biallelic line left there.  Reproduced (the bit shows in SP2 and in the bounds scan).
+  uint32_t a1_alt = 0;
   const uint32_t kDup = 0xffffffffu;
   std::unordered_map<std::string, uint32_t> by_id;
   by_id.reserve(static_cast<size_t>(variant_ct) * 2);
@@ -311,7 +365,9 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
     }
     want[2] = A.clump_p_field.empty() ? (A.clump_in_log10 ? std::vector<std::string>{"LOG10_P", "NEG_LOG10_P", "P"} : std::vector<std::string>{"P"})
                                       : A.clump_p_field;  // (:7631)
-    const std::vector<std::string> want_a1 = A.clump_force_a1 ? (A.clump_a1_field.empty() ? std::vector<std::string>{"A1"} : A.clump_a1_field) : std::vector<std::string>();
+    // (search_a1, :7624: asked for, or the dataset has a variant with several ALT alleles and --clump-a1-field was not given empty)
+    const bool search_a1 = A.clump_force_a1 || (pvar_multiallelic && !A.clump_no_a1);
+    const std::vector<std::string> want_a1 = search_a1 ? (A.clump_a1_field.empty() ? std::vector<std::string>{"A1"} : A.clump_a1_field) : std::vector<std::string>();
     int col_a1 = -1;
     size_t prio_a1 = ~size_t(0);
     int col[3] = {-1, -1, -1};
@@ -404,41 +460,50 @@ void clump_load_report(const Args& A, const Variants& V, const std::vector<uint3
         die(7, "Error: --clump variant ID '%s' appears multiple times in main dataset.\n", id.c_str());
       }
       const uint32_t k = it->second;
-      uint32_t a1_alt = 0;
-      if (A.clump_force_a1) {  // (:7783-7818)
+      const uint32_t iv = inc[k];
+      const bool multi_k = V.alt_ct[iv] > 1;
+      uint32_t aidx = 0;
+      if (multi_k || A.clump_force_a1) {  // (:7782-7818)
         if (col_a1 < 0) {
           die(7, "Error: Variant ID on line %zu of %s is multiallelic, but there is no A1 column.\n", line_idx, fname.c_str());
         }
         const std::string a1(toks[col_a1].first, toks[col_a1].second);
-        if (a1 == V.ref[inc[k]]) {
-          a1_alt = 0;
-        } else if (a1 == V.alt[inc[k]]) {
-          a1_alt = 1;
-        } else {
+        const uint32_t allele_ct = static_cast<uint32_t>(V.alt_ct[iv]) + 1;
+        for (; aidx < allele_ct; ++aidx) {
+          if (a1 == allele_text(V, iv, aidx)) {
+            break;
+          }
+        }
+        if (aidx == allele_ct) {
           if (ln_pval <= ln_p1) {
             D->missing_pairs.push_back(id + "\t" + a1);
           }
           continue;
         }
+        if (!multi_k) {
+          a1_alt = aidx;
+          aidx = 0;
+        }
       }
+      const uint32_t slot = SL.base[k] + aidx;
       if (ln_pval > load_thresh) {
         if (ln_pval > 0.0) {
           die(6, "Error: p-value > 1 on line %zu of %s.\n", line_idx, fname.c_str());
         }
         if (nonsig_needed && (D->ln_bins.empty() || (ln_pval > D->ln_bins.back()))) {
-          D->nonsig[k] += 1;
-          D->observed[k] = 1;
+          D->nonsig[slot] += 1;
+          D->observed[slot] = 1;
         }
         continue;
       }
-      if (D->best_ln[k] >= ln_pval) {  // (>=: the reports are read last to first, so ties end up with the first one, :7833)
-        D->best_ln[k] = ln_pval;
-        D->best_file[k] = static_cast<uint16_t>(file_idx1);
-        D->best_a1[k] = static_cast<uint8_t>(a1_alt);
+      if (D->best_ln[slot] >= ln_pval) {  // (>=: the reports are read last to first, so ties end up with the first one, :7833)
+        D->best_ln[slot] = ln_pval;
+        D->best_file[slot] = static_cast<uint16_t>(file_idx1);
+        D->best_a1[slot] = static_cast<uint8_t>(a1_alt);
       }
-      D->observed[k] = 1;
+      D->observed[slot] = 1;
       if (keep_entries) {
-        D->entries[k].push_back(static_cast<uint32_t>((a1_alt << 30) | (file_idx1 << 12) | (clump_bin(D->ln_bins, ln_pval) << 1) | (ln_pval > ln_p2)));
+        D->entries[slot].push_back(static_cast<uint32_t>((a1_alt << 30) | (file_idx1 << 12) | (clump_bin(D->ln_bins, ln_pval) << 1) | (ln_pval > ln_p2)));
       }
     }
   }
@@ -567,8 +632,10 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
     die(7, "Error: --clump requires at least two founders.  (--make-founders may come in handy\nhere.)\n");
   }
   const double t_start = now_s();
+  ClumpSlots SL;
+  SL.build(V, inc);
   ClumpData D;
-  clump_load_report(A, V, inc, &D);
+  clump_load_report(A, V, inc, SL, &D);
   if (!D.missing_ids.empty()) {  // natural-sorted, deduplicated (plink2_ld.cc:7909-7931)
     std::sort(D.missing_ids.begin(), D.missing_ids.end(), natural_less);
     D.missing_ids.erase(std::unique(D.missing_ids.begin(), D.missing_ids.end()), D.missing_ids.end());
@@ -601,12 +668,13 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
   }
   // observed variants (named by a usable report line) in dataset order, and the index candidates among them:
   // best p <= p1, ranked by (ln p, position in the dataset) (ClumpPvalCmp; plink2_ld.cc:7996-8040)
-  std::vector<uint32_t> obs;  // -> index into inc[]
-  for (uint32_t k = 0; k < D.observed.size(); ++k) {
-    if (D.observed[k]) {
-      obs.push_back(k);
+  std::vector<uint32_t> obs;  // -> slot (ClumpSlots: a biallelic variant, or one allele of a multiallelic one)
+  for (uint32_t slot = 0; slot < D.observed.size(); ++slot) {
+    if (D.observed[slot]) {
+      obs.push_back(slot);
     }
   }
+  auto var_of = [&](uint32_t o) { return SL.var[obs[o]]; };  // observed index -> index into inc[]
   const uint32_t n_obs = static_cast<uint32_t>(obs.size());
   std::vector<uint32_t> cand;  // -> observed index, rank order
   for (uint32_t o = 0; o < n_obs; ++o) {
@@ -637,8 +705,8 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
   // GetNextIslandIdxs plink2_ld.cc:5642, make the same cut): the engine holds those, in dataset order.
   std::vector<uint32_t> o_chr(n_obs), o_bp(n_obs);
   for (uint32_t o = 0; o < n_obs; ++o) {
-    o_chr[o] = chr_idx[obs[o]];
-    o_bp[o] = bps[obs[o]];
+    o_chr[o] = chr_idx[var_of(o)];
+    o_bp[o] = bps[var_of(o)];
   }
   std::vector<int32_t> cover(static_cast<size_t>(n_obs) + 1, 0);
   bool any_pair = false;
@@ -693,18 +761,27 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
     for (uint32_t q = 0; q < n_sub; ++q) {
       s_chr[q] = o_chr[sub[q]];
       s_bp[q] = o_bp[sub[q]];
-      s_raw[q] = inc[obs[sub[q]]];
+      s_raw[q] = inc[var_of(sub[q])];
     }
     if (ldp_set_variants_vcor(e, n_sub, s_chr.data(), s_bp.data(), A.clump_bp_radius, 0xffffffffu)) {
       die(16, "Error: engine setup failed: %s\n", ldp_last_error(e));
     }
     feed(e, s_raw);
+    // an allele of a multiallelic variant: the row PgrGetInv1 returns for it (copies of the OTHER alleles, pgenlib_read.cc:5544-5563; r^2 does not
+    // see the inversion), built on the host over the main-track row feed() has just loaded (:8813-8835)
+    std::vector<int32_t> s_aidx(n_sub, -1);
+    for (uint32_t q = 0; q < n_sub; ++q) {
+      if (SL.multiallelic(obs[sub[q]])) {
+        s_aidx[q] = static_cast<int32_t>(SL.aidx(obs[sub[q]]));
+        SX.allele_row(e, q, s_raw[q], s_aidx[q], false, founder_ct != SX.raw_sample_ct);
+      }
+    }
     // sex chromosomes: chrY rows with the female founders' calls missing; chrX pairs through the male-weighted sums when the
     // founders are of both kinds (is_x, :8472-8481), their own engine for the male founders' tuples
     std::vector<uint8_t> s_is_x(n_sub, 0);
     bool any_x = false, any_y = false;
     for (uint32_t q = 0; q < n_sub; ++q) {
-      const uint8_t cls = (*SX.vcls)[obs[sub[q]]];
+      const uint8_t cls = (*SX.vcls)[var_of(sub[q])];
       any_y = any_y || (cls == 4);
       if ((cls == 3) && SX.founder_male_ct && (SX.founder_male_ct != founder_ct)) {
         s_is_x[q] = 1;
@@ -717,8 +794,8 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
       }
       if (SX.founder_male_ct + SX.founder_nosex_ct != founder_ct) {
         for (uint32_t q = 0; q < n_sub; ++q) {
-          if ((*SX.vcls)[obs[sub[q]]] == 4) {
-            SX.females_missing(e, q, s_raw[q]);
+          if ((*SX.vcls)[var_of(sub[q])] == 4) {
+            SX.allele_row(e, q, s_raw[q], s_aidx[q], true, founder_ct != SX.raw_sample_ct);
           }
         }
       }
@@ -732,6 +809,11 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
         die(16, "Error: engine setup failed.\n");
       }
       SX.feed_cols(xw.male, s_raw, &SX.male_cols);
+      for (uint32_t q = 0; q < n_sub; ++q) {
+        if (s_aidx[q] >= 0) {
+          SX.allele_row(xw.male, q, s_raw[q], s_aidx[q], false, true);
+        }
+      }
       xw.all = e;
       xw.is_x = s_is_x;
       // one orientation for both tuples of a pair: the main engine's (the male engine chose its major alleles from the male
@@ -869,7 +951,7 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
   }
   const bool bounds_col = (cols & kClumpColBounds) || ((cols & kClumpColMaybeBounds) && ranges_col);
   const bool save_all_fidxs = (multi || A.clump_force_a1) && sp2_col;  // (:7633)
-  const bool a1_col = (cols & kClumpColA1) != 0;  // ('maybea1' wants a multiallelic variant in the dataset: those are refused above)
+  const bool a1_col = (cols & kClumpColA1) || ((cols & kClumpColMaybeA1) && SL.any_multiallelic);  // (:9017)
   const size_t bin_bound_ct = D.ln_bins.size();
   bool provref_col = false;
   if (cols & kClumpColRef) {  // ProvrefCol (plink2_common.h:1549)
@@ -913,7 +995,7 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
       continue;
     }
     const uint32_t io = cand[r];
-    const uint32_t iv = inc[obs[io]];
+    const uint32_t iv = inc[var_of(io)];
     const double index_ln = D.best_ln[obs[io]];
     if (cols & kClumpColChrom) {
       buf += V.chrom[iv];
@@ -941,8 +1023,11 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
       buf += ((SX.prov_storage == 2) || ((SX.prov_storage == 3) && ((SX.prov_bits[iv >> 3] >> (iv & 7)) & 1))) ? 'Y' : 'N';
       buf += '\t';
     }
-    if (a1_col) {  // (a biallelic variant: the best line's A1 with --clump-force-a1, else '.', :9186-9196)
-      if (A.clump_force_a1) {
+    if (a1_col) {  // (a biallelic variant: the best line's A1 with --clump-force-a1, else '.'; an allele of a multiallelic one: itself, :9186-9201)
+      if (SL.multiallelic(obs[io])) {
+        buf += allele_text(V, iv, SL.aidx(obs[io]));
+        buf += '\t';
+      } else if (A.clump_force_a1) {
         buf += D.best_a1[obs[io]] ? V.alt[iv] : V.ref[iv];
         buf += '\t';
       } else {
@@ -963,7 +1048,7 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
       uint64_t total = 0;
       std::fill(bins.begin(), bins.end(), 0);
       for (uint64_t q = mem_off[r]; q < mem_off[r + 1]; ++q) {
-        const uint32_t k = obs[members[q]];
+        const uint32_t k = obs[members[q]];  // (slot)
         bins[bin_bound_ct] += D.nonsig[k];
         for (uint32_t en : D.entries[k]) {
           ++bins[bin_bound_ct ? ((en >> 1) & 2047) : 0];
@@ -996,9 +1081,9 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
         }
         if (hit) {
           if (first_bp == 0xffffffffu) {
-            first_bp = V.bp[inc[k]];
+            first_bp = V.bp[inc[SL.var[k]]];
           }
-          last_bp = V.bp[inc[k]];
+          last_bp = V.bp[inc[SL.var[k]]];
         }
       }
     }
@@ -1031,10 +1116,10 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
         if ((en & 1) || ((m == io) && (file == index_file))) {
           continue;
         }
-        buf += V.id[inc[obs[m]]];
-        if (A.clump_force_a1) {  // (:9355-9358)
+        buf += V.id[inc[var_of(m)]];
+        if (A.clump_force_a1 || SL.multiallelic(obs[m])) {  // (:9355-9358: the entity's allele, plus the entry's forced-A1 bit)
           buf += '(';
-          buf += ((en >> 30) & 1) ? V.alt[inc[obs[m]]] : V.ref[inc[obs[m]]];
+          buf += allele_text(V, inc[var_of(m)], SL.aidx(obs[m]) + ((A.clump_force_a1 && sp2_col) ? ((en >> 30) & 1) : 0));
           buf += ')';
         }
         if (f_in_sp2) {

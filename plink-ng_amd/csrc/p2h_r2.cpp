@@ -833,30 +833,39 @@ int run_r2(Session& S) {
   auto feed_rows = [&](ldp_engine* eng, const std::vector<uint32_t>& incl) { feed_rows_cols(eng, incl, nullptr); };
   // chrY rows of the r^2 outputs and --clump: the female founders' calls count as missing (InterleavedSetMissing, plink2_ld.cc
   // :8833, :10290, :11845).  Reloads engine row `row` from raw variant `raw` that way.
-  auto females_missing = [&](ldp_engine* eng, uint32_t row_idx, uint32_t raw) {
-    std::vector<uint8_t> row(rec_bytes);
+  // --clump on a variant with several ALT alleles (aidx >= 0): the row is PgrGetInv1's for that allele -- copies of the OTHER alleles,
+  // 3 = missing (pgenlib_read.cc:5544-5563) -- over all samples of the file, from the per-sample allele pairs of the host reader.
+  std::vector<uint8_t> al_lo, al_hi;
+  auto allele_row = [&](ldp_engine* eng, uint32_t row_idx, uint32_t raw, int32_t aidx, bool fem_missing, bool mapped) {
+    std::vector<uint8_t> row(rec_bytes, 0);
     const uint8_t missing_code = (encoding == LDP_GENO_BED) ? 1 : 3;
-    if (direct_rows) {
+    if (aidx >= 0) {
+      al_lo.resize(raw_sample_ct);
+      al_hi.resize(raw_sample_ct);
+      if (ldp_pgen_read_alleles(pg, raw, V.alt_ct[raw], al_lo.data(), al_hi.data())) {
+        die(6, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
+      }
+      for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+        const uint32_t c = (al_lo[sx] == 255) ? 3u : (static_cast<uint32_t>(al_lo[sx] != aidx) + static_cast<uint32_t>(al_hi[sx] != aidx));
+        row[sx >> 2] |= static_cast<uint8_t>(c << (2 * (sx & 3)));
+      }
+    } else if (direct_rows) {
       memcpy(row.data(), direct_rows + static_cast<uint64_t>(raw) * rec_bytes, rec_bytes);
     } else if (ldp_pgen_read(pg, raw, 1, row.data(), rec_bytes, 0)) {
       die(6, "Error: %s: %s\n", gpath.c_str(), ldp_pgen_last_error(pg));
     }
-    for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+    for (uint32_t sx = 0; fem_missing && (sx < raw_sample_ct); ++sx) {
       if (is_founder[sx] && (sex[sx] == 2)) {
         uint8_t& b = row[sx >> 2];
         b = static_cast<uint8_t>((b & ~(3u << (2 * (sx & 3)))) | (missing_code << (2 * (sx & 3))));
       }
     }
-    if (ldp_load_genotypes(eng, row_idx, 1, row.data(), rec_bytes, LDP_MEM_HOST, encoding | ((founder_ct == raw_sample_ct) ? 0 : LDP_GENO_MAPPED))) {
+    if (ldp_load_genotypes(eng, row_idx, 1, row.data(), rec_bytes, LDP_MEM_HOST, encoding | (mapped ? LDP_GENO_MAPPED : 0))) {
       die(16, "Error: %s\n", ldp_last_error(eng));
     }
   };
+  auto females_missing = [&](ldp_engine* eng, uint32_t row_idx, uint32_t raw) { allele_row(eng, row_idx, raw, -1, true, founder_ct != raw_sample_ct); };
   if (A.have_clump) {
-    for (uint32_t k = 0; k < variant_ct; ++k) {
-      if (V.alt_ct[inc[k]] > 1) {  // (the reference clumps (variant, A1 allele) pairs there, plink2_ld.cc:7776-7817)
-        die(63, "Error: multiallelic variant '%s': plink2-hip's --clump handles biallelic variants only.\n", V.id[inc[k]].c_str());
-      }
-    }
     join_hip();
     ClumpSex SX;
     SX.vcls = &vcls;
@@ -877,7 +886,8 @@ int run_r2(Session& S) {
       std::copy(V.info_pr.begin(), V.info_pr.begin() + std::min(V.info_pr.size(), SX.prov_bits.size()), SX.prov_bits.begin());
     }
     SX.feed_cols = feed_rows_cols;
-    SX.females_missing = females_missing;
+    SX.allele_row = allele_row;
+    SX.raw_sample_ct = raw_sample_ct;
     const int rc = clump_reports(A, V, inc, chr_idx, bps, founder_ct, feed_rows, SX);
     if (g_log) {
       fclose(g_log);

@@ -200,7 +200,7 @@ void load_variants(const Args& A, Variants* V) {
   double last_cm = -1.7976931348623157e308;
   std::string last_cm_chrom;
   const bool keep_alleles = (A.have_r2 && (A.r2_cols & (kVcorColRef | kVcorColAlt1 | kVcorColAlt | kVcorColMaj | kVcorColNonmaj))) ||
-                            (A.have_clump && ((A.clump_cols & (kClumpColRef | kClumpColAlt1 | kClumpColAlt)) || A.clump_force_a1));
+                            A.have_clump;  // (--clump: an A1 column names alleles of multiallelic variants, and of all variants under --clump-force-a1)
   constexpr int kCap = 64;
   Tok t[kCap];
   const char* p = buf.data();

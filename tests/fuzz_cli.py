@@ -116,6 +116,65 @@ def sex_multiallelic_case(cli, ref, rng, idx, tmp, execute=True):
     return True, "case %d ok: %s (multiallelic on %s)" % (idx, " ".join(args), "/".join(names))
 
 
+def clump_multiallelic_case(cli, ref, rng, idx, tmp, execute=True):
+    """--clump over (variant, A1 allele) pairs: LD-carrying multiallelic sites on chromosome 1 / X / Y / MT (a VCF imported by the reference),
+    random sexes and non-founders, one or two reports with an allele column, --clump-force-a1 / --clump-allow-overlap / column sets"""
+    import test_clump as TC
+    import pathlib
+    n = int(rng.choice([40, 77, 150, 260]))
+    m = int(rng.integers(150, 900))
+    d = os.path.join(tmp, "c%d" % idx)
+    os.makedirs(d)
+    seed = int(rng.integers(1, 1 << 30))
+    max_alt = int(rng.integers(2, 8))
+    names = [str(x) for x in rng.permutation(["1", "X", "Y", "MT"])[:int(rng.integers(1, 5))]]
+    order_of = {"1": 0, "X": 1, "Y": 2, "MT": 3}
+    names.sort(key=lambda c: order_of[c])
+    cuts = np.sort(rng.integers(1, m, size=len(names) - 1))
+    sexes = rng.choice([1, 2, 0], size=n, p=[0.45, 0.4, 0.15])
+    sexes[:2] = [1, 2]
+    nonfounder = rng.random(n) < float(rng.choice([0.0, 0.1]))
+    nonfounder[:3] = False
+    two = rng.random() < 0.4
+    args = ["--pfile", "d", "--clump"]
+    if rng.random() < 0.5:
+        args.append("cols=" + str(rng.choice(["+a1,+bounds", "+f,+alt,+ref", "-sp2,+a1", "+bounds,-total", "-bins"])))
+    args += ["a.txt"] + (["b.txt"] if two else [])
+    args += ["--clump-unphased", "--clump-r2", str(rng.choice([0, 0.1, 0.3, 0.7])), "--clump-kb", str(rng.choice([1, 10, 60])),
+             "--clump-p1", str(rng.choice(["1e-4", "1e-2", "0.3"])), "--clump-p2", str(rng.choice(["1e-2", "0.05", "1e-6"]))]
+    if rng.random() < 0.35:
+        args.append("--clump-force-a1")
+    if rng.random() < 0.3:
+        args.append("--clump-allow-overlap")
+    if rng.random() < 0.25:
+        args += ["--clump-bins", str(rng.choice(["0.001,0.01", "1e-6,1e-3,0.05,0.5", "0.2"]))]
+    rep_seed = int(rng.integers(1, 1 << 30))
+    if not execute:
+        return True, "case %d skipped" % idx
+    alt_ct, _, _ = TC.multiallelic_clump_fileset(pathlib.Path(d), m, n, seed, chrom_of=lambda v: names[int(np.searchsorted(cuts, v, side="right"))], max_alt=max_alt,
+                                                 multi_rate=float(rng.choice([0.1, 0.4, 0.9])))
+    psam = ["#IID\tPAT\tMAT\tSEX"]
+    for q in range(n):
+        psam.append("s%d\t%s\t%s\t%s" % (q, "s0" if nonfounder[q] else "0", "s1" if nonfounder[q] else "0", "NA" if sexes[q] == 0 else str(sexes[q])))
+    open(os.path.join(d, "d.psam"), "w").write("\n".join(psam) + "\n")
+    TC.write_allele_report(os.path.join(d, "a.txt"), alt_ct, rep_seed, False, sig_rate=float(rng.choice([0.05, 0.15])))
+    if two:
+        TC.write_allele_report(os.path.join(d, "b.txt"), alt_ct, rep_seed + 1, False, sig_rate=0.08)
+    r = run([ref] + args + ["--threads", "2", "--out", "ref"], d)
+    g = run([cli] + args + ["--out", "hip"], d)
+    if r.returncode != g.returncode:
+        return False, "case %d: exit codes differ (ref %d, hip %d): %s\n%s\n%s" % (idx, r.returncode, g.returncode, " ".join(args), r.stdout[-300:], g.stdout[-400:])
+    if r.returncode != 0:
+        return True, "case %d: both refuse (%s)" % (idx, " ".join(args))
+    for e in (".clumps", ".clumps.missing_allele"):
+        have_ref, have_hip = os.path.exists(os.path.join(d, "ref" + e)), os.path.exists(os.path.join(d, "hip" + e))
+        if (not have_ref) and (not have_hip):
+            continue
+        if (have_ref != have_hip) or not filecmp.cmp(os.path.join(d, "ref" + e), os.path.join(d, "hip" + e), shallow=False):
+            return False, "case %d: %s differs: %s (multiallelic --clump on %s, n=%d m=%d seed=%d max_alt=%d)" % (idx, e, " ".join(args), "/".join(names), n, m, seed, max_alt)
+    return True, "case %d ok: %s (multiallelic --clump on %s)" % (idx, " ".join(args), "/".join(names))
+
+
 def pairphase_case(cli, ref, rng, idx, tmp, execute=True):
     if rng.random() < 0.25:
         return pairphase_multiallelic_case(cli, ref, rng, idx, tmp, execute)
@@ -333,7 +392,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--mode", default="all", choices=["all", "pairphase", "clump", "sexmulti"])
+    ap.add_argument("--mode", default="all", choices=["all", "pairphase", "clump", "sexmulti", "clumpmulti"])
     ap.add_argument("--only", type=int, default=None, help="replay the random stream but execute only this case")
     ap.add_argument("--keep", default=None, help="directory to keep the case files in (default: a temporary directory)")
     args = ap.parse_args()
@@ -350,6 +409,8 @@ def main():
         for k in range(args.cases):
             if args.mode == "sexmulti":
                 ok, desc = sex_multiallelic_case(cli, ref, rng, k, tmp, execute=(args.only is None or k == args.only))
+            elif args.mode == "clumpmulti":
+                ok, desc = clump_multiallelic_case(cli, ref, rng, k, tmp, execute=(args.only is None or k == args.only))
             else:
                 ok, desc = one_case(cli, ref, rng, k, tmp, execute=(args.only is None or k == args.only), mode=args.mode)
             if not ok:

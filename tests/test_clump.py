@@ -299,6 +299,90 @@ def test_clump_force_a1_matches_reference(cli, tmp_path, mods, extra, two):
     assert os.path.exists(str(tmp_path / "hip.clumps.missing_allele"))
 
 
+ALT_TEXT = ["C", "G", "T", "AC", "AG", "AT", "CA", "CC", "CG", "CT"]   # (ldtools.write_vcf_haps; REF is "A")
+
+
+def multiallelic_clump_fileset(tmp_path, m, n, seed, chrom_of=None, max_alt=4, multi_rate=0.35, spacing=700):
+    """LD-carrying phased haplotypes with 1..max_alt ALT alleles per site -> VCF -> the reference's own import (variable-width .pgen with the
+    multiallelic track).  Returns (alt_ct, chroms, bps)."""
+    first, second, alt_ct = T.synth_multiallelic_haps(m, n, seed, max_alt=max_alt, multi_rate=multi_rate, missing_rate=0.02, ld_copy_prob=0.75, redraw=0.05)
+    rng = np.random.default_rng(seed + 5)
+    chroms = [chrom_of(v) for v in range(m)] if chrom_of else [str(1 + (3 * v) // m) for v in range(m)]
+    bps = [int(x) for x in 1000 + np.cumsum(rng.integers(1, spacing, size=m))]
+    # (imported as one chromosome, the .pvar re-labelled afterwards: the reference's VCF import wants sex information for chrX / chrY)
+    T.write_vcf_haps(str(tmp_path / "d.vcf"), first, second, alt_ct, ["1"] * m, bps)
+    T.ref_import_vcf(str(tmp_path / "d.vcf"), str(tmp_path / "d"))
+    out, k = [], 0
+    for ln in open(str(tmp_path / "d.pvar")):
+        if not ln.startswith("#"):
+            f = ln.split("\t")
+            f[0] = chroms[k]
+            ln = "\t".join(f)
+            k += 1
+        out.append(ln)
+    open(str(tmp_path / "d.pvar"), "w").write("".join(out))
+    return alt_ct, chroms, bps
+
+
+def write_allele_report(path, alt_ct, seed, one_allele_per_variant, sig_rate=0.12, a1_name="A1"):
+    """A report with an allele column: (ID, A1) lines over REF and every ALT of the multiallelic sites, now and then an allele the variant
+    does not have; one_allele_per_variant: every line of a variant names the same allele (nothing shares a position then)."""
+    rng = np.random.default_rng(seed)
+    m = len(alt_ct)
+    lines = ["#CHROM\tPOS\tID\t%s\tTEST\tOBS_CT\tP" % a1_name]
+    fixed = np.random.default_rng(12345).integers(0, 64, size=m)   # (the same choice in every report of a test)
+    for v in rng.permutation(m):
+        k = int(alt_ct[v]) + 1
+        names = ["A"] + ALT_TEXT[:k - 1]
+        reps = 1 + int(rng.random() < 0.5) + int(rng.random() < 0.2) + (2 if (k > 2 and not one_allele_per_variant) else 0)
+        for _ in range(reps):
+            a1 = names[fixed[v] % k] if one_allele_per_variant else names[int(rng.integers(k))]
+            if rng.random() < 0.04:
+                a1 = ["GT", "N", "CT"][int(rng.integers(3))] if k < 10 else "N"
+            u = rng.random()
+            p = 10.0 ** (-rng.uniform(4, 30)) if u < sig_rate else (10.0 ** (-rng.uniform(1, 4.3)) if u < 3 * sig_rate else rng.random())
+            lines.append("1\t1\tsnp%d\t%s\tADD\t100\t%s" % (v, a1, P_FORMATS[rng.integers(len(P_FORMATS))] % p))
+    open(path, "w").write("\n".join(lines) + "\n")
+
+
+@needs_ref
+@pytest.mark.parametrize("mods,extra,two", [
+    ([], [], False),
+    (["cols=+a1,+bounds,+f"], ["--clump-p1", "0.01", "--clump-p2", "1e-3"], True),
+    ([], ["--clump-force-a1"], False),                                   # the stale forced-A1 bit on the multiallelic entries (SP2)
+    (["cols=+bounds,-total"], ["--clump-force-a1", "--clump-p1", "0.05", "--clump-p2", "1e-4"], True),
+    (["cols=-maybea1"], ["--clump-a1-field", "EFFECT"], False),
+])
+def test_clump_multiallelic_report_handling_matches_reference(cli, tmp_path, mods, extra, two):
+    """A dataset with multiallelic sites: the reference clumps (variant, A1 allele) pairs (ClumpReports, plink2_ld.cc:7776-7819, :9186-9201,
+    :9355-9358).  Here every variant is named with one allele only and positions are distinct, so a 1-bp radius pairs nothing and the report
+    side -- allele lookup, .clumps.missing_allele, the A1 column, the SP2 suffixes -- is compared without a GPU."""
+    m = 700
+    alt_ct, _, _ = multiallelic_clump_fileset(tmp_path, m, 60, 31, chrom_of=lambda v: "1")
+    a1_name = "EFFECT" if "EFFECT" in extra else "A1"
+    write_allele_report(str(tmp_path / "a.txt"), alt_ct, 41, True, a1_name=a1_name)
+    files = ["a.txt"]
+    if two:
+        write_allele_report(str(tmp_path / "b.txt"), alt_ct, 42, True, sig_rate=0.2, a1_name=a1_name)
+        files.append("b.txt")
+    common = ["--pfile", "d", "--clump"] + mods + files + ["--clump-unphased", "--clump-kb", "0.001"] + extra
+    compare_runs(cli, tmp_path, common)
+    head = open(str(tmp_path / "hip.clumps")).readline()
+    assert ("A1" in head.split("\t")) == ("cols=-maybea1" not in mods)
+    assert os.path.exists(str(tmp_path / "hip.clumps.missing_allele"))
+
+
+@needs_ref
+def test_clump_multiallelic_line_without_an_a1_column(cli, tmp_path):
+    alt_ct, _, _ = multiallelic_clump_fileset(tmp_path, 120, 50, 32, chrom_of=lambda v: "1")
+    write_allele_report(str(tmp_path / "a.txt"), alt_ct, 43, True, a1_name="ALLELE")
+    base = ["--pfile", "d", "--clump", "a.txt", "--clump-unphased", "--clump-kb", "0.001"]
+    for args in ([], ["--clump-a1-field"]):
+        ref = T.run_ref(base + args + ["--out", "ref"], str(tmp_path))
+        got = run_cli(cli, base + args + ["--out", "hip"], str(tmp_path))
+        assert ref.returncode == got.returncode == 7 and "is multiallelic, but there is no A1 column" in got.stdout, (args, ref.returncode, got.returncode, got.stdout[-300:])
+
+
 @needs_ref
 def test_clump_a1_field_rules(cli, tmp_path):
     m = 300
@@ -491,3 +575,59 @@ def test_clump_with_sex_chromosomes_matches_reference(gpu_pkg, cli, tmp_path, fm
         f = l.split("\t")
         by_chr.setdefault(f[0], []).append(f[-1] != ".")
     assert any(by_chr.get("X", [])) and any(by_chr.get("Y", [])), "multi-variant clumps on chrX and chrY must be formed"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nonfounders,mods,extra", [
+    (180, False, [], ["--clump-r2", "0.2", "--clump-kb", "40"]),
+    (251, True, ["cols=+a1,+bounds,+f"], ["--clump-r2", "0.1", "--clump-kb", "60", "--clump-p1", "0.01", "--clump-p2", "0.1"]),
+    (90, False, [], ["--clump-force-a1", "--clump-r2", "0.3", "--clump-kb", "25"]),
+    (333, False, ["cols=+alt,+ref"], ["--clump-allow-overlap", "--clump-r2", "0.05", "--clump-p1", "0.05", "--clump-kb", "30"]),
+])
+def test_clump_multiallelic_matches_reference(gpu_pkg, cli, tmp_path, n, nonfounders, mods, extra):
+    """(variant, A1 allele) pairs as clump members (ClumpHighmemR2, plink2_ld.cc:7282-7470, rows by PgrGetInv1 :8813-8835): every allele of a
+    multiallelic site is its own row -- copies of the other alleles -- with its own p-values; alleles of one site pair with each other too."""
+    assert T.have_ref()
+    m = 1500
+    alt_ct, _, _ = multiallelic_clump_fileset(tmp_path, m, n, 100 + n)
+    if nonfounders:
+        lines = open(str(tmp_path / "d.psam")).read().splitlines()
+        out = ["#IID\tPAT\tMAT\tSEX"]
+        for k, ln in enumerate(lines[1:]):
+            iid = ln.split("\t")[0]
+            out.append("%s\t%s\t0\tNA" % (iid, "s0" if (k % 7 == 3) else "0"))
+        open(str(tmp_path / "d.psam"), "w").write("\n".join(out) + "\n")
+    write_allele_report(str(tmp_path / "a.txt"), alt_ct, n, False)
+    files = ["a.txt"]
+    if "cols=+a1,+bounds,+f" in mods:
+        write_allele_report(str(tmp_path / "b.txt"), alt_ct, n + 1, False, sig_rate=0.05)
+        files.append("b.txt")
+    compare_runs(cli, tmp_path, ["--pfile", "d", "--clump"] + mods + files + ["--clump-unphased"] + extra)
+    body = [l.split("\t") for l in open(str(tmp_path / "hip.clumps")).read().split("\n")[1:-1]]
+    assert any(("(" in f[-1]) and (f[-1] != ".") for f in body), "clumps with allele-named members must be formed"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("unknown,extra", [
+    (True, ["--clump-r2", "0.15", "--clump-kb", "40", "--clump-p1", "0.01", "--clump-p2", "0.2"]),
+    (False, ["--clump-force-a1", "--clump-r2", "0.3", "--clump-kb", "25", "--clump-p1", "0.05"]),
+])
+def test_clump_multiallelic_on_sex_chromosomes_matches_reference(gpu_pkg, cli, tmp_path, unknown, extra):
+    """... and on chrX (male-weighted sums, ComputeXR2), chrY (the female founders' calls missing) and MT."""
+    assert T.have_ref()
+    m, n = 1200, 150
+    names = ["1", "X", "Y", "MT"]
+    alt_ct, chroms, _ = multiallelic_clump_fileset(tmp_path, m, n, 77, chrom_of=lambda v: names[(4 * v) // m])
+    rng = np.random.default_rng(9)
+    out = ["#IID\tSEX"]
+    for s in range(n):
+        sx = int(rng.integers(1, 3))
+        if unknown and rng.random() < 0.1:
+            sx = "NA"
+        out.append("s%d\t%s" % (s, sx))
+    open(str(tmp_path / "d.psam"), "w").write("\n".join(out) + "\n")
+    write_allele_report(str(tmp_path / "a.txt"), alt_ct, 5, False, sig_rate=0.15)
+    compare_runs(cli, tmp_path, ["--pfile", "d", "--clump", "a.txt", "--clump-unphased"] + extra)
+    body = [l.split("\t") for l in open(str(tmp_path / "hip.clumps")).read().split("\n")[1:-1]]
+    for c in ("X", "Y"):
+        assert any((f[0] == c) and ("(" in f[-1]) for f in body), "allele-named members on chr" + c
