@@ -16,9 +16,9 @@
 // --r2-unphased / --r-unphased: the matrix shapes (square/square0/triangle as bin, bin4 or text, zs), the windowed and the
 // inter-chr .vcor table with cols=, --ld-window, --ld-window-kb, --ld-window-cm, --ld-window-r2, --ld-snp / --ld-snps / --ld-snp-list,
 // --parallel; number formatting restated from dtoa_g.  --clump (several reports, --clump-allow-overlap, cols=, bins, -log10,
-// ranges, sex chromosomes).
+// ranges, sex chromosomes, (variant, A1 allele) pairs of multiallelic sites).
 // Not yet supported (reported as such with exit 63, never silently mis-handled): dosage data outside --indep-pairwise on the autosomes,
-// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT outside --indep-pairwise (round 5 built those) and in --clump, major-allele-oriented
+// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT outside --indep-pairwise and --clump (round 5 built those two), major-allele-oriented
 // r^2 outputs on chrY/MT.
 // The front-end is split into translation units of one concern each (p2h_cli.h: what they share): p2h_util.cpp (logging, number
 // scanning / formatting), p2h_args.cpp (command line), p2h_tables.cpp (.psam / .pvar tables, host-built rows), p2h_inputs.cpp (filters,
