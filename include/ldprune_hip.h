@@ -268,8 +268,11 @@ int ldp_load_pgen_records(ldp_engine* e, uint32_t first_variant, uint32_t n, con
  * the engine's founder_ct is the haplotype count, 2 x raw_sample_ct, and every sample of the file is used (no sample map).  Every
  * heterozygous call must be phased, as the reference demands of its founders (plink2_ld.cc:2045-2049): otherwise nothing of the
  * offending launch is loaded, the call returns LDP_ERR_UNPHASED and *unphased_variant (optional) receives the lowest variant of the
- * call with such a het call (UINT32_MAX when there is none).  Records with more than one ALT allele are refused
- * (LDP_ERR_UNSUPPORTED: their phase refers to allele pairs, Get1MP pgenlib_read.cc:6962 -- build those rows on the host). */
+ * call with such a het call (UINT32_MAX when there is none).  Records with more than one ALT allele (allele_ct > 2) are collapsed on their
+ * major allele as in ldp_load_pgen_records(), and the phase of a het of the collapsed row comes from the file's bit of that call the way
+ * PgrGetInv1P -> Get1MP hands it on (pgenlib_read.cc:7016, :6962: the track counts every het call of the file, ALTx/ALTy ones included; its
+ * phaseinfo is passed through as "the counted allele is on the first haplotype", which for a major allele other than REF is the complement of
+ * what the file says -- the reference prunes with that reading, and so does this). */
 int ldp_load_pgen_records_phased(ldp_engine* e, uint32_t first_variant, uint32_t n, const void* bytes, uint64_t n_bytes, int location, const ldp_pgen_rec* recs,
                                  const ldp_pgen_rec* ld_base, uint32_t raw_sample_ct, uint32_t* unphased_variant);
 /* Give the engine's device memory back (image, records, predicate rows, staging) while keeping its plan: for a caller that works

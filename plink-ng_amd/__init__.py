@@ -702,13 +702,14 @@ class LdPruneEngine:
                                                base_rec if base_rec is not None else None, pgen.sample_ct, _ptr(maj, ctypes.c_uint32)))
         return maj[:n]
 
-    def load_pgen_records_phased(self, first_variant, pgen, raw_first=None, n=None, location=LDP_MEM_HOST, device_bytes=None):
+    def load_pgen_records_phased(self, first_variant, pgen, raw_first=None, n=None, location=LDP_MEM_HOST, device_bytes=None, allele_cts=None):
         """ldp_load_pgen_records_phased (--indep-pairphase): main + hardcall-phase tracks of records [raw_first, +n) decoded on the device
         into the engine's haplotype rows (founder_ct = 2 x the file's samples).  Raises LdpError(LDP_ERR_UNPHASED) with `.variant` = the
-        lowest variant that has a het call without phase."""
+        lowest variant that has a het call without phase.  allele_cts (optional, per record; the .pvar's ALT count + 1): records with more
+        than two alleles are collapsed on their major allele, their phase bits following the collapse."""
         raw_first = first_variant if raw_first is None else raw_first
         n = pgen.variant_ct - raw_first if n is None else n
-        recs, base = pgen.record_index(raw_first, n, None)
+        recs, base = pgen.record_index(raw_first, n, allele_cts)
         base_rec = pgen.record_index(base, 1)[0] if base is not None else None
         ptr, nbytes = pgen.file_bytes()
         if location == LDP_MEM_DEVICE:

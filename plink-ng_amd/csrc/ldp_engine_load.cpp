@@ -430,9 +430,6 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
     const uint32_t type = recs[q].vrtype & 7u;
     any_ld = any_ld || (type == 2) || (type == 3);
   }
-  if (any_multi && phased) {
-    return fail(e, LDP_ERR_UNSUPPORTED, "phased records with more than one ALT allele: their phase refers to allele pairs (Get1MP, pgenlib_read.cc:6962): build those rows on the host");
-  }
   if (any_multi && mapped && !e->map_is_subset) {
     return fail(e, LDP_ERR_UNSUPPORTED, "variants with more than one ALT allele are collapsed over the file's samples or a plain subset of them: not with a sample map that repeats samples or turns het calls missing (collapse them on the host, LDP_GENO_INVERSE)");
   }
@@ -642,7 +639,9 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
       return hipfail(e, krc, "pgen_main_kernel launch");
     }
     if (phased) {
-      krc = launch_pgen_phase(DA, cnt, e->stream);  // (not the caller's ld_base row behind them: only its codes are a base)
+      // (not the caller's ld_base row behind them: only its codes are a base; records with several ALT alleles get their phase bits from
+      // pgen_aux1_kernel below, which knows their het calls)
+      krc = launch_pgen_phase(DA, cnt, e->stream);
       if (krc != hipSuccess) {
         return hipfail(e, krc, "pgen_phase_kernel launch");
       }

@@ -481,6 +481,38 @@ __device__ __forceinline__ uint32_t cat_mask(uint32_t w, uint32_t cat) {
   return (cat == 1) ? (lo & ~hi) : (hi & ~lo);
 }
 
+// bit `idx` of a track that ends at `end` (*bad: the record is too short for it)
+__device__ __forceinline__ uint32_t track_bit(const uint8_t* p, const uint8_t* end, uint64_t idx, bool* bad) {
+  const uint8_t* q = p + (idx >> 3);
+  if (q >= end) {
+    *bad = true;
+    return 0;
+  }
+  return (static_cast<uint32_t>(*q) >> (idx & 7)) & 1u;
+}
+// number of set bits among bits [b0, b0 + n) of the track
+__device__ __forceinline__ uint32_t track_popcount(const uint8_t* p, const uint8_t* end, uint64_t b0, uint32_t n, bool* bad) {
+  uint32_t ct = 0;
+  uint64_t b = b0;
+  const uint64_t b1 = b0 + n;
+  while ((b < b1) && (b & 7)) {
+    ct += track_bit(p, end, b++, bad);
+  }
+  while (b + 8 <= b1) {
+    const uint8_t* q = p + (b >> 3);
+    if (q >= end) {
+      *bad = true;
+      return ct;
+    }
+    ct += __builtin_popcount(static_cast<uint32_t>(*q));
+    b += 8;
+  }
+  while (b < b1) {
+    ct += track_bit(p, end, b++, bad);
+  }
+  return ct;
+}
+
 template <bool LDS>
 __global__ __launch_bounds__(kAuxThreads) void pgen_aux1_kernel(PgenDecodeArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t main_lds[];  // LDS: the main track, read five times below, staged once
@@ -569,6 +601,7 @@ __global__ __launch_bounds__(kAuxThreads) void pgen_aux1_kernel(PgenDecodeArgs A
   S[0].fmt = S[1].fmt = 15;
   S[0].patched = S[1].patched = 0;
   const uint8_t* rec_end = A.bytes + R.off + R.len;
+  const uint8_t* aux2 = A.bytes + A.main_end[v];  // where the track behind this one begins (the hardcall-phase track of --indep-pairphase records)
   if ((R.vrtype & 8u) && !bad) {
     ByteCursor c{A.bytes + A.main_end[v], rec_end, true};
     const uint32_t fmt = c.u8();
@@ -652,6 +685,7 @@ __global__ __launch_bounds__(kAuxThreads) void pgen_aux1_kernel(PgenDecodeArgs A
         bad = true;
       }
     }
+    aux2 = c.p;
   }
   if (bad) {
     s_bad = 1;
@@ -848,13 +882,56 @@ __global__ __launch_bounds__(kAuxThreads) void pgen_aux1_kernel(PgenDecodeArgs A
   }
   __syncthreads();
   const uint32_t maj = s_maj;
-  if (maj == 0) {
+  const bool phased = A.phase_off != 0;
+  if ((maj == 0) && !phased) {
     return;  // REF is the major allele: the main track already counts the copies of the others
+  }
+  // ---- --indep-pairphase (PgrGetInv1P -> Get1MP, pgenlib_read.cc:7016, :6962): the hardcall-phase track behind this one holds one
+  // phasepresent / phaseinfo bit per heterozygous call OF THE FILE, in sample order -- the main track's code-1 calls (REF/ALTx) and the
+  // category-2 patches with two different alleles (ALTx/ALTy; ReadGenovecHphaseSubsetUnsafe: all_hets |= aux1b hets, :5497-5510) --, while
+  // the collapsed row has a het where exactly one allele of the call is the major one.  Step 1, while the main track is still what the file
+  // holds: the file's het calls as a bitmap in the row's phase area (16 bits per code dword: each thread its own dwords; the list-form
+  // patches land where they fall, hence the atomics).
+  uint16_t* phase16 = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(row) + A.phase_off);
+  if (phased) {
+    for (uint32_t d = d0; d < d1; ++d) {
+      phase16[d] = 0;
+    }
+    __syncthreads();
+    uint32_t* het_words = reinterpret_cast<uint32_t*>(phase16);
+    auto mark_het = [&](uint32_t sample, uint32_t cat, Alleles a) {
+      if ((cat == 2) && (a.lo != a.hi)) {
+        atomicOr(het_words + (sample >> 5), 1u << (sample & 31));
+      }
+    };
+    {
+      uint32_t k[2] = {S[0].k_first, S[1].k_first}, rank[2] = {S[0].rank_first, S[1].rank_first};
+      for (uint32_t d = d0; d < d1; d += kChunk) {
+        uint32_t w[kChunk];
+        const uint32_t cnt = (d1 - d < kChunk) ? (d1 - d) : kChunk;
+#pragma unroll
+        for (uint32_t i = 0; i < kChunk; ++i) {
+          w[i] = (i < cnt) ? mtrack[d + i] : 0u;
+        }
+        walk_chunk(d, w, cnt, k, rank, [&](uint32_t /*i*/, uint32_t sample, uint32_t cat, Alleles a) { mark_het(sample, cat, a); });
+      }
+      (void)for_each_patch(true, mark_het);
+    }
+    __syncthreads();
+    for (uint32_t d = d0; d < d1; ++d) {
+      uint32_t c1 = cat_mask(mtrack[d], 1);  // bit 2 s -> bit s
+      c1 = (c1 | (c1 >> 1)) & 0x33333333u;
+      c1 = (c1 | (c1 >> 2)) & 0x0f0f0f0fu;
+      c1 = (c1 | (c1 >> 4)) & 0x00ff00ffu;
+      c1 = (c1 | (c1 >> 8)) & 0x0000ffffu;
+      phase16[d] = static_cast<uint16_t>(phase16[d] | c1);
+    }
+    __syncthreads();  // (in the form without the LDS copy the collapse below rewrites the main track other threads have just read)
   }
   // ---- pass 2: the row as copies of non-major alleles.  Main-track codes first (major = ALT1: 2 - code; a later ALT: every
   // call is two non-major copies), then the patched samples.
   auto code_of = [&](Alleles a) -> uint32_t { return 2u - ((a.lo == maj) ? 1u : 0u) - ((a.hi == maj) ? 1u : 0u); };
-  {
+  if (maj != 0) {
     uint32_t k[2] = {S[0].k_first, S[1].k_first}, rank[2] = {S[0].rank_first, S[1].rank_first};
     for (uint32_t d = d0; d < d1; d += kChunk) {
       uint32_t w[kChunk], t[kChunk];
@@ -886,8 +963,80 @@ __global__ __launch_bounds__(kAuxThreads) void pgen_aux1_kernel(PgenDecodeArgs A
       }
     }
   }
-  __syncthreads();
-  (void)for_each_patch(true, [&](uint32_t id, uint32_t /*cat*/, Alleles a) { set_field(row, id, code_of(a)); });
+  if (maj != 0) {
+    __syncthreads();
+    (void)for_each_patch(true, [&](uint32_t id, uint32_t /*cat*/, Alleles a) { set_field(row, id, code_of(a)); });
+  }
+  if (!phased) {
+    return;
+  }
+  // ---- step 2: the phase bits of the collapsed row.  A het call of the file consumes its phasepresent bit (and, when that is set, its
+  // phaseinfo bit) whether or not it is still a het after the collapse; a het of the collapsed row takes "the counted (non-major) allele is
+  // on the first haplotype" from it.  Get1MP hands the file's phaseinfo through unchanged -- "the HIGHER allele of the call is on the first
+  // haplotype" -- and HapsplitMustPhased reads it as "the counted allele is": right when the major allele is REF (the counted one is then
+  // the higher), and for a later major allele the reference's reading, which plink2-hip reproduces (p2h_tables.cpp,
+  // multiallelic_inverse_row; tests/test_pairphase.py), comes to the complement: bit ^ (major != REF).  A het of the collapsed row
+  // without phase reports the record (the reference's "not fully phased", plink2_ld.cc:2045-2049).
+  __syncthreads();  // (the list-form patches above wrote other threads' dwords)
+  uint32_t hets = 0;
+  for (uint32_t d = d0; d < d1; ++d) {
+    hets += __popc(static_cast<uint32_t>(phase16[d]));
+  }
+  uint32_t het_ct = 0;
+  const uint32_t het_before = block_exclusive<kAuxThreads>(hets, s_tmp, tid, &het_ct);
+  const bool has_track = (R.vrtype & 0x10u) != 0;
+  bool pbad = false, unphased = false, explicit_present = false;
+  const uint8_t* info = aux2;
+  uint64_t info_bit = 1;
+  uint32_t present_before = het_before;
+  if (has_track && het_ct) {
+    if ((aux2 < A.bytes + R.off) || (aux2 >= rec_end)) {
+      pbad = true;
+    } else {
+      explicit_present = (aux2[0] & 1u) != 0;
+    }
+    if (explicit_present) {
+      const uint32_t mine = track_popcount(aux2, rec_end, 1ull + het_before, hets, &pbad);
+      uint32_t present_ct = 0;
+      present_before = block_exclusive<kAuxThreads>(mine, s_tmp, tid, &present_ct);
+      info = aux2 + 1 + het_ct / 8;
+      info_bit = 0;
+      if ((!present_ct) || (info + (present_ct + 7) / 8 > rec_end)) {
+        pbad = true;
+      }
+    } else if (aux2 + 1 + het_ct / 8 > rec_end) {
+      pbad = true;
+    }
+  }
+  const uint32_t flip = (maj != 0) ? 1u : 0u;
+  uint32_t k = het_before, r = present_before;
+  for (uint32_t d = d0; d < d1; ++d) {
+    uint32_t fh = phase16[d];
+    const uint32_t w = row[d];
+    uint32_t bits16 = 0;
+    while (fh && !pbad) {
+      const uint32_t pos = static_cast<uint32_t>(__builtin_ctz(fh));
+      fh &= fh - 1;
+      const bool het_now = ((w >> (2 * pos)) & 3u) == 1u;
+      const bool present = has_track && (explicit_present ? (track_bit(aux2, rec_end, 1ull + k, &pbad) != 0) : true);
+      ++k;
+      if (present) {
+        const uint32_t b = track_bit(info, rec_end, info_bit + r, &pbad);
+        ++r;
+        if (het_now) {
+          bits16 |= (b ^ flip) << pos;
+        }
+      } else if (het_now) {
+        unphased = true;
+      }
+    }
+    phase16[d] = static_cast<uint16_t>(bits16);
+  }
+  if (pbad) {
+    atomicCAS(A.error, 0, static_cast<int>(v) + 1);
+  } else if (unphased && A.unphased) {
+    atomicMin(A.unphased, v);
+  }
 }
 
 // ---- auxiliary track 2: phased heterozygous hard-calls (--indep-pairphase) ------------------------------------------------
@@ -900,42 +1049,14 @@ __global__ __launch_bounds__(kAuxThreads) void pgen_aux1_kernel(PgenDecodeArgs A
 // among them likewise, then every thread sets the phase bits of its own samples: the row's second part (LDP_GENO_PHASED layout,
 // ldprune_hip.h: phase bit of sample s = bit s % 8 of byte phase_off + s / 8), all of it written (zero where there is no het).
 // A het call without phase -- no track at all, or a clear phasepresent bit -- reports its record: A.unphased <- the lowest index.
-__device__ __forceinline__ uint32_t track_bit(const uint8_t* p, const uint8_t* end, uint64_t idx, bool* bad) {
-  const uint8_t* q = p + (idx >> 3);
-  if (q >= end) {
-    *bad = true;
-    return 0;
-  }
-  return (static_cast<uint32_t>(*q) >> (idx & 7)) & 1u;
-}
-// number of set bits among bits [b0, b0 + n) of the track
-__device__ __forceinline__ uint32_t track_popcount(const uint8_t* p, const uint8_t* end, uint64_t b0, uint32_t n, bool* bad) {
-  uint32_t ct = 0;
-  uint64_t b = b0;
-  const uint64_t b1 = b0 + n;
-  while ((b < b1) && (b & 7)) {
-    ct += track_bit(p, end, b++, bad);
-  }
-  while (b + 8 <= b1) {
-    const uint8_t* q = p + (b >> 3);
-    if (q >= end) {
-      *bad = true;
-      return ct;
-    }
-    ct += __builtin_popcount(static_cast<uint32_t>(*q));
-    b += 8;
-  }
-  while (b < b1) {
-    ct += track_bit(p, end, b++, bad);
-  }
-  return ct;
-}
-
 __global__ __launch_bounds__(kThreads) void pgen_phase_kernel(PgenDecodeArgs A) {
   __shared__ uint32_t s_tmp[kThreads];
   const uint32_t v = blockIdx.x;
   const uint32_t tid = threadIdx.x;
   const PgenRecDesc R = A.recs[v];
+  if (R.allele_ct > 2) {
+    return;  // several ALT alleles: the phase bits of the collapsed row are pgen_aux1_kernel's (its het calls are not the main track's)
+  }
   const uint32_t n = A.sample_ct;
   uint8_t* rowb = A.rows + static_cast<uint64_t>(v) * A.stride;
   const uint32_t* row = reinterpret_cast<const uint32_t*>(rowb);

@@ -328,14 +328,13 @@ struct PruneJob {
     // Variable-width records are decoded ON THE DEVICE from the file's own bytes (ldp_load_pgen_records: main track of every
     // record type, LD-compressed chains, and -- when the engine's samples are the file's -- the collapse of variants with more
     // than one ALT allele); --indep-pairphase rows (phase track) and --debug-host-decode take the host decoder below.
-    // --indep-pairphase: main AND phase track on the device (ldp_load_pgen_records_phased) when every sample is a founder and no
-    // variant has more than one ALT allele (whose phase refers to allele pairs: host rows, below); otherwise the host decoder.
-    const bool device_phase = A.pairphase && all_founders && (!has_multiallelic) && (storage_mode != 0x01) && (storage_mode != 0x02) &&
-                              (!g_dbg.host_decode);
+    // --indep-pairphase: main AND phase track on the device (ldp_load_pgen_records_phased) when every sample is a founder -- variants with
+    // more than one ALT allele included since round 5 (collapse and phase bits in one kernel); otherwise the host decoder.
+    const bool device_phase = A.pairphase && all_founders && (storage_mode != 0x01) && (storage_mode != 0x02) && (!g_dbg.host_decode);
     const bool device_decode = (!direct) && ((!A.pairphase) || device_phase) && (storage_mode != 0x01) && (storage_mode != 0x02) && (!g_dbg.host_decode);
     // (records with several ALT alleles are collapsed on the device as well: over the file's samples, or over the founders when the
     // engines pick those through a subset sample map)
-    device_multi = device_decode && (all_founders || device_subset) && !A.pairphase;
+    device_multi = device_decode && (all_founders || device_subset);
     uint64_t file_size = 0;
     const void* file_bytes = device_decode ? ldp_pgen_file_bytes(pg, &file_size) : nullptr;
     std::vector<ldp_pgen_rec> rec_index;

@@ -2,6 +2,8 @@
 the hardcall-phase reader against reference-written .pgen files, and (GPU) the HIP path against the oracle.
 Golden files: tests/golden/make_golden_pairphase.py."""
 import ctypes
+import filecmp
+import re
 import os
 import subprocess
 
@@ -486,6 +488,35 @@ def test_cli_pairphase_multiallelic_matches_reference(tmp_path, wargs, r2, order
     gotu = _run(cli, ["--pfile", "u", "--indep-pairphase", "50", "5", "0.5", "--out", "hipu"], tmp)
     assert refu.returncode == gotu.returncode, (refu.stdout[-300:], gotu.stdout[-300:])
     assert [ln for ln in refu.stdout.splitlines() if ln.startswith("Error")] == [ln for ln in gotu.stdout.splitlines() if ln.startswith("Error")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wargs,r2,order", [(["20kb"], "0.4", 2), (["80", "9"], "0.15", 1)])
+def test_cli_pairphase_multiallelic_on_the_device_matches_reference(tmp_path, wargs, r2, order):
+    """... and with every sample a founder no row is built on the host any more (round 5): main track, multiallelic collapse and phase bits all come
+    from ldp_load_pgen_records_phased -- the front-end says so under --timing --, and --debug-host-decode gives the same lists the old way."""
+    assert T.have_ref()
+    pkg = ge.load_package()
+    cli = _cli(pkg)
+    tmp = str(tmp_path)
+    m, n = 900, 157
+    first, second, alt_ct = T.synth_multiallelic_haps(m, n, seed=60 + order, max_alt=6, multi_rate=0.4)
+    chroms = ["1"] * 500 + ["3"] * 400
+    bps = np.concatenate([1000 + 97 * np.arange(500), 1000 + 97 * np.arange(400)])
+    T.write_vcf_haps(os.path.join(tmp, "p.vcf"), first, second, alt_ct, chroms, bps)
+    T.ref_import_vcf(os.path.join(tmp, "p.vcf"), os.path.join(tmp, "p"))
+    common = ["--pfile", "p", "--indep-pairphase"] + wargs + [r2] + (["--indep-order", "1"] if order == 1 else [])
+    ref = T.run_ref(common + ["--threads", "3", "--out", "ref"], tmp)
+    assert ref.returncode == 0, ref.stdout
+    got = _run(cli, common + ["--timing", "--out", "hip"], tmp)
+    assert got.returncode == 0, got.stdout
+    line = re.search(r"host-built rows: (\d+) multiallelic \((\d+) more have REF as the major allele: main track as loaded; (\d+) collapsed on the device\)", got.stdout)
+    assert line and int(line.group(1)) == 0 and int(line.group(3)) == int((alt_ct > 1).sum()), got.stdout[-600:]
+    old = _run(cli, common + ["--debug-host-decode", "--timing", "--out", "old"], tmp)
+    assert old.returncode == 0 and re.search(r"host-built rows: (\d+) multiallelic", old.stdout).group(1) == str(int((alt_ct > 1).sum()))
+    for ext in (".prune.in", ".prune.out"):
+        assert filecmp.cmp(os.path.join(tmp, "ref" + ext), os.path.join(tmp, "hip" + ext), shallow=False), ext
+        assert filecmp.cmp(os.path.join(tmp, "ref" + ext), os.path.join(tmp, "old" + ext), shallow=False), ext
 
 
 @pytest.mark.gpu

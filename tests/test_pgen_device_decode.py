@@ -455,3 +455,103 @@ def test_phase_tracks_of_reference_imported_vcfs(gpu_pkg, tmp_path, m, n, seed, 
     host.close()
     dev.close()
     f.close()
+
+
+@pytest.mark.skipif(not T.have_ref(), reason="reference binary not built")
+@pytest.mark.parametrize("m,n,seed,max_alt,decode_rows,no_lds", [(260, 50, 1, 3, 0, 0), (400, 333, 2, 6, 7, 0), (150, 1100, 3, 9, 0, 1), (90, 70001, 4, 4, 0, 0)])
+def test_phased_multiallelic_records_on_the_device(gpu_pkg, tmp_path, m, n, seed, max_alt, decode_rows, no_lds):
+    """--indep-pairphase records with several ALT alleles (PgrGetInv1P -> Get1MP, pgenlib_read.cc:7016, :6962): the collapse on the major allele
+    AND the phase bits of the collapsed row in pgen_aux1_kernel -- the phase track counts every het call of the file (ALTx/ALTy ones too), a het
+    of the collapsed row takes its bit in the reference's reading (ldtools.pairphase_hap_rows_multiallelic, pinned to the reference's prune lists
+    in test_pairphase.py).  Against the rows plink2-hip used to build on the host; some ALTx/ALTy hets between two non-major alleles are left
+    unphased in the VCF (explicit phasepresent bits; they collapse to homozygous calls, so the variant still counts as fully phased)."""
+    pkg = gpu_pkg
+    first, second, alt_ct = T.synth_multiallelic_haps(m, n, seed, max_alt=max_alt, multi_rate=0.5, missing_rate=0.02 if n < 5000 else 0.001, ld_copy_prob=0.6, redraw=0.1)
+    rng = np.random.default_rng(seed + 100)
+    unph = np.zeros((m, n), dtype=bool)
+    for v in range(m):
+        k = int(alt_ct[v]) + 1
+        nm = first[v] >= 0
+        cnt = [int((first[v][nm] == a).sum() + (second[v][nm] == a).sum()) for a in range(k)]
+        maj, _ = T.major_allele_multi(cnt)
+        unph[v] = nm & (first[v] != second[v]) & (first[v] != maj) & (second[v] != maj) & (rng.random(n) < 0.5)
+    T.write_vcf_haps(str(tmp_path / "p.vcf"), first, second, alt_ct, ["1"] * m, np.arange(m) + 1, unphased=unph)
+    cp = T.run_ref(["--vcf", "p.vcf", "--make-pgen", "--out", "p"], str(tmp_path))
+    assert cp.returncode == 0, cp.stdout
+    f = pkg.PgenFile(str(tmp_path / "p.pgen"))
+    assert (f.variant_ct, f.sample_ct) == (m, n) and f.has_multiallelic
+    host = phased_engine(pkg, n, m)
+    host.load_genotypes_host(0, f.read_phased(threads=4), pkg.LDP_GENO_REF | pkg.LDP_GENO_PHASED)
+    multi = [v for v in range(m) if alt_ct[v] > 1]
+    assert unph[multi].any() and len(multi) > m // 4
+    for v in multi:
+        lo, hi, pp, pi = f.read_alleles_phased(v, int(alt_ct[v]))
+        nm = lo != 255
+        cnt = [int((lo[nm] == a).sum() + (hi[nm] == a).sum()) for a in range(int(alt_ct[v]) + 1)]
+        maj, mf = T.major_allele_multi(cnt)
+        a, b, sw = lo.astype(int), hi.astype(int), pi.astype(bool)
+        fst, snd = np.where(sw, b, a), np.where(sw, a, b)
+        if maj >= 1:
+            flip = (a == maj) & (b != maj)
+            fst, snd = np.where(flip, snd, fst), np.where(flip, fst, snd)
+        assert not (nm & ((a == maj) != (b == maj)) & ~pp.astype(bool)).any()
+        hap = np.full(2 * n, 3, dtype=np.uint8)
+        hap[1::2] = np.where(nm, np.where(fst != maj, 2, 0), 3)
+        hap[0::2] = np.where(nm, np.where(snd != maj, 2, 0), 3)
+        row = np.ascontiguousarray(T.pack_2bit(hap[None, :]).view(np.uint8).reshape(1, -1)[:, :(2 * n + 3) // 4])
+        host.load_genotypes_host(v, row, pkg.LDP_GENO_INVERSE)
+        host.set_maj_freqs(v, [mf])
+    dev = phased_engine(pkg, n, m)
+    if decode_rows:
+        dev.set_option("decode_rows", decode_rows)
+    if no_lds:
+        dev.set_option("decode_no_lds", 1)
+    dev.load_pgen_records_phased(0, f, allele_cts=alt_ct + 1)
+    ra, rb = host.variant_recs(), dev.variant_recs()
+    for name in ("nm_ct", "sum", "ssq", "flags"):
+        assert np.array_equal(ra[name], rb[name]), name
+    for v in (multi if n < 5000 else multi[:12]):
+        assert all(np.array_equal(x, y) for x, y in zip(host.planes(v), dev.planes(v))), (v, int(alt_ct[v]))
+    assert np.array_equal(host.maj_freqs(), dev.maj_freqs())
+    assert np.array_equal(host.run(), dev.run())
+    host.close()
+    dev.close()
+    f.close()
+
+
+@pytest.mark.skipif(not T.have_ref(), reason="reference binary not built")
+def test_phased_multiallelic_record_with_an_unphased_het_is_reported(gpu_pkg, tmp_path):
+    """... and a het of the COLLAPSED row without phase is the reference's "variant #k is not fully phased" (plink2_ld.cc:2045-2049): the lowest such
+    variant comes back, whether its record has one ALT allele (pgen_phase_kernel) or several (pgen_aux1_kernel)."""
+    pkg = gpu_pkg
+    m, n = 120, 64
+    first, second, alt_ct = T.synth_multiallelic_haps(m, n, 9, max_alt=4, multi_rate=0.5, missing_rate=0.0, ld_copy_prob=0.5, redraw=0.2)
+    unph = np.zeros((m, n), dtype=bool)
+    picked = []
+    for want_multi in (True, False):
+        for v in range(40 if want_multi else 70, m):
+            if (alt_ct[v] > 1) != want_multi:
+                continue
+            k = int(alt_ct[v]) + 1
+            cnt = [int((first[v] == a).sum() + (second[v] == a).sum()) for a in range(k)]
+            maj, _ = T.major_allele_multi(cnt)
+            hets = np.flatnonzero((first[v] != second[v]) & ((first[v] == maj) != (second[v] == maj)))
+            if len(hets):
+                unph[v, hets[0]] = True
+                picked.append(v)
+                break
+    assert len(picked) == 2 and picked[0] < picked[1]
+    T.write_vcf_haps(str(tmp_path / "p.vcf"), first, second, alt_ct, ["1"] * m, np.arange(m) + 1, unphased=unph)
+    cp = T.run_ref(["--vcf", "p.vcf", "--make-pgen", "--out", "p"], str(tmp_path))
+    assert cp.returncode == 0, cp.stdout
+    f = pkg.PgenFile(str(tmp_path / "p.pgen"))
+    dev = phased_engine(pkg, n, m)
+    with pytest.raises(pkg.LdpError) as ei:
+        dev.load_pgen_records_phased(0, f, allele_cts=alt_ct + 1)
+    assert ei.value.code == pkg.LDP_ERR_UNPHASED and ei.value.variant == picked[0]
+    with pytest.raises(pkg.LdpError) as ei:
+        dev.load_pgen_records_phased(picked[0] + 1, f, picked[0] + 1, m - picked[0] - 1, allele_cts=(alt_ct + 1)[picked[0] + 1:])
+    assert ei.value.code == pkg.LDP_ERR_UNPHASED and ei.value.variant == picked[1]
+    dev.load_pgen_records_phased(0, f, 0, picked[0], allele_cts=(alt_ct + 1)[:picked[0]])   # the head is fine
+    dev.close()
+    f.close()

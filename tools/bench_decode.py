@@ -97,9 +97,10 @@ def measure(pkg, torch, path, allele_cts, label, extra):
     return res
 
 
-def measure_phased(pkg, torch, path, label, extra):
+def measure_phased(pkg, torch, path, label, extra, allele_cts=None):
     """--indep-pairphase's load: main + hardcall-phase tracks -> haplotype rows (ldp_load_pgen_records_phased) against the host reader
-    (ldp_pgen_read_phased) followed by the same engine's load of its rows."""
+    (ldp_pgen_read_phased) followed by the same engine's load of its rows.  allele_cts: records with several ALT alleles (collapse + phase bits in
+    pgen_aux1_kernel); the host side of that comparison is the per-variant reader plink2-hip used until round 5 (ldp_pgen_read_alleles_phased)."""
     f = pkg.PgenFile(path)
     m, n = f.variant_ct, f.sample_ct
     ptr, nbytes = f.file_bytes()
@@ -111,7 +112,7 @@ def measure_phased(pkg, torch, path, label, extra):
     eng.set_variants(chr_idx, bps)
 
     def dev_call():
-        eng.load_pgen_records_phased(0, f, location=pkg.LDP_MEM_DEVICE, device_bytes=dev_bytes.data_ptr())
+        eng.load_pgen_records_phased(0, f, location=pkg.LDP_MEM_DEVICE, device_bytes=dev_bytes.data_ptr(), allele_cts=allele_cts)
         torch.cuda.synchronize()
 
     dev_call()
@@ -119,10 +120,20 @@ def measure_phased(pkg, torch, path, label, extra):
     want = eng.variant_recs().copy()
 
     def host_bytes_call():
-        eng.load_pgen_records_phased(0, f)
+        eng.load_pgen_records_phased(0, f, allele_cts=allele_cts)
         torch.cuda.synchronize()
 
     res["same_call_bytes_in_host_memory_ms"] = 1e3 * best_of(host_bytes_call)
+    if allele_cts is not None:
+        # (what the front-end did per variant before: allele pairs + phase bits on one host thread, then a row built from them)
+        def host_alleles():
+            for v in range(m):
+                f.read_alleles_phased(v, int(allele_cts[v]) - 1)
+        res["host_allele_pair_reader_one_thread_ms"] = 1e3 * best_of(host_alleles, reps=1)
+        res["device_decode_plus_count_rows_GBps"] = res["haplotype_row_bytes"] / res["device_decode_plus_count_ms"] / 1e6
+        eng.close()
+        f.close()
+        return res
     rows_host = f.read_phased(threads=0)
     res["host_decoder_all_threads_ms"] = 1e3 * best_of(lambda: f.read_phased(threads=0), reps=2)
     res["host_decoder_one_thread_ms"] = 1e3 * best_of(lambda: f.read_phased(threads=1), reps=1)
@@ -155,6 +166,23 @@ def write_phased_vcf(path, codes, rng):
             c = codes[v].astype(np.int64)
             c = np.where((c == 1) & (rng.random(n) < 0.5), 4, c)
             fh.write("1\t%d\tp%d\tA\tC\t.\t.\t.\tGT\t%s\n" % (1000 + 2875 * v, v, "\t".join(table[c])))
+
+
+def write_phased_multiallelic_vcf(path, codes, rng, third_rate):
+    """as write_multiallelic_vcf below, every call phased (a|b in either order)"""
+    m, n = codes.shape
+    fwd = np.array(["0|0", "0|1", "1|1", ".|.", "0|2", "1|2", "2|2"])
+    rev = np.array(["0|0", "1|0", "1|1", ".|.", "2|0", "2|1", "2|2"])
+    with open(path, "w") as fh:
+        fh.write("##fileformat=VCFv4.2\n##contig=<ID=1>\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"GT\">\n")
+        fh.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join("s%d" % s for s in range(n)) + "\n")
+        for v in range(m):
+            c = codes[v].astype(np.int64)
+            flip = rng.random(n) < (third_rate if v % 4 else 0.7)
+            c = np.where(flip & (c == 1), 4, c)
+            c = np.where(flip & (c == 2), np.where(rng.random(n) < 0.5, 5, 6), c)
+            gt = np.where(rng.random(n) < 0.5, fwd[c], rev[c])
+            fh.write("1\t%d\tq%d\tA\tC,G\t.\t.\t.\tGT\t%s\n" % (1000 + 2875 * v, v, "\t".join(gt)))
 
 
 def write_multiallelic_vcf(path, codes, rng, third_rate):
@@ -220,6 +248,13 @@ def main():
             assert cp.returncode == 0, cp.stdout[-500:]
             lines.append(measure_phased(pkg, torch, os.path.join(tmp, "pv.pgen"), "reference --vcf import of a fully phased file (hardcall-phase track)",
                                         {"missing_rate": args.missing_rate}))
+            qm = min(pm, args.multi_variants)
+            if qm:
+                write_phased_multiallelic_vcf(os.path.join(tmp, "q.vcf"), codes[:qm], np.random.default_rng(3), 0.1)
+                cp = subprocess.run([ref_bin, "--vcf", "q.vcf", "--make-pgen", "--out", "qv"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                assert cp.returncode == 0, cp.stdout[-500:]
+                lines.append(measure_phased(pkg, torch, os.path.join(tmp, "qv.pgen"), "reference --vcf import of a fully phased file, two ALT alleles per variant (aux track 1 + hardcall-phase track)",
+                                            {"missing_rate": args.missing_rate}, allele_cts=np.full(qm, 3)))
     finally:
         subprocess.call(["rm", "-rf", tmp])
     for r in lines:
