@@ -357,6 +357,88 @@ struct XWeighted {
     }
     return r;
   }
+  // ---- windowed plans (ldp_set_variants_vcor; --clump): the chrX run [band_first, band_first + band_ct) of the caller's rows, loaded a second time into two
+  // ALL-PAIRS engines that hold nothing else (all founders / male founders).  The pairs of a window on chrX then come from the pair kernels and the
+  // device-side weighting (ldp_r2_unphased_block_x*: ComputeXR2 as ClumpHighmemR2 and the windowed table call it, plink2_ld.cc:7122-7190, :7343),
+  // a chunk of rows at a time, instead of a list of pairs with one wave each.  (A windowed engine has no dense-block plan of its own.)
+  ldp_engine* band_all = nullptr;
+  ldp_engine* band_male = nullptr;  // nullptr: no male founders
+  uint32_t band_first = 0, band_ct = 0;
+  std::vector<uint8_t> band_flip_all, band_flip_male;  // per row of the run (empty: none)
+  bool band_ready() const { return band_all != nullptr; }
+  void band_destroy() {
+    if (band_male) {
+      ldp_destroy(band_male);
+    }
+    if (band_all) {
+      ldp_destroy(band_all);
+    }
+    band_all = band_male = nullptr;
+  }
+  // rows [j, j + R) of the run and the columns their windows reach: R about the window's width, so that the rectangle is about twice the band
+  void band_chunk(const uint32_t* lo, uint32_t j, uint32_t j1, uint32_t max_rows, uint32_t* rows, uint32_t* c0) const {
+    *c0 = std::max(lo[j], band_first);
+    const uint32_t width = j - *c0 + 1;
+    *rows = std::min(std::min(j1 - j, max_rows), std::max(512u, std::min(width, 8192u)));
+  }
+  // f(i, j, value) for every pair lo[j] <= i < j of the rows j in [j0, j1) (inside the run); NaN where the reference's value is undefined
+  template <class F>
+  void band_dense(const uint32_t* lo, uint32_t j0, uint32_t j1, F f) const {
+    const std::vector<uint8_t> ones(band_ct, 1);
+    std::vector<double> blk;
+    for (uint32_t j = j0; j < j1;) {
+      uint32_t rows, c0;
+      band_chunk(lo, j, j1, 0xffffffffu, &rows, &c0);
+      const uint32_t cols = j + rows - 1 - c0;
+      if (cols) {
+        blk.assign(static_cast<size_t>(rows) * cols, 0.0);
+        if (ldp_r2_unphased_block_x(band_all, band_male, ones.data(), band_flip_all.empty() ? nullptr : band_flip_all.data(), band_flip_male.empty() ? nullptr : band_flip_male.data(),
+                                    j - band_first, rows, c0 - band_first, cols, 0, unsquared ? 1 : 0, blk.data(), cols)) {
+          die(16, "Error: %s\n", ldp_last_error(band_all));
+        }
+        for (uint32_t q = 0; q < rows; ++q) {
+          for (uint32_t i = std::max(lo[j + q], c0); i < j + q; ++i) {
+            f(i, j + q, blk[static_cast<size_t>(q) * cols + (i - c0)]);
+          }
+        }
+      }
+      j += rows;
+    }
+  }
+  // ... those with |value| >= min_r2 (NaN never passes), in no particular order
+  template <class F>
+  void band_hits(const uint32_t* lo, uint32_t j0, uint32_t j1, double min_r2, std::vector<ldp_r2_hit>* buf, F f) const {
+    const std::vector<uint8_t> ones(band_ct, 1);
+    if (buf->size() < (1u << 20)) {
+      buf->resize(1u << 22);
+    }
+    uint32_t max_rows = 0xffffffffu;
+    for (uint32_t j = j0; j < j1;) {
+      uint32_t rows, c0;
+      band_chunk(lo, j, j1, max_rows, &rows, &c0);
+      const uint32_t cols = j + rows - 1 - c0;
+      uint64_t found = 0;
+      if (cols && ldp_r2_unphased_block_x_hits(band_all, band_male, ones.data(), band_flip_all.empty() ? nullptr : band_flip_all.data(),
+                                               band_flip_male.empty() ? nullptr : band_flip_male.data(), j - band_first, rows, c0 - band_first, cols, unsquared ? 1 : 0, min_r2,
+                                               buf->data(), buf->size(), &found)) {
+        die(16, "Error: %s\n", ldp_last_error(band_all));
+      }
+      if (found > buf->size()) {  // more passing pairs than the buffer holds: fewer rows per call
+        if (rows == 1) {
+          die(2, "Error: one chrX variant has more passing partners than the filter buffer holds.\n");
+        }
+        max_rows = std::max(1u, rows / 2);
+        continue;
+      }
+      for (uint64_t q = 0; q < found; ++q) {
+        const uint32_t i = (*buf)[q].first + band_first, jj = (*buf)[q].second + band_first;
+        if ((i >= lo[jj]) && (i < jj)) {
+          f(i, jj, (*buf)[q].r2);
+        }
+      }
+      j += rows;
+    }
+  }
   // r^2 (or r) of the listed pairs, each with at least one chrX variant; NaN where the reference's is undefined
   void pairs(const std::vector<uint32_t>& first, const std::vector<uint32_t>& second, std::vector<double>* out) const {
     const size_t n = first.size();

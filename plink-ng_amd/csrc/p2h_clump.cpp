@@ -803,32 +803,75 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
     XWeighted xw;
     std::vector<uint32_t> band_lo;
     if (any_x) {
-      ldp_params MP = RP;
-      MP.founder_ct = SX.founder_male_ct;
-      if (ldp_create(&MP, &xw.male) || ldp_set_variants_matrix(xw.male, n_sub)) {
-        die(16, "Error: engine setup failed.\n");
-      }
-      SX.feed_cols(xw.male, s_raw, &SX.male_cols);
-      for (uint32_t q = 0; q < n_sub; ++q) {
-        if (s_aidx[q] >= 0) {
-          SX.allele_row(xw.male, q, s_raw[q], s_aidx[q], false, true);
-        }
-      }
-      xw.all = e;
-      xw.is_x = s_is_x;
-      // one orientation for both tuples of a pair: the main engine's (the male engine chose its major alleles from the male
-      // founders alone).  Which one it is does not matter inside chrX: the weight is dyadic and every sum exact.
-      std::vector<ldp_variant_rec> ra(n_sub), rm(n_sub);
-      if (ldp_get_variant_recs(e, 0, n_sub, ra.data()) || ldp_get_variant_recs(xw.male, 0, n_sub, rm.data())) {
-        die(16, "Error: %s\n", ldp_last_error(e));
-      }
-      xw.flip_male.resize(n_sub);
-      for (uint32_t q = 0; q < n_sub; ++q) {
-        xw.flip_male[q] = static_cast<uint8_t>((ra[q].flags ^ rm[q].flags) & 1u);
-      }
       band_lo.resize(n_sub);
       uint64_t cand_pairs = 0;
       ldp_get_band(e, band_lo.data(), &cand_pairs);
+      // the chrX rows are one run of the engine's rows (a chromosome is): they go into two all-pairs engines of their own -- every founder, the male
+      // founders -- whose dense blocks give the windows' pairs on the pair kernels, weighted on the device (XWeighted::band_hits).  --debug-x-host: the
+      // round-4 path instead, pair lists through ldp_pair_stats and the weighting on the host.
+      uint32_t x0 = 0, x1 = 0;
+      bool one_run = true;
+      for (uint32_t q = 0; q < n_sub; ++q) {
+        if (s_is_x[q]) {
+          if (x1 == 0) {
+            x0 = q;
+          } else if (x1 != q) {
+            one_run = false;
+          }
+          x1 = q + 1;
+        }
+      }
+      const bool on_device = one_run && !g_dbg.x_host;
+      const uint32_t first = on_device ? x0 : 0, cnt = on_device ? (x1 - x0) : n_sub;
+      const std::vector<uint32_t> x_raw(s_raw.begin() + first, s_raw.begin() + first + cnt);
+      ldp_engine* xa = e;
+      ldp_engine* xm = nullptr;
+      ldp_params MP = RP;
+      MP.founder_ct = SX.founder_male_ct;
+      if (ldp_create(&MP, &xm) || ldp_set_variants_matrix(xm, cnt)) {
+        die(16, "Error: engine setup failed.\n");
+      }
+      SX.feed_cols(xm, x_raw, &SX.male_cols);
+      if (on_device) {
+        xa = nullptr;
+        if (ldp_create(&RP, &xa) || ldp_set_variants_matrix(xa, cnt)) {
+          die(16, "Error: engine setup failed.\n");
+        }
+        if (g_dbg.x_rows) {
+          (void)ldp_debug_set_option(xa, "x_rows", static_cast<double>(g_dbg.x_rows));
+        }
+        feed(xa, x_raw);
+      }
+      for (uint32_t q = 0; q < cnt; ++q) {
+        if (s_aidx[first + q] >= 0) {
+          SX.allele_row(xm, q, x_raw[q], s_aidx[first + q], false, true);
+          if (on_device) {
+            SX.allele_row(xa, q, x_raw[q], s_aidx[first + q], false, founder_ct != SX.raw_sample_ct);
+          }
+        }
+      }
+      // one orientation for both tuples of a pair: the all-founders engine's (the male engine chose its major alleles from the male
+      // founders alone).  Which one it is does not matter inside chrX: the weight is dyadic and every sum exact.
+      std::vector<ldp_variant_rec> ra(cnt), rm(cnt);
+      if (ldp_get_variant_recs(xa, 0, cnt, ra.data()) || ldp_get_variant_recs(xm, 0, cnt, rm.data())) {
+        die(16, "Error: %s\n", ldp_last_error(xa));
+      }
+      std::vector<uint8_t> flip(cnt);
+      for (uint32_t q = 0; q < cnt; ++q) {
+        flip[q] = static_cast<uint8_t>((ra[q].flags ^ rm[q].flags) & 1u);
+      }
+      if (on_device) {
+        xw.band_all = xa;
+        xw.band_male = xm;
+        xw.band_first = x0;
+        xw.band_ct = cnt;
+        xw.band_flip_male = flip;
+      } else {
+        xw.all = e;
+        xw.male = xm;
+        xw.is_x = s_is_x;
+        xw.flip_male = flip;
+      }
     }
     t_rows = now_s();
     std::vector<ldp_r2_hit> hits(1u << 24);
@@ -863,7 +906,16 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
         }
         link(h.first, h.second);
       }
-      if (any_x) {
+      if (any_x && xw.band_ready()) {
+        const uint32_t j0 = std::max(r0, xw.band_first), j1 = std::min(r0 + rows, xw.band_first + xw.band_ct);
+        if (j0 < j1) {
+          xw.band_hits(band_lo.data(), j0, j1, min_r2, &hits, [&](uint32_t i, uint32_t j, double v) {
+            if ((v > A.clump_r2) && (is_cand[sub[i]] || is_cand[sub[j]])) {
+              link(i, j);
+            }
+          });
+        }
+      } else if (any_x) {
         std::vector<uint32_t> fi, se;
         std::vector<double> vals;
         for (uint32_t j = r0; j < r0 + rows; ++j) {
@@ -886,6 +938,7 @@ int clump_reports(const Args& A, const Variants& V, const std::vector<uint32_t>&
     if (xw.male) {
       ldp_destroy(xw.male);
     }
+    xw.band_destroy();
     ldp_destroy(e);
     t_pairs = now_s();
   }

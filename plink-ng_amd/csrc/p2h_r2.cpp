@@ -418,6 +418,19 @@ int write_vcor_table(R2Job& J) {
               x_done = true;
             }
           }
+          if (any_x && (!x_done) && (!A.r2_inter) && J.xw.band_ready()) {
+            // windowed plan: the chrX run's own all-pairs engines give the windows' pairs on the pair kernels, weighted and filtered on the device
+            const XWeighted& xw = J.xw;
+            const uint32_t j0 = std::max(r0, xw.band_first), j1 = std::min(r0 + big, xw.band_first + xw.band_ct);
+            if (j0 < j1) {
+              xw.band_hits(lo.data(), j0, j1, thresh, &dev_hits, [&](uint32_t i, uint32_t j, double v) {
+                if ((i >= shard_first) && (i < shard_end)) {
+                  fresh.push_back({i, j, v});
+                }
+              });
+            }
+            x_done = true;
+          }
           if (any_x && !x_done) {  // the chunk's pairs with a chrX variant: values and filter on the host
             std::vector<uint32_t> fi, se;
             std::vector<double> vals;
@@ -580,7 +593,13 @@ int write_vcor_table(R2Job& J) {
     if (off[row_ct] && ldp_r2_unphased_band_rows(e, row_first, row_ct, 0, band.data(), off[row_ct])) {
       die(16, "Error: %s\n", ldp_last_error(e));
     }
-    if (any_x) {  // (a window never leaves its chromosome: the pairs of the chrX rows)
+    if (any_x && J.xw.band_ready()) {  // (a window never leaves its chromosome: the pairs of the chrX rows, from the run's own all-pairs engines)
+      const XWeighted& xw = J.xw;
+      const uint32_t j0 = std::max(row_first, xw.band_first), j1 = std::min(row_first + row_ct, xw.band_first + xw.band_ct);
+      if (j0 < j1) {
+        xw.band_dense(lo.data(), j0, j1, [&](uint32_t i, uint32_t j, double v) { band[off[j - row_first] + (i - lo[j])] = v; });
+      }
+    } else if (any_x) {
       std::vector<uint32_t> fi, se;
       std::vector<double> vals;
       for (uint32_t q = 0; q < row_ct; ++q) {
@@ -1152,6 +1171,55 @@ int run_r2(Session& S) {
       x_flip_male[k] = static_cast<uint8_t>((recs_male[k].flags & 1u) ^ target_alt);
     }
   }
+  // windowed table: the chrX run a second time in two all-pairs engines (XWeighted: band_*), so that its windows' pairs come from the pair kernels too
+  XWeighted band;
+  struct BandGuard {
+    XWeighted* p;
+    ~BandGuard() { p->band_destroy(); }
+  } band_guard{&band};
+  if (any_x && A.r2_table && (!A.r2_inter) && !g_dbg.x_host) {
+    uint32_t x0 = 0, x1 = 0;
+    bool one_run = true;
+    for (uint32_t k = 0; k < variant_ct; ++k) {
+      if (is_x[k]) {
+        if (x1 == 0) {
+          x0 = k;
+        } else if (x1 != k) {
+          one_run = false;
+        }
+        x1 = k + 1;
+      }
+    }
+    if (one_run && (x1 > x0)) {
+      const uint32_t cnt = x1 - x0;
+      const std::vector<uint32_t> x_inc(inc.begin() + x0, inc.begin() + x1);
+      if (ldp_create(&RP, &band.band_all) || ldp_set_variants_matrix(band.band_all, cnt)) {
+        die(16, "Error: engine setup failed.\n");
+      }
+      if (g_dbg.x_rows) {
+        (void)ldp_debug_set_option(band.band_all, "x_rows", static_cast<double>(g_dbg.x_rows));
+      }
+      feed_rows(band.band_all, x_inc);
+      if (e_male) {
+        ldp_params MP = RP;
+        MP.founder_ct = founder_male_ct;
+        if (ldp_create(&MP, &band.band_male) || ldp_set_variants_matrix(band.band_male, cnt)) {
+          die(16, "Error: engine setup failed.\n");
+        }
+        std::vector<uint32_t> male_cols;
+        for (uint32_t sx = 0; sx < raw_sample_ct; ++sx) {
+          if (is_founder[sx] && (sex[sx] == 1)) {
+            male_cols.push_back(sx);
+          }
+        }
+        feed_rows_cols(band.band_male, x_inc, &male_cols);
+      }
+      band.band_first = x0;
+      band.band_ct = cnt;
+      band.band_flip_all.assign(x_flip_all.begin() + x0, x_flip_all.begin() + x1);  // (the same rows as in `e` / `e_male`: the same orientation)
+      band.band_flip_male.assign(x_flip_male.begin() + x0, x_flip_male.begin() + x1);
+    }
+  }
   R2Job J(S);
   J.e = e;
   J.shard_first = shard_first;
@@ -1166,6 +1234,12 @@ int run_r2(Session& S) {
   J.xw.flip_all = x_flip_all;
   J.xw.flip_male = x_flip_male;
   J.xw.unsquared = A.r_unsquared;
+  J.xw.band_all = band.band_all;  // (owned by `band`: destroyed when this function returns)
+  J.xw.band_male = band.band_male;
+  J.xw.band_first = band.band_first;
+  J.xw.band_ct = band.band_ct;
+  J.xw.band_flip_all = band.band_flip_all;
+  J.xw.band_flip_male = band.band_flip_male;
   J.multi_maj = std::move(multi_maj);
   J.x_maj_alt = x_maj_alt;
   J.x_maj_freq = x_maj_freq;

@@ -149,19 +149,25 @@ def clump_multiallelic_case(cli, ref, rng, idx, tmp, execute=True):
     if rng.random() < 0.25:
         args += ["--clump-bins", str(rng.choice(["0.001,0.01", "1e-6,1e-3,0.05,0.5", "0.2"]))]
     rep_seed = int(rng.integers(1, 1 << 30))
+    multi_rate = float(rng.choice([0.1, 0.4, 0.9]))
+    sig_rate = float(rng.choice([0.05, 0.15]))   # (every draw before the early return: --only replays the same stream)
     if not execute:
         return True, "case %d skipped" % idx
     alt_ct, _, _ = TC.multiallelic_clump_fileset(pathlib.Path(d), m, n, seed, chrom_of=lambda v: names[int(np.searchsorted(cuts, v, side="right"))], max_alt=max_alt,
-                                                 multi_rate=float(rng.choice([0.1, 0.4, 0.9])))
+                                                 multi_rate=multi_rate)
     psam = ["#IID\tPAT\tMAT\tSEX"]
     for q in range(n):
         psam.append("s%d\t%s\t%s\t%s" % (q, "s0" if nonfounder[q] else "0", "s1" if nonfounder[q] else "0", "NA" if sexes[q] == 0 else str(sexes[q])))
     open(os.path.join(d, "d.psam"), "w").write("\n".join(psam) + "\n")
-    TC.write_allele_report(os.path.join(d, "a.txt"), alt_ct, rep_seed, False, sig_rate=float(rng.choice([0.05, 0.15])))
+    TC.write_allele_report(os.path.join(d, "a.txt"), alt_ct, rep_seed, False, sig_rate=sig_rate)
     if two:
         TC.write_allele_report(os.path.join(d, "b.txt"), alt_ct, rep_seed + 1, False, sig_rate=0.08)
     r = run([ref] + args + ["--threads", "2", "--out", "ref"], d)
     g = run([cli] + args + ["--out", "hip"], d)
+    if (r.returncode < 0) and ("--clump-force-a1" in args):
+        # the reference died of a signal: under --clump-force-a1 an entry of a multiallelic allele carries the forced-A1 bit of the previous biallelic
+        # line, and its SP2 printer then reads allele_storage[allele + 1] (plink2_ld.cc:9357) -- past the table's end when that allele is the last one
+        return g.returncode == 0, "case %d: the reference crashed (signal %d) on its stale forced-A1 bit, plink2-hip exit %d: %s" % (idx, -r.returncode, g.returncode, " ".join(args))
     if r.returncode != g.returncode:
         return False, "case %d: exit codes differ (ref %d, hip %d): %s\n%s\n%s" % (idx, r.returncode, g.returncode, " ".join(args), r.stdout[-300:], g.stdout[-400:])
     if r.returncode != 0:

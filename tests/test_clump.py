@@ -631,3 +631,21 @@ def test_clump_multiallelic_on_sex_chromosomes_matches_reference(gpu_pkg, cli, t
     body = [l.split("\t") for l in open(str(tmp_path / "hip.clumps")).read().split("\n")[1:-1]]
     for c in ("X", "Y"):
         assert any((f[0] == c) and ("(" in f[-1]) for f in body), "allele-named members on chr" + c
+
+
+@pytest.mark.gpu
+def test_clump_chrx_windows_on_the_pair_kernels_equal_the_pair_lists(gpu_pkg, cli, tmp_path):
+    """The chrX windows of --clump come from two all-pairs engines over the chrX run (ldp_r2_unphased_block_x_hits: pair kernels + the device-side
+    weighting, round 5); --debug-x-host keeps the pair lists and the host arithmetic; --debug-x-rows cuts the device path into many chunks: one file."""
+    from test_cli import sexed_fileset
+    m = 900
+    sexed_fileset(tmp_path, m=m, n=140, seed=12, unknown_sex=True)
+    write_report(str(tmp_path / "assoc.txt"), m, 4, sig_rate=0.12)
+    common = ["--pfile", "sx", "--clump", "assoc.txt", "--clump-unphased", "--clump-r2", "0.1", "--clump-kb", "60", "--clump-p1", "0.01", "--clump-p2", "0.2"]
+    outs = []
+    for tag, hook in (("dev", []), ("chunks", ["--debug-x-rows", "40"]), ("host", ["--debug-x-host"])):
+        got = run_cli(cli, common + hook + ["--out", tag], str(tmp_path))
+        assert got.returncode == 0, got.stdout
+        outs.append(open(str(tmp_path / (tag + ".clumps"))).read())
+    assert outs[0] == outs[2] and outs[1] == outs[2]
+    assert any((l.split("\t")[0] == "X") and (l.split("\t")[-1] != ".") for l in outs[0].split("\n")[1:-1])

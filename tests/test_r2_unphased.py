@@ -463,11 +463,15 @@ def test_chrx_weighted_blocks_on_the_device(gpu_pkg, monkeypatch, unsquared, as_
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mods,extra,ext", [(["inter-chr"], ["--ld-window-r2", "0.02"], ".vcor"), (["square", "bin"], [], ".unphased.vcor2.bin"),
-                                            (["inter-chr", "ref-based"], ["--ld-window-r2", "0"], ".vcor")])
+                                            (["inter-chr", "ref-based"], ["--ld-window-r2", "0"], ".vcor"),
+                                            ([], ["--ld-window-kb", "30", "--ld-window-r2", "0.02"], ".vcor"),       # windowed table, filter on the device
+                                            ([], ["--ld-window-kb", "50", "--ld-window-r2", "0"], ".vcor"),          # windowed table, every pair (dense band)
+                                            (["ref-based"], ["--ld-window", "40", "--ld-window-r2", "0.1"], ".vcor")])
 def test_cli_chrx_device_path_equals_the_pair_lists(gpu_pkg, tmp_path, mods, extra, ext):
-    """plink2-hip's chrX values of dense rows and of the inter-chr table come from ldp_r2_unphased_block_x[_hits]; --debug-x-host
-    takes the same pairs as lists through the one-wave-per-pair kernel and the host arithmetic (what the band writers do, pinned to the
-    reference in test_cli_r2_with_chrx_matches_reference): byte-identical files, also when the device path works in many row chunks."""
+    """plink2-hip's chrX values of dense rows, of the inter-chr table and (round 5) of the windowed table come from ldp_r2_unphased_block_x[_hits] --
+    the windowed table through two all-pairs engines that hold the chrX run alone --; --debug-x-host takes the same pairs as lists through the
+    one-wave-per-pair kernel and the host arithmetic (pinned to the reference in test_cli_r2_with_chrx_matches_reference, which now runs the
+    device path): byte-identical files, also when the device path works in many row chunks."""
     cli = gpu_pkg.build_cli()
     tmp = str(tmp_path)
     _x_fileset(tmp_path, m=900, n=210, seed=13)
