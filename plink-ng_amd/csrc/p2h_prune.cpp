@@ -806,9 +806,26 @@ struct PruneJob {
         std::vector<std::thread> pool;
         for (uint32_t t = 0; t < nthreads; ++t) {
           pool.emplace_back([&, t]() {
-            std::vector<uint8_t> raw_row(in_rec + 8);
+            std::vector<uint8_t> raw_row(in_rec + 8), lo_a, hi_a, ph_a;
             for (uint32_t w = t; w < cnt; w += nthreads) {
               const uint32_t raw_v = inc[ks[w0 + w]];
+              if (x_phased && (V.alt_ct[raw_v] > 1)) {
+                // several ALT alleles: collapsed on the major allele of chrX's allele-frequency rule, the non-males' haplotypes split in Get1MP's reading
+                if (lo_a.empty()) {
+                  lo_a.resize(raw_sample_ct);
+                  hi_a.resize(raw_sample_ct);
+                  ph_a.resize(2 * ((static_cast<size_t>(raw_sample_ct) + 7) / 8));
+                }
+                bool unph = false;
+                multiallelic_sex_row_phased(pg, raw_v, V.alt_ct[raw_v], sp, &lo_a, &hi_a, ph_a.data(), ph_a.size() / 2, rows.data() + static_cast<uint64_t>(w) * s_rec, s_rec,
+                                            &mfs[w], &unph);
+                if (unph) {
+                  uint32_t cur = x_unphased.load();
+                  while ((raw_v < cur) && !x_unphased.compare_exchange_weak(cur, raw_v)) {
+                  }
+                }
+                continue;
+              }
               if (x_phased) {
                 uint32_t at = 0;
                 const int prc = ldp_pgen_read_phased(pg, raw_v, 1, raw_row.data(), in_rec, nonmale_mask.data(), 1, &at);

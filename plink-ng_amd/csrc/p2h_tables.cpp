@@ -646,6 +646,67 @@ void multiallelic_sex_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_ct, c
   }
 }
 
+// ... under --indep-pairphase on chrX with non-male founders (plink2_ld.cc:2060-2097 after PgrGetInv1P on the chromosome's major allele): part 1 -- the males -- one
+// haplotype each as above, part 2 two haplotypes per founder split by the file's phase bits in Get1MP's reading (multiallelic_inverse_row above: the bit is passed
+// through as "the counted allele is on the first haplotype", which for a major allele other than REF is the complement of what the file says); a haplotype h is the code
+// 2h, the first haplotype of the file at the even position (build_sex_row's layout).  *unphased: a het of the collapsed row of a part-2 founder without phase.
+// phase: scratch of 2 * ceil(raw samples / 8) bytes.
+void multiallelic_sex_row_phased(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_ct, const SexPlan& sp, std::vector<uint8_t>* lo, std::vector<uint8_t>* hi, uint8_t* phase,
+                                 uint64_t phase_bytes, uint8_t* out_row, uint64_t out_rec, double* maj_freq, bool* unphased) {
+  if (ldp_pgen_read_alleles_phased(pg, raw_variant, alt_ct, lo->data(), hi->data(), phase, phase + phase_bytes)) {
+    die(6, "\nError: %s\n", ldp_pgen_last_error(pg));
+  }
+  const uint8_t* present = phase;
+  const uint8_t* info = phase + phase_bytes;
+  const uint32_t allele_ct = alt_ct + 1;
+  std::vector<uint64_t> cnt(allele_ct, 0);
+  auto add = [&](uint32_t s, uint64_t w) {
+    if ((*lo)[s] != 255) {
+      if ((*lo)[s] >= allele_ct || (*hi)[s] >= allele_ct) {
+        die(6, "\nError: allele index out of range in multiallelic record.\n");
+      }
+      cnt[(*lo)[s]] += w;
+      cnt[(*hi)[s]] += w;
+    }
+  };
+  for (uint32_t s : sp.part1) {
+    add(s, 1);
+  }
+  for (uint32_t s : sp.part2) {
+    add(s, 2);
+  }
+  const uint32_t maj = pick_major_allele(cnt, maj_freq);
+  memset(out_row, 0, out_rec);
+  uint32_t f = 0;
+  for (uint32_t s : sp.part1) {
+    uint32_t c = ((*lo)[s] == 255) ? 3u : (static_cast<uint32_t>((*lo)[s] != maj) + static_cast<uint32_t>((*hi)[s] != maj));
+    c = (c == 1) ? 3u : c;
+    out_row[f >> 2] |= static_cast<uint8_t>(c << (2 * (f & 3)));
+    ++f;
+  }
+  for (uint32_t s : sp.part2) {
+    uint32_t hap[2] = {3, 3};
+    const uint32_t a = (*lo)[s], b = (*hi)[s];
+    if (a != 255) {
+      const bool swapped = (info[s >> 3] >> (s & 7)) & 1;
+      uint32_t first_allele = swapped ? b : a;
+      uint32_t second_allele = swapped ? a : b;
+      if ((maj >= 1) && (a == maj) && (b != maj)) {
+        std::swap(first_allele, second_allele);
+      }
+      hap[0] = (first_allele != maj) ? 2 : 0;
+      hap[1] = (second_allele != maj) ? 2 : 0;
+      if (((a == maj) != (b == maj)) && !((present[s >> 3] >> (s & 7)) & 1)) {
+        *unphased = true;
+      }
+    }
+    for (int k = 0; k < 2; ++k) {
+      out_row[f >> 2] |= static_cast<uint8_t>(hap[k] << (2 * (f & 3)));
+      ++f;
+    }
+  }
+}
+
 // raw REF-coded row of one variant (decoding / .bed recoding as needed) into `buf`
 void fetch_raw_row(ldp_pgen* pg, int storage_mode, uint32_t raw_variant, uint32_t raw_sample_ct, uint64_t rec_bytes, uint8_t* buf) {
   if (ldp_pgen_read(pg, raw_variant, 1, buf, rec_bytes, 1)) {

@@ -181,6 +181,52 @@ def clump_multiallelic_case(cli, ref, rng, idx, tmp, execute=True):
     return True, "case %d ok: %s (multiallelic --clump on %s)" % (idx, " ".join(args), "/".join(names))
 
 
+def sex_multiallelic_pairphase_case(cli, ref, rng, idx, tmp, execute=True):
+    """--indep-pairphase over phased multiallelic sites on chromosome 1 / X / Y / MT (the fileset of clump_multiallelic_case), random sexes, non-founders"""
+    import test_clump as TC
+    import pathlib
+    n = int(rng.choice([60, 77, 150, 260]))
+    m = int(rng.integers(150, 700))
+    d = os.path.join(tmp, "c%d" % idx)
+    os.makedirs(d)
+    seed = int(rng.integers(1, 1 << 30))
+    max_alt = int(rng.integers(2, 8))
+    names = [str(x) for x in rng.permutation(["1", "X", "Y", "MT"])[:int(rng.integers(1, 5))]]
+    order_of = {"1": 0, "X": 1, "Y": 2, "MT": 3}
+    names.sort(key=lambda c: order_of[c])
+    cuts = np.sort(rng.integers(1, m, size=len(names) - 1))
+    sexes = rng.choice([1, 2, 0], size=n, p=[0.45, 0.4, 0.15])
+    sexes[:4] = [1, 2, 1, 2]
+    nonfounder = rng.random(n) < float(rng.choice([0.0, 0.1]))
+    nonfounder[:4] = False
+    while ("X" in names) and T.ref_pairphase_chrx_is_unreliable(sexes, ~nonfounder):   # (the reference's chrX loader reads a stale word there: ldtools)
+        sexes[np.flatnonzero((~nonfounder) & (sexes != 1))[0]] = 1
+    multi_rate = float(rng.choice([0.1, 0.4, 0.9]))
+    if rng.random() < 0.5:
+        win = ["%gkb" % float(rng.choice([5, 20, 60]))]
+    else:
+        w = int(rng.integers(2, 150))
+        win = [str(w), str(int(rng.integers(1, max(2, w))))]
+    args = ["--pfile", "d", "--indep-pairphase"] + win + [str(rng.choice([0.05, 0.1, 0.3, 0.6])), "--indep-order", str(int(rng.integers(1, 3)))]
+    if not execute:
+        return True, "case %d skipped" % idx
+    TC.multiallelic_clump_fileset(pathlib.Path(d), m, n, seed, chrom_of=lambda v: names[int(np.searchsorted(cuts, v, side="right"))], max_alt=max_alt, multi_rate=multi_rate)
+    psam = ["#IID\tPAT\tMAT\tSEX"]
+    for q in range(n):
+        psam.append("s%d\t%s\t%s\t%s" % (q, "s0" if nonfounder[q] else "0", "s1" if nonfounder[q] else "0", "NA" if sexes[q] == 0 else str(sexes[q])))
+    open(os.path.join(d, "d.psam"), "w").write("\n".join(psam) + "\n")
+    r = run([ref] + args + ["--threads", "2", "--out", "ref"], d)
+    g = run([cli] + args + ["--out", "hip"], d)
+    if r.returncode != g.returncode:
+        return False, "case %d: exit codes differ (ref %d, hip %d): %s\n%s\n%s" % (idx, r.returncode, g.returncode, " ".join(args), r.stdout[-300:], g.stdout[-400:])
+    if r.returncode != 0:
+        return True, "case %d: both refuse (%s)" % (idx, " ".join(args))
+    for e in (".prune.in", ".prune.out"):
+        if not filecmp.cmp(os.path.join(d, "ref" + e), os.path.join(d, "hip" + e), shallow=False):
+            return False, "case %d: %s differs: %s (phased multiallelic on %s, n=%d m=%d seed=%d max_alt=%d)" % (idx, e, " ".join(args), "/".join(names), n, m, seed, max_alt)
+    return True, "case %d ok: %s (phased multiallelic on %s)" % (idx, " ".join(args), "/".join(names))
+
+
 def pairphase_case(cli, ref, rng, idx, tmp, execute=True):
     if rng.random() < 0.25:
         return pairphase_multiallelic_case(cli, ref, rng, idx, tmp, execute)
@@ -398,7 +444,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--mode", default="all", choices=["all", "pairphase", "clump", "sexmulti", "clumpmulti"])
+    ap.add_argument("--mode", default="all", choices=["all", "pairphase", "clump", "sexmulti", "clumpmulti", "sexmultiphase"])
     ap.add_argument("--only", type=int, default=None, help="replay the random stream but execute only this case")
     ap.add_argument("--keep", default=None, help="directory to keep the case files in (default: a temporary directory)")
     args = ap.parse_args()
@@ -415,6 +461,8 @@ def main():
         for k in range(args.cases):
             if args.mode == "sexmulti":
                 ok, desc = sex_multiallelic_case(cli, ref, rng, k, tmp, execute=(args.only is None or k == args.only))
+            elif args.mode == "sexmultiphase":
+                ok, desc = sex_multiallelic_pairphase_case(cli, ref, rng, k, tmp, execute=(args.only is None or k == args.only))
             elif args.mode == "clumpmulti":
                 ok, desc = clump_multiallelic_case(cli, ref, rng, k, tmp, execute=(args.only is None or k == args.only))
             else:

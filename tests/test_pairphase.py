@@ -520,6 +520,44 @@ def test_cli_pairphase_multiallelic_on_the_device_matches_reference(tmp_path, wa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wargs,r2,order,unknown,nonfounders", [(["25kb"], "0.3", 2, True, False), (["70", "11"], "0.15", 1, False, True), (["40kb"], "0.6", 2, False, False)])
+def test_cli_pairphase_multiallelic_on_sex_chromosomes_matches_reference(tmp_path, wargs, r2, order, unknown, nonfounders):
+    """Variants with several ALT alleles on chrX / chrY / MT under --indep-pairphase (refused with exit 63 until round 5): the major allele from the
+    chromosome's own allele-frequency weights, chrX's non-male founders as two haplotypes split in Get1MP's reading, everybody else one haplotype
+    with het calls missing (plink2_ld.cc:2040-2097)."""
+    assert T.have_ref()
+    from test_clump import multiallelic_clump_fileset
+    pkg = ge.load_package()
+    cli = _cli(pkg)
+    tmp = str(tmp_path)
+    m, n = 1000, 143
+    names = ["2", "X", "Y", "MT"]
+    alt_ct, chroms, _ = multiallelic_clump_fileset(tmp_path, m, n, 90 + order, chrom_of=lambda v: names[(4 * v) // m], max_alt=5, multi_rate=0.4)
+    rng = np.random.default_rng(17)
+    lines = ["#IID\tPAT\tMAT\tSEX"]
+    for s in range(n):
+        sx = str(int(rng.integers(1, 3)))
+        if unknown and rng.random() < 0.12:
+            sx = "NA"
+        par = ("s0", "s1") if (nonfounders and s % 9 == 5) else ("0", "0")
+        lines.append("s%d\t%s\t%s\t%s" % (s, par[0], par[1], sx))
+    sexes_chk = np.array([0 if ln.split("\t")[3] == "NA" else int(ln.split("\t")[3]) for ln in lines[1:]])
+    founders_chk = np.array([ln.split("\t")[1] == "0" for ln in lines[1:]])
+    assert not T.ref_pairphase_chrx_is_unreliable(sexes_chk, founders_chk), "a sample layout on which the reference itself is not reproducible (ldtools)"
+    open(os.path.join(tmp, "d.psam"), "w").write("\n".join(lines) + "\n")
+    common = ["--pfile", "d", "--indep-pairphase"] + wargs + [r2] + (["--indep-order", "1"] if order == 1 else [])
+    ref = T.run_ref(common + ["--threads", "3", "--out", "ref"], tmp)
+    assert ref.returncode == 0, ref.stdout
+    got = _run(cli, common + ["--out", "hip"], tmp)
+    assert got.returncode == 0, got.stdout
+    for ext in (".prune.in", ".prune.out"):
+        assert filecmp.cmp(os.path.join(tmp, "ref" + ext), os.path.join(tmp, "hip" + ext), shallow=False), ext
+    ids_out = set(open(os.path.join(tmp, "hip.prune.out")).read().split())
+    multi_ids = {"snp%d" % v for v in range(m) if alt_ct[v] > 1 and chroms[v] != "2"}
+    assert len(ids_out & multi_ids) > 10 and len(multi_ids - ids_out) > 10, "multiallelic variants on the sex chromosomes on both lists"
+
+
+@pytest.mark.gpu
 def test_cli_pairphase_refuses_partially_phased_like_reference(tmp_path):
     assert T.have_ref()
     pkg = ge.load_package()
