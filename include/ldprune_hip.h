@@ -155,6 +155,10 @@ int ldp_device_count(void);
  * ldp_load_genotypes() of an engine on that device does not pay for it (tens to hundreds of milliseconds).  LDP_ERR_GPU without
  * such a device. */
 int ldp_prewarm(int device);
+/* NUMA node of the host the device is attached to (its PCI function's numa_node in sysfs), or -1 when the host does not say.  The
+ * library never moves its caller's threads; a caller on a multi-socket host that loads from host memory gains from running its loading
+ * threads there -- and from first-touching its buffers there -- (30 -> 39 GB/s file -> HBM on the round-5 boxes): plink2-hip does. */
+int ldp_device_numa_node(int device);
 /* Largest founder_ct whose pair statistics run on the matrix pipe (FP4 operands, f32 accumulators that hold the integers
  * exactly); larger jobs run on the popcount kernels.  Same results either way. */
 uint32_t ldp_matrix_pipe_max_founders(void);

@@ -100,13 +100,13 @@ CABI_SYMBOLS = [
     "ldp_pgen_open", "ldp_pgen_info", "ldp_pgen_has_dosage", "ldp_pgen_variant_has_dosage", "ldp_pgen_dosage_sums", "ldp_pgen_direct_rows", "ldp_pgen_direct_fd", "ldp_pgen_read", "ldp_pgen_last_error", "ldp_pgen_close",
     "ldp_pgen_variant_is_multiallelic", "ldp_pgen_provisional_ref", "ldp_pgen_open_indexed", "ldp_set_r_signed", "ldp_set_variants_vcor_cm", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_subset_samples", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
     "ldp_debug_set_option", "ldp_pgen_debug_force_portable", "ldp_matrix_pipe_max_founders", "ldp_map_rows", "ldp_release_device", "ldp_debug_wide_plan",
-    "ldp_allgather_removed", "ldp_comm_init_all", "ldp_comm_destroy", "ldp_shard_segment_words", "ldp_pack_removed_segment", "ldp_stitch_removed_segments", "ldp_load_pgen_records", "ldp_load_pgen_records_phased", "ldp_pgen_file_bytes", "ldp_pgen_record_index",
+    "ldp_allgather_removed", "ldp_comm_init_all", "ldp_comm_destroy", "ldp_shard_segment_words", "ldp_pack_removed_segment", "ldp_stitch_removed_segments", "ldp_load_pgen_records", "ldp_load_pgen_records_phased", "ldp_pgen_file_bytes", "ldp_pgen_record_index", "ldp_device_numa_node",
 ]
 
 
 def _sources():
     return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_codes.hip", "ldp_pair_mfma.hip", "ldp_pair_wide.hip", "ldp_pgen_decode.hip", "ldp_synth.hip", "ldp_engine.cpp", "ldp_engine_run.cpp", "ldp_engine_r2.cpp",
-                                          "ldp_engine_load.cpp", "ldp_engine_shard.cpp", "ldp_pgen.cpp")]
+                                          "ldp_engine_load.cpp", "ldp_engine_shard.cpp", "ldp_pgen.cpp", "ldp_topology.cpp")]
 
 
 def _stale(target, deps):

@@ -697,6 +697,8 @@ bool parse_misc_flags(Args& A, ArgCursor& c, const std::string& f) {
     g_dbg.x_host = true;          // (test hook: chrX pairs as lists through ldp_pair_stats and the host arithmetic)
   } else if (f == "--debug-host-decode") {
     g_dbg.host_decode = true;     // (measurement / test hook: variable-width records decoded by the host reader)
+  } else if (f == "--debug-no-bind") {
+    g_dbg.no_bind = true;         // (measurement: stay on whatever CPUs the scheduler picks instead of the device's NUMA node)
   } else if (f == "--debug-load-map") {
     g_dbg.load_map = true;        // (measurement: fixed-width rows copied out of the mapping instead of pread())
   } else if ((f == "--debug-x-rows") || (f == "--debug-decode-threads")) {

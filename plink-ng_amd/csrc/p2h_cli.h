@@ -234,7 +234,7 @@ enum : uint32_t {
 
 // test / measurement hooks of the front-end (hidden --debug-* flags; the library itself reads no environment, csrc/ldp_env.h)
 struct DebugHooks {
-  bool alias_devices = false, x_host = false, host_decode = false, load_map = false;
+  bool alias_devices = false, x_host = false, host_decode = false, load_map = false, no_bind = false;
   uint32_t x_rows = 0, decode_threads = 0;
 };
 extern DebugHooks g_dbg;
@@ -262,6 +262,9 @@ inline uint32_t allele_ct_for_filter(const Variants& V, size_t v) {
 }
 
 std::string slurp(const std::string& path);
+// This thread (and every thread it starts from here on) onto the CPUs of the NUMA node the device is attached to; a no-op where the host does not say
+// or the node's CPUs are not ours to use.  Returns the node, or -1.
+int bind_near_device(int device);
 void load_variants(const Args& A, Variants* V);
 int chrom_class(const std::string& name_in, bool allow_extra, bool* is_zero);
 void multiallelic_inverse_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_ct, const std::vector<uint32_t>& founder_idx,
@@ -520,10 +523,14 @@ struct Session {
   std::vector<uint32_t> mk, xk, yk, tk;  // indices into inc[]: main engine, chrX, chrY, MT under --indep-pairphase
   uint32_t m_ct = 0;
   std::vector<uint32_t> m_chr, m_bps;
+  // (... and, once the runtime is up, this thread -- the one that creates the engines, their copy threads and their pinned staging -- moves next to the device)
   void join_hip() {
     if (t_hip.joinable()) {
       t_hip.join();
       t_joined = now_s();
+      if ((A.gpus <= 1) && !g_dbg.no_bind) {
+        bind_near_device(0);
+      }
     }
   }
   ~Session() {

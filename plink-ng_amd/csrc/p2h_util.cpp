@@ -1,4 +1,6 @@
 // p2h_util.cpp -- plink2-hip: logging, the reference's number scanner and formatter (one translation unit of the front-end; plink2_hip_cli.cpp has the overview)
+#include <sched.h>
+
 #include "p2h_cli.h"
 
 namespace p2h {
@@ -258,5 +260,52 @@ char* format_g6(double x, char* out) {
 
 
 
+
+// The device's NUMA node (ldp_device_numa_node) -> its CPUs (sysfs cpulist: "0-63,128-191") -> this thread's affinity, intersected with what the process may use.
+// Threads started afterwards inherit it, and memory they touch first lands on that node: the copy pool and the pinned staging ring of a load
+// (ldp_engine_load.cpp) then feed the device's DMA engines without crossing the inter-socket fabric.
+int bind_near_device(int device) {
+  const int node = ldp_device_numa_node(device);
+  if (node < 0) {
+    return -1;
+  }
+  char path[96];
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  FILE* f = fopen(path, "r");
+  if (!f) {
+    return -1;
+  }
+  char buf[4096];
+  const size_t got = fread(buf, 1, sizeof(buf) - 1, f);
+  fclose(f);
+  buf[got] = 0;
+  cpu_set_t want, cur;
+  CPU_ZERO(&want);
+  for (const char* p = buf; *p;) {
+    while (*p && !isdigit(static_cast<unsigned char>(*p))) {
+      ++p;
+    }
+    if (!*p) {
+      break;
+    }
+    char* e = nullptr;
+    long a = strtol(p, &e, 10), b = a;
+    if (*e == '-') {
+      b = strtol(e + 1, &e, 10);
+    }
+    for (long c = a; (c <= b) && (c < CPU_SETSIZE); ++c) {
+      CPU_SET(static_cast<int>(c), &want);
+    }
+    p = e;
+  }
+  if (sched_getaffinity(0, sizeof(cur), &cur)) {
+    return -1;
+  }
+  CPU_AND(&want, &want, &cur);
+  if ((CPU_COUNT(&want) == 0) || sched_setaffinity(0, sizeof(want), &want)) {
+    return -1;
+  }
+  return node;
+}
 
 }  // namespace p2h
