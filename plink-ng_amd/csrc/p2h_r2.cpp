@@ -1033,6 +1033,7 @@ int run_r2(Session& S) {
   }
   // genotype rows -> engine (same feeder as the prune path)
   std::unordered_map<uint32_t, std::pair<uint32_t, double>> multi_maj;  // multiallelic variant -> (major allele, its frequency), for the MAJ / NONMAJ / NONMAJ_FREQ columns
+  std::vector<std::pair<uint32_t, uint32_t>> collapsed_on;  // (row, major allele) of the rows loaded as copies of the non-major alleles
   {
     feed_rows(e, inc);
     const uint64_t out_rec = (static_cast<uint64_t>(founder_ct) + 3) / 4;
@@ -1065,6 +1066,7 @@ int run_r2(Session& S) {
         if (A.r2_ref_based) {
           continue;  // (the main track's REF-vs-rest codes are the rows; only the major allele and its frequency were wanted)
         }
+        collapsed_on.emplace_back(k, maj);
         if (ldp_load_genotypes(e, k, 1, inv_row.data(), out_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) || ldp_set_maj_freqs(e, k, 1, &mf)) {
           die(16, "Error: %s\n", ldp_last_error(e));
         }
@@ -1141,6 +1143,11 @@ int run_r2(Session& S) {
         die(16, "Error: engine setup failed.\n");
       }
       feed_rows_cols(e_male, inc, &male_cols);
+      // (a pair of a chrX variant with a multiallelic one takes the male founders' tuple of BOTH, ComputeXR2 plink2_ld.cc:7122-7190: the male engine's row of the
+      // multiallelic variant is the same collapse -- copies of the alleles other than the major one the ALL-founder counts chose -- over its columns)
+      for (const auto& km : collapsed_on) {
+        allele_row(e_male, km.first, inc[km.first], static_cast<int32_t>(km.second), false, true);
+      }
       if (ldp_get_variant_recs(e_male, 0, variant_ct, recs_male.data())) {
         die(16, "Error: %s\n", ldp_last_error(e_male));
       }

@@ -926,3 +926,58 @@ def test_cli_r2_whole_genome_layout_matches_reference(gpu_pkg, tmp_path, fmt, fl
     for bad_args in (["--r-unphased"], ["--r2-unphased", "cols=+maj"], ["--r2-unphased", "inter-chr"]):
         r = subprocess.run([cli, "--pfile", "sx"] + bad_args + ["--out", "hip2"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
         assert r.returncode == 63, (bad_args, r.stdout[-300:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flag,mods,extra,ext", [
+    ("--r2-unphased", ["square", "bin"], [], ".unphased.vcor2.bin"),
+    ("--r2-unphased", ["inter-chr", "allow-ambiguous-allele"], ["--ld-window-r2", "0.03"], ".vcor"),
+    ("--r2-unphased", ["inter-chr", "cols=+maj,+nonmaj,+freq"], ["--ld-window-r2", "0.1"], ".vcor"),
+    ("--r-unphased", ["triangle", "bin"], [], ".unphased.vcor1.bin"),
+    ("--r2-unphased", ["inter-chr", "ref-based", "cols=+ref,+alt"], ["--ld-window-r2", "0.05"], ".vcor"),
+])
+def test_cli_r2_chrx_beside_multiallelic_autosomes_matches_reference(gpu_pkg, tmp_path, flag, mods, extra, ext):
+    """All-pairs outputs over chrX AND autosomal variants with several ALT alleles: a pair of a chrX variant with a multiallelic one weighs the male founders'
+    tuple of both down (ComputeXR2), so the male founders' engine has to hold the multiallelic variant collapsed on the same major allele as the all-founder engine
+    (round 5: it held the main track -- right only where REF is the major allele)."""
+    cli = gpu_pkg.build_cli()
+    tmp = str(tmp_path)
+    m, n = 420, 170
+    first, second, alt_ct = T.synth_multiallelic_haps(m, n, 55, max_alt=4, multi_rate=0.6, missing_rate=0.03, ld_copy_prob=0.6, redraw=0.1)
+    chroms = ["1"] * 150 + ["X"] * 120 + ["7"] * 150
+    for v in range(150, 270):   # chrX stays biallelic (the r^2 outputs refuse multiallelic sites there)
+        first[v] = np.where(first[v] > 1, 1, first[v])
+        second[v] = np.where(second[v] > 1, 1, second[v])
+        alt_ct[v] = 1
+    rng = np.random.default_rng(5)
+    # (several multiallelic autosomal variants must have a major allele other than REF: those are the ones the fix is about)
+    swapped = 0
+    for v in list(range(0, 150)) + list(range(270, m)):
+        if alt_ct[v] > 1 and rng.random() < 0.5:
+            a = int(rng.integers(1, alt_ct[v] + 1))
+            f0, s0 = first[v].copy(), second[v].copy()
+            first[v] = np.where(f0 == 0, a, np.where(f0 == a, 0, f0))
+            second[v] = np.where(s0 == 0, a, np.where(s0 == a, 0, s0))
+            swapped += 1
+    assert swapped > 30
+    bps = np.concatenate([1000 + 211 * np.arange(150), 1000 + 211 * np.arange(120), 1000 + 211 * np.arange(150)])
+    T.write_vcf_haps(os.path.join(tmp, "p.vcf"), first, second, alt_ct, ["1"] * m, 1000 + 211 * np.arange(m))
+    T.ref_import_vcf(os.path.join(tmp, "p.vcf"), os.path.join(tmp, "p"))
+    out, k = [], 0
+    for ln in open(os.path.join(tmp, "p.pvar")):
+        if not ln.startswith("#"):
+            f = ln.split("\t")
+            f[0], f[1] = chroms[k], str(int(bps[k]))
+            ln = "\t".join(f)
+            k += 1
+        out.append(ln)
+    open(os.path.join(tmp, "p.pvar"), "w").write("".join(out))
+    sexes = rng.choice([1, 2, 0], size=n, p=[0.5, 0.4, 0.1])
+    psam = ["#IID\tPAT\tMAT\tSEX"] + ["s%d\t%s\t%s\t%s" % (q, "s0" if q % 13 == 4 else "0", "s1" if q % 13 == 4 else "0", "NA" if sexes[q] == 0 else str(sexes[q])) for q in range(n)]
+    open(os.path.join(tmp, "p.psam"), "w").write("\n".join(psam) + "\n")
+    ref = T.run_ref(["--pfile", "p", flag] + mods + extra + ["--threads", "3", "--out", "ref"], tmp)
+    assert ref.returncode == 0, ref.stdout
+    got = subprocess.run([cli, "--pfile", "p", flag] + mods + extra + ["--out", "hip"], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert got.returncode == 0, got.stdout
+    a, b = open(os.path.join(tmp, "ref" + ext), "rb").read(), open(os.path.join(tmp, "hip" + ext), "rb").read()
+    assert len(a) > 5000 and a == b
