@@ -227,6 +227,87 @@ def sex_multiallelic_pairphase_case(cli, ref, rng, idx, tmp, execute=True):
     return True, "case %d ok: %s (phased multiallelic on %s)" % (idx, " ".join(args), "/".join(names))
 
 
+def r2_multiallelic_case(cli, ref, rng, idx, tmp, execute=True):
+    """the r^2 outputs over autosomal variants with several ALT alleles (often with a major allele other than REF) beside a biallelic chrX: matrices, the
+    inter-chr and the windowed table, r and r^2, major-allele and REF orientation, sexes incl. unknown, non-founders"""
+    n = int(rng.choice([50, 90, 170]))
+    m = int(rng.integers(120, 420))
+    d = os.path.join(tmp, "c%d" % idx)
+    os.makedirs(d)
+    seed = int(rng.integers(1, 1 << 30))
+    max_alt = int(rng.integers(2, 6))
+    with_x = rng.random() < 0.75
+    cut1, cut2 = sorted(int(x) for x in rng.integers(20, m - 20, size=2))
+    sexes = rng.choice([1, 2, 0], size=n, p=[0.5, 0.4, 0.1])
+    sexes[:2] = [1, 2]
+    nonfounder = rng.random(n) < float(rng.choice([0.0, 0.1]))
+    nonfounder[:4] = False
+    multi_rate = float(rng.choice([0.2, 0.6]))
+    swap_seed = int(rng.integers(1, 1 << 30))
+    kind = int(rng.integers(0, 7))
+    thr = str(rng.choice([0, 0.02, 0.2]))
+    if kind == 0:
+        args = ["--r2-unphased", str(rng.choice(["square", "square0", "triangle"])), str(rng.choice(["bin", "bin4"]))]
+    elif kind == 1:
+        args = ["--r2-unphased", "inter-chr", "allow-ambiguous-allele", "--ld-window-r2", thr]
+    elif kind == 2:
+        args = ["--r2-unphased", "inter-chr", "cols=+maj,+nonmaj,+freq", "--ld-window-r2", thr]
+    elif kind == 3:
+        args = ["--r-unphased", "triangle", "bin"]
+    elif kind == 4:
+        args = ["--r-unphased", "inter-chr", "cols=+maj,+nonmaj", "--ld-window-r2", thr]
+    elif kind == 5:
+        args = ["--r2-unphased", "cols=+ref,+alt", "--ld-window-kb", str(rng.choice([5, 20, 80])), "--ld-window-r2", thr] + (["ref-based"] if rng.random() < 0.4 else [])
+        if "ref-based" in args:
+            args.remove("ref-based")
+            args.insert(1, "ref-based")
+    else:
+        args = ["--r-unphased", "ref-based", "inter-chr", "cols=+ref,+alt", "--ld-window-r2", thr]
+    args = ["--pfile", "d"] + args
+    ext = ".vcor" if not any(a in args for a in ("bin", "bin4")) else (".unphased.vcor1." if args[2] == "--r-unphased" else ".unphased.vcor2.") + "bin"
+    if not execute:
+        return True, "case %d skipped" % idx
+    first, second, alt_ct = T.synth_multiallelic_haps(m, n, seed, max_alt=max_alt, multi_rate=multi_rate, missing_rate=0.02, ld_copy_prob=0.6, redraw=0.1)
+    chroms = ["1"] * cut1 + (["X"] if with_x else ["2"]) * (cut2 - cut1) + ["7"] * (m - cut2)
+    srng = np.random.default_rng(swap_seed)
+    for v in range(m):
+        if chroms[v] == "X":
+            first[v] = np.where(first[v] > 1, 1, first[v])
+            second[v] = np.where(second[v] > 1, 1, second[v])
+            alt_ct[v] = 1
+        elif alt_ct[v] > 1 and srng.random() < 0.5:   # (an ALT allele takes REF's place: the major allele is then often not REF)
+            a = int(srng.integers(1, alt_ct[v] + 1))
+            f0, s0 = first[v].copy(), second[v].copy()
+            first[v] = np.where(f0 == 0, a, np.where(f0 == a, 0, f0))
+            second[v] = np.where(s0 == 0, a, np.where(s0 == a, 0, s0))
+    pos = 1000 + np.cumsum(srng.integers(1, 900, size=m))
+    T.write_vcf_haps(os.path.join(d, "d.vcf"), first, second, alt_ct, ["1"] * m, pos)
+    T.ref_import_vcf(os.path.join(d, "d.vcf"), os.path.join(d, "d"))
+    out, k = [], 0
+    for ln in open(os.path.join(d, "d.pvar")):
+        if not ln.startswith("#"):
+            f = ln.split("\t")
+            f[0] = chroms[k]
+            ln = "\t".join(f)
+            k += 1
+        out.append(ln)
+    open(os.path.join(d, "d.pvar"), "w").write("".join(out))
+    psam = ["#IID\tPAT\tMAT\tSEX"]
+    for q in range(n):
+        psam.append("s%d\t%s\t%s\t%s" % (q, "s0" if nonfounder[q] else "0", "s1" if nonfounder[q] else "0", "NA" if sexes[q] == 0 else str(sexes[q])))
+    open(os.path.join(d, "d.psam"), "w").write("\n".join(psam) + "\n")
+    r = run([ref] + args + ["--threads", "2", "--out", "ref"], d)
+    g = run([cli] + args + ["--out", "hip"], d)
+    if r.returncode != g.returncode:
+        return False, "case %d: exit codes differ (ref %d, hip %d): %s\n%s\n%s" % (idx, r.returncode, g.returncode, " ".join(args), r.stdout[-300:], g.stdout[-400:])
+    if r.returncode != 0:
+        return True, "case %d: both refuse (%s)" % (idx, " ".join(args))
+    a, b = os.path.join(d, "ref" + ext), os.path.join(d, "hip" + ext)
+    if (not os.path.exists(a)) or (not os.path.exists(b)) or not filecmp.cmp(a, b, shallow=False):
+        return False, "case %d: %s differs: %s (multiallelic autosomes%s, n=%d m=%d seed=%d)" % (idx, ext, " ".join(args), " + chrX" if with_x else "", n, m, seed)
+    return True, "case %d ok: %s (multiallelic autosomes%s)" % (idx, " ".join(args), " + chrX" if with_x else "")
+
+
 def pairphase_case(cli, ref, rng, idx, tmp, execute=True):
     if rng.random() < 0.25:
         return pairphase_multiallelic_case(cli, ref, rng, idx, tmp, execute)
@@ -444,7 +525,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--mode", default="all", choices=["all", "pairphase", "clump", "sexmulti", "clumpmulti", "sexmultiphase"])
+    ap.add_argument("--mode", default="all", choices=["all", "pairphase", "clump", "sexmulti", "clumpmulti", "sexmultiphase", "r2multi"])
     ap.add_argument("--only", type=int, default=None, help="replay the random stream but execute only this case")
     ap.add_argument("--keep", default=None, help="directory to keep the case files in (default: a temporary directory)")
     args = ap.parse_args()
@@ -463,6 +544,8 @@ def main():
                 ok, desc = sex_multiallelic_case(cli, ref, rng, k, tmp, execute=(args.only is None or k == args.only))
             elif args.mode == "sexmultiphase":
                 ok, desc = sex_multiallelic_pairphase_case(cli, ref, rng, k, tmp, execute=(args.only is None or k == args.only))
+            elif args.mode == "r2multi":
+                ok, desc = r2_multiallelic_case(cli, ref, rng, k, tmp, execute=(args.only is None or k == args.only))
             elif args.mode == "clumpmulti":
                 ok, desc = clump_multiallelic_case(cli, ref, rng, k, tmp, execute=(args.only is None or k == args.only))
             else:
