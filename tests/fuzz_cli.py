@@ -23,6 +23,14 @@ import ldtools as T  # noqa: E402
 import __graft_entry__ as ge  # noqa: E402
 
 
+def hip_only(args, idx):
+    """plink2-hip's own flags for this case (the reference does not know them): every fourth prune case runs as N engines on the one device
+    (--gpus N --debug-alias-devices: subcontig shards, the exchange of removed bits through the host, the stitch) -- the lists must not change."""
+    if (("--indep-pairwise" in args) or ("--indep-pairphase" in args)) and (idx % 4 == 1):
+        return ["--gpus", str(2 + idx % 3 + 3 * (idx % 8 == 5)), "--debug-alias-devices"]
+    return []
+
+
 def run(cmd, cwd):
     return subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
 
@@ -49,7 +57,7 @@ def pairphase_multiallelic_case(cli, ref, rng, idx, tmp, execute=True):
         return True, "case %d skipped" % idx
     T.ref_import_vcf(os.path.join(d, "d.vcf"), os.path.join(d, "d"))
     r = run([ref] + args + ["--threads", "2", "--out", "ref"], d)
-    g = run([cli] + args + ["--out", "hip"], d)
+    g = run([cli] + args + hip_only(args, idx) + ["--out", "hip"], d)
     if r.returncode != g.returncode:
         return False, "case %d: exit codes differ (ref %d, hip %d): %s\n%s\n%s" % (idx, r.returncode, g.returncode, " ".join(args), r.stdout[-300:], g.stdout[-400:])
     if r.returncode != 0:
@@ -105,7 +113,7 @@ def sex_multiallelic_case(cli, ref, rng, idx, tmp, execute=True):
         psam.append("s%d\t%s\t%s\t%s" % (q, "s0" if nonfounder[q] else "0", "s1" if nonfounder[q] else "0", "NA" if sexes[q] == 0 else str(sexes[q])))
     open(os.path.join(d, "d.psam"), "w").write("\n".join(psam) + "\n")
     r = run([ref] + args + ["--threads", "2", "--out", "ref"], d)
-    g = run([cli] + args + ["--out", "hip"], d)
+    g = run([cli] + args + hip_only(args, idx) + ["--out", "hip"], d)
     if r.returncode != g.returncode:
         return False, "case %d: exit codes differ (ref %d, hip %d): %s\n%s\n%s" % (idx, r.returncode, g.returncode, " ".join(args), r.stdout[-300:], g.stdout[-400:])
     if r.returncode != 0:
@@ -163,7 +171,7 @@ def clump_multiallelic_case(cli, ref, rng, idx, tmp, execute=True):
     if two:
         TC.write_allele_report(os.path.join(d, "b.txt"), alt_ct, rep_seed + 1, False, sig_rate=0.08)
     r = run([ref] + args + ["--threads", "2", "--out", "ref"], d)
-    g = run([cli] + args + ["--out", "hip"], d)
+    g = run([cli] + args + hip_only(args, idx) + ["--out", "hip"], d)
     if (r.returncode < 0) and ("--clump-force-a1" in args):
         # the reference died of a signal: under --clump-force-a1 an entry of a multiallelic allele carries the forced-A1 bit of the previous biallelic
         # line, and its SP2 printer then reads allele_storage[allele + 1] (plink2_ld.cc:9357) -- past the table's end when that allele is the last one
@@ -216,7 +224,7 @@ def sex_multiallelic_pairphase_case(cli, ref, rng, idx, tmp, execute=True):
         psam.append("s%d\t%s\t%s\t%s" % (q, "s0" if nonfounder[q] else "0", "s1" if nonfounder[q] else "0", "NA" if sexes[q] == 0 else str(sexes[q])))
     open(os.path.join(d, "d.psam"), "w").write("\n".join(psam) + "\n")
     r = run([ref] + args + ["--threads", "2", "--out", "ref"], d)
-    g = run([cli] + args + ["--out", "hip"], d)
+    g = run([cli] + args + hip_only(args, idx) + ["--out", "hip"], d)
     if r.returncode != g.returncode:
         return False, "case %d: exit codes differ (ref %d, hip %d): %s\n%s\n%s" % (idx, r.returncode, g.returncode, " ".join(args), r.stdout[-300:], g.stdout[-400:])
     if r.returncode != 0:
@@ -297,7 +305,7 @@ def r2_multiallelic_case(cli, ref, rng, idx, tmp, execute=True):
         psam.append("s%d\t%s\t%s\t%s" % (q, "s0" if nonfounder[q] else "0", "s1" if nonfounder[q] else "0", "NA" if sexes[q] == 0 else str(sexes[q])))
     open(os.path.join(d, "d.psam"), "w").write("\n".join(psam) + "\n")
     r = run([ref] + args + ["--threads", "2", "--out", "ref"], d)
-    g = run([cli] + args + ["--out", "hip"], d)
+    g = run([cli] + args + hip_only(args, idx) + ["--out", "hip"], d)
     if r.returncode != g.returncode:
         return False, "case %d: exit codes differ (ref %d, hip %d): %s\n%s\n%s" % (idx, r.returncode, g.returncode, " ".join(args), r.stdout[-300:], g.stdout[-400:])
     if r.returncode != 0:
@@ -344,7 +352,7 @@ def pairphase_case(cli, ref, rng, idx, tmp, execute=True):
     if not execute:
         return True, "case %d skipped" % idx
     r = run([ref] + args + ["--out", "ref"], d)
-    g = run([cli] + args + ["--out", "hip"], d)
+    g = run([cli] + args + hip_only(args, idx) + ["--out", "hip"], d)
     if r.returncode != g.returncode:
         return False, "case %d: exit codes differ (ref %d, hip %d): %s\n%s\n%s" % (idx, r.returncode, g.returncode, " ".join(args), r.stdout[-300:], g.stdout[-400:])
     if r.returncode != 0:
@@ -507,7 +515,7 @@ def one_case(cli, ref, rng, idx, tmp, execute=True, mode="all"):
     if not execute:
         return True, "case %d skipped" % idx
     r = run([ref] + args + ["--out", "ref"], d)
-    g = run([cli] + args + ["--out", "hip"], d)
+    g = run([cli] + args + hip_only(args, idx) + ["--out", "hip"], d)
     if r.returncode != g.returncode and not (r.returncode != 0 and g.returncode != 0):
         return False, "case %d: exit codes differ (ref %d, hip %d): %s\n%s" % (idx, r.returncode, g.returncode, " ".join(args), g.stdout[-400:])
     if r.returncode != 0:
