@@ -79,6 +79,26 @@ runs = [
 for args, want in runs:
     r = subprocess.run([T + "/cli"] + args + ["--out", "o"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == want and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (args, r.returncode, r.stdout[-300:], r.stderr[-800:])
+# --clump over (variant, A1 allele) pairs (round 5): a fileset with multiallelic sites whose LAST variant is multiallelic, reports that name one allele per
+# variant (nothing pairs: no device), --clump-force-a1 with two reports -- the reference's stale forced-A1 bit then points past its allele table
+# (plink2_ld.cc:9357; it dies there), plink2-hip must print an empty name and stay inside its own
+if L.have_ref():
+    import pathlib
+    d2 = T + "/fs2"
+    os.makedirs(d2)
+    alt_ct, _, _ = TC.multiallelic_clump_fileset(pathlib.Path(d2), 300, 40, 7, chrom_of=lambda v: "1", multi_rate=0.5)
+    lines = open(d2 + "/d.pvar").read().split("\n")
+    f = lines[-2].split("\t")
+    f[4] = "C,G,T"
+    lines[-2] = "\t".join(f)           # (the genotypes do not use the added alleles; the table does)
+    open(d2 + "/d.pvar", "w").write("\n".join(lines))
+    alt_ct[-1] = 3
+    TC.write_allele_report(d2 + "/a.txt", alt_ct, 41, True, sig_rate=0.4)
+    TC.write_allele_report(d2 + "/b.txt", alt_ct, 42, True, sig_rate=0.4)
+    for extra in ([], ["--clump-force-a1"], ["--clump-force-a1", "--clump-p1", "0.5", "--clump-p2", "0.5"]):
+        r = subprocess.run([T + "/cli", "--pfile", "d", "--clump", "cols=+a1,+f,+bounds", "a.txt", "b.txt", "--clump-unphased", "--clump-kb", "0.001"] + extra + ["--out", "o"], cwd=d2,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (extra, r.returncode, r.stdout[-300:], r.stderr[-800:])
 print("plink2-hip host paths: clean")
 PY
 fi
