@@ -291,6 +291,7 @@ inline uint32_t code_at(const uint8_t* row, uint32_t s) { return (row[s >> 2] >>
 void build_sex_row(const SexPlan& sp, const uint8_t* raw_row, uint8_t* out_row, uint64_t out_rec, double* maj_freq, const uint8_t* phase = nullptr);
 void multiallelic_sex_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_ct, const SexPlan& sp, std::vector<uint8_t>* lo, std::vector<uint8_t>* hi, uint8_t* out_row,
                           uint64_t out_rec, double* maj_freq);
+uint32_t sex_major_allele(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_ct, const SexPlan& sp, std::vector<uint8_t>* lo, std::vector<uint8_t>* hi, double* maj_freq);
 void multiallelic_sex_row_phased(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_ct, const SexPlan& sp, std::vector<uint8_t>* lo, std::vector<uint8_t>* hi, uint8_t* phase,
                                  uint64_t phase_bytes, uint8_t* out_row, uint64_t out_rec, double* maj_freq, bool* unphased);
 void fetch_raw_row(ldp_pgen* pg, int storage_mode, uint32_t raw_variant, uint32_t raw_sample_ct, uint64_t rec_bytes, uint8_t* buf);

@@ -542,9 +542,6 @@ void load_inputs(Session& S, int argc, char** argv) {
       if (cls == 2) {
         die(6, "Error: Invalid chromosome code '%s'. (Use --allow-extra-chr to force it to be accepted.)\n", cur.c_str());
       }
-      if (cls >= 3 && V.alt_ct[v] > 1 && !A.have_prune && !A.have_clump) {
-        die(63, "Error: multiallelic variant '%s' on chrX/chrY/MT: plink2-hip handles those under --indep-pairwise, --indep-pairphase and --clump only.\n", V.id[v].c_str());
-      }
       vcls.push_back(static_cast<uint8_t>(cls));
       inc.push_back(v);
       chr_idx.push_back(fo);

@@ -177,12 +177,12 @@ struct VcorColumns {
       for (uint32_t k = 0; k < variant_ct; ++k) {
         const auto it = multi_maj.find(k);
         double maj_freq;
-        if (is_x[k]) {
-          maj_allele[k] = x_maj_alt[k];
-          maj_freq = x_maj_freq[k];
-        } else if (it != multi_maj.end()) {
+        if (it != multi_maj.end()) {  // (several ALT alleles, on chrX too: the allele-frequency pass's own major allele)
           maj_allele[k] = static_cast<uint8_t>(it->second.first);
           maj_freq = it->second.second;
+        } else if (is_x[k]) {
+          maj_allele[k] = x_maj_alt[k];
+          maj_freq = x_maj_freq[k];
         } else {
           const uint64_t ref_ct = 2ull * recs[k].n_homref + recs[k].n_het, alt_ct = 2ull * recs[k].n_homalt + recs[k].n_het, tot = ref_ct + alt_ct;
           double ref_freq = 0.5;
@@ -1034,6 +1034,7 @@ int run_r2(Session& S) {
   // genotype rows -> engine (same feeder as the prune path)
   std::unordered_map<uint32_t, std::pair<uint32_t, double>> multi_maj;  // multiallelic variant -> (major allele, its frequency), for the MAJ / NONMAJ / NONMAJ_FREQ columns
   std::vector<std::pair<uint32_t, uint32_t>> collapsed_on;  // (row, major allele) of the rows loaded as copies of the non-major alleles
+  std::unordered_map<uint32_t, double> multi_maj_all;       // ... and the major allele's frequency
   {
     feed_rows(e, inc);
     const uint64_t out_rec = (static_cast<uint64_t>(founder_ct) + 3) / 4;
@@ -1059,7 +1060,28 @@ int run_r2(Session& S) {
         }
         double mf = 0.0;
         uint32_t maj = 0;
-        multiallelic_inverse_row(pg, inc[k], alts, founder_idx, &lo, &hi, inv_row.data(), out_rec, &mf, nullptr, 0, nullptr, &maj);
+        if (vcls[k] >= 3) {
+          // chrX / chrY / MT (round 5; refused before): the major allele by the chromosome's own allele-frequency weights -- chrX: a male founder's allele copy counts 1, anybody
+          // else's 2; chrY: the non-female founders; MT: every founder (plink2_data.cc:2752-2895) --, the row PgrGetInv1's collapse on it over all founders
+          SexPlan sp;
+          for (uint32_t sidx : founder_idx) {
+            if (vcls[k] == 3) {
+              (sex[sidx] == 1 ? sp.part1 : sp.part2).push_back(sidx);
+            } else if ((vcls[k] == 5) || (sex[sidx] != 2)) {
+              sp.part1.push_back(sidx);
+            }
+          }
+          maj = sex_major_allele(pg, inc[k], alts, sp, &lo, &hi, &mf);
+          memset(inv_row.data(), 0, out_rec);
+          uint32_t f = 0;
+          for (uint32_t sidx : founder_idx) {
+            const uint32_t code = (lo[sidx] == 255) ? 3u : (static_cast<uint32_t>(lo[sidx] != maj) + static_cast<uint32_t>(hi[sidx] != maj));
+            inv_row[f >> 2] |= static_cast<uint8_t>(code << (2 * (f & 3)));
+            ++f;
+          }
+        } else {
+          multiallelic_inverse_row(pg, inc[k], alts, founder_idx, &lo, &hi, inv_row.data(), out_rec, &mf, nullptr, 0, nullptr, &maj);
+        }
         if (want_maj) {
           multi_maj[k] = std::make_pair(maj, mf);
         }
@@ -1067,6 +1089,7 @@ int run_r2(Session& S) {
           continue;  // (the main track's REF-vs-rest codes are the rows; only the major allele and its frequency were wanted)
         }
         collapsed_on.emplace_back(k, maj);
+        multi_maj_all[k] = mf;
         if (ldp_load_genotypes(e, k, 1, inv_row.data(), out_rec, LDP_MEM_HOST, LDP_GENO_INVERSE) || ldp_set_maj_freqs(e, k, 1, &mf)) {
           die(16, "Error: %s\n", ldp_last_error(e));
         }
@@ -1093,7 +1116,13 @@ int run_r2(Session& S) {
   if (founder_female_ct && (founder_male_ct != founder_ct)) {
     for (uint32_t k = 0; k < variant_ct; ++k) {
       if (vcls[k] == 4) {
-        females_missing(e, k, inc[k]);
+        int32_t on = -1;  // (a variant with several ALT alleles: its collapsed row, not the main track)
+        for (const auto& km : collapsed_on) {
+          if (km.first == k) {
+            on = static_cast<int32_t>(km.second);
+          }
+        }
+        allele_row(e, k, inc[k], on, true, founder_ct != raw_sample_ct);
       }
     }
   }
@@ -1115,6 +1144,7 @@ int run_r2(Session& S) {
   }
   ldp_engine* e_male = nullptr;
   std::vector<uint8_t> x_flip_all, x_flip_male, x_maj_alt;  // (x_maj_alt: the chrX-aware major allele, for the MAJ / NONMAJ columns)
+  std::vector<uint8_t> x_target;                             // the orientation the values are wanted in, per row (1: ALT counted as the major allele)
   struct EngineGuard {
     ldp_engine** p;
     ~EngineGuard() {
@@ -1154,11 +1184,17 @@ int run_r2(Session& S) {
     }
     x_flip_all.assign(variant_ct, 0);
     x_flip_male.assign(variant_ct, 0);
+    x_target.assign(variant_ct, 0);
     x_maj_alt.assign(variant_ct, 0);
     x_maj_freq.assign(variant_ct, 0.0);
     for (uint32_t k = 0; k < variant_ct; ++k) {
       uint32_t target_alt = recs_all[k].flags & 1u;  // the engine's own choice: diploid allele counts over the founders
-      if (is_x[k]) {
+      const auto mm = multi_maj_all.find(k);
+      if (is_x[k] && (mm != multi_maj_all.end())) {
+        // several ALT alleles: the row already counts the copies of the alleles other than the chrX rule's major one (loaded as LDP_GENO_INVERSE: flags bit 0 clear)
+        target_alt = 0;
+        x_maj_freq[k] = mm->second;
+      } else if (is_x[k]) {
         // the allele-frequency pass on chrX counts a male once (the arithmetic of build_sex_row above)
         const uint64_t g1 = recs_all[k].n_het, g2 = recs_all[k].n_homalt, n_all = static_cast<uint64_t>(recs_all[k].n_homref) + g1 + g2;
         const uint64_t m1 = recs_male[k].n_het, m2 = recs_male[k].n_homalt, n_male = static_cast<uint64_t>(recs_male[k].n_homref) + m1 + m2;
@@ -1174,6 +1210,7 @@ int run_r2(Session& S) {
       if (A.r2_ref_based) {
         target_alt = 0;
       }
+      x_target[k] = static_cast<uint8_t>(target_alt);
       x_flip_all[k] = static_cast<uint8_t>((recs_all[k].flags & 1u) ^ target_alt);
       x_flip_male[k] = static_cast<uint8_t>((recs_male[k].flags & 1u) ^ target_alt);
     }
@@ -1221,10 +1258,34 @@ int run_r2(Session& S) {
         }
         feed_rows_cols(band.band_male, x_inc, &male_cols);
       }
+      for (const auto& km : collapsed_on) {  // (variants of the run with several ALT alleles: the same collapse in both)
+        if ((km.first >= x0) && (km.first < x1)) {
+          allele_row(band.band_all, km.first - x0, inc[km.first], static_cast<int32_t>(km.second), false, founder_ct != raw_sample_ct);
+          if (band.band_male) {
+            allele_row(band.band_male, km.first - x0, inc[km.first], static_cast<int32_t>(km.second), false, true);
+          }
+        }
+      }
       band.band_first = x0;
       band.band_ct = cnt;
-      band.band_flip_all.assign(x_flip_all.begin() + x0, x_flip_all.begin() + x1);  // (the same rows as in `e` / `e_male`: the same orientation)
-      band.band_flip_male.assign(x_flip_male.begin() + x0, x_flip_male.begin() + x1);
+      // (the same rows as in `e` / `e_male` up to how a collapsed row was loaded: each engine's own orientation against the same target)
+      std::vector<ldp_variant_rec> rb(cnt);
+      band.band_flip_all.assign(cnt, 0);
+      band.band_flip_male.assign(cnt, 0);
+      if (ldp_get_variant_recs(band.band_all, 0, cnt, rb.data())) {
+        die(16, "Error: %s\n", ldp_last_error(band.band_all));
+      }
+      for (uint32_t q = 0; q < cnt; ++q) {
+        band.band_flip_all[q] = static_cast<uint8_t>((rb[q].flags & 1u) ^ x_target[x0 + q]);
+      }
+      if (band.band_male) {
+        if (ldp_get_variant_recs(band.band_male, 0, cnt, rb.data())) {
+          die(16, "Error: %s\n", ldp_last_error(band.band_male));
+        }
+        for (uint32_t q = 0; q < cnt; ++q) {
+          band.band_flip_male[q] = static_cast<uint8_t>((rb[q].flags & 1u) ^ x_target[x0 + q]);
+        }
+      }
     }
   }
   R2Job J(S);

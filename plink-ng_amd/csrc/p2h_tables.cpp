@@ -646,6 +646,33 @@ void multiallelic_sex_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_ct, c
   }
 }
 
+// The major allele (and its frequency) of a variant with several ALT alleles under a chromosome's own allele-frequency weights, as multiallelic_sex_row counts them: the
+// plan's part-1 founders with weight 1 per allele copy, its part-2 founders with weight 2 (chrX: males | non-males; chrY: the non-female founders; MT: every founder).
+// For the r^2 outputs, whose rows stay over all founders (the collapse is PgrGetInv1's on this allele; the sample layouts are the prune's business).
+uint32_t sex_major_allele(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_ct, const SexPlan& sp, std::vector<uint8_t>* lo, std::vector<uint8_t>* hi, double* maj_freq) {
+  if (ldp_pgen_read_alleles(pg, raw_variant, alt_ct, lo->data(), hi->data())) {
+    die(6, "\nError: %s\n", ldp_pgen_last_error(pg));
+  }
+  const uint32_t allele_ct = alt_ct + 1;
+  std::vector<uint64_t> cnt(allele_ct, 0);
+  auto add = [&](uint32_t s, uint64_t w) {
+    if ((*lo)[s] != 255) {
+      if ((*lo)[s] >= allele_ct || (*hi)[s] >= allele_ct) {
+        die(6, "\nError: allele index out of range in multiallelic record.\n");
+      }
+      cnt[(*lo)[s]] += w;
+      cnt[(*hi)[s]] += w;
+    }
+  };
+  for (uint32_t s : sp.part1) {
+    add(s, 1);
+  }
+  for (uint32_t s : sp.part2) {
+    add(s, 2);
+  }
+  return pick_major_allele(cnt, maj_freq);
+}
+
 // ... under --indep-pairphase on chrX with non-male founders (plink2_ld.cc:2060-2097 after PgrGetInv1P on the chromosome's major allele): part 1 -- the males -- one
 // haplotype each as above, part 2 two haplotypes per founder split by the file's phase bits in Get1MP's reading (multiallelic_inverse_row above: the bit is passed
 // through as "the counted allele is on the first haplotype", which for a major allele other than REF is the complement of what the file says); a haplotype h is the code

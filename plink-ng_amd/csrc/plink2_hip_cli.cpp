@@ -18,7 +18,7 @@
 // --parallel; number formatting restated from dtoa_g.  --clump (several reports, --clump-allow-overlap, cols=, bins, -log10,
 // ranges, sex chromosomes, (variant, A1 allele) pairs of multiallelic sites).
 // Not yet supported (reported as such with exit 63, never silently mis-handled): dosage data outside --indep-pairwise on the autosomes,
-// more than 254 ALT alleles, multiallelic sites on chrX/Y/MT in the r^2 outputs (--indep-pairwise, --indep-pairphase and --clump take them since round 5), major-allele-oriented
+// more than 254 ALT alleles (multiallelic sites on chrX/Y/MT are taken by every command since round 5), major-allele-oriented
 // r^2 outputs on chrY/MT.
 // The front-end is split into translation units of one concern each (p2h_cli.h: what they share): p2h_util.cpp (logging, number
 // scanning / formatting), p2h_args.cpp (command line), p2h_tables.cpp (.psam / .pvar tables, host-built rows), p2h_inputs.cpp (filters,

@@ -278,8 +278,14 @@ def r2_multiallelic_case(cli, ref, rng, idx, tmp, execute=True):
     first, second, alt_ct = T.synth_multiallelic_haps(m, n, seed, max_alt=max_alt, multi_rate=multi_rate, missing_rate=0.02, ld_copy_prob=0.6, redraw=0.1)
     chroms = ["1"] * cut1 + (["X"] if with_x else ["2"]) * (cut2 - cut1) + ["7"] * (m - cut2)
     srng = np.random.default_rng(swap_seed)
+    x_multi = srng.random() < 0.6          # (round 5: multiallelic sites on chrX stay multiallelic -- and, where plink2-hip computes them, on chrY / MT behind the autosomes)
+    tail_ok = (kind == 5) or ((kind in (0, 1)) and not with_x)
+    if tail_ok and (srng.random() < 0.6):
+        t0 = cut2 + (m - cut2) // 2
+        for v in range(t0, m):
+            chroms[v] = "Y" if v < t0 + (m - t0) // 2 else "MT"
     for v in range(m):
-        if chroms[v] == "X":
+        if (chroms[v] == "X") and not x_multi:
             first[v] = np.where(first[v] > 1, 1, first[v])
             second[v] = np.where(second[v] > 1, 1, second[v])
             alt_ct[v] = 1
