@@ -316,9 +316,17 @@ def test_cli_multiallelic_variants_on_sex_chromosomes_match_reference(gpu_pkg, c
     assert filecmp.cmp(str(tmp_path / "ref.prune.in"), str(tmp_path / "hip.prune.in"), shallow=False)
     assert filecmp.cmp(str(tmp_path / "ref.prune.out"), str(tmp_path / "hip.prune.out"), shallow=False)
     assert 0 < len(hip_out) < m
-    # --indep-pairphase and the r^2 outputs still refuse them, loudly
+    # the r^2 outputs take them too (round 5; exit 63 before): without a column that names the allele both tools ask for one, with
+    # 'allow-ambiguous-allele' the windowed table over all four chromosomes is the reference's, byte for byte
     r = run_cli(cli, ["--pfile", "mv", "--r2-unphased", "--out", "no"], str(tmp_path))
-    assert r.returncode == 63 and "multiallelic" in r.stdout
+    rr = T.run_ref(["--pfile", "mv", "--r2-unphased", "--out", "refno"], str(tmp_path))
+    assert r.returncode == rr.returncode == 7 and "allow-ambiguous-allele" in r.stdout
+    tab = ["--pfile", "mv", "--r2-unphased", "allow-ambiguous-allele", "--ld-window-kb", "2", "--ld-window-r2", "0.05"]
+    rr = T.run_ref(tab + ["--threads", "3", "--out", "reft"], str(tmp_path))
+    r = run_cli(cli, tab + ["--out", "hipt"], str(tmp_path))
+    assert rr.returncode == 0 and r.returncode == 0, (rr.stdout[-300:], r.stdout[-300:])
+    a, b = open(str(tmp_path / "reft.vcor"), "rb").read(), open(str(tmp_path / "hipt.vcor"), "rb").read()
+    assert len(a) > 2000 and a == b
 
 
 def test_vcor_number_formatting_matches_reference(cli, tmp_path):
