@@ -653,23 +653,14 @@ int write_vcor_table(R2Job& J) {
 int write_vcor_matrix(R2Job& J) {
   Session& S = J.S;
   const Args& A = S.A;
-  const Variants& V = S.V;
   ldp_engine* const e = J.e;
   ldp_pgen* const pg = S.pg;
-  const std::vector<uint32_t>&inc = S.inc, &chr_idx = S.chr_idx, &bps = S.bps;
-  const uint32_t variant_ct = S.variant_ct, raw_variant_ct = S.raw_variant_ct;
+  const uint32_t variant_ct = S.variant_ct;
   const uint32_t shard_first = J.shard_first, shard_end = J.shard_end;
   const std::string &piece_suffix = J.piece_suffix, &base = J.base;
-  const std::vector<uint8_t>& is_x = J.is_x;
-  const bool any_x = J.any_x;
-  const auto& multi_maj = J.multi_maj;
-  const std::vector<uint8_t>& x_maj_alt = J.x_maj_alt;
-  const std::vector<double>& x_maj_freq = J.x_maj_freq;
-  auto x_pairs_r2 = [&](const std::vector<uint32_t>& first, const std::vector<uint32_t>& second, std::vector<double>* out) { J.xw.pairs(first, second, out); };
   auto x_fix_dense = [&](void* buf, bool as_float, uint32_t r0, uint32_t rows, uint32_t c0, uint32_t cols, uint64_t ld) {
     J.x_fix_dense(buf, as_float, r0, rows, c0, cols, ld);
   };
-  (void)raw_variant_ct; (void)x_pairs_r2; (void)x_fix_dense; (void)multi_maj; (void)x_maj_alt; (void)x_maj_freq; (void)chr_idx; (void)bps; (void)base; (void)pg;
   const size_t esz = A.r2_float ? 4 : 8;
   const std::string mpath = base + piece_suffix + ((A.r2_text && A.r2_zs) ? ".zst" : "");
   OutFile mf;
@@ -785,21 +776,18 @@ int write_vcor_matrix(R2Job& J) {
 int run_r2(Session& S) {
   const Args& A = S.A;
   const Variants& V = S.V;
-  const double t_begin = S.t_begin;
   const std::vector<uint8_t>& is_founder = S.is_founder;
   const std::vector<uint8_t>& sex = S.sex;
   const uint32_t raw_sample_ct = S.raw_sample_ct, founder_ct = S.founder_ct, raw_variant_ct = S.raw_variant_ct;
   const std::string& gpath = S.gpath;
   ldp_pgen* const pg = S.pg;
-  const int storage_mode = S.storage_mode, encoding = S.encoding, has_multiallelic = S.has_multiallelic;
+  const int storage_mode = S.storage_mode, encoding = S.encoding;
   const uint64_t rec_bytes = S.rec_bytes;
   const uint8_t* const direct_rows = S.direct_rows;
   const std::vector<uint32_t>&inc = S.inc, &chr_idx = S.chr_idx, &bps = S.bps;
   const std::vector<uint8_t>& vcls = S.vcls;
-  const uint32_t variant_ct = S.variant_ct, m_ct = S.m_ct;
-  const std::vector<uint32_t>&mk = S.mk, &xk = S.xk, &yk = S.yk, &tk = S.tk, &m_chr = S.m_chr, &m_bps = S.m_bps;
+  const uint32_t variant_ct = S.variant_ct;
   auto join_hip = [&S]() { S.join_hip(); };
-  const double &t_hip_init = S.t_hip_init, &t_parse = S.t_parse, &t_joined = S.t_joined;
   // ---- --r2-unphased {square|square0|triangle} {bin|bin4}: every variant, every pair (Vcor, plink2_ld.cc:12050)
   if ((!A.r2_table) && variant_ct > 400000 && (A.parallel_tot == 1) && !A.yes_really) {  // plink2_ld.cc:9788
     die(7, "Error: Gigantic (over 400k variants) --r2-unphased unfiltered, non-distributed\ncomputation.  Rerun with the 'yes-really' modifier if you are SURE you have enough\nhard drive space and want to do this.\n");
@@ -883,7 +871,6 @@ int run_r2(Session& S) {
       die(16, "Error: %s\n", ldp_last_error(eng));
     }
   };
-  auto females_missing = [&](ldp_engine* eng, uint32_t row_idx, uint32_t raw) { allele_row(eng, row_idx, raw, -1, true, founder_ct != raw_sample_ct); };
   if (A.have_clump) {
     join_hip();
     ClumpSex SX;
