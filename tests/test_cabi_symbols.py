@@ -59,6 +59,22 @@ def test_device_count_never_fails(pkg):
     assert pkg.device_count() >= 0
 
 
+def test_device_numa_node_is_minus_one_where_there_is_no_such_device(pkg):
+    """ldp_device_numa_node (round 5: plink2-hip binds its loading threads to the device's NUMA node): -1 for a device that does not exist, an
+    integer >= -1 otherwise -- never an error, never a side effect on the caller's threads."""
+    import ctypes
+    import os
+    L = pkg.lib()
+    L.ldp_device_numa_node.argtypes = [ctypes.c_int]
+    L.ldp_device_numa_node.restype = ctypes.c_int
+    before = os.sched_getaffinity(0)
+    n = pkg.device_count()
+    assert L.ldp_device_numa_node(-1) == -1 and L.ldp_device_numa_node(n) == -1 and L.ldp_device_numa_node(1 << 20) == -1
+    for d in range(n):
+        assert L.ldp_device_numa_node(d) >= -1
+    assert os.sched_getaffinity(0) == before
+
+
 def test_product_does_not_reference_the_oracle():
     """oracle/ is test infrastructure: nothing under plink-ng_amd/ or include/ may mention it."""
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
