@@ -693,7 +693,7 @@ class Workload:
 def sum_counters(ctrs):
     keys = ("candidate_pairs", "pred_true", "replay_pairs", "ms_prepare", "ms_pair_kernel", "ms_pair_mfma", "ms_pair_mfma_general", "ms_pair_fast",
             "ms_pair_general", "ms_replay", "pair_kernel_launches", "mfma_block_products", "mfma_product_stages", "mfma_skipped_product_stages",
-            "sparse_exact_pairs", "route_complete_launches", "route_sparse_launches", "route_general_launches", "mfma_extra_product_stages", "wide_tiles", "four_tile_launches")
+            "sparse_exact_pairs", "route_complete_launches", "route_sparse_launches", "route_general_launches", "mfma_extra_product_stages", "wide_tiles", "four_tile_launches", "sparse_tile_launches")
     return {k: sum(c[k] for c in ctrs) for k in keys}
 
 
@@ -785,8 +785,9 @@ def pair_roofline(c, founder_ct, local_ct, missing_rate, variants, window_kb, op
     kms_valu = c["ms_pair_fast"] + c["ms_pair_general"]
     on_matrix_pipe = (kms_mfma + kms_gen) > kms_valu
     four_tiles = c.get("four_tile_launches", 0) > 0   # wide bands: the four-product form runs on quarter tiles
-    wide = c.get("wide_tiles", 0) > 0 and c["route_complete_launches"] > 0   # complete-data launches of wide-band subcontigs: the 8 x 8 tile kernel
-    kernel = (("pair_mfma_tile4_kernel" if four_tiles else "pair_mfma_general_kernel") if general else ("pair_mfma_wide_kernel" if wide else "pair_mfma_kernel")) if on_matrix_pipe else ("pair_tiles_kernel<true>" if general else "pair_tiles_kernel<false>")
+    wide = c.get("wide_tiles", 0) > 0 and (c["route_complete_launches"] > 0 or c.get("sparse_tile_launches", 0) > 0)   # the 8 x 8 tile kernel: complete-data launches of wide-band
+    # subcontigs, and (its SPARSE instantiation) launches whose rows have a few missing calls
+    kernel = (("pair_mfma_tile4_kernel" if four_tiles else "pair_mfma_general_kernel") if general else (("pair_mfma_wide_kernel<SPARSE>" if c.get("sparse_tile_launches", 0) > 0 else "pair_mfma_wide_kernel") if wide else "pair_mfma_kernel")) if on_matrix_pipe else ("pair_tiles_kernel<true>" if general else "pair_tiles_kernel<false>")
     kms = (kms_mfma + kms_gen) if on_matrix_pipe else kms_valu
     launches = max(int(c["pair_kernel_launches"]), 1)
     # MFMA side: instructions the kernel really issued.  One block product = 32 x 32 pairs; one k-step = one

@@ -143,6 +143,9 @@ typedef struct {
   uint32_t four_tile_launches;     /* launches of the last run whose tiles went to pair_mfma_tile4_kernel (wide bands, rows with missing
                                       calls, four-product form) */
   uint32_t decoded_in_place_rows; /* variant records ldp_load_pgen_records() decoded straight into the image (no scratch row, no copy) since ldp_create() */
+  uint32_t sparse_tile_launches;  /* launches of the last run whose 8 x 8 tiles ran on the route of rows with a FEW missing calls
+                                     (pair_mfma_wide_kernel's SPARSE instantiation: exact dot product, interval epilogue) */
+  uint32_t reserved0;
 } ldp_counters;
 
 /* ---- lifecycle ---- */

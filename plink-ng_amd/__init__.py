@@ -79,7 +79,7 @@ class ldp_counters(ctypes.Structure):
                 ("route_complete_launches", ctypes.c_uint32), ("route_sparse_launches", ctypes.c_uint32),
                 ("route_general_launches", ctypes.c_uint32), ("wide_tiles", ctypes.c_uint32),
                 ("mfma_extra_product_stages", ctypes.c_uint64), ("four_tile_launches", ctypes.c_uint32),
-                ("decoded_in_place_rows", ctypes.c_uint32)]
+                ("decoded_in_place_rows", ctypes.c_uint32), ("sparse_tile_launches", ctypes.c_uint32), ("reserved0", ctypes.c_uint32)]
 
     def asdict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -200,6 +200,8 @@ struct PairKernelArgs {
   const MfmaTile* wd_tiles_plain;
   uint32_t n_wd_tiles_plain;
   uint32_t wd_async;             // the tiles run on pair_mfma_wide_async_kernel (no workgroup barrier in the stage loop; EngineOptions::wide_async)
+  uint32_t wd_sparse;            // the tiles also own the launch on the kRouteSparse route (pair_mfma_wide_kernel<., SPARSE>; EngineOptions::wide_sparse):
+                                 // pair_mfma_kernel<., SPARSE = true> then skips the workgroups of their subcontigs as the complete-data kernel does
 };
 
 constexpr uint32_t kRouteComplete = 0, kRouteSparse = 1, kRouteGeneral = 2;
@@ -327,7 +329,8 @@ struct XWeightedArgs {
 };
 hipError_t launch_x_weighted(const XWeightedArgs& a, hipStream_t stream);
 // the wide-band tiles of the launch (complete-data route); queued between ev[0] and ev[1] of launch_pair_mfma by the caller's order
-hipError_t launch_pair_wide(const PairKernelArgs& a, hipStream_t stream);
+// (sparse: the SPARSE instantiation -- the same tiles on the route of launches whose rows have a few missing calls)
+hipError_t launch_pair_wide(const PairKernelArgs& a, hipStream_t stream, bool sparse = false);
 uint32_t pair_mfma_ksteps(uint32_t founder_ct);  // 64-sample k-steps per row (the unit of counters[2])
 
 // LDS rows of a work item that stages `units` 8-distance units starting at distance d0 (make_geom in the kernel)

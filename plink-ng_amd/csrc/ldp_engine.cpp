@@ -298,6 +298,8 @@ EngineOptions options_from_env() {
   o.pair_four = !(four && (strcmp(four, "0") == 0));
   const char* ft = LDP_ENV("LDP_PAIR_FOUR_TILES");
   o.four_tiles = !(ft && (strcmp(ft, "0") == 0));
+  const char* ws = LDP_ENV("LDP_WIDE_SPARSE");
+  o.wide_sparse = !(ws && (strcmp(ws, "0") == 0));
   const char* dl = LDP_ENV("LDP_DEBUG_WIDE_DIAG_LAST");
   o.wide_diag_last = dl ? static_cast<uint32_t>(std::max(0, atoi(dl))) : 2u;
   if (const char* wa = LDP_ENV("LDP_DEBUG_WIDE_ASYNC")) {
@@ -1538,6 +1540,8 @@ int ldp_debug_set_option(ldp_engine* e, const char* name, double value) {
     e->opt.sparse_frac = value;
   } else if (n == "wide_async") {
     e->opt.wide_async = (value != 0.0);
+  } else if (n == "wide_sparse") {
+    e->opt.wide_sparse = (value != 0.0);
   } else if (n == "replay_steps") {
     e->opt.replay_steps = static_cast<uint32_t>(std::max(0.0, value));
   } else if (n == "decode_rows") {

@@ -168,6 +168,7 @@ struct EngineOptions {
   bool pair_gu = true;        // option "pair_gu" 0: the four-product form multiplies x and n (rounds 2-3) instead of allele counts and missing flags
   bool four_tiles = true;     // LDP_PAIR_FOUR_TILES=0: the four-product form stays on the parallelogram plan in wide bands too
   uint32_t wide_diag_last = 2; // LDP_DEBUG_WIDE_DIAG_LAST=k: tiles fewer than k tile distances from the diagonal run at the end of their XCD stream (0: plain J order)
+  bool wide_sparse = true;     // LDP_WIDE_SPARSE=0 / option "wide_sparse" 0: launches with a few missing calls leave the 8 x 8 tiles for the parallelogram plan (rounds 2-5)
   bool wide_async = false;     // option "wide_async": the 8 x 8 tiles on pair_mfma_wide_async_kernel (flags instead of a workgroup barrier per stage)
   // test hooks (ldp_debug_set_option only; 0 = off): results never depend on them
   uint32_t replay_steps = 0;   // "replay_steps" k: ldp_debug_replay_pairs() walks every subcontig in k instalments, as the streaming replay of a run does
@@ -229,6 +230,7 @@ struct ldp_engine {
     uint32_t wd_first = 0, wd_ct = 0;    // ... and as wide-band tiles (wd_tiles)
     uint32_t wl_first = 0, wl_ct = 0;    // ... in launch order (wd_launch: eight XCD streams, padded to equal length)
     bool four_tiles = false;             // the group's last launch queued pair_mfma_tile4_kernel for them
+    bool sparse_tiles = false;           // ... and pair_mfma_wide_kernel<., SPARSE> (the tiles on the route of rows with a few missing calls)
     bool launched = false;
     hipEvent_t ev_ready = nullptr;
     hipEvent_t ev_done = nullptr;         // kernels finished and the group's predicate words are back on the host

@@ -352,6 +352,7 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.wd_tiles_plain = nullptr;
   A.n_wd_tiles_plain = 0;
   A.wd_async = e->opt.wide_async ? 1u : 0u;
+  A.wd_sparse = 0;
 }
 
 // A new load epoch begins (variants are being loaded again): whatever the pair streams still run belongs to the
@@ -431,6 +432,9 @@ int launch_group(ldp_engine* e, uint32_t gi) {
     // prune launches over rows with missing calls: the four-product form takes the tile plan's subcontigs in quarter tiles
     A.wd_general = (A.mf_four && e->opt.four_tiles && !A.stats && !A.r2_out && !A.r2_hits && A.n_wd_tiles) ? 1u : 0u;
     g.four_tiles = (A.wd_general != 0);
+    // ... and launches whose rows have only a few: the tiles' SPARSE instantiation
+    A.wd_sparse = (A.sparse_ok && e->opt.wide_sparse && A.n_wd_tiles) ? 1u : 0u;
+    g.sparse_tiles = (A.wd_sparse != 0);
   }
   hipError_t krc = launch_pair_tiles(A, e->max_rows, ps, g.ev);
   if (krc != hipSuccess) {
@@ -679,7 +683,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   kms = kms_fast + kms_general + kms_mfma + kms_mfma_general;
   // which matrix-pipe kernel route_kernel gave each launch of this run (deterministic evidence of the path taken)
   uint32_t route_ct[3] = {0, 0, 0};
-  uint32_t four_tile_launches = 0;
+  uint32_t four_tile_launches = 0, sparse_tile_launches = 0;
   if (e->mf_enabled && !e->mf_wgs.empty()) {
     const uint32_t* h_route = reinterpret_cast<const uint32_t*>(e->h_counters_pin + 4);
     if (stats) {
@@ -689,6 +693,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
         if (e->groups[gi].mf_ct) {
           ++route_ct[std::min<uint32_t>(h_route[gi], 2)];
           four_tile_launches += ((h_route[gi] >= 2) && e->groups[gi].four_tiles) ? 1u : 0u;
+          sparse_tile_launches += ((h_route[gi] == 1) && e->groups[gi].sparse_tiles) ? 1u : 0u;
         }
       }
     }
@@ -730,6 +735,7 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
   e->ctr.route_sparse_launches = route_ct[1];
   e->ctr.route_general_launches = route_ct[2];
   e->ctr.four_tile_launches = four_tile_launches;
+  e->ctr.sparse_tile_launches = sparse_tile_launches;
   e->ctr.ms_replay = replayed ? replay_busy_ms : (t_end - t_replay);  // (time spent replaying, not waiting for groups)
   e->ctr.ms_run_total = t_end - t_start;
   e->ctr.pair_kernel_launches = launches;

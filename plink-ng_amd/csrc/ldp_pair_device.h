@@ -148,5 +148,127 @@ __device__ __forceinline__ bool pair_hopeless(const PairKernelArgs& A, const uin
   return bound < gi.b * gj.b;
 }
 
+
+// ---- rows with a few missing calls: what per-variant counts say about a pair's pairwise-complete statistics ----
+// x = 0 where a call is missing, so the product the matrix pipe accumulates in the +-2 coding is already the exact `dot` of
+// ComputeIndepPairwiseR2Components (plink2_ld.cc:699-723); open are nm, the two sums and the two sums of squares.  With a row's calls
+// split by value -- plus (x = +1), minus (x = -1), het (x = 0); nm0 = their total, M = N - nm0 its missing calls -- and (u, w, a) of
+// row i's plus / minus / het calls sitting on samples where row j is missing:
+//     nm = nm0_i - (u + w + a),   sum1 = S_i - u + w,   ssq1 = Q_i - u - w          (S = plus - minus, Q = plus + minus)
+// with 0 <= u <= min(M_j, plus_i), 0 <= w <= min(M_j, minus_i), 0 <= a <= min(M_j, het_i).  var1 = ssq1 nm - sum1^2 is multilinear
+// in (u, w, a) and falls in each of them over that whole box (d/du = -((het - a) + 4 (minus - w)), d/dw = -((het - a) + 4 (plus - u)),
+// d/da = -ssq1), so its minimum over the box is the far corner and its maximum the near one -- tighter than independent intervals
+// for the three sums exactly where those are widest (a rare allele: removing hom-major calls hardly moves the variance, and there
+// are few others to remove).  cov = dot nm - sum1 sum2 takes plain interval arithmetic over nm in [N - M_i - M_j, N - max(M_i, M_j)]
+// and the two sums' ranges.  Every quantity is an integer below 2^53 (N <= kMfMaxFounders), so the bounds are exact in FP64 until
+// the squares and the triple product of the comparison: 1e-9 relative slack + 1 covers those roundings and the reference's own.
+// All inputs in ONE orientation per row (dot's): the records' (major allele) in the epilogues, the image's at a checkpoint.
+struct SparseRow {
+  double nm0, plus, minus, het;
+};
+__device__ __forceinline__ SparseRow sparse_row_of(const ldp_variant_rec& r) {
+  SparseRow s;
+  s.nm0 = static_cast<double>(r.nm_ct);
+  s.plus = 0.5 * (static_cast<double>(r.ssq) + static_cast<double>(r.sum));
+  s.minus = 0.5 * (static_cast<double>(r.ssq) - static_cast<double>(r.sum));
+  s.het = static_cast<double>(r.nm_ct) - static_cast<double>(r.ssq);
+  return s;
+}
+// the whole-row cp_gen_slot of the count pass (calls, sum z, sum z^2 with z = 0 / 1 / 2 for codes 00 / 01 / 10): the image's orientation
+__device__ __forceinline__ SparseRow sparse_row_of(const cp_gen_slot& g) {
+  SparseRow s;
+  const double n2 = 0.5 * (static_cast<double>(g.zq_r) - static_cast<double>(g.zs_r));
+  s.nm0 = static_cast<double>(g.nm_r);
+  s.het = static_cast<double>(g.zs_r) - 2.0 * n2;
+  s.minus = n2;
+  s.plus = s.nm0 - s.het - n2;
+  return s;
+}
+// dot is known to lie in [d_lo, d_hi] (integers; equal in the epilogues).  Returns 0: the reference's predicate is false whatever the
+// open statistics are, 1: it is true, 2: open (the caller recounts the pair, or keeps it alive at a checkpoint).
+__device__ __forceinline__ int sparse_decide(double thresh, double N, double d_lo, double d_hi, const SparseRow& I, const SparseRow& J) {
+  const double Mi = N - I.nm0, Mj = N - J.nm0;
+  const double n_lo = fmax(N - Mi - Mj, 0.0), n_hi = fmin(I.nm0, J.nm0);
+  const double u1 = fmin(Mj, I.plus), w1 = fmin(Mj, I.minus), a1 = fmin(Mj, I.het);
+  const double u2 = fmin(Mi, J.plus), w2 = fmin(Mi, J.minus), a2 = fmin(Mi, J.het);
+  const double Si = I.plus - I.minus, Sj = J.plus - J.minus, Qi = I.plus + I.minus, Qj = J.plus + J.minus;
+  const double s1_lo = Si - u1, s1_hi = Si + w1, s2_lo = Sj - u2, s2_hi = Sj + w2;
+  // cov = dot nm - sum1 sum2
+  const double a_lo = fmin(d_lo * n_lo, d_lo * n_hi), a_hi = fmax(d_hi * n_lo, d_hi * n_hi);  // (nm >= 0)
+  const double p0 = s1_lo * s2_lo, p1 = s1_lo * s2_hi, p2 = s1_hi * s2_lo, p3 = s1_hi * s2_hi;
+  const double b_lo = fmin(fmin(p0, p1), fmin(p2, p3)), b_hi = fmax(fmax(p0, p1), fmax(p2, p3));
+  const double c_lo = a_lo - b_hi, c_hi = a_hi - b_lo;
+  const double c2_hi = fmax(c_lo * c_lo, c_hi * c_hi);
+  const double c2_lo = ((c_lo <= 0.0) && (c_hi >= 0.0)) ? 0.0 : fmin(c_lo * c_lo, c_hi * c_hi);
+  // var = ssq nm - sum^2: the far and the near corner of the box
+  const double f1 = Si - u1 + w1, f2 = Sj - u2 + w2;
+  const double v1_lo = fmax((Qi - u1 - w1) * (I.nm0 - u1 - w1 - a1) - f1 * f1, 0.0), v1_hi = Qi * I.nm0 - Si * Si;
+  const double v2_lo = fmax((Qj - u2 - w2) * (J.nm0 - u2 - w2 - a2) - f2 * f2, 0.0), v2_hi = Qj * J.nm0 - Sj * Sj;
+  const double rhs_lo = thresh * v1_lo * v2_lo, rhs_hi = thresh * v1_hi * v2_hi;
+  if (c2_lo > rhs_hi * (1.0 + 1e-9) + 1.0) {
+    return 1;
+  }
+  if (c2_hi * (1.0 + 1e-9) + 1.0 < rhs_lo) {
+    return 0;
+  }
+  return 2;
+}
+
+// the five pairwise-complete counts of (i, j) by the whole wave, from the two rows of the code image; every lane returns the
+// same tuple (dot is the caller's).  The integers are in major-allele orientation, like the records: si / sj = the rows'
+// ALT-major flags.
+__device__ __forceinline__ ldp_pair_stats_t wave_pair_counts(const PairKernelArgs& A, uint32_t i, uint32_t j, int32_t dot, uint32_t lane, bool alt_i, bool alt_j) {
+  // 16-byte loads, two per row in flight (a lone wave is latency-bound here)
+  const uint4* __restrict__ r1 = reinterpret_cast<const uint4*>(A.codes + static_cast<uint64_t>(i) * A.code_row_bytes);
+  const uint4* __restrict__ r2 = reinterpret_cast<const uint4*>(A.codes + static_cast<uint64_t>(j) * A.code_row_bytes);
+  const uint32_t n_quads = static_cast<uint32_t>(A.code_row_bytes / 16);
+  uint32_t c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0;
+  const uint4 pad = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);  // "missing": counts nothing
+  for (uint32_t q = lane; q < n_quads; q += 128) {
+    const uint32_t qb = q + 64;
+    const bool two = qb < n_quads;
+    const uint4 w1a = r1[q], w2a = r2[q];
+    uint4 w1b = r1[two ? qb : q], w2b = r2[two ? qb : q];
+    if (!two) {
+      w1b = pad;
+      w2b = pad;
+    }
+    // sixteen samples per dword at the even bit positions: h = homozygous, p = hom-REF (x = +1), n = call present
+#define LDP_SPARSE_COUNT(W1, W2)                                                                  \
+  {                                                                                               \
+    const uint32_t h1 = ~(W1) & 0x55555555u, h2 = ~(W2) & 0x55555555u;                             \
+    const uint32_t p1 = h1 & ~((W1) >> 1), p2 = h2 & ~((W2) >> 1);                                 \
+    const uint32_t n1 = ~((W1) & ((W1) >> 1)) & 0x55555555u, n2 = ~((W2) & ((W2) >> 1)) & 0x55555555u; \
+    c2 += __popc(n1 & n2);                                                                        \
+    c3 += __popc(n1 & h2);                                                                        \
+    c4 += __popc(n1 & p2);                                                                        \
+    c5 += __popc(n2 & h1);                                                                        \
+    c6 += __popc(n2 & p1);                                                                        \
+  }
+    LDP_SPARSE_COUNT(w1a.x, w2a.x)
+    LDP_SPARSE_COUNT(w1a.y, w2a.y)
+    LDP_SPARSE_COUNT(w1a.z, w2a.z)
+    LDP_SPARSE_COUNT(w1a.w, w2a.w)
+    LDP_SPARSE_COUNT(w1b.x, w2b.x)
+    LDP_SPARSE_COUNT(w1b.y, w2b.y)
+    LDP_SPARSE_COUNT(w1b.z, w2b.z)
+    LDP_SPARSE_COUNT(w1b.w, w2b.w)
+#undef LDP_SPARSE_COUNT
+  }
+  c2 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c2));  // (the sum lands in lane 0)
+  c3 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c3));  // (the sum lands in lane 0)
+  c4 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c4));  // (the sum lands in lane 0)
+  c5 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c5));  // (the sum lands in lane 0)
+  c6 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c6));  // (the sum lands in lane 0)
+  ldp_pair_stats_t st;
+  st.nm = c2;
+  st.ssq2 = c3;
+  st.sum2 = static_cast<int32_t>(2 * c4 - c3) * (alt_j ? -1 : 1);
+  st.ssq1 = c5;
+  st.sum1 = static_cast<int32_t>(2 * c6 - c5) * (alt_i ? -1 : 1);
+  st.dot = dot;
+  return st;
+}
+
 }  // namespace ldp
 #endif

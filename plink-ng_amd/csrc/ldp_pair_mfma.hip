@@ -258,61 +258,7 @@ __device__ __forceinline__ int classify_sparse(const PairKernelArgs& A, double d
   return 2;
 }
 
-// the five pairwise-complete counts of (i, j) by the whole wave, from the two rows of the code image; every lane returns the
-// same tuple (dot is the caller's).  The integers are in major-allele orientation, like the records: si / sj = the rows'
-// ALT-major flags.
-__device__ __forceinline__ ldp_pair_stats_t wave_pair_counts(const PairKernelArgs& A, uint32_t i, uint32_t j, int32_t dot, uint32_t lane, bool alt_i, bool alt_j) {
-  // 16-byte loads, two per row in flight (a lone wave is latency-bound here)
-  const uint4* __restrict__ r1 = reinterpret_cast<const uint4*>(A.codes + static_cast<uint64_t>(i) * A.code_row_bytes);
-  const uint4* __restrict__ r2 = reinterpret_cast<const uint4*>(A.codes + static_cast<uint64_t>(j) * A.code_row_bytes);
-  const uint32_t n_quads = static_cast<uint32_t>(A.code_row_bytes / 16);
-  uint32_t c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0;
-  const uint4 pad = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);  // "missing": counts nothing
-  for (uint32_t q = lane; q < n_quads; q += 128) {
-    const uint32_t qb = q + 64;
-    const bool two = qb < n_quads;
-    const uint4 w1a = r1[q], w2a = r2[q];
-    uint4 w1b = r1[two ? qb : q], w2b = r2[two ? qb : q];
-    if (!two) {
-      w1b = pad;
-      w2b = pad;
-    }
-    // sixteen samples per dword at the even bit positions: h = homozygous, p = hom-REF (x = +1), n = call present
-#define LDP_SPARSE_COUNT(W1, W2)                                                                  \
-  {                                                                                               \
-    const uint32_t h1 = ~(W1) & 0x55555555u, h2 = ~(W2) & 0x55555555u;                             \
-    const uint32_t p1 = h1 & ~((W1) >> 1), p2 = h2 & ~((W2) >> 1);                                 \
-    const uint32_t n1 = ~((W1) & ((W1) >> 1)) & 0x55555555u, n2 = ~((W2) & ((W2) >> 1)) & 0x55555555u; \
-    c2 += __popc(n1 & n2);                                                                        \
-    c3 += __popc(n1 & h2);                                                                        \
-    c4 += __popc(n1 & p2);                                                                        \
-    c5 += __popc(n2 & h1);                                                                        \
-    c6 += __popc(n2 & p1);                                                                        \
-  }
-    LDP_SPARSE_COUNT(w1a.x, w2a.x)
-    LDP_SPARSE_COUNT(w1a.y, w2a.y)
-    LDP_SPARSE_COUNT(w1a.z, w2a.z)
-    LDP_SPARSE_COUNT(w1a.w, w2a.w)
-    LDP_SPARSE_COUNT(w1b.x, w2b.x)
-    LDP_SPARSE_COUNT(w1b.y, w2b.y)
-    LDP_SPARSE_COUNT(w1b.z, w2b.z)
-    LDP_SPARSE_COUNT(w1b.w, w2b.w)
-#undef LDP_SPARSE_COUNT
-  }
-  c2 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c2));  // (the sum lands in lane 0)
-  c3 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c3));  // (the sum lands in lane 0)
-  c4 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c4));  // (the sum lands in lane 0)
-  c5 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c5));  // (the sum lands in lane 0)
-  c6 = __builtin_amdgcn_readfirstlane(wave_reduce_add(c6));  // (the sum lands in lane 0)
-  ldp_pair_stats_t st;
-  st.nm = c2;
-  st.ssq2 = c3;
-  st.sum2 = static_cast<int32_t>(2 * c4 - c3) * (alt_j ? -1 : 1);
-  st.ssq1 = c5;
-  st.sum1 = static_cast<int32_t>(2 * c6 - c5) * (alt_i ? -1 : 1);
-  st.dot = dot;
-  return st;
-}
+// (wave_pair_counts: ldp_pair_device.h -- the tile kernel's interval epilogue recounts its open pairs the same way)
 
 // One round (the four products of one J block, already dumped to this wave's LDS scratch).
 __device__ __forceinline__ uint32_t sparse_round(const PairKernelArgs& A, const uint32_t* epi, uint32_t lane, int32_t jv, int32_t vv, uint32_t jend,
@@ -411,7 +357,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   const MfmaWG* __restrict__ wg = A.mf_wgs + item_idx;
   {
     const uint32_t kind = wg->pad;
-    if ((!SPARSE) && A.wd_active && (kind & 1u)) {
+    if (A.wd_active && (kind & 1u) && ((!SPARSE) || A.wd_sparse)) {
       return;  // a subcontig with a wide band: its complete-data launches belong to pair_mfma_wide_kernel's tiles (ldp_pair_wide.hip)
     }
     if (((kind & 2u) != 0) != DIAGFORM) {
@@ -1920,6 +1866,12 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
     }
     if (n_rest) {
       hipLaunchKernelGGL((pair_mfma_kernel<4, true, false>), dim3(((n_rest + 7) / 8) * 8), dim3(kMfWaves * 64), lds, stream, ar);
+    }
+    if (a.wd_active && a.wd_sparse) {
+      const hipError_t wrc = launch_pair_wide(a_in, stream, true);  // ... and the wide-band subcontigs' tiles on that route
+      if (wrc != hipSuccess) {
+        return wrc;
+      }
     }
   }
   if (ev) {

@@ -46,7 +46,12 @@ constexpr uint32_t kWdEpiWaveDwords = 4 * 16 * 64;                    // four pr
 constexpr uint32_t kWdLdsDwords = kWdWaves * kWdEpiWaveDwords;        // 128 KiB: epilogue scratch == two-stage ring
 constexpr uint32_t kWdCpWaveDwords = 2 * 16 * 64;                     // checkpoint: two products per wave and round
 constexpr uint32_t kWdCpScratchDwords = kWdWaves * kWdCpWaveDwords;   // 64 KiB in; 16 row-blocks x 32 rows x 32 B = 16 KiB follow
+constexpr uint32_t kWdCpSlotDwords = kWdRowBlocks * kMfBlock * 8;     // two cp_slots per staged row: 16 KiB
+constexpr uint32_t kWdCpGenDwords = kWdRowBlocks * kMfBlock * 4;      // SPARSE: + the whole-row cp_gen_slot of every staged row (8 KiB) ...
+constexpr uint32_t kWdCpRowDwords = kWdRowBlocks * kMfBlock * 8;      // ... and the SparseRow made of it (16 KiB)
 static_assert(kWdStageDwords * kWdMaxStages <= kWdLdsDwords, "ring fits the epilogue scratch");
+static_assert(kWdCpScratchDwords + kWdCpSlotDwords + kWdCpGenDwords + kWdCpRowDwords <= kWdLdsDwords, "checkpoint scratch fits");
+static_assert(sizeof(SparseRow) == 32 && sizeof(cp_gen_slot) == 16 && sizeof(cp_slot) == 16, "LDS layouts of the checkpoint");
 __device__ __forceinline__ uint32_t wd_swizzle(uint32_t row) { return (row >> 1) & 7u; }
 
 // One HALF-stage (256 samples) of a wave's 2 x 4 rectangle: J fragments of all four k-steps in registers, the four V blocks streamed past them
@@ -64,7 +69,9 @@ __device__ __forceinline__ uint32_t wd_swizzle(uint32_t row) { return (row >> 1)
 // waves run free), bit 4 (16) = no per-pair epilogue, bit 5 (32) = time stamps around the phases of every wave (results right:
 // where the cycles go), summed into g_wide_measure, bit 6 (64) = every tile stages the same 512 rows (wrong results; all of the DMA's
 // requests hit the L2: what the HBM leg of the traffic costs).
-template <int ABL>
+// GC: the allele-count coding of complete rows (ldp_mfma_device.h); false: the +-2 coding, where a missing call is 0 and the
+// accumulators hold the exact dot product (the SPARSE instantiation below)
+template <int ABL, bool GC = true>
 __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const uint32_t (&joff)[2], const uint32_t (&voff)[4], uint32_t oH, uint32_t oR,
                                            mf_v16f (&acc)[8]) {
   if constexpr ((ABL & 4) != 0) {
@@ -83,7 +90,7 @@ __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const 
       if ((ABL & 2) && ks) {
         fj0[ks] = fj0[0];
       } else {
-        fp4_expand<true>(H[ks], R[ks], fj0[ks]);
+        fp4_expand<GC>(H[ks], R[ks], fj0[ks]);
       }
     }
   }
@@ -95,7 +102,7 @@ __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const 
       if ((ABL & 2) && ks) {
         fj1[ks] = fj1[0];
       } else {
-        fp4_expand<true>(H[ks], R[ks], fj1[ks]);
+        fp4_expand<GC>(H[ks], R[ks], fj1[ks]);
       }
     }
   }
@@ -112,10 +119,10 @@ __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const 
     if ((ABL & 2) && ks) {                                     \
       fv = fj1[(ks + (b)) & 3];                                \
     } else {                                                   \
-      fp4_expand<true>(vH[B][ks], vR[B][ks], fv);              \
+      fp4_expand<GC>(vH[B][ks], vR[B][ks], fv);              \
     }                                                          \
-    acc[b] = mfma_pair<true>(fv, fj0[ks], acc[b]);                    \
-    acc[4 + (b)] = mfma_pair<true>(fv, fj1[ks], acc[4 + (b)]);        \
+    acc[b] = mfma_pair<GC>(fv, fj0[ks], acc[b]);                    \
+    acc[4 + (b)] = mfma_pair<GC>(fv, fj1[ks], acc[4 + (b)]);        \
   }
   LDP_WD_VBLOCK(0, 0)
   LDP_WD_VBLOCK(1, 1)
@@ -177,12 +184,88 @@ __device__ __forceinline__ uint32_t wide_slots_needed(uint32_t live, uint32_t a0
   return live ? ((3u << a0) | (0xfu << vslot0)) : 0u;
 }
 
-template <int ABL>
+// The SPARSE instantiation's epilogue for one J block of a wave's rectangle: its (up to) four products are in this wave's LDS scratch,
+// product pl = (the J block, V block pl), `jb` / `vb` = first variant of the J block / of V block 0, live4 = which of them hold
+// candidate pairs that are still alive.  Per pair: sparse_decide on the exact dot product and the two records; the pairs it leaves
+// open one after the other, each by the whole wave, from the two rows of the image (ldp_counters::sparse_exact_pairs counts them).
+__device__ __forceinline__ uint32_t wide_sparse_round(const PairKernelArgs& A, const uint32_t* epi, uint32_t lane, int32_t jb, int32_t vb, uint32_t jend, uint32_t live4,
+                                                      uint32_t lo_j) {
+  const uint32_t r = lane & 31, h = lane >> 5;
+  uint32_t n_true = 0, n_open = 0;
+  const int64_t j64 = static_cast<int64_t>(jb) + r;
+  const bool j_ok = (j64 < static_cast<int64_t>(jend)) && (static_cast<int64_t>(lo_j) < j64);
+  const uint32_t j = j_ok ? static_cast<uint32_t>(j64) : 0u;
+  ldp_variant_rec rj;
+  rj.nm_ct = 0;
+  rj.sum = 0;
+  rj.ssq = 0;
+  rj.flags = 0;
+  if (j_ok) {
+    rj = A.recs[j];
+  }
+  const SparseRow Jr = sparse_row_of(rj);
+  const double n_all = static_cast<double>(A.founder_ct);
+#pragma unroll 1
+  for (uint32_t pl = 0; pl < 4; ++pl) {
+    if (!(live4 & (1u << pl))) {
+      continue;  // (wave-uniform)
+    }
+    const int64_t vfirst = static_cast<int64_t>(vb) + kMfBlock * pl + 4 * h;
+#pragma unroll 1
+    for (uint32_t g = 0; g < 16; ++g) {
+      const int64_t i64 = vfirst + (g & 3) + 8 * (g >> 2);
+      const bool valid = j_ok && (i64 >= static_cast<int64_t>(lo_j)) && (i64 < j64);
+      const uint32_t i = valid ? static_cast<uint32_t>(i64) : 0u;
+      int32_t dot = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]);
+      int cls = 0;
+      uint32_t alt_ij = 0;  // bit 0: row i is ALT-major, bit 1: row j
+      if (valid) {
+        const ldp_variant_rec ri = A.recs[i];
+        alt_ij = (ri.flags & 1u) | ((rj.flags & 1u) << 1);
+        dot = ((alt_ij == 1u) || (alt_ij == 2u)) ? -dot : dot;  // the image's orientation -> the records' (major allele)
+        const double d = static_cast<double>(dot);
+        cls = sparse_decide(A.thresh, n_all, d, d, sparse_row_of(ri), Jr);
+        if (cls == 1) {
+          atomicOr(&A.pred[A.row_off[j] + ((i >> 5) - (lo_j >> 5))], 1u << (i & 31));
+          ++n_true;
+        }
+      }
+      unsigned long long open = __ballot(cls == 2);
+      while (open) {
+        const int l = __builtin_ctzll(open);
+        open &= open - 1;
+        const uint32_t ii = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(i), l));
+        const uint32_t jj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(j), l));
+        const int32_t dd = __builtin_amdgcn_readlane(dot, l);
+        const uint32_t aa = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(alt_ij), l));
+        const ldp_pair_stats_t st = wave_pair_counts(A, ii, jj, dd, lane, (aa & 1u) != 0, (aa & 2u) != 0);
+        if ((static_cast<int>(lane) == l) && exceeds(st, A.thresh)) {
+          atomicOr(&A.pred[A.row_off[j] + ((i >> 5) - (lo_j >> 5))], 1u << (i & 31));
+          ++n_true;
+        }
+        n_open += (lane == 0) ? 1u : 0u;
+      }
+    }
+  }
+  if ((lane == 0) && n_open) {
+    atomicAdd(A.counters + 3, static_cast<unsigned long long>(n_open));
+  }
+  return n_true;
+}
+
+// SPARSE: the instantiation that owns the tiles of launches whose rows have a FEW missing calls (route kRouteSparse, DESIGN.md 4.1d;
+// the reference's per-pair dispatch between DotprodWords / SumSsqWords / SumSsqNmWords, plink2_ld.cc:699-723, seen from the fast plan):
+// the +-2 coding, so the one product per block is the exact `dot` with missing calls in it; checkpoints that bound the pair from the
+// partial dot product AND what the two rows' missing calls can move (sparse_decide with the dot product's Cauchy-Schwarz interval); an
+// epilogue that decides a pair from per-variant counts where the intervals allow and recounts the few pairs they leave open from the
+// two rows (wave_pair_counts) -- no approximation reaches the output.  A kernel of its own (template parameter) because hipcc
+// re-allocates the complete-data kernel's registers as soon as the interval code shares a function with it.
+template <int ABL, bool SPARSE = false>
 __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKernelArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_need[kWdWaves];
-  if (*A.route != kRouteComplete) {
-    return;  // rows with missing calls: the parallelogram plan's kernels own the launch (ldp_pair_mfma.hip)
+  if (*A.route != (SPARSE ? kRouteSparse : kRouteComplete)) {
+    return;  // complete rows / a few missing calls / many: one kernel family owns a launch (route_kernel); the others leave at once
   }
   const uint32_t per_xcd = (A.n_wd_tiles + 7) / 8;
   const uint32_t idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // consecutive tiles on one XCD
@@ -208,7 +291,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
     return;  // (padding of an XCD's stream: the launch's streams are of equal length, ldp_engine.cpp build_shard)
   }
   const bool diag = (jv0 == vv0);
-  const int32_t g_bias = g_bias_of(A.founder_ct, kWdStageSamples);
+  [[maybe_unused]] const int32_t g_bias = g_bias_of(A.founder_ct, kWdStageSamples);
   const uint32_t row_bytes = static_cast<uint32_t>(A.code_row_bytes);
   const uint32_t n_stages = (A.founder_ct + kWdStageSamples - 1) / kWdStageSamples;  // (the image's rows are whole stages long: ldp_device.h)
   const uint32_t stage_dwords = kWdStageDwords;
@@ -370,8 +453,8 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
           wide_stage_kept<ABL>(keptR, keptH, acc);
         }
       } else if (live) {
-        wide_stage<ABL>(st4, joff, voff, oH0, oR0, acc);
-        wide_stage<ABL>(st4, joff, voff, oH1, oR1, acc);
+        wide_stage<ABL, !SPARSE>(st4, joff, voff, oH0, oR0, acc);
+        wide_stage<ABL, !SPARSE>(st4, joff, voff, oH1, oR1, acc);
       }
 #ifdef LDP_MEASURE
       if constexpr ((ABL & 32) != 0) {
@@ -404,6 +487,17 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
                                            (__attribute__((address_space(3))) void*)(lds + kWdCpScratchDwords + T * 256), 16, 0, 0);
         }
       }
+      if constexpr (SPARSE) {
+        // ... and the whole-row cp_gen_slot (calls, sum z, sum z^2: the row's calls by value) of the rows of row-block slots 2 wave, + 1
+        const uint32_t T = 2 * wave + (lane >> 5);
+        uint32_t first = static_cast<uint32_t>(slot_first(T));
+        first = (first < A.n_local) ? first : (A.n_local - 1);
+        uint32_t var = first + (lane & 31);
+        var = (var < A.n_local) ? var : (A.n_local - 1);
+        const uint64_t off = static_cast<uint64_t>(var) * (kCpStride * sizeof(cp_slot)) + kCpSlots * sizeof(cp_slot);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cps + off),
+                                         (__attribute__((address_space(3))) void*)(lds + kWdCpScratchDwords + kWdCpSlotDwords + wave * 256), 16, 0, 0);
+      }
     }
     __syncthreads();  // (drains the DMA: the slots are in LDS)
     const cp_slot* __restrict__ cpl = reinterpret_cast<const cp_slot*>(lds + kWdCpScratchDwords);  // [row-block slot][row][2]
@@ -413,7 +507,16 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
     // samples visited, no padding among them: a checkpoint sits in front of the last k-chunk).  One integer per staged row, behind the slots.
     int32_t* __restrict__ sp = reinterpret_cast<int32_t*>(lds + kWdCpScratchDwords + kWdRowBlocks * kMfBlock * 8);
     const int32_t cp_seen = static_cast<int32_t>(kc * kWdStageSamples);
-    {
+    // SPARSE: one SparseRow per staged row (its calls by value, the image's orientation) instead: the accumulators hold the partial
+    // dot product itself
+    SparseRow* __restrict__ srow = reinterpret_cast<SparseRow*>(lds + kWdCpScratchDwords + kWdCpSlotDwords + kWdCpGenDwords);
+    if constexpr (SPARSE) {
+      const cp_gen_slot* __restrict__ genl = reinterpret_cast<const cp_gen_slot*>(lds + kWdCpScratchDwords + kWdCpSlotDwords);
+      for (uint32_t q = tid; q < kWdRowBlocks * kMfBlock; q += kWdWaves * 64) {
+        srow[q] = sparse_row_of(genl[q]);
+      }
+      __syncthreads();
+    } else {
       const double n_all = static_cast<double>(A.founder_ct);
       const double kappa = sqrt(((static_cast<double>(cp_seen) < n_all) ? (n_all - static_cast<double>(cp_seen)) : 1.0) / n_all);
       for (uint32_t q = tid; q < kWdRowBlocks * kMfBlock; q += kWdWaves * 64) {
@@ -444,7 +547,11 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
         const uint32_t jslot = a0 + q;
         const cp_slot cj = cpl[(jslot * kMfBlock + r) * 2];
         const cp_slot gj = cpl[(jslot * kMfBlock + r) * 2 + 1];
-        const int32_t tj = sp[jslot * kMfBlock + r] - cp_seen;
+        const int32_t tj = SPARSE ? 0 : (sp[jslot * kMfBlock + r] - cp_seen);
+        SparseRow Jr;
+        if constexpr (SPARSE) {
+          Jr = srow[jslot * kMfBlock + r];
+        }
 #pragma unroll 1
         for (uint32_t pl = 0; pl < 2; ++pl) {
           const uint32_t p = 2 * round + pl;
@@ -460,12 +567,22 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
             const int64_t i64 = static_cast<int64_t>(vv0) + kMfBlock * (b0 + b) + row;
             if ((i64 >= lo_j) && (i64 < j64)) {
               const cp_slot ci = cpl[(vslot * kMfBlock + row) * 2];
-              const cp_slot gi = cpl[(vslot * kMfBlock + row) * 2 + 1];
-              // |N dot - S_i S_j| <= |c0| + B, see pair_hopeless() in ldp_pair_device.h (dot_p is the partial dot product)
-              const double dot_p = static_cast<double>(static_cast<int32_t>(cp_epi[(pl * 16 + g) * 64 + lane]) + tj + sp[vslot * kMfBlock + row]);
-              const double c0 = fma(static_cast<double>(A.founder_ct), dot_p, fma(ci.a, cj.a, -(gi.a * gj.a)));
-              const double bound = fabs(c0) + fma(ci.b, cj.b, 1.0);
-              hopeless = hopeless && (bound < gi.b * gj.b);
+              if constexpr (SPARSE) {
+                // N dot lies within B = b_i b_j of N dot_p + a_i a_j (Cauchy-Schwarz on the remainders of x with 0 at a missing call: the
+                // count pass's slots as they are); dot is an integer, and the +- 1 covers the slots' own rounding (ldp_pair_device.h)
+                const double n_all = static_cast<double>(A.founder_ct);
+                const double mid = fma(n_all, static_cast<double>(static_cast<int32_t>(cp_epi[(pl * 16 + g) * 64 + lane])), ci.a * cj.a);
+                const double wid = fma(ci.b, cj.b, 1.0);
+                const double d_lo = floor((mid - wid) / n_all), d_hi = ceil((mid + wid) / n_all);
+                hopeless = hopeless && (sparse_decide(A.thresh, n_all, d_lo, d_hi, srow[vslot * kMfBlock + row], Jr) == 0);
+              } else {
+                const cp_slot gi = cpl[(vslot * kMfBlock + row) * 2 + 1];
+                // |N dot - S_i S_j| <= |c0| + B, see pair_hopeless() in ldp_pair_device.h (dot_p is the partial dot product)
+                const double dot_p = static_cast<double>(static_cast<int32_t>(cp_epi[(pl * 16 + g) * 64 + lane]) + tj + sp[vslot * kMfBlock + row]);
+                const double c0 = fma(static_cast<double>(A.founder_ct), dot_p, fma(ci.a, cj.a, -(gi.a * gj.a)));
+                const double bound = fabs(c0) + fma(ci.b, cj.b, 1.0);
+                hopeless = hopeless && (bound < gi.b * gj.b);
+              }
             }
           }
           if (!__all(hopeless)) {
@@ -546,6 +663,11 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
           epi[(pl * 16 + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>((round ? acc[4 + pl] : acc[pl])[g]));
         }
       }
+    }
+    if constexpr (SPARSE) {
+      n_true += wide_sparse_round(A, epi, lane, jv0 + static_cast<int32_t>(kMfBlock * (a0 + round)), vv0 + static_cast<int32_t>(kMfBlock * b0), jend,
+                                  (live >> (4 * round)) & 0xfu, lo_j2[round]);
+      continue;
     }
     const int64_t j64 = static_cast<int64_t>(jv0) + kMfBlock * (a0 + round) + r;
     if (j64 < static_cast<int64_t>(jend)) {
@@ -1103,7 +1225,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_async_kernel(
 
 }  // namespace
 
-hipError_t launch_pair_wide(const PairKernelArgs& a_in, hipStream_t stream) {
+hipError_t launch_pair_wide(const PairKernelArgs& a_in, hipStream_t stream, bool sparse) {
   if (!a_in.n_wd_tiles) {
     return hipSuccess;
   }
@@ -1112,6 +1234,14 @@ hipError_t launch_pair_wide(const PairKernelArgs& a_in, hipStream_t stream) {
   a.lds_dwords = static_cast<uint32_t>(lds / sizeof(uint32_t));
   const uint32_t per_xcd = (a.n_wd_tiles + 7) / 8;
   const dim3 grid(per_xcd * 8), block(kWdWaves * 64);
+  if (sparse) {
+    // the same tiles for launches whose rows have a few missing calls (route kRouteSparse; always the barrier kernel)
+    static const bool sparse_attr_set =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_wide_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) == hipSuccess;
+    (void)sparse_attr_set;
+    hipLaunchKernelGGL((pair_mfma_wide_kernel<0, true>), grid, block, lds, stream, a);
+    return hipGetLastError();
+  }
 #ifdef LDP_MEASURE
   // LDP_DEBUG_WIDE_ABLATE (measurement build only; bits 0-3 give WRONG results): see wide_stage.  Read at every launch.
   const char* v = LDP_ENV("LDP_DEBUG_WIDE_ABLATE");

@@ -371,25 +371,103 @@ def test_wide_band_tiles_match_oracle(gpu_pkg, case):
     eng.close()
 
 
-def test_wide_band_with_missing_calls_falls_back_to_the_parallelogram_kernels(gpu_pkg):
-    """The tile kernel takes complete-data launches only; rows with missing calls send the launch to the interval epilogue or the
-    six-product kernel over the parallelogram plan of the same subcontigs."""
+def test_wide_band_with_missing_calls_keeps_the_tile_plan(gpu_pkg):
+    """Wide-band subcontigs keep their 8 x 8 tile plan whatever the rows miss: a few missing calls -> the tile kernel's SPARSE
+    instantiation (exact dot product, interval epilogue; ldp_counters.sparse_tile_launches says it ran), many -> the four-product form on
+    quarter tiles.  Option "wide_sparse" 0 restores rounds 2-5 (the interval epilogue over the parallelogram plan): same prune set."""
     pkg = gpu_pkg
     m, n = 800, 900
-    for miss, route in ((0.001, "route_sparse_launches"), (0.05, "route_general_launches")):
+    for miss, route, tiles in ((0.001, "route_sparse_launches", "sparse_tile_launches"), (0.05, "route_general_launches", "four_tile_launches")):
         raw = T.synth_raw_codes(m, n, 17, missing_rate=miss, ld_copy_prob=0.6, redraw=0.08)
         chr_idx = np.zeros(m, dtype=np.uint32)
         bps = np.arange(m, dtype=np.uint32)
         inv, mf, _ = T.oracle_prepare(raw)
         want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 450, 1, False, 0.3, 2)
-        eng = pkg.LdPruneEngine(n, 450, 1, False, 0.3, order=2, device=0)
-        eng.set_variants(chr_idx, None)
-        eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+        for ws in (1, 0):
+            eng = pkg.LdPruneEngine(n, 450, 1, False, 0.3, order=2, device=0)
+            eng.set_option("wide_sparse", ws)
+            eng.set_variants(chr_idx, None)
+            eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
+            got = eng.run()
+            c = eng.counters()
+            eng.close()
+            assert c["wide_tiles"] > 0 and c[route] > 0 and c["route_complete_launches"] == 0
+            assert (c[tiles] > 0) == bool(ws or tiles == "four_tile_launches")
+            assert np.array_equal(got, want)
+
+
+SPARSE_WIDE_CASES = [
+    # m, n, window, step, is_bp, r2, order, min_reach, miss, adversarial rows (rare variants with missing partners, rows that miss 7 %)
+    (1500, 20000, 600, 1, False, 0.2, 2, 12, 0.001, True),     # config 3's threshold; 19 row-blocks of reach, 40 stages
+    (1500, 30000, 600, 1, False, 0.2, 2, 12, 0.0005, False),   # ... and without the rows that keep every wave alive: checkpoints retire products
+    (1100, 6000, 1000, 1, False, 0.5, 2, 12, 0.003, True),     # the window is most of the chromosome: diagonal and far tiles, ragged last J tile
+    (1300, 9000, 400, 7, False, 0.5, 1, 12, 0.0003, False),    # count window with a step, --indep-order 1
+    (1000, 30000, 150000, 1, True, 0.3, 2, 6, 0.004, True),    # kb windows with gaps, close to the route's limit (0.5 % on average)
+    (700, 3000, 50, 5, False, 0.2, 2, 0, 0.002, True),         # a narrow band forced through the tiles (diagonal tiles only)
+    (520, 513, 519, 1, False, 0.1, 2, 0, 0.001, False),        # one window spans everything; two stages, no checkpoint
+]
+
+
+@pytest.mark.parametrize("case", SPARSE_WIDE_CASES)
+def test_wide_band_tiles_with_a_few_missing_calls(gpu_pkg, case):
+    """pair_mfma_wide_kernel's SPARSE instantiation (DESIGN 4.1d on the tile plan; the reference's per-pair dispatch, plink2_ld.cc:699-723):
+    same prune set and the same number of true predicates with early termination on and off, as the interval epilogue over the
+    parallelogram plan ("wide_sparse" 0), as the six-product kernel, and as the oracle -- with pairs that only become correlated in the
+    last 40 % of the samples, rare variants whose partners' missing calls sit on their carriers, complete rows and rows that miss 7 %."""
+    pkg = gpu_pkg
+    m, n, window, step, is_bp, r2, order, min_reach, miss, adversarial = case
+    rng = np.random.default_rng(n + m)
+    raw = T.synth_raw_codes(m, n, seed=n % 83 + 7, missing_rate=miss, ld_copy_prob=0.6, redraw=0.08)
+    cut = int(0.6 * n)
+    for v in range(40, m, 11):             # late LD with a variant 37 rows back (another row-block)
+        raw[v, :cut] = rng.permutation(raw[v, :cut])
+        raw[v, cut:] = raw[v - 37, cut:]
+    tail = np.arange(int(0.75 * n), n)
+    for v in (range(5, m - 40, 53) if adversarial else ()):   # a rare variant whose carriers come late; copies of it nearby and 33 rows on, missing on some of the carriers
+        raw[v] = 0
+        carriers = rng.choice(tail, size=min(30, len(tail)), replace=False)
+        raw[v, carriers] = 1
+        raw[v + 1] = raw[v]
+        raw[v + 1, carriers[:4]] = 3
+        raw[v + 33] = raw[v]
+        raw[v + 33, carriers[:12]] = 3
+    raw[rng.choice(m, size=30, replace=False)] = np.where(raw[3] == 3, 0, raw[3])[None, :]   # complete rows, in LD with each other
+    for v in (rng.choice(m, size=6, replace=False) if adversarial else ()):
+        raw[v, rng.random(n) < 0.07] = 3                                                    # a handful of rows far beyond the mean
+    chr_idx, bps = make_positions(m, 2, 47) if is_bp else (np.repeat(np.arange(2, dtype=np.uint32), (m + 1) // 2)[:m], None)
+    packed = T.pack_2bit(raw)
+
+    def run(options):
+        eng = pkg.LdPruneEngine(n, window, step, is_bp, r2, order=order, device=0)
+        eng.set_option("wide_min_reach", min_reach)
+        for name, value in options.items():
+            eng.set_option(name, value)
+        eng.set_variants(chr_idx, bps)
+        eng.load_genotypes_host(0, packed, pkg.LDP_GENO_REF)
         got = eng.run()
         c = eng.counters()
         eng.close()
-        assert c["wide_tiles"] > 0 and c[route] > 0 and c["route_complete_launches"] == 0
-        assert np.array_equal(got, want)
+        return got, c
+
+    on, c1 = run({})
+    off, c0 = run({"early_exit": 0})
+    plan, cp = run({"wide_sparse": 0})
+    six, c6 = run({"pair_sparse": 0, "pair_four": 0, "early_exit": 0})
+    for c in (c1, c0):
+        assert c["wide_tiles"] > 0 and c["sparse_tile_launches"] > 0 and c["route_sparse_launches"] > 0
+        assert c["route_general_launches"] == 0 and c["route_complete_launches"] == 0
+    assert cp["sparse_tile_launches"] == 0 and cp["route_sparse_launches"] > 0 and c6["route_general_launches"] > 0 and c6["sparse_tile_launches"] == 0
+    assert c0["mfma_skipped_product_stages"] == 0
+    assert np.array_equal(off, six) and c0["pred_true"] == c6["pred_true"] > 0
+    assert np.array_equal(plan, six) and cp["pred_true"] == c6["pred_true"]
+    assert np.array_equal(on, six) and c1["pred_true"] == c0["pred_true"]   # (a retired product's pairs are all false)
+    if (n >= 9000) and not adversarial:
+        assert c1["mfma_skipped_product_stages"] > 0
+    assert c1["sparse_exact_pairs"] < 0.2 * c1["candidate_pairs"]
+    if n <= 9000:
+        inv, mf, _ = T.oracle_prepare(raw)
+        want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps if bps is not None else np.arange(m, dtype=np.uint32), mf, window, step, is_bp, r2, order)
+        assert np.array_equal(on, want)
 
 
 _RCCL_ONE_RANK = r"""

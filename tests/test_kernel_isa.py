@@ -57,21 +57,32 @@ def test_wide_band_kernel_has_one_branch_free_stage_loop_and_no_scratch(tmp_path
     assert set(re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", cp.stdout)) == {"0"}
     assert set(re.findall(r"VGPRs Spill: (\d+)", cp.stdout)) == {"0"}
     assert set(int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", cp.stdout)) == {2}
-    m = re.search(r"^(_ZN3ldp\w*pair_mfma_wide_kernelILi0E\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel", open(out).read(), re.S | re.M)
-    assert m, "pair_mfma_wide_kernel<0> not found"
-    lines = m.group(2).splitlines()
-    mf = [k for k, ln in enumerate(lines) if "v_mfma_scale_f32_32x32x64_f8f6f4" in ln]
-    assert len(mf) == 64                       # one copy of the stage body: two half-stages of 32
-    body = lines[mf[0]:mf[-1] + 1]
-    assert not any(("s_cbranch" in ln) or ("scratch_" in ln) or ("v_accvgpr" in ln) for ln in body)
-    # the allele-count expansion (ldp_mfma_device.h): 2 half-stages x 6 row-blocks x 4 k-steps x 4 fragment dwords, one v_and each, and a
-    # shift for every second one (the odd samples of a code dword) -- three VALU per 16 samples
-    assert sum(("v_and_b32" in ln) and ("0x33333333" in ln) for ln in lines[mf[0] - 80:mf[-1]]) == 192
-    assert sum("v_lshrrev_b32" in ln for ln in lines[mf[0] - 80:mf[-1]]) == 96
-    for k, ln in enumerate(lines):
-        if "ds_read_b128" in ln:
-            before = [x for x in lines[max(0, k - 6):k] if not x.strip().startswith(";")]
-            assert "vmcnt(0)" not in "\n".join(before[-3:]), "s_waitcnt vmcnt(0) in front of a stage read:\n" + "\n".join(lines[k - 6:k + 1])
+    text = open(out).read()
+    # <0, false>: complete data, the allele-count coding; <0, true>: the SPARSE instantiation (rows with a few missing calls: the +-2 coding,
+    # an interval checkpoint and epilogue with FP64 interval arithmetic and a whole-wave recount around the SAME stage loop)
+    for sparse in (False, True):
+        m = re.search(r"^(_ZN3ldp\w*pair_mfma_wide_kernelILi0ELb%dE\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel" % int(sparse), text, re.S | re.M)
+        assert m, "pair_mfma_wide_kernel<0, %s> not found" % sparse
+        lines = m.group(2).splitlines()
+        mf = [k for k, ln in enumerate(lines) if "v_mfma_scale_f32_32x32x64_f8f6f4" in ln]
+        assert len(mf) == 64                       # one copy of the stage body: two half-stages of 32
+        body = lines[mf[0]:mf[-1] + 1]
+        assert not any(("s_cbranch" in ln) or ("scratch_" in ln) or ("v_accvgpr" in ln) for ln in body)
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2)).group(1)) <= 256
+        window = lines[mf[0] - 80:mf[-1]]
+        if sparse:
+            # the +-2 expansion: one v_bitop3_b32 per fragment dword and a shift for every second one -- three VALU per 16 samples, as below
+            assert sum("v_bitop3_b32" in ln for ln in window) == 192
+            assert sum("v_lshlrev_b32" in ln for ln in window) == 96
+        else:
+            # the allele-count expansion (ldp_mfma_device.h): 2 half-stages x 6 row-blocks x 4 k-steps x 4 fragment dwords, one v_and each, and a
+            # shift for every second one (the odd samples of a code dword) -- three VALU per 16 samples
+            assert sum(("v_and_b32" in ln) and ("0x33333333" in ln) for ln in window) == 192
+            assert sum("v_lshrrev_b32" in ln for ln in window) == 96
+        for k, ln in enumerate(lines):
+            if "ds_read_b128" in ln:
+                before = [x for x in lines[max(0, k - 6):k] if not x.strip().startswith(";")]
+                assert "vmcnt(0)" not in "\n".join(before[-3:]), "s_waitcnt vmcnt(0) in front of a stage read:\n" + "\n".join(lines[k - 6:k + 1])
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
