@@ -59,6 +59,8 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tools"))
+import bench_support as support  # noqa: E402  (the rocm-smi sampler, the end-to-end runs of both binaries, the in-run PMC passes)
 
 GRCH38_MB = [248.96, 242.19, 198.30, 190.21, 181.54, 170.81, 159.35, 145.14, 138.39, 133.80, 135.09, 133.28,
              114.36, 107.04, 101.99, 90.34, 83.26, 80.37, 58.62, 64.44, 46.71, 50.82]
@@ -71,7 +73,10 @@ CONFIGS = {
     "config2": dict(samples=50000, variants=1000000, spacing=2875, window_kb=200.0, r2=0.5),
     "config3": dict(samples=500000, variants=10000000, spacing=290, window_kb=500.0, r2=0.2),
 }
-PER_GPU_VARIANTS = {"config2": 1000000, "config3": 1250000}  # weak scaling: the share of one GPU (config 3: 10M / 8)
+# config5 = BASELINE.json configs[4]: config 3's shape with 5 % missing calls in every variant and 2 % of the variants multiallelic (their records
+# decoded and collapsed on the device inside every step): `--workload config5` runs its per-GPU share as the main line
+CONFIGS["config5"] = dict(CONFIGS["config3"], missing_rate=0.05, multiallelic_frac=0.02)
+PER_GPU_VARIANTS = {"config2": 1000000, "config3": 1250000, "config5": 1250000}  # weak scaling: the share of one GPU (config 3 / 5: 10M / 8)
 CHR22_FRACTION = GRCH38_MB[21] / sum(GRCH38_MB)               # end-to-end runs materialise <= one chr22-sized chromosome
 # the kernel sources a PMC profile is valid for (roofline.traffic is replayed only when their hashes match this tree)
 KERNEL_SOURCES = ["plink-ng_amd/csrc/" + f for f in ("ldp_pair_wide.hip", "ldp_pair_mfma.hip", "ldp_mfma_device.h", "ldp_pair_device.h", "ldp_device.h",
@@ -117,168 +122,6 @@ def write_plink1_fileset(prefix, host_codes, founder_ct, chr_idx, bps):
         f.write("".join("%d\tsnp%d\t0\t%d\tC\tA\n" % (chr_idx[i] + 1, i, bps[i]) for i in range(m)))
     with open(prefix + ".fam", "w") as f:
         f.write("".join("s%d s%d 0 0 2 -9\n" % (s, s) for s in range(founder_ct)))
-
-
-class SmiSampler:
-    """Socket power (W) and shader clock (MHz) as `rocm-smi -P -g --json` reports them, polled on a thread as fast as it answers (a few
-    samples per second) while a tagged window is open: tells a kernel at the socket's power cap (clock pulled below 2.4 GHz) from an
-    issue- or latency-bound one.  Reported, never used for a decision."""
-
-    def __init__(self):
-        import threading
-        self.samples, self.window, self._stop = [], None, False
-        self.cap_w = None
-        try:
-            out = subprocess.run(["/opt/rocm/bin/rocm-smi", "-M", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20).stdout
-            card = next(iter(json.loads(out).values()))
-            caps = [float(v) for k, v in card.items() if "(W)" in k]
-            self.cap_w = caps[0] if caps else None
-        except Exception:
-            pass
-        self._thread = threading.Thread(target=self._run, daemon=True)
-        self._thread.start()
-
-    def _run(self):
-        while not self._stop:
-            if self.window is None:
-                time.sleep(0.02)
-                continue
-            try:
-                out = subprocess.run(["/opt/rocm/bin/rocm-smi", "-P", "-g", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10).stdout
-                card = next(iter(json.loads(out).values()))
-                watts = [float(v) for k, v in card.items() if "ower" in k and "(W)" in k]
-                mhz = [float(mt.group(1)) for k, v in card.items() if "sclk" in k.lower() for mt in [re.search(r"(\d+)\s*Mhz", str(v))] if mt]
-                if self.window is not None:
-                    self.samples.append((self.window, watts[0] if watts else None, mhz[0] if mhz else None))
-            except Exception:
-                time.sleep(0.05)
-
-    def stop(self):
-        self._stop = True
-
-    def summary(self, tag):
-        rows = [r for r in self.samples if r[0] == tag]
-        w = sorted(r[1] for r in rows if r[1] is not None)
-        c = sorted(r[2] for r in rows if r[2] is not None)
-        med = lambda v: v[len(v) // 2] if v else None
-        return {"source": "rocm-smi -P -g polled during the timed steps (%d samples)" % len(rows), "socket_power_w_median": med(w), "socket_power_w_max": w[-1] if w else None,
-                "socket_power_cap_w": self.cap_w, "shader_clock_mhz_median": med(c), "shader_clock_mhz_min": c[0] if c else None, "shader_clock_mhz_max": c[-1] if c else None}
-
-
-class E2EChr22:
-    """BASELINE.json's second metric -- `--indep-pairwise` WALL-CLOCK -- measured, not extrapolated, at the metric's sample count on the
-    largest fileset SURVEY 8(d) allows to be materialised: a chr22-sized share of the metric's genome (176,765 of 10,000,000 variants x
-    500,000 samples, 22 chromosomes at the metric's density), written by the device generator as a fixed-width .pgen (22 GB, page cache
-    or tmpfs).  start() materialises it and starts reference plink2 (all host threads it can use) in the background, so that its
-    minutes run beside the GPU legs of this script; finish() joins it, then runs plink2-hip on the same files with the GPU idle
-    (`--timing`: its own phase split), and compares the two pairs of output files byte for byte."""
-
-    def __init__(self, pkg, torch, cfg, variants, ref_timeout_s=420):
-        self.pkg, self.torch, self.cfg, self.m, self.ref_timeout_s = pkg, torch, cfg, variants, ref_timeout_s
-        self.tmp, self.ref_proc, self.res = None, None, {}
-
-    def start(self):
-        pkg, torch, cfg, m = self.pkg, self.torch, self.cfg, self.m
-        n = cfg["samples"]
-        stride = (n + 3) // 4
-        need = m * stride * 1.15 + 2e9
-        ref_bin = os.path.join(REPO, "oracle", "_ref", "plink2")
-        if not (os.path.exists(ref_bin) and os.access(ref_bin, os.X_OK)):
-            self.res = {"skipped": "oracle/_ref/plink2 not built"}
-            return self
-        where = None
-        for d in ("/dev/shm", tempfile.gettempdir()):
-            try:
-                st = os.statvfs(d)
-                if st.f_bavail * st.f_frsize > need:
-                    where = d
-                    break
-            except OSError:
-                continue
-        if where is None:
-            self.res = {"skipped": "no %.0f GB of scratch space for the fileset" % (need / 1e9)}
-            return self
-        self.tmp = tempfile.mkdtemp(prefix="ldbench_e2e_", dir=where)
-        chr_idx, bps = genome_layout(m, 1, cfg["spacing"])
-        t0 = time.perf_counter()
-        rows_per = max(1, (1 << 30) // stride)
-        dev = torch.empty((rows_per, stride), dtype=torch.uint8, device="cuda")
-        pin = [torch.empty((rows_per, stride), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
-        with open(os.path.join(self.tmp, "g.pgen"), "wb") as f:
-            f.write(bytes([0x6C, 0x1B, 0x02]) + np.uint32(m).tobytes() + np.uint32(n).tobytes() + bytes([0x40]))   # fixed-width .pgen (pgenlib_read.cc:881-911)
-            k = 0
-            for r0 in range(0, m, rows_per):
-                cnt = min(rows_per, m - r0)
-                pkg.synth_genotypes_device(SEED, r0, cnt, n, 0.0, dev.data_ptr(), stride)
-                torch.cuda.synchronize()
-                pin[k & 1][:cnt].copy_(dev[:cnt])
-                torch.cuda.synchronize()
-                f.write(memoryview(pin[k & 1].numpy()[:cnt]))
-                k += 1
-        del dev, pin
-        torch.cuda.empty_cache()
-        with open(os.path.join(self.tmp, "g.pvar"), "w") as f:
-            f.write("#CHROM\tPOS\tID\tREF\tALT\n" + "".join("%d\t%d\tsnp%d\tA\tC\n" % (chr_idx[i] + 1, bps[i], i) for i in range(m)))
-        with open(os.path.join(self.tmp, "g.psam"), "w") as f:
-            f.write("#IID\tSEX\n" + "".join("s%d\t2\n" % q for q in range(n)))
-        self.file_bytes = 12 + m * stride
-        self.res = {"variants": m, "samples": n, "fileset": "fixed-width .pgen + .pvar + .psam under %s (%.1f GB, written by the device generator in %.1f s)" %
-                    (where, self.file_bytes / 1e9, time.perf_counter() - t0)}
-        self.cores = os.cpu_count() or 1
-        self.kb = "%gkb" % cfg["window_kb"]
-        self.ref_t0 = time.perf_counter()
-        self.ref_proc = subprocess.Popen([ref_bin, "--pfile", "g", "--indep-pairwise", self.kb, repr(cfg["r2"]), "--threads", str(self.cores), "--out", "ref"],
-                                         cwd=self.tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        return self
-
-    def finish(self):
-        if not self.tmp:
-            return self.res
-        try:
-            res = self.res
-            try:
-                ref_out, _ = self.ref_proc.communicate(timeout=self.ref_timeout_s)
-                ref_wall = time.perf_counter() - self.ref_t0
-                ref_rc = self.ref_proc.returncode
-            except subprocess.TimeoutExpired:
-                self.ref_proc.kill()
-                ref_out, ref_wall, ref_rc = "", None, -9
-            mt = re.search(r"\((\d+) compute thread", ref_out or "")
-            res["reference_plink2"] = {"wall_s": ref_wall, "rc": ref_rc, "threads_requested": self.cores, "compute_threads": int(mt.group(1)) if mt else None,
-                                       "note": "started right after the fileset was written and timed to its exit; it ran BESIDE this script's GPU legs (it uses a dozen host "
-                                               "threads, the legs one), so its wall is if anything pessimistic by the legs' host work"}
-            cli_bin = os.path.join(REPO, "plink-ng_amd", "bin", "plink2-hip")
-            self.torch.cuda.synchronize()
-            walls, phases, rc, txt = [], None, None, ""
-            for _ in range(2):   # (the second run: page cache and HIP code objects warm on both sides alike -- the reference ran once, cold HIP start-up is in run 1)
-                t1 = time.perf_counter()
-                cc = subprocess.run([cli_bin, "--pfile", "g", "--indep-pairwise", self.kb, repr(self.cfg["r2"]), "--timing", "--out", "hip"], cwd=self.tmp,
-                                    stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
-                walls.append(time.perf_counter() - t1)
-                rc, txt = cc.returncode, cc.stdout
-            ph = re.search(r"setup\+parse ([0-9.]+) s \| genotype load[^|]*?([0-9.]+) s \| run ([0-9.]+) s \(pair kernel ([0-9.]+) ms, replay ([0-9.]+) ms; (\d+) candidate pairs\)", txt)
-            tot = re.search(r"\[timing\] total ([0-9.]+) s", txt)
-            if ph:
-                load_s = float(ph.group(2))
-                phases = {"setup_and_table_parse_s": float(ph.group(1)), "file_to_hbm_s": load_s, "file_to_hbm_gbs": self.file_bytes / load_s / 1e9 if load_s > 0 else None,
-                          "run_s": float(ph.group(3)), "pair_kernels_ms": float(ph.group(4)), "host_replay_ms": float(ph.group(5)), "candidate_pairs": int(ph.group(6)),
-                          "main_total_s": float(tot.group(1)) if tot else None,
-                          "note": "plink2-hip --timing, second run; file_to_hbm covers pread() of the .pgen rows into the pinned ring, H2D and the count pass (they overlap); "
-                                  "run = pair kernels + replay behind the load; the rest of the wall is process start-up, HIP context, list writing and exit"}
-            same = False
-            if rc == 0 and ref_rc == 0:
-                same = all(open(os.path.join(self.tmp, "hip" + e), "rb").read() == open(os.path.join(self.tmp, "ref" + e), "rb").read() for e in (".prune.in", ".prune.out"))
-            res["plink2_hip"] = {"wall_s": min(walls), "wall_s_runs": walls, "rc": rc, "phases": phases}
-            res["files_identical"] = bool(same)
-            res["speedup"] = (ref_wall / min(walls)) if (ref_wall and walls and rc == 0 and ref_rc == 0) else None
-            if ph and ref_wall:
-                res["reference_candidate_pairs_per_s"] = int(ph.group(6)) / ref_wall
-            res["what"] = ("MEASURED end-to-end walls, process start to exit, same command line (--indep-pairwise %s %g) on the same fileset: %d variants (a chr22-sized share "
-                           "of the metric's 10M-variant genome: 22 chromosomes at %d bp) x %d samples" % (self.kb, self.cfg["r2"], self.m, self.cfg["spacing"], self.cfg["samples"]))
-            return res
-        finally:
-            subprocess.call(["rm", "-rf", self.tmp])
-            self.tmp = None
 
 
 def host_description():
@@ -735,50 +578,6 @@ def pmc_traffic(founder_ct, variants, window_kb, missing_rate):
     return None, None, None
 
 
-def pmc_traffic_in_run(argv_workload, timeout_s=150):
-    """HBM bytes of ONE step of the named workload measured NOW, on this box: two rocprofv3 passes over a one-step child run of this script
-    (`--kernel-trace --pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: separate passes, as MI355X_MICROARCH.md's HBM section prescribes), summed over
-    the pair kernels' dispatches; FETCH_SIZE / WRITE_SIZE are in KiB and gfx950's FETCH_SIZE reports half of a wide streaming read (x 2).
-    Returns (bytes, per-kernel dict, note) or (None, None, why)."""
-    import csv
-    import glob
-    import shutil
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
-        return None, None, "rocprofv3 not found"
-    tmp = tempfile.mkdtemp(prefix="ldbench_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
-    per_kernel = {}
-    try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, ctr)
-            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0",
-                   "--no-legs", "--no-cpu-baseline"] + argv_workload
-            cp = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
-            if cp.returncode != 0:
-                return None, None, "rocprofv3 --pmc %s failed: %s" % (ctr, cp.stdout[-200:])
-            found = False
-            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                for r in csv.DictReader(open(f)):
-                    k = r["Kernel_Name"]
-                    if r["Counter_Name"] == ctr and (("pair_mfma" in k) or ("pair_tiles_kernel" in k)):
-                        short = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("ldp::", "")
-                        d = per_kernel.setdefault(short, {"FETCH_SIZE_KiB": 0.0, "WRITE_SIZE_KiB": 0.0, "dispatches": 0})
-                        d[ctr + "_KiB"] += float(r["Counter_Value"])
-                        d["dispatches"] += 1 if ctr == "FETCH_SIZE" else 0
-                        found = True
-            if not found:
-                return None, None, "no %s rows for the pair kernels in rocprofv3's output" % ctr
-        total = sum(d["FETCH_SIZE_KiB"] * 1024.0 * 2.0 + d["WRITE_SIZE_KiB"] * 1024.0 for d in per_kernel.values())
-        return total, per_kernel, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (two passes) around one step of the same workload in a "
-                                   "child process; FETCH_SIZE x 1024 x 2 (gfx950 half-count of wide streaming reads, MI355X_MICROARCH.md HBM) + WRITE_SIZE x 1024, "
-                                   "summed over the pair kernels' dispatches")
-    except Exception as ex:  # pragma: no cover
-        return None, None, "in-run PMC failed: %s" % str(ex)[:200]
-    finally:
-        subprocess.call(["rm", "-rf", tmp])
-
-
 def pair_roofline(c, founder_ct, local_ct, missing_rate, variants, window_kb, options=None):
     kms_mfma, kms_gen = c["ms_pair_mfma"], c["ms_pair_mfma_general"]
     general = c["route_general_launches"] > 0
@@ -912,6 +711,78 @@ def config4_tiles_leg(pkg, torch, device, samples, tile, ref_slice_variants, no_
     return res
 
 
+def flatten_summary(out):
+    """The driver's record keeps `roofline` and `cpu_baseline` but only their SCALAR fields (nested objects and the other top-level keys -- legs,
+    stage_ms, power_and_clock, headline_bits_check -- are dropped).  So the numbers a reader of that record needs are repeated here as flat scalar
+    keys: per leg the kernel, ms per step, the roofline fraction with its bound, the traffic multiple; the power / clock medians of the timed steps;
+    the bits check; the end-to-end walls of both binaries on both file formats."""
+    r = out.get("roofline") or {}
+    legs = out.get("legs") or {}
+
+    def put(prefix, leg):
+        if not isinstance(leg, dict) or "error" in leg:
+            r[prefix + "_error"] = (leg or {}).get("error", "missing")[:100] if isinstance(leg, dict) else "missing"
+            return
+        rf = leg.get("roofline") or {}
+        for key, val in (("kernel", leg.get("kernel") or rf.get("kernel")), ("ms_per_step", leg.get("ms_per_step")), ("pair_kernels_ms", leg.get("pair_kernels_ms") or leg.get("kernel_ms")),
+                         ("bound", rf.get("bound")), ("frac", rf.get("frac")), ("traffic_x_compulsory", rf.get("traffic_over_compulsory") or leg.get("traffic_over_compulsory"))):
+            if val is not None:
+                r["%s_%s" % (prefix, key)] = val
+
+    if "config2" in legs:
+        L = legs["config2"]
+        put("leg_config2", L)
+        for rate in ("0.001", "0.01"):
+            M = L.get("missing_rate_" + rate) if isinstance(L, dict) else None
+            if M:
+                r["leg_config2_miss%s_kernel" % rate], r["leg_config2_miss%s_ms_per_step" % rate] = M.get("kernel"), M.get("ms_per_step")
+                r["leg_config2_miss%s_x_complete" % rate] = M.get("vs_complete_data_step")
+        cbl = (L.get("cpu_baseline") or {}) if isinstance(L, dict) else {}
+        if cbl.get("value"):
+            r["leg_config2_reference_pairs_per_s"], r["leg_config2_reference_identical"] = cbl.get("value"), cbl.get("prune_set_identical_to_hip")
+    if "config5_density" in legs:
+        L = legs["config5_density"]
+        put("leg_config5_density", L)
+        if isinstance(L, dict) and "error" not in L:
+            r["leg_config5_density_x_complete"] = L.get("vs_complete_data_step_of_the_same_slice")
+            r["leg_config3_density_complete_ms_per_step"] = (L.get("complete_data_step_of_the_same_slice") or {}).get("ms_per_step")
+            r["leg_config5_density_reference_identical"] = (L.get("reference_slice") or {}).get("files_identical")
+    for rate in ("0.001", "0.01"):
+        M = (legs.get("config3_density_missing") or {}).get("missing_rate_" + rate)
+        if M:
+            r["leg_config3_miss%s_kernel" % rate], r["leg_config3_miss%s_ms_per_step" % rate] = M.get("kernel"), M.get("ms_per_step")
+            r["leg_config3_miss%s_x_complete" % rate], r["leg_config3_miss%s_recounted_pairs" % rate] = M.get("vs_complete_data_step"), M.get("pairs_counted_exactly")
+            r["leg_config3_miss%s_traffic_x_compulsory" % rate] = M.get("traffic_over_compulsory")
+    if "config4_tiles" in legs:
+        put("leg_config4_tiles", legs["config4_tiles"])
+    pc = out.get("power_and_clock") or {}
+    for key in ("socket_power_w_median", "socket_power_cap_w", "shader_clock_mhz_median"):
+        if pc.get(key) is not None:
+            r["timed_steps_" + key] = pc[key]
+    hb = out.get("headline_bits_check") or {}
+    if hb:
+        r["headline_bits_check_identical"] = hb.get("identical", hb.get("checked"))
+    cb = out.get("cpu_baseline") or {}
+    e = cb.get("e2e_wall_s") or {}
+    if e:
+        ph = e.get("plink2_hip_phases") or {}
+        cb.update({"e2e_fixed_width_reference_s": e.get("reference_plink2"), "e2e_fixed_width_plink2_hip_s": e.get("plink2_hip"), "e2e_fixed_width_speedup": e.get("speedup"),
+                   "e2e_fixed_width_files_identical": e.get("files_identical"), "e2e_fixed_width_file_to_hbm_gbs": ph.get("file_to_hbm_gbs"), "e2e_fixed_width_pgen_bytes": e.get("pgen_bytes")})
+        v = e.get("variable_width") or {}
+        if v:
+            vh = v.get("plink2_hip") or {}
+            cb.update({"e2e_variable_width_reference_s": v.get("reference_plink2_wall_s"), "e2e_variable_width_plink2_hip_s": vh.get("wall_s"), "e2e_variable_width_speedup": v.get("speedup"),
+                       "e2e_variable_width_files_identical": v.get("files_identical_to_reference_on_the_same_file"), "e2e_variable_width_pgen_bytes": v.get("pgen_bytes"),
+                       "e2e_variable_width_bytes_vs_fixed": v.get("bytes_vs_fixed_width"), "e2e_variable_width_make_pgen_s": v.get("make_pgen_s"),
+                       "e2e_variable_width_file_to_hbm_s": (vh.get("phases") or {}).get("file_to_hbm_s")})
+    n = out.get("e2e_n_gpus") or {}
+    if n:
+        hip = n.get("plink2_hip") or {}
+        r["e2e_plink2_hip_gpus"], r["e2e_plink2_hip_gpus_wall_s"], r["e2e_plink2_hip_gpus_rc"] = n.get("gpus"), hip.get("wall_s"), hip.get("rc")
+        r["e2e_plink2_hip_gpus_file_to_hbm_s"] = (hip.get("phases") or {}).get("file_to_hbm_s")
+        r["e2e_plink2_hip_gpus_identical_to_one_gpu"] = n.get("identical_to_one_gpu")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -923,7 +794,7 @@ def main():
     ap.add_argument("--window-kb", type=float, default=None)
     ap.add_argument("--r2", type=float, default=None)
     ap.add_argument("--spacing", type=int, default=None, help="bp between consecutive variants")
-    ap.add_argument("--missing-rate", type=float, default=0.0)
+    ap.add_argument("--missing-rate", type=float, default=None, help="missing calls (MCAR, every variant); default 0, or the named workload's (config5: 0.05)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: the named configuration's genome in total, sharded over the ranks")
     ap.add_argument("--weak", action="store_true", help="weak scaling (the default): --variants per GPU on one genome")
     ap.add_argument("--cpu-sample-variants", type=int, default=0, help="0 = 440,000 up to 100k samples, 11,000 beyond")
@@ -932,6 +803,7 @@ def main():
     ap.add_argument("--no-cli-compare", action="store_true", help="do not time plink2-hip end-to-end on the CPU-baseline sample files")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes over a one-step child run); replay profiles/ instead")
     ap.add_argument("--no-e2e", action="store_true", help="skip the measured chr22-sized end-to-end run of both binaries (22 GB fileset, minutes of reference time)")
+    ap.add_argument("--no-e2e-variable", action="store_true", help="... or only its second half: the same fileset as the reference's default variable-width .pgen")
     ap.add_argument("--e2e-variants", type=int, default=0, help="variants of that fileset (0 = a chr22-sized share of the named genome: 176,765 of 10M)")
     ap.add_argument("--leg-variants", type=int, default=120000, help="variants of the config5-density leg")
     ap.add_argument("--tile", type=int, default=65536, help="side of the config4_tiles leg's cross-chromosome tile set")
@@ -987,6 +859,9 @@ def main():
     for k, v in (("samples", args.samples), ("variants", args.variants), ("window_kb", args.window_kb), ("r2", args.r2), ("spacing", args.spacing)):
         if v is not None:
             cfg[k] = v
+    if args.missing_rate is None:
+        args.missing_rate = cfg.get("missing_rate", 0.0)
+    multi_frac = cfg.get("multiallelic_frac", 0.0)
     per_gpu_variants = cfg["variants"] if not strong else None
     if not strong:
         cfg["variants"] = cfg["variants"] * world
@@ -1032,8 +907,10 @@ def main():
                 "note": "the count pass (HBM-bound: reads N/4 bytes per variant, writes only the records) and the pair kernels run back to back; "
                         "count pass: %.0f GB/s" % ((image_bytes / (cmean["ms_prepare"] * 1e-3) / 1e9) if cmean["ms_prepare"] > 0 else 0.0)}
 
-    wl = Workload(pkg, torch, cfg, args.missing_rate, rank, world, local_rank, main_options)
-    smi = SmiSampler() if rank == 0 else None
+    # (config5: runs of 400 consecutive multiallelic variants, one ldp_load_pgen_records call each -- a loader hands over records in batches --, 2 % of the rank's share)
+    main_multi = (max(1, int(round(multi_frac * (per_gpu_variants or cfg["variants"] // world) / 400.0))), 400) if multi_frac > 0 else None
+    wl = Workload(pkg, torch, cfg, args.missing_rate, rank, world, local_rank, main_options, main_multi)
+    smi = support.SmiSampler() if rank == 0 else None
 
     def open_window():
         if smi:
@@ -1102,7 +979,8 @@ def main():
                        "shard_imbalance_max_over_mean": (max(per_rank_pairs) / (total_pairs / world)) if total_pairs else 1.0,
                        "pairs_above_threshold_rank0": ctr["pred_true"], "above_threshold_pairs_consumed_by_replay_rank0": ctr["replay_pairs"],
                        "variants_removed": int(removed.sum()), "resident": bool(wl.resident), "image_gb_rank0": wl.image_bytes / 1e9,
-                       "engine_options": main_options},
+                       "engine_options": main_options,
+                       "multiallelic_variants_rank0": (wl.multi or {}).get("variants", 0)},
             "roofline": roofline,
             "stage_ms": stage_ms(cmean, wl.image_bytes),
             "power_and_clock": smi.summary("main") if smi else None,
@@ -1152,7 +1030,7 @@ def main():
         for kv in args.option:
             wargs += ["--option", kv]
         t_pmc = time.perf_counter()
-        tb, tk, tnote = pmc_traffic_in_run(wargs)
+        tb, tk, tnote = support.pmc_traffic_in_run(__file__, wargs)
         r = out["roofline"]
         if tb:
             comp = r["hbm"]["compulsory_bytes_per_step"]
@@ -1166,7 +1044,8 @@ def main():
     if rank == 0 and world == 1 and (not args.no_cpu_baseline) and (not args.no_e2e) and (not args.no_cli_compare) and cfg["samples"] > 100000:
         # the metric's wall-clock leg: materialise the chr22-sized fileset now and let the reference run beside the GPU legs below
         try:
-            e2e = E2EChr22(pkg, torch, cfg, args.e2e_variants or int(round(CONFIGS[name]["variants"] * CHR22_FRACTION))).start()
+            e2e = support.E2EChr22(pkg, torch, cfg, args.e2e_variants or int(round(CONFIGS[name]["variants"] * CHR22_FRACTION)), SEED, genome_layout)
+            e2e.start(reference=True, variable_width=not args.no_e2e_variable)
         except Exception as ex:  # pragma: no cover
             e2e = None
             out["e2e_error"] = str(ex)[:300]
@@ -1240,8 +1119,19 @@ def main():
                     except Exception as ex:  # pragma: no cover
                         L["reference_slice"] = {"error": str(ex)[:300]}
                 legs["config5_density"] = L
+                # (b') the same slice with a FEW missing calls -- what real call sets look like: 0.1 % stays on the 8 x 8 tiles (the tile
+                # kernel's SPARSE instantiation), 1 % is beyond the interval path's limit (0.5 % on average) and takes the four-product quarter tiles
+                M3 = {"what": "the config-3 density slice (%d x %d, %gkb %g) with missing calls in every variant; vs_complete_data_step is against the same slice's "
+                              "complete-data step (%.2f ms)" % (c5["samples"], c5["variants"], c5["window_kb"], c5["r2"], C["ms_per_step"])}
+                for rate in (0.001, 0.01):
+                    Q = leg(c5, rate, {}, 3)
+                    M3["missing_rate_%g" % rate] = {k: Q[k] for k in ("ms_per_step", "pair_kernels_ms", "kernel", "routes", "pairs_counted_exactly", "variants_removed")}
+                    M3["missing_rate_%g" % rate].update({"vs_complete_data_step": Q["ms_per_step"] / C["ms_per_step"], "mfma": Q["roofline"]["mfma"],
+                                                          "traffic": Q["roofline"]["traffic"], "traffic_over_compulsory": Q["roofline"]["traffic_over_compulsory"],
+                                                          "traffic_source": Q["roofline"]["traffic_source"], "same_prune_set_as_complete_data_is_not_expected": True})
+                legs["config3_density_missing"] = M3
             except Exception as e:  # pragma: no cover  (e.g. a smaller GPU)
-                legs["config5_density"] = {"error": str(e)[:300]}
+                legs.setdefault("config5_density", {"error": str(e)[:300]})
             torch.cuda.empty_cache()
         # (c) config 4: the cross-chromosome tile set of --r2-unphased inter-chr
         if args.tile > 0:
@@ -1276,7 +1166,8 @@ def main():
                     cb["e2e_wall_s"] = {"reference_plink2": ref["wall_s"], "plink2_hip": hip["wall_s"], "speedup": big.get("speedup"), "variants": big.get("variants"),
                                         "samples": big["samples"], "files_identical": big.get("files_identical"), "plink2_hip_phases": hip.get("phases"),
                                         "plink2_hip_wall_s_runs": hip.get("wall_s_runs"), "reference_compute_threads": ref.get("compute_threads"),
-                                        "fileset": big.get("fileset"), "what": big.get("what"), "reference_note": ref.get("note")}
+                                        "fileset": big.get("fileset"), "what": big.get("what"), "reference_note": ref.get("note"),
+                                        "pgen_bytes": getattr(e2e, "file_bytes", None), "variable_width": big.get("variable_width")}
                     cb["value"] = big.get("reference_candidate_pairs_per_s")
                     cb["wall_s"] = ref["wall_s"]
                     if ref.get("compute_threads"):
@@ -1290,6 +1181,26 @@ def main():
         else:
             out["cpu_baseline"] = {"value": None, "unit": "variant-pairs/s", "cores": 0, "kind": "reference",
                                    "sample": "measured at N=1 only", **host_description()}
+        if world > 1 and (not args.no_e2e) and cfg["samples"] > 100000:
+            # the wall-clock half of the metric at N GPUs: `plink2-hip --gpus N` (one feeding thread per engine, each next to its device, the shards' rows
+            # crossing N PCIe links at once) end to end on the chr22-sized fileset, and `--gpus 1` on the same files beside it.  The other ranks wait at the
+            # final barrier with their shares still resident (a chr22-sized shard is 22 GB / N per device).
+            try:
+                e2n = support.E2EChr22(pkg, torch, cfg, args.e2e_variants or int(round(CONFIGS[name]["variants"] * CHR22_FRACTION)), SEED, genome_layout)
+                e2n.start(reference=False, variable_width=False)
+                tmpdir = e2n.tmp
+                one = support.run_plink2_hip(tmpdir, "g", e2n.kb, cfg["r2"], "one", gpus=1) if tmpdir else None
+                big = e2n.finish(gpus=world, compare_with="one")   # (removes the fileset)
+                if one is not None:
+                    big["plink2_hip_one_gpu"] = {k: one[k] for k in ("wall_s", "wall_s_runs", "rc", "phases")}
+                    big["speedup_over_one_gpu"] = (one["wall_s"] / big["plink2_hip"]["wall_s"]) if (one.get("wall_s") and (big.get("plink2_hip") or {}).get("wall_s")) else None
+                out["e2e_n_gpus"] = big
+            except Exception as ex:  # pragma: no cover
+                out["e2e_n_gpus"] = {"error": str(ex)[:300]}
+        try:
+            flatten_summary(out)
+        except Exception as ex:  # pragma: no cover  (a summary must never take the line with it)
+            out["roofline"]["summary_error"] = str(ex)[:200]
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -162,6 +162,13 @@ int ldp_prewarm(int device);
  * library never moves its caller's threads; a caller on a multi-socket host that loads from host memory gains from running its loading
  * threads there -- and from first-touching its buffers there -- (30 -> 39 GB/s file -> HBM on the round-5 boxes): plink2-hip does. */
 int ldp_device_numa_node(int device);
+/* Host copy threads.  The file -> pinned-memory copies of ldp_load_genotypes*() run on a pool of copy threads that all engines of a
+ * process share (created by the first load, with that thread's CPU affinity); engines that load at the same time take turns.  A host
+ * that feeds SEVERAL engines concurrently -- one feeding thread per engine, each bound next to its engine's device, the way the
+ * reference's main thread fills every worker's slot of a batch (plink2_ld.cc:1292-1417) -- calls this once per engine FROM the thread
+ * that will feed it: the engine gets copy threads of its own, created here and inheriting the calling thread's affinity, and its
+ * pinned staging ring (allocated by its first load) is first touched by them.  Idempotent.  plink2-hip --gpus N does this. */
+int ldp_use_private_copy_threads(ldp_engine* e);
 /* Largest founder_ct whose pair statistics run on the matrix pipe (FP4 operands, f32 accumulators that hold the integers
  * exactly); larger jobs run on the popcount kernels.  Same results either way. */
 uint32_t ldp_matrix_pipe_max_founders(void);

@@ -101,6 +101,7 @@ CABI_SYMBOLS = [
     "ldp_pgen_variant_is_multiallelic", "ldp_pgen_provisional_ref", "ldp_pgen_open_indexed", "ldp_set_r_signed", "ldp_set_variants_vcor_cm", "ldp_pgen_read_alleles", "ldp_pgen_read_phased", "ldp_pgen_read_alleles_phased", "ldp_subset_samples", "ldp_phased_row_bytes", "ldp_phased_phase_offset",
     "ldp_debug_set_option", "ldp_pgen_debug_force_portable", "ldp_matrix_pipe_max_founders", "ldp_map_rows", "ldp_release_device", "ldp_debug_wide_plan",
     "ldp_allgather_removed", "ldp_comm_init_all", "ldp_comm_destroy", "ldp_shard_segment_words", "ldp_pack_removed_segment", "ldp_stitch_removed_segments", "ldp_load_pgen_records", "ldp_load_pgen_records_phased", "ldp_pgen_file_bytes", "ldp_pgen_record_index", "ldp_device_numa_node",
+    "ldp_use_private_copy_threads",
 ]
 
 

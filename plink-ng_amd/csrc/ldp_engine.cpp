@@ -1124,6 +1124,17 @@ int ldp_device_count(void) {
 // The first real use of a device creates its context and queues: 40-90 ms on the GPU box (up to half a second on a cold one), which
 // an engine otherwise pays inside its first ldp_load_genotypes().  A host that has other start-up work to do (plink2-hip: the variant
 // and sample tables) calls this on a side thread first.  Creates a stream and a small pinned allocation and frees both.
+// (see include/ldprune_hip.h: the copy threads of ONE engine, created by and bound like the thread that feeds it)
+int ldp_use_private_copy_threads(ldp_engine* e) {
+  if (!e) {
+    return LDP_ERR_INVALID;
+  }
+  if (!e->own_pool) {
+    e->own_pool.reset(new CopyPool());
+  }
+  return LDP_OK;
+}
+
 int ldp_prewarm(int device) {
   if ((device < 0) || (device >= ldp_device_count())) {
     return LDP_ERR_GPU;

@@ -73,12 +73,30 @@ void parallel_for(uint32_t n, uint32_t max_threads, F fn) {
 // The same on threads that stay: the file -> pinned-memory copies of ldp_load_genotypes() come as hundreds of short batches (one per
 // 16 MiB slot), and spawning sixteen threads for each cost as much as the copy itself.  One pool per process, created at first use;
 // run() is called from one thread at a time per pool user (the engines of a multi-device process take turns through the mutex).
+// An engine whose host feeds several engines at once, each from a thread of its own next to its device (plink2-hip --gpus N: the
+// reference's main thread fills every worker's slot of a batch and the workers run together, plink2_ld.cc:1292-1417), gets a pool of
+// ITS OWN through ldp_use_private_copy_threads(): its workers are created by -- and inherit the CPU affinity of -- the calling thread.
 class CopyPool {
  public:
   static CopyPool& get() {
     static CopyPool* pool = new CopyPool();  // (never destroyed: its threads may outlive main()'s statics)
     return *pool;
   }
+  CopyPool() { start(); }
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+      ++epoch_;
+      active_ = static_cast<uint32_t>(workers_.size());
+    }
+    cv_.notify_all();
+    for (std::thread& t : workers_) {
+      t.join();
+    }
+  }
+  CopyPool(const CopyPool&) = delete;
+  CopyPool& operator=(const CopyPool&) = delete;
   template <class F>
   void run(uint32_t n, uint32_t max_threads, F fn) {
     // (a forked child inherits the object but none of its threads: it works on its own)
@@ -115,7 +133,7 @@ class CopyPool {
   }
 
  private:
-  CopyPool() {
+  void start() {
     const uint32_t nt = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
     for (uint32_t w = 0; w + 1 < nt; ++w) {
       workers_.emplace_back([this, w]() {
@@ -126,6 +144,9 @@ class CopyPool {
           {
             std::unique_lock<std::mutex> lk(mu_);
             cv_.wait(lk, [&]() { return (epoch_ != seen) && (w < active_); });
+            if (stop_) {
+              return;
+            }
             seen = epoch_;
             f = fn_;
             n = n_;
@@ -139,10 +160,10 @@ class CopyPool {
           }
         }
       });
-      workers_.back().detach();
     }
   }
   std::vector<std::thread> workers_;
+  bool stop_ = false;
   const pid_t pid_ = getpid();
   std::mutex mu_, user_mu_;
   std::condition_variable cv_, cv_done_;
@@ -296,6 +317,7 @@ struct ldp_engine {
   hipEvent_t pair_tail[kPairStreams] = {nullptr};  // last thing queued on each pair stream
   bool pair_tail_set[kPairStreams] = {false};
   uint8_t* h_stage[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging ring for host-memory genotype input
+  std::unique_ptr<CopyPool> own_pool;  // ldp_use_private_copy_threads(): this engine's own copy threads (else the process-wide pool)
   uint8_t* d_stage[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t stage_done[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t h2d_stream[2] = {nullptr, nullptr};   // H2D copies of alternate slots (two SDMA queues: one tops out near 30 GB/s)

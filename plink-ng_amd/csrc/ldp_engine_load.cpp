@@ -197,7 +197,7 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
           }
         };
         if (use_pool) {
-          CopyPool::get().run(tasks, copy_threads, copy_task);
+          (e->own_pool ? *e->own_pool : CopyPool::get()).run(tasks, copy_threads, copy_task);
         } else {
           parallel_for(tasks, copy_threads, copy_task);
         }
@@ -583,6 +583,9 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
           break;
         }
       }
+      // the decode overwrites these rows before their records have been checked: from here on they hold nothing -- whatever happens below
+      // (a malformed record, a failed copy, launch or sync) -- until load_rows_impl has counted them again
+      std::fill(e->loaded.begin() + l_first, e->loaded.begin() + l_first + cnt, static_cast<uint8_t>(0));
     }
     const uint64_t lstride = into_image ? e->code_row_bytes : stride;
     void *p_recs = nullptr, *p_rows = nullptr, *p_end = nullptr, *p_multi = nullptr, *p_mf = nullptr, *p_mi = nullptr, *p_inv = nullptr;
@@ -675,11 +678,7 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
     const double t_s = now_ms();
     const int h_err = *h_err_pin;
     if (h_err) {
-      e->ld_base_valid = false;
-      if (into_image) {
-        // (the malformed call wrote into the image: whatever those rows held before is gone, and they do not count as loaded)
-        std::fill(e->loaded.begin() + l_first, e->loaded.begin() + l_first + cnt, static_cast<uint8_t>(0));
-      }
+      e->ld_base_valid = false;  // (rows decoded in place were marked not loaded before the launch)
       const uint32_t bad = static_cast<uint32_t>(h_err - 1);
       return fail(e, LDP_ERR_INVALID, "malformed variant record in .pgen data (variant " + std::to_string((bad < cnt) ? (first_variant + q0 + bad) : first_variant) + ((bad < cnt) ? ")" : ": its LD base)"));
     }
@@ -704,15 +703,15 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
         }
       }
     }
-    if (into_image) {
-      e->ctr.decoded_in_place_rows += cnt;
-    }
     status = load_rows_impl(e, first_variant + q0, cnt, DA.rows, lstride, LDP_MEM_DEVICE, LDP_GENO_REF | (mapped ? LDP_GENO_MAPPED : 0) | (phased ? LDP_GENO_PHASED : 0),
                             multi.empty() ? nullptr : DA.row_inverse, multi.empty() ? nullptr : h_inverse.data());
     if (LDP_ENV("LDP_DEBUG_TIMELINE")) {
       fprintf(stderr, "decode launch of %u rows: queued in %.3f ms, device done %.3f ms later, rows loaded %.3f ms after that\n", rows, t_q - t_call, t_s - t_q, now_ms() - t_s);
     }
     if (status == LDP_OK) {
+      if (into_image) {
+        e->ctr.decoded_in_place_rows += cnt;
+      }
       for (size_t k = 0; k < multi.size(); ++k) {
         const int64_t l = e->global_to_local[first_variant + q0 + multi[k]];
         if (l >= 0) {

@@ -195,6 +195,14 @@ int ldp_allgather_removed(ldp_engine* e, void* comm, const uint64_t* removed_loc
   // is enqueued aborts the communicator (ncclCommAbort wakes the other ranks with an error instead of a hang).
   const Rccl& R = rccl();
   ncclComm_t c = static_cast<ncclComm_t>(comm);
+  // A communicator an earlier failed call aborted is gone (ncclCommAbort freed it): nothing may touch the handle again -- not even
+  // ncclCommCount -- so the list of aborted handles is consulted before anything else
+  if (c) {
+    std::lock_guard<std::mutex> lk(g_aborted_mu);
+    if (g_aborted.count(c)) {
+      return fail(e, LDP_ERR_STATE, "this communicator was aborted by an earlier failed ldp_allgather_removed(): create a new one");
+    }
+  }
   // (only a handle RCCL itself has answered for is aborted: ncclCommCount on it comes first, before any other reason to leave)
   int count = 0, urank = -1;
   const bool handle_ok = c && R.ok && (R.CommCount(c, &count) == ncclSuccess) && (R.CommUserRank(c, &urank) == ncclSuccess);

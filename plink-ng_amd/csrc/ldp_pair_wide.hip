@@ -584,6 +584,11 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
                 hopeless = hopeless && (bound < gi.b * gj.b);
               }
             }
+            if constexpr (SPARSE) {
+              if (!__all(hopeless)) {
+                break;  // (the product stays: its other pairs need no answer; the interval test is ~70 FP64 operations a pair)
+              }
+            }
           }
           if (!__all(hopeless)) {
             keep |= 1u << p;

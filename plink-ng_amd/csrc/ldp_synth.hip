@@ -38,8 +38,12 @@ __host__ __device__ inline bool is_copy(uint64_t seed, uint64_t variant) {
 
 __host__ __device__ inline uint32_t alt_threshold(uint64_t seed, uint64_t variant) {
   // alt allele frequency in (0.01, 0.5), mirrored above 0.5 for half of the variants; as a 32-bit threshold
+  // (seed bits 56-62, a measurement aid like bit 63: a floor on the minor-allele frequency in percent -- what a `--maf` filter in front of
+  // the pruning step leaves; 0 = SURVEY 8(d)'s 0.01)
   const double u = variant_rnd(seed, variant, 2) * (1.0 / 4294967296.0);
-  double f = 0.01 + 0.49 * u;
+  const uint32_t floor_pct = static_cast<uint32_t>((seed >> 56) & 0x7f);
+  const double lo = (floor_pct > 1) ? ((floor_pct < 49) ? 0.01 * floor_pct : 0.49) : 0.01;
+  double f = lo + (0.5 - lo) * u;
   if ((!(seed >> 63)) && (variant_rnd(seed, variant, 3) & 1)) {  // (seed bit 63, a measurement aid: ALT is the minor allele everywhere)
     f = 1.0 - f;
   }

@@ -699,6 +699,8 @@ bool parse_misc_flags(Args& A, ArgCursor& c, const std::string& f) {
     g_dbg.host_decode = true;     // (measurement / test hook: variable-width records decoded by the host reader)
   } else if (f == "--debug-no-bind") {
     g_dbg.no_bind = true;         // (measurement: stay on whatever CPUs the scheduler picks instead of the device's NUMA node)
+  } else if (f == "--debug-serial-feed") {
+    g_dbg.serial_feed = true;     // (measurement: --gpus N feeds its engines one after the other from one thread, as rounds 2-5 did)
   } else if (f == "--debug-load-map") {
     g_dbg.load_map = true;        // (measurement: fixed-width rows copied out of the mapping instead of pread())
   } else if ((f == "--debug-x-rows") || (f == "--debug-decode-threads")) {

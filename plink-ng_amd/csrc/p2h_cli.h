@@ -234,7 +234,7 @@ enum : uint32_t {
 
 // test / measurement hooks of the front-end (hidden --debug-* flags; the library itself reads no environment, csrc/ldp_env.h)
 struct DebugHooks {
-  bool alias_devices = false, x_host = false, host_decode = false, load_map = false, no_bind = false;
+  bool alias_devices = false, x_host = false, host_decode = false, load_map = false, no_bind = false, serial_feed = false;
   uint32_t x_rows = 0, decode_threads = 0;
 };
 extern DebugHooks g_dbg;
@@ -264,7 +264,12 @@ inline uint32_t allele_ct_for_filter(const Variants& V, size_t v) {
 std::string slurp(const std::string& path);
 // This thread (and every thread it starts from here on) onto the CPUs of the NUMA node the device is attached to; a no-op where the host does not say
 // or the node's CPUs are not ours to use.  Returns the node, or -1.
-int bind_near_device(int device);
+struct AffinityMask {
+  bool valid = false;
+  unsigned long bits[16] = {0};  // a cpu_set_t (1,024 CPUs)
+};
+int bind_near_device(int device, AffinityMask* saved = nullptr);
+void restore_affinity(const AffinityMask& saved);
 void load_variants(const Args& A, Variants* V);
 int chrom_class(const std::string& name_in, bool allow_extra, bool* is_zero);
 void multiallelic_inverse_row(ldp_pgen* pg, uint32_t raw_variant, uint32_t alt_ct, const std::vector<uint32_t>& founder_idx,
@@ -530,9 +535,14 @@ struct Session {
       t_hip.join();
       t_joined = now_s();
       if ((A.gpus <= 1) && !g_dbg.no_bind) {
-        bind_near_device(0);
+        bind_near_device(0, &load_affinity);  // (several GPUs: every engine's feeding thread binds itself next to ITS device, p2h_prune.cpp)
       }
     }
+  }
+  AffinityMask load_affinity;  // what this thread ran on before join_hip() moved it next to device 0: file_to_hbm_done() puts it back
+  void file_to_hbm_done() {
+    restore_affinity(load_affinity);
+    load_affinity.valid = false;
   }
   ~Session() {
     if (t_hip.joinable()) {

@@ -79,6 +79,7 @@ struct PruneJob {
   bool alias_devices = false;
   std::vector<ldp_engine*> eng;
   uint32_t subcontig_ct = 0;
+  std::vector<uint32_t> sub_info, sub_owner;  // several engines: (length, first variant) and owning engine of every subcontig
   std::vector<uint64_t> removed;    // bit k: variant k (include order) is pruned
   std::vector<uint64_t> preferred;  // --indep-preferred, same indexing; empty: none
   std::vector<uint8_t> founder_mask;
@@ -213,7 +214,12 @@ struct PruneJob {
       }
       ldp_get_subcontigs(eng[r], &subcontig_ct, nullptr, 0);
       if (world > 1) {
-        rc = ldp_set_shard(eng[r], r, world, nullptr);
+        if (r == 0) {
+          sub_info.assign(2 * static_cast<size_t>(subcontig_ct), 0);
+          sub_owner.assign(subcontig_ct, 0);
+          ldp_get_subcontigs(eng[r], &subcontig_ct, sub_info.data(), subcontig_ct);
+        }
+        rc = ldp_set_shard(eng[r], r, world, (r == 0) ? sub_owner.data() : nullptr);
         if (rc) {
           die(16, "Error: %s\n", ldp_last_error(eng[r]));
         }
@@ -343,6 +349,130 @@ struct PruneJob {
     // takes microseconds, so a few dozen threads keep ahead of PCIe and more only get in the copies' way.
     const uint32_t decode_threads = g_dbg.decode_threads ? g_dbg.decode_threads : 32;
     double t_wait_decode = 0.0, t_load_calls = 0.0;
+    // Several engines: each is fed by a host thread of its own, all at once -- the reference's main thread fills EVERY worker's slot of a
+    // batch and the workers run together (plink2_ld.cc:1292-1417).  A feeding thread walks only the file ranges of its engine's shard,
+    // binds itself next to ITS device (NUMA node of the device's PCI function) and gives the engine copy threads and a pinned ring of
+    // its own there (ldp_use_private_copy_threads), so N PCIe links work at a time instead of one.  (Rows that reach the engines through
+    // the host decoder or the host-side founder subset keep the one-after-the-other loop below: --indep-pairphase, --debug-host-decode.)
+    if ((world > 1) && (!A.pairphase) && (!g_dbg.serial_feed) && (direct || device_decode) && (all_founders || device_subset)) {
+      struct FeedStat {
+        double t0 = -1.0, t1 = -1.0;
+        uint64_t rows = 0, calls = 0;
+        int node = -1, rc = 0;
+        std::string err;
+      };
+      std::vector<FeedStat> stat(world);
+      // variant ranges [first, end) of every engine's subcontigs, in variant order
+      std::vector<std::vector<std::pair<uint32_t, uint32_t>>> mine(world);
+      for (uint32_t s = 0; s < subcontig_ct; ++s) {
+        mine[sub_owner[s]].push_back({sub_info[2 * s + 1], sub_info[2 * s + 1] + sub_info[2 * s]});
+      }
+      for (auto& v : mine) {
+        std::sort(v.begin(), v.end());
+      }
+      std::vector<std::thread> feeders;
+      for (int r = 0; r < world; ++r) {
+        feeders.emplace_back([&, r]() {
+          FeedStat& st = stat[r];
+          AffinityMask before;
+          if (!g_dbg.no_bind) {
+            st.node = bind_near_device(r % n_devices, &before);
+          }
+          (void)ldp_use_private_copy_threads(eng[r]);
+          std::vector<ldp_pgen_rec> idx;
+          size_t at = 0;  // first range of mine[r] that may still reach the current run
+          for (const Run& rn : runs) {
+            while ((at < mine[r].size()) && (mine[r][at].second <= rn.q)) {
+              ++at;
+            }
+            uint64_t owned_rows = 0;
+            for (size_t k = at; (k < mine[r].size()) && (mine[r][k].first < rn.q + rn.n); ++k) {
+              owned_rows += std::min(mine[r][k].second, rn.q + rn.n) - std::max(mine[r][k].first, rn.q);
+            }
+            if (!owned_rows) {
+              continue;  // another engine's part of the file
+            }
+            const double tc = now_s();
+            if (st.t0 < 0.0) {
+              st.t0 = tc;
+            }
+            int rc;
+            if (device_decode) {
+              idx.resize(rn.n);
+              uint32_t base_v = UINT32_MAX;
+              ldp_pgen_rec base_rec;
+              if (ldp_pgen_record_index(pg, rn.raw0, rn.n, idx.data(), &base_v) || ((base_v != UINT32_MAX) && ldp_pgen_record_index(pg, base_v, 1, &base_rec, nullptr))) {
+                st.rc = 6;
+                st.err = gpath + ": malformed variant record index.";
+                return;
+              }
+              if (device_multi) {
+                for (uint32_t t = 0; t < rn.n; ++t) {
+                  const uint32_t alts = V.alt_ct[rn.raw0 + t];
+                  if ((alts > 1) && (vcls[mk[rn.q + t]] != 5)) {
+                    if (alts > 254) {
+                      st.rc = 63;
+                      st.err = "variant '" + V.id[rn.raw0 + t] + "' has more than 254 ALT alleles: not supported by plink2-hip.";
+                      return;
+                    }
+                    idx[t].allele_ct = static_cast<uint8_t>(alts + 1);
+                  }
+                }
+              }
+              rc = ldp_load_pgen_records(eng[r], rn.q, rn.n, file_bytes, file_size, LDP_MEM_HOST, idx.data(), (base_v != UINT32_MAX) ? &base_rec : nullptr, raw_sample_ct, nullptr);
+              if (rc) {
+                st.rc = (rc == LDP_ERR_INVALID) ? 6 : 16;
+                st.err = gpath + ": " + ldp_last_error(eng[r]);
+                return;
+              }
+            } else {
+              const int enc = load_encoding | (device_subset ? LDP_GENO_MAPPED : 0);
+              rc = (direct_fd >= 0) ? ldp_load_genotypes_fd(eng[r], rn.q, rn.n, direct_fd, direct_off + static_cast<uint64_t>(rn.raw0) * rec_bytes, in_rec, enc)
+                                    : ldp_load_genotypes(eng[r], rn.q, rn.n, direct + static_cast<uint64_t>(rn.raw0) * rec_bytes, in_rec, LDP_MEM_HOST, enc);
+              if (rc) {
+                st.rc = 16;
+                st.err = ldp_last_error(eng[r]);
+                return;
+              }
+            }
+            st.t1 = now_s();
+            st.rows += owned_rows;
+            ++st.calls;
+          }
+          restore_affinity(before);
+        });
+      }
+      for (std::thread& t : feeders) {
+        t.join();
+      }
+      for (int r = 0; r < world; ++r) {
+        if (stat[r].rc) {
+          die(stat[r].rc, "\nError: %s\n", stat[r].err.c_str());
+        }
+      }
+      if (A.timing) {
+        // the engines' load intervals (seconds since main()): they overlap when the engines are fed at the same time
+        double busy_sum = 0.0, span0 = 1e300, span1 = 0.0;
+        for (int r = 0; r < world; ++r) {
+          const FeedStat& st = stat[r];
+          if (st.t0 < 0.0) {
+            logprintf("\n[timing] engine %d (device %d): no rows of its own in this file", r, r % n_devices);
+            continue;
+          }
+          logprintf("\n[timing] engine %d (device %d, NUMA node %d): fed %.3f - %.3f s (%.3f s), %llu rows in %llu calls, %.1f GB/s", r, r % n_devices, st.node,
+                    st.t0 - t_begin, st.t1 - t_begin, st.t1 - st.t0, static_cast<unsigned long long>(st.rows), static_cast<unsigned long long>(st.calls),
+                    (st.t1 > st.t0) ? (static_cast<double>(st.rows) * static_cast<double>(direct ? rec_bytes : out_rec) / (st.t1 - st.t0) / 1e9) : 0.0);
+          busy_sum += st.t1 - st.t0;
+          span0 = std::min(span0, st.t0);
+          span1 = std::max(span1, st.t1);
+        }
+        if (span1 > span0) {
+          logprintf("\n[timing] %d engines fed concurrently: load span %.3f s, sum of the engines' own intervals %.3f s (overlap factor %.2f)\n", world, span1 - span0, busy_sum,
+                    busy_sum / (span1 - span0));
+        }
+      }
+      return;
+    }
     int decode_rc = 0;
     uint32_t unphased_at = 0;
     pending_unphased = UINT32_MAX;
@@ -941,6 +1071,7 @@ struct PruneJob {
         load_diploid_rows();
         patch_host_built_rows();
         set_dosage_frequencies();
+        S.file_to_hbm_done();  // (this thread moved next to device 0 for the file -> HBM leg, Session::join_hip: back to where it was)
         run_diploid_engines();
       }
       if (A.timing) {

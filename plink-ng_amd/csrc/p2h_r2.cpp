@@ -418,7 +418,7 @@ int write_vcor_table(R2Job& J) {
               x_done = true;
             }
           }
-          if (any_x && (!x_done) && (!A.r2_inter) && J.xw.band_ready()) {
+          if (any_x && (!x_done) && (!A.r2_inter) && (thresh >= 0.0) && J.xw.band_ready()) {  // (a negative --ld-window-r2 keeps NaN pairs: the host list path below)
             // windowed plan: the chrX run's own all-pairs engines give the windows' pairs on the pair kernels, weighted and filtered on the device
             const XWeighted& xw = J.xw;
             const uint32_t j0 = std::max(r0, xw.band_first), j1 = std::min(r0 + big, xw.band_first + xw.band_ct);

@@ -261,10 +261,15 @@ char* format_g6(double x, char* out) {
 
 
 
-// The device's NUMA node (ldp_device_numa_node) -> its CPUs (sysfs cpulist: "0-63,128-191") -> this thread's affinity, intersected with what the process may use.
-// Threads started afterwards inherit it, and memory they touch first lands on that node: the copy pool and the pinned staging ring of a load
+// The device's NUMA node (ldp_device_numa_node) -> its CPUs (sysfs cpulist: "0-63,128-191") -> this THREAD's affinity, intersected with what the process may use.
+// Threads started afterwards by this thread inherit it, and memory they touch first lands on that node: the copy pool and the pinned staging ring of a load
 // (ldp_engine_load.cpp) then feed the device's DMA engines without crossing the inter-socket fabric.
-int bind_near_device(int device) {
+// Only when the node leaves this thread enough to work with -- at least 8 of its CPUs, or at least half of them (a container whose cpuset holds one or two CPUs
+// of that node would otherwise put 32 copy threads on them) --, and `saved` (optional) receives the mask it had, for restore_affinity() once the file -> HBM leg is over.
+int bind_near_device(int device, AffinityMask* saved) {
+  if (saved) {
+    saved->valid = false;
+  }
   const int node = ldp_device_numa_node(device);
   if (node < 0) {
     return -1;
@@ -302,10 +307,27 @@ int bind_near_device(int device) {
     return -1;
   }
   CPU_AND(&want, &want, &cur);
-  if ((CPU_COUNT(&want) == 0) || sched_setaffinity(0, sizeof(want), &want)) {
+  const int keep = CPU_COUNT(&want), have = CPU_COUNT(&cur);
+  if ((keep == 0) || ((keep < 8) && (2 * keep < have))) {
     return -1;
   }
+  if (sched_setaffinity(0, sizeof(want), &want)) {
+    return -1;
+  }
+  if (saved) {
+    static_assert(sizeof(saved->bits) >= sizeof(cpu_set_t), "AffinityMask holds a cpu_set_t");
+    memcpy(saved->bits, &cur, sizeof(cur));
+    saved->valid = true;
+  }
   return node;
+}
+
+void restore_affinity(const AffinityMask& saved) {
+  if (saved.valid) {
+    cpu_set_t old;
+    memcpy(&old, saved.bits, sizeof(old));
+    (void)sched_setaffinity(0, sizeof(old), &old);
+  }
 }
 
 }  // namespace p2h

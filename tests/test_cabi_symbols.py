@@ -52,7 +52,7 @@ def test_struct_layouts_match_the_header(pkg):
     assert ctypes.sizeof(pkg.ldp_pair_stats_t) == 24 == pkg.PAIR_STATS_DTYPE.itemsize
     assert ctypes.sizeof(pkg.ldp_variant_rec) == 32 == pkg.VARIANT_REC_DTYPE.itemsize
     assert ctypes.sizeof(pkg.ldp_params) == 48
-    assert ctypes.sizeof(pkg.ldp_counters) == 192
+    assert ctypes.sizeof(pkg.ldp_counters) == 200
 
 
 def test_device_count_never_fails(pkg):
@@ -84,3 +84,24 @@ def test_product_does_not_reference_the_oracle():
                 if f.endswith((".py", ".cpp", ".hip", ".h")):
                     src = open(os.path.join(dirpath, f), errors="ignore").read()
                     assert "ldoracle" not in src and "oracle/" not in src and "ldtools" not in src, os.path.join(dirpath, f)
+
+
+def test_private_copy_threads_come_and_go_with_their_engine(pkg):
+    """ldp_use_private_copy_threads (round 6: plink2-hip --gpus N feeds every engine from a thread of its own): no device needed -- the pool is
+    host threads --, idempotent, NULL refused, and ldp_destroy joins the threads it started (the process-wide pool is never joined)."""
+    import threading
+    L = pkg.lib()
+    L.ldp_use_private_copy_threads.argtypes = [ctypes.c_void_p]
+    L.ldp_use_private_copy_threads.restype = ctypes.c_int
+    assert L.ldp_use_private_copy_threads(None) != 0
+    before = threading.active_count()
+    def native_threads():
+        return len(os.listdir("/proc/self/task"))
+    n0 = native_threads()
+    eng = pkg.LdPruneEngine(64, 10, 1, False, 0.5, device=0)
+    assert L.ldp_use_private_copy_threads(eng._h) == 0
+    n1 = native_threads()
+    assert L.ldp_use_private_copy_threads(eng._h) == 0 and native_threads() == n1   # idempotent
+    assert n1 > n0 or (os.cpu_count() or 1) == 1
+    eng.close()
+    assert native_threads() == n0 and threading.active_count() == before

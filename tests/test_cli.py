@@ -477,9 +477,20 @@ def test_cli_n_engines_match_reference(gpu_pkg, cli, tmp_path, engines, fmt, ord
                           text=True, timeout=600)
     assert many.returncode == 0, many.stdout
     assert "(%d GPUs)" % engines in many.stdout and ("%d engines on" % engines) in many.stdout, many.stdout
+    # every engine is fed by a thread of its own, all at once (round 6; the reference's main thread fills every worker's slot of a batch,
+    # plink2_ld.cc:1292-1417): the --timing lines name each engine's load interval and the overlap
+    assert ("%d engines fed concurrently" % engines) in many.stdout, many.stdout
+    assert len(re.findall(r"\[timing\] engine \d+ \(device \d+", many.stdout)) == engines, many.stdout
     for ext in (".prune.in", ".prune.out"):
         assert filecmp.cmp(str(tmp_path / ("ref" + ext)), str(tmp_path / ("many" + ext)), shallow=False)
         assert filecmp.cmp(str(tmp_path / ("one" + ext)), str(tmp_path / ("many" + ext)), shallow=False)
+    if engines == 3:
+        # --debug-serial-feed: one thread feeds the engines in turn, as rounds 2-5 did -- the same files
+        ser = subprocess.run([cli] + common + alias + ["--gpus", str(engines), "--timing", "--debug-serial-feed", "--out", "ser"], cwd=str(tmp_path), stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert ser.returncode == 0 and "fed concurrently" not in ser.stdout, ser.stdout
+        for ext in (".prune.in", ".prune.out"):
+            assert filecmp.cmp(str(tmp_path / ("ser" + ext)), str(tmp_path / ("many" + ext)), shallow=False)
 
 
 def dummy_dosage_fileset(tmp_path, name, n, m, freq, seed):

@@ -27,7 +27,10 @@ def main():
     ap.add_argument("--rates", default="0,0.001,0.01")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--sets", default="default:")
+    ap.add_argument("--maf-min", type=int, default=0, help="floor on the generator's minor-allele frequency in percent (seed bits 56-62; 0 = the bench generator's 1 %%)")
     args = ap.parse_args()
+    if args.maf_min:
+        bench.SEED = bench.SEED | (args.maf_min << 56)
     import torch
     pkg = ge.load_package()
     cfg = dict(bench.CONFIGS["config3"], variants=args.variants)
@@ -37,7 +40,7 @@ def main():
     for spec in args.sets.split(";"):
         name, _, opts = spec.partition(":")
         sets.append((name, {k: float(v) for k, v in (kv.split("=") for kv in opts.split(",") if kv)}))
-    out = {"samples": cfg["samples"], "variants": cfg["variants"], "window_kb": cfg["window_kb"], "r2": cfg["r2"], "rates": {}}
+    out = {"samples": cfg["samples"], "variants": cfg["variants"], "window_kb": cfg["window_kb"], "r2": cfg["r2"], "maf_min_percent": args.maf_min or 1, "rates": {}}
     for rate in [float(x) for x in args.rates.split(",")]:
         res, words_of = {}, {}
         for name, opts in sets:
