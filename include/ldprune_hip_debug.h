@@ -32,6 +32,10 @@ int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first
  *                     founders, engines with more use 0 by themselves); 0 = the +-2 coded x and the call flags n of rounds 2-3
  *   "pair_four_tiles" 0/1: ... and in wide bands (subcontigs with the tile plan) that form runs over quarter tiles instead of the
  *                     parallelogram plan (default 1)
+ *   "pred_csr"        0/1: prune runs return the predicate rows as their non-zero words, compacted on the device and written straight into pinned host
+ *                     memory (default 1); 0 = the dense rows are copied back whole, as in rounds 1-5
+ *   "csr_capacity"    k: (test hook, before ldp_set_variants()) the compacted rows' buffer holds k entries; a run with more non-zero words falls back
+ *                     to the dense rows (0 = a quarter of all predicate words)
  *   "wide_async"      0/1: the 8 x 8 tiles on the barrier-free experiment of round 5 (pair_mfma_wide_async_kernel; default 0).  For measurements
  *                     and tests ONLY: a wave whose LDS poll does not come true within ~2^22 polls (a fraction of a second) traps, which ends the
  *                     HIP context of the whole process with no LDP_ERR code -- timing alone can do that under a debugger, a single-stepping

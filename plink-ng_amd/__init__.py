@@ -106,7 +106,7 @@ CABI_SYMBOLS = [
 
 
 def _sources():
-    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_codes.hip", "ldp_pair_mfma.hip", "ldp_pair_wide.hip", "ldp_pgen_decode.hip", "ldp_synth.hip", "ldp_engine.cpp", "ldp_engine_run.cpp", "ldp_engine_r2.cpp",
+    return [os.path.join(CSRC, f) for f in ("ldp_kernels.hip", "ldp_codes.hip", "ldp_pair_mfma.hip", "ldp_pair_wide.hip", "ldp_pred_csr.hip", "ldp_pgen_decode.hip", "ldp_synth.hip", "ldp_engine.cpp", "ldp_engine_run.cpp", "ldp_engine_r2.cpp",
                                           "ldp_engine_load.cpp", "ldp_engine_shard.cpp", "ldp_pgen.cpp", "ldp_topology.cpp")]
 
 

@@ -206,6 +206,21 @@ struct PairKernelArgs {
 
 constexpr uint32_t kRouteComplete = 0, kRouteSparse = 1, kRouteGeneral = 2;
 
+// The predicate rows [row_first, row_end) of a launch group as CSR (ldp_pred_csr.hip): meta[j] = (first entry, entries) of row j, an entry =
+// (word index inside the row, the word's bits), ascending.  meta, ent and overflow are pinned HOST memory the kernel writes directly;
+// counter (device) runs on from launch to launch of a run.
+struct PredCsrArgs {
+  const uint32_t* pred;
+  const uint64_t* row_off;
+  uint32_t row_first, row_end;
+  uint2* meta;
+  uint2* ent;
+  unsigned long long* counter;
+  uint64_t capacity;   // entries `ent` holds
+  uint32_t* overflow;  // set to 1 when the run's non-zero words do not fit
+};
+hipError_t launch_pred_compact(const PredCsrArgs& a, hipStream_t stream);
+
 // What the rows a launch reads miss (miss_stats_kernel over their records, when the launch is queued): the largest count in a
 // row, and striped over kMissStripes words the total of missing calls and the number of rows beyond `miss_high` of them.
 constexpr uint32_t kMissStripes = 64;

@@ -73,6 +73,20 @@ void free_device(ldp_engine* e) {
   if (e->h_pred) {
     (void)hipHostFree(e->h_pred);
   }
+  if (e->h_csr_meta) {
+    (void)hipHostFree(e->h_csr_meta);
+    e->h_csr_meta = nullptr;
+  }
+  if (e->h_csr_ent) {
+    (void)hipHostFree(e->h_csr_ent);
+    e->h_csr_ent = nullptr;
+  }
+  if (e->h_csr_flag) {
+    (void)hipHostFree(e->h_csr_flag);
+    e->h_csr_flag = nullptr;
+  }
+  (void)hipFree(e->d_csr_counter);
+  e->d_csr_counter = nullptr;
   if (e->h_counters_pin) {
     (void)hipHostFree(e->h_counters_pin);
     e->h_counters_pin = nullptr;
@@ -765,6 +779,8 @@ void build_shard(ldp_engine* e) {
       g.need_end = e->items[i1 - 1].jend;
       g.word_first = e->row_off[e->items[i0].j0];
       g.word_end = e->row_off[e->items[i1 - 1].jend];
+      g.row_first = e->items[i0].j0;
+      g.row_end = e->items[i1 - 1].jend;
       e->groups.push_back(g);
       i0 = i1;
     }
@@ -963,7 +979,17 @@ int ensure_device_plan(ldp_engine* e) {
       }
     }
   }
-  HIP_TRY(e, hipHostMalloc(&e->h_pred, std::max<size_t>(e->pred_words, 1) * sizeof(uint32_t), hipHostMallocDefault));
+  // (the dense predicate rows on the host -- 270 MB of pinned memory for a config-3 share -- only when a run wants them: ensure_h_pred)
+  if (e->opt.pred_csr && e->local_ct) {
+    e->csr_capacity = e->opt.csr_capacity ? e->opt.csr_capacity : std::min<uint64_t>(std::max<uint64_t>(1u << 16, e->pred_words / 4), 0xffffffffull);
+    HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_csr_meta), static_cast<size_t>(e->local_ct) * sizeof(uint2), hipHostMallocDefault));
+    memset(e->h_csr_meta, 0, static_cast<size_t>(e->local_ct) * sizeof(uint2));  // (rows no launch group owns hold no pair: no entries, ever)
+    HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_csr_ent), static_cast<size_t>(e->csr_capacity) * sizeof(uint2), hipHostMallocDefault));
+    HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_csr_flag), 64, hipHostMallocDefault));
+    e->h_csr_flag[0] = 0;
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_csr_counter), sizeof(unsigned long long)));
+    HIP_TRY(e, hipMemsetAsync(e->d_csr_counter, 0, sizeof(unsigned long long), e->stream));
+  }
   // (4 counters, then the route words of the launch groups + the inspection launch)
   HIP_TRY(e, hipHostMalloc(&e->h_counters_pin, 4 * sizeof(unsigned long long) + (e->groups.size() + 1) * sizeof(uint32_t), hipHostMallocDefault));
   mark("pinned host buffers");
@@ -1035,7 +1061,12 @@ int ensure_staging(ldp_engine* e) {
     return LDP_OK;
   }
   const size_t row_bytes = std::max<size_t>((static_cast<size_t>(e->P.founder_ct) + 3) / 4, ldp_phased_row_bytes(e->P.founder_ct)) + 4;
-  const size_t bytes = std::max(kStageBytes, row_bytes);
+  size_t slot_bytes = kStageBytes;
+  if (const char* mb = LDP_ENV("LDP_DEBUG_STAGE_MB")) {  // (measurement build: the slot size of the pinned ring)
+    slot_bytes = static_cast<size_t>(std::max(1, atoi(mb))) << 20;
+  }
+  const size_t bytes = std::max(slot_bytes, row_bytes);
+  e->stage_bytes = bytes;
   for (uint32_t k = 0; k < kStageSlots; ++k) {
     HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_stage[k]), bytes, hipHostMallocDefault));
     HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_stage[k]), bytes));
@@ -1551,6 +1582,16 @@ int ldp_debug_set_option(ldp_engine* e, const char* name, double value) {
     e->opt.sparse_frac = value;
   } else if (n == "wide_async") {
     e->opt.wide_async = (value != 0.0);
+  } else if (n == "pred_csr") {
+    if (e->planned && e->gpu_ok && (value != 0.0) && !e->h_csr_meta) {
+      return fail(e, LDP_ERR_STATE, "pred_csr can only be switched ON before the engine's device buffers exist (ldp_set_variants)");
+    }
+    e->opt.pred_csr = (value != 0.0);
+  } else if (n == "csr_capacity") {
+    if (e->planned) {
+      return fail(e, LDP_ERR_STATE, "csr_capacity must be set before ldp_set_variants()");
+    }
+    e->opt.csr_capacity = static_cast<uint64_t>(std::max(0.0, value));
   } else if (n == "wide_sparse") {
     e->opt.wide_sparse = (value != 0.0);
   } else if (n == "replay_steps") {

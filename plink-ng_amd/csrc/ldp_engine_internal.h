@@ -189,6 +189,8 @@ struct EngineOptions {
   bool pair_gu = true;        // option "pair_gu" 0: the four-product form multiplies x and n (rounds 2-3) instead of allele counts and missing flags
   bool four_tiles = true;     // LDP_PAIR_FOUR_TILES=0: the four-product form stays on the parallelogram plan in wide bands too
   uint32_t wide_diag_last = 2; // LDP_DEBUG_WIDE_DIAG_LAST=k: tiles fewer than k tile distances from the diagonal run at the end of their XCD stream (0: plain J order)
+  uint64_t csr_capacity = 0;   // test hook "csr_capacity" k: the CSR buffer holds k entries (0: a quarter of the predicate words), to force the dense fallback
+  bool pred_csr = true;        // option "pred_csr" 0: prune runs copy their dense predicate rows back (rounds 1-5) instead of the non-zero words (ldp_pred_csr.hip)
   bool wide_sparse = true;     // LDP_WIDE_SPARSE=0 / option "wide_sparse" 0: launches with a few missing calls leave the 8 x 8 tiles for the parallelogram plan (rounds 2-5)
   bool wide_async = false;     // option "wide_async": the 8 x 8 tiles on pair_mfma_wide_async_kernel (flags instead of a workgroup barrier per stage)
   // test hooks (ldp_debug_set_option only; 0 = off): results never depend on them
@@ -246,6 +248,7 @@ struct ldp_engine {
     uint32_t item_first = 0, item_ct = 0;
     uint32_t need_end = 0;               // local variants [0, need_end) must be loaded
     uint64_t word_first = 0, word_end = 0;  // predicate words the group's J-tiles own
+    uint32_t row_first = 0, row_end = 0;    // ... = the predicate rows of these second variants
     uint32_t mf_first = 0, mf_ct = 0;    // the same J range as matrix-pipe workgroups (mf_wgs) ...
     uint32_t mf_diag_ct = 0;             // ... of which the first mf_diag_ct are all-diagonal (partition_diag)
     uint32_t wd_first = 0, wd_ct = 0;    // ... and as wide-band tiles (wd_tiles)
@@ -305,7 +308,14 @@ struct ldp_engine {
   uint32_t* d_route = nullptr;             // [g]: which matrix-pipe kernel owns launch group g (route_kernel, when the group is queued); [groups]: other launches
   uint32_t checkpoint_chunk[kCheckpoints];
   uint32_t n_checkpoints = 0;
-  uint32_t* h_pred = nullptr;  // pinned
+  uint32_t* h_pred = nullptr;  // pinned; allocated when a run needs the dense rows (inspection runs, engines without pred_csr, the overflow fallback)
+  // the predicate rows as CSR (ldp_pred_csr.hip), written by the device straight into these pinned buffers; h_csr_flag[0] = overflow
+  uint2* h_csr_meta = nullptr;
+  uint2* h_csr_ent = nullptr;
+  uint32_t* h_csr_flag = nullptr;
+  uint64_t csr_capacity = 0;
+  unsigned long long* d_csr_counter = nullptr;
+  uint32_t ctr_csr_overflows = 0;  // runs that fell back to the dense rows (test hook: option "csr_capacity")
   unsigned long long* h_counters_pin = nullptr;  // pinned: a pageable destination would make the 'async' copy block the host
   bool plan_uploaded = false;
   bool recs_registered = false;
@@ -317,6 +327,7 @@ struct ldp_engine {
   hipEvent_t pair_tail[kPairStreams] = {nullptr};  // last thing queued on each pair stream
   bool pair_tail_set[kPairStreams] = {false};
   uint8_t* h_stage[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging ring for host-memory genotype input
+  size_t stage_bytes = 0;              // bytes of one slot of the ring (ensure_staging)
   std::unique_ptr<CopyPool> own_pool;  // ldp_use_private_copy_threads(): this engine's own copy threads (else the process-wide pool)
   uint8_t* d_stage[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t stage_done[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};

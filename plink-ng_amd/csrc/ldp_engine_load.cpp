@@ -56,7 +56,7 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
     if (rc) {
       return rc;
     }
-    stage_rows = std::max<size_t>(1, kStageBytes / pack_stride);
+    stage_rows = std::max<size_t>(1, e->stage_bytes / pack_stride);
   }
   const uint64_t gather_stride = ((static_cast<uint64_t>(e->P.founder_ct) + 3) / 4 + 3) & ~static_cast<uint64_t>(3);
   size_t gather_rows = 0;
@@ -65,7 +65,7 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
       HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_sample_map), e->sample_map.size() * sizeof(uint32_t)));
       HIP_TRY(e, hipMemcpy(e->d_sample_map, e->sample_map.data(), e->sample_map.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    gather_rows = std::max<size_t>(1, std::max<size_t>(stage_rows, kStageBytes / gather_stride));
+    gather_rows = std::max<size_t>(1, std::max<size_t>(stage_rows, std::max(kStageBytes, e->stage_bytes) / gather_stride));
     if (location == LDP_MEM_HOST) {
       gather_rows = stage_rows;
     }

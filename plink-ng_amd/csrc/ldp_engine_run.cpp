@@ -26,7 +26,32 @@ inline uint32_t next_clear(const std::vector<uint32_t>& bm, uint32_t from, uint3
 // (i>>5)-(lo[j]>>5).
 // Resumable at batch boundaries (what carries over is R and first_unchecked): *cursor (nullptr: the subcontig's start) is the
 // first variant not replayed yet, and only batches whose variants all lie below `covered` -- complete predicate rows -- run.
-uint64_t replay_subcontig(const ldp_engine* e, uint32_t k, const uint32_t* pred, const double* mf, std::vector<uint32_t>& R,
+// The predicate rows the replay reads: dense bit rows (`dense` != nullptr), or their non-zero words as CSR (ldp_pred_csr.hip: meta[j] = first
+// entry / entries of row j, an entry = (word index inside the row, bits), ascending).
+struct PredView {
+  const uint32_t* dense;
+  const uint2* meta;
+  const uint2* ent;
+  uint64_t capacity;
+};
+// word `widx` of row j
+inline uint32_t pred_word(const ldp_engine* e, const PredView& pv, uint32_t j, uint32_t widx) {
+  if (pv.dense) {
+    return pv.dense[e->row_off[j] + widx];
+  }
+  const uint2 mt = pv.meta[j];
+  if (static_cast<uint64_t>(mt.x) + mt.y > pv.capacity) {
+    return 0;  // (an overflowed run: the caller replays from the dense rows afterwards)
+  }
+  for (uint32_t q = 0; q < mt.y; ++q) {
+    if (pv.ent[mt.x + q].x == widx) {
+      return pv.ent[mt.x + q].y;
+    }
+  }
+  return 0;
+}
+
+uint64_t replay_subcontig(const ldp_engine* e, uint32_t k, const PredView& pv, const double* mf, std::vector<uint32_t>& R,
                           std::vector<uint32_t>& first_unchecked, uint32_t* cursor = nullptr, uint32_t covered = 0xffffffffu) {
   uint64_t replay_pairs = 0;
   const bool plink1 = e->P.plink1_order != 0;
@@ -59,16 +84,11 @@ uint64_t replay_subcontig(const ldp_engine* e, uint32_t k, const uint32_t* pred,
         if (j <= lo) {
           continue;
         }
-        const uint32_t* row = pred + e->row_off[j];
         const uint32_t wbase = lo >> 5;
         const uint32_t nw = ((j - 1) >> 5) - wbase + 1;
         const double mf_j_eps = mf[j] * (1 + kSmallEpsilon);
         bool second_removed = false;
-        for (uint32_t w = nw; (w-- > 0) && !second_removed;) {
-          uint32_t bits = row[w];
-          if (!bits) {
-            continue;
-          }
+        auto visit = [&](uint32_t w, uint32_t bits) {  // word w of the row, highest first
           bits &= ~load32(R, wbase + w);
           while (bits) {
             const uint32_t t = 31 - __builtin_clz(bits);
@@ -81,6 +101,24 @@ uint64_t replay_subcontig(const ldp_engine* e, uint32_t k, const uint32_t* pred,
               break;
             }
             set32(R, i);
+          }
+        };
+        if (pv.dense) {
+          const uint32_t* row = pv.dense + e->row_off[j];
+          for (uint32_t w = nw; (w-- > 0) && !second_removed;) {
+            if (row[w]) {
+              visit(w, row[w]);
+            }
+          }
+        } else {
+          const uint2 mt = pv.meta[j];
+          if (static_cast<uint64_t>(mt.x) + mt.y <= pv.capacity) {
+            const uint2* en = pv.ent + mt.x;
+            for (uint32_t q = mt.y; (q-- > 0) && !second_removed;) {
+              if (en[q].x < nw) {
+                visit(en[q].x, en[q].y);
+              }
+            }
           }
         }
       }
@@ -104,7 +142,7 @@ uint64_t replay_subcontig(const ldp_engine* e, uint32_t k, const uint32_t* pred,
           }
           while (true) {
             const uint32_t lo2 = e->lo_local[second];
-            const uint32_t word = pred[e->row_off[second] + ((first >> 5) - (lo2 >> 5))];
+            const uint32_t word = pred_word(e, pv, second, (first >> 5) - (lo2 >> 5));
             ++replay_pairs;
             if ((word >> (first & 31)) & 1) {
               if (mf[first] > mf[second] * (1 + kSmallEpsilon)) {
@@ -136,7 +174,7 @@ uint64_t replay_subcontig(const ldp_engine* e, uint32_t k, const uint32_t* pred,
 
 // Replay as the launch groups come back: group g is waited for, then every subcontig whose variants all lie below
 // its need_end is replayed (concurrently) while the GPU works on the later groups.
-int replay_progressive(ldp_engine* e, const uint32_t* pred, const double* mf, std::vector<uint32_t>& R, uint64_t* replay_pairs_out, double* busy_ms_out) {
+int replay_progressive(ldp_engine* e, const PredView& pred, const double* mf, std::vector<uint32_t>& R, uint64_t* replay_pairs_out, double* busy_ms_out) {
   std::vector<uint32_t> first_unchecked;
   if (e->P.plink1_order) {
     first_unchecked.assign(e->local_ct, 0);
@@ -219,7 +257,7 @@ int replay_progressive(ldp_engine* e, const uint32_t* pred, const double* mf, st
   return LDP_OK;
 }
 
-void replay(ldp_engine* e, const uint32_t* pred, const double* mf, std::vector<uint32_t>& R, uint64_t* replay_pairs_out) {
+void replay_view(ldp_engine* e, const PredView& pred, const double* mf, std::vector<uint32_t>& R, uint64_t* replay_pairs_out) {
   std::vector<uint32_t> first_unchecked;
   if (e->P.plink1_order) {
     first_unchecked.assign(e->local_ct, 0);
@@ -248,6 +286,11 @@ void replay(ldp_engine* e, const uint32_t* pred, const double* mf, std::vector<u
     total.fetch_add(replay_subcontig(e, order[t], pred, mf, R, first_unchecked));
   });
   *replay_pairs_out = total.load();
+}
+
+void replay(ldp_engine* e, const uint32_t* pred, const double* mf, std::vector<uint32_t>& R, uint64_t* replay_pairs_out) {
+  const PredView pv = {pred, nullptr, nullptr, 0};
+  replay_view(e, pv, mf, R, replay_pairs_out);
 }
 
 int finish_removed(ldp_engine* e, const std::vector<uint32_t>& R, uint64_t* removed) {
@@ -355,6 +398,25 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.wd_sparse = 0;
 }
 
+// the dense predicate rows on the host: pinned, allocated the first time a run wants them
+int ensure_h_pred(ldp_engine* e) {
+  if (!e->h_pred) {
+    HIP_TRY(e, hipHostMalloc(&e->h_pred, std::max<size_t>(e->pred_words, 1) * sizeof(uint32_t), hipHostMallocDefault));
+  }
+  return LDP_OK;
+}
+// prune runs return their predicate rows as CSR (ldp_pred_csr.hip) unless the engine says otherwise
+inline bool use_pred_csr(const ldp_engine* e) { return e->opt.pred_csr && (e->h_csr_meta != nullptr); }
+// a new series of pair launches begins: the device-side counters they add to
+int reset_launch_counters(ldp_engine* e) {
+  HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
+  if (e->d_csr_counter) {
+    HIP_TRY(e, hipMemsetAsync(e->d_csr_counter, 0, sizeof(unsigned long long), e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->h_csr_flag, 0, sizeof(uint32_t), e->stream));  // (pinned host memory, cleared in stream order)
+  }
+  return LDP_OK;
+}
+
 // A new load epoch begins (variants are being loaded again): whatever the pair streams still run belongs to the
 // old data.  Order the main stream behind it, forget the launches and clear the counters.
 int begin_load_epoch(ldp_engine* e) {
@@ -364,7 +426,12 @@ int begin_load_epoch(ldp_engine* e) {
       e->pair_tail_set[k] = false;
     }
   }
-  HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
+  {
+    const int rrc = reset_launch_counters(e);
+    if (rrc) {
+      return rrc;
+    }
+  }
   ++e->load_epoch;
   e->loaded_prefix = 0;
   e->next_group = 0;
@@ -446,7 +513,28 @@ int launch_group(ldp_engine* e, uint32_t gi) {
       return hipfail(e, krc, "pair_mfma_kernel launch");
     }
   }
-  if (g.word_end > g.word_first) {
+  if (use_pred_csr(e)) {
+    // the group's rows go back as their non-zero words, written by the device straight into pinned host memory (plink2_ld.cc:1093-1097 writes a
+    // removed bit where it is decided; here 270 MB of predicate rows shrink to ~30 MB before they cross PCIe)
+    ldp::PredCsrArgs C;
+    C.pred = e->d_pred;
+    C.row_off = e->d_row_off;
+    C.row_first = g.row_first;
+    C.row_end = g.row_end;
+    C.meta = e->h_csr_meta;
+    C.ent = e->h_csr_ent;
+    C.counter = e->d_csr_counter;
+    C.capacity = e->csr_capacity;
+    C.overflow = e->h_csr_flag;
+    krc = launch_pred_compact(C, ps);
+    if (krc != hipSuccess) {
+      return hipfail(e, krc, "pred_compact_kernel launch");
+    }
+  } else if (g.word_end > g.word_first) {
+    const int prc = ensure_h_pred(e);
+    if (prc) {
+      return prc;
+    }
     HIP_TRY(e, hipMemcpyAsync(e->h_pred + g.word_first, e->d_pred + g.word_first, (g.word_end - g.word_first) * sizeof(uint32_t), hipMemcpyDeviceToHost, ps));
   }
   HIP_TRY(e, hipEventRecord(g.ev_done, ps));
@@ -527,6 +615,10 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     }
     HIP_TRY(e, hipMemsetAsync(e->d_pred, 0, std::max<size_t>(e->pred_words, 1) * sizeof(uint32_t), e->stream));
     HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));
+    rc = ensure_h_pred(e);  // (an inspection run reads the dense rows)
+    if (rc) {
+      return rc;
+    }
     PairKernelArgs A;
     fill_pair_args(e, &A, false);
     A.stats = d_stats;
@@ -610,7 +702,10 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
       any_launched = any_launched || g.launched;
     }
     if (!any_launched) {
-      HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(unsigned long long), e->stream));  // (ahead of every ev_ready)
+      rc = reset_launch_counters(e);  // (ahead of every ev_ready)
+      if (rc) {
+        return rc;
+      }
     }
     rc = launch_ready_groups(e);
     if (rc) {
@@ -649,13 +744,31 @@ int run_impl(ldp_engine* e, uint64_t* removed, ldp_pair_stats_t* stats, uint64_t
     tl[2] = now_ms();
     // 3. ... and replays each group's subcontigs as soon as its predicate words are back.
     t_replay = now_ms();
-    rc = replay_progressive(e, e->h_pred, mf, R, &replay_pairs, &replay_busy_ms);
+    const bool csr = use_pred_csr(e);
+    const PredView pview = csr ? PredView{nullptr, e->h_csr_meta, e->h_csr_ent, e->csr_capacity} : PredView{e->h_pred, nullptr, nullptr, 0};
+    rc = replay_progressive(e, pview, mf, R, &replay_pairs, &replay_busy_ms);
     if (rc) {
       return rc;
     }
     replayed = true;
     tl[3] = now_ms();
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (csr && e->h_csr_flag[0]) {
+      // more non-zero predicate words than the CSR buffer holds (a quarter of all words): the dense rows are still in HBM -- copy them
+      // back and replay from those
+      rc = ensure_h_pred(e);
+      if (rc) {
+        return rc;
+      }
+      HIP_TRY(e, hipMemcpyAsync(e->h_pred, e->d_pred, std::max<size_t>(e->pred_words, 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(e, hipStreamSynchronize(e->stream));
+      std::fill(R.begin(), R.end(), 0u);
+      replay_pairs = 0;
+      t_replay = now_ms();
+      replay(e, e->h_pred, mf, R, &replay_pairs);
+      replay_busy_ms = now_ms() - t_replay;
+      e->ctr_csr_overflows += 1;
+    }
     tl[4] = now_ms();
     for (ldp_engine::PairGroup& g : e->groups) {
       float f = 0.f, gen = 0.f;

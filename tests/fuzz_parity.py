@@ -18,10 +18,14 @@ import ldtools as T  # noqa: E402
 import __graft_entry__ as ge  # noqa: E402
 
 
-def one_case(pkg, rng, idx, wide_missing=False, wide_async=False):
+def one_case(pkg, rng, idx, wide_missing=False, wide_async=False, wide_sparse=False):
     n = int(rng.choice([33, 64, 100, 511, 512, 513, 1000, 1536, 2047, 2049, 3000, 5000, 9000]))
+    if wide_sparse:
+        n = int(rng.choice([1536, 2049, 5000, 9000, 20000, 40000]))   # --wide-sparse: enough 512-sample stages for the checkpoints to fire
     m = int(rng.integers(40, 700 if n <= 3000 else 350))
     miss = float(rng.choice([0.0, 0.0, 0.0, 0.001, 0.003, 0.01, 0.05, 0.2]))
+    if wide_sparse:
+        miss = float(rng.choice([0.0001, 0.0003, 0.001, 0.002, 0.004, 0.005]))   # ... a FEW missing calls in every row: the tile kernel's SPARSE instantiation
     if wide_async:
         miss = 0.0                                    # --wide-async: complete data through the tile plan on the barrier-free kernel
     if wide_missing:
@@ -57,7 +61,7 @@ def one_case(pkg, rng, idx, wide_missing=False, wide_async=False):
     want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, window, step, is_bp, r2, order)
     eng = pkg.LdPruneEngine(n, window, step, is_bp, r2, order=order, device=0)
     wide = int(rng.choice([-1, -1, 0, 1, 3]))  # (drawn for every case, so that the sequence of cases stays the same)
-    if wide_missing:
+    if wide_missing or wide_sparse:
         wide = int(idx % 3)                        # ... over the tile plan (quarter tiles of the four-product form unless switched off below)
     if wide_async:
         wide = int(idx % 3)
@@ -68,8 +72,10 @@ def one_case(pkg, rng, idx, wide_missing=False, wide_async=False):
         eng.set_option("pair_four", 0)   # the six-product form of the missing-call kernel (prune launches default to four)
     if idx % 4 == 3:
         eng.set_option("pair_four_tiles", 0)  # ... on the parallelogram plan in wide bands too (default: quarter tiles of the tile plan)
-    if idx % 5 == 4:
+    if (idx % 5 == 4) and not wide_sparse:
         eng.set_option("pair_sparse", 0)  # rows with a few missing calls through the missing-call kernel too
+    if wide_sparse and (idx % 7 == 6):
+        eng.set_option("early_exit", 0)   # ... exhaustively now and then
     eng.set_variants(chr_idx, bps)
     packed = T.pack_2bit(raw)
     if rng.random() < 0.5:
@@ -82,8 +88,9 @@ def one_case(pkg, rng, idx, wide_missing=False, wide_async=False):
     ctr = eng.counters()
     eng.close()
     ok = np.array_equal(got, want)
-    desc = "case %d: n=%d m=%d miss=%g %s window=%d step=%d r2=%g order=%d chr=%d wide_min_reach=%d tiles=%d four_tile_launches=%d removed=%d skipped=%.2f" % (
-        idx, n, m, miss, "bp" if is_bp else "count", window, step, r2, order, n_chr, wide, ctr["wide_tiles"], ctr["four_tile_launches"], int(want.sum()),
+    desc = "case %d: n=%d m=%d miss=%g %s window=%d step=%d r2=%g order=%d chr=%d wide_min_reach=%d tiles=%d four_tile_launches=%d sparse_tile_launches=%d recounted=%d removed=%d skipped=%.2f" % (
+        idx, n, m, miss, "bp" if is_bp else "count", window, step, r2, order, n_chr, wide, ctr["wide_tiles"], ctr["four_tile_launches"], ctr["sparse_tile_launches"],
+        ctr["sparse_exact_pairs"], int(want.sum()),
         (ctr["mfma_skipped_product_stages"] / ctr["mfma_product_stages"]) if ctr["mfma_product_stages"] else 0.0)
     return ok, desc
 
@@ -93,22 +100,26 @@ def main():
     ap.add_argument("--cases", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--wide-missing", action="store_true", help="every case has missing calls and takes the wide-band tile plan (pair_mfma_tile4_kernel)")
+    ap.add_argument("--wide-sparse", action="store_true", help="every case has a FEW missing calls (0.01-0.5 %) and takes the tile plan: pair_mfma_wide_kernel's SPARSE instantiation")
     ap.add_argument("--wide-async", action="store_true", help="every case is complete data on the tile plan, run by pair_mfma_wide_async_kernel (engine option wide_async)")
     args = ap.parse_args()
     pkg = ge.load_package()
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
-    skipped_any = 0
+    skipped_any = sparse_tiles = 0
     for k in range(args.cases):
-        ok, desc = one_case(pkg, rng, k, args.wide_missing, args.wide_async)
+        ok, desc = one_case(pkg, rng, k, args.wide_missing, args.wide_async, args.wide_sparse)
         if "skipped=0.00" not in desc:
             skipped_any += 1
+        if "sparse_tile_launches=0" not in desc:
+            sparse_tiles += 1
         if not ok:
             print("MISMATCH", desc, "(--seed %d)" % args.seed)
             sys.exit(1)
         if k % 25 == 0:
             print(desc, flush=True)
-    print("%d cases identical to the oracle (%d with early termination firing), %.1f s" % (args.cases, skipped_any, time.time() - t0))
+    print("%d cases identical to the oracle (%d with early termination firing, %d on the tile kernel's SPARSE instantiation), %.1f s" % (args.cases, skipped_any, sparse_tiles,
+                                                                                                                                     time.time() - t0))
 
 
 if __name__ == "__main__":

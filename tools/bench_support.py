@@ -173,7 +173,7 @@ class E2EChr22:
             self.ref_t0 = time.time()
             self.ref_proc = subprocess.Popen(["bash", "-c", (prune % ("g", "ref")) + " > ref.log 2>&1; echo $? > ref.rc; date +%s.%N > ref.end"], cwd=self.tmp, start_new_session=True)
             if variable_width:
-                sh = ("%s --pfile g --make-pgen --threads %d --out v > mk.log 2>&1 && date +%%s.%%N > v.stamp && " % (REF_BIN, self.cores) + (prune % ("v", "vref")) +
+                sh = ("%s --pfile g --make-pgen --threads %d --out v > mk.log 2>&1 && date +%%s.%%N > v.stamp && " % (REF_BIN, min(self.cores, 64)) + (prune % ("v", "vref")) +
                       " > vref.log 2>&1; echo $? > v.rc; date +%s.%N > v.end")
                 self.var_t0 = time.time()
                 self.var_proc = subprocess.Popen(["bash", "-c", sh], cwd=self.tmp, start_new_session=True)
