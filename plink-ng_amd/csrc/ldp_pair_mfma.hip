@@ -173,6 +173,71 @@ __device__ __forceinline__ void mfma_stage_diag(const mf_u4* __restrict__ st4, c
   }
 }
 
+#ifdef LDP_MEASURE
+// MEASUREMENT ONLY (profiles/r06_experiments.md: what fusing the count pass into the narrow-band pair kernel would cost in its stage loop).
+// The stage above plus what a diagonal owner would have to do to count its own J rows while it streams them:
+//   * sum g of the 32 rows of each J block: ONE v_mfma_scale_f32_16x16x128_f8f6f4 per J block and k-step against a constant selector operand
+//     (the 16 x 128 A operand read from this kernel's 32-row / 64-sample fragment puts rows r and r + 16 into different k groups; a selector
+//     whose column 0 has ones in k groups 0 and 2 and column 1 in groups 1 and 3 separates them again): 4 accumulator registers per J block;
+//     sum g^2 is already on the diagonal of the (J, J) products;
+//   * a missing call anywhere in a row: d & (d >> 1), OR-accumulated over the J blocks' code dwords, two VALU per dword.
+// The sums are folded into one number per lane that the caller keeps alive; nothing else reads them (the prototype times the loop, it does not
+// replace the count pass).
+typedef float mf_v4f __attribute__((ext_vector_type(4)));
+template <int KS, bool GC>
+__device__ __forceinline__ void mfma_stage_diag_fused(const mf_u4* __restrict__ st4, const uint32_t (&slot_off)[7], uint32_t oH, uint32_t oR, mf_v16f (&acc)[8],
+                                                      mf_v4f (&fsum)[2], const Frag& sel, uint32_t& miss) {
+  mf_u4 jH0 = st4[slot_off[0] + oH], jR0 = st4[slot_off[0] + oR];
+  mf_u4 jH1 = st4[slot_off[1] + oH], jR1 = st4[slot_off[1] + oR];
+  mf_u4 vH0 = st4[slot_off[2] + oH], vR0 = st4[slot_off[2] + oR];
+  mf_u4 vH1 = st4[slot_off[3] + oH], vR1 = st4[slot_off[3] + oR];
+  mf_u4 vH2 = st4[slot_off[4] + oH], vR2 = st4[slot_off[4] + oR];
+  opaque(jH0, jR0);
+  opaque(jH1, jR1);
+  Frag fj0[KS], fj1[KS];
+  const mf_v8i S = {static_cast<int>(sel.d[0]), static_cast<int>(sel.d[1]), static_cast<int>(sel.d[2]), static_cast<int>(sel.d[3]), 0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    fp4_expand<GC>(jH0[ks], jR0[ks], fj0[ks]);
+    fp4_expand<GC>(jH1[ks], jR1[ks], fj1[ks]);
+    miss |= (jH0[ks] & (jH0[ks] >> 1)) | (jR0[ks] & (jR0[ks] >> 1)) | (jH1[ks] & (jH1[ks] >> 1)) | (jR1[ks] & (jR1[ks] >> 1));
+    const mf_v8i A0 = {static_cast<int>(fj0[ks].d[0]), static_cast<int>(fj0[ks].d[1]), static_cast<int>(fj0[ks].d[2]), static_cast<int>(fj0[ks].d[3]), 0, 0, 0, 0};
+    const mf_v8i A1 = {static_cast<int>(fj1[ks].d[0]), static_cast<int>(fj1[ks].d[1]), static_cast<int>(fj1[ks].d[2]), static_cast<int>(fj1[ks].d[3]), 0, 0, 0, 0};
+    fsum[0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A0, S, fsum[0], 4, 4, 0, kFp4ScaleG, 0, kFp4ScaleG);
+    fsum[1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A1, S, fsum[1], 4, 4, 0, kFp4ScaleG, 0, kFp4ScaleG);
+  }
+  opaque(vH0, vR0);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    Frag fv;
+    fp4_expand<GC>(vH0[ks], vR0[ks], fv);
+    acc[0] = mfma_pair<GC>(fv, fj0[ks], acc[0]);
+    acc[7] = mfma_pair<GC>(fj1[ks], fj1[ks], acc[7]);
+  }
+  opaque(vH1, vR1);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    Frag fv;
+    fp4_expand<GC>(vH1[ks], vR1[ks], fv);
+    acc[1] = mfma_pair<GC>(fv, fj0[ks], acc[1]);
+    acc[4] = mfma_pair<GC>(fv, fj1[ks], acc[4]);
+  }
+  opaque(vH2, vR2);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    Frag fv;
+    fp4_expand<GC>(vH2[ks], vR2[ks], fv);
+    acc[2] = mfma_pair<GC>(fv, fj0[ks], acc[2]);
+    acc[5] = mfma_pair<GC>(fv, fj1[ks], acc[5]);
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    acc[3] = mfma_pair<GC>(fj0[ks], fj0[ks], acc[3]);
+    acc[6] = mfma_pair<GC>(fj0[ks], fj1[ks], acc[6]);
+  }
+}
+#endif
+
 // ... and once the four FAR products of a diagonal wave item -- (J0, V0) (J0, V1) (J1, V1) (J1, V2): block distances 2 and 3 -- are
 // provably below the threshold (on real data they are the first to go: LD decays with distance), the NEAR half alone:
 // (J0, V2) (J0, J0) (J1, J0) (J1, J1), three row-block reads and sixteen MFMAs per stage instead of five and thirty-two, and the
@@ -332,7 +397,9 @@ __device__ __forceinline__ uint32_t sparse_round(const PairKernelArgs& A, const 
 // DIAGFORM: the instantiation that takes the workgroups whose wave items are all diagonal (MfmaWG::pad bit 1), with the single
 // branch-free stage loop of mfma_stage_diag and early termination by whole waves; the other instantiation keeps the general
 // forms for everything else.  Separate kernels because a third loop form in one kernel sends hipcc into hundreds of spills.
-template <int KS, bool SPARSE, bool DIAGFORM>
+// FUSE != 0 (measurement build only, DIAGFORM, complete data): mfma_stage_diag_fused instead of mfma_stage_diag and no checkpoints -- what the
+// stage loop of a count-fused narrow-band kernel would cost (LDP_DEBUG_DIAG_FUSE=1; the results are those of the exhaustive kernel).
+template <int KS, bool SPARSE, bool DIAGFORM, int FUSE = 0>
 __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelArgs A) {
   using G = StageGeom<KS>;
   // complete data: the allele-count coding (ldp_mfma_device.h), the accumulators hold G = sum g_i g_j; the SPARSE instantiation (rows
@@ -451,7 +518,21 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
   // -- a third of the plan's MFMAs at config 2 -- and nothing earlier is (r2 0.5: at 0.30 a quarter, at 0.31 a third).  Each
   // further checkpoint costs a drained ring, three barriers and a restart for nothing: config 2 with 1 / 2 / 5 checkpoints
   // 3.50 / 3.73 / 4.32 ms, none 3.91; profiles/r03_experiments.md)
-  const uint32_t cp_all = (A.cp_stats && !SPARSE) ? A.n_checkpoints : 0;
+  const uint32_t cp_all = (A.cp_stats && (!SPARSE) && (FUSE == 0)) ? A.n_checkpoints : 0;
+#ifdef LDP_MEASURE
+  [[maybe_unused]] mf_v4f fsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  [[maybe_unused]] uint32_t fmiss = 0;
+  [[maybe_unused]] Frag fsel;
+  if constexpr (FUSE != 0) {
+    // the selector: E2M1 0.5 (block scale 2 -> 1.0) in k groups 0 and 2 for column 0, groups 1 and 3 for column 1, zero elsewhere
+    const uint32_t col = lane & 15, grp = lane >> 4;
+    const uint32_t on = (col < 2) && ((grp & 1u) == col);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      fsel.d[q] = on ? 0x11111111u : 0u;
+    }
+  }
+#endif
   const uint32_t first_cp = (DIAGFORM && (cp_all >= 2)) ? 1u : 0u;
   const uint32_t n_cp = DIAGFORM ? ((cp_all > first_cp) ? first_cp + 1 : cp_all) : cp_all;
   next_cp = first_cp;
@@ -547,6 +628,12 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
       if (live & kDiagFar) {
         for (uint32_t k2 = kc; k2 < kc_end; ++k2) {
           const mf_u4* __restrict__ st4 = advance(k2);
+#ifdef LDP_MEASURE
+          if constexpr (FUSE != 0) {
+            mfma_stage_diag_fused<KS, GC>(st4, slot_off, oH, oR, acc, fsum, fsel, fmiss);
+            continue;
+          }
+#endif
           mfma_stage_diag<KS, GC>(st4, slot_off, oH, oR, acc);
         }
       } else if (live) {
@@ -708,6 +795,14 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
     }
   }
   __syncthreads();  // staging is over: LDS becomes the epilogue's scratch (a private region per wave)
+#ifdef LDP_MEASURE
+  if constexpr (FUSE != 0) {
+    // (keeps the fused sums alive; never true on genotype data)
+    if ((fsum[0][0] + fsum[0][1] + fsum[0][2] + fsum[0][3] + fsum[1][0] + fsum[1][1] + fsum[1][2] + fsum[1][3] == -12345.f) && (fmiss == 0x5a5a5a5au)) {
+      atomicAdd(A.counters + 3, 1ull);
+    }
+  }
+#endif
   if constexpr (DIAGFORM) {
     if ((lane == 0) && live0) {
       // bookkeeping in product x k-step units (one MFMA each): what early termination saved of the plan's products, and what
@@ -1849,6 +1944,19 @@ hipError_t launch_pair_mfma(const PairKernelArgs& a_in, hipStream_t stream, hipE
   ar.mf_wgs = a.mf_wgs + n_diag;
   ar.n_mf_wgs = n_rest;
   if (n_diag) {
+#ifdef LDP_MEASURE
+    static const bool fuse = []() {
+      const char* v = LDP_ENV("LDP_DEBUG_DIAG_FUSE");
+      const bool on = v && (atoi(v) != 0);
+      if (on) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_mfma_kernel<4, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      }
+      return on;
+    }();
+    if (fuse) {
+      hipLaunchKernelGGL((pair_mfma_kernel<4, false, true, 1>), dim3(((n_diag + 7) / 8) * 8), dim3(kMfWaves * 64), lds, stream, ad);
+    } else
+#endif
     hipLaunchKernelGGL((pair_mfma_kernel<4, false, true>), dim3(((n_diag + 7) / 8) * 8), dim3(kMfWaves * 64), lds, stream, ad);
   }
   if (n_rest) {

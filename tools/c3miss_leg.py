@@ -22,7 +22,8 @@ import __graft_entry__ as ge  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", type=int, default=120000)
+    ap.add_argument("--config", default="config3", help="bench.CONFIGS entry the slice is cut from (config2: its 1,000,000 variants unless --variants says otherwise)")
+    ap.add_argument("--variants", type=int, default=None)
     ap.add_argument("--samples", type=int, default=None)
     ap.add_argument("--rates", default="0,0.001,0.01")
     ap.add_argument("--steps", type=int, default=3)
@@ -33,7 +34,8 @@ def main():
         bench.SEED = bench.SEED | (args.maf_min << 56)
     import torch
     pkg = ge.load_package()
-    cfg = dict(bench.CONFIGS["config3"], variants=args.variants)
+    cfg = dict(bench.CONFIGS[args.config])
+    cfg["variants"] = args.variants or (120000 if args.config != "config2" else cfg["variants"])
     if args.samples:
         cfg["samples"] = args.samples
     sets = []
