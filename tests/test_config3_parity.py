@@ -100,6 +100,29 @@ def test_bench_n_ranks_on_one_device(gpu_pkg, tmp_path, world):
 
 
 @pytest.mark.gpu
+def test_bench_n_ranks_time_plink2_hip_end_to_end(gpu_pkg):
+    """`bench.py --gpus N` also reports the wall-clock half of the metric at N GPUs (round 6): rank 0 writes a small fileset, runs `plink2-hip --gpus N`
+    (every engine fed by a thread of its own) and `--gpus 1` on it, and the line carries both walls, the phase split and whether the outputs agree --
+    as flat scalars inside `roofline` too, where the driver's record keeps them."""
+    world = 2
+    env = dict(os.environ, LDP_BENCH_ALIAS_DEVICES="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    args = ["--steps", "1", "--warmup", "1", "--workload", "config2", "--variants", "40000", "--samples", "100032", "--strong", "--no-cpu-baseline", "--no-legs",
+            "--e2e-variants", "3000"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", "29617",
+           os.path.join(REPO, "bench.py"), "--gpus", str(world)] + args
+    cp = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    j = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+    e = j["e2e_n_gpus"]
+    assert "error" not in e, e
+    assert e["gpus"] == world and e["plink2_hip"]["rc"] == 0 and e["plink2_hip_one_gpu"]["rc"] == 0 and e["identical_to_one_gpu"] is True
+    assert any("engines fed concurrently" in ln for ln in e["plink2_hip"]["timing_lines"]), e["plink2_hip"]["timing_lines"]
+    r = j["roofline"]
+    assert r["e2e_plink2_hip_gpus"] == world and r["e2e_plink2_hip_gpus_wall_s"] > 0 and r["e2e_plink2_hip_gpus_identical_to_one_gpu"] is True
+
+
+@pytest.mark.gpu
 def test_bench_share_that_does_not_fit_hbm(gpu_pkg):
     """bench.py's non-resident mode (a rank's share of config 3 at N = 2 / 4 exceeds HBM): forced here with a small HBM limit.
     One engine per chromosome, rows copied from one resident chromosome's worth of generated rows inside the step; every chromosome
