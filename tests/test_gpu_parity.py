@@ -818,6 +818,35 @@ def test_route_follows_the_mean_not_the_worst_row(gpu_pkg):
         assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("order", [2, 1])
+def test_predicate_rows_as_csr_dense_and_overflow_agree(gpu_pkg, order):
+    """The predicate rows go back to the host as their non-zero words (ldp_pred_csr.hip: compacted on the device, written into pinned host memory,
+    replayed entry by entry -- plink2_ld.cc:1093-1097 writes a removed bit where it is decided); `pred_csr` 0 copies the dense rows as rounds 1-5
+    did; a CSR buffer that is too small (`csr_capacity`) makes the run fall back to the dense rows.  Same prune set, both replay orders, several
+    launch groups, a second run on the same engine."""
+    pkg = gpu_pkg
+    m, n = 2600, 700
+    raw = T.synth_raw_codes(m, n, seed=77, missing_rate=0.0, ld_copy_prob=0.7, redraw=0.1)
+    chr_idx, bps = make_positions(m, 3, 11)
+    inv, mf, _ = T.oracle_prepare(raw)
+    want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps, mf, 30000, 1, True, 0.3, order)
+    assert 50 < want.sum() < m - 50
+    packed = T.pack_2bit(raw)
+    for options in ({}, {"pred_csr": 0}, {"csr_capacity": 16}):
+        eng = pkg.LdPruneEngine(n, 30000, 1, True, 0.3, order=order, device=0)
+        for name, value in options.items():
+            eng.set_option(name, value)
+        eng.set_variants(chr_idx, bps)
+        eng.load_genotypes_host(0, packed, pkg.LDP_GENO_REF)
+        got = eng.run()
+        again = eng.run()
+        c = eng.counters()
+        eng.close()
+        assert np.array_equal(got, want), options
+        assert np.array_equal(again, want), options
+        assert c["pred_true"] > 16
+
+
 def test_early_termination_late_correlation(gpu_pkg):
     """Adversarial layout: pairs that look unrelated over the first 45 % of the samples and are identical over
     the rest.  A bound that extrapolated from the visited samples would drop them; the remainder bound keeps them."""
