@@ -101,7 +101,8 @@ typedef struct {
   uint32_t nm_ct;
   int32_t sum;
   uint32_t ssq;
-  uint32_t flags;        /* bit0: ALT was major (row inverted), bit1: monomorphic (:902), bit2: has missing calls */
+  uint32_t flags;        /* bit0: ALT is the major allele (the reference inverts such a row), bit1: monomorphic (:902), bit2: has missing calls,
+                            bit3 (internal): the engine's resident row is stored inverted relative to the input (major-allele-oriented image) */
   uint32_t n_homref;     /* raw counts before inversion (all zero for LDP_GENO_INVERSE input) */
   uint32_t n_het;
   uint32_t n_homalt;
@@ -240,7 +241,12 @@ int ldp_load_genotypes_fd(ldp_engine* e, uint32_t first_variant, uint32_t n, int
  * This is the role of the raw_tgenovecs buffers the reference's main thread decodes into for its workers (plink2_ld.cc:1206,
  * 1357).  The variants must be consecutive owned rows (one subcontig run at a time).  Rows loaded from any other buffer are
  * copied into the image as before.  LDP_ERR_UNSUPPORTED when the engine keeps bit-planes instead (more founders than
- * ldp_matrix_pipe_max_founders()): load from your own buffer then. */
+ * ldp_matrix_pipe_max_founders()): load from your own buffer then.
+ * The image belongs to the engine: the load that counts a row also decides its major allele, and it keeps a row whose ALT allele is the
+ * major one INVERTED (codes 00 <-> 10 swapped: what GenovecInvertUnsafe does to the reference's rows, pgenlib_misc.cc:1090).  Loading the same
+ * mapped rows again without rewriting them is fine (the engine knows which rows it inverted); a producer that wants to REWRITE rows it has
+ * already loaded calls ldp_map_rows() on them again first -- the call puts them back into the input's orientation and returns when that is
+ * done. */
 int ldp_map_rows(ldp_engine* e, uint32_t first_variant, uint32_t n, void** device_rows, uint64_t* stride_bytes);
 /* Variant records of a variable-width .pgen file, decoded ON THE DEVICE from the file's own bytes and loaded: what the reference's
  * reader thread does one variant at a time before LdPrune's pair loop (plink2_ld.cc:1345-1390 PgrGetInv1 ->

@@ -32,6 +32,9 @@ int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first
  *                     founders, engines with more use 0 by themselves); 0 = the +-2 coded x and the call flags n of rounds 2-3
  *   "pair_four_tiles" 0/1: ... and in wide bands (subcontigs with the tile plan) that form runs over quarter tiles instead of the
  *                     parallelogram plan (default 1)
+ *   "orient_rows"     0/1: the count pass stores a row whose ALT allele is the major one with codes 00 <-> 10 swapped, so that every row of the image is
+ *                     major-allele-oriented (default 1: hom-major = operand 0 is the cheapest genotype for the power-capped pair kernels; the record
+ *                     says so in flags bit 3); 0 = rows stay as the input had them (rounds 2-5)
  *   "pred_csr"        0/1: prune runs return the predicate rows as their non-zero words, compacted on the device and written straight into pinned host
  *                     memory (default 1); 0 = the dense rows are copied back whole, as in rounds 1-5
  *   "csr_capacity"    k: (test hook, before ldp_set_variants()) the compacted rows' buffer holds k entries; a run with more non-zero words falls back

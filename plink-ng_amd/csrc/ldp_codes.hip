@@ -77,6 +77,16 @@ __device__ __forceinline__ void hap_codes_of_16(uint32_t w, uint32_t phase16, ui
   *out1 = spread_to_nibbles(miss >> 16) * 5u | (spread_to_nibbles(b1_first >> 16) << 1) | (spread_to_nibbles(b1_second >> 16) << 3);
 }
 
+// codes 00 <-> 10 of sixteen samples (01 and 11 stay): GenovecInvertUnsafe on the 2-bit codes
+__device__ __forceinline__ uint32_t invert_codes(uint32_t w) { return w ^ ((~w & 0x55555555u) << 1); }
+__device__ __forceinline__ u32x4 invert_codes(u32x4 w) {
+  w.x = invert_codes(w.x);
+  w.y = invert_codes(w.y);
+  w.z = invert_codes(w.z);
+  w.w = invert_codes(w.w);
+  return w;
+}
+
 // One block per variant, one 16-byte unit of the image row (64 samples) per thread and iteration.  ITERS > 0: the iterations
 // are unrolled with all of a thread's loads issued up front (few threads with many 16-byte loads in flight each beat many
 // threads with few, as in prepare_kernel); ITERS == 0: a rolled loop for rows beyond the register budget.
@@ -85,12 +95,16 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
   constexpr int kWaves = THREADS / 64;
   __shared__ uint32_t red[kWaves][3 + 2 * kCheckpoints + kGenCheckpoints];
   __shared__ uint32_t s_alt_major;
+  __shared__ uint32_t s_flip;     // the row changes orientation in this pass: what was read is stored with codes 00 <-> 10 swapped
+  __shared__ uint32_t s_differs;  // the FINAL image row's orientation differs from the record's (major allele)
   __shared__ int32_t s_sum;
   const uint32_t v = blockIdx.x;
   const uint32_t tid = threadIdx.x;
   const uint8_t* row = A.geno + static_cast<uint64_t>(v) * A.stride_bytes;
   uint8_t* out_row = A.codes_out + static_cast<uint64_t>(v) * A.code_row_bytes;
   const bool in_place = (row == out_row);  // a row of the image itself (ldp_map_rows): counted where it is
+  // ... and such a row may be stored inverted relative to the input by an earlier pass (major-allele-oriented image, ldp_device.h)
+  const bool inv_in = in_place && A.stored_inv && (A.stored_inv[v] != 0);
   const bool phased = (A.encoding & LDP_GENO_PHASED) != 0;
   const bool bed = ((A.encoding & 3) == LDP_GENO_BED);
   const uint32_t n_units = static_cast<uint32_t>(A.code_row_bytes / 16);
@@ -186,17 +200,17 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
     }
   };
   uint32_t slow_first = 0;  // units from here on go through slow_unit()
+  [[maybe_unused]] u32x4 w_held[(ITERS > 0) ? ITERS : 1];  // the row's whole units, kept until the row's orientation in the image is known
   if constexpr (ITERS > 0) {
-    u32x4 w[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const uint32_t u = tid + it * THREADS;
       if (u < n_fast) {
         const u32x4_a4 t = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4*>(row + 16ull * u)) : *reinterpret_cast<const u32x4_a4*>(row + 16ull * u);
-        w[it].x = t.x;
-        w[it].y = t.y;
-        w[it].z = t.z;
-        w[it].w = t.w;
+        w_held[it].x = t.x;
+        w_held[it].y = t.y;
+        w_held[it].z = t.z;
+        w_held[it].w = t.w;
       }
     }
 #pragma unroll
@@ -204,15 +218,12 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
       const uint32_t u = tid + it * THREADS;
       if (u < n_fast) {
         if (bed) {
-          w[it].x = pgen_of_bed(w[it].x);
-          w[it].y = pgen_of_bed(w[it].y);
-          w[it].z = pgen_of_bed(w[it].z);
-          w[it].w = pgen_of_bed(w[it].w);
+          w_held[it].x = pgen_of_bed(w_held[it].x);
+          w_held[it].y = pgen_of_bed(w_held[it].y);
+          w_held[it].z = pgen_of_bed(w_held[it].z);
+          w_held[it].w = pgen_of_bed(w_held[it].w);
         }
-        if (!in_place) {
-          __builtin_nontemporal_store(w[it], reinterpret_cast<u32x4*>(out_row + 16ull * u));
-        }
-        count_unit(u, w[it]);
+        count_unit(u, w_held[it]);  // (stored below, once the row's major allele -- and with it the row's orientation in the image -- is known)
       }
     }
     // (calls present = codes 0, 1, 2 = hom + (codes 0 or 1) - code 0: a thread whose units are all calls skips this)
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
       for (int it = 0; it < ITERS; ++it) {
         const uint32_t u = tid + it * THREADS;
         if (u < n_fast) {
-          count_missing(u, w[it]);
+          count_missing(u, w_held[it]);
         }
       }
     }
@@ -297,10 +308,10 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
       r2h_ct += red[w][1];
       both_ct += red[w][2];
     }
-    // genotype counts of the row as stored: code 0, 1, 2
-    const uint32_t n0 = both_ct;
+    // genotype counts of the row in the INPUT's orientation: code 0, 1, 2 (a row read inverted: 0 and 2 change places)
+    const uint32_t n0 = inv_in ? (hom_ct - both_ct) : both_ct;
     const uint32_t n1 = r2h_ct - both_ct;
-    const uint32_t n2 = hom_ct - both_ct;
+    const uint32_t n2 = inv_in ? both_ct : (hom_ct - both_ct);
     // (sample-mapped rows: the het calls that were made missing still count as one allele each)
     const uint32_t n1_alleles = n1 + (A.extra_het ? A.extra_het[v] : 0u);
     uint32_t alt_major = 0;
@@ -333,12 +344,41 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
     rec.sum = static_cast<int32_t>(plus_ct - minus_ct);
     rec.ssq = hom_ct;
     const uint32_t mono = ((!plus_ct) && (!minus_ct)) || (plus_ct == nm_ct) || (minus_ct == nm_ct);  // plink2_ld.cc:902
-    rec.flags = alt_major | (mono << 1) | ((nm_ct != A.founder_ct) ? 4u : 0u);
+    // the row's orientation in the image: inverted iff ALT is the major allele (and the engine orients its rows); whatever it was read as
+    const uint32_t want_inv = (A.orient && alt_major) ? 1u : 0u;
+    rec.flags = alt_major | (mono << 1) | ((nm_ct != A.founder_ct) ? 4u : 0u) | (want_inv ? kRecStoredInverted : 0u);
     A.recs[v] = rec;
+    if (A.stored_inv) {
+      A.stored_inv[v] = static_cast<uint8_t>(want_inv);
+    }
     s_alt_major = alt_major;
-    s_sum = static_cast<int32_t>(n0 - n2);  // the sum in the IMAGE's orientation: what the checkpoint bound pairs with the kernel's partial dot products
+    s_flip = (want_inv != (inv_in ? 1u : 0u)) ? 1u : 0u;
+    s_differs = alt_major ^ want_inv;
+    // the sum in the FINAL image's orientation: what the checkpoint bound pairs with the kernel's partial dot products
+    s_sum = (alt_major ^ want_inv) ? -rec.sum : rec.sum;
   }
   __syncthreads();
+  const bool flip_now = (s_flip != 0);
+  // ---- the stores: units held in registers go out now, in the row's final orientation; what the loop above stored (tail, padding, all of a very
+  // long row) is inverted where it lies if the row changes orientation ----
+  if constexpr (ITERS > 0) {
+    if ((!in_place) || flip_now) {
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const uint32_t u = tid + it * THREADS;
+        if (u < n_fast) {
+          __builtin_nontemporal_store(flip_now ? invert_codes(w_held[it]) : w_held[it], reinterpret_cast<u32x4*>(out_row + 16ull * u));
+        }
+      }
+    }
+  }
+  if (flip_now) {
+    for (uint32_t u = slow_first + tid; u < n_units; u += THREADS) {  // (the thread that stored a unit reads it back: program order)
+      u32x4* at = reinterpret_cast<u32x4*>(out_row + 16ull * u);
+      const u32x4 t = *at;
+      *at = invert_codes(t);
+    }
+  }
   // (the six-product kernel's slots by the LAST wave, beside the first one's: the tail of a block is a chain of latencies)
   constexpr uint32_t kGenTid0 = (kWaves > 1) ? (kWaves - 1) * 64 : kCpSlots;
   const bool cp_thread = tid < kCpSlots, gen_thread = (tid >= kGenTid0) && (tid < kGenTid0 + 1 + kGenCheckpoints);
@@ -356,6 +396,9 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
       for (int w = 0; w < kWaves; ++w) {
         hom_r += red[w][3 + tid];
         both_r += red[w][3 + kCheckpoints + tid];
+      }
+      if (flip_now) {
+        both_r = hom_r - both_r;  // (code 00 of the FINAL image row: the row is stored inverted relative to what was read)
       }
       const double s_r = static_cast<double>(static_cast<int32_t>(2 * both_r - hom_r));
       const uint64_t seen = static_cast<uint64_t>(A.checkpoint_chunk[tid]) * (kChunkDwords * 32);
@@ -384,7 +427,7 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
           both += red[w][2];
         }
         nm = hom + r2h - both;
-        flag = s_alt_major;
+        flag = s_differs;  // (gen_row turns z to the minor allele's count where the image counts the major allele's)
       } else {
         const uint32_t k = tid - kGenTid0 - 1, cp = kGenCheckpointFirst + k;
         uint32_t miss_r = 0;
@@ -397,6 +440,9 @@ __global__ __launch_bounds__(THREADS) void codes_kernel(PrepareArgs A) {
         const uint64_t seen64 = static_cast<uint64_t>(A.checkpoint_chunk[cp]) * (kChunkDwords * 32);
         const uint64_t counted = (static_cast<uint64_t>(A.founder_ct) + 63) & ~static_cast<uint64_t>(63);
         nm = (seen64 < counted) ? static_cast<uint32_t>(counted - seen64) - miss_r : 0u;
+      }
+      if (flip_now) {
+        both = hom - both;  // (as above: z is the code of the FINAL image row)
       }
       slot.gen.nm_r = nm;
       slot.gen.zs_r = nm + hom - 2 * both;
@@ -440,7 +486,7 @@ __global__ __launch_bounds__(256) void pair_stats_ref_codes_kernel(const uint8_t
   }
   if (lane == 0) {
     // the image is in the rows' own orientation; the integers are reported against the major allele
-    const int32_t s1 = (recs[i].flags & 1u) ? -1 : 1, s2 = (recs[j].flags & 1u) ? -1 : 1;
+    const int32_t s1 = img_differs(recs[i].flags) ? -1 : 1, s2 = img_differs(recs[j].flags) ? -1 : 1;
     ldp_pair_stats_t st;
     st.nm = c[2];
     st.ssq2 = c[3];
@@ -452,7 +498,32 @@ __global__ __launch_bounds__(256) void pair_stats_ref_codes_kernel(const uint8_t
   }
 }
 
+// ldp_map_rows: the rows a caller is handed are in the INPUT's orientation
+__global__ __launch_bounds__(256) void unflip_rows_kernel(uint8_t* codes, uint64_t code_row_bytes, uint8_t* stored_inv, uint32_t n) {
+  const uint32_t v = blockIdx.x;
+  if ((v >= n) || !stored_inv[v]) {
+    return;
+  }
+  u32x4* row = reinterpret_cast<u32x4*>(codes + static_cast<uint64_t>(v) * code_row_bytes);
+  const uint32_t n_units = static_cast<uint32_t>(code_row_bytes / 16);
+  for (uint32_t u = threadIdx.x; u < n_units; u += 256) {
+    row[u] = invert_codes(row[u]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    stored_inv[v] = 0;
+  }
+}
+
 }  // namespace
+
+hipError_t launch_unflip_rows(uint8_t* codes, uint64_t code_row_bytes, uint8_t* stored_inv, uint32_t n, hipStream_t stream) {
+  if (!n || !stored_inv) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(unflip_rows_kernel, dim3(n), dim3(256), 0, stream, codes, code_row_bytes, stored_inv, n);
+  return hipGetLastError();
+}
 
 hipError_t launch_codes(const PrepareArgs& a, hipStream_t stream) {
   if (!a.n_variants) {

@@ -29,6 +29,14 @@ constexpr int kLdsRowDwords = kRowChunkDwords + 4; // 36: odd number (9) of 16-B
 // prune predicate cov^2 > thr var1 var2 does not depend on the orientation, and where a sign does (the reported sums and dot
 // product, --r-unphased) the epilogue takes it from the records' ALT-major flags.  Same bytes per variant as the input: rows that
 // already are REF- / INVERSE-coded in the engine's image (ldp_map_rows) are counted in place, nothing is rewritten.
+// Rows of the image are stored MAJOR-allele-oriented since round 6 (EngineOptions::orient_rows): the count pass, which decides the major allele, stores
+// an ALT-major row with codes 00 <-> 10 swapped -- what GenovecInvertUnsafe (pgenlib_misc.cc:1090) does to the reference's rows -- and says so in the
+// record (flags bit 3) and in a per-row byte the engine keeps (a row counted in place a second time must be read as what it is).  The kernels run at the
+// socket's power cap and hom-major = code 00 = operand 0 is the cheapest genotype to multiply: 285.5 -> 273.3 ms of pair kernel on the config-3 share
+// when every row is stored that way (profiles/r06_share_alt_minor.json).  Rows that are already inverse-coded (LDP_GENO_INVERSE) are never touched.
+constexpr uint32_t kRecAltMajor = 1u, kRecStoredInverted = 8u;
+// 1: the image row's orientation differs from the record's (major allele): ALT is major and the row is stored as the input had it
+__host__ __device__ inline uint32_t img_differs(uint32_t flags) { return (flags ^ (flags >> 3)) & 1u; }
 constexpr uint32_t kCodeStageSamples = 256;
 constexpr uint32_t kCodeStageBytes = kCodeStageSamples / 4;  // 64
 // (rows are whole 512-sample k-chunks long -- 128 bytes, a cache line -- so that the wide-band kernel's stages never straddle a row end)
@@ -259,6 +267,9 @@ struct PrepareArgs {
   uint32_t miss_high;            // rows with more missing calls than this count as high rows
   const uint32_t* extra_het;     // per variant: het calls the sample map turned into missing ones (allele counts only); may be nullptr
   bool fix_cp_gen;               // redo cp_gen for rows with missing calls (cp_gen_fix_kernel)
+  uint8_t* stored_inv;           // launch_codes() only, entry 0 = variant `first`, may be nullptr: 1 = the image row is stored inverted relative to the input (read for rows
+                                 //   counted in place, written for every row)
+  int orient;                    // launch_codes(): store ALT-major rows inverted (major-allele-oriented image)
 };
 
 hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream);
@@ -266,6 +277,8 @@ hipError_t launch_prepare(const PrepareArgs& a, hipStream_t stream);
 // checkpoint statistics (in the image's own orientation); no bit-planes
 hipError_t launch_codes(const PrepareArgs& a, hipStream_t stream);
 // arbitrary pairs from the code image (the integers in major-allele orientation, like launch_pair_stats_ref)
+// image rows [0, n) with stored_inv[v] != 0 back to the input's orientation, flags cleared (ldp_map_rows: the caller is about to see / rewrite them)
+hipError_t launch_unflip_rows(uint8_t* codes, uint64_t code_row_bytes, uint8_t* stored_inv, uint32_t n, hipStream_t stream);
 hipError_t launch_pair_stats_ref_codes(const uint8_t* codes, uint64_t code_row_bytes, const ldp_variant_rec* recs, const uint32_t* first, const uint32_t* second,
                                        uint32_t n_pairs, ldp_pair_stats_t* out, hipStream_t stream);
 constexpr double kSmallEpsilon = 0.00000000000005684341886080801486968994140625;  // 2^-44 (plink2_float.h:119)

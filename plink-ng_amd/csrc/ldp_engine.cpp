@@ -87,6 +87,8 @@ void free_device(ldp_engine* e) {
   }
   (void)hipFree(e->d_csr_counter);
   e->d_csr_counter = nullptr;
+  (void)hipFree(e->d_stored_inv);
+  e->d_stored_inv = nullptr;
   if (e->h_counters_pin) {
     (void)hipHostFree(e->h_counters_pin);
     e->h_counters_pin = nullptr;
@@ -932,6 +934,9 @@ int ensure_device_plan(ldp_engine* e) {
   e->code_row_bytes = code_row_bytes_of(e->P.founder_ct);
   if (e->codes_format) {
     HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_codes), n * e->code_row_bytes));
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&e->d_stored_inv), n));
+    HIP_TRY(e, hipMemsetAsync(e->d_stored_inv, 0, n, e->stream));
+    e->any_stored_inv = false;
   } else {
     HIP_TRY(e, hipMalloc(&e->d_planes, n * e->row_dwords * sizeof(uint32_t)));
   }
@@ -1582,6 +1587,8 @@ int ldp_debug_set_option(ldp_engine* e, const char* name, double value) {
     e->opt.sparse_frac = value;
   } else if (n == "wide_async") {
     e->opt.wide_async = (value != 0.0);
+  } else if (n == "orient_rows") {
+    e->opt.orient_rows = (value != 0.0);
   } else if (n == "pred_csr") {
     if (e->planned && e->gpu_ok && (value != 0.0) && !e->h_csr_meta) {
       return fail(e, LDP_ERR_STATE, "pred_csr can only be switched ON before the engine's device buffers exist (ldp_set_variants)");
@@ -1797,7 +1804,7 @@ int ldp_get_planes(ldp_engine* e, uint32_t variant, uint32_t* hom, uint32_t* ref
         }
       }
       hom[p] = h;
-      ref2het[p] = (rec.flags & 1u) ? (r ^ h) : r;
+      ref2het[p] = ldp::img_differs(rec.flags) ? (r ^ h) : r;  // (planes in major-allele orientation, whichever way the row is stored)
     }
     return LDP_OK;
   }

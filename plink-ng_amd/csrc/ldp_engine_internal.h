@@ -190,6 +190,8 @@ struct EngineOptions {
   bool four_tiles = true;     // LDP_PAIR_FOUR_TILES=0: the four-product form stays on the parallelogram plan in wide bands too
   uint32_t wide_diag_last = 2; // LDP_DEBUG_WIDE_DIAG_LAST=k: tiles fewer than k tile distances from the diagonal run at the end of their XCD stream (0: plain J order)
   uint64_t csr_capacity = 0;   // test hook "csr_capacity" k: the CSR buffer holds k entries (0: a quarter of the predicate words), to force the dense fallback
+  bool orient_rows = true;     // option "orient_rows" 0: ALT-major rows stay in the image as the input had them (rounds 2-5); default: the count pass stores them
+                               // inverted, so that every row of the image is major-allele-oriented (ldp_device.h)
   bool pred_csr = true;        // option "pred_csr" 0: prune runs copy their dense predicate rows back (rounds 1-5) instead of the non-zero words (ldp_pred_csr.hip)
   bool wide_sparse = true;     // LDP_WIDE_SPARSE=0 / option "wide_sparse" 0: launches with a few missing calls leave the 8 x 8 tiles for the parallelogram plan (rounds 2-5)
   bool wide_async = false;     // option "wide_async": the 8 x 8 tiles on pair_mfma_wide_async_kernel (flags instead of a workgroup barrier per stage)
@@ -315,6 +317,8 @@ struct ldp_engine {
   uint32_t* h_csr_flag = nullptr;
   uint64_t csr_capacity = 0;
   unsigned long long* d_csr_counter = nullptr;
+  uint8_t* d_stored_inv = nullptr;  // per local row: 1 = the image row is stored inverted relative to the input (codes_kernel, ldp_device.h)
+  bool any_stored_inv = false;      // some load may have inverted rows since the flags were last cleared
   uint32_t ctr_csr_overflows = 0;  // runs that fell back to the dense rows (test hook: option "csr_capacity")
   unsigned long long* h_counters_pin = nullptr;  // pinned: a pageable destination would make the 'async' copy block the host
   bool plan_uploaded = false;

@@ -284,6 +284,9 @@ int load_rows_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, const void
       PA.miss_stats = nullptr;  // (the route is taken from the records when a launch is queued: queue_route)
       PA.miss_high = static_cast<uint32_t>(std::min(2.0 * e->opt.sparse_frac * static_cast<double>(e->P.founder_ct), 4294967295.0));
       PA.fix_cp_gen = !e->mf_enabled;  // (only the popcount kernel's interval bound reads cp_gen)
+      PA.stored_inv = (e->codes_format && e->d_stored_inv) ? (e->d_stored_inv + l0) : nullptr;
+      PA.orient = (e->codes_format && e->opt.orient_rows) ? 1 : 0;
+      e->any_stored_inv = e->any_stored_inv || (PA.orient != 0);
       if (!e->prep_pending) {
         HIP_TRY(e, hipEventRecord(e->prep_ev0, e->stream));
         e->prep_pending = true;
@@ -586,6 +589,9 @@ int load_pgen_records_impl(ldp_engine* e, uint32_t first_variant, uint32_t n, co
       // the decode overwrites these rows before their records have been checked: from here on they hold nothing -- whatever happens below
       // (a malformed record, a failed copy, launch or sync) -- until load_rows_impl has counted them again
       std::fill(e->loaded.begin() + l_first, e->loaded.begin() + l_first + cnt, static_cast<uint8_t>(0));
+      if (e->d_stored_inv) {
+        HIP_TRY(e, hipMemsetAsync(e->d_stored_inv + l_first, 0, cnt, e->stream));  // (... and they will be in the file's orientation)
+      }
     }
     const uint64_t lstride = into_image ? e->code_row_bytes : stride;
     void *p_recs = nullptr, *p_rows = nullptr, *p_end = nullptr, *p_multi = nullptr, *p_mf = nullptr, *p_mi = nullptr, *p_inv = nullptr;
@@ -758,6 +764,16 @@ int ldp_map_rows(ldp_engine* e, uint32_t first_variant, uint32_t n, void** devic
     if (e->global_to_local[first_variant + q] != l0 + q) {
       return fail(e, LDP_ERR_INVALID, "the variants are not consecutive rows of this engine (map one owned run at a time: ldp_get_subcontigs)");
     }
+  }
+  if (e->any_stored_inv && e->d_stored_inv) {
+    // rows an earlier load stored inverted (major-allele-oriented image) go back to the input's orientation before the caller sees or
+    // rewrites them; the call returns when that is done (the caller writes from a stream of its own)
+    HIP_TRY(e, hipSetDevice(e->device));
+    const hipError_t urc = ldp::launch_unflip_rows(e->d_codes + static_cast<uint64_t>(l0) * e->code_row_bytes, e->code_row_bytes, e->d_stored_inv + l0, n, e->stream);
+    if (urc != hipSuccess) {
+      return hipfail(e, urc, "unflip_rows_kernel launch");
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
   }
   *device_rows = e->d_codes + static_cast<uint64_t>(l0) * e->code_row_bytes;
   *stride_bytes = e->code_row_bytes;

@@ -124,8 +124,9 @@ __device__ __forceinline__ int32_t g_bias_of(uint32_t founder_ct, uint32_t stage
   const uint32_t visited = ((founder_ct + stage_samples - 1u) / stage_samples) * stage_samples;
   return static_cast<int32_t>(founder_ct + 9u * (visited - founder_ct));
 }
-// a record's sum of x in the IMAGE's orientation (the record itself is in major-allele orientation; flags bit 0 = they differ)
-__device__ __forceinline__ int32_t sum_img_of(const ldp_variant_rec& r) { return (r.flags & 1u) ? -r.sum : r.sum; }
+// a record's sum of x in the IMAGE's orientation (the record itself is in major-allele orientation; img_differs(flags): they differ -- ALT is major and
+// the row is stored as the input had it; a row the count pass stored inverted is major-oriented like its record, ldp_device.h)
+__device__ __forceinline__ int32_t sum_img_of(const ldp_variant_rec& r) { return img_differs(r.flags) ? -r.sum : r.sum; }
 
 // a record's (U, Z) over the whole row: missing calls, and the sum of the allele count over its calls (image orientation)
 __device__ __forceinline__ void uz_of_rec(const ldp_variant_rec& r, uint32_t founder_ct, int32_t* U, int32_t* Z) {

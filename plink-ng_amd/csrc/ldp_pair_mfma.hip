@@ -354,10 +354,10 @@ __device__ __forceinline__ uint32_t sparse_round(const PairKernelArgs& A, const 
       const uint32_t i = valid ? static_cast<uint32_t>(i64) : 0u;
       int32_t dot = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]);
       int cls = 0;
-      uint32_t alt_ij = 0;  // bit 0: row i is ALT-major, bit 1: row j
+      uint32_t alt_ij = 0;  // bit 0: the image's row i is not major-oriented (img_differs, ldp_device.h), bit 1: row j
       if (valid) {
         const ldp_variant_rec ri = A.recs[i];
-        alt_ij = (ri.flags & 1u) | ((rj.flags & 1u) << 1);
+        alt_ij = img_differs(ri.flags) | (img_differs(rj.flags) << 1);
         dot = ((alt_ij == 1u) || (alt_ij == 2u)) ? -dot : dot;  // the image's orientation -> the records' (major allele)
         cls = classify_sparse(A, static_cast<double>(dot), ri, rj);
         if (cls == 1) {
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
         const int32_t sum_j = A.recs[j].sum;
         const uint32_t ssq_j = A.recs[j].ssq;
         const uint32_t flags_j = A.recs[j].flags;
-        const int32_t sum_img_j = (flags_j & 1u) ? -sum_j : sum_j;
+        const int32_t sum_img_j = img_differs(flags_j) ? -sum_j : sum_j;
 #pragma unroll 1
         for (uint32_t pl = 0; pl < 4; ++pl) {
           if (!(live & (1u << (4 * round + pl)))) {
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 2) void pair_mfma_kernel(PairKernelA
             if constexpr (GC) {
               dot_img += sum_img_of(ri) + sum_img_j - g_bias;  // G -> the dot product of x = 1 - g (ldp_mfma_device.h)
             }
-            ps.dot = ((ri.flags ^ flags_j) & 1u) ? -dot_img : dot_img;  // the image's orientation -> the records' (major allele)
+            ps.dot = (img_differs(ri.flags) ^ img_differs(flags_j)) ? -dot_img : dot_img;  // the image's orientation -> the records' (major allele)
             ps.nm = A.founder_ct;
             ps.sum1 = ri.sum;
             ps.ssq1 = ri.ssq;
@@ -1349,13 +1349,13 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
   if constexpr (SIX) {
     if (live && (lo_j != 0xffffffffu) && (static_cast<int64_t>(lo_j) < j64)) {
       const uint32_t j = static_cast<uint32_t>(j64);
-      const bool alt_j = (A.recs[j].flags & 1u) != 0;
+      const bool alt_j = img_differs(A.recs[j].flags) != 0;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int64_t i64 = static_cast<int64_t>(vfirst_blk) + (g & 3) + 8 * (g >> 2) + 4 * h;
         if ((i64 >= static_cast<int64_t>(lo_j)) && (i64 < j64)) {
           // the image's orientation -> the records' (major allele): x_i, x_j change sign with their row's ALT-major flag
-          const bool alt_i = (A.recs[static_cast<uint32_t>(i64)].flags & 1u) != 0;
+          const bool alt_i = img_differs(A.recs[static_cast<uint32_t>(i64)].flags) != 0;
           ldp_pair_stats_t ps;
           const int32_t d = static_cast<int32_t>(acc[0][g]), s2 = static_cast<int32_t>(acc[2][g]), s1 = static_cast<int32_t>(acc[3][g]);
           ps.dot = (alt_i != alt_j) ? -d : d;
@@ -1385,7 +1385,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
     if (j_ok) {
       rj = A.recs[j];
     }
-    const bool alt_j = (rj.flags & 1u) != 0;
+    const bool alt_j = img_differs(rj.flags) != 0;
     const int64_t N = static_cast<int64_t>(A.founder_ct);
     uint32_t n_open = 0;
 #pragma unroll
@@ -1409,7 +1409,7 @@ __global__ __launch_bounds__(kMfWaves * 64, 3) void pair_mfma_general_kernel(Pai
       uint32_t alt_ij = 0;
       if (valid) {
         const ldp_variant_rec ri = A.recs[i];
-        const bool alt_i = (ri.flags & 1u) != 0;
+        const bool alt_i = img_differs(ri.flags) != 0;
         alt_ij = (alt_i ? 1u : 0u) | (alt_j ? 2u : 0u);
         int32_t d = static_cast<int32_t>(epi4[(0 * 8 + g8) * 64 + lane]), s2 = static_cast<int32_t>(epi4[(2 * 8 + g8) * 64 + lane]),
                 s1 = static_cast<int32_t>(epi4[(3 * 8 + g8) * 64 + lane]), nm = static_cast<int32_t>(epi4[(1 * 8 + g8) * 64 + lane]);
@@ -1838,7 +1838,7 @@ __global__ __launch_bounds__(T4<JB>::kWaves * 64, 2) void pair_mfma_tile4_kernel
   if (j_ok && live) {
     rj = A.recs[j];
   }
-  const bool alt_j = (rj.flags & 1u) != 0;
+  const bool alt_j = img_differs(rj.flags) != 0;
   const int64_t N = static_cast<int64_t>(A.founder_ct);
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
@@ -1865,7 +1865,7 @@ __global__ __launch_bounds__(T4<JB>::kWaves * 64, 2) void pair_mfma_tile4_kernel
         int cls = 0;
         if (valid) {
           const ldp_variant_rec ri = A.recs[i];
-          const bool alt_i = (ri.flags & 1u) != 0;
+          const bool alt_i = img_differs(ri.flags) != 0;
           alt_ij = (alt_i ? 1u : 0u) | (alt_j ? 2u : 0u);
           ldp_pair_stats_t ps;
           int32_t d = static_cast<int32_t>(epi4[(0 * 8 + g8) * 64 + lane]), s2 = static_cast<int32_t>(epi4[(2 * 8 + g8) * 64 + lane]),

@@ -218,10 +218,10 @@ __device__ __forceinline__ uint32_t wide_sparse_round(const PairKernelArgs& A, c
       const uint32_t i = valid ? static_cast<uint32_t>(i64) : 0u;
       int32_t dot = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]);
       int cls = 0;
-      uint32_t alt_ij = 0;  // bit 0: row i is ALT-major, bit 1: row j
+      uint32_t alt_ij = 0;  // bit 0: the image's row i is not major-oriented (img_differs, ldp_device.h), bit 1: row j
       if (valid) {
         const ldp_variant_rec ri = A.recs[i];
-        alt_ij = (ri.flags & 1u) | ((rj.flags & 1u) << 1);
+        alt_ij = img_differs(ri.flags) | (img_differs(rj.flags) << 1);
         dot = ((alt_ij == 1u) || (alt_ij == 2u)) ? -dot : dot;  // the image's orientation -> the records' (major allele)
         const double d = static_cast<double>(dot);
         cls = sparse_decide(A.thresh, n_all, d, d, sparse_row_of(ri), Jr);
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
         const int32_t sum_j = A.recs[j].sum;
         const uint32_t ssq_j = A.recs[j].ssq;
         const uint32_t flags_j = A.recs[j].flags;
-        const int32_t sum_img_j = (flags_j & 1u) ? -sum_j : sum_j;
+        const int32_t sum_img_j = img_differs(flags_j) ? -sum_j : sum_j;
 #pragma unroll 1
         for (uint32_t pl = 0; pl < 4; ++pl) {
           if (!(live & (1u << (4 * round + pl)))) {
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
             const ldp_variant_rec ri = A.recs[i];
             ldp_pair_stats_t ps;
             const int32_t dot_img = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]) + sum_img_of(ri) + sum_img_j - g_bias;  // G -> dot of x = 1 - g
-            ps.dot = ((ri.flags ^ flags_j) & 1u) ? -dot_img : dot_img;  // the image's orientation -> the records' (major allele)
+            ps.dot = (img_differs(ri.flags) ^ img_differs(flags_j)) ? -dot_img : dot_img;  // the image's orientation -> the records' (major allele)
             ps.nm = A.founder_ct;
             ps.sum1 = ri.sum;
             ps.ssq1 = ri.ssq;
@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_async_kernel(
         const int32_t sum_j = A.recs[j].sum;
         const uint32_t ssq_j = A.recs[j].ssq;
         const uint32_t flags_j = A.recs[j].flags;
-        const int32_t sum_img_j = (flags_j & 1u) ? -sum_j : sum_j;
+        const int32_t sum_img_j = img_differs(flags_j) ? -sum_j : sum_j;
 #pragma unroll 1
         for (uint32_t pl = 0; pl < 4; ++pl) {
           if (!(live & (1u << (4 * round + pl)))) {
@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_async_kernel(
             const ldp_variant_rec ri = A.recs[i];
             ldp_pair_stats_t ps;
             const int32_t dot_img = static_cast<int32_t>(epi[(pl * 16 + g) * 64 + lane]) + sum_img_of(ri) + sum_img_j - g_bias;
-            ps.dot = ((ri.flags ^ flags_j) & 1u) ? -dot_img : dot_img;
+            ps.dot = (img_differs(ri.flags) ^ img_differs(flags_j)) ? -dot_img : dot_img;
             ps.nm = A.founder_ct;
             ps.sum1 = ri.sum;
             ps.ssq1 = ri.ssq;
