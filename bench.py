@@ -34,13 +34,24 @@ One JSON line is printed by rank 0.
                 otherwise); the effective stream rate of SURVEY 8(d) (pairs x N/2 bytes) is a named side field.
   legs          (N = 1) `config2` (BASELINE.json configs[1]: the step, its roofline, early termination off, 0.1 % / 1 % missing calls,
                 the reference on a 440,000-variant sample with both binaries end to end), `config5_density` (500,000 x 120,000, 5 %
-                missing calls, 2 % multiallelic records decoded inside the step), `config4_tiles` (--r2-unphased inter-chr: a 65,536 x
-                65,536 cross-chromosome tile set at 500,000 samples, device-side filter, with plink2-hip against the reference on a
-                slice), each with kernel time, roofline and a reference comparison.
+                missing calls, 2 % multiallelic records decoded inside the step), `config3_density_missing` (the same slice at 0.1 % and
+                1 % missing calls: what a real call set looks like -- the tile kernel's SPARSE instantiation / the quarter tiles),
+                `config4_tiles` (--r2-unphased inter-chr: a 65,536 x 65,536 cross-chromosome tile set at 500,000 samples, device-side
+                filter, with plink2-hip against the reference on a slice), each with kernel time, roofline and a reference comparison.
+                The legs timed by the wall run BEFORE the background reference processes of the end-to-end leg start.
+                `--workload config5` runs config 5's per-GPU share (config 3's shape, 5 % missing calls, 2 % multiallelic records) as
+                the main line instead.
+  flat keys     the driver's record keeps `roofline` and `cpu_baseline` but only their SCALAR fields: every leg's kernel / ms per step /
+                fraction with its bound / traffic multiple (`roofline.leg_<name>_*`), the power and clock medians of the timed steps
+                (`roofline.timed_steps_*`), the bits check, and the end-to-end walls of both binaries on both file formats
+                (`cpu_baseline.e2e_fixed_width_*`, `cpu_baseline.e2e_variable_width_*`) are repeated there as flat scalars
+                (`flatten_summary`); at N > 1 `roofline.e2e_plink2_hip_gpus_*` = `plink2-hip --gpus N` end to end on rank 0.
   cpu_baseline  reference plink2 (oracle/_ref/plink2, AVX2, all host threads) on a bounded sample of the same generator,
                 prune set compared with the HIP path's; and, at the metric's sample count, BOTH binaries end to end on a chr22-sized
-                share of the metric's genome (176,765 variants x 500,000 samples, a 22 GB fixed-width .pgen: SURVEY 8(d)) --
-                `cpu_baseline.e2e_wall_s`, measured walls, plink2-hip's phase split and file -> HBM rate beside them.
+                share of the metric's genome (176,765 variants x 500,000 samples: SURVEY 8(d)) as a 22 GB fixed-width .pgen AND as the
+                reference's default variable-width .pgen of the same genotypes (`--make-pgen`, 12.6 GB: records decoded on the device)
+                -- `cpu_baseline.e2e_wall_s`, measured walls, plink2-hip's phase split and file -> HBM rate beside them
+                (tools/bench_support.py: E2EChr22).
   headline_bits_check  one chromosome of the timed share re-run alone on the popcount kernels (no matrix pipe, no early termination):
                 its removed bits must equal the timed run's.
   power_and_clock      socket power / shader clock (rocm-smi) sampled during the timed steps.
@@ -897,7 +908,8 @@ def main():
         return time.perf_counter() - t0, ks, removed
 
     def dtype_of(roofline):
-        return ("fp4 (E2M1: exact -2/0/+2, block scale 1/2) x fp4 -> f32 integer-exact MFMA accumulation + f64 predicate" if roofline["kernel"].startswith("pair_mfma")
+        return ("fp4 (E2M1 allele counts 0/1/2 at block scale 2; -2/0/+2 at scale 1/2 where rows miss calls) x fp4 -> f32 integer-exact MFMA accumulation + f64 predicate"
+                if roofline["kernel"].startswith("pair_mfma")
                 else "u32 popcount + f64 predicate")
 
     def stage_ms(cmean, image_bytes):
