@@ -106,7 +106,7 @@ if command -v hipcc > /dev/null; then
   # the engine's host logic (window planning in all three modes, sharding, greedy replay in both orders) on random
   # variant tables; the HIP runtime is linked but never finds a device here
   hipcc -std=c++17 -g -O1 --offload-arch=gfx950 -fsanitize=address,undefined -fno-omit-frame-pointer -fno-gpu-sanitize -I"$R/include" \
-      "$R/tests/sanitize/engine_host_harness.cpp" "$R/plink-ng_amd/csrc/ldp_engine.cpp" "$R/plink-ng_amd/csrc/ldp_engine_run.cpp" "$R/plink-ng_amd/csrc/ldp_engine_r2.cpp" "$R/plink-ng_amd/csrc/ldp_engine_load.cpp" "$R/plink-ng_amd/csrc/ldp_engine_shard.cpp" "$R/plink-ng_amd/csrc/ldp_kernels.hip" "$R/plink-ng_amd/csrc/ldp_pair_mfma.hip" "$R/plink-ng_amd/csrc/ldp_pair_wide.hip" "$R/plink-ng_amd/csrc/ldp_codes.hip" "$R/plink-ng_amd/csrc/ldp_pgen_decode.hip" \
+      "$R/tests/sanitize/engine_host_harness.cpp" "$R/plink-ng_amd/csrc/ldp_engine.cpp" "$R/plink-ng_amd/csrc/ldp_engine_run.cpp" "$R/plink-ng_amd/csrc/ldp_engine_r2.cpp" "$R/plink-ng_amd/csrc/ldp_engine_load.cpp" "$R/plink-ng_amd/csrc/ldp_engine_shard.cpp" "$R/plink-ng_amd/csrc/ldp_kernels.hip" "$R/plink-ng_amd/csrc/ldp_pair_mfma.hip" "$R/plink-ng_amd/csrc/ldp_pair_wide.hip" "$R/plink-ng_amd/csrc/ldp_codes.hip" "$R/plink-ng_amd/csrc/ldp_pred_csr.hip" "$R/plink-ng_amd/csrc/ldp_pgen_decode.hip" \
       "$R/plink-ng_amd/csrc/ldp_synth.hip" "$R/plink-ng_amd/csrc/ldp_pgen.cpp" -o "$T/engine" -lpthread 2> "$T/engine_build.log" || { tail -5 "$T/engine_build.log"; exit 1; }
   ASAN_OPTIONS=detect_leaks=0 "$T/engine"
 fi
