@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6, batch l: the headline step with the count pass of later rows beside the pair kernels of earlier ones
 # (LDP_EAGER_PAIRS=1: groups launched as their rows are counted; LDP_DEBUG_GROUPS: launch groups; LDP_DEBUG_COUNT_CUS: count pass confined to n CUs)
+# (the CU-masked count stream -- LDP_DEBUG_COUNT_CUS -- was an experiment of this batch only and is not in the tree: profiles/r06_experiments.md section 4)
 set -u
 mkdir -p gpurun_out
 cd "$GRAFT_REPO_ROOT"
