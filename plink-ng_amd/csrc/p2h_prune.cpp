@@ -815,6 +815,10 @@ struct PruneJob {
     ldp_get_counters(eng[0], &c);
     logprintf("\n[timing] setup+parse %.3f s | genotype load (file -> HBM bit-planes) %.3f s | run %.3f s (pair kernel %.1f ms, replay %.1f ms; %llu candidate pairs) | buffer release %.3f s\n",
               t_load0 - t_begin, t_load1 - t_load0, (t_run1 ? t_run1 : now_s()) - t_load1, c.ms_pair_kernel, c.ms_replay, static_cast<unsigned long long>(c.candidate_pairs), t_run1 ? now_s() - t_run1 : 0.0);
+    // which pair kernels the device-side route gave engine 0's launches (ldp_counters; the dispatch of plink2_ld.cc:699-723, per launch)
+    logprintf("[timing] pair launches by route: complete data %u | a few missing calls %u (%u on the 8 x 8 tiles) | missing calls %u (%u on quarter tiles) | %u tiles planned, %llu pairs recounted exactly\n",
+              c.route_complete_launches, c.route_sparse_launches, c.sparse_tile_launches, c.route_general_launches, c.four_tile_launches, c.wide_tiles,
+              static_cast<unsigned long long>(c.sparse_exact_pairs));
   }
 
   // ---- chrX, chrY: their own sample sets, rows built on the host, one engine each on device 0

@@ -40,9 +40,23 @@ def test_config3_sample_count_files_identical_to_reference(gpu_pkg, tmp_path, mi
     ref = subprocess.run([REF, "--bfile", "c3", "--indep-pairwise", "500kb", "0.2", "--threads", str(cores), "--out", "ref"], cwd=str(tmp_path),
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     assert ref.returncode == 0, ref.stdout[-1500:]
-    hip = subprocess.run([cli, "--bfile", "c3", "--indep-pairwise", "500kb", "0.2", "--out", "hip"], cwd=str(tmp_path),
+    hip = subprocess.run([cli, "--bfile", "c3", "--indep-pairwise", "500kb", "0.2", "--out", "hip", "--timing"], cwd=str(tmp_path),
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     assert hip.returncode == 0, hip.stdout[-1500:]
+    # the kernels that produced these bytes: the 8 x 8 tiles for complete data AND for 0.1 % missing calls (their SPARSE
+    # instantiation), quarter tiles for 5 %
+    import re
+    mm = re.search(r"pair launches by route: complete data (\d+) \| a few missing calls (\d+) \((\d+) on the 8 x 8 tiles\) \| missing calls (\d+) \((\d+) on quarter tiles\) \| (\d+) tiles planned",
+                   hip.stdout)
+    assert mm, hip.stdout[-1500:]
+    complete, sparse, sparse_tiles, general, quarter, tiles = (int(x) for x in mm.groups())
+    assert tiles > 0
+    if miss == 0.0:
+        assert complete > 0 and sparse == 0 and general == 0
+    elif miss == 0.001:
+        assert sparse > 0 and sparse_tiles == sparse and complete == 0 and general == 0
+    else:
+        assert general > 0 and quarter == general and complete == 0 and sparse == 0
     for ext in (".prune.in", ".prune.out"):
         a = open(os.path.join(str(tmp_path), "ref" + ext), "rb").read()
         b = open(os.path.join(str(tmp_path), "hip" + ext), "rb").read()
