@@ -143,8 +143,9 @@ class E2EChr22:
     are decoded on the device, so fewer bytes cross PCIe), and compares every pair of output files byte for byte.
     `gpus` > 1 (bench.py --gpus N, rank 0): plink2-hip --gpus N on the fixed-width file, no reference run."""
 
-    def __init__(self, pkg, torch, cfg, variants, seed, layout, ref_timeout_s=420):
+    def __init__(self, pkg, torch, cfg, variants, seed, layout, ref_timeout_s=420, missing_rate=0.0):
         self.pkg, self.torch, self.cfg, self.m, self.seed, self.layout, self.ref_timeout_s = pkg, torch, cfg, variants, seed, layout, ref_timeout_s
+        self.missing_rate = missing_rate   # (tools/e2e_chr22_missing.py: the same fileset with missing calls in every variant)
         self.tmp, self.ref_proc, self.var_proc, self.res = None, None, None, {}
 
     def start(self, reference=True, variable_width=True):
@@ -162,7 +163,7 @@ class E2EChr22:
         self.tmp = tempfile.mkdtemp(prefix="ldbench_e2e_", dir=where)
         chr_idx, bps = self.layout(m, 1, cfg["spacing"])
         t0 = time.perf_counter()
-        self.file_bytes = write_fixed_width_fileset(pkg, torch, self.tmp, n, m, self.seed, chr_idx, bps)
+        self.file_bytes = write_fixed_width_fileset(pkg, torch, self.tmp, n, m, self.seed, chr_idx, bps, missing_rate=self.missing_rate)
         self.res = {"variants": m, "samples": n, "fileset": "fixed-width .pgen + .pvar + .psam under %s (%.1f GB, written by the device generator in %.1f s)" %
                     (where, self.file_bytes / 1e9, time.perf_counter() - t0)}
         self.cores = os.cpu_count() or 1
