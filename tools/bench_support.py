@@ -109,17 +109,20 @@ _PHASES = re.compile(r"setup\+parse ([0-9.]+) s \| genotype load[^|]*?([0-9.]+) 
 
 
 def run_plink2_hip(directory, pfile, kb, r2, out, gpus=1, extra=(), runs=2, timeout_s=900):
-    """plink2-hip end to end, `runs` times (the second run: page cache and HIP code objects warm, as the reference's own run had them);
-    returns walls, return code, the --timing phase split of the last run and its raw [timing] lines."""
-    walls, rc, txt = [], None, ""
+    """plink2-hip end to end, `runs` times (page cache warm, as the reference's own run had it); returns the walls, the return code and the
+    --timing phase split and raw [timing] lines of the FASTEST run (the one whose wall is reported as wall_s)."""
+    walls, rc, txt, best = [], None, "", None
     for _ in range(runs):
         t1 = time.perf_counter()
         cc = subprocess.run([CLI_BIN, "--pfile", pfile, "--indep-pairwise", kb, repr(r2), "--timing", "--out", out] + (["--gpus", str(gpus)] if gpus > 1 else []) + list(extra),
                             cwd=directory, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
         walls.append(time.perf_counter() - t1)
-        rc, txt = cc.returncode, cc.stdout
+        rc = cc.returncode
         if rc != 0:
+            txt = cc.stdout
             break
+        if best is None or walls[-1] < best:   # (the phase split reported is that of the run whose wall is reported)
+            best, txt = walls[-1], cc.stdout
     ph = _PHASES.search(txt)
     tot = re.search(r"\[timing\] total ([0-9.]+) s", txt)
     phases = None
@@ -235,7 +238,7 @@ class E2EChr22:
             hip = run_plink2_hip(self.tmp, "g", self.kb, self.cfg["r2"], "hip", gpus=gpus, extra=extra)
             if hip["phases"] and hip["phases"]["file_to_hbm_s"] > 0:
                 hip["phases"]["file_to_hbm_gbs"] = self.file_bytes / hip["phases"]["file_to_hbm_s"] / 1e9
-                hip["phases"]["note"] = ("plink2-hip --timing, second run; file_to_hbm covers pread() of the .pgen rows into the pinned ring, H2D and the count pass (they overlap); "
+                hip["phases"]["note"] = ("plink2-hip --timing, the faster of its two runs; file_to_hbm covers pread() of the .pgen rows into the pinned ring, H2D and the count pass (they overlap); "
                                          "run = pair kernels + replay behind the load; the rest of the wall is process start-up, HIP context, list writing and exit")
             res["plink2_hip"] = hip
             res["gpus"] = gpus
