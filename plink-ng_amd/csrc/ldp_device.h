@@ -210,6 +210,8 @@ struct PairKernelArgs {
   uint32_t wd_async;             // the tiles run on pair_mfma_wide_async_kernel (no workgroup barrier in the stage loop; EngineOptions::wide_async)
   uint32_t wd_sparse;            // the tiles also own the launch on the kRouteSparse route (pair_mfma_wide_kernel<., SPARSE>; EngineOptions::wide_sparse):
                                  // pair_mfma_kernel<., SPARSE = true> then skips the workgroups of their subcontigs as the complete-data kernel does
+  uint32_t wd_diag_split;        // complete-data prune launches: the tiles on the diagonal are left to pair_mfma_wide_kernel<., false, 3> (2 x 3 rectangles on all eight
+                                 // waves), queued behind the 2 x 4 kernel (EngineOptions::wide_diag_kernel)
 };
 
 constexpr uint32_t kRouteComplete = 0, kRouteSparse = 1, kRouteGeneral = 2;

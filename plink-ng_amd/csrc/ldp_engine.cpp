@@ -826,6 +826,14 @@ void build_shard(ldp_engine* e) {
     // by J tile, and the tiles next to the diagonal at the end -- the diagonal ones and their first neighbours, which hold the rest
     // of the pairs in LD (config 3's share, kernel ms with the last 0 / 1 / 2 / 3 / 4 tile distances deferred: 330 / 302 / 296 / 297 /
     // 319; HBM traffic 6.1 -> 5.3 x compulsory with 1).  Streams are padded to equal length with empty tiles (mask 0).
+    // the diagonal tiles' own kernel covers J blocks (0,1) x V 0-2, (2,3) and (4,5) x V 0-5, (6,7) x V 0-7: every prune plan's diagonal tile lies
+    // inside (its live products are on and below the diagonal); a plan that does not keeps the 2 x 4 kernel for them
+    e->wd_diag_lower = !e->wd_tiles.empty();
+    for (const MfmaTile& t : e->wd_tiles) {
+      if ((t.jv == t.vv) && (t.mask & ~0xffff3f3f3f3f0707ull)) {
+        e->wd_diag_lower = false;
+      }
+    }
     e->wd_launch.clear();
     for (ldp_engine::PairGroup& g : e->groups) {
       g.wl_first = static_cast<uint32_t>(e->wd_launch.size());
@@ -1599,6 +1607,8 @@ int ldp_debug_set_option(ldp_engine* e, const char* name, double value) {
       return fail(e, LDP_ERR_STATE, "csr_capacity must be set before ldp_set_variants()");
     }
     e->opt.csr_capacity = static_cast<uint64_t>(std::max(0.0, value));
+  } else if (n == "wide_diag_kernel") {
+    e->opt.wide_diag_kernel = (value != 0.0);
   } else if (n == "wide_sparse") {
     e->opt.wide_sparse = (value != 0.0);
   } else if (n == "replay_steps") {

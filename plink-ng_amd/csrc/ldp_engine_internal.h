@@ -193,6 +193,7 @@ struct EngineOptions {
   bool orient_rows = true;     // option "orient_rows" 0: ALT-major rows stay in the image as the input had them (rounds 2-5); default: the count pass stores them
                                // inverted, so that every row of the image is major-allele-oriented (ldp_device.h)
   bool pred_csr = true;        // option "pred_csr" 0: prune runs copy their dense predicate rows back (rounds 1-5) instead of the non-zero words (ldp_pred_csr.hip)
+  bool wide_diag_kernel = true;  // option "wide_diag_kernel" 0: diagonal tiles stay with the 2 x 4 kernel (rounds 2-5)
   bool wide_sparse = true;     // LDP_WIDE_SPARSE=0 / option "wide_sparse" 0: launches with a few missing calls leave the 8 x 8 tiles for the parallelogram plan (rounds 2-5)
   bool wide_async = false;     // option "wide_async": the 8 x 8 tiles on pair_mfma_wide_async_kernel (flags instead of a workgroup barrier per stage)
   // test hooks (ldp_debug_set_option only; 0 = off): results never depend on them
@@ -318,6 +319,7 @@ struct ldp_engine {
   uint64_t csr_capacity = 0;
   unsigned long long* d_csr_counter = nullptr;
   uint8_t* d_stored_inv = nullptr;  // per local row: 1 = the image row is stored inverted relative to the input (codes_kernel, ldp_device.h)
+  bool wd_diag_lower = false;       // every diagonal tile's live products lie inside the 2 x 3 rectangles of pair_mfma_wide_kernel<., false, 3> (build_shard)
   bool any_stored_inv = false;      // some load may have inverted rows since the flags were last cleared
   uint32_t ctr_csr_overflows = 0;  // runs that fell back to the dense rows (test hook: option "csr_capacity")
   unsigned long long* h_counters_pin = nullptr;  // pinned: a pageable destination would make the 'async' copy block the host

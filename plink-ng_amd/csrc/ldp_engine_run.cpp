@@ -396,6 +396,7 @@ void fill_pair_args(const ldp_engine* e, PairKernelArgs* out, bool with_early_ex
   A.n_wd_tiles_plain = 0;
   A.wd_async = e->opt.wide_async ? 1u : 0u;
   A.wd_sparse = 0;
+  A.wd_diag_split = 0;
 }
 
 // the dense predicate rows on the host: pinned, allocated the first time a run wants them
@@ -501,6 +502,8 @@ int launch_group(ldp_engine* e, uint32_t gi) {
     g.four_tiles = (A.wd_general != 0);
     // ... and launches whose rows have only a few: the tiles' SPARSE instantiation
     A.wd_sparse = (A.sparse_ok && e->opt.wide_sparse && A.n_wd_tiles) ? 1u : 0u;
+    // complete data: the diagonal tiles in 2 x 3 rectangles, by a kernel of their own (prune launches: their live products lie on and below the diagonal)
+    A.wd_diag_split = (e->opt.wide_diag_kernel && !e->opt.wide_async && A.n_wd_tiles && !A.stats && !A.r2_out && !A.r2_hits && e->wd_diag_lower) ? 1u : 0u;
     g.sparse_tiles = (A.wd_sparse != 0);
   }
   hipError_t krc = launch_pair_tiles(A, e->max_rows, ps, g.ev);

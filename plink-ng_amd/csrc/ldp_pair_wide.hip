@@ -71,9 +71,10 @@ __device__ __forceinline__ uint32_t wd_swizzle(uint32_t row) { return (row >> 1)
 // requests hit the L2: what the HBM leg of the traffic costs).
 // GC: the allele-count coding of complete rows (ldp_mfma_device.h); false: the +-2 coding, where a missing call is 0 and the
 // accumulators hold the exact dot product (the SPARSE instantiation below)
-template <int ABL, bool GC = true>
-__device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const uint32_t (&joff)[2], const uint32_t (&voff)[4], uint32_t oH, uint32_t oR,
-                                           mf_v16f (&acc)[8]) {
+// VC: V blocks of the wave's rectangle -- 4 (the tiles' 2 x 4 rectangles) or 3 (the diagonal tiles' kernel: 2 x 3, see pair_mfma_wide_kernel)
+template <int ABL, bool GC = true, int VC = 4>
+__device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const uint32_t (&joff)[2], const uint32_t (&voff)[VC], uint32_t oH, uint32_t oR,
+                                           mf_v16f (&acc)[2 * VC]) {
   if constexpr ((ABL & 4) != 0) {
     // (handled by wide_stage_kept below)
     return;
@@ -109,9 +110,9 @@ __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const 
   // rows of C = first variant (A operand: a V block), columns = second variant (B operand: a J block)
   // b: V block of the wave (0..3), B: its raw buffer; products b (with J0) and 4 + b (with J1)
 #define LDP_WD_VBLOCK(b, B)                                    \
-  if ((b) < 3) {                                               \
-    vH[(B) ^ 1] = st4[voff[((b) < 3) ? (b) + 1 : 3] + oH];     \
-    vR[(B) ^ 1] = st4[voff[((b) < 3) ? (b) + 1 : 3] + oR];     \
+  if ((b) < VC - 1) {                                          \
+    vH[(B) ^ 1] = st4[voff[((b) < VC - 1) ? (b) + 1 : VC - 1] + oH]; \
+    vR[(B) ^ 1] = st4[voff[((b) < VC - 1) ? (b) + 1 : VC - 1] + oR]; \
   }                                                            \
   opaque(vH[B], vR[B]);                                        \
   _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {           \
@@ -122,12 +123,14 @@ __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const 
       fp4_expand<GC>(vH[B][ks], vR[B][ks], fv);              \
     }                                                          \
     acc[b] = mfma_pair<GC>(fv, fj0[ks], acc[b]);                    \
-    acc[4 + (b)] = mfma_pair<GC>(fv, fj1[ks], acc[4 + (b)]);        \
+    acc[VC + (b)] = mfma_pair<GC>(fv, fj1[ks], acc[VC + (b)]);      \
   }
   LDP_WD_VBLOCK(0, 0)
   LDP_WD_VBLOCK(1, 1)
   LDP_WD_VBLOCK(2, 0)
-  LDP_WD_VBLOCK(3, 1)
+  if constexpr (VC == 4) {
+    LDP_WD_VBLOCK(3, 1)
+  }
 #undef LDP_WD_VBLOCK
 }
 
@@ -180,8 +183,10 @@ __device__ __forceinline__ unsigned long long wd_clk() {
 #endif
 
 // row-block slots (bit s: slot s of the stage) a wave with a live product reads: its two J blocks and its four V blocks
+template <int VC = 4>
 __device__ __forceinline__ uint32_t wide_slots_needed(uint32_t live, uint32_t a0, uint32_t vslot0) {
-  return live ? ((3u << a0) | (0xfu << vslot0)) : 0u;
+  // (VC == 3: a diagonal tile, eight staged row-blocks -- the last wave's third V block does not exist and is never live)
+  return live ? (((3u << a0) | (((1u << VC) - 1u) << vslot0)) & ((VC == 3) ? 0xffu : 0xffffu)) : 0u;  // (live: the rectangle lies inside the tile)
 }
 
 // The SPARSE instantiation's epilogue for one J block of a wave's rectangle: its (up to) four products are in this wave's LDS scratch,
@@ -260,19 +265,20 @@ __device__ __forceinline__ uint32_t wide_sparse_round(const PairKernelArgs& A, c
 // epilogue that decides a pair from per-variant counts where the intervals allow and recounts the few pairs they leave open from the
 // two rows (wave_pair_counts) -- no approximation reaches the output.  A kernel of its own (template parameter) because hipcc
 // re-allocates the complete-data kernel's registers as soon as the interval code shares a function with it.
-template <int ABL, bool SPARSE = false>
-__global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKernelArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  __shared__ uint32_t s_need[kWdWaves];
-  if (*A.route != (SPARSE ? kRouteSparse : kRouteComplete)) {
-    return;  // complete rows / a few missing calls / many: one kernel family owns a launch (route_kernel); the others leave at once
-  }
-  const uint32_t per_xcd = (A.n_wd_tiles + 7) / 8;
-  const uint32_t idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // consecutive tiles on one XCD
-  if (idx >= A.n_wd_tiles) {
-    return;
-  }
-  const MfmaTile* __restrict__ tile = A.wd_tiles + idx;
+// VC == 3: the body for DIAGONAL tiles (PairKernelArgs::wd_diag_split; complete data, prune launches; round 6).  A diagonal tile holds 36 live
+// products -- those on and below the diagonal -- and runs to the end of the rows (the pairs in LD are there): with 2 x 4 rectangles six waves
+// compute 48 products at eight per wave while two have nothing to do, and the tile takes as long as a full one.  Here the same triangle is cut
+// into eight 2 x 3 rectangles -- J blocks (0,1) x V 0-2, (2,3) x V 0-2 | 3-5, (4,5) x V 0-2 | 3-5, (6,7) x V 0-2 | 3-5 | 6-7 -- 48 products again,
+// but six per wave on all eight waves: three quarters of the matrix-pipe time per stage.  Everything else is the code of the 2 x 4 body; the kernel
+// picks one of the two per workgroup (block-uniform), so each body keeps its ONE form of the stage loop.  Measured (profiles/r06_experiments.md
+// section 4): as a launch of its own behind the others the diagonal tiles lose the L2 sharing with their neighbours (the share 339 against 273 ms
+// of pair kernels); inside the one launch 266.7 against 273.3 ms.  2 x 2 quads for tiles with at most eight live quads (the far tile of a J tile)
+// were built too and bought nothing: those tiles are bound by their staging, not by the matrix pipe.
+template <int ABL, bool SPARSE, int VC>
+__device__ __forceinline__ void wide_tile(const PairKernelArgs& A, uint32_t* __restrict__ lds, uint32_t* __restrict__ s_need, const MfmaTile* __restrict__ tile) {
+  static_assert((VC == 4) || ((VC == 3) && !SPARSE && (ABL == 0)), "2 x 4 rectangles, or the diagonal tiles' 2 x 3");
+  constexpr uint32_t NP = 2 * VC;              // products per wave
+  constexpr uint32_t kColMask = (1u << VC) - 1u;
 #ifdef LDP_MEASURE
   unsigned long long m_t[6] = {0, 0, 0, 0, 0, 0}, m_visits[2] = {0, 0};
   const unsigned long long m_clk0 = wd_clk(), m_wall0 = __builtin_amdgcn_s_memrealtime();
@@ -298,19 +304,22 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
   uint32_t stages = A.lds_dwords / stage_dwords;
   stages = (stages > kWdMaxStages) ? kWdMaxStages : stages;
 
-  // ---- this wave's rectangle: J blocks a0, a0 + 1, V blocks b0 .. b0 + 3 ----
-  const uint32_t a0 = 2 * (wave & 3), b0 = 4 * (wave >> 2);
+  // ---- this wave's rectangle: J blocks a0, a0 + 1, V blocks b0 .. b0 + VC - 1 (product b: J block a0, V block b0 + b; VC + b: J block a0 + 1) ----
+  // VC == 3, wave 0 .. 7: (a0, b0) = (0,0) (2,0) (2,3) (4,0) (4,3) (6,0) (6,3) (6,6)
+  auto rect_a0 = [](uint32_t w) -> uint32_t { return (VC == 4) ? (2 * (w & 3)) : ((0x66644220u >> (4 * w)) & 0xfu); };
+  auto rect_b0 = [](uint32_t w) -> uint32_t { return (VC == 4) ? (4 * (w >> 2)) : ((0x63030300u >> (4 * w)) & 0xfu); };
+  const uint32_t a0 = rect_a0(wave), b0 = rect_b0(wave);
   const uint32_t vslot0 = (diag ? 0u : static_cast<uint32_t>(kWdTile)) + b0;
   auto mask_row = [&](uint32_t a) { return ((a < 4) ? (mask_lo >> (8 * a)) : (mask_hi >> (8 * (a - 4)))) & 0xffu; };
-  uint32_t live = ((mask_row(a0) >> b0) & 0xfu) | (((mask_row(a0 + 1) >> b0) & 0xfu) << 4);
+  uint32_t live = ((mask_row(a0) >> b0) & kColMask) | (((mask_row(a0 + 1) >> b0) & kColMask) << VC);
   live = __builtin_amdgcn_readfirstlane(live);
   // row-block slots the workgroup reads: the rectangles of the waves that own a live product
   uint32_t wg_need = 0;
 #pragma unroll
   for (uint32_t w = 0; w < static_cast<uint32_t>(kWdWaves); ++w) {
-    const uint32_t wa = 2 * (w & 3), wb = 4 * (w >> 2);
-    const uint32_t wl = ((mask_row(wa) | mask_row(wa + 1)) >> wb) & 0xfu;
-    wg_need |= wide_slots_needed(wl, wa, (diag ? 0u : static_cast<uint32_t>(kWdTile)) + wb);
+    const uint32_t wa = rect_a0(w), wb = rect_b0(w);
+    const uint32_t wl = ((mask_row(wa) | mask_row(wa + 1)) >> wb) & kColMask;
+    wg_need |= wide_slots_needed<VC>(wl, wa, (diag ? 0u : static_cast<uint32_t>(kWdTile)) + wb);
   }
   wg_need = __builtin_amdgcn_readfirstlane(wg_need);
   auto slot_first = [&](uint32_t s) { return (s < static_cast<uint32_t>(kWdTile)) ? (jv0 + static_cast<int32_t>(kMfBlock * s)) : (vv0 + static_cast<int32_t>(kMfBlock * (s - kWdTile))); };
@@ -346,16 +355,17 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
   };
   uint32_t mine = (ABL & 1) ? 0u : count_mine();  // DMA wave-instructions per stage this wave issues
 
-  uint32_t joff[2], voff[4];  // uint4 index of the row-block's first slot
+  uint32_t joff[2], voff[VC];  // uint4 index of the row-block's first slot
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     joff[q] = (a0 + q) * kWdBlockUnits;
   }
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    voff[b] = (vslot0 + b) * kWdBlockUnits;
+  for (int b = 0; b < VC; ++b) {
+    const uint32_t slot = vslot0 + b;
+    voff[b] = (((VC == 3) && (slot > 7u)) ? 7u : slot) * kWdBlockUnits;  // (VC == 3, last wave: a block that does not exist is read as block 7 and never live)
   }
-  uint32_t need = wide_slots_needed(live, a0, vslot0);
+  uint32_t need = wide_slots_needed<VC>(live, a0, vslot0);
   // window starts of this lane's two second variants (J0 + r, J1 + r), fetched here: the k-loop must not hold ordinary
   // global loads (hipcc would drain the DMA ring in front of every LDS read of the loop)
   uint32_t lo_j2[2] = {0xffffffffu, 0xffffffffu};  // (lo >= j: no candidate pair)
@@ -371,9 +381,9 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
   const uint32_t oH0 = r * kWdPieces + (h ^ sw), oR0 = r * kWdPieces + ((2 + h) ^ sw);
   const uint32_t oH1 = r * kWdPieces + ((4 + h) ^ sw), oR1 = r * kWdPieces + ((6 + h) ^ sw);
 
-  mf_v16f acc[8];
+  mf_v16f acc[NP];
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
+  for (int p = 0; p < static_cast<int>(NP); ++p) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       acc[p][g] = 0.f;
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
       }
       const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * stage_dwords);
       read_buf = (read_buf + 1 == stages) ? 0 : read_buf + 1;
-      if constexpr ((ABL & 4) != 0) {
+      if constexpr (((ABL & 4) != 0) && (VC == 4)) {
         if (kc == 0) {
           keptH = st4[joff[0] + oH0];
           keptR = st4[joff[0] + oR0];
@@ -453,8 +463,8 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
           wide_stage_kept<ABL>(keptR, keptH, acc);
         }
       } else if (live) {
-        wide_stage<ABL, !SPARSE>(st4, joff, voff, oH0, oR0, acc);
-        wide_stage<ABL, !SPARSE>(st4, joff, voff, oH1, oR1, acc);
+        wide_stage<ABL, !SPARSE, VC>(st4, joff, voff, oH0, oR0, acc);
+        wide_stage<ABL, !SPARSE, VC>(st4, joff, voff, oH1, oR1, acc);
       }
 #ifdef LDP_MEASURE
       if constexpr ((ABL & 32) != 0) {
@@ -527,21 +537,26 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
     if (live) {
       uint32_t keep = 0;
       uint32_t* cp_epi = lds + wave * kWdCpWaveDwords;  // two products per round
+      // (rounds of two products of ONE J block: J0's products 0 .. VC - 1 in pairs, then J1's VC .. 2 VC - 1; VC == 3: the second round of a J
+      // block holds one product)
+      constexpr int kHalf = (VC + 1) / 2;
 #pragma unroll
-      for (int round = 0; round < 4; ++round) {
-        if (!(live & (0x3u << (2 * round)))) {
+      for (int round = 0; round < 2 * kHalf; ++round) {
+        const int q = round / kHalf;  // J0 / J1
+        const int p0 = q * VC + 2 * (round % kHalf);  // the round's first product
+        const uint32_t round_bits = ((2 * (round % kHalf) + 1 < VC) ? 0x3u : 0x1u) << p0;
+        if (!(live & round_bits)) {
           continue;
         }
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
-          if (live & (1u << (2 * round + pl))) {
+          if (round_bits & live & (1u << (p0 + pl))) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-              cp_epi[(pl * 16 + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>(acc[2 * round + pl][g]));
+              cp_epi[(pl * 16 + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>(acc[(p0 + pl < static_cast<int>(NP)) ? p0 + pl : 0][g]));
             }
           }
         }
-        const int q = (round >= 2) ? 1 : 0;  // products 0..3: J0, 4..7: J1
         const int64_t j64 = static_cast<int64_t>(jv0) + kMfBlock * (a0 + q) + r;
         const int64_t lo_j = lo_j2[q];
         const uint32_t jslot = a0 + q;
@@ -554,11 +569,11 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
         }
 #pragma unroll 1
         for (uint32_t pl = 0; pl < 2; ++pl) {
-          const uint32_t p = 2 * round + pl;
-          if (!(live & (1u << p))) {
+          const uint32_t p = static_cast<uint32_t>(p0) + pl;
+          if (!(live & round_bits & (1u << p))) {
             continue;
           }
-          const uint32_t b = p & 3;  // V block of the product
+          const uint32_t b = p - static_cast<uint32_t>(q) * VC;  // V block of the product
           const uint32_t vslot = vslot0 + b;
           bool hopeless = true;
 #pragma unroll 2
@@ -598,7 +613,7 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
       keep = __builtin_amdgcn_readfirstlane(keep);
       if (keep != live) {
         live = keep;
-        need = wide_slots_needed(live, a0, vslot0);
+        need = wide_slots_needed<VC>(live, a0, vslot0);
         if (!live) {
           stop_stage = kc;  // the wave computes nothing from here on
         }
@@ -640,8 +655,8 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
     if (stop_stage < n_stages) {
       atomicAdd(A.counters + 2, static_cast<unsigned long long>(n_stages - stop_stage) * kWdKsteps * planned);
     }
-    if (planned < 8) {
-      atomicAdd(A.counters + 1, static_cast<unsigned long long>(stop_stage) * kWdKsteps * (8 - planned));
+    if (planned < NP) {
+      atomicAdd(A.counters + 1, static_cast<unsigned long long>(stop_stage) * kWdKsteps * (NP - planned));
     }
   }
 
@@ -657,15 +672,15 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
 #endif
 #pragma unroll
   for (int round = 0; round < 2; ++round) {
-    if (!(live & (0xfu << (4 * round)))) {
+    if (!(live & (kColMask << (VC * round)))) {
       continue;
     }
 #pragma unroll
-    for (int pl = 0; pl < 4; ++pl) {
-      if (live & (1u << (4 * round + pl))) {
+    for (int pl = 0; pl < VC; ++pl) {
+      if (live & (1u << (VC * round + pl))) {
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-          epi[(pl * 16 + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>((round ? acc[4 + pl] : acc[pl])[g]));
+          epi[(pl * 16 + g) * 64 + lane] = static_cast<uint32_t>(static_cast<int32_t>((round ? acc[VC + pl] : acc[pl])[g]));
         }
       }
     }
@@ -684,8 +699,8 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
         const uint32_t flags_j = A.recs[j].flags;
         const int32_t sum_img_j = img_differs(flags_j) ? -sum_j : sum_j;
 #pragma unroll 1
-        for (uint32_t pl = 0; pl < 4; ++pl) {
-          if (!(live & (1u << (4 * round + pl)))) {
+        for (uint32_t pl = 0; pl < static_cast<uint32_t>(VC); ++pl) {
+          if (!(live & (1u << (VC * round + pl)))) {
             continue;
           }
           const int64_t vfirst = static_cast<int64_t>(vv0) + kMfBlock * (b0 + pl) + 4 * h;
@@ -734,6 +749,30 @@ __global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKe
     }
   }
 #endif
+}
+
+template <int ABL, bool SPARSE = false>
+__global__ __launch_bounds__(kWdWaves * 64, 2) void pair_mfma_wide_kernel(PairKernelArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ uint32_t s_need[kWdWaves];
+  if (*A.route != (SPARSE ? kRouteSparse : kRouteComplete)) {
+    return;  // complete rows / a few missing calls / many: one kernel family owns a launch (route_kernel); the others leave at once
+  }
+  const uint32_t per_xcd = (A.n_wd_tiles + 7) / 8;
+  const uint32_t idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // consecutive tiles on one XCD
+  if (idx >= A.n_wd_tiles) {
+    return;
+  }
+  const MfmaTile* __restrict__ tile = A.wd_tiles + idx;
+  if constexpr ((ABL == 0) && !SPARSE) {
+    // a diagonal tile in 2 x 3 rectangles (block-uniform: two whole bodies side by side, each with its ONE form of the stage loop -- a second form
+    // INSIDE a loop is what made hipcc spill in rounds 3-5)
+    if (A.wd_diag_split && (tile->jv == tile->vv)) {
+      wide_tile<0, false, 3>(A, lds, s_need, tile);
+      return;
+    }
+  }
+  wide_tile<ABL, SPARSE, 4>(A, lds, s_need, tile);
 }
 
 
@@ -1237,6 +1276,9 @@ hipError_t launch_pair_wide(const PairKernelArgs& a_in, hipStream_t stream, bool
   PairKernelArgs a = a_in;
   const size_t lds = static_cast<size_t>(kWdLdsDwords) * sizeof(uint32_t);
   a.lds_dwords = static_cast<uint32_t>(lds / sizeof(uint32_t));
+  if (a.wd_async || sparse) {
+    a.wd_diag_split = 0;  // (the diagonal tiles' kernel exists for the barrier kernel on complete data)
+  }
   const uint32_t per_xcd = (a.n_wd_tiles + 7) / 8;
   const dim3 grid(per_xcd * 8), block(kWdWaves * 64);
   if (sparse) {

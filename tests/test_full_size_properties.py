@@ -142,7 +142,8 @@ def test_three_kernel_families_agree_at_config3_density(gpu_pkg):
     """N = 500,000 samples, 6,000 variants of the benchmark generator at config 3's density (290 bp, 500kb 0.2: the band reaches 54
     row-blocks, the 8 x 8 tile plan): the tile kernel with a workgroup barrier per stage, the barrier-free one (pair_mfma_wide_async_kernel)
     and the popcount kernels on bit-planes (another plan, another arithmetic: no matrix pipe, no early termination) must remove the same
-    variants and find the same number of pairs above the threshold; the two tile kernels must also retire the same work."""
+    variants and find the same number of pairs above the threshold; the two tile kernels must also retire the same work (with the same
+    rectangles: the barrier kernel's own rectangles for diagonal tiles are switched off for that comparison)."""
     import torch
     import bench
     pkg = gpu_pkg
@@ -153,7 +154,7 @@ def test_three_kernel_families_agree_at_config3_density(gpu_pkg):
     pkg.synth_genotypes_device(bench.SEED, 0, m, n, 0.0, buf.data_ptr(), stride)
     torch.cuda.synchronize()
     got = {}
-    for name, opts in (("barrier", {}), ("async", {"wide_async": 1}), ("async_exhaustive", {"wide_async": 1, "early_exit": 0}),
+    for name, opts in (("barrier", {}), ("barrier_2x4", {"wide_diag_kernel": 0}), ("async", {"wide_async": 1}), ("async_exhaustive", {"wide_async": 1, "early_exit": 0}),
                        ("popcount", {"pair_mfma": 0, "early_exit": 0})):
         eng = pkg.LdPruneEngine(n, pkg.kb_window(500.0), 1, True, 0.2, device=0)
         for k, v in opts.items():
@@ -164,10 +165,13 @@ def test_three_kernel_families_agree_at_config3_density(gpu_pkg):
         eng.close()
     base, cb = got["barrier"]
     assert cb["wide_tiles"] > 0 and cb["mfma_skipped_product_stages"] > 0 and 0.1 * m < base.sum() < 0.9 * m
-    for name in ("async", "async_exhaustive", "popcount"):
+    for name in ("barrier_2x4", "async", "async_exhaustive", "popcount"):
         r, c = got[name]
         assert np.array_equal(r, base), name
         assert c["pred_true"] == cb["pred_true"], name
-    ca = got["async"][1]
-    assert ca["wide_tiles"] == cb["wide_tiles"] and ca["mfma_skipped_product_stages"] == cb["mfma_skipped_product_stages"]
+    # (the default barrier kernel cuts diagonal tiles into 2 x 3 rectangles: other waves, other bookkeeping; with 2 x 4 rectangles everywhere the
+    # barrier kernel and the barrier-free one retire the same work)
+    ca, c4 = got["async"][1], got["barrier_2x4"][1]
+    assert ca["wide_tiles"] == c4["wide_tiles"] == cb["wide_tiles"] and ca["mfma_skipped_product_stages"] == c4["mfma_skipped_product_stages"]
+    assert cb["mfma_block_products"] == c4["mfma_block_products"]
     assert got["popcount"][1]["mfma_block_products"] == 0

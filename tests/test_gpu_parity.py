@@ -333,24 +333,33 @@ def test_wide_band_tiles_match_oracle(gpu_pkg, case):
     inv, mf, altmaj, hom, r2h, vaggs = oracle_recs(raw, n)
     want, _ = T.oracle_indep_pairwise(inv, n, chr_idx, bps if bps is not None else np.arange(m, dtype=np.uint32), mf, window, step, is_bp, r2, order)
     res = {}
-    # both forms of the tile kernel: a workgroup barrier per 512-sample stage ("wide_async" 0) and the barrier-free one whose waves
-    # exchange counters through LDS (256-sample stages, pair_mfma_wide_async_kernel)
-    for ee, wa in ((1, 0), (0, 0), (1, 1), (0, 1)):
+    # the forms of the tile kernel: a workgroup barrier per 512-sample stage ("wide_async" 0) with the diagonal tiles in 2 x 3 rectangles
+    # ("wide_diag_kernel" 1, the default) or in the 2 x 4 rectangles of every other tile (0), and the barrier-free one whose waves exchange
+    # counters through LDS (256-sample stages, pair_mfma_wide_async_kernel; 2 x 4 rectangles everywhere)
+    diag_form = {}
+    for ee, wa, dk in ((1, 0, 1), (0, 0, 1), (1, 0, 0), (0, 0, 0), (1, 1, 0), (0, 1, 0)):
         eng = pkg.LdPruneEngine(n, window, step, is_bp, r2, order=order, device=0)
         eng.set_option("wide_min_reach", min_reach)
         eng.set_option("early_exit", ee)
         eng.set_option("wide_async", wa)
+        eng.set_option("wide_diag_kernel", dk)
         eng.set_variants(chr_idx, bps)
         eng.load_genotypes_host(0, T.pack_2bit(raw), pkg.LDP_GENO_REF)
         got = eng.run()
         c = eng.counters()
         assert c["wide_tiles"] > 0 and c["route_complete_launches"] > 0
-        assert np.array_equal(got, want), (ee, wa, int(got.sum()), int(want.sum()))
+        assert np.array_equal(got, want), (ee, wa, dk, int(got.sum()), int(want.sum()))
+        if dk:
+            diag_form[ee] = c
+            eng.close()
+            continue
         if wa:
             assert (c["pred_true"], c["mfma_skipped_product_stages"], c["mfma_extra_product_stages"]) == \
                    (res[ee]["pred_true"], res[ee]["mfma_skipped_product_stages"], res[ee]["mfma_extra_product_stages"]), (ee, "the two forms retire the same work")
         else:
             res[ee] = c
+            # the diagonal tiles' own rectangles decide the same pairs (a retired product's pairs are all false either way)
+            assert diag_form[ee]["pred_true"] == c["pred_true"] and diag_form[ee]["mfma_block_products"] == c["mfma_block_products"]
         if ee == 0:
             removed, stats = eng.run_with_stats()
             lo, _ = eng.band()

@@ -46,8 +46,9 @@ def test_pair_mfma_kernel_keeps_its_dma_ring_running(tmp_path):
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
 def test_wide_band_kernel_has_one_branch_free_stage_loop_and_no_scratch(tmp_path):
-    """pair_mfma_wide_kernel (ldp_pair_wide.hip): the stage loop exists in ONE form -- 64 MFMAs behind 24 LDS reads, no branch, no
-    accumulator copy -- and the kernel uses no scratch at all (a masked form made hipcc spill inside the loop: DESIGN.md 4.1e)."""
+    """pair_mfma_wide_kernel (ldp_pair_wide.hip): every body's stage loop exists in ONE form -- 64 MFMAs behind 24 LDS reads (2 x 4 rectangles), 48
+    behind 20 (the diagonal tiles' 2 x 3), no branch, no accumulator copy -- and the kernel uses no scratch at all (a masked form made hipcc spill
+    inside the loop: DESIGN.md 4.1e)."""
     src = os.path.join(REPO, "plink-ng_amd", "csrc", "ldp_pair_wide.hip")
     out = tmp_path / "wd.s"
     cp = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--cuda-device-only", "-S",
@@ -65,20 +66,30 @@ def test_wide_band_kernel_has_one_branch_free_stage_loop_and_no_scratch(tmp_path
         assert m, "pair_mfma_wide_kernel<0, %s> not found" % sparse
         lines = m.group(2).splitlines()
         mf = [k for k, ln in enumerate(lines) if "v_mfma_scale_f32_32x32x64_f8f6f4" in ln]
-        assert len(mf) == 64                       # one copy of the stage body: two half-stages of 32
-        body = lines[mf[0]:mf[-1] + 1]
-        assert not any(("s_cbranch" in ln) or ("scratch_" in ln) or ("v_accvgpr" in ln) for ln in body)
+        # the copies of the stage body: runs of matrix instructions less than 300 lines apart.  SPARSE: one (two half-stages of 32).  Complete data: the
+        # 2 x 4 body (64) and the diagonal tiles' 2 x 3 body (48), picked per workgroup -- two whole bodies side by side, not two forms inside a loop
+        runs = [[mf[0]]]
+        for k in mf[1:]:
+            if k - runs[-1][-1] < 300:
+                runs[-1].append(k)
+            else:
+                runs.append([k])
+        assert sorted(len(r) for r in runs) == ([64] if sparse else [48, 64])
         assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2)).group(1)) <= 256
-        window = lines[mf[0] - 80:mf[-1]]
-        if sparse:
-            # the +-2 expansion: one v_bitop3_b32 per fragment dword and a shift for every second one -- three VALU per 16 samples, as below
-            assert sum("v_bitop3_b32" in ln for ln in window) == 192
-            assert sum("v_lshlrev_b32" in ln for ln in window) == 96
-        else:
-            # the allele-count expansion (ldp_mfma_device.h): 2 half-stages x 6 row-blocks x 4 k-steps x 4 fragment dwords, one v_and each, and a
-            # shift for every second one (the odd samples of a code dword) -- three VALU per 16 samples
-            assert sum(("v_and_b32" in ln) and ("0x33333333" in ln) for ln in window) == 192
-            assert sum("v_lshrrev_b32" in ln for ln in window) == 96
+        for run in runs:
+            body = lines[run[0]:run[-1] + 1]
+            assert not any(("s_cbranch" in ln) or ("scratch_" in ln) or ("v_accvgpr" in ln) for ln in body)
+            window = lines[run[0] - 80:run[-1]]
+            blocks = 6 if len(run) == 64 else 5   # row-blocks a wave expands per half-stage: 2 J + 4 V, or 2 J + 3 V
+            if sparse:
+                # the +-2 expansion: one v_bitop3_b32 per fragment dword and a shift for every second one -- three VALU per 16 samples, as below
+                assert sum("v_bitop3_b32" in ln for ln in window) == 192
+                assert sum("v_lshlrev_b32" in ln for ln in window) == 96
+            else:
+                # the allele-count expansion (ldp_mfma_device.h): 2 half-stages x row-blocks x 4 k-steps x 4 fragment dwords, one v_and each, and a
+                # shift for every second one (the odd samples of a code dword) -- three VALU per 16 samples
+                assert sum(("v_and_b32" in ln) and ("0x33333333" in ln) for ln in window) == 2 * blocks * 16
+                assert sum("v_lshrrev_b32" in ln for ln in window) == 2 * blocks * 8
         for k, ln in enumerate(lines):
             if "ds_read_b128" in ln:
                 before = [x for x in lines[max(0, k - 6):k] if not x.strip().startswith(";")]
