@@ -45,6 +45,8 @@ int ldp_debug_replay_pairs(ldp_engine* e, uint64_t n_true, const uint32_t* first
  *                     profiler or an oversubscribed device
  *   "wide_sparse"     0/1: launches whose rows have a few missing calls keep the 8 x 8 tiles of wide-band subcontigs (the tile kernel's
  *                     SPARSE instantiation; default 1); 0 = they fall back to the parallelogram plan as in rounds 2-5
+ *   "wide_diag_kernel" 0/1: complete-data prune launches run the tiles ON the diagonal (36 live products, to the end of the rows) in eight 2 x 3
+ *                     rectangles, a second body of pair_mfma_wide_kernel picked per workgroup (default 1); 0 = 2 x 4 rectangles for every tile
  *   "wide_diag_last"  k: within a launch every XCD's stream of 8 x 8 tiles runs its far tiles first and the tiles fewer than k tile
  *                     distances from the diagonal (the long ones: they hold the pairs in LD) at the end; 0 = plain J order (default 2;
  *                     before ldp_set_variants())
