@@ -134,6 +134,78 @@ __device__ __forceinline__ void wide_stage(const mf_u4* __restrict__ st4, const 
 #undef LDP_WD_VBLOCK
 }
 
+// The same half-stage with the NEXT half-stage's J fragments made beside it (round 6, tools/tile_shape_probe.hip shape "2x4pf": the stage loop alone
+// 5.74-5.78 -> 5.98 PFLOP/s).  Behind a stage's barrier the two waves of a SIMD are in the same phase: both read and expand their two J blocks (48
+// VALU behind two LDS round trips) before either has an MFMA to issue -- twice per stage.  Here fj0 / fj1 arrive ready; with PREF the pieces of the J
+// blocks at (oHn, oRn) -- the stage's second half -- are read with V blocks 1 / 2 and expanded between the MFMAs of V blocks 0 / 1 into fn0 / fn1, so
+// the second half-stage starts on the matrix pipe at once and only the first one of a stage has the head (the stage has just landed: nothing of
+// it could have been read earlier).  32 more registers.
+template <bool GC, int VC, bool PREF>
+__device__ __forceinline__ void wide_stage_pf(const mf_u4* __restrict__ st4, const uint32_t (&joff)[2], const uint32_t (&voff)[VC], uint32_t oH, uint32_t oR, uint32_t oHn,
+                                              uint32_t oRn, const Frag (&fj0)[4], const Frag (&fj1)[4], Frag (&fn0)[4], Frag (&fn1)[4], mf_v16f (&acc)[2 * VC]) {
+  mf_u4 vH[2], vR[2], jH[2], jR[2];
+  vH[0] = st4[voff[0] + oH];
+  vR[0] = st4[voff[0] + oR];
+  if constexpr (PREF) {
+    jH[0] = st4[joff[0] + oHn];
+    jR[0] = st4[joff[0] + oRn];
+  }
+#pragma unroll
+  for (int b = 0; b < VC; ++b) {
+    __builtin_amdgcn_sched_barrier(0);  // (one V block's reads, expansions and MFMAs at a time: hipcc otherwise hoists every block's reads to the front)
+    if (b + 1 < VC) {
+      vH[(b & 1) ^ 1] = st4[voff[(b + 1 < VC) ? b + 1 : b] + oH];
+      vR[(b & 1) ^ 1] = st4[voff[(b + 1 < VC) ? b + 1 : b] + oR];
+    }
+    if constexpr (PREF) {
+      if (b == 0) {
+        jH[1] = st4[joff[1] + oHn];
+        jR[1] = st4[joff[1] + oRn];
+      }
+      if (b < 2) {
+        opaque(jH[b & 1], jR[b & 1]);
+      }
+    }
+    opaque(vH[b & 1], vR[b & 1]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      Frag fv;
+      fp4_expand<GC>(vH[b & 1][ks], vR[b & 1][ks], fv);
+      if constexpr (PREF) {
+        if (b == 0) {
+          fp4_expand<GC>(jH[0][ks], jR[0][ks], fn0[ks]);
+        } else if (b == 1) {
+          fp4_expand<GC>(jH[1][ks], jR[1][ks], fn1[ks]);
+        }
+      }
+      acc[b] = mfma_pair<GC>(fv, fj0[ks], acc[b]);
+      acc[VC + b] = mfma_pair<GC>(fv, fj1[ks], acc[VC + b]);
+    }
+  }
+}
+// a stage (512 samples) of a wave's rectangle in that form
+template <bool GC, int VC>
+__device__ __forceinline__ void wide_stage_pair(const mf_u4* __restrict__ st4, const uint32_t (&joff)[2], const uint32_t (&voff)[VC], uint32_t oH0, uint32_t oR0, uint32_t oH1,
+                                                uint32_t oR1, mf_v16f (&acc)[2 * VC]) {
+  Frag fa0[4], fa1[4], fb0[4], fb1[4];
+  {
+    mf_u4 H = st4[joff[0] + oH0], R = st4[joff[0] + oR0];
+    mf_u4 H1 = st4[joff[1] + oH0], R1 = st4[joff[1] + oR0];
+    opaque(H, R);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fp4_expand<GC>(H[ks], R[ks], fa0[ks]);
+    }
+    opaque(H1, R1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fp4_expand<GC>(H1[ks], R1[ks], fa1[ks]);
+    }
+  }
+  wide_stage_pf<GC, VC, true>(st4, joff, voff, oH0, oR0, oH1, oR1, fa0, fa1, fb0, fb1, acc);
+  wide_stage_pf<GC, VC, false>(st4, joff, voff, oH1, oR1, oH1, oR1, fb0, fb1, fa0, fa1, acc);
+}
+
 // ABL bit 2: the stage without LDS reads -- every row-block's codes are the two pieces this lane read ONCE (real genotypes of the first
 // stage, the dwords rotated per block and k-step so that consecutive MFMAs still see different operands)
 template <int ABL>
@@ -463,8 +535,14 @@ __device__ __forceinline__ void wide_tile(const PairKernelArgs& A, uint32_t* __r
           wide_stage_kept<ABL>(keptR, keptH, acc);
         }
       } else if (live) {
-        wide_stage<ABL, !SPARSE, VC>(st4, joff, voff, oH0, oR0, acc);
-        wide_stage<ABL, !SPARSE, VC>(st4, joff, voff, oH1, oR1, acc);
+        if constexpr ((ABL == 0) && !SPARSE) {
+          // (the SPARSE instantiation keeps the two plain half-stages: with 32 more registers hipcc reloads a spilled pointer INSIDE its stage loop,
+          // and a scratch load's vmcnt wait drains the DMA ring)
+          wide_stage_pair<true, VC>(st4, joff, voff, oH0, oR0, oH1, oR1, acc);
+        } else {
+          wide_stage<ABL, !SPARSE, VC>(st4, joff, voff, oH0, oR0, acc);
+          wide_stage<ABL, !SPARSE, VC>(st4, joff, voff, oH1, oR1, acc);
+        }
       }
 #ifdef LDP_MEASURE
       if constexpr ((ABL & 32) != 0) {
