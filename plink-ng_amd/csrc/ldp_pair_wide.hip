@@ -536,8 +536,9 @@ __device__ __forceinline__ void wide_tile(const PairKernelArgs& A, uint32_t* __r
         }
       } else if (live) {
         if constexpr ((ABL == 0) && !SPARSE) {
-          // (the SPARSE instantiation keeps the two plain half-stages: with 32 more registers hipcc reloads a spilled pointer INSIDE its stage loop,
-          // and a scratch load's vmcnt wait drains the DMA ring)
+          // (the SPARSE instantiation keeps the two plain half-stages: measured with this form too -- 14 values parked in scratch, none inside a k-loop --
+          // the slice at 0.1 % / 0.3 % missing calls 33.35 / 33.30 against 33.30 / 33.40 ms and 40.27 / 40.23 against 40.43 / 40.39 ms of pair kernels:
+          // nothing; its waves wait for their +-2-coded operands' energy and for the interval checkpoints, not for the head of a half-stage)
           wide_stage_pair<true, VC>(st4, joff, voff, oH0, oR0, oH1, oR1, acc);
         } else {
           wide_stage<ABL, !SPARSE, VC>(st4, joff, voff, oH0, oR0, acc);
