@@ -187,16 +187,16 @@ __device__ __forceinline__ void probe_stage_2pass(const mf_u4* __restrict__ st4,
 // The half-stage with the NEXT half-stage's J fragments made beside it (for one wave per SIMD: nobody else fills the matrix pipe while a wave reads and
 // expands its J blocks at the head of a half-stage).  fj: this half-stage's J fragments, ready; PREF: during V block b < RJ the pieces of J block b at
 // (oHn, oRn) are read and expanded into fjn.  RJ x 16 more registers.
-template <int RJ, int RV, bool PREF>
-__device__ __forceinline__ void probe_stage_pref(const mf_u4* __restrict__ st4, const uint32_t (&joff)[RJ], const uint32_t (&voff)[RV], uint32_t oH, uint32_t oR, uint32_t oHn,
-                                                 uint32_t oRn, const Frag (&fj)[RJ][4], Frag (&fjn)[RJ][4], mf_v16f (&acc)[RJ * RV]) {
+template <int RJ, int RV, bool PREF, bool HOLD = false>
+__device__ __forceinline__ void probe_stage_pref(const mf_u4* __restrict__ st4, const mf_u4* __restrict__ stn4, const uint32_t (&joff)[RJ], const uint32_t (&voff)[RV], uint32_t oH,
+                                                 uint32_t oR, uint32_t oHn, uint32_t oRn, const Frag (&fj)[RJ][4], Frag (&fjn)[RJ][4], mf_v16f (&acc)[RJ * RV], Frag* held = nullptr) {
   static_assert(RJ <= RV, "a J block of the next half-stage per V block");
   mf_u4 vH[2], vR[2], jH[2], jR[2];
   vH[0] = st4[voff[0] + oH];
   vR[0] = st4[voff[0] + oR];
   if constexpr (PREF) {
-    jH[0] = st4[joff[0] + oHn];
-    jR[0] = st4[joff[0] + oRn];
+    jH[0] = stn4[joff[0] + oHn];
+    jR[0] = stn4[joff[0] + oRn];
   }
 #pragma unroll
   for (int b = 0; b < RV; ++b) {
@@ -207,8 +207,8 @@ __device__ __forceinline__ void probe_stage_pref(const mf_u4* __restrict__ st4, 
     }
     if constexpr (PREF) {
       if (b + 1 < RJ) {
-        jH[(b & 1) ^ 1] = st4[joff[(b + 1 < RJ) ? b + 1 : 0] + oHn];
-        jR[(b & 1) ^ 1] = st4[joff[(b + 1 < RJ) ? b + 1 : 0] + oRn];
+        jH[(b & 1) ^ 1] = stn4[joff[(b + 1 < RJ) ? b + 1 : 0] + oHn];
+        jR[(b & 1) ^ 1] = stn4[joff[(b + 1 < RJ) ? b + 1 : 0] + oRn];
       }
     }
     opaque(vH[b & 1], vR[b & 1]);
@@ -219,6 +219,10 @@ __device__ __forceinline__ void probe_stage_pref(const mf_u4* __restrict__ st4, 
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+      if (HOLD && (b == RV - 1)) {
+        fp4_expand<true>(vH[b & 1][ks], vR[b & 1][ks], held[ks]);  // (the last V block's MFMAs wait for the head of the next stage)
+        continue;
+      }
       Frag fv;
       fp4_expand<true>(vH[b & 1][ks], vR[b & 1][ks], fv);
       if constexpr (PREF) {
@@ -300,6 +304,20 @@ __global__ __launch_bounds__(WAVES * 64, 1) void tile_probe_kernel(const uint8_t
   dma_stage(0, 0);
   issued = 1;
   issue_buf = 1;
+  [[maybe_unused]] Frag held[4], fja[RJ][4], fjb[RJ][4];
+  if constexpr (PASSES == 5) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        held[ks].d[d] = 0;
+#pragma unroll
+        for (int q = 0; q < RJ; ++q) {
+          fjb[q][ks].d[d] = 0;
+        }
+      }
+    }
+  }
   for (uint32_t kc = 0; kc < n_stages; ++kc) {
     wait_dma_then_barrier(kDma * (issued - kc - 1));
     if (issued < n_stages) {
@@ -309,7 +327,26 @@ __global__ __launch_bounds__(WAVES * 64, 1) void tile_probe_kernel(const uint8_t
     }
     const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * kStageDwords);
     read_buf ^= 1;
-    if constexpr (PASSES == 3) {
+    if constexpr (PASSES == 5) {
+      // as PASSES == 3, and the MFMAs of the stage's LAST V block (second half-stage) are held back: they are issued at the head of the NEXT stage, between
+      // the expansions of its first J fragments, so that the matrix pipe has work while the new stage's first pieces come from LDS.  held / fjb start as
+      // zeros (the first head adds nothing); the last stage's are flushed behind the loop.  16 more registers.
+      static_assert(RJ == 2, "two J blocks");
+      const mf_u4 H0 = st4[joff[0] + oH0], R0 = st4[joff[0] + oR0];
+      const mf_u4 H1 = st4[joff[1] + oH0], R1 = st4[joff[1] + oR0];
+      mf_u4 h0 = H0, r0 = R0, h1 = H1, r1 = R1;
+      opaque(h0, r0);
+      opaque(h1, r1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        acc[RV - 1] = mfma_pair<true>(held[ks], fjb[0][ks], acc[RV - 1]);
+        acc[2 * RV - 1] = mfma_pair<true>(held[ks], fjb[1][ks], acc[2 * RV - 1]);
+        fp4_expand<true>(h0[ks], r0[ks], fja[0][ks]);
+        fp4_expand<true>(h1[ks], r1[ks], fja[1][ks]);
+      }
+      probe_stage_pref<RJ, RV, true>(st4, st4, joff, voff, oH0, oR0, oH1, oR1, fja, fjb, acc);
+      probe_stage_pref<RJ, RV, false, true>(st4, st4, joff, voff, oH1, oR1, oH1, oR1, fjb, fja, acc, held);
+    } else if constexpr (PASSES == 3) {
       // J fragments of the second half-stage made during the first; those of the first at the head of the stage (the stage has just landed)
       Frag fja[RJ][4], fjb[RJ][4];
 #pragma unroll
@@ -321,8 +358,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void tile_probe_kernel(const uint8_t
           fp4_expand<true>(H[ks], R[ks], fja[q][ks]);
         }
       }
-      probe_stage_pref<RJ, RV, true>(st4, joff, voff, oH0, oR0, oH1, oR1, fja, fjb, acc);
-      probe_stage_pref<RJ, RV, false>(st4, joff, voff, oH1, oR1, oH1, oR1, fjb, fja, acc);
+      probe_stage_pref<RJ, RV, true>(st4, st4, joff, voff, oH0, oR0, oH1, oR1, fja, fjb, acc);
+      probe_stage_pref<RJ, RV, false>(st4, st4, joff, voff, oH1, oR1, oH1, oR1, fjb, fja, acc);
     } else if constexpr (PASSES == 2) {
       probe_stage_2pass<RJ, RV>(st4, joff, voff, oH0, oR0, acc);
       probe_stage_2pass<RJ, RV>(st4, joff, voff, oH1, oR1, acc);
@@ -331,7 +368,128 @@ __global__ __launch_bounds__(WAVES * 64, 1) void tile_probe_kernel(const uint8_t
       probe_stage<RJ, RV>(st4, joff, voff, oH1, oR1, acc);
     }
   }
+  if constexpr (PASSES == 5) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      acc[RV - 1] = mfma_pair<true>(held[ks], fjb[0][ks], acc[RV - 1]);
+      acc[2 * RV - 1] = mfma_pair<true>(held[ks], fjb[1][ks], acc[2 * RV - 1]);
+    }
+  }
   const unsigned long long t1 = clock64(), w1 = wall_clock64();
+#pragma unroll
+  for (int p = 0; p < RJ * RV; ++p) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      sum += static_cast<unsigned long long>(acc[p][g]);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    sum += __shfl_down(sum, off, 64);
+  }
+  if (lane == 0) {
+    atomicAdd(out, sum);
+    if ((blockIdx.x == 0) && (wave == 0)) {
+      out[1] = t1 - t0;
+      out[2] = w1 - w0;
+    }
+  }
+}
+
+// ---- 256-sample stages in a ring of FOUR, every stage's J fragments made during the stage before (shape "2x4r4") ----
+// The two-stage ring of 512-sample stages cannot make a stage's first J fragments early: the stage lands as the one before it ends.  Here the DMA runs
+// two stages ahead (the same 64 KiB in flight), stage s + 1 has landed when stage s starts, and no half-stage begins with reads and expansions in
+// front of an idle matrix pipe -- at twice the workgroup barriers.  Geometry of a 256-sample stage as pair_mfma_kernel's (ldp_mfma_device.h
+// StageGeom<4>): four 16-byte pieces per row, piece c at unit (32 b + r) * 4 + (c ^ ((r >> 2) & 3)), lane half h reads pieces h and 2 + h.
+template <int WAVES, int RJ, int RV, int TV, int PASSES>
+__global__ __launch_bounds__(WAVES * 64, 1) void tile_probe_ring4_kernel(const uint8_t* __restrict__ codes, uint32_t row_bytes, uint32_t n_stages512, uint32_t n_tiles, uint32_t n_vt,
+                                                                         uint32_t reach_rows, unsigned long long* out) {
+  constexpr uint32_t NS = kTJ + TV;
+  constexpr uint32_t kUnits = 32 * 4;                     // 16-byte units per row-block and stage
+  constexpr uint32_t kStageDwords = NS * kUnits * 4;      // 8,192 dwords = 32 KiB at 16 row-blocks
+  constexpr uint32_t kDma = (NS * 2) / WAVES;             // DMA wave-instructions per wave and stage (an instruction = half a row-block: 16 rows x 4 pieces)
+  constexpr uint32_t WJ = kTJ / RJ;
+  static_assert((NS * 2) % WAVES == 0 && WAVES % 2 == 0 && WJ * (TV / RV) == WAVES, "shape");
+  extern __shared__ uint32_t lds[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const uint32_t per_xcd = n_tiles >> 3;
+  const uint32_t idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const uint32_t tj = idx / n_vt, kv = idx - tj * n_vt;
+  const uint32_t jv0 = reach_rows + tj * 256, vv0 = tj * 256 + kv * TV * 32;
+  const uint32_t a0 = RJ * (wave % WJ), b0 = RV * (wave / WJ);
+  const uint32_t n_stages = 2 * n_stages512;
+  const uint32_t rr = (wave & 1) * 16 + (lane >> 2);
+  const uint32_t src_off = rr * row_bytes + ((lane & 3) ^ ((rr >> 2) & 3u)) * 16;
+  const uint8_t* jbase = codes + static_cast<uint64_t>(jv0) * row_bytes;
+  const uint8_t* vbase = codes + static_cast<uint64_t>(vv0) * row_bytes;
+  uint32_t joff[RJ], voff[RV];
+#pragma unroll
+  for (int q = 0; q < RJ; ++q) {
+    joff[q] = (a0 + q) * kUnits;
+  }
+#pragma unroll
+  for (int b = 0; b < RV; ++b) {
+    voff[b] = (kTJ + b0 + b) * kUnits;
+  }
+  const uint32_t sw = (r >> 2) & 3u;
+  const uint32_t oH = r * 4 + (h ^ sw), oR = r * 4 + ((2 + h) ^ sw);
+  mf_v16f acc[RJ * RV];
+#pragma unroll
+  for (int p = 0; p < RJ * RV; ++p) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      acc[p][g] = 0.f;
+    }
+  }
+  auto dma_stage = [&](uint32_t s) {
+    const uint32_t kbyte = s * 64u;
+    uint32_t* dst = lds + (s & 3u) * kStageDwords;
+#pragma unroll
+    for (int t = 0; t < static_cast<int>(kDma); ++t) {
+      const uint32_t T = wave + WAVES * t;
+      const uint32_t slot = T >> 1;
+      const uint8_t* base = ((slot < kTJ) ? (jbase + static_cast<uint64_t>(slot) * 32 * row_bytes) : (vbase + static_cast<uint64_t>(slot - kTJ) * 32 * row_bytes)) + kbyte;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + src_off), (__attribute__((address_space(3))) void*)(dst + T * 256), 16, 0, 0);
+    }
+  };
+  auto st_of = [&](uint32_t s) { return reinterpret_cast<const mf_u4*>(lds + (s & 3u) * kStageDwords); };
+  const unsigned long long t0 = clock64(), w0 = wall_clock64();
+  uint32_t issued = 0;
+  for (; (issued < 3) && (issued < n_stages); ++issued) {
+    dma_stage(issued);
+  }
+  wait_dma_then_barrier(kDma * (issued - 1));  // stage 0 has landed
+  Frag fa[RJ][4], fb[RJ][4];
+  {
+    const mf_u4* __restrict__ st4 = st_of(0);
+#pragma unroll
+    for (int q = 0; q < RJ; ++q) {
+      mf_u4 H = st4[joff[q] + oH], R = st4[joff[q] + oR];
+      opaque(H, R);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        fp4_expand<true>(H[ks], R[ks], fa[q][ks]);
+      }
+    }
+  }
+  // top of stage s: stage s + 1 has landed (its J pieces are read during s), stage s + 2 may be in flight, stage s + 3 goes into the buffer of s - 1
+  auto top = [&](uint32_t s) {
+    const uint32_t landed = s + 2;  // stages < landed must be in LDS
+    wait_dma_then_barrier((issued > landed) ? kDma * (issued - landed) : 0u);
+    if (issued < n_stages) {
+      dma_stage(issued);
+      ++issued;
+    }
+  };
+  for (uint32_t s = 0; s < n_stages; s += 2) {
+    top(s);
+    probe_stage_pref<RJ, RV, true>(st_of(s), st_of(s + 1), joff, voff, oH, oR, oH, oR, fa, fb, acc);
+    top(s + 1);
+    probe_stage_pref<RJ, RV, true>(st_of(s + 1), st_of(s + 2), joff, voff, oH, oR, oH, oR, fb, fa, acc);
+  }
+  const unsigned long long t1 = clock64(), w1 = wall_clock64();
+  unsigned long long sum = 0;
 #pragma unroll
   for (int p = 0; p < RJ * RV; ++p) {
 #pragma unroll
@@ -363,7 +521,9 @@ static Shape shape_of(const char* name) {
 }
 
 int main(int argc, char** argv) {
-  const Shape shapes[] = {shape_of<8, 2, 4, 8>("2x4"), shape_of<4, 4, 4, 8>("4x4"), shape_of<8, 2, 6, 12>("2x6"), shape_of<4, 4, 6, 12, 2>("4x6"), shape_of<8, 2, 4, 8, 2>("2x4p2"), shape_of<4, 4, 4, 8, 2>("4x4p2"), shape_of<8, 2, 6, 12, 2>("2x6p2"), shape_of<4, 4, 4, 8, 3>("4x4pf"), shape_of<8, 2, 4, 8, 3>("2x4pf")};
+  const Shape shapes[] = {shape_of<8, 2, 4, 8>("2x4"), shape_of<4, 4, 4, 8>("4x4"), shape_of<8, 2, 6, 12>("2x6"), shape_of<4, 4, 6, 12, 2>("4x6"), shape_of<8, 2, 4, 8, 2>("2x4p2"), shape_of<4, 4, 4, 8, 2>("4x4p2"), shape_of<8, 2, 6, 12, 2>("2x6p2"), shape_of<4, 4, 4, 8, 3>("4x4pf"), shape_of<8, 2, 4, 8, 3>("2x4pf"),
+                          shape_of<8, 2, 4, 8, 5>("2x4pfh"),
+                          Shape{"2x4r4", 8, 2, 4, 8, reinterpret_cast<const void*>(&tile_probe_ring4_kernel<8, 2, 4, 8, 4>)}};
   const std::string want = (argc > 1) ? argv[1] : "2x4";
   const double seconds = (argc > 2) ? atof(argv[2]) : 3.0;
   const uint32_t n_samples = ((argc > 3) ? static_cast<uint32_t>(atol(argv[3])) : 500224u) / kStageSamples * kStageSamples;
@@ -376,7 +536,7 @@ int main(int argc, char** argv) {
     }
   }
   if (!S || (reach_blocks % S->tv) || !n_samples || (n_samples > 4000000u)) {
-    printf("usage: tile_shape_probe 2x4|4x4|2x6|4x6|2x4p2|4x4p2|2x6p2|4x4pf|2x4pf [seconds] [samples] [J tiles] [reach in row-blocks: a multiple of the tile's V blocks]\n");
+    printf("usage: tile_shape_probe 2x4|4x4|2x6|4x6|2x4p2|4x4p2|2x6p2|4x4pf|2x4pf|2x4pfh|2x4r4 [seconds] [samples] [J tiles] [reach in row-blocks: a multiple of the tile's V blocks]\n");
     return 2;
   }
   const uint32_t reach_rows = reach_blocks * 32, n_rows = reach_rows + n_jt * 256;
