@@ -6,33 +6,16 @@ mkdir -p gpurun_out
 cd "$GRAFT_REPO_ROOT"
 L=plink-ng_amd/lib
 cp $L/libldprune_hip.so $L/libldprune_hip_new.so
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_full_size_properties.py -m gpu -x -q -k "wide or tile or config3 or band or three_kernel" > gpurun_out/r06_pf_tests.log 2>&1
-tail -3 gpurun_out/r06_pf_tests.log
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_full_size_properties.py -m gpu -x -q -k "wide or tile or config3 or band or three_kernel" > gpurun_out/r06_${TAGR:-pf}_tests.log 2>&1
+tail -3 gpurun_out/r06_${TAGR:-pf}_tests.log
 timeout 300 python tests/fuzz_parity.py --seed 911 --cases 300 2>&1 | tail -1
 B="python bench.py --steps 8 --warmup 2 --no-legs --no-cpu-baseline --no-pmc --no-e2e --no-cli-compare"
 for round in 1 2; do
   for which in new base; do
     cp $L/libldprune_hip_$which.so $L/libldprune_hip.so
-    timeout 600 $B > gpurun_out/r06_pf_share_${which}_$round.json 2>> gpurun_out/r06_pf_share.err
-    timeout 600 python tools/c3miss_leg.py --rates 0 --steps 4 --sets "default:;exhaustive:early_exit=0" > gpurun_out/r06_pf_slice_${which}_$round.json 2>> gpurun_out/r06_pf_slice.err
+    timeout 600 $B > gpurun_out/r06_${TAGR:-pf}_share_${which}_$round.json 2>> gpurun_out/r06_${TAGR:-pf}_share.err
+    timeout 600 python tools/c3miss_leg.py --rates 0 --steps 4 --sets "default:;exhaustive:early_exit=0" > gpurun_out/r06_${TAGR:-pf}_slice_${which}_$round.json 2>> gpurun_out/r06_${TAGR:-pf}_slice.err
   done
 done
 cp $L/libldprune_hip_new.so $L/libldprune_hip.so
-python - <<'PY'
-import json
-for rnd in (1, 2):
-    for which in ("new", "base"):
-        try:
-            d = json.loads(open("gpurun_out/r06_pf_share_%s_%d.json" % (which, rnd)).read().strip().splitlines()[-1])
-            print("share", which, rnd, "ms/step %.2f kernels %.2f frac %.4f removed %s power %s clock %s" % (d["ms_per_step"], d["stage_ms"]["pair_kernels"], d["roofline"]["frac"], d["config"]["variants_removed"],
-                  d.get("power_and_clock", {}).get("socket_power_w_median"), d.get("power_and_clock", {}).get("shader_clock_mhz_median")))
-        except Exception as ex:
-            print("share", which, rnd, "??", ex)
-        try:
-            d = json.load(open("gpurun_out/r06_pf_slice_%s_%d.json" % (which, rnd)))
-            for name, x in d["rates"]["0"].items():
-                if isinstance(x, dict) and "pair_kernels_ms" in x:
-                    print("  slice", which, rnd, name, "pair %.2f ms executed %.1f TFLOP/s skipped %.3f removed %s" % (x["pair_kernels_ms"], x["mfma_executed_tflops"], x["early_termination_skipped_frac"], x["variants_removed"]))
-        except Exception as ex:
-            print("  slice", which, rnd, "??", ex)
-PY
+python tools/ab_summary.py ${TAGR:-pf}
