@@ -6,7 +6,7 @@
 // kernel wait for HBM: every row was fetched ~12 times (profiles/r02_c3shape_pmc_traffic.json).  Here a workgroup owns a
 // SQUARE of 8 second-variant blocks x 8 first-variant blocks: 64 products for 16 staged row-blocks (32 KiB per 256-sample
 // stage), i.e. half the bytes per product, and one workgroup per CU with a two-stage ring of 512-sample stages in 128 KiB of LDS.  Wave w owns
-// the 2 x 4 sub-rectangle J blocks 2 (w & 3), + 1 x V blocks 4 (w >> 2) .. + 3: eight accumulator sets, six row-block reads
+// the 2 x 4 sub-rectangle J blocks 2 (w & 3), + 1 x V blocks 4 ((w ^ (w >> 2)) & 1) .. + 3 (wide_tile: the map, and how it was chosen): eight accumulator sets, six row-block reads
 // and expansions per stage (the parallelogram needs seven).  Tiles are aligned to the subcontig start in both directions;
 // on the diagonal the V tile is the J tile (8 row-blocks staged) and the products above it are simply not live.
 // The launch is eight streams of tiles of equal length, one per XCD (ldp_engine.cpp build_shard): the far tiles of a stream first,
@@ -378,8 +378,12 @@ __device__ __forceinline__ void wide_tile(const PairKernelArgs& A, uint32_t* __r
 
   // ---- this wave's rectangle: J blocks a0, a0 + 1, V blocks b0 .. b0 + VC - 1 (product b: J block a0, V block b0 + b; VC + b: J block a0 + 1) ----
   // VC == 3, wave 0 .. 7: (a0, b0) = (0,0) (2,0) (2,3) (4,0) (4,3) (6,0) (6,3) (6,6)
-  auto rect_a0 = [](uint32_t w) -> uint32_t { return (VC == 4) ? (2 * (w & 3)) : ((0x66644220u >> (4 * w)) & 0xfu); };
-  auto rect_b0 = [](uint32_t w) -> uint32_t { return (VC == 4) ? (4 * (w >> 2)) : ((0x63030300u >> (4 * w)) & 0xfu); };
+  // VC == 4, wave 0 .. 7: (a0, b0) = (0,0) (2,4) (4,0) (6,4) | (0,4) (2,0) (4,4) (6,0).  Waves w and w + 4 read the same two J blocks (as in rounds 2-5); since
+  // round 6 neighbouring waves take different V halves.  Four maps, one library each, alternating on one box (profiles/r06_experiments.md 4b): this one
+  // 272.5 ms of pair kernels per step of the share; b0 = 4 (w >> 2), the map of rounds 2-5, 275.0-275.8; waves w, w + 4 sharing their V blocks instead
+  // 276.1-276.5; sharing nothing 277.2 against 271.8.
+  auto rect_a0 = [](uint32_t w) -> uint32_t { return ((VC == 4) ? (0x64206420u >> (4 * w)) : (0x66644220u >> (4 * w))) & 0xfu; };
+  auto rect_b0 = [](uint32_t w) -> uint32_t { return ((VC == 4) ? (0x04044040u >> (4 * w)) : (0x63030300u >> (4 * w))) & 0xfu; };
   const uint32_t a0 = rect_a0(wave), b0 = rect_b0(wave);
   const uint32_t vslot0 = (diag ? 0u : static_cast<uint32_t>(kWdTile)) + b0;
   auto mask_row = [&](uint32_t a) { return ((a < 4) ? (mask_lo >> (8 * a)) : (mask_hi >> (8 * (a - 4)))) & 0xffu; };
