@@ -4,7 +4,7 @@
 set -u
 cd $GRAFT_REPO_ROOT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-O=gpurun_out/final6
+O=${O:-gpurun_out/final6}
 mkdir -p $O
 (timeout 500 bash tools/profile.sh r06) > $O/prof_share.log 2>&1
 (LDP_PROF_ARGS="--workload config2" timeout 400 bash tools/profile.sh r06_config2) > $O/prof_config2.log 2>&1
