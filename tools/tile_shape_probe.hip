@@ -238,6 +238,54 @@ __device__ __forceinline__ void probe_stage_pref(const mf_u4* __restrict__ st4, 
   }
 }
 
+// The first half-stage of a stage without its head (shape "2x4pf2"): the J fragments of k-step ks are expanded right in front of V block 0's MFMAs of that k-step
+// (18 VALU in front of the first MFMA instead of 54), and the next half-stage's J fragments are made during the LAST two V blocks instead of the first two.
+template <int RV>
+__device__ __forceinline__ void probe_stage_first(const mf_u4* __restrict__ st4, const uint32_t (&joff)[2], const uint32_t (&voff)[RV], uint32_t oH, uint32_t oR, uint32_t oHn,
+                                                  uint32_t oRn, Frag (&fj)[2][4], Frag (&fjn)[2][4], mf_v16f (&acc)[2 * RV]) {
+  mf_u4 vH[2], vR[2], jH[2], jR[2];
+  jH[0] = st4[joff[0] + oH];
+  jR[0] = st4[joff[0] + oR];
+  jH[1] = st4[joff[1] + oH];
+  jR[1] = st4[joff[1] + oR];
+  vH[0] = st4[voff[0] + oH];
+  vR[0] = st4[voff[0] + oR];
+#pragma unroll
+  for (int b = 0; b < RV; ++b) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (b + 1 < RV) {
+      vH[(b & 1) ^ 1] = st4[voff[(b + 1 < RV) ? b + 1 : b] + oH];
+      vR[(b & 1) ^ 1] = st4[voff[(b + 1 < RV) ? b + 1 : b] + oR];
+    }
+    if (b == RV - 3) {  // the next half-stage's J pieces, in time for the last two V blocks
+      jH[0] = st4[joff[0] + oHn];
+      jR[0] = st4[joff[0] + oRn];
+      jH[1] = st4[joff[1] + oHn];
+      jR[1] = st4[joff[1] + oRn];
+    }
+    opaque(vH[b & 1], vR[b & 1]);
+    if ((b == 0) || (b >= RV - 2)) {
+      opaque(jH[0], jR[0]);
+      opaque(jH[1], jR[1]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      Frag fv;
+      fp4_expand<true>(vH[b & 1][ks], vR[b & 1][ks], fv);
+      if (b == 0) {
+        fp4_expand<true>(jH[0][ks], jR[0][ks], fj[0][ks]);
+        fp4_expand<true>(jH[1][ks], jR[1][ks], fj[1][ks]);
+      } else if (b == RV - 2) {
+        fp4_expand<true>(jH[0][ks], jR[0][ks], fjn[0][ks]);
+      } else if (b == RV - 1) {
+        fp4_expand<true>(jH[1][ks], jR[1][ks], fjn[1][ks]);
+      }
+      acc[b] = mfma_pair<true>(fv, fj[0][ks], acc[b]);
+      acc[RV + b] = mfma_pair<true>(fv, fj[1][ks], acc[RV + b]);
+    }
+  }
+}
+
 // tile idx of the launch: J tile idx / n_vt (J blocks from row reach_rows + 256 tj), V tile idx % n_vt (V blocks from row 256 tj + 32 TV k): the
 // n_vt V tiles of a J tile cover the `reach_rows` rows in front of it, whatever TV is
 template <int WAVES, int RJ, int RV, int TV, int PASSES>
@@ -327,7 +375,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void tile_probe_kernel(const uint8_t
     }
     const mf_u4* __restrict__ st4 = reinterpret_cast<const mf_u4*>(lds + read_buf * kStageDwords);
     read_buf ^= 1;
-    if constexpr (PASSES == 5) {
+    if constexpr (PASSES == 6) {
+      static_assert(RJ == 2 && RV >= 3, "two J blocks");
+      Frag fa[2][4], fb[2][4];
+      probe_stage_first<RV>(st4, joff, voff, oH0, oR0, oH1, oR1, fa, fb, acc);
+      probe_stage_pref<RJ, RV, false>(st4, st4, joff, voff, oH1, oR1, oH1, oR1, fb, fa, acc);
+    } else if constexpr (PASSES == 5) {
       // as PASSES == 3, and the MFMAs of the stage's LAST V block (second half-stage) are held back: they are issued at the head of the NEXT stage, between
       // the expansions of its first J fragments, so that the matrix pipe has work while the new stage's first pieces come from LDS.  held / fjb start as
       // zeros (the first head adds nothing); the last stage's are flushed behind the loop.  16 more registers.
@@ -522,7 +575,7 @@ static Shape shape_of(const char* name) {
 
 int main(int argc, char** argv) {
   const Shape shapes[] = {shape_of<8, 2, 4, 8>("2x4"), shape_of<4, 4, 4, 8>("4x4"), shape_of<8, 2, 6, 12>("2x6"), shape_of<4, 4, 6, 12, 2>("4x6"), shape_of<8, 2, 4, 8, 2>("2x4p2"), shape_of<4, 4, 4, 8, 2>("4x4p2"), shape_of<8, 2, 6, 12, 2>("2x6p2"), shape_of<4, 4, 4, 8, 3>("4x4pf"), shape_of<8, 2, 4, 8, 3>("2x4pf"),
-                          shape_of<8, 2, 4, 8, 5>("2x4pfh"),
+                          shape_of<8, 2, 4, 8, 5>("2x4pfh"), shape_of<8, 2, 4, 8, 6>("2x4pf2"),
                           Shape{"2x4r4", 8, 2, 4, 8, reinterpret_cast<const void*>(&tile_probe_ring4_kernel<8, 2, 4, 8, 4>)}};
   const std::string want = (argc > 1) ? argv[1] : "2x4";
   const double seconds = (argc > 2) ? atof(argv[2]) : 3.0;
@@ -536,7 +589,7 @@ int main(int argc, char** argv) {
     }
   }
   if (!S || (reach_blocks % S->tv) || !n_samples || (n_samples > 4000000u)) {
-    printf("usage: tile_shape_probe 2x4|4x4|2x6|4x6|2x4p2|4x4p2|2x6p2|4x4pf|2x4pf|2x4pfh|2x4r4 [seconds] [samples] [J tiles] [reach in row-blocks: a multiple of the tile's V blocks]\n");
+    printf("usage: tile_shape_probe 2x4|4x4|2x6|4x6|2x4p2|4x4p2|2x6p2|4x4pf|2x4pf|2x4pfh|2x4pf2|2x4r4 [seconds] [samples] [J tiles] [reach in row-blocks: a multiple of the tile's V blocks]\n");
     return 2;
   }
   const uint32_t reach_rows = reach_blocks * 32, n_rows = reach_rows + n_jt * 256;
