@@ -8,7 +8,7 @@ TAG=${TAG:-c}
 i=0
 for s in ${SHAPES:-2x4 4x4 4x4pf 2x4pf 2x6 4x6 2x4p2 2x4}; do
   i=$((i+1)); n=${TAG}$i
-  timeout 300 bash tools/power_sample.sh gpurun_out/r06_tile_shape_${s}_$n.smi.jsonl -- tools/_bin/tile_shape_probe $s ${SECONDS_EACH:-4} > gpurun_out/r06_tile_shape_${s}_$n.json 2> gpurun_out/r06_tile_shape_${s}_$n.err
+  timeout 300 bash tools/power_sample.sh gpurun_out/r06_tile_shape_${s}_$n.smi.jsonl -- ${PROBE_BIN:-tools/_bin/tile_shape_probe} $s ${SECONDS_EACH:-4} > gpurun_out/r06_tile_shape_${s}_$n.json 2> gpurun_out/r06_tile_shape_${s}_$n.err
   python tools/tile_shape_summary.py gpurun_out/r06_tile_shape_${s}_$n.json
 done
 if [ -z "${NO_KERNEL:-}" ]; then
