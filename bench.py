@@ -364,6 +364,20 @@ def measured_ceilings():
                                   "random operands clock down -- the shader clock of each run is printed beside it)")
         except Exception as e:  # pragma: no cover
             out["mfma_error"] = str(e)
+    loop = os.path.join(REPO, "tools", "_bin", "tile_shape_probe")
+    if os.path.exists(loop):
+        # the tile kernel's OWN stage loop in its own shape and form ("2x4pf": eight waves x 2 x 4 on 8 x 8 tiles, the second half-stage's J fragments made
+        # during the first), on full tiles without checkpoints or epilogue, 500,224 samples, 2 s on this box, checksum against a plain kernel
+        try:
+            txt = subprocess.run([loop, "2x4pf", "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=180).stdout
+            d = json.loads(txt.strip().splitlines()[-1])
+            out["stage_loop_probe"] = {k: d.get(k) for k in ("shape", "waves", "products_per_wave", "tile", "vgprs", "samples", "ms_per_launch", "pflops", "of_fp4_peak",
+                                                            "shader_clock_mhz_wg0", "l2_to_lds_tb_s", "checksum_ok")}
+            out["stage_loop_probe_tflops"] = d["pflops"] * 1000.0 if d.get("checksum_ok") else None
+            out["stage_loop_source"] = ("tools/tile_shape_probe.hip 2x4pf: pair_mfma_wide_kernel's stage loop alone (same DMA ring, LDS layout, expansion and MFMA; "
+                                        "full tiles, no checkpoints, no epilogue) -- what the kernel could reach if the band were all full tiles")
+        except Exception as e:  # pragma: no cover
+            out["stage_loop_error"] = str(e)[:200]
     copy = os.path.join(REPO, "tools", "_bin", "ubench_copy")
     if os.path.exists(copy):
         try:
@@ -1175,6 +1189,11 @@ def main():
             out["roofline"]["mfma"]["frac_of_measured_rate_random_operands"] = out["roofline"]["mfma"]["executed_tflops"] / ceil["mfma_fp4_tflops_random_operands"]
         if ceil.get("hbm_read_gbs"):
             out["roofline"]["hbm"]["frac_of_measured_read_rate"] = out["roofline"]["hbm"]["compulsory_gbs"] / ceil["hbm_read_gbs"]
+        if ceil.get("stage_loop_probe_tflops") and ("wide" in str(out["roofline"].get("kernel"))) and not args.missing_rate:  # (the probe is the complete-data tile kernel's loop)
+            # flat scalars (the driver's record keeps those): the stage loop's rate on THIS box in THIS run, and the kernel against it
+            out["roofline"]["stage_loop_probe_frac_of_peak"] = ceil["stage_loop_probe_tflops"] / out["roofline"]["mfma"]["peak_tflops"]
+            out["roofline"]["kernel_over_stage_loop_probe"] = out["roofline"]["mfma"]["executed_tflops"] / ceil["stage_loop_probe_tflops"]
+            out["roofline"]["mfma"]["frac_of_stage_loop_probe"] = out["roofline"]["kernel_over_stage_loop_probe"]
 
     start_e2e()   # (no legs in this run: start it here)
     e2e = e2e_box[0]
