@@ -1,0 +1,29 @@
+#!/bin/bash
+# round 6, batch v: more wave -> rectangle maps (2 x 4 body: map5-7, waves w / w + 4 always sharing their J blocks; mapd: the diagonal tiles' 2 x 3 body with
+# J-sharing partners), one library each against the tree's (lib/libldprune_hip_base.so): parity tests per library, then the share alternately
+set -u
+mkdir -p gpurun_out
+cd "$GRAFT_REPO_ROOT"
+L=plink-ng_amd/lib
+B="python bench.py --steps 8 --warmup 2 --no-legs --no-cpu-baseline --no-pmc --no-e2e --no-cli-compare"
+for which in map5 map6 map7 mapd; do
+  cp $L/libldprune_hip_$which.so $L/libldprune_hip.so
+  echo "tests $which: $(timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k 'wide or tile or band' 2>&1 | tail -1)"
+done
+for round in 1 2; do
+  for which in base map5 map6 map7 mapd; do
+    cp $L/libldprune_hip_$which.so $L/libldprune_hip.so
+    timeout 600 $B > gpurun_out/r06_maps2_share_${which}_$round.json 2>> gpurun_out/r06_maps2_share.err
+    python - $which $round <<'PY'
+import json, sys
+w, r = sys.argv[1], sys.argv[2]
+try:
+    d = json.loads(open("gpurun_out/r06_maps2_share_%s_%s.json" % (w, r)).read().strip().splitlines()[-1])
+    print("share", w, r, "ms/step %.2f kernels %.2f frac %.4f removed %s power %s clock %s" % (d["ms_per_step"], d["stage_ms"]["pair_kernels"], d["roofline"]["frac"], d["config"]["variants_removed"],
+          d.get("power_and_clock", {}).get("socket_power_w_median"), d.get("power_and_clock", {}).get("shader_clock_mhz_median")))
+except Exception as ex:
+    print("share", w, r, "??", ex)
+PY
+  done
+done
+cp $L/libldprune_hip_base.so $L/libldprune_hip.so
