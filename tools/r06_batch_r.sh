@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 6, batch r: the complete-data tile kernel with the second half-stage's J fragments made during the first (wide_stage_pair) against the tree's kernel:
 # parity tests on the new library, then the share and the slice alternately on the two libraries (lib/libldprune_hip_base.so = the kernel before)
+# (The libraries beside the tree's are built by hand before the call: `git stash` / a -D switch, build_library(), cp lib/libldprune_hip.so lib/libldprune_hip_<name>.so -- git-ignored,
+# they travel with the snapshot.  profiles/r06_experiments.md section 4b says which sources each one was.)
 set -u
 mkdir -p gpurun_out
 cd "$GRAFT_REPO_ROOT"

@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 6, batch s: the SPARSE instantiation of the tile kernel with the second half-stage's J fragments made during the first, against the plain form
 # (lib/libldprune_hip_base.so): parity tests on the new library, then config 3's slice at 0 / 0.1 % / 0.3 % missing calls alternately on the two libraries
+# (The libraries beside the tree's are built by hand before the call: `git stash` / a -D switch, build_library(), cp lib/libldprune_hip.so lib/libldprune_hip_<name>.so -- git-ignored,
+# they travel with the snapshot.  profiles/r06_experiments.md section 4b says which sources each one was.)
 set -u
 mkdir -p gpurun_out
 cd "$GRAFT_REPO_ROOT"

@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 6, batch t: wave -> rectangle maps of the 2 x 4 body, one library each (lib/libldprune_hip_{base,map2,map3,map4}.so), the share alternately
+# (The libraries beside the tree's are built by hand before the call: `git stash` / a -D switch, build_library(), cp lib/libldprune_hip.so lib/libldprune_hip_<name>.so -- git-ignored,
+# they travel with the snapshot.  profiles/r06_experiments.md section 4b says which sources each one was.)
 set -u
 mkdir -p gpurun_out
 cd "$GRAFT_REPO_ROOT"

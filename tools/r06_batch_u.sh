@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 6, batch u: the quarter-tile kernel (config 5) with neighbouring waves on different V pairs, against the tree's map (lib/libldprune_hip_base.so)
+# (The libraries beside the tree's are built by hand before the call: `git stash` / a -D switch, build_library(), cp lib/libldprune_hip.so lib/libldprune_hip_<name>.so -- git-ignored,
+# they travel with the snapshot.  profiles/r06_experiments.md section 4b says which sources each one was.)
 set -u
 mkdir -p gpurun_out
 cd "$GRAFT_REPO_ROOT"

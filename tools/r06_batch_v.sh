@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 6, batch v: more wave -> rectangle maps (2 x 4 body: map5-7, waves w / w + 4 always sharing their J blocks; mapd: the diagonal tiles' 2 x 3 body with
 # J-sharing partners), one library each against the tree's (lib/libldprune_hip_base.so): parity tests per library, then the share alternately
+# (The libraries beside the tree's are built by hand before the call: `git stash` / a -D switch, build_library(), cp lib/libldprune_hip.so lib/libldprune_hip_<name>.so -- git-ignored,
+# they travel with the snapshot.  profiles/r06_experiments.md section 4b says which sources each one was.)
 set -u
 mkdir -p gpurun_out
 cd "$GRAFT_REPO_ROOT"
