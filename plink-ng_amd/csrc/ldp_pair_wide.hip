@@ -539,7 +539,7 @@ __device__ __forceinline__ void wide_tile(const PairKernelArgs& A, uint32_t* __r
           wide_stage_kept<ABL>(keptR, keptH, acc);
         }
       } else if (live) {
-        if constexpr ((ABL == 0) && !SPARSE) {
+        if constexpr (((ABL & 6) == 0) && !SPARSE) {  // (measurement build: every ablation that leaves the stage's reads and expansions alone times THIS form)
           // (the SPARSE instantiation keeps the two plain half-stages: measured with this form too -- 14 values parked in scratch, none inside a k-loop --
           // the slice at 0.1 % / 0.3 % missing calls 33.35 / 33.30 against 33.30 / 33.40 ms and 40.27 / 40.23 against 40.43 / 40.39 ms of pair kernels:
           // nothing; its waves wait for their +-2-coded operands' energy and for the interval checkpoints, not for the head of a half-stage)

@@ -40,7 +40,7 @@ def main():
     L = pkg.lib()
     L.ldp_measure_wide_counters.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     torch.cuda.set_device(0)
-    smi = bench.SmiSampler()
+    smi = bench.support.SmiSampler()   # (tools/bench_support.py since round 6)
 
     def smi_summary(tag):
         q = smi.summary(tag)
