@@ -7,13 +7,19 @@
 // must be the same number for every shape and equal to the one a plain kernel computes from the rows.  So the probe answers one question: what
 // do the matrix pipe, the LDS and the L2 -> LDS leg deliver per MFMA when a wave owns RJ x RV products of a TJ x TV tile -- at which power and clock.
 //   shape   waves  products / wave   tile     staged row-blocks / products      accumulators
-//   2x4       8       2 x 4          8 x 8        16 / 64                         128 VGPRs   (the kernel's)
-//   4x4       4       4 x 4          8 x 8        16 / 64                         256         (one wave per SIMD, 512 VGPRs)
+//   2x4       8       2 x 4          8 x 8        16 / 64                         128 VGPRs   (the kernel's shape, the stage form of rounds 3-5)
+//   4x4       4       4 x 4          8 x 8        16 / 64                         256 AGPRs   (one wave per SIMD, 512 registers)
 //   2x6       8       2 x 6          8 x 12       20 / 96                         192
-//   4x6       4       4 x 6          8 x 12       20 / 96                         384         (the review's: one wave per SIMD)
-//   4x4x2     8       4 x 4          16 x 8       24 / 128                        256         -- not built: 8 waves x 512 VGPRs do not exist
+//   4x6       4       4 x 6          8 x 12       20 / 96                         384         (the review's: one wave per SIMD; two passes of two k-steps)
+//   2x4p2 / 4x4p2 / 2x6p2                                                                     the same in two passes of two k-steps (ds_read_b64)
+//   2x4pf / 4x4pf     the second half-stage's J fragments made during the first (what pair_mfma_wide_kernel's complete-data instantiation does since round 6)
+//   2x4pfh            ... and a stage's last eight MFMAs held back for the head of the next stage
+//   2x4pf2            ... or the first half-stage's J fragments expanded k-step by k-step in front of V block 0's MFMAs
+//   2x4r4             256-sample stages in a ring of four, every stage's J fragments made during the stage before
+// -DPROBE_ENC=1 / 2: other operand codings of the same genotypes (powers of two; the +-2 coding), see pexp() below.
+// Results: profiles/r06_experiments.md section 4b.  bench.py runs `tile_shape_probe 2x4pf 2` beside its other ceilings (roofline.stage_loop_probe_frac_of_peak).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I plink-ng_amd/csrc tools/tile_shape_probe.hip -o tools/_bin/tile_shape_probe
-// Run:   tile_shape_probe <shape> [seconds] [samples] [J tiles] [reach in row-blocks]
+// Run:   tile_shape_probe <shape> [seconds] [samples] [J tiles] [reach in row-blocks]        (one JSON line; tools/tile_shape_summary.py adds the power samples)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
