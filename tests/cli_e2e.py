@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--env-sets", default="", help="semicolon-separated sets of NAME=VALUE,NAME=VALUE to time plink2-hip with on the same fileset (measurement)")
     ap.add_argument("--reps", type=int, default=3, help="plink2-hip runs per setting; the reported speed-up uses the BEST wall of each tool (HIP start-up "
                     "varies by 0.1-0.3 s from run to run on one box), all walls are printed")
+    ap.add_argument("--flag-sets", default="", help="semicolon-separated sets of extra plink2-hip flags to time on the same fileset, e.g. ';--debug-load-map' (the first is the "
+                    "one the speed-up line uses)")
     ap.add_argument("--pgen", action="store_true", help="convert the .bed with the reference's --make-pgen first (variable-width .pgen) and time both tools on that")
     ap.add_argument("--phased", action="store_true", help="--indep-pairphase on a phased variable-width .pgen (haplotypes = the synthetic generator's pseudo-samples, paired up)")
     ap.add_argument("--inter-chr", action="store_true", help="time --r2-unphased inter-chr --ld-window-r2 <--r2> (all pairs; keep --variants small)")
@@ -161,18 +163,24 @@ def main():
     settings = [("LDP_DEBUG_H2D_MODE=" + mode) for mode in args.h2d_modes.split(",")] if args.h2d_modes else [""]
     if args.env_sets:
         settings = args.env_sets.split(";")
+    if args.flag_sets:
+        settings = ["FLAGS " + fs for fs in args.flag_sets.split(";")]
     t_hip = None
     for setting in settings:
         env = dict(os.environ)
-        for kv in filter(None, setting.split(",")):
-            name, _, value = kv.partition("=")
-            env[name] = value
+        extra = []
+        if setting.startswith("FLAGS "):
+            extra = setting[6:].split()
+        else:
+            for kv in filter(None, setting.split(",")):
+                name, _, value = kv.partition("=")
+                env[name] = value
         if setting:
             print("--- " + setting)
         walls = []
         for rep in range(max(1, args.reps)):
             t0 = time.perf_counter()
-            cp = subprocess.run([os.path.join(REPO, "plink-ng_amd", "bin", "plink2-hip")] + common + ["--timing", "--out", "hip"], cwd=tmp,
+            cp = subprocess.run([os.path.join(REPO, "plink-ng_amd", "bin", "plink2-hip")] + common + extra + ["--timing", "--out", "hip"], cwd=tmp,
                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
             walls.append(time.perf_counter() - t0)
             print("plink2-hip rc", cp.returncode, "wall %.3f s" % walls[-1])
